@@ -1,0 +1,300 @@
+"""ctypes binding of the CPU oracle (oracle/sybil_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg -- never by the sybil_amd package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libsybil_oracle.so")
+
+NO_VAL, INT_VAL, STR_VAL, SET_VAL = 0, 1, 2, 3
+OP_GT, OP_LT, OP_EQ, OP_NEQ, OP_RE, OP_NRE, OP_IN, OP_NIN = range(8)
+OPS = {"gt": OP_GT, "lt": OP_LT, "eq": OP_EQ, "neq": OP_NEQ, "re": OP_RE, "nre": OP_NRE, "in": OP_IN, "nin": OP_NIN}
+AGG_AVG, AGG_HIST = 0, 1
+SYN_UNIFORM, SYN_TIME, SYN_BELL = 0, 1, 2
+MAX_GROUPS = 8
+MAX_AGGS = 8
+
+
+def build(force=False):
+    """Compile the oracle with gcc (building the checker is not using it)."""
+    src = os.path.join(_HERE, "sybil_oracle.c")
+    if (not force and os.path.exists(_LIB_PATH)
+            and os.path.getmtime(_LIB_PATH) >= max(os.path.getmtime(src), os.path.getmtime(src[:-2] + ".h"))):
+        return _LIB_PATH
+    subprocess.check_call(["make", "-s", "-C", _HERE, "-B"])
+    return _LIB_PATH
+
+
+class _Col(C.Structure):
+    _fields_ = [("type", C.c_int32), ("ints", C.c_void_p), ("strs", C.c_void_p),
+                ("set_off", C.c_void_p), ("set_vals", C.c_void_p), ("populated", C.c_void_p)]
+
+
+class _Filter(C.Structure):
+    _fields_ = [("col", C.c_int32), ("op", C.c_int32), ("value", C.c_int64),
+                ("idtable", C.c_void_p), ("idtable_len", C.c_int64)]
+
+
+class _Agg(C.Structure):
+    _fields_ = [("col", C.c_int32), ("info_min", C.c_int64), ("info_max", C.c_int64)]
+
+
+class _Query(C.Structure):
+    _fields_ = [("n_filters", C.c_int32), ("filters", C.POINTER(_Filter)),
+                ("n_groups", C.c_int32), ("group_cols", C.c_int32 * MAX_GROUPS),
+                ("n_aggs", C.c_int32), ("aggs", _Agg * MAX_AGGS),
+                ("op", C.c_int32), ("hist_bucket", C.c_int64),
+                ("time_col", C.c_int32), ("time_bucket", C.c_int64),
+                ("weight_col", C.c_int32), ("block_skip", C.c_int32),
+                ("block_rows", C.c_int64), ("n_threads", C.c_int32)]
+
+
+class HistInfo(C.Structure):
+    _fields_ = [("present", C.c_int32), ("percentile_mode", C.c_int32),
+                ("num_buckets", C.c_int64), ("bucket_size", C.c_int64), ("n_values", C.c_int64),
+                ("count", C.c_int64), ("samples", C.c_int64), ("min", C.c_int64), ("max", C.c_int64),
+                ("avg", C.c_double), ("sum_exact", C.c_int64),
+                ("true_min", C.c_int64), ("true_max", C.c_int64),
+                ("n_outliers", C.c_int64), ("n_underliers", C.c_int64),
+                ("stddev_ref", C.c_double), ("stddev_exact", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        L.orc_query_run.restype = C.c_void_p
+        L.orc_query_run.argtypes = [C.POINTER(_Query), C.POINTER(_Col), C.c_int32, C.c_int64]
+        L.orc_results_free.argtypes = [C.c_void_p]
+        for f in ("orc_matched_count", "orc_blocks_scanned", "orc_blocks_skipped"):
+            getattr(L, f).restype = C.c_int64
+            getattr(L, f).argtypes = [C.c_void_p]
+        L.orc_num_results.restype = C.c_int64
+        L.orc_num_results.argtypes = [C.c_void_p, C.c_int]
+        L.orc_result_get.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.POINTER(C.c_int64),
+                                     C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        L.orc_result_hist.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.POINTER(HistInfo)]
+        L.orc_result_hist_values.restype = C.c_int64
+        L.orc_result_hist_values.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_int64]
+        L.orc_result_percentiles.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p]
+        L.orc_setup_buckets.argtypes = [C.c_int64, C.c_int64, C.c_int64] + [C.POINTER(C.c_int64)] * 3
+        L.orc_percentiles_from_values.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]
+        L.orc_stddev_from_values.restype = C.c_double
+        L.orc_stddev_from_values.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_double,
+                                             C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]
+        L.orc_combine_avg.restype = C.c_double
+        L.orc_combine_avg.argtypes = [C.c_double, C.c_int64, C.c_double, C.c_int64]
+        L.orc_time_bucket.restype = C.c_int64
+        L.orc_time_bucket.argtypes = [C.c_int64, C.c_int64]
+        L.orc_hist_new.restype = C.c_void_p
+        L.orc_hist_new.argtypes = [C.c_int64, C.c_int64, C.c_int, C.c_int64, C.c_int]
+        L.orc_hist_add.argtypes = [C.c_void_p, C.c_int64, C.c_int64]
+        L.orc_hist_combine.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_hist_info_get.argtypes = [C.c_void_p, C.POINTER(HistInfo)]
+        L.orc_hist_values.restype = C.c_int64
+        L.orc_hist_values.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        L.orc_hist_percentiles.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_hist_outliers.restype = C.c_int64
+        L.orc_hist_outliers.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        L.orc_hist_free.argtypes = [C.c_void_p]
+        L.orc_splitmix64.restype = C.c_uint64
+        L.orc_splitmix64.argtypes = [C.c_uint64]
+        L.orc_synth_fill.argtypes = [C.c_int, C.c_int64, C.c_int64, C.c_uint64, C.c_int32,
+                                     C.c_int64, C.c_int64, C.c_int64, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+# ---------------------------------------------------------------- single hist (KATs)
+class Hist:
+    def __init__(self, info_min, info_max, op="avg", hist_bucket=0, weight_col=False):
+        self.h = lib().orc_hist_new(info_min, info_max, AGG_HIST if op == "hist" else AGG_AVG, hist_bucket,
+                                    1 if weight_col else 0)
+
+    def add(self, v, w=1):
+        lib().orc_hist_add(self.h, int(v), int(w))
+
+    def combine(self, other):
+        lib().orc_hist_combine(self.h, other.h)
+
+    def info(self):
+        hi = HistInfo()
+        lib().orc_hist_info_get(self.h, C.byref(hi))
+        return hi.as_dict()
+
+    def values(self):
+        n = self.info()["n_values"]
+        out = np.zeros(max(n, 1), dtype=np.int64)
+        lib().orc_hist_values(self.h, _ptr(out), n)
+        return out[:n]
+
+    def percentiles(self):
+        out = np.zeros(100, dtype=np.int64)
+        n = lib().orc_hist_percentiles(self.h, _ptr(out))
+        return out[:n]
+
+    def outliers(self):
+        out = np.zeros(1 << 16, dtype=np.int64)
+        n = lib().orc_hist_outliers(self.h, _ptr(out), out.size)
+        return out[:n]
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_hist_free(self.h)
+            self.h = None
+
+
+def setup_buckets(info_min, info_max, hist_bucket=0):
+    a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+    lib().orc_setup_buckets(info_min, info_max, hist_bucket, C.byref(a), C.byref(b), C.byref(c))
+    return {"bucket_size": a.value, "num_buckets": b.value, "n_values": c.value}
+
+
+def percentiles_from_values(values, bucket_size, hmin, count):
+    values = np.ascontiguousarray(values, dtype=np.int64)
+    out = np.zeros(100, dtype=np.int64)
+    n = lib().orc_percentiles_from_values(_ptr(values), values.size, bucket_size, hmin, count, _ptr(out))
+    return out[:n]
+
+
+def stddev_from_values(values, bucket_size, hmin, count, avg, outliers=(), underliers=()):
+    values = np.ascontiguousarray(values, dtype=np.int64)
+    o = np.ascontiguousarray(outliers, dtype=np.int64)
+    u = np.ascontiguousarray(underliers, dtype=np.int64)
+    return lib().orc_stddev_from_values(_ptr(values), values.size, bucket_size, hmin, count, avg,
+                                        _ptr(o), o.size, _ptr(u), u.size)
+
+
+def combine_avg(a, ca, b, cb):
+    return lib().orc_combine_avg(a, ca, b, cb)
+
+
+def time_bucket(t, bucket):
+    return lib().orc_time_bucket(t, bucket)
+
+
+def splitmix64(x):
+    return lib().orc_splitmix64(x & 0xFFFFFFFFFFFFFFFF)
+
+
+def synth_fill(kind, a, b, seed, col_index, row0, n, total_rows):
+    out = np.empty(n, dtype=np.int64)
+    lib().orc_synth_fill(kind, a, b, seed, col_index, row0, n, total_rows, _ptr(out))
+    return out
+
+
+# ---------------------------------------------------------------- full query
+def run_query(cols, filters=(), groups=(), aggs=(), op="avg", hist_bucket=0, time_col=-1, time_bucket=0,
+              weight_col=-1, block_skip=False, block_rows=65536, n_threads=1, want_values=True):
+    """cols: list of dicts {type: 'int'|'str'|'set', data, populated(optional), offsets(set)}
+    filters: list of (col_index, op_name, value[, idtable]); groups: col indices;
+    aggs: list of (col_index, info_min, info_max).
+    Returns a dict with matched, results, time_results, cumulative (canonical order)."""
+    L = lib()
+    keep = []
+    ccols = (_Col * max(len(cols), 1))()
+    nrows = None
+    for i, c in enumerate(cols):
+        t = c["type"]
+        pop = c.get("populated")
+        if pop is not None:
+            pop = np.ascontiguousarray(pop, dtype=np.uint8)
+            keep.append(pop)
+        if t == "int":
+            d = np.ascontiguousarray(c["data"], dtype=np.int64)
+            keep.append(d)
+            ccols[i] = _Col(INT_VAL, _ptr(d), None, None, None, _ptr(pop))
+            n = d.size
+        elif t == "str":
+            d = np.ascontiguousarray(c["data"], dtype=np.int32)
+            keep.append(d)
+            ccols[i] = _Col(STR_VAL, None, _ptr(d), None, None, _ptr(pop))
+            n = d.size
+        elif t == "set":
+            off = np.ascontiguousarray(c["offsets"], dtype=np.int64)
+            d = np.ascontiguousarray(c["data"], dtype=np.int32)
+            keep += [off, d]
+            ccols[i] = _Col(SET_VAL, None, None, _ptr(off), _ptr(d), _ptr(pop))
+            n = off.size - 1
+        else:
+            raise ValueError(t)
+        nrows = n if nrows is None else nrows
+        assert n == nrows, "ragged columns"
+    nrows = nrows or 0
+
+    cf = (_Filter * max(len(filters), 1))()
+    for i, f in enumerate(filters):
+        col, opn, val = f[0], f[1], f[2]
+        idt = None
+        if len(f) > 3 and f[3] is not None:
+            idt = np.ascontiguousarray(f[3], dtype=np.uint8)
+            keep.append(idt)
+        cf[i] = _Filter(col, OPS[opn] if isinstance(opn, str) else opn, int(val), _ptr(idt),
+                        idt.size if idt is not None else 0)
+    q = _Query()
+    q.n_filters = len(filters)
+    q.filters = C.cast(cf, C.POINTER(_Filter))
+    q.n_groups = len(groups)
+    for i, g in enumerate(groups):
+        q.group_cols[i] = g
+    q.n_aggs = len(aggs)
+    for i, a in enumerate(aggs):
+        q.aggs[i] = _Agg(a[0], int(a[1]), int(a[2]))
+    q.op = AGG_HIST if op == "hist" else AGG_AVG
+    q.hist_bucket = hist_bucket
+    q.time_col = time_col
+    q.time_bucket = time_bucket
+    q.weight_col = weight_col
+    q.block_skip = 1 if block_skip else 0
+    q.block_rows = block_rows
+    q.n_threads = n_threads
+
+    R = L.orc_query_run(C.byref(q), ccols, len(cols), nrows)
+    try:
+        out = {"matched": L.orc_matched_count(R), "blocks_scanned": L.orc_blocks_scanned(R),
+               "blocks_skipped": L.orc_blocks_skipped(R)}
+        ng, na = len(groups), len(aggs)
+        for which, name in ((0, "results"), (1, "time_results"), (2, "cumulative")):
+            lst = []
+            for idx in range(L.orc_num_results(R, which)):
+                key = (C.c_uint8 * max(8 * ng, 1))()
+                tb, cnt, smp = C.c_int64(), C.c_int64(), C.c_int64()
+                L.orc_result_get(R, which, idx, key, C.byref(tb), C.byref(cnt), C.byref(smp))
+                kb = bytes(key)[:8 * ng]
+                r = {"key": kb, "key_vals": tuple(int.from_bytes(kb[8 * g:8 * g + 8], "little") for g in range(ng)),
+                     "time_bucket": tb.value, "count": cnt.value, "samples": smp.value, "hists": []}
+                for a in range(na):
+                    hi = HistInfo()
+                    L.orc_result_hist(R, which, idx, a, C.byref(hi))
+                    h = hi.as_dict()
+                    if h["present"] and h["percentile_mode"]:
+                        if want_values:
+                            v = np.zeros(max(h["n_values"], 1), dtype=np.int64)
+                            L.orc_result_hist_values(R, which, idx, a, _ptr(v), v.size)
+                            h["values"] = v[:h["n_values"]]
+                        p = np.zeros(100, dtype=np.int64)
+                        n = L.orc_result_percentiles(R, which, idx, a, _ptr(p))
+                        h["percentiles"] = p[:max(n, 0)]
+                    r["hists"].append(h)
+                lst.append(r)
+            out[name] = lst[0] if which == 2 else lst
+        return out
+    finally:
+        L.orc_results_free(R)

@@ -1,0 +1,186 @@
+/*
+ * sybil_oracle.h -- CPU ORACLE for the sybil scan hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This is a plain-C restatement of the reference algorithm (logv/sybil, Go) for
+ * the per-block filter -> group -> aggregate -> merge path.  It is the checker
+ * the HIP path is compared against; it is never the product.  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.
+ *
+ * Reference files restated (paths relative to the reference repo, src/lib/):
+ *   aggregate.go:56-282   FilterAndAggRecords (row loop, key format, time buckets)
+ *   aggregate.go:414-467  CombineResults
+ *   aggregate.go:43-54, 497-525  sort order
+ *   filter.go:171-195     IntFilter.Filter
+ *   filter.go:199-250     StrFilter.Filter (eq/neq; re/nre through a per-id table)
+ *   filter.go:252-285     SetFilter.Filter
+ *   hist_basic.go:34-70   SetupBuckets
+ *   hist_basic.go:101-151 AddWeightedValue
+ *   hist_basic.go:153-183 GetPercentiles
+ *   hist_basic.go:192-219 GetStdDev
+ *   hist_basic.go:259-279 BasicHist.Combine
+ *   query_spec.go:107-193 ResultMap.Combine / Result.Combine
+ *   table_block_io.go:110-182 ShouldLoadBlockFromDir (min/max block skip)
+ *
+ * Parity pinning: the reference binary cannot be built here (no Go toolchain),
+ * so the oracle is pinned against (a) the reference's golden NodeResults file
+ * (testdata/TestDecodeGoldenFiles/node_results.golden.json: Combine identity,
+ * bucket geometry, key format) and (b) the hand-derived known-answer tests of
+ * SURVEY.md section 8c.  See tests/test_oracle_*.py.
+ *
+ * Two arithmetic modes are produced by one run:
+ *   reference-order: per-block float64 running means, blocks merged in index
+ *                    order with the count-weighted float merge (what Go does,
+ *                    with goroutine completion order fixed to block order);
+ *   exact:           int64 sums/counts/buckets (what the HIP path computes).
+ */
+#ifndef SYBIL_ORACLE_H
+#define SYBIL_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* record.go:14-19 value tags */
+enum { ORC_NO_VAL = 0, ORC_INT_VAL = 1, ORC_STR_VAL = 2, ORC_SET_VAL = 3 };
+
+/* filter ops: filter.go:176-190 (int), :213-245 (str), :268-283 (set) */
+enum {
+    ORC_OP_GT = 0, ORC_OP_LT = 1, ORC_OP_EQ = 2, ORC_OP_NEQ = 3, /* int, str(eq/neq) */
+    ORC_OP_RE = 4, ORC_OP_NRE = 5,                               /* str via id table */
+    ORC_OP_IN = 6, ORC_OP_NIN = 7                                /* set */
+};
+
+enum { ORC_AGG_AVG = 0, ORC_AGG_HIST = 1 }; /* FLAGS.OP "avg" | "hist" */
+
+#define ORC_MAX_GROUPS 8
+#define ORC_MAX_AGGS 8
+#define ORC_GROUP_BY_WIDTH 8 /* aggregate.go:16 */
+
+typedef struct {
+    int32_t type;             /* ORC_INT_VAL | ORC_STR_VAL | ORC_SET_VAL */
+    const int64_t *ints;      /* INT: one value per row */
+    const int32_t *strs;      /* STR: one (table-global) dictionary id per row */
+    const int64_t *set_off;   /* SET: CSR offsets, nrows+1 */
+    const int32_t *set_vals;  /* SET: CSR member ids */
+    const uint8_t *populated; /* per row 0/1, NULL = every row populated */
+} orc_col;
+
+typedef struct {
+    int32_t col;            /* index into cols[] */
+    int32_t op;             /* ORC_OP_* */
+    int64_t value;          /* int constant, or str/set target id (-1: value not in dictionary) */
+    const uint8_t *idtable; /* RE/NRE: idtable[id] = regex matched that dictionary entry */
+    int64_t idtable_len;
+} orc_filter;
+
+typedef struct {
+    int32_t col;
+    int64_t info_min, info_max; /* table-level IntInfo.Min/Max (aggregate.go:254) */
+} orc_agg;
+
+typedef struct {
+    int32_t n_filters;
+    const orc_filter *filters;
+    int32_t n_groups;
+    int32_t group_cols[ORC_MAX_GROUPS];
+    int32_t n_aggs;
+    orc_agg aggs[ORC_MAX_AGGS];
+    int32_t op;          /* ORC_AGG_AVG | ORC_AGG_HIST */
+    int64_t hist_bucket; /* FLAGS.HIST_BUCKET (-int-bucket), 0 = auto */
+    int32_t time_col;    /* -1 = no time series */
+    int64_t time_bucket; /* QuerySpec.TimeBucket, 0 = off */
+    int32_t weight_col;  /* -1 = none (OPTS.WEIGHT_COL) */
+    int32_t block_skip;  /* apply ShouldLoadBlockFromDir using exact per-block min/max */
+    int64_t block_rows;  /* CHUNK_SIZE, 65536 in production (table.go:44) */
+    int32_t n_threads;   /* blocks scanned in parallel; merge is always in block order */
+} orc_query;
+
+/* One merged Result (query_spec.go:85-93) + its hists, both arithmetic modes. */
+typedef struct orc_result orc_result;
+typedef struct orc_results orc_results;
+
+/* Runs the scan over nrows rows of ncols columns; never returns NULL on valid input. */
+orc_results *orc_query_run(const orc_query *q, const orc_col *cols, int32_t ncols, int64_t nrows);
+void orc_results_free(orc_results *r);
+
+int64_t orc_matched_count(const orc_results *r);
+int64_t orc_blocks_scanned(const orc_results *r);
+int64_t orc_blocks_skipped(const orc_results *r);
+
+/* which: 0 = Results (all-time), 1 = TimeResults entries, 2 = Cumulative ("TOTAL", 1 entry) */
+int64_t orc_num_results(const orc_results *r, int which);
+/* Results are returned in a canonical order: (time bucket, key bytes as unsigned LE ints). */
+int orc_result_get(const orc_results *r, int which, int64_t idx,
+                   uint8_t *key /* 8*n_groups */, int64_t *time_bucket,
+                   int64_t *count, int64_t *samples);
+/* Per-aggregation state of result idx.  present=0 when the result has no hist
+ * for that aggregation (no INT value was ever added, aggregate.go:246-259). */
+typedef struct {
+    int32_t present;
+    int32_t percentile_mode;
+    int64_t num_buckets;  /* BasicHist.NumBuckets */
+    int64_t bucket_size;  /* BasicHist.BucketSize */
+    int64_t n_values;     /* len(Values) */
+    int64_t count;        /* h.Count (weighted) */
+    int64_t samples;      /* h.Samples */
+    int64_t min, max;     /* h.Min / h.Max incl. the reference's initial values */
+    double avg;           /* reference-order running / merged mean */
+    int64_t sum_exact;    /* exact Σ v*w over accepted values (wraps mod 2^64) */
+    int64_t true_min, true_max; /* extrema over accepted values only */
+    int64_t n_outliers;   /* accepted values clipped into the last bucket (all blocks) */
+    int64_t n_underliers;
+    double stddev_ref;    /* GetStdDev on the merged hist as the reference would hold it
+                             (outlier list of the first block only, hist_basic.go:259-279) */
+    double stddev_exact;  /* GetStdDev with avg = sum_exact/count and every outlier */
+} orc_hist_info;
+int orc_result_hist(const orc_results *r, int which, int64_t idx, int agg, orc_hist_info *out);
+/* Copies len(Values) bucket counts; returns n_values or <0. */
+int64_t orc_result_hist_values(const orc_results *r, int which, int64_t idx, int agg, int64_t *out, int64_t cap);
+/* GetPercentiles (hist_basic.go:153-183): writes up to 100 entries, returns how many (0 if Count==0). */
+int orc_result_percentiles(const orc_results *r, int which, int64_t idx, int agg, int64_t *out100);
+
+/* ---- stand-alone pieces, exposed so known-answer tests can pin them ---- */
+
+/* hist_basic.go:34-70 */
+void orc_setup_buckets(int64_t info_min, int64_t info_max, int64_t hist_bucket,
+                       int64_t *bucket_size, int64_t *num_buckets, int64_t *n_values);
+/* GetPercentiles over an explicit Values array */
+int orc_percentiles_from_values(const int64_t *values, int64_t n_values, int64_t bucket_size,
+                                int64_t hmin, int64_t count, int64_t *out100);
+/* GetStdDev over explicit state */
+double orc_stddev_from_values(const int64_t *values, int64_t n_values, int64_t bucket_size,
+                              int64_t hmin, int64_t count, double avg,
+                              const int64_t *outliers, int64_t n_out,
+                              const int64_t *underliers, int64_t n_under);
+/* BasicHist.Combine mean merge (hist_basic.go:264-265) */
+double orc_combine_avg(double avg_a, int64_t count_a, double avg_b, int64_t count_b);
+/* aggregate.go:174 */
+int64_t orc_time_bucket(int64_t t, int64_t bucket);
+
+/* A tiny single-hist driver for KATs: feeds (v,w) pairs through AddWeightedValue. */
+typedef struct orc_hist orc_hist;
+orc_hist *orc_hist_new(int64_t info_min, int64_t info_max, int op, int64_t hist_bucket, int weight_col_mode);
+void orc_hist_add(orc_hist *h, int64_t v, int64_t w);
+void orc_hist_combine(orc_hist *h, const orc_hist *other);
+void orc_hist_info_get(const orc_hist *h, orc_hist_info *out);
+int64_t orc_hist_values(const orc_hist *h, int64_t *out, int64_t cap);
+int orc_hist_percentiles(const orc_hist *h, int64_t *out100);
+int64_t orc_hist_outliers(const orc_hist *h, int64_t *out, int64_t cap);
+void orc_hist_free(orc_hist *h);
+
+/* ---- synthetic table generator (OURS, not the reference's; DESIGN.md "Synthetic table") ---- */
+enum {
+    ORC_SYN_UNIFORM = 0, /* uniform in [a, a+b)                     */
+    ORC_SYN_TIME = 1,    /* a + floor(i * b / N)   (non-decreasing)  */
+    ORC_SYN_BELL = 2     /* sum of four uniform [0, b) + a           */
+};
+uint64_t orc_splitmix64(uint64_t x);
+void orc_synth_fill(int kind, int64_t a, int64_t b, uint64_t seed, int32_t col_index,
+                    int64_t row0, int64_t n, int64_t total_rows, int64_t *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

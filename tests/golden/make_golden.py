@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Regenerates tests/golden/node_results_hists.json from the reference's own golden
+NodeResults file (src/lib/testdata/TestDecodeGoldenFiles/node_results.golden.json,
+pinned by src/lib/decoding_test.go:20-74).  Run in the build container only --
+/root/reference does not exist on the GPU box; the JSON it writes is committed.
+
+What is kept: for the Cumulative result and each of the 12 group results, the
+BasicHist fields the scan path produces (Values, Count, Avg, Min, Max, Outliers,
+BucketSize, NumBuckets, Info.Min/Max) plus Result.Count/Samples/BinaryByKey/GroupByKey.
+Bucket `Averages` are dropped (not merged by Combine, not printed).
+"""
+import json
+import os
+import sys
+
+REF = "/root/reference/src/lib/testdata/TestDecodeGoldenFiles/node_results.golden.json"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "node_results_hists.json")
+
+
+def hist(h):
+    return {"NumBuckets": h["NumBuckets"], "BucketSize": h["BucketSize"], "Values": h["Values"],
+            "PercentileMode": h["PercentileMode"], "Outliers": h["Outliers"] or [],
+            "Underliers": h["Underliers"] or [], "Max": h["Max"], "Min": h["Min"], "Samples": h["Samples"],
+            "Count": h["Count"], "Avg": h["Avg"], "InfoMin": h["Info"]["Min"], "InfoMax": h["Info"]["Max"]}
+
+
+def result(r):
+    return {"GroupByKey": r["GroupByKey"], "BinaryByKeyHex": r["BinaryByKey"].encode("latin-1").hex(),
+            "Count": r["Count"], "Samples": r["Samples"],
+            "Hists": {k: hist(v) for k, v in r["Hists"].items()}}
+
+
+def main():
+    qs = json.load(open(REF))["QuerySpec"]
+    out = {"source": "logv/sybil src/lib/testdata/TestDecodeGoldenFiles/node_results.golden.json",
+           "Groups": [g["Name"] for g in qs["Groups"]],
+           "Aggregations": qs["Aggregations"], "OrderBy": qs["OrderBy"], "Limit": qs["Limit"],
+           "MatchedCount": qs["MatchedCount"],
+           "Cumulative": result(qs["Cumulative"]),
+           "Results": {k: result(v) for k, v in qs["Results"].items()},
+           "SortedKeys": [r["GroupByKey"] for r in qs["Sorted"]]}
+    json.dump(out, open(OUT, "w"), separators=(",", ":"), sort_keys=True)
+    print("wrote", OUT, os.path.getsize(OUT), "bytes")
+
+
+if __name__ == "__main__":
+    sys.exit(main())
