@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""bench.py -- rows scanned/sec + achieved HBM GB/s of the sybil scan hot path on MI355X.
+
+Workload (BASELINE.json metric / configs[2], "config 3" of BASELINE.md): the synthetic
+1 B-row x 32-int-column table (only the 7 referenced columns are resident, as the reference
+only opens referenced column files), 3 ANDed int-range filters, group-by 2 columns,
+count / sum / avg / stddev of 2 columns.  A step = one full pass of the hot path over the
+table: scan kernel + per-workgroup table fold (+ the SUM/MAX all-reduce of the partial group
+tables over RCCL when N > 1) + finalize on rank 0.  Inputs are resident in HBM before the
+timed region.  The 1 B rows are block-sharded across the N ranks (strong scaling).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--rows R] [--workload NAME]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable by a copy
+
+
+def cpu_baseline(workload, total_rows, budget_s=15.0):
+    """The CPU oracle (a C restatement of the reference algorithm, kind "port") timed on this
+    host's cores on a bounded sample of the same workload.  Reported, never the target."""
+    from oracle import oracle as orc
+    from sybil_amd import synth
+    from tests import parity
+    wl = synth.WORKLOADS[workload]
+    names, q = wl["columns"], wl["query"]
+    info = {n: (synth.COLUMNS[n][4], synth.COLUMNS[n][5]) for n in names}
+    cores = os.cpu_count() or 1
+    kw = parity.oracle_query_kwargs(names, info, q)
+
+    def run(nrows):
+        cols = parity.oracle_synth_cols(orc, names, total_rows, 0, nrows)
+        t0 = time.perf_counter()
+        r = orc.run_query(cols, n_threads=cores, want_values=False, **kw)
+        dt = time.perf_counter() - t0
+        return dt, r["matched"]
+
+    probe = 2_000_000
+    dt, _ = run(probe)
+    rate = probe / dt
+    sample = int(min(max(rate * budget_s, probe), 96_000_000, total_rows))
+    sample = max(65536, sample // 65536 * 65536)
+    dt, matched = run(sample)
+    return {"value": sample / dt, "unit": "rows/s", "cores": cores, "kind": "port",
+            "sample": "%d rows (first blocks) of %s, oracle/sybil_oracle.c with %d threads, %.1f s" % (
+                sample, workload, cores, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rows", type=int, default=0, help="total rows (default: the workload's BASELINE size)")
+    ap.add_argument("--workload", default="cfg3_filter3_group2_stddev")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--collective", choices=["torch", "rccl"], default="torch",
+                    help="torch.distributed (RCCL backend) or the library's own RCCL communicator")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import sybil_amd
+    from sybil_amd import synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    device = "cuda:%d" % local_rank
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(device))
+
+    wl = synth.WORKLOADS[args.workload]
+    names, q = wl["columns"], wl["query"]
+    total_rows = args.rows or wl["rows"]
+    ctx = sybil_amd.Context(local_rank)
+    dev = ctx.device_info()
+    bytes_per_row = 8 * len(names)
+    # fit check (single GPU must hold its shard)
+    row0, nrows = synth.shard(total_rows, rank, world)
+    if nrows * bytes_per_row > dev["hbm_bytes"] * 0.9:
+        raise SystemExit("shard of %d rows x %d B does not fit in %d B of HBM" % (nrows, bytes_per_row, dev["hbm_bytes"]))
+
+    table = ctx.synth_table("bench", synth.SEED, total_rows, row0, nrows, synth.synth_cols(names))
+    # identical direct-mapped layout on every rank: declare the generator's value bounds
+    for n in names:
+        kind, _, a, b, _, _ = synth.COLUMNS[n]
+        hi = a + 4 * (b - 1) if kind == synth.BELL else a + b - 1
+        table.set_bounds(n, a, hi)
+    query = table.query(**q)
+    if world > 1:
+        if args.collective == "torch":
+            query.bind_torch(device)
+            # run the engine on torch's current stream: scan -> all-reduce -> finalize are then
+            # ordered on the device without host round trips
+            ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        else:
+            uid = [ctx.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            ctx.comm_init(uid[0], world, rank)
+
+    scan_ms = []
+
+    def step():
+        query.scan()
+        if world > 1:
+            if args.collective == "torch":
+                query.allreduce_torch()
+            else:
+                query.allreduce()
+        res = None
+        if rank == 0:
+            res = query.finalize()
+        else:
+            ctx.sync()
+        scan_ms.append(query.stats()["scan_ms"])
+        return res
+
+    def fence():
+        ctx.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    res = None
+    for _ in range(args.warmup):
+        r = step()
+        if r is not None:
+            r.free()
+    fence()
+    del scan_ms[:]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        r = step()
+        if r is not None:
+            if res is not None:
+                res.free()
+            res = r
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    stats = query.stats()
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = total_rows * args.steps / dt
+        k_ms = sum(scan_ms) / len(scan_ms)
+        alg_bytes = stats["algorithmic_bytes"]  # this rank's rows x 56 B: per launch, per GPU
+        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+        out = {
+            "metric": "rows scanned/sec (1B-row x 32-int-col synthetic table, 3 ANDed int-range filters, "
+                      "group-by 2 cols, count/sum/avg/stddev of 2 cols)",
+            "value": value, "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "int64", "data": "synthetic",
+            "config": {"workload": args.workload, "reference_flags": wl["flags"], "rows": total_rows,
+                       "table_columns": wl["table_cols"], "resident_columns": names, "bytes_per_row": bytes_per_row,
+                       "sharding": "contiguous 65536-row blocks per rank", "collective": args.collective if world > 1 else None,
+                       "device": dev["name"], "matched_rows": res.matched if res is not None else None,
+                       "groups": len(res.results) if res is not None else None,
+                       "strategy": "lds" if stats["strategy"] == 0 else "global-atomics",
+                       "lds_bytes": stats["lds_bytes"], "workgroups": stats["n_workgroups"]},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_scan<7,lds>", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.workload, total_rows)
+        print(json.dumps(out))
+        sys.stdout.flush()
+    if res is not None:
+        res.free()
+    query.free()
+    table.free()
+    if world > 1 and args.collective == "rccl":
+        ctx.comm_free()
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,279 @@
+/*
+ * sybilgpu.h -- C ABI of the MI355X-native scan/aggregate engine for logv/sybil.
+ *
+ * This is the drop-in boundary for sybil's query hot path.  The reference has no
+ * FFI/plugin interface; the seam this library replaces is the body of the per-block
+ * loop in  src/lib/table_query.go:111-220  (LoadBlockFromDir -> CopyQuerySpec ->
+ * FilterAndAggRecords -> block_specs[...]) together with the merge that follows
+ * (MultiCombineResults/CombineResults, table_query.go:230-257,397-404 and
+ * aggregate.go:361-467).  One call level up, the whole of
+ *     count = t.LoadAndQueryRecords(&loadSpec, &querySpec)   (src/cmd/cmd_query.go:362)
+ * maps to  sybl_query_prepare + sybl_query_scan (+ all-reduce) + sybl_query_finalize.
+ * INTEGRATION.md shows the cgo shim a sybil maintainer would add.
+ *
+ * Conventions:
+ *  - plain C types only; every entry point returns int (0 = ok, <0 = SYBL_E_*),
+ *    sybl_last_error() gives the text for the calling thread; no exceptions or abort()
+ *    cross the boundary.
+ *  - the library never keeps a caller pointer after a call returns (cgo rule); inputs
+ *    are consumed during the call, outputs live in library-owned memory until the
+ *    matching *_free.
+ *  - no globals: everything the reference reads from FLAGS/OPTS (config.go:119-120)
+ *    is an explicit field of sybl_query_desc.
+ *  - one sybl_ctx per GPU (one process per GPU under RCCL); calls on different ctx
+ *    objects may run concurrently from any OS thread; calls on one ctx are serialised
+ *    by the caller.
+ *  - there is NO CPU fallback: without a usable HIP device every compute call fails
+ *    with SYBL_E_NODEVICE.
+ */
+#ifndef SYBILGPU_H
+#define SYBILGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SYBL_ABI_VERSION 1
+
+enum {
+    SYBL_OK = 0,
+    SYBL_E_INVAL = -1,    /* bad argument / unknown column / unsupported query shape */
+    SYBL_E_NODEVICE = -2, /* no HIP device, or a HIP call failed */
+    SYBL_E_NOMEM = -3,
+    SYBL_E_IO = -4,       /* table directory / gob decode problem */
+    SYBL_E_STATE = -5,    /* call order violated (e.g. finalize before scan) */
+    SYBL_E_BLOCK = -6     /* a block was rejected (the reference skips such blocks) */
+};
+
+/* record.go:14-19 */
+enum { SYBL_NO_VAL = 0, SYBL_INT_VAL = 1, SYBL_STR_VAL = 2, SYBL_SET_VAL = 3 };
+
+/* filter ops: filter.go:176-190 (int), :213-245 (str), :268-283 (set) */
+enum {
+    SYBL_OP_GT = 0, SYBL_OP_LT = 1, SYBL_OP_EQ = 2, SYBL_OP_NEQ = 3,
+    SYBL_OP_RE = 4, SYBL_OP_NRE = 5, SYBL_OP_IN = 6, SYBL_OP_NIN = 7
+};
+
+/* FLAGS.OP (aggregate.go:24-29) */
+enum { SYBL_AGG_AVG = 0, SYBL_AGG_HIST = 1 };
+
+#define SYBL_MAX_GROUPS 4
+#define SYBL_MAX_AGGS 6
+#define SYBL_MAX_FILTERS 16
+#define SYBL_GROUP_BY_WIDTH 8 /* aggregate.go:16 */
+#define SYBL_BLOCK_ROWS 65536 /* table.go:44 CHUNK_SIZE */
+
+typedef struct sybl_ctx sybl_ctx;
+typedef struct sybl_table sybl_table;
+typedef struct sybl_query sybl_query;
+typedef struct sybl_result sybl_result;
+
+/* ------------------------------------------------------------------ context */
+
+int sybl_abi_version(void);
+/* Text of the last error raised on the calling thread ("" if none). */
+const char *sybl_last_error(void);
+
+/* device: HIP device ordinal of this process' GPU (LOCAL_RANK under torchrun). */
+int sybl_init(int device, sybl_ctx **out);
+void sybl_shutdown(sybl_ctx *ctx);
+/* Run all work of this ctx on an existing hipStream_t (e.g. the host framework's
+ * current stream); NULL restores the ctx's own stream. */
+int sybl_ctx_set_stream(sybl_ctx *ctx, void *hip_stream);
+int sybl_ctx_sync(sybl_ctx *ctx);
+int sybl_device_info(sybl_ctx *ctx, char *name, size_t name_cap, int *n_cus, int64_t *hbm_bytes);
+
+/* ------------------------------------------------------------------ tables
+ * A table is the HBM-resident form of a sybil table: one dense array per column
+ * (reference value types: IntField int64, StrField int32 dictionary id, SetField
+ * []int32 -- record_fields.go:8-10), a validity bitmap for columns with missing
+ * rows, and a table-global string dictionary per str/set column (the reference's
+ * are block-local, table_column.go:27-48; SURVEY.md 8a note 8).                  */
+
+int sybl_table_create(sybl_ctx *ctx, const char *name, sybl_table **out);
+void sybl_table_free(sybl_table *t);
+
+/* Declare a column before the first block is appended.  info_min/info_max are the
+ * table-level IntInfo.Min/Max (table_column_info.go:18-24, loaded from info.db by
+ * the host) that hist geometry and the outlier gate use (aggregate.go:254,
+ * hist_basic.go:104).  Pass min > max to let the library use the exact extrema. */
+int sybl_table_add_column(sybl_table *t, const char *name, int type, int64_t info_min, int64_t info_max);
+
+/* One host-decoded column of one block (what unpackIntCol/unpackStrCol/unpackSetCol
+ * produce, column_store_io.go:493-780), handed over columnar. */
+typedef struct {
+    const char *name;
+    int32_t type;             /* SYBL_INT_VAL | SYBL_STR_VAL | SYBL_SET_VAL */
+    const int64_t *ints;      /* INT: nrows values */
+    const int32_t *str_ids;   /* STR: nrows ids into `strings` (block-local dictionary) */
+    const int64_t *set_off;   /* SET: nrows+1 CSR offsets */
+    const int32_t *set_ids;   /* SET: member ids into `strings` */
+    const uint8_t *populated; /* nrows bytes 0/1 (Record.Populated != _NO_VAL); NULL = all rows */
+    const char *const *strings; /* STR/SET: block StringTable */
+    int32_t n_strings;
+} sybl_col_view;
+
+/* Appends one block (<= 65536 rows in the reference, any size here).  Columns of the
+ * table that are absent from `cols` are unpopulated for the whole block. */
+int sybl_table_append_block(sybl_table *t, int64_t nrows, int32_t ncols, const sybl_col_view *cols);
+
+/* Device-side deterministic generator for benchmarks and parity tests (SURVEY.md 8d;
+ * the formula is restated in oracle/sybil_oracle.c:orc_synth_fill).  Every column is a
+ * fully populated INT column. */
+enum { SYBL_SYN_UNIFORM = 0, SYBL_SYN_TIME = 1, SYBL_SYN_BELL = 2 };
+typedef struct {
+    const char *name;
+    int32_t kind;      /* SYBL_SYN_* */
+    int32_t col_index; /* salt of the per-column hash stream */
+    int64_t a, b;      /* UNIFORM: [a, a+b)   TIME: a + floor(i*b/N)   BELL: a + 4 x [0,b) */
+    int64_t info_min, info_max; /* IntInfo given to hists; min > max = exact extrema */
+} sybl_synth_col;
+/* Rows [row0, row0+nrows) of a virtual table of total_rows rows (a rank's shard). */
+int sybl_table_create_synth(sybl_ctx *ctx, const char *name, uint64_t seed, int64_t total_rows,
+                            int64_t row0, int64_t nrows, int32_t ncols, const sybl_synth_col *cols,
+                            sybl_table **out);
+
+/* Native loader: reads a sybil table directory written by the reference
+ * (<dir>/<table>/info.db and <block>/{info.db,int_*.db,str_*.db,set_*.db}[.gz],
+ * table_io.go:132, table_block_io.go:225-310) straight into HBM.  `columns` limits
+ * the load to the referenced columns like LoadSpec does (table_load_spec.go:59-73);
+ * NULL loads every column.  rank/nranks shard the block list contiguously. */
+int sybl_table_open(sybl_ctx *ctx, const char *dir, const char *table, const char *const *columns,
+                    int32_t n_columns, int32_t rank, int32_t nranks, sybl_table **out);
+
+int64_t sybl_table_rows(const sybl_table *t);
+int64_t sybl_table_blocks(const sybl_table *t);
+int64_t sybl_table_hbm_bytes(const sybl_table *t);
+/* Exact extrema of an INT column over resident rows and the IntInfo in force. */
+int sybl_table_column_info(const sybl_table *t, const char *name, int *type, int64_t *exact_min,
+                           int64_t *exact_max, int64_t *info_min, int64_t *info_max, int *has_missing);
+/* Multi-rank hosts: declare bounds that hold on EVERY rank (all-reduce the exact extrema
+ * first) so that the direct-mapped group layout, and therefore the partial tables, are
+ * identical across ranks.  has_missing != 0 reserves the MISSING_VALUE key slot. */
+int sybl_table_set_bounds(sybl_table *t, const char *name, int64_t lo, int64_t hi, int has_missing);
+/* Copies rows [row0,row0+n) of an INT column back to the host (tests, samples). */
+int sybl_table_read_int(const sybl_table *t, const char *name, int64_t row0, int64_t n, int64_t *out);
+
+/* ------------------------------------------------------------------ queries
+ * sybl_query_desc mirrors QueryParams (query_spec.go:25-41) plus the FLAGS/OPTS the
+ * hot loop reads (aggregate.go:100, hist_basic.go:79,111, hist.go:29-31).         */
+
+typedef struct {
+    const char *col;
+    int32_t op;            /* SYBL_OP_* ; the column's type selects Int/Str/SetFilter */
+    int64_t int_value;     /* IntFilter.Value */
+    const char *str_value; /* StrFilter/SetFilter.Value (literal, or regex for RE/NRE) */
+    /* optional: RE/NRE evaluated by the host per dictionary entry (Go's regexp), one
+     * byte per table-global id; overrides str_value when non-NULL */
+    const uint8_t *id_match;
+    int64_t id_match_len;
+} sybl_filter;
+
+typedef struct {
+    int32_t n_filters;
+    const sybl_filter *filters; /* ANDed (aggregate.go:105-116) */
+    int32_t n_groups;
+    const char *const *groups;  /* int or str columns (set group-by is rejected, cmd_query.go:254) */
+    int32_t n_aggs;
+    const char *const *aggs;    /* int columns */
+    int32_t op;                 /* SYBL_AGG_AVG | SYBL_AGG_HIST */
+    int64_t hist_bucket;        /* FLAGS.HIST_BUCKET, 0 = auto */
+    /* HIST only: 1 = keep every bucket array (percentiles and buckets can be output);
+     * 0 = moments only: count/sum/avg/min/max and the reference's bucket-quantised
+     * stddev are produced from four exact integer accumulators. */
+    int32_t want_percentiles;
+    const char *time_col;       /* with time_bucket > 0: time-series query */
+    int64_t time_bucket;        /* QuerySpec.TimeBucket */
+    const char *weight_col;     /* OPTS.WEIGHT_COL */
+    const char *order_by;       /* "$COUNT", an aggregated column, or NULL/"" = unsorted */
+    int32_t order_asc;
+    int32_t limit;              /* FLAGS.LIMIT; <= 0 = all groups */
+    int32_t block_skip;         /* ShouldLoadBlockFromDir min/max pruning (table_block_io.go:110-182) */
+} sybl_query_desc;
+
+int sybl_query_prepare(sybl_table *t, const sybl_query_desc *desc, sybl_query **out);
+void sybl_query_free(sybl_query *q);
+
+/* Launches the scan of this rank's resident rows on the ctx stream; asynchronous. */
+int sybl_query_scan(sybl_query *q);
+
+/* The rank-local partial group table, laid out identically on every rank of a job:
+ * `sum` words combine with SUM, `max` words with MAX (minima are stored negated).
+ * Multi-GPU hosts all-reduce both buffers in place (RCCL over xGMI) between
+ * sybl_query_scan and sybl_query_finalize; single-GPU hosts skip this. */
+int sybl_query_partials(sybl_query *q, void **d_sum, int64_t *n_sum_words, void **d_max, int64_t *n_max_words);
+/* Optional: make the scan write its partials into caller-owned device buffers
+ * (e.g. torch tensors) of at least the sizes sybl_query_partials reports. */
+int sybl_query_bind_partials(sybl_query *q, void *d_sum, void *d_max);
+
+/* In-library RCCL path for hosts without a collective runtime of their own (the Go
+ * host): unique_id is the 128-byte ncclUniqueId produced by sybl_comm_unique_id on
+ * rank 0 and distributed by the host. */
+int sybl_comm_unique_id(void *id128);
+int sybl_comm_init(sybl_ctx *ctx, const void *id128, int32_t nranks, int32_t rank);
+int sybl_comm_free(sybl_ctx *ctx);
+int sybl_query_allreduce(sybl_query *q);
+
+/* Copies the (reduced) partials to the host, derives avg/stddev/percentiles, builds
+ * GroupByKey strings, sorts and applies the limit.  Synchronises the stream. */
+int sybl_query_finalize(sybl_query *q, sybl_result **out);
+
+/* ------------------------------------------------------------------ results */
+
+typedef struct {
+    int32_t present;      /* 0: this group never saw an INT value for the aggregation */
+    int64_t count;        /* BasicHist.Count (weighted) */
+    int64_t samples;      /* BasicHist.Samples */
+    int64_t sum;          /* exact  sum(v*w)  over accepted values */
+    double avg;           /* sum/count      (reference: running mean, <=1e-6 rel) */
+    double stddev;        /* GetStdDev semantics (hist_basic.go:192-219); 0 in AVG mode */
+    int64_t min, max;     /* BasicHist.Min/Max incl. the reference's initial values */
+    int64_t bucket_size;  /* HIST: BasicHist.BucketSize */
+    int64_t num_buckets;  /* HIST: BasicHist.NumBuckets */
+    int64_t n_values;     /* HIST: len(Values) */
+    const int64_t *values;      /* HIST + want_percentiles: bucket counts, else NULL */
+    const int64_t *percentiles; /* HIST + want_percentiles: 100 entries (GetPercentiles), else NULL */
+    int64_t n_outliers;   /* accepted values clipped into the last bucket */
+} sybl_agg_out;
+
+typedef struct {
+    const uint8_t *binary_key; /* Result.BinaryByKey: 8 LE bytes per group column */
+    const char *group_by_key;  /* Result.GroupByKey: values joined and terminated by '\t' */
+    int64_t time_bucket;       /* TimeResults key (0 for all-time results) */
+    int64_t count;             /* Result.Count */
+    int64_t samples;           /* Result.Samples */
+    const sybl_agg_out *aggs;  /* n_aggs entries */
+} sybl_group_row;
+
+/* which: 0 = Results (every group, sorted by order_by; the limit is applied when rendering,
+ *            as printSortedResults does), 1 = TimeResults (by bucket, then key),
+ *        2 = Cumulative ("TOTAL", one row) */
+int sybl_result_rows(const sybl_result *r, int which, const sybl_group_row **rows, int64_t *n);
+int64_t sybl_result_matched(const sybl_result *r); /* QuerySpec.MatchedCount */
+void sybl_result_free(sybl_result *r);
+
+typedef struct {
+    int64_t rows_scanned;     /* rows of blocks that were not skipped */
+    int64_t blocks_scanned, blocks_skipped;
+    int64_t algorithmic_bytes;/* rows_scanned x sum of stored widths of referenced columns */
+    double scan_ms;           /* hipEvent time of the scan kernel(s) of the last sybl_query_scan */
+    double reduce_ms;         /* partial-table fold kernels */
+    int32_t n_cells;          /* direct-mapped group cells */
+    int32_t strategy;         /* 0 = LDS-resident table, 1 = global atomics, ... */
+    int32_t lds_bytes, n_workgroups, replicas;
+} sybl_run_stats;
+/* Valid after the stream has been synchronised (sybl_query_finalize / sybl_ctx_sync). */
+int sybl_query_stats(sybl_query *q, sybl_run_stats *out);
+
+/* reference output surface (printer.go:109-232,291-308): renders a result the way
+ * `sybil query` prints it.  format: 0 = text table, 1 = -json.  Returns a
+ * library-owned NUL-terminated buffer valid until the result is freed. */
+const char *sybl_result_render(sybl_result *r, int format);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SYBILGPU_H */

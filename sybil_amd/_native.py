@@ -1,0 +1,146 @@
+"""ctypes view of the C ABI in include/sybilgpu.h (libsybilgpu.so).
+
+The library is built in-tree by `__graft_entry__.build()` / `make -C sybil_amd/csrc`.
+There is no CPU fallback: if the shared object is missing, loading fails loudly.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsybilgpu.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "sybilgpu.h")
+
+OK, E_INVAL, E_NODEVICE, E_NOMEM, E_IO, E_STATE, E_BLOCK = 0, -1, -2, -3, -4, -5, -6
+NO_VAL, INT_VAL, STR_VAL, SET_VAL = 0, 1, 2, 3
+OPS = {"gt": 0, "lt": 1, "eq": 2, "neq": 3, "re": 4, "nre": 5, "in": 6, "nin": 7}
+AGG_AVG, AGG_HIST = 0, 1
+SYN_UNIFORM, SYN_TIME, SYN_BELL = 0, 1, 2
+MAX_GROUPS, MAX_AGGS, MAX_FILTERS = 4, 6, 16
+
+
+class SyblError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("sybilgpu error %d: %s" % (code, msg))
+        self.code = code
+
+
+class ColView(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("type", C.c_int32), ("ints", C.c_void_p), ("str_ids", C.c_void_p),
+                ("set_off", C.c_void_p), ("set_ids", C.c_void_p), ("populated", C.c_void_p),
+                ("strings", C.POINTER(C.c_char_p)), ("n_strings", C.c_int32)]
+
+
+class SynthCol(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("kind", C.c_int32), ("col_index", C.c_int32), ("a", C.c_int64),
+                ("b", C.c_int64), ("info_min", C.c_int64), ("info_max", C.c_int64)]
+
+
+class Filter(C.Structure):
+    _fields_ = [("col", C.c_char_p), ("op", C.c_int32), ("int_value", C.c_int64), ("str_value", C.c_char_p),
+                ("id_match", C.c_void_p), ("id_match_len", C.c_int64)]
+
+
+class QueryDesc(C.Structure):
+    _fields_ = [("n_filters", C.c_int32), ("filters", C.POINTER(Filter)),
+                ("n_groups", C.c_int32), ("groups", C.POINTER(C.c_char_p)),
+                ("n_aggs", C.c_int32), ("aggs", C.POINTER(C.c_char_p)),
+                ("op", C.c_int32), ("hist_bucket", C.c_int64), ("want_percentiles", C.c_int32),
+                ("time_col", C.c_char_p), ("time_bucket", C.c_int64), ("weight_col", C.c_char_p),
+                ("order_by", C.c_char_p), ("order_asc", C.c_int32), ("limit", C.c_int32),
+                ("block_skip", C.c_int32)]
+
+
+class AggOut(C.Structure):
+    _fields_ = [("present", C.c_int32), ("count", C.c_int64), ("samples", C.c_int64), ("sum", C.c_int64),
+                ("avg", C.c_double), ("stddev", C.c_double), ("min", C.c_int64), ("max", C.c_int64),
+                ("bucket_size", C.c_int64), ("num_buckets", C.c_int64), ("n_values", C.c_int64),
+                ("values", C.POINTER(C.c_int64)), ("percentiles", C.POINTER(C.c_int64)),
+                ("n_outliers", C.c_int64)]
+
+
+class GroupRow(C.Structure):
+    _fields_ = [("binary_key", C.POINTER(C.c_uint8)), ("group_by_key", C.c_char_p), ("time_bucket", C.c_int64),
+                ("count", C.c_int64), ("samples", C.c_int64), ("aggs", C.POINTER(AggOut))]
+
+
+class RunStats(C.Structure):
+    _fields_ = [("rows_scanned", C.c_int64), ("blocks_scanned", C.c_int64), ("blocks_skipped", C.c_int64),
+                ("algorithmic_bytes", C.c_int64), ("scan_ms", C.c_double), ("reduce_ms", C.c_double),
+                ("n_cells", C.c_int32), ("strategy", C.c_int32), ("lds_bytes", C.c_int32),
+                ("n_workgroups", C.c_int32), ("replicas", C.c_int32)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+# every symbol include/sybilgpu.h declares: (restype, argtypes)
+P = C.c_void_p
+SIGNATURES = {
+    "sybl_abi_version": (C.c_int, []),
+    "sybl_last_error": (C.c_char_p, []),
+    "sybl_init": (C.c_int, [C.c_int, C.POINTER(P)]),
+    "sybl_shutdown": (None, [P]),
+    "sybl_ctx_set_stream": (C.c_int, [P, P]),
+    "sybl_ctx_sync": (C.c_int, [P]),
+    "sybl_device_info": (C.c_int, [P, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
+    "sybl_table_create": (C.c_int, [P, C.c_char_p, C.POINTER(P)]),
+    "sybl_table_free": (None, [P]),
+    "sybl_table_add_column": (C.c_int, [P, C.c_char_p, C.c_int, C.c_int64, C.c_int64]),
+    "sybl_table_append_block": (C.c_int, [P, C.c_int64, C.c_int32, C.POINTER(ColView)]),
+    "sybl_table_create_synth": (C.c_int, [P, C.c_char_p, C.c_uint64, C.c_int64, C.c_int64, C.c_int64, C.c_int32,
+                                          C.POINTER(SynthCol), C.POINTER(P)]),
+    "sybl_table_open": (C.c_int, [P, C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), C.c_int32, C.c_int32, C.c_int32,
+                                  C.POINTER(P)]),
+    "sybl_table_rows": (C.c_int64, [P]),
+    "sybl_table_blocks": (C.c_int64, [P]),
+    "sybl_table_hbm_bytes": (C.c_int64, [P]),
+    "sybl_table_column_info": (C.c_int, [P, C.c_char_p, C.POINTER(C.c_int)] + [C.POINTER(C.c_int64)] * 4
+                               + [C.POINTER(C.c_int)]),
+    "sybl_table_set_bounds": (C.c_int, [P, C.c_char_p, C.c_int64, C.c_int64, C.c_int]),
+    "sybl_table_read_int": (C.c_int, [P, C.c_char_p, C.c_int64, C.c_int64, P]),
+    "sybl_query_prepare": (C.c_int, [P, C.POINTER(QueryDesc), C.POINTER(P)]),
+    "sybl_query_free": (None, [P]),
+    "sybl_query_scan": (C.c_int, [P]),
+    "sybl_query_partials": (C.c_int, [P, C.POINTER(P), C.POINTER(C.c_int64), C.POINTER(P), C.POINTER(C.c_int64)]),
+    "sybl_query_bind_partials": (C.c_int, [P, P, P]),
+    "sybl_comm_unique_id": (C.c_int, [P]),
+    "sybl_comm_init": (C.c_int, [P, P, C.c_int32, C.c_int32]),
+    "sybl_comm_free": (C.c_int, [P]),
+    "sybl_query_allreduce": (C.c_int, [P]),
+    "sybl_query_finalize": (C.c_int, [P, C.POINTER(P)]),
+    "sybl_result_rows": (C.c_int, [P, C.c_int, C.POINTER(C.POINTER(GroupRow)), C.POINTER(C.c_int64)]),
+    "sybl_result_matched": (C.c_int64, [P]),
+    "sybl_result_free": (None, [P]),
+    "sybl_query_stats": (C.c_int, [P, C.POINTER(RunStats)]),
+    "sybl_result_render": (C.c_char_p, [P, C.c_int]),
+}
+
+_lib = None
+
+
+def lib():
+    """Loads libsybilgpu.so; raises if it has not been built (no silent fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "%s is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()' "
+                "or make -C sybil_amd/csrc). sybil_amd has no CPU fallback." % LIB_PATH)
+        # torch wheels bundle their own ROCm runtime (libamdhip64.so.7, libhsa-runtime64.so.1,
+        # librccl.so.1) under torch/lib with the same sonames as /opt/rocm/lib.  Whichever copy is
+        # loaded first serves the whole process, so load torch's first: the engine then shares ONE
+        # HIP runtime (streams, device memory, RCCL) with torch instead of mixing two.
+        import torch  # noqa: F401
+        L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the .so does not export what the header declares
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise SyblError(rc, (lib().sybl_last_error() or b"").decode("utf-8", "replace"))
+    return rc

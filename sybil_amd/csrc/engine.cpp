@@ -1,0 +1,1077 @@
+// engine.cpp -- context, HBM-resident tables, the query planner and the scan driver
+// behind the C ABI of include/sybilgpu.h.
+//
+// Reference mapping (src/lib/ of logv/sybil):
+//   Table / Column            <- table.go, table_column.go, record_slab.go (AoS row slabs become
+//                                dense per-column arrays in HBM)
+//   sybl_table_append_block   <- the output of LoadBlockFromDir (table_block_io.go:225-310)
+//   block skipping            <- ShouldLoadBlockFromDir (table_block_io.go:110-182)
+//   sybl_query_prepare        <- BuildFilters/Grouping/Aggregation (filter.go:59, query_spec.go:214-219)
+//   sybl_query_scan           <- the block loop of LoadAndQueryRecords (table_query.go:96-231)
+// There is no CPU fallback in this file: without a HIP device every call fails.
+#include "engine.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <regex>
+
+namespace sybl {
+
+static thread_local std::string g_err;
+
+void set_error(const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+
+int fail(int code, const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+int hip_fail(hipError_t e, const char *what) {
+    g_err = std::string("HIP error: ") + hipGetErrorString(e) + " in " + what;
+    return e == hipErrorOutOfMemory ? SYBL_E_NOMEM : SYBL_E_NODEVICE;
+}
+
+Column *Table::find(const char *n) const {
+    if (!n) return nullptr;
+    auto it = col_ix.find(n);
+    return it == col_ix.end() ? nullptr : cols[it->second].get();
+}
+
+static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+// ------------------------------------------------------------------ device arrays
+
+int table_reserve(Table *t, Column *c, int64_t phys_rows) {
+    // + one tile of slack: the scan's 16-byte loads and its prefetch may touch up to one
+    // row past a segment end (never used, but it must be mapped)
+    int64_t need = phys_rows + kTileRows;
+    if (need <= c->cap_rows) return SYBL_OK;
+    int64_t cap = std::max<int64_t>(need, c->cap_rows + c->cap_rows / 2);
+    void *nd = nullptr;
+    SYBL_HIP(hipMalloc(&nd, (size_t)cap * c->elem));
+    if (c->d_data) {
+        SYBL_HIP(hipMemcpyAsync(nd, c->d_data, (size_t)t->phys_rows * c->elem, hipMemcpyDeviceToDevice, t->ctx->stream));
+        SYBL_HIP(hipStreamSynchronize(t->ctx->stream));
+        SYBL_HIP(hipFree(c->d_data));
+    }
+    c->d_data = nd;
+    c->cap_rows = cap;
+    return SYBL_OK;
+}
+
+static int valid_reserve(Table *t, Column *c, int64_t phys_rows) {
+    int64_t words = round_up(phys_rows + kTileRows, 32) / 32 + 1;
+    if (c->d_valid && words <= c->valid_cap_words) return SYBL_OK;
+    int64_t cap = std::max<int64_t>(words, c->valid_cap_words * 2);
+    uint32_t *nd = nullptr;
+    SYBL_HIP(hipMalloc((void **)&nd, (size_t)cap * 4));
+    int64_t old_words = round_up(t->phys_rows, 32) / 32;
+    if (c->d_valid) {
+        SYBL_HIP(hipMemcpyAsync(nd, c->d_valid, (size_t)old_words * 4, hipMemcpyDeviceToDevice, t->ctx->stream));
+    } else {
+        // every earlier row of this column was populated
+        SYBL_HIP(hipMemsetAsync(nd, 0xFF, (size_t)old_words * 4, t->ctx->stream));
+    }
+    SYBL_HIP(hipMemsetAsync(nd + old_words, 0, (size_t)(cap - old_words) * 4, t->ctx->stream));
+    SYBL_HIP(hipStreamSynchronize(t->ctx->stream));
+    if (c->d_valid) SYBL_HIP(hipFree(c->d_valid));
+    c->d_valid = nd;
+    c->valid_cap_words = cap;
+    return SYBL_OK;
+}
+
+int table_ensure_stats(Table *t) {
+    int64_t nb = (int64_t)t->blocks.size();
+    bool pending = false;
+    for (auto &c : t->cols)
+        if (c->type != SYBL_SET_VAL && c->stats_blocks < nb) pending = true;
+    if (!pending) return SYBL_OK;
+    hipStream_t st = t->ctx->stream;
+    if (t->d_blocks_n < nb) {
+        if (t->d_blocks) SYBL_HIP(hipFree(t->d_blocks));
+        SYBL_HIP(hipMalloc((void **)&t->d_blocks, (size_t)nb * sizeof(Segment)));
+        t->d_blocks_n = nb;
+    }
+    SYBL_HIP(hipMemcpyAsync(t->d_blocks, t->blocks.data(), (size_t)nb * sizeof(Segment), hipMemcpyHostToDevice, st));
+    int64_t *d_out = nullptr;
+    SYBL_HIP(hipMalloc((void **)&d_out, (size_t)nb * 3 * sizeof(int64_t)));
+    std::vector<int64_t> h((size_t)nb * 3);
+    for (auto &cp : t->cols) {
+        Column *c = cp.get();
+        if (c->type == SYBL_SET_VAL || c->stats_blocks >= nb) continue;
+        int64_t b0 = c->stats_blocks, n = nb - b0;
+        hipError_t e = launch_block_minmax(c->d_data, c->elem == 4, c->d_valid, t->d_blocks + b0, (int)n, d_out,
+                                           d_out + nb, d_out + 2 * nb, st);
+        if (e != hipSuccess) {
+            hipFree(d_out);
+            return hip_fail(e, "k_block_minmax");
+        }
+        SYBL_HIP(hipMemcpyAsync(h.data(), d_out, (size_t)nb * 3 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        SYBL_HIP(hipStreamSynchronize(st));
+        c->blk_min.resize((size_t)nb);
+        c->blk_max.resize((size_t)nb);
+        c->blk_pop.resize((size_t)nb);
+        for (int64_t k = 0; k < n; k++) {
+            c->blk_min[(size_t)(b0 + k)] = h[(size_t)k];
+            c->blk_max[(size_t)(b0 + k)] = h[(size_t)(nb + k)];
+            c->blk_pop[(size_t)(b0 + k)] = h[(size_t)(2 * nb + k)];
+            if (h[(size_t)(2 * nb + k)] > 0) {
+                c->exact_min = std::min(c->exact_min, h[(size_t)k]);
+                c->exact_max = std::max(c->exact_max, h[(size_t)(nb + k)]);
+            }
+            c->n_pop += h[(size_t)(2 * nb + k)];
+            if (h[(size_t)(2 * nb + k)] < t->blocks[(size_t)(b0 + k)].n) c->has_missing = true;
+        }
+        c->stats_blocks = nb;
+    }
+    SYBL_HIP(hipFree(d_out));
+    return SYBL_OK;
+}
+
+static void column_free(Column *c) {
+    if (c->d_data) hipFree(c->d_data);
+    if (c->d_valid) hipFree(c->d_valid);
+    if (c->d_set_off) hipFree(c->d_set_off);
+    if (c->d_set_vals) hipFree(c->d_set_vals);
+}
+
+static int32_t dict_intern(Column *c, const std::string &s) {
+    auto it = c->dict_ix.find(s);
+    if (it != c->dict_ix.end()) return it->second;
+    int32_t id = (int32_t)c->dict.size();
+    c->dict.push_back(s);
+    c->dict_ix.emplace(s, id);
+    return id;
+}
+
+// ------------------------------------------------------------------ planner
+
+struct HostFilterFold {
+    bool has_range = false;
+    int64_t lo = INT64_MIN, hi = INT64_MAX;
+    std::vector<int64_t> neq;
+    bool has_mask = false;
+    std::vector<uint8_t> mask;  // per dictionary id, ANDed over the column's str filters
+};
+
+// hist_basic.go:34-70
+static void setup_buckets(int64_t info_min, int64_t info_max, int64_t hist_bucket, int64_t *bucket_size,
+                          int64_t *num_buckets, int64_t *n_values) {
+    int64_t size = info_max - info_min;
+    int64_t nb = 1000;  // NUM_BUCKETS, hist.go:3
+    int64_t bs = size / nb;
+    if (hist_bucket > 0) bs = hist_bucket;
+    if (bs == 0) {
+        if (size < 100) {
+            bs = 1;
+            nb = size;
+        } else {
+            bs = size / 100;
+            nb = size / bs;
+        }
+    }
+    nb += 1;
+    *bucket_size = bs;
+    *num_buckets = nb;
+    *n_values = nb + 1;
+}
+
+static void free_query(Query *q) {
+    if (!q) return;
+    if (q->d_plan) hipFree(q->d_plan);
+    if (q->d_segs) hipFree(q->d_segs);
+    if (q->d_wg_seg_begin) hipFree(q->d_wg_seg_begin);
+    for (void *p : q->d_idmasks) hipFree(p);
+    if (q->own_partials) {
+        if (q->d_sum) hipFree(q->d_sum);
+        if (q->d_max) hipFree(q->d_max);
+    }
+    if (q->d_ws_sum) hipFree(q->d_ws_sum);
+    if (q->d_ws_max) hipFree(q->d_ws_max);
+    for (auto &e : q->ev)
+        if (e) hipEventDestroy(e);
+    delete q;
+}
+
+// ShouldLoadBlockFromDir (table_block_io.go:110-182) on exact per-block extrema: a gt/lt
+// filter that is false on BOTH the block minimum and maximum, or an eq constant outside
+// [min,max], skips the block; a filter column without a single populated row in the block
+// fails on both pseudo-records as well.
+static bool should_scan_block(const Table *t, const sybl_query_desc *d, int64_t b) {
+    for (int i = 0; i < d->n_filters; i++) {
+        const sybl_filter &f = d->filters[i];
+        const Column *c = t->find(f.col);
+        if (!c || c->type != SYBL_INT_VAL) continue;
+        if (f.op != SYBL_OP_GT && f.op != SYBL_OP_LT && f.op != SYBL_OP_EQ) continue;
+        if (c->blk_pop[(size_t)b] == 0) return false;
+        int64_t mn = c->blk_min[(size_t)b], mx = c->blk_max[(size_t)b], v = f.int_value;
+        if (f.op == SYBL_OP_GT && !(mn > v) && !(mx > v)) return false;
+        if (f.op == SYBL_OP_LT && !(mn < v) && !(mx < v)) return false;
+        if (f.op == SYBL_OP_EQ && (mn > v || mx < v)) return false;
+    }
+    return true;
+}
+
+static int plan_query(Table *t, const sybl_query_desc *d, Query *q) {
+    Ctx *ctx = t->ctx;
+    if (d->n_groups > SYBL_MAX_GROUPS) return fail(SYBL_E_INVAL, "too many group columns (%d > %d)", d->n_groups, SYBL_MAX_GROUPS);
+    if (d->n_aggs > SYBL_MAX_AGGS) return fail(SYBL_E_INVAL, "too many aggregations (%d > %d)", d->n_aggs, SYBL_MAX_AGGS);
+    if (d->n_filters > SYBL_MAX_FILTERS) return fail(SYBL_E_INVAL, "too many filters");
+    if (d->op != SYBL_AGG_AVG && d->op != SYBL_AGG_HIST) return fail(SYBL_E_INVAL, "unknown op %d", d->op);
+    int rc = table_ensure_stats(t);
+    if (rc) return rc;
+
+    q->op = d->op;
+    q->hist_bucket = d->hist_bucket;
+    q->want_percentiles = d->op == SYBL_AGG_HIST && d->want_percentiles;
+    q->order_by = d->order_by ? d->order_by : "";
+    q->order_asc = d->order_asc != 0;
+    q->limit = d->limit;
+    q->time_mode = d->time_bucket > 0 && d->time_col && d->time_col[0];
+    q->time_bucket = q->time_mode ? d->time_bucket : 0;
+    q->weighted = d->weight_col && d->weight_col[0];
+
+    ScanPlan &P = q->plan;
+    memset(&P, 0, sizeof(P));
+    P.time_slot = -1;
+    P.weight_slot = -1;
+    P.f_samples = -1;
+    P.hist_mode = d->op == SYBL_AGG_HIST;
+    P.weighted = q->weighted;
+
+    // ---- slots: one per distinct referenced column
+    std::vector<int> slot_col;  // table column index per slot
+    std::vector<HostFilterFold> folds;
+    auto slot_of = [&](const char *name, int *out) -> int {
+        Column *c = t->find(name);
+        if (!c) return fail(SYBL_E_INVAL, "unknown column '%s'", name ? name : "(null)");
+        int ci = t->col_ix[name];
+        for (size_t s = 0; s < slot_col.size(); s++)
+            if (slot_col[s] == ci) {
+                *out = (int)s;
+                return SYBL_OK;
+            }
+        if ((int)slot_col.size() >= kMaxSlots) return fail(SYBL_E_INVAL, "query references more than %d columns", kMaxSlots);
+        slot_col.push_back(ci);
+        folds.emplace_back();
+        *out = (int)slot_col.size() - 1;
+        return SYBL_OK;
+    };
+
+    // ---- filters (filter.go:171-285), folded per column
+    for (int i = 0; i < d->n_filters; i++) {
+        const sybl_filter &f = d->filters[i];
+        int s;
+        if ((rc = slot_of(f.col, &s))) return rc;
+        Column *c = t->cols[(size_t)slot_col[(size_t)s]].get();
+        HostFilterFold &ff = folds[(size_t)s];
+        if (c->type == SYBL_INT_VAL) {
+            int64_t v = f.int_value;
+            switch (f.op) {
+            case SYBL_OP_GT:  // field > v
+                ff.has_range = true;
+                if (v == INT64_MAX) q->never_matches = true; else ff.lo = std::max(ff.lo, v + 1);
+                break;
+            case SYBL_OP_LT:
+                ff.has_range = true;
+                if (v == INT64_MIN) q->never_matches = true; else ff.hi = std::min(ff.hi, v - 1);
+                break;
+            case SYBL_OP_EQ:
+                ff.has_range = true;
+                ff.lo = std::max(ff.lo, v);
+                ff.hi = std::min(ff.hi, v);
+                break;
+            case SYBL_OP_NEQ:
+                if ((int)ff.neq.size() >= kMaxNeq) return fail(SYBL_E_INVAL, "more than %d neq filters on '%s'", kMaxNeq, f.col);
+                ff.neq.push_back(v);
+                break;
+            default:
+                // IntFilter.Filter's default branch returns false for every row (filter.go:189-193)
+                q->never_matches = true;
+                ff.has_range = true;
+            }
+        } else if (c->type == SYBL_STR_VAL) {
+            // eq/neq compare dictionary ids, re/nre go through a per-id match table
+            // (the reference's RCache, filter.go:213-236); all become one bit per id.
+            size_t n = c->dict.size();
+            std::vector<uint8_t> m(n, 0);
+            if (f.op == SYBL_OP_EQ || f.op == SYBL_OP_NEQ) {
+                auto it = c->dict_ix.find(f.str_value ? f.str_value : "");
+                for (size_t k = 0; k < n; k++) m[k] = f.op == SYBL_OP_NEQ;
+                if (it != c->dict_ix.end()) m[(size_t)it->second] = f.op == SYBL_OP_EQ;
+            } else if (f.op == SYBL_OP_RE || f.op == SYBL_OP_NRE) {
+                if (f.id_match) {
+                    for (size_t k = 0; k < n; k++) {
+                        bool hit = (int64_t)k < f.id_match_len && f.id_match[k];
+                        m[k] = f.op == SYBL_OP_NRE ? !hit : hit;
+                    }
+                } else {
+                    try {
+                        std::regex re(f.str_value ? f.str_value : "", std::regex::ECMAScript);
+                        for (size_t k = 0; k < n; k++) {
+                            bool hit = std::regex_search(c->dict[k], re);
+                            m[k] = f.op == SYBL_OP_NRE ? !hit : hit;
+                        }
+                    } catch (const std::regex_error &e) {
+                        return fail(SYBL_E_INVAL, "bad regex '%s': %s", f.str_value ? f.str_value : "", e.what());
+                    }
+                }
+            } else {
+                q->never_matches = true;  // StrFilter default branch: ret stays false
+            }
+            if (!ff.has_mask) {
+                ff.mask = m;
+                ff.has_mask = true;
+            } else {
+                for (size_t k = 0; k < n; k++) ff.mask[k] = ff.mask[k] && m[k];
+            }
+        } else {
+            return fail(SYBL_E_INVAL, "set filters are not supported by this build yet ('%s')", f.col);
+        }
+    }
+
+    // ---- group columns (aggregate.go:125-143); direct-mapped on declared or exact bounds
+    int64_t cells = 1;
+    for (int g = 0; g < d->n_groups; g++) {
+        int s;
+        if ((rc = slot_of(d->groups[g], &s))) return rc;
+        Column *c = t->cols[(size_t)slot_col[(size_t)s]].get();
+        if (c->type == SYBL_SET_VAL) return fail(SYBL_E_INVAL, "cannot group by set column '%s' (cmd_query.go:254)", c->name.c_str());
+        if (P.slot[s].flags & kSlotGroup) return fail(SYBL_E_INVAL, "column '%s' grouped twice", c->name.c_str());
+        GroupInfo gi;
+        gi.col = slot_col[(size_t)s];
+        gi.type = c->type;
+        gi.has_missing = c->has_missing;
+        int64_t lo, hi;
+        if (c->bounds_set) {
+            lo = c->bound_lo;
+            hi = c->bound_hi;
+        } else if (c->type == SYBL_STR_VAL) {
+            lo = 0;
+            hi = (int64_t)c->dict.size() - 1;
+        } else {
+            lo = c->exact_min;
+            hi = c->exact_max;
+        }
+        if (c->n_pop == 0 && !c->bounds_set) {
+            lo = 0;
+            hi = -1;
+        }
+        unsigned __int128 card = hi >= lo ? (unsigned __int128)((__int128)hi - (__int128)lo) + 1 : 0;
+        if (gi.has_missing) card += 1;
+        if (card == 0) card = 1;
+        if (card * (unsigned __int128)cells > ((unsigned __int128)1 << 27))
+            return fail(SYBL_E_INVAL,
+                        "group-by on '%s' needs more than 2^27 direct-mapped cells (value range [%lld,%lld]); "
+                        "hash group-by is not available in this build",
+                        c->name.c_str(), (long long)lo, (long long)hi);
+        gi.gmin = lo;
+        gi.gcard = (int32_t)card;
+        q->groups.push_back(gi);
+        cells *= (int64_t)card;
+    }
+    // strides: first group column is the most significant digit (keeps canonical key order
+    // equal to cell order)
+    {
+        int64_t stride = cells;
+        for (size_t g = 0; g < q->groups.size(); g++) {
+            stride /= q->groups[g].gcard;
+            int s = -1;
+            for (size_t k = 0; k < slot_col.size(); k++)
+                if (slot_col[k] == q->groups[g].col) s = (int)k;
+            SlotDesc &sd = P.slot[s];
+            sd.flags |= kSlotGroup;
+            sd.gmin = q->groups[g].gmin;
+            sd.gcard = q->groups[g].gcard;
+            sd.gstride = (int32_t)stride;
+            sd.gmissing = q->groups[g].has_missing ? (int32_t)((q->groups[g].gcard - 1) * stride) : -1;
+        }
+    }
+    q->group_cells = cells;
+
+    // ---- time series (aggregate.go:146-183)
+    P.n_tb = 1;
+    P.tb_stride = (int32_t)cells;
+    if (q->time_mode) {
+        int s;
+        if ((rc = slot_of(d->time_col, &s))) return rc;
+        Column *c = t->cols[(size_t)slot_col[(size_t)s]].get();
+        if (c->type != SYBL_INT_VAL) return fail(SYBL_E_INVAL, "time column '%s' is not an int column", c->name.c_str());
+        P.slot[s].flags |= kSlotTime;
+        P.time_slot = s;
+        P.time_bucket = d->time_bucket;
+        P.inv_time_bucket = 1.0 / (double)d->time_bucket;
+        int64_t lo = c->bounds_set ? c->bound_lo : c->exact_min, hi = c->bounds_set ? c->bound_hi : c->exact_max;
+        if (c->n_pop == 0 && !c->bounds_set) lo = hi = 0;
+        int64_t tlo = lo / d->time_bucket, thi = hi / d->time_bucket;  // truncating, like aggregate.go:174
+        P.tb_min = tlo;
+        int64_t ntb = thi - tlo + 1;
+        if (ntb * cells > ((int64_t)1 << 27)) return fail(SYBL_E_INVAL, "time buckets x groups exceeds 2^27 cells");
+        P.n_tb = (int32_t)ntb;
+        uint64_t amax = (uint64_t)std::max(llabs((long long)lo), llabs((long long)hi));
+        P.tb_big_div = amax >= ((uint64_t)1 << 51);
+    }
+    int64_t n_cells = cells * P.n_tb;
+    P.n_cells = (int32_t)n_cells;
+
+    // ---- weight column (aggregate.go:100-102)
+    if (q->weighted) {
+        int s;
+        if ((rc = slot_of(d->weight_col, &s))) return rc;
+        Column *c = t->cols[(size_t)slot_col[(size_t)s]].get();
+        if (c->type != SYBL_INT_VAL) return fail(SYBL_E_INVAL, "weight column '%s' is not an int column", c->name.c_str());
+        if (c->has_missing)
+            return fail(SYBL_E_INVAL, "weight column '%s' has missing rows (the reference's carry-over of the previous "
+                        "row's weight, aggregate.go:68, is not reproduced)", c->name.c_str());
+        P.slot[s].flags |= kSlotWeight;
+        P.weight_slot = s;
+    }
+
+    // ---- aggregations (aggregate.go:246-261, hist_basic.go:72-151)
+    int F = 1;  // field 0: Result.Count
+    if (q->weighted) P.f_samples = F++;
+    int M = 0;
+    int64_t hist_stride = 0;
+    for (int a = 0; a < d->n_aggs; a++) {
+        int s;
+        if ((rc = slot_of(d->aggs[a], &s))) return rc;
+        Column *c = t->cols[(size_t)slot_col[(size_t)s]].get();
+        if (c->type != SYBL_INT_VAL) {
+            // the reference silently ignores non-int aggregation columns (aggregate.go:247-248)
+            return fail(SYBL_E_INVAL, "aggregation column '%s' is not an int column", c->name.c_str());
+        }
+        if (P.slot[s].flags & kSlotAgg) return fail(SYBL_E_INVAL, "column '%s' aggregated twice", c->name.c_str());
+        AggInfo ai;
+        ai.col = slot_col[(size_t)s];
+        ai.name = c->name;
+        memset(&ai.d, 0, sizeof(ai.d));
+        AggDesc &A = ai.d;
+        int64_t lo = c->bounds_set ? c->bound_lo : c->exact_min, hi = c->bounds_set ? c->bound_hi : c->exact_max;
+        bool empty = c->n_pop == 0 && !c->bounds_set;
+        int64_t imin = c->info_given ? c->info_min : (empty ? 0 : lo);
+        int64_t imax = c->info_given ? c->info_max : (empty ? 0 : hi);
+        A.info_min = imin;
+        A.max10 = (int64_t)((uint64_t)imax * 10u);  // Go's wrapping int64 multiply (hist_basic.go:104)
+        A.f_sum = F++;
+        bool can_reject = c->has_missing || (!empty && (lo < A.info_min || hi > A.max10));
+        A.f_cnt = (q->weighted || can_reject) ? F++ : -1;
+        A.f_smp = q->weighted ? F++ : -1;
+        A.f_sb = A.f_sb2 = A.f_out = -1;
+        A.m_max = M++;
+        A.m_nmin = M++;
+        ai.f_out = -1;
+        ai.num_buckets = 0;
+        ai.info_max = imax;
+        if (d->op == SYBL_AGG_HIST) {
+            if (imax < imin) return fail(SYBL_E_INVAL, "IntInfo of '%s' has max < min", c->name.c_str());
+            int64_t bs, nb, nv;
+            setup_buckets(imin, imax, d->hist_bucket, &bs, &nb, &nv);
+            if (bs <= 0 || nv <= 0 || nv > (1 << 20)) return fail(SYBL_E_INVAL, "bad bucket geometry for '%s'", c->name.c_str());
+            A.hmin = imin;
+            A.bucket_size = bs;
+            A.inv_bucket = 1.0 / (double)bs;
+            A.n_values = (int32_t)nv;
+            ai.num_buckets = nb;
+            // accepted values lie in [max(lo,imin), min(hi,max10)]
+            int64_t vhi = empty ? imin : std::min(hi, A.max10), vlo = empty ? imin : std::max(lo, imin);
+            unsigned __int128 span = vhi >= A.hmin ? (unsigned __int128)((__int128)vhi - (__int128)A.hmin) : 0;
+            A.big_div = span >= ((unsigned __int128)1 << 51);
+            bool can_outlie = span / (unsigned __int128)bs >= (unsigned __int128)nv || vlo < A.hmin;
+            if (can_outlie) {
+                A.f_out = F;
+                ai.f_out = F;
+                F += 6;
+            }
+            if (q->want_percentiles) {
+                A.hist_full = 1;
+                P.hist_agg_off[a] = hist_stride;
+                hist_stride += nv;
+            } else {
+                A.f_sb = F++;
+                A.f_sb2 = F++;
+            }
+        }
+        P.slot[s].flags |= kSlotAgg;
+        P.slot[s].agg_index = a;
+        P.agg[a] = A;
+        q->aggs.push_back(ai);
+    }
+    P.n_aggs = d->n_aggs;
+    P.n_sum_fields = F;
+    P.n_max_fields = M;
+    P.hist_stride = hist_stride;
+    P.hist_off = kHeaderWords + (int64_t)F * n_cells;
+    if ((unsigned __int128)n_cells * (unsigned __int128)hist_stride > ((unsigned __int128)1 << 31))
+        return fail(SYBL_E_INVAL, "groups x buckets = %lld x %lld words does not fit the 16 GiB histogram budget",
+                    (long long)n_cells, (long long)hist_stride);
+
+    // ---- finish slots
+    if (slot_col.empty()) {
+        // count(*) with no referenced column still needs the row count: stream any column
+        if (t->cols.empty()) return fail(SYBL_E_INVAL, "table has no columns");
+        int pick = -1;
+        for (size_t k = 0; k < t->cols.size(); k++)
+            if (t->cols[k]->type != SYBL_SET_VAL) { pick = (int)k; break; }
+        if (pick < 0) return fail(SYBL_E_INVAL, "table has no int/str column to drive the scan");
+        slot_col.push_back(pick);
+        folds.emplace_back();
+    }
+    P.n_slots = (int)slot_col.size();
+    for (int s = 0; s < P.n_slots; s++) {
+        Column *c = t->cols[(size_t)slot_col[(size_t)s]].get();
+        SlotDesc &sd = P.slot[s];
+        sd.base = c->d_data;
+        sd.valid = c->d_valid;
+        if (c->elem == 4) sd.flags |= kSlotW32;
+        HostFilterFold &ff = folds[(size_t)s];
+        if (ff.has_range) {
+            sd.flags |= kSlotRange;
+            sd.lo = ff.lo;
+            sd.hi = ff.hi;
+        }
+        if (!ff.neq.empty()) {
+            sd.flags |= kSlotNeq;
+            sd.n_neq = (int)ff.neq.size();
+            for (size_t k = 0; k < ff.neq.size(); k++) sd.neq[k] = ff.neq[k];
+        }
+        if (ff.has_mask) {
+            sd.flags |= kSlotIdMask;
+            size_t nbits = ff.mask.size(), nw = (nbits + 31) / 32 + 1;
+            std::vector<uint32_t> bits(nw, 0);
+            for (size_t k = 0; k < nbits; k++)
+                if (ff.mask[k]) bits[k >> 5] |= 1u << (k & 31);
+            uint32_t *dm = nullptr;
+            SYBL_HIP(hipMalloc((void **)&dm, nw * 4));
+            q->d_idmasks.push_back(dm);
+            SYBL_HIP(hipMemcpy(dm, bits.data(), nw * 4, hipMemcpyHostToDevice));
+            sd.idmask = dm;
+            sd.idmask_bits = (int32_t)nbits;
+        }
+    }
+
+    // ---- strategy: cell table in LDS when it fits (DESIGN.md "Strategies")
+    q->n_wg = ctx->n_cus > 0 ? ctx->n_cus : 256;
+    int64_t lds_words = (int64_t)(F + M) * n_cells;
+    q->use_lds = lds_words * 8 <= kLdsBudgetBytes;
+    P.rep_shift = 0;
+    if (q->use_lds) {
+        int rs = 0;
+        while (rs < 6 && (lds_words * 8 << (rs + 1)) <= kLdsBudgetBytes) rs++;
+        P.rep_shift = rs;
+        q->lds_bytes = (size_t)(lds_words * 8) << rs;
+    }
+    q->n_sum_words = kHeaderWords + (int64_t)F * n_cells + n_cells * hist_stride;
+    q->n_max_words = std::max<int64_t>((int64_t)M * n_cells, 1);
+
+    // ---- work: non-skipped blocks -> runs of physical rows -> an equal share of tiles per workgroup
+    std::vector<Segment> runs;
+    int64_t rows_scanned = 0, skipped = 0;
+    for (size_t b = 0; b < t->blocks.size(); b++) {
+        if (t->blocks[b].n == 0) continue;
+        if (d->block_skip && !should_scan_block(t, d, (int64_t)b)) {
+            skipped++;
+            continue;
+        }
+        rows_scanned += t->blocks[b].n;
+        const Segment &blk = t->blocks[b];
+        if (!runs.empty() && runs.back().start + runs.back().n == blk.start) {
+            runs.back().n += blk.n;
+        } else {
+            runs.push_back(blk);
+        }
+    }
+    int64_t total_tiles = 0;
+    for (auto &r : runs) total_tiles += (r.n + kTileRows - 1) / kTileRows;
+    q->segs.clear();
+    q->wg_seg_begin.assign((size_t)q->n_wg + 1, 0);
+    {
+        size_t ri = 0;
+        int64_t tile_in_run = 0;  // tiles of runs[ri] already handed out
+        for (int w = 0; w < q->n_wg; w++) {
+            q->wg_seg_begin[(size_t)w] = (int32_t)q->segs.size();
+            int64_t want = total_tiles * (w + 1) / q->n_wg - total_tiles * w / q->n_wg;
+            while (want > 0 && ri < runs.size()) {
+                int64_t run_tiles = (runs[ri].n + kTileRows - 1) / kTileRows;
+                int64_t take = std::min(want, run_tiles - tile_in_run);
+                Segment sg;
+                sg.start = runs[ri].start + tile_in_run * kTileRows;
+                int64_t end = std::min(runs[ri].start + runs[ri].n, sg.start + take * kTileRows);
+                sg.n = end - sg.start;
+                q->segs.push_back(sg);
+                tile_in_run += take;
+                want -= take;
+                if (tile_in_run == run_tiles) {
+                    ri++;
+                    tile_in_run = 0;
+                }
+            }
+        }
+        q->wg_seg_begin[(size_t)q->n_wg] = (int32_t)q->segs.size();
+    }
+    q->stats.rows_scanned = rows_scanned;
+    q->stats.blocks_skipped = skipped;
+    q->stats.blocks_scanned = (int64_t)t->blocks.size() - skipped;
+    int64_t width = 0;
+    for (int s = 0; s < P.n_slots; s++) width += t->cols[(size_t)slot_col[(size_t)s]]->elem;
+    q->stats.algorithmic_bytes = rows_scanned * width;
+    q->stats.n_cells = (int32_t)n_cells;
+    q->stats.strategy = q->use_lds ? 0 : 1;
+    q->stats.lds_bytes = (int32_t)q->lds_bytes;
+    q->stats.n_workgroups = q->n_wg;
+    q->stats.replicas = 1 << P.rep_shift;
+
+    // ---- device-side copies
+    size_t nseg = std::max<size_t>(q->segs.size(), 1);
+    SYBL_HIP(hipMalloc((void **)&q->d_segs, nseg * sizeof(Segment)));
+    if (!q->segs.empty())
+        SYBL_HIP(hipMemcpy(q->d_segs, q->segs.data(), q->segs.size() * sizeof(Segment), hipMemcpyHostToDevice));
+    SYBL_HIP(hipMalloc((void **)&q->d_wg_seg_begin, q->wg_seg_begin.size() * 4));
+    SYBL_HIP(hipMemcpy(q->d_wg_seg_begin, q->wg_seg_begin.data(), q->wg_seg_begin.size() * 4, hipMemcpyHostToDevice));
+    P.segs = q->d_segs;
+    P.wg_seg_begin = q->d_wg_seg_begin;
+    if (q->use_lds) {
+        SYBL_HIP(hipMalloc((void **)&q->d_ws_sum, (size_t)q->n_wg * F * n_cells * 8));
+        SYBL_HIP(hipMalloc((void **)&q->d_ws_max, (size_t)q->n_wg * std::max<int64_t>((int64_t)M * n_cells, 1) * 8));
+        P.ws_sum = q->d_ws_sum;
+        P.ws_max = q->d_ws_max;
+    }
+    SYBL_HIP(hipMalloc((void **)&q->d_plan, sizeof(ScanPlan)));
+    for (auto &e : q->ev) SYBL_HIP(hipEventCreate(&e));
+    q->plan_dirty = true;
+    return SYBL_OK;
+}
+
+static int ensure_partials(Query *q) {
+    if (q->d_sum && q->d_max) return SYBL_OK;
+    SYBL_HIP(hipMalloc((void **)&q->d_sum, (size_t)q->n_sum_words * 8));
+    SYBL_HIP(hipMalloc((void **)&q->d_max, (size_t)q->n_max_words * 8));
+    q->own_partials = true;
+    q->plan_dirty = true;
+    return SYBL_OK;
+}
+
+static int scan(Query *q) {
+    int rc = ensure_partials(q);
+    if (rc) return rc;
+    hipStream_t st = q->ctx->stream;
+    ScanPlan &P = q->plan;
+    if (q->plan_dirty) {
+        P.sum_out = q->d_sum;
+        P.max_out = q->d_max;
+        // synchronous copy: the plan object may be rewritten by the host right after
+        SYBL_HIP(hipMemcpy(q->d_plan, &P, sizeof(ScanPlan), hipMemcpyHostToDevice));
+        q->plan_dirty = false;
+    }
+    SYBL_HIP(hipMemsetAsync(q->d_sum, 0, (size_t)q->n_sum_words * 8, st));
+    hipError_t e = launch_fill64(q->d_max, q->n_max_words, INT64_MIN, st);
+    if (e != hipSuccess) return hip_fail(e, "k_fill64");
+    SYBL_HIP(hipEventRecord(q->ev[0], st));
+    if (!q->never_matches && !q->segs.empty()) {
+        e = launch_scan(q->d_plan, P.n_slots, q->n_wg, q->use_lds, q->lds_bytes, st);
+        if (e != hipSuccess) return hip_fail(e, "k_scan");
+    }
+    SYBL_HIP(hipEventRecord(q->ev[1], st));
+    if (q->use_lds && !q->never_matches && !q->segs.empty()) {
+        int64_t wsum = (int64_t)P.n_sum_fields * P.n_cells, wmax = (int64_t)P.n_max_fields * P.n_cells;
+        e = launch_fold(q->d_ws_sum, q->d_sum + kHeaderWords, wsum, q->n_wg, false, st);
+        if (e != hipSuccess) return hip_fail(e, "k_fold(sum)");
+        e = launch_fold(q->d_ws_max, q->d_max, wmax, q->n_wg, true, st);
+        if (e != hipSuccess) return hip_fail(e, "k_fold(max)");
+    }
+    SYBL_HIP(hipEventRecord(q->ev[2], st));
+    q->scanned = true;
+    return SYBL_OK;
+}
+
+}  // namespace sybl
+
+using namespace sybl;
+
+// ==================================================================== C ABI
+
+extern "C" {
+
+int sybl_abi_version(void) { return SYBL_ABI_VERSION; }
+
+const char *sybl_last_error(void) { return g_err.c_str(); }
+
+int sybl_init(int device, sybl_ctx **out) {
+    if (!out) return fail(SYBL_E_INVAL, "sybl_init: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(SYBL_E_NODEVICE, "no HIP device available (%s); this library has no CPU fallback",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+    if (device < 0 || device >= n) return fail(SYBL_E_INVAL, "device %d out of range (have %d)", device, n);
+    SYBL_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    SYBL_HIP(hipGetDeviceProperties(&prop, device));
+    sybl_ctx *c = new sybl_ctx();
+    c->device = device;
+    c->n_cus = prop.multiProcessorCount;
+    c->hbm_bytes = (int64_t)prop.totalGlobalMem;
+    c->dev_name = prop.name;
+    e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete c;
+        return hip_fail(e, "hipStreamCreate");
+    }
+    c->stream = c->own_stream;
+    *out = c;
+    return SYBL_OK;
+}
+
+void sybl_shutdown(sybl_ctx *ctx) {
+    if (!ctx) return;
+    sybl_comm_free(ctx);
+    if (ctx->own_stream) {
+        hipStreamSynchronize(ctx->own_stream);
+        hipStreamDestroy(ctx->own_stream);
+    }
+    delete ctx;
+}
+
+int sybl_ctx_set_stream(sybl_ctx *ctx, void *hip_stream) {
+    if (!ctx) return fail(SYBL_E_INVAL, "ctx is NULL");
+    SYBL_HIP(hipSetDevice(ctx->device));
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return SYBL_OK;
+}
+
+int sybl_ctx_sync(sybl_ctx *ctx) {
+    if (!ctx) return fail(SYBL_E_INVAL, "ctx is NULL");
+    SYBL_HIP(hipSetDevice(ctx->device));
+    SYBL_HIP(hipStreamSynchronize(ctx->stream));
+    return SYBL_OK;
+}
+
+int sybl_device_info(sybl_ctx *ctx, char *name, size_t name_cap, int *n_cus, int64_t *hbm_bytes) {
+    if (!ctx) return fail(SYBL_E_INVAL, "ctx is NULL");
+    if (name && name_cap) snprintf(name, name_cap, "%s", ctx->dev_name.c_str());
+    if (n_cus) *n_cus = ctx->n_cus;
+    if (hbm_bytes) *hbm_bytes = ctx->hbm_bytes;
+    return SYBL_OK;
+}
+
+// ------------------------------------------------------------------ tables
+
+int sybl_table_create(sybl_ctx *ctx, const char *name, sybl_table **out) {
+    if (!ctx || !out) return fail(SYBL_E_INVAL, "sybl_table_create: NULL argument");
+    sybl_table *t = new sybl_table();
+    t->ctx = ctx;
+    t->name = name ? name : "";
+    *out = t;
+    return SYBL_OK;
+}
+
+void sybl_table_free(sybl_table *t) {
+    if (!t) return;
+    hipSetDevice(t->ctx->device);
+    hipStreamSynchronize(t->ctx->stream);
+    for (auto &c : t->cols) column_free(c.get());
+    if (t->d_blocks) hipFree(t->d_blocks);
+    delete t;
+}
+
+int sybl_table_add_column(sybl_table *t, const char *name, int type, int64_t info_min, int64_t info_max) {
+    if (!t || !name) return fail(SYBL_E_INVAL, "sybl_table_add_column: NULL argument");
+    if (type != SYBL_INT_VAL && type != SYBL_STR_VAL && type != SYBL_SET_VAL) return fail(SYBL_E_INVAL, "bad column type %d", type);
+    if (t->col_ix.count(name)) return fail(SYBL_E_INVAL, "column '%s' already exists", name);
+    if (!t->blocks.empty()) return fail(SYBL_E_STATE, "columns must be declared before the first block");
+    auto c = std::make_unique<Column>();
+    c->name = name;
+    c->type = type;
+    c->elem = type == SYBL_INT_VAL ? 8 : 4;
+    c->info_given = info_min <= info_max;
+    c->info_min = info_min;
+    c->info_max = info_max;
+    t->col_ix[name] = (int)t->cols.size();
+    t->cols.push_back(std::move(c));
+    return SYBL_OK;
+}
+
+int sybl_table_append_block(sybl_table *t, int64_t nrows, int32_t ncols, const sybl_col_view *cols) {
+    if (!t || nrows < 0 || (ncols > 0 && !cols)) return fail(SYBL_E_INVAL, "sybl_table_append_block: bad argument");
+    SYBL_HIP(hipSetDevice(t->ctx->device));
+    hipStream_t st = t->ctx->stream;
+    for (int i = 0; i < ncols; i++) {
+        Column *c = t->find(cols[i].name);
+        if (!c) return fail(SYBL_E_BLOCK, "block has unknown column '%s'", cols[i].name ? cols[i].name : "(null)");
+        if (c->type != cols[i].type) return fail(SYBL_E_BLOCK, "column '%s' type mismatch", c->name.c_str());
+    }
+    int64_t start = round_up(t->phys_rows, 32);
+    int64_t new_phys = start + nrows;
+    std::vector<uint32_t> bits;
+    std::vector<int32_t> ids;
+    for (auto &cp : t->cols) {
+        Column *c = cp.get();
+        const sybl_col_view *v = nullptr;
+        for (int i = 0; i < ncols; i++)
+            if (c->name == cols[i].name) v = &cols[i];
+        int rc = SYBL_OK;
+        if (c->type != SYBL_SET_VAL) {
+            if ((rc = table_reserve(t, c, new_phys))) return rc;
+        }
+        bool any_missing = !v || v->populated != nullptr;
+        if (v && v->populated) {
+            any_missing = false;
+            for (int64_t r = 0; r < nrows; r++)
+                if (!v->populated[r]) { any_missing = true; break; }
+        }
+        if (nrows == 0) any_missing = false;
+        if (any_missing || c->d_valid) {
+            if ((rc = valid_reserve(t, c, new_phys))) return rc;
+            bits.assign((size_t)(round_up(nrows, 32) / 32), 0);
+            if (v) {
+                for (int64_t r = 0; r < nrows; r++)
+                    if (!v->populated || v->populated[r]) bits[(size_t)(r >> 5)] |= 1u << (r & 31);
+            }
+            if (!bits.empty())
+                SYBL_HIP(hipMemcpyAsync(c->d_valid + start / 32, bits.data(), bits.size() * 4, hipMemcpyHostToDevice, st));
+            SYBL_HIP(hipStreamSynchronize(st));
+            if (any_missing) c->has_missing = true;
+        }
+        if (!v || nrows == 0) {
+            if (c->type != SYBL_SET_VAL && nrows > 0)
+                SYBL_HIP(hipMemsetAsync((char *)c->d_data + (size_t)start * c->elem, 0, (size_t)nrows * c->elem, st));
+            continue;
+        }
+        if (c->type == SYBL_INT_VAL) {
+            if (!v->ints) return fail(SYBL_E_BLOCK, "int column '%s' without values", c->name.c_str());
+            SYBL_HIP(hipMemcpyAsync((int64_t *)c->d_data + start, v->ints, (size_t)nrows * 8, hipMemcpyHostToDevice, st));
+            SYBL_HIP(hipStreamSynchronize(st));
+        } else if (c->type == SYBL_STR_VAL) {
+            if (!v->str_ids) return fail(SYBL_E_BLOCK, "str column '%s' without ids", c->name.c_str());
+            // block-local dictionary ids -> table-global ids (SURVEY.md 8a note 8)
+            std::vector<int32_t> lut((size_t)std::max(v->n_strings, 0));
+            for (int k = 0; k < v->n_strings; k++) lut[(size_t)k] = dict_intern(c, v->strings[k] ? v->strings[k] : "");
+            ids.resize((size_t)nrows);
+            for (int64_t r = 0; r < nrows; r++) {
+                int32_t id = v->str_ids[r];
+                bool pop = !v->populated || v->populated[r];
+                if (pop && (id < 0 || id >= v->n_strings)) return fail(SYBL_E_BLOCK, "str id %d outside the block StringTable of '%s'", id, c->name.c_str());
+                ids[(size_t)r] = pop ? lut[(size_t)id] : 0;
+            }
+            SYBL_HIP(hipMemcpyAsync((int32_t *)c->d_data + start, ids.data(), (size_t)nrows * 4, hipMemcpyHostToDevice, st));
+            SYBL_HIP(hipStreamSynchronize(st));
+        } else {
+            return fail(SYBL_E_INVAL, "set columns are not supported by this build yet ('%s')", c->name.c_str());
+        }
+    }
+    Segment blk;
+    blk.start = start;
+    blk.n = nrows;
+    t->blocks.push_back(blk);
+    t->phys_rows = new_phys;
+    t->logical_rows += nrows;
+    return SYBL_OK;
+}
+
+int sybl_table_create_synth(sybl_ctx *ctx, const char *name, uint64_t seed, int64_t total_rows, int64_t row0,
+                            int64_t nrows, int32_t ncols, const sybl_synth_col *cols, sybl_table **out) {
+    if (!ctx || !out || !cols || ncols <= 0 || nrows < 0 || total_rows <= 0 || row0 < 0 || row0 + nrows > total_rows)
+        return fail(SYBL_E_INVAL, "sybl_table_create_synth: bad argument");
+    SYBL_HIP(hipSetDevice(ctx->device));
+    sybl_table *t = nullptr;
+    int rc = sybl_table_create(ctx, name, &t);
+    if (rc) return rc;
+    for (int i = 0; i < ncols; i++) {
+        if ((rc = sybl_table_add_column(t, cols[i].name, SYBL_INT_VAL, cols[i].info_min, cols[i].info_max))) {
+            sybl_table_free(t);
+            return rc;
+        }
+    }
+    for (int i = 0; i < ncols; i++) {
+        Column *c = t->cols[(size_t)i].get();
+        if ((rc = table_reserve(t, c, nrows))) {
+            sybl_table_free(t);
+            return rc;
+        }
+        uint64_t cs = seed ^ ((uint64_t)(cols[i].col_index + 1) * 0x9E3779B97F4A7C15ull);
+        hipError_t e = launch_synth((int64_t *)c->d_data, nrows, row0, total_rows, cols[i].kind, cols[i].a, cols[i].b, cs, ctx->stream);
+        if (e != hipSuccess) {
+            sybl_table_free(t);
+            return hip_fail(e, "k_synth");
+        }
+    }
+    for (int64_t r = 0; r < nrows; r += SYBL_BLOCK_ROWS) {
+        Segment blk;
+        blk.start = r;
+        blk.n = std::min<int64_t>(SYBL_BLOCK_ROWS, nrows - r);
+        t->blocks.push_back(blk);
+    }
+    t->phys_rows = nrows;
+    t->logical_rows = nrows;
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        sybl_table_free(t);
+        return hip_fail(e, "synth sync");
+    }
+    *out = t;
+    return SYBL_OK;
+}
+
+int64_t sybl_table_rows(const sybl_table *t) { return t ? t->logical_rows : 0; }
+int64_t sybl_table_blocks(const sybl_table *t) { return t ? (int64_t)t->blocks.size() : 0; }
+
+int64_t sybl_table_hbm_bytes(const sybl_table *t) {
+    if (!t) return 0;
+    int64_t b = 0;
+    for (auto &c : t->cols) b += c->cap_rows * c->elem + c->valid_cap_words * 4 + c->set_vals_cap * 4;
+    return b;
+}
+
+int sybl_table_column_info(const sybl_table *tc, const char *name, int *type, int64_t *exact_min, int64_t *exact_max,
+                           int64_t *info_min, int64_t *info_max, int *has_missing) {
+    sybl_table *t = const_cast<sybl_table *>(tc);
+    if (!t) return fail(SYBL_E_INVAL, "table is NULL");
+    Column *c = t->find(name);
+    if (!c) return fail(SYBL_E_INVAL, "unknown column '%s'", name ? name : "(null)");
+    SYBL_HIP(hipSetDevice(t->ctx->device));
+    int rc = table_ensure_stats(t);
+    if (rc) return rc;
+    if (type) *type = c->type;
+    if (exact_min) *exact_min = c->exact_min;
+    if (exact_max) *exact_max = c->exact_max;
+    if (info_min) *info_min = c->info_given ? c->info_min : c->exact_min;
+    if (info_max) *info_max = c->info_given ? c->info_max : c->exact_max;
+    if (has_missing) *has_missing = c->has_missing;
+    return SYBL_OK;
+}
+
+int sybl_table_set_bounds(sybl_table *t, const char *name, int64_t lo, int64_t hi, int has_missing) {
+    if (!t) return fail(SYBL_E_INVAL, "table is NULL");
+    Column *c = t->find(name);
+    if (!c) return fail(SYBL_E_INVAL, "unknown column '%s'", name ? name : "(null)");
+    c->bounds_set = true;
+    c->bound_lo = lo;
+    c->bound_hi = hi;
+    if (has_missing) c->has_missing = true;
+    return SYBL_OK;
+}
+
+int sybl_table_read_int(const sybl_table *t, const char *name, int64_t row0, int64_t n, int64_t *out) {
+    if (!t || !out) return fail(SYBL_E_INVAL, "NULL argument");
+    Column *c = t->find(name);
+    if (!c || c->type != SYBL_INT_VAL) return fail(SYBL_E_INVAL, "unknown int column '%s'", name ? name : "(null)");
+    if (row0 < 0 || n < 0 || row0 + n > t->logical_rows) return fail(SYBL_E_INVAL, "row range out of bounds");
+    SYBL_HIP(hipSetDevice(t->ctx->device));
+    SYBL_HIP(hipStreamSynchronize(t->ctx->stream));
+    // logical -> physical: walk the blocks
+    int64_t lbase = 0, done = 0;
+    for (auto &b : t->blocks) {
+        int64_t lo = std::max(row0, lbase), hi = std::min(row0 + n, lbase + b.n);
+        if (hi > lo) {
+            SYBL_HIP(hipMemcpy(out + (lo - row0), (const int64_t *)c->d_data + b.start + (lo - lbase), (size_t)(hi - lo) * 8,
+                               hipMemcpyDeviceToHost));
+            done += hi - lo;
+        }
+        lbase += b.n;
+    }
+    return done == n ? SYBL_OK : fail(SYBL_E_INVAL, "short read");
+}
+
+// ------------------------------------------------------------------ queries
+
+int sybl_query_prepare(sybl_table *t, const sybl_query_desc *desc, sybl_query **out) {
+    if (!t || !desc || !out) return fail(SYBL_E_INVAL, "sybl_query_prepare: NULL argument");
+    *out = nullptr;
+    SYBL_HIP(hipSetDevice(t->ctx->device));
+    sybl_query *q = new sybl_query();
+    q->t = t;
+    q->ctx = t->ctx;
+    int rc = plan_query(t, desc, q);
+    if (rc) {
+        free_query(q);
+        return rc;
+    }
+    *out = q;
+    return SYBL_OK;
+}
+
+void sybl_query_free(sybl_query *q) {
+    if (!q) return;
+    hipSetDevice(q->ctx->device);
+    hipStreamSynchronize(q->ctx->stream);
+    free_query(q);
+}
+
+int sybl_query_scan(sybl_query *q) {
+    if (!q) return fail(SYBL_E_INVAL, "query is NULL");
+    SYBL_HIP(hipSetDevice(q->ctx->device));
+    return scan(q);
+}
+
+int sybl_query_partials(sybl_query *q, void **d_sum, int64_t *n_sum_words, void **d_max, int64_t *n_max_words) {
+    if (!q) return fail(SYBL_E_INVAL, "query is NULL");
+    SYBL_HIP(hipSetDevice(q->ctx->device));
+    if (d_sum || d_max) {
+        int rc = ensure_partials(q);
+        if (rc) return rc;
+    }
+    if (d_sum) *d_sum = q->d_sum;
+    if (d_max) *d_max = q->d_max;
+    if (n_sum_words) *n_sum_words = q->n_sum_words;
+    if (n_max_words) *n_max_words = q->n_max_words;
+    return SYBL_OK;
+}
+
+int sybl_query_bind_partials(sybl_query *q, void *d_sum, void *d_max) {
+    if (!q || !d_sum || !d_max) return fail(SYBL_E_INVAL, "sybl_query_bind_partials: NULL argument");
+    SYBL_HIP(hipSetDevice(q->ctx->device));
+    if (q->own_partials) {
+        SYBL_HIP(hipStreamSynchronize(q->ctx->stream));
+        if (q->d_sum) hipFree(q->d_sum);
+        if (q->d_max) hipFree(q->d_max);
+        q->own_partials = false;
+    }
+    q->d_sum = (int64_t *)d_sum;
+    q->d_max = (int64_t *)d_max;
+    q->plan_dirty = true;
+    return SYBL_OK;
+}
+
+int sybl_query_stats(sybl_query *q, sybl_run_stats *out) {
+    if (!q || !out) return fail(SYBL_E_INVAL, "NULL argument");
+    if (q->scanned) {
+        SYBL_HIP(hipSetDevice(q->ctx->device));
+        SYBL_HIP(hipEventSynchronize(q->ev[2]));
+        float a = 0, b = 0;
+        SYBL_HIP(hipEventElapsedTime(&a, q->ev[0], q->ev[1]));
+        SYBL_HIP(hipEventElapsedTime(&b, q->ev[1], q->ev[2]));
+        q->stats.scan_ms = a;
+        q->stats.reduce_ms = b;
+    }
+    *out = q->stats;
+    return SYBL_OK;
+}
+
+int sybl_query_finalize(sybl_query *q, sybl_result **out) {
+    if (!q || !out) return fail(SYBL_E_INVAL, "NULL argument");
+    if (!q->scanned) return fail(SYBL_E_STATE, "sybl_query_finalize before sybl_query_scan");
+    SYBL_HIP(hipSetDevice(q->ctx->device));
+    Result *r = nullptr;
+    int rc = query_finalize(q, &r);
+    if (rc) return rc;
+    *out = (sybl_result *)r;
+    return SYBL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,154 @@
+// engine.h -- host-side objects behind the C ABI (include/sybilgpu.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <map>
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/sybilgpu.h"
+#include "plan.h"
+
+namespace sybl {
+
+void set_error(const char *fmt, ...);
+int fail(int code, const char *fmt, ...);
+int hip_fail(hipError_t e, const char *what);
+#define SYBL_HIP(expr)                                         \
+    do {                                                       \
+        hipError_t e__ = (expr);                               \
+        if (e__ != hipSuccess) return hip_fail(e__, #expr);    \
+    } while (0)
+
+// kernels.hip
+hipError_t launch_scan(const ScanPlan *d_plan, int n_slots, int n_wg, bool use_lds, size_t lds_bytes, hipStream_t st);
+hipError_t launch_fold(const int64_t *ws, int64_t *out, int64_t words, int n_wg, bool is_max, hipStream_t st);
+hipError_t launch_fill64(int64_t *p, int64_t n, int64_t v, hipStream_t st);
+hipError_t launch_synth(int64_t *out, int64_t n, int64_t row0, int64_t total_rows, int kind, int64_t a, int64_t b,
+                        uint64_t col_seed, hipStream_t st);
+hipError_t launch_block_minmax(const void *col, bool w32, const uint32_t *valid, const Segment *blocks, int n_blocks,
+                               int64_t *out_min, int64_t *out_max, int64_t *out_pop, hipStream_t st);
+
+struct Ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;  // stream in force (own or the host framework's)
+    int n_cus = 0;
+    int64_t hbm_bytes = 0;
+    std::string dev_name;
+    void *comm = nullptr;  // ncclComm_t (rccl.cpp)
+    int comm_rank = 0, comm_nranks = 1;
+};
+
+struct Column {
+    std::string name;
+    int type = SYBL_INT_VAL;
+    int elem = 8;  // bytes per stored value (int64 / int32 ids)
+    bool info_given = false;
+    int64_t info_min = 0, info_max = 0;
+    void *d_data = nullptr;
+    int64_t cap_rows = 0;
+    uint32_t *d_valid = nullptr;  // bit per physical row; nullptr = fully populated
+    int64_t valid_cap_words = 0;
+    bool has_missing = false;
+    // per-block statistics (exact, over populated rows)
+    std::vector<int64_t> blk_min, blk_max, blk_pop;
+    int64_t stats_blocks = 0;  // blocks covered by blk_*
+    int64_t exact_min = INT64_MAX, exact_max = INT64_MIN, n_pop = 0;
+    // bounds declared by a multi-rank host (global over all ranks)
+    bool bounds_set = false;
+    int64_t bound_lo = 0, bound_hi = 0;
+    // table-global dictionary (str / set)
+    std::vector<std::string> dict;
+    std::unordered_map<std::string, int32_t> dict_ix;
+    // set columns: CSR over physical rows
+    int64_t *d_set_off = nullptr;
+    int32_t *d_set_vals = nullptr;
+    int64_t set_vals_cap = 0, set_vals_n = 0;
+    std::vector<int64_t> h_set_off;  // host mirror of offsets (appended per block)
+};
+
+struct Table {
+    Ctx *ctx = nullptr;
+    std::string name;
+    std::vector<std::unique_ptr<Column>> cols;
+    std::map<std::string, int> col_ix;
+    int64_t phys_rows = 0;     // physical rows incl. per-block padding to 32
+    int64_t logical_rows = 0;
+    std::vector<Segment> blocks;  // physical start / logical row count
+    Segment *d_blocks = nullptr;
+    int64_t d_blocks_n = 0;
+    Column *find(const char *name) const;
+};
+
+int table_ensure_stats(Table *t);
+int table_reserve(Table *t, Column *c, int64_t phys_rows);
+
+struct GroupInfo {
+    int col;
+    int type;
+    int64_t gmin;
+    int32_t gcard;
+    bool has_missing;
+};
+
+struct AggInfo {
+    int col;
+    std::string name;
+    AggDesc d;
+    int32_t f_out;  // base of 6 outlier fields (n, sum, sq limb0..3) or -1
+    int64_t num_buckets;
+    int64_t info_max;
+};
+
+struct Result;
+
+struct Query {
+    Table *t = nullptr;
+    Ctx *ctx = nullptr;
+    // copied descriptor
+    int op = SYBL_AGG_AVG;
+    int64_t hist_bucket = 0;
+    bool want_percentiles = false;
+    bool weighted = false;
+    bool time_mode = false;
+    int64_t time_bucket = 0;
+    std::string order_by;
+    bool order_asc = false;
+    int limit = 0;
+    std::vector<GroupInfo> groups;
+    std::vector<AggInfo> aggs;
+    // plan
+    ScanPlan plan;
+    ScanPlan *d_plan = nullptr;
+    bool plan_dirty = true;
+    int n_wg = 0;
+    bool use_lds = false;
+    size_t lds_bytes = 0;
+    int64_t group_cells = 0;
+    std::vector<Segment> segs;
+    std::vector<int32_t> wg_seg_begin;
+    Segment *d_segs = nullptr;
+    int32_t *d_wg_seg_begin = nullptr;
+    std::vector<void *> d_idmasks;
+    int64_t n_sum_words = 0, n_max_words = 0;
+    int64_t *d_sum = nullptr, *d_max = nullptr;
+    bool own_partials = false;
+    int64_t *d_ws_sum = nullptr, *d_ws_max = nullptr;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    bool scanned = false;
+    sybl_run_stats stats{};
+    bool never_matches = false;
+};
+
+int query_finalize(Query *q, Result **out);
+
+}  // namespace sybl
+
+// opaque C types are the C++ objects
+struct sybl_ctx : sybl::Ctx {};
+struct sybl_table : sybl::Table {};
+struct sybl_query : sybl::Query {};

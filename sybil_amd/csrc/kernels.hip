@@ -1,0 +1,484 @@
+// kernels.hip -- hand-written CDNA4 (gfx950) kernels for sybil's scan hot path.
+//
+// k_scan<NC,USE_LDS> is the per-row body of FilterAndAggRecords (reference
+// src/lib/aggregate.go:96-263) + BasicHist.AddWeightedValue (hist_basic.go:101-151),
+// restructured for the machine:
+//   * columnar: each referenced column ("slot") is streamed once with 16-byte
+//     non-temporal loads, 64 lanes x 16 B = 1 KiB per wave instruction; the next tile
+//     is requested before the current one is consumed (register double buffer);
+//   * filters are folded to an inclusive range / neq list / dictionary bitmask per
+//     slot and evaluated in registers; the matched count is a per-lane register
+//     reduced once per wave at the end;
+//   * group-by is a direct-mapped cell index; the cell table (Count, per-agg
+//     sum / sum(b) / sum(b^2) / extrema) lives in LDS, replicated across lanes at low
+//     cardinality to defeat same-address serialisation, and is written out ONCE per
+//     workgroup; k_fold then reduces the per-workgroup tables;
+//   * when the cell table does not fit in LDS the same body accumulates with
+//     device-scope atomics straight into HBM (USE_LDS = false);
+//   * no MFMA anywhere: the path is HBM-bound integer work.
+//
+// Everything is integer-exact, so results do not depend on the order rows are
+// visited in -- which is what lets 256 workgroups x N GPUs own disjoint row ranges
+// and be merged with a SUM/MAX all-reduce.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "plan.h"
+
+namespace sybl {
+
+typedef long long ll2 __attribute__((ext_vector_type(2)));
+// The plan lives in device memory and is read through the constant address space so every
+// field access is a scalar (s_load) through the scalar cache: the plan is wave-uniform, far
+// larger than the SGPR file, and must never be copied to scratch.
+typedef const ScanPlan __attribute__((address_space(4))) CPlan;
+typedef const SlotDesc __attribute__((address_space(4))) CSlot;
+typedef const AggDesc __attribute__((address_space(4))) CAgg;
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+
+// ---------------------------------------------------------------- small helpers
+
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+// floor(n / d) for 0 <= n, d > 0 without the ~100-instruction 64-bit divide:
+// double reciprocal + one correction step (exact while n < 2^52).
+__device__ __forceinline__ uint64_t udiv_fast(uint64_t n, uint64_t d, double inv_d, int big) {
+    if (big) return n / d;
+    uint64_t q = (uint64_t)((double)n * inv_d);
+    int64_t r = (int64_t)(n - q * d);
+    if (r < 0) {
+        q -= 1;
+    } else if ((uint64_t)r >= d) {
+        q += 1;
+    }
+    return q;
+}
+
+// Go's truncating int64 division by a positive constant (aggregate.go:174, hist_basic.go:130)
+__device__ __forceinline__ int64_t sdiv_trunc(int64_t x, int64_t d, double inv_d, int big) {
+    uint64_t ux = x < 0 ? (uint64_t)0 - (uint64_t)x : (uint64_t)x;
+    uint64_t q = udiv_fast(ux, (uint64_t)d, inv_d, big);
+    return x < 0 ? -(int64_t)q : (int64_t)q;
+}
+
+template <bool USE_LDS>
+__device__ __forceinline__ void acc_add(int64_t *tab, int64_t idx, int64_t v) {
+    if (USE_LDS) {
+        __hip_atomic_fetch_add(&tab[idx], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else {
+        __hip_atomic_fetch_add(&tab[idx], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+template <bool USE_LDS>
+__device__ __forceinline__ void acc_max(int64_t *tab, int64_t idx, int64_t v) {
+    // a plain read first: after warm-up almost no value raises the extremum, and a stale
+    // (smaller) read only costs one redundant atomic
+    if (v > tab[idx]) {
+        if (USE_LDS) {
+            __hip_atomic_fetch_max(&tab[idx], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+            __hip_atomic_fetch_max(&tab[idx], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+__device__ __forceinline__ void gadd(int64_t *p, int64_t v) {
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ int64_t wave_sum(int64_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ---------------------------------------------------------------- the scan
+
+template <int NC>
+struct Tile {
+    ll2 v[NC];         // two consecutive rows per slot
+    uint32_t pop[NC];  // 2 validity bits per slot (bit0 = row0, bit1 = row1)
+};
+
+template <int NC>
+__device__ __forceinline__ void load_tile(CPlan &P, int64_t row, bool in_range, Tile<NC> &t) {
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        CSlot &s = P.slot[c];
+        ll2 v = {0, 0};
+        uint32_t pop = 0;
+        if (in_range) {
+            if (s.flags & kSlotW32) {
+                i32x2 w = __builtin_nontemporal_load((const i32x2 *)((const int32_t *)s.base + row));
+                v.x = w.x;
+                v.y = w.y;
+            } else {
+                v = __builtin_nontemporal_load((const ll2 *)((const int64_t *)s.base + row));
+            }
+            pop = 3u;
+            if (s.valid) pop = (s.valid[row >> 5] >> (row & 31)) & 3u;
+        }
+        t.v[c] = v;
+        t.pop[c] = pop;
+    }
+}
+
+template <int NC, bool USE_LDS>
+__device__ __forceinline__ void process_tile(CPlan &P, const Tile<NC> &t, int nvalid, int64_t *sumtab,
+                                             int64_t *maxtab, int rep, int64_t &matched, int64_t &overflow) {
+    const int rs = USE_LDS ? P.rep_shift : 0;
+#pragma unroll
+    for (int r = 0; r < kRowsPerThread; r++) {
+        if (r >= nvalid) break;
+        bool pass = true;
+        bool in_bounds = true;
+        int32_t cell = 0;
+        // ---- filters (aggregate.go:105-116) and group key (aggregate.go:125-143)
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            CSlot &s = P.slot[c];
+            const int64_t x = r == 0 ? t.v[c].x : t.v[c].y;
+            const bool pop = (t.pop[c] >> r) & 1u;
+            if (s.flags & kSlotRange) pass = pass && pop && x >= s.lo && x <= s.hi;
+            if (s.flags & kSlotNeq) {
+                pass = pass && pop;
+                for (int k = 0; k < s.n_neq; k++) pass = pass && x != s.neq[k];
+            }
+            if (s.flags & kSlotIdMask) {
+                bool ok = false;
+                if (pop && (uint64_t)x < (uint64_t)s.idmask_bits) ok = (s.idmask[x >> 5] >> (x & 31)) & 1u;
+                pass = pass && ok;
+            }
+            if (s.flags & kSlotGroup) {
+                if (pop) {
+                    uint64_t d = (uint64_t)x - (uint64_t)s.gmin;
+                    uint32_t lim = (uint32_t)(s.gmissing >= 0 ? s.gcard - 1 : s.gcard);
+                    if (d >= lim) in_bounds = false;
+                    cell += (int32_t)d * s.gstride;
+                } else if (s.gmissing >= 0) {
+                    cell += s.gmissing;
+                } else {
+                    in_bounds = false;
+                }
+            }
+        }
+        if (!pass) continue;
+        matched += 1;  // aggregate.go:117
+
+        // ---- weight (aggregate.go:100-102)
+        int64_t w = 1;
+        if (P.weight_slot >= 0) {
+#pragma unroll
+            for (int c = 0; c < NC; c++)
+                if (c == P.weight_slot) w = r == 0 ? t.v[c].x : t.v[c].y;
+        }
+        // ---- time bucket (aggregate.go:146-183): rows without a time value are dropped
+        //      after they were counted as matched
+        if (P.time_slot >= 0) {
+            int64_t tv = 0;
+            bool tpop = false;
+#pragma unroll
+            for (int c = 0; c < NC; c++)
+                if (c == P.time_slot) {
+                    tv = r == 0 ? t.v[c].x : t.v[c].y;
+                    tpop = (t.pop[c] >> r) & 1u;
+                }
+            if (!tpop) continue;
+            int64_t tb = sdiv_trunc(tv, P.time_bucket, P.inv_time_bucket, P.tb_big_div) - P.tb_min;
+            if ((uint64_t)tb >= (uint64_t)P.n_tb) in_bounds = false;
+            cell += (int32_t)tb * P.tb_stride;
+        }
+        if (!in_bounds) {
+            overflow += 1;
+            continue;
+        }
+
+        const int64_t ncell = P.n_cells;
+        // field f of cell: ((f * n_cells + cell) << rep_shift) + rep
+        const int64_t cidx = ((int64_t)cell << rs) + rep;
+        acc_add<USE_LDS>(sumtab, cidx, w);  // Result.Count += weight (aggregate.go:203)
+        if (P.f_samples >= 0) acc_add<USE_LDS>(sumtab, ((int64_t)P.f_samples * ncell << rs) + cidx, 1);
+
+        // ---- aggregations (aggregate.go:246-261, hist_basic.go:101-151)
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            CSlot &s = P.slot[c];
+            if (!(s.flags & kSlotAgg)) continue;
+            const int64_t x = r == 0 ? t.v[c].x : t.v[c].y;
+            const bool pop = (t.pop[c] >> r) & 1u;
+            CAgg &A = P.agg[s.agg_index];
+            if (!pop || x > A.max10 || x < A.info_min) continue;  // hist_basic.go:104
+            acc_add<USE_LDS>(sumtab, ((int64_t)A.f_sum * ncell << rs) + cidx, (int64_t)((uint64_t)x * (uint64_t)w));
+            if (A.f_cnt >= 0) acc_add<USE_LDS>(sumtab, ((int64_t)A.f_cnt * ncell << rs) + cidx, w);
+            if (A.f_smp >= 0) acc_add<USE_LDS>(sumtab, ((int64_t)A.f_smp * ncell << rs) + cidx, 1);
+            acc_max<USE_LDS>(maxtab, ((int64_t)A.m_max * ncell << rs) + cidx, x);
+            acc_max<USE_LDS>(maxtab, ((int64_t)A.m_nmin * ncell << rs) + cidx, x == INT64_MIN ? INT64_MAX : -x);
+            if (P.hist_mode) {
+                // bucket_value := (value - h.Min) / BucketSize  (hist_basic.go:130)
+                int64_t b = sdiv_trunc(x - A.hmin, A.bucket_size, A.inv_bucket, A.big_div);
+                if (b >= A.n_values || b < 0) {
+                    // Outliers / Underliers (hist_basic.go:132-142): clipped into the edge bucket
+                    // AND remembered.  Their exact n, sum(o), sum(o^2) live in six extra cell
+                    // fields that the planner allocates only when the column bounds make an
+                    // outlier possible at all.
+                    if (A.f_out >= 0) {
+                        const int64_t step = ncell << rs;
+                        int64_t fi = ((int64_t)A.f_out * ncell << rs) + cidx;
+                        unsigned __int128 sq = (unsigned __int128)((__int128)x * (__int128)x);
+                        acc_add<USE_LDS>(sumtab, fi, 1);
+                        acc_add<USE_LDS>(sumtab, fi + step, x);
+                        acc_add<USE_LDS>(sumtab, fi + 2 * step, (int64_t)(uint64_t)(sq & 0xFFFFFFFFu));
+                        acc_add<USE_LDS>(sumtab, fi + 3 * step, (int64_t)(uint64_t)((sq >> 32) & 0xFFFFFFFFu));
+                        acc_add<USE_LDS>(sumtab, fi + 4 * step, (int64_t)(uint64_t)((sq >> 64) & 0xFFFFFFFFu));
+                        acc_add<USE_LDS>(sumtab, fi + 5 * step, (int64_t)(uint64_t)(sq >> 96));
+                    } else {
+                        overflow += 1;  // declared bounds violated; reported by finalize
+                    }
+                    b = b < 0 ? 0 : A.n_values - 1;
+                }
+                if (A.hist_full) {
+                    gadd(P.sum_out + P.hist_off + (int64_t)cell * P.hist_stride + P.hist_agg_off[s.agg_index] + b, w);
+                } else {
+                    acc_add<USE_LDS>(sumtab, ((int64_t)A.f_sb * ncell << rs) + cidx, b * w);
+                    acc_add<USE_LDS>(sumtab, ((int64_t)A.f_sb2 * ncell << rs) + cidx, b * b * w);
+                }
+            }
+        }
+    }
+}
+
+template <int NC, bool USE_LDS>
+__global__ __launch_bounds__(kWgThreads) void k_scan(CPlan *Pp) {
+    CPlan &P = *Pp;
+    extern __shared__ int64_t lds[];
+    const int tid = threadIdx.x;
+    const int64_t words_sum = (int64_t)P.n_sum_fields * P.n_cells;
+    const int64_t words_max = (int64_t)P.n_max_fields * P.n_cells;
+    int64_t *sumtab, *maxtab;
+    int rep = 0;
+    if (USE_LDS) {
+        const int R = 1 << P.rep_shift;
+        sumtab = lds;
+        maxtab = lds + words_sum * R;
+        for (int64_t i = tid; i < words_sum * R; i += kWgThreads) sumtab[i] = 0;
+        for (int64_t i = tid; i < words_max * R; i += kWgThreads) maxtab[i] = INT64_MIN;
+        rep = tid & (R - 1);
+        __syncthreads();
+    } else {
+        sumtab = P.sum_out + kHeaderWords;
+        maxtab = P.max_out;
+    }
+
+    int64_t matched = 0, overflow = 0;
+    const int s0 = P.wg_seg_begin[blockIdx.x], s1 = P.wg_seg_begin[blockIdx.x + 1];
+    for (int si = s0; si < s1; si++) {
+        const Segment seg = P.segs[si];
+        const int64_t end = seg.start + seg.n;
+        int64_t row = seg.start + (int64_t)tid * kRowsPerThread;
+        Tile<NC> cur, nxt;
+        load_tile<NC>(P, row, row < end, cur);
+        for (int64_t base = seg.start; base < end; base += kTileRows) {
+            const int64_t nrow = row + kTileRows;
+            load_tile<NC>(P, nrow, nrow < end, nxt);  // prefetch: HBM latency hides under the LDS work
+            int64_t left = end - row;
+            int nvalid = left >= kRowsPerThread ? kRowsPerThread : (left > 0 ? (int)left : 0);
+            process_tile<NC, USE_LDS>(P, cur, nvalid, sumtab, maxtab, rep, matched, overflow);
+            cur = nxt;
+            row = nrow;
+        }
+    }
+
+    matched = wave_sum(matched);
+    overflow = wave_sum(overflow);
+    if ((tid & 63) == 0) {
+        if (matched) gadd(P.sum_out + kHdrMatched, matched);
+        if (overflow) gadd(P.sum_out + kHdrOverflow, overflow);
+    }
+
+    if (USE_LDS) {
+        // fold the lane replicas and publish this workgroup's table (plain stores, no atomics)
+        __syncthreads();
+        const int R = 1 << P.rep_shift;
+        int64_t *ws = P.ws_sum + (int64_t)blockIdx.x * words_sum;
+        for (int64_t i = tid; i < words_sum; i += kWgThreads) {
+            int64_t a = 0;
+            for (int k = 0; k < R; k++) a += sumtab[(i << P.rep_shift) + k];
+            ws[i] = a;
+        }
+        int64_t *wm = P.ws_max + (int64_t)blockIdx.x * words_max;
+        for (int64_t i = tid; i < words_max; i += kWgThreads) {
+            int64_t a = INT64_MIN;
+            for (int k = 0; k < R; k++) {
+                int64_t b = maxtab[(i << P.rep_shift) + k];
+                a = b > a ? b : a;
+            }
+            wm[i] = a;
+        }
+    }
+}
+
+// out[i] = reduce over workgroups of ws[w][i]   (SUM or MAX)
+__global__ __launch_bounds__(256) void k_fold(const int64_t *__restrict__ ws, int64_t *__restrict__ out, int64_t words,
+                                              int n_wg, int is_max) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= words) return;
+    int64_t a = is_max ? INT64_MIN : 0;
+    for (int w = 0; w < n_wg; w++) {
+        int64_t b = ws[(int64_t)w * words + i];
+        a = is_max ? (b > a ? b : a) : a + b;
+    }
+    out[i] = a;
+}
+
+__global__ __launch_bounds__(256) void k_fill64(int64_t *p, int64_t n, int64_t v) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) p[i] = v;
+}
+
+// ---------------------------------------------------------------- synthetic columns
+// Bit-identical to oracle/sybil_oracle.c:orc_synth_fill (the generator is ours, not the
+// reference's: SURVEY.md 8d).
+__global__ __launch_bounds__(256) void k_synth(int64_t *out, int64_t n, int64_t row0, int64_t total_rows, int kind,
+                                               int64_t a, int64_t b, uint64_t col_seed) {
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; k < n; k += stride) {
+        const uint64_t i = (uint64_t)(row0 + k);
+        int64_t v;
+        if (kind == 1) {  // TIME
+            v = a + (int64_t)((i * (uint64_t)b) / (uint64_t)total_rows);
+        } else if (kind == 2) {  // BELL
+            uint64_t h = splitmix64(col_seed ^ i);
+            uint64_t s = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) s += (((h >> (16 * j)) & 0xFFFFu) * (uint64_t)b) >> 16;
+            v = a + (int64_t)s;
+        } else {  // UNIFORM
+            uint64_t h = splitmix64(col_seed ^ i);
+            v = a + (int64_t)__umul64hi(h, (uint64_t)b);
+        }
+        out[k] = v;
+    }
+}
+
+// ---------------------------------------------------------------- per-block extrema
+// One workgroup per block of rows: min/max over populated values.  Feeds block skipping
+// (table_block_io.go:110-182) and the direct-mapped group layout.
+template <typename T>
+__global__ __launch_bounds__(256) void k_block_minmax(const T *__restrict__ col, const uint32_t *__restrict__ valid,
+                                                      const Segment *__restrict__ blocks, int64_t *__restrict__ out_min,
+                                                      int64_t *__restrict__ out_max, int64_t *__restrict__ out_pop) {
+    const Segment b = blocks[blockIdx.x];
+    int64_t mn = INT64_MAX, mx = INT64_MIN, pc = 0;
+    for (int64_t i = threadIdx.x; i < b.n; i += blockDim.x) {
+        const int64_t row = b.start + i;
+        if (valid && !((valid[row >> 5] >> (row & 31)) & 1u)) continue;
+        const int64_t v = (int64_t)col[row];
+        mn = v < mn ? v : mn;
+        mx = v > mx ? v : mx;
+        pc++;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        int64_t m2 = __shfl_xor(mn, o, 64), x2 = __shfl_xor(mx, o, 64);
+        mn = m2 < mn ? m2 : mn;
+        mx = x2 > mx ? x2 : mx;
+        pc += __shfl_xor(pc, o, 64);
+    }
+    __shared__ int64_t smn[4], smx[4], spc[4];
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        smn[wave] = mn;
+        smx[wave] = mx;
+        spc[wave] = pc;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 4; k++) {
+            mn = smn[k] < mn ? smn[k] : mn;
+            mx = smx[k] > mx ? smx[k] : mx;
+            pc += spc[k];
+        }
+        out_min[blockIdx.x] = mn;
+        out_max[blockIdx.x] = mx;
+        out_pop[blockIdx.x] = pc;
+    }
+}
+
+// ---------------------------------------------------------------- launchers (host)
+
+template <int NC>
+static hipError_t launch_scan_nc(const ScanPlan *d_plan, int n_wg, bool use_lds, size_t lds_bytes, hipStream_t st) {
+    if (use_lds) {
+        auto kfn = k_scan<NC, true>;
+        hipError_t e = hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kfn, dim3(n_wg), dim3(kWgThreads), lds_bytes, st, (CPlan *)d_plan);
+    } else {
+        hipLaunchKernelGGL((k_scan<NC, false>), dim3(n_wg), dim3(kWgThreads), 0, st, (CPlan *)d_plan);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_scan(const ScanPlan *d_plan, int n_slots, int n_wg, bool use_lds, size_t lds_bytes, hipStream_t st) {
+    switch (n_slots) {
+    case 1: return launch_scan_nc<1>(d_plan, n_wg, use_lds, lds_bytes, st);
+    case 2: return launch_scan_nc<2>(d_plan, n_wg, use_lds, lds_bytes, st);
+    case 3: return launch_scan_nc<3>(d_plan, n_wg, use_lds, lds_bytes, st);
+    case 4: return launch_scan_nc<4>(d_plan, n_wg, use_lds, lds_bytes, st);
+    case 5: return launch_scan_nc<5>(d_plan, n_wg, use_lds, lds_bytes, st);
+    case 6: return launch_scan_nc<6>(d_plan, n_wg, use_lds, lds_bytes, st);
+    case 7: return launch_scan_nc<7>(d_plan, n_wg, use_lds, lds_bytes, st);
+    case 8: return launch_scan_nc<8>(d_plan, n_wg, use_lds, lds_bytes, st);
+    case 9: return launch_scan_nc<9>(d_plan, n_wg, use_lds, lds_bytes, st);
+    case 10: return launch_scan_nc<10>(d_plan, n_wg, use_lds, lds_bytes, st);
+    case 11: return launch_scan_nc<11>(d_plan, n_wg, use_lds, lds_bytes, st);
+    case 12: return launch_scan_nc<12>(d_plan, n_wg, use_lds, lds_bytes, st);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_fold(const int64_t *ws, int64_t *out, int64_t words, int n_wg, bool is_max, hipStream_t st) {
+    if (words <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_fold, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, ws, out, words, n_wg, is_max ? 1 : 0);
+    return hipGetLastError();
+}
+
+hipError_t launch_fill64(int64_t *p, int64_t n, int64_t v, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_fill64, dim3((unsigned)blocks), dim3(256), 0, st, p, n, v);
+    return hipGetLastError();
+}
+
+hipError_t launch_synth(int64_t *out, int64_t n, int64_t row0, int64_t total_rows, int kind, int64_t a, int64_t b,
+                        uint64_t col_seed, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_synth, dim3((unsigned)blocks), dim3(256), 0, st, out, n, row0, total_rows, kind, a, b, col_seed);
+    return hipGetLastError();
+}
+
+hipError_t launch_block_minmax(const void *col, bool w32, const uint32_t *valid, const Segment *blocks, int n_blocks,
+                               int64_t *out_min, int64_t *out_max, int64_t *out_pop, hipStream_t st) {
+    if (n_blocks <= 0) return hipSuccess;
+    if (w32) {
+        hipLaunchKernelGGL((k_block_minmax<int32_t>), dim3(n_blocks), dim3(256), 0, st, (const int32_t *)col, valid, blocks,
+                           out_min, out_max, out_pop);
+    } else {
+        hipLaunchKernelGGL((k_block_minmax<int64_t>), dim3(n_blocks), dim3(256), 0, st, (const int64_t *)col, valid, blocks,
+                           out_min, out_max, out_pop);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace sybl

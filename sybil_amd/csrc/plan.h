@@ -1,0 +1,115 @@
+// plan.h -- the device-visible description of one scan (shared by engine.cpp and kernels.hip).
+//
+// A "slot" is one referenced column as the scan kernel sees it: every role the
+// reference's row loop gives that column (filter operand, group-by key part,
+// aggregation input, time column, weight column -- aggregate.go:96-263) is a flag on
+// the slot, so each referenced column is streamed from HBM exactly once per row.
+#pragma once
+#include <stdint.h>
+
+namespace sybl {
+
+constexpr int kMaxSlots = 12;
+constexpr int kMaxAggs = 6;   // == SYBL_MAX_AGGS
+constexpr int kMaxNeq = 4;    // neq constants folded per slot
+constexpr int kWgThreads = 1024;
+constexpr int kRowsPerThread = 2;                        // one 16-byte load per int64 column
+constexpr int kTileRows = kWgThreads * kRowsPerThread;   // rows per workgroup iteration
+constexpr int kHeaderWords = 64;                         // SUM-section header
+constexpr int kLdsBudgetBytes = 152 * 1024;              // of 160 KiB per CU
+
+enum SlotFlags : uint32_t {
+    kSlotRange = 1u << 0,   // lo <= x <= hi   (gt/lt/eq int filters folded, filter.go:171-195)
+    kSlotNeq = 1u << 1,     // x != neq[i]
+    kSlotIdMask = 1u << 2,  // str filter as a bit per dictionary id (filter.go:199-250)
+    kSlotGroup = 1u << 3,   // key part (aggregate.go:125-143)
+    kSlotAgg = 1u << 4,     // aggregation input (aggregate.go:246-261)
+    kSlotTime = 1u << 5,    // time column (aggregate.go:146-183)
+    kSlotWeight = 1u << 6,  // weight column (aggregate.go:100-102)
+    kSlotW32 = 1u << 7,     // stored as int32 (str dictionary ids)
+    kSlotFilter = kSlotRange | kSlotNeq | kSlotIdMask,
+};
+
+struct SlotDesc {
+    const void *base;        // column values (int64, or int32 with kSlotW32)
+    const uint32_t *valid;   // bit per physical row, nullptr = every row populated
+    const uint32_t *idmask;  // kSlotIdMask: bit per dictionary id, 1 = row passes
+    int64_t lo, hi;          // kSlotRange (inclusive)
+    int64_t neq[kMaxNeq];    // kSlotNeq
+    int64_t gmin;            // kSlotGroup: cell += (x - gmin) * gstride
+    uint32_t flags;
+    int32_t n_neq;
+    int32_t idmask_bits;
+    int32_t gcard;           // distinct key values incl. the MISSING slot
+    int32_t gstride;
+    int32_t gmissing;        // (gcard-1)*gstride when the column has missing rows, else -1
+    int32_t agg_index;
+    int32_t pad_;
+};
+
+struct AggDesc {
+    int64_t info_min;     // hist_basic.go:104  reject v < Info.Min
+    int64_t max10;        //                    reject v > Info.Max*10 (wrapping like Go)
+    int64_t hmin;         // BasicHist.Min at setup (= Info.Min in hist mode)
+    int64_t bucket_size;  // BasicHist.BucketSize
+    double inv_bucket;    // 1.0 / bucket_size
+    int32_t n_values;     // len(Values)
+    int32_t big_div;      // value range too wide for the double-reciprocal divide
+    // field indices into the cell table (-1 = not tracked)
+    int32_t f_sum;        // sum(v*w)
+    int32_t f_cnt;        // sum(w) over accepted values (only if rejection/missing/weights possible)
+    int32_t f_smp;        // accepted values (weighted queries)
+    int32_t f_sb;         // moments: sum(b*w)
+    int32_t f_sb2;        // moments: sum(b*b*w)
+    int32_t f_out;        // 6 fields: n, sum(o), sum(o^2) as four 32-bit limbs -- only when the
+                          // column's bounds allow a value to land beyond the last bucket
+    int32_t m_max;        // MAX-section field: max(v)
+    int32_t m_nmin;       // MAX-section field: max(-v)
+    int32_t hist_full;    // 1: bucket arrays in the SUM section (global atomics)
+    int32_t pad_;
+};
+
+struct Segment {           // a run of physical rows one workgroup scans
+    int64_t start;         // even
+    int64_t n;
+};
+
+struct ScanPlan {
+    SlotDesc slot[kMaxSlots];
+    AggDesc agg[kMaxAggs];
+    int32_t n_slots, n_aggs;
+    int32_t hist_mode;       // FLAGS.OP == "hist"
+    int32_t weighted;        // OPTS.WEIGHT_COL
+    int32_t time_slot;       // -1 = none
+    int32_t weight_slot;     // -1 = none
+    int64_t time_bucket;     // QuerySpec.TimeBucket
+    double inv_time_bucket;
+    int64_t tb_min;          // trunc(tmin / time_bucket)
+    int32_t n_tb;
+    int32_t tb_stride;       // = number of group cells
+    int32_t tb_big_div;
+    int32_t n_cells;         // n_tb * group cells
+    int32_t n_sum_fields;    // F: [F][n_cells] int64, field 0 = Count, (field 1 = Samples)
+    int32_t n_max_fields;    // M: [M][n_cells] int64 (MAX-combined)
+    int32_t f_samples;       // -1 unless weighted
+    int32_t rep_shift;       // LDS replicas = 1 << rep_shift
+    int64_t hist_off;        // word offset of bucket arrays in the SUM section
+    int64_t hist_stride;     // words per cell = sum of n_values over full-hist aggs
+    int64_t hist_agg_off[kMaxAggs];
+    // outputs
+    int64_t *sum_out;        // SUM section: [header][F*n_cells][hist]
+    int64_t *max_out;        // MAX section: [M*n_cells]
+    int64_t *ws_sum;         // LDS strategy: [n_wg][F*n_cells]
+    int64_t *ws_max;         // LDS strategy: [n_wg][M*n_cells]
+    // work
+    const Segment *segs;
+    const int32_t *wg_seg_begin;  // [n_wg+1]
+};
+
+// SUM-section header words
+enum Header : int {
+    kHdrMatched = 0,     // QuerySpec.MatchedCount
+    kHdrOverflow = 1,    // rows whose key / bucket fell outside the declared bounds (must be 0)
+};
+
+}  // namespace sybl

@@ -1,0 +1,644 @@
+// result.cpp -- turns the (all-reduced) partial group table back into sybil's result model.
+//
+// Reference mapping (src/lib/ of logv/sybil):
+//   cell -> Result{BinaryByKey, GroupByKey, Count, Samples, Hists}   query_spec.go:85-93,
+//                                                                    aggregate.go:125-143,284-324
+//   Cumulative ("TOTAL")                                             aggregate.go:422-438
+//   TimeResults / all-time Results in time-series mode               aggregate.go:146-183
+//   avg / stddev / percentiles from exact integers                   hist_basic.go:153-219
+//   sort                                                             aggregate.go:43-54,497-525
+//   text / JSON rendering                                            printer.go:109-232,291-308
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "engine.h"
+
+namespace sybl {
+
+struct AggAcc {
+    bool tracked_cnt = false;
+    int64_t cnt = 0, smp = 0;
+    uint64_t sum = 0;
+    int64_t sb = 0, sb2 = 0;
+    int64_t n_out = 0;
+    uint64_t sum_out = 0;
+    uint64_t sq[4] = {0, 0, 0, 0};
+    int64_t vmax = INT64_MIN, nmin = INT64_MIN;
+    std::vector<int64_t> values;
+};
+
+struct CellAcc {
+    int64_t count = 0, samples = 0;
+    std::vector<AggAcc> aggs;
+};
+
+struct RowStore {
+    std::vector<uint8_t> key;
+    std::string gbk;
+    int64_t time_bucket = 0, count = 0, samples = 0;
+    std::vector<sybl_agg_out> aggs;
+    std::vector<std::vector<int64_t>> values, pcts;
+};
+
+struct Result {
+    std::vector<RowStore> rows[3];
+    std::vector<sybl_group_row> view[3];
+    int64_t matched = 0;
+    // for rendering
+    int op = 0;
+    bool weighted = false, time_mode = false, want_percentiles = false;
+    int limit = 0;
+    std::string order_by;
+    std::vector<std::string> group_names, agg_names;
+    std::string rendered[2];
+};
+
+static void acc_add(AggAcc &d, const AggAcc &s) {
+    d.cnt += s.cnt;
+    d.smp += s.smp;
+    d.sum += s.sum;
+    d.sb += s.sb;
+    d.sb2 += s.sb2;
+    d.n_out += s.n_out;
+    d.sum_out += s.sum_out;
+    for (int k = 0; k < 4; k++) d.sq[k] += s.sq[k];
+    d.vmax = std::max(d.vmax, s.vmax);
+    d.nmin = std::max(d.nmin, s.nmin);
+    if (!s.values.empty()) {
+        if (d.values.empty()) d.values.assign(s.values.size(), 0);
+        for (size_t k = 0; k < s.values.size(); k++) d.values[k] += s.values[k];
+    }
+}
+
+// GetPercentiles, hist_basic.go:153-183 (same loop as the reference, including the
+// percentiles[p] = k overwrite that later iterations repair)
+static void percentiles_from_values(const std::vector<int64_t> &values, int64_t bucket_size, int64_t hmin,
+                                    int64_t count, std::vector<int64_t> &out) {
+    out.clear();
+    if (count == 0) return;
+    int64_t pct[101];
+    memset(pct, 0, sizeof(pct));
+    pct[0] = hmin;
+    int64_t c = 0, prev_p = 0;
+    for (size_t k = 0; k < values.size(); k++) {
+        c += values[k];
+        int64_t p = (100 * c) / count;
+        p = std::min<int64_t>(std::max<int64_t>(p, 0), 100);
+        for (int64_t ip = prev_p; ip <= p; ip++) pct[ip] = (int64_t)k * bucket_size + hmin;
+        pct[p] = (int64_t)k;
+        prev_p = p;
+    }
+    out.assign(pct, pct + 100);
+}
+
+static void agg_finish(const Query *q, const AggInfo &ai, const AggAcc &a, int64_t row_count, sybl_agg_out &o,
+                       std::vector<int64_t> &values, std::vector<int64_t> &pcts) {
+    memset(&o, 0, sizeof(o));
+    const AggDesc &A = ai.d;
+    int64_t cnt = a.tracked_cnt ? a.cnt : row_count;
+    bool present = q->weighted ? a.smp > 0 : cnt > 0;
+    if (!a.tracked_cnt && row_count > 0) present = true;
+    if (!present) return;
+    o.present = 1;
+    o.count = cnt;
+    o.samples = q->weighted ? a.smp : 0;  // BasicHist.Samples only moves with a weight column (hist_basic.go:111-116)
+    o.sum = (int64_t)a.sum;
+    long double avg_l = cnt != 0 ? (long double)(int64_t)a.sum / (long double)cnt : 0.0L;
+    o.avg = (double)avg_l;
+    int64_t tmax = a.vmax, tmin = a.nmin == INT64_MIN ? INT64_MAX : -a.nmin;
+    if (q->op == SYBL_AGG_HIST) {
+        o.min = std::min(A.info_min, tmin);                            // SetupBuckets: h.Min = Info.Min
+        o.max = std::max(ai.info_max, tmax);                           //               h.Max = Info.Max
+        o.bucket_size = A.bucket_size;
+        o.num_buckets = ai.num_buckets;
+        o.n_values = A.n_values;
+        o.n_outliers = a.n_out;
+    } else {
+        o.min = std::min<int64_t>(0, tmin);  // avg mode: Go zero values (hist_basic.go:72-85)
+        o.max = std::max<int64_t>(0, tmax);
+    }
+    if (q->op != SYBL_AGG_HIST) return;
+
+    // outlier term of GetStdDev: sum (o - avg)^2 / Count, from exact n, sum(o), sum(o^2)
+    long double out_term = 0;
+    if (a.n_out > 0 && cnt != 0) {
+        long double sq = (long double)a.sq[0] + ldexpl((long double)a.sq[1], 32) + ldexpl((long double)a.sq[2], 64) +
+                         ldexpl((long double)a.sq[3], 96);
+        long double A1 = (long double)o.avg;
+        out_term = (sq - 2.0L * A1 * (long double)(int64_t)a.sum_out + (long double)a.n_out * A1 * A1) / (long double)cnt;
+    }
+    if (q->want_percentiles) {
+        values = a.values;
+        if (values.empty()) values.assign((size_t)A.n_values, 0);
+        percentiles_from_values(values, A.bucket_size, A.hmin, cnt, pcts);
+        // GetStdDev, hist_basic.go:192-219, with Avg = sum/count
+        double sum_variance = 0;
+        for (size_t b = 0; b < values.size(); b++) {
+            int64_t val = (int64_t)b * A.bucket_size + A.hmin;
+            double delta = (double)val - o.avg;
+            double ratio = (double)values[b] / (double)cnt;
+            sum_variance += (delta * delta) * ratio;
+        }
+        o.stddev = sqrt(sum_variance + (double)out_term);
+    } else {
+        // moments form of the same sum: e_b - avg = BS*b + (hmin - avg)
+        long double BS = (long double)A.bucket_size, c = (long double)A.hmin - (long double)o.avg;
+        long double var = cnt != 0 ? (BS * BS * (long double)a.sb2 + 2.0L * BS * c * (long double)a.sb + c * c * (long double)cnt) /
+                                         (long double)cnt
+                                   : 0.0L;
+        var += out_term;
+        o.stddev = var > 0 ? (double)sqrtl(var) : 0.0;
+    }
+}
+
+static void build_key(const Query *q, int64_t gcell, std::vector<uint8_t> &key, std::string &gbk) {
+    size_t ng = q->groups.size();
+    key.assign(ng * 8, 0);
+    gbk.clear();
+    if (ng == 0) gbk = "total";  // translate_group_by, aggregate.go:294-296
+    int64_t rem = gcell, stride = q->group_cells;
+    for (size_t g = 0; g < ng; g++) {
+        const GroupInfo &gi = q->groups[g];
+        stride /= gi.gcard;
+        int64_t digit = rem / stride;
+        rem -= digit * stride;
+        uint64_t v;
+        bool missing = gi.has_missing && digit == gi.gcard - 1;
+        if (missing) {
+            v = UINT64_MAX;  // MISSING_VALUE, aggregate.go:31
+        } else {
+            v = (uint64_t)(gi.gmin + digit);
+            const Column *c = q->t->cols[(size_t)gi.col].get();
+            if (gi.type == SYBL_STR_VAL) {
+                size_t id = (size_t)(gi.gmin + digit);
+                if (id < c->dict.size()) gbk += c->dict[id];
+            } else {
+                gbk += std::to_string((long long)(gi.gmin + digit));
+            }
+        }
+        for (int b = 0; b < 8; b++) key[g * 8 + b] = (uint8_t)(v >> (8 * b));
+        gbk += "\t";
+    }
+}
+
+static void finish_row(const Query *q, const CellAcc &acc, RowStore &row) {
+    row.count = acc.count;
+    row.samples = acc.samples;
+    size_t na = q->aggs.size();
+    row.aggs.resize(na);
+    row.values.resize(na);
+    row.pcts.resize(na);
+    for (size_t a = 0; a < na; a++) {
+        if (acc.aggs.empty()) {
+            memset(&row.aggs[a], 0, sizeof(sybl_agg_out));
+            continue;
+        }
+        agg_finish(q, q->aggs[a], acc.aggs[a], acc.count, row.aggs[a], row.values[a], row.pcts[a]);
+    }
+}
+
+static void make_views(Result *R) {
+    for (int w = 0; w < 3; w++) {
+        R->view[w].resize(R->rows[w].size());
+        for (size_t i = 0; i < R->rows[w].size(); i++) {
+            RowStore &r = R->rows[w][i];
+            for (size_t a = 0; a < r.aggs.size(); a++) {
+                r.aggs[a].values = r.values[a].empty() ? nullptr : r.values[a].data();
+                r.aggs[a].percentiles = r.pcts[a].empty() ? nullptr : r.pcts[a].data();
+            }
+            sybl_group_row &v = R->view[w][i];
+            v.binary_key = r.key.data();
+            v.group_by_key = r.gbk.c_str();
+            v.time_bucket = r.time_bucket;
+            v.count = r.count;
+            v.samples = r.samples;
+            v.aggs = r.aggs.data();
+        }
+    }
+}
+
+int query_finalize(Query *q, Result **out) {
+    hipStream_t st = q->ctx->stream;
+    const ScanPlan &P = q->plan;
+    std::vector<int64_t> hs((size_t)q->n_sum_words), hm((size_t)q->n_max_words);
+    SYBL_HIP(hipMemcpyAsync(hs.data(), q->d_sum, hs.size() * 8, hipMemcpyDeviceToHost, st));
+    SYBL_HIP(hipMemcpyAsync(hm.data(), q->d_max, hm.size() * 8, hipMemcpyDeviceToHost, st));
+    SYBL_HIP(hipStreamSynchronize(st));
+    if (hs[kHdrOverflow] != 0)
+        return fail(SYBL_E_STATE,
+                    "%lld rows fell outside the declared column bounds (sybl_table_set_bounds) -- results would be incomplete",
+                    (long long)hs[kHdrOverflow]);
+
+    Result *R = new Result();
+    R->matched = hs[kHdrMatched];
+    R->op = q->op;
+    R->weighted = q->weighted;
+    R->time_mode = q->time_mode;
+    R->want_percentiles = q->want_percentiles;
+    R->limit = q->limit;
+    R->order_by = q->order_by;
+    for (auto &g : q->groups) R->group_names.push_back(q->t->cols[(size_t)g.col]->name);
+    for (auto &a : q->aggs) R->agg_names.push_back(a.name);
+
+    const int64_t ncell = P.n_cells, gcells = q->group_cells;
+    const int64_t *F = hs.data() + kHeaderWords;
+    const int64_t *H = hs.data() + P.hist_off;
+    size_t na = q->aggs.size();
+
+    auto load_cell = [&](int64_t cell, CellAcc &acc) -> bool {
+        acc.count = F[cell];
+        acc.samples = P.f_samples >= 0 ? F[(int64_t)P.f_samples * ncell + cell] : acc.count;
+        bool exists = q->weighted ? acc.samples != 0 : acc.count != 0;
+        if (!exists) return false;
+        acc.aggs.assign(na, AggAcc());
+        for (size_t a = 0; a < na; a++) {
+            const AggDesc &A = q->aggs[a].d;
+            AggAcc &x = acc.aggs[a];
+            x.sum = (uint64_t)F[(int64_t)A.f_sum * ncell + cell];
+            x.tracked_cnt = A.f_cnt >= 0;
+            if (A.f_cnt >= 0) x.cnt = F[(int64_t)A.f_cnt * ncell + cell];
+            if (A.f_smp >= 0) x.smp = F[(int64_t)A.f_smp * ncell + cell];
+            if (A.f_sb >= 0) x.sb = F[(int64_t)A.f_sb * ncell + cell];
+            if (A.f_sb2 >= 0) x.sb2 = F[(int64_t)A.f_sb2 * ncell + cell];
+            if (A.f_out >= 0) {
+                x.n_out = F[(int64_t)A.f_out * ncell + cell];
+                x.sum_out = (uint64_t)F[(int64_t)(A.f_out + 1) * ncell + cell];
+                for (int k = 0; k < 4; k++) x.sq[k] = (uint64_t)F[(int64_t)(A.f_out + 2 + k) * ncell + cell];
+            }
+            x.vmax = hm[(size_t)((int64_t)A.m_max * ncell + cell)];
+            x.nmin = hm[(size_t)((int64_t)A.m_nmin * ncell + cell)];
+            if (A.hist_full) {
+                const int64_t *hv = H + cell * P.hist_stride + P.hist_agg_off[a];
+                x.values.assign(hv, hv + A.n_values);
+            }
+        }
+        return true;
+    };
+
+    // When count is not tracked per aggregation it equals the row count of the cell; for
+    // merged accumulators (Cumulative) make that explicit before adding.
+    auto normalise = [&](CellAcc &acc) {
+        for (size_t a = 0; a < na; a++) {
+            AggAcc &x = acc.aggs[a];
+            if (!x.tracked_cnt) {
+                x.cnt = acc.count;
+                x.tracked_cnt = true;
+            }
+        }
+    };
+
+    CellAcc total;
+    total.aggs.assign(q->time_mode ? 0 : na, AggAcc());
+    for (auto &x : total.aggs) x.tracked_cnt = true;
+    std::vector<int64_t> all_count, all_samples;
+    if (q->time_mode) {
+        all_count.assign((size_t)gcells, 0);
+        all_samples.assign((size_t)gcells, 0);
+    }
+
+    for (int64_t cell = 0; cell < ncell; cell++) {
+        CellAcc acc;
+        if (!load_cell(cell, acc)) continue;
+        normalise(acc);
+        int64_t tbi = cell / gcells, gcell = cell - tbi * gcells;
+        RowStore row;
+        build_key(q, gcell, row.key, row.gbk);
+        if (q->time_mode) {
+            row.time_bucket = (P.tb_min + tbi) * P.time_bucket;
+            all_count[(size_t)gcell] += acc.count;
+            all_samples[(size_t)gcell] += acc.samples;
+            finish_row(q, acc, row);
+            R->rows[1].push_back(std::move(row));
+        } else {
+            finish_row(q, acc, row);
+            R->rows[0].push_back(std::move(row));
+            for (size_t a = 0; a < na; a++) acc_add(total.aggs[a], acc.aggs[a]);
+        }
+        total.count += acc.count;
+        total.samples += acc.samples;
+    }
+    if (q->time_mode) {
+        // all-time Results carry Count/Samples only (aggregate.go:156-169)
+        for (int64_t g = 0; g < gcells; g++) {
+            bool exists = q->weighted ? all_samples[(size_t)g] != 0 : all_count[(size_t)g] != 0;
+            if (!exists) continue;
+            RowStore row;
+            build_key(q, g, row.key, row.gbk);
+            CellAcc acc;
+            acc.count = all_count[(size_t)g];
+            acc.samples = all_samples[(size_t)g];
+            finish_row(q, acc, row);
+            R->rows[0].push_back(std::move(row));
+        }
+    }
+    // Cumulative, aggregate.go:422-438
+    {
+        RowStore row;
+        row.gbk = "TOTAL";
+        for (size_t g = 1; g < q->groups.size(); g++) row.gbk += "\t";
+        finish_row(q, total, row);
+        R->rows[2].push_back(std::move(row));
+    }
+
+    // SortResults, aggregate.go:497-525 (stable over the canonical key order)
+    if (!q->order_by.empty()) {
+        int by = -1;
+        if (q->order_by != "$COUNT") {
+            for (size_t a = 0; a < na; a++)
+                if (q->aggs[a].name == q->order_by) by = (int)a;
+            if (by < 0) {
+                delete R;
+                return fail(SYBL_E_INVAL, "order_by '%s' is neither $COUNT nor an aggregated column", q->order_by.c_str());
+            }
+        }
+        auto less = [&](const RowStore &x, const RowStore &y) {
+            if (by < 0) return x.count > y.count;
+            double mx = x.aggs[(size_t)by].present ? x.aggs[(size_t)by].avg : -INFINITY;
+            double my = y.aggs[(size_t)by].present ? y.aggs[(size_t)by].avg : -INFINITY;
+            return mx > my;
+        };
+        std::stable_sort(R->rows[0].begin(), R->rows[0].end(), less);
+        if (q->order_asc) std::reverse(R->rows[0].begin(), R->rows[0].end());
+    }
+    make_views(R);
+    *out = R;
+    return SYBL_OK;
+}
+
+// ------------------------------------------------------------------ rendering (printer.go)
+
+static void json_escape(const std::string &s, std::string &o) {
+    o += '"';
+    for (unsigned char ch : s) {
+        switch (ch) {
+        case '"': o += "\\\""; break;
+        case '\\': o += "\\\\"; break;
+        case '\n': o += "\\n"; break;
+        case '\r': o += "\\r"; break;
+        case '\t': o += "\\t"; break;
+        case '<': o += "\\u003c"; break;  // encoding/json escapes HTML by default
+        case '>': o += "\\u003e"; break;
+        case '&': o += "\\u0026"; break;
+        default:
+            if (ch < 0x20) {
+                char b[8];
+                snprintf(b, sizeof(b), "\\u%04x", ch);
+                o += b;
+            } else {
+                o += (char)ch;
+            }
+        }
+    }
+    o += '"';
+}
+
+// encoding/json float formatting: shortest repr that round-trips, 'e' form outside [1e-6,1e21)
+static std::string go_float(double f) {
+    if (f == 0) return signbit(f) ? "-0" : "0";
+    if (!isfinite(f)) return "null";  // json.Marshal would fail; the reference prints nothing useful
+    char buf[64];
+    int prec = 1;
+    for (; prec <= 17; prec++) {
+        snprintf(buf, sizeof(buf), "%.*e", prec - 1, f);
+        if (strtod(buf, nullptr) == f) break;
+    }
+    double af = fabs(f);
+    if (af < 1e-6 || af >= 1e21) {
+        // mantissa 'e' exponent with at least... Go: strconv 'e' then trims "e-07" -> "e-7"
+        std::string s(buf);
+        size_t e = s.find('e');
+        std::string mant = s.substr(0, e), ex = s.substr(e + 1);
+        int exv = atoi(ex.c_str());
+        char eb[16];
+        snprintf(eb, sizeof(eb), "e%s%02d", exv < 0 ? "-" : "+", abs(exv));
+        std::string r = mant + eb;
+        // encoding/json: clean up e-09 to e-9
+        size_t n = r.size();
+        if (n >= 4 && r[n - 4] == 'e' && r[n - 3] == '-' && r[n - 2] == '0') {
+            r[n - 2] = r[n - 1];
+            r.resize(n - 1);
+        }
+        return r;
+    }
+    // 'f' form with the same digits
+    int decimals = 0;
+    {
+        std::string s(buf);
+        size_t e = s.find('e');
+        int exv = atoi(s.c_str() + e + 1);
+        decimals = std::max(0, (prec - 1) - exv);
+    }
+    snprintf(buf, sizeof(buf), "%.*f", decimals, f);
+    return buf;
+}
+
+static void json_agg(const Result *R, const RowStore &r, size_t a, std::string &o) {
+    const sybl_agg_out &g = r.aggs[a];
+    if (R->op == SYBL_AGG_AVG) {
+        o += g.present ? go_float(g.avg) : "null";
+        return;
+    }
+    o += "{";
+    if (g.present) {
+        // keys in the order encoding/json emits a map: sorted
+        o += "\"avg\":" + go_float(g.avg);
+        if (R->want_percentiles && !r.values[a].empty()) {
+            // GetStrBuckets + getSparseBuckets: non-zero buckets keyed by their lower edge, sorted as strings
+            std::vector<std::pair<std::string, int64_t>> bk;
+            for (size_t b = 0; b < r.values[a].size(); b++)
+                if (r.values[a][b] > 0)
+                    bk.emplace_back(std::to_string((long long)((int64_t)b * g.bucket_size + g.min)), r.values[a][b]);
+            std::sort(bk.begin(), bk.end());
+            o += ",\"buckets\":{";
+            for (size_t k = 0; k < bk.size(); k++) {
+                if (k) o += ",";
+                o += "\"" + bk[k].first + "\":" + std::to_string((long long)bk[k].second);
+            }
+            o += "}";
+            o += ",\"percentiles\":[";
+            for (size_t k = 0; k < r.pcts[a].size(); k++) {
+                if (k) o += ",";
+                o += std::to_string((long long)r.pcts[a][k]);
+            }
+            o += "]";
+        }
+        o += ",\"samples\":" + std::to_string((long long)g.count);  // "samples" = TotalCount() (printer.go:123)
+        o += ",\"stddev\":" + go_float(g.stddev);
+        o += ",\"sum\":" + go_float(g.avg * (double)g.count);  // Mean()*TotalCount(), printer.go:122
+    }
+    o += "}";
+}
+
+static void json_row(const Result *R, const RowStore &r, std::string &o) {
+    // ResultJSON is a map: keys are emitted sorted
+    std::vector<std::pair<std::string, std::string>> kv;
+    for (size_t a = 0; a < R->agg_names.size(); a++) {
+        std::string v;
+        json_agg(R, r, a, v);
+        kv.emplace_back(R->agg_names[a], v);
+    }
+    size_t pos = 0;
+    for (size_t g = 0; g < R->group_names.size(); g++) {
+        size_t e = r.gbk.find('\t', pos);
+        std::string part = r.gbk.substr(pos, e == std::string::npos ? std::string::npos : e - pos);
+        pos = e == std::string::npos ? r.gbk.size() : e + 1;
+        std::string v;
+        json_escape(part, v);
+        kv.emplace_back(R->group_names[g], v);
+    }
+    kv.emplace_back("Count", std::to_string((long long)r.count));
+    kv.emplace_back("Samples", std::to_string((long long)r.samples));
+    std::stable_sort(kv.begin(), kv.end(), [](const auto &x, const auto &y) { return x.first < y.first; });
+    // later duplicates of a key overwrite earlier ones in a Go map
+    o += "{";
+    bool first = true;
+    for (size_t k = 0; k < kv.size(); k++) {
+        if (k + 1 < kv.size() && kv[k + 1].first == kv[k].first) continue;
+        if (!first) o += ",";
+        first = false;
+        json_escape(kv[k].first, o);
+        o += ":" + kv[k].second;
+    }
+    o += "}";
+}
+
+static void text_row(const Result *R, const RowStore &r, std::string &o) {
+    // printResult, printer.go:183-232
+    std::string gk = r.gbk;
+    std::replace(gk.begin(), gk.end(), '\t', ',');
+    while (!gk.empty() && gk.back() == ',') gk.pop_back();
+    char b[64];
+    snprintf(b, sizeof(b), "%-20s", gk.c_str());
+    std::string pad(b);
+    o += pad.substr(0, 20);
+    if (r.count != 0) o += std::to_string((long long)r.count);  // "%.0d" prints nothing for 0
+    if (R->weighted) o += " (" + std::to_string((long long)r.samples) + ")";
+    o += "\n";
+    for (size_t a = 0; a < R->agg_names.size(); a++) {
+        const sybl_agg_out &g = r.aggs[a];
+        snprintf(b, sizeof(b), "  %5s", R->agg_names[a].c_str());
+        std::string col = b;
+        if (R->op == SYBL_AGG_HIST) {
+            if (!g.present) continue;
+            if (r.pcts[a].size() >= 100) {
+                const auto &p = r.pcts[a];
+                char line[512];
+                snprintf(line, sizeof(line), "%s | %lld %lld | %.2f | %lld %lld %lld %lld %lld | %.2f\n", col.c_str(),
+                         (long long)p[0], (long long)p[99], g.avg, (long long)p[0], (long long)p[25], (long long)p[50],
+                         (long long)p[75], (long long)p[99], g.stddev);
+                o += line;
+            } else if (!R->want_percentiles) {
+                // moments-only result: no percentile columns to print
+                char line[256];
+                snprintf(line, sizeof(line), "%s | %.2f | %.2f\n", col.c_str(), g.avg, g.stddev);
+                o += line;
+            } else {
+                o += col + " No Data\n";
+            }
+        } else {
+            char line[128];
+            snprintf(line, sizeof(line), "%s %.2f\n", col.c_str(), g.present ? g.avg : 0.0);
+            o += line;
+        }
+    }
+}
+
+}  // namespace sybl
+
+using namespace sybl;
+
+extern "C" {
+
+int sybl_result_rows(const sybl_result *r, int which, const sybl_group_row **rows, int64_t *n) {
+    const Result *R = (const Result *)r;
+    if (!R || which < 0 || which > 2) return fail(SYBL_E_INVAL, "sybl_result_rows: bad argument");
+    if (rows) *rows = R->view[which].data();
+    if (n) *n = (int64_t)R->view[which].size();
+    return SYBL_OK;
+}
+
+int64_t sybl_result_matched(const sybl_result *r) { return r ? ((const Result *)r)->matched : 0; }
+
+void sybl_result_free(sybl_result *r) { delete (Result *)r; }
+
+const char *sybl_result_render(sybl_result *r, int format) {
+    Result *R = (Result *)r;
+    if (!R || (format != 0 && format != 1)) {
+        set_error("sybl_result_render: bad argument");
+        return nullptr;
+    }
+    std::string &o = R->rendered[format];
+    o.clear();
+    size_t lim = R->rows[0].size();
+    if (R->limit > 0 && (size_t)R->limit < lim) lim = (size_t)R->limit;
+    if (R->time_mode) {
+        // printTimeResults, printer.go:25-107
+        std::vector<const RowStore *> top;
+        for (size_t i = 0; i < lim; i++) top.push_back(&R->rows[0][i]);
+        auto is_top = [&](const RowStore &x) {
+            for (auto *t : top)
+                if (t->gbk == x.gbk) return true;
+            return false;
+        };
+        if (format == 1) {
+            // map[string][]ResultJSON keyed by the bucket as a decimal string (sorted as strings)
+            std::vector<std::pair<std::string, std::string>> kv;
+            size_t i = 0;
+            while (i < R->rows[1].size()) {
+                int64_t tb = R->rows[1][i].time_bucket;
+                std::string arr = "[";
+                bool first = true;
+                for (; i < R->rows[1].size() && R->rows[1][i].time_bucket == tb; i++) {
+                    if (!is_top(R->rows[1][i])) continue;
+                    if (!first) arr += ",";
+                    first = false;
+                    json_row(R, R->rows[1][i], arr);
+                }
+                arr += "]";
+                kv.emplace_back(std::to_string((long long)tb), arr);
+            }
+            std::sort(kv.begin(), kv.end());
+            o += "{";
+            for (size_t k = 0; k < kv.size(); k++) {
+                if (k) o += ",";
+                o += "\"" + kv[k].first + "\":" + kv[k].second;
+            }
+            o += "}";
+        } else {
+            for (auto &row : R->rows[1]) {
+                char line[512];
+                if (R->agg_names.empty()) {
+                    snprintf(line, sizeof(line), "%lld %lld %s\n", (long long)row.time_bucket, (long long)row.count, row.gbk.c_str());
+                    o += line;
+                }
+                for (size_t a = 0; a < R->agg_names.size(); a++) {
+                    if (!row.aggs[a].present) continue;
+                    snprintf(line, sizeof(line), "%lld %lld %s %s %.2f\n", (long long)row.time_bucket, (long long)row.count,
+                             row.gbk.c_str(), R->agg_names[a].c_str(), row.aggs[a].avg);
+                    o += line;
+                }
+            }
+        }
+        return o.c_str();
+    }
+    if (format == 1) {
+        o += "[";
+        for (size_t i = 0; i < lim; i++) {
+            if (i) o += ",";
+            json_row(R, R->rows[0][i], o);
+        }
+        o += "]";
+    } else {
+        // printSortedResults / printResults: the cumulative row first when there is more than one group
+        if (lim > 1 && !R->rows[2].empty()) text_row(R, R->rows[2][0], o);
+        for (size_t i = 0; i < lim; i++) text_row(R, R->rows[0][i], o);
+    }
+    return o.c_str();
+}
+
+}  // extern "C"

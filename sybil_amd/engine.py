@@ -1,0 +1,345 @@
+"""Host-side mirror of the reference's query surface over the C ABI.
+
+Names follow logv/sybil (src/lib): a Table holds columns, a query is described by
+filters (`IntFilter`/`StrFilter`/`SetFilter`, filter.go:143-168), `Grouping`s and
+`Aggregation`s (query_spec.go:73-83) plus the FLAGS the hot loop reads
+(op avg|hist, -int-bucket, -time/-time-col/-time-bucket, -weight-col, -sort, -limit),
+and `LoadAndQueryRecords` (table_query.go:18) becomes prepare -> scan -> [all-reduce] ->
+finalize.  Everything computes on the GPU through libsybilgpu.so; nothing here falls
+back to the CPU.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _native as N
+
+
+def _b(s):
+    return s.encode("utf-8") if isinstance(s, str) else s
+
+
+class Context:
+    """One GPU (one process per GPU under RCCL)."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        N.check(N.lib().sybl_init(device, C.byref(self._h)))
+        self.device = device
+
+    def close(self):
+        if self._h:
+            N.lib().sybl_shutdown(self._h)
+            self._h = C.c_void_p()
+
+    def set_stream(self, hip_stream_ptr):
+        N.check(N.lib().sybl_ctx_set_stream(self._h, C.c_void_p(hip_stream_ptr)))
+
+    def sync(self):
+        N.check(N.lib().sybl_ctx_sync(self._h))
+
+    def device_info(self):
+        name = C.create_string_buffer(256)
+        cus, hbm = C.c_int(), C.c_int64()
+        N.check(N.lib().sybl_device_info(self._h, name, 256, C.byref(cus), C.byref(hbm)))
+        return {"name": name.value.decode(), "n_cus": cus.value, "hbm_bytes": hbm.value}
+
+    # ---- RCCL inside the library (hosts without a collective runtime of their own)
+    @staticmethod
+    def comm_unique_id():
+        buf = C.create_string_buffer(128)
+        N.check(N.lib().sybl_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, unique_id, nranks, rank):
+        N.check(N.lib().sybl_comm_init(self._h, unique_id, nranks, rank))
+
+    def comm_free(self):
+        N.check(N.lib().sybl_comm_free(self._h))
+
+    def create_table(self, name):
+        h = C.c_void_p()
+        N.check(N.lib().sybl_table_create(self._h, _b(name), C.byref(h)))
+        return Table(self, h, name)
+
+    def synth_table(self, name, seed, total_rows, row0, nrows, cols):
+        """cols: list of dicts {name, kind, col_index, a, b, info_min, info_max}."""
+        arr = (N.SynthCol * len(cols))()
+        keep = []
+        for i, c in enumerate(cols):
+            nm = _b(c["name"])
+            keep.append(nm)
+            arr[i] = N.SynthCol(nm, c["kind"], c["col_index"], c["a"], c["b"], c.get("info_min", 1), c.get("info_max", 0))
+        h = C.c_void_p()
+        N.check(N.lib().sybl_table_create_synth(self._h, _b(name), seed, total_rows, row0, nrows, len(cols), arr,
+                                                C.byref(h)))
+        return Table(self, h, name)
+
+    def open_table(self, directory, table, columns=None, rank=0, nranks=1):
+        h = C.c_void_p()
+        if columns:
+            names = [_b(c) for c in columns]
+            arr = (C.c_char_p * len(names))(*names)
+            n = len(names)
+        else:
+            arr, n = None, 0
+        N.check(N.lib().sybl_table_open(self._h, _b(directory), _b(table), arr, n, rank, nranks, C.byref(h)))
+        return Table(self, h, table)
+
+
+class Table:
+    def __init__(self, ctx, handle, name):
+        self.ctx, self._h, self.name = ctx, handle, name
+
+    def free(self):
+        if self._h:
+            N.lib().sybl_table_free(self._h)
+            self._h = C.c_void_p()
+
+    def add_column(self, name, type="int", info_min=1, info_max=0):
+        t = {"int": N.INT_VAL, "str": N.STR_VAL, "set": N.SET_VAL}[type]
+        N.check(N.lib().sybl_table_add_column(self._h, _b(name), t, info_min, info_max))
+
+    def append_block(self, nrows, columns):
+        """columns: {name: spec}.  int: ndarray or (ndarray, populated);  str: dict(ids=, strings=,
+        populated=);  set: dict(offsets=, ids=, strings=, populated=)."""
+        views = (N.ColView * max(len(columns), 1))()
+        keep = []
+        for i, (name, spec) in enumerate(columns.items()):
+            nm = _b(name)
+            keep.append(nm)
+            v = N.ColView()
+            v.name = nm
+            pop = None
+            if isinstance(spec, dict):
+                pop = spec.get("populated")
+                strings = [_b(s) for s in spec["strings"]]
+                sarr = (C.c_char_p * max(len(strings), 1))(*strings)
+                keep += [strings, sarr]
+                v.strings = C.cast(sarr, C.POINTER(C.c_char_p))
+                v.n_strings = len(strings)
+                ids = np.ascontiguousarray(spec["ids"], dtype=np.int32)
+                keep.append(ids)
+                if "offsets" in spec:
+                    off = np.ascontiguousarray(spec["offsets"], dtype=np.int64)
+                    keep.append(off)
+                    v.type = N.SET_VAL
+                    v.set_off = off.ctypes.data
+                    v.set_ids = ids.ctypes.data
+                else:
+                    v.type = N.STR_VAL
+                    v.str_ids = ids.ctypes.data
+            else:
+                if isinstance(spec, tuple):
+                    spec, pop = spec
+                d = np.ascontiguousarray(spec, dtype=np.int64)
+                keep.append(d)
+                v.type = N.INT_VAL
+                v.ints = d.ctypes.data
+            if pop is not None:
+                p = np.ascontiguousarray(pop, dtype=np.uint8)
+                keep.append(p)
+                v.populated = p.ctypes.data
+            views[i] = v
+        N.check(N.lib().sybl_table_append_block(self._h, nrows, len(columns), views))
+
+    @property
+    def rows(self):
+        return N.lib().sybl_table_rows(self._h)
+
+    @property
+    def blocks(self):
+        return N.lib().sybl_table_blocks(self._h)
+
+    @property
+    def hbm_bytes(self):
+        return N.lib().sybl_table_hbm_bytes(self._h)
+
+    def column_info(self, name):
+        t, hm = C.c_int(), C.c_int()
+        a, b, c, d = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+        N.check(N.lib().sybl_table_column_info(self._h, _b(name), C.byref(t), C.byref(a), C.byref(b), C.byref(c),
+                                               C.byref(d), C.byref(hm)))
+        return {"type": t.value, "exact_min": a.value, "exact_max": b.value, "info_min": c.value,
+                "info_max": d.value, "has_missing": bool(hm.value)}
+
+    def set_bounds(self, name, lo, hi, has_missing=False):
+        N.check(N.lib().sybl_table_set_bounds(self._h, _b(name), lo, hi, 1 if has_missing else 0))
+
+    def read_int(self, name, row0, n):
+        out = np.empty(n, dtype=np.int64)
+        N.check(N.lib().sybl_table_read_int(self._h, _b(name), row0, n, out.ctypes.data))
+        return out
+
+    # reference-named constructors (filter.go:287-318, query_spec.go:214-219)
+    @staticmethod
+    def IntFilter(col, op, value):
+        return (col, op, int(value))
+
+    @staticmethod
+    def StrFilter(col, op, value):
+        return (col, op, str(value))
+
+    @staticmethod
+    def SetFilter(col, op, value):
+        return (col, op, str(value))
+
+    def query(self, filters=(), groups=(), aggs=(), op="avg", hist_bucket=0, want_percentiles=True, time_col=None,
+              time_bucket=0, weight_col=None, order_by="$COUNT", order_asc=False, limit=0, block_skip=False):
+        keep = []
+        farr = (N.Filter * max(len(filters), 1))()
+        for i, f in enumerate(filters):
+            col, opn, val = f[0], f[1], f[2]
+            ff = N.Filter()
+            ff.col = _b(col)
+            ff.op = N.OPS[opn]
+            if isinstance(val, (int, np.integer)):
+                ff.int_value = int(val)
+            else:
+                ff.str_value = _b(val)
+            if len(f) > 3 and f[3] is not None:
+                m = np.ascontiguousarray(f[3], dtype=np.uint8)
+                keep.append(m)
+                ff.id_match = m.ctypes.data
+                ff.id_match_len = m.size
+            farr[i] = ff
+        g = [_b(x) for x in groups]
+        a = [_b(x) for x in aggs]
+        garr = (C.c_char_p * max(len(g), 1))(*g)
+        aarr = (C.c_char_p * max(len(a), 1))(*a)
+        d = N.QueryDesc()
+        d.n_filters, d.filters = len(filters), C.cast(farr, C.POINTER(N.Filter))
+        d.n_groups, d.groups = len(g), C.cast(garr, C.POINTER(C.c_char_p))
+        d.n_aggs, d.aggs = len(a), C.cast(aarr, C.POINTER(C.c_char_p))
+        d.op = N.AGG_HIST if op == "hist" else N.AGG_AVG
+        d.hist_bucket = hist_bucket
+        d.want_percentiles = 1 if want_percentiles else 0
+        d.time_col = _b(time_col) if time_col else None
+        d.time_bucket = time_bucket
+        d.weight_col = _b(weight_col) if weight_col else None
+        d.order_by = _b(order_by) if order_by else None
+        d.order_asc = 1 if order_asc else 0
+        d.limit = limit
+        d.block_skip = 1 if block_skip else 0
+        h = C.c_void_p()
+        N.check(N.lib().sybl_query_prepare(self._h, C.byref(d), C.byref(h)))
+        return Query(self, h, list(groups), list(aggs))
+
+
+class Query:
+    def __init__(self, table, handle, groups, aggs):
+        self.table, self._h, self.groups, self.aggs = table, handle, groups, aggs
+        self._bound = None
+
+    def free(self):
+        if self._h:
+            N.lib().sybl_query_free(self._h)
+            self._h = C.c_void_p()
+
+    def scan(self):
+        N.check(N.lib().sybl_query_scan(self._h))
+        return self
+
+    def partial_sizes(self):
+        ns, nm = C.c_int64(), C.c_int64()
+        N.check(N.lib().sybl_query_partials(self._h, None, C.byref(ns), None, C.byref(nm)))
+        return ns.value, nm.value
+
+    def partials(self):
+        ps, pm = C.c_void_p(), C.c_void_p()
+        ns, nm = C.c_int64(), C.c_int64()
+        N.check(N.lib().sybl_query_partials(self._h, C.byref(ps), C.byref(ns), C.byref(pm), C.byref(nm)))
+        return ps.value, ns.value, pm.value, nm.value
+
+    def bind_partials(self, d_sum_ptr, d_max_ptr):
+        N.check(N.lib().sybl_query_bind_partials(self._h, C.c_void_p(d_sum_ptr), C.c_void_p(d_max_ptr)))
+
+    def bind_torch(self, device):
+        """Allocates the partial tables as torch tensors (so torch.distributed can all-reduce
+        them over RCCL) and makes the scan write into them."""
+        import torch
+        ns, nm = self.partial_sizes()
+        s = torch.zeros(ns, dtype=torch.int64, device=device)
+        m = torch.zeros(nm, dtype=torch.int64, device=device)
+        torch.cuda.synchronize(device)  # the fills ran on torch's stream, the scan runs on the ctx stream
+        self.bind_partials(s.data_ptr(), m.data_ptr())
+        self._bound = (s, m)
+        return s, m
+
+    def allreduce_torch(self, group=None):
+        """The one collective on the path: SUM over counts/sums/buckets, MAX over extrema."""
+        import torch.distributed as dist
+        s, m = self._bound
+        dist.all_reduce(s, op=dist.ReduceOp.SUM, group=group)
+        dist.all_reduce(m, op=dist.ReduceOp.MAX, group=group)
+
+    def allreduce(self):
+        N.check(N.lib().sybl_query_allreduce(self._h))
+
+    def stats(self):
+        st = N.RunStats()
+        N.check(N.lib().sybl_query_stats(self._h, C.byref(st)))
+        return st.as_dict()
+
+    def finalize(self):
+        h = C.c_void_p()
+        N.check(N.lib().sybl_query_finalize(self._h, C.byref(h)))
+        return Result(h, len(self.groups), len(self.aggs))
+
+    def run(self):
+        return self.scan().finalize()
+
+
+class Result:
+    def __init__(self, handle, n_groups, n_aggs):
+        self._h, self.n_groups, self.n_aggs = handle, n_groups, n_aggs
+
+    def free(self):
+        if self._h:
+            N.lib().sybl_result_free(self._h)
+            self._h = C.c_void_p()
+
+    @property
+    def matched(self):
+        return N.lib().sybl_result_matched(self._h)
+
+    def rows(self, which=0, want_values=True):
+        rows = C.POINTER(N.GroupRow)()
+        n = C.c_int64()
+        N.check(N.lib().sybl_result_rows(self._h, which, C.byref(rows), C.byref(n)))
+        out = []
+        for i in range(n.value):
+            r = rows[i]
+            kb = bytes(bytearray(r.binary_key[k] for k in range(8 * self.n_groups))) if self.n_groups and which != 2 else b""
+            row = {"key": kb,
+                   "key_vals": tuple(int.from_bytes(kb[8 * g:8 * g + 8], "little") for g in range(len(kb) // 8)),
+                   "group_by_key": r.group_by_key.decode("utf-8", "replace"),
+                   "time_bucket": r.time_bucket, "count": r.count, "samples": r.samples, "hists": []}
+            for a in range(self.n_aggs):
+                g = r.aggs[a]
+                h = {k: getattr(g, k) for k, _ in N.AggOut._fields_ if k not in ("values", "percentiles")}
+                if want_values and g.values:
+                    h["values"] = np.ctypeslib.as_array(g.values, shape=(g.n_values,)).copy()
+                if g.percentiles:
+                    h["percentiles"] = np.ctypeslib.as_array(g.percentiles, shape=(100,)).copy()
+                row["hists"].append(h)
+            out.append(row)
+        return out
+
+    @property
+    def results(self):
+        return self.rows(0)
+
+    @property
+    def time_results(self):
+        return self.rows(1)
+
+    @property
+    def cumulative(self):
+        return self.rows(2)[0]
+
+    def render(self, fmt="text"):
+        s = N.lib().sybl_result_render(self._h, 1 if fmt == "json" else 0)
+        if s is None:
+            raise N.SyblError(N.E_INVAL, (N.lib().sybl_last_error() or b"").decode())
+        return s.decode("utf-8", "replace")

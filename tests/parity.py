@@ -1,0 +1,105 @@
+"""Shared helpers for the GPU-vs-oracle parity tests (test infrastructure)."""
+import numpy as np
+
+from sybil_amd import synth
+
+REL = 1e-6  # north_star: avg / stddev / percentile-derived floats within 1e-6 relative
+
+
+def oracle_synth_cols(orc, names, total_rows, row0, nrows):
+    cols = []
+    for n in names:
+        kind, idx, a, b, _, _ = synth.COLUMNS[n]
+        cols.append({"type": "int", "data": orc.synth_fill(kind, a, b, synth.SEED, idx, row0, nrows, total_rows)})
+    return cols
+
+
+def oracle_query_kwargs(names, info, q):
+    """Translates sybil_amd query kwargs (column names) into oracle.run_query kwargs (indices).
+    info: {name: (info_min, info_max)}"""
+    ix = {n: i for i, n in enumerate(names)}
+    kw = {}
+    kw["filters"] = [(ix[f[0]],) + tuple(f[1:]) for f in q.get("filters", [])]
+    kw["groups"] = [ix[g] for g in q.get("groups", [])]
+    kw["aggs"] = [(ix[a], info[a][0], info[a][1]) for a in q.get("aggs", [])]
+    kw["op"] = q.get("op", "avg")
+    kw["hist_bucket"] = q.get("hist_bucket", 0)
+    if q.get("time_col"):
+        kw["time_col"] = ix[q["time_col"]]
+        kw["time_bucket"] = q.get("time_bucket", 0)
+    if q.get("weight_col"):
+        kw["weight_col"] = ix[q["weight_col"]]
+    kw["block_skip"] = q.get("block_skip", False)
+    return kw
+
+
+def _close(a, b, rel=REL):
+    if a == b:
+        return True
+    return abs(a - b) <= rel * max(abs(a), abs(b))
+
+
+def compare_hist(g, o, op, full, ctx=""):
+    assert bool(g["present"]) == bool(o["present"]), ctx
+    if not o["present"]:
+        return
+    assert g["count"] == o["count"], (ctx, g["count"], o["count"])
+    assert g["samples"] == o["samples"], ctx
+    assert g["sum"] == o["sum_exact"], (ctx, g["sum"], o["sum_exact"])
+    assert (g["min"], g["max"]) == (o["min"], o["max"]), (ctx, g["min"], g["max"], o["min"], o["max"])
+    # avg: exact sum/count here vs the reference-order running mean of the oracle
+    assert _close(g["avg"], o["avg"]), (ctx, g["avg"], o["avg"])
+    if op == "hist":
+        assert g["bucket_size"] == o["bucket_size"] and g["n_values"] == o["n_values"], ctx
+        assert g["num_buckets"] == o["num_buckets"], ctx
+        assert g["n_outliers"] == o["n_outliers"] + o["n_underliers"], ctx
+        assert _close(g["stddev"], o["stddev_exact"], 1e-9), (ctx, g["stddev"], o["stddev_exact"])
+        if o["n_outliers"] + o["n_underliers"] == 0:
+            assert _close(g["stddev"], o["stddev_ref"]), (ctx, g["stddev"], o["stddev_ref"])
+        if full:
+            assert np.array_equal(g["values"], o["values"]), ctx
+            assert np.array_equal(g["percentiles"], o["percentiles"]), ctx
+    else:
+        assert g["stddev"] == 0.0, ctx
+
+
+def compare(gres, ores, op="avg", full=True, n_aggs=0, time_mode=False):
+    """gres: sybil_amd.Result; ores: dict from oracle.run_query.  Bit-exact on counts, sums, keys,
+    buckets, percentiles, extrema; REL on avg/stddev."""
+    assert gres.matched == ores["matched"], (gres.matched, ores["matched"])
+    for which, name in ((0, "results"), (1, "time_results")):
+        grows = gres.rows(which)
+        orows = ores[name]
+        gmap = {(r["time_bucket"], r["key"]): r for r in grows}
+        omap = {(r["time_bucket"], r["key"]): r for r in orows}
+        assert len(gmap) == len(grows), "duplicate keys from the GPU path"
+        assert set(gmap) == set(omap), (name, len(gmap), len(omap), sorted(set(gmap) ^ set(omap))[:5])
+        for k, o in omap.items():
+            g = gmap[k]
+            assert g["count"] == o["count"] and g["samples"] == o["samples"], (name, k, g["count"], o["count"])
+            for a in range(n_aggs):
+                compare_hist(g["hists"][a], o["hists"][a], op, full, ctx=(name, k, a))
+    gc, oc = gres.cumulative, ores["cumulative"]
+    assert gc["count"] == oc["count"] and gc["samples"] == oc["samples"]
+    if not time_mode:
+        for a in range(n_aggs):
+            compare_hist(gc["hists"][a], oc["hists"][a], op, full, ctx=("cumulative", a))
+
+
+def run_both(ctx, orc, names, total_rows, row0, nrows, q, block_rows=65536, oracle_threads=4):
+    """Synthetic table on the GPU and in host memory; same query through both."""
+    t = ctx.synth_table("synth", synth.SEED, total_rows, row0, nrows, synth.synth_cols(names))
+    try:
+        query = t.query(**q)
+        try:
+            gres = query.run()
+            stats = query.stats()
+        finally:
+            query.free()
+        info = {n: (synth.COLUMNS[n][4], synth.COLUMNS[n][5]) for n in names}
+        ocols = oracle_synth_cols(orc, names, total_rows, row0, nrows)
+        ores = orc.run_query(ocols, block_rows=block_rows, n_threads=oracle_threads,
+                             **oracle_query_kwargs(names, info, q))
+        return gres, ores, stats
+    finally:
+        t.free()

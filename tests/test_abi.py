@@ -1,0 +1,65 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports exactly what
+include/sybilgpu.h declares, and fails loudly (no CPU fallback) when there is no GPU."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    src = open(os.path.join(ROOT, "include", "sybilgpu.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = re.findall(r"\b(sybl_[a-z0-9_]+)\s*\(", src)
+    return sorted(set(names))
+
+
+def test_header_symbols_are_exported_and_bound():
+    from sybil_amd import _native
+    lib = _native.lib()
+    declared = _declared_functions()
+    assert len(declared) >= 30
+    for name in declared:
+        assert hasattr(lib, name), "libsybilgpu.so does not export %s" % name
+        assert name in _native.SIGNATURES, "no ctypes signature for %s" % name
+    assert sorted(_native.SIGNATURES) == declared
+    assert lib.sybl_abi_version() == 1
+
+
+def test_header_compiles_as_plain_c(tmp_path):
+    import subprocess
+    c = tmp_path / "t.c"
+    c.write_text('#include "sybilgpu.h"\nint main(void){ sybl_query_desc d; (void)d; return SYBL_OK; }\n')
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", str(c),
+                           "-o", str(tmp_path / "t.o")])
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    import sybil_amd
+    with pytest.raises(sybil_amd.SyblError) as ei:
+        sybil_amd.Context(0)
+    assert ei.value.code == -2 and "no CPU fallback" in str(ei.value)
+
+
+def test_struct_layouts_match_header():
+    # sizes the C compiler gives the boundary structs vs the ctypes mirrors
+    import subprocess
+    import tempfile
+    from sybil_amd import _native as N
+    prog = r'''
+#include <stdio.h>
+#include "sybilgpu.h"
+int main(void){ printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(sybl_col_view), sizeof(sybl_synth_col),
+  sizeof(sybl_filter), sizeof(sybl_query_desc), sizeof(sybl_agg_out), sizeof(sybl_group_row), sizeof(sybl_run_stats)); return 0; }
+'''
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "s.c"), "w").write(prog)
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "s.c"), "-o", os.path.join(d, "s")])
+        out = subprocess.check_output([os.path.join(d, "s")]).split()
+    sizes = [ctypes.sizeof(x) for x in (N.ColView, N.SynthCol, N.Filter, N.QueryDesc, N.AggOut, N.GroupRow, N.RunStats)]
+    assert [int(x) for x in out] == sizes
