@@ -177,11 +177,12 @@ def main():
                        "sharding": "contiguous 65536-row blocks per rank", "collective": args.collective if world > 1 else None,
                        "device": dev["name"], "matched_rows": res.matched if res is not None else None,
                        "groups": len(res.results) if res is not None else None,
-                       "strategy": "lds" if stats["strategy"] == 0 else "global-atomics",
+                       "strategy": {0: "lds-generic", 1: "global-atomics", 2: "lds-fast"}[stats["strategy"]],
                        "lds_bytes": stats["lds_bytes"], "workgroups": stats["n_workgroups"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_scan<7,lds>", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes},
+                         "kernel": "k_scan_fast<3,2,2,moments>" if stats["strategy"] == 2 else "k_scan<%d>" % len(names),
+                         "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload, total_rows)

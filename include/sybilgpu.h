@@ -262,7 +262,7 @@ typedef struct {
     double scan_ms;           /* hipEvent time of the scan kernel(s) of the last sybl_query_scan */
     double reduce_ms;         /* partial-table fold kernels */
     int32_t n_cells;          /* direct-mapped group cells */
-    int32_t strategy;         /* 0 = LDS-resident table, 1 = global atomics, ... */
+    int32_t strategy;         /* 0 = LDS cell table (generic kernel), 1 = global atomics, 2 = LDS cell table (role-specialised kernel) */
     int32_t lds_bytes, n_workgroups, replicas;
 } sybl_run_stats;
 /* Valid after the stream has been synchronised (sybl_query_finalize / sybl_ctx_sync). */

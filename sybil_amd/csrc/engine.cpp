@@ -14,6 +14,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -226,6 +227,100 @@ static bool should_scan_block(const Table *t, const sybl_query_desc *d, int64_t 
         if (f.op == SYBL_OP_EQ && (mn > v || mx < v)) return false;
     }
     return true;
+}
+
+// Role-specialised kernels (scan_fast.h) cover the common shape; everything else runs k_scan.
+static void select_fast_path(Table *t, Query *q, const std::vector<int> &slot_col, const std::vector<HostFilterFold> &folds) {
+    q->fast = false;
+    const ScanPlan &P = q->plan;
+    if (getenv("SYBL_NO_FAST")) return;
+    if (!q->use_lds || q->time_mode || q->weighted) return;
+    FastPlan &FP = q->fplan;
+    memset(&FP, 0, sizeof(FP));
+    int nf = 0, ng = 0, na = 0;
+    // group slots must come in key order (most significant first): walk q->groups
+    std::vector<int> order;
+    for (size_t s = 0; s < slot_col.size(); s++) {
+        const SlotDesc &sd = P.slot[s];
+        const Column *c = t->cols[(size_t)slot_col[s]].get();
+        if (c->type != SYBL_INT_VAL || c->elem != 8 || c->d_valid || c->has_missing) return;
+        uint32_t roles = sd.flags & (kSlotFilter | kSlotGroup | kSlotAgg);
+        if (sd.flags & (kSlotNeq | kSlotIdMask | kSlotTime | kSlotWeight | kSlotW32)) return;
+        if (roles != kSlotRange && roles != kSlotGroup && roles != kSlotAgg && roles != 0) return;  // one role per column
+        (void)folds;
+    }
+    for (size_t s = 0; s < slot_col.size(); s++) {
+        const SlotDesc &sd = P.slot[s];
+        if (!(sd.flags & kSlotRange)) continue;
+        if (nf >= kFastMaxF) return;
+        FP.fcol[nf] = (const int64_t *)sd.base;
+        FP.lo[nf] = sd.lo;
+        FP.hi[nf] = sd.hi;
+        nf++;
+    }
+    for (auto &gi : q->groups) {
+        if (ng >= kFastMaxG) return;
+        int s = -1;
+        for (size_t k = 0; k < slot_col.size(); k++)
+            if (slot_col[k] == gi.col) s = (int)k;
+        const SlotDesc &sd = P.slot[s];
+        if (sd.gmissing >= 0) return;
+        FP.gcol[ng] = (const int64_t *)sd.base;
+        FP.gmin[ng] = sd.gmin;
+        FP.gcard[ng] = (uint32_t)sd.gcard;
+        FP.gstride[ng] = sd.gstride;
+        ng++;
+    }
+    bool any_max = false, all_max = true;
+    for (auto &ai : q->aggs) {
+        if (na >= kFastMaxA) return;
+        const AggDesc &A = ai.d;
+        if (A.f_cnt >= 0 || A.f_smp >= 0 || A.f_out >= 0 || A.m_nmin >= 0) return;
+        if (q->op == SYBL_AGG_HIST) {
+            if (A.m_max >= 0 || A.big_div || A.bucket_size >= ((int64_t)1 << 32)) return;
+            const Column *c = t->cols[(size_t)ai.col].get();
+            int64_t hi = c->bounds_set ? c->bound_hi : c->exact_max;
+            if (c->n_pop > 0 || c->bounds_set)
+                if ((unsigned __int128)((__int128)hi - (__int128)A.hmin) >= ((unsigned __int128)1 << 32)) return;
+        }
+        any_max = any_max || A.m_max >= 0;
+        all_max = all_max && A.m_max >= 0;
+        int s = -1;
+        for (size_t k = 0; k < slot_col.size(); k++)
+            if (slot_col[k] == ai.col) s = (int)k;
+        FP.acol[na] = (const int64_t *)P.slot[s].base;
+        FP.hmin[na] = A.hmin;
+        FP.inv_bucket[na] = A.inv_bucket;
+        FP.bucket_size[na] = (uint32_t)A.bucket_size;
+        FP.n_values[na] = A.n_values;
+        FP.f_sum[na] = A.f_sum;
+        FP.f_sb[na] = A.f_sb;
+        FP.f_sb2[na] = A.f_sb2;
+        FP.m_max[na] = A.m_max;
+        FP.hist_agg_off[na] = P.hist_agg_off[na];
+        na++;
+    }
+    if (nf + ng + na == 0) return;  // nothing to stream: the generic kernel picks a driver column
+    int mode;
+    if (q->op == SYBL_AGG_HIST) {
+        mode = q->want_percentiles ? kFastHist : kFastMoments;
+    } else {
+        if (any_max && !all_max) return;
+        mode = any_max ? kFastAvgMax : kFastAvg;
+    }
+    FP.hist_off = P.hist_off;
+    FP.hist_stride = P.hist_stride;
+    FP.n_cells = P.n_cells;
+    FP.n_sum_fields = P.n_sum_fields;
+    FP.n_max_fields = P.n_max_fields;
+    FP.rep_shift = P.rep_shift;
+    q->fast = true;
+    q->fast_nf = nf;
+    q->fast_ng = ng;
+    q->fast_na = na;
+    q->fast_mode = mode;
+    const char *pf = getenv("SYBL_FAST_PREFETCH");
+    q->fast_prefetch = pf ? atoi(pf) != 0 : true;
 }
 
 static int plan_query(Table *t, const sybl_query_desc *d, Query *q) {
@@ -473,8 +568,16 @@ static int plan_query(Table *t, const sybl_query_desc *d, Query *q) {
         A.f_cnt = (q->weighted || can_reject) ? F++ : -1;
         A.f_smp = q->weighted ? F++ : -1;
         A.f_sb = A.f_sb2 = A.f_out = -1;
-        A.m_max = M++;
-        A.m_nmin = M++;
+        // BasicHist.Min/Max start at Info.Min/Info.Max in hist mode and at 0 in avg mode
+        // (hist_basic.go:34-40,72-85) and accepted values are >= Info.Min, so the running
+        // extrema only need tracking when the column bounds let a value beat the start value.
+        {
+            bool need_max = d->op == SYBL_AGG_HIST ? (empty ? false : hi > imax) : (empty ? false : hi > 0);
+            bool need_min = d->op == SYBL_AGG_HIST ? false : (empty ? false : lo < 0);
+            if (c->bounds_set == false && empty) need_max = need_min = false;
+            A.m_max = need_max ? M++ : -1;
+            A.m_nmin = need_min ? M++ : -1;
+        }
         ai.f_out = -1;
         ai.num_buckets = 0;
         ai.info_max = imax;
@@ -567,6 +670,7 @@ static int plan_query(Table *t, const sybl_query_desc *d, Query *q) {
 
     // ---- strategy: cell table in LDS when it fits (DESIGN.md "Strategies")
     q->n_wg = ctx->n_cus > 0 ? ctx->n_cus : 256;
+    if (const char *e = getenv("SYBL_WG_PER_CU")) q->n_wg *= std::max(1, atoi(e));
     int64_t lds_words = (int64_t)(F + M) * n_cells;
     q->use_lds = lds_words * 8 <= kLdsBudgetBytes;
     P.rep_shift = 0;
@@ -576,6 +680,7 @@ static int plan_query(Table *t, const sybl_query_desc *d, Query *q) {
         P.rep_shift = rs;
         q->lds_bytes = (size_t)(lds_words * 8) << rs;
     }
+    select_fast_path(t, q, slot_col, folds);
     q->n_sum_words = kHeaderWords + (int64_t)F * n_cells + n_cells * hist_stride;
     q->n_max_words = std::max<int64_t>((int64_t)M * n_cells, 1);
 
@@ -631,7 +736,7 @@ static int plan_query(Table *t, const sybl_query_desc *d, Query *q) {
     for (int s = 0; s < P.n_slots; s++) width += t->cols[(size_t)slot_col[(size_t)s]]->elem;
     q->stats.algorithmic_bytes = rows_scanned * width;
     q->stats.n_cells = (int32_t)n_cells;
-    q->stats.strategy = q->use_lds ? 0 : 1;
+    q->stats.strategy = q->use_lds ? (q->fast ? 2 : 0) : 1;
     q->stats.lds_bytes = (int32_t)q->lds_bytes;
     q->stats.n_workgroups = q->n_wg;
     q->stats.replicas = 1 << P.rep_shift;
@@ -651,6 +756,10 @@ static int plan_query(Table *t, const sybl_query_desc *d, Query *q) {
         P.ws_sum = q->d_ws_sum;
         P.ws_max = q->d_ws_max;
     }
+    q->fplan.segs = q->d_segs;
+    q->fplan.wg_seg_begin = q->d_wg_seg_begin;
+    q->fplan.ws_sum = q->d_ws_sum;
+    q->fplan.ws_max = q->d_ws_max;
     SYBL_HIP(hipMalloc((void **)&q->d_plan, sizeof(ScanPlan)));
     for (auto &e : q->ev) SYBL_HIP(hipEventCreate(&e));
     q->plan_dirty = true;
@@ -683,8 +792,16 @@ static int scan(Query *q) {
     if (e != hipSuccess) return hip_fail(e, "k_fill64");
     SYBL_HIP(hipEventRecord(q->ev[0], st));
     if (!q->never_matches && !q->segs.empty()) {
-        e = launch_scan(q->d_plan, P.n_slots, q->n_wg, q->use_lds, q->lds_bytes, st);
-        if (e != hipSuccess) return hip_fail(e, "k_scan");
+        if (q->fast) {
+            q->fplan.sum_out = q->d_sum;
+            q->fplan.max_out = q->d_max;
+            e = launch_scan_fast(q->fplan, q->fast_nf, q->fast_ng, q->fast_na, q->fast_mode, q->fast_prefetch, q->n_wg,
+                                 q->lds_bytes, st);
+            if (e != hipSuccess) return hip_fail(e, "k_scan_fast");
+        } else {
+            e = launch_scan(q->d_plan, P.n_slots, q->n_wg, q->use_lds, q->lds_bytes, st);
+            if (e != hipSuccess) return hip_fail(e, "k_scan");
+        }
     }
     SYBL_HIP(hipEventRecord(q->ev[1], st));
     if (q->use_lds && !q->never_matches && !q->segs.empty()) {

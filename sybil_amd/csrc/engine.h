@@ -11,6 +11,7 @@
 
 #include "../../include/sybilgpu.h"
 #include "plan.h"
+#include "scan_fast.h"
 
 namespace sybl {
 
@@ -142,6 +143,10 @@ struct Query {
     bool scanned = false;
     sybl_run_stats stats{};
     bool never_matches = false;
+    // role-specialised kernel (scan_fast.h)
+    bool fast = false, fast_prefetch = true;
+    int fast_nf = 0, fast_ng = 0, fast_na = 0, fast_mode = 0;
+    FastPlan fplan;
 };
 
 int query_finalize(Query *q, Result **out);

@@ -217,8 +217,8 @@ __device__ __forceinline__ void process_tile(CPlan &P, const Tile<NC> &t, int nv
             acc_add<USE_LDS>(sumtab, ((int64_t)A.f_sum * ncell << rs) + cidx, (int64_t)((uint64_t)x * (uint64_t)w));
             if (A.f_cnt >= 0) acc_add<USE_LDS>(sumtab, ((int64_t)A.f_cnt * ncell << rs) + cidx, w);
             if (A.f_smp >= 0) acc_add<USE_LDS>(sumtab, ((int64_t)A.f_smp * ncell << rs) + cidx, 1);
-            acc_max<USE_LDS>(maxtab, ((int64_t)A.m_max * ncell << rs) + cidx, x);
-            acc_max<USE_LDS>(maxtab, ((int64_t)A.m_nmin * ncell << rs) + cidx, x == INT64_MIN ? INT64_MAX : -x);
+            if (A.m_max >= 0) acc_max<USE_LDS>(maxtab, ((int64_t)A.m_max * ncell << rs) + cidx, x);
+            if (A.m_nmin >= 0) acc_max<USE_LDS>(maxtab, ((int64_t)A.m_nmin * ncell << rs) + cidx, x == INT64_MIN ? INT64_MAX : -x);
             if (P.hist_mode) {
                 // bucket_value := (value - h.Min) / BucketSize  (hist_basic.go:130)
                 int64_t b = sdiv_trunc(x - A.hmin, A.bucket_size, A.inv_bucket, A.big_div);

@@ -1,0 +1,11 @@
+// kernels_fast_3.hip -- k_scan_fast<NF=3, ...> instantiations (see scan_fast.h).
+#include "scan_fast.h"
+
+namespace sybl {
+
+hipError_t launch_scan_fast_nf3(const FastPlan &P, int ng, int na, int mode, bool prefetch, int n_wg, size_t lds,
+                                hipStream_t st) {
+    return fast_launch_nf<3>(P, ng, na, mode, prefetch, n_wg, lds, st);
+}
+
+}  // namespace sybl

@@ -270,8 +270,8 @@ int query_finalize(Query *q, Result **out) {
                 x.sum_out = (uint64_t)F[(int64_t)(A.f_out + 1) * ncell + cell];
                 for (int k = 0; k < 4; k++) x.sq[k] = (uint64_t)F[(int64_t)(A.f_out + 2 + k) * ncell + cell];
             }
-            x.vmax = hm[(size_t)((int64_t)A.m_max * ncell + cell)];
-            x.nmin = hm[(size_t)((int64_t)A.m_nmin * ncell + cell)];
+            if (A.m_max >= 0) x.vmax = hm[(size_t)((int64_t)A.m_max * ncell + cell)];
+            if (A.m_nmin >= 0) x.nmin = hm[(size_t)((int64_t)A.m_nmin * ncell + cell)];
             if (A.hist_full) {
                 const int64_t *hv = H + cell * P.hist_stride + P.hist_agg_off[a];
                 x.values.assign(hv, hv + A.n_values);

@@ -1,0 +1,266 @@
+// scan_fast.h -- role-specialised scan kernels (the hot path of the hot path).
+//
+// k_scan (kernels.hip) interprets a per-slot flag word at run time; that generality costs
+// ~260 VALU + ~240 SALU instructions per row and hundreds of scalar reloads of the plan.
+// The common query shape -- NF int-range filter columns, NG int group columns, NA int
+// aggregation columns, every column a fully populated int64 column whose bounds rule out
+// rejects and outliers -- is compiled here as k_scan_fast<NF,NG,NA,MODE>: slot roles are
+// template parameters, the plan is a small by-value kernel argument that stays in SGPRs,
+// and the row body is ~50 VALU instructions.  Same reference semantics
+// (aggregate.go:96-263, hist_basic.go:101-151), same cell-table layout, so k_fold, the
+// all-reduce and finalize are shared with the generic kernel.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "plan.h"
+
+namespace sybl {
+
+constexpr int kFastMaxF = 4, kFastMaxG = 2, kFastMaxA = 2;
+
+enum FastMode : int {
+    kFastAvg = 0,      // op avg:  Count, sum(v)                        (extrema provably == initial values)
+    kFastAvgMax = 1,   // op avg:  Count, sum(v), max(v)                (values >= 0 with a positive maximum)
+    kFastMoments = 2,  // op hist, moments: Count, sum(v), sum(b), sum(b^2)
+    kFastHist = 3,     // op hist, full:    Count, sum(v) in LDS + bucket arrays in HBM
+    kFastModes = 4,
+};
+
+struct FastPlan {
+    const int64_t *fcol[kFastMaxF];
+    const int64_t *gcol[kFastMaxG];
+    const int64_t *acol[kFastMaxA];
+    int64_t lo[kFastMaxF], hi[kFastMaxF];  // inclusive
+    int64_t gmin[kFastMaxG];
+    uint32_t gcard[kFastMaxG];
+    int32_t gstride[kFastMaxG];
+    int64_t hmin[kFastMaxA];
+    double inv_bucket[kFastMaxA];
+    uint32_t bucket_size[kFastMaxA];
+    int32_t n_values[kFastMaxA];
+    int32_t f_sum[kFastMaxA], f_sb[kFastMaxA], f_sb2[kFastMaxA], m_max[kFastMaxA];
+    int64_t hist_agg_off[kFastMaxA];
+    int64_t hist_off, hist_stride;
+    int32_t n_cells, n_sum_fields, n_max_fields, rep_shift;
+    int64_t *sum_out, *max_out, *ws_sum, *ws_max;
+    const Segment *segs;
+    const int32_t *wg_seg_begin;
+};
+
+hipError_t launch_scan_fast(const FastPlan &P, int nf, int ng, int na, int mode, bool prefetch, int n_wg,
+                            size_t lds_bytes, hipStream_t st);
+
+#ifdef __HIPCC__
+
+typedef long long fll2 __attribute__((ext_vector_type(2)));
+
+template <int N>
+struct FastTile {
+    fll2 v[N > 0 ? N : 1];
+};
+
+template <int NF, int NG, int NA>
+__device__ __forceinline__ void fast_load(const FastPlan &P, int64_t row, FastTile<NF> &f, FastTile<NG> &g,
+                                          FastTile<NA> &a) {
+#pragma unroll
+    for (int c = 0; c < NF; c++) f.v[c] = __builtin_nontemporal_load((const fll2 *)(P.fcol[c] + row));
+#pragma unroll
+    for (int c = 0; c < NG; c++) g.v[c] = __builtin_nontemporal_load((const fll2 *)(P.gcol[c] + row));
+#pragma unroll
+    for (int c = 0; c < NA; c++) a.v[c] = __builtin_nontemporal_load((const fll2 *)(P.acol[c] + row));
+}
+
+__device__ __forceinline__ void lds_add64(int64_t *lds, uint32_t idx, int64_t v) {
+    __hip_atomic_fetch_add(lds + idx, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+template <int NF, int NG, int NA, int MODE>
+__device__ __forceinline__ void fast_row(const FastPlan &P, const FastTile<NF> &f, const FastTile<NG> &g,
+                                         const FastTile<NA> &a, const int r, int64_t *lds, const uint32_t rep,
+                                         const uint32_t max_base, uint32_t &matched, uint32_t &overflow) {
+    bool pass = true;
+#pragma unroll
+    for (int c = 0; c < NF; c++) {
+        const int64_t x = r == 0 ? f.v[c].x : f.v[c].y;
+        pass = pass && x >= P.lo[c] && x <= P.hi[c];  // filter.go:171-195, folded to a range
+    }
+    if (!pass) return;
+    matched += 1;  // aggregate.go:117
+    uint32_t cell = 0;
+    bool inb = true;
+#pragma unroll
+    for (int c = 0; c < NG; c++) {
+        const int64_t x = r == 0 ? g.v[c].x : g.v[c].y;
+        const uint64_t d = (uint64_t)x - (uint64_t)P.gmin[c];
+        inb = inb && d < (uint64_t)P.gcard[c];
+        cell += (uint32_t)d * (uint32_t)P.gstride[c];  // aggregate.go:125-143 as a direct-mapped index
+    }
+    if (!inb) {
+        overflow += 1;
+        return;
+    }
+    const uint32_t rs = (uint32_t)P.rep_shift;
+    const uint32_t ncell = (uint32_t)P.n_cells;
+    const uint32_t cidx = (cell << rs) + rep;
+    lds_add64(lds, cidx, 1);  // Result.Count (aggregate.go:203); Samples == Count without a weight column
+#pragma unroll
+    for (int c = 0; c < NA; c++) {
+        const int64_t x = r == 0 ? a.v[c].x : a.v[c].y;
+        lds_add64(lds, (((uint32_t)P.f_sum[c] * ncell) << rs) + cidx, x);
+        if (MODE == kFastAvgMax) {
+            int64_t *m = lds + max_base + (((uint32_t)P.m_max[c] * ncell) << rs) + cidx;
+            if (x > *m) __hip_atomic_fetch_max(m, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        if (MODE == kFastMoments || MODE == kFastHist) {
+            // bucket_value := (value - h.Min) / BucketSize, hist_basic.go:130.  The planner only
+            // selects this kernel when 0 <= value - h.Min < 2^32 and no value can reach
+            // len(Values), so one f64 multiply + a correction step is exact.
+            const uint32_t n = (uint32_t)((uint64_t)x - (uint64_t)P.hmin[c]);
+            uint32_t b = (uint32_t)((double)n * P.inv_bucket[c]);
+            const int32_t rem = (int32_t)(n - b * P.bucket_size[c]);
+            if (rem < 0) {
+                b -= 1;
+            } else if ((uint32_t)rem >= P.bucket_size[c]) {
+                b += 1;
+            }
+            if (MODE == kFastMoments) {
+                lds_add64(lds, (((uint32_t)P.f_sb[c] * ncell) << rs) + cidx, (int64_t)b);
+                lds_add64(lds, (((uint32_t)P.f_sb2[c] * ncell) << rs) + cidx, (int64_t)((uint64_t)b * (uint64_t)b));
+            } else {
+                __hip_atomic_fetch_add(P.sum_out + P.hist_off + (int64_t)cell * P.hist_stride + P.hist_agg_off[c] + b,
+                                       (int64_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+}
+
+template <int NF, int NG, int NA, int MODE, bool PREFETCH>
+__global__ __launch_bounds__(kWgThreads, PREFETCH ? 4 : 8) void k_scan_fast(const FastPlan P) {
+    extern __shared__ int64_t lds[];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t R = 1u << P.rep_shift;
+    const uint32_t words_sum = (uint32_t)P.n_sum_fields * (uint32_t)P.n_cells;
+    const uint32_t words_max = (uint32_t)P.n_max_fields * (uint32_t)P.n_cells;
+    const uint32_t max_base = words_sum << P.rep_shift;
+    for (uint32_t i = tid; i < words_sum * R; i += kWgThreads) lds[i] = 0;
+    for (uint32_t i = tid; i < words_max * R; i += kWgThreads) lds[max_base + i] = INT64_MIN;
+    const uint32_t rep = tid & (R - 1);
+    __syncthreads();
+
+    uint32_t matched = 0, overflow = 0;
+    const int s0 = P.wg_seg_begin[blockIdx.x], s1 = P.wg_seg_begin[blockIdx.x + 1];
+    for (int si = s0; si < s1; si++) {
+        const Segment seg = P.segs[si];
+        const int64_t end = seg.start + seg.n;
+        int64_t row = seg.start + (int64_t)tid * kRowsPerThread;
+        FastTile<NF> f0, f1;
+        FastTile<NG> g0, g1;
+        FastTile<NA> a0, a1;
+        if (PREFETCH) {
+            if (row < end) fast_load<NF, NG, NA>(P, row, f0, g0, a0);
+            for (; row < end; row += kTileRows) {
+                const int64_t nrow = row + kTileRows;
+                if (nrow < end) fast_load<NF, NG, NA>(P, nrow, f1, g1, a1);
+                fast_row<NF, NG, NA, MODE>(P, f0, g0, a0, 0, lds, rep, max_base, matched, overflow);
+                if (row + 1 < end) fast_row<NF, NG, NA, MODE>(P, f0, g0, a0, 1, lds, rep, max_base, matched, overflow);
+                f0 = f1;
+                g0 = g1;
+                a0 = a1;
+            }
+        } else {
+            for (; row < end; row += kTileRows) {
+                fast_load<NF, NG, NA>(P, row, f0, g0, a0);
+                fast_row<NF, NG, NA, MODE>(P, f0, g0, a0, 0, lds, rep, max_base, matched, overflow);
+                if (row + 1 < end) fast_row<NF, NG, NA, MODE>(P, f0, g0, a0, 1, lds, rep, max_base, matched, overflow);
+            }
+        }
+    }
+
+    // matched rows: one add per wave (64-wide butterfly)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        matched += __shfl_xor(matched, o, 64);
+        overflow += __shfl_xor(overflow, o, 64);
+    }
+    if ((tid & 63) == 0) {
+        if (matched) __hip_atomic_fetch_add(P.sum_out + kHdrMatched, (int64_t)matched, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (overflow) __hip_atomic_fetch_add(P.sum_out + kHdrOverflow, (int64_t)overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+
+    // fold the lane replicas and publish this workgroup's table (plain stores)
+    __syncthreads();
+    int64_t *ws = P.ws_sum + (int64_t)blockIdx.x * words_sum;
+    for (uint32_t i = tid; i < words_sum; i += kWgThreads) {
+        int64_t acc = 0;
+        for (uint32_t k = 0; k < R; k++) acc += lds[(i << P.rep_shift) + k];
+        ws[i] = acc;
+    }
+    int64_t *wm = P.ws_max + (int64_t)blockIdx.x * words_max;
+    for (uint32_t i = tid; i < words_max; i += kWgThreads) {
+        int64_t acc = INT64_MIN;
+        for (uint32_t k = 0; k < R; k++) {
+            const int64_t b = lds[max_base + (i << P.rep_shift) + k];
+            acc = b > acc ? b : acc;
+        }
+        wm[i] = acc;
+    }
+}
+
+// One translation unit per NF keeps the build parallel (Makefile: kernels_fast_<NF>.o).
+template <int NF, int NG, int NA, int MODE>
+static hipError_t fast_launch_one(const FastPlan &P, bool prefetch, int n_wg, size_t lds_bytes, hipStream_t st) {
+    hipError_t e;
+    if (prefetch) {
+        auto k = k_scan_fast<NF, NG, NA, MODE, true>;
+        e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k, dim3(n_wg), dim3(kWgThreads), lds_bytes, st, P);
+    } else {
+        auto k = k_scan_fast<NF, NG, NA, MODE, false>;
+        e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k, dim3(n_wg), dim3(kWgThreads), lds_bytes, st, P);
+    }
+    return hipGetLastError();
+}
+
+template <int NF, int NG, int NA>
+static hipError_t fast_launch_mode(const FastPlan &P, int mode, bool prefetch, int n_wg, size_t lds, hipStream_t st) {
+    if (NA == 0) return fast_launch_one<NF, NG, 0, kFastAvg>(P, prefetch, n_wg, lds, st);
+    switch (mode) {
+    case kFastAvg: return fast_launch_one<NF, NG, NA, kFastAvg>(P, prefetch, n_wg, lds, st);
+    case kFastAvgMax: return fast_launch_one<NF, NG, NA, kFastAvgMax>(P, prefetch, n_wg, lds, st);
+    case kFastMoments: return fast_launch_one<NF, NG, NA, kFastMoments>(P, prefetch, n_wg, lds, st);
+    case kFastHist: return fast_launch_one<NF, NG, NA, kFastHist>(P, prefetch, n_wg, lds, st);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+template <int NF>
+static hipError_t fast_launch_nf(const FastPlan &P, int ng, int na, int mode, bool prefetch, int n_wg, size_t lds,
+                                 hipStream_t st) {
+    switch (ng * 3 + na) {
+    case 0: return fast_launch_mode<NF, 0, 0>(P, mode, prefetch, n_wg, lds, st);
+    case 1: return fast_launch_mode<NF, 0, 1>(P, mode, prefetch, n_wg, lds, st);
+    case 2: return fast_launch_mode<NF, 0, 2>(P, mode, prefetch, n_wg, lds, st);
+    case 3: return fast_launch_mode<NF, 1, 0>(P, mode, prefetch, n_wg, lds, st);
+    case 4: return fast_launch_mode<NF, 1, 1>(P, mode, prefetch, n_wg, lds, st);
+    case 5: return fast_launch_mode<NF, 1, 2>(P, mode, prefetch, n_wg, lds, st);
+    case 6: return fast_launch_mode<NF, 2, 0>(P, mode, prefetch, n_wg, lds, st);
+    case 7: return fast_launch_mode<NF, 2, 1>(P, mode, prefetch, n_wg, lds, st);
+    case 8: return fast_launch_mode<NF, 2, 2>(P, mode, prefetch, n_wg, lds, st);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+#endif  // __HIPCC__
+
+// per-NF entry points (kernels_fast_<NF>.hip)
+hipError_t launch_scan_fast_nf0(const FastPlan &P, int ng, int na, int mode, bool prefetch, int n_wg, size_t lds, hipStream_t st);
+hipError_t launch_scan_fast_nf1(const FastPlan &P, int ng, int na, int mode, bool prefetch, int n_wg, size_t lds, hipStream_t st);
+hipError_t launch_scan_fast_nf2(const FastPlan &P, int ng, int na, int mode, bool prefetch, int n_wg, size_t lds, hipStream_t st);
+hipError_t launch_scan_fast_nf3(const FastPlan &P, int ng, int na, int mode, bool prefetch, int n_wg, size_t lds, hipStream_t st);
+hipError_t launch_scan_fast_nf4(const FastPlan &P, int ng, int na, int mode, bool prefetch, int n_wg, size_t lds, hipStream_t st);
+
+}  // namespace sybl
