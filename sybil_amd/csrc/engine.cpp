@@ -205,6 +205,8 @@ static void free_query(Query *q) {
     }
     if (q->d_ws_sum) hipFree(q->d_ws_sum);
     if (q->d_ws_max) hipFree(q->d_ws_max);
+    if (q->h_sum) hipHostFree(q->h_sum);
+    if (q->h_max) hipHostFree(q->h_max);
     for (auto &e : q->ev)
         if (e) hipEventDestroy(e);
     delete q;
@@ -770,6 +772,8 @@ static int ensure_partials(Query *q) {
     if (q->d_sum && q->d_max) return SYBL_OK;
     SYBL_HIP(hipMalloc((void **)&q->d_sum, (size_t)q->n_sum_words * 8));
     SYBL_HIP(hipMalloc((void **)&q->d_max, (size_t)q->n_max_words * 8));
+    SYBL_HIP(hipMemset(q->d_sum, 0, (size_t)q->n_sum_words * 8));
+    SYBL_HIP(hipMemset(q->d_max, 0, (size_t)q->n_max_words * 8));
     q->own_partials = true;
     q->plan_dirty = true;
     return SYBL_OK;
@@ -787,11 +791,20 @@ static int scan(Query *q) {
         SYBL_HIP(hipMemcpy(q->d_plan, &P, sizeof(ScanPlan), hipMemcpyHostToDevice));
         q->plan_dirty = false;
     }
-    SYBL_HIP(hipMemsetAsync(q->d_sum, 0, (size_t)q->n_sum_words * 8, st));
-    hipError_t e = launch_fill64(q->d_max, q->n_max_words, INT64_MIN, st);
-    if (e != hipSuccess) return hip_fail(e, "k_fill64");
+    const bool ran = !q->never_matches && !q->segs.empty();
+    hipError_t e = hipSuccess;
+    if (q->use_lds && ran) {
+        // the fold overwrites every cell field; only the header and the bucket arrays accumulate
+        SYBL_HIP(hipMemsetAsync(q->d_sum, 0, (size_t)kHeaderWords * 8, st));
+        if (P.hist_stride > 0)
+            SYBL_HIP(hipMemsetAsync(q->d_sum + P.hist_off, 0, (size_t)(P.n_cells * P.hist_stride) * 8, st));
+    } else {
+        SYBL_HIP(hipMemsetAsync(q->d_sum, 0, (size_t)q->n_sum_words * 8, st));
+        e = launch_fill64(q->d_max, q->n_max_words, INT64_MIN, st);
+        if (e != hipSuccess) return hip_fail(e, "k_fill64");
+    }
     SYBL_HIP(hipEventRecord(q->ev[0], st));
-    if (!q->never_matches && !q->segs.empty()) {
+    if (ran) {
         if (q->fast) {
             q->fplan.sum_out = q->d_sum;
             q->fplan.max_out = q->d_max;
@@ -804,12 +817,10 @@ static int scan(Query *q) {
         }
     }
     SYBL_HIP(hipEventRecord(q->ev[1], st));
-    if (q->use_lds && !q->never_matches && !q->segs.empty()) {
+    if (q->use_lds && ran) {
         int64_t wsum = (int64_t)P.n_sum_fields * P.n_cells, wmax = (int64_t)P.n_max_fields * P.n_cells;
-        e = launch_fold(q->d_ws_sum, q->d_sum + kHeaderWords, wsum, q->n_wg, false, st);
-        if (e != hipSuccess) return hip_fail(e, "k_fold(sum)");
-        e = launch_fold(q->d_ws_max, q->d_max, wmax, q->n_wg, true, st);
-        if (e != hipSuccess) return hip_fail(e, "k_fold(max)");
+        e = launch_fold(q->d_ws_sum, q->d_sum + kHeaderWords, wsum, q->d_ws_max, q->d_max, wmax, q->n_wg, st);
+        if (e != hipSuccess) return hip_fail(e, "k_fold");
     }
     SYBL_HIP(hipEventRecord(q->ev[2], st));
     q->scanned = true;

@@ -26,7 +26,8 @@ int hip_fail(hipError_t e, const char *what);
 
 // kernels.hip
 hipError_t launch_scan(const ScanPlan *d_plan, int n_slots, int n_wg, bool use_lds, size_t lds_bytes, hipStream_t st);
-hipError_t launch_fold(const int64_t *ws, int64_t *out, int64_t words, int n_wg, bool is_max, hipStream_t st);
+hipError_t launch_fold(const int64_t *ws_sum, int64_t *out_sum, int64_t words_sum, const int64_t *ws_max, int64_t *out_max,
+                       int64_t words_max, int n_wg, hipStream_t st);
 hipError_t launch_fill64(int64_t *p, int64_t n, int64_t v, hipStream_t st);
 hipError_t launch_synth(int64_t *out, int64_t n, int64_t row0, int64_t total_rows, int kind, int64_t a, int64_t b,
                         uint64_t col_seed, hipStream_t st);
@@ -139,6 +140,7 @@ struct Query {
     int64_t *d_sum = nullptr, *d_max = nullptr;
     bool own_partials = false;
     int64_t *d_ws_sum = nullptr, *d_ws_max = nullptr;
+    int64_t *h_sum = nullptr, *h_max = nullptr;  // pinned staging for finalize
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     bool scanned = false;
     sybl_run_stats stats{};

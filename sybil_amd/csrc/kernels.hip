@@ -323,17 +323,37 @@ __global__ __launch_bounds__(kWgThreads) void k_scan(CPlan *Pp) {
     }
 }
 
-// out[i] = reduce over workgroups of ws[w][i]   (SUM or MAX)
-__global__ __launch_bounds__(256) void k_fold(const int64_t *__restrict__ ws, int64_t *__restrict__ out, int64_t words,
-                                              int n_wg, int is_max) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= words) return;
+// out[i] = reduce over workgroups of ws[w][i]: SUM for the first nb_sum blocks, MAX for the rest.
+// A block owns 64 consecutive words; its 16 waves stride over the workgroup tables (coalesced
+// 512-byte reads, 16 independent loads per lane) and meet in LDS.
+__global__ __launch_bounds__(1024) void k_fold(const int64_t *__restrict__ ws_sum, int64_t *__restrict__ out_sum,
+                                               int64_t words_sum, const int64_t *__restrict__ ws_max,
+                                               int64_t *__restrict__ out_max, int64_t words_max, int n_wg, int nb_sum) {
+    __shared__ int64_t part[16][64];
+    const bool is_max = (int)blockIdx.x >= nb_sum;
+    const int64_t *ws = is_max ? ws_max : ws_sum;
+    int64_t *out = is_max ? out_max : out_sum;
+    const int64_t words = is_max ? words_max : words_sum;
+    const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
+    const int64_t i = (int64_t)(is_max ? blockIdx.x - nb_sum : blockIdx.x) * 64 + lane;
     int64_t a = is_max ? INT64_MIN : 0;
-    for (int w = 0; w < n_wg; w++) {
-        int64_t b = ws[(int64_t)w * words + i];
-        a = is_max ? (b > a ? b : a) : a + b;
+    if (i < words) {
+#pragma unroll 4
+        for (int w = sub; w < n_wg; w += 16) {
+            const int64_t b = ws[(int64_t)w * words + i];
+            a = is_max ? (b > a ? b : a) : a + b;
+        }
     }
-    out[i] = a;
+    part[sub][lane] = a;
+    __syncthreads();
+    if (sub == 0 && i < words) {
+#pragma unroll
+        for (int s = 1; s < 16; s++) {
+            const int64_t b = part[s][lane];
+            a = is_max ? (b > a ? b : a) : a + b;
+        }
+        out[i] = a;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_fill64(int64_t *p, int64_t n, int64_t v) {
@@ -445,9 +465,12 @@ hipError_t launch_scan(const ScanPlan *d_plan, int n_slots, int n_wg, bool use_l
     }
 }
 
-hipError_t launch_fold(const int64_t *ws, int64_t *out, int64_t words, int n_wg, bool is_max, hipStream_t st) {
-    if (words <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_fold, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, ws, out, words, n_wg, is_max ? 1 : 0);
+hipError_t launch_fold(const int64_t *ws_sum, int64_t *out_sum, int64_t words_sum, const int64_t *ws_max, int64_t *out_max,
+                       int64_t words_max, int n_wg, hipStream_t st) {
+    const int nb_sum = (int)((words_sum + 63) / 64), nb_max = (int)((words_max + 63) / 64);
+    if (nb_sum + nb_max <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_fold, dim3((unsigned)(nb_sum + nb_max)), dim3(1024), 0, st, ws_sum, out_sum, words_sum, ws_max, out_max,
+                       words_max, n_wg, nb_sum);
     return hipGetLastError();
 }
 

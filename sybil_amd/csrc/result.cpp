@@ -29,80 +29,70 @@ struct AggAcc {
     uint64_t sum_out = 0;
     uint64_t sq[4] = {0, 0, 0, 0};
     int64_t vmax = INT64_MIN, nmin = INT64_MIN;
-    std::vector<int64_t> values;
+    const int64_t *values = nullptr;  // bucket counts (full-hist mode), n_values long
 };
 
 struct CellAcc {
     int64_t count = 0, samples = 0;
-    std::vector<AggAcc> aggs;
+    bool has_aggs = false;
+    AggAcc aggs[kMaxAggs];
 };
 
 struct RowStore {
-    std::vector<uint8_t> key;
+    uint8_t key[SYBL_MAX_GROUPS * SYBL_GROUP_BY_WIDTH];
     std::string gbk;
     int64_t time_bucket = 0, count = 0, samples = 0;
-    std::vector<sybl_agg_out> aggs;
-    std::vector<std::vector<int64_t>> values, pcts;
+    int64_t agg_off = 0;  // this row's n_aggs entries in Result::agg_pool / val_pool / pctoff_pool
 };
 
 struct Result {
     std::vector<RowStore> rows[3];
     std::vector<sybl_group_row> view[3];
     int64_t matched = 0;
+    std::vector<int64_t> hist_copy;               // bucket arrays the rows point into
+    std::vector<std::vector<int64_t>> total_vals; // Cumulative bucket arrays
+    std::vector<int64_t> pct_pool;                // 100 entries per (row, agg) with percentiles
+    std::vector<sybl_agg_out> agg_pool;           // n_aggs entries per row, all row kinds
+    std::vector<const int64_t *> val_pool;
+    std::vector<int64_t> pctoff_pool;             // offset into pct_pool, -1 = none
     // for rendering
     int op = 0;
     bool weighted = false, time_mode = false, want_percentiles = false;
     int limit = 0;
+    int n_aggs = 0;
+    std::vector<int64_t> n_values;
     std::string order_by;
     std::vector<std::string> group_names, agg_names;
     std::string rendered[2];
 };
 
-static void acc_add(AggAcc &d, const AggAcc &s) {
-    d.cnt += s.cnt;
-    d.smp += s.smp;
-    d.sum += s.sum;
-    d.sb += s.sb;
-    d.sb2 += s.sb2;
-    d.n_out += s.n_out;
-    d.sum_out += s.sum_out;
-    for (int k = 0; k < 4; k++) d.sq[k] += s.sq[k];
-    d.vmax = std::max(d.vmax, s.vmax);
-    d.nmin = std::max(d.nmin, s.nmin);
-    if (!s.values.empty()) {
-        if (d.values.empty()) d.values.assign(s.values.size(), 0);
-        for (size_t k = 0; k < s.values.size(); k++) d.values[k] += s.values[k];
-    }
-}
-
 // GetPercentiles, hist_basic.go:153-183 (same loop as the reference, including the
 // percentiles[p] = k overwrite that later iterations repair)
-static void percentiles_from_values(const std::vector<int64_t> &values, int64_t bucket_size, int64_t hmin,
-                                    int64_t count, std::vector<int64_t> &out) {
-    out.clear();
-    if (count == 0) return;
+static void percentiles_from_values(const int64_t *values, int64_t n_values, int64_t bucket_size, int64_t hmin,
+                                    int64_t count, int64_t *out100) {
     int64_t pct[101];
     memset(pct, 0, sizeof(pct));
     pct[0] = hmin;
     int64_t c = 0, prev_p = 0;
-    for (size_t k = 0; k < values.size(); k++) {
+    for (int64_t k = 0; k < n_values; k++) {
         c += values[k];
         int64_t p = (100 * c) / count;
         p = std::min<int64_t>(std::max<int64_t>(p, 0), 100);
-        for (int64_t ip = prev_p; ip <= p; ip++) pct[ip] = (int64_t)k * bucket_size + hmin;
-        pct[p] = (int64_t)k;
+        for (int64_t ip = prev_p; ip <= p; ip++) pct[ip] = k * bucket_size + hmin;
+        pct[p] = k;
         prev_p = p;
     }
-    out.assign(pct, pct + 100);
+    memcpy(out100, pct, 100 * sizeof(int64_t));
 }
 
-static void agg_finish(const Query *q, const AggInfo &ai, const AggAcc &a, int64_t row_count, sybl_agg_out &o,
-                       std::vector<int64_t> &values, std::vector<int64_t> &pcts) {
+static void agg_finish(const Query *q, Result *R, const AggInfo &ai, const AggAcc &a, int64_t row_count, sybl_agg_out &o,
+                       const int64_t *&values_out, int64_t &pct_off) {
     memset(&o, 0, sizeof(o));
+    values_out = nullptr;
+    pct_off = -1;
     const AggDesc &A = ai.d;
     int64_t cnt = a.tracked_cnt ? a.cnt : row_count;
     bool present = q->weighted ? a.smp > 0 : cnt > 0;
-    if (!a.tracked_cnt && row_count > 0) present = true;
     if (!present) return;
     o.present = 1;
     o.count = cnt;
@@ -112,8 +102,8 @@ static void agg_finish(const Query *q, const AggInfo &ai, const AggAcc &a, int64
     o.avg = (double)avg_l;
     int64_t tmax = a.vmax, tmin = a.nmin == INT64_MIN ? INT64_MAX : -a.nmin;
     if (q->op == SYBL_AGG_HIST) {
-        o.min = std::min(A.info_min, tmin);                            // SetupBuckets: h.Min = Info.Min
-        o.max = std::max(ai.info_max, tmax);                           //               h.Max = Info.Max
+        o.min = std::min(A.info_min, tmin);   // SetupBuckets: h.Min = Info.Min
+        o.max = std::max(ai.info_max, tmax);  //               h.Max = Info.Max
         o.bucket_size = A.bucket_size;
         o.num_buckets = ai.num_buckets;
         o.n_values = A.n_values;
@@ -132,16 +122,19 @@ static void agg_finish(const Query *q, const AggInfo &ai, const AggAcc &a, int64
         long double A1 = (long double)o.avg;
         out_term = (sq - 2.0L * A1 * (long double)(int64_t)a.sum_out + (long double)a.n_out * A1 * A1) / (long double)cnt;
     }
-    if (q->want_percentiles) {
-        values = a.values;
-        if (values.empty()) values.assign((size_t)A.n_values, 0);
-        percentiles_from_values(values, A.bucket_size, A.hmin, cnt, pcts);
+    if (q->want_percentiles && a.values) {
+        values_out = a.values;
+        if (cnt != 0) {
+            pct_off = (int64_t)R->pct_pool.size();
+            R->pct_pool.resize(R->pct_pool.size() + 100);
+            percentiles_from_values(a.values, A.n_values, A.bucket_size, A.hmin, cnt, R->pct_pool.data() + pct_off);
+        }
         // GetStdDev, hist_basic.go:192-219, with Avg = sum/count
         double sum_variance = 0;
-        for (size_t b = 0; b < values.size(); b++) {
-            int64_t val = (int64_t)b * A.bucket_size + A.hmin;
+        for (int64_t b = 0; b < A.n_values; b++) {
+            int64_t val = b * A.bucket_size + A.hmin;
             double delta = (double)val - o.avg;
-            double ratio = (double)values[b] / (double)cnt;
+            double ratio = (double)a.values[b] / (double)cnt;
             sum_variance += (delta * delta) * ratio;
         }
         o.stddev = sqrt(sum_variance + (double)out_term);
@@ -156,12 +149,13 @@ static void agg_finish(const Query *q, const AggInfo &ai, const AggAcc &a, int64
     }
 }
 
-static void build_key(const Query *q, int64_t gcell, std::vector<uint8_t> &key, std::string &gbk) {
+static void build_key(const Query *q, int64_t gcell, uint8_t *key, std::string &gbk) {
     size_t ng = q->groups.size();
-    key.assign(ng * 8, 0);
+    memset(key, 0, SYBL_MAX_GROUPS * SYBL_GROUP_BY_WIDTH);
     gbk.clear();
     if (ng == 0) gbk = "total";  // translate_group_by, aggregate.go:294-296
     int64_t rem = gcell, stride = q->group_cells;
+    char num[24];
     for (size_t g = 0; g < ng; g++) {
         const GroupInfo &gi = q->groups[g];
         stride /= gi.gcard;
@@ -173,12 +167,21 @@ static void build_key(const Query *q, int64_t gcell, std::vector<uint8_t> &key, 
             v = UINT64_MAX;  // MISSING_VALUE, aggregate.go:31
         } else {
             v = (uint64_t)(gi.gmin + digit);
-            const Column *c = q->t->cols[(size_t)gi.col].get();
             if (gi.type == SYBL_STR_VAL) {
+                const Column *c = q->t->cols[(size_t)gi.col].get();
                 size_t id = (size_t)(gi.gmin + digit);
                 if (id < c->dict.size()) gbk += c->dict[id];
             } else {
-                gbk += std::to_string((long long)(gi.gmin + digit));
+                // strconv.FormatInt(v, 10)
+                int64_t sv = gi.gmin + digit;
+                uint64_t uv = sv < 0 ? (uint64_t)0 - (uint64_t)sv : (uint64_t)sv;
+                int pos = (int)sizeof(num);
+                do {
+                    num[--pos] = (char)('0' + uv % 10);
+                    uv /= 10;
+                } while (uv);
+                if (sv < 0) num[--pos] = '-';
+                gbk.append(num + pos, sizeof(num) - (size_t)pos);
             }
         }
         for (int b = 0; b < 8; b++) key[g * 8 + b] = (uint8_t)(v >> (8 * b));
@@ -186,38 +189,42 @@ static void build_key(const Query *q, int64_t gcell, std::vector<uint8_t> &key, 
     }
 }
 
-static void finish_row(const Query *q, const CellAcc &acc, RowStore &row) {
+static void finish_row(const Query *q, Result *R, const CellAcc &acc, RowStore &row) {
     row.count = acc.count;
     row.samples = acc.samples;
     size_t na = q->aggs.size();
-    row.aggs.resize(na);
-    row.values.resize(na);
-    row.pcts.resize(na);
+    row.agg_off = (int64_t)R->agg_pool.size();
+    R->agg_pool.resize(R->agg_pool.size() + na);
+    R->val_pool.resize(R->val_pool.size() + na);
+    R->pctoff_pool.resize(R->pctoff_pool.size() + na);
     for (size_t a = 0; a < na; a++) {
-        if (acc.aggs.empty()) {
-            memset(&row.aggs[a], 0, sizeof(sybl_agg_out));
+        size_t k = (size_t)row.agg_off + a;
+        if (!acc.has_aggs) {
+            memset(&R->agg_pool[k], 0, sizeof(sybl_agg_out));
+            R->val_pool[k] = nullptr;
+            R->pctoff_pool[k] = -1;
             continue;
         }
-        agg_finish(q, q->aggs[a], acc.aggs[a], acc.count, row.aggs[a], row.values[a], row.pcts[a]);
+        agg_finish(q, R, q->aggs[a], acc.aggs[a], acc.count, R->agg_pool[k], R->val_pool[k], R->pctoff_pool[k]);
     }
 }
 
 static void make_views(Result *R) {
+    for (size_t k = 0; k < R->agg_pool.size(); k++) {
+        R->agg_pool[k].values = R->val_pool[k];
+        R->agg_pool[k].percentiles = R->pctoff_pool[k] >= 0 ? R->pct_pool.data() + R->pctoff_pool[k] : nullptr;
+    }
     for (int w = 0; w < 3; w++) {
         R->view[w].resize(R->rows[w].size());
         for (size_t i = 0; i < R->rows[w].size(); i++) {
             RowStore &r = R->rows[w][i];
-            for (size_t a = 0; a < r.aggs.size(); a++) {
-                r.aggs[a].values = r.values[a].empty() ? nullptr : r.values[a].data();
-                r.aggs[a].percentiles = r.pcts[a].empty() ? nullptr : r.pcts[a].data();
-            }
             sybl_group_row &v = R->view[w][i];
-            v.binary_key = r.key.data();
+            v.binary_key = r.key;
             v.group_by_key = r.gbk.c_str();
             v.time_bucket = r.time_bucket;
             v.count = r.count;
             v.samples = r.samples;
-            v.aggs = r.aggs.data();
+            v.aggs = R->agg_pool.data() + r.agg_off;
         }
     }
 }
@@ -225,10 +232,15 @@ static void make_views(Result *R) {
 int query_finalize(Query *q, Result **out) {
     hipStream_t st = q->ctx->stream;
     const ScanPlan &P = q->plan;
-    std::vector<int64_t> hs((size_t)q->n_sum_words), hm((size_t)q->n_max_words);
-    SYBL_HIP(hipMemcpyAsync(hs.data(), q->d_sum, hs.size() * 8, hipMemcpyDeviceToHost, st));
-    SYBL_HIP(hipMemcpyAsync(hm.data(), q->d_max, hm.size() * 8, hipMemcpyDeviceToHost, st));
+    // pinned staging buffers, allocated once per query
+    if (!q->h_sum) {
+        SYBL_HIP(hipHostMalloc((void **)&q->h_sum, (size_t)q->n_sum_words * 8, hipHostMallocDefault));
+        SYBL_HIP(hipHostMalloc((void **)&q->h_max, (size_t)q->n_max_words * 8, hipHostMallocDefault));
+    }
+    SYBL_HIP(hipMemcpyAsync(q->h_sum, q->d_sum, (size_t)q->n_sum_words * 8, hipMemcpyDeviceToHost, st));
+    if (P.n_max_fields > 0) SYBL_HIP(hipMemcpyAsync(q->h_max, q->d_max, (size_t)q->n_max_words * 8, hipMemcpyDeviceToHost, st));
     SYBL_HIP(hipStreamSynchronize(st));
+    const int64_t *hs = q->h_sum, *hm = q->h_max;
     if (hs[kHdrOverflow] != 0)
         return fail(SYBL_E_STATE,
                     "%lld rows fell outside the declared column bounds (sybl_table_set_bounds) -- results would be incomplete",
@@ -242,26 +254,37 @@ int query_finalize(Query *q, Result **out) {
     R->want_percentiles = q->want_percentiles;
     R->limit = q->limit;
     R->order_by = q->order_by;
+    R->n_aggs = (int)q->aggs.size();
     for (auto &g : q->groups) R->group_names.push_back(q->t->cols[(size_t)g.col]->name);
-    for (auto &a : q->aggs) R->agg_names.push_back(a.name);
+    for (auto &a : q->aggs) {
+        R->agg_names.push_back(a.name);
+        R->n_values.push_back(a.d.n_values);
+    }
 
     const int64_t ncell = P.n_cells, gcells = q->group_cells;
-    const int64_t *F = hs.data() + kHeaderWords;
-    const int64_t *H = hs.data() + P.hist_off;
-    size_t na = q->aggs.size();
+    const int64_t *F = hs + kHeaderWords;
+    const int64_t *H = nullptr;
+    if (P.hist_stride > 0) {
+        // the rows' bucket arrays outlive the next scan: keep a private copy
+        R->hist_copy.assign(hs + P.hist_off, hs + P.hist_off + ncell * P.hist_stride);
+        H = R->hist_copy.data();
+    }
+    const size_t na = q->aggs.size();
 
     auto load_cell = [&](int64_t cell, CellAcc &acc) -> bool {
         acc.count = F[cell];
         acc.samples = P.f_samples >= 0 ? F[(int64_t)P.f_samples * ncell + cell] : acc.count;
         bool exists = q->weighted ? acc.samples != 0 : acc.count != 0;
         if (!exists) return false;
-        acc.aggs.assign(na, AggAcc());
+        acc.has_aggs = true;
         for (size_t a = 0; a < na; a++) {
             const AggDesc &A = q->aggs[a].d;
             AggAcc &x = acc.aggs[a];
+            x = AggAcc();
             x.sum = (uint64_t)F[(int64_t)A.f_sum * ncell + cell];
-            x.tracked_cnt = A.f_cnt >= 0;
-            if (A.f_cnt >= 0) x.cnt = F[(int64_t)A.f_cnt * ncell + cell];
+            // when the count is not tracked per aggregation it equals the row count of the cell
+            x.tracked_cnt = true;
+            x.cnt = A.f_cnt >= 0 ? F[(int64_t)A.f_cnt * ncell + cell] : acc.count;
             if (A.f_smp >= 0) x.smp = F[(int64_t)A.f_smp * ncell + cell];
             if (A.f_sb >= 0) x.sb = F[(int64_t)A.f_sb * ncell + cell];
             if (A.f_sb2 >= 0) x.sb2 = F[(int64_t)A.f_sb2 * ncell + cell];
@@ -270,54 +293,74 @@ int query_finalize(Query *q, Result **out) {
                 x.sum_out = (uint64_t)F[(int64_t)(A.f_out + 1) * ncell + cell];
                 for (int k = 0; k < 4; k++) x.sq[k] = (uint64_t)F[(int64_t)(A.f_out + 2 + k) * ncell + cell];
             }
-            if (A.m_max >= 0) x.vmax = hm[(size_t)((int64_t)A.m_max * ncell + cell)];
-            if (A.m_nmin >= 0) x.nmin = hm[(size_t)((int64_t)A.m_nmin * ncell + cell)];
-            if (A.hist_full) {
-                const int64_t *hv = H + cell * P.hist_stride + P.hist_agg_off[a];
-                x.values.assign(hv, hv + A.n_values);
-            }
+            if (A.m_max >= 0) x.vmax = hm[(int64_t)A.m_max * ncell + cell];
+            if (A.m_nmin >= 0) x.nmin = hm[(int64_t)A.m_nmin * ncell + cell];
+            if (A.hist_full) x.values = H + cell * P.hist_stride + P.hist_agg_off[a];
         }
         return true;
     };
 
-    // When count is not tracked per aggregation it equals the row count of the cell; for
-    // merged accumulators (Cumulative) make that explicit before adding.
-    auto normalise = [&](CellAcc &acc) {
-        for (size_t a = 0; a < na; a++) {
-            AggAcc &x = acc.aggs[a];
-            if (!x.tracked_cnt) {
-                x.cnt = acc.count;
-                x.tracked_cnt = true;
-            }
-        }
-    };
-
     CellAcc total;
-    total.aggs.assign(q->time_mode ? 0 : na, AggAcc());
-    for (auto &x : total.aggs) x.tracked_cnt = true;
+    total.has_aggs = !q->time_mode;
+    R->total_vals.resize(na);
+    for (size_t a = 0; a < na; a++) {
+        total.aggs[a].tracked_cnt = true;
+        if (!q->time_mode && q->aggs[a].d.hist_full) {
+            R->total_vals[a].assign((size_t)q->aggs[a].d.n_values, 0);
+            total.aggs[a].values = R->total_vals[a].data();
+        }
+    }
     std::vector<int64_t> all_count, all_samples;
     if (q->time_mode) {
         all_count.assign((size_t)gcells, 0);
         all_samples.assign((size_t)gcells, 0);
     }
+    // count the live cells first so the row vectors are allocated once
+    {
+        size_t live = 0;
+        const int64_t *E = P.f_samples >= 0 ? F + (int64_t)P.f_samples * ncell : F;
+        for (int64_t cell = 0; cell < ncell; cell++) live += E[cell] != 0;
+        R->rows[q->time_mode ? 1 : 0].reserve(live);
+        if (q->want_percentiles) R->pct_pool.reserve((live + 1) * na * 100);
+        size_t nrows_all = live + 1 + (q->time_mode ? (size_t)gcells : 0);
+        R->agg_pool.reserve(nrows_all * na);
+        R->val_pool.reserve(nrows_all * na);
+        R->pctoff_pool.reserve(nrows_all * na);
+    }
 
+    CellAcc acc;
     for (int64_t cell = 0; cell < ncell; cell++) {
-        CellAcc acc;
         if (!load_cell(cell, acc)) continue;
-        normalise(acc);
         int64_t tbi = cell / gcells, gcell = cell - tbi * gcells;
-        RowStore row;
+        auto &dst = R->rows[q->time_mode ? 1 : 0];
+        dst.emplace_back();
+        RowStore &row = dst.back();
         build_key(q, gcell, row.key, row.gbk);
         if (q->time_mode) {
             row.time_bucket = (P.tb_min + tbi) * P.time_bucket;
             all_count[(size_t)gcell] += acc.count;
             all_samples[(size_t)gcell] += acc.samples;
-            finish_row(q, acc, row);
-            R->rows[1].push_back(std::move(row));
+            finish_row(q, R, acc, row);
         } else {
-            finish_row(q, acc, row);
-            R->rows[0].push_back(std::move(row));
-            for (size_t a = 0; a < na; a++) acc_add(total.aggs[a], acc.aggs[a]);
+            finish_row(q, R, acc, row);
+            for (size_t a = 0; a < na; a++) {
+                AggAcc &d = total.aggs[a];
+                const AggAcc &s = acc.aggs[a];
+                d.cnt += s.cnt;
+                d.smp += s.smp;
+                d.sum += s.sum;
+                d.sb += s.sb;
+                d.sb2 += s.sb2;
+                d.n_out += s.n_out;
+                d.sum_out += s.sum_out;
+                for (int k = 0; k < 4; k++) d.sq[k] += s.sq[k];
+                d.vmax = std::max(d.vmax, s.vmax);
+                d.nmin = std::max(d.nmin, s.nmin);
+                if (s.values) {
+                    int64_t *tv = R->total_vals[a].data();
+                    for (int64_t k = 0; k < q->aggs[a].d.n_values; k++) tv[k] += s.values[k];
+                }
+            }
         }
         total.count += acc.count;
         total.samples += acc.samples;
@@ -327,22 +370,23 @@ int query_finalize(Query *q, Result **out) {
         for (int64_t g = 0; g < gcells; g++) {
             bool exists = q->weighted ? all_samples[(size_t)g] != 0 : all_count[(size_t)g] != 0;
             if (!exists) continue;
-            RowStore row;
+            R->rows[0].emplace_back();
+            RowStore &row = R->rows[0].back();
             build_key(q, g, row.key, row.gbk);
-            CellAcc acc;
-            acc.count = all_count[(size_t)g];
-            acc.samples = all_samples[(size_t)g];
-            finish_row(q, acc, row);
-            R->rows[0].push_back(std::move(row));
+            CellAcc a2;
+            a2.count = all_count[(size_t)g];
+            a2.samples = all_samples[(size_t)g];
+            finish_row(q, R, a2, row);
         }
     }
     // Cumulative, aggregate.go:422-438
     {
-        RowStore row;
+        R->rows[2].emplace_back();
+        RowStore &row = R->rows[2].back();
+        memset(row.key, 0, sizeof(row.key));
         row.gbk = "TOTAL";
         for (size_t g = 1; g < q->groups.size(); g++) row.gbk += "\t";
-        finish_row(q, total, row);
-        R->rows[2].push_back(std::move(row));
+        finish_row(q, R, total, row);
     }
 
     // SortResults, aggregate.go:497-525 (stable over the canonical key order)
@@ -356,14 +400,23 @@ int query_finalize(Query *q, Result **out) {
                 return fail(SYBL_E_INVAL, "order_by '%s' is neither $COUNT nor an aggregated column", q->order_by.c_str());
             }
         }
-        auto less = [&](const RowStore &x, const RowStore &y) {
+        std::vector<RowStore> &rows = R->rows[0];
+        auto less = [&](uint32_t ix, uint32_t iy) {
+            const RowStore &x = rows[ix], &y = rows[iy];
             if (by < 0) return x.count > y.count;
-            double mx = x.aggs[(size_t)by].present ? x.aggs[(size_t)by].avg : -INFINITY;
-            double my = y.aggs[(size_t)by].present ? y.aggs[(size_t)by].avg : -INFINITY;
+            const sybl_agg_out &ax = R->agg_pool[(size_t)x.agg_off + by], &ay = R->agg_pool[(size_t)y.agg_off + by];
+            double mx = ax.present ? ax.avg : -INFINITY;
+            double my = ay.present ? ay.avg : -INFINITY;
             return mx > my;
         };
-        std::stable_sort(R->rows[0].begin(), R->rows[0].end(), less);
-        if (q->order_asc) std::reverse(R->rows[0].begin(), R->rows[0].end());
+        std::vector<uint32_t> order(rows.size());
+        for (size_t i = 0; i < order.size(); i++) order[i] = (uint32_t)i;
+        std::stable_sort(order.begin(), order.end(), less);
+        if (q->order_asc) std::reverse(order.begin(), order.end());
+        std::vector<RowStore> sorted;
+        sorted.reserve(rows.size());
+        for (uint32_t i : order) sorted.push_back(std::move(rows[i]));
+        rows.swap(sorted);
     }
     make_views(R);
     *out = R;
@@ -438,7 +491,10 @@ static std::string go_float(double f) {
 }
 
 static void json_agg(const Result *R, const RowStore &r, size_t a, std::string &o) {
-    const sybl_agg_out &g = r.aggs[a];
+    const size_t pk = (size_t)r.agg_off + a;
+    const sybl_agg_out &g = R->agg_pool[pk];
+    const int64_t *vals = R->val_pool[pk];
+    const int64_t poff = R->pctoff_pool[pk];
     if (R->op == SYBL_AGG_AVG) {
         o += g.present ? go_float(g.avg) : "null";
         return;
@@ -447,12 +503,12 @@ static void json_agg(const Result *R, const RowStore &r, size_t a, std::string &
     if (g.present) {
         // keys in the order encoding/json emits a map: sorted
         o += "\"avg\":" + go_float(g.avg);
-        if (R->want_percentiles && !r.values[a].empty()) {
+        if (R->want_percentiles && vals) {
             // GetStrBuckets + getSparseBuckets: non-zero buckets keyed by their lower edge, sorted as strings
             std::vector<std::pair<std::string, int64_t>> bk;
-            for (size_t b = 0; b < r.values[a].size(); b++)
-                if (r.values[a][b] > 0)
-                    bk.emplace_back(std::to_string((long long)((int64_t)b * g.bucket_size + g.min)), r.values[a][b]);
+            for (size_t b = 0; b < (size_t)R->n_values[a]; b++)
+                if (vals[b] > 0)
+                    bk.emplace_back(std::to_string((long long)((int64_t)b * g.bucket_size + g.min)), vals[b]);
             std::sort(bk.begin(), bk.end());
             o += ",\"buckets\":{";
             for (size_t k = 0; k < bk.size(); k++) {
@@ -461,9 +517,9 @@ static void json_agg(const Result *R, const RowStore &r, size_t a, std::string &
             }
             o += "}";
             o += ",\"percentiles\":[";
-            for (size_t k = 0; k < r.pcts[a].size(); k++) {
+            for (size_t k = 0; poff >= 0 && k < 100; k++) {
                 if (k) o += ",";
-                o += std::to_string((long long)r.pcts[a][k]);
+                o += std::to_string((long long)R->pct_pool[(size_t)poff + k]);
             }
             o += "]";
         }
@@ -520,13 +576,14 @@ static void text_row(const Result *R, const RowStore &r, std::string &o) {
     if (R->weighted) o += " (" + std::to_string((long long)r.samples) + ")";
     o += "\n";
     for (size_t a = 0; a < R->agg_names.size(); a++) {
-        const sybl_agg_out &g = r.aggs[a];
+        const sybl_agg_out &g = R->agg_pool[(size_t)r.agg_off + a];
+        const int64_t poff = R->pctoff_pool[(size_t)r.agg_off + a];
         snprintf(b, sizeof(b), "  %5s", R->agg_names[a].c_str());
         std::string col = b;
         if (R->op == SYBL_AGG_HIST) {
             if (!g.present) continue;
-            if (r.pcts[a].size() >= 100) {
-                const auto &p = r.pcts[a];
+            if (poff >= 0) {
+                const int64_t *p = R->pct_pool.data() + poff;
                 char line[512];
                 snprintf(line, sizeof(line), "%s | %lld %lld | %.2f | %lld %lld %lld %lld %lld | %.2f\n", col.c_str(),
                          (long long)p[0], (long long)p[99], g.avg, (long long)p[0], (long long)p[25], (long long)p[50],
@@ -617,9 +674,10 @@ const char *sybl_result_render(sybl_result *r, int format) {
                     o += line;
                 }
                 for (size_t a = 0; a < R->agg_names.size(); a++) {
-                    if (!row.aggs[a].present) continue;
+                    const sybl_agg_out &g = R->agg_pool[(size_t)row.agg_off + a];
+                    if (!g.present) continue;
                     snprintf(line, sizeof(line), "%lld %lld %s %s %.2f\n", (long long)row.time_bucket, (long long)row.count,
-                             row.gbk.c_str(), R->agg_names[a].c_str(), row.aggs[a].avg);
+                             row.gbk.c_str(), R->agg_names[a].c_str(), g.avg);
                     o += line;
                 }
             }
