@@ -34,7 +34,9 @@ def cpu_baseline(workload, total_rows, budget_s=15.0):
     wl = synth.WORKLOADS[workload]
     names, q = wl["columns"], wl["query"]
     info = {n: (synth.COLUMNS[n][4], synth.COLUMNS[n][5]) for n in names}
-    cores = os.cpu_count() or 1
+    # the reference keeps at most 16 blocks in flight between merges (table_query.go:230-231,
+    # CHUNKS_BEFORE_GC=16) and merges them on one goroutine, so more threads do not help it
+    cores = min(os.cpu_count() or 1, 16)
     kw = parity.oracle_query_kwargs(names, info, q)
 
     def run(nrows):
@@ -53,6 +55,21 @@ def cpu_baseline(workload, total_rows, budget_s=15.0):
     return {"value": sample / dt, "unit": "rows/s", "cores": cores, "kind": "port",
             "sample": "%d rows (first blocks) of %s, oracle/sybil_oracle.c with %d threads, %.1f s" % (
                 sample, workload, cores, dt)}
+
+
+def measured_traffic(stats, names):
+    """HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE x2 per
+    the gfx950 correction + WRITE_SIZE, in their own runs): bytes per scanned row x this launch's rows.
+    None when no profile of this kernel shape has been recorded."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        rec = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    key = "%d_cols_strategy_%d" % (len(names), stats["strategy"])
+    if key not in rec:
+        return None
+    return rec[key]["hbm_bytes_per_row"] * stats["rows_scanned"]
 
 
 def main():
@@ -180,7 +197,7 @@ def main():
                        "strategy": {0: "lds-generic", 1: "global-atomics", 2: "lds-fast"}[stats["strategy"]],
                        "lds_bytes": stats["lds_bytes"], "workgroups": stats["n_workgroups"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(stats, names),
                          "kernel": "k_scan_fast<3,2,2,moments>" if stats["strategy"] == 2 else "k_scan<%d>" % len(names),
                          "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes},
         }
