@@ -264,6 +264,8 @@ typedef struct {
     int32_t n_cells;          /* direct-mapped group cells */
     int32_t strategy;         /* 0 = LDS cell table (generic kernel), 1 = global atomics, 2 = LDS cell table (role-specialised kernel) */
     int32_t lds_bytes, n_workgroups, replicas;
+    int32_t n_sum_fields;     /* int64 fields per cell in the SUM section */
+    int32_t n_max_fields;     /* fields per cell in the MAX section; 0 = nothing to MAX-reduce */
 } sybl_run_stats;
 /* Valid after the stream has been synchronised (sybl_query_finalize / sybl_ctx_sync). */
 int sybl_query_stats(sybl_query *q, sybl_run_stats *out);

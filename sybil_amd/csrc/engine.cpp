@@ -742,6 +742,8 @@ static int plan_query(Table *t, const sybl_query_desc *d, Query *q) {
     q->stats.lds_bytes = (int32_t)q->lds_bytes;
     q->stats.n_workgroups = q->n_wg;
     q->stats.replicas = 1 << P.rep_shift;
+    q->stats.n_sum_fields = P.n_sum_fields;
+    q->stats.n_max_fields = P.n_max_fields;
 
     // ---- device-side copies
     size_t nseg = std::max<size_t>(q->segs.size(), 1);

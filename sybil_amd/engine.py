@@ -230,6 +230,7 @@ class Query:
     def __init__(self, table, handle, groups, aggs):
         self.table, self._h, self.groups, self.aggs = table, handle, groups, aggs
         self._bound = None
+        self._has_max = None
 
     def free(self):
         if self._h:
@@ -268,10 +269,11 @@ class Query:
 
     def allreduce_torch(self, group=None):
         """The one collective on the path: SUM over counts/sums/buckets, MAX over extrema."""
-        import torch.distributed as dist
+        from . import dist as sdist
         s, m = self._bound
-        dist.all_reduce(s, op=dist.ReduceOp.SUM, group=group)
-        dist.all_reduce(m, op=dist.ReduceOp.MAX, group=group)
+        if self._has_max is None:
+            self._has_max = self.stats()["n_max_fields"] > 0
+        sdist.merge_partials(s, m, group=group, has_max=self._has_max)
 
     def allreduce(self):
         N.check(N.lib().sybl_query_allreduce(self._h))
