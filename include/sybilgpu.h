@@ -144,6 +144,11 @@ int sybl_table_create_synth(sybl_ctx *ctx, const char *name, uint64_t seed, int6
 int sybl_table_open(sybl_ctx *ctx, const char *dir, const char *table, const char *const *columns,
                     int32_t n_columns, int32_t rank, int32_t nranks, sybl_table **out);
 
+/* Blocks sybl_table_open skipped the way the reference does: unreadable block info.db, NumRecords
+ * <= 0, or a column file whose record ids / value count exceed NumRecords ("BLOCK SIZE CHANGED
+ * DURING QUERY", column_store_io.go:524-526,572-574,733-735; table_query.go:134-139). */
+int64_t sybl_table_broken_blocks(const sybl_table *t);
+
 int64_t sybl_table_rows(const sybl_table *t);
 int64_t sybl_table_blocks(const sybl_table *t);
 int64_t sybl_table_hbm_bytes(const sybl_table *t);
@@ -274,6 +279,10 @@ int sybl_query_stats(sybl_query *q, sybl_run_stats *out);
  * `sybil query` prints it.  format: 0 = text table, 1 = -json.  Returns a
  * library-owned NUL-terminated buffer valid until the result is freed. */
 const char *sybl_result_render(sybl_result *r, int format);
+
+/* Test/diagnostic hook: decodes one gob file (info.db, int_/str_/set_*.db, optionally .gz) to JSON
+ * with the library's gob reader.  Library-owned buffer, valid until the next call on the thread. */
+const char *sybl_debug_gob_to_json(const char *path);
 
 #ifdef __cplusplus
 }

@@ -56,111 +56,6 @@ Column *Table::find(const char *n) const {
 
 static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
-// ------------------------------------------------------------------ device arrays
-
-int table_reserve(Table *t, Column *c, int64_t phys_rows) {
-    // + one tile of slack: the scan's 16-byte loads and its prefetch may touch up to one
-    // row past a segment end (never used, but it must be mapped)
-    int64_t need = phys_rows + kTileRows;
-    if (need <= c->cap_rows) return SYBL_OK;
-    int64_t cap = std::max<int64_t>(need, c->cap_rows + c->cap_rows / 2);
-    void *nd = nullptr;
-    SYBL_HIP(hipMalloc(&nd, (size_t)cap * c->elem));
-    if (c->d_data) {
-        SYBL_HIP(hipMemcpyAsync(nd, c->d_data, (size_t)t->phys_rows * c->elem, hipMemcpyDeviceToDevice, t->ctx->stream));
-        SYBL_HIP(hipStreamSynchronize(t->ctx->stream));
-        SYBL_HIP(hipFree(c->d_data));
-    }
-    c->d_data = nd;
-    c->cap_rows = cap;
-    return SYBL_OK;
-}
-
-static int valid_reserve(Table *t, Column *c, int64_t phys_rows) {
-    int64_t words = round_up(phys_rows + kTileRows, 32) / 32 + 1;
-    if (c->d_valid && words <= c->valid_cap_words) return SYBL_OK;
-    int64_t cap = std::max<int64_t>(words, c->valid_cap_words * 2);
-    uint32_t *nd = nullptr;
-    SYBL_HIP(hipMalloc((void **)&nd, (size_t)cap * 4));
-    int64_t old_words = round_up(t->phys_rows, 32) / 32;
-    if (c->d_valid) {
-        SYBL_HIP(hipMemcpyAsync(nd, c->d_valid, (size_t)old_words * 4, hipMemcpyDeviceToDevice, t->ctx->stream));
-    } else {
-        // every earlier row of this column was populated
-        SYBL_HIP(hipMemsetAsync(nd, 0xFF, (size_t)old_words * 4, t->ctx->stream));
-    }
-    SYBL_HIP(hipMemsetAsync(nd + old_words, 0, (size_t)(cap - old_words) * 4, t->ctx->stream));
-    SYBL_HIP(hipStreamSynchronize(t->ctx->stream));
-    if (c->d_valid) SYBL_HIP(hipFree(c->d_valid));
-    c->d_valid = nd;
-    c->valid_cap_words = cap;
-    return SYBL_OK;
-}
-
-int table_ensure_stats(Table *t) {
-    int64_t nb = (int64_t)t->blocks.size();
-    bool pending = false;
-    for (auto &c : t->cols)
-        if (c->type != SYBL_SET_VAL && c->stats_blocks < nb) pending = true;
-    if (!pending) return SYBL_OK;
-    hipStream_t st = t->ctx->stream;
-    if (t->d_blocks_n < nb) {
-        if (t->d_blocks) SYBL_HIP(hipFree(t->d_blocks));
-        SYBL_HIP(hipMalloc((void **)&t->d_blocks, (size_t)nb * sizeof(Segment)));
-        t->d_blocks_n = nb;
-    }
-    SYBL_HIP(hipMemcpyAsync(t->d_blocks, t->blocks.data(), (size_t)nb * sizeof(Segment), hipMemcpyHostToDevice, st));
-    int64_t *d_out = nullptr;
-    SYBL_HIP(hipMalloc((void **)&d_out, (size_t)nb * 3 * sizeof(int64_t)));
-    std::vector<int64_t> h((size_t)nb * 3);
-    for (auto &cp : t->cols) {
-        Column *c = cp.get();
-        if (c->type == SYBL_SET_VAL || c->stats_blocks >= nb) continue;
-        int64_t b0 = c->stats_blocks, n = nb - b0;
-        hipError_t e = launch_block_minmax(c->d_data, c->elem == 4, c->d_valid, t->d_blocks + b0, (int)n, d_out,
-                                           d_out + nb, d_out + 2 * nb, st);
-        if (e != hipSuccess) {
-            hipFree(d_out);
-            return hip_fail(e, "k_block_minmax");
-        }
-        SYBL_HIP(hipMemcpyAsync(h.data(), d_out, (size_t)nb * 3 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
-        SYBL_HIP(hipStreamSynchronize(st));
-        c->blk_min.resize((size_t)nb);
-        c->blk_max.resize((size_t)nb);
-        c->blk_pop.resize((size_t)nb);
-        for (int64_t k = 0; k < n; k++) {
-            c->blk_min[(size_t)(b0 + k)] = h[(size_t)k];
-            c->blk_max[(size_t)(b0 + k)] = h[(size_t)(nb + k)];
-            c->blk_pop[(size_t)(b0 + k)] = h[(size_t)(2 * nb + k)];
-            if (h[(size_t)(2 * nb + k)] > 0) {
-                c->exact_min = std::min(c->exact_min, h[(size_t)k]);
-                c->exact_max = std::max(c->exact_max, h[(size_t)(nb + k)]);
-            }
-            c->n_pop += h[(size_t)(2 * nb + k)];
-            if (h[(size_t)(2 * nb + k)] < t->blocks[(size_t)(b0 + k)].n) c->has_missing = true;
-        }
-        c->stats_blocks = nb;
-    }
-    SYBL_HIP(hipFree(d_out));
-    return SYBL_OK;
-}
-
-static void column_free(Column *c) {
-    if (c->d_data) hipFree(c->d_data);
-    if (c->d_valid) hipFree(c->d_valid);
-    if (c->d_set_off) hipFree(c->d_set_off);
-    if (c->d_set_vals) hipFree(c->d_set_vals);
-}
-
-static int32_t dict_intern(Column *c, const std::string &s) {
-    auto it = c->dict_ix.find(s);
-    if (it != c->dict_ix.end()) return it->second;
-    int32_t id = (int32_t)c->dict.size();
-    c->dict.push_back(s);
-    c->dict_ix.emplace(s, id);
-    return id;
-}
-
 // ------------------------------------------------------------------ planner
 
 struct HostFilterFold {
@@ -169,6 +64,7 @@ struct HostFilterFold {
     std::vector<int64_t> neq;
     bool has_mask = false;
     std::vector<uint8_t> mask;  // per dictionary id, ANDed over the column's str filters
+    std::vector<std::pair<int32_t, int32_t>> setp;  // set predicates: (member id, 1 = in / 0 = nin)
 };
 
 // hist_basic.go:34-70
@@ -439,7 +335,16 @@ static int plan_query(Table *t, const sybl_query_desc *d, Query *q) {
                 for (size_t k = 0; k < n; k++) ff.mask[k] = ff.mask[k] && m[k];
             }
         } else {
-            return fail(SYBL_E_INVAL, "set filters are not supported by this build yet ('%s')", f.col);
+            // SetFilter.Filter, filter.go:252-285; get_val_id of an unseen string yields an id no
+            // member can have (table_column.go:27-48)
+            if (f.op != SYBL_OP_IN && f.op != SYBL_OP_NIN) {
+                q->never_matches = true;  // default branch: ret stays false
+                ff.setp.emplace_back(-1, 1);
+                continue;
+            }
+            if ((int)ff.setp.size() >= kMaxNeq) return fail(SYBL_E_INVAL, "more than %d set filters on '%s'", kMaxNeq, f.col);
+            auto it = c->dict_ix.find(f.str_value ? f.str_value : "");
+            ff.setp.emplace_back(it == c->dict_ix.end() ? -1 : it->second, f.op == SYBL_OP_IN ? 1 : 0);
         }
     }
 
@@ -644,6 +549,17 @@ static int plan_query(Table *t, const sybl_query_desc *d, Query *q) {
         sd.base = c->d_data;
         sd.valid = c->d_valid;
         if (c->elem == 4) sd.flags |= kSlotW32;
+        if (c->type == SYBL_SET_VAL) {
+            if ((rc = column_upload_set(t, c))) return rc;
+            sd.flags = (sd.flags & ~kSlotW32) | kSlotSet;
+            sd.base = c->d_set_off;
+            sd.set_vals = c->d_set_vals;
+            sd.n_setp = (int)folds[(size_t)s].setp.size();
+            for (int k = 0; k < sd.n_setp; k++) {
+                sd.set_id[k] = folds[(size_t)s].setp[(size_t)k].first;
+                sd.set_in[k] = folds[(size_t)s].setp[(size_t)k].second;
+            }
+        }
         HostFilterFold &ff = folds[(size_t)s];
         if (ff.has_range) {
             sd.flags |= kSlotRange;
@@ -735,8 +651,17 @@ static int plan_query(Table *t, const sybl_query_desc *d, Query *q) {
     q->stats.blocks_skipped = skipped;
     q->stats.blocks_scanned = (int64_t)t->blocks.size() - skipped;
     int64_t width = 0;
-    for (int s = 0; s < P.n_slots; s++) width += t->cols[(size_t)slot_col[(size_t)s]]->elem;
-    q->stats.algorithmic_bytes = rows_scanned * width;
+    int64_t set_bytes = 0;
+    for (int s = 0; s < P.n_slots; s++) {
+        const Column *c = t->cols[(size_t)slot_col[(size_t)s]].get();
+        if (c->type == SYBL_SET_VAL) {
+            width += 8;  // one CSR offset per row
+            set_bytes += (int64_t)c->h_set_vals.size() * 4;
+        } else {
+            width += c->elem;
+        }
+    }
+    q->stats.algorithmic_bytes = rows_scanned * width + set_bytes;
     q->stats.n_cells = (int32_t)n_cells;
     q->stats.strategy = q->use_lds ? (q->fast ? 2 : 0) : 1;
     q->stats.lds_bytes = (int32_t)q->lds_bytes;
@@ -900,224 +825,6 @@ int sybl_device_info(sybl_ctx *ctx, char *name, size_t name_cap, int *n_cus, int
     return SYBL_OK;
 }
 
-// ------------------------------------------------------------------ tables
-
-int sybl_table_create(sybl_ctx *ctx, const char *name, sybl_table **out) {
-    if (!ctx || !out) return fail(SYBL_E_INVAL, "sybl_table_create: NULL argument");
-    sybl_table *t = new sybl_table();
-    t->ctx = ctx;
-    t->name = name ? name : "";
-    *out = t;
-    return SYBL_OK;
-}
-
-void sybl_table_free(sybl_table *t) {
-    if (!t) return;
-    hipSetDevice(t->ctx->device);
-    hipStreamSynchronize(t->ctx->stream);
-    for (auto &c : t->cols) column_free(c.get());
-    if (t->d_blocks) hipFree(t->d_blocks);
-    delete t;
-}
-
-int sybl_table_add_column(sybl_table *t, const char *name, int type, int64_t info_min, int64_t info_max) {
-    if (!t || !name) return fail(SYBL_E_INVAL, "sybl_table_add_column: NULL argument");
-    if (type != SYBL_INT_VAL && type != SYBL_STR_VAL && type != SYBL_SET_VAL) return fail(SYBL_E_INVAL, "bad column type %d", type);
-    if (t->col_ix.count(name)) return fail(SYBL_E_INVAL, "column '%s' already exists", name);
-    if (!t->blocks.empty()) return fail(SYBL_E_STATE, "columns must be declared before the first block");
-    auto c = std::make_unique<Column>();
-    c->name = name;
-    c->type = type;
-    c->elem = type == SYBL_INT_VAL ? 8 : 4;
-    c->info_given = info_min <= info_max;
-    c->info_min = info_min;
-    c->info_max = info_max;
-    t->col_ix[name] = (int)t->cols.size();
-    t->cols.push_back(std::move(c));
-    return SYBL_OK;
-}
-
-int sybl_table_append_block(sybl_table *t, int64_t nrows, int32_t ncols, const sybl_col_view *cols) {
-    if (!t || nrows < 0 || (ncols > 0 && !cols)) return fail(SYBL_E_INVAL, "sybl_table_append_block: bad argument");
-    SYBL_HIP(hipSetDevice(t->ctx->device));
-    hipStream_t st = t->ctx->stream;
-    for (int i = 0; i < ncols; i++) {
-        Column *c = t->find(cols[i].name);
-        if (!c) return fail(SYBL_E_BLOCK, "block has unknown column '%s'", cols[i].name ? cols[i].name : "(null)");
-        if (c->type != cols[i].type) return fail(SYBL_E_BLOCK, "column '%s' type mismatch", c->name.c_str());
-    }
-    int64_t start = round_up(t->phys_rows, 32);
-    int64_t new_phys = start + nrows;
-    std::vector<uint32_t> bits;
-    std::vector<int32_t> ids;
-    for (auto &cp : t->cols) {
-        Column *c = cp.get();
-        const sybl_col_view *v = nullptr;
-        for (int i = 0; i < ncols; i++)
-            if (c->name == cols[i].name) v = &cols[i];
-        int rc = SYBL_OK;
-        if (c->type != SYBL_SET_VAL) {
-            if ((rc = table_reserve(t, c, new_phys))) return rc;
-        }
-        bool any_missing = !v || v->populated != nullptr;
-        if (v && v->populated) {
-            any_missing = false;
-            for (int64_t r = 0; r < nrows; r++)
-                if (!v->populated[r]) { any_missing = true; break; }
-        }
-        if (nrows == 0) any_missing = false;
-        if (any_missing || c->d_valid) {
-            if ((rc = valid_reserve(t, c, new_phys))) return rc;
-            bits.assign((size_t)(round_up(nrows, 32) / 32), 0);
-            if (v) {
-                for (int64_t r = 0; r < nrows; r++)
-                    if (!v->populated || v->populated[r]) bits[(size_t)(r >> 5)] |= 1u << (r & 31);
-            }
-            if (!bits.empty())
-                SYBL_HIP(hipMemcpyAsync(c->d_valid + start / 32, bits.data(), bits.size() * 4, hipMemcpyHostToDevice, st));
-            SYBL_HIP(hipStreamSynchronize(st));
-            if (any_missing) c->has_missing = true;
-        }
-        if (!v || nrows == 0) {
-            if (c->type != SYBL_SET_VAL && nrows > 0)
-                SYBL_HIP(hipMemsetAsync((char *)c->d_data + (size_t)start * c->elem, 0, (size_t)nrows * c->elem, st));
-            continue;
-        }
-        if (c->type == SYBL_INT_VAL) {
-            if (!v->ints) return fail(SYBL_E_BLOCK, "int column '%s' without values", c->name.c_str());
-            SYBL_HIP(hipMemcpyAsync((int64_t *)c->d_data + start, v->ints, (size_t)nrows * 8, hipMemcpyHostToDevice, st));
-            SYBL_HIP(hipStreamSynchronize(st));
-        } else if (c->type == SYBL_STR_VAL) {
-            if (!v->str_ids) return fail(SYBL_E_BLOCK, "str column '%s' without ids", c->name.c_str());
-            // block-local dictionary ids -> table-global ids (SURVEY.md 8a note 8)
-            std::vector<int32_t> lut((size_t)std::max(v->n_strings, 0));
-            for (int k = 0; k < v->n_strings; k++) lut[(size_t)k] = dict_intern(c, v->strings[k] ? v->strings[k] : "");
-            ids.resize((size_t)nrows);
-            for (int64_t r = 0; r < nrows; r++) {
-                int32_t id = v->str_ids[r];
-                bool pop = !v->populated || v->populated[r];
-                if (pop && (id < 0 || id >= v->n_strings)) return fail(SYBL_E_BLOCK, "str id %d outside the block StringTable of '%s'", id, c->name.c_str());
-                ids[(size_t)r] = pop ? lut[(size_t)id] : 0;
-            }
-            SYBL_HIP(hipMemcpyAsync((int32_t *)c->d_data + start, ids.data(), (size_t)nrows * 4, hipMemcpyHostToDevice, st));
-            SYBL_HIP(hipStreamSynchronize(st));
-        } else {
-            return fail(SYBL_E_INVAL, "set columns are not supported by this build yet ('%s')", c->name.c_str());
-        }
-    }
-    Segment blk;
-    blk.start = start;
-    blk.n = nrows;
-    t->blocks.push_back(blk);
-    t->phys_rows = new_phys;
-    t->logical_rows += nrows;
-    return SYBL_OK;
-}
-
-int sybl_table_create_synth(sybl_ctx *ctx, const char *name, uint64_t seed, int64_t total_rows, int64_t row0,
-                            int64_t nrows, int32_t ncols, const sybl_synth_col *cols, sybl_table **out) {
-    if (!ctx || !out || !cols || ncols <= 0 || nrows < 0 || total_rows <= 0 || row0 < 0 || row0 + nrows > total_rows)
-        return fail(SYBL_E_INVAL, "sybl_table_create_synth: bad argument");
-    SYBL_HIP(hipSetDevice(ctx->device));
-    sybl_table *t = nullptr;
-    int rc = sybl_table_create(ctx, name, &t);
-    if (rc) return rc;
-    for (int i = 0; i < ncols; i++) {
-        if ((rc = sybl_table_add_column(t, cols[i].name, SYBL_INT_VAL, cols[i].info_min, cols[i].info_max))) {
-            sybl_table_free(t);
-            return rc;
-        }
-    }
-    for (int i = 0; i < ncols; i++) {
-        Column *c = t->cols[(size_t)i].get();
-        if ((rc = table_reserve(t, c, nrows))) {
-            sybl_table_free(t);
-            return rc;
-        }
-        uint64_t cs = seed ^ ((uint64_t)(cols[i].col_index + 1) * 0x9E3779B97F4A7C15ull);
-        hipError_t e = launch_synth((int64_t *)c->d_data, nrows, row0, total_rows, cols[i].kind, cols[i].a, cols[i].b, cs, ctx->stream);
-        if (e != hipSuccess) {
-            sybl_table_free(t);
-            return hip_fail(e, "k_synth");
-        }
-    }
-    for (int64_t r = 0; r < nrows; r += SYBL_BLOCK_ROWS) {
-        Segment blk;
-        blk.start = r;
-        blk.n = std::min<int64_t>(SYBL_BLOCK_ROWS, nrows - r);
-        t->blocks.push_back(blk);
-    }
-    t->phys_rows = nrows;
-    t->logical_rows = nrows;
-    hipError_t e = hipStreamSynchronize(ctx->stream);
-    if (e != hipSuccess) {
-        sybl_table_free(t);
-        return hip_fail(e, "synth sync");
-    }
-    *out = t;
-    return SYBL_OK;
-}
-
-int64_t sybl_table_rows(const sybl_table *t) { return t ? t->logical_rows : 0; }
-int64_t sybl_table_blocks(const sybl_table *t) { return t ? (int64_t)t->blocks.size() : 0; }
-
-int64_t sybl_table_hbm_bytes(const sybl_table *t) {
-    if (!t) return 0;
-    int64_t b = 0;
-    for (auto &c : t->cols) b += c->cap_rows * c->elem + c->valid_cap_words * 4 + c->set_vals_cap * 4;
-    return b;
-}
-
-int sybl_table_column_info(const sybl_table *tc, const char *name, int *type, int64_t *exact_min, int64_t *exact_max,
-                           int64_t *info_min, int64_t *info_max, int *has_missing) {
-    sybl_table *t = const_cast<sybl_table *>(tc);
-    if (!t) return fail(SYBL_E_INVAL, "table is NULL");
-    Column *c = t->find(name);
-    if (!c) return fail(SYBL_E_INVAL, "unknown column '%s'", name ? name : "(null)");
-    SYBL_HIP(hipSetDevice(t->ctx->device));
-    int rc = table_ensure_stats(t);
-    if (rc) return rc;
-    if (type) *type = c->type;
-    if (exact_min) *exact_min = c->exact_min;
-    if (exact_max) *exact_max = c->exact_max;
-    if (info_min) *info_min = c->info_given ? c->info_min : c->exact_min;
-    if (info_max) *info_max = c->info_given ? c->info_max : c->exact_max;
-    if (has_missing) *has_missing = c->has_missing;
-    return SYBL_OK;
-}
-
-int sybl_table_set_bounds(sybl_table *t, const char *name, int64_t lo, int64_t hi, int has_missing) {
-    if (!t) return fail(SYBL_E_INVAL, "table is NULL");
-    Column *c = t->find(name);
-    if (!c) return fail(SYBL_E_INVAL, "unknown column '%s'", name ? name : "(null)");
-    c->bounds_set = true;
-    c->bound_lo = lo;
-    c->bound_hi = hi;
-    if (has_missing) c->has_missing = true;
-    return SYBL_OK;
-}
-
-int sybl_table_read_int(const sybl_table *t, const char *name, int64_t row0, int64_t n, int64_t *out) {
-    if (!t || !out) return fail(SYBL_E_INVAL, "NULL argument");
-    Column *c = t->find(name);
-    if (!c || c->type != SYBL_INT_VAL) return fail(SYBL_E_INVAL, "unknown int column '%s'", name ? name : "(null)");
-    if (row0 < 0 || n < 0 || row0 + n > t->logical_rows) return fail(SYBL_E_INVAL, "row range out of bounds");
-    SYBL_HIP(hipSetDevice(t->ctx->device));
-    SYBL_HIP(hipStreamSynchronize(t->ctx->stream));
-    // logical -> physical: walk the blocks
-    int64_t lbase = 0, done = 0;
-    for (auto &b : t->blocks) {
-        int64_t lo = std::max(row0, lbase), hi = std::min(row0 + n, lbase + b.n);
-        if (hi > lo) {
-            SYBL_HIP(hipMemcpy(out + (lo - row0), (const int64_t *)c->d_data + b.start + (lo - lbase), (size_t)(hi - lo) * 8,
-                               hipMemcpyDeviceToHost));
-            done += hi - lo;
-        }
-        lbase += b.n;
-    }
-    return done == n ? SYBL_OK : fail(SYBL_E_INVAL, "short read");
-}
-
 // ------------------------------------------------------------------ queries
 
 int sybl_query_prepare(sybl_table *t, const sybl_query_desc *desc, sybl_query **out) {
@@ -1205,3 +912,4 @@ int sybl_query_finalize(sybl_query *q, sybl_result **out) {
 }
 
 }  // extern "C"
+

@@ -34,6 +34,11 @@ hipError_t launch_synth(int64_t *out, int64_t n, int64_t row0, int64_t total_row
 hipError_t launch_block_minmax(const void *col, bool w32, const uint32_t *valid, const Segment *blocks, int n_blocks,
                                int64_t *out_min, int64_t *out_max, int64_t *out_pop, hipStream_t st);
 
+hipError_t launch_decode_bins(const uint32_t *recs, const int64_t *bin_off, const int64_t *bin_val, int n_bins,
+                              bool delta_encoded, void *col, bool w32, uint32_t *valid, uint32_t nrows, hipStream_t st);
+hipError_t launch_decode_delta(const int64_t *deltas, int64_t n, bool value_encoded, int64_t *col, hipStream_t st);
+hipError_t launch_remap_ids(const int32_t *local, const int32_t *lut, int32_t n_lut, int64_t n, int32_t *col, hipStream_t st);
+
 struct Ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
@@ -70,7 +75,9 @@ struct Column {
     int64_t *d_set_off = nullptr;
     int32_t *d_set_vals = nullptr;
     int64_t set_vals_cap = 0, set_vals_n = 0;
-    std::vector<int64_t> h_set_off;  // host mirror of offsets (appended per block)
+    std::vector<int64_t> h_set_off;  // host mirror: CSR offsets per physical row (+1)
+    std::vector<int32_t> h_set_vals; // host mirror: member ids (table-global)
+    bool set_dirty = false;          // host mirror newer than the device copy
 };
 
 struct Table {
@@ -83,11 +90,28 @@ struct Table {
     std::vector<Segment> blocks;  // physical start / logical row count
     Segment *d_blocks = nullptr;
     int64_t d_blocks_n = 0;
+    int64_t broken_blocks = 0;  // blocks the loader skipped (unreadable info / column unpack error)
     Column *find(const char *name) const;
 };
 
 int table_ensure_stats(Table *t);
 int table_reserve(Table *t, Column *c, int64_t phys_rows);
+int valid_reserve(Table *t, Column *c, int64_t phys_rows);
+void column_free(Column *c);
+int32_t dict_intern(Column *c, const std::string &s);
+int column_upload_set(Table *t, Column *c);
+
+struct BlockWriter {
+    Table *t = nullptr;
+    int64_t start = 0, nrows = 0, new_phys = 0;
+};
+int block_begin(Table *t, int64_t nrows, BlockWriter *w);
+int block_col_device(BlockWriter &w, Column *c, bool all_populated, void **col, uint32_t **valid);
+int block_col_absent(BlockWriter &w, Column *c);
+int block_col_int_host(BlockWriter &w, Column *c, const int64_t *vals, const uint8_t *populated);
+int block_col_str_host(BlockWriter &w, Column *c, const int32_t *global_ids, const uint8_t *populated);
+int block_col_set_host(BlockWriter &w, Column *c, const int64_t *off, const int32_t *global_ids, const uint8_t *populated);
+int block_commit(BlockWriter &w);
 
 struct GroupInfo {
     int col;

@@ -1,0 +1,452 @@
+// gob.cpp -- see gob.h.  Wire format as specified by Go's encoding/gob documentation
+// ("Encoding Details"); sybil's use of it: column_store_io.go, table_io.go, file_decoder.go.
+#include "gob.h"
+
+#include <stdio.h>
+#include <string.h>
+#include <zlib.h>
+
+namespace sybl {
+namespace gob {
+
+namespace {
+
+// predefined type ids (encoding/gob/type.go)
+enum { tBool = 1, tInt = 2, tUint = 3, tFloat = 4, tBytes = 5, tString = 6, tComplex = 7, tInterface = 8 };
+
+struct TypeDef {
+    enum Kind { kArray, kSlice, kStruct, kMap, kOpaque } kind = kOpaque;
+    std::string name;
+    int64_t elem = 0, key = 0, len = 0;
+    std::vector<std::pair<std::string, int64_t>> fields;
+};
+
+struct Reader {
+    const uint8_t *p, *end;
+    std::string *err;
+    bool ok = true;
+
+    bool fail(const char *what) {
+        if (ok) *err = std::string("gob: ") + what;
+        ok = false;
+        return false;
+    }
+    size_t left() const { return (size_t)(end - p); }
+    uint64_t uvarint() {
+        if (p >= end) {
+            fail("truncated uint");
+            return 0;
+        }
+        uint8_t b = *p++;
+        if (b < 128) return b;
+        int n = 256 - (int)b;  // byte count, stored negated
+        if (n > 8 || (size_t)n > left()) {
+            fail("bad uint length");
+            return 0;
+        }
+        uint64_t v = 0;
+        for (int i = 0; i < n; i++) v = (v << 8) | *p++;
+        return v;
+    }
+    int64_t svarint() {
+        uint64_t u = uvarint();
+        return (u & 1) ? (int64_t) ~(u >> 1) : (int64_t)(u >> 1);
+    }
+    double float64() {
+        uint64_t u = uvarint(), r = 0;  // IEEE bits, byte-reversed
+        for (int i = 0; i < 8; i++) r |= ((u >> (8 * i)) & 0xFF) << (8 * (7 - i));
+        double d;
+        memcpy(&d, &r, 8);
+        return d;
+    }
+    bool bytes(std::string &out) {
+        uint64_t n = uvarint();
+        if (!ok) return false;
+        if (n > left()) return fail("truncated string");
+        out.assign((const char *)p, (size_t)n);
+        p += n;
+        return true;
+    }
+};
+
+struct Decoder {
+    std::map<int64_t, TypeDef> types;
+    std::string *err;
+
+    bool fail(const std::string &m) {
+        *err = "gob: " + m;
+        return false;
+    }
+
+    // CommonType{Name string, Id typeId}
+    bool common_type(Reader &r, std::string &name) {
+        int64_t f = -1;
+        for (;;) {
+            uint64_t d = r.uvarint();
+            if (!r.ok) return false;
+            if (d == 0) return true;
+            f += (int64_t)d;
+            if (f == 0) {
+                if (!r.bytes(name)) return false;
+            } else if (f == 1) {
+                r.svarint();
+            } else {
+                return fail("unexpected CommonType field");
+            }
+        }
+    }
+
+    // one of arrayType / sliceType / structType / mapType / gobEncoderType
+    bool type_body(Reader &r, int which, TypeDef &td) {
+        int64_t f = -1;
+        for (;;) {
+            uint64_t d = r.uvarint();
+            if (!r.ok) return false;
+            if (d == 0) return true;
+            f += (int64_t)d;
+            if (f == 0) {
+                if (!common_type(r, td.name)) return false;
+                continue;
+            }
+            switch (which) {
+            case 0:  // ArrayT: Elem, Len
+                if (f == 1) td.elem = r.svarint();
+                else if (f == 2) td.len = r.svarint();
+                else return fail("unexpected arrayType field");
+                break;
+            case 1:  // SliceT: Elem
+                if (f == 1) td.elem = r.svarint();
+                else return fail("unexpected sliceType field");
+                break;
+            case 2:  // StructT: Field []fieldType{Name string, Id typeId}
+                if (f == 1) {
+                    uint64_t n = r.uvarint();
+                    for (uint64_t i = 0; i < n && r.ok; i++) {
+                        std::string fname;
+                        int64_t fid = 0, ff = -1;
+                        for (;;) {
+                            uint64_t dd = r.uvarint();
+                            if (!r.ok) return false;
+                            if (dd == 0) break;
+                            ff += (int64_t)dd;
+                            if (ff == 0) {
+                                if (!r.bytes(fname)) return false;
+                            } else if (ff == 1) {
+                                fid = r.svarint();
+                            } else {
+                                return fail("unexpected fieldType field");
+                            }
+                        }
+                        td.fields.emplace_back(fname, fid);
+                    }
+                } else {
+                    return fail("unexpected structType field");
+                }
+                break;
+            case 3:  // MapT: Key, Elem
+                if (f == 1) td.key = r.svarint();
+                else if (f == 2) td.elem = r.svarint();
+                else return fail("unexpected mapType field");
+                break;
+            default:
+                return fail("unexpected field in opaque type definition");
+            }
+            if (!r.ok) return false;
+        }
+    }
+
+    // wireType{ArrayT, SliceT, StructT, MapT, GobEncoderT, BinaryMarshalerT, TextMarshalerT}
+    bool wire_type(Reader &r, TypeDef &td) {
+        int64_t f = -1;
+        for (;;) {
+            uint64_t d = r.uvarint();
+            if (!r.ok) return false;
+            if (d == 0) return true;
+            f += (int64_t)d;
+            if (f < 0 || f > 6) return fail("unexpected wireType field");
+            static const TypeDef::Kind kinds[] = {TypeDef::kArray, TypeDef::kSlice, TypeDef::kStruct, TypeDef::kMap,
+                                                  TypeDef::kOpaque, TypeDef::kOpaque, TypeDef::kOpaque};
+            td.kind = kinds[f];
+            if (!type_body(r, (int)f, td)) return false;
+        }
+    }
+
+    bool is_int_kind(int64_t id) const { return id == tInt || id == tUint; }
+
+    bool value(Reader &r, int64_t id, Value &out, int depth) {
+        if (depth > 64) return fail("nesting too deep");
+        switch (id) {
+        case tBool:
+            out.kind = Value::kBool;
+            out.i = r.uvarint() != 0;
+            return r.ok;
+        case tInt:
+            out.kind = Value::kInt;
+            out.i = r.svarint();
+            return r.ok;
+        case tUint:
+            out.kind = Value::kUint;
+            out.u = r.uvarint();
+            out.i = (int64_t)out.u;
+            return r.ok;
+        case tFloat:
+            out.kind = Value::kFloat;
+            out.f = r.float64();
+            return r.ok;
+        case tBytes:
+        case tString:
+            out.kind = Value::kString;
+            return r.bytes(out.s);
+        case tComplex:
+            return fail("complex values are not supported");
+        case tInterface:
+            return fail("interface values are not supported (not used by sybil's column/info files)");
+        default:
+            break;
+        }
+        auto it = types.find(id);
+        if (it == types.end()) return fail("value of undefined type id " + std::to_string((long long)id));
+        const TypeDef &td = it->second;
+        out.type_name = td.name;
+        switch (td.kind) {
+        case TypeDef::kStruct: {
+            out.kind = Value::kStruct;
+            int64_t f = -1;
+            for (;;) {
+                uint64_t d = r.uvarint();
+                if (!r.ok) return false;
+                if (d == 0) return true;
+                f += (int64_t)d;
+                if (f < 0 || f >= (int64_t)td.fields.size()) return fail("struct field index out of range in " + td.name);
+                ValuePtr v = std::make_shared<Value>();
+                if (!value(r, td.fields[(size_t)f].second, *v, depth + 1)) return false;
+                out.fields.emplace_back(td.fields[(size_t)f].first, v);
+            }
+        }
+        case TypeDef::kArray:
+        case TypeDef::kSlice: {
+            uint64_t n = r.uvarint();
+            if (!r.ok) return false;
+            if (n > r.left()) return fail("slice longer than the message");
+            if (is_int_kind(td.elem)) {
+                out.kind = Value::kIntVec;
+                out.ints.resize((size_t)n);
+                if (td.elem == tInt) {
+                    for (uint64_t k = 0; k < n; k++) out.ints[(size_t)k] = r.svarint();
+                } else {
+                    for (uint64_t k = 0; k < n; k++) out.ints[(size_t)k] = (int64_t)r.uvarint();
+                }
+                return r.ok;
+            }
+            if (td.elem == tFloat) {
+                out.kind = Value::kFloatVec;
+                out.floats.resize((size_t)n);
+                for (uint64_t k = 0; k < n; k++) out.floats[(size_t)k] = r.float64();
+                return r.ok;
+            }
+            out.kind = Value::kSlice;
+            out.items.reserve((size_t)n);
+            for (uint64_t k = 0; k < n; k++) {
+                ValuePtr v = std::make_shared<Value>();
+                if (!value(r, td.elem, *v, depth + 1)) return false;
+                out.items.push_back(v);
+            }
+            return true;
+        }
+        case TypeDef::kMap: {
+            uint64_t n = r.uvarint();
+            if (!r.ok) return false;
+            if (n > r.left()) return fail("map longer than the message");
+            out.kind = Value::kMap;
+            for (uint64_t k = 0; k < n; k++) {
+                ValuePtr kv = std::make_shared<Value>(), vv = std::make_shared<Value>();
+                if (!value(r, td.key, *kv, depth + 1)) return false;
+                if (!value(r, td.elem, *vv, depth + 1)) return false;
+                out.entries.emplace_back(kv, vv);
+            }
+            return true;
+        }
+        default:
+            // GobEncoder / BinaryMarshaler / TextMarshaler: opaque bytes
+            out.kind = Value::kString;
+            return r.bytes(out.s);
+        }
+    }
+
+    bool run(const uint8_t *data, size_t size, Value &out) {
+        const uint8_t *p = data, *end = data + size;
+        while (p < end) {
+            Reader hdr{p, end, err};
+            uint64_t mlen = hdr.uvarint();
+            if (!hdr.ok) return false;
+            if (mlen > hdr.left()) return fail("truncated message");
+            Reader r{hdr.p, hdr.p + mlen, err};
+            p = hdr.p + mlen;
+            int64_t id = r.svarint();
+            if (!r.ok) return false;
+            if (id < 0) {
+                TypeDef td;
+                if (!wire_type(r, td)) return false;
+                types[-id] = td;
+                continue;
+            }
+            auto it = types.find(id);
+            bool is_struct = it != types.end() && it->second.kind == TypeDef::kStruct;
+            if (!is_struct) {
+                // a top-level non-struct value is preceded by a zero field delta
+                if (r.uvarint() != 0) return fail("missing singleton marker");
+            }
+            return value(r, id, out, 0);
+        }
+        return fail("no value in stream");
+    }
+};
+
+}  // namespace
+
+const Value *Value::field(const char *name) const {
+    for (auto &f : fields)
+        if (f.first == name) return f.second.get();
+    return nullptr;
+}
+
+int64_t Value::as_int(int64_t dflt) const {
+    switch (kind) {
+    case kBool:
+    case kInt:
+    case kUint: return i;
+    case kFloat: return (int64_t)f;
+    default: return dflt;
+    }
+}
+
+bool decode(const uint8_t *data, size_t size, Value &out, std::string &err) {
+    Decoder d;
+    d.err = &err;
+    return d.run(data, size, out);
+}
+
+bool read_file(const std::string &path, std::vector<uint8_t> &out, std::string &err) {
+    std::string use = path;
+    FILE *f = fopen(use.c_str(), "rb");
+    if (!f) {
+        use = path + ".gz";
+        f = fopen(use.c_str(), "rb");
+    }
+    if (!f) {
+        err = "cannot open " + path;
+        return false;
+    }
+    fclose(f);
+    bool gz = use.size() > 3 && use.compare(use.size() - 3, 3, ".gz") == 0;
+    out.clear();
+    if (gz) {
+        gzFile g = gzopen(use.c_str(), "rb");
+        if (!g) {
+            err = "cannot gzopen " + use;
+            return false;
+        }
+        uint8_t buf[1 << 16];
+        int n;
+        while ((n = gzread(g, buf, sizeof(buf))) > 0) out.insert(out.end(), buf, buf + n);
+        bool bad = n < 0;
+        gzclose(g);
+        if (bad) {
+            err = "gzip error in " + use;
+            return false;
+        }
+        return true;
+    }
+    f = fopen(use.c_str(), "rb");
+    fseek(f, 0, SEEK_END);
+    long sz = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    out.resize(sz > 0 ? (size_t)sz : 0);
+    size_t got = sz > 0 ? fread(out.data(), 1, (size_t)sz, f) : 0;
+    fclose(f);
+    if (got != out.size()) {
+        err = "short read on " + use;
+        return false;
+    }
+    return true;
+}
+
+static void json_str(const std::string &s, std::string &o) {
+    o += '"';
+    for (unsigned char c : s) {
+        if (c == '"') o += "\\\"";
+        else if (c == '\\') o += "\\\\";
+        else if (c == '\n') o += "\\n";
+        else if (c == '\t') o += "\\t";
+        else if (c == '\r') o += "\\r";
+        else if (c < 0x20) {
+            char b[8];
+            snprintf(b, sizeof(b), "\\u%04x", c);
+            o += b;
+        } else o += (char)c;
+    }
+    o += '"';
+}
+
+void to_json(const Value &v, std::string &o) {
+    char b[64];
+    switch (v.kind) {
+    case Value::kNil: o += "null"; break;
+    case Value::kBool: o += v.i ? "true" : "false"; break;
+    case Value::kInt: snprintf(b, sizeof(b), "%lld", (long long)v.i); o += b; break;
+    case Value::kUint: snprintf(b, sizeof(b), "%llu", (unsigned long long)v.u); o += b; break;
+    case Value::kFloat: snprintf(b, sizeof(b), "%.17g", v.f); o += b; break;
+    case Value::kString: json_str(v.s, o); break;
+    case Value::kStruct:
+        o += "{";
+        for (size_t i = 0; i < v.fields.size(); i++) {
+            if (i) o += ",";
+            json_str(v.fields[i].first, o);
+            o += ":";
+            to_json(*v.fields[i].second, o);
+        }
+        o += "}";
+        break;
+    case Value::kSlice:
+        o += "[";
+        for (size_t i = 0; i < v.items.size(); i++) {
+            if (i) o += ",";
+            to_json(*v.items[i], o);
+        }
+        o += "]";
+        break;
+    case Value::kMap:
+        o += "[";
+        for (size_t i = 0; i < v.entries.size(); i++) {
+            if (i) o += ",";
+            o += "[";
+            to_json(*v.entries[i].first, o);
+            o += ",";
+            to_json(*v.entries[i].second, o);
+            o += "]";
+        }
+        o += "]";
+        break;
+    case Value::kIntVec:
+        o += "[";
+        for (size_t i = 0; i < v.ints.size(); i++) {
+            if (i) o += ",";
+            snprintf(b, sizeof(b), "%lld", (long long)v.ints[i]);
+            o += b;
+        }
+        o += "]";
+        break;
+    case Value::kFloatVec:
+        o += "[";
+        for (size_t i = 0; i < v.floats.size(); i++) {
+            if (i) o += ",";
+            snprintf(b, sizeof(b), "%.17g", v.floats[i]);
+            o += b;
+        }
+        o += "]";
+        break;
+    }
+}
+
+}  // namespace gob
+}  // namespace sybl

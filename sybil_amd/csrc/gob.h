@@ -1,0 +1,55 @@
+// gob.h -- a small decoder for Go's encoding/gob wire format, enough to read what sybil
+// writes with gob.NewEncoder(...).Encode(struct): table info.db (table_io.go:72-78), block
+// info.db (column_store_io.go:308-358) and the int_/str_/set_ column files
+// (column_store.go:22-74).  Format notes: SURVEY.md 8c "gob wire format".
+//
+// The decoder is schema-driven: it reads the wireType definitions that precede the value
+// and builds a generic tree, so field order / omitted zero fields / extra fields in newer
+// files do not matter.  Slices of Go int/uint kinds decode into flat int64 vectors (the
+// record-id and value arrays are the bulk of every column file).  Interface-typed values
+// do not occur in those files and are rejected.
+#pragma once
+#include <stdint.h>
+
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace sybl {
+namespace gob {
+
+struct Value;
+typedef std::shared_ptr<Value> ValuePtr;
+
+struct Value {
+    enum Kind { kNil, kBool, kInt, kUint, kFloat, kString, kStruct, kSlice, kMap, kIntVec, kFloatVec };
+    Kind kind = kNil;
+    int64_t i = 0;    // kBool / kInt
+    uint64_t u = 0;   // kUint
+    double f = 0;     // kFloat
+    std::string s;    // kString / bytes
+    std::vector<std::pair<std::string, ValuePtr>> fields;  // kStruct (only fields present on the wire)
+    std::vector<ValuePtr> items;                           // kSlice
+    std::vector<std::pair<ValuePtr, ValuePtr>> entries;    // kMap
+    std::vector<int64_t> ints;                             // kIntVec
+    std::vector<double> floats;                            // kFloatVec
+    std::string type_name;
+
+    const Value *field(const char *name) const;  // nullptr when the (zero-valued) field was omitted
+    int64_t as_int(int64_t dflt = 0) const;
+    bool as_bool() const { return as_int(0) != 0; }
+};
+
+// Decodes the first top-level value of a gob stream.  Returns false and sets err on failure.
+bool decode(const uint8_t *data, size_t size, Value &out, std::string &err);
+
+// Reads a file, transparently gunzipping "*.gz" (or trying "<path>.gz" when <path> is missing,
+// like GetFileDecoder, file_decoder.go:55-81).
+bool read_file(const std::string &path, std::vector<uint8_t> &out, std::string &err);
+
+// JSON rendering of a decoded tree (struct field order = wire order); used by tests.
+void to_json(const Value &v, std::string &out);
+
+}  // namespace gob
+}  // namespace sybl

@@ -113,7 +113,10 @@ __device__ __forceinline__ void load_tile(CPlan &P, int64_t row, bool in_range, 
         CSlot &s = P.slot[c];
         ll2 v = {0, 0};
         uint32_t pop = 0;
-        if (in_range) {
+        if (in_range && (s.flags & kSlotSet)) {
+            pop = 3u;
+            if (s.valid) pop = (s.valid[row >> 5] >> (row & 31)) & 3u;
+        } else if (in_range) {
             if (s.flags & kSlotW32) {
                 i32x2 w = __builtin_nontemporal_load((const i32x2 *)((const int32_t *)s.base + row));
                 v.x = w.x;
@@ -130,7 +133,7 @@ __device__ __forceinline__ void load_tile(CPlan &P, int64_t row, bool in_range, 
 }
 
 template <int NC, bool USE_LDS>
-__device__ __forceinline__ void process_tile(CPlan &P, const Tile<NC> &t, int nvalid, int64_t *sumtab,
+__device__ __forceinline__ void process_tile(CPlan &P, const Tile<NC> &t, int64_t row0, int nvalid, int64_t *sumtab,
                                              int64_t *maxtab, int rep, int64_t &matched, int64_t &overflow) {
     const int rs = USE_LDS ? P.rep_shift : 0;
 #pragma unroll
@@ -149,6 +152,22 @@ __device__ __forceinline__ void process_tile(CPlan &P, const Tile<NC> &t, int nv
             if (s.flags & kSlotNeq) {
                 pass = pass && pop;
                 for (int k = 0; k < s.n_neq; k++) pass = pass && x != s.neq[k];
+            }
+            if (s.flags & kSlotSet) {
+                // SetFilter.Filter, filter.go:252-285: "in" = some member equals the id, "nin" = none;
+                // a row without the set column fails both
+                bool ok = pop;
+                if (pop) {
+                    const int64_t *off = (const int64_t *)s.base;
+                    const int64_t lo = off[row0 + r], hi = off[row0 + r + 1];
+                    uint32_t hit = 0;
+                    for (int64_t m = lo; m < hi; m++) {
+                        const int32_t id = s.set_vals[m];
+                        for (int p = 0; p < s.n_setp; p++) hit |= (id == s.set_id[p] ? 1u : 0u) << p;
+                    }
+                    for (int p = 0; p < s.n_setp; p++) ok = ok && (((hit >> p) & 1u) == (uint32_t)s.set_in[p]);
+                }
+                pass = pass && ok;
             }
             if (s.flags & kSlotIdMask) {
                 bool ok = false;
@@ -288,7 +307,7 @@ __global__ __launch_bounds__(kWgThreads) void k_scan(CPlan *Pp) {
             load_tile<NC>(P, nrow, nrow < end, nxt);  // prefetch: HBM latency hides under the LDS work
             int64_t left = end - row;
             int nvalid = left >= kRowsPerThread ? kRowsPerThread : (left > 0 ? (int)left : 0);
-            process_tile<NC, USE_LDS>(P, cur, nvalid, sumtab, maxtab, rep, matched, overflow);
+            process_tile<NC, USE_LDS>(P, cur, row, nvalid, sumtab, maxtab, rep, matched, overflow);
             cur = nxt;
             row = nrow;
         }
@@ -430,6 +449,119 @@ __global__ __launch_bounds__(256) void k_block_minmax(const T *__restrict__ col,
         out_max[blockIdx.x] = mx;
         out_pop[blockIdx.x] = pc;
     }
+}
+
+// ---------------------------------------------------------------- column decode (TableBlock load)
+// unpackIntCol / unpackStrCol, column_store_io.go:493-609,690-780, as kernels: the gob stream is
+// parsed on the host (varints are a byte-serial format), the compact decoded form -- per-bin
+// value + delta-encoded ascending record ids, or a delta-encoded value array -- crosses PCIe,
+// and the un-delta + scatter into the dense column happens here.
+
+__device__ __forceinline__ uint32_t block_inclusive_scan_256(uint32_t v, uint32_t *wave_tot /*[4]*/, uint32_t &total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t u = __shfl_up(v, o, 64);
+        if (lane >= o) v += u;
+    }
+    if (lane == 63) wave_tot[wave] = v;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int w = 0; w < wave; w++) base += wave_tot[w];
+    total = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+    __syncthreads();
+    return v + base;
+}
+
+// One workgroup per bin: record ids are ascending and (optionally) delta-encoded
+// (delta_encode_col, column_store_io.go:21-30); every listed row gets the bin's value.
+template <typename T>
+__global__ __launch_bounds__(256) void k_decode_bins(const uint32_t *__restrict__ recs, const int64_t *__restrict__ bin_off,
+                                                     const int64_t *__restrict__ bin_val, int delta_encoded,
+                                                     T *__restrict__ col, uint32_t *__restrict__ valid, uint32_t nrows) {
+    __shared__ uint32_t wave_tot[4];
+    const int64_t b0 = bin_off[blockIdx.x], b1 = bin_off[blockIdx.x + 1];
+    const T value = (T)bin_val[blockIdx.x];
+    uint32_t carry = 0;
+    for (int64_t base = b0; base < b1; base += 256) {
+        const int64_t i = base + threadIdx.x;
+        uint32_t d = i < b1 ? recs[i] : 0u;
+        uint32_t r = d;
+        if (delta_encoded) {
+            uint32_t total;
+            r = carry + block_inclusive_scan_256(d, wave_tot, total);
+            carry += total;
+        }
+        if (i < b1 && r < nrows) {
+            col[r] = value;
+            if (valid) atomicOr(&valid[r >> 5], 1u << (r & 31));
+        }
+    }
+}
+
+// Value-encoded int column: Values[r] is a delta from Values[r-1] (column_store_io.go:109-113,748-777).
+// One workgroup of 1024 threads owns the whole block (<= 65536 rows in the reference).
+__global__ __launch_bounds__(1024) void k_decode_delta(const int64_t *__restrict__ deltas, int64_t n, int value_encoded,
+                                                       int64_t *__restrict__ col) {
+    __shared__ int64_t wave_tot[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int64_t carry = 0;
+    for (int64_t base = 0; base < n; base += 1024) {
+        const int64_t i = base + threadIdx.x;
+        int64_t v = i < n ? deltas[i] : 0;
+        if (value_encoded) {
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                int64_t u = __shfl_up(v, o, 64);
+                if (lane >= o) v += u;
+            }
+            if (lane == 63) wave_tot[wave] = v;
+            __syncthreads();
+            int64_t pre = 0, total = 0;
+            for (int w = 0; w < 16; w++) {
+                if (w < wave) pre += wave_tot[w];
+                total += wave_tot[w];
+            }
+            v += pre + carry;
+            carry += total;
+            __syncthreads();
+        }
+        if (i < n) col[i] = v;
+    }
+}
+
+// Per-row block-local dictionary ids -> table-global ids (non-bucket str columns)
+__global__ __launch_bounds__(256) void k_remap_ids(const int32_t *__restrict__ local, const int32_t *__restrict__ lut,
+                                                   int32_t n_lut, int64_t n, int32_t *__restrict__ col) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int32_t id = local[i];
+    col[i] = (id >= 0 && id < n_lut) ? lut[id] : 0;
+}
+
+hipError_t launch_decode_bins(const uint32_t *recs, const int64_t *bin_off, const int64_t *bin_val, int n_bins,
+                              bool delta_encoded, void *col, bool w32, uint32_t *valid, uint32_t nrows, hipStream_t st) {
+    if (n_bins <= 0) return hipSuccess;
+    if (w32) {
+        hipLaunchKernelGGL((k_decode_bins<int32_t>), dim3(n_bins), dim3(256), 0, st, recs, bin_off, bin_val,
+                           delta_encoded ? 1 : 0, (int32_t *)col, valid, nrows);
+    } else {
+        hipLaunchKernelGGL((k_decode_bins<int64_t>), dim3(n_bins), dim3(256), 0, st, recs, bin_off, bin_val,
+                           delta_encoded ? 1 : 0, (int64_t *)col, valid, nrows);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_decode_delta(const int64_t *deltas, int64_t n, bool value_encoded, int64_t *col, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_decode_delta, dim3(1), dim3(1024), 0, st, deltas, n, value_encoded ? 1 : 0, col);
+    return hipGetLastError();
+}
+
+hipError_t launch_remap_ids(const int32_t *local, const int32_t *lut, int32_t n_lut, int64_t n, int32_t *col, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_remap_ids, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, local, lut, n_lut, n, col);
+    return hipGetLastError();
 }
 
 // ---------------------------------------------------------------- launchers (host)

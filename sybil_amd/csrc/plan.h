@@ -27,6 +27,7 @@ enum SlotFlags : uint32_t {
     kSlotTime = 1u << 5,    // time column (aggregate.go:146-183)
     kSlotWeight = 1u << 6,  // weight column (aggregate.go:100-102)
     kSlotW32 = 1u << 7,     // stored as int32 (str dictionary ids)
+    kSlotSet = 1u << 8,     // set column: base = CSR offsets per physical row, filters in setp[]
     kSlotFilter = kSlotRange | kSlotNeq | kSlotIdMask,
 };
 
@@ -44,7 +45,11 @@ struct SlotDesc {
     int32_t gstride;
     int32_t gmissing;        // (gcard-1)*gstride when the column has missing rows, else -1
     int32_t agg_index;
-    int32_t pad_;
+    // kSlotSet (filter.go:252-285): predicate p passes when (any member == set_id[p]) == set_in[p]
+    int32_t n_setp;
+    const int32_t *set_vals;  // CSR member ids (table-global dictionary)
+    int32_t set_id[kMaxNeq];
+    int32_t set_in[kMaxNeq];
 };
 
 struct AggDesc {

@@ -152,6 +152,10 @@ class Table:
         return N.lib().sybl_table_blocks(self._h)
 
     @property
+    def broken_blocks(self):
+        return N.lib().sybl_table_broken_blocks(self._h)
+
+    @property
     def hbm_bytes(self):
         return N.lib().sybl_table_hbm_bytes(self._h)
 

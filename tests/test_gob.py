@@ -1,0 +1,123 @@
+"""Pins the Python gob encoder/decoder (tests/gobfmt.py) and, through it, the fixtures the
+native loader is tested with, against the reference's golden gob file
+(src/lib/testdata/TestDecodeGoldenFiles/flag_defs.golden.gob, decoding_test.go:20-74; copied
+verbatim to tests/golden/ -- it is test data, 941 bytes)."""
+import json
+import os
+
+from tests import gobfmt as G
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_decode_golden_flag_defs_matches_golden_json():
+    data = open(os.path.join(GOLD, "flag_defs.golden.gob"), "rb").read()
+    v, order = G.decode(data, want_types=True)
+    want = json.load(open(os.path.join(GOLD, "flag_defs.golden.json")))
+    assert order == [(65, "struct", "FlagDefs")]
+    # Go re-marshals nil pointers as null; gob omitted them
+    assert v == {k: x for k, x in want.items() if x is not None}
+
+
+def test_reencode_golden_flag_defs_byte_exact():
+    """Decode the golden stream, rebuild the struct type from its own type definition, encode it
+    with our Encoder: the bytes must equal Go's (PrintBytes appends '\\n', printer.go:272-282)."""
+    data = open(os.path.join(GOLD, "flag_defs.golden.gob"), "rb").read()
+    v = G.decode(data)
+    # recover the field list (name, type id) from the definition message
+    h = G.Reader(data)
+    n = h.uint()
+    r = G.Reader(data, h.p, h.p + n)
+    assert r.int() == -65
+    td = G._read_wiretype(r)
+    basic = {G.BOOL: G.Bool, G.INT: G.Int, G.UINT: G.Uint, G.FLOAT: G.Float, G.STRING: G.String}
+    t = G.Struct(td["name"], [(fname, basic[fid]) for fname, fid in td["fields"]])
+    assert G.encode(t, v) + b"\n" == data
+
+
+def test_primitives():
+    assert G.enc_uint(0) == b"\x00" and G.enc_uint(127) == b"\x7f" and G.enc_uint(850) == b"\xfe\x03\x52"
+    assert G.enc_int(-1) == b"\x01" and G.enc_int(1) == b"\x02" and G.enc_int(-129) == b"\xfe\x01\x01"
+    assert G.enc_float(17.0) == b"\xfe\x31\x40"       # gob doc: 17.0 -> fe 31 40
+    for x in (0, 1, -1, 2 ** 40, -2 ** 40, 2 ** 62, -2 ** 63):
+        assert G.Reader(G.enc_int(x)).int() == x
+    for x in (0.0, 1.5, -2.25e300, 3.141592653589793):
+        assert G.Reader(G.enc_float(x)).float() == x
+
+
+def test_round_trip_column_structs():
+    col = {"Name": "age", "DeltaEncodedIDs": True, "BucketEncoded": True, "VERSION": 1,
+           "Bins": [{"Value": -5, "Records": [0, 1, 1]}, {"Value": 1 << 50, "Records": [1, 7]}]}
+    data = G.encode(G.saved_int_column(), col)
+    v, order = G.decode(data, want_types=True)
+    assert v == col
+    # id allocation follows encoding/gob: struct ids at creation, slice ids after their element
+    assert [o[0] for o in order] == [65, 68, 66, 67, 69]
+    assert dict((o[0], o[2]) for o in order) == {65: "SavedIntColumn", 66: "SavedIntBucket", 67: "[]uint32",
+                                                  68: "[]sybil.SavedIntBucket", 69: "[]int64"}
+    sc = {"Name": "tags", "Values": [[1, 2], [], [3]], "StringTable": ["a", "b", "c", "d"], "VERSION": 1}
+    assert G.decode(G.encode(G.saved_set_column(), sc)) == {k: v for k, v in sc.items()}
+    info = {"NumRecords": 100, "IntInfoMap": {"age": {"Min": 10, "Max": 29, "Avg": 19.5, "M2": 3.25, "Count": 100}}}
+    assert G.decode(G.encode(G.saved_column_info(), info)) == info
+
+
+# ---- the library's C++ gob reader (csrc/gob.cpp) through the sybl_debug_gob_to_json hook
+
+def _cxx_json(path):
+    from sybil_amd import _native as N
+    s = N.lib().sybl_debug_gob_to_json(path.encode())
+    assert s is not None, N.lib().sybl_last_error()
+    return json.loads(s)
+
+
+def test_cxx_reader_on_golden_flag_defs():
+    got = _cxx_json(os.path.join(GOLD, "flag_defs.golden.gob"))
+    want = json.load(open(os.path.join(GOLD, "flag_defs.golden.json")))
+    assert got == {k: x for k, x in want.items() if x is not None}
+
+
+def test_cxx_reader_on_fixture_column_files(tmp_path):
+    import numpy as np
+    from tests import sybil_fixture as F
+    rng = np.random.default_rng(0)
+    n = 3000
+    vals = rng.integers(-1000, 1 << 45, size=n)
+    pop = rng.random(n) > 0.1
+    strs = [None if rng.random() < 0.1 else "s%d" % rng.integers(0, 40) for _ in range(n)]
+    sets = [None if rng.random() < 0.2 else ["t%d" % x for x in rng.integers(0, 9, size=rng.integers(1, 4))] for _ in range(n)]
+    for gz in (False, True):
+        for thr in (5000, 10):   # bucket-encoded and value-encoded variants
+            root = str(tmp_path / ("t_%s_%d" % (gz, thr)))
+            F.write_table(root, "tab", [{"v": ("int", vals, pop), "s": ("str", strs), "z": ("set", sets)}], gz=gz, threshold=thr)
+            bdir = os.path.join(root, "tab", "block000000001")
+            for fname, schema in (("int_v.db", G.saved_int_column), ("str_s.db", G.saved_str_column),
+                                  ("set_z.db", G.saved_set_column), ("info.db", G.saved_column_info)):
+                path = os.path.join(bdir, fname)
+                raw = open(path + ".gz", "rb").read() if gz else open(path, "rb").read()
+                if gz:
+                    import gzip
+                    raw = gzip.decompress(raw)
+                want = G.decode(raw)
+                got = _cxx_json(path)
+                # the C++ reader renders maps as [[k, v], ...]
+                def norm(x):
+                    if isinstance(x, dict):
+                        return {k: norm(v) for k, v in x.items()}
+                    if isinstance(x, list):
+                        if x and all(isinstance(p, list) and len(p) == 2 and not isinstance(p[0], (list, dict)) for p in x) \
+                                and fname == "info.db":
+                            return {str(p[0]): norm(p[1]) for p in x}
+                        return [norm(v) for v in x]
+                    return x
+                assert norm(got) == norm(want), (fname, gz, thr)
+            tinfo = _cxx_json(os.path.join(root, "tab", "info.db"))
+            assert tinfo["Name"] == "tab" and sorted(k for k, _ in tinfo["KeyTable"]) == ["s", "v", "z"]
+
+
+def test_cxx_reader_rejects_garbage(tmp_path):
+    from sybil_amd import _native as N
+    p = tmp_path / "bad.db"
+    p.write_bytes(b"\x05\xff\x81\x03\x01")
+    assert N.lib().sybl_debug_gob_to_json(str(p).encode()) is None
+    assert b"gob" in N.lib().sybl_last_error()
+    assert N.lib().sybl_debug_gob_to_json(str(tmp_path / "missing.db").encode()) is None
