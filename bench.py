@@ -80,6 +80,8 @@ def main():
     ap.add_argument("--rows", type=int, default=0, help="total rows (default: the workload's BASELINE size)")
     ap.add_argument("--workload", default="cfg3_filter3_group2_stddev")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="take the N>1 code path (process group, bound partial tables, all-reduce) even with one rank")
     ap.add_argument("--collective", choices=["torch", "rccl"], default="torch",
                     help="torch.distributed (RCCL backend) or the library's own RCCL communicator")
     args = ap.parse_args()
@@ -98,9 +100,11 @@ def main():
         args.gpus = world
     torch.cuda.set_device(local_rank)
     device = "cuda:%d" % local_rank
-    if world > 1:
+    multi = world > 1 or args.force_dist
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(device))
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
 
     wl = synth.WORKLOADS[args.workload]
     names, q = wl["columns"], wl["query"]
@@ -120,7 +124,7 @@ def main():
         hi = a + 4 * (b - 1) if kind == synth.BELL else a + b - 1
         table.set_bounds(n, a, hi)
     query = table.query(**q)
-    if world > 1:
+    if multi:
         if args.collective == "torch":
             query.bind_torch(device)
             # run the engine on torch's current stream: scan -> all-reduce -> finalize are then
@@ -135,7 +139,7 @@ def main():
 
     def step():
         query.scan()
-        if world > 1:
+        if multi:
             if args.collective == "torch":
                 query.allreduce_torch()
             else:
@@ -151,7 +155,7 @@ def main():
     def fence():
         ctx.sync()
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -171,7 +175,7 @@ def main():
             res = r
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         tmax = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -191,7 +195,7 @@ def main():
             "dtype": "int64", "data": "synthetic",
             "config": {"workload": args.workload, "reference_flags": wl["flags"], "rows": total_rows,
                        "table_columns": wl["table_cols"], "resident_columns": names, "bytes_per_row": bytes_per_row,
-                       "sharding": "contiguous 65536-row blocks per rank", "collective": args.collective if world > 1 else None,
+                       "sharding": "contiguous 65536-row blocks per rank", "collective": args.collective if multi else None,
                        "device": dev["name"], "matched_rows": res.matched if res is not None else None,
                        "groups": len(res.results) if res is not None else None,
                        "strategy": {0: "lds-generic", 1: "global-atomics", 2: "lds-fast"}[stats["strategy"]],
@@ -209,10 +213,10 @@ def main():
         res.free()
     query.free()
     table.free()
-    if world > 1 and args.collective == "rccl":
+    if multi and args.collective == "rccl":
         ctx.comm_free()
     ctx.close()
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 
