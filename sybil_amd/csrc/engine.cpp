@@ -94,6 +94,7 @@ static void free_query(Query *q) {
     if (q->d_plan) hipFree(q->d_plan);
     if (q->d_segs) hipFree(q->d_segs);
     if (q->d_wg_seg_begin) hipFree(q->d_wg_seg_begin);
+    if (q->d_wg_cell_base) hipFree(q->d_wg_cell_base);
     for (void *p : q->d_idmasks) hipFree(p);
     if (q->own_partials) {
         if (q->d_sum) hipFree(q->d_sum);
@@ -647,6 +648,56 @@ static int plan_query(Table *t, const sybl_query_desc *d, Query *q) {
         }
         q->wg_seg_begin[(size_t)q->n_wg] = (int32_t)q->segs.size();
     }
+    // ---- LDS-window strategy: a time-series table too large for LDS, scanned by workgroups whose
+    // contiguous rows each span only a few time buckets (tables are digested in time order,
+    // table_io.go:119-122 sorts by Timestamp).  Exact per-block extrema of the time column give
+    // every workgroup its window.
+    P.windowed = 0;
+    P.lds_cells = (int32_t)n_cells;
+    P.wg_cell_base = nullptr;
+    if (!q->use_lds && q->time_mode && !getenv("SYBL_NO_WINDOW") && !t->blocks.empty()) {
+        const Column *tc = t->cols[(size_t)slot_col[(size_t)P.time_slot]].get();
+        std::vector<int32_t> base((size_t)q->n_wg, 0);
+        int64_t wmax = 1;
+        bool ok = true;
+        for (int w = 0; w < q->n_wg && ok; w++) {
+            int64_t lo = INT64_MAX, hi = INT64_MIN;
+            for (int32_t si = q->wg_seg_begin[(size_t)w]; si < q->wg_seg_begin[(size_t)w + 1]; si++) {
+                const Segment &sg = q->segs[(size_t)si];
+                // first block whose end is beyond the segment start
+                size_t b = (size_t)(std::upper_bound(t->blocks.begin(), t->blocks.end(), sg.start,
+                                                     [](int64_t v, const Segment &blk) { return v < blk.start + blk.n; }) -
+                                    t->blocks.begin());
+                for (; b < t->blocks.size() && t->blocks[b].start < sg.start + sg.n; b++) {
+                    if (tc->blk_pop[b] == 0) continue;
+                    lo = std::min(lo, tc->blk_min[b]);
+                    hi = std::max(hi, tc->blk_max[b]);
+                }
+            }
+            if (hi < lo) continue;  // no populated time value: every row is dropped anyway
+            int64_t tlo = lo / d->time_bucket - P.tb_min, thi = hi / d->time_bucket - P.tb_min;
+            if (tlo < 0 || thi >= P.n_tb) {
+                ok = false;  // declared bounds narrower than the data: the kernel would count overflow
+                break;
+            }
+            base[(size_t)w] = (int32_t)(tlo * cells);
+            wmax = std::max(wmax, thi - tlo + 1);
+        }
+        int64_t lds_cells = wmax * cells;
+        if (ok && lds_cells * (F + M) * 8 <= kLdsBudgetBytes) {
+            q->use_lds = true;
+            P.windowed = 1;
+            P.lds_cells = (int32_t)lds_cells;
+            int rs = 0;
+            int64_t words = lds_cells * (F + M);
+            while (rs < 6 && (words * 8 << (rs + 1)) <= kLdsBudgetBytes) rs++;
+            P.rep_shift = rs;
+            q->lds_bytes = (size_t)(words * 8) << rs;
+            SYBL_HIP(hipMalloc((void **)&q->d_wg_cell_base, base.size() * 4));
+            SYBL_HIP(hipMemcpy(q->d_wg_cell_base, base.data(), base.size() * 4, hipMemcpyHostToDevice));
+            P.wg_cell_base = q->d_wg_cell_base;
+        }
+    }
     q->stats.rows_scanned = rows_scanned;
     q->stats.blocks_skipped = skipped;
     q->stats.blocks_scanned = (int64_t)t->blocks.size() - skipped;
@@ -663,7 +714,7 @@ static int plan_query(Table *t, const sybl_query_desc *d, Query *q) {
     }
     q->stats.algorithmic_bytes = rows_scanned * width + set_bytes;
     q->stats.n_cells = (int32_t)n_cells;
-    q->stats.strategy = q->use_lds ? (q->fast ? 2 : 0) : 1;
+    q->stats.strategy = q->use_lds ? (P.windowed ? 3 : (q->fast ? 2 : 0)) : 1;
     q->stats.lds_bytes = (int32_t)q->lds_bytes;
     q->stats.n_workgroups = q->n_wg;
     q->stats.replicas = 1 << P.rep_shift;
@@ -679,7 +730,7 @@ static int plan_query(Table *t, const sybl_query_desc *d, Query *q) {
     SYBL_HIP(hipMemcpy(q->d_wg_seg_begin, q->wg_seg_begin.data(), q->wg_seg_begin.size() * 4, hipMemcpyHostToDevice));
     P.segs = q->d_segs;
     P.wg_seg_begin = q->d_wg_seg_begin;
-    if (q->use_lds) {
+    if (q->use_lds && !P.windowed) {
         SYBL_HIP(hipMalloc((void **)&q->d_ws_sum, (size_t)q->n_wg * F * n_cells * 8));
         SYBL_HIP(hipMalloc((void **)&q->d_ws_max, (size_t)q->n_wg * std::max<int64_t>((int64_t)M * n_cells, 1) * 8));
         P.ws_sum = q->d_ws_sum;
@@ -720,7 +771,7 @@ static int scan(Query *q) {
     }
     const bool ran = !q->never_matches && !q->segs.empty();
     hipError_t e = hipSuccess;
-    if (q->use_lds && ran) {
+    if (q->use_lds && ran && !P.windowed) {
         // the fold overwrites every cell field; only the header and the bucket arrays accumulate
         SYBL_HIP(hipMemsetAsync(q->d_sum, 0, (size_t)kHeaderWords * 8, st));
         if (P.hist_stride > 0)
@@ -744,7 +795,7 @@ static int scan(Query *q) {
         }
     }
     SYBL_HIP(hipEventRecord(q->ev[1], st));
-    if (q->use_lds && ran) {
+    if (q->use_lds && ran && !P.windowed) {
         int64_t wsum = (int64_t)P.n_sum_fields * P.n_cells, wmax = (int64_t)P.n_max_fields * P.n_cells;
         e = launch_fold(q->d_ws_sum, q->d_sum + kHeaderWords, wsum, q->d_ws_max, q->d_max, wmax, q->n_wg, st);
         if (e != hipSuccess) return hip_fail(e, "k_fold");

@@ -159,6 +159,7 @@ struct Query {
     std::vector<int32_t> wg_seg_begin;
     Segment *d_segs = nullptr;
     int32_t *d_wg_seg_begin = nullptr;
+    int32_t *d_wg_cell_base = nullptr;
     std::vector<void *> d_idmasks;
     int64_t n_sum_words = 0, n_max_words = 0;
     int64_t *d_sum = nullptr, *d_max = nullptr;

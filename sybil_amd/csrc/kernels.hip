@@ -134,7 +134,8 @@ __device__ __forceinline__ void load_tile(CPlan &P, int64_t row, bool in_range, 
 
 template <int NC, bool USE_LDS>
 __device__ __forceinline__ void process_tile(CPlan &P, const Tile<NC> &t, int64_t row0, int nvalid, int64_t *sumtab,
-                                             int64_t *maxtab, int rep, int64_t &matched, int64_t &overflow) {
+                                             int64_t *maxtab, int rep, int32_t cell_base, int64_t &matched,
+                                             int64_t &overflow) {
     const int rs = USE_LDS ? P.rep_shift : 0;
 #pragma unroll
     for (int r = 0; r < kRowsPerThread; r++) {
@@ -218,9 +219,16 @@ __device__ __forceinline__ void process_tile(CPlan &P, const Tile<NC> &t, int64_
             continue;
         }
 
-        const int64_t ncell = P.n_cells;
-        // field f of cell: ((f * n_cells + cell) << rep_shift) + rep
-        const int64_t cidx = ((int64_t)cell << rs) + rep;
+        // the table this lane accumulates into: the whole cell table, or (LDS window) the
+        // lds_cells cells starting at the workgroup's base
+        const int64_t ncell = USE_LDS ? P.lds_cells : P.n_cells;
+        const int32_t lcell = cell - cell_base;
+        if ((uint32_t)lcell >= (uint32_t)ncell) {
+            overflow += 1;
+            continue;
+        }
+        // field f of cell: ((f * ncell + lcell) << rep_shift) + rep
+        const int64_t cidx = ((int64_t)lcell << rs) + rep;
         acc_add<USE_LDS>(sumtab, cidx, w);  // Result.Count += weight (aggregate.go:203)
         if (P.f_samples >= 0) acc_add<USE_LDS>(sumtab, ((int64_t)P.f_samples * ncell << rs) + cidx, 1);
 
@@ -277,8 +285,10 @@ __global__ __launch_bounds__(kWgThreads) void k_scan(CPlan *Pp) {
     CPlan &P = *Pp;
     extern __shared__ int64_t lds[];
     const int tid = threadIdx.x;
-    const int64_t words_sum = (int64_t)P.n_sum_fields * P.n_cells;
-    const int64_t words_max = (int64_t)P.n_max_fields * P.n_cells;
+    const int64_t tab_cells = USE_LDS ? P.lds_cells : P.n_cells;
+    const int64_t words_sum = (int64_t)P.n_sum_fields * tab_cells;
+    const int64_t words_max = (int64_t)P.n_max_fields * tab_cells;
+    const int32_t cell_base = (USE_LDS && P.windowed) ? P.wg_cell_base[blockIdx.x] : 0;
     int64_t *sumtab, *maxtab;
     int rep = 0;
     if (USE_LDS) {
@@ -307,7 +317,7 @@ __global__ __launch_bounds__(kWgThreads) void k_scan(CPlan *Pp) {
             load_tile<NC>(P, nrow, nrow < end, nxt);  // prefetch: HBM latency hides under the LDS work
             int64_t left = end - row;
             int nvalid = left >= kRowsPerThread ? kRowsPerThread : (left > 0 ? (int)left : 0);
-            process_tile<NC, USE_LDS>(P, cur, row, nvalid, sumtab, maxtab, rep, matched, overflow);
+            process_tile<NC, USE_LDS>(P, cur, row, nvalid, sumtab, maxtab, rep, cell_base, matched, overflow);
             cur = nxt;
             row = nrow;
         }
@@ -324,6 +334,30 @@ __global__ __launch_bounds__(kWgThreads) void k_scan(CPlan *Pp) {
         // fold the lane replicas and publish this workgroup's table (plain stores, no atomics)
         __syncthreads();
         const int R = 1 << P.rep_shift;
+        if (P.windowed) {
+            // flush the window into the global table: only touched cells, device-scope atomics
+            int64_t *gs = P.sum_out + kHeaderWords;
+            for (int64_t i = tid; i < words_sum; i += kWgThreads) {
+                int64_t a = 0;
+                for (int k = 0; k < R; k++) a += sumtab[(i << P.rep_shift) + k];
+                if (a != 0) {
+                    const int64_t f = i / tab_cells, c = i - f * tab_cells;
+                    gadd(gs + f * P.n_cells + cell_base + c, a);
+                }
+            }
+            for (int64_t i = tid; i < words_max; i += kWgThreads) {
+                int64_t a = INT64_MIN;
+                for (int k = 0; k < R; k++) {
+                    int64_t b = maxtab[(i << P.rep_shift) + k];
+                    a = b > a ? b : a;
+                }
+                if (a != INT64_MIN) {
+                    const int64_t f = i / tab_cells, c = i - f * tab_cells;
+                    __hip_atomic_fetch_max(P.max_out + f * P.n_cells + cell_base + c, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            return;
+        }
         int64_t *ws = P.ws_sum + (int64_t)blockIdx.x * words_sum;
         for (int64_t i = tid; i < words_sum; i += kWgThreads) {
             int64_t a = 0;

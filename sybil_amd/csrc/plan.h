@@ -98,6 +98,12 @@ struct ScanPlan {
     int32_t n_max_fields;    // M: [M][n_cells] int64 (MAX-combined)
     int32_t f_samples;       // -1 unless weighted
     int32_t rep_shift;       // LDS replicas = 1 << rep_shift
+    // LDS-window strategy (time-sorted tables): each workgroup's rows span only a few time
+    // buckets, so its LDS table covers cells [wg_cell_base[wg], +lds_cells) of the global table
+    // and is flushed with atomics at the end instead of being folded.
+    int32_t windowed;
+    int32_t lds_cells;       // cells per LDS table (== n_cells unless windowed)
+    const int32_t *wg_cell_base;
     int64_t hist_off;        // word offset of bucket arrays in the SUM section
     int64_t hist_stride;     // words per cell = sum of n_values over full-hist aggs
     int64_t hist_agg_off[kMaxAggs];

@@ -12,8 +12,11 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <stdlib.h>
+
 #include <algorithm>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "engine.h"
@@ -86,7 +89,7 @@ static void percentiles_from_values(const int64_t *values, int64_t n_values, int
 }
 
 static void agg_finish(const Query *q, Result *R, const AggInfo &ai, const AggAcc &a, int64_t row_count, sybl_agg_out &o,
-                       const int64_t *&values_out, int64_t &pct_off) {
+                       const int64_t *&values_out, int64_t &pct_off, int64_t pct_slot) {
     memset(&o, 0, sizeof(o));
     values_out = nullptr;
     pct_off = -1;
@@ -125,8 +128,7 @@ static void agg_finish(const Query *q, Result *R, const AggInfo &ai, const AggAc
     if (q->want_percentiles && a.values) {
         values_out = a.values;
         if (cnt != 0) {
-            pct_off = (int64_t)R->pct_pool.size();
-            R->pct_pool.resize(R->pct_pool.size() + 100);
+            pct_off = pct_slot;  // pre-sized pool: one 100-entry slot per (row, agg)
             percentiles_from_values(a.values, A.n_values, A.bucket_size, A.hmin, cnt, R->pct_pool.data() + pct_off);
         }
         // GetStdDev, hist_basic.go:192-219, with Avg = sum/count
@@ -189,14 +191,12 @@ static void build_key(const Query *q, int64_t gcell, uint8_t *key, std::string &
     }
 }
 
+// Writes row `row` whose pool slot (agg_off) was assigned by the caller; thread safe because
+// every pool is pre-sized and rows own disjoint slots.
 static void finish_row(const Query *q, Result *R, const CellAcc &acc, RowStore &row) {
     row.count = acc.count;
     row.samples = acc.samples;
     size_t na = q->aggs.size();
-    row.agg_off = (int64_t)R->agg_pool.size();
-    R->agg_pool.resize(R->agg_pool.size() + na);
-    R->val_pool.resize(R->val_pool.size() + na);
-    R->pctoff_pool.resize(R->pctoff_pool.size() + na);
     for (size_t a = 0; a < na; a++) {
         size_t k = (size_t)row.agg_off + a;
         if (!acc.has_aggs) {
@@ -205,7 +205,7 @@ static void finish_row(const Query *q, Result *R, const CellAcc &acc, RowStore &
             R->pctoff_pool[k] = -1;
             continue;
         }
-        agg_finish(q, R, q->aggs[a], acc.aggs[a], acc.count, R->agg_pool[k], R->val_pool[k], R->pctoff_pool[k]);
+        agg_finish(q, R, q->aggs[a], acc.aggs[a], acc.count, R->agg_pool[k], R->val_pool[k], R->pctoff_pool[k], (int64_t)k * 100);
     }
 }
 
@@ -315,74 +315,139 @@ int query_finalize(Query *q, Result **out) {
         all_count.assign((size_t)gcells, 0);
         all_samples.assign((size_t)gcells, 0);
     }
-    // count the live cells first so the row vectors are allocated once
+    // pass 1 (serial, cheap): the live cells, and in time-series mode the all-time Count/Samples
+    std::vector<int64_t> live;
     {
-        size_t live = 0;
         const int64_t *E = P.f_samples >= 0 ? F + (int64_t)P.f_samples * ncell : F;
-        for (int64_t cell = 0; cell < ncell; cell++) live += E[cell] != 0;
-        R->rows[q->time_mode ? 1 : 0].reserve(live);
-        if (q->want_percentiles) R->pct_pool.reserve((live + 1) * na * 100);
-        size_t nrows_all = live + 1 + (q->time_mode ? (size_t)gcells : 0);
-        R->agg_pool.reserve(nrows_all * na);
-        R->val_pool.reserve(nrows_all * na);
-        R->pctoff_pool.reserve(nrows_all * na);
+        size_t n_live = 0;
+        for (int64_t cell = 0; cell < ncell; cell++) n_live += E[cell] != 0;
+        live.reserve(n_live);
+        for (int64_t cell = 0; cell < ncell; cell++)
+            if (E[cell] != 0) live.push_back(cell);
     }
+    std::vector<int64_t> alltime;  // group cells with any row (time-series mode)
+    if (q->time_mode) {
+        for (int64_t cell : live) {
+            int64_t gcell = cell % gcells;
+            all_count[(size_t)gcell] += F[cell];
+            all_samples[(size_t)gcell] += P.f_samples >= 0 ? F[(int64_t)P.f_samples * ncell + cell] : F[cell];
+        }
+        for (int64_t g = 0; g < gcells; g++)
+            if (q->weighted ? all_samples[(size_t)g] != 0 : all_count[(size_t)g] != 0) alltime.push_back(g);
+    }
+    std::vector<RowStore> &cell_rows = R->rows[q->time_mode ? 1 : 0];
+    cell_rows.resize(live.size());
+    const size_t n_all_rows = live.size() + alltime.size() + 1;
+    R->agg_pool.resize(n_all_rows * na);
+    R->val_pool.resize(n_all_rows * na);
+    R->pctoff_pool.resize(n_all_rows * na);
+    if (q->want_percentiles) R->pct_pool.resize(n_all_rows * na * 100);
 
-    CellAcc acc;
-    for (int64_t cell = 0; cell < ncell; cell++) {
-        if (!load_cell(cell, acc)) continue;
-        int64_t tbi = cell / gcells, gcell = cell - tbi * gcells;
-        auto &dst = R->rows[q->time_mode ? 1 : 0];
-        dst.emplace_back();
-        RowStore &row = dst.back();
-        build_key(q, gcell, row.key, row.gbk);
-        if (q->time_mode) {
-            row.time_bucket = (P.tb_min + tbi) * P.time_bucket;
-            all_count[(size_t)gcell] += acc.count;
-            all_samples[(size_t)gcell] += acc.samples;
+    // pass 2: one row per live cell.  Rows own disjoint pool slots, so ranges of cells are
+    // finished by worker threads when there are enough of them to pay for the threads.
+    auto work = [&](size_t i0, size_t i1, CellAcc *tot, std::vector<std::vector<int64_t>> *tot_vals) {
+        CellAcc acc;
+        for (size_t i = i0; i < i1; i++) {
+            const int64_t cell = live[i];
+            load_cell(cell, acc);
+            const int64_t tbi = cell / gcells, gcell = cell - tbi * gcells;
+            RowStore &row = cell_rows[i];
+            row.agg_off = (int64_t)(i * na);
+            build_key(q, gcell, row.key, row.gbk);
+            if (q->time_mode) row.time_bucket = (P.tb_min + tbi) * P.time_bucket;
             finish_row(q, R, acc, row);
-        } else {
-            finish_row(q, R, acc, row);
-            for (size_t a = 0; a < na; a++) {
-                AggAcc &d = total.aggs[a];
-                const AggAcc &s = acc.aggs[a];
-                d.cnt += s.cnt;
-                d.smp += s.smp;
-                d.sum += s.sum;
-                d.sb += s.sb;
-                d.sb2 += s.sb2;
-                d.n_out += s.n_out;
-                d.sum_out += s.sum_out;
-                for (int k = 0; k < 4; k++) d.sq[k] += s.sq[k];
-                d.vmax = std::max(d.vmax, s.vmax);
-                d.nmin = std::max(d.nmin, s.nmin);
-                if (s.values) {
-                    int64_t *tv = R->total_vals[a].data();
-                    for (int64_t k = 0; k < q->aggs[a].d.n_values; k++) tv[k] += s.values[k];
+            if (!q->time_mode) {
+                for (size_t a = 0; a < na; a++) {
+                    AggAcc &d = tot->aggs[a];
+                    const AggAcc &s = acc.aggs[a];
+                    d.cnt += s.cnt;
+                    d.smp += s.smp;
+                    d.sum += s.sum;
+                    d.sb += s.sb;
+                    d.sb2 += s.sb2;
+                    d.n_out += s.n_out;
+                    d.sum_out += s.sum_out;
+                    for (int k = 0; k < 4; k++) d.sq[k] += s.sq[k];
+                    d.vmax = std::max(d.vmax, s.vmax);
+                    d.nmin = std::max(d.nmin, s.nmin);
+                    if (s.values) {
+                        int64_t *tv = (*tot_vals)[a].data();
+                        for (int64_t k = 0; k < q->aggs[a].d.n_values; k++) tv[k] += s.values[k];
+                    }
                 }
             }
+            tot->count += acc.count;
+            tot->samples += acc.samples;
         }
-        total.count += acc.count;
-        total.samples += acc.samples;
+    };
+    size_t n_threads = 1;
+    {
+        // cost estimate: buckets touched per row dominate in full-histogram mode
+        size_t per_row = 64 + (size_t)(q->want_percentiles ? P.hist_stride * 3 : 0);
+        size_t cost = live.size() * per_row;
+        unsigned hw = std::thread::hardware_concurrency();
+        size_t cap = std::min<size_t>(hw ? hw : 1, 32);
+        if (const char *e = getenv("SYBL_FINALIZE_THREADS")) cap = (size_t)std::max(1, atoi(e));
+        n_threads = std::max<size_t>(1, std::min(cap, cost / (1u << 20)));
     }
+    if (n_threads <= 1) {
+        work(0, live.size(), &total, &R->total_vals);
+    } else {
+        std::vector<CellAcc> part(n_threads);
+        std::vector<std::vector<std::vector<int64_t>>> part_vals(n_threads);
+        std::vector<std::thread> th;
+        for (size_t k = 0; k < n_threads; k++) {
+            part[k].has_aggs = total.has_aggs;
+            part_vals[k].resize(na);
+            for (size_t a = 0; a < na; a++) {
+                part[k].aggs[a].tracked_cnt = true;
+                if (!R->total_vals[a].empty()) part_vals[k][a].assign(R->total_vals[a].size(), 0);
+            }
+            size_t i0 = live.size() * k / n_threads, i1 = live.size() * (k + 1) / n_threads;
+            th.emplace_back(work, i0, i1, &part[k], &part_vals[k]);
+        }
+        for (auto &x : th) x.join();
+        for (size_t k = 0; k < n_threads; k++) {
+            total.count += part[k].count;
+            total.samples += part[k].samples;
+            for (size_t a = 0; a < na; a++) {
+                AggAcc &d = total.aggs[a];
+                const AggAcc &s2 = part[k].aggs[a];
+                d.cnt += s2.cnt;
+                d.smp += s2.smp;
+                d.sum += s2.sum;
+                d.sb += s2.sb;
+                d.sb2 += s2.sb2;
+                d.n_out += s2.n_out;
+                d.sum_out += s2.sum_out;
+                for (int j = 0; j < 4; j++) d.sq[j] += s2.sq[j];
+                d.vmax = std::max(d.vmax, s2.vmax);
+                d.nmin = std::max(d.nmin, s2.nmin);
+                for (size_t j = 0; j < part_vals[k][a].size(); j++) R->total_vals[a][j] += part_vals[k][a][j];
+            }
+        }
+    }
+    size_t next_slot = live.size();
     if (q->time_mode) {
         // all-time Results carry Count/Samples only (aggregate.go:156-169)
-        for (int64_t g = 0; g < gcells; g++) {
-            bool exists = q->weighted ? all_samples[(size_t)g] != 0 : all_count[(size_t)g] != 0;
-            if (!exists) continue;
-            R->rows[0].emplace_back();
-            RowStore &row = R->rows[0].back();
+        R->rows[0].resize(alltime.size());
+        for (size_t i = 0; i < alltime.size(); i++) {
+            const int64_t g = alltime[i];
+            RowStore &row = R->rows[0][i];
+            row.agg_off = (int64_t)((next_slot + i) * na);
             build_key(q, g, row.key, row.gbk);
             CellAcc a2;
             a2.count = all_count[(size_t)g];
             a2.samples = all_samples[(size_t)g];
             finish_row(q, R, a2, row);
         }
+        next_slot += alltime.size();
     }
     // Cumulative, aggregate.go:422-438
     {
         R->rows[2].emplace_back();
         RowStore &row = R->rows[2].back();
+        row.agg_off = (int64_t)(next_slot * na);
         memset(row.key, 0, sizeof(row.key));
         row.gbk = "TOTAL";
         for (size_t g = 1; g < q->groups.size(); g++) row.gbk += "\t";
