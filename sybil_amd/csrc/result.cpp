@@ -11,6 +11,7 @@
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
+#include <time.h>
 
 #include <stdlib.h>
 
@@ -732,19 +733,68 @@ const char *sybl_result_render(sybl_result *r, int format) {
             }
             o += "}";
         } else {
+            // printTimeResults text form (printer.go:64-107): every row is written through a
+            // text/tabwriter (minwidth 0, tabwidth 1, padding 0, padchar ' ', AlignRight) as
+            //   Fprintln(w, time_str, "\t", Count, "\t", GroupByKey, "\t"[, agg, "\t", avg, "\t"])
+            // (Fprintln puts a space between operands); time_str = time.Unix(bucket, 0) in
+            // OPTS.TIME_FORMAT "2006-01-02 15:04:05.999999999 -0700 MST" (config.go:127), local zone.
+            std::vector<std::string> lines;
+            auto time_str = [](int64_t tb) {
+                time_t tt = (time_t)tb;
+                struct tm tmv;
+                localtime_r(&tt, &tmv);
+                char b[96];
+                strftime(b, sizeof(b), "%Y-%m-%d %H:%M:%S %z %Z", &tmv);
+                return std::string(b);
+            };
             for (auto &row : R->rows[1]) {
-                char line[512];
-                if (R->agg_names.empty()) {
-                    snprintf(line, sizeof(line), "%lld %lld %s\n", (long long)row.time_bucket, (long long)row.count, row.gbk.c_str());
-                    o += line;
-                }
+                std::string head = time_str(row.time_bucket) + " \t " + std::to_string((long long)row.count) + " \t " + row.gbk + " \t";
+                bool any = false;
                 for (size_t a = 0; a < R->agg_names.size(); a++) {
                     const sybl_agg_out &g = R->agg_pool[(size_t)row.agg_off + a];
                     if (!g.present) continue;
-                    snprintf(line, sizeof(line), "%lld %lld %s %s %.2f\n", (long long)row.time_bucket, (long long)row.count,
-                             row.gbk.c_str(), R->agg_names[a].c_str(), g.avg);
-                    o += line;
+                    char avg[64];
+                    snprintf(avg, sizeof(avg), "%.2f", g.avg);
+                    lines.push_back(head + " " + R->agg_names[a] + " \t " + avg + " \t");
+                    any = true;
                 }
+                if (!any) lines.push_back(head);  // len(r.Hists) == 0
+            }
+            // tabwriter: cells end at a tab; a column's width is the widest cell of the
+            // contiguous run of lines that have that column; AlignRight pads on the left
+            std::vector<std::vector<std::string>> cells(lines.size());
+            std::vector<std::string> tail(lines.size());
+            size_t maxcols = 0;
+            for (size_t i = 0; i < lines.size(); i++) {
+                size_t pos = 0;
+                for (;;) {
+                    size_t e = lines[i].find('\t', pos);
+                    if (e == std::string::npos) break;
+                    cells[i].push_back(lines[i].substr(pos, e - pos));
+                    pos = e + 1;
+                }
+                tail[i] = lines[i].substr(pos);
+                maxcols = std::max(maxcols, cells[i].size());
+            }
+            std::vector<std::vector<size_t>> width(lines.size());
+            for (size_t i = 0; i < lines.size(); i++) width[i].assign(cells[i].size(), 0);
+            for (size_t c = 0; c < maxcols; c++) {
+                size_t i = 0;
+                while (i < lines.size()) {
+                    if (cells[i].size() <= c) { i++; continue; }
+                    size_t j = i, w = 0;
+                    while (j < lines.size() && cells[j].size() > c) { w = std::max(w, cells[j][c].size()); j++; }
+                    for (size_t k = i; k < j; k++) width[k][c] = w;
+                    i = j;
+                }
+            }
+            for (size_t i = 0; i < lines.size(); i++) {
+                for (size_t c = 0; c < cells[i].size(); c++) {
+                    o.append(width[i][c] - cells[i][c].size(), ' ');
+                    o += cells[i][c];
+                }
+                o += tail[i];
+                o += "\n";
             }
         }
         return o.c_str();

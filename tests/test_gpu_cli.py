@@ -1,0 +1,130 @@
+"""GPU: the output surface (`sybil query` text / -json formats, src/lib/printer.go:25-308) through
+the sybil-gpu-query CLI (tools/sybil_gpu_query.cpp), which accepts the reference's query flags
+(src/cmd/cmd_query.go:19-74).  Expected strings are derived by hand from printer.go's format
+verbs; numeric content is checked against the CPU oracle."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests import sybil_fixture as F
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "sybil_amd", "sybil-gpu-query")
+
+
+def _run(*args, tz="UTC"):
+    env = dict(os.environ, TZ=tz)
+    p = subprocess.run([CLI] + list(args), stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=120)
+    assert p.returncode == 0, p.stderr.decode()
+    return p.stdout.decode()
+
+
+@pytest.fixture(scope="module")
+def db(tmp_path_factory):
+    root = str(tmp_path_factory.mktemp("clidb"))
+    # two blocks of a tiny, fully known table
+    b1 = {"browser": ("str", ["edge", "edge", "gecko", "webkit", "gecko", "edge"]),
+          "load": ("int", np.array([100, 300, 50, 1000, 150, 200])),
+          "time": ("int", np.array([1700000000, 1700000100, 1700003700, 1700003800, 1700007300, 1700007400])),
+          "tags": ("set", [["a"], ["a", "b"], None, ["b"], ["c"], ["a", "c"]])}
+    b2 = {"browser": ("str", ["webkit", "gecko", "edge", "edge"]),
+          "load": ("int", np.array([400, 250, 500, 600])),
+          "time": ("int", np.array([1700007500, 1700010900, 1700011000, 1700011100])),
+          "tags": ("set", [["b"], ["a"], None, ["c"]])}
+    F.write_table(root, "pages", [b1, b2], int_info={"load": (0, 1000)})
+    return root
+
+
+def test_text_avg(db):
+    out = _run("-dir", db, "-table", "pages", "-group", "browser", "-int", "load")
+    # printSortedResults: TOTAL first (more than one result), groups by Count desc; printResult:
+    # "%-20s"[:20] key, "%.0d" count, then "  %5s" name and "%.2f" mean (printer.go:183-232)
+    assert out == ("TOTAL               10\n"
+                   "   load 355.00\n"
+                   "edge                5\n"
+                   "   load 340.00\n"
+                   "gecko               3\n"
+                   "   load 150.00\n"
+                   "webkit              2\n"
+                   "   load 700.00\n")
+
+
+def test_text_hist_and_filters(db):
+    out = _run("-dir", db, "-table", "pages", "-group", "browser", "-int", "load", "-op", "hist",
+               "-int-filter", "load:gt:99,load:lt:601", "-set-filter", "tags:nin:b")
+    lines = out.splitlines()
+    # edge rows passing: 100, 200 (tags a / a,c) + 600 (c); 300 has tag b, 500 has no tags -> nin fails
+    # gecko: 150 (c), 250 (a);  webkit: 1000 filtered by lt, 400 has b
+    assert lines[0].startswith("TOTAL               5")
+    assert lines[2] == "edge                3" and lines[4] == "gecko               2"
+    # Info [0,1000] -> BucketSize 1: percentiles are exact values; "  load | p0 p99 | avg | p0 p25 p50 p75 p99 | std"
+    assert lines[3] == "   load | 100 600 | 300.00 | 100 100 200 600 600 | 216.02"
+    assert lines[5] == "   load | 150 250 | 200.00 | 150 150 250 250 250 | 50.00"
+
+
+def test_json_hist(db, oracle):
+    out = _run("-dir", db, "-table", "pages", "-group", "browser", "-int", "load", "-op", "hist", "-json", "-limit", "2")
+    rows = json.loads(out)
+    assert [r["browser"] for r in rows] == ["edge", "gecko"]        # sorted by count, limited to 2
+    e = rows[0]
+    assert e["Count"] == 5 and e["Samples"] == 5
+    h = e["load"]
+    assert sorted(h) == ["avg", "buckets", "percentiles", "samples", "stddev", "sum"]   # toResultJSON, printer.go:109-125
+    assert h["avg"] == 340.0 and h["sum"] == 1700.0 and h["samples"] == 5
+    assert h["buckets"] == {"100": 1, "200": 1, "300": 1, "500": 1, "600": 1}
+    assert len(h["percentiles"]) == 100 and h["percentiles"][0] == 100 and h["percentiles"][99] == 600
+    ref = oracle.Hist(0, 1000, "hist")
+    for v in (100, 300, 200, 500, 600):
+        ref.add(v)
+    assert h["stddev"] == pytest.approx(ref.info()["stddev_ref"], rel=1e-9)
+    assert list(ref.percentiles()) == h["percentiles"]
+    # encoding/json writes map keys sorted and floats in shortest form
+    assert out.startswith('[{"Count":5,"Samples":5,"browser":"edge","load":{"avg":340,"buckets":{"100":1,')
+
+
+def test_json_avg_and_no_groups(db):
+    rows = json.loads(_run("-dir", db, "-table", "pages", "-int", "load", "-json"))
+    assert rows == [{"Count": 10, "Samples": 10, "load": 355}]
+    rows = json.loads(_run("-dir", db, "-table", "pages", "-group", "browser", "-json", "-str-filter", "browser:re:^e"))
+    assert rows == [{"Count": 5, "Samples": 5, "browser": "edge"}]
+    rows = json.loads(_run("-dir", db, "-table", "pages", "-group", "browser", "-json", "-str-filter", "browser:neq:edge",
+                           "-sort-asc"))
+    assert [(r["browser"], r["Count"]) for r in rows] == [("webkit", 2), ("gecko", 3)]
+
+
+def test_time_series_json_and_text(db):
+    out = _run("-dir", db, "-table", "pages", "-time", "-time-col", "time", "-time-bucket", "3600", "-group", "browser",
+               "-int", "load", "-json")
+    got = json.loads(out)
+    # buckets: truncating division of the timestamp (aggregate.go:174)
+    assert sorted(got) == ["1699999200", "1700002800", "1700006400", "1700010000"]
+    first = {r["browser"]: r for r in got["1699999200"]}
+    assert first == {"edge": {"Count": 2, "Samples": 2, "browser": "edge", "load": 200}}
+    assert {r["browser"]: r["Count"] for r in got["1700006400"]} == {"gecko": 1, "edge": 1, "webkit": 1}
+    text = _run("-dir", db, "-table", "pages", "-time", "-time-bucket", "3600", "-group", "browser", "-int", "load")
+    lines = text.splitlines()
+    assert len(lines) == 8
+    # Fprintln gives "<time> \t <count> \t <key>\t \t <agg> \t <avg> \t"; tabwriter (AlignRight, padding 0)
+    # right-aligns each tab-terminated cell to its column's widest cell: " edge" -> 7 (" webkit"),
+    # " 200.00 " -> 9 (" 1000.00 ")
+    assert lines[0] == "2023-11-14 22:00:00 +0000 UTC  2    edge  load   200.00 "
+    assert "2023-11-14 23:00:00 +0000 UTC  1  webkit  load  1000.00 " in lines
+    assert "2023-11-14 23:00:00 +0000 UTC  1   gecko  load    50.00 " in lines
+    assert all(l.startswith("2023-11-1") for l in lines)
+    # a time filter is aligned down to its bucket in a time-series query (filter.go:86-95)
+    got2 = json.loads(_run("-dir", db, "-table", "pages", "-time", "-time-bucket", "3600", "-group", "browser", "-json",
+                           "-int-filter", "time:gt:1700006500"))
+    assert sorted(got2) == ["1700006400", "1700010000"]
+
+
+def test_cli_errors(db):
+    p = subprocess.run([CLI, "-dir", db, "-table", "nope"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 1 and b"open table" in p.stderr
+    p = subprocess.run([CLI, "-dir", db, "-table", "pages", "-bogus"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 2 and b"flag provided but not defined" in p.stderr
+    p = subprocess.run([CLI, "-dir", db, "-table", "pages", "-group", "tags"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 1 and b"set column" in p.stderr

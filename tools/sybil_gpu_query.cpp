@@ -1,0 +1,191 @@
+// sybil-gpu-query -- `sybil query` on the MI355X engine.
+//
+// A stand-in for the reference CLI's query subcommand (src/cmd/cmd_query.go:19-372) for hosts
+// without a Go toolchain: same flag names and defaults, same output formats, but the scan runs
+// through the sybl_* C ABI (include/sybilgpu.h) instead of LoadAndQueryRecords.  With a Go
+// toolchain the real CLI gets the same effect through the cgo shim in INTEGRATION.md.
+//
+//   sybil-gpu-query -dir db -table events -group browser,device -int pageload -op hist
+//       -int-filter "pageload:gt:100" -json
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <map>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "../include/sybilgpu.h"
+
+static std::vector<std::string> split(const std::string &s, const std::string &sep) {
+    std::vector<std::string> out;
+    if (s.empty()) return out;
+    size_t pos = 0;
+    for (;;) {
+        size_t e = sep.empty() ? std::string::npos : s.find(sep, pos);
+        out.push_back(s.substr(pos, e == std::string::npos ? std::string::npos : e - pos));
+        if (e == std::string::npos) break;
+        pos = e + sep.size();
+    }
+    return out;
+}
+
+static int die(const char *what) {
+    fprintf(stderr, "sybil-gpu-query: %s: %s\n", what, sybl_last_error());
+    return 1;
+}
+
+int main(int argc, char **argv) {
+    // flag defaults: src/cmd/cmd_query.go:19-74, src/lib/config.go:147-176
+    std::map<std::string, std::string> f = {
+        {"dir", "./db/"}, {"table", ""}, {"op", "avg"}, {"limit", "100"}, {"print", "true"}, {"json", "false"},
+        {"sort", "$COUNT"}, {"sort-asc", "false"}, {"time", "false"}, {"time-col", "time"}, {"time-bucket", "3600"},
+        {"weight-col", ""}, {"int-filter", ""}, {"str-filter", ""}, {"set-filter", ""}, {"int-bucket", "0"},
+        {"int", ""}, {"str", ""}, {"set", ""}, {"group", ""}, {"field-separator", ","}, {"filter-separator", ":"},
+        {"device", "0"}, {"block-skip", "true"}, {"stats", "false"}};
+    const std::set<std::string> bools = {"print", "json", "sort-asc", "time", "block-skip", "stats"};
+    for (int i = 1; i < argc; i++) {
+        std::string a = argv[i];
+        if (a.size() < 2 || a[0] != '-') {
+            fprintf(stderr, "unexpected argument %s\n", a.c_str());
+            return 2;
+        }
+        a = a.substr(a[1] == '-' ? 2 : 1);
+        std::string val;
+        size_t eq = a.find('=');
+        bool has_val = eq != std::string::npos;
+        if (has_val) {
+            val = a.substr(eq + 1);
+            a = a.substr(0, eq);
+        }
+        if (!f.count(a)) {
+            fprintf(stderr, "flag provided but not defined: -%s\n", a.c_str());
+            return 2;
+        }
+        if (bools.count(a)) {
+            f[a] = has_val ? val : "true";
+        } else {
+            if (!has_val) {
+                if (i + 1 >= argc) {
+                    fprintf(stderr, "flag needs an argument: -%s\n", a.c_str());
+                    return 2;
+                }
+                val = argv[++i];
+            }
+            f[a] = val;
+        }
+    }
+    auto on = [&](const char *k) { return f[k] == "true" || f[k] == "1"; };
+    if (f["table"].empty()) {
+        fprintf(stderr, "no table specified (-table)\n");
+        return 2;
+    }
+    const std::string fs = f["field-separator"], ps = f["filter-separator"];
+    std::vector<std::string> ints = split(f["int"], fs), groups = split(f["group"], fs);
+
+    // ---- filters (BuildFilters, filter.go:59-139)
+    struct Filt {
+        std::string col, op, val;
+        int kind;
+    };
+    std::vector<Filt> filts;
+    const char *fkeys[3] = {"int-filter", "str-filter", "set-filter"};
+    for (int k = 0; k < 3; k++)
+        for (auto &spec : split(f[fkeys[k]], fs)) {
+            std::vector<std::string> tok = split(spec, ps);
+            if (tok.size() < 3) {
+                fprintf(stderr, "bad filter '%s' (want col%sop%sval)\n", spec.c_str(), ps.c_str(), ps.c_str());
+                return 2;
+            }
+            filts.push_back({tok[0], tok[1], tok[2], k});
+        }
+    const int64_t time_bucket = atoll(f["time-bucket"].c_str());
+
+    // ---- the columns the query references (the LoadSpec, table_load_spec.go:59-73)
+    std::vector<std::string> cols;
+    auto use = [&](const std::string &c) {
+        for (auto &x : cols)
+            if (x == c) return;
+        if (!c.empty()) cols.push_back(c);
+    };
+    for (auto &c : ints) use(c);
+    for (auto &c : groups) use(c);
+    for (auto &x : filts) use(x.col);
+    if (on("time")) use(f["time-col"]);
+    use(f["weight-col"]);
+
+    sybl_ctx *ctx = nullptr;
+    if (sybl_init(atoi(f["device"].c_str()), &ctx)) return die("init");
+    sybl_table *tab = nullptr;
+    std::vector<const char *> cptr;
+    for (auto &c : cols) cptr.push_back(c.c_str());
+    if (sybl_table_open(ctx, f["dir"].c_str(), f["table"].c_str(), cptr.empty() ? nullptr : cptr.data(), (int32_t)cptr.size(), 0, 1,
+                        &tab))
+        return die("open table");
+
+    static const std::map<std::string, int> opcode = {{"gt", SYBL_OP_GT}, {"lt", SYBL_OP_LT}, {"eq", SYBL_OP_EQ},
+                                                      {"neq", SYBL_OP_NEQ}, {"re", SYBL_OP_RE}, {"nre", SYBL_OP_NRE},
+                                                      {"in", SYBL_OP_IN}, {"nin", SYBL_OP_NIN}};
+    std::vector<sybl_filter> cf(filts.size());
+    for (size_t i = 0; i < filts.size(); i++) {
+        memset(&cf[i], 0, sizeof(sybl_filter));
+        cf[i].col = filts[i].col.c_str();
+        auto it = opcode.find(filts[i].op);
+        cf[i].op = it == opcode.end() ? -1 : it->second;  // unknown op: the filter matches nothing, like the reference
+        if (filts[i].kind == 0) {
+            int64_t v = strtoll(filts[i].val.c_str(), nullptr, 10);
+            // a time filter is aligned down to the bucket in a time-series query (filter.go:86-95)
+            if (on("time") && filts[i].col == f["time-col"] && time_bucket > 0) v = v / time_bucket * time_bucket;
+            cf[i].int_value = v;
+        } else {
+            cf[i].str_value = filts[i].val.c_str();
+        }
+    }
+    std::vector<const char *> gptr, aptr;
+    for (auto &g : groups) gptr.push_back(g.c_str());
+    for (auto &a : ints) aptr.push_back(a.c_str());
+    sybl_query_desc d;
+    memset(&d, 0, sizeof(d));
+    d.n_filters = (int32_t)cf.size();
+    d.filters = cf.empty() ? nullptr : cf.data();
+    d.n_groups = (int32_t)gptr.size();
+    d.groups = gptr.empty() ? nullptr : gptr.data();
+    d.n_aggs = (int32_t)aptr.size();
+    d.aggs = aptr.empty() ? nullptr : aptr.data();
+    d.op = f["op"] == "hist" ? SYBL_AGG_HIST : SYBL_AGG_AVG;
+    d.hist_bucket = atoll(f["int-bucket"].c_str());
+    d.want_percentiles = 1;  // both printers output percentiles in hist mode
+    if (on("time")) {
+        d.time_col = f["time-col"].c_str();
+        d.time_bucket = time_bucket;
+    }
+    d.weight_col = f["weight-col"].empty() ? nullptr : f["weight-col"].c_str();
+    d.order_by = f["sort"].c_str();
+    d.order_asc = on("sort-asc");
+    d.limit = atoi(f["limit"].c_str());
+    d.block_skip = on("block-skip");
+
+    sybl_query *q = nullptr;
+    if (sybl_query_prepare(tab, &d, &q)) return die("prepare");
+    if (sybl_query_scan(q)) return die("scan");
+    sybl_result *res = nullptr;
+    if (sybl_query_finalize(q, &res)) return die("finalize");
+    if (on("print")) {
+        const char *out = sybl_result_render(res, on("json") ? 1 : 0);
+        if (!out) return die("render");
+        fputs(out, stdout);
+    }
+    if (on("stats")) {
+        sybl_run_stats st;
+        sybl_query_stats(q, &st);
+        fprintf(stderr, "rows=%lld blocks=%lld skipped=%lld scan_ms=%.3f GB/s=%.1f strategy=%d\n", (long long)st.rows_scanned,
+                (long long)st.blocks_scanned, (long long)st.blocks_skipped, st.scan_ms,
+                st.scan_ms > 0 ? st.algorithmic_bytes / (st.scan_ms * 1e-3) / 1e9 : 0.0, st.strategy);
+    }
+    sybl_result_free(res);
+    sybl_query_free(q);
+    sybl_table_free(tab);
+    sybl_shutdown(ctx);
+    return 0;
+}
