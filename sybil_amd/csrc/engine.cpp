@@ -133,7 +133,8 @@ static void select_fast_path(Table *t, Query *q, const std::vector<int> &slot_co
     q->fast = false;
     const ScanPlan &P = q->plan;
     if (getenv("SYBL_NO_FAST")) return;
-    if (!q->use_lds || q->time_mode || q->weighted) return;
+    if (!q->use_lds || q->weighted) return;
+    if (q->time_mode && P.tb_big_div) return;
     FastPlan &FP = q->fplan;
     memset(&FP, 0, sizeof(FP));
     int nf = 0, ng = 0, na = 0;
@@ -144,8 +145,9 @@ static void select_fast_path(Table *t, Query *q, const std::vector<int> &slot_co
         const Column *c = t->cols[(size_t)slot_col[s]].get();
         if (c->type != SYBL_INT_VAL || c->elem != 8 || c->d_valid || c->has_missing) return;
         uint32_t roles = sd.flags & (kSlotFilter | kSlotGroup | kSlotAgg);
-        if (sd.flags & (kSlotNeq | kSlotIdMask | kSlotTime | kSlotWeight | kSlotW32)) return;
+        if (sd.flags & (kSlotNeq | kSlotIdMask | kSlotWeight | kSlotW32 | kSlotSet)) return;
         if (roles != kSlotRange && roles != kSlotGroup && roles != kSlotAgg && roles != 0) return;  // one role per column
+        if ((sd.flags & kSlotTime) && roles != 0) return;  // the time column plays no second role here
         (void)folds;
     }
     for (size_t s = 0; s < slot_col.size(); s++) {
@@ -199,7 +201,18 @@ static void select_fast_path(Table *t, Query *q, const std::vector<int> &slot_co
         FP.hist_agg_off[na] = P.hist_agg_off[na];
         na++;
     }
-    if (nf + ng + na == 0) return;  // nothing to stream: the generic kernel picks a driver column
+    if (nf + ng + na == 0 && !q->time_mode) return;  // nothing to stream: the generic kernel picks a driver column
+    if (q->time_mode) {
+        FP.tcol = (const int64_t *)P.slot[P.time_slot].base;
+        FP.time_bucket = P.time_bucket;
+        FP.inv_time_bucket = P.inv_time_bucket;
+        FP.tb_min = P.tb_min;
+        FP.n_tb = P.n_tb;
+        FP.tb_stride = P.tb_stride;
+    }
+    FP.windowed = P.windowed;
+    FP.lds_cells = P.lds_cells;
+    FP.wg_cell_base = P.wg_cell_base;
     int mode;
     if (q->op == SYBL_AGG_HIST) {
         mode = q->want_percentiles ? kFastHist : kFastMoments;
@@ -218,8 +231,6 @@ static void select_fast_path(Table *t, Query *q, const std::vector<int> &slot_co
     q->fast_ng = ng;
     q->fast_na = na;
     q->fast_mode = mode;
-    const char *pf = getenv("SYBL_FAST_PREFETCH");
-    q->fast_prefetch = pf ? atoi(pf) != 0 : true;
 }
 
 static int plan_query(Table *t, const sybl_query_desc *d, Query *q) {
@@ -599,7 +610,6 @@ static int plan_query(Table *t, const sybl_query_desc *d, Query *q) {
         P.rep_shift = rs;
         q->lds_bytes = (size_t)(lds_words * 8) << rs;
     }
-    select_fast_path(t, q, slot_col, folds);
     q->n_sum_words = kHeaderWords + (int64_t)F * n_cells + n_cells * hist_stride;
     q->n_max_words = std::max<int64_t>((int64_t)M * n_cells, 1);
 
@@ -698,6 +708,7 @@ static int plan_query(Table *t, const sybl_query_desc *d, Query *q) {
             P.wg_cell_base = q->d_wg_cell_base;
         }
     }
+    select_fast_path(t, q, slot_col, folds);
     q->stats.rows_scanned = rows_scanned;
     q->stats.blocks_skipped = skipped;
     q->stats.blocks_scanned = (int64_t)t->blocks.size() - skipped;
@@ -714,7 +725,7 @@ static int plan_query(Table *t, const sybl_query_desc *d, Query *q) {
     }
     q->stats.algorithmic_bytes = rows_scanned * width + set_bytes;
     q->stats.n_cells = (int32_t)n_cells;
-    q->stats.strategy = q->use_lds ? (P.windowed ? 3 : (q->fast ? 2 : 0)) : 1;
+    q->stats.strategy = q->use_lds ? (P.windowed ? (q->fast ? 4 : 3) : (q->fast ? 2 : 0)) : 1;
     q->stats.lds_bytes = (int32_t)q->lds_bytes;
     q->stats.n_workgroups = q->n_wg;
     q->stats.replicas = 1 << P.rep_shift;
@@ -786,7 +797,7 @@ static int scan(Query *q) {
         if (q->fast) {
             q->fplan.sum_out = q->d_sum;
             q->fplan.max_out = q->d_max;
-            e = launch_scan_fast(q->fplan, q->fast_nf, q->fast_ng, q->fast_na, q->fast_mode, q->fast_prefetch, q->n_wg,
+            e = launch_scan_fast(q->fplan, q->fast_nf, q->fast_ng, q->fast_na, q->fast_mode, q->time_mode, q->n_wg,
                                  q->lds_bytes, st);
             if (e != hipSuccess) return hip_fail(e, "k_scan_fast");
         } else {

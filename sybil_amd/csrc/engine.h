@@ -171,7 +171,7 @@ struct Query {
     sybl_run_stats stats{};
     bool never_matches = false;
     // role-specialised kernel (scan_fast.h)
-    bool fast = false, fast_prefetch = true;
+    bool fast = false;
     int fast_nf = 0, fast_ng = 0, fast_na = 0, fast_mode = 0;
     FastPlan fplan;
 };

@@ -3,9 +3,9 @@
 
 namespace sybl {
 
-hipError_t launch_scan_fast_nf4(const FastPlan &P, int ng, int na, int mode, bool prefetch, int n_wg, size_t lds,
+hipError_t launch_scan_fast_nf4(const FastPlan &P, int ng, int na, int mode, bool time, int n_wg, size_t lds,
                                 hipStream_t st) {
-    return fast_launch_nf<4>(P, ng, na, mode, prefetch, n_wg, lds, st);
+    return fast_launch_nf<4>(P, ng, na, mode, time, n_wg, lds, st);
 }
 
 }  // namespace sybl

@@ -43,12 +43,19 @@ struct FastPlan {
     int64_t hist_agg_off[kFastMaxA];
     int64_t hist_off, hist_stride;
     int32_t n_cells, n_sum_fields, n_max_fields, rep_shift;
+    // time series (aggregate.go:146-183) and the per-workgroup LDS window over time buckets
+    const int64_t *tcol;
+    int64_t time_bucket, tb_min;
+    double inv_time_bucket;
+    int32_t n_tb, tb_stride;
+    int32_t windowed, lds_cells;   // lds_cells == n_cells unless windowed
+    const int32_t *wg_cell_base;
     int64_t *sum_out, *max_out, *ws_sum, *ws_max;
     const Segment *segs;
     const int32_t *wg_seg_begin;
 };
 
-hipError_t launch_scan_fast(const FastPlan &P, int nf, int ng, int na, int mode, bool prefetch, int n_wg,
+hipError_t launch_scan_fast(const FastPlan &P, int nf, int ng, int na, int mode, bool time, int n_wg,
                             size_t lds_bytes, hipStream_t st);
 
 #ifdef __HIPCC__
@@ -60,9 +67,10 @@ struct FastTile {
     fll2 v[N > 0 ? N : 1];
 };
 
-template <int NF, int NG, int NA>
+template <int NF, int NG, int NA, bool TIME>
 __device__ __forceinline__ void fast_load(const FastPlan &P, int64_t row, FastTile<NF> &f, FastTile<NG> &g,
-                                          FastTile<NA> &a) {
+                                          FastTile<NA> &a, FastTile<1> &t) {
+    if (TIME) t.v[0] = __builtin_nontemporal_load((const fll2 *)(P.tcol + row));
 #pragma unroll
     for (int c = 0; c < NF; c++) f.v[c] = __builtin_nontemporal_load((const fll2 *)(P.fcol[c] + row));
 #pragma unroll
@@ -75,10 +83,11 @@ __device__ __forceinline__ void lds_add64(int64_t *lds, uint32_t idx, int64_t v)
     __hip_atomic_fetch_add(lds + idx, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-template <int NF, int NG, int NA, int MODE>
+template <int NF, int NG, int NA, int MODE, bool TIME>
 __device__ __forceinline__ void fast_row(const FastPlan &P, const FastTile<NF> &f, const FastTile<NG> &g,
-                                         const FastTile<NA> &a, const int r, int64_t *lds, const uint32_t rep,
-                                         const uint32_t max_base, uint32_t &matched, uint32_t &overflow) {
+                                         const FastTile<NA> &a, const FastTile<1> &t, const int r, int64_t *lds,
+                                         const uint32_t rep, const uint32_t max_base, const uint32_t cell_base,
+                                         uint32_t &matched, uint32_t &overflow) {
     bool pass = true;
 #pragma unroll
     for (int c = 0; c < NF; c++) {
@@ -96,13 +105,29 @@ __device__ __forceinline__ void fast_row(const FastPlan &P, const FastTile<NF> &
         inb = inb && d < (uint64_t)P.gcard[c];
         cell += (uint32_t)d * (uint32_t)P.gstride[c];  // aggregate.go:125-143 as a direct-mapped index
     }
-    if (!inb) {
+    if (TIME) {
+        // val = int(val) / TimeBucket * TimeBucket, truncating (aggregate.go:174); |t| < 2^51 here
+        const int64_t tv = r == 0 ? t.v[0].x : t.v[0].y;
+        const uint64_t ut = tv < 0 ? (uint64_t)0 - (uint64_t)tv : (uint64_t)tv;
+        uint64_t qd = (uint64_t)((double)ut * P.inv_time_bucket);
+        const int64_t rem = (int64_t)(ut - qd * (uint64_t)P.time_bucket);
+        if (rem < 0) {
+            qd -= 1;
+        } else if (rem >= P.time_bucket) {
+            qd += 1;
+        }
+        const int64_t tb = (tv < 0 ? -(int64_t)qd : (int64_t)qd) - P.tb_min;
+        inb = inb && (uint64_t)tb < (uint64_t)P.n_tb;
+        cell += (uint32_t)tb * (uint32_t)P.tb_stride;
+    }
+    const uint32_t ncell = (uint32_t)P.lds_cells;
+    const uint32_t lcell = cell - cell_base;  // position inside this workgroup's LDS table
+    if (!inb || lcell >= ncell) {
         overflow += 1;
         return;
     }
     const uint32_t rs = (uint32_t)P.rep_shift;
-    const uint32_t ncell = (uint32_t)P.n_cells;
-    const uint32_t cidx = (cell << rs) + rep;
+    const uint32_t cidx = (lcell << rs) + rep;
     lds_add64(lds, cidx, 1);  // Result.Count (aggregate.go:203); Samples == Count without a weight column
 #pragma unroll
     for (int c = 0; c < NA; c++) {
@@ -135,14 +160,16 @@ __device__ __forceinline__ void fast_row(const FastPlan &P, const FastTile<NF> &
     }
 }
 
-template <int NF, int NG, int NA, int MODE, bool PREFETCH>
-__global__ __launch_bounds__(kWgThreads, PREFETCH ? 4 : 8) void k_scan_fast(const FastPlan P) {
+template <int NF, int NG, int NA, int MODE, bool TIME>
+__global__ __launch_bounds__(kWgThreads, 4) void k_scan_fast(const FastPlan P) {
     extern __shared__ int64_t lds[];
     const uint32_t tid = threadIdx.x;
     const uint32_t R = 1u << P.rep_shift;
-    const uint32_t words_sum = (uint32_t)P.n_sum_fields * (uint32_t)P.n_cells;
-    const uint32_t words_max = (uint32_t)P.n_max_fields * (uint32_t)P.n_cells;
+    const uint32_t tab_cells = (uint32_t)P.lds_cells;
+    const uint32_t words_sum = (uint32_t)P.n_sum_fields * tab_cells;
+    const uint32_t words_max = (uint32_t)P.n_max_fields * tab_cells;
     const uint32_t max_base = words_sum << P.rep_shift;
+    const uint32_t cell_base = P.windowed ? (uint32_t)P.wg_cell_base[blockIdx.x] : 0u;
     for (uint32_t i = tid; i < words_sum * R; i += kWgThreads) lds[i] = 0;
     for (uint32_t i = tid; i < words_max * R; i += kWgThreads) lds[max_base + i] = INT64_MIN;
     const uint32_t rep = tid & (R - 1);
@@ -157,23 +184,19 @@ __global__ __launch_bounds__(kWgThreads, PREFETCH ? 4 : 8) void k_scan_fast(cons
         FastTile<NF> f0, f1;
         FastTile<NG> g0, g1;
         FastTile<NA> a0, a1;
-        if (PREFETCH) {
-            if (row < end) fast_load<NF, NG, NA>(P, row, f0, g0, a0);
-            for (; row < end; row += kTileRows) {
-                const int64_t nrow = row + kTileRows;
-                if (nrow < end) fast_load<NF, NG, NA>(P, nrow, f1, g1, a1);
-                fast_row<NF, NG, NA, MODE>(P, f0, g0, a0, 0, lds, rep, max_base, matched, overflow);
-                if (row + 1 < end) fast_row<NF, NG, NA, MODE>(P, f0, g0, a0, 1, lds, rep, max_base, matched, overflow);
-                f0 = f1;
-                g0 = g1;
-                a0 = a1;
-            }
-        } else {
-            for (; row < end; row += kTileRows) {
-                fast_load<NF, NG, NA>(P, row, f0, g0, a0);
-                fast_row<NF, NG, NA, MODE>(P, f0, g0, a0, 0, lds, rep, max_base, matched, overflow);
-                if (row + 1 < end) fast_row<NF, NG, NA, MODE>(P, f0, g0, a0, 1, lds, rep, max_base, matched, overflow);
-            }
+        FastTile<1> t0, t1;
+        // register double buffer: the next tile's loads are in flight while this one is consumed
+        if (row < end) fast_load<NF, NG, NA, TIME>(P, row, f0, g0, a0, t0);
+        for (; row < end; row += kTileRows) {
+            const int64_t nrow = row + kTileRows;
+            if (nrow < end) fast_load<NF, NG, NA, TIME>(P, nrow, f1, g1, a1, t1);
+            fast_row<NF, NG, NA, MODE, TIME>(P, f0, g0, a0, t0, 0, lds, rep, max_base, cell_base, matched, overflow);
+            if (row + 1 < end)
+                fast_row<NF, NG, NA, MODE, TIME>(P, f0, g0, a0, t0, 1, lds, rep, max_base, cell_base, matched, overflow);
+            f0 = f1;
+            g0 = g1;
+            a0 = a1;
+            t0 = t1;
         }
     }
 
@@ -188,8 +211,32 @@ __global__ __launch_bounds__(kWgThreads, PREFETCH ? 4 : 8) void k_scan_fast(cons
         if (overflow) __hip_atomic_fetch_add(P.sum_out + kHdrOverflow, (int64_t)overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 
-    // fold the lane replicas and publish this workgroup's table (plain stores)
     __syncthreads();
+    if (P.windowed) {
+        // flush the touched cells of this workgroup's window into the global table
+        int64_t *gs = P.sum_out + kHeaderWords;
+        for (uint32_t i = tid; i < words_sum; i += kWgThreads) {
+            int64_t acc = 0;
+            for (uint32_t k = 0; k < R; k++) acc += lds[(i << P.rep_shift) + k];
+            if (acc != 0) {
+                const uint32_t fi = i / tab_cells, c = i - fi * tab_cells;
+                __hip_atomic_fetch_add(gs + (int64_t)fi * P.n_cells + cell_base + c, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        for (uint32_t i = tid; i < words_max; i += kWgThreads) {
+            int64_t acc = INT64_MIN;
+            for (uint32_t k = 0; k < R; k++) {
+                const int64_t b = lds[max_base + (i << P.rep_shift) + k];
+                acc = b > acc ? b : acc;
+            }
+            if (acc != INT64_MIN) {
+                const uint32_t fi = i / tab_cells, c = i - fi * tab_cells;
+                __hip_atomic_fetch_max(P.max_out + (int64_t)fi * P.n_cells + cell_base + c, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        return;
+    }
+    // fold the lane replicas and publish this workgroup's table (plain stores)
     int64_t *ws = P.ws_sum + (int64_t)blockIdx.x * words_sum;
     for (uint32_t i = tid; i < words_sum; i += kWgThreads) {
         int64_t acc = 0;
@@ -209,9 +256,9 @@ __global__ __launch_bounds__(kWgThreads, PREFETCH ? 4 : 8) void k_scan_fast(cons
 
 // One translation unit per NF keeps the build parallel (Makefile: kernels_fast_<NF>.o).
 template <int NF, int NG, int NA, int MODE>
-static hipError_t fast_launch_one(const FastPlan &P, bool prefetch, int n_wg, size_t lds_bytes, hipStream_t st) {
+static hipError_t fast_launch_one(const FastPlan &P, bool time, int n_wg, size_t lds_bytes, hipStream_t st) {
     hipError_t e;
-    if (prefetch) {
+    if (time) {
         auto k = k_scan_fast<NF, NG, NA, MODE, true>;
         e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
@@ -226,30 +273,30 @@ static hipError_t fast_launch_one(const FastPlan &P, bool prefetch, int n_wg, si
 }
 
 template <int NF, int NG, int NA>
-static hipError_t fast_launch_mode(const FastPlan &P, int mode, bool prefetch, int n_wg, size_t lds, hipStream_t st) {
-    if (NA == 0) return fast_launch_one<NF, NG, 0, kFastAvg>(P, prefetch, n_wg, lds, st);
+static hipError_t fast_launch_mode(const FastPlan &P, int mode, bool time, int n_wg, size_t lds, hipStream_t st) {
+    if (NA == 0) return fast_launch_one<NF, NG, 0, kFastAvg>(P, time, n_wg, lds, st);
     switch (mode) {
-    case kFastAvg: return fast_launch_one<NF, NG, NA, kFastAvg>(P, prefetch, n_wg, lds, st);
-    case kFastAvgMax: return fast_launch_one<NF, NG, NA, kFastAvgMax>(P, prefetch, n_wg, lds, st);
-    case kFastMoments: return fast_launch_one<NF, NG, NA, kFastMoments>(P, prefetch, n_wg, lds, st);
-    case kFastHist: return fast_launch_one<NF, NG, NA, kFastHist>(P, prefetch, n_wg, lds, st);
+    case kFastAvg: return fast_launch_one<NF, NG, NA, kFastAvg>(P, time, n_wg, lds, st);
+    case kFastAvgMax: return fast_launch_one<NF, NG, NA, kFastAvgMax>(P, time, n_wg, lds, st);
+    case kFastMoments: return fast_launch_one<NF, NG, NA, kFastMoments>(P, time, n_wg, lds, st);
+    case kFastHist: return fast_launch_one<NF, NG, NA, kFastHist>(P, time, n_wg, lds, st);
     default: return hipErrorInvalidValue;
     }
 }
 
 template <int NF>
-static hipError_t fast_launch_nf(const FastPlan &P, int ng, int na, int mode, bool prefetch, int n_wg, size_t lds,
+static hipError_t fast_launch_nf(const FastPlan &P, int ng, int na, int mode, bool time, int n_wg, size_t lds,
                                  hipStream_t st) {
     switch (ng * 3 + na) {
-    case 0: return fast_launch_mode<NF, 0, 0>(P, mode, prefetch, n_wg, lds, st);
-    case 1: return fast_launch_mode<NF, 0, 1>(P, mode, prefetch, n_wg, lds, st);
-    case 2: return fast_launch_mode<NF, 0, 2>(P, mode, prefetch, n_wg, lds, st);
-    case 3: return fast_launch_mode<NF, 1, 0>(P, mode, prefetch, n_wg, lds, st);
-    case 4: return fast_launch_mode<NF, 1, 1>(P, mode, prefetch, n_wg, lds, st);
-    case 5: return fast_launch_mode<NF, 1, 2>(P, mode, prefetch, n_wg, lds, st);
-    case 6: return fast_launch_mode<NF, 2, 0>(P, mode, prefetch, n_wg, lds, st);
-    case 7: return fast_launch_mode<NF, 2, 1>(P, mode, prefetch, n_wg, lds, st);
-    case 8: return fast_launch_mode<NF, 2, 2>(P, mode, prefetch, n_wg, lds, st);
+    case 0: return fast_launch_mode<NF, 0, 0>(P, mode, time, n_wg, lds, st);
+    case 1: return fast_launch_mode<NF, 0, 1>(P, mode, time, n_wg, lds, st);
+    case 2: return fast_launch_mode<NF, 0, 2>(P, mode, time, n_wg, lds, st);
+    case 3: return fast_launch_mode<NF, 1, 0>(P, mode, time, n_wg, lds, st);
+    case 4: return fast_launch_mode<NF, 1, 1>(P, mode, time, n_wg, lds, st);
+    case 5: return fast_launch_mode<NF, 1, 2>(P, mode, time, n_wg, lds, st);
+    case 6: return fast_launch_mode<NF, 2, 0>(P, mode, time, n_wg, lds, st);
+    case 7: return fast_launch_mode<NF, 2, 1>(P, mode, time, n_wg, lds, st);
+    case 8: return fast_launch_mode<NF, 2, 2>(P, mode, time, n_wg, lds, st);
     default: return hipErrorInvalidValue;
     }
 }
@@ -257,10 +304,10 @@ static hipError_t fast_launch_nf(const FastPlan &P, int ng, int na, int mode, bo
 #endif  // __HIPCC__
 
 // per-NF entry points (kernels_fast_<NF>.hip)
-hipError_t launch_scan_fast_nf0(const FastPlan &P, int ng, int na, int mode, bool prefetch, int n_wg, size_t lds, hipStream_t st);
-hipError_t launch_scan_fast_nf1(const FastPlan &P, int ng, int na, int mode, bool prefetch, int n_wg, size_t lds, hipStream_t st);
-hipError_t launch_scan_fast_nf2(const FastPlan &P, int ng, int na, int mode, bool prefetch, int n_wg, size_t lds, hipStream_t st);
-hipError_t launch_scan_fast_nf3(const FastPlan &P, int ng, int na, int mode, bool prefetch, int n_wg, size_t lds, hipStream_t st);
-hipError_t launch_scan_fast_nf4(const FastPlan &P, int ng, int na, int mode, bool prefetch, int n_wg, size_t lds, hipStream_t st);
+hipError_t launch_scan_fast_nf0(const FastPlan &P, int ng, int na, int mode, bool time, int n_wg, size_t lds, hipStream_t st);
+hipError_t launch_scan_fast_nf1(const FastPlan &P, int ng, int na, int mode, bool time, int n_wg, size_t lds, hipStream_t st);
+hipError_t launch_scan_fast_nf2(const FastPlan &P, int ng, int na, int mode, bool time, int n_wg, size_t lds, hipStream_t st);
+hipError_t launch_scan_fast_nf3(const FastPlan &P, int ng, int na, int mode, bool time, int n_wg, size_t lds, hipStream_t st);
+hipError_t launch_scan_fast_nf4(const FastPlan &P, int ng, int na, int mode, bool time, int n_wg, size_t lds, hipStream_t st);
 
 }  // namespace sybl
