@@ -95,6 +95,8 @@ static void free_query(Query *q) {
     if (q->d_segs) hipFree(q->d_segs);
     if (q->d_wg_seg_begin) hipFree(q->d_wg_seg_begin);
     if (q->d_wg_cell_base) hipFree(q->d_wg_cell_base);
+    if (q->d_recs) hipFree(q->d_recs);
+    if (q->d_cursor) hipFree(q->d_cursor);
     for (void *p : q->d_idmasks) hipFree(p);
     if (q->own_partials) {
         if (q->d_sum) hipFree(q->d_sum);
@@ -102,7 +104,6 @@ static void free_query(Query *q) {
     }
     if (q->d_ws_sum) hipFree(q->d_ws_sum);
     if (q->d_ws_max) hipFree(q->d_ws_max);
-    if (q->h_sum) hipHostFree(q->h_sum);
     if (q->h_max) hipHostFree(q->h_max);
     for (auto &e : q->ev)
         if (e) hipEventDestroy(e);
@@ -128,64 +129,60 @@ static bool should_scan_block(const Table *t, const sybl_query_desc *d, int64_t 
     return true;
 }
 
-// Role-specialised kernels (scan_fast.h) cover the common shape; everything else runs k_scan.
-static void select_fast_path(Table *t, Query *q, const std::vector<int> &slot_col, const std::vector<HostFilterFold> &folds) {
-    q->fast = false;
+// Fills the column / filter / group / bucket part of a FastPlan when the query has the shape the
+// role-specialised kernels cover: <= 4 range-filter, <= 2 group, <= 2 aggregation columns, all
+// fully populated int64, one role per column, no rejects / outliers / minima to track.
+static bool fill_fast_columns(Table *t, Query *q, const std::vector<int> &slot_col, FastPlan &FP, int *pnf, int *png,
+                              int *pna, bool *any_max, bool *all_max) {
     const ScanPlan &P = q->plan;
-    if (getenv("SYBL_NO_FAST")) return;
-    if (!q->use_lds || q->weighted) return;
-    if (q->time_mode && P.tb_big_div) return;
-    FastPlan &FP = q->fplan;
     memset(&FP, 0, sizeof(FP));
     int nf = 0, ng = 0, na = 0;
-    // group slots must come in key order (most significant first): walk q->groups
-    std::vector<int> order;
     for (size_t s = 0; s < slot_col.size(); s++) {
         const SlotDesc &sd = P.slot[s];
         const Column *c = t->cols[(size_t)slot_col[s]].get();
-        if (c->type != SYBL_INT_VAL || c->elem != 8 || c->d_valid || c->has_missing) return;
+        if (c->type != SYBL_INT_VAL || c->elem != 8 || c->d_valid || c->has_missing) return false;
         uint32_t roles = sd.flags & (kSlotFilter | kSlotGroup | kSlotAgg);
-        if (sd.flags & (kSlotNeq | kSlotIdMask | kSlotWeight | kSlotW32 | kSlotSet)) return;
-        if (roles != kSlotRange && roles != kSlotGroup && roles != kSlotAgg && roles != 0) return;  // one role per column
-        if ((sd.flags & kSlotTime) && roles != 0) return;  // the time column plays no second role here
-        (void)folds;
+        if (sd.flags & (kSlotNeq | kSlotIdMask | kSlotWeight | kSlotW32 | kSlotSet)) return false;
+        if (roles != kSlotRange && roles != kSlotGroup && roles != kSlotAgg && roles != 0) return false;  // one role per column
+        if ((sd.flags & kSlotTime) && roles != 0) return false;  // the time column plays no second role here
     }
     for (size_t s = 0; s < slot_col.size(); s++) {
         const SlotDesc &sd = P.slot[s];
         if (!(sd.flags & kSlotRange)) continue;
-        if (nf >= kFastMaxF) return;
+        if (nf >= kFastMaxF) return false;
         FP.fcol[nf] = (const int64_t *)sd.base;
         FP.lo[nf] = sd.lo;
         FP.hi[nf] = sd.hi;
         nf++;
     }
     for (auto &gi : q->groups) {
-        if (ng >= kFastMaxG) return;
+        if (ng >= kFastMaxG) return false;
         int s = -1;
         for (size_t k = 0; k < slot_col.size(); k++)
             if (slot_col[k] == gi.col) s = (int)k;
         const SlotDesc &sd = P.slot[s];
-        if (sd.gmissing >= 0) return;
+        if (sd.gmissing >= 0) return false;
         FP.gcol[ng] = (const int64_t *)sd.base;
         FP.gmin[ng] = sd.gmin;
         FP.gcard[ng] = (uint32_t)sd.gcard;
         FP.gstride[ng] = sd.gstride;
         ng++;
     }
-    bool any_max = false, all_max = true;
+    *any_max = false;
+    *all_max = true;
     for (auto &ai : q->aggs) {
-        if (na >= kFastMaxA) return;
+        if (na >= kFastMaxA) return false;
         const AggDesc &A = ai.d;
-        if (A.f_cnt >= 0 || A.f_smp >= 0 || A.f_out >= 0 || A.m_nmin >= 0) return;
+        if (A.f_cnt >= 0 || A.f_smp >= 0 || A.f_out >= 0 || A.m_nmin >= 0) return false;
         if (q->op == SYBL_AGG_HIST) {
-            if (A.m_max >= 0 || A.big_div || A.bucket_size >= ((int64_t)1 << 32)) return;
+            if (A.big_div || A.bucket_size >= ((int64_t)1 << 32)) return false;
             const Column *c = t->cols[(size_t)ai.col].get();
             int64_t hi = c->bounds_set ? c->bound_hi : c->exact_max;
             if (c->n_pop > 0 || c->bounds_set)
-                if ((unsigned __int128)((__int128)hi - (__int128)A.hmin) >= ((unsigned __int128)1 << 32)) return;
+                if ((unsigned __int128)((__int128)hi - (__int128)A.hmin) >= ((unsigned __int128)1 << 32)) return false;
         }
-        any_max = any_max || A.m_max >= 0;
-        all_max = all_max && A.m_max >= 0;
+        *any_max = *any_max || A.m_max >= 0;
+        *all_max = *all_max && A.m_max >= 0;
         int s = -1;
         for (size_t k = 0; k < slot_col.size(); k++)
             if (slot_col[k] == ai.col) s = (int)k;
@@ -201,6 +198,33 @@ static void select_fast_path(Table *t, Query *q, const std::vector<int> &slot_co
         FP.hist_agg_off[na] = P.hist_agg_off[na];
         na++;
     }
+    FP.hist_off = P.hist_off;
+    FP.hist_stride = P.hist_stride;
+    FP.n_cells = P.n_cells;
+    FP.n_sum_fields = P.n_sum_fields;
+    FP.n_max_fields = P.n_max_fields;
+    FP.rep_shift = P.rep_shift;
+    FP.windowed = P.windowed;
+    FP.lds_cells = P.lds_cells;
+    FP.wg_cell_base = P.wg_cell_base;
+    *pnf = nf;
+    *png = ng;
+    *pna = na;
+    return true;
+}
+
+// Role-specialised kernels (scan_fast.h) cover the common shape; everything else runs k_scan.
+static void select_fast_path(Table *t, Query *q, const std::vector<int> &slot_col) {
+    q->fast = false;
+    const ScanPlan &P = q->plan;
+    if (getenv("SYBL_NO_FAST")) return;
+    if (!q->use_lds || q->weighted) return;
+    if (q->time_mode && P.tb_big_div) return;
+    FastPlan &FP = q->fplan;
+    int nf, ng, na;
+    bool any_max, all_max;
+    if (!fill_fast_columns(t, q, slot_col, FP, &nf, &ng, &na, &any_max, &all_max)) return;
+    if (q->op == SYBL_AGG_HIST && any_max) return;
     if (nf + ng + na == 0 && !q->time_mode) return;  // nothing to stream: the generic kernel picks a driver column
     if (q->time_mode) {
         FP.tcol = (const int64_t *)P.slot[P.time_slot].base;
@@ -210,9 +234,6 @@ static void select_fast_path(Table *t, Query *q, const std::vector<int> &slot_co
         FP.n_tb = P.n_tb;
         FP.tb_stride = P.tb_stride;
     }
-    FP.windowed = P.windowed;
-    FP.lds_cells = P.lds_cells;
-    FP.wg_cell_base = P.wg_cell_base;
     int mode;
     if (q->op == SYBL_AGG_HIST) {
         mode = q->want_percentiles ? kFastHist : kFastMoments;
@@ -220,17 +241,81 @@ static void select_fast_path(Table *t, Query *q, const std::vector<int> &slot_co
         if (any_max && !all_max) return;
         mode = any_max ? kFastAvgMax : kFastAvg;
     }
-    FP.hist_off = P.hist_off;
-    FP.hist_stride = P.hist_stride;
-    FP.n_cells = P.n_cells;
-    FP.n_sum_fields = P.n_sum_fields;
-    FP.n_max_fields = P.n_max_fields;
-    FP.rep_shift = P.rep_shift;
     q->fast = true;
     q->fast_nf = nf;
     q->fast_ng = ng;
     q->fast_na = na;
     q->fast_mode = mode;
+}
+
+// Partitioned histograms (strategy 5, scan_fast.h): full-histogram queries whose (cell, agg)
+// pairs fit kMaxParts partitions of kPartCells pairs.
+static int select_part_hist(Table *t, Query *q, const std::vector<int> &slot_col, int64_t rows_scanned) {
+    q->part_hist = false;
+    const ScanPlan &P = q->plan;
+    if (getenv("SYBL_NO_PARTHIST")) return SYBL_OK;
+    if (q->op != SYBL_AGG_HIST || !q->want_percentiles || q->time_mode || q->weighted || q->aggs.empty()) return SYBL_OK;
+    EmitPlan &E = q->eplan;
+    int nf, ng, na;
+    bool any_max, all_max;
+    if (!fill_fast_columns(t, q, slot_col, E.fp, &nf, &ng, &na, &any_max, &all_max)) return SYBL_OK;
+    int rb = 0;
+    for (auto &ai : q->aggs) {
+        if (ai.d.n_values > (1 << kBucketBits)) return SYBL_OK;
+        int bits = 0;
+        while (((int64_t)1 << bits) < ai.d.bucket_size) bits++;
+        rb = std::max(rb, bits);
+    }
+    if (kPartCellBits + kBucketBits + rb > 32) return SYBL_OK;
+    int64_t pairs = (int64_t)P.n_cells * na;
+    int64_t n_parts = (pairs + kPartCells - 1) / kPartCells;
+    if (n_parts > kMaxParts) return SYBL_OK;
+    // capacity: 1.5x the mean share of the worst case (every scanned row matches) + slack; a
+    // partition that still overflows makes finalize fall back to the atomic strategy
+    int64_t cap = rows_scanned * na / n_parts;
+    cap = cap + cap / 2 + 8192;
+    if (cap >= ((int64_t)1 << 32)) return SYBL_OK;
+    size_t bytes = (size_t)n_parts * (size_t)cap * 4, free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || bytes + ((size_t)1 << 30) > free_b) return SYBL_OK;
+    SYBL_HIP(hipMalloc((void **)&q->d_recs, bytes));
+    SYBL_HIP(hipMalloc((void **)&q->d_cursor, (size_t)n_parts * 4));
+    E.recs = q->d_recs;
+    E.cursor = q->d_cursor;
+    E.part_cap = cap;
+    E.n_parts = (int32_t)n_parts;
+    E.n_aggs = na;
+    E.slots = (int32_t)std::min<int64_t>(1023, std::max<int64_t>(15, (kEmitLdsWords - n_parts) / n_parts));
+    PartHistPlan &H = q->pplan;
+    memset(&H, 0, sizeof(H));
+    H.recs = q->d_recs;
+    H.cursor = q->d_cursor;
+    H.part_cap = cap;
+    H.n_parts = (int32_t)n_parts;
+    H.n_aggs = na;
+    H.n_cells = P.n_cells;
+    H.hist_off = P.hist_off;
+    H.hist_stride = P.hist_stride;
+    int nv_max = 0;
+    for (int a = 0; a < na; a++) {
+        const AggDesc &A = q->aggs[(size_t)a].d;
+        E.rem_bits[a] = rb;
+        H.rem_bits[a] = rb;
+        H.n_values[a] = A.n_values;
+        H.f_sum[a] = A.f_sum;
+        H.m_max[a] = A.m_max;
+        H.hmin[a] = A.hmin;
+        H.bucket_size[a] = A.bucket_size;
+        H.hist_agg_off[a] = P.hist_agg_off[a];
+        nv_max = std::max(nv_max, A.n_values);
+    }
+    H.nv_max = nv_max;
+    // few partitions: several workgroups share one so the whole chip is busy
+    H.split = (int32_t)std::max<int64_t>(1, std::min<int64_t>(8, (int64_t)q->n_wg / n_parts));
+    q->part_nf = nf;
+    q->part_ng = ng;
+    q->part_na = na;
+    q->part_hist = true;
+    return SYBL_OK;
 }
 
 static int plan_query(Table *t, const sybl_query_desc *d, Query *q) {
@@ -708,7 +793,8 @@ static int plan_query(Table *t, const sybl_query_desc *d, Query *q) {
             P.wg_cell_base = q->d_wg_cell_base;
         }
     }
-    select_fast_path(t, q, slot_col, folds);
+    select_fast_path(t, q, slot_col);
+    if ((rc = select_part_hist(t, q, slot_col, rows_scanned))) return rc;
     q->stats.rows_scanned = rows_scanned;
     q->stats.blocks_skipped = skipped;
     q->stats.blocks_scanned = (int64_t)t->blocks.size() - skipped;
@@ -725,7 +811,7 @@ static int plan_query(Table *t, const sybl_query_desc *d, Query *q) {
     }
     q->stats.algorithmic_bytes = rows_scanned * width + set_bytes;
     q->stats.n_cells = (int32_t)n_cells;
-    q->stats.strategy = q->use_lds ? (P.windowed ? (q->fast ? 4 : 3) : (q->fast ? 2 : 0)) : 1;
+    q->stats.strategy = q->part_hist ? 5 : (q->use_lds ? (P.windowed ? (q->fast ? 4 : 3) : (q->fast ? 2 : 0)) : 1);
     q->stats.lds_bytes = (int32_t)q->lds_bytes;
     q->stats.n_workgroups = q->n_wg;
     q->stats.replicas = 1 << P.rep_shift;
@@ -747,6 +833,8 @@ static int plan_query(Table *t, const sybl_query_desc *d, Query *q) {
         P.ws_sum = q->d_ws_sum;
         P.ws_max = q->d_ws_max;
     }
+    q->eplan.fp.segs = q->d_segs;
+    q->eplan.fp.wg_seg_begin = q->d_wg_seg_begin;
     q->fplan.segs = q->d_segs;
     q->fplan.wg_seg_begin = q->d_wg_seg_begin;
     q->fplan.ws_sum = q->d_ws_sum;
@@ -782,6 +870,31 @@ static int scan(Query *q) {
     }
     const bool ran = !q->never_matches && !q->segs.empty();
     hipError_t e = hipSuccess;
+    if (q->part_hist && ran) {
+        // k_part_hist overwrites every cell field, bucket and extremum: only the header and the
+        // partition cursors start from zero
+        if (q->pplan.split > 1) {
+            // shared partitions accumulate with atomics into a zeroed table
+            SYBL_HIP(hipMemsetAsync(q->d_sum, 0, (size_t)q->n_sum_words * 8, st));
+            e = launch_fill64(q->d_max, q->n_max_words, INT64_MIN, st);
+            if (e != hipSuccess) return hip_fail(e, "k_fill64");
+        } else {
+            SYBL_HIP(hipMemsetAsync(q->d_sum, 0, (size_t)kHeaderWords * 8, st));
+        }
+        SYBL_HIP(hipMemsetAsync(q->d_cursor, 0, (size_t)q->eplan.n_parts * 4, st));
+        SYBL_HIP(hipEventRecord(q->ev[0], st));
+        q->eplan.sum_out = q->d_sum;
+        q->pplan.sum_out = q->d_sum;
+        q->pplan.max_out = q->d_max;
+        e = launch_emit(q->eplan, q->part_nf, q->part_ng, q->part_na, q->n_wg, st);
+        if (e != hipSuccess) return hip_fail(e, "k_emit");
+        e = launch_part_hist(q->pplan, st);
+        if (e != hipSuccess) return hip_fail(e, "k_part_hist");
+        SYBL_HIP(hipEventRecord(q->ev[1], st));
+        SYBL_HIP(hipEventRecord(q->ev[2], st));
+        q->scanned = true;
+        return SYBL_OK;
+    }
     if (q->use_lds && ran && !P.windowed) {
         // the fold overwrites every cell field; only the header and the bucket arrays accumulate
         SYBL_HIP(hipMemsetAsync(q->d_sum, 0, (size_t)kHeaderWords * 8, st));
@@ -814,6 +927,13 @@ static int scan(Query *q) {
     SYBL_HIP(hipEventRecord(q->ev[2], st));
     q->scanned = true;
     return SYBL_OK;
+}
+
+// A partition buffer overflowed (badly skewed keys): redo the scan with per-value atomics.
+int query_rescan_without_part_hist(Query *q) {
+    q->part_hist = false;
+    q->stats.strategy = q->use_lds ? (q->plan.windowed ? (q->fast ? 4 : 3) : (q->fast ? 2 : 0)) : 1;
+    return scan(q);
 }
 
 }  // namespace sybl

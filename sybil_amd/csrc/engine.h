@@ -113,6 +113,14 @@ int block_col_str_host(BlockWriter &w, Column *c, const int32_t *global_ids, con
 int block_col_set_host(BlockWriter &w, Column *c, const int64_t *off, const int32_t *global_ids, const uint8_t *populated);
 int block_commit(BlockWriter &w);
 
+// pinned host memory owned jointly by a query and the results that point into it
+struct HostBuf {
+    int64_t *p = nullptr;
+    ~HostBuf() {
+        if (p) (void)hipHostFree(p);
+    }
+};
+
 struct GroupInfo {
     int col;
     int type;
@@ -165,7 +173,8 @@ struct Query {
     int64_t *d_sum = nullptr, *d_max = nullptr;
     bool own_partials = false;
     int64_t *d_ws_sum = nullptr, *d_ws_max = nullptr;
-    int64_t *h_sum = nullptr, *h_max = nullptr;  // pinned staging for finalize
+    std::shared_ptr<HostBuf> h_sum_buf;          // pinned snapshot of the SUM section (shared with results)
+    int64_t *h_sum = nullptr, *h_max = nullptr;  // h_sum = h_sum_buf->p; h_max: pinned staging
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     bool scanned = false;
     sybl_run_stats stats{};
@@ -174,7 +183,15 @@ struct Query {
     bool fast = false;
     int fast_nf = 0, fast_ng = 0, fast_na = 0, fast_mode = 0;
     FastPlan fplan;
+    // partitioned histograms (strategy 5)
+    bool part_hist = false;
+    int part_nf = 0, part_ng = 0, part_na = 0;
+    EmitPlan eplan;
+    PartHistPlan pplan;
+    uint32_t *d_recs = nullptr, *d_cursor = nullptr;
 };
+
+int query_rescan_without_part_hist(Query *q);
 
 int query_finalize(Query *q, Result **out);
 

@@ -24,6 +24,7 @@
 #include <stdint.h>
 
 #include "plan.h"
+#include "scan_fast.h"
 
 namespace sybl {
 
@@ -595,6 +596,96 @@ hipError_t launch_decode_delta(const int64_t *deltas, int64_t n, bool value_enco
 hipError_t launch_remap_ids(const int32_t *local, const int32_t *lut, int32_t n_lut, int64_t n, int32_t *col, hipStream_t st) {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_remap_ids, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, local, lut, n_lut, n, col);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- partitioned histograms
+// k_part_hist: one workgroup owns one partition = kPartCells (cell, agg) pairs.  Their bucket
+// arrays (uint32), counts and exact sums live in LDS; every record costs two or three LDS
+// atomics; the results are written with plain stores (each pair has exactly one owner), so the
+// [cell][agg][bucket] table, Count and sum(v) come out deterministic and atomics-free in HBM.
+__global__ __launch_bounds__(kWgThreads) void k_part_hist(const PartHistPlan P) {
+    extern __shared__ uint32_t plds[];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t nv = (uint32_t)P.nv_max;
+    uint32_t *hist = plds;                                       // [kPartCells][nv]
+    uint32_t *cnt = plds + kPartCells * nv;                      // [kPartCells]
+    unsigned long long *sum = (unsigned long long *)(cnt + kPartCells + (kPartCells & 1));  // [kPartCells]
+    long long *vmax = (long long *)(sum + kPartCells);           // [kPartCells]
+    for (uint32_t i = tid; i < kPartCells * nv; i += kWgThreads) hist[i] = 0;
+    if (tid < kPartCells) {
+        cnt[tid] = 0;
+        sum[tid] = 0;
+        vmax[tid] = INT64_MIN;
+    }
+    __syncthreads();
+
+    const uint32_t split = (uint32_t)P.split;
+    const uint32_t part = blockIdx.x / split, sub = blockIdx.x % split;
+    const uint32_t n_all = P.cursor[part];
+    const uint32_t i0 = (uint32_t)((uint64_t)n_all * sub / split), i1 = (uint32_t)((uint64_t)n_all * (sub + 1) / split);
+    const uint32_t *recs = P.recs + (int64_t)part * P.part_cap;
+    const uint32_t pair0 = part * kPartCells;
+    const uint32_t rb = (uint32_t)P.rem_bits[0];  // equal for every aggregation (planner)
+    for (uint32_t i = i0 + tid; i < i1; i += kWgThreads) {
+        const uint32_t rec = __builtin_nontemporal_load(recs + i);
+        const uint32_t rem = rec & ((1u << rb) - 1);
+        const uint32_t b = (rec >> rb) & ((1u << kBucketBits) - 1);
+        const uint32_t local = rec >> (rb + kBucketBits);
+        const uint32_t a = P.n_aggs == 1 ? 0u : (pair0 + local) % (uint32_t)P.n_aggs;
+        __hip_atomic_fetch_add(hist + local * nv + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(cnt + local, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const unsigned long long off = (unsigned long long)b * (unsigned long long)P.bucket_size[a] + rem;
+        __hip_atomic_fetch_add(sum + local, off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (P.m_max[a] >= 0) {
+            const long long v = (long long)((unsigned long long)P.hmin[a] + off);
+            if (v > vmax[local]) __hip_atomic_fetch_max(vmax + local, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    __syncthreads();
+
+    int64_t *F = P.sum_out + kHeaderWords;
+    const uint32_t total_pairs = (uint32_t)P.n_cells * (uint32_t)P.n_aggs;
+    for (uint32_t l = 0; l < (uint32_t)kPartCells; l++) {
+        const uint32_t pair = pair0 + l;
+        if (pair >= total_pairs) break;
+        const uint32_t cell = pair / (uint32_t)P.n_aggs, a = pair % (uint32_t)P.n_aggs;
+        int64_t *h = P.sum_out + P.hist_off + (int64_t)cell * P.hist_stride + P.hist_agg_off[a];
+        const uint32_t c = cnt[l];
+        // every aggregation accepts every row here (planner: no rejects / missing values), so
+        // Result.Count of the cell is the count of any of its aggregations
+        const int64_t vsum = (int64_t)(sum[l] + (unsigned long long)c * (unsigned long long)P.hmin[a]);
+        if (split == 1) {
+            // sole owner of the pair: plain stores, nothing to zero beforehand
+            for (uint32_t b = tid; b < (uint32_t)P.n_values[a]; b += kWgThreads) h[b] = (int64_t)hist[l * nv + b];
+            if (tid == 0) {
+                if (a == 0) F[cell] = (int64_t)c;
+                F[(int64_t)P.f_sum[a] * P.n_cells + cell] = vsum;
+                if (P.m_max[a] >= 0) P.max_out[(int64_t)P.m_max[a] * P.n_cells + cell] = vmax[l];
+            }
+        } else {
+            // `split` workgroups share the pair: combine into the zeroed table
+            for (uint32_t b = tid; b < (uint32_t)P.n_values[a]; b += kWgThreads) {
+                const uint32_t x = hist[l * nv + b];
+                if (x) gadd(h + b, (int64_t)x);
+            }
+            if (tid == 0 && c) {
+                if (a == 0) gadd(F + cell, (int64_t)c);
+                gadd(F + (int64_t)P.f_sum[a] * P.n_cells + cell, vsum);
+                if (P.m_max[a] >= 0)
+                    __hip_atomic_fetch_max(P.max_out + (int64_t)P.m_max[a] * P.n_cells + cell, (int64_t)vmax[l], __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+}
+
+hipError_t launch_part_hist(const PartHistPlan &P, hipStream_t st) {
+    if (P.n_parts <= 0) return hipSuccess;
+    size_t lds = ((size_t)kPartCells * P.nv_max + kPartCells + 2) * 4 + (size_t)kPartCells * 16 + 16;
+    hipError_t e = hipFuncSetAttribute((const void *)k_part_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_part_hist, dim3(P.n_parts * P.split), dim3(kWgThreads), lds, st, P);
     return hipGetLastError();
 }
 

@@ -121,6 +121,7 @@ struct ScanPlan {
 enum Header : int {
     kHdrMatched = 0,     // QuerySpec.MatchedCount
     kHdrOverflow = 1,    // rows whose key / bucket fell outside the declared bounds (must be 0)
+    kHdrPartOverflow = 2, // partitioned histograms: records that did not fit their partition buffer
 };
 
 }  // namespace sybl

@@ -16,6 +16,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
@@ -53,7 +54,8 @@ struct Result {
     std::vector<RowStore> rows[3];
     std::vector<sybl_group_row> view[3];
     int64_t matched = 0;
-    std::vector<int64_t> hist_copy;               // bucket arrays the rows point into
+    std::shared_ptr<HostBuf> keep;                // the pinned snapshot of the partial table the bucket
+                                                  // arrays of the rows point into
     std::vector<std::vector<int64_t>> total_vals; // Cumulative bucket arrays
     std::vector<int64_t> pct_pool;                // 100 entries per (row, agg) with percentiles
     std::vector<sybl_agg_out> agg_pool;           // n_aggs entries per row, all row kinds
@@ -233,15 +235,26 @@ static void make_views(Result *R) {
 int query_finalize(Query *q, Result **out) {
     hipStream_t st = q->ctx->stream;
     const ScanPlan &P = q->plan;
-    // pinned staging buffers, allocated once per query
-    if (!q->h_sum) {
-        SYBL_HIP(hipHostMalloc((void **)&q->h_sum, (size_t)q->n_sum_words * 8, hipHostMallocDefault));
-        SYBL_HIP(hipHostMalloc((void **)&q->h_max, (size_t)q->n_max_words * 8, hipHostMallocDefault));
+    // Pinned snapshot of the (reduced) partial table.  Results keep a reference to the snapshot
+    // their bucket arrays point into; the query reuses the buffer for the next finalize unless a
+    // live result still holds it (then a fresh one is allocated) -- so a 525 MB histogram table
+    // is never copied, page-faulted or unmapped per query.
+    if (!q->h_sum_buf || q->h_sum_buf.use_count() > 1) {
+        auto nb = std::make_shared<HostBuf>();
+        SYBL_HIP(hipHostMalloc((void **)&nb->p, (size_t)q->n_sum_words * 8, hipHostMallocDefault));
+        q->h_sum_buf = nb;
     }
+    if (!q->h_max) SYBL_HIP(hipHostMalloc((void **)&q->h_max, (size_t)q->n_max_words * 8, hipHostMallocDefault));
+    q->h_sum = q->h_sum_buf->p;
     SYBL_HIP(hipMemcpyAsync(q->h_sum, q->d_sum, (size_t)q->n_sum_words * 8, hipMemcpyDeviceToHost, st));
     if (P.n_max_fields > 0) SYBL_HIP(hipMemcpyAsync(q->h_max, q->d_max, (size_t)q->n_max_words * 8, hipMemcpyDeviceToHost, st));
     SYBL_HIP(hipStreamSynchronize(st));
     const int64_t *hs = q->h_sum, *hm = q->h_max;
+    if (hs[kHdrPartOverflow] != 0 && q->part_hist) {
+        int rc = query_rescan_without_part_hist(q);
+        if (rc) return rc;
+        return query_finalize(q, out);
+    }
     if (hs[kHdrOverflow] != 0)
         return fail(SYBL_E_STATE,
                     "%lld rows fell outside the declared column bounds (sybl_table_set_bounds) -- results would be incomplete",
@@ -266,9 +279,8 @@ int query_finalize(Query *q, Result **out) {
     const int64_t *F = hs + kHeaderWords;
     const int64_t *H = nullptr;
     if (P.hist_stride > 0) {
-        // the rows' bucket arrays outlive the next scan: keep a private copy
-        R->hist_copy.assign(hs + P.hist_off, hs + P.hist_off + ncell * P.hist_stride);
-        H = R->hist_copy.data();
+        R->keep = q->h_sum_buf;  // the rows' bucket arrays live in the snapshot
+        H = hs + P.hist_off;
     }
     const size_t na = q->aggs.size();
 

@@ -58,6 +58,45 @@ struct FastPlan {
 hipError_t launch_scan_fast(const FastPlan &P, int nf, int ng, int na, int mode, bool time, int n_wg,
                             size_t lds_bytes, hipStream_t st);
 
+// ---- partitioned histograms (strategy 5) -------------------------------------------------
+// Full-histogram queries over many cells cannot keep [cell][agg][bucket] in LDS, and one
+// device-scope atomic per value runs at ~23 G atomics/s (config 4: 129 ms per 1e9 rows).
+// Instead k_emit writes one 4-byte record per accepted (row, agg) into the buffer of the
+// PARTITION that owns the value's (cell, agg) pair -- kPartCells pairs per partition -- and
+// k_part_hist then lets one workgroup own a partition: its 32 bucket arrays, counts and sums
+// live in LDS, are updated with LDS atomics and are written out with plain stores.
+constexpr int kPartCells = 32;       // (cell, agg) pairs per partition
+constexpr int kPartCellBits = 5;
+constexpr int kBucketBits = 10;      // len(Values) <= 1002
+constexpr int kMaxParts = 2048;      // LDS staging in k_emit: n_parts x slots records
+constexpr int kEmitLdsWords = 32768; // 128 KB of staging: slots = (kEmitLdsWords - n_parts) / n_parts, 15..1023
+
+struct EmitPlan {
+    FastPlan fp;                     // columns, filters, group mapping, hmin / bucket geometry
+    uint32_t *recs;                  // [n_parts][part_cap] records
+    uint32_t *cursor;                // [n_parts] records written
+    int64_t part_cap;
+    int32_t n_parts, n_aggs;
+    int32_t slots;                   // LDS staging slots per partition
+    int32_t rem_bits[kFastMaxA];     // bits of (v - hmin) % BucketSize kept in the record
+    int64_t *sum_out;                // header: matched / overflow / partition overflow
+};
+
+struct PartHistPlan {
+    const uint32_t *recs;
+    const uint32_t *cursor;
+    int64_t part_cap;
+    int32_t n_parts, n_aggs, n_cells, nv_max;
+    int32_t split;                   // workgroups per partition (> 1: results are combined with atomics)
+    int32_t rem_bits[kFastMaxA], n_values[kFastMaxA], f_sum[kFastMaxA], m_max[kFastMaxA];
+    int64_t hmin[kFastMaxA], bucket_size[kFastMaxA], hist_agg_off[kFastMaxA];
+    int64_t hist_off, hist_stride;
+    int64_t *sum_out, *max_out;
+};
+
+hipError_t launch_emit(const EmitPlan &P, int nf, int ng, int na, int n_wg, hipStream_t st);
+hipError_t launch_part_hist(const PartHistPlan &P, hipStream_t st);
+
 #ifdef __HIPCC__
 
 typedef long long fll2 __attribute__((ext_vector_type(2)));
@@ -254,6 +293,174 @@ __global__ __launch_bounds__(kWgThreads, 4) void k_scan_fast(const FastPlan P) {
     }
 }
 
+// k_emit: filters + cell index exactly as k_scan_fast, but instead of accumulating it appends
+// rec = (local pair << 10 | bucket) << rem_bits | remainder to the owning partition.  Records are
+// staged in LDS bins (E.slots per partition) and flushed in runs so that the global cursor
+// sees one atomic per run instead of one per record.
+template <int NF, int NG, int NA>
+__global__ __launch_bounds__(kWgThreads, 4) void k_emit(const EmitPlan E) {
+    extern __shared__ uint32_t elds[];
+    const FastPlan &P = E.fp;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t np = (uint32_t)E.n_parts;
+    const uint32_t slots = (uint32_t)E.slots;
+    uint32_t *bin_cnt = elds;                 // [np]
+    uint32_t *bins = elds + np;               // [np][slots]
+    for (uint32_t i = tid; i < np; i += kWgThreads) bin_cnt[i] = 0;
+    __syncthreads();
+
+    // Flushes every bin holding >= min_fill records as ONE run: a single cursor bump, then a
+    // contiguous copy.  Small bins (many partitions) are copied by one thread each; big bins (few
+    // partitions) by a whole wave so the copy is coalesced.
+    auto flush = [&](uint32_t min_fill) {
+        if (slots <= 32) {
+            for (uint32_t p = tid; p < np; p += kWgThreads) {
+                uint32_t n = bin_cnt[p];
+                if (n > slots) n = slots;
+                if (n == 0 || n < min_fill) continue;
+                const uint32_t pos = __hip_atomic_fetch_add(E.cursor + p, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((int64_t)pos + n <= E.part_cap) {
+                    uint32_t *dst = E.recs + (int64_t)p * E.part_cap + pos;
+                    for (uint32_t k = 0; k < n; k++) dst[k] = bins[p * slots + k];
+                } else {
+                    __hip_atomic_fetch_add(E.sum_out + kHdrPartOverflow, (int64_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                bin_cnt[p] = 0;
+            }
+        } else {
+            const uint32_t lane = tid & 63, wave = tid >> 6;
+            for (uint32_t p = wave; p < np; p += kWgThreads / 64) {
+                uint32_t n = bin_cnt[p];
+                if (n > slots) n = slots;
+                if (n == 0 || n < min_fill) continue;  // wave-uniform
+                uint32_t pos = 0;
+                if (lane == 0) pos = __hip_atomic_fetch_add(E.cursor + p, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                pos = __shfl(pos, 0, 64);
+                if ((int64_t)pos + n <= E.part_cap) {
+                    uint32_t *dst = E.recs + (int64_t)p * E.part_cap + pos;
+                    for (uint32_t k = lane; k < n; k += 64) dst[k] = bins[p * slots + k];
+                } else if (lane == 0) {
+                    __hip_atomic_fetch_add(E.sum_out + kHdrPartOverflow, (int64_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (lane == 0) bin_cnt[p] = 0;
+            }
+        }
+    };
+
+    uint32_t matched = 0, overflow = 0;
+    const int s0 = P.wg_seg_begin[blockIdx.x], s1 = P.wg_seg_begin[blockIdx.x + 1];
+    for (int si = s0; si < s1; si++) {
+        const Segment seg = P.segs[si];
+        const int64_t end = seg.start + seg.n;
+        // every thread runs the same number of tiles so the barriers line up
+        const int64_t n_tiles = (seg.n + kTileRows - 1) / kTileRows;
+        int64_t row = seg.start + (int64_t)tid * kRowsPerThread;
+        FastTile<NF> f0, f1;
+        FastTile<NG> g0, g1;
+        FastTile<NA> a0, a1;
+        FastTile<1> t0;
+        if (row < end) fast_load<NF, NG, NA, false>(P, row, f0, g0, a0, t0);
+        for (int64_t it = 0; it < n_tiles; it++, row += kTileRows) {
+            const int64_t nrow = row + kTileRows;
+            if (nrow < end) fast_load<NF, NG, NA, false>(P, nrow, f1, g1, a1, t0);
+#pragma unroll
+            for (int r = 0; r < kRowsPerThread; r++) {
+                if (row + r >= end) break;
+                bool pass = true;
+#pragma unroll
+                for (int c = 0; c < NF; c++) {
+                    const int64_t x = r == 0 ? f0.v[c].x : f0.v[c].y;
+                    pass = pass && x >= P.lo[c] && x <= P.hi[c];
+                }
+                if (!pass) continue;
+                matched += 1;
+                uint32_t cell = 0;
+                bool inb = true;
+#pragma unroll
+                for (int c = 0; c < NG; c++) {
+                    const int64_t x = r == 0 ? g0.v[c].x : g0.v[c].y;
+                    const uint64_t d = (uint64_t)x - (uint64_t)P.gmin[c];
+                    inb = inb && d < (uint64_t)P.gcard[c];
+                    cell += (uint32_t)d * (uint32_t)P.gstride[c];
+                }
+                if (!inb) {
+                    overflow += 1;
+                    continue;
+                }
+#pragma unroll
+                for (int c = 0; c < NA; c++) {
+                    const int64_t x = r == 0 ? a0.v[c].x : a0.v[c].y;
+                    const uint32_t n = (uint32_t)((uint64_t)x - (uint64_t)P.hmin[c]);
+                    uint32_t b = (uint32_t)((double)n * P.inv_bucket[c]);
+                    int32_t rem = (int32_t)(n - b * P.bucket_size[c]);
+                    if (rem < 0) {
+                        b -= 1;
+                        rem += (int32_t)P.bucket_size[c];
+                    } else if ((uint32_t)rem >= P.bucket_size[c]) {
+                        b += 1;
+                        rem -= (int32_t)P.bucket_size[c];
+                    }
+                    const uint32_t pair = cell * (uint32_t)NA + (uint32_t)c;
+                    const uint32_t part = pair >> kPartCellBits;
+                    const uint32_t rec = ((((pair & (kPartCells - 1)) << kBucketBits) | b) << E.rem_bits[c]) | (uint32_t)rem;
+                    const uint32_t slot = __hip_atomic_fetch_add(bin_cnt + part, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (slot < slots) {
+                        bins[part * slots + slot] = rec;
+                    } else {
+                        // the bin is full until the next flush: append this record directly
+                        const uint32_t pos = __hip_atomic_fetch_add(E.cursor + part, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if ((int64_t)pos < E.part_cap) {
+                            E.recs[(int64_t)part * E.part_cap + pos] = rec;
+                        } else {
+                            __hip_atomic_fetch_add(E.sum_out + kHdrPartOverflow, (int64_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    }
+                }
+            }
+            f0 = f1;
+            g0 = g1;
+            a0 = a1;
+            __syncthreads();
+            flush(slots / 2);
+            __syncthreads();
+        }
+    }
+    flush(1);
+
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        matched += __shfl_xor(matched, o, 64);
+        overflow += __shfl_xor(overflow, o, 64);
+    }
+    if ((tid & 63) == 0) {
+        if (matched) __hip_atomic_fetch_add(E.sum_out + kHdrMatched, (int64_t)matched, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (overflow) __hip_atomic_fetch_add(E.sum_out + kHdrOverflow, (int64_t)overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+template <int NF>
+static hipError_t emit_launch_nf(const EmitPlan &E, int ng, int na, int n_wg, hipStream_t st) {
+    const size_t lds = (size_t)E.n_parts * (1 + (size_t)E.slots) * 4;
+#define SYBL_EMIT_CASE(G, A)                                                                               \
+    case (G)*3 + (A): {                                                                                    \
+        auto k = k_emit<NF, G, A>;                                                                         \
+        hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (e != hipSuccess) return e;                                                                     \
+        hipLaunchKernelGGL(k, dim3(n_wg), dim3(kWgThreads), lds, st, E);                                   \
+        return hipGetLastError();                                                                          \
+    }
+    switch (ng * 3 + na) {
+        SYBL_EMIT_CASE(0, 1)
+        SYBL_EMIT_CASE(0, 2)
+        SYBL_EMIT_CASE(1, 1)
+        SYBL_EMIT_CASE(1, 2)
+        SYBL_EMIT_CASE(2, 1)
+        SYBL_EMIT_CASE(2, 2)
+    default: return hipErrorInvalidValue;
+    }
+#undef SYBL_EMIT_CASE
+}
+
 // One translation unit per NF keeps the build parallel (Makefile: kernels_fast_<NF>.o).
 template <int NF, int NG, int NA, int MODE>
 static hipError_t fast_launch_one(const FastPlan &P, bool time, int n_wg, size_t lds_bytes, hipStream_t st) {
@@ -304,6 +511,11 @@ static hipError_t fast_launch_nf(const FastPlan &P, int ng, int na, int mode, bo
 #endif  // __HIPCC__
 
 // per-NF entry points (kernels_fast_<NF>.hip)
+hipError_t launch_emit_nf0(const EmitPlan &E, int ng, int na, int n_wg, hipStream_t st);
+hipError_t launch_emit_nf1(const EmitPlan &E, int ng, int na, int n_wg, hipStream_t st);
+hipError_t launch_emit_nf2(const EmitPlan &E, int ng, int na, int n_wg, hipStream_t st);
+hipError_t launch_emit_nf3(const EmitPlan &E, int ng, int na, int n_wg, hipStream_t st);
+hipError_t launch_emit_nf4(const EmitPlan &E, int ng, int na, int n_wg, hipStream_t st);
 hipError_t launch_scan_fast_nf0(const FastPlan &P, int ng, int na, int mode, bool time, int n_wg, size_t lds, hipStream_t st);
 hipError_t launch_scan_fast_nf1(const FastPlan &P, int ng, int na, int mode, bool time, int n_wg, size_t lds, hipStream_t st);
 hipError_t launch_scan_fast_nf2(const FastPlan &P, int ng, int na, int mode, bool time, int n_wg, size_t lds, hipStream_t st);

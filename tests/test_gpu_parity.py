@@ -52,9 +52,42 @@ def test_cfg3_with_full_histograms(ctx, oracle):
 def test_cfg4_high_cardinality_histograms(ctx, oracle):
     wl = _wl("cfg4_hist_highcard")
     gres, ores, stats = parity.run_both(ctx, oracle, wl["columns"], 400_000, 0, 400_000, wl["query"])
-    assert stats["strategy"] == 1  # 65536 groups do not fit in LDS: global-atomic strategy
+    assert stats["strategy"] == 5  # 65536 groups x 1002 buckets: partitioned histograms
     parity.compare(gres, ores, op="hist", full=True, n_aggs=1)
     gres.free()
+
+
+def test_cfg4_global_atomic_strategy(ctx, oracle, monkeypatch):
+    # the fallback when a query is not eligible for partitioned histograms
+    monkeypatch.setenv("SYBL_NO_PARTHIST", "1")
+    wl = _wl("cfg4_hist_highcard")
+    gres, ores, stats = parity.run_both(ctx, oracle, wl["columns"], 300_000, 0, 300_000, wl["query"])
+    assert stats["strategy"] == 1
+    parity.compare(gres, ores, op="hist", full=True, n_aggs=1)
+    gres.free()
+
+
+def test_partition_overflow_falls_back(ctx, oracle):
+    """All rows land in ONE of 2048 partitions (declared bounds far wider than the data): the
+    partition buffer overflows, finalize redoes the scan with per-value atomics, results unchanged."""
+    from sybil_amd import synth
+    n = 400_000
+    cols = [dict(name="g", kind=synth.UNIFORM, col_index=1, a=7, b=1, info_min=0, info_max=65535),
+            dict(name="v", kind=synth.UNIFORM, col_index=7, a=0, b=1_000_000, info_min=0, info_max=999_999)]
+    t = ctx.synth_table("skew", synth.SEED, n, 0, n, cols)
+    t.set_bounds("g", 0, 65535)
+    q = t.query(groups=["g"], aggs=["v"], op="hist")
+    assert q.stats()["strategy"] == 5
+    r = q.run()
+    assert q.stats()["strategy"] == 1          # fell back
+    v = oracle.synth_fill(synth.UNIFORM, 0, 1_000_000, synth.SEED, 7, 0, n, n)
+    g = np.full(n, 7, dtype=np.int64)
+    o = oracle.run_query([{"type": "int", "data": g}, {"type": "int", "data": v}], groups=[0], aggs=[(1, 0, 999_999)],
+                         op="hist")
+    parity.compare(r, o, op="hist", full=True, n_aggs=1)
+    r.free()
+    q.free()
+    t.free()
 
 
 def test_shard_of_a_larger_table(ctx, oracle):
