@@ -473,7 +473,20 @@ static int plan_query(Table *t, const sybl_query_desc *d, Query *q) {
             hi = -1;
         }
         unsigned __int128 card = hi >= lo ? (unsigned __int128)((__int128)hi - (__int128)lo) + 1 : 0;
-        if (gi.has_missing) card += 1;
+        // A missing key is written as MISSING_VALUE = 0xFFFFFFFFFFFFFFFF (aggregate.go:31,138), which
+        // is also the 8-byte image of the int value -1: the reference folds both into ONE group.
+        // When -1 is inside the key range the missing rows share its cell; otherwise they get an
+        // extra digit of their own.
+        gi.missing_digit = -1;
+        gi.value_card = (int32_t)card;
+        if (gi.has_missing) {
+            if (c->type == SYBL_INT_VAL && hi >= lo && lo <= -1 && hi >= -1) {
+                gi.missing_digit = (int32_t)(-1 - lo);
+            } else {
+                gi.missing_digit = (int32_t)card;
+                card += 1;
+            }
+        }
         if (card == 0) card = 1;
         if (card * (unsigned __int128)cells > ((unsigned __int128)1 << 27))
             return fail(SYBL_E_INVAL,
@@ -499,7 +512,8 @@ static int plan_query(Table *t, const sybl_query_desc *d, Query *q) {
             sd.gmin = q->groups[g].gmin;
             sd.gcard = q->groups[g].gcard;
             sd.gstride = (int32_t)stride;
-            sd.gmissing = q->groups[g].has_missing ? (int32_t)((q->groups[g].gcard - 1) * stride) : -1;
+            sd.gmissing = q->groups[g].missing_digit >= 0 ? (int32_t)(q->groups[g].missing_digit * stride) : -1;
+            sd.gvalues = q->groups[g].value_card;
         }
     }
     q->group_cells = cells;
@@ -571,6 +585,7 @@ static int plan_query(Table *t, const sybl_query_desc *d, Query *q) {
         bool can_reject = c->has_missing || (!empty && (lo < A.info_min || hi > A.max10));
         A.f_cnt = (q->weighted || can_reject) ? F++ : -1;
         A.f_smp = q->weighted ? F++ : -1;
+        A.f_pop = c->has_missing ? F++ : -1;
         A.f_sb = A.f_sb2 = A.f_out = -1;
         // BasicHist.Min/Max start at Info.Min/Info.Max in hist mode and at 0 in avg mode
         // (hist_basic.go:34-40,72-85) and accepted values are >= Info.Min, so the running

@@ -125,7 +125,9 @@ struct GroupInfo {
     int col;
     int type;
     int64_t gmin;
-    int32_t gcard;
+    int32_t gcard;       // digits of this key column incl. a separate MISSING digit, if any
+    int32_t value_card;  // digits that are real values
+    int32_t missing_digit;  // digit missing rows map to (-1: column has no missing rows)
     bool has_missing;
 };
 

@@ -179,8 +179,7 @@ __device__ __forceinline__ void process_tile(CPlan &P, const Tile<NC> &t, int64_
             if (s.flags & kSlotGroup) {
                 if (pop) {
                     uint64_t d = (uint64_t)x - (uint64_t)s.gmin;
-                    uint32_t lim = (uint32_t)(s.gmissing >= 0 ? s.gcard - 1 : s.gcard);
-                    if (d >= lim) in_bounds = false;
+                    if (d >= (uint32_t)s.gvalues) in_bounds = false;
                     cell += (int32_t)d * s.gstride;
                 } else if (s.gmissing >= 0) {
                     cell += s.gmissing;
@@ -241,7 +240,9 @@ __device__ __forceinline__ void process_tile(CPlan &P, const Tile<NC> &t, int64_
             const int64_t x = r == 0 ? t.v[c].x : t.v[c].y;
             const bool pop = (t.pop[c] >> r) & 1u;
             CAgg &A = P.agg[s.agg_index];
-            if (!pop || x > A.max10 || x < A.info_min) continue;  // hist_basic.go:104
+            if (!pop) continue;
+            if (A.f_pop >= 0) acc_add<USE_LDS>(sumtab, ((int64_t)A.f_pop * ncell << rs) + cidx, 1);
+            if (x > A.max10 || x < A.info_min) continue;  // hist_basic.go:104
             acc_add<USE_LDS>(sumtab, ((int64_t)A.f_sum * ncell << rs) + cidx, (int64_t)((uint64_t)x * (uint64_t)w));
             if (A.f_cnt >= 0) acc_add<USE_LDS>(sumtab, ((int64_t)A.f_cnt * ncell << rs) + cidx, w);
             if (A.f_smp >= 0) acc_add<USE_LDS>(sumtab, ((int64_t)A.f_smp * ncell << rs) + cidx, 1);

@@ -41,10 +41,13 @@ struct SlotDesc {
     uint32_t flags;
     int32_t n_neq;
     int32_t idmask_bits;
-    int32_t gcard;           // distinct key values incl. the MISSING slot
+    int32_t gcard;           // digits incl. a separate MISSING digit
+    int32_t gvalues;         // digits that are real values (x - gmin must be below this)
     int32_t gstride;
-    int32_t gmissing;        // (gcard-1)*gstride when the column has missing rows, else -1
+    int32_t gmissing;        // cell offset of missing rows (their own digit, or the digit of the value
+                             // -1 whose 8-byte image equals MISSING_VALUE), -1 = column has no missing rows
     int32_t agg_index;
+    int32_t pad_;
     // kSlotSet (filter.go:252-285): predicate p passes when (any member == set_id[p]) == set_in[p]
     int32_t n_setp;
     const int32_t *set_vals;  // CSR member ids (table-global dictionary)
@@ -64,6 +67,9 @@ struct AggDesc {
     int32_t f_sum;        // sum(v*w)
     int32_t f_cnt;        // sum(w) over accepted values (only if rejection/missing/weights possible)
     int32_t f_smp;        // accepted values (weighted queries)
+    int32_t f_pop;        // populated values incl. rejected ones: the group owns a hist for the
+                          // aggregation as soon as one INT value was seen (aggregate.go:246-258);
+                          // tracked only for columns with missing rows (else == row count)
     int32_t f_sb;         // moments: sum(b*w)
     int32_t f_sb2;        // moments: sum(b*b*w)
     int32_t f_out;        // 6 fields: n, sum(o), sum(o^2) as four 32-bit limbs -- only when the
@@ -71,7 +77,6 @@ struct AggDesc {
     int32_t m_max;        // MAX-section field: max(v)
     int32_t m_nmin;       // MAX-section field: max(-v)
     int32_t hist_full;    // 1: bucket arrays in the SUM section (global atomics)
-    int32_t pad_;
 };
 
 struct Segment {           // a run of physical rows one workgroup scans

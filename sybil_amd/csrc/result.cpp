@@ -27,7 +27,7 @@ namespace sybl {
 
 struct AggAcc {
     bool tracked_cnt = false;
-    int64_t cnt = 0, smp = 0;
+    int64_t cnt = 0, smp = 0, pop = 0;
     uint64_t sum = 0;
     int64_t sb = 0, sb2 = 0;
     int64_t n_out = 0;
@@ -98,8 +98,9 @@ static void agg_finish(const Query *q, Result *R, const AggInfo &ai, const AggAc
     pct_off = -1;
     const AggDesc &A = ai.d;
     int64_t cnt = a.tracked_cnt ? a.cnt : row_count;
-    bool present = q->weighted ? a.smp > 0 : cnt > 0;
-    if (!present) return;
+    // the hist exists once the group saw ONE populated value for the column, accepted or not
+    // (aggregate.go:246-258 creates it before AddWeightedValue can reject)
+    if (a.pop <= 0) return;
     o.present = 1;
     o.count = cnt;
     o.samples = q->weighted ? a.smp : 0;  // BasicHist.Samples only moves with a weight column (hist_basic.go:111-116)
@@ -150,7 +151,7 @@ static void agg_finish(const Query *q, Result *R, const AggInfo &ai, const AggAc
                                          (long double)cnt
                                    : 0.0L;
         var += out_term;
-        o.stddev = var > 0 ? (double)sqrtl(var) : 0.0;
+        o.stddev = cnt == 0 ? (double)NAN : (var > 0 ? (double)sqrtl(var) : 0.0);  // Go: 0/0 ratios -> NaN
     }
 }
 
@@ -167,11 +168,13 @@ static void build_key(const Query *q, int64_t gcell, uint8_t *key, std::string &
         int64_t digit = rem / stride;
         rem -= digit * stride;
         uint64_t v;
-        bool missing = gi.has_missing && digit == gi.gcard - 1;
-        if (missing) {
-            v = UINT64_MAX;  // MISSING_VALUE, aggregate.go:31
+        bool missing = digit >= gi.value_card;  // the separate MISSING digit
+        if (!missing) v = (uint64_t)(gi.gmin + digit);
+        if (missing || (gi.type == SYBL_INT_VAL && v == UINT64_MAX)) {
+            // MISSING_VALUE (aggregate.go:31).  The int value -1 has the same 8-byte image, shares the
+            // group, and translate_group_by prints nothing for it either (aggregate.go:308-316).
+            v = UINT64_MAX;
         } else {
-            v = (uint64_t)(gi.gmin + digit);
             if (gi.type == SYBL_STR_VAL) {
                 const Column *c = q->t->cols[(size_t)gi.col].get();
                 size_t id = (size_t)(gi.gmin + digit);
@@ -299,6 +302,7 @@ int query_finalize(Query *q, Result **out) {
             x.tracked_cnt = true;
             x.cnt = A.f_cnt >= 0 ? F[(int64_t)A.f_cnt * ncell + cell] : acc.count;
             if (A.f_smp >= 0) x.smp = F[(int64_t)A.f_smp * ncell + cell];
+            x.pop = A.f_pop >= 0 ? F[(int64_t)A.f_pop * ncell + cell] : (P.f_samples >= 0 ? acc.samples : acc.count);
             if (A.f_sb >= 0) x.sb = F[(int64_t)A.f_sb * ncell + cell];
             if (A.f_sb2 >= 0) x.sb2 = F[(int64_t)A.f_sb2 * ncell + cell];
             if (A.f_out >= 0) {
@@ -375,6 +379,7 @@ int query_finalize(Query *q, Result **out) {
                     const AggAcc &s = acc.aggs[a];
                     d.cnt += s.cnt;
                     d.smp += s.smp;
+                    d.pop += s.pop;
                     d.sum += s.sum;
                     d.sb += s.sb;
                     d.sb2 += s.sb2;
@@ -428,6 +433,7 @@ int query_finalize(Query *q, Result **out) {
                 const AggAcc &s2 = part[k].aggs[a];
                 d.cnt += s2.cnt;
                 d.smp += s2.smp;
+                d.pop += s2.pop;
                 d.sum += s2.sum;
                 d.sb += s2.sb;
                 d.sb2 += s2.sb2;

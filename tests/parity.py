@@ -36,7 +36,7 @@ def oracle_query_kwargs(names, info, q):
 def _close(a, b, rel=REL, scale=0.0):
     """|a-b| <= rel * max(|a|,|b|,scale): `scale` is the magnitude of the data the quantity was
     derived from (a stddev of 0 vs 2e-15 on values ~1e3 is agreement, not a 100% error)."""
-    if a == b:
+    if a == b or (a != a and b != b):  # both NaN: an existing hist without accepted values (0/0 in Go too)
         return True
     return abs(a - b) <= rel * max(abs(a), abs(b), scale)
 
@@ -49,19 +49,26 @@ def compare_hist(g, o, op, full, ctx=""):
     assert g["samples"] == o["samples"], ctx
     assert g["sum"] == o["sum_exact"], (ctx, g["sum"], o["sum_exact"])
     assert (g["min"], g["max"]) == (o["min"], o["max"]), (ctx, g["min"], g["max"], o["min"], o["max"])
-    # avg: exact sum/count here vs the reference-order running mean of the oracle
-    assert _close(g["avg"], o["avg"]), (ctx, g["avg"], o["avg"])
+    # avg: exact sum/count here vs the reference-order running mean of the oracle.  The reference's
+    # mean turns into NaN for good once a hist with Count == 0 (every value of the group in that
+    # block rejected by the Info.Min/Max gate) is combined (0/0 in hist_basic.go:264-265) -- and
+    # whether that happens depends on block completion order.  The engine returns the exact mean.
+    o_avg = o["avg"]
+    if o_avg != o_avg:
+        o_avg = o["sum_exact"] / o["count"] if o["count"] else 0.0
+    assert _close(g["avg"], o_avg), (ctx, g["avg"], o["avg"])
     if op == "hist":
         assert g["bucket_size"] == o["bucket_size"] and g["n_values"] == o["n_values"], ctx
         assert g["num_buckets"] == o["num_buckets"], ctx
         assert g["n_outliers"] == o["n_outliers"] + o["n_underliers"], ctx
         scale = max(abs(o["avg"]), abs(o["bucket_size"]), 1.0)
         assert _close(g["stddev"], o["stddev_exact"], 1e-9, scale), (ctx, g["stddev"], o["stddev_exact"])
-        if o["n_outliers"] + o["n_underliers"] == 0:
+        if o["n_outliers"] + o["n_underliers"] == 0 and o["avg"] == o["avg"]:
             assert _close(g["stddev"], o["stddev_ref"], REL, scale), (ctx, g["stddev"], o["stddev_ref"])
         if full:
             assert np.array_equal(g["values"], o["values"]), ctx
-            assert np.array_equal(g["percentiles"], o["percentiles"]), ctx
+            # GetPercentiles returns an empty slice while Count == 0 (hist_basic.go:154-156)
+            assert np.array_equal(g.get("percentiles", np.zeros(0, dtype=np.int64)), o["percentiles"]), ctx
     else:
         assert g["stddev"] == 0.0, ctx
 
