@@ -104,3 +104,97 @@ def test_random_queries(ctx, oracle, seed):
         gres.free()
         query.free()
     tb.free()
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_queries_with_strings_and_sets(ctx, oracle, seed):
+    import re
+    rng = np.random.default_rng(5000 + seed)
+    n = int(rng.integers(50, 20_000))
+    block_rows = int(rng.choice([512, 3000, 65536]))
+    vocab = ["%s%d" % (p, i) for p in ("ab", "ba", "zz") for i in range(int(rng.integers(1, 12)))]
+    tags = ["t%d" % i for i in range(int(rng.integers(1, 9)))]
+    s_ids = rng.integers(0, len(vocab), size=n)
+    s_pop = (rng.random(n) > 0.1).astype(np.uint8)
+    g = rng.integers(0, 6, size=n).astype(np.int64)
+    v = rng.integers(0, 10_000, size=n).astype(np.int64)
+    set_rows = [sorted(set(rng.integers(0, len(tags), size=int(rng.integers(0, 4))).tolist())) for _ in range(n)]
+    set_pop = np.array([1 if (r and rng.random() > 0.05) else 0 for r in set_rows], dtype=np.uint8)
+    tb = ctx.create_table("fz")
+    tb.add_column("s", "str")
+    tb.add_column("g", "int")
+    tb.add_column("v", "int", 0, 9_999)
+    tb.add_column("z", "set")
+    for r0 in range(0, n, block_rows):
+        r1 = min(r0 + block_rows, n)
+        # a block-local dictionary in scrambled order, as the reference's blocks have
+        perm = rng.permutation(len(vocab))
+        inv = np.argsort(perm)
+        off, flat = [0], []
+        for r in range(r0, r1):
+            flat += set_rows[r]
+            off.append(len(flat))
+        tb.append_block(r1 - r0, {
+            "s": {"ids": inv[s_ids[r0:r1]].astype(np.int32), "strings": [vocab[i] for i in perm], "populated": s_pop[r0:r1]},
+            "g": g[r0:r1], "v": v[r0:r1],
+            "z": {"ids": np.array(flat, dtype=np.int32), "offsets": np.array(off, dtype=np.int64), "strings": tags,
+                  "populated": set_pop[r0:r1]}})
+    off, flat = [0], []
+    for r in range(n):
+        flat += set_rows[r] if set_pop[r] else []
+        off.append(len(flat))
+    ocols = [{"type": "str", "data": s_ids.astype(np.int32), "populated": s_pop}, {"type": "int", "data": g},
+             {"type": "int", "data": v},
+             {"type": "set", "data": np.array(flat, dtype=np.int32), "offsets": np.array(off, dtype=np.int64), "populated": set_pop}]
+    for k in range(6):
+        filters, ofilters = [], []
+        for _ in range(int(rng.integers(0, 3))):
+            kind = rng.choice(["str", "set", "int"])
+            if kind == "str":
+                op = str(rng.choice(["eq", "neq", "re", "nre"]))
+                if op in ("eq", "neq"):
+                    val = str(rng.choice(vocab + ["nope"]))
+                    filters.append(("s", op, val))
+                    ofilters.append((0, op, vocab.index(val) if val in vocab else -1))
+                else:
+                    pat = str(rng.choice(["^ab", "1$", "^z", "a[0-3]", "b"]))
+                    filters.append(("s", op, pat))
+                    ofilters.append((0, op, 0, np.array([bool(re.search(pat, x)) for x in vocab], dtype=np.uint8)))
+            elif kind == "set":
+                op = str(rng.choice(["in", "nin"]))
+                val = str(rng.choice(tags + ["none"]))
+                filters.append(("z", op, val))
+                ofilters.append((3, op, tags.index(val) if val in tags else -1))
+            else:
+                op = str(rng.choice(["gt", "lt", "neq"]))
+                val = int(rng.integers(0, 10_000))
+                filters.append(("v", op, val))
+                ofilters.append((2, op, val))
+        groups = [str(x) for x in rng.choice(["s", "g"], size=int(rng.integers(0, 3)), replace=False)]
+        q = dict(filters=filters, groups=groups, aggs=["v"] if rng.random() < 0.7 else [], op=str(rng.choice(["avg", "hist"])))
+        query = tb.query(**q)
+        gres = query.run()
+        ores = oracle.run_query(ocols, filters=ofilters, groups=[{"s": 0, "g": 1}[x] for x in groups],
+                                aggs=[(2, 0, 9_999)] if q["aggs"] else [], op=q["op"], block_rows=block_rows)
+        # str group keys are engine-private dictionary ids: compare through the translated strings
+        def tr(keyvals):
+            out = ""
+            for name, kv in zip(groups, keyvals):
+                if kv == 0xFFFFFFFFFFFFFFFF:
+                    out += "\t"
+                elif name == "s":
+                    out += vocab[kv] + "\t"
+                else:
+                    out += "%d\t" % kv
+            return out or "total"
+        gmap = {r["group_by_key"]: r for r in gres.results}
+        omap = {tr(r["key_vals"]): r for r in ores["results"]}
+        assert gres.matched == ores["matched"], (seed, k, q)
+        assert set(gmap) == set(omap), (seed, k, q)
+        for key, o in omap.items():
+            assert gmap[key]["count"] == o["count"], (seed, k, q, key)
+            if q["aggs"]:
+                parity.compare_hist(gmap[key]["hists"][0], o["hists"][0], q["op"], True, ctx=(seed, k, key))
+        gres.free()
+        query.free()
+    tb.free()
