@@ -15,7 +15,12 @@
 #include <string.h>
 #include <sys/stat.h>
 
+#include <stdlib.h>
+
 #include <algorithm>
+#include <deque>
+#include <future>
+#include <thread>
 
 #include "engine.h"
 #include "gob.h"
@@ -64,18 +69,38 @@ struct Stage {  // grow-only device staging buffers for one table load
     }
 };
 
-// Flattens Bins []{Value, Records []uint32}: validates ids against num_records the way the
-// reference does ("BLOCK SIZE CHANGED DURING QUERY", column_store_io.go:733-735) and counts rows.
+// ---- phase 1 (worker threads, pure CPU): read + gob-decode + flatten one block's column files.
+// Validation follows the reference: a record id or value count beyond NumRecords marks the block
+// broken ("BLOCK SIZE CHANGED DURING QUERY", column_store_io.go:524-526,572-574,733-735).
+
 struct FlatBins {
     std::vector<int64_t> val, off;
     std::vector<uint32_t> recs;
 };
 
-static int flatten_bins(const gob::Value *bins, bool delta, int64_t num_records, FlatBins &fb, const char *col) {
-    fb.val.clear();
+struct PreparedCol {
+    enum Kind { kAbsent, kIntBins, kIntValues, kStrBins, kStrValues, kSet } kind = kAbsent;
+    FlatBins fb;                       // *Bins
+    bool delta = false, venc = false;
+    std::vector<int64_t> values;       // kIntValues (delta-encoded when venc)
+    std::vector<int32_t> local;        // kStrValues: block-local ids per row
+    std::vector<std::string> strings;  // block StringTable (str / set)
+    std::vector<int64_t> set_off;      // kSet: CSR over the block's rows, block-local member ids
+    std::vector<int32_t> set_ids;
+    std::vector<uint8_t> set_pop;
+};
+
+struct PreparedBlock {
+    int64_t nrows = 0;
+    bool unreadable = false;  // block info.db missing / undecodable / NumRecords <= 0
+    bool broken = false;      // a column failed validation
+    std::string why;
+    std::vector<PreparedCol> cols;
+};
+
+static bool flatten_bins(const gob::Value *bins, bool delta, int64_t num_records, FlatBins &fb) {
     fb.off.assign(1, 0);
-    fb.recs.clear();
-    if (!bins) return SYBL_OK;
+    if (!bins) return true;
     for (auto &b : bins->items) {
         const gob::Value *v = b->field("Value"), *r = b->field("Records");
         fb.val.push_back(v ? v->as_int() : 0);
@@ -83,16 +108,134 @@ static int flatten_bins(const gob::Value *bins, bool delta, int64_t num_records,
             uint64_t abs = 0;
             for (int64_t x : r->ints) {
                 abs = delta ? abs + (uint64_t)x : (uint64_t)x;
-                if (abs >= (uint64_t)num_records)
-                    return fail(SYBL_E_BLOCK, "BLOCK SIZE CHANGED DURING QUERY: record id %llu >= %lld in column '%s'",
-                                (unsigned long long)abs, (long long)num_records, col);
+                if (abs >= (uint64_t)num_records) return false;
                 fb.recs.push_back((uint32_t)x);
             }
         }
         fb.off.push_back((int64_t)fb.recs.size());
     }
-    return SYBL_OK;
+    return true;
 }
+
+static void string_table(const gob::Value &v, std::vector<std::string> &out) {
+    const gob::Value *st = v.field("StringTable");
+    if (!st) return;
+    for (auto &s : st->items) out.push_back(s->s);
+}
+
+struct ColSpec {
+    std::string name;
+    int type;
+};
+
+static PreparedBlock prepare_block(const std::string &bdir, const std::vector<ColSpec> &specs) {
+    static const char *prefix[] = {"", "int_", "str_", "set_"};
+    PreparedBlock pb;
+    std::string err;
+    gob::Value binfo;
+    if (!decode_file(bdir + "/info.db", binfo, err)) {
+        pb.unreadable = true;  // "COULDNT READ BLOCK INFO" -> block skipped (table_block_io.go:234-237)
+        return pb;
+    }
+    const gob::Value *nr = binfo.field("NumRecords");
+    pb.nrows = nr ? nr->as_int() : 0;
+    if (pb.nrows <= 0) {
+        pb.unreadable = true;  // "NUM RECORDS BELOW 0"
+        return pb;
+    }
+    pb.cols.resize(specs.size());
+    for (size_t ci = 0; ci < specs.size(); ci++) {
+        PreparedCol &pc = pb.cols[ci];
+        std::string path = bdir + "/" + prefix[specs[ci].type] + specs[ci].name + ".db";
+        gob::Value v;
+        // a missing file = column unpopulated in this block; "DECODE COL ERR": the reference logs and
+        // carries on with an empty column
+        if (!file_exists(path) || !decode_file(path, v, err)) continue;
+        const gob::Value *f;
+        bool bucket = (f = v.field("BucketEncoded")) && f->as_bool();
+        pc.delta = (f = v.field("DeltaEncodedIDs")) && f->as_bool();
+        pc.venc = (f = v.field("ValueEncoded")) && f->as_bool();
+        bool ok = true;
+        if (specs[ci].type == SYBL_INT_VAL) {  // unpackIntCol, column_store_io.go:690-780
+            if (bucket) {
+                pc.kind = PreparedCol::kIntBins;
+                ok = flatten_bins(v.field("Bins"), pc.delta, pb.nrows, pc.fb);
+            } else {
+                pc.kind = PreparedCol::kIntValues;
+                const gob::Value *vals = v.field("Values");
+                if (vals && vals->kind == gob::Value::kIntVec) pc.values = vals->ints;
+                ok = (int64_t)pc.values.size() <= pb.nrows;
+            }
+        } else if (specs[ci].type == SYBL_STR_VAL) {  // unpackStrCol, :493-609 (without -str-replace)
+            string_table(v, pc.strings);
+            ok = (int64_t)pc.strings.size() <= pb.nrows;
+            if (ok && bucket) {
+                pc.kind = PreparedCol::kStrBins;
+                ok = flatten_bins(v.field("Bins"), pc.delta, pb.nrows, pc.fb);
+                for (auto x : pc.fb.val) ok = ok && x >= 0 && x < (int64_t)pc.strings.size();
+            } else if (ok) {
+                pc.kind = PreparedCol::kStrValues;
+                const gob::Value *vals = v.field("Values");
+                if (vals && vals->kind == gob::Value::kIntVec) {
+                    pc.local.resize(vals->ints.size());
+                    for (size_t r = 0; r < vals->ints.size(); r++) pc.local[r] = (int32_t)vals->ints[r];
+                }
+                ok = (int64_t)pc.local.size() <= pb.nrows;
+            }
+        } else {  // unpackSetCol, :611-688: variable-length sets become CSR (member order is immaterial)
+            pc.kind = PreparedCol::kSet;
+            string_table(v, pc.strings);
+            std::vector<std::vector<int32_t>> rows((size_t)pb.nrows);
+            pc.set_pop.assign((size_t)pb.nrows, 0);
+            if (bucket) {
+                const gob::Value *bins = v.field("Bins");
+                if (bins)
+                    for (auto &b : bins->items) {
+                        const gob::Value *bv = b->field("Value"), *br = b->field("Records");
+                        int64_t id = bv ? bv->as_int() : 0;
+                        if (id < 0 || id >= (int64_t)pc.strings.size()) ok = false;
+                        uint64_t abs = 0;
+                        if (ok && br && br->kind == gob::Value::kIntVec)
+                            for (int64_t x : br->ints) {
+                                abs = pc.delta ? abs + (uint64_t)x : (uint64_t)x;
+                                if (abs >= (uint64_t)pb.nrows) {
+                                    ok = false;
+                                    break;
+                                }
+                                rows[(size_t)abs].push_back((int32_t)id);
+                                pc.set_pop[(size_t)abs] = 1;
+                            }
+                    }
+            } else {
+                const gob::Value *vals = v.field("Values");
+                int64_t n = vals && vals->kind == gob::Value::kSlice ? (int64_t)vals->items.size() : 0;
+                ok = n <= pb.nrows;
+                for (int64_t r = 0; ok && r < n; r++) {
+                    pc.set_pop[(size_t)r] = 1;  // Populated = SET_VAL for every row below len(Values) (:681-684)
+                    const gob::Value &m = *vals->items[(size_t)r];
+                    if (m.kind == gob::Value::kIntVec)
+                        for (int64_t id : m.ints) {
+                            if (id < 0 || id >= (int64_t)pc.strings.size()) ok = false;
+                            else rows[(size_t)r].push_back((int32_t)id);
+                        }
+                }
+            }
+            pc.set_off.assign(1, 0);
+            for (int64_t r = 0; ok && r < pb.nrows; r++) {
+                pc.set_ids.insert(pc.set_ids.end(), rows[(size_t)r].begin(), rows[(size_t)r].end());
+                pc.set_off.push_back((int64_t)pc.set_ids.size());
+            }
+        }
+        if (!ok) {
+            pb.broken = true;  // "ERROR DURING COLUMN UNPACK ... SKIPPING BLOCK" (table_block_io.go:297-301)
+            pb.why = "BLOCK SIZE CHANGED DURING QUERY in column '" + specs[ci].name + "'";
+            return pb;
+        }
+    }
+    return pb;
+}
+
+// ---- phase 2 (serial, in block order): dictionaries, PCIe, decode kernels
 
 static int upload_bins(Table *t, Stage &stage, const FlatBins &fb, const uint32_t **d_recs, const int64_t **d_off,
                        const int64_t **d_val) {
@@ -111,170 +254,78 @@ static int upload_bins(Table *t, Stage &stage, const FlatBins &fb, const uint32_
     return SYBL_OK;
 }
 
-// unpackIntCol, column_store_io.go:690-780
-static int load_int_col(BlockWriter &w, Column *c, const gob::Value &v, Stage &stage) {
+static int put_prefix_valid(BlockWriter &w, uint32_t *valid, int64_t n) {
+    // every row below len(Values) becomes populated, holes included (column_store_io.go:758-766)
+    if (!valid || n <= 0) return SYBL_OK;
+    std::vector<uint32_t> bits((size_t)((w.nrows + 31) / 32), 0);
+    for (int64_t r = 0; r < n; r++) bits[(size_t)(r >> 5)] |= 1u << (r & 31);
+    hipStream_t st = w.t->ctx->stream;
+    SYBL_HIP(hipMemcpyAsync(valid, bits.data(), bits.size() * 4, hipMemcpyHostToDevice, st));
+    SYBL_HIP(hipStreamSynchronize(st));
+    return SYBL_OK;
+}
+
+static int apply_col(BlockWriter &w, Column *c, PreparedCol &pc, Stage &stage) {
     Table *t = w.t;
     hipStream_t st = t->ctx->stream;
-    const gob::Value *f;
-    bool bucket = (f = v.field("BucketEncoded")) && f->as_bool();
-    bool delta = (f = v.field("DeltaEncodedIDs")) && f->as_bool();
-    bool venc = (f = v.field("ValueEncoded")) && f->as_bool();
     void *col = nullptr;
     uint32_t *valid = nullptr;
     int rc;
-    if (bucket) {
-        FlatBins fb;
-        if ((rc = flatten_bins(v.field("Bins"), delta, w.nrows, fb, c->name.c_str()))) return rc;
-        bool all = (int64_t)fb.recs.size() == w.nrows;
+    std::vector<int32_t> lut;
+    for (auto &s : pc.strings) lut.push_back(dict_intern(c, s));  // block-local id -> table-global id
+    switch (pc.kind) {
+    case PreparedCol::kAbsent: return block_col_absent(w, c);
+    case PreparedCol::kIntBins:
+    case PreparedCol::kStrBins: {
+        bool w32 = pc.kind == PreparedCol::kStrBins;
+        if (w32)
+            for (auto &x : pc.fb.val) x = lut[(size_t)x];
+        bool all = (int64_t)pc.fb.recs.size() == w.nrows;
         if ((rc = block_col_device(w, c, all, &col, &valid))) return rc;
         const uint32_t *d_recs;
         const int64_t *d_off, *d_val;
-        if ((rc = upload_bins(t, stage, fb, &d_recs, &d_off, &d_val))) return rc;
-        hipError_t e = launch_decode_bins(d_recs, d_off, d_val, (int)fb.val.size(), delta, col, false, valid, (uint32_t)w.nrows, st);
+        if ((rc = upload_bins(t, stage, pc.fb, &d_recs, &d_off, &d_val))) return rc;
+        hipError_t e = launch_decode_bins(d_recs, d_off, d_val, (int)pc.fb.val.size(), pc.delta, col, w32, valid, (uint32_t)w.nrows, st);
         if (e != hipSuccess) return hip_fail(e, "k_decode_bins");
         SYBL_HIP(hipStreamSynchronize(st));  // staging is reused by the next column
         return SYBL_OK;
     }
-    const gob::Value *vals = v.field("Values");
-    int64_t n = vals && vals->kind == gob::Value::kIntVec ? (int64_t)vals->ints.size() : 0;
-    if (n > w.nrows) return fail(SYBL_E_BLOCK, "BLOCK SIZE CHANGED DURING QUERY: %lld values > %lld records in '%s'",
-                                 (long long)n, (long long)w.nrows, c->name.c_str());
-    // every row below len(Values) becomes populated, holes included (column_store_io.go:758-766)
-    bool all = n == w.nrows;
-    if ((rc = block_col_device(w, c, all, &col, &valid))) return rc;
-    if (valid && n > 0) {
-        std::vector<uint32_t> bits((size_t)((w.nrows + 31) / 32), 0);
-        for (int64_t r = 0; r < n; r++) bits[(size_t)(r >> 5)] |= 1u << (r & 31);
-        SYBL_HIP(hipMemcpyAsync(valid, bits.data(), bits.size() * 4, hipMemcpyHostToDevice, st));
-        SYBL_HIP(hipStreamSynchronize(st));
-    }
-    if (n > 0) {
-        if ((rc = stage.ensure((size_t)n * 8))) return rc;
-        SYBL_HIP(hipMemcpyAsync(stage.d, vals->ints.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
-        hipError_t e = launch_decode_delta((const int64_t *)stage.d, n, venc, (int64_t *)col, st);
-        if (e != hipSuccess) return hip_fail(e, "k_decode_delta");
-        SYBL_HIP(hipStreamSynchronize(st));
-    }
-    return SYBL_OK;
-}
-
-static void string_table(const gob::Value &v, Column *c, std::vector<int32_t> &lut) {
-    lut.clear();
-    const gob::Value *st = v.field("StringTable");
-    if (!st) return;
-    for (auto &s : st->items) lut.push_back(dict_intern(c, s->s));
-}
-
-// unpackStrCol, column_store_io.go:493-609 (without -str-replace)
-static int load_str_col(BlockWriter &w, Column *c, const gob::Value &v, Stage &stage) {
-    Table *t = w.t;
-    hipStream_t st = t->ctx->stream;
-    const gob::Value *f;
-    bool bucket = (f = v.field("BucketEncoded")) && f->as_bool();
-    bool delta = (f = v.field("DeltaEncodedIDs")) && f->as_bool();
-    const gob::Value *stv = v.field("StringTable");
-    if (stv && (int64_t)stv->items.size() > w.nrows)
-        return fail(SYBL_E_BLOCK, "BLOCK SIZE CHANGED DURING QUERY: string table larger than the block in '%s'", c->name.c_str());
-    std::vector<int32_t> lut;
-    string_table(v, c, lut);
-    void *col = nullptr;
-    uint32_t *valid = nullptr;
-    int rc;
-    if (bucket) {
-        FlatBins fb;
-        if ((rc = flatten_bins(v.field("Bins"), delta, w.nrows, fb, c->name.c_str()))) return rc;
-        for (auto &x : fb.val) {
-            if (x < 0 || x >= (int64_t)lut.size()) return fail(SYBL_E_BLOCK, "str bin id outside the StringTable of '%s'", c->name.c_str());
-            x = lut[(size_t)x];  // block-local id -> table-global id
+    case PreparedCol::kIntValues: {
+        int64_t n = (int64_t)pc.values.size();
+        if ((rc = block_col_device(w, c, n == w.nrows, &col, &valid))) return rc;
+        if ((rc = put_prefix_valid(w, valid, n))) return rc;
+        if (n > 0) {
+            if ((rc = stage.ensure((size_t)n * 8))) return rc;
+            SYBL_HIP(hipMemcpyAsync(stage.d, pc.values.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
+            hipError_t e = launch_decode_delta((const int64_t *)stage.d, n, pc.venc, (int64_t *)col, st);
+            if (e != hipSuccess) return hip_fail(e, "k_decode_delta");
+            SYBL_HIP(hipStreamSynchronize(st));
         }
-        bool all = (int64_t)fb.recs.size() == w.nrows;
-        if ((rc = block_col_device(w, c, all, &col, &valid))) return rc;
-        const uint32_t *d_recs;
-        const int64_t *d_off, *d_val;
-        if ((rc = upload_bins(t, stage, fb, &d_recs, &d_off, &d_val))) return rc;
-        hipError_t e = launch_decode_bins(d_recs, d_off, d_val, (int)fb.val.size(), delta, col, true, valid, (uint32_t)w.nrows, st);
-        if (e != hipSuccess) return hip_fail(e, "k_decode_bins");
-        SYBL_HIP(hipStreamSynchronize(st));
         return SYBL_OK;
     }
-    const gob::Value *vals = v.field("Values");
-    int64_t n = vals && vals->kind == gob::Value::kIntVec ? (int64_t)vals->ints.size() : 0;
-    if (n > w.nrows) return fail(SYBL_E_BLOCK, "BLOCK SIZE CHANGED DURING QUERY: %lld values > %lld records in '%s'",
-                                 (long long)n, (long long)w.nrows, c->name.c_str());
-    bool all = n == w.nrows;
-    if ((rc = block_col_device(w, c, all, &col, &valid))) return rc;
-    if (valid && n > 0) {
-        std::vector<uint32_t> bits((size_t)((w.nrows + 31) / 32), 0);
-        for (int64_t r = 0; r < n; r++) bits[(size_t)(r >> 5)] |= 1u << (r & 31);
-        SYBL_HIP(hipMemcpyAsync(valid, bits.data(), bits.size() * 4, hipMemcpyHostToDevice, st));
-        SYBL_HIP(hipStreamSynchronize(st));
+    case PreparedCol::kStrValues: {
+        int64_t n = (int64_t)pc.local.size();
+        if ((rc = block_col_device(w, c, n == w.nrows, &col, &valid))) return rc;
+        if ((rc = put_prefix_valid(w, valid, n))) return rc;
+        if (n > 0) {
+            size_t b_local = ((size_t)n * 4 + 15) / 16 * 16;
+            if ((rc = stage.ensure(b_local + std::max<size_t>(lut.size(), 1) * 4))) return rc;
+            SYBL_HIP(hipMemcpyAsync(stage.d, pc.local.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+            if (!lut.empty())
+                SYBL_HIP(hipMemcpyAsync((char *)stage.d + b_local, lut.data(), lut.size() * 4, hipMemcpyHostToDevice, st));
+            hipError_t e = launch_remap_ids((const int32_t *)stage.d, (const int32_t *)((char *)stage.d + b_local),
+                                            (int32_t)lut.size(), n, (int32_t *)col, st);
+            if (e != hipSuccess) return hip_fail(e, "k_remap_ids");
+            SYBL_HIP(hipStreamSynchronize(st));
+        }
+        return SYBL_OK;
     }
-    if (n > 0) {
-        std::vector<int32_t> local((size_t)n);
-        for (int64_t r = 0; r < n; r++) local[(size_t)r] = (int32_t)vals->ints[(size_t)r];
-        size_t b_local = ((size_t)n * 4 + 15) / 16 * 16;
-        if ((rc = stage.ensure(b_local + std::max<size_t>(lut.size(), 1) * 4))) return rc;
-        SYBL_HIP(hipMemcpyAsync(stage.d, local.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
-        if (!lut.empty())
-            SYBL_HIP(hipMemcpyAsync((char *)stage.d + b_local, lut.data(), lut.size() * 4, hipMemcpyHostToDevice, st));
-        hipError_t e = launch_remap_ids((const int32_t *)stage.d, (const int32_t *)((char *)stage.d + b_local), (int32_t)lut.size(),
-                                        n, (int32_t *)col, st);
-        if (e != hipSuccess) return hip_fail(e, "k_remap_ids");
-        SYBL_HIP(hipStreamSynchronize(st));
+    case PreparedCol::kSet: {
+        for (auto &id : pc.set_ids) id = lut[(size_t)id];
+        return block_col_set_host(w, c, pc.set_off.data(), pc.set_ids.data(), pc.set_pop.data());
+    }
     }
     return SYBL_OK;
-}
-
-// unpackSetCol, column_store_io.go:611-688.  Sets are variable length; the CSR is assembled on
-// the host (members keep bin order) and uploaded with the column's other blocks before a query.
-static int load_set_col(BlockWriter &w, Column *c, const gob::Value &v) {
-    const gob::Value *f;
-    bool bucket = (f = v.field("BucketEncoded")) && f->as_bool();
-    bool delta = (f = v.field("DeltaEncodedIDs")) && f->as_bool();
-    std::vector<int32_t> lut;
-    string_table(v, c, lut);
-    std::vector<std::vector<int32_t>> rows((size_t)w.nrows);
-    std::vector<uint8_t> pop((size_t)w.nrows, 0);
-    if (bucket) {
-        const gob::Value *bins = v.field("Bins");
-        if (bins)
-            for (auto &b : bins->items) {
-                const gob::Value *bv = b->field("Value"), *br = b->field("Records");
-                int64_t id = bv ? bv->as_int() : 0;
-                if (id < 0 || id >= (int64_t)lut.size()) return fail(SYBL_E_BLOCK, "set bin id outside the StringTable of '%s'", c->name.c_str());
-                uint64_t abs = 0;
-                if (br && br->kind == gob::Value::kIntVec)
-                    for (int64_t x : br->ints) {
-                        abs = delta ? abs + (uint64_t)x : (uint64_t)x;
-                        if (abs >= (uint64_t)w.nrows)
-                            return fail(SYBL_E_BLOCK, "BLOCK SIZE CHANGED DURING QUERY: record id %llu >= %lld in set column '%s'",
-                                        (unsigned long long)abs, (long long)w.nrows, c->name.c_str());
-                        rows[(size_t)abs].push_back(lut[(size_t)id]);
-                        pop[(size_t)abs] = 1;
-                    }
-            }
-    } else {
-        const gob::Value *vals = v.field("Values");
-        int64_t n = vals ? (int64_t)(vals->kind == gob::Value::kSlice ? vals->items.size() : 0) : 0;
-        if (n > w.nrows) return fail(SYBL_E_BLOCK, "BLOCK SIZE CHANGED DURING QUERY: %lld set rows > %lld records in '%s'",
-                                     (long long)n, (long long)w.nrows, c->name.c_str());
-        for (int64_t r = 0; r < n; r++) {
-            pop[(size_t)r] = 1;  // Populated = SET_VAL for every row below len(Values) (:681-684)
-            const gob::Value &m = *vals->items[(size_t)r];
-            if (m.kind == gob::Value::kIntVec)
-                for (int64_t id : m.ints) {
-                    if (id < 0 || id >= (int64_t)lut.size()) return fail(SYBL_E_BLOCK, "set member id outside the StringTable of '%s'", c->name.c_str());
-                    rows[(size_t)r].push_back(lut[(size_t)id]);
-                }
-        }
-    }
-    std::vector<int64_t> off(1, 0);
-    std::vector<int32_t> ids;
-    for (int64_t r = 0; r < w.nrows; r++) {
-        ids.insert(ids.end(), rows[(size_t)r].begin(), rows[(size_t)r].end());
-        off.push_back((int64_t)ids.size());
-    }
-    return block_col_set_host(w, c, off.data(), ids.data(), pop.data());
 }
 
 static int open_table(Ctx *ctx, const char *dir, const char *table, const char *const *columns, int32_t n_columns,
@@ -344,55 +395,37 @@ static int open_table(Ctx *ctx, const char *dir, const char *table, const char *
     size_t b0 = blocks.size() * (size_t)rank / (size_t)nranks, b1 = blocks.size() * (size_t)(rank + 1) / (size_t)nranks;
 
     Stage stage;
-    static const char *prefix[] = {"", "int_", "str_", "set_"};
-    for (size_t bi = b0; bi < b1; bi++) {
-        std::string bdir = tdir + "/" + blocks[bi];
-        gob::Value binfo;
-        if (!decode_file(bdir + "/info.db", binfo, err)) {
-            t->broken_blocks++;  // "COULDNT READ BLOCK INFO" -> block skipped (table_block_io.go:234-237)
-            continue;
+    std::vector<ColSpec> specs;
+    for (auto &cp : t->cols) specs.push_back({cp->name, cp->type});
+    // worker threads decode a window of blocks ahead of the (serial, in-order) GPU phase
+    size_t n_workers = std::min<size_t>(32, std::max<unsigned>(1, std::thread::hardware_concurrency()));
+    if (const char *e = getenv("SYBL_LOADER_THREADS")) n_workers = (size_t)std::max(1, atoi(e));
+    const size_t window = n_workers * 2;
+    std::deque<std::future<PreparedBlock>> inflight;
+    size_t next = b0;
+    auto submit = [&]() {
+        while (next < b1 && inflight.size() < window) {
+            std::string bdir = tdir + "/" + blocks[next++];
+            inflight.push_back(std::async(n_workers > 1 ? std::launch::async : std::launch::deferred,
+                                          [bdir, &specs]() { return prepare_block(bdir, specs); }));
         }
-        const gob::Value *nr = binfo.field("NumRecords");
-        int64_t nrows = nr ? nr->as_int() : 0;
-        if (nrows <= 0) {
-            t->broken_blocks++;  // "NUM RECORDS BELOW 0"
+    };
+    submit();
+    while (!inflight.empty()) {
+        PreparedBlock pb = inflight.front().get();
+        inflight.pop_front();
+        submit();
+        if (pb.unreadable || pb.broken) {
+            t->broken_blocks++;
             continue;
         }
         BlockWriter w;
-        if ((rc = block_begin(t, nrows, &w))) return bail(rc);
-        bool broken = false;
-        for (auto &cp : t->cols) {
-            Column *c = cp.get();
-            std::string path = bdir + "/" + prefix[c->type] + c->name + ".db";
-            if (!file_exists(path)) {
-                if ((rc = block_col_absent(w, c))) return bail(rc);
-                continue;
+        if ((rc = block_begin(t, pb.nrows, &w))) return bail(rc);
+        for (size_t ci = 0; ci < t->cols.size(); ci++)
+            if ((rc = apply_col(w, t->cols[ci].get(), pb.cols[ci], stage))) {
+                for (auto &f : inflight) f.wait();
+                return bail(rc);
             }
-            gob::Value cv;
-            if (!decode_file(path, cv, err)) {
-                // "DECODE COL ERR": the reference logs and carries on with an empty column
-                if ((rc = block_col_absent(w, c))) return bail(rc);
-                continue;
-            }
-            if (c->type == SYBL_INT_VAL) rc = load_int_col(w, c, cv, stage);
-            else if (c->type == SYBL_STR_VAL) rc = load_str_col(w, c, cv, stage);
-            else rc = load_set_col(w, c, cv);
-            if (rc == SYBL_E_BLOCK) {
-                broken = true;  // "ERROR DURING COLUMN UNPACK ... SKIPPING BLOCK" (table_block_io.go:297-301)
-                break;
-            }
-            if (rc) return bail(rc);
-        }
-        if (broken) {
-            t->broken_blocks++;
-            // set columns already extended their CSR mirror for this block: roll it back
-            for (auto &cp : t->cols)
-                if (cp->type == SYBL_SET_VAL && (int64_t)cp->h_set_off.size() > w.start + 1) {
-                    cp->h_set_vals.resize((size_t)cp->h_set_off[(size_t)w.start]);
-                    cp->h_set_off.resize((size_t)w.start + 1);
-                }
-            continue;
-        }
         if ((rc = block_commit(w))) return bail(rc);
     }
     *out = t;
