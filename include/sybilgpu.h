@@ -159,6 +159,14 @@ int sybl_table_column_info(const sybl_table *t, const char *name, int *type, int
  * first) so that the direct-mapped group layout, and therefore the partial tables, are
  * identical across ranks.  has_missing != 0 reserves the MISSING_VALUE key slot. */
 int sybl_table_set_bounds(sybl_table *t, const char *name, int64_t lo, int64_t hi, int has_missing);
+/* Group-by on a key column whose value RANGE is too wide for direct mapping (more than 2^22
+ * values, or more than 2^27 cells together with the other keys) goes through a dictionary of the
+ * column's DISTINCT values (at most 2^22), built on the GPU on first use.  Multi-rank hosts make
+ * the dictionaries identical: gather sybl_table_column_distinct from every rank, install the
+ * union with sybl_table_set_group_dict on every rank.  `values` is library-owned (valid until the
+ * column changes). */
+int sybl_table_column_distinct(sybl_table *t, const char *name, const int64_t **values, int64_t *n);
+int sybl_table_set_group_dict(sybl_table *t, const char *name, const int64_t *values, int64_t n);
 /* Copies rows [row0,row0+n) of an INT column back to the host (tests, samples). */
 int sybl_table_read_int(const sybl_table *t, const char *name, int64_t row0, int64_t n, int64_t *out);
 

@@ -142,7 +142,7 @@ static bool fill_fast_columns(Table *t, Query *q, const std::vector<int> &slot_c
         const Column *c = t->cols[(size_t)slot_col[s]].get();
         if (c->type != SYBL_INT_VAL || c->elem != 8 || c->d_valid || c->has_missing) return false;
         uint32_t roles = sd.flags & (kSlotFilter | kSlotGroup | kSlotAgg);
-        if (sd.flags & (kSlotNeq | kSlotIdMask | kSlotWeight | kSlotW32 | kSlotSet)) return false;
+        if (sd.flags & (kSlotNeq | kSlotIdMask | kSlotWeight | kSlotW32 | kSlotSet | kSlotDict)) return false;
         if (roles != kSlotRange && roles != kSlotGroup && roles != kSlotAgg && roles != 0) return false;  // one role per column
         if ((sd.flags & kSlotTime) && roles != 0) return false;  // the time column plays no second role here
     }
@@ -478,10 +478,25 @@ static int plan_query(Table *t, const sybl_query_desc *d, Query *q) {
         // When -1 is inside the key range the missing rows share its cell; otherwise they get an
         // extra digit of their own.
         gi.missing_digit = -1;
+        gi.dict = false;
+        // sparse / wide key range: one digit per DISTINCT value instead of one per value of the range
+        if (c->type == SYBL_INT_VAL && !getenv("SYBL_NO_GDICT") &&
+            (c->gdict_blocks == -2 || card > ((unsigned __int128)1 << 22) || card * (unsigned __int128)cells > ((unsigned __int128)1 << 27))) {
+            if ((rc = column_build_gdict(t, c))) return rc;
+            gi.dict = true;
+            card = c->gdict.size();
+        }
         gi.value_card = (int32_t)card;
         if (gi.has_missing) {
-            if (c->type == SYBL_INT_VAL && hi >= lo && lo <= -1 && hi >= -1) {
-                gi.missing_digit = (int32_t)(-1 - lo);
+            int64_t minus1 = -1;
+            if (gi.dict) {
+                auto it = std::lower_bound(c->gdict.begin(), c->gdict.end(), (int64_t)-1);
+                minus1 = it != c->gdict.end() && *it == -1 ? (int64_t)(it - c->gdict.begin()) : -1;
+            } else if (c->type == SYBL_INT_VAL && hi >= lo && lo <= -1 && hi >= -1) {
+                minus1 = -1 - lo;
+            }
+            if (minus1 >= 0) {
+                gi.missing_digit = (int32_t)minus1;
             } else {
                 gi.missing_digit = (int32_t)card;
                 card += 1;
@@ -514,6 +529,13 @@ static int plan_query(Table *t, const sybl_query_desc *d, Query *q) {
             sd.gstride = (int32_t)stride;
             sd.gmissing = q->groups[g].missing_digit >= 0 ? (int32_t)(q->groups[g].missing_digit * stride) : -1;
             sd.gvalues = q->groups[g].value_card;
+            if (q->groups[g].dict) {
+                const Column *gc = t->cols[(size_t)q->groups[g].col].get();
+                sd.flags |= kSlotDict;
+                sd.dkeys = gc->d_gdict_keys;
+                sd.dranks = gc->d_gdict_ranks;
+                sd.dmask = gc->gdict_mask;
+            }
         }
     }
     q->group_cells = cells;

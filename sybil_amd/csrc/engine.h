@@ -34,6 +34,8 @@ hipError_t launch_synth(int64_t *out, int64_t n, int64_t row0, int64_t total_row
 hipError_t launch_block_minmax(const void *col, bool w32, const uint32_t *valid, const Segment *blocks, int n_blocks,
                                int64_t *out_min, int64_t *out_max, int64_t *out_pop, hipStream_t st);
 
+hipError_t launch_distinct(const void *col, bool w32, const uint32_t *valid, const Segment *blocks, int n_blocks, int64_t *keys,
+                           uint32_t mask, unsigned long long *n_distinct, unsigned long long limit, hipStream_t st);
 hipError_t launch_decode_bins(const uint32_t *recs, const int64_t *bin_off, const int64_t *bin_val, int n_bins,
                               bool delta_encoded, void *col, bool w32, uint32_t *valid, uint32_t nrows, hipStream_t st);
 hipError_t launch_decode_delta(const int64_t *deltas, int64_t n, bool value_encoded, int64_t *col, hipStream_t st);
@@ -68,6 +70,12 @@ struct Column {
     // bounds declared by a multi-rank host (global over all ranks)
     bool bounds_set = false;
     int64_t bound_lo = 0, bound_hi = 0;
+    // group dictionary for sparse key ranges: sorted distinct values + device value->rank map
+    std::vector<int64_t> gdict;        // sorted distinct values (host)
+    int64_t gdict_blocks = -1;         // blocks covered when it was built (-1: none); set by the host = -2
+    int64_t *d_gdict_keys = nullptr;
+    int32_t *d_gdict_ranks = nullptr;
+    uint32_t gdict_mask = 0;
     // table-global dictionary (str / set)
     std::vector<std::string> dict;
     std::unordered_map<std::string, int32_t> dict_ix;
@@ -100,6 +108,8 @@ int valid_reserve(Table *t, Column *c, int64_t phys_rows);
 void column_free(Column *c);
 int32_t dict_intern(Column *c, const std::string &s);
 int column_upload_set(Table *t, Column *c);
+int column_build_gdict(Table *t, Column *c);           // distinct values of the resident rows
+int column_install_gdict(Table *t, Column *c);         // sorted gdict -> device value->rank map
 
 struct BlockWriter {
     Table *t = nullptr;
@@ -128,6 +138,7 @@ struct GroupInfo {
     int32_t gcard;       // digits of this key column incl. a separate MISSING digit, if any
     int32_t value_card;  // digits that are real values
     int32_t missing_digit;  // digit missing rows map to (-1: column has no missing rows)
+    bool dict = false;      // digits are ranks in the column's sorted distinct values (Column::gdict)
     bool has_missing;
 };
 

@@ -67,6 +67,8 @@ __device__ __forceinline__ int64_t sdiv_trunc(int64_t x, int64_t d, double inv_d
     return x < 0 ? -(int64_t)q : (int64_t)q;
 }
 
+__device__ __forceinline__ uint32_t dict_hash(int64_t x) { return (uint32_t)(splitmix64((uint64_t)x) >> 32); }
+
 template <bool USE_LDS>
 __device__ __forceinline__ void acc_add(int64_t *tab, int64_t idx, int64_t v) {
     if (USE_LDS) {
@@ -176,7 +178,28 @@ __device__ __forceinline__ void process_tile(CPlan &P, const Tile<NC> &t, int64_
                 if (pop && (uint64_t)x < (uint64_t)s.idmask_bits) ok = (s.idmask[x >> 5] >> (x & 31)) & 1u;
                 pass = pass && ok;
             }
-            if (s.flags & kSlotGroup) {
+            if ((s.flags & kSlotGroup) && (s.flags & kSlotDict)) {
+                // sparse key range: the digit is the value's rank among the column's distinct values
+                if (pop) {
+                    uint32_t h = dict_hash(x) & s.dmask;
+                    int32_t rank = -1;
+                    for (uint32_t probe = 0; probe <= s.dmask; probe++) {
+                        const int64_t kx = s.dkeys[h];
+                        if (kx == x) {
+                            rank = s.dranks[h];
+                            break;
+                        }
+                        if (kx == kDictEmpty) break;
+                        h = (h + 1) & s.dmask;
+                    }
+                    if (rank < 0) in_bounds = false;
+                    cell += rank * s.gstride;
+                } else if (s.gmissing >= 0) {
+                    cell += s.gmissing;
+                } else {
+                    in_bounds = false;
+                }
+            } else if (s.flags & kSlotGroup) {
                 if (pop) {
                     uint64_t d = (uint64_t)x - (uint64_t)s.gmin;
                     if (d >= (uint32_t)s.gvalues) in_bounds = false;
@@ -485,6 +508,52 @@ __global__ __launch_bounds__(256) void k_block_minmax(const T *__restrict__ col,
         out_max[blockIdx.x] = mx;
         out_pop[blockIdx.x] = pc;
     }
+}
+
+// ---------------------------------------------------------------- distinct values of a column
+// Inserts every populated value into an open-addressing set (capacity = mask + 1, empty =
+// kDictEmpty).  Most probes hit an existing key with a plain load; only first sightings CAS.
+// *n_distinct counts insertions; the host gives up when it exceeds the dictionary budget.
+template <typename T>
+__global__ __launch_bounds__(256) void k_distinct(const T *__restrict__ col, const uint32_t *__restrict__ valid,
+                                                  const Segment *__restrict__ blocks, int64_t *keys, uint32_t mask,
+                                                  unsigned long long *n_distinct, unsigned long long limit) {
+    const Segment b = blocks[blockIdx.x];
+    for (int64_t i = threadIdx.x; i < b.n; i += blockDim.x) {
+        const int64_t row = b.start + i;
+        if (valid && !((valid[row >> 5] >> (row & 31)) & 1u)) continue;
+        const int64_t x = (int64_t)col[row];
+        if (x == kDictEmpty) continue;  // the sentinel itself cannot be stored; reported by the host
+        uint32_t h = dict_hash(x) & mask;
+        for (uint32_t probe = 0; probe <= mask; probe++) {
+            long long cur = __hip_atomic_load((long long *)keys + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (cur == x) break;
+            if (cur == kDictEmpty) {
+                long long expected = kDictEmpty;
+                if (__hip_atomic_compare_exchange_strong((long long *)keys + h, &expected, (long long)x, __ATOMIC_RELAXED,
+                                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    __hip_atomic_fetch_add(n_distinct, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+                if (expected == x) break;
+            }
+            h = (h + 1) & mask;
+        }
+        if (__hip_atomic_load(n_distinct, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > limit) return;
+    }
+}
+
+hipError_t launch_distinct(const void *col, bool w32, const uint32_t *valid, const Segment *blocks, int n_blocks, int64_t *keys,
+                           uint32_t mask, unsigned long long *n_distinct, unsigned long long limit, hipStream_t st) {
+    if (n_blocks <= 0) return hipSuccess;
+    if (w32) {
+        hipLaunchKernelGGL((k_distinct<int32_t>), dim3(n_blocks), dim3(256), 0, st, (const int32_t *)col, valid, blocks, keys, mask,
+                           n_distinct, limit);
+    } else {
+        hipLaunchKernelGGL((k_distinct<int64_t>), dim3(n_blocks), dim3(256), 0, st, (const int64_t *)col, valid, blocks, keys, mask,
+                           n_distinct, limit);
+    }
+    return hipGetLastError();
 }
 
 // ---------------------------------------------------------------- column decode (TableBlock load)

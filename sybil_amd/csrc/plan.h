@@ -17,6 +17,8 @@ constexpr int kRowsPerThread = 2;                        // one 16-byte load per
 constexpr int kTileRows = kWgThreads * kRowsPerThread;   // rows per workgroup iteration
 constexpr int kHeaderWords = 64;                         // SUM-section header
 constexpr int kLdsBudgetBytes = 152 * 1024;              // of 160 KiB per CU
+constexpr int64_t kDictEmpty = INT64_MIN;                // free slot of a group dictionary
+constexpr int64_t kDictMaxDistinct = 1 << 22;            // distinct values a dictionary may hold
 
 enum SlotFlags : uint32_t {
     kSlotRange = 1u << 0,   // lo <= x <= hi   (gt/lt/eq int filters folded, filter.go:171-195)
@@ -28,6 +30,7 @@ enum SlotFlags : uint32_t {
     kSlotWeight = 1u << 6,  // weight column (aggregate.go:100-102)
     kSlotW32 = 1u << 7,     // stored as int32 (str dictionary ids)
     kSlotSet = 1u << 8,     // set column: base = CSR offsets per physical row, filters in setp[]
+    kSlotDict = 1u << 9,    // group key through a value -> rank hash map (sparse / wide key ranges)
     kSlotFilter = kSlotRange | kSlotNeq | kSlotIdMask,
 };
 
@@ -53,6 +56,12 @@ struct SlotDesc {
     const int32_t *set_vals;  // CSR member ids (table-global dictionary)
     int32_t set_id[kMaxNeq];
     int32_t set_in[kMaxNeq];
+    // kSlotDict: open-addressing map of the column's distinct values to their rank in sorted
+    // order; dkeys[h] == kDictEmpty marks a free slot
+    const int64_t *dkeys;
+    const int32_t *dranks;
+    uint32_t dmask;
+    int32_t pad2_;
 };
 
 struct AggDesc {

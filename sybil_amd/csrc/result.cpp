@@ -169,7 +169,9 @@ static void build_key(const Query *q, int64_t gcell, uint8_t *key, std::string &
         rem -= digit * stride;
         uint64_t v;
         bool missing = digit >= gi.value_card;  // the separate MISSING digit
-        if (!missing) v = (uint64_t)(gi.gmin + digit);
+        int64_t sv = gi.gmin + digit;
+        if (gi.dict && !missing) sv = q->t->cols[(size_t)gi.col]->gdict[(size_t)digit];
+        if (!missing) v = (uint64_t)sv;
         if (missing || (gi.type == SYBL_INT_VAL && v == UINT64_MAX)) {
             // MISSING_VALUE (aggregate.go:31).  The int value -1 has the same 8-byte image, shares the
             // group, and translate_group_by prints nothing for it either (aggregate.go:308-316).
@@ -177,11 +179,10 @@ static void build_key(const Query *q, int64_t gcell, uint8_t *key, std::string &
         } else {
             if (gi.type == SYBL_STR_VAL) {
                 const Column *c = q->t->cols[(size_t)gi.col].get();
-                size_t id = (size_t)(gi.gmin + digit);
+                size_t id = (size_t)sv;
                 if (id < c->dict.size()) gbk += c->dict[id];
             } else {
                 // strconv.FormatInt(v, 10)
-                int64_t sv = gi.gmin + digit;
                 uint64_t uv = sv < 0 ? (uint64_t)0 - (uint64_t)sv : (uint64_t)sv;
                 int pos = (int)sizeof(num);
                 do {

@@ -108,6 +108,8 @@ void column_free(Column *c) {
     if (c->d_valid) hipFree(c->d_valid);
     if (c->d_set_off) hipFree(c->d_set_off);
     if (c->d_set_vals) hipFree(c->d_set_vals);
+    if (c->d_gdict_keys) hipFree(c->d_gdict_keys);
+    if (c->d_gdict_ranks) hipFree(c->d_gdict_ranks);
 }
 
 int32_t dict_intern(Column *c, const std::string &s) {
@@ -246,6 +248,98 @@ int block_commit(BlockWriter &w) {
     t->blocks.push_back(blk);
     t->phys_rows = w.new_phys;
     t->logical_rows += w.nrows;
+    return SYBL_OK;
+}
+
+// ------------------------------------------------------------------ group dictionaries
+// Direct mapping needs one cell per value of the key RANGE; a sparse key (user ids, raw
+// timestamps) gets one cell per DISTINCT value instead: k_distinct collects the distinct values
+// into a hash set, the host sorts them (rank order == key order, so results stay in canonical
+// order and every rank of a multi-GPU job that installs the same dictionary gets the same
+// layout), and the scan looks values up in a value -> rank open-addressing map.
+
+static inline uint32_t host_dict_hash(int64_t x) {
+    uint64_t z = (uint64_t)x + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (uint32_t)(z >> 32);
+}
+
+int column_build_gdict(Table *t, Column *c) {
+    int64_t nb = (int64_t)t->blocks.size();
+    if (c->gdict_blocks == nb || c->gdict_blocks == -2) return SYBL_OK;  // current, or supplied by the host
+    hipStream_t st = t->ctx->stream;
+    int rc = table_ensure_stats(t);
+    if (rc) return rc;
+    int64_t want = std::min<int64_t>(4 * kDictMaxDistinct, std::max<int64_t>(1024, 4 * c->n_pop));
+    uint32_t cap = 1024;
+    while ((int64_t)cap < want) cap <<= 1;
+    int64_t *d_keys = nullptr;
+    unsigned long long *d_n = nullptr;
+    SYBL_HIP(hipMalloc((void **)&d_keys, (size_t)cap * 8));
+    SYBL_HIP(hipMalloc((void **)&d_n, 8));
+    auto cleanup = [&]() {
+        hipFree(d_keys);
+        hipFree(d_n);
+    };
+    hipError_t e = launch_fill64(d_keys, cap, kDictEmpty, st);
+    if (e != hipSuccess) {
+        cleanup();
+        return hip_fail(e, "k_fill64");
+    }
+    SYBL_HIP(hipMemsetAsync(d_n, 0, 8, st));
+    e = launch_distinct(c->d_data, c->elem == 4, c->d_valid, t->d_blocks, (int)nb, d_keys, cap - 1, d_n,
+                        (unsigned long long)kDictMaxDistinct, st);
+    if (e != hipSuccess) {
+        cleanup();
+        return hip_fail(e, "k_distinct");
+    }
+    unsigned long long n = 0;
+    SYBL_HIP(hipMemcpyAsync(&n, d_n, 8, hipMemcpyDeviceToHost, st));
+    SYBL_HIP(hipStreamSynchronize(st));
+    if ((int64_t)n > kDictMaxDistinct) {
+        cleanup();
+        return fail(SYBL_E_INVAL, "column '%s' has more than %lld distinct values: too many groups for this build",
+                    c->name.c_str(), (long long)kDictMaxDistinct);
+    }
+    std::vector<int64_t> h(cap);
+    SYBL_HIP(hipMemcpy(h.data(), d_keys, (size_t)cap * 8, hipMemcpyDeviceToHost));
+    cleanup();
+    c->gdict.clear();
+    c->gdict.reserve((size_t)n);
+    for (int64_t x : h)
+        if (x != kDictEmpty) c->gdict.push_back(x);
+    if (c->n_pop > 0 && c->exact_min == kDictEmpty) c->gdict.push_back(kDictEmpty);  // the sentinel value itself
+    std::sort(c->gdict.begin(), c->gdict.end());
+    c->gdict_blocks = nb;
+    return column_install_gdict(t, c);
+}
+
+int column_install_gdict(Table *t, Column *c) {
+    (void)t;
+    size_t D = c->gdict.size();
+    uint32_t cap = 16;
+    while ((size_t)cap < 2 * D + 2) cap <<= 1;
+    std::vector<int64_t> keys(cap, kDictEmpty);
+    std::vector<int32_t> ranks(cap, -1);
+    for (size_t r = 0; r < D; r++) {
+        int64_t x = c->gdict[r];
+        if (x == kDictEmpty) continue;  // cannot be represented in the map; such rows are reported as overflow
+        uint32_t hh = host_dict_hash(x) & (cap - 1);
+        while (keys[hh] != kDictEmpty) hh = (hh + 1) & (cap - 1);
+        keys[hh] = x;
+        ranks[hh] = (int32_t)r;
+    }
+    if (c->d_gdict_keys) SYBL_HIP(hipFree(c->d_gdict_keys));
+    if (c->d_gdict_ranks) SYBL_HIP(hipFree(c->d_gdict_ranks));
+    c->d_gdict_keys = nullptr;
+    c->d_gdict_ranks = nullptr;
+    SYBL_HIP(hipMalloc((void **)&c->d_gdict_keys, (size_t)cap * 8));
+    SYBL_HIP(hipMalloc((void **)&c->d_gdict_ranks, (size_t)cap * 4));
+    SYBL_HIP(hipMemcpy(c->d_gdict_keys, keys.data(), (size_t)cap * 8, hipMemcpyHostToDevice));
+    SYBL_HIP(hipMemcpy(c->d_gdict_ranks, ranks.data(), (size_t)cap * 4, hipMemcpyHostToDevice));
+    c->gdict_mask = cap - 1;
     return SYBL_OK;
 }
 
@@ -452,6 +546,32 @@ int sybl_table_set_bounds(sybl_table *t, const char *name, int64_t lo, int64_t h
     c->bound_hi = hi;
     if (has_missing) c->has_missing = true;
     return SYBL_OK;
+}
+
+int sybl_table_column_distinct(sybl_table *t, const char *name, const int64_t **values, int64_t *n) {
+    if (!t || !values || !n) return fail(SYBL_E_INVAL, "NULL argument");
+    Column *c = t->find(name);
+    if (!c || c->type == SYBL_SET_VAL) return fail(SYBL_E_INVAL, "unknown int/str column '%s'", name ? name : "(null)");
+    SYBL_HIP(hipSetDevice(t->ctx->device));
+    int rc = column_build_gdict(t, c);
+    if (rc) return rc;
+    *values = c->gdict.data();
+    *n = (int64_t)c->gdict.size();
+    return SYBL_OK;
+}
+
+int sybl_table_set_group_dict(sybl_table *t, const char *name, const int64_t *values, int64_t n) {
+    if (!t || (n > 0 && !values) || n < 0) return fail(SYBL_E_INVAL, "bad argument");
+    Column *c = t->find(name);
+    if (!c || c->type == SYBL_SET_VAL) return fail(SYBL_E_INVAL, "unknown int/str column '%s'", name ? name : "(null)");
+    if (n > kDictMaxDistinct) return fail(SYBL_E_INVAL, "dictionary of %lld values exceeds the limit of %lld", (long long)n, (long long)kDictMaxDistinct);
+    SYBL_HIP(hipSetDevice(t->ctx->device));
+    std::vector<int64_t> v(values, values + n);
+    std::sort(v.begin(), v.end());
+    v.erase(std::unique(v.begin(), v.end()), v.end());
+    c->gdict.swap(v);
+    c->gdict_blocks = -2;
+    return column_install_gdict(t, c);
 }
 
 int sybl_table_read_int(const sybl_table *t, const char *name, int64_t row0, int64_t n, int64_t *out) {

@@ -53,3 +53,19 @@ def apply_bounds(table, bounds):
     for name, b in bounds.items():
         if b["hi"] >= b["lo"]:
             table.set_bounds(name, b["lo"], b["hi"], b["has_missing"])
+
+
+def agree_group_dict(table, column, group=None):
+    """Sparse group keys (sybl_table_column_distinct / sybl_table_set_group_dict): every rank installs
+    the sorted union of the ranks' distinct values, so digits (= ranks in that union) and therefore
+    the partial tables line up across ranks."""
+    import numpy as np
+    mine = table.column_distinct(column)
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        parts = [None] * dist.get_world_size(group)
+        dist.all_gather_object(parts, mine, group=group)
+        union = np.unique(np.concatenate(parts)) if parts else mine
+    else:
+        union = mine
+    table.set_group_dict(column, union)
+    return union

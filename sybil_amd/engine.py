@@ -170,6 +170,15 @@ class Table:
     def set_bounds(self, name, lo, hi, has_missing=False):
         N.check(N.lib().sybl_table_set_bounds(self._h, _b(name), lo, hi, 1 if has_missing else 0))
 
+    def column_distinct(self, name):
+        vals, n = C.POINTER(C.c_int64)(), C.c_int64()
+        N.check(N.lib().sybl_table_column_distinct(self._h, _b(name), C.byref(vals), C.byref(n)))
+        return np.ctypeslib.as_array(vals, shape=(n.value,)).copy() if n.value else np.zeros(0, dtype=np.int64)
+
+    def set_group_dict(self, name, values):
+        v = np.ascontiguousarray(values, dtype=np.int64)
+        N.check(N.lib().sybl_table_set_group_dict(self._h, _b(name), v.ctypes.data, v.size))
+
     def read_int(self, name, row0, n):
         out = np.empty(n, dtype=np.int64)
         N.check(N.lib().sybl_table_read_int(self._h, _b(name), row0, n, out.ctypes.data))

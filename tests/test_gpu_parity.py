@@ -422,3 +422,85 @@ def test_generator_matches_oracle(ctx, oracle):
         ci = t.column_info(name)
         assert ci["exact_min"] == int(oc["data"].min()) and ci["exact_max"] == int(oc["data"].max())
     t.free()
+
+
+# ---------------------------------------------------------------- sparse group keys (dictionary)
+
+def test_group_by_sparse_keys(ctx, oracle):
+    """Key ranges far beyond direct mapping (40-bit ids): digits are ranks among the distinct values."""
+    rng = np.random.default_rng(11)
+    n = 120_000
+    pool = np.unique(rng.integers(-(1 << 40), 1 << 40, size=3000))
+    pool = np.concatenate([pool, [-1]])
+    uid = pool[rng.integers(0, pool.size, size=n)].astype(np.int64)
+    upop = (rng.random(n) > 0.1).astype(np.uint8)
+    g2 = rng.integers(0, 5, size=n).astype(np.int64)
+    v = rng.integers(0, 100_000, size=n).astype(np.int64)
+    tb = ctx.create_table("sparse")
+    tb.add_column("uid", "int")
+    tb.add_column("g2", "int")
+    tb.add_column("v", "int", 0, 99_999)
+    _append_in_blocks(tb, n, 8192, {"uid": (uid, upop), "g2": g2, "v": v})
+    ocols = [{"type": "int", "data": uid, "populated": upop}, {"type": "int", "data": g2}, {"type": "int", "data": v}]
+    names = ["uid", "g2", "v"]
+    info = {"v": (0, 99_999)}
+    assert np.array_equal(tb.column_distinct("uid"), np.unique(uid[upop == 1]))
+    for q in (dict(groups=["uid"], aggs=["v"], op="avg"),
+              dict(groups=["g2", "uid"], aggs=["v"], op="hist", want_percentiles=False),
+              dict(filters=[("v", "gt", 50_000)], groups=["uid", "g2"])):
+        query = tb.query(**q)
+        gres = query.run()
+        ores = oracle.run_query(ocols, block_rows=8192, **parity.oracle_query_kwargs(names, info, q))
+        parity.compare(gres, ores, op=q.get("op", "avg"), full=False, n_aggs=len(q.get("aggs", [])))
+        # canonical order = key order; -1 and missing share the MISSING_VALUE group and print as ""
+        if q["groups"] == ["uid"]:
+            keys = [int.from_bytes(r["key"], "little", signed=True) for r in sorted(gres.results, key=lambda r: -r["count"])]
+            assert len(keys) == len(set(keys))
+            assert any(r["group_by_key"] == "\t" for r in gres.results)
+        gres.free()
+        query.free()
+    tb.free()
+
+
+def test_sparse_keys_across_ranks(ctx, oracle):
+    """Two shards see different subsets of the ids: with the union dictionary installed on both,
+    their partial tables add up to the table of the whole."""
+    import torch
+    rng = np.random.default_rng(12)
+    n = 60_000
+    pool = np.unique(rng.integers(0, 1 << 45, size=500))
+    uid = pool[rng.integers(0, pool.size, size=n)].astype(np.int64)
+    uid[: n // 2] = np.where(uid[: n // 2] % 3 == 0, uid[: n // 2], pool[0])   # shard 0 misses most ids
+    v = rng.integers(0, 1000, size=n).astype(np.int64)
+    parts, acc = [], None
+    union = None
+    for rank in range(2):
+        sl = slice(rank * n // 2, (rank + 1) * n // 2)
+        tb = ctx.create_table("p%d" % rank)
+        tb.add_column("uid", "int")
+        tb.add_column("v", "int", 0, 999)
+        tb.append_block(n // 2, {"uid": uid[sl], "v": v[sl]})
+        parts.append(tb)
+    union = np.unique(np.concatenate([p.column_distinct("uid") for p in parts]))
+    queries = []
+    for tb in parts:
+        tb.set_group_dict("uid", union)
+        tb.set_bounds("v", 0, 999)
+        q = tb.query(groups=["uid"], aggs=["v"], op="avg")
+        s, m = q.bind_torch("cuda:0")
+        q.scan()
+        ctx.sync()
+        acc = (s.clone(), m.clone()) if acc is None else (acc[0] + s, torch.maximum(acc[1], m))
+        queries.append(q)
+    s0, m0 = queries[0]._bound
+    s0.copy_(acc[0])
+    m0.copy_(acc[1])
+    torch.cuda.synchronize()
+    gres = queries[0].finalize()
+    ores = oracle.run_query([{"type": "int", "data": uid}, {"type": "int", "data": v}], groups=[0], aggs=[(1, 0, 999)])
+    parity.compare(gres, ores, op="avg", n_aggs=1)
+    gres.free()
+    for q in queries:
+        q.free()
+    for tb in parts:
+        tb.free()
