@@ -285,6 +285,13 @@ static int select_part_hist(Table *t, Query *q, const std::vector<int> &slot_col
     E.n_parts = (int32_t)n_parts;
     E.n_aggs = na;
     E.slots = (int32_t)std::min<int64_t>(1023, std::max<int64_t>(15, (kEmitLdsWords - n_parts) / n_parts));
+    {
+        // records per partition per tile if every row matched
+        double per_tile = (double)kTileRows * na / (double)n_parts;
+        int64_t period = (int64_t)((double)E.slots / (4.0 * std::max(per_tile, 0.25)));
+        if (const char *e = getenv("SYBL_EMIT_FLUSH_PERIOD")) period = atoi(e);
+        E.flush_period = (int32_t)std::min<int64_t>(8, std::max<int64_t>(1, period));
+    }
     PartHistPlan &H = q->pplan;
     memset(&H, 0, sizeof(H));
     H.recs = q->d_recs;
@@ -1058,6 +1065,7 @@ int sybl_query_prepare(sybl_table *t, const sybl_query_desc *desc, sybl_query **
         free_query(q);
         return rc;
     }
+    q->table_version = t->version;  // after planning: building a group dictionary does not count
     *out = q;
     return SYBL_OK;
 }
@@ -1071,6 +1079,8 @@ void sybl_query_free(sybl_query *q) {
 
 int sybl_query_scan(sybl_query *q) {
     if (!q) return fail(SYBL_E_INVAL, "query is NULL");
+    if (q->table_version != q->t->version)
+        return fail(SYBL_E_STATE, "the table changed (blocks appended, bounds or dictionaries set) after this query was prepared");
     SYBL_HIP(hipSetDevice(q->ctx->device));
     return scan(q);
 }

@@ -98,6 +98,7 @@ struct Table {
     std::vector<Segment> blocks;  // physical start / logical row count
     Segment *d_blocks = nullptr;
     int64_t d_blocks_n = 0;
+    int64_t version = 0;        // bumped by every change a prepared query would not know about
     int64_t broken_blocks = 0;  // blocks the loader skipped (unreadable info / column unpack error)
     Column *find(const char *name) const;
 };
@@ -156,6 +157,7 @@ struct Result;
 struct Query {
     Table *t = nullptr;
     Ctx *ctx = nullptr;
+    int64_t table_version = 0;  // Table::version at prepare time
     // copied descriptor
     int op = SYBL_AGG_AVG;
     int64_t hist_bucket = 0;

@@ -78,6 +78,7 @@ struct EmitPlan {
     int64_t part_cap;
     int32_t n_parts, n_aggs;
     int32_t slots;                   // LDS staging slots per partition
+    int32_t flush_period;            // tiles between flushes of the staging bins
     int32_t rem_bits[kFastMaxA];     // bits of (v - hmin) % BucketSize kept in the record
     int64_t *sum_out;                // header: matched / overflow / partition overflow
 };
@@ -420,11 +421,16 @@ __global__ __launch_bounds__(kWgThreads, 4) void k_emit(const EmitPlan E) {
             f0 = f1;
             g0 = g1;
             a0 = a1;
-            __syncthreads();
-            flush(slots / 2);
-            __syncthreads();
+            // bins fill at ~tile_records / n_parts per tile: flush (two barriers) only every
+            // flush_period tiles; a bin that fills up earlier spills record by record
+            if ((it + 1) % E.flush_period == 0 || it + 1 == n_tiles) {
+                __syncthreads();
+                flush(slots / 2);
+                __syncthreads();
+            }
         }
     }
+    __syncthreads();
     flush(1);
 
 #pragma unroll

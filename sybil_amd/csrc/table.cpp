@@ -248,6 +248,7 @@ int block_commit(BlockWriter &w) {
     t->blocks.push_back(blk);
     t->phys_rows = w.new_phys;
     t->logical_rows += w.nrows;
+    t->version++;
     return SYBL_OK;
 }
 
@@ -545,6 +546,7 @@ int sybl_table_set_bounds(sybl_table *t, const char *name, int64_t lo, int64_t h
     c->bound_lo = lo;
     c->bound_hi = hi;
     if (has_missing) c->has_missing = true;
+    t->version++;
     return SYBL_OK;
 }
 
@@ -571,6 +573,7 @@ int sybl_table_set_group_dict(sybl_table *t, const char *name, const int64_t *va
     v.erase(std::unique(v.begin(), v.end()), v.end());
     c->gdict.swap(v);
     c->gdict_blocks = -2;
+    t->version++;
     return column_install_gdict(t, c);
 }
 

@@ -279,6 +279,14 @@ def test_error_paths(ctx):
     r = q.run()
     assert r.matched == 2
     r.free()
+    tb.append_block(1, {"a": np.array([3], dtype=np.int64)})
+    with pytest.raises(sybil_amd.SyblError):
+        q.scan()                                                         # stale plan: table changed after prepare
+    q.free()
+    q = tb.query()
+    r = q.run()
+    assert r.matched == 3
+    r.free()
     q.free()
     tb.free()
 
