@@ -278,16 +278,22 @@ static int select_part_hist(Table *t, Query *q, const std::vector<int> &slot_col
     size_t bytes = (size_t)n_parts * (size_t)cap * 4, free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || bytes + ((size_t)1 << 30) > free_b) return SYBL_OK;
     SYBL_HIP(hipMalloc((void **)&q->d_recs, bytes));
-    SYBL_HIP(hipMalloc((void **)&q->d_cursor, (size_t)n_parts * 4));
+    SYBL_HIP(hipMalloc((void **)&q->d_cursor, (size_t)n_parts * kCursorStride * 4));
     E.recs = q->d_recs;
     E.cursor = q->d_cursor;
     E.part_cap = cap;
     E.n_parts = (int32_t)n_parts;
     E.n_aggs = na;
-    E.slots = (int32_t)std::min<int64_t>(1023, std::max<int64_t>(15, (kEmitLdsWords - n_parts) / n_parts));
     {
-        // records per partition per tile if every row matched
-        double per_tile = (double)kTileRows * na / (double)n_parts;
+            // A handful of sub-bins per partition relieves same-address serialisation of the LDS
+        // counters when there are very few partitions; runs stay long (few cursor atomics).
+        int ss = 0;
+        while ((n_parts << ss) < 8) ss++;
+        int64_t bins = n_parts << ss;
+        E.sub_shift = ss;
+        E.slots = (int32_t)std::min<int64_t>(8191, std::max<int64_t>(15, (kEmitLdsWords - bins) / bins));
+        // records per bin per tile if every row matched
+        double per_tile = (double)kTileRows * na / (double)bins;
         int64_t period = (int64_t)((double)E.slots / (4.0 * std::max(per_tile, 0.25)));
         if (const char *e = getenv("SYBL_EMIT_FLUSH_PERIOD")) period = atoi(e);
         E.flush_period = (int32_t)std::min<int64_t>(8, std::max<int64_t>(1, period));
@@ -317,7 +323,7 @@ static int select_part_hist(Table *t, Query *q, const std::vector<int> &slot_col
     }
     H.nv_max = nv_max;
     // few partitions: several workgroups share one so the whole chip is busy
-    H.split = (int32_t)std::max<int64_t>(1, std::min<int64_t>(8, (int64_t)q->n_wg / n_parts));
+    H.split = (int32_t)std::max<int64_t>(1, (int64_t)q->n_wg / n_parts);
     q->part_nf = nf;
     q->part_ng = ng;
     q->part_na = na;
@@ -925,7 +931,7 @@ static int scan(Query *q) {
         } else {
             SYBL_HIP(hipMemsetAsync(q->d_sum, 0, (size_t)kHeaderWords * 8, st));
         }
-        SYBL_HIP(hipMemsetAsync(q->d_cursor, 0, (size_t)q->eplan.n_parts * 4, st));
+        SYBL_HIP(hipMemsetAsync(q->d_cursor, 0, (size_t)q->eplan.n_parts * kCursorStride * 4, st));
         SYBL_HIP(hipEventRecord(q->ev[0], st));
         q->eplan.sum_out = q->d_sum;
         q->pplan.sum_out = q->d_sum;

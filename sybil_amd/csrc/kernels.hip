@@ -692,7 +692,7 @@ __global__ __launch_bounds__(kWgThreads) void k_part_hist(const PartHistPlan P) 
 
     const uint32_t split = (uint32_t)P.split;
     const uint32_t part = blockIdx.x / split, sub = blockIdx.x % split;
-    const uint32_t n_all = P.cursor[part];
+    const uint32_t n_all = P.cursor[part * kCursorStride];
     const uint32_t i0 = (uint32_t)((uint64_t)n_all * sub / split), i1 = (uint32_t)((uint64_t)n_all * (sub + 1) / split);
     const uint32_t *recs = P.recs + (int64_t)part * P.part_cap;
     const uint32_t pair0 = part * kPartCells;

@@ -69,6 +69,7 @@ constexpr int kPartCells = 32;       // (cell, agg) pairs per partition
 constexpr int kPartCellBits = 5;
 constexpr int kBucketBits = 10;      // len(Values) <= 1002
 constexpr int kMaxParts = 2048;      // LDS staging in k_emit: n_parts x slots records
+constexpr int kCursorStride = 32;     // partition cursors sit on separate 128-byte lines
 constexpr int kEmitLdsWords = 32768; // 128 KB of staging: slots = (kEmitLdsWords - n_parts) / n_parts, 15..1023
 
 struct EmitPlan {
@@ -77,7 +78,9 @@ struct EmitPlan {
     uint32_t *cursor;                // [n_parts] records written
     int64_t part_cap;
     int32_t n_parts, n_aggs;
-    int32_t slots;                   // LDS staging slots per partition
+    int32_t slots;                   // LDS staging slots per bin
+    int32_t sub_shift;               // bins per partition = 1 << sub_shift (lanes spread over them so that
+                                     // few partitions do not serialise on one LDS counter)
     int32_t flush_period;            // tiles between flushes of the staging bins
     int32_t rem_bits[kFastMaxA];     // bits of (v - hmin) % BucketSize kept in the record
     int64_t *sum_out;                // header: matched / overflow / partition overflow
@@ -303,7 +306,9 @@ __global__ __launch_bounds__(kWgThreads, 4) void k_emit(const EmitPlan E) {
     extern __shared__ uint32_t elds[];
     const FastPlan &P = E.fp;
     const uint32_t tid = threadIdx.x;
-    const uint32_t np = (uint32_t)E.n_parts;
+    const uint32_t ss = (uint32_t)E.sub_shift;
+    const uint32_t np = (uint32_t)E.n_parts << ss;   // staging bins
+    const uint32_t sub = tid & ((1u << ss) - 1);      // this lane's sub-bin
     const uint32_t slots = (uint32_t)E.slots;
     uint32_t *bin_cnt = elds;                 // [np]
     uint32_t *bins = elds + np;               // [np][slots]
@@ -319,9 +324,9 @@ __global__ __launch_bounds__(kWgThreads, 4) void k_emit(const EmitPlan E) {
                 uint32_t n = bin_cnt[p];
                 if (n > slots) n = slots;
                 if (n == 0 || n < min_fill) continue;
-                const uint32_t pos = __hip_atomic_fetch_add(E.cursor + p, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t pos = __hip_atomic_fetch_add(E.cursor + (p >> ss) * kCursorStride, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if ((int64_t)pos + n <= E.part_cap) {
-                    uint32_t *dst = E.recs + (int64_t)p * E.part_cap + pos;
+                    uint32_t *dst = E.recs + (int64_t)(p >> ss) * E.part_cap + pos;
                     for (uint32_t k = 0; k < n; k++) dst[k] = bins[p * slots + k];
                 } else {
                     __hip_atomic_fetch_add(E.sum_out + kHdrPartOverflow, (int64_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -335,10 +340,10 @@ __global__ __launch_bounds__(kWgThreads, 4) void k_emit(const EmitPlan E) {
                 if (n > slots) n = slots;
                 if (n == 0 || n < min_fill) continue;  // wave-uniform
                 uint32_t pos = 0;
-                if (lane == 0) pos = __hip_atomic_fetch_add(E.cursor + p, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane == 0) pos = __hip_atomic_fetch_add(E.cursor + (p >> ss) * kCursorStride, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 pos = __shfl(pos, 0, 64);
                 if ((int64_t)pos + n <= E.part_cap) {
-                    uint32_t *dst = E.recs + (int64_t)p * E.part_cap + pos;
+                    uint32_t *dst = E.recs + (int64_t)(p >> ss) * E.part_cap + pos;
                     for (uint32_t k = lane; k < n; k += 64) dst[k] = bins[p * slots + k];
                 } else if (lane == 0) {
                     __hip_atomic_fetch_add(E.sum_out + kHdrPartOverflow, (int64_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -404,12 +409,13 @@ __global__ __launch_bounds__(kWgThreads, 4) void k_emit(const EmitPlan E) {
                     const uint32_t pair = cell * (uint32_t)NA + (uint32_t)c;
                     const uint32_t part = pair >> kPartCellBits;
                     const uint32_t rec = ((((pair & (kPartCells - 1)) << kBucketBits) | b) << E.rem_bits[c]) | (uint32_t)rem;
-                    const uint32_t slot = __hip_atomic_fetch_add(bin_cnt + part, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    const uint32_t bin = (part << ss) | sub;
+                    const uint32_t slot = __hip_atomic_fetch_add(bin_cnt + bin, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     if (slot < slots) {
-                        bins[part * slots + slot] = rec;
+                        bins[bin * slots + slot] = rec;
                     } else {
                         // the bin is full until the next flush: append this record directly
-                        const uint32_t pos = __hip_atomic_fetch_add(E.cursor + part, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const uint32_t pos = __hip_atomic_fetch_add(E.cursor + part * kCursorStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         if ((int64_t)pos < E.part_cap) {
                             E.recs[(int64_t)part * E.part_cap + pos] = rec;
                         } else {
@@ -446,7 +452,7 @@ __global__ __launch_bounds__(kWgThreads, 4) void k_emit(const EmitPlan E) {
 
 template <int NF>
 static hipError_t emit_launch_nf(const EmitPlan &E, int ng, int na, int n_wg, hipStream_t st) {
-    const size_t lds = (size_t)E.n_parts * (1 + (size_t)E.slots) * 4;
+    const size_t lds = ((size_t)E.n_parts << E.sub_shift) * (1 + (size_t)E.slots) * 4;
 #define SYBL_EMIT_CASE(G, A)                                                                               \
     case (G)*3 + (A): {                                                                                    \
         auto k = k_emit<NF, G, A>;                                                                         \
