@@ -198,7 +198,7 @@ def main():
                        "sharding": "contiguous 65536-row blocks per rank", "collective": args.collective if multi else None,
                        "device": dev["name"], "matched_rows": res.matched if res is not None else None,
                        "groups": len(res.results) if res is not None else None,
-                       "strategy": {0: "lds-generic", 1: "global-atomics", 2: "lds-fast", 3: "lds-window-generic", 4: "lds-window-fast"}[stats["strategy"]],
+                       "strategy": {0: "lds-generic", 1: "global-atomics", 2: "lds-fast", 3: "lds-window-generic", 4: "lds-window-fast", 5: "partitioned-hist", 6: "lds-hist"}[stats["strategy"]],
                        "lds_bytes": stats["lds_bytes"], "workgroups": stats["n_workgroups"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(stats, names),

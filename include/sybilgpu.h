@@ -277,7 +277,8 @@ typedef struct {
     int32_t n_cells;          /* direct-mapped group cells */
     int32_t strategy;         /* 0 = LDS cell table (generic kernel), 1 = global atomics, 2 = LDS cell table
                                * (role-specialised kernel), 3 / 4 = per-workgroup LDS time window (generic /
-                               * role-specialised kernel) */
+                               * role-specialised kernel), 5 = partitioned histograms, 6 = cell table AND
+                               * bucket arrays in LDS */
     int32_t lds_bytes, n_workgroups, replicas;
     int32_t n_sum_fields;     /* int64 fields per cell in the SUM section */
     int32_t n_max_fields;     /* fields per cell in the MAX section; 0 = nothing to MAX-reduce */

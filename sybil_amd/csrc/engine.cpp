@@ -241,6 +241,21 @@ static void select_fast_path(Table *t, Query *q, const std::vector<int> &slot_co
         if (any_max && !all_max) return;
         mode = any_max ? kFastAvgMax : kFastAvg;
     }
+    FP.hist_lds = 0;
+    if (mode == kFastHist && !P.windowed && !getenv("SYBL_NO_LDSHIST")) {
+        // few cells: the bucket arrays themselves fit in LDS as uint32 next to the cell table
+        // (a workgroup scans far fewer than 2^32 rows); shrink the lane replication to make room
+        int64_t hist_bytes = (int64_t)P.n_cells * P.hist_stride * 4;
+        int64_t field_bytes = (int64_t)(P.n_sum_fields + P.n_max_fields) * P.n_cells * 8;
+        if (hist_bytes + field_bytes <= kLdsBudgetBytes) {
+            int rs = 0;
+            while (rs < 6 && hist_bytes + (field_bytes << (rs + 1)) <= kLdsBudgetBytes) rs++;
+            q->plan.rep_shift = rs;
+            FP.rep_shift = rs;
+            q->lds_bytes = (size_t)((field_bytes << rs) + hist_bytes + 16);
+            FP.hist_lds = 1;
+        }
+    }
     q->fast = true;
     q->fast_nf = nf;
     q->fast_ng = ng;
@@ -255,6 +270,7 @@ static int select_part_hist(Table *t, Query *q, const std::vector<int> &slot_col
     const ScanPlan &P = q->plan;
     if (getenv("SYBL_NO_PARTHIST")) return SYBL_OK;
     if (q->op != SYBL_AGG_HIST || !q->want_percentiles || q->time_mode || q->weighted || q->aggs.empty()) return SYBL_OK;
+    if (q->fast && q->fplan.hist_lds) return SYBL_OK;  // the bucket arrays already live in LDS
     EmitPlan &E = q->eplan;
     int nf, ng, na;
     bool any_max, all_max;
@@ -861,7 +877,7 @@ static int plan_query(Table *t, const sybl_query_desc *d, Query *q) {
     }
     q->stats.algorithmic_bytes = rows_scanned * width + set_bytes;
     q->stats.n_cells = (int32_t)n_cells;
-    q->stats.strategy = q->part_hist ? 5 : (q->use_lds ? (P.windowed ? (q->fast ? 4 : 3) : (q->fast ? 2 : 0)) : 1);
+    q->stats.strategy = q->part_hist ? 5 : (q->use_lds ? (P.windowed ? (q->fast ? 4 : 3) : (q->fast ? (q->fplan.hist_lds ? 6 : 2) : 0)) : 1);
     q->stats.lds_bytes = (int32_t)q->lds_bytes;
     q->stats.n_workgroups = q->n_wg;
     q->stats.replicas = 1 << P.rep_shift;

@@ -49,6 +49,8 @@ struct FastPlan {
     double inv_time_bucket;
     int32_t n_tb, tb_stride;
     int32_t windowed, lds_cells;   // lds_cells == n_cells unless windowed
+    int32_t hist_lds;              // kFastHist: bucket arrays as uint32 in LDS (few cells), flushed once
+    int32_t pad_;
     const int32_t *wg_cell_base;
     int64_t *sum_out, *max_out, *ws_sum, *ws_max;
     const Segment *segs;
@@ -130,7 +132,7 @@ template <int NF, int NG, int NA, int MODE, bool TIME>
 __device__ __forceinline__ void fast_row(const FastPlan &P, const FastTile<NF> &f, const FastTile<NG> &g,
                                          const FastTile<NA> &a, const FastTile<1> &t, const int r, int64_t *lds,
                                          const uint32_t rep, const uint32_t max_base, const uint32_t cell_base,
-                                         uint32_t &matched, uint32_t &overflow) {
+                                         uint32_t *hist32, uint32_t &matched, uint32_t &overflow) {
     bool pass = true;
 #pragma unroll
     for (int c = 0; c < NF; c++) {
@@ -195,6 +197,9 @@ __device__ __forceinline__ void fast_row(const FastPlan &P, const FastTile<NF> &
             if (MODE == kFastMoments) {
                 lds_add64(lds, (((uint32_t)P.f_sb[c] * ncell) << rs) + cidx, (int64_t)b);
                 lds_add64(lds, (((uint32_t)P.f_sb2[c] * ncell) << rs) + cidx, (int64_t)((uint64_t)b * (uint64_t)b));
+            } else if (P.hist_lds) {
+                __hip_atomic_fetch_add(hist32 + lcell * (uint32_t)P.hist_stride + (uint32_t)P.hist_agg_off[c] + b, 1u,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             } else {
                 __hip_atomic_fetch_add(P.sum_out + P.hist_off + (int64_t)cell * P.hist_stride + P.hist_agg_off[c] + b,
                                        (int64_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -215,6 +220,9 @@ __global__ __launch_bounds__(kWgThreads, 4) void k_scan_fast(const FastPlan P) {
     const uint32_t cell_base = P.windowed ? (uint32_t)P.wg_cell_base[blockIdx.x] : 0u;
     for (uint32_t i = tid; i < words_sum * R; i += kWgThreads) lds[i] = 0;
     for (uint32_t i = tid; i < words_max * R; i += kWgThreads) lds[max_base + i] = INT64_MIN;
+    uint32_t *hist32 = (uint32_t *)(lds + max_base + (words_max << P.rep_shift));
+    const uint32_t hist_words = (MODE == kFastHist && P.hist_lds) ? tab_cells * (uint32_t)P.hist_stride : 0u;
+    for (uint32_t i = tid; i < hist_words; i += kWgThreads) hist32[i] = 0;
     const uint32_t rep = tid & (R - 1);
     __syncthreads();
 
@@ -233,9 +241,9 @@ __global__ __launch_bounds__(kWgThreads, 4) void k_scan_fast(const FastPlan P) {
         for (; row < end; row += kTileRows) {
             const int64_t nrow = row + kTileRows;
             if (nrow < end) fast_load<NF, NG, NA, TIME>(P, nrow, f1, g1, a1, t1);
-            fast_row<NF, NG, NA, MODE, TIME>(P, f0, g0, a0, t0, 0, lds, rep, max_base, cell_base, matched, overflow);
+            fast_row<NF, NG, NA, MODE, TIME>(P, f0, g0, a0, t0, 0, lds, rep, max_base, cell_base, hist32, matched, overflow);
             if (row + 1 < end)
-                fast_row<NF, NG, NA, MODE, TIME>(P, f0, g0, a0, t0, 1, lds, rep, max_base, cell_base, matched, overflow);
+                fast_row<NF, NG, NA, MODE, TIME>(P, f0, g0, a0, t0, 1, lds, rep, max_base, cell_base, hist32, matched, overflow);
             f0 = f1;
             g0 = g1;
             a0 = a1;
@@ -255,6 +263,12 @@ __global__ __launch_bounds__(kWgThreads, 4) void k_scan_fast(const FastPlan P) {
     }
 
     __syncthreads();
+    // LDS bucket arrays: one atomic per touched bucket per workgroup into the zeroed global table
+    for (uint32_t i = tid; i < hist_words; i += kWgThreads) {
+        const uint32_t x = hist32[i];
+        if (x) __hip_atomic_fetch_add(P.sum_out + P.hist_off + (int64_t)cell_base * P.hist_stride + i, (int64_t)x, __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_AGENT);
+    }
     if (P.windowed) {
         // flush the touched cells of this workgroup's window into the global table
         int64_t *gs = P.sum_out + kHeaderWords;
