@@ -167,6 +167,11 @@ int sybl_table_set_bounds(sybl_table *t, const char *name, int64_t lo, int64_t h
  * column changes). */
 int sybl_table_column_distinct(sybl_table *t, const char *name, const int64_t **values, int64_t *n);
 int sybl_table_set_group_dict(sybl_table *t, const char *name, const int64_t *values, int64_t n);
+/* Str / set dictionaries (table-global ids are assigned in first-seen order per process).  Ranks of
+ * a multi-GPU job gather every rank's dictionary and install the same union everywhere; resident
+ * ids are remapped in place.  The new dictionary must contain every resident value. */
+int sybl_table_column_dict(sybl_table *t, const char *name, const char *const **strings, int64_t *n);
+int sybl_table_set_dict(sybl_table *t, const char *name, const char *const *strings, int64_t n);
 /* Copies rows [row0,row0+n) of an INT column back to the host (tests, samples). */
 int sybl_table_read_int(const sybl_table *t, const char *name, int64_t row0, int64_t n, int64_t *out);
 

@@ -103,6 +103,8 @@ SIGNATURES = {
     "sybl_table_read_int": (C.c_int, [P, C.c_char_p, C.c_int64, C.c_int64, P]),
     "sybl_table_column_distinct": (C.c_int, [P, C.c_char_p, C.POINTER(C.POINTER(C.c_int64)), C.POINTER(C.c_int64)]),
     "sybl_table_set_group_dict": (C.c_int, [P, C.c_char_p, P, C.c_int64]),
+    "sybl_table_column_dict": (C.c_int, [P, C.c_char_p, C.POINTER(C.POINTER(C.c_char_p)), C.POINTER(C.c_int64)]),
+    "sybl_table_set_dict": (C.c_int, [P, C.c_char_p, C.POINTER(C.c_char_p), C.c_int64]),
     "sybl_query_prepare": (C.c_int, [P, C.POINTER(QueryDesc), C.POINTER(P)]),
     "sybl_query_free": (None, [P]),
     "sybl_query_scan": (C.c_int, [P]),

@@ -79,6 +79,7 @@ struct Column {
     // table-global dictionary (str / set)
     std::vector<std::string> dict;
     std::unordered_map<std::string, int32_t> dict_ix;
+    std::vector<const char *> dict_view;  // sybl_table_column_dict
     // set columns: CSR over physical rows
     int64_t *d_set_off = nullptr;
     int32_t *d_set_vals = nullptr;

@@ -577,6 +577,68 @@ int sybl_table_set_group_dict(sybl_table *t, const char *name, const int64_t *va
     return column_install_gdict(t, c);
 }
 
+// Str / set dictionaries across ranks: ids are assigned in first-seen order per process, so ranks
+// of a multi-GPU job must agree on ONE dictionary before a str group-by (or a str/set filter
+// evaluated per id) means the same thing everywhere.  Hosts gather sybl_table_column_dict from every
+// rank and install the (sorted) union with sybl_table_set_dict; resident ids are remapped in place.
+int sybl_table_column_dict(sybl_table *t, const char *name, const char *const **strings, int64_t *n) {
+    if (!t || !strings || !n) return fail(SYBL_E_INVAL, "NULL argument");
+    Column *c = t->find(name);
+    if (!c || c->type == SYBL_INT_VAL) return fail(SYBL_E_INVAL, "unknown str/set column '%s'", name ? name : "(null)");
+    c->dict_view.clear();
+    for (auto &s : c->dict) c->dict_view.push_back(s.c_str());
+    *strings = c->dict_view.data();
+    *n = (int64_t)c->dict_view.size();
+    return SYBL_OK;
+}
+
+int sybl_table_set_dict(sybl_table *t, const char *name, const char *const *strings, int64_t n) {
+    if (!t || n < 0 || (n > 0 && !strings)) return fail(SYBL_E_INVAL, "bad argument");
+    Column *c = t->find(name);
+    if (!c || c->type == SYBL_INT_VAL) return fail(SYBL_E_INVAL, "unknown str/set column '%s'", name ? name : "(null)");
+    SYBL_HIP(hipSetDevice(t->ctx->device));
+    std::vector<std::string> nd;
+    std::unordered_map<std::string, int32_t> nix;
+    for (int64_t i = 0; i < n; i++) {
+        std::string s = strings[i] ? strings[i] : "";
+        if (nix.emplace(s, (int32_t)nd.size()).second) nd.push_back(s);
+    }
+    std::vector<int32_t> lut(c->dict.size());
+    for (size_t i = 0; i < c->dict.size(); i++) {
+        auto it = nix.find(c->dict[i]);
+        if (it == nix.end()) return fail(SYBL_E_INVAL, "new dictionary of '%s' lacks the resident value '%s'", c->name.c_str(), c->dict[i].c_str());
+        lut[i] = it->second;
+    }
+    hipStream_t st = t->ctx->stream;
+    if (c->type == SYBL_STR_VAL && t->phys_rows > 0 && !lut.empty()) {
+        int32_t *d_lut = nullptr;
+        SYBL_HIP(hipMalloc((void **)&d_lut, lut.size() * 4));
+        SYBL_HIP(hipMemcpyAsync(d_lut, lut.data(), lut.size() * 4, hipMemcpyHostToDevice, st));
+        hipError_t e = launch_remap_ids((const int32_t *)c->d_data, d_lut, (int32_t)lut.size(), t->phys_rows, (int32_t *)c->d_data, st);
+        if (e != hipSuccess) {
+            hipFree(d_lut);
+            return hip_fail(e, "k_remap_ids");
+        }
+        SYBL_HIP(hipStreamSynchronize(st));
+        SYBL_HIP(hipFree(d_lut));
+    } else if (c->type == SYBL_SET_VAL) {
+        for (auto &id : c->h_set_vals) id = lut[(size_t)id];
+        c->set_dirty = true;
+    }
+    c->dict.swap(nd);
+    c->dict_ix.swap(nix);
+    // ids changed: block statistics of a str column (min/max id) and any group dictionary are stale
+    if (c->type == SYBL_STR_VAL) {
+        c->stats_blocks = 0;
+        c->exact_min = INT64_MAX;
+        c->exact_max = INT64_MIN;
+        c->n_pop = 0;
+        c->gdict_blocks = -1;
+    }
+    t->version++;
+    return SYBL_OK;
+}
+
 int sybl_table_read_int(const sybl_table *t, const char *name, int64_t row0, int64_t n, int64_t *out) {
     if (!t || !out) return fail(SYBL_E_INVAL, "NULL argument");
     Column *c = t->find(name);

@@ -69,3 +69,18 @@ def agree_group_dict(table, column, group=None):
         union = mine
     table.set_group_dict(column, union)
     return union
+
+
+def agree_str_dict(table, column, group=None):
+    """Str / set columns: every rank installs the sorted union of the ranks' dictionaries, so a
+    dictionary id -- and with it a str group cell or a per-id filter mask -- means the same string on
+    every rank (the reference merges blocks by translated string key, aggregate.go:284-324)."""
+    mine = table.column_dict(column)
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        parts = [None] * dist.get_world_size(group)
+        dist.all_gather_object(parts, mine, group=group)
+        union = sorted(set(s for p in parts for s in p))
+    else:
+        union = sorted(set(mine))
+    table.set_dict(column, union)
+    return union

@@ -179,6 +179,16 @@ class Table:
         v = np.ascontiguousarray(values, dtype=np.int64)
         N.check(N.lib().sybl_table_set_group_dict(self._h, _b(name), v.ctypes.data, v.size))
 
+    def column_dict(self, name):
+        arr, n = C.POINTER(C.c_char_p)(), C.c_int64()
+        N.check(N.lib().sybl_table_column_dict(self._h, _b(name), C.byref(arr), C.byref(n)))
+        return [arr[i].decode("utf-8", "replace") for i in range(n.value)]
+
+    def set_dict(self, name, strings):
+        bs = [_b(s) for s in strings]
+        arr = (C.c_char_p * max(len(bs), 1))(*bs)
+        N.check(N.lib().sybl_table_set_dict(self._h, _b(name), arr, len(bs)))
+
     def read_int(self, name, row0, n):
         out = np.empty(n, dtype=np.int64)
         N.check(N.lib().sybl_table_read_int(self._h, _b(name), row0, n, out.ctypes.data))

@@ -512,3 +512,69 @@ def test_sparse_keys_across_ranks(ctx, oracle):
         q.free()
     for tb in parts:
         tb.free()
+
+
+def test_str_dictionaries_across_ranks(ctx, oracle):
+    """Two shards built their str dictionaries in different first-seen orders; after installing
+    the union on both (sybil_amd.dist.agree_str_dict's protocol) their partial tables add up."""
+    import torch
+    rng = np.random.default_rng(21)
+    n = 40_000
+    vocab = ["host%02d" % i for i in range(30)]
+    ids = rng.integers(0, 30, size=n)
+    ids[: n // 2] = ids[: n // 2] % 11            # shard 0 never sees most hosts
+    v = rng.integers(0, 1000, size=n).astype(np.int64)
+    tags_off = np.arange(0, n + 1, dtype=np.int64)
+    tag_ids = (ids % 4).astype(np.int32)
+    tag_names = ["t0", "t1", "t2", "t3"]
+    parts = []
+    for rank in range(2):
+        sl = slice(rank * n // 2, (rank + 1) * n // 2)
+        perm = rng.permutation(30)
+        inv = np.argsort(perm)
+        tperm = rng.permutation(4)
+        tinv = np.argsort(tperm)
+        tb = ctx.create_table("r%d" % rank)
+        tb.add_column("host", "str")
+        tb.add_column("v", "int", 0, 999)
+        tb.add_column("tags", "set")
+        tb.append_block(n // 2, {"host": {"ids": inv[ids[sl]].astype(np.int32), "strings": [vocab[i] for i in perm]},
+                                 "v": v[sl],
+                                 "tags": {"ids": tinv[tag_ids[sl]].astype(np.int32), "offsets": tags_off[: n // 2 + 1],
+                                          "strings": [tag_names[i] for i in tperm]}})
+        parts.append(tb)
+    union = sorted(set(s for p in parts for s in p.column_dict("host")))
+    assert union == vocab
+    tunion = sorted(set(s for p in parts for s in p.column_dict("tags")))
+    queries, acc = [], None
+    for tb in parts:
+        tb.set_dict("host", union)
+        tb.set_dict("tags", tunion)
+        tb.set_bounds("v", 0, 999)
+        q = tb.query(filters=[("tags", "nin", "t1"), ("host", "neq", "host03")], groups=["host"], aggs=["v"], op="avg")
+        s, m = q.bind_torch("cuda:0")
+        q.scan()
+        ctx.sync()
+        acc = (s.clone(), m.clone()) if acc is None else (acc[0] + s, torch.maximum(acc[1], m))
+        queries.append(q)
+    s0, m0 = queries[0]._bound
+    s0.copy_(acc[0])
+    m0.copy_(acc[1])
+    torch.cuda.synchronize()
+    gres = queries[0].finalize()
+    ores = oracle.run_query([{"type": "str", "data": ids.astype(np.int32)}, {"type": "int", "data": v},
+                             {"type": "set", "data": tag_ids, "offsets": tags_off}],
+                            filters=[(2, "nin", 1), (0, "neq", 3)], groups=[0], aggs=[(1, 0, 999)])
+    gmap = {r["group_by_key"]: r for r in gres.results}
+    omap = {vocab[r["key_vals"][0]] + "\t": r for r in ores["results"]}
+    assert gres.matched == ores["matched"] and set(gmap) == set(omap)
+    for k, o in omap.items():
+        assert gmap[k]["count"] == o["count"] and gmap[k]["hists"][0]["sum"] == o["hists"][0]["sum_exact"]
+    import sybil_amd
+    with pytest.raises(sybil_amd.SyblError):
+        parts[0].set_dict("host", ["host00"])       # must contain every resident value
+    gres.free()
+    for q in queries:
+        q.free()
+    for tb in parts:
+        tb.free()
