@@ -116,3 +116,53 @@ def test_single_process_is_a_noop():
     b = sdist.agree_bounds({"a": {"exact_min": 3, "exact_max": 9, "has_missing": False},
                             "e": {"exact_min": 1, "exact_max": 0, "has_missing": True}})
     assert b["a"] == {"lo": 3, "hi": 9, "has_missing": False} and b["e"]["hi"] < b["e"]["lo"]
+
+
+class _FakeTable:
+    """Stands in for sybil_amd.Table on a box without a GPU: only the dictionary accessors."""
+
+    def __init__(self, distinct, strings):
+        self.distinct, self.strings = np.asarray(distinct, dtype=np.int64), list(strings)
+        self.installed = {}
+
+    def column_distinct(self, name):
+        return self.distinct
+
+    def set_group_dict(self, name, values):
+        self.installed["g:" + name] = np.asarray(values)
+
+    def column_dict(self, name):
+        return self.strings
+
+    def set_dict(self, name, strings):
+        self.installed["s:" + name] = list(strings)
+
+
+def _dict_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from sybil_amd import dist as sdist
+        t = _FakeTable([5, 1 << 40, -3] if rank == 0 else [7, 5, 9], ["b", "a"] if rank == 0 else ["c", "a"])
+        u = sdist.agree_group_dict(t, "uid")
+        s = sdist.agree_str_dict(t, "host")
+        q.put((rank, u.tolist(), s, t.installed["g:uid"].tolist(), t.installed["s:host"]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dictionary_agreement_two_ranks():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dict_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = sorted((q.get(timeout=120) for _ in range(2)), key=lambda x: x[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, u, s, gu, gs in outs:
+        assert u == gu == [-3, 5, 7, 9, 1 << 40]       # sorted union: rank order == key order on every rank
+        assert s == gs == ["a", "b", "c"]
