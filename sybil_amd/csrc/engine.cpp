@@ -133,16 +133,24 @@ static bool should_scan_block(const Table *t, const sybl_query_desc *d, int64_t 
 // role-specialised kernels cover: <= 4 range-filter, <= 2 group, <= 2 aggregation columns, all
 // fully populated int64, one role per column, no rejects / outliers / minima to track.
 static bool fill_fast_columns(Table *t, Query *q, const std::vector<int> &slot_col, FastPlan &FP, int *pnf, int *png,
-                              int *pna, bool *any_max, bool *all_max) {
+                              int *pna, bool *any_max, bool *all_max, bool allow_gen, bool *gen) {
     const ScanPlan &P = q->plan;
     memset(&FP, 0, sizeof(FP));
     int nf = 0, ng = 0, na = 0;
+    *gen = false;
     for (size_t s = 0; s < slot_col.size(); s++) {
         const SlotDesc &sd = P.slot[s];
         const Column *c = t->cols[(size_t)slot_col[s]].get();
-        if (c->type != SYBL_INT_VAL || c->elem != 8 || c->d_valid || c->has_missing) return false;
+        bool plain = c->type == SYBL_INT_VAL && c->elem == 8 && !c->d_valid && !c->has_missing;
+        if (!plain) {
+            // GEN kernels: int columns with missing rows in any role, str columns as group keys
+            if (!allow_gen) return false;
+            bool str_group = c->type == SYBL_STR_VAL && (sd.flags & (kSlotFilter | kSlotGroup | kSlotAgg | kSlotTime)) == kSlotGroup;
+            if (c->type != SYBL_INT_VAL && !str_group) return false;
+            *gen = true;
+        }
         uint32_t roles = sd.flags & (kSlotFilter | kSlotGroup | kSlotAgg);
-        if (sd.flags & (kSlotNeq | kSlotIdMask | kSlotWeight | kSlotW32 | kSlotSet | kSlotDict)) return false;
+        if (sd.flags & (kSlotNeq | kSlotIdMask | kSlotWeight | kSlotSet | kSlotDict)) return false;
         if (roles != kSlotRange && roles != kSlotGroup && roles != kSlotAgg && roles != 0) return false;  // one role per column
         if ((sd.flags & kSlotTime) && roles != 0) return false;  // the time column plays no second role here
     }
@@ -151,6 +159,7 @@ static bool fill_fast_columns(Table *t, Query *q, const std::vector<int> &slot_c
         if (!(sd.flags & kSlotRange)) continue;
         if (nf >= kFastMaxF) return false;
         FP.fcol[nf] = (const int64_t *)sd.base;
+        FP.fvalid[nf] = sd.valid;
         FP.lo[nf] = sd.lo;
         FP.hi[nf] = sd.hi;
         nf++;
@@ -161,7 +170,11 @@ static bool fill_fast_columns(Table *t, Query *q, const std::vector<int> &slot_c
         for (size_t k = 0; k < slot_col.size(); k++)
             if (slot_col[k] == gi.col) s = (int)k;
         const SlotDesc &sd = P.slot[s];
-        if (sd.gmissing >= 0) return false;
+        if (sd.gmissing >= 0 && !allow_gen) return false;
+        FP.gvalid[ng] = sd.valid;
+        FP.gw32[ng] = (sd.flags & kSlotW32) ? 1 : 0;
+        FP.gmissing[ng] = sd.gmissing;
+        FP.gvalues[ng] = sd.gvalues;
         FP.gcol[ng] = (const int64_t *)sd.base;
         FP.gmin[ng] = sd.gmin;
         FP.gcard[ng] = (uint32_t)sd.gcard;
@@ -173,7 +186,11 @@ static bool fill_fast_columns(Table *t, Query *q, const std::vector<int> &slot_c
     for (auto &ai : q->aggs) {
         if (na >= kFastMaxA) return false;
         const AggDesc &A = ai.d;
-        if (A.f_cnt >= 0 || A.f_smp >= 0 || A.f_out >= 0 || A.m_nmin >= 0) return false;
+        if (A.f_smp >= 0 || A.f_out >= 0 || A.m_nmin >= 0) return false;
+        if (A.f_cnt >= 0 || A.f_pop >= 0) {
+            if (!allow_gen) return false;
+            *gen = true;  // rejects / missing values: per-aggregation counts
+        }
         if (q->op == SYBL_AGG_HIST) {
             if (A.big_div || A.bucket_size >= ((int64_t)1 << 32)) return false;
             const Column *c = t->cols[(size_t)ai.col].get();
@@ -187,6 +204,11 @@ static bool fill_fast_columns(Table *t, Query *q, const std::vector<int> &slot_c
         for (size_t k = 0; k < slot_col.size(); k++)
             if (slot_col[k] == ai.col) s = (int)k;
         FP.acol[na] = (const int64_t *)P.slot[s].base;
+        FP.avalid[na] = P.slot[s].valid;
+        FP.f_cnt[na] = A.f_cnt;
+        FP.f_pop[na] = A.f_pop;
+        FP.info_min[na] = A.info_min;
+        FP.max10[na] = A.max10;
         FP.hmin[na] = A.hmin;
         FP.inv_bucket[na] = A.inv_bucket;
         FP.bucket_size[na] = (uint32_t)A.bucket_size;
@@ -222,12 +244,14 @@ static void select_fast_path(Table *t, Query *q, const std::vector<int> &slot_co
     if (q->time_mode && P.tb_big_div) return;
     FastPlan &FP = q->fplan;
     int nf, ng, na;
-    bool any_max, all_max;
-    if (!fill_fast_columns(t, q, slot_col, FP, &nf, &ng, &na, &any_max, &all_max)) return;
+    bool any_max, all_max, gen;
+    if (!fill_fast_columns(t, q, slot_col, FP, &nf, &ng, &na, &any_max, &all_max, !getenv("SYBL_NO_FASTGEN"), &gen)) return;
     if (q->op == SYBL_AGG_HIST && any_max) return;
+    q->fast_gen = gen;
     if (nf + ng + na == 0 && !q->time_mode) return;  // nothing to stream: the generic kernel picks a driver column
     if (q->time_mode) {
         FP.tcol = (const int64_t *)P.slot[P.time_slot].base;
+        FP.tvalid = P.slot[P.time_slot].valid;
         FP.time_bucket = P.time_bucket;
         FP.inv_time_bucket = P.inv_time_bucket;
         FP.tb_min = P.tb_min;
@@ -273,8 +297,8 @@ static int select_part_hist(Table *t, Query *q, const std::vector<int> &slot_col
     if (q->fast && q->fplan.hist_lds) return SYBL_OK;  // the bucket arrays already live in LDS
     EmitPlan &E = q->eplan;
     int nf, ng, na;
-    bool any_max, all_max;
-    if (!fill_fast_columns(t, q, slot_col, E.fp, &nf, &ng, &na, &any_max, &all_max)) return SYBL_OK;
+    bool any_max, all_max, gen;
+    if (!fill_fast_columns(t, q, slot_col, E.fp, &nf, &ng, &na, &any_max, &all_max, false, &gen)) return SYBL_OK;
     int rb = 0;
     for (auto &ai : q->aggs) {
         if (ai.d.n_values > (1 << kBucketBits)) return SYBL_OK;
@@ -976,7 +1000,7 @@ static int scan(Query *q) {
         if (q->fast) {
             q->fplan.sum_out = q->d_sum;
             q->fplan.max_out = q->d_max;
-            e = launch_scan_fast(q->fplan, q->fast_nf, q->fast_ng, q->fast_na, q->fast_mode, q->time_mode, q->n_wg,
+            e = launch_scan_fast(q->fplan, q->fast_nf, q->fast_ng, q->fast_na, q->fast_mode, q->time_mode, q->fast_gen, q->n_wg,
                                  q->lds_bytes, st);
             if (e != hipSuccess) return hip_fail(e, "k_scan_fast");
         } else {

@@ -196,7 +196,7 @@ struct Query {
     sybl_run_stats stats{};
     bool never_matches = false;
     // role-specialised kernel (scan_fast.h)
-    bool fast = false;
+    bool fast = false, fast_gen = false;
     int fast_nf = 0, fast_ng = 0, fast_na = 0, fast_mode = 0;
     FastPlan fplan;
     // partitioned histograms (strategy 5)

@@ -7,9 +7,9 @@ hipError_t launch_emit_nf4(const EmitPlan &E, int ng, int na, int n_wg, hipStrea
     return emit_launch_nf<4>(E, ng, na, n_wg, st);
 }
 
-hipError_t launch_scan_fast_nf4(const FastPlan &P, int ng, int na, int mode, bool time, int n_wg, size_t lds,
+hipError_t launch_scan_fast_nf4(const FastPlan &P, int ng, int na, int mode, bool time, bool gen, int n_wg, size_t lds,
                                 hipStream_t st) {
-    return fast_launch_nf<4>(P, ng, na, mode, time, n_wg, lds, st);
+    return fast_launch_nf<4>(P, ng, na, mode, time, gen, n_wg, lds, st);
 }
 
 }  // namespace sybl

@@ -51,13 +51,19 @@ struct FastPlan {
     int32_t windowed, lds_cells;   // lds_cells == n_cells unless windowed
     int32_t hist_lds;              // kFastHist: bucket arrays as uint32 in LDS (few cells), flushed once
     int32_t pad_;
+    // GEN kernels only: validity bitmaps (nullptr = fully populated), int32 group ids (str columns),
+    // missing-key cells, and the reject gate / per-aggregation counts of hist_basic.go:104
+    const uint32_t *fvalid[kFastMaxF], *gvalid[kFastMaxG], *avalid[kFastMaxA], *tvalid;
+    int32_t gw32[kFastMaxG], gmissing[kFastMaxG], gvalues[kFastMaxG];
+    int32_t f_cnt[kFastMaxA], f_pop[kFastMaxA];
+    int64_t info_min[kFastMaxA], max10[kFastMaxA];
     const int32_t *wg_cell_base;
     int64_t *sum_out, *max_out, *ws_sum, *ws_max;
     const Segment *segs;
     const int32_t *wg_seg_begin;
 };
 
-hipError_t launch_scan_fast(const FastPlan &P, int nf, int ng, int na, int mode, bool time, int n_wg,
+hipError_t launch_scan_fast(const FastPlan &P, int nf, int ng, int na, int mode, bool time, bool gen, int n_wg,
                             size_t lds_bytes, hipStream_t st);
 
 // ---- partitioned histograms (strategy 5) -------------------------------------------------
@@ -110,25 +116,50 @@ typedef long long fll2 __attribute__((ext_vector_type(2)));
 template <int N>
 struct FastTile {
     fll2 v[N > 0 ? N : 1];
+    uint32_t pop[N > 0 ? N : 1];  // GEN kernels: validity bits of the two rows
 };
 
-template <int NF, int NG, int NA, bool TIME>
+typedef int fi32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t fast_pop(const uint32_t *valid, int64_t row) {
+    return valid ? (valid[row >> 5] >> (row & 31)) & 3u : 3u;
+}
+
+template <int NF, int NG, int NA, bool TIME, bool GEN>
 __device__ __forceinline__ void fast_load(const FastPlan &P, int64_t row, FastTile<NF> &f, FastTile<NG> &g,
                                           FastTile<NA> &a, FastTile<1> &t) {
-    if (TIME) t.v[0] = __builtin_nontemporal_load((const fll2 *)(P.tcol + row));
+    if (TIME) {
+        t.v[0] = __builtin_nontemporal_load((const fll2 *)(P.tcol + row));
+        if (GEN) t.pop[0] = fast_pop(P.tvalid, row);
+    }
 #pragma unroll
-    for (int c = 0; c < NF; c++) f.v[c] = __builtin_nontemporal_load((const fll2 *)(P.fcol[c] + row));
+    for (int c = 0; c < NF; c++) {
+        f.v[c] = __builtin_nontemporal_load((const fll2 *)(P.fcol[c] + row));
+        if (GEN) f.pop[c] = fast_pop(P.fvalid[c], row);
+    }
 #pragma unroll
-    for (int c = 0; c < NG; c++) g.v[c] = __builtin_nontemporal_load((const fll2 *)(P.gcol[c] + row));
+    for (int c = 0; c < NG; c++) {
+        if (GEN && P.gw32[c]) {  // str column: int32 dictionary ids
+            const fi32x2 w = __builtin_nontemporal_load((const fi32x2 *)((const int32_t *)P.gcol[c] + row));
+            g.v[c].x = w.x;
+            g.v[c].y = w.y;
+        } else {
+            g.v[c] = __builtin_nontemporal_load((const fll2 *)(P.gcol[c] + row));
+        }
+        if (GEN) g.pop[c] = fast_pop(P.gvalid[c], row);
+    }
 #pragma unroll
-    for (int c = 0; c < NA; c++) a.v[c] = __builtin_nontemporal_load((const fll2 *)(P.acol[c] + row));
+    for (int c = 0; c < NA; c++) {
+        a.v[c] = __builtin_nontemporal_load((const fll2 *)(P.acol[c] + row));
+        if (GEN) a.pop[c] = fast_pop(P.avalid[c], row);
+    }
 }
 
 __device__ __forceinline__ void lds_add64(int64_t *lds, uint32_t idx, int64_t v) {
     __hip_atomic_fetch_add(lds + idx, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-template <int NF, int NG, int NA, int MODE, bool TIME>
+template <int NF, int NG, int NA, int MODE, bool TIME, bool GEN>
 __device__ __forceinline__ void fast_row(const FastPlan &P, const FastTile<NF> &f, const FastTile<NG> &g,
                                          const FastTile<NA> &a, const FastTile<1> &t, const int r, int64_t *lds,
                                          const uint32_t rep, const uint32_t max_base, const uint32_t cell_base,
@@ -138,6 +169,7 @@ __device__ __forceinline__ void fast_row(const FastPlan &P, const FastTile<NF> &
     for (int c = 0; c < NF; c++) {
         const int64_t x = r == 0 ? f.v[c].x : f.v[c].y;
         pass = pass && x >= P.lo[c] && x <= P.hi[c];  // filter.go:171-195, folded to a range
+        if (GEN) pass = pass && ((f.pop[c] >> r) & 1u);  // an unpopulated value fails every int filter
     }
     if (!pass) return;
     matched += 1;  // aggregate.go:117
@@ -146,10 +178,17 @@ __device__ __forceinline__ void fast_row(const FastPlan &P, const FastTile<NF> &
 #pragma unroll
     for (int c = 0; c < NG; c++) {
         const int64_t x = r == 0 ? g.v[c].x : g.v[c].y;
+        if (GEN && !((g.pop[c] >> r) & 1u)) {
+            // MISSING_VALUE key (aggregate.go:138): its own digit, or the digit of the value -1
+            inb = inb && P.gmissing[c] >= 0;
+            cell += (uint32_t)P.gmissing[c];
+            continue;
+        }
         const uint64_t d = (uint64_t)x - (uint64_t)P.gmin[c];
-        inb = inb && d < (uint64_t)P.gcard[c];
+        inb = inb && d < (uint64_t)(GEN ? (uint32_t)P.gvalues[c] : P.gcard[c]);
         cell += (uint32_t)d * (uint32_t)P.gstride[c];  // aggregate.go:125-143 as a direct-mapped index
     }
+    if (TIME && GEN && !((t.pop[0] >> r) & 1u)) return;  // no time value: dropped after it was counted (aggregate.go:147-153)
     if (TIME) {
         // val = int(val) / TimeBucket * TimeBucket, truncating (aggregate.go:174); |t| < 2^51 here
         const int64_t tv = r == 0 ? t.v[0].x : t.v[0].y;
@@ -177,6 +216,14 @@ __device__ __forceinline__ void fast_row(const FastPlan &P, const FastTile<NF> &
 #pragma unroll
     for (int c = 0; c < NA; c++) {
         const int64_t x = r == 0 ? a.v[c].x : a.v[c].y;
+        if (GEN) {
+            if (!((a.pop[c] >> r) & 1u)) continue;
+            if (P.f_pop[c] >= 0) lds_add64(lds, (((uint32_t)P.f_pop[c] * ncell) << rs) + cidx, 1);
+            if (P.f_cnt[c] >= 0) {
+                if (x > P.max10[c] || x < P.info_min[c]) continue;  // hist_basic.go:104
+                lds_add64(lds, (((uint32_t)P.f_cnt[c] * ncell) << rs) + cidx, 1);
+            }
+        }
         lds_add64(lds, (((uint32_t)P.f_sum[c] * ncell) << rs) + cidx, x);
         if (MODE == kFastAvgMax) {
             int64_t *m = lds + max_base + (((uint32_t)P.m_max[c] * ncell) << rs) + cidx;
@@ -208,7 +255,7 @@ __device__ __forceinline__ void fast_row(const FastPlan &P, const FastTile<NF> &
     }
 }
 
-template <int NF, int NG, int NA, int MODE, bool TIME>
+template <int NF, int NG, int NA, int MODE, bool TIME, bool GEN>
 __global__ __launch_bounds__(kWgThreads, 4) void k_scan_fast(const FastPlan P) {
     extern __shared__ int64_t lds[];
     const uint32_t tid = threadIdx.x;
@@ -237,13 +284,13 @@ __global__ __launch_bounds__(kWgThreads, 4) void k_scan_fast(const FastPlan P) {
         FastTile<NA> a0, a1;
         FastTile<1> t0, t1;
         // register double buffer: the next tile's loads are in flight while this one is consumed
-        if (row < end) fast_load<NF, NG, NA, TIME>(P, row, f0, g0, a0, t0);
+        if (row < end) fast_load<NF, NG, NA, TIME, GEN>(P, row, f0, g0, a0, t0);
         for (; row < end; row += kTileRows) {
             const int64_t nrow = row + kTileRows;
-            if (nrow < end) fast_load<NF, NG, NA, TIME>(P, nrow, f1, g1, a1, t1);
-            fast_row<NF, NG, NA, MODE, TIME>(P, f0, g0, a0, t0, 0, lds, rep, max_base, cell_base, hist32, matched, overflow);
+            if (nrow < end) fast_load<NF, NG, NA, TIME, GEN>(P, nrow, f1, g1, a1, t1);
+            fast_row<NF, NG, NA, MODE, TIME, GEN>(P, f0, g0, a0, t0, 0, lds, rep, max_base, cell_base, hist32, matched, overflow);
             if (row + 1 < end)
-                fast_row<NF, NG, NA, MODE, TIME>(P, f0, g0, a0, t0, 1, lds, rep, max_base, cell_base, hist32, matched, overflow);
+                fast_row<NF, NG, NA, MODE, TIME, GEN>(P, f0, g0, a0, t0, 1, lds, rep, max_base, cell_base, hist32, matched, overflow);
             f0 = f1;
             g0 = g1;
             a0 = a1;
@@ -379,10 +426,10 @@ __global__ __launch_bounds__(kWgThreads, 4) void k_emit(const EmitPlan E) {
         FastTile<NG> g0, g1;
         FastTile<NA> a0, a1;
         FastTile<1> t0;
-        if (row < end) fast_load<NF, NG, NA, false>(P, row, f0, g0, a0, t0);
+        if (row < end) fast_load<NF, NG, NA, false, false>(P, row, f0, g0, a0, t0);
         for (int64_t it = 0; it < n_tiles; it++, row += kTileRows) {
             const int64_t nrow = row + kTileRows;
-            if (nrow < end) fast_load<NF, NG, NA, false>(P, nrow, f1, g1, a1, t0);
+            if (nrow < end) fast_load<NF, NG, NA, false, false>(P, nrow, f1, g1, a1, t0);
 #pragma unroll
             for (int r = 0; r < kRowsPerThread; r++) {
                 if (row + r >= end) break;
@@ -488,48 +535,48 @@ static hipError_t emit_launch_nf(const EmitPlan &E, int ng, int na, int n_wg, hi
 }
 
 // One translation unit per NF keeps the build parallel (Makefile: kernels_fast_<NF>.o).
-template <int NF, int NG, int NA, int MODE>
-static hipError_t fast_launch_one(const FastPlan &P, bool time, int n_wg, size_t lds_bytes, hipStream_t st) {
-    hipError_t e;
-    if (time) {
-        auto k = k_scan_fast<NF, NG, NA, MODE, true>;
-        e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k, dim3(n_wg), dim3(kWgThreads), lds_bytes, st, P);
-    } else {
-        auto k = k_scan_fast<NF, NG, NA, MODE, false>;
-        e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k, dim3(n_wg), dim3(kWgThreads), lds_bytes, st, P);
-    }
+template <int NF, int NG, int NA, int MODE, bool TIME, bool GEN>
+static hipError_t fast_launch_k(const FastPlan &P, int n_wg, size_t lds_bytes, hipStream_t st) {
+    auto k = k_scan_fast<NF, NG, NA, MODE, TIME, GEN>;
+    hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, dim3(n_wg), dim3(kWgThreads), lds_bytes, st, P);
     return hipGetLastError();
 }
 
+template <int NF, int NG, int NA, int MODE>
+static hipError_t fast_launch_one(const FastPlan &P, bool time, bool gen, int n_wg, size_t lds_bytes, hipStream_t st) {
+    if (time) return gen ? fast_launch_k<NF, NG, NA, MODE, true, true>(P, n_wg, lds_bytes, st)
+                         : fast_launch_k<NF, NG, NA, MODE, true, false>(P, n_wg, lds_bytes, st);
+    return gen ? fast_launch_k<NF, NG, NA, MODE, false, true>(P, n_wg, lds_bytes, st)
+               : fast_launch_k<NF, NG, NA, MODE, false, false>(P, n_wg, lds_bytes, st);
+}
+
 template <int NF, int NG, int NA>
-static hipError_t fast_launch_mode(const FastPlan &P, int mode, bool time, int n_wg, size_t lds, hipStream_t st) {
-    if (NA == 0) return fast_launch_one<NF, NG, 0, kFastAvg>(P, time, n_wg, lds, st);
+static hipError_t fast_launch_mode(const FastPlan &P, int mode, bool time, bool gen, int n_wg, size_t lds, hipStream_t st) {
+    if (NA == 0) return fast_launch_one<NF, NG, 0, kFastAvg>(P, time, gen, n_wg, lds, st);
     switch (mode) {
-    case kFastAvg: return fast_launch_one<NF, NG, NA, kFastAvg>(P, time, n_wg, lds, st);
-    case kFastAvgMax: return fast_launch_one<NF, NG, NA, kFastAvgMax>(P, time, n_wg, lds, st);
-    case kFastMoments: return fast_launch_one<NF, NG, NA, kFastMoments>(P, time, n_wg, lds, st);
-    case kFastHist: return fast_launch_one<NF, NG, NA, kFastHist>(P, time, n_wg, lds, st);
+    case kFastAvg: return fast_launch_one<NF, NG, NA, kFastAvg>(P, time, gen, n_wg, lds, st);
+    case kFastAvgMax: return fast_launch_one<NF, NG, NA, kFastAvgMax>(P, time, gen, n_wg, lds, st);
+    case kFastMoments: return fast_launch_one<NF, NG, NA, kFastMoments>(P, time, gen, n_wg, lds, st);
+    case kFastHist: return fast_launch_one<NF, NG, NA, kFastHist>(P, time, gen, n_wg, lds, st);
     default: return hipErrorInvalidValue;
     }
 }
 
 template <int NF>
-static hipError_t fast_launch_nf(const FastPlan &P, int ng, int na, int mode, bool time, int n_wg, size_t lds,
+static hipError_t fast_launch_nf(const FastPlan &P, int ng, int na, int mode, bool time, bool gen, int n_wg, size_t lds,
                                  hipStream_t st) {
     switch (ng * 3 + na) {
-    case 0: return fast_launch_mode<NF, 0, 0>(P, mode, time, n_wg, lds, st);
-    case 1: return fast_launch_mode<NF, 0, 1>(P, mode, time, n_wg, lds, st);
-    case 2: return fast_launch_mode<NF, 0, 2>(P, mode, time, n_wg, lds, st);
-    case 3: return fast_launch_mode<NF, 1, 0>(P, mode, time, n_wg, lds, st);
-    case 4: return fast_launch_mode<NF, 1, 1>(P, mode, time, n_wg, lds, st);
-    case 5: return fast_launch_mode<NF, 1, 2>(P, mode, time, n_wg, lds, st);
-    case 6: return fast_launch_mode<NF, 2, 0>(P, mode, time, n_wg, lds, st);
-    case 7: return fast_launch_mode<NF, 2, 1>(P, mode, time, n_wg, lds, st);
-    case 8: return fast_launch_mode<NF, 2, 2>(P, mode, time, n_wg, lds, st);
+    case 0: return fast_launch_mode<NF, 0, 0>(P, mode, time, gen, n_wg, lds, st);
+    case 1: return fast_launch_mode<NF, 0, 1>(P, mode, time, gen, n_wg, lds, st);
+    case 2: return fast_launch_mode<NF, 0, 2>(P, mode, time, gen, n_wg, lds, st);
+    case 3: return fast_launch_mode<NF, 1, 0>(P, mode, time, gen, n_wg, lds, st);
+    case 4: return fast_launch_mode<NF, 1, 1>(P, mode, time, gen, n_wg, lds, st);
+    case 5: return fast_launch_mode<NF, 1, 2>(P, mode, time, gen, n_wg, lds, st);
+    case 6: return fast_launch_mode<NF, 2, 0>(P, mode, time, gen, n_wg, lds, st);
+    case 7: return fast_launch_mode<NF, 2, 1>(P, mode, time, gen, n_wg, lds, st);
+    case 8: return fast_launch_mode<NF, 2, 2>(P, mode, time, gen, n_wg, lds, st);
     default: return hipErrorInvalidValue;
     }
 }
@@ -542,10 +589,10 @@ hipError_t launch_emit_nf1(const EmitPlan &E, int ng, int na, int n_wg, hipStrea
 hipError_t launch_emit_nf2(const EmitPlan &E, int ng, int na, int n_wg, hipStream_t st);
 hipError_t launch_emit_nf3(const EmitPlan &E, int ng, int na, int n_wg, hipStream_t st);
 hipError_t launch_emit_nf4(const EmitPlan &E, int ng, int na, int n_wg, hipStream_t st);
-hipError_t launch_scan_fast_nf0(const FastPlan &P, int ng, int na, int mode, bool time, int n_wg, size_t lds, hipStream_t st);
-hipError_t launch_scan_fast_nf1(const FastPlan &P, int ng, int na, int mode, bool time, int n_wg, size_t lds, hipStream_t st);
-hipError_t launch_scan_fast_nf2(const FastPlan &P, int ng, int na, int mode, bool time, int n_wg, size_t lds, hipStream_t st);
-hipError_t launch_scan_fast_nf3(const FastPlan &P, int ng, int na, int mode, bool time, int n_wg, size_t lds, hipStream_t st);
-hipError_t launch_scan_fast_nf4(const FastPlan &P, int ng, int na, int mode, bool time, int n_wg, size_t lds, hipStream_t st);
+hipError_t launch_scan_fast_nf0(const FastPlan &P, int ng, int na, int mode, bool time, bool gen, int n_wg, size_t lds, hipStream_t st);
+hipError_t launch_scan_fast_nf1(const FastPlan &P, int ng, int na, int mode, bool time, bool gen, int n_wg, size_t lds, hipStream_t st);
+hipError_t launch_scan_fast_nf2(const FastPlan &P, int ng, int na, int mode, bool time, bool gen, int n_wg, size_t lds, hipStream_t st);
+hipError_t launch_scan_fast_nf3(const FastPlan &P, int ng, int na, int mode, bool time, bool gen, int n_wg, size_t lds, hipStream_t st);
+hipError_t launch_scan_fast_nf4(const FastPlan &P, int ng, int na, int mode, bool time, bool gen, int n_wg, size_t lds, hipStream_t st);
 
 }  // namespace sybl
