@@ -124,12 +124,19 @@ def main():
         hi = a + 4 * (b - 1) if kind == synth.BELL else a + b - 1
         table.set_bounds(n, a, hi)
     query = table.query(**q)
+    side = None
     if multi:
         if args.collective == "torch":
-            query.bind_torch(device)
-            # run the engine on torch's current stream: scan -> all-reduce -> finalize are then
-            # ordered on the device without host round trips
-            ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+            # One explicit (non-default) stream carries scan -> all-reduce -> finalize: the engine is
+            # pointed at it and torch.distributed orders its collective against torch's CURRENT stream,
+            # which is this one inside the `with` below.  (The default stream's handle is NULL, which
+            # sybl_ctx_set_stream would read as "use the engine's own stream" -- and then nothing would
+            # order the all-reduce after the scan.)
+            side = torch.cuda.Stream(device=device)
+            assert side.cuda_stream != 0
+            with torch.cuda.stream(side):
+                query.bind_torch(device)
+            ctx.set_stream(side.cuda_stream)
         else:
             uid = [ctx.comm_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(uid, src=0)
@@ -141,7 +148,8 @@ def main():
         query.scan()
         if multi:
             if args.collective == "torch":
-                query.allreduce_torch()
+                with torch.cuda.stream(side):
+                    query.allreduce_torch()
             else:
                 query.allreduce()
         res = None
@@ -160,9 +168,11 @@ def main():
         torch.cuda.synchronize()
 
     res = None
+    seen_matched = set()
     for _ in range(args.warmup):
         r = step()
         if r is not None:
+            seen_matched.add(r.matched)
             r.free()
     fence()
     del scan_ms[:]
@@ -170,6 +180,7 @@ def main():
     for i in range(args.steps):
         r = step()
         if r is not None:
+            seen_matched.add(r.matched)
             if res is not None:
                 res.free()
             res = r
@@ -182,6 +193,10 @@ def main():
 
     stats = query.stats()
     if rank == 0:
+        # every step scans the same table: the merged result must not change from step to step (it
+        # would if the all-reduce ever ran ahead of a rank's scan) and group counts must add up
+        assert len(seen_matched) == 1, "matched count varies across steps: %r" % sorted(seen_matched)
+        assert sum(g["count"] for g in res.results) == res.matched
         ms_per_step = dt / args.steps * 1e3
         value = total_rows * args.steps / dt
         k_ms = sum(scan_ms) / len(scan_ms)

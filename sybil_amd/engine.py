@@ -291,7 +291,10 @@ class Query:
         return s, m
 
     def allreduce_torch(self, group=None):
-        """The one collective on the path: SUM over counts/sums/buckets, MAX over extrema."""
+        """The one collective on the path: SUM over counts/sums/buckets, MAX over extrema.
+        torch.distributed orders the collective against torch's CURRENT stream: call this inside
+        `with torch.cuda.stream(s)` for the stream `s` the Context was pointed at (Context.set_stream),
+        or synchronise the Context first."""
         from . import dist as sdist
         s, m = self._bound
         if self._has_max is None:
