@@ -25,7 +25,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable by a copy
 
 
-def cpu_baseline(workload, total_rows, budget_s=15.0):
+def cpu_baseline(workload, total_rows, budget_s=20.0):
     """The CPU oracle (a C restatement of the reference algorithm, kind "port") timed on this
     host's cores on a bounded sample of the same workload.  Reported, never the target."""
     from oracle import oracle as orc

@@ -150,7 +150,8 @@ static bool fill_fast_columns(Table *t, Query *q, const std::vector<int> &slot_c
             *gen = true;
         }
         uint32_t roles = sd.flags & (kSlotFilter | kSlotGroup | kSlotAgg);
-        if (sd.flags & (kSlotNeq | kSlotIdMask | kSlotWeight | kSlotSet | kSlotDict)) return false;
+        if (sd.flags & (kSlotNeq | kSlotIdMask | kSlotSet | kSlotDict)) return false;
+        if ((sd.flags & kSlotWeight) && (roles != 0 || (sd.flags & kSlotTime) || !allow_gen)) return false;
         if (roles != kSlotRange && roles != kSlotGroup && roles != kSlotAgg && roles != 0) return false;  // one role per column
         if ((sd.flags & kSlotTime) && roles != 0) return false;  // the time column plays no second role here
     }
@@ -186,7 +187,8 @@ static bool fill_fast_columns(Table *t, Query *q, const std::vector<int> &slot_c
     for (auto &ai : q->aggs) {
         if (na >= kFastMaxA) return false;
         const AggDesc &A = ai.d;
-        if (A.f_smp >= 0 || A.f_out >= 0 || A.m_nmin >= 0) return false;
+        if (A.f_out >= 0 || A.m_nmin >= 0) return false;
+        if (A.f_smp >= 0 && !allow_gen) return false;
         if (A.f_cnt >= 0 || A.f_pop >= 0) {
             if (!allow_gen) return false;
             *gen = true;  // rejects / missing values: per-aggregation counts
@@ -207,6 +209,7 @@ static bool fill_fast_columns(Table *t, Query *q, const std::vector<int> &slot_c
         FP.avalid[na] = P.slot[s].valid;
         FP.f_cnt[na] = A.f_cnt;
         FP.f_pop[na] = A.f_pop;
+        FP.f_smp[na] = A.f_smp;
         FP.info_min[na] = A.info_min;
         FP.max10[na] = A.max10;
         FP.hmin[na] = A.hmin;
@@ -219,6 +222,12 @@ static bool fill_fast_columns(Table *t, Query *q, const std::vector<int> &slot_c
         FP.m_max[na] = A.m_max;
         FP.hist_agg_off[na] = P.hist_agg_off[na];
         na++;
+    }
+    FP.f_samples = P.f_samples;
+    if (q->weighted) {
+        if (!allow_gen) return false;
+        FP.wcol = (const int64_t *)P.slot[P.weight_slot].base;
+        *gen = true;
     }
     FP.hist_off = P.hist_off;
     FP.hist_stride = P.hist_stride;
@@ -240,13 +249,14 @@ static void select_fast_path(Table *t, Query *q, const std::vector<int> &slot_co
     q->fast = false;
     const ScanPlan &P = q->plan;
     if (getenv("SYBL_NO_FAST")) return;
-    if (!q->use_lds || q->weighted) return;
+    if (!q->use_lds) return;
     if (q->time_mode && P.tb_big_div) return;
     FastPlan &FP = q->fplan;
     int nf, ng, na;
     bool any_max, all_max, gen;
     if (!fill_fast_columns(t, q, slot_col, FP, &nf, &ng, &na, &any_max, &all_max, !getenv("SYBL_NO_FASTGEN"), &gen)) return;
     if (q->op == SYBL_AGG_HIST && any_max) return;
+    if (q->weighted && q->op == SYBL_AGG_HIST && q->want_percentiles) return;  // weighted bucket increments: generic kernel
     q->fast_gen = gen;
     if (nf + ng + na == 0 && !q->time_mode) return;  // nothing to stream: the generic kernel picks a driver column
     if (q->time_mode) {

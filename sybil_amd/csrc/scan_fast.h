@@ -55,8 +55,11 @@ struct FastPlan {
     // missing-key cells, and the reject gate / per-aggregation counts of hist_basic.go:104
     const uint32_t *fvalid[kFastMaxF], *gvalid[kFastMaxG], *avalid[kFastMaxA], *tvalid;
     int32_t gw32[kFastMaxG], gmissing[kFastMaxG], gvalues[kFastMaxG];
-    int32_t f_cnt[kFastMaxA], f_pop[kFastMaxA];
+    int32_t f_cnt[kFastMaxA], f_pop[kFastMaxA], f_smp[kFastMaxA];
     int64_t info_min[kFastMaxA], max10[kFastMaxA];
+    const int64_t *wcol;           // weight column (OPTS.WEIGHT_COL, aggregate.go:100-102), fully populated
+    int32_t f_samples;             // Result.Samples field when weighted, else -1
+    int32_t pad2_;
     const int32_t *wg_cell_base;
     int64_t *sum_out, *max_out, *ws_sum, *ws_max;
     const Segment *segs;
@@ -127,7 +130,8 @@ __device__ __forceinline__ uint32_t fast_pop(const uint32_t *valid, int64_t row)
 
 template <int NF, int NG, int NA, bool TIME, bool GEN>
 __device__ __forceinline__ void fast_load(const FastPlan &P, int64_t row, FastTile<NF> &f, FastTile<NG> &g,
-                                          FastTile<NA> &a, FastTile<1> &t) {
+                                          FastTile<NA> &a, FastTile<1> &t, FastTile<1> &w) {
+    if (GEN && P.wcol) w.v[0] = __builtin_nontemporal_load((const fll2 *)(P.wcol + row));
     if (TIME) {
         t.v[0] = __builtin_nontemporal_load((const fll2 *)(P.tcol + row));
         if (GEN) t.pop[0] = fast_pop(P.tvalid, row);
@@ -161,7 +165,8 @@ __device__ __forceinline__ void lds_add64(int64_t *lds, uint32_t idx, int64_t v)
 
 template <int NF, int NG, int NA, int MODE, bool TIME, bool GEN>
 __device__ __forceinline__ void fast_row(const FastPlan &P, const FastTile<NF> &f, const FastTile<NG> &g,
-                                         const FastTile<NA> &a, const FastTile<1> &t, const int r, int64_t *lds,
+                                         const FastTile<NA> &a, const FastTile<1> &t, const FastTile<1> &w, const int r,
+                                         int64_t *lds,
                                          const uint32_t rep, const uint32_t max_base, const uint32_t cell_base,
                                          uint32_t *hist32, uint32_t &matched, uint32_t &overflow) {
     bool pass = true;
@@ -212,7 +217,10 @@ __device__ __forceinline__ void fast_row(const FastPlan &P, const FastTile<NF> &
     }
     const uint32_t rs = (uint32_t)P.rep_shift;
     const uint32_t cidx = (lcell << rs) + rep;
-    lds_add64(lds, cidx, 1);  // Result.Count (aggregate.go:203); Samples == Count without a weight column
+    // weight := r.Ints[WEIGHT_COL] (aggregate.go:100-102); 1 without a weight column
+    const int64_t wt = (GEN && P.wcol) ? (r == 0 ? w.v[0].x : w.v[0].y) : 1;
+    lds_add64(lds, cidx, wt);  // Result.Count += weight (aggregate.go:203)
+    if (GEN && P.f_samples >= 0) lds_add64(lds, (((uint32_t)P.f_samples * ncell) << rs) + cidx, 1);  // Result.Samples++
 #pragma unroll
     for (int c = 0; c < NA; c++) {
         const int64_t x = r == 0 ? a.v[c].x : a.v[c].y;
@@ -221,10 +229,11 @@ __device__ __forceinline__ void fast_row(const FastPlan &P, const FastTile<NF> &
             if (P.f_pop[c] >= 0) lds_add64(lds, (((uint32_t)P.f_pop[c] * ncell) << rs) + cidx, 1);
             if (P.f_cnt[c] >= 0) {
                 if (x > P.max10[c] || x < P.info_min[c]) continue;  // hist_basic.go:104
-                lds_add64(lds, (((uint32_t)P.f_cnt[c] * ncell) << rs) + cidx, 1);
+                lds_add64(lds, (((uint32_t)P.f_cnt[c] * ncell) << rs) + cidx, wt);  // h.Count += weight
             }
+            if (P.f_smp[c] >= 0) lds_add64(lds, (((uint32_t)P.f_smp[c] * ncell) << rs) + cidx, 1);  // h.Samples++
         }
-        lds_add64(lds, (((uint32_t)P.f_sum[c] * ncell) << rs) + cidx, x);
+        lds_add64(lds, (((uint32_t)P.f_sum[c] * ncell) << rs) + cidx, (int64_t)((uint64_t)x * (uint64_t)wt));
         if (MODE == kFastAvgMax) {
             int64_t *m = lds + max_base + (((uint32_t)P.m_max[c] * ncell) << rs) + cidx;
             if (x > *m) __hip_atomic_fetch_max(m, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -242,8 +251,8 @@ __device__ __forceinline__ void fast_row(const FastPlan &P, const FastTile<NF> &
                 b += 1;
             }
             if (MODE == kFastMoments) {
-                lds_add64(lds, (((uint32_t)P.f_sb[c] * ncell) << rs) + cidx, (int64_t)b);
-                lds_add64(lds, (((uint32_t)P.f_sb2[c] * ncell) << rs) + cidx, (int64_t)((uint64_t)b * (uint64_t)b));
+                lds_add64(lds, (((uint32_t)P.f_sb[c] * ncell) << rs) + cidx, (int64_t)b * wt);
+                lds_add64(lds, (((uint32_t)P.f_sb2[c] * ncell) << rs) + cidx, (int64_t)((uint64_t)b * (uint64_t)b) * wt);
             } else if (P.hist_lds) {
                 __hip_atomic_fetch_add(hist32 + lcell * (uint32_t)P.hist_stride + (uint32_t)P.hist_agg_off[c] + b, 1u,
                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -282,19 +291,20 @@ __global__ __launch_bounds__(kWgThreads, 4) void k_scan_fast(const FastPlan P) {
         FastTile<NF> f0, f1;
         FastTile<NG> g0, g1;
         FastTile<NA> a0, a1;
-        FastTile<1> t0, t1;
+        FastTile<1> t0, t1, w0, w1;
         // register double buffer: the next tile's loads are in flight while this one is consumed
-        if (row < end) fast_load<NF, NG, NA, TIME, GEN>(P, row, f0, g0, a0, t0);
+        if (row < end) fast_load<NF, NG, NA, TIME, GEN>(P, row, f0, g0, a0, t0, w0);
         for (; row < end; row += kTileRows) {
             const int64_t nrow = row + kTileRows;
-            if (nrow < end) fast_load<NF, NG, NA, TIME, GEN>(P, nrow, f1, g1, a1, t1);
-            fast_row<NF, NG, NA, MODE, TIME, GEN>(P, f0, g0, a0, t0, 0, lds, rep, max_base, cell_base, hist32, matched, overflow);
+            if (nrow < end) fast_load<NF, NG, NA, TIME, GEN>(P, nrow, f1, g1, a1, t1, w1);
+            fast_row<NF, NG, NA, MODE, TIME, GEN>(P, f0, g0, a0, t0, w0, 0, lds, rep, max_base, cell_base, hist32, matched, overflow);
             if (row + 1 < end)
-                fast_row<NF, NG, NA, MODE, TIME, GEN>(P, f0, g0, a0, t0, 1, lds, rep, max_base, cell_base, hist32, matched, overflow);
+                fast_row<NF, NG, NA, MODE, TIME, GEN>(P, f0, g0, a0, t0, w0, 1, lds, rep, max_base, cell_base, hist32, matched, overflow);
             f0 = f1;
             g0 = g1;
             a0 = a1;
             t0 = t1;
+            w0 = w1;
         }
     }
 
@@ -426,10 +436,10 @@ __global__ __launch_bounds__(kWgThreads, 4) void k_emit(const EmitPlan E) {
         FastTile<NG> g0, g1;
         FastTile<NA> a0, a1;
         FastTile<1> t0;
-        if (row < end) fast_load<NF, NG, NA, false, false>(P, row, f0, g0, a0, t0);
+        if (row < end) fast_load<NF, NG, NA, false, false>(P, row, f0, g0, a0, t0, t0);
         for (int64_t it = 0; it < n_tiles; it++, row += kTileRows) {
             const int64_t nrow = row + kTileRows;
-            if (nrow < end) fast_load<NF, NG, NA, false, false>(P, nrow, f1, g1, a1, t0);
+            if (nrow < end) fast_load<NF, NG, NA, false, false>(P, nrow, f1, g1, a1, t0, t0);
 #pragma unroll
             for (int r = 0; r < kRowsPerThread; r++) {
                 if (row + r >= end) break;

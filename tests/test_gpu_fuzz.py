@@ -63,7 +63,7 @@ def _random_query(rng, info):
     return q
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(40))
 def test_random_queries(ctx, oracle, seed):
     rng = np.random.default_rng(1000 + seed)
     n = int(rng.integers(1, 60_000))
