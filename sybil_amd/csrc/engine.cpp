@@ -187,8 +187,9 @@ static bool fill_fast_columns(Table *t, Query *q, const std::vector<int> &slot_c
     for (auto &ai : q->aggs) {
         if (na >= kFastMaxA) return false;
         const AggDesc &A = ai.d;
-        if (A.f_out >= 0 || A.m_nmin >= 0) return false;
-        if (A.f_smp >= 0 && !allow_gen) return false;
+        if (A.m_nmin >= 0) return false;
+        if ((A.f_smp >= 0 || A.f_out >= 0) && !allow_gen) return false;
+        if (A.f_out >= 0 || (q->op == SYBL_AGG_HIST && A.m_max >= 0)) *gen = true;  // outliers / h.Max live in the GEN body
         if (A.f_cnt >= 0 || A.f_pop >= 0) {
             if (!allow_gen) return false;
             *gen = true;  // rejects / missing values: per-aggregation counts
@@ -210,6 +211,7 @@ static bool fill_fast_columns(Table *t, Query *q, const std::vector<int> &slot_c
         FP.f_cnt[na] = A.f_cnt;
         FP.f_pop[na] = A.f_pop;
         FP.f_smp[na] = A.f_smp;
+        FP.f_out[na] = A.f_out;
         FP.info_min[na] = A.info_min;
         FP.max10[na] = A.max10;
         FP.hmin[na] = A.hmin;
@@ -255,7 +257,7 @@ static void select_fast_path(Table *t, Query *q, const std::vector<int> &slot_co
     int nf, ng, na;
     bool any_max, all_max, gen;
     if (!fill_fast_columns(t, q, slot_col, FP, &nf, &ng, &na, &any_max, &all_max, !getenv("SYBL_NO_FASTGEN"), &gen)) return;
-    if (q->op == SYBL_AGG_HIST && any_max) return;
+    if (q->op == SYBL_AGG_HIST && any_max && !gen) return;
     if (q->weighted && q->op == SYBL_AGG_HIST && q->want_percentiles) return;  // weighted bucket increments: generic kernel
     q->fast_gen = gen;
     if (nf + ng + na == 0 && !q->time_mode) return;  // nothing to stream: the generic kernel picks a driver column

@@ -55,7 +55,7 @@ struct FastPlan {
     // missing-key cells, and the reject gate / per-aggregation counts of hist_basic.go:104
     const uint32_t *fvalid[kFastMaxF], *gvalid[kFastMaxG], *avalid[kFastMaxA], *tvalid;
     int32_t gw32[kFastMaxG], gmissing[kFastMaxG], gvalues[kFastMaxG];
-    int32_t f_cnt[kFastMaxA], f_pop[kFastMaxA], f_smp[kFastMaxA];
+    int32_t f_cnt[kFastMaxA], f_pop[kFastMaxA], f_smp[kFastMaxA], f_out[kFastMaxA];
     int64_t info_min[kFastMaxA], max10[kFastMaxA];
     const int64_t *wcol;           // weight column (OPTS.WEIGHT_COL, aggregate.go:100-102), fully populated
     int32_t f_samples;             // Result.Samples field when weighted, else -1
@@ -249,6 +249,31 @@ __device__ __forceinline__ void fast_row(const FastPlan &P, const FastTile<NF> &
                 b -= 1;
             } else if ((uint32_t)rem >= P.bucket_size[c]) {
                 b += 1;
+            }
+            if (GEN) {
+                // h.Max starts at Info.Max: track only when the column can exceed it
+                if (P.m_max[c] >= 0) {
+                    int64_t *m = lds + max_base + (((uint32_t)P.m_max[c] * ncell) << rs) + cidx;
+                    if (x > *m) __hip_atomic_fetch_max(m, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                if (b >= (uint32_t)P.n_values[c]) {
+                    // Outlier (hist_basic.go:132-135): clipped into the last bucket AND remembered as
+                    // exact n, sum(o), sum(o^2) (four 32-bit limbs)
+                    if (P.f_out[c] >= 0) {
+                        const uint32_t step = ncell << rs;
+                        const uint32_t fi = (((uint32_t)P.f_out[c] * ncell) << rs) + cidx;
+                        const unsigned __int128 sq = (unsigned __int128)((__int128)x * (__int128)x);
+                        lds_add64(lds, fi, 1);
+                        lds_add64(lds, fi + step, x);
+                        lds_add64(lds, fi + 2 * step, (int64_t)(uint64_t)(sq & 0xFFFFFFFFu));
+                        lds_add64(lds, fi + 3 * step, (int64_t)(uint64_t)((sq >> 32) & 0xFFFFFFFFu));
+                        lds_add64(lds, fi + 4 * step, (int64_t)(uint64_t)((sq >> 64) & 0xFFFFFFFFu));
+                        lds_add64(lds, fi + 5 * step, (int64_t)(uint64_t)(sq >> 96));
+                    } else {
+                        overflow += 1;
+                    }
+                    b = (uint32_t)P.n_values[c] - 1;
+                }
             }
             if (MODE == kFastMoments) {
                 lds_add64(lds, (((uint32_t)P.f_sb[c] * ncell) << rs) + cidx, (int64_t)b * wt);
