@@ -145,24 +145,36 @@ static bool fill_fast_columns(Table *t, Query *q, const std::vector<int> &slot_c
         if (!plain) {
             // GEN kernels: int columns with missing rows in any role, str columns as group keys
             if (!allow_gen) return false;
-            bool str_group = c->type == SYBL_STR_VAL && (sd.flags & (kSlotFilter | kSlotGroup | kSlotAgg | kSlotTime)) == kSlotGroup;
-            if (c->type != SYBL_INT_VAL && !str_group) return false;
+            uint32_t r2 = sd.flags & (kSlotFilter | kSlotGroup | kSlotAgg | kSlotTime);
+            bool str_ok = c->type == SYBL_STR_VAL && (r2 == kSlotGroup || r2 == kSlotIdMask || r2 == (kSlotGroup | kSlotIdMask));
+            if (c->type != SYBL_INT_VAL && !str_ok) return false;
             *gen = true;
         }
         uint32_t roles = sd.flags & (kSlotFilter | kSlotGroup | kSlotAgg);
-        if (sd.flags & (kSlotNeq | kSlotIdMask | kSlotSet | kSlotDict)) return false;
+        if (sd.flags & (kSlotNeq | kSlotSet | kSlotDict)) return false;
+        if ((sd.flags & kSlotIdMask) && !allow_gen) return false;
         if ((sd.flags & kSlotWeight) && (roles != 0 || (sd.flags & kSlotTime) || !allow_gen)) return false;
-        if (roles != kSlotRange && roles != kSlotGroup && roles != kSlotAgg && roles != 0) return false;  // one role per column
-        if ((sd.flags & kSlotTime) && roles != 0) return false;  // the time column plays no second role here
+        // a column may be filtered AND be a key / an aggregation input / the time column (it is then
+        // streamed once per role; the second read hits L1/L2), but not key and aggregation input at once
+        uint32_t fpart = roles & kSlotFilter, rest = roles & (kSlotGroup | kSlotAgg);
+        if (fpart != 0 && fpart != kSlotRange && fpart != kSlotIdMask) return false;
+        if (rest == (kSlotGroup | kSlotAgg)) return false;
+        if ((sd.flags & kSlotTime) && rest != 0) return false;
     }
     for (size_t s = 0; s < slot_col.size(); s++) {
         const SlotDesc &sd = P.slot[s];
-        if (!(sd.flags & kSlotRange)) continue;
+        if (!(sd.flags & (kSlotRange | kSlotIdMask))) continue;
         if (nf >= kFastMaxF) return false;
         FP.fcol[nf] = (const int64_t *)sd.base;
         FP.fvalid[nf] = sd.valid;
         FP.lo[nf] = sd.lo;
         FP.hi[nf] = sd.hi;
+        if (sd.flags & kSlotIdMask) {
+            FP.fmask[nf] = sd.idmask;
+            FP.fmask_bits[nf] = sd.idmask_bits;
+            FP.fw32[nf] = (sd.flags & kSlotW32) ? 1 : 0;
+            *gen = true;
+        }
         nf++;
     }
     for (auto &gi : q->groups) {

@@ -55,6 +55,9 @@ struct FastPlan {
     // missing-key cells, and the reject gate / per-aggregation counts of hist_basic.go:104
     const uint32_t *fvalid[kFastMaxF], *gvalid[kFastMaxG], *avalid[kFastMaxA], *tvalid;
     int32_t gw32[kFastMaxG], gmissing[kFastMaxG], gvalues[kFastMaxG];
+    // str filters (filter.go:199-250) as one bit per dictionary id: fmask != nullptr replaces the range
+    const uint32_t *fmask[kFastMaxF];
+    int32_t fmask_bits[kFastMaxF], fw32[kFastMaxF];
     int32_t f_cnt[kFastMaxA], f_pop[kFastMaxA], f_smp[kFastMaxA], f_out[kFastMaxA];
     int64_t info_min[kFastMaxA], max10[kFastMaxA];
     const int64_t *wcol;           // weight column (OPTS.WEIGHT_COL, aggregate.go:100-102), fully populated
@@ -138,7 +141,13 @@ __device__ __forceinline__ void fast_load(const FastPlan &P, int64_t row, FastTi
     }
 #pragma unroll
     for (int c = 0; c < NF; c++) {
-        f.v[c] = __builtin_nontemporal_load((const fll2 *)(P.fcol[c] + row));
+        if (GEN && P.fw32[c]) {  // str column: int32 dictionary ids
+            const fi32x2 w = __builtin_nontemporal_load((const fi32x2 *)((const int32_t *)P.fcol[c] + row));
+            f.v[c].x = w.x;
+            f.v[c].y = w.y;
+        } else {
+            f.v[c] = __builtin_nontemporal_load((const fll2 *)(P.fcol[c] + row));
+        }
         if (GEN) f.pop[c] = fast_pop(P.fvalid[c], row);
     }
 #pragma unroll
@@ -173,8 +182,15 @@ __device__ __forceinline__ void fast_row(const FastPlan &P, const FastTile<NF> &
 #pragma unroll
     for (int c = 0; c < NF; c++) {
         const int64_t x = r == 0 ? f.v[c].x : f.v[c].y;
-        pass = pass && x >= P.lo[c] && x <= P.hi[c];  // filter.go:171-195, folded to a range
-        if (GEN) pass = pass && ((f.pop[c] >> r) & 1u);  // an unpopulated value fails every int filter
+        if (GEN && P.fmask[c]) {
+            // StrFilter eq / neq / re / nre, evaluated per dictionary id on the host (filter.go:199-250)
+            bool ok = false;
+            if ((uint64_t)x < (uint64_t)P.fmask_bits[c]) ok = (P.fmask[c][x >> 5] >> (x & 31)) & 1u;
+            pass = pass && ok;
+        } else {
+            pass = pass && x >= P.lo[c] && x <= P.hi[c];  // filter.go:171-195, folded to a range
+        }
+        if (GEN) pass = pass && ((f.pop[c] >> r) & 1u);  // an unpopulated value fails every filter
     }
     if (!pass) return;
     matched += 1;  // aggregate.go:117

@@ -611,6 +611,8 @@ def test_weighted_and_nullable_take_the_fast_kernels(ctx, oracle):
               dict(groups=["s"], aggs=["v2"], op="hist", want_percentiles=False, weight_col="w"),
               dict(filters=[("f", "lt", 500)], groups=["g"], aggs=["v2"], op="hist", want_percentiles=False),
               dict(groups=["s", "g"], aggs=["v"], op="avg"),
+              dict(filters=[("s", "neq", "k3"), ("f", "gt", 50)], groups=["g"], aggs=["v"], op="avg"),      # str filter as id mask
+              dict(filters=[("s", "re", "k[0-2]")], groups=["s"], aggs=["v2"], op="hist", want_percentiles=False),
               # IntInfo [100, 40000] vs data [0, 50000): rejects below, h.Max above, outliers beyond the last bucket
               dict(groups=["s"], aggs=["v"], op="hist", want_percentiles=False),
               dict(groups=["g"], aggs=["v"], op="hist", want_percentiles=True)):
@@ -618,6 +620,10 @@ def test_weighted_and_nullable_take_the_fast_kernels(ctx, oracle):
         assert query.stats()["strategy"] == (6 if q.get("want_percentiles", False) else 2), q
         gres = query.run()
         okw = parity.oracle_query_kwargs(names, info, q)
+        import re as _re
+        okw["filters"] = [(f[0], f[1], strings.index(f[2])) if f[1] in ("eq", "neq") and isinstance(f[2], str) else
+                          ((f[0], f[1], 0, np.array([bool(_re.search(f[2], x)) for x in strings], dtype=np.uint8))
+                           if f[1] in ("re", "nre") else f) for f in okw["filters"]]
         ores = oracle.run_query(ocols, block_rows=7000, **okw)
         # str group ids are engine-private but here the block dictionary order == id order
         parity.compare(gres, ores, op=q["op"], full=q.get("want_percentiles", False), n_aggs=1)
