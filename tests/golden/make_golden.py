@@ -13,8 +13,15 @@ import json
 import os
 import sys
 
-REF = "/root/reference/src/lib/testdata/TestDecodeGoldenFiles/node_results.golden.json"
-OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "node_results_hists.json")
+REFDIR = "/root/reference/src/lib/testdata/TestDecodeGoldenFiles"
+REF = REFDIR + "/node_results.golden.json"
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(HERE, "node_results_hists.json")
+# the reference's second golden (decoding_test.go:26): a gob-encoded FlagDefs.  Kept as a hex dump of
+# the stream (the byte-exact pin of tests/gobfmt.py and csrc/gob.cpp) and as the expected decoded
+# value (the fields Go re-marshals as non-null).
+FLAGS_HEX = os.path.join(HERE, "flagdefs_stream.hex")
+FLAGS_EXPECT = os.path.join(HERE, "flagdefs_expected.json")
 
 
 def hist(h):
@@ -41,6 +48,11 @@ def main():
            "SortedKeys": [r["GroupByKey"] for r in qs["Sorted"]]}
     json.dump(out, open(OUT, "w"), separators=(",", ":"), sort_keys=True)
     print("wrote", OUT, os.path.getsize(OUT), "bytes")
+    raw = open(REFDIR + "/flag_defs.golden.gob", "rb").read()
+    open(FLAGS_HEX, "w").write("\n".join(raw[i:i + 32].hex() for i in range(0, len(raw), 32)) + "\n")
+    want = json.load(open(REFDIR + "/flag_defs.golden.json"))
+    json.dump({k: v for k, v in want.items() if v is not None}, open(FLAGS_EXPECT, "w"), indent=1, sort_keys=True)
+    print("wrote", FLAGS_HEX, "and", FLAGS_EXPECT)
 
 
 if __name__ == "__main__":

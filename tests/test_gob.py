@@ -1,7 +1,7 @@
 """Pins the Python gob encoder/decoder (tests/gobfmt.py) and, through it, the fixtures the
-native loader is tested with, against the reference's golden gob file
-(src/lib/testdata/TestDecodeGoldenFiles/flag_defs.golden.gob, decoding_test.go:20-74; copied
-verbatim to tests/golden/ -- it is test data, 941 bytes)."""
+native loader is tested with, against the reference's golden gob stream
+(src/lib/testdata/TestDecodeGoldenFiles/flag_defs.golden.gob, decoding_test.go:20-74): a hex dump
+of the 941-byte stream and the expected decoded value, written by tests/golden/make_golden.py."""
 import json
 import os
 
@@ -10,19 +10,26 @@ from tests import gobfmt as G
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 
+def _golden_stream():
+    return bytes.fromhex("".join(open(os.path.join(GOLD, "flagdefs_stream.hex")).read().split()))
+
+
+def _golden_expected():
+    return json.load(open(os.path.join(GOLD, "flagdefs_expected.json")))
+
+
 def test_decode_golden_flag_defs_matches_golden_json():
-    data = open(os.path.join(GOLD, "flag_defs.golden.gob"), "rb").read()
+    data = _golden_stream()
     v, order = G.decode(data, want_types=True)
-    want = json.load(open(os.path.join(GOLD, "flag_defs.golden.json")))
     assert order == [(65, "struct", "FlagDefs")]
-    # Go re-marshals nil pointers as null; gob omitted them
-    assert v == {k: x for k, x in want.items() if x is not None}
+    # Go re-marshals nil pointers as null (dropped from the expectation); gob omitted them
+    assert v == _golden_expected()
 
 
 def test_reencode_golden_flag_defs_byte_exact():
     """Decode the golden stream, rebuild the struct type from its own type definition, encode it
     with our Encoder: the bytes must equal Go's (PrintBytes appends '\\n', printer.go:272-282)."""
-    data = open(os.path.join(GOLD, "flag_defs.golden.gob"), "rb").read()
+    data = _golden_stream()
     v = G.decode(data)
     # recover the field list (name, type id) from the definition message
     h = G.Reader(data)
@@ -70,10 +77,10 @@ def _cxx_json(path):
     return json.loads(s)
 
 
-def test_cxx_reader_on_golden_flag_defs():
-    got = _cxx_json(os.path.join(GOLD, "flag_defs.golden.gob"))
-    want = json.load(open(os.path.join(GOLD, "flag_defs.golden.json")))
-    assert got == {k: x for k, x in want.items() if x is not None}
+def test_cxx_reader_on_golden_flag_defs(tmp_path):
+    p = tmp_path / "flagdefs.gob"
+    p.write_bytes(_golden_stream())
+    assert _cxx_json(str(p)) == _golden_expected()
 
 
 def test_cxx_reader_on_fixture_column_files(tmp_path):
