@@ -395,37 +395,27 @@ static int select_part_hist(Table *t, Query *q, const std::vector<int> &slot_col
     return SYBL_OK;
 }
 
-static int plan_query(Table *t, const sybl_query_desc *d, Query *q) {
-    Ctx *ctx = t->ctx;
-    if (d->n_groups > SYBL_MAX_GROUPS) return fail(SYBL_E_INVAL, "too many group columns (%d > %d)", d->n_groups, SYBL_MAX_GROUPS);
-    if (d->n_aggs > SYBL_MAX_AGGS) return fail(SYBL_E_INVAL, "too many aggregations (%d > %d)", d->n_aggs, SYBL_MAX_AGGS);
-    if (d->n_filters > SYBL_MAX_FILTERS) return fail(SYBL_E_INVAL, "too many filters");
-    if (d->op != SYBL_AGG_AVG && d->op != SYBL_AGG_HIST) return fail(SYBL_E_INVAL, "unknown op %d", d->op);
-    int rc = table_ensure_stats(t);
-    if (rc) return rc;
+// The planner: sybl_query_desc + table statistics -> ScanPlan (+ FastPlan / EmitPlan), work list and
+// device buffers.  One method per step, in the order the reference builds a query
+// (cmd_query.go:204-333: filters, groupings, aggregations, time / weight options).
+struct Planner {
+    Table *t;
+    const sybl_query_desc *d;
+    Query *q;
+    Ctx *ctx;
+    ScanPlan &P;
+    std::vector<int> slot_col;          // table column index per slot
+    std::vector<HostFilterFold> folds;  // per slot
+    int64_t cells = 1;                  // group cells (product of key digits)
+    int64_t n_cells = 1;                // cells x time buckets
+    int F = 1, M = 0;                   // SUM / MAX fields per cell
+    int64_t hist_stride = 0;            // bucket-array words per cell
+    int64_t rows_scanned = 0, skipped = 0;
 
-    q->op = d->op;
-    q->hist_bucket = d->hist_bucket;
-    q->want_percentiles = d->op == SYBL_AGG_HIST && d->want_percentiles;
-    q->order_by = d->order_by ? d->order_by : "";
-    q->order_asc = d->order_asc != 0;
-    q->limit = d->limit;
-    q->time_mode = d->time_bucket > 0 && d->time_col && d->time_col[0];
-    q->time_bucket = q->time_mode ? d->time_bucket : 0;
-    q->weighted = d->weight_col && d->weight_col[0];
+    Planner(Table *t_, const sybl_query_desc *d_, Query *q_) : t(t_), d(d_), q(q_), ctx(t_->ctx), P(q_->plan) {}
 
-    ScanPlan &P = q->plan;
-    memset(&P, 0, sizeof(P));
-    P.time_slot = -1;
-    P.weight_slot = -1;
-    P.f_samples = -1;
-    P.hist_mode = d->op == SYBL_AGG_HIST;
-    P.weighted = q->weighted;
-
-    // ---- slots: one per distinct referenced column
-    std::vector<int> slot_col;  // table column index per slot
-    std::vector<HostFilterFold> folds;
-    auto slot_of = [&](const char *name, int *out) -> int {
+    // one slot per distinct referenced column
+    int slot_of(const char *name, int *out) {
         Column *c = t->find(name);
         if (!c) return fail(SYBL_E_INVAL, "unknown column '%s'", name ? name : "(null)");
         int ci = t->col_ix[name];
@@ -439,524 +429,611 @@ static int plan_query(Table *t, const sybl_query_desc *d, Query *q) {
         folds.emplace_back();
         *out = (int)slot_col.size() - 1;
         return SYBL_OK;
-    };
+    }
 
-    // ---- filters (filter.go:171-285), folded per column
-    for (int i = 0; i < d->n_filters; i++) {
-        const sybl_filter &f = d->filters[i];
-        int s;
-        if ((rc = slot_of(f.col, &s))) return rc;
-        Column *c = t->cols[(size_t)slot_col[(size_t)s]].get();
-        HostFilterFold &ff = folds[(size_t)s];
-        if (c->type == SYBL_INT_VAL) {
-            int64_t v = f.int_value;
-            switch (f.op) {
-            case SYBL_OP_GT:  // field > v
-                ff.has_range = true;
-                if (v == INT64_MAX) q->never_matches = true; else ff.lo = std::max(ff.lo, v + 1);
-                break;
-            case SYBL_OP_LT:
-                ff.has_range = true;
-                if (v == INT64_MIN) q->never_matches = true; else ff.hi = std::min(ff.hi, v - 1);
-                break;
-            case SYBL_OP_EQ:
-                ff.has_range = true;
-                ff.lo = std::max(ff.lo, v);
-                ff.hi = std::min(ff.hi, v);
-                break;
-            case SYBL_OP_NEQ:
-                if ((int)ff.neq.size() >= kMaxNeq) return fail(SYBL_E_INVAL, "more than %d neq filters on '%s'", kMaxNeq, f.col);
-                ff.neq.push_back(v);
-                break;
-            default:
-                // IntFilter.Filter's default branch returns false for every row (filter.go:189-193)
-                q->never_matches = true;
-                ff.has_range = true;
-            }
-        } else if (c->type == SYBL_STR_VAL) {
-            // eq/neq compare dictionary ids, re/nre go through a per-id match table
-            // (the reference's RCache, filter.go:213-236); all become one bit per id.
-            size_t n = c->dict.size();
-            std::vector<uint8_t> m(n, 0);
-            if (f.op == SYBL_OP_EQ || f.op == SYBL_OP_NEQ) {
-                auto it = c->dict_ix.find(f.str_value ? f.str_value : "");
-                for (size_t k = 0; k < n; k++) m[k] = f.op == SYBL_OP_NEQ;
-                if (it != c->dict_ix.end()) m[(size_t)it->second] = f.op == SYBL_OP_EQ;
-            } else if (f.op == SYBL_OP_RE || f.op == SYBL_OP_NRE) {
-                if (f.id_match) {
-                    for (size_t k = 0; k < n; k++) {
-                        bool hit = (int64_t)k < f.id_match_len && f.id_match[k];
-                        m[k] = f.op == SYBL_OP_NRE ? !hit : hit;
-                    }
-                } else {
-                    try {
-                        std::regex re(f.str_value ? f.str_value : "", std::regex::ECMAScript);
+    int setup() {
+        int rc;
+        if (d->n_groups > SYBL_MAX_GROUPS) return fail(SYBL_E_INVAL, "too many group columns (%d > %d)", d->n_groups, SYBL_MAX_GROUPS);
+        if (d->n_aggs > SYBL_MAX_AGGS) return fail(SYBL_E_INVAL, "too many aggregations (%d > %d)", d->n_aggs, SYBL_MAX_AGGS);
+        if (d->n_filters > SYBL_MAX_FILTERS) return fail(SYBL_E_INVAL, "too many filters");
+        if (d->op != SYBL_AGG_AVG && d->op != SYBL_AGG_HIST) return fail(SYBL_E_INVAL, "unknown op %d", d->op);
+        rc = table_ensure_stats(t);
+        if (rc) return rc;
+
+        q->op = d->op;
+        q->hist_bucket = d->hist_bucket;
+        q->want_percentiles = d->op == SYBL_AGG_HIST && d->want_percentiles;
+        q->order_by = d->order_by ? d->order_by : "";
+        q->order_asc = d->order_asc != 0;
+        q->limit = d->limit;
+        q->time_mode = d->time_bucket > 0 && d->time_col && d->time_col[0];
+        q->time_bucket = q->time_mode ? d->time_bucket : 0;
+        q->weighted = d->weight_col && d->weight_col[0];
+
+        memset(&P, 0, sizeof(P));
+        P.time_slot = -1;
+        P.weight_slot = -1;
+        P.f_samples = -1;
+        P.hist_mode = d->op == SYBL_AGG_HIST;
+        P.weighted = q->weighted;
+
+        return SYBL_OK;
+    }
+
+    int filters() {
+        int rc;
+        // ---- filters (filter.go:171-285), folded per column
+        for (int i = 0; i < d->n_filters; i++) {
+            const sybl_filter &f = d->filters[i];
+            int s;
+            if ((rc = slot_of(f.col, &s))) return rc;
+            Column *c = t->cols[(size_t)slot_col[(size_t)s]].get();
+            HostFilterFold &ff = folds[(size_t)s];
+            if (c->type == SYBL_INT_VAL) {
+                int64_t v = f.int_value;
+                switch (f.op) {
+                case SYBL_OP_GT:  // field > v
+                    ff.has_range = true;
+                    if (v == INT64_MAX) q->never_matches = true; else ff.lo = std::max(ff.lo, v + 1);
+                    break;
+                case SYBL_OP_LT:
+                    ff.has_range = true;
+                    if (v == INT64_MIN) q->never_matches = true; else ff.hi = std::min(ff.hi, v - 1);
+                    break;
+                case SYBL_OP_EQ:
+                    ff.has_range = true;
+                    ff.lo = std::max(ff.lo, v);
+                    ff.hi = std::min(ff.hi, v);
+                    break;
+                case SYBL_OP_NEQ:
+                    if ((int)ff.neq.size() >= kMaxNeq) return fail(SYBL_E_INVAL, "more than %d neq filters on '%s'", kMaxNeq, f.col);
+                    ff.neq.push_back(v);
+                    break;
+                default:
+                    // IntFilter.Filter's default branch returns false for every row (filter.go:189-193)
+                    q->never_matches = true;
+                    ff.has_range = true;
+                }
+            } else if (c->type == SYBL_STR_VAL) {
+                // eq/neq compare dictionary ids, re/nre go through a per-id match table
+                // (the reference's RCache, filter.go:213-236); all become one bit per id.
+                size_t n = c->dict.size();
+                std::vector<uint8_t> m(n, 0);
+                if (f.op == SYBL_OP_EQ || f.op == SYBL_OP_NEQ) {
+                    auto it = c->dict_ix.find(f.str_value ? f.str_value : "");
+                    for (size_t k = 0; k < n; k++) m[k] = f.op == SYBL_OP_NEQ;
+                    if (it != c->dict_ix.end()) m[(size_t)it->second] = f.op == SYBL_OP_EQ;
+                } else if (f.op == SYBL_OP_RE || f.op == SYBL_OP_NRE) {
+                    if (f.id_match) {
                         for (size_t k = 0; k < n; k++) {
-                            bool hit = std::regex_search(c->dict[k], re);
+                            bool hit = (int64_t)k < f.id_match_len && f.id_match[k];
                             m[k] = f.op == SYBL_OP_NRE ? !hit : hit;
                         }
-                    } catch (const std::regex_error &e) {
-                        return fail(SYBL_E_INVAL, "bad regex '%s': %s", f.str_value ? f.str_value : "", e.what());
+                    } else {
+                        try {
+                            std::regex re(f.str_value ? f.str_value : "", std::regex::ECMAScript);
+                            for (size_t k = 0; k < n; k++) {
+                                bool hit = std::regex_search(c->dict[k], re);
+                                m[k] = f.op == SYBL_OP_NRE ? !hit : hit;
+                            }
+                        } catch (const std::regex_error &e) {
+                            return fail(SYBL_E_INVAL, "bad regex '%s': %s", f.str_value ? f.str_value : "", e.what());
+                        }
                     }
+                } else {
+                    q->never_matches = true;  // StrFilter default branch: ret stays false
+                }
+                if (!ff.has_mask) {
+                    ff.mask = m;
+                    ff.has_mask = true;
+                } else {
+                    for (size_t k = 0; k < n; k++) ff.mask[k] = ff.mask[k] && m[k];
                 }
             } else {
-                q->never_matches = true;  // StrFilter default branch: ret stays false
+                // SetFilter.Filter, filter.go:252-285; get_val_id of an unseen string yields an id no
+                // member can have (table_column.go:27-48)
+                if (f.op != SYBL_OP_IN && f.op != SYBL_OP_NIN) {
+                    q->never_matches = true;  // default branch: ret stays false
+                    ff.setp.emplace_back(-1, 1);
+                    continue;
+                }
+                if ((int)ff.setp.size() >= kMaxNeq) return fail(SYBL_E_INVAL, "more than %d set filters on '%s'", kMaxNeq, f.col);
+                auto it = c->dict_ix.find(f.str_value ? f.str_value : "");
+                ff.setp.emplace_back(it == c->dict_ix.end() ? -1 : it->second, f.op == SYBL_OP_IN ? 1 : 0);
             }
-            if (!ff.has_mask) {
-                ff.mask = m;
-                ff.has_mask = true;
+        }
+        return SYBL_OK;
+    }
+
+    int groups() {
+        int rc;
+        // ---- group columns (aggregate.go:125-143); direct-mapped on declared or exact bounds
+        cells = 1;
+        for (int g = 0; g < d->n_groups; g++) {
+            int s;
+            if ((rc = slot_of(d->groups[g], &s))) return rc;
+            Column *c = t->cols[(size_t)slot_col[(size_t)s]].get();
+            if (c->type == SYBL_SET_VAL) return fail(SYBL_E_INVAL, "cannot group by set column '%s' (cmd_query.go:254)", c->name.c_str());
+            if (P.slot[s].flags & kSlotGroup) return fail(SYBL_E_INVAL, "column '%s' grouped twice", c->name.c_str());
+            GroupInfo gi;
+            gi.col = slot_col[(size_t)s];
+            gi.type = c->type;
+            gi.has_missing = c->has_missing;
+            int64_t lo, hi;
+            if (c->bounds_set) {
+                lo = c->bound_lo;
+                hi = c->bound_hi;
+            } else if (c->type == SYBL_STR_VAL) {
+                lo = 0;
+                hi = (int64_t)c->dict.size() - 1;
             } else {
-                for (size_t k = 0; k < n; k++) ff.mask[k] = ff.mask[k] && m[k];
+                lo = c->exact_min;
+                hi = c->exact_max;
             }
-        } else {
-            // SetFilter.Filter, filter.go:252-285; get_val_id of an unseen string yields an id no
-            // member can have (table_column.go:27-48)
-            if (f.op != SYBL_OP_IN && f.op != SYBL_OP_NIN) {
-                q->never_matches = true;  // default branch: ret stays false
-                ff.setp.emplace_back(-1, 1);
+            if (c->n_pop == 0 && !c->bounds_set) {
+                lo = 0;
+                hi = -1;
+            }
+            unsigned __int128 card = hi >= lo ? (unsigned __int128)((__int128)hi - (__int128)lo) + 1 : 0;
+            // A missing key is written as MISSING_VALUE = 0xFFFFFFFFFFFFFFFF (aggregate.go:31,138), which
+            // is also the 8-byte image of the int value -1: the reference folds both into ONE group.
+            // When -1 is inside the key range the missing rows share its cell; otherwise they get an
+            // extra digit of their own.
+            gi.missing_digit = -1;
+            gi.dict = false;
+            // sparse / wide key range: one digit per DISTINCT value instead of one per value of the range
+            if (c->type == SYBL_INT_VAL && !getenv("SYBL_NO_GDICT") &&
+                (c->gdict_blocks == -2 || card > ((unsigned __int128)1 << 22) || card * (unsigned __int128)cells > ((unsigned __int128)1 << 27))) {
+                if ((rc = column_build_gdict(t, c))) return rc;
+                gi.dict = true;
+                card = c->gdict.size();
+            }
+            gi.value_card = (int32_t)card;
+            if (gi.has_missing) {
+                int64_t minus1 = -1;
+                if (gi.dict) {
+                    auto it = std::lower_bound(c->gdict.begin(), c->gdict.end(), (int64_t)-1);
+                    minus1 = it != c->gdict.end() && *it == -1 ? (int64_t)(it - c->gdict.begin()) : -1;
+                } else if (c->type == SYBL_INT_VAL && hi >= lo && lo <= -1 && hi >= -1) {
+                    minus1 = -1 - lo;
+                }
+                if (minus1 >= 0) {
+                    gi.missing_digit = (int32_t)minus1;
+                } else {
+                    gi.missing_digit = (int32_t)card;
+                    card += 1;
+                }
+            }
+            if (card == 0) card = 1;
+            if (card * (unsigned __int128)cells > ((unsigned __int128)1 << 27))
+                return fail(SYBL_E_INVAL,
+                            "group-by on '%s' needs more than 2^27 direct-mapped cells (value range [%lld,%lld]); "
+                            "hash group-by is not available in this build",
+                            c->name.c_str(), (long long)lo, (long long)hi);
+            gi.gmin = lo;
+            gi.gcard = (int32_t)card;
+            q->groups.push_back(gi);
+            cells *= (int64_t)card;
+        }
+        // strides: first group column is the most significant digit (keeps canonical key order
+        // equal to cell order)
+        {
+            int64_t stride = cells;
+            for (size_t g = 0; g < q->groups.size(); g++) {
+                stride /= q->groups[g].gcard;
+                int s = -1;
+                for (size_t k = 0; k < slot_col.size(); k++)
+                    if (slot_col[k] == q->groups[g].col) s = (int)k;
+                SlotDesc &sd = P.slot[s];
+                sd.flags |= kSlotGroup;
+                sd.gmin = q->groups[g].gmin;
+                sd.gcard = q->groups[g].gcard;
+                sd.gstride = (int32_t)stride;
+                sd.gmissing = q->groups[g].missing_digit >= 0 ? (int32_t)(q->groups[g].missing_digit * stride) : -1;
+                sd.gvalues = q->groups[g].value_card;
+                if (q->groups[g].dict) {
+                    const Column *gc = t->cols[(size_t)q->groups[g].col].get();
+                    sd.flags |= kSlotDict;
+                    sd.dkeys = gc->d_gdict_keys;
+                    sd.dranks = gc->d_gdict_ranks;
+                    sd.dmask = gc->gdict_mask;
+                }
+            }
+        }
+        q->group_cells = cells;
+        return SYBL_OK;
+    }
+
+    int time_series() {
+        int rc;
+        // ---- time series (aggregate.go:146-183)
+        P.n_tb = 1;
+        P.tb_stride = (int32_t)cells;
+        if (q->time_mode) {
+            int s;
+            if ((rc = slot_of(d->time_col, &s))) return rc;
+            Column *c = t->cols[(size_t)slot_col[(size_t)s]].get();
+            if (c->type != SYBL_INT_VAL) return fail(SYBL_E_INVAL, "time column '%s' is not an int column", c->name.c_str());
+            P.slot[s].flags |= kSlotTime;
+            P.time_slot = s;
+            P.time_bucket = d->time_bucket;
+            P.inv_time_bucket = 1.0 / (double)d->time_bucket;
+            int64_t lo = c->bounds_set ? c->bound_lo : c->exact_min, hi = c->bounds_set ? c->bound_hi : c->exact_max;
+            if (c->n_pop == 0 && !c->bounds_set) lo = hi = 0;
+            int64_t tlo = lo / d->time_bucket, thi = hi / d->time_bucket;  // truncating, like aggregate.go:174
+            P.tb_min = tlo;
+            int64_t ntb = thi - tlo + 1;
+            if (ntb * cells > ((int64_t)1 << 27)) return fail(SYBL_E_INVAL, "time buckets x groups exceeds 2^27 cells");
+            P.n_tb = (int32_t)ntb;
+            uint64_t amax = (uint64_t)std::max(llabs((long long)lo), llabs((long long)hi));
+            P.tb_big_div = amax >= ((uint64_t)1 << 51);
+        }
+        n_cells = cells * P.n_tb;
+        P.n_cells = (int32_t)n_cells;
+        return SYBL_OK;
+    }
+
+    int weight() {
+        int rc;
+        // ---- weight column (aggregate.go:100-102)
+        if (q->weighted) {
+            int s;
+            if ((rc = slot_of(d->weight_col, &s))) return rc;
+            Column *c = t->cols[(size_t)slot_col[(size_t)s]].get();
+            if (c->type != SYBL_INT_VAL) return fail(SYBL_E_INVAL, "weight column '%s' is not an int column", c->name.c_str());
+            if (c->has_missing)
+                return fail(SYBL_E_INVAL, "weight column '%s' has missing rows (the reference's carry-over of the previous "
+                            "row's weight, aggregate.go:68, is not reproduced)", c->name.c_str());
+            P.slot[s].flags |= kSlotWeight;
+            P.weight_slot = s;
+        }
+        return SYBL_OK;
+    }
+
+    int aggregations() {
+        int rc;
+        // ---- aggregations (aggregate.go:246-261, hist_basic.go:72-151)
+        F = 1;  // field 0: Result.Count
+        if (q->weighted) P.f_samples = F++;
+        M = 0;
+        hist_stride = 0;
+        for (int a = 0; a < d->n_aggs; a++) {
+            int s;
+            if ((rc = slot_of(d->aggs[a], &s))) return rc;
+            Column *c = t->cols[(size_t)slot_col[(size_t)s]].get();
+            if (c->type != SYBL_INT_VAL) {
+                // the reference silently ignores non-int aggregation columns (aggregate.go:247-248)
+                return fail(SYBL_E_INVAL, "aggregation column '%s' is not an int column", c->name.c_str());
+            }
+            if (P.slot[s].flags & kSlotAgg) return fail(SYBL_E_INVAL, "column '%s' aggregated twice", c->name.c_str());
+            AggInfo ai;
+            ai.col = slot_col[(size_t)s];
+            ai.name = c->name;
+            memset(&ai.d, 0, sizeof(ai.d));
+            AggDesc &A = ai.d;
+            int64_t lo = c->bounds_set ? c->bound_lo : c->exact_min, hi = c->bounds_set ? c->bound_hi : c->exact_max;
+            bool empty = c->n_pop == 0 && !c->bounds_set;
+            int64_t imin = c->info_given ? c->info_min : (empty ? 0 : lo);
+            int64_t imax = c->info_given ? c->info_max : (empty ? 0 : hi);
+            A.info_min = imin;
+            A.max10 = (int64_t)((uint64_t)imax * 10u);  // Go's wrapping int64 multiply (hist_basic.go:104)
+            A.f_sum = F++;
+            bool can_reject = c->has_missing || (!empty && (lo < A.info_min || hi > A.max10));
+            A.f_cnt = (q->weighted || can_reject) ? F++ : -1;
+            A.f_smp = q->weighted ? F++ : -1;
+            A.f_pop = c->has_missing ? F++ : -1;
+            A.f_sb = A.f_sb2 = A.f_out = -1;
+            // BasicHist.Min/Max start at Info.Min/Info.Max in hist mode and at 0 in avg mode
+            // (hist_basic.go:34-40,72-85) and accepted values are >= Info.Min, so the running
+            // extrema only need tracking when the column bounds let a value beat the start value.
+            {
+                bool need_max = d->op == SYBL_AGG_HIST ? (empty ? false : hi > imax) : (empty ? false : hi > 0);
+                bool need_min = d->op == SYBL_AGG_HIST ? false : (empty ? false : lo < 0);
+                if (c->bounds_set == false && empty) need_max = need_min = false;
+                A.m_max = need_max ? M++ : -1;
+                A.m_nmin = need_min ? M++ : -1;
+            }
+            ai.f_out = -1;
+            ai.num_buckets = 0;
+            ai.info_max = imax;
+            if (d->op == SYBL_AGG_HIST) {
+                if (imax < imin) return fail(SYBL_E_INVAL, "IntInfo of '%s' has max < min", c->name.c_str());
+                int64_t bs, nb, nv;
+                setup_buckets(imin, imax, d->hist_bucket, &bs, &nb, &nv);
+                if (bs <= 0 || nv <= 0 || nv > (1 << 20)) return fail(SYBL_E_INVAL, "bad bucket geometry for '%s'", c->name.c_str());
+                A.hmin = imin;
+                A.bucket_size = bs;
+                A.inv_bucket = 1.0 / (double)bs;
+                A.n_values = (int32_t)nv;
+                ai.num_buckets = nb;
+                // accepted values lie in [max(lo,imin), min(hi,max10)]
+                int64_t vhi = empty ? imin : std::min(hi, A.max10), vlo = empty ? imin : std::max(lo, imin);
+                unsigned __int128 span = vhi >= A.hmin ? (unsigned __int128)((__int128)vhi - (__int128)A.hmin) : 0;
+                A.big_div = span >= ((unsigned __int128)1 << 51);
+                bool can_outlie = span / (unsigned __int128)bs >= (unsigned __int128)nv || vlo < A.hmin;
+                if (can_outlie) {
+                    A.f_out = F;
+                    ai.f_out = F;
+                    F += 6;
+                }
+                if (q->want_percentiles) {
+                    A.hist_full = 1;
+                    P.hist_agg_off[a] = hist_stride;
+                    hist_stride += nv;
+                } else {
+                    A.f_sb = F++;
+                    A.f_sb2 = F++;
+                }
+            }
+            P.slot[s].flags |= kSlotAgg;
+            P.slot[s].agg_index = a;
+            P.agg[a] = A;
+            q->aggs.push_back(ai);
+        }
+        P.n_aggs = d->n_aggs;
+        P.n_sum_fields = F;
+        P.n_max_fields = M;
+        P.hist_stride = hist_stride;
+        P.hist_off = kHeaderWords + (int64_t)F * n_cells;
+        if ((unsigned __int128)n_cells * (unsigned __int128)hist_stride > ((unsigned __int128)1 << 31))
+            return fail(SYBL_E_INVAL, "groups x buckets = %lld x %lld words does not fit the 16 GiB histogram budget",
+                        (long long)n_cells, (long long)hist_stride);
+        return SYBL_OK;
+    }
+
+    int finish_slots() {
+        int rc;
+        // ---- finish slots
+        if (slot_col.empty()) {
+            // count(*) with no referenced column still needs the row count: stream any column
+            if (t->cols.empty()) return fail(SYBL_E_INVAL, "table has no columns");
+            int pick = -1;
+            for (size_t k = 0; k < t->cols.size(); k++)
+                if (t->cols[k]->type != SYBL_SET_VAL) { pick = (int)k; break; }
+            if (pick < 0) return fail(SYBL_E_INVAL, "table has no int/str column to drive the scan");
+            slot_col.push_back(pick);
+            folds.emplace_back();
+        }
+        P.n_slots = (int)slot_col.size();
+        for (int s = 0; s < P.n_slots; s++) {
+            Column *c = t->cols[(size_t)slot_col[(size_t)s]].get();
+            SlotDesc &sd = P.slot[s];
+            sd.base = c->d_data;
+            sd.valid = c->d_valid;
+            if (c->elem == 4) sd.flags |= kSlotW32;
+            if (c->type == SYBL_SET_VAL) {
+                if ((rc = column_upload_set(t, c))) return rc;
+                sd.flags = (sd.flags & ~kSlotW32) | kSlotSet;
+                sd.base = c->d_set_off;
+                sd.set_vals = c->d_set_vals;
+                sd.n_setp = (int)folds[(size_t)s].setp.size();
+                for (int k = 0; k < sd.n_setp; k++) {
+                    sd.set_id[k] = folds[(size_t)s].setp[(size_t)k].first;
+                    sd.set_in[k] = folds[(size_t)s].setp[(size_t)k].second;
+                }
+            }
+            HostFilterFold &ff = folds[(size_t)s];
+            if (ff.has_range) {
+                sd.flags |= kSlotRange;
+                sd.lo = ff.lo;
+                sd.hi = ff.hi;
+            }
+            if (!ff.neq.empty()) {
+                sd.flags |= kSlotNeq;
+                sd.n_neq = (int)ff.neq.size();
+                for (size_t k = 0; k < ff.neq.size(); k++) sd.neq[k] = ff.neq[k];
+            }
+            if (ff.has_mask) {
+                sd.flags |= kSlotIdMask;
+                size_t nbits = ff.mask.size(), nw = (nbits + 31) / 32 + 1;
+                std::vector<uint32_t> bits(nw, 0);
+                for (size_t k = 0; k < nbits; k++)
+                    if (ff.mask[k]) bits[k >> 5] |= 1u << (k & 31);
+                uint32_t *dm = nullptr;
+                SYBL_HIP(hipMalloc((void **)&dm, nw * 4));
+                q->d_idmasks.push_back(dm);
+                SYBL_HIP(hipMemcpy(dm, bits.data(), nw * 4, hipMemcpyHostToDevice));
+                sd.idmask = dm;
+                sd.idmask_bits = (int32_t)nbits;
+            }
+        }
+        return SYBL_OK;
+    }
+
+    int strategy() {
+        // ---- strategy: cell table in LDS when it fits (DESIGN.md "Strategies")
+        q->n_wg = ctx->n_cus > 0 ? ctx->n_cus : 256;
+        if (const char *e = getenv("SYBL_WG_PER_CU")) q->n_wg *= std::max(1, atoi(e));
+        int64_t lds_words = (int64_t)(F + M) * n_cells;
+        q->use_lds = lds_words * 8 <= kLdsBudgetBytes;
+        P.rep_shift = 0;
+        if (q->use_lds) {
+            int rs = 0;
+            while (rs < 6 && (lds_words * 8 << (rs + 1)) <= kLdsBudgetBytes) rs++;
+            P.rep_shift = rs;
+            q->lds_bytes = (size_t)(lds_words * 8) << rs;
+        }
+        q->n_sum_words = kHeaderWords + (int64_t)F * n_cells + n_cells * hist_stride;
+        q->n_max_words = std::max<int64_t>((int64_t)M * n_cells, 1);
+        return SYBL_OK;
+    }
+
+    int work() {
+        // ---- work: non-skipped blocks -> runs of physical rows -> an equal share of tiles per workgroup
+        std::vector<Segment> runs;
+        rows_scanned = 0;
+        skipped = 0;
+        for (size_t b = 0; b < t->blocks.size(); b++) {
+            if (t->blocks[b].n == 0) continue;
+            if (d->block_skip && !should_scan_block(t, d, (int64_t)b)) {
+                skipped++;
                 continue;
             }
-            if ((int)ff.setp.size() >= kMaxNeq) return fail(SYBL_E_INVAL, "more than %d set filters on '%s'", kMaxNeq, f.col);
-            auto it = c->dict_ix.find(f.str_value ? f.str_value : "");
-            ff.setp.emplace_back(it == c->dict_ix.end() ? -1 : it->second, f.op == SYBL_OP_IN ? 1 : 0);
-        }
-    }
-
-    // ---- group columns (aggregate.go:125-143); direct-mapped on declared or exact bounds
-    int64_t cells = 1;
-    for (int g = 0; g < d->n_groups; g++) {
-        int s;
-        if ((rc = slot_of(d->groups[g], &s))) return rc;
-        Column *c = t->cols[(size_t)slot_col[(size_t)s]].get();
-        if (c->type == SYBL_SET_VAL) return fail(SYBL_E_INVAL, "cannot group by set column '%s' (cmd_query.go:254)", c->name.c_str());
-        if (P.slot[s].flags & kSlotGroup) return fail(SYBL_E_INVAL, "column '%s' grouped twice", c->name.c_str());
-        GroupInfo gi;
-        gi.col = slot_col[(size_t)s];
-        gi.type = c->type;
-        gi.has_missing = c->has_missing;
-        int64_t lo, hi;
-        if (c->bounds_set) {
-            lo = c->bound_lo;
-            hi = c->bound_hi;
-        } else if (c->type == SYBL_STR_VAL) {
-            lo = 0;
-            hi = (int64_t)c->dict.size() - 1;
-        } else {
-            lo = c->exact_min;
-            hi = c->exact_max;
-        }
-        if (c->n_pop == 0 && !c->bounds_set) {
-            lo = 0;
-            hi = -1;
-        }
-        unsigned __int128 card = hi >= lo ? (unsigned __int128)((__int128)hi - (__int128)lo) + 1 : 0;
-        // A missing key is written as MISSING_VALUE = 0xFFFFFFFFFFFFFFFF (aggregate.go:31,138), which
-        // is also the 8-byte image of the int value -1: the reference folds both into ONE group.
-        // When -1 is inside the key range the missing rows share its cell; otherwise they get an
-        // extra digit of their own.
-        gi.missing_digit = -1;
-        gi.dict = false;
-        // sparse / wide key range: one digit per DISTINCT value instead of one per value of the range
-        if (c->type == SYBL_INT_VAL && !getenv("SYBL_NO_GDICT") &&
-            (c->gdict_blocks == -2 || card > ((unsigned __int128)1 << 22) || card * (unsigned __int128)cells > ((unsigned __int128)1 << 27))) {
-            if ((rc = column_build_gdict(t, c))) return rc;
-            gi.dict = true;
-            card = c->gdict.size();
-        }
-        gi.value_card = (int32_t)card;
-        if (gi.has_missing) {
-            int64_t minus1 = -1;
-            if (gi.dict) {
-                auto it = std::lower_bound(c->gdict.begin(), c->gdict.end(), (int64_t)-1);
-                minus1 = it != c->gdict.end() && *it == -1 ? (int64_t)(it - c->gdict.begin()) : -1;
-            } else if (c->type == SYBL_INT_VAL && hi >= lo && lo <= -1 && hi >= -1) {
-                minus1 = -1 - lo;
-            }
-            if (minus1 >= 0) {
-                gi.missing_digit = (int32_t)minus1;
+            rows_scanned += t->blocks[b].n;
+            const Segment &blk = t->blocks[b];
+            if (!runs.empty() && runs.back().start + runs.back().n == blk.start) {
+                runs.back().n += blk.n;
             } else {
-                gi.missing_digit = (int32_t)card;
-                card += 1;
+                runs.push_back(blk);
             }
         }
-        if (card == 0) card = 1;
-        if (card * (unsigned __int128)cells > ((unsigned __int128)1 << 27))
-            return fail(SYBL_E_INVAL,
-                        "group-by on '%s' needs more than 2^27 direct-mapped cells (value range [%lld,%lld]); "
-                        "hash group-by is not available in this build",
-                        c->name.c_str(), (long long)lo, (long long)hi);
-        gi.gmin = lo;
-        gi.gcard = (int32_t)card;
-        q->groups.push_back(gi);
-        cells *= (int64_t)card;
-    }
-    // strides: first group column is the most significant digit (keeps canonical key order
-    // equal to cell order)
-    {
-        int64_t stride = cells;
-        for (size_t g = 0; g < q->groups.size(); g++) {
-            stride /= q->groups[g].gcard;
-            int s = -1;
-            for (size_t k = 0; k < slot_col.size(); k++)
-                if (slot_col[k] == q->groups[g].col) s = (int)k;
-            SlotDesc &sd = P.slot[s];
-            sd.flags |= kSlotGroup;
-            sd.gmin = q->groups[g].gmin;
-            sd.gcard = q->groups[g].gcard;
-            sd.gstride = (int32_t)stride;
-            sd.gmissing = q->groups[g].missing_digit >= 0 ? (int32_t)(q->groups[g].missing_digit * stride) : -1;
-            sd.gvalues = q->groups[g].value_card;
-            if (q->groups[g].dict) {
-                const Column *gc = t->cols[(size_t)q->groups[g].col].get();
-                sd.flags |= kSlotDict;
-                sd.dkeys = gc->d_gdict_keys;
-                sd.dranks = gc->d_gdict_ranks;
-                sd.dmask = gc->gdict_mask;
-            }
-        }
-    }
-    q->group_cells = cells;
-
-    // ---- time series (aggregate.go:146-183)
-    P.n_tb = 1;
-    P.tb_stride = (int32_t)cells;
-    if (q->time_mode) {
-        int s;
-        if ((rc = slot_of(d->time_col, &s))) return rc;
-        Column *c = t->cols[(size_t)slot_col[(size_t)s]].get();
-        if (c->type != SYBL_INT_VAL) return fail(SYBL_E_INVAL, "time column '%s' is not an int column", c->name.c_str());
-        P.slot[s].flags |= kSlotTime;
-        P.time_slot = s;
-        P.time_bucket = d->time_bucket;
-        P.inv_time_bucket = 1.0 / (double)d->time_bucket;
-        int64_t lo = c->bounds_set ? c->bound_lo : c->exact_min, hi = c->bounds_set ? c->bound_hi : c->exact_max;
-        if (c->n_pop == 0 && !c->bounds_set) lo = hi = 0;
-        int64_t tlo = lo / d->time_bucket, thi = hi / d->time_bucket;  // truncating, like aggregate.go:174
-        P.tb_min = tlo;
-        int64_t ntb = thi - tlo + 1;
-        if (ntb * cells > ((int64_t)1 << 27)) return fail(SYBL_E_INVAL, "time buckets x groups exceeds 2^27 cells");
-        P.n_tb = (int32_t)ntb;
-        uint64_t amax = (uint64_t)std::max(llabs((long long)lo), llabs((long long)hi));
-        P.tb_big_div = amax >= ((uint64_t)1 << 51);
-    }
-    int64_t n_cells = cells * P.n_tb;
-    P.n_cells = (int32_t)n_cells;
-
-    // ---- weight column (aggregate.go:100-102)
-    if (q->weighted) {
-        int s;
-        if ((rc = slot_of(d->weight_col, &s))) return rc;
-        Column *c = t->cols[(size_t)slot_col[(size_t)s]].get();
-        if (c->type != SYBL_INT_VAL) return fail(SYBL_E_INVAL, "weight column '%s' is not an int column", c->name.c_str());
-        if (c->has_missing)
-            return fail(SYBL_E_INVAL, "weight column '%s' has missing rows (the reference's carry-over of the previous "
-                        "row's weight, aggregate.go:68, is not reproduced)", c->name.c_str());
-        P.slot[s].flags |= kSlotWeight;
-        P.weight_slot = s;
-    }
-
-    // ---- aggregations (aggregate.go:246-261, hist_basic.go:72-151)
-    int F = 1;  // field 0: Result.Count
-    if (q->weighted) P.f_samples = F++;
-    int M = 0;
-    int64_t hist_stride = 0;
-    for (int a = 0; a < d->n_aggs; a++) {
-        int s;
-        if ((rc = slot_of(d->aggs[a], &s))) return rc;
-        Column *c = t->cols[(size_t)slot_col[(size_t)s]].get();
-        if (c->type != SYBL_INT_VAL) {
-            // the reference silently ignores non-int aggregation columns (aggregate.go:247-248)
-            return fail(SYBL_E_INVAL, "aggregation column '%s' is not an int column", c->name.c_str());
-        }
-        if (P.slot[s].flags & kSlotAgg) return fail(SYBL_E_INVAL, "column '%s' aggregated twice", c->name.c_str());
-        AggInfo ai;
-        ai.col = slot_col[(size_t)s];
-        ai.name = c->name;
-        memset(&ai.d, 0, sizeof(ai.d));
-        AggDesc &A = ai.d;
-        int64_t lo = c->bounds_set ? c->bound_lo : c->exact_min, hi = c->bounds_set ? c->bound_hi : c->exact_max;
-        bool empty = c->n_pop == 0 && !c->bounds_set;
-        int64_t imin = c->info_given ? c->info_min : (empty ? 0 : lo);
-        int64_t imax = c->info_given ? c->info_max : (empty ? 0 : hi);
-        A.info_min = imin;
-        A.max10 = (int64_t)((uint64_t)imax * 10u);  // Go's wrapping int64 multiply (hist_basic.go:104)
-        A.f_sum = F++;
-        bool can_reject = c->has_missing || (!empty && (lo < A.info_min || hi > A.max10));
-        A.f_cnt = (q->weighted || can_reject) ? F++ : -1;
-        A.f_smp = q->weighted ? F++ : -1;
-        A.f_pop = c->has_missing ? F++ : -1;
-        A.f_sb = A.f_sb2 = A.f_out = -1;
-        // BasicHist.Min/Max start at Info.Min/Info.Max in hist mode and at 0 in avg mode
-        // (hist_basic.go:34-40,72-85) and accepted values are >= Info.Min, so the running
-        // extrema only need tracking when the column bounds let a value beat the start value.
+        int64_t total_tiles = 0;
+        for (auto &r : runs) total_tiles += (r.n + kTileRows - 1) / kTileRows;
+        q->segs.clear();
+        q->wg_seg_begin.assign((size_t)q->n_wg + 1, 0);
         {
-            bool need_max = d->op == SYBL_AGG_HIST ? (empty ? false : hi > imax) : (empty ? false : hi > 0);
-            bool need_min = d->op == SYBL_AGG_HIST ? false : (empty ? false : lo < 0);
-            if (c->bounds_set == false && empty) need_max = need_min = false;
-            A.m_max = need_max ? M++ : -1;
-            A.m_nmin = need_min ? M++ : -1;
-        }
-        ai.f_out = -1;
-        ai.num_buckets = 0;
-        ai.info_max = imax;
-        if (d->op == SYBL_AGG_HIST) {
-            if (imax < imin) return fail(SYBL_E_INVAL, "IntInfo of '%s' has max < min", c->name.c_str());
-            int64_t bs, nb, nv;
-            setup_buckets(imin, imax, d->hist_bucket, &bs, &nb, &nv);
-            if (bs <= 0 || nv <= 0 || nv > (1 << 20)) return fail(SYBL_E_INVAL, "bad bucket geometry for '%s'", c->name.c_str());
-            A.hmin = imin;
-            A.bucket_size = bs;
-            A.inv_bucket = 1.0 / (double)bs;
-            A.n_values = (int32_t)nv;
-            ai.num_buckets = nb;
-            // accepted values lie in [max(lo,imin), min(hi,max10)]
-            int64_t vhi = empty ? imin : std::min(hi, A.max10), vlo = empty ? imin : std::max(lo, imin);
-            unsigned __int128 span = vhi >= A.hmin ? (unsigned __int128)((__int128)vhi - (__int128)A.hmin) : 0;
-            A.big_div = span >= ((unsigned __int128)1 << 51);
-            bool can_outlie = span / (unsigned __int128)bs >= (unsigned __int128)nv || vlo < A.hmin;
-            if (can_outlie) {
-                A.f_out = F;
-                ai.f_out = F;
-                F += 6;
+            size_t ri = 0;
+            int64_t tile_in_run = 0;  // tiles of runs[ri] already handed out
+            for (int w = 0; w < q->n_wg; w++) {
+                q->wg_seg_begin[(size_t)w] = (int32_t)q->segs.size();
+                int64_t want = total_tiles * (w + 1) / q->n_wg - total_tiles * w / q->n_wg;
+                while (want > 0 && ri < runs.size()) {
+                    int64_t run_tiles = (runs[ri].n + kTileRows - 1) / kTileRows;
+                    int64_t take = std::min(want, run_tiles - tile_in_run);
+                    Segment sg;
+                    sg.start = runs[ri].start + tile_in_run * kTileRows;
+                    int64_t end = std::min(runs[ri].start + runs[ri].n, sg.start + take * kTileRows);
+                    sg.n = end - sg.start;
+                    q->segs.push_back(sg);
+                    tile_in_run += take;
+                    want -= take;
+                    if (tile_in_run == run_tiles) {
+                        ri++;
+                        tile_in_run = 0;
+                    }
+                }
             }
-            if (q->want_percentiles) {
-                A.hist_full = 1;
-                P.hist_agg_off[a] = hist_stride;
-                hist_stride += nv;
+            q->wg_seg_begin[(size_t)q->n_wg] = (int32_t)q->segs.size();
+        }
+        return SYBL_OK;
+    }
+
+    int window() {
+        int rc;
+        // ---- LDS-window strategy: a time-series table too large for LDS, scanned by workgroups whose
+        // contiguous rows each span only a few time buckets (tables are digested in time order,
+        // table_io.go:119-122 sorts by Timestamp).  Exact per-block extrema of the time column give
+        // every workgroup its window.
+        P.windowed = 0;
+        P.lds_cells = (int32_t)n_cells;
+        P.wg_cell_base = nullptr;
+        if (!q->use_lds && q->time_mode && !getenv("SYBL_NO_WINDOW") && !t->blocks.empty()) {
+            const Column *tc = t->cols[(size_t)slot_col[(size_t)P.time_slot]].get();
+            std::vector<int32_t> base((size_t)q->n_wg, 0);
+            int64_t wmax = 1;
+            bool ok = true;
+            for (int w = 0; w < q->n_wg && ok; w++) {
+                int64_t lo = INT64_MAX, hi = INT64_MIN;
+                for (int32_t si = q->wg_seg_begin[(size_t)w]; si < q->wg_seg_begin[(size_t)w + 1]; si++) {
+                    const Segment &sg = q->segs[(size_t)si];
+                    // first block whose end is beyond the segment start
+                    size_t b = (size_t)(std::upper_bound(t->blocks.begin(), t->blocks.end(), sg.start,
+                                                         [](int64_t v, const Segment &blk) { return v < blk.start + blk.n; }) -
+                                        t->blocks.begin());
+                    for (; b < t->blocks.size() && t->blocks[b].start < sg.start + sg.n; b++) {
+                        if (tc->blk_pop[b] == 0) continue;
+                        lo = std::min(lo, tc->blk_min[b]);
+                        hi = std::max(hi, tc->blk_max[b]);
+                    }
+                }
+                if (hi < lo) continue;  // no populated time value: every row is dropped anyway
+                int64_t tlo = lo / d->time_bucket - P.tb_min, thi = hi / d->time_bucket - P.tb_min;
+                if (tlo < 0 || thi >= P.n_tb) {
+                    ok = false;  // declared bounds narrower than the data: the kernel would count overflow
+                    break;
+                }
+                base[(size_t)w] = (int32_t)(tlo * cells);
+                wmax = std::max(wmax, thi - tlo + 1);
+            }
+            int64_t lds_cells = wmax * cells;
+            if (ok && lds_cells * (F + M) * 8 <= kLdsBudgetBytes) {
+                q->use_lds = true;
+                P.windowed = 1;
+                P.lds_cells = (int32_t)lds_cells;
+                int rs = 0;
+                int64_t words = lds_cells * (F + M);
+                while (rs < 6 && (words * 8 << (rs + 1)) <= kLdsBudgetBytes) rs++;
+                P.rep_shift = rs;
+                q->lds_bytes = (size_t)(words * 8) << rs;
+                SYBL_HIP(hipMalloc((void **)&q->d_wg_cell_base, base.size() * 4));
+                SYBL_HIP(hipMemcpy(q->d_wg_cell_base, base.data(), base.size() * 4, hipMemcpyHostToDevice));
+                P.wg_cell_base = q->d_wg_cell_base;
+            }
+        }
+        select_fast_path(t, q, slot_col);
+        if ((rc = select_part_hist(t, q, slot_col, rows_scanned))) return rc;
+        q->stats.rows_scanned = rows_scanned;
+        q->stats.blocks_skipped = skipped;
+        q->stats.blocks_scanned = (int64_t)t->blocks.size() - skipped;
+        int64_t width = 0;
+        int64_t set_bytes = 0;
+        for (int s = 0; s < P.n_slots; s++) {
+            const Column *c = t->cols[(size_t)slot_col[(size_t)s]].get();
+            if (c->type == SYBL_SET_VAL) {
+                width += 8;  // one CSR offset per row
+                set_bytes += (int64_t)c->h_set_vals.size() * 4;
             } else {
-                A.f_sb = F++;
-                A.f_sb2 = F++;
+                width += c->elem;
             }
         }
-        P.slot[s].flags |= kSlotAgg;
-        P.slot[s].agg_index = a;
-        P.agg[a] = A;
-        q->aggs.push_back(ai);
-    }
-    P.n_aggs = d->n_aggs;
-    P.n_sum_fields = F;
-    P.n_max_fields = M;
-    P.hist_stride = hist_stride;
-    P.hist_off = kHeaderWords + (int64_t)F * n_cells;
-    if ((unsigned __int128)n_cells * (unsigned __int128)hist_stride > ((unsigned __int128)1 << 31))
-        return fail(SYBL_E_INVAL, "groups x buckets = %lld x %lld words does not fit the 16 GiB histogram budget",
-                    (long long)n_cells, (long long)hist_stride);
-
-    // ---- finish slots
-    if (slot_col.empty()) {
-        // count(*) with no referenced column still needs the row count: stream any column
-        if (t->cols.empty()) return fail(SYBL_E_INVAL, "table has no columns");
-        int pick = -1;
-        for (size_t k = 0; k < t->cols.size(); k++)
-            if (t->cols[k]->type != SYBL_SET_VAL) { pick = (int)k; break; }
-        if (pick < 0) return fail(SYBL_E_INVAL, "table has no int/str column to drive the scan");
-        slot_col.push_back(pick);
-        folds.emplace_back();
-    }
-    P.n_slots = (int)slot_col.size();
-    for (int s = 0; s < P.n_slots; s++) {
-        Column *c = t->cols[(size_t)slot_col[(size_t)s]].get();
-        SlotDesc &sd = P.slot[s];
-        sd.base = c->d_data;
-        sd.valid = c->d_valid;
-        if (c->elem == 4) sd.flags |= kSlotW32;
-        if (c->type == SYBL_SET_VAL) {
-            if ((rc = column_upload_set(t, c))) return rc;
-            sd.flags = (sd.flags & ~kSlotW32) | kSlotSet;
-            sd.base = c->d_set_off;
-            sd.set_vals = c->d_set_vals;
-            sd.n_setp = (int)folds[(size_t)s].setp.size();
-            for (int k = 0; k < sd.n_setp; k++) {
-                sd.set_id[k] = folds[(size_t)s].setp[(size_t)k].first;
-                sd.set_in[k] = folds[(size_t)s].setp[(size_t)k].second;
-            }
-        }
-        HostFilterFold &ff = folds[(size_t)s];
-        if (ff.has_range) {
-            sd.flags |= kSlotRange;
-            sd.lo = ff.lo;
-            sd.hi = ff.hi;
-        }
-        if (!ff.neq.empty()) {
-            sd.flags |= kSlotNeq;
-            sd.n_neq = (int)ff.neq.size();
-            for (size_t k = 0; k < ff.neq.size(); k++) sd.neq[k] = ff.neq[k];
-        }
-        if (ff.has_mask) {
-            sd.flags |= kSlotIdMask;
-            size_t nbits = ff.mask.size(), nw = (nbits + 31) / 32 + 1;
-            std::vector<uint32_t> bits(nw, 0);
-            for (size_t k = 0; k < nbits; k++)
-                if (ff.mask[k]) bits[k >> 5] |= 1u << (k & 31);
-            uint32_t *dm = nullptr;
-            SYBL_HIP(hipMalloc((void **)&dm, nw * 4));
-            q->d_idmasks.push_back(dm);
-            SYBL_HIP(hipMemcpy(dm, bits.data(), nw * 4, hipMemcpyHostToDevice));
-            sd.idmask = dm;
-            sd.idmask_bits = (int32_t)nbits;
-        }
+        q->stats.algorithmic_bytes = rows_scanned * width + set_bytes;
+        q->stats.n_cells = (int32_t)n_cells;
+        q->stats.strategy = q->part_hist ? 5 : (q->use_lds ? (P.windowed ? (q->fast ? 4 : 3) : (q->fast ? (q->fplan.hist_lds ? 6 : 2) : 0)) : 1);
+        q->stats.lds_bytes = (int32_t)q->lds_bytes;
+        q->stats.n_workgroups = q->n_wg;
+        q->stats.replicas = 1 << P.rep_shift;
+        q->stats.n_sum_fields = P.n_sum_fields;
+        q->stats.n_max_fields = P.n_max_fields;
+        return SYBL_OK;
     }
 
-    // ---- strategy: cell table in LDS when it fits (DESIGN.md "Strategies")
-    q->n_wg = ctx->n_cus > 0 ? ctx->n_cus : 256;
-    if (const char *e = getenv("SYBL_WG_PER_CU")) q->n_wg *= std::max(1, atoi(e));
-    int64_t lds_words = (int64_t)(F + M) * n_cells;
-    q->use_lds = lds_words * 8 <= kLdsBudgetBytes;
-    P.rep_shift = 0;
-    if (q->use_lds) {
-        int rs = 0;
-        while (rs < 6 && (lds_words * 8 << (rs + 1)) <= kLdsBudgetBytes) rs++;
-        P.rep_shift = rs;
-        q->lds_bytes = (size_t)(lds_words * 8) << rs;
+    int device_copies() {
+        // ---- device-side copies
+        size_t nseg = std::max<size_t>(q->segs.size(), 1);
+        SYBL_HIP(hipMalloc((void **)&q->d_segs, nseg * sizeof(Segment)));
+        if (!q->segs.empty())
+            SYBL_HIP(hipMemcpy(q->d_segs, q->segs.data(), q->segs.size() * sizeof(Segment), hipMemcpyHostToDevice));
+        SYBL_HIP(hipMalloc((void **)&q->d_wg_seg_begin, q->wg_seg_begin.size() * 4));
+        SYBL_HIP(hipMemcpy(q->d_wg_seg_begin, q->wg_seg_begin.data(), q->wg_seg_begin.size() * 4, hipMemcpyHostToDevice));
+        P.segs = q->d_segs;
+        P.wg_seg_begin = q->d_wg_seg_begin;
+        if (q->use_lds && !P.windowed) {
+            SYBL_HIP(hipMalloc((void **)&q->d_ws_sum, (size_t)q->n_wg * F * n_cells * 8));
+            SYBL_HIP(hipMalloc((void **)&q->d_ws_max, (size_t)q->n_wg * std::max<int64_t>((int64_t)M * n_cells, 1) * 8));
+            P.ws_sum = q->d_ws_sum;
+            P.ws_max = q->d_ws_max;
+        }
+        q->eplan.fp.segs = q->d_segs;
+        q->eplan.fp.wg_seg_begin = q->d_wg_seg_begin;
+        q->fplan.segs = q->d_segs;
+        q->fplan.wg_seg_begin = q->d_wg_seg_begin;
+        q->fplan.ws_sum = q->d_ws_sum;
+        q->fplan.ws_max = q->d_ws_max;
+        SYBL_HIP(hipMalloc((void **)&q->d_plan, sizeof(ScanPlan)));
+        for (auto &e : q->ev) SYBL_HIP(hipEventCreate(&e));
+        q->plan_dirty = true;
+        return SYBL_OK;
     }
-    q->n_sum_words = kHeaderWords + (int64_t)F * n_cells + n_cells * hist_stride;
-    q->n_max_words = std::max<int64_t>((int64_t)M * n_cells, 1);
 
-    // ---- work: non-skipped blocks -> runs of physical rows -> an equal share of tiles per workgroup
-    std::vector<Segment> runs;
-    int64_t rows_scanned = 0, skipped = 0;
-    for (size_t b = 0; b < t->blocks.size(); b++) {
-        if (t->blocks[b].n == 0) continue;
-        if (d->block_skip && !should_scan_block(t, d, (int64_t)b)) {
-            skipped++;
-            continue;
-        }
-        rows_scanned += t->blocks[b].n;
-        const Segment &blk = t->blocks[b];
-        if (!runs.empty() && runs.back().start + runs.back().n == blk.start) {
-            runs.back().n += blk.n;
-        } else {
-            runs.push_back(blk);
-        }
+    int run() {
+        int rc;
+        if ((rc = setup())) return rc;
+        if ((rc = filters())) return rc;
+        if ((rc = groups())) return rc;
+        if ((rc = time_series())) return rc;
+        if ((rc = weight())) return rc;
+        if ((rc = aggregations())) return rc;
+        if ((rc = finish_slots())) return rc;
+        if ((rc = strategy())) return rc;
+        if ((rc = work())) return rc;
+        if ((rc = window())) return rc;
+        return device_copies();
     }
-    int64_t total_tiles = 0;
-    for (auto &r : runs) total_tiles += (r.n + kTileRows - 1) / kTileRows;
-    q->segs.clear();
-    q->wg_seg_begin.assign((size_t)q->n_wg + 1, 0);
-    {
-        size_t ri = 0;
-        int64_t tile_in_run = 0;  // tiles of runs[ri] already handed out
-        for (int w = 0; w < q->n_wg; w++) {
-            q->wg_seg_begin[(size_t)w] = (int32_t)q->segs.size();
-            int64_t want = total_tiles * (w + 1) / q->n_wg - total_tiles * w / q->n_wg;
-            while (want > 0 && ri < runs.size()) {
-                int64_t run_tiles = (runs[ri].n + kTileRows - 1) / kTileRows;
-                int64_t take = std::min(want, run_tiles - tile_in_run);
-                Segment sg;
-                sg.start = runs[ri].start + tile_in_run * kTileRows;
-                int64_t end = std::min(runs[ri].start + runs[ri].n, sg.start + take * kTileRows);
-                sg.n = end - sg.start;
-                q->segs.push_back(sg);
-                tile_in_run += take;
-                want -= take;
-                if (tile_in_run == run_tiles) {
-                    ri++;
-                    tile_in_run = 0;
-                }
-            }
-        }
-        q->wg_seg_begin[(size_t)q->n_wg] = (int32_t)q->segs.size();
-    }
-    // ---- LDS-window strategy: a time-series table too large for LDS, scanned by workgroups whose
-    // contiguous rows each span only a few time buckets (tables are digested in time order,
-    // table_io.go:119-122 sorts by Timestamp).  Exact per-block extrema of the time column give
-    // every workgroup its window.
-    P.windowed = 0;
-    P.lds_cells = (int32_t)n_cells;
-    P.wg_cell_base = nullptr;
-    if (!q->use_lds && q->time_mode && !getenv("SYBL_NO_WINDOW") && !t->blocks.empty()) {
-        const Column *tc = t->cols[(size_t)slot_col[(size_t)P.time_slot]].get();
-        std::vector<int32_t> base((size_t)q->n_wg, 0);
-        int64_t wmax = 1;
-        bool ok = true;
-        for (int w = 0; w < q->n_wg && ok; w++) {
-            int64_t lo = INT64_MAX, hi = INT64_MIN;
-            for (int32_t si = q->wg_seg_begin[(size_t)w]; si < q->wg_seg_begin[(size_t)w + 1]; si++) {
-                const Segment &sg = q->segs[(size_t)si];
-                // first block whose end is beyond the segment start
-                size_t b = (size_t)(std::upper_bound(t->blocks.begin(), t->blocks.end(), sg.start,
-                                                     [](int64_t v, const Segment &blk) { return v < blk.start + blk.n; }) -
-                                    t->blocks.begin());
-                for (; b < t->blocks.size() && t->blocks[b].start < sg.start + sg.n; b++) {
-                    if (tc->blk_pop[b] == 0) continue;
-                    lo = std::min(lo, tc->blk_min[b]);
-                    hi = std::max(hi, tc->blk_max[b]);
-                }
-            }
-            if (hi < lo) continue;  // no populated time value: every row is dropped anyway
-            int64_t tlo = lo / d->time_bucket - P.tb_min, thi = hi / d->time_bucket - P.tb_min;
-            if (tlo < 0 || thi >= P.n_tb) {
-                ok = false;  // declared bounds narrower than the data: the kernel would count overflow
-                break;
-            }
-            base[(size_t)w] = (int32_t)(tlo * cells);
-            wmax = std::max(wmax, thi - tlo + 1);
-        }
-        int64_t lds_cells = wmax * cells;
-        if (ok && lds_cells * (F + M) * 8 <= kLdsBudgetBytes) {
-            q->use_lds = true;
-            P.windowed = 1;
-            P.lds_cells = (int32_t)lds_cells;
-            int rs = 0;
-            int64_t words = lds_cells * (F + M);
-            while (rs < 6 && (words * 8 << (rs + 1)) <= kLdsBudgetBytes) rs++;
-            P.rep_shift = rs;
-            q->lds_bytes = (size_t)(words * 8) << rs;
-            SYBL_HIP(hipMalloc((void **)&q->d_wg_cell_base, base.size() * 4));
-            SYBL_HIP(hipMemcpy(q->d_wg_cell_base, base.data(), base.size() * 4, hipMemcpyHostToDevice));
-            P.wg_cell_base = q->d_wg_cell_base;
-        }
-    }
-    select_fast_path(t, q, slot_col);
-    if ((rc = select_part_hist(t, q, slot_col, rows_scanned))) return rc;
-    q->stats.rows_scanned = rows_scanned;
-    q->stats.blocks_skipped = skipped;
-    q->stats.blocks_scanned = (int64_t)t->blocks.size() - skipped;
-    int64_t width = 0;
-    int64_t set_bytes = 0;
-    for (int s = 0; s < P.n_slots; s++) {
-        const Column *c = t->cols[(size_t)slot_col[(size_t)s]].get();
-        if (c->type == SYBL_SET_VAL) {
-            width += 8;  // one CSR offset per row
-            set_bytes += (int64_t)c->h_set_vals.size() * 4;
-        } else {
-            width += c->elem;
-        }
-    }
-    q->stats.algorithmic_bytes = rows_scanned * width + set_bytes;
-    q->stats.n_cells = (int32_t)n_cells;
-    q->stats.strategy = q->part_hist ? 5 : (q->use_lds ? (P.windowed ? (q->fast ? 4 : 3) : (q->fast ? (q->fplan.hist_lds ? 6 : 2) : 0)) : 1);
-    q->stats.lds_bytes = (int32_t)q->lds_bytes;
-    q->stats.n_workgroups = q->n_wg;
-    q->stats.replicas = 1 << P.rep_shift;
-    q->stats.n_sum_fields = P.n_sum_fields;
-    q->stats.n_max_fields = P.n_max_fields;
+};
 
-    // ---- device-side copies
-    size_t nseg = std::max<size_t>(q->segs.size(), 1);
-    SYBL_HIP(hipMalloc((void **)&q->d_segs, nseg * sizeof(Segment)));
-    if (!q->segs.empty())
-        SYBL_HIP(hipMemcpy(q->d_segs, q->segs.data(), q->segs.size() * sizeof(Segment), hipMemcpyHostToDevice));
-    SYBL_HIP(hipMalloc((void **)&q->d_wg_seg_begin, q->wg_seg_begin.size() * 4));
-    SYBL_HIP(hipMemcpy(q->d_wg_seg_begin, q->wg_seg_begin.data(), q->wg_seg_begin.size() * 4, hipMemcpyHostToDevice));
-    P.segs = q->d_segs;
-    P.wg_seg_begin = q->d_wg_seg_begin;
-    if (q->use_lds && !P.windowed) {
-        SYBL_HIP(hipMalloc((void **)&q->d_ws_sum, (size_t)q->n_wg * F * n_cells * 8));
-        SYBL_HIP(hipMalloc((void **)&q->d_ws_max, (size_t)q->n_wg * std::max<int64_t>((int64_t)M * n_cells, 1) * 8));
-        P.ws_sum = q->d_ws_sum;
-        P.ws_max = q->d_ws_max;
-    }
-    q->eplan.fp.segs = q->d_segs;
-    q->eplan.fp.wg_seg_begin = q->d_wg_seg_begin;
-    q->fplan.segs = q->d_segs;
-    q->fplan.wg_seg_begin = q->d_wg_seg_begin;
-    q->fplan.ws_sum = q->d_ws_sum;
-    q->fplan.ws_max = q->d_ws_max;
-    SYBL_HIP(hipMalloc((void **)&q->d_plan, sizeof(ScanPlan)));
-    for (auto &e : q->ev) SYBL_HIP(hipEventCreate(&e));
-    q->plan_dirty = true;
-    return SYBL_OK;
+static int plan_query(Table *t, const sybl_query_desc *d, Query *q) {
+    Planner p(t, d, q);
+    return p.run();
 }
 
 static int ensure_partials(Query *q) {
