@@ -172,6 +172,17 @@ int sybl_table_set_group_dict(sybl_table *t, const char *name, const int64_t *va
  * ids are remapped in place.  The new dictionary must contain every resident value. */
 int sybl_table_column_dict(sybl_table *t, const char *name, const char *const **strings, int64_t *n);
 int sybl_table_set_dict(sybl_table *t, const char *name, const char *const *strings, int64_t n);
+/* Compact storage.  Canonical device storage mirrors the reference's Record fields: int64 per INT
+ * value (IntField, record_fields.go:8), int32 per STR id (StrField).  sybl_table_compact re-encodes
+ * every INT / STR column as unsigned offsets from the column's exact minimum at the narrowest of
+ * 1, 2, 4 bytes that holds max - min (8 when it does not fit) -- the in-HBM counterpart of the
+ * reference's bucket / delta encoded column files (column_store_io.go:64-358).  Every kernel decodes
+ * while loading, so query results are identical; a scan streams the compact bytes.  Appending a
+ * block or installing a dictionary returns the table to canonical storage (call compact again).
+ * Prepared queries must be prepared again afterwards (SYBL_E_STATE otherwise). */
+int sybl_table_compact(sybl_table *t);
+/* bytes per stored value and the value base of a column as currently laid out in HBM */
+int sybl_table_column_storage(const sybl_table *t, const char *name, int32_t *width, int64_t *base);
 /* Copies rows [row0,row0+n) of an INT column back to the host (tests, samples). */
 int sybl_table_read_int(const sybl_table *t, const char *name, int64_t row0, int64_t n, int64_t *out);
 
@@ -276,7 +287,8 @@ void sybl_result_free(sybl_result *r);
 typedef struct {
     int64_t rows_scanned;     /* rows of blocks that were not skipped */
     int64_t blocks_scanned, blocks_skipped;
-    int64_t algorithmic_bytes;/* rows_scanned x sum of stored widths of referenced columns */
+    int64_t algorithmic_bytes;/* rows_scanned x sum of stored widths of referenced columns (as laid out in HBM) */
+    int64_t canonical_bytes;  /* the same with canonical widths (8 per INT value, 4 per STR id) */
     double scan_ms;           /* hipEvent time of the scan kernel(s) of the last sybl_query_scan */
     double reduce_ms;         /* partial-table fold kernels */
     int32_t n_cells;          /* direct-mapped group cells */

@@ -65,7 +65,7 @@ class GroupRow(C.Structure):
 
 class RunStats(C.Structure):
     _fields_ = [("rows_scanned", C.c_int64), ("blocks_scanned", C.c_int64), ("blocks_skipped", C.c_int64),
-                ("algorithmic_bytes", C.c_int64), ("scan_ms", C.c_double), ("reduce_ms", C.c_double),
+                ("algorithmic_bytes", C.c_int64), ("canonical_bytes", C.c_int64), ("scan_ms", C.c_double), ("reduce_ms", C.c_double),
                 ("n_cells", C.c_int32), ("strategy", C.c_int32), ("lds_bytes", C.c_int32),
                 ("n_workgroups", C.c_int32), ("replicas", C.c_int32), ("n_sum_fields", C.c_int32),
                 ("n_max_fields", C.c_int32)]
@@ -101,6 +101,8 @@ SIGNATURES = {
                                + [C.POINTER(C.c_int)]),
     "sybl_table_set_bounds": (C.c_int, [P, C.c_char_p, C.c_int64, C.c_int64, C.c_int]),
     "sybl_table_read_int": (C.c_int, [P, C.c_char_p, C.c_int64, C.c_int64, P]),
+    "sybl_table_compact": (C.c_int, [P]),
+    "sybl_table_column_storage": (C.c_int, [P, C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "sybl_table_column_distinct": (C.c_int, [P, C.c_char_p, C.POINTER(C.POINTER(C.c_int64)), C.POINTER(C.c_int64)]),
     "sybl_table_set_group_dict": (C.c_int, [P, C.c_char_p, P, C.c_int64]),
     "sybl_table_column_dict": (C.c_int, [P, C.c_char_p, C.POINTER(C.POINTER(C.c_char_p)), C.POINTER(C.c_int64)]),

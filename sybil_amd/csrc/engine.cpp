@@ -141,7 +141,7 @@ static bool fill_fast_columns(Table *t, Query *q, const std::vector<int> &slot_c
     for (size_t s = 0; s < slot_col.size(); s++) {
         const SlotDesc &sd = P.slot[s];
         const Column *c = t->cols[(size_t)slot_col[s]].get();
-        bool plain = c->type == SYBL_INT_VAL && c->elem == 8 && !c->d_valid && !c->has_missing;
+        bool plain = c->type == SYBL_INT_VAL && !c->packed() && !c->d_valid && !c->has_missing;
         if (!plain) {
             // GEN kernels: int columns with missing rows in any role, str columns as group keys
             if (!allow_gen) return false;
@@ -166,13 +166,14 @@ static bool fill_fast_columns(Table *t, Query *q, const std::vector<int> &slot_c
         if (!(sd.flags & (kSlotRange | kSlotIdMask))) continue;
         if (nf >= kFastMaxF) return false;
         FP.fcol[nf] = (const int64_t *)sd.base;
+        FP.fwid[nf] = sd.width;
+        FP.fbase[nf] = sd.vbase;
         FP.fvalid[nf] = sd.valid;
         FP.lo[nf] = sd.lo;
         FP.hi[nf] = sd.hi;
         if (sd.flags & kSlotIdMask) {
             FP.fmask[nf] = sd.idmask;
             FP.fmask_bits[nf] = sd.idmask_bits;
-            FP.fw32[nf] = (sd.flags & kSlotW32) ? 1 : 0;
             *gen = true;
         }
         nf++;
@@ -185,7 +186,8 @@ static bool fill_fast_columns(Table *t, Query *q, const std::vector<int> &slot_c
         const SlotDesc &sd = P.slot[s];
         if (sd.gmissing >= 0 && !allow_gen) return false;
         FP.gvalid[ng] = sd.valid;
-        FP.gw32[ng] = (sd.flags & kSlotW32) ? 1 : 0;
+        FP.gwid[ng] = sd.width;
+        FP.gbase[ng] = sd.vbase;
         FP.gmissing[ng] = sd.gmissing;
         FP.gvalues[ng] = sd.gvalues;
         FP.gcol[ng] = (const int64_t *)sd.base;
@@ -219,6 +221,8 @@ static bool fill_fast_columns(Table *t, Query *q, const std::vector<int> &slot_c
         for (size_t k = 0; k < slot_col.size(); k++)
             if (slot_col[k] == ai.col) s = (int)k;
         FP.acol[na] = (const int64_t *)P.slot[s].base;
+        FP.awid[na] = P.slot[s].width;
+        FP.abase[na] = P.slot[s].vbase;
         FP.avalid[na] = P.slot[s].valid;
         FP.f_cnt[na] = A.f_cnt;
         FP.f_pop[na] = A.f_pop;
@@ -241,6 +245,8 @@ static bool fill_fast_columns(Table *t, Query *q, const std::vector<int> &slot_c
     if (q->weighted) {
         if (!allow_gen) return false;
         FP.wcol = (const int64_t *)P.slot[P.weight_slot].base;
+        FP.wwid = P.slot[P.weight_slot].width;
+        FP.wbase = P.slot[P.weight_slot].vbase;
         *gen = true;
     }
     FP.hist_off = P.hist_off;
@@ -276,6 +282,8 @@ static void select_fast_path(Table *t, Query *q, const std::vector<int> &slot_co
     if (q->time_mode) {
         FP.tcol = (const int64_t *)P.slot[P.time_slot].base;
         FP.tvalid = P.slot[P.time_slot].valid;
+        FP.twid = P.slot[P.time_slot].width;
+        FP.tbase = P.slot[P.time_slot].vbase;
         FP.time_bucket = P.time_bucket;
         FP.inv_time_bucket = P.inv_time_bucket;
         FP.tb_min = P.tb_min;
@@ -800,10 +808,11 @@ struct Planner {
             SlotDesc &sd = P.slot[s];
             sd.base = c->d_data;
             sd.valid = c->d_valid;
-            if (c->elem == 4) sd.flags |= kSlotW32;
+            sd.width = c->elem;
+            sd.vbase = c->vbase;
             if (c->type == SYBL_SET_VAL) {
                 if ((rc = column_upload_set(t, c))) return rc;
-                sd.flags = (sd.flags & ~kSlotW32) | kSlotSet;
+                sd.flags |= kSlotSet;
                 sd.base = c->d_set_off;
                 sd.set_vals = c->d_set_vals;
                 sd.n_setp = (int)folds[(size_t)s].setp.size();
@@ -965,18 +974,21 @@ struct Planner {
         q->stats.rows_scanned = rows_scanned;
         q->stats.blocks_skipped = skipped;
         q->stats.blocks_scanned = (int64_t)t->blocks.size() - skipped;
-        int64_t width = 0;
+        int64_t width = 0, canon_width = 0;
         int64_t set_bytes = 0;
         for (int s = 0; s < P.n_slots; s++) {
             const Column *c = t->cols[(size_t)slot_col[(size_t)s]].get();
             if (c->type == SYBL_SET_VAL) {
                 width += 8;  // one CSR offset per row
+                canon_width += 8;
                 set_bytes += (int64_t)c->h_set_vals.size() * 4;
             } else {
                 width += c->elem;
+                canon_width += c->canon();
             }
         }
         q->stats.algorithmic_bytes = rows_scanned * width + set_bytes;
+        q->stats.canonical_bytes = rows_scanned * canon_width + set_bytes;
         q->stats.n_cells = (int32_t)n_cells;
         q->stats.strategy = q->part_hist ? 5 : (q->use_lds ? (P.windowed ? (q->fast ? 4 : 3) : (q->fast ? (q->fplan.hist_lds ? 6 : 2) : 0)) : 1);
         q->stats.lds_bytes = (int32_t)q->lds_bytes;

@@ -31,11 +31,12 @@ hipError_t launch_fold(const int64_t *ws_sum, int64_t *out_sum, int64_t words_su
 hipError_t launch_fill64(int64_t *p, int64_t n, int64_t v, hipStream_t st);
 hipError_t launch_synth(int64_t *out, int64_t n, int64_t row0, int64_t total_rows, int kind, int64_t a, int64_t b,
                         uint64_t col_seed, hipStream_t st);
-hipError_t launch_block_minmax(const void *col, bool w32, const uint32_t *valid, const Segment *blocks, int n_blocks,
+hipError_t launch_block_minmax(const void *col, int width, int64_t vbase, const uint32_t *valid, const Segment *blocks, int n_blocks,
                                int64_t *out_min, int64_t *out_max, int64_t *out_pop, hipStream_t st);
+hipError_t launch_repack(const void *src, int sw, int64_t sbase, void *dst, int dw, int64_t dbase, int64_t n, hipStream_t st);
 
-hipError_t launch_distinct(const void *col, bool w32, const uint32_t *valid, const Segment *blocks, int n_blocks, int64_t *keys,
-                           uint32_t mask, unsigned long long *n_distinct, unsigned long long limit, hipStream_t st);
+hipError_t launch_distinct(const void *col, int width, int64_t vbase, const uint32_t *valid, const Segment *blocks, int n_blocks,
+                           int64_t *keys, uint32_t mask, unsigned long long *n_distinct, unsigned long long limit, hipStream_t st);
 hipError_t launch_decode_bins(const uint32_t *recs, const int64_t *bin_off, const int64_t *bin_val, int n_bins,
                               bool delta_encoded, void *col, bool w32, uint32_t *valid, uint32_t nrows, hipStream_t st);
 hipError_t launch_decode_delta(const int64_t *deltas, int64_t n, bool value_encoded, int64_t *col, hipStream_t st);
@@ -55,7 +56,11 @@ struct Ctx {
 struct Column {
     std::string name;
     int type = SYBL_INT_VAL;
-    int elem = 8;  // bytes per stored value (int64 / int32 ids)
+    int elem = 8;    // bytes per stored value: canonical (8 = int64 values, 4 = int32 dictionary ids) or,
+                     // after sybl_table_compact, the narrowest of 1/2/4 that holds max - min
+    int64_t vbase = 0;  // value = vbase + zero-extended stored bits (0 for canonical storage)
+    int canon() const { return type == SYBL_INT_VAL ? 8 : 4; }
+    bool packed() const { return elem != canon() || vbase != 0; }
     bool info_given = false;
     int64_t info_min = 0, info_max = 0;
     void *d_data = nullptr;
@@ -112,6 +117,8 @@ int32_t dict_intern(Column *c, const std::string &s);
 int column_upload_set(Table *t, Column *c);
 int column_build_gdict(Table *t, Column *c);           // distinct values of the resident rows
 int column_install_gdict(Table *t, Column *c);         // sorted gdict -> device value->rank map
+int column_repack(Table *t, Column *c, int width, int64_t vbase);  // change the stored width in place
+int table_unpack(Table *t);                            // every column back to canonical storage
 
 struct BlockWriter {
     Table *t = nullptr;

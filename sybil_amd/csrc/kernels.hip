@@ -35,7 +35,7 @@ typedef long long ll2 __attribute__((ext_vector_type(2)));
 typedef const ScanPlan __attribute__((address_space(4))) CPlan;
 typedef const SlotDesc __attribute__((address_space(4))) CSlot;
 typedef const AggDesc __attribute__((address_space(4))) CAgg;
-typedef int i32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 // ---------------------------------------------------------------- small helpers
 
@@ -109,6 +109,36 @@ struct Tile {
     uint32_t pop[NC];  // 2 validity bits per slot (bit0 = row0, bit1 = row1)
 };
 
+// Two consecutive rows of one column, decoded: value = vbase + zero-extended raw.  The width is
+// wave-uniform, so the switch is a scalar branch; a width-8 column is stored as the value itself.
+__device__ __forceinline__ ll2 load_rows2(const void *base, int width, int64_t vbase, int64_t row) {
+    ll2 v;
+    switch (width) {
+    case 8: return __builtin_nontemporal_load((const ll2 *)((const int64_t *)base + row));
+    case 4: {
+        const u32x2 w = __builtin_nontemporal_load((const u32x2 *)((const uint32_t *)base + row));
+        v.x = w.x;
+        v.y = w.y;
+        break;
+    }
+    case 2: {
+        const uint32_t w = __builtin_nontemporal_load((const uint32_t *)((const uint16_t *)base + row));
+        v.x = w & 0xFFFFu;
+        v.y = w >> 16;
+        break;
+    }
+    default: {
+        const uint32_t w = __builtin_nontemporal_load((const uint16_t *)((const uint8_t *)base + row));
+        v.x = w & 0xFFu;
+        v.y = w >> 8;
+        break;
+    }
+    }
+    v.x += vbase;
+    v.y += vbase;
+    return v;
+}
+
 template <int NC>
 __device__ __forceinline__ void load_tile(CPlan &P, int64_t row, bool in_range, Tile<NC> &t) {
 #pragma unroll
@@ -120,13 +150,7 @@ __device__ __forceinline__ void load_tile(CPlan &P, int64_t row, bool in_range, 
             pop = 3u;
             if (s.valid) pop = (s.valid[row >> 5] >> (row & 31)) & 3u;
         } else if (in_range) {
-            if (s.flags & kSlotW32) {
-                i32x2 w = __builtin_nontemporal_load((const i32x2 *)((const int32_t *)s.base + row));
-                v.x = w.x;
-                v.y = w.y;
-            } else {
-                v = __builtin_nontemporal_load((const ll2 *)((const int64_t *)s.base + row));
-            }
+            v = load_rows2(s.base, s.width, s.vbase, row);
             pop = 3u;
             if (s.valid) pop = (s.valid[row >> 5] >> (row & 31)) & 3u;
         }
@@ -466,11 +490,21 @@ __global__ __launch_bounds__(256) void k_synth(int64_t *out, int64_t n, int64_t 
     }
 }
 
+// one stored value of a column, decoded (one-time kernels: statistics, distinct values, repacking)
+__device__ __forceinline__ int64_t load_val(const void *base, int width, int64_t vbase, int64_t row) {
+    switch (width) {
+    case 8: return ((const int64_t *)base)[row];
+    case 4: return vbase + (int64_t)((const uint32_t *)base)[row];
+    case 2: return vbase + (int64_t)((const uint16_t *)base)[row];
+    default: return vbase + (int64_t)((const uint8_t *)base)[row];
+    }
+}
+
 // ---------------------------------------------------------------- per-block extrema
 // One workgroup per block of rows: min/max over populated values.  Feeds block skipping
 // (table_block_io.go:110-182) and the direct-mapped group layout.
-template <typename T>
-__global__ __launch_bounds__(256) void k_block_minmax(const T *__restrict__ col, const uint32_t *__restrict__ valid,
+__global__ __launch_bounds__(256) void k_block_minmax(const void *__restrict__ col, int width, int64_t vbase,
+                                                      const uint32_t *__restrict__ valid,
                                                       const Segment *__restrict__ blocks, int64_t *__restrict__ out_min,
                                                       int64_t *__restrict__ out_max, int64_t *__restrict__ out_pop) {
     const Segment b = blocks[blockIdx.x];
@@ -478,7 +512,7 @@ __global__ __launch_bounds__(256) void k_block_minmax(const T *__restrict__ col,
     for (int64_t i = threadIdx.x; i < b.n; i += blockDim.x) {
         const int64_t row = b.start + i;
         if (valid && !((valid[row >> 5] >> (row & 31)) & 1u)) continue;
-        const int64_t v = (int64_t)col[row];
+        const int64_t v = load_val(col, width, vbase, row);
         mn = v < mn ? v : mn;
         mx = v > mx ? v : mx;
         pc++;
@@ -514,15 +548,15 @@ __global__ __launch_bounds__(256) void k_block_minmax(const T *__restrict__ col,
 // Inserts every populated value into an open-addressing set (capacity = mask + 1, empty =
 // kDictEmpty).  Most probes hit an existing key with a plain load; only first sightings CAS.
 // *n_distinct counts insertions; the host gives up when it exceeds the dictionary budget.
-template <typename T>
-__global__ __launch_bounds__(256) void k_distinct(const T *__restrict__ col, const uint32_t *__restrict__ valid,
+__global__ __launch_bounds__(256) void k_distinct(const void *__restrict__ col, int width, int64_t vbase,
+                                                  const uint32_t *__restrict__ valid,
                                                   const Segment *__restrict__ blocks, int64_t *keys, uint32_t mask,
                                                   unsigned long long *n_distinct, unsigned long long limit) {
     const Segment b = blocks[blockIdx.x];
     for (int64_t i = threadIdx.x; i < b.n; i += blockDim.x) {
         const int64_t row = b.start + i;
         if (valid && !((valid[row >> 5] >> (row & 31)) & 1u)) continue;
-        const int64_t x = (int64_t)col[row];
+        const int64_t x = load_val(col, width, vbase, row);
         if (x == kDictEmpty) continue;  // the sentinel itself cannot be stored; reported by the host
         uint32_t h = dict_hash(x) & mask;
         for (uint32_t probe = 0; probe <= mask; probe++) {
@@ -543,16 +577,36 @@ __global__ __launch_bounds__(256) void k_distinct(const T *__restrict__ col, con
     }
 }
 
-hipError_t launch_distinct(const void *col, bool w32, const uint32_t *valid, const Segment *blocks, int n_blocks, int64_t *keys,
-                           uint32_t mask, unsigned long long *n_distinct, unsigned long long limit, hipStream_t st) {
+hipError_t launch_distinct(const void *col, int width, int64_t vbase, const uint32_t *valid, const Segment *blocks, int n_blocks,
+                           int64_t *keys, uint32_t mask, unsigned long long *n_distinct, unsigned long long limit, hipStream_t st) {
     if (n_blocks <= 0) return hipSuccess;
-    if (w32) {
-        hipLaunchKernelGGL((k_distinct<int32_t>), dim3(n_blocks), dim3(256), 0, st, (const int32_t *)col, valid, blocks, keys, mask,
-                           n_distinct, limit);
-    } else {
-        hipLaunchKernelGGL((k_distinct<int64_t>), dim3(n_blocks), dim3(256), 0, st, (const int64_t *)col, valid, blocks, keys, mask,
-                           n_distinct, limit);
+    hipLaunchKernelGGL(k_distinct, dim3(n_blocks), dim3(256), 0, st, col, width, vbase, valid, blocks, keys, mask, n_distinct, limit);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- compact storage
+// dst = the same values at another width / base (sybl_table_compact and its inverse).  Rows are
+// independent; unpopulated rows carry don't-care bits either way.
+__global__ __launch_bounds__(256) void k_repack(const void *__restrict__ src, int sw, int64_t sbase, void *__restrict__ dst, int dw,
+                                                int64_t dbase, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const uint64_t u = (uint64_t)load_val(src, sw, sbase, i) - (uint64_t)dbase;
+        switch (dw) {
+        case 8: ((int64_t *)dst)[i] = (int64_t)u; break;
+        case 4: ((uint32_t *)dst)[i] = (uint32_t)u; break;
+        case 2: ((uint16_t *)dst)[i] = (uint16_t)u; break;
+        default: ((uint8_t *)dst)[i] = (uint8_t)u; break;
+        }
     }
+}
+
+hipError_t launch_repack(const void *src, int sw, int64_t sbase, void *dst, int dw, int64_t dbase, int64_t n, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(k_repack, dim3((unsigned)blocks), dim3(256), 0, st, src, sw, sbase, dst, dw, dbase, n);
     return hipGetLastError();
 }
 
@@ -818,16 +872,10 @@ hipError_t launch_synth(int64_t *out, int64_t n, int64_t row0, int64_t total_row
     return hipGetLastError();
 }
 
-hipError_t launch_block_minmax(const void *col, bool w32, const uint32_t *valid, const Segment *blocks, int n_blocks,
+hipError_t launch_block_minmax(const void *col, int width, int64_t vbase, const uint32_t *valid, const Segment *blocks, int n_blocks,
                                int64_t *out_min, int64_t *out_max, int64_t *out_pop, hipStream_t st) {
     if (n_blocks <= 0) return hipSuccess;
-    if (w32) {
-        hipLaunchKernelGGL((k_block_minmax<int32_t>), dim3(n_blocks), dim3(256), 0, st, (const int32_t *)col, valid, blocks,
-                           out_min, out_max, out_pop);
-    } else {
-        hipLaunchKernelGGL((k_block_minmax<int64_t>), dim3(n_blocks), dim3(256), 0, st, (const int64_t *)col, valid, blocks,
-                           out_min, out_max, out_pop);
-    }
+    hipLaunchKernelGGL(k_block_minmax, dim3(n_blocks), dim3(256), 0, st, col, width, vbase, valid, blocks, out_min, out_max, out_pop);
     return hipGetLastError();
 }
 

@@ -28,14 +28,15 @@ enum SlotFlags : uint32_t {
     kSlotAgg = 1u << 4,     // aggregation input (aggregate.go:246-261)
     kSlotTime = 1u << 5,    // time column (aggregate.go:146-183)
     kSlotWeight = 1u << 6,  // weight column (aggregate.go:100-102)
-    kSlotW32 = 1u << 7,     // stored as int32 (str dictionary ids)
     kSlotSet = 1u << 8,     // set column: base = CSR offsets per physical row, filters in setp[]
     kSlotDict = 1u << 9,    // group key through a value -> rank hash map (sparse / wide key ranges)
     kSlotFilter = kSlotRange | kSlotNeq | kSlotIdMask,
 };
 
 struct SlotDesc {
-    const void *base;        // column values (int64, or int32 with kSlotW32)
+    const void *base;        // column values: `width` bytes per row, value = vbase + zero-extended raw
+                             // (canonical int columns: width 8, vbase 0; str ids: width 4, vbase 0;
+                             // compacted columns: the narrowest width holding max - min)
     const uint32_t *valid;   // bit per physical row, nullptr = every row populated
     const uint32_t *idmask;  // kSlotIdMask: bit per dictionary id, 1 = row passes
     int64_t lo, hi;          // kSlotRange (inclusive)
@@ -61,7 +62,8 @@ struct SlotDesc {
     const int64_t *dkeys;
     const int32_t *dranks;
     uint32_t dmask;
-    int32_t pad2_;
+    int32_t width;           // bytes per stored value: 1, 2, 4 or 8
+    int64_t vbase;           // added to the raw (unsigned) stored value
 };
 
 struct AggDesc {

@@ -54,15 +54,19 @@ struct FastPlan {
     // GEN kernels only: validity bitmaps (nullptr = fully populated), int32 group ids (str columns),
     // missing-key cells, and the reject gate / per-aggregation counts of hist_basic.go:104
     const uint32_t *fvalid[kFastMaxF], *gvalid[kFastMaxG], *avalid[kFastMaxA], *tvalid;
-    int32_t gw32[kFastMaxG], gmissing[kFastMaxG], gvalues[kFastMaxG];
+    int32_t gmissing[kFastMaxG], gvalues[kFastMaxG];
     // str filters (filter.go:199-250) as one bit per dictionary id: fmask != nullptr replaces the range
     const uint32_t *fmask[kFastMaxF];
-    int32_t fmask_bits[kFastMaxF], fw32[kFastMaxF];
+    int32_t fmask_bits[kFastMaxF];
     int32_t f_cnt[kFastMaxA], f_pop[kFastMaxA], f_smp[kFastMaxA], f_out[kFastMaxA];
     int64_t info_min[kFastMaxA], max10[kFastMaxA];
     const int64_t *wcol;           // weight column (OPTS.WEIGHT_COL, aggregate.go:100-102), fully populated
     int32_t f_samples;             // Result.Samples field when weighted, else -1
     int32_t pad2_;
+    // stored width (bytes: 1, 2, 4, 8) and value base per column: value = base + zero-extended raw
+    // (canonical int64 columns: width 8, base 0 -- loaded as they are)
+    int32_t fwid[kFastMaxF], gwid[kFastMaxG], awid[kFastMaxA], twid, wwid;
+    int64_t fbase[kFastMaxF], gbase[kFastMaxG], abase[kFastMaxA], tbase, wbase;
     const int32_t *wg_cell_base;
     int64_t *sum_out, *max_out, *ws_sum, *ws_max;
     const Segment *segs;
@@ -125,45 +129,71 @@ struct FastTile {
     uint32_t pop[N > 0 ? N : 1];  // GEN kernels: validity bits of the two rows
 };
 
-typedef int fi32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int fu32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ uint32_t fast_pop(const uint32_t *valid, int64_t row) {
     return valid ? (valid[row >> 5] >> (row & 31)) & 3u : 3u;
 }
 
+// Two consecutive rows of one column, decoded.  The width is a kernel argument (wave-uniform), so
+// the switch is a scalar branch; canonical int64 columns take the first case untouched.
+__device__ __forceinline__ fll2 fast_load2(const int64_t *col, int width, int64_t base, int64_t row) {
+    fll2 v;
+    switch (width) {
+    case 8: return __builtin_nontemporal_load((const fll2 *)(col + row));
+    case 4: {
+        const fu32x2 w = __builtin_nontemporal_load((const fu32x2 *)((const uint32_t *)col + row));
+        v.x = w.x;
+        v.y = w.y;
+        break;
+    }
+    case 2: {
+        const uint32_t w = __builtin_nontemporal_load((const uint32_t *)((const uint16_t *)col + row));
+        v.x = w & 0xFFFFu;
+        v.y = w >> 16;
+        break;
+    }
+    default: {
+        const uint32_t w = __builtin_nontemporal_load((const uint16_t *)((const uint8_t *)col + row));
+        v.x = w & 0xFFu;
+        v.y = w >> 8;
+        break;
+    }
+    }
+    v.x += base;
+    v.y += base;
+    return v;
+}
+
+// GEN kernels read any stored width; the plain kernels are compiled for canonical int64 columns only
+// (the width switch costs them ~25 VGPRs and pushes the 2-group / 2-aggregation bodies into scratch).
+template <bool GEN>
+__device__ __forceinline__ fll2 fast_col2(const int64_t *col, int width, int64_t base, int64_t row) {
+    if (GEN) return fast_load2(col, width, base, row);
+    return __builtin_nontemporal_load((const fll2 *)(col + row));
+}
+
 template <int NF, int NG, int NA, bool TIME, bool GEN>
 __device__ __forceinline__ void fast_load(const FastPlan &P, int64_t row, FastTile<NF> &f, FastTile<NG> &g,
                                           FastTile<NA> &a, FastTile<1> &t, FastTile<1> &w) {
-    if (GEN && P.wcol) w.v[0] = __builtin_nontemporal_load((const fll2 *)(P.wcol + row));
+    if (GEN && P.wcol) w.v[0] = fast_load2(P.wcol, P.wwid, P.wbase, row);
     if (TIME) {
-        t.v[0] = __builtin_nontemporal_load((const fll2 *)(P.tcol + row));
+        t.v[0] = fast_col2<GEN>(P.tcol, P.twid, P.tbase, row);
         if (GEN) t.pop[0] = fast_pop(P.tvalid, row);
     }
 #pragma unroll
     for (int c = 0; c < NF; c++) {
-        if (GEN && P.fw32[c]) {  // str column: int32 dictionary ids
-            const fi32x2 w = __builtin_nontemporal_load((const fi32x2 *)((const int32_t *)P.fcol[c] + row));
-            f.v[c].x = w.x;
-            f.v[c].y = w.y;
-        } else {
-            f.v[c] = __builtin_nontemporal_load((const fll2 *)(P.fcol[c] + row));
-        }
+        f.v[c] = fast_col2<GEN>(P.fcol[c], P.fwid[c], P.fbase[c], row);
         if (GEN) f.pop[c] = fast_pop(P.fvalid[c], row);
     }
 #pragma unroll
     for (int c = 0; c < NG; c++) {
-        if (GEN && P.gw32[c]) {  // str column: int32 dictionary ids
-            const fi32x2 w = __builtin_nontemporal_load((const fi32x2 *)((const int32_t *)P.gcol[c] + row));
-            g.v[c].x = w.x;
-            g.v[c].y = w.y;
-        } else {
-            g.v[c] = __builtin_nontemporal_load((const fll2 *)(P.gcol[c] + row));
-        }
+        g.v[c] = fast_col2<GEN>(P.gcol[c], P.gwid[c], P.gbase[c], row);
         if (GEN) g.pop[c] = fast_pop(P.gvalid[c], row);
     }
 #pragma unroll
     for (int c = 0; c < NA; c++) {
-        a.v[c] = __builtin_nontemporal_load((const fll2 *)(P.acol[c] + row));
+        a.v[c] = fast_col2<GEN>(P.acol[c], P.awid[c], P.abase[c], row);
         if (GEN) a.pop[c] = fast_pop(P.avalid[c], row);
     }
 }

@@ -75,7 +75,7 @@ int table_ensure_stats(Table *t) {
         Column *c = cp.get();
         if (c->type == SYBL_SET_VAL || c->stats_blocks >= nb) continue;
         int64_t b0 = c->stats_blocks, n = nb - b0;
-        hipError_t e = launch_block_minmax(c->d_data, c->elem == 4, c->d_valid, t->d_blocks + b0, (int)n, d_out,
+        hipError_t e = launch_block_minmax(c->d_data, c->elem, c->vbase, c->d_valid, t->d_blocks + b0, (int)n, d_out,
                                            d_out + nb, d_out + 2 * nb, st);
         if (e != hipSuccess) {
             hipFree(d_out);
@@ -100,6 +100,40 @@ int table_ensure_stats(Table *t) {
         c->stats_blocks = nb;
     }
     SYBL_HIP(hipFree(d_out));
+    return SYBL_OK;
+}
+
+// Re-encodes a column at another stored width / value base (out of place, then swaps the arrays).
+int column_repack(Table *t, Column *c, int width, int64_t vbase) {
+    if (c->type == SYBL_SET_VAL) return SYBL_OK;
+    if (width == c->elem && vbase == c->vbase) return SYBL_OK;
+    if (c->d_data) {
+        hipStream_t st = t->ctx->stream;
+        void *nd = nullptr;
+        SYBL_HIP(hipMalloc(&nd, (size_t)c->cap_rows * (size_t)width));
+        hipError_t e = launch_repack(c->d_data, c->elem, c->vbase, nd, width, vbase, t->phys_rows, st);
+        if (e != hipSuccess) {
+            hipFree(nd);
+            return hip_fail(e, "k_repack");
+        }
+        SYBL_HIP(hipStreamSynchronize(st));
+        SYBL_HIP(hipFree(c->d_data));
+        c->d_data = nd;
+    }
+    c->elem = width;
+    c->vbase = vbase;
+    return SYBL_OK;
+}
+
+int table_unpack(Table *t) {
+    bool any = false;
+    for (auto &c : t->cols) {
+        if (c->type == SYBL_SET_VAL || !c->packed()) continue;
+        int rc = column_repack(t, c.get(), c->canon(), 0);
+        if (rc) return rc;
+        any = true;
+    }
+    if (any) t->version++;
     return SYBL_OK;
 }
 
@@ -130,6 +164,9 @@ int32_t dict_intern(Column *c, const std::string &s) {
 
 int block_begin(Table *t, int64_t nrows, BlockWriter *w) {
     if (nrows < 0) return fail(SYBL_E_INVAL, "negative row count");
+    // writers produce canonical values: a compacted table goes back to canonical storage first
+    int rc = table_unpack(t);
+    if (rc) return rc;
     w->t = t;
     w->nrows = nrows;
     w->start = round_up(t->phys_rows, 32);
@@ -290,7 +327,7 @@ int column_build_gdict(Table *t, Column *c) {
         return hip_fail(e, "k_fill64");
     }
     SYBL_HIP(hipMemsetAsync(d_n, 0, 8, st));
-    e = launch_distinct(c->d_data, c->elem == 4, c->d_valid, t->d_blocks, (int)nb, d_keys, cap - 1, d_n,
+    e = launch_distinct(c->d_data, c->elem, c->vbase, c->d_valid, t->d_blocks, (int)nb, d_keys, cap - 1, d_n,
                         (unsigned long long)kDictMaxDistinct, st);
     if (e != hipSuccess) {
         cleanup();
@@ -611,6 +648,8 @@ int sybl_table_set_dict(sybl_table *t, const char *name, const char *const *stri
     }
     hipStream_t st = t->ctx->stream;
     if (c->type == SYBL_STR_VAL && t->phys_rows > 0 && !lut.empty()) {
+        int rc = column_repack(t, c, c->canon(), 0);  // ids are rewritten as int32
+        if (rc) return rc;
         int32_t *d_lut = nullptr;
         SYBL_HIP(hipMalloc((void **)&d_lut, lut.size() * 4));
         SYBL_HIP(hipMemcpyAsync(d_lut, lut.data(), lut.size() * 4, hipMemcpyHostToDevice, st));
@@ -639,6 +678,44 @@ int sybl_table_set_dict(sybl_table *t, const char *name, const char *const *stri
     return SYBL_OK;
 }
 
+int sybl_table_compact(sybl_table *t) {
+    if (!t) return fail(SYBL_E_INVAL, "NULL table");
+    SYBL_HIP(hipSetDevice(t->ctx->device));
+    int rc = table_ensure_stats(t);
+    if (rc) return rc;
+    bool any = false;
+    for (auto &cp : t->cols) {
+        Column *c = cp.get();
+        if (c->type == SYBL_SET_VAL || !c->d_data) continue;
+        int width = c->canon();
+        int64_t base = 0;
+        if (c->n_pop == 0) {
+            width = 1;  // no populated row: the stored bits are never looked at
+        } else {
+            const unsigned __int128 range = (unsigned __int128)((__int128)c->exact_max - (__int128)c->exact_min);
+            int fit = range < 256 ? 1 : range < 65536 ? 2 : range < ((unsigned __int128)1 << 32) ? 4 : 8;
+            if (fit < width) {
+                width = fit;
+                base = c->exact_min;
+            }
+        }
+        if (width >= c->elem) continue;  // already this narrow
+        if ((rc = column_repack(t, c, width, base))) return rc;
+        any = true;
+    }
+    if (any) t->version++;
+    return SYBL_OK;
+}
+
+int sybl_table_column_storage(const sybl_table *t, const char *name, int32_t *width, int64_t *base) {
+    if (!t) return fail(SYBL_E_INVAL, "NULL table");
+    Column *c = t->find(name);
+    if (!c) return fail(SYBL_E_INVAL, "unknown column '%s'", name ? name : "(null)");
+    if (width) *width = c->type == SYBL_SET_VAL ? 0 : c->elem;
+    if (base) *base = c->vbase;
+    return SYBL_OK;
+}
+
 int sybl_table_read_int(const sybl_table *t, const char *name, int64_t row0, int64_t n, int64_t *out) {
     if (!t || !out) return fail(SYBL_E_INVAL, "NULL argument");
     Column *c = t->find(name);
@@ -651,9 +728,20 @@ int sybl_table_read_int(const sybl_table *t, const char *name, int64_t row0, int
     for (auto &b : t->blocks) {
         int64_t lo = std::max(row0, lbase), hi = std::min(row0 + n, lbase + b.n);
         if (hi > lo) {
-            SYBL_HIP(hipMemcpy(out + (lo - row0), (const int64_t *)c->d_data + b.start + (lo - lbase), (size_t)(hi - lo) * 8,
-                               hipMemcpyDeviceToHost));
-            done += hi - lo;
+            const int64_t first = b.start + (lo - lbase), cnt = hi - lo;
+            if (c->elem == 8) {
+                SYBL_HIP(hipMemcpy(out + (lo - row0), (const int64_t *)c->d_data + first, (size_t)cnt * 8, hipMemcpyDeviceToHost));
+            } else {
+                // compact storage: raw bytes to the host, decoded there
+                std::vector<uint8_t> raw((size_t)cnt * (size_t)c->elem);
+                SYBL_HIP(hipMemcpy(raw.data(), (const char *)c->d_data + (size_t)first * (size_t)c->elem, raw.size(), hipMemcpyDeviceToHost));
+                for (int64_t k = 0; k < cnt; k++) {
+                    uint64_t u = 0;
+                    memcpy(&u, raw.data() + (size_t)k * (size_t)c->elem, (size_t)c->elem);
+                    out[lo - row0 + k] = (int64_t)((uint64_t)c->vbase + u);
+                }
+            }
+            done += cnt;
         }
         lbase += b.n;
     }

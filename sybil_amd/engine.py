@@ -189,6 +189,18 @@ class Table:
         arr = (C.c_char_p * max(len(bs), 1))(*bs)
         N.check(N.lib().sybl_table_set_dict(self._h, _b(name), arr, len(bs)))
 
+    def compact(self):
+        """Re-encode every int / str column at the narrowest width that holds max - min
+        (sybl_table_compact); query results are unchanged, scans stream fewer bytes."""
+        N.check(N.lib().sybl_table_compact(self._h))
+        return self
+
+    def column_storage(self, name):
+        """(bytes per stored value, value base) of a column as laid out in HBM."""
+        w, b = C.c_int32(0), C.c_int64(0)
+        N.check(N.lib().sybl_table_column_storage(self._h, _b(name), C.byref(w), C.byref(b)))
+        return int(w.value), int(b.value)
+
     def read_int(self, name, row0, n):
         out = np.empty(n, dtype=np.int64)
         N.check(N.lib().sybl_table_read_int(self._h, _b(name), row0, n, out.ctypes.data))

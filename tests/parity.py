@@ -96,10 +96,12 @@ def compare(gres, ores, op="avg", full=True, n_aggs=0, time_mode=False):
             compare_hist(gc["hists"][a], oc["hists"][a], op, full, ctx=("cumulative", a))
 
 
-def run_both(ctx, orc, names, total_rows, row0, nrows, q, block_rows=65536, oracle_threads=4):
+def run_both(ctx, orc, names, total_rows, row0, nrows, q, block_rows=65536, oracle_threads=4, compact=False):
     """Synthetic table on the GPU and in host memory; same query through both."""
     t = ctx.synth_table("synth", synth.SEED, total_rows, row0, nrows, synth.synth_cols(names))
     try:
+        if compact:
+            t.compact()
         query = t.query(**q)
         try:
             gres = query.run()

@@ -1,0 +1,142 @@
+"""GPU: compact storage (sybl_table_compact).  Columns re-encoded as 1/2/4-byte offsets from the
+column minimum must give the same answers as canonical int64 / int32 storage -- against the CPU
+oracle, bit-exact -- while the scan streams fewer bytes."""
+import numpy as np
+import pytest
+
+import sybil_amd
+from sybil_amd import synth
+from tests import parity
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = sybil_amd.Context(0)
+    yield c
+    c.close()
+
+
+def test_widths_and_read_back(ctx, oracle):
+    names = ["c00", "c01", "c02", "c03", "c04", "c07", "c08", "c09"]
+    n = 300_000
+    t = ctx.synth_table("w", synth.SEED, n, 0, n, synth.synth_cols(names))
+    before = {c: t.read_int(c, 1000, 5000) for c in names}
+    assert all(t.column_storage(c) == (8, 0) for c in names)
+    bytes_before = t.hbm_bytes
+    t.compact()
+    widths = {c: t.column_storage(c)[0] for c in names}
+    assert widths == {"c00": 4, "c01": 1, "c02": 1, "c03": 2, "c04": 2, "c07": 4, "c08": 4, "c09": 2}, widths
+    assert t.column_storage("c00")[1] >= 1_700_000_000      # the base is the column minimum
+    assert t.hbm_bytes < bytes_before / 2
+    for c in names:
+        assert np.array_equal(t.read_int(c, 1000, 5000), before[c]), c
+    t.compact()  # idempotent
+    assert {c: t.column_storage(c)[0] for c in names} == widths
+    t.free()
+
+
+@pytest.mark.parametrize("name,rows", [
+    ("cfg1_count_range", 600_003),
+    ("cfg2_group1_avg2", 800_000),
+    ("cfg3_filter3_group2_stddev", 1_000_000),
+    ("cfg4_hist_highcard", 300_000),
+    ("cfg5_time_rollup", 900_000),
+])
+def test_baseline_workloads_compact(ctx, oracle, name, rows):
+    wl = synth.WORKLOADS[name]
+    q = wl["query"]
+    gres, ores, stats = parity.run_both(ctx, oracle, wl["columns"], rows, 0, rows, q, compact=True)
+    parity.compare(gres, ores, op=q.get("op", "avg"), full=q.get("want_percentiles", True) and q.get("op") == "hist",
+                   n_aggs=len(q.get("aggs", [])), time_mode=bool(q.get("time_col")))
+    assert stats["algorithmic_bytes"] < stats["canonical_bytes"]
+    assert stats["canonical_bytes"] == rows * 8 * len(wl["columns"])
+    gres.free()
+
+
+@pytest.mark.parametrize("q", [
+    dict(aggs=["c07"], op="hist"),
+    dict(groups=["c01"], aggs=["c07", "c08"], op="hist", hist_bucket=5000),
+    dict(filters=[("c04", "neq", 500), ("c04", "neq", 7), ("c05", "gt", 10)], groups=["c01"]),
+    dict(filters=[("c04", "gt", 2000)], groups=["c01"], aggs=["c07"]),
+    dict(groups=["c01", "c02"], aggs=["c07"], op="avg", order_by="c07"),
+    dict(groups=["c04"], aggs=["c04"], op="hist"),
+    dict(filters=[("c04", "gt", 99), ("c04", "lt", 900)], groups=["c01", "c02"], aggs=["c07", "c08"], op="hist"),
+])
+def test_query_shapes_compact(ctx, oracle, q):
+    names = ["c01", "c02", "c04", "c05", "c07", "c08"]
+    gres, ores, _ = parity.run_both(ctx, oracle, names, 500_001, 0, 500_001, q, compact=True)
+    parity.compare(gres, ores, op=q.get("op", "avg"), full=True, n_aggs=len(q.get("aggs", [])))
+    gres.free()
+
+
+def test_negative_wide_and_missing_values(ctx, oracle):
+    rng = np.random.default_rng(77)
+    n = 90_000
+    cols = {
+        "neg": rng.integers(-300, -100, size=n),                       # 1 byte, negative base
+        "mid": rng.integers(-40_000, 20_000, size=n),                  # 2 bytes
+        "big": rng.integers(-(1 << 40), 1 << 40, size=n),              # does not fit 4 bytes: stays int64
+        "edge": rng.integers((1 << 62) - 200, (1 << 62), size=n),      # 1 byte at a huge base
+        "v": rng.integers(0, 70_000, size=n),
+    }
+    cols = {k: v.astype(np.int64) for k, v in cols.items()}
+    pop = (rng.random(n) > 0.25).astype(np.uint8)
+    info = {k: (int(v.min()), int(v.max())) for k, v in cols.items()}
+    tb = ctx.create_table("nw")
+    for c in cols:
+        tb.add_column(c, "int", *info[c])
+    for r0 in range(0, n, 20_000):
+        r1 = min(n, r0 + 20_000)
+        tb.append_block(r1 - r0, {c: ((cols[c][r0:r1], pop[r0:r1]) if c == "mid" else cols[c][r0:r1]) for c in cols})
+    tb.compact()
+    assert [tb.column_storage(c)[0] for c in cols] == [1, 2, 8, 1, 4]
+    assert tb.column_storage("edge")[1] == info["edge"][0]
+    names = list(cols)
+    ocols = [{"type": "int", "data": cols[c], **({"populated": pop} if c == "mid" else {})} for c in names]
+    for q in (dict(groups=["neg"], aggs=["mid", "v"], op="hist"),
+              dict(filters=[("mid", "gt", -10_000), ("big", "lt", 0)], groups=["edge"], aggs=["v"], op="avg"),
+              dict(filters=[("edge", "gt", (1 << 62) - 100)], aggs=["big", "mid"], op="avg"),
+              dict(groups=["mid"], aggs=["v"], op="avg")):
+        query = tb.query(**q)
+        r = query.run()
+        o = oracle.run_query(ocols, block_rows=20_000, **parity.oracle_query_kwargs(names, info, q))
+        parity.compare(r, o, op=q["op"], full=True, n_aggs=len(q["aggs"]))
+        r.free()
+        query.free()
+    tb.free()
+
+
+def test_append_after_compact_returns_to_canonical(ctx, oracle):
+    n = 50_000
+    rng = np.random.default_rng(5)
+    g = rng.integers(0, 10, size=n).astype(np.int64)
+    v = rng.integers(0, 1000, size=n).astype(np.int64)
+    tb = ctx.create_table("ap")
+    tb.add_column("g", "int")
+    tb.add_column("v", "int", 0, 5_000_000)
+    tb.append_block(n, {"g": g, "v": v})
+    tb.compact()
+    assert tb.column_storage("v")[0] == 2
+    query = tb.query(groups=["g"], aggs=["v"])
+    r = query.run()
+    r.free()
+    # values far outside the compact range arrive: storage goes back to int64, the old plan is stale
+    g2 = rng.integers(0, 10, size=n).astype(np.int64)
+    v2 = rng.integers(1_000_000, 5_000_000, size=n).astype(np.int64)
+    tb.append_block(n, {"g": g2, "v": v2})
+    assert tb.column_storage("v") == (8, 0)
+    with pytest.raises(sybil_amd.SyblError):
+        query.run()
+    query.free()
+    tb.compact()
+    assert tb.column_storage("v")[0] == 4
+    query = tb.query(groups=["g"], aggs=["v"], op="hist")
+    r = query.run()
+    o = oracle.run_query([{"type": "int", "data": np.concatenate([g, g2])}, {"type": "int", "data": np.concatenate([v, v2])}],
+                         groups=[0], aggs=[(1, 0, 5_000_000)], op="hist", block_rows=n)
+    parity.compare(r, o, op="hist", full=True, n_aggs=1)
+    r.free()
+    query.free()
+    tb.free()

@@ -83,6 +83,8 @@ def test_random_queries(ctx, oracle, seed):
     for r0 in range(0, n, block_rows):
         r1 = min(r0 + block_rows, n)
         tb.append_block(r1 - r0, {c: ((cols[c][r0:r1], pops[c][r0:r1]) if c in pops else cols[c][r0:r1]) for c in names})
+    if seed % 2:
+        tb.compact()  # odd seeds: compact storage (narrow offsets), same results expected
     ocols = [{"type": "int", "data": cols[c], **({"populated": pops[c]} if c in pops else {})} for c in names]
     seen = set()
     for k in range(6):
@@ -139,6 +141,8 @@ def test_random_queries_with_strings_and_sets(ctx, oracle, seed):
             "g": g[r0:r1], "v": v[r0:r1],
             "z": {"ids": np.array(flat, dtype=np.int32), "offsets": np.array(off, dtype=np.int64), "strings": tags,
                   "populated": set_pop[r0:r1]}})
+    if seed % 2:
+        tb.compact()
     off, flat = [0], []
     for r in range(n):
         flat += set_rows[r] if set_pop[r] else []
