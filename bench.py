@@ -79,6 +79,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rows", type=int, default=0, help="total rows (default: the workload's BASELINE size)")
     ap.add_argument("--workload", default="cfg3_filter3_group2_stddev")
+    ap.add_argument("--storage", choices=["canonical", "compact"], default="canonical",
+                    help="canonical: int64 per value (the reference's in-memory IntField); compact: sybl_table_compact "
+                         "(1/2/4-byte offsets from the column minimum)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the N>1 code path (process group, bound partial tables, all-reduce) even with one rank")
@@ -123,6 +126,8 @@ def main():
         kind, _, a, b, _, _ = synth.COLUMNS[n]
         hi = a + 4 * (b - 1) if kind == synth.BELL else a + b - 1
         table.set_bounds(n, a, hi)
+    if args.storage == "compact":
+        table.compact()
     query = table.query(**q)
     side = None
     if multi:

@@ -299,6 +299,7 @@ typedef struct {
     int32_t lds_bytes, n_workgroups, replicas;
     int32_t n_sum_fields;     /* int64 fields per cell in the SUM section */
     int32_t n_max_fields;     /* fields per cell in the MAX section; 0 = nothing to MAX-reduce */
+    int32_t packed_kernel;    /* 1: the scan ran k_scan_packed (compact storage, 32-bit offset domain) */
 } sybl_run_stats;
 /* Valid after the stream has been synchronised (sybl_query_finalize / sybl_ctx_sync). */
 int sybl_query_stats(sybl_query *q, sybl_run_stats *out);

@@ -129,19 +129,64 @@ static bool should_scan_block(const Table *t, const sybl_query_desc *d, int64_t 
     return true;
 }
 
+// k_scan_packed works on stored offsets: rebases filter bounds, key digits, bucket numerators and
+// the time value onto each column's base.  False when a quantity does not fit the 32-bit domain.
+static bool fill_packed(Table *t, Query *q, const std::vector<int> &slot_col, FastPlan &FP, int nf, int ng, int na) {
+    const ScanPlan &P = q->plan;
+    if (getenv("SYBL_NO_PACKED")) return false;
+    if (P.n_cells >= (1 << 24)) return false;  // 24-bit multiplies build the cell index
+    for (int c = 0; c < nf; c++) {
+        const __int128 umax = ((__int128)1 << (8 * FP.fwid[c])) - 1;
+        const __int128 L = (__int128)FP.lo[c] - FP.fbase[c], H = (__int128)FP.hi[c] - FP.fbase[c];
+        if (H < 0 || L > umax || L > H) {
+            FP.plo[c] = 1;
+            FP.phi[c] = 0;
+        } else {
+            FP.plo[c] = (uint32_t)(L < 0 ? 0 : L);
+            FP.phi[c] = (uint32_t)(H > umax ? umax : H);
+        }
+    }
+    for (int c = 0; c < ng; c++) FP.gdoff[c] = (uint32_t)((uint64_t)FP.gbase[c] - (uint64_t)FP.gmin[c]);
+    const double shave = 1.0 - 1.0 / (double)((int64_t)1 << 40);
+    for (int c = 0; c < na; c++) {
+        FP.adoff[c] = (uint32_t)((uint64_t)FP.abase[c] - (uint64_t)FP.hmin[c]);
+        FP.pinv_bucket[c] = FP.bucket_size[c] ? (1.0 / (double)FP.bucket_size[c]) * shave : 0.0;
+    }
+    if (q->time_mode) {
+        const SlotDesc &ts = P.slot[P.time_slot];
+        const Column *tc = t->cols[(size_t)slot_col[(size_t)P.time_slot]].get();
+        if (P.tb_big_div || P.time_bucket >= ((int64_t)1 << 32)) return false;
+        if (tc->n_pop > 0 && tc->exact_min < 0) return false;  // truncation == floor only for val >= 0
+        const __int128 t0 = (__int128)P.tb_min * P.time_bucket;
+        const __int128 off = (__int128)ts.vbase - t0;
+        // offsets are at most exact_max - vbase: the rebased time value stays below 2^32
+        const __int128 top = tc->n_pop > 0 ? (__int128)tc->exact_max - t0 : off;
+        if (off < 0 || top >= ((__int128)1 << 32)) return false;
+        FP.tdoff = (uint32_t)off;
+        FP.pinv_time = (1.0 / (double)P.time_bucket) * shave;
+    }
+    return true;
+}
+
 // Fills the column / filter / group / bucket part of a FastPlan when the query has the shape the
 // role-specialised kernels cover: <= 4 range-filter, <= 2 group, <= 2 aggregation columns, all
 // fully populated int64, one role per column, no rejects / outliers / minima to track.
 static bool fill_fast_columns(Table *t, Query *q, const std::vector<int> &slot_col, FastPlan &FP, int *pnf, int *png,
-                              int *pna, bool *any_max, bool *all_max, bool allow_gen, bool *gen) {
+                              int *pna, bool *any_max, bool *all_max, bool allow_gen, bool *gen, bool *packed = nullptr) {
     const ScanPlan &P = q->plan;
     memset(&FP, 0, sizeof(FP));
     int nf = 0, ng = 0, na = 0;
     *gen = false;
+    // compact storage: k_scan_packed when every column is a plain int column of <= 4 stored bytes,
+    // else the GEN kernels (any width); the plain kernels read canonical int64 only
+    bool any_packed = false, all_narrow = true;
+    if (packed) *packed = false;
     for (size_t s = 0; s < slot_col.size(); s++) {
         const SlotDesc &sd = P.slot[s];
         const Column *c = t->cols[(size_t)slot_col[s]].get();
-        bool plain = c->type == SYBL_INT_VAL && !c->packed() && !c->d_valid && !c->has_missing;
+        bool plain = c->type == SYBL_INT_VAL && !c->d_valid && !c->has_missing;
+        any_packed = any_packed || c->packed();
+        all_narrow = all_narrow && c->elem <= 4;
         if (!plain) {
             // GEN kernels: int columns with missing rows in any role, str columns as group keys
             if (!allow_gen) return false;
@@ -261,6 +306,15 @@ static bool fill_fast_columns(Table *t, Query *q, const std::vector<int> &slot_c
     *pnf = nf;
     *png = ng;
     *pna = na;
+    if (any_packed) {
+        if (!*gen && all_narrow && packed && fill_packed(t, q, slot_col, FP, nf, ng, na)) {
+            *packed = true;
+        } else if (allow_gen) {
+            *gen = true;
+        } else {
+            return false;
+        }
+    }
     return true;
 }
 
@@ -273,8 +327,9 @@ static void select_fast_path(Table *t, Query *q, const std::vector<int> &slot_co
     if (q->time_mode && P.tb_big_div) return;
     FastPlan &FP = q->fplan;
     int nf, ng, na;
-    bool any_max, all_max, gen;
-    if (!fill_fast_columns(t, q, slot_col, FP, &nf, &ng, &na, &any_max, &all_max, !getenv("SYBL_NO_FASTGEN"), &gen)) return;
+    bool any_max, all_max, gen, packed = false;
+    q->fast_packed = false;
+    if (!fill_fast_columns(t, q, slot_col, FP, &nf, &ng, &na, &any_max, &all_max, !getenv("SYBL_NO_FASTGEN"), &gen, &packed)) return;
     if (q->op == SYBL_AGG_HIST && any_max && !gen) return;
     if (q->weighted && q->op == SYBL_AGG_HIST && q->want_percentiles) return;  // weighted bucket increments: generic kernel
     q->fast_gen = gen;
@@ -313,6 +368,7 @@ static void select_fast_path(Table *t, Query *q, const std::vector<int> &slot_co
         }
     }
     q->fast = true;
+    q->fast_packed = packed;
     q->fast_nf = nf;
     q->fast_ng = ng;
     q->fast_na = na;
@@ -329,8 +385,10 @@ static int select_part_hist(Table *t, Query *q, const std::vector<int> &slot_col
     if (q->fast && q->fplan.hist_lds) return SYBL_OK;  // the bucket arrays already live in LDS
     EmitPlan &E = q->eplan;
     int nf, ng, na;
-    bool any_max, all_max, gen;
-    if (!fill_fast_columns(t, q, slot_col, E.fp, &nf, &ng, &na, &any_max, &all_max, false, &gen)) return SYBL_OK;
+    bool any_max, all_max, gen, packed = false;
+    if (!fill_fast_columns(t, q, slot_col, E.fp, &nf, &ng, &na, &any_max, &all_max, false, &gen, &packed)) return SYBL_OK;
+    q->part_packed = packed;
+    const int tile_rows = packed ? kPackedTileRows : kTileRows;
     int rb = 0;
     for (auto &ai : q->aggs) {
         if (ai.d.n_values > (1 << kBucketBits)) return SYBL_OK;
@@ -365,7 +423,7 @@ static int select_part_hist(Table *t, Query *q, const std::vector<int> &slot_col
         E.sub_shift = ss;
         E.slots = (int32_t)std::min<int64_t>(8191, std::max<int64_t>(15, (kEmitLdsWords - bins) / bins));
         // records per bin per tile if every row matched
-        double per_tile = (double)kTileRows * na / (double)bins;
+        double per_tile = (double)tile_rows * na / (double)bins;
         int64_t period = (int64_t)((double)E.slots / (4.0 * std::max(per_tile, 0.25)));
         if (const char *e = getenv("SYBL_EMIT_FLUSH_PERIOD")) period = atoi(e);
         E.flush_period = (int32_t)std::min<int64_t>(8, std::max<int64_t>(1, period));
@@ -990,6 +1048,7 @@ struct Planner {
         q->stats.algorithmic_bytes = rows_scanned * width + set_bytes;
         q->stats.canonical_bytes = rows_scanned * canon_width + set_bytes;
         q->stats.n_cells = (int32_t)n_cells;
+        q->stats.packed_kernel = q->part_hist ? q->part_packed : (q->fast && q->fast_packed);
         q->stats.strategy = q->part_hist ? 5 : (q->use_lds ? (P.windowed ? (q->fast ? 4 : 3) : (q->fast ? (q->fplan.hist_lds ? 6 : 2) : 0)) : 1);
         q->stats.lds_bytes = (int32_t)q->lds_bytes;
         q->stats.n_workgroups = q->n_wg;
@@ -1089,7 +1148,8 @@ static int scan(Query *q) {
         q->eplan.sum_out = q->d_sum;
         q->pplan.sum_out = q->d_sum;
         q->pplan.max_out = q->d_max;
-        e = launch_emit(q->eplan, q->part_nf, q->part_ng, q->part_na, q->n_wg, st);
+        e = q->part_packed ? launch_emit_packed(q->eplan, q->part_nf, q->part_ng, q->part_na, q->n_wg, st)
+                           : launch_emit(q->eplan, q->part_nf, q->part_ng, q->part_na, q->n_wg, st);
         if (e != hipSuccess) return hip_fail(e, "k_emit");
         e = launch_part_hist(q->pplan, st);
         if (e != hipSuccess) return hip_fail(e, "k_part_hist");
@@ -1113,9 +1173,13 @@ static int scan(Query *q) {
         if (q->fast) {
             q->fplan.sum_out = q->d_sum;
             q->fplan.max_out = q->d_max;
-            e = launch_scan_fast(q->fplan, q->fast_nf, q->fast_ng, q->fast_na, q->fast_mode, q->time_mode, q->fast_gen, q->n_wg,
-                                 q->lds_bytes, st);
-            if (e != hipSuccess) return hip_fail(e, "k_scan_fast");
+            if (q->fast_packed) {
+                e = launch_scan_packed(q->fplan, q->fast_nf, q->fast_ng, q->fast_na, q->fast_mode, q->time_mode, q->n_wg, q->lds_bytes, st);
+            } else {
+                e = launch_scan_fast(q->fplan, q->fast_nf, q->fast_ng, q->fast_na, q->fast_mode, q->time_mode, q->fast_gen, q->n_wg,
+                                     q->lds_bytes, st);
+            }
+            if (e != hipSuccess) return hip_fail(e, q->fast_packed ? "k_scan_packed" : "k_scan_fast");
         } else {
             e = launch_scan(q->d_plan, P.n_slots, q->n_wg, q->use_lds, q->lds_bytes, st);
             if (e != hipSuccess) return hip_fail(e, "k_scan");
@@ -1135,6 +1199,7 @@ static int scan(Query *q) {
 // A partition buffer overflowed (badly skewed keys): redo the scan with per-value atomics.
 int query_rescan_without_part_hist(Query *q) {
     q->part_hist = false;
+    q->stats.packed_kernel = q->fast && q->fast_packed;
     q->stats.strategy = q->use_lds ? (q->plan.windowed ? (q->fast ? 4 : 3) : (q->fast ? 2 : 0)) : 1;
     return scan(q);
 }

@@ -12,6 +12,7 @@
 #include "../../include/sybilgpu.h"
 #include "plan.h"
 #include "scan_fast.h"
+#include "scan_packed.h"
 
 namespace sybl {
 
@@ -203,11 +204,11 @@ struct Query {
     sybl_run_stats stats{};
     bool never_matches = false;
     // role-specialised kernel (scan_fast.h)
-    bool fast = false, fast_gen = false;
+    bool fast = false, fast_gen = false, fast_packed = false;
     int fast_nf = 0, fast_ng = 0, fast_na = 0, fast_mode = 0;
     FastPlan fplan;
     // partitioned histograms (strategy 5)
-    bool part_hist = false;
+    bool part_hist = false, part_packed = false;
     int part_nf = 0, part_ng = 0, part_na = 0;
     EmitPlan eplan;
     PartHistPlan pplan;

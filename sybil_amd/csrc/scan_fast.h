@@ -67,6 +67,14 @@ struct FastPlan {
     // (canonical int64 columns: width 8, base 0 -- loaded as they are)
     int32_t fwid[kFastMaxF], gwid[kFastMaxG], awid[kFastMaxA], twid, wwid;
     int64_t fbase[kFastMaxF], gbase[kFastMaxG], abase[kFastMaxA], tbase, wbase;
+    // k_scan_packed (scan_packed.h) works on the stored offsets: filter bounds, key digits, bucket
+    // numerators and the time value rebased by the planner
+    uint32_t plo[kFastMaxF], phi[kFastMaxF];   // offset range that passes (plo > phi: nothing does)
+    uint32_t gdoff[kFastMaxG];                 // gbase - gmin   (mod 2^32)
+    uint32_t adoff[kFastMaxA];                 // abase - h.Min  (mod 2^32)
+    uint32_t tdoff;                            // tbase - tb_min * time_bucket
+    int32_t pad3_;
+    double pinv_bucket[kFastMaxA], pinv_time;  // reciprocals scaled by (1 - 2^-40): never above the true quotient
     const int32_t *wg_cell_base;
     int64_t *sum_out, *max_out, *ws_sum, *ws_max;
     const Segment *segs;
@@ -335,23 +343,106 @@ __device__ __forceinline__ void fast_row(const FastPlan &P, const FastTile<NF> &
     }
 }
 
+// LDS layout of one workgroup: [sum fields][max fields][uint32 bucket arrays (hist_lds)], every
+// field replicated 1 << rep_shift times per cell.
+struct FastLds {
+    uint32_t tab_cells, words_sum, words_max, max_base, cell_base, hist_words, rep;
+    uint32_t *hist32;
+};
+
+template <int MODE>
+__device__ __forceinline__ FastLds fast_begin(const FastPlan &P, int64_t *lds) {
+    FastLds L;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t R = 1u << P.rep_shift;
+    L.tab_cells = (uint32_t)P.lds_cells;
+    L.words_sum = (uint32_t)P.n_sum_fields * L.tab_cells;
+    L.words_max = (uint32_t)P.n_max_fields * L.tab_cells;
+    L.max_base = L.words_sum << P.rep_shift;
+    L.cell_base = P.windowed ? (uint32_t)P.wg_cell_base[blockIdx.x] : 0u;
+    for (uint32_t i = tid; i < L.words_sum * R; i += kWgThreads) lds[i] = 0;
+    for (uint32_t i = tid; i < L.words_max * R; i += kWgThreads) lds[L.max_base + i] = INT64_MIN;
+    L.hist32 = (uint32_t *)(lds + L.max_base + (L.words_max << P.rep_shift));
+    L.hist_words = (MODE == kFastHist && P.hist_lds) ? L.tab_cells * (uint32_t)P.hist_stride : 0u;
+    for (uint32_t i = tid; i < L.hist_words; i += kWgThreads) L.hist32[i] = 0;
+    L.rep = tid & (R - 1);
+    __syncthreads();
+    return L;
+}
+
+// Publishes the workgroup's results: matched / overflow counters, LDS bucket arrays, and the cell
+// table -- flushed with atomics (LDS window) or stored to the workgroup's slice for k_fold.
+__device__ __forceinline__ void fast_finish(const FastPlan &P, int64_t *lds, const FastLds &L, uint32_t matched, uint32_t overflow) {
+    const uint32_t tid = threadIdx.x;
+    const uint32_t R = 1u << P.rep_shift;
+    const uint32_t words_sum = L.words_sum, words_max = L.words_max, max_base = L.max_base, tab_cells = L.tab_cells;
+    // matched rows: one add per wave (64-wide butterfly)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        matched += __shfl_xor(matched, o, 64);
+        overflow += __shfl_xor(overflow, o, 64);
+    }
+    if ((tid & 63) == 0) {
+        if (matched) __hip_atomic_fetch_add(P.sum_out + kHdrMatched, (int64_t)matched, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (overflow) __hip_atomic_fetch_add(P.sum_out + kHdrOverflow, (int64_t)overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+
+    __syncthreads();
+    // LDS bucket arrays: one atomic per touched bucket per workgroup into the zeroed global table
+    for (uint32_t i = tid; i < L.hist_words; i += kWgThreads) {
+        const uint32_t x = L.hist32[i];
+        if (x) __hip_atomic_fetch_add(P.sum_out + P.hist_off + (int64_t)L.cell_base * P.hist_stride + i, (int64_t)x, __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (P.windowed) {
+        // flush the touched cells of this workgroup's window into the global table
+        int64_t *gs = P.sum_out + kHeaderWords;
+        for (uint32_t i = tid; i < words_sum; i += kWgThreads) {
+            int64_t acc = 0;
+            for (uint32_t k = 0; k < R; k++) acc += lds[(i << P.rep_shift) + k];
+            if (acc != 0) {
+                const uint32_t fi = i / tab_cells, c = i - fi * tab_cells;
+                __hip_atomic_fetch_add(gs + (int64_t)fi * P.n_cells + L.cell_base + c, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        for (uint32_t i = tid; i < words_max; i += kWgThreads) {
+            int64_t acc = INT64_MIN;
+            for (uint32_t k = 0; k < R; k++) {
+                const int64_t b = lds[max_base + (i << P.rep_shift) + k];
+                acc = b > acc ? b : acc;
+            }
+            if (acc != INT64_MIN) {
+                const uint32_t fi = i / tab_cells, c = i - fi * tab_cells;
+                __hip_atomic_fetch_max(P.max_out + (int64_t)fi * P.n_cells + L.cell_base + c, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        return;
+    }
+    // fold the lane replicas and publish this workgroup's table (plain stores)
+    int64_t *ws = P.ws_sum + (int64_t)blockIdx.x * words_sum;
+    for (uint32_t i = tid; i < words_sum; i += kWgThreads) {
+        int64_t acc = 0;
+        for (uint32_t k = 0; k < R; k++) acc += lds[(i << P.rep_shift) + k];
+        ws[i] = acc;
+    }
+    int64_t *wm = P.ws_max + (int64_t)blockIdx.x * words_max;
+    for (uint32_t i = tid; i < words_max; i += kWgThreads) {
+        int64_t acc = INT64_MIN;
+        for (uint32_t k = 0; k < R; k++) {
+            const int64_t b = lds[max_base + (i << P.rep_shift) + k];
+            acc = b > acc ? b : acc;
+        }
+        wm[i] = acc;
+    }
+}
+
 template <int NF, int NG, int NA, int MODE, bool TIME, bool GEN>
 __global__ __launch_bounds__(kWgThreads, 4) void k_scan_fast(const FastPlan P) {
     extern __shared__ int64_t lds[];
     const uint32_t tid = threadIdx.x;
-    const uint32_t R = 1u << P.rep_shift;
-    const uint32_t tab_cells = (uint32_t)P.lds_cells;
-    const uint32_t words_sum = (uint32_t)P.n_sum_fields * tab_cells;
-    const uint32_t words_max = (uint32_t)P.n_max_fields * tab_cells;
-    const uint32_t max_base = words_sum << P.rep_shift;
-    const uint32_t cell_base = P.windowed ? (uint32_t)P.wg_cell_base[blockIdx.x] : 0u;
-    for (uint32_t i = tid; i < words_sum * R; i += kWgThreads) lds[i] = 0;
-    for (uint32_t i = tid; i < words_max * R; i += kWgThreads) lds[max_base + i] = INT64_MIN;
-    uint32_t *hist32 = (uint32_t *)(lds + max_base + (words_max << P.rep_shift));
-    const uint32_t hist_words = (MODE == kFastHist && P.hist_lds) ? tab_cells * (uint32_t)P.hist_stride : 0u;
-    for (uint32_t i = tid; i < hist_words; i += kWgThreads) hist32[i] = 0;
-    const uint32_t rep = tid & (R - 1);
-    __syncthreads();
+    const FastLds L = fast_begin<MODE>(P, lds);
+    const uint32_t rep = L.rep, max_base = L.max_base, cell_base = L.cell_base;
+    uint32_t *hist32 = L.hist32;
 
     uint32_t matched = 0, overflow = 0;
     const int s0 = P.wg_seg_begin[blockIdx.x], s1 = P.wg_seg_begin[blockIdx.x + 1];
@@ -378,122 +469,113 @@ __global__ __launch_bounds__(kWgThreads, 4) void k_scan_fast(const FastPlan P) {
             w0 = w1;
         }
     }
-
-    // matched rows: one add per wave (64-wide butterfly)
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        matched += __shfl_xor(matched, o, 64);
-        overflow += __shfl_xor(overflow, o, 64);
-    }
-    if ((tid & 63) == 0) {
-        if (matched) __hip_atomic_fetch_add(P.sum_out + kHdrMatched, (int64_t)matched, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (overflow) __hip_atomic_fetch_add(P.sum_out + kHdrOverflow, (int64_t)overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-
-    __syncthreads();
-    // LDS bucket arrays: one atomic per touched bucket per workgroup into the zeroed global table
-    for (uint32_t i = tid; i < hist_words; i += kWgThreads) {
-        const uint32_t x = hist32[i];
-        if (x) __hip_atomic_fetch_add(P.sum_out + P.hist_off + (int64_t)cell_base * P.hist_stride + i, (int64_t)x, __ATOMIC_RELAXED,
-                                     __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (P.windowed) {
-        // flush the touched cells of this workgroup's window into the global table
-        int64_t *gs = P.sum_out + kHeaderWords;
-        for (uint32_t i = tid; i < words_sum; i += kWgThreads) {
-            int64_t acc = 0;
-            for (uint32_t k = 0; k < R; k++) acc += lds[(i << P.rep_shift) + k];
-            if (acc != 0) {
-                const uint32_t fi = i / tab_cells, c = i - fi * tab_cells;
-                __hip_atomic_fetch_add(gs + (int64_t)fi * P.n_cells + cell_base + c, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-        for (uint32_t i = tid; i < words_max; i += kWgThreads) {
-            int64_t acc = INT64_MIN;
-            for (uint32_t k = 0; k < R; k++) {
-                const int64_t b = lds[max_base + (i << P.rep_shift) + k];
-                acc = b > acc ? b : acc;
-            }
-            if (acc != INT64_MIN) {
-                const uint32_t fi = i / tab_cells, c = i - fi * tab_cells;
-                __hip_atomic_fetch_max(P.max_out + (int64_t)fi * P.n_cells + cell_base + c, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-        return;
-    }
-    // fold the lane replicas and publish this workgroup's table (plain stores)
-    int64_t *ws = P.ws_sum + (int64_t)blockIdx.x * words_sum;
-    for (uint32_t i = tid; i < words_sum; i += kWgThreads) {
-        int64_t acc = 0;
-        for (uint32_t k = 0; k < R; k++) acc += lds[(i << P.rep_shift) + k];
-        ws[i] = acc;
-    }
-    int64_t *wm = P.ws_max + (int64_t)blockIdx.x * words_max;
-    for (uint32_t i = tid; i < words_max; i += kWgThreads) {
-        int64_t acc = INT64_MIN;
-        for (uint32_t k = 0; k < R; k++) {
-            const int64_t b = lds[max_base + (i << P.rep_shift) + k];
-            acc = b > acc ? b : acc;
-        }
-        wm[i] = acc;
-    }
+    fast_finish(P, lds, L, matched, overflow);
 }
 
 // k_emit: filters + cell index exactly as k_scan_fast, but instead of accumulating it appends
 // rec = (local pair << 10 | bucket) << rem_bits | remainder to the owning partition.  Records are
 // staged in LDS bins (E.slots per partition) and flushed in runs so that the global cursor
 // sees one atomic per run instead of one per record.
+// LDS staging of k_emit / k_emit_packed: bin_cnt[np] counters + bins[np][slots] records, np =
+// n_parts << sub_shift bins.
+struct EmitLds {
+    uint32_t *bin_cnt, *bins;
+    uint32_t np, slots, ss, sub;
+};
+
+__device__ __forceinline__ EmitLds emit_begin(const EmitPlan &E, uint32_t *elds) {
+    EmitLds S;
+    const uint32_t tid = threadIdx.x;
+    S.ss = (uint32_t)E.sub_shift;
+    S.np = (uint32_t)E.n_parts << S.ss;     // staging bins
+    S.sub = tid & ((1u << S.ss) - 1);        // this lane's sub-bin
+    S.slots = (uint32_t)E.slots;
+    S.bin_cnt = elds;                        // [np]
+    S.bins = elds + S.np;                    // [np][slots]
+    for (uint32_t i = tid; i < S.np; i += kWgThreads) S.bin_cnt[i] = 0;
+    __syncthreads();
+    return S;
+}
+
+// Flushes every bin holding >= min_fill records as ONE run: a single cursor bump, then a
+// contiguous copy.  Small bins (many partitions) are copied by one thread each; big bins (few
+// partitions) by a whole wave so the copy is coalesced.
+__device__ __forceinline__ void emit_flush(const EmitPlan &E, const EmitLds &S, uint32_t min_fill) {
+    const uint32_t tid = threadIdx.x, np = S.np, slots = S.slots, ss = S.ss;
+    uint32_t *bin_cnt = S.bin_cnt, *bins = S.bins;
+    if (slots <= 32) {
+        for (uint32_t p = tid; p < np; p += kWgThreads) {
+            uint32_t n = bin_cnt[p];
+            if (n > slots) n = slots;
+            if (n == 0 || n < min_fill) continue;
+            const uint32_t pos = __hip_atomic_fetch_add(E.cursor + (p >> ss) * kCursorStride, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((int64_t)pos + n <= E.part_cap) {
+                uint32_t *dst = E.recs + (int64_t)(p >> ss) * E.part_cap + pos;
+                for (uint32_t k = 0; k < n; k++) dst[k] = bins[p * slots + k];
+            } else {
+                __hip_atomic_fetch_add(E.sum_out + kHdrPartOverflow, (int64_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            bin_cnt[p] = 0;
+        }
+    } else {
+        const uint32_t lane = tid & 63, wave = tid >> 6;
+        for (uint32_t p = wave; p < np; p += kWgThreads / 64) {
+            uint32_t n = bin_cnt[p];
+            if (n > slots) n = slots;
+            if (n == 0 || n < min_fill) continue;  // wave-uniform
+            uint32_t pos = 0;
+            if (lane == 0) pos = __hip_atomic_fetch_add(E.cursor + (p >> ss) * kCursorStride, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            pos = __shfl(pos, 0, 64);
+            if ((int64_t)pos + n <= E.part_cap) {
+                uint32_t *dst = E.recs + (int64_t)(p >> ss) * E.part_cap + pos;
+                for (uint32_t k = lane; k < n; k += 64) dst[k] = bins[p * slots + k];
+            } else if (lane == 0) {
+                __hip_atomic_fetch_add(E.sum_out + kHdrPartOverflow, (int64_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (lane == 0) bin_cnt[p] = 0;
+        }
+    }
+}
+
+// One record for (cell, aggregation c) with bucket b and remainder rem: staged in the lane's
+// sub-bin of the owning partition, or appended directly when the bin is full until the next flush.
+__device__ __forceinline__ void emit_push(const EmitPlan &E, const EmitLds &S, uint32_t pair, uint32_t b, uint32_t rem, int rem_bits) {
+    const uint32_t part = pair >> kPartCellBits;
+    const uint32_t rec = ((((pair & (kPartCells - 1)) << kBucketBits) | b) << rem_bits) | rem;
+    const uint32_t bin = (part << S.ss) | S.sub;
+    const uint32_t slot = __hip_atomic_fetch_add(S.bin_cnt + bin, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (slot < S.slots) {
+        S.bins[bin * S.slots + slot] = rec;
+    } else {
+        const uint32_t pos = __hip_atomic_fetch_add(E.cursor + part * kCursorStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((int64_t)pos < E.part_cap) {
+            E.recs[(int64_t)part * E.part_cap + pos] = rec;
+        } else {
+            __hip_atomic_fetch_add(E.sum_out + kHdrPartOverflow, (int64_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+__device__ __forceinline__ void emit_finish(const EmitPlan &E, const EmitLds &S, uint32_t matched, uint32_t overflow) {
+    __syncthreads();
+    emit_flush(E, S, 1);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        matched += __shfl_xor(matched, o, 64);
+        overflow += __shfl_xor(overflow, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (matched) __hip_atomic_fetch_add(E.sum_out + kHdrMatched, (int64_t)matched, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (overflow) __hip_atomic_fetch_add(E.sum_out + kHdrOverflow, (int64_t)overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 template <int NF, int NG, int NA>
 __global__ __launch_bounds__(kWgThreads, 4) void k_emit(const EmitPlan E) {
     extern __shared__ uint32_t elds[];
     const FastPlan &P = E.fp;
     const uint32_t tid = threadIdx.x;
-    const uint32_t ss = (uint32_t)E.sub_shift;
-    const uint32_t np = (uint32_t)E.n_parts << ss;   // staging bins
-    const uint32_t sub = tid & ((1u << ss) - 1);      // this lane's sub-bin
-    const uint32_t slots = (uint32_t)E.slots;
-    uint32_t *bin_cnt = elds;                 // [np]
-    uint32_t *bins = elds + np;               // [np][slots]
-    for (uint32_t i = tid; i < np; i += kWgThreads) bin_cnt[i] = 0;
-    __syncthreads();
-
-    // Flushes every bin holding >= min_fill records as ONE run: a single cursor bump, then a
-    // contiguous copy.  Small bins (many partitions) are copied by one thread each; big bins (few
-    // partitions) by a whole wave so the copy is coalesced.
-    auto flush = [&](uint32_t min_fill) {
-        if (slots <= 32) {
-            for (uint32_t p = tid; p < np; p += kWgThreads) {
-                uint32_t n = bin_cnt[p];
-                if (n > slots) n = slots;
-                if (n == 0 || n < min_fill) continue;
-                const uint32_t pos = __hip_atomic_fetch_add(E.cursor + (p >> ss) * kCursorStride, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((int64_t)pos + n <= E.part_cap) {
-                    uint32_t *dst = E.recs + (int64_t)(p >> ss) * E.part_cap + pos;
-                    for (uint32_t k = 0; k < n; k++) dst[k] = bins[p * slots + k];
-                } else {
-                    __hip_atomic_fetch_add(E.sum_out + kHdrPartOverflow, (int64_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                bin_cnt[p] = 0;
-            }
-        } else {
-            const uint32_t lane = tid & 63, wave = tid >> 6;
-            for (uint32_t p = wave; p < np; p += kWgThreads / 64) {
-                uint32_t n = bin_cnt[p];
-                if (n > slots) n = slots;
-                if (n == 0 || n < min_fill) continue;  // wave-uniform
-                uint32_t pos = 0;
-                if (lane == 0) pos = __hip_atomic_fetch_add(E.cursor + (p >> ss) * kCursorStride, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                pos = __shfl(pos, 0, 64);
-                if ((int64_t)pos + n <= E.part_cap) {
-                    uint32_t *dst = E.recs + (int64_t)(p >> ss) * E.part_cap + pos;
-                    for (uint32_t k = lane; k < n; k += 64) dst[k] = bins[p * slots + k];
-                } else if (lane == 0) {
-                    __hip_atomic_fetch_add(E.sum_out + kHdrPartOverflow, (int64_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                if (lane == 0) bin_cnt[p] = 0;
-            }
-        }
-    };
+    const EmitLds S = emit_begin(E, elds);
 
     uint32_t matched = 0, overflow = 0;
     const int s0 = P.wg_seg_begin[blockIdx.x], s1 = P.wg_seg_begin[blockIdx.x + 1];
@@ -548,22 +630,7 @@ __global__ __launch_bounds__(kWgThreads, 4) void k_emit(const EmitPlan E) {
                         b += 1;
                         rem -= (int32_t)P.bucket_size[c];
                     }
-                    const uint32_t pair = cell * (uint32_t)NA + (uint32_t)c;
-                    const uint32_t part = pair >> kPartCellBits;
-                    const uint32_t rec = ((((pair & (kPartCells - 1)) << kBucketBits) | b) << E.rem_bits[c]) | (uint32_t)rem;
-                    const uint32_t bin = (part << ss) | sub;
-                    const uint32_t slot = __hip_atomic_fetch_add(bin_cnt + bin, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if (slot < slots) {
-                        bins[bin * slots + slot] = rec;
-                    } else {
-                        // the bin is full until the next flush: append this record directly
-                        const uint32_t pos = __hip_atomic_fetch_add(E.cursor + part * kCursorStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if ((int64_t)pos < E.part_cap) {
-                            E.recs[(int64_t)part * E.part_cap + pos] = rec;
-                        } else {
-                            __hip_atomic_fetch_add(E.sum_out + kHdrPartOverflow, (int64_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        }
-                    }
+                    emit_push(E, S, cell * (uint32_t)NA + (uint32_t)c, b, (uint32_t)rem, E.rem_bits[c]);
                 }
             }
             f0 = f1;
@@ -573,23 +640,12 @@ __global__ __launch_bounds__(kWgThreads, 4) void k_emit(const EmitPlan E) {
             // flush_period tiles; a bin that fills up earlier spills record by record
             if ((it + 1) % E.flush_period == 0 || it + 1 == n_tiles) {
                 __syncthreads();
-                flush(slots / 2);
+                emit_flush(E, S, S.slots / 2);
                 __syncthreads();
             }
         }
     }
-    __syncthreads();
-    flush(1);
-
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        matched += __shfl_xor(matched, o, 64);
-        overflow += __shfl_xor(overflow, o, 64);
-    }
-    if ((tid & 63) == 0) {
-        if (matched) __hip_atomic_fetch_add(E.sum_out + kHdrMatched, (int64_t)matched, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (overflow) __hip_atomic_fetch_add(E.sum_out + kHdrOverflow, (int64_t)overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    emit_finish(E, S, matched, overflow);
 }
 
 template <int NF>

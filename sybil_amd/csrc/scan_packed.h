@@ -1,0 +1,391 @@
+// scan_packed.h -- the role-specialised scan over COMPACT storage (sybl_table_compact).
+//
+// Columns stored as 1 / 2 / 4-byte unsigned offsets from the column minimum make the scan of the
+// common shape 2-4x lighter on HBM, which moves the bound from the memory system to instruction
+// issue and LDS atomics.  k_scan_packed therefore works in the 32-bit OFFSET domain end to end:
+//   * four consecutive rows per lane and tile: one 4 / 8 / 16-byte load per column (1 / 2 / 4-byte
+//     values), fully coalesced across the wave, next tile in flight while this one is consumed;
+//   * filters compare the raw offset against bounds the planner rebased (filter.go:171-195);
+//   * the group digit is offset + (base - gmin), one 24-bit multiply-add per key column
+//     (aggregate.go:125-143 as a direct-mapped cell index);
+//   * the histogram bucket is (offset + (base - h.Min)) / BucketSize (hist_basic.go:130); the 64-bit
+//     value is only rebuilt for the exact sum.
+// Cell table, LDS layout, publication and fold are those of k_scan_fast (scan_fast.h), so the
+// all-reduce and finalize do not care which kernel ran.
+#pragma once
+#include "scan_fast.h"
+
+namespace sybl {
+
+constexpr int kPackedRows = 4;                                // rows per lane and tile
+constexpr int kPackedTileRows = kWgThreads * kPackedRows;
+
+hipError_t launch_scan_packed(const FastPlan &P, int nf, int ng, int na, int mode, bool time, int n_wg, size_t lds_bytes,
+                              hipStream_t st);
+hipError_t launch_emit_packed(const EmitPlan &E, int nf, int ng, int na, int n_wg, hipStream_t st);
+hipError_t launch_emit_packed_nf0(const EmitPlan &E, int ng, int na, int n_wg, hipStream_t st);
+hipError_t launch_emit_packed_nf1(const EmitPlan &E, int ng, int na, int n_wg, hipStream_t st);
+hipError_t launch_emit_packed_nf2(const EmitPlan &E, int ng, int na, int n_wg, hipStream_t st);
+hipError_t launch_emit_packed_nf3(const EmitPlan &E, int ng, int na, int n_wg, hipStream_t st);
+hipError_t launch_emit_packed_nf4(const EmitPlan &E, int ng, int na, int n_wg, hipStream_t st);
+hipError_t launch_scan_packed_nf0(const FastPlan &P, int ng, int na, int mode, bool time, int n_wg, size_t lds, hipStream_t st);
+hipError_t launch_scan_packed_nf1(const FastPlan &P, int ng, int na, int mode, bool time, int n_wg, size_t lds, hipStream_t st);
+hipError_t launch_scan_packed_nf2(const FastPlan &P, int ng, int na, int mode, bool time, int n_wg, size_t lds, hipStream_t st);
+hipError_t launch_scan_packed_nf3(const FastPlan &P, int ng, int na, int mode, bool time, int n_wg, size_t lds, hipStream_t st);
+hipError_t launch_scan_packed_nf4(const FastPlan &P, int ng, int na, int mode, bool time, int n_wg, size_t lds, hipStream_t st);
+
+#ifdef __HIPCC__
+
+typedef unsigned int pu32x4 __attribute__((ext_vector_type(4)));
+
+template <int N>
+struct PackedTile {
+    uint32_t u[N > 0 ? N : 1][kPackedRows];  // stored offsets (value - column base), zero-extended
+};
+
+template <int N>
+struct PackedRaw {
+    pu32x4 v[N > 0 ? N : 1];  // the loaded bytes of four rows: 1 / 2 / 4 dwords are meaningful
+};
+
+// Issues the load of four consecutive rows of one column.  `col` is the (wave-uniform) address of
+// the chunk's first row and `r` the lane's row inside the chunk, so the address is an SGPR pair plus
+// a 32-bit VGPR offset.  The instruction is the same 16-byte load for every stored width -- a
+// narrower column simply over-reads into its neighbours' rows (same cache lines, no extra HBM
+// traffic; the arrays carry a tile of slack) -- so issuing needs no branch and nothing here waits
+// for the data: the width only matters when the registers are decoded.
+typedef pu32x4 pu32x4_a4 __attribute__((aligned(4)));
+
+__device__ __forceinline__ void packed_issue(const uint8_t *col, int wshift, uint32_t r, pu32x4 &raw) {
+    raw = __builtin_nontemporal_load((const pu32x4_a4 *)(col + (size_t)(r << wshift)));
+}
+
+__device__ __forceinline__ void packed_decode(int width, const pu32x4 &raw, uint32_t (&u)[kPackedRows]) {
+    if (width == 4) {
+        u[0] = raw.x;
+        u[1] = raw.y;
+        u[2] = raw.z;
+        u[3] = raw.w;
+    } else if (width == 2) {
+        u[0] = raw.x & 0xFFFFu;
+        u[1] = raw.x >> 16;
+        u[2] = raw.y & 0xFFFFu;
+        u[3] = raw.y >> 16;
+    } else {
+        u[0] = raw.x & 0xFFu;
+        u[1] = (raw.x >> 8) & 0xFFu;
+        u[2] = (raw.x >> 16) & 0xFFu;
+        u[3] = raw.x >> 24;
+    }
+}
+
+// chunk-relative column addresses (wave-uniform)
+template <int NF, int NG, int NA>
+struct PackedBases {
+    const uint8_t *f[NF > 0 ? NF : 1], *g[NG > 0 ? NG : 1], *a[NA > 0 ? NA : 1], *t;
+};
+
+template <int NF, int NG, int NA, bool TIME>
+__device__ __forceinline__ void packed_issue_all(const FastPlan &P, const PackedBases<NF, NG, NA> &B, uint32_t r, PackedRaw<NF> &f,
+                                                 PackedRaw<NG> &g, PackedRaw<NA> &a, PackedRaw<1> &t) {
+    if (TIME) packed_issue(B.t, P.twid >> 1, r, t.v[0]);  // width 1, 2, 4 -> shift 0, 1, 2
+#pragma unroll
+    for (int c = 0; c < NF; c++) packed_issue(B.f[c], P.fwid[c] >> 1, r, f.v[c]);
+#pragma unroll
+    for (int c = 0; c < NG; c++) packed_issue(B.g[c], P.gwid[c] >> 1, r, g.v[c]);
+#pragma unroll
+    for (int c = 0; c < NA; c++) packed_issue(B.a[c], P.awid[c] >> 1, r, a.v[c]);
+}
+
+template <int NF, int NG, int NA, bool TIME>
+__device__ __forceinline__ void packed_decode_all(const FastPlan &P, const PackedRaw<NF> &rf, const PackedRaw<NG> &rg,
+                                                  const PackedRaw<NA> &ra, const PackedRaw<1> &rt, PackedTile<NF> &f,
+                                                  PackedTile<NG> &g, PackedTile<NA> &a, PackedTile<1> &t) {
+    if (TIME) packed_decode(P.twid, rt.v[0], t.u[0]);
+#pragma unroll
+    for (int c = 0; c < NF; c++) packed_decode(P.fwid[c], rf.v[c], f.u[c]);
+#pragma unroll
+    for (int c = 0; c < NG; c++) packed_decode(P.gwid[c], rg.v[c], g.u[c]);
+#pragma unroll
+    for (int c = 0; c < NA; c++) packed_decode(P.awid[c], ra.v[c], a.u[c]);
+}
+
+// floor(n / d) for 32-bit n, d >= 1.  inv_lo is 1/d scaled down by (1 - 2^-40), so the product never
+// exceeds the true quotient and is at most 1 short of it: one one-sided correction step is exact.
+__device__ __forceinline__ uint32_t packed_udiv(uint32_t n, uint32_t d, double inv_lo) {
+    uint32_t q = (uint32_t)((double)n * inv_lo);
+    if (n - q * d >= d) q += 1;
+    return q;
+}
+
+template <int NF, int NG, int NA, int MODE, bool TIME>
+__device__ __forceinline__ void packed_row(const FastPlan &P, const PackedTile<NF> &f, const PackedTile<NG> &g,
+                                           const PackedTile<NA> &a, const PackedTile<1> &t, const int r, bool pass, int64_t *lds,
+                                           const FastLds &L, uint32_t &matched, uint32_t &overflow) {
+    // no short-circuit anywhere: one predicate, one exec-masked region per row
+#pragma unroll
+    for (int c = 0; c < NF; c++) {
+        const uint32_t u = f.u[c][r];
+        pass = pass & (u >= P.plo[c]) & (u <= P.phi[c]);  // filter.go:171-195, folded to a range of offsets
+    }
+    uint32_t cell = 0;
+    bool inb = true;
+#pragma unroll
+    for (int c = 0; c < NG; c++) {
+        const uint32_t d = g.u[c][r] + P.gdoff[c];  // value - gmin
+        inb = inb & (d < P.gcard[c]);
+        cell += __umul24(d, (uint32_t)P.gstride[c]);  // aggregate.go:125-143 as a direct-mapped index
+    }
+    if (TIME) {
+        // int(val) / TimeBucket (aggregate.go:174) for val >= 0, relative to the first bucket
+        const uint32_t tb = packed_udiv(t.u[0][r] + P.tdoff, (uint32_t)P.time_bucket, P.pinv_time);
+        inb = inb & (tb < (uint32_t)P.n_tb);
+        cell += __umul24(tb, (uint32_t)P.tb_stride);
+    }
+    const uint32_t ncell = L.tab_cells;
+    const uint32_t lcell = cell - L.cell_base;  // position inside this workgroup's LDS table
+    inb = inb & (lcell < ncell);
+    matched += pass ? 1u : 0u;                  // aggregate.go:117
+    overflow += (pass & !inb) ? 1u : 0u;
+    if (!(pass & inb)) return;
+    // byte address of the cell's Count word; every other field of the cell is a wave-uniform byte
+    // offset away (one VALU add per atomic)
+    const uint32_t rs = (uint32_t)P.rep_shift;
+    char *const cell_p = (char *)lds + (((lcell << rs) + L.rep) << 3);
+    const uint32_t fstep = (ncell << rs) << 3;  // bytes between consecutive fields
+    auto add = [&](uint32_t field, int64_t v) {
+        __hip_atomic_fetch_add((int64_t *)(cell_p + field * fstep), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    add(0, 1);  // Result.Count++ (aggregate.go:203)
+#pragma unroll
+    for (int c = 0; c < NA; c++) {
+        const uint32_t u = a.u[c][r];
+        const int64_t x = (int64_t)((uint64_t)P.abase[c] + u);
+        add((uint32_t)P.f_sum[c], x);
+        if (MODE == kFastAvgMax) {
+            int64_t *m = (int64_t *)(cell_p + ((uint32_t)P.n_sum_fields + (uint32_t)P.m_max[c]) * fstep);
+            if (x > *m) __hip_atomic_fetch_max(m, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        if (MODE == kFastMoments || MODE == kFastHist) {
+            // bucket_value := (value - h.Min) / BucketSize, hist_basic.go:130; the planner guarantees
+            // 0 <= value - h.Min < 2^32 and that no value reaches len(Values)
+            const uint32_t b = packed_udiv(u + P.adoff[c], P.bucket_size[c], P.pinv_bucket[c]);
+            if (MODE == kFastMoments) {
+                add((uint32_t)P.f_sb[c], (int64_t)(uint64_t)b);
+                add((uint32_t)P.f_sb2[c], (int64_t)(uint64_t)(uint32_t)__umul24(b, b));
+            } else if (P.hist_lds) {
+                __hip_atomic_fetch_add(L.hist32 + lcell * (uint32_t)P.hist_stride + (uint32_t)P.hist_agg_off[c] + b, 1u,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else {
+                __hip_atomic_fetch_add(P.sum_out + P.hist_off + (int64_t)cell * P.hist_stride + P.hist_agg_off[c] + b,
+                                       (int64_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+}
+
+constexpr int64_t kPackedChunkRows = (int64_t)1 << 28;  // rows addressed with one 32-bit byte offset (x4 bytes)
+
+template <int NF, int NG, int NA, int MODE, bool TIME>
+__global__ __launch_bounds__(kWgThreads, 4) void k_scan_packed(const FastPlan P) {
+    extern __shared__ int64_t lds[];
+    const uint32_t tid = threadIdx.x;
+    const FastLds L = fast_begin<MODE>(P, lds);
+
+    uint32_t matched = 0, overflow = 0;
+    const int s0 = P.wg_seg_begin[blockIdx.x], s1 = P.wg_seg_begin[blockIdx.x + 1];
+    for (int si = s0; si < s1; si++) {
+        const Segment seg = P.segs[si];
+        for (int64_t c0 = 0; c0 < seg.n; c0 += kPackedChunkRows) {
+            const int64_t first = seg.start + c0;
+            const uint32_t n = (uint32_t)(seg.n - c0 < kPackedChunkRows ? seg.n - c0 : kPackedChunkRows);
+            PackedBases<NF, NG, NA> B;
+#pragma unroll
+            for (int c = 0; c < NF; c++) B.f[c] = (const uint8_t *)P.fcol[c] + first * P.fwid[c];
+#pragma unroll
+            for (int c = 0; c < NG; c++) B.g[c] = (const uint8_t *)P.gcol[c] + first * P.gwid[c];
+#pragma unroll
+            for (int c = 0; c < NA; c++) B.a[c] = (const uint8_t *)P.acol[c] + first * P.awid[c];
+            B.t = TIME ? (const uint8_t *)P.tcol + first * P.twid : nullptr;
+
+            PackedRaw<NF> rf;
+            PackedRaw<NG> rg;
+            PackedRaw<NA> ra;
+            PackedRaw<1> rt;
+            PackedTile<NF> f;
+            PackedTile<NG> g;
+            PackedTile<NA> a;
+            PackedTile<1> t;
+            uint32_t r = tid * kPackedRows;
+            if (r < n) {
+                packed_issue_all<NF, NG, NA, TIME>(P, B, r, rf, rg, ra, rt);
+                packed_decode_all<NF, NG, NA, TIME>(P, rf, rg, ra, rt, f, g, a, t);
+            }
+            for (; r < n; r += kPackedTileRows) {
+                // the next tile's loads are in flight while this one is consumed; they are decoded
+                // (the first use of the loaded registers) only after the rows below
+                const uint32_t rn = r + kPackedTileRows;
+                const bool more = rn < n;
+                if (more) packed_issue_all<NF, NG, NA, TIME>(P, B, rn, rf, rg, ra, rt);
+                const uint32_t left = n - r;
+#pragma unroll
+                for (int k = 0; k < kPackedRows; k++)
+                    packed_row<NF, NG, NA, MODE, TIME>(P, f, g, a, t, k, (uint32_t)k < left, lds, L, matched, overflow);
+                if (more) packed_decode_all<NF, NG, NA, TIME>(P, rf, rg, ra, rt, f, g, a, t);
+            }
+        }
+    }
+    fast_finish(P, lds, L, matched, overflow);
+}
+
+// k_emit over compact storage (strategy 5, see k_emit in scan_fast.h): the same records, staged and
+// flushed the same way; rows are loaded and filtered in the offset domain like k_scan_packed.
+template <int NF, int NG, int NA>
+__global__ __launch_bounds__(kWgThreads, 4) void k_emit_packed(const EmitPlan E) {
+    extern __shared__ uint32_t elds[];
+    const FastPlan &P = E.fp;
+    const uint32_t tid = threadIdx.x;
+    const EmitLds S = emit_begin(E, elds);
+
+    uint32_t matched = 0, overflow = 0;
+    const int s0 = P.wg_seg_begin[blockIdx.x], s1 = P.wg_seg_begin[blockIdx.x + 1];
+    for (int si = s0; si < s1; si++) {
+        const Segment seg = P.segs[si];
+        for (int64_t c0 = 0; c0 < seg.n; c0 += kPackedChunkRows) {
+            const int64_t first = seg.start + c0;
+            const uint32_t n = (uint32_t)(seg.n - c0 < kPackedChunkRows ? seg.n - c0 : kPackedChunkRows);
+            PackedBases<NF, NG, NA> B;
+#pragma unroll
+            for (int c = 0; c < NF; c++) B.f[c] = (const uint8_t *)P.fcol[c] + first * P.fwid[c];
+#pragma unroll
+            for (int c = 0; c < NG; c++) B.g[c] = (const uint8_t *)P.gcol[c] + first * P.gwid[c];
+#pragma unroll
+            for (int c = 0; c < NA; c++) B.a[c] = (const uint8_t *)P.acol[c] + first * P.awid[c];
+            B.t = nullptr;
+            PackedRaw<NF> rf;
+            PackedRaw<NG> rg;
+            PackedRaw<NA> ra;
+            PackedRaw<1> rt;
+            PackedTile<NF> f;
+            PackedTile<NG> g;
+            PackedTile<NA> a;
+            PackedTile<1> t;
+            // every thread runs the same number of tiles so the barriers line up
+            const uint32_t n_tiles = (n + kPackedTileRows - 1) / kPackedTileRows;
+            uint32_t r = tid * kPackedRows;
+            if (r < n) {
+                packed_issue_all<NF, NG, NA, false>(P, B, r, rf, rg, ra, rt);
+                packed_decode_all<NF, NG, NA, false>(P, rf, rg, ra, rt, f, g, a, t);
+            }
+            for (uint32_t it = 0; it < n_tiles; it++, r += kPackedTileRows) {
+                const uint32_t rn = r + kPackedTileRows;
+                const bool more = rn < n;
+                if (more) packed_issue_all<NF, NG, NA, false>(P, B, rn, rf, rg, ra, rt);
+                const uint32_t left = r < n ? n - r : 0u;
+#pragma unroll
+                for (int k = 0; k < kPackedRows; k++) {
+                    bool pass = (uint32_t)k < left;
+#pragma unroll
+                    for (int c = 0; c < NF; c++) {
+                        const uint32_t u = f.u[c][k];
+                        pass = pass & (u >= P.plo[c]) & (u <= P.phi[c]);
+                    }
+                    uint32_t cell = 0;
+                    bool inb = true;
+#pragma unroll
+                    for (int c = 0; c < NG; c++) {
+                        const uint32_t d = g.u[c][k] + P.gdoff[c];
+                        inb = inb & (d < P.gcard[c]);
+                        cell += __umul24(d, (uint32_t)P.gstride[c]);
+                    }
+                    matched += pass ? 1u : 0u;
+                    overflow += (pass & !inb) ? 1u : 0u;
+                    if (pass & inb) {
+#pragma unroll
+                        for (int c = 0; c < NA; c++) {
+                            const uint32_t n32 = a.u[c][k] + P.adoff[c];  // value - h.Min
+                            const uint32_t b = packed_udiv(n32, P.bucket_size[c], P.pinv_bucket[c]);
+                            emit_push(E, S, cell * (uint32_t)NA + (uint32_t)c, b, n32 - b * P.bucket_size[c], E.rem_bits[c]);
+                        }
+                    }
+                }
+                if (more) packed_decode_all<NF, NG, NA, false>(P, rf, rg, ra, rt, f, g, a, t);
+                // bins fill at ~tile_records / n_parts per tile: flush (two barriers) only every
+                // flush_period tiles; a bin that fills up earlier spills record by record
+                if ((it + 1) % (uint32_t)E.flush_period == 0 || it + 1 == n_tiles) {
+                    __syncthreads();
+                    emit_flush(E, S, S.slots / 2);
+                    __syncthreads();
+                }
+            }
+        }
+    }
+    emit_finish(E, S, matched, overflow);
+}
+
+template <int NF>
+static hipError_t emit_packed_launch_nf(const EmitPlan &E, int ng, int na, int n_wg, hipStream_t st) {
+    const size_t lds = ((size_t)E.n_parts << E.sub_shift) * (1 + (size_t)E.slots) * 4;
+#define SYBL_EMITP_CASE(G, A)                                                                              \
+    case (G)*3 + (A): {                                                                                    \
+        auto k = k_emit_packed<NF, G, A>;                                                                  \
+        hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (e != hipSuccess) return e;                                                                     \
+        hipLaunchKernelGGL(k, dim3(n_wg), dim3(kWgThreads), lds, st, E);                                   \
+        return hipGetLastError();                                                                          \
+    }
+    switch (ng * 3 + na) {
+        SYBL_EMITP_CASE(0, 1)
+        SYBL_EMITP_CASE(0, 2)
+        SYBL_EMITP_CASE(1, 1)
+        SYBL_EMITP_CASE(1, 2)
+        SYBL_EMITP_CASE(2, 1)
+        SYBL_EMITP_CASE(2, 2)
+    default: return hipErrorInvalidValue;
+    }
+#undef SYBL_EMITP_CASE
+}
+
+template <int NF, int NG, int NA, int MODE, bool TIME>
+static hipError_t packed_launch_k(const FastPlan &P, int n_wg, size_t lds_bytes, hipStream_t st) {
+    auto k = k_scan_packed<NF, NG, NA, MODE, TIME>;
+    hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, dim3(n_wg), dim3(kWgThreads), lds_bytes, st, P);
+    return hipGetLastError();
+}
+
+template <int NF, int NG, int NA>
+static hipError_t packed_launch_mode(const FastPlan &P, int mode, bool time, int n_wg, size_t lds, hipStream_t st) {
+#define SYBL_PACKED_MODE(M) \
+    return time ? packed_launch_k<NF, NG, NA, M, true>(P, n_wg, lds, st) : packed_launch_k<NF, NG, NA, M, false>(P, n_wg, lds, st)
+    if (NA == 0) SYBL_PACKED_MODE(kFastAvg);
+    switch (mode) {
+    case kFastAvg: SYBL_PACKED_MODE(kFastAvg);
+    case kFastAvgMax: SYBL_PACKED_MODE(kFastAvgMax);
+    case kFastMoments: SYBL_PACKED_MODE(kFastMoments);
+    case kFastHist: SYBL_PACKED_MODE(kFastHist);
+    default: return hipErrorInvalidValue;
+    }
+#undef SYBL_PACKED_MODE
+}
+
+template <int NF>
+static hipError_t packed_launch_nf(const FastPlan &P, int ng, int na, int mode, bool time, int n_wg, size_t lds, hipStream_t st) {
+    switch (ng * 3 + na) {
+    case 0: return packed_launch_mode<NF, 0, 0>(P, mode, time, n_wg, lds, st);
+    case 1: return packed_launch_mode<NF, 0, 1>(P, mode, time, n_wg, lds, st);
+    case 2: return packed_launch_mode<NF, 0, 2>(P, mode, time, n_wg, lds, st);
+    case 3: return packed_launch_mode<NF, 1, 0>(P, mode, time, n_wg, lds, st);
+    case 4: return packed_launch_mode<NF, 1, 1>(P, mode, time, n_wg, lds, st);
+    case 5: return packed_launch_mode<NF, 1, 2>(P, mode, time, n_wg, lds, st);
+    case 6: return packed_launch_mode<NF, 2, 0>(P, mode, time, n_wg, lds, st);
+    case 7: return packed_launch_mode<NF, 2, 1>(P, mode, time, n_wg, lds, st);
+    case 8: return packed_launch_mode<NF, 2, 2>(P, mode, time, n_wg, lds, st);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+#endif  // __HIPCC__
+
+}  // namespace sybl
