@@ -66,7 +66,7 @@ def measured_traffic(stats, names):
         rec = json.load(open(path))
     except (OSError, ValueError):
         return None
-    key = "%d_cols_strategy_%d" % (len(names), stats["strategy"])
+    key = "%d_cols_strategy_%d%s" % (len(names), stats["strategy"], "_packed" if stats.get("packed_kernel") else "")
     if key not in rec:
         return None
     return rec[key]["hbm_bytes_per_row"] * stats["rows_scanned"]
@@ -79,7 +79,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rows", type=int, default=0, help="total rows (default: the workload's BASELINE size)")
     ap.add_argument("--workload", default="cfg3_filter3_group2_stddev")
-    ap.add_argument("--storage", choices=["canonical", "compact"], default="canonical",
+    ap.add_argument("--no-canonical", action="store_true", help="skip the secondary canonical-storage measurement")
+    ap.add_argument("--storage", choices=["canonical", "compact"], default="compact",
                     help="canonical: int64 per value (the reference's in-memory IntField); compact: sybl_table_compact "
                          "(1/2/4-byte offsets from the column minimum)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -126,44 +127,20 @@ def main():
         kind, _, a, b, _, _ = synth.COLUMNS[n]
         hi = a + 4 * (b - 1) if kind == synth.BELL else a + b - 1
         table.set_bounds(n, a, hi)
-    if args.storage == "compact":
-        table.compact()
-    query = table.query(**q)
+    if multi and args.collective == "rccl":
+        uid = [ctx.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        ctx.comm_init(uid[0], world, rank)
     side = None
-    if multi:
-        if args.collective == "torch":
-            # One explicit (non-default) stream carries scan -> all-reduce -> finalize: the engine is
-            # pointed at it and torch.distributed orders its collective against torch's CURRENT stream,
-            # which is this one inside the `with` below.  (The default stream's handle is NULL, which
-            # sybl_ctx_set_stream would read as "use the engine's own stream" -- and then nothing would
-            # order the all-reduce after the scan.)
-            side = torch.cuda.Stream(device=device)
-            assert side.cuda_stream != 0
-            with torch.cuda.stream(side):
-                query.bind_torch(device)
-            ctx.set_stream(side.cuda_stream)
-        else:
-            uid = [ctx.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(uid, src=0)
-            ctx.comm_init(uid[0], world, rank)
-
-    scan_ms = []
-
-    def step():
-        query.scan()
-        if multi:
-            if args.collective == "torch":
-                with torch.cuda.stream(side):
-                    query.allreduce_torch()
-            else:
-                query.allreduce()
-        res = None
-        if rank == 0:
-            res = query.finalize()
-        else:
-            ctx.sync()
-        scan_ms.append(query.stats()["scan_ms"])
-        return res
+    if multi and args.collective == "torch":
+        # One explicit (non-default) stream carries scan -> all-reduce -> finalize: the engine is
+        # pointed at it and torch.distributed orders its collective against torch's CURRENT stream,
+        # which is this one inside the `with` below.  (The default stream's handle is NULL, which
+        # sybl_ctx_set_stream would read as "use the engine's own stream" -- and then nothing would
+        # order the all-reduce after the scan.)
+        side = torch.cuda.Stream(device=device)
+        assert side.cuda_stream != 0
+        ctx.set_stream(side.cuda_stream)
 
     def fence():
         ctx.sync()
@@ -172,41 +149,99 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    res = None
-    seen_matched = set()
-    for _ in range(args.warmup):
-        r = step()
-        if r is not None:
-            seen_matched.add(r.matched)
-            r.free()
-    fence()
-    del scan_ms[:]
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        r = step()
-        if r is not None:
-            seen_matched.add(r.matched)
-            if res is not None:
-                res.free()
-            res = r
-    fence()
-    dt = time.perf_counter() - t0
-    if multi:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    def run_phase(steps, warmup):
+        """Prepares the query against the table as currently laid out, does `warmup` untimed steps and
+        times exactly `steps` steps (barrier + synchronize on both sides, max over ranks)."""
+        query = table.query(**q)
+        if multi and args.collective == "torch":
+            with torch.cuda.stream(side):
+                query.bind_torch(device)
+        scan_ms = []
 
-    stats = query.stats()
+        def step():
+            query.scan()
+            if multi:
+                if args.collective == "torch":
+                    with torch.cuda.stream(side):
+                        query.allreduce_torch()
+                else:
+                    query.allreduce()
+            res = None
+            if rank == 0:
+                res = query.finalize()
+            else:
+                ctx.sync()
+            scan_ms.append(query.stats()["scan_ms"])
+            return res
+
+        res = None
+        seen_matched = set()
+        for _ in range(warmup):
+            r = step()
+            if r is not None:
+                seen_matched.add(r.matched)
+                r.free()
+        fence()
+        del scan_ms[:]
+        t0 = time.perf_counter()
+        for i in range(steps):
+            r = step()
+            if r is not None:
+                seen_matched.add(r.matched)
+                if res is not None:
+                    res.free()
+                res = r
+        fence()
+        dt = time.perf_counter() - t0
+        if multi:
+            tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        stats = query.stats()
+        out = {"dt": dt, "stats": stats, "kernel_ms": sum(scan_ms) / len(scan_ms)}
+        if rank == 0:
+            # every step scans the same table: the merged result must not change from step to step (it
+            # would if the all-reduce ever ran ahead of a rank's scan) and group counts must add up
+            assert len(seen_matched) == 1, "matched count varies across steps: %r" % sorted(seen_matched)
+            assert sum(g["count"] for g in res.results) == res.matched
+            out["matched"] = res.matched
+            out["groups"] = len(res.results)
+            out["digest"] = sorted((g["key"], g["count"]) + tuple(h["sum"] for h in g["hists"]) for g in res.results)
+            res.free()
+        query.free()
+        return out
+
+    STRATEGY = {0: "lds-generic", 1: "global-atomics", 2: "lds-fast", 3: "lds-window-generic", 4: "lds-window-fast",
+                5: "partitioned-hist", 6: "lds-hist"}
+
+    def roofline(ph, storage):
+        stats = ph["stats"]
+        alg = stats["algorithmic_bytes"]  # this rank's rows x stored bytes per row: per launch, per GPU
+        achieved = alg / (ph["kernel_ms"] * 1e-3) / 1e9
+        kernel = ("k_scan_packed<3,2,2,moments>" if stats["packed_kernel"] else "k_scan_fast<3,2,2,moments>") \
+            if stats["strategy"] == 2 else "k_scan<%d>" % len(names)
+        return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": measured_traffic(stats, names), "kernel": kernel, "kernel_ms": ph["kernel_ms"],
+                "algorithmic_bytes_per_launch": alg, "stored_bytes_per_row": alg / max(stats["rows_scanned"], 1),
+                "int64_canonical_bytes_per_launch": stats["canonical_bytes"],
+                "int64_canonical_equivalent_GBps": stats["canonical_bytes"] / (ph["kernel_ms"] * 1e-3) / 1e9,
+                "strategy": STRATEGY[stats["strategy"]], "lds_bytes": stats["lds_bytes"], "workgroups": stats["n_workgroups"]}
+
+    # Secondary, untimed-for-the-headline measurement: the same table in canonical int64 storage
+    # (the reference's in-memory IntField) before it is compacted.
+    canon = None
+    if args.storage == "compact" and not args.no_canonical:
+        canon = run_phase(min(args.steps, 10), min(args.warmup, 2))
+    if args.storage == "compact":
+        table.compact()
+    head = run_phase(args.steps, args.warmup)
+
     if rank == 0:
-        # every step scans the same table: the merged result must not change from step to step (it
-        # would if the all-reduce ever ran ahead of a rank's scan) and group counts must add up
-        assert len(seen_matched) == 1, "matched count varies across steps: %r" % sorted(seen_matched)
-        assert sum(g["count"] for g in res.results) == res.matched
+        if canon is not None:
+            assert canon["digest"] == head["digest"], "compact and canonical storage disagree"
+        dt, stats = head["dt"], head["stats"]
         ms_per_step = dt / args.steps * 1e3
         value = total_rows * args.steps / dt
-        k_ms = sum(scan_ms) / len(scan_ms)
-        alg_bytes = stats["algorithmic_bytes"]  # this rank's rows x 56 B: per launch, per GPU
-        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
         out = {
             "metric": "rows scanned/sec (1B-row x 32-int-col synthetic table, 3 ANDed int-range filters, "
                       "group-by 2 cols, count/sum/avg/stddev of 2 cols)",
@@ -214,24 +249,20 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "int64", "data": "synthetic",
             "config": {"workload": args.workload, "reference_flags": wl["flags"], "rows": total_rows,
-                       "table_columns": wl["table_cols"], "resident_columns": names, "bytes_per_row": bytes_per_row,
+                       "table_columns": wl["table_cols"], "resident_columns": names,
+                       "storage": args.storage,
+                       "stored_widths": {n: table.column_storage(n)[0] for n in names},
                        "sharding": "contiguous 65536-row blocks per rank", "collective": args.collective if multi else None,
-                       "device": dev["name"], "matched_rows": res.matched if res is not None else None,
-                       "groups": len(res.results) if res is not None else None,
-                       "strategy": {0: "lds-generic", 1: "global-atomics", 2: "lds-fast", 3: "lds-window-generic", 4: "lds-window-fast", 5: "partitioned-hist", 6: "lds-hist"}[stats["strategy"]],
-                       "lds_bytes": stats["lds_bytes"], "workgroups": stats["n_workgroups"]},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(stats, names),
-                         "kernel": "k_scan_fast<3,2,2,moments>" if stats["strategy"] == 2 else "k_scan<%d>" % len(names),
-                         "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes},
+                       "device": dev["name"], "matched_rows": head["matched"], "groups": head["groups"]},
+            "roofline": roofline(head, args.storage),
         }
+        if canon is not None:
+            out["canonical_storage"] = {"value": total_rows * min(args.steps, 10) / canon["dt"], "unit": "rows/s",
+                                        "steps": min(args.steps, 10), "roofline": roofline(canon, "canonical")}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload, total_rows)
         print(json.dumps(out))
         sys.stdout.flush()
-    if res is not None:
-        res.free()
-    query.free()
     table.free()
     if multi and args.collective == "rccl":
         ctx.comm_free()

@@ -57,7 +57,7 @@ struct PackedRaw {
 typedef pu32x4 pu32x4_a4 __attribute__((aligned(4)));
 
 __device__ __forceinline__ void packed_issue(const uint8_t *col, int wshift, uint32_t r, pu32x4 &raw) {
-    raw = __builtin_nontemporal_load((const pu32x4_a4 *)(col + (size_t)(r << wshift)));
+    raw = *(const pu32x4_a4 *)(col + (size_t)(r << wshift));
 }
 
 __device__ __forceinline__ void packed_decode(int width, const pu32x4 &raw, uint32_t (&u)[kPackedRows]) {
