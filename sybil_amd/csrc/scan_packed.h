@@ -48,16 +48,19 @@ struct PackedRaw {
     pu32x4 v[N > 0 ? N : 1];  // the loaded bytes of four rows: 1 / 2 / 4 dwords are meaningful
 };
 
-// Issues the load of four consecutive rows of one column.  `col` is the (wave-uniform) address of
-// the chunk's first row and `r` the lane's row inside the chunk, so the address is an SGPR pair plus
-// a 32-bit VGPR offset.  The instruction is the same 16-byte load for every stored width -- a
-// narrower column simply over-reads into its neighbours' rows (same cache lines, no extra HBM
-// traffic; the arrays carry a tile of slack) -- so issuing needs no branch and nothing here waits
-// for the data: the width only matters when the registers are decoded.
-typedef pu32x4 pu32x4_a4 __attribute__((aligned(4)));
+// Issues the load of four consecutive rows of one column.  The instruction is the same 16-byte
+// buffer load for every stored width, so issuing needs no branch and nothing here waits for the
+// data (the width only matters when the registers are decoded).  A narrower column would over-read
+// into its neighbours' rows; the buffer descriptor is therefore set to exactly the wave's 256 rows
+// (`col` = wave-uniform address of the wave's first row, `voff` = the lane's byte offset inside
+// them), and the hardware range check drops the out-of-range dwords without touching memory --
+// HBM traffic stays at the stored bytes.
+constexpr uint32_t kBufferRsrcWord3 = 0x00020000;  // raw buffer, 32-bit data format (gfx9 family)
 
-__device__ __forceinline__ void packed_issue(const uint8_t *col, int wshift, uint32_t r, pu32x4 &raw) {
-    raw = *(const pu32x4_a4 *)(col + (size_t)(r << wshift));
+__device__ __forceinline__ void packed_issue(const uint8_t *col, int wshift, uint32_t voff, pu32x4 &raw) {
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void *)col, 0, (int)((64u * kPackedRows) << wshift), (int)kBufferRsrcWord3);
+    raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, 0, 0);
 }
 
 __device__ __forceinline__ void packed_decode(int width, const pu32x4 &raw, uint32_t (&u)[kPackedRows]) {
@@ -85,16 +88,23 @@ struct PackedBases {
     const uint8_t *f[NF > 0 ? NF : 1], *g[NG > 0 ? NG : 1], *a[NA > 0 ? NA : 1], *t;
 };
 
+// r: the lane's first row inside the chunk; the wave's first row is that of its first lane
 template <int NF, int NG, int NA, bool TIME>
 __device__ __forceinline__ void packed_issue_all(const FastPlan &P, const PackedBases<NF, NG, NA> &B, uint32_t r, PackedRaw<NF> &f,
                                                  PackedRaw<NG> &g, PackedRaw<NA> &a, PackedRaw<1> &t) {
-    if (TIME) packed_issue(B.t, P.twid >> 1, r, t.v[0]);  // width 1, 2, 4 -> shift 0, 1, 2
+    const uint32_t r0 = __builtin_amdgcn_readfirstlane(r);
+    const uint32_t lane_row = r - r0;
+    auto issue = [&](const uint8_t *col, int width, pu32x4 &raw) {
+        const int ws = width >> 1;  // width 1, 2, 4 -> shift 0, 1, 2
+        packed_issue(col + ((size_t)r0 << ws), ws, lane_row << ws, raw);
+    };
+    if (TIME) issue(B.t, P.twid, t.v[0]);
 #pragma unroll
-    for (int c = 0; c < NF; c++) packed_issue(B.f[c], P.fwid[c] >> 1, r, f.v[c]);
+    for (int c = 0; c < NF; c++) issue(B.f[c], P.fwid[c], f.v[c]);
 #pragma unroll
-    for (int c = 0; c < NG; c++) packed_issue(B.g[c], P.gwid[c] >> 1, r, g.v[c]);
+    for (int c = 0; c < NG; c++) issue(B.g[c], P.gwid[c], g.v[c]);
 #pragma unroll
-    for (int c = 0; c < NA; c++) packed_issue(B.a[c], P.awid[c] >> 1, r, a.v[c]);
+    for (int c = 0; c < NA; c++) issue(B.a[c], P.awid[c], a.v[c]);
 }
 
 template <int NF, int NG, int NA, bool TIME>
