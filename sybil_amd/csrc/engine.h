@@ -162,6 +162,7 @@ struct AggInfo {
 };
 
 struct Result;
+struct ResultPool;  // result.cpp: result arrays recycled between the finalizes of one query
 
 struct Query {
     Table *t = nullptr;
@@ -197,6 +198,7 @@ struct Query {
     int64_t *d_sum = nullptr, *d_max = nullptr;
     bool own_partials = false;
     int64_t *d_ws_sum = nullptr, *d_ws_max = nullptr;
+    std::shared_ptr<ResultPool> rpool;
     std::shared_ptr<HostBuf> h_sum_buf;          // pinned snapshot of the SUM section (shared with results)
     int64_t *h_sum = nullptr, *h_max = nullptr;  // h_sum = h_sum_buf->p; h_max: pinned staging
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};

@@ -16,7 +16,9 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <chrono>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -50,17 +52,54 @@ struct RowStore {
     int64_t agg_off = 0;  // this row's n_aggs entries in Result::agg_pool / val_pool / pctoff_pool
 };
 
-struct Result {
+// The big per-result arrays, recycled between the results of one query: a time-series or
+// high-cardinality result is tens of MB, and allocating it afresh costs more in page faults (and
+// in munmap on free) than building its rows does.
+struct ResultStore {
     std::vector<RowStore> rows[3];
     std::vector<sybl_group_row> view[3];
+    std::vector<int64_t> pct_pool, pctoff_pool;
+    std::vector<sybl_agg_out> agg_pool;
+    std::vector<const int64_t *> val_pool;
+    std::vector<int64_t> live, alltime, all_count, all_samples;  // finalize scratch
+    void swap(ResultStore &o) {
+        for (int w = 0; w < 3; w++) {
+            rows[w].swap(o.rows[w]);
+            view[w].swap(o.view[w]);
+        }
+        pct_pool.swap(o.pct_pool);
+        pctoff_pool.swap(o.pctoff_pool);
+        agg_pool.swap(o.agg_pool);
+        val_pool.swap(o.val_pool);
+        live.swap(o.live);
+        alltime.swap(o.alltime);
+        all_count.swap(o.all_count);
+        all_samples.swap(o.all_samples);
+    }
+};
+
+struct ResultPool {
+    std::mutex m;
+    bool full = false;
+    ResultStore spare;
+};
+
+struct Result : ResultStore {
+    std::shared_ptr<ResultPool> pool;  // where the arrays go back to when the result is freed
+    ~Result() {
+        if (!pool) return;
+        std::lock_guard<std::mutex> lk(pool->m);
+        if (!pool->full) {
+            pool->spare.swap(*this);
+            pool->full = true;
+        }
+    }
     int64_t matched = 0;
     std::shared_ptr<HostBuf> keep;                // the pinned snapshot of the partial table the bucket
                                                   // arrays of the rows point into
     std::vector<std::vector<int64_t>> total_vals; // Cumulative bucket arrays
-    std::vector<int64_t> pct_pool;                // 100 entries per (row, agg) with percentiles
-    std::vector<sybl_agg_out> agg_pool;           // n_aggs entries per row, all row kinds
-    std::vector<const int64_t *> val_pool;
-    std::vector<int64_t> pctoff_pool;             // offset into pct_pool, -1 = none
+    // (ResultStore) pct_pool: 100 entries per (row, agg) with percentiles; agg_pool / val_pool /
+    // pctoff_pool: n_aggs entries per row, all row kinds (pctoff: offset into pct_pool, -1 = none)
     // for rendering
     int op = 0;
     bool weighted = false, time_mode = false, want_percentiles = false;
@@ -216,29 +255,68 @@ static void finish_row(const Query *q, Result *R, const CellAcc &acc, RowStore &
     }
 }
 
-static void make_views(Result *R) {
-    for (size_t k = 0; k < R->agg_pool.size(); k++) {
-        R->agg_pool[k].values = R->val_pool[k];
-        R->agg_pool[k].percentiles = R->pctoff_pool[k] >= 0 ? R->pct_pool.data() + R->pctoff_pool[k] : nullptr;
+// f(i0, i1) over [0, n) on worker threads when n is large enough to pay for them
+template <typename F>
+static void parallel_ranges(size_t n, size_t min_per_thread, F f) {
+    unsigned hw = std::thread::hardware_concurrency();
+    size_t cap = std::min<size_t>(hw ? hw : 1, 32);
+    if (const char *e = getenv("SYBL_FINALIZE_THREADS")) cap = (size_t)std::max(1, atoi(e));
+    size_t nt = std::max<size_t>(1, std::min(cap, n / std::max<size_t>(min_per_thread, 1)));
+    if (nt <= 1) {
+        f((size_t)0, n);
+        return;
     }
+    std::vector<std::thread> th;
+    for (size_t k = 0; k < nt; k++) th.emplace_back(f, n * k / nt, n * (k + 1) / nt);
+    for (auto &x : th) x.join();
+}
+
+static void make_views(Result *R) {
+    parallel_ranges(R->agg_pool.size(), 1 << 15, [&](size_t k0, size_t k1) {
+        for (size_t k = k0; k < k1; k++) {
+            R->agg_pool[k].values = R->val_pool[k];
+            R->agg_pool[k].percentiles = R->pctoff_pool[k] >= 0 ? R->pct_pool.data() + R->pctoff_pool[k] : nullptr;
+        }
+    });
     for (int w = 0; w < 3; w++) {
         R->view[w].resize(R->rows[w].size());
-        for (size_t i = 0; i < R->rows[w].size(); i++) {
-            RowStore &r = R->rows[w][i];
-            sybl_group_row &v = R->view[w][i];
-            v.binary_key = r.key;
-            v.group_by_key = r.gbk.c_str();
-            v.time_bucket = r.time_bucket;
-            v.count = r.count;
-            v.samples = r.samples;
-            v.aggs = R->agg_pool.data() + r.agg_off;
-        }
+        parallel_ranges(R->rows[w].size(), 1 << 15, [&, w](size_t i0, size_t i1) {
+            for (size_t i = i0; i < i1; i++) {
+                RowStore &r = R->rows[w][i];
+                sybl_group_row &v = R->view[w][i];
+                v.binary_key = r.key;
+                v.group_by_key = r.gbk.c_str();
+                v.time_bucket = r.time_bucket;
+                v.count = r.count;
+                v.samples = r.samples;
+                v.aggs = R->agg_pool.data() + r.agg_off;
+            }
+        });
     }
 }
+
+// SYBL_FINALIZE_TRACE=1: per-phase host timings of query_finalize on stderr
+struct PhaseTrace {
+    bool on = getenv("SYBL_FINALIZE_TRACE") != nullptr;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    std::string line;
+    void mark(const char *what) {
+        if (!on) return;
+        auto t1 = std::chrono::steady_clock::now();
+        char b[64];
+        snprintf(b, sizeof(b), " %s=%.1fus", what, std::chrono::duration<double, std::micro>(t1 - t0).count());
+        line += b;
+        t0 = t1;
+    }
+    ~PhaseTrace() {
+        if (on) fprintf(stderr, "finalize:%s\n", line.c_str());
+    }
+};
 
 int query_finalize(Query *q, Result **out) {
     hipStream_t st = q->ctx->stream;
     const ScanPlan &P = q->plan;
+    PhaseTrace trace;
     // Pinned snapshot of the (reduced) partial table.  Results keep a reference to the snapshot
     // their bucket arrays point into; the query reuses the buffer for the next finalize unless a
     // live result still holds it (then a fresh one is allocated) -- so a 525 MB histogram table
@@ -253,6 +331,7 @@ int query_finalize(Query *q, Result **out) {
     SYBL_HIP(hipMemcpyAsync(q->h_sum, q->d_sum, (size_t)q->n_sum_words * 8, hipMemcpyDeviceToHost, st));
     if (P.n_max_fields > 0) SYBL_HIP(hipMemcpyAsync(q->h_max, q->d_max, (size_t)q->n_max_words * 8, hipMemcpyDeviceToHost, st));
     SYBL_HIP(hipStreamSynchronize(st));
+    trace.mark("copy+sync");
     const int64_t *hs = q->h_sum, *hm = q->h_max;
     if (hs[kHdrPartOverflow] != 0 && q->part_hist) {
         int rc = query_rescan_without_part_hist(q);
@@ -265,6 +344,15 @@ int query_finalize(Query *q, Result **out) {
                     (long long)hs[kHdrOverflow]);
 
     Result *R = new Result();
+    if (!q->rpool) q->rpool = std::make_shared<ResultPool>();
+    R->pool = q->rpool;
+    {
+        std::lock_guard<std::mutex> lk(q->rpool->m);
+        if (q->rpool->full) {
+            R->swap(q->rpool->spare);
+            q->rpool->full = false;
+        }
+    }
     R->matched = hs[kHdrMatched];
     R->op = q->op;
     R->weighted = q->weighted;
@@ -328,22 +416,26 @@ int query_finalize(Query *q, Result **out) {
             total.aggs[a].values = R->total_vals[a].data();
         }
     }
-    std::vector<int64_t> all_count, all_samples;
+    std::vector<int64_t> &all_count = R->all_count, &all_samples = R->all_samples;
     if (q->time_mode) {
         all_count.assign((size_t)gcells, 0);
         all_samples.assign((size_t)gcells, 0);
     }
     // pass 1 (serial, cheap): the live cells, and in time-series mode the all-time Count/Samples
-    std::vector<int64_t> live;
+    std::vector<int64_t> &live = R->live;
     {
         const int64_t *E = P.f_samples >= 0 ? F + (int64_t)P.f_samples * ncell : F;
+        live.resize((size_t)ncell);
         size_t n_live = 0;
-        for (int64_t cell = 0; cell < ncell; cell++) n_live += E[cell] != 0;
-        live.reserve(n_live);
-        for (int64_t cell = 0; cell < ncell; cell++)
-            if (E[cell] != 0) live.push_back(cell);
+        int64_t *lv = live.data();
+        for (int64_t cell = 0; cell < ncell; cell++) {
+            lv[n_live] = cell;
+            n_live += E[cell] != 0;  // branch-free compaction
+        }
+        live.resize(n_live);
     }
-    std::vector<int64_t> alltime;  // group cells with any row (time-series mode)
+    std::vector<int64_t> &alltime = R->alltime;  // group cells with any row (time-series mode)
+    alltime.clear();
     if (q->time_mode) {
         for (int64_t cell : live) {
             int64_t gcell = cell % gcells;
@@ -353,14 +445,17 @@ int query_finalize(Query *q, Result **out) {
         for (int64_t g = 0; g < gcells; g++)
             if (q->weighted ? all_samples[(size_t)g] != 0 : all_count[(size_t)g] != 0) alltime.push_back(g);
     }
+    trace.mark("live");
     std::vector<RowStore> &cell_rows = R->rows[q->time_mode ? 1 : 0];
+    if (!q->time_mode) R->rows[1].clear();
     cell_rows.resize(live.size());
     const size_t n_all_rows = live.size() + alltime.size() + 1;
     R->agg_pool.resize(n_all_rows * na);
     R->val_pool.resize(n_all_rows * na);
     R->pctoff_pool.resize(n_all_rows * na);
-    if (q->want_percentiles) R->pct_pool.resize(n_all_rows * na * 100);
+    R->pct_pool.resize(q->want_percentiles ? n_all_rows * na * 100 : 0);
 
+    trace.mark("alloc");
     // pass 2: one row per live cell.  Rows own disjoint pool slots, so ranges of cells are
     // finished by worker threads when there are enough of them to pay for the threads.
     auto work = [&](size_t i0, size_t i1, CellAcc *tot, std::vector<std::vector<int64_t>> *tot_vals) {
@@ -372,7 +467,7 @@ int query_finalize(Query *q, Result **out) {
             RowStore &row = cell_rows[i];
             row.agg_off = (int64_t)(i * na);
             build_key(q, gcell, row.key, row.gbk);
-            if (q->time_mode) row.time_bucket = (P.tb_min + tbi) * P.time_bucket;
+            row.time_bucket = q->time_mode ? (P.tb_min + tbi) * P.time_bucket : 0;  // (rows are recycled: assign every field)
             finish_row(q, R, acc, row);
             if (!q->time_mode) {
                 for (size_t a = 0; a < na; a++) {
@@ -447,6 +542,7 @@ int query_finalize(Query *q, Result **out) {
             }
         }
     }
+    trace.mark("rows");
     size_t next_slot = live.size();
     if (q->time_mode) {
         // all-time Results carry Count/Samples only (aggregate.go:156-169)
@@ -455,6 +551,7 @@ int query_finalize(Query *q, Result **out) {
             const int64_t g = alltime[i];
             RowStore &row = R->rows[0][i];
             row.agg_off = (int64_t)((next_slot + i) * na);
+            row.time_bucket = 0;
             build_key(q, g, row.key, row.gbk);
             CellAcc a2;
             a2.count = all_count[(size_t)g];
@@ -465,15 +562,17 @@ int query_finalize(Query *q, Result **out) {
     }
     // Cumulative, aggregate.go:422-438
     {
-        R->rows[2].emplace_back();
+        R->rows[2].resize(1);
         RowStore &row = R->rows[2].back();
         row.agg_off = (int64_t)(next_slot * na);
+        row.time_bucket = 0;
         memset(row.key, 0, sizeof(row.key));
         row.gbk = "TOTAL";
         for (size_t g = 1; g < q->groups.size(); g++) row.gbk += "\t";
         finish_row(q, R, total, row);
     }
 
+    trace.mark("alltime+total");
     // SortResults, aggregate.go:497-525 (stable over the canonical key order)
     if (!q->order_by.empty()) {
         int by = -1;
@@ -503,7 +602,9 @@ int query_finalize(Query *q, Result **out) {
         for (uint32_t i : order) sorted.push_back(std::move(rows[i]));
         rows.swap(sorted);
     }
+    trace.mark("sort");
     make_views(R);
+    trace.mark("views");
     *out = R;
     return SYBL_OK;
 }

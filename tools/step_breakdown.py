@@ -9,6 +9,8 @@ rows = int(sys.argv[1]) if len(sys.argv) > 1 else 125_000_000
 wl = synth.WORKLOADS["cfg3_filter3_group2_stddev"]
 ctx = sybil_amd.Context(0)
 t = ctx.synth_table("b", synth.SEED, rows, 0, rows, synth.synth_cols(wl["columns"]))
+if len(sys.argv) > 2 and sys.argv[2] == "compact":
+    t.compact()
 q = t.query(**wl["query"])
 for _ in range(3):
     q.run().free()
