@@ -79,6 +79,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rows", type=int, default=0, help="total rows (default: the workload's BASELINE size)")
     ap.add_argument("--workload", default="cfg3_filter3_group2_stddev")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="finish every step (finalize on the host) before the next scan is launched")
     ap.add_argument("--no-canonical", action="store_true", help="skip the secondary canonical-storage measurement")
     ap.add_argument("--storage", choices=["canonical", "compact"], default="compact",
                     help="canonical: int64 per value (the reference's in-memory IntField); compact: sybl_table_compact "
@@ -151,64 +153,92 @@ def main():
 
     def run_phase(steps, warmup):
         """Prepares the query against the table as currently laid out, does `warmup` untimed steps and
-        times exactly `steps` steps (barrier + synchronize on both sides, max over ranks)."""
-        query = table.query(**q)
+        times exactly `steps` steps (barrier + synchronize on both sides, max over ranks).
+
+        Steps are software-pipelined one deep (two prepared queries, alternating): the host-side
+        finalize of step i -- waiting for its snapshot, deriving avg / stddev, building and sorting the
+        result rows -- runs while the GPU already scans step i+1.  Every step does all of its work and
+        every result is complete inside the timed region; --no-pipeline serialises them."""
+        nq = 1 if args.no_pipeline else 2
+        queries = [table.query(**q) for _ in range(nq)]
         if multi and args.collective == "torch":
             with torch.cuda.stream(side):
-                query.bind_torch(device)
+                for qy in queries:
+                    qy.bind_torch(device)
         scan_ms = []
 
-        def step():
-            query.scan()
+        def launch(i):
+            qy = queries[i % nq]
+            qy.scan()
             if multi:
                 if args.collective == "torch":
                     with torch.cuda.stream(side):
-                        query.allreduce_torch()
+                        qy.allreduce_torch()
                 else:
-                    query.allreduce()
+                    qy.allreduce()
+            if rank == 0:
+                qy.snapshot()  # D2H copy of the reduced table, queued behind the all-reduce
+
+        def finish(i):
+            qy = queries[i % nq]
             res = None
             if rank == 0:
-                res = query.finalize()
-            else:
+                res = qy.finalize()
+                scan_ms.append(qy.stats()["scan_ms"])
+            elif nq == 1:
                 ctx.sync()
-            scan_ms.append(query.stats()["scan_ms"])
             return res
 
-        res = None
+        def run_steps(n, keep):
+            res = None
+            for i in range(n):
+                launch(i)
+                j = i - (nq - 1)  # the step whose result is due
+                if j >= 0:
+                    r = finish(j)
+                    if r is not None:
+                        seen_matched.add(r.matched)
+                        if res is not None:
+                            res.free()
+                        res = r
+            for j in range(max(n - (nq - 1), 0), n):
+                r = finish(j)
+                if r is not None:
+                    seen_matched.add(r.matched)
+                    if res is not None:
+                        res.free()
+                    res = r
+            if not keep and res is not None:
+                res.free()
+                res = None
+            return res
+
         seen_matched = set()
-        for _ in range(warmup):
-            r = step()
-            if r is not None:
-                seen_matched.add(r.matched)
-                r.free()
+        run_steps(warmup, False)
         fence()
         del scan_ms[:]
         t0 = time.perf_counter()
-        for i in range(steps):
-            r = step()
-            if r is not None:
-                seen_matched.add(r.matched)
-                if res is not None:
-                    res.free()
-                res = r
+        res = run_steps(steps, True)
         fence()
         dt = time.perf_counter() - t0
         if multi:
             tmax = torch.tensor([dt], dtype=torch.float64, device=device)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = float(tmax.item())
-        stats = query.stats()
-        out = {"dt": dt, "stats": stats, "kernel_ms": sum(scan_ms) / len(scan_ms)}
+        stats = queries[0].stats()
+        out = {"dt": dt, "stats": stats, "kernel_ms": (sum(scan_ms) / len(scan_ms)) if scan_ms else stats["scan_ms"]}
         if rank == 0:
             # every step scans the same table: the merged result must not change from step to step (it
             # would if the all-reduce ever ran ahead of a rank's scan) and group counts must add up
             assert len(seen_matched) == 1, "matched count varies across steps: %r" % sorted(seen_matched)
+            assert len(scan_ms) == steps
             assert sum(g["count"] for g in res.results) == res.matched
             out["matched"] = res.matched
             out["groups"] = len(res.results)
             out["digest"] = sorted((g["key"], g["count"]) + tuple(h["sum"] for h in g["hists"]) for g in res.results)
             res.free()
-        query.free()
+        for qy in queries:
+            qy.free()
         return out
 
     STRATEGY = {0: "lds-generic", 1: "global-atomics", 2: "lds-fast", 3: "lds-window-generic", 4: "lds-window-fast",
@@ -251,6 +281,9 @@ def main():
             "config": {"workload": args.workload, "reference_flags": wl["flags"], "rows": total_rows,
                        "table_columns": wl["table_cols"], "resident_columns": names,
                        "storage": args.storage,
+                       "pipelined": None if args.no_pipeline else "finalize(i) on the host overlaps scan(i+1) on the GPU "
+                                                                  "(two prepared queries); all work of the K steps is "
+                                                                  "inside the timed region",
                        "stored_widths": {n: table.column_storage(n)[0] for n in names},
                        "sharding": "contiguous 65536-row blocks per rank", "collective": args.collective if multi else None,
                        "device": dev["name"], "matched_rows": head["matched"], "groups": head["groups"]},

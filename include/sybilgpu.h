@@ -246,8 +246,14 @@ int sybl_comm_init(sybl_ctx *ctx, const void *id128, int32_t nranks, int32_t ran
 int sybl_comm_free(sybl_ctx *ctx);
 int sybl_query_allreduce(sybl_query *q);
 
-/* Copies the (reduced) partials to the host, derives avg/stddev/percentiles, builds
- * GroupByKey strings, sorts and applies the limit.  Synchronises the stream. */
+/* Optional: enqueue the device -> host copy of the (reduced) partials now (after the all-reduce on
+ * multi-GPU hosts).  A following sybl_query_finalize then waits for that copy only, not for work
+ * enqueued behind it -- a host serving a stream of queries overlaps the finalize of one query with
+ * the scan of the next (two prepared queries, alternating). */
+int sybl_query_snapshot(sybl_query *q);
+/* Copies the (reduced) partials to the host (unless sybl_query_snapshot already did), derives
+ * avg/stddev/percentiles, builds GroupByKey strings, sorts and applies the limit.  Waits for the
+ * copy (hence for the scan and the all-reduce before it). */
 int sybl_query_finalize(sybl_query *q, sybl_result **out);
 
 /* ------------------------------------------------------------------ results */

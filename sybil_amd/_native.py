@@ -117,6 +117,7 @@ SIGNATURES = {
     "sybl_comm_free": (C.c_int, [P]),
     "sybl_query_allreduce": (C.c_int, [P]),
     "sybl_query_finalize": (C.c_int, [P, C.POINTER(P)]),
+    "sybl_query_snapshot": (C.c_int, [P]),
     "sybl_result_rows": (C.c_int, [P, C.c_int, C.POINTER(C.POINTER(GroupRow)), C.POINTER(C.c_int64)]),
     "sybl_result_matched": (C.c_int64, [P]),
     "sybl_result_free": (None, [P]),

@@ -107,6 +107,7 @@ static void free_query(Query *q) {
     if (q->h_max) hipHostFree(q->h_max);
     for (auto &e : q->ev)
         if (e) hipEventDestroy(e);
+    if (q->ev_snap) hipEventDestroy(q->ev_snap);
     delete q;
 }
 
@@ -1156,6 +1157,7 @@ static int scan(Query *q) {
         SYBL_HIP(hipEventRecord(q->ev[1], st));
         SYBL_HIP(hipEventRecord(q->ev[2], st));
         q->scanned = true;
+        q->snapshot_pending = false;
         return SYBL_OK;
     }
     if (q->use_lds && ran && !P.windowed) {
@@ -1193,6 +1195,7 @@ static int scan(Query *q) {
     }
     SYBL_HIP(hipEventRecord(q->ev[2], st));
     q->scanned = true;
+    q->snapshot_pending = false;
     return SYBL_OK;
 }
 
@@ -1351,6 +1354,13 @@ int sybl_query_stats(sybl_query *q, sybl_run_stats *out) {
     }
     *out = q->stats;
     return SYBL_OK;
+}
+
+int sybl_query_snapshot(sybl_query *q) {
+    if (!q) return fail(SYBL_E_INVAL, "NULL argument");
+    if (!q->scanned) return fail(SYBL_E_STATE, "sybl_query_snapshot before sybl_query_scan");
+    SYBL_HIP(hipSetDevice(q->ctx->device));
+    return query_snapshot(q);
 }
 
 int sybl_query_finalize(sybl_query *q, sybl_result **out) {

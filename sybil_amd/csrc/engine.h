@@ -202,6 +202,8 @@ struct Query {
     std::shared_ptr<HostBuf> h_sum_buf;          // pinned snapshot of the SUM section (shared with results)
     int64_t *h_sum = nullptr, *h_max = nullptr;  // h_sum = h_sum_buf->p; h_max: pinned staging
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_snap = nullptr;   // the device -> host snapshot of the partial tables has landed
+    bool snapshot_pending = false;
     bool scanned = false;
     sybl_run_stats stats{};
     bool never_matches = false;
@@ -219,6 +221,7 @@ struct Query {
 
 int query_rescan_without_part_hist(Query *q);
 
+int query_snapshot(Query *q);
 int query_finalize(Query *q, Result **out);
 
 }  // namespace sybl

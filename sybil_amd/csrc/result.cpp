@@ -295,6 +295,28 @@ static void make_views(Result *R) {
     }
 }
 
+// Enqueues the device -> host copy of the (reduced) partial tables behind whatever the stream holds.
+// Pinned snapshot: results keep a reference to the snapshot their bucket arrays point into; the
+// query reuses the buffer for the next finalize unless a live result still holds it (then a fresh
+// one is allocated) -- so a 525 MB histogram table is never copied, page-faulted or unmapped per query.
+int query_snapshot(Query *q) {
+    hipStream_t st = q->ctx->stream;
+    if (!q->h_sum_buf || q->h_sum_buf.use_count() > 1) {
+        auto nb = std::make_shared<HostBuf>();
+        SYBL_HIP(hipHostMalloc((void **)&nb->p, (size_t)q->n_sum_words * 8, hipHostMallocDefault));
+        q->h_sum_buf = nb;
+    }
+    if (!q->h_max) SYBL_HIP(hipHostMalloc((void **)&q->h_max, (size_t)q->n_max_words * 8, hipHostMallocDefault));
+    q->h_sum = q->h_sum_buf->p;
+    SYBL_HIP(hipMemcpyAsync(q->h_sum, q->d_sum, (size_t)q->n_sum_words * 8, hipMemcpyDeviceToHost, st));
+    if (q->plan.n_max_fields > 0)
+        SYBL_HIP(hipMemcpyAsync(q->h_max, q->d_max, (size_t)q->n_max_words * 8, hipMemcpyDeviceToHost, st));
+    if (!q->ev_snap) SYBL_HIP(hipEventCreateWithFlags(&q->ev_snap, hipEventDisableTiming));
+    SYBL_HIP(hipEventRecord(q->ev_snap, st));
+    q->snapshot_pending = true;
+    return SYBL_OK;
+}
+
 // SYBL_FINALIZE_TRACE=1: per-phase host timings of query_finalize on stderr
 struct PhaseTrace {
     bool on = getenv("SYBL_FINALIZE_TRACE") != nullptr;
@@ -314,23 +336,15 @@ struct PhaseTrace {
 };
 
 int query_finalize(Query *q, Result **out) {
-    hipStream_t st = q->ctx->stream;
     const ScanPlan &P = q->plan;
     PhaseTrace trace;
-    // Pinned snapshot of the (reduced) partial table.  Results keep a reference to the snapshot
-    // their bucket arrays point into; the query reuses the buffer for the next finalize unless a
-    // live result still holds it (then a fresh one is allocated) -- so a 525 MB histogram table
-    // is never copied, page-faulted or unmapped per query.
-    if (!q->h_sum_buf || q->h_sum_buf.use_count() > 1) {
-        auto nb = std::make_shared<HostBuf>();
-        SYBL_HIP(hipHostMalloc((void **)&nb->p, (size_t)q->n_sum_words * 8, hipHostMallocDefault));
-        q->h_sum_buf = nb;
+    if (!q->snapshot_pending) {
+        int rc = query_snapshot(q);
+        if (rc) return rc;
     }
-    if (!q->h_max) SYBL_HIP(hipHostMalloc((void **)&q->h_max, (size_t)q->n_max_words * 8, hipHostMallocDefault));
-    q->h_sum = q->h_sum_buf->p;
-    SYBL_HIP(hipMemcpyAsync(q->h_sum, q->d_sum, (size_t)q->n_sum_words * 8, hipMemcpyDeviceToHost, st));
-    if (P.n_max_fields > 0) SYBL_HIP(hipMemcpyAsync(q->h_max, q->d_max, (size_t)q->n_max_words * 8, hipMemcpyDeviceToHost, st));
-    SYBL_HIP(hipStreamSynchronize(st));
+    // only the snapshot is waited for: work enqueued behind it (the scan of another query) keeps running
+    SYBL_HIP(hipEventSynchronize(q->ev_snap));
+    q->snapshot_pending = false;
     trace.mark("copy+sync");
     const int64_t *hs = q->h_sum, *hm = q->h_max;
     if (hs[kHdrPartOverflow] != 0 && q->part_hist) {

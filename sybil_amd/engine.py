@@ -321,6 +321,12 @@ class Query:
         N.check(N.lib().sybl_query_stats(self._h, C.byref(st)))
         return st.as_dict()
 
+    def snapshot(self):
+        """Enqueue the device -> host copy of the (reduced) partial tables; finalize() then waits for
+        that copy only, so the scan of another query can run underneath it."""
+        N.check(N.lib().sybl_query_snapshot(self._h))
+        return self
+
     def finalize(self):
         h = C.c_void_p()
         N.check(N.lib().sybl_query_finalize(self._h, C.byref(h)))

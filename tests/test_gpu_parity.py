@@ -630,3 +630,40 @@ def test_weighted_and_nullable_take_the_fast_kernels(ctx, oracle):
         gres.free()
         query.free()
     tb.free()
+
+
+def test_snapshot_lets_finalize_overlap_the_next_scan(ctx, oracle):
+    """sybl_query_snapshot: two prepared queries alternate; finalize(i) is called only after scan(i+1)
+    was launched and must still see step i's table (and wait for nothing but its own snapshot)."""
+    wl = _wl("cfg3_filter3_group2_stddev")
+    from sybil_amd import synth
+    rows = 700_000
+    t = ctx.synth_table("snap", synth.SEED, rows, 0, rows, synth.synth_cols(wl["columns"]))
+    t.compact()
+    qa = t.query(**wl["query"])
+    qb = t.query(**dict(wl["query"], filters=[("c04", "gt", 499)]))  # a different query: results must not mix
+    ra = qa.run()
+    rb = qb.run()
+    want_a = sorted((g["key"], g["count"], g["hists"][0]["sum"]) for g in ra.results)
+    want_b = sorted((g["key"], g["count"], g["hists"][0]["sum"]) for g in rb.results)
+    assert want_a != want_b
+    ra.free()
+    rb.free()
+    pending = None
+    for i in range(6):
+        q, want = (qa, want_a) if i % 2 == 0 else (qb, want_b)
+        q.scan().snapshot()
+        if pending is not None:
+            pq, pwant = pending
+            r = pq.finalize()
+            assert sorted((g["key"], g["count"], g["hists"][0]["sum"]) for g in r.results) == pwant
+            r.free()
+        pending = (q, want)
+    r = pending[0].finalize()
+    assert sorted((g["key"], g["count"], g["hists"][0]["sum"]) for g in r.results) == pending[1]
+    r.free()
+    with pytest.raises(Exception):
+        t.query(**wl["query"]).snapshot()  # before any scan
+    qa.free()
+    qb.free()
+    t.free()
