@@ -392,10 +392,23 @@ def test_full_size_properties(ctx):
     total_sums = [r.cumulative["hists"][a]["sum"] for a in range(2)]
     matched = r.matched
     key_counts = {g["key"]: g["count"] for g in groups}
+    full = {g["key"]: (g["count"],) + tuple((h["sum"], h["count"], h["stddev"], h["avg"]) for h in g["hists"]) for g in groups}
     for x in (r, rc):
         x.free()
     for x in (q, qc):
         x.free()
+    # the same table in compact storage (16 stored bytes per row, k_scan_packed): identical integers,
+    # hence identical floats
+    t.compact()
+    qk = t.query(**wl["query"])
+    rk = qk.run()
+    st = qk.stats()
+    assert st["packed_kernel"] == 1 and st["algorithmic_bytes"] == rows * 16 and st["canonical_bytes"] == rows * 56
+    assert rk.matched == matched
+    assert {g["key"]: (g["count"],) + tuple((h["sum"], h["count"], h["stddev"], h["avg"]) for h in g["hists"])
+            for g in rk.results} == full
+    rk.free()
+    qk.free()
     t.free()
     # halves add up (what the multi-GPU merge relies on)
     acc = {}
@@ -404,6 +417,8 @@ def test_full_size_properties(ctx):
     for rank in range(2):
         row0, n = synth.shard(rows, rank, 2)
         th = ctx.synth_table("half", synth.SEED, rows, row0, n, synth.synth_cols(wl["columns"]))
+        if rank == 1:
+            th.compact()  # ranks may use different storage: the partial tables still add up
         qh = th.query(**wl["query"])
         rh = qh.run()
         m2 += rh.matched
