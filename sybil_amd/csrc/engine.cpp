@@ -108,6 +108,14 @@ static void free_query(Query *q) {
     for (auto &e : q->ev)
         if (e) hipEventDestroy(e);
     if (q->ev_snap) hipEventDestroy(q->ev_snap);
+    if (q->d_pct) hipFree(q->d_pct);
+    if (q->d_mom) hipFree(q->d_mom);
+    if (q->d_total) hipFree(q->d_total);
+    if (q->h_pct) hipHostFree(q->h_pct);
+    if (q->h_mom) hipHostFree(q->h_mom);
+    if (q->h_total) hipHostFree(q->h_total);
+    if (q->d_top) hipFree(q->d_top);
+    if (q->d_top_cells) hipFree(q->d_top_cells);
     delete q;
 }
 
@@ -1249,6 +1257,7 @@ int sybl_init(int device, sybl_ctx **out) {
 void sybl_shutdown(sybl_ctx *ctx) {
     if (!ctx) return;
     sybl_comm_free(ctx);
+    if (ctx->aux_stream) hipStreamDestroy(ctx->aux_stream);
     if (ctx->own_stream) {
         hipStreamSynchronize(ctx->own_stream);
         hipStreamDestroy(ctx->own_stream);

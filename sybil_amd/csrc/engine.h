@@ -43,6 +43,9 @@ hipError_t launch_decode_bins(const uint32_t *recs, const int64_t *bin_off, cons
 hipError_t launch_decode_delta(const int64_t *deltas, int64_t n, bool value_encoded, int64_t *col, hipStream_t st);
 hipError_t launch_remap_ids(const int32_t *local, const int32_t *lut, int32_t n_lut, int64_t n, int32_t *col, hipStream_t st);
 
+hipError_t launch_hist_summary(const HistSummaryPlan &S, int64_t *total, hipStream_t st);
+hipError_t launch_hist_gather(const int64_t *H, int64_t hist_stride, const int64_t *d_cells, int64_t n, int64_t *out, hipStream_t st);
+
 struct Ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
@@ -52,6 +55,7 @@ struct Ctx {
     std::string dev_name;
     void *comm = nullptr;  // ncclComm_t (rccl.cpp)
     int comm_rank = 0, comm_nranks = 1;
+    hipStream_t aux_stream = nullptr;  // small finalize-side copies that must not queue behind another query's scan
 };
 
 struct Column {
@@ -202,6 +206,14 @@ struct Query {
     std::shared_ptr<HostBuf> h_sum_buf;          // pinned snapshot of the SUM section (shared with results)
     int64_t *h_sum = nullptr, *h_max = nullptr;  // h_sum = h_sum_buf->p; h_max: pinned staging
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    // GPU-side histogram summaries (percentiles, bucket moments, Cumulative buckets) for queries with
+    // many cells: only they, not the bucket arrays, cross PCIe unless every row's buckets are wanted
+    bool hist_summary = false;
+    bool snap_has_buckets = true;   // the last snapshot carried the bucket arrays
+    int64_t *d_pct = nullptr, *d_mom = nullptr, *d_total = nullptr;
+    int64_t *h_pct = nullptr, *h_mom = nullptr, *h_total = nullptr;  // pinned
+    int64_t *d_top_cells = nullptr, *d_top = nullptr;               // bucket arrays of the printed rows
+    int64_t top_cap = 0;
     hipEvent_t ev_snap = nullptr;   // the device -> host snapshot of the partial tables has landed
     bool snapshot_pending = false;
     bool scanned = false;

@@ -813,6 +813,76 @@ hipError_t launch_part_hist(const PartHistPlan &P, hipStream_t st) {
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------- histogram summaries (finalize)
+// With tens of thousands of groups the [cell][agg][bucket] table is hundreds of MB: copying it to
+// the host and walking it there costs more than the scan.  These kernels derive what the result
+// rows need -- GetPercentiles (hist_basic.go:153-183), the bucket moments of GetStdDev
+// (:192-219) and the Cumulative bucket arrays (aggregate.go:422-438) -- where the table lives.
+// one thread per (cell, aggregation): the reference's loop, literally
+__global__ __launch_bounds__(256) void k_hist_summary(const HistSummaryPlan S) {
+    const int64_t pair = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pair >= S.n_cells * S.n_aggs) return;
+    const int64_t cell = pair / S.n_aggs;
+    const int a = (int)(pair - cell * S.n_aggs);
+    const int64_t *v = S.H + cell * S.hist_stride + S.agg_off[a];
+    const int64_t count = S.F[(int64_t)S.f_cnt[a] * S.n_cells + cell];
+    int64_t *out = S.pct + pair * 100;
+    const int64_t bs = S.bucket_size[a], hmin = S.hmin[a];
+    int64_t sb = 0, sb2 = 0, c = 0, prev_p = 0;
+    if (count != 0) out[0] = hmin;
+    for (int64_t k = 0; k < S.n_values[a]; k++) {
+        const int64_t x = v[k];
+        sb += k * x;
+        sb2 += k * k * x;
+        if (count == 0) continue;
+        c += x;
+        int64_t p = (100 * c) / count;
+        p = p < 0 ? 0 : (p > 100 ? 100 : p);
+        const int64_t val = k * bs + hmin;
+        for (int64_t ip = prev_p; ip <= p; ip++)
+            if (ip < 100) out[ip] = val;
+        if (p < 100) out[p] = k;
+        prev_p = p;
+    }
+    S.mom[pair * 2] = sb;
+    S.mom[pair * 2 + 1] = sb2;
+}
+
+// total[w] = sum over cells of H[cell][w]: a block owns a range of cells, threads stride over the
+// words of a cell (coalesced), one atomic per word and block into the zeroed total
+__global__ __launch_bounds__(256) void k_hist_total(const int64_t *__restrict__ H, int64_t hist_stride, int64_t n_cells,
+                                                    int64_t cells_per_block, int64_t *__restrict__ total) {
+    const int64_t c0 = (int64_t)blockIdx.x * cells_per_block;
+    const int64_t c1 = c0 + cells_per_block < n_cells ? c0 + cells_per_block : n_cells;
+    for (int64_t w = threadIdx.x; w < hist_stride; w += blockDim.x) {
+        int64_t acc = 0;
+        for (int64_t cell = c0; cell < c1; cell++) acc += H[cell * hist_stride + w];
+        if (acc) gadd(total + w, acc);
+    }
+}
+
+// out[i][w] = H[cells[i]][w]: the bucket arrays of the rows that will be printed
+__global__ __launch_bounds__(256) void k_hist_gather(const int64_t *__restrict__ H, int64_t hist_stride,
+                                                     const int64_t *__restrict__ cells, int64_t *__restrict__ out) {
+    const int64_t cell = cells[blockIdx.x];
+    for (int64_t w = threadIdx.x; w < hist_stride; w += blockDim.x) out[(int64_t)blockIdx.x * hist_stride + w] = H[cell * hist_stride + w];
+}
+
+hipError_t launch_hist_summary(const HistSummaryPlan &S, int64_t *total, hipStream_t st) {
+    const int64_t pairs = S.n_cells * S.n_aggs;
+    if (pairs <= 0) return hipSuccess;
+    const int64_t cpb = 64;
+    hipLaunchKernelGGL(k_hist_total, dim3((unsigned)((S.n_cells + cpb - 1) / cpb)), dim3(256), 0, st, S.H, S.hist_stride, S.n_cells, cpb, total);
+    hipLaunchKernelGGL(k_hist_summary, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, st, S);
+    return hipGetLastError();
+}
+
+hipError_t launch_hist_gather(const int64_t *H, int64_t hist_stride, const int64_t *d_cells, int64_t n, int64_t *out, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_hist_gather, dim3((unsigned)n), dim3(256), 0, st, H, hist_stride, d_cells, out);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------- launchers (host)
 
 template <int NC>

@@ -133,6 +133,18 @@ struct ScanPlan {
     const int32_t *wg_seg_begin;  // [n_wg+1]
 };
 
+// finalize-side histogram summaries (kernels.hip: k_hist_summary / k_hist_total)
+struct HistSummaryPlan {
+    const int64_t *H;          // [cell][hist_stride]
+    const int64_t *F;          // cell fields [field][n_cells]
+    int64_t hist_stride, n_cells;
+    int32_t n_aggs, pad_;
+    int64_t agg_off[kMaxAggs], n_values[kMaxAggs], bucket_size[kMaxAggs], hmin[kMaxAggs];
+    int32_t f_cnt[kMaxAggs];   // field holding the aggregation's count (0 = Result.Count)
+    int64_t *pct;              // [cell * n_aggs + a][100], zeroed
+    int64_t *mom;              // [cell * n_aggs + a][2]: sum(b * Values[b]), sum(b^2 * Values[b])
+};
+
 // SUM-section header words
 enum Header : int {
     kHdrMatched = 0,     // QuerySpec.MatchedCount

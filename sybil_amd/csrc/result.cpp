@@ -29,6 +29,8 @@ namespace sybl {
 
 struct AggAcc {
     bool tracked_cnt = false;
+    const int64_t *pct_gpu = nullptr;  // GetPercentiles computed by k_hist_summary (100 entries)
+    bool moments = false;              // sb / sb2 are valid even though the query keeps bucket arrays
     int64_t cnt = 0, smp = 0, pop = 0;
     uint64_t sum = 0;
     int64_t sb = 0, sb2 = 0;
@@ -50,6 +52,7 @@ struct RowStore {
     std::string gbk;
     int64_t time_bucket = 0, count = 0, samples = 0;
     int64_t agg_off = 0;  // this row's n_aggs entries in Result::agg_pool / val_pool / pctoff_pool
+    int64_t cell = -1;    // group cell (rows of Results / TimeResults)
 };
 
 // The big per-result arrays, recycled between the results of one query: a time-series or
@@ -57,6 +60,7 @@ struct RowStore {
 // in munmap on free) than building its rows does.
 struct ResultStore {
     std::vector<RowStore> rows[3];
+    std::vector<RowStore> rows_tmp;  // sort scratch
     std::vector<sybl_group_row> view[3];
     std::vector<int64_t> pct_pool, pctoff_pool;
     std::vector<sybl_agg_out> agg_pool;
@@ -67,6 +71,7 @@ struct ResultStore {
             rows[w].swap(o.rows[w]);
             view[w].swap(o.view[w]);
         }
+        rows_tmp.swap(o.rows_tmp);
         pct_pool.swap(o.pct_pool);
         pctoff_pool.swap(o.pctoff_pool);
         agg_pool.swap(o.agg_pool);
@@ -98,6 +103,7 @@ struct Result : ResultStore {
     std::shared_ptr<HostBuf> keep;                // the pinned snapshot of the partial table the bucket
                                                   // arrays of the rows point into
     std::vector<std::vector<int64_t>> total_vals; // Cumulative bucket arrays
+    std::vector<int64_t> top_vals;                // bucket arrays of the first `limit` rows (GPU summary path)
     // (ResultStore) pct_pool: 100 entries per (row, agg) with percentiles; agg_pool / val_pool /
     // pctoff_pool: n_aggs entries per row, all row kinds (pctoff: offset into pct_pool, -1 = none)
     // for rendering
@@ -168,12 +174,18 @@ static void agg_finish(const Query *q, Result *R, const AggInfo &ai, const AggAc
         long double A1 = (long double)o.avg;
         out_term = (sq - 2.0L * A1 * (long double)(int64_t)a.sum_out + (long double)a.n_out * A1 * A1) / (long double)cnt;
     }
-    if (q->want_percentiles && a.values) {
-        values_out = a.values;
+    if (q->want_percentiles && (a.values || a.pct_gpu)) {
+        values_out = a.values;  // nullptr on the GPU-summary path: attached later for the printed rows
         if (cnt != 0) {
             pct_off = pct_slot;  // pre-sized pool: one 100-entry slot per (row, agg)
-            percentiles_from_values(a.values, A.n_values, A.bucket_size, A.hmin, cnt, R->pct_pool.data() + pct_off);
+            if (a.pct_gpu) {
+                memcpy(R->pct_pool.data() + pct_off, a.pct_gpu, 100 * sizeof(int64_t));
+            } else {
+                percentiles_from_values(a.values, A.n_values, A.bucket_size, A.hmin, cnt, R->pct_pool.data() + pct_off);
+            }
         }
+    }
+    if (q->want_percentiles && a.values && !a.moments) {
         // GetStdDev, hist_basic.go:192-219, with Avg = sum/count
         double sum_variance = 0;
         for (int64_t b = 0; b < A.n_values; b++) {
@@ -299,8 +311,19 @@ static void make_views(Result *R) {
 // Pinned snapshot: results keep a reference to the snapshot their bucket arrays point into; the
 // query reuses the buffer for the next finalize unless a live result still holds it (then a fresh
 // one is allocated) -- so a 525 MB histogram table is never copied, page-faulted or unmapped per query.
+// Many cells with bucket arrays: percentiles / bucket moments / Cumulative buckets come from the GPU.
+static bool wants_hist_summary(const Query *q) {
+    const ScanPlan &P = q->plan;
+    if (getenv("SYBL_NO_HISTSUMMARY")) return false;
+    if (q->op != SYBL_AGG_HIST || !q->want_percentiles || q->time_mode || P.hist_stride <= 0 || q->aggs.empty()) return false;
+    for (auto &a : q->aggs)
+        if (!a.d.hist_full) return false;
+    return P.n_cells >= 2048;
+}
+
 int query_snapshot(Query *q) {
     hipStream_t st = q->ctx->stream;
+    const ScanPlan &P = q->plan;
     if (!q->h_sum_buf || q->h_sum_buf.use_count() > 1) {
         auto nb = std::make_shared<HostBuf>();
         SYBL_HIP(hipHostMalloc((void **)&nb->p, (size_t)q->n_sum_words * 8, hipHostMallocDefault));
@@ -308,12 +331,83 @@ int query_snapshot(Query *q) {
     }
     if (!q->h_max) SYBL_HIP(hipHostMalloc((void **)&q->h_max, (size_t)q->n_max_words * 8, hipHostMallocDefault));
     q->h_sum = q->h_sum_buf->p;
-    SYBL_HIP(hipMemcpyAsync(q->h_sum, q->d_sum, (size_t)q->n_sum_words * 8, hipMemcpyDeviceToHost, st));
-    if (q->plan.n_max_fields > 0)
+    q->hist_summary = wants_hist_summary(q);
+    // the bucket arrays cross PCIe only when every row's are wanted (no limit); otherwise the printed
+    // rows' arrays are gathered after the sort (query_finalize)
+    q->snap_has_buckets = !q->hist_summary || q->limit <= 0;
+    if (q->hist_summary) {
+        const int64_t pairs = (int64_t)P.n_cells * (int64_t)q->aggs.size();
+        if (!q->d_pct) {
+            SYBL_HIP(hipMalloc((void **)&q->d_pct, (size_t)pairs * 100 * 8));
+            SYBL_HIP(hipMalloc((void **)&q->d_mom, (size_t)pairs * 2 * 8));
+            SYBL_HIP(hipMalloc((void **)&q->d_total, (size_t)P.hist_stride * 8));
+            SYBL_HIP(hipHostMalloc((void **)&q->h_pct, (size_t)pairs * 100 * 8, hipHostMallocDefault));
+            SYBL_HIP(hipHostMalloc((void **)&q->h_mom, (size_t)pairs * 2 * 8, hipHostMallocDefault));
+            SYBL_HIP(hipHostMalloc((void **)&q->h_total, (size_t)P.hist_stride * 8, hipHostMallocDefault));
+        }
+        SYBL_HIP(hipMemsetAsync(q->d_pct, 0, (size_t)pairs * 100 * 8, st));
+        SYBL_HIP(hipMemsetAsync(q->d_total, 0, (size_t)P.hist_stride * 8, st));
+        HistSummaryPlan S;
+        memset(&S, 0, sizeof(S));
+        S.H = q->d_sum + P.hist_off;
+        S.F = q->d_sum + kHeaderWords;
+        S.hist_stride = P.hist_stride;
+        S.n_cells = P.n_cells;
+        S.n_aggs = (int32_t)q->aggs.size();
+        for (size_t a = 0; a < q->aggs.size(); a++) {
+            const AggDesc &A = q->aggs[a].d;
+            S.agg_off[a] = P.hist_agg_off[a];
+            S.n_values[a] = A.n_values;
+            S.bucket_size[a] = A.bucket_size;
+            S.hmin[a] = A.hmin;
+            S.f_cnt[a] = A.f_cnt >= 0 ? A.f_cnt : 0;
+        }
+        S.pct = q->d_pct;
+        S.mom = q->d_mom;
+        hipError_t e = launch_hist_summary(S, q->d_total, st);
+        if (e != hipSuccess) return hip_fail(e, "k_hist_summary");
+        SYBL_HIP(hipMemcpyAsync(q->h_pct, q->d_pct, (size_t)pairs * 100 * 8, hipMemcpyDeviceToHost, st));
+        SYBL_HIP(hipMemcpyAsync(q->h_mom, q->d_mom, (size_t)pairs * 2 * 8, hipMemcpyDeviceToHost, st));
+        SYBL_HIP(hipMemcpyAsync(q->h_total, q->d_total, (size_t)P.hist_stride * 8, hipMemcpyDeviceToHost, st));
+    }
+    const int64_t words = q->snap_has_buckets ? q->n_sum_words : P.hist_off;
+    SYBL_HIP(hipMemcpyAsync(q->h_sum, q->d_sum, (size_t)words * 8, hipMemcpyDeviceToHost, st));
+    if (P.n_max_fields > 0)
         SYBL_HIP(hipMemcpyAsync(q->h_max, q->d_max, (size_t)q->n_max_words * 8, hipMemcpyDeviceToHost, st));
     if (!q->ev_snap) SYBL_HIP(hipEventCreateWithFlags(&q->ev_snap, hipEventDisableTiming));
     SYBL_HIP(hipEventRecord(q->ev_snap, st));
     q->snapshot_pending = true;
+    return SYBL_OK;
+}
+
+// The bucket arrays of the first `top` rows of Results (the rows a printer shows) -- gathered on
+// the GPU into one buffer and copied in one piece.  Runs on the context's auxiliary stream: the
+// main stream may already be busy with the scan of another query.
+static int attach_top_values(Query *q, Result *R, size_t top) {
+    const ScanPlan &P = q->plan;
+    Ctx *ctx = q->ctx;
+    const size_t na = q->aggs.size();
+    if (top == 0) return SYBL_OK;
+    if (!ctx->aux_stream) SYBL_HIP(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+    if ((int64_t)top > q->top_cap) {
+        if (q->d_top) SYBL_HIP(hipFree(q->d_top));
+        if (q->d_top_cells) SYBL_HIP(hipFree(q->d_top_cells));
+        SYBL_HIP(hipMalloc((void **)&q->d_top, top * (size_t)P.hist_stride * 8));
+        SYBL_HIP(hipMalloc((void **)&q->d_top_cells, top * 8));
+        q->top_cap = (int64_t)top;
+    }
+    std::vector<int64_t> cells(top);
+    for (size_t i = 0; i < top; i++) cells[i] = R->rows[0][i].cell;
+    R->top_vals.resize(top * (size_t)P.hist_stride);
+    SYBL_HIP(hipMemcpyAsync(q->d_top_cells, cells.data(), top * 8, hipMemcpyHostToDevice, ctx->aux_stream));
+    hipError_t e = launch_hist_gather(q->d_sum + P.hist_off, P.hist_stride, q->d_top_cells, (int64_t)top, q->d_top, ctx->aux_stream);
+    if (e != hipSuccess) return hip_fail(e, "k_hist_gather");
+    SYBL_HIP(hipMemcpyAsync(R->top_vals.data(), q->d_top, R->top_vals.size() * 8, hipMemcpyDeviceToHost, ctx->aux_stream));
+    SYBL_HIP(hipStreamSynchronize(ctx->aux_stream));
+    for (size_t i = 0; i < top; i++)
+        for (size_t a = 0; a < na; a++)
+            if (R->agg_pool[(size_t)R->rows[0][i].agg_off + a].present)
+                R->val_pool[(size_t)R->rows[0][i].agg_off + a] = R->top_vals.data() + i * (size_t)P.hist_stride + P.hist_agg_off[a];
     return SYBL_OK;
 }
 
@@ -384,10 +478,11 @@ int query_finalize(Query *q, Result **out) {
     const int64_t ncell = P.n_cells, gcells = q->group_cells;
     const int64_t *F = hs + kHeaderWords;
     const int64_t *H = nullptr;
-    if (P.hist_stride > 0) {
+    if (P.hist_stride > 0 && q->snap_has_buckets) {
         R->keep = q->h_sum_buf;  // the rows' bucket arrays live in the snapshot
         H = hs + P.hist_off;
     }
+    const bool summary = q->hist_summary;
     const size_t na = q->aggs.size();
 
     auto load_cell = [&](int64_t cell, CellAcc &acc) -> bool {
@@ -415,7 +510,14 @@ int query_finalize(Query *q, Result **out) {
             }
             if (A.m_max >= 0) x.vmax = hm[(int64_t)A.m_max * ncell + cell];
             if (A.m_nmin >= 0) x.nmin = hm[(int64_t)A.m_nmin * ncell + cell];
-            if (A.hist_full) x.values = H + cell * P.hist_stride + P.hist_agg_off[a];
+            if (A.hist_full && H) x.values = H + cell * P.hist_stride + P.hist_agg_off[a];
+            if (A.hist_full && summary) {
+                const int64_t pair = cell * (int64_t)na + (int64_t)a;
+                x.pct_gpu = q->h_pct + pair * 100;
+                x.sb = q->h_mom[pair * 2];
+                x.sb2 = q->h_mom[pair * 2 + 1];
+                x.moments = true;
+            }
         }
         return true;
     };
@@ -480,6 +582,7 @@ int query_finalize(Query *q, Result **out) {
             const int64_t tbi = cell / gcells, gcell = cell - tbi * gcells;
             RowStore &row = cell_rows[i];
             row.agg_off = (int64_t)(i * na);
+            row.cell = cell;
             build_key(q, gcell, row.key, row.gbk);
             row.time_bucket = q->time_mode ? (P.tb_min + tbi) * P.time_bucket : 0;  // (rows are recycled: assign every field)
             finish_row(q, R, acc, row);
@@ -556,6 +659,10 @@ int query_finalize(Query *q, Result **out) {
             }
         }
     }
+    if (summary)
+        for (size_t a = 0; a < na; a++)
+            if (!R->total_vals[a].empty())
+                memcpy(R->total_vals[a].data(), q->h_total + P.hist_agg_off[a], R->total_vals[a].size() * sizeof(int64_t));
     trace.mark("rows");
     size_t next_slot = live.size();
     if (q->time_mode) {
@@ -599,24 +706,69 @@ int query_finalize(Query *q, Result **out) {
             }
         }
         std::vector<RowStore> &rows = R->rows[0];
-        auto less = [&](uint32_t ix, uint32_t iy) {
-            const RowStore &x = rows[ix], &y = rows[iy];
-            if (by < 0) return x.count > y.count;
-            const sybl_agg_out &ax = R->agg_pool[(size_t)x.agg_off + by], &ay = R->agg_pool[(size_t)y.agg_off + by];
-            double mx = ax.present ? ax.avg : -INFINITY;
-            double my = ay.present ? ay.avg : -INFINITY;
-            return mx > my;
-        };
-        std::vector<uint32_t> order(rows.size());
-        for (size_t i = 0; i < order.size(); i++) order[i] = (uint32_t)i;
-        std::stable_sort(order.begin(), order.end(), less);
+        const size_t n = rows.size();
+        std::vector<uint32_t> order(n);
+        for (size_t i = 0; i < n; i++) order[i] = (uint32_t)i;
+        if (n < 8192) {
+            auto less = [&](uint32_t ix, uint32_t iy) {
+                const RowStore &x = rows[ix], &y = rows[iy];
+                if (by < 0) return x.count > y.count;
+                const sybl_agg_out &ax = R->agg_pool[(size_t)x.agg_off + by], &ay = R->agg_pool[(size_t)y.agg_off + by];
+                double mx = ax.present ? ax.avg : -INFINITY;
+                double my = ay.present ? ay.avg : -INFINITY;
+                return mx > my;
+            };
+            std::stable_sort(order.begin(), order.end(), less);
+        } else {
+            // many groups: stable LSD radix sort (16-bit digits) on a key whose ascending unsigned order is
+            // the descending order of Count / of the mean
+            std::vector<uint64_t> key(n);
+            for (size_t i = 0; i < n; i++) {
+                uint64_t u;
+                if (by < 0) {
+                    u = (uint64_t)rows[i].count ^ 0x8000000000000000ull;
+                } else {
+                    const sybl_agg_out &ax = R->agg_pool[(size_t)rows[i].agg_off + by];
+                    double m = ax.present ? ax.avg : -INFINITY;
+                    if (m == 0.0) m = 0.0;  // -0.0 and +0.0 compare equal
+                    uint64_t b;
+                    memcpy(&b, &m, 8);
+                    u = (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+                }
+                key[i] = ~u;
+            }
+            std::vector<uint32_t> tmp(n);
+            std::vector<uint32_t> cnt(65536);
+            for (int shift = 0; shift < 64; shift += 16) {
+                std::fill(cnt.begin(), cnt.end(), 0u);
+                for (size_t i = 0; i < n; i++) cnt[(key[order[i]] >> shift) & 0xFFFFu]++;
+                if (cnt[(key[order[0]] >> shift) & 0xFFFFu] == n) continue;  // every key shares this digit
+                uint32_t run = 0;
+                for (size_t d = 0; d < 65536; d++) {
+                    uint32_t c2 = cnt[d];
+                    cnt[d] = run;
+                    run += c2;
+                }
+                for (size_t i = 0; i < n; i++) tmp[cnt[(key[order[i]] >> shift) & 0xFFFFu]++] = order[i];
+                order.swap(tmp);
+            }
+        }
         if (q->order_asc) std::reverse(order.begin(), order.end());
-        std::vector<RowStore> sorted;
-        sorted.reserve(rows.size());
-        for (uint32_t i : order) sorted.push_back(std::move(rows[i]));
+        std::vector<RowStore> &sorted = R->rows_tmp;  // (recycled like the other arrays)
+        sorted.resize(n);
+        for (size_t i = 0; i < n; i++) std::swap(sorted[i], rows[order[i]]);
         rows.swap(sorted);
     }
     trace.mark("sort");
+    R->top_vals.clear();
+    if (summary && !q->snap_has_buckets) {
+        int rc = attach_top_values(q, R, std::min<size_t>((size_t)q->limit, R->rows[0].size()));
+        if (rc) {
+            delete R;
+            return rc;
+        }
+        trace.mark("top-values");
+    }
     make_views(R);
     trace.mark("views");
     *out = R;

@@ -8,7 +8,10 @@ rows = int(sys.argv[2]) if len(sys.argv) > 2 else 200_000_000
 wl = synth.WORKLOADS[name]
 ctx = sybil_amd.Context(0)
 t = ctx.synth_table("b", synth.SEED, rows, 0, rows, synth.synth_cols(wl["columns"]))
-q = t.query(**wl["query"])
+kw = dict(wl["query"])
+if len(sys.argv) > 3:
+    kw["limit"] = int(sys.argv[3])
+q = t.query(**kw)
 q.run().free()
 for _ in range(3):
     t0 = time.perf_counter(); q.scan(); ctx.sync(); t1 = time.perf_counter(); r = q.finalize(); t2 = time.perf_counter(); r.free(); t3 = time.perf_counter()
