@@ -144,6 +144,13 @@ int sybl_table_create_synth(sybl_ctx *ctx, const char *name, uint64_t seed, int6
 int sybl_table_open(sybl_ctx *ctx, const char *dir, const char *table, const char *const *columns,
                     int32_t n_columns, int32_t rank, int32_t nranks, sybl_table **out);
 
+/* sybl_table_open with options.  SYBL_OPEN_COMPACT: the table is in compact storage from the first
+ * block on (each decoded block is packed into place, columns widen when a block needs it), so a table
+ * whose canonical form would not fit in HBM can still be loaded. */
+#define SYBL_OPEN_COMPACT 1
+int sybl_table_open_flags(sybl_ctx *ctx, const char *dir, const char *table, const char *const *columns,
+                          int32_t n_columns, int32_t rank, int32_t nranks, int32_t flags, sybl_table **out);
+
 /* Blocks sybl_table_open skipped the way the reference does: unreadable block info.db, NumRecords
  * <= 0, or a column file whose record ids / value count exceed NumRecords ("BLOCK SIZE CHANGED
  * DURING QUERY", column_store_io.go:524-526,572-574,733-735; table_query.go:134-139). */
@@ -177,8 +184,10 @@ int sybl_table_set_dict(sybl_table *t, const char *name, const char *const *stri
  * every INT / STR column as unsigned offsets from the column's exact minimum at the narrowest of
  * 1, 2, 4 bytes that holds max - min (8 when it does not fit) -- the in-HBM counterpart of the
  * reference's bucket / delta encoded column files (column_store_io.go:64-358).  Every kernel decodes
- * while loading, so query results are identical; a scan streams the compact bytes.  Appending a
- * block or installing a dictionary returns the table to canonical storage (call compact again).
+ * while loading, so query results are identical; a scan streams the compact bytes.  The table stays
+ * in compact mode: blocks appended later are packed into place (a column is re-encoded wider when a
+ * block does not fit its width / base; call compact again to re-narrow).  On an empty table the call
+ * only switches the mode on.  Installing a str dictionary returns that column to int32 ids.
  * Prepared queries must be prepared again afterwards (SYBL_E_STATE otherwise). */
 int sybl_table_compact(sybl_table *t);
 /* bytes per stored value and the value base of a column as currently laid out in HBM */

@@ -97,6 +97,9 @@ struct Column {
     std::vector<int64_t> h_set_off;  // host mirror: CSR offsets per physical row (+1)
     std::vector<int32_t> h_set_vals; // host mirror: member ids (table-global)
     bool set_dirty = false;          // host mirror newer than the device copy
+    // compact mode: writers fill this canonical-width staging block, block_commit packs it in place
+    void *d_stage = nullptr;
+    int64_t stage_cap = 0;           // bytes
 };
 
 struct Table {
@@ -109,6 +112,8 @@ struct Table {
     std::vector<Segment> blocks;  // physical start / logical row count
     Segment *d_blocks = nullptr;
     int64_t d_blocks_n = 0;
+    bool compact_mode = false;  // sybl_table_compact was called: appended blocks are packed in place
+    int64_t *d_scratch = nullptr;  // one Segment + min/max/pop of a staged block
     int64_t version = 0;        // bumped by every change a prepared query would not know about
     int64_t broken_blocks = 0;  // blocks the loader skipped (unreadable info / column unpack error)
     Column *find(const char *name) const;
@@ -123,11 +128,11 @@ int column_upload_set(Table *t, Column *c);
 int column_build_gdict(Table *t, Column *c);           // distinct values of the resident rows
 int column_install_gdict(Table *t, Column *c);         // sorted gdict -> device value->rank map
 int column_repack(Table *t, Column *c, int width, int64_t vbase);  // change the stored width in place
-int table_unpack(Table *t);                            // every column back to canonical storage
 
 struct BlockWriter {
     Table *t = nullptr;
     int64_t start = 0, nrows = 0, new_phys = 0;
+    std::vector<Column *> staged;  // compact mode: columns whose block sits in Column::d_stage
 };
 int block_begin(Table *t, int64_t nrows, BlockWriter *w);
 int block_col_device(BlockWriter &w, Column *c, bool all_populated, void **col, uint32_t **valid);

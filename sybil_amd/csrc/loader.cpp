@@ -329,7 +329,7 @@ static int apply_col(BlockWriter &w, Column *c, PreparedCol &pc, Stage &stage) {
 }
 
 static int open_table(Ctx *ctx, const char *dir, const char *table, const char *const *columns, int32_t n_columns,
-                      int32_t rank, int32_t nranks, sybl_table **out) {
+                      int32_t rank, int32_t nranks, int32_t flags, sybl_table **out) {
     std::string tdir = std::string(dir ? dir : ".") + "/" + table;
     std::string err;
     // ---- table info.db: KeyTable, KeyTypes, IntInfo (table_io.go:145-180)
@@ -351,6 +351,7 @@ static int open_table(Ctx *ctx, const char *dir, const char *table, const char *
 
     sybl_table *t = nullptr;
     int rc = sybl_table_create((sybl_ctx *)ctx, table, &t);
+    if (rc == SYBL_OK && (flags & SYBL_OPEN_COMPACT)) t->compact_mode = true;  // every block is packed as it arrives
     if (rc) return rc;
     auto bail = [&](int code) {
         sybl_table_free(t);
@@ -443,7 +444,15 @@ int sybl_table_open(sybl_ctx *ctx, const char *dir, const char *table, const cha
     if (!ctx || !table || !out || rank < 0 || (nranks > 0 && rank >= nranks)) return fail(SYBL_E_INVAL, "sybl_table_open: bad argument");
     *out = nullptr;
     SYBL_HIP(hipSetDevice(ctx->device));
-    return open_table(ctx, dir, table, columns, n_columns, rank, nranks, out);
+    return open_table(ctx, dir, table, columns, n_columns, rank, nranks, 0, out);
+}
+
+int sybl_table_open_flags(sybl_ctx *ctx, const char *dir, const char *table, const char *const *columns, int32_t n_columns,
+                          int32_t rank, int32_t nranks, int32_t flags, sybl_table **out) {
+    if (!ctx || !table || !out || rank < 0 || (nranks > 0 && rank >= nranks)) return fail(SYBL_E_INVAL, "sybl_table_open: bad argument");
+    *out = nullptr;
+    SYBL_HIP(hipSetDevice(ctx->device));
+    return open_table(ctx, dir, table, columns, n_columns, rank, nranks, flags, out);
 }
 
 int64_t sybl_table_broken_blocks(const sybl_table *t) { return t ? t->broken_blocks : 0; }

@@ -125,18 +125,6 @@ int column_repack(Table *t, Column *c, int width, int64_t vbase) {
     return SYBL_OK;
 }
 
-int table_unpack(Table *t) {
-    bool any = false;
-    for (auto &c : t->cols) {
-        if (c->type == SYBL_SET_VAL || !c->packed()) continue;
-        int rc = column_repack(t, c.get(), c->canon(), 0);
-        if (rc) return rc;
-        any = true;
-    }
-    if (any) t->version++;
-    return SYBL_OK;
-}
-
 void column_free(Column *c) {
     if (c->d_data) hipFree(c->d_data);
     if (c->d_valid) hipFree(c->d_valid);
@@ -144,6 +132,7 @@ void column_free(Column *c) {
     if (c->d_set_vals) hipFree(c->d_set_vals);
     if (c->d_gdict_keys) hipFree(c->d_gdict_keys);
     if (c->d_gdict_ranks) hipFree(c->d_gdict_ranks);
+    if (c->d_stage) hipFree(c->d_stage);
 }
 
 int32_t dict_intern(Column *c, const std::string &s) {
@@ -164,10 +153,8 @@ int32_t dict_intern(Column *c, const std::string &s) {
 
 int block_begin(Table *t, int64_t nrows, BlockWriter *w) {
     if (nrows < 0) return fail(SYBL_E_INVAL, "negative row count");
-    // writers produce canonical values: a compacted table goes back to canonical storage first
-    int rc = table_unpack(t);
-    if (rc) return rc;
     w->t = t;
+    w->staged.clear();
     w->nrows = nrows;
     w->start = round_up(t->phys_rows, 32);
     w->new_phys = w->start + nrows;
@@ -180,7 +167,20 @@ int block_col_device(BlockWriter &w, Column *c, bool all_populated, void **col, 
     Table *t = w.t;
     hipStream_t st = t->ctx->stream;
     int rc;
-    if (c->type != SYBL_SET_VAL) {
+    if (c->type != SYBL_SET_VAL && t->compact_mode) {
+        // writers produce canonical values: they go to a staging block that block_commit packs into
+        // the column at whatever width the column has (or needs) by then
+        const int64_t need = std::max<int64_t>(w.nrows, 1) * c->canon();
+        if (need > c->stage_cap) {
+            if (c->d_stage) SYBL_HIP(hipFree(c->d_stage));
+            c->d_stage = nullptr;
+            SYBL_HIP(hipMalloc(&c->d_stage, (size_t)need));
+            c->stage_cap = need;
+        }
+        *col = c->d_stage;
+        if (!all_populated && w.nrows > 0) SYBL_HIP(hipMemsetAsync(*col, 0, (size_t)w.nrows * c->canon(), st));
+        w.staged.push_back(c);
+    } else if (c->type != SYBL_SET_VAL) {
         if ((rc = table_reserve(t, c, w.new_phys))) return rc;
         *col = (char *)c->d_data + (size_t)w.start * c->elem;
         if (!all_populated && w.nrows > 0) SYBL_HIP(hipMemsetAsync(*col, 0, (size_t)w.nrows * c->elem, st));
@@ -205,7 +205,7 @@ int block_col_device(BlockWriter &w, Column *c, bool all_populated, void **col, 
 }
 
 // populated: nrows bytes, nullptr = every row; absent column: pass all zero via block_col_absent
-static int put_valid_bits(BlockWriter &w, Column *c, const uint8_t *populated, bool absent) {
+static int put_valid_bits(BlockWriter &w, Column *c, const uint8_t *populated, bool absent, void **col_out = nullptr) {
     bool all = !absent;
     if (!absent && populated) {
         for (int64_t r = 0; r < w.nrows; r++)
@@ -215,6 +215,7 @@ static int put_valid_bits(BlockWriter &w, Column *c, const uint8_t *populated, b
     uint32_t *valid = nullptr;
     int rc = block_col_device(w, c, all, &col, &valid);
     if (rc) return rc;
+    if (col_out) *col_out = col;
     if (valid && !absent) {
         std::vector<uint32_t> bits((size_t)(round_up(w.nrows, 32) / 32), 0);
         for (int64_t r = 0; r < w.nrows; r++)
@@ -243,20 +244,22 @@ int block_col_absent(BlockWriter &w, Column *c) {
 }
 
 int block_col_int_host(BlockWriter &w, Column *c, const int64_t *vals, const uint8_t *populated) {
-    int rc = put_valid_bits(w, c, populated, false);
+    void *col = nullptr;
+    int rc = put_valid_bits(w, c, populated, false, &col);
     if (rc || w.nrows == 0) return rc;
     hipStream_t st = w.t->ctx->stream;
-    SYBL_HIP(hipMemcpyAsync((int64_t *)c->d_data + w.start, vals, (size_t)w.nrows * 8, hipMemcpyHostToDevice, st));
+    SYBL_HIP(hipMemcpyAsync(col, vals, (size_t)w.nrows * 8, hipMemcpyHostToDevice, st));
     SYBL_HIP(hipStreamSynchronize(st));
     return SYBL_OK;
 }
 
 // ids: table-global dictionary ids
 int block_col_str_host(BlockWriter &w, Column *c, const int32_t *global_ids, const uint8_t *populated) {
-    int rc = put_valid_bits(w, c, populated, false);
+    void *col = nullptr;
+    int rc = put_valid_bits(w, c, populated, false, &col);
     if (rc || w.nrows == 0) return rc;
     hipStream_t st = w.t->ctx->stream;
-    SYBL_HIP(hipMemcpyAsync((int32_t *)c->d_data + w.start, global_ids, (size_t)w.nrows * 4, hipMemcpyHostToDevice, st));
+    SYBL_HIP(hipMemcpyAsync(col, global_ids, (size_t)w.nrows * 4, hipMemcpyHostToDevice, st));
     SYBL_HIP(hipStreamSynchronize(st));
     return SYBL_OK;
 }
@@ -277,8 +280,100 @@ int block_col_set_host(BlockWriter &w, Column *c, const int64_t *off, const int3
     return SYBL_OK;
 }
 
+// narrowest (width, base) that holds [lo, hi]; canonical storage when nothing narrower does
+static void fit_storage(const Column *c, bool any, int64_t lo, int64_t hi, int *width, int64_t *base) {
+    *width = c->canon();
+    *base = 0;
+    if (!any) {
+        *width = 1;  // no populated row: the stored bits are never looked at
+        return;
+    }
+    const unsigned __int128 range = (unsigned __int128)((__int128)hi - (__int128)lo);
+    int fit = range < 256 ? 1 : range < 65536 ? 2 : range < ((unsigned __int128)1 << 32) ? 4 : 8;
+    if (fit < *width) {
+        *width = fit;
+        *base = lo;
+    }
+}
+
+// Compact mode: the staged canonical block of one column -> the column's compact array.  The block's
+// exact extrema decide whether the column's current (width, base) still holds every value; if not the
+// resident rows are re-encoded once at the wider layout.  The block statistics come for free.
+static int commit_staged(BlockWriter &w, Column *c) {
+    Table *t = w.t;
+    hipStream_t st = t->ctx->stream;
+    const int64_t nb = (int64_t)t->blocks.size();
+    int rc = table_ensure_stats(t);  // extrema of the resident rows (no-op when current)
+    if (rc) return rc;
+    int64_t bmin = INT64_MAX, bmax = INT64_MIN, bpop = 0;
+    if (w.nrows > 0) {
+        if (!t->d_scratch) SYBL_HIP(hipMalloc((void **)&t->d_scratch, 64));
+        Segment seg;
+        seg.start = w.start;
+        seg.n = w.nrows;
+        SYBL_HIP(hipMemcpyAsync(t->d_scratch, &seg, sizeof(seg), hipMemcpyHostToDevice, st));
+        // k_block_minmax indexes values and validity bits by physical row: shift the staging base so
+        // that physical row w.start is its first element
+        const char *virt = (const char *)c->d_stage - (size_t)w.start * (size_t)c->canon();
+        hipError_t e = launch_block_minmax(virt, c->canon(), 0, c->d_valid, (const Segment *)t->d_scratch, 1, t->d_scratch + 2,
+                                           t->d_scratch + 3, t->d_scratch + 4, st);
+        if (e != hipSuccess) return hip_fail(e, "k_block_minmax");
+        int64_t h[3];
+        SYBL_HIP(hipMemcpyAsync(h, t->d_scratch + 2, sizeof(h), hipMemcpyDeviceToHost, st));
+        SYBL_HIP(hipStreamSynchronize(st));
+        bmin = h[0];
+        bmax = h[1];
+        bpop = h[2];
+    }
+    const bool any = c->n_pop > 0 || bpop > 0;
+    const int64_t lo = std::min(c->n_pop > 0 ? c->exact_min : INT64_MAX, bpop > 0 ? bmin : INT64_MAX);
+    const int64_t hi = std::max(c->n_pop > 0 ? c->exact_max : INT64_MIN, bpop > 0 ? bmax : INT64_MIN);
+    bool holds = true;
+    if (any && c->elem < 8) {
+        const __int128 top = (__int128)c->vbase + (((__int128)1 << (8 * c->elem)) - 1);
+        holds = lo >= c->vbase && (__int128)hi <= top;
+    }
+    if (!holds || !c->d_data) {
+        int width;
+        int64_t base;
+        fit_storage(c, any, lo, hi, &width, &base);
+        if (c->d_data && width < c->elem) {  // never narrow resident rows here (sybl_table_compact does)
+            width = c->elem;
+            base = c->elem == c->canon() ? 0 : std::min(lo, c->vbase);
+            if (c->elem < 8 && (__int128)hi > (__int128)base + (((__int128)1 << (8 * c->elem)) - 1))
+                fit_storage(c, any, lo, hi, &width, &base);  // the old width cannot span the new range
+        }
+        if ((rc = column_repack(t, c, width, base))) return rc;
+    }
+    if ((rc = table_reserve(t, c, w.new_phys))) return rc;
+    if (w.nrows > 0) {
+        hipError_t e = launch_repack(c->d_stage, c->canon(), 0, (char *)c->d_data + (size_t)w.start * (size_t)c->elem, c->elem, c->vbase,
+                                     w.nrows, st);
+        if (e != hipSuccess) return hip_fail(e, "k_repack");
+        SYBL_HIP(hipStreamSynchronize(st));
+    }
+    if (c->stats_blocks == nb) {
+        c->blk_min.push_back(bmin);
+        c->blk_max.push_back(bmax);
+        c->blk_pop.push_back(bpop);
+        if (bpop > 0) {
+            c->exact_min = std::min(c->exact_min, bmin);
+            c->exact_max = std::max(c->exact_max, bmax);
+        }
+        c->n_pop += bpop;
+        if (bpop < w.nrows) c->has_missing = true;
+        c->stats_blocks = nb + 1;
+    }
+    return SYBL_OK;
+}
+
 int block_commit(BlockWriter &w) {
     Table *t = w.t;
+    for (Column *c : w.staged) {
+        int rc = commit_staged(w, c);
+        if (rc) return rc;
+    }
+    w.staged.clear();
     Segment blk;
     blk.start = w.start;
     blk.n = w.nrows;
@@ -425,6 +520,7 @@ void sybl_table_free(sybl_table *t) {
     hipStreamSynchronize(t->ctx->stream);
     for (auto &c : t->cols) column_free(c.get());
     if (t->d_blocks) hipFree(t->d_blocks);
+    if (t->d_scratch) hipFree(t->d_scratch);
     delete t;
 }
 
@@ -678,32 +774,26 @@ int sybl_table_set_dict(sybl_table *t, const char *name, const char *const *stri
     return SYBL_OK;
 }
 
+static int compact_column(Table *t, Column *c) {
+    if (c->type == SYBL_SET_VAL || !c->d_data) return SYBL_OK;
+    int width;
+    int64_t base;
+    fit_storage(c, c->n_pop > 0, c->exact_min, c->exact_max, &width, &base);
+    if (width >= c->elem) return SYBL_OK;  // already this narrow
+    return column_repack(t, c, width, base);
+}
+
 int sybl_table_compact(sybl_table *t) {
     if (!t) return fail(SYBL_E_INVAL, "NULL table");
     SYBL_HIP(hipSetDevice(t->ctx->device));
     int rc = table_ensure_stats(t);
     if (rc) return rc;
-    bool any = false;
     for (auto &cp : t->cols) {
-        Column *c = cp.get();
-        if (c->type == SYBL_SET_VAL || !c->d_data) continue;
-        int width = c->canon();
-        int64_t base = 0;
-        if (c->n_pop == 0) {
-            width = 1;  // no populated row: the stored bits are never looked at
-        } else {
-            const unsigned __int128 range = (unsigned __int128)((__int128)c->exact_max - (__int128)c->exact_min);
-            int fit = range < 256 ? 1 : range < 65536 ? 2 : range < ((unsigned __int128)1 << 32) ? 4 : 8;
-            if (fit < width) {
-                width = fit;
-                base = c->exact_min;
-            }
-        }
-        if (width >= c->elem) continue;  // already this narrow
-        if ((rc = column_repack(t, c, width, base))) return rc;
-        any = true;
+        const int before = cp->elem;
+        if ((rc = compact_column(t, cp.get()))) return rc;
+        if (cp->elem != before) t->version++;
     }
-    if (any) t->version++;
+    t->compact_mode = true;  // blocks appended from now on are packed in place
     return SYBL_OK;
 }
 

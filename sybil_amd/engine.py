@@ -75,7 +75,7 @@ class Context:
                                                 C.byref(h)))
         return Table(self, h, name)
 
-    def open_table(self, directory, table, columns=None, rank=0, nranks=1):
+    def open_table(self, directory, table, columns=None, rank=0, nranks=1, compact=False):
         h = C.c_void_p()
         if columns:
             names = [_b(c) for c in columns]
@@ -83,7 +83,8 @@ class Context:
             n = len(names)
         else:
             arr, n = None, 0
-        N.check(N.lib().sybl_table_open(self._h, _b(directory), _b(table), arr, n, rank, nranks, C.byref(h)))
+        N.check(N.lib().sybl_table_open_flags(self._h, _b(directory), _b(table), arr, n, rank, nranks, 1 if compact else 0,
+                                              C.byref(h)))
         return Table(self, h, table)
 
 

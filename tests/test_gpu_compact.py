@@ -112,7 +112,7 @@ def test_negative_wide_and_missing_values(ctx, oracle):
     tb.free()
 
 
-def test_append_after_compact_returns_to_canonical(ctx, oracle):
+def test_append_to_compact_table_packs_in_place_and_widens(ctx, oracle):
     n = 50_000
     rng = np.random.default_rng(5)
     g = rng.integers(0, 10, size=n).astype(np.int64)
@@ -122,25 +122,76 @@ def test_append_after_compact_returns_to_canonical(ctx, oracle):
     tb.add_column("v", "int", 0, 5_000_000)
     tb.append_block(n, {"g": g, "v": v})
     tb.compact()
-    assert tb.column_storage("v")[0] == 2
+    assert tb.column_storage("v") == (2, int(v.min())) and tb.column_storage("g")[0] == 1
     query = tb.query(groups=["g"], aggs=["v"])
     r = query.run()
     r.free()
-    # values far outside the compact range arrive: storage goes back to int64, the old plan is stale
+    # a block that fits the compact layout is packed into place ...
+    g1 = rng.integers(0, 10, size=n).astype(np.int64)
+    v1 = rng.integers(int(v.min()), 1000, size=n).astype(np.int64)
+    tb.append_block(n, {"g": g1, "v": v1})
+    assert tb.column_storage("v") == (2, int(v.min()))
+    with pytest.raises(sybil_amd.SyblError):
+        query.run()          # the plan predates the append
+    query.free()
+    # ... one that does not makes the column wider (resident rows re-encoded once), never canonical
     g2 = rng.integers(0, 10, size=n).astype(np.int64)
     v2 = rng.integers(1_000_000, 5_000_000, size=n).astype(np.int64)
-    tb.append_block(n, {"g": g2, "v": v2})
-    assert tb.column_storage("v") == (8, 0)
-    with pytest.raises(sybil_amd.SyblError):
-        query.run()
-    query.free()
-    tb.compact()
-    assert tb.column_storage("v")[0] == 4
+    pop2 = (rng.random(n) > 0.3).astype(np.uint8)
+    tb.append_block(n, {"g": g2, "v": (v2, pop2)})
+    assert tb.column_storage("v")[0] == 4 and tb.column_storage("g")[0] == 1
+    assert np.array_equal(tb.read_int("v", 0, 2 * n), np.concatenate([v, v1]))
     query = tb.query(groups=["g"], aggs=["v"], op="hist")
     r = query.run()
-    o = oracle.run_query([{"type": "int", "data": np.concatenate([g, g2])}, {"type": "int", "data": np.concatenate([v, v2])}],
+    assert query.stats()["algorithmic_bytes"] == 3 * n * 5
+    o = oracle.run_query([{"type": "int", "data": np.concatenate([g, g1, g2])},
+                          {"type": "int", "data": np.concatenate([v, v1, v2]),
+                           "populated": np.concatenate([np.ones(2 * n, dtype=np.uint8), pop2])}],
                          groups=[0], aggs=[(1, 0, 5_000_000)], op="hist", block_rows=n)
     parity.compare(r, o, op="hist", full=True, n_aggs=1)
     r.free()
     query.free()
+    tb.free()
+
+
+def test_compact_from_the_first_block(ctx, oracle):
+    """compact() on an empty table only switches the mode on: every block is packed as it arrives,
+    the canonical form of the table never exists in HBM."""
+    rng = np.random.default_rng(11)
+    n, nb = 30_000, 6
+    tb = ctx.create_table("cf")
+    tb.add_column("k", "int")
+    tb.add_column("s", "str")
+    tb.add_column("v", "int", 0, 100_000)
+    tb.compact()
+    vocab = ["w%03d" % i for i in range(300)]
+    ks, ss, vs = [], [], []
+    for b in range(nb):
+        k = rng.integers(-5 - b, 20 + 400 * b, size=n).astype(np.int64)      # the range grows block by block
+        s = rng.integers(0, 50 * (b + 1), size=n).astype(np.int32)          # ... and so does the dictionary
+        v = rng.integers(0, 1 + 20_000 * b, size=n).astype(np.int64)
+        tb.append_block(n, {"k": k, "s": {"ids": s, "strings": vocab}, "v": v})
+        ks.append(k), ss.append(s), vs.append(v)
+    assert [tb.column_storage(c)[0] for c in ("k", "s", "v")] == [2, 2, 4]
+    assert tb.column_storage("k")[1] == -5 - (nb - 1)
+    k, s, v = np.concatenate(ks), np.concatenate(ss), np.concatenate(vs)
+    assert np.array_equal(tb.read_int("k", 0, n * nb), k)
+    for q, okw in ((dict(groups=["k"], aggs=["v"], op="hist"), dict(groups=[0], aggs=[(2, 0, 100_000)], op="hist")),
+                   (dict(filters=[("v", "gt", 5_000), ("k", "lt", 100)], groups=["s"], aggs=["v"]),
+                    dict(filters=[(2, "gt", 5_000), (0, "lt", 100)], groups=[1], aggs=[(2, 0, 100_000)]))):
+        query = tb.query(**q)
+        r = query.run()
+        o = oracle.run_query([{"type": "int", "data": k}, {"type": "str", "data": s}, {"type": "int", "data": v}],
+                             block_rows=n, **okw)
+        if "s" in q["groups"]:
+            gmap = {g["group_by_key"]: g for g in r.results}
+            omap = {vocab[x["key_vals"][0]] + "\t": x for x in o["results"]}
+            assert set(gmap) == set(omap) and r.matched == o["matched"]
+            for key, x in omap.items():
+                assert gmap[key]["count"] == x["count"]
+                parity.compare_hist(gmap[key]["hists"][0], x["hists"][0], "avg", True, ctx=key)
+        else:
+            parity.compare(r, o, op=q["op"], full=True, n_aggs=1)
+        r.free()
+        query.free()
     tb.free()

@@ -80,6 +80,8 @@ def test_random_queries(ctx, oracle, seed):
     tb = ctx.create_table("fuzz")
     for c in names:
         tb.add_column(c, "int", info[c][0], info[c][1])
+    if seed % 4 == 3:
+        tb.compact()  # compact mode from the first block: every block is packed as it arrives
     for r0 in range(0, n, block_rows):
         r1 = min(r0 + block_rows, n)
         tb.append_block(r1 - r0, {c: ((cols[c][r0:r1], pops[c][r0:r1]) if c in pops else cols[c][r0:r1]) for c in names})
@@ -127,6 +129,8 @@ def test_random_queries_with_strings_and_sets(ctx, oracle, seed):
     tb.add_column("g", "int")
     tb.add_column("v", "int", 0, 9_999)
     tb.add_column("z", "set")
+    if seed % 4 == 3:
+        tb.compact()
     for r0 in range(0, n, block_rows):
         r1 = min(r0 + block_rows, n)
         # a block-local dictionary in scrambled order, as the reference's blocks have

@@ -76,12 +76,15 @@ def _logical_after_load(logical, threshold):
             np.concatenate(tag_pop))
 
 
-@pytest.mark.parametrize("gz,threshold", [(False, 5000), (True, 5000), (False, 8)])
-def test_open_table_and_query(ctx, oracle, tmp_path, gz, threshold):
+@pytest.mark.parametrize("gz,threshold,compact", [(False, 5000, False), (True, 5000, False), (False, 8, False),
+                                                  (False, 5000, True), (False, 8, True)])
+def test_open_table_and_query(ctx, oracle, tmp_path, gz, threshold, compact):
     blocks, logical = _make_blocks(4, 3000)
     root = str(tmp_path / "db")
     F.write_table(root, "events", blocks, gz=gz, threshold=threshold, int_info={"big": (-(1 << 40), 1 << 40)})
-    tb = ctx.open_table(root, "events")
+    tb = ctx.open_table(root, "events", compact=compact)   # compact: every decoded block packed as it arrives
+    if compact:
+        assert tb.column_storage("age")[0] == 1 and tb.column_storage("big")[0] == 8
     age, t, big, big_pop, names, name_pop, tags, tag_pop = _logical_after_load(logical, threshold)
     n = age.size
     assert tb.rows == n and tb.blocks == 4 and tb.broken_blocks == 0
