@@ -113,7 +113,8 @@ struct Table {
     Segment *d_blocks = nullptr;
     int64_t d_blocks_n = 0;
     bool compact_mode = false;  // sybl_table_compact was called: appended blocks are packed in place
-    int64_t *d_scratch = nullptr;  // one Segment + min/max/pop of a staged block
+    int64_t *d_scratch = nullptr;  // one Segment + min/max/pop per staged column of a block
+    int64_t scratch_words = 0;
     int64_t version = 0;        // bumped by every change a prepared query would not know about
     int64_t broken_blocks = 0;  // blocks the loader skipped (unreadable info / column unpack error)
     Column *find(const char *name) const;

@@ -296,83 +296,94 @@ static void fit_storage(const Column *c, bool any, int64_t lo, int64_t hi, int *
     }
 }
 
-// Compact mode: the staged canonical block of one column -> the column's compact array.  The block's
-// exact extrema decide whether the column's current (width, base) still holds every value; if not the
-// resident rows are re-encoded once at the wider layout.  The block statistics come for free.
-static int commit_staged(BlockWriter &w, Column *c) {
+// Compact mode: the staged canonical blocks of the columns -> the columns' compact arrays.  The
+// block's exact extrema (one k_block_minmax launch per column, ONE readback for all of them) decide
+// whether a column's current (width, base) still holds every value; if not the resident rows are
+// re-encoded once at the wider layout.  The block statistics come for free.
+static int commit_staged(BlockWriter &w) {
     Table *t = w.t;
     hipStream_t st = t->ctx->stream;
     const int64_t nb = (int64_t)t->blocks.size();
+    const size_t ns = w.staged.size();
+    if (ns == 0) return SYBL_OK;
     int rc = table_ensure_stats(t);  // extrema of the resident rows (no-op when current)
     if (rc) return rc;
-    int64_t bmin = INT64_MAX, bmax = INT64_MIN, bpop = 0;
+    std::vector<int64_t> h(ns * 3, 0);
     if (w.nrows > 0) {
-        if (!t->d_scratch) SYBL_HIP(hipMalloc((void **)&t->d_scratch, 64));
+        const size_t need = 2 + ns * 3;  // one Segment, then min / max / pop per staged column
+        if ((int64_t)need > t->scratch_words) {
+            if (t->d_scratch) SYBL_HIP(hipFree(t->d_scratch));
+            t->d_scratch = nullptr;
+            SYBL_HIP(hipMalloc((void **)&t->d_scratch, need * 8));
+            t->scratch_words = (int64_t)need;
+        }
         Segment seg;
         seg.start = w.start;
         seg.n = w.nrows;
         SYBL_HIP(hipMemcpyAsync(t->d_scratch, &seg, sizeof(seg), hipMemcpyHostToDevice, st));
-        // k_block_minmax indexes values and validity bits by physical row: shift the staging base so
-        // that physical row w.start is its first element
-        const char *virt = (const char *)c->d_stage - (size_t)w.start * (size_t)c->canon();
-        hipError_t e = launch_block_minmax(virt, c->canon(), 0, c->d_valid, (const Segment *)t->d_scratch, 1, t->d_scratch + 2,
-                                           t->d_scratch + 3, t->d_scratch + 4, st);
-        if (e != hipSuccess) return hip_fail(e, "k_block_minmax");
-        int64_t h[3];
-        SYBL_HIP(hipMemcpyAsync(h, t->d_scratch + 2, sizeof(h), hipMemcpyDeviceToHost, st));
-        SYBL_HIP(hipStreamSynchronize(st));
-        bmin = h[0];
-        bmax = h[1];
-        bpop = h[2];
-    }
-    const bool any = c->n_pop > 0 || bpop > 0;
-    const int64_t lo = std::min(c->n_pop > 0 ? c->exact_min : INT64_MAX, bpop > 0 ? bmin : INT64_MAX);
-    const int64_t hi = std::max(c->n_pop > 0 ? c->exact_max : INT64_MIN, bpop > 0 ? bmax : INT64_MIN);
-    bool holds = true;
-    if (any && c->elem < 8) {
-        const __int128 top = (__int128)c->vbase + (((__int128)1 << (8 * c->elem)) - 1);
-        holds = lo >= c->vbase && (__int128)hi <= top;
-    }
-    if (!holds || !c->d_data) {
-        int width;
-        int64_t base;
-        fit_storage(c, any, lo, hi, &width, &base);
-        if (c->d_data && width < c->elem) {  // never narrow resident rows here (sybl_table_compact does)
-            width = c->elem;
-            base = c->elem == c->canon() ? 0 : std::min(lo, c->vbase);
-            if (c->elem < 8 && (__int128)hi > (__int128)base + (((__int128)1 << (8 * c->elem)) - 1))
-                fit_storage(c, any, lo, hi, &width, &base);  // the old width cannot span the new range
+        for (size_t k = 0; k < ns; k++) {
+            Column *c = w.staged[k];
+            // k_block_minmax indexes values and validity bits by physical row: shift the staging base so
+            // that physical row w.start is its first element
+            const char *virt = (const char *)c->d_stage - (size_t)w.start * (size_t)c->canon();
+            int64_t *out = t->d_scratch + 2 + k * 3;
+            hipError_t e = launch_block_minmax(virt, c->canon(), 0, c->d_valid, (const Segment *)t->d_scratch, 1, out, out + 1, out + 2, st);
+            if (e != hipSuccess) return hip_fail(e, "k_block_minmax");
         }
-        if ((rc = column_repack(t, c, width, base))) return rc;
-    }
-    if ((rc = table_reserve(t, c, w.new_phys))) return rc;
-    if (w.nrows > 0) {
-        hipError_t e = launch_repack(c->d_stage, c->canon(), 0, (char *)c->d_data + (size_t)w.start * (size_t)c->elem, c->elem, c->vbase,
-                                     w.nrows, st);
-        if (e != hipSuccess) return hip_fail(e, "k_repack");
+        SYBL_HIP(hipMemcpyAsync(h.data(), t->d_scratch + 2, ns * 3 * 8, hipMemcpyDeviceToHost, st));
         SYBL_HIP(hipStreamSynchronize(st));
     }
-    if (c->stats_blocks == nb) {
-        c->blk_min.push_back(bmin);
-        c->blk_max.push_back(bmax);
-        c->blk_pop.push_back(bpop);
-        if (bpop > 0) {
-            c->exact_min = std::min(c->exact_min, bmin);
-            c->exact_max = std::max(c->exact_max, bmax);
+    for (size_t k = 0; k < ns; k++) {
+        Column *c = w.staged[k];
+        const int64_t bmin = w.nrows > 0 ? h[k * 3] : INT64_MAX, bmax = w.nrows > 0 ? h[k * 3 + 1] : INT64_MIN;
+        const int64_t bpop = w.nrows > 0 ? h[k * 3 + 2] : 0;
+        const bool any = c->n_pop > 0 || bpop > 0;
+        const int64_t lo = std::min(c->n_pop > 0 ? c->exact_min : INT64_MAX, bpop > 0 ? bmin : INT64_MAX);
+        const int64_t hi = std::max(c->n_pop > 0 ? c->exact_max : INT64_MIN, bpop > 0 ? bmax : INT64_MIN);
+        bool holds = true;
+        if (any && c->elem < 8) {
+            const __int128 top = (__int128)c->vbase + (((__int128)1 << (8 * c->elem)) - 1);
+            holds = lo >= c->vbase && (__int128)hi <= top;
         }
-        c->n_pop += bpop;
-        if (bpop < w.nrows) c->has_missing = true;
-        c->stats_blocks = nb + 1;
+        if (!holds || !c->d_data) {
+            int width;
+            int64_t base;
+            fit_storage(c, any, lo, hi, &width, &base);
+            if (c->d_data && width < c->elem) {  // never narrow resident rows here (sybl_table_compact does)
+                width = c->elem;
+                base = c->elem == c->canon() ? 0 : std::min(lo, c->vbase);
+                if (c->elem < 8 && (__int128)hi > (__int128)base + (((__int128)1 << (8 * c->elem)) - 1))
+                    fit_storage(c, any, lo, hi, &width, &base);  // the old width cannot span the new range
+            }
+            if ((rc = column_repack(t, c, width, base))) return rc;
+        }
+        if ((rc = table_reserve(t, c, w.new_phys))) return rc;
+        if (w.nrows > 0) {
+            // stream-ordered: the next writer of this column's staging block queues behind the repack
+            hipError_t e = launch_repack(c->d_stage, c->canon(), 0, (char *)c->d_data + (size_t)w.start * (size_t)c->elem, c->elem,
+                                         c->vbase, w.nrows, st);
+            if (e != hipSuccess) return hip_fail(e, "k_repack");
+        }
+        if (c->stats_blocks == nb) {
+            c->blk_min.push_back(bmin);
+            c->blk_max.push_back(bmax);
+            c->blk_pop.push_back(bpop);
+            if (bpop > 0) {
+                c->exact_min = std::min(c->exact_min, bmin);
+                c->exact_max = std::max(c->exact_max, bmax);
+            }
+            c->n_pop += bpop;
+            if (bpop < w.nrows) c->has_missing = true;
+            c->stats_blocks = nb + 1;
+        }
     }
     return SYBL_OK;
 }
 
 int block_commit(BlockWriter &w) {
     Table *t = w.t;
-    for (Column *c : w.staged) {
-        int rc = commit_staged(w, c);
-        if (rc) return rc;
-    }
+    int rc = commit_staged(w);
+    if (rc) return rc;
     w.staged.clear();
     Segment blk;
     blk.start = w.start;

@@ -25,12 +25,13 @@ for b in range(4, n_blocks):
 size = sum(os.path.getsize(os.path.join(dp, f)) for dp, _, fs in os.walk(tdir) for f in fs)
 print("fixture: %d blocks, %.1f MB of gob files, built in %.1f s" % (n_blocks, size / 1e6, time.perf_counter() - t0))
 ctx = sybil_amd.Context(0)
-for rep in range(2):
+for rep in range(4):
+    compact = rep >= 2
     t0 = time.perf_counter()
-    tb = ctx.open_table(root, "t")
+    tb = ctx.open_table(root, "t", compact=compact)
     dt = time.perf_counter() - t0
-    print("open_table: %d rows in %.3f s = %.1f M rows/s, %.1f MB/s of column files, %d columns" % (
-        tb.rows, dt, tb.rows / dt / 1e6, size / dt / 1e6, 4))
+    print("open_table(%s): %d rows in %.3f s = %.1f M rows/s, %.1f MB/s of column files, %d columns, %.1f MB in HBM" % (
+        "compact" if compact else "canonical", tb.rows, dt, tb.rows / dt / 1e6, size / dt / 1e6, 4, tb.hbm_bytes / 1e6))
     q = tb.query(groups=["status"], aggs=["latency"])
     r = q.run()
     assert r.matched == tb.rows
