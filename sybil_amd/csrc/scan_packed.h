@@ -60,7 +60,7 @@ constexpr uint32_t kBufferRsrcWord3 = 0x00020000;  // raw buffer, 32-bit data fo
 __device__ __forceinline__ void packed_issue(const uint8_t *col, int wshift, uint32_t voff, pu32x4 &raw) {
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc((void *)col, 0, (int)((64u * kPackedRows) << wshift), (int)kBufferRsrcWord3);
-    raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, 0, 0);
+    raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, 0, 2);  // aux 2 = nt: streamed once
 }
 
 __device__ __forceinline__ void packed_decode(int width, const pu32x4 &raw, uint32_t (&u)[kPackedRows]) {
