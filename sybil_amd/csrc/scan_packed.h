@@ -88,8 +88,18 @@ struct PackedBases {
     const uint8_t *f[NF > 0 ? NF : 1], *g[NG > 0 ? NG : 1], *a[NA > 0 ? NA : 1], *t;
 };
 
+// 1-byte columns: four rows are ONE dword.  Loaded with the 16-byte instruction they cost the address
+// pipeline as much as a 4-byte column for a quarter of the data (loads-only: 4.0 TB/s against 6.1), and
+// the instruction cannot depend on a run-time width (see packed_issue) -- so "every group column is one
+// byte wide" (low-cardinality keys: the common case) is a compile-time property of the kernel (G1) and
+// those columns are read with 4-byte loads.
+__device__ __forceinline__ void packed_issue1(const uint8_t *col, uint32_t voff, pu32x4 &raw) {
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)col, 0, (int)(64u * kPackedRows), (int)kBufferRsrcWord3);
+    raw.x = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)voff, 0, 2);
+}
+
 // r: the lane's first row inside the chunk; the wave's first row is that of its first lane
-template <int NF, int NG, int NA, bool TIME>
+template <int NF, int NG, int NA, bool TIME, bool G1>
 __device__ __forceinline__ void packed_issue_all(const FastPlan &P, const PackedBases<NF, NG, NA> &B, uint32_t r, PackedRaw<NF> &f,
                                                  PackedRaw<NG> &g, PackedRaw<NA> &a, PackedRaw<1> &t) {
     const uint32_t r0 = __builtin_amdgcn_readfirstlane(r);
@@ -102,12 +112,18 @@ __device__ __forceinline__ void packed_issue_all(const FastPlan &P, const Packed
 #pragma unroll
     for (int c = 0; c < NF; c++) issue(B.f[c], P.fwid[c], f.v[c]);
 #pragma unroll
-    for (int c = 0; c < NG; c++) issue(B.g[c], P.gwid[c], g.v[c]);
+    for (int c = 0; c < NG; c++) {
+        if (G1) {
+            packed_issue1(B.g[c] + (size_t)r0, lane_row, g.v[c]);
+        } else {
+            issue(B.g[c], P.gwid[c], g.v[c]);
+        }
+    }
 #pragma unroll
     for (int c = 0; c < NA; c++) issue(B.a[c], P.awid[c], a.v[c]);
 }
 
-template <int NF, int NG, int NA, bool TIME>
+template <int NF, int NG, int NA, bool TIME, bool G1>
 __device__ __forceinline__ void packed_decode_all(const FastPlan &P, const PackedRaw<NF> &rf, const PackedRaw<NG> &rg,
                                                   const PackedRaw<NA> &ra, const PackedRaw<1> &rt, PackedTile<NF> &f,
                                                   PackedTile<NG> &g, PackedTile<NA> &a, PackedTile<1> &t) {
@@ -115,7 +131,7 @@ __device__ __forceinline__ void packed_decode_all(const FastPlan &P, const Packe
 #pragma unroll
     for (int c = 0; c < NF; c++) packed_decode(P.fwid[c], rf.v[c], f.u[c]);
 #pragma unroll
-    for (int c = 0; c < NG; c++) packed_decode(P.gwid[c], rg.v[c], g.u[c]);
+    for (int c = 0; c < NG; c++) packed_decode(G1 ? 1 : P.gwid[c], rg.v[c], g.u[c]);
 #pragma unroll
     for (int c = 0; c < NA; c++) packed_decode(P.awid[c], ra.v[c], a.u[c]);
 }
@@ -196,7 +212,7 @@ __device__ __forceinline__ void packed_row(const FastPlan &P, const PackedTile<N
 
 constexpr int64_t kPackedChunkRows = (int64_t)1 << 28;  // rows addressed with one 32-bit byte offset (x4 bytes)
 
-template <int NF, int NG, int NA, int MODE, bool TIME>
+template <int NF, int NG, int NA, int MODE, bool TIME, bool G1>
 __global__ __launch_bounds__(kWgThreads, 4) void k_scan_packed(const FastPlan P) {
     extern __shared__ int64_t lds[];
     const uint32_t tid = threadIdx.x;
@@ -228,20 +244,20 @@ __global__ __launch_bounds__(kWgThreads, 4) void k_scan_packed(const FastPlan P)
             PackedTile<1> t;
             uint32_t r = tid * kPackedRows;
             if (r < n) {
-                packed_issue_all<NF, NG, NA, TIME>(P, B, r, rf, rg, ra, rt);
-                packed_decode_all<NF, NG, NA, TIME>(P, rf, rg, ra, rt, f, g, a, t);
+                packed_issue_all<NF, NG, NA, TIME, G1>(P, B, r, rf, rg, ra, rt);
+                packed_decode_all<NF, NG, NA, TIME, G1>(P, rf, rg, ra, rt, f, g, a, t);
             }
             for (; r < n; r += kPackedTileRows) {
                 // the next tile's loads are in flight while this one is consumed; they are decoded
                 // (the first use of the loaded registers) only after the rows below
                 const uint32_t rn = r + kPackedTileRows;
                 const bool more = rn < n;
-                if (more) packed_issue_all<NF, NG, NA, TIME>(P, B, rn, rf, rg, ra, rt);
+                if (more) packed_issue_all<NF, NG, NA, TIME, G1>(P, B, rn, rf, rg, ra, rt);
                 const uint32_t left = n - r;
 #pragma unroll
                 for (int k = 0; k < kPackedRows; k++)
                     packed_row<NF, NG, NA, MODE, TIME>(P, f, g, a, t, k, (uint32_t)k < left, lds, L, matched, overflow);
-                if (more) packed_decode_all<NF, NG, NA, TIME>(P, rf, rg, ra, rt, f, g, a, t);
+                if (more) packed_decode_all<NF, NG, NA, TIME, G1>(P, rf, rg, ra, rt, f, g, a, t);
             }
         }
     }
@@ -284,13 +300,13 @@ __global__ __launch_bounds__(kWgThreads, 4) void k_emit_packed(const EmitPlan E)
             const uint32_t n_tiles = (n + kPackedTileRows - 1) / kPackedTileRows;
             uint32_t r = tid * kPackedRows;
             if (r < n) {
-                packed_issue_all<NF, NG, NA, false>(P, B, r, rf, rg, ra, rt);
-                packed_decode_all<NF, NG, NA, false>(P, rf, rg, ra, rt, f, g, a, t);
+                packed_issue_all<NF, NG, NA, false, false>(P, B, r, rf, rg, ra, rt);
+                packed_decode_all<NF, NG, NA, false, false>(P, rf, rg, ra, rt, f, g, a, t);
             }
             for (uint32_t it = 0; it < n_tiles; it++, r += kPackedTileRows) {
                 const uint32_t rn = r + kPackedTileRows;
                 const bool more = rn < n;
-                if (more) packed_issue_all<NF, NG, NA, false>(P, B, rn, rf, rg, ra, rt);
+                if (more) packed_issue_all<NF, NG, NA, false, false>(P, B, rn, rf, rg, ra, rt);
                 const uint32_t left = r < n ? n - r : 0u;
 #pragma unroll
                 for (int k = 0; k < kPackedRows; k++) {
@@ -319,7 +335,7 @@ __global__ __launch_bounds__(kWgThreads, 4) void k_emit_packed(const EmitPlan E)
                         }
                     }
                 }
-                if (more) packed_decode_all<NF, NG, NA, false>(P, rf, rg, ra, rt, f, g, a, t);
+                if (more) packed_decode_all<NF, NG, NA, false, false>(P, rf, rg, ra, rt, f, g, a, t);
                 // bins fill at ~tile_records / n_parts per tile: flush (two barriers) only every
                 // flush_period tiles; a bin that fills up earlier spills record by record
                 if ((it + 1) % (uint32_t)E.flush_period == 0 || it + 1 == n_tiles) {
@@ -356,13 +372,21 @@ static hipError_t emit_packed_launch_nf(const EmitPlan &E, int ng, int na, int n
 #undef SYBL_EMITP_CASE
 }
 
-template <int NF, int NG, int NA, int MODE, bool TIME>
-static hipError_t packed_launch_k(const FastPlan &P, int n_wg, size_t lds_bytes, hipStream_t st) {
-    auto k = k_scan_packed<NF, NG, NA, MODE, TIME>;
+template <int NF, int NG, int NA, int MODE, bool TIME, bool G1>
+static hipError_t packed_launch_k1(const FastPlan &P, int n_wg, size_t lds_bytes, hipStream_t st) {
+    auto k = k_scan_packed<NF, NG, NA, MODE, TIME, G1>;
     hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(n_wg), dim3(kWgThreads), lds_bytes, st, P);
     return hipGetLastError();
+}
+
+template <int NF, int NG, int NA, int MODE, bool TIME>
+static hipError_t packed_launch_k(const FastPlan &P, int n_wg, size_t lds_bytes, hipStream_t st) {
+    bool g1 = NG > 0;  // every group column is stored in one byte
+    for (int c = 0; c < NG; c++) g1 = g1 && P.gwid[c] == 1;
+    if (NG > 0 && g1) return packed_launch_k1<NF, NG, NA, MODE, TIME, (NG > 0)>(P, n_wg, lds_bytes, st);
+    return packed_launch_k1<NF, NG, NA, MODE, TIME, false>(P, n_wg, lds_bytes, st);
 }
 
 template <int NF, int NG, int NA>
