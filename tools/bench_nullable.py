@@ -20,7 +20,10 @@ pop = (rng.random(br) > 0.1).astype(np.uint8)
 for b in range(n_blocks):
     tb.append_block(br, {"f1": (f1, pop), "f2": f2, "g1": g1, "v1": (v1, pop), "v2": v2, "gs": {"ids": gs, "strings": strings}})
 rows = tb.rows
-for label, env in (("fast-gen", None), ("generic", "1")):
+for label, env in (("fast-gen", None), ("generic", "1"), ("compact fast-gen", None), ("compact generic", "1")):
+    if label == "compact fast-gen":
+        tb.compact()
+    os.environ.pop("SYBL_NO_FASTGEN", None)
     if env:
         os.environ["SYBL_NO_FASTGEN"] = env
     q = tb.query(filters=[("f1", "gt", 99), ("f1", "lt", 900), ("f2", "gt", 99), ("f2", "lt", 900)], groups=["g1", "gs"],
@@ -31,6 +34,6 @@ for label, env in (("fast-gen", None), ("generic", "1")):
         q.run().free(); ms.append(q.stats()["scan_ms"])
     st = q.stats()
     k = sorted(ms)[2]
-    print("%-9s strategy %d  kernel %.3f ms  %.0f GB/s  (%d rows, %d B/row)" % (label, st["strategy"], k, st["algorithmic_bytes"] / k / 1e6,
+    print("%-17s strategy %d  kernel %.3f ms  %.0f GB/s  (%d rows, %d B/row)" % (label, st["strategy"], k, st["algorithmic_bytes"] / k / 1e6,
                                                                           rows, st["algorithmic_bytes"] // rows))
     q.free()
