@@ -156,6 +156,19 @@ static bool fill_packed(Table *t, Query *q, const std::vector<int> &slot_col, Fa
         }
     }
     for (int c = 0; c < ng; c++) FP.gdoff[c] = (uint32_t)((uint64_t)FP.gbase[c] - (uint64_t)FP.gmin[c]);
+    for (int c = 0; c < na; c++) {
+        // Info.Min <= v <= Info.Max*10 (hist_basic.go:104) as a range of offsets; only looked at when the
+        // aggregation tracks its own count
+        const __int128 L = (__int128)FP.info_min[c] - FP.abase[c], H = (__int128)FP.max10[c] - FP.abase[c];
+        const __int128 umax = ((__int128)1 << 32) - 1;
+        if (H < 0 || L > umax || L > H) {
+            FP.alo[c] = 1;
+            FP.ahi[c] = 0;
+        } else {
+            FP.alo[c] = (uint32_t)(L < 0 ? 0 : L);
+            FP.ahi[c] = (uint32_t)(H > umax ? umax : H);
+        }
+    }
     const double shave = 1.0 - 1.0 / (double)((int64_t)1 << 40);
     for (int c = 0; c < na; c++) {
         FP.adoff[c] = (uint32_t)((uint64_t)FP.abase[c] - (uint64_t)FP.hmin[c]);
@@ -189,6 +202,7 @@ static bool fill_fast_columns(Table *t, Query *q, const std::vector<int> &slot_c
     // compact storage: k_scan_packed when every column is a plain int column of <= 4 stored bytes,
     // else the GEN kernels (any width); the plain kernels read canonical int64 only
     bool any_packed = false, all_narrow = true;
+    bool heavy = false;  // GEN features k_scan_packed<NUL> leaves out: weights, outliers, h.Max
     if (packed) *packed = false;
     for (size_t s = 0; s < slot_col.size(); s++) {
         const SlotDesc &sd = P.slot[s];
@@ -257,7 +271,11 @@ static bool fill_fast_columns(Table *t, Query *q, const std::vector<int> &slot_c
         const AggDesc &A = ai.d;
         if (A.m_nmin >= 0) return false;
         if ((A.f_smp >= 0 || A.f_out >= 0) && !allow_gen) return false;
-        if (A.f_out >= 0 || (q->op == SYBL_AGG_HIST && A.m_max >= 0)) *gen = true;  // outliers / h.Max live in the GEN body
+        if (A.f_out >= 0 || (q->op == SYBL_AGG_HIST && A.m_max >= 0)) {
+            *gen = true;  // outliers / h.Max live in the GEN body
+            heavy = true;
+        }
+        if (A.f_smp >= 0) heavy = true;
         if (A.f_cnt >= 0 || A.f_pop >= 0) {
             if (!allow_gen) return false;
             *gen = true;  // rejects / missing values: per-aggregation counts
@@ -302,6 +320,7 @@ static bool fill_fast_columns(Table *t, Query *q, const std::vector<int> &slot_c
         FP.wwid = P.slot[P.weight_slot].width;
         FP.wbase = P.slot[P.weight_slot].vbase;
         *gen = true;
+        heavy = true;
     }
     FP.hist_off = P.hist_off;
     FP.hist_stride = P.hist_stride;
@@ -316,8 +335,9 @@ static bool fill_fast_columns(Table *t, Query *q, const std::vector<int> &slot_c
     *png = ng;
     *pna = na;
     if (any_packed) {
-        if (!*gen && all_narrow && packed && fill_packed(t, q, slot_col, FP, nf, ng, na)) {
+        if ((!*gen || (allow_gen && !heavy)) && all_narrow && packed && fill_packed(t, q, slot_col, FP, nf, ng, na)) {
             *packed = true;
+            FP.nul = *gen ? 1 : 0;  // missing rows / str ids / reject gate: k_scan_packed<NUL>
         } else if (allow_gen) {
             *gen = true;
         } else {

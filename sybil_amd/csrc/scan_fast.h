@@ -75,6 +75,10 @@ struct FastPlan {
     uint32_t tdoff;                            // tbase - tb_min * time_bucket
     int32_t pad3_;
     double pinv_bucket[kFastMaxA], pinv_time;  // reciprocals scaled by (1 - 2^-40): never above the true quotient
+    // k_scan_packed<NUL>: columns with missing rows / str ids / the Info.Min..Max*10 reject gate, rebased:
+    // a value is accepted iff alo <= offset <= ahi
+    uint32_t alo[kFastMaxA], ahi[kFastMaxA];
+    int32_t nul, pad4_;
     const int32_t *wg_cell_base;
     int64_t *sum_out, *max_out, *ws_sum, *ws_max;
     const Segment *segs;

@@ -41,11 +41,13 @@ typedef unsigned int pu32x4 __attribute__((ext_vector_type(4)));
 template <int N>
 struct PackedTile {
     uint32_t u[N > 0 ? N : 1][kPackedRows];  // stored offsets (value - column base), zero-extended
+    uint32_t pop[N > 0 ? N : 1];             // NUL kernels: validity bits of the four rows
 };
 
 template <int N>
 struct PackedRaw {
-    pu32x4 v[N > 0 ? N : 1];  // the loaded bytes of four rows: 1 / 2 / 4 dwords are meaningful
+    pu32x4 v[N > 0 ? N : 1];     // the loaded bytes of four rows: 1 / 2 / 4 dwords are meaningful
+    uint32_t pw[N > 0 ? N : 1];  // NUL kernels: the validity word holding the four rows' bits
 };
 
 // Issues the load of four consecutive rows of one column.  The instruction is the same 16-byte
@@ -86,6 +88,7 @@ __device__ __forceinline__ void packed_decode(int width, const pu32x4 &raw, uint
 template <int NF, int NG, int NA>
 struct PackedBases {
     const uint8_t *f[NF > 0 ? NF : 1], *g[NG > 0 ? NG : 1], *a[NA > 0 ? NA : 1], *t;
+    int64_t first;  // physical row of the chunk's first row (validity bitmaps are indexed by physical row)
 };
 
 // 1-byte columns: four rows are ONE dword.  Loaded with the 16-byte instruction they cost the address
@@ -99,11 +102,22 @@ __device__ __forceinline__ void packed_issue1(const uint8_t *col, uint32_t voff,
 }
 
 // r: the lane's first row inside the chunk; the wave's first row is that of its first lane
-template <int NF, int NG, int NA, bool TIME, bool G1>
+template <int NF, int NG, int NA, bool TIME, bool G1, bool NUL>
 __device__ __forceinline__ void packed_issue_all(const FastPlan &P, const PackedBases<NF, NG, NA> &B, uint32_t r, PackedRaw<NF> &f,
                                                  PackedRaw<NG> &g, PackedRaw<NA> &a, PackedRaw<1> &t) {
     const uint32_t r0 = __builtin_amdgcn_readfirstlane(r);
     const uint32_t lane_row = r - r0;
+    if (NUL) {
+        // validity words of the lane's four rows (nullptr: every row populated)
+        const int64_t w = (B.first + r) >> 5;
+        if (TIME) t.pw[0] = P.tvalid ? P.tvalid[w] : 0xFFFFFFFFu;
+#pragma unroll
+        for (int c = 0; c < NF; c++) f.pw[c] = P.fvalid[c] ? P.fvalid[c][w] : 0xFFFFFFFFu;
+#pragma unroll
+        for (int c = 0; c < NG; c++) g.pw[c] = P.gvalid[c] ? P.gvalid[c][w] : 0xFFFFFFFFu;
+#pragma unroll
+        for (int c = 0; c < NA; c++) a.pw[c] = P.avalid[c] ? P.avalid[c][w] : 0xFFFFFFFFu;
+    }
     auto issue = [&](const uint8_t *col, int width, pu32x4 &raw) {
         const int ws = width >> 1;  // width 1, 2, 4 -> shift 0, 1, 2
         packed_issue(col + ((size_t)r0 << ws), ws, lane_row << ws, raw);
@@ -123,10 +137,19 @@ __device__ __forceinline__ void packed_issue_all(const FastPlan &P, const Packed
     for (int c = 0; c < NA; c++) issue(B.a[c], P.awid[c], a.v[c]);
 }
 
-template <int NF, int NG, int NA, bool TIME, bool G1>
+template <int NF, int NG, int NA, bool TIME, bool G1, bool NUL>
 __device__ __forceinline__ void packed_decode_all(const FastPlan &P, const PackedRaw<NF> &rf, const PackedRaw<NG> &rg,
                                                   const PackedRaw<NA> &ra, const PackedRaw<1> &rt, PackedTile<NF> &f,
-                                                  PackedTile<NG> &g, PackedTile<NA> &a, PackedTile<1> &t) {
+                                                  PackedTile<NG> &g, PackedTile<NA> &a, PackedTile<1> &t, uint32_t bit0) {
+    if (NUL) {  // bit0 = (physical row of the lane's first row) & 31, a multiple of 4
+        if (TIME) t.pop[0] = (rt.pw[0] >> bit0) & 0xFu;
+#pragma unroll
+        for (int c = 0; c < NF; c++) f.pop[c] = (rf.pw[c] >> bit0) & 0xFu;
+#pragma unroll
+        for (int c = 0; c < NG; c++) g.pop[c] = (rg.pw[c] >> bit0) & 0xFu;
+#pragma unroll
+        for (int c = 0; c < NA; c++) a.pop[c] = (ra.pw[c] >> bit0) & 0xFu;
+    }
     if (TIME) packed_decode(P.twid, rt.v[0], t.u[0]);
 #pragma unroll
     for (int c = 0; c < NF; c++) packed_decode(P.fwid[c], rf.v[c], f.u[c]);
@@ -144,7 +167,7 @@ __device__ __forceinline__ uint32_t packed_udiv(uint32_t n, uint32_t d, double i
     return q;
 }
 
-template <int NF, int NG, int NA, int MODE, bool TIME>
+template <int NF, int NG, int NA, int MODE, bool TIME, bool NUL>
 __device__ __forceinline__ void packed_row(const FastPlan &P, const PackedTile<NF> &f, const PackedTile<NG> &g,
                                            const PackedTile<NA> &a, const PackedTile<1> &t, const int r, bool pass, int64_t *lds,
                                            const FastLds &L, uint32_t &matched, uint32_t &overflow) {
@@ -152,28 +175,53 @@ __device__ __forceinline__ void packed_row(const FastPlan &P, const PackedTile<N
 #pragma unroll
     for (int c = 0; c < NF; c++) {
         const uint32_t u = f.u[c][r];
-        pass = pass & (u >= P.plo[c]) & (u <= P.phi[c]);  // filter.go:171-195, folded to a range of offsets
+        bool ok = (u >= P.plo[c]) & (u <= P.phi[c]);  // filter.go:171-195, folded to a range of offsets
+        if (NUL) {
+            if (P.fmask[c]) {
+                // StrFilter eq / neq / re / nre, evaluated per dictionary id on the host (filter.go:199-250)
+                const uint32_t id = u + (uint32_t)P.fbase[c];
+                ok = id < (uint32_t)P.fmask_bits[c];
+                if (ok) ok = (P.fmask[c][id >> 5] >> (id & 31)) & 1u;
+            }
+            ok = ok & ((f.pop[c] >> r) & 1u);  // an unpopulated value fails every filter
+        }
+        pass = pass & ok;
     }
     uint32_t cell = 0;
     bool inb = true;
 #pragma unroll
     for (int c = 0; c < NG; c++) {
         const uint32_t d = g.u[c][r] + P.gdoff[c];  // value - gmin
-        inb = inb & (d < P.gcard[c]);
-        cell += __umul24(d, (uint32_t)P.gstride[c]);  // aggregate.go:125-143 as a direct-mapped index
+        if (NUL) {
+            // MISSING_VALUE key (aggregate.go:138): its own digit, or the digit of the value -1
+            const bool p = (g.pop[c] >> r) & 1u;
+            inb = inb & (p ? d < (uint32_t)P.gvalues[c] : P.gmissing[c] >= 0);
+            cell += p ? __umul24(d, (uint32_t)P.gstride[c]) : (uint32_t)P.gmissing[c];
+        } else {
+            inb = inb & (d < P.gcard[c]);
+            cell += __umul24(d, (uint32_t)P.gstride[c]);  // aggregate.go:125-143 as a direct-mapped index
+        }
     }
+    bool live = pass;
     if (TIME) {
         // int(val) / TimeBucket (aggregate.go:174) for val >= 0, relative to the first bucket
         const uint32_t tb = packed_udiv(t.u[0][r] + P.tdoff, (uint32_t)P.time_bucket, P.pinv_time);
-        inb = inb & (tb < (uint32_t)P.n_tb);
+        if (NUL) {
+            // no time value: the row was matched, then dropped (aggregate.go:147-153)
+            const bool tp = (t.pop[0] >> r) & 1u;
+            live = live & tp;
+            inb = inb & (tb < (uint32_t)P.n_tb || !tp);
+        } else {
+            inb = inb & (tb < (uint32_t)P.n_tb);
+        }
         cell += __umul24(tb, (uint32_t)P.tb_stride);
     }
     const uint32_t ncell = L.tab_cells;
     const uint32_t lcell = cell - L.cell_base;  // position inside this workgroup's LDS table
     inb = inb & (lcell < ncell);
     matched += pass ? 1u : 0u;                  // aggregate.go:117
-    overflow += (pass & !inb) ? 1u : 0u;
-    if (!(pass & inb)) return;
+    overflow += (live & !inb) ? 1u : 0u;
+    if (!(live & inb)) return;
     // byte address of the cell's Count word; every other field of the cell is a wave-uniform byte
     // offset away (one VALU add per atomic)
     const uint32_t rs = (uint32_t)P.rep_shift;
@@ -186,6 +234,14 @@ __device__ __forceinline__ void packed_row(const FastPlan &P, const PackedTile<N
 #pragma unroll
     for (int c = 0; c < NA; c++) {
         const uint32_t u = a.u[c][r];
+        if (NUL) {
+            if (!((a.pop[c] >> r) & 1u)) continue;  // no value: no hist for this row
+            if (P.f_pop[c] >= 0) add((uint32_t)P.f_pop[c], 1);
+            if (P.f_cnt[c] >= 0) {
+                if (u < P.alo[c] || u > P.ahi[c]) continue;  // hist_basic.go:104, rebased
+                add((uint32_t)P.f_cnt[c], 1);                // h.Count++
+            }
+        }
         const int64_t x = (int64_t)((uint64_t)P.abase[c] + u);
         add((uint32_t)P.f_sum[c], x);
         if (MODE == kFastAvgMax) {
@@ -212,7 +268,7 @@ __device__ __forceinline__ void packed_row(const FastPlan &P, const PackedTile<N
 
 constexpr int64_t kPackedChunkRows = (int64_t)1 << 28;  // rows addressed with one 32-bit byte offset (x4 bytes)
 
-template <int NF, int NG, int NA, int MODE, bool TIME, bool G1>
+template <int NF, int NG, int NA, int MODE, bool TIME, bool G1, bool NUL>
 __global__ __launch_bounds__(kWgThreads, 4) void k_scan_packed(const FastPlan P) {
     extern __shared__ int64_t lds[];
     const uint32_t tid = threadIdx.x;
@@ -233,6 +289,7 @@ __global__ __launch_bounds__(kWgThreads, 4) void k_scan_packed(const FastPlan P)
 #pragma unroll
             for (int c = 0; c < NA; c++) B.a[c] = (const uint8_t *)P.acol[c] + first * P.awid[c];
             B.t = TIME ? (const uint8_t *)P.tcol + first * P.twid : nullptr;
+            B.first = first;
 
             PackedRaw<NF> rf;
             PackedRaw<NG> rg;
@@ -244,20 +301,20 @@ __global__ __launch_bounds__(kWgThreads, 4) void k_scan_packed(const FastPlan P)
             PackedTile<1> t;
             uint32_t r = tid * kPackedRows;
             if (r < n) {
-                packed_issue_all<NF, NG, NA, TIME, G1>(P, B, r, rf, rg, ra, rt);
-                packed_decode_all<NF, NG, NA, TIME, G1>(P, rf, rg, ra, rt, f, g, a, t);
+                packed_issue_all<NF, NG, NA, TIME, G1, NUL>(P, B, r, rf, rg, ra, rt);
+                packed_decode_all<NF, NG, NA, TIME, G1, NUL>(P, rf, rg, ra, rt, f, g, a, t, (uint32_t)(first + r) & 31u);
             }
             for (; r < n; r += kPackedTileRows) {
                 // the next tile's loads are in flight while this one is consumed; they are decoded
                 // (the first use of the loaded registers) only after the rows below
                 const uint32_t rn = r + kPackedTileRows;
                 const bool more = rn < n;
-                if (more) packed_issue_all<NF, NG, NA, TIME, G1>(P, B, rn, rf, rg, ra, rt);
+                if (more) packed_issue_all<NF, NG, NA, TIME, G1, NUL>(P, B, rn, rf, rg, ra, rt);
                 const uint32_t left = n - r;
 #pragma unroll
                 for (int k = 0; k < kPackedRows; k++)
-                    packed_row<NF, NG, NA, MODE, TIME>(P, f, g, a, t, k, (uint32_t)k < left, lds, L, matched, overflow);
-                if (more) packed_decode_all<NF, NG, NA, TIME, G1>(P, rf, rg, ra, rt, f, g, a, t);
+                    packed_row<NF, NG, NA, MODE, TIME, NUL>(P, f, g, a, t, k, (uint32_t)k < left, lds, L, matched, overflow);
+                if (more) packed_decode_all<NF, NG, NA, TIME, G1, NUL>(P, rf, rg, ra, rt, f, g, a, t, (uint32_t)(first + rn) & 31u);
             }
         }
     }
@@ -300,13 +357,13 @@ __global__ __launch_bounds__(kWgThreads, 4) void k_emit_packed(const EmitPlan E)
             const uint32_t n_tiles = (n + kPackedTileRows - 1) / kPackedTileRows;
             uint32_t r = tid * kPackedRows;
             if (r < n) {
-                packed_issue_all<NF, NG, NA, false, false>(P, B, r, rf, rg, ra, rt);
-                packed_decode_all<NF, NG, NA, false, false>(P, rf, rg, ra, rt, f, g, a, t);
+                packed_issue_all<NF, NG, NA, false, false, false>(P, B, r, rf, rg, ra, rt);
+                packed_decode_all<NF, NG, NA, false, false, false>(P, rf, rg, ra, rt, f, g, a, t, 0u);
             }
             for (uint32_t it = 0; it < n_tiles; it++, r += kPackedTileRows) {
                 const uint32_t rn = r + kPackedTileRows;
                 const bool more = rn < n;
-                if (more) packed_issue_all<NF, NG, NA, false, false>(P, B, rn, rf, rg, ra, rt);
+                if (more) packed_issue_all<NF, NG, NA, false, false, false>(P, B, rn, rf, rg, ra, rt);
                 const uint32_t left = r < n ? n - r : 0u;
 #pragma unroll
                 for (int k = 0; k < kPackedRows; k++) {
@@ -335,7 +392,7 @@ __global__ __launch_bounds__(kWgThreads, 4) void k_emit_packed(const EmitPlan E)
                         }
                     }
                 }
-                if (more) packed_decode_all<NF, NG, NA, false, false>(P, rf, rg, ra, rt, f, g, a, t);
+                if (more) packed_decode_all<NF, NG, NA, false, false, false>(P, rf, rg, ra, rt, f, g, a, t, 0u);
                 // bins fill at ~tile_records / n_parts per tile: flush (two barriers) only every
                 // flush_period tiles; a bin that fills up earlier spills record by record
                 if ((it + 1) % (uint32_t)E.flush_period == 0 || it + 1 == n_tiles) {
@@ -372,9 +429,9 @@ static hipError_t emit_packed_launch_nf(const EmitPlan &E, int ng, int na, int n
 #undef SYBL_EMITP_CASE
 }
 
-template <int NF, int NG, int NA, int MODE, bool TIME, bool G1>
+template <int NF, int NG, int NA, int MODE, bool TIME, bool G1, bool NUL>
 static hipError_t packed_launch_k1(const FastPlan &P, int n_wg, size_t lds_bytes, hipStream_t st) {
-    auto k = k_scan_packed<NF, NG, NA, MODE, TIME, G1>;
+    auto k = k_scan_packed<NF, NG, NA, MODE, TIME, G1, NUL>;
     hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(n_wg), dim3(kWgThreads), lds_bytes, st, P);
@@ -385,8 +442,10 @@ template <int NF, int NG, int NA, int MODE, bool TIME>
 static hipError_t packed_launch_k(const FastPlan &P, int n_wg, size_t lds_bytes, hipStream_t st) {
     bool g1 = NG > 0;  // every group column is stored in one byte
     for (int c = 0; c < NG; c++) g1 = g1 && P.gwid[c] == 1;
-    if (NG > 0 && g1) return packed_launch_k1<NF, NG, NA, MODE, TIME, (NG > 0)>(P, n_wg, lds_bytes, st);
-    return packed_launch_k1<NF, NG, NA, MODE, TIME, false>(P, n_wg, lds_bytes, st);
+    // NUL: missing rows / str ids / the reject gate (validity bitmaps are loaded next to the columns)
+    if (P.nul) return packed_launch_k1<NF, NG, NA, MODE, TIME, false, true>(P, n_wg, lds_bytes, st);
+    if (NG > 0 && g1) return packed_launch_k1<NF, NG, NA, MODE, TIME, (NG > 0), false>(P, n_wg, lds_bytes, st);
+    return packed_launch_k1<NF, NG, NA, MODE, TIME, false, false>(P, n_wg, lds_bytes, st);
 }
 
 template <int NF, int NG, int NA>

@@ -195,3 +195,53 @@ def test_compact_from_the_first_block(ctx, oracle):
         r.free()
         query.free()
     tb.free()
+
+
+def test_nullable_and_str_columns_run_the_packed_kernel(ctx, oracle):
+    """Missing rows in filter / group / aggregation columns, a str group column and a str filter over a
+    compact table: k_scan_packed<NUL> (validity bitmaps next to the offsets), not the 2-row GEN kernel."""
+    rng = np.random.default_rng(23)
+    n, nb = 40_000, 5
+    vocab = ["s%02d" % i for i in range(40)]
+    tb = ctx.create_table("nul")
+    for c in ("f1", "g1", "v1", "v2"):
+        tb.add_column(c, "int", 0, 999_999)
+    tb.add_column("gs", "str")
+    tb.compact()
+    cols = {k: [] for k in ("f1", "g1", "v1", "v2", "gs", "pf", "pg", "pv")}
+    for b in range(nb):
+        f1 = rng.integers(0, 1000, size=n)
+        g1 = rng.integers(0, 12, size=n)
+        v1 = rng.integers(0, 1_000_000, size=n)
+        v2 = rng.integers(0, 60_000, size=n)
+        gs = rng.integers(0, len(vocab), size=n).astype(np.int32)
+        pf, pg, pv = [(rng.random(n) > p).astype(np.uint8) for p in (0.1, 0.2, 0.15)]
+        tb.append_block(n, {"f1": (f1, pf), "g1": (g1, pg), "v1": (v1, pv), "v2": v2, "gs": {"ids": gs, "strings": vocab}})
+        for k, x in (("f1", f1), ("g1", g1), ("v1", v1), ("v2", v2), ("gs", gs), ("pf", pf), ("pg", pg), ("pv", pv)):
+            cols[k].append(x)
+    cat = {k: np.concatenate(v) for k, v in cols.items()}
+    assert [tb.column_storage(c)[0] for c in ("f1", "g1", "v1", "v2", "gs")] == [2, 1, 4, 2, 1]
+    ocols = [{"type": "int", "data": cat["f1"].astype(np.int64), "populated": cat["pf"]},
+             {"type": "int", "data": cat["g1"].astype(np.int64), "populated": cat["pg"]},
+             {"type": "int", "data": cat["v1"].astype(np.int64), "populated": cat["pv"]},
+             {"type": "int", "data": cat["v2"].astype(np.int64)},
+             {"type": "str", "data": cat["gs"]}]
+    import re
+    for q, okw in (
+        (dict(filters=[("f1", "gt", 99), ("f1", "lt", 900)], groups=["g1"], aggs=["v1", "v2"], op="hist", want_percentiles=False),
+         dict(filters=[(0, "gt", 99), (0, "lt", 900)], groups=[1], aggs=[(2, 0, 999_999), (3, 0, 999_999)], op="hist")),
+        (dict(filters=[("gs", "re", "^s[01]")], groups=["g1"], aggs=["v1"], op="avg"),
+         dict(filters=[(4, "re", 0, np.array([bool(re.search("^s[01]", s)) for s in vocab], dtype=np.uint8))], groups=[1],
+              aggs=[(2, 0, 999_999)], op="avg")),
+        (dict(filters=[("f1", "lt", 500)], groups=["g1"], aggs=["v1"], op="hist", time_col="v2", time_bucket=20_000, want_percentiles=False),
+         dict(filters=[(0, "lt", 500)], groups=[1], aggs=[(2, 0, 999_999)], op="hist", time_col=3, time_bucket=20_000)),
+    ):
+        query = tb.query(**q)
+        r = query.run()
+        st = query.stats()
+        assert st["packed_kernel"] == 1 and st["strategy"] == 2, st
+        o = oracle.run_query(ocols, block_rows=n, **okw)
+        parity.compare(r, o, op=q["op"], full=False, n_aggs=len(q["aggs"]), time_mode=bool(q.get("time_col")))
+        r.free()
+        query.free()
+    tb.free()
