@@ -35,7 +35,6 @@ typedef long long ll2 __attribute__((ext_vector_type(2)));
 typedef const ScanPlan __attribute__((address_space(4))) CPlan;
 typedef const SlotDesc __attribute__((address_space(4))) CSlot;
 typedef const AggDesc __attribute__((address_space(4))) CAgg;
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 // ---------------------------------------------------------------- small helpers
 
@@ -109,53 +108,68 @@ struct Tile {
     uint32_t pop[NC];  // 2 validity bits per slot (bit0 = row0, bit1 = row1)
 };
 
-// Two consecutive rows of one column, decoded: value = vbase + zero-extended raw.  The width is
-// wave-uniform, so the switch is a scalar branch; a width-8 column is stored as the value itself.
-__device__ __forceinline__ ll2 load_rows2(const void *base, int width, int64_t vbase, int64_t row) {
-    ll2 v;
-    switch (width) {
-    case 8: return __builtin_nontemporal_load((const ll2 *)((const int64_t *)base + row));
-    case 4: {
-        const u32x2 w = __builtin_nontemporal_load((const u32x2 *)((const uint32_t *)base + row));
-        v.x = w.x;
-        v.y = w.y;
-        break;
+// The loaded bits of a tile are kept raw and decoded (value = vbase + zero-extended raw) only when the
+// tile is consumed.  The load instruction is the same 16-byte buffer load for every stored width -- its
+// descriptor spans exactly the wave's 128 rows, so the lanes of a narrow column read nothing beyond
+// them -- which keeps the issue branch-free and a tile's loads back to back (see fast_issue in
+// scan_fast.h for what a width switch around the loads costs).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+template <int NC>
+struct RawTile {
+    u32x4 v[NC];
+    uint32_t pw[NC];  // validity word of the two rows (all ones: fully populated column)
+};
+
+template <int NC>
+__device__ __forceinline__ void issue_tile(CPlan &P, int64_t row, RawTile<NC> &t) {
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)row), hi = __builtin_amdgcn_readfirstlane((uint32_t)(row >> 32));
+    const int64_t row0 = (int64_t)(((uint64_t)hi << 32) | lo);  // the wave's first row
+    const uint32_t lane_row = (uint32_t)(row - row0);
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        CSlot &s = P.slot[c];
+        if (!(s.flags & kSlotSet)) {  // set columns: the CSR is walked per row (process_tile)
+            const int ws = s.width == 8 ? 3 : s.width >> 1;
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)s.base + (row0 << ws)), 0,
+                                                                                  (int)((64u * kRowsPerThread) << ws), 0x00020000);
+            t.v[c] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)((lane_row << ws) & ~3u), 0, 2);
+        }
+        t.pw[c] = s.valid ? s.valid[row >> 5] : 0xFFFFFFFFu;
     }
-    case 2: {
-        const uint32_t w = __builtin_nontemporal_load((const uint32_t *)((const uint16_t *)base + row));
-        v.x = w & 0xFFFFu;
-        v.y = w >> 16;
-        break;
-    }
-    default: {
-        const uint32_t w = __builtin_nontemporal_load((const uint16_t *)((const uint8_t *)base + row));
-        v.x = w & 0xFFu;
-        v.y = w >> 8;
-        break;
-    }
-    }
-    v.x += vbase;
-    v.y += vbase;
-    return v;
 }
 
 template <int NC>
-__device__ __forceinline__ void load_tile(CPlan &P, int64_t row, bool in_range, Tile<NC> &t) {
+__device__ __forceinline__ void decode_tile(CPlan &P, int64_t row, bool in_range, const RawTile<NC> &r, Tile<NC> &t) {
 #pragma unroll
     for (int c = 0; c < NC; c++) {
         CSlot &s = P.slot[c];
         ll2 v = {0, 0};
-        uint32_t pop = 0;
-        if (in_range && (s.flags & kSlotSet)) {
-            pop = 3u;
-            if (s.valid) pop = (s.valid[row >> 5] >> (row & 31)) & 3u;
-        } else if (in_range) {
-            v = load_rows2(s.base, s.width, s.vbase, row);
-            pop = 3u;
-            if (s.valid) pop = (s.valid[row >> 5] >> (row & 31)) & 3u;
+        if (!(s.flags & kSlotSet)) {
+            const u32x4 w = r.v[c];
+            switch (s.width) {
+            case 8:
+                v.x = (long long)(((unsigned long long)w.y << 32) | w.x);
+                v.y = (long long)(((unsigned long long)w.w << 32) | w.z);
+                break;
+            case 4:
+                v.x = s.vbase + (long long)w.x;
+                v.y = s.vbase + (long long)w.y;
+                break;
+            case 2:
+                v.x = s.vbase + (long long)(w.x & 0xFFFFu);
+                v.y = s.vbase + (long long)(w.x >> 16);
+                break;
+            default: {
+                const uint32_t x = w.x >> ((uint32_t)(row & 2) * 8u);  // rows 4k+2, 4k+3 sit in the upper half
+                v.x = s.vbase + (long long)(x & 0xFFu);
+                v.y = s.vbase + (long long)((x >> 8) & 0xFFu);
+                break;
+            }
+            }
         }
         t.v[c] = v;
-        t.pop[c] = pop;
+        t.pop[c] = in_range ? (r.pw[c] >> (row & 31)) & 3u : 0u;
     }
 }
 
@@ -359,15 +373,19 @@ __global__ __launch_bounds__(kWgThreads) void k_scan(CPlan *Pp) {
         const Segment seg = P.segs[si];
         const int64_t end = seg.start + seg.n;
         int64_t row = seg.start + (int64_t)tid * kRowsPerThread;
-        Tile<NC> cur, nxt;
-        load_tile<NC>(P, row, row < end, cur);
+        Tile<NC> cur;
+        RawTile<NC> raw;
+        if (row < end) issue_tile<NC>(P, row, raw);
+        decode_tile<NC>(P, row, row < end, raw, cur);
         for (int64_t base = seg.start; base < end; base += kTileRows) {
+            // prefetch: the next tile's raw bits are in flight under the LDS work and are decoded (their
+            // first use) only after it
             const int64_t nrow = row + kTileRows;
-            load_tile<NC>(P, nrow, nrow < end, nxt);  // prefetch: HBM latency hides under the LDS work
+            if (nrow < end) issue_tile<NC>(P, nrow, raw);
             int64_t left = end - row;
             int nvalid = left >= kRowsPerThread ? kRowsPerThread : (left > 0 ? (int)left : 0);
             process_tile<NC, USE_LDS>(P, cur, row, nvalid, sumtab, maxtab, rep, cell_base, matched, overflow);
-            cur = nxt;
+            decode_tile<NC>(P, nrow, nrow < end, raw, cur);
             row = nrow;
         }
     }
