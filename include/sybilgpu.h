@@ -324,6 +324,12 @@ int sybl_query_stats(sybl_query *q, sybl_run_stats *out);
  * library-owned NUL-terminated buffer valid until the result is freed. */
 const char *sybl_result_render(sybl_result *r, int format);
 
+/* `-encode-results` (printer.go:284-289): the result as encoding/gob of NodeResults{QuerySpec{QueryParams,
+ * QueryResults{Cumulative, Results, TimeResults, MatchedCount, Sorted}}} with HistCompat histograms --
+ * what `sybil aggregate` (node_aggregator.go) and src/api consume.  Library-owned buffer valid until the
+ * result is freed; bucket arrays are included for the rows that carry them. */
+const void *sybl_result_encode(sybl_result *r, int64_t *n_bytes);
+
 /* Test/diagnostic hook: decodes one gob file (info.db, int_/str_/set_*.db, optionally .gz) to JSON
  * with the library's gob reader.  Library-owned buffer, valid until the next call on the thread. */
 const char *sybl_debug_gob_to_json(const char *path);

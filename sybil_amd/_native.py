@@ -125,6 +125,7 @@ SIGNATURES = {
     "sybl_result_free": (None, [P]),
     "sybl_query_stats": (C.c_int, [P, C.POINTER(RunStats)]),
     "sybl_result_render": (C.c_char_p, [P, C.c_int]),
+    "sybl_result_encode": (C.c_void_p, [P, C.POINTER(C.c_int64)]),
 }
 
 _lib = None

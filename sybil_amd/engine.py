@@ -385,6 +385,14 @@ class Result:
     def cumulative(self):
         return self.rows(2)[0]
 
+    def encode(self):
+        """`-encode-results`: the gob-encoded NodeResults (bytes)."""
+        n = C.c_int64(0)
+        p = N.lib().sybl_result_encode(self._h, C.byref(n))
+        if not p:
+            raise N.SyblError(N.E_INVAL, (N.lib().sybl_last_error() or b"").decode())
+        return C.string_at(p, n.value)
+
     def render(self, fmt="text"):
         s = N.lib().sybl_result_render(self._h, 1 if fmt == "json" else 0)
         if s is None:

@@ -296,6 +296,27 @@ def decode(data, want_types=False):
             return r.bytes()
         if tid == STRING:
             return r.bytes().decode("utf-8", "replace")
+        if tid == INTERFACE:
+            # name of the registered concrete type ("" = nil), its type id -- preceded by any type
+            # definitions first needed here, each followed by a count to skip -- then the byte count of
+            # the value and the value itself (encode.go:encodeInterface / decode.go:decodeInterface)
+            name = r.bytes().decode()
+            if not name:
+                return None
+            while True:
+                cid = r.int()
+                if cid >= 0:
+                    break
+                types[-cid] = _read_wiretype(r)
+                order.append((-cid, types[-cid]["kind"], types[-cid]["name"]))
+                r.uint()
+            n = r.uint()
+            end = r.p + n
+            if cid not in types or types[cid]["kind"] != "struct":
+                assert r.uint() == 0
+            v = value(r, cid)
+            assert r.p == end, (r.p, end)
+            return {"@type": name, "@id": cid, "value": v}
         td = types[tid]
         if td["kind"] == "struct":
             out, f = {}, -1

@@ -53,6 +53,35 @@ def main():
     want = json.load(open(REFDIR + "/flag_defs.golden.json"))
     json.dump({k: v for k, v in want.items() if v is not None}, open(FLAGS_EXPECT, "w"), indent=1, sort_keys=True)
     print("wrote", FLAGS_HEX, "and", FLAGS_EXPECT)
+    # the WIRE TYPES of the reference's gob-encoded NodeResults (node_results.golden.gob): struct / field
+    # names and the kind of every field, which is what a Go decoder matches an incoming stream against --
+    # the pin for sybl_result_encode (-encode-results)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from tests import gobfmt
+    src = open(gobfmt.__file__).read().replace("return (v, order) if want_types else v",
+                                               "return (v, order, types) if want_types else v")
+    ns = {}
+    exec(compile(src, "gobfmt_types", "exec"), ns)
+    _, _, types = ns["decode"](open(REFDIR + "/node_results.golden.gob", "rb").read(), want_types=True)
+    builtin = {1: "bool", 2: "int", 3: "uint", 4: "float", 5: "bytes", 6: "string", 8: "interface"}
+
+    def kind(tid):
+        if tid in builtin:
+            return builtin[tid]
+        t = types[tid]
+        if t["kind"] == "struct":
+            return "struct:" + t["name"]
+        if t["kind"] == "map":
+            return "map[%s]%s" % (kind(t["key"]), kind(t["elem"]))
+        if t["kind"] in ("slice", "array"):
+            return "[]" + kind(t["elem"])
+        return t["kind"]
+
+    wire = {t["name"]: {f: kind(fid) for f, fid in t["fields"]} for t in types.values() if t["kind"] == "struct" and t["name"]}
+    keep = ("NodeResults", "QuerySpec", "QueryParams", "Grouping", "Aggregation", "QueryResults", "Result", "HistCompat",
+            "BasicHist", "BasicHistCachedInfo")
+    json.dump({k: wire[k] for k in keep}, open(os.path.join(HERE, "node_results_wiretypes.json"), "w"), indent=1, sort_keys=True)
+    print("wrote node_results_wiretypes.json")
 
 
 if __name__ == "__main__":

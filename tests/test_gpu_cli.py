@@ -128,3 +128,115 @@ def test_cli_errors(db):
     assert p.returncode == 2 and b"flag provided but not defined" in p.stderr
     p = subprocess.run([CLI, "-dir", db, "-table", "pages", "-group", "tags"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert p.returncode == 1 and b"set column" in p.stderr
+
+
+# ---------------------------------------------------------------- -encode-results (gob NodeResults)
+
+def _wire_kinds(types):
+    builtin = {1: "bool", 2: "int", 3: "uint", 4: "float", 5: "bytes", 6: "string", 8: "interface"}
+
+    def kind(tid):
+        if tid in builtin:
+            return builtin[tid]
+        t = types[tid]
+        if t["kind"] == "struct":
+            return "struct"
+        if t["kind"] == "map":
+            return "map[%s]%s" % (kind(t["key"]), kind(t["elem"]))
+        if t["kind"] in ("slice", "array"):
+            return "[]" + kind(t["elem"])
+        return t["kind"]
+
+    return {t["name"]: {f: kind(fid) for f, fid in t["fields"]} for t in types.values() if t["kind"] == "struct" and t["name"]}
+
+
+def _decode_with_types(data):
+    from tests import gobfmt
+    src = open(gobfmt.__file__).read().replace("return (v, order) if want_types else v", "return (v, order, types) if want_types else v")
+    ns = {}
+    exec(compile(src, "gobfmt_types", "exec"), ns)
+    return ns["decode"](data, want_types=True)
+
+
+def test_encode_results_is_a_gob_node_results():
+    """sybl_result_encode: a Go decoder matches an incoming stream against its own structs by struct / field
+    NAME and wire kind.  Every struct the engine sends must therefore be a subset of what the reference's own
+    gob-encoded NodeResults (node_results.golden.gob -> tests/golden/node_results_wiretypes.json) defines;
+    the values are checked against the result rows."""
+    import re
+    import sybil_amd
+    golden = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "node_results_wiretypes.json")))
+    ctx = sybil_amd.Context(0)
+    rng = np.random.default_rng(9)
+    n = 20_000
+    browsers, devices = ["webkit", "edge", "gecko"], ["laptop", "desktop", "phone", "tablet"]
+    b = rng.integers(0, 3, size=n).astype(np.int32)
+    d = rng.integers(0, 4, size=n).astype(np.int32)
+    pl = rng.integers(30, 23_500, size=n).astype(np.int64)
+    t = 1_700_000_000 + np.sort(rng.integers(0, 3 * 3600, size=n)).astype(np.int64)
+    tb = ctx.create_table("enc")
+    tb.add_column("browser", "str")
+    tb.add_column("device", "str")
+    tb.add_column("pageload", "int", 30, 23_500)
+    tb.add_column("time", "int")
+    tb.append_block(n, {"browser": {"ids": b, "strings": browsers}, "device": {"ids": d, "strings": devices}, "pageload": pl, "time": t})
+    for q in (dict(groups=["browser", "device"], aggs=["pageload"], op="hist", order_by="$COUNT", limit=100),
+              dict(groups=["device"], aggs=["pageload"], op="avg", time_col="time", time_bucket=3600)):
+        query = tb.query(**q)
+        r = query.run()
+        v, _, types = _decode_with_types(r.encode())
+        mine = _wire_kinds(types)
+        for name, fields in mine.items():
+            if name == "IntInfo":      # anonymous in the golden stream (a field of BasicHistCachedInfo)
+                continue
+            assert name in golden, name
+            for f, k in fields.items():
+                if (name, f) == ("QueryParams", "OrderAsc"):   # query_spec.go:33, newer than the golden stream
+                    assert k == "bool"
+                    continue
+                assert f in golden[name], (name, f)
+                assert re.sub(r"struct:\w*", "struct", golden[name][f]) == k, (name, f, golden[name][f], k)
+        qs = v["QuerySpec"]
+        assert [g["Name"] for g in qs["QueryParams"]["Groups"]] == q["groups"]
+        assert qs["QueryParams"]["Aggregations"] == [{"Op": q["op"], "Name": "pageload", "HistType": "basic"}]
+        res = qs["QueryResults"]
+        assert res["MatchedCount"] == r.matched == n
+
+        def check(enc, row):
+            assert enc.get("Count", 0) == row["count"] and enc.get("Samples", 0) == row["samples"]
+            assert enc.get("GroupByKey", "") == row["group_by_key"]
+            assert enc.get("BinaryByKey", "").encode("utf-8") == row["key"]  # (small dictionary ids: plain ASCII range)
+            h = row["hists"][0]
+            if not h["present"]:
+                assert "Hists" not in enc
+                return
+            iv = enc["Hists"]["pageload"]
+            assert iv["@type"] == "*sybil.HistCompat"
+            ci = iv["value"]["BasicHist"]["BasicHistCachedInfo"]
+            assert ci.get("Count", 0) == h["count"] and ci.get("Avg", 0.0) == h["avg"]
+            assert ci.get("Min", 0) == h["min"] and ci.get("Max", 0) == h["max"]
+            assert ci["Info"] == {"Min": 30, "Max": 23_500}
+            if q["op"] == "hist":
+                assert ci["PercentileMode"] is True and ci["BucketSize"] == h["bucket_size"] and ci["NumBuckets"] == h["num_buckets"]
+                assert ci["Values"] == h["values"].tolist()
+            else:
+                assert "Values" not in ci
+
+        check(res["Cumulative"], r.cumulative)
+        if q.get("time_col"):
+            rows = r.time_results
+            assert sum(len(m) for m in res["TimeResults"].values()) == len(rows)
+            for row in rows:
+                check(res["TimeResults"][row["time_bucket"]][row["group_by_key"]], row)
+            for row in r.results:                      # all-time Results: Count / Samples only
+                check(res["Results"][row["group_by_key"]], row)
+        else:
+            rows = r.results
+            assert set(res["Results"]) == {x["group_by_key"] for x in rows} and len(res["Sorted"]) == len(rows)
+            for row, s in zip(rows, res["Sorted"]):
+                check(res["Results"][row["group_by_key"]], row)
+                check(s, row)
+        r.free()
+        query.free()
+    tb.free()
+    ctx.close()

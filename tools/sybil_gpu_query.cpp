@@ -43,8 +43,8 @@ int main(int argc, char **argv) {
         {"sort", "$COUNT"}, {"sort-asc", "false"}, {"time", "false"}, {"time-col", "time"}, {"time-bucket", "3600"},
         {"weight-col", ""}, {"int-filter", ""}, {"str-filter", ""}, {"set-filter", ""}, {"int-bucket", "0"},
         {"int", ""}, {"str", ""}, {"set", ""}, {"group", ""}, {"field-separator", ","}, {"filter-separator", ":"},
-        {"device", "0"}, {"block-skip", "true"}, {"stats", "false"}};
-    const std::set<std::string> bools = {"print", "json", "sort-asc", "time", "block-skip", "stats"};
+        {"device", "0"}, {"block-skip", "true"}, {"stats", "false"}, {"encode-results", "false"}};
+    const std::set<std::string> bools = {"print", "json", "sort-asc", "time", "block-skip", "stats", "encode-results"};
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         if (a.size() < 2 || a[0] != '-') {
@@ -171,7 +171,13 @@ int main(int argc, char **argv) {
     if (sybl_query_scan(q)) return die("scan");
     sybl_result *res = nullptr;
     if (sybl_query_finalize(q, &res)) return die("finalize");
-    if (on("print")) {
+    if (on("encode-results")) {
+        // PrintResults: -encode-results wins over -print (printer.go:291-297); gob NodeResults on stdout
+        int64_t n = 0;
+        const void *bytes = sybl_result_encode(res, &n);
+        if (!bytes) return die("encode");
+        fwrite(bytes, 1, (size_t)n, stdout);
+    } else if (on("print")) {
         const char *out = sybl_result_render(res, on("json") ? 1 : 0);
         if (!out) return die("render");
         fputs(out, stdout);
