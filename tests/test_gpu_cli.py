@@ -240,3 +240,18 @@ def test_encode_results_is_a_gob_node_results():
         query.free()
     tb.free()
     ctx.close()
+
+
+def test_cli_encode_results(db):
+    env = dict(os.environ, TZ="UTC")
+    p = subprocess.run([CLI, "-dir", db, "-table", "pages", "-group", "browser", "-int", "load", "-op", "hist", "-encode-results"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=120)
+    assert p.returncode == 0, p.stderr.decode()
+    from tests import gobfmt
+    v = gobfmt.decode(p.stdout)
+    res = v["QuerySpec"]["QueryResults"]
+    assert res["MatchedCount"] == 10 and res["Cumulative"]["Count"] == 10
+    assert {k: r["Count"] for k, r in res["Results"].items()} == {"edge\t": 5, "gecko\t": 3, "webkit\t": 2}
+    assert [r["GroupByKey"] for r in res["Sorted"]] == ["edge\t", "gecko\t", "webkit\t"]
+    ci = res["Results"]["webkit\t"]["Hists"]["load"]["value"]["BasicHist"]["BasicHistCachedInfo"]
+    assert ci["Count"] == 2 and ci["Avg"] == 700.0 and sum(ci["Values"]) == 2 and ci["Info"] == {"Max": 1000}
