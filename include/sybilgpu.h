@@ -151,6 +151,12 @@ int sybl_table_open(sybl_ctx *ctx, const char *dir, const char *table, const cha
 int sybl_table_open_flags(sybl_ctx *ctx, const char *dir, const char *table, const char *const *columns,
                           int32_t n_columns, int32_t rank, int32_t nranks, int32_t flags, sybl_table **out);
 
+/* Writes the resident table under <dir>/<table name>/ in the reference's on-disk format (block
+ * directories with info.db + int_/str_/set_<col>.db gob files, table info.db: column_store_io.go:64-358,
+ * table_io.go:40-78) -- bucket encoded at <= 5000 distinct values per block, else value encoded -- so a
+ * `sybil` binary or sybl_table_open can read it back. */
+int sybl_table_save(sybl_table *t, const char *dir);
+
 /* Blocks sybl_table_open skipped the way the reference does: unreadable block info.db, NumRecords
  * <= 0, or a column file whose record ids / value count exceed NumRecords ("BLOCK SIZE CHANGED
  * DURING QUERY", column_store_io.go:524-526,572-574,733-735; table_query.go:134-139). */

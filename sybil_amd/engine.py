@@ -190,6 +190,10 @@ class Table:
         arr = (C.c_char_p * max(len(bs), 1))(*bs)
         N.check(N.lib().sybl_table_set_dict(self._h, _b(name), arr, len(bs)))
 
+    def save(self, directory):
+        """Write the table under directory/<name>/ in the reference's on-disk format (sybl_table_save)."""
+        N.check(N.lib().sybl_table_save(self._h, _b(directory)))
+
     def compact(self):
         """Re-encode every int / str column at the narrowest width that holds max - min
         (sybl_table_compact); query results are unchanged, scans stream fewer bytes."""
