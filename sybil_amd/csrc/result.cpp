@@ -17,6 +17,8 @@
 
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -272,20 +274,77 @@ static void finish_row(const Query *q, Result *R, const CellAcc &acc, RowStore &
     }
 }
 
-// f(i0, i1) over [0, n) on worker threads when n is large enough to pay for them
+// Persistent finalize workers: starting 20-odd threads per finalize cost more than the rows they built.
+// run(nt, fn) executes fn(0) .. fn(nt - 1), the caller taking its share; one job at a time.  The pool is
+// never destroyed (workers block on a condition variable and die with the process).
+class WorkerPool {
+   public:
+    static WorkerPool &get() {
+        static WorkerPool *p = new WorkerPool();
+        return *p;
+    }
+    static size_t cap() {
+        unsigned hw = std::thread::hardware_concurrency();
+        size_t c = std::min<size_t>(hw ? hw : 1, 32);
+        if (const char *e = getenv("SYBL_FINALIZE_THREADS")) c = (size_t)std::max(1, atoi(e));
+        return c;
+    }
+    template <typename F>
+    void run(size_t nt, F fn) {
+        if (nt <= 1) {
+            fn((size_t)0);
+            return;
+        }
+        std::lock_guard<std::mutex> job(job_m_);  // one job at a time
+        std::function<void(size_t)> f = fn;
+        {
+            std::unique_lock<std::mutex> lk(m_);
+            while (workers_ < nt - 1) {
+                std::thread(&WorkerPool::loop, this, workers_).detach();
+                workers_++;
+            }
+            fn_ = &f;
+            n_ = nt;
+            next_ = 1;  // task 0 is the caller's
+            left_ = nt - 1;
+            gen_++;
+        }
+        cv_.notify_all();
+        fn((size_t)0);
+        std::unique_lock<std::mutex> lk(m_);
+        done_.wait(lk, [&] { return left_ == 0; });
+        fn_ = nullptr;
+    }
+
+   private:
+    void loop(size_t) {
+        uint64_t seen = 0;
+        std::unique_lock<std::mutex> lk(m_);
+        for (;;) {
+            cv_.wait(lk, [&] { return gen_ != seen && fn_ && next_ < n_; });
+            seen = gen_;
+            while (fn_ && next_ < n_) {
+                const size_t k = next_++;
+                const std::function<void(size_t)> *f = fn_;
+                lk.unlock();
+                (*f)(k);
+                lk.lock();
+                if (--left_ == 0) done_.notify_all();
+            }
+        }
+    }
+    std::mutex m_, job_m_;
+    std::condition_variable cv_, done_;
+    const std::function<void(size_t)> *fn_ = nullptr;
+    size_t n_ = 0, next_ = 0, left_ = 0, workers_ = 0;
+    uint64_t gen_ = 0;
+};
+
+// f(i0, i1) over [0, n) on the finalize workers when n is large enough to pay for them
 template <typename F>
 static void parallel_ranges(size_t n, size_t min_per_thread, F f) {
-    unsigned hw = std::thread::hardware_concurrency();
-    size_t cap = std::min<size_t>(hw ? hw : 1, 32);
-    if (const char *e = getenv("SYBL_FINALIZE_THREADS")) cap = (size_t)std::max(1, atoi(e));
-    size_t nt = std::max<size_t>(1, std::min(cap, n / std::max<size_t>(min_per_thread, 1)));
-    if (nt <= 1) {
-        f((size_t)0, n);
-        return;
-    }
-    std::vector<std::thread> th;
-    for (size_t k = 0; k < nt; k++) th.emplace_back(f, n * k / nt, n * (k + 1) / nt);
-    for (auto &x : th) x.join();
+    size_t nt = std::max<size_t>(1, std::min(WorkerPool::cap(), n / std::max<size_t>(min_per_thread, 1)));
+    WorkerPool::get().run(nt, [&](size_t k) { f(n * k / nt, n * (k + 1) / nt); });
 }
 
 static void make_views(Result *R) {
@@ -624,17 +683,13 @@ int query_finalize(Query *q, Result **out) {
         // cost estimate: buckets touched per row dominate in full-histogram mode
         size_t per_row = 64 + (size_t)(q->want_percentiles ? P.hist_stride * 3 : 0);
         size_t cost = live.size() * per_row;
-        unsigned hw = std::thread::hardware_concurrency();
-        size_t cap = std::min<size_t>(hw ? hw : 1, 32);
-        if (const char *e = getenv("SYBL_FINALIZE_THREADS")) cap = (size_t)std::max(1, atoi(e));
-        n_threads = std::max<size_t>(1, std::min(cap, cost / (1u << 20)));
+        n_threads = std::max<size_t>(1, std::min(WorkerPool::cap(), cost / (1u << 20)));
     }
     if (n_threads <= 1) {
         work(0, live.size(), &total, &R->total_vals);
     } else {
         std::vector<CellAcc> part(n_threads);
         std::vector<std::vector<std::vector<int64_t>>> part_vals(n_threads);
-        std::vector<std::thread> th;
         for (size_t k = 0; k < n_threads; k++) {
             part[k].has_aggs = total.has_aggs;
             part_vals[k].resize(na);
@@ -642,10 +697,10 @@ int query_finalize(Query *q, Result **out) {
                 part[k].aggs[a].tracked_cnt = true;
                 if (!R->total_vals[a].empty()) part_vals[k][a].assign(R->total_vals[a].size(), 0);
             }
-            size_t i0 = live.size() * k / n_threads, i1 = live.size() * (k + 1) / n_threads;
-            th.emplace_back(work, i0, i1, &part[k], &part_vals[k]);
         }
-        for (auto &x : th) x.join();
+        WorkerPool::get().run(n_threads, [&](size_t k) {
+            work(live.size() * k / n_threads, live.size() * (k + 1) / n_threads, &part[k], &part_vals[k]);
+        });
         for (size_t k = 0; k < n_threads; k++) {
             total.count += part[k].count;
             total.samples += part[k].samples;
