@@ -53,18 +53,50 @@ static bool file_exists(const std::string &p) {
     return stat(p.c_str(), &st) == 0 || stat((p + ".gz").c_str(), &st) == 0;
 }
 
-struct Stage {  // grow-only device staging buffers for one table load
-    void *d = nullptr;
-    size_t cap = 0;
-    int ensure(size_t bytes) {
-        if (bytes <= cap) return SYBL_OK;
-        if (d) SYBL_HIP(hipFree(d));
-        d = nullptr;
-        cap = std::max(bytes, cap * 2);
-        SYBL_HIP(hipMalloc(&d, cap));
+// Staging for one table load: a pinned host ring and a device ring of the same size, handed out in
+// lock step.  The decoded pieces of a column (bins, deltas, dictionary look-up tables, validity words) are
+// copied into the pinned slice, sent with a truly asynchronous copy and consumed by the decode kernel on
+// the same stream -- nothing waits for them; the stream is synchronised only when the ring wraps around
+// (every few dozen blocks) instead of once per column.
+struct Stage {
+    char *h = nullptr, *d = nullptr;
+    size_t cap = 0, off = 0;
+    hipStream_t st = nullptr;
+    int take(size_t bytes, void **hp, void **dp) {
+        bytes = (bytes + 255) / 256 * 256;
+        if (bytes > cap) {
+            SYBL_HIP(hipStreamSynchronize(st));
+            if (h) SYBL_HIP(hipHostFree(h));
+            if (d) SYBL_HIP(hipFree(d));
+            h = d = nullptr;
+            cap = std::max<size_t>(std::max(bytes * 4, cap * 2), (size_t)32 << 20);
+            SYBL_HIP(hipHostMalloc((void **)&h, cap, hipHostMallocDefault));
+            SYBL_HIP(hipMalloc((void **)&d, cap));
+            off = 0;
+        }
+        if (off + bytes > cap) {
+            SYBL_HIP(hipStreamSynchronize(st));  // everything queued so far has consumed its slices
+            off = 0;
+        }
+        *hp = h + off;
+        *dp = d + off;
+        off += bytes;
+        return SYBL_OK;
+    }
+    // host -> pinned slice -> device slice (async); returns the device pointer
+    int send(const void *src, size_t bytes, void **dp) {
+        void *hp;
+        int rc = take(std::max<size_t>(bytes, 16), &hp, dp);
+        if (rc) return rc;
+        if (bytes) {
+            memcpy(hp, src, bytes);
+            SYBL_HIP(hipMemcpyAsync(*dp, hp, bytes, hipMemcpyHostToDevice, st));
+        }
         return SYBL_OK;
     }
     ~Stage() {
+        if (st && (h || d)) (void)hipStreamSynchronize(st);  // the last slices may still be in use
+        if (h) hipHostFree(h);
         if (d) hipFree(d);
     }
 };
@@ -237,31 +269,29 @@ static PreparedBlock prepare_block(const std::string &bdir, const std::vector<Co
 
 // ---- phase 2 (serial, in block order): dictionaries, PCIe, decode kernels
 
-static int upload_bins(Table *t, Stage &stage, const FlatBins &fb, const uint32_t **d_recs, const int64_t **d_off,
-                       const int64_t **d_val) {
-    size_t nb = fb.val.size();
-    size_t b_recs = (fb.recs.size() * 4 + 15) / 16 * 16, b_off = (nb + 1) * 8, b_val = std::max<size_t>(nb, 1) * 8;
-    int rc = stage.ensure(b_recs + b_off + b_val + 64);
-    if (rc) return rc;
-    char *base = (char *)stage.d;
-    hipStream_t st = t->ctx->stream;
-    if (!fb.recs.empty()) SYBL_HIP(hipMemcpyAsync(base, fb.recs.data(), fb.recs.size() * 4, hipMemcpyHostToDevice, st));
-    SYBL_HIP(hipMemcpyAsync(base + b_recs, fb.off.data(), b_off, hipMemcpyHostToDevice, st));
-    if (nb) SYBL_HIP(hipMemcpyAsync(base + b_recs + b_off, fb.val.data(), nb * 8, hipMemcpyHostToDevice, st));
-    *d_recs = (const uint32_t *)base;
-    *d_off = (const int64_t *)(base + b_recs);
-    *d_val = (const int64_t *)(base + b_recs + b_off);
+static int upload_bins(Stage &stage, const FlatBins &fb, const uint32_t **d_recs, const int64_t **d_off, const int64_t **d_val) {
+    int rc;
+    void *p;
+    if ((rc = stage.send(fb.recs.data(), fb.recs.size() * 4, &p))) return rc;
+    *d_recs = (const uint32_t *)p;
+    if ((rc = stage.send(fb.off.data(), fb.off.size() * 8, &p))) return rc;
+    *d_off = (const int64_t *)p;
+    if ((rc = stage.send(fb.val.data(), fb.val.size() * 8, &p))) return rc;
+    *d_val = (const int64_t *)p;
     return SYBL_OK;
 }
 
-static int put_prefix_valid(BlockWriter &w, uint32_t *valid, int64_t n) {
+static int put_prefix_valid(BlockWriter &w, Stage &stage, uint32_t *valid, int64_t n) {
     // every row below len(Values) becomes populated, holes included (column_store_io.go:758-766)
     if (!valid || n <= 0) return SYBL_OK;
     std::vector<uint32_t> bits((size_t)((w.nrows + 31) / 32), 0);
     for (int64_t r = 0; r < n; r++) bits[(size_t)(r >> 5)] |= 1u << (r & 31);
-    hipStream_t st = w.t->ctx->stream;
-    SYBL_HIP(hipMemcpyAsync(valid, bits.data(), bits.size() * 4, hipMemcpyHostToDevice, st));
-    SYBL_HIP(hipStreamSynchronize(st));
+    void *hp, *dp;
+    int rc = stage.take(bits.size() * 4, &hp, &dp);
+    if (rc) return rc;
+    memcpy(hp, bits.data(), bits.size() * 4);
+    // (pinned source: the copy is asynchronous and ordered behind the memset block_col_device queued)
+    SYBL_HIP(hipMemcpyAsync(valid, hp, bits.size() * 4, hipMemcpyHostToDevice, stage.st));
     return SYBL_OK;
 }
 
@@ -284,39 +314,33 @@ static int apply_col(BlockWriter &w, Column *c, PreparedCol &pc, Stage &stage) {
         if ((rc = block_col_device(w, c, all, &col, &valid))) return rc;
         const uint32_t *d_recs;
         const int64_t *d_off, *d_val;
-        if ((rc = upload_bins(t, stage, pc.fb, &d_recs, &d_off, &d_val))) return rc;
+        if ((rc = upload_bins(stage, pc.fb, &d_recs, &d_off, &d_val))) return rc;
         hipError_t e = launch_decode_bins(d_recs, d_off, d_val, (int)pc.fb.val.size(), pc.delta, col, w32, valid, (uint32_t)w.nrows, st);
         if (e != hipSuccess) return hip_fail(e, "k_decode_bins");
-        SYBL_HIP(hipStreamSynchronize(st));  // staging is reused by the next column
         return SYBL_OK;
     }
     case PreparedCol::kIntValues: {
         int64_t n = (int64_t)pc.values.size();
         if ((rc = block_col_device(w, c, n == w.nrows, &col, &valid))) return rc;
-        if ((rc = put_prefix_valid(w, valid, n))) return rc;
+        if ((rc = put_prefix_valid(w, stage, valid, n))) return rc;
         if (n > 0) {
-            if ((rc = stage.ensure((size_t)n * 8))) return rc;
-            SYBL_HIP(hipMemcpyAsync(stage.d, pc.values.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
-            hipError_t e = launch_decode_delta((const int64_t *)stage.d, n, pc.venc, (int64_t *)col, st);
+            void *d_vals;
+            if ((rc = stage.send(pc.values.data(), (size_t)n * 8, &d_vals))) return rc;
+            hipError_t e = launch_decode_delta((const int64_t *)d_vals, n, pc.venc, (int64_t *)col, st);
             if (e != hipSuccess) return hip_fail(e, "k_decode_delta");
-            SYBL_HIP(hipStreamSynchronize(st));
         }
         return SYBL_OK;
     }
     case PreparedCol::kStrValues: {
         int64_t n = (int64_t)pc.local.size();
         if ((rc = block_col_device(w, c, n == w.nrows, &col, &valid))) return rc;
-        if ((rc = put_prefix_valid(w, valid, n))) return rc;
+        if ((rc = put_prefix_valid(w, stage, valid, n))) return rc;
         if (n > 0) {
-            size_t b_local = ((size_t)n * 4 + 15) / 16 * 16;
-            if ((rc = stage.ensure(b_local + std::max<size_t>(lut.size(), 1) * 4))) return rc;
-            SYBL_HIP(hipMemcpyAsync(stage.d, pc.local.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
-            if (!lut.empty())
-                SYBL_HIP(hipMemcpyAsync((char *)stage.d + b_local, lut.data(), lut.size() * 4, hipMemcpyHostToDevice, st));
-            hipError_t e = launch_remap_ids((const int32_t *)stage.d, (const int32_t *)((char *)stage.d + b_local),
-                                            (int32_t)lut.size(), n, (int32_t *)col, st);
+            void *d_local, *d_lut;
+            if ((rc = stage.send(pc.local.data(), (size_t)n * 4, &d_local))) return rc;
+            if ((rc = stage.send(lut.data(), lut.size() * 4, &d_lut))) return rc;
+            hipError_t e = launch_remap_ids((const int32_t *)d_local, (const int32_t *)d_lut, (int32_t)lut.size(), n, (int32_t *)col, st);
             if (e != hipSuccess) return hip_fail(e, "k_remap_ids");
-            SYBL_HIP(hipStreamSynchronize(st));
         }
         return SYBL_OK;
     }
@@ -396,6 +420,7 @@ static int open_table(Ctx *ctx, const char *dir, const char *table, const char *
     size_t b0 = blocks.size() * (size_t)rank / (size_t)nranks, b1 = blocks.size() * (size_t)(rank + 1) / (size_t)nranks;
 
     Stage stage;
+    stage.st = ctx->stream;
     std::vector<ColSpec> specs;
     for (auto &cp : t->cols) specs.push_back({cp->name, cp->type});
     // worker threads decode a window of blocks ahead of the (serial, in-order) GPU phase
