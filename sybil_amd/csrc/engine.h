@@ -133,11 +133,19 @@ int column_repack(Table *t, Column *c, int width, int64_t vbase);  // change the
 struct BlockWriter {
     Table *t = nullptr;
     int64_t start = 0, nrows = 0, new_phys = 0;
-    std::vector<Column *> staged;  // compact mode: columns whose block sits in Column::d_stage
+    // compact mode: columns whose block sits in Column::d_stage, with the block's extrema when the writer
+    // already knows them (block_col_stats) -- else block_commit computes them on the GPU and waits
+    struct Staged {
+        Column *c = nullptr;
+        bool have_stats = false;
+        int64_t mn = 0, mx = 0, pop = 0;
+    };
+    std::vector<Staged> staged;
 };
 int block_begin(Table *t, int64_t nrows, BlockWriter *w);
 int block_col_device(BlockWriter &w, Column *c, bool all_populated, void **col, uint32_t **valid);
 int block_col_absent(BlockWriter &w, Column *c);
+void block_col_stats(BlockWriter &w, Column *c, int64_t mn, int64_t mx, int64_t pop);  // min / max over the pop populated rows
 int block_col_int_host(BlockWriter &w, Column *c, const int64_t *vals, const uint8_t *populated);
 int block_col_str_host(BlockWriter &w, Column *c, const int32_t *global_ids, const uint8_t *populated);
 int block_col_set_host(BlockWriter &w, Column *c, const int64_t *off, const int32_t *global_ids, const uint8_t *populated);

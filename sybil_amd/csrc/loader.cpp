@@ -120,6 +120,10 @@ struct PreparedCol {
     std::vector<int64_t> set_off;      // kSet: CSR over the block's rows, block-local member ids
     std::vector<int32_t> set_ids;
     std::vector<uint8_t> set_pop;
+    // int columns: extrema over the populated rows, found by the worker (compact mode packs the block
+    // without asking the GPU for them)
+    bool have_stats = false;
+    int64_t vmin = INT64_MAX, vmax = INT64_MIN, vpop = 0;
 };
 
 struct PreparedBlock {
@@ -192,11 +196,28 @@ static PreparedBlock prepare_block(const std::string &bdir, const std::vector<Co
             if (bucket) {
                 pc.kind = PreparedCol::kIntBins;
                 ok = flatten_bins(v.field("Bins"), pc.delta, pb.nrows, pc.fb);
+                for (size_t k = 0; ok && k < pc.fb.val.size(); k++)
+                    if (pc.fb.off[k + 1] > pc.fb.off[k]) {
+                        pc.vmin = std::min(pc.vmin, pc.fb.val[k]);
+                        pc.vmax = std::max(pc.vmax, pc.fb.val[k]);
+                    }
+                // (record ids of different bins are disjoint in a well-formed file; if they are not, a row is
+                // only counted twice here, which makes the column look less populated than it is -- harmless)
+                pc.vpop = std::min<int64_t>((int64_t)pc.fb.recs.size(), pb.nrows);
+                pc.have_stats = ok;
             } else {
                 pc.kind = PreparedCol::kIntValues;
                 const gob::Value *vals = v.field("Values");
                 if (vals && vals->kind == gob::Value::kIntVec) pc.values = vals->ints;
                 ok = (int64_t)pc.values.size() <= pb.nrows;
+                int64_t run = 0;  // every row below len(Values) is populated (column_store_io.go:758-766)
+                for (int64_t x : pc.values) {
+                    run = pc.venc ? (int64_t)((uint64_t)run + (uint64_t)x) : x;
+                    pc.vmin = std::min(pc.vmin, run);
+                    pc.vmax = std::max(pc.vmax, run);
+                }
+                pc.vpop = (int64_t)pc.values.size();
+                pc.have_stats = ok;
             }
         } else if (specs[ci].type == SYBL_STR_VAL) {  // unpackStrCol, :493-609 (without -str-replace)
             string_table(v, pc.strings);
@@ -317,6 +338,17 @@ static int apply_col(BlockWriter &w, Column *c, PreparedCol &pc, Stage &stage) {
         if ((rc = upload_bins(stage, pc.fb, &d_recs, &d_off, &d_val))) return rc;
         hipError_t e = launch_decode_bins(d_recs, d_off, d_val, (int)pc.fb.val.size(), pc.delta, col, w32, valid, (uint32_t)w.nrows, st);
         if (e != hipSuccess) return hip_fail(e, "k_decode_bins");
+        if (w32) {  // str bins: the values are table-global ids now
+            int64_t mn = INT64_MAX, mx = INT64_MIN;
+            for (size_t k = 0; k < pc.fb.val.size(); k++)
+                if (pc.fb.off[k + 1] > pc.fb.off[k]) {
+                    mn = std::min(mn, pc.fb.val[k]);
+                    mx = std::max(mx, pc.fb.val[k]);
+                }
+            block_col_stats(w, c, mn, mx, std::min<int64_t>((int64_t)pc.fb.recs.size(), w.nrows));
+        } else if (pc.have_stats) {
+            block_col_stats(w, c, pc.vmin, pc.vmax, pc.vpop);
+        }
         return SYBL_OK;
     }
     case PreparedCol::kIntValues: {
@@ -329,6 +361,7 @@ static int apply_col(BlockWriter &w, Column *c, PreparedCol &pc, Stage &stage) {
             hipError_t e = launch_decode_delta((const int64_t *)d_vals, n, pc.venc, (int64_t *)col, st);
             if (e != hipSuccess) return hip_fail(e, "k_decode_delta");
         }
+        if (pc.have_stats) block_col_stats(w, c, pc.vmin, pc.vmax, pc.vpop);
         return SYBL_OK;
     }
     case PreparedCol::kStrValues: {

@@ -179,7 +179,7 @@ int block_col_device(BlockWriter &w, Column *c, bool all_populated, void **col, 
         }
         *col = c->d_stage;
         if (!all_populated && w.nrows > 0) SYBL_HIP(hipMemsetAsync(*col, 0, (size_t)w.nrows * c->canon(), st));
-        w.staged.push_back(c);
+        w.staged.push_back(BlockWriter::Staged{c, false, 0, 0, 0});
     } else if (c->type != SYBL_SET_VAL) {
         if ((rc = table_reserve(t, c, w.new_phys))) return rc;
         *col = (char *)c->d_data + (size_t)w.start * c->elem;
@@ -202,6 +202,16 @@ int block_col_device(BlockWriter &w, Column *c, bool all_populated, void **col, 
         }
     }
     return SYBL_OK;
+}
+
+void block_col_stats(BlockWriter &w, Column *c, int64_t mn, int64_t mx, int64_t pop) {
+    for (auto &s : w.staged)
+        if (s.c == c) {
+            s.have_stats = true;
+            s.mn = pop > 0 ? mn : INT64_MAX;
+            s.mx = pop > 0 ? mx : INT64_MIN;
+            s.pop = pop;
+        }
 }
 
 // populated: nrows bytes, nullptr = every row; absent column: pass all zero via block_col_absent
@@ -248,6 +258,16 @@ int block_col_int_host(BlockWriter &w, Column *c, const int64_t *vals, const uin
     int rc = put_valid_bits(w, c, populated, false, &col);
     if (rc || w.nrows == 0) return rc;
     hipStream_t st = w.t->ctx->stream;
+    if (w.t->compact_mode) {
+        int64_t mn = INT64_MAX, mx = INT64_MIN, pop = 0;
+        for (int64_t r = 0; r < w.nrows; r++)
+            if (!populated || populated[r]) {
+                mn = std::min(mn, vals[r]);
+                mx = std::max(mx, vals[r]);
+                pop++;
+            }
+        block_col_stats(w, c, mn, mx, pop);
+    }
     SYBL_HIP(hipMemcpyAsync(col, vals, (size_t)w.nrows * 8, hipMemcpyHostToDevice, st));
     SYBL_HIP(hipStreamSynchronize(st));
     return SYBL_OK;
@@ -259,6 +279,16 @@ int block_col_str_host(BlockWriter &w, Column *c, const int32_t *global_ids, con
     int rc = put_valid_bits(w, c, populated, false, &col);
     if (rc || w.nrows == 0) return rc;
     hipStream_t st = w.t->ctx->stream;
+    if (w.t->compact_mode) {
+        int64_t mn = INT64_MAX, mx = INT64_MIN, pop = 0;
+        for (int64_t r = 0; r < w.nrows; r++)
+            if (!populated || populated[r]) {
+                mn = std::min<int64_t>(mn, global_ids[r]);
+                mx = std::max<int64_t>(mx, global_ids[r]);
+                pop++;
+            }
+        block_col_stats(w, c, mn, mx, pop);
+    }
     SYBL_HIP(hipMemcpyAsync(col, global_ids, (size_t)w.nrows * 4, hipMemcpyHostToDevice, st));
     SYBL_HIP(hipStreamSynchronize(st));
     return SYBL_OK;
@@ -309,7 +339,18 @@ static int commit_staged(BlockWriter &w) {
     int rc = table_ensure_stats(t);  // extrema of the resident rows (no-op when current)
     if (rc) return rc;
     std::vector<int64_t> h(ns * 3, 0);
-    if (w.nrows > 0) {
+    bool need_gpu = false;
+    for (size_t k = 0; k < ns; k++) {
+        const BlockWriter::Staged &s = w.staged[k];
+        if (s.have_stats) {
+            h[k * 3] = s.mn;
+            h[k * 3 + 1] = s.mx;
+            h[k * 3 + 2] = s.pop;
+        } else {
+            need_gpu = true;
+        }
+    }
+    if (w.nrows > 0 && need_gpu) {
         const size_t need = 2 + ns * 3;  // one Segment, then min / max / pop per staged column
         if ((int64_t)need > t->scratch_words) {
             if (t->d_scratch) SYBL_HIP(hipFree(t->d_scratch));
@@ -322,7 +363,8 @@ static int commit_staged(BlockWriter &w) {
         seg.n = w.nrows;
         SYBL_HIP(hipMemcpyAsync(t->d_scratch, &seg, sizeof(seg), hipMemcpyHostToDevice, st));
         for (size_t k = 0; k < ns; k++) {
-            Column *c = w.staged[k];
+            if (w.staged[k].have_stats) continue;
+            Column *c = w.staged[k].c;
             // k_block_minmax indexes values and validity bits by physical row: shift the staging base so
             // that physical row w.start is its first element
             const char *virt = (const char *)c->d_stage - (size_t)w.start * (size_t)c->canon();
@@ -330,11 +372,15 @@ static int commit_staged(BlockWriter &w) {
             hipError_t e = launch_block_minmax(virt, c->canon(), 0, c->d_valid, (const Segment *)t->d_scratch, 1, out, out + 1, out + 2, st);
             if (e != hipSuccess) return hip_fail(e, "k_block_minmax");
         }
-        SYBL_HIP(hipMemcpyAsync(h.data(), t->d_scratch + 2, ns * 3 * 8, hipMemcpyDeviceToHost, st));
+        std::vector<int64_t> g(ns * 3, 0);
+        SYBL_HIP(hipMemcpyAsync(g.data(), t->d_scratch + 2, ns * 3 * 8, hipMemcpyDeviceToHost, st));
         SYBL_HIP(hipStreamSynchronize(st));
+        for (size_t k = 0; k < ns; k++)
+            if (!w.staged[k].have_stats)
+                for (int j = 0; j < 3; j++) h[k * 3 + j] = g[k * 3 + j];
     }
     for (size_t k = 0; k < ns; k++) {
-        Column *c = w.staged[k];
+        Column *c = w.staged[k].c;
         const int64_t bmin = w.nrows > 0 ? h[k * 3] : INT64_MAX, bmax = w.nrows > 0 ? h[k * 3 + 1] : INT64_MIN;
         const int64_t bpop = w.nrows > 0 ? h[k * 3 + 2] : 0;
         const bool any = c->n_pop > 0 || bpop > 0;
