@@ -432,7 +432,7 @@ static int select_part_hist(Table *t, Query *q, const std::vector<int> &slot_col
     // capacity: 1.5x the mean share of the worst case (every scanned row matches) + slack; a
     // partition that still overflows makes finalize fall back to the atomic strategy
     int64_t cap = rows_scanned * na / n_parts;
-    cap = cap + cap / 2 + 8192;
+    cap = (cap + cap / 2 + 8192 + 3) & ~(int64_t)3;  // (a multiple of 4: k_part_hist reads 16-byte aligned record quads)
     if (cap >= ((int64_t)1 << 32)) return SYBL_OK;
     size_t bytes = (size_t)n_parts * (size_t)cap * 4, free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || bytes + ((size_t)1 << 30) > free_b) return SYBL_OK;

@@ -769,20 +769,49 @@ __global__ __launch_bounds__(kWgThreads) void k_part_hist(const PartHistPlan P) 
     const uint32_t *recs = P.recs + (int64_t)part * P.part_cap;
     const uint32_t pair0 = part * kPartCells;
     const uint32_t rb = (uint32_t)P.rem_bits[0];  // equal for every aggregation (planner)
-    for (uint32_t i = i0 + tid; i < i1; i += kWgThreads) {
-        const uint32_t rec = __builtin_nontemporal_load(recs + i);
+    auto add_record = [&](uint32_t rec) {
         const uint32_t rem = rec & ((1u << rb) - 1);
         const uint32_t b = (rec >> rb) & ((1u << kBucketBits) - 1);
         const uint32_t local = rec >> (rb + kBucketBits);
         const uint32_t a = P.n_aggs == 1 ? 0u : (pair0 + local) % (uint32_t)P.n_aggs;
+        // (the pair's count is the sum of its buckets: taken at read-out, not with a third atomic per record)
         __hip_atomic_fetch_add(hist + local * nv + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(cnt + local, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         const unsigned long long off = (unsigned long long)b * (unsigned long long)P.bucket_size[a] + rem;
         __hip_atomic_fetch_add(sum + local, off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (P.m_max[a] >= 0) {
             const long long v = (long long)((unsigned long long)P.hmin[a] + off);
             if (v > vmax[local]) __hip_atomic_fetch_max(vmax + local, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
+    };
+    // Four records per lane and load, the next 16 bytes requested before these are consumed: with one
+    // 4-byte load per lane a CU had 4 KB in flight and the kernel ran at the latency, not the bandwidth.
+    typedef unsigned int rec4 __attribute__((ext_vector_type(4)));
+    const uint32_t a0 = (i0 + 3u) & ~3u;                       // first 16-byte aligned record of the range
+    const uint32_t a1 = a0 <= i1 ? a0 + ((i1 - a0) & ~3u) : a0;  // end of the aligned body
+    for (uint32_t i = i0 + tid; i < (a0 < i1 ? a0 : i1); i += kWgThreads) add_record(recs[i]);
+    if (a0 < a1) {
+        uint32_t i = a0 + tid * 4u;
+        rec4 cur = {0, 0, 0, 0}, nxt = {0, 0, 0, 0};
+        if (i < a1) cur = __builtin_nontemporal_load((const rec4 *)(recs + i));
+        for (; i < a1; i += kWgThreads * 4u) {
+            const uint32_t ni = i + kWgThreads * 4u;
+            if (ni < a1) nxt = __builtin_nontemporal_load((const rec4 *)(recs + ni));
+            add_record(cur.x);
+            add_record(cur.y);
+            add_record(cur.z);
+            add_record(cur.w);
+            cur = nxt;
+        }
+        for (uint32_t k = a1 + tid; k < i1; k += kWgThreads) add_record(recs[k]);
+    }
+    __syncthreads();
+    // cnt[l] = sum over the buckets of pair l: each wave sums a strided share, one LDS atomic per wave
+    for (uint32_t l = 0; l < (uint32_t)kPartCells; l++) {
+        uint32_t part = 0;
+        for (uint32_t b = tid; b < nv; b += kWgThreads) part += hist[l * nv + b];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+        if ((tid & 63) == 0 && part) __hip_atomic_fetch_add(cnt + l, part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     __syncthreads();
 
