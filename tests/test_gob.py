@@ -128,3 +128,37 @@ def test_cxx_reader_rejects_garbage(tmp_path):
     assert N.lib().sybl_debug_gob_to_json(str(p).encode()) is None
     assert b"gob" in N.lib().sybl_last_error()
     assert N.lib().sybl_debug_gob_to_json(str(tmp_path / "missing.db").encode()) is None
+
+
+def test_encoded_results_sample_decodes():
+    """tests/golden/encoded_results_sample.hex: two `-encode-results` streams written by sybl_result_encode on the
+    GPU (tools/make_encoded_sample.py) for a ten-row table whose answers are known by hand -- decoded here with
+    the same decoder that reads the reference's own golden gob files (interface values included)."""
+    import os
+    from tests import gobfmt
+    lines = open(os.path.join(os.path.dirname(__file__), "golden", "encoded_results_sample.hex")).read().split()
+    hist, times = (gobfmt.decode(bytes.fromhex(x)) for x in lines)
+    qs = hist["QuerySpec"]
+    assert qs["QueryParams"] == {"Groups": [{"Name": "browser"}], "Aggregations": [{"Op": "hist", "Name": "load", "HistType": "basic"}],
+                                 "OrderBy": "$COUNT", "Limit": 100}
+    res = qs["QueryResults"]
+    assert res["MatchedCount"] == 10
+    assert [(r["GroupByKey"], r["Count"]) for r in res["Sorted"]] == [("edge\t", 5), ("gecko\t", 3), ("webkit\t", 2)]
+    edge = res["Results"]["edge\t"]
+    assert edge["BinaryByKey"] == "\x00" * 8 and edge["Samples"] == 5
+    iv = edge["Hists"]["load"]
+    assert iv["@type"] == "*sybil.HistCompat"
+    ci = iv["value"]["BasicHist"]["BasicHistCachedInfo"]
+    # Info [0, 1000]: BucketSize 1, NumBuckets 1001 -> 1002 Values (hist_basic.go:34-70)
+    assert (ci["NumBuckets"], ci["BucketSize"], len(ci["Values"]), ci["PercentileMode"]) == (1001, 1, 1002, True)
+    assert [i for i, x in enumerate(ci["Values"]) if x] == [100, 200, 300, 500, 600]
+    assert (ci["Count"], ci["Avg"], ci["Max"], ci["Info"]) == (5, 340.0, 1000, {"Max": 1000})
+    total = res["Cumulative"]["Hists"]["load"]["value"]["BasicHist"]["BasicHistCachedInfo"]
+    assert total["Count"] == 10 and total["Avg"] == 355.0 and sum(total["Values"]) == 10
+    # time series: TimeResults[bucket][key] carries the hists, Results only Count / Samples (aggregate.go:156-183)
+    tres = times["QuerySpec"]["QueryResults"]
+    assert times["QuerySpec"]["QueryParams"]["TimeBucket"] == 3600
+    assert sorted(tres["TimeResults"]) == [1699999200, 1700002800, 1700006400, 1700010000]
+    assert {k: v["Count"] for k, v in tres["TimeResults"][1700006400].items()} == {"edge\t": 1, "gecko\t": 1, "webkit\t": 1}
+    assert tres["TimeResults"][1699999200]["edge\t"]["Hists"]["load"]["value"]["BasicHist"]["BasicHistCachedInfo"]["Avg"] == 200.0
+    assert "Hists" not in tres["Results"]["edge\t"] and tres["Results"]["edge\t"]["Count"] == 5
