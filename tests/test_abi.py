@@ -36,6 +36,17 @@ def test_header_compiles_as_plain_c(tmp_path):
                            "-o", str(tmp_path / "t.o")])
 
 
+def test_c_example_links_against_the_library(tmp_path):
+    """tools/example_query.c: the whole open -> prepare -> scan -> finalize -> rows -> encode flow from C99,
+    linked against the in-tree library (what a cgo build does)."""
+    import subprocess
+    import sybil_amd
+    libdir = os.path.dirname(os.path.abspath(sybil_amd.__file__))
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tools", "example_query.c"), "-L", libdir, "-lsybilgpu",
+                           "-Wl,-rpath," + libdir, "-Wl,-rpath-link,/opt/rocm/lib", "-o", str(tmp_path / "example_query")])
+
+
 def test_no_cpu_fallback_without_gpu():
     import torch
     if torch.cuda.is_available():
