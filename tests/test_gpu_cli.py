@@ -255,3 +255,19 @@ def test_cli_encode_results(db):
     assert [r["GroupByKey"] for r in res["Sorted"]] == ["edge\t", "gecko\t", "webkit\t"]
     ci = res["Results"]["webkit\t"]["Hists"]["load"]["value"]["BasicHist"]["BasicHistCachedInfo"]
     assert ci["Count"] == 2 and ci["Avg"] == 700.0 and sum(ci["Values"]) == 2 and ci["Info"] == {"Max": 1000}
+
+
+def test_c_example_runs(db, tmp_path):
+    import sybil_amd
+    libdir = os.path.dirname(os.path.abspath(sybil_amd.__file__))
+    exe = str(tmp_path / "example_query")
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tools", "example_query.c"),
+                           "-L", libdir, "-lsybilgpu", "-Wl,-rpath," + libdir, "-Wl,-rpath-link,/opt/rocm/lib", "-o", exe])
+    p = subprocess.run([exe, db, "pages", "browser", "load", "100"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert p.returncode == 0, p.stderr.decode()
+    lines = p.stdout.decode().splitlines()
+    # load > 100: edge {300, 200, 500, 600}, gecko {150, 250}, webkit {1000, 400}
+    assert lines[0] == "matched 8 rows, 3 groups"
+    assert lines[1].split() == ["edge", "count", "4", "avg", "400.00", "p50", "500", "p99", "600"]
+    assert lines[2].split()[:5] == ["gecko", "count", "2", "avg", "200.00"] and lines[3].split()[:5] == ["webkit", "count", "2", "avg", "700.00"]
+    assert lines[4].startswith("-encode-results:")
