@@ -1,0 +1,283 @@
+// encode.cpp -- `-encode-results`: the result as encoding/gob of NodeResults (printer.go:284-289).
+#include <string.h>
+
+#include "gobenc.h"
+#include "result.h"
+
+using namespace sybl;
+
+extern "C" {
+
+// ------------------------------------------------------------------ -encode-results (printer.go:284-289)
+// encoding/gob of NodeResults{QuerySpec{QueryParams, QueryResults}} (node_aggregator.go:8-13,
+// query_spec.go:16-93) -- what `sybil query -encode-results` prints and `sybil aggregate` / src/api read.
+// gob matches struct fields by NAME, so only the fields the engine fills are defined and sent; the
+// reference's golden NodeResults (testdata/TestDecodeGoldenFiles/node_results.golden.gob) carries the
+// same type and field names (tests/test_gpu_cli.py decodes both with the same decoder).
+namespace {
+
+using GobW = gobenc::Buf;
+using gobenc::Fields;
+
+enum GobId : int {  // builtin ids, then ours in definition order
+    G_BOOL = 1, G_INT = 2, G_FLOAT = 4, G_STRING = 6, G_IFACE = 8,
+    T_NODE = 65, T_QSPEC, T_QPARAMS, T_GROUPING, T_GROUPINGS, T_AGG, T_AGGS, T_QRESULTS, T_RESULT, T_HISTMAP, T_RESULTMAP,
+    T_TIMEMAP, T_SORTED, T_HISTCOMPAT, T_BASICHIST, T_CACHED, T_I64S, T_INTINFO,
+};
+
+struct GobStream {
+    std::string out;
+    void message(const std::string &payload) {
+        GobW h;
+        h.u(payload.size());
+        out += h.b;
+        out += payload;
+    }
+    static void common(GobW &w, const char *name, int id) {  // CommonType{Name, Id}
+        if (name && name[0]) {
+            w.u(1);
+            w.s(name);
+            w.u(1);
+        } else {
+            w.u(2);
+        }
+        w.i(id);
+        w.u(0);
+    }
+    void def_struct(int id, const char *name, std::initializer_list<std::pair<const char *, int>> fields) {
+        GobW w;
+        w.i(-id);
+        w.u(3);  // wireType.StructT
+        w.u(1);
+        common(w, name, id);
+        w.u(1);
+        w.u(fields.size());
+        for (auto &fd : fields) {
+            w.u(1);
+            w.s(fd.first);
+            w.u(1);
+            w.i(fd.second);
+            w.u(0);
+        }
+        w.u(0);
+        w.u(0);
+        message(w.b);
+    }
+    void def_slice(int id, const char *name, int elem) {
+        GobW w;
+        w.i(-id);
+        w.u(2);  // wireType.SliceT
+        w.u(1);
+        common(w, name, id);
+        w.u(1);
+        w.i(elem);
+        w.u(0);
+        w.u(0);
+        message(w.b);
+    }
+    void def_map(int id, const char *name, int key, int elem) {
+        GobW w;
+        w.i(-id);
+        w.u(4);  // wireType.MapT
+        w.u(1);
+        common(w, name, id);
+        w.u(1);
+        w.i(key);
+        w.u(1);
+        w.i(elem);
+        w.u(0);
+        w.u(0);
+        message(w.b);
+    }
+};
+
+static void gob_hist(GobW &w, const Result *R, const sybl_agg_out &o, int a) {
+    // Histogram interface value: registered name, concrete type id, byte count, HistCompat{BasicHist{BasicHistCachedInfo}}
+    GobW v;
+    Fields hc(v);
+    hc.at(0);  // HistCompat.BasicHist
+    Fields bh(v);
+    bh.at(0);  // BasicHist.BasicHistCachedInfo
+    Fields ci(v);
+    ci.put_int(0, o.num_buckets);
+    ci.put_int(1, o.bucket_size);
+    if (o.values && o.n_values > 0) {
+        ci.at(2);  // Values []int64
+        v.u((uint64_t)o.n_values);
+        for (int64_t k = 0; k < o.n_values; k++) v.i(o.values[k]);
+    }
+    if (R->op == SYBL_AGG_HIST) {
+        ci.at(3);  // PercentileMode
+        v.u(1);
+    }
+    ci.put_int(4, o.max);
+    ci.put_int(5, o.min);
+    ci.put_int(6, o.samples);
+    ci.put_int(7, o.count);
+    if (o.avg != 0.0) {
+        ci.at(8);
+        v.f(o.avg);
+    }
+    {
+        ci.at(9);  // Info IntInfo{Min, Max}
+        Fields in(v);
+        in.put_int(0, R->agg_info[(size_t)a].first);
+        in.put_int(1, R->agg_info[(size_t)a].second);
+        in.end();
+    }
+    ci.end();
+    bh.end();
+    hc.end();
+    w.s("*sybil.HistCompat");
+    w.i(T_HISTCOMPAT);
+    w.u(v.b.size());
+    w.b += v.b;
+}
+
+static void gob_result(GobW &w, const Result *R, const RowStore &row, size_t n_groups) {
+    Fields f(w);
+    bool any = false;
+    for (int a = 0; a < R->n_aggs; a++) any = any || R->agg_pool[(size_t)row.agg_off + a].present;
+    if (any) {
+        f.at(0);  // Hists map[string]Histogram
+        size_t n = 0;
+        for (int a = 0; a < R->n_aggs; a++) n += R->agg_pool[(size_t)row.agg_off + a].present ? 1 : 0;
+        w.u(n);
+        for (int a = 0; a < R->n_aggs; a++) {
+            const sybl_agg_out &o = R->agg_pool[(size_t)row.agg_off + a];
+            if (!o.present) continue;
+            w.s(R->agg_names[(size_t)a]);
+            gob_hist(w, R, o, a);
+        }
+    }
+    f.put_str(1, row.gbk);
+    if (n_groups > 0) {
+        f.at(2);  // BinaryByKey: 8 little-endian bytes per group column
+        w.s((const char *)row.key, n_groups * SYBL_GROUP_BY_WIDTH);
+    }
+    f.put_int(3, row.count);
+    f.put_int(4, row.samples);
+    f.end();
+}
+
+static void gob_result_map(GobW &w, const Result *R, const std::vector<RowStore> &rows, size_t i0, size_t i1, size_t n_groups) {
+    w.u(i1 - i0);
+    for (size_t i = i0; i < i1; i++) {
+        w.s(rows[i].gbk);
+        gob_result(w, R, rows[i], n_groups);
+    }
+}
+
+}  // namespace
+
+const void *sybl_result_encode(sybl_result *r, int64_t *n_bytes) {
+    Result *R = (Result *)r;
+    if (!R || !n_bytes) {
+        set_error("sybl_result_encode: NULL argument");
+        return nullptr;
+    }
+    GobStream S;
+    S.def_struct(T_NODE, "NodeResults", {{"QuerySpec", T_QSPEC}});
+    S.def_struct(T_QSPEC, "QuerySpec", {{"QueryParams", T_QPARAMS}, {"QueryResults", T_QRESULTS}});
+    S.def_struct(T_QPARAMS, "QueryParams",
+                 {{"Groups", T_GROUPINGS}, {"Aggregations", T_AGGS}, {"OrderBy", G_STRING}, {"OrderAsc", G_BOOL}, {"Limit", G_INT},
+                  {"TimeBucket", G_INT}});
+    S.def_struct(T_GROUPING, "Grouping", {{"Name", G_STRING}});
+    S.def_slice(T_GROUPINGS, "[]sybil.Grouping", T_GROUPING);
+    S.def_struct(T_AGG, "Aggregation", {{"Op", G_STRING}, {"Name", G_STRING}, {"HistType", G_STRING}});
+    S.def_slice(T_AGGS, "[]sybil.Aggregation", T_AGG);
+    S.def_struct(T_QRESULTS, "QueryResults",
+                 {{"Cumulative", T_RESULT}, {"Results", T_RESULTMAP}, {"TimeResults", T_TIMEMAP}, {"MatchedCount", G_INT},
+                  {"Sorted", T_SORTED}});
+    S.def_struct(T_RESULT, "Result",
+                 {{"Hists", T_HISTMAP}, {"GroupByKey", G_STRING}, {"BinaryByKey", G_STRING}, {"Count", G_INT}, {"Samples", G_INT}});
+    S.def_map(T_HISTMAP, "map[string]sybil.Histogram", G_STRING, G_IFACE);
+    S.def_map(T_RESULTMAP, "ResultMap", G_STRING, T_RESULT);
+    S.def_map(T_TIMEMAP, "map[int]sybil.ResultMap", G_INT, T_RESULTMAP);
+    S.def_slice(T_SORTED, "[]*sybil.Result", T_RESULT);
+    S.def_struct(T_HISTCOMPAT, "HistCompat", {{"BasicHist", T_BASICHIST}});
+    S.def_struct(T_BASICHIST, "BasicHist", {{"BasicHistCachedInfo", T_CACHED}});
+    S.def_struct(T_CACHED, "BasicHistCachedInfo",
+                 {{"NumBuckets", G_INT}, {"BucketSize", G_INT}, {"Values", T_I64S}, {"PercentileMode", G_BOOL}, {"Max", G_INT},
+                  {"Min", G_INT}, {"Samples", G_INT}, {"Count", G_INT}, {"Avg", G_FLOAT}, {"Info", T_INTINFO}});
+    S.def_slice(T_I64S, "[]int64", G_INT);
+    S.def_struct(T_INTINFO, "IntInfo", {{"Min", G_INT}, {"Max", G_INT}});
+
+    const size_t ng = R->group_names.size();
+    GobW w;
+    w.i(T_NODE);
+    Fields node(w);
+    node.at(0);  // NodeResults.QuerySpec
+    Fields qs(w);
+    qs.at(0);  // QueryParams
+    {
+        Fields qp(w);
+        if (ng > 0) {
+            qp.at(0);
+            w.u(ng);
+            for (auto &g : R->group_names) {
+                Fields gf(w);
+                gf.put_str(0, g);
+                gf.end();
+            }
+        }
+        if (R->n_aggs > 0) {
+            qp.at(1);
+            w.u((uint64_t)R->n_aggs);
+            for (auto &a : R->agg_names) {
+                Fields af(w);
+                af.put_str(0, R->op == SYBL_AGG_HIST ? "hist" : "avg");
+                af.put_str(1, a);
+                af.put_str(2, "basic");
+                af.end();
+            }
+        }
+        qp.put_str(2, R->order_by);
+        if (R->order_asc) {
+            qp.at(3);
+            w.u(1);
+        }
+        qp.put_int(4, R->limit);
+        qp.put_int(5, R->time_mode ? R->time_bucket : 0);
+        qp.end();
+    }
+    qs.at(1);  // QueryResults
+    {
+        Fields qr(w);
+        qr.at(0);  // Cumulative
+        gob_result(w, R, R->rows[2][0], 0);
+        if (!R->rows[0].empty()) {
+            qr.at(1);  // Results
+            gob_result_map(w, R, R->rows[0], 0, R->rows[0].size(), ng);
+        }
+        if (!R->rows[1].empty()) {
+            qr.at(2);  // TimeResults map[int]ResultMap: rows[1] is ordered by bucket
+            const std::vector<RowStore> &tr = R->rows[1];
+            size_t n_buckets = 0;
+            for (size_t i = 0; i < tr.size(); i++) n_buckets += i == 0 || tr[i].time_bucket != tr[i - 1].time_bucket;
+            w.u(n_buckets);
+            for (size_t i = 0; i < tr.size();) {
+                size_t j = i;
+                while (j < tr.size() && tr[j].time_bucket == tr[i].time_bucket) j++;
+                w.i(tr[i].time_bucket);
+                gob_result_map(w, R, tr, i, j, ng);
+                i = j;
+            }
+        }
+        qr.put_int(3, R->matched);
+        if (!R->rows[0].empty() && !R->order_by.empty()) {
+            qr.at(4);  // Sorted []*Result (SortResults, aggregate.go:497-525): the rows are already in that order
+            w.u(R->rows[0].size());
+            for (auto &row : R->rows[0]) gob_result(w, R, row, ng);
+        }
+        qr.end();
+    }
+    qs.end();
+    node.end();
+    S.message(w.b);
+    R->encoded.swap(S.out);
+    *n_bytes = (int64_t)R->encoded.size();
+    return R->encoded.data();
+}
+
+}  // extern "C"

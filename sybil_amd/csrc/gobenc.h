@@ -87,6 +87,10 @@ struct Buf {
         u(x.size());
         b += x;
     }
+    void s(const char *p, size_t n) {
+        u(n);
+        b.append(p, n);
+    }
 };
 
 // struct value writer: field deltas, zero values are simply not put (gob omits them)

@@ -7,122 +7,21 @@
 //   TimeResults / all-time Results in time-series mode               aggregate.go:146-183
 //   avg / stddev / percentiles from exact integers                   hist_basic.go:153-219
 //   sort                                                             aggregate.go:43-54,497-525
-//   text / JSON rendering                                            printer.go:109-232,291-308
+// Rendering lives in render.cpp (printer.go), -encode-results in encode.cpp.
 #include <math.h>
 #include <stdio.h>
-#include <string.h>
-#include <time.h>
-
 #include <stdlib.h>
+#include <string.h>
 
 #include <algorithm>
 #include <chrono>
 #include <condition_variable>
 #include <functional>
-#include <memory>
-#include <mutex>
-#include <string>
 #include <thread>
-#include <vector>
 
-#include "engine.h"
+#include "result.h"
 
 namespace sybl {
-
-struct AggAcc {
-    bool tracked_cnt = false;
-    const int64_t *pct_gpu = nullptr;  // GetPercentiles computed by k_hist_summary (100 entries)
-    bool moments = false;              // sb / sb2 are valid even though the query keeps bucket arrays
-    int64_t cnt = 0, smp = 0, pop = 0;
-    uint64_t sum = 0;
-    int64_t sb = 0, sb2 = 0;
-    int64_t n_out = 0;
-    uint64_t sum_out = 0;
-    uint64_t sq[4] = {0, 0, 0, 0};
-    int64_t vmax = INT64_MIN, nmin = INT64_MIN;
-    const int64_t *values = nullptr;  // bucket counts (full-hist mode), n_values long
-};
-
-struct CellAcc {
-    int64_t count = 0, samples = 0;
-    bool has_aggs = false;
-    AggAcc aggs[kMaxAggs];
-};
-
-struct RowStore {
-    uint8_t key[SYBL_MAX_GROUPS * SYBL_GROUP_BY_WIDTH];
-    std::string gbk;
-    int64_t time_bucket = 0, count = 0, samples = 0;
-    int64_t agg_off = 0;  // this row's n_aggs entries in Result::agg_pool / val_pool / pctoff_pool
-    int64_t cell = -1;    // group cell (rows of Results / TimeResults)
-};
-
-// The big per-result arrays, recycled between the results of one query: a time-series or
-// high-cardinality result is tens of MB, and allocating it afresh costs more in page faults (and
-// in munmap on free) than building its rows does.
-struct ResultStore {
-    std::vector<RowStore> rows[3];
-    std::vector<RowStore> rows_tmp;  // sort scratch
-    std::vector<sybl_group_row> view[3];
-    std::vector<int64_t> pct_pool, pctoff_pool;
-    std::vector<sybl_agg_out> agg_pool;
-    std::vector<const int64_t *> val_pool;
-    std::vector<int64_t> live, alltime, all_count, all_samples;  // finalize scratch
-    void swap(ResultStore &o) {
-        for (int w = 0; w < 3; w++) {
-            rows[w].swap(o.rows[w]);
-            view[w].swap(o.view[w]);
-        }
-        rows_tmp.swap(o.rows_tmp);
-        pct_pool.swap(o.pct_pool);
-        pctoff_pool.swap(o.pctoff_pool);
-        agg_pool.swap(o.agg_pool);
-        val_pool.swap(o.val_pool);
-        live.swap(o.live);
-        alltime.swap(o.alltime);
-        all_count.swap(o.all_count);
-        all_samples.swap(o.all_samples);
-    }
-};
-
-struct ResultPool {
-    std::mutex m;
-    bool full = false;
-    ResultStore spare;
-};
-
-struct Result : ResultStore {
-    std::shared_ptr<ResultPool> pool;  // where the arrays go back to when the result is freed
-    ~Result() {
-        if (!pool) return;
-        std::lock_guard<std::mutex> lk(pool->m);
-        if (!pool->full) {
-            pool->spare.swap(*this);
-            pool->full = true;
-        }
-    }
-    int64_t matched = 0;
-    std::shared_ptr<HostBuf> keep;                // the pinned snapshot of the partial table the bucket
-                                                  // arrays of the rows point into
-    std::vector<std::vector<int64_t>> total_vals; // Cumulative bucket arrays
-    std::vector<int64_t> top_vals;                // bucket arrays of the first `limit` rows (GPU summary path)
-    // (ResultStore) pct_pool: 100 entries per (row, agg) with percentiles; agg_pool / val_pool /
-    // pctoff_pool: n_aggs entries per row, all row kinds (pctoff: offset into pct_pool, -1 = none)
-    // for rendering
-    int op = 0;
-    bool weighted = false, time_mode = false, want_percentiles = false;
-    int limit = 0;
-    int n_aggs = 0;
-    std::vector<int64_t> n_values;
-    std::string order_by;
-    std::vector<std::string> group_names, agg_names;
-    std::string rendered[2];
-    // -encode-results
-    std::vector<std::pair<int64_t, int64_t>> agg_info;  // Info.Min / Info.Max per aggregation
-    int64_t time_bucket = 0;
-    bool order_asc = false;
-    std::string encoded;
-};
 
 // GetPercentiles, hist_basic.go:153-183 (same loop as the reference, including the
 // percentiles[p] = k overwrite that later iterations repair)
@@ -838,188 +737,6 @@ int query_finalize(Query *q, Result **out) {
     return SYBL_OK;
 }
 
-// ------------------------------------------------------------------ rendering (printer.go)
-
-static void json_escape(const std::string &s, std::string &o) {
-    o += '"';
-    for (unsigned char ch : s) {
-        switch (ch) {
-        case '"': o += "\\\""; break;
-        case '\\': o += "\\\\"; break;
-        case '\n': o += "\\n"; break;
-        case '\r': o += "\\r"; break;
-        case '\t': o += "\\t"; break;
-        case '<': o += "\\u003c"; break;  // encoding/json escapes HTML by default
-        case '>': o += "\\u003e"; break;
-        case '&': o += "\\u0026"; break;
-        default:
-            if (ch < 0x20) {
-                char b[8];
-                snprintf(b, sizeof(b), "\\u%04x", ch);
-                o += b;
-            } else {
-                o += (char)ch;
-            }
-        }
-    }
-    o += '"';
-}
-
-// encoding/json float formatting: shortest repr that round-trips, 'e' form outside [1e-6,1e21)
-static std::string go_float(double f) {
-    if (f == 0) return signbit(f) ? "-0" : "0";
-    if (!isfinite(f)) return "null";  // json.Marshal would fail; the reference prints nothing useful
-    char buf[64];
-    int prec = 1;
-    for (; prec <= 17; prec++) {
-        snprintf(buf, sizeof(buf), "%.*e", prec - 1, f);
-        if (strtod(buf, nullptr) == f) break;
-    }
-    double af = fabs(f);
-    if (af < 1e-6 || af >= 1e21) {
-        // mantissa 'e' exponent with at least... Go: strconv 'e' then trims "e-07" -> "e-7"
-        std::string s(buf);
-        size_t e = s.find('e');
-        std::string mant = s.substr(0, e), ex = s.substr(e + 1);
-        int exv = atoi(ex.c_str());
-        char eb[16];
-        snprintf(eb, sizeof(eb), "e%s%02d", exv < 0 ? "-" : "+", abs(exv));
-        std::string r = mant + eb;
-        // encoding/json: clean up e-09 to e-9
-        size_t n = r.size();
-        if (n >= 4 && r[n - 4] == 'e' && r[n - 3] == '-' && r[n - 2] == '0') {
-            r[n - 2] = r[n - 1];
-            r.resize(n - 1);
-        }
-        return r;
-    }
-    // 'f' form with the same digits
-    int decimals = 0;
-    {
-        std::string s(buf);
-        size_t e = s.find('e');
-        int exv = atoi(s.c_str() + e + 1);
-        decimals = std::max(0, (prec - 1) - exv);
-    }
-    snprintf(buf, sizeof(buf), "%.*f", decimals, f);
-    return buf;
-}
-
-static void json_agg(const Result *R, const RowStore &r, size_t a, std::string &o) {
-    const size_t pk = (size_t)r.agg_off + a;
-    const sybl_agg_out &g = R->agg_pool[pk];
-    const int64_t *vals = R->val_pool[pk];
-    const int64_t poff = R->pctoff_pool[pk];
-    if (R->op == SYBL_AGG_AVG) {
-        o += g.present ? go_float(g.avg) : "null";
-        return;
-    }
-    o += "{";
-    if (g.present) {
-        // keys in the order encoding/json emits a map: sorted
-        o += "\"avg\":" + go_float(g.avg);
-        if (R->want_percentiles && vals) {
-            // GetStrBuckets + getSparseBuckets: non-zero buckets keyed by their lower edge, sorted as strings
-            std::vector<std::pair<std::string, int64_t>> bk;
-            for (size_t b = 0; b < (size_t)R->n_values[a]; b++)
-                if (vals[b] > 0)
-                    bk.emplace_back(std::to_string((long long)((int64_t)b * g.bucket_size + g.min)), vals[b]);
-            std::sort(bk.begin(), bk.end());
-            o += ",\"buckets\":{";
-            for (size_t k = 0; k < bk.size(); k++) {
-                if (k) o += ",";
-                o += "\"" + bk[k].first + "\":" + std::to_string((long long)bk[k].second);
-            }
-            o += "}";
-            o += ",\"percentiles\":[";
-            for (size_t k = 0; poff >= 0 && k < 100; k++) {
-                if (k) o += ",";
-                o += std::to_string((long long)R->pct_pool[(size_t)poff + k]);
-            }
-            o += "]";
-        }
-        o += ",\"samples\":" + std::to_string((long long)g.count);  // "samples" = TotalCount() (printer.go:123)
-        o += ",\"stddev\":" + go_float(g.stddev);
-        o += ",\"sum\":" + go_float(g.avg * (double)g.count);  // Mean()*TotalCount(), printer.go:122
-    }
-    o += "}";
-}
-
-static void json_row(const Result *R, const RowStore &r, std::string &o) {
-    // ResultJSON is a map: keys are emitted sorted
-    std::vector<std::pair<std::string, std::string>> kv;
-    for (size_t a = 0; a < R->agg_names.size(); a++) {
-        std::string v;
-        json_agg(R, r, a, v);
-        kv.emplace_back(R->agg_names[a], v);
-    }
-    size_t pos = 0;
-    for (size_t g = 0; g < R->group_names.size(); g++) {
-        size_t e = r.gbk.find('\t', pos);
-        std::string part = r.gbk.substr(pos, e == std::string::npos ? std::string::npos : e - pos);
-        pos = e == std::string::npos ? r.gbk.size() : e + 1;
-        std::string v;
-        json_escape(part, v);
-        kv.emplace_back(R->group_names[g], v);
-    }
-    kv.emplace_back("Count", std::to_string((long long)r.count));
-    kv.emplace_back("Samples", std::to_string((long long)r.samples));
-    std::stable_sort(kv.begin(), kv.end(), [](const auto &x, const auto &y) { return x.first < y.first; });
-    // later duplicates of a key overwrite earlier ones in a Go map
-    o += "{";
-    bool first = true;
-    for (size_t k = 0; k < kv.size(); k++) {
-        if (k + 1 < kv.size() && kv[k + 1].first == kv[k].first) continue;
-        if (!first) o += ",";
-        first = false;
-        json_escape(kv[k].first, o);
-        o += ":" + kv[k].second;
-    }
-    o += "}";
-}
-
-static void text_row(const Result *R, const RowStore &r, std::string &o) {
-    // printResult, printer.go:183-232
-    std::string gk = r.gbk;
-    std::replace(gk.begin(), gk.end(), '\t', ',');
-    while (!gk.empty() && gk.back() == ',') gk.pop_back();
-    char b[64];
-    snprintf(b, sizeof(b), "%-20s", gk.c_str());
-    std::string pad(b);
-    o += pad.substr(0, 20);
-    if (r.count != 0) o += std::to_string((long long)r.count);  // "%.0d" prints nothing for 0
-    if (R->weighted) o += " (" + std::to_string((long long)r.samples) + ")";
-    o += "\n";
-    for (size_t a = 0; a < R->agg_names.size(); a++) {
-        const sybl_agg_out &g = R->agg_pool[(size_t)r.agg_off + a];
-        const int64_t poff = R->pctoff_pool[(size_t)r.agg_off + a];
-        snprintf(b, sizeof(b), "  %5s", R->agg_names[a].c_str());
-        std::string col = b;
-        if (R->op == SYBL_AGG_HIST) {
-            if (!g.present) continue;
-            if (poff >= 0) {
-                const int64_t *p = R->pct_pool.data() + poff;
-                char line[512];
-                snprintf(line, sizeof(line), "%s | %lld %lld | %.2f | %lld %lld %lld %lld %lld | %.2f\n", col.c_str(),
-                         (long long)p[0], (long long)p[99], g.avg, (long long)p[0], (long long)p[25], (long long)p[50],
-                         (long long)p[75], (long long)p[99], g.stddev);
-                o += line;
-            } else if (!R->want_percentiles) {
-                // moments-only result: no percentile columns to print
-                char line[256];
-                snprintf(line, sizeof(line), "%s | %.2f | %.2f\n", col.c_str(), g.avg, g.stddev);
-                o += line;
-            } else {
-                o += col + " No Data\n";
-            }
-        } else {
-            char line[128];
-            snprintf(line, sizeof(line), "%s %.2f\n", col.c_str(), g.present ? g.avg : 0.0);
-            o += line;
-        }
-    }
-}
-
 }  // namespace sybl
 
 using namespace sybl;
@@ -1037,454 +754,5 @@ int sybl_result_rows(const sybl_result *r, int which, const sybl_group_row **row
 int64_t sybl_result_matched(const sybl_result *r) { return r ? ((const Result *)r)->matched : 0; }
 
 void sybl_result_free(sybl_result *r) { delete (Result *)r; }
-
-// ------------------------------------------------------------------ -encode-results (printer.go:284-289)
-// encoding/gob of NodeResults{QuerySpec{QueryParams, QueryResults}} (node_aggregator.go:8-13,
-// query_spec.go:16-93) -- what `sybil query -encode-results` prints and `sybil aggregate` / src/api read.
-// gob matches struct fields by NAME, so only the fields the engine fills are defined and sent; the
-// reference's golden NodeResults (testdata/TestDecodeGoldenFiles/node_results.golden.gob) carries the
-// same type and field names (tests/test_gpu_cli.py decodes both with the same decoder).
-namespace {
-
-struct GobW {
-    std::string b;
-    void u(uint64_t x) {
-        if (x < 128) {
-            b.push_back((char)x);
-            return;
-        }
-        char tmp[8];
-        int n = 0;
-        while (x) {
-            tmp[n++] = (char)(x & 0xFF);
-            x >>= 8;
-        }
-        b.push_back((char)(256 - n));
-        while (n) b.push_back(tmp[--n]);
-    }
-    void i(int64_t x) { u(x < 0 ? ((~(uint64_t)x) << 1) | 1 : (uint64_t)x << 1); }
-    void f(double d) {
-        uint64_t bits, rev = 0;
-        memcpy(&bits, &d, 8);
-        for (int k = 0; k < 8; k++) rev |= ((bits >> (8 * k)) & 0xFF) << (8 * (7 - k));
-        u(rev);
-    }
-    void s(const std::string &x) {
-        u(x.size());
-        b += x;
-    }
-    void s(const char *p, size_t n) {
-        u(n);
-        b.append(p, n);
-    }
-};
-
-enum GobId : int {  // builtin ids, then ours in definition order
-    G_BOOL = 1, G_INT = 2, G_FLOAT = 4, G_STRING = 6, G_IFACE = 8,
-    T_NODE = 65, T_QSPEC, T_QPARAMS, T_GROUPING, T_GROUPINGS, T_AGG, T_AGGS, T_QRESULTS, T_RESULT, T_HISTMAP, T_RESULTMAP,
-    T_TIMEMAP, T_SORTED, T_HISTCOMPAT, T_BASICHIST, T_CACHED, T_I64S, T_INTINFO,
-};
-
-struct GobStream {
-    std::string out;
-    void message(const std::string &payload) {
-        GobW h;
-        h.u(payload.size());
-        out += h.b;
-        out += payload;
-    }
-    static void common(GobW &w, const char *name, int id) {  // CommonType{Name, Id}
-        if (name && name[0]) {
-            w.u(1);
-            w.s(name);
-            w.u(1);
-        } else {
-            w.u(2);
-        }
-        w.i(id);
-        w.u(0);
-    }
-    void def_struct(int id, const char *name, std::initializer_list<std::pair<const char *, int>> fields) {
-        GobW w;
-        w.i(-id);
-        w.u(3);  // wireType.StructT
-        w.u(1);
-        common(w, name, id);
-        w.u(1);
-        w.u(fields.size());
-        for (auto &fd : fields) {
-            w.u(1);
-            w.s(fd.first);
-            w.u(1);
-            w.i(fd.second);
-            w.u(0);
-        }
-        w.u(0);
-        w.u(0);
-        message(w.b);
-    }
-    void def_slice(int id, const char *name, int elem) {
-        GobW w;
-        w.i(-id);
-        w.u(2);  // wireType.SliceT
-        w.u(1);
-        common(w, name, id);
-        w.u(1);
-        w.i(elem);
-        w.u(0);
-        w.u(0);
-        message(w.b);
-    }
-    void def_map(int id, const char *name, int key, int elem) {
-        GobW w;
-        w.i(-id);
-        w.u(4);  // wireType.MapT
-        w.u(1);
-        common(w, name, id);
-        w.u(1);
-        w.i(key);
-        w.u(1);
-        w.i(elem);
-        w.u(0);
-        w.u(0);
-        message(w.b);
-    }
-};
-
-// struct field writer: deltas between sent fields, zero values omitted (gob rule)
-struct Fields {
-    GobW &w;
-    int prev = -1;
-    explicit Fields(GobW &w_) : w(w_) {}
-    void at(int ix) {
-        w.u((uint64_t)(ix - prev));
-        prev = ix;
-    }
-    void put_int(int ix, int64_t v) {
-        if (v == 0) return;
-        at(ix);
-        w.i(v);
-    }
-    void put_str(int ix, const std::string &v) {
-        if (v.empty()) return;
-        at(ix);
-        w.s(v);
-    }
-    void end() { w.u(0); }
-};
-
-static void gob_hist(GobW &w, const Result *R, const sybl_agg_out &o, int a) {
-    // Histogram interface value: registered name, concrete type id, byte count, HistCompat{BasicHist{BasicHistCachedInfo}}
-    GobW v;
-    Fields hc(v);
-    hc.at(0);  // HistCompat.BasicHist
-    Fields bh(v);
-    bh.at(0);  // BasicHist.BasicHistCachedInfo
-    Fields ci(v);
-    ci.put_int(0, o.num_buckets);
-    ci.put_int(1, o.bucket_size);
-    if (o.values && o.n_values > 0) {
-        ci.at(2);  // Values []int64
-        v.u((uint64_t)o.n_values);
-        for (int64_t k = 0; k < o.n_values; k++) v.i(o.values[k]);
-    }
-    if (R->op == SYBL_AGG_HIST) {
-        ci.at(3);  // PercentileMode
-        v.u(1);
-    }
-    ci.put_int(4, o.max);
-    ci.put_int(5, o.min);
-    ci.put_int(6, o.samples);
-    ci.put_int(7, o.count);
-    if (o.avg != 0.0) {
-        ci.at(8);
-        v.f(o.avg);
-    }
-    {
-        ci.at(9);  // Info IntInfo{Min, Max}
-        Fields in(v);
-        in.put_int(0, R->agg_info[(size_t)a].first);
-        in.put_int(1, R->agg_info[(size_t)a].second);
-        in.end();
-    }
-    ci.end();
-    bh.end();
-    hc.end();
-    w.s("*sybil.HistCompat");
-    w.i(T_HISTCOMPAT);
-    w.u(v.b.size());
-    w.b += v.b;
-}
-
-static void gob_result(GobW &w, const Result *R, const RowStore &row, size_t n_groups) {
-    Fields f(w);
-    bool any = false;
-    for (int a = 0; a < R->n_aggs; a++) any = any || R->agg_pool[(size_t)row.agg_off + a].present;
-    if (any) {
-        f.at(0);  // Hists map[string]Histogram
-        size_t n = 0;
-        for (int a = 0; a < R->n_aggs; a++) n += R->agg_pool[(size_t)row.agg_off + a].present ? 1 : 0;
-        w.u(n);
-        for (int a = 0; a < R->n_aggs; a++) {
-            const sybl_agg_out &o = R->agg_pool[(size_t)row.agg_off + a];
-            if (!o.present) continue;
-            w.s(R->agg_names[(size_t)a]);
-            gob_hist(w, R, o, a);
-        }
-    }
-    f.put_str(1, row.gbk);
-    if (n_groups > 0) {
-        f.at(2);  // BinaryByKey: 8 little-endian bytes per group column
-        w.s((const char *)row.key, n_groups * SYBL_GROUP_BY_WIDTH);
-    }
-    f.put_int(3, row.count);
-    f.put_int(4, row.samples);
-    f.end();
-}
-
-static void gob_result_map(GobW &w, const Result *R, const std::vector<RowStore> &rows, size_t i0, size_t i1, size_t n_groups) {
-    w.u(i1 - i0);
-    for (size_t i = i0; i < i1; i++) {
-        w.s(rows[i].gbk);
-        gob_result(w, R, rows[i], n_groups);
-    }
-}
-
-}  // namespace
-
-const void *sybl_result_encode(sybl_result *r, int64_t *n_bytes) {
-    Result *R = (Result *)r;
-    if (!R || !n_bytes) {
-        set_error("sybl_result_encode: NULL argument");
-        return nullptr;
-    }
-    GobStream S;
-    S.def_struct(T_NODE, "NodeResults", {{"QuerySpec", T_QSPEC}});
-    S.def_struct(T_QSPEC, "QuerySpec", {{"QueryParams", T_QPARAMS}, {"QueryResults", T_QRESULTS}});
-    S.def_struct(T_QPARAMS, "QueryParams",
-                 {{"Groups", T_GROUPINGS}, {"Aggregations", T_AGGS}, {"OrderBy", G_STRING}, {"OrderAsc", G_BOOL}, {"Limit", G_INT},
-                  {"TimeBucket", G_INT}});
-    S.def_struct(T_GROUPING, "Grouping", {{"Name", G_STRING}});
-    S.def_slice(T_GROUPINGS, "[]sybil.Grouping", T_GROUPING);
-    S.def_struct(T_AGG, "Aggregation", {{"Op", G_STRING}, {"Name", G_STRING}, {"HistType", G_STRING}});
-    S.def_slice(T_AGGS, "[]sybil.Aggregation", T_AGG);
-    S.def_struct(T_QRESULTS, "QueryResults",
-                 {{"Cumulative", T_RESULT}, {"Results", T_RESULTMAP}, {"TimeResults", T_TIMEMAP}, {"MatchedCount", G_INT},
-                  {"Sorted", T_SORTED}});
-    S.def_struct(T_RESULT, "Result",
-                 {{"Hists", T_HISTMAP}, {"GroupByKey", G_STRING}, {"BinaryByKey", G_STRING}, {"Count", G_INT}, {"Samples", G_INT}});
-    S.def_map(T_HISTMAP, "map[string]sybil.Histogram", G_STRING, G_IFACE);
-    S.def_map(T_RESULTMAP, "ResultMap", G_STRING, T_RESULT);
-    S.def_map(T_TIMEMAP, "map[int]sybil.ResultMap", G_INT, T_RESULTMAP);
-    S.def_slice(T_SORTED, "[]*sybil.Result", T_RESULT);
-    S.def_struct(T_HISTCOMPAT, "HistCompat", {{"BasicHist", T_BASICHIST}});
-    S.def_struct(T_BASICHIST, "BasicHist", {{"BasicHistCachedInfo", T_CACHED}});
-    S.def_struct(T_CACHED, "BasicHistCachedInfo",
-                 {{"NumBuckets", G_INT}, {"BucketSize", G_INT}, {"Values", T_I64S}, {"PercentileMode", G_BOOL}, {"Max", G_INT},
-                  {"Min", G_INT}, {"Samples", G_INT}, {"Count", G_INT}, {"Avg", G_FLOAT}, {"Info", T_INTINFO}});
-    S.def_slice(T_I64S, "[]int64", G_INT);
-    S.def_struct(T_INTINFO, "IntInfo", {{"Min", G_INT}, {"Max", G_INT}});
-
-    const size_t ng = R->group_names.size();
-    GobW w;
-    w.i(T_NODE);
-    Fields node(w);
-    node.at(0);  // NodeResults.QuerySpec
-    Fields qs(w);
-    qs.at(0);  // QueryParams
-    {
-        Fields qp(w);
-        if (ng > 0) {
-            qp.at(0);
-            w.u(ng);
-            for (auto &g : R->group_names) {
-                Fields gf(w);
-                gf.put_str(0, g);
-                gf.end();
-            }
-        }
-        if (R->n_aggs > 0) {
-            qp.at(1);
-            w.u((uint64_t)R->n_aggs);
-            for (auto &a : R->agg_names) {
-                Fields af(w);
-                af.put_str(0, R->op == SYBL_AGG_HIST ? "hist" : "avg");
-                af.put_str(1, a);
-                af.put_str(2, "basic");
-                af.end();
-            }
-        }
-        qp.put_str(2, R->order_by);
-        if (R->order_asc) {
-            qp.at(3);
-            w.u(1);
-        }
-        qp.put_int(4, R->limit);
-        qp.put_int(5, R->time_mode ? R->time_bucket : 0);
-        qp.end();
-    }
-    qs.at(1);  // QueryResults
-    {
-        Fields qr(w);
-        qr.at(0);  // Cumulative
-        gob_result(w, R, R->rows[2][0], 0);
-        if (!R->rows[0].empty()) {
-            qr.at(1);  // Results
-            gob_result_map(w, R, R->rows[0], 0, R->rows[0].size(), ng);
-        }
-        if (!R->rows[1].empty()) {
-            qr.at(2);  // TimeResults map[int]ResultMap: rows[1] is ordered by bucket
-            const std::vector<RowStore> &tr = R->rows[1];
-            size_t n_buckets = 0;
-            for (size_t i = 0; i < tr.size(); i++) n_buckets += i == 0 || tr[i].time_bucket != tr[i - 1].time_bucket;
-            w.u(n_buckets);
-            for (size_t i = 0; i < tr.size();) {
-                size_t j = i;
-                while (j < tr.size() && tr[j].time_bucket == tr[i].time_bucket) j++;
-                w.i(tr[i].time_bucket);
-                gob_result_map(w, R, tr, i, j, ng);
-                i = j;
-            }
-        }
-        qr.put_int(3, R->matched);
-        if (!R->rows[0].empty() && !R->order_by.empty()) {
-            qr.at(4);  // Sorted []*Result (SortResults, aggregate.go:497-525): the rows are already in that order
-            w.u(R->rows[0].size());
-            for (auto &row : R->rows[0]) gob_result(w, R, row, ng);
-        }
-        qr.end();
-    }
-    qs.end();
-    node.end();
-    S.message(w.b);
-    R->encoded.swap(S.out);
-    *n_bytes = (int64_t)R->encoded.size();
-    return R->encoded.data();
-}
-
-const char *sybl_result_render(sybl_result *r, int format) {
-    Result *R = (Result *)r;
-    if (!R || (format != 0 && format != 1)) {
-        set_error("sybl_result_render: bad argument");
-        return nullptr;
-    }
-    std::string &o = R->rendered[format];
-    o.clear();
-    size_t lim = R->rows[0].size();
-    if (R->limit > 0 && (size_t)R->limit < lim) lim = (size_t)R->limit;
-    if (R->time_mode) {
-        // printTimeResults, printer.go:25-107
-        std::vector<const RowStore *> top;
-        for (size_t i = 0; i < lim; i++) top.push_back(&R->rows[0][i]);
-        auto is_top = [&](const RowStore &x) {
-            for (auto *t : top)
-                if (t->gbk == x.gbk) return true;
-            return false;
-        };
-        if (format == 1) {
-            // map[string][]ResultJSON keyed by the bucket as a decimal string (sorted as strings)
-            std::vector<std::pair<std::string, std::string>> kv;
-            size_t i = 0;
-            while (i < R->rows[1].size()) {
-                int64_t tb = R->rows[1][i].time_bucket;
-                std::string arr = "[";
-                bool first = true;
-                for (; i < R->rows[1].size() && R->rows[1][i].time_bucket == tb; i++) {
-                    if (!is_top(R->rows[1][i])) continue;
-                    if (!first) arr += ",";
-                    first = false;
-                    json_row(R, R->rows[1][i], arr);
-                }
-                arr += "]";
-                kv.emplace_back(std::to_string((long long)tb), arr);
-            }
-            std::sort(kv.begin(), kv.end());
-            o += "{";
-            for (size_t k = 0; k < kv.size(); k++) {
-                if (k) o += ",";
-                o += "\"" + kv[k].first + "\":" + kv[k].second;
-            }
-            o += "}";
-        } else {
-            // printTimeResults text form (printer.go:64-107): every row is written through a
-            // text/tabwriter (minwidth 0, tabwidth 1, padding 0, padchar ' ', AlignRight) as
-            //   Fprintln(w, time_str, "\t", Count, "\t", GroupByKey, "\t"[, agg, "\t", avg, "\t"])
-            // (Fprintln puts a space between operands); time_str = time.Unix(bucket, 0) in
-            // OPTS.TIME_FORMAT "2006-01-02 15:04:05.999999999 -0700 MST" (config.go:127), local zone.
-            std::vector<std::string> lines;
-            auto time_str = [](int64_t tb) {
-                time_t tt = (time_t)tb;
-                struct tm tmv;
-                localtime_r(&tt, &tmv);
-                char b[96];
-                strftime(b, sizeof(b), "%Y-%m-%d %H:%M:%S %z %Z", &tmv);
-                return std::string(b);
-            };
-            for (auto &row : R->rows[1]) {
-                std::string head = time_str(row.time_bucket) + " \t " + std::to_string((long long)row.count) + " \t " + row.gbk + " \t";
-                bool any = false;
-                for (size_t a = 0; a < R->agg_names.size(); a++) {
-                    const sybl_agg_out &g = R->agg_pool[(size_t)row.agg_off + a];
-                    if (!g.present) continue;
-                    char avg[64];
-                    snprintf(avg, sizeof(avg), "%.2f", g.avg);
-                    lines.push_back(head + " " + R->agg_names[a] + " \t " + avg + " \t");
-                    any = true;
-                }
-                if (!any) lines.push_back(head);  // len(r.Hists) == 0
-            }
-            // tabwriter: cells end at a tab; a column's width is the widest cell of the
-            // contiguous run of lines that have that column; AlignRight pads on the left
-            std::vector<std::vector<std::string>> cells(lines.size());
-            std::vector<std::string> tail(lines.size());
-            size_t maxcols = 0;
-            for (size_t i = 0; i < lines.size(); i++) {
-                size_t pos = 0;
-                for (;;) {
-                    size_t e = lines[i].find('\t', pos);
-                    if (e == std::string::npos) break;
-                    cells[i].push_back(lines[i].substr(pos, e - pos));
-                    pos = e + 1;
-                }
-                tail[i] = lines[i].substr(pos);
-                maxcols = std::max(maxcols, cells[i].size());
-            }
-            std::vector<std::vector<size_t>> width(lines.size());
-            for (size_t i = 0; i < lines.size(); i++) width[i].assign(cells[i].size(), 0);
-            for (size_t c = 0; c < maxcols; c++) {
-                size_t i = 0;
-                while (i < lines.size()) {
-                    if (cells[i].size() <= c) { i++; continue; }
-                    size_t j = i, w = 0;
-                    while (j < lines.size() && cells[j].size() > c) { w = std::max(w, cells[j][c].size()); j++; }
-                    for (size_t k = i; k < j; k++) width[k][c] = w;
-                    i = j;
-                }
-            }
-            for (size_t i = 0; i < lines.size(); i++) {
-                for (size_t c = 0; c < cells[i].size(); c++) {
-                    o.append(width[i][c] - cells[i][c].size(), ' ');
-                    o += cells[i][c];
-                }
-                o += tail[i];
-                o += "\n";
-            }
-        }
-        return o.c_str();
-    }
-    if (format == 1) {
-        o += "[";
-        for (size_t i = 0; i < lim; i++) {
-            if (i) o += ",";
-            json_row(R, R->rows[0][i], o);
-        }
-        o += "]";
-    } else {
-        // printSortedResults / printResults: the cumulative row first when there is more than one group
-        if (lim > 1 && !R->rows[2].empty()) text_row(R, R->rows[2][0], o);
-        for (size_t i = 0; i < lim; i++) text_row(R, R->rows[0][i], o);
-    }
-    return o.c_str();
-}
 
 }  // extern "C"

@@ -1,0 +1,108 @@
+// result.h -- the host-side result model shared by finalize (result.cpp), the renderers (render.cpp) and the
+// -encode-results writer (encode.cpp).
+#pragma once
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "engine.h"
+
+namespace sybl {
+
+struct AggAcc {
+    bool tracked_cnt = false;
+    const int64_t *pct_gpu = nullptr;  // GetPercentiles computed by k_hist_summary (100 entries)
+    bool moments = false;              // sb / sb2 are valid even though the query keeps bucket arrays
+    int64_t cnt = 0, smp = 0, pop = 0;
+    uint64_t sum = 0;
+    int64_t sb = 0, sb2 = 0;
+    int64_t n_out = 0;
+    uint64_t sum_out = 0;
+    uint64_t sq[4] = {0, 0, 0, 0};
+    int64_t vmax = INT64_MIN, nmin = INT64_MIN;
+    const int64_t *values = nullptr;  // bucket counts (full-hist mode), n_values long
+};
+
+struct CellAcc {
+    int64_t count = 0, samples = 0;
+    bool has_aggs = false;
+    AggAcc aggs[kMaxAggs];
+};
+
+struct RowStore {
+    uint8_t key[SYBL_MAX_GROUPS * SYBL_GROUP_BY_WIDTH];
+    std::string gbk;
+    int64_t time_bucket = 0, count = 0, samples = 0;
+    int64_t agg_off = 0;  // this row's n_aggs entries in Result::agg_pool / val_pool / pctoff_pool
+    int64_t cell = -1;    // group cell (rows of Results / TimeResults)
+};
+
+// The big per-result arrays, recycled between the results of one query: a time-series or
+// high-cardinality result is tens of MB, and allocating it afresh costs more in page faults (and
+// in munmap on free) than building its rows does.
+struct ResultStore {
+    std::vector<RowStore> rows[3];
+    std::vector<RowStore> rows_tmp;  // sort scratch
+    std::vector<sybl_group_row> view[3];
+    std::vector<int64_t> pct_pool, pctoff_pool;
+    std::vector<sybl_agg_out> agg_pool;
+    std::vector<const int64_t *> val_pool;
+    std::vector<int64_t> live, alltime, all_count, all_samples;  // finalize scratch
+    void swap(ResultStore &o) {
+        for (int w = 0; w < 3; w++) {
+            rows[w].swap(o.rows[w]);
+            view[w].swap(o.view[w]);
+        }
+        rows_tmp.swap(o.rows_tmp);
+        pct_pool.swap(o.pct_pool);
+        pctoff_pool.swap(o.pctoff_pool);
+        agg_pool.swap(o.agg_pool);
+        val_pool.swap(o.val_pool);
+        live.swap(o.live);
+        alltime.swap(o.alltime);
+        all_count.swap(o.all_count);
+        all_samples.swap(o.all_samples);
+    }
+};
+
+struct ResultPool {
+    std::mutex m;
+    bool full = false;
+    ResultStore spare;
+};
+
+struct Result : ResultStore {
+    std::shared_ptr<ResultPool> pool;  // where the arrays go back to when the result is freed
+    ~Result() {
+        if (!pool) return;
+        std::lock_guard<std::mutex> lk(pool->m);
+        if (!pool->full) {
+            pool->spare.swap(*this);
+            pool->full = true;
+        }
+    }
+    int64_t matched = 0;
+    std::shared_ptr<HostBuf> keep;                // the pinned snapshot of the partial table the bucket
+                                                  // arrays of the rows point into
+    std::vector<std::vector<int64_t>> total_vals; // Cumulative bucket arrays
+    std::vector<int64_t> top_vals;                // bucket arrays of the first `limit` rows (GPU summary path)
+    // (ResultStore) pct_pool: 100 entries per (row, agg) with percentiles; agg_pool / val_pool /
+    // pctoff_pool: n_aggs entries per row, all row kinds (pctoff: offset into pct_pool, -1 = none)
+    // for rendering
+    int op = 0;
+    bool weighted = false, time_mode = false, want_percentiles = false;
+    int limit = 0;
+    int n_aggs = 0;
+    std::vector<int64_t> n_values;
+    std::string order_by;
+    std::vector<std::string> group_names, agg_names;
+    std::string rendered[2];
+    // -encode-results
+    std::vector<std::pair<int64_t, int64_t>> agg_info;  // Info.Min / Info.Max per aggregation
+    int64_t time_bucket = 0;
+    bool order_asc = false;
+    std::string encoded;
+};
+
+}  // namespace sybl
