@@ -1,5 +1,5 @@
-// engine.cpp -- context, HBM-resident tables, the query planner and the scan driver
-// behind the C ABI of include/sybilgpu.h.
+// engine.cpp -- context, error reporting, the scan driver and the query half of the C ABI of
+// include/sybilgpu.h (the planner lives in planner.cpp, tables in table.cpp, finalize in result.cpp).
 //
 // Reference mapping (src/lib/ of logv/sybil):
 //   Table / Column            <- table.go, table_column.go, record_slab.go (AoS row slabs become
@@ -56,39 +56,6 @@ Column *Table::find(const char *n) const {
 
 static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
-// ------------------------------------------------------------------ planner
-
-struct HostFilterFold {
-    bool has_range = false;
-    int64_t lo = INT64_MIN, hi = INT64_MAX;
-    std::vector<int64_t> neq;
-    bool has_mask = false;
-    std::vector<uint8_t> mask;  // per dictionary id, ANDed over the column's str filters
-    std::vector<std::pair<int32_t, int32_t>> setp;  // set predicates: (member id, 1 = in / 0 = nin)
-};
-
-// hist_basic.go:34-70
-static void setup_buckets(int64_t info_min, int64_t info_max, int64_t hist_bucket, int64_t *bucket_size,
-                          int64_t *num_buckets, int64_t *n_values) {
-    int64_t size = info_max - info_min;
-    int64_t nb = 1000;  // NUM_BUCKETS, hist.go:3
-    int64_t bs = size / nb;
-    if (hist_bucket > 0) bs = hist_bucket;
-    if (bs == 0) {
-        if (size < 100) {
-            bs = 1;
-            nb = size;
-        } else {
-            bs = size / 100;
-            nb = size / bs;
-        }
-    }
-    nb += 1;
-    *bucket_size = bs;
-    *num_buckets = nb;
-    *n_values = nb + 1;
-}
-
 static void free_query(Query *q) {
     if (!q) return;
     if (q->d_plan) hipFree(q->d_plan);
@@ -118,1025 +85,6 @@ static void free_query(Query *q) {
     if (q->d_top_cells) hipFree(q->d_top_cells);
     delete q;
 }
-
-// ShouldLoadBlockFromDir (table_block_io.go:110-182) on exact per-block extrema: a gt/lt
-// filter that is false on BOTH the block minimum and maximum, or an eq constant outside
-// [min,max], skips the block; a filter column without a single populated row in the block
-// fails on both pseudo-records as well.
-static bool should_scan_block(const Table *t, const sybl_query_desc *d, int64_t b) {
-    for (int i = 0; i < d->n_filters; i++) {
-        const sybl_filter &f = d->filters[i];
-        const Column *c = t->find(f.col);
-        if (!c || c->type != SYBL_INT_VAL) continue;
-        if (f.op != SYBL_OP_GT && f.op != SYBL_OP_LT && f.op != SYBL_OP_EQ) continue;
-        if (c->blk_pop[(size_t)b] == 0) return false;
-        int64_t mn = c->blk_min[(size_t)b], mx = c->blk_max[(size_t)b], v = f.int_value;
-        if (f.op == SYBL_OP_GT && !(mn > v) && !(mx > v)) return false;
-        if (f.op == SYBL_OP_LT && !(mn < v) && !(mx < v)) return false;
-        if (f.op == SYBL_OP_EQ && (mn > v || mx < v)) return false;
-    }
-    return true;
-}
-
-// k_scan_packed works on stored offsets: rebases filter bounds, key digits, bucket numerators and
-// the time value onto each column's base.  False when a quantity does not fit the 32-bit domain.
-static bool fill_packed(Table *t, Query *q, const std::vector<int> &slot_col, FastPlan &FP, int nf, int ng, int na) {
-    const ScanPlan &P = q->plan;
-    if (getenv("SYBL_NO_PACKED")) return false;
-    if (P.n_cells >= (1 << 24)) return false;  // 24-bit multiplies build the cell index
-    for (int c = 0; c < nf; c++) {
-        const __int128 umax = ((__int128)1 << (8 * FP.fwid[c])) - 1;
-        const __int128 L = (__int128)FP.lo[c] - FP.fbase[c], H = (__int128)FP.hi[c] - FP.fbase[c];
-        if (H < 0 || L > umax || L > H) {
-            FP.plo[c] = 1;
-            FP.phi[c] = 0;
-        } else {
-            FP.plo[c] = (uint32_t)(L < 0 ? 0 : L);
-            FP.phi[c] = (uint32_t)(H > umax ? umax : H);
-        }
-    }
-    for (int c = 0; c < ng; c++) FP.gdoff[c] = (uint32_t)((uint64_t)FP.gbase[c] - (uint64_t)FP.gmin[c]);
-    for (int c = 0; c < na; c++) {
-        // Info.Min <= v <= Info.Max*10 (hist_basic.go:104) as a range of offsets; only looked at when the
-        // aggregation tracks its own count
-        const __int128 L = (__int128)FP.info_min[c] - FP.abase[c], H = (__int128)FP.max10[c] - FP.abase[c];
-        const __int128 umax = ((__int128)1 << 32) - 1;
-        if (H < 0 || L > umax || L > H) {
-            FP.alo[c] = 1;
-            FP.ahi[c] = 0;
-        } else {
-            FP.alo[c] = (uint32_t)(L < 0 ? 0 : L);
-            FP.ahi[c] = (uint32_t)(H > umax ? umax : H);
-        }
-    }
-    const double shave = 1.0 - 1.0 / (double)((int64_t)1 << 40);
-    for (int c = 0; c < na; c++) {
-        FP.adoff[c] = (uint32_t)((uint64_t)FP.abase[c] - (uint64_t)FP.hmin[c]);
-        FP.pinv_bucket[c] = FP.bucket_size[c] ? (1.0 / (double)FP.bucket_size[c]) * shave : 0.0;
-    }
-    if (q->time_mode) {
-        const SlotDesc &ts = P.slot[P.time_slot];
-        const Column *tc = t->cols[(size_t)slot_col[(size_t)P.time_slot]].get();
-        if (P.tb_big_div || P.time_bucket >= ((int64_t)1 << 32)) return false;
-        if (tc->n_pop > 0 && tc->exact_min < 0) return false;  // truncation == floor only for val >= 0
-        const __int128 t0 = (__int128)P.tb_min * P.time_bucket;
-        const __int128 off = (__int128)ts.vbase - t0;
-        // offsets are at most exact_max - vbase: the rebased time value stays below 2^32
-        const __int128 top = tc->n_pop > 0 ? (__int128)tc->exact_max - t0 : off;
-        if (off < 0 || top >= ((__int128)1 << 32)) return false;
-        FP.tdoff = (uint32_t)off;
-        FP.pinv_time = (1.0 / (double)P.time_bucket) * shave;
-    }
-    return true;
-}
-
-// Fills the column / filter / group / bucket part of a FastPlan when the query has the shape the
-// role-specialised kernels cover: <= 4 range-filter, <= 2 group, <= 2 aggregation columns, all
-// fully populated int64, one role per column, no rejects / outliers / minima to track.
-static bool fill_fast_columns(Table *t, Query *q, const std::vector<int> &slot_col, FastPlan &FP, int *pnf, int *png,
-                              int *pna, bool *any_max, bool *all_max, bool allow_gen, bool *gen, bool *packed = nullptr) {
-    const ScanPlan &P = q->plan;
-    memset(&FP, 0, sizeof(FP));
-    int nf = 0, ng = 0, na = 0;
-    *gen = false;
-    // compact storage: k_scan_packed when every column is a plain int column of <= 4 stored bytes,
-    // else the GEN kernels (any width); the plain kernels read canonical int64 only
-    bool any_packed = false, all_narrow = true;
-    bool heavy = false;  // GEN features k_scan_packed<NUL> leaves out: weights, outliers, h.Max
-    if (packed) *packed = false;
-    for (size_t s = 0; s < slot_col.size(); s++) {
-        const SlotDesc &sd = P.slot[s];
-        const Column *c = t->cols[(size_t)slot_col[s]].get();
-        bool plain = c->type == SYBL_INT_VAL && !c->d_valid && !c->has_missing;
-        any_packed = any_packed || c->packed();
-        all_narrow = all_narrow && c->elem <= 4;
-        if (!plain) {
-            // GEN kernels: int columns with missing rows in any role, str columns as group keys
-            if (!allow_gen) return false;
-            uint32_t r2 = sd.flags & (kSlotFilter | kSlotGroup | kSlotAgg | kSlotTime);
-            bool str_ok = c->type == SYBL_STR_VAL && (r2 == kSlotGroup || r2 == kSlotIdMask || r2 == (kSlotGroup | kSlotIdMask));
-            if (c->type != SYBL_INT_VAL && !str_ok) return false;
-            *gen = true;
-        }
-        uint32_t roles = sd.flags & (kSlotFilter | kSlotGroup | kSlotAgg);
-        if (sd.flags & (kSlotNeq | kSlotSet | kSlotDict)) return false;
-        if ((sd.flags & kSlotIdMask) && !allow_gen) return false;
-        if ((sd.flags & kSlotWeight) && (roles != 0 || (sd.flags & kSlotTime) || !allow_gen)) return false;
-        // a column may be filtered AND be a key / an aggregation input / the time column (it is then
-        // streamed once per role; the second read hits L1/L2), but not key and aggregation input at once
-        uint32_t fpart = roles & kSlotFilter, rest = roles & (kSlotGroup | kSlotAgg);
-        if (fpart != 0 && fpart != kSlotRange && fpart != kSlotIdMask) return false;
-        if (rest == (kSlotGroup | kSlotAgg)) return false;
-        if ((sd.flags & kSlotTime) && rest != 0) return false;
-    }
-    for (size_t s = 0; s < slot_col.size(); s++) {
-        const SlotDesc &sd = P.slot[s];
-        if (!(sd.flags & (kSlotRange | kSlotIdMask))) continue;
-        if (nf >= kFastMaxF) return false;
-        FP.fcol[nf] = (const int64_t *)sd.base;
-        FP.fwid[nf] = sd.width;
-        FP.fbase[nf] = sd.vbase;
-        FP.fvalid[nf] = sd.valid;
-        FP.lo[nf] = sd.lo;
-        FP.hi[nf] = sd.hi;
-        if (sd.flags & kSlotIdMask) {
-            FP.fmask[nf] = sd.idmask;
-            FP.fmask_bits[nf] = sd.idmask_bits;
-            *gen = true;
-        }
-        nf++;
-    }
-    for (auto &gi : q->groups) {
-        if (ng >= kFastMaxG) return false;
-        int s = -1;
-        for (size_t k = 0; k < slot_col.size(); k++)
-            if (slot_col[k] == gi.col) s = (int)k;
-        const SlotDesc &sd = P.slot[s];
-        if (sd.gmissing >= 0 && !allow_gen) return false;
-        FP.gvalid[ng] = sd.valid;
-        FP.gwid[ng] = sd.width;
-        FP.gbase[ng] = sd.vbase;
-        FP.gmissing[ng] = sd.gmissing;
-        FP.gvalues[ng] = sd.gvalues;
-        FP.gcol[ng] = (const int64_t *)sd.base;
-        FP.gmin[ng] = sd.gmin;
-        FP.gcard[ng] = (uint32_t)sd.gcard;
-        FP.gstride[ng] = sd.gstride;
-        ng++;
-    }
-    *any_max = false;
-    *all_max = true;
-    for (auto &ai : q->aggs) {
-        if (na >= kFastMaxA) return false;
-        const AggDesc &A = ai.d;
-        if (A.m_nmin >= 0) return false;
-        if ((A.f_smp >= 0 || A.f_out >= 0) && !allow_gen) return false;
-        if (A.f_out >= 0 || (q->op == SYBL_AGG_HIST && A.m_max >= 0)) {
-            *gen = true;  // outliers / h.Max live in the GEN body
-            heavy = true;
-        }
-        if (A.f_smp >= 0) heavy = true;
-        if (A.f_cnt >= 0 || A.f_pop >= 0) {
-            if (!allow_gen) return false;
-            *gen = true;  // rejects / missing values: per-aggregation counts
-        }
-        if (q->op == SYBL_AGG_HIST) {
-            if (A.big_div || A.bucket_size >= ((int64_t)1 << 32)) return false;
-            const Column *c = t->cols[(size_t)ai.col].get();
-            int64_t hi = c->bounds_set ? c->bound_hi : c->exact_max;
-            if (c->n_pop > 0 || c->bounds_set)
-                if ((unsigned __int128)((__int128)hi - (__int128)A.hmin) >= ((unsigned __int128)1 << 32)) return false;
-        }
-        *any_max = *any_max || A.m_max >= 0;
-        *all_max = *all_max && A.m_max >= 0;
-        int s = -1;
-        for (size_t k = 0; k < slot_col.size(); k++)
-            if (slot_col[k] == ai.col) s = (int)k;
-        FP.acol[na] = (const int64_t *)P.slot[s].base;
-        FP.awid[na] = P.slot[s].width;
-        FP.abase[na] = P.slot[s].vbase;
-        FP.avalid[na] = P.slot[s].valid;
-        FP.f_cnt[na] = A.f_cnt;
-        FP.f_pop[na] = A.f_pop;
-        FP.f_smp[na] = A.f_smp;
-        FP.f_out[na] = A.f_out;
-        FP.info_min[na] = A.info_min;
-        FP.max10[na] = A.max10;
-        FP.hmin[na] = A.hmin;
-        FP.inv_bucket[na] = A.inv_bucket;
-        FP.bucket_size[na] = (uint32_t)A.bucket_size;
-        FP.n_values[na] = A.n_values;
-        FP.f_sum[na] = A.f_sum;
-        FP.f_sb[na] = A.f_sb;
-        FP.f_sb2[na] = A.f_sb2;
-        FP.m_max[na] = A.m_max;
-        FP.hist_agg_off[na] = P.hist_agg_off[na];
-        na++;
-    }
-    FP.f_samples = P.f_samples;
-    if (q->weighted) {
-        if (!allow_gen) return false;
-        FP.wcol = (const int64_t *)P.slot[P.weight_slot].base;
-        FP.wwid = P.slot[P.weight_slot].width;
-        FP.wbase = P.slot[P.weight_slot].vbase;
-        *gen = true;
-        heavy = true;
-    }
-    FP.hist_off = P.hist_off;
-    FP.hist_stride = P.hist_stride;
-    FP.n_cells = P.n_cells;
-    FP.n_sum_fields = P.n_sum_fields;
-    FP.n_max_fields = P.n_max_fields;
-    FP.rep_shift = P.rep_shift;
-    FP.windowed = P.windowed;
-    FP.lds_cells = P.lds_cells;
-    FP.wg_cell_base = P.wg_cell_base;
-    *pnf = nf;
-    *png = ng;
-    *pna = na;
-    if (any_packed) {
-        if ((!*gen || (allow_gen && !heavy)) && all_narrow && packed && fill_packed(t, q, slot_col, FP, nf, ng, na)) {
-            *packed = true;
-            FP.nul = *gen ? 1 : 0;  // missing rows / str ids / reject gate: k_scan_packed<NUL>
-        } else if (allow_gen) {
-            *gen = true;
-        } else {
-            return false;
-        }
-    }
-    return true;
-}
-
-// Role-specialised kernels (scan_fast.h) cover the common shape; everything else runs k_scan.
-static void select_fast_path(Table *t, Query *q, const std::vector<int> &slot_col) {
-    q->fast = false;
-    const ScanPlan &P = q->plan;
-    if (getenv("SYBL_NO_FAST")) return;
-    if (!q->use_lds) return;
-    if (q->time_mode && P.tb_big_div) return;
-    FastPlan &FP = q->fplan;
-    int nf, ng, na;
-    bool any_max, all_max, gen, packed = false;
-    q->fast_packed = false;
-    if (!fill_fast_columns(t, q, slot_col, FP, &nf, &ng, &na, &any_max, &all_max, !getenv("SYBL_NO_FASTGEN"), &gen, &packed)) return;
-    if (q->op == SYBL_AGG_HIST && any_max && !gen) return;
-    if (q->weighted && q->op == SYBL_AGG_HIST && q->want_percentiles) return;  // weighted bucket increments: generic kernel
-    q->fast_gen = gen;
-    if (nf + ng + na == 0 && !q->time_mode) return;  // nothing to stream: the generic kernel picks a driver column
-    if (q->time_mode) {
-        FP.tcol = (const int64_t *)P.slot[P.time_slot].base;
-        FP.tvalid = P.slot[P.time_slot].valid;
-        FP.twid = P.slot[P.time_slot].width;
-        FP.tbase = P.slot[P.time_slot].vbase;
-        FP.time_bucket = P.time_bucket;
-        FP.inv_time_bucket = P.inv_time_bucket;
-        FP.tb_min = P.tb_min;
-        FP.n_tb = P.n_tb;
-        FP.tb_stride = P.tb_stride;
-    }
-    int mode;
-    if (q->op == SYBL_AGG_HIST) {
-        mode = q->want_percentiles ? kFastHist : kFastMoments;
-    } else {
-        if (any_max && !all_max) return;
-        mode = any_max ? kFastAvgMax : kFastAvg;
-    }
-    FP.hist_lds = 0;
-    if (mode == kFastHist && !P.windowed && !getenv("SYBL_NO_LDSHIST")) {
-        // few cells: the bucket arrays themselves fit in LDS as uint32 next to the cell table
-        // (a workgroup scans far fewer than 2^32 rows); shrink the lane replication to make room
-        int64_t hist_bytes = (int64_t)P.n_cells * P.hist_stride * 4;
-        int64_t field_bytes = (int64_t)(P.n_sum_fields + P.n_max_fields) * P.n_cells * 8;
-        if (hist_bytes + field_bytes <= kLdsBudgetBytes) {
-            int rs = 0;
-            while (rs < 6 && hist_bytes + (field_bytes << (rs + 1)) <= kLdsBudgetBytes) rs++;
-            q->plan.rep_shift = rs;
-            FP.rep_shift = rs;
-            q->lds_bytes = (size_t)((field_bytes << rs) + hist_bytes + 16);
-            FP.hist_lds = 1;
-        }
-    }
-    q->fast = true;
-    q->fast_packed = packed;
-    q->fast_nf = nf;
-    q->fast_ng = ng;
-    q->fast_na = na;
-    q->fast_mode = mode;
-}
-
-// Partitioned histograms (strategy 5, scan_fast.h): full-histogram queries whose (cell, agg)
-// pairs fit kMaxParts partitions of kPartCells pairs.
-static int select_part_hist(Table *t, Query *q, const std::vector<int> &slot_col, int64_t rows_scanned) {
-    q->part_hist = false;
-    const ScanPlan &P = q->plan;
-    if (getenv("SYBL_NO_PARTHIST")) return SYBL_OK;
-    if (q->op != SYBL_AGG_HIST || !q->want_percentiles || q->time_mode || q->weighted || q->aggs.empty()) return SYBL_OK;
-    if (q->fast && q->fplan.hist_lds) return SYBL_OK;  // the bucket arrays already live in LDS
-    EmitPlan &E = q->eplan;
-    int nf, ng, na;
-    bool any_max, all_max, gen, packed = false;
-    if (!fill_fast_columns(t, q, slot_col, E.fp, &nf, &ng, &na, &any_max, &all_max, false, &gen, &packed)) return SYBL_OK;
-    q->part_packed = packed;
-    const int tile_rows = packed ? kPackedTileRows : kTileRows;
-    int rb = 0;
-    for (auto &ai : q->aggs) {
-        if (ai.d.n_values > (1 << kBucketBits)) return SYBL_OK;
-        int bits = 0;
-        while (((int64_t)1 << bits) < ai.d.bucket_size) bits++;
-        rb = std::max(rb, bits);
-    }
-    if (kPartCellBits + kBucketBits + rb > 32) return SYBL_OK;
-    int64_t pairs = (int64_t)P.n_cells * na;
-    int64_t n_parts = (pairs + kPartCells - 1) / kPartCells;
-    if (n_parts > kMaxParts) return SYBL_OK;
-    // capacity: 1.5x the mean share of the worst case (every scanned row matches) + slack; a
-    // partition that still overflows makes finalize fall back to the atomic strategy
-    int64_t cap = rows_scanned * na / n_parts;
-    cap = (cap + cap / 2 + 8192 + 3) & ~(int64_t)3;  // (a multiple of 4: k_part_hist reads 16-byte aligned record quads)
-    if (cap >= ((int64_t)1 << 32)) return SYBL_OK;
-    size_t bytes = (size_t)n_parts * (size_t)cap * 4, free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || bytes + ((size_t)1 << 30) > free_b) return SYBL_OK;
-    SYBL_HIP(hipMalloc((void **)&q->d_recs, bytes));
-    SYBL_HIP(hipMalloc((void **)&q->d_cursor, (size_t)n_parts * kCursorStride * 4));
-    E.recs = q->d_recs;
-    E.cursor = q->d_cursor;
-    E.part_cap = cap;
-    E.n_parts = (int32_t)n_parts;
-    E.n_aggs = na;
-    {
-            // A handful of sub-bins per partition relieves same-address serialisation of the LDS
-        // counters when there are very few partitions; runs stay long (few cursor atomics).
-        int ss = 0;
-        while ((n_parts << ss) < 8) ss++;
-        int64_t bins = n_parts << ss;
-        E.sub_shift = ss;
-        E.slots = (int32_t)std::min<int64_t>(8191, std::max<int64_t>(15, (kEmitLdsWords - bins) / bins));
-        // records per bin per tile if every row matched
-        double per_tile = (double)tile_rows * na / (double)bins;
-        // (measured on config 4: 8.9 ms at 2 tiles between flushes, 9.5 at 1, 9.3 at 4)
-        int64_t period = (int64_t)((double)E.slots / ((packed ? 3.5 : 4.0) * std::max(per_tile, 0.25)));
-        if (const char *e = getenv("SYBL_EMIT_FLUSH_PERIOD")) period = atoi(e);
-        E.flush_period = (int32_t)std::min<int64_t>(8, std::max<int64_t>(1, period));
-    }
-    PartHistPlan &H = q->pplan;
-    memset(&H, 0, sizeof(H));
-    H.recs = q->d_recs;
-    H.cursor = q->d_cursor;
-    H.part_cap = cap;
-    H.n_parts = (int32_t)n_parts;
-    H.n_aggs = na;
-    H.n_cells = P.n_cells;
-    H.hist_off = P.hist_off;
-    H.hist_stride = P.hist_stride;
-    int nv_max = 0;
-    for (int a = 0; a < na; a++) {
-        const AggDesc &A = q->aggs[(size_t)a].d;
-        E.rem_bits[a] = rb;
-        H.rem_bits[a] = rb;
-        H.n_values[a] = A.n_values;
-        H.f_sum[a] = A.f_sum;
-        H.m_max[a] = A.m_max;
-        H.hmin[a] = A.hmin;
-        H.bucket_size[a] = A.bucket_size;
-        H.hist_agg_off[a] = P.hist_agg_off[a];
-        nv_max = std::max(nv_max, A.n_values);
-    }
-    H.nv_max = nv_max;
-    // few partitions: several workgroups share one so the whole chip is busy
-    H.split = (int32_t)std::max<int64_t>(1, (int64_t)q->n_wg / n_parts);
-    q->part_nf = nf;
-    q->part_ng = ng;
-    q->part_na = na;
-    q->part_hist = true;
-    return SYBL_OK;
-}
-
-// The planner: sybl_query_desc + table statistics -> ScanPlan (+ FastPlan / EmitPlan), work list and
-// device buffers.  One method per step, in the order the reference builds a query
-// (cmd_query.go:204-333: filters, groupings, aggregations, time / weight options).
-struct Planner {
-    Table *t;
-    const sybl_query_desc *d;
-    Query *q;
-    Ctx *ctx;
-    ScanPlan &P;
-    std::vector<int> slot_col;          // table column index per slot
-    std::vector<HostFilterFold> folds;  // per slot
-    int64_t cells = 1;                  // group cells (product of key digits)
-    int64_t n_cells = 1;                // cells x time buckets
-    int F = 1, M = 0;                   // SUM / MAX fields per cell
-    int64_t hist_stride = 0;            // bucket-array words per cell
-    int64_t rows_scanned = 0, skipped = 0;
-
-    Planner(Table *t_, const sybl_query_desc *d_, Query *q_) : t(t_), d(d_), q(q_), ctx(t_->ctx), P(q_->plan) {}
-
-    // one slot per distinct referenced column
-    int slot_of(const char *name, int *out) {
-        Column *c = t->find(name);
-        if (!c) return fail(SYBL_E_INVAL, "unknown column '%s'", name ? name : "(null)");
-        int ci = t->col_ix[name];
-        for (size_t s = 0; s < slot_col.size(); s++)
-            if (slot_col[s] == ci) {
-                *out = (int)s;
-                return SYBL_OK;
-            }
-        if ((int)slot_col.size() >= kMaxSlots) return fail(SYBL_E_INVAL, "query references more than %d columns", kMaxSlots);
-        slot_col.push_back(ci);
-        folds.emplace_back();
-        *out = (int)slot_col.size() - 1;
-        return SYBL_OK;
-    }
-
-    int setup() {
-        int rc;
-        if (d->n_groups > SYBL_MAX_GROUPS) return fail(SYBL_E_INVAL, "too many group columns (%d > %d)", d->n_groups, SYBL_MAX_GROUPS);
-        if (d->n_aggs > SYBL_MAX_AGGS) return fail(SYBL_E_INVAL, "too many aggregations (%d > %d)", d->n_aggs, SYBL_MAX_AGGS);
-        if (d->n_filters > SYBL_MAX_FILTERS) return fail(SYBL_E_INVAL, "too many filters");
-        if (d->op != SYBL_AGG_AVG && d->op != SYBL_AGG_HIST) return fail(SYBL_E_INVAL, "unknown op %d", d->op);
-        rc = table_ensure_stats(t);
-        if (rc) return rc;
-
-        q->op = d->op;
-        q->hist_bucket = d->hist_bucket;
-        q->want_percentiles = d->op == SYBL_AGG_HIST && d->want_percentiles;
-        q->order_by = d->order_by ? d->order_by : "";
-        q->order_asc = d->order_asc != 0;
-        q->limit = d->limit;
-        q->time_mode = d->time_bucket > 0 && d->time_col && d->time_col[0];
-        q->time_bucket = q->time_mode ? d->time_bucket : 0;
-        q->weighted = d->weight_col && d->weight_col[0];
-
-        memset(&P, 0, sizeof(P));
-        P.time_slot = -1;
-        P.weight_slot = -1;
-        P.f_samples = -1;
-        P.hist_mode = d->op == SYBL_AGG_HIST;
-        P.weighted = q->weighted;
-
-        return SYBL_OK;
-    }
-
-    int filters() {
-        int rc;
-        // ---- filters (filter.go:171-285), folded per column
-        for (int i = 0; i < d->n_filters; i++) {
-            const sybl_filter &f = d->filters[i];
-            int s;
-            if ((rc = slot_of(f.col, &s))) return rc;
-            Column *c = t->cols[(size_t)slot_col[(size_t)s]].get();
-            HostFilterFold &ff = folds[(size_t)s];
-            if (c->type == SYBL_INT_VAL) {
-                int64_t v = f.int_value;
-                switch (f.op) {
-                case SYBL_OP_GT:  // field > v
-                    ff.has_range = true;
-                    if (v == INT64_MAX) q->never_matches = true; else ff.lo = std::max(ff.lo, v + 1);
-                    break;
-                case SYBL_OP_LT:
-                    ff.has_range = true;
-                    if (v == INT64_MIN) q->never_matches = true; else ff.hi = std::min(ff.hi, v - 1);
-                    break;
-                case SYBL_OP_EQ:
-                    ff.has_range = true;
-                    ff.lo = std::max(ff.lo, v);
-                    ff.hi = std::min(ff.hi, v);
-                    break;
-                case SYBL_OP_NEQ:
-                    if ((int)ff.neq.size() >= kMaxNeq) return fail(SYBL_E_INVAL, "more than %d neq filters on '%s'", kMaxNeq, f.col);
-                    ff.neq.push_back(v);
-                    break;
-                default:
-                    // IntFilter.Filter's default branch returns false for every row (filter.go:189-193)
-                    q->never_matches = true;
-                    ff.has_range = true;
-                }
-            } else if (c->type == SYBL_STR_VAL) {
-                // eq/neq compare dictionary ids, re/nre go through a per-id match table
-                // (the reference's RCache, filter.go:213-236); all become one bit per id.
-                size_t n = c->dict.size();
-                std::vector<uint8_t> m(n, 0);
-                if (f.op == SYBL_OP_EQ || f.op == SYBL_OP_NEQ) {
-                    auto it = c->dict_ix.find(f.str_value ? f.str_value : "");
-                    for (size_t k = 0; k < n; k++) m[k] = f.op == SYBL_OP_NEQ;
-                    if (it != c->dict_ix.end()) m[(size_t)it->second] = f.op == SYBL_OP_EQ;
-                } else if (f.op == SYBL_OP_RE || f.op == SYBL_OP_NRE) {
-                    if (f.id_match) {
-                        for (size_t k = 0; k < n; k++) {
-                            bool hit = (int64_t)k < f.id_match_len && f.id_match[k];
-                            m[k] = f.op == SYBL_OP_NRE ? !hit : hit;
-                        }
-                    } else {
-                        try {
-                            std::regex re(f.str_value ? f.str_value : "", std::regex::ECMAScript);
-                            for (size_t k = 0; k < n; k++) {
-                                bool hit = std::regex_search(c->dict[k], re);
-                                m[k] = f.op == SYBL_OP_NRE ? !hit : hit;
-                            }
-                        } catch (const std::regex_error &e) {
-                            return fail(SYBL_E_INVAL, "bad regex '%s': %s", f.str_value ? f.str_value : "", e.what());
-                        }
-                    }
-                } else {
-                    q->never_matches = true;  // StrFilter default branch: ret stays false
-                }
-                if (!ff.has_mask) {
-                    ff.mask = m;
-                    ff.has_mask = true;
-                } else {
-                    for (size_t k = 0; k < n; k++) ff.mask[k] = ff.mask[k] && m[k];
-                }
-            } else {
-                // SetFilter.Filter, filter.go:252-285; get_val_id of an unseen string yields an id no
-                // member can have (table_column.go:27-48)
-                if (f.op != SYBL_OP_IN && f.op != SYBL_OP_NIN) {
-                    q->never_matches = true;  // default branch: ret stays false
-                    ff.setp.emplace_back(-1, 1);
-                    continue;
-                }
-                if ((int)ff.setp.size() >= kMaxNeq) return fail(SYBL_E_INVAL, "more than %d set filters on '%s'", kMaxNeq, f.col);
-                auto it = c->dict_ix.find(f.str_value ? f.str_value : "");
-                ff.setp.emplace_back(it == c->dict_ix.end() ? -1 : it->second, f.op == SYBL_OP_IN ? 1 : 0);
-            }
-        }
-        return SYBL_OK;
-    }
-
-    int groups() {
-        int rc;
-        // ---- group columns (aggregate.go:125-143); direct-mapped on declared or exact bounds
-        cells = 1;
-        for (int g = 0; g < d->n_groups; g++) {
-            int s;
-            if ((rc = slot_of(d->groups[g], &s))) return rc;
-            Column *c = t->cols[(size_t)slot_col[(size_t)s]].get();
-            if (c->type == SYBL_SET_VAL) return fail(SYBL_E_INVAL, "cannot group by set column '%s' (cmd_query.go:254)", c->name.c_str());
-            if (P.slot[s].flags & kSlotGroup) return fail(SYBL_E_INVAL, "column '%s' grouped twice", c->name.c_str());
-            GroupInfo gi;
-            gi.col = slot_col[(size_t)s];
-            gi.type = c->type;
-            gi.has_missing = c->has_missing;
-            int64_t lo, hi;
-            if (c->bounds_set) {
-                lo = c->bound_lo;
-                hi = c->bound_hi;
-            } else if (c->type == SYBL_STR_VAL) {
-                lo = 0;
-                hi = (int64_t)c->dict.size() - 1;
-            } else {
-                lo = c->exact_min;
-                hi = c->exact_max;
-            }
-            if (c->n_pop == 0 && !c->bounds_set) {
-                lo = 0;
-                hi = -1;
-            }
-            unsigned __int128 card = hi >= lo ? (unsigned __int128)((__int128)hi - (__int128)lo) + 1 : 0;
-            // A missing key is written as MISSING_VALUE = 0xFFFFFFFFFFFFFFFF (aggregate.go:31,138), which
-            // is also the 8-byte image of the int value -1: the reference folds both into ONE group.
-            // When -1 is inside the key range the missing rows share its cell; otherwise they get an
-            // extra digit of their own.
-            gi.missing_digit = -1;
-            gi.dict = false;
-            // sparse / wide key range: one digit per DISTINCT value instead of one per value of the range
-            if (c->type == SYBL_INT_VAL && !getenv("SYBL_NO_GDICT") &&
-                (c->gdict_blocks == -2 || card > ((unsigned __int128)1 << 22) || card * (unsigned __int128)cells > ((unsigned __int128)1 << 27))) {
-                if ((rc = column_build_gdict(t, c))) return rc;
-                gi.dict = true;
-                card = c->gdict.size();
-            }
-            gi.value_card = (int32_t)card;
-            if (gi.has_missing) {
-                int64_t minus1 = -1;
-                if (gi.dict) {
-                    auto it = std::lower_bound(c->gdict.begin(), c->gdict.end(), (int64_t)-1);
-                    minus1 = it != c->gdict.end() && *it == -1 ? (int64_t)(it - c->gdict.begin()) : -1;
-                } else if (c->type == SYBL_INT_VAL && hi >= lo && lo <= -1 && hi >= -1) {
-                    minus1 = -1 - lo;
-                }
-                if (minus1 >= 0) {
-                    gi.missing_digit = (int32_t)minus1;
-                } else {
-                    gi.missing_digit = (int32_t)card;
-                    card += 1;
-                }
-            }
-            if (card == 0) card = 1;
-            if (card * (unsigned __int128)cells > ((unsigned __int128)1 << 27))
-                return fail(SYBL_E_INVAL,
-                            "group-by on '%s' needs more than 2^27 direct-mapped cells (value range [%lld,%lld]); "
-                            "hash group-by is not available in this build",
-                            c->name.c_str(), (long long)lo, (long long)hi);
-            gi.gmin = lo;
-            gi.gcard = (int32_t)card;
-            q->groups.push_back(gi);
-            cells *= (int64_t)card;
-        }
-        // strides: first group column is the most significant digit (keeps canonical key order
-        // equal to cell order)
-        {
-            int64_t stride = cells;
-            for (size_t g = 0; g < q->groups.size(); g++) {
-                stride /= q->groups[g].gcard;
-                int s = -1;
-                for (size_t k = 0; k < slot_col.size(); k++)
-                    if (slot_col[k] == q->groups[g].col) s = (int)k;
-                SlotDesc &sd = P.slot[s];
-                sd.flags |= kSlotGroup;
-                sd.gmin = q->groups[g].gmin;
-                sd.gcard = q->groups[g].gcard;
-                sd.gstride = (int32_t)stride;
-                sd.gmissing = q->groups[g].missing_digit >= 0 ? (int32_t)(q->groups[g].missing_digit * stride) : -1;
-                sd.gvalues = q->groups[g].value_card;
-                if (q->groups[g].dict) {
-                    const Column *gc = t->cols[(size_t)q->groups[g].col].get();
-                    sd.flags |= kSlotDict;
-                    sd.dkeys = gc->d_gdict_keys;
-                    sd.dranks = gc->d_gdict_ranks;
-                    sd.dmask = gc->gdict_mask;
-                }
-            }
-        }
-        q->group_cells = cells;
-        return SYBL_OK;
-    }
-
-    int time_series() {
-        int rc;
-        // ---- time series (aggregate.go:146-183)
-        P.n_tb = 1;
-        P.tb_stride = (int32_t)cells;
-        if (q->time_mode) {
-            int s;
-            if ((rc = slot_of(d->time_col, &s))) return rc;
-            Column *c = t->cols[(size_t)slot_col[(size_t)s]].get();
-            if (c->type != SYBL_INT_VAL) return fail(SYBL_E_INVAL, "time column '%s' is not an int column", c->name.c_str());
-            P.slot[s].flags |= kSlotTime;
-            P.time_slot = s;
-            P.time_bucket = d->time_bucket;
-            P.inv_time_bucket = 1.0 / (double)d->time_bucket;
-            int64_t lo = c->bounds_set ? c->bound_lo : c->exact_min, hi = c->bounds_set ? c->bound_hi : c->exact_max;
-            if (c->n_pop == 0 && !c->bounds_set) lo = hi = 0;
-            int64_t tlo = lo / d->time_bucket, thi = hi / d->time_bucket;  // truncating, like aggregate.go:174
-            P.tb_min = tlo;
-            int64_t ntb = thi - tlo + 1;
-            if (ntb * cells > ((int64_t)1 << 27)) return fail(SYBL_E_INVAL, "time buckets x groups exceeds 2^27 cells");
-            P.n_tb = (int32_t)ntb;
-            uint64_t amax = (uint64_t)std::max(llabs((long long)lo), llabs((long long)hi));
-            P.tb_big_div = amax >= ((uint64_t)1 << 51);
-        }
-        n_cells = cells * P.n_tb;
-        P.n_cells = (int32_t)n_cells;
-        return SYBL_OK;
-    }
-
-    int weight() {
-        int rc;
-        // ---- weight column (aggregate.go:100-102)
-        if (q->weighted) {
-            int s;
-            if ((rc = slot_of(d->weight_col, &s))) return rc;
-            Column *c = t->cols[(size_t)slot_col[(size_t)s]].get();
-            if (c->type != SYBL_INT_VAL) return fail(SYBL_E_INVAL, "weight column '%s' is not an int column", c->name.c_str());
-            if (c->has_missing)
-                return fail(SYBL_E_INVAL, "weight column '%s' has missing rows (the reference's carry-over of the previous "
-                            "row's weight, aggregate.go:68, is not reproduced)", c->name.c_str());
-            P.slot[s].flags |= kSlotWeight;
-            P.weight_slot = s;
-        }
-        return SYBL_OK;
-    }
-
-    int aggregations() {
-        int rc;
-        // ---- aggregations (aggregate.go:246-261, hist_basic.go:72-151)
-        F = 1;  // field 0: Result.Count
-        if (q->weighted) P.f_samples = F++;
-        M = 0;
-        hist_stride = 0;
-        for (int a = 0; a < d->n_aggs; a++) {
-            int s;
-            if ((rc = slot_of(d->aggs[a], &s))) return rc;
-            Column *c = t->cols[(size_t)slot_col[(size_t)s]].get();
-            if (c->type != SYBL_INT_VAL) {
-                // the reference silently ignores non-int aggregation columns (aggregate.go:247-248)
-                return fail(SYBL_E_INVAL, "aggregation column '%s' is not an int column", c->name.c_str());
-            }
-            if (P.slot[s].flags & kSlotAgg) return fail(SYBL_E_INVAL, "column '%s' aggregated twice", c->name.c_str());
-            AggInfo ai;
-            ai.col = slot_col[(size_t)s];
-            ai.name = c->name;
-            memset(&ai.d, 0, sizeof(ai.d));
-            AggDesc &A = ai.d;
-            int64_t lo = c->bounds_set ? c->bound_lo : c->exact_min, hi = c->bounds_set ? c->bound_hi : c->exact_max;
-            bool empty = c->n_pop == 0 && !c->bounds_set;
-            int64_t imin = c->info_given ? c->info_min : (empty ? 0 : lo);
-            int64_t imax = c->info_given ? c->info_max : (empty ? 0 : hi);
-            A.info_min = imin;
-            A.max10 = (int64_t)((uint64_t)imax * 10u);  // Go's wrapping int64 multiply (hist_basic.go:104)
-            A.f_sum = F++;
-            bool can_reject = c->has_missing || (!empty && (lo < A.info_min || hi > A.max10));
-            A.f_cnt = (q->weighted || can_reject) ? F++ : -1;
-            A.f_smp = q->weighted ? F++ : -1;
-            A.f_pop = c->has_missing ? F++ : -1;
-            A.f_sb = A.f_sb2 = A.f_out = -1;
-            // BasicHist.Min/Max start at Info.Min/Info.Max in hist mode and at 0 in avg mode
-            // (hist_basic.go:34-40,72-85) and accepted values are >= Info.Min, so the running
-            // extrema only need tracking when the column bounds let a value beat the start value.
-            {
-                bool need_max = d->op == SYBL_AGG_HIST ? (empty ? false : hi > imax) : (empty ? false : hi > 0);
-                bool need_min = d->op == SYBL_AGG_HIST ? false : (empty ? false : lo < 0);
-                if (c->bounds_set == false && empty) need_max = need_min = false;
-                A.m_max = need_max ? M++ : -1;
-                A.m_nmin = need_min ? M++ : -1;
-            }
-            ai.f_out = -1;
-            ai.num_buckets = 0;
-            ai.info_max = imax;
-            if (d->op == SYBL_AGG_HIST) {
-                if (imax < imin) return fail(SYBL_E_INVAL, "IntInfo of '%s' has max < min", c->name.c_str());
-                int64_t bs, nb, nv;
-                setup_buckets(imin, imax, d->hist_bucket, &bs, &nb, &nv);
-                if (bs <= 0 || nv <= 0 || nv > (1 << 20)) return fail(SYBL_E_INVAL, "bad bucket geometry for '%s'", c->name.c_str());
-                A.hmin = imin;
-                A.bucket_size = bs;
-                A.inv_bucket = 1.0 / (double)bs;
-                A.n_values = (int32_t)nv;
-                ai.num_buckets = nb;
-                // accepted values lie in [max(lo,imin), min(hi,max10)]
-                int64_t vhi = empty ? imin : std::min(hi, A.max10), vlo = empty ? imin : std::max(lo, imin);
-                unsigned __int128 span = vhi >= A.hmin ? (unsigned __int128)((__int128)vhi - (__int128)A.hmin) : 0;
-                A.big_div = span >= ((unsigned __int128)1 << 51);
-                bool can_outlie = span / (unsigned __int128)bs >= (unsigned __int128)nv || vlo < A.hmin;
-                if (can_outlie) {
-                    A.f_out = F;
-                    ai.f_out = F;
-                    F += 6;
-                }
-                if (q->want_percentiles) {
-                    A.hist_full = 1;
-                    P.hist_agg_off[a] = hist_stride;
-                    hist_stride += nv;
-                } else {
-                    A.f_sb = F++;
-                    A.f_sb2 = F++;
-                }
-            }
-            P.slot[s].flags |= kSlotAgg;
-            P.slot[s].agg_index = a;
-            P.agg[a] = A;
-            q->aggs.push_back(ai);
-        }
-        P.n_aggs = d->n_aggs;
-        P.n_sum_fields = F;
-        P.n_max_fields = M;
-        P.hist_stride = hist_stride;
-        P.hist_off = kHeaderWords + (int64_t)F * n_cells;
-        if ((unsigned __int128)n_cells * (unsigned __int128)hist_stride > ((unsigned __int128)1 << 31))
-            return fail(SYBL_E_INVAL, "groups x buckets = %lld x %lld words does not fit the 16 GiB histogram budget",
-                        (long long)n_cells, (long long)hist_stride);
-        return SYBL_OK;
-    }
-
-    int finish_slots() {
-        int rc;
-        // ---- finish slots
-        if (slot_col.empty()) {
-            // count(*) with no referenced column still needs the row count: stream any column
-            if (t->cols.empty()) return fail(SYBL_E_INVAL, "table has no columns");
-            int pick = -1;
-            for (size_t k = 0; k < t->cols.size(); k++)
-                if (t->cols[k]->type != SYBL_SET_VAL) { pick = (int)k; break; }
-            if (pick < 0) return fail(SYBL_E_INVAL, "table has no int/str column to drive the scan");
-            slot_col.push_back(pick);
-            folds.emplace_back();
-        }
-        P.n_slots = (int)slot_col.size();
-        for (int s = 0; s < P.n_slots; s++) {
-            Column *c = t->cols[(size_t)slot_col[(size_t)s]].get();
-            SlotDesc &sd = P.slot[s];
-            sd.base = c->d_data;
-            sd.valid = c->d_valid;
-            sd.width = c->elem;
-            sd.vbase = c->vbase;
-            if (c->type == SYBL_SET_VAL) {
-                if ((rc = column_upload_set(t, c))) return rc;
-                sd.flags |= kSlotSet;
-                sd.base = c->d_set_off;
-                sd.set_vals = c->d_set_vals;
-                sd.n_setp = (int)folds[(size_t)s].setp.size();
-                for (int k = 0; k < sd.n_setp; k++) {
-                    sd.set_id[k] = folds[(size_t)s].setp[(size_t)k].first;
-                    sd.set_in[k] = folds[(size_t)s].setp[(size_t)k].second;
-                }
-            }
-            HostFilterFold &ff = folds[(size_t)s];
-            if (ff.has_range) {
-                sd.flags |= kSlotRange;
-                sd.lo = ff.lo;
-                sd.hi = ff.hi;
-            }
-            if (!ff.neq.empty()) {
-                sd.flags |= kSlotNeq;
-                sd.n_neq = (int)ff.neq.size();
-                for (size_t k = 0; k < ff.neq.size(); k++) sd.neq[k] = ff.neq[k];
-            }
-            if (ff.has_mask) {
-                sd.flags |= kSlotIdMask;
-                size_t nbits = ff.mask.size(), nw = (nbits + 31) / 32 + 1;
-                std::vector<uint32_t> bits(nw, 0);
-                for (size_t k = 0; k < nbits; k++)
-                    if (ff.mask[k]) bits[k >> 5] |= 1u << (k & 31);
-                uint32_t *dm = nullptr;
-                SYBL_HIP(hipMalloc((void **)&dm, nw * 4));
-                q->d_idmasks.push_back(dm);
-                SYBL_HIP(hipMemcpy(dm, bits.data(), nw * 4, hipMemcpyHostToDevice));
-                sd.idmask = dm;
-                sd.idmask_bits = (int32_t)nbits;
-            }
-        }
-        return SYBL_OK;
-    }
-
-    int strategy() {
-        // ---- strategy: cell table in LDS when it fits (DESIGN.md "Strategies")
-        q->n_wg = ctx->n_cus > 0 ? ctx->n_cus : 256;
-        if (const char *e = getenv("SYBL_WG_PER_CU")) q->n_wg *= std::max(1, atoi(e));
-        int64_t lds_words = (int64_t)(F + M) * n_cells;
-        q->use_lds = lds_words * 8 <= kLdsBudgetBytes;
-        P.rep_shift = 0;
-        if (q->use_lds) {
-            int rs = 0;
-            while (rs < 6 && (lds_words * 8 << (rs + 1)) <= kLdsBudgetBytes) rs++;
-            P.rep_shift = rs;
-            q->lds_bytes = (size_t)(lds_words * 8) << rs;
-        }
-        q->n_sum_words = kHeaderWords + (int64_t)F * n_cells + n_cells * hist_stride;
-        q->n_max_words = std::max<int64_t>((int64_t)M * n_cells, 1);
-        return SYBL_OK;
-    }
-
-    int work() {
-        // ---- work: non-skipped blocks -> runs of physical rows -> an equal share of tiles per workgroup
-        std::vector<Segment> runs;
-        rows_scanned = 0;
-        skipped = 0;
-        for (size_t b = 0; b < t->blocks.size(); b++) {
-            if (t->blocks[b].n == 0) continue;
-            if (d->block_skip && !should_scan_block(t, d, (int64_t)b)) {
-                skipped++;
-                continue;
-            }
-            rows_scanned += t->blocks[b].n;
-            const Segment &blk = t->blocks[b];
-            if (!runs.empty() && runs.back().start + runs.back().n == blk.start) {
-                runs.back().n += blk.n;
-            } else {
-                runs.push_back(blk);
-            }
-        }
-        int64_t total_tiles = 0;
-        for (auto &r : runs) total_tiles += (r.n + kTileRows - 1) / kTileRows;
-        q->segs.clear();
-        q->wg_seg_begin.assign((size_t)q->n_wg + 1, 0);
-        {
-            size_t ri = 0;
-            int64_t tile_in_run = 0;  // tiles of runs[ri] already handed out
-            for (int w = 0; w < q->n_wg; w++) {
-                q->wg_seg_begin[(size_t)w] = (int32_t)q->segs.size();
-                int64_t want = total_tiles * (w + 1) / q->n_wg - total_tiles * w / q->n_wg;
-                while (want > 0 && ri < runs.size()) {
-                    int64_t run_tiles = (runs[ri].n + kTileRows - 1) / kTileRows;
-                    int64_t take = std::min(want, run_tiles - tile_in_run);
-                    Segment sg;
-                    sg.start = runs[ri].start + tile_in_run * kTileRows;
-                    int64_t end = std::min(runs[ri].start + runs[ri].n, sg.start + take * kTileRows);
-                    sg.n = end - sg.start;
-                    q->segs.push_back(sg);
-                    tile_in_run += take;
-                    want -= take;
-                    if (tile_in_run == run_tiles) {
-                        ri++;
-                        tile_in_run = 0;
-                    }
-                }
-            }
-            q->wg_seg_begin[(size_t)q->n_wg] = (int32_t)q->segs.size();
-        }
-        return SYBL_OK;
-    }
-
-    int window() {
-        int rc;
-        // ---- LDS-window strategy: a time-series table too large for LDS, scanned by workgroups whose
-        // contiguous rows each span only a few time buckets (tables are digested in time order,
-        // table_io.go:119-122 sorts by Timestamp).  Exact per-block extrema of the time column give
-        // every workgroup its window.
-        P.windowed = 0;
-        P.lds_cells = (int32_t)n_cells;
-        P.wg_cell_base = nullptr;
-        if (!q->use_lds && q->time_mode && !getenv("SYBL_NO_WINDOW") && !t->blocks.empty()) {
-            const Column *tc = t->cols[(size_t)slot_col[(size_t)P.time_slot]].get();
-            std::vector<int32_t> base((size_t)q->n_wg, 0);
-            int64_t wmax = 1;
-            bool ok = true;
-            for (int w = 0; w < q->n_wg && ok; w++) {
-                int64_t lo = INT64_MAX, hi = INT64_MIN;
-                for (int32_t si = q->wg_seg_begin[(size_t)w]; si < q->wg_seg_begin[(size_t)w + 1]; si++) {
-                    const Segment &sg = q->segs[(size_t)si];
-                    // first block whose end is beyond the segment start
-                    size_t b = (size_t)(std::upper_bound(t->blocks.begin(), t->blocks.end(), sg.start,
-                                                         [](int64_t v, const Segment &blk) { return v < blk.start + blk.n; }) -
-                                        t->blocks.begin());
-                    for (; b < t->blocks.size() && t->blocks[b].start < sg.start + sg.n; b++) {
-                        if (tc->blk_pop[b] == 0) continue;
-                        lo = std::min(lo, tc->blk_min[b]);
-                        hi = std::max(hi, tc->blk_max[b]);
-                    }
-                }
-                if (hi < lo) continue;  // no populated time value: every row is dropped anyway
-                int64_t tlo = lo / d->time_bucket - P.tb_min, thi = hi / d->time_bucket - P.tb_min;
-                if (tlo < 0 || thi >= P.n_tb) {
-                    ok = false;  // declared bounds narrower than the data: the kernel would count overflow
-                    break;
-                }
-                base[(size_t)w] = (int32_t)(tlo * cells);
-                wmax = std::max(wmax, thi - tlo + 1);
-            }
-            int64_t lds_cells = wmax * cells;
-            if (ok && lds_cells * (F + M) * 8 <= kLdsBudgetBytes) {
-                q->use_lds = true;
-                P.windowed = 1;
-                P.lds_cells = (int32_t)lds_cells;
-                int rs = 0;
-                int64_t words = lds_cells * (F + M);
-                while (rs < 6 && (words * 8 << (rs + 1)) <= kLdsBudgetBytes) rs++;
-                P.rep_shift = rs;
-                q->lds_bytes = (size_t)(words * 8) << rs;
-                SYBL_HIP(hipMalloc((void **)&q->d_wg_cell_base, base.size() * 4));
-                SYBL_HIP(hipMemcpy(q->d_wg_cell_base, base.data(), base.size() * 4, hipMemcpyHostToDevice));
-                P.wg_cell_base = q->d_wg_cell_base;
-            }
-        }
-        select_fast_path(t, q, slot_col);
-        if ((rc = select_part_hist(t, q, slot_col, rows_scanned))) return rc;
-        q->stats.rows_scanned = rows_scanned;
-        q->stats.blocks_skipped = skipped;
-        q->stats.blocks_scanned = (int64_t)t->blocks.size() - skipped;
-        int64_t width = 0, canon_width = 0;
-        int64_t set_bytes = 0;
-        for (int s = 0; s < P.n_slots; s++) {
-            const Column *c = t->cols[(size_t)slot_col[(size_t)s]].get();
-            if (c->type == SYBL_SET_VAL) {
-                width += 8;  // one CSR offset per row
-                canon_width += 8;
-                set_bytes += (int64_t)c->h_set_vals.size() * 4;
-            } else {
-                width += c->elem;
-                canon_width += c->canon();
-            }
-        }
-        q->stats.algorithmic_bytes = rows_scanned * width + set_bytes;
-        q->stats.canonical_bytes = rows_scanned * canon_width + set_bytes;
-        q->stats.n_cells = (int32_t)n_cells;
-        q->stats.packed_kernel = q->part_hist ? q->part_packed : (q->fast && q->fast_packed);
-        q->stats.strategy = q->part_hist ? 5 : (q->use_lds ? (P.windowed ? (q->fast ? 4 : 3) : (q->fast ? (q->fplan.hist_lds ? 6 : 2) : 0)) : 1);
-        q->stats.lds_bytes = (int32_t)q->lds_bytes;
-        q->stats.n_workgroups = q->n_wg;
-        q->stats.replicas = 1 << P.rep_shift;
-        q->stats.n_sum_fields = P.n_sum_fields;
-        q->stats.n_max_fields = P.n_max_fields;
-        return SYBL_OK;
-    }
-
-    int device_copies() {
-        // ---- device-side copies
-        size_t nseg = std::max<size_t>(q->segs.size(), 1);
-        SYBL_HIP(hipMalloc((void **)&q->d_segs, nseg * sizeof(Segment)));
-        if (!q->segs.empty())
-            SYBL_HIP(hipMemcpy(q->d_segs, q->segs.data(), q->segs.size() * sizeof(Segment), hipMemcpyHostToDevice));
-        SYBL_HIP(hipMalloc((void **)&q->d_wg_seg_begin, q->wg_seg_begin.size() * 4));
-        SYBL_HIP(hipMemcpy(q->d_wg_seg_begin, q->wg_seg_begin.data(), q->wg_seg_begin.size() * 4, hipMemcpyHostToDevice));
-        P.segs = q->d_segs;
-        P.wg_seg_begin = q->d_wg_seg_begin;
-        if (q->use_lds && !P.windowed) {
-            SYBL_HIP(hipMalloc((void **)&q->d_ws_sum, (size_t)q->n_wg * F * n_cells * 8));
-            SYBL_HIP(hipMalloc((void **)&q->d_ws_max, (size_t)q->n_wg * std::max<int64_t>((int64_t)M * n_cells, 1) * 8));
-            P.ws_sum = q->d_ws_sum;
-            P.ws_max = q->d_ws_max;
-        }
-        q->eplan.fp.segs = q->d_segs;
-        q->eplan.fp.wg_seg_begin = q->d_wg_seg_begin;
-        q->fplan.segs = q->d_segs;
-        q->fplan.wg_seg_begin = q->d_wg_seg_begin;
-        q->fplan.ws_sum = q->d_ws_sum;
-        q->fplan.ws_max = q->d_ws_max;
-        SYBL_HIP(hipMalloc((void **)&q->d_plan, sizeof(ScanPlan)));
-        for (auto &e : q->ev) SYBL_HIP(hipEventCreate(&e));
-        q->plan_dirty = true;
-        return SYBL_OK;
-    }
-
-    int run() {
-        int rc;
-        if ((rc = setup())) return rc;
-        if ((rc = filters())) return rc;
-        if ((rc = groups())) return rc;
-        if ((rc = time_series())) return rc;
-        if ((rc = weight())) return rc;
-        if ((rc = aggregations())) return rc;
-        if ((rc = finish_slots())) return rc;
-        if ((rc = strategy())) return rc;
-        if ((rc = work())) return rc;
-        if ((rc = window())) return rc;
-        return device_copies();
-    }
-};
-
-static int plan_query(Table *t, const sybl_query_desc *d, Query *q) {
-    Planner p(t, d, q);
-    return p.run();
-}
-
 static int ensure_partials(Query *q) {
     if (q->d_sum && q->d_max) return SYBL_OK;
     SYBL_HIP(hipMalloc((void **)&q->d_sum, (size_t)q->n_sum_words * 8));

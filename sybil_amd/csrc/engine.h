@@ -245,6 +245,7 @@ struct Query {
     uint32_t *d_recs = nullptr, *d_cursor = nullptr;
 };
 
+int plan_query(Table *t, const sybl_query_desc *d, Query *q);  // planner.cpp
 int query_rescan_without_part_hist(Query *q);
 
 int query_snapshot(Query *q);
