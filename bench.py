@@ -39,22 +39,38 @@ def cpu_baseline(workload, total_rows, budget_s=20.0):
     cores = min(os.cpu_count() or 1, 16)
     kw = parity.oracle_query_kwargs(names, info, q)
 
-    def run(nrows):
+    def run(nrows, columnar=False):
         cols = parity.oracle_synth_cols(orc, names, total_rows, 0, nrows)
         t0 = time.perf_counter()
         r = orc.run_query(cols, n_threads=cores, want_values=False, **kw)
         dt = time.perf_counter() - t0
-        return dt, r["matched"]
+        col = None
+        if columnar and workload == "cfg3_filter3_group2_stddev":
+            # variant (ii) of BASELINE.md section 2: a plain columnar multi-threaded scan of the same sample on
+            # every host thread (direct-mapped cell table per thread, no Record rows, no maps)
+            d = {n: c["data"] for n, c in zip(names, cols)}
+            threads = os.cpu_count() or 1
+            args = ([d["c04"], d["c05"], d["c06"]], [(100, 899)] * 3, [d["c01"], d["c02"]], [(0, 16), (0, 64)],
+                    [d["c07"], d["c08"]], [(0, 999), (0, 999)])
+            orc.columnar_scan(*args, n_threads=threads)  # warm the thread pool / page in
+            t1 = time.perf_counter()
+            m, tab = orc.columnar_scan(*args, n_threads=threads)
+            dt2 = time.perf_counter() - t1
+            assert m == r["matched"] and int(tab[0].sum()) == r["matched"]
+            col = {"value": nrows / dt2, "unit": "rows/s", "cores": threads, "kind": "port-columnar",
+                   "sample": "%d rows, oracle/sybil_oracle.c:orc_columnar_scan with %d threads, %.2f s" % (nrows, threads, dt2)}
+        return dt, r["matched"], col
 
     probe = 2_000_000
-    dt, _ = run(probe)
+    dt, _, _ = run(probe)
     rate = probe / dt
     sample = int(min(max(rate * budget_s, probe), 96_000_000, total_rows))
     sample = max(65536, sample // 65536 * 65536)
-    dt, matched = run(sample)
-    return {"value": sample / dt, "unit": "rows/s", "cores": cores, "kind": "port",
-            "sample": "%d rows (first blocks) of %s, oracle/sybil_oracle.c with %d threads, %.1f s" % (
-                sample, workload, cores, dt)}
+    dt, matched, col = run(sample, columnar=True)
+    out = {"value": sample / dt, "unit": "rows/s", "cores": cores, "kind": "port",
+           "sample": "%d rows (first blocks) of %s, oracle/sybil_oracle.c with %d threads, %.1f s" % (
+               sample, workload, cores, dt)}
+    return out, col
 
 
 def measured_traffic(stats, names):
@@ -293,7 +309,9 @@ def main():
             out["canonical_storage"] = {"value": total_rows * min(args.steps, 10) / canon["dt"], "unit": "rows/s",
                                         "steps": min(args.steps, 10), "roofline": roofline(canon, "canonical")}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.workload, total_rows)
+            out["cpu_baseline"], columnar = cpu_baseline(args.workload, total_rows)
+            if columnar is not None:
+                out["cpu_baseline_columnar"] = columnar
         print(json.dumps(out))
         sys.stdout.flush()
     table.free()

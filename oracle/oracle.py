@@ -114,6 +114,9 @@ def lib():
         L.orc_splitmix64.argtypes = [C.c_uint64]
         L.orc_synth_fill.argtypes = [C.c_int, C.c_int64, C.c_int64, C.c_uint64, C.c_int32,
                                      C.c_int64, C.c_int64, C.c_int64, C.c_void_p]
+        L.orc_columnar_scan.restype = C.c_int64
+        L.orc_columnar_scan.argtypes = [C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
         _lib = L
     return _lib
 
@@ -198,6 +201,27 @@ def synth_fill(kind, a, b, seed, col_index, row0, n, total_rows):
     out = np.empty(n, dtype=np.int64)
     lib().orc_synth_fill(kind, a, b, seed, col_index, row0, n, total_rows, _ptr(out))
     return out
+
+
+def columnar_scan(fcols, ranges, gcols, gbounds, acols, ageom, n_threads=0):
+    """The columnar CPU baseline (orc_columnar_scan): fcols / gcols / acols are lists of int64 arrays,
+    ranges = [(lo, hi)] inclusive, gbounds = [(gmin, gcard)], ageom = [(hmin, bucket_size)].
+    Returns (matched, table) with table[field][cell]: Count, then sum(v), sum(b), sum(b^2) per aggregation."""
+    def ptrs(arrs):
+        a = (C.c_void_p * max(len(arrs), 1))(*[x.ctypes.data for x in arrs])
+        return a
+    def vec(vals):
+        return np.asarray(vals, dtype=np.int64)
+    nrows = len((fcols + gcols + acols)[0])
+    lo, hi = vec([r[0] for r in ranges]), vec([r[1] for r in ranges])
+    gmin, gcard = vec([g[0] for g in gbounds]), vec([g[1] for g in gbounds])
+    hmin, bs = vec([a[0] for a in ageom]), vec([a[1] for a in ageom])
+    cells = int(np.prod(gcard)) if len(gbounds) else 1
+    out = np.zeros((1 + 3 * len(acols), cells), dtype=np.int64)
+    fp, gp, ap = ptrs(fcols), ptrs(gcols), ptrs(acols)
+    m = lib().orc_columnar_scan(nrows, len(fcols), fp, _ptr(lo), _ptr(hi), len(gcols), gp, _ptr(gmin), _ptr(gcard), len(acols), ap,
+                                _ptr(hmin), _ptr(bs), n_threads, _ptr(out))
+    return m, out
 
 
 # ---------------------------------------------------------------- full query

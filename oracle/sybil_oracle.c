@@ -795,3 +795,55 @@ void orc_synth_fill(int kind, int64_t a, int64_t b, uint64_t seed, int32_t col_i
         out[k] = v;
     }
 }
+
+/* ------------------------------------------------------------------ */
+/* columnar CPU baseline (see sybil_oracle.h)                           */
+/* ------------------------------------------------------------------ */
+int64_t orc_columnar_scan(int64_t nrows, int32_t nf, const int64_t *const *fcols, const int64_t *lo, const int64_t *hi,
+                          int32_t ng, const int64_t *const *gcols, const int64_t *gmin, const int64_t *gcard, int32_t na,
+                          const int64_t *const *acols, const int64_t *hmin, const int64_t *bucket_size, int32_t n_threads,
+                          int64_t *out) {
+    int64_t cells = 1;
+    for (int g = 0; g < ng; g++) cells *= gcard[g];
+    const int64_t fields = 1 + 3 * (int64_t)na, words = fields * cells;
+    memset(out, 0, (size_t)words * sizeof(int64_t));
+    int64_t matched = 0;
+    int bad = 0;
+#ifdef _OPENMP
+    if (n_threads > 0) omp_set_num_threads(n_threads);
+#else
+    (void)n_threads;
+#endif
+#pragma omp parallel reduction(+ : matched) reduction(| : bad)
+    {
+        int64_t *tab = (int64_t *)calloc((size_t)words, sizeof(int64_t));
+#pragma omp for schedule(static)
+        for (int64_t blk = 0; blk < (nrows + 65535) / 65536; blk++) {
+            const int64_t r0 = blk * 65536, r1 = r0 + 65536 < nrows ? r0 + 65536 : nrows;
+            for (int64_t r = r0; r < r1; r++) {
+                int pass = 1;
+                for (int f = 0; f < nf; f++) pass &= fcols[f][r] >= lo[f] && fcols[f][r] <= hi[f];
+                if (!pass) continue;
+                matched++;
+                int64_t cell = 0;
+                for (int g = 0; g < ng; g++) {
+                    const int64_t d = gcols[g][r] - gmin[g];
+                    if (d < 0 || d >= gcard[g]) bad = 1;
+                    cell = cell * gcard[g] + d;
+                }
+                if (bad) continue;
+                tab[cell] += 1;
+                for (int a = 0; a < na; a++) {
+                    const int64_t v = acols[a][r], b = (v - hmin[a]) / bucket_size[a];
+                    tab[(1 + 3 * a) * cells + cell] += v;
+                    tab[(2 + 3 * a) * cells + cell] += b;
+                    tab[(3 + 3 * a) * cells + cell] += b * b;
+                }
+            }
+        }
+#pragma omp critical
+        for (int64_t i = 0; i < words; i++) out[i] += tab[i];
+        free(tab);
+    }
+    return bad ? -1 : matched;
+}

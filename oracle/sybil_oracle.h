@@ -180,6 +180,19 @@ uint64_t orc_splitmix64(uint64_t x);
 void orc_synth_fill(int kind, int64_t a, int64_t b, uint64_t seed, int32_t col_index,
                     int64_t row0, int64_t n, int64_t total_rows, int64_t *out);
 
+/* ---- columnar CPU baseline (OURS: BASELINE.md section 2, variant ii) --------------------------------
+ * What a straightforward columnar engine does on the host for the config-3 query shape -- no Record rows,
+ * no maps: nf inclusive int ranges, ng direct-mapped int group columns, na aggregation columns with the
+ * moments Count / sum(v) / sum(b) / sum(b^2) of the reference's bucket index b = (v - hmin) / bucket_size
+ * (hist_basic.go:130) per cell; one thread-local cell table per OpenMP thread, summed at the end.
+ * out: [1 + 3 * na][cells] int64 (Count, then sum(v), sum(b), sum(b^2) per aggregation).  Returns the
+ * matched-row count, or -1 when a key falls outside [gmin, gmin + gcard).  Test / bench infrastructure
+ * only, like everything in this directory. */
+int64_t orc_columnar_scan(int64_t nrows, int32_t nf, const int64_t *const *fcols, const int64_t *lo, const int64_t *hi,
+                          int32_t ng, const int64_t *const *gcols, const int64_t *gmin, const int64_t *gcard, int32_t na,
+                          const int64_t *const *acols, const int64_t *hmin, const int64_t *bucket_size, int32_t n_threads,
+                          int64_t *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -152,3 +152,32 @@ def test_synth_generator_is_counter_based(oracle):
     bell = oracle.synth_fill(oracle.SYN_BELL, 0, 250_000, 20241022, 8, 0, 10_000, 10_000)
     assert 0 <= bell.min() and bell.max() <= 999_996
     assert oracle.splitmix64(0) == 0xE220A8397B1DCDAF
+
+
+def test_columnar_baseline_matches_the_reference_shaped_oracle(oracle):
+    """orc_columnar_scan (the plain columnar CPU baseline bench.py times beside the reference-shaped one) must
+    produce the same integers as the per-block hash-map restatement on the config-3 query."""
+    from sybil_amd import synth
+    from tests import parity
+    wl = synth.WORKLOADS["cfg3_filter3_group2_stddev"]
+    names = wl["columns"]
+    n = 300_000
+    cols = parity.oracle_synth_cols(oracle, names, 1_000_000_000, 0, n)
+    d = {nm: c["data"] for nm, c in zip(names, cols)}
+    m, tab = oracle.columnar_scan([d["c04"], d["c05"], d["c06"]], [(100, 899)] * 3, [d["c01"], d["c02"]], [(0, 16), (0, 64)],
+                                  [d["c07"], d["c08"]], [(0, 999), (0, 999)], n_threads=3)
+    info = {x: (synth.COLUMNS[x][4], synth.COLUMNS[x][5]) for x in names}
+    o = oracle.run_query(cols, n_threads=2, want_values=True, **parity.oracle_query_kwargs(names, info, dict(wl["query"], want_percentiles=True)))
+    assert m == o["matched"] == int(tab[0].sum())
+    import numpy as np
+    for r in o["results"]:
+        cell = r["key_vals"][0] * 64 + r["key_vals"][1]
+        assert tab[0][cell] == r["count"]
+        for a in range(2):
+            h = r["hists"][a]
+            assert tab[1 + 3 * a][cell] == h["sum_exact"]
+            b = np.arange(len(h["values"]), dtype=np.int64)
+            assert tab[2 + 3 * a][cell] == int((b * h["values"]).sum())
+            assert tab[3 + 3 * a][cell] == int((b * b * h["values"]).sum())
+    # a key outside the declared bounds is reported, not silently dropped
+    assert oracle.columnar_scan([], [], [d["c02"]], [(0, 8)], [], [], n_threads=1)[0] == -1
