@@ -157,6 +157,12 @@ int sybl_table_open_flags(sybl_ctx *ctx, const char *dir, const char *table, con
  * `sybil` binary or sybl_table_open can read it back. */
 int sybl_table_save(sybl_table *t, const char *dir);
 
+/* Test hook (no GPU needed): the gob bytes sybl_table_save writes for one block of an INT column (kind
+ * SYBL_INT_VAL) or a STR column (SYBL_STR_VAL; vals = ids into dict).  Library-owned, valid until the next call
+ * on the thread. */
+const void *sybl_debug_encode_column(int kind, const char *name, const int64_t *vals, const uint8_t *populated, int64_t n,
+                                     const char *const *dict, int64_t n_dict, int64_t *n_bytes);
+
 /* Blocks sybl_table_open skipped the way the reference does: unreadable block info.db, NumRecords
  * <= 0, or a column file whose record ids / value count exceed NumRecords ("BLOCK SIZE CHANGED
  * DURING QUERY", column_store_io.go:524-526,572-574,733-735; table_query.go:134-139). */

@@ -269,6 +269,30 @@ void put_int_info(Buf &w, int64_t mn, int64_t mx, double avg, double m2, int64_t
 
 using namespace sybl;
 
+// Test hook (no GPU needed): the gob bytes sybl_table_save would write for one block of an int column
+// (kind 1) or a str column (kind 2; vals = dictionary ids into dict).  Library-owned buffer, valid until the
+// next call on the thread.
+extern "C" const void *sybl_debug_encode_column(int kind, const char *name, const int64_t *vals, const uint8_t *populated, int64_t n,
+                                                const char *const *dict, int64_t n_dict, int64_t *n_bytes) {
+    static thread_local std::string out;
+    if (!name || n < 0 || (n > 0 && !vals) || !n_bytes || (kind != SYBL_INT_VAL && kind != SYBL_STR_VAL)) {
+        set_error("sybl_debug_encode_column: bad argument");
+        return nullptr;
+    }
+    std::vector<int64_t> v(vals, vals + n);
+    std::vector<uint8_t> pop((size_t)n, 1);
+    if (populated) pop.assign(populated, populated + n);
+    if (kind == SYBL_INT_VAL) {
+        out = encode_int_column(name, v, pop);
+    } else {
+        std::vector<std::string> d;
+        for (int64_t i = 0; i < n_dict; i++) d.push_back(dict[i] ? dict[i] : "");
+        out = encode_str_column(name, v, pop, d);
+    }
+    *n_bytes = (int64_t)out.size();
+    return out.data();
+}
+
 extern "C" int sybl_table_save(sybl_table *t, const char *dir) {
     if (!t || !dir) return fail(SYBL_E_INVAL, "sybl_table_save: NULL argument");
     SYBL_HIP(hipSetDevice(t->ctx->device));

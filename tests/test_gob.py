@@ -3,6 +3,8 @@ native loader is tested with, against the reference's golden gob stream
 (src/lib/testdata/TestDecodeGoldenFiles/flag_defs.golden.gob, decoding_test.go:20-74): a hex dump
 of the 941-byte stream and the expected decoded value, written by tests/golden/make_golden.py."""
 import json
+
+import numpy as np
 import os
 
 from tests import gobfmt as G
@@ -162,3 +164,44 @@ def test_encoded_results_sample_decodes():
     assert {k: v["Count"] for k, v in tres["TimeResults"][1700006400].items()} == {"edge\t": 1, "gecko\t": 1, "webkit\t": 1}
     assert tres["TimeResults"][1699999200]["edge\t"]["Hists"]["load"]["value"]["BasicHist"]["BasicHistCachedInfo"]["Avg"] == 200.0
     assert "Hists" not in tres["Results"]["edge\t"] and tres["Results"]["edge\t"]["Count"] == 5
+
+
+def _encode_column(kind, name, vals, pop=None, dict_strings=None):
+    import ctypes as C
+    from sybil_amd import _native as N
+    vals = np.ascontiguousarray(vals, dtype=np.int64)
+    popa = None if pop is None else np.ascontiguousarray(pop, dtype=np.uint8)
+    n = C.c_int64(0)
+    ds = [s.encode() for s in (dict_strings or [])]
+    arr = (C.c_char_p * max(len(ds), 1))(*ds)
+    p = N.lib().sybl_debug_encode_column(kind, name.encode(), vals.ctypes.data, None if popa is None else popa.ctypes.data,
+                                         len(vals), arr, len(ds), C.byref(n))
+    assert p, N.lib().sybl_last_error()
+    return C.string_at(p, n.value)
+
+
+def test_native_column_writer_matches_the_python_writer():
+    """The C++ gob encoder behind sybl_table_save (csrc/writer.cpp, csrc/gobenc.h) against the Go-faithful Python
+    writer (tests/sybil_fixture.py) -- byte for byte, for bucket- and value-encoded int columns with and without
+    missing rows and for str columns (no GPU involved)."""
+    from tests import sybil_fixture as F
+    rng = np.random.default_rng(3)
+    n = 20_000
+    low = rng.integers(-5, 40, size=n)                      # <= 5000 distinct: bucket encoded
+    high = rng.integers(-(1 << 45), 1 << 45, size=n)        # > 5000 distinct: value encoded, wide deltas
+    pop = (rng.random(n) > 0.3).astype(np.uint8)
+    for name, vals, p in (("low", low, None), ("low", low, pop), ("high", high, None), ("high", high, pop),
+                          ("one", np.array([7]), None), ("none", np.array([1, 2, 3]), np.zeros(3, dtype=np.uint8)),
+                          ("empty", np.zeros(0, dtype=np.int64), None)):
+        want = F.int_column(name, np.asarray(vals, dtype=np.int64), p)
+        got = _encode_column(1, name, vals, p)
+        assert got == want, (name, len(got), len(want))
+    vocab = ["host%04d" % i for i in range(6000)]
+    few = rng.integers(0, 50, size=n)
+    many = rng.integers(0, 6000, size=n)                    # > 5000 distinct strings: per-row Values
+    spop = rng.random(n) > 0.2
+    for name, ids, p in (("few", few, None), ("few", few, spop), ("many", many, None), ("many", many, spop)):
+        strings = [vocab[i] if (p is None or p[k]) else None for k, i in enumerate(ids)]
+        want = F.str_column(name, strings)
+        got = _encode_column(2, name, ids, None if p is None else p.astype(np.uint8), vocab)
+        assert got == want, (name, len(got), len(want))
