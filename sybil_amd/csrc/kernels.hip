@@ -802,8 +802,8 @@ __global__ __launch_bounds__(kWgThreads) void k_part_hist(const PartHistPlan P) 
             add_record(cur.w);
             cur = nxt;
         }
-        for (uint32_t k = a1 + tid; k < i1; k += kWgThreads) add_record(recs[k]);
     }
+    for (uint32_t k = a1 + tid; k < i1; k += kWgThreads) add_record(recs[k]);  // (< 4 records; none when a0 > i1)
     __syncthreads();
     // cnt[l] = sum over the buckets of pair l: each wave sums a strided share, one LDS atomic per wave
     for (uint32_t l = 0; l < (uint32_t)kPartCells; l++) {

@@ -63,7 +63,9 @@ def _random_query(rng, info):
     return q
 
 
-@pytest.mark.parametrize("seed", range(40))
+# 205, 206, 238, 294: found by tools/fuzz_more.py (a partition whose record range ended less than four records
+# after a 16-byte boundary lost its tail in k_part_hist)
+@pytest.mark.parametrize("seed", list(range(40)) + [205, 206, 238, 294])
 def test_random_queries(ctx, oracle, seed):
     rng = np.random.default_rng(1000 + seed)
     n = int(rng.integers(1, 60_000))
