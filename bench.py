@@ -264,8 +264,13 @@ def main():
         stats = ph["stats"]
         alg = stats["algorithmic_bytes"]  # this rank's rows x stored bytes per row: per launch, per GPU
         achieved = alg / (ph["kernel_ms"] * 1e-3) / 1e9
-        kernel = ("k_scan_packed<3,2,2,moments>" if stats["packed_kernel"] else "k_scan_fast<3,2,2,moments>") \
-            if stats["strategy"] == 2 else "k_scan<%d>" % len(names)
+        shape = "<3,2,2,moments>" if args.workload == "cfg3_filter3_group2_stddev" else ""
+        if stats["strategy"] in (2, 4, 6):
+            kernel = ("k_scan_packed" if stats["packed_kernel"] else "k_scan_fast") + shape
+        elif stats["strategy"] == 5:
+            kernel = ("k_emit_packed" if stats["packed_kernel"] else "k_emit") + " + k_part_hist"
+        else:
+            kernel = "k_scan<%d>" % len(names)
         return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": measured_traffic(stats, names), "kernel": kernel, "kernel_ms": ph["kernel_ms"],
                 "algorithmic_bytes_per_launch": alg, "stored_bytes_per_row": alg / max(stats["rows_scanned"], 1),
