@@ -331,6 +331,14 @@ typedef struct {
 /* Valid after the stream has been synchronised (sybl_query_finalize / sybl_ctx_sync). */
 int sybl_query_stats(sybl_query *q, sybl_run_stats *out);
 
+/* Test hook: the exact integer accumulators behind the last finalized result, by direct-mapped cell
+ * (cell = time-bucket index x group cells + sum of (key - min) x stride, first group column most
+ * significant): which = 0 Count, 1 sum(v), 2 sum(b), 3 sum(b^2) of aggregation `agg` (b = the reference's
+ * bucket index, hist_basic.go:130; 2 and 3 exist in moments mode and when percentiles were summarised on
+ * the GPU).  Writes min(cap, n_cells) values; *n_cells = cells of the query.  Full-size parity tests compare
+ * these with the CPU oracle bit for bit. */
+int sybl_debug_query_cells(sybl_query *q, int which, int agg, int64_t *out, int64_t cap, int64_t *n_cells);
+
 /* reference output surface (printer.go:109-232,291-308): renders a result the way
  * `sybil query` prints it.  format: 0 = text table, 1 = -json.  Returns a
  * library-owned NUL-terminated buffer valid until the result is freed. */

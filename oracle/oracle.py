@@ -114,6 +114,8 @@ def lib():
         L.orc_splitmix64.argtypes = [C.c_uint64]
         L.orc_synth_fill.argtypes = [C.c_int, C.c_int64, C.c_int64, C.c_uint64, C.c_int32,
                                      C.c_int64, C.c_int64, C.c_int64, C.c_void_p]
+        L.orc_synth_scan.restype = C.c_int64
+        L.orc_synth_scan.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_columnar_scan.restype = C.c_int64
         L.orc_columnar_scan.argtypes = [C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
@@ -222,6 +224,94 @@ def columnar_scan(fcols, ranges, gcols, gbounds, acols, ageom, n_threads=0):
     m = lib().orc_columnar_scan(nrows, len(fcols), fp, _ptr(lo), _ptr(hi), len(gcols), gp, _ptr(gmin), _ptr(gcard), len(acols), ap,
                                 _ptr(hmin), _ptr(bs), n_threads, _ptr(out))
     return m, out
+
+
+# ---------------------------------------------------------------- full-size checker
+class _SynCol(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("col_index", C.c_int32), ("a", C.c_int64), ("b", C.c_int64)]
+
+
+class _SynthQuery(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("total_rows", C.c_int64), ("row0", C.c_int64), ("nrows", C.c_int64),
+                ("nf", C.c_int32), ("ng", C.c_int32), ("na", C.c_int32), ("has_time", C.c_int32),
+                ("fcol", _SynCol * 4), ("gcol", _SynCol * 4), ("acol", _SynCol * 4), ("tcol", _SynCol),
+                ("lo", C.c_int64 * 4), ("hi", C.c_int64 * 4), ("gmin", C.c_int64 * 4), ("gcard", C.c_int64 * 4),
+                ("hmin", C.c_int64 * 4), ("bucket_size", C.c_int64 * 4), ("n_values", C.c_int64 * 4),
+                ("time_bucket", C.c_int64), ("tb_min", C.c_int64), ("n_tb", C.c_int64), ("nv_max", C.c_int64),
+                ("n_threads", C.c_int32), ("pad_", C.c_int32)]
+
+
+def synth_scan(columns, seed, total_rows, row0, nrows, filters=(), groups=(), aggs=(), time_col=None, time_bucket=0,
+               want_buckets=False, n_threads=0):
+    """orc_synth_scan over rows [row0, row0 + nrows) of the synthetic table: `columns` maps a column name to
+    (kind, col_index, a, b, info_min, info_max) as sybil_amd.synth.COLUMNS does (passed in: the oracle never
+    imports the product package); filters = [(col, 'gt'|'lt'|'eq', value)] folded to inclusive ranges per
+    column like IntFilter (filter.go:171-195); groups / aggs = column names; bucket geometry from
+    orc_setup_buckets on the columns' IntInfo.  Returns a dict: matched, cells = (n_tb, gcard...),
+    count[cell], sum[a][cell], sb[a][cell], sb2[a][cell], buckets[cell][a][nv_max] (want_buckets), tb_min."""
+    q = _SynthQuery()
+    q.seed, q.total_rows, q.row0, q.nrows = seed, total_rows, row0, nrows
+
+    def syn(name):
+        kind, idx, a, b = columns[name][:4]
+        return _SynCol(kind, idx, a, b)
+
+    def bounds(name):
+        kind, idx, a, b = columns[name][:4]
+        if kind == SYN_UNIFORM:
+            return a, a + b - 1
+        if kind == SYN_BELL:
+            return a, a + 4 * (b - 1)
+        return a, a + b - 1  # TIME: a + floor(i * b / N) < a + b
+
+    ranges = {}
+    for col, op, val in filters:
+        lo, hi = ranges.get(col, (-(1 << 62), 1 << 62))
+        if op == "gt":
+            lo = max(lo, val + 1)
+        elif op == "lt":
+            hi = min(hi, val - 1)
+        elif op == "eq":
+            lo, hi = max(lo, val), min(hi, val)
+        else:
+            raise ValueError(op)
+        ranges[col] = (lo, hi)
+    q.nf = len(ranges)
+    for i, (col, (lo, hi)) in enumerate(ranges.items()):
+        q.fcol[i], q.lo[i], q.hi[i] = syn(col), lo, hi
+    q.ng = len(groups)
+    gcard = []
+    for i, col in enumerate(groups):
+        lo, hi = bounds(col)
+        q.gcol[i], q.gmin[i], q.gcard[i] = syn(col), lo, hi - lo + 1
+        gcard.append(hi - lo + 1)
+    q.na = len(aggs)
+    nv_max = 1
+    for i, col in enumerate(aggs):
+        info_min, info_max = columns[col][4], columns[col][5]
+        geo = setup_buckets(info_min, info_max, 0)
+        bs, nv = geo["bucket_size"], geo["n_values"]
+        q.acol[i], q.hmin[i], q.bucket_size[i], q.n_values[i] = syn(col), info_min, bs, nv
+        nv_max = max(nv_max, nv)
+    q.nv_max = nv_max
+    n_tb, tb_min = 1, 0
+    if time_col:
+        lo, hi = bounds(time_col)
+        q.has_time, q.tcol, q.time_bucket = 1, syn(time_col), time_bucket
+        tb_min = lib().orc_time_bucket(lo, time_bucket) // time_bucket
+        n_tb = lib().orc_time_bucket(hi, time_bucket) // time_bucket - tb_min + 1
+        q.tb_min, q.n_tb = tb_min, n_tb
+    q.n_threads = n_threads
+    cells = n_tb * int(np.prod(gcard)) if gcard else n_tb
+    fields = np.zeros((1 + 3 * len(aggs), cells), dtype=np.int64)
+    hist = np.zeros((cells, max(len(aggs), 1), nv_max), dtype=np.int64) if want_buckets else None
+    m = lib().orc_synth_scan(C.byref(q), _ptr(fields), _ptr(hist) if want_buckets else None)
+    out = {"matched": m, "cells": (n_tb,) + tuple(gcard), "tb_min": tb_min, "count": fields[0],
+           "sum": [fields[1 + 3 * a] for a in range(len(aggs))], "sb": [fields[2 + 3 * a] for a in range(len(aggs))],
+           "sb2": [fields[3 + 3 * a] for a in range(len(aggs))], "buckets": hist,
+           "gmin": [q.gmin[i] for i in range(len(groups))], "bucket_size": [q.bucket_size[i] for i in range(len(aggs))],
+           "n_values": [q.n_values[i] for i in range(len(aggs))], "hmin": [q.hmin[i] for i in range(len(aggs))]}
+    return out
 
 
 # ---------------------------------------------------------------- full query

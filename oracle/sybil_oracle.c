@@ -847,3 +847,90 @@ int64_t orc_columnar_scan(int64_t nrows, int32_t nf, const int64_t *const *fcols
     }
     return bad ? -1 : matched;
 }
+
+/* ---- full-size checker: generator + direct-mapped row loop, one block at a time (see sybil_oracle.h) ---- */
+int64_t orc_synth_scan(const orc_synth_query *q, int64_t *out_fields, int64_t *out_hist) {
+    int64_t gcells = 1;
+    for (int g = 0; g < q->ng; g++) gcells *= q->gcard[g];
+    const int64_t cells = gcells * (q->has_time ? q->n_tb : 1);
+    const int64_t fields = 1 + 3 * (int64_t)q->na, words = fields * cells;
+    memset(out_fields, 0, (size_t)words * sizeof(int64_t));
+    if (out_hist) memset(out_hist, 0, (size_t)(cells * q->na * q->nv_max) * sizeof(int64_t));
+    int64_t matched = 0;
+    int bad = 0;
+    const int64_t B = 65536;
+    const int64_t nblk = (q->nrows + B - 1) / B;
+#ifdef _OPENMP
+    if (q->n_threads > 0) omp_set_num_threads(q->n_threads);
+#endif
+#pragma omp parallel reduction(+ : matched) reduction(| : bad)
+    {
+        int64_t *tab = (int64_t *)calloc((size_t)words, sizeof(int64_t));
+        const int ncol = q->nf + q->ng + q->na + (q->has_time ? 1 : 0);
+        int64_t *buf = (int64_t *)malloc((size_t)(ncol > 0 ? ncol : 1) * (size_t)B * sizeof(int64_t));
+        const int64_t *fc[4], *gc[4], *ac[4], *tc = NULL;
+#pragma omp for schedule(dynamic, 4)
+        for (int64_t blk = 0; blk < nblk; blk++) {
+            const int64_t r0 = blk * B, n = r0 + B < q->nrows ? B : q->nrows - r0;
+            int k = 0;
+            for (int f = 0; f < q->nf; f++, k++) {
+                orc_synth_fill(q->fcol[f].kind, q->fcol[f].a, q->fcol[f].b, q->seed, q->fcol[f].col_index, q->row0 + r0, n,
+                               q->total_rows, buf + (int64_t)k * B);
+                fc[f] = buf + (int64_t)k * B;
+            }
+            for (int g = 0; g < q->ng; g++, k++) {
+                orc_synth_fill(q->gcol[g].kind, q->gcol[g].a, q->gcol[g].b, q->seed, q->gcol[g].col_index, q->row0 + r0, n,
+                               q->total_rows, buf + (int64_t)k * B);
+                gc[g] = buf + (int64_t)k * B;
+            }
+            for (int a = 0; a < q->na; a++, k++) {
+                orc_synth_fill(q->acol[a].kind, q->acol[a].a, q->acol[a].b, q->seed, q->acol[a].col_index, q->row0 + r0, n,
+                               q->total_rows, buf + (int64_t)k * B);
+                ac[a] = buf + (int64_t)k * B;
+            }
+            if (q->has_time) {
+                orc_synth_fill(q->tcol.kind, q->tcol.a, q->tcol.b, q->seed, q->tcol.col_index, q->row0 + r0, n, q->total_rows,
+                               buf + (int64_t)k * B);
+                tc = buf + (int64_t)k * B;
+            }
+            for (int64_t r = 0; r < n; r++) {
+                int pass = 1;
+                for (int f = 0; f < q->nf; f++) pass &= fc[f][r] >= q->lo[f] && fc[f][r] <= q->hi[f];
+                if (!pass) continue;
+                matched++;
+                int64_t cell = 0;
+                int oob = 0;
+                if (q->has_time) {
+                    const int64_t tb = orc_time_bucket(tc[r], q->time_bucket) / q->time_bucket - q->tb_min;
+                    if (tb < 0 || tb >= q->n_tb) oob = 1;
+                    cell = tb;
+                }
+                for (int g = 0; g < q->ng; g++) {
+                    const int64_t d = gc[g][r] - q->gmin[g];
+                    if (d < 0 || d >= q->gcard[g]) oob = 1;
+                    cell = cell * q->gcard[g] + d;
+                }
+                if (oob) {
+                    bad = 1;
+                    continue;
+                }
+                tab[cell] += 1;
+                for (int a = 0; a < q->na; a++) {
+                    const int64_t v = ac[a][r];
+                    int64_t b = (v - q->hmin[a]) / q->bucket_size[a];
+                    if (b >= q->n_values[a]) b = q->n_values[a] - 1; /* hist_basic.go:132-142 */
+                    if (b < 0) b = 0;
+                    tab[(1 + 3 * a) * cells + cell] += v;
+                    tab[(2 + 3 * a) * cells + cell] += b;
+                    tab[(3 + 3 * a) * cells + cell] += b * b;
+                    if (out_hist) __atomic_fetch_add(&out_hist[(cell * q->na + a) * q->nv_max + b], 1, __ATOMIC_RELAXED);
+                }
+            }
+        }
+#pragma omp critical
+        for (int64_t i = 0; i < words; i++) out_fields[i] += tab[i];
+        free(tab);
+        free(buf);
+    }
+    return bad ? -1 : matched;
+}

@@ -193,6 +193,38 @@ int64_t orc_columnar_scan(int64_t nrows, int32_t nf, const int64_t *const *fcols
                           const int64_t *const *acols, const int64_t *hmin, const int64_t *bucket_size, int32_t n_threads,
                           int64_t *out);
 
+/* ---- full-size checker (OURS): the columnar scan above, fused with the synthetic generator ----------------
+ * The BASELINE.json configurations are 10^9 rows: too many to materialise on the host or to push through the
+ * per-row hash maps of orc_query_run in test time.  orc_synth_scan regenerates every referenced column of the
+ * synthetic table block by block (orc_synth_fill, one 65536-row block per OpenMP task, nothing bigger than a
+ * block is ever held) and runs the reference's row loop in its direct-mapped columnar form:
+ *   filters   lo <= x <= hi                                   (filter.go:171-195, gt/lt/eq folded)
+ *   time      tb = t / time_bucket * time_bucket              (aggregate.go:174)
+ *   cell      ((tb / time_bucket - tb_min) * cells_g) + sum over group columns of (x - gmin) radix gcard
+ *             -- first group column most significant          (aggregate.go:125-143 key order)
+ *   per agg   b = (v - hmin) / bucket_size, clipped into [0, n_values)   (hist_basic.go:130-150)
+ * out_fields: [1 + 3 * na][cells] int64 = Count, then per aggregation sum(v), sum(b), sum(b^2).
+ * out_hist:   NULL, or [cells][na][nv_max] int64 bucket counts (relaxed atomic adds on one shared table).
+ * Returns the matched-row count, -1 when a key or time bucket falls outside the declared ranges.
+ * tests/test_oracle_query.py checks it against orc_query_run on the same (materialised) table. */
+typedef struct {
+    int32_t kind, col_index;
+    int64_t a, b;
+} orc_synth_col;
+typedef struct {
+    uint64_t seed;
+    int64_t total_rows, row0, nrows;
+    int32_t nf, ng, na, has_time;
+    orc_synth_col fcol[4], gcol[4], acol[4], tcol;
+    int64_t lo[4], hi[4];
+    int64_t gmin[4], gcard[4];
+    int64_t hmin[4], bucket_size[4], n_values[4];
+    int64_t time_bucket, tb_min, n_tb;
+    int64_t nv_max; /* stride of out_hist per (cell, agg) */
+    int32_t n_threads, pad_;
+} orc_synth_query;
+int64_t orc_synth_scan(const orc_synth_query *q, int64_t *out_fields, int64_t *out_hist);
+
 #ifdef __cplusplus
 }
 #endif

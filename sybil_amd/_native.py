@@ -127,6 +127,7 @@ SIGNATURES = {
     "sybl_result_matched": (C.c_int64, [P]),
     "sybl_result_free": (None, [P]),
     "sybl_query_stats": (C.c_int, [P, C.POINTER(RunStats)]),
+    "sybl_debug_query_cells": (C.c_int, [P, C.c_int, C.c_int, P, C.c_int64, C.POINTER(C.c_int64)]),
     "sybl_result_render": (C.c_char_p, [P, C.c_int]),
     "sybl_result_encode": (C.c_void_p, [P, C.POINTER(C.c_int64)]),
 }

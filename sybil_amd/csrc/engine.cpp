@@ -121,11 +121,17 @@ static int scan(Query *q) {
         } else {
             SYBL_HIP(hipMemsetAsync(q->d_sum, 0, (size_t)kHeaderWords * 8, st));
         }
-        SYBL_HIP(hipMemsetAsync(q->d_cursor, 0, (size_t)q->eplan.n_parts * kCursorStride * 4, st));
         SYBL_HIP(hipEventRecord(q->ev[0], st));
         q->eplan.sum_out = q->d_sum;
         q->pplan.sum_out = q->d_sum;
         q->pplan.max_out = q->d_max;
+        // counting sort: count per (workgroup, partition) -> exact regions -> scatter
+        SYBL_HIP(hipMemsetAsync(q->eplan.part_tot, 0, (size_t)q->eplan.n_parts * 4, st));
+        e = q->part_packed ? launch_count_packed(q->eplan, q->part_nf, q->part_ng, q->n_wg, st)
+                           : launch_count(q->eplan, q->part_nf, q->part_ng, q->n_wg, st);
+        if (e != hipSuccess) return hip_fail(e, "k_count");
+        e = launch_part_offsets(q->eplan, st);
+        if (e != hipSuccess) return hip_fail(e, "k_part_offsets");
         e = q->part_packed ? launch_emit_packed(q->eplan, q->part_nf, q->part_ng, q->part_na, q->n_wg, st)
                            : launch_emit(q->eplan, q->part_nf, q->part_ng, q->part_na, q->n_wg, st);
         if (e != hipSuccess) return hip_fail(e, "k_emit");
@@ -331,6 +337,35 @@ int sybl_query_stats(sybl_query *q, sybl_run_stats *out) {
         q->stats.reduce_ms = b;
     }
     *out = q->stats;
+    return SYBL_OK;
+}
+
+int sybl_debug_query_cells(sybl_query *q, int which, int agg, int64_t *out, int64_t cap, int64_t *n_cells) {
+    if (!q || !out || !n_cells) return fail(SYBL_E_INVAL, "NULL argument");
+    if (!q->scanned || !q->h_sum || q->snapshot_pending) return fail(SYBL_E_STATE, "sybl_debug_query_cells: no finalized scan");
+    if (which < 0 || which > 3 || (which > 0 && (agg < 0 || agg >= (int)q->aggs.size()))) return fail(SYBL_E_INVAL, "bad field");
+    const ScanPlan &P = q->plan;
+    const int64_t ncell = P.n_cells, na = (int64_t)q->aggs.size();
+    const int64_t *F = q->h_sum + kHeaderWords;
+    *n_cells = ncell;
+    const int64_t n = std::min<int64_t>(cap, ncell);
+    if (which == 0) {
+        for (int64_t c = 0; c < n; c++) out[c] = F[c];
+        return SYBL_OK;
+    }
+    const AggDesc &A = q->aggs[(size_t)agg].d;
+    if (which == 1) {
+        for (int64_t c = 0; c < n; c++) out[c] = F[(int64_t)A.f_sum * ncell + c];
+        return SYBL_OK;
+    }
+    const int f = which == 2 ? A.f_sb : A.f_sb2;
+    if (f >= 0) {
+        for (int64_t c = 0; c < n; c++) out[c] = F[(int64_t)f * ncell + c];
+    } else if (q->hist_summary && q->h_mom && A.hist_full) {
+        for (int64_t c = 0; c < n; c++) out[c] = q->h_mom[(c * na + agg) * 2 + (which - 2)];
+    } else {
+        return fail(SYBL_E_STATE, "the query keeps no bucket moments");
+    }
     return SYBL_OK;
 }
 

@@ -743,75 +743,108 @@ hipError_t launch_remap_ids(const int32_t *local, const int32_t *lut, int32_t n_
 
 // ---------------------------------------------------------------- partitioned histograms
 // k_part_hist: one workgroup owns one partition = kPartCells (cell, agg) pairs.  Their bucket
-// arrays (uint32), counts and exact sums live in LDS; every record costs two or three LDS
-// atomics; the results are written with plain stores (each pair has exactly one owner), so the
-// [cell][agg][bucket] table, Count and sum(v) come out deterministic and atomics-free in HBM.
+// arrays (uint32) and exact remainder sums live in LDS; every record costs two LDS atomics (three
+// when a maximum is tracked); the results are written with plain stores (each pair has exactly one
+// owner), so the [cell][agg][bucket] table, Count and sum(v) come out deterministic and
+// atomics-free in HBM.  The partition buffer is whole 16-record chunks up to its cursor, padded
+// with kRecSentinel (scan_fast.h).
+constexpr int kPartSumRep = 8;   // replicas of the per-pair remainder sums (lanes of a wave hit only 32 pairs)
+constexpr int kPartUnroll = 4;   // 16-byte record loads per lane in flight, twice (current + next)
+
 __global__ __launch_bounds__(kWgThreads) void k_part_hist(const PartHistPlan P) {
     extern __shared__ uint32_t plds[];
     const uint32_t tid = threadIdx.x;
     const uint32_t nv = (uint32_t)P.nv_max;
     uint32_t *hist = plds;                                       // [kPartCells][nv]
     uint32_t *cnt = plds + kPartCells * nv;                      // [kPartCells]
-    unsigned long long *sum = (unsigned long long *)(cnt + kPartCells + (kPartCells & 1));  // [kPartCells]
-    long long *vmax = (long long *)(sum + kPartCells);           // [kPartCells]
+    unsigned long long *sum = (unsigned long long *)(cnt + kPartCells + (kPartCells & 1));  // [kPartSumRep][kPartCells]
+    long long *vmax = (long long *)(sum + kPartSumRep * kPartCells);                        // [kPartCells]
     for (uint32_t i = tid; i < kPartCells * nv; i += kWgThreads) hist[i] = 0;
+    if (tid < kPartSumRep * kPartCells) sum[tid] = 0;
     if (tid < kPartCells) {
         cnt[tid] = 0;
-        sum[tid] = 0;
         vmax[tid] = INT64_MIN;
     }
     __syncthreads();
 
     const uint32_t split = (uint32_t)P.split;
     const uint32_t part = blockIdx.x / split, sub = blockIdx.x % split;
-    const uint32_t n_all = P.cursor[part * kCursorStride];
-    const uint32_t i0 = (uint32_t)((uint64_t)n_all * sub / split), i1 = (uint32_t)((uint64_t)n_all * (sub + 1) / split);
-    const uint32_t *recs = P.recs + (int64_t)part * P.part_cap;
+    const uint32_t p0 = P.part_off[part], n_chunks = (P.part_off[part + 1] - p0) / kEmitChunk;
+    const uint32_t i0 = p0 + (uint32_t)((uint64_t)n_chunks * sub / split) * kEmitChunk;
+    const uint32_t i1 = p0 + (uint32_t)((uint64_t)n_chunks * (sub + 1) / split) * kEmitChunk;
+    const uint32_t *recs = P.recs;
     const uint32_t pair0 = part * kPartCells;
     const uint32_t rb = (uint32_t)P.rem_bits[0];  // equal for every aggregation (planner)
+    unsigned long long *my_sum = sum + (tid & (kPartSumRep - 1)) * kPartCells;
+    const bool track_max = P.m_max[0] >= 0 || (P.n_aggs > 1 && P.m_max[1] >= 0);
     auto add_record = [&](uint32_t rec) {
+        if (rec == kRecSentinel) return;
         const uint32_t rem = rec & ((1u << rb) - 1);
         const uint32_t b = (rec >> rb) & ((1u << kBucketBits) - 1);
         const uint32_t local = rec >> (rb + kBucketBits);
-        const uint32_t a = P.n_aggs == 1 ? 0u : (pair0 + local) % (uint32_t)P.n_aggs;
-        // (the pair's count is the sum of its buckets: taken at read-out, not with a third atomic per record)
+        // (the pair's count is the sum of its buckets and sum(b * BucketSize) follows from them: both are
+        // taken at read-out, only the remainders need an accumulator of their own)
         __hip_atomic_fetch_add(hist + local * nv + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        const unsigned long long off = (unsigned long long)b * (unsigned long long)P.bucket_size[a] + rem;
-        __hip_atomic_fetch_add(sum + local, off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (P.m_max[a] >= 0) {
-            const long long v = (long long)((unsigned long long)P.hmin[a] + off);
-            if (v > vmax[local]) __hip_atomic_fetch_max(vmax + local, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(my_sum + local, (unsigned long long)rem, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (track_max) {
+            const uint32_t a = P.n_aggs == 1 ? 0u : (pair0 + local) % (uint32_t)P.n_aggs;
+            if (P.m_max[a] >= 0) {
+                const long long v = (long long)((unsigned long long)P.hmin[a] + (unsigned long long)b * (unsigned long long)P.bucket_size[a] + rem);
+                if (v > vmax[local]) __hip_atomic_fetch_max(vmax + local, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
         }
     };
-    // Four records per lane and load, the next 16 bytes requested before these are consumed: with one
-    // 4-byte load per lane a CU had 4 KB in flight and the kernel ran at the latency, not the bandwidth.
+    // Four records per load and kPartUnroll loads per lane, the next round requested before this one is
+    // consumed: 128 KB in flight per CU (one 16-byte load per lane, 16 KB, ran at the latency: 1.4 TB/s).
     typedef unsigned int rec4 __attribute__((ext_vector_type(4)));
-    const uint32_t a0 = (i0 + 3u) & ~3u;                       // first 16-byte aligned record of the range
-    const uint32_t a1 = a0 <= i1 ? a0 + ((i1 - a0) & ~3u) : a0;  // end of the aligned body
-    for (uint32_t i = i0 + tid; i < (a0 < i1 ? a0 : i1); i += kWgThreads) add_record(recs[i]);
-    if (a0 < a1) {
-        uint32_t i = a0 + tid * 4u;
-        rec4 cur = {0, 0, 0, 0}, nxt = {0, 0, 0, 0};
-        if (i < a1) cur = __builtin_nontemporal_load((const rec4 *)(recs + i));
-        for (; i < a1; i += kWgThreads * 4u) {
-            const uint32_t ni = i + kWgThreads * 4u;
-            if (ni < a1) nxt = __builtin_nontemporal_load((const rec4 *)(recs + ni));
-            add_record(cur.x);
-            add_record(cur.y);
-            add_record(cur.z);
-            add_record(cur.w);
-            cur = nxt;
+    const rec4 none = {kRecSentinel, kRecSentinel, kRecSentinel, kRecSentinel};
+    constexpr uint32_t kStep = kWgThreads * 4u;  // records per load round of the workgroup
+    auto load4 = [&](uint32_t i) -> rec4 { return i < i1 ? __builtin_nontemporal_load((const rec4 *)(recs + i)) : none; };
+    rec4 cur[kPartUnroll], nxt[kPartUnroll];
+    uint32_t base = i0 + tid * 4u;
+#pragma unroll
+    for (int u = 0; u < kPartUnroll; u++) cur[u] = load4(base + (uint32_t)u * kStep);
+    for (; base < i1; base += kPartUnroll * kStep) {
+#pragma unroll
+        for (int u = 0; u < kPartUnroll; u++) nxt[u] = load4(base + (uint32_t)(kPartUnroll + u) * kStep);
+#pragma unroll
+        for (int u = 0; u < kPartUnroll; u++) {
+            add_record(cur[u].x);
+            add_record(cur[u].y);
+            add_record(cur[u].z);
+            add_record(cur[u].w);
+        }
+#pragma unroll
+        for (int u = 0; u < kPartUnroll; u++) cur[u] = nxt[u];
+    }
+    __syncthreads();
+    // cnt[l] = sum over the buckets of pair l, sum[0][l] += sum over the buckets of b * hist[l][b] * BucketSize:
+    // each wave sums a strided share, one LDS atomic per wave
+    for (uint32_t l = 0; l < (uint32_t)kPartCells; l++) {
+        const uint32_t a = P.n_aggs == 1 ? 0u : (pair0 + l) % (uint32_t)P.n_aggs;
+        uint32_t n = 0;
+        unsigned long long sb = 0;
+        for (uint32_t b = tid; b < nv; b += kWgThreads) {
+            const uint32_t x = hist[l * nv + b];
+            n += x;
+            sb += (unsigned long long)b * x;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            n += __shfl_xor(n, o, 64);
+            sb += __shfl_xor(sb, o, 64);
+        }
+        if ((tid & 63) == 0 && n) {
+            __hip_atomic_fetch_add(cnt + l, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(sum + l, sb * (unsigned long long)P.bucket_size[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
-    for (uint32_t k = a1 + tid; k < i1; k += kWgThreads) add_record(recs[k]);  // (< 4 records; none when a0 > i1)
     __syncthreads();
-    // cnt[l] = sum over the buckets of pair l: each wave sums a strided share, one LDS atomic per wave
-    for (uint32_t l = 0; l < (uint32_t)kPartCells; l++) {
-        uint32_t part = 0;
-        for (uint32_t b = tid; b < nv; b += kWgThreads) part += hist[l * nv + b];
+    if (tid < kPartCells) {
+        unsigned long long t = 0;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
-        if ((tid & 63) == 0 && part) __hip_atomic_fetch_add(cnt + l, part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        for (int r = 0; r < kPartSumRep; r++) t += sum[r * kPartCells + tid];
+        sum[tid] = t;
     }
     __syncthreads();
 
@@ -851,9 +884,63 @@ __global__ __launch_bounds__(kWgThreads) void k_part_hist(const PartHistPlan P) 
     }
 }
 
+// k_part_offsets: counts[workgroup][partition] -> the region of every workgroup in every partition buffer.
+// Partition buffers follow each other in `recs`; inside a partition the workgroups' regions follow each
+// other in workgroup order, each a whole number of chunks (emit_region_chunks).  k_count has already summed
+// every partition's chunks into part_tot.  A block owns 64 partitions (counts are read and regions written
+// coalesced along the partition axis); its four waves each walk a quarter of the workgroups.
+__global__ __launch_bounds__(256) void k_part_offsets(const EmitPlan E) {
+    __shared__ uint32_t red[4], excl[64], qs[4][64];
+    const uint32_t np = (uint32_t)E.n_parts, nw = (uint32_t)E.n_wg, nsub = 1u << E.sub_shift;
+    const uint32_t tid = threadIdx.x, tw = tid >> 6, tp = tid & 63, p0 = blockIdx.x * 64u, p = p0 + tp;
+    // chunks of all partitions before this block's
+    uint32_t acc = 0;
+    for (uint32_t j = tid; j < p0; j += 256) acc += E.part_tot[j];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (tp == 0) red[tw] = acc;
+    // exclusive scan of the block's own partitions (wave 0)
+    const uint32_t mine = p < np ? E.part_tot[p] : 0u;
+    if (tw == 0) {
+        uint32_t x = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = __shfl_up(x, o, 64);
+            if ((int)tp >= o) x += y;
+        }
+        excl[tp] = x - mine;
+    }
+    // this wave's quarter of the workgroups
+    const uint32_t q = (nw + 3) / 4, w0 = tw * q < nw ? tw * q : nw, w1 = w0 + q < nw ? w0 + q : nw;
+    uint32_t sum = 0;
+    if (p < np)
+        for (uint32_t w = w0; w < w1; w++) sum += emit_region_chunks(E.counts[(size_t)w * np + p], nsub);
+    qs[tw][tp] = sum;
+    __syncthreads();
+    if (p >= np) return;
+    const uint32_t base = red[0] + red[1] + red[2] + red[3] + excl[tp];
+    uint32_t at = base;
+    for (uint32_t t = 0; t < tw; t++) at += qs[t][tp];
+    at *= kEmitChunk;
+    for (uint32_t w = w0; w < w1; w++) {
+        E.woff[(size_t)w * np + p] = at;
+        at += emit_region_chunks(E.counts[(size_t)w * np + p], nsub) * kEmitChunk;
+        E.wend[(size_t)w * np + p] = at;
+    }
+    if (tw == 0) {
+        E.part_off[p] = base * kEmitChunk;
+        if (p == np - 1) E.part_off[np] = (base + mine) * kEmitChunk;
+    }
+}
+
+hipError_t launch_part_offsets(const EmitPlan &E, hipStream_t st) {
+    hipLaunchKernelGGL(k_part_offsets, dim3((unsigned)((E.n_parts + 63) / 64)), dim3(256), 0, st, E);
+    return hipGetLastError();
+}
+
 hipError_t launch_part_hist(const PartHistPlan &P, hipStream_t st) {
     if (P.n_parts <= 0) return hipSuccess;
-    size_t lds = ((size_t)kPartCells * P.nv_max + kPartCells + 2) * 4 + (size_t)kPartCells * 16 + 16;
+    size_t lds = ((size_t)kPartCells * P.nv_max + kPartCells + 2) * 4 + (size_t)kPartCells * (kPartSumRep + 1) * 8 + 16;
     hipError_t e = hipFuncSetAttribute((const void *)k_part_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_part_hist, dim3(P.n_parts * P.split), dim3(kWgThreads), lds, st, P);
@@ -865,34 +952,61 @@ hipError_t launch_part_hist(const PartHistPlan &P, hipStream_t st) {
 // the host and walking it there costs more than the scan.  These kernels derive what the result
 // rows need -- GetPercentiles (hist_basic.go:153-183), the bucket moments of GetStdDev
 // (:192-219) and the Cumulative bucket arrays (aggregate.go:422-438) -- where the table lives.
-// one thread per (cell, aggregation): the reference's loop, literally
+// One wave per (cell, aggregation); lanes own consecutive buckets, so the bucket array is read with
+// coalesced 512-byte wave loads (a thread per pair walking its own 8 KB row ran at 0.33 TB/s).
+// GetPercentiles in the reference walks the buckets k in order with the running count c(k),
+//   p(k) = clamp(100 c(k) / Count, 0, 100);  for ip in [p(k-1), p(k)]: out[ip] = k * BucketSize + Min (ip < 100);
+//   if p(k) < 100: out[p(k)] = k     -- overwritten by the next bucket's range, which starts at p(k)
+// so slot ip ends up with the value of the FIRST bucket whose p(k) exceeds ip: bucket k owns the slots
+// [p(k-1), p(k)) and those ranges are disjoint -- every lane writes its own.  What is left when the
+// last bucket stops short of 100 (Count larger than the bucket total) is the last iteration's
+// out[p] = k on slot p(n-1), and untouched zeros above it.
 __global__ __launch_bounds__(256) void k_hist_summary(const HistSummaryPlan S) {
-    const int64_t pair = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t pair = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (pair >= S.n_cells * S.n_aggs) return;
+    const uint32_t lane = threadIdx.x & 63;
     const int64_t cell = pair / S.n_aggs;
     const int a = (int)(pair - cell * S.n_aggs);
     const int64_t *v = S.H + cell * S.hist_stride + S.agg_off[a];
     const int64_t count = S.F[(int64_t)S.f_cnt[a] * S.n_cells + cell];
     int64_t *out = S.pct + pair * 100;
-    const int64_t bs = S.bucket_size[a], hmin = S.hmin[a];
-    int64_t sb = 0, sb2 = 0, c = 0, prev_p = 0;
-    if (count != 0) out[0] = hmin;
-    for (int64_t k = 0; k < S.n_values[a]; k++) {
-        const int64_t x = v[k];
+    const int64_t bs = S.bucket_size[a], hmin = S.hmin[a], nvals = S.n_values[a];
+    int64_t sb = 0, sb2 = 0, carry = 0, carry_p = 0;
+    for (int64_t k0 = 0; k0 < nvals; k0 += 64) {
+        const int64_t k = k0 + lane;
+        const int64_t x = k < nvals ? v[k] : 0;
         sb += k * x;
         sb2 += k * k * x;
         if (count == 0) continue;
-        c += x;
+        // inclusive scan of x over the wave
+        int64_t c = x;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int64_t y = __shfl_up(c, o, 64);
+            if ((int)lane >= o) c += y;
+        }
+        c += carry;
         int64_t p = (100 * c) / count;
         p = p < 0 ? 0 : (p > 100 ? 100 : p);
-        const int64_t val = k * bs + hmin;
-        for (int64_t ip = prev_p; ip <= p; ip++)
-            if (ip < 100) out[ip] = val;
-        if (p < 100) out[p] = k;
-        prev_p = p;
+        int64_t pp = __shfl_up(p, 1, 64);
+        if (lane == 0) pp = carry_p;
+        if (k < nvals) {
+            const int64_t val = k * bs + hmin;
+            for (int64_t ip = pp; ip < p; ip++) out[ip] = val;  // (p <= 100: ip < 100)
+            if (k == nvals - 1 && p < 100) out[p] = k;
+        }
+        carry = __shfl(c, 63, 64);
+        carry_p = __shfl(p, 63, 64);
     }
-    S.mom[pair * 2] = sb;
-    S.mom[pair * 2 + 1] = sb2;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        sb += __shfl_xor(sb, o, 64);
+        sb2 += __shfl_xor(sb2, o, 64);
+    }
+    if (lane == 0) {
+        S.mom[pair * 2] = sb;
+        S.mom[pair * 2 + 1] = sb2;
+    }
 }
 
 // total[w] = sum over cells of H[cell][w]: a block owns a range of cells, threads stride over the
@@ -920,7 +1034,7 @@ hipError_t launch_hist_summary(const HistSummaryPlan &S, int64_t *total, hipStre
     if (pairs <= 0) return hipSuccess;
     const int64_t cpb = 64;
     hipLaunchKernelGGL(k_hist_total, dim3((unsigned)((S.n_cells + cpb - 1) / cpb)), dim3(256), 0, st, S.H, S.hist_stride, S.n_cells, cpb, total);
-    hipLaunchKernelGGL(k_hist_summary, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, st, S);
+    hipLaunchKernelGGL(k_hist_summary, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, st, S);
     return hipGetLastError();
 }
 

@@ -3,6 +3,8 @@
 
 namespace sybl {
 
+hipError_t launch_count_nf0(const EmitPlan &E, int ng, int n_wg, hipStream_t st) { return count_launch_nf<0>(E, ng, n_wg, st); }
+
 hipError_t launch_emit_nf0(const EmitPlan &E, int ng, int na, int n_wg, hipStream_t st) {
     return emit_launch_nf<0>(E, ng, na, n_wg, st);
 }
@@ -21,6 +23,17 @@ hipError_t launch_scan_fast(const FastPlan &P, int nf, int ng, int na, int mode,
     case 2: return launch_scan_fast_nf2(P, ng, na, mode, time, gen, n_wg, lds_bytes, st);
     case 3: return launch_scan_fast_nf3(P, ng, na, mode, time, gen, n_wg, lds_bytes, st);
     case 4: return launch_scan_fast_nf4(P, ng, na, mode, time, gen, n_wg, lds_bytes, st);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_count(const EmitPlan &E, int nf, int ng, int n_wg, hipStream_t st) {
+    switch (nf) {
+    case 0: return launch_count_nf0(E, ng, n_wg, st);
+    case 1: return launch_count_nf1(E, ng, n_wg, st);
+    case 2: return launch_count_nf2(E, ng, n_wg, st);
+    case 3: return launch_count_nf3(E, ng, n_wg, st);
+    case 4: return launch_count_nf4(E, ng, n_wg, st);
     default: return hipErrorInvalidValue;
     }
 }

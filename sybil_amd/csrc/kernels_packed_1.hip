@@ -3,6 +3,8 @@
 
 namespace sybl {
 
+hipError_t launch_count_packed_nf1(const EmitPlan &E, int ng, int n_wg, hipStream_t st) { return count_packed_launch_nf<1>(E, ng, n_wg, st); }
+
 hipError_t launch_emit_packed_nf1(const EmitPlan &E, int ng, int na, int n_wg, hipStream_t st) {
     return emit_packed_launch_nf<1>(E, ng, na, n_wg, st);
 }

@@ -150,6 +150,7 @@ enum Header : int {
     kHdrMatched = 0,     // QuerySpec.MatchedCount
     kHdrOverflow = 1,    // rows whose key / bucket fell outside the declared bounds (must be 0)
     kHdrPartOverflow = 2, // partitioned histograms: records that did not fit their partition buffer
+    kHdrEmitStall = 3,    // partitioned histograms: a lane gave up waiting for a staging chunk (must be 0: a bug)
 };
 
 }  // namespace sybl

@@ -352,7 +352,6 @@ static int select_part_hist(Table *t, Query *q, const std::vector<int> &slot_col
     bool any_max, all_max, gen, packed = false;
     if (!fill_fast_columns(t, q, slot_col, E.fp, &nf, &ng, &na, &any_max, &all_max, false, &gen, &packed)) return SYBL_OK;
     q->part_packed = packed;
-    const int tile_rows = packed ? kPackedTileRows : kTileRows;
     int rb = 0;
     for (auto &ai : q->aggs) {
         if (ai.d.n_values > (1 << kBucketBits)) return SYBL_OK;
@@ -361,43 +360,51 @@ static int select_part_hist(Table *t, Query *q, const std::vector<int> &slot_col
         rb = std::max(rb, bits);
     }
     if (kPartCellBits + kBucketBits + rb > 32) return SYBL_OK;
+    // kRecSentinel (all ones) must not be a record: it would need local pair 31, bucket 1023 and every
+    // remainder bit set
+    if (kPartCellBits + kBucketBits + rb == 32)
+        for (auto &ai : q->aggs)
+            if (ai.d.n_values >= (1 << kBucketBits) && ai.d.bucket_size == ((int64_t)1 << rb)) return SYBL_OK;
     int64_t pairs = (int64_t)P.n_cells * na;
     int64_t n_parts = (pairs + kPartCells - 1) / kPartCells;
     if (n_parts > kMaxParts) return SYBL_OK;
-    // capacity: 1.5x the mean share of the worst case (every scanned row matches) + slack; a
-    // partition that still overflows makes finalize fall back to the atomic strategy
-    int64_t cap = rows_scanned * na / n_parts;
-    cap = (cap + cap / 2 + 8192 + 3) & ~(int64_t)3;  // (a multiple of 4: k_part_hist reads 16-byte aligned record quads)
-    if (cap >= ((int64_t)1 << 32)) return SYBL_OK;
-    size_t bytes = (size_t)n_parts * (size_t)cap * 4, free_b = 0, total_b = 0;
+    // Staging bins: a partition is spread over 1 << ss bins (a lane's bin follows from its lane number) so that
+    // few partitions do not serialise on a handful of LDS counters; fewer bins when a workgroup's share of
+    // the records would leave most of a bin's chunks padding.
+    const int64_t recs_all = rows_scanned * na;
+    const int64_t n_wg = std::max(1, q->n_wg);
+    int ss = 0;
+    while ((n_parts << (ss + 1)) <= kEmitMaxBins) ss++;
+    while (ss > 0 && recs_all / (n_wg * (n_parts << ss)) < 64) ss--;
+    // the partition buffers are sized exactly by k_count at scan time; this is their upper bound: every
+    // record + one partly filled chunk per (workgroup, bin).  Record indices are 32-bit.
+    const int64_t cap = recs_all + n_wg * (n_parts << ss) * (int64_t)kEmitChunk + kEmitChunk;
+    if (cap >= ((int64_t)1 << 32) - ((int64_t)1 << 22)) return SYBL_OK;
+    const size_t table_words = (size_t)n_wg * (size_t)n_parts;
+    size_t bytes = (size_t)cap * 4 + 3 * table_words * 4, free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || bytes + ((size_t)1 << 30) > free_b) return SYBL_OK;
-    SYBL_HIP(hipMalloc((void **)&q->d_recs, bytes));
-    SYBL_HIP(hipMalloc((void **)&q->d_cursor, (size_t)n_parts * kCursorStride * 4));
+    SYBL_HIP(hipMalloc((void **)&q->d_recs, (size_t)cap * 4));
+    // counts | woff | wend | part_off | part_tot in one allocation
+    SYBL_HIP(hipMalloc((void **)&q->d_cursor, (3 * table_words + 2 * (size_t)n_parts + 1) * 4));
     E.recs = q->d_recs;
-    E.cursor = q->d_cursor;
-    E.part_cap = cap;
+    E.counts = q->d_cursor;
+    E.woff = E.counts + table_words;
+    E.wend = E.woff + table_words;
+    E.part_off = E.wend + table_words;
+    E.part_tot = E.part_off + n_parts + 1;
     E.n_parts = (int32_t)n_parts;
     E.n_aggs = na;
+    E.n_wg = (int32_t)n_wg;
+    E.sub_shift = ss;
     {
-            // A handful of sub-bins per partition relieves same-address serialisation of the LDS
-        // counters when there are very few partitions; runs stay long (few cursor atomics).
-        int ss = 0;
-        while ((n_parts << ss) < 8) ss++;
-        int64_t bins = n_parts << ss;
-        E.sub_shift = ss;
-        E.slots = (int32_t)std::min<int64_t>(8191, std::max<int64_t>(15, (kEmitLdsWords - bins) / bins));
-        // records per bin per tile if every row matched
-        double per_tile = (double)tile_rows * na / (double)bins;
-        // (measured on config 4: 8.9 ms at 2 tiles between flushes, 9.5 at 1, 9.3 at 4)
-        int64_t period = (int64_t)((double)E.slots / ((packed ? 3.5 : 4.0) * std::max(per_tile, 0.25)));
-        if (const char *e = getenv("SYBL_EMIT_FLUSH_PERIOD")) period = atoi(e);
-        E.flush_period = (int32_t)std::min<int64_t>(8, std::max<int64_t>(1, period));
+        int rs = 0;
+        while ((1 << (rs + 1)) <= kCountRepMax && (n_parts << (rs + 1)) <= kMaxParts) rs++;
+        E.count_rep_shift = rs;
     }
     PartHistPlan &H = q->pplan;
     memset(&H, 0, sizeof(H));
     H.recs = q->d_recs;
-    H.cursor = q->d_cursor;
-    H.part_cap = cap;
+    H.part_off = E.part_off;
     H.n_parts = (int32_t)n_parts;
     H.n_aggs = na;
     H.n_cells = P.n_cells;

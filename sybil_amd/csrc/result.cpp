@@ -404,6 +404,8 @@ int query_finalize(Query *q, Result **out) {
     q->snapshot_pending = false;
     trace.mark("copy+sync");
     const int64_t *hs = q->h_sum, *hm = q->h_max;
+    if (hs[kHdrEmitStall] != 0)
+        return fail(SYBL_E_STATE, "k_emit: %lld records were dropped by a stalled staging bin (engine bug)", (long long)hs[kHdrEmitStall]);
     if (hs[kHdrPartOverflow] != 0 && q->part_hist) {
         int rc = query_rescan_without_part_hist(q);
         if (rc) return rc;

@@ -95,31 +95,44 @@ hipError_t launch_scan_fast(const FastPlan &P, int nf, int ng, int na, int mode,
 // PARTITION that owns the value's (cell, agg) pair -- kPartCells pairs per partition -- and
 // k_part_hist then lets one workgroup own a partition: its 32 bucket arrays, counts and sums
 // live in LDS, are updated with LDS atomics and are written out with plain stores.
+//
+// Records leave k_emit in CHUNKS of 16 (64 bytes, 64-byte aligned): round 1 flushed per-bin runs of ~9
+// records at arbitrary offsets behind one device-scope cursor atomic each and measured 112 M atomics and
+// 262 M write requests (77 % of them 32-byte partials, 10.3 GB written for 4 GB of records) per 1e9 rows.
+// Now the pass is a counting sort: k_count first counts every workgroup's records per partition (it reads
+// only the filter and key columns), k_part_offsets turns the counts into one exactly sized REGION per
+// (partition, workgroup) -- regions of a partition are contiguous, so k_part_hist reads one range -- and
+// k_emit stages one chunk per bin in LDS; the lane whose record completes a chunk copies it to the next
+// free chunk of its workgroup's region (an LDS cursor: no device-scope atomics, no overflow, the same
+// bytes in the same places on every run).  Partly filled chunks are padded with kRecSentinel.
 constexpr int kPartCells = 32;       // (cell, agg) pairs per partition
 constexpr int kPartCellBits = 5;
-constexpr int kBucketBits = 10;      // len(Values) <= 1002
-constexpr int kMaxParts = 2048;      // LDS staging in k_emit: n_parts x slots records
-constexpr int kCursorStride = 32;     // partition cursors sit on separate 128-byte lines
-constexpr int kEmitLdsWords = 32768; // 128 KB of staging: slots = (kEmitLdsWords - n_parts) / n_parts, 15..1023
+constexpr int kBucketBits = 10;      // len(Values) <= 1024
+constexpr int kMaxParts = 2048;      // LDS staging in k_emit: one 16-record chunk per bin
+constexpr int kEmitMaxBins = 2048;   // bins = n_parts << sub_shift
+constexpr uint32_t kEmitChunk = 16;  // records per chunk
+constexpr int kEmitBinWords = 2 + (int)kEmitChunk;  // LDS words per bin: cnt, wr + the chunk (+ one cursor per partition)
+constexpr uint32_t kRecSentinel = 0xFFFFFFFFu;      // padding record (never a real one: planner)
+constexpr int kCountRepMax = 8;      // k_count: replicas of the LDS counters when there are few partitions
 
 struct EmitPlan {
     FastPlan fp;                     // columns, filters, group mapping, hmin / bucket geometry
-    uint32_t *recs;                  // [n_parts][part_cap] records
-    uint32_t *cursor;                // [n_parts] records written
-    int64_t part_cap;
-    int32_t n_parts, n_aggs;
-    int32_t slots;                   // LDS staging slots per bin
+    uint32_t *recs;                  // the partition buffers, back to back (part_off)
+    uint32_t *counts;                // [n_wg][n_parts] records per (workgroup, partition): k_count
+    uint32_t *woff, *wend;           // [n_wg][n_parts] region of a workgroup in a partition buffer (record indices into recs)
+    uint32_t *part_off;              // [n_parts + 1] partition buffers in recs (record indices, multiples of kEmitChunk)
+    uint32_t *part_tot;              // [n_parts] chunks of a partition buffer: summed by k_count (zeroed before)
+    int32_t n_parts, n_aggs, n_wg;
     int32_t sub_shift;               // bins per partition = 1 << sub_shift (lanes spread over them so that
                                      // few partitions do not serialise on one LDS counter)
-    int32_t flush_period;            // tiles between flushes of the staging bins
+    int32_t count_rep_shift;         // k_count: 1 << count_rep_shift replicas of the partition counters
     int32_t rem_bits[kFastMaxA];     // bits of (v - hmin) % BucketSize kept in the record
-    int64_t *sum_out;                // header: matched / overflow / partition overflow
+    int64_t *sum_out;                // header: matched / overflow
 };
 
 struct PartHistPlan {
     const uint32_t *recs;
-    const uint32_t *cursor;
-    int64_t part_cap;
+    const uint32_t *part_off;
     int32_t n_parts, n_aggs, n_cells, nv_max;
     int32_t split;                   // workgroups per partition (> 1: results are combined with atomics)
     int32_t rem_bits[kFastMaxA], n_values[kFastMaxA], f_sum[kFastMaxA], m_max[kFastMaxA];
@@ -128,6 +141,20 @@ struct PartHistPlan {
     int64_t *sum_out, *max_out;
 };
 
+// tiles of column loads a lane keeps in flight: a tile is only 8..16 bytes per column and lane, and a CU needs
+// ~64 KB on the way to keep HBM busy; bounded by registers (one 16-byte register quad per column and tile)
+constexpr int emit_depth(int n_cols) { return n_cols <= 2 ? 4 : n_cols <= 4 ? 2 : 1; }
+constexpr int count_depth(int n_cols) { return n_cols <= 1 ? 8 : n_cols <= 2 ? 4 : n_cols <= 4 ? 2 : 1; }
+inline size_t emit_lds_bytes(const EmitPlan &E) { return (((size_t)E.n_parts << E.sub_shift) * kEmitBinWords + (size_t)E.n_parts) * 4; }
+inline size_t count_lds_bytes(const EmitPlan &E) { return ((size_t)E.n_parts << E.count_rep_shift) * 4; }
+// chunks a (workgroup, partition) region needs for c records spread over nsub bins
+__host__ __device__ inline uint32_t emit_region_chunks(uint32_t c, uint32_t nsub) {
+    return nsub == 1 ? (c + kEmitChunk - 1) / kEmitChunk : c / kEmitChunk + (c < nsub ? c : nsub);
+}
+
+hipError_t launch_count(const EmitPlan &P, int nf, int ng, int n_wg, hipStream_t st);
+hipError_t launch_count_packed(const EmitPlan &P, int nf, int ng, int n_wg, hipStream_t st);
+hipError_t launch_part_offsets(const EmitPlan &P, hipStream_t st);
 hipError_t launch_emit(const EmitPlan &P, int nf, int ng, int na, int n_wg, hipStream_t st);
 hipError_t launch_part_hist(const PartHistPlan &P, hipStream_t st);
 
@@ -524,92 +551,170 @@ __global__ __launch_bounds__(kWgThreads, 4) void k_scan_fast(const FastPlan P) {
 }
 
 // k_emit: filters + cell index exactly as k_scan_fast, but instead of accumulating it appends
-// rec = (local pair << 10 | bucket) << rem_bits | remainder to the owning partition.  Records are
-// staged in LDS bins (E.slots per partition) and flushed in runs so that the global cursor
-// sees one atomic per run instead of one per record.
-// LDS staging of k_emit / k_emit_packed: bin_cnt[np] counters + bins[np][slots] records, np =
-// n_parts << sub_shift bins.
+// rec = (local pair << 10 | bucket) << rem_bits | remainder to the owning partition.
+//
+// LDS staging of k_emit / k_emit_packed, per bin (nb = n_parts << sub_shift bins):
+//   cnt   records pushed so far: a push takes slot s = cnt++, generation g = s / 16
+//   wr    17 * (generations written out) + records of the current generation in place: the
+//         generation-g record may be written once wr >= 17 g (generation g - 1 is out of the chunk),
+//         each writer then bumps wr, and the one that finds 17 g + 15 owns the complete chunk: it
+//         copies it to the partition buffer and bumps wr once more (-> 17 (g + 1))
+//   chunk 16 records; a record's place is rotated by bin / 2 so bins that fill in step spread over
+//         the LDS banks (the order of records inside a chunk is immaterial)
+// and per partition `pos`: the next free chunk of this workgroup's region.
+// There is no workgroup barrier between the prologue and the final drain: waves run free, a wave
+// only ever waits (re-polls wr) for a chunk that another lane is about to write out.  Every lane that
+// holds a slot is inside emit_push_all and retries all its pending records on every pass, and the
+// oldest incomplete generation of a bin can always be written, so the protocol cannot deadlock.
 struct EmitLds {
-    uint32_t *bin_cnt, *bins;
-    uint32_t np, slots, ss, sub;
+    uint32_t *cnt, *wr, *pos, *chunk;
+    uint32_t nb, ss, sub;
 };
 
 __device__ __forceinline__ EmitLds emit_begin(const EmitPlan &E, uint32_t *elds) {
     EmitLds S;
     const uint32_t tid = threadIdx.x;
     S.ss = (uint32_t)E.sub_shift;
-    S.np = (uint32_t)E.n_parts << S.ss;     // staging bins
+    S.nb = (uint32_t)E.n_parts << S.ss;      // staging bins
     S.sub = tid & ((1u << S.ss) - 1);        // this lane's sub-bin
-    S.slots = (uint32_t)E.slots;
-    S.bin_cnt = elds;                        // [np]
-    S.bins = elds + S.np;                    // [np][slots]
-    for (uint32_t i = tid; i < S.np; i += kWgThreads) S.bin_cnt[i] = 0;
+    S.chunk = elds;                          // [nb][16]  (64-byte aligned rows)
+    S.cnt = elds + S.nb * kEmitChunk;        // [nb]
+    S.wr = S.cnt + S.nb;                     // [nb]
+    S.pos = S.wr + S.nb;                     // [n_parts]
+    for (uint32_t i = tid; i < 2 * S.nb; i += kWgThreads) S.cnt[i] = 0;
+    const uint32_t *woff = E.woff + (size_t)blockIdx.x * (uint32_t)E.n_parts;
+    for (uint32_t i = tid; i < (uint32_t)E.n_parts; i += kWgThreads) S.pos[i] = woff[i];
     __syncthreads();
     return S;
 }
 
-// Flushes every bin holding >= min_fill records as ONE run: a single cursor bump, then a
-// contiguous copy.  Small bins (many partitions) are copied by one thread each; big bins (few
-// partitions) by a whole wave so the copy is coalesced.
-__device__ __forceinline__ void emit_flush(const EmitPlan &E, const EmitLds &S, uint32_t min_fill) {
-    const uint32_t tid = threadIdx.x, np = S.np, slots = S.slots, ss = S.ss;
-    uint32_t *bin_cnt = S.bin_cnt, *bins = S.bins;
-    if (slots <= 32) {
-        for (uint32_t p = tid; p < np; p += kWgThreads) {
-            uint32_t n = bin_cnt[p];
-            if (n > slots) n = slots;
-            if (n == 0 || n < min_fill) continue;
-            const uint32_t pos = __hip_atomic_fetch_add(E.cursor + (p >> ss) * kCursorStride, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((int64_t)pos + n <= E.part_cap) {
-                uint32_t *dst = E.recs + (int64_t)(p >> ss) * E.part_cap + pos;
-                for (uint32_t k = 0; k < n; k++) dst[k] = bins[p * slots + k];
-            } else {
-                __hip_atomic_fetch_add(E.sum_out + kHdrPartOverflow, (int64_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            bin_cnt[p] = 0;
+// Writes one chunk (16 records, 64 bytes) of `bin` to the workgroup's region of its partition.
+__device__ __forceinline__ void emit_store_chunk(const EmitPlan &E, const EmitLds &S, uint32_t p, const fu32x4 &r0, const fu32x4 &r1,
+                                                 const fu32x4 &r2, const fu32x4 &r3) {
+    fu32x4 *dst = (fu32x4 *)(E.recs + p);
+    dst[0] = r0;
+    dst[1] = r1;
+    dst[2] = r2;
+    dst[3] = r3;
+}
+
+// bin numbers (< 2^16) of a lane's records packed four to a 64-bit word, so that picking the bin of record i
+// is a shift: indexing the register array with a run-time i sent it to scratch memory (a VMEM round trip
+// and a vmcnt(0) wait per chunk)
+template <int N>
+struct EmitBinPack {
+    unsigned long long w[(N + 3) / 4];
+    __device__ __forceinline__ explicit EmitBinPack(const uint32_t (&bin)[N]) {
+#pragma unroll
+        for (int k = 0; k < (N + 3) / 4; k++) w[k] = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) w[i / 4] |= (unsigned long long)(bin[i] & 0xFFFFu) << (16 * (i % 4));
+    }
+    __device__ __forceinline__ uint32_t get(uint32_t i) const {
+        unsigned long long x = w[0];
+        if (N > 4) x = i >= 4 ? w[(N + 3) / 4 - 1] : x;
+        static_assert(N <= 8, "at most eight records per lane and tile");
+        return (uint32_t)(x >> (16 * (i & 3))) & 0xFFFFu;
+    }
+};
+
+// LDS operations of a wave are carried out in issue order, so ordering two of them only takes keeping the
+// compiler from moving them and -- where a returned value gates the next step -- the wait for the LDS
+// counter.  A workgroup-scope fence would also wait for vmcnt(0), i.e. for the prefetched column loads:
+// measured, it made every tile pay the full HBM latency.
+__device__ __forceinline__ void lds_order() { __atomic_signal_fence(__ATOMIC_SEQ_CST); }  // compiler-only
+__device__ __forceinline__ void lds_wait() {
+    lds_order();
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // gfx9 encoding of lgkmcnt(0) alone (vmcnt / expcnt fields at their maxima)
+    lds_order();
+}
+
+// Pushes the lane's records i with bit i of `act` set: rec[i] into bin[i].
+template <int N>
+__device__ __forceinline__ void emit_push_all(const EmitPlan &E, const EmitLds &S, const uint32_t (&bin)[N], const uint32_t (&rec)[N],
+                                              uint32_t act) {
+    uint32_t slot[N];
+#pragma unroll
+    for (int i = 0; i < N; i++)
+        slot[i] = (act >> i) & 1u ? __hip_atomic_fetch_add(S.cnt + bin[i], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
+    uint32_t pend = act, passes = 0;
+    while (pend) {
+        // (bounded: a protocol bug must surface as an error from finalize, not as a hung GPU)
+        if (++passes > (1u << 22)) {
+            __hip_atomic_fetch_add(E.sum_out + kHdrEmitStall, (int64_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
         }
-    } else {
-        const uint32_t lane = tid & 63, wave = tid >> 6;
-        for (uint32_t p = wave; p < np; p += kWgThreads / 64) {
-            uint32_t n = bin_cnt[p];
-            if (n > slots) n = slots;
-            if (n == 0 || n < min_fill) continue;  // wave-uniform
-            uint32_t pos = 0;
-            if (lane == 0) pos = __hip_atomic_fetch_add(E.cursor + (p >> ss) * kCursorStride, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            pos = __shfl(pos, 0, 64);
-            if ((int64_t)pos + n <= E.part_cap) {
-                uint32_t *dst = E.recs + (int64_t)(p >> ss) * E.part_cap + pos;
-                for (uint32_t k = lane; k < n; k += 64) dst[k] = bins[p * slots + k];
-            } else if (lane == 0) {
-                __hip_atomic_fetch_add(E.sum_out + kHdrPartOverflow, (int64_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t w[N];
+#pragma unroll
+        for (int i = 0; i < N; i++)
+            w[i] = (pend >> i) & 1u ? __hip_atomic_load(S.wr + bin[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
+        lds_order();
+        uint32_t ok = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            if (((pend >> i) & 1u) && w[i] >= 17u * (slot[i] >> 4)) {
+                S.chunk[bin[i] * kEmitChunk + ((slot[i] + (bin[i] >> 1)) & (kEmitChunk - 1))] = rec[i];
+                ok |= 1u << i;
             }
-            if (lane == 0) bin_cnt[p] = 0;
         }
+        lds_order();  // the records go to LDS before wr says so (issue order)
+        uint32_t old[N];
+#pragma unroll
+        for (int i = 0; i < N; i++)
+            old[i] = (ok >> i) & 1u ? __hip_atomic_fetch_add(S.wr + bin[i], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
+        uint32_t full = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++)
+            full |= ((ok >> i) & 1u) && old[i] == 17u * (slot[i] >> 4) + (kEmitChunk - 1) ? 1u << i : 0u;
+        lds_order();  // the chunk is read after wr showed the other 15 records in place
+        // complete chunks: a lane rarely owns more than one per tile, so loop over the lane's own
+        // instead of running the copy once per record position
+        const EmitBinPack<N> packed_bins(bin);
+        while (full) {
+            const uint32_t i = (uint32_t)__builtin_ctz(full);
+            full &= full - 1;
+            const uint32_t b = packed_bins.get(i);
+            const uint32_t p = __hip_atomic_fetch_add(S.pos + (b >> S.ss), kEmitChunk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const fu32x4 *c = (const fu32x4 *)(S.chunk + b * kEmitChunk);
+            const fu32x4 r0 = c[0], r1 = c[1], r2 = c[2], r3 = c[3];
+            emit_store_chunk(E, S, p, r0, r1, r2, r3);
+            lds_wait();  // the chunk has been read before the next generation may write
+            __hip_atomic_fetch_add(S.wr + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        pend &= ~ok;
     }
 }
 
-// One record for (cell, aggregation c) with bucket b and remainder rem: staged in the lane's
-// sub-bin of the owning partition, or appended directly when the bin is full until the next flush.
-__device__ __forceinline__ void emit_push(const EmitPlan &E, const EmitLds &S, uint32_t pair, uint32_t b, uint32_t rem, int rem_bits) {
-    const uint32_t part = pair >> kPartCellBits;
-    const uint32_t rec = ((((pair & (kPartCells - 1)) << kBucketBits) | b) << rem_bits) | rem;
-    const uint32_t bin = (part << S.ss) | S.sub;
-    const uint32_t slot = __hip_atomic_fetch_add(S.bin_cnt + bin, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    if (slot < S.slots) {
-        S.bins[bin * S.slots + slot] = rec;
-    } else {
-        const uint32_t pos = __hip_atomic_fetch_add(E.cursor + part * kCursorStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((int64_t)pos < E.part_cap) {
-            E.recs[(int64_t)part * E.part_cap + pos] = rec;
-        } else {
-            __hip_atomic_fetch_add(E.sum_out + kHdrPartOverflow, (int64_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
+__device__ __forceinline__ uint32_t emit_record(uint32_t pair, uint32_t b, uint32_t rem, int rem_bits) {
+    return ((((pair & (kPartCells - 1)) << kBucketBits) | b) << rem_bits) | rem;
 }
+__device__ __forceinline__ uint32_t emit_bin(const EmitLds &S, uint32_t pair) { return ((pair >> kPartCellBits) << S.ss) | S.sub; }
 
+// Final drain: every bin's incomplete chunk goes out padded with sentinels, and so do the chunks of the
+// workgroup's regions that were provisioned for partly filled sub-bins but not needed.
 __device__ __forceinline__ void emit_finish(const EmitPlan &E, const EmitLds &S, uint32_t matched, uint32_t overflow) {
     __syncthreads();
-    emit_flush(E, S, 1);
+    const fu32x4 pad = {kRecSentinel, kRecSentinel, kRecSentinel, kRecSentinel};
+    for (uint32_t bin = threadIdx.x; bin < S.nb; bin += kWgThreads) {
+        const uint32_t left = S.cnt[bin] & (kEmitChunk - 1);
+        if (left) {
+            uint32_t r[kEmitChunk];
+#pragma unroll
+            for (uint32_t k = 0; k < kEmitChunk; k++) {
+                // the record in place k was pushed as number (k - rotation) mod 16 of its generation
+                const uint32_t logical = (k - (bin >> 1)) & (kEmitChunk - 1);
+                r[k] = logical < left ? S.chunk[bin * kEmitChunk + k] : kRecSentinel;
+            }
+            const fu32x4 r0 = {r[0], r[1], r[2], r[3]}, r1 = {r[4], r[5], r[6], r[7]}, r2 = {r[8], r[9], r[10], r[11]},
+                         r3 = {r[12], r[13], r[14], r[15]};
+            const uint32_t p = __hip_atomic_fetch_add(S.pos + (bin >> S.ss), kEmitChunk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            emit_store_chunk(E, S, p, r0, r1, r2, r3);
+        }
+    }
+    __syncthreads();
+    const uint32_t *wend = E.wend + (size_t)blockIdx.x * (uint32_t)E.n_parts;
+    for (uint32_t part = threadIdx.x; part < (uint32_t)E.n_parts; part += kWgThreads)
+        for (uint32_t p = S.pos[part]; p < wend[part]; p += kEmitChunk) emit_store_chunk(E, S, p, pad, pad, pad, pad);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         matched += __shfl_xor(matched, o, 64);
@@ -619,6 +724,81 @@ __device__ __forceinline__ void emit_finish(const EmitPlan &E, const EmitLds &S,
         if (matched) __hip_atomic_fetch_add(E.sum_out + kHdrMatched, (int64_t)matched, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (overflow) __hip_atomic_fetch_add(E.sum_out + kHdrOverflow, (int64_t)overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+}
+
+// k_count: the first pass of the counting sort -- the same rows, filters and cell computation as k_emit
+// for the same workgroup, but only the filter and key columns are read and a workgroup's records are
+// only counted per partition: counts[workgroup][partition].
+__device__ __forceinline__ uint32_t *count_begin(const EmitPlan &E, uint32_t *clds) {
+    const uint32_t n = (uint32_t)E.n_parts << E.count_rep_shift;
+    for (uint32_t i = threadIdx.x; i < n; i += kWgThreads) clds[i] = 0;
+    __syncthreads();
+    return clds + (threadIdx.x & ((1u << E.count_rep_shift) - 1)) * (uint32_t)E.n_parts;  // this lane's replica
+}
+__device__ __forceinline__ void count_finish(const EmitPlan &E, const uint32_t *clds) {
+    __syncthreads();
+    uint32_t *out = E.counts + (size_t)blockIdx.x * (uint32_t)E.n_parts;
+    for (uint32_t p = threadIdx.x; p < (uint32_t)E.n_parts; p += kWgThreads) {
+        uint32_t n = 0;
+        for (uint32_t r = 0; r < (1u << E.count_rep_shift); r++) n += clds[r * (uint32_t)E.n_parts + p];
+        out[p] = n;
+        const uint32_t chunks = emit_region_chunks(n, 1u << E.sub_shift);
+        if (chunks) __hip_atomic_fetch_add(E.part_tot + p, chunks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+template <int NF, int NG>
+__global__ __launch_bounds__(kWgThreads, 4) void k_count(const EmitPlan E) {
+    extern __shared__ uint32_t elds[];
+    const FastPlan &P = E.fp;
+    const uint32_t tid = threadIdx.x;
+    uint32_t *mine = count_begin(E, elds);
+    const uint32_t na = (uint32_t)E.n_aggs;
+    const int s0 = P.wg_seg_begin[blockIdx.x], s1 = P.wg_seg_begin[blockIdx.x + 1];
+    for (int si = s0; si < s1; si++) {
+        const Segment seg = P.segs[si];
+        const int64_t end = seg.start + seg.n;
+        const int64_t n_tiles = (seg.n + kTileRows - 1) / kTileRows;
+        const int64_t row_first = seg.start + (int64_t)tid * kRowsPerThread;
+        constexpr int D = count_depth(NF + NG);
+        FastTile<NF> fr[D];
+        FastTile<NG> gr[D];
+        FastTile<0> a0;
+        FastTile<1> t0;
+#pragma unroll
+        for (int d = 0; d < D; d++)
+            if (row_first + (int64_t)d * kTileRows < end) fast_load<NF, NG, 0, false>(P, row_first + (int64_t)d * kTileRows, fr[d], gr[d], a0, t0);
+        for (int64_t it0 = 0; it0 < n_tiles; it0 += D) {
+#pragma unroll
+          for (int d = 0; d < D; d++) {
+            if (it0 + d >= n_tiles) break;
+            const int64_t row = row_first + (it0 + d) * kTileRows;
+            const FastTile<NF> f0 = fr[d];
+            const FastTile<NG> g0 = gr[d];
+            if (row + (int64_t)D * kTileRows < end) fast_load<NF, NG, 0, false>(P, row + (int64_t)D * kTileRows, fr[d], gr[d], a0, t0);
+#pragma unroll
+            for (int r = 0; r < kRowsPerThread; r++) {
+                bool pass = row + r < end;
+#pragma unroll
+                for (int c = 0; c < NF; c++) {
+                    const int64_t x = r == 0 ? f0.v[c].x : f0.v[c].y;
+                    pass = pass && x >= P.lo[c] && x <= P.hi[c];
+                }
+                uint32_t cell = 0;
+#pragma unroll
+                for (int c = 0; c < NG; c++) {
+                    const int64_t x = r == 0 ? g0.v[c].x : g0.v[c].y;
+                    const uint64_t d = (uint64_t)x - (uint64_t)P.gmin[c];
+                    pass = pass && d < (uint64_t)P.gcard[c];
+                    cell += (uint32_t)d * (uint32_t)P.gstride[c];
+                }
+                // the row's records (one per aggregation) are consecutive pairs of one partition: kPartCells is even
+                if (pass) __hip_atomic_fetch_add(mine + ((cell * na) >> kPartCellBits), na, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+          }
+        }
+    }
+    count_finish(E, elds);
 }
 
 template <int NF, int NG, int NA>
@@ -633,28 +813,35 @@ __global__ __launch_bounds__(kWgThreads, 4) void k_emit(const EmitPlan E) {
     for (int si = s0; si < s1; si++) {
         const Segment seg = P.segs[si];
         const int64_t end = seg.start + seg.n;
-        // every thread runs the same number of tiles so the barriers line up
         const int64_t n_tiles = (seg.n + kTileRows - 1) / kTileRows;
-        int64_t row = seg.start + (int64_t)tid * kRowsPerThread;
-        FastTile<NF> f0, f1;
-        FastTile<NG> g0, g1;
-        FastTile<NA> a0, a1;
+        const int64_t row_first = seg.start + (int64_t)tid * kRowsPerThread;
+        // D tiles of loads in flight per lane (narrow queries move few bytes per tile)
+        constexpr int D = emit_depth(NF + NG + NA);
+        FastTile<NF> fr[D];
+        FastTile<NG> gr[D];
+        FastTile<NA> ar[D];
         FastTile<1> t0;
-        if (row < end) fast_load<NF, NG, NA, false>(P, row, f0, g0, a0, t0);
-        for (int64_t it = 0; it < n_tiles; it++, row += kTileRows) {
-            const int64_t nrow = row + kTileRows;
-            if (nrow < end) fast_load<NF, NG, NA, false>(P, nrow, f1, g1, a1, t0);
+#pragma unroll
+        for (int d = 0; d < D; d++)
+            if (row_first + (int64_t)d * kTileRows < end) fast_load<NF, NG, NA, false>(P, row_first + (int64_t)d * kTileRows, fr[d], gr[d], ar[d], t0);
+        for (int64_t it0 = 0; it0 < n_tiles; it0 += D) {
+#pragma unroll
+          for (int d = 0; d < D; d++) {
+            if (it0 + d >= n_tiles) break;
+            const int64_t row = row_first + (it0 + d) * kTileRows;
+            const FastTile<NF> f0 = fr[d];
+            const FastTile<NG> g0 = gr[d];
+            const FastTile<NA> a0 = ar[d];
+            if (row + (int64_t)D * kTileRows < end) fast_load<NF, NG, NA, false>(P, row + (int64_t)D * kTileRows, fr[d], gr[d], ar[d], t0);
+            uint32_t bin[kRowsPerThread * NA], rec[kRowsPerThread * NA], act = 0;
 #pragma unroll
             for (int r = 0; r < kRowsPerThread; r++) {
-                if (row + r >= end) break;
-                bool pass = true;
+                bool pass = row + r < end;
 #pragma unroll
                 for (int c = 0; c < NF; c++) {
                     const int64_t x = r == 0 ? f0.v[c].x : f0.v[c].y;
                     pass = pass && x >= P.lo[c] && x <= P.hi[c];
                 }
-                if (!pass) continue;
-                matched += 1;
                 uint32_t cell = 0;
                 bool inb = true;
 #pragma unroll
@@ -664,10 +851,8 @@ __global__ __launch_bounds__(kWgThreads, 4) void k_emit(const EmitPlan E) {
                     inb = inb && d < (uint64_t)P.gcard[c];
                     cell += (uint32_t)d * (uint32_t)P.gstride[c];
                 }
-                if (!inb) {
-                    overflow += 1;
-                    continue;
-                }
+                matched += pass ? 1u : 0u;
+                overflow += (pass && !inb) ? 1u : 0u;
 #pragma unroll
                 for (int c = 0; c < NA; c++) {
                     const int64_t x = r == 0 ? a0.v[c].x : a0.v[c].y;
@@ -681,27 +866,34 @@ __global__ __launch_bounds__(kWgThreads, 4) void k_emit(const EmitPlan E) {
                         b += 1;
                         rem -= (int32_t)P.bucket_size[c];
                     }
-                    emit_push(E, S, cell * (uint32_t)NA + (uint32_t)c, b, (uint32_t)rem, E.rem_bits[c]);
+                    const uint32_t pair = cell * (uint32_t)NA + (uint32_t)c;
+                    bin[r * NA + c] = emit_bin(S, pair);
+                    rec[r * NA + c] = emit_record(pair, b, (uint32_t)rem, E.rem_bits[c]);
+                    act |= (pass && inb) ? 1u << (r * NA + c) : 0u;
                 }
             }
-            f0 = f1;
-            g0 = g1;
-            a0 = a1;
-            // bins fill at ~tile_records / n_parts per tile: flush (two barriers) only every
-            // flush_period tiles; a bin that fills up earlier spills record by record
-            if ((it + 1) % E.flush_period == 0 || it + 1 == n_tiles) {
-                __syncthreads();
-                emit_flush(E, S, S.slots / 2);
-                __syncthreads();
-            }
+            emit_push_all<kRowsPerThread * NA>(E, S, bin, rec, act);
+          }
         }
     }
     emit_finish(E, S, matched, overflow);
 }
 
 template <int NF>
+static hipError_t count_launch_nf(const EmitPlan &E, int ng, int n_wg, hipStream_t st) {
+    const size_t lds = count_lds_bytes(E);
+    switch (ng) {
+    case 0: hipLaunchKernelGGL((k_count<NF, 0>), dim3(n_wg), dim3(kWgThreads), lds, st, E); break;
+    case 1: hipLaunchKernelGGL((k_count<NF, 1>), dim3(n_wg), dim3(kWgThreads), lds, st, E); break;
+    case 2: hipLaunchKernelGGL((k_count<NF, 2>), dim3(n_wg), dim3(kWgThreads), lds, st, E); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+template <int NF>
 static hipError_t emit_launch_nf(const EmitPlan &E, int ng, int na, int n_wg, hipStream_t st) {
-    const size_t lds = ((size_t)E.n_parts << E.sub_shift) * (1 + (size_t)E.slots) * 4;
+    const size_t lds = emit_lds_bytes(E);
 #define SYBL_EMIT_CASE(G, A)                                                                               \
     case (G)*3 + (A): {                                                                                    \
         auto k = k_emit<NF, G, A>;                                                                         \
@@ -772,6 +964,11 @@ static hipError_t fast_launch_nf(const FastPlan &P, int ng, int na, int mode, bo
 #endif  // __HIPCC__
 
 // per-NF entry points (kernels_fast_<NF>.hip)
+hipError_t launch_count_nf0(const EmitPlan &E, int ng, int n_wg, hipStream_t st);
+hipError_t launch_count_nf1(const EmitPlan &E, int ng, int n_wg, hipStream_t st);
+hipError_t launch_count_nf2(const EmitPlan &E, int ng, int n_wg, hipStream_t st);
+hipError_t launch_count_nf3(const EmitPlan &E, int ng, int n_wg, hipStream_t st);
+hipError_t launch_count_nf4(const EmitPlan &E, int ng, int n_wg, hipStream_t st);
 hipError_t launch_emit_nf0(const EmitPlan &E, int ng, int na, int n_wg, hipStream_t st);
 hipError_t launch_emit_nf1(const EmitPlan &E, int ng, int na, int n_wg, hipStream_t st);
 hipError_t launch_emit_nf2(const EmitPlan &E, int ng, int na, int n_wg, hipStream_t st);

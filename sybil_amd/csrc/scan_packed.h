@@ -23,6 +23,11 @@ constexpr int kPackedTileRows = kWgThreads * kPackedRows;
 hipError_t launch_scan_packed(const FastPlan &P, int nf, int ng, int na, int mode, bool time, int n_wg, size_t lds_bytes,
                               hipStream_t st);
 hipError_t launch_emit_packed(const EmitPlan &E, int nf, int ng, int na, int n_wg, hipStream_t st);
+hipError_t launch_count_packed_nf0(const EmitPlan &E, int ng, int n_wg, hipStream_t st);
+hipError_t launch_count_packed_nf1(const EmitPlan &E, int ng, int n_wg, hipStream_t st);
+hipError_t launch_count_packed_nf2(const EmitPlan &E, int ng, int n_wg, hipStream_t st);
+hipError_t launch_count_packed_nf3(const EmitPlan &E, int ng, int n_wg, hipStream_t st);
+hipError_t launch_count_packed_nf4(const EmitPlan &E, int ng, int n_wg, hipStream_t st);
 hipError_t launch_emit_packed_nf0(const EmitPlan &E, int ng, int na, int n_wg, hipStream_t st);
 hipError_t launch_emit_packed_nf1(const EmitPlan &E, int ng, int na, int n_wg, hipStream_t st);
 hipError_t launch_emit_packed_nf2(const EmitPlan &E, int ng, int na, int n_wg, hipStream_t st);
@@ -345,26 +350,32 @@ __global__ __launch_bounds__(kWgThreads, 4) void k_emit_packed(const EmitPlan E)
 #pragma unroll
             for (int c = 0; c < NA; c++) B.a[c] = (const uint8_t *)P.acol[c] + first * P.awid[c];
             B.t = nullptr;
-            PackedRaw<NF> rf;
-            PackedRaw<NG> rg;
-            PackedRaw<NA> ra;
+            // D tiles of loads in flight per lane (narrow queries move few bytes per tile)
+            constexpr int D = emit_depth(NF + NG + NA);
+            PackedRaw<NF> rf[D];
+            PackedRaw<NG> rg[D];
+            PackedRaw<NA> ra[D];
             PackedRaw<1> rt;
             PackedTile<NF> f;
             PackedTile<NG> g;
             PackedTile<NA> a;
             PackedTile<1> t;
-            // every thread runs the same number of tiles so the barriers line up
             const uint32_t n_tiles = (n + kPackedTileRows - 1) / kPackedTileRows;
-            uint32_t r = tid * kPackedRows;
-            if (r < n) {
-                packed_issue_all<NF, NG, NA, false, false, false>(P, B, r, rf, rg, ra, rt);
-                packed_decode_all<NF, NG, NA, false, false, false>(P, rf, rg, ra, rt, f, g, a, t, 0u);
-            }
-            for (uint32_t it = 0; it < n_tiles; it++, r += kPackedTileRows) {
-                const uint32_t rn = r + kPackedTileRows;
-                const bool more = rn < n;
-                if (more) packed_issue_all<NF, NG, NA, false, false, false>(P, B, rn, rf, rg, ra, rt);
+            const uint32_t r_first = tid * kPackedRows;
+#pragma unroll
+            for (int d = 0; d < D; d++)
+                if (r_first + (uint32_t)d * kPackedTileRows < n)
+                    packed_issue_all<NF, NG, NA, false, false, false>(P, B, r_first + (uint32_t)d * kPackedTileRows, rf[d], rg[d], ra[d], rt);
+            for (uint32_t it0 = 0; it0 < n_tiles; it0 += D) {
+#pragma unroll
+              for (int d = 0; d < D; d++) {
+                if (it0 + d >= n_tiles) break;
+                const uint32_t r = r_first + (it0 + d) * kPackedTileRows;   // (< 2^28 + 2^12: no wrap)
+                packed_decode_all<NF, NG, NA, false, false, false>(P, rf[d], rg[d], ra[d], rt, f, g, a, t, 0u);
+                if ((uint64_t)r + (uint64_t)D * kPackedTileRows < n)
+                    packed_issue_all<NF, NG, NA, false, false, false>(P, B, r + (uint32_t)D * kPackedTileRows, rf[d], rg[d], ra[d], rt);
                 const uint32_t left = r < n ? n - r : 0u;
+                uint32_t bin[kPackedRows * NA], rec[kPackedRows * NA], act = 0;
 #pragma unroll
                 for (int k = 0; k < kPackedRows; k++) {
                     bool pass = (uint32_t)k < left;
@@ -383,32 +394,108 @@ __global__ __launch_bounds__(kWgThreads, 4) void k_emit_packed(const EmitPlan E)
                     }
                     matched += pass ? 1u : 0u;
                     overflow += (pass & !inb) ? 1u : 0u;
-                    if (pass & inb) {
 #pragma unroll
-                        for (int c = 0; c < NA; c++) {
-                            const uint32_t n32 = a.u[c][k] + P.adoff[c];  // value - h.Min
-                            const uint32_t b = packed_udiv(n32, P.bucket_size[c], P.pinv_bucket[c]);
-                            emit_push(E, S, cell * (uint32_t)NA + (uint32_t)c, b, n32 - b * P.bucket_size[c], E.rem_bits[c]);
-                        }
+                    for (int c = 0; c < NA; c++) {
+                        const uint32_t n32 = a.u[c][k] + P.adoff[c];  // value - h.Min
+                        const uint32_t b = packed_udiv(n32, P.bucket_size[c], P.pinv_bucket[c]);
+                        const uint32_t pair = cell * (uint32_t)NA + (uint32_t)c;
+                        bin[k * NA + c] = emit_bin(S, pair);
+                        rec[k * NA + c] = emit_record(pair, b, n32 - b * P.bucket_size[c], E.rem_bits[c]);
+                        act |= (pass & inb) ? 1u << (k * NA + c) : 0u;
                     }
                 }
-                if (more) packed_decode_all<NF, NG, NA, false, false, false>(P, rf, rg, ra, rt, f, g, a, t, 0u);
-                // bins fill at ~tile_records / n_parts per tile: flush (two barriers) only every
-                // flush_period tiles; a bin that fills up earlier spills record by record
-                if ((it + 1) % (uint32_t)E.flush_period == 0 || it + 1 == n_tiles) {
-                    __syncthreads();
-                    emit_flush(E, S, S.slots / 2);
-                    __syncthreads();
-                }
+                emit_push_all<kPackedRows * NA>(E, S, bin, rec, act);
+              }
             }
         }
     }
     emit_finish(E, S, matched, overflow);
 }
 
+// k_count over compact storage: the counting pass of k_emit_packed (see k_count in scan_fast.h).
+template <int NF, int NG>
+__global__ __launch_bounds__(kWgThreads, 4) void k_count_packed(const EmitPlan E) {
+    extern __shared__ uint32_t elds[];
+    const FastPlan &P = E.fp;
+    const uint32_t tid = threadIdx.x;
+    uint32_t *mine = count_begin(E, elds);
+    const uint32_t na = (uint32_t)E.n_aggs;
+    const int s0 = P.wg_seg_begin[blockIdx.x], s1 = P.wg_seg_begin[blockIdx.x + 1];
+    for (int si = s0; si < s1; si++) {
+        const Segment seg = P.segs[si];
+        for (int64_t c0 = 0; c0 < seg.n; c0 += kPackedChunkRows) {
+            const int64_t first = seg.start + c0;
+            const uint32_t n = (uint32_t)(seg.n - c0 < kPackedChunkRows ? seg.n - c0 : kPackedChunkRows);
+            PackedBases<NF, NG, 0> B;
+#pragma unroll
+            for (int c = 0; c < NF; c++) B.f[c] = (const uint8_t *)P.fcol[c] + first * P.fwid[c];
+#pragma unroll
+            for (int c = 0; c < NG; c++) B.g[c] = (const uint8_t *)P.gcol[c] + first * P.gwid[c];
+            B.a[0] = nullptr;
+            B.t = nullptr;
+            constexpr int D = count_depth(NF + NG);
+            PackedRaw<NF> rf[D];
+            PackedRaw<NG> rg[D];
+            PackedRaw<0> ra;
+            PackedRaw<1> rt;
+            PackedTile<NF> f;
+            PackedTile<NG> g;
+            PackedTile<0> a;
+            PackedTile<1> t;
+            const uint32_t n_tiles = (n + kPackedTileRows - 1) / kPackedTileRows;
+            const uint32_t r_first = tid * kPackedRows;
+#pragma unroll
+            for (int d = 0; d < D; d++)
+                if (r_first + (uint32_t)d * kPackedTileRows < n)
+                    packed_issue_all<NF, NG, 0, false, false, false>(P, B, r_first + (uint32_t)d * kPackedTileRows, rf[d], rg[d], ra, rt);
+            for (uint32_t it0 = 0; it0 < n_tiles; it0 += D) {
+#pragma unroll
+              for (int d = 0; d < D; d++) {
+                if (it0 + d >= n_tiles) break;
+                const uint32_t r = r_first + (it0 + d) * kPackedTileRows;
+                packed_decode_all<NF, NG, 0, false, false, false>(P, rf[d], rg[d], ra, rt, f, g, a, t, 0u);
+                if ((uint64_t)r + (uint64_t)D * kPackedTileRows < n)
+                    packed_issue_all<NF, NG, 0, false, false, false>(P, B, r + (uint32_t)D * kPackedTileRows, rf[d], rg[d], ra, rt);
+                const uint32_t left = r < n ? n - r : 0u;
+#pragma unroll
+                for (int k = 0; k < kPackedRows; k++) {
+                    bool pass = (uint32_t)k < left;
+#pragma unroll
+                    for (int c = 0; c < NF; c++) {
+                        const uint32_t u = f.u[c][k];
+                        pass = pass & (u >= P.plo[c]) & (u <= P.phi[c]);
+                    }
+                    uint32_t cell = 0;
+#pragma unroll
+                    for (int c = 0; c < NG; c++) {
+                        const uint32_t d = g.u[c][k] + P.gdoff[c];
+                        pass = pass & (d < P.gcard[c]);
+                        cell += __umul24(d, (uint32_t)P.gstride[c]);
+                    }
+                    if (pass) __hip_atomic_fetch_add(mine + ((cell * na) >> kPartCellBits), na, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+              }
+            }
+        }
+    }
+    count_finish(E, elds);
+}
+
+template <int NF>
+static hipError_t count_packed_launch_nf(const EmitPlan &E, int ng, int n_wg, hipStream_t st) {
+    const size_t lds = count_lds_bytes(E);
+    switch (ng) {
+    case 0: hipLaunchKernelGGL((k_count_packed<NF, 0>), dim3(n_wg), dim3(kWgThreads), lds, st, E); break;
+    case 1: hipLaunchKernelGGL((k_count_packed<NF, 1>), dim3(n_wg), dim3(kWgThreads), lds, st, E); break;
+    case 2: hipLaunchKernelGGL((k_count_packed<NF, 2>), dim3(n_wg), dim3(kWgThreads), lds, st, E); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
 template <int NF>
 static hipError_t emit_packed_launch_nf(const EmitPlan &E, int ng, int na, int n_wg, hipStream_t st) {
-    const size_t lds = ((size_t)E.n_parts << E.sub_shift) * (1 + (size_t)E.slots) * 4;
+    const size_t lds = emit_lds_bytes(E);
 #define SYBL_EMITP_CASE(G, A)                                                                              \
     case (G)*3 + (A): {                                                                                    \
         auto k = k_emit_packed<NF, G, A>;                                                                  \

@@ -326,6 +326,17 @@ class Query:
         N.check(N.lib().sybl_query_stats(self._h, C.byref(st)))
         return st.as_dict()
 
+    def debug_cells(self, which, agg=0):
+        """Test hook (sybl_debug_query_cells): the exact per-cell integers behind the last finalized result;
+        which = "count" | "sum" | "sb" | "sb2"."""
+        w = {"count": 0, "sum": 1, "sb": 2, "sb2": 3}[which]
+        n = C.c_int64(0)
+        probe = np.zeros(1, dtype=np.int64)
+        N.check(N.lib().sybl_debug_query_cells(self._h, w, agg, probe.ctypes.data, 1, C.byref(n)))
+        out = np.zeros(n.value, dtype=np.int64)
+        N.check(N.lib().sybl_debug_query_cells(self._h, w, agg, out.ctypes.data, out.size, C.byref(n)))
+        return out
+
     def snapshot(self):
         """Enqueue the device -> host copy of the (reduced) partial tables; finalize() then waits for
         that copy only, so the scan of another query can run underneath it."""
