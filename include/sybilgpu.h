@@ -176,7 +176,8 @@ int sybl_table_column_info(const sybl_table *t, const char *name, int *type, int
                            int64_t *exact_max, int64_t *info_min, int64_t *info_max, int *has_missing);
 /* Multi-rank hosts: declare bounds that hold on EVERY rank (all-reduce the exact extrema
  * first) so that the direct-mapped group layout, and therefore the partial tables, are
- * identical across ranks.  has_missing != 0 reserves the MISSING_VALUE key slot. */
+ * identical across ranks.  has_missing != 0 reserves the MISSING_VALUE key slot.  lo > hi (no rank holds a
+ * value) declares no bounds but still applies has_missing. */
 int sybl_table_set_bounds(sybl_table *t, const char *name, int64_t lo, int64_t hi, int has_missing);
 /* Group-by on a key column whose value RANGE is too wide for direct mapping (more than 2^22
  * values, or more than 2^27 cells together with the other keys) goes through a dictionary of the
@@ -349,6 +350,11 @@ const char *sybl_result_render(sybl_result *r, int format);
  * what `sybil aggregate` (node_aggregator.go) and src/api consume.  Library-owned buffer valid until the
  * result is freed; bucket arrays are included for the rows that carry them. */
 const void *sybl_result_encode(sybl_result *r, int64_t *n_bytes);
+
+/* Test hook (no GPU needed): the library's regular-expression engine for re / nre str filters -- Go regexp
+ * (RE2) syntax, unanchored search like regexp.MatchString (filter.go:213-236).  1 = match, 0 = no match,
+ * -1 = the pattern does not compile (sybl_last_error says why). */
+int sybl_debug_regex_match(const char *pattern, const char *text, int64_t text_len);
 
 /* Test/diagnostic hook: decodes one gob file (info.db, int_/str_/set_*.db, optionally .gz) to JSON
  * with the library's gob reader.  Library-owned buffer, valid until the next call on the thread. */

@@ -99,6 +99,7 @@ SIGNATURES = {
                                               C.POINTER(C.c_int64)]),
     "sybl_table_broken_blocks": (C.c_int64, [P]),
     "sybl_debug_gob_to_json": (C.c_char_p, [C.c_char_p]),
+    "sybl_debug_regex_match": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int64]),
     "sybl_table_rows": (C.c_int64, [P]),
     "sybl_table_blocks": (C.c_int64, [P]),
     "sybl_table_hbm_bytes": (C.c_int64, [P]),

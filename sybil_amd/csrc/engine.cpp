@@ -10,6 +10,7 @@
 //   sybl_query_scan           <- the block loop of LoadAndQueryRecords (table_query.go:96-231)
 // There is no CPU fallback in this file: without a HIP device every call fails.
 #include "engine.h"
+#include "re2lite.h"
 
 #include <math.h>
 #include <stdarg.h>
@@ -338,6 +339,17 @@ int sybl_query_stats(sybl_query *q, sybl_run_stats *out) {
     }
     *out = q->stats;
     return SYBL_OK;
+}
+
+int sybl_debug_regex_match(const char *pattern, const char *text, int64_t text_len) {
+    if (!pattern || (!text && text_len > 0)) return fail(SYBL_E_INVAL, "NULL argument");
+    Re2Lite re;
+    std::string why;
+    if (!re.compile(pattern, &why)) {
+        set_error("bad regex '%s': %s", pattern, why.c_str());
+        return -1;
+    }
+    return re.search(text ? text : "", (size_t)text_len) ? 1 : 0;
 }
 
 int sybl_debug_query_cells(sybl_query *q, int which, int agg, int64_t *out, int64_t cap, int64_t *n_cells) {

@@ -358,6 +358,10 @@ bool read_file(const std::string &path, std::vector<uint8_t> &out, std::string &
         return true;
     }
     f = fopen(use.c_str(), "rb");
+    if (!f) {
+        err = "cannot open " + use;
+        return false;
+    }
     fseek(f, 0, SEEK_END);
     long sz = ftell(f);
     fseek(f, 0, SEEK_SET);

@@ -708,8 +708,9 @@ __global__ __launch_bounds__(1024) void k_decode_delta(const int64_t *__restrict
 }
 
 // Per-row block-local dictionary ids -> table-global ids (non-bucket str columns)
-__global__ __launch_bounds__(256) void k_remap_ids(const int32_t *__restrict__ local, const int32_t *__restrict__ lut,
-                                                   int32_t n_lut, int64_t n, int32_t *__restrict__ col) {
+// (local and col may be the same array -- sybl_table_set_dict remaps resident ids in place -- so neither is restrict)
+__global__ __launch_bounds__(256) void k_remap_ids(const int32_t *local, const int32_t *__restrict__ lut, int32_t n_lut, int64_t n,
+                                                   int32_t *col) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     int32_t id = local[i];

@@ -164,7 +164,23 @@ struct ColSpec {
     int type;
 };
 
+constexpr int64_t kMaxBlockRows = (int64_t)1 << 24;  // 256 x the reference's block size
+
+static PreparedBlock prepare_block_unguarded(const std::string &bdir, const std::vector<ColSpec> &specs);
+// A worker thread must not let an exception escape (std::bad_alloc / length_error from a damaged file): it
+// would be rethrown by future::get() and leave the extern "C" entry point.  The block is skipped instead,
+// like every other block the reference cannot read.
 static PreparedBlock prepare_block(const std::string &bdir, const std::vector<ColSpec> &specs) {
+    try {
+        return prepare_block_unguarded(bdir, specs);
+    } catch (const std::exception &) {
+        PreparedBlock pb;
+        pb.unreadable = true;
+        return pb;
+    }
+}
+
+static PreparedBlock prepare_block_unguarded(const std::string &bdir, const std::vector<ColSpec> &specs) {
     static const char *prefix[] = {"", "int_", "str_", "set_"};
     PreparedBlock pb;
     std::string err;
@@ -175,7 +191,9 @@ static PreparedBlock prepare_block(const std::string &bdir, const std::vector<Co
     }
     const gob::Value *nr = binfo.field("NumRecords");
     pb.nrows = nr ? nr->as_int() : 0;
-    if (pb.nrows <= 0) {
+    // NumRecords is an int32 in the reference and blocks hold CHUNK_SIZE = 65536 rows (table.go:44); a larger value
+    // can only come from a damaged or hostile info.db and would size every per-row array of this block
+    if (pb.nrows <= 0 || pb.nrows > kMaxBlockRows) {
         pb.unreadable = true;  // "NUM RECORDS BELOW 0"
         return pb;
     }
@@ -510,7 +528,12 @@ int sybl_table_open_flags(sybl_ctx *ctx, const char *dir, const char *table, con
     if (!ctx || !table || !out || rank < 0 || (nranks > 0 && rank >= nranks)) return fail(SYBL_E_INVAL, "sybl_table_open: bad argument");
     *out = nullptr;
     SYBL_HIP(hipSetDevice(ctx->device));
-    return open_table(ctx, dir, table, columns, n_columns, rank, nranks, flags, out);
+    try {
+        return open_table(ctx, dir, table, columns, n_columns, rank, nranks, flags, out);
+    } catch (const std::exception &e) {
+        *out = nullptr;
+        return fail(SYBL_E_IO, "sybl_table_open: %s", e.what());
+    }
 }
 
 int64_t sybl_table_broken_blocks(const sybl_table *t) { return t ? t->broken_blocks : 0; }

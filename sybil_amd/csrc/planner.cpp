@@ -12,9 +12,9 @@
 #include <string.h>
 
 #include <algorithm>
-#include <regex>
 
 #include "engine.h"
+#include "re2lite.h"
 
 namespace sybl {
 
@@ -548,14 +548,14 @@ struct Planner {
                             m[k] = f.op == SYBL_OP_NRE ? !hit : hit;
                         }
                     } else {
-                        try {
-                            std::regex re(f.str_value ? f.str_value : "", std::regex::ECMAScript);
-                            for (size_t k = 0; k < n; k++) {
-                                bool hit = std::regex_search(c->dict[k], re);
-                                m[k] = f.op == SYBL_OP_NRE ? !hit : hit;
-                            }
-                        } catch (const std::regex_error &e) {
-                            return fail(SYBL_E_INVAL, "bad regex '%s': %s", f.str_value ? f.str_value : "", e.what());
+                        // Go's regexp (RE2 syntax, linear-time matching): re2lite.h
+                        Re2Lite re;
+                        std::string why;
+                        if (!re.compile(f.str_value ? f.str_value : "", &why))
+                            return fail(SYBL_E_INVAL, "bad regex '%s': %s", f.str_value ? f.str_value : "", why.c_str());
+                        for (size_t k = 0; k < n; k++) {
+                            bool hit = re.search(c->dict[k]);
+                            m[k] = f.op == SYBL_OP_NRE ? !hit : hit;
                         }
                     }
                 } else {

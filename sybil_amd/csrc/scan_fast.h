@@ -555,17 +555,20 @@ __global__ __launch_bounds__(kWgThreads, 4) void k_scan_fast(const FastPlan P) {
 //
 // LDS staging of k_emit / k_emit_packed, per bin (nb = n_parts << sub_shift bins):
 //   cnt   records pushed so far: a push takes slot s = cnt++, generation g = s / 16
-//   wr    17 * (generations written out) + records of the current generation in place: the
+//   wr    17 * (generations copied out) + records of the current generation in place: the
 //         generation-g record may be written once wr >= 17 g (generation g - 1 is out of the chunk),
 //         each writer then bumps wr, and the one that finds 17 g + 15 owns the complete chunk: it
 //         copies it to the partition buffer and bumps wr once more (-> 17 (g + 1))
 //   chunk 16 records; a record's place is rotated by bin / 2 so bins that fill in step spread over
 //         the LDS banks (the order of records inside a chunk is immaterial)
 // and per partition `pos`: the next free chunk of this workgroup's region.
-// There is no workgroup barrier between the prologue and the final drain: waves run free, a wave
-// only ever waits (re-polls wr) for a chunk that another lane is about to write out.  Every lane that
-// holds a slot is inside emit_push_all and retries all its pending records on every pass, and the
-// oldest incomplete generation of a bin can always be written, so the protocol cannot deadlock.
+// There is no workgroup barrier between the prologue and the final drain: waves run free.  A record that
+// finds its chunk still waiting to be copied out keeps its slot and is written on the lane's next visit
+// (EmitCarry); a wave only polls when one of its lanes has two such records, and then every lane of the
+// wave keeps retrying everything it holds -- the oldest incomplete generation of a bin can always be
+// written and its sixteenth writer copies it out at once, so the protocol cannot deadlock.
+// (Tried and dropped, measured on config 4: dedicated store waves polling wr -- 4.9 ms against 3.8: the
+// polling costs more LDS bandwidth and issue slots than the stores cost the scanning waves.)
 struct EmitLds {
     uint32_t *cnt, *wr, *pos, *chunk;
     uint32_t nb, ss, sub;
@@ -588,15 +591,33 @@ __device__ __forceinline__ EmitLds emit_begin(const EmitPlan &E, uint32_t *elds)
     return S;
 }
 
-// Writes one chunk (16 records, 64 bytes) of `bin` to the workgroup's region of its partition.
-__device__ __forceinline__ void emit_store_chunk(const EmitPlan &E, const EmitLds &S, uint32_t p, const fu32x4 &r0, const fu32x4 &r1,
-                                                 const fu32x4 &r2, const fu32x4 &r3) {
+// Writes one chunk (16 records, 64 bytes) at record index p of the partition buffers.
+__device__ __forceinline__ void emit_store_chunk(const EmitPlan &E, uint32_t p, const fu32x4 &r0, const fu32x4 &r1, const fu32x4 &r2,
+                                                 const fu32x4 &r3) {
     fu32x4 *dst = (fu32x4 *)(E.recs + p);
     dst[0] = r0;
     dst[1] = r1;
     dst[2] = r2;
     dst[3] = r3;
 }
+
+// LDS operations of a wave are carried out in issue order, so ordering two of them only takes keeping the
+// compiler from moving them and -- where a returned value gates the next step -- the wait for the LDS
+// counter.  (A workgroup-scope fence also waits for vmcnt(0), i.e. for the prefetched column loads.)
+__device__ __forceinline__ void lds_order() { __atomic_signal_fence(__ATOMIC_SEQ_CST); }  // compiler-only
+__device__ __forceinline__ void lds_wait() {
+    lds_order();
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // gfx9 encoding of lgkmcnt(0) alone (vmcnt / expcnt fields at their maxima)
+    lds_order();
+}
+
+// A record whose chunk was still waiting to be copied out when its lane came by: it keeps its slot and is
+// written on the lane's next visit (one tile later, when the copy has long happened).  Without it a wave
+// stops and polls whenever ANY of its 256 records of a tile finds its bin in that state -- with 2048 bins
+// completing a chunk every eight tiles that is most tiles.
+struct EmitCarry {
+    uint32_t bin, rec, slot, valid;
+};
 
 // bin numbers (< 2^16) of a lane's records packed four to a 64-bit word, so that picking the bin of record i
 // is a shift: indexing the register array with a run-time i sent it to scratch memory (a VMEM round trip
@@ -611,65 +632,63 @@ struct EmitBinPack {
         for (int i = 0; i < N; i++) w[i / 4] |= (unsigned long long)(bin[i] & 0xFFFFu) << (16 * (i % 4));
     }
     __device__ __forceinline__ uint32_t get(uint32_t i) const {
+        static_assert(N <= 12, "at most twelve records per lane and call");
         unsigned long long x = w[0];
-        if (N > 4) x = i >= 4 ? w[(N + 3) / 4 - 1] : x;
-        static_assert(N <= 8, "at most eight records per lane and tile");
+        if (N > 4) x = i >= 4 ? w[1] : x;
+        if (N > 8) x = i >= 8 ? w[(N + 3) / 4 - 1] : x;
         return (uint32_t)(x >> (16 * (i & 3))) & 0xFFFFu;
     }
 };
 
-// LDS operations of a wave are carried out in issue order, so ordering two of them only takes keeping the
-// compiler from moving them and -- where a returned value gates the next step -- the wait for the LDS
-// counter.  A workgroup-scope fence would also wait for vmcnt(0), i.e. for the prefetched column loads:
-// measured, it made every tile pay the full HBM latency.
-__device__ __forceinline__ void lds_order() { __atomic_signal_fence(__ATOMIC_SEQ_CST); }  // compiler-only
-__device__ __forceinline__ void lds_wait() {
-    lds_order();
-    __builtin_amdgcn_s_waitcnt(0xC07F);  // gfx9 encoding of lgkmcnt(0) alone (vmcnt / expcnt fields at their maxima)
-    lds_order();
-}
-
-// Pushes the lane's records i with bit i of `act` set: rec[i] into bin[i].
+// Pushes the lane's records i with bit i of `act` set, rec[i] into bin[i], and the record carried over from
+// the previous call; last_call: nothing may be left behind.
 template <int N>
-__device__ __forceinline__ void emit_push_all(const EmitPlan &E, const EmitLds &S, const uint32_t (&bin)[N], const uint32_t (&rec)[N],
-                                              uint32_t act) {
-    uint32_t slot[N];
+__device__ __forceinline__ void emit_push_all(const EmitPlan &E, const EmitLds &S, const uint32_t (&bin_in)[N], const uint32_t (&rec_in)[N],
+                                              uint32_t act, EmitCarry &carry, bool last_call = false) {
+    constexpr int M = N + 1;
+    uint32_t bin[M], rec[M], slot[M], w[M];
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        bin[i] = bin_in[i];
+        rec[i] = rec_in[i];
+    }
+    bin[N] = carry.bin;
+    rec[N] = carry.rec;
+    // one LDS round trip in the common case: the slots and the bins' wr words (wr only grows: a value read
+    // early errs on the side of waiting)
 #pragma unroll
     for (int i = 0; i < N; i++)
         slot[i] = (act >> i) & 1u ? __hip_atomic_fetch_add(S.cnt + bin[i], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
-    uint32_t pend = act, passes = 0;
-    while (pend) {
-        // (bounded: a protocol bug must surface as an error from finalize, not as a hung GPU)
-        if (++passes > (1u << 22)) {
-            __hip_atomic_fetch_add(E.sum_out + kHdrEmitStall, (int64_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            break;
-        }
-        uint32_t w[N];
+    slot[N] = carry.slot;
+    uint32_t pend = act | (carry.valid ? 1u << N : 0u);
 #pragma unroll
-        for (int i = 0; i < N; i++)
-            w[i] = (pend >> i) & 1u ? __hip_atomic_load(S.wr + bin[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
+    for (int i = 0; i < M; i++)
+        w[i] = (pend >> i) & 1u ? __hip_atomic_load(S.wr + bin[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
+    const EmitBinPack<M> packed_bins(bin);
+    uint32_t passes = 0;
+    carry.valid = 0;
+    while (true) {
         lds_order();
         uint32_t ok = 0;
 #pragma unroll
-        for (int i = 0; i < N; i++) {
+        for (int i = 0; i < M; i++) {
             if (((pend >> i) & 1u) && w[i] >= 17u * (slot[i] >> 4)) {
                 S.chunk[bin[i] * kEmitChunk + ((slot[i] + (bin[i] >> 1)) & (kEmitChunk - 1))] = rec[i];
                 ok |= 1u << i;
             }
         }
         lds_order();  // the records go to LDS before wr says so (issue order)
-        uint32_t old[N];
+        uint32_t old[M];
 #pragma unroll
-        for (int i = 0; i < N; i++)
+        for (int i = 0; i < M; i++)
             old[i] = (ok >> i) & 1u ? __hip_atomic_fetch_add(S.wr + bin[i], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
         uint32_t full = 0;
 #pragma unroll
-        for (int i = 0; i < N; i++)
+        for (int i = 0; i < M; i++)
             full |= ((ok >> i) & 1u) && old[i] == 17u * (slot[i] >> 4) + (kEmitChunk - 1) ? 1u << i : 0u;
         lds_order();  // the chunk is read after wr showed the other 15 records in place
         // complete chunks: a lane rarely owns more than one per tile, so loop over the lane's own
         // instead of running the copy once per record position
-        const EmitBinPack<N> packed_bins(bin);
         while (full) {
             const uint32_t i = (uint32_t)__builtin_ctz(full);
             full &= full - 1;
@@ -677,12 +696,45 @@ __device__ __forceinline__ void emit_push_all(const EmitPlan &E, const EmitLds &
             const uint32_t p = __hip_atomic_fetch_add(S.pos + (b >> S.ss), kEmitChunk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             const fu32x4 *c = (const fu32x4 *)(S.chunk + b * kEmitChunk);
             const fu32x4 r0 = c[0], r1 = c[1], r2 = c[2], r3 = c[3];
-            emit_store_chunk(E, S, p, r0, r1, r2, r3);
+            emit_store_chunk(E, p, r0, r1, r2, r3);
             lds_wait();  // the chunk has been read before the next generation may write
             __hip_atomic_fetch_add(S.wr + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         pend &= ~ok;
+        // Leave with at most one record per lane in hand -- but only if that holds for the WHOLE wave: a lane
+        // that stays to poll may be waiting for a generation another lane of this wave has a slot in, and
+        // that lane must then keep retrying too (it cannot come back before the wave leaves this call).
+        const bool must_stay = pend != 0 && (last_call || passes != 0 || (pend & (pend - 1)) != 0);
+        if (!__builtin_amdgcn_ballot_w64(must_stay)) {
+            if (pend) {
+                carry.valid = 1;
+                const uint32_t i = (uint32_t)__builtin_ctz(pend);
+                carry.bin = packed_bins.get(i);
+#pragma unroll
+                for (int k = 0; k < M; k++)
+                    if (i == (uint32_t)k) {
+                        carry.rec = rec[k];
+                        carry.slot = slot[k];
+                    }
+            }
+            break;
+        }
+        if (!pend) break;
+        // poll again (bounded: a protocol bug must surface as an error from finalize, not as a hung GPU)
+        if (++passes > (1u << 22)) {
+            __hip_atomic_fetch_add(E.sum_out + kHdrEmitStall, (int64_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+#pragma unroll
+        for (int i = 0; i < M; i++)
+            w[i] = (pend >> i) & 1u ? __hip_atomic_load(S.wr + bin[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
     }
+}
+
+// A wave has pushed its last record: the carried one, if any, goes in now.
+__device__ __forceinline__ void emit_scan_done(const EmitPlan &E, const EmitLds &S, EmitCarry &carry) {
+    const uint32_t none[1] = {0};
+    emit_push_all<1>(E, S, none, none, 0u, carry, true);
 }
 
 __device__ __forceinline__ uint32_t emit_record(uint32_t pair, uint32_t b, uint32_t rem, int rem_bits) {
@@ -708,13 +760,13 @@ __device__ __forceinline__ void emit_finish(const EmitPlan &E, const EmitLds &S,
             const fu32x4 r0 = {r[0], r[1], r[2], r[3]}, r1 = {r[4], r[5], r[6], r[7]}, r2 = {r[8], r[9], r[10], r[11]},
                          r3 = {r[12], r[13], r[14], r[15]};
             const uint32_t p = __hip_atomic_fetch_add(S.pos + (bin >> S.ss), kEmitChunk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            emit_store_chunk(E, S, p, r0, r1, r2, r3);
+            emit_store_chunk(E, p, r0, r1, r2, r3);
         }
     }
     __syncthreads();
     const uint32_t *wend = E.wend + (size_t)blockIdx.x * (uint32_t)E.n_parts;
     for (uint32_t part = threadIdx.x; part < (uint32_t)E.n_parts; part += kWgThreads)
-        for (uint32_t p = S.pos[part]; p < wend[part]; p += kEmitChunk) emit_store_chunk(E, S, p, pad, pad, pad, pad);
+        for (uint32_t p = S.pos[part]; p < wend[part]; p += kEmitChunk) emit_store_chunk(E, p, pad, pad, pad, pad);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         matched += __shfl_xor(matched, o, 64);
@@ -765,9 +817,12 @@ __global__ __launch_bounds__(kWgThreads, 4) void k_count(const EmitPlan E) {
         FastTile<NG> gr[D];
         FastTile<0> a0;
         FastTile<1> t0;
+        auto in_seg = [&](int64_t r) { return r < end ? r : seg.start; };
 #pragma unroll
-        for (int d = 0; d < D; d++)
-            if (row_first + (int64_t)d * kTileRows < end) fast_load<NF, NG, 0, false>(P, row_first + (int64_t)d * kTileRows, fr[d], gr[d], a0, t0);
+        for (int d = 0; d < D; d++) {
+                fast_load<NF, NG, 0, false>(P, in_seg(row_first + (int64_t)d * kTileRows), fr[d], gr[d], a0, t0);
+                __builtin_amdgcn_sched_barrier(0);  // oldest tile first: the ring is consumed in this order
+            }
         for (int64_t it0 = 0; it0 < n_tiles; it0 += D) {
 #pragma unroll
           for (int d = 0; d < D; d++) {
@@ -775,7 +830,7 @@ __global__ __launch_bounds__(kWgThreads, 4) void k_count(const EmitPlan E) {
             const int64_t row = row_first + (it0 + d) * kTileRows;
             const FastTile<NF> f0 = fr[d];
             const FastTile<NG> g0 = gr[d];
-            if (row + (int64_t)D * kTileRows < end) fast_load<NF, NG, 0, false>(P, row + (int64_t)D * kTileRows, fr[d], gr[d], a0, t0);
+            fast_load<NF, NG, 0, false>(P, in_seg(row + (int64_t)D * kTileRows), fr[d], gr[d], a0, t0);
 #pragma unroll
             for (int r = 0; r < kRowsPerThread; r++) {
                 bool pass = row + r < end;
@@ -809,11 +864,13 @@ __global__ __launch_bounds__(kWgThreads, 4) void k_emit(const EmitPlan E) {
     const EmitLds S = emit_begin(E, elds);
 
     uint32_t matched = 0, overflow = 0;
+    constexpr int64_t kTile = kTileRows;
+    EmitCarry carry = {0, 0, 0, 0};
     const int s0 = P.wg_seg_begin[blockIdx.x], s1 = P.wg_seg_begin[blockIdx.x + 1];
     for (int si = s0; si < s1; si++) {
         const Segment seg = P.segs[si];
         const int64_t end = seg.start + seg.n;
-        const int64_t n_tiles = (seg.n + kTileRows - 1) / kTileRows;
+        const int64_t n_tiles = (seg.n + kTile - 1) / kTile;
         const int64_t row_first = seg.start + (int64_t)tid * kRowsPerThread;
         // D tiles of loads in flight per lane (narrow queries move few bytes per tile)
         constexpr int D = emit_depth(NF + NG + NA);
@@ -821,18 +878,23 @@ __global__ __launch_bounds__(kWgThreads, 4) void k_emit(const EmitPlan E) {
         FastTile<NG> gr[D];
         FastTile<NA> ar[D];
         FastTile<1> t0;
+        // (every lane always issues its loads -- rows past the end re-read the segment's first rows and are ignored --
+        // so that the compiler's load counting, and with it the depth of the pipeline, is exact: see packed_issue_always)
+        auto in_seg = [&](int64_t r) { return r < end ? r : seg.start; };
 #pragma unroll
-        for (int d = 0; d < D; d++)
-            if (row_first + (int64_t)d * kTileRows < end) fast_load<NF, NG, NA, false>(P, row_first + (int64_t)d * kTileRows, fr[d], gr[d], ar[d], t0);
+        for (int d = 0; d < D; d++) {
+                fast_load<NF, NG, NA, false>(P, in_seg(row_first + (int64_t)d * kTile), fr[d], gr[d], ar[d], t0);
+                __builtin_amdgcn_sched_barrier(0);  // oldest tile first: the ring is consumed in this order
+            }
         for (int64_t it0 = 0; it0 < n_tiles; it0 += D) {
 #pragma unroll
           for (int d = 0; d < D; d++) {
             if (it0 + d >= n_tiles) break;
-            const int64_t row = row_first + (it0 + d) * kTileRows;
+            const int64_t row = row_first + (it0 + d) * kTile;
             const FastTile<NF> f0 = fr[d];
             const FastTile<NG> g0 = gr[d];
             const FastTile<NA> a0 = ar[d];
-            if (row + (int64_t)D * kTileRows < end) fast_load<NF, NG, NA, false>(P, row + (int64_t)D * kTileRows, fr[d], gr[d], ar[d], t0);
+            fast_load<NF, NG, NA, false>(P, in_seg(row + (int64_t)D * kTile), fr[d], gr[d], ar[d], t0);
             uint32_t bin[kRowsPerThread * NA], rec[kRowsPerThread * NA], act = 0;
 #pragma unroll
             for (int r = 0; r < kRowsPerThread; r++) {
@@ -872,10 +934,11 @@ __global__ __launch_bounds__(kWgThreads, 4) void k_emit(const EmitPlan E) {
                     act |= (pass && inb) ? 1u << (r * NA + c) : 0u;
                 }
             }
-            emit_push_all<kRowsPerThread * NA>(E, S, bin, rec, act);
+            emit_push_all<kRowsPerThread * NA>(E, S, bin, rec, act, carry);
           }
         }
     }
+    emit_scan_done(E, S, carry);
     emit_finish(E, S, matched, overflow);
 }
 

@@ -142,6 +142,33 @@ __device__ __forceinline__ void packed_issue_all(const FastPlan &P, const Packed
     for (int c = 0; c < NA; c++) issue(B.a[c], P.awid[c], a.v[c]);
 }
 
+// The same loads for the staged kernels (k_count_packed / k_emit_packed), which keep several tiles in flight:
+// every lane ALWAYS issues them -- a tile (or the lanes of a wave) beyond the end of the chunk gets a
+// descriptor that ends at row n, so the range check returns zeros without touching memory.  Loads issued
+// under a condition make the compiler assume the younger ones may not exist, and it then waits for all but
+// the newest whenever it needs the oldest (s_waitcnt vmcnt(1) instead of vmcnt(6)).
+template <int NF, int NG, int NA>
+__device__ __forceinline__ void packed_issue_always(const FastPlan &P, const PackedBases<NF, NG, NA> &B, uint32_t r, uint32_t n,
+                                                    PackedRaw<NF> &f, PackedRaw<NG> &g, PackedRaw<NA> &a) {
+    const uint32_t r0 = __builtin_amdgcn_readfirstlane(r);
+    const uint32_t lane_row = r - r0;
+    // wave-uniform; whole lanes (4 rows: at least one dword at any width -- the range check drops a dword that is
+    // only partly inside), which never reaches past the padding every block ends with
+    const uint32_t rows = r0 < n ? (n - r0 < 64u * kPackedRows ? (n - r0 + kPackedRows - 1) & ~(uint32_t)(kPackedRows - 1) : 64u * kPackedRows) : 0u;
+    auto issue = [&](const uint8_t *col, int width, pu32x4 &raw) {
+        const int ws = width >> 1;  // width 1, 2, 4 -> shift 0, 1, 2
+        const __amdgpu_buffer_rsrc_t rsrc =
+            __builtin_amdgcn_make_buffer_rsrc((void *)(col + ((size_t)(rows ? r0 : 0u) << ws)), 0, (int)(rows << ws), (int)kBufferRsrcWord3);
+        raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(lane_row << ws), 0, 2);  // aux 2 = nt: streamed once
+    };
+#pragma unroll
+    for (int c = 0; c < NF; c++) issue(B.f[c], P.fwid[c], f.v[c]);
+#pragma unroll
+    for (int c = 0; c < NG; c++) issue(B.g[c], P.gwid[c], g.v[c]);
+#pragma unroll
+    for (int c = 0; c < NA; c++) issue(B.a[c], P.awid[c], a.v[c]);
+}
+
 template <int NF, int NG, int NA, bool TIME, bool G1, bool NUL>
 __device__ __forceinline__ void packed_decode_all(const FastPlan &P, const PackedRaw<NF> &rf, const PackedRaw<NG> &rg,
                                                   const PackedRaw<NA> &ra, const PackedRaw<1> &rt, PackedTile<NF> &f,
@@ -336,6 +363,8 @@ __global__ __launch_bounds__(kWgThreads, 4) void k_emit_packed(const EmitPlan E)
     const EmitLds S = emit_begin(E, elds);
 
     uint32_t matched = 0, overflow = 0;
+    constexpr uint32_t kTile = kPackedTileRows;
+    EmitCarry carry = {0, 0, 0, 0};
     const int s0 = P.wg_seg_begin[blockIdx.x], s1 = P.wg_seg_begin[blockIdx.x + 1];
     for (int si = s0; si < s1; si++) {
         const Segment seg = P.segs[si];
@@ -360,20 +389,20 @@ __global__ __launch_bounds__(kWgThreads, 4) void k_emit_packed(const EmitPlan E)
             PackedTile<NG> g;
             PackedTile<NA> a;
             PackedTile<1> t;
-            const uint32_t n_tiles = (n + kPackedTileRows - 1) / kPackedTileRows;
+            const uint32_t n_tiles = (n + kTile - 1) / kTile;
             const uint32_t r_first = tid * kPackedRows;
 #pragma unroll
-            for (int d = 0; d < D; d++)
-                if (r_first + (uint32_t)d * kPackedTileRows < n)
-                    packed_issue_all<NF, NG, NA, false, false, false>(P, B, r_first + (uint32_t)d * kPackedTileRows, rf[d], rg[d], ra[d], rt);
+            for (int d = 0; d < D; d++) {
+                packed_issue_always<NF, NG, NA>(P, B, r_first + (uint32_t)d * kTile, n, rf[d], rg[d], ra[d]);
+                __builtin_amdgcn_sched_barrier(0);  // oldest tile first: the ring is consumed in this order
+            }
             for (uint32_t it0 = 0; it0 < n_tiles; it0 += D) {
 #pragma unroll
               for (int d = 0; d < D; d++) {
                 if (it0 + d >= n_tiles) break;
-                const uint32_t r = r_first + (it0 + d) * kPackedTileRows;   // (< 2^28 + 2^12: no wrap)
+                const uint32_t r = r_first + (it0 + d) * kTile;   // (< 2^28 + 2^12: no wrap)
                 packed_decode_all<NF, NG, NA, false, false, false>(P, rf[d], rg[d], ra[d], rt, f, g, a, t, 0u);
-                if ((uint64_t)r + (uint64_t)D * kPackedTileRows < n)
-                    packed_issue_all<NF, NG, NA, false, false, false>(P, B, r + (uint32_t)D * kPackedTileRows, rf[d], rg[d], ra[d], rt);
+                packed_issue_always<NF, NG, NA>(P, B, r + (uint32_t)D * kTile, n, rf[d], rg[d], ra[d]);
                 const uint32_t left = r < n ? n - r : 0u;
                 uint32_t bin[kPackedRows * NA], rec[kPackedRows * NA], act = 0;
 #pragma unroll
@@ -404,11 +433,12 @@ __global__ __launch_bounds__(kWgThreads, 4) void k_emit_packed(const EmitPlan E)
                         act |= (pass & inb) ? 1u << (k * NA + c) : 0u;
                     }
                 }
-                emit_push_all<kPackedRows * NA>(E, S, bin, rec, act);
+                emit_push_all<kPackedRows * NA>(E, S, bin, rec, act, carry);
               }
             }
         }
     }
+    emit_scan_done(E, S, carry);
     emit_finish(E, S, matched, overflow);
 }
 
@@ -445,17 +475,17 @@ __global__ __launch_bounds__(kWgThreads, 4) void k_count_packed(const EmitPlan E
             const uint32_t n_tiles = (n + kPackedTileRows - 1) / kPackedTileRows;
             const uint32_t r_first = tid * kPackedRows;
 #pragma unroll
-            for (int d = 0; d < D; d++)
-                if (r_first + (uint32_t)d * kPackedTileRows < n)
-                    packed_issue_all<NF, NG, 0, false, false, false>(P, B, r_first + (uint32_t)d * kPackedTileRows, rf[d], rg[d], ra, rt);
+            for (int d = 0; d < D; d++) {
+                packed_issue_always<NF, NG, 0>(P, B, r_first + (uint32_t)d * kPackedTileRows, n, rf[d], rg[d], ra);
+                __builtin_amdgcn_sched_barrier(0);  // oldest tile first: the ring is consumed in this order
+            }
             for (uint32_t it0 = 0; it0 < n_tiles; it0 += D) {
 #pragma unroll
               for (int d = 0; d < D; d++) {
                 if (it0 + d >= n_tiles) break;
                 const uint32_t r = r_first + (it0 + d) * kPackedTileRows;
                 packed_decode_all<NF, NG, 0, false, false, false>(P, rf[d], rg[d], ra, rt, f, g, a, t, 0u);
-                if ((uint64_t)r + (uint64_t)D * kPackedTileRows < n)
-                    packed_issue_all<NF, NG, 0, false, false, false>(P, B, r + (uint32_t)D * kPackedTileRows, rf[d], rg[d], ra, rt);
+                packed_issue_always<NF, NG, 0>(P, B, r + (uint32_t)D * kPackedTileRows, n, rf[d], rg[d], ra);
                 const uint32_t left = r < n ? n - r : 0u;
 #pragma unroll
                 for (int k = 0; k < kPackedRows; k++) {

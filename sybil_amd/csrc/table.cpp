@@ -732,9 +732,13 @@ int sybl_table_set_bounds(sybl_table *t, const char *name, int64_t lo, int64_t h
     if (!t) return fail(SYBL_E_INVAL, "table is NULL");
     Column *c = t->find(name);
     if (!c) return fail(SYBL_E_INVAL, "unknown column '%s'", name ? name : "(null)");
-    c->bounds_set = true;
-    c->bound_lo = lo;
-    c->bound_hi = hi;
+    // lo > hi: no rank holds a value of this column -- nothing to bound, but the agreed has_missing flag still
+    // applies (the MISSING key digit / populated-count field must exist on every rank or on none)
+    if (lo <= hi) {
+        c->bounds_set = true;
+        c->bound_lo = lo;
+        c->bound_hi = hi;
+    }
     if (has_missing) c->has_missing = true;
     t->version++;
     return SYBL_OK;

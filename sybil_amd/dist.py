@@ -28,31 +28,56 @@ def merge_partials(sum_words, max_words, group=None, has_max=True):
 def agree_bounds(infos, device="cpu", group=None):
     """infos: {column: {"exact_min", "exact_max", "has_missing"}} of this rank's shard (a rank with no
     populated row reports exact_min > exact_max).  Returns the bounds every rank must declare with
-    sybl_table_set_bounds so that the direct-mapped layout is identical everywhere."""
+    sybl_table_set_bounds so that the direct-mapped layout is identical everywhere.
+
+    One MAX all-reduce: minima travel as their bitwise complement (~x = -x - 1 is order-reversing and, unlike
+    -x, cannot overflow at INT64_MIN), and a separate flag says whether any rank holds a value at all."""
     names = sorted(infos)
-    lo = torch.tensor([-infos[n]["exact_min"] if infos[n]["exact_min"] <= infos[n]["exact_max"] else INT64_MIN
-                       for n in names], dtype=torch.int64, device=device)
-    hi = torch.tensor([infos[n]["exact_max"] if infos[n]["exact_min"] <= infos[n]["exact_max"] else INT64_MIN
-                       for n in names], dtype=torch.int64, device=device)
+    has = [infos[n]["exact_min"] <= infos[n]["exact_max"] for n in names]
+    lo = torch.tensor([~infos[n]["exact_min"] if h else INT64_MIN for n, h in zip(names, has)], dtype=torch.int64, device=device)
+    hi = torch.tensor([infos[n]["exact_max"] if h else INT64_MIN for n, h in zip(names, has)], dtype=torch.int64, device=device)
     miss = torch.tensor([1 if infos[n].get("has_missing") else 0 for n in names], dtype=torch.int64, device=device)
-    packed = torch.cat([lo, hi, miss])
+    rows = torch.tensor([1 if h else 0 for h in has], dtype=torch.int64, device=device)
+    packed = torch.cat([lo, hi, miss, rows])
     if dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(packed, op=dist.ReduceOp.MAX, group=group)
     k = len(names)
     out = {}
     for i, n in enumerate(names):
-        nlo, h, m = int(packed[i]), int(packed[k + i]), int(packed[2 * k + i])
-        if nlo == INT64_MIN:  # no rank holds a value
+        nlo, h, m, any_rows = int(packed[i]), int(packed[k + i]), int(packed[2 * k + i]), int(packed[3 * k + i])
+        if not any_rows:  # no rank holds a value
             out[n] = {"lo": 0, "hi": -1, "has_missing": bool(m)}
         else:
-            out[n] = {"lo": -nlo, "hi": h, "has_missing": bool(m)}
+            out[n] = {"lo": ~nlo, "hi": h, "has_missing": bool(m)}
     return out
 
 
 def apply_bounds(table, bounds):
+    """Declares the agreed bounds on this rank.  A column no rank holds a value of still gets its agreed
+    has_missing flag (an empty range): the MISSING key digit and the populated-count field must exist on
+    every rank or on none, or the partial tables would differ in size."""
     for name, b in bounds.items():
         if b["hi"] >= b["lo"]:
             table.set_bounds(name, b["lo"], b["hi"], b["has_missing"])
+        else:
+            table.set_bounds(name, 0, -1, b["has_missing"])
+
+
+def check_layout(query, group=None):
+    """Every rank must hold the same partial-table layout before the merge: a mismatch would make the all-reduce
+    hang or add unrelated words.  Raises on every rank when the sizes differ."""
+    ns, nm = query.partial_sizes()
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return ns, nm
+    t = torch.tensor([ns, -ns, nm, -nm], dtype=torch.int64)
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    t = t.to(dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    if int(t[0]) != -int(t[1]) or int(t[2]) != -int(t[3]):
+        raise RuntimeError("partial tables differ across ranks: SUM words %d..%d, MAX words %d..%d -- declare the same bounds / "
+                           "dictionaries on every rank (agree_bounds, agree_group_dict, agree_str_dict)"
+                           % (-int(t[1]), int(t[0]), -int(t[3]), int(t[2])))
+    return ns, nm
 
 
 def agree_group_dict(table, column, group=None):

@@ -116,6 +116,22 @@ def test_single_process_is_a_noop():
     b = sdist.agree_bounds({"a": {"exact_min": 3, "exact_max": 9, "has_missing": False},
                             "e": {"exact_min": 1, "exact_max": 0, "has_missing": True}})
     assert b["a"] == {"lo": 3, "hi": 9, "has_missing": False} and b["e"]["hi"] < b["e"]["lo"]
+    # the agreed has_missing flag of a column nobody holds a value of is still declared (an empty range), and the
+    # extreme int64 values survive the encoding of the minimum
+    assert b["e"]["has_missing"] is True
+    lo, hi = -(1 << 63), (1 << 63) - 1
+    x = sdist.agree_bounds({"m": {"exact_min": lo, "exact_max": hi, "has_missing": False}})
+    assert x["m"] == {"lo": lo, "hi": hi, "has_missing": False}
+
+    class T:
+        calls = []
+
+        def set_bounds(self, name, lo, hi, has_missing=False):
+            self.calls.append((name, lo, hi, has_missing))
+
+    t = T()
+    sdist.apply_bounds(t, b)
+    assert ("a", 3, 9, False) in t.calls and any(c[0] == "e" and c[1] > c[2] and c[3] is True for c in t.calls)
 
 
 class _FakeTable:

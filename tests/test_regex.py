@@ -1,0 +1,78 @@
+"""The library's regular-expression engine for re / nre str filters (csrc/re2lite.cpp): Go regexp (RE2) syntax,
+unanchored search like regexp.MatchString (filter.go:213-236).  Checked against Python's `re` on the syntax the
+two share, and on hand-derived cases for what is specific to Go's syntax.  No GPU needed."""
+import re
+
+import pytest
+
+from sybil_amd import _native as N
+
+
+def match(pattern, text):
+    t = text.encode("utf-8")
+    return N.lib().sybl_debug_regex_match(pattern.encode("utf-8"), t, len(t))
+
+
+CORPUS = ["", "a", "ab", "abc", "aaa", "abab", "2", "20", "21", "29", "12", "102", "x2", "hello world", "Hello", "HELLO",
+          "foo.bar", "foo_bar", "foo-bar", "a\nb", "line1\nline2", "tab\there", "  padded  ", "user@example.com",
+          "10.0.0.1", "192.168.1.254", "2024-01-15", "abc123", "123abc", "___", "a+b", "a*b", "(x)", "[y]", "{z}", "a|b",
+          "café", "é", "naïve", "中文", "edge", "gecko", "desktop", "tablet", "aXb", "a.b", "ab" * 40]
+
+SHARED = [r"^2", r"2$", r"^2\d$", r"a", r"^$", r"ab*", r"ab+c?", r"(ab)+", r"(?:ab){2}", r"a{2,3}", r"a{2,}", r"^a{0,1}$",
+          r"a|b", r"^(foo|bar)", r"[abc]", r"[^abc]", r"[a-c0-2]+", r"^[^a-z]*$", r"\d+", r"\D+", r"\w+@\w+\.\w+", r"\s", r"\S+\s\S+",
+          r"^\s+\S", r"\bfoo\b", r"\Bo", r"foo\.bar", r"foo.bar", r"a\+b", r"a\*b", r"\(x\)", r"\[y\]", r"a\|b", r".", r"^.$",
+          r"^..$", r"a.b", r"(?i)hello", r"(?i)^HELLO$", r"(?i:h)ello", r"(?s)a.b", r"(?m)^line2$", r"(?m)^b",
+          r"^(\d{1,3}\.){3}\d{1,3}$", r"^\d{4}-\d{2}-\d{2}$", r"(a|ab)(c|bcd)?", r"(a*)*b", r"(a+)+$", r"(a|a)*c", r"x*", r"(?:)",
+          r"[a-]", r"[]a]", r"[\d_]+$", r"[^\W\d]", r"caf.", r"^.{4}$", r"\x61", r"\t", r"[\t ]+$", r"e$|^g", r"(?P<n>ab)c",
+          r"a??b", r"a*?b", r"a+?", r"a{2}?", r"\A2", r"^$|^a$", r"[[]", r"[a\]]", r"\.\d+\."]
+
+
+@pytest.mark.parametrize("pattern", SHARED)
+def test_agrees_with_python_re(pattern):
+    rx = re.compile(pattern, re.ASCII)   # Go: \w \d \s \b are ASCII classes
+    for text in CORPUS:
+        assert match(pattern, text) == (1 if rx.search(text) else 0), (pattern, text)
+
+
+def test_go_specific_syntax():
+    # \z (end of text; Python spells it \Z), $ without (?m) is end of TEXT (a trailing newline does not count)
+    assert match(r"b\z", "ab") == 1 and match(r"a\z", "ab") == 0
+    assert match(r"a$", "a\n") == 0 and match(r"(?m)a$", "a\nb") == 1
+    # POSIX classes inside sets
+    assert match(r"^[[:alpha:]]+$", "Hello") == 1 and match(r"^[[:alpha:]]+$", "abc123") == 0
+    assert match(r"[[:digit:][:space:]]", "x y") == 1 and match(r"^[[:^digit:]]+$", "abc") == 1 and match(r"^[[:^digit:]]+$", "ab1") == 0
+    assert match(r"[[:word:]]", "_") == 1 and match(r"[[:punct:]]", "a-b") == 1 and match(r"[[:upper:]]", "abc") == 0
+    # \s is [\t\n\f\r ] -- no vertical tab (unlike Perl / Python)
+    assert match(r"\s", "\v") == 0 and match(r"[[:space:]]", "\v") == 1
+    # flags: (?U) swaps greedy / lazy (immaterial for a yes / no match); (?-i) switches folding off again
+    assert match(r"(?U)a+b", "aab") == 1 and match(r"(?i)a(?-i)b", "AB") == 0 and match(r"(?i)a(?-i)b", "Ab") == 1
+    # a flag group in mid-pattern applies from there on (Python would apply it to the whole pattern)
+    assert match(r"h(?i)ELLO", "hello") == 1 and match(r"h(?i)ELLO", "Hello") == 0
+    assert match(r"\x{e9}", "caf\u00e9") == 1 and match(r"\x{4e2d}", "\u4e2d\u6587") == 1 and match(r"\x{e9}", "cafe") == 0
+    # named groups, both spellings; \Q...\E quotes
+    assert match(r"(?P<x>a)(?<y>b)", "ab") == 1 and match(r"\Qa.b\E", "a.b") == 1 and match(r"\Qa.b\E", "axb") == 0
+    # a brace that is no repetition is a literal
+    assert match(r"a{", "a{") == 1 and match(r"a{x}", "a{x}") == 1 and match(r"{z}", "{z}") == 1
+    # . matches a whole rune, not a byte
+    assert match(r"^.$", "é") == 1 and match(r"^..$", "中文") == 1
+    # flags of one alternation branch stay in force to the end of the group
+    assert match(r"(?:a(?i)b|c)", "C") == 1
+
+
+@pytest.mark.parametrize("pattern", [r"a**", r"a++", r"*a", r"(ab", r"ab)", r"[a", r"a{1001}", r"a{3,2}", r"\pL", r"[\p{Greek}]",
+                                     r"\1", r"(?<=a)b", r"(?=a)", r"\8", r"\C", r"(?z)", "\\"])
+def test_rejects_what_go_rejects_or_what_is_not_supported(pattern):
+    assert match(pattern, "abc") == -1
+    assert N.lib().sybl_last_error()
+
+
+def test_linear_time_on_pathological_patterns():
+    # exponential for a backtracking matcher (round 1 used std::regex), linear for a Thompson NFA
+    import time
+    t0 = time.perf_counter()
+    assert match(r"(a*)*b", "a" * 5000) == 0
+    assert match(r"(a|aa)+$", "a" * 5000 + "b") == 0
+    assert match(r"(x+x+)+y", "x" * 3000) == 0
+    assert time.perf_counter() - t0 < 10
+    # long dictionary strings: no recursion on the input
+    assert match(r"^(ab)*$", "ab" * 200_000) == 1
