@@ -74,18 +74,81 @@ def cpu_baseline(workload, total_rows, budget_s=20.0):
 
 
 def measured_traffic(stats, names):
-    """HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE x2 per
-    the gfx950 correction + WRITE_SIZE, in their own runs): bytes per scanned row x this launch's rows.
-    None when no profile of this kernel shape has been recorded."""
+    """(HBM bytes per launch, where the figure comes from): the rocprofv3 PMC passes committed under profiles/
+    (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE, in their own runs) give bytes per scanned row, times this
+    launch's rows.  (None, None) when no profile of this kernel shape has been recorded."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         rec = json.load(open(path))
     except (OSError, ValueError):
-        return None
+        return None, None
     key = "%d_cols_strategy_%d%s" % (len(names), stats["strategy"], "_packed" if stats.get("packed_kernel") else "")
     if key not in rec:
-        return None
-    return rec[key]["hbm_bytes_per_row"] * stats["rows_scanned"]
+        return None, None
+    # (a constant from the committed counter passes x this launch's rows -- not something this run measured)
+    return rec[key]["hbm_bytes_per_row"] * stats["rows_scanned"], "profiles/traffic.json[%s]: %s" % (key, rec[key]["source"])
+
+
+def oracle_check(workload, q, total_rows, head):
+    """The headline result against the CPU oracle at the FULL size, bit for bit: orc_synth_scan regenerates the table
+    on every host thread and runs the reference's row loop in its direct-mapped form (oracle/sybil_oracle.h).  Checker
+    only -- outside every timed region."""
+    from oracle import oracle as orc
+    from sybil_amd import synth
+    t0 = time.perf_counter()
+    o = orc.synth_scan(synth.COLUMNS, synth.SEED, total_rows, 0, total_rows, filters=q.get("filters", ()), groups=q.get("groups", ()),
+                       aggs=q.get("aggs", ()), time_col=q.get("time_col"), time_bucket=q.get("time_bucket", 0), want_buckets=False,
+                       n_threads=os.cpu_count() or 1)
+    dt = time.perf_counter() - t0
+    assert head["matched"] == o["matched"], ("matched rows differ from the oracle", head["matched"], o["matched"])
+    cards = o["cells"][1:]
+    n_aggs = len(q.get("aggs", ()))
+    for row in head["digest"]:
+        tb, key, count, sums = row[0], row[1], row[2], row[3:]
+        cell = tb // q["time_bucket"] - o["tb_min"] if q.get("time_col") else 0
+        for g, card in enumerate(cards):
+            cell = cell * card + (int.from_bytes(key[8 * g:8 * g + 8], "little", signed=True) - o["gmin"][g])
+        assert count == o["count"][cell] and all(sums[a] == o["sum"][a][cell] for a in range(n_aggs)), ("cell differs from the oracle", row)
+    assert len(head["digest"]) == int((o["count"] != 0).sum())
+    return {"rows": total_rows, "matched": int(o["matched"]), "groups": len(head["digest"]),
+            "checked": "matched rows, every group's Count and exact sum(v) per aggregation == orc_synth_scan (bit-exact)",
+            "oracle_seconds": round(dt, 2), "threads": os.cpu_count() or 1}
+
+
+def load_path(ctx, rows=100 * 1024 * 1024 // 65536 * 65536):
+    """Disk -> HBM: the TableBlock load half of the hot path (table_block_io.go:225-310, column_store_io.go:493-780).  A
+    synthetic table is written in the reference's on-disk format (sybl_table_save) and read back with the native loader
+    into compact storage (sybl_table_open_flags); outside every timed scan region."""
+    import shutil
+    import tempfile
+    from sybil_amd import synth
+    names = ["c00", "c01", "c07", "c09"]  # time (delta-friendly), 16 values (bucket encoded), 1e6 values (value encoded), 500 ids
+    root = tempfile.mkdtemp(prefix="sybl_bench_load_")
+    try:
+        t = ctx.synth_table("loadbench", synth.SEED, rows, 0, rows, synth.synth_cols(names))
+        t0 = time.perf_counter()
+        t.save(root)
+        save_s = time.perf_counter() - t0
+        t.free()
+        tdir = os.path.join(root, "loadbench")
+        size = sum(os.path.getsize(os.path.join(dp, f)) for dp, _, fs in os.walk(tdir) for f in fs)
+        best = None
+        for _ in range(2):
+            t0 = time.perf_counter()
+            tb = ctx.open_table(root, "loadbench", compact=True)
+            dt = time.perf_counter() - t0
+            assert tb.rows == rows
+            st = tb.load_stats()
+            hbm = tb.hbm_bytes
+            tb.free()
+            if best is None or dt < best[0]:
+                best = (dt, st, hbm)
+        dt, st, hbm = best
+        return {"rows_per_s": rows / dt, "rows": rows, "columns": names, "seconds": round(dt, 3), "bytes_on_disk": size,
+                "disk_bytes_per_row": size / rows, "hbm_bytes": hbm, "stage_breakdown": st, "save_seconds": round(save_s, 2),
+                "what": "sybl_table_save -> sybl_table_open_flags(SYBL_OPEN_COMPACT), best of 2 (page cache warm)"}
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
 
 
 def main():
@@ -104,8 +167,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the N>1 code path (process group, bound partial tables, all-reduce) even with one rank")
-    ap.add_argument("--collective", choices=["torch", "rccl"], default="torch",
-                    help="torch.distributed (RCCL backend) or the library's own RCCL communicator")
+    ap.add_argument("--collective", choices=["torch", "rccl"], default="rccl",
+                    help="rccl: the library's own communicator (sybl_comm_init / sybl_query_allreduce -- what a Go host "
+                         "calls, the product path); torch: torch.distributed all-reduces of the bound partial tables")
+    ap.add_argument("--no-load", action="store_true", help="skip the disk -> HBM load measurement (N=1 only)")
+    ap.add_argument("--no-oracle-check", action="store_true",
+                    help="skip the full-size bit-exact check of the result against the CPU oracle (N=1 only)")
     args = ap.parse_args()
 
     import torch
@@ -129,7 +196,9 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
 
     wl = synth.WORKLOADS[args.workload]
-    names, q = wl["columns"], wl["query"]
+    names, q = wl["columns"], dict(wl["query"])
+    if args.workload == "cfg4_hist_highcard":
+        q["limit"] = 100  # FLAGS.LIMIT defaults to 100 (cmd_query.go): only the printed rows carry their bucket arrays
     total_rows = args.rows or wl["rows"]
     ctx = sybil_amd.Context(local_rank)
     dev = ctx.device_info()
@@ -183,6 +252,8 @@ def main():
                     qy.bind_torch(device)
         scan_ms = []
 
+        everyone = [False]  # snapshot / finalize are collective calls (bucket arrays merged by reduce-scatter)
+
         def launch(i):
             qy = queries[i % nq]
             qy.scan()
@@ -192,15 +263,20 @@ def main():
                         qy.allreduce_torch()
                 else:
                     qy.allreduce()
-            if rank == 0:
+                    everyone[0] = qy.collective_finalize()
+            if rank == 0 or everyone[0]:
                 qy.snapshot()  # D2H copy of the reduced table, queued behind the all-reduce
 
         def finish(i):
             qy = queries[i % nq]
             res = None
-            if rank == 0:
+            if rank == 0 or everyone[0]:
                 res = qy.finalize()
-                scan_ms.append(qy.stats()["scan_ms"])
+                if rank == 0:
+                    scan_ms.append(qy.stats()["scan_ms"])
+                else:
+                    res.free()
+                    res = None
             elif nq == 1:
                 ctx.sync()
             return res
@@ -248,10 +324,11 @@ def main():
             # would if the all-reduce ever ran ahead of a rank's scan) and group counts must add up
             assert len(seen_matched) == 1, "matched count varies across steps: %r" % sorted(seen_matched)
             assert len(scan_ms) == steps
-            assert sum(g["count"] for g in res.results) == res.matched
+            rows_out = res.time_results if q.get("time_col") else res.rows(0, want_values=False)
+            assert sum(g["count"] for g in rows_out) == res.matched
             out["matched"] = res.matched
-            out["groups"] = len(res.results)
-            out["digest"] = sorted((g["key"], g["count"]) + tuple(h["sum"] for h in g["hists"]) for g in res.results)
+            out["groups"] = len(rows_out)
+            out["digest"] = sorted((g["time_bucket"], g["key"], g["count"]) + tuple(h["sum"] for h in g["hists"]) for g in rows_out)
             res.free()
         for qy in queries:
             qy.free()
@@ -268,14 +345,15 @@ def main():
         if stats["strategy"] in (2, 4, 6):
             kernel = ("k_scan_packed" if stats["packed_kernel"] else "k_scan_fast") + shape
         elif stats["strategy"] == 5:
-            kernel = ("k_emit_packed" if stats["packed_kernel"] else "k_emit") + " + k_part_hist"
+            pk = "_packed" if stats["packed_kernel"] else ""
+            kernel = "k_count%s + k_part_offsets + k_emit%s + k_part_hist" % (pk, pk)
         else:
             kernel = "k_scan<%d>" % len(names)
+        traffic, traffic_source = measured_traffic(stats, names)
         return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": measured_traffic(stats, names), "kernel": kernel, "kernel_ms": ph["kernel_ms"],
+                "traffic": traffic, "traffic_source": traffic_source, "kernel": kernel, "kernel_ms": ph["kernel_ms"],
                 "algorithmic_bytes_per_launch": alg, "stored_bytes_per_row": alg / max(stats["rows_scanned"], 1),
                 "int64_canonical_bytes_per_launch": stats["canonical_bytes"],
-                "int64_canonical_equivalent_GBps": stats["canonical_bytes"] / (ph["kernel_ms"] * 1e-3) / 1e9,
                 "strategy": STRATEGY[stats["strategy"]], "lds_bytes": stats["lds_bytes"], "workgroups": stats["n_workgroups"]}
 
     # Secondary, untimed-for-the-headline measurement: the same table in canonical int64 storage
@@ -293,9 +371,14 @@ def main():
         dt, stats = head["dt"], head["stats"]
         ms_per_step = dt / args.steps * 1e3
         value = total_rows * args.steps / dt
+        what = {"cfg3_filter3_group2_stddev": "3 ANDed int-range filters, group-by 2 cols, count/sum/avg/stddev of 2 cols",
+                "cfg4_hist_highcard": "histogram (p25/p50/p99, every bucket) of 1 col grouped by a 65536-value col, -limit 100",
+                "cfg5_time_rollup": "hourly time buckets x group-by 1 str-like col, sum+count",
+                "cfg2_group1_avg2": "group-by 1 low-card col, sum+avg of 2 cols",
+                "cfg1_count_range": "count(*) with one int-range predicate"}[args.workload]
         out = {
-            "metric": "rows scanned/sec (1B-row x 32-int-col synthetic table, 3 ANDed int-range filters, "
-                      "group-by 2 cols, count/sum/avg/stddev of 2 cols)",
+            "metric": "rows scanned/sec (%s-row x %d-int-col synthetic table, %s)" % (
+                "1B" if total_rows == 1_000_000_000 else str(total_rows), wl["table_cols"], what),
             "value": value, "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "int64", "data": "synthetic",
@@ -317,6 +400,10 @@ def main():
             out["cpu_baseline"], columnar = cpu_baseline(args.workload, total_rows)
             if columnar is not None:
                 out["cpu_baseline_columnar"] = columnar
+            if not args.no_oracle_check:
+                out["oracle_check"] = oracle_check(args.workload, q, total_rows, head)
+        if world == 1 and not args.no_load:
+            out["load"] = load_path(ctx)
         print(json.dumps(out))
         sys.stdout.flush()
     table.free()

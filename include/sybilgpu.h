@@ -163,6 +163,21 @@ int sybl_table_save(sybl_table *t, const char *dir);
 const void *sybl_debug_encode_column(int kind, const char *name, const int64_t *vals, const uint8_t *populated, int64_t n,
                                      const char *const *dict, int64_t n_dict, int64_t *n_bytes);
 
+/* Where the time of the last sybl_table_open of this table went (disk -> HBM, the "TableBlock load" half of the hot
+ * path).  Worker threads read and gob-decode column files a window of blocks ahead; the calling thread interns
+ * dictionaries, copies the compact decoded pieces through a pinned ring and launches the decode kernels in block
+ * order. */
+typedef struct {
+    double wall_s;          /* sybl_table_open, start to finish */
+    double parse_cpu_s;     /* summed over worker threads: file read + gob decode + flatten */
+    double wait_s;          /* calling thread blocked on the next block's worker */
+    double apply_s;         /* calling thread: dictionaries, pinned-ring copies, kernel launches, block commit */
+    int64_t file_bytes;     /* bytes read from column / info files (after gunzip) */
+    int64_t h2d_bytes;      /* bytes that crossed PCIe */
+    int32_t workers, blocks;
+} sybl_load_stats;
+int sybl_table_load_stats(const sybl_table *t, sybl_load_stats *out);
+
 /* Blocks sybl_table_open skipped the way the reference does: unreadable block info.db, NumRecords
  * <= 0, or a column file whose record ids / value count exceed NumRecords ("BLOCK SIZE CHANGED
  * DURING QUERY", column_store_io.go:524-526,572-574,733-735; table_query.go:134-139). */
@@ -267,6 +282,12 @@ int sybl_comm_unique_id(void *id128);
 int sybl_comm_init(sybl_ctx *ctx, const void *id128, int32_t nranks, int32_t rank);
 int sybl_comm_free(sybl_ctx *ctx);
 int sybl_query_allreduce(sybl_query *q);
+
+/* 1 when the last sybl_query_allreduce merged the bucket arrays by reduce-scatter (big histogram tables with a
+ * row limit: every rank keeps the reduced arrays of a slice of the cells, derives its percentiles there and the
+ * summaries are all-gathered).  sybl_query_snapshot and sybl_query_finalize are then COLLECTIVE: every rank
+ * calls them, in the same order; every rank gets the full result.  0: rank-local calls as usual. */
+int sybl_query_collective_finalize(const sybl_query *q);
 
 /* Optional: enqueue the device -> host copy of the (reduced) partials now (after the all-reduce on
  * multi-GPU hosts).  A following sybl_query_finalize then waits for that copy only, not for work

@@ -63,6 +63,14 @@ class GroupRow(C.Structure):
                 ("count", C.c_int64), ("samples", C.c_int64), ("aggs", C.POINTER(AggOut))]
 
 
+class LoadStats(C.Structure):
+    _fields_ = [("wall_s", C.c_double), ("parse_cpu_s", C.c_double), ("wait_s", C.c_double), ("apply_s", C.c_double),
+                ("file_bytes", C.c_int64), ("h2d_bytes", C.c_int64), ("workers", C.c_int32), ("blocks", C.c_int32)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
 class RunStats(C.Structure):
     _fields_ = [("rows_scanned", C.c_int64), ("blocks_scanned", C.c_int64), ("blocks_skipped", C.c_int64),
                 ("algorithmic_bytes", C.c_int64), ("canonical_bytes", C.c_int64), ("scan_ms", C.c_double), ("reduce_ms", C.c_double),
@@ -98,6 +106,7 @@ SIGNATURES = {
     "sybl_debug_encode_column": (C.c_void_p, [C.c_int, C.c_char_p, P, P, C.c_int64, C.POINTER(C.c_char_p), C.c_int64,
                                               C.POINTER(C.c_int64)]),
     "sybl_table_broken_blocks": (C.c_int64, [P]),
+    "sybl_table_load_stats": (C.c_int, [P, C.POINTER(LoadStats)]),
     "sybl_debug_gob_to_json": (C.c_char_p, [C.c_char_p]),
     "sybl_debug_regex_match": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int64]),
     "sybl_table_rows": (C.c_int64, [P]),
@@ -124,6 +133,7 @@ SIGNATURES = {
     "sybl_query_allreduce": (C.c_int, [P]),
     "sybl_query_finalize": (C.c_int, [P, C.POINTER(P)]),
     "sybl_query_snapshot": (C.c_int, [P]),
+    "sybl_query_collective_finalize": (C.c_int, [P]),
     "sybl_result_rows": (C.c_int, [P, C.c_int, C.POINTER(C.POINTER(GroupRow)), C.POINTER(C.c_int64)]),
     "sybl_result_matched": (C.c_int64, [P]),
     "sybl_result_free": (None, [P]),

@@ -100,6 +100,7 @@ static int ensure_partials(Query *q) {
 static int scan(Query *q) {
     int rc = ensure_partials(q);
     if (rc) return rc;
+    q->rs_active = false;
     hipStream_t st = q->ctx->stream;
     ScanPlan &P = q->plan;
     if (q->plan_dirty) {
@@ -380,6 +381,8 @@ int sybl_debug_query_cells(sybl_query *q, int which, int agg, int64_t *out, int6
     }
     return SYBL_OK;
 }
+
+int sybl_query_collective_finalize(const sybl_query *q) { return q && q->rs_active ? 1 : 0; }
 
 int sybl_query_snapshot(sybl_query *q) {
     if (!q) return fail(SYBL_E_INVAL, "NULL argument");

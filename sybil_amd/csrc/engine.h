@@ -44,7 +44,8 @@ hipError_t launch_decode_delta(const int64_t *deltas, int64_t n, bool value_enco
 hipError_t launch_remap_ids(const int32_t *local, const int32_t *lut, int32_t n_lut, int64_t n, int32_t *col, hipStream_t st);
 
 hipError_t launch_hist_summary(const HistSummaryPlan &S, int64_t *total, hipStream_t st);
-hipError_t launch_hist_gather(const int64_t *H, int64_t hist_stride, const int64_t *d_cells, int64_t n, int64_t *out, hipStream_t st);
+hipError_t launch_hist_gather(const int64_t *H, int64_t hist_stride, const int64_t *d_cells, int64_t n, int64_t cell0, int64_t cell1,
+                              int64_t *out, hipStream_t st);
 
 struct Ctx {
     int device = 0;
@@ -117,6 +118,7 @@ struct Table {
     int64_t scratch_words = 0;
     int64_t version = 0;        // bumped by every change a prepared query would not know about
     int64_t broken_blocks = 0;  // blocks the loader skipped (unreadable info / column unpack error)
+    sybl_load_stats load_stats{};  // of the sybl_table_open that built this table
     Column *find(const char *name) const;
 };
 
@@ -163,9 +165,9 @@ struct GroupInfo {
     int col;
     int type;
     int64_t gmin;
-    int32_t gcard;       // digits of this key column incl. a separate MISSING digit, if any
-    int32_t value_card;  // digits that are real values
-    int32_t missing_digit;  // digit missing rows map to (-1: column has no missing rows)
+    int64_t gcard;       // digits of this key column incl. a separate MISSING digit, if any
+    int64_t value_card;  // digits that are real values
+    int64_t missing_digit;  // digit missing rows map to (-1: column has no missing rows)
     bool dict = false;      // digits are ranks in the column's sorted distinct values (Column::gdict)
     bool has_missing;
 };
@@ -230,9 +232,29 @@ struct Query {
     int64_t top_cap = 0;
     hipEvent_t ev_snap = nullptr;   // the device -> host snapshot of the partial tables has landed
     bool snapshot_pending = false;
+    // multi-GPU merge of big bucket tables (rccl.cpp): the bucket arrays were reduce-SCATTERED over cell ranges, this
+    // rank holds the reduced arrays of cells [rs_cell0, rs_cell1) only; percentiles / moments are derived per slice
+    // and all-gathered.  snapshot and finalize are then collective calls (every rank makes them).
+    bool rs_active = false;
+    int64_t rs_cells_per = 0, rs_cell0 = 0, rs_cell1 = 0;
     bool scanned = false;
     sybl_run_stats stats{};
     bool never_matches = false;
+    // hash group-by (strategy 7): the cell table is an open-addressing table over the composite key; after the scan the
+    // live slots are compacted into dense arrays in key order (hash_compact), which is what the all-reduce and
+    // finalize see
+    bool hash_mode = false;
+    uint64_t *d_hash_keys = nullptr;        // [n_cells] slot -> composite key
+    int64_t hash_live = 0;                  // live keys after the last compaction
+    uint64_t *d_dense_keys = nullptr;       // [hash_cap] sorted composite keys
+    uint32_t *d_dense_slots = nullptr;      // [hash_cap] their slots
+    int64_t *d_dense_sum = nullptr, *d_dense_max = nullptr;  // [header][F][hash_live] / [M][hash_live]
+    void *d_sort_tmp = nullptr;
+    size_t sort_tmp_bytes = 0;
+    int64_t hash_cap = 0;                   // dense capacity (= slots)
+    uint64_t *d_hash_count = nullptr;
+    std::vector<uint64_t> h_dense_keys;     // host copy of the sorted keys (finalize, multi-rank union)
+    bool hash_compacted = false;
     // role-specialised kernel (scan_fast.h)
     bool fast = false, fast_gen = false, fast_packed = false;
     int fast_nf = 0, fast_ng = 0, fast_na = 0, fast_mode = 0;
@@ -248,6 +270,12 @@ struct Query {
 int plan_query(Table *t, const sybl_query_desc *d, Query *q);  // planner.cpp
 int query_rescan_without_part_hist(Query *q);
 
+constexpr int kMaxScatterRanks = 64;  // the SUM section is padded so that a reduce-scatter over up to this many ranks fits in place
+bool query_wants_hist_summary(const Query *q);
+// rccl.cpp: collectives on the ctx communicator and stream (SYBL_E_STATE without a communicator)
+int comm_allgather_inplace(Ctx *ctx, int64_t *buf, size_t words_per_rank);
+int comm_allreduce_sum(Ctx *ctx, int64_t *buf, size_t words);
+int query_hash_compact(Query *q);   // hashgroup.hip: live slots -> dense arrays in key order
 int query_snapshot(Query *q);
 int query_finalize(Query *q, Result **out);
 

@@ -183,7 +183,7 @@ __device__ __forceinline__ void process_tile(CPlan &P, const Tile<NC> &t, int64_
         if (r >= nvalid) break;
         bool pass = true;
         bool in_bounds = true;
-        int32_t cell = 0;
+        uint64_t key = 0;  // composite group key: the cell number, or (hash group-by) what is looked up in the hash table
         // ---- filters (aggregate.go:105-116) and group key (aggregate.go:125-143)
 #pragma unroll
         for (int c = 0; c < NC; c++) {
@@ -231,19 +231,19 @@ __device__ __forceinline__ void process_tile(CPlan &P, const Tile<NC> &t, int64_
                         h = (h + 1) & s.dmask;
                     }
                     if (rank < 0) in_bounds = false;
-                    cell += rank * s.gstride;
-                } else if (s.gmissing >= 0) {
-                    cell += s.gmissing;
+                    key += (uint64_t)(int64_t)rank * (uint64_t)s.gstride64;
+                } else if (s.gmissing64 >= 0) {
+                    key += (uint64_t)s.gmissing64;
                 } else {
                     in_bounds = false;
                 }
             } else if (s.flags & kSlotGroup) {
                 if (pop) {
                     uint64_t d = (uint64_t)x - (uint64_t)s.gmin;
-                    if (d >= (uint32_t)s.gvalues) in_bounds = false;
-                    cell += (int32_t)d * s.gstride;
-                } else if (s.gmissing >= 0) {
-                    cell += s.gmissing;
+                    if (d >= (uint64_t)s.gvalues64) in_bounds = false;
+                    key += d * (uint64_t)s.gstride64;
+                } else if (s.gmissing64 >= 0) {
+                    key += (uint64_t)s.gmissing64;
                 } else {
                     in_bounds = false;
                 }
@@ -273,11 +273,38 @@ __device__ __forceinline__ void process_tile(CPlan &P, const Tile<NC> &t, int64_
             if (!tpop) continue;
             int64_t tb = sdiv_trunc(tv, P.time_bucket, P.inv_time_bucket, P.tb_big_div) - P.tb_min;
             if ((uint64_t)tb >= (uint64_t)P.n_tb) in_bounds = false;
-            cell += (int32_t)tb * P.tb_stride;
+            key += (uint64_t)tb * (uint64_t)(int64_t)P.tb_stride;
         }
         if (!in_bounds) {
             overflow += 1;
             continue;
+        }
+        int32_t cell = (int32_t)key;
+        if (!USE_LDS && P.hash_mode) {
+            // hash group-by: find or claim the key's slot (linear probing; a claimed slot never changes hands)
+            const uint32_t mask = (uint32_t)P.n_cells - 1u;
+            uint32_t h = (uint32_t)(splitmix64(key) >> 32) & mask;
+            cell = -1;
+            for (uint32_t probe = 0; probe <= mask; probe++) {
+                uint64_t k = __hip_atomic_load(P.hash_keys + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (k == kHashEmpty) {
+                    unsigned long long expect = kHashEmpty;
+                    if (__hip_atomic_compare_exchange_strong((unsigned long long *)P.hash_keys + h, &expect, (unsigned long long)key, __ATOMIC_RELAXED,
+                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                        k = key;
+                    else
+                        k = expect;
+                }
+                if (k == key) {
+                    cell = (int32_t)h;
+                    break;
+                }
+                h = (h + 1) & mask;
+            }
+            if (cell < 0) {  // the table is full: reported by finalize
+                gadd(P.sum_out + kHdrHashFull, 1);
+                continue;
+            }
         }
 
         // the table this lane accumulates into: the whole cell table, or (LDS window) the
@@ -963,8 +990,8 @@ hipError_t launch_part_hist(const PartHistPlan &P, hipStream_t st) {
 // last bucket stops short of 100 (Count larger than the bucket total) is the last iteration's
 // out[p] = k on slot p(n-1), and untouched zeros above it.
 __global__ __launch_bounds__(256) void k_hist_summary(const HistSummaryPlan S) {
-    const int64_t pair = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (pair >= S.n_cells * S.n_aggs) return;
+    const int64_t pair = S.cell0 * S.n_aggs + (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pair >= S.cell1 * S.n_aggs) return;
     const uint32_t lane = threadIdx.x & 63;
     const int64_t cell = pair / S.n_aggs;
     const int a = (int)(pair - cell * S.n_aggs);
@@ -1012,10 +1039,10 @@ __global__ __launch_bounds__(256) void k_hist_summary(const HistSummaryPlan S) {
 
 // total[w] = sum over cells of H[cell][w]: a block owns a range of cells, threads stride over the
 // words of a cell (coalesced), one atomic per word and block into the zeroed total
-__global__ __launch_bounds__(256) void k_hist_total(const int64_t *__restrict__ H, int64_t hist_stride, int64_t n_cells,
+__global__ __launch_bounds__(256) void k_hist_total(const int64_t *__restrict__ H, int64_t hist_stride, int64_t cell0, int64_t cell1,
                                                     int64_t cells_per_block, int64_t *__restrict__ total) {
-    const int64_t c0 = (int64_t)blockIdx.x * cells_per_block;
-    const int64_t c1 = c0 + cells_per_block < n_cells ? c0 + cells_per_block : n_cells;
+    const int64_t c0 = cell0 + (int64_t)blockIdx.x * cells_per_block;
+    const int64_t c1 = c0 + cells_per_block < cell1 ? c0 + cells_per_block : cell1;
     for (int64_t w = threadIdx.x; w < hist_stride; w += blockDim.x) {
         int64_t acc = 0;
         for (int64_t cell = c0; cell < c1; cell++) acc += H[cell * hist_stride + w];
@@ -1023,25 +1050,31 @@ __global__ __launch_bounds__(256) void k_hist_total(const int64_t *__restrict__ 
     }
 }
 
-// out[i][w] = H[cells[i]][w]: the bucket arrays of the rows that will be printed
+// out[i][w] = H[cells[i]][w]: the bucket arrays of the rows that will be printed.  After a reduce-scatter a rank
+// holds only the cells [cell0, cell1): the other rows are zero and the ranks' buffers are summed.
 __global__ __launch_bounds__(256) void k_hist_gather(const int64_t *__restrict__ H, int64_t hist_stride,
-                                                     const int64_t *__restrict__ cells, int64_t *__restrict__ out) {
+                                                     const int64_t *__restrict__ cells, int64_t cell0, int64_t cell1,
+                                                     int64_t *__restrict__ out) {
     const int64_t cell = cells[blockIdx.x];
-    for (int64_t w = threadIdx.x; w < hist_stride; w += blockDim.x) out[(int64_t)blockIdx.x * hist_stride + w] = H[cell * hist_stride + w];
+    const bool mine = cell >= cell0 && cell < cell1;
+    for (int64_t w = threadIdx.x; w < hist_stride; w += blockDim.x)
+        out[(int64_t)blockIdx.x * hist_stride + w] = mine ? H[cell * hist_stride + w] : 0;
 }
 
 hipError_t launch_hist_summary(const HistSummaryPlan &S, int64_t *total, hipStream_t st) {
-    const int64_t pairs = S.n_cells * S.n_aggs;
+    const int64_t pairs = (S.cell1 - S.cell0) * S.n_aggs;
     if (pairs <= 0) return hipSuccess;
     const int64_t cpb = 64;
-    hipLaunchKernelGGL(k_hist_total, dim3((unsigned)((S.n_cells + cpb - 1) / cpb)), dim3(256), 0, st, S.H, S.hist_stride, S.n_cells, cpb, total);
+    hipLaunchKernelGGL(k_hist_total, dim3((unsigned)((S.cell1 - S.cell0 + cpb - 1) / cpb)), dim3(256), 0, st, S.H, S.hist_stride, S.cell0,
+                       S.cell1, cpb, total);
     hipLaunchKernelGGL(k_hist_summary, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, st, S);
     return hipGetLastError();
 }
 
-hipError_t launch_hist_gather(const int64_t *H, int64_t hist_stride, const int64_t *d_cells, int64_t n, int64_t *out, hipStream_t st) {
+hipError_t launch_hist_gather(const int64_t *H, int64_t hist_stride, const int64_t *d_cells, int64_t n, int64_t cell0, int64_t cell1,
+                              int64_t *out, hipStream_t st) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_hist_gather, dim3((unsigned)n), dim3(256), 0, st, H, hist_stride, d_cells, out);
+    hipLaunchKernelGGL(k_hist_gather, dim3((unsigned)n), dim3(256), 0, st, H, hist_stride, d_cells, cell0, cell1, out);
     return hipGetLastError();
 }
 

@@ -18,6 +18,8 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <deque>
 #include <future>
 #include <thread>
@@ -42,10 +44,18 @@ static bool looks_like_block(const std::string &name) {
     return true;
 }
 
+static std::atomic<int64_t> g_file_bytes{0};   // (statistics of the load in progress: sybl_table_load_stats)
+static std::atomic<int64_t> g_parse_ns{0};
+
 static bool decode_file(const std::string &path, gob::Value &v, std::string &err) {
     std::vector<uint8_t> data;
     if (!gob::read_file(path, data, err)) return false;
+    g_file_bytes += (int64_t)data.size();
     return gob::decode(data.data(), data.size(), v, err);
+}
+
+static double seconds_since(std::chrono::steady_clock::time_point t0) {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
 
 static bool file_exists(const std::string &p) {
@@ -61,6 +71,7 @@ static bool file_exists(const std::string &p) {
 struct Stage {
     char *h = nullptr, *d = nullptr;
     size_t cap = 0, off = 0;
+    int64_t sent = 0;  // bytes handed to hipMemcpyAsync
     hipStream_t st = nullptr;
     int take(size_t bytes, void **hp, void **dp) {
         bytes = (bytes + 255) / 256 * 256;
@@ -91,6 +102,7 @@ struct Stage {
         if (bytes) {
             memcpy(hp, src, bytes);
             SYBL_HIP(hipMemcpyAsync(*dp, hp, bytes, hipMemcpyHostToDevice, st));
+            sent += (int64_t)bytes;
         }
         return SYBL_OK;
     }
@@ -171,6 +183,11 @@ static PreparedBlock prepare_block_unguarded(const std::string &bdir, const std:
 // would be rethrown by future::get() and leave the extern "C" entry point.  The block is skipped instead,
 // like every other block the reference cannot read.
 static PreparedBlock prepare_block(const std::string &bdir, const std::vector<ColSpec> &specs) {
+    const auto t0 = std::chrono::steady_clock::now();
+    struct Tally {
+        std::chrono::steady_clock::time_point t0;
+        ~Tally() { g_parse_ns += (int64_t)(seconds_since(t0) * 1e9); }
+    } tally{t0};
     try {
         return prepare_block_unguarded(bdir, specs);
     } catch (const std::exception &) {
@@ -475,7 +492,9 @@ static int open_table(Ctx *ctx, const char *dir, const char *table, const char *
     std::vector<ColSpec> specs;
     for (auto &cp : t->cols) specs.push_back({cp->name, cp->type});
     // worker threads decode a window of blocks ahead of the (serial, in-order) GPU phase
-    size_t n_workers = std::min<size_t>(32, std::max<unsigned>(1, std::thread::hardware_concurrency()));
+    // (the calling thread's serial phase sustains ~600 M rows/s; round 1's cap of 32 workers left the load parse-bound at
+    // 180 M rows/s on a 256-thread host)
+    size_t n_workers = std::min<size_t>(128, std::max<unsigned>(1, std::thread::hardware_concurrency() / 2));
     if (const char *e = getenv("SYBL_LOADER_THREADS")) n_workers = (size_t)std::max(1, atoi(e));
     const size_t window = n_workers * 2;
     std::deque<std::future<PreparedBlock>> inflight;
@@ -487,11 +506,22 @@ static int open_table(Ctx *ctx, const char *dir, const char *table, const char *
                                           [bdir, &specs]() { return prepare_block(bdir, specs); }));
         }
     };
+    const auto t_open = std::chrono::steady_clock::now();
+    g_file_bytes = 0;
+    g_parse_ns = 0;
+    double wait_s = 0, apply_s = 0;
     submit();
     while (!inflight.empty()) {
+        auto tw = std::chrono::steady_clock::now();
         PreparedBlock pb = inflight.front().get();
+        wait_s += seconds_since(tw);
         inflight.pop_front();
         submit();
+        struct Apply {
+            std::chrono::steady_clock::time_point t0;
+            double *acc;
+            ~Apply() { *acc += seconds_since(t0); }
+        } apply{std::chrono::steady_clock::now(), &apply_s};
         if (pb.unreadable || pb.broken) {
             t->broken_blocks++;
             continue;
@@ -505,6 +535,15 @@ static int open_table(Ctx *ctx, const char *dir, const char *table, const char *
             }
         if ((rc = block_commit(w))) return bail(rc);
     }
+    SYBL_HIP(hipStreamSynchronize(ctx->stream));  // the table is resident when the call returns (and the wall time says so)
+    t->load_stats.wall_s = seconds_since(t_open);
+    t->load_stats.parse_cpu_s = (double)g_parse_ns.load() * 1e-9;
+    t->load_stats.wait_s = wait_s;
+    t->load_stats.apply_s = apply_s;
+    t->load_stats.file_bytes = g_file_bytes.load();
+    t->load_stats.h2d_bytes = stage.sent;
+    t->load_stats.workers = (int32_t)n_workers;
+    t->load_stats.blocks = (int32_t)(b1 - b0);
     *out = t;
     return SYBL_OK;
 }
@@ -537,6 +576,12 @@ int sybl_table_open_flags(sybl_ctx *ctx, const char *dir, const char *table, con
 }
 
 int64_t sybl_table_broken_blocks(const sybl_table *t) { return t ? t->broken_blocks : 0; }
+
+int sybl_table_load_stats(const sybl_table *t, sybl_load_stats *out) {
+    if (!t || !out) return fail(SYBL_E_INVAL, "NULL argument");
+    *out = t->load_stats;
+    return SYBL_OK;
+}
 
 // Test hook: decodes a gob file (optionally gzipped) into JSON; the buffer is owned by the
 // library and valid until the next call on this thread.

@@ -64,6 +64,9 @@ struct SlotDesc {
     uint32_t dmask;
     int32_t width;           // bytes per stored value: 1, 2, 4 or 8
     int64_t vbase;           // added to the raw (unsigned) stored value
+    // the key digit's weight in the 64-bit composite key (== gstride / gmissing / gvalues unless the query groups
+    // through the hash table, where the key space may be as wide as 2^62)
+    int64_t gstride64, gmissing64, gvalues64;
 };
 
 struct AggDesc {
@@ -120,6 +123,11 @@ struct ScanPlan {
     int32_t windowed;
     int32_t lds_cells;       // cells per LDS table (== n_cells unless windowed)
     const int32_t *wg_cell_base;
+    // Hash group-by (strategy 7): the composite key of a row -- sum of digit x gstride64, below 2^62 -- does not index the
+    // cell table but is looked up / inserted in an open-addressing table of n_cells slots (a power of two); the slot
+    // number then plays the role of the cell.  hash_keys[slot] == kHashEmpty marks a free slot.
+    int32_t hash_mode, pad_hash_;
+    uint64_t *hash_keys;
     int64_t hist_off;        // word offset of bucket arrays in the SUM section
     int64_t hist_stride;     // words per cell = sum of n_values over full-hist aggs
     int64_t hist_agg_off[kMaxAggs];
@@ -141,9 +149,13 @@ struct HistSummaryPlan {
     int32_t n_aggs, pad_;
     int64_t agg_off[kMaxAggs], n_values[kMaxAggs], bucket_size[kMaxAggs], hmin[kMaxAggs];
     int32_t f_cnt[kMaxAggs];   // field holding the aggregation's count (0 = Result.Count)
+    int64_t cell0, cell1;      // cells to summarise (a rank's slice after a reduce-scatter; else all of them)
     int64_t *pct;              // [cell * n_aggs + a][100], zeroed
     int64_t *mom;              // [cell * n_aggs + a][2]: sum(b * Values[b]), sum(b^2 * Values[b])
 };
+
+constexpr uint64_t kHashEmpty = ~(uint64_t)0;   // free slot of the group hash table (composite keys are below 2^62)
+constexpr int64_t kHashMaxSlots = (int64_t)1 << 27;
 
 // SUM-section header words
 enum Header : int {
@@ -151,6 +163,7 @@ enum Header : int {
     kHdrOverflow = 1,    // rows whose key / bucket fell outside the declared bounds (must be 0)
     kHdrPartOverflow = 2, // partitioned histograms: records that did not fit their partition buffer
     kHdrEmitStall = 3,    // partitioned histograms: a lane gave up waiting for a staging chunk (must be 0: a bug)
+    kHdrHashFull = 4,     // hash group-by: rows whose key found no free slot (more distinct keys than the table holds)
 };
 
 }  // namespace sybl

@@ -620,13 +620,22 @@ struct Planner {
             gi.missing_digit = -1;
             gi.dict = false;
             // sparse / wide key range: one digit per DISTINCT value instead of one per value of the range
+            const bool hash_ok = !q->time_mode && !getenv("SYBL_NO_HASH");
             if (c->type == SYBL_INT_VAL && !getenv("SYBL_NO_GDICT") &&
                 (c->gdict_blocks == -2 || card > ((unsigned __int128)1 << 22) || card * (unsigned __int128)cells > ((unsigned __int128)1 << 27))) {
-                if ((rc = column_build_gdict(t, c))) return rc;
-                gi.dict = true;
-                card = c->gdict.size();
+                rc = column_build_gdict(t, c);
+                if (rc == SYBL_OK) {
+                    gi.dict = true;
+                    card = c->gdict.size();
+                } else if (rc == SYBL_E_INVAL && hash_ok && card < ((unsigned __int128)1 << 62)) {
+                    // more distinct values than a dictionary holds: the digit is the value's offset in its range and the
+                    // query goes through the hash table
+                    set_error("%s", "");
+                } else {
+                    return rc;
+                }
             }
-            gi.value_card = (int32_t)card;
+            gi.value_card = (int64_t)card;
             if (gi.has_missing) {
                 int64_t minus1 = -1;
                 if (gi.dict) {
@@ -636,23 +645,29 @@ struct Planner {
                     minus1 = -1 - lo;
                 }
                 if (minus1 >= 0) {
-                    gi.missing_digit = (int32_t)minus1;
+                    gi.missing_digit = (int64_t)minus1;
                 } else {
-                    gi.missing_digit = (int32_t)card;
+                    gi.missing_digit = (int64_t)card;
                     card += 1;
                 }
             }
             if (card == 0) card = 1;
-            if (card * (unsigned __int128)cells > ((unsigned __int128)1 << 27))
-                return fail(SYBL_E_INVAL,
-                            "group-by on '%s' needs more than 2^27 direct-mapped cells (value range [%lld,%lld]); "
-                            "hash group-by is not available in this build",
-                            c->name.c_str(), (long long)lo, (long long)hi);
+            if (card * (unsigned __int128)cells > ((unsigned __int128)1 << 27)) {
+                // The reference groups on arbitrary keys through a map (aggregate.go:186-200).  Key spaces that do not
+                // direct-map go through the hash table (strategy 7) as long as the composite key fits 62 bits.
+                if (!hash_ok || card * (unsigned __int128)cells >= ((unsigned __int128)1 << 62))
+                    return fail(SYBL_E_INVAL,
+                                "group-by on '%s' needs more than %s cells (value range [%lld,%lld])",
+                                c->name.c_str(), hash_ok ? "2^62 hashed" : "2^27 direct-mapped (time series do not hash)", (long long)lo,
+                                (long long)hi);
+                q->hash_mode = true;
+            }
             gi.gmin = lo;
-            gi.gcard = (int32_t)card;
+            gi.gcard = (int64_t)card;
             q->groups.push_back(gi);
             cells *= (int64_t)card;
         }
+        if (getenv("SYBL_FORCE_HASH") && !q->time_mode && !q->groups.empty()) q->hash_mode = true;  // (tests: small key spaces too)
         // strides: first group column is the most significant digit (keeps canonical key order
         // equal to cell order)
         {
@@ -665,10 +680,14 @@ struct Planner {
                 SlotDesc &sd = P.slot[s];
                 sd.flags |= kSlotGroup;
                 sd.gmin = q->groups[g].gmin;
-                sd.gcard = q->groups[g].gcard;
-                sd.gstride = (int32_t)stride;
-                sd.gmissing = q->groups[g].missing_digit >= 0 ? (int32_t)(q->groups[g].missing_digit * stride) : -1;
-                sd.gvalues = q->groups[g].value_card;
+                sd.gstride64 = stride;
+                sd.gmissing64 = q->groups[g].missing_digit >= 0 ? q->groups[g].missing_digit * stride : -1;
+                sd.gvalues64 = q->groups[g].value_card;
+                // (the 32-bit copies serve the direct-mapped kernels; a hashed query never reads them)
+                sd.gcard = (int32_t)std::min<int64_t>(q->groups[g].gcard, INT32_MAX);
+                sd.gstride = (int32_t)std::min<int64_t>(stride, INT32_MAX);
+                sd.gmissing = q->groups[g].missing_digit >= 0 ? (int32_t)std::min<int64_t>(q->groups[g].missing_digit * stride, INT32_MAX) : -1;
+                sd.gvalues = (int32_t)std::min<int64_t>(q->groups[g].value_card, INT32_MAX);
                 if (q->groups[g].dict) {
                     const Column *gc = t->cols[(size_t)q->groups[g].col].get();
                     sd.flags |= kSlotDict;
@@ -707,6 +726,15 @@ struct Planner {
             P.tb_big_div = amax >= ((uint64_t)1 << 51);
         }
         n_cells = cells * P.n_tb;
+        if (q->hash_mode) {
+            // slots: twice the keys the table can possibly hold (a row each / the whole key space), a power of two
+            int64_t want = 2 * std::min<int64_t>(std::max<int64_t>(t->logical_rows, 1), cells);
+            if (const char *e = getenv("SYBL_HASH_SLOTS")) want = atoll(e);
+            int64_t slots = 1 << 12;
+            while (slots < want && slots < kHashMaxSlots) slots <<= 1;
+            n_cells = slots;
+            P.hash_mode = 1;
+        }
         P.n_cells = (int32_t)n_cells;
         return SYBL_OK;
     }
@@ -892,7 +920,8 @@ struct Planner {
             P.rep_shift = rs;
             q->lds_bytes = (size_t)(lds_words * 8) << rs;
         }
-        q->n_sum_words = kHeaderWords + (int64_t)F * n_cells + n_cells * hist_stride;
+        // (+ room for the in-place reduce-scatter of the bucket arrays over cell slices of equal size, rccl.cpp)
+        q->n_sum_words = kHeaderWords + (int64_t)F * n_cells + (n_cells + (hist_stride > 0 ? kMaxScatterRanks : 0)) * hist_stride;
         q->n_max_words = std::max<int64_t>((int64_t)M * n_cells, 1);
         return SYBL_OK;
     }

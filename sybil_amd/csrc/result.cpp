@@ -275,7 +275,7 @@ static void make_views(Result *R) {
 // query reuses the buffer for the next finalize unless a live result still holds it (then a fresh
 // one is allocated) -- so a 525 MB histogram table is never copied, page-faulted or unmapped per query.
 // Many cells with bucket arrays: percentiles / bucket moments / Cumulative buckets come from the GPU.
-static bool wants_hist_summary(const Query *q) {
+bool query_wants_hist_summary(const Query *q) {
     const ScanPlan &P = q->plan;
     if (getenv("SYBL_NO_HISTSUMMARY")) return false;
     if (q->op != SYBL_AGG_HIST || !q->want_percentiles || q->time_mode || P.hist_stride <= 0 || q->aggs.empty()) return false;
@@ -294,12 +294,13 @@ int query_snapshot(Query *q) {
     }
     if (!q->h_max) SYBL_HIP(hipHostMalloc((void **)&q->h_max, (size_t)q->n_max_words * 8, hipHostMallocDefault));
     q->h_sum = q->h_sum_buf->p;
-    q->hist_summary = wants_hist_summary(q);
+    q->hist_summary = query_wants_hist_summary(q);
     // the bucket arrays cross PCIe only when every row's are wanted (no limit); otherwise the printed
     // rows' arrays are gathered after the sort (query_finalize)
     q->snap_has_buckets = !q->hist_summary || q->limit <= 0;
     if (q->hist_summary) {
-        const int64_t pairs = (int64_t)P.n_cells * (int64_t)q->aggs.size();
+        // (sized for the padded cell count an in-place all-gather of equal slices needs)
+        const int64_t pairs = ((int64_t)P.n_cells + kMaxScatterRanks) * (int64_t)q->aggs.size();
         if (!q->d_pct) {
             SYBL_HIP(hipMalloc((void **)&q->d_pct, (size_t)pairs * 100 * 8));
             SYBL_HIP(hipMalloc((void **)&q->d_mom, (size_t)pairs * 2 * 8));
@@ -327,10 +328,21 @@ int query_snapshot(Query *q) {
         }
         S.pct = q->d_pct;
         S.mom = q->d_mom;
+        S.cell0 = q->rs_active ? q->rs_cell0 : 0;
+        S.cell1 = q->rs_active ? q->rs_cell1 : P.n_cells;
         hipError_t e = launch_hist_summary(S, q->d_total, st);
         if (e != hipSuccess) return hip_fail(e, "k_hist_summary");
-        SYBL_HIP(hipMemcpyAsync(q->h_pct, q->d_pct, (size_t)pairs * 100 * 8, hipMemcpyDeviceToHost, st));
-        SYBL_HIP(hipMemcpyAsync(q->h_mom, q->d_mom, (size_t)pairs * 2 * 8, hipMemcpyDeviceToHost, st));
+        if (q->rs_active) {
+            // every rank summarised its slice of cells: gather the slices, add up the Cumulative buckets
+            const size_t na = q->aggs.size(), per = (size_t)q->rs_cells_per;
+            int rc = comm_allgather_inplace(q->ctx, q->d_pct, per * na * 100);
+            if (!rc) rc = comm_allgather_inplace(q->ctx, q->d_mom, per * na * 2);
+            if (!rc) rc = comm_allreduce_sum(q->ctx, q->d_total, (size_t)P.hist_stride);
+            if (rc) return rc;
+        }
+        const int64_t real_pairs = (int64_t)P.n_cells * (int64_t)q->aggs.size();
+        SYBL_HIP(hipMemcpyAsync(q->h_pct, q->d_pct, (size_t)real_pairs * 100 * 8, hipMemcpyDeviceToHost, st));
+        SYBL_HIP(hipMemcpyAsync(q->h_mom, q->d_mom, (size_t)real_pairs * 2 * 8, hipMemcpyDeviceToHost, st));
         SYBL_HIP(hipMemcpyAsync(q->h_total, q->d_total, (size_t)P.hist_stride * 8, hipMemcpyDeviceToHost, st));
     }
     const int64_t words = q->snap_has_buckets ? q->n_sum_words : P.hist_off;
@@ -362,11 +374,24 @@ static int attach_top_values(Query *q, Result *R, size_t top) {
     std::vector<int64_t> cells(top);
     for (size_t i = 0; i < top; i++) cells[i] = R->rows[0][i].cell;
     R->top_vals.resize(top * (size_t)P.hist_stride);
-    SYBL_HIP(hipMemcpyAsync(q->d_top_cells, cells.data(), top * 8, hipMemcpyHostToDevice, ctx->aux_stream));
-    hipError_t e = launch_hist_gather(q->d_sum + P.hist_off, P.hist_stride, q->d_top_cells, (int64_t)top, q->d_top, ctx->aux_stream);
-    if (e != hipSuccess) return hip_fail(e, "k_hist_gather");
-    SYBL_HIP(hipMemcpyAsync(R->top_vals.data(), q->d_top, R->top_vals.size() * 8, hipMemcpyDeviceToHost, ctx->aux_stream));
-    SYBL_HIP(hipStreamSynchronize(ctx->aux_stream));
+    if (q->rs_active) {
+        // the printed rows' bucket arrays live on the ranks that own their cells: every rank gathers its own (zeros for
+        // the others) and the buffers are summed -- on the main stream, in step with the other collectives
+        hipStream_t st = ctx->stream;
+        SYBL_HIP(hipMemcpyAsync(q->d_top_cells, cells.data(), top * 8, hipMemcpyHostToDevice, st));
+        hipError_t e = launch_hist_gather(q->d_sum + P.hist_off, P.hist_stride, q->d_top_cells, (int64_t)top, q->rs_cell0, q->rs_cell1, q->d_top, st);
+        if (e != hipSuccess) return hip_fail(e, "k_hist_gather");
+        int rc = comm_allreduce_sum(ctx, q->d_top, top * (size_t)P.hist_stride);
+        if (rc) return rc;
+        SYBL_HIP(hipMemcpyAsync(R->top_vals.data(), q->d_top, R->top_vals.size() * 8, hipMemcpyDeviceToHost, st));
+        SYBL_HIP(hipStreamSynchronize(st));
+    } else {
+        SYBL_HIP(hipMemcpyAsync(q->d_top_cells, cells.data(), top * 8, hipMemcpyHostToDevice, ctx->aux_stream));
+        hipError_t e = launch_hist_gather(q->d_sum + P.hist_off, P.hist_stride, q->d_top_cells, (int64_t)top, 0, P.n_cells, q->d_top, ctx->aux_stream);
+        if (e != hipSuccess) return hip_fail(e, "k_hist_gather");
+        SYBL_HIP(hipMemcpyAsync(R->top_vals.data(), q->d_top, R->top_vals.size() * 8, hipMemcpyDeviceToHost, ctx->aux_stream));
+        SYBL_HIP(hipStreamSynchronize(ctx->aux_stream));
+    }
     for (size_t i = 0; i < top; i++)
         for (size_t a = 0; a < na; a++)
             if (R->agg_pool[(size_t)R->rows[0][i].agg_off + a].present)

@@ -156,6 +156,12 @@ class Table:
     def broken_blocks(self):
         return N.lib().sybl_table_broken_blocks(self._h)
 
+    def load_stats(self):
+        """Where the time of the sybl_table_open that built this table went (sybl_table_load_stats)."""
+        st = N.LoadStats()
+        N.check(N.lib().sybl_table_load_stats(self._h, C.byref(st)))
+        return st.as_dict()
+
     @property
     def hbm_bytes(self):
         return N.lib().sybl_table_hbm_bytes(self._h)
@@ -320,6 +326,11 @@ class Query:
 
     def allreduce(self):
         N.check(N.lib().sybl_query_allreduce(self._h))
+
+    def collective_finalize(self):
+        """True when the last allreduce() scattered the bucket arrays over the ranks: snapshot() and finalize() are
+        then collective calls (every rank makes them and gets the full result)."""
+        return bool(N.lib().sybl_query_collective_finalize(self._h))
 
     def stats(self):
         st = N.RunStats()
