@@ -60,7 +60,7 @@ enum {
 /* FLAGS.OP (aggregate.go:24-29) */
 enum { SYBL_AGG_AVG = 0, SYBL_AGG_HIST = 1 };
 
-#define SYBL_MAX_GROUPS 4
+#define SYBL_MAX_GROUPS 8
 #define SYBL_MAX_AGGS 6
 #define SYBL_MAX_FILTERS 16
 #define SYBL_GROUP_BY_WIDTH 8 /* aggregate.go:16 */
@@ -283,6 +283,18 @@ int sybl_comm_init(sybl_ctx *ctx, const void *id128, int32_t nranks, int32_t ran
 int sybl_comm_free(sybl_ctx *ctx);
 int sybl_query_allreduce(sybl_query *q);
 
+/* Hash group-by (group keys that do not direct-map: more than 2^27 possible cells, or a key column with more than 2^22
+ * distinct values -- the reference's map[string]*Result, aggregate.go:186-200).  The scan aggregates into an
+ * open-addressing table; afterwards the partial table is the DENSE, key-ordered list of the groups this rank found, so
+ * its size is only known after the scan (sybl_query_partials then reports it; sybl_query_bind_partials is refused).
+ * sybl_query_allreduce runs the whole multi-rank protocol.  Hosts with their own collective runtime do it in three
+ * steps: gather every rank's sybl_query_hash_keys (ascending 62-bit composite keys; n = 0 and keys = NULL for a
+ * direct-mapped query), install the sorted union on every rank with sybl_query_hash_install_union (the partial tables
+ * then have identical layouts), all-reduce the buffers sybl_query_partials returns.  `keys` is library-owned, valid
+ * until the next scan / union install of the query. */
+int sybl_query_hash_keys(sybl_query *q, const uint64_t **keys, int64_t *n);
+int sybl_query_hash_install_union(sybl_query *q, const uint64_t *keys, int64_t n);
+
 /* 1 when the last sybl_query_allreduce merged the bucket arrays by reduce-scatter (big histogram tables with a
  * row limit: every rank keeps the reduced arrays of a slice of the cells, derives its percentiles there and the
  * summaries are all-gathered).  sybl_query_snapshot and sybl_query_finalize are then COLLECTIVE: every rank
@@ -344,7 +356,8 @@ typedef struct {
     int32_t strategy;         /* 0 = LDS cell table (generic kernel), 1 = global atomics, 2 = LDS cell table
                                * (role-specialised kernel), 3 / 4 = per-workgroup LDS time window (generic /
                                * role-specialised kernel), 5 = partitioned histograms, 6 = cell table AND
-                               * bucket arrays in LDS */
+                               * bucket arrays in LDS, 7 = hash group-by (open-addressing table in HBM behind an
+                               * LDS staging table; n_cells = slots of the table) */
     int32_t lds_bytes, n_workgroups, replicas;
     int32_t n_sum_fields;     /* int64 fields per cell in the SUM section */
     int32_t n_max_fields;     /* fields per cell in the MAX section; 0 = nothing to MAX-reduce */

@@ -226,6 +226,27 @@ def columnar_scan(fcols, ranges, gcols, gbounds, acols, ageom, n_threads=0):
     return m, out
 
 
+def group_count_sum(key_cols, value_col, mask=None):
+    """Exact group-by for high-cardinality checks (numpy; the map-based orc_query_run takes minutes per million groups):
+    the reference's  result.Count++ / hist sum  per distinct key tuple (aggregate.go:125-143,186-203), with
+    mean = sum / count.  key_cols: list of int64 arrays; returns (keys[n_groups][n_cols] in ascending tuple order,
+    count[n_groups], sum[n_groups]) -- int64 throughout, so the sums are exact."""
+    keys = np.stack([np.asarray(k, dtype=np.int64) for k in key_cols], axis=1)
+    vals = np.asarray(value_col, dtype=np.int64)
+    if mask is not None:
+        keys, vals = keys[mask], vals[mask]
+    order = np.lexsort(tuple(keys[:, c] for c in range(keys.shape[1] - 1, -1, -1)))
+    keys, vals = keys[order], vals[order]
+    if len(keys) == 0:
+        return keys, np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64)
+    new = np.ones(len(keys), dtype=bool)
+    new[1:] = np.any(keys[1:] != keys[:-1], axis=1)
+    starts = np.flatnonzero(new)
+    counts = np.diff(np.append(starts, len(keys))).astype(np.int64)
+    sums = np.add.reduceat(vals, starts).astype(np.int64)
+    return keys[starts], counts, sums
+
+
 # ---------------------------------------------------------------- full-size checker
 class _SynCol(C.Structure):
     _fields_ = [("kind", C.c_int32), ("col_index", C.c_int32), ("a", C.c_int64), ("b", C.c_int64)]

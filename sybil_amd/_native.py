@@ -15,7 +15,7 @@ NO_VAL, INT_VAL, STR_VAL, SET_VAL = 0, 1, 2, 3
 OPS = {"gt": 0, "lt": 1, "eq": 2, "neq": 3, "re": 4, "nre": 5, "in": 6, "nin": 7}
 AGG_AVG, AGG_HIST = 0, 1
 SYN_UNIFORM, SYN_TIME, SYN_BELL = 0, 1, 2
-MAX_GROUPS, MAX_AGGS, MAX_FILTERS = 4, 6, 16
+MAX_GROUPS, MAX_AGGS, MAX_FILTERS = 8, 6, 16
 
 
 class SyblError(RuntimeError):
@@ -131,6 +131,8 @@ SIGNATURES = {
     "sybl_comm_init": (C.c_int, [P, P, C.c_int32, C.c_int32]),
     "sybl_comm_free": (C.c_int, [P]),
     "sybl_query_allreduce": (C.c_int, [P]),
+    "sybl_query_hash_keys": (C.c_int, [P, C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.c_int64)]),
+    "sybl_query_hash_install_union": (C.c_int, [P, P, C.c_int64]),
     "sybl_query_finalize": (C.c_int, [P, C.POINTER(P)]),
     "sybl_query_snapshot": (C.c_int, [P]),
     "sybl_query_collective_finalize": (C.c_int, [P]),

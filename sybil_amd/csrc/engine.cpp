@@ -84,6 +84,7 @@ static void free_query(Query *q) {
     if (q->h_total) hipHostFree(q->h_total);
     if (q->d_top) hipFree(q->d_top);
     if (q->d_top_cells) hipFree(q->d_top_cells);
+    query_hash_free(q);
     delete q;
 }
 static int ensure_partials(Query *q) {
@@ -103,6 +104,7 @@ static int scan(Query *q) {
     q->rs_active = false;
     hipStream_t st = q->ctx->stream;
     ScanPlan &P = q->plan;
+    if (q->hash_mode && (rc = query_hash_reset(q))) return rc;  // (allocates the key table on first use: before the plan is copied)
     if (q->plan_dirty) {
         P.sum_out = q->d_sum;
         P.max_out = q->d_max;
@@ -156,7 +158,10 @@ static int scan(Query *q) {
         if (e != hipSuccess) return hip_fail(e, "k_fill64");
     }
     SYBL_HIP(hipEventRecord(q->ev[0], st));
-    if (ran) {
+    if (ran && q->hash_mode) {
+        e = launch_scan_hash(q->d_plan, P.n_slots, q->n_wg, q->lds_bytes, st);
+        if (e != hipSuccess) return hip_fail(e, "k_scan_hash");
+    } else if (ran) {
         if (q->fast) {
             q->fplan.sum_out = q->d_sum;
             q->fplan.max_out = q->d_max;
@@ -188,7 +193,7 @@ static int scan(Query *q) {
 int query_rescan_without_part_hist(Query *q) {
     q->part_hist = false;
     q->stats.packed_kernel = q->fast && q->fast_packed;
-    q->stats.strategy = q->use_lds ? (q->plan.windowed ? (q->fast ? 4 : 3) : (q->fast ? 2 : 0)) : 1;
+    q->stats.strategy = q->use_lds ? (q->plan.windowed ? (q->fast ? 4 : 3) : (q->fast ? 2 : 0)) : (q->hash_mode ? 7 : 1);
     return scan(q);
 }
 
@@ -301,6 +306,17 @@ int sybl_query_scan(sybl_query *q) {
 int sybl_query_partials(sybl_query *q, void **d_sum, int64_t *n_sum_words, void **d_max, int64_t *n_max_words) {
     if (!q) return fail(SYBL_E_INVAL, "query is NULL");
     SYBL_HIP(hipSetDevice(q->ctx->device));
+    if (q->hash_mode) {
+        // the canonical (dense, key-ordered) form of the hash table: sizes are known once the scan has run
+        if (!q->scanned) return fail(SYBL_E_STATE, "a hash group-by has no partial-table layout before its scan (sybl_query_scan first)");
+        int rc = query_hash_compact(q);
+        if (rc) return rc;
+        if (d_sum) *d_sum = q->d_dense_sum;
+        if (d_max) *d_max = q->d_dense_max;
+        if (n_sum_words) *n_sum_words = hash_dense_sum_words(q, q->hash_live);
+        if (n_max_words) *n_max_words = hash_dense_max_words(q, q->hash_live);
+        return SYBL_OK;
+    }
     if (d_sum || d_max) {
         int rc = ensure_partials(q);
         if (rc) return rc;
@@ -315,6 +331,9 @@ int sybl_query_partials(sybl_query *q, void **d_sum, int64_t *n_sum_words, void 
 int sybl_query_bind_partials(sybl_query *q, void *d_sum, void *d_max) {
     if (!q || !d_sum || !d_max) return fail(SYBL_E_INVAL, "sybl_query_bind_partials: NULL argument");
     SYBL_HIP(hipSetDevice(q->ctx->device));
+    if (q->hash_mode)
+        return fail(SYBL_E_INVAL, "a hash group-by keeps its partials in library-owned buffers whose size follows the keys found "
+                                  "(sybl_query_partials after the scan)");
     if (q->own_partials) {
         SYBL_HIP(hipStreamSynchronize(q->ctx->stream));
         if (q->d_sum) hipFree(q->d_sum);
@@ -358,7 +377,7 @@ int sybl_debug_query_cells(sybl_query *q, int which, int agg, int64_t *out, int6
     if (!q->scanned || !q->h_sum || q->snapshot_pending) return fail(SYBL_E_STATE, "sybl_debug_query_cells: no finalized scan");
     if (which < 0 || which > 3 || (which > 0 && (agg < 0 || agg >= (int)q->aggs.size()))) return fail(SYBL_E_INVAL, "bad field");
     const ScanPlan &P = q->plan;
-    const int64_t ncell = P.n_cells, na = (int64_t)q->aggs.size();
+    const int64_t ncell = q->hash_mode ? q->hash_live : P.n_cells, na = (int64_t)q->aggs.size();
     const int64_t *F = q->h_sum + kHeaderWords;
     *n_cells = ncell;
     const int64_t n = std::min<int64_t>(cap, ncell);
@@ -383,6 +402,30 @@ int sybl_debug_query_cells(sybl_query *q, int which, int agg, int64_t *out, int6
 }
 
 int sybl_query_collective_finalize(const sybl_query *q) { return q && q->rs_active ? 1 : 0; }
+
+int sybl_query_hash_keys(sybl_query *q, const uint64_t **keys, int64_t *n) {
+    if (!q || !keys || !n) return fail(SYBL_E_INVAL, "NULL argument");
+    *keys = nullptr;
+    *n = 0;
+    if (!q->hash_mode) return SYBL_OK;  // direct-mapped: every rank has the same cells already
+    if (!q->scanned) return fail(SYBL_E_STATE, "sybl_query_hash_keys before sybl_query_scan");
+    SYBL_HIP(hipSetDevice(q->ctx->device));
+    int rc = query_hash_compact(q);
+    if (rc) return rc;
+    *keys = q->h_dense_keys.data();
+    *n = q->hash_live;
+    return SYBL_OK;
+}
+
+int sybl_query_hash_install_union(sybl_query *q, const uint64_t *keys, int64_t n) {
+    if (!q) return fail(SYBL_E_INVAL, "NULL argument");
+    if (!q->hash_mode) return fail(SYBL_E_STATE, "the query is direct-mapped (sybl_query_hash_keys returned no keys)");
+    if (!q->scanned) return fail(SYBL_E_STATE, "sybl_query_hash_install_union before sybl_query_scan");
+    SYBL_HIP(hipSetDevice(q->ctx->device));
+    int rc = query_hash_compact(q);
+    if (rc) return rc;
+    return query_hash_install_union(q, keys, n);
+}
 
 int sybl_query_snapshot(sybl_query *q) {
     if (!q) return fail(SYBL_E_INVAL, "NULL argument");

@@ -156,6 +156,7 @@ int block_commit(BlockWriter &w);
 // pinned host memory owned jointly by a query and the results that point into it
 struct HostBuf {
     int64_t *p = nullptr;
+    int64_t words = 0;
     ~HostBuf() {
         if (p) (void)hipHostFree(p);
     }
@@ -240,21 +241,25 @@ struct Query {
     bool scanned = false;
     sybl_run_stats stats{};
     bool never_matches = false;
-    // hash group-by (strategy 7): the cell table is an open-addressing table over the composite key; after the scan the
-    // live slots are compacted into dense arrays in key order (hash_compact), which is what the all-reduce and
-    // finalize see
+    // hash group-by (strategy 7, hashgroup.hip): the cell table is an open-addressing table over the composite key; after
+    // the scan the live slots are compacted into dense arrays in key order (query_hash_compact), which is what the
+    // all-reduce and finalize see
     bool hash_mode = false;
     uint64_t *d_hash_keys = nullptr;        // [n_cells] slot -> composite key
-    int64_t hash_live = 0;                  // live keys after the last compaction
-    uint64_t *d_dense_keys = nullptr;       // [hash_cap] sorted composite keys
-    uint32_t *d_dense_slots = nullptr;      // [hash_cap] their slots
-    int64_t *d_dense_sum = nullptr, *d_dense_max = nullptr;  // [header][F][hash_live] / [M][hash_live]
+    bool hash_compacted = false;
+    int64_t hash_live = 0;                  // keys of the dense form (live slots; after a union install: the union)
+    uint64_t *d_pair_keys = nullptr;        // (key, slot) of the live slots, unsorted
+    uint32_t *d_pair_slots = nullptr;
+    uint64_t *d_dense_keys = nullptr;       // sorted composite keys
+    uint32_t *d_dense_slots = nullptr;      // their slots
+    int64_t *d_dense_sum = nullptr;         // [header][F][hash_live], then [hash_live][hist_stride]
+    int64_t *d_dense_max = nullptr;         // [M][hash_live]
+    int64_t pair_cap = 0, pair_slots_cap = 0, dense_keys_cap = 0, dense_slots_cap = 0, dense_sum_cap = 0, dense_max_cap = 0;
     void *d_sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
-    int64_t hash_cap = 0;                   // dense capacity (= slots)
     uint64_t *d_hash_count = nullptr;
     std::vector<uint64_t> h_dense_keys;     // host copy of the sorted keys (finalize, multi-rank union)
-    bool hash_compacted = false;
+    int64_t h_max_words = 0;                // capacity of h_max
     // role-specialised kernel (scan_fast.h)
     bool fast = false, fast_gen = false, fast_packed = false;
     int fast_nf = 0, fast_ng = 0, fast_na = 0, fast_mode = 0;
@@ -275,7 +280,16 @@ bool query_wants_hist_summary(const Query *q);
 // rccl.cpp: collectives on the ctx communicator and stream (SYBL_E_STATE without a communicator)
 int comm_allgather_inplace(Ctx *ctx, int64_t *buf, size_t words_per_rank);
 int comm_allreduce_sum(Ctx *ctx, int64_t *buf, size_t words);
-int query_hash_compact(Query *q);   // hashgroup.hip: live slots -> dense arrays in key order
+// hashgroup.hip
+hipError_t launch_scan_hash(const ScanPlan *d_plan, int n_slots, int n_wg, size_t lds_bytes, hipStream_t st);
+int query_hash_reset(Query *q);     // every slot free (before a scan)
+int query_hash_compact(Query *q);   // live slots -> dense arrays in key order
+int query_hash_install_union(Query *q, const uint64_t *keys, int64_t n);                // host keys
+int query_hash_install_union_device(Query *q, const uint64_t *d_union, int64_t n);      // device keys
+int hash_union_of_lists(Query *q, const uint64_t *d_lists, int64_t total, uint64_t **out, int64_t *n_out);
+int64_t hash_dense_sum_words(const Query *q, int64_t n);
+int64_t hash_dense_max_words(const Query *q, int64_t n);
+void query_hash_free(Query *q);
 int query_snapshot(Query *q);
 int query_finalize(Query *q, Result **out);
 

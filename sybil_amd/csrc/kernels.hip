@@ -25,153 +25,12 @@
 
 #include "plan.h"
 #include "scan_fast.h"
+#include "scan_generic.h"
 
 namespace sybl {
 
-typedef long long ll2 __attribute__((ext_vector_type(2)));
-// The plan lives in device memory and is read through the constant address space so every
-// field access is a scalar (s_load) through the scalar cache: the plan is wave-uniform, far
-// larger than the SGPR file, and must never be copied to scratch.
-typedef const ScanPlan __attribute__((address_space(4))) CPlan;
-typedef const SlotDesc __attribute__((address_space(4))) CSlot;
-typedef const AggDesc __attribute__((address_space(4))) CAgg;
-
-// ---------------------------------------------------------------- small helpers
-
-__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
-    x += 0x9E3779B97F4A7C15ull;
-    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-    return x ^ (x >> 31);
-}
-
-// floor(n / d) for 0 <= n, d > 0 without the ~100-instruction 64-bit divide:
-// double reciprocal + one correction step (exact while n < 2^52).
-__device__ __forceinline__ uint64_t udiv_fast(uint64_t n, uint64_t d, double inv_d, int big) {
-    if (big) return n / d;
-    uint64_t q = (uint64_t)((double)n * inv_d);
-    int64_t r = (int64_t)(n - q * d);
-    if (r < 0) {
-        q -= 1;
-    } else if ((uint64_t)r >= d) {
-        q += 1;
-    }
-    return q;
-}
-
-// Go's truncating int64 division by a positive constant (aggregate.go:174, hist_basic.go:130)
-__device__ __forceinline__ int64_t sdiv_trunc(int64_t x, int64_t d, double inv_d, int big) {
-    uint64_t ux = x < 0 ? (uint64_t)0 - (uint64_t)x : (uint64_t)x;
-    uint64_t q = udiv_fast(ux, (uint64_t)d, inv_d, big);
-    return x < 0 ? -(int64_t)q : (int64_t)q;
-}
-
-__device__ __forceinline__ uint32_t dict_hash(int64_t x) { return (uint32_t)(splitmix64((uint64_t)x) >> 32); }
-
-template <bool USE_LDS>
-__device__ __forceinline__ void acc_add(int64_t *tab, int64_t idx, int64_t v) {
-    if (USE_LDS) {
-        __hip_atomic_fetch_add(&tab[idx], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    } else {
-        __hip_atomic_fetch_add(&tab[idx], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
-template <bool USE_LDS>
-__device__ __forceinline__ void acc_max(int64_t *tab, int64_t idx, int64_t v) {
-    // a plain read first: after warm-up almost no value raises the extremum, and a stale
-    // (smaller) read only costs one redundant atomic
-    if (v > tab[idx]) {
-        if (USE_LDS) {
-            __hip_atomic_fetch_max(&tab[idx], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        } else {
-            __hip_atomic_fetch_max(&tab[idx], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-}
-
-__device__ __forceinline__ void gadd(int64_t *p, int64_t v) {
-    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-__device__ __forceinline__ int64_t wave_sum(int64_t v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-
 // ---------------------------------------------------------------- the scan
-
-template <int NC>
-struct Tile {
-    ll2 v[NC];         // two consecutive rows per slot
-    uint32_t pop[NC];  // 2 validity bits per slot (bit0 = row0, bit1 = row1)
-};
-
-// The loaded bits of a tile are kept raw and decoded (value = vbase + zero-extended raw) only when the
-// tile is consumed.  The load instruction is the same 16-byte buffer load for every stored width -- its
-// descriptor spans exactly the wave's 128 rows, so the lanes of a narrow column read nothing beyond
-// them -- which keeps the issue branch-free and a tile's loads back to back (see fast_issue in
-// scan_fast.h for what a width switch around the loads costs).
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-template <int NC>
-struct RawTile {
-    u32x4 v[NC];
-    uint32_t pw[NC];  // validity word of the two rows (all ones: fully populated column)
-};
-
-template <int NC>
-__device__ __forceinline__ void issue_tile(CPlan &P, int64_t row, RawTile<NC> &t) {
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)row), hi = __builtin_amdgcn_readfirstlane((uint32_t)(row >> 32));
-    const int64_t row0 = (int64_t)(((uint64_t)hi << 32) | lo);  // the wave's first row
-    const uint32_t lane_row = (uint32_t)(row - row0);
-#pragma unroll
-    for (int c = 0; c < NC; c++) {
-        CSlot &s = P.slot[c];
-        if (!(s.flags & kSlotSet)) {  // set columns: the CSR is walked per row (process_tile)
-            const int ws = s.width == 8 ? 3 : s.width >> 1;
-            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)s.base + (row0 << ws)), 0,
-                                                                                  (int)((64u * kRowsPerThread) << ws), 0x00020000);
-            t.v[c] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)((lane_row << ws) & ~3u), 0, 2);
-        }
-        t.pw[c] = s.valid ? s.valid[row >> 5] : 0xFFFFFFFFu;
-    }
-}
-
-template <int NC>
-__device__ __forceinline__ void decode_tile(CPlan &P, int64_t row, bool in_range, const RawTile<NC> &r, Tile<NC> &t) {
-#pragma unroll
-    for (int c = 0; c < NC; c++) {
-        CSlot &s = P.slot[c];
-        ll2 v = {0, 0};
-        if (!(s.flags & kSlotSet)) {
-            const u32x4 w = r.v[c];
-            switch (s.width) {
-            case 8:
-                v.x = (long long)(((unsigned long long)w.y << 32) | w.x);
-                v.y = (long long)(((unsigned long long)w.w << 32) | w.z);
-                break;
-            case 4:
-                v.x = s.vbase + (long long)w.x;
-                v.y = s.vbase + (long long)w.y;
-                break;
-            case 2:
-                v.x = s.vbase + (long long)(w.x & 0xFFFFu);
-                v.y = s.vbase + (long long)(w.x >> 16);
-                break;
-            default: {
-                const uint32_t x = w.x >> ((uint32_t)(row & 2) * 8u);  // rows 4k+2, 4k+3 sit in the upper half
-                v.x = s.vbase + (long long)(x & 0xFFu);
-                v.y = s.vbase + (long long)((x >> 8) & 0xFFu);
-                break;
-            }
-            }
-        }
-        t.v[c] = v;
-        t.pop[c] = in_range ? (r.pw[c] >> (row & 31)) & 3u : 0u;
-    }
-}
+// (tile loads, the row body and the small helpers live in scan_generic.h, shared with k_scan_hash)
 
 template <int NC, bool USE_LDS>
 __device__ __forceinline__ void process_tile(CPlan &P, const Tile<NC> &t, int64_t row0, int nvalid, int64_t *sumtab,
@@ -181,132 +40,17 @@ __device__ __forceinline__ void process_tile(CPlan &P, const Tile<NC> &t, int64_
 #pragma unroll
     for (int r = 0; r < kRowsPerThread; r++) {
         if (r >= nvalid) break;
-        bool pass = true;
-        bool in_bounds = true;
-        uint64_t key = 0;  // composite group key: the cell number, or (hash group-by) what is looked up in the hash table
-        // ---- filters (aggregate.go:105-116) and group key (aggregate.go:125-143)
-#pragma unroll
-        for (int c = 0; c < NC; c++) {
-            CSlot &s = P.slot[c];
-            const int64_t x = r == 0 ? t.v[c].x : t.v[c].y;
-            const bool pop = (t.pop[c] >> r) & 1u;
-            if (s.flags & kSlotRange) pass = pass && pop && x >= s.lo && x <= s.hi;
-            if (s.flags & kSlotNeq) {
-                pass = pass && pop;
-                for (int k = 0; k < s.n_neq; k++) pass = pass && x != s.neq[k];
-            }
-            if (s.flags & kSlotSet) {
-                // SetFilter.Filter, filter.go:252-285: "in" = some member equals the id, "nin" = none;
-                // a row without the set column fails both
-                bool ok = pop;
-                if (pop) {
-                    const int64_t *off = (const int64_t *)s.base;
-                    const int64_t lo = off[row0 + r], hi = off[row0 + r + 1];
-                    uint32_t hit = 0;
-                    for (int64_t m = lo; m < hi; m++) {
-                        const int32_t id = s.set_vals[m];
-                        for (int p = 0; p < s.n_setp; p++) hit |= (id == s.set_id[p] ? 1u : 0u) << p;
-                    }
-                    for (int p = 0; p < s.n_setp; p++) ok = ok && (((hit >> p) & 1u) == (uint32_t)s.set_in[p]);
-                }
-                pass = pass && ok;
-            }
-            if (s.flags & kSlotIdMask) {
-                bool ok = false;
-                if (pop && (uint64_t)x < (uint64_t)s.idmask_bits) ok = (s.idmask[x >> 5] >> (x & 31)) & 1u;
-                pass = pass && ok;
-            }
-            if ((s.flags & kSlotGroup) && (s.flags & kSlotDict)) {
-                // sparse key range: the digit is the value's rank among the column's distinct values
-                if (pop) {
-                    uint32_t h = dict_hash(x) & s.dmask;
-                    int32_t rank = -1;
-                    for (uint32_t probe = 0; probe <= s.dmask; probe++) {
-                        const int64_t kx = s.dkeys[h];
-                        if (kx == x) {
-                            rank = s.dranks[h];
-                            break;
-                        }
-                        if (kx == kDictEmpty) break;
-                        h = (h + 1) & s.dmask;
-                    }
-                    if (rank < 0) in_bounds = false;
-                    key += (uint64_t)(int64_t)rank * (uint64_t)s.gstride64;
-                } else if (s.gmissing64 >= 0) {
-                    key += (uint64_t)s.gmissing64;
-                } else {
-                    in_bounds = false;
-                }
-            } else if (s.flags & kSlotGroup) {
-                if (pop) {
-                    uint64_t d = (uint64_t)x - (uint64_t)s.gmin;
-                    if (d >= (uint64_t)s.gvalues64) in_bounds = false;
-                    key += d * (uint64_t)s.gstride64;
-                } else if (s.gmissing64 >= 0) {
-                    key += (uint64_t)s.gmissing64;
-                } else {
-                    in_bounds = false;
-                }
-            }
-        }
-        if (!pass) continue;
+        uint64_t key;
+        int64_t w;
+        const int st = row_prepare<NC>(P, t, r, row0, key, w);
+        if (st == kRowFail) continue;
         matched += 1;  // aggregate.go:117
-
-        // ---- weight (aggregate.go:100-102)
-        int64_t w = 1;
-        if (P.weight_slot >= 0) {
-#pragma unroll
-            for (int c = 0; c < NC; c++)
-                if (c == P.weight_slot) w = r == 0 ? t.v[c].x : t.v[c].y;
-        }
-        // ---- time bucket (aggregate.go:146-183): rows without a time value are dropped
-        //      after they were counted as matched
-        if (P.time_slot >= 0) {
-            int64_t tv = 0;
-            bool tpop = false;
-#pragma unroll
-            for (int c = 0; c < NC; c++)
-                if (c == P.time_slot) {
-                    tv = r == 0 ? t.v[c].x : t.v[c].y;
-                    tpop = (t.pop[c] >> r) & 1u;
-                }
-            if (!tpop) continue;
-            int64_t tb = sdiv_trunc(tv, P.time_bucket, P.inv_time_bucket, P.tb_big_div) - P.tb_min;
-            if ((uint64_t)tb >= (uint64_t)P.n_tb) in_bounds = false;
-            key += (uint64_t)tb * (uint64_t)(int64_t)P.tb_stride;
-        }
-        if (!in_bounds) {
+        if (st == kRowDropped) continue;
+        if (st == kRowOverflow) {
             overflow += 1;
             continue;
         }
-        int32_t cell = (int32_t)key;
-        if (!USE_LDS && P.hash_mode) {
-            // hash group-by: find or claim the key's slot (linear probing; a claimed slot never changes hands)
-            const uint32_t mask = (uint32_t)P.n_cells - 1u;
-            uint32_t h = (uint32_t)(splitmix64(key) >> 32) & mask;
-            cell = -1;
-            for (uint32_t probe = 0; probe <= mask; probe++) {
-                uint64_t k = __hip_atomic_load(P.hash_keys + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (k == kHashEmpty) {
-                    unsigned long long expect = kHashEmpty;
-                    if (__hip_atomic_compare_exchange_strong((unsigned long long *)P.hash_keys + h, &expect, (unsigned long long)key, __ATOMIC_RELAXED,
-                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-                        k = key;
-                    else
-                        k = expect;
-                }
-                if (k == key) {
-                    cell = (int32_t)h;
-                    break;
-                }
-                h = (h + 1) & mask;
-            }
-            if (cell < 0) {  // the table is full: reported by finalize
-                gadd(P.sum_out + kHdrHashFull, 1);
-                continue;
-            }
-        }
-
+        const int32_t cell = (int32_t)key;
         // the table this lane accumulates into: the whole cell table, or (LDS window) the
         // lds_cells cells starting at the workgroup's base
         const int64_t ncell = USE_LDS ? P.lds_cells : P.n_cells;
@@ -317,56 +61,7 @@ __device__ __forceinline__ void process_tile(CPlan &P, const Tile<NC> &t, int64_
         }
         // field f of cell: ((f * ncell + lcell) << rep_shift) + rep
         const int64_t cidx = ((int64_t)lcell << rs) + rep;
-        acc_add<USE_LDS>(sumtab, cidx, w);  // Result.Count += weight (aggregate.go:203)
-        if (P.f_samples >= 0) acc_add<USE_LDS>(sumtab, ((int64_t)P.f_samples * ncell << rs) + cidx, 1);
-
-        // ---- aggregations (aggregate.go:246-261, hist_basic.go:101-151)
-#pragma unroll
-        for (int c = 0; c < NC; c++) {
-            CSlot &s = P.slot[c];
-            if (!(s.flags & kSlotAgg)) continue;
-            const int64_t x = r == 0 ? t.v[c].x : t.v[c].y;
-            const bool pop = (t.pop[c] >> r) & 1u;
-            CAgg &A = P.agg[s.agg_index];
-            if (!pop) continue;
-            if (A.f_pop >= 0) acc_add<USE_LDS>(sumtab, ((int64_t)A.f_pop * ncell << rs) + cidx, 1);
-            if (x > A.max10 || x < A.info_min) continue;  // hist_basic.go:104
-            acc_add<USE_LDS>(sumtab, ((int64_t)A.f_sum * ncell << rs) + cidx, (int64_t)((uint64_t)x * (uint64_t)w));
-            if (A.f_cnt >= 0) acc_add<USE_LDS>(sumtab, ((int64_t)A.f_cnt * ncell << rs) + cidx, w);
-            if (A.f_smp >= 0) acc_add<USE_LDS>(sumtab, ((int64_t)A.f_smp * ncell << rs) + cidx, 1);
-            if (A.m_max >= 0) acc_max<USE_LDS>(maxtab, ((int64_t)A.m_max * ncell << rs) + cidx, x);
-            if (A.m_nmin >= 0) acc_max<USE_LDS>(maxtab, ((int64_t)A.m_nmin * ncell << rs) + cidx, x == INT64_MIN ? INT64_MAX : -x);
-            if (P.hist_mode) {
-                // bucket_value := (value - h.Min) / BucketSize  (hist_basic.go:130)
-                int64_t b = sdiv_trunc(x - A.hmin, A.bucket_size, A.inv_bucket, A.big_div);
-                if (b >= A.n_values || b < 0) {
-                    // Outliers / Underliers (hist_basic.go:132-142): clipped into the edge bucket
-                    // AND remembered.  Their exact n, sum(o), sum(o^2) live in six extra cell
-                    // fields that the planner allocates only when the column bounds make an
-                    // outlier possible at all.
-                    if (A.f_out >= 0) {
-                        const int64_t step = ncell << rs;
-                        int64_t fi = ((int64_t)A.f_out * ncell << rs) + cidx;
-                        unsigned __int128 sq = (unsigned __int128)((__int128)x * (__int128)x);
-                        acc_add<USE_LDS>(sumtab, fi, 1);
-                        acc_add<USE_LDS>(sumtab, fi + step, x);
-                        acc_add<USE_LDS>(sumtab, fi + 2 * step, (int64_t)(uint64_t)(sq & 0xFFFFFFFFu));
-                        acc_add<USE_LDS>(sumtab, fi + 3 * step, (int64_t)(uint64_t)((sq >> 32) & 0xFFFFFFFFu));
-                        acc_add<USE_LDS>(sumtab, fi + 4 * step, (int64_t)(uint64_t)((sq >> 64) & 0xFFFFFFFFu));
-                        acc_add<USE_LDS>(sumtab, fi + 5 * step, (int64_t)(uint64_t)(sq >> 96));
-                    } else {
-                        overflow += 1;  // declared bounds violated; reported by finalize
-                    }
-                    b = b < 0 ? 0 : A.n_values - 1;
-                }
-                if (A.hist_full) {
-                    gadd(P.sum_out + P.hist_off + (int64_t)cell * P.hist_stride + P.hist_agg_off[s.agg_index] + b, w);
-                } else {
-                    acc_add<USE_LDS>(sumtab, ((int64_t)A.f_sb * ncell << rs) + cidx, b * w);
-                    acc_add<USE_LDS>(sumtab, ((int64_t)A.f_sb2 * ncell << rs) + cidx, b * b * w);
-                }
-            }
-        }
+        row_accumulate<NC, USE_LDS>(P, t, r, sumtab, maxtab, ncell, rs, cidx, (int64_t)cell, w, overflow);
     }
 }
 

@@ -344,7 +344,7 @@ static void select_fast_path(Table *t, Query *q, const std::vector<int> &slot_co
 static int select_part_hist(Table *t, Query *q, const std::vector<int> &slot_col, int64_t rows_scanned) {
     q->part_hist = false;
     const ScanPlan &P = q->plan;
-    if (getenv("SYBL_NO_PARTHIST")) return SYBL_OK;
+    if (getenv("SYBL_NO_PARTHIST") || q->hash_mode) return SYBL_OK;
     if (q->op != SYBL_AGG_HIST || !q->want_percentiles || q->time_mode || q->weighted || q->aggs.empty()) return SYBL_OK;
     if (q->fast && q->fplan.hist_lds) return SYBL_OK;  // the bucket arrays already live in LDS
     EmitPlan &E = q->eplan;
@@ -912,7 +912,7 @@ struct Planner {
         q->n_wg = ctx->n_cus > 0 ? ctx->n_cus : 256;
         if (const char *e = getenv("SYBL_WG_PER_CU")) q->n_wg *= std::max(1, atoi(e));
         int64_t lds_words = (int64_t)(F + M) * n_cells;
-        q->use_lds = lds_words * 8 <= kLdsBudgetBytes;
+        q->use_lds = lds_words * 8 <= kLdsBudgetBytes && !q->hash_mode;
         P.rep_shift = 0;
         if (q->use_lds) {
             int rs = 0;
@@ -985,6 +985,18 @@ struct Planner {
         P.windowed = 0;
         P.lds_cells = (int32_t)n_cells;
         P.wg_cell_base = nullptr;
+        if (q->hash_mode) {
+            // LDS staging table of k_scan_hash: keys + every cell field per slot, as many slots (a power of two) as fit.
+            // Bucket arrays cannot be staged (they live in the global table only).
+            int64_t L = 0;
+            if (hist_stride == 0 && !getenv("SYBL_NO_HASH_LDS")) {
+                L = 1;
+                while (2 * L * 8 * (1 + F + M) <= kLdsBudgetBytes) L <<= 1;
+                if (L < 64) L = 0;
+            }
+            P.lds_cells = (int32_t)L;
+            q->lds_bytes = (size_t)(L * 8 * (1 + F + M));
+        }
         if (!q->use_lds && q->time_mode && !getenv("SYBL_NO_WINDOW") && !t->blocks.empty()) {
             const Column *tc = t->cols[(size_t)slot_col[(size_t)P.time_slot]].get();
             std::vector<int32_t> base((size_t)q->n_wg, 0);
@@ -1050,7 +1062,7 @@ struct Planner {
         q->stats.canonical_bytes = rows_scanned * canon_width + set_bytes;
         q->stats.n_cells = (int32_t)n_cells;
         q->stats.packed_kernel = q->part_hist ? q->part_packed : (q->fast && q->fast_packed);
-        q->stats.strategy = q->part_hist ? 5 : (q->use_lds ? (P.windowed ? (q->fast ? 4 : 3) : (q->fast ? (q->fplan.hist_lds ? 6 : 2) : 0)) : 1);
+        q->stats.strategy = q->part_hist ? 5 : (q->use_lds ? (P.windowed ? (q->fast ? 4 : 3) : (q->fast ? (q->fplan.hist_lds ? 6 : 2) : 0)) : (q->hash_mode ? 7 : 1));
         q->stats.lds_bytes = (int32_t)q->lds_bytes;
         q->stats.n_workgroups = q->n_wg;
         q->stats.replicas = 1 << P.rep_shift;

@@ -11,6 +11,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <vector>
 
 #include "engine.h"
 
@@ -36,6 +37,55 @@ int comm_allgather_inplace(Ctx *ctx, int64_t *buf, size_t words_per_rank) {
 int comm_allreduce_sum(Ctx *ctx, int64_t *buf, size_t words) {
     if (!ctx->comm) return fail(SYBL_E_STATE, "no communicator");
     SYBL_NCCL(ncclAllReduce(buf, buf, words, ncclInt64, ncclSum, (ncclComm_t)ctx->comm, ctx->stream));
+    return SYBL_OK;
+}
+
+// Hash group-by across ranks: which keys exist differs from rank to rank, so the ranks first agree on the sorted union of
+// their key lists (all-gather of the counts, all-gather of the padded lists, sort + unique on every GPU), re-lay their
+// dense arrays out over it, and then merge with the usual SUM (+ MAX) all-reduce.
+static int query_hash_allreduce(Query *q) {
+    Ctx *ctx = q->ctx;
+    ncclComm_t comm = (ncclComm_t)ctx->comm;
+    hipStream_t st = ctx->stream;
+    const int R = ctx->comm_nranks, me = ctx->comm_rank;
+    int rc = query_hash_compact(q);
+    if (rc) return rc;
+    int64_t *d_counts = nullptr;
+    SYBL_HIP(hipMalloc((void **)&d_counts, (size_t)R * 8));
+    std::vector<int64_t> counts((size_t)R, 0);
+    counts[(size_t)me] = q->hash_live;
+    SYBL_HIP(hipMemcpyAsync(d_counts + me, &counts[(size_t)me], 8, hipMemcpyHostToDevice, st));
+    ncclResult_t nr = ncclAllGather(d_counts + me, d_counts, 1, ncclInt64, comm, st);
+    hipError_t e = nr == ncclSuccess ? hipMemcpyAsync(counts.data(), d_counts, (size_t)R * 8, hipMemcpyDeviceToHost, st) : hipSuccess;
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(d_counts);
+    if (nr != ncclSuccess) return nccl_fail(nr, "ncclAllGather(key counts)");
+    if (e != hipSuccess) return hip_fail(e, "key counts");
+    int64_t per = 0;
+    for (int r = 0; r < R; r++) per = std::max(per, counts[(size_t)r]);
+    if (per > 0) {
+        uint64_t *d_lists = nullptr, *d_union = nullptr;
+        int64_t n_union = 0;
+        SYBL_HIP(hipMalloc((void **)&d_lists, (size_t)(per * R) * 8));
+        e = hipMemsetAsync(d_lists, 0xFF, (size_t)(per * R) * 8, st);  // padding = kHashEmpty, sorts last
+        if (e == hipSuccess && q->hash_live > 0)
+            e = hipMemcpyAsync(d_lists + (int64_t)me * per, q->d_dense_keys, (size_t)q->hash_live * 8, hipMemcpyDeviceToDevice, st);
+        if (e == hipSuccess) nr = ncclAllGather(d_lists + (int64_t)me * per, d_lists, (size_t)per, ncclUint64, comm, st);
+        if (e == hipSuccess && nr == ncclSuccess) rc = hash_union_of_lists(q, d_lists, per * R, &d_union, &n_union);
+        if (e == hipSuccess && nr == ncclSuccess && !rc) rc = query_hash_install_union_device(q, d_union, n_union);
+        (void)hipStreamSynchronize(st);
+        (void)hipFree(d_lists);
+        if (d_union) (void)hipFree(d_union);
+        if (e != hipSuccess) return hip_fail(e, "hash key exchange");
+        if (nr != ncclSuccess) return nccl_fail(nr, "ncclAllGather(keys)");
+        if (rc) return rc;
+    }
+    const int64_t n = q->hash_live;
+    SYBL_NCCL(ncclGroupStart());
+    SYBL_NCCL(ncclAllReduce(q->d_dense_sum, q->d_dense_sum, (size_t)hash_dense_sum_words(q, n), ncclInt64, ncclSum, comm, st));
+    if (q->plan.n_max_fields > 0 && n > 0)
+        SYBL_NCCL(ncclAllReduce(q->d_dense_max, q->d_dense_max, (size_t)hash_dense_max_words(q, n), ncclInt64, ncclMax, comm, st));
+    SYBL_NCCL(ncclGroupEnd());
     return SYBL_OK;
 }
 
@@ -83,6 +133,7 @@ int sybl_query_allreduce(sybl_query *q) {
     if (!ctx->comm) return fail(SYBL_E_STATE, "no communicator: call sybl_comm_init first");
     SYBL_HIP(hipSetDevice(ctx->device));
     ncclComm_t comm = (ncclComm_t)ctx->comm;
+    if (q->hash_mode) return query_hash_allreduce(q);
     const ScanPlan &P = q->plan;
     const bool has_max = P.n_max_fields > 0;  // (cfg 3: no extremum is tracked -- ONE collective per step)
     const int64_t hist_words = (int64_t)P.n_cells * P.hist_stride, small_words = q->n_sum_words - (hist_words + (P.hist_stride > 0 ? kMaxScatterRanks * P.hist_stride : 0));

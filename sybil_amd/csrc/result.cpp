@@ -277,7 +277,7 @@ static void make_views(Result *R) {
 // Many cells with bucket arrays: percentiles / bucket moments / Cumulative buckets come from the GPU.
 bool query_wants_hist_summary(const Query *q) {
     const ScanPlan &P = q->plan;
-    if (getenv("SYBL_NO_HISTSUMMARY")) return false;
+    if (getenv("SYBL_NO_HISTSUMMARY") || q->hash_mode) return false;
     if (q->op != SYBL_AGG_HIST || !q->want_percentiles || q->time_mode || P.hist_stride <= 0 || q->aggs.empty()) return false;
     for (auto &a : q->aggs)
         if (!a.d.hist_full) return false;
@@ -287,12 +287,25 @@ bool query_wants_hist_summary(const Query *q) {
 int query_snapshot(Query *q) {
     hipStream_t st = q->ctx->stream;
     const ScanPlan &P = q->plan;
-    if (!q->h_sum_buf || q->h_sum_buf.use_count() > 1) {
+    if (q->hash_mode) {
+        int rc = query_hash_compact(q);  // (no-op when the all-reduce already did it)
+        if (rc) return rc;
+    }
+    // a hash group-by snapshots its dense, key-ordered arrays, whose size follows the keys found
+    const int64_t sum_words = q->hash_mode ? hash_dense_sum_words(q, q->hash_live) : q->n_sum_words;
+    const int64_t max_words = q->hash_mode ? hash_dense_max_words(q, q->hash_live) : q->n_max_words;
+    if (!q->h_sum_buf || q->h_sum_buf.use_count() > 1 || q->h_sum_buf->words < sum_words) {
         auto nb = std::make_shared<HostBuf>();
-        SYBL_HIP(hipHostMalloc((void **)&nb->p, (size_t)q->n_sum_words * 8, hipHostMallocDefault));
+        SYBL_HIP(hipHostMalloc((void **)&nb->p, (size_t)sum_words * 8, hipHostMallocDefault));
+        nb->words = sum_words;
         q->h_sum_buf = nb;
     }
-    if (!q->h_max) SYBL_HIP(hipHostMalloc((void **)&q->h_max, (size_t)q->n_max_words * 8, hipHostMallocDefault));
+    if (!q->h_max || q->h_max_words < max_words) {
+        if (q->h_max) SYBL_HIP(hipHostFree(q->h_max));
+        q->h_max = nullptr;
+        SYBL_HIP(hipHostMalloc((void **)&q->h_max, (size_t)max_words * 8, hipHostMallocDefault));
+        q->h_max_words = max_words;
+    }
     q->h_sum = q->h_sum_buf->p;
     q->hist_summary = query_wants_hist_summary(q);
     // the bucket arrays cross PCIe only when every row's are wanted (no limit); otherwise the printed
@@ -345,10 +358,15 @@ int query_snapshot(Query *q) {
         SYBL_HIP(hipMemcpyAsync(q->h_mom, q->d_mom, (size_t)real_pairs * 2 * 8, hipMemcpyDeviceToHost, st));
         SYBL_HIP(hipMemcpyAsync(q->h_total, q->d_total, (size_t)P.hist_stride * 8, hipMemcpyDeviceToHost, st));
     }
-    const int64_t words = q->snap_has_buckets ? q->n_sum_words : P.hist_off;
-    SYBL_HIP(hipMemcpyAsync(q->h_sum, q->d_sum, (size_t)words * 8, hipMemcpyDeviceToHost, st));
-    if (P.n_max_fields > 0)
-        SYBL_HIP(hipMemcpyAsync(q->h_max, q->d_max, (size_t)q->n_max_words * 8, hipMemcpyDeviceToHost, st));
+    if (q->hash_mode) {
+        SYBL_HIP(hipMemcpyAsync(q->h_sum, q->d_dense_sum, (size_t)sum_words * 8, hipMemcpyDeviceToHost, st));
+        if (P.n_max_fields > 0) SYBL_HIP(hipMemcpyAsync(q->h_max, q->d_dense_max, (size_t)max_words * 8, hipMemcpyDeviceToHost, st));
+    } else {
+        const int64_t words = q->snap_has_buckets ? q->n_sum_words : P.hist_off;
+        SYBL_HIP(hipMemcpyAsync(q->h_sum, q->d_sum, (size_t)words * 8, hipMemcpyDeviceToHost, st));
+        if (P.n_max_fields > 0)
+            SYBL_HIP(hipMemcpyAsync(q->h_max, q->d_max, (size_t)q->n_max_words * 8, hipMemcpyDeviceToHost, st));
+    }
     if (!q->ev_snap) SYBL_HIP(hipEventCreateWithFlags(&q->ev_snap, hipEventDisableTiming));
     SYBL_HIP(hipEventRecord(q->ev_snap, st));
     q->snapshot_pending = true;
@@ -436,6 +454,9 @@ int query_finalize(Query *q, Result **out) {
         if (rc) return rc;
         return query_finalize(q, out);
     }
+    if (hs[kHdrHashFull] != 0)
+        return fail(SYBL_E_NOMEM, "hash group-by: the query has more distinct group keys than the %d-slot table holds (%lld rows lost)",
+                    P.n_cells, (long long)hs[kHdrHashFull]);
     if (hs[kHdrOverflow] != 0)
         return fail(SYBL_E_STATE,
                     "%lld rows fell outside the declared column bounds (sybl_table_set_bounds) -- results would be incomplete",
@@ -468,12 +489,14 @@ int query_finalize(Query *q, Result **out) {
         R->n_values.push_back(a.d.n_values);
     }
 
-    const int64_t ncell = P.n_cells, gcells = q->group_cells;
+    // (hash group-by: "cell" i is the i-th key of the dense, key-ordered arrays)
+    const bool hashed = q->hash_mode;
+    const int64_t ncell = hashed ? q->hash_live : P.n_cells, gcells = q->group_cells;
     const int64_t *F = hs + kHeaderWords;
     const int64_t *H = nullptr;
     if (P.hist_stride > 0 && q->snap_has_buckets) {
         R->keep = q->h_sum_buf;  // the rows' bucket arrays live in the snapshot
-        H = hs + P.hist_off;
+        H = hashed ? F + (int64_t)P.n_sum_fields * ncell : hs + P.hist_off;
     }
     const bool summary = q->hist_summary;
     const size_t na = q->aggs.size();
@@ -572,7 +595,7 @@ int query_finalize(Query *q, Result **out) {
         for (size_t i = i0; i < i1; i++) {
             const int64_t cell = live[i];
             load_cell(cell, acc);
-            const int64_t tbi = cell / gcells, gcell = cell - tbi * gcells;
+            const int64_t tbi = hashed ? 0 : cell / gcells, gcell = hashed ? (int64_t)q->h_dense_keys[(size_t)cell] : cell - tbi * gcells;
             RowStore &row = cell_rows[i];
             row.agg_off = (int64_t)(i * na);
             row.cell = cell;

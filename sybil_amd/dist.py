@@ -25,6 +25,29 @@ def merge_partials(sum_words, max_words, group=None, has_max=True):
         dist.all_reduce(max_words, op=dist.ReduceOp.MAX, group=group)
 
 
+def merge_hash_partials(query, device, group=None):
+    """Hash group-by (sybl_query_hash_keys / sybl_query_hash_install_union): the ranks found different key sets, so
+    they first install the sorted union of their keys -- the dense partial arrays then line up -- and merge with the
+    usual SUM / MAX all-reduce.  Call after query.scan(); query.finalize() on any rank then gives the whole result."""
+    import numpy as np
+    mine = query.hash_keys()
+    multi = dist.is_initialized() and dist.get_world_size(group) > 1
+    if multi:
+        parts = [None] * dist.get_world_size(group)
+        dist.all_gather_object(parts, mine, group=group)
+        union = np.unique(np.concatenate(parts))
+    else:
+        union = mine
+    query.hash_install_union(union)
+    if multi:
+        s, m = query.partials_torch(device)
+        query.table.ctx.sync()  # the install ran on the ctx stream, the collective runs on torch's
+        merge_partials(s, m, group=group, has_max=query.stats()["n_max_fields"] > 0)
+        import torch
+        torch.cuda.synchronize(device)
+    return union
+
+
 def agree_bounds(infos, device="cpu", group=None):
     """infos: {column: {"exact_min", "exact_max", "has_missing"}} of this rank's shard (a rank with no
     populated row reports exact_min > exact_max).  Returns the bounds every rank must declare with

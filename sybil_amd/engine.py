@@ -327,6 +327,29 @@ class Query:
     def allreduce(self):
         N.check(N.lib().sybl_query_allreduce(self._h))
 
+    def hash_keys(self):
+        """Hash group-by: the ascending composite keys of the groups this rank found (sybl_query_hash_keys); an empty
+        array for a direct-mapped query."""
+        keys, n = C.POINTER(C.c_uint64)(), C.c_int64()
+        N.check(N.lib().sybl_query_hash_keys(self._h, C.byref(keys), C.byref(n)))
+        return np.ctypeslib.as_array(keys, shape=(n.value,)).copy() if n.value else np.zeros(0, dtype=np.uint64)
+
+    def hash_install_union(self, keys):
+        """Re-lays this rank's dense partial arrays out over the sorted union of every rank's keys."""
+        k = np.ascontiguousarray(keys, dtype=np.uint64)
+        N.check(N.lib().sybl_query_hash_install_union(self._h, k.ctypes.data, k.size))
+
+    def partials_torch(self, device):
+        """The library-owned partial tables as torch tensors sharing the memory (hash group-by: the dense arrays, which
+        cannot be bound to caller tensors because their size follows the keys found)."""
+        import torch
+        ps, ns, pm, nm = self.partials()
+
+        class _Dev:
+            def __init__(self, ptr, n):
+                self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i8", "data": (ptr, False), "version": 2}
+        return (torch.as_tensor(_Dev(ps, ns), device=device), torch.as_tensor(_Dev(pm, nm), device=device))
+
     def collective_finalize(self):
         """True when the last allreduce() scattered the bucket arrays over the ranks: snapshot() and finalize() are
         then collective calls (every rank makes them and gets the full result)."""
