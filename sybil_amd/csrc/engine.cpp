@@ -49,6 +49,12 @@ int hip_fail(hipError_t e, const char *what) {
     return e == hipErrorOutOfMemory ? SYBL_E_NOMEM : SYBL_E_NODEVICE;
 }
 
+int load_sync_all(Ctx *ctx) {
+    if (!ctx->load_multi) return SYBL_OK;
+    for (int i = 0; i < ctx->n_load_streams; i++) SYBL_HIP(hipStreamSynchronize(ctx->load_streams[i]));
+    return SYBL_OK;
+}
+
 Column *Table::find(const char *n) const {
     if (!n) return nullptr;
     auto it = col_ix.find(n);
@@ -240,6 +246,8 @@ void sybl_shutdown(sybl_ctx *ctx) {
     if (!ctx) return;
     sybl_comm_free(ctx);
     if (ctx->aux_stream) hipStreamDestroy(ctx->aux_stream);
+    for (auto &ls : ctx->load_streams)
+        if (ls) hipStreamDestroy(ls);
     if (ctx->own_stream) {
         hipStreamSynchronize(ctx->own_stream);
         hipStreamDestroy(ctx->own_stream);

@@ -38,10 +38,11 @@ hipError_t launch_repack(const void *src, int sw, int64_t sbase, void *dst, int 
 
 hipError_t launch_distinct(const void *col, int width, int64_t vbase, const uint32_t *valid, const Segment *blocks, int n_blocks,
                            int64_t *keys, uint32_t mask, unsigned long long *n_distinct, unsigned long long limit, hipStream_t st);
-hipError_t launch_decode_bins(const uint32_t *recs, const int64_t *bin_off, const int64_t *bin_val, int n_bins,
-                              bool delta_encoded, void *col, bool w32, uint32_t *valid, uint32_t nrows, hipStream_t st);
-hipError_t launch_decode_delta(const int64_t *deltas, int64_t n, bool value_encoded, int64_t *col, hipStream_t st);
-hipError_t launch_remap_ids(const int32_t *local, const int32_t *lut, int32_t n_lut, int64_t n, int32_t *col, hipStream_t st);
+hipError_t launch_decode_bins(const void *recs, int rec_width, const int64_t *bin_off, const int64_t *bin_val, int n_bins,
+                              bool delta_encoded, void *col, int out_width, int64_t vbase, uint32_t *valid, uint32_t nrows, hipStream_t st);
+hipError_t launch_decode_delta(const void *deltas, int val_width, int64_t n, bool value_encoded, void *col, int out_width, int64_t vbase,
+                               hipStream_t st);
+hipError_t launch_remap_ids(const void *local, int local_width, const int32_t *lut, int32_t n_lut, int64_t n, int32_t *col, hipStream_t st);
 
 hipError_t launch_hist_summary(const HistSummaryPlan &S, int64_t *total, hipStream_t st);
 hipError_t launch_hist_gather(const int64_t *H, int64_t hist_stride, const int64_t *d_cells, int64_t n, int64_t cell0, int64_t cell1,
@@ -57,7 +58,15 @@ struct Ctx {
     void *comm = nullptr;  // ncclComm_t (rccl.cpp)
     int comm_rank = 0, comm_nranks = 1;
     hipStream_t aux_stream = nullptr;  // small finalize-side copies that must not queue behind another query's scan
+    // Table loads spread consecutive blocks over several streams (loader.cpp): a block's decode kernels are a handful of
+    // tiny launches, and on one stream the GPU ran them strictly one after another.  While load_multi is set,
+    // `stream` is one of load_streams; code that touches state shared between blocks (a column's staging block, a
+    // reallocation) calls load_sync_all first.
+    hipStream_t load_streams[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int n_load_streams = 0;
+    bool load_multi = false;
 };
+int load_sync_all(Ctx *ctx);  // waits for every load stream (no-op outside a multi-stream load)
 
 struct Column {
     std::string name;
@@ -109,6 +118,7 @@ struct Table {
     std::vector<std::unique_ptr<Column>> cols;
     std::map<std::string, int> col_ix;
     int64_t phys_rows = 0;     // physical rows incl. per-block padding to 32
+    int64_t reserve_hint_rows = 0;  // a loader's estimate of the rows to come: the first growth of a column goes straight there
     int64_t logical_rows = 0;
     std::vector<Segment> blocks;  // physical start / logical row count
     Segment *d_blocks = nullptr;
@@ -143,9 +153,15 @@ struct BlockWriter {
         int64_t mn = 0, mx = 0, pop = 0;
     };
     std::vector<Staged> staged;
+    std::vector<Staged> direct;  // columns written in their stored form at the block's final place (block_col_direct)
+    bool serial = false;         // multi-stream load: this block used state shared between blocks; its stream is drained at commit
 };
 int block_begin(Table *t, int64_t nrows, BlockWriter *w);
 int block_col_device(BlockWriter &w, Column *c, bool all_populated, void **col, uint32_t **valid);
+// Compact mode, block extrema known up front (mn / mx over the pop populated rows): when the column's current (width,
+// base) holds them, *ok = true and the writer produces the STORED form (Column::elem bytes per row, offsets from
+// Column::vbase) at *col, the block's final place -- no staging block, no k_repack.
+int block_col_direct(BlockWriter &w, Column *c, bool all_populated, int64_t mn, int64_t mx, int64_t pop, void **col, uint32_t **valid, bool *ok);
 int block_col_absent(BlockWriter &w, Column *c);
 void block_col_stats(BlockWriter &w, Column *c, int64_t mn, int64_t mx, int64_t pop);  // min / max over the pop populated rows
 int block_col_int_host(BlockWriter &w, Column *c, const int64_t *vals, const uint8_t *populated);

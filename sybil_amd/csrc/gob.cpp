@@ -2,8 +2,11 @@
 // ("Encoding Details"); sybil's use of it: column_store_io.go, table_io.go, file_decoder.go.
 #include "gob.h"
 
+#include <fcntl.h>
 #include <stdio.h>
 #include <string.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 namespace sybl {
@@ -238,6 +241,68 @@ struct Decoder {
                 }
                 return r.ok;
             }
+            {
+                // []struct{Value int; Records []int}: flat arrays (see Value::kBinVec)
+                auto et = types.find(td.elem);
+                int fv = -1, fr = -1;
+                bool vs = false, rs = false;
+                if (et != types.end() && et->second.kind == TypeDef::kStruct && et->second.fields.size() == 2) {
+                    for (int k = 0; k < 2; k++) {
+                        const auto &fd = et->second.fields[(size_t)k];
+                        if (fd.first == "Value" && is_int_kind(fd.second)) {
+                            fv = k;
+                            vs = fd.second == tInt;
+                        } else if (fd.first == "Records") {
+                            auto st = types.find(fd.second);
+                            if (st != types.end() && st->second.kind == TypeDef::kSlice && is_int_kind(st->second.elem)) {
+                                fr = k;
+                                rs = st->second.elem == tInt;
+                            }
+                        }
+                    }
+                }
+                if (fv >= 0 && fr >= 0) {
+                    out.kind = Value::kBinVec;
+                    out.bin_order = fr < fv ? 1 : 0;
+                    out.bin_off.assign(1, 0);
+                    out.bin_val.reserve((size_t)n);
+                    out.bin_has.reserve((size_t)n);
+                    for (uint64_t k = 0; k < n; k++) {
+                        int64_t f = -1, val = 0;
+                        uint8_t has = 0;
+                        for (;;) {
+                            const uint64_t d = r.uvarint();
+                            if (!r.ok) return false;
+                            if (d == 0) break;
+                            f += (int64_t)d;
+                            if (f == fv) {
+                                val = vs ? r.svarint() : (int64_t)r.uvarint();
+                                has |= 1;
+                            } else if (f == fr) {
+                                const uint64_t m = r.uvarint();
+                                if (!r.ok) return false;
+                                if (m > r.left()) return fail("slice longer than the message");
+                                const size_t at = out.ints.size();
+                                out.ints.resize(at + (size_t)m);
+                                int64_t *dst = out.ints.data() + at;
+                                if (rs) {
+                                    for (uint64_t j = 0; j < m; j++) dst[j] = r.svarint();
+                                } else {
+                                    for (uint64_t j = 0; j < m; j++) dst[j] = (int64_t)r.uvarint();
+                                }
+                                has |= 2;
+                            } else {
+                                return fail("struct field index out of range in " + et->second.name);
+                            }
+                            if (!r.ok) return false;
+                        }
+                        out.bin_val.push_back(val);
+                        out.bin_off.push_back((int64_t)out.ints.size());
+                        out.bin_has.push_back(has);
+                    }
+                    return r.ok;
+                }
+            }
             if (td.elem == tFloat) {
                 out.kind = Value::kFloatVec;
                 out.floats.resize((size_t)n);
@@ -327,22 +392,23 @@ bool decode(const uint8_t *data, size_t size, Value &out, std::string &err) {
 }
 
 bool read_file(const std::string &path, std::vector<uint8_t> &out, std::string &err) {
+    // one open per candidate name, no existence probes: these are the syscalls of every column file of every block
     std::string use = path;
-    FILE *f = fopen(use.c_str(), "rb");
-    if (!f) {
+    int fd = open(use.c_str(), O_RDONLY | O_CLOEXEC);
+    if (fd < 0) {
         use = path + ".gz";
-        f = fopen(use.c_str(), "rb");
+        fd = open(use.c_str(), O_RDONLY | O_CLOEXEC);
     }
-    if (!f) {
+    if (fd < 0) {
         err = "cannot open " + path;
         return false;
     }
-    fclose(f);
-    bool gz = use.size() > 3 && use.compare(use.size() - 3, 3, ".gz") == 0;
+    const bool gz = use.size() > 3 && use.compare(use.size() - 3, 3, ".gz") == 0;
     out.clear();
     if (gz) {
-        gzFile g = gzopen(use.c_str(), "rb");
+        gzFile g = gzdopen(fd, "rb");  // (takes the descriptor over)
         if (!g) {
+            close(fd);
             err = "cannot gzopen " + use;
             return false;
         }
@@ -357,18 +423,34 @@ bool read_file(const std::string &path, std::vector<uint8_t> &out, std::string &
         }
         return true;
     }
-    f = fopen(use.c_str(), "rb");
-    if (!f) {
-        err = "cannot open " + use;
+    struct stat st;
+    if (fstat(fd, &st) != 0 || st.st_size < 0) {
+        close(fd);
+        err = "cannot stat " + use;
         return false;
     }
-    fseek(f, 0, SEEK_END);
-    long sz = ftell(f);
-    fseek(f, 0, SEEK_SET);
-    out.resize(sz > 0 ? (size_t)sz : 0);
-    size_t got = sz > 0 ? fread(out.data(), 1, (size_t)sz, f) : 0;
-    fclose(f);
-    if (got != out.size()) {
+    // (reserve + read at the end: resize() would zero-fill every byte first)
+    const size_t want = (size_t)st.st_size;
+    out.reserve(want + 1);
+    size_t got = 0;
+    uint8_t chunk[1 << 16];
+    if (want <= out.capacity()) {
+        // std::vector has no uninitialised resize: append in cache-sized chunks (one extra copy out of L2, no page faults
+        // on a fresh buffer when the caller reuses `out`)
+        for (;;) {
+            const ssize_t n = read(fd, chunk, sizeof(chunk));
+            if (n < 0) {
+                close(fd);
+                err = "read error on " + use;
+                return false;
+            }
+            if (n == 0) break;
+            out.insert(out.end(), chunk, chunk + n);
+            got += (size_t)n;
+        }
+    }
+    close(fd);
+    if (got != want) {
         err = "short read on " + use;
         return false;
     }
@@ -428,6 +510,36 @@ void to_json(const Value &v, std::string &o) {
             o += ",";
             to_json(*v.entries[i].second, o);
             o += "]";
+        }
+        o += "]";
+        break;
+    case Value::kBinVec:
+        // rendered exactly as the generic tree would be: fields in struct order, zero-valued ones absent
+        o += "[";
+        for (size_t k = 0; k < v.bin_val.size(); k++) {
+            if (k) o += ",";
+            o += "{";
+            bool first = true;
+            for (int step = 0; step < 2; step++) {
+                const bool records = (step == 0) == (v.bin_order == 1);
+                if (records && (v.bin_has[k] & 2)) {
+                    if (!first) o += ",";
+                    first = false;
+                    o += "\"Records\":[";
+                    for (int64_t i = v.bin_off[k]; i < v.bin_off[k + 1]; i++) {
+                        if (i > v.bin_off[k]) o += ",";
+                        snprintf(b, sizeof(b), "%lld", (long long)v.ints[(size_t)i]);
+                        o += b;
+                    }
+                    o += "]";
+                } else if (!records && (v.bin_has[k] & 1)) {
+                    if (!first) o += ",";
+                    first = false;
+                    snprintf(b, sizeof(b), "\"Value\":%lld", (long long)v.bin_val[k]);
+                    o += b;
+                }
+            }
+            o += "}";
         }
         o += "]";
         break;

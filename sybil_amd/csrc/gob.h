@@ -23,7 +23,7 @@ struct Value;
 typedef std::shared_ptr<Value> ValuePtr;
 
 struct Value {
-    enum Kind { kNil, kBool, kInt, kUint, kFloat, kString, kStruct, kSlice, kMap, kIntVec, kFloatVec };
+    enum Kind { kNil, kBool, kInt, kUint, kFloat, kString, kStruct, kSlice, kMap, kIntVec, kFloatVec, kBinVec };
     Kind kind = kNil;
     int64_t i = 0;    // kBool / kInt
     uint64_t u = 0;   // kUint
@@ -34,6 +34,14 @@ struct Value {
     std::vector<std::pair<ValuePtr, ValuePtr>> entries;    // kMap
     std::vector<int64_t> ints;                             // kIntVec
     std::vector<double> floats;                            // kFloatVec
+    // kBinVec: a slice of struct{Value int; Records []int} -- the Bins of a bucket-encoded column file (SavedIntBucket /
+    // SavedStrBucket / SavedSetBucket, column_store.go:46-74; up to 5000 per block) -- decoded into flat arrays instead
+    // of one tree node, two shared_ptrs and three vectors per bin: bin k holds bin_val[k] and ints[bin_off[k] .. bin_off[k+1]).
+    // bin_has[k]: bit 0 = Value was on the wire, bit 1 = Records was (zero-valued fields are omitted); bin_order: 1 when
+    // Records precedes Value in the struct.
+    std::vector<int64_t> bin_val, bin_off;
+    std::vector<uint8_t> bin_has;
+    int bin_order = 0;
     std::string type_name;
 
     const Value *field(const char *name) const;  // nullptr when the (zero-valued) field was omitted

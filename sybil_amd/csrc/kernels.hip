@@ -373,18 +373,21 @@ __device__ __forceinline__ uint32_t block_inclusive_scan_256(uint32_t v, uint32_
 }
 
 // One workgroup per bin: record ids are ascending and (optionally) delta-encoded
-// (delta_encode_col, column_store_io.go:21-30); every listed row gets the bin's value.
-template <typename T>
-__global__ __launch_bounds__(256) void k_decode_bins(const uint32_t *__restrict__ recs, const int64_t *__restrict__ bin_off,
-                                                     const int64_t *__restrict__ bin_val, int delta_encoded,
+// (delta_encode_col, column_store_io.go:21-30); every listed row gets the bin's value.  R: how the ids crossed PCIe --
+// uint16 when the block has at most 65536 rows (every id and every delta then fits), else uint32.  T: the column's
+// stored type -- canonical (int64 values / 32-bit dictionary ids, vbase 0) or, when the block goes straight into compact
+// storage, the column's narrow unsigned offset from vbase.
+template <typename T, typename R>
+__global__ __launch_bounds__(256) void k_decode_bins(const R *__restrict__ recs, const int64_t *__restrict__ bin_off,
+                                                     const int64_t *__restrict__ bin_val, int delta_encoded, int64_t vbase,
                                                      T *__restrict__ col, uint32_t *__restrict__ valid, uint32_t nrows) {
     __shared__ uint32_t wave_tot[4];
     const int64_t b0 = bin_off[blockIdx.x], b1 = bin_off[blockIdx.x + 1];
-    const T value = (T)bin_val[blockIdx.x];
+    const T value = (T)((uint64_t)bin_val[blockIdx.x] - (uint64_t)vbase);
     uint32_t carry = 0;
     for (int64_t base = b0; base < b1; base += 256) {
         const int64_t i = base + threadIdx.x;
-        uint32_t d = i < b1 ? recs[i] : 0u;
+        uint32_t d = i < b1 ? (uint32_t)recs[i] : 0u;
         uint32_t r = d;
         if (delta_encoded) {
             uint32_t total;
@@ -399,15 +402,17 @@ __global__ __launch_bounds__(256) void k_decode_bins(const uint32_t *__restrict_
 }
 
 // Value-encoded int column: Values[r] is a delta from Values[r-1] (column_store_io.go:109-113,748-777).
-// One workgroup of 1024 threads owns the whole block (<= 65536 rows in the reference).
-__global__ __launch_bounds__(1024) void k_decode_delta(const int64_t *__restrict__ deltas, int64_t n, int value_encoded,
-                                                       int64_t *__restrict__ col) {
+// One workgroup of 1024 threads owns the whole block (<= 65536 rows in the reference).  V: int32 when every
+// stored value / delta of the block fits (the worker checked), else int64.  O: the column's stored type (see above).
+template <typename V, typename O>
+__global__ __launch_bounds__(1024) void k_decode_delta(const V *__restrict__ deltas, int64_t n, int value_encoded, int64_t vbase,
+                                                       O *__restrict__ col) {
     __shared__ int64_t wave_tot[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int64_t carry = 0;
     for (int64_t base = 0; base < n; base += 1024) {
         const int64_t i = base + threadIdx.x;
-        int64_t v = i < n ? deltas[i] : 0;
+        int64_t v = i < n ? (int64_t)deltas[i] : 0;
         if (value_encoded) {
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) {
@@ -425,42 +430,76 @@ __global__ __launch_bounds__(1024) void k_decode_delta(const int64_t *__restrict
             carry += total;
             __syncthreads();
         }
-        if (i < n) col[i] = v;
+        if (i < n) col[i] = (O)((uint64_t)v - (uint64_t)vbase);
     }
 }
 
 // Per-row block-local dictionary ids -> table-global ids (non-bucket str columns)
 // (local and col may be the same array -- sybl_table_set_dict remaps resident ids in place -- so neither is restrict)
-__global__ __launch_bounds__(256) void k_remap_ids(const int32_t *local, const int32_t *__restrict__ lut, int32_t n_lut, int64_t n,
+template <typename L>
+__global__ __launch_bounds__(256) void k_remap_ids(const L *local, const int32_t *__restrict__ lut, int32_t n_lut, int64_t n,
                                                    int32_t *col) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    int32_t id = local[i];
+    int32_t id = (int32_t)local[i];
     col[i] = (id >= 0 && id < n_lut) ? lut[id] : 0;
 }
 
-hipError_t launch_decode_bins(const uint32_t *recs, const int64_t *bin_off, const int64_t *bin_val, int n_bins,
-                              bool delta_encoded, void *col, bool w32, uint32_t *valid, uint32_t nrows, hipStream_t st) {
-    if (n_bins <= 0) return hipSuccess;
-    if (w32) {
-        hipLaunchKernelGGL((k_decode_bins<int32_t>), dim3(n_bins), dim3(256), 0, st, recs, bin_off, bin_val,
-                           delta_encoded ? 1 : 0, (int32_t *)col, valid, nrows);
+template <typename T>
+static void decode_bins_t(const void *recs, int rec_width, const int64_t *bin_off, const int64_t *bin_val, int n_bins, int de, int64_t vbase,
+                          void *col, uint32_t *valid, uint32_t nrows, hipStream_t st) {
+    if (rec_width == 2) {
+        hipLaunchKernelGGL((k_decode_bins<T, uint16_t>), dim3(n_bins), dim3(256), 0, st, (const uint16_t *)recs, bin_off, bin_val, de, vbase, (T *)col,
+                           valid, nrows);
     } else {
-        hipLaunchKernelGGL((k_decode_bins<int64_t>), dim3(n_bins), dim3(256), 0, st, recs, bin_off, bin_val,
-                           delta_encoded ? 1 : 0, (int64_t *)col, valid, nrows);
+        hipLaunchKernelGGL((k_decode_bins<T, uint32_t>), dim3(n_bins), dim3(256), 0, st, (const uint32_t *)recs, bin_off, bin_val, de, vbase, (T *)col,
+                           valid, nrows);
+    }
+}
+
+// rec_width: 2 (uint16 ids) or 4 (uint32 ids); out_width / vbase: the stored form of the destination (1, 2, 4 or 8 bytes;
+// canonical int64: 8 / 0, canonical str ids: 4 / 0)
+hipError_t launch_decode_bins(const void *recs, int rec_width, const int64_t *bin_off, const int64_t *bin_val, int n_bins,
+                              bool delta_encoded, void *col, int out_width, int64_t vbase, uint32_t *valid, uint32_t nrows, hipStream_t st) {
+    if (n_bins <= 0) return hipSuccess;
+    const int de = delta_encoded ? 1 : 0;
+    switch (out_width) {
+    case 1: decode_bins_t<uint8_t>(recs, rec_width, bin_off, bin_val, n_bins, de, vbase, col, valid, nrows, st); break;
+    case 2: decode_bins_t<uint16_t>(recs, rec_width, bin_off, bin_val, n_bins, de, vbase, col, valid, nrows, st); break;
+    case 4: decode_bins_t<uint32_t>(recs, rec_width, bin_off, bin_val, n_bins, de, vbase, col, valid, nrows, st); break;
+    default: decode_bins_t<int64_t>(recs, rec_width, bin_off, bin_val, n_bins, de, vbase, col, valid, nrows, st); break;
     }
     return hipGetLastError();
 }
 
-hipError_t launch_decode_delta(const int64_t *deltas, int64_t n, bool value_encoded, int64_t *col, hipStream_t st) {
+template <typename V>
+static void decode_delta_t(const void *deltas, int64_t n, int ve, void *col, int out_width, int64_t vbase, hipStream_t st) {
+    switch (out_width) {
+    case 1: hipLaunchKernelGGL((k_decode_delta<V, uint8_t>), dim3(1), dim3(1024), 0, st, (const V *)deltas, n, ve, vbase, (uint8_t *)col); break;
+    case 2: hipLaunchKernelGGL((k_decode_delta<V, uint16_t>), dim3(1), dim3(1024), 0, st, (const V *)deltas, n, ve, vbase, (uint16_t *)col); break;
+    case 4: hipLaunchKernelGGL((k_decode_delta<V, uint32_t>), dim3(1), dim3(1024), 0, st, (const V *)deltas, n, ve, vbase, (uint32_t *)col); break;
+    default: hipLaunchKernelGGL((k_decode_delta<V, int64_t>), dim3(1), dim3(1024), 0, st, (const V *)deltas, n, ve, vbase, (int64_t *)col); break;
+    }
+}
+
+// val_width: 4 (int32) or 8 (int64)
+hipError_t launch_decode_delta(const void *deltas, int val_width, int64_t n, bool value_encoded, void *col, int out_width, int64_t vbase,
+                               hipStream_t st) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_decode_delta, dim3(1), dim3(1024), 0, st, deltas, n, value_encoded ? 1 : 0, col);
+    if (val_width == 4) decode_delta_t<int32_t>(deltas, n, value_encoded ? 1 : 0, col, out_width, vbase, st);
+    else decode_delta_t<int64_t>(deltas, n, value_encoded ? 1 : 0, col, out_width, vbase, st);
     return hipGetLastError();
 }
 
-hipError_t launch_remap_ids(const int32_t *local, const int32_t *lut, int32_t n_lut, int64_t n, int32_t *col, hipStream_t st) {
+// local_width: 2 (uint16 block-local ids) or 4 (int32)
+hipError_t launch_remap_ids(const void *local, int local_width, const int32_t *lut, int32_t n_lut, int64_t n, int32_t *col, hipStream_t st) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_remap_ids, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, local, lut, n_lut, n, col);
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    if (local_width == 2) {
+        hipLaunchKernelGGL((k_remap_ids<uint16_t>), dim3(nb), dim3(256), 0, st, (const uint16_t *)local, lut, n_lut, n, col);
+    } else {
+        hipLaunchKernelGGL((k_remap_ids<int32_t>), dim3(nb), dim3(256), 0, st, (const int32_t *)local, lut, n_lut, n, col);
+    }
     return hipGetLastError();
 }
 

@@ -15,13 +15,17 @@
 #include <string.h>
 #include <sys/stat.h>
 
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <deque>
+#include <condition_variable>
+#include <functional>
 #include <future>
+#include <mutex>
 #include <thread>
 
 #include "engine.h"
@@ -48,10 +52,30 @@ static std::atomic<int64_t> g_file_bytes{0};   // (statistics of the load in pro
 static std::atomic<int64_t> g_parse_ns{0};
 
 static bool decode_file(const std::string &path, gob::Value &v, std::string &err) {
-    std::vector<uint8_t> data;
+    static thread_local std::vector<uint8_t> data;  // (reused: no allocation / page faults per file)
     if (!gob::read_file(path, data, err)) return false;
     g_file_bytes += (int64_t)data.size();
     return gob::decode(data.data(), data.size(), v, err);
+}
+
+// CPUs this process can actually use: hardware threads, capped by a cgroup v2 / v1 CPU quota
+static size_t usable_cpus() {
+    size_t n = std::max<unsigned>(1, std::thread::hardware_concurrency());
+    long long quota = -1, period = 0;
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[32] = {0};
+        if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atoll(q);
+        fclose(f);
+    } else if (FILE *f1 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+        if (fscanf(f1, "%lld", &quota) != 1) quota = -1;
+        fclose(f1);
+        if (FILE *f2 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+            if (fscanf(f2, "%lld", &period) != 1) period = 0;
+            fclose(f2);
+        }
+    }
+    if (quota > 0 && period > 0) n = std::min<size_t>(n, (size_t)std::max<long long>(1, (quota + period - 1) / period));
+    return n;
 }
 
 static double seconds_since(std::chrono::steady_clock::time_point t0) {
@@ -63,71 +87,135 @@ static bool file_exists(const std::string &p) {
     return stat(p.c_str(), &st) == 0 || stat((p + ".gz").c_str(), &st) == 0;
 }
 
-// Staging for one table load: a pinned host ring and a device ring of the same size, handed out in
-// lock step.  The decoded pieces of a column (bins, deltas, dictionary look-up tables, validity words) are
-// copied into the pinned slice, sent with a truly asynchronous copy and consumed by the decode kernel on
-// the same stream -- nothing waits for them; the stream is synchronised only when the ring wraps around
-// (every few dozen blocks) instead of once per column.
-struct Stage {
+// Staging for one table load.  Everything a block sends across PCIe -- bin values, record ids, delta-encoded
+// value arrays, block-local str ids, look-up tables, validity prefixes -- is laid out by the WORKER that decoded the
+// block in a pinned host slab (narrowed on the way: record ids of a block of <= 65536 rows travel as uint16, value
+// deltas as int32 when they fit), crosses with ONE asynchronous copy into the slab's device twin and is consumed there
+// by the decode kernels.  The calling thread only interns dictionaries, queues the copy and launches kernels: round 2
+// measured its share at 0.38 s of a 0.46 s load when it still copied 2.1 GB of decoded pieces into a pinned ring itself.
+struct Slab {
     char *h = nullptr, *d = nullptr;
-    size_t cap = 0, off = 0;
-    int64_t sent = 0;  // bytes handed to hipMemcpyAsync
-    hipStream_t st = nullptr;
-    int take(size_t bytes, void **hp, void **dp) {
-        bytes = (bytes + 255) / 256 * 256;
-        if (bytes > cap) {
-            SYBL_HIP(hipStreamSynchronize(st));
-            if (h) SYBL_HIP(hipHostFree(h));
-            if (d) SYBL_HIP(hipFree(d));
-            h = d = nullptr;
-            cap = std::max<size_t>(std::max(bytes * 4, cap * 2), (size_t)32 << 20);
-            SYBL_HIP(hipHostMalloc((void **)&h, cap, hipHostMallocDefault));
-            SYBL_HIP(hipMalloc((void **)&d, cap));
-            off = 0;
-        }
-        if (off + bytes > cap) {
-            SYBL_HIP(hipStreamSynchronize(st));  // everything queued so far has consumed its slices
-            off = 0;
-        }
-        *hp = h + off;
-        *dp = d + off;
-        off += bytes;
+    size_t cap = 0;
+    hipEvent_t done = nullptr;  // recorded behind the last kernel that reads d
+};
+
+// The slabs are carved out of ONE pinned and ONE device allocation: pinning and unpinning 190 slabs one by one cost
+// 0.1 s of a 0.4 s load (hipHostFree alone ~0.3 ms each).
+struct SlabPool {
+    std::vector<Slab> slabs;
+    std::vector<int> free_;
+    std::deque<int> pending;  // applied, event recorded, not yet known to be finished
+    size_t slab_bytes = 0, max_slabs = 0;
+    char *arena_h = nullptr, *arena_d = nullptr;
+    int init() {
+        SYBL_HIP(hipHostMalloc((void **)&arena_h, slab_bytes * max_slabs, hipHostMallocDefault));
+        SYBL_HIP(hipMalloc((void **)&arena_d, slab_bytes * max_slabs));
         return SYBL_OK;
     }
-    // host -> pinned slice -> device slice (async); returns the device pointer
-    int send(const void *src, size_t bytes, void **dp) {
-        void *hp;
-        int rc = take(std::max<size_t>(bytes, 16), &hp, dp);
-        if (rc) return rc;
-        if (bytes) {
-            memcpy(hp, src, bytes);
-            SYBL_HIP(hipMemcpyAsync(*dp, hp, bytes, hipMemcpyHostToDevice, st));
-            sent += (int64_t)bytes;
+    // *out = -1 when no slab can be had right now (must_wait: block until the oldest pending one is done)
+    int acquire(bool must_wait, int *out) {
+        *out = -1;
+        if (free_.empty() && !pending.empty()) {
+            const int i = pending.front();
+            hipError_t e = must_wait ? hipEventSynchronize(slabs[(size_t)i].done) : hipEventQuery(slabs[(size_t)i].done);
+            if (e == hipSuccess) {
+                pending.pop_front();
+                free_.push_back(i);
+            } else if (e != hipErrorNotReady) {
+                return hip_fail(e, "slab event");
+            } else {
+                (void)hipGetLastError();  // "not ready" is an answer, not an error a later hipGetLastError() should report
+            }
         }
+        if (free_.empty() && slabs.size() < max_slabs) {
+            Slab s;
+            s.h = arena_h + slabs.size() * slab_bytes;
+            s.d = arena_d + slabs.size() * slab_bytes;
+            SYBL_HIP(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+            s.cap = slab_bytes;
+            slabs.push_back(s);
+            free_.push_back((int)slabs.size() - 1);
+        }
+        if (free_.empty()) return SYBL_OK;
+        *out = free_.back();
+        free_.pop_back();
         return SYBL_OK;
     }
-    ~Stage() {
-        if (st && (h || d)) (void)hipStreamSynchronize(st);  // the last slices may still be in use
-        if (h) hipHostFree(h);
-        if (d) hipFree(d);
+    void release_after(int i, hipStream_t st) {
+        (void)hipEventRecord(slabs[(size_t)i].done, st);
+        pending.push_back(i);
+    }
+    void give_back(int i) { free_.push_back(i); }
+    ~SlabPool() {
+        for (auto &s : slabs)
+            if (s.done) {
+                (void)hipEventSynchronize(s.done);
+                (void)hipEventDestroy(s.done);
+            }
+        if (arena_h) (void)hipHostFree(arena_h);
+        if (arena_d) (void)hipFree(arena_d);
     }
 };
 
-// ---- phase 1 (worker threads, pure CPU): read + gob-decode + flatten one block's column files.
-// Validation follows the reference: a record id or value count beyond NumRecords marks the block
-// broken ("BLOCK SIZE CHANGED DURING QUERY", column_store_io.go:524-526,572-574,733-735).
+// Worker threads of one table load (std::async started a thread per block: 1600 thread creations, 27 us each on the
+// calling thread, for a 100 M-row table).
+class LoadWorkers {
+   public:
+    explicit LoadWorkers(size_t n) {
+        for (size_t i = 0; i < n; i++) threads_.emplace_back([this]() { loop(); });
+    }
+    ~LoadWorkers() {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto &t : threads_) t.join();
+    }
+    void run(std::function<void()> job) {
+        if (threads_.empty()) {
+            job();
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            jobs_.push_back(std::move(job));
+        }
+        cv_.notify_one();
+    }
 
-struct FlatBins {
-    std::vector<int64_t> val, off;
-    std::vector<uint32_t> recs;
+   private:
+    void loop() {
+        for (;;) {
+            std::function<void()> job;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return stop_ || !jobs_.empty(); });
+                if (jobs_.empty()) return;  // (stop requested and nothing left)
+                job = std::move(jobs_.front());
+                jobs_.pop_front();
+            }
+            job();
+        }
+    }
+    std::vector<std::thread> threads_;
+    std::deque<std::function<void()>> jobs_;
+    std::mutex m_;
+    std::condition_variable cv_;
+    bool stop_ = false;
 };
+
+// ---- phase 1 (worker threads, pure CPU): read + gob-decode one block's column files and lay the decoded pieces out
+// in the block's slab.  Validation follows the reference: a record id or value count beyond NumRecords marks the
+// block broken ("BLOCK SIZE CHANGED DURING QUERY", column_store_io.go:524-526,572-574,733-735).
 
 struct PreparedCol {
     enum Kind { kAbsent, kIntBins, kIntValues, kStrBins, kStrValues, kSet } kind = kAbsent;
-    FlatBins fb;                       // *Bins
     bool delta = false, venc = false;
-    std::vector<int64_t> values;       // kIntValues (delta-encoded when venc)
-    std::vector<int32_t> local;        // kStrValues: block-local ids per row
+    // offsets into the slab (16-byte aligned) and element widths
+    size_t rec_at = 0, binoff_at = 0, binval_at = 0, val_at = 0, local_at = 0, lut_at = 0, bits_at = 0;
+    int rec_w = 4, val_w = 8, local_w = 4;
+    int64_t n_recs = 0, n_bins = 0, n_vals = 0, n_local = 0, bits_words = 0;
     std::vector<std::string> strings;  // block StringTable (str / set)
     std::vector<int64_t> set_off;      // kSet: CSR over the block's rows, block-local member ids
     std::vector<int32_t> set_ids;
@@ -144,26 +232,11 @@ struct PreparedBlock {
     bool broken = false;      // a column failed validation
     std::string why;
     std::vector<PreparedCol> cols;
+    size_t bytes = 0;          // of the slab that are in use
+    char *own_h = nullptr, *own_d = nullptr;  // a block too large for the pool's slabs brings its own pair
 };
 
-static bool flatten_bins(const gob::Value *bins, bool delta, int64_t num_records, FlatBins &fb) {
-    fb.off.assign(1, 0);
-    if (!bins) return true;
-    for (auto &b : bins->items) {
-        const gob::Value *v = b->field("Value"), *r = b->field("Records");
-        fb.val.push_back(v ? v->as_int() : 0);
-        if (r && r->kind == gob::Value::kIntVec) {
-            uint64_t abs = 0;
-            for (int64_t x : r->ints) {
-                abs = delta ? abs + (uint64_t)x : (uint64_t)x;
-                if (abs >= (uint64_t)num_records) return false;
-                fb.recs.push_back((uint32_t)x);
-            }
-        }
-        fb.off.push_back((int64_t)fb.recs.size());
-    }
-    return true;
-}
+static inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 
 static void string_table(const gob::Value &v, std::vector<std::string> &out) {
     const gob::Value *st = v.field("StringTable");
@@ -178,18 +251,18 @@ struct ColSpec {
 
 constexpr int64_t kMaxBlockRows = (int64_t)1 << 24;  // 256 x the reference's block size
 
-static PreparedBlock prepare_block_unguarded(const std::string &bdir, const std::vector<ColSpec> &specs);
+static PreparedBlock prepare_block_unguarded(const std::string &bdir, const std::vector<ColSpec> &specs, char *slab_h, size_t slab_cap, int device);
 // A worker thread must not let an exception escape (std::bad_alloc / length_error from a damaged file): it
 // would be rethrown by future::get() and leave the extern "C" entry point.  The block is skipped instead,
 // like every other block the reference cannot read.
-static PreparedBlock prepare_block(const std::string &bdir, const std::vector<ColSpec> &specs) {
+static PreparedBlock prepare_block(const std::string &bdir, const std::vector<ColSpec> &specs, char *slab_h, size_t slab_cap, int device) {
     const auto t0 = std::chrono::steady_clock::now();
     struct Tally {
         std::chrono::steady_clock::time_point t0;
         ~Tally() { g_parse_ns += (int64_t)(seconds_since(t0) * 1e9); }
     } tally{t0};
     try {
-        return prepare_block_unguarded(bdir, specs);
+        return prepare_block_unguarded(bdir, specs, slab_h, slab_cap, device);
     } catch (const std::exception &) {
         PreparedBlock pb;
         pb.unreadable = true;
@@ -197,7 +270,61 @@ static PreparedBlock prepare_block(const std::string &bdir, const std::vector<Co
     }
 }
 
-static PreparedBlock prepare_block_unguarded(const std::string &bdir, const std::vector<ColSpec> &specs) {
+// The Bins of a bucket-encoded column as flat arrays.  The gob reader produces them directly (Value::kBinVec); a file
+// whose bucket struct carries other fields went through the generic tree and is flattened here.
+struct BinsView {
+    int64_t n = 0;
+    const int64_t *val = nullptr, *off = nullptr, *recs = nullptr;
+    std::vector<int64_t> own_val, own_off, own_recs;
+    explicit BinsView(const gob::Value *bins) {
+        static const int64_t zero = 0;
+        off = &zero;
+        if (!bins) return;
+        if (bins->kind == gob::Value::kBinVec) {
+            n = (int64_t)bins->bin_val.size();
+            val = bins->bin_val.data();
+            off = bins->bin_off.data();
+            recs = bins->ints.data();
+            return;
+        }
+        own_off.push_back(0);
+        for (auto &b : bins->items) {
+            const gob::Value *v = b->field("Value"), *r = b->field("Records");
+            own_val.push_back(v ? v->as_int() : 0);
+            if (r && r->kind == gob::Value::kIntVec) own_recs.insert(own_recs.end(), r->ints.begin(), r->ints.end());
+            own_off.push_back((int64_t)own_recs.size());
+        }
+        n = (int64_t)own_val.size();
+        val = own_val.data();
+        off = own_off.data();
+        recs = own_recs.data();
+    }
+};
+
+// Bins -> slab: bin values (int64), bin offsets (int64, n_bins + 1) and the record ids as they are in the file
+// (absolute or delta-encoded) at rec_w bytes each.  False: an id beyond NumRecords.
+static bool fill_bins(const BinsView &bv, bool delta, int64_t num_records, char *base, PreparedCol &pc) {
+    int64_t *off = (int64_t *)(base + pc.binoff_at), *val = (int64_t *)(base + pc.binval_at);
+    uint16_t *r16 = (uint16_t *)(base + pc.rec_at);
+    uint32_t *r32 = (uint32_t *)(base + pc.rec_at);
+    if (bv.n > 0) memcpy(val, bv.val, (size_t)bv.n * 8);
+    memcpy(off, bv.off, (size_t)(bv.n + 1) * 8);
+    for (int64_t k = 0; k < bv.n; k++) {
+        uint64_t abs = 0;
+        for (int64_t i = bv.off[k]; i < bv.off[k + 1]; i++) {
+            const int64_t x = bv.recs[i];
+            abs = delta ? abs + (uint64_t)x : (uint64_t)x;
+            if (abs >= (uint64_t)num_records) return false;
+            // (an id or delta below NumRecords <= 65536 fits 16 bits; a NEGATIVE delta in a damaged file
+            // wraps `abs` and was caught above)
+            if (pc.rec_w == 2) r16[i] = (uint16_t)x;
+            else r32[i] = (uint32_t)x;
+        }
+    }
+    return true;
+}
+
+static PreparedBlock prepare_block_unguarded(const std::string &bdir, const std::vector<ColSpec> &specs, char *slab_h, size_t slab_cap, int device) {
     static const char *prefix[] = {"", "int_", "str_", "set_"};
     PreparedBlock pb;
     std::string err;
@@ -215,87 +342,181 @@ static PreparedBlock prepare_block_unguarded(const std::string &bdir, const std:
         return pb;
     }
     pb.cols.resize(specs.size());
+    // ---- pass 1: decode the files, plan the slab layout
+    std::vector<gob::Value> trees(specs.size());
+    std::vector<char> have(specs.size(), 0), bucketed(specs.size(), 0);
+    size_t total = 0;
+    auto reserve = [&](size_t bytes) {
+        total = align16(total);
+        const size_t at = total;
+        total += bytes;
+        return at;
+    };
     for (size_t ci = 0; ci < specs.size(); ci++) {
         PreparedCol &pc = pb.cols[ci];
         std::string path = bdir + "/" + prefix[specs[ci].type] + specs[ci].name + ".db";
-        gob::Value v;
+        gob::Value &v = trees[ci];
         // a missing file = column unpopulated in this block; "DECODE COL ERR": the reference logs and
         // carries on with an empty column
-        if (!file_exists(path) || !decode_file(path, v, err)) continue;
+        if (!decode_file(path, v, err)) continue;
+        have[ci] = 1;
         const gob::Value *f;
-        bool bucket = (f = v.field("BucketEncoded")) && f->as_bool();
+        const bool bucket = (f = v.field("BucketEncoded")) && f->as_bool();
+        bucketed[ci] = bucket;
         pc.delta = (f = v.field("DeltaEncodedIDs")) && f->as_bool();
         pc.venc = (f = v.field("ValueEncoded")) && f->as_bool();
         bool ok = true;
-        if (specs[ci].type == SYBL_INT_VAL) {  // unpackIntCol, column_store_io.go:690-780
-            if (bucket) {
-                pc.kind = PreparedCol::kIntBins;
-                ok = flatten_bins(v.field("Bins"), pc.delta, pb.nrows, pc.fb);
-                for (size_t k = 0; ok && k < pc.fb.val.size(); k++)
-                    if (pc.fb.off[k + 1] > pc.fb.off[k]) {
-                        pc.vmin = std::min(pc.vmin, pc.fb.val[k]);
-                        pc.vmax = std::max(pc.vmax, pc.fb.val[k]);
+        if (specs[ci].type == SYBL_SET_VAL) continue;  // sets stay on the host (CSR mirror)
+        if (specs[ci].type == SYBL_STR_VAL) {
+            string_table(v, pc.strings);
+            ok = (int64_t)pc.strings.size() <= pb.nrows;
+        }
+        const gob::Value *bins = v.field("Bins"), *vals = v.field("Values");
+        if (ok && bucket) {
+            pc.kind = specs[ci].type == SYBL_INT_VAL ? PreparedCol::kIntBins : PreparedCol::kStrBins;
+            const BinsView bv(bins);
+            pc.n_bins = bv.n;
+            pc.n_recs = bv.off[bv.n];
+            pc.rec_w = pb.nrows <= 65536 ? 2 : 4;
+            pc.binval_at = reserve((size_t)std::max<int64_t>(pc.n_bins, 1) * 8);
+            pc.binoff_at = reserve((size_t)(pc.n_bins + 1) * 8);
+            pc.rec_at = reserve((size_t)std::max<int64_t>(pc.n_recs, 1) * (size_t)pc.rec_w);
+        } else if (ok) {
+            const int64_t n = vals && vals->kind == gob::Value::kIntVec ? (int64_t)vals->ints.size() : 0;
+            ok = n <= pb.nrows;  // unpackIntCol / unpackStrCol: more values than NumRecords
+            if (specs[ci].type == SYBL_INT_VAL) {
+                pc.kind = PreparedCol::kIntValues;
+                pc.n_vals = n;
+                pc.val_w = 4;
+                for (int64_t k = 0; ok && k < n; k++)
+                    if (vals->ints[(size_t)k] < INT32_MIN || vals->ints[(size_t)k] > INT32_MAX) {
+                        pc.val_w = 8;
+                        break;
+                    }
+                pc.val_at = reserve((size_t)std::max<int64_t>(n, 1) * (size_t)pc.val_w);
+            } else {
+                pc.kind = PreparedCol::kStrValues;
+                pc.n_local = n;
+                pc.local_w = 2;
+                for (int64_t k = 0; ok && k < n; k++)
+                    if (vals->ints[(size_t)k] < 0 || vals->ints[(size_t)k] > 65535) {
+                        pc.local_w = 4;
+                        break;
+                    }
+                pc.local_at = reserve((size_t)std::max<int64_t>(n, 1) * (size_t)pc.local_w);
+                pc.lut_at = reserve(std::max<size_t>(pc.strings.size(), 1) * 4);
+            }
+            if (ok && n < pb.nrows && n > 0) {
+                // every row below len(Values) becomes populated, holes included (column_store_io.go:758-766)
+                pc.bits_words = (pb.nrows + 31) / 32;
+                pc.bits_at = reserve((size_t)pc.bits_words * 4);
+            }
+        }
+        if (!ok) {
+            pb.broken = true;  // "ERROR DURING COLUMN UNPACK ... SKIPPING BLOCK" (table_block_io.go:297-301)
+            pb.why = "BLOCK SIZE CHANGED DURING QUERY in column '" + specs[ci].name + "'";
+            return pb;
+        }
+    }
+    pb.bytes = align16(total);
+    char *base = slab_h;
+    if (pb.bytes > slab_cap) {
+        // larger than the pool's slabs (an over-sized block): a pinned / device pair of its own
+        if (hipSetDevice(device) != hipSuccess || hipHostMalloc((void **)&pb.own_h, pb.bytes, hipHostMallocDefault) != hipSuccess ||
+            hipMalloc((void **)&pb.own_d, pb.bytes) != hipSuccess) {
+            if (pb.own_h) (void)hipHostFree(pb.own_h);
+            pb.own_h = pb.own_d = nullptr;
+            pb.unreadable = true;
+            return pb;
+        }
+        base = pb.own_h;
+    }
+    // ---- pass 2: fill
+    for (size_t ci = 0; ci < specs.size(); ci++) {
+        PreparedCol &pc = pb.cols[ci];
+        if (!have[ci]) continue;
+        const gob::Value &v = trees[ci];
+        const gob::Value *bins = v.field("Bins"), *vals = v.field("Values");
+        bool ok = true;
+        switch (pc.kind) {
+        case PreparedCol::kIntBins:
+        case PreparedCol::kStrBins: {
+            ok = fill_bins(BinsView(bins), pc.delta, pb.nrows, base, pc);
+            const int64_t *off = (const int64_t *)(base + pc.binoff_at), *val = (const int64_t *)(base + pc.binval_at);
+            if (ok && pc.kind == PreparedCol::kIntBins) {
+                for (int64_t k = 0; k < pc.n_bins; k++)
+                    if (off[k + 1] > off[k]) {
+                        pc.vmin = std::min(pc.vmin, val[k]);
+                        pc.vmax = std::max(pc.vmax, val[k]);
                     }
                 // (record ids of different bins are disjoint in a well-formed file; if they are not, a row is
                 // only counted twice here, which makes the column look less populated than it is -- harmless)
-                pc.vpop = std::min<int64_t>((int64_t)pc.fb.recs.size(), pb.nrows);
-                pc.have_stats = ok;
-            } else {
-                pc.kind = PreparedCol::kIntValues;
-                const gob::Value *vals = v.field("Values");
-                if (vals && vals->kind == gob::Value::kIntVec) pc.values = vals->ints;
-                ok = (int64_t)pc.values.size() <= pb.nrows;
-                int64_t run = 0;  // every row below len(Values) is populated (column_store_io.go:758-766)
-                for (int64_t x : pc.values) {
+                pc.vpop = std::min<int64_t>(pc.n_recs, pb.nrows);
+                pc.have_stats = true;
+            } else if (ok) {
+                for (int64_t k = 0; k < pc.n_bins; k++) ok = ok && val[k] >= 0 && val[k] < (int64_t)pc.strings.size();
+            }
+            break;
+        }
+        case PreparedCol::kIntValues: {
+            int64_t run = 0, k = 0;  // every row below len(Values) is populated (column_store_io.go:758-766)
+            int32_t *o32 = (int32_t *)(base + pc.val_at);
+            int64_t *o64 = (int64_t *)(base + pc.val_at);
+            if (vals && vals->kind == gob::Value::kIntVec)
+                for (int64_t x : vals->ints) {
                     run = pc.venc ? (int64_t)((uint64_t)run + (uint64_t)x) : x;
                     pc.vmin = std::min(pc.vmin, run);
                     pc.vmax = std::max(pc.vmax, run);
+                    if (pc.val_w == 4) o32[k++] = (int32_t)x;
+                    else o64[k++] = x;
                 }
-                pc.vpop = (int64_t)pc.values.size();
-                pc.have_stats = ok;
-            }
-        } else if (specs[ci].type == SYBL_STR_VAL) {  // unpackStrCol, :493-609 (without -str-replace)
-            string_table(v, pc.strings);
-            ok = (int64_t)pc.strings.size() <= pb.nrows;
-            if (ok && bucket) {
-                pc.kind = PreparedCol::kStrBins;
-                ok = flatten_bins(v.field("Bins"), pc.delta, pb.nrows, pc.fb);
-                for (auto x : pc.fb.val) ok = ok && x >= 0 && x < (int64_t)pc.strings.size();
-            } else if (ok) {
-                pc.kind = PreparedCol::kStrValues;
-                const gob::Value *vals = v.field("Values");
-                if (vals && vals->kind == gob::Value::kIntVec) {
-                    pc.local.resize(vals->ints.size());
-                    for (size_t r = 0; r < vals->ints.size(); r++) pc.local[r] = (int32_t)vals->ints[r];
+            pc.vpop = pc.n_vals;
+            pc.have_stats = true;
+            break;
+        }
+        case PreparedCol::kStrValues: {
+            int64_t k = 0;
+            uint16_t *o16 = (uint16_t *)(base + pc.local_at);
+            int32_t *o32 = (int32_t *)(base + pc.local_at);
+            if (vals && vals->kind == gob::Value::kIntVec)
+                for (int64_t x : vals->ints) {
+                    if (pc.local_w == 2) o16[k++] = (uint16_t)x;
+                    else o32[k++] = (int32_t)x;
                 }
-                ok = (int64_t)pc.local.size() <= pb.nrows;
+            break;
+        }
+        default: break;
+        }
+        if (ok && pc.bits_words > 0) {
+            uint32_t *bits = (uint32_t *)(base + pc.bits_at);
+            const int64_t n = pc.kind == PreparedCol::kIntValues ? pc.n_vals : pc.n_local;
+            for (int64_t wd = 0; wd < pc.bits_words; wd++) {
+                const int64_t lo = wd * 32;
+                bits[wd] = n >= lo + 32 ? 0xFFFFFFFFu : (n > lo ? (1u << (n - lo)) - 1u : 0u);
             }
-        } else {  // unpackSetCol, :611-688: variable-length sets become CSR (member order is immaterial)
+        }
+        if (ok && specs[ci].type == SYBL_SET_VAL) {  // unpackSetCol, :611-688: variable-length sets become CSR (member order is immaterial)
             pc.kind = PreparedCol::kSet;
             string_table(v, pc.strings);
             std::vector<std::vector<int32_t>> rows((size_t)pb.nrows);
             pc.set_pop.assign((size_t)pb.nrows, 0);
-            if (bucket) {
-                const gob::Value *bins = v.field("Bins");
-                if (bins)
-                    for (auto &b : bins->items) {
-                        const gob::Value *bv = b->field("Value"), *br = b->field("Records");
-                        int64_t id = bv ? bv->as_int() : 0;
-                        if (id < 0 || id >= (int64_t)pc.strings.size()) ok = false;
-                        uint64_t abs = 0;
-                        if (ok && br && br->kind == gob::Value::kIntVec)
-                            for (int64_t x : br->ints) {
-                                abs = pc.delta ? abs + (uint64_t)x : (uint64_t)x;
-                                if (abs >= (uint64_t)pb.nrows) {
-                                    ok = false;
-                                    break;
-                                }
-                                rows[(size_t)abs].push_back((int32_t)id);
-                                pc.set_pop[(size_t)abs] = 1;
-                            }
+            if (bucketed[ci]) {
+                const BinsView bv(bins);
+                for (int64_t k = 0; ok && k < bv.n; k++) {
+                    const int64_t id = bv.val[k];
+                    if (id < 0 || id >= (int64_t)pc.strings.size()) ok = false;
+                    uint64_t abs = 0;
+                    for (int64_t i = bv.off[k]; ok && i < bv.off[k + 1]; i++) {
+                        abs = pc.delta ? abs + (uint64_t)bv.recs[i] : (uint64_t)bv.recs[i];
+                        if (abs >= (uint64_t)pb.nrows) {
+                            ok = false;
+                            break;
+                        }
+                        rows[(size_t)abs].push_back((int32_t)id);
+                        pc.set_pop[(size_t)abs] = 1;
                     }
+                }
             } else {
-                const gob::Value *vals = v.field("Values");
                 int64_t n = vals && vals->kind == gob::Value::kSlice ? (int64_t)vals->items.size() : 0;
                 ok = n <= pb.nrows;
                 for (int64_t r = 0; ok && r < n; r++) {
@@ -315,7 +536,7 @@ static PreparedBlock prepare_block_unguarded(const std::string &bdir, const std:
             }
         }
         if (!ok) {
-            pb.broken = true;  // "ERROR DURING COLUMN UNPACK ... SKIPPING BLOCK" (table_block_io.go:297-301)
+            pb.broken = true;
             pb.why = "BLOCK SIZE CHANGED DURING QUERY in column '" + specs[ci].name + "'";
             return pb;
         }
@@ -323,99 +544,82 @@ static PreparedBlock prepare_block_unguarded(const std::string &bdir, const std:
     return pb;
 }
 
-// ---- phase 2 (serial, in block order): dictionaries, PCIe, decode kernels
+// ---- phase 2 (serial, in block order): dictionaries, ONE copy across PCIe, decode kernels
 
-static int upload_bins(Stage &stage, const FlatBins &fb, const uint32_t **d_recs, const int64_t **d_off, const int64_t **d_val) {
-    int rc;
-    void *p;
-    if ((rc = stage.send(fb.recs.data(), fb.recs.size() * 4, &p))) return rc;
-    *d_recs = (const uint32_t *)p;
-    if ((rc = stage.send(fb.off.data(), fb.off.size() * 8, &p))) return rc;
-    *d_off = (const int64_t *)p;
-    if ((rc = stage.send(fb.val.data(), fb.val.size() * 8, &p))) return rc;
-    *d_val = (const int64_t *)p;
-    return SYBL_OK;
+// dictionaries first (they decide what some slab bytes are): block-local id -> table-global id tables, written into
+// the slab where the kernels expect them
+static void apply_dictionaries(Table *t, PreparedBlock &pb, char *H, std::vector<std::vector<int32_t>> &luts) {
+    luts.assign(t->cols.size(), std::vector<int32_t>());
+    for (size_t ci = 0; ci < t->cols.size(); ci++) {
+        PreparedCol &pc = pb.cols[ci];
+        Column *c = t->cols[ci].get();
+        std::vector<int32_t> &lut = luts[ci];
+        for (auto &s : pc.strings) lut.push_back(dict_intern(c, s));
+        if (pc.kind == PreparedCol::kStrBins) {
+            int64_t *val = (int64_t *)(H + pc.binval_at);
+            for (int64_t k = 0; k < pc.n_bins; k++) val[k] = lut[(size_t)val[k]];  // the bins' values are table-global ids now
+        } else if (pc.kind == PreparedCol::kStrValues) {
+            if (!lut.empty()) memcpy(H + pc.lut_at, lut.data(), lut.size() * 4);
+        } else if (pc.kind == PreparedCol::kSet) {
+            for (auto &id : pc.set_ids) id = lut[(size_t)id];
+        }
+    }
 }
 
-static int put_prefix_valid(BlockWriter &w, Stage &stage, uint32_t *valid, int64_t n) {
-    // every row below len(Values) becomes populated, holes included (column_store_io.go:758-766)
-    if (!valid || n <= 0) return SYBL_OK;
-    std::vector<uint32_t> bits((size_t)((w.nrows + 31) / 32), 0);
-    for (int64_t r = 0; r < n; r++) bits[(size_t)(r >> 5)] |= 1u << (r & 31);
-    void *hp, *dp;
-    int rc = stage.take(bits.size() * 4, &hp, &dp);
-    if (rc) return rc;
-    memcpy(hp, bits.data(), bits.size() * 4);
-    // (pinned source: the copy is asynchronous and ordered behind the memset block_col_device queued)
-    SYBL_HIP(hipMemcpyAsync(valid, hp, bits.size() * 4, hipMemcpyHostToDevice, stage.st));
-    return SYBL_OK;
-}
-
-static int apply_col(BlockWriter &w, Column *c, PreparedCol &pc, Stage &stage) {
+static int apply_col(BlockWriter &w, Column *c, PreparedCol &pc, const char *H, char *D, size_t n_strings) {
     Table *t = w.t;
     hipStream_t st = t->ctx->stream;
     void *col = nullptr;
     uint32_t *valid = nullptr;
     int rc;
-    std::vector<int32_t> lut;
-    for (auto &s : pc.strings) lut.push_back(dict_intern(c, s));  // block-local id -> table-global id
     switch (pc.kind) {
     case PreparedCol::kAbsent: return block_col_absent(w, c);
     case PreparedCol::kIntBins:
     case PreparedCol::kStrBins: {
-        bool w32 = pc.kind == PreparedCol::kStrBins;
-        if (w32)
-            for (auto &x : pc.fb.val) x = lut[(size_t)x];
-        bool all = (int64_t)pc.fb.recs.size() == w.nrows;
-        if ((rc = block_col_device(w, c, all, &col, &valid))) return rc;
-        const uint32_t *d_recs;
-        const int64_t *d_off, *d_val;
-        if ((rc = upload_bins(stage, pc.fb, &d_recs, &d_off, &d_val))) return rc;
-        hipError_t e = launch_decode_bins(d_recs, d_off, d_val, (int)pc.fb.val.size(), pc.delta, col, w32, valid, (uint32_t)w.nrows, st);
-        if (e != hipSuccess) return hip_fail(e, "k_decode_bins");
+        const bool w32 = pc.kind == PreparedCol::kStrBins;
+        const bool all = pc.n_recs == w.nrows;
+        int64_t mn = pc.vmin, mx = pc.vmax, pop = pc.vpop;
         if (w32) {  // str bins: the values are table-global ids now
-            int64_t mn = INT64_MAX, mx = INT64_MIN;
-            for (size_t k = 0; k < pc.fb.val.size(); k++)
-                if (pc.fb.off[k + 1] > pc.fb.off[k]) {
-                    mn = std::min(mn, pc.fb.val[k]);
-                    mx = std::max(mx, pc.fb.val[k]);
+            const int64_t *off = (const int64_t *)(H + pc.binoff_at), *val = (const int64_t *)(H + pc.binval_at);
+            mn = INT64_MAX;
+            mx = INT64_MIN;
+            for (int64_t k = 0; k < pc.n_bins; k++)
+                if (off[k + 1] > off[k]) {
+                    mn = std::min(mn, val[k]);
+                    mx = std::max(mx, val[k]);
                 }
-            block_col_stats(w, c, mn, mx, std::min<int64_t>((int64_t)pc.fb.recs.size(), w.nrows));
-        } else if (pc.have_stats) {
-            block_col_stats(w, c, pc.vmin, pc.vmax, pc.vpop);
+            pop = std::min<int64_t>(pc.n_recs, w.nrows);
         }
+        const bool stats = w32 || pc.have_stats;
+        bool direct = false;
+        if (stats && (rc = block_col_direct(w, c, all, mn, mx, pop, &col, &valid, &direct))) return rc;
+        if (!direct && (rc = block_col_device(w, c, all, &col, &valid))) return rc;
+        hipError_t e = launch_decode_bins(D + pc.rec_at, pc.rec_w, (const int64_t *)(D + pc.binoff_at), (const int64_t *)(D + pc.binval_at),
+                                          (int)pc.n_bins, pc.delta, col, direct ? c->elem : c->canon(), direct ? c->vbase : 0, valid,
+                                          (uint32_t)w.nrows, st);
+        if (e != hipSuccess) return hip_fail(e, "k_decode_bins");
+        if (!direct && stats) block_col_stats(w, c, mn, mx, pop);
         return SYBL_OK;
     }
-    case PreparedCol::kIntValues: {
-        int64_t n = (int64_t)pc.values.size();
-        if ((rc = block_col_device(w, c, n == w.nrows, &col, &valid))) return rc;
-        if ((rc = put_prefix_valid(w, stage, valid, n))) return rc;
-        if (n > 0) {
-            void *d_vals;
-            if ((rc = stage.send(pc.values.data(), (size_t)n * 8, &d_vals))) return rc;
-            hipError_t e = launch_decode_delta((const int64_t *)d_vals, n, pc.venc, (int64_t *)col, st);
-            if (e != hipSuccess) return hip_fail(e, "k_decode_delta");
-        }
-        if (pc.have_stats) block_col_stats(w, c, pc.vmin, pc.vmax, pc.vpop);
-        return SYBL_OK;
-    }
+    case PreparedCol::kIntValues:
     case PreparedCol::kStrValues: {
-        int64_t n = (int64_t)pc.local.size();
-        if ((rc = block_col_device(w, c, n == w.nrows, &col, &valid))) return rc;
-        if ((rc = put_prefix_valid(w, stage, valid, n))) return rc;
+        const bool ints = pc.kind == PreparedCol::kIntValues;
+        const int64_t n = ints ? pc.n_vals : pc.n_local;
+        bool direct = false;
+        if (ints && pc.have_stats && (rc = block_col_direct(w, c, n == w.nrows, pc.vmin, pc.vmax, pc.vpop, &col, &valid, &direct))) return rc;
+        if (!direct && (rc = block_col_device(w, c, n == w.nrows, &col, &valid))) return rc;
+        if (valid && pc.bits_words > 0)
+            SYBL_HIP(hipMemcpyAsync(valid, D + pc.bits_at, (size_t)pc.bits_words * 4, hipMemcpyDeviceToDevice, st));
         if (n > 0) {
-            void *d_local, *d_lut;
-            if ((rc = stage.send(pc.local.data(), (size_t)n * 4, &d_local))) return rc;
-            if ((rc = stage.send(lut.data(), lut.size() * 4, &d_lut))) return rc;
-            hipError_t e = launch_remap_ids((const int32_t *)d_local, (const int32_t *)d_lut, (int32_t)lut.size(), n, (int32_t *)col, st);
-            if (e != hipSuccess) return hip_fail(e, "k_remap_ids");
+            hipError_t e = ints ? launch_decode_delta(D + pc.val_at, pc.val_w, n, pc.venc, col, direct ? c->elem : 8, direct ? c->vbase : 0, st)
+                                : launch_remap_ids(D + pc.local_at, pc.local_w, (const int32_t *)(D + pc.lut_at), (int32_t)n_strings, n,
+                                                   (int32_t *)col, st);
+            if (e != hipSuccess) return hip_fail(e, ints ? "k_decode_delta" : "k_remap_ids");
         }
+        if (ints && !direct && pc.have_stats) block_col_stats(w, c, pc.vmin, pc.vmax, pc.vpop);
         return SYBL_OK;
     }
-    case PreparedCol::kSet: {
-        for (auto &id : pc.set_ids) id = lut[(size_t)id];
-        return block_col_set_host(w, c, pc.set_off.data(), pc.set_ids.data(), pc.set_pop.data());
-    }
+    case PreparedCol::kSet: return block_col_set_host(w, c, pc.set_off.data(), pc.set_ids.data(), pc.set_pop.data());
     }
     return SYBL_OK;
 }
@@ -446,6 +650,7 @@ static int open_table(Ctx *ctx, const char *dir, const char *table, const char *
     if (rc == SYBL_OK && (flags & SYBL_OPEN_COMPACT)) t->compact_mode = true;  // every block is packed as it arrives
     if (rc) return rc;
     auto bail = [&](int code) {
+        (void)load_sync_all(ctx);  // (blocks of a multi-stream load may still be decoding into the table)
         sybl_table_free(t);
         return code;
     };
@@ -487,61 +692,163 @@ static int open_table(Ctx *ctx, const char *dir, const char *table, const char *
     if (nranks < 1) nranks = 1;
     size_t b0 = blocks.size() * (size_t)rank / (size_t)nranks, b1 = blocks.size() * (size_t)(rank + 1) / (size_t)nranks;
 
-    Stage stage;
-    stage.st = ctx->stream;
     std::vector<ColSpec> specs;
     for (auto &cp : t->cols) specs.push_back({cp->name, cp->type});
     // worker threads decode a window of blocks ahead of the (serial, in-order) GPU phase
-    // (the calling thread's serial phase sustains ~600 M rows/s; round 1's cap of 32 workers left the load parse-bound at
-    // 180 M rows/s on a 256-thread host)
-    size_t n_workers = std::min<size_t>(128, std::max<unsigned>(1, std::thread::hardware_concurrency() / 2));
+    // (twice the CPUs this process may use: a container's CFS quota -- 16 CPUs on the 256-thread GPU boxes of round 2 --
+    // throttles every thread of the group once a burst of 128 workers has spent the period's budget)
+    size_t n_workers = std::min<size_t>(128, std::max<size_t>(2, 2 * usable_cpus()));
     if (const char *e = getenv("SYBL_LOADER_THREADS")) n_workers = (size_t)std::max(1, atoi(e));
-    const size_t window = n_workers * 2;
-    std::deque<std::future<PreparedBlock>> inflight;
-    size_t next = b0;
-    auto submit = [&]() {
-        while (next < b1 && inflight.size() < window) {
-            std::string bdir = tdir + "/" + blocks[next++];
-            inflight.push_back(std::async(n_workers > 1 ? std::launch::async : std::launch::deferred,
-                                          [bdir, &specs]() { return prepare_block(bdir, specs); }));
-        }
+    // one slab per block in flight: sized for a reference block (65536 rows) of every requested column -- a value-
+    // encoded int column is at most 8 bytes per row, a str column adds its look-up table; larger blocks bring their own
+    SlabPool pool;
+    {
+        size_t per_block = 65536;
+        for (auto &sp : specs) per_block += sp.type == SYBL_SET_VAL ? 0 : (size_t)65536 * (sp.type == SYBL_STR_VAL ? 12 : 8) + ((size_t)96 << 10);
+        pool.slab_bytes = align16(per_block);
+        if (const char *e = getenv("SYBL_LOADER_SLAB_BYTES")) pool.slab_bytes = align16((size_t)std::max(16, atoi(e)));  // (tests: over-sized blocks)
+        pool.max_slabs = std::min<size_t>(std::max<size_t>(((size_t)512 << 20) / pool.slab_bytes, 4), std::max<size_t>(2 * n_workers, 4));
+        pool.max_slabs = std::min<size_t>(pool.max_slabs, std::max<size_t>(b1 - b0, 1));
+        if ((rc = pool.init())) return bail(rc);
+    }
+    const size_t window = std::min(n_workers * 2, pool.max_slabs);
+    struct InFlight {
+        std::future<PreparedBlock> fut;
+        int slab;
     };
+    std::deque<InFlight> inflight;
+    LoadWorkers workers(n_workers > 1 ? n_workers : 0);  // (declared after the pool and the queue: joined first)
+    size_t next = b0;
+    const int device = ctx->device;
+    auto submit = [&]() -> int {
+        while (next < b1 && inflight.size() < window) {
+            int slab = -1;
+            int rc2 = pool.acquire(inflight.empty(), &slab);
+            if (rc2) return rc2;
+            if (slab < 0) break;  // every slab is in flight or still being read by the GPU
+            std::string bdir = tdir + "/" + blocks[next++];
+            char *sh = pool.slabs[(size_t)slab].h;
+            const size_t scap = pool.slabs[(size_t)slab].cap;
+            auto prom = std::make_shared<std::promise<PreparedBlock>>();
+            inflight.push_back(InFlight{prom->get_future(), slab});
+            workers.run([prom, bdir, &specs, sh, scap, device]() { prom->set_value(prepare_block(bdir, specs, sh, scap, device)); });
+        }
+        return SYBL_OK;
+    };
+    auto drain = [&]() {
+        for (auto &f : inflight) {
+            PreparedBlock pb = f.fut.get();
+            if (pb.own_h) (void)hipHostFree(pb.own_h);
+            if (pb.own_d) (void)hipFree(pb.own_d);
+        }
+        inflight.clear();
+    };
+    // the columns grow to about this many rows: reserve once instead of doubling through ~20 reallocations (each a
+    // device malloc + copy + synchronise + free)
+    t->reserve_hint_rows = std::max(t->reserve_hint_rows, t->phys_rows + (int64_t)(b1 - b0) * (SYBL_BLOCK_ROWS + 32));
+    // consecutive blocks go to different streams (Ctx::load_streams): restored, and everything drained, on every way out
+    struct StreamGuard {
+        Ctx *ctx;
+        hipStream_t saved;
+        ~StreamGuard() {
+            (void)load_sync_all(ctx);
+            ctx->load_multi = false;
+            ctx->stream = saved;
+        }
+    } stream_guard{ctx, ctx->stream};
+    {
+        int ns = 4;
+        if (const char *e = getenv("SYBL_LOADER_STREAMS")) ns = std::max(1, std::min(8, atoi(e)));
+        if (ns > 1) {
+            SYBL_HIP(hipStreamSynchronize(ctx->stream));  // whatever the caller queued comes first
+            for (int i = 0; i < ns; i++)
+                if (!ctx->load_streams[i]) SYBL_HIP(hipStreamCreateWithFlags(&ctx->load_streams[i], hipStreamNonBlocking));
+            ctx->n_load_streams = ns;
+            ctx->load_multi = true;
+        }
+    }
+    int64_t block_no = 0;
     const auto t_open = std::chrono::steady_clock::now();
     g_file_bytes = 0;
     g_parse_ns = 0;
     double wait_s = 0, apply_s = 0;
-    submit();
+    int64_t h2d_bytes = 0;
+    std::vector<std::vector<int32_t>> luts;
+    // SYBL_LOADER_TRACE=1: where the calling thread's time goes (stderr)
+    const bool trace = getenv("SYBL_LOADER_TRACE") != nullptr;
+    double tr[5] = {0, 0, 0, 0, 0};  // dictionaries, copy, column kernels, commit, submit
+    auto lap = [&](int k, std::chrono::steady_clock::time_point &t0) {
+        if (!trace) return;
+        auto t1 = std::chrono::steady_clock::now();
+        tr[k] += std::chrono::duration<double>(t1 - t0).count();
+        t0 = t1;
+    };
+    if ((rc = submit())) return bail(rc);
     while (!inflight.empty()) {
         auto tw = std::chrono::steady_clock::now();
-        PreparedBlock pb = inflight.front().get();
+        PreparedBlock pb = inflight.front().fut.get();
+        const int slab = inflight.front().slab;
         wait_s += seconds_since(tw);
         inflight.pop_front();
-        submit();
         struct Apply {
             std::chrono::steady_clock::time_point t0;
             double *acc;
             ~Apply() { *acc += seconds_since(t0); }
         } apply{std::chrono::steady_clock::now(), &apply_s};
+        auto fail_out = [&](int code) {
+            if (pb.own_h) (void)hipHostFree(pb.own_h);
+            if (pb.own_d) (void)hipFree(pb.own_d);
+            drain();
+            return bail(code);
+        };
         if (pb.unreadable || pb.broken) {
             t->broken_blocks++;
+            pool.give_back(slab);
+            if ((rc = submit())) return fail_out(rc);
             continue;
         }
+        char *H = pb.own_h ? pb.own_h : pool.slabs[(size_t)slab].h, *D = pb.own_h ? pb.own_d : pool.slabs[(size_t)slab].d;
+        if (ctx->load_multi) ctx->stream = ctx->load_streams[block_no++ % ctx->n_load_streams];
+        auto tl = std::chrono::steady_clock::now();
+        apply_dictionaries(t, pb, H, luts);
+        lap(0, tl);
+        if (pb.bytes > 0) {
+            hipError_t e = hipMemcpyAsync(D, H, pb.bytes, hipMemcpyHostToDevice, ctx->stream);
+            if (e != hipSuccess) return fail_out(hip_fail(e, "hipMemcpyAsync(block slab)"));
+            h2d_bytes += (int64_t)pb.bytes;
+        }
+        lap(1, tl);
         BlockWriter w;
-        if ((rc = block_begin(t, pb.nrows, &w))) return bail(rc);
+        if ((rc = block_begin(t, pb.nrows, &w))) return fail_out(rc);
         for (size_t ci = 0; ci < t->cols.size(); ci++)
-            if ((rc = apply_col(w, t->cols[ci].get(), pb.cols[ci], stage))) {
-                for (auto &f : inflight) f.wait();
-                return bail(rc);
-            }
-        if ((rc = block_commit(w))) return bail(rc);
+            if ((rc = apply_col(w, t->cols[ci].get(), pb.cols[ci], H, D, luts[ci].size()))) return fail_out(rc);
+        lap(2, tl);
+        if ((rc = block_commit(w))) return fail_out(rc);
+        lap(3, tl);
+        if (pb.own_h) {
+            // an over-sized block's private pair: wait for its kernels, then let it go
+            (void)hipStreamSynchronize(ctx->stream);
+            (void)hipHostFree(pb.own_h);
+            (void)hipFree(pb.own_d);
+            pb.own_h = pb.own_d = nullptr;
+            pool.give_back(slab);
+        } else {
+            pool.release_after(slab, ctx->stream);
+        }
+        if ((rc = submit())) return fail_out(rc);
+        lap(4, tl);
     }
+    if (trace)
+        fprintf(stderr, "loader: dictionaries %.3f s, copy %.3f s, column kernels %.3f s, commit %.3f s, submit %.3f s, wait %.3f s, slabs %zu x %zu KB\n",
+                tr[0], tr[1], tr[2], tr[3], tr[4], wait_s, pool.slabs.size(), pool.slab_bytes >> 10);
+    if ((rc = load_sync_all(ctx))) return bail(rc);
     SYBL_HIP(hipStreamSynchronize(ctx->stream));  // the table is resident when the call returns (and the wall time says so)
     t->load_stats.wall_s = seconds_since(t_open);
     t->load_stats.parse_cpu_s = (double)g_parse_ns.load() * 1e-9;
     t->load_stats.wait_s = wait_s;
     t->load_stats.apply_s = apply_s;
     t->load_stats.file_bytes = g_file_bytes.load();
-    t->load_stats.h2d_bytes = stage.sent;
+    t->load_stats.h2d_bytes = h2d_bytes;
     t->load_stats.workers = (int32_t)n_workers;
     t->load_stats.blocks = (int32_t)(b1 - b0);
     *out = t;
@@ -556,10 +863,7 @@ extern "C" {
 
 int sybl_table_open(sybl_ctx *ctx, const char *dir, const char *table, const char *const *columns, int32_t n_columns,
                     int32_t rank, int32_t nranks, sybl_table **out) {
-    if (!ctx || !table || !out || rank < 0 || (nranks > 0 && rank >= nranks)) return fail(SYBL_E_INVAL, "sybl_table_open: bad argument");
-    *out = nullptr;
-    SYBL_HIP(hipSetDevice(ctx->device));
-    return open_table(ctx, dir, table, columns, n_columns, rank, nranks, 0, out);
+    return sybl_table_open_flags(ctx, dir, table, columns, n_columns, rank, nranks, 0, out);
 }
 
 int sybl_table_open_flags(sybl_ctx *ctx, const char *dir, const char *table, const char *const *columns, int32_t n_columns,

@@ -22,7 +22,15 @@ int table_reserve(Table *t, Column *c, int64_t phys_rows) {
     int64_t need = phys_rows + kTileRows;
     if (need <= c->cap_rows) return SYBL_OK;
     int64_t cap = std::max<int64_t>(need, c->cap_rows + c->cap_rows / 2);
+    if (t->reserve_hint_rows + kTileRows > cap) {
+        // (a hint that does not fit in memory is only a hint)
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (size_t)(t->reserve_hint_rows + kTileRows) * (size_t)c->elem < free_b / 2)
+            cap = t->reserve_hint_rows + kTileRows;
+    }
     void *nd = nullptr;
+    int rc0 = load_sync_all(t->ctx);  // (other blocks of a multi-stream load may still be writing the old array)
+    if (rc0) return rc0;
     SYBL_HIP(hipMalloc(&nd, (size_t)cap * c->elem));
     if (c->d_data) {
         SYBL_HIP(hipMemcpyAsync(nd, c->d_data, (size_t)t->phys_rows * c->elem, hipMemcpyDeviceToDevice, t->ctx->stream));
@@ -38,7 +46,10 @@ int valid_reserve(Table *t, Column *c, int64_t phys_rows) {
     int64_t words = round_up(phys_rows + kTileRows, 32) / 32 + 1;
     if (c->d_valid && words <= c->valid_cap_words) return SYBL_OK;
     int64_t cap = std::max<int64_t>(words, c->valid_cap_words * 2);
+    cap = std::max<int64_t>(cap, round_up(t->reserve_hint_rows + kTileRows, 32) / 32 + 1);
     uint32_t *nd = nullptr;
+    int rc0 = load_sync_all(t->ctx);
+    if (rc0) return rc0;
     SYBL_HIP(hipMalloc((void **)&nd, (size_t)cap * 4));
     int64_t old_words = round_up(t->phys_rows, 32) / 32;
     if (c->d_valid) {
@@ -108,6 +119,8 @@ int column_repack(Table *t, Column *c, int width, int64_t vbase) {
     if (c->type == SYBL_SET_VAL) return SYBL_OK;
     if (width == c->elem && vbase == c->vbase) return SYBL_OK;
     if (c->d_data) {
+        int rc0 = load_sync_all(t->ctx);
+        if (rc0) return rc0;
         hipStream_t st = t->ctx->stream;
         void *nd = nullptr;
         SYBL_HIP(hipMalloc(&nd, (size_t)c->cap_rows * (size_t)width));
@@ -155,9 +168,33 @@ int block_begin(Table *t, int64_t nrows, BlockWriter *w) {
     if (nrows < 0) return fail(SYBL_E_INVAL, "negative row count");
     w->t = t;
     w->staged.clear();
+    w->direct.clear();
+    w->serial = false;
     w->nrows = nrows;
     w->start = round_up(t->phys_rows, 32);
     w->new_phys = w->start + nrows;
+    return SYBL_OK;
+}
+
+// the validity words of the block: all ones / zeroed for the writer to set (valid == nullptr: nothing left to set)
+static int block_valid(BlockWriter &w, Column *c, bool all_populated, uint32_t **valid) {
+    Table *t = w.t;
+    hipStream_t st = t->ctx->stream;
+    int rc;
+    *valid = nullptr;
+    if (w.nrows == 0) return SYBL_OK;
+    if (!all_populated || c->d_valid) {
+        if ((rc = valid_reserve(t, c, w.new_phys))) return rc;
+        *valid = c->d_valid + w.start / 32;
+        size_t words = (size_t)(round_up(w.nrows, 32) / 32);
+        if (all_populated) {
+            SYBL_HIP(hipMemsetAsync(*valid, 0xFF, words * 4, st));
+            *valid = nullptr;  // nothing left to set
+        } else {
+            SYBL_HIP(hipMemsetAsync(*valid, 0, words * 4, st));
+            c->has_missing = true;
+        }
+    }
     return SYBL_OK;
 }
 
@@ -169,7 +206,13 @@ int block_col_device(BlockWriter &w, Column *c, bool all_populated, void **col, 
     int rc;
     if (c->type != SYBL_SET_VAL && t->compact_mode) {
         // writers produce canonical values: they go to a staging block that block_commit packs into
-        // the column at whatever width the column has (or needs) by then
+        // the column at whatever width the column has (or needs) by then.  The staging block is shared by
+        // consecutive blocks: in a multi-stream load the others finish first and this block's stream is drained
+        // at commit.
+        if (t->ctx->load_multi) {
+            if ((rc = load_sync_all(t->ctx))) return rc;
+            w.serial = true;
+        }
         const int64_t need = std::max<int64_t>(w.nrows, 1) * c->canon();
         if (need > c->stage_cap) {
             if (c->d_stage) SYBL_HIP(hipFree(c->d_stage));
@@ -187,20 +230,25 @@ int block_col_device(BlockWriter &w, Column *c, bool all_populated, void **col, 
     } else if (col) {
         *col = nullptr;
     }
-    *valid = nullptr;
-    if (w.nrows == 0) return SYBL_OK;
-    if (!all_populated || c->d_valid) {
-        if ((rc = valid_reserve(t, c, w.new_phys))) return rc;
-        *valid = c->d_valid + w.start / 32;
-        size_t words = (size_t)(round_up(w.nrows, 32) / 32);
-        if (all_populated) {
-            SYBL_HIP(hipMemsetAsync(*valid, 0xFF, words * 4, st));
-            *valid = nullptr;  // nothing left to set
-        } else {
-            SYBL_HIP(hipMemsetAsync(*valid, 0, words * 4, st));
-            c->has_missing = true;
-        }
+    return block_valid(w, c, all_populated, valid);
+}
+
+int block_col_direct(BlockWriter &w, Column *c, bool all_populated, int64_t mn, int64_t mx, int64_t pop, void **col, uint32_t **valid, bool *ok) {
+    Table *t = w.t;
+    *ok = false;
+    if (!t->compact_mode || c->type == SYBL_SET_VAL || !c->d_data || w.nrows == 0 || getenv("SYBL_NO_DIRECT_DECODE")) return SYBL_OK;
+    if (c->stats_blocks != (int64_t)t->blocks.size()) return SYBL_OK;  // (block statistics are appended at commit)
+    if (pop > 0 && c->elem < 8) {
+        const __int128 top = (__int128)c->vbase + (((__int128)1 << (8 * c->elem)) - 1);
+        if (mn < c->vbase || (__int128)mx > top) return SYBL_OK;  // the block widens the column: staged + repacked at commit
     }
+    int rc;
+    if ((rc = table_reserve(t, c, w.new_phys))) return rc;
+    *col = (char *)c->d_data + (size_t)w.start * (size_t)c->elem;
+    if (!all_populated) SYBL_HIP(hipMemsetAsync(*col, 0, (size_t)w.nrows * (size_t)c->elem, t->ctx->stream));
+    if ((rc = block_valid(w, c, all_populated, valid))) return rc;
+    w.direct.push_back(BlockWriter::Staged{c, true, pop > 0 ? mn : INT64_MAX, pop > 0 ? mx : INT64_MIN, pop});
+    *ok = true;
     return SYBL_OK;
 }
 
@@ -431,6 +479,25 @@ int block_commit(BlockWriter &w) {
     int rc = commit_staged(w);
     if (rc) return rc;
     w.staged.clear();
+    for (auto &s : w.direct) {  // columns already in place: only their block statistics are left to record
+        Column *c = s.c;
+        if (c->stats_blocks != (int64_t)t->blocks.size()) continue;
+        c->blk_min.push_back(s.mn);
+        c->blk_max.push_back(s.mx);
+        c->blk_pop.push_back(s.pop);
+        if (s.pop > 0) {
+            c->exact_min = std::min(c->exact_min, s.mn);
+            c->exact_max = std::max(c->exact_max, s.mx);
+        }
+        c->n_pop += s.pop;
+        if (s.pop < w.nrows) c->has_missing = true;
+        c->stats_blocks = (int64_t)t->blocks.size() + 1;
+    }
+    w.direct.clear();
+    if (w.serial) {
+        SYBL_HIP(hipStreamSynchronize(t->ctx->stream));
+        w.serial = false;
+    }
     Segment blk;
     blk.start = w.start;
     blk.n = w.nrows;
@@ -810,7 +877,7 @@ int sybl_table_set_dict(sybl_table *t, const char *name, const char *const *stri
         int32_t *d_lut = nullptr;
         SYBL_HIP(hipMalloc((void **)&d_lut, lut.size() * 4));
         SYBL_HIP(hipMemcpyAsync(d_lut, lut.data(), lut.size() * 4, hipMemcpyHostToDevice, st));
-        hipError_t e = launch_remap_ids((const int32_t *)c->d_data, d_lut, (int32_t)lut.size(), t->phys_rows, (int32_t *)c->d_data, st);
+        hipError_t e = launch_remap_ids((const int32_t *)c->d_data, 4, d_lut, (int32_t)lut.size(), t->phys_rows, (int32_t *)c->d_data, st);
         if (e != hipSuccess) {
             hipFree(d_lut);
             return hip_fail(e, "k_remap_ids");

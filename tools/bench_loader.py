@@ -32,6 +32,7 @@ for rep in range(4):
     dt = time.perf_counter() - t0
     print("open_table(%s): %d rows in %.3f s = %.1f M rows/s, %.1f MB/s of column files, %d columns, %.1f MB in HBM" % (
         "compact" if compact else "canonical", tb.rows, dt, tb.rows / dt / 1e6, size / dt / 1e6, 4, tb.hbm_bytes / 1e6))
+    print("   ", tb.load_stats())
     q = tb.query(groups=["status"], aggs=["latency"])
     r = q.run()
     assert r.matched == tb.rows

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Config 3 (3 ANDed int-range filters, group-by 2, moments of 2 columns) at different selectivities on compact
+storage: does the row body's LDS-atomic issue still cost time when almost no row matches?
+usage: bench_selectivity.py [rows] [steps]"""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import sybil_amd
+from sybil_amd import synth
+
+rows = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000_000
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+wl = synth.WORKLOADS["cfg3_filter3_group2_stddev"]
+ctx = sybil_amd.Context(0)
+t = ctx.synth_table("sel", synth.SEED, rows, 0, rows, synth.synth_cols(wl["columns"]))
+t.compact()
+cases = [
+    ("51% (gt:99,lt:900 x3: the headline)", wl["query"]["filters"]),
+    ("10% (gt:535 x3)", [("c04", "gt", 535), ("c05", "gt", 535), ("c06", "gt", 535)]),
+    ("1% (gt:989 on c04 only)", [("c04", "gt", 989), ("c05", "gt", -1), ("c06", "gt", -1)]),
+    ("0.1% (gt:899 x3)", [("c04", "gt", 899), ("c05", "gt", 899), ("c06", "gt", 899)]),
+    ("1e-6 (gt:989 x3)", [("c04", "gt", 989), ("c05", "gt", 989), ("c06", "gt", 989)]),
+    ("0 (gt:999 on c04)", [("c04", "gt", 999), ("c05", "gt", -1), ("c06", "gt", -1)]),
+]
+for label, filters in cases:
+    q = t.query(**dict(wl["query"], filters=filters))
+    q.run().free()
+    ms = []
+    for _ in range(steps):
+        r = q.run()
+        ms.append(q.stats()["scan_ms"])
+        matched = r.matched
+        r.free()
+    st = q.stats()
+    k = sorted(ms)[len(ms) // 2]
+    print(json.dumps({"selectivity": label, "rows": rows, "matched": matched, "match_frac": matched / rows, "kernel_ms": round(k, 3),
+                      "GBps": st["algorithmic_bytes"] / (k * 1e-3) / 1e9, "packed_kernel": st["packed_kernel"], "strategy": st["strategy"]}))
+    sys.stdout.flush()
+    q.free()
+t.free()
