@@ -178,6 +178,15 @@ typedef struct {
 } sybl_load_stats;
 int sybl_table_load_stats(const sybl_table *t, sybl_load_stats *out);
 
+/* Makes a table opened with sybl_table_open* follow its directory: block directories that appeared since are loaded
+ * behind the resident ones, blocks that vanished leave the scan, blocks whose <block>/info.db changed (digest rewrote
+ * them) are dropped and loaded again, and the columns' IntInfo is re-read from the table's info.db.  The resident
+ * table replaces the reference's per-query re-listing of the directory (table_query.go:40-106) and its per-block
+ * result cache (query_cache.go:30-64); this call is what keeps it current.  Prepared queries must be prepared again
+ * (SYBL_E_STATE otherwise).  Any of the counters may be NULL.  Dropped rows stay in HBM, unreferenced, until the table
+ * is reopened. */
+int sybl_table_refresh(sybl_table *t, int64_t *n_added, int64_t *n_dropped, int64_t *n_reloaded);
+
 /* Blocks sybl_table_open skipped the way the reference does: unreadable block info.db, NumRecords
  * <= 0, or a column file whose record ids / value count exceed NumRecords ("BLOCK SIZE CHANGED
  * DURING QUERY", column_store_io.go:524-526,572-574,733-735; table_query.go:134-139). */

@@ -103,6 +103,7 @@ SIGNATURES = {
     "sybl_table_open_flags": (C.c_int, [P, C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), C.c_int32, C.c_int32, C.c_int32,
                                         C.c_int32, C.POINTER(P)]),
     "sybl_table_save": (C.c_int, [P, C.c_char_p]),
+    "sybl_table_refresh": (C.c_int, [P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "sybl_debug_encode_column": (C.c_void_p, [C.c_int, C.c_char_p, P, P, C.c_int64, C.POINTER(C.c_char_p), C.c_int64,
                                               C.POINTER(C.c_int64)]),
     "sybl_table_broken_blocks": (C.c_int64, [P]),

@@ -112,6 +112,13 @@ struct Column {
     int64_t stage_cap = 0;           // bytes
 };
 
+// a block directory the loader has seen (sybl_table_open / sybl_table_refresh)
+struct LoadedBlock {
+    std::string name;
+    int64_t mtime_ns = 0, size = 0;  // of <block>/info.db when it was read
+    int64_t index = -1;              // into Table::blocks; -1: skipped as broken / unreadable
+};
+
 struct Table {
     Ctx *ctx = nullptr;
     std::string name;
@@ -128,7 +135,10 @@ struct Table {
     int64_t scratch_words = 0;
     int64_t version = 0;        // bumped by every change a prepared query would not know about
     int64_t broken_blocks = 0;  // blocks the loader skipped (unreadable info / column unpack error)
-    sybl_load_stats load_stats{};  // of the sybl_table_open that built this table
+    sybl_load_stats load_stats{};  // of the sybl_table_open / sybl_table_refresh that last loaded blocks
+    std::string src_dir;           // <dir>/<table> the table was opened from ("" = built through the ABI)
+    int src_rank = 0, src_nranks = 1;
+    std::vector<LoadedBlock> loaded;
     Column *find(const char *name) const;
 };
 

@@ -624,62 +624,35 @@ static int apply_col(BlockWriter &w, Column *c, PreparedCol &pc, const char *H, 
     return SYBL_OK;
 }
 
-static int open_table(Ctx *ctx, const char *dir, const char *table, const char *const *columns, int32_t n_columns,
-                      int32_t rank, int32_t nranks, int32_t flags, sybl_table **out) {
-    std::string tdir = std::string(dir ? dir : ".") + "/" + table;
-    std::string err;
-    // ---- table info.db: KeyTable, KeyTypes, IntInfo (table_io.go:145-180)
-    gob::Value info;
-    if (!decode_file(tdir + "/info.db", info, err)) return fail(SYBL_E_IO, "%s", err.c_str());
+struct TableInfo {
     std::map<std::string, int64_t> key_id;
     std::map<int64_t, int> key_type;
     std::map<int64_t, std::pair<int64_t, int64_t>> int_info;
+};
+
+// <table>/info.db: KeyTable, KeyTypes, IntInfo (table_io.go:145-180)
+static int read_table_info(const std::string &tdir, TableInfo &ti) {
+    std::string err;
+    gob::Value info;
+    if (!decode_file(tdir + "/info.db", info, err)) return fail(SYBL_E_IO, "%s", err.c_str());
     if (const gob::Value *kt = info.field("KeyTable"))
-        for (auto &e : kt->entries) key_id[e.first->s] = e.second->as_int();
+        for (auto &e : kt->entries) ti.key_id[e.first->s] = e.second->as_int();
     if (const gob::Value *ky = info.field("KeyTypes"))
-        for (auto &e : ky->entries) key_type[e.first->as_int()] = (int)e.second->as_int();
+        for (auto &e : ky->entries) ti.key_type[e.first->as_int()] = (int)e.second->as_int();
     if (const gob::Value *ii = info.field("IntInfo"))
         for (auto &e : ii->entries) {
             const gob::Value *mn = e.second->field("Min"), *mx = e.second->field("Max");
-            int_info[e.first->as_int()] = {mn ? mn->as_int() : 0, mx ? mx->as_int() : 0};
+            ti.int_info[e.first->as_int()] = {mn ? mn->as_int() : 0, mx ? mx->as_int() : 0};
         }
-    if (key_id.empty()) return fail(SYBL_E_IO, "%s/info.db has no KeyTable", tdir.c_str());
+    if (ti.key_id.empty()) return fail(SYBL_E_IO, "%s/info.db has no KeyTable", tdir.c_str());
+    return SYBL_OK;
+}
 
-    sybl_table *t = nullptr;
-    int rc = sybl_table_create((sybl_ctx *)ctx, table, &t);
-    if (rc == SYBL_OK && (flags & SYBL_OPEN_COMPACT)) t->compact_mode = true;  // every block is packed as it arrives
-    if (rc) return rc;
-    auto bail = [&](int code) {
-        (void)load_sync_all(ctx);  // (blocks of a multi-stream load may still be decoding into the table)
-        sybl_table_free(t);
-        return code;
-    };
-    std::vector<std::string> want;
-    if (columns && n_columns > 0) {
-        for (int i = 0; i < n_columns; i++) want.push_back(columns[i] ? columns[i] : "");
-    } else {
-        for (auto &kv : key_id) want.push_back(kv.first);
-    }
-    for (auto &name : want) {
-        auto it = key_id.find(name);
-        if (it == key_id.end()) return bail(fail(SYBL_E_INVAL, "column '%s' is not in the table's KeyTable", name.c_str()));
-        auto ty = key_type.find(it->second);
-        int type = ty == key_type.end() ? SYBL_NO_VAL : ty->second;
-        if (type != SYBL_INT_VAL && type != SYBL_STR_VAL && type != SYBL_SET_VAL)
-            return bail(fail(SYBL_E_IO, "column '%s' has unknown key type %d", name.c_str(), type));
-        int64_t imin = 1, imax = 0;
-        auto ii = int_info.find(it->second);
-        if (type == SYBL_INT_VAL && ii != int_info.end()) {
-            imin = ii->second.first;
-            imax = ii->second.second;
-        }
-        if ((rc = sybl_table_add_column(t, name.c_str(), type, imin, imax))) return bail(rc);
-    }
-
-    // ---- block directories, in name order (ioutil.ReadDir sorts), sharded contiguously over ranks
+// block directories in name order (ioutil.ReadDir sorts), this rank's contiguous share of them
+static int list_blocks(const std::string &tdir, int32_t rank, int32_t nranks, std::vector<std::string> &mine) {
     std::vector<std::string> blocks;
     DIR *d = opendir(tdir.c_str());
-    if (!d) return bail(fail(SYBL_E_IO, "cannot list %s", tdir.c_str()));
+    if (!d) return fail(SYBL_E_IO, "cannot list %s", tdir.c_str());
     while (struct dirent *e = readdir(d)) {
         std::string name = e->d_name;
         if (name == "." || name == "..") continue;
@@ -690,8 +663,27 @@ static int open_table(Ctx *ctx, const char *dir, const char *table, const char *
     closedir(d);
     std::sort(blocks.begin(), blocks.end());
     if (nranks < 1) nranks = 1;
-    size_t b0 = blocks.size() * (size_t)rank / (size_t)nranks, b1 = blocks.size() * (size_t)(rank + 1) / (size_t)nranks;
+    const size_t b0 = blocks.size() * (size_t)rank / (size_t)nranks, b1 = blocks.size() * (size_t)(rank + 1) / (size_t)nranks;
+    mine.assign(blocks.begin() + (long)b0, blocks.begin() + (long)b1);
+    return SYBL_OK;
+}
 
+// what a block looked like when it was loaded: <block>/info.db's modification time (ns) and size -- digest rewrites
+// it whenever it rewrites the block (column_store_io.go:308-358)
+static std::pair<int64_t, int64_t> block_signature(const std::string &bdir) {
+    struct stat st;
+    if (stat((bdir + "/info.db").c_str(), &st) != 0 && stat((bdir + "/info.db.gz").c_str(), &st) != 0) return {-1, -1};
+    return {(int64_t)st.st_mtim.tv_sec * 1000000000ll + (int64_t)st.st_mtim.tv_nsec, (int64_t)st.st_size};
+}
+
+// Loads the named block directories of tdir, in order, behind the table's resident blocks (the pipeline of
+// sybl_table_open and sybl_table_refresh).  Every block is committed atomically; on an error the blocks appended so far
+// stay.
+static int load_blocks(Ctx *ctx, Table *t, const std::string &tdir, const std::vector<std::string> &names) {
+    int rc;
+    const size_t n_names = names.size();
+    std::vector<std::pair<int64_t, int64_t>> sigs(n_names);
+    for (size_t i = 0; i < n_names; i++) sigs[i] = block_signature(tdir + "/" + names[i]);
     std::vector<ColSpec> specs;
     for (auto &cp : t->cols) specs.push_back({cp->name, cp->type});
     // worker threads decode a window of blocks ahead of the (serial, in-order) GPU phase
@@ -708,29 +700,30 @@ static int open_table(Ctx *ctx, const char *dir, const char *table, const char *
         pool.slab_bytes = align16(per_block);
         if (const char *e = getenv("SYBL_LOADER_SLAB_BYTES")) pool.slab_bytes = align16((size_t)std::max(16, atoi(e)));  // (tests: over-sized blocks)
         pool.max_slabs = std::min<size_t>(std::max<size_t>(((size_t)512 << 20) / pool.slab_bytes, 4), std::max<size_t>(2 * n_workers, 4));
-        pool.max_slabs = std::min<size_t>(pool.max_slabs, std::max<size_t>(b1 - b0, 1));
-        if ((rc = pool.init())) return bail(rc);
+        pool.max_slabs = std::min<size_t>(pool.max_slabs, std::max<size_t>(n_names, 1));
+        if ((rc = pool.init())) return (rc);
     }
     const size_t window = std::min(n_workers * 2, pool.max_slabs);
     struct InFlight {
         std::future<PreparedBlock> fut;
         int slab;
+        size_t name_ix;
     };
     std::deque<InFlight> inflight;
     LoadWorkers workers(n_workers > 1 ? n_workers : 0);  // (declared after the pool and the queue: joined first)
-    size_t next = b0;
+    size_t next = 0;
     const int device = ctx->device;
     auto submit = [&]() -> int {
-        while (next < b1 && inflight.size() < window) {
+        while (next < n_names && inflight.size() < window) {
             int slab = -1;
             int rc2 = pool.acquire(inflight.empty(), &slab);
             if (rc2) return rc2;
             if (slab < 0) break;  // every slab is in flight or still being read by the GPU
-            std::string bdir = tdir + "/" + blocks[next++];
+            std::string bdir = tdir + "/" + names[next++];
             char *sh = pool.slabs[(size_t)slab].h;
             const size_t scap = pool.slabs[(size_t)slab].cap;
             auto prom = std::make_shared<std::promise<PreparedBlock>>();
-            inflight.push_back(InFlight{prom->get_future(), slab});
+            inflight.push_back(InFlight{prom->get_future(), slab, next - 1});
             workers.run([prom, bdir, &specs, sh, scap, device]() { prom->set_value(prepare_block(bdir, specs, sh, scap, device)); });
         }
         return SYBL_OK;
@@ -745,7 +738,7 @@ static int open_table(Ctx *ctx, const char *dir, const char *table, const char *
     };
     // the columns grow to about this many rows: reserve once instead of doubling through ~20 reallocations (each a
     // device malloc + copy + synchronise + free)
-    t->reserve_hint_rows = std::max(t->reserve_hint_rows, t->phys_rows + (int64_t)(b1 - b0) * (SYBL_BLOCK_ROWS + 32));
+    t->reserve_hint_rows = std::max(t->reserve_hint_rows, t->phys_rows + (int64_t)n_names * (SYBL_BLOCK_ROWS + 32));
     // consecutive blocks go to different streams (Ctx::load_streams): restored, and everything drained, on every way out
     struct StreamGuard {
         Ctx *ctx;
@@ -783,11 +776,12 @@ static int open_table(Ctx *ctx, const char *dir, const char *table, const char *
         tr[k] += std::chrono::duration<double>(t1 - t0).count();
         t0 = t1;
     };
-    if ((rc = submit())) return bail(rc);
+    if ((rc = submit())) return (rc);
     while (!inflight.empty()) {
         auto tw = std::chrono::steady_clock::now();
         PreparedBlock pb = inflight.front().fut.get();
         const int slab = inflight.front().slab;
+        const size_t name_ix = inflight.front().name_ix;
         wait_s += seconds_since(tw);
         inflight.pop_front();
         struct Apply {
@@ -799,10 +793,11 @@ static int open_table(Ctx *ctx, const char *dir, const char *table, const char *
             if (pb.own_h) (void)hipHostFree(pb.own_h);
             if (pb.own_d) (void)hipFree(pb.own_d);
             drain();
-            return bail(code);
+            return code;
         };
         if (pb.unreadable || pb.broken) {
             t->broken_blocks++;
+            t->loaded.push_back(LoadedBlock{names[name_ix], sigs[name_ix].first, sigs[name_ix].second, -1});
             pool.give_back(slab);
             if ((rc = submit())) return fail_out(rc);
             continue;
@@ -824,6 +819,7 @@ static int open_table(Ctx *ctx, const char *dir, const char *table, const char *
             if ((rc = apply_col(w, t->cols[ci].get(), pb.cols[ci], H, D, luts[ci].size()))) return fail_out(rc);
         lap(2, tl);
         if ((rc = block_commit(w))) return fail_out(rc);
+        t->loaded.push_back(LoadedBlock{names[name_ix], sigs[name_ix].first, sigs[name_ix].second, (int64_t)t->blocks.size() - 1});
         lap(3, tl);
         if (pb.own_h) {
             // an over-sized block's private pair: wait for its kernels, then let it go
@@ -841,7 +837,7 @@ static int open_table(Ctx *ctx, const char *dir, const char *table, const char *
     if (trace)
         fprintf(stderr, "loader: dictionaries %.3f s, copy %.3f s, column kernels %.3f s, commit %.3f s, submit %.3f s, wait %.3f s, slabs %zu x %zu KB\n",
                 tr[0], tr[1], tr[2], tr[3], tr[4], wait_s, pool.slabs.size(), pool.slab_bytes >> 10);
-    if ((rc = load_sync_all(ctx))) return bail(rc);
+    if ((rc = load_sync_all(ctx))) return (rc);
     SYBL_HIP(hipStreamSynchronize(ctx->stream));  // the table is resident when the call returns (and the wall time says so)
     t->load_stats.wall_s = seconds_since(t_open);
     t->load_stats.parse_cpu_s = (double)g_parse_ns.load() * 1e-9;
@@ -850,8 +846,127 @@ static int open_table(Ctx *ctx, const char *dir, const char *table, const char *
     t->load_stats.file_bytes = g_file_bytes.load();
     t->load_stats.h2d_bytes = h2d_bytes;
     t->load_stats.workers = (int32_t)n_workers;
-    t->load_stats.blocks = (int32_t)(b1 - b0);
+    t->load_stats.blocks = (int32_t)n_names;
+    return SYBL_OK;
+}
+
+static int open_table(Ctx *ctx, const char *dir, const char *table, const char *const *columns, int32_t n_columns,
+                      int32_t rank, int32_t nranks, int32_t flags, sybl_table **out) {
+    std::string tdir = std::string(dir ? dir : ".") + "/" + table;
+    TableInfo ti;
+    int rc = read_table_info(tdir, ti);
+    if (rc) return rc;
+    sybl_table *t = nullptr;
+    rc = sybl_table_create((sybl_ctx *)ctx, table, &t);
+    if (rc == SYBL_OK && (flags & SYBL_OPEN_COMPACT)) t->compact_mode = true;  // every block is packed as it arrives
+    if (rc) return rc;
+    auto bail = [&](int code) {
+        (void)load_sync_all(ctx);  // (blocks of a multi-stream load may still be decoding into the table)
+        sybl_table_free(t);
+        return code;
+    };
+    std::vector<std::string> want;
+    if (columns && n_columns > 0) {
+        for (int i = 0; i < n_columns; i++) want.push_back(columns[i] ? columns[i] : "");
+    } else {
+        for (auto &kv : ti.key_id) want.push_back(kv.first);
+    }
+    for (auto &name : want) {
+        auto it = ti.key_id.find(name);
+        if (it == ti.key_id.end()) return bail(fail(SYBL_E_INVAL, "column '%s' is not in the table's KeyTable", name.c_str()));
+        auto ty = ti.key_type.find(it->second);
+        int type = ty == ti.key_type.end() ? SYBL_NO_VAL : ty->second;
+        if (type != SYBL_INT_VAL && type != SYBL_STR_VAL && type != SYBL_SET_VAL)
+            return bail(fail(SYBL_E_IO, "column '%s' has unknown key type %d", name.c_str(), type));
+        int64_t imin = 1, imax = 0;
+        auto ii = ti.int_info.find(it->second);
+        if (type == SYBL_INT_VAL && ii != ti.int_info.end()) {
+            imin = ii->second.first;
+            imax = ii->second.second;
+        }
+        if ((rc = sybl_table_add_column(t, name.c_str(), type, imin, imax))) return bail(rc);
+    }
+    std::vector<std::string> names;
+    if ((rc = list_blocks(tdir, rank, nranks, names))) return bail(rc);
+    t->src_dir = tdir;
+    t->src_rank = rank;
+    t->src_nranks = nranks < 1 ? 1 : nranks;
+    if ((rc = load_blocks(ctx, t, tdir, names))) return bail(rc);
     *out = t;
+    return SYBL_OK;
+}
+
+// sybl_table_refresh: the resident table follows its directory.  The reference re-lists and re-reads the block
+// directories on every query (table_query.go:40-106) and keeps per-block results in a cache keyed by the block
+// (query_cache.go:30-64); here the blocks stay decoded in HBM, so what has to be noticed is a block that appeared
+// (digest wrote a new one), vanished (trim / expire) or was rewritten (digest into a partly filled block:
+// <block>/info.db changed).
+static int refresh_table(Table *t, int64_t *n_added, int64_t *n_dropped, int64_t *n_reloaded) {
+    Ctx *ctx = t->ctx;
+    if (t->src_dir.empty()) return fail(SYBL_E_STATE, "the table was not opened from a directory (sybl_table_open)");
+    TableInfo ti;
+    int rc = read_table_info(t->src_dir, ti);
+    if (rc) return rc;
+    // IntInfo may have moved with the new records (table_column_info.go:75-131)
+    bool info_changed = false;
+    for (auto &cp : t->cols) {
+        auto it = ti.key_id.find(cp->name);
+        if (it == ti.key_id.end() || cp->type != SYBL_INT_VAL) continue;
+        auto ii = ti.int_info.find(it->second);
+        if (ii == ti.int_info.end()) continue;
+        if (!cp->info_given || cp->info_min != ii->second.first || cp->info_max != ii->second.second) info_changed = true;
+        cp->info_given = true;
+        cp->info_min = ii->second.first;
+        cp->info_max = ii->second.second;
+    }
+    std::vector<std::string> names;
+    if ((rc = list_blocks(t->src_dir, t->src_rank, t->src_nranks, names))) return rc;
+    std::map<std::string, size_t> wanted;
+    for (size_t i = 0; i < names.size(); i++) wanted[names[i]] = i;
+    if ((rc = table_ensure_stats(t))) return rc;
+    int64_t added = 0, dropped = 0, reloaded = 0;
+    std::vector<LoadedBlock> keep;
+    std::vector<std::string> to_load;
+    std::map<std::string, bool> resident;
+    for (auto &lb : t->loaded) {
+        auto w = wanted.find(lb.name);
+        bool same = false;
+        if (w != wanted.end()) {
+            auto sig = block_signature(t->src_dir + "/" + lb.name);
+            same = sig.first == lb.mtime_ns && sig.second == lb.size;
+        }
+        if (same) {
+            keep.push_back(lb);
+            resident[lb.name] = true;
+            continue;
+        }
+        // vanished, moved to another rank's share, or rewritten: its rows leave the scan (they stay in HBM, unreferenced,
+        // until the table is reopened)
+        if (lb.index >= 0 && lb.index < (int64_t)t->blocks.size() && t->blocks[(size_t)lb.index].n > 0) {
+            const int64_t n = t->blocks[(size_t)lb.index].n;
+            t->blocks[(size_t)lb.index].n = 0;
+            t->logical_rows -= n;
+            for (auto &cp : t->cols) {
+                Column *c = cp.get();
+                if (c->type == SYBL_SET_VAL || (int64_t)c->blk_pop.size() <= lb.index) continue;
+                c->n_pop -= c->blk_pop[(size_t)lb.index];
+                c->blk_pop[(size_t)lb.index] = 0;  // (exact_min / exact_max stay: bounds of a superset are still bounds)
+            }
+        } else if (lb.index < 0) {
+            t->broken_blocks--;
+        }
+        if (w != wanted.end()) reloaded++;
+        else dropped++;
+    }
+    for (auto &nm : names)
+        if (!resident.count(nm)) to_load.push_back(nm);
+    added = (int64_t)to_load.size() - reloaded;
+    t->loaded.swap(keep);
+    if (info_changed || dropped + reloaded > 0) t->version++;  // (appended blocks bump it themselves)
+    if (!to_load.empty() && (rc = load_blocks(ctx, t, t->src_dir, to_load))) return rc;
+    if (n_added) *n_added = added;
+    if (n_dropped) *n_dropped = dropped;
+    if (n_reloaded) *n_reloaded = reloaded;
     return SYBL_OK;
 }
 
@@ -876,6 +991,16 @@ int sybl_table_open_flags(sybl_ctx *ctx, const char *dir, const char *table, con
     } catch (const std::exception &e) {
         *out = nullptr;
         return fail(SYBL_E_IO, "sybl_table_open: %s", e.what());
+    }
+}
+
+int sybl_table_refresh(sybl_table *t, int64_t *n_added, int64_t *n_dropped, int64_t *n_reloaded) {
+    if (!t) return fail(SYBL_E_INVAL, "sybl_table_refresh: NULL table");
+    SYBL_HIP(hipSetDevice(t->ctx->device));
+    try {
+        return refresh_table(t, n_added, n_dropped, n_reloaded);
+    } catch (const std::exception &e) {
+        return fail(SYBL_E_IO, "sybl_table_refresh: %s", e.what());
     }
 }
 

@@ -200,6 +200,12 @@ class Table:
         """Write the table under directory/<name>/ in the reference's on-disk format (sybl_table_save)."""
         N.check(N.lib().sybl_table_save(self._h, _b(directory)))
 
+    def refresh(self):
+        """Follow the directory the table was opened from (sybl_table_refresh): returns (added, dropped, reloaded) blocks."""
+        a, d, r = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        N.check(N.lib().sybl_table_refresh(self._h, C.byref(a), C.byref(d), C.byref(r)))
+        return a.value, d.value, r.value
+
     def compact(self):
         """Re-encode every int / str column at the narrowest width that holds max - min
         (sybl_table_compact); query results are unchanged, scans stream fewer bytes."""

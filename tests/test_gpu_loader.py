@@ -181,6 +181,54 @@ def test_blocks_larger_than_a_staging_slab(ctx, tmp_path, monkeypatch):
     ref.free()
 
 
+def _summary(tb, q):
+    query = tb.query(**q)
+    r = query.run()
+    out = (r.matched, sorted((x["group_by_key"], x["count"], tuple((h["count"], h["sum"]) for h in x["hists"])) for x in r.results))
+    r.free()
+    query.free()
+    return out
+
+
+def test_refresh_follows_the_directory(ctx, tmp_path):
+    """sybl_table_refresh: a block that appeared is loaded, one that vanished leaves the scan, one that was rewritten
+    with another NumRecords (the reference's resized-block case, table_query_test.go:11-158) is loaded again -- and the
+    table then answers like a freshly opened one."""
+    import shutil
+    import sybil_amd
+    blocks, _ = _make_blocks(4, 3000, seed=21, ragged=False)
+    info = {"big": (-(1 << 40), 1 << 40)}
+    root, spare = str(tmp_path / "db"), str(tmp_path / "spare")
+    F.write_table(root, "events", blocks[:3], threshold=8, int_info=info)
+    tb = ctx.open_table(root, "events", compact=True)
+    queries = [dict(groups=["age"], aggs=["big", "time"]), dict(filters=[("tags", "in", "tag3")], groups=["name"], aggs=["age"], op="hist")]
+    stale = tb.query(**queries[0])
+    stale.run().free()
+    assert tb.refresh() == (0, 0, 0) and tb.rows == 9000
+    stale.run().free()  # nothing changed: the prepared query is still good... after being prepared again
+    # the directory moves on: block 4 appears, block 2 vanishes, block 1 is rewritten with fewer rows
+    resized = {c: (spec[0],) + tuple(x[:1234] for x in spec[1:]) for c, spec in blocks[0].items()}
+    F.write_table(spare, "events", [resized, blocks[1], blocks[2], blocks[3]], threshold=8, int_info=info)
+    tdir, sdir = str(tmp_path / "db" / "events"), str(tmp_path / "spare" / "events")
+    shutil.rmtree(tdir + "/block000000002")
+    shutil.rmtree(tdir + "/block000000001")
+    shutil.copytree(sdir + "/block000000001", tdir + "/block000000001")
+    shutil.copytree(sdir + "/block000000004", tdir + "/block000000004")
+    shutil.copy(sdir + "/info.db", tdir + "/info.db")
+    assert tb.refresh() == (1, 1, 1)
+    assert tb.rows == 1234 + 3000 + 3000 and tb.broken_blocks == 0
+    with pytest.raises(sybil_amd.SyblError):
+        stale.scan()  # prepared before the table changed
+    stale.free()
+    fresh = ctx.open_table(root, "events", compact=True)
+    assert fresh.rows == tb.rows
+    for q in queries:
+        assert _summary(tb, q) == _summary(fresh, q), q
+    assert tb.refresh() == (0, 0, 0)
+    fresh.free()
+    tb.free()
+
+
 def test_column_subset_and_rank_sharding(ctx, tmp_path):
     blocks, logical = _make_blocks(6, 2000, ragged=False)
     root = str(tmp_path / "db")
