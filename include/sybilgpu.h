@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SYBL_ABI_VERSION 1
+#define SYBL_ABI_VERSION 2
 
 enum {
     SYBL_OK = 0,
@@ -335,7 +335,16 @@ typedef struct {
     int64_t n_values;     /* HIST: len(Values) */
     const int64_t *values;      /* HIST + want_percentiles: bucket counts, else NULL */
     const int64_t *percentiles; /* HIST + want_percentiles: 100 entries (GetPercentiles), else NULL */
-    int64_t n_outliers;   /* accepted values clipped into the last bucket */
+    int64_t n_outliers;   /* accepted values clipped into an edge bucket (BasicHist.Outliers + Underliers, all blocks) */
+    /* HIST + want_percentiles: the outliers' values (ascending; those below hist Min are the reference's Underliers),
+     * as the reference remembers them (hist_basic.go:132-142) and prints them as buckets of their own (:239-257).
+     * n_outlier_values = -1: not available -- the query's outlier log overflowed (SYBL_OUTLIER_LOG_CAP, default 2^20
+     * values per query) or the result was merged across ranks (the values stay on the rank that saw them); the
+     * renderers then refuse -json / -encode-results for rows with outliers instead of printing wrong buckets.
+     * The reference itself keeps only ONE block's list per histogram after merging (BasicHist.Combine does not merge
+     * them, hist_basic.go:259-279) and none in Cumulative: this is the deterministic superset. */
+    const int64_t *outlier_values;
+    int64_t n_outlier_values;
 } sybl_agg_out;
 
 typedef struct {

@@ -90,6 +90,8 @@ def lib():
         L.orc_result_hist_values.restype = C.c_int64
         L.orc_result_hist_values.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_int64]
         L.orc_result_percentiles.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p]
+        L.orc_result_outliers.restype = C.c_int64
+        L.orc_result_outliers.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_int64]
         L.orc_setup_buckets.argtypes = [C.c_int64, C.c_int64, C.c_int64] + [C.POINTER(C.c_int64)] * 3
         L.orc_percentiles_from_values.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]
         L.orc_stddev_from_values.restype = C.c_double
@@ -427,6 +429,10 @@ def run_query(cols, filters=(), groups=(), aggs=(), op="avg", hist_bucket=0, tim
                         p = np.zeros(100, dtype=np.int64)
                         n = L.orc_result_percentiles(R, which, idx, a, _ptr(p))
                         h["percentiles"] = p[:max(n, 0)]
+                        no = h["n_outliers"] + h["n_underliers"]
+                        ov = np.zeros(max(no, 1), dtype=np.int64)
+                        got = L.orc_result_outliers(R, which, idx, a, _ptr(ov), ov.size)
+                        h["outlier_values"] = ov[:max(min(got, no), 0)]
                     r["hists"].append(h)
                 lst.append(r)
             out[name] = lst[0] if which == 2 else lst

@@ -754,6 +754,23 @@ int64_t orc_result_hist_values(const orc_results *R, int which, int64_t idx, int
     return orc_hist_values(r->hists[agg], out, cap);
 }
 
+/* every outlier and underlier value of the hist, merged across blocks (the "exact" side-state), ascending */
+static int cmp_i64(const void *a, const void *b) {
+    const int64_t x = *(const int64_t *)a, y = *(const int64_t *)b;
+    return x < y ? -1 : x > y;
+}
+int64_t orc_result_outliers(const orc_results *R, int which, int64_t idx, int agg, int64_t *out, int64_t cap) {
+    const orc_result *r = get_result(R, which, idx);
+    if (!r || agg < 0 || agg >= R->q.n_aggs || !r->hists[agg]) return -1;
+    const orc_hist *h = r->hists[agg];
+    const int64_t n = h->all_outliers.n + h->all_underliers.n;
+    if (cap < n) return n;
+    if (h->all_outliers.n) memcpy(out, h->all_outliers.v, (size_t)h->all_outliers.n * sizeof(int64_t));
+    if (h->all_underliers.n) memcpy(out + h->all_outliers.n, h->all_underliers.v, (size_t)h->all_underliers.n * sizeof(int64_t));
+    qsort(out, (size_t)n, sizeof(int64_t), cmp_i64);
+    return n;
+}
+
 int orc_result_percentiles(const orc_results *R, int which, int64_t idx, int agg, int64_t *out100) {
     const orc_result *r = get_result(R, which, idx);
     if (!r || agg < 0 || agg >= R->q.n_aggs || !r->hists[agg]) return -1;

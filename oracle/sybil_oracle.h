@@ -168,6 +168,8 @@ void orc_hist_info_get(const orc_hist *h, orc_hist_info *out);
 int64_t orc_hist_values(const orc_hist *h, int64_t *out, int64_t cap);
 int orc_hist_percentiles(const orc_hist *h, int64_t *out100);
 int64_t orc_hist_outliers(const orc_hist *h, int64_t *out, int64_t cap);
+/* all outliers + underliers of a result's hist over every block, ascending; returns the count (nothing written if > cap) */
+int64_t orc_result_outliers(const orc_results *R, int which, int64_t idx, int agg, int64_t *out, int64_t cap);
 void orc_hist_free(orc_hist *h);
 
 /* ---- synthetic table generator (OURS, not the reference's; DESIGN.md "Synthetic table") ---- */

@@ -55,7 +55,7 @@ class AggOut(C.Structure):
                 ("avg", C.c_double), ("stddev", C.c_double), ("min", C.c_int64), ("max", C.c_int64),
                 ("bucket_size", C.c_int64), ("num_buckets", C.c_int64), ("n_values", C.c_int64),
                 ("values", C.POINTER(C.c_int64)), ("percentiles", C.POINTER(C.c_int64)),
-                ("n_outliers", C.c_int64)]
+                ("n_outliers", C.c_int64), ("outlier_values", C.POINTER(C.c_int64)), ("n_outlier_values", C.c_int64)]
 
 
 class GroupRow(C.Structure):

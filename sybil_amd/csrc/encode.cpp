@@ -22,7 +22,7 @@ using gobenc::Fields;
 enum GobId : int {  // builtin ids, then ours in definition order
     G_BOOL = 1, G_INT = 2, G_FLOAT = 4, G_STRING = 6, G_IFACE = 8,
     T_NODE = 65, T_QSPEC, T_QPARAMS, T_GROUPING, T_GROUPINGS, T_AGG, T_AGGS, T_QRESULTS, T_RESULT, T_HISTMAP, T_RESULTMAP,
-    T_TIMEMAP, T_SORTED, T_HISTCOMPAT, T_BASICHIST, T_CACHED, T_I64S, T_INTINFO,
+    T_TIMEMAP, T_SORTED, T_HISTCOMPAT, T_BASICHIST, T_CACHED, T_I64S, T_INTINFO, T_F64S,
 };
 
 struct GobStream {
@@ -106,20 +106,38 @@ static void gob_hist(GobW &w, const Result *R, const sybl_agg_out &o, int a) {
         v.u((uint64_t)o.n_values);
         for (int64_t k = 0; k < o.n_values; k++) v.i(o.values[k]);
     }
+    // (Averages []float64, field 3: the per-bucket running means are written by AddWeightedValue and read by nothing
+    // (hist_basic.go:144-150; Combine, GetPercentiles, GetStdDev and the printers ignore them).  They are not tracked:
+    // omitted, i.e. nil to a Go decoder.)
     if (R->op == SYBL_AGG_HIST) {
-        ci.at(3);  // PercentileMode
+        ci.at(4);  // PercentileMode
         v.u(1);
     }
-    ci.put_int(4, o.max);
-    ci.put_int(5, o.min);
-    ci.put_int(6, o.samples);
-    ci.put_int(7, o.count);
+    if (o.n_outlier_values > 0) {
+        // Outliers (beyond the last bucket) / Underliers (below hist Min), hist_basic.go:132-142; values ascending
+        int64_t n_under = 0;
+        while (n_under < o.n_outlier_values && o.outlier_values[n_under] < R->agg_info[(size_t)a].first) n_under++;
+        if (o.n_outlier_values > n_under) {
+            ci.at(5);
+            v.u((uint64_t)(o.n_outlier_values - n_under));
+            for (int64_t k = n_under; k < o.n_outlier_values; k++) v.i(o.outlier_values[k]);
+        }
+        if (n_under > 0) {
+            ci.at(6);
+            v.u((uint64_t)n_under);
+            for (int64_t k = 0; k < n_under; k++) v.i(o.outlier_values[k]);
+        }
+    }
+    ci.put_int(7, o.max);
+    ci.put_int(8, o.min);
+    ci.put_int(9, o.samples);
+    ci.put_int(10, o.count);
     if (o.avg != 0.0) {
-        ci.at(8);
+        ci.at(11);
         v.f(o.avg);
     }
     {
-        ci.at(9);  // Info IntInfo{Min, Max}
+        ci.at(12);  // Info IntInfo{Min, Max}
         Fields in(v);
         in.put_int(0, R->agg_info[(size_t)a].first);
         in.put_int(1, R->agg_info[(size_t)a].second);
@@ -176,6 +194,12 @@ const void *sybl_result_encode(sybl_result *r, int64_t *n_bytes) {
         set_error("sybl_result_encode: NULL argument");
         return nullptr;
     }
+    for (auto &o : R->agg_pool)
+        if (o.present && o.n_outlier_values < 0) {
+            set_error("histograms with outliers cannot be encoded: their values were not kept (outlier log overflow, or a result merged "
+                      "across ranks)");
+            return nullptr;
+        }
     GobStream S;
     S.def_struct(T_NODE, "NodeResults", {{"QuerySpec", T_QSPEC}});
     S.def_struct(T_QSPEC, "QuerySpec", {{"QueryParams", T_QPARAMS}, {"QueryResults", T_QRESULTS}});
@@ -198,9 +222,11 @@ const void *sybl_result_encode(sybl_result *r, int64_t *n_bytes) {
     S.def_struct(T_HISTCOMPAT, "HistCompat", {{"BasicHist", T_BASICHIST}});
     S.def_struct(T_BASICHIST, "BasicHist", {{"BasicHistCachedInfo", T_CACHED}});
     S.def_struct(T_CACHED, "BasicHistCachedInfo",
-                 {{"NumBuckets", G_INT}, {"BucketSize", G_INT}, {"Values", T_I64S}, {"PercentileMode", G_BOOL}, {"Max", G_INT},
-                  {"Min", G_INT}, {"Samples", G_INT}, {"Count", G_INT}, {"Avg", G_FLOAT}, {"Info", T_INTINFO}});
+                 {{"NumBuckets", G_INT}, {"BucketSize", G_INT}, {"Values", T_I64S}, {"Averages", T_F64S}, {"PercentileMode", G_BOOL},
+                  {"Outliers", T_I64S}, {"Underliers", T_I64S}, {"Max", G_INT}, {"Min", G_INT}, {"Samples", G_INT}, {"Count", G_INT},
+                  {"Avg", G_FLOAT}, {"Info", T_INTINFO}});
     S.def_slice(T_I64S, "[]int64", G_INT);
+    S.def_slice(T_F64S, "[]float64", G_FLOAT);
     S.def_struct(T_INTINFO, "IntInfo", {{"Min", G_INT}, {"Max", G_INT}});
 
     const size_t ng = R->group_names.size();

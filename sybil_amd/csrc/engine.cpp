@@ -90,6 +90,7 @@ static void free_query(Query *q) {
     if (q->h_total) hipHostFree(q->h_total);
     if (q->d_top) hipFree(q->d_top);
     if (q->d_top_cells) hipFree(q->d_top_cells);
+    if (q->d_out_log) hipFree(q->d_out_log);
     query_hash_free(q);
     delete q;
 }
@@ -108,6 +109,7 @@ static int scan(Query *q) {
     int rc = ensure_partials(q);
     if (rc) return rc;
     q->rs_active = false;
+    q->out_log_partial = false;
     hipStream_t st = q->ctx->stream;
     ScanPlan &P = q->plan;
     if (q->hash_mode && (rc = query_hash_reset(q))) return rc;  // (allocates the key table on first use: before the plan is copied)

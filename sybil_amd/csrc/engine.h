@@ -264,6 +264,10 @@ struct Query {
     // and all-gathered.  snapshot and finalize are then collective calls (every rank makes them).
     bool rs_active = false;
     int64_t rs_cells_per = 0, rs_cell0 = 0, rs_cell1 = 0;
+    // outlier log (plan.h): values of the outliers / underliers of queries that keep bucket arrays
+    int64_t *d_out_log = nullptr;
+    int64_t out_cap = 0;
+    bool out_log_partial = false;  // the partial tables were merged across ranks: the log only holds this rank's values
     bool scanned = false;
     sybl_run_stats stats{};
     bool never_matches = false;

@@ -96,14 +96,14 @@ __device__ __forceinline__ void hash_row(CPlan &P, const Tile<NC> &cur, const in
         }
     }
     if (ls >= 0) {
-        row_accumulate<NC, true>(P, cur, r, lsum, lmax, L, 0, (int64_t)ls, (int64_t)-1, w, overflow);
+        row_accumulate<NC, true>(P, cur, r, lsum, lmax, L, 0, (int64_t)ls, (int64_t)-1, (int64_t)key, w, overflow);
     } else {
         const int32_t g = hash_find_or_insert(P.hash_keys, (uint32_t)P.n_cells - 1u, key);
         if (g < 0) {  // more distinct keys than the table holds: reported by finalize
             full += 1;
             return;
         }
-        row_accumulate<NC, false>(P, cur, r, P.sum_out + kHeaderWords, P.max_out, (int64_t)P.n_cells, 0, (int64_t)g, (int64_t)g, w, overflow);
+        row_accumulate<NC, false>(P, cur, r, P.sum_out + kHeaderWords, P.max_out, (int64_t)P.n_cells, 0, (int64_t)g, (int64_t)g, (int64_t)key, w, overflow);
     }
 }
 

@@ -61,7 +61,7 @@ __device__ __forceinline__ void process_tile(CPlan &P, const Tile<NC> &t, int64_
         }
         // field f of cell: ((f * ncell + lcell) << rep_shift) + rep
         const int64_t cidx = ((int64_t)lcell << rs) + rep;
-        row_accumulate<NC, USE_LDS>(P, t, r, sumtab, maxtab, ncell, rs, cidx, (int64_t)cell, w, overflow);
+        row_accumulate<NC, USE_LDS>(P, t, r, sumtab, maxtab, ncell, rs, cidx, (int64_t)cell, (int64_t)cell, w, overflow);
     }
 }
 

@@ -128,6 +128,12 @@ struct ScanPlan {
     // number then plays the role of the cell.  hash_keys[slot] == kHashEmpty marks a free slot.
     int32_t hash_mode, pad_hash_;
     uint64_t *hash_keys;
+    // Outlier log (queries that keep bucket arrays and whose column bounds allow a value beyond the last bucket):
+    // every outlier / underlier is appended as (cell or composite key, aggregation, value) -- the reference remembers
+    // the values themselves (hist_basic.go:132-142) and prints them as buckets of their own (GetStrBuckets, :239-257).
+    // The cursor is header word kHdrOutLog; records beyond out_cap are only counted.
+    int64_t *out_log;
+    int64_t out_cap;
     int64_t hist_off;        // word offset of bucket arrays in the SUM section
     int64_t hist_stride;     // words per cell = sum of n_values over full-hist aggs
     int64_t hist_agg_off[kMaxAggs];
@@ -154,6 +160,8 @@ struct HistSummaryPlan {
     int64_t *mom;              // [cell * n_aggs + a][2]: sum(b * Values[b]), sum(b^2 * Values[b])
 };
 
+constexpr int kOutLogWords = 3;                  // int64 words per outlier record: cell / key, aggregation, value
+constexpr int64_t kOutLogDefaultCap = 1 << 20;   // records
 constexpr uint64_t kHashEmpty = ~(uint64_t)0;   // free slot of the group hash table (composite keys are below 2^62)
 constexpr int64_t kHashMaxSlots = (int64_t)1 << 27;
 
@@ -164,6 +172,7 @@ enum Header : int {
     kHdrPartOverflow = 2, // partitioned histograms: records that did not fit their partition buffer
     kHdrEmitStall = 3,    // partitioned histograms: a lane gave up waiting for a staging chunk (must be 0: a bug)
     kHdrHashFull = 4,     // hash group-by: rows whose key found no free slot (more distinct keys than the table holds)
+    kHdrOutLog = 5,       // outlier log: records appended (may exceed the log's capacity: the rest was dropped)
 };
 
 }  // namespace sybl

@@ -257,6 +257,8 @@ static bool fill_fast_columns(Table *t, Query *q, const std::vector<int> &slot_c
         *gen = true;
         heavy = true;
     }
+    FP.out_log = P.out_log;
+    FP.out_cap = P.out_cap;
     FP.hist_off = P.hist_off;
     FP.hist_stride = P.hist_stride;
     FP.n_cells = P.n_cells;
@@ -835,6 +837,18 @@ struct Planner {
             P.slot[s].agg_index = a;
             P.agg[a] = A;
             q->aggs.push_back(ai);
+        }
+        // outlier values are only ever shown next to bucket arrays (-json buckets, -encode-results)
+        {
+            bool any_out = false;
+            for (auto &ai : q->aggs) any_out = any_out || ai.d.f_out >= 0;
+            if (any_out && q->want_percentiles && !getenv("SYBL_NO_OUTLIER_LOG")) {
+                q->out_cap = kOutLogDefaultCap;
+                if (const char *e = getenv("SYBL_OUTLIER_LOG_CAP")) q->out_cap = std::max<int64_t>(1, atoll(e));
+                SYBL_HIP(hipMalloc((void **)&q->d_out_log, (size_t)q->out_cap * kOutLogWords * 8));
+                P.out_log = q->d_out_log;
+                P.out_cap = q->out_cap;
+            }
         }
         P.n_aggs = d->n_aggs;
         P.n_sum_fields = F;

@@ -133,6 +133,7 @@ int sybl_query_allreduce(sybl_query *q) {
     if (!ctx->comm) return fail(SYBL_E_STATE, "no communicator: call sybl_comm_init first");
     SYBL_HIP(hipSetDevice(ctx->device));
     ncclComm_t comm = (ncclComm_t)ctx->comm;
+    if (ctx->comm_nranks > 1) q->out_log_partial = true;  // (outlier VALUES stay on the rank that saw them)
     if (q->hash_mode) return query_hash_allreduce(q);
     const ScanPlan &P = q->plan;
     const bool has_max = P.n_max_fields > 0;  // (cfg 3: no extremum is tracked -- ONE collective per step)

@@ -7,6 +7,7 @@
 #include <time.h>
 
 #include <algorithm>
+#include <map>
 
 #include "result.h"
 
@@ -79,7 +80,7 @@ static std::string go_float(double f) {
     return buf;
 }
 
-static void json_agg(const Result *R, const RowStore &r, size_t a, std::string &o) {
+static void json_agg(Result *R, const RowStore &r, size_t a, std::string &o) {
     const size_t pk = (size_t)r.agg_off + a;
     const sybl_agg_out &g = R->agg_pool[pk];
     const int64_t *vals = R->val_pool[pk];
@@ -94,11 +95,13 @@ static void json_agg(const Result *R, const RowStore &r, size_t a, std::string &
         o += "\"avg\":" + go_float(g.avg);
         if (R->want_percentiles && vals) {
             // GetStrBuckets + getSparseBuckets: non-zero buckets keyed by their lower edge, sorted as strings
-            std::vector<std::pair<std::string, int64_t>> bk;
+            // -- plus one per outlier / underlier under its own value (hist_basic.go:246-254)
+            std::map<std::string, int64_t> bmap;
             for (size_t b = 0; b < (size_t)R->n_values[a]; b++)
-                if (vals[b] > 0)
-                    bk.emplace_back(std::to_string((long long)((int64_t)b * g.bucket_size + g.min)), vals[b]);
-            std::sort(bk.begin(), bk.end());
+                if (vals[b] > 0) bmap[std::to_string((long long)((int64_t)b * g.bucket_size + g.min))] += vals[b];
+            if (g.n_outlier_values < 0) R->render_refused = true;  // outliers exist but their values were not kept
+            for (int64_t k = 0; k < g.n_outlier_values; k++) bmap[std::to_string((long long)g.outlier_values[k])] += 1;
+            std::vector<std::pair<std::string, int64_t>> bk(bmap.begin(), bmap.end());
             o += ",\"buckets\":{";
             for (size_t k = 0; k < bk.size(); k++) {
                 if (k) o += ",";
@@ -119,7 +122,7 @@ static void json_agg(const Result *R, const RowStore &r, size_t a, std::string &
     o += "}";
 }
 
-static void json_row(const Result *R, const RowStore &r, std::string &o) {
+static void json_row(Result *R, const RowStore &r, std::string &o) {
     // ResultJSON is a map: keys are emitted sorted
     std::vector<std::pair<std::string, std::string>> kv;
     for (size_t a = 0; a < R->agg_names.size(); a++) {
@@ -208,6 +211,7 @@ const char *sybl_result_render(sybl_result *r, int format) {
     }
     std::string &o = R->rendered[format];
     o.clear();
+    R->render_refused = false;
     size_t lim = R->rows[0].size();
     if (R->limit > 0 && (size_t)R->limit < lim) lim = (size_t)R->limit;
     if (R->time_mode) {
@@ -308,6 +312,10 @@ const char *sybl_result_render(sybl_result *r, int format) {
                 o += "\n";
             }
         }
+        if (R->render_refused) {
+            set_error("rows with outliers cannot be printed as -json: their values were not kept (outlier log overflow, or a result merged across ranks)");
+            return nullptr;
+        }
         return o.c_str();
     }
     if (format == 1) {
@@ -321,6 +329,10 @@ const char *sybl_result_render(sybl_result *r, int format) {
         // printSortedResults / printResults: the cumulative row first when there is more than one group
         if (lim > 1 && !R->rows[2].empty()) text_row(R, R->rows[2][0], o);
         for (size_t i = 0; i < lim; i++) text_row(R, R->rows[0][i], o);
+    }
+    if (R->render_refused) {
+        set_error("rows with outliers cannot be printed as -json: their values were not kept (outlier log overflow, or a result merged across ranks)");
+        return nullptr;
     }
     return o.c_str();
 }

@@ -705,6 +705,47 @@ int query_finalize(Query *q, Result **out) {
         finish_row(q, R, total, row);
     }
 
+    // ---- outlier values (plan.h: outlier log) -> the rows that own them
+    {
+        const bool logged = q->d_out_log != nullptr;
+        const int64_t n_log = logged ? hs[kHdrOutLog] : 0;
+        const bool usable = logged && !q->out_log_partial && n_log <= q->out_cap;
+        for (size_t k = 0; k < R->agg_pool.size(); k++) {
+            R->agg_pool[k].outlier_values = nullptr;
+            R->agg_pool[k].n_outlier_values = (R->agg_pool[k].n_outliers > 0 && q->want_percentiles && !usable) ? -1 : 0;
+        }
+        R->outlier_vals.clear();
+        if (usable && n_log > 0) {
+            std::vector<int64_t> log((size_t)n_log * kOutLogWords);
+            SYBL_HIP(hipMemcpy(log.data(), q->d_out_log, log.size() * 8, hipMemcpyDeviceToHost));
+            // (pool slot of the row's aggregation, value), sorted: slots ascending, values ascending inside a slot
+            std::vector<std::pair<int64_t, int64_t>> recs;
+            recs.reserve((size_t)n_log);
+            for (int64_t i = 0; i < n_log; i++) {
+                int64_t cell = log[(size_t)i * kOutLogWords];
+                const int64_t a = log[(size_t)i * kOutLogWords + 1];
+                if (hashed) {  // the log names the group by its composite key
+                    auto it = std::lower_bound(q->h_dense_keys.begin(), q->h_dense_keys.begin() + ncell, (uint64_t)cell);
+                    if (it == q->h_dense_keys.begin() + ncell || *it != (uint64_t)cell) continue;
+                    cell = (int64_t)(it - q->h_dense_keys.begin());
+                }
+                auto lv = std::lower_bound(live.begin(), live.end(), cell);
+                if (lv == live.end() || *lv != cell || a < 0 || a >= (int64_t)na) continue;
+                recs.emplace_back((int64_t)((size_t)(lv - live.begin()) * na + (size_t)a), log[(size_t)i * kOutLogWords + 2]);
+            }
+            std::sort(recs.begin(), recs.end());
+            R->outlier_vals.resize(recs.size());
+            for (size_t i = 0; i < recs.size(); i++) R->outlier_vals[i] = recs[i].second;
+            for (size_t i = 0; i < recs.size();) {
+                size_t j = i;
+                while (j < recs.size() && recs[j].first == recs[i].first) j++;
+                sybl_agg_out &o = R->agg_pool[(size_t)recs[i].first];  // (cell rows own the first live.size() * na pool slots)
+                o.outlier_values = R->outlier_vals.data() + i;
+                o.n_outlier_values = (int64_t)(j - i);
+                i = j;
+            }
+        }
+    }
     trace.mark("alltime+total");
     // SortResults, aggregate.go:497-525 (stable over the canonical key order)
     if (!q->order_by.empty()) {

@@ -87,6 +87,7 @@ struct Result : ResultStore {
                                                   // arrays of the rows point into
     std::vector<std::vector<int64_t>> total_vals; // Cumulative bucket arrays
     std::vector<int64_t> top_vals;                // bucket arrays of the first `limit` rows (GPU summary path)
+    std::vector<int64_t> outlier_vals;            // the outliers' values, grouped by (row, aggregation): sybl_agg_out::outlier_values
     // (ResultStore) pct_pool: 100 entries per (row, agg) with percentiles; agg_pool / val_pool /
     // pctoff_pool: n_aggs entries per row, all row kinds (pctoff: offset into pct_pool, -1 = none)
     // for rendering
@@ -98,6 +99,7 @@ struct Result : ResultStore {
     std::string order_by;
     std::vector<std::string> group_names, agg_names;
     std::string rendered[2];
+    bool render_refused = false;  // a printed row has outliers whose values are not available
     // -encode-results
     std::vector<std::pair<int64_t, int64_t>> agg_info;  // Info.Min / Info.Max per aggregation
     int64_t time_bucket = 0;

@@ -80,6 +80,8 @@ struct FastPlan {
     uint32_t alo[kFastMaxA], ahi[kFastMaxA];
     int32_t nul, pad4_;
     const int32_t *wg_cell_base;
+    int64_t *out_log;   // outlier log (plan.h), nullptr = not kept
+    int64_t out_cap;
     int64_t *sum_out, *max_out, *ws_sum, *ws_max;
     const Segment *segs;
     const int32_t *wg_seg_begin;
@@ -381,6 +383,14 @@ __device__ __forceinline__ void fast_row(const FastPlan &P, const FastTile<NF> &
                         lds_add64(lds, fi + 3 * step, (int64_t)(uint64_t)((sq >> 32) & 0xFFFFFFFFu));
                         lds_add64(lds, fi + 4 * step, (int64_t)(uint64_t)((sq >> 64) & 0xFFFFFFFFu));
                         lds_add64(lds, fi + 5 * step, (int64_t)(uint64_t)(sq >> 96));
+                        if (P.out_log) {
+                            const int64_t i = __hip_atomic_fetch_add(P.sum_out + kHdrOutLog, (int64_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (i < P.out_cap) {
+                                P.out_log[i * kOutLogWords] = (int64_t)cell;
+                                P.out_log[i * kOutLogWords + 1] = c;
+                                P.out_log[i * kOutLogWords + 2] = x;
+                            }
+                        }
                     } else {
                         overflow += 1;
                     }

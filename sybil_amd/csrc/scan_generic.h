@@ -78,6 +78,16 @@ __device__ __forceinline__ void gadd(int64_t *p, int64_t v) {
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// one record of the outlier log (plan.h)
+__device__ __forceinline__ void log_outlier(int64_t *header, int64_t *log, int64_t cap, int64_t where, int agg, int64_t value) {
+    const int64_t i = __hip_atomic_fetch_add(header + kHdrOutLog, (int64_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (i < cap) {
+        log[i * kOutLogWords] = where;
+        log[i * kOutLogWords + 1] = agg;
+        log[i * kOutLogWords + 2] = value;
+    }
+}
+
 __device__ __forceinline__ int64_t wave_sum(int64_t v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -265,9 +275,10 @@ __device__ __forceinline__ int row_prepare(CPlan &P, const Tile<NC> &t, int r, i
 // Count / Samples and the aggregations of one matched row (aggregate.go:202-261, hist_basic.go:101-151) into the cell
 // table `sumtab` / `maxtab` laid out [field][ncell << rs]; cidx = (local cell << rs) + lane replica.  gcell is the
 // cell's number in the global table: the bucket arrays of full-histogram aggregations live there ([gcell][hist_stride]).
+// logkey: what the outlier log calls the group (the cell number; the composite key under hash group-by).
 template <int NC, bool USE_LDS>
 __device__ __forceinline__ void row_accumulate(CPlan &P, const Tile<NC> &t, int r, int64_t *sumtab, int64_t *maxtab, int64_t ncell,
-                                               int rs, int64_t cidx, int64_t gcell, int64_t w, int64_t &overflow) {
+                                               int rs, int64_t cidx, int64_t gcell, int64_t logkey, int64_t w, int64_t &overflow) {
     acc_add<USE_LDS>(sumtab, cidx, w);  // Result.Count += weight (aggregate.go:203)
     if (P.f_samples >= 0) acc_add<USE_LDS>(sumtab, ((int64_t)P.f_samples * ncell << rs) + cidx, 1);
 #pragma unroll
@@ -303,6 +314,7 @@ __device__ __forceinline__ void row_accumulate(CPlan &P, const Tile<NC> &t, int 
                     acc_add<USE_LDS>(sumtab, fi + 3 * step, (int64_t)(uint64_t)((sq >> 32) & 0xFFFFFFFFu));
                     acc_add<USE_LDS>(sumtab, fi + 4 * step, (int64_t)(uint64_t)((sq >> 64) & 0xFFFFFFFFu));
                     acc_add<USE_LDS>(sumtab, fi + 5 * step, (int64_t)(uint64_t)(sq >> 96));
+                    if (P.out_log) log_outlier(P.sum_out, P.out_log, P.out_cap, logkey, s.agg_index, x);
                 } else {
                     overflow += 1;  // declared bounds violated; reported by finalize
                 }

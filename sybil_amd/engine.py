@@ -419,7 +419,9 @@ class Result:
                    "time_bucket": r.time_bucket, "count": r.count, "samples": r.samples, "hists": []}
             for a in range(self.n_aggs):
                 g = r.aggs[a]
-                h = {k: getattr(g, k) for k, _ in N.AggOut._fields_ if k not in ("values", "percentiles")}
+                h = {k: getattr(g, k) for k, _ in N.AggOut._fields_ if k not in ("values", "percentiles", "outlier_values")}
+                if g.n_outlier_values > 0:
+                    h["outlier_values"] = np.ctypeslib.as_array(g.outlier_values, shape=(g.n_outlier_values,)).copy()
                 if want_values and g.values:
                     h["values"] = np.ctypeslib.as_array(g.values, shape=(g.n_values,)).copy()
                 if g.percentiles:

@@ -41,7 +41,7 @@ def _close(a, b, rel=REL, scale=0.0):
     return abs(a - b) <= rel * max(abs(a), abs(b), scale)
 
 
-def compare_hist(g, o, op, full, ctx=""):
+def compare_hist(g, o, op, full, ctx="", cumulative=False):
     assert bool(g["present"]) == bool(o["present"]), ctx
     if not o["present"]:
         return
@@ -69,6 +69,9 @@ def compare_hist(g, o, op, full, ctx=""):
             assert np.array_equal(g["values"], o["values"]), ctx
             # GetPercentiles returns an empty slice while Count == 0 (hist_basic.go:154-156)
             assert np.array_equal(g.get("percentiles", np.zeros(0, dtype=np.int64)), o["percentiles"]), ctx
+            # the outliers' values (every block's, where the reference keeps one block's: hist_basic.go:259-279)
+            if g["n_outlier_values"] >= 0 and not cumulative:
+                assert np.array_equal(g.get("outlier_values", np.zeros(0, dtype=np.int64)), o["outlier_values"]), ctx
     else:
         assert g["stddev"] == 0.0, ctx
 
@@ -93,7 +96,7 @@ def compare(gres, ores, op="avg", full=True, n_aggs=0, time_mode=False):
     assert gc["count"] == oc["count"] and gc["samples"] == oc["samples"]
     if not time_mode:
         for a in range(n_aggs):
-            compare_hist(gc["hists"][a], oc["hists"][a], op, full, ctx=("cumulative", a))
+            compare_hist(gc["hists"][a], oc["hists"][a], op, full, ctx=("cumulative", a), cumulative=True)
 
 
 def run_both(ctx, orc, names, total_rows, row0, nrows, q, block_rows=65536, oracle_threads=4, compact=False):

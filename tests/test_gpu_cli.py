@@ -219,6 +219,9 @@ def test_encode_results_is_a_gob_node_results():
             if q["op"] == "hist":
                 assert ci["PercentileMode"] is True and ci["BucketSize"] == h["bucket_size"] and ci["NumBuckets"] == h["num_buckets"]
                 assert ci["Values"] == h["values"].tolist()
+                # values beyond the last bucket (30 + 1002 * 23 = 23076 and up) are remembered as Outliers (hist_basic.go:132-135)
+                assert ci.get("Outliers", []) == h.get("outlier_values", np.zeros(0)).tolist() and "Underliers" not in ci
+                assert len(ci.get("Outliers", [])) == (h["n_outliers"] if enc is not res["Cumulative"] else 0)
             else:
                 assert "Values" not in ci
 

@@ -719,3 +719,68 @@ def test_many_groups_with_limit_fetches_only_printed_bucket_arrays(ctx, oracle):
     assert avgs == sorted(avgs) and len(avgs) == len(ores["results"])
     assert sorted(r["key"] for r in gres.results) == sorted(r["key"] for r in ores["results"])
     gres.free()
+
+
+def test_outlier_values_are_kept_and_printed(ctx, oracle, monkeypatch):
+    """-hist-bucket leaves NumBuckets at 1000, so values beyond Min + 1001 * bucket are Outliers: clipped into the last
+    bucket AND remembered (hist_basic.go:132-142).  GetStrBuckets prints each under its own value (:239-257) and the gob
+    HistCompat carries the list.  The engine keeps every block's outliers (the reference: one block's, Combine does
+    not merge them)."""
+    import json
+    import sybil_amd
+    rng = np.random.default_rng(77)
+    n = 150_000
+    g = rng.integers(0, 5, size=n).astype(np.int64)
+    v = rng.integers(0, 4000, size=n).astype(np.int64)
+    v[rng.random(n) < 0.01] += 50_000  # far outliers
+    cols = [{"type": "int", "data": g}, {"type": "int", "data": v}]
+    for compact, generic in ((False, False), (True, False), (False, True)):
+        if generic:
+            monkeypatch.setenv("SYBL_NO_FAST", "1")  # the plan-interpreting kernel instead of the role-specialised one
+        tb = ctx.create_table("o")
+        tb.add_column("g", "int")
+        tb.add_column("v", "int", 0, 60_000)
+        for r0 in range(0, n, 40_000):
+            tb.append_block(min(40_000, n - r0), {"g": g[r0:r0 + 40_000], "v": v[r0:r0 + 40_000]})
+        if compact:
+            tb.compact()
+        q = dict(groups=["g"], aggs=["v"], op="hist", hist_bucket=3, want_percentiles=True)
+        query = tb.query(**q)
+        gres = query.run()
+        ores = oracle.run_query(cols, groups=[0], aggs=[(1, 0, 60_000)], op="hist", hist_bucket=3, block_rows=40_000, n_threads=2)
+        parity.compare(gres, ores, op="hist", full=True, n_aggs=1)  # includes the outlier values
+        rows = {r["key_vals"][0]: r for r in gres.results}
+        assert all(r["hists"][0]["n_outliers"] > 0 and r["hists"][0]["n_outlier_values"] == r["hists"][0]["n_outliers"] for r in rows.values())
+        out = json.loads(gres.render("json"))
+        for jr in out:
+            h = rows[int(jr["g"])]["hists"][0]
+            want = {}
+            for b, c in enumerate(h["values"]):
+                if c > 0:
+                    want[str(b * 3)] = want.get(str(b * 3), 0) + int(c)
+            for x in h["outlier_values"]:
+                want[str(int(x))] = want.get(str(int(x)), 0) + 1
+            assert jr["v"]["buckets"] == want
+        from tests import gobfmt
+        enc = gobfmt.decode(gres.encode())["QuerySpec"]["QueryResults"]["Results"]
+        for key, e in enc.items():
+            ci = e["Hists"]["v"]["value"]["BasicHist"]["BasicHistCachedInfo"]
+            assert ci["Outliers"] == rows[int(key.strip())]["hists"][0]["outlier_values"].tolist()
+        gres.free()
+        query.free()
+        # a log too small for the outliers: counts and sigma stay exact, the values are reported as unavailable and the
+        # printers refuse instead of showing buckets without them
+        monkeypatch.setenv("SYBL_OUTLIER_LOG_CAP", "16")
+        query = tb.query(**q)
+        gres = query.run()
+        monkeypatch.delenv("SYBL_OUTLIER_LOG_CAP")
+        parity.compare(gres, ores, op="hist", full=True, n_aggs=1)
+        assert all(r["hists"][0]["n_outlier_values"] == -1 for r in gres.results)
+        with pytest.raises(sybil_amd.SyblError):
+            gres.render("json")
+        with pytest.raises(sybil_amd.SyblError):
+            gres.encode()
+        assert "g" not in gres.render("text")[:1]  # (the text table prints no buckets: it still renders)
+        gres.free()
+        query.free()
+        tb.free()
