@@ -267,6 +267,10 @@ typedef struct {
     int32_t order_asc;
     int32_t limit;              /* FLAGS.LIMIT; <= 0 = all groups */
     int32_t block_skip;         /* ShouldLoadBlockFromDir min/max pruning (table_block_io.go:110-182) */
+    /* FLAGS.LOG_HIST (-loghist): MultiHist instead of BasicHist (hist.go:27-38, hist_multi.go) -- with op HIST a chain
+     * of sub-histograms whose ranges halve from Info.Max downwards; percentiles and stddev come from the union of their
+     * buckets.  Bucket arrays are always kept (want_percentiles is implied); sybl_result_subhists describes them. */
+    int32_t loghist;
 } sybl_query_desc;
 
 int sybl_query_prepare(sybl_table *t, const sybl_query_desc *desc, sybl_query **out);
@@ -355,6 +359,21 @@ typedef struct {
     int64_t samples;           /* Result.Samples */
     const sybl_agg_out *aggs;  /* n_aggs entries */
 } sybl_group_row;
+
+/* -loghist results: how the `values` array of aggregation `agg` is laid out.  Sub-histogram k (Subhists[k] of the
+ * reference's MultiHist, hist_multi.go:223-257) owns values[offset .. offset + n_values): its BasicHist.Values; and
+ * values[ext_offset .. ext_offset + n_ext): one exact counter per value from ext_first upwards -- how often that value
+ * was an Outlier of the sub-histogram (beyond its last bucket: clipped into it AND remembered, hist_basic.go:132-135;
+ * counted per occurrence, not per weight).  sybl_agg_out.bucket_size / num_buckets are 0 for such rows and
+ * n_outliers is the sum of the ext counters.  The array is library-owned (valid until the result is freed); n = 0
+ * for a query without loghist. */
+typedef struct {
+    int64_t info_min, info_max;   /* the sub-histogram's Info range (inclusive) */
+    int64_t bucket_size, num_buckets, n_values;
+    int64_t offset;               /* of its Values inside sybl_agg_out.values */
+    int64_t ext_first, n_ext, ext_offset;
+} sybl_subhist;
+int sybl_result_subhists(const sybl_result *r, int agg, const sybl_subhist **subs, int64_t *n);
 
 /* which: 0 = Results (every group, sorted by order_by; the limit is applied when rendering,
  *            as printSortedResults does), 1 = TimeResults (by bucket, then key),

@@ -52,7 +52,7 @@ class _Query(C.Structure):
                 ("op", C.c_int32), ("hist_bucket", C.c_int64),
                 ("time_col", C.c_int32), ("time_bucket", C.c_int64),
                 ("weight_col", C.c_int32), ("block_skip", C.c_int32),
-                ("block_rows", C.c_int64), ("n_threads", C.c_int32)]
+                ("block_rows", C.c_int64), ("n_threads", C.c_int32), ("loghist", C.c_int32)]
 
 
 class HistInfo(C.Structure):
@@ -90,6 +90,16 @@ def lib():
         L.orc_result_hist_values.restype = C.c_int64
         L.orc_result_hist_values.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_int64]
         L.orc_result_percentiles.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p]
+        L.orc_result_n_sub.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int]
+        L.orc_result_sub.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p]
+        L.orc_result_sparse.restype = C.c_int64
+        L.orc_result_sparse.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_int64]
+        L.orc_hist_new_multi.restype = C.c_void_p
+        L.orc_hist_new_multi.argtypes = [C.c_int64, C.c_int64, C.c_int, C.c_int64, C.c_int]
+        L.orc_hist_n_sub.argtypes = [C.c_void_p]
+        L.orc_hist_sub.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_hist_sparse.restype = C.c_int64
+        L.orc_hist_sparse.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
         L.orc_result_outliers.restype = C.c_int64
         L.orc_result_outliers.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_int64]
         L.orc_setup_buckets.argtypes = [C.c_int64, C.c_int64, C.c_int64] + [C.POINTER(C.c_int64)] * 3
@@ -131,9 +141,25 @@ def _ptr(a):
 
 # ---------------------------------------------------------------- single hist (KATs)
 class Hist:
-    def __init__(self, info_min, info_max, op="avg", hist_bucket=0, weight_col=False):
-        self.h = lib().orc_hist_new(info_min, info_max, AGG_HIST if op == "hist" else AGG_AVG, hist_bucket,
-                                    1 if weight_col else 0)
+    def __init__(self, info_min, info_max, op="avg", hist_bucket=0, weight_col=False, loghist=False):
+        new = lib().orc_hist_new_multi if loghist else lib().orc_hist_new
+        self.h = new(info_min, info_max, AGG_HIST if op == "hist" else AGG_AVG, hist_bucket, 1 if weight_col else 0)
+
+    def subhists(self):
+        """-loghist: [(Info.Min, Info.Max, BucketSize, NumBuckets, len(Values), offset into values())]"""
+        out = []
+        for k in range(lib().orc_hist_n_sub(self.h)):
+            six = np.zeros(6, dtype=np.int64)
+            lib().orc_hist_sub(self.h, k, _ptr(six))
+            out.append(tuple(int(x) for x in six))
+        return out
+
+    def sparse(self):
+        """-loghist: the union of the sub-histograms' sparse buckets, {key: count}"""
+        n = lib().orc_hist_sparse(self.h, None, None, 0)
+        keys, counts = np.zeros(max(n, 1), dtype=np.int64), np.zeros(max(n, 1), dtype=np.int64)
+        lib().orc_hist_sparse(self.h, _ptr(keys), _ptr(counts), n)
+        return dict(zip(keys[:n].tolist(), counts[:n].tolist()))
 
     def add(self, v, w=1):
         lib().orc_hist_add(self.h, int(v), int(w))
@@ -339,7 +365,7 @@ def synth_scan(columns, seed, total_rows, row0, nrows, filters=(), groups=(), ag
 
 # ---------------------------------------------------------------- full query
 def run_query(cols, filters=(), groups=(), aggs=(), op="avg", hist_bucket=0, time_col=-1, time_bucket=0,
-              weight_col=-1, block_skip=False, block_rows=65536, n_threads=1, want_values=True):
+              weight_col=-1, block_skip=False, block_rows=65536, n_threads=1, want_values=True, loghist=False):
     """cols: list of dicts {type: 'int'|'str'|'set', data, populated(optional), offsets(set)}
     filters: list of (col_index, op_name, value[, idtable]); groups: col indices;
     aggs: list of (col_index, info_min, info_max).
@@ -402,6 +428,7 @@ def run_query(cols, filters=(), groups=(), aggs=(), op="avg", hist_bucket=0, tim
     q.block_skip = 1 if block_skip else 0
     q.block_rows = block_rows
     q.n_threads = n_threads
+    q.loghist = 1 if loghist else 0
 
     R = L.orc_query_run(C.byref(q), ccols, len(cols), nrows)
     try:
@@ -433,6 +460,17 @@ def run_query(cols, filters=(), groups=(), aggs=(), op="avg", hist_bucket=0, tim
                         ov = np.zeros(max(no, 1), dtype=np.int64)
                         got = L.orc_result_outliers(R, which, idx, a, _ptr(ov), ov.size)
                         h["outlier_values"] = ov[:max(min(got, no), 0)]
+                        ns = L.orc_result_n_sub(R, which, idx, a)
+                        if ns > 0:  # -loghist
+                            h["subhists"] = []
+                            for k in range(ns):
+                                six = np.zeros(6, dtype=np.int64)
+                                L.orc_result_sub(R, which, idx, a, k, _ptr(six))
+                                h["subhists"].append(tuple(int(x) for x in six))
+                            nk = L.orc_result_sparse(R, which, idx, a, None, None, 0)
+                            keys, counts = np.zeros(max(nk, 1), dtype=np.int64), np.zeros(max(nk, 1), dtype=np.int64)
+                            L.orc_result_sparse(R, which, idx, a, _ptr(keys), _ptr(counts), nk)
+                            h["sparse"] = dict(zip(keys[:nk].tolist(), counts[:nk].tolist()))
                     r["hists"].append(h)
                 lst.append(r)
             out[name] = lst[0] if which == 2 else lst

@@ -55,6 +55,11 @@ struct orc_hist {
     uint64_t sum_exact;
     int64_t true_min, true_max;
     i64vec all_outliers, all_underliers; /* merged across blocks */
+    /* MultiHist (hist_multi.go:6-19): the fields above are its Max / Min / Samples / Count / Avg / Info; values,
+     * buckets and outliers live in the sub-histograms */
+    int multi;
+    int n_sub;
+    struct orc_hist **sub;
 };
 
 /* hist_basic.go:34-70 SetupBuckets */
@@ -101,8 +106,151 @@ orc_hist *orc_hist_new(int64_t info_min, int64_t info_max, int op, int64_t hist_
     return h;
 }
 
+/* hist_multi.go:23-38 newMultiHist + :223-257 TrackPercentiles */
+orc_hist *orc_hist_new_multi(int64_t info_min, int64_t info_max, int op, int64_t hist_bucket, int weight_mode) {
+    orc_hist *h = (orc_hist *)calloc(1, sizeof(*h));
+    h->multi = 1;
+    h->info_min = info_min;
+    h->info_max = info_max;
+    h->op = op;
+    h->hist_bucket = hist_bucket;
+    h->weight_mode = weight_mode;
+    h->true_min = INT64_MAX;
+    h->true_max = INT64_MIN;
+    h->min = info_min; /* :31-32, in avg mode too (unlike BasicHist) */
+    h->max = info_max;
+    if (op == ORC_AGG_HIST) {
+        h->percentile_mode = 1;
+        int64_t bucket_size = h->max - h->min;
+        int num_hists = 0;
+        /* 1:1 buckets for the smallest range, then logarithmically wider ones (HIST_FACTOR_POW = 1) */
+        for (int64_t t = bucket_size; t > NUM_BUCKETS; t >>= 1) num_hists++;
+        h->n_sub = num_hists + 1;
+        h->sub = (orc_hist **)calloc((size_t)h->n_sub, sizeof(orc_hist *));
+        int64_t right_edge = h->max;
+        for (int i = 0; i < num_hists; i++) {
+            bucket_size >>= 1;
+            const int64_t smin = right_edge - bucket_size, smax = right_edge;
+            right_edge = smin;
+            h->sub[i] = orc_hist_new(smin, smax, ORC_AGG_HIST, hist_bucket, weight_mode);
+        }
+        /* the smallest hist at the end: h.Min -> the last bucket's left edge */
+        h->sub[num_hists] = orc_hist_new(h->min, right_edge, ORC_AGG_HIST, hist_bucket, weight_mode);
+    }
+    return h;
+}
+
+int orc_hist_n_sub(const orc_hist *h) { return h->multi ? h->n_sub : 0; }
+
+int orc_hist_sub(const orc_hist *h, int k, int64_t *out6) {
+    if (!h->multi || k < 0 || k >= h->n_sub) return -1;
+    int64_t off = 0;
+    for (int i = 0; i < k; i++) off += h->sub[i]->n_values;
+    const orc_hist *s = h->sub[k];
+    out6[0] = s->info_min;
+    out6[1] = s->info_max;
+    out6[2] = s->bucket_size;
+    out6[3] = s->num_buckets;
+    out6[4] = s->n_values;
+    out6[5] = off;
+    return 0;
+}
+
+typedef struct {
+    int64_t key, count;
+} kc_pair;
+static int cmp_kc(const void *a, const void *b) {
+    const int64_t x = ((const kc_pair *)a)->key, y = ((const kc_pair *)b)->key;
+    return x < y ? -1 : x > y;
+}
+
+/* MultiHist.GetSparseBuckets, hist_multi.go:190-207, over BasicHist.GetSparseBuckets (hist_basic.go:221-237): non-zero
+ * buckets keyed by their lower edge, every outlier / underlier (of every block: the exact variant) +1 under its own
+ * value, equal keys of different sub-histograms added up.  Sorted by key; the caller frees *out. */
+static int64_t multi_sparse(const orc_hist *h, kc_pair **out) {
+    int64_t cap = 0;
+    for (int i = 0; i < h->n_sub; i++) cap += h->sub[i]->n_values + h->sub[i]->all_outliers.n + h->sub[i]->all_underliers.n;
+    kc_pair *v = (kc_pair *)malloc(sizeof(kc_pair) * (size_t)(cap ? cap : 1));
+    int64_t n = 0;
+    for (int i = 0; i < h->n_sub; i++) {
+        const orc_hist *s = h->sub[i];
+        for (int64_t k = 0; k < s->n_values; k++)
+            if (s->values[k] > 0) {
+                v[n].key = k * s->bucket_size + s->min;
+                v[n++].count = s->values[k];
+            }
+        for (int64_t j = 0; j < s->all_outliers.n; j++) {
+            v[n].key = s->all_outliers.v[j];
+            v[n++].count = 1;
+        }
+        for (int64_t j = 0; j < s->all_underliers.n; j++) {
+            v[n].key = s->all_underliers.v[j];
+            v[n++].count = 1;
+        }
+    }
+    qsort(v, (size_t)n, sizeof(kc_pair), cmp_kc);
+    int64_t m = 0;
+    for (int64_t i = 0; i < n; i++) {
+        if (m > 0 && v[m - 1].key == v[i].key) v[m - 1].count += v[i].count;
+        else v[m++] = v[i];
+    }
+    *out = v;
+    return m;
+}
+
+int64_t orc_hist_sparse(const orc_hist *h, int64_t *keys, int64_t *counts, int64_t cap) {
+    if (!h->multi) return -1;
+    kc_pair *v;
+    const int64_t n = multi_sparse(h, &v);
+    for (int64_t i = 0; i < n && i < cap; i++) {
+        keys[i] = v[i].key;
+        counts[i] = v[i].count;
+    }
+    free(v);
+    return n;
+}
+
+/* MultiHist.GetPercentiles, hist_multi.go:93-128, literally -- over the sorted keys of the union */
+static int multi_percentiles(const orc_hist *h, int64_t *out100) {
+    if (h->count == 0) return 0;
+    kc_pair *v;
+    const int64_t n = multi_sparse(h, &v);
+    int64_t total = 0;
+    for (int64_t i = 0; i < n; i++) total += v[i].count;
+    int64_t pct[101];
+    memset(pct, 0, sizeof(pct));
+    int64_t prev_p = 0, count = 0;
+    for (int64_t i = 0; i < n && total > 0; i++) {
+        count += v[i].count;
+        const int64_t p = (100 * count) / total;
+        for (int64_t ip = prev_p; ip <= p; ip++)
+            if (ip <= 100) pct[ip] = v[i].key;
+        if (p <= 100) pct[p] = v[i].key;
+        prev_p = p;
+    }
+    free(v);
+    memcpy(out100, pct, 100 * sizeof(int64_t));
+    return 100;
+}
+
+/* MultiHist.GetStdDev, hist_multi.go:140-155: sqrt(sum over the union's keys of (key - Avg)^2 * count / Count) */
+static double multi_stddev(const orc_hist *h, double avg) {
+    kc_pair *v;
+    const int64_t n = multi_sparse(h, &v);
+    double sum_variance = 0;
+    for (int64_t i = 0; i < n; i++) {
+        const double delta = (double)v[i].key - avg;
+        const double ratio = (double)v[i].count / (double)h->count;
+        sum_variance += (delta * delta) * ratio;
+    }
+    free(v);
+    return sqrt(sum_variance);
+}
+
 void orc_hist_free(orc_hist *h) {
     if (!h) return;
+    for (int i = 0; i < h->n_sub; i++) orc_hist_free(h->sub[i]);
+    free(h->sub);
     free(h->values);
     free(h->averages);
     free(h->outliers.v);
@@ -139,6 +287,17 @@ void orc_hist_add(orc_hist *h, int64_t value, int64_t weight) {
 
     if (!h->percentile_mode) return;
 
+    if (h->multi) {
+        /* hist_multi.go:84-89: the first sub-histogram whose range holds the value takes it -- through ITS
+         * AddWeightedValue, reject gate (Info.Max*10 of the sub-range: negative maxima reject) included */
+        for (int i = 0; i < h->n_sub; i++)
+            if (value >= h->sub[i]->info_min && value <= h->sub[i]->info_max) {
+                orc_hist_add(h->sub[i], value, weight);
+                break;
+            }
+        return;
+    }
+
     int64_t b = (value - h->min) / h->bucket_size; /* :130, truncating */
     if (b >= h->n_values) {
         vec_push(&h->outliers, value);
@@ -162,6 +321,8 @@ double orc_combine_avg(double avg_a, int64_t count_a, double avg_b, int64_t coun
 
 /* hist_basic.go:259-279 Combine.  Averages/Outliers/Underliers are NOT merged there. */
 void orc_hist_combine(orc_hist *h, const orc_hist *o) {
+    if (h->multi) /* hist_multi.go:209-212: the sub-histograms pairwise, then the outer fields like BasicHist */
+        for (int i = 0; i < h->n_sub && i < o->n_sub; i++) orc_hist_combine(h->sub[i], o->sub[i]);
     for (int64_t k = 0; k < o->n_values && k < h->n_values; k++) h->values[k] += o->values[k];
     int64_t total = h->count + o->count;
     h->avg = orc_combine_avg(h->avg, h->count, o->avg, o->count);
@@ -242,6 +403,20 @@ void orc_hist_info_get(const orc_hist *h, orc_hist_info *out) {
     out->true_max = h->true_max;
     out->n_outliers = h->all_outliers.n;
     out->n_underliers = h->all_underliers.n;
+    if (h->multi) {
+        out->num_buckets = 0;
+        out->bucket_size = 0;
+        out->n_values = 0;
+        for (int i = 0; i < h->n_sub; i++) {
+            out->n_values += h->sub[i]->n_values;
+            out->n_outliers += h->sub[i]->all_outliers.n;
+            out->n_underliers += h->sub[i]->all_underliers.n;
+        }
+        const double avg_exact = h->count ? (double)((long double)(int64_t)h->sum_exact / (long double)h->count) : 0.0;
+        out->stddev_ref = h->percentile_mode ? multi_stddev(h, h->avg) : 0.0;
+        out->stddev_exact = h->percentile_mode ? multi_stddev(h, avg_exact) : 0.0;
+        return;
+    }
     out->stddev_ref = orc_stddev_from_values(h->values, h->n_values, h->bucket_size, h->min, h->count, h->avg,
                                              h->outliers.v, h->outliers.n, h->underliers.v, h->underliers.n);
     {
@@ -253,12 +428,24 @@ void orc_hist_info_get(const orc_hist *h, orc_hist_info *out) {
 }
 
 int64_t orc_hist_values(const orc_hist *h, int64_t *out, int64_t cap) {
+    if (h->multi) { /* the sub-histograms' Values, Subhists[0] first */
+        int64_t n = 0;
+        for (int i = 0; i < h->n_sub; i++) n += h->sub[i]->n_values;
+        if (cap < n) return -1;
+        n = 0;
+        for (int i = 0; i < h->n_sub; i++) {
+            memcpy(out + n, h->sub[i]->values, (size_t)h->sub[i]->n_values * sizeof(int64_t));
+            n += h->sub[i]->n_values;
+        }
+        return n;
+    }
     if (cap < h->n_values) return -1;
     memcpy(out, h->values, (size_t)h->n_values * sizeof(int64_t));
     return h->n_values;
 }
 
 int orc_hist_percentiles(const orc_hist *h, int64_t *out100) {
+    if (h->multi) return multi_percentiles(h, out100);
     return orc_percentiles_from_values(h->values, h->n_values, h->bucket_size, h->min, h->count, out100);
 }
 
@@ -379,7 +566,8 @@ static void result_combine(orc_result *rs, const orc_result *next, const orc_que
         if (!h) continue;
         if (!rs->hists[a]) {
             /* nh := h.NewHist(); nh.Combine(h) */
-            rs->hists[a] = orc_hist_new(h->info_min, h->info_max, h->op, h->hist_bucket, h->weight_mode);
+            rs->hists[a] = h->multi ? orc_hist_new_multi(h->info_min, h->info_max, h->op, h->hist_bucket, h->weight_mode)
+                                    : orc_hist_new(h->info_min, h->info_max, h->op, h->hist_bucket, h->weight_mode);
         }
         orc_hist_combine(rs->hists[a], h);
     }
@@ -550,7 +738,8 @@ static void scan_block(const orc_query *q, const orc_col *cols, int64_t row0, in
             const orc_col *c = &cols[q->aggs[a].col];
             if (c->type != ORC_INT_VAL || !col_populated(c, i)) continue;
             if (!r->hists[a])
-                r->hists[a] = orc_hist_new(q->aggs[a].info_min, q->aggs[a].info_max, q->op, q->hist_bucket, weight_mode);
+                r->hists[a] = q->loghist ? orc_hist_new_multi(q->aggs[a].info_min, q->aggs[a].info_max, q->op, q->hist_bucket, weight_mode)
+                                         : orc_hist_new(q->aggs[a].info_min, q->aggs[a].info_max, q->op, q->hist_bucket, weight_mode);
             orc_hist_add(r->hists[a], c->ints[i], weight);
         }
     }
@@ -763,12 +952,35 @@ int64_t orc_result_outliers(const orc_results *R, int which, int64_t idx, int ag
     const orc_result *r = get_result(R, which, idx);
     if (!r || agg < 0 || agg >= R->q.n_aggs || !r->hists[agg]) return -1;
     const orc_hist *h = r->hists[agg];
-    const int64_t n = h->all_outliers.n + h->all_underliers.n;
+    int64_t n = h->all_outliers.n + h->all_underliers.n;
+    for (int i = 0; i < h->n_sub; i++) n += h->sub[i]->all_outliers.n + h->sub[i]->all_underliers.n;
     if (cap < n) return n;
-    if (h->all_outliers.n) memcpy(out, h->all_outliers.v, (size_t)h->all_outliers.n * sizeof(int64_t));
-    if (h->all_underliers.n) memcpy(out + h->all_outliers.n, h->all_underliers.v, (size_t)h->all_underliers.n * sizeof(int64_t));
+    int64_t at = 0;
+    for (int i = -1; i < h->n_sub; i++) {
+        const orc_hist *s = i < 0 ? h : h->sub[i];
+        if (s->all_outliers.n) memcpy(out + at, s->all_outliers.v, (size_t)s->all_outliers.n * sizeof(int64_t));
+        at += s->all_outliers.n;
+        if (s->all_underliers.n) memcpy(out + at, s->all_underliers.v, (size_t)s->all_underliers.n * sizeof(int64_t));
+        at += s->all_underliers.n;
+    }
     qsort(out, (size_t)n, sizeof(int64_t), cmp_i64);
     return n;
+}
+
+int orc_result_n_sub(const orc_results *R, int which, int64_t idx, int agg) {
+    const orc_result *r = get_result(R, which, idx);
+    if (!r || agg < 0 || agg >= R->q.n_aggs || !r->hists[agg]) return -1;
+    return orc_hist_n_sub(r->hists[agg]);
+}
+int orc_result_sub(const orc_results *R, int which, int64_t idx, int agg, int k, int64_t *out6) {
+    const orc_result *r = get_result(R, which, idx);
+    if (!r || agg < 0 || agg >= R->q.n_aggs || !r->hists[agg]) return -1;
+    return orc_hist_sub(r->hists[agg], k, out6);
+}
+int64_t orc_result_sparse(const orc_results *R, int which, int64_t idx, int agg, int64_t *keys, int64_t *counts, int64_t cap) {
+    const orc_result *r = get_result(R, which, idx);
+    if (!r || agg < 0 || agg >= R->q.n_aggs || !r->hists[agg]) return -1;
+    return orc_hist_sparse(r->hists[agg], keys, counts, cap);
 }
 
 int orc_result_percentiles(const orc_results *R, int which, int64_t idx, int agg, int64_t *out100) {

@@ -95,6 +95,7 @@ typedef struct {
     int32_t block_skip;  /* apply ShouldLoadBlockFromDir using exact per-block min/max */
     int64_t block_rows;  /* CHUNK_SIZE, 65536 in production (table.go:44) */
     int32_t n_threads;   /* blocks scanned in parallel; merge is always in block order */
+    int32_t loghist;     /* FLAGS.LOG_HIST: MultiHist instead of BasicHist (hist.go:27-38, hist_multi.go) */
 } orc_query;
 
 /* One merged Result (query_spec.go:85-93) + its hists, both arithmetic modes. */
@@ -168,8 +169,28 @@ void orc_hist_info_get(const orc_hist *h, orc_hist_info *out);
 int64_t orc_hist_values(const orc_hist *h, int64_t *out, int64_t cap);
 int orc_hist_percentiles(const orc_hist *h, int64_t *out100);
 int64_t orc_hist_outliers(const orc_hist *h, int64_t *out, int64_t cap);
+
+/* -loghist: MultiHist (hist_multi.go): an outer Count / Avg / Min / Max behind the same Info.Min .. Info.Max*10 gate and,
+ * in hist mode, a chain of BasicHist sub-histograms whose ranges halve from Info.Max downwards (TrackPercentiles,
+ * :223-257); a value goes to the FIRST sub-histogram whose [Info.Min, Info.Max] holds it (:84-89).  An orc_hist made
+ * by orc_hist_new_multi answers orc_hist_add / orc_hist_combine / orc_hist_info_get like any other; its percentiles
+ * and standard deviation are GetPercentiles (:93-128) and GetStdDev (:140-155) over the union of the sub-histograms'
+ * sparse buckets -- "exact" variant: every block's outliers, mean = exact sum / count, keys summed in ascending
+ * order (the reference keeps one block's outlier lists and sums in map order). */
+orc_hist *orc_hist_new_multi(int64_t info_min, int64_t info_max, int op, int64_t hist_bucket, int weight_mode);
+int orc_hist_n_sub(const orc_hist *h);
+/* sub-histogram k: out6 = {Info.Min, Info.Max, BucketSize, NumBuckets, len(Values), offset of its Values in the
+ * concatenated array orc_hist_values returns} */
+int orc_hist_sub(const orc_hist *h, int k, int64_t *out6);
+/* the union of the sub-histograms' sparse buckets (GetSparseBuckets, :190-207), keys ascending; returns the number of
+ * keys (nothing written beyond cap) */
+int64_t orc_hist_sparse(const orc_hist *h, int64_t *keys, int64_t *counts, int64_t cap);
 /* all outliers + underliers of a result's hist over every block, ascending; returns the count (nothing written if > cap) */
 int64_t orc_result_outliers(const orc_results *R, int which, int64_t idx, int agg, int64_t *out, int64_t cap);
+/* -loghist results: see orc_hist_n_sub / orc_hist_sub / orc_hist_sparse */
+int orc_result_n_sub(const orc_results *R, int which, int64_t idx, int agg);
+int orc_result_sub(const orc_results *R, int which, int64_t idx, int agg, int k, int64_t *out6);
+int64_t orc_result_sparse(const orc_results *R, int which, int64_t idx, int agg, int64_t *keys, int64_t *counts, int64_t cap);
 void orc_hist_free(orc_hist *h);
 
 /* ---- synthetic table generator (OURS, not the reference's; DESIGN.md "Synthetic table") ---- */

@@ -47,7 +47,7 @@ class QueryDesc(C.Structure):
                 ("op", C.c_int32), ("hist_bucket", C.c_int64), ("want_percentiles", C.c_int32),
                 ("time_col", C.c_char_p), ("time_bucket", C.c_int64), ("weight_col", C.c_char_p),
                 ("order_by", C.c_char_p), ("order_asc", C.c_int32), ("limit", C.c_int32),
-                ("block_skip", C.c_int32)]
+                ("block_skip", C.c_int32), ("loghist", C.c_int32)]
 
 
 class AggOut(C.Structure):
@@ -56,6 +56,12 @@ class AggOut(C.Structure):
                 ("bucket_size", C.c_int64), ("num_buckets", C.c_int64), ("n_values", C.c_int64),
                 ("values", C.POINTER(C.c_int64)), ("percentiles", C.POINTER(C.c_int64)),
                 ("n_outliers", C.c_int64), ("outlier_values", C.POINTER(C.c_int64)), ("n_outlier_values", C.c_int64)]
+
+
+class SubHist(C.Structure):
+    _fields_ = [("info_min", C.c_int64), ("info_max", C.c_int64), ("bucket_size", C.c_int64), ("num_buckets", C.c_int64),
+                ("n_values", C.c_int64), ("offset", C.c_int64), ("ext_first", C.c_int64), ("n_ext", C.c_int64),
+                ("ext_offset", C.c_int64)]
 
 
 class GroupRow(C.Structure):
@@ -139,6 +145,7 @@ SIGNATURES = {
     "sybl_query_collective_finalize": (C.c_int, [P]),
     "sybl_result_rows": (C.c_int, [P, C.c_int, C.POINTER(C.POINTER(GroupRow)), C.POINTER(C.c_int64)]),
     "sybl_result_matched": (C.c_int64, [P]),
+    "sybl_result_subhists": (C.c_int, [P, C.c_int, C.POINTER(C.POINTER(SubHist)), C.POINTER(C.c_int64)]),
     "sybl_result_free": (None, [P]),
     "sybl_query_stats": (C.c_int, [P, C.POINTER(RunStats)]),
     "sybl_debug_query_cells": (C.c_int, [P, C.c_int, C.c_int, P, C.c_int64, C.POINTER(C.c_int64)]),

@@ -194,6 +194,10 @@ const void *sybl_result_encode(sybl_result *r, int64_t *n_bytes) {
         set_error("sybl_result_encode: NULL argument");
         return nullptr;
     }
+    if (R->loghist) {
+        set_error("-encode-results of a -loghist result (MultiHistCompat) is not implemented");
+        return nullptr;
+    }
     for (auto &o : R->agg_pool)
         if (o.present && o.n_outlier_values < 0) {
             set_error("histograms with outliers cannot be encoded: their values were not kept (outlier log overflow, or a result merged "

@@ -91,6 +91,7 @@ static void free_query(Query *q) {
     if (q->d_top) hipFree(q->d_top);
     if (q->d_top_cells) hipFree(q->d_top_cells);
     if (q->d_out_log) hipFree(q->d_out_log);
+    if (q->d_multi) hipFree(q->d_multi);
     query_hash_free(q);
     delete q;
 }

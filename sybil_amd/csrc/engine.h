@@ -206,6 +206,7 @@ struct AggInfo {
     int32_t f_out;  // base of 6 outlier fields (n, sum, sq limb0..3) or -1
     int64_t num_buckets;
     int64_t info_max;
+    std::vector<sybl_subhist> subs;  // -loghist: the sub-histograms (layout of the aggregation's bucket words)
 };
 
 struct Result;
@@ -220,6 +221,9 @@ struct Query {
     int64_t hist_bucket = 0;
     bool want_percentiles = false;
     bool weighted = false;
+    bool loghist = false;          // FLAGS.LOG_HIST: MultiHist (hist_multi.go)
+    std::vector<MultiSub> h_multi; // every aggregation's sub-histograms, as the kernels see them
+    MultiSub *d_multi = nullptr;
     bool time_mode = false;
     int64_t time_bucket = 0;
     std::string order_by;

@@ -91,6 +91,23 @@ struct AggDesc {
     int32_t m_max;        // MAX-section field: max(v)
     int32_t m_nmin;       // MAX-section field: max(-v)
     int32_t hist_full;    // 1: bucket arrays in the SUM section (global atomics)
+    int32_t multi_n;      // -loghist: sub-histograms of this aggregation (0 = BasicHist), ScanPlan::multi[multi_off ..]
+    int32_t multi_off;
+};
+
+// -loghist (MultiHist, hist_multi.go): one sub-histogram of an aggregation.  A value goes to the FIRST sub-histogram
+// whose [mn, mx] holds it (:84-89), through that BasicHist's own AddWeightedValue: its reject gate (v > Info.Max*10 of
+// the SUB-range: a negative maximum rejects most of its own range), b = (v - mn) / bs, and when b reaches len(Values)
+// the value is clipped into the last bucket and remembered -- here counted in an exact per-value counter, since the
+// outliers of a sub-histogram all lie in [ext_first, mx].
+struct MultiSub {
+    int64_t mn, mx, max10, bs;
+    double inv_bs;
+    int32_t nv, big_div;
+    int64_t off;        // of the sub-histogram's Values inside the aggregation's bucket words
+    int64_t ext_off;    // of its outlier counters
+    int64_t ext_first;  // value of the first outlier counter (= mn + nv * bs)
+    int64_t n_ext;
 };
 
 struct Segment {           // a run of physical rows one workgroup scans
@@ -134,6 +151,7 @@ struct ScanPlan {
     // The cursor is header word kHdrOutLog; records beyond out_cap are only counted.
     int64_t *out_log;
     int64_t out_cap;
+    const MultiSub *multi;   // -loghist: every aggregation's sub-histograms
     int64_t hist_off;        // word offset of bucket arrays in the SUM section
     int64_t hist_stride;     // words per cell = sum of n_values over full-hist aggs
     int64_t hist_agg_off[kMaxAggs];

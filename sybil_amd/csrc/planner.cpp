@@ -288,7 +288,7 @@ static bool fill_fast_columns(Table *t, Query *q, const std::vector<int> &slot_c
 static void select_fast_path(Table *t, Query *q, const std::vector<int> &slot_col) {
     q->fast = false;
     const ScanPlan &P = q->plan;
-    if (getenv("SYBL_NO_FAST")) return;
+    if (getenv("SYBL_NO_FAST") || q->loghist) return;  // (MultiHist: the plan-interpreting kernels only)
     if (!q->use_lds) return;
     if (q->time_mode && P.tb_big_div) return;
     FastPlan &FP = q->fplan;
@@ -346,7 +346,7 @@ static void select_fast_path(Table *t, Query *q, const std::vector<int> &slot_co
 static int select_part_hist(Table *t, Query *q, const std::vector<int> &slot_col, int64_t rows_scanned) {
     q->part_hist = false;
     const ScanPlan &P = q->plan;
-    if (getenv("SYBL_NO_PARTHIST") || q->hash_mode) return SYBL_OK;
+    if (getenv("SYBL_NO_PARTHIST") || q->hash_mode || q->loghist) return SYBL_OK;
     if (q->op != SYBL_AGG_HIST || !q->want_percentiles || q->time_mode || q->weighted || q->aggs.empty()) return SYBL_OK;
     if (q->fast && q->fplan.hist_lds) return SYBL_OK;  // the bucket arrays already live in LDS
     EmitPlan &E = q->eplan;
@@ -482,7 +482,9 @@ struct Planner {
 
         q->op = d->op;
         q->hist_bucket = d->hist_bucket;
-        q->want_percentiles = d->op == SYBL_AGG_HIST && d->want_percentiles;
+        q->loghist = d->loghist != 0;
+        // (a MultiHist's percentiles and stddev both come from its sub-histograms' buckets: they are always kept)
+        q->want_percentiles = d->op == SYBL_AGG_HIST && (d->want_percentiles || q->loghist);
         q->order_by = d->order_by ? d->order_by : "";
         q->order_asc = d->order_asc != 0;
         q->limit = d->limit;
@@ -795,8 +797,10 @@ struct Planner {
             // (hist_basic.go:34-40,72-85) and accepted values are >= Info.Min, so the running
             // extrema only need tracking when the column bounds let a value beat the start value.
             {
-                bool need_max = d->op == SYBL_AGG_HIST ? (empty ? false : hi > imax) : (empty ? false : hi > 0);
-                bool need_min = d->op == SYBL_AGG_HIST ? false : (empty ? false : lo < 0);
+                // (a MultiHist starts at Info.Min / Info.Max in avg mode too, hist_multi.go:31-32)
+                const bool info_start = d->op == SYBL_AGG_HIST || q->loghist;
+                bool need_max = info_start ? (empty ? false : hi > imax) : (empty ? false : hi > 0);
+                bool need_min = info_start ? false : (empty ? false : lo < 0);
                 if (c->bounds_set == false && empty) need_max = need_min = false;
                 A.m_max = need_max ? M++ : -1;
                 A.m_nmin = need_min ? M++ : -1;
@@ -804,7 +808,72 @@ struct Planner {
             ai.f_out = -1;
             ai.num_buckets = 0;
             ai.info_max = imax;
-            if (d->op == SYBL_AGG_HIST) {
+            if (d->op == SYBL_AGG_HIST && q->loghist) {
+                // MultiHist.TrackPercentiles, hist_multi.go:223-257: sub-histograms over ranges that halve from Info.Max
+                // downwards until one is at most NUM_BUCKETS wide, the last one from Info.Min to the left edge reached
+                if (imax < imin) return fail(SYBL_E_INVAL, "IntInfo of '%s' has max < min", c->name.c_str());
+                if ((unsigned __int128)((__int128)imax - (__int128)imin) >= ((unsigned __int128)1 << 62))
+                    return fail(SYBL_E_INVAL, "IntInfo range of '%s' is too wide for -loghist", c->name.c_str());
+                std::vector<std::pair<int64_t, int64_t>> ranges;
+                {
+                    int64_t width = imax - imin, right = imax;
+                    int n = 0;
+                    for (int64_t tw = width; tw > 1000; tw >>= 1) n++;
+                    for (int k = 0; k < n; k++) {
+                        width >>= 1;
+                        ranges.emplace_back(right - width, right);
+                        right -= width;
+                    }
+                    ranges.emplace_back(imin, right);
+                }
+                A.hmin = imin;
+                A.bucket_size = 1;
+                A.inv_bucket = 1.0;
+                A.multi_off = (int32_t)q->h_multi.size();
+                A.multi_n = (int32_t)ranges.size();
+                int64_t words = 0;
+                for (auto &rg : ranges) {
+                    int64_t bs, nb, nv;
+                    setup_buckets(rg.first, rg.second, d->hist_bucket, &bs, &nb, &nv);
+                    if (bs <= 0 || nv <= 0) return fail(SYBL_E_INVAL, "bad bucket geometry for '%s'", c->name.c_str());
+                    // outliers of the sub-histogram: values from mn + nv * bs up to mx, one exact counter each
+                    const __int128 first = (__int128)rg.first + (__int128)nv * bs;
+                    const int64_t n_ext = first <= rg.second ? (int64_t)((__int128)rg.second - first + 1) : 0;
+                    MultiSub S;
+                    memset(&S, 0, sizeof(S));
+                    S.mn = rg.first;
+                    S.mx = rg.second;
+                    S.max10 = (int64_t)((uint64_t)rg.second * 10u);
+                    S.bs = bs;
+                    S.inv_bs = 1.0 / (double)bs;
+                    S.nv = (int32_t)std::min<int64_t>(nv, INT32_MAX);
+                    S.big_div = (rg.second - rg.first) >= ((int64_t)1 << 51);
+                    S.off = words;
+                    S.ext_off = words + nv;
+                    S.ext_first = n_ext > 0 ? (int64_t)first : rg.second;
+                    S.n_ext = n_ext;
+                    words += nv + n_ext;
+                    if (words > (1 << 20))
+                        return fail(SYBL_E_INVAL, "-loghist on '%s' needs more than 2^20 bucket words per group (with -int-bucket the "
+                                                  "sub-histograms' outliers span the whole range)", c->name.c_str());
+                    q->h_multi.push_back(S);
+                    sybl_subhist sh;
+                    sh.info_min = rg.first;
+                    sh.info_max = rg.second;
+                    sh.bucket_size = bs;
+                    sh.num_buckets = nb;
+                    sh.n_values = nv;
+                    sh.offset = S.off;
+                    sh.ext_first = S.ext_first;
+                    sh.n_ext = n_ext;
+                    sh.ext_offset = S.ext_off;
+                    ai.subs.push_back(sh);
+                }
+                A.n_values = (int32_t)words;
+                A.hist_full = 1;
+                P.hist_agg_off[a] = hist_stride;
+                hist_stride += words;
+            } else if (d->op == SYBL_AGG_HIST) {
                 if (imax < imin) return fail(SYBL_E_INVAL, "IntInfo of '%s' has max < min", c->name.c_str());
                 int64_t bs, nb, nv;
                 setup_buckets(imin, imax, d->hist_bucket, &bs, &nb, &nv);
@@ -1107,6 +1176,11 @@ struct Planner {
         q->fplan.wg_seg_begin = q->d_wg_seg_begin;
         q->fplan.ws_sum = q->d_ws_sum;
         q->fplan.ws_max = q->d_ws_max;
+        if (!q->h_multi.empty()) {
+            SYBL_HIP(hipMalloc((void **)&q->d_multi, q->h_multi.size() * sizeof(MultiSub)));
+            SYBL_HIP(hipMemcpy(q->d_multi, q->h_multi.data(), q->h_multi.size() * sizeof(MultiSub), hipMemcpyHostToDevice));
+            P.multi = q->d_multi;
+        }
         SYBL_HIP(hipMalloc((void **)&q->d_plan, sizeof(ScanPlan)));
         for (auto &e : q->ev) SYBL_HIP(hipEventCreate(&e));
         q->plan_dirty = true;

@@ -97,10 +97,23 @@ static void json_agg(Result *R, const RowStore &r, size_t a, std::string &o) {
             // GetStrBuckets + getSparseBuckets: non-zero buckets keyed by their lower edge, sorted as strings
             // -- plus one per outlier / underlier under its own value (hist_basic.go:246-254)
             std::map<std::string, int64_t> bmap;
-            for (size_t b = 0; b < (size_t)R->n_values[a]; b++)
-                if (vals[b] > 0) bmap[std::to_string((long long)((int64_t)b * g.bucket_size + g.min))] += vals[b];
-            if (g.n_outlier_values < 0) R->render_refused = true;  // outliers exist but their values were not kept
-            for (int64_t k = 0; k < g.n_outlier_values; k++) bmap[std::to_string((long long)g.outlier_values[k])] += 1;
+            if (R->loghist) {
+                // MultiHist.GetStrBuckets (hist_multi.go:175-188): every sub-histogram's GetStrBuckets in turn, a later
+                // one REPLACING an equal key of an earlier one (where GetSparseBuckets, behind percentiles and stddev, adds)
+                for (const sybl_subhist &S : R->subs[a]) {
+                    std::map<std::string, int64_t> sub;
+                    for (int64_t k = 0; k < S.n_values; k++) sub[std::to_string((long long)(k * S.bucket_size + S.info_min))] = vals[S.offset + k];
+                    for (int64_t k = 0; k < S.n_ext; k++)
+                        if (vals[S.ext_offset + k] > 0) sub[std::to_string((long long)(S.ext_first + k))] += vals[S.ext_offset + k];
+                    for (auto &kv : sub) bmap[kv.first] = kv.second;
+                }
+                for (auto it = bmap.begin(); it != bmap.end();) it = it->second > 0 ? std::next(it) : bmap.erase(it);
+            } else {
+                for (size_t b = 0; b < (size_t)R->n_values[a]; b++)
+                    if (vals[b] > 0) bmap[std::to_string((long long)((int64_t)b * g.bucket_size + g.min))] += vals[b];
+                if (g.n_outlier_values < 0) R->render_refused = true;  // outliers exist but their values were not kept
+                for (int64_t k = 0; k < g.n_outlier_values; k++) bmap[std::to_string((long long)g.outlier_values[k])] += 1;
+            }
             std::vector<std::pair<std::string, int64_t>> bk(bmap.begin(), bmap.end());
             o += ",\"buckets\":{";
             for (size_t k = 0; k < bk.size(); k++) {

@@ -66,11 +66,68 @@ static void agg_finish(const Query *q, Result *R, const AggInfo &ai, const AggAc
         o.num_buckets = ai.num_buckets;
         o.n_values = A.n_values;
         o.n_outliers = a.n_out;
+    } else if (q->loghist) {
+        o.min = std::min(A.info_min, tmin);  // a MultiHist starts at Info.Min / Info.Max in avg mode too (hist_multi.go:31-32)
+        o.max = std::max(ai.info_max, tmax);
     } else {
         o.min = std::min<int64_t>(0, tmin);  // avg mode: Go zero values (hist_basic.go:72-85)
         o.max = std::max<int64_t>(0, tmax);
     }
     if (q->op != SYBL_AGG_HIST) return;
+    if (q->loghist) {
+        // MultiHist: percentiles (GetPercentiles, hist_multi.go:93-128) and stddev (GetStdDev, :140-155) over the union
+        // of the sub-histograms' sparse buckets (:190-207) -- non-zero buckets keyed by their lower edge, every
+        // outlier once more under its own value, equal keys added up.  Mean = exact sum / count; keys in ascending order.
+        o.bucket_size = 0;
+        o.num_buckets = 0;
+        o.n_values = A.n_values;
+        o.n_outliers = 0;
+        values_out = a.values;
+        if (!a.values) return;
+        std::vector<std::pair<int64_t, int64_t>> kc;
+        for (const sybl_subhist &S : ai.subs) {
+            const int64_t *v = a.values + S.offset, *e = a.values + S.ext_offset;
+            for (int64_t k = 0; k < S.n_values; k++)
+                if (v[k] > 0) kc.emplace_back(k * S.bucket_size + S.info_min, v[k]);
+            for (int64_t k = 0; k < S.n_ext; k++)
+                if (e[k] > 0) {
+                    kc.emplace_back(S.ext_first + k, e[k]);
+                    o.n_outliers += e[k];
+                }
+        }
+        std::sort(kc.begin(), kc.end());
+        size_t m = 0;
+        for (size_t i = 0; i < kc.size(); i++) {
+            if (m > 0 && kc[m - 1].first == kc[i].first) kc[m - 1].second += kc[i].second;
+            else kc[m++] = kc[i];
+        }
+        kc.resize(m);
+        int64_t total = 0;
+        for (auto &p : kc) total += p.second;
+        if (cnt != 0) {
+            pct_off = pct_slot;
+            int64_t pct[101];
+            memset(pct, 0, sizeof(pct));
+            int64_t prev_p = 0, c = 0;
+            for (auto &p : kc) {
+                if (total <= 0) break;
+                c += p.second;
+                const int64_t pp = (100 * c) / total;
+                for (int64_t ip = prev_p; ip <= pp; ip++)
+                    if (ip <= 100) pct[ip] = p.first;
+                if (pp <= 100 && pp >= 0) pct[pp] = p.first;
+                prev_p = pp;
+            }
+            memcpy(R->pct_pool.data() + pct_off, pct, 100 * sizeof(int64_t));
+        }
+        long double var = 0;
+        for (auto &p : kc) {
+            const long double d = (long double)p.first - avg_l;
+            var += d * d * ((long double)p.second / (long double)cnt);
+        }
+        o.stddev = cnt == 0 ? (kc.empty() ? 0.0 : (double)NAN) : (double)sqrtl(var);
+        return;
+    }
 
     // outlier term of GetStdDev: sum (o - avg)^2 / Count, from exact n, sum(o), sum(o^2)
     long double out_term = 0;
@@ -277,7 +334,7 @@ static void make_views(Result *R) {
 // Many cells with bucket arrays: percentiles / bucket moments / Cumulative buckets come from the GPU.
 bool query_wants_hist_summary(const Query *q) {
     const ScanPlan &P = q->plan;
-    if (getenv("SYBL_NO_HISTSUMMARY") || q->hash_mode) return false;
+    if (getenv("SYBL_NO_HISTSUMMARY") || q->hash_mode || q->loghist) return false;
     if (q->op != SYBL_AGG_HIST || !q->want_percentiles || q->time_mode || P.hist_stride <= 0 || q->aggs.empty()) return false;
     for (auto &a : q->aggs)
         if (!a.d.hist_full) return false;
@@ -482,6 +539,9 @@ int query_finalize(Query *q, Result **out) {
     R->order_asc = q->order_asc;
     R->time_bucket = q->time_bucket;
     for (auto &a : q->aggs) R->agg_info.emplace_back(a.d.info_min, a.info_max);
+    R->loghist = q->loghist;
+    R->subs.clear();
+    for (auto &a : q->aggs) R->subs.push_back(a.subs);
     R->n_aggs = (int)q->aggs.size();
     for (auto &g : q->groups) R->group_names.push_back(q->t->cols[(size_t)g.col]->name);
     for (auto &a : q->aggs) {
@@ -839,6 +899,14 @@ int sybl_result_rows(const sybl_result *r, int which, const sybl_group_row **row
     if (!R || which < 0 || which > 2) return fail(SYBL_E_INVAL, "sybl_result_rows: bad argument");
     if (rows) *rows = R->view[which].data();
     if (n) *n = (int64_t)R->view[which].size();
+    return SYBL_OK;
+}
+
+int sybl_result_subhists(const sybl_result *r, int agg, const sybl_subhist **subs, int64_t *n) {
+    const Result *R = (const Result *)r;
+    if (!R || !subs || !n || agg < 0 || agg >= R->n_aggs) return fail(SYBL_E_INVAL, "sybl_result_subhists: bad argument");
+    *subs = (size_t)agg < R->subs.size() && !R->subs[(size_t)agg].empty() ? R->subs[(size_t)agg].data() : nullptr;
+    *n = (size_t)agg < R->subs.size() ? (int64_t)R->subs[(size_t)agg].size() : 0;
     return SYBL_OK;
 }
 

@@ -92,7 +92,8 @@ struct Result : ResultStore {
     // pctoff_pool: n_aggs entries per row, all row kinds (pctoff: offset into pct_pool, -1 = none)
     // for rendering
     int op = 0;
-    bool weighted = false, time_mode = false, want_percentiles = false;
+    bool weighted = false, time_mode = false, want_percentiles = false, loghist = false;
+    std::vector<std::vector<sybl_subhist>> subs;  // -loghist: per aggregation, the layout of its values arrays
     int limit = 0;
     int n_aggs = 0;
     std::vector<int64_t> n_values;

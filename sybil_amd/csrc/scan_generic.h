@@ -296,7 +296,23 @@ __device__ __forceinline__ void row_accumulate(CPlan &P, const Tile<NC> &t, int 
         if (A.f_smp >= 0) acc_add<USE_LDS>(sumtab, ((int64_t)A.f_smp * ncell << rs) + cidx, 1);
         if (A.m_max >= 0) acc_max<USE_LDS>(maxtab, ((int64_t)A.m_max * ncell << rs) + cidx, x);
         if (A.m_nmin >= 0) acc_max<USE_LDS>(maxtab, ((int64_t)A.m_nmin * ncell << rs) + cidx, x == INT64_MIN ? INT64_MAX : -x);
-        if (P.hist_mode) {
+        if (P.hist_mode && A.multi_n > 0) {
+            // -loghist: the first sub-histogram whose range holds the value (hist_multi.go:84-89)
+            int64_t *H = P.sum_out + P.hist_off + gcell * P.hist_stride + P.hist_agg_off[s.agg_index];
+            for (int k = 0; k < A.multi_n; k++) {
+                const MultiSub S = P.multi[A.multi_off + k];
+                if (x < S.mn || x > S.mx) continue;
+                if (x > S.max10) break;  // the sub-histogram's own gate (hist_basic.go:104)
+                int64_t b = sdiv_trunc(x - S.mn, S.bs, S.inv_bs, S.big_div);
+                if (b >= S.nv) {  // Outlier of the sub-histogram: remembered (one exact counter per value) and clipped
+                    if (x - S.ext_first < S.n_ext) gadd(H + S.ext_off + (x - S.ext_first), 1);
+                    else overflow += 1;
+                    b = S.nv - 1;
+                }
+                gadd(H + S.off + b, w);
+                break;
+            }
+        } else if (P.hist_mode) {
             // bucket_value := (value - h.Min) / BucketSize  (hist_basic.go:130)
             int64_t b = sdiv_trunc(x - A.hmin, A.bucket_size, A.inv_bucket, A.big_div);
             if (b >= A.n_values || b < 0) {

@@ -237,7 +237,7 @@ class Table:
         return (col, op, str(value))
 
     def query(self, filters=(), groups=(), aggs=(), op="avg", hist_bucket=0, want_percentiles=True, time_col=None,
-              time_bucket=0, weight_col=None, order_by="$COUNT", order_asc=False, limit=0, block_skip=False):
+              time_bucket=0, weight_col=None, order_by="$COUNT", order_asc=False, limit=0, block_skip=False, loghist=False):
         keep = []
         farr = (N.Filter * max(len(filters), 1))()
         for i, f in enumerate(filters):
@@ -273,6 +273,7 @@ class Table:
         d.order_asc = 1 if order_asc else 0
         d.limit = limit
         d.block_skip = 1 if block_skip else 0
+        d.loghist = 1 if loghist else 0
         h = C.c_void_p()
         N.check(N.lib().sybl_query_prepare(self._h, C.byref(d), C.byref(h)))
         return Query(self, h, list(groups), list(aggs))
@@ -429,6 +430,12 @@ class Result:
                 row["hists"].append(h)
             out.append(row)
         return out
+
+    def subhists(self, agg=0):
+        """-loghist: the layout of the aggregation's `values` arrays (sybl_result_subhists) as a list of dicts."""
+        subs, n = C.POINTER(N.SubHist)(), C.c_int64()
+        N.check(N.lib().sybl_result_subhists(self._h, agg, C.byref(subs), C.byref(n)))
+        return [{k: getattr(subs[i], k) for k, _ in N.SubHist._fields_} for i in range(n.value)]
 
     @property
     def results(self):

@@ -1,0 +1,154 @@
+"""GPU: -loghist (MultiHist, reference src/lib/hist_multi.go) against the CPU oracle: sub-histogram geometry, every
+bucket, the sub-histograms' outliers, percentiles (bit-exact), stddev / avg (1e-6), text / -json rendering."""
+import json
+
+import numpy as np
+import pytest
+
+import sybil_amd
+from tests import parity
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = sybil_amd.Context(0)
+    yield c
+    c.close()
+
+
+def compare_loghist(g, o, subs, ctx=""):
+    assert bool(g["present"]) == bool(o["present"]), ctx
+    if not o["present"]:
+        return
+    assert (g["count"], g["samples"], g["sum"]) == (o["count"], o["samples"], o["sum_exact"]), ctx
+    assert (g["min"], g["max"]) == (o["min"], o["max"]), (ctx, g["min"], g["max"], o["min"], o["max"])
+    o_avg = o["avg"] if o["avg"] == o["avg"] else (o["sum_exact"] / o["count"] if o["count"] else 0.0)
+    assert parity._close(g["avg"], o_avg), (ctx, g["avg"], o["avg"])
+    if "subhists" not in o:  # avg mode: no sub-histograms
+        assert g["stddev"] == 0.0
+        return
+    assert [(s["info_min"], s["info_max"], s["bucket_size"], s["num_buckets"], s["n_values"]) for s in subs] == \
+           [s[:5] for s in o["subhists"]], ctx
+    outliers = []
+    for s, os_ in zip(subs, o["subhists"]):
+        assert np.array_equal(g["values"][s["offset"]:s["offset"] + s["n_values"]], o["values"][os_[5]:os_[5] + os_[4]]), (ctx, s)
+        ext = g["values"][s["ext_offset"]:s["ext_offset"] + s["n_ext"]]
+        for k in np.flatnonzero(ext):
+            outliers += [s["ext_first"] + int(k)] * int(ext[k])
+    assert sorted(outliers) == o["outlier_values"].tolist(), ctx
+    assert g["n_outliers"] == len(outliers)
+    assert np.array_equal(g.get("percentiles", np.zeros(0, dtype=np.int64)), o["percentiles"]), ctx
+    scale = max(abs(o_avg), 1.0)
+    assert parity._close(g["stddev"], o["stddev_exact"], 1e-9, scale), (ctx, g["stddev"], o["stddev_exact"])
+
+
+def compare(gres, ores, n_aggs, time_mode=False):
+    assert gres.matched == ores["matched"]
+    subs = [gres.subhists(a) for a in range(n_aggs)]
+    for which, name in ((0, "results"), (1, "time_results")):
+        gmap = {(r["time_bucket"], r["key"]): r for r in gres.rows(which)}
+        omap = {(r["time_bucket"], r["key"]): r for r in ores[name]}
+        assert set(gmap) == set(omap), name
+        for k, o in omap.items():
+            assert gmap[k]["count"] == o["count"] and gmap[k]["samples"] == o["samples"]
+            for a in range(n_aggs):
+                compare_loghist(gmap[k]["hists"][a], o["hists"][a], subs[a], ctx=(name, k, a))
+    if not time_mode:
+        for a in range(n_aggs):
+            compare_loghist(gres.cumulative["hists"][a], ores["cumulative"]["hists"][a], subs[a], ctx=("cumulative", a))
+
+
+def _table(ctx, cols, info, pops=None, block_rows=20_000, compact=False):
+    names = list(cols)
+    n = len(cols[names[0]])
+    tb = ctx.create_table("lh")
+    for c in names:
+        lo, hi = info.get(c, (1, 0))
+        tb.add_column(c, "int", lo, hi)
+    for r0 in range(0, n, block_rows):
+        r1 = min(r0 + block_rows, n)
+        tb.append_block(r1 - r0, {c: ((cols[c][r0:r1], pops[c][r0:r1]) if pops and c in pops else cols[c][r0:r1]) for c in names})
+    if compact:
+        tb.compact()
+    return tb
+
+
+@pytest.mark.parametrize("lo,hi,bucket", [(0, 999_999, 0), (10, 29, 0), (-5000, 70_000, 0), (-90_000, -100, 0), (0, 30_000, 7)])
+def test_loghist_matches_the_oracle(ctx, oracle, lo, hi, bucket):
+    rng = np.random.default_rng(abs(hi) + bucket)
+    n = 70_000
+    cols = {"g": rng.integers(0, 6, size=n).astype(np.int64),
+            "v": rng.integers(lo - 20, hi + 100, size=n).astype(np.int64),
+            "u": rng.integers(0, 5000, size=n).astype(np.int64),
+            "w": rng.integers(1, 4, size=n).astype(np.int64)}
+    cols["v"][:3] = [lo, hi, hi * 10 if hi > 0 else hi]
+    pops = {"v": (rng.random(n) > 0.1).astype(np.uint8)}
+    info = {"v": (lo, hi), "u": (0, 4999)}
+    ocols = [{"type": "int", "data": cols[c], **({"populated": pops[c]} if c in pops else {})} for c in cols]
+    for compact in (False, True):
+        tb = _table(ctx, cols, info, pops, compact=compact)
+        for q, okw in ((dict(groups=["g"], aggs=["v", "u"], op="hist", hist_bucket=bucket, loghist=True),
+                        dict(groups=[0], aggs=[(1, lo, hi), (2, 0, 4999)], op="hist", hist_bucket=bucket)),
+                       (dict(filters=[("u", "gt", 999)], aggs=["v"], op="hist", hist_bucket=bucket, loghist=True, weight_col="w"),
+                        dict(filters=[(2, "gt", 999)], aggs=[(1, lo, hi)], op="hist", hist_bucket=bucket, weight_col=3)),
+                       (dict(groups=["g"], aggs=["v"], op="avg", loghist=True), dict(groups=[0], aggs=[(1, lo, hi)], op="avg"))):
+            query = tb.query(**q)
+            gres = query.run()
+            ores = oracle.run_query(ocols, block_rows=20_000, n_threads=2, loghist=True, **okw)
+            compare(gres, ores, len(q["aggs"]))
+            gres.free()
+            query.free()
+        tb.free()
+
+
+def test_loghist_time_series_hash_and_rendering(ctx, oracle, monkeypatch):
+    rng = np.random.default_rng(41)
+    n = 50_000
+    cols = {"g": rng.integers(0, 4, size=n).astype(np.int64), "t": np.sort(1_700_000_000 + rng.integers(0, 4 * 3600, size=n)).astype(np.int64),
+            "v": rng.integers(0, 200_000, size=n).astype(np.int64)}
+    info = {"v": (0, 199_999)}
+    ocols = [{"type": "int", "data": cols[c]} for c in cols]
+    tb = _table(ctx, cols, info)
+    # time series
+    q = dict(groups=["g"], aggs=["v"], op="hist", loghist=True, time_col="t", time_bucket=3600)
+    query = tb.query(**q)
+    gres = query.run()
+    ores = oracle.run_query(ocols, groups=[0], aggs=[(2, 0, 199_999)], op="hist", loghist=True, time_col=1, time_bucket=3600, block_rows=20_000)
+    compare(gres, ores, 1, time_mode=True)
+    gres.free()
+    query.free()
+    # through the hash table (bucket words follow the key's slot, then the dense order)
+    monkeypatch.setenv("SYBL_FORCE_HASH", "1")
+    q = dict(groups=["g"], aggs=["v"], op="hist", loghist=True)
+    query = tb.query(**q)
+    gres = query.run()
+    assert query.stats()["strategy"] == 7
+    monkeypatch.delenv("SYBL_FORCE_HASH")
+    ores = oracle.run_query(ocols, groups=[0], aggs=[(2, 0, 199_999)], op="hist", loghist=True, block_rows=20_000)
+    compare(gres, ores, 1)
+    # -json: percentiles, stddev, and GetStrBuckets' union (a later sub-histogram REPLACES an equal key, hist_multi.go:175-188)
+    out = json.loads(gres.render("json"))
+    rows = {r["key_vals"][0]: r for r in gres.results}
+    omap = {r["key_vals"][0]: r for r in ores["results"]}
+    subs = gres.subhists(0)
+    for jr in out:
+        h, o = rows[int(jr["g"])]["hists"][0], omap[int(jr["g"])]["hists"][0]
+        assert jr["v"]["percentiles"] == o["percentiles"].tolist() and jr["Count"] == rows[int(jr["g"])]["count"]
+        assert abs(jr["v"]["stddev"] - o["stddev_exact"]) <= 1e-6 * o["stddev_exact"]
+        want = {}
+        for s in subs:
+            sub = {str(k * s["bucket_size"] + s["info_min"]): int(h["values"][s["offset"] + k]) for k in range(s["n_values"])}
+            for k in range(s["n_ext"]):
+                c = int(h["values"][s["ext_offset"] + k])
+                if c:
+                    sub[str(s["ext_first"] + k)] = sub.get(str(s["ext_first"] + k), 0) + c
+            want.update(sub)
+        assert jr["v"]["buckets"] == {k: c for k, c in want.items() if c > 0}
+    assert "v" in gres.render("text") or gres.render("text")
+    with pytest.raises(sybil_amd.SyblError):
+        gres.encode()
+    gres.free()
+    query.free()
+    tb.free()

@@ -1,3 +1,3 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-timeout 1500 python -m pytest tests -m gpu -q -x --tb=short --deselect tests/test_gpu_fullsize.py > gpurun_out/pytest_gpu.log 2>&1; tail -15 gpurun_out/pytest_gpu.log
+timeout 900 python -m pytest tests/test_gpu_loghist.py -q -x --tb=short > gpurun_out/pytest_loghist.log 2>&1; tail -30 gpurun_out/pytest_loghist.log
