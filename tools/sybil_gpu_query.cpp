@@ -43,8 +43,8 @@ int main(int argc, char **argv) {
         {"sort", "$COUNT"}, {"sort-asc", "false"}, {"time", "false"}, {"time-col", "time"}, {"time-bucket", "3600"},
         {"weight-col", ""}, {"int-filter", ""}, {"str-filter", ""}, {"set-filter", ""}, {"int-bucket", "0"},
         {"int", ""}, {"str", ""}, {"set", ""}, {"group", ""}, {"field-separator", ","}, {"filter-separator", ":"},
-        {"device", "0"}, {"block-skip", "true"}, {"stats", "false"}, {"encode-results", "false"}};
-    const std::set<std::string> bools = {"print", "json", "sort-asc", "time", "block-skip", "stats", "encode-results"};
+        {"device", "0"}, {"block-skip", "true"}, {"stats", "false"}, {"encode-results", "false"}, {"loghist", "false"}};
+    const std::set<std::string> bools = {"print", "json", "sort-asc", "time", "block-skip", "stats", "encode-results", "loghist"};
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         if (a.size() < 2 || a[0] != '-') {
@@ -165,6 +165,7 @@ int main(int argc, char **argv) {
     d.order_asc = on("sort-asc");
     d.limit = atoi(f["limit"].c_str());
     d.block_skip = on("block-skip");
+    d.loghist = on("loghist");  // FLAGS.LOG_HIST (cmd_query.go:43)
 
     sybl_query *q = nullptr;
     if (sybl_query_prepare(tab, &d, &q)) return die("prepare");
