@@ -247,6 +247,20 @@ typedef struct {
     int64_t id_match_len;
 } sybl_filter;
 
+/* -str-replace col:pattern:replacement (table_query.go:33-46, column_store_io.go:517-545): when a block is unpacked, every
+ * string of the column's StringTable is rewritten with regexp.ReplaceAllString and strings that become equal share one
+ * id -- so str filters compare, and group-by groups, the REWRITTEN strings.  Here the dictionaries are resident and
+ * table-global: the rewrite is a property of the query.  Either `pattern` + `replace` (the library's RE2 engine,
+ * $1 / ${name} / $$ expanded as regexp.Expand does) or, when `replaced` is non-NULL, the host's own result: one
+ * rewritten string per table-global dictionary id (sybl_table_column_dict order).  Only str columns are rewritten. */
+typedef struct {
+    const char *col;
+    const char *pattern;
+    const char *replace;
+    const char *const *replaced;
+    int64_t n_replaced;
+} sybl_str_replace;
+
 typedef struct {
     int32_t n_filters;
     const sybl_filter *filters; /* ANDed (aggregate.go:105-116) */
@@ -271,6 +285,8 @@ typedef struct {
      * of sub-histograms whose ranges halve from Info.Max downwards; percentiles and stddev come from the union of their
      * buckets.  Bucket arrays are always kept (want_percentiles is implied); sybl_result_subhists describes them. */
     int32_t loghist;
+    int32_t n_str_replace;              /* QueryParams.StrReplace (query_spec.go:30) */
+    const sybl_str_replace *str_replace;
 } sybl_query_desc;
 
 int sybl_query_prepare(sybl_table *t, const sybl_query_desc *desc, sybl_query **out);
@@ -426,6 +442,11 @@ const void *sybl_result_encode(sybl_result *r, int64_t *n_bytes);
  * (RE2) syntax, unanchored search like regexp.MatchString (filter.go:213-236).  1 = match, 0 = no match,
  * -1 = the pattern does not compile (sybl_last_error says why). */
 int sybl_debug_regex_match(const char *pattern, const char *text, int64_t text_len);
+
+/* Test hook (no GPU needed): regexp.ReplaceAllString(text, templ) of the same engine -- what -str-replace applies to
+ * every dictionary string (column_store_io.go:517-530).  NULL = the pattern does not compile.  Library-owned buffer,
+ * valid until the next call on the thread. */
+const char *sybl_debug_regex_replace(const char *pattern, const char *text, const char *templ);
 
 /* Test/diagnostic hook: decodes one gob file (info.db, int_/str_/set_*.db, optionally .gz) to JSON
  * with the library's gob reader.  Library-owned buffer, valid until the next call on the thread. */

@@ -40,6 +40,11 @@ class Filter(C.Structure):
                 ("id_match", C.c_void_p), ("id_match_len", C.c_int64)]
 
 
+class StrReplace(C.Structure):
+    _fields_ = [("col", C.c_char_p), ("pattern", C.c_char_p), ("replace", C.c_char_p), ("replaced", C.POINTER(C.c_char_p)),
+                ("n_replaced", C.c_int64)]
+
+
 class QueryDesc(C.Structure):
     _fields_ = [("n_filters", C.c_int32), ("filters", C.POINTER(Filter)),
                 ("n_groups", C.c_int32), ("groups", C.POINTER(C.c_char_p)),
@@ -47,7 +52,7 @@ class QueryDesc(C.Structure):
                 ("op", C.c_int32), ("hist_bucket", C.c_int64), ("want_percentiles", C.c_int32),
                 ("time_col", C.c_char_p), ("time_bucket", C.c_int64), ("weight_col", C.c_char_p),
                 ("order_by", C.c_char_p), ("order_asc", C.c_int32), ("limit", C.c_int32),
-                ("block_skip", C.c_int32), ("loghist", C.c_int32)]
+                ("block_skip", C.c_int32), ("loghist", C.c_int32), ("n_str_replace", C.c_int32), ("str_replace", C.POINTER(StrReplace))]
 
 
 class AggOut(C.Structure):
@@ -116,6 +121,7 @@ SIGNATURES = {
     "sybl_table_load_stats": (C.c_int, [P, C.POINTER(LoadStats)]),
     "sybl_debug_gob_to_json": (C.c_char_p, [C.c_char_p]),
     "sybl_debug_regex_match": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int64]),
+    "sybl_debug_regex_replace": (C.c_char_p, [C.c_char_p, C.c_char_p, C.c_char_p]),
     "sybl_table_rows": (C.c_int64, [P]),
     "sybl_table_blocks": (C.c_int64, [P]),
     "sybl_table_hbm_bytes": (C.c_int64, [P]),

@@ -92,6 +92,10 @@ static void free_query(Query *q) {
     if (q->d_top_cells) hipFree(q->d_top_cells);
     if (q->d_out_log) hipFree(q->d_out_log);
     if (q->d_multi) hipFree(q->d_multi);
+    for (auto &kv : q->replaced) {
+        if (kv.second->d_keys) hipFree(kv.second->d_keys);
+        if (kv.second->d_ranks) hipFree(kv.second->d_ranks);
+    }
     query_hash_free(q);
     delete q;
 }
@@ -381,6 +385,22 @@ int sybl_debug_regex_match(const char *pattern, const char *text, int64_t text_l
         return -1;
     }
     return re.search(text ? text : "", (size_t)text_len) ? 1 : 0;
+}
+
+const char *sybl_debug_regex_replace(const char *pattern, const char *text, const char *templ) {
+    static thread_local std::string out;
+    if (!pattern || !text || !templ) {
+        set_error("NULL argument");
+        return nullptr;
+    }
+    Re2Lite re;
+    std::string why;
+    if (!re.compile(pattern, &why)) {
+        set_error("bad regex '%s': %s", pattern, why.c_str());
+        return nullptr;
+    }
+    out = re.replace_all(text, templ);
+    return out.c_str();
 }
 
 int sybl_debug_query_cells(sybl_query *q, int which, int agg, int64_t *out, int64_t cap, int64_t *n_cells) {

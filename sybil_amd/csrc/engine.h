@@ -188,6 +188,15 @@ struct HostBuf {
     }
 };
 
+// -str-replace on one str column: dictionary id -> id of the rewritten string (first id that rewrites to it)
+struct StrReplaced {
+    std::vector<std::string> strs;  // [new id]
+    std::vector<int32_t> remap;     // [table-global dictionary id] -> new id
+    int64_t *d_keys = nullptr;      // device map old id -> new id (the kSlotDict layout)
+    int32_t *d_ranks = nullptr;
+    uint32_t mask = 0;
+};
+
 struct GroupInfo {
     int col;
     int type;
@@ -196,6 +205,7 @@ struct GroupInfo {
     int64_t value_card;  // digits that are real values
     int64_t missing_digit;  // digit missing rows map to (-1: column has no missing rows)
     bool dict = false;      // digits are ranks in the column's sorted distinct values (Column::gdict)
+    const StrReplaced *replaced = nullptr;  // -str-replace: digits are ids of the rewritten strings
     bool has_missing;
 };
 
@@ -222,6 +232,7 @@ struct Query {
     bool want_percentiles = false;
     bool weighted = false;
     bool loghist = false;          // FLAGS.LOG_HIST: MultiHist (hist_multi.go)
+    std::map<int, std::unique_ptr<StrReplaced>> replaced;  // -str-replace, by table column index
     std::vector<MultiSub> h_multi; // every aggregation's sub-histograms, as the kernels see them
     MultiSub *d_multi = nullptr;
     bool time_mode = false;

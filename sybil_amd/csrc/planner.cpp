@@ -492,6 +492,35 @@ struct Planner {
         q->time_bucket = q->time_mode ? d->time_bucket : 0;
         q->weighted = d->weight_col && d->weight_col[0];
 
+        // ---- -str-replace (column_store_io.go:517-545): rewritten dictionaries of this query
+        for (int i = 0; i < d->n_str_replace; i++) {
+            const sybl_str_replace &sr = d->str_replace[i];
+            Column *c = t->find(sr.col);
+            if (!c || c->type != SYBL_STR_VAL) continue;  // (the reference only consults the map while unpacking str columns)
+            auto R = std::make_unique<StrReplaced>();
+            Re2Lite re;
+            if (!sr.replaced) {
+                std::string why;
+                if (!re.compile(sr.pattern ? sr.pattern : "", &why))
+                    return fail(SYBL_E_INVAL, "bad -str-replace pattern '%s': %s", sr.pattern ? sr.pattern : "", why.c_str());
+            } else if (sr.n_replaced < (int64_t)c->dict.size()) {
+                return fail(SYBL_E_INVAL, "-str-replace on '%s': %lld rewritten strings for a dictionary of %zu", c->name.c_str(),
+                            (long long)sr.n_replaced, c->dict.size());
+            }
+            std::unordered_map<std::string, int32_t> seen;
+            R->remap.resize(c->dict.size());
+            for (size_t k = 0; k < c->dict.size(); k++) {
+                std::string nv = sr.replaced ? std::string(sr.replaced[k] ? sr.replaced[k] : "") : re.replace_all(c->dict[k], sr.replace ? sr.replace : "");
+                auto it = seen.find(nv);
+                if (it == seen.end()) {
+                    it = seen.emplace(nv, (int32_t)R->strs.size()).first;
+                    R->strs.push_back(nv);
+                }
+                R->remap[k] = it->second;
+            }
+            q->replaced[t->col_ix[c->name]] = std::move(R);
+        }
+
         memset(&P, 0, sizeof(P));
         P.time_slot = -1;
         P.weight_slot = -1;
@@ -541,7 +570,14 @@ struct Planner {
                 // (the reference's RCache, filter.go:213-236); all become one bit per id.
                 size_t n = c->dict.size();
                 std::vector<uint8_t> m(n, 0);
-                if (f.op == SYBL_OP_EQ || f.op == SYBL_OP_NEQ) {
+                // -str-replace: the filters see the rewritten strings
+                auto rp = q->replaced.find(slot_col[(size_t)s]);
+                const StrReplaced *RW = rp == q->replaced.end() ? nullptr : rp->second.get();
+                auto str_of = [&](size_t k) -> const std::string & { return RW ? RW->strs[(size_t)RW->remap[k]] : c->dict[k]; };
+                if ((f.op == SYBL_OP_EQ || f.op == SYBL_OP_NEQ) && RW) {
+                    const std::string want = f.str_value ? f.str_value : "";
+                    for (size_t k = 0; k < n; k++) m[k] = (str_of(k) == want) == (f.op == SYBL_OP_EQ);
+                } else if (f.op == SYBL_OP_EQ || f.op == SYBL_OP_NEQ) {
                     auto it = c->dict_ix.find(f.str_value ? f.str_value : "");
                     for (size_t k = 0; k < n; k++) m[k] = f.op == SYBL_OP_NEQ;
                     if (it != c->dict_ix.end()) m[(size_t)it->second] = f.op == SYBL_OP_EQ;
@@ -558,7 +594,7 @@ struct Planner {
                         if (!re.compile(f.str_value ? f.str_value : "", &why))
                             return fail(SYBL_E_INVAL, "bad regex '%s': %s", f.str_value ? f.str_value : "", why.c_str());
                         for (size_t k = 0; k < n; k++) {
-                            bool hit = re.search(c->dict[k]);
+                            bool hit = re.search(str_of(k));
                             m[k] = f.op == SYBL_OP_NRE ? !hit : hit;
                         }
                     }
@@ -623,6 +659,38 @@ struct Planner {
             // extra digit of their own.
             gi.missing_digit = -1;
             gi.dict = false;
+            {
+                auto rp = q->replaced.find(gi.col);
+                if (rp != q->replaced.end()) {
+                    // the digit is the id of the rewritten string, looked up through a device map old id -> new id
+                    StrReplaced *RW = rp->second.get();
+                    gi.replaced = RW;
+                    if (!RW->d_keys) {
+                        uint32_t cap = 16;
+                        while ((size_t)cap < 2 * RW->remap.size() + 2) cap <<= 1;
+                        std::vector<int64_t> keys(cap, kDictEmpty);
+                        std::vector<int32_t> ranks(cap, -1);
+                        for (size_t k = 0; k < RW->remap.size(); k++) {
+                            uint64_t z = (uint64_t)k + 0x9E3779B97F4A7C15ull;  // dict_hash (scan_generic.h)
+                            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+                            z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+                            z = z ^ (z >> 31);
+                            uint32_t hh = (uint32_t)(z >> 32) & (cap - 1);
+                            while (keys[hh] != kDictEmpty) hh = (hh + 1) & (cap - 1);
+                            keys[hh] = (int64_t)k;
+                            ranks[hh] = RW->remap[k];
+                        }
+                        SYBL_HIP(hipMalloc((void **)&RW->d_keys, (size_t)cap * 8));
+                        SYBL_HIP(hipMalloc((void **)&RW->d_ranks, (size_t)cap * 4));
+                        SYBL_HIP(hipMemcpy(RW->d_keys, keys.data(), (size_t)cap * 8, hipMemcpyHostToDevice));
+                        SYBL_HIP(hipMemcpy(RW->d_ranks, ranks.data(), (size_t)cap * 4, hipMemcpyHostToDevice));
+                        RW->mask = cap - 1;
+                    }
+                    lo = 0;
+                    hi = (int64_t)RW->strs.size() - 1;
+                    card = RW->strs.size();
+                }
+            }
             // sparse / wide key range: one digit per DISTINCT value instead of one per value of the range
             const bool hash_ok = !q->time_mode && !getenv("SYBL_NO_HASH");
             if (c->type == SYBL_INT_VAL && !getenv("SYBL_NO_GDICT") &&
@@ -692,7 +760,12 @@ struct Planner {
                 sd.gstride = (int32_t)std::min<int64_t>(stride, INT32_MAX);
                 sd.gmissing = q->groups[g].missing_digit >= 0 ? (int32_t)std::min<int64_t>(q->groups[g].missing_digit * stride, INT32_MAX) : -1;
                 sd.gvalues = (int32_t)std::min<int64_t>(q->groups[g].value_card, INT32_MAX);
-                if (q->groups[g].dict) {
+                if (q->groups[g].replaced) {
+                    sd.flags |= kSlotDict;
+                    sd.dkeys = q->groups[g].replaced->d_keys;
+                    sd.dranks = q->groups[g].replaced->d_ranks;
+                    sd.dmask = q->groups[g].replaced->mask;
+                } else if (q->groups[g].dict) {
                     const Column *gc = t->cols[(size_t)q->groups[g].col].get();
                     sd.flags |= kSlotDict;
                     sd.dkeys = gc->d_gdict_keys;

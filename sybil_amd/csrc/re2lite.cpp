@@ -15,7 +15,9 @@ constexpr size_t kMaxProg = 100000;  // instructions after expanding counted rep
 constexpr int32_t kMaxRune = 0x10FFFF;
 
 struct Node {
-    enum Kind { kEmpty, kSet, kAny, kAnyNotNl, kCat, kAlt, kStar, kPlus, kQuest, kRepeat, kAssert } kind = kEmpty;
+    enum Kind { kEmpty, kSet, kAny, kAnyNotNl, kCat, kAlt, kStar, kPlus, kQuest, kRepeat, kAssert, kCapture } kind = kEmpty;
+    bool lazy = false;  // repetitions: prefer fewer (x*?); only submatch extraction can tell
+    int cap = 0;        // kCapture: group number (1-based)
     std::vector<std::unique_ptr<Node>> kids;
     std::vector<std::pair<int32_t, int32_t>> ranges;  // kSet
     bool negated = false;                             // kSet
@@ -49,8 +51,10 @@ struct Re2Parser {
     std::vector<int32_t> pat;  // runes of the pattern
     size_t at = 0;
     std::string err;
-    bool fold = false, dot_nl = false, multi = false;
+    bool fold = false, dot_nl = false, multi = false, ungreedy = false;
     int depth = 0;
+    int n_cap = 0;
+    std::vector<std::string> cap_names = {""};  // [0] = the whole match
 
     bool fail(const std::string &m) {
         if (err.empty()) err = m;
@@ -251,19 +255,23 @@ struct Re2Parser {
     }
 
     // group flags after "(?": returns 0 on error, 1 = flags only "(?i)", 2 = scoped group "(?i:" / "(?:" / named
+    std::string last_name;  // of the named group parse_group_header just read
+    // 3 = named capturing group
     int parse_group_header(bool *sfold, bool *sdot, bool *smulti) {
         if (peek() == 'P' && peek(1) == '<') at += 1;  // (?P<name>
         if (peek() == '<') {                           // (?<name>
             at++;
             size_t n = 0;
+            last_name.clear();
             while (more() && peek() != '>') {
                 if (!is_word(peek())) return fail("invalid named capture"), 0;
+                last_name.push_back((char)peek());
                 at++;
                 n++;
             }
             if (!more() || n == 0) return fail("invalid named capture"), 0;
             at++;
-            return 2;
+            return 3;
         }
         bool f = fold, d = dot_nl, m = multi, neg = false, any = false;
         while (more()) {
@@ -273,7 +281,7 @@ struct Re2Parser {
             case 'i': f = !neg; any = true; break;
             case 's': d = !neg; any = true; break;
             case 'm': m = !neg; any = true; break;
-            case 'U': any = true; break;  // swaps greedy / lazy: immaterial for a yes / no match
+            case 'U': ungreedy = !neg; any = true; break;  // swaps greedy / lazy (only submatch extraction can tell)
             case '-':
                 if (neg) return fail("invalid or unsupported Perl syntax"), 0;
                 neg = true;
@@ -299,11 +307,13 @@ struct Re2Parser {
         case '(': {
             at++;
             if (++depth > 200) return fail("expression nests too deeply"), nullptr;
-            const bool of = fold, od = dot_nl, om = multi;
+            const bool of = fold, od = dot_nl, om = multi, ou = ungreedy;
+            int cap = 0;  // > 0: a capturing group
             if (peek() == '?') {
                 at++;
                 bool f, d, m;
                 f = fold, d = dot_nl, m = multi;
+                const bool u_before = ungreedy;
                 const int kind = parse_group_header(&f, &d, &m);
                 if (!kind) return nullptr;
                 fold = f, dot_nl = d, multi = m;
@@ -312,13 +322,27 @@ struct Re2Parser {
                     n->kind = Node::kEmpty;
                     return n;
                 }
+                if (kind == 3) {
+                    ungreedy = u_before;
+                    cap = ++n_cap;
+                    cap_names.push_back(last_name);
+                }
+            } else {
+                cap = ++n_cap;
+                cap_names.push_back("");
             }
             NodeP inner = parse_alt();
             if (!inner) return nullptr;
             if (peek() != ')') return fail("missing closing )"), nullptr;
             at++;
             depth--;
-            fold = of, dot_nl = od, multi = om;
+            fold = of, dot_nl = od, multi = om, ungreedy = ou;
+            if (cap > 0) {
+                n->kind = Node::kCapture;
+                n->cap = cap;
+                n->kids.push_back(std::move(inner));
+                return n;
+            }
             return inner;
         }
         case '[': at++; return parse_set();
@@ -417,7 +441,11 @@ struct Re2Parser {
                 break;
             }
             if (repeated) return fail("invalid nested repetition operator"), nullptr;
-            if (peek() == '?') at++;  // lazy: the same set of strings matches
+            r->lazy = ungreedy;
+            if (peek() == '?') {  // x*?: prefer fewer (under (?U): prefer more)
+                at++;
+                r->lazy = !ungreedy;
+            }
             repeated = true;
             r->kids.push_back(std::move(a));
             a = std::move(r);
@@ -492,26 +520,39 @@ struct Re2Parser {
             for (int32_t j : jumps) P[(size_t)j].x = (int32_t)P.size();
             return true;
         }
+        // kSplit tries x before y (thread priority): greedy repetitions prefer the body, lazy ones the way out
+        case Node::kCapture: {
+            add(Re2Lite::kSave, 0, 2 * n->cap, 0);
+            if (!emit(n->kids[0].get())) return false;
+            add(Re2Lite::kSave, 0, 2 * n->cap + 1, 0);
+            return true;
+        }
         case Node::kStar: {
             const int32_t split = add(Re2Lite::kSplit, 0, 0, 0);
-            P[(size_t)split].x = (int32_t)P.size();
+            const int32_t body = (int32_t)P.size();
             if (!emit(n->kids[0].get())) return false;
             add(Re2Lite::kJmp, 0, split, 0);
-            P[(size_t)split].y = (int32_t)P.size();
+            const int32_t out = (int32_t)P.size();
+            P[(size_t)split].x = n->lazy ? out : body;
+            P[(size_t)split].y = n->lazy ? body : out;
             return true;
         }
         case Node::kPlus: {
             const int32_t start = (int32_t)P.size();
             if (!emit(n->kids[0].get())) return false;
-            const int32_t split = add(Re2Lite::kSplit, 0, start, 0);
-            P[(size_t)split].y = (int32_t)P.size();
+            const int32_t split = add(Re2Lite::kSplit, 0, 0, 0);
+            const int32_t out = (int32_t)P.size();
+            P[(size_t)split].x = n->lazy ? out : start;
+            P[(size_t)split].y = n->lazy ? start : out;
             return true;
         }
         case Node::kQuest: {
             const int32_t split = add(Re2Lite::kSplit, 0, 0, 0);
-            P[(size_t)split].x = (int32_t)P.size();
+            const int32_t body = (int32_t)P.size();
             if (!emit(n->kids[0].get())) return false;
-            P[(size_t)split].y = (int32_t)P.size();
+            const int32_t out = (int32_t)P.size();
+            P[(size_t)split].x = n->lazy ? out : body;
+            P[(size_t)split].y = n->lazy ? body : out;
             return true;
         }
         case Node::kRepeat: {
@@ -520,6 +561,7 @@ struct Re2Parser {
             if (n->max < 0) {
                 Node star;
                 star.kind = Node::kStar;
+                star.lazy = n->lazy;
                 // (borrow the child for the duration of the call)
                 star.kids.emplace_back(const_cast<Node *>(n->kids[0].get()));
                 const bool ok = emit(&star);
@@ -533,7 +575,10 @@ struct Re2Parser {
                 P[(size_t)splits.back()].x = (int32_t)P.size();
                 if (!emit(n->kids[0].get())) return false;
             }
-            for (int32_t s : splits) P[(size_t)s].y = (int32_t)P.size();
+            for (int32_t s : splits) {
+                P[(size_t)s].y = (int32_t)P.size();
+                if (n->lazy) std::swap(P[(size_t)s].x, P[(size_t)s].y);
+            }
             return true;
         }
         }
@@ -568,6 +613,8 @@ bool Re2Lite::compile(const std::string &pattern, std::string *err) {
         return false;
     }
     prog_.push_back(Inst{kMatch, 0, 0, 0});
+    n_cap_ = ps.n_cap;
+    cap_names_ = ps.cap_names;
     return true;
 }
 
@@ -598,6 +645,7 @@ bool Re2Lite::search(const char *text, size_t n) const {
             const Inst &in = prog_[(size_t)pc];
             switch (in.op) {
             case kJmp: stack.push_back(in.x); break;
+            case kSave: stack.push_back(pc + 1); break;  // (submatches: match_from)
             case kSplit:
                 stack.push_back(in.y);
                 stack.push_back(in.x);
@@ -656,6 +704,175 @@ bool Re2Lite::search(const char *text, size_t n) const {
         clist.swap(nlist);
     }
     return false;
+}
+
+// Pike VM with submatch tracking, leftmost-first (Go's default, non-POSIX semantics): threads are kept in priority
+// order, a thread that reaches kMatch cuts off every thread of lower priority, and new start positions are only tried
+// while nothing has matched.
+bool Re2Lite::match_from(const std::vector<int32_t> &runes, size_t start, std::vector<int> &cap) const {
+    if (prog_.empty()) return false;
+    const size_t len = runes.size(), np = prog_.size(), nslot = 2 * (size_t)(n_cap_ + 1);
+    struct Thread {
+        int32_t pc;
+        std::vector<int> cap;
+    };
+    std::vector<Thread> clist, nlist;
+    std::vector<uint32_t> mark(np, 0);
+    uint32_t gen = 0;
+    bool matched = false;
+    // follows the empty transitions in priority order (recursion depth is bounded by the program size)
+    struct Frame {
+        int32_t pc;
+        std::vector<int> cap;
+    };
+    auto add_thread = [&](std::vector<Thread> &list, int32_t pc0, size_t i, const std::vector<int> &cap0) {
+        std::vector<Frame> stack;
+        stack.push_back(Frame{pc0, cap0});
+        while (!stack.empty()) {
+            Frame f = std::move(stack.back());
+            stack.pop_back();
+            if (mark[(size_t)f.pc] == gen) continue;
+            mark[(size_t)f.pc] = gen;
+            const Inst &in = prog_[(size_t)f.pc];
+            switch (in.op) {
+            case kJmp: stack.push_back(Frame{in.x, std::move(f.cap)}); break;
+            case kSplit:
+                stack.push_back(Frame{in.y, f.cap});
+                stack.push_back(Frame{in.x, std::move(f.cap)});
+                break;
+            case kSave:
+                if ((size_t)in.x < nslot) f.cap[(size_t)in.x] = (int)i;
+                stack.push_back(Frame{f.pc + 1, std::move(f.cap)});
+                break;
+            case kAssert: {
+                const int32_t prev = i > 0 ? runes[i - 1] : -1, next = i < len ? runes[i] : -1;
+                bool ok = false;
+                switch (in.arg) {
+                case kBol:
+                case kBot: ok = i == 0; break;
+                case kEol:
+                case kEot: ok = i == len; break;
+                case kBolM: ok = i == 0 || prev == '\n'; break;
+                case kEolM: ok = i == len || next == '\n'; break;
+                case kWordB: ok = (prev >= 0 && is_word(prev)) != (next >= 0 && is_word(next)); break;
+                case kNotWordB: ok = (prev >= 0 && is_word(prev)) == (next >= 0 && is_word(next)); break;
+                }
+                if (ok) stack.push_back(Frame{f.pc + 1, std::move(f.cap)});
+                break;
+            }
+            default: list.push_back(Thread{f.pc, std::move(f.cap)}); break;  // kChar / kAny / kAnyNotNl / kMatch
+            }
+        }
+    };
+    std::vector<int> fresh(nslot, -1);
+    for (size_t i = start; i <= len; i++) {
+        if (i == start) gen++;
+        if (!matched) {  // a later start has the lowest priority, and none once something matched
+            fresh[0] = (int)i;
+            add_thread(clist, 0, i, fresh);
+        }
+        if (clist.empty()) {
+            if (matched) break;
+            gen++;     // (the start thread died on an assertion: the next position gets its own, under fresh marks)
+            continue;
+        }
+        gen++;
+        nlist.clear();
+        const int32_t c = i < len ? runes[i] : -1;
+        for (size_t t = 0; t < clist.size(); t++) {
+            const Inst &in = prog_[(size_t)clist[t].pc];
+            if (in.op == kMatch) {
+                cap = clist[t].cap;
+                cap[1] = (int)i;
+                matched = true;
+                break;  // lower-priority threads are cut off
+            }
+            if (c < 0) continue;
+            bool hit = false;
+            switch (in.op) {
+            case kAny: hit = true; break;
+            case kAnyNotNl: hit = c != '\n'; break;
+            case kChar: {
+                bool inset = false;
+                for (int32_t r = in.x; r < in.y; r++)
+                    if (c >= ranges_[(size_t)r].lo && c <= ranges_[(size_t)r].hi) {
+                        inset = true;
+                        break;
+                    }
+                hit = inset != (in.arg != 0);
+                break;
+            }
+            default: break;
+            }
+            if (hit) add_thread(nlist, clist[t].pc + 1, i + 1, clist[t].cap);
+        }
+        clist.swap(nlist);
+    }
+    return matched;
+}
+
+std::string Re2Lite::replace_all(const std::string &text, const std::string &templ) const {
+    // runes of the text with their byte offsets (Go ranges over the string the same way)
+    std::vector<int32_t> runes;
+    std::vector<size_t> off;
+    for (size_t i = 0; i < text.size();) {
+        size_t w;
+        runes.push_back(decode_rune((const unsigned char *)text.data() + i, text.size() - i, &w));
+        off.push_back(i);
+        i += w;
+    }
+    off.push_back(text.size());
+    // regexp.Expand: $name / ${name} / $$; a name is the longest run of letters, digits and _; all digits = a group number
+    auto expand = [&](const std::vector<int> &cap, std::string &out) {
+        const std::string &t = templ;
+        for (size_t i = 0; i < t.size();) {
+            if (t[i] != '$' || i + 1 >= t.size()) {
+                out.push_back(t[i++]);
+                continue;
+            }
+            if (t[i + 1] == '$') {
+                out.push_back('$');
+                i += 2;
+                continue;
+            }
+            size_t j = i + 1;
+            const bool brace = t[j] == '{';
+            if (brace) j++;
+            const size_t n0 = j;
+            while (j < t.size() && is_word((unsigned char)t[j])) j++;
+            if (j == n0 || (brace && (j >= t.size() || t[j] != '}'))) {  // malformed: the $ is literal text
+                out.push_back(t[i++]);
+                continue;
+            }
+            const std::string name = t.substr(n0, j - n0);
+            if (brace) j++;
+            int g = -1;
+            if (name.find_first_not_of("0123456789") == std::string::npos) {
+                g = name.size() <= 6 ? atoi(name.c_str()) : -1;
+            } else {
+                for (size_t k = 1; k < cap_names_.size(); k++)
+                    if (cap_names_[k] == name) g = (int)k;
+            }
+            if (g >= 0 && g <= n_cap_ && cap[2 * (size_t)g] >= 0 && cap[2 * (size_t)g + 1] >= 0)
+                out.append(text, off[(size_t)cap[2 * (size_t)g]], off[(size_t)cap[2 * (size_t)g + 1]] - off[(size_t)cap[2 * (size_t)g]]);
+            i = j;
+        }
+    };
+    std::string out;
+    size_t last_end = 0, pos = 0;  // rune indices
+    std::vector<int> cap;
+    while (pos <= runes.size()) {
+        if (!match_from(runes, pos, cap)) break;
+        const size_t m0 = (size_t)cap[0], m1 = (size_t)cap[1];
+        out.append(text, off[last_end], off[m0] - off[last_end]);
+        // no replacement for an empty match right behind another match
+        if (m1 > last_end || m0 == 0) expand(cap, out);
+        last_end = m1;
+        if (pos + 1 > m1) pos += 1;  // always advance at least one rune
+        else pos = m1;
+    }
+    out.append(text, off[last_end], text.size() - off[last_end]);
+    return out;
 }
 
 }  // namespace sybl

@@ -30,9 +30,13 @@ public:
     // regexp.MatchString: does the pattern match anywhere in `text`?
     bool search(const char *text, size_t n) const;
     bool search(const std::string &s) const { return search(s.data(), s.size()); }
+    // regexp.ReplaceAllString (-str-replace, column_store_io.go:517-530): every non-overlapping leftmost-first match
+    // replaced by `templ` with $1 / ${1} / $name / ${name} / $$ expanded as regexp.Expand does
+    std::string replace_all(const std::string &text, const std::string &templ) const;
+    int num_captures() const { return n_cap_; }
 
 private:
-    enum Op : uint8_t { kChar, kAny, kAnyNotNl, kSplit, kJmp, kMatch, kAssert };
+    enum Op : uint8_t { kChar, kAny, kAnyNotNl, kSplit, kJmp, kMatch, kAssert, kSave };
     enum Assert : uint8_t { kBol, kEol, kBot, kEot, kWordB, kNotWordB, kBolM, kEolM };
     struct Range {
         int32_t lo, hi;
@@ -44,6 +48,10 @@ private:
     };
     std::vector<Inst> prog_;
     std::vector<Range> ranges_;
+    int n_cap_ = 0;                       // capture groups (group 0 = the whole match, not counted)
+    std::vector<std::string> cap_names_;  // [group] name, "" = unnamed
+    // leftmost-first match starting at or after rune `start`: cap[2g], cap[2g+1] = rune range of group g (-1: unset)
+    bool match_from(const std::vector<int32_t> &runes, size_t start, std::vector<int> &cap) const;
     friend struct Re2Parser;
 };
 

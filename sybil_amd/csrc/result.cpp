@@ -191,7 +191,9 @@ static void build_key(const Query *q, int64_t gcell, uint8_t *key, std::string &
             // group, and translate_group_by prints nothing for it either (aggregate.go:308-316).
             v = UINT64_MAX;
         } else {
-            if (gi.type == SYBL_STR_VAL) {
+            if (gi.type == SYBL_STR_VAL && gi.replaced) {
+                if ((size_t)sv < gi.replaced->strs.size()) gbk += gi.replaced->strs[(size_t)sv];  // -str-replace: the rewritten string
+            } else if (gi.type == SYBL_STR_VAL) {
                 const Column *c = q->t->cols[(size_t)gi.col].get();
                 size_t id = (size_t)sv;
                 if (id < c->dict.size()) gbk += c->dict[id];

@@ -237,7 +237,8 @@ class Table:
         return (col, op, str(value))
 
     def query(self, filters=(), groups=(), aggs=(), op="avg", hist_bucket=0, want_percentiles=True, time_col=None,
-              time_bucket=0, weight_col=None, order_by="$COUNT", order_asc=False, limit=0, block_skip=False, loghist=False):
+              time_bucket=0, weight_col=None, order_by="$COUNT", order_asc=False, limit=0, block_skip=False, loghist=False, str_replace=()):
+        """str_replace: [(col, pattern, replacement)] or [(col, [replaced string per dictionary id])] (-str-replace)."""
         keep = []
         farr = (N.Filter * max(len(filters), 1))()
         for i, f in enumerate(filters):
@@ -274,6 +275,18 @@ class Table:
         d.limit = limit
         d.block_skip = 1 if block_skip else 0
         d.loghist = 1 if loghist else 0
+        sarr = (N.StrReplace * max(len(str_replace), 1))()
+        for i, sr in enumerate(str_replace):
+            sarr[i].col = _b(sr[0])
+            if len(sr) == 2:
+                strs = [_b(x) for x in sr[1]]
+                arr = (C.c_char_p * max(len(strs), 1))(*strs)
+                keep += [strs, arr]
+                sarr[i].replaced = C.cast(arr, C.POINTER(C.c_char_p))
+                sarr[i].n_replaced = len(strs)
+            else:
+                sarr[i].pattern, sarr[i].replace = _b(sr[1]), _b(sr[2])
+        d.n_str_replace, d.str_replace = len(str_replace), C.cast(sarr, C.POINTER(N.StrReplace))
         h = C.c_void_p()
         N.check(N.lib().sybl_query_prepare(self._h, C.byref(d), C.byref(h)))
         return Query(self, h, list(groups), list(aggs))

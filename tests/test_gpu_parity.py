@@ -784,3 +784,74 @@ def test_outlier_values_are_kept_and_printed(ctx, oracle, monkeypatch):
         gres.free()
         query.free()
         tb.free()
+
+
+def test_str_replace_rewrites_the_dictionary_for_filters_and_groups(ctx, oracle):
+    """-str-replace col:pattern:replacement (column_store_io.go:517-545): str filters and group-by see the rewritten
+    strings, and strings that become equal share a group.  Oracle: the same rows with the rewritten strings' ids."""
+    import re
+    rng = np.random.default_rng(61)
+    n = 90_000
+    hosts = ["web%02d.%s.example.com" % (i, dc) for i in range(40) for dc in ("ams", "sfo", "nrt")]
+    ids = rng.integers(0, len(hosts), size=n).astype(np.int32)
+    pop = (rng.random(n) > 0.05).astype(np.uint8)
+    v = rng.integers(0, 5000, size=n).astype(np.int64)
+    g = rng.integers(0, 3, size=n).astype(np.int64)
+    for compact in (False, True):
+        tb = ctx.create_table("sr")
+        tb.add_column("host", "str")
+        tb.add_column("g", "int")
+        tb.add_column("v", "int", 0, 4999)
+        for r0 in range(0, n, 32_768):
+            r1 = min(r0 + 32_768, n)
+            perm = rng.permutation(len(hosts))  # block-local dictionaries in scrambled order
+            inv = np.argsort(perm)
+            tb.append_block(r1 - r0, {"host": {"ids": inv[ids[r0:r1]].astype(np.int32), "strings": [hosts[i] for i in perm], "populated": pop[r0:r1]},
+                                      "g": g[r0:r1], "v": v[r0:r1]})
+        if compact:
+            tb.compact()
+        for pattern, templ, py in ((r"^web\d+\.", "", ""), (r"^(web\d)\d\.(\w+)\..*$", "$2-$1", r"\2-\1"), (r"\d", "#", "#")):
+            rewritten = [re.sub(pattern, py, h) for h in hosts]
+            uniq = sorted(set(rewritten))
+            new_ids = np.array([uniq.index(rewritten[i]) for i in ids], dtype=np.int32)
+            ocols = [{"type": "str", "data": new_ids, "populated": pop}, {"type": "int", "data": g}, {"type": "int", "data": v}]
+            target = rewritten[7]
+            cases = [
+                (dict(groups=["host"], aggs=["v"], op="hist"), dict(groups=[0], aggs=[(2, 0, 4999)], op="hist")),
+                (dict(filters=[("host", "eq", target)], groups=["g", "host"], aggs=["v"]),
+                 dict(filters=[(0, "eq", uniq.index(target))], groups=[1, 0], aggs=[(2, 0, 4999)])),
+                (dict(filters=[("host", "neq", target), ("host", "re", "s")], groups=["host"]),
+                 dict(filters=[(0, "neq", uniq.index(target)), (0, "re", 0, np.array([bool(re.search("s", u)) for u in uniq], dtype=np.uint8))],
+                      groups=[0])),
+            ]
+            for q, okw in cases:
+                for sr in ([("host", pattern, templ)], [("host", rewritten_for(tb, pattern, py))]):
+                    query = tb.query(str_replace=sr, **q)
+                    gres = query.run()
+                    ores = oracle.run_query(ocols, block_rows=32_768, n_threads=2, **okw)
+                    assert gres.matched == ores["matched"]
+                    hpos = q["groups"].index("host")
+
+                    def tr(r, names):
+                        kv = r["key_vals"][hpos]
+                        return tuple("" if (i == hpos and kv == 0xFFFFFFFFFFFFFFFF) else (names[kv] if i == hpos else x)
+                                     for i, x in enumerate(r["key_vals"]))
+                    omap = {tr(r, uniq): r for r in ores["results"]}
+                    gmap = {}
+                    for r in gres.results:
+                        parts = r["group_by_key"].split("\t")[:-1]
+                        gmap[tuple(parts[i] if i == hpos else r["key_vals"][i] for i in range(len(parts)))] = r
+                    assert set(gmap) == set(omap), (pattern, q)
+                    for k, o in omap.items():
+                        assert gmap[k]["count"] == o["count"]
+                        for a in range(len(q.get("aggs", []))):
+                            parity.compare_hist(gmap[k]["hists"][a], o["hists"][a], q.get("op", "avg"), True, ctx=(pattern, k))
+                    gres.free()
+                    query.free()
+        tb.free()
+
+
+def rewritten_for(tb, pattern, py):
+    """the host-evaluated form of -str-replace: one rewritten string per table-global dictionary id"""
+    import re
+    return [re.sub(pattern, py, s) for s in tb.column_dict("host")]

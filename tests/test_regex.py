@@ -76,3 +76,42 @@ def test_linear_time_on_pathological_patterns():
     assert time.perf_counter() - t0 < 10
     # long dictionary strings: no recursion on the input
     assert match(r"^(ab)*$", "ab" * 200_000) == 1
+
+
+# regexp.ReplaceAllString / Expand known answers (Go's regexp documentation and package tests; "$1W" names group "1W",
+# which does not exist; an empty match right behind another match gets no replacement)
+REPLACE_KATS = [
+    ("a(x*)b", "-ab-axxb-", "T", "-T-T-"), ("a(x*)b", "-ab-axxb-", "$1", "--xx-"), ("a(x*)b", "-ab-axxb-", "$1W", "---"),
+    ("a(x*)b", "-ab-axxb-", "${1}W", "-W-xxW-"), ("a+", "baaab", "x", "bxb"), ("a*", "baaac", "x", "xbxcx"), ("", "abc", "-", "-a-b-c-"),
+    (r"(?P<first>\w+) (?P<last>\w+)", "john smith", "$last, $first", "smith, john"), (r"(\d+)\.(\d+)", "v1.22 and 3.4", "${2}_$1", "v22_1 and 4_3"),
+    (r"(\d+)\.(\d+)", "v1.22 and 3.4", "$2_$1", "v1 and 3"), (r"^www\.", "www.example.www.com", "", "example.www.com"), ("b*?", "abb", "x", "xaxbxbx"),
+    ("a.*?c", "abcabc", "X", "XX"), ("(?U)a.*c", "abcabc", "X", "XX"), ("a.*c", "abcabc", "X", "X"), (r"\$", "cost $5", "$$", "cost $5"),
+    ("(a)|(b)", "ab", "[$1|$2]", "[a|][|b]"), ("x*", "\u00e9x", "-", "-\u00e9-"), ("[aeiou]", "education", "$0$0", "eeduucaatiioon"),
+    ("(?i)HOST", "host1.Host2", "<$0>", "<host>1.<Host>2"), ("[0-9]+$", "user123", "", "user"), ("$", "ab", "!", "ab!"),
+]
+
+
+@pytest.mark.parametrize("pattern,text,templ,want", REPLACE_KATS)
+def test_replace_all_known_answers(pattern, text, templ, want):
+    from sybil_amd import _native as N
+    got = N.lib().sybl_debug_regex_replace(pattern.encode(), text.encode(), templ.encode())
+    assert got is not None and got.decode() == want
+
+
+def test_replace_all_agrees_with_python_where_the_semantics_coincide():
+    """Patterns that cannot match the empty string, templates with numbered groups: Perl-style leftmost-first
+    backtracking (Python's re) and Go's leftmost-first RE2 agree."""
+    import random
+    import re as pyre
+    from sybil_amd import _native as N
+    rng = random.Random(5)
+    pats = [r"(\d+)", r"([a-c]+)(\d)", r"user(\d\d?)", r"\.(com|org)$", r"^(\w)\w*", r"(a|ab)(c|bcd)", r"x+?y", r"[^a-z]+", r"(\w+)@(\w+)\.com"]
+    for pat in pats:
+        for _ in range(200):
+            text = "".join(rng.choice("abcxy019.@ user_com org") for _ in range(rng.randint(0, 24)))
+            for templ, py in (("<$1>", r"<\1>"), ("", ""), ("[$0]", r"[\g<0>]")):
+                if "$1" in templ and "(" not in pat:
+                    continue
+                got = N.lib().sybl_debug_regex_replace(pat.encode(), text.encode(), templ.encode()).decode()
+                assert got == pyre.sub(pat, py, text), (pat, text, templ)
+

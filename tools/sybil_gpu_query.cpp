@@ -43,7 +43,7 @@ int main(int argc, char **argv) {
         {"sort", "$COUNT"}, {"sort-asc", "false"}, {"time", "false"}, {"time-col", "time"}, {"time-bucket", "3600"},
         {"weight-col", ""}, {"int-filter", ""}, {"str-filter", ""}, {"set-filter", ""}, {"int-bucket", "0"},
         {"int", ""}, {"str", ""}, {"set", ""}, {"group", ""}, {"field-separator", ","}, {"filter-separator", ":"},
-        {"device", "0"}, {"block-skip", "true"}, {"stats", "false"}, {"encode-results", "false"}, {"loghist", "false"}};
+        {"device", "0"}, {"block-skip", "true"}, {"stats", "false"}, {"encode-results", "false"}, {"loghist", "false"}, {"str-replace", ""}};
     const std::set<std::string> bools = {"print", "json", "sort-asc", "time", "block-skip", "stats", "encode-results", "loghist"};
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
@@ -166,6 +166,22 @@ int main(int argc, char **argv) {
     d.limit = atoi(f["limit"].c_str());
     d.block_skip = on("block-skip");
     d.loghist = on("loghist");  // FLAGS.LOG_HIST (cmd_query.go:43)
+    // -str-replace col:find:replace[,col:find:replace...]  (cmd_query.go:51, table_query.go:33-46: split on ':' whatever the
+    // filter separator is; fewer than three tokens = ignored)
+    std::vector<std::vector<std::string>> sr_tok;
+    for (auto &spec : split(f["str-replace"], fs)) {
+        std::vector<std::string> tok = split(spec, ":");
+        if (tok.size() > 2) sr_tok.push_back(tok);
+    }
+    std::vector<sybl_str_replace> sr(sr_tok.size());
+    for (size_t i = 0; i < sr_tok.size(); i++) {
+        memset(&sr[i], 0, sizeof(sybl_str_replace));
+        sr[i].col = sr_tok[i][0].c_str();
+        sr[i].pattern = sr_tok[i][1].c_str();
+        sr[i].replace = sr_tok[i][2].c_str();
+    }
+    d.n_str_replace = (int32_t)sr.size();
+    d.str_replace = sr.empty() ? nullptr : sr.data();
 
     sybl_query *q = nullptr;
     if (sybl_query_prepare(tab, &d, &q)) return die("prepare");
