@@ -1,10 +1,7 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-cd /tmp && export TMPDIR=/tmp
-for MODE in async sync; do
-  if [ $MODE = async ]; then export SYBL_EMIT_ASYNC=1; else unset SYBL_EMIT_ASYNC; fi
-  rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof_$MODE -o kt -- python $GRAFT_REPO_ROOT/tools/bench_configs.py 0 3 cfg4,cfg3 compact > $GRAFT_REPO_ROOT/gpurun_out/prof_$MODE.log 2>&1
-  echo "== $MODE"; grep '^{' $GRAFT_REPO_ROOT/gpurun_out/prof_$MODE.log | cut -c1-200
-  python $GRAFT_REPO_ROOT/tools/rocpd_summary.py $GRAFT_REPO_ROOT/gpurun_out/prof_$MODE/*.db 2>/dev/null | grep -v "rocclr\|k_synth\|k_block_minmax\|k_fill\|k_repack" | cut -c1-150 | head -14
-  rm -rf $GRAFT_REPO_ROOT/gpurun_out/prof_$MODE
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py tests/test_gpu_compact.py tests/test_gpu_fullsize.py -q -x --tb=short > gpurun_out/pytest_div32.log 2>&1; tail -4 gpurun_out/pytest_div32.log
+for M in div32 nodiv32; do
+  if [ $M = nodiv32 ]; then export SYBL_NO_DIV32=1; else unset SYBL_NO_DIV32; fi
+  echo "== $M"; timeout 300 python tools/bench_configs.py 0 7 cfg3,cfg4,cfg2 compact 2>&1 | grep '^{' | cut -c1-230
 done
