@@ -30,6 +30,8 @@ def oracle_query_kwargs(names, info, q):
     if q.get("weight_col"):
         kw["weight_col"] = ix[q["weight_col"]]
     kw["block_skip"] = q.get("block_skip", False)
+    if q.get("loghist"):
+        kw["loghist"] = True
     return kw
 
 
@@ -76,10 +78,51 @@ def compare_hist(g, o, op, full, ctx="", cumulative=False):
         assert g["stddev"] == 0.0, ctx
 
 
-def compare(gres, ores, op="avg", full=True, n_aggs=0, time_mode=False):
+def compare_loghist(g, o, subs, ctx=""):
+    """-loghist (MultiHist): outer fields, sub-histogram geometry, every bucket, the sub-histograms' outliers (exact
+    counters on the engine side), percentiles bit-exact, stddev against the oracle's exact variant."""
+    assert bool(g["present"]) == bool(o["present"]), ctx
+    if not o["present"]:
+        return
+    assert (g["count"], g["samples"], g["sum"]) == (o["count"], o["samples"], o["sum_exact"]), ctx
+    assert (g["min"], g["max"]) == (o["min"], o["max"]), (ctx, g["min"], g["max"], o["min"], o["max"])
+    o_avg = o["avg"] if o["avg"] == o["avg"] else (o["sum_exact"] / o["count"] if o["count"] else 0.0)
+    assert _close(g["avg"], o_avg), (ctx, g["avg"], o["avg"])
+    if "subhists" not in o:  # avg mode: no sub-histograms
+        assert g["stddev"] == 0.0
+        return
+    assert [(s["info_min"], s["info_max"], s["bucket_size"], s["num_buckets"], s["n_values"]) for s in subs] == \
+           [s[:5] for s in o["subhists"]], ctx
+    outliers = []
+    for s, os_ in zip(subs, o["subhists"]):
+        assert np.array_equal(g["values"][s["offset"]:s["offset"] + s["n_values"]], o["values"][os_[5]:os_[5] + os_[4]]), (ctx, s)
+        ext = g["values"][s["ext_offset"]:s["ext_offset"] + s["n_ext"]]
+        for k in np.flatnonzero(ext):
+            outliers += [s["ext_first"] + int(k)] * int(ext[k])
+    assert sorted(outliers) == o["outlier_values"].tolist(), ctx
+    assert g["n_outliers"] == len(outliers)
+    assert np.array_equal(g.get("percentiles", np.zeros(0, dtype=np.int64)), o["percentiles"]), ctx
+    assert _close(g["stddev"], o["stddev_exact"], 1e-9, max(abs(o_avg), 1.0)), (ctx, g["stddev"], o["stddev_exact"])
+
+
+def compare(gres, ores, op="avg", full=True, n_aggs=0, time_mode=False, loghist=False):
     """gres: sybil_amd.Result; ores: dict from oracle.run_query.  Bit-exact on counts, sums, keys,
     buckets, percentiles, extrema; REL on avg/stddev."""
     assert gres.matched == ores["matched"], (gres.matched, ores["matched"])
+    if loghist:
+        subs = [gres.subhists(a) for a in range(n_aggs)]
+        for which, name in ((0, "results"), (1, "time_results")):
+            gmap = {(r["time_bucket"], r["key"]): r for r in gres.rows(which)}
+            omap = {(r["time_bucket"], r["key"]): r for r in ores[name]}
+            assert set(gmap) == set(omap), name
+            for k, o in omap.items():
+                assert gmap[k]["count"] == o["count"] and gmap[k]["samples"] == o["samples"]
+                for a in range(n_aggs):
+                    compare_loghist(gmap[k]["hists"][a], o["hists"][a], subs[a], ctx=(name, k, a))
+        if not time_mode:
+            for a in range(n_aggs):
+                compare_loghist(gres.cumulative["hists"][a], ores["cumulative"]["hists"][a], subs[a], ctx=("cumulative", a))
+        return
     for which, name in ((0, "results"), (1, "time_results")):
         grows = gres.rows(which)
         orows = ores[name]

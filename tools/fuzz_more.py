@@ -7,13 +7,34 @@ import sybil_amd
 from oracle import oracle as orc
 from tests import test_gpu_fuzz as T
 
+
+
+class _Env:
+    """the two methods of pytest's monkeypatch the tests use"""
+    def setenv(self, k, v):
+        os.environ[k] = v
+
+    def delenv(self, k):
+        os.environ.pop(k, None)
+
+
 a, b = int(sys.argv[1]), int(sys.argv[2])
 ctx = sybil_amd.Context(0)
 bad = []
 for seed in range(a, b):
+    # every fourth seed sends the grouped queries through the hash table (strategy 7), half of those without LDS staging
+    os.environ.pop("SYBL_FORCE_HASH", None)
+    os.environ.pop("SYBL_NO_HASH_LDS", None)
+    if seed % 4 == 0:
+        os.environ["SYBL_FORCE_HASH"] = "1"
+        if seed % 8 == 0:
+            os.environ["SYBL_NO_HASH_LDS"] = "1"
     for fn in (T.test_random_queries, T.test_random_queries_with_strings_and_sets):
         try:
-            fn.__wrapped__(ctx, orc, seed) if hasattr(fn, "__wrapped__") else fn(ctx, orc, seed)
+            if fn is T.test_random_queries:
+                fn(ctx, orc, seed, _Env())
+            else:
+                fn(ctx, orc, seed)
         except Exception as e:  # noqa
             bad.append((seed, fn.__name__, str(e)[:300]))
             traceback.print_exc(limit=2)
