@@ -22,7 +22,7 @@ using gobenc::Fields;
 enum GobId : int {  // builtin ids, then ours in definition order
     G_BOOL = 1, G_INT = 2, G_FLOAT = 4, G_STRING = 6, G_IFACE = 8,
     T_NODE = 65, T_QSPEC, T_QPARAMS, T_GROUPING, T_GROUPINGS, T_AGG, T_AGGS, T_QRESULTS, T_RESULT, T_HISTMAP, T_RESULTMAP,
-    T_TIMEMAP, T_SORTED, T_HISTCOMPAT, T_BASICHIST, T_CACHED, T_I64S, T_INTINFO, T_F64S,
+    T_TIMEMAP, T_SORTED, T_HISTCOMPAT, T_BASICHIST, T_CACHED, T_I64S, T_INTINFO, T_F64S, T_MULTICOMPAT, T_MULTI, T_SUBHISTS,
 };
 
 struct GobStream {
@@ -91,61 +91,169 @@ struct GobStream {
     }
 };
 
-static void gob_hist(GobW &w, const Result *R, const sybl_agg_out &o, int a) {
-    // Histogram interface value: registered name, concrete type id, byte count, HistCompat{BasicHist{BasicHistCachedInfo}}
-    GobW v;
+// one HistCompat{BasicHist{BasicHistCachedInfo{...}}} value
+struct BasicFields {
+    int64_t num_buckets = 0, bucket_size = 0;
+    const int64_t *values = nullptr;
+    int64_t n_values = 0;
+    bool percentile_mode = false;
+    const int64_t *outliers = nullptr;  // ascending; those below info_min are the Underliers
+    int64_t n_outliers = 0;
+    const int64_t *out_counts = nullptr;  // non-NULL: outlier k is the value out_first + k, out_counts[k] times
+    int64_t out_first = 0;
+    int64_t max = 0, min = 0, samples = 0, count = 0;
+    double avg = 0;
+    int64_t info_min = 0, info_max = 0;
+};
+
+static void gob_histcompat(GobW &v, const BasicFields &b) {
     Fields hc(v);
     hc.at(0);  // HistCompat.BasicHist
     Fields bh(v);
     bh.at(0);  // BasicHist.BasicHistCachedInfo
     Fields ci(v);
-    ci.put_int(0, o.num_buckets);
-    ci.put_int(1, o.bucket_size);
-    if (o.values && o.n_values > 0) {
+    ci.put_int(0, b.num_buckets);
+    ci.put_int(1, b.bucket_size);
+    if (b.values && b.n_values > 0) {
         ci.at(2);  // Values []int64
-        v.u((uint64_t)o.n_values);
-        for (int64_t k = 0; k < o.n_values; k++) v.i(o.values[k]);
+        v.u((uint64_t)b.n_values);
+        for (int64_t k = 0; k < b.n_values; k++) v.i(b.values[k]);
     }
     // (Averages []float64, field 3: the per-bucket running means are written by AddWeightedValue and read by nothing
     // (hist_basic.go:144-150; Combine, GetPercentiles, GetStdDev and the printers ignore them).  They are not tracked:
     // omitted, i.e. nil to a Go decoder.)
-    if (R->op == SYBL_AGG_HIST) {
-        ci.at(4);  // PercentileMode
+    if (b.percentile_mode) {
+        ci.at(4);
         v.u(1);
     }
-    if (o.n_outlier_values > 0) {
+    if (b.out_counts) {
+        // a sub-histogram of a MultiHist: its Outliers from the exact per-value counters
+        int64_t n = 0;
+        for (int64_t k = 0; k < b.n_outliers; k++) n += b.out_counts[k];
+        if (n > 0) {
+            ci.at(5);
+            v.u((uint64_t)n);
+            for (int64_t k = 0; k < b.n_outliers; k++)
+                for (int64_t j = 0; j < b.out_counts[k]; j++) v.i(b.out_first + k);
+        }
+    } else if (b.n_outliers > 0) {
         // Outliers (beyond the last bucket) / Underliers (below hist Min), hist_basic.go:132-142; values ascending
         int64_t n_under = 0;
-        while (n_under < o.n_outlier_values && o.outlier_values[n_under] < R->agg_info[(size_t)a].first) n_under++;
-        if (o.n_outlier_values > n_under) {
+        while (n_under < b.n_outliers && b.outliers[n_under] < b.info_min) n_under++;
+        if (b.n_outliers > n_under) {
             ci.at(5);
-            v.u((uint64_t)(o.n_outlier_values - n_under));
-            for (int64_t k = n_under; k < o.n_outlier_values; k++) v.i(o.outlier_values[k]);
+            v.u((uint64_t)(b.n_outliers - n_under));
+            for (int64_t k = n_under; k < b.n_outliers; k++) v.i(b.outliers[k]);
         }
         if (n_under > 0) {
             ci.at(6);
             v.u((uint64_t)n_under);
-            for (int64_t k = 0; k < n_under; k++) v.i(o.outlier_values[k]);
+            for (int64_t k = 0; k < n_under; k++) v.i(b.outliers[k]);
         }
     }
-    ci.put_int(7, o.max);
-    ci.put_int(8, o.min);
-    ci.put_int(9, o.samples);
-    ci.put_int(10, o.count);
-    if (o.avg != 0.0) {
+    ci.put_int(7, b.max);
+    ci.put_int(8, b.min);
+    ci.put_int(9, b.samples);
+    ci.put_int(10, b.count);
+    if (b.avg != 0.0) {
         ci.at(11);
-        v.f(o.avg);
+        v.f(b.avg);
     }
     {
         ci.at(12);  // Info IntInfo{Min, Max}
         Fields in(v);
-        in.put_int(0, R->agg_info[(size_t)a].first);
-        in.put_int(1, R->agg_info[(size_t)a].second);
+        in.put_int(0, b.info_min);
+        in.put_int(1, b.info_max);
         in.end();
     }
     ci.end();
     bh.end();
     hc.end();
+}
+
+// MultiHist{Max, Min, Samples, Count, Avg, PercentileMode, Subhists []*HistCompat, Info *IntInfo} (hist_multi.go:6-19).
+// Of a sub-histogram only what the reference reads back is known here: its buckets, its outliers, Count = their sum
+// and the range; its own Avg / Samples (read by nothing: MultiHist keeps the mean) stay zero.
+static void gob_multihist(GobW &v, const Result *R, const sybl_agg_out &o, int a) {
+    Fields mh(v);
+    mh.put_int(0, o.max);
+    mh.put_int(1, o.min);
+    mh.put_int(2, o.samples);
+    mh.put_int(3, o.count);
+    if (o.avg != 0.0) {
+        mh.at(4);
+        v.f(o.avg);
+    }
+    const std::vector<sybl_subhist> &subs = R->subs[(size_t)a];
+    if (R->op == SYBL_AGG_HIST) {
+        mh.at(5);  // PercentileMode
+        v.u(1);
+        if (!subs.empty() && o.values) {
+            mh.at(6);
+            v.u(subs.size());
+            for (const sybl_subhist &S : subs) {
+                BasicFields b;
+                b.num_buckets = S.num_buckets;
+                b.bucket_size = S.bucket_size;
+                b.values = o.values + S.offset;
+                b.n_values = S.n_values;
+                b.percentile_mode = true;
+                b.out_counts = o.values + S.ext_offset;
+                b.n_outliers = S.n_ext;
+                b.out_first = S.ext_first;
+                b.max = S.info_max;
+                b.min = S.info_min;
+                for (int64_t k = 0; k < S.n_values; k++) b.count += b.values[k];
+                b.info_min = S.info_min;
+                b.info_max = S.info_max;
+                gob_histcompat(v, b);
+            }
+        }
+    }
+    {
+        mh.at(7);  // Info *IntInfo
+        Fields in(v);
+        in.put_int(0, R->agg_info[(size_t)a].first);
+        in.put_int(1, R->agg_info[(size_t)a].second);
+        in.end();
+    }
+    mh.end();
+}
+
+static void gob_hist(GobW &w, const Result *R, const sybl_agg_out &o, int a) {
+    // Histogram interface value: registered name, concrete type id, byte count, the value
+    GobW v;
+    if (R->loghist) {
+        // MultiHistCompat{*MultiHist; Histogram *MultiHist} (hist_compat.go:50-54): both point at the same histogram and
+        // gob flattens pointers, so it travels twice
+        Fields mc(v);
+        mc.at(0);
+        gob_multihist(v, R, o, a);
+        mc.at(1);
+        gob_multihist(v, R, o, a);
+        mc.end();
+        w.s("*sybil.MultiHistCompat");
+        w.i(T_MULTICOMPAT);
+        w.u(v.b.size());
+        w.b += v.b;
+        return;
+    }
+    BasicFields b;
+    b.num_buckets = o.num_buckets;
+    b.bucket_size = o.bucket_size;
+    b.values = o.values;
+    b.n_values = o.n_values;
+    b.percentile_mode = R->op == SYBL_AGG_HIST;
+    b.outliers = o.outlier_values;
+    b.n_outliers = o.n_outlier_values > 0 ? o.n_outlier_values : 0;
+    b.max = o.max;
+    b.min = o.min;
+    b.samples = o.samples;
+    b.count = o.count;
+    b.avg = o.avg;
+    b.info_min = R->agg_info[(size_t)a].first;
+    b.info_max = R->agg_info[(size_t)a].second;
+    gob_histcompat(v, b);
     w.s("*sybil.HistCompat");
     w.i(T_HISTCOMPAT);
     w.u(v.b.size());
@@ -195,8 +303,13 @@ const void *sybl_result_encode(sybl_result *r, int64_t *n_bytes) {
         return nullptr;
     }
     if (R->loghist) {
-        set_error("-encode-results of a -loghist result (MultiHistCompat) is not implemented");
-        return nullptr;
+        // (every outlier of every sub-histogram is written out as a value: bound it)
+        int64_t total = 0;
+        for (auto &o : R->agg_pool) total += o.present ? o.n_outliers : 0;
+        if (total > ((int64_t)1 << 26)) {
+            set_error("-encode-results of this -loghist result would list %lld outlier values", (long long)total);
+            return nullptr;
+        }
     }
     for (auto &o : R->agg_pool)
         if (o.present && o.n_outlier_values < 0) {
@@ -232,6 +345,13 @@ const void *sybl_result_encode(sybl_result *r, int64_t *n_bytes) {
     S.def_slice(T_I64S, "[]int64", G_INT);
     S.def_slice(T_F64S, "[]float64", G_FLOAT);
     S.def_struct(T_INTINFO, "IntInfo", {{"Min", G_INT}, {"Max", G_INT}});
+    if (R->loghist) {
+        S.def_struct(T_MULTICOMPAT, "MultiHistCompat", {{"MultiHist", T_MULTI}, {"Histogram", T_MULTI}});
+        S.def_struct(T_MULTI, "MultiHist",
+                     {{"Max", G_INT}, {"Min", G_INT}, {"Samples", G_INT}, {"Count", G_INT}, {"Avg", G_FLOAT}, {"PercentileMode", G_BOOL},
+                      {"Subhists", T_SUBHISTS}, {"Info", T_INTINFO}});
+        S.def_slice(T_SUBHISTS, "[]*sybil.HistCompat", T_HISTCOMPAT);
+    }
 
     const size_t ng = R->group_names.size();
     GobW w;
@@ -258,7 +378,7 @@ const void *sybl_result_encode(sybl_result *r, int64_t *n_bytes) {
                 Fields af(w);
                 af.put_str(0, R->op == SYBL_AGG_HIST ? "hist" : "avg");
                 af.put_str(1, a);
-                af.put_str(2, "basic");
+                af.put_str(2, R->loghist ? "multi" : "basic");  // query_spec.go:225-231
                 af.end();
             }
         }

@@ -774,7 +774,8 @@ int query_finalize(Query *q, Result **out) {
         const bool usable = logged && !q->out_log_partial && n_log <= q->out_cap;
         for (size_t k = 0; k < R->agg_pool.size(); k++) {
             R->agg_pool[k].outlier_values = nullptr;
-            R->agg_pool[k].n_outlier_values = (R->agg_pool[k].n_outliers > 0 && q->want_percentiles && !usable) ? -1 : 0;
+            // (-loghist keeps its sub-histograms' outliers as exact counters inside `values`: nothing is ever missing)
+            R->agg_pool[k].n_outlier_values = (R->agg_pool[k].n_outliers > 0 && q->want_percentiles && !usable && !q->loghist) ? -1 : 0;
         }
         R->outlier_vals.clear();
         if (usable && n_log > 0) {

@@ -108,9 +108,27 @@ def test_loghist_time_series_hash_and_rendering(ctx, oracle, monkeypatch):
                     sub[str(s["ext_first"] + k)] = sub.get(str(s["ext_first"] + k), 0) + c
             want.update(sub)
         assert jr["v"]["buckets"] == {k: c for k, c in want.items() if c > 0}
-    assert "v" in gres.render("text") or gres.render("text")
-    with pytest.raises(sybil_amd.SyblError):
-        gres.encode()
+    assert gres.render("text")
+    # -encode-results: *sybil.MultiHistCompat{MultiHist, Histogram} (both the same histogram: gob flattens pointers),
+    # each sub-histogram a HistCompat with its buckets and its outliers written out
+    from tests import gobfmt
+    enc = gobfmt.decode(gres.encode())["QuerySpec"]
+    assert enc["QueryParams"]["Aggregations"] == [{"Op": "hist", "Name": "v", "HistType": "multi"}]
+    for key, e in enc["QueryResults"]["Results"].items():
+        h = rows[int(key.strip())]["hists"][0]
+        iv = e["Hists"]["v"]
+        assert iv["@type"] == "*sybil.MultiHistCompat" and iv["value"]["MultiHist"] == iv["value"]["Histogram"]
+        mh = iv["value"]["MultiHist"]
+        assert (mh["Count"], mh["Max"], mh.get("Min", 0), mh["Avg"], mh["PercentileMode"]) == (h["count"], h["max"], h["min"], h["avg"], True)
+        assert mh["Info"] == {"Max": 199_999} and len(mh["Subhists"]) == len(subs)
+        for s, sh in zip(subs, mh["Subhists"]):
+            ci = sh["BasicHist"]["BasicHistCachedInfo"]
+            vals = h["values"][s["offset"]:s["offset"] + s["n_values"]]
+            assert ci.get("Values", [0] * s["n_values"]) == vals.tolist() or (not vals.any() and "Values" in ci)
+            assert ci["BucketSize"] == s["bucket_size"] and ci["NumBuckets"] == s["num_buckets"] and ci.get("Count", 0) == int(vals.sum())
+            want_out = [s["ext_first"] + k for k in range(s["n_ext"]) for _ in range(int(h["values"][s["ext_offset"] + k]))]
+            assert ci.get("Outliers", []) == want_out
+            assert ci["Info"] == {k: v for k, v in (("Min", s["info_min"]), ("Max", s["info_max"])) if v != 0}
     gres.free()
     query.free()
     tb.free()
