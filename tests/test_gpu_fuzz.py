@@ -122,6 +122,54 @@ def test_random_queries(ctx, oracle, seed, monkeypatch):
     tb.free()
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_random_queries_many_tiles_per_workgroup(ctx, oracle, seed, monkeypatch):
+    """The same random queries over tables of 2.5-4 M rows: every workgroup walks several tiles (double-buffered loads,
+    tile tails, LDS staging tables that fill up and flush, windows that move), where the small fuzz tables fit in one."""
+    rng = np.random.default_rng(7000 + seed)
+    n = int(rng.integers(2_500_000, 4_000_000))
+    block_rows = 65536
+    cols, pops = _random_table(rng, n)
+    names = list(cols)
+    info = {}
+    for c in names:
+        lo, hi = int(cols[c].min()), int(cols[c].max())
+        if rng.random() < 0.3 and hi - lo > 10:
+            lo, hi = lo + (hi - lo) // 10, hi - (hi - lo) // 3
+        info[c] = (lo, hi)
+    tb = ctx.create_table("fuzz_big")
+    for c in names:
+        tb.add_column(c, "int", info[c][0], info[c][1])
+    if seed % 2:
+        tb.compact()
+    for r0 in range(0, n, block_rows):
+        r1 = min(r0 + block_rows, n)
+        tb.append_block(r1 - r0, {c: ((cols[c][r0:r1], pops[c][r0:r1]) if c in pops else cols[c][r0:r1]) for c in names})
+    ocols = [{"type": "int", "data": cols[c], **({"populated": pops[c]} if c in pops else {})} for c in names]
+    side = np.random.default_rng(9500 + seed)
+    for k in range(4):
+        q = _random_query(rng, info, side)
+        if k == 3 and q["groups"] and not q.get("time_col"):
+            monkeypatch.setenv("SYBL_FORCE_HASH", "1")  # the last query of every seed goes through the hash table
+        try:
+            query = tb.query(**q)
+        except sybil_amd.SyblError as e:
+            assert "histogram budget" in str(e) or "exceeds 2^27" in str(e) or "2^20 bucket words" in str(e), str(e)
+            continue
+        finally:
+            monkeypatch.delenv("SYBL_FORCE_HASH", raising=False)
+        gres = query.run()
+        ores = oracle.run_query(ocols, block_rows=block_rows, n_threads=8, **parity.oracle_query_kwargs(names, info, q))
+        try:
+            parity.compare(gres, ores, op=q["op"], full=q.get("want_percentiles", True) and q["op"] == "hist",
+                           n_aggs=len(q["aggs"]), time_mode=bool(q.get("time_col")), loghist=bool(q.get("loghist")))
+        except AssertionError as e:
+            raise AssertionError("seed %d query %d %r strategy %d: %s" % (seed, k, q, query.stats()["strategy"], e))
+        gres.free()
+        query.free()
+    tb.free()
+
+
 @pytest.mark.parametrize("seed", range(10))
 def test_random_queries_with_strings_and_sets(ctx, oracle, seed):
     import re
