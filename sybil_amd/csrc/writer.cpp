@@ -15,6 +15,8 @@
 #include <sys/stat.h>
 
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <unordered_map>
 
 #include "engine.h"
@@ -304,14 +306,14 @@ extern "C" int sybl_table_save(sybl_table *t, const char *dir) {
     const std::string tdir = std::string(dir) + "/" + t->name;
     if ((rc = make_dir(tdir))) return rc;
 
+    // blocks are independent: worker threads fetch, encode and write them (one thread took 16 s for a 105 M-row, 4-column
+    // table); the table-level IntInfo is merged from the threads' partial statistics afterwards
     std::vector<IntStat> tstat(t->cols.size());
-    std::vector<int64_t> vals;
-    std::vector<uint8_t> pop;
-    int64_t out_block = 0;
-    for (size_t b = 0; b < t->blocks.size(); b++) {
+    auto save_block = [&](size_t b, std::vector<IntStat> &tstat, std::vector<int64_t> &vals, std::vector<uint8_t> &pop) -> int {
+        int rc;
         const Segment &blk = t->blocks[b];
         char bname[32];
-        snprintf(bname, sizeof(bname), "block%09lld", (long long)++out_block);
+        snprintf(bname, sizeof(bname), "block%09lld", (long long)(b + 1));
         const std::string bdir = tdir + "/" + bname;
         if ((rc = make_dir(bdir))) return rc;
         // SavedColumnInfo{NumRecords, StrInfoMap, IntInfoMap} (column_store.go:39-44)
@@ -367,7 +369,46 @@ extern "C" int sybl_table_save(sybl_table *t, const char *dir) {
             w.b += infos.b;
         }
         f.end();
-        if ((rc = write_file(bdir + "/info.db", gobenc::Encoder().finish(info_t, w.b)))) return rc;
+        return write_file(bdir + "/info.db", gobenc::Encoder().finish(info_t, w.b));
+    };
+    {
+        size_t n_threads = std::min<size_t>(std::max<unsigned>(1, std::thread::hardware_concurrency()), 16);
+        if (const char *e = getenv("SYBL_WRITER_THREADS")) n_threads = (size_t)std::max(1, atoi(e));
+        n_threads = std::min(n_threads, std::max<size_t>(t->blocks.size(), 1));
+        std::vector<std::vector<IntStat>> part(n_threads, std::vector<IntStat>(t->cols.size()));
+        std::vector<int> rcs(n_threads, SYBL_OK);
+        std::vector<std::string> errs(n_threads);
+        std::atomic<size_t> next{0};
+        const int device = t->ctx->device;
+        auto work = [&](size_t k) {
+            if (hipSetDevice(device) != hipSuccess) {
+                rcs[k] = SYBL_E_NODEVICE;
+                return;
+            }
+            std::vector<int64_t> vals;
+            std::vector<uint8_t> pop;
+            for (size_t b = next++; b < t->blocks.size() && rcs[k] == SYBL_OK; b = next++) {
+                rcs[k] = save_block(b, part[k], vals, pop);
+                if (rcs[k]) errs[k] = sybl_last_error();
+            }
+        };
+        std::vector<std::thread> threads;
+        for (size_t k = 1; k < n_threads; k++) threads.emplace_back(work, k);
+        work(0);
+        for (auto &th : threads) th.join();
+        for (size_t k = 0; k < n_threads; k++)
+            if (rcs[k]) return fail(rcs[k], "%s", errs[k].c_str());
+        for (size_t k = 0; k < n_threads; k++)
+            for (size_t ci = 0; ci < t->cols.size(); ci++) {
+                const IntStat &st = part[k][ci];
+                if (!st.any) continue;
+                IntStat &ts = tstat[ci];
+                ts.mn = ts.any ? std::min(ts.mn, st.mn) : st.mn;
+                ts.mx = ts.any ? std::max(ts.mx, st.mx) : st.mx;
+                ts.any = true;
+                ts.count += st.count;
+                ts.isum += st.isum;
+            }
     }
 
     // table info.db: getSaveTable (table_io.go:72-78): Name, KeyTable, KeyTypes, StrInfo, IntInfo
