@@ -82,11 +82,6 @@ static double seconds_since(std::chrono::steady_clock::time_point t0) {
     return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
 
-static bool file_exists(const std::string &p) {
-    struct stat st;
-    return stat(p.c_str(), &st) == 0 || stat((p + ".gz").c_str(), &st) == 0;
-}
-
 // Staging for one table load.  Everything a block sends across PCIe -- bin values, record ids, delta-encoded
 // value arrays, block-local str ids, look-up tables, validity prefixes -- is laid out by the WORKER that decoded the
 // block in a pinned host slab (narrowed on the way: record ids of a block of <= 65536 rows travel as uint16, value
