@@ -251,6 +251,7 @@ def main():
                 for qy in queries:
                     qy.bind_torch(device)
         scan_ms = []
+        host_ms = {"launch": [], "finish": []}  # host time inside the two halves of a step
 
         everyone = [False]  # snapshot / finalize are collective calls (bucket arrays merged by reduce-scatter)
 
@@ -284,10 +285,14 @@ def main():
         def run_steps(n, keep):
             res = None
             for i in range(n):
+                h0 = time.perf_counter()
                 launch(i)
+                h1 = time.perf_counter()
+                host_ms["launch"].append((h1 - h0) * 1e3)
                 j = i - (nq - 1)  # the step whose result is due
                 if j >= 0:
                     r = finish(j)
+                    host_ms["finish"].append((time.perf_counter() - h1) * 1e3)
                     if r is not None:
                         seen_matched.add(r.matched)
                         if res is not None:
@@ -309,6 +314,7 @@ def main():
         run_steps(warmup, False)
         fence()
         del scan_ms[:]
+        del host_ms["launch"][:], host_ms["finish"][:]
         t0 = time.perf_counter()
         res = run_steps(steps, True)
         fence()
@@ -318,7 +324,8 @@ def main():
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = float(tmax.item())
         stats = queries[0].stats()
-        out = {"dt": dt, "stats": stats, "kernel_ms": (sum(scan_ms) / len(scan_ms)) if scan_ms else stats["scan_ms"]}
+        out = {"dt": dt, "stats": stats, "kernel_ms": (sum(scan_ms) / len(scan_ms)) if scan_ms else stats["scan_ms"],
+               "host_ms": {k: round(sum(v) / len(v), 3) if v else None for k, v in host_ms.items()}}
         if rank == 0:
             # every step scans the same table: the merged result must not change from step to step (it
             # would if the all-reduce ever ran ahead of a rank's scan) and group counts must add up
@@ -390,7 +397,8 @@ def main():
                                                                   "inside the timed region",
                        "stored_widths": {n: table.column_storage(n)[0] for n in names},
                        "sharding": "contiguous 65536-row blocks per rank", "collective": args.collective if multi else None,
-                       "device": dev["name"], "matched_rows": head["matched"], "groups": head["groups"]},
+                       "device": dev["name"], "matched_rows": head["matched"], "groups": head["groups"],
+                       "host_ms_per_step": head["host_ms"]},
             "roofline": roofline(head, args.storage),
         }
         if canon is not None:

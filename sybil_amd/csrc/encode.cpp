@@ -418,7 +418,7 @@ const void *sybl_result_encode(sybl_result *r, int64_t *n_bytes) {
         if (!R->rows[0].empty() && !R->order_by.empty()) {
             qr.at(4);  // Sorted []*Result (SortResults, aggregate.go:497-525): the rows are already in that order
             w.u(R->rows[0].size());
-            for (auto &row : R->rows[0]) gob_result(w, R, row, ng);
+            for (size_t i = 0; i < R->rows[0].size(); i++) gob_result(w, R, R->sorted0(i), ng);
         }
         qr.end();
     }

@@ -63,6 +63,16 @@ Column *Table::find(const char *n) const {
 
 static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
+// Side streams get a priority of their own.  HIP multiplexes the streams of one priority onto a few hardware queues
+// (in order within a queue), so a normal-priority side stream can land on the queue the caller's stream feeds and sit
+// behind a whole scan; the queues of another priority level are separate.  toward > 0: lowest priority, < 0: highest.
+hipError_t create_side_stream(hipStream_t *out, int toward) {
+    int least = 0, greatest = 0;
+    hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+    if (e != hipSuccess) return e;
+    return hipStreamCreateWithPriority(out, hipStreamNonBlocking, toward < 0 ? greatest : least);
+}
+
 static void free_query(Query *q) {
     if (!q) return;
     if (q->d_plan) hipFree(q->d_plan);
@@ -81,10 +91,13 @@ static void free_query(Query *q) {
     if (q->h_max) hipHostFree(q->h_max);
     for (auto &e : q->ev)
         if (e) hipEventDestroy(e);
+    if (q->snap_on_aux && q->ev_snap) (void)hipEventSynchronize(q->ev_snap);  // (a copy may still be reading the tables)
     if (q->ev_snap) hipEventDestroy(q->ev_snap);
+    if (q->ev_ready) hipEventDestroy(q->ev_ready);
     if (q->d_pct) hipFree(q->d_pct);
     if (q->d_mom) hipFree(q->d_mom);
     if (q->d_total) hipFree(q->d_total);
+    if (q->h_top) hipHostFree(q->h_top);
     if (q->h_pct) hipHostFree(q->h_pct);
     if (q->h_mom) hipHostFree(q->h_mom);
     if (q->h_total) hipHostFree(q->h_total);
@@ -117,6 +130,12 @@ static int scan(Query *q) {
     q->out_log_partial = false;
     hipStream_t st = q->ctx->stream;
     ScanPlan &P = q->plan;
+    if (q->snap_on_aux && q->ev_snap) {
+        // the previous snapshot of this query is (or was) copied out by the auxiliary stream: nothing below may touch the
+        // tables before it is done (a wait on the GPU's side, not the host's)
+        SYBL_HIP(hipStreamWaitEvent(st, q->ev_snap, 0));
+        q->snap_on_aux = false;
+    }
     if (q->hash_mode && (rc = query_hash_reset(q))) return rc;  // (allocates the key table on first use: before the plan is copied)
     if (q->plan_dirty) {
         P.sum_out = q->d_sum;
@@ -253,6 +272,7 @@ void sybl_shutdown(sybl_ctx *ctx) {
     if (!ctx) return;
     sybl_comm_free(ctx);
     if (ctx->aux_stream) hipStreamDestroy(ctx->aux_stream);
+    if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
     for (auto &ls : ctx->load_streams)
         if (ls) hipStreamDestroy(ls);
     if (ctx->own_stream) {

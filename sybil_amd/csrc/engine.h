@@ -48,6 +48,8 @@ hipError_t launch_hist_summary(const HistSummaryPlan &S, int64_t *total, hipStre
 hipError_t launch_hist_gather(const int64_t *H, int64_t hist_stride, const int64_t *d_cells, int64_t n, int64_t cell0, int64_t cell1,
                               int64_t *out, hipStream_t st);
 
+hipError_t create_side_stream(hipStream_t *out, int toward);  // engine.cpp: a stream on a priority level (and so hardware queues) of its own
+
 struct Ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
@@ -58,6 +60,8 @@ struct Ctx {
     void *comm = nullptr;  // ncclComm_t (rccl.cpp)
     int comm_rank = 0, comm_nranks = 1;
     hipStream_t aux_stream = nullptr;  // small finalize-side copies that must not queue behind another query's scan
+    hipStream_t copy_stream = nullptr; // big snapshots (result.cpp: query_snapshot); not the aux stream: a finalize's gather
+                                       // must not queue behind the NEXT query's snapshot, which waits for that query's scan
     // Table loads spread consecutive blocks over several streams (loader.cpp): a block's decode kernels are a handful of
     // tiny launches, and on one stream the GPU ran them strictly one after another.  While load_multi is set,
     // `stream` is one of load_streams; code that touches state shared between blocks (a column's staging block, a
@@ -273,6 +277,10 @@ struct Query {
     int64_t *d_top_cells = nullptr, *d_top = nullptr;               // bucket arrays of the printed rows
     int64_t top_cap = 0;
     hipEvent_t ev_snap = nullptr;   // the device -> host snapshot of the partial tables has landed
+    int64_t *h_top = nullptr;       // pinned: the printed rows' bucket arrays (result.cpp: attach_top_values)
+    int64_t h_top_words = 0;
+    hipEvent_t ev_ready = nullptr;  // the tables are ready to be copied (big snapshots leave through Ctx::aux_stream)
+    bool snap_on_aux = false;       // the last snapshot was queued on the auxiliary stream: a rescan must wait for it
     bool snapshot_pending = false;
     // multi-GPU merge of big bucket tables (rccl.cpp): the bucket arrays were reduce-SCATTERED over cell ranges, this
     // rank holds the reduced arrays of cells [rs_cell0, rs_cell1) only; percentiles / moments are derived per slice

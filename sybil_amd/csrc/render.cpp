@@ -230,7 +230,7 @@ const char *sybl_result_render(sybl_result *r, int format) {
     if (R->time_mode) {
         // printTimeResults, printer.go:25-107
         std::vector<const RowStore *> top;
-        for (size_t i = 0; i < lim; i++) top.push_back(&R->rows[0][i]);
+        for (size_t i = 0; i < lim; i++) top.push_back(&R->sorted0(i));
         auto is_top = [&](const RowStore &x) {
             for (auto *t : top)
                 if (t->gbk == x.gbk) return true;
@@ -335,13 +335,13 @@ const char *sybl_result_render(sybl_result *r, int format) {
         o += "[";
         for (size_t i = 0; i < lim; i++) {
             if (i) o += ",";
-            json_row(R, R->rows[0][i], o);
+            json_row(R, R->sorted0(i), o);
         }
         o += "]";
     } else {
         // printSortedResults / printResults: the cumulative row first when there is more than one group
         if (lim > 1 && !R->rows[2].empty()) text_row(R, R->rows[2][0], o);
-        for (size_t i = 0; i < lim; i++) text_row(R, R->rows[0][i], o);
+        for (size_t i = 0; i < lim; i++) text_row(R, R->sorted0(i), o);
     }
     if (R->render_refused) {
         set_error("rows with outliers cannot be printed as -json: their values were not kept (outlier log overflow, or a result merged across ranks)");

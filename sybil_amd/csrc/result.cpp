@@ -316,7 +316,7 @@ static void make_views(Result *R) {
         R->view[w].resize(R->rows[w].size());
         parallel_ranges(R->rows[w].size(), 1 << 15, [&, w](size_t i0, size_t i1) {
             for (size_t i = i0; i < i1; i++) {
-                RowStore &r = R->rows[w][i];
+                RowStore &r = w == 0 ? R->sorted0(i) : R->rows[w][i];
                 sybl_group_row &v = R->view[w][i];
                 v.binary_key = r.key;
                 v.group_by_key = r.gbk.c_str();
@@ -412,22 +412,39 @@ int query_snapshot(Query *q) {
             if (!rc) rc = comm_allreduce_sum(q->ctx, q->d_total, (size_t)P.hist_stride);
             if (rc) return rc;
         }
-        const int64_t real_pairs = (int64_t)P.n_cells * (int64_t)q->aggs.size();
-        SYBL_HIP(hipMemcpyAsync(q->h_pct, q->d_pct, (size_t)real_pairs * 100 * 8, hipMemcpyDeviceToHost, st));
-        SYBL_HIP(hipMemcpyAsync(q->h_mom, q->d_mom, (size_t)real_pairs * 2 * 8, hipMemcpyDeviceToHost, st));
-        SYBL_HIP(hipMemcpyAsync(q->h_total, q->d_total, (size_t)P.hist_stride * 8, hipMemcpyDeviceToHost, st));
+    }
+    // Big snapshots (config 4: 52 MB of percentiles, 2 ms of PCIe) leave through a copy stream of their own, ordered behind
+    // everything queued so far by an event: the copy engine then works under the next query's scan instead of in front
+    // of it (config 4, 10 pipelined steps: 7.3 ms per step with the copy on the main stream, 6.4 ms this way).  Small ones (config 3: 57 KB) stay on the main stream -- an event
+    // round trip costs more than they do.
+    const int64_t real_pairs = q->hist_summary ? (int64_t)P.n_cells * (int64_t)q->aggs.size() : 0;
+    const int64_t main_words = q->hash_mode ? sum_words : (q->snap_has_buckets ? q->n_sum_words : P.hist_off);
+    hipStream_t cs = st;
+    q->snap_on_aux = false;
+    if ((real_pairs * 102 + main_words) * 8 >= ((int64_t)4 << 20) && !getenv("SYBL_NO_COPY_STREAM")) {
+        Ctx *ctx = q->ctx;
+        if (!ctx->copy_stream) SYBL_HIP(create_side_stream(&ctx->copy_stream, +1));
+        if (!q->ev_ready) SYBL_HIP(hipEventCreateWithFlags(&q->ev_ready, hipEventDisableTiming));
+        SYBL_HIP(hipEventRecord(q->ev_ready, st));
+        SYBL_HIP(hipStreamWaitEvent(ctx->copy_stream, q->ev_ready, 0));
+        cs = ctx->copy_stream;
+        q->snap_on_aux = true;
+    }
+    if (q->hist_summary) {
+        SYBL_HIP(hipMemcpyAsync(q->h_pct, q->d_pct, (size_t)real_pairs * 100 * 8, hipMemcpyDeviceToHost, cs));
+        SYBL_HIP(hipMemcpyAsync(q->h_mom, q->d_mom, (size_t)real_pairs * 2 * 8, hipMemcpyDeviceToHost, cs));
+        SYBL_HIP(hipMemcpyAsync(q->h_total, q->d_total, (size_t)P.hist_stride * 8, hipMemcpyDeviceToHost, cs));
     }
     if (q->hash_mode) {
-        SYBL_HIP(hipMemcpyAsync(q->h_sum, q->d_dense_sum, (size_t)sum_words * 8, hipMemcpyDeviceToHost, st));
-        if (P.n_max_fields > 0) SYBL_HIP(hipMemcpyAsync(q->h_max, q->d_dense_max, (size_t)max_words * 8, hipMemcpyDeviceToHost, st));
+        SYBL_HIP(hipMemcpyAsync(q->h_sum, q->d_dense_sum, (size_t)sum_words * 8, hipMemcpyDeviceToHost, cs));
+        if (P.n_max_fields > 0) SYBL_HIP(hipMemcpyAsync(q->h_max, q->d_dense_max, (size_t)max_words * 8, hipMemcpyDeviceToHost, cs));
     } else {
-        const int64_t words = q->snap_has_buckets ? q->n_sum_words : P.hist_off;
-        SYBL_HIP(hipMemcpyAsync(q->h_sum, q->d_sum, (size_t)words * 8, hipMemcpyDeviceToHost, st));
+        SYBL_HIP(hipMemcpyAsync(q->h_sum, q->d_sum, (size_t)main_words * 8, hipMemcpyDeviceToHost, cs));
         if (P.n_max_fields > 0)
-            SYBL_HIP(hipMemcpyAsync(q->h_max, q->d_max, (size_t)q->n_max_words * 8, hipMemcpyDeviceToHost, st));
+            SYBL_HIP(hipMemcpyAsync(q->h_max, q->d_max, (size_t)q->n_max_words * 8, hipMemcpyDeviceToHost, cs));
     }
     if (!q->ev_snap) SYBL_HIP(hipEventCreateWithFlags(&q->ev_snap, hipEventDisableTiming));
-    SYBL_HIP(hipEventRecord(q->ev_snap, st));
+    SYBL_HIP(hipEventRecord(q->ev_snap, cs));
     q->snapshot_pending = true;
     return SYBL_OK;
 }
@@ -435,12 +452,14 @@ int query_snapshot(Query *q) {
 // The bucket arrays of the first `top` rows of Results (the rows a printer shows) -- gathered on
 // the GPU into one buffer and copied in one piece.  Runs on the context's auxiliary stream: the
 // main stream may already be busy with the scan of another query.
+static const size_t kTopDmaRows = 512;
+
 static int attach_top_values(Query *q, Result *R, size_t top) {
     const ScanPlan &P = q->plan;
     Ctx *ctx = q->ctx;
     const size_t na = q->aggs.size();
     if (top == 0) return SYBL_OK;
-    if (!ctx->aux_stream) SYBL_HIP(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+    if (!ctx->aux_stream) SYBL_HIP(create_side_stream(&ctx->aux_stream, -1));
     if ((int64_t)top > q->top_cap) {
         if (q->d_top) SYBL_HIP(hipFree(q->d_top));
         if (q->d_top_cells) SYBL_HIP(hipFree(q->d_top_cells));
@@ -449,7 +468,7 @@ static int attach_top_values(Query *q, Result *R, size_t top) {
         q->top_cap = (int64_t)top;
     }
     std::vector<int64_t> cells(top);
-    for (size_t i = 0; i < top; i++) cells[i] = R->rows[0][i].cell;
+    for (size_t i = 0; i < top; i++) cells[i] = R->sorted0(i).cell;
     R->top_vals.resize(top * (size_t)P.hist_stride);
     if (q->rs_active) {
         // the printed rows' bucket arrays live on the ranks that own their cells: every rank gathers its own (zeros for
@@ -462,6 +481,22 @@ static int attach_top_values(Query *q, Result *R, size_t top) {
         if (rc) return rc;
         SYBL_HIP(hipMemcpyAsync(R->top_vals.data(), q->d_top, R->top_vals.size() * 8, hipMemcpyDeviceToHost, st));
         SYBL_HIP(hipStreamSynchronize(st));
+    } else if (top <= kTopDmaRows && !getenv("SYBL_TOP_GATHER_KERNEL")) {
+        // A printer's worth of rows: one DMA copy per row, straight out of the table into pinned memory.  No kernel:
+        // a gather kernel on the auxiliary stream gets no CU while another query's persistent scan workgroups hold the
+        // register files (measured: it waited 4.7 ms for k_emit to end), the copy engines are not part of that.
+        const size_t words = top * (size_t)P.hist_stride;
+        if ((int64_t)words > q->h_top_words) {
+            if (q->h_top) SYBL_HIP(hipHostFree(q->h_top));
+            q->h_top = nullptr;
+            SYBL_HIP(hipHostMalloc((void **)&q->h_top, words * 8, hipHostMallocDefault));
+            q->h_top_words = (int64_t)words;
+        }
+        for (size_t i = 0; i < top; i++)
+            SYBL_HIP(hipMemcpyAsync(q->h_top + i * (size_t)P.hist_stride, q->d_sum + P.hist_off + cells[i] * P.hist_stride,
+                                    (size_t)P.hist_stride * 8, hipMemcpyDeviceToHost, ctx->aux_stream));
+        SYBL_HIP(hipStreamSynchronize(ctx->aux_stream));
+        memcpy(R->top_vals.data(), q->h_top, words * 8);
     } else {
         SYBL_HIP(hipMemcpyAsync(q->d_top_cells, cells.data(), top * 8, hipMemcpyHostToDevice, ctx->aux_stream));
         hipError_t e = launch_hist_gather(q->d_sum + P.hist_off, P.hist_stride, q->d_top_cells, (int64_t)top, 0, P.n_cells, q->d_top, ctx->aux_stream);
@@ -471,8 +506,8 @@ static int attach_top_values(Query *q, Result *R, size_t top) {
     }
     for (size_t i = 0; i < top; i++)
         for (size_t a = 0; a < na; a++)
-            if (R->agg_pool[(size_t)R->rows[0][i].agg_off + a].present)
-                R->val_pool[(size_t)R->rows[0][i].agg_off + a] = R->top_vals.data() + i * (size_t)P.hist_stride + P.hist_agg_off[a];
+            if (R->agg_pool[(size_t)R->sorted0(i).agg_off + a].present)
+                R->val_pool[(size_t)R->sorted0(i).agg_off + a] = R->top_vals.data() + i * (size_t)P.hist_stride + P.hist_agg_off[a];
     return SYBL_OK;
 }
 
@@ -823,9 +858,10 @@ int query_finalize(Query *q, Result **out) {
         }
         std::vector<RowStore> &rows = R->rows[0];
         const size_t n = rows.size();
-        std::vector<uint32_t> order(n);
-        for (size_t i = 0; i < n; i++) order[i] = (uint32_t)i;
+        std::vector<uint32_t> &order = R->order0;
+        order.resize(n);
         if (n < 8192) {
+            for (size_t i = 0; i < n; i++) order[i] = (uint32_t)i;
             auto less = [&](uint32_t ix, uint32_t iy) {
                 const RowStore &x = rows[ix], &y = rows[iy];
                 if (by < 0) return x.count > y.count;
@@ -836,9 +872,15 @@ int query_finalize(Query *q, Result **out) {
             };
             std::stable_sort(order.begin(), order.end(), less);
         } else {
-            // many groups: stable LSD radix sort (16-bit digits) on a key whose ascending unsigned order is
-            // the descending order of Count / of the mean
-            std::vector<uint64_t> key(n);
+            // many groups: stable LSD radix sort (16-bit digits) of (key, index) pairs, the key's ascending unsigned
+            // order being the descending order of Count / of the mean.  Digits every key agrees on are skipped
+            // (counts of a uniform 65536-group table differ in their low 16 bits only: one pass).
+            struct KeyIx {
+                uint64_t key;
+                uint64_t ix;
+            };
+            std::vector<KeyIx> cur(n), nxt(n);
+            uint64_t differ = 0;
             for (size_t i = 0; i < n; i++) {
                 uint64_t u;
                 if (by < 0) {
@@ -851,29 +893,29 @@ int query_finalize(Query *q, Result **out) {
                     memcpy(&b, &m, 8);
                     u = (b >> 63) ? ~b : (b | 0x8000000000000000ull);
                 }
-                key[i] = ~u;
+                cur[i].key = ~u;
+                cur[i].ix = i;
+                differ |= cur[i].key ^ cur[0].key;
             }
-            std::vector<uint32_t> tmp(n);
             std::vector<uint32_t> cnt(65536);
             for (int shift = 0; shift < 64; shift += 16) {
+                if (((differ >> shift) & 0xFFFFu) == 0) continue;
                 std::fill(cnt.begin(), cnt.end(), 0u);
-                for (size_t i = 0; i < n; i++) cnt[(key[order[i]] >> shift) & 0xFFFFu]++;
-                if (cnt[(key[order[0]] >> shift) & 0xFFFFu] == n) continue;  // every key shares this digit
+                for (size_t i = 0; i < n; i++) cnt[(cur[i].key >> shift) & 0xFFFFu]++;
                 uint32_t run = 0;
                 for (size_t d = 0; d < 65536; d++) {
                     uint32_t c2 = cnt[d];
                     cnt[d] = run;
                     run += c2;
                 }
-                for (size_t i = 0; i < n; i++) tmp[cnt[(key[order[i]] >> shift) & 0xFFFFu]++] = order[i];
-                order.swap(tmp);
+                for (size_t i = 0; i < n; i++) nxt[cnt[(cur[i].key >> shift) & 0xFFFFu]++] = cur[i];
+                cur.swap(nxt);
             }
+            for (size_t i = 0; i < n; i++) order[i] = (uint32_t)cur[i].ix;
         }
         if (q->order_asc) std::reverse(order.begin(), order.end());
-        std::vector<RowStore> &sorted = R->rows_tmp;  // (recycled like the other arrays)
-        sorted.resize(n);
-        for (size_t i = 0; i < n; i++) std::swap(sorted[i], rows[order[i]]);
-        rows.swap(sorted);
+    } else {
+        R->order0.clear();
     }
     trace.mark("sort");
     R->top_vals.clear();

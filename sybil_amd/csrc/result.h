@@ -43,7 +43,7 @@ struct RowStore {
 // in munmap on free) than building its rows does.
 struct ResultStore {
     std::vector<RowStore> rows[3];
-    std::vector<RowStore> rows_tmp;  // sort scratch
+    std::vector<uint32_t> order0;    // SortResults: position -> index into rows[0] (empty = as built); the rows stay where they were built
     std::vector<sybl_group_row> view[3];
     std::vector<int64_t> pct_pool, pctoff_pool;
     std::vector<sybl_agg_out> agg_pool;
@@ -54,7 +54,7 @@ struct ResultStore {
             rows[w].swap(o.rows[w]);
             view[w].swap(o.view[w]);
         }
-        rows_tmp.swap(o.rows_tmp);
+        order0.swap(o.order0);
         pct_pool.swap(o.pct_pool);
         pctoff_pool.swap(o.pctoff_pool);
         agg_pool.swap(o.agg_pool);
@@ -73,6 +73,8 @@ struct ResultPool {
 };
 
 struct Result : ResultStore {
+    const RowStore &sorted0(size_t i) const { return rows[0][order0.empty() ? i : order0[i]]; }
+    RowStore &sorted0(size_t i) { return rows[0][order0.empty() ? i : order0[i]]; }
     std::shared_ptr<ResultPool> pool;  // where the arrays go back to when the result is freed
     ~Result() {
         if (!pool) return;
