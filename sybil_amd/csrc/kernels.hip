@@ -517,12 +517,12 @@ hipError_t launch_remap_ids(const void *local, int local_width, const int32_t *l
 
 // ---------------------------------------------------------------- partitioned histograms
 // k_part_hist: one workgroup owns one partition = kPartCells (cell, agg) pairs.  Their bucket
-// arrays (uint32) and exact remainder sums live in LDS; every record costs two LDS atomics (three
+// arrays (uint32) and exact sums of v - h.Min live in LDS (the bucket divide is done here, not in k_emit); every record costs two LDS atomics (three
 // when a maximum is tracked); the results are written with plain stores (each pair has exactly one
 // owner), so the [cell][agg][bucket] table, Count and sum(v) come out deterministic and
 // atomics-free in HBM.  The partition buffer is whole 16-record chunks up to its cursor, padded
 // with kRecSentinel (scan_fast.h).
-constexpr int kPartSumRep = 8;   // replicas of the per-pair remainder sums (lanes of a wave hit only 32 pairs)
+constexpr int kPartSumRep = 8;   // replicas of the per-pair value sums (lanes of a wave hit only 32 pairs)
 constexpr int kPartUnroll = 4;   // 16-byte record loads per lane in flight, twice (current + next)
 
 __global__ __launch_bounds__(kWgThreads) void k_part_hist(const PartHistPlan P) {
@@ -548,22 +548,29 @@ __global__ __launch_bounds__(kWgThreads) void k_part_hist(const PartHistPlan P) 
     const uint32_t i1 = p0 + (uint32_t)((uint64_t)n_chunks * (sub + 1) / split) * kEmitChunk;
     const uint32_t *recs = P.recs;
     const uint32_t pair0 = part * kPartCells;
-    const uint32_t rb = (uint32_t)P.rem_bits[0];  // equal for every aggregation (planner)
     unsigned long long *my_sum = sum + (tid & (kPartSumRep - 1)) * kPartCells;
     const bool track_max = P.m_max[0] >= 0 || (P.n_aggs > 1 && P.m_max[1] >= 0);
+    // pair0 is a multiple of kPartCells, so with one or two aggregations a pair's aggregation is a bit of `local`
+    const bool two = P.n_aggs == 2;
+    const uint32_t bs0 = (uint32_t)P.bucket_size[0], bs1 = (uint32_t)P.bucket_size[two ? 1 : 0];
+    const double inv0 = P.pinv_bucket[0], inv1 = P.pinv_bucket[two ? 1 : 0];
     auto add_record = [&](uint32_t rec) {
         if (rec == kRecSentinel) return;
-        const uint32_t rem = rec & ((1u << rb) - 1);
-        const uint32_t b = (rec >> rb) & ((1u << kBucketBits) - 1);
-        const uint32_t local = rec >> (rb + kBucketBits);
-        // (the pair's count is the sum of its buckets and sum(b * BucketSize) follows from them: both are
-        // taken at read-out, only the remainders need an accumulator of their own)
+        const uint32_t n32 = rec & ((1u << kRecValueBits) - 1);  // v - h.Min
+        const uint32_t local = rec >> kRecValueBits;
+        const uint32_t a = two ? (local & 1u) : (P.n_aggs == 1 ? 0u : (pair0 + local) % (uint32_t)P.n_aggs);
+        const uint32_t bs = P.n_aggs <= 2 ? (a ? bs1 : bs0) : (uint32_t)P.bucket_size[a];
+        const double inv = P.n_aggs <= 2 ? (a ? inv1 : inv0) : P.pinv_bucket[a];
+        // floor(n32 / BucketSize), hist_basic.go:130-150: the estimate is never above the quotient and at most one short
+        // of it (scan_packed.h: packed_udiv); bucket < 2^10 and BucketSize < 2^24 (planner), so the product takes 24 bits
+        uint32_t b = (uint32_t)((double)n32 * inv);
+        if (n32 - __umul24(b, bs) >= bs) b += 1;
+        // (the pair's count is the sum of its buckets, taken at read-out; sum(v - h.Min) is accumulated exactly)
         __hip_atomic_fetch_add(hist + local * nv + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(my_sum + local, (unsigned long long)rem, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(my_sum + local, (unsigned long long)n32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (track_max) {
-            const uint32_t a = P.n_aggs == 1 ? 0u : (pair0 + local) % (uint32_t)P.n_aggs;
             if (P.m_max[a] >= 0) {
-                const long long v = (long long)((unsigned long long)P.hmin[a] + (unsigned long long)b * (unsigned long long)P.bucket_size[a] + rem);
+                const long long v = (long long)((unsigned long long)P.hmin[a] + (unsigned long long)n32);
                 if (v > vmax[local]) __hip_atomic_fetch_max(vmax + local, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
@@ -592,26 +599,13 @@ __global__ __launch_bounds__(kWgThreads) void k_part_hist(const PartHistPlan P) 
         for (int u = 0; u < kPartUnroll; u++) cur[u] = nxt[u];
     }
     __syncthreads();
-    // cnt[l] = sum over the buckets of pair l, sum[0][l] += sum over the buckets of b * hist[l][b] * BucketSize:
-    // each wave sums a strided share, one LDS atomic per wave
+    // cnt[l] = sum over the buckets of pair l: each wave sums a strided share, one LDS atomic per wave
     for (uint32_t l = 0; l < (uint32_t)kPartCells; l++) {
-        const uint32_t a = P.n_aggs == 1 ? 0u : (pair0 + l) % (uint32_t)P.n_aggs;
         uint32_t n = 0;
-        unsigned long long sb = 0;
-        for (uint32_t b = tid; b < nv; b += kWgThreads) {
-            const uint32_t x = hist[l * nv + b];
-            n += x;
-            sb += (unsigned long long)b * x;
-        }
+        for (uint32_t b = tid; b < nv; b += kWgThreads) n += hist[l * nv + b];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            n += __shfl_xor(n, o, 64);
-            sb += __shfl_xor(sb, o, 64);
-        }
-        if ((tid & 63) == 0 && n) {
-            __hip_atomic_fetch_add(cnt + l, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_add(sum + l, sb * (unsigned long long)P.bucket_size[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
+        for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
+        if ((tid & 63) == 0 && n) __hip_atomic_fetch_add(cnt + l, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     __syncthreads();
     if (tid < kPartCells) {

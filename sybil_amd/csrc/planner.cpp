@@ -354,19 +354,12 @@ static int select_part_hist(Table *t, Query *q, const std::vector<int> &slot_col
     bool any_max, all_max, gen, packed = false;
     if (!fill_fast_columns(t, q, slot_col, E.fp, &nf, &ng, &na, &any_max, &all_max, false, &gen, &packed)) return SYBL_OK;
     q->part_packed = packed;
-    int rb = 0;
+    // a record is (local pair, v - h.Min): the value part must fit kRecValueBits, stay clear of kRecSentinel (all ones:
+    // local pair 31 and every value bit set), and k_part_hist's divide multiplies bucket x BucketSize in 24 bits
     for (auto &ai : q->aggs) {
-        if (ai.d.n_values > (1 << kBucketBits)) return SYBL_OK;
-        int bits = 0;
-        while (((int64_t)1 << bits) < ai.d.bucket_size) bits++;
-        rb = std::max(rb, bits);
+        if (ai.d.n_values > (1 << kBucketBits) || ai.d.bucket_size >= ((int64_t)1 << 24)) return SYBL_OK;
+        if ((int64_t)ai.d.n_values * ai.d.bucket_size >= ((int64_t)1 << kRecValueBits)) return SYBL_OK;
     }
-    if (kPartCellBits + kBucketBits + rb > 32) return SYBL_OK;
-    // kRecSentinel (all ones) must not be a record: it would need local pair 31, bucket 1023 and every
-    // remainder bit set
-    if (kPartCellBits + kBucketBits + rb == 32)
-        for (auto &ai : q->aggs)
-            if (ai.d.n_values >= (1 << kBucketBits) && ai.d.bucket_size == ((int64_t)1 << rb)) return SYBL_OK;
     int64_t pairs = (int64_t)P.n_cells * na;
     int64_t n_parts = (pairs + kPartCells - 1) / kPartCells;
     if (n_parts > kMaxParts) return SYBL_OK;
@@ -415,8 +408,7 @@ static int select_part_hist(Table *t, Query *q, const std::vector<int> &slot_col
     int nv_max = 0;
     for (int a = 0; a < na; a++) {
         const AggDesc &A = q->aggs[(size_t)a].d;
-        E.rem_bits[a] = rb;
-        H.rem_bits[a] = rb;
+        H.pinv_bucket[a] = (1.0 / (double)A.bucket_size) * (1.0 - 0x1p-40);
         H.n_values[a] = A.n_values;
         H.f_sum[a] = A.f_sum;
         H.m_max[a] = A.m_max;

@@ -482,9 +482,11 @@ static int attach_top_values(Query *q, Result *R, size_t top) {
         SYBL_HIP(hipMemcpyAsync(R->top_vals.data(), q->d_top, R->top_vals.size() * 8, hipMemcpyDeviceToHost, st));
         SYBL_HIP(hipStreamSynchronize(st));
     } else if (top <= kTopDmaRows && !getenv("SYBL_TOP_GATHER_KERNEL")) {
-        // A printer's worth of rows: one DMA copy per row, straight out of the table into pinned memory.  No kernel:
-        // a gather kernel on the auxiliary stream gets no CU while another query's persistent scan workgroups hold the
-        // register files (measured: it waited 4.7 ms for k_emit to end), the copy engines are not part of that.
+        // A printer's worth of rows: one asynchronous copy per row, straight out of the table into pinned memory.
+        // Measured on config 4 (two queries pipelined): the gather kernel below, queued on the auxiliary stream with
+        // pageable source / destination buffers, completed only when the other query's k_emit had ended (4.7 ms per
+        // finalize, whatever the stream's priority); these copies (the runtime turns each into a one-workgroup
+        // __amd_rocclr_copyBuffer blit, profiles/r02c_cfg4_kernel_trace.txt) take 0.3-0.7 ms under the same scan.
         const size_t words = top * (size_t)P.hist_stride;
         if ((int64_t)words > q->h_top_words) {
             if (q->h_top) SYBL_HIP(hipHostFree(q->h_top));

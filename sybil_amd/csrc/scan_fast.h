@@ -110,6 +110,7 @@ hipError_t launch_scan_fast(const FastPlan &P, int nf, int ng, int na, int mode,
 constexpr int kPartCells = 32;       // (cell, agg) pairs per partition
 constexpr int kPartCellBits = 5;
 constexpr int kBucketBits = 10;      // len(Values) <= 1024
+constexpr int kRecValueBits = 27;    // v - h.Min < len(Values) * BucketSize <= 2^10 * 2^17 (planner: select_part_hist)
 constexpr int kMaxParts = 2048;      // LDS staging in k_emit: one 16-record chunk per bin
 constexpr int kEmitMaxBins = 2048;   // bins = n_parts << sub_shift
 constexpr uint32_t kEmitChunk = 16;  // records per chunk
@@ -128,7 +129,6 @@ struct EmitPlan {
     int32_t sub_shift;               // bins per partition = 1 << sub_shift (lanes spread over them so that
                                      // few partitions do not serialise on one LDS counter)
     int32_t count_rep_shift;         // k_count: 1 << count_rep_shift replicas of the partition counters
-    int32_t rem_bits[kFastMaxA];     // bits of (v - hmin) % BucketSize kept in the record
     int64_t *sum_out;                // header: matched / overflow
 };
 
@@ -137,8 +137,9 @@ struct PartHistPlan {
     const uint32_t *part_off;
     int32_t n_parts, n_aggs, n_cells, nv_max;
     int32_t split;                   // workgroups per partition (> 1: results are combined with atomics)
-    int32_t rem_bits[kFastMaxA], n_values[kFastMaxA], f_sum[kFastMaxA], m_max[kFastMaxA];
+    int32_t n_values[kFastMaxA], f_sum[kFastMaxA], m_max[kFastMaxA];
     int64_t hmin[kFastMaxA], bucket_size[kFastMaxA], hist_agg_off[kFastMaxA];
+    double pinv_bucket[kFastMaxA];   // 1 / BucketSize scaled by (1 - 2^-40): the quotient estimate is never above the true one
     int64_t hist_off, hist_stride;
     int64_t *sum_out, *max_out;
 };
@@ -561,7 +562,8 @@ __global__ __launch_bounds__(kWgThreads, 4) void k_scan_fast(const FastPlan P) {
 }
 
 // k_emit: filters + cell index exactly as k_scan_fast, but instead of accumulating it appends
-// rec = (local pair << 10 | bucket) << rem_bits | remainder to the owning partition.
+// rec = local pair << 27 | (v - h.Min) to the owning partition (the bucket divide happens in k_part_hist, which has
+// the issue slots to spare: k_emit is VALU-issue bound).
 //
 // LDS staging of k_emit / k_emit_packed, per bin (nb = n_parts << sub_shift bins):
 //   cnt   records pushed so far: a push takes slot s = cnt++, generation g = s / 16
@@ -650,75 +652,91 @@ struct EmitBinPack {
     }
 };
 
-// Pushes the lane's records i with bit i of `act` set, rec[i] into bin[i], and the record carried over from
-// the previous call; last_call: nothing may be left behind.
+// The chunks this lane's writes completed (bit i of `full`: record i was the sixteenth of its generation): copied to
+// the next free chunk of the workgroup's region.  A lane rarely owns more than one per tile, so loop over the lane's
+// own instead of running the copy once per record position.
+template <int M>
+__device__ __forceinline__ void emit_copy_full(const EmitPlan &E, const EmitLds &S, const EmitBinPack<M> &packed_bins, uint32_t full) {
+    while (full) {
+        const uint32_t i = (uint32_t)__builtin_ctz(full);
+        full &= full - 1;
+        const uint32_t b = packed_bins.get(i);
+        const uint32_t p = __hip_atomic_fetch_add(S.pos + (b >> S.ss), kEmitChunk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const fu32x4 *c = (const fu32x4 *)(S.chunk + b * kEmitChunk);
+        const fu32x4 r0 = c[0], r1 = c[1], r2 = c[2], r3 = c[3];
+        emit_store_chunk(E, p, r0, r1, r2, r3);
+        lds_wait();  // the chunk has been read before the next generation may write
+        __hip_atomic_fetch_add(S.wr + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+}
+
+// Pushes the lane's records i with act[i] set, rec[i] into bin[i], and the record carried over from the previous
+// call; last_call: nothing may be left behind.  The first pass -- all there is for most lanes and tiles -- keeps its
+// predicates as booleans (lane masks in scalar registers); only a wave with a record left over goes on to the
+// bit-mask bookkeeping of the retry loop (a bit mask per lane costs a v_and + v_cmp per record and use: 45 VALU
+// instructions per tile in a kernel that is VALU-issue bound).
 template <int N>
 __device__ __forceinline__ void emit_push_all(const EmitPlan &E, const EmitLds &S, const uint32_t (&bin_in)[N], const uint32_t (&rec_in)[N],
-                                              uint32_t act, EmitCarry &carry, bool last_call = false) {
+                                              const bool (&act)[N], EmitCarry &carry, bool last_call = false) {
     constexpr int M = N + 1;
     uint32_t bin[M], rec[M], slot[M], w[M];
+    bool pend[M];
 #pragma unroll
     for (int i = 0; i < N; i++) {
         bin[i] = bin_in[i];
         rec[i] = rec_in[i];
+        pend[i] = act[i];
     }
     bin[N] = carry.bin;
     rec[N] = carry.rec;
+    pend[N] = carry.valid != 0;
     // one LDS round trip in the common case: the slots and the bins' wr words (wr only grows: a value read
     // early errs on the side of waiting)
 #pragma unroll
     for (int i = 0; i < N; i++)
-        slot[i] = (act >> i) & 1u ? __hip_atomic_fetch_add(S.cnt + bin[i], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
+        slot[i] = pend[i] ? __hip_atomic_fetch_add(S.cnt + bin[i], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
     slot[N] = carry.slot;
-    uint32_t pend = act | (carry.valid ? 1u << N : 0u);
 #pragma unroll
-    for (int i = 0; i < M; i++)
-        w[i] = (pend >> i) & 1u ? __hip_atomic_load(S.wr + bin[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
+    for (int i = 0; i < M; i++) w[i] = pend[i] ? __hip_atomic_load(S.wr + bin[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
     const EmitBinPack<M> packed_bins(bin);
-    uint32_t passes = 0;
     carry.valid = 0;
+    // ---- first pass
+    lds_order();
+    bool ok[M];
+#pragma unroll
+    for (int i = 0; i < M; i++) {
+        ok[i] = pend[i] && w[i] >= 17u * (slot[i] >> 4);
+        if (ok[i]) S.chunk[bin[i] * kEmitChunk + ((slot[i] + (bin[i] >> 1)) & (kEmitChunk - 1))] = rec[i];
+    }
+    lds_order();  // the records go to LDS before wr says so (issue order)
+    uint32_t old[M];
+#pragma unroll
+    for (int i = 0; i < M; i++) old[i] = ok[i] ? __hip_atomic_fetch_add(S.wr + bin[i], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
+    uint32_t full = 0;
+    bool left = false;
+#pragma unroll
+    for (int i = 0; i < M; i++) {
+        full |= ok[i] && old[i] == 17u * (slot[i] >> 4) + (kEmitChunk - 1) ? 1u << i : 0u;
+        pend[i] = pend[i] && !ok[i];
+        left = left || pend[i];
+    }
+    lds_order();  // the chunk is read after wr showed the other 15 records in place
+    emit_copy_full<M>(E, S, packed_bins, full);
+    if (!__builtin_amdgcn_ballot_w64(left)) return;
+    // ---- some lane of the wave holds a record whose chunk is still waiting to be copied out
+    uint32_t pmask = 0;
+#pragma unroll
+    for (int i = 0; i < M; i++) pmask |= pend[i] ? 1u << i : 0u;
+    uint32_t passes = 0;
     while (true) {
-        lds_order();
-        uint32_t ok = 0;
-#pragma unroll
-        for (int i = 0; i < M; i++) {
-            if (((pend >> i) & 1u) && w[i] >= 17u * (slot[i] >> 4)) {
-                S.chunk[bin[i] * kEmitChunk + ((slot[i] + (bin[i] >> 1)) & (kEmitChunk - 1))] = rec[i];
-                ok |= 1u << i;
-            }
-        }
-        lds_order();  // the records go to LDS before wr says so (issue order)
-        uint32_t old[M];
-#pragma unroll
-        for (int i = 0; i < M; i++)
-            old[i] = (ok >> i) & 1u ? __hip_atomic_fetch_add(S.wr + bin[i], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
-        uint32_t full = 0;
-#pragma unroll
-        for (int i = 0; i < M; i++)
-            full |= ((ok >> i) & 1u) && old[i] == 17u * (slot[i] >> 4) + (kEmitChunk - 1) ? 1u << i : 0u;
-        lds_order();  // the chunk is read after wr showed the other 15 records in place
-        // complete chunks: a lane rarely owns more than one per tile, so loop over the lane's own
-        // instead of running the copy once per record position
-        while (full) {
-            const uint32_t i = (uint32_t)__builtin_ctz(full);
-            full &= full - 1;
-            const uint32_t b = packed_bins.get(i);
-            const uint32_t p = __hip_atomic_fetch_add(S.pos + (b >> S.ss), kEmitChunk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            const fu32x4 *c = (const fu32x4 *)(S.chunk + b * kEmitChunk);
-            const fu32x4 r0 = c[0], r1 = c[1], r2 = c[2], r3 = c[3];
-            emit_store_chunk(E, p, r0, r1, r2, r3);
-            lds_wait();  // the chunk has been read before the next generation may write
-            __hip_atomic_fetch_add(S.wr + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-        pend &= ~ok;
         // Leave with at most one record per lane in hand -- but only if that holds for the WHOLE wave: a lane
         // that stays to poll may be waiting for a generation another lane of this wave has a slot in, and
         // that lane must then keep retrying too (it cannot come back before the wave leaves this call).
-        const bool must_stay = pend != 0 && (last_call || passes != 0 || (pend & (pend - 1)) != 0);
+        const bool must_stay = pmask != 0 && (last_call || passes != 0 || (pmask & (pmask - 1)) != 0);
         if (!__builtin_amdgcn_ballot_w64(must_stay)) {
-            if (pend) {
+            if (pmask) {
                 carry.valid = 1;
-                const uint32_t i = (uint32_t)__builtin_ctz(pend);
+                const uint32_t i = (uint32_t)__builtin_ctz(pmask);
                 carry.bin = packed_bins.get(i);
 #pragma unroll
                 for (int k = 0; k < M; k++)
@@ -729,7 +747,7 @@ __device__ __forceinline__ void emit_push_all(const EmitPlan &E, const EmitLds &
             }
             break;
         }
-        if (!pend) break;
+        if (!pmask) break;
         // poll again (bounded: a protocol bug must surface as an error from finalize, not as a hung GPU)
         if (++passes > (1u << 22)) {
             __hip_atomic_fetch_add(E.sum_out + kHdrEmitStall, (int64_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -737,19 +755,38 @@ __device__ __forceinline__ void emit_push_all(const EmitPlan &E, const EmitLds &
         }
 #pragma unroll
         for (int i = 0; i < M; i++)
-            w[i] = (pend >> i) & 1u ? __hip_atomic_load(S.wr + bin[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
+            w[i] = (pmask >> i) & 1u ? __hip_atomic_load(S.wr + bin[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
+        lds_order();
+        uint32_t okm = 0;
+#pragma unroll
+        for (int i = 0; i < M; i++) {
+            if (((pmask >> i) & 1u) && w[i] >= 17u * (slot[i] >> 4)) {
+                S.chunk[bin[i] * kEmitChunk + ((slot[i] + (bin[i] >> 1)) & (kEmitChunk - 1))] = rec[i];
+                okm |= 1u << i;
+            }
+        }
+        lds_order();
+#pragma unroll
+        for (int i = 0; i < M; i++)
+            old[i] = (okm >> i) & 1u ? __hip_atomic_fetch_add(S.wr + bin[i], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
+        full = 0;
+#pragma unroll
+        for (int i = 0; i < M; i++)
+            full |= ((okm >> i) & 1u) && old[i] == 17u * (slot[i] >> 4) + (kEmitChunk - 1) ? 1u << i : 0u;
+        lds_order();
+        emit_copy_full<M>(E, S, packed_bins, full);
+        pmask &= ~okm;
     }
 }
 
 // A wave has pushed its last record: the carried one, if any, goes in now.
 __device__ __forceinline__ void emit_scan_done(const EmitPlan &E, const EmitLds &S, EmitCarry &carry) {
     const uint32_t none[1] = {0};
-    emit_push_all<1>(E, S, none, none, 0u, carry, true);
+    const bool nobody[1] = {false};
+    emit_push_all<1>(E, S, none, none, nobody, carry, true);
 }
 
-__device__ __forceinline__ uint32_t emit_record(uint32_t pair, uint32_t b, uint32_t rem, int rem_bits) {
-    return ((((pair & (kPartCells - 1)) << kBucketBits) | b) << rem_bits) | rem;
-}
+__device__ __forceinline__ uint32_t emit_record(uint32_t pair, uint32_t n32) { return ((pair & (kPartCells - 1)) << kRecValueBits) | n32; }
 __device__ __forceinline__ uint32_t emit_bin(const EmitLds &S, uint32_t pair) { return ((pair >> kPartCellBits) << S.ss) | S.sub; }
 
 // Final drain: every bin's incomplete chunk goes out padded with sentinels, and so do the chunks of the
@@ -905,7 +942,8 @@ __global__ __launch_bounds__(kWgThreads, 4) void k_emit(const EmitPlan E) {
             const FastTile<NG> g0 = gr[d];
             const FastTile<NA> a0 = ar[d];
             fast_load<NF, NG, NA, false>(P, in_seg(row + (int64_t)D * kTile), fr[d], gr[d], ar[d], t0);
-            uint32_t bin[kRowsPerThread * NA], rec[kRowsPerThread * NA], act = 0;
+            uint32_t bin[kRowsPerThread * NA], rec[kRowsPerThread * NA];
+            bool act[kRowsPerThread * NA];
 #pragma unroll
             for (int r = 0; r < kRowsPerThread; r++) {
                 bool pass = row + r < end;
@@ -929,19 +967,10 @@ __global__ __launch_bounds__(kWgThreads, 4) void k_emit(const EmitPlan E) {
                 for (int c = 0; c < NA; c++) {
                     const int64_t x = r == 0 ? a0.v[c].x : a0.v[c].y;
                     const uint32_t n = (uint32_t)((uint64_t)x - (uint64_t)P.hmin[c]);
-                    uint32_t b = (uint32_t)((double)n * P.inv_bucket[c]);
-                    int32_t rem = (int32_t)(n - b * P.bucket_size[c]);
-                    if (rem < 0) {
-                        b -= 1;
-                        rem += (int32_t)P.bucket_size[c];
-                    } else if ((uint32_t)rem >= P.bucket_size[c]) {
-                        b += 1;
-                        rem -= (int32_t)P.bucket_size[c];
-                    }
                     const uint32_t pair = cell * (uint32_t)NA + (uint32_t)c;
                     bin[r * NA + c] = emit_bin(S, pair);
-                    rec[r * NA + c] = emit_record(pair, b, (uint32_t)rem, E.rem_bits[c]);
-                    act |= (pass && inb) ? 1u << (r * NA + c) : 0u;
+                    rec[r * NA + c] = emit_record(pair, n);
+                    act[r * NA + c] = pass && inb;
                 }
             }
             emit_push_all<kRowsPerThread * NA>(E, S, bin, rec, act, carry);

@@ -404,7 +404,8 @@ __global__ __launch_bounds__(kWgThreads, 4) void k_emit_packed(const EmitPlan E)
                 packed_decode_all<NF, NG, NA, false, false, false>(P, rf[d], rg[d], ra[d], rt, f, g, a, t, 0u);
                 packed_issue_always<NF, NG, NA>(P, B, r + (uint32_t)D * kTile, n, rf[d], rg[d], ra[d]);
                 const uint32_t left = r < n ? n - r : 0u;
-                uint32_t bin[kPackedRows * NA], rec[kPackedRows * NA], act = 0;
+                uint32_t bin[kPackedRows * NA], rec[kPackedRows * NA];
+                bool act[kPackedRows * NA];
 #pragma unroll
                 for (int k = 0; k < kPackedRows; k++) {
                     bool pass = (uint32_t)k < left;
@@ -426,11 +427,10 @@ __global__ __launch_bounds__(kWgThreads, 4) void k_emit_packed(const EmitPlan E)
 #pragma unroll
                     for (int c = 0; c < NA; c++) {
                         const uint32_t n32 = a.u[c][k] + P.adoff[c];  // value - h.Min
-                        const uint32_t b = packed_udiv(n32, P.bucket_size[c], P.pinv_bucket[c]);
                         const uint32_t pair = cell * (uint32_t)NA + (uint32_t)c;
                         bin[k * NA + c] = emit_bin(S, pair);
-                        rec[k * NA + c] = emit_record(pair, b, n32 - b * P.bucket_size[c], E.rem_bits[c]);
-                        act |= (pass & inb) ? 1u << (k * NA + c) : 0u;
+                        rec[k * NA + c] = emit_record(pair, n32);
+                        act[k * NA + c] = pass & inb;
                     }
                 }
                 emit_push_all<kPackedRows * NA>(E, S, bin, rec, act, carry);

@@ -11,12 +11,12 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd $R
 CMD="python tools/bench_configs.py ${ROWS:-0} 3 $WL $STORAGE"
-rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt -- $CMD > $OUT/kt.log 2>&1
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $OUT/pmc1 -o pmc1 -- $CMD > $OUT/pmc1.log 2>&1
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES -d $OUT/pmc2 -o pmc2 -- $CMD > $OUT/pmc2.log 2>&1
-rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE -d $OUT/pmc3 -o pmc3 -- $CMD > $OUT/pmc3.log 2>&1
-rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d $OUT/pmc4 -o pmc4 -- $CMD > $OUT/pmc4.log 2>&1
-rocprofv3 --pmc TCC_ATOMIC_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_RDREQ_sum -d $OUT/pmc5 -o pmc5 -- $CMD > $OUT/pmc5.log 2>&1
+timeout -k 10 900 rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt -- $CMD > $OUT/kt.log 2>&1
+timeout -k 10 900 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $OUT/pmc1 -o pmc1 -- $CMD > $OUT/pmc1.log 2>&1
+timeout -k 10 900 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES -d $OUT/pmc2 -o pmc2 -- $CMD > $OUT/pmc2.log 2>&1
+timeout -k 10 900 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE -d $OUT/pmc3 -o pmc3 -- $CMD > $OUT/pmc3.log 2>&1
+timeout -k 10 900 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d $OUT/pmc4 -o pmc4 -- $CMD > $OUT/pmc4.log 2>&1
+timeout -k 10 900 rocprofv3 --pmc TCC_ATOMIC_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_RDREQ_sum -d $OUT/pmc5 -o pmc5 -- $CMD > $OUT/pmc5.log 2>&1
 FILT="rocclr\|k_synth\|k_block_minmax\|k_fill\|k_repack"
 {
   echo "# rocprofv3 --kernel-trace --stats -- $CMD   (MI355X, $(date -u +%Y-%m-%dT%H:%MZ))"

@@ -1,6 +1,6 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; cd $R; mkdir -p gpurun_out/prof5
-rocprofv3 --kernel-trace --stats -d gpurun_out/prof5/kt -o kt -- python tools/bench_fewgroups.py > gpurun_out/prof5/kt.log 2>&1
+timeout -k 10 900 rocprofv3 --kernel-trace --stats -d gpurun_out/prof5/kt -o kt -- python tools/bench_fewgroups.py > gpurun_out/prof5/kt.log 2>&1
 python - <<'PY'
 import sqlite3, glob
 c = sqlite3.connect(glob.glob('gpurun_out/prof5/kt/*.db')[0])

@@ -1,9 +1,9 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; cd $R; mkdir -p gpurun_out/prof4
-rocprofv3 --kernel-trace --stats -d gpurun_out/prof4/kt -o kt -- python tools/bench_configs.py 0 3 cfg4 > gpurun_out/prof4/kt.log 2>&1
+timeout -k 10 900 rocprofv3 --kernel-trace --stats -d gpurun_out/prof4/kt -o kt -- python tools/bench_configs.py 0 3 cfg4 > gpurun_out/prof4/kt.log 2>&1
 python tools/rocpd_summary.py gpurun_out/prof4/kt/*.db | cut -c1-170 | head -12
 grep "^{" gpurun_out/prof4/kt.log
-rocprofv3 --kernel-trace --stats -d gpurun_out/prof4/kt3 -o kt3 -- python -c "
+timeout -k 10 900 rocprofv3 --kernel-trace --stats -d gpurun_out/prof4/kt3 -o kt3 -- python -c "
 import sys; sys.path.insert(0,'.')
 import sybil_amd
 from sybil_amd import synth
