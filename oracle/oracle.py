@@ -19,6 +19,7 @@ AGG_AVG, AGG_HIST = 0, 1
 SYN_UNIFORM, SYN_TIME, SYN_BELL = 0, 1, 2
 MAX_GROUPS = 8
 MAX_AGGS = 8
+LLB_M = 1 << 14  # ORC_LLB_M: registers of a count-distinct sketch
 
 
 def build(force=False):
@@ -52,7 +53,9 @@ class _Query(C.Structure):
                 ("op", C.c_int32), ("hist_bucket", C.c_int64),
                 ("time_col", C.c_int32), ("time_bucket", C.c_int64),
                 ("weight_col", C.c_int32), ("block_skip", C.c_int32),
-                ("block_rows", C.c_int64), ("n_threads", C.c_int32), ("loghist", C.c_int32)]
+                ("block_rows", C.c_int64), ("n_threads", C.c_int32), ("loghist", C.c_int32),
+                ("n_distincts", C.c_int32), ("distinct_cols", C.c_int32 * MAX_GROUPS),
+                ("distinct_dicts", C.POINTER(C.c_char_p) * MAX_GROUPS), ("distinct_dict_len", C.c_int64 * MAX_GROUPS)]
 
 
 class HistInfo(C.Structure):
@@ -87,6 +90,15 @@ def lib():
         L.orc_result_get.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.POINTER(C.c_int64),
                                      C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.orc_result_hist.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.POINTER(HistInfo)]
+        L.orc_result_distinct.restype = C.c_int64
+        L.orc_result_distinct.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p]
+        L.orc_metro64.restype = C.c_uint64
+        L.orc_metro64.argtypes = [C.c_char_p, C.c_int64, C.c_uint64]
+        L.orc_llb_add_hash.argtypes = [C.c_void_p, C.c_uint64]
+        L.orc_llb_add.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+        L.orc_llb_merge.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_llb_cardinality.restype = C.c_uint64
+        L.orc_llb_cardinality.argtypes = [C.c_void_p]
         L.orc_result_hist_values.restype = C.c_int64
         L.orc_result_hist_values.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_int64]
         L.orc_result_percentiles.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p]
@@ -133,6 +145,30 @@ def lib():
                                         C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
         _lib = L
     return _lib
+
+
+def metro64(data, seed=1337):
+    """MetroHash64 of bytes (go-metro Hash64; loglogbeta hashes with seed 1337)."""
+    return lib().orc_metro64(bytes(data), len(data), seed)
+
+
+class LogLogBeta:
+    """The reference's count-distinct sketch (github.com/logv/loglogbeta, restated: see sybil_oracle.h)."""
+
+    def __init__(self, registers=None):
+        self.registers = np.zeros(LLB_M, dtype=np.uint8) if registers is None else np.array(registers, dtype=np.uint8)
+
+    def add(self, value):
+        lib().orc_llb_add(_ptr(self.registers), bytes(value), len(value))
+
+    def add_hash(self, x):
+        lib().orc_llb_add_hash(_ptr(self.registers), x)
+
+    def merge(self, other):
+        lib().orc_llb_merge(_ptr(self.registers), _ptr(other.registers))
+
+    def cardinality(self):
+        return lib().orc_llb_cardinality(_ptr(self.registers))
 
 
 def _ptr(a):
@@ -365,8 +401,11 @@ def synth_scan(columns, seed, total_rows, row0, nrows, filters=(), groups=(), ag
 
 # ---------------------------------------------------------------- full query
 def run_query(cols, filters=(), groups=(), aggs=(), op="avg", hist_bucket=0, time_col=-1, time_bucket=0,
-              weight_col=-1, block_skip=False, block_rows=65536, n_threads=1, want_values=True, loghist=False):
+              weight_col=-1, block_skip=False, block_rows=65536, n_threads=1, want_values=True, loghist=False,
+              distincts=(), distinct_dicts=None, want_registers=False):
     """cols: list of dicts {type: 'int'|'str'|'set', data, populated(optional), offsets(set)}
+    distincts: col indices of a count-distinct query (-distinct); distinct_dicts: {col index: [str, ...]} for str columns
+    (the reference's slow path hashes the strings).  Every result then carries "distinct" (+ "registers").
     filters: list of (col_index, op_name, value[, idtable]); groups: col indices;
     aggs: list of (col_index, info_min, info_max).
     Returns a dict with matched, results, time_results, cumulative (canonical order)."""
@@ -429,6 +468,15 @@ def run_query(cols, filters=(), groups=(), aggs=(), op="avg", hist_bucket=0, tim
     q.block_rows = block_rows
     q.n_threads = n_threads
     q.loghist = 1 if loghist else 0
+    q.n_distincts = len(distincts)
+    for i, d in enumerate(distincts):
+        q.distinct_cols[i] = d
+        strs = (distinct_dicts or {}).get(d)
+        if strs is not None:
+            arr = (C.c_char_p * max(len(strs), 1))(*[x.encode() if isinstance(x, str) else x for x in strs])
+            keep.append(arr)
+            q.distinct_dicts[i] = C.cast(arr, C.POINTER(C.c_char_p))
+            q.distinct_dict_len[i] = len(strs)
 
     R = L.orc_query_run(C.byref(q), ccols, len(cols), nrows)
     try:
@@ -444,6 +492,11 @@ def run_query(cols, filters=(), groups=(), aggs=(), op="avg", hist_bucket=0, tim
                 kb = bytes(key)[:8 * ng]
                 r = {"key": kb, "key_vals": tuple(int.from_bytes(kb[8 * g:8 * g + 8], "little") for g in range(ng)),
                      "time_bucket": tb.value, "count": cnt.value, "samples": smp.value, "hists": []}
+                if distincts:
+                    regs = np.zeros(LLB_M, dtype=np.uint8) if want_registers else None
+                    r["distinct"] = L.orc_result_distinct(R, which, idx, _ptr(regs))
+                    if want_registers:
+                        r["registers"] = regs
                 for a in range(na):
                     hi = HistInfo()
                     L.orc_result_hist(R, which, idx, a, C.byref(hi))

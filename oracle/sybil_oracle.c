@@ -9,6 +9,7 @@
 #include "sybil_oracle.h"
 
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #ifdef _OPENMP
@@ -468,6 +469,7 @@ struct orc_result {
     int64_t time_bucket;
     int64_t count, samples;
     orc_hist *hists[ORC_MAX_AGGS];
+    uint8_t *llb; /* Result.Distinct (query_spec.go:87): ORC_LLB_M registers, NULL = none added yet (all zero) */
 };
 
 typedef struct {
@@ -546,6 +548,7 @@ static orc_result *result_new(const uint8_t *key, int key_len, int64_t tb) {
 static void result_free(orc_result *r) {
     if (!r) return;
     for (int a = 0; a < ORC_MAX_AGGS; a++) orc_hist_free(r->hists[a]);
+    free(r->llb);
     free(r);
 }
 
@@ -571,15 +574,143 @@ static void result_combine(orc_result *rs, const orc_result *next, const orc_que
         }
         orc_hist_combine(rs->hists[a], h);
     }
+    /* query_spec.go:180-188 combine count distincts */
+    if (next->llb) {
+        if (!rs->llb) rs->llb = (uint8_t *)calloc(ORC_LLB_M, 1);
+        orc_llb_merge(rs->llb, next->llb);
+    }
     rs->samples += next->samples;
     rs->count += next->count;
+}
+
+/* ------------------------------------------------------------------ */
+/* Count distinct: github.com/logv/loglogbeta (see the header: unpinned) */
+/* ------------------------------------------------------------------ */
+
+static inline int col_populated(const orc_col *c, int64_t row) { return c->populated ? c->populated[row] != 0 : 1; }
+
+static inline uint64_t rotr64(uint64_t v, unsigned k) { return (v >> k) | (v << (64 - k)); }
+static inline uint64_t rd_le(const uint8_t *p, int n) {
+    uint64_t v = 0;
+    for (int i = 0; i < n; i++) v |= (uint64_t)p[i] << (8 * i);
+    return v;
+}
+
+/* MetroHash64 v1 (metrohash64.cpp, MetroHash64::Hash) == go-metro Hash64(buffer, seed) */
+uint64_t orc_metro64(const uint8_t *ptr, int64_t len, uint64_t seed) {
+    const uint64_t k0 = 0xD6D018F5ull, k1 = 0xA2AA033Bull, k2 = 0x62992FC1ull, k3 = 0x30BC5B29ull;
+    const uint8_t *end = ptr + len;
+    uint64_t hash = (seed + k2) * k0;
+    if (len >= 32) {
+        uint64_t v0 = hash, v1 = hash, v2 = hash, v3 = hash;
+        do {
+            v0 += rd_le(ptr, 8) * k0; ptr += 8; v0 = rotr64(v0, 29) + v2;
+            v1 += rd_le(ptr, 8) * k1; ptr += 8; v1 = rotr64(v1, 29) + v3;
+            v2 += rd_le(ptr, 8) * k2; ptr += 8; v2 = rotr64(v2, 29) + v0;
+            v3 += rd_le(ptr, 8) * k3; ptr += 8; v3 = rotr64(v3, 29) + v1;
+        } while (ptr <= end - 32);
+        v2 ^= rotr64(((v0 + v3) * k0) + v1, 37) * k1;
+        v3 ^= rotr64(((v1 + v2) * k1) + v0, 37) * k0;
+        v0 ^= rotr64(((v0 + v2) * k0) + v3, 37) * k1;
+        v1 ^= rotr64(((v1 + v3) * k1) + v2, 37) * k0;
+        hash += v0 ^ v1;
+    }
+    if (end - ptr >= 16) {
+        uint64_t v0 = hash + rd_le(ptr, 8) * k2; ptr += 8; v0 = rotr64(v0, 29) * k3;
+        uint64_t v1 = hash + rd_le(ptr, 8) * k2; ptr += 8; v1 = rotr64(v1, 29) * k3;
+        v0 ^= rotr64(v0 * k0, 21) + v1;
+        v1 ^= rotr64(v1 * k3, 21) + v0;
+        hash += v1;
+    }
+    if (end - ptr >= 8) { hash += rd_le(ptr, 8) * k3; ptr += 8; hash ^= rotr64(hash, 55) * k1; }
+    if (end - ptr >= 4) { hash += rd_le(ptr, 4) * k3; ptr += 4; hash ^= rotr64(hash, 26) * k1; }
+    if (end - ptr >= 2) { hash += rd_le(ptr, 2) * k3; ptr += 2; hash ^= rotr64(hash, 48) * k1; }
+    if (end - ptr >= 1) { hash += rd_le(ptr, 1) * k3; hash ^= rotr64(hash, 37) * k1; }
+    hash ^= rotr64(hash, 28);
+    hash *= k0;
+    hash ^= rotr64(hash, 29);
+    return hash;
+}
+
+/* loglogbeta.go AddHash: k = top 14 bits; val = leading zeros of the rest (a guard of 14 one-bits below it) + 1 */
+void orc_llb_add_hash(uint8_t *regs, uint64_t x) {
+    const uint64_t k = x >> (64 - ORC_LLB_P);
+    const uint64_t rest = (x << ORC_LLB_P) ^ (UINT64_MAX >> (64 - ORC_LLB_P));
+    const uint8_t val = (uint8_t)(__builtin_clzll(rest) + 1); /* rest != 0: its low 14 bits are ones */
+    if (regs[k] < val) regs[k] = val;
+}
+
+void orc_llb_add(uint8_t *regs, const uint8_t *value, int64_t len) { orc_llb_add_hash(regs, orc_metro64(value, len, 1337)); }
+
+void orc_llb_merge(uint8_t *regs, const uint8_t *other) {
+    for (int i = 0; i < ORC_LLB_M; i++)
+        if (regs[i] < other[i]) regs[i] = other[i];
+}
+
+/* loglogbeta.go Cardinality: alpha m (m - ez) / (beta(ez) + sum 2^-reg), registers summed in index order */
+uint64_t orc_llb_cardinality(const uint8_t *regs) {
+    const double m = (double)ORC_LLB_M;
+    const double alpha = 0.7213 / (1.0 + 1.079 / m);
+    double sum = 0.0, ez = 0.0;
+    for (int i = 0; i < ORC_LLB_M; i++) {
+        if (regs[i] == 0) ez += 1.0;
+        sum += 1.0 / pow(2.0, (double)regs[i]);
+    }
+    const double zl = log(ez + 1.0);
+    const double beta = -0.370393911 * ez + 0.070471823 * zl + 0.17393686 * pow(zl, 2) + 0.16339839 * pow(zl, 3) +
+                        -0.09237745 * pow(zl, 4) + 0.03738027 * pow(zl, 5) + -0.005384159 * pow(zl, 6) + 0.00042419 * pow(zl, 7);
+    return (uint64_t)(alpha * m * (m - ez) / (beta + sum));
+}
+
+/* aggregate.go:205-243: the row's distinct value goes into the Result's sketch */
+static void distinct_add(const orc_query *q, const orc_col *cols, int64_t row, orc_result *r) {
+    if (!r->llb) r->llb = (uint8_t *)calloc(ORC_LLB_M, 1);
+    int only_ints = 1; /* :84-91, by column type */
+    for (int g = 0; g < q->n_distincts; g++)
+        if (cols[q->distinct_cols[g]].type != ORC_INT_VAL) only_ints = 0;
+    if (only_ints) { /* :208-222 fast path: 8 bytes per column, little endian, MISSING_VALUE when unpopulated */
+        uint8_t buf[ORC_GROUP_BY_WIDTH * ORC_MAX_GROUPS];
+        for (int g = 0; g < q->n_distincts; g++) {
+            const orc_col *c = &cols[q->distinct_cols[g]];
+            const uint64_t v = col_populated(c, row) ? (uint64_t)c->ints[row] : UINT64_MAX;
+            for (int b = 0; b < 8; b++) buf[g * 8 + b] = (uint8_t)(v >> (8 * b));
+        }
+        orc_llb_add(r->llb, buf, (int64_t)q->n_distincts * ORC_GROUP_BY_WIDTH);
+        return;
+    }
+    /* :224-239 slow path: decimal ints / dictionary strings, each followed by GROUP_DELIMITER ("\t") */
+    size_t cap = 64, n = 0;
+    char *buf = (char *)malloc(cap);
+    for (int g = 0; g < q->n_distincts; g++) {
+        const orc_col *c = &cols[q->distinct_cols[g]];
+        char num[32];
+        const char *piece = "";
+        if (col_populated(c, row)) {
+            if (c->type == ORC_INT_VAL) {
+                snprintf(num, sizeof(num), "%lld", (long long)c->ints[row]);
+                piece = num;
+            } else if (c->type == ORC_STR_VAL) {
+                const int64_t id = c->strs[row];
+                if (q->distinct_dicts[g] && id >= 0 && id < q->distinct_dict_len[g]) piece = q->distinct_dicts[g][id];
+            }
+        }
+        const size_t len = strlen(piece);
+        if (n + len + 1 > cap) {
+            while (n + len + 1 > cap) cap *= 2;
+            buf = (char *)realloc(buf, cap);
+        }
+        memcpy(buf + n, piece, len);
+        n += len;
+        buf[n++] = '\t';
+    }
+    orc_llb_add(r->llb, (const uint8_t *)buf, (int64_t)n);
+    free(buf);
 }
 
 /* ------------------------------------------------------------------ */
 /* Filters (filter.go)                                                  */
 /* ------------------------------------------------------------------ */
 
-static inline int col_populated(const orc_col *c, int64_t row) { return c->populated ? c->populated[row] != 0 : 1; }
 
 static int filter_row(const orc_filter *f, const orc_col *cols, int64_t row) {
     const orc_col *c = &cols[f->col];
@@ -732,6 +863,7 @@ static void scan_block(const orc_query *q, const orc_col *cols, int64_t row0, in
         }
         r->samples++; /* :202-203 */
         r->count += weight;
+        if (q->n_distincts > 0) distinct_add(q, cols, i, r); /* :205-243 */
 
         /* :246-261 aggregations */
         for (int a = 0; a < q->n_aggs; a++) {
@@ -924,6 +1056,15 @@ int orc_result_get(const orc_results *R, int which, int64_t idx, uint8_t *key, i
     if (count) *count = r->count;
     if (samples) *samples = r->samples;
     return 0;
+}
+
+int64_t orc_result_distinct(const orc_results *R, int which, int64_t idx, uint8_t *regs_out) {
+    const orc_result *r = get_result(R, which, idx);
+    if (!r) return -1;
+    static const uint8_t empty[ORC_LLB_M] = {0};
+    const uint8_t *regs = r->llb ? r->llb : empty; /* NewResult: hll.New() */
+    if (regs_out) memcpy(regs_out, regs, ORC_LLB_M);
+    return (int64_t)orc_llb_cardinality(regs);
 }
 
 int orc_result_hist(const orc_results *R, int which, int64_t idx, int agg, orc_hist_info *out) {

@@ -42,6 +42,20 @@
 extern "C" {
 #endif
 
+/* Count-distinct sketch.  PARITY UNPINNED against the reference's dependency: the reference imports
+ * github.com/logv/loglogbeta (query_spec.go:8; no go.mod / vendor directory, so no pinned version; a fork of
+ * github.com/seiflotfy/loglogbeta) and holds no test or golden value for -distinct.  Restated from the published
+ * algorithms: LogLog-Beta (Qin, Kim, Tung 2016), precision 14, the paper's beta(14) polynomial, and MetroHash64
+ * (J. A. Rogers 2015) with seed 1337 as go-metro's Hash64 -- the hash is pinned on MetroHash64's published test
+ * vectors (tests/test_oracle_distinct.py). */
+#define ORC_LLB_P 14
+#define ORC_LLB_M (1 << ORC_LLB_P)
+uint64_t orc_metro64(const uint8_t *p, int64_t len, uint64_t seed);
+void orc_llb_add_hash(uint8_t *regs, uint64_t x);                /* LogLogBeta.AddHash */
+void orc_llb_add(uint8_t *regs, const uint8_t *value, int64_t len); /* LogLogBeta.Add: metro64(value, 1337) */
+void orc_llb_merge(uint8_t *regs, const uint8_t *other);         /* LogLogBeta.Merge: register-wise max */
+uint64_t orc_llb_cardinality(const uint8_t *regs);               /* LogLogBeta.Cardinality */
+
 /* record.go:14-19 value tags */
 enum { ORC_NO_VAL = 0, ORC_INT_VAL = 1, ORC_STR_VAL = 2, ORC_SET_VAL = 3 };
 
@@ -96,6 +110,13 @@ typedef struct {
     int64_t block_rows;  /* CHUNK_SIZE, 65536 in production (table.go:44) */
     int32_t n_threads;   /* blocks scanned in parallel; merge is always in block order */
     int32_t loghist;     /* FLAGS.LOG_HIST: MultiHist instead of BasicHist (hist.go:27-38, hist_multi.go) */
+    /* -distinct (query_spec.go:29 Distincts): columns whose combined value feeds each Result's LogLog-Beta sketch
+     * (aggregate.go:205-243).  distinct_dicts[i]: the strings of a STR column's dictionary ids (the slow path,
+     * aggregate.go:225-239); NULL for INT columns. */
+    int32_t n_distincts;
+    int32_t distinct_cols[ORC_MAX_GROUPS];
+    const char *const *distinct_dicts[ORC_MAX_GROUPS];
+    int64_t distinct_dict_len[ORC_MAX_GROUPS];
 } orc_query;
 
 /* One merged Result (query_spec.go:85-93) + its hists, both arithmetic modes. */
@@ -137,6 +158,9 @@ typedef struct {
     double stddev_exact;  /* GetStdDev with avg = sum_exact/count and every outlier */
 } orc_hist_info;
 int orc_result_hist(const orc_results *r, int which, int64_t idx, int agg, orc_hist_info *out);
+/* Result.Distinct.Cardinality() (printer.go:79-80,142-144,204-205); regs_out (ORC_LLB_M bytes, may be NULL) receives
+ * the sketch's registers.  -1: no such result. */
+int64_t orc_result_distinct(const orc_results *r, int which, int64_t idx, uint8_t *regs_out);
 /* Copies len(Values) bucket counts; returns n_values or <0. */
 int64_t orc_result_hist_values(const orc_results *r, int which, int64_t idx, int agg, int64_t *out, int64_t cap);
 /* GetPercentiles (hist_basic.go:153-183): writes up to 100 entries, returns how many (0 if Count==0). */
