@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SYBL_ABI_VERSION 2
+#define SYBL_ABI_VERSION 3
 
 enum {
     SYBL_OK = 0,
@@ -287,6 +287,14 @@ typedef struct {
     int32_t loghist;
     int32_t n_str_replace;              /* QueryParams.StrReplace (query_spec.go:30) */
     const sybl_str_replace *str_replace;
+    /* -distinct (QuerySpec.Distincts, query_spec.go:29; aggregate.go:205-243): every Result also keeps a count-distinct
+     * sketch of the listed columns' combined value; sybl_result_distinct reads it and the renderers print it where the
+     * reference prints Distinct.Cardinality() (printer.go:79-80,142-144,204-205).  Either int columns (at most
+     * SYBL_MAX_GROUPS; the reference's fast path) or exactly one str column (its slow path over one column); a list
+     * mixing str with other columns is refused (SYBL_E_INVAL).  The sketch is the reference's dependency
+     * github.com/logv/loglogbeta restated from the published algorithms (PARITY UNPINNED: DESIGN.md section 7). */
+    int32_t n_distincts;
+    const char *const *distincts;
 } sybl_query_desc;
 
 int sybl_query_prepare(sybl_table *t, const sybl_query_desc *desc, sybl_query **out);
@@ -396,6 +404,13 @@ int sybl_result_subhists(const sybl_result *r, int agg, const sybl_subhist **sub
  *        2 = Cumulative ("TOTAL", one row) */
 int sybl_result_rows(const sybl_result *r, int which, const sybl_group_row **rows, int64_t *n);
 int64_t sybl_result_matched(const sybl_result *r); /* QuerySpec.MatchedCount */
+
+/* Count-distinct queries (sybl_query_desc.distincts): Result.Distinct of row `row` of sybl_result_rows(which) --
+ * *cardinality = Distinct.Cardinality(); *registers (may be NULL) = the sketch's SYBL_HLL_REGISTERS bytes, library-owned
+ * until the result is freed (a host that merges results of several nodes takes the register-wise maximum,
+ * query_spec.go:180-188).  SYBL_E_INVAL for a query without distincts or a row out of range. */
+#define SYBL_HLL_REGISTERS 16384
+int sybl_result_distinct(const sybl_result *r, int which, int64_t row, int64_t *cardinality, const uint8_t **registers);
 void sybl_result_free(sybl_result *r);
 
 typedef struct {
@@ -447,6 +462,15 @@ int sybl_debug_regex_match(const char *pattern, const char *text, int64_t text_l
  * every dictionary string (column_store_io.go:517-530).  NULL = the pattern does not compile.  Library-owned buffer,
  * valid until the next call on the thread. */
 const char *sybl_debug_regex_replace(const char *pattern, const char *text, const char *templ);
+
+/* Test hooks (no GPU needed) for the count-distinct sketch: the host build of the very functions the kernel uses
+ * (csrc/hll.h).  sybl_debug_hll_ints: rows of n_cols int64 values (row-major; populated: one byte per value, NULL = all
+ * populated) pushed into `registers` (SYBL_HLL_REGISTERS bytes, updated in place) the way the int fast path does;
+ * sybl_debug_hll_bytes: MetroHash64(seed 1337) of a byte string pushed the way the str path does, returns the hash;
+ * sybl_debug_hll_cardinality: Cardinality() of a register array. */
+int sybl_debug_hll_ints(const int64_t *values, const uint8_t *populated, int64_t n_rows, int32_t n_cols, uint8_t *registers);
+uint64_t sybl_debug_hll_bytes(const uint8_t *bytes, int64_t len, uint8_t *registers);
+int64_t sybl_debug_hll_cardinality(const uint8_t *registers);
 
 /* Test/diagnostic hook: decodes one gob file (info.db, int_/str_/set_*.db, optionally .gz) to JSON
  * with the library's gob reader.  Library-owned buffer, valid until the next call on the thread. */

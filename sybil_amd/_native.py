@@ -52,7 +52,8 @@ class QueryDesc(C.Structure):
                 ("op", C.c_int32), ("hist_bucket", C.c_int64), ("want_percentiles", C.c_int32),
                 ("time_col", C.c_char_p), ("time_bucket", C.c_int64), ("weight_col", C.c_char_p),
                 ("order_by", C.c_char_p), ("order_asc", C.c_int32), ("limit", C.c_int32),
-                ("block_skip", C.c_int32), ("loghist", C.c_int32), ("n_str_replace", C.c_int32), ("str_replace", C.POINTER(StrReplace))]
+                ("block_skip", C.c_int32), ("loghist", C.c_int32), ("n_str_replace", C.c_int32), ("str_replace", C.POINTER(StrReplace)),
+                ("n_distincts", C.c_int32), ("distincts", C.POINTER(C.c_char_p))]
 
 
 class AggOut(C.Structure):
@@ -152,6 +153,10 @@ SIGNATURES = {
     "sybl_result_rows": (C.c_int, [P, C.c_int, C.POINTER(C.POINTER(GroupRow)), C.POINTER(C.c_int64)]),
     "sybl_result_matched": (C.c_int64, [P]),
     "sybl_result_subhists": (C.c_int, [P, C.c_int, C.POINTER(C.POINTER(SubHist)), C.POINTER(C.c_int64)]),
+    "sybl_result_distinct": (C.c_int, [P, C.c_int, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.POINTER(C.c_uint8))]),
+    "sybl_debug_hll_ints": (C.c_int, [P, P, C.c_int64, C.c_int32, P]),
+    "sybl_debug_hll_bytes": (C.c_uint64, [C.c_char_p, C.c_int64, P]),
+    "sybl_debug_hll_cardinality": (C.c_int64, [P]),
     "sybl_result_free": (None, [P]),
     "sybl_query_stats": (C.c_int, [P, C.POINTER(RunStats)]),
     "sybl_debug_query_cells": (C.c_int, [P, C.c_int, C.c_int, P, C.c_int64, C.POINTER(C.c_int64)]),

@@ -302,6 +302,12 @@ const void *sybl_result_encode(sybl_result *r, int64_t *n_bytes) {
         set_error("sybl_result_encode: NULL argument");
         return nullptr;
     }
+    if (R->has_distinct) {
+        // Result.Distinct is a *hll.LogLogBeta: how gob sees it is the dependency's business (its only field is
+        // unexported), and that library is not in the reference tree -- sybl_result_distinct hands the registers out
+        set_error("-encode-results of a count-distinct result is not supported (the wire form of loglogbeta's sketch is unpinned)");
+        return nullptr;
+    }
     if (R->loghist) {
         // (every outlier of every sub-histogram is written out as a value: bound it)
         int64_t total = 0;

@@ -105,6 +105,9 @@ static void free_query(Query *q) {
     if (q->d_top_cells) hipFree(q->d_top_cells);
     if (q->d_out_log) hipFree(q->d_out_log);
     if (q->d_multi) hipFree(q->d_multi);
+    if (q->d_dplan) hipFree(q->d_dplan);
+    if (q->d_hll) hipFree(q->d_hll);
+    if (q->d_hll_idhash) hipFree(q->d_hll_idhash);
     for (auto &kv : q->replaced) {
         if (kv.second->d_keys) hipFree(kv.second->d_keys);
         if (kv.second->d_ranks) hipFree(kv.second->d_ranks);
@@ -120,6 +123,16 @@ static int ensure_partials(Query *q) {
     SYBL_HIP(hipMemset(q->d_max, 0, (size_t)q->n_max_words * 8));
     q->own_partials = true;
     q->plan_dirty = true;
+    return SYBL_OK;
+}
+
+// Count distinct: the sketches start empty and are filled by a pass of their own behind the scan (distinct.hip).
+static int scan_distinct(Query *q, bool ran, hipStream_t st) {
+    if (!q->n_distinct) return SYBL_OK;
+    SYBL_HIP(hipMemsetAsync(q->d_hll, 0, (size_t)q->hll_bytes, st));
+    if (!ran) return SYBL_OK;
+    hipError_t e = launch_scan_distinct(q->d_dplan, q->dplan.n_slots, q->n_wg, st);
+    if (e != hipSuccess) return hip_fail(e, "k_scan_distinct");
     return SYBL_OK;
 }
 
@@ -175,6 +188,7 @@ static int scan(Query *q) {
         if (e != hipSuccess) return hip_fail(e, "k_part_hist");
         SYBL_HIP(hipEventRecord(q->ev[1], st));
         SYBL_HIP(hipEventRecord(q->ev[2], st));
+        if ((rc = scan_distinct(q, ran, st))) return rc;
         q->scanned = true;
         q->snapshot_pending = false;
         return SYBL_OK;
@@ -216,6 +230,7 @@ static int scan(Query *q) {
         if (e != hipSuccess) return hip_fail(e, "k_fold");
     }
     SYBL_HIP(hipEventRecord(q->ev[2], st));
+    if ((rc = scan_distinct(q, ran, st))) return rc;
     q->scanned = true;
     q->snapshot_pending = false;
     return SYBL_OK;
@@ -369,6 +384,9 @@ int sybl_query_bind_partials(sybl_query *q, void *d_sum, void *d_max) {
     if (q->hash_mode)
         return fail(SYBL_E_INVAL, "a hash group-by keeps its partials in library-owned buffers whose size follows the keys found "
                                   "(sybl_query_partials after the scan)");
+    if (q->n_distinct)
+        return fail(SYBL_E_INVAL, "a count-distinct query merges its sketches (register-wise maximum) in sybl_query_allreduce: its partials "
+                                  "cannot be bound to caller-owned buffers for an external all-reduce");
     if (q->own_partials) {
         SYBL_HIP(hipStreamSynchronize(q->ctx->stream));
         if (q->d_sum) hipFree(q->d_sum);

@@ -239,6 +239,14 @@ struct Query {
     std::map<int, std::unique_ptr<StrReplaced>> replaced;  // -str-replace, by table column index
     std::vector<MultiSub> h_multi; // every aggregation's sub-histograms, as the kernels see them
     MultiSub *d_multi = nullptr;
+    // count distinct (hll.h, distinct.hip): a pass of its own after the scan, reading dplan = the scan's plan + the
+    // distinct columns' slots
+    int n_distinct = 0;
+    ScanPlan dplan;
+    ScanPlan *d_dplan = nullptr;
+    uint8_t *d_hll = nullptr;          // [n_cells][kHllRegs]
+    uint64_t *d_hll_idhash = nullptr;  // one str column: hash per dictionary id
+    int64_t hll_bytes = 0;
     bool time_mode = false;
     int64_t time_bucket = 0;
     std::string order_by;
@@ -335,6 +343,8 @@ int comm_allgather_inplace(Ctx *ctx, int64_t *buf, size_t words_per_rank);
 int comm_allreduce_sum(Ctx *ctx, int64_t *buf, size_t words);
 // hashgroup.hip
 hipError_t launch_scan_hash(const ScanPlan *d_plan, int n_slots, int n_wg, size_t lds_bytes, hipStream_t st);
+// distinct.hip
+hipError_t launch_scan_distinct(const ScanPlan *d_plan, int n_slots, int n_wg, hipStream_t st);
 int query_hash_reset(Query *q);     // every slot free (before a scan)
 int query_hash_compact(Query *q);   // live slots -> dense arrays in key order
 int query_hash_install_union(Query *q, const uint64_t *keys, int64_t n);                // host keys

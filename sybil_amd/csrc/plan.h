@@ -163,6 +163,17 @@ struct ScanPlan {
     // work
     const Segment *segs;
     const int32_t *wg_seg_begin;  // [n_wg+1]
+    // Count distinct (hll.h; only in the copy of the plan that k_scan_distinct reads, Query::dplan): every matched row
+    // raises one register of its cell's sketch.  Int columns: the hashed buffer holds 8 bytes per column in list order
+    // (distinct_slot[i] = the slot of the i-th column).  One str column: the hash of (string + "\t") was computed per
+    // dictionary id on the host (hll_idhash; hll_missing for a row without the column).
+    uint8_t *hll;                // [n_cells][kHllRegs]
+    const uint64_t *hll_idhash;
+    uint64_t hll_missing;
+    int64_t hll_ids;
+    int32_t n_distinct;
+    int32_t distinct_slot[8];
+    int32_t pad_distinct_;
 };
 
 // finalize-side histogram summaries (kernels.hip: k_hist_summary / k_hist_total)

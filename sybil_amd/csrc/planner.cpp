@@ -14,6 +14,7 @@
 #include <algorithm>
 
 #include "engine.h"
+#include "hll.h"
 #include "re2lite.h"
 
 namespace sybl {
@@ -1252,6 +1253,81 @@ struct Planner {
         return SYBL_OK;
     }
 
+    // ---- count distinct (aggregate.go:78-91,205-243): the sketches and the plan k_scan_distinct reads -- the scan's
+    // own plan (filters, group key, time bucket: row_prepare) plus a slot per distinct column it does not reference
+    int distinct() {
+        q->n_distinct = 0;
+        const int n = d->n_distincts;
+        if (n <= 0) return SYBL_OK;
+        if (n > kMaxDistinct) return fail(SYBL_E_INVAL, "too many distinct columns (%d > %d)", n, kMaxDistinct);
+        if (q->hash_mode) return fail(SYBL_E_INVAL, "count distinct needs a group key that maps directly to cells (this one goes through the hash table)");
+        if (n_cells * (int64_t)kHllRegs > ((int64_t)8 << 30))
+            return fail(SYBL_E_INVAL, "count distinct: %lld groups x 16 KB of sketch exceed 8 GiB", (long long)n_cells);
+        std::vector<Column *> cols;
+        int n_str = 0;
+        for (int i = 0; i < n; i++) {
+            Column *c = t->find(d->distincts[i]);
+            if (!c) return fail(SYBL_E_INVAL, "unknown column '%s'", d->distincts[i] ? d->distincts[i] : "(null)");
+            if (c->type == SYBL_SET_VAL) return fail(SYBL_E_INVAL, "count distinct over the set column '%s'", c->name.c_str());
+            n_str += c->type == SYBL_STR_VAL;
+            cols.push_back(c);
+        }
+        // only_ints_in_distinct (:84-91) or the slow path over one str column (its hash follows from the dictionary id);
+        // a buffer concatenated from several columns' strings has no per-column decomposition
+        if (n_str > 0 && n != 1)
+            return fail(SYBL_E_INVAL, "count distinct over a str column together with other columns is not supported");
+        ScanPlan &D = q->dplan;
+        D = P;
+        for (int i = 0; i < n; i++) {
+            const int ci = t->col_ix[cols[(size_t)i]->name];
+            int s = -1;
+            for (size_t k = 0; k < slot_col.size(); k++)
+                if (slot_col[k] == ci) s = (int)k;
+            if (s < 0) {
+                if (D.n_slots >= kMaxSlots) return fail(SYBL_E_INVAL, "query references more than %d columns", kMaxSlots);
+                s = D.n_slots++;
+                slot_col.push_back(ci);  // (after the scan's own slots: nothing below looks at them as scan slots)
+                SlotDesc &sd = D.slot[s];
+                memset(&sd, 0, sizeof(sd));
+                sd.base = cols[(size_t)i]->d_data;
+                sd.valid = cols[(size_t)i]->d_valid;
+                sd.width = cols[(size_t)i]->elem;
+                sd.vbase = cols[(size_t)i]->vbase;
+                sd.gmissing = -1;
+                sd.gmissing64 = -1;
+                sd.agg_index = -1;
+            }
+            D.distinct_slot[i] = s;
+        }
+        D.n_distinct = n;
+        q->hll_bytes = n_cells * (int64_t)kHllRegs;
+        SYBL_HIP(hipMalloc((void **)&q->d_hll, (size_t)q->hll_bytes));
+        D.hll = q->d_hll;
+        if (n_str) {
+            // aggregate.go:225-239: the string, then GROUP_DELIMITER; a row without the column hashes the delimiter alone.
+            // (-str-replace rewrote the dictionary at load time in the reference: the rewritten string is what is hashed)
+            Column *c = cols[0];
+            const StrReplaced *rep = nullptr;
+            auto it = q->replaced.find(t->col_ix[c->name]);
+            if (it != q->replaced.end()) rep = it->second.get();
+            std::vector<uint64_t> h(std::max<size_t>(c->dict.size(), 1));
+            for (size_t id = 0; id < c->dict.size(); id++) {
+                std::string v = rep ? rep->strs[(size_t)rep->remap[id]] : c->dict[id];
+                v += "\t";
+                h[id] = metro64_bytes((const uint8_t *)v.data(), v.size(), kHllSeed);
+            }
+            SYBL_HIP(hipMalloc((void **)&q->d_hll_idhash, h.size() * 8));
+            SYBL_HIP(hipMemcpy(q->d_hll_idhash, h.data(), h.size() * 8, hipMemcpyHostToDevice));
+            D.hll_idhash = q->d_hll_idhash;
+            D.hll_ids = (int64_t)c->dict.size();
+            D.hll_missing = metro64_bytes((const uint8_t *)"\t", 1, kHllSeed);
+        }
+        SYBL_HIP(hipMalloc((void **)&q->d_dplan, sizeof(ScanPlan)));
+        SYBL_HIP(hipMemcpy(q->d_dplan, &D, sizeof(ScanPlan), hipMemcpyHostToDevice));
+        q->n_distinct = n;
+        return SYBL_OK;
+    }
+
     int run() {
         int rc;
         if ((rc = setup())) return rc;
@@ -1264,7 +1340,8 @@ struct Planner {
         if ((rc = strategy())) return rc;
         if ((rc = work())) return rc;
         if ((rc = window())) return rc;
-        return device_copies();
+        if ((rc = device_copies())) return rc;
+        return distinct();
     }
 };
 

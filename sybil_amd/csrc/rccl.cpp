@@ -161,6 +161,8 @@ int sybl_query_allreduce(sybl_query *q) {
         q->rs_cell1 = std::min<int64_t>(P.n_cells, q->rs_cell0 + per);
     }
     if (has_max) SYBL_NCCL(ncclAllReduce(q->d_max, q->d_max, (size_t)q->n_max_words, ncclInt64, ncclMax, comm, ctx->stream));
+    // count distinct: Result.Combine merges the sketches register by register (query_spec.go:180-188)
+    if (q->n_distinct) SYBL_NCCL(ncclAllReduce(q->d_hll, q->d_hll, (size_t)q->hll_bytes, ncclUint8, ncclMax, comm, ctx->stream));
     SYBL_NCCL(ncclGroupEnd());
     return SYBL_OK;
 }

@@ -152,8 +152,14 @@ static void json_row(Result *R, const RowStore &r, std::string &o) {
         json_escape(part, v);
         kv.emplace_back(R->group_names[g], v);
     }
-    kv.emplace_back("Count", std::to_string((long long)r.count));
-    kv.emplace_back("Samples", std::to_string((long long)r.samples));
+    if (R->has_distinct) {
+        // printer.go:142-144: the cardinality stands in for Count as well, and Samples is not written
+        kv.emplace_back("Distinct", std::to_string((long long)R->distinct_of(r)));
+        kv.emplace_back("Count", std::to_string((long long)R->distinct_of(r)));
+    } else {
+        kv.emplace_back("Count", std::to_string((long long)r.count));
+        kv.emplace_back("Samples", std::to_string((long long)r.samples));
+    }
     std::stable_sort(kv.begin(), kv.end(), [](const auto &x, const auto &y) { return x.first < y.first; });
     // later duplicates of a key overwrite earlier ones in a Go map
     o += "{";
@@ -179,6 +185,7 @@ static void text_row(const Result *R, const RowStore &r, std::string &o) {
     o += pad.substr(0, 20);
     if (r.count != 0) o += std::to_string((long long)r.count);  // "%.0d" prints nothing for 0
     if (R->weighted) o += " (" + std::to_string((long long)r.samples) + ")";
+    if (R->has_distinct) o += " Distinct: " + std::to_string((long long)R->distinct_of(r));  // printer.go:204-205
     o += "\n";
     for (size_t a = 0; a < R->agg_names.size(); a++) {
         const sybl_agg_out &g = R->agg_pool[(size_t)r.agg_off + a];
@@ -276,6 +283,10 @@ const char *sybl_result_render(sybl_result *r, int format) {
                 return std::string(b);
             };
             for (auto &row : R->rows[1]) {
+                if (R->has_distinct) {  // printer.go:79-80: the cardinality, and no aggregation columns
+                    lines.push_back(time_str(row.time_bucket) + " \t " + std::to_string((long long)R->distinct_of(row)) + " \t " + row.gbk + " \t");
+                    continue;
+                }
                 std::string head = time_str(row.time_bucket) + " \t " + std::to_string((long long)row.count) + " \t " + row.gbk + " \t";
                 bool any = false;
                 for (size_t a = 0; a < R->agg_names.size(); a++) {

@@ -20,6 +20,7 @@
 #include <thread>
 
 #include "result.h"
+#include "hll.h"
 
 namespace sybl {
 
@@ -303,6 +304,21 @@ template <typename F>
 static void parallel_ranges(size_t n, size_t min_per_thread, F f) {
     size_t nt = std::max<size_t>(1, std::min(WorkerPool::cap(), n / std::max<size_t>(min_per_thread, 1)));
     WorkerPool::get().run(nt, [&](size_t k) { f(n * k / nt, n * (k + 1) / nt); });
+}
+
+// LogLogBeta.Cardinality (hll.h): the sum in register order, as the reference's loop and the oracle's
+uint64_t hll_cardinality(const uint8_t *regs) {
+    const double m = (double)kHllRegs;
+    const double alpha = 0.7213 / (1.0 + 1.079 / m);
+    double sum = 0.0, ez = 0.0;
+    for (int i = 0; i < kHllRegs; i++) {
+        if (regs[i] == 0) ez += 1.0;
+        sum += 1.0 / pow(2.0, (double)regs[i]);
+    }
+    const double zl = log(ez + 1.0);
+    const double beta = -0.370393911 * ez + 0.070471823 * zl + 0.17393686 * pow(zl, 2) + 0.16339839 * pow(zl, 3) +
+                        -0.09237745 * pow(zl, 4) + 0.03738027 * pow(zl, 5) + -0.005384159 * pow(zl, 6) + 0.00042419 * pow(zl, 7);
+    return (uint64_t)(alpha * m * (m - ez) / (beta + sum));
 }
 
 static void make_views(Result *R) {
@@ -784,6 +800,7 @@ int query_finalize(Query *q, Result **out) {
             RowStore &row = R->rows[0][i];
             row.agg_off = (int64_t)((next_slot + i) * na);
             row.time_bucket = 0;
+            row.cell = -1;  // (rows are recycled)
             build_key(q, g, row.key, row.gbk);
             CellAcc a2;
             a2.count = all_count[(size_t)g];
@@ -800,8 +817,34 @@ int query_finalize(Query *q, Result **out) {
         row.time_bucket = 0;
         memset(row.key, 0, sizeof(row.key));
         row.gbk = "TOTAL";
+        row.cell = -1;
         for (size_t g = 1; g < q->groups.size(); g++) row.gbk += "\t";
         finish_row(q, R, total, row);
+    }
+
+    // ---- count distinct (query_spec.go:87,180-188): every row's sketch and its Cardinality()
+    R->has_distinct = q->n_distinct > 0;
+    if (R->has_distinct) {
+        R->hll_cells = P.n_cells;
+        R->hll.resize((size_t)(P.n_cells + 2) * kHllRegs);
+        // (the sketches are complete: the pass that fills them was queued before the snapshot this finalize waited for)
+        SYBL_HIP(hipMemcpy(R->hll.data(), q->d_hll, (size_t)q->hll_bytes, hipMemcpyDeviceToHost));
+        uint8_t *total_regs = R->hll.data() + (size_t)P.n_cells * kHllRegs;
+        memset(total_regs, 0, 2 * (size_t)kHllRegs);
+        if (!q->time_mode) {
+            // Cumulative combines every Result (aggregate.go:431-434): the register-wise maximum.  (In a time series it
+            // combines the all-time Results, whose sketches stay empty: aggregate.go:156-169 only counts there.)
+            for (const RowStore &row : R->rows[0]) {
+                const uint8_t *regs = R->row_registers(0, row);
+                for (int k = 0; k < kHllRegs; k++) total_regs[k] = std::max(total_regs[k], regs[k]);
+            }
+        }
+        for (int w = 0; w < 3; w++) {
+            R->distinct[w].resize(R->rows[w].size());
+            parallel_ranges(R->rows[w].size(), 256, [&, w](size_t i0, size_t i1) {
+                for (size_t i = i0; i < i1; i++) R->distinct[w][i] = (int64_t)hll_cardinality(R->row_registers(w, R->rows[w][i]));
+            });
+        }
     }
 
     // ---- outlier values (plan.h: outlier log) -> the rows that own them
@@ -956,6 +999,42 @@ int sybl_result_subhists(const sybl_result *r, int agg, const sybl_subhist **sub
     *n = (size_t)agg < R->subs.size() ? (int64_t)R->subs[(size_t)agg].size() : 0;
     return SYBL_OK;
 }
+
+int sybl_result_distinct(const sybl_result *r, int which, int64_t row, int64_t *cardinality, const uint8_t **registers) {
+    const Result *R = (const Result *)r;
+    if (!R || !R->has_distinct) return fail(SYBL_E_INVAL, "not a count-distinct result");
+    if (which < 0 || which > 2 || row < 0 || row >= (int64_t)R->rows[which].size()) return fail(SYBL_E_INVAL, "no such row");
+    // (Results are handed out in sorted order: Result::order0)
+    const size_t built = which == 0 && !R->order0.empty() ? (size_t)R->order0[(size_t)row] : (size_t)row;
+    if (cardinality) *cardinality = R->distinct[which][built];
+    if (registers) *registers = R->row_registers(which, R->rows[which][built]);
+    return SYBL_OK;
+}
+
+int sybl_debug_hll_ints(const int64_t *values, const uint8_t *populated, int64_t n_rows, int32_t n_cols, uint8_t *registers) {
+    if (!values || !registers || n_cols < 1 || n_cols > kMaxDistinct) return fail(SYBL_E_INVAL, "bad arguments");
+    for (int64_t i = 0; i < n_rows; i++) {
+        uint64_t w[kMaxDistinct];
+        for (int c = 0; c < kMaxDistinct; c++)
+            w[c] = c < n_cols && (!populated || populated[i * n_cols + c]) ? (uint64_t)values[i * n_cols + c] : ~(uint64_t)0;
+        uint32_t reg, rank;
+        hll_place(metro64_words(w, n_cols, kHllSeed), reg, rank);
+        if (registers[reg] < rank) registers[reg] = (uint8_t)rank;
+    }
+    return SYBL_OK;
+}
+
+uint64_t sybl_debug_hll_bytes(const uint8_t *bytes, int64_t len, uint8_t *registers) {
+    const uint64_t h = metro64_bytes(bytes, (size_t)len, kHllSeed);
+    if (registers) {
+        uint32_t reg, rank;
+        hll_place(h, reg, rank);
+        if (registers[reg] < rank) registers[reg] = (uint8_t)rank;
+    }
+    return h;
+}
+
+int64_t sybl_debug_hll_cardinality(const uint8_t *registers) { return registers ? (int64_t)hll_cardinality(registers) : -1; }
 
 int64_t sybl_result_matched(const sybl_result *r) { return r ? ((const Result *)r)->matched : 0; }
 

@@ -90,6 +90,23 @@ struct Result : ResultStore {
     std::vector<std::vector<int64_t>> total_vals; // Cumulative bucket arrays
     std::vector<int64_t> top_vals;                // bucket arrays of the first `limit` rows (GPU summary path)
     std::vector<int64_t> outlier_vals;            // the outliers' values, grouped by (row, aggregation): sybl_agg_out::outlier_values
+    // count distinct: the cells' sketches ([n_cells][kHllRegs]) followed by Cumulative's (the union) and an empty one
+    // (rows that own none: the all-time Results of a time series); a row finds its own through RowStore::cell
+    bool has_distinct = false;
+    std::vector<uint8_t> hll;
+    int64_t hll_cells = 0;
+    std::vector<int64_t> distinct[3];             // Distinct.Cardinality() per row of rows[w] (as built, not as sorted)
+    // Distinct.Cardinality() of a row the renderers hold by reference
+    int64_t distinct_of(const RowStore &row) const {
+        for (int w = 0; w < 3; w++)
+            if (!rows[w].empty() && &row >= rows[w].data() && &row < rows[w].data() + rows[w].size())
+                return distinct[w][(size_t)(&row - rows[w].data())];
+        return 0;
+    }
+    const uint8_t *row_registers(int w, const RowStore &row) const {
+        const int64_t slot = w == 2 ? hll_cells : ((w == 0 && time_mode) || row.cell < 0 || row.cell >= hll_cells ? hll_cells + 1 : row.cell);
+        return hll.data() + (size_t)slot * 16384;
+    }
     // (ResultStore) pct_pool: 100 entries per (row, agg) with percentiles; agg_pool / val_pool /
     // pctoff_pool: n_aggs entries per row, all row kinds (pctoff: offset into pct_pool, -1 = none)
     // for rendering

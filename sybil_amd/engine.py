@@ -237,8 +237,10 @@ class Table:
         return (col, op, str(value))
 
     def query(self, filters=(), groups=(), aggs=(), op="avg", hist_bucket=0, want_percentiles=True, time_col=None,
-              time_bucket=0, weight_col=None, order_by="$COUNT", order_asc=False, limit=0, block_skip=False, loghist=False, str_replace=()):
-        """str_replace: [(col, pattern, replacement)] or [(col, [replaced string per dictionary id])] (-str-replace)."""
+              time_bucket=0, weight_col=None, order_by="$COUNT", order_asc=False, limit=0, block_skip=False, loghist=False, str_replace=(),
+              distincts=()):
+        """str_replace: [(col, pattern, replacement)] or [(col, [replaced string per dictionary id])] (-str-replace).
+        distincts: columns of a count-distinct query (-distinct): rows then carry "distinct" (Result.distinct())."""
         keep = []
         farr = (N.Filter * max(len(filters), 1))()
         for i, f in enumerate(filters):
@@ -287,9 +289,14 @@ class Table:
             else:
                 sarr[i].pattern, sarr[i].replace = _b(sr[1]), _b(sr[2])
         d.n_str_replace, d.str_replace = len(str_replace), C.cast(sarr, C.POINTER(N.StrReplace))
+        dn = [_b(x) for x in distincts]
+        darr = (C.c_char_p * max(len(dn), 1))(*dn)
+        d.n_distincts, d.distincts = len(dn), C.cast(darr, C.POINTER(C.c_char_p))
         h = C.c_void_p()
         N.check(N.lib().sybl_query_prepare(self._h, C.byref(d), C.byref(h)))
-        return Query(self, h, list(groups), list(aggs))
+        qy = Query(self, h, list(groups), list(aggs))
+        qy.n_distincts = len(dn)
+        return qy
 
 
 class Query:
@@ -400,7 +407,9 @@ class Query:
     def finalize(self):
         h = C.c_void_p()
         N.check(N.lib().sybl_query_finalize(self._h, C.byref(h)))
-        return Result(h, len(self.groups), len(self.aggs))
+        res = Result(h, len(self.groups), len(self.aggs))
+        res.has_distinct = getattr(self, "n_distincts", 0) > 0
+        return res
 
     def run(self):
         return self.scan().finalize()
@@ -409,6 +418,7 @@ class Query:
 class Result:
     def __init__(self, handle, n_groups, n_aggs):
         self._h, self.n_groups, self.n_aggs = handle, n_groups, n_aggs
+        self.has_distinct = False
 
     def free(self):
         if self._h:
@@ -441,8 +451,18 @@ class Result:
                 if g.percentiles:
                     h["percentiles"] = np.ctypeslib.as_array(g.percentiles, shape=(100,)).copy()
                 row["hists"].append(h)
+            if self.has_distinct:
+                row["distinct"] = self.distinct(which, i)
             out.append(row)
         return out
+
+    def distinct(self, which=0, row=0, registers=False):
+        """Count-distinct queries: Result.Distinct.Cardinality() of a row of rows(which) (+ the sketch's registers)."""
+        card, regs = C.c_int64(), C.POINTER(C.c_uint8)()
+        N.check(N.lib().sybl_result_distinct(self._h, which, row, C.byref(card), C.byref(regs)))
+        if registers:
+            return card.value, np.ctypeslib.as_array(regs, shape=(16384,)).copy()
+        return card.value
 
     def subhists(self, agg=0):
         """-loghist: the layout of the aggregation's `values` arrays (sybl_result_subhists) as a list of dicts."""

@@ -43,7 +43,7 @@ int main(int argc, char **argv) {
         {"sort", "$COUNT"}, {"sort-asc", "false"}, {"time", "false"}, {"time-col", "time"}, {"time-bucket", "3600"},
         {"weight-col", ""}, {"int-filter", ""}, {"str-filter", ""}, {"set-filter", ""}, {"int-bucket", "0"},
         {"int", ""}, {"str", ""}, {"set", ""}, {"group", ""}, {"field-separator", ","}, {"filter-separator", ":"},
-        {"device", "0"}, {"block-skip", "true"}, {"stats", "false"}, {"encode-results", "false"}, {"loghist", "false"}, {"str-replace", ""}};
+        {"device", "0"}, {"block-skip", "true"}, {"stats", "false"}, {"encode-results", "false"}, {"loghist", "false"}, {"str-replace", ""}, {"distinct", ""}};
     const std::set<std::string> bools = {"print", "json", "sort-asc", "time", "block-skip", "stats", "encode-results", "loghist"};
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
@@ -83,6 +83,14 @@ int main(int argc, char **argv) {
     }
     const std::string fs = f["field-separator"], ps = f["filter-separator"];
     std::vector<std::string> ints = split(f["int"], fs), groups = split(f["group"], fs);
+    // -distinct a,b (cmd_query.go:61,124-126,216-219); -op distinct counts the -group columns instead of grouping by
+    // them (:221-224) -- its aggregations are computed but printed by neither printer, so they are not requested here
+    std::vector<std::string> distincts = split(f["distinct"], fs);
+    if (f["op"] == "distinct") {
+        distincts = groups;
+        groups.clear();
+        ints.clear();
+    }
 
     // ---- filters (BuildFilters, filter.go:59-139)
     struct Filt {
@@ -111,6 +119,7 @@ int main(int argc, char **argv) {
     };
     for (auto &c : ints) use(c);
     for (auto &c : groups) use(c);
+    for (auto &c : distincts) use(c);
     for (auto &x : filts) use(x.col);
     if (on("time")) use(f["time-col"]);
     use(f["weight-col"]);
@@ -182,6 +191,10 @@ int main(int argc, char **argv) {
     }
     d.n_str_replace = (int32_t)sr.size();
     d.str_replace = sr.empty() ? nullptr : sr.data();
+    std::vector<const char *> dptr;
+    for (auto &c : distincts) dptr.push_back(c.c_str());
+    d.n_distincts = (int32_t)dptr.size();
+    d.distincts = dptr.empty() ? nullptr : dptr.data();
 
     sybl_query *q = nullptr;
     if (sybl_query_prepare(tab, &d, &q)) return die("prepare");
