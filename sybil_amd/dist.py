@@ -25,6 +25,15 @@ def merge_partials(sum_words, max_words, group=None, has_max=True):
         dist.all_reduce(max_words, op=dist.ReduceOp.MAX, group=group)
 
 
+def merge_sketches(registers, group=None):
+    """Count-distinct queries: the ranks' sketches ([cell][16384] uint8 registers) combine by the register-wise maximum
+    (Result.Combine -> Distinct.Merge, query_spec.go:180-188) -- one MAX all-reduce, in place.  (sybl_query_allreduce
+    does the same over RCCL inside the library.)"""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    dist.all_reduce(registers, op=dist.ReduceOp.MAX, group=group)
+
+
 def merge_hash_partials(query, device, group=None):
     """Hash group-by (sybl_query_hash_keys / sybl_query_hash_install_union): the ranks found different key sets, so
     they first install the sorted union of their keys -- the dense partial arrays then line up -- and merge with the

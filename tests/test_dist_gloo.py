@@ -182,3 +182,51 @@ def test_dictionary_agreement_two_ranks():
     for rank, u, s, gu, gs in outs:
         assert u == gu == [-3, 5, 7, 9, 1 << 40]       # sorted union: rank order == key order on every rank
         assert s == gs == ["a", "b", "c"]
+
+
+def _sketch_worker(rank, world, port, total_rows, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import oracle as orc
+        from sybil_amd import dist as sdist
+        row0, nrows = sdist.shard(total_rows, rank, world, block_rows=4096)
+        rng = np.random.default_rng(77)                      # the same table on every rank, sliced by shard
+        g = rng.integers(0, 6, total_rows)[row0:row0 + nrows]
+        user = rng.integers(0, 40_000, total_rows)[row0:row0 + nrows]
+        res = orc.run_query([{"type": "int", "data": g}, {"type": "int", "data": user}], groups=[0], distincts=[1],
+                            block_rows=4096, want_registers=True)
+        regs = np.zeros((6, orc.LLB_M), dtype=np.uint8)      # direct-mapped cells, as the engine lays them out
+        for r in res["results"]:
+            regs[r["key_vals"][0]] = r["registers"]
+        t = torch.from_numpy(regs.reshape(-1).copy())
+        sdist.merge_sketches(t)
+        q.put((rank, t.numpy().reshape(6, orc.LLB_M).copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_sketch_merge_equals_whole_table():
+    """Count distinct across ranks: the MAX all-reduce of the shards' sketches is the whole table's sketch."""
+    from oracle import oracle as orc
+    total = 60_000
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sketch_worker, args=(r, 2, port, total, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    rng = np.random.default_rng(77)
+    g = rng.integers(0, 6, total)
+    user = rng.integers(0, 40_000, total)
+    whole = orc.run_query([{"type": "int", "data": g}, {"type": "int", "data": user}], groups=[0], distincts=[1], want_registers=True)
+    assert np.array_equal(got[0], got[1])
+    for r in whole["results"]:
+        k = r["key_vals"][0]
+        assert np.array_equal(got[0][k], r["registers"])
+        assert orc.LogLogBeta(got[0][k]).cardinality() == r["distinct"]
