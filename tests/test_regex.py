@@ -115,3 +115,57 @@ def test_replace_all_agrees_with_python_where_the_semantics_coincide():
                 got = N.lib().sybl_debug_regex_replace(pat.encode(), text.encode(), templ.encode()).decode()
                 assert got == pyre.sub(pat, py, text), (pat, text, templ)
 
+
+
+def _random_pattern(rng, depth=0):
+    """A random pattern in the syntax Go's regexp and Python's re share (ASCII classes; no look-around, no backrefs)."""
+    atoms = ["a", "b", "c", "2", ".", r"\d", r"\w", r"\s", "[ab]", "[^a]", "[a-c2]", r"\.", "x"]
+    parts = []
+    for _ in range(int(rng.integers(1, 4))):
+        r = rng.random()
+        if r < 0.2 and depth < 2:
+            inner = _random_pattern(rng, depth + 1)
+            a = ("(%s)" if rng.random() < 0.5 else "(?:%s)") % inner
+        else:
+            a = atoms[int(rng.integers(0, len(atoms)))]
+        r = rng.random()
+        if r < 0.15:
+            a += "*"
+        elif r < 0.3:
+            a += "+"
+        elif r < 0.4:
+            a += "?"
+        elif r < 0.48:
+            a += "{%d,%d}" % (int(rng.integers(0, 2)), int(rng.integers(2, 4)))
+        elif r < 0.53:
+            a += "*?"
+        parts.append(a)
+    p = "".join(parts)
+    if depth == 0:
+        if rng.random() < 0.2:
+            p = "^" + p
+        if rng.random() < 0.2:
+            p = p + "$"
+    if rng.random() < 0.25 and depth < 2:
+        p = p + "|" + _random_pattern(rng, depth + 1)
+    return p
+
+
+def test_random_patterns_agree_with_python_re():
+    """Differential check of MatchString (unanchored search, a boolean) on 1500 random patterns x 40 random texts."""
+    import numpy as np
+    rng = np.random.default_rng(2024)
+    alphabet = "abc2x. \t"
+    texts = ["".join(alphabet[int(i)] for i in rng.integers(0, len(alphabet), int(rng.integers(0, 12)))) for _ in range(40)]
+    checked = 0
+    for _ in range(1500):
+        pat = _random_pattern(rng)
+        try:
+            rx = re.compile(pat, re.ASCII)
+        except re.error:
+            continue
+        for text in texts:
+            got = match(pat, text)
+            assert got == (1 if rx.search(text) else 0), (pat, text, got)
+            checked += 1
+    assert checked > 40_000
