@@ -342,7 +342,7 @@ def main():
         return out
 
     STRATEGY = {0: "lds-generic", 1: "global-atomics", 2: "lds-fast", 3: "lds-window-generic", 4: "lds-window-fast",
-                5: "partitioned-hist", 6: "lds-hist"}
+                5: "partitioned-hist", 6: "lds-hist", 7: "hash"}
 
     def roofline(ph, storage):
         stats = ph["stats"]
