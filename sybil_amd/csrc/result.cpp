@@ -827,8 +827,9 @@ int query_finalize(Query *q, Result **out) {
     if (R->has_distinct) {
         R->hll_cells = P.n_cells;
         R->hll.resize((size_t)(P.n_cells + 2) * kHllRegs);
-        // (the sketches are complete: the pass that fills them was queued before the snapshot this finalize waited for)
-        SYBL_HIP(hipMemcpy(R->hll.data(), q->d_hll, (size_t)q->hll_bytes, hipMemcpyDeviceToHost));
+        // the pass that fills the sketches (and their all-reduce) was queued on the context's stream: copy behind it
+        SYBL_HIP(hipMemcpyAsync(R->hll.data(), q->d_hll, (size_t)q->hll_bytes, hipMemcpyDeviceToHost, q->ctx->stream));
+        SYBL_HIP(hipStreamSynchronize(q->ctx->stream));
         uint8_t *total_regs = R->hll.data() + (size_t)P.n_cells * kHllRegs;
         memset(total_regs, 0, 2 * (size_t)kHllRegs);
         if (!q->time_mode) {
