@@ -174,13 +174,12 @@ static int scan(Query *q) {
         q->eplan.sum_out = q->d_sum;
         q->pplan.sum_out = q->d_sum;
         q->pplan.max_out = q->d_max;
-        // counting sort: count per (workgroup, partition) -> exact regions -> scatter
-        SYBL_HIP(hipMemsetAsync(q->eplan.part_tot, 0, (size_t)q->eplan.n_parts * 4, st));
+        // counting sort: count per (workgroup, bin) -> exact regions -> scatter
         e = q->part_packed ? launch_count_packed(q->eplan, q->part_nf, q->part_ng, q->n_wg, st)
                            : launch_count(q->eplan, q->part_nf, q->part_ng, q->n_wg, st);
         if (e != hipSuccess) return hip_fail(e, "k_count");
-        e = launch_part_offsets(q->eplan, st);
-        if (e != hipSuccess) return hip_fail(e, "k_part_offsets");
+        e = launch_part_bases(q->eplan, st);
+        if (e != hipSuccess) return hip_fail(e, "k_part_bases");
         e = q->part_packed ? launch_emit_packed(q->eplan, q->part_nf, q->part_ng, q->part_na, q->n_wg, st)
                            : launch_emit(q->eplan, q->part_nf, q->part_ng, q->part_na, q->n_wg, st);
         if (e != hipSuccess) return hip_fail(e, "k_emit");

@@ -543,9 +543,6 @@ __global__ __launch_bounds__(kWgThreads) void k_part_hist(const PartHistPlan P) 
 
     const uint32_t split = (uint32_t)P.split;
     const uint32_t part = blockIdx.x / split, sub = blockIdx.x % split;
-    const uint32_t p0 = P.part_off[part], n_chunks = (P.part_off[part + 1] - p0) / kEmitChunk;
-    const uint32_t i0 = p0 + (uint32_t)((uint64_t)n_chunks * sub / split) * kEmitChunk;
-    const uint32_t i1 = p0 + (uint32_t)((uint64_t)n_chunks * (sub + 1) / split) * kEmitChunk;
     const uint32_t *recs = P.recs;
     const uint32_t pair0 = part * kPartCells;
     unsigned long long *my_sum = sum + (tid & (kPartSumRep - 1)) * kPartCells;
@@ -575,28 +572,67 @@ __global__ __launch_bounds__(kWgThreads) void k_part_hist(const PartHistPlan P) 
             }
         }
     };
-    // Four records per load and kPartUnroll loads per lane, the next round requested before this one is
-    // consumed: 128 KB in flight per CU (one 16-byte load per lane, 16 KB, ran at the latency: 1.4 TB/s).
+    // The partition's records: one region per scanning workgroup w (the partition's sub-bins are neighbours in w's
+    // output: chunks boff[w][part << ss] .. boff[w][(part + 1) << ss] behind wbase[w]).  `split` workgroups share a
+    // partition by taking every split-th region; inside a workgroup every wave walks its own regions, 16-byte pieces
+    // (four records) per lane and kPartUnroll loads per lane in flight twice over (current + next batch) -- raw buffer
+    // loads whose descriptor is the region, so nothing depends on a lane's bounds when the loads are issued.
     typedef unsigned int rec4 __attribute__((ext_vector_type(4)));
-    const rec4 none = {kRecSentinel, kRecSentinel, kRecSentinel, kRecSentinel};
-    constexpr uint32_t kStep = kWgThreads * 4u;  // records per load round of the workgroup
-    auto load4 = [&](uint32_t i) -> rec4 { return i < i1 ? __builtin_nontemporal_load((const rec4 *)(recs + i)) : none; };
+    const uint32_t lane = tid & 63u, wave = tid >> 6, nb1 = ((uint32_t)P.n_parts << P.sub_shift) + 1u;
+    const uint32_t b_lo = part << P.sub_shift, b_hi = (part + 1u) << P.sub_shift;
+    const uint32_t n_reg = (uint32_t)P.n_wg > sub ? ((uint32_t)P.n_wg - sub + split - 1u) / split : 0u;
+    constexpr uint32_t kBatch = 64u * kPartUnroll;  // pieces per wave and batch
+    uint32_t r = wave, i0 = 0, n4 = 0, c0 = 0;      // region, first piece of the next batch, pieces, first chunk (wave-uniform)
+    auto open_region = [&]() {
+        // skips empty regions; n4 == 0 afterwards: no region left
+        n4 = 0;
+        while (r < n_reg) {
+            const uint32_t w = __builtin_amdgcn_readfirstlane(sub + r * split);
+            const uint32_t *bo = P.boff + (size_t)w * nb1;
+            const uint32_t lo = bo[b_lo], hi = bo[b_hi];
+            if (hi > lo) {
+                c0 = P.wbase[w] + lo;
+                n4 = (hi - lo) * (kEmitChunk / 4u);
+                i0 = 0;
+                return;
+            }
+            r += kWgThreads / 64;
+        }
+    };
+    auto issue = [&](rec4 (&d)[kPartUnroll], uint32_t &first, uint32_t &pieces) {
+        const __amdgpu_buffer_rsrc_t rsrc =
+            __builtin_amdgcn_make_buffer_rsrc((void *)(recs + (size_t)c0 * kEmitChunk), 0, (int)(n4 * 16u), (int)0x00020000);
+#pragma unroll
+        for (int u = 0; u < kPartUnroll; u++) d[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)((i0 + (uint32_t)u * 64u + lane) * 16u), 0, 2);
+        first = i0;
+        pieces = n4;
+        if (n4) {
+            i0 += kBatch;
+            if (i0 >= n4) {
+                r += kWgThreads / 64;
+                open_region();
+            }
+        }
+    };
     rec4 cur[kPartUnroll], nxt[kPartUnroll];
-    uint32_t base = i0 + tid * 4u;
-#pragma unroll
-    for (int u = 0; u < kPartUnroll; u++) cur[u] = load4(base + (uint32_t)u * kStep);
-    for (; base < i1; base += kPartUnroll * kStep) {
-#pragma unroll
-        for (int u = 0; u < kPartUnroll; u++) nxt[u] = load4(base + (uint32_t)(kPartUnroll + u) * kStep);
+    uint32_t cur_first, cur_n, nxt_first, nxt_n;
+    open_region();
+    issue(cur, cur_first, cur_n);
+    while (cur_n) {
+        issue(nxt, nxt_first, nxt_n);
 #pragma unroll
         for (int u = 0; u < kPartUnroll; u++) {
-            add_record(cur[u].x);
-            add_record(cur[u].y);
-            add_record(cur[u].z);
-            add_record(cur[u].w);
+            if (cur_first + (uint32_t)u * 64u + lane < cur_n) {
+                add_record(cur[u].x);
+                add_record(cur[u].y);
+                add_record(cur[u].z);
+                add_record(cur[u].w);
+            }
         }
 #pragma unroll
         for (int u = 0; u < kPartUnroll; u++) cur[u] = nxt[u];
+        cur_first = nxt_first;
+        cur_n = nxt_n;
     }
     __syncthreads();
     // cnt[l] = sum over the buckets of pair l: each wave sums a strided share, one LDS atomic per wave
@@ -652,57 +688,40 @@ __global__ __launch_bounds__(kWgThreads) void k_part_hist(const PartHistPlan P) 
     }
 }
 
-// k_part_offsets: counts[workgroup][partition] -> the region of every workgroup in every partition buffer.
-// Partition buffers follow each other in `recs`; inside a partition the workgroups' regions follow each
-// other in workgroup order, each a whole number of chunks (emit_region_chunks).  k_count has already summed
-// every partition's chunks into part_tot.  A block owns 64 partitions (counts are read and regions written
-// coalesced along the partition axis); its four waves each walk a quarter of the workgroups.
-__global__ __launch_bounds__(256) void k_part_offsets(const EmitPlan E) {
-    __shared__ uint32_t red[4], excl[64], qs[4][64];
-    const uint32_t np = (uint32_t)E.n_parts, nw = (uint32_t)E.n_wg, nsub = 1u << E.sub_shift;
-    const uint32_t tid = threadIdx.x, tw = tid >> 6, tp = tid & 63, p0 = blockIdx.x * 64u, p = p0 + tp;
-    // chunks of all partitions before this block's
-    uint32_t acc = 0;
-    for (uint32_t j = tid; j < p0; j += 256) acc += E.part_tot[j];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-    if (tp == 0) red[tw] = acc;
-    // exclusive scan of the block's own partitions (wave 0)
-    const uint32_t mine = p < np ? E.part_tot[p] : 0u;
-    if (tw == 0) {
+// k_part_bases: wbase[w] = the chunks of the workgroups before w (boff[w][nb] is w's own total: k_count), wbase[n_wg] =
+// all chunks.  One workgroup; n_wg is a few hundred.
+__global__ __launch_bounds__(kWgThreads) void k_part_bases(const EmitPlan E) {
+    __shared__ uint32_t wave_tot[kWgThreads / 64];
+    __shared__ uint32_t carry_s;
+    const uint32_t tid = threadIdx.x, nw = (uint32_t)E.n_wg, nb1 = ((uint32_t)E.n_parts << E.sub_shift) + 1u;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (uint32_t w0 = 0; w0 < nw; w0 += kWgThreads) {
+        const uint32_t w = w0 + tid;
+        const uint32_t mine = w < nw ? E.boff[(size_t)w * nb1 + (nb1 - 1)] : 0u;
         uint32_t x = mine;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const uint32_t y = __shfl_up(x, o, 64);
-            if ((int)tp >= o) x += y;
+            if ((int)(tid & 63) >= o) x += y;
         }
-        excl[tp] = x - mine;
+        if ((tid & 63) == 63) wave_tot[tid >> 6] = x;
+        __syncthreads();
+        uint32_t before = carry_s, total = 0;
+        for (uint32_t v = 0; v < kWgThreads / 64; v++) {
+            before += v < (tid >> 6) ? wave_tot[v] : 0u;
+            total += wave_tot[v];
+        }
+        if (w < nw) E.wbase[w] = before + x - mine;
+        __syncthreads();
+        if (tid == 0) carry_s += total;
+        __syncthreads();
     }
-    // this wave's quarter of the workgroups
-    const uint32_t q = (nw + 3) / 4, w0 = tw * q < nw ? tw * q : nw, w1 = w0 + q < nw ? w0 + q : nw;
-    uint32_t sum = 0;
-    if (p < np)
-        for (uint32_t w = w0; w < w1; w++) sum += emit_region_chunks(E.counts[(size_t)w * np + p], nsub);
-    qs[tw][tp] = sum;
-    __syncthreads();
-    if (p >= np) return;
-    const uint32_t base = red[0] + red[1] + red[2] + red[3] + excl[tp];
-    uint32_t at = base;
-    for (uint32_t t = 0; t < tw; t++) at += qs[t][tp];
-    at *= kEmitChunk;
-    for (uint32_t w = w0; w < w1; w++) {
-        E.woff[(size_t)w * np + p] = at;
-        at += emit_region_chunks(E.counts[(size_t)w * np + p], nsub) * kEmitChunk;
-        E.wend[(size_t)w * np + p] = at;
-    }
-    if (tw == 0) {
-        E.part_off[p] = base * kEmitChunk;
-        if (p == np - 1) E.part_off[np] = (base + mine) * kEmitChunk;
-    }
+    if (tid == 0) E.wbase[nw] = carry_s;
 }
 
-hipError_t launch_part_offsets(const EmitPlan &E, hipStream_t st) {
-    hipLaunchKernelGGL(k_part_offsets, dim3((unsigned)((E.n_parts + 63) / 64)), dim3(256), 0, st, E);
+hipError_t launch_part_bases(const EmitPlan &E, hipStream_t st) {
+    hipLaunchKernelGGL(k_part_bases, dim3(1), dim3(kWgThreads), 0, st, E);
     return hipGetLastError();
 }
 

@@ -372,35 +372,40 @@ static int select_part_hist(Table *t, Query *q, const std::vector<int> &slot_col
     int ss = 0;
     while ((n_parts << (ss + 1)) <= kEmitMaxBins) ss++;
     while (ss > 0 && recs_all / (n_wg * (n_parts << ss)) < 64) ss--;
-    // the partition buffers are sized exactly by k_count at scan time; this is their upper bound: every
-    // record + one partly filled chunk per (workgroup, bin).  Record indices are 32-bit.
-    const int64_t cap = recs_all + n_wg * (n_parts << ss) * (int64_t)kEmitChunk + kEmitChunk;
+    // the workgroups' outputs are sized exactly by k_count at scan time; this is their upper bound: every record + one
+    // partly filled chunk per (workgroup, bin).  Chunk indices are 32-bit; a workgroup's output is addressed with a
+    // 32-bit byte offset below kEmitDropOffset (2 GiB).
+    const int64_t nb = n_parts << ss;
+    const int64_t cap = recs_all + n_wg * nb * (int64_t)kEmitChunk + kEmitChunk;
     if (cap >= ((int64_t)1 << 32) - ((int64_t)1 << 22)) return SYBL_OK;
-    const size_t table_words = (size_t)n_wg * (size_t)n_parts;
-    size_t bytes = (size_t)cap * 4 + 3 * table_words * 4, free_b = 0, total_b = 0;
+    int64_t wg_rows_max = 0;
+    {
+        std::vector<int64_t> per_wg((size_t)n_wg, 0);
+        for (int64_t w = 0; w < n_wg && (size_t)w + 1 < q->wg_seg_begin.size(); w++)
+            for (int si = q->wg_seg_begin[(size_t)w]; si < q->wg_seg_begin[(size_t)w + 1]; si++) per_wg[(size_t)w] += q->segs[(size_t)si].n;
+        for (int64_t v : per_wg) wg_rows_max = std::max(wg_rows_max, v);
+    }
+    if ((wg_rows_max * na + nb * (int64_t)kEmitChunk) * 4 >= (int64_t)kEmitDropOffset) return SYBL_OK;
+    const size_t table_words = (size_t)n_wg * (size_t)(nb + 1) + (size_t)n_wg + 1;
+    size_t bytes = (size_t)cap * 4 + table_words * 4, free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || bytes + ((size_t)1 << 30) > free_b) return SYBL_OK;
     SYBL_HIP(hipMalloc((void **)&q->d_recs, (size_t)cap * 4));
-    // counts | woff | wend | part_off | part_tot in one allocation
-    SYBL_HIP(hipMalloc((void **)&q->d_cursor, (3 * table_words + 2 * (size_t)n_parts + 1) * 4));
+    // boff | wbase in one allocation
+    SYBL_HIP(hipMalloc((void **)&q->d_cursor, table_words * 4));
     E.recs = q->d_recs;
-    E.counts = q->d_cursor;
-    E.woff = E.counts + table_words;
-    E.wend = E.woff + table_words;
-    E.part_off = E.wend + table_words;
-    E.part_tot = E.part_off + n_parts + 1;
+    E.boff = q->d_cursor;
+    E.wbase = E.boff + (size_t)n_wg * (size_t)(nb + 1);
     E.n_parts = (int32_t)n_parts;
     E.n_aggs = na;
     E.n_wg = (int32_t)n_wg;
     E.sub_shift = ss;
-    {
-        int rs = 0;
-        while ((1 << (rs + 1)) <= kCountRepMax && (n_parts << (rs + 1)) <= kMaxParts) rs++;
-        E.count_rep_shift = rs;
-    }
     PartHistPlan &H = q->pplan;
     memset(&H, 0, sizeof(H));
     H.recs = q->d_recs;
-    H.part_off = E.part_off;
+    H.boff = E.boff;
+    H.wbase = E.wbase;
+    H.n_wg = (int32_t)n_wg;
+    H.sub_shift = ss;
     H.n_parts = (int32_t)n_parts;
     H.n_aggs = na;
     H.n_cells = P.n_cells;

@@ -98,15 +98,27 @@ hipError_t launch_scan_fast(const FastPlan &P, int nf, int ng, int na, int mode,
 // k_part_hist then lets one workgroup own a partition: its 32 bucket arrays, counts and sums
 // live in LDS, are updated with LDS atomics and are written out with plain stores.
 //
-// Records leave k_emit in CHUNKS of 16 (64 bytes, 64-byte aligned): round 1 flushed per-bin runs of ~9
-// records at arbitrary offsets behind one device-scope cursor atomic each and measured 112 M atomics and
-// 262 M write requests (77 % of them 32-byte partials, 10.3 GB written for 4 GB of records) per 1e9 rows.
-// Now the pass is a counting sort: k_count first counts every workgroup's records per partition (it reads
-// only the filter and key columns), k_part_offsets turns the counts into one exactly sized REGION per
-// (partition, workgroup) -- regions of a partition are contiguous, so k_part_hist reads one range -- and
-// k_emit stages one chunk per bin in LDS; the lane whose record completes a chunk copies it to the next
-// free chunk of its workgroup's region (an LDS cursor: no device-scope atomics, no overflow, the same
-// bytes in the same places on every run).  Partly filled chunks are padded with kRecSentinel.
+// The pass is a counting sort.  Records leave k_emit in CHUNKS of 16 (64 bytes, 64-byte aligned), one
+// staging chunk per BIN in LDS (a bin = a partition, or one of 1 << sub_shift sub-bins of a partition
+// chosen by the lane number when there are few partitions).  k_count first counts every workgroup's
+// records per bin (it reads only the filter and key columns) and lays the workgroup's output out as one
+// exactly sized REGION per bin, bins in order (boff); k_part_bases puts the workgroups' outputs behind
+// each other (wbase).  A bin's g-th full chunk therefore has a fixed place -- region start + g -- and
+// k_emit needs neither cursors nor device-scope atomics; the same bytes land in the same places on
+// every run; a region's last chunk is padded with kRecSentinel.  k_part_hist walks the n_wg regions of
+// its partition (the sub-bins of a partition are neighbours in a workgroup's output: one range).
+//
+// History (all measured on config 4, 1e9 rows): round 1 appended per-bin runs of ~9 records behind
+// device-scope cursors (112 M atomics, 77 % partial-line writes, 10.3 GB written for 4 GB of records:
+// 6.1 ms); round 2 made it a counting sort with partition-major regions, every lane copying the chunks
+// it completed with four 16-byte stores (3.9 ms); round 3 found what that waited for (profiles/
+// r03_cfg4_before_pmc.txt): 251 M 16-byte write requests from the L1s (four per chunk) with the L1's
+// write path saturated 80 % of the time, and -- loads and stores retiring in order on one counter --
+// a `s_waitcnt vmcnt(6)` for the column loads issued four tiles earlier that in fact waited for the
+// stores of the previous tile.  Now four neighbouring lanes write one chunk (one 64-byte request), a
+// wave writes its completed chunks with a FIXED number of store instructions per tile (lanes without a
+// chunk aim past the end of the workgroup's buffer descriptor: dropped by the range check), so the
+// compiler's count of younger operations is exact again and the column loads stay four tiles ahead.
 constexpr int kPartCells = 32;       // (cell, agg) pairs per partition
 constexpr int kPartCellBits = 5;
 constexpr int kBucketBits = 10;      // len(Values) <= 1024
@@ -114,28 +126,29 @@ constexpr int kRecValueBits = 27;    // v - h.Min < len(Values) * BucketSize <= 
 constexpr int kMaxParts = 2048;      // LDS staging in k_emit: one 16-record chunk per bin
 constexpr int kEmitMaxBins = 2048;   // bins = n_parts << sub_shift
 constexpr uint32_t kEmitChunk = 16;  // records per chunk
-constexpr int kEmitBinWords = 2 + (int)kEmitChunk;  // LDS words per bin: cnt, wr + the chunk (+ one cursor per partition)
+constexpr uint32_t kEmitQueue = 32;  // completed chunks a wave copies out per drain (two store instructions)
+constexpr int kEmitBinWords = 3 + (int)kEmitChunk;  // LDS words per bin: cnt, {wr, region start} + the chunk
 constexpr uint32_t kRecSentinel = 0xFFFFFFFFu;      // padding record (never a real one: planner)
-constexpr int kCountRepMax = 8;      // k_count: replicas of the LDS counters when there are few partitions
+constexpr uint32_t kEmitDropOffset = 0x80000000u;   // byte offset past any workgroup's output (< 2 GB: planner)
 
 struct EmitPlan {
     FastPlan fp;                     // columns, filters, group mapping, hmin / bucket geometry
-    uint32_t *recs;                  // the partition buffers, back to back (part_off)
-    uint32_t *counts;                // [n_wg][n_parts] records per (workgroup, partition): k_count
-    uint32_t *woff, *wend;           // [n_wg][n_parts] region of a workgroup in a partition buffer (record indices into recs)
-    uint32_t *part_off;              // [n_parts + 1] partition buffers in recs (record indices, multiples of kEmitChunk)
-    uint32_t *part_tot;              // [n_parts] chunks of a partition buffer: summed by k_count (zeroed before)
+    uint32_t *recs;                  // the workgroups' outputs, back to back (wbase)
+    uint32_t *boff;                  // [n_wg][nb + 1] first chunk of a bin's region inside its workgroup's output
+                                     // ([nb]: the output's chunks): k_count
+    uint32_t *wbase;                 // [n_wg + 1] first chunk of a workgroup's output in recs: k_part_bases
     int32_t n_parts, n_aggs, n_wg;
-    int32_t sub_shift;               // bins per partition = 1 << sub_shift (lanes spread over them so that
-                                     // few partitions do not serialise on one LDS counter)
-    int32_t count_rep_shift;         // k_count: 1 << count_rep_shift replicas of the partition counters
+    int32_t sub_shift;               // bins per partition = 1 << sub_shift (a lane's sub-bin follows from its lane
+                                     // number, in k_count and k_emit alike, so that few partitions do not serialise
+                                     // on a handful of LDS counters)
     int64_t *sum_out;                // header: matched / overflow
 };
 
 struct PartHistPlan {
     const uint32_t *recs;
-    const uint32_t *part_off;
+    const uint32_t *boff, *wbase;    // as in EmitPlan
     int32_t n_parts, n_aggs, n_cells, nv_max;
+    int32_t n_wg, sub_shift;
     int32_t split;                   // workgroups per partition (> 1: results are combined with atomics)
     int32_t n_values[kFastMaxA], f_sum[kFastMaxA], m_max[kFastMaxA];
     int64_t hmin[kFastMaxA], bucket_size[kFastMaxA], hist_agg_off[kFastMaxA];
@@ -148,16 +161,14 @@ struct PartHistPlan {
 // ~64 KB on the way to keep HBM busy; bounded by registers (one 16-byte register quad per column and tile)
 constexpr int emit_depth(int n_cols) { return n_cols <= 2 ? 4 : n_cols <= 4 ? 2 : 1; }
 constexpr int count_depth(int n_cols) { return n_cols <= 1 ? 8 : n_cols <= 2 ? 4 : n_cols <= 4 ? 2 : 1; }
-inline size_t emit_lds_bytes(const EmitPlan &E) { return (((size_t)E.n_parts << E.sub_shift) * kEmitBinWords + (size_t)E.n_parts) * 4; }
-inline size_t count_lds_bytes(const EmitPlan &E) { return ((size_t)E.n_parts << E.count_rep_shift) * 4; }
-// chunks a (workgroup, partition) region needs for c records spread over nsub bins
-__host__ __device__ inline uint32_t emit_region_chunks(uint32_t c, uint32_t nsub) {
-    return nsub == 1 ? (c + kEmitChunk - 1) / kEmitChunk : c / kEmitChunk + (c < nsub ? c : nsub);
+inline size_t emit_lds_bytes(const EmitPlan &E) {
+    return ((size_t)E.n_parts << E.sub_shift) * kEmitBinWords * 4 + (size_t)(kWgThreads / 64) * kEmitQueue * 8;
 }
+inline size_t count_lds_bytes(const EmitPlan &E) { return (((size_t)E.n_parts << E.sub_shift) + 64) * 4; }
 
 hipError_t launch_count(const EmitPlan &P, int nf, int ng, int n_wg, hipStream_t st);
 hipError_t launch_count_packed(const EmitPlan &P, int nf, int ng, int n_wg, hipStream_t st);
-hipError_t launch_part_offsets(const EmitPlan &P, hipStream_t st);
+hipError_t launch_part_bases(const EmitPlan &P, hipStream_t st);
 hipError_t launch_emit(const EmitPlan &P, int nf, int ng, int na, int n_wg, hipStream_t st);
 hipError_t launch_part_hist(const PartHistPlan &P, hipStream_t st);
 
@@ -562,27 +573,33 @@ __global__ __launch_bounds__(kWgThreads, 4) void k_scan_fast(const FastPlan P) {
 }
 
 // k_emit: filters + cell index exactly as k_scan_fast, but instead of accumulating it appends
-// rec = local pair << 27 | (v - h.Min) to the owning partition (the bucket divide happens in k_part_hist, which has
-// the issue slots to spare: k_emit is VALU-issue bound).
+// rec = local pair << 27 | (v - h.Min) to the owning partition (the bucket divide happens in k_part_hist).
 //
 // LDS staging of k_emit / k_emit_packed, per bin (nb = n_parts << sub_shift bins):
 //   cnt   records pushed so far: a push takes slot s = cnt++, generation g = s / 16
 //   wr    17 * (generations copied out) + records of the current generation in place: the
 //         generation-g record may be written once wr >= 17 g (generation g - 1 is out of the chunk),
-//         each writer then bumps wr, and the one that finds 17 g + 15 owns the complete chunk: it
-//         copies it to the partition buffer and bumps wr once more (-> 17 (g + 1))
+//         each writer then bumps wr, and the one that finds 17 g + 15 has completed the chunk: its wave
+//         copies it to chunk g of the bin's region and bumps wr once more (-> 17 (g + 1))
+//   start the bin's region inside the workgroup's output (in chunks; next to wr, so that one 8-byte read
+//         brings both)
 //   chunk 16 records; a record's place is rotated by bin / 2 so bins that fill in step spread over
 //         the LDS banks (the order of records inside a chunk is immaterial)
-// and per partition `pos`: the next free chunk of this workgroup's region.
+// and per wave a QUEUE of the chunks its last writes completed.
 // There is no workgroup barrier between the prologue and the final drain: waves run free.  A record that
 // finds its chunk still waiting to be copied out keeps its slot and is written on the lane's next visit
 // (EmitCarry); a wave only polls when one of its lanes has two such records, and then every lane of the
 // wave keeps retrying everything it holds -- the oldest incomplete generation of a bin can always be
-// written and its sixteenth writer copies it out at once, so the protocol cannot deadlock.
+// written and its sixteenth writer's wave copies it out at once, so the protocol cannot deadlock.
 // (Tried and dropped, measured on config 4: dedicated store waves polling wr -- 4.9 ms against 3.8: the
-// polling costs more LDS bandwidth and issue slots than the stores cost the scanning waves.)
+// polling costs more LDS bandwidth and issue slots than the stores cost the scanning waves; a barrier per
+// tile instead of the publication counter -- 5.0 ms.)
 struct EmitLds {
-    uint32_t *cnt, *wr, *pos, *chunk;
+    uint32_t *chunk, *cnt;  // [nb][16], [nb]
+    uint2 *meta;            // [nb] {wr, start}
+    uint2 *queue;           // [kEmitQueue] of this wave: {bin, chunk index in the workgroup's output}
+    uint32_t *out;          // the workgroup's output in recs
+    uint32_t out_bytes;
     uint32_t nb, ss, sub;
 };
 
@@ -593,24 +610,20 @@ __device__ __forceinline__ EmitLds emit_begin(const EmitPlan &E, uint32_t *elds)
     S.nb = (uint32_t)E.n_parts << S.ss;      // staging bins
     S.sub = tid & ((1u << S.ss) - 1);        // this lane's sub-bin
     S.chunk = elds;                          // [nb][16]  (64-byte aligned rows)
-    S.cnt = elds + S.nb * kEmitChunk;        // [nb]
-    S.wr = S.cnt + S.nb;                     // [nb]
-    S.pos = S.wr + S.nb;                     // [n_parts]
-    for (uint32_t i = tid; i < 2 * S.nb; i += kWgThreads) S.cnt[i] = 0;
-    const uint32_t *woff = E.woff + (size_t)blockIdx.x * (uint32_t)E.n_parts;
-    for (uint32_t i = tid; i < (uint32_t)E.n_parts; i += kWgThreads) S.pos[i] = woff[i];
+    S.meta = (uint2 *)(elds + S.nb * kEmitChunk);
+    uint2 *queues = S.meta + S.nb;           // [waves][kEmitQueue]
+    S.queue = queues + (tid >> 6) * kEmitQueue;
+    S.cnt = (uint32_t *)(queues + (kWgThreads / 64) * kEmitQueue);
+    const uint32_t *boff = E.boff + (size_t)blockIdx.x * (S.nb + 1);
+    for (uint32_t i = tid; i < S.nb; i += kWgThreads) {
+        S.cnt[i] = 0;
+        S.meta[i] = make_uint2(0u, boff[i]);
+    }
+    if (tid < (kWgThreads / 64) * kEmitQueue) queues[tid] = make_uint2(0u, 0u);
+    S.out = E.recs + (size_t)E.wbase[blockIdx.x] * kEmitChunk;
+    S.out_bytes = boff[S.nb] * (kEmitChunk * 4u);
     __syncthreads();
     return S;
-}
-
-// Writes one chunk (16 records, 64 bytes) at record index p of the partition buffers.
-__device__ __forceinline__ void emit_store_chunk(const EmitPlan &E, uint32_t p, const fu32x4 &r0, const fu32x4 &r1, const fu32x4 &r2,
-                                                 const fu32x4 &r3) {
-    fu32x4 *dst = (fu32x4 *)(E.recs + p);
-    dst[0] = r0;
-    dst[1] = r1;
-    dst[2] = r2;
-    dst[3] = r3;
 }
 
 // LDS operations of a wave are carried out in issue order, so ordering two of them only takes keeping the
@@ -631,55 +644,91 @@ struct EmitCarry {
     uint32_t bin, rec, slot, valid;
 };
 
-// bin numbers (< 2^16) of a lane's records packed four to a 64-bit word, so that picking the bin of record i
-// is a shift: indexing the register array with a run-time i sent it to scratch memory (a VMEM round trip
-// and a vmcnt(0) wait per chunk)
-template <int N>
-struct EmitBinPack {
-    unsigned long long w[(N + 3) / 4];
-    __device__ __forceinline__ explicit EmitBinPack(const uint32_t (&bin)[N]) {
-#pragma unroll
-        for (int k = 0; k < (N + 3) / 4; k++) w[k] = 0;
-#pragma unroll
-        for (int i = 0; i < N; i++) w[i / 4] |= (unsigned long long)(bin[i] & 0xFFFFu) << (16 * (i % 4));
-    }
-    __device__ __forceinline__ uint32_t get(uint32_t i) const {
-        static_assert(N <= 12, "at most twelve records per lane and call");
-        unsigned long long x = w[0];
-        if (N > 4) x = i >= 4 ? w[1] : x;
-        if (N > 8) x = i >= 8 ? w[(N + 3) / 4 - 1] : x;
-        return (uint32_t)(x >> (16 * (i & 3))) & 0xFFFFu;
-    }
-};
-
-// The chunks this lane's writes completed (bit i of `full`: record i was the sixteenth of its generation): copied to
-// the next free chunk of the workgroup's region.  A lane rarely owns more than one per tile, so loop over the lane's
-// own instead of running the copy once per record position.
+// Copies out the chunks this wave's writes completed (bit i of `full`: the lane's record i was the sixteenth of its
+// generation).  The owners queue {bin, destination chunk}; then lanes 4g .. 4g+3 copy queue entry g: each reads one
+// 16-byte quarter of the staged chunk and the four stores of a quad are ONE 64-byte write request (the lanes' own
+// stores of round 2 were four 16-byte requests per chunk, and their number saturated the L1's write path).  The
+// stores are raw buffer stores into the workgroup's output: a lane without an entry aims at kEmitDropOffset and the
+// descriptor's range check drops it, so every pass through here issues exactly kEmitQueue / 16 store instructions
+// -- with loads and stores retiring in order on one counter, a data-dependent number of stores between the column
+// loads and their use makes the compiler's `s_waitcnt vmcnt(N)` wait for the stores of the current tile instead of
+// the loads of four tiles ago.
 template <int M>
-__device__ __forceinline__ void emit_copy_full(const EmitPlan &E, const EmitLds &S, const EmitBinPack<M> &packed_bins, uint32_t full) {
-    while (full) {
-        const uint32_t i = (uint32_t)__builtin_ctz(full);
-        full &= full - 1;
-        const uint32_t b = packed_bins.get(i);
-        const uint32_t p = __hip_atomic_fetch_add(S.pos + (b >> S.ss), kEmitChunk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        const fu32x4 *c = (const fu32x4 *)(S.chunk + b * kEmitChunk);
-        const fu32x4 r0 = c[0], r1 = c[1], r2 = c[2], r3 = c[3];
-        emit_store_chunk(E, p, r0, r1, r2, r3);
-        lds_wait();  // the chunk has been read before the next generation may write
-        __hip_atomic_fetch_add(S.wr + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+__device__ __forceinline__ void emit_copy_full(const EmitLds &S, const uint32_t (&bin)[M], const uint32_t (&dest)[M], uint32_t full) {
+    const uint32_t lane = threadIdx.x & 63u, g = lane >> 2, j = lane & 3u;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)S.out, 0, (int)S.out_bytes, (int)0x00020000);
+    for (;;) {
+        uint32_t nq = 0;  // wave-uniform
+        for (;;) {
+            const bool has = full != 0;
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(has);
+            if (!m) break;
+            const uint32_t at = nq + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            if (has && at < kEmitQueue) {
+                const uint32_t i = (uint32_t)__builtin_ctz(full);
+                full &= full - 1;
+                uint32_t b = bin[0], d = dest[0];
+#pragma unroll
+                for (int k = 1; k < M; k++) {
+                    b = i == (uint32_t)k ? bin[k] : b;
+                    d = i == (uint32_t)k ? dest[k] : d;
+                }
+                S.queue[at] = make_uint2(b, d);
+            }
+            nq += (uint32_t)__builtin_popcountll(m);
+            if (nq >= kEmitQueue) {
+                nq = kEmitQueue;
+                break;
+            }
+        }
+        lds_order();
+        uint2 qe[kEmitQueue / 16];
+#pragma unroll
+        for (uint32_t k = 0; k < kEmitQueue / 16; k++) qe[k] = S.queue[k * 16 + g];
+        lds_wait();
+        fu32x4 piece[kEmitQueue / 16];
+        bool valid[kEmitQueue / 16];
+#pragma unroll
+        for (uint32_t k = 0; k < kEmitQueue / 16; k++) {
+            valid[k] = k * 16 + g < nq;
+            const uint32_t b = valid[k] ? qe[k].x : 0u;
+            piece[k] = ((const fu32x4 *)(S.chunk + b * kEmitChunk))[j];
+        }
+        lds_wait();  // (also: the chunks have been read before the next generation may write)
+#pragma unroll
+        for (uint32_t k = 0; k < kEmitQueue / 16; k++) {
+            const uint32_t off = valid[k] ? qe[k].y * (kEmitChunk * 4u) + j * 16u : kEmitDropOffset;
+            __builtin_amdgcn_raw_buffer_store_b128(piece[k], rsrc, (int)off, 0, 0);
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < kEmitQueue / 16; k++)
+            if (valid[k] && j == 0) __hip_atomic_fetch_add(&S.meta[qe[k].x].x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        lds_order();
+        if (!__builtin_amdgcn_ballot_w64(full != 0)) break;
     }
+}
+
+// The store instructions of one drain with every lane aimed past the end: k_emit's prologue issues them behind each
+// tile of column loads, so that the ring of loads and stores the compiler counts on the way into the tile loop is the
+// one every later round has (otherwise the waits of the whole loop are sized for the first round: three tiles of
+// loads and no stores between a tile's loads and their use).
+__device__ __forceinline__ void emit_pad_stores(const EmitLds &S) {
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)S.out, 0, (int)S.out_bytes, (int)0x00020000);
+    const fu32x4 none = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (uint32_t k = 0; k < kEmitQueue / 16; k++) __builtin_amdgcn_raw_buffer_store_b128(none, rsrc, (int)(kEmitDropOffset + 16u * k), 0, 0);  // (distinct, or they merge)
 }
 
 // Pushes the lane's records i with act[i] set, rec[i] into bin[i], and the record carried over from the previous
 // call; last_call: nothing may be left behind.  The first pass -- all there is for most lanes and tiles -- keeps its
 // predicates as booleans (lane masks in scalar registers); only a wave with a record left over goes on to the
-// bit-mask bookkeeping of the retry loop (a bit mask per lane costs a v_and + v_cmp per record and use: 45 VALU
-// instructions per tile in a kernel that is VALU-issue bound).
+// bit-mask bookkeeping of the retry loop.
 template <int N>
 __device__ __forceinline__ void emit_push_all(const EmitPlan &E, const EmitLds &S, const uint32_t (&bin_in)[N], const uint32_t (&rec_in)[N],
                                               const bool (&act)[N], EmitCarry &carry, bool last_call = false) {
     constexpr int M = N + 1;
-    uint32_t bin[M], rec[M], slot[M], w[M];
+    uint32_t bin[M], rec[M], slot[M], dest[M];
+    uint2 w[M];
     bool pend[M];
 #pragma unroll
     for (int i = 0; i < N; i++) {
@@ -690,28 +739,32 @@ __device__ __forceinline__ void emit_push_all(const EmitPlan &E, const EmitLds &
     bin[N] = carry.bin;
     rec[N] = carry.rec;
     pend[N] = carry.valid != 0;
-    // one LDS round trip in the common case: the slots and the bins' wr words (wr only grows: a value read
-    // early errs on the side of waiting)
+    // one LDS round trip in the common case: the slots and the bins' {wr, start} words (wr only grows: a value
+    // read early errs on the side of waiting)
 #pragma unroll
     for (int i = 0; i < N; i++)
         slot[i] = pend[i] ? __hip_atomic_fetch_add(S.cnt + bin[i], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
     slot[N] = carry.slot;
+    lds_order();
 #pragma unroll
-    for (int i = 0; i < M; i++) w[i] = pend[i] ? __hip_atomic_load(S.wr + bin[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
-    const EmitBinPack<M> packed_bins(bin);
+    for (int i = 0; i < M; i++) {
+        const unsigned long long x = pend[i] ? __hip_atomic_load((const unsigned long long *)(S.meta + bin[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0ull;
+        w[i] = make_uint2((uint32_t)x, (uint32_t)(x >> 32));
+    }
     carry.valid = 0;
     // ---- first pass
     lds_order();
     bool ok[M];
 #pragma unroll
     for (int i = 0; i < M; i++) {
-        ok[i] = pend[i] && w[i] >= 17u * (slot[i] >> 4);
+        ok[i] = pend[i] && w[i].x >= 17u * (slot[i] >> 4);
+        dest[i] = w[i].y + (slot[i] >> 4);
         if (ok[i]) S.chunk[bin[i] * kEmitChunk + ((slot[i] + (bin[i] >> 1)) & (kEmitChunk - 1))] = rec[i];
     }
     lds_order();  // the records go to LDS before wr says so (issue order)
     uint32_t old[M];
 #pragma unroll
-    for (int i = 0; i < M; i++) old[i] = ok[i] ? __hip_atomic_fetch_add(S.wr + bin[i], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
+    for (int i = 0; i < M; i++) old[i] = ok[i] ? __hip_atomic_fetch_add(&S.meta[bin[i]].x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
     uint32_t full = 0;
     bool left = false;
 #pragma unroll
@@ -721,7 +774,7 @@ __device__ __forceinline__ void emit_push_all(const EmitPlan &E, const EmitLds &
         left = left || pend[i];
     }
     lds_order();  // the chunk is read after wr showed the other 15 records in place
-    emit_copy_full<M>(E, S, packed_bins, full);
+    emit_copy_full<M>(S, bin, dest, full);
     if (!__builtin_amdgcn_ballot_w64(left)) return;
     // ---- some lane of the wave holds a record whose chunk is still waiting to be copied out
     uint32_t pmask = 0;
@@ -737,17 +790,17 @@ __device__ __forceinline__ void emit_push_all(const EmitPlan &E, const EmitLds &
             if (pmask) {
                 carry.valid = 1;
                 const uint32_t i = (uint32_t)__builtin_ctz(pmask);
-                carry.bin = packed_bins.get(i);
 #pragma unroll
                 for (int k = 0; k < M; k++)
                     if (i == (uint32_t)k) {
+                        carry.bin = bin[k];
                         carry.rec = rec[k];
                         carry.slot = slot[k];
                     }
             }
             break;
         }
-        if (!pmask) break;
+        if (!__builtin_amdgcn_ballot_w64(pmask != 0)) break;
         // poll again (bounded: a protocol bug must surface as an error from finalize, not as a hung GPU)
         if (++passes > (1u << 22)) {
             __hip_atomic_fetch_add(E.sum_out + kHdrEmitStall, (int64_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -755,12 +808,12 @@ __device__ __forceinline__ void emit_push_all(const EmitPlan &E, const EmitLds &
         }
 #pragma unroll
         for (int i = 0; i < M; i++)
-            w[i] = (pmask >> i) & 1u ? __hip_atomic_load(S.wr + bin[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
+            w[i].x = (pmask >> i) & 1u ? __hip_atomic_load(&S.meta[bin[i]].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
         lds_order();
         uint32_t okm = 0;
 #pragma unroll
         for (int i = 0; i < M; i++) {
-            if (((pmask >> i) & 1u) && w[i] >= 17u * (slot[i] >> 4)) {
+            if (((pmask >> i) & 1u) && w[i].x >= 17u * (slot[i] >> 4)) {
                 S.chunk[bin[i] * kEmitChunk + ((slot[i] + (bin[i] >> 1)) & (kEmitChunk - 1))] = rec[i];
                 okm |= 1u << i;
             }
@@ -768,13 +821,13 @@ __device__ __forceinline__ void emit_push_all(const EmitPlan &E, const EmitLds &
         lds_order();
 #pragma unroll
         for (int i = 0; i < M; i++)
-            old[i] = (okm >> i) & 1u ? __hip_atomic_fetch_add(S.wr + bin[i], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
+            old[i] = (okm >> i) & 1u ? __hip_atomic_fetch_add(&S.meta[bin[i]].x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
         full = 0;
 #pragma unroll
         for (int i = 0; i < M; i++)
             full |= ((okm >> i) & 1u) && old[i] == 17u * (slot[i] >> 4) + (kEmitChunk - 1) ? 1u << i : 0u;
         lds_order();
-        emit_copy_full<M>(E, S, packed_bins, full);
+        emit_copy_full<M>(S, bin, dest, full);
         pmask &= ~okm;
     }
 }
@@ -789,13 +842,11 @@ __device__ __forceinline__ void emit_scan_done(const EmitPlan &E, const EmitLds 
 __device__ __forceinline__ uint32_t emit_record(uint32_t pair, uint32_t n32) { return ((pair & (kPartCells - 1)) << kRecValueBits) | n32; }
 __device__ __forceinline__ uint32_t emit_bin(const EmitLds &S, uint32_t pair) { return ((pair >> kPartCellBits) << S.ss) | S.sub; }
 
-// Final drain: every bin's incomplete chunk goes out padded with sentinels, and so do the chunks of the
-// workgroup's regions that were provisioned for partly filled sub-bins but not needed.
+// Final drain: every bin's incomplete chunk goes out as the last chunk of its region, padded with sentinels.
 __device__ __forceinline__ void emit_finish(const EmitPlan &E, const EmitLds &S, uint32_t matched, uint32_t overflow) {
     __syncthreads();
-    const fu32x4 pad = {kRecSentinel, kRecSentinel, kRecSentinel, kRecSentinel};
     for (uint32_t bin = threadIdx.x; bin < S.nb; bin += kWgThreads) {
-        const uint32_t left = S.cnt[bin] & (kEmitChunk - 1);
+        const uint32_t n = S.cnt[bin], left = n & (kEmitChunk - 1);
         if (left) {
             uint32_t r[kEmitChunk];
 #pragma unroll
@@ -804,16 +855,13 @@ __device__ __forceinline__ void emit_finish(const EmitPlan &E, const EmitLds &S,
                 const uint32_t logical = (k - (bin >> 1)) & (kEmitChunk - 1);
                 r[k] = logical < left ? S.chunk[bin * kEmitChunk + k] : kRecSentinel;
             }
-            const fu32x4 r0 = {r[0], r[1], r[2], r[3]}, r1 = {r[4], r[5], r[6], r[7]}, r2 = {r[8], r[9], r[10], r[11]},
-                         r3 = {r[12], r[13], r[14], r[15]};
-            const uint32_t p = __hip_atomic_fetch_add(S.pos + (bin >> S.ss), kEmitChunk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            emit_store_chunk(E, p, r0, r1, r2, r3);
+            fu32x4 *dst = (fu32x4 *)(S.out + (size_t)(S.meta[bin].y + (n >> 4)) * kEmitChunk);
+            dst[0] = fu32x4{r[0], r[1], r[2], r[3]};
+            dst[1] = fu32x4{r[4], r[5], r[6], r[7]};
+            dst[2] = fu32x4{r[8], r[9], r[10], r[11]};
+            dst[3] = fu32x4{r[12], r[13], r[14], r[15]};
         }
     }
-    __syncthreads();
-    const uint32_t *wend = E.wend + (size_t)blockIdx.x * (uint32_t)E.n_parts;
-    for (uint32_t part = threadIdx.x; part < (uint32_t)E.n_parts; part += kWgThreads)
-        for (uint32_t p = S.pos[part]; p < wend[part]; p += kEmitChunk) emit_store_chunk(E, p, pad, pad, pad, pad);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         matched += __shfl_xor(matched, o, 64);
@@ -825,25 +873,44 @@ __device__ __forceinline__ void emit_finish(const EmitPlan &E, const EmitLds &S,
     }
 }
 
-// k_count: the first pass of the counting sort -- the same rows, filters and cell computation as k_emit
-// for the same workgroup, but only the filter and key columns are read and a workgroup's records are
-// only counted per partition: counts[workgroup][partition].
+// k_count: the first pass of the counting sort -- the same rows, filters, cell computation and lane -> sub-bin
+// mapping as k_emit for the same workgroup, but only the filter and key columns are read and a workgroup's
+// records are only counted per bin.  Its epilogue lays the workgroup's output out: boff[workgroup][bin] = the
+// chunks of the bins before it (every bin's region is a whole number of chunks), boff[workgroup][nb] = all of them.
 __device__ __forceinline__ uint32_t *count_begin(const EmitPlan &E, uint32_t *clds) {
-    const uint32_t n = (uint32_t)E.n_parts << E.count_rep_shift;
-    for (uint32_t i = threadIdx.x; i < n; i += kWgThreads) clds[i] = 0;
+    const uint32_t nb = (uint32_t)E.n_parts << E.sub_shift;
+    for (uint32_t i = threadIdx.x; i < nb + 64; i += kWgThreads) clds[i] = 0;
     __syncthreads();
-    return clds + (threadIdx.x & ((1u << E.count_rep_shift) - 1)) * (uint32_t)E.n_parts;  // this lane's replica
+    return clds + (threadIdx.x & ((1u << E.sub_shift) - 1));  // counter of bin (part, this lane's sub-bin): mine[part << ss]
 }
-__device__ __forceinline__ void count_finish(const EmitPlan &E, const uint32_t *clds) {
+__device__ __forceinline__ void count_finish(const EmitPlan &E, uint32_t *clds) {
     __syncthreads();
-    uint32_t *out = E.counts + (size_t)blockIdx.x * (uint32_t)E.n_parts;
-    for (uint32_t p = threadIdx.x; p < (uint32_t)E.n_parts; p += kWgThreads) {
-        uint32_t n = 0;
-        for (uint32_t r = 0; r < (1u << E.count_rep_shift); r++) n += clds[r * (uint32_t)E.n_parts + p];
-        out[p] = n;
-        const uint32_t chunks = emit_region_chunks(n, 1u << E.sub_shift);
-        if (chunks) __hip_atomic_fetch_add(E.part_tot + p, chunks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t nb = (uint32_t)E.n_parts << E.sub_shift, tid = threadIdx.x;
+    static_assert(kEmitMaxBins <= 2 * kWgThreads, "two bins per thread");
+    uint32_t *wave_tot = clds + nb;  // [16]
+    // exclusive scan of the bins' chunk counts: two consecutive bins per thread, wave scan, wave totals
+    const uint32_t c0 = 2 * tid < nb ? (clds[2 * tid] + kEmitChunk - 1) / kEmitChunk : 0u;
+    const uint32_t c1 = 2 * tid + 1 < nb ? (clds[2 * tid + 1] + kEmitChunk - 1) / kEmitChunk : 0u;
+    uint32_t x = c0 + c1;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t y = __shfl_up(x, o, 64);
+        if ((int)(tid & 63) >= o) x += y;
     }
+    if ((tid & 63) == 63) wave_tot[tid >> 6] = x;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+#pragma unroll
+    for (uint32_t v = 0; v < kWgThreads / 64; v++) {
+        const uint32_t t = wave_tot[v];
+        before += v < (tid >> 6) ? t : 0u;
+        total += t;
+    }
+    const uint32_t excl = before + x - (c0 + c1);
+    uint32_t *out = E.boff + (size_t)blockIdx.x * (nb + 1);
+    if (2 * tid < nb) out[2 * tid] = excl;
+    if (2 * tid + 1 < nb) out[2 * tid + 1] = excl + c0;
+    if (tid == 0) out[nb] = total;
 }
 
 template <int NF, int NG>
@@ -852,7 +919,7 @@ __global__ __launch_bounds__(kWgThreads, 4) void k_count(const EmitPlan E) {
     const FastPlan &P = E.fp;
     const uint32_t tid = threadIdx.x;
     uint32_t *mine = count_begin(E, elds);
-    const uint32_t na = (uint32_t)E.n_aggs;
+    const uint32_t na = (uint32_t)E.n_aggs, ss = (uint32_t)E.sub_shift;
     const int s0 = P.wg_seg_begin[blockIdx.x], s1 = P.wg_seg_begin[blockIdx.x + 1];
     for (int si = s0; si < s1; si++) {
         const Segment seg = P.segs[si];
@@ -895,7 +962,7 @@ __global__ __launch_bounds__(kWgThreads, 4) void k_count(const EmitPlan E) {
                     cell += (uint32_t)d * (uint32_t)P.gstride[c];
                 }
                 // the row's records (one per aggregation) are consecutive pairs of one partition: kPartCells is even
-                if (pass) __hip_atomic_fetch_add(mine + ((cell * na) >> kPartCellBits), na, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (pass) __hip_atomic_fetch_add(mine + (((cell * na) >> kPartCellBits) << ss), na, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
           }
         }
@@ -931,12 +998,13 @@ __global__ __launch_bounds__(kWgThreads, 4) void k_emit(const EmitPlan E) {
 #pragma unroll
         for (int d = 0; d < D; d++) {
                 fast_load<NF, NG, NA, false>(P, in_seg(row_first + (int64_t)d * kTile), fr[d], gr[d], ar[d], t0);
+                emit_pad_stores(S);  // (the ring as the steady state has it: see emit_pad_stores)
                 __builtin_amdgcn_sched_barrier(0);  // oldest tile first: the ring is consumed in this order
             }
         for (int64_t it0 = 0; it0 < n_tiles; it0 += D) {
 #pragma unroll
           for (int d = 0; d < D; d++) {
-            if (it0 + d >= n_tiles) break;
+            // (no early exit inside a round: the rows of a tile past the end fail `row + r < end`; see k_emit_packed)
             const int64_t row = row_first + (it0 + d) * kTile;
             const FastTile<NF> f0 = fr[d];
             const FastTile<NG> g0 = gr[d];

@@ -394,12 +394,15 @@ __global__ __launch_bounds__(kWgThreads, 4) void k_emit_packed(const EmitPlan E)
 #pragma unroll
             for (int d = 0; d < D; d++) {
                 packed_issue_always<NF, NG, NA>(P, B, r_first + (uint32_t)d * kTile, n, rf[d], rg[d], ra[d]);
+                emit_pad_stores(S);  // (the ring as the steady state has it: see emit_pad_stores)
                 __builtin_amdgcn_sched_barrier(0);  // oldest tile first: the ring is consumed in this order
             }
             for (uint32_t it0 = 0; it0 < n_tiles; it0 += D) {
 #pragma unroll
               for (int d = 0; d < D; d++) {
-                if (it0 + d >= n_tiles) break;
+                // (no early exit inside a round: a tile past the end loads nothing -- the descriptor's range check -- and
+                // pushes nothing; a conditional exit here is one more path the compiler's load / store counting must
+                // take the minimum over)
                 const uint32_t r = r_first + (it0 + d) * kTile;   // (< 2^28 + 2^12: no wrap)
                 packed_decode_all<NF, NG, NA, false, false, false>(P, rf[d], rg[d], ra[d], rt, f, g, a, t, 0u);
                 packed_issue_always<NF, NG, NA>(P, B, r + (uint32_t)D * kTile, n, rf[d], rg[d], ra[d]);
@@ -449,7 +452,7 @@ __global__ __launch_bounds__(kWgThreads, 4) void k_count_packed(const EmitPlan E
     const FastPlan &P = E.fp;
     const uint32_t tid = threadIdx.x;
     uint32_t *mine = count_begin(E, elds);
-    const uint32_t na = (uint32_t)E.n_aggs;
+    const uint32_t na = (uint32_t)E.n_aggs, ss = (uint32_t)E.sub_shift;
     const int s0 = P.wg_seg_begin[blockIdx.x], s1 = P.wg_seg_begin[blockIdx.x + 1];
     for (int si = s0; si < s1; si++) {
         const Segment seg = P.segs[si];
@@ -502,7 +505,7 @@ __global__ __launch_bounds__(kWgThreads, 4) void k_count_packed(const EmitPlan E
                         pass = pass & (d < P.gcard[c]);
                         cell += __umul24(d, (uint32_t)P.gstride[c]);
                     }
-                    if (pass) __hip_atomic_fetch_add(mine + ((cell * na) >> kPartCellBits), na, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (pass) __hip_atomic_fetch_add(mine + (((cell * na) >> kPartCellBits) << ss), na, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
               }
             }
