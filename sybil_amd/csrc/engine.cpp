@@ -183,8 +183,11 @@ static int scan(Query *q) {
         e = q->part_packed ? launch_emit_packed(q->eplan, q->part_nf, q->part_ng, q->part_na, q->n_wg, st)
                            : launch_emit(q->eplan, q->part_nf, q->part_ng, q->part_na, q->n_wg, st);
         if (e != hipSuccess) return hip_fail(e, "k_emit");
+        SYBL_HIP(hipMemsetAsync(q->pplan.wrap_log, 0, 8, st));
         e = launch_part_hist(q->pplan, st);
         if (e != hipSuccess) return hip_fail(e, "k_part_hist");
+        e = launch_part_fix(q->pplan, st);
+        if (e != hipSuccess) return hip_fail(e, "k_part_fix");
         SYBL_HIP(hipEventRecord(q->ev[1], st));
         SYBL_HIP(hipEventRecord(q->ev[2], st));
         if ((rc = scan_distinct(q, ran, st))) return rc;

@@ -516,62 +516,107 @@ hipError_t launch_remap_ids(const void *local, int local_width, const int32_t *l
 }
 
 // ---------------------------------------------------------------- partitioned histograms
-// k_part_hist: one workgroup owns one partition = kPartCells (cell, agg) pairs.  Their bucket
-// arrays (uint32) and exact sums of v - h.Min live in LDS (the bucket divide is done here, not in k_emit); every record costs two LDS atomics (three
-// when a maximum is tracked); the results are written with plain stores (each pair has exactly one
-// owner), so the [cell][agg][bucket] table, Count and sum(v) come out deterministic and
-// atomics-free in HBM.  The partition buffer is whole 16-record chunks up to its cursor, padded
-// with kRecSentinel (scan_fast.h).
-constexpr int kPartSumRep = 8;   // replicas of the per-pair value sums (lanes of a wave hit only 32 pairs)
+// k_part_hist: one workgroup owns one partition = kPartCells (cell, agg) pairs.  Their bucket arrays and exact sums of
+// v - h.Min live in LDS (the bucket divide is done here, not in k_emit); every record costs two LDS atomics (three when a
+// maximum is tracked); the results are written with plain stores (each pair has exactly one owner), so the
+// [cell][agg][bucket] table, Count and sum(v) come out deterministic and atomics-free in HBM.
+//
+// The bucket counters are 16 bits wide, two to an LDS word (64 pairs x 1002 buckets x 2 B = 125 KB: what lets a
+// partition be 64 pairs and k_emit stage two chunks per bin, scan_fast.h).  A counter that wraps is not lost: the
+// atomic add returns the word as it was, so the one lane whose add wrapped a field sees it (field == 0xFFFF before the
+// add) and logs the event; k_part_fix adds the logged 65536s to the table afterwards.  A wrap of the low field also
+// carries into the high field of the same word: the same lane logs a -1 for that bucket, and a +65536 if the carry in
+// turn wrapped it (old word == 0xFFFFFFFF).  Every wrap of every field is seen by exactly one add, so
+//   true count = field + 65536 x (logged wraps) - (logged carries in)
+// holds exactly whatever the order.  At most 3 entries per 65536 records: the log is sized for that.
+constexpr int kPartSumRep = 8;   // replicas of the per-pair value sums (lanes of a wave hit only 64 pairs)
 constexpr int kPartUnroll = 4;   // 16-byte record loads per lane in flight, twice (current + next)
+constexpr uint32_t kWrapPlus = 0u, kWrapMinusOne = 1u;  // log entry kinds: +65536 / -1
 
+__device__ __noinline__ void part_log_wrap(const PartHistPlan &P, uint32_t pair, uint32_t bucket, uint32_t old, uint32_t nv) {
+    // (rare path) bucket's field was 0xFFFF before this lane's add; old >> 16 = an even bucket's neighbour field then
+    uint32_t kinds[3], buckets[3], n = 0;
+    buckets[n] = bucket, kinds[n++] = kWrapPlus;
+    if ((bucket & 1u) == 0 && bucket + 1 < nv) {
+        buckets[n] = bucket + 1, kinds[n++] = kWrapMinusOne;                        // the carry into the high field
+        if ((old >> 16) == 0xFFFFu) buckets[n] = bucket + 1, kinds[n++] = kWrapPlus;  // ... which wrapped it
+    }
+    const uint32_t at = __hip_atomic_fetch_add(P.wrap_log, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (at + n > P.wrap_cap) {
+        __hip_atomic_fetch_add(P.sum_out + kHdrPartOverflow, (int64_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    for (uint32_t k = 0; k < n; k++) {
+        P.wrap_log[2 + 2 * (at + k)] = pair;
+        P.wrap_log[3 + 2 * (at + k)] = buckets[k] | kinds[k] << 16;
+    }
+}
+
+template <int NA, bool TRACK_MAX>
 __global__ __launch_bounds__(kWgThreads) void k_part_hist(const PartHistPlan P) {
     extern __shared__ uint32_t plds[];
     const uint32_t tid = threadIdx.x;
-    const uint32_t nv = (uint32_t)P.nv_max;
-    uint32_t *hist = plds;                                       // [kPartCells][nv]
-    uint32_t *cnt = plds + kPartCells * nv;                      // [kPartCells]
-    unsigned long long *sum = (unsigned long long *)(cnt + kPartCells + (kPartCells & 1));  // [kPartSumRep][kPartCells]
+    const uint32_t nv = (uint32_t)P.nv_max, nw = (nv + 1u) >> 1;  // buckets, words per pair
+    uint32_t *hist = plds;                                       // [kPartCells][nw] two 16-bit counters per word
+    uint32_t *cnt = plds + kPartCells * nw;                      // [kPartCells]
+    unsigned long long *sum = (unsigned long long *)(cnt + kPartCells);                     // [kPartCells][kPartSumRep]
     long long *vmax = (long long *)(sum + kPartSumRep * kPartCells);                        // [kPartCells]
-    for (uint32_t i = tid; i < kPartCells * nv; i += kWgThreads) hist[i] = 0;
+    for (uint32_t i = tid; i < kPartCells * nw; i += kWgThreads) hist[i] = 0;
     if (tid < kPartSumRep * kPartCells) sum[tid] = 0;
     if (tid < kPartCells) {
         cnt[tid] = 0;
         vmax[tid] = INT64_MIN;
     }
-    __syncthreads();
 
     const uint32_t split = (uint32_t)P.split;
     const uint32_t part = blockIdx.x / split, sub = blockIdx.x % split;
     const uint32_t *recs = P.recs;
     const uint32_t pair0 = part * kPartCells;
-    unsigned long long *my_sum = sum + (tid & (kPartSumRep - 1)) * kPartCells;
-    const bool track_max = P.m_max[0] >= 0 || (P.n_aggs > 1 && P.m_max[1] >= 0);
-    // pair0 is a multiple of kPartCells, so with one or two aggregations a pair's aggregation is a bit of `local`
-    const bool two = P.n_aggs == 2;
+    unsigned long long *my_sum = sum + (tid & (kPartSumRep - 1));  // [pair][replica]: the replicas of a pair in different banks
+    // pair0 is a multiple of kPartCells, so with two aggregations a pair's aggregation is the low bit of `local`
+    // (NA, and whether any maximum is tracked, are template parameters: as run-time values they cost a chain of
+    // selects per record in a kernel whose vector ALUs are ~70 % busy)
+    constexpr bool two = NA == 2;
     const uint32_t bs0 = (uint32_t)P.bucket_size[0], bs1 = (uint32_t)P.bucket_size[two ? 1 : 0];
     const double inv0 = P.pinv_bucket[0], inv1 = P.pinv_bucket[two ? 1 : 0];
-    auto add_record = [&](uint32_t rec) {
-        if (rec == kRecSentinel) return;
-        const uint32_t n32 = rec & ((1u << kRecValueBits) - 1);  // v - h.Min
-        const uint32_t local = rec >> kRecValueBits;
-        const uint32_t a = two ? (local & 1u) : (P.n_aggs == 1 ? 0u : (pair0 + local) % (uint32_t)P.n_aggs);
-        const uint32_t bs = P.n_aggs <= 2 ? (a ? bs1 : bs0) : (uint32_t)P.bucket_size[a];
-        const double inv = P.n_aggs <= 2 ? (a ? inv1 : inv0) : P.pinv_bucket[a];
+    auto bucket_of = [&](uint32_t rec, uint32_t &local, uint32_t &n32) -> uint32_t {
+        n32 = rec & ((1u << kRecValueBits) - 1);  // v - h.Min
+        local = rec >> kRecValueBits;
+        const uint32_t a = two ? (local & 1u) : 0u;
+        const uint32_t bs = two && a ? bs1 : bs0;
+        const double inv = two && a ? inv1 : inv0;
         // floor(n32 / BucketSize), hist_basic.go:130-150: the estimate is never above the quotient and at most one short
         // of it (scan_packed.h: packed_udiv); bucket < 2^10 and BucketSize < 2^24 (planner), so the product takes 24 bits
         uint32_t b = (uint32_t)((double)n32 * inv);
         if (n32 - __umul24(b, bs) >= bs) b += 1;
+        return b;
+    };
+    // returns the word as it was before the add, shifted so that the bucket's own field is the low half (an even
+    // bucket's neighbour field is then the high half); 0 for a padding record
+    auto add_record = [&](uint32_t rec) -> uint32_t {
+        if (rec == kRecSentinel) return 0u;
+        uint32_t local, n32;
+        const uint32_t b = bucket_of(rec, local, n32);
         // (the pair's count is the sum of its buckets, taken at read-out; sum(v - h.Min) is accumulated exactly)
-        __hip_atomic_fetch_add(hist + local * nv + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(my_sum + local, (unsigned long long)n32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (track_max) {
+        const uint32_t sh = (b & 1u) << 4;
+        const uint32_t old = __hip_atomic_fetch_add(hist + local * nw + (b >> 1), 1u << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(my_sum + local * kPartSumRep, (unsigned long long)n32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (TRACK_MAX) {
+            const uint32_t a = two ? (local & 1u) : 0u;
             if (P.m_max[a] >= 0) {
                 const long long v = (long long)((unsigned long long)P.hmin[a] + (unsigned long long)n32);
                 if (v > vmax[local]) __hip_atomic_fetch_max(vmax + local, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
+        return old >> sh;
     };
+    auto wrapped = [](uint32_t seen) { return (seen & 0xFFFFu) == 0xFFFFu; };
+    auto log_wrap = [&](uint32_t rec, uint32_t seen) {  // (rare)
+        uint32_t local, n32;
+        const uint32_t b = bucket_of(rec, local, n32);
+        part_log_wrap(P, pair0 + local, b, (b & 1u) ? 0u : seen, nv);
+    };
+
     // The partition's records: one region per scanning workgroup w (the partition's sub-bins are neighbours in w's
     // output: chunks boff[w][part << ss] .. boff[w][(part + 1) << ss] behind wbase[w]).  `split` workgroups share a
     // partition by taking every split-th region; inside a workgroup every wave walks its own regions, 16-byte pieces
@@ -582,17 +627,25 @@ __global__ __launch_bounds__(kWgThreads) void k_part_hist(const PartHistPlan P) 
     const uint32_t b_lo = part << P.sub_shift, b_hi = (part + 1u) << P.sub_shift;
     const uint32_t n_reg = (uint32_t)P.n_wg > sub ? ((uint32_t)P.n_wg - sub + split - 1u) / split : 0u;
     constexpr uint32_t kBatch = 64u * kPartUnroll;  // pieces per wave and batch
+    // this workgroup's regions {first chunk, pieces}, fetched once (boff is [workgroup][bin]: a strided read)
+    uint2 *regions = (uint2 *)(vmax + kPartCells);  // [n_reg]
+    for (uint32_t k = tid; k < n_reg; k += kWgThreads) {
+        const uint32_t w = sub + k * split;
+        const uint32_t *bo = P.boff + (size_t)w * nb1;
+        const uint32_t lo = bo[b_lo], hi = bo[b_hi];
+        regions[k] = make_uint2(P.wbase[w] + lo, (hi - lo) * (kEmitChunk / 4u));
+    }
+    __syncthreads();
     uint32_t r = wave, i0 = 0, n4 = 0, c0 = 0;      // region, first piece of the next batch, pieces, first chunk (wave-uniform)
     auto open_region = [&]() {
         // skips empty regions; n4 == 0 afterwards: no region left
         n4 = 0;
         while (r < n_reg) {
-            const uint32_t w = __builtin_amdgcn_readfirstlane(sub + r * split);
-            const uint32_t *bo = P.boff + (size_t)w * nb1;
-            const uint32_t lo = bo[b_lo], hi = bo[b_hi];
-            if (hi > lo) {
-                c0 = P.wbase[w] + lo;
-                n4 = (hi - lo) * (kEmitChunk / 4u);
+            const uint2 g = regions[r];
+            const uint32_t pieces = __builtin_amdgcn_readfirstlane(g.y);
+            if (pieces) {
+                c0 = __builtin_amdgcn_readfirstlane(g.x);
+                n4 = pieces;
                 i0 = 0;
                 return;
             }
@@ -620,13 +673,26 @@ __global__ __launch_bounds__(kWgThreads) void k_part_hist(const PartHistPlan P) 
     issue(cur, cur_first, cur_n);
     while (cur_n) {
         issue(nxt, nxt_first, nxt_n);
+        uint32_t seen[kPartUnroll][4];
 #pragma unroll
         for (int u = 0; u < kPartUnroll; u++) {
-            if (cur_first + (uint32_t)u * 64u + lane < cur_n) {
-                add_record(cur[u].x);
-                add_record(cur[u].y);
-                add_record(cur[u].z);
-                add_record(cur[u].w);
+            const bool in = cur_first + (uint32_t)u * 64u + lane < cur_n;
+            seen[u][0] = add_record(in ? cur[u].x : kRecSentinel);
+            seen[u][1] = add_record(in ? cur[u].y : kRecSentinel);
+            seen[u][2] = add_record(in ? cur[u].z : kRecSentinel);
+            seen[u][3] = add_record(in ? cur[u].w : kRecSentinel);
+        }
+        bool any = false;
+#pragma unroll
+        for (int u = 0; u < kPartUnroll; u++)
+            any = any || wrapped(seen[u][0]) || wrapped(seen[u][1]) || wrapped(seen[u][2]) || wrapped(seen[u][3]);
+        if (any) {
+#pragma unroll
+            for (int u = 0; u < kPartUnroll; u++) {
+                if (wrapped(seen[u][0])) log_wrap(cur[u].x, seen[u][0]);
+                if (wrapped(seen[u][1])) log_wrap(cur[u].y, seen[u][1]);
+                if (wrapped(seen[u][2])) log_wrap(cur[u].z, seen[u][2]);
+                if (wrapped(seen[u][3])) log_wrap(cur[u].w, seen[u][3]);
             }
         }
 #pragma unroll
@@ -635,37 +701,43 @@ __global__ __launch_bounds__(kWgThreads) void k_part_hist(const PartHistPlan P) 
         cur_n = nxt_n;
     }
     __syncthreads();
-    // cnt[l] = sum over the buckets of pair l: each wave sums a strided share, one LDS atomic per wave
+    // cnt[l] = sum over the buckets of pair l (as the fields hold them: k_part_fix adds what the log says): each wave
+    // sums a strided share, one LDS atomic per wave
     for (uint32_t l = 0; l < (uint32_t)kPartCells; l++) {
         uint32_t n = 0;
-        for (uint32_t b = tid; b < nv; b += kWgThreads) n += hist[l * nv + b];
+        for (uint32_t k = tid; k < nw; k += kWgThreads) {
+            const uint32_t x = hist[l * nw + k];
+            n += (x & 0xFFFFu) + (x >> 16);
+        }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
         if ((tid & 63) == 0 && n) __hip_atomic_fetch_add(cnt + l, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     __syncthreads();
+    unsigned long long pair_sum = 0;
     if (tid < kPartCells) {
-        unsigned long long t = 0;
 #pragma unroll
-        for (int r = 0; r < kPartSumRep; r++) t += sum[r * kPartCells + tid];
-        sum[tid] = t;
+        for (int r2 = 0; r2 < kPartSumRep; r2++) pair_sum += sum[tid * kPartSumRep + r2];
     }
+    __syncthreads();
+    if (tid < kPartCells) sum[tid] = pair_sum;
     __syncthreads();
 
     int64_t *F = P.sum_out + kHeaderWords;
-    const uint32_t total_pairs = (uint32_t)P.n_cells * (uint32_t)P.n_aggs;
+    const uint32_t total_pairs = (uint32_t)P.n_cells * (uint32_t)NA;
     for (uint32_t l = 0; l < (uint32_t)kPartCells; l++) {
         const uint32_t pair = pair0 + l;
         if (pair >= total_pairs) break;
-        const uint32_t cell = pair / (uint32_t)P.n_aggs, a = pair % (uint32_t)P.n_aggs;
+        const uint32_t cell = pair / (uint32_t)NA, a = pair % (uint32_t)NA;
         int64_t *h = P.sum_out + P.hist_off + (int64_t)cell * P.hist_stride + P.hist_agg_off[a];
         const uint32_t c = cnt[l];
         // every aggregation accepts every row here (planner: no rejects / missing values), so
         // Result.Count of the cell is the count of any of its aggregations
         const int64_t vsum = (int64_t)(sum[l] + (unsigned long long)c * (unsigned long long)P.hmin[a]);
+        const uint32_t *hl = hist + l * nw;
         if (split == 1) {
             // sole owner of the pair: plain stores, nothing to zero beforehand
-            for (uint32_t b = tid; b < (uint32_t)P.n_values[a]; b += kWgThreads) h[b] = (int64_t)hist[l * nv + b];
+            for (uint32_t b = tid; b < (uint32_t)P.n_values[a]; b += kWgThreads) h[b] = (int64_t)((hl[b >> 1] >> ((b & 1u) << 4)) & 0xFFFFu);
             if (tid == 0) {
                 if (a == 0) F[cell] = (int64_t)c;
                 F[(int64_t)P.f_sum[a] * P.n_cells + cell] = vsum;
@@ -674,7 +746,7 @@ __global__ __launch_bounds__(kWgThreads) void k_part_hist(const PartHistPlan P) 
         } else {
             // `split` workgroups share the pair: combine into the zeroed table
             for (uint32_t b = tid; b < (uint32_t)P.n_values[a]; b += kWgThreads) {
-                const uint32_t x = hist[l * nv + b];
+                const uint32_t x = (hl[b >> 1] >> ((b & 1u) << 4)) & 0xFFFFu;
                 if (x) gadd(h + b, (int64_t)x);
             }
             if (tid == 0 && c) {
@@ -686,6 +758,28 @@ __global__ __launch_bounds__(kWgThreads) void k_part_hist(const PartHistPlan P) 
             }
         }
     }
+}
+
+// k_part_fix: the wraps k_part_hist logged (see there), applied to the finished table: +65536 (or -1) on the bucket,
+// and what follows from it for the pair's count -- Result.Count of the cell (taken from aggregation 0) and sum(v) =
+// sum(v - h.Min) + count x h.Min.  Runs behind k_part_hist on the same stream; the log is empty unless some
+// (group, bucket) of one partition pass holds 65536 or more values.
+__global__ __launch_bounds__(256) void k_part_fix(const PartHistPlan P) {
+    const uint32_t n = min(P.wrap_log[0], P.wrap_cap);
+    int64_t *F = P.sum_out + kHeaderWords;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t pair = P.wrap_log[2 + 2 * i], e = P.wrap_log[3 + 2 * i];
+        const uint32_t bucket = e & 0xFFFFu, cell = pair / (uint32_t)P.n_aggs, a = pair % (uint32_t)P.n_aggs;
+        const int64_t delta = (e >> 16) == kWrapPlus ? 65536 : -1;
+        gadd(P.sum_out + P.hist_off + (int64_t)cell * P.hist_stride + P.hist_agg_off[a] + bucket, delta);
+        if (a == 0) gadd(F + cell, delta);
+        gadd(F + (int64_t)P.f_sum[a] * P.n_cells + cell, delta * P.hmin[a]);
+    }
+}
+
+hipError_t launch_part_fix(const PartHistPlan &P, hipStream_t st) {
+    hipLaunchKernelGGL(k_part_fix, dim3(64), dim3(256), 0, st, P);
+    return hipGetLastError();
 }
 
 // k_part_bases: wbase[w] = the chunks of the workgroups before w (boff[w][nb] is w's own total: k_count), wbase[n_wg] =
@@ -725,13 +819,23 @@ hipError_t launch_part_bases(const EmitPlan &E, hipStream_t st) {
     return hipGetLastError();
 }
 
+template <int NA, bool TRACK_MAX>
+static hipError_t part_hist_launch(const PartHistPlan &P, size_t lds, hipStream_t st) {
+    auto k = k_part_hist<NA, TRACK_MAX>;
+    hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, dim3(P.n_parts * P.split), dim3(kWgThreads), lds, st, P);
+    return hipGetLastError();
+}
+
 hipError_t launch_part_hist(const PartHistPlan &P, hipStream_t st) {
     if (P.n_parts <= 0) return hipSuccess;
-    size_t lds = ((size_t)kPartCells * P.nv_max + kPartCells + 2) * 4 + (size_t)kPartCells * (kPartSumRep + 1) * 8 + 16;
-    hipError_t e = hipFuncSetAttribute((const void *)k_part_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_part_hist, dim3(P.n_parts * P.split), dim3(kWgThreads), lds, st, P);
-    return hipGetLastError();
+    const uint32_t n_reg = ((uint32_t)P.n_wg + (uint32_t)P.split - 1u) / (uint32_t)P.split;
+    size_t lds = ((size_t)kPartCells * ((P.nv_max + 1) / 2) + kPartCells) * 4 + (size_t)kPartCells * (kPartSumRep + 1) * 8 + (size_t)n_reg * 8 + 16;
+    const bool track_max = P.m_max[0] >= 0 || (P.n_aggs > 1 && P.m_max[1] >= 0);
+    if (P.n_aggs == 1) return track_max ? part_hist_launch<1, true>(P, lds, st) : part_hist_launch<1, false>(P, lds, st);
+    if (P.n_aggs == 2) return track_max ? part_hist_launch<2, true>(P, lds, st) : part_hist_launch<2, false>(P, lds, st);
+    return hipErrorInvalidValue;
 }
 
 // ---------------------------------------------------------------- histogram summaries (finalize)

@@ -369,6 +369,7 @@ static int select_part_hist(Table *t, Query *q, const std::vector<int> &slot_col
     // the records would leave most of a bin's chunks padding.
     const int64_t recs_all = rows_scanned * na;
     const int64_t n_wg = std::max(1, q->n_wg);
+    if (n_wg > 2048) return SYBL_OK;  // k_part_hist keeps one region descriptor per scanning workgroup in LDS
     int ss = 0;
     while ((n_parts << (ss + 1)) <= kEmitMaxBins) ss++;
     while (ss > 0 && recs_all / (n_wg * (n_parts << ss)) < 64) ss--;
@@ -386,11 +387,13 @@ static int select_part_hist(Table *t, Query *q, const std::vector<int> &slot_col
         for (int64_t v : per_wg) wg_rows_max = std::max(wg_rows_max, v);
     }
     if ((wg_rows_max * na + nb * (int64_t)kEmitChunk) * 4 >= (int64_t)kEmitDropOffset) return SYBL_OK;
-    const size_t table_words = (size_t)n_wg * (size_t)(nb + 1) + (size_t)n_wg + 1;
+    // k_part_hist's 16-bit bucket counters log their wraps: at most 3 entries per 65536 records (kernels.hip)
+    const size_t wrap_cap = (size_t)(3 * (recs_all / 65536 + 1) + 4096);
+    const size_t table_words = (size_t)n_wg * (size_t)(nb + 1) + (size_t)n_wg + 1 + 2 + 2 * wrap_cap;
     size_t bytes = (size_t)cap * 4 + table_words * 4, free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || bytes + ((size_t)1 << 30) > free_b) return SYBL_OK;
     SYBL_HIP(hipMalloc((void **)&q->d_recs, (size_t)cap * 4));
-    // boff | wbase in one allocation
+    // boff | wbase | wrap log in one allocation
     SYBL_HIP(hipMalloc((void **)&q->d_cursor, table_words * 4));
     E.recs = q->d_recs;
     E.boff = q->d_cursor;
@@ -406,6 +409,8 @@ static int select_part_hist(Table *t, Query *q, const std::vector<int> &slot_col
     H.wbase = E.wbase;
     H.n_wg = (int32_t)n_wg;
     H.sub_shift = ss;
+    H.wrap_log = E.wbase + n_wg + 1;
+    H.wrap_cap = (uint32_t)wrap_cap;
     H.n_parts = (int32_t)n_parts;
     H.n_aggs = na;
     H.n_cells = P.n_cells;

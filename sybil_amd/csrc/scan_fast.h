@@ -118,16 +118,22 @@ hipError_t launch_scan_fast(const FastPlan &P, int nf, int ng, int na, int mode,
 // stores of the previous tile.  Now four neighbouring lanes write one chunk (one 64-byte request), a
 // wave writes its completed chunks with a FIXED number of store instructions per tile (lanes without a
 // chunk aim past the end of the workgroup's buffer descriptor: dropped by the range check), so the
-// compiler's count of younger operations is exact again and the column loads stay four tiles ahead.
-constexpr int kPartCells = 32;       // (cell, agg) pairs per partition
-constexpr int kPartCellBits = 5;
+// compiler's count of younger operations is exact again and the column loads stay four tiles ahead
+// (3.3 ms).  That left the vector ALUs 80 % busy (profiles/r03_cfg4_v3_pmc.txt), 40 % of it on records
+// that found their bin's single staging chunk complete but not yet copied out (5 % of all records: one
+// retry pass per tile and a carried record per lane).  So a bin now stages TWO chunks, generations
+// alternating between them: a record only waits when its bin receives sixteen more records while a
+// chunk is being copied out, and the retry path is cold.  The LDS for that comes from halving the bins:
+// a partition is 64 (cell, agg) pairs, whose bucket arrays k_part_hist keeps as 16-bit counters.
+constexpr int kPartCells = 64;       // (cell, agg) pairs per partition
+constexpr int kPartCellBits = 6;
 constexpr int kBucketBits = 10;      // len(Values) <= 1024
-constexpr int kRecValueBits = 27;    // v - h.Min < len(Values) * BucketSize <= 2^10 * 2^17 (planner: select_part_hist)
-constexpr int kMaxParts = 2048;      // LDS staging in k_emit: one 16-record chunk per bin
-constexpr int kEmitMaxBins = 2048;   // bins = n_parts << sub_shift
+constexpr int kRecValueBits = 26;    // v - h.Min < len(Values) * BucketSize < 2^26 (planner: select_part_hist)
+constexpr int kMaxParts = 1024;      // LDS staging in k_emit: two 16-record chunks per bin
+constexpr int kEmitMaxBins = 1024;   // bins = n_parts << sub_shift
 constexpr uint32_t kEmitChunk = 16;  // records per chunk
 constexpr uint32_t kEmitQueue = 32;  // completed chunks a wave copies out per drain (two store instructions)
-constexpr int kEmitBinWords = 3 + (int)kEmitChunk;  // LDS words per bin: cnt, {wr, region start} + the chunk
+constexpr int kEmitBinWords = 4 + 2 * (int)kEmitChunk;  // LDS words per bin: {cnt, wr0, wr1, region start} + two chunks
 constexpr uint32_t kRecSentinel = 0xFFFFFFFFu;      // padding record (never a real one: planner)
 constexpr uint32_t kEmitDropOffset = 0x80000000u;   // byte offset past any workgroup's output (< 2 GB: planner)
 
@@ -150,6 +156,8 @@ struct PartHistPlan {
     int32_t n_parts, n_aggs, n_cells, nv_max;
     int32_t n_wg, sub_shift;
     int32_t split;                   // workgroups per partition (> 1: results are combined with atomics)
+    uint32_t *wrap_log;              // [0]: entries used, then {pair, bucket | kind << 16}: 16-bit counters that wrapped
+    uint32_t wrap_cap;               // entries the log holds
     int32_t n_values[kFastMaxA], f_sum[kFastMaxA], m_max[kFastMaxA];
     int64_t hmin[kFastMaxA], bucket_size[kFastMaxA], hist_agg_off[kFastMaxA];
     double pinv_bucket[kFastMaxA];   // 1 / BucketSize scaled by (1 - 2^-40): the quotient estimate is never above the true one
@@ -171,6 +179,7 @@ hipError_t launch_count_packed(const EmitPlan &P, int nf, int ng, int n_wg, hipS
 hipError_t launch_part_bases(const EmitPlan &P, hipStream_t st);
 hipError_t launch_emit(const EmitPlan &P, int nf, int ng, int na, int n_wg, hipStream_t st);
 hipError_t launch_part_hist(const PartHistPlan &P, hipStream_t st);
+hipError_t launch_part_fix(const PartHistPlan &P, hipStream_t st);
 
 #ifdef __HIPCC__
 
@@ -576,28 +585,27 @@ __global__ __launch_bounds__(kWgThreads, 4) void k_scan_fast(const FastPlan P) {
 // rec = local pair << 27 | (v - h.Min) to the owning partition (the bucket divide happens in k_part_hist).
 //
 // LDS staging of k_emit / k_emit_packed, per bin (nb = n_parts << sub_shift bins):
-//   cnt   records pushed so far: a push takes slot s = cnt++, generation g = s / 16
-//   wr    17 * (generations copied out) + records of the current generation in place: the
-//         generation-g record may be written once wr >= 17 g (generation g - 1 is out of the chunk),
-//         each writer then bumps wr, and the one that finds 17 g + 15 has completed the chunk: its wave
-//         copies it to chunk g of the bin's region and bumps wr once more (-> 17 (g + 1))
-//   start the bin's region inside the workgroup's output (in chunks; next to wr, so that one 8-byte read
-//         brings both)
-//   chunk 16 records; a record's place is rotated by bin / 2 so bins that fill in step spread over
-//         the LDS banks (the order of records inside a chunk is immaterial)
+//   cnt    records pushed so far: a push takes slot s = cnt++, generation g = s / 16, which uses chunk g & 1
+//          of the bin for the (g / 2 + 1)-th time
+//   wr[h]  of chunk h: 17 * (generations copied out of it) + records of its current generation in place: a
+//          generation-g record may be written once wr[g & 1] >= 17 (g / 2) (generation g - 2 is out of the chunk),
+//          each writer then bumps it, and the one that finds 17 (g / 2) + 15 has completed the chunk: its wave
+//          copies it to chunk g of the bin's region and bumps wr once more (-> 17 (g / 2 + 1))
+//   start  the bin's region inside the workgroup's output (in chunks; {cnt, wr0, wr1, start} are one 16-byte read)
+//   chunks 2 x 16 records; a record's place is rotated by the bin number so bins that fill in step spread over
+//          the LDS banks (the order of records inside a chunk is immaterial)
 // and per wave a QUEUE of the chunks its last writes completed.
-// There is no workgroup barrier between the prologue and the final drain: waves run free.  A record that
-// finds its chunk still waiting to be copied out keeps its slot and is written on the lane's next visit
-// (EmitCarry); a wave only polls when one of its lanes has two such records, and then every lane of the
-// wave keeps retrying everything it holds -- the oldest incomplete generation of a bin can always be
-// written and its sixteenth writer's wave copies it out at once, so the protocol cannot deadlock.
+// There is no workgroup barrier between the prologue and the final drain: waves run free.  A record whose chunk
+// still holds generation g - 2 (its bin received 16 more records while that was being copied out: rare) makes its
+// wave poll -- every lane of the wave keeps retrying everything it holds; the oldest incomplete generation of a bin
+// can always be written and its sixteenth writer's wave copies it out at once, so the protocol cannot deadlock.
 // (Tried and dropped, measured on config 4: dedicated store waves polling wr -- 4.9 ms against 3.8: the
 // polling costs more LDS bandwidth and issue slots than the stores cost the scanning waves; a barrier per
-// tile instead of the publication counter -- 5.0 ms.)
+// tile instead of the publication counters -- 5.0 ms.)
 struct EmitLds {
-    uint32_t *chunk, *cnt;  // [nb][16], [nb]
-    uint2 *meta;            // [nb] {wr, start}
-    uint2 *queue;           // [kEmitQueue] of this wave: {bin, chunk index in the workgroup's output}
+    uint32_t *chunk;        // [nb][2][16]
+    uint4 *meta;            // [nb] {cnt, wr0, wr1, start}
+    uint2 *queue;           // [kEmitQueue] of this wave: {bin << 1 | chunk of the bin, chunk index in the workgroup's output}
     uint32_t *out;          // the workgroup's output in recs
     uint32_t out_bytes;
     uint32_t nb, ss, sub;
@@ -609,16 +617,12 @@ __device__ __forceinline__ EmitLds emit_begin(const EmitPlan &E, uint32_t *elds)
     S.ss = (uint32_t)E.sub_shift;
     S.nb = (uint32_t)E.n_parts << S.ss;      // staging bins
     S.sub = tid & ((1u << S.ss) - 1);        // this lane's sub-bin
-    S.chunk = elds;                          // [nb][16]  (64-byte aligned rows)
-    S.meta = (uint2 *)(elds + S.nb * kEmitChunk);
-    uint2 *queues = S.meta + S.nb;           // [waves][kEmitQueue]
+    S.chunk = elds;                          // [nb][2][16]  (128-byte rows)
+    S.meta = (uint4 *)(elds + S.nb * 2 * kEmitChunk);
+    uint2 *queues = (uint2 *)(S.meta + S.nb);  // [waves][kEmitQueue]
     S.queue = queues + (tid >> 6) * kEmitQueue;
-    S.cnt = (uint32_t *)(queues + (kWgThreads / 64) * kEmitQueue);
     const uint32_t *boff = E.boff + (size_t)blockIdx.x * (S.nb + 1);
-    for (uint32_t i = tid; i < S.nb; i += kWgThreads) {
-        S.cnt[i] = 0;
-        S.meta[i] = make_uint2(0u, boff[i]);
-    }
+    for (uint32_t i = tid; i < S.nb; i += kWgThreads) S.meta[i] = make_uint4(0u, 0u, 0u, boff[i]);
     if (tid < (kWgThreads / 64) * kEmitQueue) queues[tid] = make_uint2(0u, 0u);
     S.out = E.recs + (size_t)E.wbase[blockIdx.x] * kEmitChunk;
     S.out_bytes = boff[S.nb] * (kEmitChunk * 4u);
@@ -636,25 +640,17 @@ __device__ __forceinline__ void lds_wait() {
     lds_order();
 }
 
-// A record whose chunk was still waiting to be copied out when its lane came by: it keeps its slot and is
-// written on the lane's next visit (one tile later, when the copy has long happened).  Without it a wave
-// stops and polls whenever ANY of its 256 records of a tile finds its bin in that state -- with 2048 bins
-// completing a chunk every eight tiles that is most tiles.
-struct EmitCarry {
-    uint32_t bin, rec, slot, valid;
-};
-
 // Copies out the chunks this wave's writes completed (bit i of `full`: the lane's record i was the sixteenth of its
-// generation).  The owners queue {bin, destination chunk}; then lanes 4g .. 4g+3 copy queue entry g: each reads one
-// 16-byte quarter of the staged chunk and the four stores of a quad are ONE 64-byte write request (the lanes' own
-// stores of round 2 were four 16-byte requests per chunk, and their number saturated the L1's write path).  The
-// stores are raw buffer stores into the workgroup's output: a lane without an entry aims at kEmitDropOffset and the
-// descriptor's range check drops it, so every pass through here issues exactly kEmitQueue / 16 store instructions
-// -- with loads and stores retiring in order on one counter, a data-dependent number of stores between the column
-// loads and their use makes the compiler's `s_waitcnt vmcnt(N)` wait for the stores of the current tile instead of
-// the loads of four tiles ago.
+// generation; which[i] = bin << 1 | chunk of the bin, dest[i] = its place in the workgroup's output).  The owners queue
+// {which, dest}; then lanes 4g .. 4g+3 copy queue entry g: each reads one 16-byte quarter of the staged chunk and the
+// four stores of a quad are ONE 64-byte write request (the lanes' own stores of round 2 were four 16-byte requests per
+// chunk, and their number saturated the L1's write path).  The stores are raw buffer stores into the workgroup's
+// output: a lane without an entry aims at kEmitDropOffset and the descriptor's range check drops it, so every pass
+// through here issues exactly kEmitQueue / 16 store instructions -- with loads and stores retiring in order on one
+// counter, a data-dependent number of stores between the column loads and their use makes the compiler's
+// `s_waitcnt vmcnt(N)` wait for the stores of the current tile instead of the loads of four tiles ago.
 template <int M>
-__device__ __forceinline__ void emit_copy_full(const EmitLds &S, const uint32_t (&bin)[M], const uint32_t (&dest)[M], uint32_t full) {
+__device__ __forceinline__ void emit_copy_full(const EmitLds &S, const uint32_t (&which)[M], const uint32_t (&dest)[M], uint32_t full) {
     const uint32_t lane = threadIdx.x & 63u, g = lane >> 2, j = lane & 3u;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)S.out, 0, (int)S.out_bytes, (int)0x00020000);
     for (;;) {
@@ -667,10 +663,10 @@ __device__ __forceinline__ void emit_copy_full(const EmitLds &S, const uint32_t 
             if (has && at < kEmitQueue) {
                 const uint32_t i = (uint32_t)__builtin_ctz(full);
                 full &= full - 1;
-                uint32_t b = bin[0], d = dest[0];
+                uint32_t b = which[0], d = dest[0];
 #pragma unroll
                 for (int k = 1; k < M; k++) {
-                    b = i == (uint32_t)k ? bin[k] : b;
+                    b = i == (uint32_t)k ? which[k] : b;
                     d = i == (uint32_t)k ? dest[k] : d;
                 }
                 S.queue[at] = make_uint2(b, d);
@@ -691,10 +687,10 @@ __device__ __forceinline__ void emit_copy_full(const EmitLds &S, const uint32_t 
 #pragma unroll
         for (uint32_t k = 0; k < kEmitQueue / 16; k++) {
             valid[k] = k * 16 + g < nq;
-            const uint32_t b = valid[k] ? qe[k].x : 0u;
-            piece[k] = ((const fu32x4 *)(S.chunk + b * kEmitChunk))[j];
+            const uint32_t c = valid[k] ? qe[k].x : 0u;
+            piece[k] = ((const fu32x4 *)(S.chunk + c * kEmitChunk))[j];
         }
-        lds_wait();  // (also: the chunks have been read before the next generation may write)
+        lds_wait();  // (also: the chunks have been read before their next generation may write)
 #pragma unroll
         for (uint32_t k = 0; k < kEmitQueue / 16; k++) {
             const uint32_t off = valid[k] ? qe[k].y * (kEmitChunk * 4u) + j * 16u : kEmitDropOffset;
@@ -702,7 +698,8 @@ __device__ __forceinline__ void emit_copy_full(const EmitLds &S, const uint32_t 
         }
 #pragma unroll
         for (uint32_t k = 0; k < kEmitQueue / 16; k++)
-            if (valid[k] && j == 0) __hip_atomic_fetch_add(&S.meta[qe[k].x].x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (valid[k] && j == 0)
+                __hip_atomic_fetch_add((uint32_t *)(S.meta + (qe[k].x >> 1)) + 1 + (qe[k].x & 1u), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         lds_order();
         if (!__builtin_amdgcn_ballot_w64(full != 0)) break;
     }
@@ -719,124 +716,93 @@ __device__ __forceinline__ void emit_pad_stores(const EmitLds &S) {
     for (uint32_t k = 0; k < kEmitQueue / 16; k++) __builtin_amdgcn_raw_buffer_store_b128(none, rsrc, (int)(kEmitDropOffset + 16u * k), 0, 0);  // (distinct, or they merge)
 }
 
-// Pushes the lane's records i with act[i] set, rec[i] into bin[i], and the record carried over from the previous
-// call; last_call: nothing may be left behind.  The first pass -- all there is for most lanes and tiles -- keeps its
-// predicates as booleans (lane masks in scalar registers); only a wave with a record left over goes on to the
-// bit-mask bookkeeping of the retry loop.
+// Pushes the lane's records i with act[i] set, rec[i] into bin[i].  The first pass -- all there is for nearly every
+// tile -- keeps its predicates as booleans (lane masks in scalar registers); only a wave with a record whose chunk still
+// holds the generation before last goes on to the bit-mask bookkeeping of the retry loop.
 template <int N>
-__device__ __forceinline__ void emit_push_all(const EmitPlan &E, const EmitLds &S, const uint32_t (&bin_in)[N], const uint32_t (&rec_in)[N],
-                                              const bool (&act)[N], EmitCarry &carry, bool last_call = false) {
-    constexpr int M = N + 1;
-    uint32_t bin[M], rec[M], slot[M], dest[M];
-    uint2 w[M];
-    bool pend[M];
-#pragma unroll
-    for (int i = 0; i < N; i++) {
-        bin[i] = bin_in[i];
-        rec[i] = rec_in[i];
-        pend[i] = act[i];
-    }
-    bin[N] = carry.bin;
-    rec[N] = carry.rec;
-    pend[N] = carry.valid != 0;
-    // one LDS round trip in the common case: the slots and the bins' {wr, start} words (wr only grows: a value
-    // read early errs on the side of waiting)
+__device__ __forceinline__ void emit_push_all(const EmitPlan &E, const EmitLds &S, const uint32_t (&bin)[N], const uint32_t (&rec)[N],
+                                              const bool (&act)[N]) {
+    uint32_t slot[N], dest[N], which[N], thr[N], pos[N];
+    fu32x4 w[N];
+    bool pend[N];
+    // one LDS round trip in the common case: the slots and the bins' {cnt, wr0, wr1, start} words (wr only grows: a
+    // value read early errs on the side of waiting)
 #pragma unroll
     for (int i = 0; i < N; i++)
-        slot[i] = pend[i] ? __hip_atomic_fetch_add(S.cnt + bin[i], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
-    slot[N] = carry.slot;
+        slot[i] = act[i] ? __hip_atomic_fetch_add((uint32_t *)(S.meta + bin[i]), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
     lds_order();
 #pragma unroll
-    for (int i = 0; i < M; i++) {
-        const unsigned long long x = pend[i] ? __hip_atomic_load((const unsigned long long *)(S.meta + bin[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0ull;
-        w[i] = make_uint2((uint32_t)x, (uint32_t)(x >> 32));
+    for (int i = 0; i < N; i++) {
+        // (two relaxed 8-byte loads: a volatile 16-byte one makes the compiler drain every counter around it)
+        const unsigned long long *m = (const unsigned long long *)(S.meta + bin[i]);
+        const unsigned long long lo = act[i] ? __hip_atomic_load(m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0ull;
+        const unsigned long long hi = act[i] ? __hip_atomic_load(m + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0ull;
+        w[i] = fu32x4{(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)};
     }
-    carry.valid = 0;
     // ---- first pass
     lds_order();
-    bool ok[M];
+    bool ok[N];
 #pragma unroll
-    for (int i = 0; i < M; i++) {
-        ok[i] = pend[i] && w[i].x >= 17u * (slot[i] >> 4);
-        dest[i] = w[i].y + (slot[i] >> 4);
-        if (ok[i]) S.chunk[bin[i] * kEmitChunk + ((slot[i] + (bin[i] >> 1)) & (kEmitChunk - 1))] = rec[i];
+    for (int i = 0; i < N; i++) {
+        const uint32_t gen = slot[i] >> 4, h = gen & 1u;
+        thr[i] = 17u * (gen >> 1);
+        which[i] = bin[i] << 1 | h;
+        dest[i] = w[i].w + gen;
+        pos[i] = which[i] * kEmitChunk + ((slot[i] + bin[i]) & (kEmitChunk - 1));
+        ok[i] = act[i] && (h ? w[i].z : w[i].y) >= thr[i];
+        if (ok[i]) S.chunk[pos[i]] = rec[i];
     }
     lds_order();  // the records go to LDS before wr says so (issue order)
-    uint32_t old[M];
+    uint32_t old[N];
 #pragma unroll
-    for (int i = 0; i < M; i++) old[i] = ok[i] ? __hip_atomic_fetch_add(&S.meta[bin[i]].x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
+    for (int i = 0; i < N; i++)
+        old[i] = ok[i] ? __hip_atomic_fetch_add((uint32_t *)(S.meta + bin[i]) + 1 + (which[i] & 1u), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
     uint32_t full = 0;
     bool left = false;
 #pragma unroll
-    for (int i = 0; i < M; i++) {
-        full |= ok[i] && old[i] == 17u * (slot[i] >> 4) + (kEmitChunk - 1) ? 1u << i : 0u;
-        pend[i] = pend[i] && !ok[i];
+    for (int i = 0; i < N; i++) {
+        full |= ok[i] && old[i] == thr[i] + (kEmitChunk - 1) ? 1u << i : 0u;
+        pend[i] = act[i] && !ok[i];
         left = left || pend[i];
     }
     lds_order();  // the chunk is read after wr showed the other 15 records in place
-    emit_copy_full<M>(S, bin, dest, full);
+    emit_copy_full<N>(S, which, dest, full);
     if (!__builtin_amdgcn_ballot_w64(left)) return;
-    // ---- some lane of the wave holds a record whose chunk is still waiting to be copied out
+    // ---- some lane of the wave holds a record whose chunk is still waiting to be copied out (rare)
     uint32_t pmask = 0;
 #pragma unroll
-    for (int i = 0; i < M; i++) pmask |= pend[i] ? 1u << i : 0u;
+    for (int i = 0; i < N; i++) pmask |= pend[i] ? 1u << i : 0u;
     uint32_t passes = 0;
-    while (true) {
-        // Leave with at most one record per lane in hand -- but only if that holds for the WHOLE wave: a lane
-        // that stays to poll may be waiting for a generation another lane of this wave has a slot in, and
-        // that lane must then keep retrying too (it cannot come back before the wave leaves this call).
-        const bool must_stay = pmask != 0 && (last_call || passes != 0 || (pmask & (pmask - 1)) != 0);
-        if (!__builtin_amdgcn_ballot_w64(must_stay)) {
-            if (pmask) {
-                carry.valid = 1;
-                const uint32_t i = (uint32_t)__builtin_ctz(pmask);
-#pragma unroll
-                for (int k = 0; k < M; k++)
-                    if (i == (uint32_t)k) {
-                        carry.bin = bin[k];
-                        carry.rec = rec[k];
-                        carry.slot = slot[k];
-                    }
-            }
-            break;
-        }
-        if (!__builtin_amdgcn_ballot_w64(pmask != 0)) break;
-        // poll again (bounded: a protocol bug must surface as an error from finalize, not as a hung GPU)
+    while (__builtin_amdgcn_ballot_w64(pmask != 0)) {
+        // poll (bounded: a protocol bug must surface as an error from finalize, not as a hung GPU)
         if (++passes > (1u << 22)) {
             __hip_atomic_fetch_add(E.sum_out + kHdrEmitStall, (int64_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             break;
         }
+        uint32_t wr[N];
 #pragma unroll
-        for (int i = 0; i < M; i++)
-            w[i].x = (pmask >> i) & 1u ? __hip_atomic_load(&S.meta[bin[i]].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
+        for (int i = 0; i < N; i++)
+            wr[i] = (pmask >> i) & 1u ? __hip_atomic_load((uint32_t *)(S.meta + bin[i]) + 1 + (which[i] & 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
         lds_order();
         uint32_t okm = 0;
 #pragma unroll
-        for (int i = 0; i < M; i++) {
-            if (((pmask >> i) & 1u) && w[i].x >= 17u * (slot[i] >> 4)) {
-                S.chunk[bin[i] * kEmitChunk + ((slot[i] + (bin[i] >> 1)) & (kEmitChunk - 1))] = rec[i];
+        for (int i = 0; i < N; i++) {
+            if (((pmask >> i) & 1u) && wr[i] >= thr[i]) {
+                S.chunk[pos[i]] = rec[i];
                 okm |= 1u << i;
             }
         }
         lds_order();
 #pragma unroll
-        for (int i = 0; i < M; i++)
-            old[i] = (okm >> i) & 1u ? __hip_atomic_fetch_add(&S.meta[bin[i]].x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
+        for (int i = 0; i < N; i++)
+            old[i] = (okm >> i) & 1u ? __hip_atomic_fetch_add((uint32_t *)(S.meta + bin[i]) + 1 + (which[i] & 1u), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
         full = 0;
 #pragma unroll
-        for (int i = 0; i < M; i++)
-            full |= ((okm >> i) & 1u) && old[i] == 17u * (slot[i] >> 4) + (kEmitChunk - 1) ? 1u << i : 0u;
+        for (int i = 0; i < N; i++) full |= ((okm >> i) & 1u) && old[i] == thr[i] + (kEmitChunk - 1) ? 1u << i : 0u;
         lds_order();
-        emit_copy_full<M>(S, bin, dest, full);
+        emit_copy_full<N>(S, which, dest, full);
         pmask &= ~okm;
     }
-}
-
-// A wave has pushed its last record: the carried one, if any, goes in now.
-__device__ __forceinline__ void emit_scan_done(const EmitPlan &E, const EmitLds &S, EmitCarry &carry) {
-    const uint32_t none[1] = {0};
-    const bool nobody[1] = {false};
-    emit_push_all<1>(E, S, none, none, nobody, carry, true);
 }
 
 __device__ __forceinline__ uint32_t emit_record(uint32_t pair, uint32_t n32) { return ((pair & (kPartCells - 1)) << kRecValueBits) | n32; }
@@ -846,16 +812,18 @@ __device__ __forceinline__ uint32_t emit_bin(const EmitLds &S, uint32_t pair) { 
 __device__ __forceinline__ void emit_finish(const EmitPlan &E, const EmitLds &S, uint32_t matched, uint32_t overflow) {
     __syncthreads();
     for (uint32_t bin = threadIdx.x; bin < S.nb; bin += kWgThreads) {
-        const uint32_t n = S.cnt[bin], left = n & (kEmitChunk - 1);
+        const uint4 m = S.meta[bin];
+        const uint32_t n = m.x, left = n & (kEmitChunk - 1), gen = n >> 4;
         if (left) {
+            const uint32_t *c = S.chunk + (bin << 1 | (gen & 1u)) * kEmitChunk;
             uint32_t r[kEmitChunk];
 #pragma unroll
             for (uint32_t k = 0; k < kEmitChunk; k++) {
                 // the record in place k was pushed as number (k - rotation) mod 16 of its generation
-                const uint32_t logical = (k - (bin >> 1)) & (kEmitChunk - 1);
-                r[k] = logical < left ? S.chunk[bin * kEmitChunk + k] : kRecSentinel;
+                const uint32_t logical = (k - bin) & (kEmitChunk - 1);
+                r[k] = logical < left ? c[k] : kRecSentinel;
             }
-            fu32x4 *dst = (fu32x4 *)(S.out + (size_t)(S.meta[bin].y + (n >> 4)) * kEmitChunk);
+            fu32x4 *dst = (fu32x4 *)(S.out + (size_t)(m.w + gen) * kEmitChunk);
             dst[0] = fu32x4{r[0], r[1], r[2], r[3]};
             dst[1] = fu32x4{r[4], r[5], r[6], r[7]};
             dst[2] = fu32x4{r[8], r[9], r[10], r[11]};
@@ -979,7 +947,6 @@ __global__ __launch_bounds__(kWgThreads, 4) void k_emit(const EmitPlan E) {
 
     uint32_t matched = 0, overflow = 0;
     constexpr int64_t kTile = kTileRows;
-    EmitCarry carry = {0, 0, 0, 0};
     const int s0 = P.wg_seg_begin[blockIdx.x], s1 = P.wg_seg_begin[blockIdx.x + 1];
     for (int si = s0; si < s1; si++) {
         const Segment seg = P.segs[si];
@@ -1041,11 +1008,10 @@ __global__ __launch_bounds__(kWgThreads, 4) void k_emit(const EmitPlan E) {
                     act[r * NA + c] = pass && inb;
                 }
             }
-            emit_push_all<kRowsPerThread * NA>(E, S, bin, rec, act, carry);
+            emit_push_all<kRowsPerThread * NA>(E, S, bin, rec, act);
           }
         }
     }
-    emit_scan_done(E, S, carry);
     emit_finish(E, S, matched, overflow);
 }
 

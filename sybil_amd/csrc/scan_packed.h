@@ -364,7 +364,6 @@ __global__ __launch_bounds__(kWgThreads, 4) void k_emit_packed(const EmitPlan E)
 
     uint32_t matched = 0, overflow = 0;
     constexpr uint32_t kTile = kPackedTileRows;
-    EmitCarry carry = {0, 0, 0, 0};
     const int s0 = P.wg_seg_begin[blockIdx.x], s1 = P.wg_seg_begin[blockIdx.x + 1];
     for (int si = s0; si < s1; si++) {
         const Segment seg = P.segs[si];
@@ -436,12 +435,11 @@ __global__ __launch_bounds__(kWgThreads, 4) void k_emit_packed(const EmitPlan E)
                         act[k * NA + c] = pass & inb;
                     }
                 }
-                emit_push_all<kPackedRows * NA>(E, S, bin, rec, act, carry);
+                emit_push_all<kPackedRows * NA>(E, S, bin, rec, act);
               }
             }
         }
     }
-    emit_scan_done(E, S, carry);
     emit_finish(E, S, matched, overflow);
 }
 
