@@ -171,6 +171,8 @@ def main():
                     help="rccl: the library's own communicator (sybl_comm_init / sybl_query_allreduce -- what a Go host "
                          "calls, the product path); torch: torch.distributed all-reduces of the bound partial tables")
     ap.add_argument("--no-load", action="store_true", help="skip the disk -> HBM load measurement (N=1 only)")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="only the headline workload: skip the cfg2 / cfg4 / cfg5 records of the `configs` key")
     ap.add_argument("--no-oracle-check", action="store_true",
                     help="skip the full-size bit-exact check of the result against the CPU oracle (N=1 only)")
     args = ap.parse_args()
@@ -195,25 +197,8 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
 
-    wl = synth.WORKLOADS[args.workload]
-    names, q = wl["columns"], dict(wl["query"])
-    if args.workload == "cfg4_hist_highcard":
-        q["limit"] = 100  # FLAGS.LIMIT defaults to 100 (cmd_query.go): only the printed rows carry their bucket arrays
-    total_rows = args.rows or wl["rows"]
     ctx = sybil_amd.Context(local_rank)
     dev = ctx.device_info()
-    bytes_per_row = 8 * len(names)
-    # fit check (single GPU must hold its shard)
-    row0, nrows = synth.shard(total_rows, rank, world)
-    if nrows * bytes_per_row > dev["hbm_bytes"] * 0.9:
-        raise SystemExit("shard of %d rows x %d B does not fit in %d B of HBM" % (nrows, bytes_per_row, dev["hbm_bytes"]))
-
-    table = ctx.synth_table("bench", synth.SEED, total_rows, row0, nrows, synth.synth_cols(names))
-    # identical direct-mapped layout on every rank: declare the generator's value bounds
-    for n in names:
-        kind, _, a, b, _, _ = synth.COLUMNS[n]
-        hi = a + 4 * (b - 1) if kind == synth.BELL else a + b - 1
-        table.set_bounds(n, a, hi)
     if multi and args.collective == "rccl":
         uid = [ctx.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
@@ -236,185 +221,222 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run_phase(steps, warmup):
-        """Prepares the query against the table as currently laid out, does `warmup` untimed steps and
-        times exactly `steps` steps (barrier + synchronize on both sides, max over ranks).
+    STRATEGY = {0: "lds-generic", 1: "global-atomics", 2: "lds-fast", 3: "lds-window-generic", 4: "lds-window-fast",
+                5: "partitioned-hist", 6: "lds-hist", 7: "hash"}
+    WHAT = {"cfg3_filter3_group2_stddev": "3 ANDed int-range filters, group-by 2 cols, count/sum/avg/stddev of 2 cols",
+            "cfg4_hist_highcard": "histogram (p25/p50/p99, every bucket) of 1 col grouped by a 65536-value col, -limit 100",
+            "cfg5_time_rollup": "hourly time buckets x group-by 1 str-like col, sum+count",
+            "cfg2_group1_avg2": "group-by 1 low-card col, sum+avg of 2 cols",
+            "cfg1_count_range": "count(*) with one int-range predicate"}
 
-        Steps are software-pipelined one deep (two prepared queries, alternating): the host-side
-        finalize of step i -- waiting for its snapshot, deriving avg / stddev, building and sorting the
-        result rows -- runs while the GPU already scans step i+1.  Every step does all of its work and
-        every result is complete inside the timed region; --no-pipeline serialises them."""
-        nq = 1 if args.no_pipeline else 2
-        queries = [table.query(**q) for _ in range(nq)]
-        if multi and args.collective == "torch":
-            with torch.cuda.stream(side):
-                for qy in queries:
-                    qy.bind_torch(device)
-        scan_ms = []
-        host_ms = {"launch": [], "finish": []}  # host time inside the two halves of a step
+    def measure(workload, total_rows, steps, warmup, storage, canonical_too):
+        """One BASELINE workload: builds this rank's shard of the synthetic table, times `steps` steps (after `warmup`)
+        in `storage`, optionally the same table in canonical int64 storage first.  Returns the record rank 0 prints."""
+        wl = synth.WORKLOADS[workload]
+        names, q = wl["columns"], dict(wl["query"])
+        if workload == "cfg4_hist_highcard":
+            q["limit"] = 100  # FLAGS.LIMIT defaults to 100 (cmd_query.go): only the printed rows carry their bucket arrays
+        total_rows = total_rows or wl["rows"]
+        bytes_per_row = 8 * len(names)
+        # fit check (single GPU must hold its shard)
+        row0, nrows = synth.shard(total_rows, rank, world)
+        if nrows * bytes_per_row > dev["hbm_bytes"] * 0.9:
+            raise SystemExit("shard of %d rows x %d B does not fit in %d B of HBM" % (nrows, bytes_per_row, dev["hbm_bytes"]))
+        table = ctx.synth_table("bench", synth.SEED, total_rows, row0, nrows, synth.synth_cols(names))
+        # identical direct-mapped layout on every rank: declare the generator's value bounds
+        for n in names:
+            kind, _, a, b, _, _ = synth.COLUMNS[n]
+            hi = a + 4 * (b - 1) if kind == synth.BELL else a + b - 1
+            table.set_bounds(n, a, hi)
 
-        everyone = [False]  # snapshot / finalize are collective calls (bucket arrays merged by reduce-scatter)
+        def run_phase(steps, warmup):
+            """Prepares the query against the table as currently laid out, does `warmup` untimed steps and
+            times exactly `steps` steps (barrier + synchronize on both sides, max over ranks).
 
-        def launch(i):
-            qy = queries[i % nq]
-            qy.scan()
-            if multi:
-                if args.collective == "torch":
-                    with torch.cuda.stream(side):
-                        qy.allreduce_torch()
-                else:
-                    qy.allreduce()
-                    everyone[0] = qy.collective_finalize()
-            if rank == 0 or everyone[0]:
-                qy.snapshot()  # D2H copy of the reduced table, queued behind the all-reduce
+            Steps are software-pipelined one deep (two prepared queries, alternating): the host-side
+            finalize of step i -- waiting for its snapshot, deriving avg / stddev, building and sorting the
+            result rows -- runs while the GPU already scans step i+1.  Every step does all of its work and
+            every result is complete inside the timed region; --no-pipeline serialises them."""
+            nq = 1 if args.no_pipeline else 2
+            queries = [table.query(**q) for _ in range(nq)]
+            if multi and args.collective == "torch":
+                with torch.cuda.stream(side):
+                    for qy in queries:
+                        qy.bind_torch(device)
+            scan_ms = []
+            host_ms = {"launch": [], "finish": []}  # host time inside the two halves of a step
 
-        def finish(i):
-            qy = queries[i % nq]
-            res = None
-            if rank == 0 or everyone[0]:
-                res = qy.finalize()
-                if rank == 0:
-                    scan_ms.append(qy.stats()["scan_ms"])
-                else:
-                    res.free()
-                    res = None
-            elif nq == 1:
-                ctx.sync()
-            return res
+            everyone = [False]  # snapshot / finalize are collective calls (bucket arrays merged by reduce-scatter)
 
-        def run_steps(n, keep):
-            res = None
-            for i in range(n):
-                h0 = time.perf_counter()
-                launch(i)
-                h1 = time.perf_counter()
-                host_ms["launch"].append((h1 - h0) * 1e3)
-                j = i - (nq - 1)  # the step whose result is due
-                if j >= 0:
+            def launch(i):
+                qy = queries[i % nq]
+                qy.scan()
+                if multi:
+                    if args.collective == "torch":
+                        with torch.cuda.stream(side):
+                            qy.allreduce_torch()
+                    else:
+                        qy.allreduce()
+                        everyone[0] = qy.collective_finalize()
+                if rank == 0 or everyone[0]:
+                    qy.snapshot()  # D2H copy of the reduced table, queued behind the all-reduce
+
+            def finish(i):
+                qy = queries[i % nq]
+                res = None
+                if rank == 0 or everyone[0]:
+                    res = qy.finalize()
+                    if rank == 0:
+                        scan_ms.append(qy.stats()["scan_ms"])
+                    else:
+                        res.free()
+                        res = None
+                elif nq == 1:
+                    ctx.sync()
+                return res
+
+            def run_steps(n, keep):
+                res = None
+                for i in range(n):
+                    h0 = time.perf_counter()
+                    launch(i)
+                    h1 = time.perf_counter()
+                    host_ms["launch"].append((h1 - h0) * 1e3)
+                    j = i - (nq - 1)  # the step whose result is due
+                    if j >= 0:
+                        r = finish(j)
+                        host_ms["finish"].append((time.perf_counter() - h1) * 1e3)
+                        if r is not None:
+                            seen_matched.add(r.matched)
+                            if res is not None:
+                                res.free()
+                            res = r
+                for j in range(max(n - (nq - 1), 0), n):
                     r = finish(j)
-                    host_ms["finish"].append((time.perf_counter() - h1) * 1e3)
                     if r is not None:
                         seen_matched.add(r.matched)
                         if res is not None:
                             res.free()
                         res = r
-            for j in range(max(n - (nq - 1), 0), n):
-                r = finish(j)
-                if r is not None:
-                    seen_matched.add(r.matched)
-                    if res is not None:
-                        res.free()
-                    res = r
-            if not keep and res is not None:
-                res.free()
-                res = None
-            return res
+                if not keep and res is not None:
+                    res.free()
+                    res = None
+                return res
 
-        seen_matched = set()
-        run_steps(warmup, False)
-        fence()
-        del scan_ms[:]
-        del host_ms["launch"][:], host_ms["finish"][:]
-        t0 = time.perf_counter()
-        res = run_steps(steps, True)
-        fence()
-        dt = time.perf_counter() - t0
-        if multi:
-            tmax = torch.tensor([dt], dtype=torch.float64, device=device)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            dt = float(tmax.item())
-        stats = queries[0].stats()
-        out = {"dt": dt, "stats": stats, "kernel_ms": (sum(scan_ms) / len(scan_ms)) if scan_ms else stats["scan_ms"],
-               "host_ms": {k: round(sum(v) / len(v), 3) if v else None for k, v in host_ms.items()}}
+            seen_matched = set()
+            run_steps(warmup, False)
+            fence()
+            del scan_ms[:]
+            del host_ms["launch"][:], host_ms["finish"][:]
+            t0 = time.perf_counter()
+            res = run_steps(steps, True)
+            fence()
+            dt = time.perf_counter() - t0
+            if multi:
+                tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+                dt = float(tmax.item())
+            stats = queries[0].stats()
+            out = {"dt": dt, "stats": stats, "kernel_ms": (sum(scan_ms) / len(scan_ms)) if scan_ms else stats["scan_ms"],
+                   "host_ms": {k: round(sum(v) / len(v), 3) if v else None for k, v in host_ms.items()}}
+            if rank == 0:
+                # every step scans the same table: the merged result must not change from step to step (it
+                # would if the all-reduce ever ran ahead of a rank's scan) and group counts must add up
+                assert len(seen_matched) == 1, "matched count varies across steps: %r" % sorted(seen_matched)
+                assert len(scan_ms) == steps
+                rows_out = res.time_results if q.get("time_col") else res.rows(0, want_values=False)
+                assert sum(g["count"] for g in rows_out) == res.matched
+                out["matched"] = res.matched
+                out["groups"] = len(rows_out)
+                out["digest"] = sorted((g["time_bucket"], g["key"], g["count"]) + tuple(h["sum"] for h in g["hists"]) for g in rows_out)
+                res.free()
+            for qy in queries:
+                qy.free()
+            return out
+
+        def roofline(ph):
+            stats = ph["stats"]
+            alg = stats["algorithmic_bytes"]  # this rank's rows x stored bytes per row: per launch, per GPU
+            achieved = alg / (ph["kernel_ms"] * 1e-3) / 1e9
+            shape = "<3,2,2,moments>" if workload == "cfg3_filter3_group2_stddev" else ""
+            if stats["strategy"] in (2, 4, 6):
+                kernel = ("k_scan_packed" if stats["packed_kernel"] else "k_scan_fast") + shape
+            elif stats["strategy"] == 5:
+                pk = "_packed" if stats["packed_kernel"] else ""
+                kernel = "k_count%s + k_part_bases + k_emit%s + k_part_hist + k_part_fix" % (pk, pk)
+            else:
+                kernel = "k_scan<%d>" % len(names)
+            traffic, traffic_source = measured_traffic(stats, names)
+            return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                    "traffic": traffic, "traffic_source": traffic_source, "kernel": kernel, "kernel_ms": ph["kernel_ms"],
+                    "algorithmic_bytes_per_launch": alg, "stored_bytes_per_row": alg / max(stats["rows_scanned"], 1),
+                    "int64_canonical_bytes_per_launch": stats["canonical_bytes"],
+                    "strategy": STRATEGY[stats["strategy"]], "lds_bytes": stats["lds_bytes"], "workgroups": stats["n_workgroups"]}
+
+        # Secondary, untimed-for-the-headline measurement: the same table in canonical int64 storage
+        # (the reference's in-memory IntField) before it is compacted.
+        canon = None
+        if storage == "compact" and canonical_too:
+            canon = run_phase(min(steps, 10), min(warmup, 2))
+        if storage == "compact":
+            table.compact()
+        head = run_phase(steps, warmup)
+        out = None
         if rank == 0:
-            # every step scans the same table: the merged result must not change from step to step (it
-            # would if the all-reduce ever ran ahead of a rank's scan) and group counts must add up
-            assert len(seen_matched) == 1, "matched count varies across steps: %r" % sorted(seen_matched)
-            assert len(scan_ms) == steps
-            rows_out = res.time_results if q.get("time_col") else res.rows(0, want_values=False)
-            assert sum(g["count"] for g in rows_out) == res.matched
-            out["matched"] = res.matched
-            out["groups"] = len(rows_out)
-            out["digest"] = sorted((g["time_bucket"], g["key"], g["count"]) + tuple(h["sum"] for h in g["hists"]) for g in rows_out)
-            res.free()
-        for qy in queries:
-            qy.free()
+            if canon is not None:
+                assert canon["digest"] == head["digest"], "compact and canonical storage disagree"
+            dt = head["dt"]
+            out = {
+                "metric": "rows scanned/sec (%s-row x %d-int-col synthetic table, %s)" % (
+                    "1B" if total_rows == 1_000_000_000 else str(total_rows), wl["table_cols"], WHAT[workload]),
+                "value": total_rows * steps / dt, "unit": "rows/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+                "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                "dtype": "int64", "data": "synthetic",
+                "config": {"workload": workload, "reference_flags": wl["flags"], "rows": total_rows,
+                           "table_columns": wl["table_cols"], "resident_columns": names,
+                           "storage": storage,
+                           "pipelined": None if args.no_pipeline else "finalize(i) on the host overlaps scan(i+1) on the GPU "
+                                                                      "(two prepared queries); all work of the K steps is "
+                                                                      "inside the timed region",
+                           "stored_widths": {n: table.column_storage(n)[0] for n in names},
+                           "sharding": "contiguous 65536-row blocks per rank", "collective": args.collective if multi else None,
+                           "device": dev["name"], "matched_rows": head["matched"], "groups": head["groups"],
+                           "host_ms_per_step": head["host_ms"]},
+                "roofline": roofline(head),
+            }
+            if canon is not None:
+                out["canonical_storage"] = {"value": total_rows * min(steps, 10) / canon["dt"], "unit": "rows/s",
+                                            "steps": min(steps, 10), "roofline": roofline(canon)}
+            if world == 1 and not args.no_oracle_check:
+                out["oracle_check"] = oracle_check(workload, q, total_rows, head)
+        table.free()
         return out
 
-    STRATEGY = {0: "lds-generic", 1: "global-atomics", 2: "lds-fast", 3: "lds-window-generic", 4: "lds-window-fast",
-                5: "partitioned-hist", 6: "lds-hist", 7: "hash"}
-
-    def roofline(ph, storage):
-        stats = ph["stats"]
-        alg = stats["algorithmic_bytes"]  # this rank's rows x stored bytes per row: per launch, per GPU
-        achieved = alg / (ph["kernel_ms"] * 1e-3) / 1e9
-        shape = "<3,2,2,moments>" if args.workload == "cfg3_filter3_group2_stddev" else ""
-        if stats["strategy"] in (2, 4, 6):
-            kernel = ("k_scan_packed" if stats["packed_kernel"] else "k_scan_fast") + shape
-        elif stats["strategy"] == 5:
-            pk = "_packed" if stats["packed_kernel"] else ""
-            kernel = "k_count%s + k_part_offsets + k_emit%s + k_part_hist" % (pk, pk)
-        else:
-            kernel = "k_scan<%d>" % len(names)
-        traffic, traffic_source = measured_traffic(stats, names)
-        return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic, "traffic_source": traffic_source, "kernel": kernel, "kernel_ms": ph["kernel_ms"],
-                "algorithmic_bytes_per_launch": alg, "stored_bytes_per_row": alg / max(stats["rows_scanned"], 1),
-                "int64_canonical_bytes_per_launch": stats["canonical_bytes"],
-                "strategy": STRATEGY[stats["strategy"]], "lds_bytes": stats["lds_bytes"], "workgroups": stats["n_workgroups"]}
-
-    # Secondary, untimed-for-the-headline measurement: the same table in canonical int64 storage
-    # (the reference's in-memory IntField) before it is compacted.
-    canon = None
-    if args.storage == "compact" and not args.no_canonical:
-        canon = run_phase(min(args.steps, 10), min(args.warmup, 2))
-    if args.storage == "compact":
-        table.compact()
-    head = run_phase(args.steps, args.warmup)
-
+    out = measure(args.workload, args.rows, args.steps, args.warmup, args.storage, not args.no_canonical)
     if rank == 0:
-        if canon is not None:
-            assert canon["digest"] == head["digest"], "compact and canonical storage disagree"
-        dt, stats = head["dt"], head["stats"]
-        ms_per_step = dt / args.steps * 1e3
-        value = total_rows * args.steps / dt
-        what = {"cfg3_filter3_group2_stddev": "3 ANDed int-range filters, group-by 2 cols, count/sum/avg/stddev of 2 cols",
-                "cfg4_hist_highcard": "histogram (p25/p50/p99, every bucket) of 1 col grouped by a 65536-value col, -limit 100",
-                "cfg5_time_rollup": "hourly time buckets x group-by 1 str-like col, sum+count",
-                "cfg2_group1_avg2": "group-by 1 low-card col, sum+avg of 2 cols",
-                "cfg1_count_range": "count(*) with one int-range predicate"}[args.workload]
-        out = {
-            "metric": "rows scanned/sec (%s-row x %d-int-col synthetic table, %s)" % (
-                "1B" if total_rows == 1_000_000_000 else str(total_rows), wl["table_cols"], what),
-            "value": value, "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "int64", "data": "synthetic",
-            "config": {"workload": args.workload, "reference_flags": wl["flags"], "rows": total_rows,
-                       "table_columns": wl["table_cols"], "resident_columns": names,
-                       "storage": args.storage,
-                       "pipelined": None if args.no_pipeline else "finalize(i) on the host overlaps scan(i+1) on the GPU "
-                                                                  "(two prepared queries); all work of the K steps is "
-                                                                  "inside the timed region",
-                       "stored_widths": {n: table.column_storage(n)[0] for n in names},
-                       "sharding": "contiguous 65536-row blocks per rank", "collective": args.collective if multi else None,
-                       "device": dev["name"], "matched_rows": head["matched"], "groups": head["groups"],
-                       "host_ms_per_step": head["host_ms"]},
-            "roofline": roofline(head, args.storage),
-        }
-        if canon is not None:
-            out["canonical_storage"] = {"value": total_rows * min(args.steps, 10) / canon["dt"], "unit": "rows/s",
-                                        "steps": min(args.steps, 10), "roofline": roofline(canon, "canonical")}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"], columnar = cpu_baseline(args.workload, total_rows)
+            out["cpu_baseline"], columnar = cpu_baseline(args.workload, args.rows or synth.WORKLOADS[args.workload]["rows"])
             if columnar is not None:
                 out["cpu_baseline_columnar"] = columnar
-            if not args.no_oracle_check:
-                out["oracle_check"] = oracle_check(args.workload, q, total_rows, head)
+        if "oracle_check" in out:  # (key order of the round-2 line: cpu_baseline before oracle_check)
+            out["oracle_check"] = out.pop("oracle_check")
+    # The other BASELINE.json configurations that fit one GPU, driver-measured in the same run: same table generator,
+    # same step (scan + fold (+ all-reduce) + finalize, pipelined one deep), compact storage, fewer steps.
+    if not args.no_configs and args.workload == "cfg3_filter3_group2_stddev" and not args.rows:
+        recs = []
+        for name in ("cfg2_group1_avg2", "cfg4_hist_highcard", "cfg5_time_rollup"):
+            rec = measure(name, 0, min(args.steps, 10), min(args.warmup, 2), "compact", False)
+            if rank == 0:
+                recs.append({k: rec[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "config", "roofline")
+                             + (("oracle_check",) if "oracle_check" in rec else ())})
+                recs[-1]["kernel_ms"] = rec["roofline"]["kernel_ms"]
+        if rank == 0:
+            out["configs"] = recs
+    if rank == 0:
         if world == 1 and not args.no_load:
             out["load"] = load_path(ctx)
         print(json.dumps(out))
         sys.stdout.flush()
-    table.free()
     if multi and args.collective == "rccl":
         ctx.comm_free()
     ctx.close()

@@ -604,7 +604,9 @@ __global__ __launch_bounds__(kWgThreads, 4) void k_scan_fast(const FastPlan P) {
 // tile instead of the publication counters -- 5.0 ms.)
 struct EmitLds {
     uint32_t *chunk;        // [nb][2][16]
-    uint4 *meta;            // [nb] {cnt, wr0, wr1, start}
+    uint32_t *cnt, *start;  // [nb] each: arrays of their own, so that the bins spread over all 32 LDS banks (as one
+    uint2 *wr;              // [nb]   16-byte struct per bin the counters of 64 lanes fell into 8 banks: 71 % of the LDS
+                            //        pipe's cycles were bank conflicts, profiles/r03_cfg4_v4_pmc.txt)
     uint2 *queue;           // [kEmitQueue] of this wave: {bin << 1 | chunk of the bin, chunk index in the workgroup's output}
     uint32_t *out;          // the workgroup's output in recs
     uint32_t out_bytes;
@@ -618,11 +620,17 @@ __device__ __forceinline__ EmitLds emit_begin(const EmitPlan &E, uint32_t *elds)
     S.nb = (uint32_t)E.n_parts << S.ss;      // staging bins
     S.sub = tid & ((1u << S.ss) - 1);        // this lane's sub-bin
     S.chunk = elds;                          // [nb][2][16]  (128-byte rows)
-    S.meta = (uint4 *)(elds + S.nb * 2 * kEmitChunk);
-    uint2 *queues = (uint2 *)(S.meta + S.nb);  // [waves][kEmitQueue]
+    S.wr = (uint2 *)(elds + S.nb * 2 * kEmitChunk);
+    uint2 *queues = S.wr + S.nb;             // [waves][kEmitQueue]
     S.queue = queues + (tid >> 6) * kEmitQueue;
+    S.cnt = (uint32_t *)(queues + (kWgThreads / 64) * kEmitQueue);
+    S.start = S.cnt + S.nb;
     const uint32_t *boff = E.boff + (size_t)blockIdx.x * (S.nb + 1);
-    for (uint32_t i = tid; i < S.nb; i += kWgThreads) S.meta[i] = make_uint4(0u, 0u, 0u, boff[i]);
+    for (uint32_t i = tid; i < S.nb; i += kWgThreads) {
+        S.cnt[i] = 0;
+        S.wr[i] = make_uint2(0u, 0u);
+        S.start[i] = boff[i];
+    }
     if (tid < (kWgThreads / 64) * kEmitQueue) queues[tid] = make_uint2(0u, 0u);
     S.out = E.recs + (size_t)E.wbase[blockIdx.x] * kEmitChunk;
     S.out_bytes = boff[S.nb] * (kEmitChunk * 4u);
@@ -699,7 +707,7 @@ __device__ __forceinline__ void emit_copy_full(const EmitLds &S, const uint32_t 
 #pragma unroll
         for (uint32_t k = 0; k < kEmitQueue / 16; k++)
             if (valid[k] && j == 0)
-                __hip_atomic_fetch_add((uint32_t *)(S.meta + (qe[k].x >> 1)) + 1 + (qe[k].x & 1u), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add((uint32_t *)S.wr + qe[k].x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         lds_order();
         if (!__builtin_amdgcn_ballot_w64(full != 0)) break;
     }
@@ -722,22 +730,19 @@ __device__ __forceinline__ void emit_pad_stores(const EmitLds &S) {
 template <int N>
 __device__ __forceinline__ void emit_push_all(const EmitPlan &E, const EmitLds &S, const uint32_t (&bin)[N], const uint32_t (&rec)[N],
                                               const bool (&act)[N]) {
-    uint32_t slot[N], dest[N], which[N], thr[N], pos[N];
-    fu32x4 w[N];
+    uint32_t slot[N], dest[N], which[N], thr[N], pos[N], st[N];
+    unsigned long long w[N];  // {wr0, wr1}
     bool pend[N];
-    // one LDS round trip in the common case: the slots and the bins' {cnt, wr0, wr1, start} words (wr only grows: a
-    // value read early errs on the side of waiting)
+    // one LDS round trip in the common case: the slots, the bins' {wr0, wr1} and region starts (wr only grows: a value
+    // read early errs on the side of waiting)
 #pragma unroll
     for (int i = 0; i < N; i++)
-        slot[i] = act[i] ? __hip_atomic_fetch_add((uint32_t *)(S.meta + bin[i]), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
+        slot[i] = act[i] ? __hip_atomic_fetch_add(S.cnt + bin[i], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
     lds_order();
 #pragma unroll
     for (int i = 0; i < N; i++) {
-        // (two relaxed 8-byte loads: a volatile 16-byte one makes the compiler drain every counter around it)
-        const unsigned long long *m = (const unsigned long long *)(S.meta + bin[i]);
-        const unsigned long long lo = act[i] ? __hip_atomic_load(m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0ull;
-        const unsigned long long hi = act[i] ? __hip_atomic_load(m + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0ull;
-        w[i] = fu32x4{(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)};
+        w[i] = act[i] ? __hip_atomic_load((const unsigned long long *)(S.wr + bin[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0ull;
+        st[i] = act[i] ? __hip_atomic_load(S.start + bin[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
     }
     // ---- first pass
     lds_order();
@@ -747,16 +752,16 @@ __device__ __forceinline__ void emit_push_all(const EmitPlan &E, const EmitLds &
         const uint32_t gen = slot[i] >> 4, h = gen & 1u;
         thr[i] = 17u * (gen >> 1);
         which[i] = bin[i] << 1 | h;
-        dest[i] = w[i].w + gen;
+        dest[i] = st[i] + gen;
         pos[i] = which[i] * kEmitChunk + ((slot[i] + bin[i]) & (kEmitChunk - 1));
-        ok[i] = act[i] && (h ? w[i].z : w[i].y) >= thr[i];
+        ok[i] = act[i] && (uint32_t)(w[i] >> (h << 5)) >= thr[i];
         if (ok[i]) S.chunk[pos[i]] = rec[i];
     }
     lds_order();  // the records go to LDS before wr says so (issue order)
     uint32_t old[N];
 #pragma unroll
     for (int i = 0; i < N; i++)
-        old[i] = ok[i] ? __hip_atomic_fetch_add((uint32_t *)(S.meta + bin[i]) + 1 + (which[i] & 1u), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
+        old[i] = ok[i] ? __hip_atomic_fetch_add((uint32_t *)S.wr + which[i], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
     uint32_t full = 0;
     bool left = false;
 #pragma unroll
@@ -782,7 +787,7 @@ __device__ __forceinline__ void emit_push_all(const EmitPlan &E, const EmitLds &
         uint32_t wr[N];
 #pragma unroll
         for (int i = 0; i < N; i++)
-            wr[i] = (pmask >> i) & 1u ? __hip_atomic_load((uint32_t *)(S.meta + bin[i]) + 1 + (which[i] & 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
+            wr[i] = (pmask >> i) & 1u ? __hip_atomic_load((uint32_t *)S.wr + which[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
         lds_order();
         uint32_t okm = 0;
 #pragma unroll
@@ -795,7 +800,7 @@ __device__ __forceinline__ void emit_push_all(const EmitPlan &E, const EmitLds &
         lds_order();
 #pragma unroll
         for (int i = 0; i < N; i++)
-            old[i] = (okm >> i) & 1u ? __hip_atomic_fetch_add((uint32_t *)(S.meta + bin[i]) + 1 + (which[i] & 1u), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
+            old[i] = (okm >> i) & 1u ? __hip_atomic_fetch_add((uint32_t *)S.wr + which[i], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
         full = 0;
 #pragma unroll
         for (int i = 0; i < N; i++) full |= ((okm >> i) & 1u) && old[i] == thr[i] + (kEmitChunk - 1) ? 1u << i : 0u;
@@ -812,8 +817,7 @@ __device__ __forceinline__ uint32_t emit_bin(const EmitLds &S, uint32_t pair) { 
 __device__ __forceinline__ void emit_finish(const EmitPlan &E, const EmitLds &S, uint32_t matched, uint32_t overflow) {
     __syncthreads();
     for (uint32_t bin = threadIdx.x; bin < S.nb; bin += kWgThreads) {
-        const uint4 m = S.meta[bin];
-        const uint32_t n = m.x, left = n & (kEmitChunk - 1), gen = n >> 4;
+        const uint32_t n = S.cnt[bin], left = n & (kEmitChunk - 1), gen = n >> 4;
         if (left) {
             const uint32_t *c = S.chunk + (bin << 1 | (gen & 1u)) * kEmitChunk;
             uint32_t r[kEmitChunk];
@@ -823,7 +827,7 @@ __device__ __forceinline__ void emit_finish(const EmitPlan &E, const EmitLds &S,
                 const uint32_t logical = (k - bin) & (kEmitChunk - 1);
                 r[k] = logical < left ? c[k] : kRecSentinel;
             }
-            fu32x4 *dst = (fu32x4 *)(S.out + (size_t)(m.w + gen) * kEmitChunk);
+            fu32x4 *dst = (fu32x4 *)(S.out + (size_t)(S.start[bin] + gen) * kEmitChunk);
             dst[0] = fu32x4{r[0], r[1], r[2], r[3]};
             dst[1] = fu32x4{r[4], r[5], r[6], r[7]};
             dst[2] = fu32x4{r[8], r[9], r[10], r[11]};

@@ -257,3 +257,23 @@ def test_table_full_is_reported(ctx, monkeypatch):
     assert "more distinct group keys" in str(e.value)
     query.free()
     tb.free()
+
+
+def test_table_full_at_default_sizing_fails_fast(ctx):
+    """150 M rows keyed on a column of 2^40 values: ~150 M distinct keys against the 2^27-slot ceiling of the table
+    (planner default sizing, no SYBL_HASH_SLOTS).  Probing is bounded and the first row that gives up tells the others
+    (csrc/hashgroup.hip: hash_find_or_insert), so the query fails with SYBL_E_NOMEM in about the time of a scan instead
+    of walking a full table for every remaining row."""
+    import time
+    n = 150_000_000
+    t = ctx.synth_table("toomany", synth.SEED, n, 0, n, [
+        {"name": "k", "kind": synth.UNIFORM, "col_index": 40, "a": 0, "b": 1 << 40}])
+    query = t.query(groups=["k"], aggs=[], op="avg", order_by=None)
+    assert query.stats()["strategy"] == 7 and query.stats()["n_cells"] == 1 << 27
+    t0 = time.perf_counter()
+    with pytest.raises(sybil_amd.SyblError) as e:
+        query.run()
+    assert "more distinct group keys" in str(e.value)
+    assert time.perf_counter() - t0 < 20.0
+    query.free()
+    t.free()

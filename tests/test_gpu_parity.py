@@ -855,3 +855,38 @@ def rewritten_for(tb, pattern, py):
     """the host-evaluated form of -str-replace: one rewritten string per table-global dictionary id"""
     import re
     return [re.sub(pattern, py, s) for s in tb.column_dict("host")]
+
+
+@pytest.mark.parametrize("compact", [False, True])
+def test_bucket_counters_that_wrap(ctx, oracle, compact):
+    """k_part_hist keeps its bucket arrays as 16-bit LDS counters, two to a word, and logs every wrap for k_part_fix
+    (csrc/kernels.hip).  One group holds most rows and two NEIGHBOURING buckets of it -- an even one and the odd one
+    sharing its word -- take > 450 000 values each: both fields wrap several times and every wrap of the low field
+    carries into the high one.  Buckets, Count and the exact sum must come out as the oracle's."""
+    rng = np.random.default_rng(20260926)
+    n = 1_300_000
+    g = rng.integers(0, 4096, n, dtype=np.int64)
+    g[rng.random(n) < 0.85] = 5
+    v = rng.integers(0, 1_000_000, n, dtype=np.int64)
+    u = rng.random(n)
+    heavy = g == 5
+    v[heavy & (u < 0.45)] = rng.integers(0, 999, int((heavy & (u < 0.45)).sum()))      # bucket 0 (BucketSize 999)
+    v[heavy & (u >= 0.45) & (u < 0.9)] = 1000                                          # bucket 1
+    tb = ctx.create_table("wrap")
+    tb.add_column("g", "int", 0, 4095)
+    tb.add_column("v", "int", 0, 999_999)
+    for r0 in range(0, n, 65536):
+        r1 = min(r0 + 65536, n)
+        tb.append_block(r1 - r0, {"g": g[r0:r1], "v": v[r0:r1]})
+    if compact:
+        tb.compact()
+    q = tb.query(groups=["g"], aggs=["v"], op="hist")
+    r = q.run()
+    assert q.stats()["strategy"] == 5
+    o = oracle.run_query([{"type": "int", "data": g}, {"type": "int", "data": v}], groups=[0], aggs=[(1, 0, 999_999)], op="hist")
+    parity.compare(r, o, op="hist", full=True, n_aggs=1)
+    big = [x for x in o["results"] if x["count"] > 1_000_000]
+    assert len(big) == 1 and big[0]["hists"][0]["values"][0] > 7 * 65536 and big[0]["hists"][0]["values"][1] > 7 * 65536
+    r.free()
+    q.free()
+    tb.free()

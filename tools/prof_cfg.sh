@@ -1,7 +1,7 @@
 #!/bin/bash
 # Profile of one BASELINE.json workload through tools/bench_configs.py: kernel trace + the PMC passes of
 # MI355X_MICROARCH.md (counters in their own runs; FETCH_SIZE and WRITE_SIZE in separate passes).
-# usage (on the GPU box): WL=cfg4 TAG=r02_cfg4 [STORAGE=compact] bash tools/prof_cfg.sh
+# usage (on the GPU box): WL=cfg4 TAG=r02_cfg4 [STORAGE=compact] [EXTRA=1 | LEAN=1 (kernel trace + the two HBM passes only)] bash tools/prof_cfg.sh
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 WL=${WL:-cfg4}
@@ -12,11 +12,13 @@ mkdir -p $OUT
 cd $R
 CMD="python tools/bench_configs.py ${ROWS:-0} 3 $WL $STORAGE"
 timeout -k 10 900 rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt -- $CMD > $OUT/kt.log 2>&1
+if [ -z "$LEAN" ]; then
 timeout -k 10 900 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $OUT/pmc1 -o pmc1 -- $CMD > $OUT/pmc1.log 2>&1
 timeout -k 10 900 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES -d $OUT/pmc2 -o pmc2 -- $CMD > $OUT/pmc2.log 2>&1
+fi
 timeout -k 10 900 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE -d $OUT/pmc3 -o pmc3 -- $CMD > $OUT/pmc3.log 2>&1
 timeout -k 10 900 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d $OUT/pmc4 -o pmc4 -- $CMD > $OUT/pmc4.log 2>&1
-timeout -k 10 900 rocprofv3 --pmc TCC_ATOMIC_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_RDREQ_sum -d $OUT/pmc5 -o pmc5 -- $CMD > $OUT/pmc5.log 2>&1
+[ -z "$LEAN" ] && timeout -k 10 900 rocprofv3 --pmc TCC_ATOMIC_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_RDREQ_sum -d $OUT/pmc5 -o pmc5 -- $CMD > $OUT/pmc5.log 2>&1
 # EXTRA=1: the passes DESIGN 3.2 asks for to find what k_emit waits for (counter names as rocprofv3 -L lists them on
 # gfx942/gfx950; a pass whose counter does not exist fails on its own and is reported below)
 EXTRA_PASSES=""
