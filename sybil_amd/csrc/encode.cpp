@@ -276,7 +276,7 @@ static void gob_result(GobW &w, const Result *R, const RowStore &row, size_t n_g
             gob_hist(w, R, o, a);
         }
     }
-    f.put_str(1, row.gbk);
+    f.put_str(1, row.gbk());
     if (n_groups > 0) {
         f.at(2);  // BinaryByKey: 8 little-endian bytes per group column
         w.s((const char *)row.key, n_groups * SYBL_GROUP_BY_WIDTH);
@@ -289,7 +289,7 @@ static void gob_result(GobW &w, const Result *R, const RowStore &row, size_t n_g
 static void gob_result_map(GobW &w, const Result *R, const std::vector<RowStore> &rows, size_t i0, size_t i1, size_t n_groups) {
     w.u(i1 - i0);
     for (size_t i = i0; i < i1; i++) {
-        w.s(rows[i].gbk);
+        w.s(rows[i].gbk());
         gob_result(w, R, rows[i], n_groups);
     }
 }

@@ -98,7 +98,7 @@ static void free_query(Query *q) {
     if (q->d_mom) hipFree(q->d_mom);
     if (q->d_total) hipFree(q->d_total);
     if (q->h_top) hipHostFree(q->h_top);
-    if (q->h_pct) hipHostFree(q->h_pct);
+    q->h_pct_buf.reset();
     if (q->h_mom) hipHostFree(q->h_mom);
     if (q->h_total) hipHostFree(q->h_total);
     if (q->d_top) hipFree(q->d_top);
@@ -137,8 +137,10 @@ static int scan_distinct(Query *q, bool ran, hipStream_t st) {
 }
 
 static int scan(Query *q) {
+    PhaseTrace trace("scan");
     int rc = ensure_partials(q);
     if (rc) return rc;
+    trace.mark("partials");
     q->rs_active = false;
     q->out_log_partial = false;
     hipStream_t st = q->ctx->stream;
@@ -178,16 +180,19 @@ static int scan(Query *q) {
         e = q->part_packed ? launch_count_packed(q->eplan, q->part_nf, q->part_ng, q->n_wg, st)
                            : launch_count(q->eplan, q->part_nf, q->part_ng, q->n_wg, st);
         if (e != hipSuccess) return hip_fail(e, "k_count");
+        trace.mark("count");
         e = launch_part_bases(q->eplan, st);
         if (e != hipSuccess) return hip_fail(e, "k_part_bases");
         e = q->part_packed ? launch_emit_packed(q->eplan, q->part_nf, q->part_ng, q->part_na, q->n_wg, st)
                            : launch_emit(q->eplan, q->part_nf, q->part_ng, q->part_na, q->n_wg, st);
         if (e != hipSuccess) return hip_fail(e, "k_emit");
+        trace.mark("emit");
         SYBL_HIP(hipMemsetAsync(q->pplan.wrap_log, 0, 8, st));
         e = launch_part_hist(q->pplan, st);
         if (e != hipSuccess) return hip_fail(e, "k_part_hist");
         e = launch_part_fix(q->pplan, st);
         if (e != hipSuccess) return hip_fail(e, "k_part_fix");
+        trace.mark("hist");
         SYBL_HIP(hipEventRecord(q->ev[1], st));
         SYBL_HIP(hipEventRecord(q->ev[2], st));
         if ((rc = scan_distinct(q, ran, st))) return rc;

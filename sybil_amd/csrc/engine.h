@@ -7,6 +7,12 @@
 #include <memory>
 #include <string>
 #include <unordered_map>
+#include <string.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <algorithm>
+#include <chrono>
+#include <thread>
 #include <vector>
 
 #include "../../include/sybilgpu.h"
@@ -184,6 +190,47 @@ int block_col_set_host(BlockWriter &w, Column *c, const int64_t *off, const int3
 int block_commit(BlockWriter &w);
 
 // pinned host memory owned jointly by a query and the results that point into it
+// CPUs this process can actually use: hardware threads, capped by a cgroup v2 / v1 CPU quota
+inline size_t usable_cpus() {
+    size_t n = std::max<unsigned>(1, std::thread::hardware_concurrency());
+    long long quota = -1, period = 0;
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[32] = {0};
+        if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atoll(q);
+        fclose(f);
+    } else if (FILE *f1 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+        if (fscanf(f1, "%lld", &quota) != 1) quota = -1;
+        fclose(f1);
+        if (FILE *f2 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+            if (fscanf(f2, "%lld", &period) != 1) period = 0;
+            fclose(f2);
+        }
+    }
+    if (quota > 0 && period > 0) n = std::min<size_t>(n, (size_t)std::max<long long>(1, (quota + period - 1) / period));
+    return n;
+}
+
+// SYBL_FINALIZE_TRACE=1: per-phase host timings of scan / snapshot / finalize on stderr
+struct PhaseTrace {
+    const char *what_ = "finalize";
+    PhaseTrace() {}
+    explicit PhaseTrace(const char *w) : what_(w) {}
+    bool on = getenv("SYBL_FINALIZE_TRACE") != nullptr;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    std::string line;
+    void mark(const char *what) {
+        if (!on) return;
+        auto t1 = std::chrono::steady_clock::now();
+        char b[64];
+        snprintf(b, sizeof(b), " %s=%.1fus", what, std::chrono::duration<double, std::micro>(t1 - t0).count());
+        line += b;
+        t0 = t1;
+    }
+    ~PhaseTrace() {
+        if (on) fprintf(stderr, "%s:%s\n", what_, line.c_str());
+    }
+};
+
 struct HostBuf {
     int64_t *p = nullptr;
     int64_t words = 0;
@@ -281,7 +328,10 @@ struct Query {
     bool hist_summary = false;
     bool snap_has_buckets = true;   // the last snapshot carried the bucket arrays
     int64_t *d_pct = nullptr, *d_mom = nullptr, *d_total = nullptr;
-    int64_t *h_pct = nullptr, *h_mom = nullptr, *h_total = nullptr;  // pinned
+    std::shared_ptr<HostBuf> h_pct_buf;          // pinned snapshot of the GPU-computed percentiles (shared with results)
+    std::vector<std::shared_ptr<HostBuf>> host_bufs;  // pinned snapshot buffers of this query, reused once no result holds them
+    int64_t *h_pct = nullptr, *h_mom = nullptr, *h_total = nullptr;  // pinned (h_pct = h_pct_buf->p)
+    std::shared_ptr<struct KeyStore> key_cache;  // the group cells' BinaryByKey / GroupByKey (result.h), built by the first finalize
     int64_t *d_top_cells = nullptr, *d_top = nullptr;               // bucket arrays of the printed rows
     int64_t top_cap = 0;
     hipEvent_t ev_snap = nullptr;   // the device -> host snapshot of the partial tables has landed

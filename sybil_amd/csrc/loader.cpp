@@ -58,26 +58,6 @@ static bool decode_file(const std::string &path, gob::Value &v, std::string &err
     return gob::decode(data.data(), data.size(), v, err);
 }
 
-// CPUs this process can actually use: hardware threads, capped by a cgroup v2 / v1 CPU quota
-static size_t usable_cpus() {
-    size_t n = std::max<unsigned>(1, std::thread::hardware_concurrency());
-    long long quota = -1, period = 0;
-    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
-        char q[32] = {0};
-        if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atoll(q);
-        fclose(f);
-    } else if (FILE *f1 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
-        if (fscanf(f1, "%lld", &quota) != 1) quota = -1;
-        fclose(f1);
-        if (FILE *f2 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
-            if (fscanf(f2, "%lld", &period) != 1) period = 0;
-            fclose(f2);
-        }
-    }
-    if (quota > 0 && period > 0) n = std::min<size_t>(n, (size_t)std::max<long long>(1, (quota + period - 1) / period));
-    return n;
-}
-
 static double seconds_since(std::chrono::steady_clock::time_point t0) {
     return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }

@@ -124,7 +124,7 @@ static void json_agg(Result *R, const RowStore &r, size_t a, std::string &o) {
             o += ",\"percentiles\":[";
             for (size_t k = 0; poff >= 0 && k < 100; k++) {
                 if (k) o += ",";
-                o += std::to_string((long long)R->pct_pool[(size_t)poff + k]);
+                o += std::to_string((long long)g.percentiles[k]);
             }
             o += "]";
         }
@@ -145,9 +145,9 @@ static void json_row(Result *R, const RowStore &r, std::string &o) {
     }
     size_t pos = 0;
     for (size_t g = 0; g < R->group_names.size(); g++) {
-        size_t e = r.gbk.find('\t', pos);
-        std::string part = r.gbk.substr(pos, e == std::string::npos ? std::string::npos : e - pos);
-        pos = e == std::string::npos ? r.gbk.size() : e + 1;
+        size_t e = r.gbk().find('\t', pos);
+        std::string part = r.gbk().substr(pos, e == std::string::npos ? std::string::npos : e - pos);
+        pos = e == std::string::npos ? r.gbk().size() : e + 1;
         std::string v;
         json_escape(part, v);
         kv.emplace_back(R->group_names[g], v);
@@ -176,7 +176,7 @@ static void json_row(Result *R, const RowStore &r, std::string &o) {
 
 static void text_row(const Result *R, const RowStore &r, std::string &o) {
     // printResult, printer.go:183-232
-    std::string gk = r.gbk;
+    std::string gk = r.gbk();
     std::replace(gk.begin(), gk.end(), '\t', ',');
     while (!gk.empty() && gk.back() == ',') gk.pop_back();
     char b[64];
@@ -195,7 +195,7 @@ static void text_row(const Result *R, const RowStore &r, std::string &o) {
         if (R->op == SYBL_AGG_HIST) {
             if (!g.present) continue;
             if (poff >= 0) {
-                const int64_t *p = R->pct_pool.data() + poff;
+                const int64_t *p = g.percentiles;
                 char line[512];
                 snprintf(line, sizeof(line), "%s | %lld %lld | %.2f | %lld %lld %lld %lld %lld | %.2f\n", col.c_str(),
                          (long long)p[0], (long long)p[99], g.avg, (long long)p[0], (long long)p[25], (long long)p[50],
@@ -240,7 +240,7 @@ const char *sybl_result_render(sybl_result *r, int format) {
         for (size_t i = 0; i < lim; i++) top.push_back(&R->sorted0(i));
         auto is_top = [&](const RowStore &x) {
             for (auto *t : top)
-                if (t->gbk == x.gbk) return true;
+                if (t->gbk() == x.gbk()) return true;
             return false;
         };
         if (format == 1) {
@@ -284,10 +284,10 @@ const char *sybl_result_render(sybl_result *r, int format) {
             };
             for (auto &row : R->rows[1]) {
                 if (R->has_distinct) {  // printer.go:79-80: the cardinality, and no aggregation columns
-                    lines.push_back(time_str(row.time_bucket) + " \t " + std::to_string((long long)R->distinct_of(row)) + " \t " + row.gbk + " \t");
+                    lines.push_back(time_str(row.time_bucket) + " \t " + std::to_string((long long)R->distinct_of(row)) + " \t " + row.gbk() + " \t");
                     continue;
                 }
-                std::string head = time_str(row.time_bucket) + " \t " + std::to_string((long long)row.count) + " \t " + row.gbk + " \t";
+                std::string head = time_str(row.time_bucket) + " \t " + std::to_string((long long)row.count) + " \t " + row.gbk() + " \t";
                 bool any = false;
                 for (size_t a = 0; a < R->agg_names.size(); a++) {
                     const sybl_agg_out &g = R->agg_pool[(size_t)row.agg_off + a];

@@ -120,6 +120,7 @@ static void agg_finish(const Query *q, Result *R, const AggInfo &ai, const AggAc
                 prev_p = pp;
             }
             memcpy(R->pct_pool.data() + pct_off, pct, 100 * sizeof(int64_t));
+            o.percentiles = R->pct_pool.data() + pct_off;
         }
         long double var = 0;
         for (auto &p : kc) {
@@ -143,9 +144,10 @@ static void agg_finish(const Query *q, Result *R, const AggInfo &ai, const AggAc
         if (cnt != 0) {
             pct_off = pct_slot;  // pre-sized pool: one 100-entry slot per (row, agg)
             if (a.pct_gpu) {
-                memcpy(R->pct_pool.data() + pct_off, a.pct_gpu, 100 * sizeof(int64_t));
+                o.percentiles = a.pct_gpu;  // straight out of the snapshot (Result::keep_pct): 800 B per row not copied
             } else {
                 percentiles_from_values(a.values, A.n_values, A.bucket_size, A.hmin, cnt, R->pct_pool.data() + pct_off);
+                o.percentiles = R->pct_pool.data() + pct_off;
             }
         }
     }
@@ -217,7 +219,7 @@ static void build_key(const Query *q, int64_t gcell, uint8_t *key, std::string &
 
 // Writes row `row` whose pool slot (agg_off) was assigned by the caller; thread safe because
 // every pool is pre-sized and rows own disjoint slots.
-static void finish_row(const Query *q, Result *R, const CellAcc &acc, RowStore &row) {
+static void finish_row(const Query *q, Result *R, const CellAcc &acc, RowStore &row, bool outliers_logged) {
     row.count = acc.count;
     row.samples = acc.samples;
     size_t na = q->aggs.size();
@@ -229,7 +231,12 @@ static void finish_row(const Query *q, Result *R, const CellAcc &acc, RowStore &
             R->pctoff_pool[k] = -1;
             continue;
         }
-        agg_finish(q, R, q->aggs[a], acc.aggs[a], acc.count, R->agg_pool[k], R->val_pool[k], R->pctoff_pool[k], (int64_t)k * 100);
+        sybl_agg_out &o = R->agg_pool[k];
+        agg_finish(q, R, q->aggs[a], acc.aggs[a], acc.count, o, R->val_pool[k], R->pctoff_pool[k], (int64_t)k * 100);
+        o.values = R->val_pool[k];
+        // the outliers' values are attached later when they were logged; -1: wanted but not available
+        // (-loghist keeps its sub-histograms' outliers as exact counters inside `values`: nothing is ever missing)
+        o.n_outlier_values = (o.n_outliers > 0 && q->want_percentiles && !outliers_logged && !q->loghist) ? -1 : 0;
     }
 }
 
@@ -243,8 +250,9 @@ class WorkerPool {
         return *p;
     }
     static size_t cap() {
-        unsigned hw = std::thread::hardware_concurrency();
-        size_t c = std::min<size_t>(hw ? hw : 1, 32);
+        // (the CPUs the process may actually use: 22 ranges on a 16-CPU quota run as two rounds)
+        static const size_t usable = usable_cpus();
+        size_t c = std::min<size_t>(usable, 32);
         if (const char *e = getenv("SYBL_FINALIZE_THREADS")) c = (size_t)std::max(1, atoi(e));
         return c;
     }
@@ -322,12 +330,7 @@ uint64_t hll_cardinality(const uint8_t *regs) {
 }
 
 static void make_views(Result *R) {
-    parallel_ranges(R->agg_pool.size(), 1 << 15, [&](size_t k0, size_t k1) {
-        for (size_t k = k0; k < k1; k++) {
-            R->agg_pool[k].values = R->val_pool[k];
-            R->agg_pool[k].percentiles = R->pctoff_pool[k] >= 0 ? R->pct_pool.data() + R->pctoff_pool[k] : nullptr;
-        }
-    });
+    // (sybl_agg_out::values / percentiles / outlier fields were set when the rows were built)
     for (int w = 0; w < 3; w++) {
         R->view[w].resize(R->rows[w].size());
         parallel_ranges(R->rows[w].size(), 1 << 15, [&, w](size_t i0, size_t i1) {
@@ -335,7 +338,7 @@ static void make_views(Result *R) {
                 RowStore &r = w == 0 ? R->sorted0(i) : R->rows[w][i];
                 sybl_group_row &v = R->view[w][i];
                 v.binary_key = r.key;
-                v.group_by_key = r.gbk.c_str();
+                v.group_by_key = r.gbkp->c_str();
                 v.time_bucket = r.time_bucket;
                 v.count = r.count;
                 v.samples = r.samples;
@@ -350,6 +353,27 @@ static void make_views(Result *R) {
 // query reuses the buffer for the next finalize unless a live result still holds it (then a fresh
 // one is allocated) -- so a 525 MB histogram table is never copied, page-faulted or unmapped per query.
 // Many cells with bucket arrays: percentiles / bucket moments / Cumulative buckets come from the GPU.
+// A pinned host buffer of at least `words` int64 that no result holds any more (use count 1: only the query's list),
+// or a new one: results keep the snapshot their rows point into, and a pipelined host frees a result only after the
+// query's next snapshot was queued -- allocating 52 MB of pinned memory per step instead cost 1.8 ms of every step.
+static int acquire_host_buf(Query *q, int64_t words, std::shared_ptr<HostBuf> &cur) {
+    cur.reset();
+    for (auto &b : q->host_bufs)
+        if (b.use_count() == 1 && b->words >= words) {
+            cur = b;
+            return SYBL_OK;
+        }
+    for (size_t i = 0; i < q->host_bufs.size();)  // drop free buffers that are too small
+        if (q->host_bufs[i].use_count() == 1) q->host_bufs.erase(q->host_bufs.begin() + (long)i);
+        else i++;
+    auto nb = std::make_shared<HostBuf>();
+    SYBL_HIP(hipHostMalloc((void **)&nb->p, (size_t)words * 8, hipHostMallocDefault));
+    nb->words = words;
+    q->host_bufs.push_back(nb);
+    cur = nb;
+    return SYBL_OK;
+}
+
 bool query_wants_hist_summary(const Query *q) {
     const ScanPlan &P = q->plan;
     if (getenv("SYBL_NO_HISTSUMMARY") || q->hash_mode || q->loghist) return false;
@@ -360,6 +384,7 @@ bool query_wants_hist_summary(const Query *q) {
 }
 
 int query_snapshot(Query *q) {
+    PhaseTrace trace("snapshot");
     hipStream_t st = q->ctx->stream;
     const ScanPlan &P = q->plan;
     if (q->hash_mode) {
@@ -369,11 +394,9 @@ int query_snapshot(Query *q) {
     // a hash group-by snapshots its dense, key-ordered arrays, whose size follows the keys found
     const int64_t sum_words = q->hash_mode ? hash_dense_sum_words(q, q->hash_live) : q->n_sum_words;
     const int64_t max_words = q->hash_mode ? hash_dense_max_words(q, q->hash_live) : q->n_max_words;
-    if (!q->h_sum_buf || q->h_sum_buf.use_count() > 1 || q->h_sum_buf->words < sum_words) {
-        auto nb = std::make_shared<HostBuf>();
-        SYBL_HIP(hipHostMalloc((void **)&nb->p, (size_t)sum_words * 8, hipHostMallocDefault));
-        nb->words = sum_words;
-        q->h_sum_buf = nb;
+    if (!q->h_sum_buf || q->h_sum_buf.use_count() > 2 || q->h_sum_buf->words < sum_words) {
+        int rc = acquire_host_buf(q, sum_words, q->h_sum_buf);
+        if (rc) return rc;
     }
     if (!q->h_max || q->h_max_words < max_words) {
         if (q->h_max) SYBL_HIP(hipHostFree(q->h_max));
@@ -382,6 +405,7 @@ int query_snapshot(Query *q) {
         q->h_max_words = max_words;
     }
     q->h_sum = q->h_sum_buf->p;
+    trace.mark("buffers");
     q->hist_summary = query_wants_hist_summary(q);
     // the bucket arrays cross PCIe only when every row's are wanted (no limit); otherwise the printed
     // rows' arrays are gathered after the sort (query_finalize)
@@ -393,10 +417,24 @@ int query_snapshot(Query *q) {
             SYBL_HIP(hipMalloc((void **)&q->d_pct, (size_t)pairs * 100 * 8));
             SYBL_HIP(hipMalloc((void **)&q->d_mom, (size_t)pairs * 2 * 8));
             SYBL_HIP(hipMalloc((void **)&q->d_total, (size_t)P.hist_stride * 8));
-            SYBL_HIP(hipHostMalloc((void **)&q->h_pct, (size_t)pairs * 100 * 8, hipHostMallocDefault));
             SYBL_HIP(hipHostMalloc((void **)&q->h_mom, (size_t)pairs * 2 * 8, hipHostMallocDefault));
             SYBL_HIP(hipHostMalloc((void **)&q->h_total, (size_t)P.hist_stride * 8, hipHostMallocDefault));
         }
+        // the rows' percentiles point straight into this snapshot: a result that is still alive keeps its own
+        if (!q->h_pct_buf) {
+            // a pipelined host holds the previous result of this query while the next snapshot is queued: two buffers
+            // from the start (allocating the second one when it is first missed costs a step 3.5 ms of pinned allocation)
+            std::shared_ptr<HostBuf> spare;
+            int rc = acquire_host_buf(q, pairs * 100, spare);
+            if (rc) return rc;
+            rc = acquire_host_buf(q, pairs * 100, q->h_pct_buf);  // (`spare` is held: a second buffer)
+            if (rc) return rc;
+        }
+        if (q->h_pct_buf.use_count() > 2 || q->h_pct_buf->words < pairs * 100) {
+            int rc = acquire_host_buf(q, pairs * 100, q->h_pct_buf);
+            if (rc) return rc;
+        }
+        q->h_pct = q->h_pct_buf->p;
         SYBL_HIP(hipMemsetAsync(q->d_pct, 0, (size_t)pairs * 100 * 8, st));
         SYBL_HIP(hipMemsetAsync(q->d_total, 0, (size_t)P.hist_stride * 8, st));
         HistSummaryPlan S;
@@ -433,6 +471,7 @@ int query_snapshot(Query *q) {
     // everything queued so far by an event: the copy engine then works under the next query's scan instead of in front
     // of it (config 4, 10 pipelined steps: 7.3 ms per step with the copy on the main stream, 6.4 ms this way).  Small ones (config 3: 57 KB) stay on the main stream -- an event
     // round trip costs more than they do.
+    trace.mark("summary-kernels");
     const int64_t real_pairs = q->hist_summary ? (int64_t)P.n_cells * (int64_t)q->aggs.size() : 0;
     const int64_t main_words = q->hash_mode ? sum_words : (q->snap_has_buckets ? q->n_sum_words : P.hist_off);
     hipStream_t cs = st;
@@ -462,6 +501,7 @@ int query_snapshot(Query *q) {
     if (!q->ev_snap) SYBL_HIP(hipEventCreateWithFlags(&q->ev_snap, hipEventDisableTiming));
     SYBL_HIP(hipEventRecord(q->ev_snap, cs));
     q->snapshot_pending = true;
+    trace.mark("copies");
     return SYBL_OK;
 }
 
@@ -524,28 +564,13 @@ static int attach_top_values(Query *q, Result *R, size_t top) {
     }
     for (size_t i = 0; i < top; i++)
         for (size_t a = 0; a < na; a++)
-            if (R->agg_pool[(size_t)R->sorted0(i).agg_off + a].present)
-                R->val_pool[(size_t)R->sorted0(i).agg_off + a] = R->top_vals.data() + i * (size_t)P.hist_stride + P.hist_agg_off[a];
+            if (R->agg_pool[(size_t)R->sorted0(i).agg_off + a].present) {
+                const size_t k = (size_t)R->sorted0(i).agg_off + a;
+                R->val_pool[k] = R->top_vals.data() + i * (size_t)P.hist_stride + P.hist_agg_off[a];
+                R->agg_pool[k].values = R->val_pool[k];
+            }
     return SYBL_OK;
 }
-
-// SYBL_FINALIZE_TRACE=1: per-phase host timings of query_finalize on stderr
-struct PhaseTrace {
-    bool on = getenv("SYBL_FINALIZE_TRACE") != nullptr;
-    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
-    std::string line;
-    void mark(const char *what) {
-        if (!on) return;
-        auto t1 = std::chrono::steady_clock::now();
-        char b[64];
-        snprintf(b, sizeof(b), " %s=%.1fus", what, std::chrono::duration<double, std::micro>(t1 - t0).count());
-        line += b;
-        t0 = t1;
-    }
-    ~PhaseTrace() {
-        if (on) fprintf(stderr, "finalize:%s\n", line.c_str());
-    }
-};
 
 int query_finalize(Query *q, Result **out) {
     const ScanPlan &P = q->plan;
@@ -614,7 +639,12 @@ int query_finalize(Query *q, Result **out) {
         H = hashed ? F + (int64_t)P.n_sum_fields * ncell : hs + P.hist_off;
     }
     const bool summary = q->hist_summary;
+    if (summary) R->keep_pct = q->h_pct_buf;  // the rows' percentiles live in the snapshot
     const size_t na = q->aggs.size();
+    // outlier values (plan.h: outlier log): usable when every one of them was logged
+    const bool out_logged = q->d_out_log != nullptr;
+    const int64_t n_out_log = out_logged ? hs[kHdrOutLog] : 0;
+    const bool out_usable = out_logged && !q->out_log_partial && n_out_log <= q->out_cap;
 
     auto load_cell = [&](int64_t cell, CellAcc &acc) -> bool {
         acc.count = F[cell];
@@ -668,27 +698,49 @@ int query_finalize(Query *q, Result **out) {
         all_count.assign((size_t)gcells, 0);
         all_samples.assign((size_t)gcells, 0);
     }
-    // pass 1 (serial, cheap): the live cells, and in time-series mode the all-time Count/Samples
+    // pass 1: the live cells (ascending), and in time-series mode the all-time Count/Samples.  Ranges of cells are
+    // compacted by worker threads into their own slice of `live` and the slices closed up afterwards (721 x 500 cells
+    // took 0.65 ms serially: a quarter of what the scan kernel of config 5 takes).
     std::vector<int64_t> &live = R->live;
     {
         const int64_t *E = P.f_samples >= 0 ? F + (int64_t)P.f_samples * ncell : F;
         live.resize((size_t)ncell);
-        size_t n_live = 0;
         int64_t *lv = live.data();
-        for (int64_t cell = 0; cell < ncell; cell++) {
-            lv[n_live] = cell;
-            n_live += E[cell] != 0;  // branch-free compaction
+        const size_t grain = (size_t)1 << 16, n_chunks = ((size_t)ncell + grain - 1) / grain;
+        std::vector<size_t> found(n_chunks, 0);
+        parallel_ranges(n_chunks, 1, [&](size_t c0, size_t c1) {
+            for (size_t c = c0; c < c1; c++) {
+                const int64_t b = (int64_t)(c * grain), e = std::min<int64_t>(ncell, b + (int64_t)grain);
+                size_t n = 0;
+                int64_t *dst = lv + b;
+                for (int64_t cell = b; cell < e; cell++) {
+                    dst[n] = cell;
+                    n += E[cell] != 0;  // branch-free compaction
+                }
+                found[c] = n;
+            }
+        });
+        size_t n_live = 0;
+        for (size_t c = 0; c < n_chunks; c++) {
+            if (n_live != c * grain) memmove(lv + n_live, lv + c * grain, found[c] * sizeof(int64_t));
+            n_live += found[c];
         }
         live.resize(n_live);
     }
     std::vector<int64_t> &alltime = R->alltime;  // group cells with any row (time-series mode)
     alltime.clear();
     if (q->time_mode) {
-        for (int64_t cell : live) {
-            int64_t gcell = cell % gcells;
-            all_count[(size_t)gcell] += F[cell];
-            all_samples[(size_t)gcell] += P.f_samples >= 0 ? F[(int64_t)P.f_samples * ncell + cell] : F[cell];
-        }
+        // (time bucket major, group minor: walk a bucket's cells as one contiguous run per group range)
+        const int64_t *S = P.f_samples >= 0 ? F + (int64_t)P.f_samples * ncell : F;
+        parallel_ranges((size_t)gcells, 1 << 12, [&](size_t g0, size_t g1) {
+            for (int64_t tb = 0; tb * gcells < ncell; tb++) {
+                const int64_t *fc = F + tb * gcells, *fs = S + tb * gcells;
+                for (size_t g = g0; g < g1; g++) {
+                    all_count[g] += fc[g];
+                    all_samples[g] += fs[g];
+                }
+            }
+        });
         for (int64_t g = 0; g < gcells; g++)
             if (q->weighted ? all_samples[(size_t)g] != 0 : all_count[(size_t)g] != 0) alltime.push_back(g);
     }
@@ -702,6 +754,28 @@ int query_finalize(Query *q, Result **out) {
     R->pctoff_pool.resize(n_all_rows * na);
     R->pct_pool.resize(q->want_percentiles ? n_all_rows * na * 100 : 0);
 
+    // BinaryByKey / GroupByKey per group cell: the query's cache (built by its first finalize), or per row
+    const bool keys_cached = !hashed && gcells <= ((int64_t)1 << 18);
+    std::shared_ptr<KeyStore> ks;
+    if (keys_cached) {
+        if (!q->key_cache) {
+            auto kc = std::make_shared<KeyStore>();
+            kc->resize((size_t)gcells + 1);
+            parallel_ranges((size_t)gcells, 1 << 10, [&](size_t g0, size_t g1) {
+                for (size_t g = g0; g < g1; g++) build_key(q, (int64_t)g, kc->key(g), kc->gbk[g]);
+            });
+            memset(kc->key((size_t)gcells), 0, KeyStore::kKeyBytes);
+            kc->gbk[(size_t)gcells] = "TOTAL";
+            for (size_t g = 1; g < q->groups.size(); g++) kc->gbk[(size_t)gcells] += "\t";
+            q->key_cache = kc;
+        }
+        ks = q->key_cache;
+    } else {
+        if (!R->own_keys) R->own_keys = std::make_shared<KeyStore>();
+        ks = R->own_keys;
+        ks->resize(n_all_rows);
+    }
+    R->keys = ks;
     trace.mark("alloc");
     // pass 2: one row per live cell.  Rows own disjoint pool slots, so ranges of cells are
     // finished by worker threads when there are enough of them to pay for the threads.
@@ -714,9 +788,16 @@ int query_finalize(Query *q, Result **out) {
             RowStore &row = cell_rows[i];
             row.agg_off = (int64_t)(i * na);
             row.cell = cell;
-            build_key(q, gcell, row.key, row.gbk);
+            if (keys_cached) {
+                row.key = ks->key((size_t)gcell);
+                row.gbkp = &ks->gbk[(size_t)gcell];
+            } else {
+                build_key(q, gcell, ks->key(i), ks->gbk[i]);
+                row.key = ks->key(i);
+                row.gbkp = &ks->gbk[i];
+            }
             row.time_bucket = q->time_mode ? (P.tb_min + tbi) * P.time_bucket : 0;  // (rows are recycled: assign every field)
-            finish_row(q, R, acc, row);
+            finish_row(q, R, acc, row, out_usable);
             if (!q->time_mode) {
                 for (size_t a = 0; a < na; a++) {
                     AggAcc &d = tot->aggs[a];
@@ -801,11 +882,14 @@ int query_finalize(Query *q, Result **out) {
             row.agg_off = (int64_t)((next_slot + i) * na);
             row.time_bucket = 0;
             row.cell = -1;  // (rows are recycled)
-            build_key(q, g, row.key, row.gbk);
+            const size_t e = keys_cached ? (size_t)g : next_slot + i;
+            if (!keys_cached) build_key(q, g, ks->key(e), ks->gbk[e]);
+            row.key = ks->key(e);
+            row.gbkp = &ks->gbk[e];
             CellAcc a2;
             a2.count = all_count[(size_t)g];
             a2.samples = all_samples[(size_t)g];
-            finish_row(q, R, a2, row);
+            finish_row(q, R, a2, row, out_usable);
         }
         next_slot += alltime.size();
     }
@@ -815,11 +899,16 @@ int query_finalize(Query *q, Result **out) {
         RowStore &row = R->rows[2].back();
         row.agg_off = (int64_t)(next_slot * na);
         row.time_bucket = 0;
-        memset(row.key, 0, sizeof(row.key));
-        row.gbk = "TOTAL";
+        const size_t e = keys_cached ? (size_t)gcells : next_slot;
+        if (!keys_cached) {
+            memset(ks->key(e), 0, KeyStore::kKeyBytes);
+            ks->gbk[e] = "TOTAL";
+            for (size_t g = 1; g < q->groups.size(); g++) ks->gbk[e] += "\t";
+        }
+        row.key = ks->key(e);
+        row.gbkp = &ks->gbk[e];
         row.cell = -1;
-        for (size_t g = 1; g < q->groups.size(); g++) row.gbk += "\t";
-        finish_row(q, R, total, row);
+        finish_row(q, R, total, row, out_usable);
     }
 
     // ---- count distinct (query_spec.go:87,180-188): every row's sketch and its Cardinality()
@@ -850,14 +939,8 @@ int query_finalize(Query *q, Result **out) {
 
     // ---- outlier values (plan.h: outlier log) -> the rows that own them
     {
-        const bool logged = q->d_out_log != nullptr;
-        const int64_t n_log = logged ? hs[kHdrOutLog] : 0;
-        const bool usable = logged && !q->out_log_partial && n_log <= q->out_cap;
-        for (size_t k = 0; k < R->agg_pool.size(); k++) {
-            R->agg_pool[k].outlier_values = nullptr;
-            // (-loghist keeps its sub-histograms' outliers as exact counters inside `values`: nothing is ever missing)
-            R->agg_pool[k].n_outlier_values = (R->agg_pool[k].n_outliers > 0 && q->want_percentiles && !usable && !q->loghist) ? -1 : 0;
-        }
+        const int64_t n_log = n_out_log;
+        const bool usable = out_usable;
         R->outlier_vals.clear();
         if (usable && n_log > 0) {
             std::vector<int64_t> log((size_t)n_log * kOutLogWords);

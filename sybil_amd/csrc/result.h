@@ -30,9 +30,25 @@ struct CellAcc {
     AggAcc aggs[kMaxAggs];
 };
 
+// Result.BinaryByKey / Result.GroupByKey of the rows: one entry per GROUP CELL, built once per prepared query (a query's
+// key space and dictionaries cannot change after prepare) and shared by every result of it -- a time series has
+// n_buckets x groups rows but only `groups` keys, and a bench step used to build 360 000 strings per finalize -- or,
+// when the key space is too wide for that (hash group-by), one entry per row, owned by the result.
+struct KeyStore {
+    static constexpr size_t kKeyBytes = SYBL_MAX_GROUPS * SYBL_GROUP_BY_WIDTH;
+    std::vector<std::string> gbk;
+    std::vector<uint8_t> keys;  // [entry][kKeyBytes]
+    void resize(size_t n) {
+        gbk.resize(n);
+        keys.resize(n * kKeyBytes);
+    }
+    uint8_t *key(size_t i) { return keys.data() + i * kKeyBytes; }
+};
+
 struct RowStore {
-    uint8_t key[SYBL_MAX_GROUPS * SYBL_GROUP_BY_WIDTH];
-    std::string gbk;
+    const uint8_t *key = nullptr;       // into Result::keys
+    const std::string *gbkp = nullptr;
+    const std::string &gbk() const { return *gbkp; }
     int64_t time_bucket = 0, count = 0, samples = 0;
     int64_t agg_off = 0;  // this row's n_aggs entries in Result::agg_pool / val_pool / pctoff_pool
     int64_t cell = -1;    // group cell (rows of Results / TimeResults)
@@ -49,7 +65,9 @@ struct ResultStore {
     std::vector<sybl_agg_out> agg_pool;
     std::vector<const int64_t *> val_pool;
     std::vector<int64_t> live, alltime, all_count, all_samples;  // finalize scratch
+    std::shared_ptr<KeyStore> own_keys;  // per-row keys (hash group-by / very wide key spaces)
     void swap(ResultStore &o) {
+        own_keys.swap(o.own_keys);
         for (int w = 0; w < 3; w++) {
             rows[w].swap(o.rows[w]);
             view[w].swap(o.view[w]);
@@ -85,6 +103,8 @@ struct Result : ResultStore {
         }
     }
     int64_t matched = 0;
+    std::shared_ptr<KeyStore> keys;               // what the rows' key / gbkp point into (the query's cache or own_keys)
+    std::shared_ptr<HostBuf> keep_pct;            // the snapshot of the GPU-computed percentiles the rows point into
     std::shared_ptr<HostBuf> keep;                // the pinned snapshot of the partial table the bucket
                                                   // arrays of the rows point into
     std::vector<std::vector<int64_t>> total_vals; // Cumulative bucket arrays
