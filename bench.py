@@ -115,14 +115,13 @@ def oracle_check(workload, q, total_rows, head):
             "oracle_seconds": round(dt, 2), "threads": os.cpu_count() or 1}
 
 
-def load_path(ctx, rows=100 * 1024 * 1024 // 65536 * 65536):
+def load_path(ctx, names, rows=100 * 1024 * 1024 // 65536 * 65536):
     """Disk -> HBM: the TableBlock load half of the hot path (table_block_io.go:225-310, column_store_io.go:493-780).  A
     synthetic table is written in the reference's on-disk format (sybl_table_save) and read back with the native loader
     into compact storage (sybl_table_open_flags); outside every timed scan region."""
     import shutil
     import tempfile
     from sybil_amd import synth
-    names = ["c00", "c01", "c07", "c09"]  # time (delta-friendly), 16 values (bucket encoded), 1e6 values (value encoded), 500 ids
     root = tempfile.mkdtemp(prefix="sybl_bench_load_")
     try:
         t = ctx.synth_table("loadbench", synth.SEED, rows, 0, rows, synth.synth_cols(names))
@@ -434,7 +433,10 @@ def main():
             out["configs"] = recs
     if rank == 0:
         if world == 1 and not args.no_load:
-            out["load"] = load_path(ctx)
+            # the bench's own table (the 7 referenced columns of config 3: five bucket-encoded, two value-encoded), and
+            # the mix of round 2's record: time (delta-friendly), 16 values, 1e6 values (value encoded), 500 ids
+            out["load"] = load_path(ctx, synth.WORKLOADS["cfg3_filter3_group2_stddev"]["columns"])
+            out["load_mixed_4col"] = load_path(ctx, ["c00", "c01", "c07", "c09"])
         print(json.dumps(out))
         sys.stdout.flush()
     if multi and args.collective == "rccl":

@@ -402,48 +402,56 @@ __global__ __launch_bounds__(256) void k_decode_bins(const R *__restrict__ recs,
 }
 
 // Value-encoded int column: Values[r] is a delta from Values[r-1] (column_store_io.go:109-113,748-777).
-// One workgroup of 1024 threads owns the whole block (<= 65536 rows in the reference): a lane takes kDeltaPerThread
-// consecutive values per round (8192 per round: eight rounds per block; one value per lane and round took 64 rounds
-// of two barriers each, 114 us per block -- 80 % of the GPU time of a table load).  V: int32 when every stored value /
-// delta of the block fits (the worker checked), else int64.  O: the column's stored type (see above).
+// A block (<= 65536 rows in the reference) is split into segments of 1024 x kDeltaPerThread values, one workgroup each:
+// the workgroup first sums the deltas AHEAD of its segment (a plain reduction: up to 56 values per lane), then scans its
+// own 8192 values in one round -- lane totals through a wave scan, wave totals through LDS.  (Round 2 ran one workgroup
+// per block: eight dependent rounds of two barriers each, 114 us per block and 78 % of the GPU time of a table load;
+// the extra reads of the reduction are a few hundred KB per block.)  V: int32 when every stored value / delta of the
+// block fits (the worker checked), else int64.  O: the column's stored type (see above).
 constexpr int kDeltaPerThread = 8;
+constexpr int64_t kDeltaSegment = 1024 * kDeltaPerThread;
 template <typename V, typename O>
 __global__ __launch_bounds__(1024) void k_decode_delta(const V *__restrict__ deltas, int64_t n, int value_encoded, int64_t vbase,
                                                        O *__restrict__ col) {
     __shared__ int64_t wave_tot[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int64_t carry = 0;
-    for (int64_t base = 0; base < n; base += 1024 * kDeltaPerThread) {
-        const int64_t i0 = base + (int64_t)threadIdx.x * kDeltaPerThread;
-        int64_t v[kDeltaPerThread];
+    const int64_t base = (int64_t)blockIdx.x * kDeltaSegment;
+    int64_t carry = 0;  // the sum of everything ahead of this segment
+    if (value_encoded && base > 0) {
+        int64_t t = 0;
+        for (int64_t i = threadIdx.x; i < base; i += 1024) t += (int64_t)deltas[i];
 #pragma unroll
-        for (int j = 0; j < kDeltaPerThread; j++) v[j] = i0 + j < n ? (int64_t)deltas[i0 + j] : 0;
-        if (value_encoded) {
-#pragma unroll
-            for (int j = 1; j < kDeltaPerThread; j++) v[j] += v[j - 1];  // the lane's own running sum
-            int64_t t = v[kDeltaPerThread - 1];                           // inclusive scan of the lanes' totals
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                int64_t u = __shfl_up(t, o, 64);
-                if (lane >= o) t += u;
-            }
-            if (lane == 63) wave_tot[wave] = t;
-            __syncthreads();
-            int64_t pre = 0, total = 0;
-            for (int w = 0; w < 16; w++) {
-                if (w < wave) pre += wave_tot[w];
-                total += wave_tot[w];
-            }
-            const int64_t before = t - v[kDeltaPerThread - 1] + pre + carry;  // everything ahead of this lane's values
-#pragma unroll
-            for (int j = 0; j < kDeltaPerThread; j++) v[j] += before;
-            carry += total;
-            __syncthreads();
-        }
-#pragma unroll
-        for (int j = 0; j < kDeltaPerThread; j++)
-            if (i0 + j < n) col[i0 + j] = (O)((uint64_t)v[j] - (uint64_t)vbase);
+        for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+        if (lane == 0) wave_tot[wave] = t;
+        __syncthreads();
+        for (int w = 0; w < 16; w++) carry += wave_tot[w];
+        __syncthreads();
     }
+    const int64_t i0 = base + (int64_t)threadIdx.x * kDeltaPerThread;
+    int64_t v[kDeltaPerThread];
+#pragma unroll
+    for (int j = 0; j < kDeltaPerThread; j++) v[j] = i0 + j < n ? (int64_t)deltas[i0 + j] : 0;
+    if (value_encoded) {
+#pragma unroll
+        for (int j = 1; j < kDeltaPerThread; j++) v[j] += v[j - 1];  // the lane's own running sum
+        int64_t t = v[kDeltaPerThread - 1];                           // inclusive scan of the lanes' totals
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            int64_t u = __shfl_up(t, o, 64);
+            if (lane >= o) t += u;
+        }
+        if (lane == 63) wave_tot[wave] = t;
+        __syncthreads();
+        int64_t pre = 0;
+        for (int w = 0; w < 16; w++)
+            if (w < wave) pre += wave_tot[w];
+        const int64_t before = t - v[kDeltaPerThread - 1] + pre + carry;  // everything ahead of this lane's values
+#pragma unroll
+        for (int j = 0; j < kDeltaPerThread; j++) v[j] += before;
+    }
+#pragma unroll
+    for (int j = 0; j < kDeltaPerThread; j++)
+        if (i0 + j < n) col[i0 + j] = (O)((uint64_t)v[j] - (uint64_t)vbase);
 }
 
 // Per-row block-local dictionary ids -> table-global ids (non-bucket str columns)
@@ -486,11 +494,12 @@ hipError_t launch_decode_bins(const void *recs, int rec_width, const int64_t *bi
 
 template <typename V>
 static void decode_delta_t(const void *deltas, int64_t n, int ve, void *col, int out_width, int64_t vbase, hipStream_t st) {
+    const dim3 grid((unsigned)((n + kDeltaSegment - 1) / kDeltaSegment));
     switch (out_width) {
-    case 1: hipLaunchKernelGGL((k_decode_delta<V, uint8_t>), dim3(1), dim3(1024), 0, st, (const V *)deltas, n, ve, vbase, (uint8_t *)col); break;
-    case 2: hipLaunchKernelGGL((k_decode_delta<V, uint16_t>), dim3(1), dim3(1024), 0, st, (const V *)deltas, n, ve, vbase, (uint16_t *)col); break;
-    case 4: hipLaunchKernelGGL((k_decode_delta<V, uint32_t>), dim3(1), dim3(1024), 0, st, (const V *)deltas, n, ve, vbase, (uint32_t *)col); break;
-    default: hipLaunchKernelGGL((k_decode_delta<V, int64_t>), dim3(1), dim3(1024), 0, st, (const V *)deltas, n, ve, vbase, (int64_t *)col); break;
+    case 1: hipLaunchKernelGGL((k_decode_delta<V, uint8_t>), grid, dim3(1024), 0, st, (const V *)deltas, n, ve, vbase, (uint8_t *)col); break;
+    case 2: hipLaunchKernelGGL((k_decode_delta<V, uint16_t>), grid, dim3(1024), 0, st, (const V *)deltas, n, ve, vbase, (uint16_t *)col); break;
+    case 4: hipLaunchKernelGGL((k_decode_delta<V, uint32_t>), grid, dim3(1024), 0, st, (const V *)deltas, n, ve, vbase, (uint32_t *)col); break;
+    default: hipLaunchKernelGGL((k_decode_delta<V, int64_t>), grid, dim3(1024), 0, st, (const V *)deltas, n, ve, vbase, (int64_t *)col); break;
     }
 }
 

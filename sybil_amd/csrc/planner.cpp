@@ -90,6 +90,11 @@ static bool fill_packed(Table *t, Query *q, const std::vector<int> &slot_col, Fa
             FP.plo[c] = (uint32_t)(L < 0 ? 0 : L);
             FP.phi[c] = (uint32_t)(H > umax ? umax : H);
         }
+        FP.npneq[c] = 0;
+        for (int k = 0; k < FP.nneq[c]; k++) {
+            const __int128 off = (__int128)FP.neq[c][k] - FP.fbase[c];
+            if (off >= 0 && off <= umax) FP.pneq[c][FP.npneq[c]++] = (uint32_t)off;  // (else: no stored value equals it)
+        }
     }
     for (int c = 0; c < ng; c++) FP.gdoff[c] = (uint32_t)((uint64_t)FP.gbase[c] - (uint64_t)FP.gmin[c]);
     for (int c = 0; c < na; c++) {
@@ -155,26 +160,32 @@ static bool fill_fast_columns(Table *t, Query *q, const std::vector<int> &slot_c
             *gen = true;
         }
         uint32_t roles = sd.flags & (kSlotFilter | kSlotGroup | kSlotAgg);
-        if (sd.flags & (kSlotNeq | kSlotSet | kSlotDict)) return false;
+        if (sd.flags & (kSlotSet | kSlotDict)) return false;
+        if ((sd.flags & kSlotNeq) && (!allow_gen || c->type != SYBL_INT_VAL)) return false;
         if ((sd.flags & kSlotIdMask) && !allow_gen) return false;
         if ((sd.flags & kSlotWeight) && (roles != 0 || (sd.flags & kSlotTime) || !allow_gen)) return false;
         // a column may be filtered AND be a key / an aggregation input / the time column (it is then
         // streamed once per role; the second read hits L1/L2), but not key and aggregation input at once
         uint32_t fpart = roles & kSlotFilter, rest = roles & (kSlotGroup | kSlotAgg);
-        if (fpart != 0 && fpart != kSlotRange && fpart != kSlotIdMask) return false;
+        if (fpart != 0 && fpart != kSlotRange && fpart != kSlotIdMask && fpart != kSlotNeq && fpart != (kSlotRange | kSlotNeq)) return false;
         if (rest == (kSlotGroup | kSlotAgg)) return false;
         if ((sd.flags & kSlotTime) && rest != 0) return false;
     }
     for (size_t s = 0; s < slot_col.size(); s++) {
         const SlotDesc &sd = P.slot[s];
-        if (!(sd.flags & (kSlotRange | kSlotIdMask))) continue;
+        if (!(sd.flags & (kSlotRange | kSlotIdMask | kSlotNeq))) continue;
         if (nf >= kFastMaxF) return false;
         FP.fcol[nf] = (const int64_t *)sd.base;
         FP.fwid[nf] = sd.width;
         FP.fbase[nf] = sd.vbase;
         FP.fvalid[nf] = sd.valid;
-        FP.lo[nf] = sd.lo;
-        FP.hi[nf] = sd.hi;
+        FP.lo[nf] = (sd.flags & kSlotRange) ? sd.lo : INT64_MIN;
+        FP.hi[nf] = (sd.flags & kSlotRange) ? sd.hi : INT64_MAX;
+        if (sd.flags & kSlotNeq) {
+            FP.nneq[nf] = sd.n_neq;
+            for (int k = 0; k < sd.n_neq; k++) FP.neq[nf][k] = sd.neq[k];
+            *gen = true;  // the neq constants are compared in the GEN / NUL row bodies
+        }
         if (sd.flags & kSlotIdMask) {
             FP.fmask[nf] = sd.idmask;
             FP.fmask_bits[nf] = sd.idmask_bits;

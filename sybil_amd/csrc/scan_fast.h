@@ -58,6 +58,11 @@ struct FastPlan {
     // str filters (filter.go:199-250) as one bit per dictionary id: fmask != nullptr replaces the range
     const uint32_t *fmask[kFastMaxF];
     int32_t fmask_bits[kFastMaxF];
+    // int `neq` filters (filter.go:171-195: up to kMaxNeq constants per column, next to or without a range);
+    // pneq: the same constants as stored offsets for k_scan_packed<NUL> (one that no offset can equal is dropped)
+    int32_t nneq[kFastMaxF], npneq[kFastMaxF];
+    int64_t neq[kFastMaxF][kMaxNeq];
+    uint32_t pneq[kFastMaxF][kMaxNeq];
     int32_t f_cnt[kFastMaxA], f_pop[kFastMaxA], f_smp[kFastMaxA], f_out[kFastMaxA];
     int64_t info_min[kFastMaxA], max10[kFastMaxA];
     const int64_t *wcol;           // weight column (OPTS.WEIGHT_COL, aggregate.go:100-102), fully populated
@@ -309,7 +314,10 @@ __device__ __forceinline__ void fast_row(const FastPlan &P, const FastTile<NF> &
         } else {
             pass = pass && x >= P.lo[c] && x <= P.hi[c];  // filter.go:171-195, folded to a range
         }
-        if (GEN) pass = pass && ((f.pop[c] >> r) & 1u);  // an unpopulated value fails every filter
+        if (GEN) {
+            for (int k = 0; k < P.nneq[c]; k++) pass = pass && x != P.neq[c][k];
+            pass = pass && ((f.pop[c] >> r) & 1u);  // an unpopulated value fails every filter
+        }
     }
     if (!pass) return;
     matched += 1;  // aggregate.go:117

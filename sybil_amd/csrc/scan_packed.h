@@ -215,6 +215,7 @@ __device__ __forceinline__ void packed_row(const FastPlan &P, const PackedTile<N
                 ok = id < (uint32_t)P.fmask_bits[c];
                 if (ok) ok = (P.fmask[c][id >> 5] >> (id & 31)) & 1u;
             }
+            for (int k = 0; k < P.npneq[c]; k++) ok = ok & (u != P.pneq[c][k]);  // int neq, rebased
             ok = ok & ((f.pop[c] >> r) & 1u);  // an unpopulated value fails every filter
         }
         pass = pass & ok;

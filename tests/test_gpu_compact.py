@@ -245,3 +245,18 @@ def test_nullable_and_str_columns_run_the_packed_kernel(ctx, oracle):
         r.free()
         query.free()
     tb.free()
+
+
+@pytest.mark.parametrize("compact", [False, True])
+def test_int_neq_runs_the_specialised_kernels(ctx, oracle, compact):
+    """Config 3 with an int `neq` (two constants on one filter column, one of them next to the range; a third on a
+    column of its own): the role-specialised kernels take it (k_scan_fast<GEN> / k_scan_packed<NUL>), not the
+    plan-interpreting k_scan (filter.go:171-195)."""
+    wl = synth.WORKLOADS["cfg3_filter3_group2_stddev"]
+    q = dict(wl["query"])
+    q["filters"] = list(q["filters"]) + [("c04", "neq", 500), ("c04", "neq", 123), ("c02", "neq", 7)]
+    gres, ores, stats = parity.run_both(ctx, oracle, wl["columns"], 900_000, 0, 900_000, q, compact=compact)
+    assert stats["strategy"] == 2 and stats["packed_kernel"] == (1 if compact else 0), stats
+    parity.compare(gres, ores, op="hist", full=False, n_aggs=2)
+    assert len(gres.results) == 16 * 63     # c02 = 7 is gone
+    gres.free()
