@@ -80,6 +80,7 @@ static void free_query(Query *q) {
     if (q->d_wg_seg_begin) hipFree(q->d_wg_seg_begin);
     if (q->d_wg_cell_base) hipFree(q->d_wg_cell_base);
     if (q->d_recs) hipFree(q->d_recs);
+    if (q->d_h32) hipFree(q->d_h32);
     if (q->d_cursor) hipFree(q->d_cursor);
     for (void *p : q->d_idmasks) hipFree(p);
     if (q->own_partials) {

@@ -847,6 +847,32 @@ hipError_t launch_part_hist(const PartHistPlan &P, hipStream_t st) {
     return hipErrorInvalidValue;
 }
 
+// Bucket tables on their way through a reduce-scatter (rccl.cpp): int64 counters narrowed to int32 when the ranks'
+// rows together stay below 2^31 (half the bytes over xGMI), and the reduced slice widened again in place.
+__global__ __launch_bounds__(256) void k_pack32(const int64_t *__restrict__ src, int32_t *__restrict__ dst, int64_t n) {
+    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2; i < n; i += (int64_t)gridDim.x * blockDim.x * 2) {
+        if (i + 1 < n) {
+            const ll2 v = *(const ll2 *)(src + i);
+            *(int2 *)(dst + i) = make_int2((int32_t)v.x, (int32_t)v.y);
+        } else {
+            dst[i] = (int32_t)src[i];
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_unpack32(const int32_t *__restrict__ src, int64_t *__restrict__ dst, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = (int64_t)src[i];
+}
+hipError_t launch_pack32(const int64_t *src, int32_t *dst, int64_t n, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_pack32, dim3(2048), dim3(256), 0, st, src, dst, n);
+    return hipGetLastError();
+}
+hipError_t launch_unpack32(const int32_t *src, int64_t *dst, int64_t n, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_unpack32, dim3(2048), dim3(256), 0, st, src, dst, n);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------- histogram summaries (finalize)
 // With tens of thousands of groups the [cell][agg][bucket] table is hundreds of MB: copying it to
 // the host and walking it there costs more than the scan.  These kernels derive what the result

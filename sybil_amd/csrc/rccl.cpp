@@ -89,6 +89,52 @@ static int query_hash_allreduce(Query *q) {
     return SYBL_OK;
 }
 
+// Every rank's outlier log into every rank's log (after the header, with the log's cursor, was summed): the counts
+// are all-gathered, the logs all-gathered padded to the longest, and the pieces closed up in rank order.  More records
+// than the log holds: the result stays marked partial (the printers then refuse rows with outliers, as on one GPU).
+static int gather_outlier_logs(Query *q, int64_t local) {
+    Ctx *ctx = q->ctx;
+    ncclComm_t comm = (ncclComm_t)ctx->comm;
+    hipStream_t st = ctx->stream;
+    const int R = ctx->comm_nranks, me = ctx->comm_rank;
+    local = std::min<int64_t>(local, q->out_cap);  // (records beyond the capacity were only counted)
+    int64_t *d_counts = nullptr;
+    SYBL_HIP(hipMalloc((void **)&d_counts, (size_t)R * 8));
+    std::vector<int64_t> counts((size_t)R, 0);
+    SYBL_HIP(hipMemcpyAsync(d_counts + me, &local, 8, hipMemcpyHostToDevice, st));
+    ncclResult_t nr = ncclAllGather(d_counts + me, d_counts, 1, ncclInt64, comm, st);
+    hipError_t e = nr == ncclSuccess ? hipMemcpyAsync(counts.data(), d_counts, (size_t)R * 8, hipMemcpyDeviceToHost, st) : hipSuccess;
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(d_counts);
+    if (nr != ncclSuccess) return nccl_fail(nr, "ncclAllGather(outlier counts)");
+    if (e != hipSuccess) return hip_fail(e, "outlier counts");
+    int64_t per = 0, total = 0;
+    for (int r = 0; r < R; r++) {
+        per = std::max(per, counts[(size_t)r]);
+        total += counts[(size_t)r];
+    }
+    if (total > q->out_cap) return SYBL_OK;  // stays partial
+    if (per > 0) {
+        int64_t *d_all = nullptr;
+        const size_t words = (size_t)per * kOutLogWords;
+        SYBL_HIP(hipMalloc((void **)&d_all, words * (size_t)R * 8));
+        e = hipMemcpyAsync(d_all + (size_t)me * words, q->d_out_log, (size_t)local * kOutLogWords * 8, hipMemcpyDeviceToDevice, st);
+        if (e == hipSuccess) nr = ncclAllGather(d_all + (size_t)me * words, d_all, words, ncclInt64, comm, st);
+        int64_t at = 0;
+        for (int r = 0; r < R && e == hipSuccess && nr == ncclSuccess; r++) {
+            e = hipMemcpyAsync(q->d_out_log + at * kOutLogWords, d_all + (size_t)r * words, (size_t)counts[(size_t)r] * kOutLogWords * 8,
+                               hipMemcpyDeviceToDevice, st);
+            at += counts[(size_t)r];
+        }
+        (void)hipStreamSynchronize(st);
+        (void)hipFree(d_all);
+        if (nr != ncclSuccess) return nccl_fail(nr, "ncclAllGather(outlier logs)");
+        if (e != hipSuccess) return hip_fail(e, "outlier logs");
+    }
+    q->out_log_partial = false;
+    return SYBL_OK;
+}
+
 }  // namespace sybl
 
 extern "C" {
@@ -133,8 +179,20 @@ int sybl_query_allreduce(sybl_query *q) {
     if (!ctx->comm) return fail(SYBL_E_STATE, "no communicator: call sybl_comm_init first");
     SYBL_HIP(hipSetDevice(ctx->device));
     ncclComm_t comm = (ncclComm_t)ctx->comm;
-    if (ctx->comm_nranks > 1) q->out_log_partial = true;  // (outlier VALUES stay on the rank that saw them)
-    if (q->hash_mode) return query_hash_allreduce(q);
+    if (ctx->comm_nranks > 1) q->out_log_partial = true;  // (until gather_outlier_logs has brought every rank's in)
+    // Outlier values (plan.h: outlier log): every rank logged its own; the merged result needs all of them
+    // (hist_basic.go:132-142,221-257: printed as buckets of their own).  The local count is read before the header is
+    // summed -- a host round trip, but only queries whose column bounds allow an outlier at all keep a log.
+    int64_t out_local = -1;
+    if (q->d_out_log && (ctx->comm_nranks > 1 || getenv("SYBL_FORCE_SCATTER"))) {
+        SYBL_HIP(hipMemcpyAsync(&out_local, q->d_sum + kHdrOutLog, 8, hipMemcpyDeviceToHost, ctx->stream));
+        SYBL_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    if (q->hash_mode) {
+        int rc = query_hash_allreduce(q);
+        if (!rc && out_local >= 0) rc = gather_outlier_logs(q, out_local);
+        return rc;
+    }
     const ScanPlan &P = q->plan;
     const bool has_max = P.n_max_fields > 0;  // (cfg 3: no extremum is tracked -- ONE collective per step)
     const int64_t hist_words = (int64_t)P.n_cells * P.hist_stride, small_words = q->n_sum_words - (hist_words + (P.hist_stride > 0 ? kMaxScatterRanks * P.hist_stride : 0));
@@ -146,6 +204,21 @@ int sybl_query_allreduce(sybl_query *q) {
     // snapshot and finalize then are collective calls.
     const bool scatter = P.hist_stride > 0 && query_wants_hist_summary(q) && q->limit > 0 && ctx->comm_nranks <= kMaxScatterRanks &&
                          (ctx->comm_nranks > 1 || getenv("SYBL_FORCE_SCATTER"));
+    // int32 slices: decided once per query, from a bound every rank computes alike -- the largest shard's rows (one
+    // blocking MAX all-reduce at the query's first collective) times the ranks; a bucket of the merged table cannot
+    // exceed that.  Weighted queries keep int64 (a bucket holds a sum of weights).
+    if (scatter && q->rs_int32 < 0) {
+        int64_t *d_rows = nullptr, rows = q->stats.rows_scanned;
+        SYBL_HIP(hipMalloc((void **)&d_rows, 8));
+        SYBL_HIP(hipMemcpyAsync(d_rows, &rows, 8, hipMemcpyHostToDevice, ctx->stream));
+        ncclResult_t nr = ncclAllReduce(d_rows, d_rows, 1, ncclInt64, ncclMax, comm, ctx->stream);
+        hipError_t e = nr == ncclSuccess ? hipMemcpyAsync(&rows, d_rows, 8, hipMemcpyDeviceToHost, ctx->stream) : hipSuccess;
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        (void)hipFree(d_rows);
+        if (nr != ncclSuccess) return nccl_fail(nr, "ncclAllReduce(shard rows)");
+        if (e != hipSuccess) return hip_fail(e, "shard rows");
+        q->rs_int32 = (!q->weighted && !getenv("SYBL_NO_SCATTER32") && rows * (int64_t)ctx->comm_nranks < ((int64_t)1 << 31)) ? 1 : 0;
+    }
     SYBL_NCCL(ncclGroupStart());
     if (!scatter) {
         SYBL_NCCL(ncclAllReduce(q->d_sum, q->d_sum, (size_t)(small_words + hist_words), ncclInt64, ncclSum, comm, ctx->stream));
@@ -154,7 +227,14 @@ int sybl_query_allreduce(sybl_query *q) {
         int64_t *H = q->d_sum + P.hist_off;
         SYBL_NCCL(ncclAllReduce(q->d_sum, q->d_sum, (size_t)small_words, ncclInt64, ncclSum, comm, ctx->stream));
         // (cells past n_cells in the last slice are the zeroed padding of the SUM section)
-        SYBL_NCCL(ncclReduceScatter(H, H + (int64_t)ctx->comm_rank * count, (size_t)count, ncclInt64, ncclSum, comm, ctx->stream));
+        if (q->rs_int32 == 1) {
+            if (!q->d_h32) SYBL_HIP(hipMalloc((void **)&q->d_h32, (size_t)(count * (R + 1)) * 4));
+            hipError_t e = launch_pack32(H, q->d_h32, count * R, ctx->stream);
+            if (e != hipSuccess) return hip_fail(e, "k_pack32");
+            SYBL_NCCL(ncclReduceScatter(q->d_h32, q->d_h32 + count * R, (size_t)count, ncclInt32, ncclSum, comm, ctx->stream));
+        } else {
+            SYBL_NCCL(ncclReduceScatter(H, H + (int64_t)ctx->comm_rank * count, (size_t)count, ncclInt64, ncclSum, comm, ctx->stream));
+        }
         q->rs_active = true;
         q->rs_cells_per = per;
         q->rs_cell0 = std::min<int64_t>(P.n_cells, (int64_t)ctx->comm_rank * per);
@@ -164,6 +244,15 @@ int sybl_query_allreduce(sybl_query *q) {
     // count distinct: Result.Combine merges the sketches register by register (query_spec.go:180-188)
     if (q->n_distinct) SYBL_NCCL(ncclAllReduce(q->d_hll, q->d_hll, (size_t)q->hll_bytes, ncclUint8, ncclMax, comm, ctx->stream));
     SYBL_NCCL(ncclGroupEnd());
+    if (scatter && q->rs_int32 == 1) {
+        const int64_t R = ctx->comm_nranks, per = (P.n_cells + R - 1) / R, count = per * P.hist_stride;
+        hipError_t e = launch_unpack32(q->d_h32 + count * R, q->d_sum + P.hist_off + (int64_t)ctx->comm_rank * count, count, ctx->stream);
+        if (e != hipSuccess) return hip_fail(e, "k_unpack32");
+    }
+    if (out_local >= 0) {
+        int rc = gather_outlier_logs(q, out_local);
+        if (rc) return rc;
+    }
     return SYBL_OK;
 }
 

@@ -360,6 +360,67 @@ def test_inlibrary_rccl_single_rank(ctx):
     ctx.comm_free()
 
 
+@pytest.mark.parametrize("slices32", [True, False])
+def test_inlibrary_scatter_and_outlier_gather_single_rank(ctx, oracle, monkeypatch, slices32):
+    """The N > 1 forms of the in-library merge with a 1-rank communicator (SYBL_FORCE_SCATTER): the bucket table leaves
+    through the reduce-scatter -- as int32 slices (k_pack32 / k_unpack32) or, SYBL_NO_SCATTER32, as int64 -- with the
+    collective finalize behind it, and a query with outliers has its outlier log gathered (rccl.cpp)."""
+    from sybil_amd import synth
+    monkeypatch.setenv("SYBL_FORCE_SCATTER", "1")
+    if not slices32:
+        monkeypatch.setenv("SYBL_NO_SCATTER32", "1")
+    ctx.comm_init(ctx.comm_unique_id(), 1, 0)
+    try:
+        n = 500_000
+        wl = _wl("cfg4_hist_highcard")
+        t = ctx.synth_table("rs", synth.SEED, n, 0, n, synth.synth_cols(wl["columns"]))
+        q = t.query(**dict(wl["query"], limit=40))
+        q.scan()
+        q.allreduce()
+        assert q.collective_finalize()
+        r = q.finalize()
+        ocols = parity.oracle_synth_cols(oracle, wl["columns"], n, 0, n)
+        info = {c: (synth.COLUMNS[c][4], synth.COLUMNS[c][5]) for c in wl["columns"]}
+        o = oracle.run_query(ocols, n_threads=4, **parity.oracle_query_kwargs(wl["columns"], info, wl["query"]))
+        omap = {x["key"]: x for x in o["results"]}
+        rows = r.results
+        assert r.matched == o["matched"] and len(rows) == len(omap)
+        for i, g in enumerate(rows):
+            oh, h = omap[g["key"]]["hists"][0], g["hists"][0]
+            assert (g["count"], h["sum"]) == (omap[g["key"]]["count"], oh["sum_exact"])
+            assert np.array_equal(h["percentiles"], oh["percentiles"])
+            if i < 40:
+                assert np.array_equal(h["values"], oh["values"])
+        r.free()
+        q.free()
+        t.free()
+        # outliers (the table of test_outlier_values_are_logged...): the log is gathered, the values stay available
+        rng = np.random.default_rng(77)
+        m = 150_000
+        g = rng.integers(0, 5, size=m).astype(np.int64)
+        v = rng.integers(0, 4000, size=m).astype(np.int64)
+        v[rng.random(m) < 0.01] += 50_000
+        tb = ctx.create_table("ro")
+        tb.add_column("g", "int")
+        tb.add_column("v", "int", 0, 60_000)
+        for r0 in range(0, m, 40_000):
+            tb.append_block(min(40_000, m - r0), {"g": g[r0:r0 + 40_000], "v": v[r0:r0 + 40_000]})
+        qd = dict(groups=["g"], aggs=["v"], op="hist", hist_bucket=3, want_percentiles=True)
+        q = tb.query(**qd)
+        q.scan()
+        q.allreduce()
+        r = q.finalize()
+        o = oracle.run_query([{"type": "int", "data": g}, {"type": "int", "data": v}], groups=[0], aggs=[(1, 0, 60_000)], op="hist",
+                             hist_bucket=3, block_rows=40_000, n_threads=2)
+        parity.compare(r, o, op="hist", full=True, n_aggs=1)  # includes the outlier values
+        assert all(x["hists"][0]["n_outliers"] > 0 and x["hists"][0]["n_outlier_values"] == x["hists"][0]["n_outliers"] for x in r.results)
+        r.free()
+        q.free()
+        tb.free()
+    finally:
+        ctx.comm_free()
+
+
 # ---------------------------------------------------------------- full BASELINE size: properties
 
 def test_full_size_properties(ctx):
