@@ -213,7 +213,14 @@ static int scan(Query *q) {
     }
     SYBL_HIP(hipEventRecord(q->ev[0], st));
     if (ran && q->hash_mode) {
-        e = launch_scan_hash(q->d_plan, P.n_slots, q->n_wg, q->lds_bytes, st);
+        if (q->hash_fast) {
+            q->fplan.sum_out = q->d_sum;
+            q->fplan.max_out = q->d_max;
+            e = launch_scan_hash_fast(q->fplan, P.hash_keys, q->fast_nf, q->fast_ng, q->fast_na, q->fast_mode, q->time_mode, P.lds_cells,
+                                      P.n_sum_fields, P.n_max_fields, q->n_wg, q->lds_bytes, st);
+        } else {
+            e = launch_scan_hash(q->d_plan, P.n_slots, q->n_wg, q->lds_bytes, st);
+        }
         if (e != hipSuccess) return hip_fail(e, "k_scan_hash");
     } else if (ran) {
         if (q->fast) {

@@ -127,7 +127,8 @@ struct ScanPlan {
     double inv_time_bucket;
     int64_t tb_min;          // trunc(tmin / time_bucket)
     int32_t n_tb;
-    int32_t tb_stride;       // = number of group cells
+    int32_t tb_stride;       // = number of group cells (direct-mapped kernels)
+    int64_t tb_stride64;     // the same as the time bucket's weight in the 64-bit composite key (hash group-by)
     int32_t tb_big_div;
     int32_t n_cells;         // n_tb * group cells
     int32_t n_sum_fields;    // F: [F][n_cells] int64, field 0 = Count, (field 1 = Samples)

@@ -135,7 +135,8 @@ static bool fill_packed(Table *t, Query *q, const std::vector<int> &slot_col, Fa
 // role-specialised kernels cover: <= 4 range-filter, <= 2 group, <= 2 aggregation columns, all
 // fully populated int64, one role per column, no rejects / outliers / minima to track.
 static bool fill_fast_columns(Table *t, Query *q, const std::vector<int> &slot_col, FastPlan &FP, int *pnf, int *png,
-                              int *pna, bool *any_max, bool *all_max, bool allow_gen, bool *gen, bool *packed = nullptr) {
+                              int *pna, bool *any_max, bool *all_max, bool allow_gen, bool *gen, bool *packed = nullptr,
+                              int max_groups = 2) {
     const ScanPlan &P = q->plan;
     memset(&FP, 0, sizeof(FP));
     int nf = 0, ng = 0, na = 0;
@@ -194,7 +195,7 @@ static bool fill_fast_columns(Table *t, Query *q, const std::vector<int> &slot_c
         nf++;
     }
     for (auto &gi : q->groups) {
-        if (ng >= kFastMaxG) return false;
+        if (ng >= max_groups) return false;
         int s = -1;
         for (size_t k = 0; k < slot_col.size(); k++)
             if (slot_col[k] == gi.col) s = (int)k;
@@ -209,6 +210,9 @@ static bool fill_fast_columns(Table *t, Query *q, const std::vector<int> &slot_c
         FP.gmin[ng] = sd.gmin;
         FP.gcard[ng] = (uint32_t)sd.gcard;
         FP.gstride[ng] = sd.gstride;
+        FP.gstride64[ng] = sd.gstride64;
+        FP.gmissing64[ng] = sd.gmissing64;
+        FP.gvalues64[ng] = sd.gvalues64;
         ng++;
     }
     *any_max = false;
@@ -347,6 +351,45 @@ static void select_fast_path(Table *t, Query *q, const std::vector<int> &slot_co
     }
     q->fast = true;
     q->fast_packed = packed;
+    q->fast_nf = nf;
+    q->fast_ng = ng;
+    q->fast_na = na;
+    q->fast_mode = mode;
+}
+
+// Hash group-by (strategy 7) through the role-specialised row body (k_scan_hash_fast, hashgroup.hip) when the query has
+// the shape select_fast_path takes -- with up to four group columns; everything else runs the plan-interpreting
+// k_scan_hash.
+static void select_hash_fast(Table *t, Query *q, const std::vector<int> &slot_col) {
+    q->hash_fast = false;
+    const ScanPlan &P = q->plan;
+    if (!q->hash_mode || getenv("SYBL_NO_FAST") || getenv("SYBL_NO_HASH_FAST") || getenv("SYBL_NO_FASTGEN") || q->loghist) return;
+    if (q->time_mode && P.tb_big_div) return;
+    FastPlan &FP = q->fplan;
+    int nf, ng, na;
+    bool any_max, all_max, gen;
+    if (!fill_fast_columns(t, q, slot_col, FP, &nf, &ng, &na, &any_max, &all_max, true, &gen, nullptr, kFastMaxG)) return;
+    if (q->weighted && q->op == SYBL_AGG_HIST && q->want_percentiles) return;  // weighted bucket increments: generic kernel
+    if (q->time_mode) {
+        FP.tcol = (const int64_t *)P.slot[P.time_slot].base;
+        FP.tvalid = P.slot[P.time_slot].valid;
+        FP.twid = P.slot[P.time_slot].width;
+        FP.tbase = P.slot[P.time_slot].vbase;
+        FP.time_bucket = P.time_bucket;
+        FP.inv_time_bucket = P.inv_time_bucket;
+        FP.tb_min = P.tb_min;
+        FP.n_tb = P.n_tb;
+        FP.tb_stride64 = P.tb_stride64;
+    }
+    int mode;
+    if (q->op == SYBL_AGG_HIST) {
+        mode = q->want_percentiles ? kFastHist : kFastMoments;
+    } else {
+        if (any_max && !all_max) return;
+        mode = any_max ? kFastAvgMax : kFastAvg;
+    }
+    FP.hist_lds = 0;
+    q->hash_fast = true;
     q->fast_nf = nf;
     q->fast_ng = ng;
     q->fast_na = na;
@@ -706,7 +749,7 @@ struct Planner {
                 }
             }
             // sparse / wide key range: one digit per DISTINCT value instead of one per value of the range
-            const bool hash_ok = !q->time_mode && !getenv("SYBL_NO_HASH");
+            const bool hash_ok = !getenv("SYBL_NO_HASH");
             if (c->type == SYBL_INT_VAL && !getenv("SYBL_NO_GDICT") &&
                 (c->gdict_blocks == -2 || card > ((unsigned __int128)1 << 22) || card * (unsigned __int128)cells > ((unsigned __int128)1 << 27))) {
                 rc = column_build_gdict(t, c);
@@ -744,7 +787,7 @@ struct Planner {
                 if (!hash_ok || card * (unsigned __int128)cells >= ((unsigned __int128)1 << 62))
                     return fail(SYBL_E_INVAL,
                                 "group-by on '%s' needs more than %s cells (value range [%lld,%lld])",
-                                c->name.c_str(), hash_ok ? "2^62 hashed" : "2^27 direct-mapped (time series do not hash)", (long long)lo,
+                                c->name.c_str(), hash_ok ? "2^62 hashed" : "2^27 direct-mapped (SYBL_NO_HASH)", (long long)lo,
                                 (long long)hi);
                 q->hash_mode = true;
             }
@@ -753,7 +796,7 @@ struct Planner {
             q->groups.push_back(gi);
             cells *= (int64_t)card;
         }
-        if (getenv("SYBL_FORCE_HASH") && !q->time_mode && !q->groups.empty()) q->hash_mode = true;  // (tests: small key spaces too)
+        if (getenv("SYBL_FORCE_HASH") && !q->groups.empty()) q->hash_mode = true;  // (tests: small key spaces too)
         // strides: first group column is the most significant digit (keeps canonical key order
         // equal to cell order)
         {
@@ -796,7 +839,8 @@ struct Planner {
         int rc;
         // ---- time series (aggregate.go:146-183)
         P.n_tb = 1;
-        P.tb_stride = (int32_t)cells;
+        P.tb_stride = (int32_t)std::min<int64_t>(cells, INT32_MAX);
+        P.tb_stride64 = cells;
         if (q->time_mode) {
             int s;
             if ((rc = slot_of(d->time_col, &s))) return rc;
@@ -811,15 +855,25 @@ struct Planner {
             int64_t tlo = lo / d->time_bucket, thi = hi / d->time_bucket;  // truncating, like aggregate.go:174
             P.tb_min = tlo;
             int64_t ntb = thi - tlo + 1;
-            if (ntb * cells > ((int64_t)1 << 27)) return fail(SYBL_E_INVAL, "time buckets x groups exceeds 2^27 cells");
+            if (ntb >= ((int64_t)1 << 31)) return fail(SYBL_E_INVAL, "more than 2^31 time buckets");
+            if (!q->hash_mode && (unsigned __int128)ntb * (unsigned __int128)cells > ((unsigned __int128)1 << 27)) {
+                // the reference groups arbitrary keys inside every time bucket (aggregate.go:146-200): [time bucket || key]
+                // through the hash table when the product does not direct-map
+                if (getenv("SYBL_NO_HASH") || q->groups.empty())
+                    return fail(SYBL_E_INVAL, "time buckets x groups exceeds 2^27 cells");
+                q->hash_mode = true;
+            }
+            if (q->hash_mode && (unsigned __int128)ntb * (unsigned __int128)cells >= ((unsigned __int128)1 << 62))
+                return fail(SYBL_E_INVAL, "time buckets x group keys exceed the 2^62 composite keys of the hash table");
             P.n_tb = (int32_t)ntb;
             uint64_t amax = (uint64_t)std::max(llabs((long long)lo), llabs((long long)hi));
             P.tb_big_div = amax >= ((uint64_t)1 << 51);
         }
-        n_cells = cells * P.n_tb;
+        n_cells = q->hash_mode ? 0 : cells * P.n_tb;
         if (q->hash_mode) {
             // slots: twice the keys the table can possibly hold (a row each / the whole key space), a power of two
-            int64_t want = 2 * std::min<int64_t>(std::max<int64_t>(t->logical_rows, 1), cells);
+            const unsigned __int128 space = (unsigned __int128)cells * (unsigned __int128)P.n_tb;
+            int64_t want = 2 * (int64_t)std::min<unsigned __int128>((unsigned __int128)std::max<int64_t>(t->logical_rows, 1), space);
             if (const char *e = getenv("SYBL_HASH_SLOTS")) want = atoll(e);
             int64_t slots = 1 << 12;
             while (slots < want && slots < kHashMaxSlots) slots <<= 1;
@@ -1211,6 +1265,7 @@ struct Planner {
             }
         }
         select_fast_path(t, q, slot_col);
+        select_hash_fast(t, q, slot_col);
         if ((rc = select_part_hist(t, q, slot_col, rows_scanned))) return rc;
         q->stats.rows_scanned = rows_scanned;
         q->stats.blocks_skipped = skipped;

@@ -694,7 +694,7 @@ int query_finalize(Query *q, Result **out) {
         }
     }
     std::vector<int64_t> &all_count = R->all_count, &all_samples = R->all_samples;
-    if (q->time_mode) {
+    if (q->time_mode && !hashed) {
         all_count.assign((size_t)gcells, 0);
         all_samples.assign((size_t)gcells, 0);
     }
@@ -729,7 +729,30 @@ int query_finalize(Query *q, Result **out) {
     }
     std::vector<int64_t> &alltime = R->alltime;  // group cells with any row (time-series mode)
     alltime.clear();
-    if (q->time_mode) {
+    if (q->time_mode && hashed) {
+        // hash group-by: the all-time Results are the distinct group keys of the [time bucket || key] rows; all_count /
+        // all_samples are indexed like `alltime` here, not by group cell (the key space is up to 2^62 wide)
+        const int64_t *S = P.f_samples >= 0 ? F + (int64_t)P.f_samples * ncell : F;
+        std::vector<std::pair<int64_t, int64_t>> byg(live.size());  // (group key, dense row)
+        for (size_t i = 0; i < live.size(); i++) byg[i] = {(int64_t)(q->h_dense_keys[(size_t)live[i]] % (uint64_t)gcells), live[i]};
+        std::sort(byg.begin(), byg.end());
+        all_count.clear();
+        all_samples.clear();
+        for (size_t i = 0; i < byg.size();) {
+            int64_t c = 0, sm = 0;
+            size_t j = i;
+            for (; j < byg.size() && byg[j].first == byg[i].first; j++) {
+                c += F[byg[j].second];
+                sm += S[byg[j].second];
+            }
+            if (q->weighted ? sm != 0 : c != 0) {
+                alltime.push_back(byg[i].first);
+                all_count.push_back(c);
+                all_samples.push_back(sm);
+            }
+            i = j;
+        }
+    } else if (q->time_mode) {
         // (time bucket major, group minor: walk a bucket's cells as one contiguous run per group range)
         const int64_t *S = P.f_samples >= 0 ? F + (int64_t)P.f_samples * ncell : F;
         parallel_ranges((size_t)gcells, 1 << 12, [&](size_t g0, size_t g1) {
@@ -784,7 +807,9 @@ int query_finalize(Query *q, Result **out) {
         for (size_t i = i0; i < i1; i++) {
             const int64_t cell = live[i];
             load_cell(cell, acc);
-            const int64_t tbi = hashed ? 0 : cell / gcells, gcell = hashed ? (int64_t)q->h_dense_keys[(size_t)cell] : cell - tbi * gcells;
+            // (hash group-by: the composite key is [time bucket || group key], the dense arrays are in key order)
+            const int64_t ckey = hashed ? (int64_t)q->h_dense_keys[(size_t)cell] : cell;
+            const int64_t tbi = hashed && !q->time_mode ? 0 : ckey / gcells, gcell = ckey - tbi * gcells;
             RowStore &row = cell_rows[i];
             row.agg_off = (int64_t)(i * na);
             row.cell = cell;
@@ -887,8 +912,8 @@ int query_finalize(Query *q, Result **out) {
             row.key = ks->key(e);
             row.gbkp = &ks->gbk[e];
             CellAcc a2;
-            a2.count = all_count[(size_t)g];
-            a2.samples = all_samples[(size_t)g];
+            a2.count = all_count[hashed ? i : (size_t)g];
+            a2.samples = all_samples[hashed ? i : (size_t)g];
             finish_row(q, R, a2, row, out_usable);
         }
         next_slot += alltime.size();

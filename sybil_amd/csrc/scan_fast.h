@@ -17,7 +17,7 @@
 
 namespace sybl {
 
-constexpr int kFastMaxF = 4, kFastMaxG = 2, kFastMaxA = 2;
+constexpr int kFastMaxF = 4, kFastMaxG = 4, kFastMaxA = 2;  // (the direct-mapped kernels are instantiated for <= 2 group columns)
 
 enum FastMode : int {
     kFastAvg = 0,      // op avg:  Count, sum(v)                        (extrema provably == initial values)
@@ -55,6 +55,8 @@ struct FastPlan {
     // missing-key cells, and the reject gate / per-aggregation counts of hist_basic.go:104
     const uint32_t *fvalid[kFastMaxF], *gvalid[kFastMaxG], *avalid[kFastMaxA], *tvalid;
     int32_t gmissing[kFastMaxG], gvalues[kFastMaxG];
+    // hash group-by (k_scan_hash_fast, hashgroup.hip): the digits' weights in the 64-bit composite key
+    int64_t gstride64[kFastMaxG], gmissing64[kFastMaxG], gvalues64[kFastMaxG], tb_stride64;
     // str filters (filter.go:199-250) as one bit per dictionary id: fmask != nullptr replaces the range
     const uint32_t *fmask[kFastMaxF];
     int32_t fmask_bits[kFastMaxF];
@@ -296,15 +298,33 @@ __device__ __forceinline__ void lds_add64(int64_t *lds, uint32_t idx, int64_t v)
     __hip_atomic_fetch_add(lds + idx, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-template <int NF, int NG, int NA, int MODE, bool TIME, bool GEN>
-__device__ __forceinline__ void fast_row(const FastPlan &P, const FastTile<NF> &f, const FastTile<NG> &g,
-                                         const FastTile<NA> &a, const FastTile<1> &t, const FastTile<1> &w, const int r,
-                                         int64_t *lds,
-                                         const uint32_t rep, const uint32_t max_base, const uint32_t cell_base,
-                                         uint32_t *hist32, uint32_t &matched, uint32_t &overflow) {
+// One accumulator word: an LDS atomic (the workgroup's cell / staging table) or a device-scope one (the global table of
+// a hash group-by, hashgroup.hip).
+template <bool LDS>
+__device__ __forceinline__ void fast_add64(int64_t *tab, uint64_t idx, int64_t v) {
+    if (LDS) __hip_atomic_fetch_add(tab + (uint32_t)idx, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else __hip_atomic_fetch_add(tab + idx, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <bool LDS>
+__device__ __forceinline__ void fast_max64(int64_t *tab, uint64_t idx, int64_t v) {
+    int64_t *m = LDS ? tab + (uint32_t)idx : tab + idx;
+    if (v > *m) {
+        if (LDS) __hip_atomic_fetch_max(m, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else __hip_atomic_fetch_max(m, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// filters (aggregate.go:105-116), group key (aggregate.go:125-143), time bucket (:146-183) of one row.
+// Returns 0: the row does not count any further (a filter failed, or -- after it was counted as matched -- it has no
+// time value); 1: `cell` is the row's cell (KEY64: its composite key, hash group-by); 2: key / time bucket outside the
+// declared bounds.  ng: the group columns actually present (== NG for the direct-mapped kernels).
+template <int NF, int NG, bool TIME, bool GEN, bool KEY64>
+__device__ __forceinline__ int fast_prepare(const FastPlan &P, const FastTile<NF> &f, const FastTile<NG> &g, const FastTile<1> &t,
+                                            const int r, const int nf, const int ng, uint64_t &cell, uint32_t &matched) {
     bool pass = true;
 #pragma unroll
     for (int c = 0; c < NF; c++) {
+        if (c >= nf) break;
         const int64_t x = r == 0 ? f.v[c].x : f.v[c].y;
         if (GEN && P.fmask[c]) {
             // StrFilter eq / neq / re / nre, evaluated per dictionary id on the host (filter.go:199-250)
@@ -319,24 +339,35 @@ __device__ __forceinline__ void fast_row(const FastPlan &P, const FastTile<NF> &
             pass = pass && ((f.pop[c] >> r) & 1u);  // an unpopulated value fails every filter
         }
     }
-    if (!pass) return;
+    if (!pass) return 0;
     matched += 1;  // aggregate.go:117
-    uint32_t cell = 0;
+    cell = 0;
     bool inb = true;
 #pragma unroll
     for (int c = 0; c < NG; c++) {
+        if (c >= ng) break;
         const int64_t x = r == 0 ? g.v[c].x : g.v[c].y;
         if (GEN && !((g.pop[c] >> r) & 1u)) {
             // MISSING_VALUE key (aggregate.go:138): its own digit, or the digit of the value -1
-            inb = inb && P.gmissing[c] >= 0;
-            cell += (uint32_t)P.gmissing[c];
+            if (KEY64) {
+                inb = inb && P.gmissing64[c] >= 0;
+                cell += (uint64_t)P.gmissing64[c];
+            } else {
+                inb = inb && P.gmissing[c] >= 0;
+                cell += (uint32_t)P.gmissing[c];
+            }
             continue;
         }
         const uint64_t d = (uint64_t)x - (uint64_t)P.gmin[c];
-        inb = inb && d < (uint64_t)(GEN ? (uint32_t)P.gvalues[c] : P.gcard[c]);
-        cell += (uint32_t)d * (uint32_t)P.gstride[c];  // aggregate.go:125-143 as a direct-mapped index
+        if (KEY64) {
+            inb = inb && d < (uint64_t)P.gvalues64[c];
+            cell += d * (uint64_t)P.gstride64[c];
+        } else {
+            inb = inb && d < (uint64_t)(GEN ? (uint32_t)P.gvalues[c] : P.gcard[c]);
+            cell = (uint32_t)cell + (uint32_t)d * (uint32_t)P.gstride[c];  // aggregate.go:125-143 as a direct-mapped index
+        }
     }
-    if (TIME && GEN && !((t.pop[0] >> r) & 1u)) return;  // no time value: dropped after it was counted (aggregate.go:147-153)
+    if (TIME && GEN && !((t.pop[0] >> r) & 1u)) return 0;  // no time value: dropped after it was counted (aggregate.go:147-153)
     if (TIME) {
         // val = int(val) / TimeBucket * TimeBucket, truncating (aggregate.go:174); |t| < 2^51 here
         const int64_t tv = r == 0 ? t.v[0].x : t.v[0].y;
@@ -350,37 +381,39 @@ __device__ __forceinline__ void fast_row(const FastPlan &P, const FastTile<NF> &
         }
         const int64_t tb = (tv < 0 ? -(int64_t)qd : (int64_t)qd) - P.tb_min;
         inb = inb && (uint64_t)tb < (uint64_t)P.n_tb;
-        cell += (uint32_t)tb * (uint32_t)P.tb_stride;
+        if (KEY64) cell += (uint64_t)tb * (uint64_t)P.tb_stride64;
+        else cell = (uint32_t)cell + (uint32_t)tb * (uint32_t)P.tb_stride;
     }
-    const uint32_t ncell = (uint32_t)P.lds_cells;
-    const uint32_t lcell = cell - cell_base;  // position inside this workgroup's LDS table
-    if (!inb || lcell >= ncell) {
-        overflow += 1;
-        return;
-    }
-    const uint32_t rs = (uint32_t)P.rep_shift;
-    const uint32_t cidx = (lcell << rs) + rep;
+    return inb ? 1 : 2;
+}
+
+// Count / Samples and the aggregations of one matched row (aggregate.go:202-261, hist_basic.go:101-151) into a table
+// laid out [field][ncell << rs] (+ the MAX fields from max_base on); cidx = (local cell << rs) + lane replica.  gcell:
+// the cell's number in the global table (bucket arrays, [gcell][hist_stride]); lcell: its place in the workgroup's LDS
+// bucket arrays (hist_lds); logkey: what the outlier log calls the group.
+template <int NA, int MODE, bool GEN, bool LDS>
+__device__ __forceinline__ void fast_accumulate(const FastPlan &P, const FastTile<NA> &a, const FastTile<1> &w, const int r,
+                                                int64_t *tab, int64_t *maxtab, const uint64_t ncell, const uint32_t rs, const uint64_t cidx,
+                                                const int64_t gcell, const uint32_t lcell, const int64_t logkey, uint32_t *hist32,
+                                                uint32_t &overflow) {
     // weight := r.Ints[WEIGHT_COL] (aggregate.go:100-102); 1 without a weight column
     const int64_t wt = (GEN && P.wcol) ? (r == 0 ? w.v[0].x : w.v[0].y) : 1;
-    lds_add64(lds, cidx, wt);  // Result.Count += weight (aggregate.go:203)
-    if (GEN && P.f_samples >= 0) lds_add64(lds, (((uint32_t)P.f_samples * ncell) << rs) + cidx, 1);  // Result.Samples++
+    fast_add64<LDS>(tab, cidx, wt);  // Result.Count += weight (aggregate.go:203)
+    if (GEN && P.f_samples >= 0) fast_add64<LDS>(tab, (((uint64_t)(uint32_t)P.f_samples * ncell) << rs) + cidx, 1);  // Result.Samples++
 #pragma unroll
     for (int c = 0; c < NA; c++) {
         const int64_t x = r == 0 ? a.v[c].x : a.v[c].y;
         if (GEN) {
             if (!((a.pop[c] >> r) & 1u)) continue;
-            if (P.f_pop[c] >= 0) lds_add64(lds, (((uint32_t)P.f_pop[c] * ncell) << rs) + cidx, 1);
+            if (P.f_pop[c] >= 0) fast_add64<LDS>(tab, (((uint64_t)(uint32_t)P.f_pop[c] * ncell) << rs) + cidx, 1);
             if (P.f_cnt[c] >= 0) {
                 if (x > P.max10[c] || x < P.info_min[c]) continue;  // hist_basic.go:104
-                lds_add64(lds, (((uint32_t)P.f_cnt[c] * ncell) << rs) + cidx, wt);  // h.Count += weight
+                fast_add64<LDS>(tab, (((uint64_t)(uint32_t)P.f_cnt[c] * ncell) << rs) + cidx, wt);  // h.Count += weight
             }
-            if (P.f_smp[c] >= 0) lds_add64(lds, (((uint32_t)P.f_smp[c] * ncell) << rs) + cidx, 1);  // h.Samples++
+            if (P.f_smp[c] >= 0) fast_add64<LDS>(tab, (((uint64_t)(uint32_t)P.f_smp[c] * ncell) << rs) + cidx, 1);  // h.Samples++
         }
-        lds_add64(lds, (((uint32_t)P.f_sum[c] * ncell) << rs) + cidx, (int64_t)((uint64_t)x * (uint64_t)wt));
-        if (MODE == kFastAvgMax) {
-            int64_t *m = lds + max_base + (((uint32_t)P.m_max[c] * ncell) << rs) + cidx;
-            if (x > *m) __hip_atomic_fetch_max(m, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
+        fast_add64<LDS>(tab, (((uint64_t)(uint32_t)P.f_sum[c] * ncell) << rs) + cidx, (int64_t)((uint64_t)x * (uint64_t)wt));
+        if (MODE == kFastAvgMax) fast_max64<LDS>(maxtab, (((uint64_t)(uint32_t)P.m_max[c] * ncell) << rs) + cidx, x);
         if (MODE == kFastMoments || MODE == kFastHist) {
             // bucket_value := (value - h.Min) / BucketSize, hist_basic.go:130.  The planner only
             // selects this kernel when 0 <= value - h.Min < 2^32 and no value can reach
@@ -395,27 +428,24 @@ __device__ __forceinline__ void fast_row(const FastPlan &P, const FastTile<NF> &
             }
             if (GEN) {
                 // h.Max starts at Info.Max: track only when the column can exceed it
-                if (P.m_max[c] >= 0) {
-                    int64_t *m = lds + max_base + (((uint32_t)P.m_max[c] * ncell) << rs) + cidx;
-                    if (x > *m) __hip_atomic_fetch_max(m, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
+                if (P.m_max[c] >= 0) fast_max64<LDS>(maxtab, (((uint64_t)(uint32_t)P.m_max[c] * ncell) << rs) + cidx, x);
                 if (b >= (uint32_t)P.n_values[c]) {
                     // Outlier (hist_basic.go:132-135): clipped into the last bucket AND remembered as
                     // exact n, sum(o), sum(o^2) (four 32-bit limbs)
                     if (P.f_out[c] >= 0) {
-                        const uint32_t step = ncell << rs;
-                        const uint32_t fi = (((uint32_t)P.f_out[c] * ncell) << rs) + cidx;
+                        const uint64_t step = ncell << rs;
+                        const uint64_t fi = (((uint64_t)(uint32_t)P.f_out[c] * ncell) << rs) + cidx;
                         const unsigned __int128 sq = (unsigned __int128)((__int128)x * (__int128)x);
-                        lds_add64(lds, fi, 1);
-                        lds_add64(lds, fi + step, x);
-                        lds_add64(lds, fi + 2 * step, (int64_t)(uint64_t)(sq & 0xFFFFFFFFu));
-                        lds_add64(lds, fi + 3 * step, (int64_t)(uint64_t)((sq >> 32) & 0xFFFFFFFFu));
-                        lds_add64(lds, fi + 4 * step, (int64_t)(uint64_t)((sq >> 64) & 0xFFFFFFFFu));
-                        lds_add64(lds, fi + 5 * step, (int64_t)(uint64_t)(sq >> 96));
+                        fast_add64<LDS>(tab, fi, 1);
+                        fast_add64<LDS>(tab, fi + step, x);
+                        fast_add64<LDS>(tab, fi + 2 * step, (int64_t)(uint64_t)(sq & 0xFFFFFFFFu));
+                        fast_add64<LDS>(tab, fi + 3 * step, (int64_t)(uint64_t)((sq >> 32) & 0xFFFFFFFFu));
+                        fast_add64<LDS>(tab, fi + 4 * step, (int64_t)(uint64_t)((sq >> 64) & 0xFFFFFFFFu));
+                        fast_add64<LDS>(tab, fi + 5 * step, (int64_t)(uint64_t)(sq >> 96));
                         if (P.out_log) {
                             const int64_t i = __hip_atomic_fetch_add(P.sum_out + kHdrOutLog, (int64_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             if (i < P.out_cap) {
-                                P.out_log[i * kOutLogWords] = (int64_t)cell;
+                                P.out_log[i * kOutLogWords] = logkey;
                                 P.out_log[i * kOutLogWords + 1] = c;
                                 P.out_log[i * kOutLogWords + 2] = x;
                             }
@@ -427,17 +457,39 @@ __device__ __forceinline__ void fast_row(const FastPlan &P, const FastTile<NF> &
                 }
             }
             if (MODE == kFastMoments) {
-                lds_add64(lds, (((uint32_t)P.f_sb[c] * ncell) << rs) + cidx, (int64_t)b * wt);
-                lds_add64(lds, (((uint32_t)P.f_sb2[c] * ncell) << rs) + cidx, (int64_t)((uint64_t)b * (uint64_t)b) * wt);
-            } else if (P.hist_lds) {
+                fast_add64<LDS>(tab, (((uint64_t)(uint32_t)P.f_sb[c] * ncell) << rs) + cidx, (int64_t)b * wt);
+                fast_add64<LDS>(tab, (((uint64_t)(uint32_t)P.f_sb2[c] * ncell) << rs) + cidx, (int64_t)((uint64_t)b * (uint64_t)b) * wt);
+            } else if (LDS && P.hist_lds) {
                 __hip_atomic_fetch_add(hist32 + lcell * (uint32_t)P.hist_stride + (uint32_t)P.hist_agg_off[c] + b, 1u,
                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             } else {
-                __hip_atomic_fetch_add(P.sum_out + P.hist_off + (int64_t)cell * P.hist_stride + P.hist_agg_off[c] + b,
+                __hip_atomic_fetch_add(P.sum_out + P.hist_off + gcell * P.hist_stride + P.hist_agg_off[c] + b,
                                        (int64_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }
+}
+
+template <int NF, int NG, int NA, int MODE, bool TIME, bool GEN>
+__device__ __forceinline__ void fast_row(const FastPlan &P, const FastTile<NF> &f, const FastTile<NG> &g,
+                                         const FastTile<NA> &a, const FastTile<1> &t, const FastTile<1> &w, const int r,
+                                         int64_t *lds,
+                                         const uint32_t rep, const uint32_t max_base, const uint32_t cell_base,
+                                         uint32_t *hist32, uint32_t &matched, uint32_t &overflow) {
+    uint64_t cell64;
+    const int st = fast_prepare<NF, NG, TIME, GEN, false>(P, f, g, t, r, NF, NG, cell64, matched);
+    if (st == 0) return;
+    const uint32_t cell = (uint32_t)cell64;
+    const uint32_t ncell = (uint32_t)P.lds_cells;
+    const uint32_t lcell = cell - cell_base;  // position inside this workgroup's LDS table
+    if (st == 2 || lcell >= ncell) {
+        overflow += 1;
+        return;
+    }
+    const uint32_t rs = (uint32_t)P.rep_shift;
+    const uint32_t cidx = (lcell << rs) + rep;
+    fast_accumulate<NA, MODE, GEN, true>(P, a, w, r, lds, lds + max_base, (uint64_t)ncell, rs, (uint64_t)cidx, (int64_t)cell, lcell, (int64_t)cell,
+                                         hist32, overflow);
 }
 
 // LDS layout of one workgroup: [sum fields][max fields][uint32 bucket arrays (hist_lds)], every

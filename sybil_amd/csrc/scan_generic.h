@@ -267,7 +267,7 @@ __device__ __forceinline__ int row_prepare(CPlan &P, const Tile<NC> &t, int r, i
         if (!tpop) return kRowDropped;
         int64_t tb = sdiv_trunc(tv, P.time_bucket, P.inv_time_bucket, P.tb_big_div) - P.tb_min;
         if ((uint64_t)tb >= (uint64_t)P.n_tb) in_bounds = false;
-        key += (uint64_t)tb * (uint64_t)(int64_t)P.tb_stride;
+        key += (uint64_t)tb * (uint64_t)P.tb_stride64;
     }
     return in_bounds ? kRowOk : kRowOverflow;
 }

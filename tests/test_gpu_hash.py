@@ -40,11 +40,15 @@ def _ocols(cols, pops=None):
 
 @pytest.mark.parametrize("staging", [True, False])
 @pytest.mark.parametrize("full", [False, True])
-def test_forced_hash_equals_direct_mapped_and_oracle(ctx, oracle, monkeypatch, staging, full):
+@pytest.mark.parametrize("specialised", [True, False])
+def test_forced_hash_equals_direct_mapped_and_oracle(ctx, oracle, monkeypatch, staging, full, specialised):
     """Config 3 (1024 groups) through the hash table: every row hits the LDS staging table (or, without it, the
-    global table with device-scope atomics); bucket arrays (full) always live in the global table."""
+    global table with device-scope atomics); bucket arrays (full) always live in the global table.  Both row bodies:
+    the role-specialised k_scan_hash_fast and (SYBL_NO_HASH_FAST) the plan-interpreting k_scan_hash."""
     wl = synth.WORKLOADS["cfg3_filter3_group2_stddev"]
     monkeypatch.setenv("SYBL_FORCE_HASH", "1")
+    if not specialised:
+        monkeypatch.setenv("SYBL_NO_HASH_FAST", "1")
     if not staging:
         monkeypatch.setenv("SYBL_NO_HASH_LDS", "1")
     q = dict(wl["query"], want_percentiles=full)
@@ -275,5 +279,35 @@ def test_table_full_at_default_sizing_fails_fast(ctx):
         query.run()
     assert "more distinct group keys" in str(e.value)
     assert time.perf_counter() - t0 < 20.0
+    query.free()
+    t.free()
+
+
+def test_time_series_through_the_hash_table(ctx, oracle, monkeypatch):
+    """The reference groups arbitrary keys inside every time bucket (aggregate.go:146-200).  (a) config 5's 721 x 500
+    cells forced through the table; (b) 721 hourly buckets x a key of 2^20 values = 7.6e8 cells, more than direct mapping
+    takes: [time bucket || key] composite keys, TimeResults in (bucket, key) order, all-time Results per key."""
+    wl = synth.WORKLOADS["cfg5_time_rollup"]
+    monkeypatch.setenv("SYBL_FORCE_HASH", "1")
+    gres, ores, stats = parity.run_both(ctx, oracle, wl["columns"], 900_000, 0, 900_000, wl["query"], oracle_threads=4)
+    assert stats["strategy"] == 7, stats
+    parity.compare(gres, ores, op="avg", n_aggs=1, time_mode=True)
+    gres.free()
+    monkeypatch.delenv("SYBL_FORCE_HASH")
+    n = 1_500_000
+    cols = [dict(name="c00", kind=synth.TIME, col_index=0, a=1_700_000_000, b=2_592_000, info_min=1_700_000_000, info_max=1_702_591_999),
+            dict(name="k", kind=synth.UNIFORM, col_index=43, a=-5, b=1 << 20, info_min=-5, info_max=(1 << 20) - 6),
+            dict(name="v", kind=synth.UNIFORM, col_index=44, a=0, b=1_000_000, info_min=0, info_max=999_999)]
+    t = ctx.synth_table("tsh", synth.SEED, n, 0, n, cols)
+    q = dict(groups=["k"], aggs=["v"], op="hist", want_percentiles=False, time_col="c00", time_bucket=3600)
+    query = t.query(**q)
+    gres = query.run()
+    assert query.stats()["strategy"] == 7, query.stats()
+    ocols = [{"type": "int", "data": oracle.synth_fill(c["kind"], c["a"], c["b"], synth.SEED, c["col_index"], 0, n, n)} for c in cols]
+    ores = oracle.run_query(ocols, groups=[1], aggs=[(2, 0, 999_999)], op="hist", time_col=0, time_bucket=3600, n_threads=4)
+    parity.compare(gres, ores, op="hist", full=False, n_aggs=1, time_mode=True)
+    tr = gres.time_results
+    assert len(tr) > 1_400_000 and [x["time_bucket"] for x in tr[:2000]] == sorted(x["time_bucket"] for x in tr[:2000])
+    gres.free()
     query.free()
     t.free()
