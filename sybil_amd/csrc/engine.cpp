@@ -216,7 +216,10 @@ static int scan(Query *q) {
         if (q->hash_fast) {
             q->fplan.sum_out = q->d_sum;
             q->fplan.max_out = q->d_max;
-            e = launch_scan_hash_fast(q->fplan, P.hash_keys, q->fast_nf, q->fast_ng, q->fast_na, q->fast_mode, q->time_mode, P.lds_cells,
+            e = q->hash_packed
+                    ? launch_scan_hash_packed(q->fplan, P.hash_keys, q->fast_nf, q->fast_ng, q->fast_na, q->fast_mode, q->time_mode, P.lds_cells,
+                                              P.n_sum_fields, P.n_max_fields, q->n_wg, q->lds_bytes, st)
+                    : launch_scan_hash_fast(q->fplan, P.hash_keys, q->fast_nf, q->fast_ng, q->fast_na, q->fast_mode, q->time_mode, P.lds_cells,
                                       P.n_sum_fields, P.n_max_fields, q->n_wg, q->lds_bytes, st);
         } else {
             e = launch_scan_hash(q->d_plan, P.n_slots, q->n_wg, q->lds_bytes, st);

@@ -346,6 +346,7 @@ struct Query {
     // rank holds the reduced arrays of cells [rs_cell0, rs_cell1) only; percentiles / moments are derived per slice
     // and all-gathered.  snapshot and finalize are then collective calls (every rank makes them).
     bool hash_fast = false;     // hash group-by through k_scan_hash_fast (fplan, fast_nf / ng / na / mode)
+    bool hash_packed = false;   // ... through k_scan_hash_packed (compact storage, 32-bit composite key)
     bool rs_active = false;
     int rs_int32 = -1;          // -1: not decided yet (first collective of the query), 0 / 1: the bucket slices travel as int64 / int32
     int32_t *d_h32 = nullptr;   // int32 staging of the bucket table + room for the reduced slice
@@ -398,6 +399,8 @@ int comm_allgather_inplace(Ctx *ctx, int64_t *buf, size_t words_per_rank);
 int comm_allreduce_sum(Ctx *ctx, int64_t *buf, size_t words);
 // hashgroup.hip
 hipError_t launch_scan_hash(const ScanPlan *d_plan, int n_slots, int n_wg, size_t lds_bytes, hipStream_t st);
+hipError_t launch_scan_hash_packed(const FastPlan &P, uint64_t *keys, int nf, int ng, int na, int mode, bool time, int L, int F, int M, int n_wg,
+                                   size_t lds_bytes, hipStream_t st);
 hipError_t launch_scan_hash_fast(const FastPlan &P, uint64_t *keys, int nf, int ng, int na, int mode, bool time, int L, int F, int M, int n_wg,
                                  size_t lds_bytes, hipStream_t st);
 // distinct.hip

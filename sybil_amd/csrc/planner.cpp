@@ -368,8 +368,17 @@ static void select_hash_fast(Table *t, Query *q, const std::vector<int> &slot_co
     FastPlan &FP = q->fplan;
     int nf, ng, na;
     bool any_max, all_max, gen;
-    if (!fill_fast_columns(t, q, slot_col, FP, &nf, &ng, &na, &any_max, &all_max, true, &gen, nullptr, kFastMaxG)) return;
+    // compact storage, a composite key below 2^32 and no bucket arrays: the offset-domain row body (k_scan_hash_packed)
+    bool packed = false;
+    q->hash_packed = false;
+    const unsigned __int128 key_space = (unsigned __int128)q->group_cells * (unsigned __int128)std::max(P.n_tb, 1);
+    const bool try_packed = !getenv("SYBL_NO_HASH_PACKED") && key_space < ((unsigned __int128)1 << 32) &&
+                            !(q->op == SYBL_AGG_HIST && q->want_percentiles) && q->groups.size() <= 2;
+    if (!fill_fast_columns(t, q, slot_col, FP, &nf, &ng, &na, &any_max, &all_max, true, &gen, try_packed ? &packed : nullptr,
+                           try_packed ? 2 : kFastMaxG))
+        return;
     if (q->weighted && q->op == SYBL_AGG_HIST && q->want_percentiles) return;  // weighted bucket increments: generic kernel
+    q->hash_packed = packed;
     if (q->time_mode) {
         FP.tcol = (const int64_t *)P.slot[P.time_slot].base;
         FP.tvalid = P.slot[P.time_slot].valid;

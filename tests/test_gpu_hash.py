@@ -40,15 +40,17 @@ def _ocols(cols, pops=None):
 
 @pytest.mark.parametrize("staging", [True, False])
 @pytest.mark.parametrize("full", [False, True])
-@pytest.mark.parametrize("specialised", [True, False])
+@pytest.mark.parametrize("specialised", ["packed", "fast", "generic"])
 def test_forced_hash_equals_direct_mapped_and_oracle(ctx, oracle, monkeypatch, staging, full, specialised):
     """Config 3 (1024 groups) through the hash table: every row hits the LDS staging table (or, without it, the
     global table with device-scope atomics); bucket arrays (full) always live in the global table.  Both row bodies:
-    the role-specialised k_scan_hash_fast and (SYBL_NO_HASH_FAST) the plan-interpreting k_scan_hash."""
+    k_scan_hash_packed (compact storage, no bucket arrays), k_scan_hash_fast (SYBL_NO_HASH_PACKED) and the plan-interpreting k_scan_hash (SYBL_NO_HASH_FAST)."""
     wl = synth.WORKLOADS["cfg3_filter3_group2_stddev"]
     monkeypatch.setenv("SYBL_FORCE_HASH", "1")
-    if not specialised:
+    if specialised == "generic":
         monkeypatch.setenv("SYBL_NO_HASH_FAST", "1")
+    elif specialised == "fast":
+        monkeypatch.setenv("SYBL_NO_HASH_PACKED", "1")
     if not staging:
         monkeypatch.setenv("SYBL_NO_HASH_LDS", "1")
     q = dict(wl["query"], want_percentiles=full)

@@ -10,8 +10,8 @@ ctx = sybil_amd.Context(0)
 wl = synth.WORKLOADS["cfg3_filter3_group2_stddev"]
 t = ctx.synth_table("a", synth.SEED, rows, 0, rows, synth.synth_cols(wl["columns"]))
 t.compact()
-for label, env in (("packed", {}), ("gen", {"SYBL_NO_PACKED": "1"}), ("hash_fast", {"SYBL_FORCE_HASH": "1"}),
-                   ("hash_generic", {"SYBL_FORCE_HASH": "1", "SYBL_NO_HASH_FAST": "1"}), ("generic", {"SYBL_NO_FAST": "1"})):
+for label, env in (("packed", {}), ("gen", {"SYBL_NO_PACKED": "1"}), ("hash_fast", {"SYBL_FORCE_HASH": "1", "SYBL_NO_HASH_PACKED": "1"}),
+                   ("hash_packed", {"SYBL_FORCE_HASH": "1"}), ("hash_generic", {"SYBL_FORCE_HASH": "1", "SYBL_NO_HASH_FAST": "1"}), ("generic", {"SYBL_NO_FAST": "1"})):
     os.environ.update(env)
     q = t.query(**dict(wl["query"], order_by=None))
     q.scan(); ctx.sync()
