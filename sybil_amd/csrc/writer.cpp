@@ -312,6 +312,9 @@ extern "C" int sybl_table_save(sybl_table *t, const char *dir) {
     auto save_block = [&](size_t b, std::vector<IntStat> &tstat, std::vector<int64_t> &vals, std::vector<uint8_t> &pop) -> int {
         int rc;
         const Segment &blk = t->blocks[b];
+        // blocks sybl_table_refresh dropped (vanished / rewritten on disk: n = 0, their rows unreferenced) are not written:
+        // the reference treats a block directory with NumRecords = 0 as broken
+        if (blk.n <= 0) return SYBL_OK;
         char bname[32];
         snprintf(bname, sizeof(bname), "block%09lld", (long long)(b + 1));
         const std::string bdir = tdir + "/" + bname;
