@@ -229,7 +229,9 @@ static int scan(Query *q) {
         if (q->fast) {
             q->fplan.sum_out = q->d_sum;
             q->fplan.max_out = q->d_max;
-            if (q->fast_packed) {
+            if (q->fast_packed_n) {
+                e = launch_scan_packed_n(q->fplan, q->fast_nf, q->fast_ng, q->fast_na, q->fast_mode, q->time_mode, q->n_wg, q->lds_bytes, st);
+            } else if (q->fast_packed) {
                 e = launch_scan_packed(q->fplan, q->fast_nf, q->fast_ng, q->fast_na, q->fast_mode, q->time_mode, q->n_wg, q->lds_bytes, st);
             } else {
                 e = launch_scan_fast(q->fplan, q->fast_nf, q->fast_ng, q->fast_na, q->fast_mode, q->time_mode, q->fast_gen, q->n_wg,

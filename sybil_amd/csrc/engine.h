@@ -379,6 +379,7 @@ struct Query {
     int64_t h_max_words = 0;                // capacity of h_max
     // role-specialised kernel (scan_fast.h)
     bool fast = false, fast_gen = false, fast_packed = false;
+    bool fast_packed_n = false;  // ... the run-time-column-count form of the packed kernel (3-4 group columns)
     int fast_nf = 0, fast_ng = 0, fast_na = 0, fast_mode = 0;
     FastPlan fplan;
     // partitioned histograms (strategy 5)
@@ -399,6 +400,7 @@ int comm_allgather_inplace(Ctx *ctx, int64_t *buf, size_t words_per_rank);
 int comm_allreduce_sum(Ctx *ctx, int64_t *buf, size_t words);
 // hashgroup.hip
 hipError_t launch_scan_hash(const ScanPlan *d_plan, int n_slots, int n_wg, size_t lds_bytes, hipStream_t st);
+hipError_t launch_scan_packed_n(const FastPlan &P, int nf, int ng, int na, int mode, bool time, int n_wg, size_t lds_bytes, hipStream_t st);
 hipError_t launch_scan_hash_packed(const FastPlan &P, uint64_t *keys, int nf, int ng, int na, int mode, bool time, int L, int F, int M, int n_wg,
                                    size_t lds_bytes, hipStream_t st);
 hipError_t launch_scan_hash_fast(const FastPlan &P, uint64_t *keys, int nf, int ng, int na, int mode, bool time, int L, int F, int M, int n_wg,

@@ -419,7 +419,7 @@ hipError_t launch_scan_hash_fast(const FastPlan &P, uint64_t *keys, int nf, int 
 // with a multiplicative 32-bit hash; misses and the flush go through hash_find_or_insert like every other writer of the
 // global table.  nf / ng / time are run-time (wave-uniform) so that one instantiation per (aggregations, mode, NUL)
 // serves every column count; bucket arrays (hist mode) never stage in LDS and stay with k_scan_hash_fast.
-template <int NA, int MODE, bool NUL>
+template <int NA, int MODE, bool NUL, bool HASH>
 __global__ __launch_bounds__(kWgThreads) void k_scan_hash_packed(const FastPlan P, uint64_t *hash_keys, const int nf, const int ng, const int time,
                                                                  const int L_, const int F, const int M) {
     extern __shared__ int64_t lds[];
@@ -428,17 +428,22 @@ __global__ __launch_bounds__(kWgThreads) void k_scan_hash_packed(const FastPlan 
     const uint32_t L = (uint32_t)L_;
     uint64_t *lkeys = (uint64_t *)lds;
     int64_t *lsum = lds + L, *lmax = lsum + (size_t)F * L;
-    for (uint32_t i = tid; i < L; i += kWgThreads) lkeys[i] = kHashEmpty;
-    for (uint32_t i = tid; i < (uint32_t)F * L; i += kWgThreads) lsum[i] = 0;
-    for (uint32_t i = tid; i < (uint32_t)M * L; i += kWgThreads) lmax[i] = INT64_MIN;
-    if (tid == 0) l_used = 0;
-    __syncthreads();
+    FastLds DL = {};  // !HASH: the direct-mapped cell table of the k_scan_fast family (replicas, LDS window)
+    if (HASH) {
+        for (uint32_t i = tid; i < L; i += kWgThreads) lkeys[i] = kHashEmpty;
+        for (uint32_t i = tid; i < (uint32_t)F * L; i += kWgThreads) lsum[i] = 0;
+        for (uint32_t i = tid; i < (uint32_t)M * L; i += kWgThreads) lmax[i] = INT64_MIN;
+        if (tid == 0) l_used = 0;
+        __syncthreads();
+    } else {
+        DL = fast_begin<MODE>(P, lds);
+    }
     int64_t *gsum = P.sum_out + kHeaderWords, *gmax = P.max_out;
     const uint32_t gmask = (uint32_t)P.n_cells - 1u;
     const uint32_t lmask = L - 1u, l_limit = L - (L >> 2), lshift = L > 1 ? 32u - (uint32_t)__builtin_ctz(L) : 31u;
 
     uint32_t matched = 0, overflow = 0, full = 0;
-    constexpr int MF = kFastMaxF, MG = 2;  // (the packed planner takes at most two group columns)
+    constexpr int MF = kFastMaxF, MG = HASH ? 2 : kFastMaxG;  // (hashed: the planner takes at most two group columns here)
     auto accumulate = [&](auto lds_tag, int64_t *tab, int64_t *maxtab, const uint32_t ncell, const uint32_t slot, const PackedTile<NA> &a, const int r) {
         constexpr bool LDS = decltype(lds_tag)::value;
         fast_add64<LDS>(tab, slot, 1);  // Result.Count++ (aggregate.go:203)
@@ -509,6 +514,16 @@ __global__ __launch_bounds__(kWgThreads) void k_scan_hash_packed(const FastPlan 
             key += tb * (uint32_t)P.tb_stride64;
         }
         matched += pass ? 1u : 0u;
+        if (!HASH) {
+            // direct-mapped: the key IS the cell (aggregate.go:125-143), inside this workgroup's LDS table / window
+            const uint32_t lcell = key - DL.cell_base;
+            inb = inb & (lcell < DL.tab_cells);
+            overflow += (live & !inb) ? 1u : 0u;
+            if (!(live & inb)) return;
+            const uint32_t rs = (uint32_t)P.rep_shift;
+            accumulate(std::true_type{}, lds, lds + DL.max_base, DL.tab_cells << rs, (lcell << rs) + DL.rep, a, r);
+            return;
+        }
         overflow += (live & !inb) ? 1u : 0u;
         if (!(live & inb)) return;
         int32_t ls = -1;
@@ -629,6 +644,10 @@ __global__ __launch_bounds__(kWgThreads) void k_scan_hash_packed(const FastPlan 
         }
     }
 
+    if (!HASH) {
+        fast_finish(P, lds, DL, matched, overflow);
+        return;
+    }
     if (L > 0) {
         __syncthreads();
         for (uint32_t i = tid; i < L; i += kWgThreads) {
@@ -657,10 +676,10 @@ __global__ __launch_bounds__(kWgThreads) void k_scan_hash_packed(const FastPlan 
     }
 }
 
-template <int NA, int MODE, bool NUL>
+template <int NA, int MODE, bool NUL, bool HASH = true>
 static hipError_t hash_packed_launch(const FastPlan &P, uint64_t *keys, int nf, int ng, int time, int L, int F, int M, int n_wg, size_t lds_bytes,
                                      hipStream_t st) {
-    auto kfn = k_scan_hash_packed<NA, MODE, NUL>;
+    auto kfn = k_scan_hash_packed<NA, MODE, NUL, HASH>;
     hipError_t e = hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max<size_t>(lds_bytes, 16));
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kfn, dim3(n_wg), dim3(kWgThreads), lds_bytes, st, P, keys, nf, ng, time, L, F, M);
@@ -682,6 +701,33 @@ static hipError_t hash_packed_mode(const FastPlan &P, uint64_t *keys, int nf, in
     default: return hipErrorInvalidValue;
     }
 #undef SYBL_HP
+}
+
+// The same row body direct-mapped (HASH = false): what k_scan_packed does, for the column counts it is not instantiated
+// for -- three or four group columns -- with run-time column counts.
+template <int NA>
+static hipError_t packed_n_mode(const FastPlan &P, int nf, int ng, int mode, int time, int n_wg, size_t lds, hipStream_t st) {
+    const bool nul = P.nul != 0;
+#define SYBL_PN(MODE_) \
+    return nul ? hash_packed_launch<NA, MODE_, true, false>(P, nullptr, nf, ng, time, 0, 0, 0, n_wg, lds, st) \
+               : hash_packed_launch<NA, MODE_, false, false>(P, nullptr, nf, ng, time, 0, 0, 0, n_wg, lds, st)
+    if (NA == 0) SYBL_PN(kFastAvg);
+    switch (mode) {
+    case kFastAvg: SYBL_PN(kFastAvg);
+    case kFastAvgMax: SYBL_PN(kFastAvgMax);
+    case kFastMoments: SYBL_PN(kFastMoments);
+    default: return hipErrorInvalidValue;
+    }
+#undef SYBL_PN
+}
+
+hipError_t launch_scan_packed_n(const FastPlan &P, int nf, int ng, int na, int mode, bool time, int n_wg, size_t lds_bytes, hipStream_t st) {
+    switch (na) {
+    case 0: return packed_n_mode<0>(P, nf, ng, mode, time ? 1 : 0, n_wg, lds_bytes, st);
+    case 1: return packed_n_mode<1>(P, nf, ng, mode, time ? 1 : 0, n_wg, lds_bytes, st);
+    case 2: return packed_n_mode<2>(P, nf, ng, mode, time ? 1 : 0, n_wg, lds_bytes, st);
+    default: return hipErrorInvalidValue;
+    }
 }
 
 hipError_t launch_scan_hash_packed(const FastPlan &P, uint64_t *keys, int nf, int ng, int na, int mode, bool time, int L, int F, int M, int n_wg,

@@ -311,7 +311,16 @@ static void select_fast_path(Table *t, Query *q, const std::vector<int> &slot_co
     int nf, ng, na;
     bool any_max, all_max, gen, packed = false;
     q->fast_packed = false;
-    if (!fill_fast_columns(t, q, slot_col, FP, &nf, &ng, &na, &any_max, &all_max, !getenv("SYBL_NO_FASTGEN"), &gen, &packed)) return;
+    q->fast_packed_n = false;
+    if (!fill_fast_columns(t, q, slot_col, FP, &nf, &ng, &na, &any_max, &all_max, !getenv("SYBL_NO_FASTGEN"), &gen, &packed)) {
+        // three or four group columns over compact storage: the packed row body with run-time column counts
+        // (k_scan_hash_packed<.., HASH = false>, hashgroup.hip); no bucket arrays
+        if (q->groups.size() <= 2 || (int)q->groups.size() > kFastMaxG || getenv("SYBL_NO_PACKED_N") || getenv("SYBL_NO_FASTGEN")) return;
+        if (q->op == SYBL_AGG_HIST && q->want_percentiles) return;
+        packed = false;
+        if (!fill_fast_columns(t, q, slot_col, FP, &nf, &ng, &na, &any_max, &all_max, true, &gen, &packed, kFastMaxG) || !packed) return;
+        q->fast_packed_n = true;
+    }
     if (q->op == SYBL_AGG_HIST && any_max && !gen) return;
     if (q->weighted && q->op == SYBL_AGG_HIST && q->want_percentiles) return;  // weighted bucket increments: generic kernel
     q->fast_gen = gen;
@@ -326,6 +335,7 @@ static void select_fast_path(Table *t, Query *q, const std::vector<int> &slot_co
         FP.tb_min = P.tb_min;
         FP.n_tb = P.n_tb;
         FP.tb_stride = P.tb_stride;
+        FP.tb_stride64 = P.tb_stride64;
     }
     int mode;
     if (q->op == SYBL_AGG_HIST) {

@@ -260,3 +260,39 @@ def test_int_neq_runs_the_specialised_kernels(ctx, oracle, compact):
     parity.compare(gres, ores, op="hist", full=False, n_aggs=2)
     assert len(gres.results) == 16 * 63     # c02 = 7 is gone
     gres.free()
+
+
+def test_three_and_four_group_columns_run_the_packed_body(ctx, oracle):
+    """More group columns than k_scan_packed is instantiated for: the same offset-domain row body with run-time column
+    counts (k_scan_hash_packed<.., HASH = false>) over compact storage -- a missing-value key digit, a filter with a
+    neq, moments and avg modes (aggregate.go:125-143)."""
+    rng = np.random.default_rng(314)
+    n = 700_000
+    cols = {"g1": rng.integers(0, 4, n), "g2": rng.integers(10, 15, n), "g3": rng.integers(-3, 3, n), "g4": rng.integers(0, 3, n),
+            "f": rng.integers(0, 1000, n), "v": rng.integers(0, 1000, n), "u": rng.integers(100, 900, n)}
+    cols = {k: v.astype(np.int64) for k, v in cols.items()}
+    pops = {"g2": (rng.random(n) > 0.1).astype(np.uint8)}
+    info = {"v": (0, 999), "u": (100, 899)}   # (bucket geometries without outliers: those run the GEN body)
+    tb = ctx.create_table("g4")
+    for c in cols:
+        lo, hi = info.get(c, (1, 0))
+        tb.add_column(c, "int", lo, hi)
+    for r0 in range(0, n, 65536):
+        r1 = min(r0 + 65536, n)
+        tb.append_block(r1 - r0, {c: ((cols[c][r0:r1], pops[c][r0:r1]) if c in pops else cols[c][r0:r1]) for c in cols})
+    tb.compact()
+    names = list(cols)
+    ocols = [{"type": "int", "data": cols[c], **({"populated": pops[c]} if c in pops else {})} for c in names]
+    for q, okw in ((dict(filters=[("f", "gt", 99), ("f", "neq", 500)], groups=["g1", "g2", "g3"], aggs=["v", "u"], op="hist", want_percentiles=False),
+                    dict(filters=[(4, "gt", 99), (4, "neq", 500)], groups=[0, 1, 2], aggs=[(5, 0, 999), (6, 100, 899)], op="hist")),
+                   (dict(groups=["g1", "g2", "g3", "g4"], aggs=["v"], op="avg"),
+                    dict(groups=[0, 1, 2, 3], aggs=[(5, 0, 999)], op="avg"))):
+        query = tb.query(**q)
+        gres = query.run()
+        st = query.stats()
+        assert st["strategy"] == 2 and st["packed_kernel"] == 1, st
+        ores = oracle.run_query(ocols, n_threads=4, **okw)
+        parity.compare(gres, ores, op=q["op"], full=False, n_aggs=len(q["aggs"]))
+        gres.free()
+        query.free()
+    tb.free()
