@@ -1159,7 +1159,10 @@ struct Planner {
         P.rep_shift = 0;
         if (q->use_lds) {
             int rs = 0;
-            while (rs < 6 && (lds_words * 8 << (rs + 1)) <= kLdsBudgetBytes) rs++;
+            // (SYBL_REP_BUDGET_KB: tuning -- a smaller cell table lets SYBL_WG_PER_CU workgroups share a CU)
+            int64_t rep_budget = kLdsBudgetBytes;
+            if (const char *e = getenv("SYBL_REP_BUDGET_KB")) rep_budget = std::min<int64_t>(kLdsBudgetBytes, std::max<int64_t>(1, atoll(e)) * 1024);
+            while (rs < 6 && (lds_words * 8 << (rs + 1)) <= rep_budget) rs++;
             P.rep_shift = rs;
             q->lds_bytes = (size_t)(lds_words * 8) << rs;
         }

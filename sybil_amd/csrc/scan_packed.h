@@ -301,8 +301,11 @@ __device__ __forceinline__ void packed_row(const FastPlan &P, const PackedTile<N
 
 constexpr int64_t kPackedChunkRows = (int64_t)1 << 28;  // rows addressed with one 32-bit byte offset (x4 bytes)
 
+#ifndef SYBL_PACKED_WAVES_PER_EU
+#define SYBL_PACKED_WAVES_PER_EU 4
+#endif
 template <int NF, int NG, int NA, int MODE, bool TIME, bool G1, bool NUL>
-__global__ __launch_bounds__(kWgThreads, 4) void k_scan_packed(const FastPlan P) {
+__global__ __launch_bounds__(kWgThreads, SYBL_PACKED_WAVES_PER_EU) void k_scan_packed(const FastPlan P) {
     extern __shared__ int64_t lds[];
     const uint32_t tid = threadIdx.x;
     const FastLds L = fast_begin<MODE>(P, lds);
