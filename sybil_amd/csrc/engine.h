@@ -233,6 +233,20 @@ struct PhaseTrace {
     }
 };
 
+// a device allocation that is freed on every exit unless ownership was passed on (release())
+struct DevOwner {
+    void *p = nullptr;
+    ~DevOwner() {
+        if (p) (void)hipFree(p);
+    }
+    template <typename T>
+    T *release() {
+        T *x = (T *)p;
+        p = nullptr;
+        return x;
+    }
+};
+
 struct HostBuf {
     int64_t *p = nullptr;
     int64_t words = 0;

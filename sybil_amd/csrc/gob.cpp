@@ -55,6 +55,33 @@ struct Reader {
         uint64_t u = uvarint();
         return (u & 1) ? (int64_t) ~(u >> 1) : (int64_t)(u >> 1);
     }
+    // n unsigned (or, SIGNED, zig-zag) integers into dst.  When the message certainly holds them (9 bytes each at most,
+    // + 8 of slack for the unaligned load) every value is one byte test and, past 127, ONE unaligned big-endian 8-byte
+    // load shifted down -- no per-byte loop, no per-value bounds checks: the record-id lists of bucket-encoded columns
+    // are 65 536 values per column and block, and this loop was most of a table load's 3.3 s of parse CPU.
+    template <bool SIGNED>
+    bool ints(int64_t *dst, uint64_t n) {
+        uint64_t k = 0;
+        if (left() >= 9 * n + 8) {
+            const uint8_t *q = p;
+            for (; k < n; k++) {
+                uint64_t v = *q++;
+                if (v >= 128) {
+                    const unsigned len = 256u - (unsigned)v;  // byte count, stored negated
+                    if (len > 8 || len == 0) break;           // malformed: the checked loop below reports it
+                    uint64_t be;
+                    memcpy(&be, q, 8);
+                    v = __builtin_bswap64(be) >> (64 - 8 * len);
+                    q += len;
+                }
+                dst[k] = SIGNED ? ((v & 1) ? (int64_t) ~(v >> 1) : (int64_t)(v >> 1)) : (int64_t)v;
+            }
+            p = q;
+            if (k < n) p = q - 1;  // (back onto the length byte of the value that stopped the fast loop)
+        }
+        for (; k < n && ok; k++) dst[k] = SIGNED ? svarint() : (int64_t)uvarint();
+        return ok;
+    }
     double float64() {
         uint64_t u = uvarint(), r = 0;  // IEEE bits, byte-reversed
         for (int i = 0; i < 8; i++) r |= ((u >> (8 * i)) & 0xFF) << (8 * (7 - i));
@@ -234,12 +261,7 @@ struct Decoder {
             if (is_int_kind(td.elem)) {
                 out.kind = Value::kIntVec;
                 out.ints.resize((size_t)n);
-                if (td.elem == tInt) {
-                    for (uint64_t k = 0; k < n; k++) out.ints[(size_t)k] = r.svarint();
-                } else {
-                    for (uint64_t k = 0; k < n; k++) out.ints[(size_t)k] = (int64_t)r.uvarint();
-                }
-                return r.ok;
+                return td.elem == tInt ? r.ints<true>(out.ints.data(), n) : r.ints<false>(out.ints.data(), n);
             }
             {
                 // []struct{Value int; Records []int}: flat arrays (see Value::kBinVec)
@@ -285,11 +307,8 @@ struct Decoder {
                                 const size_t at = out.ints.size();
                                 out.ints.resize(at + (size_t)m);
                                 int64_t *dst = out.ints.data() + at;
-                                if (rs) {
-                                    for (uint64_t j = 0; j < m; j++) dst[j] = r.svarint();
-                                } else {
-                                    for (uint64_t j = 0; j < m; j++) dst[j] = (int64_t)r.uvarint();
-                                }
+                                if (rs) r.ints<true>(dst, m);
+                                else r.ints<false>(dst, m);
                                 has |= 2;
                             } else {
                                 return fail("struct field index out of range in " + et->second.name);

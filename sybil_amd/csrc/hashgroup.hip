@@ -940,9 +940,13 @@ int query_hash_install_union_device(Query *q, const uint64_t *d_union, int64_t n
     uint64_t *new_keys = nullptr;
     const int64_t sum_words = hash_dense_sum_words(q, n), max_words = hash_dense_max_words(q, n);
     const int64_t sum_cap = sum_words + sum_words / 8, max_cap = max_words + max_words / 8, key_cap = std::max<int64_t>(n + n / 8, 64);
-    SYBL_HIP(hipMalloc((void **)&new_sum, (size_t)sum_cap * 8));
-    SYBL_HIP(hipMalloc((void **)&new_max, (size_t)max_cap * 8));
-    SYBL_HIP(hipMalloc((void **)&new_keys, (size_t)key_cap * 8));
+    DevOwner own_sum, own_max, own_keys;  // (freed on every error return below)
+    SYBL_HIP(hipMalloc(&own_sum.p, (size_t)sum_cap * 8));
+    SYBL_HIP(hipMalloc(&own_max.p, (size_t)max_cap * 8));
+    SYBL_HIP(hipMalloc(&own_keys.p, (size_t)key_cap * 8));
+    new_sum = (int64_t *)own_sum.p;
+    new_max = (int64_t *)own_max.p;
+    new_keys = (uint64_t *)own_keys.p;
     SYBL_HIP(hipMemcpyAsync(new_keys, d_union, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
     SYBL_HIP(hipMemsetAsync(new_sum, 0, (size_t)sum_words * 8, st));
     SYBL_HIP(hipMemcpyAsync(new_sum, q->d_dense_sum, (size_t)kHeaderWords * 8, hipMemcpyDeviceToDevice, st));
@@ -970,27 +974,19 @@ int query_hash_install_union_device(Query *q, const uint64_t *d_union, int64_t n
     SYBL_HIP(hipStreamSynchronize(st));
     e = hipGetLastError();
     if (e != hipSuccess || missing) {
-        (void)hipFree(new_sum);
-        (void)hipFree(new_max);
-        (void)hipFree(new_keys);
         if (e != hipSuccess) return hip_fail(e, "hash union");
         return fail(SYBL_E_INVAL, "the union lacks %llu of this rank's keys", (unsigned long long)missing);
     }
     for (int64_t i = 1; i < n; i++)
-        if (q->h_dense_keys[(size_t)i - 1] >= q->h_dense_keys[(size_t)i]) {
-            (void)hipFree(new_sum);
-            (void)hipFree(new_max);
-            (void)hipFree(new_keys);
-            return fail(SYBL_E_INVAL, "union keys must be strictly ascending");
-        }
+        if (q->h_dense_keys[(size_t)i - 1] >= q->h_dense_keys[(size_t)i]) return fail(SYBL_E_INVAL, "union keys must be strictly ascending");
     (void)hipFree(q->d_dense_sum);
     (void)hipFree(q->d_dense_max);
     (void)hipFree(q->d_dense_keys);
-    q->d_dense_sum = new_sum;
+    q->d_dense_sum = own_sum.release<int64_t>();
     q->dense_sum_cap = sum_cap;
-    q->d_dense_max = new_max;
+    q->d_dense_max = own_max.release<int64_t>();
     q->dense_max_cap = max_cap;
-    q->d_dense_keys = new_keys;
+    q->d_dense_keys = own_keys.release<uint64_t>();
     q->dense_keys_cap = key_cap;
     q->hash_live = n;
     return SYBL_OK;

@@ -751,6 +751,11 @@ static int load_blocks(Ctx *ctx, Table *t, const std::string &tdir, const std::v
         tr[k] += std::chrono::duration<double>(t1 - t0).count();
         t0 = t1;
     };
+    // (workers still hold references to this frame's state: every way out drains what is in flight)
+    struct DrainGuard {
+        decltype(drain) &d;
+        ~DrainGuard() { d(); }
+    } drain_guard{drain};
     if ((rc = submit())) return (rc);
     while (!inflight.empty()) {
         auto tw = std::chrono::steady_clock::now();

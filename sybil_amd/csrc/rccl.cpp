@@ -66,7 +66,9 @@ static int query_hash_allreduce(Query *q) {
     if (per > 0) {
         uint64_t *d_lists = nullptr, *d_union = nullptr;
         int64_t n_union = 0;
-        SYBL_HIP(hipMalloc((void **)&d_lists, (size_t)(per * R) * 8));
+        DevOwner own_lists;  // (freed on every exit)
+        SYBL_HIP(hipMalloc(&own_lists.p, (size_t)(per * R) * 8));
+        d_lists = (uint64_t *)own_lists.p;
         e = hipMemsetAsync(d_lists, 0xFF, (size_t)(per * R) * 8, st);  // padding = kHashEmpty, sorts last
         if (e == hipSuccess && q->hash_live > 0)
             e = hipMemcpyAsync(d_lists + (int64_t)me * per, q->d_dense_keys, (size_t)q->hash_live * 8, hipMemcpyDeviceToDevice, st);
@@ -74,7 +76,6 @@ static int query_hash_allreduce(Query *q) {
         if (e == hipSuccess && nr == ncclSuccess) rc = hash_union_of_lists(q, d_lists, per * R, &d_union, &n_union);
         if (e == hipSuccess && nr == ncclSuccess && !rc) rc = query_hash_install_union_device(q, d_union, n_union);
         (void)hipStreamSynchronize(st);
-        (void)hipFree(d_lists);
         if (d_union) (void)hipFree(d_union);
         if (e != hipSuccess) return hip_fail(e, "hash key exchange");
         if (nr != ncclSuccess) return nccl_fail(nr, "ncclAllGather(keys)");

@@ -23,6 +23,7 @@ struct Node {
     bool negated = false;                             // kSet
     int min = 0, max = 0;                             // kRepeat (max < 0: unbounded)
     int which = 0;                                    // kAssert
+    bool quoted = false;                              // kCat from \Q..\E: a following quantifier binds to its last rune only
 };
 typedef std::unique_ptr<Node> NodeP;
 
@@ -381,6 +382,7 @@ struct Re2Parser {
             if (e == 'Q') {  // literal text up to \E
                 at++;
                 n->kind = Node::kCat;
+                n->quoted = true;
                 while (more() && !(peek() == '\\' && peek(1) == 'E')) {
                     n->kids.push_back(literal(peek()));
                     at++;
@@ -404,7 +406,8 @@ struct Re2Parser {
         auto num = [&](int *v) {
             size_t s = p;
             long x = 0;
-            while (p < pat.size() && pat[p] >= '0' && pat[p] <= '9' && p - s < 6) x = x * 10 + (pat[p++] - '0');
+            // (every digit: Go reads the whole number and rejects a count above 1000 -- `x{1234567}` is an error, not a literal)
+            while (p < pat.size() && pat[p] >= '0' && pat[p] <= '9') x = std::min<long>(x * 10 + (pat[p++] - '0'), 1000000);
             *v = (int)x;
             return p > s;
         };
@@ -447,6 +450,12 @@ struct Re2Parser {
                 r->lazy = !ungreedy;
             }
             repeated = true;
+            if (a->kind == Node::kCat && a->quoted && a->kids.size() > 1) {
+                // \Qab\E+ is a(b+) in Go: the quoted runes are ordinary literals of the enclosing concatenation
+                r->kids.push_back(std::move(a->kids.back()));
+                a->kids.back() = std::move(r);
+                continue;
+            }
             r->kids.push_back(std::move(a));
             a = std::move(r);
         }
@@ -848,7 +857,8 @@ std::string Re2Lite::replace_all(const std::string &text, const std::string &tem
             if (brace) j++;
             int g = -1;
             if (name.find_first_not_of("0123456789") == std::string::npos) {
-                g = name.size() <= 6 ? atoi(name.c_str()) : -1;
+                // (Go: a number with a leading zero is not a group number -- and no group has such a name: empty)
+                g = name.size() <= 6 && !(name.size() > 1 && name[0] == '0') ? atoi(name.c_str()) : -1;
             } else {
                 for (size_t k = 1; k < cap_names_.size(); k++)
                     if (cap_names_[k] == name) g = (int)k;

@@ -396,8 +396,11 @@ __device__ __forceinline__ void fast_accumulate(const FastPlan &P, const FastTil
                                                 int64_t *tab, int64_t *maxtab, const uint64_t ncell, const uint32_t rs, const uint64_t cidx,
                                                 const int64_t gcell, const uint32_t lcell, const int64_t logkey, uint32_t *hist32,
                                                 uint32_t &overflow) {
-    // weight := r.Ints[WEIGHT_COL] (aggregate.go:100-102); 1 without a weight column
-    const int64_t wt = (GEN && P.wcol) ? (r == 0 ? w.v[0].x : w.v[0].y) : 1;
+    // weight := r.Ints[WEIGHT_COL] (aggregate.go:100-102); 1 without a weight column -- and then no 64-bit multiply
+    // per accumulated word (the branch is wave-uniform; the GEN body spent three of them per aggregation on wt == 1)
+    const bool weighted = GEN && P.wcol != nullptr;
+    const int64_t wt = weighted ? (r == 0 ? w.v[0].x : w.v[0].y) : 1;
+    auto times_w = [&](int64_t v) -> int64_t { return weighted ? (int64_t)((uint64_t)v * (uint64_t)wt) : v; };
     fast_add64<LDS>(tab, cidx, wt);  // Result.Count += weight (aggregate.go:203)
     if (GEN && P.f_samples >= 0) fast_add64<LDS>(tab, (((uint64_t)(uint32_t)P.f_samples * ncell) << rs) + cidx, 1);  // Result.Samples++
 #pragma unroll
@@ -412,7 +415,7 @@ __device__ __forceinline__ void fast_accumulate(const FastPlan &P, const FastTil
             }
             if (P.f_smp[c] >= 0) fast_add64<LDS>(tab, (((uint64_t)(uint32_t)P.f_smp[c] * ncell) << rs) + cidx, 1);  // h.Samples++
         }
-        fast_add64<LDS>(tab, (((uint64_t)(uint32_t)P.f_sum[c] * ncell) << rs) + cidx, (int64_t)((uint64_t)x * (uint64_t)wt));
+        fast_add64<LDS>(tab, (((uint64_t)(uint32_t)P.f_sum[c] * ncell) << rs) + cidx, times_w(x));
         if (MODE == kFastAvgMax) fast_max64<LDS>(maxtab, (((uint64_t)(uint32_t)P.m_max[c] * ncell) << rs) + cidx, x);
         if (MODE == kFastMoments || MODE == kFastHist) {
             // bucket_value := (value - h.Min) / BucketSize, hist_basic.go:130.  The planner only
@@ -457,8 +460,8 @@ __device__ __forceinline__ void fast_accumulate(const FastPlan &P, const FastTil
                 }
             }
             if (MODE == kFastMoments) {
-                fast_add64<LDS>(tab, (((uint64_t)(uint32_t)P.f_sb[c] * ncell) << rs) + cidx, (int64_t)b * wt);
-                fast_add64<LDS>(tab, (((uint64_t)(uint32_t)P.f_sb2[c] * ncell) << rs) + cidx, (int64_t)((uint64_t)b * (uint64_t)b) * wt);
+                fast_add64<LDS>(tab, (((uint64_t)(uint32_t)P.f_sb[c] * ncell) << rs) + cidx, times_w((int64_t)b));
+                fast_add64<LDS>(tab, (((uint64_t)(uint32_t)P.f_sb2[c] * ncell) << rs) + cidx, times_w((int64_t)((uint64_t)b * (uint64_t)b)));
             } else if (LDS && P.hist_lds) {
                 __hip_atomic_fetch_add(hist32 + lcell * (uint32_t)P.hist_stride + (uint32_t)P.hist_agg_off[c] + b, 1u,
                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);

@@ -51,6 +51,8 @@ def test_go_specific_syntax():
     assert match(r"\x{e9}", "caf\u00e9") == 1 and match(r"\x{4e2d}", "\u4e2d\u6587") == 1 and match(r"\x{e9}", "cafe") == 0
     # named groups, both spellings; \Q...\E quotes
     assert match(r"(?P<x>a)(?<y>b)", "ab") == 1 and match(r"\Qa.b\E", "a.b") == 1 and match(r"\Qa.b\E", "axb") == 0
+    # a quantifier behind \Q..\E binds to the LAST quoted rune only (the quoted runes are ordinary literals)
+    assert match(r"^\Qab\E+$", "abbb") == 1 and match(r"^\Qab\E+$", "abab") == 0 and match(r"^\Qa.\E{2}$", "a..") == 1
     # a brace that is no repetition is a literal
     assert match(r"a{", "a{") == 1 and match(r"a{x}", "a{x}") == 1 and match(r"{z}", "{z}") == 1
     # . matches a whole rune, not a byte
@@ -59,7 +61,7 @@ def test_go_specific_syntax():
     assert match(r"(?:a(?i)b|c)", "C") == 1
 
 
-@pytest.mark.parametrize("pattern", [r"a**", r"a++", r"*a", r"(ab", r"ab)", r"[a", r"a{1001}", r"a{3,2}", r"\pL", r"[\p{Greek}]",
+@pytest.mark.parametrize("pattern", [r"a**", r"a++", r"*a", r"(ab", r"ab)", r"[a", r"a{1001}", r"a{1234567}", r"a{2,12345678}", r"a{3,2}", r"\pL", r"[\p{Greek}]",
                                      r"\1", r"(?<=a)b", r"(?=a)", r"\8", r"\C", r"(?z)", "\\"])
 def test_rejects_what_go_rejects_or_what_is_not_supported(pattern):
     assert match(pattern, "abc") == -1
@@ -88,6 +90,7 @@ REPLACE_KATS = [
     ("a.*?c", "abcabc", "X", "XX"), ("(?U)a.*c", "abcabc", "X", "XX"), ("a.*c", "abcabc", "X", "X"), (r"\$", "cost $5", "$$", "cost $5"),
     ("(a)|(b)", "ab", "[$1|$2]", "[a|][|b]"), ("x*", "\u00e9x", "-", "-\u00e9-"), ("[aeiou]", "education", "$0$0", "eeduucaatiioon"),
     ("(?i)HOST", "host1.Host2", "<$0>", "<host>1.<Host>2"), ("[0-9]+$", "user123", "", "user"), ("$", "ab", "!", "ab!"),
+    ("(a)", "a", "[$01]", "[]"), ("(a)", "a", "[${01}]", "[]"), ("(a)", "a", "[$0][$1]", "[a][a]"),   # a leading zero is no group number
 ]
 
 
