@@ -421,16 +421,19 @@ def main():
             out["oracle_check"] = out.pop("oracle_check")
     # The other BASELINE.json configurations that fit one GPU, driver-measured in the same run: same table generator,
     # same step (scan + fold (+ all-reduce) + finalize, pipelined one deep), compact storage, fewer steps.
-    if not args.no_configs and args.workload == "cfg3_filter3_group2_stddev" and not args.rows:
+    # (single-GPU runs only: the N > 1 scaling runs measure the headline, whose collective path is the one exercised on
+    # one GPU by --force-dist; a config that fails is reported, it does not take the headline line with it)
+    if not args.no_configs and args.workload == "cfg3_filter3_group2_stddev" and not args.rows and not multi:
         recs = []
         for name in ("cfg2_group1_avg2", "cfg4_hist_highcard", "cfg5_time_rollup"):
-            rec = measure(name, 0, min(args.steps, 10), min(args.warmup, 2), "compact", False)
-            if rank == 0:
+            try:
+                rec = measure(name, 0, min(args.steps, 10), min(args.warmup, 4), "compact", False)
                 recs.append({k: rec[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "config", "roofline")
                              + (("oracle_check",) if "oracle_check" in rec else ())})
                 recs[-1]["kernel_ms"] = rec["roofline"]["kernel_ms"]
-        if rank == 0:
-            out["configs"] = recs
+            except Exception as e:  # noqa: BLE001 -- reported in the line
+                recs.append({"config": {"workload": name}, "error": "%s: %s" % (type(e).__name__, e)})
+        out["configs"] = recs
     if rank == 0:
         if world == 1 and not args.no_load:
             # the bench's own table (the 7 referenced columns of config 3: five bucket-encoded, two value-encoded), and
