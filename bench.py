@@ -420,14 +420,14 @@ def main():
         if "oracle_check" in out:  # (key order of the round-2 line: cpu_baseline before oracle_check)
             out["oracle_check"] = out.pop("oracle_check")
     # The other BASELINE.json configurations that fit one GPU, driver-measured in the same run: same table generator,
-    # same step (scan + fold (+ all-reduce) + finalize, pipelined one deep), compact storage, fewer steps.
+    # same step (scan + fold (+ all-reduce) + finalize, pipelined one deep), compact storage, at most 20 steps.
     # (single-GPU runs only: the N > 1 scaling runs measure the headline, whose collective path is the one exercised on
     # one GPU by --force-dist; a config that fails is reported, it does not take the headline line with it)
     if not args.no_configs and args.workload == "cfg3_filter3_group2_stddev" and not args.rows and not multi:
         recs = []
         for name in ("cfg2_group1_avg2", "cfg4_hist_highcard", "cfg5_time_rollup"):
             try:
-                rec = measure(name, 0, min(args.steps, 10), min(args.warmup, 4), "compact", False)
+                rec = measure(name, 0, min(args.steps, 20), min(args.warmup, 4), "compact", False)
                 recs.append({k: rec[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "config", "roofline")
                              + (("oracle_check",) if "oracle_check" in rec else ())})
                 recs[-1]["kernel_ms"] = rec["roofline"]["kernel_ms"]

@@ -898,9 +898,13 @@ __global__ __launch_bounds__(256) void k_hist_summary(const HistSummaryPlan S) {
     int64_t *out = S.pct + pair * 100;
     const int64_t bs = S.bucket_size[a], hmin = S.hmin[a], nvals = S.n_values[a];
     int64_t sb = 0, sb2 = 0, carry = 0, carry_p = 0;
+    // (loading the whole bucket array into registers first -- sixteen wave loads in flight -- measured slower: 0.33 ms against
+    // 0.28 for config 4's 65 536 arrays; the next chunk is requested while this one is scanned instead)
+    int64_t x_next = lane < nvals ? v[lane] : 0;
     for (int64_t k0 = 0; k0 < nvals; k0 += 64) {
         const int64_t k = k0 + lane;
-        const int64_t x = k < nvals ? v[k] : 0;
+        const int64_t x = x_next;
+        x_next = k + 64 < nvals ? v[k + 64] : 0;
         sb += k * x;
         sb2 += k * k * x;
         if (count == 0) continue;
@@ -943,7 +947,15 @@ __global__ __launch_bounds__(256) void k_hist_total(const int64_t *__restrict__ 
     const int64_t c1 = c0 + cells_per_block < cell1 ? c0 + cells_per_block : cell1;
     for (int64_t w = threadIdx.x; w < hist_stride; w += blockDim.x) {
         int64_t acc = 0;
-        for (int64_t cell = c0; cell < c1; cell++) acc += H[cell * hist_stride + w];
+        int64_t cell = c0;
+        for (; cell + 8 <= c1; cell += 8) {  // eight independent loads in flight per lane
+            int64_t x[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) x[u] = __builtin_nontemporal_load(H + (cell + u) * hist_stride + w);
+#pragma unroll
+            for (int u = 0; u < 8; u++) acc += x[u];
+        }
+        for (; cell < c1; cell++) acc += H[cell * hist_stride + w];
         if (acc) gadd(total + w, acc);
     }
 }
@@ -962,7 +974,7 @@ __global__ __launch_bounds__(256) void k_hist_gather(const int64_t *__restrict__
 hipError_t launch_hist_summary(const HistSummaryPlan &S, int64_t *total, hipStream_t st) {
     const int64_t pairs = (S.cell1 - S.cell0) * S.n_aggs;
     if (pairs <= 0) return hipSuccess;
-    const int64_t cpb = 64;
+    const int64_t cpb = 128;
     hipLaunchKernelGGL(k_hist_total, dim3((unsigned)((S.cell1 - S.cell0 + cpb - 1) / cpb)), dim3(256), 0, st, S.H, S.hist_stride, S.cell0,
                        S.cell1, cpb, total);
     hipLaunchKernelGGL(k_hist_summary, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, st, S);
