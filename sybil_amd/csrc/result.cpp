@@ -438,6 +438,11 @@ int query_snapshot(Query *q) {
             if (rc) return rc;
             rc = acquire_host_buf(q, pairs * 100, q->h_pct_buf);  // (`spare` is held: a second buffer)
             if (rc) return rc;
+            // first device write into each of them now (a 52 MB copy into a pinned buffer the device has not written
+            // before was seen to block its hipMemcpyAsync for 13-18 ms: once, but inside a timed region of ten steps)
+            SYBL_HIP(hipMemcpyAsync(spare->p, q->d_pct, (size_t)pairs * 100 * 8, hipMemcpyDeviceToHost, st));
+            SYBL_HIP(hipMemcpyAsync(q->h_pct_buf->p, q->d_pct, (size_t)pairs * 100 * 8, hipMemcpyDeviceToHost, st));
+            SYBL_HIP(hipStreamSynchronize(st));
         }
         if (q->h_pct_buf.use_count() > 2 || q->h_pct_buf->words < pairs * 100) {
             int rc = acquire_host_buf(q, pairs * 100, q->h_pct_buf);
@@ -494,10 +499,13 @@ int query_snapshot(Query *q) {
         cs = ctx->copy_stream;
         q->snap_on_aux = true;
     }
+    trace.mark("copy-stream");
     if (q->hist_summary) {
         SYBL_HIP(hipMemcpyAsync(q->h_pct, q->d_pct, (size_t)real_pairs * 100 * 8, hipMemcpyDeviceToHost, cs));
+        trace.mark("pct");
         SYBL_HIP(hipMemcpyAsync(q->h_mom, q->d_mom, (size_t)real_pairs * 2 * 8, hipMemcpyDeviceToHost, cs));
         SYBL_HIP(hipMemcpyAsync(q->h_total, q->d_total, (size_t)P.hist_stride * 8, hipMemcpyDeviceToHost, cs));
+        trace.mark("mom+total");
     }
     if (q->hash_mode) {
         SYBL_HIP(hipMemcpyAsync(q->h_sum, q->d_dense_sum, (size_t)sum_words * 8, hipMemcpyDeviceToHost, cs));
