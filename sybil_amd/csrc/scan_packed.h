@@ -169,6 +169,46 @@ __device__ __forceinline__ void packed_issue_always(const FastPlan &P, const Pac
     for (int c = 0; c < NA; c++) issue(B.a[c], P.awid[c], a.v[c]);
 }
 
+// packed_issue_all for a ring of tiles in flight (k_scan_packed without NUL): like packed_issue_always every lane ALWAYS
+// issues -- the descriptor ends at row n, so a tile (or the lanes of a wave) past the end of the chunk loads nothing --
+// and the load count between a tile's loads and their use is the same on every path: the compiler's vmcnt is exact.
+template <int NF, int NG, int NA, bool TIME, bool G1>
+__device__ __forceinline__ void packed_issue_ring(const FastPlan &P, const PackedBases<NF, NG, NA> &B, uint32_t r, uint32_t n,
+                                                  PackedRaw<NF> &f, PackedRaw<NG> &g, PackedRaw<NA> &a, PackedRaw<1> &t) {
+    const uint32_t r0 = __builtin_amdgcn_readfirstlane(r);
+    const uint32_t lane_row = r - r0;
+    const uint32_t rows = r0 < n ? (n - r0 < 64u * kPackedRows ? (n - r0 + kPackedRows - 1) & ~(uint32_t)(kPackedRows - 1) : 64u * kPackedRows) : 0u;
+    const uint32_t base_row = rows ? r0 : 0u;
+    auto issue = [&](const uint8_t *col, int width, pu32x4 &raw) {
+        const int ws = width >> 1;  // width 1, 2, 4 -> shift 0, 1, 2
+        const __amdgpu_buffer_rsrc_t rsrc =
+            __builtin_amdgcn_make_buffer_rsrc((void *)(col + ((size_t)base_row << ws)), 0, (int)(rows << ws), (int)kBufferRsrcWord3);
+        raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(lane_row << ws), 0, 2);  // aux 2 = nt: streamed once
+    };
+    if (TIME) issue(B.t, P.twid, t.v[0]);
+#pragma unroll
+    for (int c = 0; c < NF; c++) issue(B.f[c], P.fwid[c], f.v[c]);
+#pragma unroll
+    for (int c = 0; c < NG; c++) {
+        if (G1) {
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(B.g[c] + (size_t)base_row), 0, (int)rows, (int)kBufferRsrcWord3);
+            g.v[c].x = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)lane_row, 0, 2);
+        } else {
+            issue(B.g[c], P.gwid[c], g.v[c]);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NA; c++) issue(B.a[c], P.awid[c], a.v[c]);
+}
+
+// Tiles of loads a lane keeps in flight in k_scan_packed: ONE (the next tile is requested before the current one is
+// consumed).  A ring of two or three tiles (RING > 1: the k_emit structure, every lane always issuing) was measured on one
+// box against it (tools/bench_ring.py, round 3): config 2 (three columns) 0.177 ms with one tile, 0.180 with two, 0.182
+// with three; the seven-column headline 2.81 / 2.92 / 2.92 ms; the time rollup 1.74 ms whichever -- the row bodies cover the
+// latency of one tile, and the ring's clamped descriptors cost scalar work per load.  (Round 2 had found the same for
+// queries of <= 3 columns.)  SYBL_PACKED_RING keeps the variants reachable for the BASELINE shapes.
+constexpr int packed_depth(int) { return 1; }
+
 template <int NF, int NG, int NA, bool TIME, bool G1, bool NUL>
 __device__ __forceinline__ void packed_decode_all(const FastPlan &P, const PackedRaw<NF> &rf, const PackedRaw<NG> &rg,
                                                   const PackedRaw<NA> &ra, const PackedRaw<1> &rt, PackedTile<NF> &f,
@@ -304,7 +344,7 @@ constexpr int64_t kPackedChunkRows = (int64_t)1 << 28;  // rows addressed with o
 #ifndef SYBL_PACKED_WAVES_PER_EU
 #define SYBL_PACKED_WAVES_PER_EU 4
 #endif
-template <int NF, int NG, int NA, int MODE, bool TIME, bool G1, bool NUL>
+template <int NF, int NG, int NA, int MODE, bool TIME, bool G1, bool NUL, int RING = 0>
 __global__ __launch_bounds__(kWgThreads, SYBL_PACKED_WAVES_PER_EU) void k_scan_packed(const FastPlan P) {
     extern __shared__ int64_t lds[];
     const uint32_t tid = threadIdx.x;
@@ -327,14 +367,43 @@ __global__ __launch_bounds__(kWgThreads, SYBL_PACKED_WAVES_PER_EU) void k_scan_p
             B.t = TIME ? (const uint8_t *)P.tcol + first * P.twid : nullptr;
             B.first = first;
 
-            PackedRaw<NF> rf;
-            PackedRaw<NG> rg;
-            PackedRaw<NA> ra;
-            PackedRaw<1> rt;
             PackedTile<NF> f;
             PackedTile<NG> g;
             PackedTile<NA> a;
             PackedTile<1> t;
+            constexpr int D = NUL ? 1 : (RING > 0 ? RING : packed_depth(NF + NG + NA + (TIME ? 1 : 0)));
+            if (D > 1) {
+                // a ring of D tiles of loads in flight, consumed oldest first; no exit inside a round (a tile past the end
+                // loads nothing and its rows fail `k < left`)
+                PackedRaw<NF> rf[D];
+                PackedRaw<NG> rg[D];
+                PackedRaw<NA> ra[D];
+                PackedRaw<1> rt[D];
+                const uint32_t n_tiles = (n + kPackedTileRows - 1) / kPackedTileRows;
+                const uint32_t r_first = tid * kPackedRows;
+#pragma unroll
+                for (int d = 0; d < D; d++) {
+                    packed_issue_ring<NF, NG, NA, TIME, G1>(P, B, r_first + (uint32_t)d * kPackedTileRows, n, rf[d], rg[d], ra[d], rt[d]);
+                    __builtin_amdgcn_sched_barrier(0);  // oldest tile first: the ring is consumed in this order
+                }
+                for (uint32_t it0 = 0; it0 < n_tiles; it0 += D) {
+#pragma unroll
+                    for (int d = 0; d < D; d++) {
+                        const uint32_t r = r_first + (it0 + d) * kPackedTileRows;  // (< 2^28 + 2^14: no wrap)
+                        packed_decode_all<NF, NG, NA, TIME, G1, false>(P, rf[d], rg[d], ra[d], rt[d], f, g, a, t, 0u);
+                        packed_issue_ring<NF, NG, NA, TIME, G1>(P, B, r + (uint32_t)D * kPackedTileRows, n, rf[d], rg[d], ra[d], rt[d]);
+                        const uint32_t left = r < n ? n - r : 0u;
+#pragma unroll
+                        for (int k = 0; k < kPackedRows; k++)
+                            packed_row<NF, NG, NA, MODE, TIME, false>(P, f, g, a, t, k, (uint32_t)k < left, lds, L, matched, overflow);
+                    }
+                }
+                continue;
+            }
+            PackedRaw<NF> rf;
+            PackedRaw<NG> rg;
+            PackedRaw<NA> ra;
+            PackedRaw<1> rt;
             uint32_t r = tid * kPackedRows;
             if (r < n) {
                 packed_issue_all<NF, NG, NA, TIME, G1, NUL>(P, B, r, rf, rg, ra, rt);
@@ -553,6 +622,24 @@ static hipError_t emit_packed_launch_nf(const EmitPlan &E, int ng, int na, int n
 
 template <int NF, int NG, int NA, int MODE, bool TIME, bool G1, bool NUL>
 static hipError_t packed_launch_k1(const FastPlan &P, int n_wg, size_t lds_bytes, hipStream_t st) {
+    // SYBL_PACKED_RING=1..3 (tuning): the BASELINE shapes with an explicit ring depth, for same-box A/B runs
+    constexpr bool kAb = !NUL && ((NF == 3 && NG == 2 && NA == 2 && MODE == kFastMoments && !TIME && G1) ||
+                                  (NF == 0 && NG == 1 && NA == 2 && MODE == kFastAvgMax && !TIME && G1) ||
+                                  (NF == 0 && NG == 1 && NA == 1 && MODE == kFastAvg && TIME && !G1));
+    if (kAb) {
+        if (const char *e = getenv("SYBL_PACKED_RING")) {
+            const int d = atoi(e);
+            auto launch = [&](auto kern) {
+                hipError_t e2 = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+                if (e2 != hipSuccess) return e2;
+                hipLaunchKernelGGL(kern, dim3(n_wg), dim3(kWgThreads), lds_bytes, st, P);
+                return hipGetLastError();
+            };
+            if (d == 1) return launch(k_scan_packed<NF, NG, NA, MODE, TIME, G1, NUL, kAb ? 1 : 0>);
+            if (d == 2) return launch(k_scan_packed<NF, NG, NA, MODE, TIME, G1, NUL, kAb ? 2 : 0>);
+            if (d == 3) return launch(k_scan_packed<NF, NG, NA, MODE, TIME, G1, NUL, kAb ? 3 : 0>);
+        }
+    }
     auto k = k_scan_packed<NF, NG, NA, MODE, TIME, G1, NUL>;
     hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
