@@ -98,6 +98,7 @@ static void free_query(Query *q) {
     if (q->d_pct) hipFree(q->d_pct);
     if (q->d_mom) hipFree(q->d_mom);
     if (q->d_total) hipFree(q->d_total);
+    if (q->d_dirty) hipFree(q->d_dirty);
     if (q->h_top) hipHostFree(q->h_top);
     q->h_pct_buf.reset();
     if (q->h_mom) hipHostFree(q->h_mom);
@@ -143,6 +144,7 @@ static int scan(Query *q) {
     if (rc) return rc;
     trace.mark("partials");
     q->rs_active = false;
+    q->fused_summary = false;
     q->out_log_partial = false;
     hipStream_t st = q->ctx->stream;
     ScanPlan &P = q->plan;
@@ -189,6 +191,24 @@ static int scan(Query *q) {
         if (e != hipSuccess) return hip_fail(e, "k_emit");
         trace.mark("emit");
         SYBL_HIP(hipMemsetAsync(q->pplan.wrap_log, 0, 8, st));
+        // SYBL_FUSED_SUMMARY=1 (one workgroup per partition, one rank): the result rows' percentiles / bucket moments /
+        // Cumulative buckets come out of k_part_hist's LDS histograms instead of k_hist_summary / k_hist_total re-reading
+        // the finished table (sybl_query_allreduce withdraws it when ranks merge afterwards).  Off by default -- measured
+        // on one box (config 4, 20 steps): 4.63 ms per step fused against 4.71, but k_part_hist grows by 0.32 ms (one
+        // workgroup per CU walks its 64 pairs' percentiles four at a time) for the 0.40 ms the two kernels took.
+        q->fused_summary = query_wants_hist_summary(q) && q->pplan.split == 1 && getenv("SYBL_FUSED_SUMMARY") != nullptr;
+        q->pplan.fuse = q->fused_summary ? 1 : 0;
+        if (q->fused_summary) {
+            if ((rc = query_summary_buffers(q))) return rc;
+            const int64_t pairs = ((int64_t)P.n_cells + kMaxScatterRanks) * (int64_t)q->aggs.size();
+            SYBL_HIP(hipMemsetAsync(q->d_pct, 0, (size_t)pairs * 100 * 8, st));
+            SYBL_HIP(hipMemsetAsync(q->d_total, 0, (size_t)P.hist_stride * 8, st));
+            SYBL_HIP(hipMemsetAsync(q->d_dirty, 0, (size_t)((pairs + 31) / 32) * 4, st));
+            q->pplan.pct = q->d_pct;
+            q->pplan.mom = q->d_mom;
+            q->pplan.total = q->d_total;
+            q->pplan.dirty = q->d_dirty;
+        }
         e = launch_part_hist(q->pplan, st);
         if (e != hipSuccess) return hip_fail(e, "k_part_hist");
         e = launch_part_fix(q->pplan, st);

@@ -732,6 +732,69 @@ __global__ __launch_bounds__(kWgThreads) void k_part_hist(const PartHistPlan P) 
     if (tid < kPartCells) sum[tid] = pair_sum;
     __syncthreads();
 
+    if (P.fuse && split == 1) {
+        // What k_hist_summary / k_hist_total would read back out of HBM (see there for GetPercentiles): one wave per pair,
+        // lanes own consecutive buckets.  A pair whose counters wrapped gets wrong numbers here; k_part_fix marks it
+        // dirty and k_hist_summary redoes it from the fixed table.
+        const uint32_t total_pairs_f = (uint32_t)P.n_cells * (uint32_t)NA;
+        for (uint32_t l = wave; l < (uint32_t)kPartCells; l += kWgThreads / 64) {
+            const uint32_t pair = pair0 + l;
+            if (pair >= total_pairs_f) break;
+            const uint32_t a = pair % (uint32_t)NA;
+            const int64_t count = (int64_t)cnt[l], bsz = P.bucket_size[a], hmn = P.hmin[a], nvals = P.n_values[a];
+            const uint32_t *hl = hist + l * nw;
+            int64_t *out = P.pct + (int64_t)pair * 100;
+            int64_t sb = 0, sb2 = 0, carry = 0, carry_p = 0;
+            for (int64_t k0 = 0; k0 < nvals; k0 += 64) {
+                const int64_t k = k0 + lane;
+                const int64_t x = k < nvals ? (int64_t)((hl[k >> 1] >> ((k & 1) << 4)) & 0xFFFFu) : 0;
+                sb += k * x;
+                sb2 += k * k * x;
+                if (count == 0) continue;
+                int64_t c = x;  // inclusive scan of x over the wave
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int64_t y = __shfl_up(c, o, 64);
+                    if ((int)lane >= o) c += y;
+                }
+                c += carry;
+                int64_t pc = (100 * c) / count;
+                pc = pc < 0 ? 0 : (pc > 100 ? 100 : pc);
+                int64_t pp = __shfl_up(pc, 1, 64);
+                if (lane == 0) pp = carry_p;
+                if (k < nvals) {
+                    const int64_t val = k * bsz + hmn;
+                    for (int64_t ip = pp; ip < pc; ip++) out[ip] = val;  // (pc <= 100: ip < 100)
+                    if (k == nvals - 1 && pc < 100) out[pc] = k;
+                }
+                carry = __shfl(c, 63, 64);
+                carry_p = __shfl(pc, 63, 64);
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                sb += __shfl_xor(sb, o, 64);
+                sb2 += __shfl_xor(sb2, o, 64);
+            }
+            if (lane == 0) {
+                P.mom[(int64_t)pair * 2] = sb;
+                P.mom[(int64_t)pair * 2 + 1] = sb2;
+            }
+        }
+        // Cumulative: this partition's share of every (aggregation, bucket), one atomic per non-zero word
+        for (uint32_t b = tid; b < nv; b += kWgThreads) {
+            int64_t acc[NA];
+#pragma unroll
+            for (int a = 0; a < NA; a++) acc[a] = 0;
+            for (uint32_t l = 0; l < (uint32_t)kPartCells; l++) {
+                if (pair0 + l >= total_pairs_f) break;
+                acc[l % NA] += (int64_t)((hist[l * nw + (b >> 1)] >> ((b & 1u) << 4)) & 0xFFFFu);
+            }
+#pragma unroll
+            for (int a = 0; a < NA; a++)
+                if (acc[a] && b < (uint32_t)P.n_values[a]) gadd(P.total + P.hist_agg_off[a] + b, acc[a]);
+        }
+    }
+
     int64_t *F = P.sum_out + kHeaderWords;
     const uint32_t total_pairs = (uint32_t)P.n_cells * (uint32_t)NA;
     for (uint32_t l = 0; l < (uint32_t)kPartCells; l++) {
@@ -783,6 +846,10 @@ __global__ __launch_bounds__(256) void k_part_fix(const PartHistPlan P) {
         gadd(P.sum_out + P.hist_off + (int64_t)cell * P.hist_stride + P.hist_agg_off[a] + bucket, delta);
         if (a == 0) gadd(F + cell, delta);
         gadd(F + (int64_t)P.f_sum[a] * P.n_cells + cell, delta * P.hmin[a]);
+        if (P.fuse) {
+            gadd(P.total + P.hist_agg_off[a] + bucket, delta);
+            atomicOr(P.dirty + (pair >> 5), 1u << (pair & 31u));
+        }
     }
 }
 
@@ -896,6 +963,12 @@ __global__ __launch_bounds__(256) void k_hist_summary(const HistSummaryPlan S) {
     const int64_t *v = S.H + cell * S.hist_stride + S.agg_off[a];
     const int64_t count = S.F[(int64_t)S.f_cnt[a] * S.n_cells + cell];
     int64_t *out = S.pct + pair * 100;
+    if (S.dirty) {
+        // only the pairs k_part_hist could not summarise itself (wrapped counters): start from zeros again
+        if (!((S.dirty[pair >> 5] >> (pair & 31)) & 1u)) return;
+        out[lane] = 0;
+        if (lane + 64 < 100) out[lane + 64] = 0;
+    }
     const int64_t bs = S.bucket_size[a], hmin = S.hmin[a], nvals = S.n_values[a];
     int64_t sb = 0, sb2 = 0, carry = 0, carry_p = 0;
     // (loading the whole bucket array into registers first -- sixteen wave loads in flight -- measured slower: 0.33 ms against
@@ -975,7 +1048,8 @@ hipError_t launch_hist_summary(const HistSummaryPlan &S, int64_t *total, hipStre
     const int64_t pairs = (S.cell1 - S.cell0) * S.n_aggs;
     if (pairs <= 0) return hipSuccess;
     const int64_t cpb = 128;
-    hipLaunchKernelGGL(k_hist_total, dim3((unsigned)((S.cell1 - S.cell0 + cpb - 1) / cpb)), dim3(256), 0, st, S.H, S.hist_stride, S.cell0,
+    if (total)  // (nullptr: k_part_hist summed the Cumulative buckets itself)
+        hipLaunchKernelGGL(k_hist_total, dim3((unsigned)((S.cell1 - S.cell0 + cpb - 1) / cpb)), dim3(256), 0, st, S.H, S.hist_stride, S.cell0,
                        S.cell1, cpb, total);
     hipLaunchKernelGGL(k_hist_summary, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, st, S);
     return hipGetLastError();

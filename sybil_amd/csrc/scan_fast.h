@@ -165,6 +165,13 @@ struct PartHistPlan {
     int32_t split;                   // workgroups per partition (> 1: results are combined with atomics)
     uint32_t *wrap_log;              // [0]: entries used, then {pair, bucket | kind << 16}: 16-bit counters that wrapped
     uint32_t wrap_cap;               // entries the log holds
+    // the result rows' summaries, derived where the partition's histograms sit in LDS instead of by a second and third
+    // pass over the finished 525 MB table (k_hist_summary / k_hist_total): GetPercentiles, the bucket moments of
+    // GetStdDev, the Cumulative bucket arrays.  fuse = 0: left to those kernels (several workgroups per partition, a
+    // result that is merged across ranks first)
+    int64_t *pct, *mom, *total;
+    uint32_t *dirty;                 // bit per pair: a logged wrap touched it (k_part_fix): k_hist_summary redoes those
+    int32_t fuse, pad_;
     int32_t n_values[kFastMaxA], f_sum[kFastMaxA], m_max[kFastMaxA];
     int64_t hmin[kFastMaxA], bucket_size[kFastMaxA], hist_agg_off[kFastMaxA];
     double pinv_bucket[kFastMaxA];   // 1 / BucketSize scaled by (1 - 2^-40): the quotient estimate is never above the true one
