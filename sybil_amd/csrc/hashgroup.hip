@@ -309,28 +309,30 @@ __global__ __launch_bounds__(kWgThreads) void k_scan_hash_fast(const FastPlan P,
             const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)at), hi = __builtin_amdgcn_readfirstlane((uint32_t)(at >> 32));
             const int64_t row0 = (int64_t)(((uint64_t)hi << 32) | lo);
             const uint32_t lane_row = (uint32_t)(at - row0);
-            if (P.wcol) fast_issue(P.wcol, P.wwid, nullptr, row0, lane_row, rw.v[0], rw.pw[0]);
-            if (TIME) fast_issue(P.tcol, P.twid, P.tvalid, row0, lane_row, rt.v[0], rt.pw[0]);
+            const FastPlan &Q = plan_fresh<true>(P);
+            if (Q.wcol) fast_issue(Q.wcol, Q.wwid, nullptr, row0, lane_row, rw.v[0], rw.pw[0]);
+            if (TIME) fast_issue(Q.tcol, Q.twid, Q.tvalid, row0, lane_row, rt.v[0], rt.pw[0]);
 #pragma unroll
             for (int c = 0; c < kFastMaxF; c++)
-                if (c < nf) fast_issue(P.fcol[c], P.fwid[c], P.fvalid[c], row0, lane_row, rf.v[c], rf.pw[c]);
+                if (c < nf) fast_issue(Q.fcol[c], Q.fwid[c], Q.fvalid[c], row0, lane_row, rf.v[c], rf.pw[c]);
 #pragma unroll
             for (int c = 0; c < kFastMaxG; c++)
-                if (c < ng) fast_issue(P.gcol[c], P.gwid[c], P.gvalid[c], row0, lane_row, rg.v[c], rg.pw[c]);
+                if (c < ng) fast_issue(Q.gcol[c], Q.gwid[c], Q.gvalid[c], row0, lane_row, rg.v[c], rg.pw[c]);
 #pragma unroll
-            for (int c = 0; c < NA; c++) fast_issue(P.acol[c], P.awid[c], P.avalid[c], row0, lane_row, ra.v[c], ra.pw[c]);
+            for (int c = 0; c < NA; c++) fast_issue(Q.acol[c], Q.awid[c], Q.avalid[c], row0, lane_row, ra.v[c], ra.pw[c]);
         };
         auto decode = [&](int64_t at) {
-            if (P.wcol) fast_decode(P.wwid, P.wbase, rw.v[0], rw.pw[0], at, w0.v[0], w0.pop[0]);
-            if (TIME) fast_decode(P.twid, P.tbase, rt.v[0], rt.pw[0], at, t0.v[0], t0.pop[0]);
+            const FastPlan &Q = plan_fresh<true>(P);
+            if (Q.wcol) fast_decode(Q.wwid, Q.wbase, rw.v[0], rw.pw[0], at, w0.v[0], w0.pop[0]);
+            if (TIME) fast_decode(Q.twid, Q.tbase, rt.v[0], rt.pw[0], at, t0.v[0], t0.pop[0]);
 #pragma unroll
             for (int c = 0; c < kFastMaxF; c++)
-                if (c < nf) fast_decode(P.fwid[c], P.fbase[c], rf.v[c], rf.pw[c], at, f0.v[c], f0.pop[c]);
+                if (c < nf) fast_decode(Q.fwid[c], Q.fbase[c], rf.v[c], rf.pw[c], at, f0.v[c], f0.pop[c]);
 #pragma unroll
             for (int c = 0; c < kFastMaxG; c++)
-                if (c < ng) fast_decode(P.gwid[c], P.gbase[c], rg.v[c], rg.pw[c], at, g0.v[c], g0.pop[c]);
+                if (c < ng) fast_decode(Q.gwid[c], Q.gbase[c], rg.v[c], rg.pw[c], at, g0.v[c], g0.pop[c]);
 #pragma unroll
-            for (int c = 0; c < NA; c++) fast_decode(P.awid[c], P.abase[c], ra.v[c], ra.pw[c], at, a0.v[c], a0.pop[c]);
+            for (int c = 0; c < NA; c++) fast_decode(Q.awid[c], Q.abase[c], ra.v[c], ra.pw[c], at, a0.v[c], a0.pop[c]);
         };
         if (row < end) {
             issue(row);

@@ -256,6 +256,18 @@ __device__ __forceinline__ void fast_decode(int width, int64_t base, const fu32x
     pop = (pw >> (row & 31)) & 3u;
 }
 
+// GEN bodies name ~150 plan words; hoisted out of the tile loop they do not fit the 100 scalar registers and come back
+// through v_readlane.  plan_fresh() hands out the kernel argument again behind a compiler barrier, so the words a stage
+// uses are s_load'ed (scalar cache) where they are used.
+template <bool FRESH>
+__device__ __forceinline__ const FastPlan &plan_fresh(const FastPlan &P) {
+    if (!FRESH) return P;
+    typedef const char __attribute__((address_space(4))) *KP;
+    KP p = (KP)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return *(const FastPlan *)p;
+}
+
 template <int NF, int NG, int NA, bool TIME>
 __device__ __forceinline__ void fast_issue_all(const FastPlan &P, int64_t row, FastRaw<NF> &f, FastRaw<NG> &g, FastRaw<NA> &a,
                                                FastRaw<1> &t, FastRaw<1> &w) {
@@ -263,28 +275,30 @@ __device__ __forceinline__ void fast_issue_all(const FastPlan &P, int64_t row, F
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)row), hi = __builtin_amdgcn_readfirstlane((uint32_t)(row >> 32));
     const int64_t row0 = (int64_t)(((uint64_t)hi << 32) | lo);
     const uint32_t lane_row = (uint32_t)(row - row0);
-    if (P.wcol) fast_issue(P.wcol, P.wwid, nullptr, row0, lane_row, w.v[0], w.pw[0]);
-    if (TIME) fast_issue(P.tcol, P.twid, P.tvalid, row0, lane_row, t.v[0], t.pw[0]);
+    const FastPlan &Q = plan_fresh<true>(P);
+    if (Q.wcol) fast_issue(Q.wcol, Q.wwid, nullptr, row0, lane_row, w.v[0], w.pw[0]);
+    if (TIME) fast_issue(Q.tcol, Q.twid, Q.tvalid, row0, lane_row, t.v[0], t.pw[0]);
 #pragma unroll
-    for (int c = 0; c < NF; c++) fast_issue(P.fcol[c], P.fwid[c], P.fvalid[c], row0, lane_row, f.v[c], f.pw[c]);
+    for (int c = 0; c < NF; c++) fast_issue(Q.fcol[c], Q.fwid[c], Q.fvalid[c], row0, lane_row, f.v[c], f.pw[c]);
 #pragma unroll
-    for (int c = 0; c < NG; c++) fast_issue(P.gcol[c], P.gwid[c], P.gvalid[c], row0, lane_row, g.v[c], g.pw[c]);
+    for (int c = 0; c < NG; c++) fast_issue(Q.gcol[c], Q.gwid[c], Q.gvalid[c], row0, lane_row, g.v[c], g.pw[c]);
 #pragma unroll
-    for (int c = 0; c < NA; c++) fast_issue(P.acol[c], P.awid[c], P.avalid[c], row0, lane_row, a.v[c], a.pw[c]);
+    for (int c = 0; c < NA; c++) fast_issue(Q.acol[c], Q.awid[c], Q.avalid[c], row0, lane_row, a.v[c], a.pw[c]);
 }
 
 template <int NF, int NG, int NA, bool TIME>
 __device__ __forceinline__ void fast_decode_all(const FastPlan &P, int64_t row, const FastRaw<NF> &rf, const FastRaw<NG> &rg,
                                                 const FastRaw<NA> &ra, const FastRaw<1> &rt, const FastRaw<1> &rw, FastTile<NF> &f,
                                                 FastTile<NG> &g, FastTile<NA> &a, FastTile<1> &t, FastTile<1> &w) {
-    if (P.wcol) fast_decode(P.wwid, P.wbase, rw.v[0], rw.pw[0], row, w.v[0], w.pop[0]);
-    if (TIME) fast_decode(P.twid, P.tbase, rt.v[0], rt.pw[0], row, t.v[0], t.pop[0]);
+    const FastPlan &Q = plan_fresh<true>(P);
+    if (Q.wcol) fast_decode(Q.wwid, Q.wbase, rw.v[0], rw.pw[0], row, w.v[0], w.pop[0]);
+    if (TIME) fast_decode(Q.twid, Q.tbase, rt.v[0], rt.pw[0], row, t.v[0], t.pop[0]);
 #pragma unroll
-    for (int c = 0; c < NF; c++) fast_decode(P.fwid[c], P.fbase[c], rf.v[c], rf.pw[c], row, f.v[c], f.pop[c]);
+    for (int c = 0; c < NF; c++) fast_decode(Q.fwid[c], Q.fbase[c], rf.v[c], rf.pw[c], row, f.v[c], f.pop[c]);
 #pragma unroll
-    for (int c = 0; c < NG; c++) fast_decode(P.gwid[c], P.gbase[c], rg.v[c], rg.pw[c], row, g.v[c], g.pop[c]);
+    for (int c = 0; c < NG; c++) fast_decode(Q.gwid[c], Q.gbase[c], rg.v[c], rg.pw[c], row, g.v[c], g.pop[c]);
 #pragma unroll
-    for (int c = 0; c < NA; c++) fast_decode(P.awid[c], P.abase[c], ra.v[c], ra.pw[c], row, a.v[c], a.pop[c]);
+    for (int c = 0; c < NA; c++) fast_decode(Q.awid[c], Q.abase[c], ra.v[c], ra.pw[c], row, a.v[c], a.pop[c]);
 }
 
 // the plain kernels (and k_emit) are compiled for canonical, fully populated int64 columns: two rows = one
@@ -326,12 +340,13 @@ __device__ __forceinline__ void fast_max64(int64_t *tab, uint64_t idx, int64_t v
 // time value); 1: `cell` is the row's cell (KEY64: its composite key, hash group-by); 2: key / time bucket outside the
 // declared bounds.  ng: the group columns actually present (== NG for the direct-mapped kernels).
 template <int NF, int NG, bool TIME, bool GEN, bool KEY64>
-__device__ __forceinline__ int fast_prepare(const FastPlan &P, const FastTile<NF> &f, const FastTile<NG> &g, const FastTile<1> &t,
+__device__ __forceinline__ int fast_prepare(const FastPlan &P0, const FastTile<NF> &f, const FastTile<NG> &g, const FastTile<1> &t,
                                             const int r, const int nf, const int ng, uint64_t &cell, uint32_t &matched) {
     bool pass = true;
 #pragma unroll
     for (int c = 0; c < NF; c++) {
         if (c >= nf) break;
+        const FastPlan &P = plan_fresh<GEN>(P0);
         const int64_t x = r == 0 ? f.v[c].x : f.v[c].y;
         if (GEN && P.fmask[c]) {
             // StrFilter eq / neq / re / nre, evaluated per dictionary id on the host (filter.go:199-250)
@@ -353,6 +368,7 @@ __device__ __forceinline__ int fast_prepare(const FastPlan &P, const FastTile<NF
 #pragma unroll
     for (int c = 0; c < NG; c++) {
         if (c >= ng) break;
+        const FastPlan &P = plan_fresh<GEN>(P0);
         const int64_t x = r == 0 ? g.v[c].x : g.v[c].y;
         if (GEN && !((g.pop[c] >> r) & 1u)) {
             // MISSING_VALUE key (aggregate.go:138): its own digit, or the digit of the value -1
@@ -374,6 +390,7 @@ __device__ __forceinline__ int fast_prepare(const FastPlan &P, const FastTile<NF
             cell = (uint32_t)cell + (uint32_t)d * (uint32_t)P.gstride[c];  // aggregate.go:125-143 as a direct-mapped index
         }
     }
+    const FastPlan &P = plan_fresh<GEN>(P0);
     if (TIME && GEN && !((t.pop[0] >> r) & 1u)) return 0;  // no time value: dropped after it was counted (aggregate.go:147-153)
     if (TIME) {
         // val = int(val) / TimeBucket * TimeBucket, truncating (aggregate.go:174); |t| < 2^51 here
@@ -399,19 +416,21 @@ __device__ __forceinline__ int fast_prepare(const FastPlan &P, const FastTile<NF
 // the cell's number in the global table (bucket arrays, [gcell][hist_stride]); lcell: its place in the workgroup's LDS
 // bucket arrays (hist_lds); logkey: what the outlier log calls the group.
 template <int NA, int MODE, bool GEN, bool LDS>
-__device__ __forceinline__ void fast_accumulate(const FastPlan &P, const FastTile<NA> &a, const FastTile<1> &w, const int r,
+__device__ __forceinline__ void fast_accumulate(const FastPlan &P0, const FastTile<NA> &a, const FastTile<1> &w, const int r,
                                                 int64_t *tab, int64_t *maxtab, const uint64_t ncell, const uint32_t rs, const uint64_t cidx,
                                                 const int64_t gcell, const uint32_t lcell, const int64_t logkey, uint32_t *hist32,
                                                 uint32_t &overflow) {
     // weight := r.Ints[WEIGHT_COL] (aggregate.go:100-102); 1 without a weight column -- and then no 64-bit multiply
     // per accumulated word (the branch is wave-uniform; the GEN body spent three of them per aggregation on wt == 1)
-    const bool weighted = GEN && P.wcol != nullptr;
+    const FastPlan &Ph = plan_fresh<GEN>(P0);
+    const bool weighted = GEN && Ph.wcol != nullptr;
     const int64_t wt = weighted ? (r == 0 ? w.v[0].x : w.v[0].y) : 1;
     auto times_w = [&](int64_t v) -> int64_t { return weighted ? (int64_t)((uint64_t)v * (uint64_t)wt) : v; };
     fast_add64<LDS>(tab, cidx, wt);  // Result.Count += weight (aggregate.go:203)
-    if (GEN && P.f_samples >= 0) fast_add64<LDS>(tab, (((uint64_t)(uint32_t)P.f_samples * ncell) << rs) + cidx, 1);  // Result.Samples++
+    if (GEN && Ph.f_samples >= 0) fast_add64<LDS>(tab, (((uint64_t)(uint32_t)Ph.f_samples * ncell) << rs) + cidx, 1);  // Result.Samples++
 #pragma unroll
     for (int c = 0; c < NA; c++) {
+        const FastPlan &P = plan_fresh<GEN>(P0);
         const int64_t x = r == 0 ? a.v[c].x : a.v[c].y;
         if (GEN) {
             if (!((a.pop[c] >> r) & 1u)) continue;
