@@ -22,6 +22,7 @@
 // and be merged with a SUM/MAX all-reduce.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "plan.h"
 #include "scan_fast.h"
@@ -578,7 +579,9 @@ __global__ __launch_bounds__(kWgThreads) void k_part_hist(const PartHistPlan P) 
     }
 
     const uint32_t split = (uint32_t)P.split;
-    const uint32_t part = blockIdx.x / split, sub = blockIdx.x % split;
+    // (wave-uniform by construction; said so explicitly: the divide goes through the vector ALU, and with these in
+    // vector registers every region loop and record load below became a divergent loop / a waterfall loop)
+    const uint32_t part = __builtin_amdgcn_readfirstlane(blockIdx.x / split), sub = __builtin_amdgcn_readfirstlane(blockIdx.x % split);
     const uint32_t *recs = P.recs;
     const uint32_t pair0 = part * kPartCells;
     unsigned long long *my_sum = sum + (tid & (kPartSumRep - 1));  // [pair][replica]: the replicas of a pair in different banks
@@ -600,17 +603,24 @@ __global__ __launch_bounds__(kWgThreads) void k_part_hist(const PartHistPlan P) 
         if (n32 - __umul24(b, bs) >= bs) b += 1;
         return b;
     };
-    // returns the word as it was before the add, shifted so that the bucket's own field is the low half (an even
-    // bucket's neighbour field is then the high half); 0 for a padding record
-    auto add_record = [&](uint32_t rec) -> uint32_t {
-        if (rec == kRecSentinel) return 0u;
+    // One record: returns the word as it was before the add, shifted so that the bucket's own field is the low half (an
+    // even bucket's neighbour field is then the high half).  No branch per record: a padding record (or a lane past the
+    // region's end) aims its two atomics at a scratch word of its own -- behind the region table -- instead of being
+    // skipped, so the sixteen adds of a batch are in flight together and their results are looked at once (what comes
+    // back from a scratch word is checked for liveness again on the wrap path).  Measured against sixteen `if (live)`
+    // blocks, each waiting for its returned counter: the same 1.3 ms -- the kernel is not bound there.
+    uint32_t *dummy32 = nullptr;
+    unsigned long long *dummy64 = nullptr;
+    auto add_record = [&](uint32_t rec, bool in) -> uint32_t {
+        const bool live = in && rec != kRecSentinel;
         uint32_t local, n32;
         const uint32_t b = bucket_of(rec, local, n32);
-        // (the pair's count is the sum of its buckets, taken at read-out; sum(v - h.Min) is accumulated exactly)
         const uint32_t sh = (b & 1u) << 4;
-        const uint32_t old = __hip_atomic_fetch_add(hist + local * nw + (b >> 1), 1u << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(my_sum + local * kPartSumRep, (unsigned long long)n32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (TRACK_MAX) {
+        uint32_t *hp = live ? hist + __umul24(local, nw) + (b >> 1) : dummy32;
+        unsigned long long *sp = live ? my_sum + local * kPartSumRep : dummy64;
+        const uint32_t old = __hip_atomic_fetch_add(hp, 1u << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(sp, (unsigned long long)n32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (TRACK_MAX && live) {
             const uint32_t a = two ? (local & 1u) : 0u;
             if (P.m_max[a] >= 0) {
                 const long long v = (long long)((unsigned long long)P.hmin[a] + (unsigned long long)n32);
@@ -632,12 +642,14 @@ __global__ __launch_bounds__(kWgThreads) void k_part_hist(const PartHistPlan P) 
     // (four records) per lane and kPartUnroll loads per lane in flight twice over (current + next batch) -- raw buffer
     // loads whose descriptor is the region, so nothing depends on a lane's bounds when the loads are issued.
     typedef unsigned int rec4 __attribute__((ext_vector_type(4)));
-    const uint32_t lane = tid & 63u, wave = tid >> 6, nb1 = ((uint32_t)P.n_parts << P.sub_shift) + 1u;
+    const uint32_t lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nb1 = ((uint32_t)P.n_parts << P.sub_shift) + 1u;
     const uint32_t b_lo = part << P.sub_shift, b_hi = (part + 1u) << P.sub_shift;
-    const uint32_t n_reg = (uint32_t)P.n_wg > sub ? ((uint32_t)P.n_wg - sub + split - 1u) / split : 0u;
+    const uint32_t n_reg = __builtin_amdgcn_readfirstlane((uint32_t)P.n_wg > sub ? ((uint32_t)P.n_wg - sub + split - 1u) / split : 0u);
     constexpr uint32_t kBatch = 64u * kPartUnroll;  // pieces per wave and batch
     // this workgroup's regions {first chunk, pieces}, fetched once (boff is [workgroup][bin]: a strided read)
     uint2 *regions = (uint2 *)(vmax + kPartCells);  // [n_reg]
+    dummy64 = (unsigned long long *)(regions + n_reg) + lane;          // [64]
+    dummy32 = (uint32_t *)((unsigned long long *)(regions + n_reg) + 64) + lane;  // [64]
     for (uint32_t k = tid; k < n_reg; k += kWgThreads) {
         const uint32_t w = sub + k * split;
         const uint32_t *bo = P.boff + (size_t)w * nb1;
@@ -662,8 +674,11 @@ __global__ __launch_bounds__(kWgThreads) void k_part_hist(const PartHistPlan P) 
         }
     };
     auto issue = [&](rec4 (&d)[kPartUnroll], uint32_t &first, uint32_t &pieces) {
+        const uint64_t at = (uint64_t)(recs + (size_t)c0 * kEmitChunk);  // (wave-uniform: kept in scalar registers)
+        const uint32_t at_lo = __builtin_amdgcn_readfirstlane((uint32_t)at), at_hi = __builtin_amdgcn_readfirstlane((uint32_t)(at >> 32));
+        const uint64_t at_s = (uint64_t)at_lo | (uint64_t)at_hi << 32;  // (the builtin returns int: through uint32_t, no sign extension)
         const __amdgpu_buffer_rsrc_t rsrc =
-            __builtin_amdgcn_make_buffer_rsrc((void *)(recs + (size_t)c0 * kEmitChunk), 0, (int)(n4 * 16u), (int)0x00020000);
+            __builtin_amdgcn_make_buffer_rsrc((void *)at_s, 0, (int)__builtin_amdgcn_readfirstlane(n4 * 16u), (int)0x00020000);
 #pragma unroll
         for (int u = 0; u < kPartUnroll; u++) d[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)((i0 + (uint32_t)u * 64u + lane) * 16u), 0, 2);
         first = i0;
@@ -686,10 +701,10 @@ __global__ __launch_bounds__(kWgThreads) void k_part_hist(const PartHistPlan P) 
 #pragma unroll
         for (int u = 0; u < kPartUnroll; u++) {
             const bool in = cur_first + (uint32_t)u * 64u + lane < cur_n;
-            seen[u][0] = add_record(in ? cur[u].x : kRecSentinel);
-            seen[u][1] = add_record(in ? cur[u].y : kRecSentinel);
-            seen[u][2] = add_record(in ? cur[u].z : kRecSentinel);
-            seen[u][3] = add_record(in ? cur[u].w : kRecSentinel);
+            seen[u][0] = add_record(cur[u].x, in);
+            seen[u][1] = add_record(cur[u].y, in);
+            seen[u][2] = add_record(cur[u].z, in);
+            seen[u][3] = add_record(cur[u].w, in);
         }
         bool any = false;
 #pragma unroll
@@ -698,10 +713,11 @@ __global__ __launch_bounds__(kWgThreads) void k_part_hist(const PartHistPlan P) 
         if (any) {
 #pragma unroll
             for (int u = 0; u < kPartUnroll; u++) {
-                if (wrapped(seen[u][0])) log_wrap(cur[u].x, seen[u][0]);
-                if (wrapped(seen[u][1])) log_wrap(cur[u].y, seen[u][1]);
-                if (wrapped(seen[u][2])) log_wrap(cur[u].z, seen[u][2]);
-                if (wrapped(seen[u][3])) log_wrap(cur[u].w, seen[u][3]);
+                const bool in = cur_first + (uint32_t)u * 64u + lane < cur_n;  // (a scratch word's old value is no wrap)
+                if (in && cur[u].x != kRecSentinel && wrapped(seen[u][0])) log_wrap(cur[u].x, seen[u][0]);
+                if (in && cur[u].y != kRecSentinel && wrapped(seen[u][1])) log_wrap(cur[u].y, seen[u][1]);
+                if (in && cur[u].z != kRecSentinel && wrapped(seen[u][2])) log_wrap(cur[u].z, seen[u][2]);
+                if (in && cur[u].w != kRecSentinel && wrapped(seen[u][3])) log_wrap(cur[u].w, seen[u][3]);
             }
         }
 #pragma unroll
@@ -907,7 +923,8 @@ static hipError_t part_hist_launch(const PartHistPlan &P, size_t lds, hipStream_
 hipError_t launch_part_hist(const PartHistPlan &P, hipStream_t st) {
     if (P.n_parts <= 0) return hipSuccess;
     const uint32_t n_reg = ((uint32_t)P.n_wg + (uint32_t)P.split - 1u) / (uint32_t)P.split;
-    size_t lds = ((size_t)kPartCells * ((P.nv_max + 1) / 2) + kPartCells) * 4 + (size_t)kPartCells * (kPartSumRep + 1) * 8 + (size_t)n_reg * 8 + 16;
+    size_t lds = ((size_t)kPartCells * ((P.nv_max + 1) / 2) + kPartCells) * 4 + (size_t)kPartCells * (kPartSumRep + 1) * 8 + (size_t)n_reg * 8 + 16 +
+                 64 * 12;  // + a scratch word pair per lane (add_record)
     const bool track_max = P.m_max[0] >= 0 || (P.n_aggs > 1 && P.m_max[1] >= 0);
     if (P.n_aggs == 1) return track_max ? part_hist_launch<1, true>(P, lds, st) : part_hist_launch<1, false>(P, lds, st);
     if (P.n_aggs == 2) return track_max ? part_hist_launch<2, true>(P, lds, st) : part_hist_launch<2, false>(P, lds, st);
