@@ -30,41 +30,12 @@
 #include <type_traits>
 
 #include "engine.h"
+#include "hash_table.h"
 #include "scan_generic.h"
-#include "scan_packed.h"
 
 namespace sybl {
 
-constexpr int kHashLdsProbes = 8;  // probes a row spends on the LDS staging table before it goes to HBM
-
-// find the key's slot or claim a free one (linear probing; a claimed slot never changes hands); -1: the table is full.
-// The probe count is bounded: with twice as many slots as keys a probe sequence is a handful of slots long, and a key that
-// finds neither itself nor a free slot within kHashMaxProbes means the table holds (nearly) as many keys as slots -- the
-// query is going to fail with SYBL_E_NOMEM.  The first row that gives up says so in the header, and every later row that
-// would have to insert a key gives up at once instead of walking a full table (up to 2^27 device-scope loads per row).
-constexpr uint32_t kHashMaxProbes = 512;
-__device__ __forceinline__ int32_t hash_find_or_insert(uint64_t *keys, uint32_t mask, uint64_t key, int64_t *hdr) {
-    uint32_t h = (uint32_t)(splitmix64(key) >> 32) & mask;
-    const uint32_t limit = mask + 1u < kHashMaxProbes ? mask + 1u : kHashMaxProbes;
-    for (uint32_t probe = 0; probe < limit; probe++) {
-        uint64_t k = __hip_atomic_load(keys + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (k == kHashEmpty) {
-            if (__hip_atomic_load(hdr + kHdrHashFull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return -1;  // (lost already)
-            unsigned long long expect = kHashEmpty;
-            if (__hip_atomic_compare_exchange_strong((unsigned long long *)keys + h, &expect, (unsigned long long)key, __ATOMIC_RELAXED,
-                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-                k = key;
-            else
-                k = expect;
-        }
-        if (k == key) return (int32_t)h;
-        h = (h + 1) & mask;
-        // a long walk: has another row already found the table full?
-        if ((probe & 31u) == 31u && __hip_atomic_load(hdr + kHdrHashFull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return -1;
-    }
-    __hip_atomic_fetch_add(hdr + kHdrHashFull, (int64_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return -1;
-}
+// (probe limits and hash_find_or_insert: hash_table.h; k_scan_hash_fast: hashfast.hip; k_scan_hash_packed: hashpacked.hip)
 
 // one row: LDS staging table first, the global table when the key finds no room there
 template <int NC>
@@ -214,530 +185,6 @@ hipError_t launch_scan_hash(const ScanPlan *d_plan, int n_slots, int n_wg, size_
     case 10: return launch_scan_hash_nc<10>(d_plan, n_wg, lds_bytes, st);
     case 11: return launch_scan_hash_nc<11>(d_plan, n_wg, lds_bytes, st);
     case 12: return launch_scan_hash_nc<12>(d_plan, n_wg, lds_bytes, st);
-    default: return hipErrorInvalidValue;
-    }
-}
-
-// ---------------------------------------------------------------- the role-specialised form
-// k_scan_hash_fast: the same two table levels behind the row body of k_scan_fast<GEN> (scan_fast.h) -- the plan by value
-// in scalar registers, roles known at compile time, raw 16-byte buffer loads of any stored width decoded when the tile is
-// consumed -- for the queries select_fast_path would take if their keys direct-mapped: range / id-mask / neq filters,
-// up to four group columns, up to two aggregations, optional time and weight columns.  Round 2 measured the
-// plan-interpreting k_scan_hash at 26 ms per 1e9 rows on config 3's 1024 groups (every row staged in LDS: the
-// interpretation, not the table, was the cost).  nf / ng are run-time counts (a wave-uniform `break` per column): one
-// instantiation per (aggregations, mode, time) instead of one per column-count combination.
-template <int NA, int MODE, bool TIME>
-__global__ __launch_bounds__(kWgThreads) void k_scan_hash_fast(const FastPlan P, uint64_t *hash_keys, const int nf, const int ng, const int L_,
-                                                               const int F, const int M) {
-    extern __shared__ int64_t lds[];
-    __shared__ uint32_t l_used;
-    const uint32_t tid = threadIdx.x;
-    const uint32_t L = (uint32_t)L_;  // LDS staging slots (a power of two); 0: every row goes to the global table
-    uint64_t *lkeys = (uint64_t *)lds;
-    int64_t *lsum = lds + L, *lmax = lsum + (size_t)F * L;
-    for (uint32_t i = tid; i < L; i += kWgThreads) lkeys[i] = kHashEmpty;
-    for (uint32_t i = tid; i < (uint32_t)F * L; i += kWgThreads) lsum[i] = 0;
-    for (uint32_t i = tid; i < (uint32_t)M * L; i += kWgThreads) lmax[i] = INT64_MIN;
-    if (tid == 0) l_used = 0;
-    __syncthreads();
-    int64_t *gsum = P.sum_out + kHeaderWords, *gmax = P.max_out;
-    const uint32_t gmask = (uint32_t)P.n_cells - 1u;
-    const uint32_t lmask = L - 1u, l_limit = L - (L >> 2);
-
-    uint32_t matched = 0, overflow = 0, full = 0;
-    auto one_row = [&](const FastTile<kFastMaxF> &f, const FastTile<kFastMaxG> &g, const FastTile<NA> &a, const FastTile<1> &t,
-                       const FastTile<1> &w, const int r) {
-        uint64_t key;
-        const int st = fast_prepare<kFastMaxF, kFastMaxG, TIME, true, true>(P, f, g, t, r, nf, ng, key, matched);
-        if (st == 0) return;
-        if (st == 2) {
-            overflow += 1;
-            return;
-        }
-        int32_t ls = -1;
-        if (L > 0) {
-            // (the low half of the hash: independent of the slot the key gets in the global table)
-            uint32_t h = (uint32_t)splitmix64(key) & lmask;
-            for (int probe = 0; probe < kHashLdsProbes; probe++) {
-                uint64_t k = __hip_atomic_load(lkeys + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (k == kHashEmpty) {
-                    if (__hip_atomic_load(&l_used, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= l_limit) break;
-                    unsigned long long expect = kHashEmpty;
-                    if (__hip_atomic_compare_exchange_strong((unsigned long long *)lkeys + h, &expect, (unsigned long long)key, __ATOMIC_RELAXED,
-                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
-                        __hip_atomic_fetch_add(&l_used, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        k = key;
-                    } else {
-                        k = expect;
-                    }
-                }
-                if (k == key) {
-                    ls = (int32_t)h;
-                    break;
-                }
-                h = (h + 1) & lmask;
-            }
-        }
-        if (ls >= 0) {
-            fast_accumulate<NA, MODE, true, true>(P, a, w, r, lsum, lmax, (uint64_t)L, 0u, (uint64_t)(uint32_t)ls, (int64_t)-1, 0u, (int64_t)key, nullptr,
-                                                  overflow);
-        } else {
-            const int32_t gs = hash_find_or_insert(hash_keys, gmask, key, P.sum_out);
-            if (gs < 0) {  // more distinct keys than the table holds: reported by finalize
-                full += 1;
-                return;
-            }
-            fast_accumulate<NA, MODE, true, false>(P, a, w, r, gsum, gmax, (uint64_t)(uint32_t)P.n_cells, 0u, (uint64_t)(uint32_t)gs, (int64_t)gs, 0u,
-                                                   (int64_t)key, nullptr, overflow);
-        }
-    };
-
-    const int s0 = P.wg_seg_begin[blockIdx.x], s1 = P.wg_seg_begin[blockIdx.x + 1];
-    for (int si = s0; si < s1; si++) {
-        const Segment seg = P.segs[si];
-        const int64_t end = seg.start + seg.n;
-        int64_t row = seg.start + (int64_t)tid * kRowsPerThread;
-        FastTile<kFastMaxF> f0;
-        FastTile<kFastMaxG> g0;
-        FastTile<NA> a0;
-        FastTile<1> t0, w0;
-        FastRaw<kFastMaxF> rf;
-        FastRaw<kFastMaxG> rg;
-        FastRaw<NA> ra;
-        FastRaw<1> rt, rw;
-        auto issue = [&](int64_t at) {
-            const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)at), hi = __builtin_amdgcn_readfirstlane((uint32_t)(at >> 32));
-            const int64_t row0 = (int64_t)(((uint64_t)hi << 32) | lo);
-            const uint32_t lane_row = (uint32_t)(at - row0);
-            const FastPlan &Q = plan_fresh<true>(P);
-            if (Q.wcol) fast_issue(Q.wcol, Q.wwid, nullptr, row0, lane_row, rw.v[0], rw.pw[0]);
-            if (TIME) fast_issue(Q.tcol, Q.twid, Q.tvalid, row0, lane_row, rt.v[0], rt.pw[0]);
-#pragma unroll
-            for (int c = 0; c < kFastMaxF; c++)
-                if (c < nf) fast_issue(Q.fcol[c], Q.fwid[c], Q.fvalid[c], row0, lane_row, rf.v[c], rf.pw[c]);
-#pragma unroll
-            for (int c = 0; c < kFastMaxG; c++)
-                if (c < ng) fast_issue(Q.gcol[c], Q.gwid[c], Q.gvalid[c], row0, lane_row, rg.v[c], rg.pw[c]);
-#pragma unroll
-            for (int c = 0; c < NA; c++) fast_issue(Q.acol[c], Q.awid[c], Q.avalid[c], row0, lane_row, ra.v[c], ra.pw[c]);
-        };
-        auto decode = [&](int64_t at) {
-            const FastPlan &Q = plan_fresh<true>(P);
-            if (Q.wcol) fast_decode(Q.wwid, Q.wbase, rw.v[0], rw.pw[0], at, w0.v[0], w0.pop[0]);
-            if (TIME) fast_decode(Q.twid, Q.tbase, rt.v[0], rt.pw[0], at, t0.v[0], t0.pop[0]);
-#pragma unroll
-            for (int c = 0; c < kFastMaxF; c++)
-                if (c < nf) fast_decode(Q.fwid[c], Q.fbase[c], rf.v[c], rf.pw[c], at, f0.v[c], f0.pop[c]);
-#pragma unroll
-            for (int c = 0; c < kFastMaxG; c++)
-                if (c < ng) fast_decode(Q.gwid[c], Q.gbase[c], rg.v[c], rg.pw[c], at, g0.v[c], g0.pop[c]);
-#pragma unroll
-            for (int c = 0; c < NA; c++) fast_decode(Q.awid[c], Q.abase[c], ra.v[c], ra.pw[c], at, a0.v[c], a0.pop[c]);
-        };
-        if (row < end) {
-            issue(row);
-            decode(row);
-        }
-        for (; row < end; row += kTileRows) {
-            const int64_t nrow = row + kTileRows;
-            if (nrow < end) issue(nrow);
-            one_row(f0, g0, a0, t0, w0, 0);
-            if (row + 1 < end) one_row(f0, g0, a0, t0, w0, 1);
-            if (nrow < end) decode(nrow);
-        }
-    }
-
-    // flush the staging table: one find-or-claim per staged key, one atomic per non-zero field
-    if (L > 0) {
-        __syncthreads();
-        for (uint32_t i = tid; i < L; i += kWgThreads) {
-            const uint64_t k = lkeys[i];
-            if (k == kHashEmpty) continue;
-            const int32_t gs = hash_find_or_insert(hash_keys, gmask, k, P.sum_out);
-            if (gs < 0) {
-                full += 1;
-                continue;
-            }
-            for (int fi = 0; fi < F; fi++) {
-                const int64_t v = lsum[(size_t)fi * L + i];
-                if (v != 0) gadd(gsum + (int64_t)fi * P.n_cells + gs, v);
-            }
-            for (int m = 0; m < M; m++) {
-                const int64_t v = lmax[(size_t)m * L + i];
-                if (v != INT64_MIN) __hip_atomic_fetch_max(gmax + (int64_t)m * P.n_cells + gs, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-    }
-    int64_t m64 = wave_sum((int64_t)matched), o64 = wave_sum((int64_t)overflow), f64 = wave_sum((int64_t)full);
-    if ((tid & 63) == 0) {
-        if (m64) gadd(P.sum_out + kHdrMatched, m64);
-        if (o64) gadd(P.sum_out + kHdrOverflow, o64);
-        if (f64) gadd(P.sum_out + kHdrHashFull, f64);
-    }
-}
-
-template <int NA, int MODE, bool TIME>
-static hipError_t hash_fast_launch(const FastPlan &P, uint64_t *keys, int nf, int ng, int L, int F, int M, int n_wg, size_t lds_bytes, hipStream_t st) {
-    auto kfn = k_scan_hash_fast<NA, MODE, TIME>;
-    hipError_t e = hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max<size_t>(lds_bytes, 16));
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kfn, dim3(n_wg), dim3(kWgThreads), lds_bytes, st, P, keys, nf, ng, L, F, M);
-    return hipGetLastError();
-}
-
-template <int NA, int MODE>
-static hipError_t hash_fast_time(const FastPlan &P, uint64_t *keys, int nf, int ng, bool time, int L, int F, int M, int n_wg, size_t lds, hipStream_t st) {
-    return time ? hash_fast_launch<NA, MODE, true>(P, keys, nf, ng, L, F, M, n_wg, lds, st) : hash_fast_launch<NA, MODE, false>(P, keys, nf, ng, L, F, M, n_wg, lds, st);
-}
-
-template <int NA>
-static hipError_t hash_fast_mode(const FastPlan &P, uint64_t *keys, int nf, int ng, int mode, bool time, int L, int F, int M, int n_wg, size_t lds, hipStream_t st) {
-    if (NA == 0) return hash_fast_time<0, kFastAvg>(P, keys, nf, ng, time, L, F, M, n_wg, lds, st);
-    switch (mode) {
-    case kFastAvg: return hash_fast_time<NA, kFastAvg>(P, keys, nf, ng, time, L, F, M, n_wg, lds, st);
-    case kFastAvgMax: return hash_fast_time<NA, kFastAvgMax>(P, keys, nf, ng, time, L, F, M, n_wg, lds, st);
-    case kFastMoments: return hash_fast_time<NA, kFastMoments>(P, keys, nf, ng, time, L, F, M, n_wg, lds, st);
-    case kFastHist: return hash_fast_time<NA, kFastHist>(P, keys, nf, ng, time, L, F, M, n_wg, lds, st);
-    default: return hipErrorInvalidValue;
-    }
-}
-
-hipError_t launch_scan_hash_fast(const FastPlan &P, uint64_t *keys, int nf, int ng, int na, int mode, bool time, int L, int F, int M, int n_wg,
-                                 size_t lds_bytes, hipStream_t st) {
-    switch (na) {
-    case 0: return hash_fast_mode<0>(P, keys, nf, ng, mode, time, L, F, M, n_wg, lds_bytes, st);
-    case 1: return hash_fast_mode<1>(P, keys, nf, ng, mode, time, L, F, M, n_wg, lds_bytes, st);
-    case 2: return hash_fast_mode<2>(P, keys, nf, ng, mode, time, L, F, M, n_wg, lds_bytes, st);
-    default: return hipErrorInvalidValue;
-    }
-}
-
-// ---------------------------------------------------------------- ... over compact storage, in the offset domain
-// k_scan_hash_packed: the row body of k_scan_packed (scan_packed.h: stored 1 / 2 / 4-byte offsets, four rows per lane,
-// 32-bit compares and multiplies) in front of the same two table levels, for hashed queries over compact tables whose
-// composite key fits 32 bits.  Measured on config 3's 1024 groups forced through the table (1e9 rows, profiles/
-// r03_hash_variants.txt): k_scan_hash 26.4 ms (7.1 G vector instructions), k_scan_hash_fast 24.3 ms (8.8 G: the 64-bit
-// row body of the GEN kernels alone is 4.4 G), k_scan_packed direct-mapped 2.9 ms (1.0 G).  The staging table is probed
-// with a multiplicative 32-bit hash; misses and the flush go through hash_find_or_insert like every other writer of the
-// global table.  nf / ng / time are run-time (wave-uniform) so that one instantiation per (aggregations, mode, NUL)
-// serves every column count; bucket arrays (hist mode) never stage in LDS and stay with k_scan_hash_fast.
-template <int NA, int MODE, bool NUL, bool HASH>
-__global__ __launch_bounds__(kWgThreads) void k_scan_hash_packed(const FastPlan P, uint64_t *hash_keys, const int nf, const int ng, const int time,
-                                                                 const int L_, const int F, const int M) {
-    extern __shared__ int64_t lds[];
-    __shared__ uint32_t l_used;
-    const uint32_t tid = threadIdx.x;
-    const uint32_t L = (uint32_t)L_;
-    uint64_t *lkeys = (uint64_t *)lds;
-    int64_t *lsum = lds + L, *lmax = lsum + (size_t)F * L;
-    FastLds DL = {};  // !HASH: the direct-mapped cell table of the k_scan_fast family (replicas, LDS window)
-    if (HASH) {
-        for (uint32_t i = tid; i < L; i += kWgThreads) lkeys[i] = kHashEmpty;
-        for (uint32_t i = tid; i < (uint32_t)F * L; i += kWgThreads) lsum[i] = 0;
-        for (uint32_t i = tid; i < (uint32_t)M * L; i += kWgThreads) lmax[i] = INT64_MIN;
-        if (tid == 0) l_used = 0;
-        __syncthreads();
-    } else {
-        DL = fast_begin<MODE>(P, lds);
-    }
-    int64_t *gsum = P.sum_out + kHeaderWords, *gmax = P.max_out;
-    const uint32_t gmask = (uint32_t)P.n_cells - 1u;
-    const uint32_t lmask = L - 1u, l_limit = L - (L >> 2), lshift = L > 1 ? 32u - (uint32_t)__builtin_ctz(L) : 31u;
-
-    uint32_t matched = 0, overflow = 0, full = 0;
-    constexpr int MF = kFastMaxF, MG = HASH ? 2 : kFastMaxG;  // (hashed: the planner takes at most two group columns here)
-    auto accumulate = [&](auto lds_tag, int64_t *tab, int64_t *maxtab, const uint32_t ncell, const uint32_t slot, const PackedTile<NA> &a, const int r) {
-        constexpr bool LDS = decltype(lds_tag)::value;
-        fast_add64<LDS>(tab, slot, 1);  // Result.Count++ (aggregate.go:203)
-#pragma unroll
-        for (int c = 0; c < NA; c++) {
-            const uint32_t u = a.u[c][r];
-            if (NUL) {
-                if (!((a.pop[c] >> r) & 1u)) continue;  // no value: no hist for this row
-                if (P.f_pop[c] >= 0) fast_add64<LDS>(tab, (uint64_t)((uint32_t)P.f_pop[c] * ncell + slot), 1);
-                if (P.f_cnt[c] >= 0) {
-                    if (u < P.alo[c] || u > P.ahi[c]) continue;  // hist_basic.go:104, rebased
-                    fast_add64<LDS>(tab, (uint64_t)((uint32_t)P.f_cnt[c] * ncell + slot), 1);
-                }
-            }
-            const int64_t x = (int64_t)((uint64_t)P.abase[c] + u);
-            fast_add64<LDS>(tab, (uint64_t)(uint32_t)P.f_sum[c] * ncell + slot, x);
-            if (MODE == kFastAvgMax) fast_max64<LDS>(maxtab, (uint64_t)(uint32_t)P.m_max[c] * ncell + slot, x);
-            if (MODE == kFastMoments) {
-                const uint32_t b = packed_udiv(u + P.adoff[c], P.bucket_size[c], P.pinv_bucket[c]);
-                fast_add64<LDS>(tab, (uint64_t)(uint32_t)P.f_sb[c] * ncell + slot, (int64_t)(uint64_t)b);
-                fast_add64<LDS>(tab, (uint64_t)(uint32_t)P.f_sb2[c] * ncell + slot, (int64_t)(uint64_t)(uint32_t)__umul24(b, b));
-            }
-        }
-    };
-    auto one_row = [&](const PackedTile<MF> &f, const PackedTile<MG> &g, const PackedTile<NA> &a, const PackedTile<1> &t, const int r, bool pass) {
-        // (packed_row's filters and key, scan_packed.h: one predicate, no short-circuit)
-#pragma unroll
-        for (int c = 0; c < MF; c++) {
-            if (c >= nf) break;
-            const uint32_t u = f.u[c][r];
-            bool ok = (u >= P.plo[c]) & (u <= P.phi[c]);
-            if (NUL) {
-                if (P.fmask[c]) {
-                    const uint32_t id = u + (uint32_t)P.fbase[c];
-                    ok = id < (uint32_t)P.fmask_bits[c];
-                    if (ok) ok = (P.fmask[c][id >> 5] >> (id & 31)) & 1u;
-                }
-                for (int k = 0; k < P.npneq[c]; k++) ok = ok & (u != P.pneq[c][k]);
-                ok = ok & ((f.pop[c] >> r) & 1u);
-            }
-            pass = pass & ok;
-        }
-        uint32_t key = 0;
-        bool inb = true;
-#pragma unroll
-        for (int c = 0; c < MG; c++) {
-            if (c >= ng) break;
-            const uint32_t d = g.u[c][r] + P.gdoff[c];
-            if (NUL) {
-                const bool p = (g.pop[c] >> r) & 1u;
-                inb = inb & (p ? d < (uint32_t)P.gvalues64[c] : P.gmissing64[c] >= 0);
-                key += p ? d * (uint32_t)P.gstride64[c] : (uint32_t)P.gmissing64[c];
-            } else {
-                inb = inb & (d < (uint32_t)P.gvalues64[c]);
-                key += d * (uint32_t)P.gstride64[c];
-            }
-        }
-        bool live = pass;
-        if (time) {
-            const uint32_t tb = packed_udiv(t.u[0][r] + P.tdoff, (uint32_t)P.time_bucket, P.pinv_time);
-            if (NUL) {
-                const bool tp = (t.pop[0] >> r) & 1u;
-                live = live & tp;
-                inb = inb & (tb < (uint32_t)P.n_tb || !tp);
-            } else {
-                inb = inb & (tb < (uint32_t)P.n_tb);
-            }
-            key += tb * (uint32_t)P.tb_stride64;
-        }
-        matched += pass ? 1u : 0u;
-        if (!HASH) {
-            // direct-mapped: the key IS the cell (aggregate.go:125-143), inside this workgroup's LDS table / window
-            const uint32_t lcell = key - DL.cell_base;
-            inb = inb & (lcell < DL.tab_cells);
-            overflow += (live & !inb) ? 1u : 0u;
-            if (!(live & inb)) return;
-            const uint32_t rs = (uint32_t)P.rep_shift;
-            accumulate(std::true_type{}, lds, lds + DL.max_base, DL.tab_cells << rs, (lcell << rs) + DL.rep, a, r);
-            return;
-        }
-        overflow += (live & !inb) ? 1u : 0u;
-        if (!(live & inb)) return;
-        int32_t ls = -1;
-        if (L > 0) {
-            uint32_t h = (key * 0x9E3779B1u) >> lshift;
-            for (int probe = 0; probe < kHashLdsProbes; probe++) {
-                uint64_t k = __hip_atomic_load(lkeys + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (k == kHashEmpty) {
-                    if (__hip_atomic_load(&l_used, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= l_limit) break;
-                    unsigned long long expect = kHashEmpty;
-                    if (__hip_atomic_compare_exchange_strong((unsigned long long *)lkeys + h, &expect, (unsigned long long)key, __ATOMIC_RELAXED,
-                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
-                        __hip_atomic_fetch_add(&l_used, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        k = key;
-                    } else {
-                        k = expect;
-                    }
-                }
-                if (k == (uint64_t)key) {
-                    ls = (int32_t)h;
-                    break;
-                }
-                h = (h + 1) & lmask;
-            }
-        }
-        if (ls >= 0) {
-            accumulate(std::true_type{}, lsum, lmax, L, (uint32_t)ls, a, r);
-        } else {
-            const int32_t gs = hash_find_or_insert(hash_keys, gmask, (uint64_t)key, P.sum_out);
-            if (gs < 0) {
-                full += 1;
-                return;
-            }
-            accumulate(std::false_type{}, gsum, gmax, (uint32_t)P.n_cells, (uint32_t)gs, a, r);
-        }
-    };
-
-    const int s0 = P.wg_seg_begin[blockIdx.x], s1 = P.wg_seg_begin[blockIdx.x + 1];
-    for (int si = s0; si < s1; si++) {
-        const Segment seg = P.segs[si];
-        for (int64_t c0 = 0; c0 < seg.n; c0 += kPackedChunkRows) {
-            const int64_t first = seg.start + c0;
-            const uint32_t n = (uint32_t)(seg.n - c0 < kPackedChunkRows ? seg.n - c0 : kPackedChunkRows);
-            PackedRaw<MF> rf;
-            PackedRaw<MG> rg;
-            PackedRaw<NA> ra;
-            PackedRaw<1> rt;
-            PackedTile<MF> f;
-            PackedTile<MG> g;
-            PackedTile<NA> a;
-            PackedTile<1> t;
-            auto issue = [&](uint32_t r) {
-                const uint32_t r0 = __builtin_amdgcn_readfirstlane(r);
-                const uint32_t lane_row = r - r0;
-                auto ld = [&](const void *col, int width, pu32x4 &raw) {
-                    const int ws = width >> 1;
-                    packed_issue((const uint8_t *)col + (size_t)(first + r0) * (size_t)width, ws, lane_row << ws, raw);
-                };
-                if (NUL) {
-                    const int64_t wd = (first + r) >> 5;
-                    if (time) rt.pw[0] = P.tvalid ? P.tvalid[wd] : 0xFFFFFFFFu;
-#pragma unroll
-                    for (int c = 0; c < MF; c++)
-                        if (c < nf) rf.pw[c] = P.fvalid[c] ? P.fvalid[c][wd] : 0xFFFFFFFFu;
-#pragma unroll
-                    for (int c = 0; c < MG; c++)
-                        if (c < ng) rg.pw[c] = P.gvalid[c] ? P.gvalid[c][wd] : 0xFFFFFFFFu;
-#pragma unroll
-                    for (int c = 0; c < NA; c++) ra.pw[c] = P.avalid[c] ? P.avalid[c][wd] : 0xFFFFFFFFu;
-                }
-                if (time) ld(P.tcol, P.twid, rt.v[0]);
-#pragma unroll
-                for (int c = 0; c < MF; c++)
-                    if (c < nf) ld(P.fcol[c], P.fwid[c], rf.v[c]);
-#pragma unroll
-                for (int c = 0; c < MG; c++)
-                    if (c < ng) ld(P.gcol[c], P.gwid[c], rg.v[c]);
-#pragma unroll
-                for (int c = 0; c < NA; c++) ld(P.acol[c], P.awid[c], ra.v[c]);
-            };
-            auto decode = [&](uint32_t r) {
-                const uint32_t bit0 = (uint32_t)(first + r) & 31u;
-                if (NUL) {
-                    if (time) t.pop[0] = (rt.pw[0] >> bit0) & 0xFu;
-#pragma unroll
-                    for (int c = 0; c < MF; c++)
-                        if (c < nf) f.pop[c] = (rf.pw[c] >> bit0) & 0xFu;
-#pragma unroll
-                    for (int c = 0; c < MG; c++)
-                        if (c < ng) g.pop[c] = (rg.pw[c] >> bit0) & 0xFu;
-#pragma unroll
-                    for (int c = 0; c < NA; c++) a.pop[c] = (ra.pw[c] >> bit0) & 0xFu;
-                }
-                if (time) packed_decode(P.twid, rt.v[0], t.u[0]);
-#pragma unroll
-                for (int c = 0; c < MF; c++)
-                    if (c < nf) packed_decode(P.fwid[c], rf.v[c], f.u[c]);
-#pragma unroll
-                for (int c = 0; c < MG; c++)
-                    if (c < ng) packed_decode(P.gwid[c], rg.v[c], g.u[c]);
-#pragma unroll
-                for (int c = 0; c < NA; c++) packed_decode(P.awid[c], ra.v[c], a.u[c]);
-            };
-            uint32_t r = tid * kPackedRows;
-            if (r < n) {
-                issue(r);
-                decode(r);
-            }
-            for (; r < n; r += kPackedTileRows) {
-                const uint32_t rn = r + kPackedTileRows;
-                const bool more = rn < n;
-                if (more) issue(rn);
-                const uint32_t left = n - r;
-#pragma unroll
-                for (int k = 0; k < kPackedRows; k++) one_row(f, g, a, t, k, (uint32_t)k < left);
-                if (more) decode(rn);
-            }
-        }
-    }
-
-    if (!HASH) {
-        fast_finish(P, lds, DL, matched, overflow);
-        return;
-    }
-    if (L > 0) {
-        __syncthreads();
-        for (uint32_t i = tid; i < L; i += kWgThreads) {
-            const uint64_t k = lkeys[i];
-            if (k == kHashEmpty) continue;
-            const int32_t gs = hash_find_or_insert(hash_keys, gmask, k, P.sum_out);
-            if (gs < 0) {
-                full += 1;
-                continue;
-            }
-            for (int fi = 0; fi < F; fi++) {
-                const int64_t v = lsum[(size_t)fi * L + i];
-                if (v != 0) gadd(gsum + (int64_t)fi * P.n_cells + gs, v);
-            }
-            for (int m = 0; m < M; m++) {
-                const int64_t v = lmax[(size_t)m * L + i];
-                if (v != INT64_MIN) __hip_atomic_fetch_max(gmax + (int64_t)m * P.n_cells + gs, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-    }
-    int64_t m64 = wave_sum((int64_t)matched), o64 = wave_sum((int64_t)overflow), f64 = wave_sum((int64_t)full);
-    if ((tid & 63) == 0) {
-        if (m64) gadd(P.sum_out + kHdrMatched, m64);
-        if (o64) gadd(P.sum_out + kHdrOverflow, o64);
-        if (f64) gadd(P.sum_out + kHdrHashFull, f64);
-    }
-}
-
-template <int NA, int MODE, bool NUL, bool HASH = true>
-static hipError_t hash_packed_launch(const FastPlan &P, uint64_t *keys, int nf, int ng, int time, int L, int F, int M, int n_wg, size_t lds_bytes,
-                                     hipStream_t st) {
-    auto kfn = k_scan_hash_packed<NA, MODE, NUL, HASH>;
-    hipError_t e = hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max<size_t>(lds_bytes, 16));
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kfn, dim3(n_wg), dim3(kWgThreads), lds_bytes, st, P, keys, nf, ng, time, L, F, M);
-    return hipGetLastError();
-}
-
-template <int NA>
-static hipError_t hash_packed_mode(const FastPlan &P, uint64_t *keys, int nf, int ng, int mode, int time, int L, int F, int M, int n_wg, size_t lds,
-                                   hipStream_t st) {
-    const bool nul = P.nul != 0;
-#define SYBL_HP(MODE_) \
-    return nul ? hash_packed_launch<NA, MODE_, true>(P, keys, nf, ng, time, L, F, M, n_wg, lds, st) \
-               : hash_packed_launch<NA, MODE_, false>(P, keys, nf, ng, time, L, F, M, n_wg, lds, st)
-    if (NA == 0) SYBL_HP(kFastAvg);
-    switch (mode) {
-    case kFastAvg: SYBL_HP(kFastAvg);
-    case kFastAvgMax: SYBL_HP(kFastAvgMax);
-    case kFastMoments: SYBL_HP(kFastMoments);
-    default: return hipErrorInvalidValue;
-    }
-#undef SYBL_HP
-}
-
-// The same row body direct-mapped (HASH = false): what k_scan_packed does, for the column counts it is not instantiated
-// for -- three or four group columns -- with run-time column counts.
-template <int NA>
-static hipError_t packed_n_mode(const FastPlan &P, int nf, int ng, int mode, int time, int n_wg, size_t lds, hipStream_t st) {
-    const bool nul = P.nul != 0;
-#define SYBL_PN(MODE_) \
-    return nul ? hash_packed_launch<NA, MODE_, true, false>(P, nullptr, nf, ng, time, 0, 0, 0, n_wg, lds, st) \
-               : hash_packed_launch<NA, MODE_, false, false>(P, nullptr, nf, ng, time, 0, 0, 0, n_wg, lds, st)
-    if (NA == 0) SYBL_PN(kFastAvg);
-    switch (mode) {
-    case kFastAvg: SYBL_PN(kFastAvg);
-    case kFastAvgMax: SYBL_PN(kFastAvgMax);
-    case kFastMoments: SYBL_PN(kFastMoments);
-    default: return hipErrorInvalidValue;
-    }
-#undef SYBL_PN
-}
-
-hipError_t launch_scan_packed_n(const FastPlan &P, int nf, int ng, int na, int mode, bool time, int n_wg, size_t lds_bytes, hipStream_t st) {
-    switch (na) {
-    case 0: return packed_n_mode<0>(P, nf, ng, mode, time ? 1 : 0, n_wg, lds_bytes, st);
-    case 1: return packed_n_mode<1>(P, nf, ng, mode, time ? 1 : 0, n_wg, lds_bytes, st);
-    case 2: return packed_n_mode<2>(P, nf, ng, mode, time ? 1 : 0, n_wg, lds_bytes, st);
-    default: return hipErrorInvalidValue;
-    }
-}
-
-hipError_t launch_scan_hash_packed(const FastPlan &P, uint64_t *keys, int nf, int ng, int na, int mode, bool time, int L, int F, int M, int n_wg,
-                                   size_t lds_bytes, hipStream_t st) {
-    switch (na) {
-    case 0: return hash_packed_mode<0>(P, keys, nf, ng, mode, time ? 1 : 0, L, F, M, n_wg, lds_bytes, st);
-    case 1: return hash_packed_mode<1>(P, keys, nf, ng, mode, time ? 1 : 0, L, F, M, n_wg, lds_bytes, st);
-    case 2: return hash_packed_mode<2>(P, keys, nf, ng, mode, time ? 1 : 0, L, F, M, n_wg, lds_bytes, st);
     default: return hipErrorInvalidValue;
     }
 }
