@@ -920,8 +920,9 @@ static int refresh_table(Table *t, int64_t *n_added, int64_t *n_dropped, int64_t
             resident[lb.name] = true;
             continue;
         }
-        // vanished, moved to another rank's share, or rewritten: its rows leave the scan (they stay in HBM, unreferenced,
-        // until the table is reopened)
+        // vanished, moved to another rank's share, or rewritten: its rows leave the scan.  Those of trailing blocks are
+        // reused by the blocks loaded below (table_drop_dead_tail: the rewritten last block of an ingest loop); rows in
+        // the middle of the table stay in HBM, unreferenced, until it is reopened
         if (lb.index >= 0 && lb.index < (int64_t)t->blocks.size() && t->blocks[(size_t)lb.index].n > 0) {
             const int64_t n = t->blocks[(size_t)lb.index].n;
             t->blocks[(size_t)lb.index].n = 0;
@@ -943,6 +944,9 @@ static int refresh_table(Table *t, int64_t *n_added, int64_t *n_dropped, int64_t
     added = (int64_t)to_load.size() - reloaded;
     t->loaded.swap(keep);
     if (info_changed || dropped + reloaded > 0) t->version++;  // (appended blocks bump it themselves)
+    int64_t keep_blocks = 0;
+    for (auto &lb : t->loaded) keep_blocks = std::max(keep_blocks, lb.index + 1);
+    table_drop_dead_tail(t, keep_blocks);
     if (!to_load.empty() && (rc = load_blocks(ctx, t, t->src_dir, to_load))) return rc;
     if (n_added) *n_added = added;
     if (n_dropped) *n_dropped = dropped;

@@ -508,6 +508,44 @@ int block_commit(BlockWriter &w) {
     return SYBL_OK;
 }
 
+// Gives the rows of trailing blocks that left the scan (Segment::n == 0: sybl_table_refresh) back to the table, so the
+// blocks loaded next take their place.  Sybil's ingest rewrites the last, partly filled block on every digest
+// (table_ingest.go / table_block_io.go SaveRecordsToBlock): without this every refresh of a long-running host would append
+// up to 65 536 rows per column and free nothing.  keep_blocks: blocks [0, keep_blocks) stay whatever their row count (a
+// resident block directory refers to them by number).  Returns the blocks dropped.
+int64_t table_drop_dead_tail(Table *t, int64_t keep_blocks) {
+    int64_t dropped = 0;
+    while ((int64_t)t->blocks.size() > keep_blocks && t->blocks.back().n == 0) {
+        t->blocks.pop_back();
+        dropped++;
+    }
+    if (!dropped) return 0;
+    const int64_t nb = (int64_t)t->blocks.size();
+    t->phys_rows = nb ? t->blocks.back().start + t->blocks.back().n : 0;
+    for (auto &cp : t->cols) {
+        Column *c = cp.get();
+        if (c->type == SYBL_SET_VAL) {
+            if ((int64_t)c->h_set_off.size() > t->phys_rows + 1) {
+                c->h_set_off.resize((size_t)t->phys_rows + 1);
+                c->h_set_vals.resize((size_t)c->h_set_off.back());
+                c->set_dirty = true;
+            }
+            continue;
+        }
+        if ((int64_t)c->blk_min.size() > nb) {
+            c->blk_min.resize((size_t)nb);
+            c->blk_max.resize((size_t)nb);
+            c->blk_pop.resize((size_t)nb);
+        }
+        c->stats_blocks = std::min(c->stats_blocks, nb);
+        // (exact_min / exact_max / the stored width stay: bounds of a superset are still bounds; a dictionary built
+        // over the dropped rows is built again -- the block COUNT may come back to what it was with other values)
+        if (c->gdict_blocks >= 0) c->gdict_blocks = -1;
+    }
+    t->version++;
+    return dropped;
+}
+
 // ------------------------------------------------------------------ group dictionaries
 // Direct mapping needs one cell per value of the key RANGE; a sparse key (user ids, raw
 // timestamps) gets one cell per DISTINCT value instead: k_distinct collects the distinct values

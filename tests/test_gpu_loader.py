@@ -229,6 +229,41 @@ def test_refresh_follows_the_directory(ctx, tmp_path):
     tb.free()
 
 
+def test_refresh_reuses_the_rows_of_a_rewritten_last_block(ctx, tmp_path):
+    """Sybil's ingest rewrites the last, partly filled block on every digest: a resident table that follows its directory
+    must not grow by a block per refresh.  The rewritten block's rows are the table's tail, so the reloaded block takes
+    their place (block count and HBM footprint stay put) -- with missing values, a set column and str keys in play --
+    and the table answers like a freshly opened one every time."""
+    import shutil
+    blocks, _ = _make_blocks(4, 3000, seed=33, ragged=False)
+    info = {"big": (-(1 << 40), 1 << 40)}
+    root = str(tmp_path / "db")
+    F.write_table(root, "events", blocks[:3], threshold=8, int_info=info)
+    tb = ctx.open_table(root, "events", compact=True)
+    queries = [dict(groups=["age"], aggs=["big", "time"]), dict(filters=[("tags", "in", "tag3")], groups=["name"], aggs=["age"], op="hist")]
+    assert tb.blocks == 3
+    hbm = None
+    tdir = str(tmp_path / "db" / "events")
+    for turn, n in enumerate((2100, 2999, 700, 3000)):
+        spare = str(tmp_path / ("spare%d" % turn))
+        last = {c: (spec[0],) + tuple(x[:n] for x in spec[1:]) for c, spec in blocks[3 if turn % 2 else 2].items()}
+        F.write_table(spare, "events", [blocks[0], blocks[1], last], threshold=8, int_info=info)
+        sdir = spare + "/events"
+        shutil.rmtree(tdir + "/block000000003")  # (the fixture numbers block directories from 1)
+        shutil.copytree(sdir + "/block000000003", tdir + "/block000000003")
+        shutil.copy(sdir + "/info.db", tdir + "/info.db")
+        assert tb.refresh() == (0, 0, 1)
+        assert tb.blocks == 3 and tb.rows == 6000 + n and tb.broken_blocks == 0
+        fresh = ctx.open_table(root, "events", compact=True)
+        for q in queries:
+            assert _summary(tb, q) == _summary(fresh, q), (turn, q)
+        fresh.free()
+        if hbm is None:
+            hbm = tb.hbm_bytes
+        assert tb.hbm_bytes < hbm * 1.02  # (set members / dictionaries move with the content; no block's worth of rows per refresh)
+    tb.free()
+
+
 def test_column_subset_and_rank_sharding(ctx, tmp_path):
     blocks, logical = _make_blocks(6, 2000, ragged=False)
     root = str(tmp_path / "db")
