@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <memory>
+#include <unordered_map>
 
 namespace sybl {
 
@@ -492,6 +493,7 @@ struct Re2Parser {
 
     // ---- code generation
     Re2Lite *re = nullptr;
+    std::unordered_map<const Node *, std::pair<int32_t, int32_t>> set_ranges;
     bool emit(const Node *n) {
         auto &P = re->prog_;
         if (P.size() > kMaxProg) return fail("expression too large");
@@ -502,9 +504,15 @@ struct Re2Parser {
         switch (n->kind) {
         case Node::kEmpty: return true;
         case Node::kSet: {
-            const int32_t r0 = (int32_t)re->ranges_.size();
-            for (auto &r : n->ranges) re->ranges_.push_back(Re2Lite::Range{r.first, r.second});
-            add(Re2Lite::kChar, n->negated ? 1 : 0, r0, (int32_t)re->ranges_.size());
+            // (one range table per class, shared by the copies a counted repetition makes of it: [..]{1000} inside
+            // another {1000} would otherwise hold a million copies of the table before kMaxProg trips)
+            auto it = set_ranges.find(n);
+            if (it == set_ranges.end()) {
+                const int32_t r0 = (int32_t)re->ranges_.size();
+                for (auto &r : n->ranges) re->ranges_.push_back(Re2Lite::Range{r.first, r.second});
+                it = set_ranges.emplace(n, std::make_pair(r0, (int32_t)re->ranges_.size())).first;
+            }
+            add(Re2Lite::kChar, n->negated ? 1 : 0, it->second.first, it->second.second);
             return true;
         }
         case Node::kAny: add(Re2Lite::kAny, 0, 0, 0); return true;
