@@ -305,7 +305,10 @@ static hipError_t hash_packed_mode(const FastPlan &P, uint64_t *keys, int nf, in
 }
 
 // The same row body direct-mapped (HASH = false): what k_scan_packed does, for the column counts it is not instantiated
-// for -- three or four group columns -- with run-time column counts.
+// for -- three or four group columns, three or four aggregation columns -- with run-time filter / group column counts.
+// (plan_fresh, scan_fast.h, was tried on this kernel: config 3 through the table 4.8 -> 5.6 ms.  Its 230-500 spilled scalar
+// registers cost less than the scalar loads and their waits between the LDS atomics; the same on k_scan_packed: 2.72 ->
+// 3.32 ms, SYBL_PACKED_RING=4.)
 template <int NA>
 static hipError_t packed_n_mode(const FastPlan &P, int nf, int ng, int mode, int time, int n_wg, size_t lds, hipStream_t st) {
     const bool nul = P.nul != 0;
@@ -327,6 +330,8 @@ hipError_t launch_scan_packed_n(const FastPlan &P, int nf, int ng, int na, int m
     case 0: return packed_n_mode<0>(P, nf, ng, mode, time ? 1 : 0, n_wg, lds_bytes, st);
     case 1: return packed_n_mode<1>(P, nf, ng, mode, time ? 1 : 0, n_wg, lds_bytes, st);
     case 2: return packed_n_mode<2>(P, nf, ng, mode, time ? 1 : 0, n_wg, lds_bytes, st);
+    case 3: return packed_n_mode<3>(P, nf, ng, mode, time ? 1 : 0, n_wg, lds_bytes, st);
+    case 4: return packed_n_mode<4>(P, nf, ng, mode, time ? 1 : 0, n_wg, lds_bytes, st);
     default: return hipErrorInvalidValue;
     }
 }
@@ -337,6 +342,8 @@ hipError_t launch_scan_hash_packed(const FastPlan &P, uint64_t *keys, int nf, in
     case 0: return hash_packed_mode<0>(P, keys, nf, ng, mode, time ? 1 : 0, L, F, M, n_wg, lds_bytes, st);
     case 1: return hash_packed_mode<1>(P, keys, nf, ng, mode, time ? 1 : 0, L, F, M, n_wg, lds_bytes, st);
     case 2: return hash_packed_mode<2>(P, keys, nf, ng, mode, time ? 1 : 0, L, F, M, n_wg, lds_bytes, st);
+    case 3: return hash_packed_mode<3>(P, keys, nf, ng, mode, time ? 1 : 0, L, F, M, n_wg, lds_bytes, st);
+    case 4: return hash_packed_mode<4>(P, keys, nf, ng, mode, time ? 1 : 0, L, F, M, n_wg, lds_bytes, st);
     default: return hipErrorInvalidValue;
     }
 }

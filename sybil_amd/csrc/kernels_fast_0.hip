@@ -16,7 +16,7 @@ hipError_t launch_scan_fast_nf0(const FastPlan &P, int ng, int na, int mode, boo
 
 hipError_t launch_scan_fast(const FastPlan &P, int nf, int ng, int na, int mode, bool time, bool gen, int n_wg, size_t lds_bytes,
                             hipStream_t st) {
-    if (ng < 0 || ng > kFastMaxG || na < 0 || na > kFastMaxA) return hipErrorInvalidValue;
+    if (ng < 0 || ng > kFastMaxG || na < 0 || na > kFastTemplatedA) return hipErrorInvalidValue;
     switch (nf) {
     case 0: return launch_scan_fast_nf0(P, ng, na, mode, time, gen, n_wg, lds_bytes, st);
     case 1: return launch_scan_fast_nf1(P, ng, na, mode, time, gen, n_wg, lds_bytes, st);

@@ -37,7 +37,7 @@ hipError_t launch_emit_packed(const EmitPlan &E, int nf, int ng, int na, int n_w
 
 hipError_t launch_scan_packed(const FastPlan &P, int nf, int ng, int na, int mode, bool time, int n_wg, size_t lds_bytes,
                               hipStream_t st) {
-    if (ng < 0 || ng > kFastMaxG || na < 0 || na > kFastMaxA) return hipErrorInvalidValue;
+    if (ng < 0 || ng > kFastMaxG || na < 0 || na > kFastTemplatedA) return hipErrorInvalidValue;
     switch (nf) {
     case 0: return launch_scan_packed_nf0(P, ng, na, mode, time, n_wg, lds_bytes, st);
     case 1: return launch_scan_packed_nf1(P, ng, na, mode, time, n_wg, lds_bytes, st);

@@ -136,7 +136,7 @@ static bool fill_packed(Table *t, Query *q, const std::vector<int> &slot_col, Fa
 // fully populated int64, one role per column, no rejects / outliers / minima to track.
 static bool fill_fast_columns(Table *t, Query *q, const std::vector<int> &slot_col, FastPlan &FP, int *pnf, int *png,
                               int *pna, bool *any_max, bool *all_max, bool allow_gen, bool *gen, bool *packed = nullptr,
-                              int max_groups = 2) {
+                              int max_groups = kFastTemplatedG, int max_aggs = kFastTemplatedA) {
     const ScanPlan &P = q->plan;
     memset(&FP, 0, sizeof(FP));
     int nf = 0, ng = 0, na = 0;
@@ -218,7 +218,7 @@ static bool fill_fast_columns(Table *t, Query *q, const std::vector<int> &slot_c
     *any_max = false;
     *all_max = true;
     for (auto &ai : q->aggs) {
-        if (na >= kFastMaxA) return false;
+        if (na >= max_aggs) return false;
         const AggDesc &A = ai.d;
         if (A.m_nmin >= 0) return false;
         if ((A.f_smp >= 0 || A.f_out >= 0) && !allow_gen) return false;
@@ -313,12 +313,13 @@ static void select_fast_path(Table *t, Query *q, const std::vector<int> &slot_co
     q->fast_packed = false;
     q->fast_packed_n = false;
     if (!fill_fast_columns(t, q, slot_col, FP, &nf, &ng, &na, &any_max, &all_max, !getenv("SYBL_NO_FASTGEN"), &gen, &packed)) {
-        // three or four group columns over compact storage: the packed row body with run-time column counts
-        // (k_scan_hash_packed<.., HASH = false>, hashgroup.hip); no bucket arrays
-        if (q->groups.size() <= 2 || (int)q->groups.size() > kFastMaxG || getenv("SYBL_NO_PACKED_N") || getenv("SYBL_NO_FASTGEN")) return;
+        // three or four group columns, three or four aggregation columns over compact storage: the packed row body with
+        // run-time column counts (k_scan_hash_packed<.., HASH = false>, hashpacked.hip); no bucket arrays
+        const bool wide = (int)q->groups.size() > kFastTemplatedG || (int)q->aggs.size() > kFastTemplatedA;
+        if (!wide || (int)q->groups.size() > kFastMaxG || (int)q->aggs.size() > kFastMaxA || getenv("SYBL_NO_PACKED_N") || getenv("SYBL_NO_FASTGEN")) return;
         if (q->op == SYBL_AGG_HIST && q->want_percentiles) return;
         packed = false;
-        if (!fill_fast_columns(t, q, slot_col, FP, &nf, &ng, &na, &any_max, &all_max, true, &gen, &packed, kFastMaxG) || !packed) return;
+        if (!fill_fast_columns(t, q, slot_col, FP, &nf, &ng, &na, &any_max, &all_max, true, &gen, &packed, kFastMaxG, kFastMaxA) || !packed) return;
         q->fast_packed_n = true;
     }
     if (q->op == SYBL_AGG_HIST && any_max && !gen) return;
@@ -385,8 +386,9 @@ static void select_hash_fast(Table *t, Query *q, const std::vector<int> &slot_co
     const bool try_packed = !getenv("SYBL_NO_HASH_PACKED") && key_space < ((unsigned __int128)1 << 32) &&
                             !(q->op == SYBL_AGG_HIST && q->want_percentiles) && q->groups.size() <= 2;
     if (!fill_fast_columns(t, q, slot_col, FP, &nf, &ng, &na, &any_max, &all_max, true, &gen, try_packed ? &packed : nullptr,
-                           try_packed ? 2 : kFastMaxG))
+                           try_packed ? 2 : kFastMaxG, try_packed ? kFastMaxA : kFastTemplatedA))
         return;
+    if (!packed && na > kFastTemplatedA) return;  // (k_scan_hash_fast is instantiated for <= 2 aggregations)
     if (q->weighted && q->op == SYBL_AGG_HIST && q->want_percentiles) return;  // weighted bucket increments: generic kernel
     q->hash_packed = packed;
     if (q->time_mode) {

@@ -17,7 +17,10 @@
 
 namespace sybl {
 
-constexpr int kFastMaxF = 4, kFastMaxG = 4, kFastMaxA = 2;  // (the direct-mapped kernels are instantiated for <= 2 group columns)
+constexpr int kFastMaxF = 4, kFastMaxG = 4, kFastMaxA = 4;
+// (the kernels with compile-time column counts -- k_scan_fast, k_scan_packed, k_emit*, k_scan_hash_fast -- are instantiated
+// for <= 2 group and <= 2 aggregation columns; the run-time-count packed body, hashpacked.hip, takes kFastMaxG / kFastMaxA)
+constexpr int kFastTemplatedG = 2, kFastTemplatedA = 2;
 
 enum FastMode : int {
     kFastAvg = 0,      // op avg:  Count, sum(v)                        (extrema provably == initial values)

@@ -279,6 +279,9 @@ __device__ __forceinline__ int row_prepare(CPlan &P, const Tile<NC> &t, int r, i
 template <int NC, bool USE_LDS>
 __device__ __forceinline__ void row_accumulate(CPlan &P, const Tile<NC> &t, int r, int64_t *sumtab, int64_t *maxtab, int64_t ncell,
                                                int rs, int64_t cidx, int64_t gcell, int64_t logkey, int64_t w, int64_t &overflow) {
+    // w == 1 unless the query names a weight column: no 64-bit multiply per accumulated word then (wave-uniform branch)
+    const bool weighted = P.weight_slot >= 0;
+    auto times_w = [&](int64_t v) -> int64_t { return weighted ? (int64_t)((uint64_t)v * (uint64_t)w) : v; };
     acc_add<USE_LDS>(sumtab, cidx, w);  // Result.Count += weight (aggregate.go:203)
     if (P.f_samples >= 0) acc_add<USE_LDS>(sumtab, ((int64_t)P.f_samples * ncell << rs) + cidx, 1);
 #pragma unroll
@@ -291,7 +294,7 @@ __device__ __forceinline__ void row_accumulate(CPlan &P, const Tile<NC> &t, int 
         if (!pop) continue;
         if (A.f_pop >= 0) acc_add<USE_LDS>(sumtab, ((int64_t)A.f_pop * ncell << rs) + cidx, 1);
         if (x > A.max10 || x < A.info_min) continue;  // hist_basic.go:104
-        acc_add<USE_LDS>(sumtab, ((int64_t)A.f_sum * ncell << rs) + cidx, (int64_t)((uint64_t)x * (uint64_t)w));
+        acc_add<USE_LDS>(sumtab, ((int64_t)A.f_sum * ncell << rs) + cidx, times_w(x));
         if (A.f_cnt >= 0) acc_add<USE_LDS>(sumtab, ((int64_t)A.f_cnt * ncell << rs) + cidx, w);
         if (A.f_smp >= 0) acc_add<USE_LDS>(sumtab, ((int64_t)A.f_smp * ncell << rs) + cidx, 1);
         if (A.m_max >= 0) acc_max<USE_LDS>(maxtab, ((int64_t)A.m_max * ncell << rs) + cidx, x);
@@ -339,8 +342,8 @@ __device__ __forceinline__ void row_accumulate(CPlan &P, const Tile<NC> &t, int 
             if (A.hist_full) {
                 gadd(P.sum_out + P.hist_off + gcell * P.hist_stride + P.hist_agg_off[s.agg_index] + b, w);
             } else {
-                acc_add<USE_LDS>(sumtab, ((int64_t)A.f_sb * ncell << rs) + cidx, b * w);
-                acc_add<USE_LDS>(sumtab, ((int64_t)A.f_sb2 * ncell << rs) + cidx, b * b * w);
+                acc_add<USE_LDS>(sumtab, ((int64_t)A.f_sb * ncell << rs) + cidx, times_w(b));
+                acc_add<USE_LDS>(sumtab, ((int64_t)A.f_sb2 * ncell << rs) + cidx, times_w((int64_t)((uint64_t)b * (uint64_t)b)));
             }
         }
     }

@@ -107,9 +107,10 @@ __device__ __forceinline__ void packed_issue1(const uint8_t *col, uint32_t voff,
 }
 
 // r: the lane's first row inside the chunk; the wave's first row is that of its first lane
-template <int NF, int NG, int NA, bool TIME, bool G1, bool NUL>
-__device__ __forceinline__ void packed_issue_all(const FastPlan &P, const PackedBases<NF, NG, NA> &B, uint32_t r, PackedRaw<NF> &f,
+template <int NF, int NG, int NA, bool TIME, bool G1, bool NUL, bool FRESH = false>
+__device__ __forceinline__ void packed_issue_all(const FastPlan &P0, const PackedBases<NF, NG, NA> &B, uint32_t r, PackedRaw<NF> &f,
                                                  PackedRaw<NG> &g, PackedRaw<NA> &a, PackedRaw<1> &t) {
+    const FastPlan &P = plan_fresh<FRESH>(P0);  // (FRESH: the plan words a stage uses are reloaded there, scan_fast.h)
     const uint32_t r0 = __builtin_amdgcn_readfirstlane(r);
     const uint32_t lane_row = r - r0;
     if (NUL) {
@@ -209,10 +210,11 @@ __device__ __forceinline__ void packed_issue_ring(const FastPlan &P, const Packe
 // queries of <= 3 columns.)  SYBL_PACKED_RING keeps the variants reachable for the BASELINE shapes.
 constexpr int packed_depth(int) { return 1; }
 
-template <int NF, int NG, int NA, bool TIME, bool G1, bool NUL>
-__device__ __forceinline__ void packed_decode_all(const FastPlan &P, const PackedRaw<NF> &rf, const PackedRaw<NG> &rg,
+template <int NF, int NG, int NA, bool TIME, bool G1, bool NUL, bool FRESH = false>
+__device__ __forceinline__ void packed_decode_all(const FastPlan &P0, const PackedRaw<NF> &rf, const PackedRaw<NG> &rg,
                                                   const PackedRaw<NA> &ra, const PackedRaw<1> &rt, PackedTile<NF> &f,
                                                   PackedTile<NG> &g, PackedTile<NA> &a, PackedTile<1> &t, uint32_t bit0) {
+    const FastPlan &P = plan_fresh<FRESH>(P0);
     if (NUL) {  // bit0 = (physical row of the lane's first row) & 31, a multiple of 4
         if (TIME) t.pop[0] = (rt.pw[0] >> bit0) & 0xFu;
 #pragma unroll
@@ -239,13 +241,14 @@ __device__ __forceinline__ uint32_t packed_udiv(uint32_t n, uint32_t d, double i
     return q;
 }
 
-template <int NF, int NG, int NA, int MODE, bool TIME, bool NUL>
-__device__ __forceinline__ void packed_row(const FastPlan &P, const PackedTile<NF> &f, const PackedTile<NG> &g,
+template <int NF, int NG, int NA, int MODE, bool TIME, bool NUL, bool FRESH = false>
+__device__ __forceinline__ void packed_row(const FastPlan &P0, const PackedTile<NF> &f, const PackedTile<NG> &g,
                                            const PackedTile<NA> &a, const PackedTile<1> &t, const int r, bool pass, int64_t *lds,
                                            const FastLds &L, uint32_t &matched, uint32_t &overflow) {
     // no short-circuit anywhere: one predicate, one exec-masked region per row
 #pragma unroll
     for (int c = 0; c < NF; c++) {
+        const FastPlan &P = plan_fresh<FRESH>(P0);
         const uint32_t u = f.u[c][r];
         bool ok = (u >= P.plo[c]) & (u <= P.phi[c]);  // filter.go:171-195, folded to a range of offsets
         if (NUL) {
@@ -264,6 +267,7 @@ __device__ __forceinline__ void packed_row(const FastPlan &P, const PackedTile<N
     bool inb = true;
 #pragma unroll
     for (int c = 0; c < NG; c++) {
+        const FastPlan &P = plan_fresh<FRESH>(P0);
         const uint32_t d = g.u[c][r] + P.gdoff[c];  // value - gmin
         if (NUL) {
             // MISSING_VALUE key (aggregate.go:138): its own digit, or the digit of the value -1
@@ -276,6 +280,7 @@ __device__ __forceinline__ void packed_row(const FastPlan &P, const PackedTile<N
         }
     }
     bool live = pass;
+    const FastPlan &P = plan_fresh<FRESH>(P0);
     if (TIME) {
         // int(val) / TimeBucket (aggregate.go:174) for val >= 0, relative to the first bucket
         const uint32_t tb = packed_udiv(t.u[0][r] + P.tdoff, (uint32_t)P.time_bucket, P.pinv_time);
@@ -306,6 +311,7 @@ __device__ __forceinline__ void packed_row(const FastPlan &P, const PackedTile<N
     add(0, 1);  // Result.Count++ (aggregate.go:203)
 #pragma unroll
     for (int c = 0; c < NA; c++) {
+        const FastPlan &P = plan_fresh<FRESH>(P0);
         const uint32_t u = a.u[c][r];
         if (NUL) {
             if (!((a.pop[c] >> r) & 1u)) continue;  // no value: no hist for this row
@@ -371,7 +377,8 @@ __global__ __launch_bounds__(kWgThreads, SYBL_PACKED_WAVES_PER_EU) void k_scan_p
             PackedTile<NG> g;
             PackedTile<NA> a;
             PackedTile<1> t;
-            constexpr int D = NUL ? 1 : (RING > 0 ? RING : packed_depth(NF + NG + NA + (TIME ? 1 : 0)));
+            constexpr bool FRESH = RING == 4;  // (A/B: plan words reloaded per stage instead of spilled scalar registers)
+            constexpr int D = NUL ? 1 : (RING > 0 && RING < 4 ? RING : packed_depth(NF + NG + NA + (TIME ? 1 : 0)));
             if (D > 1) {
                 // a ring of D tiles of loads in flight, consumed oldest first; no exit inside a round (a tile past the end
                 // loads nothing and its rows fail `k < left`)
@@ -406,20 +413,20 @@ __global__ __launch_bounds__(kWgThreads, SYBL_PACKED_WAVES_PER_EU) void k_scan_p
             PackedRaw<1> rt;
             uint32_t r = tid * kPackedRows;
             if (r < n) {
-                packed_issue_all<NF, NG, NA, TIME, G1, NUL>(P, B, r, rf, rg, ra, rt);
-                packed_decode_all<NF, NG, NA, TIME, G1, NUL>(P, rf, rg, ra, rt, f, g, a, t, (uint32_t)(first + r) & 31u);
+                packed_issue_all<NF, NG, NA, TIME, G1, NUL, FRESH>(P, B, r, rf, rg, ra, rt);
+                packed_decode_all<NF, NG, NA, TIME, G1, NUL, FRESH>(P, rf, rg, ra, rt, f, g, a, t, (uint32_t)(first + r) & 31u);
             }
             for (; r < n; r += kPackedTileRows) {
                 // the next tile's loads are in flight while this one is consumed; they are decoded
                 // (the first use of the loaded registers) only after the rows below
                 const uint32_t rn = r + kPackedTileRows;
                 const bool more = rn < n;
-                if (more) packed_issue_all<NF, NG, NA, TIME, G1, NUL>(P, B, rn, rf, rg, ra, rt);
+                if (more) packed_issue_all<NF, NG, NA, TIME, G1, NUL, FRESH>(P, B, rn, rf, rg, ra, rt);
                 const uint32_t left = n - r;
 #pragma unroll
                 for (int k = 0; k < kPackedRows; k++)
-                    packed_row<NF, NG, NA, MODE, TIME, NUL>(P, f, g, a, t, k, (uint32_t)k < left, lds, L, matched, overflow);
-                if (more) packed_decode_all<NF, NG, NA, TIME, G1, NUL>(P, rf, rg, ra, rt, f, g, a, t, (uint32_t)(first + rn) & 31u);
+                    packed_row<NF, NG, NA, MODE, TIME, NUL, FRESH>(P, f, g, a, t, k, (uint32_t)k < left, lds, L, matched, overflow);
+                if (more) packed_decode_all<NF, NG, NA, TIME, G1, NUL, FRESH>(P, rf, rg, ra, rt, f, g, a, t, (uint32_t)(first + rn) & 31u);
             }
         }
     }
@@ -638,6 +645,7 @@ static hipError_t packed_launch_k1(const FastPlan &P, int n_wg, size_t lds_bytes
             if (d == 1) return launch(k_scan_packed<NF, NG, NA, MODE, TIME, G1, NUL, kAb ? 1 : 0>);
             if (d == 2) return launch(k_scan_packed<NF, NG, NA, MODE, TIME, G1, NUL, kAb ? 2 : 0>);
             if (d == 3) return launch(k_scan_packed<NF, NG, NA, MODE, TIME, G1, NUL, kAb ? 3 : 0>);
+            if (d == 4) return launch(k_scan_packed<NF, NG, NA, MODE, TIME, G1, NUL, kAb ? 4 : 0>);
         }
     }
     auto k = k_scan_packed<NF, NG, NA, MODE, TIME, G1, NUL>;

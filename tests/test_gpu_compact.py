@@ -296,3 +296,47 @@ def test_three_and_four_group_columns_run_the_packed_body(ctx, oracle):
         gres.free()
         query.free()
     tb.free()
+
+
+def test_three_and_four_aggregation_columns_run_the_packed_body(ctx, oracle, monkeypatch):
+    """More aggregation columns than k_scan_packed is instantiated for (`-int a,b,c[,d]`): the run-time-count packed body
+    takes them over compact storage -- moments and avg modes, a column with missing rows (its own count / populated-count
+    fields), and the same through the hash table (aggregate.go:246-261)."""
+    rng = np.random.default_rng(2718)
+    n = 600_000
+    cols = {"g1": rng.integers(0, 6, n), "g2": rng.integers(20, 27, n), "f": rng.integers(0, 1000, n),
+            "a": rng.integers(0, 1000, n), "b": rng.integers(100, 900, n), "c": rng.integers(0, 1000, n), "d": rng.integers(5, 250, n)}
+    cols = {k: v.astype(np.int64) for k, v in cols.items()}
+    pops = {"c": (rng.random(n) > 0.2).astype(np.uint8)}
+    info = {"a": (0, 999), "b": (100, 899), "c": (0, 999), "d": (5, 249)}   # (bucket geometries without outliers: those run the GEN body)
+    tb = ctx.create_table("a4")
+    for c in cols:
+        lo, hi = info.get(c, (1, 0))
+        tb.add_column(c, "int", lo, hi)
+    for r0 in range(0, n, 65536):
+        r1 = min(r0 + 65536, n)
+        tb.append_block(r1 - r0, {c: ((cols[c][r0:r1], pops[c][r0:r1]) if c in pops else cols[c][r0:r1]) for c in cols})
+    tb.compact()
+    names = list(cols)
+    ocols = [{"type": "int", "data": cols[c], **({"populated": pops[c]} if c in pops else {})} for c in names]
+    ix = {c: i for i, c in enumerate(names)}
+    agg = lambda c: (ix[c],) + info[c]
+    cases = ((dict(filters=[("f", "gt", 99), ("f", "lt", 900)], groups=["g1", "g2"], aggs=["a", "b", "d"], op="hist", want_percentiles=False),
+              dict(filters=[(ix["f"], "gt", 99), (ix["f"], "lt", 900)], groups=[ix["g1"], ix["g2"]], aggs=[agg("a"), agg("b"), agg("d")], op="hist")),
+             (dict(groups=["g1"], aggs=["a", "b", "c", "d"], op="avg"),
+              dict(groups=[ix["g1"]], aggs=[agg("a"), agg("b"), agg("c"), agg("d")], op="avg")),
+             (dict(filters=[("f", "neq", 7)], groups=["g2"], aggs=["c", "a", "b"], op="hist", want_percentiles=False),
+              dict(filters=[(ix["f"], "neq", 7)], groups=[ix["g2"]], aggs=[agg("c"), agg("a"), agg("b")], op="hist")))
+    for hashed in (False, True):
+        if hashed:
+            monkeypatch.setenv("SYBL_FORCE_HASH", "1")
+        for q, okw in cases:
+            query = tb.query(**q)
+            gres = query.run()
+            st = query.stats()
+            assert st["strategy"] == (7 if hashed else 2) and (hashed or st["packed_kernel"] == 1), st
+            ores = oracle.run_query(ocols, n_threads=4, **okw)
+            parity.compare(gres, ores, op=q["op"], full=False, n_aggs=len(q["aggs"]))
+            gres.free()
+            query.free()
+    tb.free()
