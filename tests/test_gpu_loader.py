@@ -242,7 +242,7 @@ def test_refresh_reuses_the_rows_of_a_rewritten_last_block(ctx, tmp_path):
     tb = ctx.open_table(root, "events", compact=True)
     queries = [dict(groups=["age"], aggs=["big", "time"]), dict(filters=[("tags", "in", "tag3")], groups=["name"], aggs=["age"], op="hist")]
     assert tb.blocks == 3
-    hbm = None
+    hbm = tb.hbm_bytes  # three full blocks resident
     tdir = str(tmp_path / "db" / "events")
     for turn, n in enumerate((2100, 2999, 700, 3000)):
         spare = str(tmp_path / ("spare%d" % turn))
@@ -258,9 +258,9 @@ def test_refresh_reuses_the_rows_of_a_rewritten_last_block(ctx, tmp_path):
         for q in queries:
             assert _summary(tb, q) == _summary(fresh, q), (turn, q)
         fresh.free()
-        if hbm is None:
-            hbm = tb.hbm_bytes
-        assert tb.hbm_bytes < hbm * 1.02  # (set members / dictionaries move with the content; no block's worth of rows per refresh)
+        # (set members, dictionaries and staging blocks move with the content; a leaked block per refresh would add a third
+        # of the table every turn)
+        assert tb.hbm_bytes < hbm * 1.15, (turn, tb.hbm_bytes, hbm)
     tb.free()
 
 
