@@ -196,7 +196,7 @@ static int scan(Query *q) {
         // the finished table (sybl_query_allreduce withdraws it when ranks merge afterwards).  Off by default -- measured
         // on one box (config 4, 20 steps): 4.63 ms per step fused against 4.71, but k_part_hist grows by 0.32 ms (one
         // workgroup per CU walks its 64 pairs' percentiles four at a time) for the 0.40 ms the two kernels took.
-        q->fused_summary = query_wants_hist_summary(q) && q->pplan.split == 1 && getenv("SYBL_FUSED_SUMMARY") != nullptr;
+        q->fused_summary = query_wants_hist_summary(q) && q->pplan.split == 1 && q->part_more.empty() && getenv("SYBL_FUSED_SUMMARY") != nullptr;
         q->pplan.fuse = q->fused_summary ? 1 : 0;
         if (q->fused_summary) {
             if ((rc = query_summary_buffers(q))) return rc;
@@ -213,6 +213,23 @@ static int scan(Query *q) {
         if (e != hipSuccess) return hip_fail(e, "k_part_hist");
         e = launch_part_fix(q->pplan, st);
         if (e != hipSuccess) return hip_fail(e, "k_part_fix");
+        // aggregations 2.. of a query with three or four: the same sequence over the same rows and buffers
+        for (auto &pp : q->part_more) {
+            pp.E.sum_out = q->d_sum;
+            pp.H.sum_out = q->d_sum;
+            pp.H.max_out = q->d_max;
+            e = pp.packed ? launch_count_packed(pp.E, q->part_nf, q->part_ng, q->n_wg, st) : launch_count(pp.E, q->part_nf, q->part_ng, q->n_wg, st);
+            if (e != hipSuccess) return hip_fail(e, "k_count");
+            e = launch_part_bases(pp.E, st);
+            if (e != hipSuccess) return hip_fail(e, "k_part_bases");
+            e = pp.packed ? launch_emit_packed(pp.E, q->part_nf, q->part_ng, pp.na, q->n_wg, st) : launch_emit(pp.E, q->part_nf, q->part_ng, pp.na, q->n_wg, st);
+            if (e != hipSuccess) return hip_fail(e, "k_emit");
+            SYBL_HIP(hipMemsetAsync(pp.H.wrap_log, 0, 8, st));
+            e = launch_part_hist(pp.H, st);
+            if (e != hipSuccess) return hip_fail(e, "k_part_hist");
+            e = launch_part_fix(pp.H, st);
+            if (e != hipSuccess) return hip_fail(e, "k_part_fix");
+        }
         trace.mark("hist");
         SYBL_HIP(hipEventRecord(q->ev[1], st));
         SYBL_HIP(hipEventRecord(q->ev[2], st));

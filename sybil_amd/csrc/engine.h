@@ -404,6 +404,16 @@ struct Query {
     int part_nf = 0, part_ng = 0, part_na = 0;
     EmitPlan eplan;
     PartHistPlan pplan;
+    // a query with three or four aggregations: the kernels of strategy 5 are instantiated for one or two, so aggregations
+    // 2.. go through the same count -> emit -> k_part_hist sequence again (same rows, same record buffers, their own
+    // bucket arrays and sum fields of the one cell table)
+    struct PartPass {
+        EmitPlan E;
+        PartHistPlan H;
+        int na = 0;
+        bool packed = false;
+    };
+    std::vector<PartPass> part_more;
     uint32_t *d_recs = nullptr, *d_cursor = nullptr;
 };
 

@@ -827,7 +827,7 @@ __global__ __launch_bounds__(kWgThreads) void k_part_hist(const PartHistPlan P) 
             // sole owner of the pair: plain stores, nothing to zero beforehand
             for (uint32_t b = tid; b < (uint32_t)P.n_values[a]; b += kWgThreads) h[b] = (int64_t)((hl[b >> 1] >> ((b & 1u) << 4)) & 0xFFFFu);
             if (tid == 0) {
-                if (a == 0) F[cell] = (int64_t)c;
+                if (a == 0 && !P.no_count) F[cell] = (int64_t)c;
                 F[(int64_t)P.f_sum[a] * P.n_cells + cell] = vsum;
                 if (P.m_max[a] >= 0) P.max_out[(int64_t)P.m_max[a] * P.n_cells + cell] = vmax[l];
             }
@@ -838,7 +838,7 @@ __global__ __launch_bounds__(kWgThreads) void k_part_hist(const PartHistPlan P) 
                 if (x) gadd(h + b, (int64_t)x);
             }
             if (tid == 0 && c) {
-                if (a == 0) gadd(F + cell, (int64_t)c);
+                if (a == 0 && !P.no_count) gadd(F + cell, (int64_t)c);
                 gadd(F + (int64_t)P.f_sum[a] * P.n_cells + cell, vsum);
                 if (P.m_max[a] >= 0)
                     __hip_atomic_fetch_max(P.max_out + (int64_t)P.m_max[a] * P.n_cells + cell, (int64_t)vmax[l], __ATOMIC_RELAXED,
@@ -860,7 +860,7 @@ __global__ __launch_bounds__(256) void k_part_fix(const PartHistPlan P) {
         const uint32_t bucket = e & 0xFFFFu, cell = pair / (uint32_t)P.n_aggs, a = pair % (uint32_t)P.n_aggs;
         const int64_t delta = (e >> 16) == kWrapPlus ? 65536 : -1;
         gadd(P.sum_out + P.hist_off + (int64_t)cell * P.hist_stride + P.hist_agg_off[a] + bucket, delta);
-        if (a == 0) gadd(F + cell, delta);
+        if (a == 0 && !P.no_count) gadd(F + cell, delta);
         gadd(F + (int64_t)P.f_sum[a] * P.n_cells + cell, delta * P.hmin[a]);
         if (P.fuse) {
             gadd(P.total + P.hist_agg_off[a] + bucket, delta);

@@ -419,96 +419,148 @@ static void select_hash_fast(Table *t, Query *q, const std::vector<int> &slot_co
 
 // Partitioned histograms (strategy 5, scan_fast.h): full-histogram queries whose (cell, agg)
 // pairs fit kMaxParts partitions of kPartCells pairs.
-static int select_part_hist(Table *t, Query *q, const std::vector<int> &slot_col, int64_t rows_scanned) {
-    q->part_hist = false;
+//
+// One pass of it over the aggregations [a0, a0 + n) of the query (n <= kFastTemplatedA: what k_emit / k_part_hist are
+// instantiated for): column roles, partition / bin geometry and the sizes of its buffers.  ok = false: not eligible.
+struct PartGeom {
+    int nf = 0, ng = 0, na = 0, ss = 0;
+    bool packed = false;
+    int64_t n_parts = 0, nb = 0, cap = 0, n_wg = 0;
+    size_t wrap_cap = 0, table_words = 0;
+};
+static bool plan_part_pass(Table *t, Query *q, const std::vector<int> &slot_col, int64_t rows_scanned, int a0, int n, EmitPlan &E, PartGeom &G) {
     const ScanPlan &P = q->plan;
-    if (getenv("SYBL_NO_PARTHIST") || q->hash_mode || q->loghist) return SYBL_OK;
-    if (q->op != SYBL_AGG_HIST || !q->want_percentiles || q->time_mode || q->weighted || q->aggs.empty()) return SYBL_OK;
-    if (q->fast && q->fplan.hist_lds) return SYBL_OK;  // the bucket arrays already live in LDS
-    EmitPlan &E = q->eplan;
-    int nf, ng, na;
-    bool any_max, all_max, gen, packed = false;
-    if (!fill_fast_columns(t, q, slot_col, E.fp, &nf, &ng, &na, &any_max, &all_max, false, &gen, &packed)) return SYBL_OK;
-    q->part_packed = packed;
+    bool any_max, all_max, gen;
+    // (fill_fast_columns walks q->aggs: hand it the slice)
+    std::vector<AggInfo> all;
+    all.swap(q->aggs);
+    q->aggs.assign(all.begin() + a0, all.begin() + a0 + n);
+    const bool shape = fill_fast_columns(t, q, slot_col, E.fp, &G.nf, &G.ng, &G.na, &any_max, &all_max, false, &gen, &G.packed);
+    q->aggs.swap(all);
+    if (!shape) return false;
+    const int na = G.na;
     // a record is (local pair, v - h.Min): the value part must fit kRecValueBits, stay clear of kRecSentinel (all ones:
     // local pair 31 and every value bit set), and k_part_hist's divide multiplies bucket x BucketSize in 24 bits
-    for (auto &ai : q->aggs) {
-        if (ai.d.n_values > (1 << kBucketBits) || ai.d.bucket_size >= ((int64_t)1 << 24)) return SYBL_OK;
-        if ((int64_t)ai.d.n_values * ai.d.bucket_size >= ((int64_t)1 << kRecValueBits)) return SYBL_OK;
+    for (int a = a0; a < a0 + n; a++) {
+        const AggDesc &A = q->aggs[(size_t)a].d;
+        if (A.n_values > (1 << kBucketBits) || A.bucket_size >= ((int64_t)1 << 24)) return false;
+        if ((int64_t)A.n_values * A.bucket_size >= ((int64_t)1 << kRecValueBits)) return false;
     }
     int64_t pairs = (int64_t)P.n_cells * na;
-    int64_t n_parts = (pairs + kPartCells - 1) / kPartCells;
-    if (n_parts > kMaxParts) return SYBL_OK;
+    G.n_parts = (pairs + kPartCells - 1) / kPartCells;
+    if (G.n_parts > kMaxParts) return false;
     // Staging bins: a partition is spread over 1 << ss bins (a lane's bin follows from its lane number) so that
     // few partitions do not serialise on a handful of LDS counters; fewer bins when a workgroup's share of
     // the records would leave most of a bin's chunks padding.
     const int64_t recs_all = rows_scanned * na;
-    const int64_t n_wg = std::max(1, q->n_wg);
-    if (n_wg > 2048) return SYBL_OK;  // k_part_hist keeps one region descriptor per scanning workgroup in LDS
+    G.n_wg = std::max(1, q->n_wg);
+    if (G.n_wg > 2048) return false;  // k_part_hist keeps one region descriptor per scanning workgroup in LDS
     int ss = 0;
-    while ((n_parts << (ss + 1)) <= kEmitMaxBins) ss++;
-    while (ss > 0 && recs_all / (n_wg * (n_parts << ss)) < 64) ss--;
+    while ((G.n_parts << (ss + 1)) <= kEmitMaxBins) ss++;
+    while (ss > 0 && recs_all / (G.n_wg * (G.n_parts << ss)) < 64) ss--;
+    G.ss = ss;
     // the workgroups' outputs are sized exactly by k_count at scan time; this is their upper bound: every record + one
     // partly filled chunk per (workgroup, bin).  Chunk indices are 32-bit; a workgroup's output is addressed with a
     // 32-bit byte offset below kEmitDropOffset (2 GiB).
-    const int64_t nb = n_parts << ss;
-    const int64_t cap = recs_all + n_wg * nb * (int64_t)kEmitChunk + kEmitChunk;
-    if (cap >= ((int64_t)1 << 32) - ((int64_t)1 << 22)) return SYBL_OK;
+    G.nb = G.n_parts << ss;
+    G.cap = recs_all + G.n_wg * G.nb * (int64_t)kEmitChunk + kEmitChunk;
+    if (G.cap >= ((int64_t)1 << 32) - ((int64_t)1 << 22)) return false;
     int64_t wg_rows_max = 0;
     {
-        std::vector<int64_t> per_wg((size_t)n_wg, 0);
-        for (int64_t w = 0; w < n_wg && (size_t)w + 1 < q->wg_seg_begin.size(); w++)
+        std::vector<int64_t> per_wg((size_t)G.n_wg, 0);
+        for (int64_t w = 0; w < G.n_wg && (size_t)w + 1 < q->wg_seg_begin.size(); w++)
             for (int si = q->wg_seg_begin[(size_t)w]; si < q->wg_seg_begin[(size_t)w + 1]; si++) per_wg[(size_t)w] += q->segs[(size_t)si].n;
         for (int64_t v : per_wg) wg_rows_max = std::max(wg_rows_max, v);
     }
-    if ((wg_rows_max * na + nb * (int64_t)kEmitChunk) * 4 >= (int64_t)kEmitDropOffset) return SYBL_OK;
+    if ((wg_rows_max * na + G.nb * (int64_t)kEmitChunk) * 4 >= (int64_t)kEmitDropOffset) return false;
     // k_part_hist's 16-bit bucket counters log their wraps: at most 3 entries per 65536 records (kernels.hip)
-    const size_t wrap_cap = (size_t)(3 * (recs_all / 65536 + 1) + 4096);
-    const size_t table_words = (size_t)n_wg * (size_t)(nb + 1) + (size_t)n_wg + 1 + 2 + 2 * wrap_cap;
-    size_t bytes = (size_t)cap * 4 + table_words * 4, free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || bytes + ((size_t)1 << 30) > free_b) return SYBL_OK;
-    SYBL_HIP(hipMalloc((void **)&q->d_recs, (size_t)cap * 4));
-    // boff | wbase | wrap log in one allocation
-    SYBL_HIP(hipMalloc((void **)&q->d_cursor, table_words * 4));
-    E.recs = q->d_recs;
-    E.boff = q->d_cursor;
-    E.wbase = E.boff + (size_t)n_wg * (size_t)(nb + 1);
-    E.n_parts = (int32_t)n_parts;
-    E.n_aggs = na;
-    E.n_wg = (int32_t)n_wg;
-    E.sub_shift = ss;
-    PartHistPlan &H = q->pplan;
+    G.wrap_cap = (size_t)(3 * (recs_all / 65536 + 1) + 4096);
+    G.table_words = (size_t)G.n_wg * (size_t)(G.nb + 1) + (size_t)G.n_wg + 1 + 2 + 2 * G.wrap_cap;
+    return true;
+}
+
+// ... and its plans over the (shared) buffers
+static void bind_part_pass(Query *q, int a0, const PartGeom &G, uint32_t *d_recs, uint32_t *d_tables, EmitPlan &E, PartHistPlan &H) {
+    const ScanPlan &P = q->plan;
+    E.recs = d_recs;
+    E.boff = d_tables;
+    E.wbase = E.boff + (size_t)G.n_wg * (size_t)(G.nb + 1);
+    E.n_parts = (int32_t)G.n_parts;
+    E.n_aggs = G.na;
+    E.n_wg = (int32_t)G.n_wg;
+    E.sub_shift = G.ss;
+    E.quiet = a0 > 0 ? 1 : 0;
     memset(&H, 0, sizeof(H));
-    H.recs = q->d_recs;
+    H.no_count = a0 > 0 ? 1 : 0;
+    H.recs = d_recs;
     H.boff = E.boff;
     H.wbase = E.wbase;
-    H.n_wg = (int32_t)n_wg;
-    H.sub_shift = ss;
-    H.wrap_log = E.wbase + n_wg + 1;
-    H.wrap_cap = (uint32_t)wrap_cap;
-    H.n_parts = (int32_t)n_parts;
-    H.n_aggs = na;
+    H.n_wg = (int32_t)G.n_wg;
+    H.sub_shift = G.ss;
+    H.wrap_log = E.wbase + G.n_wg + 1;
+    H.wrap_cap = (uint32_t)G.wrap_cap;
+    H.n_parts = (int32_t)G.n_parts;
+    H.n_aggs = G.na;
     H.n_cells = P.n_cells;
     H.hist_off = P.hist_off;
     H.hist_stride = P.hist_stride;
     int nv_max = 0;
-    for (int a = 0; a < na; a++) {
-        const AggDesc &A = q->aggs[(size_t)a].d;
+    for (int a = 0; a < G.na; a++) {
+        const AggDesc &A = q->aggs[(size_t)(a0 + a)].d;
         H.pinv_bucket[a] = (1.0 / (double)A.bucket_size) * (1.0 - 0x1p-40);
         H.n_values[a] = A.n_values;
         H.f_sum[a] = A.f_sum;
         H.m_max[a] = A.m_max;
         H.hmin[a] = A.hmin;
         H.bucket_size[a] = A.bucket_size;
-        H.hist_agg_off[a] = P.hist_agg_off[a];
+        H.hist_agg_off[a] = P.hist_agg_off[a0 + a];
         nv_max = std::max(nv_max, A.n_values);
     }
     H.nv_max = nv_max;
     // few partitions: several workgroups share one so the whole chip is busy
-    H.split = (int32_t)std::max<int64_t>(1, (int64_t)q->n_wg / n_parts);
-    q->part_nf = nf;
-    q->part_ng = ng;
-    q->part_na = na;
+    H.split = (int32_t)std::max<int64_t>(1, (int64_t)q->n_wg / G.n_parts);
+}
+
+static int select_part_hist(Table *t, Query *q, const std::vector<int> &slot_col, int64_t rows_scanned) {
+    q->part_hist = false;
+    q->part_more.clear();
+    if (getenv("SYBL_NO_PARTHIST") || q->hash_mode || q->loghist) return SYBL_OK;
+    if (q->op != SYBL_AGG_HIST || !q->want_percentiles || q->time_mode || q->weighted || q->aggs.empty()) return SYBL_OK;
+    if (q->fast && q->fplan.hist_lds) return SYBL_OK;  // the bucket arrays already live in LDS
+    // k_emit / k_part_hist take one or two aggregations: a query with three or four runs the sequence twice (same rows,
+    // same buffers; every pass fills its own aggregations' bucket arrays and sum fields of the one cell table)
+    const int n_all = (int)q->aggs.size();
+    if (n_all > kFastMaxA) return SYBL_OK;
+    const int n_pass = (n_all + kFastTemplatedA - 1) / kFastTemplatedA;
+    std::vector<PartGeom> geo((size_t)n_pass);
+    std::vector<EmitPlan> eps((size_t)n_pass);
+    size_t rec_words = 0, table_words = 0;
+    for (int p = 0; p < n_pass; p++) {
+        const int a0 = p * kFastTemplatedA, n = std::min(kFastTemplatedA, n_all - a0);
+        memset(&eps[(size_t)p], 0, sizeof(EmitPlan));
+        if (!plan_part_pass(t, q, slot_col, rows_scanned, a0, n, eps[(size_t)p], geo[(size_t)p])) return SYBL_OK;
+        rec_words = std::max(rec_words, (size_t)geo[(size_t)p].cap);
+        table_words = std::max(table_words, geo[(size_t)p].table_words);
+    }
+    size_t bytes = rec_words * 4 + table_words * 4, free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || bytes + ((size_t)1 << 30) > free_b) return SYBL_OK;
+    SYBL_HIP(hipMalloc((void **)&q->d_recs, rec_words * 4));
+    // boff | wbase | wrap log in one allocation
+    SYBL_HIP(hipMalloc((void **)&q->d_cursor, table_words * 4));
+    q->eplan = eps[0];
+    bind_part_pass(q, 0, geo[0], q->d_recs, q->d_cursor, q->eplan, q->pplan);
+    q->part_packed = geo[0].packed;
+    q->part_nf = geo[0].nf;
+    q->part_ng = geo[0].ng;
+    q->part_na = geo[0].na;
+    for (int p = 1; p < n_pass; p++) {
+        Query::PartPass pp;
+        pp.E = eps[(size_t)p];
+        pp.na = geo[(size_t)p].na;
+        pp.packed = geo[(size_t)p].packed;
+        bind_part_pass(q, p * kFastTemplatedA, geo[(size_t)p], q->d_recs, q->d_cursor, pp.E, pp.H);
+        q->part_more.push_back(pp);
+    }
     q->part_hist = true;
     return SYBL_OK;
 }
@@ -1338,6 +1390,10 @@ struct Planner {
         }
         q->eplan.fp.segs = q->d_segs;
         q->eplan.fp.wg_seg_begin = q->d_wg_seg_begin;
+        for (auto &pp : q->part_more) {
+            pp.E.fp.segs = q->d_segs;
+            pp.E.fp.wg_seg_begin = q->d_wg_seg_begin;
+        }
         q->fplan.segs = q->d_segs;
         q->fplan.wg_seg_begin = q->d_wg_seg_begin;
         q->fplan.ws_sum = q->d_ws_sum;

@@ -157,6 +157,8 @@ struct EmitPlan {
     int32_t sub_shift;               // bins per partition = 1 << sub_shift (a lane's sub-bin follows from its lane
                                      // number, in k_count and k_emit alike, so that few partitions do not serialise
                                      // on a handful of LDS counters)
+    int32_t quiet, pad_;             // quiet: a later pass over the same rows (the third / fourth aggregation of a query,
+                                     // Query::part_more): matched / overflow were counted by the first
     int64_t *sum_out;                // header: matched / overflow
 };
 
@@ -174,7 +176,9 @@ struct PartHistPlan {
     // result that is merged across ranks first)
     int64_t *pct, *mom, *total;
     uint32_t *dirty;                 // bit per pair: a logged wrap touched it (k_part_fix): k_hist_summary redoes those
-    int32_t fuse, pad_;
+    int32_t fuse;
+    int32_t no_count;                // a later pass of a query with three or four aggregations: Result.Count of the cells
+                                     // was written by the first (every aggregation accepts every row here)
     int32_t n_values[kFastMaxA], f_sum[kFastMaxA], m_max[kFastMaxA];
     int64_t hmin[kFastMaxA], bucket_size[kFastMaxA], hist_agg_off[kFastMaxA];
     double pinv_bucket[kFastMaxA];   // 1 / BucketSize scaled by (1 - 2^-40): the quotient estimate is never above the true one
@@ -932,8 +936,8 @@ __device__ __forceinline__ void emit_finish(const EmitPlan &E, const EmitLds &S,
         overflow += __shfl_xor(overflow, o, 64);
     }
     if ((threadIdx.x & 63) == 0) {
-        if (matched) __hip_atomic_fetch_add(E.sum_out + kHdrMatched, (int64_t)matched, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (overflow) __hip_atomic_fetch_add(E.sum_out + kHdrOverflow, (int64_t)overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (matched && !E.quiet) __hip_atomic_fetch_add(E.sum_out + kHdrMatched, (int64_t)matched, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (overflow && !E.quiet) __hip_atomic_fetch_add(E.sum_out + kHdrOverflow, (int64_t)overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 

@@ -61,6 +61,22 @@ def test_cfg4_high_cardinality_histograms(ctx, oracle, monkeypatch, fused):
     gres.free()
 
 
+@pytest.mark.parametrize("compact", [False, True])
+@pytest.mark.parametrize("aggs", [["c07", "c08", "c09"], ["c07", "c08", "c09", "c04"]])
+def test_three_and_four_aggregations_with_full_histograms(ctx, oracle, compact, aggs):
+    """`-op hist -int a,b,c[,d]` over 1024 groups: the kernels of the partitioned histograms take one or two aggregations,
+    so the third / fourth go through the count -> emit -> k_part_hist sequence a second time (same rows, same record
+    buffers, their own bucket arrays; matched rows and Result.Count are counted once) -- every bucket and percentile
+    against the oracle (hist_basic.go:101-183)."""
+    wl = _wl("cfg3_filter3_group2_stddev")
+    cols = wl["columns"] + ["c09"]
+    q = dict(wl["query"], aggs=aggs, want_percentiles=True)
+    gres, ores, stats = parity.run_both(ctx, oracle, cols, 700_000, 0, 700_000, q, compact=compact)
+    assert stats["strategy"] == 5, stats
+    parity.compare(gres, ores, op="hist", full=True, n_aggs=len(aggs))
+    gres.free()
+
+
 def test_cfg4_global_atomic_strategy(ctx, oracle, monkeypatch):
     # the fallback when a query is not eligible for partitioned histograms
     monkeypatch.setenv("SYBL_NO_PARTHIST", "1")

@@ -12,9 +12,12 @@ wl = synth.WORKLOADS["cfg3_filter3_group2_stddev"]
 cols = wl["columns"] + ["c09"]
 t = ctx.synth_table("a", synth.SEED, rows, 0, rows, synth.synth_cols(cols))
 t.compact()
-for label, q in (("hist x4", dict(wl["query"], aggs=["c07", "c08", "c09", "c04"], order_by=None)),
-                 ("avg x3", dict(wl["query"], aggs=["c07", "c08", "c09"], op="avg", order_by=None))):
-    for env in ({}, {"SYBL_NO_PACKED_N": "1"}):
+for label, q, off in (("hist x4", dict(wl["query"], aggs=["c07", "c08", "c09", "c04"], order_by=None), "SYBL_NO_PACKED_N"),
+                      ("avg x3", dict(wl["query"], aggs=["c07", "c08", "c09"], op="avg", order_by=None), "SYBL_NO_PACKED_N"),
+                      # every bucket wanted (percentiles): two passes of the partitioned histograms against one device-scope
+                      # atomic per value
+                      ("hist x4 + buckets", dict(wl["query"], aggs=["c07", "c08", "c09", "c04"], want_percentiles=True, order_by=None), "SYBL_NO_PARTHIST")):
+    for env in ({}, {off: "1"}):
         os.environ.update(env)
         qy = t.query(**q)
         qy.scan(); ctx.sync()
