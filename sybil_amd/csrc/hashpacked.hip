@@ -45,7 +45,8 @@ __global__ __launch_bounds__(kWgThreads) void k_scan_hash_packed(const FastPlan 
 
     uint32_t matched = 0, overflow = 0, full = 0;
     constexpr int MF = kFastMaxF, MG = HASH ? 2 : kFastMaxG;  // (hashed: the planner takes at most two group columns here)
-    auto accumulate = [&](auto lds_tag, int64_t *tab, int64_t *maxtab, const uint32_t ncell, const uint32_t slot, const PackedTile<NA> &a, const int r) {
+    auto accumulate = [&](auto lds_tag, int64_t *tab, int64_t *maxtab, const uint32_t ncell, const uint32_t slot, const PackedTile<NA> &a, const int r,
+                          const int64_t logkey) {
         constexpr bool LDS = decltype(lds_tag)::value;
         fast_add64<LDS>(tab, slot, 1);  // Result.Count++ (aggregate.go:203)
 #pragma unroll
@@ -63,7 +64,31 @@ __global__ __launch_bounds__(kWgThreads) void k_scan_hash_packed(const FastPlan 
             fast_add64<LDS>(tab, (uint64_t)(uint32_t)P.f_sum[c] * ncell + slot, x);
             if (MODE == kFastAvgMax) fast_max64<LDS>(maxtab, (uint64_t)(uint32_t)P.m_max[c] * ncell + slot, x);
             if (MODE == kFastMoments) {
-                const uint32_t b = packed_udiv(u + P.adoff[c], P.bucket_size[c], P.pinv_bucket[c]);
+                uint32_t b = packed_udiv(u + P.adoff[c], P.bucket_size[c], P.pinv_bucket[c]);
+                if (NUL && b >= (uint32_t)P.n_values[c]) {
+                    // Outlier (hist_basic.go:132-135): as in packed_row (scan_packed.h)
+                    if (P.f_out[c] >= 0) {
+                        const unsigned __int128 sq = (unsigned __int128)((__int128)x * (__int128)x);
+                        const uint64_t fo = (uint64_t)(uint32_t)P.f_out[c] * ncell + slot;
+                        fast_add64<LDS>(tab, fo, 1);
+                        fast_add64<LDS>(tab, fo + ncell, x);
+                        fast_add64<LDS>(tab, fo + 2 * (uint64_t)ncell, (int64_t)(uint64_t)(sq & 0xFFFFFFFFu));
+                        fast_add64<LDS>(tab, fo + 3 * (uint64_t)ncell, (int64_t)(uint64_t)((sq >> 32) & 0xFFFFFFFFu));
+                        fast_add64<LDS>(tab, fo + 4 * (uint64_t)ncell, (int64_t)(uint64_t)((sq >> 64) & 0xFFFFFFFFu));
+                        fast_add64<LDS>(tab, fo + 5 * (uint64_t)ncell, (int64_t)(uint64_t)(sq >> 96));
+                        if (P.out_log) {
+                            const int64_t i = __hip_atomic_fetch_add(P.sum_out + kHdrOutLog, (int64_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (i < P.out_cap) {
+                                P.out_log[i * kOutLogWords] = logkey;
+                                P.out_log[i * kOutLogWords + 1] = c;
+                                P.out_log[i * kOutLogWords + 2] = x;
+                            }
+                        }
+                    } else {
+                        overflow += 1;
+                    }
+                    b = (uint32_t)P.n_values[c] - 1;
+                }
                 fast_add64<LDS>(tab, (uint64_t)(uint32_t)P.f_sb[c] * ncell + slot, (int64_t)(uint64_t)b);
                 fast_add64<LDS>(tab, (uint64_t)(uint32_t)P.f_sb2[c] * ncell + slot, (int64_t)(uint64_t)(uint32_t)__umul24(b, b));
             }
@@ -122,7 +147,7 @@ __global__ __launch_bounds__(kWgThreads) void k_scan_hash_packed(const FastPlan 
             overflow += (live & !inb) ? 1u : 0u;
             if (!(live & inb)) return;
             const uint32_t rs = (uint32_t)P.rep_shift;
-            accumulate(std::true_type{}, lds, lds + DL.max_base, DL.tab_cells << rs, (lcell << rs) + DL.rep, a, r);
+            accumulate(std::true_type{}, lds, lds + DL.max_base, DL.tab_cells << rs, (lcell << rs) + DL.rep, a, r, (int64_t)key);
             return;
         }
         overflow += (live & !inb) ? 1u : 0u;
@@ -151,14 +176,14 @@ __global__ __launch_bounds__(kWgThreads) void k_scan_hash_packed(const FastPlan 
             }
         }
         if (ls >= 0) {
-            accumulate(std::true_type{}, lsum, lmax, L, (uint32_t)ls, a, r);
+            accumulate(std::true_type{}, lsum, lmax, L, (uint32_t)ls, a, r, (int64_t)key);
         } else {
             const int32_t gs = hash_find_or_insert(hash_keys, gmask, (uint64_t)key, P.sum_out);
             if (gs < 0) {
                 full += 1;
                 return;
             }
-            accumulate(std::false_type{}, gsum, gmax, (uint32_t)P.n_cells, (uint32_t)gs, a, r);
+            accumulate(std::false_type{}, gsum, gmax, (uint32_t)P.n_cells, (uint32_t)gs, a, r, (int64_t)key);
         }
     };
 

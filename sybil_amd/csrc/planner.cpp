@@ -222,8 +222,9 @@ static bool fill_fast_columns(Table *t, Query *q, const std::vector<int> &slot_c
         const AggDesc &A = ai.d;
         if (A.m_nmin >= 0) return false;
         if ((A.f_smp >= 0 || A.f_out >= 0) && !allow_gen) return false;
-        if (A.f_out >= 0 || (q->op == SYBL_AGG_HIST && A.m_max >= 0)) {
-            *gen = true;  // outliers / h.Max live in the GEN body
+        if (A.f_out >= 0) *gen = true;  // outliers: the GEN body, or the NUL variants of the packed bodies
+        if (q->op == SYBL_AGG_HIST && A.m_max >= 0) {
+            *gen = true;  // h.Max lives in the GEN body
             heavy = true;
         }
         if (A.f_smp >= 0) heavy = true;

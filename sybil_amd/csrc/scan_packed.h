@@ -330,7 +330,33 @@ __device__ __forceinline__ void packed_row(const FastPlan &P0, const PackedTile<
         if (MODE == kFastMoments || MODE == kFastHist) {
             // bucket_value := (value - h.Min) / BucketSize, hist_basic.go:130; the planner guarantees
             // 0 <= value - h.Min < 2^32 and that no value reaches len(Values)
-            const uint32_t b = packed_udiv(u + P.adoff[c], P.bucket_size[c], P.pinv_bucket[c]);
+            uint32_t b = packed_udiv(u + P.adoff[c], P.bucket_size[c], P.pinv_bucket[c]);
+            if (NUL && b >= (uint32_t)P.n_values[c]) {
+                // Outlier (hist_basic.go:132-135; BucketSize = size / 1000 truncates, so the top of many a column's range
+                // lies beyond the last bucket): clipped into the last bucket AND remembered as exact n, sum(o), sum(o^2)
+                // in four 32-bit limbs (+ the value itself in the log when bucket arrays are kept); a cold path
+                if (P.f_out[c] >= 0) {
+                    const unsigned __int128 sq = (unsigned __int128)((__int128)x * (__int128)x);
+                    const uint32_t fo = (uint32_t)P.f_out[c];
+                    add(fo, 1);
+                    add(fo + 1, x);
+                    add(fo + 2, (int64_t)(uint64_t)(sq & 0xFFFFFFFFu));
+                    add(fo + 3, (int64_t)(uint64_t)((sq >> 32) & 0xFFFFFFFFu));
+                    add(fo + 4, (int64_t)(uint64_t)((sq >> 64) & 0xFFFFFFFFu));
+                    add(fo + 5, (int64_t)(uint64_t)(sq >> 96));
+                    if (P.out_log) {
+                        const int64_t i = __hip_atomic_fetch_add(P.sum_out + kHdrOutLog, (int64_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (i < P.out_cap) {
+                            P.out_log[i * kOutLogWords] = (int64_t)cell;
+                            P.out_log[i * kOutLogWords + 1] = c;
+                            P.out_log[i * kOutLogWords + 2] = x;
+                        }
+                    }
+                } else {
+                    overflow += 1;
+                }
+                b = (uint32_t)P.n_values[c] - 1;
+            }
             if (MODE == kFastMoments) {
                 add((uint32_t)P.f_sb[c], (int64_t)(uint64_t)b);
                 add((uint32_t)P.f_sb2[c], (int64_t)(uint64_t)(uint32_t)__umul24(b, b));

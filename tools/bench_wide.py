@@ -16,7 +16,10 @@ for label, q, off in (("hist x4", dict(wl["query"], aggs=["c07", "c08", "c09", "
                       ("avg x3", dict(wl["query"], aggs=["c07", "c08", "c09"], op="avg", order_by=None), "SYBL_NO_PACKED_N"),
                       # every bucket wanted (percentiles): two passes of the partitioned histograms against one device-scope
                       # atomic per value
-                      ("hist x4 + buckets", dict(wl["query"], aggs=["c07", "c08", "c09", "c04"], want_percentiles=True, order_by=None), "SYBL_NO_PARTHIST")):
+                      ("hist x4 + buckets", dict(wl["query"], aggs=["c07", "c08", "c09", "c04"], want_percentiles=True, order_by=None), "SYBL_NO_PARTHIST"),
+                      # config 3 with -hist-bucket 990: the top ~1 % of c07 / c08 lie beyond the last bucket (outliers): the NUL
+                      # variant of k_scan_packed against the any-width GEN body
+                      ("cfg3, ~1 % outliers", dict(wl["query"], hist_bucket=990, order_by=None), "SYBL_NO_PACKED")):
     for env in ({}, {off: "1"}):
         os.environ.update(env)
         qy = t.query(**q)
