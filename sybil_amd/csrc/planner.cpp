@@ -144,7 +144,7 @@ static bool fill_fast_columns(Table *t, Query *q, const std::vector<int> &slot_c
     // compact storage: k_scan_packed when every column is a plain int column of <= 4 stored bytes,
     // else the GEN kernels (any width); the plain kernels read canonical int64 only
     bool any_packed = false, all_narrow = true;
-    bool heavy = false;  // GEN features k_scan_packed<NUL> leaves out: weights, outliers, h.Max
+    bool heavy = false;  // GEN features k_scan_packed<NUL> leaves out: weights, h.Max
     if (packed) *packed = false;
     for (size_t s = 0; s < slot_col.size(); s++) {
         const SlotDesc &sd = P.slot[s];
