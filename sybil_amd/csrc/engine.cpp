@@ -173,7 +173,11 @@ static int scan(Query *q) {
             e = launch_fill64(q->d_max, q->n_max_words, INT64_MIN, st);
             if (e != hipSuccess) return hip_fail(e, "k_fill64");
         } else {
-            SYBL_HIP(hipMemsetAsync(q->d_sum, 0, (size_t)kHeaderWords * 8, st));
+            // (outlier fields are accumulated with atomics: with them the cell fields start from zero as well)
+            bool outliers = false;
+            for (auto &ai : q->aggs) outliers = outliers || ai.d.f_out >= 0;
+            const size_t words = (size_t)kHeaderWords + (outliers ? (size_t)P.n_sum_fields * (size_t)P.n_cells : 0);
+            SYBL_HIP(hipMemsetAsync(q->d_sum, 0, words * 8, st));
         }
         SYBL_HIP(hipEventRecord(q->ev[0], st));
         q->eplan.sum_out = q->d_sum;

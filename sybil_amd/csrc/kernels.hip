@@ -562,7 +562,28 @@ __device__ __noinline__ void part_log_wrap(const PartHistPlan &P, uint32_t pair,
     }
 }
 
-template <int NA, bool TRACK_MAX>
+// (rare path) a value beyond the last bucket: remembered exactly -- n, sum(o), sum(o^2) in four 32-bit limbs, as the GEN row
+// body does (scan_fast.h: fast_accumulate) -- in the cell's outlier fields (zeroed by the scan: these are atomics, several
+// workgroups may share a cell's pairs), and the value itself in the log when one is kept
+__device__ __noinline__ void part_outlier(const PartHistPlan &P, uint32_t pair, uint32_t n32) {
+    const uint32_t na = (uint32_t)P.n_aggs, cell = pair / na, a = pair % na;
+    const int64_t x = (int64_t)((uint64_t)P.hmin[a] + (uint64_t)n32);
+    if (P.f_out[a] < 0) {  // declared bounds violated: reported by finalize
+        gadd(P.sum_out + kHdrOverflow, 1);
+        return;
+    }
+    int64_t *F = P.sum_out + kHeaderWords + (int64_t)P.f_out[a] * P.n_cells + cell;
+    const unsigned __int128 sq = (unsigned __int128)((__int128)x * (__int128)x);
+    gadd(F, 1);
+    gadd(F + P.n_cells, x);
+    gadd(F + 2 * (int64_t)P.n_cells, (int64_t)(uint64_t)(sq & 0xFFFFFFFFu));
+    gadd(F + 3 * (int64_t)P.n_cells, (int64_t)(uint64_t)((sq >> 32) & 0xFFFFFFFFu));
+    gadd(F + 4 * (int64_t)P.n_cells, (int64_t)(uint64_t)((sq >> 64) & 0xFFFFFFFFu));
+    gadd(F + 5 * (int64_t)P.n_cells, (int64_t)(uint64_t)(sq >> 96));
+    if (P.out_log) log_outlier(P.sum_out, P.out_log, P.out_cap, (int64_t)cell, P.agg0 + (int)a, x);
+}
+
+template <int NA, bool TRACK_MAX, bool OUT>
 __global__ __launch_bounds__(kWgThreads) void k_part_hist(const PartHistPlan P) {
     extern __shared__ uint32_t plds[];
     const uint32_t tid = threadIdx.x;
@@ -590,6 +611,7 @@ __global__ __launch_bounds__(kWgThreads) void k_part_hist(const PartHistPlan P) 
     // selects per record in a kernel whose vector ALUs are ~70 % busy)
     constexpr bool two = NA == 2;
     const uint32_t bs0 = (uint32_t)P.bucket_size[0], bs1 = (uint32_t)P.bucket_size[two ? 1 : 0];
+    const uint32_t nv0 = (uint32_t)P.n_values[0], nv1 = (uint32_t)P.n_values[two ? 1 : 0];
     const double inv0 = P.pinv_bucket[0], inv1 = P.pinv_bucket[two ? 1 : 0];
     auto bucket_of = [&](uint32_t rec, uint32_t &local, uint32_t &n32) -> uint32_t {
         n32 = rec & ((1u << kRecValueBits) - 1);  // v - h.Min
@@ -614,7 +636,15 @@ __global__ __launch_bounds__(kWgThreads) void k_part_hist(const PartHistPlan P) 
     auto add_record = [&](uint32_t rec, bool in) -> uint32_t {
         const bool live = in && rec != kRecSentinel;
         uint32_t local, n32;
-        const uint32_t b = bucket_of(rec, local, n32);
+        uint32_t b = bucket_of(rec, local, n32);
+        if (OUT) {
+            // Outlier (hist_basic.go:132-135): clipped into the last bucket and remembered (part_outlier)
+            const uint32_t nva = two && (local & 1u) ? nv1 : nv0;
+            if (b >= nva) {
+                if (live) part_outlier(P, pair0 + local, n32);
+                b = nva - 1u;
+            }
+        }
         const uint32_t sh = (b & 1u) << 4;
         uint32_t *hp = live ? hist + __umul24(local, nw) + (b >> 1) : dummy32;
         unsigned long long *sp = live ? my_sum + local * kPartSumRep : dummy64;
@@ -632,7 +662,11 @@ __global__ __launch_bounds__(kWgThreads) void k_part_hist(const PartHistPlan P) 
     auto wrapped = [](uint32_t seen) { return (seen & 0xFFFFu) == 0xFFFFu; };
     auto log_wrap = [&](uint32_t rec, uint32_t seen) {  // (rare)
         uint32_t local, n32;
-        const uint32_t b = bucket_of(rec, local, n32);
+        uint32_t b = bucket_of(rec, local, n32);
+        if (OUT) {
+            const uint32_t nva = two && (local & 1u) ? nv1 : nv0;
+            b = b >= nva ? nva - 1u : b;  // (an outlier was counted in the last bucket)
+        }
         part_log_wrap(P, pair0 + local, b, (b & 1u) ? 0u : seen, nv);
     };
 
@@ -913,7 +947,9 @@ hipError_t launch_part_bases(const EmitPlan &E, hipStream_t st) {
 
 template <int NA, bool TRACK_MAX>
 static hipError_t part_hist_launch(const PartHistPlan &P, size_t lds, hipStream_t st) {
-    auto k = k_part_hist<NA, TRACK_MAX>;
+    bool out = false;  // a column whose bounds let a value land beyond the last bucket
+    for (int a = 0; a < NA; a++) out = out || P.f_out[a] >= 0;
+    auto k = out ? k_part_hist<NA, TRACK_MAX, true> : k_part_hist<NA, TRACK_MAX, false>;
     hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(P.n_parts * P.split), dim3(kWgThreads), lds, st, P);

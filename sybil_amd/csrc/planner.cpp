@@ -136,7 +136,7 @@ static bool fill_packed(Table *t, Query *q, const std::vector<int> &slot_col, Fa
 // fully populated int64, one role per column, no rejects / outliers / minima to track.
 static bool fill_fast_columns(Table *t, Query *q, const std::vector<int> &slot_col, FastPlan &FP, int *pnf, int *png,
                               int *pna, bool *any_max, bool *all_max, bool allow_gen, bool *gen, bool *packed = nullptr,
-                              int max_groups = kFastTemplatedG, int max_aggs = kFastTemplatedA) {
+                              int max_groups = kFastTemplatedG, int max_aggs = kFastTemplatedA, bool part = false) {
     const ScanPlan &P = q->plan;
     memset(&FP, 0, sizeof(FP));
     int nf = 0, ng = 0, na = 0;
@@ -221,8 +221,9 @@ static bool fill_fast_columns(Table *t, Query *q, const std::vector<int> &slot_c
         if (na >= max_aggs) return false;
         const AggDesc &A = ai.d;
         if (A.m_nmin >= 0) return false;
-        if ((A.f_smp >= 0 || A.f_out >= 0) && !allow_gen) return false;
-        if (A.f_out >= 0) *gen = true;  // outliers: the GEN body, or the NUL variants of the packed bodies
+        // (part: the scan half of the partitioned histograms only emits v - h.Min; outliers are k_part_hist's business)
+        if ((A.f_smp >= 0 || (A.f_out >= 0 && !part)) && !allow_gen) return false;
+        if (A.f_out >= 0 && !part) *gen = true;  // outliers: the GEN body, or the NUL variants of the packed bodies
         if (q->op == SYBL_AGG_HIST && A.m_max >= 0) {
             *gen = true;  // h.Max lives in the GEN body
             heavy = true;
@@ -436,7 +437,8 @@ static bool plan_part_pass(Table *t, Query *q, const std::vector<int> &slot_col,
     std::vector<AggInfo> all;
     all.swap(q->aggs);
     q->aggs.assign(all.begin() + a0, all.begin() + a0 + n);
-    const bool shape = fill_fast_columns(t, q, slot_col, E.fp, &G.nf, &G.ng, &G.na, &any_max, &all_max, false, &gen, &G.packed);
+    const bool shape = fill_fast_columns(t, q, slot_col, E.fp, &G.nf, &G.ng, &G.na, &any_max, &all_max, false, &gen, &G.packed,
+                                         kFastTemplatedG, kFastTemplatedA, true);
     q->aggs.swap(all);
     if (!shape) return false;
     const int na = G.na;
@@ -446,6 +448,15 @@ static bool plan_part_pass(Table *t, Query *q, const std::vector<int> &slot_col,
         const AggDesc &A = q->aggs[(size_t)a].d;
         if (A.n_values > (1 << kBucketBits) || A.bucket_size >= ((int64_t)1 << 24)) return false;
         if ((int64_t)A.n_values * A.bucket_size >= ((int64_t)1 << kRecValueBits)) return false;
+        if (A.f_out >= 0) {
+            // outliers: every accepted value, not only the bucket range, must fit the record, and k_part_hist's quotient
+            // (a 24-bit multiply checks it) stays below 2^24
+            const Column *c = t->cols[(size_t)q->aggs[(size_t)a].col].get();
+            const int64_t hi = std::min(c->bounds_set ? c->bound_hi : c->exact_max, A.max10);
+            if (hi < A.hmin) continue;
+            const unsigned __int128 span = (unsigned __int128)((__int128)hi - (__int128)A.hmin);
+            if (span >= ((unsigned __int128)1 << kRecValueBits) - 1 || span / (unsigned __int128)A.bucket_size >= ((unsigned __int128)1 << 24)) return false;
+        }
     }
     int64_t pairs = (int64_t)P.n_cells * na;
     G.n_parts = (pairs + kPartCells - 1) / kPartCells;
@@ -512,12 +523,16 @@ static void bind_part_pass(Query *q, int a0, const PartGeom &G, uint32_t *d_recs
         H.n_values[a] = A.n_values;
         H.f_sum[a] = A.f_sum;
         H.m_max[a] = A.m_max;
+        H.f_out[a] = A.f_out;
         H.hmin[a] = A.hmin;
         H.bucket_size[a] = A.bucket_size;
         H.hist_agg_off[a] = P.hist_agg_off[a0 + a];
         nv_max = std::max(nv_max, A.n_values);
     }
     H.nv_max = nv_max;
+    H.agg0 = a0;
+    H.out_log = P.out_log;
+    H.out_cap = P.out_cap;
     // few partitions: several workgroups share one so the whole chip is busy
     H.split = (int32_t)std::max<int64_t>(1, (int64_t)q->n_wg / G.n_parts);
 }

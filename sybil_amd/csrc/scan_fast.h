@@ -180,6 +180,11 @@ struct PartHistPlan {
     int32_t no_count;                // a later pass of a query with three or four aggregations: Result.Count of the cells
                                      // was written by the first (every aggregation accepts every row here)
     int32_t n_values[kFastMaxA], f_sum[kFastMaxA], m_max[kFastMaxA];
+    int32_t f_out[kFastMaxA];        // outliers (a value beyond the last bucket, hist_basic.go:132-135): base of the cell's six
+                                     // fields n, sum(o), sum(o^2) as four 32-bit limbs; -1: the column's bounds rule them out
+    int32_t agg0, pad_;              // number of this pass's first aggregation in the query (the outlier log names it)
+    int64_t *out_log;                // outlier log (plan.h), nullptr = not kept
+    int64_t out_cap;
     int64_t hmin[kFastMaxA], bucket_size[kFastMaxA], hist_agg_off[kFastMaxA];
     double pinv_bucket[kFastMaxA];   // 1 / BucketSize scaled by (1 - 2^-40): the quotient estimate is never above the true one
     int64_t hist_off, hist_stride;

@@ -77,6 +77,28 @@ def test_three_and_four_aggregations_with_full_histograms(ctx, oracle, compact, 
     gres.free()
 
 
+@pytest.mark.parametrize("compact", [False, True])
+def test_partitioned_histograms_with_outliers(ctx, oracle, compact):
+    """`-hist-bucket 990` puts the top ~1 % of c07 beyond the last bucket (as BucketSize = size / 1000 does for many an
+    ordinary column): k_part_hist clips them into the last bucket and remembers them -- exact count / sum / sum of squares in
+    the cell's outlier fields, the values themselves in the log -- instead of the query falling back to one device-scope
+    atomic per value (hist_basic.go:132-135, 221-257).  65 536 groups (one pass), then config 3's 1024 groups with three
+    aggregations (two passes, several workgroups per partition)."""
+    wl = _wl("cfg4_hist_highcard")
+    gres, ores, stats = parity.run_both(ctx, oracle, wl["columns"], 400_000, 0, 400_000, dict(wl["query"], hist_bucket=990), compact=compact)
+    assert stats["strategy"] == 5, stats
+    parity.compare(gres, ores, op="hist", full=True, n_aggs=1)  # includes the outlier values
+    assert sum(r["hists"][0]["n_outliers"] for r in gres.results) > 1000
+    gres.free()
+    wl = _wl("cfg3_filter3_group2_stddev")
+    q = dict(wl["query"], aggs=["c07", "c08", "c09"], want_percentiles=True, hist_bucket=990)
+    gres, ores, stats = parity.run_both(ctx, oracle, wl["columns"] + ["c09"], 700_000, 0, 700_000, q, compact=compact)
+    assert stats["strategy"] == 5, stats
+    parity.compare(gres, ores, op="hist", full=True, n_aggs=3)
+    assert sum(r["hists"][0]["n_outliers"] for r in gres.results) > 1000
+    gres.free()
+
+
 def test_cfg4_global_atomic_strategy(ctx, oracle, monkeypatch):
     # the fallback when a query is not eligible for partitioned histograms
     monkeypatch.setenv("SYBL_NO_PARTHIST", "1")
