@@ -33,3 +33,22 @@ for label, q, off in (("hist x4", dict(wl["query"], aggs=["c07", "c08", "c09", "
         sys.stdout.flush()
         qy.free()
         for k in env: del os.environ[k]
+t.free()
+# config 4 (65 536 groups, every bucket kept) with -hist-bucket 990: ~1 % of c07 are outliers; the partitioned histograms
+# (k_part_hist remembers them) against one device-scope atomic per value
+wl4 = synth.WORKLOADS["cfg4_hist_highcard"]
+t = ctx.synth_table("b", synth.SEED, rows, 0, rows, synth.synth_cols(wl4["columns"]))
+t.compact()
+for env in ({}, {"SYBL_NO_PARTHIST": "1"}):
+    os.environ.update(env)
+    qy = t.query(**dict(wl4["query"], hist_bucket=990, order_by=None))
+    qy.scan(); ctx.sync()
+    ms = []
+    for _ in range(3):
+        qy.scan(); ctx.sync(); ms.append(qy.stats()["scan_ms"])
+    st = qy.stats()
+    print(json.dumps({"query": "cfg4, ~1 % outliers", "env": env, "strategy": st["strategy"], "packed_kernel": st["packed_kernel"],
+                      "scan_ms": round(sorted(ms)[1], 3), "GBps": round(st["algorithmic_bytes"] / (sorted(ms)[1] * 1e-3) / 1e9, 1)}))
+    sys.stdout.flush()
+    qy.free()
+    for k in env: del os.environ[k]
