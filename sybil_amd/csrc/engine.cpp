@@ -19,6 +19,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <vector>
 #include <regex>
 
 namespace sybl {
@@ -106,6 +107,7 @@ static void free_query(Query *q) {
     if (q->d_top) hipFree(q->d_top);
     if (q->d_top_cells) hipFree(q->d_top_cells);
     if (q->d_out_log) hipFree(q->d_out_log);
+    if (q->d_out_stage) hipFree(q->d_out_stage);
     if (q->d_multi) hipFree(q->d_multi);
     if (q->d_dplan) hipFree(q->d_dplan);
     if (q->d_hll) hipFree(q->d_hll);
@@ -138,6 +140,19 @@ static int scan_distinct(Query *q, bool ran, hipStream_t st) {
     return SYBL_OK;
 }
 
+// Outlier log (plan.h): the stripes' cursors start from zero; behind the scan kernels the stripes are closed up into the
+// dense log and the record count lands in the header.
+static int out_log_begin(Query *q, hipStream_t st) {
+    if (q->d_out_stage) SYBL_HIP(hipMemsetAsync(q->d_out_stage, 0, (size_t)kOutStripes * kOutCursorWords * 8, st));
+    return SYBL_OK;
+}
+static int out_log_end(Query *q, bool ran, hipStream_t st) {
+    if (!q->d_out_stage || !ran) return SYBL_OK;
+    hipError_t e = launch_outlog_gather(q->d_out_stage, q->out_cap, q->d_out_log, q->d_sum, st);
+    if (e != hipSuccess) return hip_fail(e, "k_outlog_gather");
+    return SYBL_OK;
+}
+
 static int scan(Query *q) {
     PhaseTrace trace("scan");
     int rc = ensure_partials(q);
@@ -164,10 +179,15 @@ static int scan(Query *q) {
     }
     const bool ran = !q->never_matches && !q->segs.empty();
     hipError_t e = hipSuccess;
+    if ((rc = out_log_begin(q, st))) return rc;
     if (q->part_hist && ran) {
         // k_part_hist overwrites every cell field, bucket and extremum: only the header and the
         // partition cursors start from zero
-        if (q->pplan.split > 1) {
+        // (every pass of a three / four aggregation query computes its own split: a later pass has fewer partitions and
+        // may share them between workgroups when the first does not)
+        bool any_split = q->pplan.split > 1;
+        for (auto &pp : q->part_more) any_split = any_split || pp.H.split > 1;
+        if (any_split) {
             // shared partitions accumulate with atomics into a zeroed table
             SYBL_HIP(hipMemsetAsync(q->d_sum, 0, (size_t)q->n_sum_words * 8, st));
             e = launch_fill64(q->d_max, q->n_max_words, INT64_MIN, st);
@@ -213,8 +233,30 @@ static int scan(Query *q) {
             q->pplan.total = q->d_total;
             q->pplan.dirty = q->d_dirty;
         }
+        // SYBL_PARTHIST_TRACE=<file> (diagnostic): k_part_hist's phase timestamps of this scan, one line per workgroup
+        const char *ph_trace = getenv("SYBL_PARTHIST_TRACE");
+        DevOwner own_trace;
+        const size_t trace_words = (size_t)q->pplan.n_parts * (size_t)q->pplan.split * kPartTraceWords;
+        q->pplan.trace = nullptr;
+        if (ph_trace) {
+            SYBL_HIP(hipMalloc(&own_trace.p, trace_words * 8));
+            SYBL_HIP(hipMemsetAsync(own_trace.p, 0, trace_words * 8, st));
+            q->pplan.trace = (unsigned long long *)own_trace.p;
+        }
         e = launch_part_hist(q->pplan, st);
         if (e != hipSuccess) return hip_fail(e, "k_part_hist");
+        if (ph_trace) {
+            std::vector<unsigned long long> tr(trace_words);
+            SYBL_HIP(hipStreamSynchronize(st));
+            SYBL_HIP(hipMemcpy(tr.data(), own_trace.p, trace_words * 8, hipMemcpyDeviceToHost));
+            if (FILE *f = fopen(ph_trace, "w")) {
+                for (size_t w = 0; w < trace_words / kPartTraceWords; w++) {
+                    for (int k = 0; k < kPartTraceWords; k++) fprintf(f, "%llu%c", tr[w * kPartTraceWords + k], k + 1 < kPartTraceWords ? ' ' : '\n');
+                }
+                fclose(f);
+            }
+            q->pplan.trace = nullptr;
+        }
         e = launch_part_fix(q->pplan, st);
         if (e != hipSuccess) return hip_fail(e, "k_part_fix");
         // aggregations 2.. of a query with three or four: the same sequence over the same rows and buffers
@@ -235,6 +277,7 @@ static int scan(Query *q) {
             if (e != hipSuccess) return hip_fail(e, "k_part_fix");
         }
         trace.mark("hist");
+        if ((rc = out_log_end(q, ran, st))) return rc;
         SYBL_HIP(hipEventRecord(q->ev[1], st));
         SYBL_HIP(hipEventRecord(q->ev[2], st));
         if ((rc = scan_distinct(q, ran, st))) return rc;
@@ -284,6 +327,7 @@ static int scan(Query *q) {
             if (e != hipSuccess) return hip_fail(e, "k_scan");
         }
     }
+    if ((rc = out_log_end(q, ran, st))) return rc;
     SYBL_HIP(hipEventRecord(q->ev[1], st));
     if (q->use_lds && ran && !P.windowed) {
         int64_t wsum = (int64_t)P.n_sum_fields * P.n_cells, wmax = (int64_t)P.n_max_fields * P.n_cells;

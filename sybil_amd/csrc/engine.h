@@ -45,6 +45,7 @@ hipError_t launch_repack(const void *src, int sw, int64_t sbase, void *dst, int 
 hipError_t launch_distinct(const void *col, int width, int64_t vbase, const uint32_t *valid, const Segment *blocks, int n_blocks,
                            int64_t *keys, uint32_t mask, unsigned long long *n_distinct, unsigned long long limit, hipStream_t st);
 hipError_t launch_pack32(const int64_t *src, int32_t *dst, int64_t n, hipStream_t st);
+hipError_t launch_outlog_gather(const int64_t *stage, int64_t cap, int64_t *log, int64_t *header, hipStream_t st);
 hipError_t launch_unpack32(const int32_t *src, int64_t *dst, int64_t n, hipStream_t st);
 hipError_t launch_decode_bins(const void *recs, int rec_width, const int64_t *bin_off, const int64_t *bin_val, int n_bins,
                               bool delta_encoded, void *col, int out_width, int64_t vbase, uint32_t *valid, uint32_t nrows, hipStream_t st);
@@ -369,7 +370,8 @@ struct Query {
     int32_t *d_h32 = nullptr;   // int32 staging of the bucket table + room for the reduced slice
     int64_t rs_cells_per = 0, rs_cell0 = 0, rs_cell1 = 0;
     // outlier log (plan.h): values of the outliers / underliers of queries that keep bucket arrays
-    int64_t *d_out_log = nullptr;
+    int64_t *d_out_log = nullptr;    // the dense outlier log (k_outlog_gather), read by finalize and the multi-rank merge
+    int64_t *d_out_stage = nullptr;  // what the scan kernels append to: cursors + stripes (plan.h)
     int64_t out_cap = 0;
     bool out_log_partial = false;  // the partial tables were merged across ranks: the log only holds this rank's values
     bool scanned = false;

@@ -16,7 +16,11 @@ constexpr int kHashLdsProbes = 8;  // probes a row spends on the LDS staging tab
 // finds neither itself nor a free slot within kHashMaxProbes means the table holds (nearly) as many keys as slots -- the
 // query is going to fail with SYBL_E_NOMEM.  The first row that gives up says so in the header, and every later row that
 // would have to insert a key gives up at once instead of walking a full table (up to 2^27 device-scope loads per row).
-constexpr uint32_t kHashMaxProbes = 512;
+// Default sizing keeps the load factor at or below 1/2.  When the slot count is capped (kHashMaxSlots) or set through
+// SYBL_HASH_SLOTS the load factor can approach 1: linear probing's unsuccessful search then walks ~(1 + 1/(1-a)^2)/2
+// slots (a = 0.95: 200, 0.98: 1250, 0.99: 5000), so the bound below reports a table as full (SYBL_E_NOMEM) from about
+// 98-99 % occupancy on, a little before its last free slot is taken.
+constexpr uint32_t kHashMaxProbes = 4096;
 __device__ __forceinline__ int32_t hash_find_or_insert(uint64_t *keys, uint32_t mask, uint64_t key, int64_t *hdr) {
     uint32_t h = (uint32_t)(splitmix64(key) >> 32) & mask;
     const uint32_t limit = mask + 1u < kHashMaxProbes ? mask + 1u : kHashMaxProbes;

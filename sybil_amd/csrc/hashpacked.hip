@@ -76,16 +76,7 @@ __global__ __launch_bounds__(kWgThreads) void k_scan_hash_packed(const FastPlan 
                         fast_add64<LDS>(tab, fo + 3 * (uint64_t)ncell, (int64_t)(uint64_t)((sq >> 32) & 0xFFFFFFFFu));
                         fast_add64<LDS>(tab, fo + 4 * (uint64_t)ncell, (int64_t)(uint64_t)((sq >> 64) & 0xFFFFFFFFu));
                         fast_add64<LDS>(tab, fo + 5 * (uint64_t)ncell, (int64_t)(uint64_t)(sq >> 96));
-                        if (P.out_log) {
-                            // (a full log is noticed with a load and left alone: scan_generic.h, log_outlier)
-                            const bool room = __hip_atomic_load(P.sum_out + kHdrOutLog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= P.out_cap;
-                            const int64_t i = room ? __hip_atomic_fetch_add(P.sum_out + kHdrOutLog, (int64_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : P.out_cap;
-                            if (i < P.out_cap) {
-                                P.out_log[i * kOutLogWords] = logkey;
-                                P.out_log[i * kOutLogWords + 1] = c;
-                                P.out_log[i * kOutLogWords + 2] = x;
-                            }
-                        }
+                        if (P.out_log) log_outlier(P.out_log, P.out_cap, logkey, c, x);
                     } else {
                         overflow += 1;
                     }

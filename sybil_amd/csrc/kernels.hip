@@ -580,13 +580,20 @@ __device__ __noinline__ void part_outlier(const PartHistPlan &P, uint32_t pair, 
     gadd(F + 3 * (int64_t)P.n_cells, (int64_t)(uint64_t)((sq >> 32) & 0xFFFFFFFFu));
     gadd(F + 4 * (int64_t)P.n_cells, (int64_t)(uint64_t)((sq >> 64) & 0xFFFFFFFFu));
     gadd(F + 5 * (int64_t)P.n_cells, (int64_t)(uint64_t)(sq >> 96));
-    if (P.out_log) log_outlier(P.sum_out, P.out_log, P.out_cap, (int64_t)cell, P.agg0 + (int)a, x);
+    if (P.out_log) log_outlier(P.out_log, P.out_cap, (int64_t)cell, P.agg0 + (int)a, x);
 }
 
 template <int NA, bool TRACK_MAX, bool OUT>
 __global__ __launch_bounds__(kWgThreads) void k_part_hist(const PartHistPlan P) {
     extern __shared__ uint32_t plds[];
     const uint32_t tid = threadIdx.x;
+    // (diagnostic, SYBL_PARTHIST_TRACE: the 100 MHz wall clock at the phase boundaries; word 0 start, 1 tables zeroed and
+    // regions read, 2 records walked, 3 counts and sums reduced, 4 table written, 5 the compute unit, 16.. when each wave
+    // finished its walk)
+    auto stamp = [&](int k) {
+        if (P.trace && tid == 0) P.trace[(size_t)blockIdx.x * kPartTraceWords + k] = wall_clock64();
+    };
+    stamp(0);
     const uint32_t nv = (uint32_t)P.nv_max, nw = (nv + 1u) >> 1;  // buckets, words per pair
     uint32_t *hist = plds;                                       // [kPartCells][nw] two 16-bit counters per word
     uint32_t *cnt = plds + kPartCells * nw;                      // [kPartCells]
@@ -663,11 +670,11 @@ __global__ __launch_bounds__(kWgThreads) void k_part_hist(const PartHistPlan P) 
     auto log_wrap = [&](uint32_t rec, uint32_t seen) {  // (rare)
         uint32_t local, n32;
         uint32_t b = bucket_of(rec, local, n32);
-        if (OUT) {
-            const uint32_t nva = two && (local & 1u) ? nv1 : nv0;
-            b = b >= nva ? nva - 1u : b;  // (an outlier was counted in the last bucket)
-        }
-        part_log_wrap(P, pair0 + local, b, (b & 1u) ? 0u : seen, nv);
+        const uint32_t nva = two && (local & 1u) ? nv1 : nv0;
+        if (OUT) b = b >= nva ? nva - 1u : b;  // (an outlier was counted in the last bucket)
+        // (the aggregation's own bucket count: the high field next to an even last bucket belongs to nobody -- a carry
+        // into it is neither logged nor, below, counted)
+        part_log_wrap(P, pair0 + local, b, (b & 1u) ? 0u : seen, nva);
     };
 
     // The partition's records: one region per scanning workgroup w (the partition's sub-bins are neighbours in w's
@@ -691,6 +698,7 @@ __global__ __launch_bounds__(kWgThreads) void k_part_hist(const PartHistPlan P) 
         regions[k] = make_uint2(P.wbase[w] + lo, (hi - lo) * (kEmitChunk / 4u));
     }
     __syncthreads();
+    stamp(1);
     uint32_t r = wave, i0 = 0, n4 = 0, c0 = 0;      // region, first piece of the next batch, pieces, first chunk (wave-uniform)
     auto open_region = [&]() {
         // skips empty regions; n4 == 0 afterwards: no region left
@@ -759,14 +767,17 @@ __global__ __launch_bounds__(kWgThreads) void k_part_hist(const PartHistPlan P) 
         cur_first = nxt_first;
         cur_n = nxt_n;
     }
+    if (P.trace && lane == 0) P.trace[(size_t)blockIdx.x * kPartTraceWords + 16 + wave] = wall_clock64();
     __syncthreads();
+    stamp(2);
     // cnt[l] = sum over the buckets of pair l (as the fields hold them: k_part_fix adds what the log says): each wave
     // sums a strided share, one LDS atomic per wave
     for (uint32_t l = 0; l < (uint32_t)kPartCells; l++) {
         uint32_t n = 0;
-        for (uint32_t k = tid; k < nw; k += kWgThreads) {
+        const uint32_t nva = two && (l & 1u) ? nv1 : nv0;
+        for (uint32_t k = tid; 2u * k < nva; k += kWgThreads) {
             const uint32_t x = hist[l * nw + k];
-            n += (x & 0xFFFFu) + (x >> 16);
+            n += (x & 0xFFFFu) + (2u * k + 1u < nva ? x >> 16 : 0u);
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
@@ -781,6 +792,7 @@ __global__ __launch_bounds__(kWgThreads) void k_part_hist(const PartHistPlan P) 
     __syncthreads();
     if (tid < kPartCells) sum[tid] = pair_sum;
     __syncthreads();
+    stamp(3);
 
     if (P.fuse && split == 1) {
         // What k_hist_summary / k_hist_total would read back out of HBM (see there for GetPercentiles): one wave per pair,
@@ -880,6 +892,14 @@ __global__ __launch_bounds__(kWgThreads) void k_part_hist(const PartHistPlan P) 
             }
         }
     }
+    stamp(4);
+    if (P.trace && tid == 0) {
+        uint32_t hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        uint32_t xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        P.trace[(size_t)blockIdx.x * kPartTraceWords + 5] = (unsigned long long)hwid | (unsigned long long)xcc << 32;
+    }
 }
 
 // k_part_fix: the wraps k_part_hist logged (see there), applied to the finished table: +65536 (or -1) on the bucket,
@@ -967,13 +987,41 @@ hipError_t launch_part_hist(const PartHistPlan &P, hipStream_t st) {
     return hipErrorInvalidValue;
 }
 
+// k_outlog_gather: the staging stripes of the outlier log (outlog.h) closed up into the query's dense log, stripe after
+// stripe, and the number of records appended into the header.  A stripe that received more than its share lost records
+// although the log as a whole may still have room: the header then says "more than the capacity" (the printers treat
+// the values as unavailable, as when the whole log overflowed).
+__global__ __launch_bounds__(256) void k_outlog_gather(const int64_t *__restrict__ stage, int64_t cap, int64_t *__restrict__ log, int64_t *header) {
+    const int64_t per = cap / kOutStripes;
+    const int s = blockIdx.x;
+    int64_t before = 0, total = 0, mine = 0;
+    bool lost = false;
+    for (int k = 0; k < kOutStripes; k++) {
+        const int64_t c = stage[(size_t)k * kOutCursorWords];
+        const int64_t n = c < per ? c : per;
+        lost = lost || c > per;
+        total += c;
+        before += k < s ? n : 0;
+        mine = k == s ? n : mine;
+    }
+    const int64_t *src = stage + (size_t)kOutStripes * kOutCursorWords + (size_t)s * (size_t)per * kOutLogWords;
+    int64_t *dst = log + before * kOutLogWords;
+    for (int64_t i = threadIdx.x; i < mine * kOutLogWords; i += blockDim.x) dst[i] = src[i];
+    if (s == 0 && threadIdx.x == 0) header[kHdrOutLog] = lost && total <= cap ? cap + 1 : total;
+}
+hipError_t launch_outlog_gather(const int64_t *stage, int64_t cap, int64_t *log, int64_t *header, hipStream_t st) {
+    hipLaunchKernelGGL(k_outlog_gather, dim3(kOutStripes), dim3(256), 0, st, stage, cap, log, header);
+    return hipGetLastError();
+}
+
 // Bucket tables on their way through a reduce-scatter (rccl.cpp): int64 counters narrowed to int32 when the ranks'
 // rows together stay below 2^31 (half the bytes over xGMI), and the reduced slice widened again in place.
 __global__ __launch_bounds__(256) void k_pack32(const int64_t *__restrict__ src, int32_t *__restrict__ dst, int64_t n) {
+    // (src = d_sum + hist_off is only 8-byte aligned -- hist_off may be odd, d_sum may be caller-bound: two 8-byte loads)
     for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2; i < n; i += (int64_t)gridDim.x * blockDim.x * 2) {
         if (i + 1 < n) {
-            const ll2 v = *(const ll2 *)(src + i);
-            *(int2 *)(dst + i) = make_int2((int32_t)v.x, (int32_t)v.y);
+            const int64_t v0 = src[i], v1 = src[i + 1];
+            *(int2 *)(dst + i) = make_int2((int32_t)v0, (int32_t)v1);
         } else {
             dst[i] = (int32_t)src[i];
         }

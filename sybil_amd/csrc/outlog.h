@@ -1,0 +1,45 @@
+// outlog.h -- appending to the outlier log (plan.h) from any scan kernel's row body.
+// Reference: BasicHist.AddWeightedValue remembers the values it clips (hist_basic.go:132-142).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "plan.h"
+
+namespace sybl {
+
+#ifdef __HIPCC__
+// one record of the outlier log (plan.h), called by whichever lanes of a wave hold an outlier at this point of the row
+// body.  Round 3 took every record's place from ONE cursor: 10^7 outliers were 2^20 same-address device-scope atomics
+// (~45 ms) before the log was full.  Now (a) the lanes that are here together reserve their places with one atomic
+// (ballot of the active lanes, the first one adds their number, the others take their rank's offset), and (b) the wave
+// appends to one of kOutStripes staging stripes, each behind a cursor on a line of its own, chosen by workgroup and wave
+// number -- with ~1 % outliers only one or two lanes of a wave meet here, so it is the stripes that spread the
+// contention.  A full stripe is noticed with a load and left alone (its cursor then says "more than its share").
+__device__ __forceinline__ void log_outlier(int64_t *stage, int64_t cap, int64_t where, int agg, int64_t value) {
+    const uint32_t stripe = ((blockIdx.x * 16u + (threadIdx.x >> 6)) * 0x9E3779B1u) >> 26;  // (wave-uniform; kOutStripes = 64)
+    static_assert(kOutStripes == 64, "six hash bits pick the stripe");
+    int64_t *cursor = stage + (size_t)stripe * kOutCursorWords;
+    const int64_t per = cap / kOutStripes;
+    if (__hip_atomic_load(cursor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > per) return;
+    const unsigned long long here = __builtin_amdgcn_ballot_w64(true);  // the lanes in this branch together
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(here >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)here, 0u));
+    uint32_t lo = 0, hi = 0;
+    if (rank == 0) {
+        const int64_t b = __hip_atomic_fetch_add(cursor, (int64_t)__builtin_popcountll(here), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        lo = (uint32_t)(uint64_t)b;
+        hi = (uint32_t)((uint64_t)b >> 32);
+    }
+    lo = __builtin_amdgcn_readfirstlane(lo);  // (the first active lane is the one of rank 0)
+    hi = __builtin_amdgcn_readfirstlane(hi);
+    const int64_t i = (int64_t)((uint64_t)lo | (uint64_t)hi << 32) + (int64_t)rank;
+    if (i < per) {
+        int64_t *rec = stage + (size_t)kOutStripes * kOutCursorWords + ((size_t)stripe * (size_t)per + (size_t)i) * kOutLogWords;
+        rec[0] = where;
+        rec[1] = agg;
+        rec[2] = value;
+    }
+}
+#endif  // __HIPCC__
+
+}  // namespace sybl

@@ -149,9 +149,12 @@ struct ScanPlan {
     // Outlier log (queries that keep bucket arrays and whose column bounds allow a value beyond the last bucket):
     // every outlier / underlier is appended as (cell or composite key, aggregation, value) -- the reference remembers
     // the values themselves (hist_basic.go:132-142) and prints them as buckets of their own (GetStrBuckets, :239-257).
-    // The cursor is header word kHdrOutLog; records beyond out_cap are only counted.
-    int64_t *out_log;
-    int64_t out_cap;
+    // The kernels append to a STAGING log of kOutStripes stripes, each behind a cursor of its own (a wave picks its
+    // stripe from its workgroup and wave number and reserves the places of all its outlier lanes with one atomic:
+    // scan_generic.h, log_outlier); k_outlog_gather closes the stripes up into the query's dense log behind the scan and
+    // writes the number of records appended to header word kHdrOutLog (more than out_cap: some were only counted).
+    int64_t *out_log;        // staging: [kOutStripes][kOutCursorWords] cursors, then [kOutStripes][out_cap / kOutStripes] records
+    int64_t out_cap;         // records the log holds (a multiple of kOutStripes)
     const MultiSub *multi;   // -loghist: every aggregation's sub-histograms
     int64_t hist_off;        // word offset of bucket arrays in the SUM section
     int64_t hist_stride;     // words per cell = sum of n_values over full-hist aggs
@@ -193,6 +196,8 @@ struct HistSummaryPlan {
 };
 
 constexpr int kOutLogWords = 3;                  // int64 words per outlier record: cell / key, aggregation, value
+constexpr int kOutStripes = 64;                  // staging stripes of the outlier log (one cursor each)
+constexpr int kOutCursorWords = 16;              // a 128-byte line per cursor
 constexpr int64_t kOutLogDefaultCap = 1 << 20;   // records
 constexpr uint64_t kHashEmpty = ~(uint64_t)0;   // free slot of the group hash table (composite keys are below 2^62)
 constexpr int64_t kHashMaxSlots = (int64_t)1 << 27;
@@ -204,7 +209,7 @@ enum Header : int {
     kHdrPartOverflow = 2, // partitioned histograms: records that did not fit their partition buffer
     kHdrEmitStall = 3,    // partitioned histograms: a lane gave up waiting for a staging chunk (must be 0: a bug)
     kHdrHashFull = 4,     // hash group-by: rows whose key found no free slot (more distinct keys than the table holds)
-    kHdrOutLog = 5,       // outlier log: records appended (may exceed the log's capacity: the rest was dropped)
+    kHdrOutLog = 5,       // outlier log: records appended (k_outlog_gather; more than the log's capacity: some were dropped)
 };
 
 }  // namespace sybl

@@ -1144,8 +1144,10 @@ struct Planner {
             if (any_out && q->want_percentiles && !getenv("SYBL_NO_OUTLIER_LOG")) {
                 q->out_cap = kOutLogDefaultCap;
                 if (const char *e = getenv("SYBL_OUTLIER_LOG_CAP")) q->out_cap = std::max<int64_t>(1, atoll(e));
+                q->out_cap = (q->out_cap + kOutStripes - 1) / kOutStripes * kOutStripes;  // (equal stripes)
                 SYBL_HIP(hipMalloc((void **)&q->d_out_log, (size_t)q->out_cap * kOutLogWords * 8));
-                P.out_log = q->d_out_log;
+                SYBL_HIP(hipMalloc((void **)&q->d_out_stage, ((size_t)kOutStripes * kOutCursorWords + (size_t)q->out_cap * kOutLogWords) * 8));
+                P.out_log = q->d_out_stage;
                 P.out_cap = q->out_cap;
             }
         }

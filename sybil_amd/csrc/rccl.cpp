@@ -26,6 +26,16 @@ static int nccl_fail(ncclResult_t r, const char *what) {
         if (r__ != ncclSuccess) return nccl_fail(r__, #expr); \
     } while (0)
 
+// ... between ncclGroupStart and ncclGroupEnd: a failing call closes the group before it returns
+#define SYBL_NCCL_G(expr)                                 \
+    do {                                                  \
+        ncclResult_t r__ = (expr);                        \
+        if (r__ != ncclSuccess) {                         \
+            (void)ncclGroupEnd();                         \
+            return nccl_fail(r__, #expr);                 \
+        }                                                 \
+    } while (0)
+
 namespace sybl {
 
 int comm_allgather_inplace(Ctx *ctx, int64_t *buf, size_t words_per_rank) {
@@ -83,9 +93,9 @@ static int query_hash_allreduce(Query *q) {
     }
     const int64_t n = q->hash_live;
     SYBL_NCCL(ncclGroupStart());
-    SYBL_NCCL(ncclAllReduce(q->d_dense_sum, q->d_dense_sum, (size_t)hash_dense_sum_words(q, n), ncclInt64, ncclSum, comm, st));
+    SYBL_NCCL_G(ncclAllReduce(q->d_dense_sum, q->d_dense_sum, (size_t)hash_dense_sum_words(q, n), ncclInt64, ncclSum, comm, st));
     if (q->plan.n_max_fields > 0 && n > 0)
-        SYBL_NCCL(ncclAllReduce(q->d_dense_max, q->d_dense_max, (size_t)hash_dense_max_words(q, n), ncclInt64, ncclMax, comm, st));
+        SYBL_NCCL_G(ncclAllReduce(q->d_dense_max, q->d_dense_max, (size_t)hash_dense_max_words(q, n), ncclInt64, ncclMax, comm, st));
     SYBL_NCCL(ncclGroupEnd());
     return SYBL_OK;
 }
@@ -99,14 +109,14 @@ static int gather_outlier_logs(Query *q, int64_t local) {
     hipStream_t st = ctx->stream;
     const int R = ctx->comm_nranks, me = ctx->comm_rank;
     local = std::min<int64_t>(local, q->out_cap);  // (records beyond the capacity were only counted)
-    int64_t *d_counts = nullptr;
-    SYBL_HIP(hipMalloc((void **)&d_counts, (size_t)R * 8));
+    DevOwner own_counts, own_all;  // (freed on every exit)
+    SYBL_HIP(hipMalloc(&own_counts.p, (size_t)R * 8));
+    int64_t *d_counts = (int64_t *)own_counts.p;
     std::vector<int64_t> counts((size_t)R, 0);
     SYBL_HIP(hipMemcpyAsync(d_counts + me, &local, 8, hipMemcpyHostToDevice, st));
     ncclResult_t nr = ncclAllGather(d_counts + me, d_counts, 1, ncclInt64, comm, st);
     hipError_t e = nr == ncclSuccess ? hipMemcpyAsync(counts.data(), d_counts, (size_t)R * 8, hipMemcpyDeviceToHost, st) : hipSuccess;
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    (void)hipFree(d_counts);
     if (nr != ncclSuccess) return nccl_fail(nr, "ncclAllGather(outlier counts)");
     if (e != hipSuccess) return hip_fail(e, "outlier counts");
     int64_t per = 0, total = 0;
@@ -116,9 +126,9 @@ static int gather_outlier_logs(Query *q, int64_t local) {
     }
     if (total > q->out_cap) return SYBL_OK;  // stays partial
     if (per > 0) {
-        int64_t *d_all = nullptr;
         const size_t words = (size_t)per * kOutLogWords;
-        SYBL_HIP(hipMalloc((void **)&d_all, words * (size_t)R * 8));
+        SYBL_HIP(hipMalloc(&own_all.p, words * (size_t)R * 8));
+        int64_t *d_all = (int64_t *)own_all.p;
         e = hipMemcpyAsync(d_all + (size_t)me * words, q->d_out_log, (size_t)local * kOutLogWords * 8, hipMemcpyDeviceToDevice, st);
         if (e == hipSuccess) nr = ncclAllGather(d_all + (size_t)me * words, d_all, words, ncclInt64, comm, st);
         int64_t at = 0;
@@ -128,7 +138,6 @@ static int gather_outlier_logs(Query *q, int64_t local) {
             at += counts[(size_t)r];
         }
         (void)hipStreamSynchronize(st);
-        (void)hipFree(d_all);
         if (nr != ncclSuccess) return nccl_fail(nr, "ncclAllGather(outlier logs)");
         if (e != hipSuccess) return hip_fail(e, "outlier logs");
     }
@@ -210,41 +219,47 @@ int sybl_query_allreduce(sybl_query *q) {
     // blocking MAX all-reduce at the query's first collective) times the ranks; a bucket of the merged table cannot
     // exceed that.  Weighted queries keep int64 (a bucket holds a sum of weights).
     if (scatter && q->rs_int32 < 0) {
-        int64_t *d_rows = nullptr, rows = q->stats.rows_scanned;
-        SYBL_HIP(hipMalloc((void **)&d_rows, 8));
+        DevOwner own_rows;
+        int64_t rows = q->stats.rows_scanned;
+        SYBL_HIP(hipMalloc(&own_rows.p, 8));
+        int64_t *d_rows = (int64_t *)own_rows.p;
         SYBL_HIP(hipMemcpyAsync(d_rows, &rows, 8, hipMemcpyHostToDevice, ctx->stream));
         ncclResult_t nr = ncclAllReduce(d_rows, d_rows, 1, ncclInt64, ncclMax, comm, ctx->stream);
         hipError_t e = nr == ncclSuccess ? hipMemcpyAsync(&rows, d_rows, 8, hipMemcpyDeviceToHost, ctx->stream) : hipSuccess;
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        (void)hipFree(d_rows);
         if (nr != ncclSuccess) return nccl_fail(nr, "ncclAllReduce(shard rows)");
         if (e != hipSuccess) return hip_fail(e, "shard rows");
         q->rs_int32 = (!q->weighted && !getenv("SYBL_NO_SCATTER32") && rows * (int64_t)ctx->comm_nranks < ((int64_t)1 << 31)) ? 1 : 0;
     }
+    // (everything that can fail on its own -- the int32 staging buffer, k_pack32 -- runs before the group is opened: an
+    // early return between ncclGroupStart and ncclGroupEnd would leave the group open)
+    if (scatter && q->rs_int32 == 1) {
+        const int64_t R = ctx->comm_nranks, per = (P.n_cells + R - 1) / R, count = per * P.hist_stride;
+        if (!q->d_h32) SYBL_HIP(hipMalloc((void **)&q->d_h32, (size_t)(count * (R + 1)) * 4));
+        hipError_t e = launch_pack32(q->d_sum + P.hist_off, q->d_h32, count * R, ctx->stream);
+        if (e != hipSuccess) return hip_fail(e, "k_pack32");
+    }
     SYBL_NCCL(ncclGroupStart());
     if (!scatter) {
-        SYBL_NCCL(ncclAllReduce(q->d_sum, q->d_sum, (size_t)(small_words + hist_words), ncclInt64, ncclSum, comm, ctx->stream));
+        SYBL_NCCL_G(ncclAllReduce(q->d_sum, q->d_sum, (size_t)(small_words + hist_words), ncclInt64, ncclSum, comm, ctx->stream));
     } else {
         const int64_t R = ctx->comm_nranks, per = (P.n_cells + R - 1) / R, count = per * P.hist_stride;
         int64_t *H = q->d_sum + P.hist_off;
-        SYBL_NCCL(ncclAllReduce(q->d_sum, q->d_sum, (size_t)small_words, ncclInt64, ncclSum, comm, ctx->stream));
+        SYBL_NCCL_G(ncclAllReduce(q->d_sum, q->d_sum, (size_t)small_words, ncclInt64, ncclSum, comm, ctx->stream));
         // (cells past n_cells in the last slice are the zeroed padding of the SUM section)
         if (q->rs_int32 == 1) {
-            if (!q->d_h32) SYBL_HIP(hipMalloc((void **)&q->d_h32, (size_t)(count * (R + 1)) * 4));
-            hipError_t e = launch_pack32(H, q->d_h32, count * R, ctx->stream);
-            if (e != hipSuccess) return hip_fail(e, "k_pack32");
-            SYBL_NCCL(ncclReduceScatter(q->d_h32, q->d_h32 + count * R, (size_t)count, ncclInt32, ncclSum, comm, ctx->stream));
+            SYBL_NCCL_G(ncclReduceScatter(q->d_h32, q->d_h32 + count * R, (size_t)count, ncclInt32, ncclSum, comm, ctx->stream));
         } else {
-            SYBL_NCCL(ncclReduceScatter(H, H + (int64_t)ctx->comm_rank * count, (size_t)count, ncclInt64, ncclSum, comm, ctx->stream));
+            SYBL_NCCL_G(ncclReduceScatter(H, H + (int64_t)ctx->comm_rank * count, (size_t)count, ncclInt64, ncclSum, comm, ctx->stream));
         }
         q->rs_active = true;
         q->rs_cells_per = per;
         q->rs_cell0 = std::min<int64_t>(P.n_cells, (int64_t)ctx->comm_rank * per);
         q->rs_cell1 = std::min<int64_t>(P.n_cells, q->rs_cell0 + per);
     }
-    if (has_max) SYBL_NCCL(ncclAllReduce(q->d_max, q->d_max, (size_t)q->n_max_words, ncclInt64, ncclMax, comm, ctx->stream));
+    if (has_max) SYBL_NCCL_G(ncclAllReduce(q->d_max, q->d_max, (size_t)q->n_max_words, ncclInt64, ncclMax, comm, ctx->stream));
     // count distinct: Result.Combine merges the sketches register by register (query_spec.go:180-188)
-    if (q->n_distinct) SYBL_NCCL(ncclAllReduce(q->d_hll, q->d_hll, (size_t)q->hll_bytes, ncclUint8, ncclMax, comm, ctx->stream));
+    if (q->n_distinct) SYBL_NCCL_G(ncclAllReduce(q->d_hll, q->d_hll, (size_t)q->hll_bytes, ncclUint8, ncclMax, comm, ctx->stream));
     SYBL_NCCL(ncclGroupEnd());
     if (scatter && q->rs_int32 == 1) {
         const int64_t R = ctx->comm_nranks, per = (P.n_cells + R - 1) / R, count = per * P.hist_stride;

@@ -14,6 +14,7 @@
 #include <stdint.h>
 
 #include "plan.h"
+#include "outlog.h"
 
 namespace sybl {
 
@@ -189,7 +190,9 @@ struct PartHistPlan {
     double pinv_bucket[kFastMaxA];   // 1 / BucketSize scaled by (1 - 2^-40): the quotient estimate is never above the true one
     int64_t hist_off, hist_stride;
     int64_t *sum_out, *max_out;
+    unsigned long long *trace;       // SYBL_PARTHIST_TRACE (diagnostic): [workgroup][kPartTraceWords] timestamps of the phases
 };
+constexpr int kPartTraceWords = 32;
 
 // tiles of column loads a lane keeps in flight: a tile is only 8..16 bytes per column and lane, and a CU needs
 // ~64 KB on the way to keep HBM busy; bounded by registers (one 16-byte register quad per column and tile)
@@ -483,16 +486,7 @@ __device__ __forceinline__ void fast_accumulate(const FastPlan &P0, const FastTi
                         fast_add64<LDS>(tab, fi + 3 * step, (int64_t)(uint64_t)((sq >> 32) & 0xFFFFFFFFu));
                         fast_add64<LDS>(tab, fi + 4 * step, (int64_t)(uint64_t)((sq >> 64) & 0xFFFFFFFFu));
                         fast_add64<LDS>(tab, fi + 5 * step, (int64_t)(uint64_t)(sq >> 96));
-                        if (P.out_log) {
-                            // (a full log is noticed with a load and left alone: scan_generic.h, log_outlier)
-                            const bool room = __hip_atomic_load(P.sum_out + kHdrOutLog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= P.out_cap;
-                            const int64_t i = room ? __hip_atomic_fetch_add(P.sum_out + kHdrOutLog, (int64_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : P.out_cap;
-                            if (i < P.out_cap) {
-                                P.out_log[i * kOutLogWords] = logkey;
-                                P.out_log[i * kOutLogWords + 1] = c;
-                                P.out_log[i * kOutLogWords + 2] = x;
-                            }
-                        }
+                        if (P.out_log) log_outlier(P.out_log, P.out_cap, logkey, c, x);
                     } else {
                         overflow += 1;
                     }

@@ -9,6 +9,7 @@
 #include <stdint.h>
 
 #include "plan.h"
+#include "outlog.h"
 
 namespace sybl {
 
@@ -76,20 +77,6 @@ __device__ __forceinline__ void acc_max(int64_t *tab, int64_t idx, int64_t v) {
 
 __device__ __forceinline__ void gadd(int64_t *p, int64_t v) {
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// one record of the outlier log (plan.h)
-__device__ __forceinline__ void log_outlier(int64_t *header, int64_t *log, int64_t cap, int64_t where, int agg, int64_t value) {
-    // Every record takes its place from ONE cursor: 10^7 outliers (1 % of 10^9 values) are 10^7 atomics on one address,
-    // ~100 ms.  Once the cursor is past the capacity the rest is dropped anyway and finalize only needs to see
-    // "more than cap": a full log is noticed with a load and left alone.
-    if (__hip_atomic_load(header + kHdrOutLog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > cap) return;
-    const int64_t i = __hip_atomic_fetch_add(header + kHdrOutLog, (int64_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (i < cap) {
-        log[i * kOutLogWords] = where;
-        log[i * kOutLogWords + 1] = agg;
-        log[i * kOutLogWords + 2] = value;
-    }
 }
 
 __device__ __forceinline__ int64_t wave_sum(int64_t v) {
@@ -337,7 +324,7 @@ __device__ __forceinline__ void row_accumulate(CPlan &P, const Tile<NC> &t, int 
                     acc_add<USE_LDS>(sumtab, fi + 3 * step, (int64_t)(uint64_t)((sq >> 32) & 0xFFFFFFFFu));
                     acc_add<USE_LDS>(sumtab, fi + 4 * step, (int64_t)(uint64_t)((sq >> 64) & 0xFFFFFFFFu));
                     acc_add<USE_LDS>(sumtab, fi + 5 * step, (int64_t)(uint64_t)(sq >> 96));
-                    if (P.out_log) log_outlier(P.sum_out, P.out_log, P.out_cap, logkey, s.agg_index, x);
+                    if (P.out_log) log_outlier(P.out_log, P.out_cap, logkey, s.agg_index, x);
                 } else {
                     overflow += 1;  // declared bounds violated; reported by finalize
                 }

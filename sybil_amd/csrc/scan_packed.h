@@ -344,16 +344,7 @@ __device__ __forceinline__ void packed_row(const FastPlan &P0, const PackedTile<
                     add(fo + 3, (int64_t)(uint64_t)((sq >> 32) & 0xFFFFFFFFu));
                     add(fo + 4, (int64_t)(uint64_t)((sq >> 64) & 0xFFFFFFFFu));
                     add(fo + 5, (int64_t)(uint64_t)(sq >> 96));
-                    if (P.out_log) {
-                        // (a full log is noticed with a load and left alone: scan_generic.h, log_outlier)
-                        const bool room = __hip_atomic_load(P.sum_out + kHdrOutLog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= P.out_cap;
-                        const int64_t i = room ? __hip_atomic_fetch_add(P.sum_out + kHdrOutLog, (int64_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : P.out_cap;
-                        if (i < P.out_cap) {
-                            P.out_log[i * kOutLogWords] = (int64_t)cell;
-                            P.out_log[i * kOutLogWords + 1] = c;
-                            P.out_log[i * kOutLogWords + 2] = x;
-                        }
-                    }
+                    if (P.out_log) log_outlier(P.out_log, P.out_cap, (int64_t)cell, c, x);
                 } else {
                     overflow += 1;
                 }

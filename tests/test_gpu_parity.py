@@ -995,3 +995,75 @@ def test_bucket_counters_that_wrap(ctx, oracle, monkeypatch, compact, fused):
     r.free()
     q.free()
     tb.free()
+
+
+def _append_all(tb, n, cols):
+    for r0 in range(0, n, 65536):
+        r1 = min(r0 + 65536, n)
+        tb.append_block(r1 - r0, {k: v[r0:r1] for k, v in cols.items()})
+
+
+@pytest.mark.parametrize("compact", [False, True])
+def test_three_aggregations_rescanned_with_unequal_splits(ctx, oracle, compact):
+    """Three aggregations over ~6000 groups: the first partitioned-histogram pass (two aggregations, > 128 partitions) gives
+    every partition to one workgroup, the second (one aggregation, half the partitions) shares its partitions between
+    workgroups and accumulates with atomics -- into a table that must start from zero on EVERY scan of the prepared query,
+    not only on the first (the allocation is memset once)."""
+    rng = np.random.default_rng(41)
+    n = 900_000
+    g = rng.integers(0, 6000, n, dtype=np.int64)
+    a = rng.integers(0, 1_000_000, n, dtype=np.int64)
+    b = rng.integers(0, 50_000, n, dtype=np.int64)
+    c = rng.integers(0, 1_000_000, n, dtype=np.int64)
+    tb = ctx.create_table("resplit")
+    tb.add_column("g", "int", 0, 5999)
+    tb.add_column("a", "int", 0, 999_999)
+    tb.add_column("b", "int", 0, 49_999)
+    tb.add_column("c", "int", 0, 999_999)
+    _append_all(tb, n, {"g": g, "a": a, "b": b, "c": c})
+    if compact:
+        tb.compact()
+    q = tb.query(groups=["g"], aggs=["a", "b", "c"], op="hist")
+    o = oracle.run_query([{"type": "int", "data": x} for x in (g, a, b, c)], groups=[0],
+                         aggs=[(1, 0, 999_999), (2, 0, 49_999), (3, 0, 999_999)], op="hist")
+    for _ in range(3):
+        r = q.run()
+        assert q.stats()["strategy"] == 5
+        parity.compare(r, o, op="hist", full=True, n_aggs=3)
+        r.free()
+    q.free()
+    tb.free()
+
+
+@pytest.mark.parametrize("two", [False, True])
+def test_wrapping_last_bucket_of_an_odd_bucket_count(ctx, oracle, two):
+    """Info = [0, 99] gives 101 buckets (hist_basic.go:34-70): the last one, index 100, is the LOW half of a counter word
+    whose high half belongs to no bucket, and it is where values beyond the range are clipped to (outliers, accepted up
+    to Info.Max x 10).  > 65 536 of them in one group wrap the 16-bit field and carry into that unused half: the carry must
+    neither be counted nor logged as a -1 for a bucket that does not exist (with a second, 1002-bucket aggregation the
+    words are laid out for 1002: the -1 would land in the neighbour's bucket 0)."""
+    rng = np.random.default_rng(43)
+    n = 600_000
+    g = rng.integers(0, 3000, n, dtype=np.int64)
+    g[rng.random(n) < 0.6] = 7
+    v = rng.integers(0, 100, n, dtype=np.int64)
+    hot = (g == 7) & (rng.random(n) < 0.5)
+    v[hot] = rng.integers(200, 990, int(hot.sum()))  # outliers: beyond bucket 100's lower edge, within Info.Max x 10
+    w = rng.integers(0, 1_000_000, n, dtype=np.int64)
+    tb = ctx.create_table("oddwrap")
+    tb.add_column("g", "int", 0, 2999)
+    tb.add_column("v", "int", 0, 99)
+    tb.add_column("w", "int", 0, 999_999)
+    _append_all(tb, n, {"g": g, "v": v, "w": w})
+    aggs = ["v", "w"] if two else ["v"]
+    q = tb.query(groups=["g"], aggs=aggs, op="hist")
+    r = q.run()
+    assert q.stats()["strategy"] == 5, q.stats()
+    o = oracle.run_query([{"type": "int", "data": x} for x in (g, v, w)], groups=[0],
+                         aggs=[(1, 0, 99), (2, 0, 999_999)][:len(aggs)], op="hist")
+    big = [x for x in o["results"] if x["count"] > 300_000]
+    assert len(big) == 1 and big[0]["hists"][0]["n_values"] == 101 and big[0]["hists"][0]["values"][100] > 2 * 65536
+    parity.compare(r, o, op="hist", full=True, n_aggs=len(aggs))
+    r.free()
+    q.free()
+    tb.free()
