@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <algorithm>
 
 #include "plan.h"
 #include "scan_fast.h"
@@ -583,322 +584,326 @@ __device__ __noinline__ void part_outlier(const PartHistPlan &P, uint32_t pair, 
     if (P.out_log) log_outlier(P.out_log, P.out_cap, (int64_t)cell, P.agg0 + (int)a, x);
 }
 
+// Round 4: the kernel is PERSISTENT -- one workgroup per compute unit claims (partition, share) items from a counter
+// until none is left -- and its waves claim the regions of an item from an LDS cursor instead of owning every 16th.
+// The phase trace of the one-workgroup-per-item version (SYBL_PARTHIST_TRACE, config 4: 1024 workgroups over 256 CUs)
+// showed why it ran at 75 % occupancy: per item 18 us of launch + zeroing + region table, 267 us of walk in which the
+// waves of a workgroup finished up to 98 us apart (54 us of idle wave time on average: older waves win the issue
+// arbitration), 28 us for 64 serial count reductions, 20 us of write-out and 9 us until the next workgroup started.
+// The epilogue is one pass now: the wave that owns a pair reads its counters once, stores the buckets and sums them.
 template <int NA, bool TRACK_MAX, bool OUT>
 __global__ __launch_bounds__(kWgThreads) void k_part_hist(const PartHistPlan P) {
     extern __shared__ uint32_t plds[];
     const uint32_t tid = threadIdx.x;
-    // (diagnostic, SYBL_PARTHIST_TRACE: the 100 MHz wall clock at the phase boundaries; word 0 start, 1 tables zeroed and
-    // regions read, 2 records walked, 3 counts and sums reduced, 4 table written, 5 the compute unit, 16.. when each wave
-    // finished its walk)
-    auto stamp = [&](int k) {
-        if (P.trace && tid == 0) P.trace[(size_t)blockIdx.x * kPartTraceWords + k] = wall_clock64();
-    };
-    stamp(0);
     const uint32_t nv = (uint32_t)P.nv_max, nw = (nv + 1u) >> 1;  // buckets, words per pair
+    const uint32_t split = (uint32_t)P.split, n_items = (uint32_t)P.n_parts * split;
+    const uint32_t n_reg_max = ((uint32_t)P.n_wg + split - 1u) / split;
     uint32_t *hist = plds;                                       // [kPartCells][nw] two 16-bit counters per word
-    uint32_t *cnt = plds + kPartCells * nw;                      // [kPartCells]
-    unsigned long long *sum = (unsigned long long *)(cnt + kPartCells);                     // [kPartCells][kPartSumRep]
+    unsigned long long *sum = (unsigned long long *)(hist + kPartCells * nw);               // [kPartCells][kPartSumRep]
     long long *vmax = (long long *)(sum + kPartSumRep * kPartCells);                        // [kPartCells]
-    for (uint32_t i = tid; i < kPartCells * nw; i += kWgThreads) hist[i] = 0;
-    if (tid < kPartSumRep * kPartCells) sum[tid] = 0;
-    if (tid < kPartCells) {
-        cnt[tid] = 0;
-        vmax[tid] = INT64_MIN;
-    }
-
-    const uint32_t split = (uint32_t)P.split;
-    // (wave-uniform by construction; said so explicitly: the divide goes through the vector ALU, and with these in
-    // vector registers every region loop and record load below became a divergent loop / a waterfall loop)
-    const uint32_t part = __builtin_amdgcn_readfirstlane(blockIdx.x / split), sub = __builtin_amdgcn_readfirstlane(blockIdx.x % split);
-    const uint32_t *recs = P.recs;
-    const uint32_t pair0 = part * kPartCells;
+    uint2 *regions = (uint2 *)(vmax + kPartCells);                                          // [n_reg_max] {first chunk, pieces}
+    const uint32_t lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned long long *dummy64 = (unsigned long long *)(regions + n_reg_max) + lane;       // [64] scratch words (add_record)
+    uint32_t *dummy32 = (uint32_t *)((unsigned long long *)(regions + n_reg_max) + 64) + lane;  // [64]
+    uint32_t *ctl = (uint32_t *)((unsigned long long *)(regions + n_reg_max) + 64) + 64;    // [1] region cursor, [2], [3] the item claimed / the next one
+    // (diagnostic, SYBL_PARTHIST_TRACE: the 100 MHz wall clock at the phase boundaries of every item; word 0 claimed, 1 tables
+    // zeroed and regions read, 2 records walked, 4 table written, 5 the compute unit, 16.. when each wave finished its walk)
+    uint32_t item = 0;
+    auto stamp = [&](int k) {
+        if (P.trace && tid == 0) P.trace[(size_t)item * kPartTraceWords + k] = wall_clock64();
+    };
     unsigned long long *my_sum = sum + (tid & (kPartSumRep - 1));  // [pair][replica]: the replicas of a pair in different banks
     // pair0 is a multiple of kPartCells, so with two aggregations a pair's aggregation is the low bit of `local`
     // (NA, and whether any maximum is tracked, are template parameters: as run-time values they cost a chain of
-    // selects per record in a kernel whose vector ALUs are ~70 % busy)
+    // selects per record in a kernel whose vector ALUs are ~60 % busy)
     constexpr bool two = NA == 2;
     const uint32_t bs0 = (uint32_t)P.bucket_size[0], bs1 = (uint32_t)P.bucket_size[two ? 1 : 0];
     const uint32_t nv0 = (uint32_t)P.n_values[0], nv1 = (uint32_t)P.n_values[two ? 1 : 0];
     const double inv0 = P.pinv_bucket[0], inv1 = P.pinv_bucket[two ? 1 : 0];
-    auto bucket_of = [&](uint32_t rec, uint32_t &local, uint32_t &n32) -> uint32_t {
-        n32 = rec & ((1u << kRecValueBits) - 1);  // v - h.Min
-        local = rec >> kRecValueBits;
-        const uint32_t a = two ? (local & 1u) : 0u;
-        const uint32_t bs = two && a ? bs1 : bs0;
-        const double inv = two && a ? inv1 : inv0;
-        // floor(n32 / BucketSize), hist_basic.go:130-150: the estimate is never above the quotient and at most one short
-        // of it (scan_packed.h: packed_udiv); bucket < 2^10 and BucketSize < 2^24 (planner), so the product takes 24 bits
-        uint32_t b = (uint32_t)((double)n32 * inv);
-        if (n32 - __umul24(b, bs) >= bs) b += 1;
-        return b;
-    };
-    // One record: returns the word as it was before the add, shifted so that the bucket's own field is the low half (an
-    // even bucket's neighbour field is then the high half).  No branch per record: a padding record (or a lane past the
-    // region's end) aims its two atomics at a scratch word of its own -- behind the region table -- instead of being
-    // skipped, so the sixteen adds of a batch are in flight together and their results are looked at once (what comes
-    // back from a scratch word is checked for liveness again on the wrap path).  Measured against sixteen `if (live)`
-    // blocks, each waiting for its returned counter: the same 1.3 ms -- the kernel is not bound there.
-    uint32_t *dummy32 = nullptr;
-    unsigned long long *dummy64 = nullptr;
-    auto add_record = [&](uint32_t rec, bool in) -> uint32_t {
-        const bool live = in && rec != kRecSentinel;
-        uint32_t local, n32;
-        uint32_t b = bucket_of(rec, local, n32);
-        if (OUT) {
-            // Outlier (hist_basic.go:132-135): clipped into the last bucket and remembered (part_outlier)
-            const uint32_t nva = two && (local & 1u) ? nv1 : nv0;
-            if (b >= nva) {
-                if (live) part_outlier(P, pair0 + local, n32);
-                b = nva - 1u;
-            }
-        }
-        const uint32_t sh = (b & 1u) << 4;
-        uint32_t *hp = live ? hist + __umul24(local, nw) + (b >> 1) : dummy32;
-        unsigned long long *sp = live ? my_sum + local * kPartSumRep : dummy64;
-        const uint32_t old = __hip_atomic_fetch_add(hp, 1u << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(sp, (unsigned long long)n32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (TRACK_MAX && live) {
-            const uint32_t a = two ? (local & 1u) : 0u;
-            if (P.m_max[a] >= 0) {
-                const long long v = (long long)((unsigned long long)P.hmin[a] + (unsigned long long)n32);
-                if (v > vmax[local]) __hip_atomic_fetch_max(vmax + local, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-        }
-        return old >> sh;
-    };
-    auto wrapped = [](uint32_t seen) { return (seen & 0xFFFFu) == 0xFFFFu; };
-    auto log_wrap = [&](uint32_t rec, uint32_t seen) {  // (rare)
-        uint32_t local, n32;
-        uint32_t b = bucket_of(rec, local, n32);
-        const uint32_t nva = two && (local & 1u) ? nv1 : nv0;
-        if (OUT) b = b >= nva ? nva - 1u : b;  // (an outlier was counted in the last bucket)
-        // (the aggregation's own bucket count: the high field next to an even last bucket belongs to nobody -- a carry
-        // into it is neither logged nor, below, counted)
-        part_log_wrap(P, pair0 + local, b, (b & 1u) ? 0u : seen, nva);
-    };
-
-    // The partition's records: one region per scanning workgroup w (the partition's sub-bins are neighbours in w's
-    // output: chunks boff[w][part << ss] .. boff[w][(part + 1) << ss] behind wbase[w]).  `split` workgroups share a
-    // partition by taking every split-th region; inside a workgroup every wave walks its own regions, 16-byte pieces
-    // (four records) per lane and kPartUnroll loads per lane in flight twice over (current + next batch) -- raw buffer
-    // loads whose descriptor is the region, so nothing depends on a lane's bounds when the loads are issued.
+    const uint32_t *recs = P.recs;
+    const uint32_t nb1 = ((uint32_t)P.n_parts << P.sub_shift) + 1u;
+    const uint32_t total_pairs = (uint32_t)P.n_cells * (uint32_t)NA;
+    int64_t *F = P.sum_out + kHeaderWords;
     typedef unsigned int rec4 __attribute__((ext_vector_type(4)));
-    const uint32_t lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nb1 = ((uint32_t)P.n_parts << P.sub_shift) + 1u;
-    const uint32_t b_lo = part << P.sub_shift, b_hi = (part + 1u) << P.sub_shift;
-    const uint32_t n_reg = __builtin_amdgcn_readfirstlane((uint32_t)P.n_wg > sub ? ((uint32_t)P.n_wg - sub + split - 1u) / split : 0u);
     constexpr uint32_t kBatch = 64u * kPartUnroll;  // pieces per wave and batch
-    // this workgroup's regions {first chunk, pieces}, fetched once (boff is [workgroup][bin]: a strided read)
-    uint2 *regions = (uint2 *)(vmax + kPartCells);  // [n_reg]
-    dummy64 = (unsigned long long *)(regions + n_reg) + lane;          // [64]
-    dummy32 = (uint32_t *)((unsigned long long *)(regions + n_reg) + 64) + lane;  // [64]
-    for (uint32_t k = tid; k < n_reg; k += kWgThreads) {
-        const uint32_t w = sub + k * split;
-        const uint32_t *bo = P.boff + (size_t)w * nb1;
-        const uint32_t lo = bo[b_lo], hi = bo[b_hi];
-        regions[k] = make_uint2(P.wbase[w] + lo, (hi - lo) * (kEmitChunk / 4u));
-    }
-    __syncthreads();
-    stamp(1);
-    uint32_t r = wave, i0 = 0, n4 = 0, c0 = 0;      // region, first piece of the next batch, pieces, first chunk (wave-uniform)
-    auto open_region = [&]() {
-        // skips empty regions; n4 == 0 afterwards: no region left
-        n4 = 0;
-        while (r < n_reg) {
-            const uint2 g = regions[r];
-            const uint32_t pieces = __builtin_amdgcn_readfirstlane(g.y);
-            if (pieces) {
-                c0 = __builtin_amdgcn_readfirstlane(g.x);
-                n4 = pieces;
-                i0 = 0;
-                return;
+
+    // (an item is claimed one item ahead -- behind the previous item's region table, its device-scope round trip hidden
+    // under that item's walk -- into ctl[2 | 3] by turns)
+    if (tid == 0) ctl[2] = __hip_atomic_fetch_add(P.wrap_log + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (uint32_t turn = 0;; turn ^= 1u) {
+        // ---- the tables start from zero
+        if (tid == 0) ctl[1] = kWgThreads / 64;  // (every wave starts with the region of its own number)
+        {
+            typedef unsigned int z4 __attribute__((ext_vector_type(4)));
+            const z4 zero = {0u, 0u, 0u, 0u};
+            for (uint32_t i = tid; i < kPartCells * nw / 4u; i += kWgThreads) ((z4 *)hist)[i] = zero;  // (kPartCells x nw words: a multiple of 4)
+        }
+        if (tid < kPartSumRep * kPartCells) sum[tid] = 0;
+        if (tid < kPartCells) vmax[tid] = INT64_MIN;
+        __syncthreads();
+        item = __builtin_amdgcn_readfirstlane(ctl[2u + turn]);
+        if (item >= n_items) break;
+        stamp(0);
+        // (wave-uniform by construction; said so explicitly: the divide goes through the vector ALU, and with these in
+        // vector registers every region loop and record load below became a divergent loop / a waterfall loop)
+        const uint32_t part = __builtin_amdgcn_readfirstlane(item / split), sub = __builtin_amdgcn_readfirstlane(item % split);
+        const uint32_t pair0 = part * kPartCells;
+        const uint32_t b_lo = part << P.sub_shift, b_hi = (part + 1u) << P.sub_shift;
+        const uint32_t n_reg = __builtin_amdgcn_readfirstlane((uint32_t)P.n_wg > sub ? ((uint32_t)P.n_wg - sub + split - 1u) / split : 0u);
+        // The item's records: one region per scanning workgroup w (the partition's sub-bins are neighbours in w's
+        // output: chunks boff[w][part << ss] .. boff[w][(part + 1) << ss] behind wbase[w]).  `split` workgroups share a
+        // partition by taking every split-th region (boff is [workgroup][bin]: a strided read, once per item).
+        for (uint32_t k = tid; k < n_reg; k += kWgThreads) {
+            const uint32_t w = sub + k * split;
+            const uint32_t *bo = P.boff + (size_t)w * nb1;
+            const uint32_t lo = bo[b_lo], hi = bo[b_hi];
+            regions[k] = make_uint2(P.wbase[w] + lo, (hi - lo) * (kEmitChunk / 4u));
+        }
+        uint32_t claimed = 0;  // (stored behind the walk: nobody waits for the round trip at a barrier)
+        if (tid == kWgThreads - 1) claimed = __hip_atomic_fetch_add(P.wrap_log + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        stamp(1);
+
+        auto bucket_of = [&](uint32_t rec, uint32_t &local, uint32_t &n32) -> uint32_t {
+            n32 = rec & ((1u << kRecValueBits) - 1);  // v - h.Min
+            local = rec >> kRecValueBits;
+            const uint32_t a = two ? (local & 1u) : 0u;
+            const uint32_t bs = two && a ? bs1 : bs0;
+            const double inv = two && a ? inv1 : inv0;
+            // floor(n32 / BucketSize), hist_basic.go:130-150: the estimate is never above the quotient and at most one short
+            // of it (scan_packed.h: packed_udiv); bucket < 2^10 and BucketSize < 2^24 (planner), so the product takes 24 bits
+            uint32_t b = (uint32_t)((double)n32 * inv);
+            if (n32 - __umul24(b, bs) >= bs) b += 1;
+            return b;
+        };
+        // One record: returns the word as it was before the add, shifted so that the bucket's own field is the low half (an
+        // even bucket's neighbour field is then the high half).  No branch per record: a padding record (or a lane past the
+        // region's end) aims its two atomics at a scratch word of its own instead of being skipped, so the sixteen adds of a
+        // batch are in flight together and their results are looked at once (what comes back from a scratch word is
+        // checked for liveness again on the wrap path).
+        auto add_record = [&](uint32_t rec, bool in) -> uint32_t {
+            const bool live = in && rec != kRecSentinel;
+            uint32_t local, n32;
+            uint32_t b = bucket_of(rec, local, n32);
+            if (OUT) {
+                // Outlier (hist_basic.go:132-135): clipped into the last bucket and remembered (part_outlier)
+                const uint32_t nva = two && (local & 1u) ? nv1 : nv0;
+                if (b >= nva) {
+                    if (live) part_outlier(P, pair0 + local, n32);
+                    b = nva - 1u;
+                }
             }
-            r += kWgThreads / 64;
-        }
-    };
-    auto issue = [&](rec4 (&d)[kPartUnroll], uint32_t &first, uint32_t &pieces) {
-        const uint64_t at = (uint64_t)(recs + (size_t)c0 * kEmitChunk);  // (wave-uniform: kept in scalar registers)
-        const uint32_t at_lo = __builtin_amdgcn_readfirstlane((uint32_t)at), at_hi = __builtin_amdgcn_readfirstlane((uint32_t)(at >> 32));
-        const uint64_t at_s = (uint64_t)at_lo | (uint64_t)at_hi << 32;  // (the builtin returns int: through uint32_t, no sign extension)
-        const __amdgpu_buffer_rsrc_t rsrc =
-            __builtin_amdgcn_make_buffer_rsrc((void *)at_s, 0, (int)__builtin_amdgcn_readfirstlane(n4 * 16u), (int)0x00020000);
-#pragma unroll
-        for (int u = 0; u < kPartUnroll; u++) d[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)((i0 + (uint32_t)u * 64u + lane) * 16u), 0, 2);
-        first = i0;
-        pieces = n4;
-        if (n4) {
-            i0 += kBatch;
-            if (i0 >= n4) {
-                r += kWgThreads / 64;
-                open_region();
+            const uint32_t sh = (b & 1u) << 4;
+            uint32_t *hp = live ? hist + __umul24(local, nw) + (b >> 1) : dummy32;
+            unsigned long long *sp = live ? my_sum + local * kPartSumRep : dummy64;
+            const uint32_t old = __hip_atomic_fetch_add(hp, 1u << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(sp, (unsigned long long)n32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (TRACK_MAX && live) {
+                const uint32_t a = two ? (local & 1u) : 0u;
+                if (P.m_max[a] >= 0) {
+                    const long long v = (long long)((unsigned long long)P.hmin[a] + (unsigned long long)n32);
+                    if (v > vmax[local]) __hip_atomic_fetch_max(vmax + local, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
             }
-        }
-    };
-    rec4 cur[kPartUnroll], nxt[kPartUnroll];
-    uint32_t cur_first, cur_n, nxt_first, nxt_n;
-    open_region();
-    issue(cur, cur_first, cur_n);
-    while (cur_n) {
-        issue(nxt, nxt_first, nxt_n);
-        uint32_t seen[kPartUnroll][4];
+            return old >> sh;
+        };
+        auto wrapped = [](uint32_t seen) { return (seen & 0xFFFFu) == 0xFFFFu; };
+        auto log_wrap = [&](uint32_t rec, uint32_t seen) {  // (rare)
+            uint32_t local, n32;
+            uint32_t b = bucket_of(rec, local, n32);
+            const uint32_t nva = two && (local & 1u) ? nv1 : nv0;
+            if (OUT) b = b >= nva ? nva - 1u : b;  // (an outlier was counted in the last bucket)
+            // (the aggregation's own bucket count: the high field next to an even last bucket belongs to nobody -- a carry
+            // into it is neither logged nor, below, counted)
+            part_log_wrap(P, pair0 + local, b, (b & 1u) ? 0u : seen, nva);
+        };
+
+        // ---- the walk: every wave takes regions from the cursor (its first one is its own number), 16-byte pieces (four
+        // records) per lane and kPartUnroll loads per lane in flight twice over (current + next batch) -- raw buffer loads
+        // whose descriptor is the region, so nothing depends on a lane's bounds when the loads are issued.
+        uint32_t r = wave, i0 = 0, n4 = 0, c0 = 0;      // region, first piece of the next batch, pieces, first chunk (wave-uniform)
+        auto open_region = [&]() {
+            // skips empty regions; n4 == 0 afterwards: no region left
+            n4 = 0;
+            while (r < n_reg) {
+                const uint2 g = regions[r];
+                const uint32_t pieces = __builtin_amdgcn_readfirstlane(g.y);
+                if (pieces) {
+                    c0 = __builtin_amdgcn_readfirstlane(g.x);
+                    n4 = pieces;
+                    i0 = 0;
+                    return;
+                }
+                uint32_t nxt_r = 0;
+                if (lane == 0) nxt_r = __hip_atomic_fetch_add(ctl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                r = __builtin_amdgcn_readfirstlane(nxt_r);
+            }
+        };
+        auto issue = [&](rec4 (&d)[kPartUnroll], uint32_t &first, uint32_t &pieces) {
+            const uint64_t at = (uint64_t)(recs + (size_t)c0 * kEmitChunk);  // (wave-uniform: kept in scalar registers)
+            const uint32_t at_lo = __builtin_amdgcn_readfirstlane((uint32_t)at), at_hi = __builtin_amdgcn_readfirstlane((uint32_t)(at >> 32));
+            const uint64_t at_s = (uint64_t)at_lo | (uint64_t)at_hi << 32;  // (the builtin returns int: through uint32_t, no sign extension)
+            const __amdgpu_buffer_rsrc_t rsrc =
+                __builtin_amdgcn_make_buffer_rsrc((void *)at_s, 0, (int)__builtin_amdgcn_readfirstlane(n4 * 16u), (int)0x00020000);
 #pragma unroll
-        for (int u = 0; u < kPartUnroll; u++) {
-            const bool in = cur_first + (uint32_t)u * 64u + lane < cur_n;
-            seen[u][0] = add_record(cur[u].x, in);
-            seen[u][1] = add_record(cur[u].y, in);
-            seen[u][2] = add_record(cur[u].z, in);
-            seen[u][3] = add_record(cur[u].w, in);
-        }
-        bool any = false;
-#pragma unroll
-        for (int u = 0; u < kPartUnroll; u++)
-            any = any || wrapped(seen[u][0]) || wrapped(seen[u][1]) || wrapped(seen[u][2]) || wrapped(seen[u][3]);
-        if (any) {
+            for (int u = 0; u < kPartUnroll; u++) d[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)((i0 + (uint32_t)u * 64u + lane) * 16u), 0, 2);
+            first = i0;
+            pieces = n4;
+            if (n4) {
+                i0 += kBatch;
+                if (i0 >= n4) {
+                    uint32_t nxt_r = 0;
+                    if (lane == 0) nxt_r = __hip_atomic_fetch_add(ctl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    r = __builtin_amdgcn_readfirstlane(nxt_r);
+                    open_region();
+                }
+            }
+        };
+        rec4 cur[kPartUnroll], nxt[kPartUnroll];
+        uint32_t cur_first, cur_n, nxt_first, nxt_n;
+        open_region();
+        issue(cur, cur_first, cur_n);
+        while (cur_n) {
+            issue(nxt, nxt_first, nxt_n);
+            uint32_t seen[kPartUnroll][4];
 #pragma unroll
             for (int u = 0; u < kPartUnroll; u++) {
-                const bool in = cur_first + (uint32_t)u * 64u + lane < cur_n;  // (a scratch word's old value is no wrap)
-                if (in && cur[u].x != kRecSentinel && wrapped(seen[u][0])) log_wrap(cur[u].x, seen[u][0]);
-                if (in && cur[u].y != kRecSentinel && wrapped(seen[u][1])) log_wrap(cur[u].y, seen[u][1]);
-                if (in && cur[u].z != kRecSentinel && wrapped(seen[u][2])) log_wrap(cur[u].z, seen[u][2]);
-                if (in && cur[u].w != kRecSentinel && wrapped(seen[u][3])) log_wrap(cur[u].w, seen[u][3]);
+                const bool in = cur_first + (uint32_t)u * 64u + lane < cur_n;
+                seen[u][0] = add_record(cur[u].x, in);
+                seen[u][1] = add_record(cur[u].y, in);
+                seen[u][2] = add_record(cur[u].z, in);
+                seen[u][3] = add_record(cur[u].w, in);
             }
+            bool any = false;
+#pragma unroll
+            for (int u = 0; u < kPartUnroll; u++)
+                any = any || wrapped(seen[u][0]) || wrapped(seen[u][1]) || wrapped(seen[u][2]) || wrapped(seen[u][3]);
+            if (any) {
+#pragma unroll
+                for (int u = 0; u < kPartUnroll; u++) {
+                    const bool in = cur_first + (uint32_t)u * 64u + lane < cur_n;  // (a scratch word's old value is no wrap)
+                    if (in && cur[u].x != kRecSentinel && wrapped(seen[u][0])) log_wrap(cur[u].x, seen[u][0]);
+                    if (in && cur[u].y != kRecSentinel && wrapped(seen[u][1])) log_wrap(cur[u].y, seen[u][1]);
+                    if (in && cur[u].z != kRecSentinel && wrapped(seen[u][2])) log_wrap(cur[u].z, seen[u][2]);
+                    if (in && cur[u].w != kRecSentinel && wrapped(seen[u][3])) log_wrap(cur[u].w, seen[u][3]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kPartUnroll; u++) cur[u] = nxt[u];
+            cur_first = nxt_first;
+            cur_n = nxt_n;
         }
-#pragma unroll
-        for (int u = 0; u < kPartUnroll; u++) cur[u] = nxt[u];
-        cur_first = nxt_first;
-        cur_n = nxt_n;
-    }
-    if (P.trace && lane == 0) P.trace[(size_t)blockIdx.x * kPartTraceWords + 16 + wave] = wall_clock64();
-    __syncthreads();
-    stamp(2);
-    // cnt[l] = sum over the buckets of pair l (as the fields hold them: k_part_fix adds what the log says): each wave
-    // sums a strided share, one LDS atomic per wave
-    for (uint32_t l = 0; l < (uint32_t)kPartCells; l++) {
-        uint32_t n = 0;
-        const uint32_t nva = two && (l & 1u) ? nv1 : nv0;
-        for (uint32_t k = tid; 2u * k < nva; k += kWgThreads) {
-            const uint32_t x = hist[l * nw + k];
-            n += (x & 0xFFFFu) + (2u * k + 1u < nva ? x >> 16 : 0u);
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
-        if ((tid & 63) == 0 && n) __hip_atomic_fetch_add(cnt + l, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-    __syncthreads();
-    unsigned long long pair_sum = 0;
-    if (tid < kPartCells) {
-#pragma unroll
-        for (int r2 = 0; r2 < kPartSumRep; r2++) pair_sum += sum[tid * kPartSumRep + r2];
-    }
-    __syncthreads();
-    if (tid < kPartCells) sum[tid] = pair_sum;
-    __syncthreads();
-    stamp(3);
+        if (P.trace && lane == 0) P.trace[(size_t)item * kPartTraceWords + 16 + wave] = wall_clock64();
+        if (tid == kWgThreads - 1) ctl[3u - turn] = claimed;
+        __syncthreads();
+        stamp(2);
 
-    if (P.fuse && split == 1) {
-        // What k_hist_summary / k_hist_total would read back out of HBM (see there for GetPercentiles): one wave per pair,
-        // lanes own consecutive buckets.  A pair whose counters wrapped gets wrong numbers here; k_part_fix marks it
-        // dirty and k_hist_summary redoes it from the fixed table.
-        const uint32_t total_pairs_f = (uint32_t)P.n_cells * (uint32_t)NA;
+        // ---- the epilogue: the wave that owns a pair (every 16th) reads the pair's counters once -- lanes own consecutive
+        // buckets, so a store instruction writes 512 contiguous bytes -- stores them and sums them up: a pair's count is the
+        // sum of its buckets as the fields hold them (k_part_fix adds what the wrap log says); sum(v) = sum(v - h.Min) +
+        // count x h.Min.  With SYBL_FUSED_SUMMARY the same wave goes on to the pair's percentiles and bucket moments (what
+        // k_hist_summary would read back out of HBM; a pair whose counters wrapped gets wrong numbers here: k_part_fix
+        // marks it dirty and k_hist_summary redoes it from the fixed table).
         for (uint32_t l = wave; l < (uint32_t)kPartCells; l += kWgThreads / 64) {
             const uint32_t pair = pair0 + l;
-            if (pair >= total_pairs_f) break;
-            const uint32_t a = pair % (uint32_t)NA;
-            const int64_t count = (int64_t)cnt[l], bsz = P.bucket_size[a], hmn = P.hmin[a], nvals = P.n_values[a];
+            if (pair >= total_pairs) break;
+            const uint32_t cell = pair / (uint32_t)NA, a = pair % (uint32_t)NA;
+            const uint32_t nva = (uint32_t)P.n_values[a];
+            int64_t *h = P.sum_out + P.hist_off + (int64_t)cell * P.hist_stride + P.hist_agg_off[a];
             const uint32_t *hl = hist + l * nw;
-            int64_t *out = P.pct + (int64_t)pair * 100;
-            int64_t sb = 0, sb2 = 0, carry = 0, carry_p = 0;
-            for (int64_t k0 = 0; k0 < nvals; k0 += 64) {
-                const int64_t k = k0 + lane;
-                const int64_t x = k < nvals ? (int64_t)((hl[k >> 1] >> ((k & 1) << 4)) & 0xFFFFu) : 0;
-                sb += k * x;
-                sb2 += k * k * x;
-                if (count == 0) continue;
-                int64_t c = x;  // inclusive scan of x over the wave
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
-                    const int64_t y = __shfl_up(c, o, 64);
-                    if ((int)lane >= o) c += y;
-                }
-                c += carry;
-                int64_t pc = (100 * c) / count;
-                pc = pc < 0 ? 0 : (pc > 100 ? 100 : pc);
-                int64_t pp = __shfl_up(pc, 1, 64);
-                if (lane == 0) pp = carry_p;
-                if (k < nvals) {
-                    const int64_t val = k * bsz + hmn;
-                    for (int64_t ip = pp; ip < pc; ip++) out[ip] = val;  // (pc <= 100: ip < 100)
-                    if (k == nvals - 1 && pc < 100) out[pc] = k;
-                }
-                carry = __shfl(c, 63, 64);
-                carry_p = __shfl(pc, 63, 64);
+            uint32_t n = 0;
+            for (uint32_t b = lane; b < nva; b += 64u) {
+                const uint32_t x = (hl[b >> 1] >> ((b & 1u) << 4)) & 0xFFFFu;
+                n += x;
+                if (split == 1) h[b] = (int64_t)x;          // sole owner of the pair: plain stores, nothing to zero beforehand
+                else if (x) gadd(h + b, (int64_t)x);         // `split` workgroups share the pair: into the zeroed table
             }
+            unsigned long long vs = lane < (uint32_t)kPartSumRep ? sum[l * kPartSumRep + lane] : 0ull;
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) {
-                sb += __shfl_xor(sb, o, 64);
-                sb2 += __shfl_xor(sb2, o, 64);
+                n += __shfl_xor(n, o, 64);
+                vs += __shfl_xor(vs, o, 64);
             }
+            // every aggregation accepts every row here (planner: no rejects / missing values), so
+            // Result.Count of the cell is the count of any of its aggregations
+            const int64_t vsum = (int64_t)(vs + (unsigned long long)n * (unsigned long long)P.hmin[a]);
             if (lane == 0) {
-                P.mom[(int64_t)pair * 2] = sb;
-                P.mom[(int64_t)pair * 2 + 1] = sb2;
+                if (split == 1) {
+                    if (a == 0 && !P.no_count) F[cell] = (int64_t)n;
+                    F[(int64_t)P.f_sum[a] * P.n_cells + cell] = vsum;
+                    if (P.m_max[a] >= 0) P.max_out[(int64_t)P.m_max[a] * P.n_cells + cell] = vmax[l];
+                } else if (n) {
+                    if (a == 0 && !P.no_count) gadd(F + cell, (int64_t)n);
+                    gadd(F + (int64_t)P.f_sum[a] * P.n_cells + cell, vsum);
+                    if (P.m_max[a] >= 0)
+                        __hip_atomic_fetch_max(P.max_out + (int64_t)P.m_max[a] * P.n_cells + cell, (int64_t)vmax[l], __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
-        }
-        // Cumulative: this partition's share of every (aggregation, bucket), one atomic per non-zero word
-        for (uint32_t b = tid; b < nv; b += kWgThreads) {
-            int64_t acc[NA];
+            if (P.fuse && split == 1) {
+                // GetPercentiles (see k_hist_summary), lanes own consecutive buckets
+                const int64_t count = (int64_t)n, bsz = P.bucket_size[a], hmn = P.hmin[a], nvals = P.n_values[a];
+                int64_t *out = P.pct + (int64_t)pair * 100;
+                int64_t sb = 0, sb2 = 0, carry = 0, carry_p = 0;
+                for (int64_t k0 = 0; k0 < nvals; k0 += 64) {
+                    const int64_t k = k0 + lane;
+                    const int64_t x = k < nvals ? (int64_t)((hl[k >> 1] >> ((k & 1) << 4)) & 0xFFFFu) : 0;
+                    sb += k * x;
+                    sb2 += k * k * x;
+                    if (count == 0) continue;
+                    int64_t c = x;  // inclusive scan of x over the wave
 #pragma unroll
-            for (int a = 0; a < NA; a++) acc[a] = 0;
-            for (uint32_t l = 0; l < (uint32_t)kPartCells; l++) {
-                if (pair0 + l >= total_pairs_f) break;
-                acc[l % NA] += (int64_t)((hist[l * nw + (b >> 1)] >> ((b & 1u) << 4)) & 0xFFFFu);
-            }
+                    for (int o = 1; o < 64; o <<= 1) {
+                        const int64_t y = __shfl_up(c, o, 64);
+                        if ((int)lane >= o) c += y;
+                    }
+                    c += carry;
+                    int64_t pc = (100 * c) / count;
+                    pc = pc < 0 ? 0 : (pc > 100 ? 100 : pc);
+                    int64_t pp = __shfl_up(pc, 1, 64);
+                    if (lane == 0) pp = carry_p;
+                    if (k < nvals) {
+                        const int64_t val = k * bsz + hmn;
+                        for (int64_t ip = pp; ip < pc; ip++) out[ip] = val;  // (pc <= 100: ip < 100)
+                        if (k == nvals - 1 && pc < 100) out[pc] = k;
+                    }
+                    carry = __shfl(c, 63, 64);
+                    carry_p = __shfl(pc, 63, 64);
+                }
 #pragma unroll
-            for (int a = 0; a < NA; a++)
-                if (acc[a] && b < (uint32_t)P.n_values[a]) gadd(P.total + P.hist_agg_off[a] + b, acc[a]);
-        }
-    }
-
-    int64_t *F = P.sum_out + kHeaderWords;
-    const uint32_t total_pairs = (uint32_t)P.n_cells * (uint32_t)NA;
-    for (uint32_t l = 0; l < (uint32_t)kPartCells; l++) {
-        const uint32_t pair = pair0 + l;
-        if (pair >= total_pairs) break;
-        const uint32_t cell = pair / (uint32_t)NA, a = pair % (uint32_t)NA;
-        int64_t *h = P.sum_out + P.hist_off + (int64_t)cell * P.hist_stride + P.hist_agg_off[a];
-        const uint32_t c = cnt[l];
-        // every aggregation accepts every row here (planner: no rejects / missing values), so
-        // Result.Count of the cell is the count of any of its aggregations
-        const int64_t vsum = (int64_t)(sum[l] + (unsigned long long)c * (unsigned long long)P.hmin[a]);
-        const uint32_t *hl = hist + l * nw;
-        if (split == 1) {
-            // sole owner of the pair: plain stores, nothing to zero beforehand
-            for (uint32_t b = tid; b < (uint32_t)P.n_values[a]; b += kWgThreads) h[b] = (int64_t)((hl[b >> 1] >> ((b & 1u) << 4)) & 0xFFFFu);
-            if (tid == 0) {
-                if (a == 0 && !P.no_count) F[cell] = (int64_t)c;
-                F[(int64_t)P.f_sum[a] * P.n_cells + cell] = vsum;
-                if (P.m_max[a] >= 0) P.max_out[(int64_t)P.m_max[a] * P.n_cells + cell] = vmax[l];
-            }
-        } else {
-            // `split` workgroups share the pair: combine into the zeroed table
-            for (uint32_t b = tid; b < (uint32_t)P.n_values[a]; b += kWgThreads) {
-                const uint32_t x = (hl[b >> 1] >> ((b & 1u) << 4)) & 0xFFFFu;
-                if (x) gadd(h + b, (int64_t)x);
-            }
-            if (tid == 0 && c) {
-                if (a == 0 && !P.no_count) gadd(F + cell, (int64_t)c);
-                gadd(F + (int64_t)P.f_sum[a] * P.n_cells + cell, vsum);
-                if (P.m_max[a] >= 0)
-                    __hip_atomic_fetch_max(P.max_out + (int64_t)P.m_max[a] * P.n_cells + cell, (int64_t)vmax[l], __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_AGENT);
+                for (int o = 32; o > 0; o >>= 1) {
+                    sb += __shfl_xor(sb, o, 64);
+                    sb2 += __shfl_xor(sb2, o, 64);
+                }
+                if (lane == 0) {
+                    P.mom[(int64_t)pair * 2] = sb;
+                    P.mom[(int64_t)pair * 2 + 1] = sb2;
+                }
             }
         }
-    }
-    stamp(4);
-    if (P.trace && tid == 0) {
-        uint32_t hwid;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-        uint32_t xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        P.trace[(size_t)blockIdx.x * kPartTraceWords + 5] = (unsigned long long)hwid | (unsigned long long)xcc << 32;
+        if (P.fuse && split == 1) {
+            // Cumulative: this partition's share of every (aggregation, bucket), one atomic per non-zero word
+            for (uint32_t b = tid; b < nv; b += kWgThreads) {
+                int64_t acc[NA];
+#pragma unroll
+                for (int a = 0; a < NA; a++) acc[a] = 0;
+                for (uint32_t l = 0; l < (uint32_t)kPartCells; l++) {
+                    if (pair0 + l >= total_pairs) break;
+                    acc[l % NA] += (int64_t)((hist[l * nw + (b >> 1)] >> ((b & 1u) << 4)) & 0xFFFFu);
+                }
+#pragma unroll
+                for (int a = 0; a < NA; a++)
+                    if (acc[a] && b < (uint32_t)P.n_values[a]) gadd(P.total + P.hist_agg_off[a] + b, acc[a]);
+            }
+        }
+        stamp(4);
+        if (P.trace && tid == 0) {
+            uint32_t hwid, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            P.trace[(size_t)item * kPartTraceWords + 5] = (unsigned long long)hwid | (unsigned long long)xcc << 32;
+        }
+        __syncthreads();  // (the tables are zeroed for the next item)
     }
 }
 
@@ -972,15 +977,17 @@ static hipError_t part_hist_launch(const PartHistPlan &P, size_t lds, hipStream_
     auto k = out ? k_part_hist<NA, TRACK_MAX, true> : k_part_hist<NA, TRACK_MAX, false>;
     hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k, dim3(P.n_parts * P.split), dim3(kWgThreads), lds, st, P);
+    // persistent: one workgroup per compute unit (its ~135 KB of LDS would not let two share one anyway)
+    const int items = P.n_parts * P.split;
+    hipLaunchKernelGGL(k, dim3(std::min(items, std::max(P.n_cus, 1))), dim3(kWgThreads), lds, st, P);
     return hipGetLastError();
 }
 
 hipError_t launch_part_hist(const PartHistPlan &P, hipStream_t st) {
     if (P.n_parts <= 0) return hipSuccess;
     const uint32_t n_reg = ((uint32_t)P.n_wg + (uint32_t)P.split - 1u) / (uint32_t)P.split;
-    size_t lds = ((size_t)kPartCells * ((P.nv_max + 1) / 2) + kPartCells) * 4 + (size_t)kPartCells * (kPartSumRep + 1) * 8 + (size_t)n_reg * 8 + 16 +
-                 64 * 12;  // + a scratch word pair per lane (add_record)
+    size_t lds = (size_t)kPartCells * ((P.nv_max + 1) / 2) * 4 + (size_t)kPartCells * (kPartSumRep + 1) * 8 + (size_t)n_reg * 8 +
+                 64 * 12 + 16;  // + a scratch word pair per lane (add_record) + item / region cursors
     const bool track_max = P.m_max[0] >= 0 || (P.n_aggs > 1 && P.m_max[1] >= 0);
     if (P.n_aggs == 1) return track_max ? part_hist_launch<1, true>(P, lds, st) : part_hist_launch<1, false>(P, lds, st);
     if (P.n_aggs == 2) return track_max ? part_hist_launch<2, true>(P, lds, st) : part_hist_launch<2, false>(P, lds, st);

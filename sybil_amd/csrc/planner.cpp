@@ -535,6 +535,7 @@ static void bind_part_pass(Query *q, int a0, const PartGeom &G, uint32_t *d_recs
     H.out_cap = P.out_cap;
     // few partitions: several workgroups share one so the whole chip is busy
     H.split = (int32_t)std::max<int64_t>(1, (int64_t)q->n_wg / G.n_parts);
+    H.n_cus = q->ctx->n_cus;
 }
 
 static int select_part_hist(Table *t, Query *q, const std::vector<int> &slot_col, int64_t rows_scanned) {

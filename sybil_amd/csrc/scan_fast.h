@@ -143,7 +143,8 @@ constexpr int kRecValueBits = 26;    // v - h.Min < len(Values) * BucketSize < 2
 constexpr int kMaxParts = 1024;      // LDS staging in k_emit: two 16-record chunks per bin
 constexpr int kEmitMaxBins = 1024;   // bins = n_parts << sub_shift
 constexpr uint32_t kEmitChunk = 16;  // records per chunk
-constexpr uint32_t kEmitQueue = 32;  // completed chunks a wave copies out per drain (two store instructions)
+constexpr uint32_t kEmitQueue = 32;  // completed chunks a wave copies out per drain (two store instructions) ...
+constexpr uint32_t kEmitQueueMax = 64;  // ... four when a push holds eight records per lane (k_emit_packed, two tiles at a time); LDS is sized for this
 constexpr int kEmitBinWords = 4 + 2 * (int)kEmitChunk;  // LDS words per bin: {cnt, wr0, wr1, region start} + two chunks
 constexpr uint32_t kRecSentinel = 0xFFFFFFFFu;      // padding record (never a real one: planner)
 constexpr uint32_t kEmitDropOffset = 0x80000000u;   // byte offset past any workgroup's output (< 2 GB: planner)
@@ -168,8 +169,10 @@ struct PartHistPlan {
     const uint32_t *boff, *wbase;    // as in EmitPlan
     int32_t n_parts, n_aggs, n_cells, nv_max;
     int32_t n_wg, sub_shift;
-    int32_t split;                   // workgroups per partition (> 1: results are combined with atomics)
-    uint32_t *wrap_log;              // [0]: entries used, then {pair, bucket | kind << 16}: 16-bit counters that wrapped
+    int32_t split;                   // shares of a partition (> 1: results are combined with atomics)
+    int32_t n_cus, pad_cus_;         // the persistent kernel's grid: one workgroup per compute unit claims (partition, share) items
+    uint32_t *wrap_log;              // [0]: entries used, [1]: items claimed (k_part_hist's work counter), then {pair, bucket | kind << 16}:
+                                     // 16-bit counters that wrapped
     uint32_t wrap_cap;               // entries the log holds
     // the result rows' summaries, derived where the partition's histograms sit in LDS instead of by a second and third
     // pass over the finished 525 MB table (k_hist_summary / k_hist_total): GetPercentiles, the bucket moments of
@@ -199,7 +202,7 @@ constexpr int kPartTraceWords = 32;
 constexpr int emit_depth(int n_cols) { return n_cols <= 2 ? 4 : n_cols <= 4 ? 2 : 1; }
 constexpr int count_depth(int n_cols) { return n_cols <= 1 ? 8 : n_cols <= 2 ? 4 : n_cols <= 4 ? 2 : 1; }
 inline size_t emit_lds_bytes(const EmitPlan &E) {
-    return ((size_t)E.n_parts << E.sub_shift) * kEmitBinWords * 4 + (size_t)(kWgThreads / 64) * kEmitQueue * 8;
+    return ((size_t)E.n_parts << E.sub_shift) * kEmitBinWords * 4 + (size_t)(kWgThreads / 64) * kEmitQueueMax * 8;
 }
 inline size_t count_lds_bytes(const EmitPlan &E) { return (((size_t)E.n_parts << E.sub_shift) + 64) * 4; }
 
@@ -704,7 +707,7 @@ struct EmitLds {
     uint32_t *cnt, *start;  // [nb] each: arrays of their own, so that the bins spread over all 32 LDS banks (as one
     uint2 *wr;              // [nb]   16-byte struct per bin the counters of 64 lanes fell into 8 banks: 71 % of the LDS
                             //        pipe's cycles were bank conflicts, profiles/r03_cfg4_v4_pmc.txt)
-    uint2 *queue;           // [kEmitQueue] of this wave: {bin << 1 | chunk of the bin, chunk index in the workgroup's output}
+    uint2 *queue;           // [kEmitQueueMax] of this wave: {bin << 1 | chunk of the bin, generation = the chunk's number in the bin's region}
     uint32_t *out;          // the workgroup's output in recs
     uint32_t out_bytes;
     uint32_t nb, ss, sub;
@@ -718,9 +721,9 @@ __device__ __forceinline__ EmitLds emit_begin(const EmitPlan &E, uint32_t *elds)
     S.sub = tid & ((1u << S.ss) - 1);        // this lane's sub-bin
     S.chunk = elds;                          // [nb][2][16]  (128-byte rows)
     S.wr = (uint2 *)(elds + S.nb * 2 * kEmitChunk);
-    uint2 *queues = S.wr + S.nb;             // [waves][kEmitQueue]
-    S.queue = queues + (tid >> 6) * kEmitQueue;
-    S.cnt = (uint32_t *)(queues + (kWgThreads / 64) * kEmitQueue);
+    uint2 *queues = S.wr + S.nb;             // [waves][kEmitQueueMax]
+    S.queue = queues + (tid >> 6) * kEmitQueueMax;
+    S.cnt = (uint32_t *)(queues + (kWgThreads / 64) * kEmitQueueMax);
     S.start = S.cnt + S.nb;
     const uint32_t *boff = E.boff + (size_t)blockIdx.x * (S.nb + 1);
     for (uint32_t i = tid; i < S.nb; i += kWgThreads) {
@@ -728,7 +731,7 @@ __device__ __forceinline__ EmitLds emit_begin(const EmitPlan &E, uint32_t *elds)
         S.wr[i] = make_uint2(0u, 0u);
         S.start[i] = boff[i];
     }
-    if (tid < (kWgThreads / 64) * kEmitQueue) queues[tid] = make_uint2(0u, 0u);
+    if (tid < (kWgThreads / 64) * kEmitQueueMax) queues[tid] = make_uint2(0u, 0u);
     S.out = E.recs + (size_t)E.wbase[blockIdx.x] * kEmitChunk;
     S.out_bytes = boff[S.nb] * (kEmitChunk * 4u);
     __syncthreads();
@@ -754,8 +757,8 @@ __device__ __forceinline__ void lds_wait() {
 // through here issues exactly kEmitQueue / 16 store instructions -- with loads and stores retiring in order on one
 // counter, a data-dependent number of stores between the column loads and their use makes the compiler's
 // `s_waitcnt vmcnt(N)` wait for the stores of the current tile instead of the loads of four tiles ago.
-template <int M>
-__device__ __forceinline__ void emit_copy_full(const EmitLds &S, const uint32_t (&which)[M], const uint32_t (&dest)[M], uint32_t full) {
+template <int M, uint32_t Q = kEmitQueue>
+__device__ __forceinline__ void emit_copy_full(const EmitLds &S, const uint32_t (&which)[M], const uint32_t (&gen)[M], uint32_t full) {
     const uint32_t lane = threadIdx.x & 63u, g = lane >> 2, j = lane & 3u;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)S.out, 0, (int)S.out_bytes, (int)0x00020000);
     for (;;) {
@@ -765,46 +768,53 @@ __device__ __forceinline__ void emit_copy_full(const EmitLds &S, const uint32_t 
             const unsigned long long m = __builtin_amdgcn_ballot_w64(has);
             if (!m) break;
             const uint32_t at = nq + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            if (has && at < kEmitQueue) {
+            if (has && at < Q) {
                 const uint32_t i = (uint32_t)__builtin_ctz(full);
                 full &= full - 1;
-                uint32_t b = which[0], d = dest[0];
+                uint32_t b = which[0], d = gen[0];
 #pragma unroll
                 for (int k = 1; k < M; k++) {
                     b = i == (uint32_t)k ? which[k] : b;
-                    d = i == (uint32_t)k ? dest[k] : d;
+                    d = i == (uint32_t)k ? gen[k] : d;
                 }
                 S.queue[at] = make_uint2(b, d);
             }
             nq += (uint32_t)__builtin_popcountll(m);
-            if (nq >= kEmitQueue) {
-                nq = kEmitQueue;
+            if (nq >= Q) {
+                nq = Q;
                 break;
             }
         }
         lds_order();
-        uint2 qe[kEmitQueue / 16];
+        // (two queue entries per lane at a time: with four the staged pieces alone are 16 registers)
 #pragma unroll
-        for (uint32_t k = 0; k < kEmitQueue / 16; k++) qe[k] = S.queue[k * 16 + g];
-        lds_wait();
-        fu32x4 piece[kEmitQueue / 16];
-        bool valid[kEmitQueue / 16];
+        for (uint32_t k0 = 0; k0 < Q / 16; k0 += 2) {
+            uint2 qe[2];
 #pragma unroll
-        for (uint32_t k = 0; k < kEmitQueue / 16; k++) {
-            valid[k] = k * 16 + g < nq;
-            const uint32_t c = valid[k] ? qe[k].x : 0u;
-            piece[k] = ((const fu32x4 *)(S.chunk + c * kEmitChunk))[j];
+            for (uint32_t k = 0; k < 2; k++) qe[k] = S.queue[(k0 + k) * 16 + g];
+            lds_wait();
+            fu32x4 piece[2];
+            uint32_t st[2];
+            bool valid[2];
+#pragma unroll
+            for (uint32_t k = 0; k < 2; k++) {
+                valid[k] = (k0 + k) * 16 + g < nq;
+                const uint32_t c = valid[k] ? qe[k].x : 0u;
+                piece[k] = ((const fu32x4 *)(S.chunk + c * kEmitChunk))[j];
+                // the chunk's place: the bin's region start + its generation (read here, once per chunk, not once per record)
+                st[k] = S.start[c >> 1];
+            }
+            lds_wait();  // (also: the chunks have been read before their next generation may write)
+#pragma unroll
+            for (uint32_t k = 0; k < 2; k++) {
+                const uint32_t off = valid[k] ? (st[k] + qe[k].y) * (kEmitChunk * 4u) + j * 16u : kEmitDropOffset;
+                __builtin_amdgcn_raw_buffer_store_b128(piece[k], rsrc, (int)off, 0, 0);
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < 2; k++)
+                if (valid[k] && j == 0)
+                    __hip_atomic_fetch_add((uint32_t *)S.wr + qe[k].x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-        lds_wait();  // (also: the chunks have been read before their next generation may write)
-#pragma unroll
-        for (uint32_t k = 0; k < kEmitQueue / 16; k++) {
-            const uint32_t off = valid[k] ? qe[k].y * (kEmitChunk * 4u) + j * 16u : kEmitDropOffset;
-            __builtin_amdgcn_raw_buffer_store_b128(piece[k], rsrc, (int)off, 0, 0);
-        }
-#pragma unroll
-        for (uint32_t k = 0; k < kEmitQueue / 16; k++)
-            if (valid[k] && j == 0)
-                __hip_atomic_fetch_add((uint32_t *)S.wr + qe[k].x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         lds_order();
         if (!__builtin_amdgcn_ballot_w64(full != 0)) break;
     }
@@ -814,24 +824,25 @@ __device__ __forceinline__ void emit_copy_full(const EmitLds &S, const uint32_t 
 // tile of column loads, so that the ring of loads and stores the compiler counts on the way into the tile loop is the
 // one every later round has (otherwise the waits of the whole loop are sized for the first round: three tiles of
 // loads and no stores between a tile's loads and their use).
+template <uint32_t Q = kEmitQueue>
 __device__ __forceinline__ void emit_pad_stores(const EmitLds &S) {
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)S.out, 0, (int)S.out_bytes, (int)0x00020000);
     const fu32x4 none = {0u, 0u, 0u, 0u};
 #pragma unroll
-    for (uint32_t k = 0; k < kEmitQueue / 16; k++) __builtin_amdgcn_raw_buffer_store_b128(none, rsrc, (int)(kEmitDropOffset + 16u * k), 0, 0);  // (distinct, or they merge)
+    for (uint32_t k = 0; k < Q / 16; k++) __builtin_amdgcn_raw_buffer_store_b128(none, rsrc, (int)(kEmitDropOffset + 16u * k), 0, 0);  // (distinct, or they merge)
 }
 
 // Pushes the lane's records i with act[i] set, rec[i] into bin[i].  The first pass -- all there is for nearly every
 // tile -- keeps its predicates as booleans (lane masks in scalar registers); only a wave with a record whose chunk still
 // holds the generation before last goes on to the bit-mask bookkeeping of the retry loop.
-template <int N>
+template <int N, uint32_t Q = kEmitQueue>
 __device__ __forceinline__ void emit_push_all(const EmitPlan &E, const EmitLds &S, const uint32_t (&bin)[N], const uint32_t (&rec)[N],
                                               const bool (&act)[N]) {
-    uint32_t slot[N], dest[N], which[N], thr[N], pos[N], st[N];
+    uint32_t slot[N], gens[N], which[N], thr[N], pos[N];
     unsigned long long w[N];  // {wr0, wr1}
     bool pend[N];
-    // one LDS round trip in the common case: the slots, the bins' {wr0, wr1} and region starts (wr only grows: a value
-    // read early errs on the side of waiting)
+    // one LDS round trip in the common case: the slots and the bins' {wr0, wr1} (wr only grows: a value read early errs
+    // on the side of waiting)
 #pragma unroll
     for (int i = 0; i < N; i++)
         slot[i] = act[i] ? __hip_atomic_fetch_add(S.cnt + bin[i], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
@@ -839,7 +850,6 @@ __device__ __forceinline__ void emit_push_all(const EmitPlan &E, const EmitLds &
 #pragma unroll
     for (int i = 0; i < N; i++) {
         w[i] = act[i] ? __hip_atomic_load((const unsigned long long *)(S.wr + bin[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0ull;
-        st[i] = act[i] ? __hip_atomic_load(S.start + bin[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
     }
     // ---- first pass
     lds_order();
@@ -849,7 +859,7 @@ __device__ __forceinline__ void emit_push_all(const EmitPlan &E, const EmitLds &
         const uint32_t gen = slot[i] >> 4, h = gen & 1u;
         thr[i] = 17u * (gen >> 1);
         which[i] = bin[i] << 1 | h;
-        dest[i] = st[i] + gen;
+        gens[i] = gen;
         pos[i] = which[i] * kEmitChunk + ((slot[i] + bin[i]) & (kEmitChunk - 1));
         ok[i] = act[i] && (uint32_t)(w[i] >> (h << 5)) >= thr[i];
         if (ok[i]) S.chunk[pos[i]] = rec[i];
@@ -868,7 +878,7 @@ __device__ __forceinline__ void emit_push_all(const EmitPlan &E, const EmitLds &
         left = left || pend[i];
     }
     lds_order();  // the chunk is read after wr showed the other 15 records in place
-    emit_copy_full<N>(S, which, dest, full);
+    emit_copy_full<N, Q>(S, which, gens, full);
     if (!__builtin_amdgcn_ballot_w64(left)) return;
     // ---- some lane of the wave holds a record whose chunk is still waiting to be copied out (rare)
     uint32_t pmask = 0;
@@ -902,7 +912,7 @@ __device__ __forceinline__ void emit_push_all(const EmitPlan &E, const EmitLds &
 #pragma unroll
         for (int i = 0; i < N; i++) full |= ((okm >> i) & 1u) && old[i] == thr[i] + (kEmitChunk - 1) ? 1u << i : 0u;
         lds_order();
-        emit_copy_full<N>(S, which, dest, full);
+        emit_copy_full<N, Q>(S, which, gens, full);
         pmask &= ~okm;
     }
 }

@@ -479,6 +479,11 @@ __global__ __launch_bounds__(kWgThreads, 4) void k_emit_packed(const EmitPlan E)
             B.t = nullptr;
             // D tiles of loads in flight per lane (narrow queries move few bytes per tile)
             constexpr int D = emit_depth(NF + NG + NA);
+            // With one aggregation a tile is only four records per lane, and a push is a chain of ~7 dependent LDS round
+            // trips (slot, wr, write + publish, queue, chunk, copy) that four waves per SIMD do not hide: two tiles are
+            // pushed together (eight records per round trip; the drain then has four store instructions).
+            constexpr int T = (NA == 1 && D % 2 == 0) ? 2 : 1;
+            constexpr uint32_t Q = T == 2 ? kEmitQueueMax : kEmitQueue;
             PackedRaw<NF> rf[D];
             PackedRaw<NG> rg[D];
             PackedRaw<NA> ra[D];
@@ -492,49 +497,54 @@ __global__ __launch_bounds__(kWgThreads, 4) void k_emit_packed(const EmitPlan E)
 #pragma unroll
             for (int d = 0; d < D; d++) {
                 packed_issue_always<NF, NG, NA>(P, B, r_first + (uint32_t)d * kTile, n, rf[d], rg[d], ra[d]);
-                emit_pad_stores(S);  // (the ring as the steady state has it: see emit_pad_stores)
+                if (d % T == T - 1) emit_pad_stores<Q>(S);  // (the ring as the steady state has it: see emit_pad_stores)
                 __builtin_amdgcn_sched_barrier(0);  // oldest tile first: the ring is consumed in this order
             }
             for (uint32_t it0 = 0; it0 < n_tiles; it0 += D) {
 #pragma unroll
-              for (int d = 0; d < D; d++) {
+              for (int d0 = 0; d0 < D; d0 += T) {
                 // (no early exit inside a round: a tile past the end loads nothing -- the descriptor's range check -- and
                 // pushes nothing; a conditional exit here is one more path the compiler's load / store counting must
                 // take the minimum over)
-                const uint32_t r = r_first + (it0 + d) * kTile;   // (< 2^28 + 2^12: no wrap)
-                packed_decode_all<NF, NG, NA, false, false, false>(P, rf[d], rg[d], ra[d], rt, f, g, a, t, 0u);
-                packed_issue_always<NF, NG, NA>(P, B, r + (uint32_t)D * kTile, n, rf[d], rg[d], ra[d]);
-                const uint32_t left = r < n ? n - r : 0u;
-                uint32_t bin[kPackedRows * NA], rec[kPackedRows * NA];
-                bool act[kPackedRows * NA];
+                uint32_t bin[kPackedRows * NA * T], rec[kPackedRows * NA * T];
+                bool act[kPackedRows * NA * T];
 #pragma unroll
-                for (int k = 0; k < kPackedRows; k++) {
-                    bool pass = (uint32_t)k < left;
+                for (int dd = 0; dd < T; dd++) {
+                    const int d = d0 + dd;
+                    const uint32_t r = r_first + (it0 + d) * kTile;   // (< 2^28 + 2^12: no wrap)
+                    packed_decode_all<NF, NG, NA, false, false, false>(P, rf[d], rg[d], ra[d], rt, f, g, a, t, 0u);
+                    packed_issue_always<NF, NG, NA>(P, B, r + (uint32_t)D * kTile, n, rf[d], rg[d], ra[d]);
+                    const uint32_t left = r < n ? n - r : 0u;
 #pragma unroll
-                    for (int c = 0; c < NF; c++) {
-                        const uint32_t u = f.u[c][k];
-                        pass = pass & (u >= P.plo[c]) & (u <= P.phi[c]);
-                    }
-                    uint32_t cell = 0;
-                    bool inb = true;
+                    for (int k = 0; k < kPackedRows; k++) {
+                        bool pass = (uint32_t)k < left;
 #pragma unroll
-                    for (int c = 0; c < NG; c++) {
-                        const uint32_t d = g.u[c][k] + P.gdoff[c];
-                        inb = inb & (d < P.gcard[c]);
-                        cell += __umul24(d, (uint32_t)P.gstride[c]);
-                    }
-                    matched += pass ? 1u : 0u;
-                    overflow += (pass & !inb) ? 1u : 0u;
+                        for (int c = 0; c < NF; c++) {
+                            const uint32_t u = f.u[c][k];
+                            pass = pass & (u >= P.plo[c]) & (u <= P.phi[c]);
+                        }
+                        uint32_t cell = 0;
+                        bool inb = true;
 #pragma unroll
-                    for (int c = 0; c < NA; c++) {
-                        const uint32_t n32 = a.u[c][k] + P.adoff[c];  // value - h.Min
-                        const uint32_t pair = cell * (uint32_t)NA + (uint32_t)c;
-                        bin[k * NA + c] = emit_bin(S, pair);
-                        rec[k * NA + c] = emit_record(pair, n32);
-                        act[k * NA + c] = pass & inb;
+                        for (int c = 0; c < NG; c++) {
+                            const uint32_t d = g.u[c][k] + P.gdoff[c];
+                            inb = inb & (d < P.gcard[c]);
+                            cell += __umul24(d, (uint32_t)P.gstride[c]);
+                        }
+                        matched += pass ? 1u : 0u;
+                        overflow += (pass & !inb) ? 1u : 0u;
+#pragma unroll
+                        for (int c = 0; c < NA; c++) {
+                            const uint32_t n32 = a.u[c][k] + P.adoff[c];  // value - h.Min
+                            const uint32_t pair = cell * (uint32_t)NA + (uint32_t)c;
+                            const int at = (dd * kPackedRows + k) * NA + c;
+                            bin[at] = emit_bin(S, pair);
+                            rec[at] = emit_record(pair, n32);
+                            act[at] = pass & inb;
+                        }
                     }
                 }
-                emit_push_all<kPackedRows * NA>(E, S, bin, rec, act);
+                emit_push_all<kPackedRows * NA * T, Q>(E, S, bin, rec, act);
               }
             }
         }

@@ -7,8 +7,8 @@ import numpy as np
 t = np.loadtxt(sys.argv[1], dtype=np.uint64).astype(np.int64)
 t0 = t[:, 0].min()
 us = lambda x: x / 100.0
-ph = {"zero+regions": t[:, 1] - t[:, 0], "walk": t[:, 2] - t[:, 1], "reduce": t[:, 3] - t[:, 2], "write-out": t[:, 4] - t[:, 3], "whole": t[:, 4] - t[:, 0]}
-print("workgroups", len(t), " kernel span %.1f us" % us(t[:, 4].max() - t0))
+ph = {"regions": t[:, 1] - t[:, 0], "walk": t[:, 2] - t[:, 1], "epilogue": t[:, 4] - t[:, 2], "whole": t[:, 4] - t[:, 0]}
+print("items", len(t), " kernel span %.1f us" % us(t[:, 4].max() - t0))
 for k, v in ph.items():
     print("%-14s mean %8.1f  min %8.1f  max %8.1f us" % (k, us(v.mean()), us(v.min()), us(v.max())))
 wv = t[:, 16:32]
