@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsybilgpu.so")
+# (SYBL_LIBRARY: another build of the same library, for same-box A/B timing runs)
+LIB_PATH = os.environ.get("SYBL_LIBRARY") or os.path.join(_HERE, "libsybilgpu.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "sybilgpu.h")
 
 OK, E_INVAL, E_NODEVICE, E_NOMEM, E_IO, E_STATE, E_BLOCK = 0, -1, -2, -3, -4, -5, -6

@@ -99,7 +99,6 @@ static void free_query(Query *q) {
     if (q->d_pct) hipFree(q->d_pct);
     if (q->d_mom) hipFree(q->d_mom);
     if (q->d_total) hipFree(q->d_total);
-    if (q->d_dirty) hipFree(q->d_dirty);
     if (q->h_top) hipHostFree(q->h_top);
     q->h_pct_buf.reset();
     if (q->h_mom) hipHostFree(q->h_mom);
@@ -159,7 +158,6 @@ static int scan(Query *q) {
     if (rc) return rc;
     trace.mark("partials");
     q->rs_active = false;
-    q->fused_summary = false;
     q->out_log_partial = false;
     hipStream_t st = q->ctx->stream;
     ScanPlan &P = q->plan;
@@ -199,6 +197,8 @@ static int scan(Query *q) {
             const size_t words = (size_t)kHeaderWords + (outliers ? (size_t)P.n_sum_fields * (size_t)P.n_cells : 0);
             SYBL_HIP(hipMemsetAsync(q->d_sum, 0, words * 8, st));
         }
+        // (the wrap log's cursor and k_part_hist's item counter: zeroed here, not between k_emit and k_part_hist)
+        SYBL_HIP(hipMemsetAsync(q->pplan.wrap_log, 0, 8, st));
         SYBL_HIP(hipEventRecord(q->ev[0], st));
         q->eplan.sum_out = q->d_sum;
         q->pplan.sum_out = q->d_sum;
@@ -208,31 +208,10 @@ static int scan(Query *q) {
                            : launch_count(q->eplan, q->part_nf, q->part_ng, q->n_wg, st);
         if (e != hipSuccess) return hip_fail(e, "k_count");
         trace.mark("count");
-        e = launch_part_bases(q->eplan, st);
-        if (e != hipSuccess) return hip_fail(e, "k_part_bases");
         e = q->part_packed ? launch_emit_packed(q->eplan, q->part_nf, q->part_ng, q->part_na, q->n_wg, st)
                            : launch_emit(q->eplan, q->part_nf, q->part_ng, q->part_na, q->n_wg, st);
         if (e != hipSuccess) return hip_fail(e, "k_emit");
         trace.mark("emit");
-        SYBL_HIP(hipMemsetAsync(q->pplan.wrap_log, 0, 8, st));
-        // SYBL_FUSED_SUMMARY=1 (one workgroup per partition, one rank): the result rows' percentiles / bucket moments /
-        // Cumulative buckets come out of k_part_hist's LDS histograms instead of k_hist_summary / k_hist_total re-reading
-        // the finished table (sybl_query_allreduce withdraws it when ranks merge afterwards).  Off by default -- measured
-        // on one box (config 4, 20 steps): 4.63 ms per step fused against 4.71, but k_part_hist grows by 0.32 ms (one
-        // workgroup per CU walks its 64 pairs' percentiles four at a time) for the 0.40 ms the two kernels took.
-        q->fused_summary = query_wants_hist_summary(q) && q->pplan.split == 1 && q->part_more.empty() && getenv("SYBL_FUSED_SUMMARY") != nullptr;
-        q->pplan.fuse = q->fused_summary ? 1 : 0;
-        if (q->fused_summary) {
-            if ((rc = query_summary_buffers(q))) return rc;
-            const int64_t pairs = ((int64_t)P.n_cells + kMaxScatterRanks) * (int64_t)q->aggs.size();
-            SYBL_HIP(hipMemsetAsync(q->d_pct, 0, (size_t)pairs * 100 * 8, st));
-            SYBL_HIP(hipMemsetAsync(q->d_total, 0, (size_t)P.hist_stride * 8, st));
-            SYBL_HIP(hipMemsetAsync(q->d_dirty, 0, (size_t)((pairs + 31) / 32) * 4, st));
-            q->pplan.pct = q->d_pct;
-            q->pplan.mom = q->d_mom;
-            q->pplan.total = q->d_total;
-            q->pplan.dirty = q->d_dirty;
-        }
         // SYBL_PARTHIST_TRACE=<file> (diagnostic): k_part_hist's phase timestamps of this scan, one line per workgroup
         const char *ph_trace = getenv("SYBL_PARTHIST_TRACE");
         DevOwner own_trace;
@@ -261,16 +240,14 @@ static int scan(Query *q) {
         if (e != hipSuccess) return hip_fail(e, "k_part_fix");
         // aggregations 2.. of a query with three or four: the same sequence over the same rows and buffers
         for (auto &pp : q->part_more) {
+            SYBL_HIP(hipMemsetAsync(pp.H.wrap_log, 0, 8, st));  // (behind the previous pass's k_part_fix)
             pp.E.sum_out = q->d_sum;
             pp.H.sum_out = q->d_sum;
             pp.H.max_out = q->d_max;
             e = pp.packed ? launch_count_packed(pp.E, q->part_nf, q->part_ng, q->n_wg, st) : launch_count(pp.E, q->part_nf, q->part_ng, q->n_wg, st);
             if (e != hipSuccess) return hip_fail(e, "k_count");
-            e = launch_part_bases(pp.E, st);
-            if (e != hipSuccess) return hip_fail(e, "k_part_bases");
             e = pp.packed ? launch_emit_packed(pp.E, q->part_nf, q->part_ng, pp.na, q->n_wg, st) : launch_emit(pp.E, q->part_nf, q->part_ng, pp.na, q->n_wg, st);
             if (e != hipSuccess) return hip_fail(e, "k_emit");
-            SYBL_HIP(hipMemsetAsync(pp.H.wrap_log, 0, 8, st));
             e = launch_part_hist(pp.H, st);
             if (e != hipSuccess) return hip_fail(e, "k_part_hist");
             e = launch_part_fix(pp.H, st);

@@ -346,8 +346,6 @@ struct Query {
     bool hist_summary = false;
     bool snap_has_buckets = true;   // the last snapshot carried the bucket arrays
     int64_t *d_pct = nullptr, *d_mom = nullptr, *d_total = nullptr;
-    uint32_t *d_dirty = nullptr;   // bit per (cell, aggregation) pair: see PartHistPlan::dirty
-    bool fused_summary = false;    // the last scan's k_part_hist wrote d_pct / d_mom / d_total itself
     std::shared_ptr<HostBuf> h_pct_buf;          // pinned snapshot of the GPU-computed percentiles (shared with results)
     std::vector<std::shared_ptr<HostBuf>> host_bufs;  // pinned snapshot buffers of this query, reused once no result holds them
     int64_t *h_pct = nullptr, *h_mom = nullptr, *h_total = nullptr;  // pinned (h_pct = h_pct_buf->p)
@@ -424,7 +422,7 @@ int query_rescan_without_part_hist(Query *q);
 
 constexpr int kMaxScatterRanks = 64;  // the SUM section is padded so that a reduce-scatter over up to this many ranks fits in place
 bool query_wants_hist_summary(const Query *q);
-int query_summary_buffers(Query *q);  // (result.cpp) d_pct / d_mom / d_total / d_dirty + their pinned twins
+int query_summary_buffers(Query *q);  // (result.cpp) d_pct / d_mom / d_total + their pinned twins
 // rccl.cpp: collectives on the ctx communicator and stream (SYBL_E_STATE without a communicator)
 int comm_allgather_inplace(Ctx *ctx, int64_t *buf, size_t words_per_rank);
 int comm_allreduce_sum(Ctx *ctx, int64_t *buf, size_t words);

@@ -544,14 +544,16 @@ constexpr int kPartSumRep = 8;   // replicas of the per-pair value sums (lanes o
 constexpr int kPartUnroll = 4;   // 16-byte record loads per lane in flight, twice (current + next)
 constexpr uint32_t kWrapPlus = 0u, kWrapMinusOne = 1u;  // log entry kinds: +65536 / -1
 
-__device__ __noinline__ void part_log_wrap(const PartHistPlan &P, uint32_t pair, uint32_t bucket, uint32_t old, uint32_t nv) {
-    // (rare path) bucket's field was 0xFFFF before this lane's add; old >> 16 = an even bucket's neighbour field then
+__device__ __noinline__ void part_log_wrap(const PartHistPlan &P, uint32_t pair, uint32_t field, uint32_t old, uint32_t n_fields) {
+    // (rare path) `field` was 0xFFFF before this lane's add; old >> 16 = an even field's neighbour then.  Field f holds
+    // bucket f - 1; field 0 is where padding records are counted (k_part_hist): its own wraps mean nothing, its carries do
     uint32_t kinds[3], buckets[3], n = 0;
-    buckets[n] = bucket, kinds[n++] = kWrapPlus;
-    if ((bucket & 1u) == 0 && bucket + 1 < nv) {
-        buckets[n] = bucket + 1, kinds[n++] = kWrapMinusOne;                        // the carry into the high field
-        if ((old >> 16) == 0xFFFFu) buckets[n] = bucket + 1, kinds[n++] = kWrapPlus;  // ... which wrapped it
+    if (field > 0) buckets[n] = field - 1, kinds[n++] = kWrapPlus;
+    if ((field & 1u) == 0 && field + 1 < n_fields) {
+        buckets[n] = field, kinds[n++] = kWrapMinusOne;                         // the carry into the high field
+        if ((old >> 16) == 0xFFFFu) buckets[n] = field, kinds[n++] = kWrapPlus;  // ... which wrapped it
     }
+    if (!n) return;
     const uint32_t at = __hip_atomic_fetch_add(P.wrap_log, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (at + n > P.wrap_cap) {
         __hip_atomic_fetch_add(P.sum_out + kHdrPartOverflow, (int64_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -595,7 +597,12 @@ template <int NA, bool TRACK_MAX, bool OUT>
 __global__ __launch_bounds__(kWgThreads) void k_part_hist(const PartHistPlan P) {
     extern __shared__ uint32_t plds[];
     const uint32_t tid = threadIdx.x;
-    const uint32_t nv = (uint32_t)P.nv_max, nw = (nv + 1u) >> 1;  // buckets, words per pair
+    // A record is (local pair) << 26 | (v - h.Min + BucketSize): its quotient by BucketSize is the bucket + 1, the FIELD
+    // the record counts in.  Field 0 of every pair counts nothing real: the all-zero word -- a region's padding, and what
+    // the range-checked loads return past a region's end -- lands in field 0 of pair 0 and adds 0 to its sum, so the walk
+    // needs no "is this lane's record real" test at all (round 3 spent ~5 of its ~30 vector instructions per record on
+    // it: bounds compare, sentinel compare, two address selects towards per-lane scratch words).
+    const uint32_t nv = (uint32_t)P.nv_max, nw = (nv + 2u) >> 1;  // buckets; words per pair (nv + 1 fields, two to a word)
     const uint32_t split = (uint32_t)P.split, n_items = (uint32_t)P.n_parts * split;
     const uint32_t n_reg_max = ((uint32_t)P.n_wg + split - 1u) / split;
     uint32_t *hist = plds;                                       // [kPartCells][nw] two 16-bit counters per word
@@ -603,9 +610,7 @@ __global__ __launch_bounds__(kWgThreads) void k_part_hist(const PartHistPlan P) 
     long long *vmax = (long long *)(sum + kPartSumRep * kPartCells);                        // [kPartCells]
     uint2 *regions = (uint2 *)(vmax + kPartCells);                                          // [n_reg_max] {first chunk, pieces}
     const uint32_t lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    unsigned long long *dummy64 = (unsigned long long *)(regions + n_reg_max) + lane;       // [64] scratch words (add_record)
-    uint32_t *dummy32 = (uint32_t *)((unsigned long long *)(regions + n_reg_max) + 64) + lane;  // [64]
-    uint32_t *ctl = (uint32_t *)((unsigned long long *)(regions + n_reg_max) + 64) + 64;    // [1] region cursor, [2], [3] the item claimed / the next one
+    uint32_t *ctl = (uint32_t *)(regions + n_reg_max);  // [1] region cursor, [2], [3] the item claimed / the next one
     // (diagnostic, SYBL_PARTHIST_TRACE: the 100 MHz wall clock at the phase boundaries of every item; word 0 claimed, 1 tables
     // zeroed and regions read, 2 records walked, 4 table written, 5 the compute unit, 16.. when each wave finished its walk)
     uint32_t item = 0;
@@ -664,44 +669,39 @@ __global__ __launch_bounds__(kWgThreads) void k_part_hist(const PartHistPlan P) 
         __syncthreads();
         stamp(1);
 
-        auto bucket_of = [&](uint32_t rec, uint32_t &local, uint32_t &n32) -> uint32_t {
-            n32 = rec & ((1u << kRecValueBits) - 1);  // v - h.Min
+        auto field_of = [&](uint32_t rec, uint32_t &local, uint32_t &val) -> uint32_t {
+            val = rec & ((1u << kRecValueBits) - 1);  // v - h.Min + BucketSize
             local = rec >> kRecValueBits;
             const uint32_t a = two ? (local & 1u) : 0u;
             const uint32_t bs = two && a ? bs1 : bs0;
             const double inv = two && a ? inv1 : inv0;
-            // floor(n32 / BucketSize), hist_basic.go:130-150: the estimate is never above the quotient and at most one short
-            // of it (scan_packed.h: packed_udiv); bucket < 2^10 and BucketSize < 2^24 (planner), so the product takes 24 bits
-            uint32_t b = (uint32_t)((double)n32 * inv);
-            if (n32 - __umul24(b, bs) >= bs) b += 1;
-            return b;
+            // floor(val / BucketSize) = bucket + 1, hist_basic.go:130-150: the estimate is never above the quotient and at most
+            // one short of it (scan_packed.h: packed_udiv); field <= 2^10 and BucketSize < 2^24 (planner): a 24-bit product
+            uint32_t f = (uint32_t)((double)val * inv);
+            if (val - __umul24(f, bs) >= bs) f += 1;
+            return f;
         };
-        // One record: returns the word as it was before the add, shifted so that the bucket's own field is the low half (an
-        // even bucket's neighbour field is then the high half).  No branch per record: a padding record (or a lane past the
-        // region's end) aims its two atomics at a scratch word of its own instead of being skipped, so the sixteen adds of a
-        // batch are in flight together and their results are looked at once (what comes back from a scratch word is
-        // checked for liveness again on the wrap path).
-        auto add_record = [&](uint32_t rec, bool in) -> uint32_t {
-            const bool live = in && rec != kRecSentinel;
-            uint32_t local, n32;
-            uint32_t b = bucket_of(rec, local, n32);
+        // One record: returns the word as it was before the add, shifted so that the field's own half is the low one (an
+        // even field's neighbour is then the high half).  No branch per record, and the sixteen adds of a batch are in
+        // flight together: their results are looked at once.
+        auto add_record = [&](uint32_t rec) -> uint32_t {
+            uint32_t local, val;
+            uint32_t f = field_of(rec, local, val);
             if (OUT) {
                 // Outlier (hist_basic.go:132-135): clipped into the last bucket and remembered (part_outlier)
                 const uint32_t nva = two && (local & 1u) ? nv1 : nv0;
-                if (b >= nva) {
-                    if (live) part_outlier(P, pair0 + local, n32);
-                    b = nva - 1u;
+                if (f > nva) {
+                    part_outlier(P, pair0 + local, val - (two && (local & 1u) ? bs1 : bs0));
+                    f = nva;
                 }
             }
-            const uint32_t sh = (b & 1u) << 4;
-            uint32_t *hp = live ? hist + __umul24(local, nw) + (b >> 1) : dummy32;
-            unsigned long long *sp = live ? my_sum + local * kPartSumRep : dummy64;
-            const uint32_t old = __hip_atomic_fetch_add(hp, 1u << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_add(sp, (unsigned long long)n32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (TRACK_MAX && live) {
+            const uint32_t sh = (f & 1u) << 4;
+            const uint32_t old = __hip_atomic_fetch_add(hist + __umul24(local, nw) + (f >> 1), 1u << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(my_sum + local * kPartSumRep, (unsigned long long)val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (TRACK_MAX && rec != kRecSentinel) {
                 const uint32_t a = two ? (local & 1u) : 0u;
                 if (P.m_max[a] >= 0) {
-                    const long long v = (long long)((unsigned long long)P.hmin[a] + (unsigned long long)n32);
+                    const long long v = (long long)((unsigned long long)P.hmin[a] + (unsigned long long)(val - (two && a ? bs1 : bs0)));
                     if (v > vmax[local]) __hip_atomic_fetch_max(vmax + local, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
@@ -709,13 +709,13 @@ __global__ __launch_bounds__(kWgThreads) void k_part_hist(const PartHistPlan P) 
         };
         auto wrapped = [](uint32_t seen) { return (seen & 0xFFFFu) == 0xFFFFu; };
         auto log_wrap = [&](uint32_t rec, uint32_t seen) {  // (rare)
-            uint32_t local, n32;
-            uint32_t b = bucket_of(rec, local, n32);
+            uint32_t local, val;
+            uint32_t f = field_of(rec, local, val);
             const uint32_t nva = two && (local & 1u) ? nv1 : nv0;
-            if (OUT) b = b >= nva ? nva - 1u : b;  // (an outlier was counted in the last bucket)
-            // (the aggregation's own bucket count: the high field next to an even last bucket belongs to nobody -- a carry
+            if (OUT) f = f > nva ? nva : f;  // (an outlier was counted in the last bucket)
+            // (the aggregation's own field count: the high half next to an even last field belongs to nobody -- a carry
             // into it is neither logged nor, below, counted)
-            part_log_wrap(P, pair0 + local, b, (b & 1u) ? 0u : seen, nva);
+            part_log_wrap(P, pair0 + local, f, (f & 1u) ? 0u : seen, nva + 1u);
         };
 
         // ---- the walk: every wave takes regions from the cursor (its first one is its own number), 16-byte pieces (four
@@ -766,13 +766,27 @@ __global__ __launch_bounds__(kWgThreads) void k_part_hist(const PartHistPlan P) 
         while (cur_n) {
             issue(nxt, nxt_first, nxt_n);
             uint32_t seen[kPartUnroll][4];
+            if (cur_first + kBatch <= cur_n || P.tail_mode == 0) {
 #pragma unroll
-            for (int u = 0; u < kPartUnroll; u++) {
-                const bool in = cur_first + (uint32_t)u * 64u + lane < cur_n;
-                seen[u][0] = add_record(cur[u].x, in);
-                seen[u][1] = add_record(cur[u].y, in);
-                seen[u][2] = add_record(cur[u].z, in);
-                seen[u][3] = add_record(cur[u].w, in);
+                for (int u = 0; u < kPartUnroll; u++) {
+                    seen[u][0] = add_record(cur[u].x);
+                    seen[u][1] = add_record(cur[u].y);
+                    seen[u][2] = add_record(cur[u].z);
+                    seen[u][3] = add_record(cur[u].w);
+                }
+            } else {
+                // a region's last batch: the lanes past its end hold zeros, which would all add to ONE word (field 0 of pair
+                // 0) -- same-address LDS atomics of a wave are carried out one after the other
+#pragma unroll
+                for (int u = 0; u < kPartUnroll; u++) {
+                    seen[u][0] = seen[u][1] = seen[u][2] = seen[u][3] = 0u;
+                    if (cur_first + (uint32_t)u * 64u + lane < cur_n) {
+                        seen[u][0] = add_record(cur[u].x);
+                        seen[u][1] = add_record(cur[u].y);
+                        seen[u][2] = add_record(cur[u].z);
+                        seen[u][3] = add_record(cur[u].w);
+                    }
+                }
             }
             bool any = false;
 #pragma unroll
@@ -781,11 +795,10 @@ __global__ __launch_bounds__(kWgThreads) void k_part_hist(const PartHistPlan P) 
             if (any) {
 #pragma unroll
                 for (int u = 0; u < kPartUnroll; u++) {
-                    const bool in = cur_first + (uint32_t)u * 64u + lane < cur_n;  // (a scratch word's old value is no wrap)
-                    if (in && cur[u].x != kRecSentinel && wrapped(seen[u][0])) log_wrap(cur[u].x, seen[u][0]);
-                    if (in && cur[u].y != kRecSentinel && wrapped(seen[u][1])) log_wrap(cur[u].y, seen[u][1]);
-                    if (in && cur[u].z != kRecSentinel && wrapped(seen[u][2])) log_wrap(cur[u].z, seen[u][2]);
-                    if (in && cur[u].w != kRecSentinel && wrapped(seen[u][3])) log_wrap(cur[u].w, seen[u][3]);
+                    if (wrapped(seen[u][0])) log_wrap(cur[u].x, seen[u][0]);
+                    if (wrapped(seen[u][1])) log_wrap(cur[u].y, seen[u][1]);
+                    if (wrapped(seen[u][2])) log_wrap(cur[u].z, seen[u][2]);
+                    if (wrapped(seen[u][3])) log_wrap(cur[u].w, seen[u][3]);
                 }
             }
 #pragma unroll
@@ -801,9 +814,7 @@ __global__ __launch_bounds__(kWgThreads) void k_part_hist(const PartHistPlan P) 
         // ---- the epilogue: the wave that owns a pair (every 16th) reads the pair's counters once -- lanes own consecutive
         // buckets, so a store instruction writes 512 contiguous bytes -- stores them and sums them up: a pair's count is the
         // sum of its buckets as the fields hold them (k_part_fix adds what the wrap log says); sum(v) = sum(v - h.Min) +
-        // count x h.Min.  With SYBL_FUSED_SUMMARY the same wave goes on to the pair's percentiles and bucket moments (what
-        // k_hist_summary would read back out of HBM; a pair whose counters wrapped gets wrong numbers here: k_part_fix
-        // marks it dirty and k_hist_summary redoes it from the fixed table).
+        // count x h.Min.
         for (uint32_t l = wave; l < (uint32_t)kPartCells; l += kWgThreads / 64) {
             const uint32_t pair = pair0 + l;
             if (pair >= total_pairs) break;
@@ -813,7 +824,7 @@ __global__ __launch_bounds__(kWgThreads) void k_part_hist(const PartHistPlan P) 
             const uint32_t *hl = hist + l * nw;
             uint32_t n = 0;
             for (uint32_t b = lane; b < nva; b += 64u) {
-                const uint32_t x = (hl[b >> 1] >> ((b & 1u) << 4)) & 0xFFFFu;
+                const uint32_t x = (hl[(b + 1u) >> 1] >> (((b + 1u) & 1u) << 4)) & 0xFFFFu;  // bucket b is field b + 1
                 n += x;
                 if (split == 1) h[b] = (int64_t)x;          // sole owner of the pair: plain stores, nothing to zero beforehand
                 else if (x) gadd(h + b, (int64_t)x);         // `split` workgroups share the pair: into the zeroed table
@@ -826,7 +837,8 @@ __global__ __launch_bounds__(kWgThreads) void k_part_hist(const PartHistPlan P) 
             }
             // every aggregation accepts every row here (planner: no rejects / missing values), so
             // Result.Count of the cell is the count of any of its aggregations
-            const int64_t vsum = (int64_t)(vs + (unsigned long long)n * (unsigned long long)P.hmin[a]);
+            // (the records carry v - h.Min + BucketSize)
+            const int64_t vsum = (int64_t)(vs + (unsigned long long)n * ((unsigned long long)P.hmin[a] - (unsigned long long)P.bucket_size[a]));
             if (lane == 0) {
                 if (split == 1) {
                     if (a == 0 && !P.no_count) F[cell] = (int64_t)n;
@@ -839,61 +851,6 @@ __global__ __launch_bounds__(kWgThreads) void k_part_hist(const PartHistPlan P) 
                         __hip_atomic_fetch_max(P.max_out + (int64_t)P.m_max[a] * P.n_cells + cell, (int64_t)vmax[l], __ATOMIC_RELAXED,
                                                __HIP_MEMORY_SCOPE_AGENT);
                 }
-            }
-            if (P.fuse && split == 1) {
-                // GetPercentiles (see k_hist_summary), lanes own consecutive buckets
-                const int64_t count = (int64_t)n, bsz = P.bucket_size[a], hmn = P.hmin[a], nvals = P.n_values[a];
-                int64_t *out = P.pct + (int64_t)pair * 100;
-                int64_t sb = 0, sb2 = 0, carry = 0, carry_p = 0;
-                for (int64_t k0 = 0; k0 < nvals; k0 += 64) {
-                    const int64_t k = k0 + lane;
-                    const int64_t x = k < nvals ? (int64_t)((hl[k >> 1] >> ((k & 1) << 4)) & 0xFFFFu) : 0;
-                    sb += k * x;
-                    sb2 += k * k * x;
-                    if (count == 0) continue;
-                    int64_t c = x;  // inclusive scan of x over the wave
-#pragma unroll
-                    for (int o = 1; o < 64; o <<= 1) {
-                        const int64_t y = __shfl_up(c, o, 64);
-                        if ((int)lane >= o) c += y;
-                    }
-                    c += carry;
-                    int64_t pc = (100 * c) / count;
-                    pc = pc < 0 ? 0 : (pc > 100 ? 100 : pc);
-                    int64_t pp = __shfl_up(pc, 1, 64);
-                    if (lane == 0) pp = carry_p;
-                    if (k < nvals) {
-                        const int64_t val = k * bsz + hmn;
-                        for (int64_t ip = pp; ip < pc; ip++) out[ip] = val;  // (pc <= 100: ip < 100)
-                        if (k == nvals - 1 && pc < 100) out[pc] = k;
-                    }
-                    carry = __shfl(c, 63, 64);
-                    carry_p = __shfl(pc, 63, 64);
-                }
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {
-                    sb += __shfl_xor(sb, o, 64);
-                    sb2 += __shfl_xor(sb2, o, 64);
-                }
-                if (lane == 0) {
-                    P.mom[(int64_t)pair * 2] = sb;
-                    P.mom[(int64_t)pair * 2 + 1] = sb2;
-                }
-            }
-        }
-        if (P.fuse && split == 1) {
-            // Cumulative: this partition's share of every (aggregation, bucket), one atomic per non-zero word
-            for (uint32_t b = tid; b < nv; b += kWgThreads) {
-                int64_t acc[NA];
-#pragma unroll
-                for (int a = 0; a < NA; a++) acc[a] = 0;
-                for (uint32_t l = 0; l < (uint32_t)kPartCells; l++) {
-                    if (pair0 + l >= total_pairs) break;
-                    acc[l % NA] += (int64_t)((hist[l * nw + (b >> 1)] >> ((b & 1u) << 4)) & 0xFFFFu);
-                }
-#pragma unroll
-                for (int a = 0; a < NA; a++)
-                    if (acc[a] && b < (uint32_t)P.n_values[a]) gadd(P.total + P.hist_agg_off[a] + b, acc[a]);
             }
         }
         stamp(4);
@@ -920,53 +877,13 @@ __global__ __launch_bounds__(256) void k_part_fix(const PartHistPlan P) {
         const int64_t delta = (e >> 16) == kWrapPlus ? 65536 : -1;
         gadd(P.sum_out + P.hist_off + (int64_t)cell * P.hist_stride + P.hist_agg_off[a] + bucket, delta);
         if (a == 0 && !P.no_count) gadd(F + cell, delta);
-        gadd(F + (int64_t)P.f_sum[a] * P.n_cells + cell, delta * P.hmin[a]);
-        if (P.fuse) {
-            gadd(P.total + P.hist_agg_off[a] + bucket, delta);
-            atomicOr(P.dirty + (pair >> 5), 1u << (pair & 31u));
-        }
+        // (k_part_hist's sum of the records' value parts is exact; what was off is the count its h.Min - BucketSize went in with)
+        gadd(F + (int64_t)P.f_sum[a] * P.n_cells + cell, delta * (P.hmin[a] - P.bucket_size[a]));
     }
 }
 
 hipError_t launch_part_fix(const PartHistPlan &P, hipStream_t st) {
     hipLaunchKernelGGL(k_part_fix, dim3(64), dim3(256), 0, st, P);
-    return hipGetLastError();
-}
-
-// k_part_bases: wbase[w] = the chunks of the workgroups before w (boff[w][nb] is w's own total: k_count), wbase[n_wg] =
-// all chunks.  One workgroup; n_wg is a few hundred.
-__global__ __launch_bounds__(kWgThreads) void k_part_bases(const EmitPlan E) {
-    __shared__ uint32_t wave_tot[kWgThreads / 64];
-    __shared__ uint32_t carry_s;
-    const uint32_t tid = threadIdx.x, nw = (uint32_t)E.n_wg, nb1 = ((uint32_t)E.n_parts << E.sub_shift) + 1u;
-    if (tid == 0) carry_s = 0;
-    __syncthreads();
-    for (uint32_t w0 = 0; w0 < nw; w0 += kWgThreads) {
-        const uint32_t w = w0 + tid;
-        const uint32_t mine = w < nw ? E.boff[(size_t)w * nb1 + (nb1 - 1)] : 0u;
-        uint32_t x = mine;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t y = __shfl_up(x, o, 64);
-            if ((int)(tid & 63) >= o) x += y;
-        }
-        if ((tid & 63) == 63) wave_tot[tid >> 6] = x;
-        __syncthreads();
-        uint32_t before = carry_s, total = 0;
-        for (uint32_t v = 0; v < kWgThreads / 64; v++) {
-            before += v < (tid >> 6) ? wave_tot[v] : 0u;
-            total += wave_tot[v];
-        }
-        if (w < nw) E.wbase[w] = before + x - mine;
-        __syncthreads();
-        if (tid == 0) carry_s += total;
-        __syncthreads();
-    }
-    if (tid == 0) E.wbase[nw] = carry_s;
-}
-
-hipError_t launch_part_bases(const EmitPlan &E, hipStream_t st) {
-    hipLaunchKernelGGL(k_part_bases, dim3(1), dim3(kWgThreads), 0, st, E);
     return hipGetLastError();
 }
 
@@ -986,8 +903,7 @@ static hipError_t part_hist_launch(const PartHistPlan &P, size_t lds, hipStream_
 hipError_t launch_part_hist(const PartHistPlan &P, hipStream_t st) {
     if (P.n_parts <= 0) return hipSuccess;
     const uint32_t n_reg = ((uint32_t)P.n_wg + (uint32_t)P.split - 1u) / (uint32_t)P.split;
-    size_t lds = (size_t)kPartCells * ((P.nv_max + 1) / 2) * 4 + (size_t)kPartCells * (kPartSumRep + 1) * 8 + (size_t)n_reg * 8 +
-                 64 * 12 + 16;  // + a scratch word pair per lane (add_record) + item / region cursors
+    size_t lds = (size_t)kPartCells * ((P.nv_max + 2) / 2) * 4 + (size_t)kPartCells * (kPartSumRep + 1) * 8 + (size_t)n_reg * 8 + 16;  // + item / region cursors
     const bool track_max = P.m_max[0] >= 0 || (P.n_aggs > 1 && P.m_max[1] >= 0);
     if (P.n_aggs == 1) return track_max ? part_hist_launch<1, true>(P, lds, st) : part_hist_launch<1, false>(P, lds, st);
     if (P.n_aggs == 2) return track_max ? part_hist_launch<2, true>(P, lds, st) : part_hist_launch<2, false>(P, lds, st);
@@ -1071,12 +987,6 @@ __global__ __launch_bounds__(256) void k_hist_summary(const HistSummaryPlan S) {
     const int64_t *v = S.H + cell * S.hist_stride + S.agg_off[a];
     const int64_t count = S.F[(int64_t)S.f_cnt[a] * S.n_cells + cell];
     int64_t *out = S.pct + pair * 100;
-    if (S.dirty) {
-        // only the pairs k_part_hist could not summarise itself (wrapped counters): start from zeros again
-        if (!((S.dirty[pair >> 5] >> (pair & 31)) & 1u)) return;
-        out[lane] = 0;
-        if (lane + 64 < 100) out[lane + 64] = 0;
-    }
     const int64_t bs = S.bucket_size[a], hmin = S.hmin[a], nvals = S.n_values[a];
     int64_t sb = 0, sb2 = 0, carry = 0, carry_p = 0;
     // (loading the whole bucket array into registers first -- sixteen wave loads in flight -- measured slower: 0.33 ms against

@@ -191,8 +191,6 @@ struct HistSummaryPlan {
     int64_t cell0, cell1;      // cells to summarise (a rank's slice after a reduce-scatter; else all of them)
     int64_t *pct;              // [cell * n_aggs + a][100], zeroed
     int64_t *mom;              // [cell * n_aggs + a][2]: sum(b * Values[b]), sum(b^2 * Values[b])
-    const uint32_t *dirty;     // nullptr: every pair; else only the pairs whose bit is set (k_part_hist summarised the rest
-                               // itself; these had bucket counters that wrapped and were fixed up afterwards)
 };
 
 constexpr int kOutLogWords = 3;                  // int64 words per outlier record: cell / key, aggregation, value

@@ -442,19 +442,26 @@ static bool plan_part_pass(Table *t, Query *q, const std::vector<int> &slot_col,
     q->aggs.swap(all);
     if (!shape) return false;
     const int na = G.na;
-    // a record is (local pair, v - h.Min): the value part must fit kRecValueBits, stay clear of kRecSentinel (all ones:
-    // local pair 31 and every value bit set), and k_part_hist's divide multiplies bucket x BucketSize in 24 bits
+    // (the emitting kernels subtract h.Min -- canonical storage -- or add adoff = base - h.Min -- compact storage: biased
+    // by BucketSize, the record's value part comes out as v - h.Min + BucketSize at no cost)
+    for (int c = 0; c < na; c++) {
+        E.fp.hmin[c] -= (int64_t)E.fp.bucket_size[c];
+        if (G.packed) E.fp.adoff[c] += E.fp.bucket_size[c];
+    }
+    // a record is (local pair, v - h.Min + BucketSize) -- k_part_hist's quotient is the bucket + 1, and the all-zero word is
+    // free to mean "no record" (kRecSentinel) --: the value part must fit kRecValueBits, and k_part_hist's divide multiplies
+    // (bucket + 1) x BucketSize in 24 bits
     for (int a = a0; a < a0 + n; a++) {
         const AggDesc &A = q->aggs[(size_t)a].d;
         if (A.n_values > (1 << kBucketBits) || A.bucket_size >= ((int64_t)1 << 24)) return false;
-        if ((int64_t)A.n_values * A.bucket_size >= ((int64_t)1 << kRecValueBits)) return false;
+        if (((int64_t)A.n_values + 1) * A.bucket_size >= ((int64_t)1 << kRecValueBits)) return false;
         if (A.f_out >= 0) {
             // outliers: every accepted value, not only the bucket range, must fit the record, and k_part_hist's quotient
             // (a 24-bit multiply checks it) stays below 2^24
             const Column *c = t->cols[(size_t)q->aggs[(size_t)a].col].get();
             const int64_t hi = std::min(c->bounds_set ? c->bound_hi : c->exact_max, A.max10);
             if (hi < A.hmin) continue;
-            const unsigned __int128 span = (unsigned __int128)((__int128)hi - (__int128)A.hmin);
+            const unsigned __int128 span = (unsigned __int128)((__int128)hi - (__int128)A.hmin) + (unsigned __int128)A.bucket_size;
             if (span >= ((unsigned __int128)1 << kRecValueBits) - 1 || span / (unsigned __int128)A.bucket_size >= ((unsigned __int128)1 << 24)) return false;
         }
     }
@@ -536,6 +543,7 @@ static void bind_part_pass(Query *q, int a0, const PartGeom &G, uint32_t *d_recs
     // few partitions: several workgroups share one so the whole chip is busy
     H.split = (int32_t)std::max<int64_t>(1, (int64_t)q->n_wg / G.n_parts);
     H.n_cus = q->ctx->n_cus;
+    H.tail_mode = getenv("SYBL_PARTHIST_TAIL") ? atoi(getenv("SYBL_PARTHIST_TAIL")) : 1;
 }
 
 static int select_part_hist(Table *t, Query *q, const std::vector<int> &slot_col, int64_t rows_scanned) {

@@ -190,7 +190,6 @@ int sybl_query_allreduce(sybl_query *q) {
     SYBL_HIP(hipSetDevice(ctx->device));
     ncclComm_t comm = (ncclComm_t)ctx->comm;
     if (ctx->comm_nranks > 1) q->out_log_partial = true;  // (until gather_outlier_logs has brought every rank's in)
-    q->fused_summary = false;  // (k_part_hist summarised this rank's rows only: the merged table is summarised by the snapshot)
     // Outlier values (plan.h: outlier log): every rank logged its own; the merged result needs all of them
     // (hist_basic.go:132-142,221-257: printed as buckets of their own).  The local count is read before the header is
     // summed -- a host round trip, but only queries whose column bounds allow an outlier at all keep a log.

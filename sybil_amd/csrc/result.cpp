@@ -391,7 +391,6 @@ int query_summary_buffers(Query *q) {
     SYBL_HIP(hipMalloc((void **)&q->d_pct, (size_t)pairs * 100 * 8));
     SYBL_HIP(hipMalloc((void **)&q->d_mom, (size_t)pairs * 2 * 8));
     SYBL_HIP(hipMalloc((void **)&q->d_total, (size_t)P.hist_stride * 8));
-    SYBL_HIP(hipMalloc((void **)&q->d_dirty, (size_t)((pairs + 31) / 32) * 4));
     SYBL_HIP(hipHostMalloc((void **)&q->h_mom, (size_t)pairs * 2 * 8, hipHostMallocDefault));
     SYBL_HIP(hipHostMalloc((void **)&q->h_total, (size_t)P.hist_stride * 8, hipHostMallocDefault));
     return SYBL_OK;
@@ -460,12 +459,8 @@ int query_snapshot(Query *q) {
             if (rc) return rc;
         }
         q->h_pct = q->h_pct_buf->p;
-        // (fused: k_part_hist wrote the summaries during the scan; only pairs a logged wrap touched are redone here)
-        const bool fused = q->fused_summary && !q->rs_active;
-        if (!fused) {
-            SYBL_HIP(hipMemsetAsync(q->d_pct, 0, (size_t)pairs * 100 * 8, st));
-            SYBL_HIP(hipMemsetAsync(q->d_total, 0, (size_t)P.hist_stride * 8, st));
-        }
+        SYBL_HIP(hipMemsetAsync(q->d_pct, 0, (size_t)pairs * 100 * 8, st));
+        SYBL_HIP(hipMemsetAsync(q->d_total, 0, (size_t)P.hist_stride * 8, st));
         HistSummaryPlan S;
         memset(&S, 0, sizeof(S));
         S.H = q->d_sum + P.hist_off;
@@ -485,8 +480,7 @@ int query_snapshot(Query *q) {
         S.mom = q->d_mom;
         S.cell0 = q->rs_active ? q->rs_cell0 : 0;
         S.cell1 = q->rs_active ? q->rs_cell1 : P.n_cells;
-        S.dirty = fused ? q->d_dirty : nullptr;
-        hipError_t e = launch_hist_summary(S, fused ? nullptr : q->d_total, st);
+        hipError_t e = launch_hist_summary(S, q->d_total, st);
         if (e != hipSuccess) return hip_fail(e, "k_hist_summary");
         if (q->rs_active) {
             // every rank summarised its slice of cells: gather the slices, add up the Cumulative buckets

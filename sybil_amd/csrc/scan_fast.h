@@ -139,14 +139,15 @@ hipError_t launch_scan_fast(const FastPlan &P, int nf, int ng, int na, int mode,
 constexpr int kPartCells = 64;       // (cell, agg) pairs per partition
 constexpr int kPartCellBits = 6;
 constexpr int kBucketBits = 10;      // len(Values) <= 1024
-constexpr int kRecValueBits = 26;    // v - h.Min < len(Values) * BucketSize < 2^26 (planner: select_part_hist)
+constexpr int kRecValueBits = 26;    // v - h.Min + BucketSize < (len(Values) + 1) * BucketSize < 2^26 (planner: select_part_hist)
 constexpr int kMaxParts = 1024;      // LDS staging in k_emit: two 16-record chunks per bin
 constexpr int kEmitMaxBins = 1024;   // bins = n_parts << sub_shift
 constexpr uint32_t kEmitChunk = 16;  // records per chunk
 constexpr uint32_t kEmitQueue = 32;  // completed chunks a wave copies out per drain (two store instructions) ...
 constexpr uint32_t kEmitQueueMax = 64;  // ... four when a push holds eight records per lane (k_emit_packed, two tiles at a time); LDS is sized for this
 constexpr int kEmitBinWords = 4 + 2 * (int)kEmitChunk;  // LDS words per bin: {cnt, wr0, wr1, region start} + two chunks
-constexpr uint32_t kRecSentinel = 0xFFFFFFFFu;      // padding record (never a real one: planner)
+constexpr uint32_t kRecSentinel = 0u;               // padding record: never a real one -- a record's value part is v - h.Min + BucketSize >= 1
+                                                    // -- and what a range-checked load past a region's end returns (k_part_hist counts it nowhere)
 constexpr uint32_t kEmitDropOffset = 0x80000000u;   // byte offset past any workgroup's output (< 2 GB: planner)
 
 struct EmitPlan {
@@ -170,17 +171,10 @@ struct PartHistPlan {
     int32_t n_parts, n_aggs, n_cells, nv_max;
     int32_t n_wg, sub_shift;
     int32_t split;                   // shares of a partition (> 1: results are combined with atomics)
-    int32_t n_cus, pad_cus_;         // the persistent kernel's grid: one workgroup per compute unit claims (partition, share) items
+    int32_t n_cus, tail_mode;        // (tail_mode: SYBL_PARTHIST_TAIL, diagnostic) the persistent kernel's grid: one workgroup per compute unit claims (partition, share) items
     uint32_t *wrap_log;              // [0]: entries used, [1]: items claimed (k_part_hist's work counter), then {pair, bucket | kind << 16}:
                                      // 16-bit counters that wrapped
     uint32_t wrap_cap;               // entries the log holds
-    // the result rows' summaries, derived where the partition's histograms sit in LDS instead of by a second and third
-    // pass over the finished 525 MB table (k_hist_summary / k_hist_total): GetPercentiles, the bucket moments of
-    // GetStdDev, the Cumulative bucket arrays.  fuse = 0: left to those kernels (several workgroups per partition, a
-    // result that is merged across ranks first)
-    int64_t *pct, *mom, *total;
-    uint32_t *dirty;                 // bit per pair: a logged wrap touched it (k_part_fix): k_hist_summary redoes those
-    int32_t fuse;
     int32_t no_count;                // a later pass of a query with three or four aggregations: Result.Count of the cells
                                      // was written by the first (every aggregation accepts every row here)
     int32_t n_values[kFastMaxA], f_sum[kFastMaxA], m_max[kFastMaxA];
@@ -208,7 +202,6 @@ inline size_t count_lds_bytes(const EmitPlan &E) { return (((size_t)E.n_parts <<
 
 hipError_t launch_count(const EmitPlan &P, int nf, int ng, int n_wg, hipStream_t st);
 hipError_t launch_count_packed(const EmitPlan &P, int nf, int ng, int n_wg, hipStream_t st);
-hipError_t launch_part_bases(const EmitPlan &P, hipStream_t st);
 hipError_t launch_emit(const EmitPlan &P, int nf, int ng, int na, int n_wg, hipStream_t st);
 hipError_t launch_part_hist(const PartHistPlan &P, hipStream_t st);
 hipError_t launch_part_fix(const PartHistPlan &P, hipStream_t st);
@@ -732,7 +725,23 @@ __device__ __forceinline__ EmitLds emit_begin(const EmitPlan &E, uint32_t *elds)
         S.start[i] = boff[i];
     }
     if (tid < (kWgThreads / 64) * kEmitQueueMax) queues[tid] = make_uint2(0u, 0u);
-    S.out = E.recs + (size_t)E.wbase[blockIdx.x] * kEmitChunk;
+    // wbase[w] = the chunks of the workgroups before w (boff[w'][nb] is w's own total: k_count).  Every workgroup adds them
+    // up for itself -- a few hundred words -- and leaves the result where k_part_hist looks for it (round 3: a one-workgroup
+    // kernel of its own between k_count and k_emit, i.e. two more kernel boundaries per scan).
+    uint32_t before = 0;
+    for (uint32_t w = tid; w < blockIdx.x; w += kWgThreads) before += E.boff[(size_t)w * (S.nb + 1) + S.nb];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o, 64);
+    uint32_t *wave_part = (uint32_t *)S.queue;  // (this wave's queue, still unused: one word of it)
+    if ((tid & 63u) == 0) wave_part[0] = before;
+    __syncthreads();
+    before = 0;
+#pragma unroll
+    for (uint32_t v = 0; v < kWgThreads / 64; v++) before += ((const uint32_t *)(queues + v * kEmitQueueMax))[0];
+    __syncthreads();
+    if ((tid & 63u) == 0) S.queue[0] = make_uint2(0u, 0u);
+    if (tid == 0) E.wbase[blockIdx.x] = before;
+    S.out = E.recs + (size_t)before * kEmitChunk;
     S.out_bytes = boff[S.nb] * (kEmitChunk * 4u);
     __syncthreads();
     return S;

@@ -49,11 +49,7 @@ def test_cfg3_with_full_histograms(ctx, oracle):
     gres.free()
 
 
-@pytest.mark.parametrize("fused", [False, True])
-def test_cfg4_high_cardinality_histograms(ctx, oracle, monkeypatch, fused):
-    # fused: percentiles / bucket moments / Cumulative buckets out of k_part_hist's epilogue (SYBL_FUSED_SUMMARY, opt-in)
-    if fused:
-        monkeypatch.setenv("SYBL_FUSED_SUMMARY", "1")
+def test_cfg4_high_cardinality_histograms(ctx, oracle):
     wl = _wl("cfg4_hist_highcard")
     gres, ores, stats = parity.run_both(ctx, oracle, wl["columns"], 400_000, 0, 400_000, wl["query"])
     assert stats["strategy"] == 5  # 65536 groups x 1002 buckets: partitioned histograms
@@ -960,14 +956,12 @@ def rewritten_for(tb, pattern, py):
     return [re.sub(pattern, py, s) for s in tb.column_dict("host")]
 
 
-@pytest.mark.parametrize("compact,fused", [(False, False), (True, False), (True, True)])
-def test_bucket_counters_that_wrap(ctx, oracle, monkeypatch, compact, fused):
+@pytest.mark.parametrize("compact", [False, True])
+def test_bucket_counters_that_wrap(ctx, oracle, compact):
     """k_part_hist keeps its bucket arrays as 16-bit LDS counters, two to a word, and logs every wrap for k_part_fix
     (csrc/kernels.hip).  One group holds most rows and two NEIGHBOURING buckets of it -- an even one and the odd one
     sharing its word -- take > 450 000 values each: both fields wrap several times and every wrap of the low field
     carries into the high one.  Buckets, Count and the exact sum must come out as the oracle's."""
-    if fused:  # (the pairs a logged wrap touched are summarised again from the fixed table: PartHistPlan::dirty)
-        monkeypatch.setenv("SYBL_FUSED_SUMMARY", "1")
     rng = np.random.default_rng(20260926)
     n = 1_300_000
     g = rng.integers(0, 4096, n, dtype=np.int64)
