@@ -366,6 +366,12 @@ __device__ __forceinline__ void packed_row(const FastPlan &P0, const PackedTile<
 
 constexpr int64_t kPackedChunkRows = (int64_t)1 << 28;  // rows addressed with one 32-bit byte offset (x4 bytes)
 
+// SYBL_PACKED_LATE=0 at build time: k_scan_packed without late materialisation (same-box A/B builds)
+#ifndef SYBL_PACKED_LATE
+#define SYBL_PACKED_LATE 1
+#endif
+constexpr bool kPackedLate = SYBL_PACKED_LATE != 0;
+
 #ifndef SYBL_PACKED_WAVES_PER_EU
 #define SYBL_PACKED_WAVES_PER_EU 4
 #endif
@@ -430,6 +436,90 @@ __global__ __launch_bounds__(kWgThreads, SYBL_PACKED_WAVES_PER_EU) void k_scan_p
             PackedRaw<NG> rg;
             PackedRaw<NA> ra;
             PackedRaw<1> rt;
+            if (kPackedLate && !NUL && NF > 0 && NG + NA + (TIME ? 1 : 0) > 0) {
+                // Late materialisation (the reference's row loop leaves a row at its first failing filter, aggregate.go:105-116):
+                // the filter columns run one tile ahead of the key / aggregation / time columns, the tile's predicate is
+                // evaluated as soon as they arrive, and a WAVE none of whose 256 rows passes does not read the other columns
+                // of that tile.  The load instructions are still issued -- a fixed count per iteration keeps the compiler's
+                // vmcnt exact (packed_issue_always) -- but through a descriptor of zero records: the range check answers
+                // without touching memory, so the skipped lines are never fetched (a wave's tile of 256 rows is whole 128-byte
+                // lines at every stored width: 256, 512 or 1024 bytes).
+                // Iteration t: decode keys / values of tile t and the filters of t + 1, issue keys / values of t + 1 (or
+                // nothing) and the filters of t + 2, then the rows of t with the predicate bits kept from last time.
+                const uint32_t r_first = tid * kPackedRows;
+                const uint32_t n_tiles = (n + kPackedTileRows - 1) / kPackedTileRows;
+                PackedTile<0> f0;
+                auto issue_filters = [&](uint32_t r) {
+                    const uint32_t r0 = __builtin_amdgcn_readfirstlane(r), lane_row = r - r0;
+                    const uint32_t rows = r0 < n ? (n - r0 < 64u * kPackedRows ? (n - r0 + kPackedRows - 1) & ~(uint32_t)(kPackedRows - 1) : 64u * kPackedRows) : 0u;
+                    const uint32_t base_row = rows ? r0 : 0u;
+#pragma unroll
+                    for (int c = 0; c < NF; c++) {
+                        const int ws = P.fwid[c] >> 1;
+                        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(B.f[c] + ((size_t)base_row << ws)), 0, (int)(rows << ws), (int)kBufferRsrcWord3);
+                        rf.v[c] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(lane_row << ws), 0, 2);
+                    }
+                };
+                auto issue_rest = [&](uint32_t r, bool wanted) {
+                    const uint32_t r0 = __builtin_amdgcn_readfirstlane(r), lane_row = r - r0;
+                    uint32_t rows = r0 < n ? (n - r0 < 64u * kPackedRows ? (n - r0 + kPackedRows - 1) & ~(uint32_t)(kPackedRows - 1) : 64u * kPackedRows) : 0u;
+                    rows = wanted ? rows : 0u;  // (wave-uniform: nothing of this tile is wanted -> a descriptor of zero records)
+                    const uint32_t base_row = rows ? r0 : 0u;
+                    auto issue = [&](const uint8_t *col, int width, pu32x4 &raw) {
+                        const int ws = width >> 1;
+                        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(col + ((size_t)base_row << ws)), 0, (int)(rows << ws), (int)kBufferRsrcWord3);
+                        raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(lane_row << ws), 0, 2);
+                    };
+                    if (TIME) issue(B.t, P.twid, rt.v[0]);
+#pragma unroll
+                    for (int c = 0; c < NG; c++) {
+                        if (G1) {
+                            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(B.g[c] + (size_t)base_row), 0, (int)rows, (int)kBufferRsrcWord3);
+                            rg.v[c].x = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)lane_row, 0, 2);
+                        } else {
+                            issue(B.g[c], P.gwid[c], rg.v[c]);
+                        }
+                    }
+#pragma unroll
+                    for (int c = 0; c < NA; c++) issue(B.a[c], P.awid[c], ra.v[c]);
+                };
+                auto filter_bits = [&](uint32_t r) -> uint32_t {
+                    // (decodes rf: the first use of the filter loads issued an iteration ago)
+#pragma unroll
+                    for (int c = 0; c < NF; c++) packed_decode(P.fwid[c], rf.v[c], f.u[c]);
+                    const uint32_t left = r < n ? n - r : 0u;
+                    uint32_t bits = 0;
+#pragma unroll
+                    for (int k = 0; k < kPackedRows; k++) {
+                        bool pass = (uint32_t)k < left;
+#pragma unroll
+                        for (int c = 0; c < NF; c++) pass = pass & (f.u[c][k] >= P.plo[c]) & (f.u[c][k] <= P.phi[c]);
+                        bits |= pass ? 1u << k : 0u;
+                    }
+                    return bits;
+                };
+                issue_filters(r_first);
+                uint32_t bits = filter_bits(r_first);
+                issue_rest(r_first, __builtin_amdgcn_ballot_w64(bits != 0) != 0);
+                issue_filters(r_first + kPackedTileRows);
+                for (uint32_t it = 0; it < n_tiles; it++) {
+                    const uint32_t r = r_first + it * kPackedTileRows;  // (< 2^28 + 2^13: no wrap)
+                    // keys / values / time of tile `it` (their loads were issued an iteration ago; zeros if nothing was wanted)
+                    if (TIME) packed_decode(P.twid, rt.v[0], t.u[0]);
+#pragma unroll
+                    for (int c = 0; c < NG; c++) packed_decode(G1 ? 1 : P.gwid[c], rg.v[c], g.u[c]);
+#pragma unroll
+                    for (int c = 0; c < NA; c++) packed_decode(P.awid[c], ra.v[c], a.u[c]);
+                    const uint32_t next_bits = filter_bits(r + kPackedTileRows);
+                    issue_rest(r + kPackedTileRows, __builtin_amdgcn_ballot_w64(next_bits != 0) != 0);
+                    issue_filters(r + 2u * kPackedTileRows);
+#pragma unroll
+                    for (int k = 0; k < kPackedRows; k++)
+                        packed_row<0, NG, NA, MODE, TIME, false>(P, f0, g, a, t, k, (bits >> k) & 1u, lds, L, matched, overflow);
+                    bits = next_bits;
+                }
+                continue;
+            }
             uint32_t r = tid * kPackedRows;
             if (r < n) {
                 packed_issue_all<NF, NG, NA, TIME, G1, NUL, FRESH>(P, B, r, rf, rg, ra, rt);

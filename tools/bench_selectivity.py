@@ -23,13 +23,15 @@ cases = [
 ]
 for label, filters in cases:
     q = t.query(**dict(wl["query"], filters=filters))
-    q.run().free()
     ms = []
-    for _ in range(steps):
-        r = q.run()
+    for _ in range(steps + 3):  # (back-to-back scans, no finalize in between: the GPU stays at its working clocks)
+        q.scan()
+        ctx.sync()
         ms.append(q.stats()["scan_ms"])
-        matched = r.matched
-        r.free()
+    ms = ms[3:]
+    r = q.finalize()
+    matched = r.matched
+    r.free()
     st = q.stats()
     k = sorted(ms)[len(ms) // 2]
     print(json.dumps({"selectivity": label, "rows": rows, "matched": matched, "match_frac": matched / rows, "kernel_ms": round(k, 3),
