@@ -371,6 +371,10 @@ constexpr int64_t kPackedChunkRows = (int64_t)1 << 28;  // rows addressed with o
 #define SYBL_PACKED_LATE 1
 #endif
 constexpr bool kPackedLate = SYBL_PACKED_LATE != 0;
+#ifndef SYBL_PACKED_LATE_BRANCH
+#define SYBL_PACKED_LATE_BRANCH 1
+#endif
+constexpr bool kPackedLateBranch = SYBL_PACKED_LATE_BRANCH != 0;
 
 #ifndef SYBL_PACKED_WAVES_PER_EU
 #define SYBL_PACKED_WAVES_PER_EU 4
@@ -511,7 +515,11 @@ __global__ __launch_bounds__(kWgThreads, SYBL_PACKED_WAVES_PER_EU) void k_scan_p
 #pragma unroll
                     for (int c = 0; c < NA; c++) packed_decode(P.awid[c], ra.v[c], a.u[c]);
                     const uint32_t next_bits = filter_bits(r + kPackedTileRows);
-                    issue_rest(r + kPackedTileRows, __builtin_amdgcn_ballot_w64(next_bits != 0) != 0);
+                    if (kPackedLateBranch) {
+                        if (__builtin_amdgcn_ballot_w64(next_bits != 0) != 0) issue_rest(r + kPackedTileRows, true);
+                    } else {
+                        issue_rest(r + kPackedTileRows, __builtin_amdgcn_ballot_w64(next_bits != 0) != 0);
+                    }
                     issue_filters(r + 2u * kPackedTileRows);
 #pragma unroll
                     for (int k = 0; k < kPackedRows; k++)
