@@ -360,12 +360,19 @@ def main():
                 dt = float(tmax.item())
             stats = queries[0].stats()
             out = {"dt": dt, "stats": stats, "kernel_ms": (sum(scan_ms) / len(scan_ms)) if scan_ms else stats["scan_ms"],
-                   "host_ms": {k: round(sum(v) / len(v), 3) if v else None for k, v in host_ms.items()}}
+                   "host_ms": dict({k: round(sum(v) / len(v), 3) if v else None for k, v in host_ms.items()},
+                                   finish_median=round(sorted(host_ms["finish"])[len(host_ms["finish"]) // 2], 3) if host_ms["finish"] else None,
+                                   finish_max=round(max(host_ms["finish"]), 3) if host_ms["finish"] else None)}
             if rank == 0:
                 # every step scans the same table: the merged result must not change from step to step (it
                 # would if the all-reduce ever ran ahead of a rank's scan) and group counts must add up
                 assert len(seen_matched) == 1, "matched count varies across steps: %r" % sorted(seen_matched)
                 assert len(scan_ms) == steps
+                # (a big result's rows are built when first asked for -- sybl_query_finalize finds the live cells, sorts and keeps
+                # the snapshot --: what that costs is reported beside the step, from the last step's result)
+                t_rows = time.perf_counter()
+                res.materialize()
+                out["rows_first_access_ms"] = round((time.perf_counter() - t_rows) * 1e3, 3)
                 rows_out = res.time_results if q.get("time_col") else res.rows(0, want_values=False)
                 assert sum(g["count"] for g in rows_out) == res.matched
                 out["matched"] = res.matched
@@ -423,7 +430,8 @@ def main():
                            "stored_widths": {n: table.column_storage(n)[0] for n in names},
                            "sharding": "contiguous 65536-row blocks per rank", "collective": args.collective if multi else None,
                            "device": dev["name"], "matched_rows": head["matched"], "groups": head["groups"],
-                           "host_ms_per_step": head["host_ms"]},
+                           "host_ms_per_step": head["host_ms"],
+                           "rows_first_access_ms": head.get("rows_first_access_ms")},
                 "roofline": roofline(head),
             }
             if canon is not None:

@@ -298,6 +298,7 @@ static void gob_result_map(GobW &w, const Result *R, const std::vector<RowStore>
 
 const void *sybl_result_encode(sybl_result *r, int64_t *n_bytes) {
     Result *R = (Result *)r;
+    if (R) result_ensure_rows(R);
     if (!R || !n_bytes) {
         set_error("sybl_result_encode: NULL argument");
         return nullptr;

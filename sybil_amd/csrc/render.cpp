@@ -225,6 +225,7 @@ extern "C" {
 
 const char *sybl_result_render(sybl_result *r, int format) {
     Result *R = (Result *)r;
+    if (R) result_ensure_rows(R);
     if (!R || (format != 0 && format != 1)) {
         set_error("sybl_result_render: bad argument");
         return nullptr;

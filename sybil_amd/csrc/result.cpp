@@ -44,7 +44,9 @@ static void percentiles_from_values(const int64_t *values, int64_t n_values, int
     memcpy(out100, pct, 100 * sizeof(int64_t));
 }
 
-static void agg_finish(const Query *q, Result *R, const AggInfo &ai, const AggAcc &a, int64_t row_count, sybl_agg_out &o,
+// (Q: what the row builders read of the query -- op, weighted, loghist, want_percentiles, aggs: FinCtx, the result's own copy)
+template <class Q>
+static void agg_finish(const Q *q, Result *R, const AggInfo &ai, const AggAcc &a, int64_t row_count, sybl_agg_out &o,
                        const int64_t *&values_out, int64_t &pct_off, int64_t pct_slot) {
     memset(&o, 0, sizeof(o));
     values_out = nullptr;
@@ -220,7 +222,8 @@ static void build_key(const Query *q, int64_t gcell, uint8_t *key, std::string &
 
 // Writes row `row` whose pool slot (agg_off) was assigned by the caller; thread safe because
 // every pool is pre-sized and rows own disjoint slots.
-static void finish_row(const Query *q, Result *R, const CellAcc &acc, RowStore &row, bool outliers_logged) {
+template <class Q>
+static void finish_row(const Q *q, Result *R, const CellAcc &acc, RowStore &row, bool outliers_logged) {
     row.count = acc.count;
     row.samples = acc.samples;
     size_t na = q->aggs.size();
@@ -537,10 +540,9 @@ int query_snapshot(Query *q) {
 // main stream may already be busy with the scan of another query.
 static const size_t kTopDmaRows = 512;
 
-static int attach_top_values(Query *q, Result *R, size_t top) {
+static int fetch_top_values(Query *q, Result *R, size_t top) {
     const ScanPlan &P = q->plan;
     Ctx *ctx = q->ctx;
-    const size_t na = q->aggs.size();
     if (top == 0) return SYBL_OK;
     if (!ctx->aux_stream) SYBL_HIP(create_side_stream(&ctx->aux_stream, -1));
     if ((int64_t)top > q->top_cap) {
@@ -551,7 +553,7 @@ static int attach_top_values(Query *q, Result *R, size_t top) {
         q->top_cap = (int64_t)top;
     }
     std::vector<int64_t> cells(top);
-    for (size_t i = 0; i < top; i++) cells[i] = R->sorted0(i).cell;
+    for (size_t i = 0; i < top; i++) cells[i] = R->row0_cell(i);
     R->top_vals.resize(top * (size_t)P.hist_stride);
     if (q->rs_active) {
         // the printed rows' bucket arrays live on the ranks that own their cells: every rank gathers its own (zeros for
@@ -589,13 +591,7 @@ static int attach_top_values(Query *q, Result *R, size_t top) {
         SYBL_HIP(hipMemcpyAsync(R->top_vals.data(), q->d_top, R->top_vals.size() * 8, hipMemcpyDeviceToHost, ctx->aux_stream));
         SYBL_HIP(hipStreamSynchronize(ctx->aux_stream));
     }
-    for (size_t i = 0; i < top; i++)
-        for (size_t a = 0; a < na; a++)
-            if (R->agg_pool[(size_t)R->sorted0(i).agg_off + a].present) {
-                const size_t k = (size_t)R->sorted0(i).agg_off + a;
-                R->val_pool[k] = R->top_vals.data() + i * (size_t)P.hist_stride + P.hist_agg_off[a];
-                R->agg_pool[k].values = R->val_pool[k];
-            }
+    R->top_n = top;  // (the rows get their pointers when they are built: result_ensure_rows)
     return SYBL_OK;
 }
 
@@ -661,10 +657,8 @@ int query_finalize(Query *q, Result **out) {
     const int64_t ncell = hashed ? q->hash_live : P.n_cells, gcells = q->group_cells;
     const int64_t *F = hs + kHeaderWords;
     const int64_t *H = nullptr;
-    if (P.hist_stride > 0 && q->snap_has_buckets) {
-        R->keep = q->h_sum_buf;  // the rows' bucket arrays live in the snapshot
-        H = hashed ? F + (int64_t)P.n_sum_fields * ncell : hs + P.hist_off;
-    }
+    if (P.hist_stride > 0 && q->snap_has_buckets) H = hashed ? F + (int64_t)P.n_sum_fields * ncell : hs + P.hist_off;
+    R->keep = q->h_sum_buf;  // the rows are built from (and their bucket arrays live in) the snapshot
     const bool summary = q->hist_summary;
     if (summary) R->keep_pct = q->h_pct_buf;  // the rows' percentiles live in the snapshot
     const size_t na = q->aggs.size();
@@ -673,52 +667,30 @@ int query_finalize(Query *q, Result **out) {
     const int64_t n_out_log = out_logged ? hs[kHdrOutLog] : 0;
     const bool out_usable = out_logged && !q->out_log_partial && n_out_log <= q->out_cap;
 
-    auto load_cell = [&](int64_t cell, CellAcc &acc) -> bool {
-        acc.count = F[cell];
-        acc.samples = P.f_samples >= 0 ? F[(int64_t)P.f_samples * ncell + cell] : acc.count;
-        bool exists = q->weighted ? acc.samples != 0 : acc.count != 0;
-        if (!exists) return false;
-        acc.has_aggs = true;
-        for (size_t a = 0; a < na; a++) {
-            const AggDesc &A = q->aggs[a].d;
-            AggAcc &x = acc.aggs[a];
-            x = AggAcc();
-            x.sum = (uint64_t)F[(int64_t)A.f_sum * ncell + cell];
-            // when the count is not tracked per aggregation it equals the row count of the cell
-            x.tracked_cnt = true;
-            x.cnt = A.f_cnt >= 0 ? F[(int64_t)A.f_cnt * ncell + cell] : acc.count;
-            if (A.f_smp >= 0) x.smp = F[(int64_t)A.f_smp * ncell + cell];
-            x.pop = A.f_pop >= 0 ? F[(int64_t)A.f_pop * ncell + cell] : (P.f_samples >= 0 ? acc.samples : acc.count);
-            if (A.f_sb >= 0) x.sb = F[(int64_t)A.f_sb * ncell + cell];
-            if (A.f_sb2 >= 0) x.sb2 = F[(int64_t)A.f_sb2 * ncell + cell];
-            if (A.f_out >= 0) {
-                x.n_out = F[(int64_t)A.f_out * ncell + cell];
-                x.sum_out = (uint64_t)F[(int64_t)(A.f_out + 1) * ncell + cell];
-                for (int k = 0; k < 4; k++) x.sq[k] = (uint64_t)F[(int64_t)(A.f_out + 2 + k) * ncell + cell];
-            }
-            if (A.m_max >= 0) x.vmax = hm[(int64_t)A.m_max * ncell + cell];
-            if (A.m_nmin >= 0) x.nmin = hm[(int64_t)A.m_nmin * ncell + cell];
-            if (A.hist_full && H) x.values = H + cell * P.hist_stride + P.hist_agg_off[a];
-            if (A.hist_full && summary) {
-                const int64_t pair = cell * (int64_t)na + (int64_t)a;
-                x.pct_gpu = q->h_pct + pair * 100;
-                x.sb = q->h_mom[pair * 2];
-                x.sb2 = q->h_mom[pair * 2 + 1];
-                x.moments = true;
-            }
-        }
-        return true;
-    };
+    FinCtx &C = R->fin;
+    C.op = q->op;
+    C.weighted = q->weighted;
+    C.loghist = q->loghist;
+    C.want_percentiles = q->want_percentiles;
+    C.time_mode = q->time_mode;
+    C.hashed = hashed;
+    C.summary = summary;
+    C.out_usable = out_usable;
+    C.aggs = q->aggs;
+    C.P = P;
+    C.ncell = ncell;
+    C.gcells = gcells;
+    C.n_groups = q->groups.size();
+    C.F = F;
+    C.H = H;
+    C.hm = hm;
+    C.h_pct = summary ? q->h_pct : nullptr;
+    C.q = q;
 
-    CellAcc total;
-    total.has_aggs = !q->time_mode;
     R->total_vals.resize(na);
     for (size_t a = 0; a < na; a++) {
-        total.aggs[a].tracked_cnt = true;
-        if (!q->time_mode && q->aggs[a].d.hist_full) {
-            R->total_vals[a].assign((size_t)q->aggs[a].d.n_values, 0);
-            total.aggs[a].values = R->total_vals[a].data();
-        }
+        if (!q->time_mode && q->aggs[a].d.hist_full) R->total_vals[a].assign((size_t)q->aggs[a].d.n_values, 0);
+        else R->total_vals[a].clear();
     }
     std::vector<int64_t> &all_count = R->all_count, &all_samples = R->all_samples;
     if (q->time_mode && !hashed) {
@@ -795,17 +767,11 @@ int query_finalize(Query *q, Result **out) {
             if (q->weighted ? all_samples[(size_t)g] != 0 : all_count[(size_t)g] != 0) alltime.push_back(g);
     }
     trace.mark("live");
-    std::vector<RowStore> &cell_rows = R->rows[q->time_mode ? 1 : 0];
-    if (!q->time_mode) R->rows[1].clear();
-    cell_rows.resize(live.size());
-    const size_t n_all_rows = live.size() + alltime.size() + 1;
-    R->agg_pool.resize(n_all_rows * na);
-    R->val_pool.resize(n_all_rows * na);
-    R->pctoff_pool.resize(n_all_rows * na);
-    R->pct_pool.resize(q->want_percentiles ? n_all_rows * na * 100 : 0);
 
     // BinaryByKey / GroupByKey per group cell: the query's cache (built by its first finalize), or per row
     const bool keys_cached = !hashed && gcells <= ((int64_t)1 << 18);
+    C.keys_cached = keys_cached;
+    const size_t n_all_rows = live.size() + alltime.size() + 1;
     std::shared_ptr<KeyStore> ks;
     if (keys_cached) {
         if (!q->key_cache) {
@@ -827,6 +793,252 @@ int query_finalize(Query *q, Result **out) {
     }
     R->keys = ks;
     trace.mark("alloc");
+
+    // Lazy rows: a direct-mapped result whose keys are cached needs nothing of the query to build its rows later.  What
+    // the query's next snapshot would overwrite is copied (bucket moments, extrema); the snapshots themselves are
+    // reference counted.  Small results are built right away (the threshold only keeps trivial results simple to debug),
+    // count-distinct results as well (their sketches are fetched here).
+    // (SYBL_LAZY_ROWS=1: whatever the size -- the test suite runs once that way)
+    const bool lazy = keys_cached && !q->n_distinct && (live.size() >= 2048 || getenv("SYBL_LAZY_ROWS")) && !getenv("SYBL_EAGER_ROWS");
+    if (summary) {
+        C.mom.assign(q->h_mom, q->h_mom + (size_t)P.n_cells * na * 2);
+        for (size_t a = 0; a < na; a++)
+            if (!R->total_vals[a].empty())
+                memcpy(R->total_vals[a].data(), q->h_total + P.hist_agg_off[a], R->total_vals[a].size() * sizeof(int64_t));
+    }
+    if (lazy && P.n_max_fields > 0) {
+        C.hm_copy.assign(hm, hm + (size_t)q->n_max_words);
+        C.hm = C.hm_copy.data();
+    }
+    R->rows_pending = true;
+    R->out_recs.clear();
+    R->top_n = 0;
+
+    // ---- outlier values (plan.h: outlier log) -> (pool slot of the row's aggregation, value), sorted: slots ascending,
+    // values ascending inside a slot (cell rows own the first live.size() * na pool slots); attached when the rows exist
+    R->outlier_vals.clear();
+    if (out_usable && n_out_log > 0) {
+        const int64_t n_log = n_out_log;
+        std::vector<int64_t> log((size_t)n_log * kOutLogWords);
+        SYBL_HIP(hipMemcpy(log.data(), q->d_out_log, log.size() * 8, hipMemcpyDeviceToHost));
+        std::vector<std::pair<int64_t, int64_t>> &recs = R->out_recs;
+        recs.reserve((size_t)n_log);
+        for (int64_t i = 0; i < n_log; i++) {
+            int64_t cell = log[(size_t)i * kOutLogWords];
+            const int64_t a = log[(size_t)i * kOutLogWords + 1];
+            if (hashed) {  // the log names the group by its composite key
+                auto it = std::lower_bound(q->h_dense_keys.begin(), q->h_dense_keys.begin() + ncell, (uint64_t)cell);
+                if (it == q->h_dense_keys.begin() + ncell || *it != (uint64_t)cell) continue;
+                cell = (int64_t)(it - q->h_dense_keys.begin());
+            }
+            auto lv = std::lower_bound(live.begin(), live.end(), cell);
+            if (lv == live.end() || *lv != cell || a < 0 || a >= (int64_t)na) continue;
+            recs.emplace_back((int64_t)((size_t)(lv - live.begin()) * na + (size_t)a), log[(size_t)i * kOutLogWords + 2]);
+        }
+        std::sort(recs.begin(), recs.end());
+    }
+
+    // SortResults, aggregate.go:497-525 (stable over the canonical key order), straight from the cell fields: row i of
+    // Results is live cell i (a time series: all-time group i, Count only -- no aggregation is present there)
+    if (!q->order_by.empty()) {
+        int by = -1;
+        if (q->order_by != "$COUNT") {
+            for (size_t a = 0; a < na; a++)
+                if (q->aggs[a].name == q->order_by) by = (int)a;
+            if (by < 0) {
+                delete R;
+                return fail(SYBL_E_INVAL, "order_by '%s' is neither $COUNT nor an aggregated column", q->order_by.c_str());
+            }
+        }
+        const size_t n = q->time_mode ? alltime.size() : live.size();
+        auto row_count = [&](size_t i) -> int64_t { return q->time_mode ? all_count[hashed ? i : (size_t)alltime[i]] : F[live[i]]; };
+        auto row_mean = [&](size_t i) -> double {  // agg_finish's avg of aggregation `by`; -inf when the row has no such hist
+            if (q->time_mode) return -INFINITY;
+            const AggDesc &A = q->aggs[(size_t)by].d;
+            const int64_t cell = live[i], count = F[cell];
+            const int64_t samples = P.f_samples >= 0 ? F[(int64_t)P.f_samples * ncell + cell] : count;
+            const int64_t pop = A.f_pop >= 0 ? F[(int64_t)A.f_pop * ncell + cell] : (P.f_samples >= 0 ? samples : count);
+            if (pop <= 0) return -INFINITY;
+            const int64_t cnt = A.f_cnt >= 0 ? F[(int64_t)A.f_cnt * ncell + cell] : count;
+            const long double avg_l = cnt != 0 ? (long double)F[(int64_t)A.f_sum * ncell + cell] / (long double)cnt : 0.0L;
+            return (double)avg_l;
+        };
+        std::vector<uint32_t> &order = R->order0;
+        order.resize(n);
+        if (n < 8192) {
+            std::vector<int64_t> kc(by < 0 ? n : 0);
+            std::vector<double> km(by < 0 ? 0 : n);
+            for (size_t i = 0; i < n; i++) {
+                order[i] = (uint32_t)i;
+                if (by < 0) kc[i] = row_count(i);
+                else km[i] = row_mean(i);
+            }
+            auto less = [&](uint32_t ix, uint32_t iy) { return by < 0 ? kc[ix] > kc[iy] : km[ix] > km[iy]; };
+            std::stable_sort(order.begin(), order.end(), less);
+        } else {
+            // many groups: stable LSD radix sort (16-bit digits) of (key, index) pairs, the key's ascending unsigned
+            // order being the descending order of Count / of the mean.  Digits every key agrees on are skipped
+            // (counts of a uniform 65536-group table differ in their low 16 bits only: one pass).
+            struct KeyIx {
+                uint64_t key;
+                uint64_t ix;
+            };
+            std::vector<KeyIx> cur(n), nxt(n);
+            uint64_t differ = 0;
+            for (size_t i = 0; i < n; i++) {
+                uint64_t u;
+                if (by < 0) {
+                    u = (uint64_t)row_count(i) ^ 0x8000000000000000ull;
+                } else {
+                    double m = row_mean(i);
+                    if (m == 0.0) m = 0.0;  // -0.0 and +0.0 compare equal
+                    uint64_t b;
+                    memcpy(&b, &m, 8);
+                    u = (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+                }
+                cur[i].key = ~u;
+                cur[i].ix = i;
+                differ |= cur[i].key ^ cur[0].key;
+            }
+            std::vector<uint32_t> cnt(65536);
+            for (int shift = 0; shift < 64; shift += 16) {
+                if (((differ >> shift) & 0xFFFFu) == 0) continue;
+                std::fill(cnt.begin(), cnt.end(), 0u);
+                for (size_t i = 0; i < n; i++) cnt[(cur[i].key >> shift) & 0xFFFFu]++;
+                uint32_t run = 0;
+                for (size_t d = 0; d < 65536; d++) {
+                    uint32_t c2 = cnt[d];
+                    cnt[d] = run;
+                    run += c2;
+                }
+                for (size_t i = 0; i < n; i++) nxt[cnt[(cur[i].key >> shift) & 0xFFFFu]++] = cur[i];
+                cur.swap(nxt);
+            }
+            for (size_t i = 0; i < n; i++) order[i] = (uint32_t)cur[i].ix;
+        }
+        if (q->order_asc) std::reverse(order.begin(), order.end());
+    } else {
+        R->order0.clear();
+    }
+    trace.mark("sort");
+    // the bucket arrays of the rows a printer shows (GPU summary path): fetched now, while the table is the scan's
+    R->top_vals.clear();
+    if (summary && !q->snap_has_buckets) {
+        int rc = fetch_top_values(q, R, std::min<size_t>((size_t)q->limit, q->time_mode ? alltime.size() : live.size()));
+        if (rc) {
+            delete R;
+            return rc;
+        }
+        trace.mark("top-values");
+    }
+    if (!lazy) {
+        result_ensure_rows(R);
+        trace.mark("rows");
+        // ---- count distinct (query_spec.go:87,180-188): every row's sketch and its Cardinality()
+        R->has_distinct = q->n_distinct > 0;
+        if (R->has_distinct) {
+            R->hll_cells = P.n_cells;
+            R->hll.resize((size_t)(P.n_cells + 2) * kHllRegs);
+            // the pass that fills the sketches (and their all-reduce) was queued on the context's stream: copy behind it
+            SYBL_HIP(hipMemcpyAsync(R->hll.data(), q->d_hll, (size_t)q->hll_bytes, hipMemcpyDeviceToHost, q->ctx->stream));
+            SYBL_HIP(hipStreamSynchronize(q->ctx->stream));
+            uint8_t *total_regs = R->hll.data() + (size_t)P.n_cells * kHllRegs;
+            memset(total_regs, 0, 2 * (size_t)kHllRegs);
+            if (!q->time_mode) {
+                // Cumulative combines every Result (aggregate.go:431-434): the register-wise maximum.  (In a time series it
+                // combines the all-time Results, whose sketches stay empty: aggregate.go:156-169 only counts there.)
+                for (const RowStore &row : R->rows[0]) {
+                    const uint8_t *regs = R->row_registers(0, row);
+                    for (int k = 0; k < kHllRegs; k++) total_regs[k] = std::max(total_regs[k], regs[k]);
+                }
+            }
+            for (int w = 0; w < 3; w++) {
+                R->distinct[w].resize(R->rows[w].size());
+                parallel_ranges(R->rows[w].size(), 256, [&, w](size_t i0, size_t i1) {
+                    for (size_t i = i0; i < i1; i++) R->distinct[w][i] = (int64_t)hll_cardinality(R->row_registers(w, R->rows[w][i]));
+                });
+            }
+        }
+    } else {
+        R->has_distinct = false;
+    }
+    C.q = nullptr;  // (nothing built later may look at the query)
+    *out = R;
+    return SYBL_OK;
+}
+
+// The rows of a result, from its own context (FinCtx) and snapshots: one row per live cell (worker threads when there are
+// enough of them), the all-time Results of a time series, Cumulative; then the outliers' values, the printed rows' bucket
+// arrays and the sybl_group_row views.
+void result_ensure_rows(Result *R) {
+    std::lock_guard<std::mutex> lk(R->rows_m);
+    if (!R->rows_pending) return;
+    R->rows_pending = false;
+    const FinCtx &C = R->fin;
+    const FinCtx *q = &C;
+    const ScanPlan &P = C.P;
+    const bool hashed = C.hashed, summary = C.summary, keys_cached = C.keys_cached, out_usable = C.out_usable;
+    const int64_t ncell = C.ncell, gcells = C.gcells;
+    const int64_t *F = C.F, *H = C.H, *hm = C.hm;
+    const size_t na = C.aggs.size();
+    std::vector<int64_t> &live = R->live, &alltime = R->alltime, &all_count = R->all_count, &all_samples = R->all_samples;
+    KeyStore *ks = R->keys.get();
+    auto load_cell = [&](int64_t cell, CellAcc &acc) -> bool {
+        acc.count = F[cell];
+        acc.samples = P.f_samples >= 0 ? F[(int64_t)P.f_samples * ncell + cell] : acc.count;
+        bool exists = C.weighted ? acc.samples != 0 : acc.count != 0;
+        if (!exists) return false;
+        acc.has_aggs = true;
+        for (size_t a = 0; a < na; a++) {
+            const AggDesc &A = C.aggs[a].d;
+            AggAcc &x = acc.aggs[a];
+            x = AggAcc();
+            x.sum = (uint64_t)F[(int64_t)A.f_sum * ncell + cell];
+            // when the count is not tracked per aggregation it equals the row count of the cell
+            x.tracked_cnt = true;
+            x.cnt = A.f_cnt >= 0 ? F[(int64_t)A.f_cnt * ncell + cell] : acc.count;
+            if (A.f_smp >= 0) x.smp = F[(int64_t)A.f_smp * ncell + cell];
+            x.pop = A.f_pop >= 0 ? F[(int64_t)A.f_pop * ncell + cell] : (P.f_samples >= 0 ? acc.samples : acc.count);
+            if (A.f_sb >= 0) x.sb = F[(int64_t)A.f_sb * ncell + cell];
+            if (A.f_sb2 >= 0) x.sb2 = F[(int64_t)A.f_sb2 * ncell + cell];
+            if (A.f_out >= 0) {
+                x.n_out = F[(int64_t)A.f_out * ncell + cell];
+                x.sum_out = (uint64_t)F[(int64_t)(A.f_out + 1) * ncell + cell];
+                for (int k = 0; k < 4; k++) x.sq[k] = (uint64_t)F[(int64_t)(A.f_out + 2 + k) * ncell + cell];
+            }
+            if (A.m_max >= 0) x.vmax = hm[(int64_t)A.m_max * ncell + cell];
+            if (A.m_nmin >= 0) x.nmin = hm[(int64_t)A.m_nmin * ncell + cell];
+            if (A.hist_full && H) x.values = H + cell * P.hist_stride + P.hist_agg_off[a];
+            if (A.hist_full && summary) {
+                const int64_t pair = cell * (int64_t)na + (int64_t)a;
+                x.pct_gpu = C.h_pct + pair * 100;
+                x.sb = C.mom[(size_t)pair * 2];
+                x.sb2 = C.mom[(size_t)pair * 2 + 1];
+                x.moments = true;
+            }
+        }
+        return true;
+    };
+
+    CellAcc total;
+    total.has_aggs = !C.time_mode;
+    std::vector<std::vector<int64_t>> summary_totals;
+    if (summary) summary_totals = R->total_vals;  // (k_hist_total's Cumulative buckets: put back below)
+    for (size_t a = 0; a < na; a++) {
+        total.aggs[a].tracked_cnt = true;
+        if (!R->total_vals[a].empty()) {
+            std::fill(R->total_vals[a].begin(), R->total_vals[a].end(), 0);
+            total.aggs[a].values = R->total_vals[a].data();
+        }
+    }
+    std::vector<RowStore> &cell_rows = R->rows[C.time_mode ? 1 : 0];
+    if (!C.time_mode) R->rows[1].clear();
+    cell_rows.resize(live.size());
+    const size_t n_all_rows = live.size() + alltime.size() + 1;
+    R->agg_pool.resize(n_all_rows * na);
+    R->val_pool.resize(n_all_rows * na);
+    R->pctoff_pool.resize(n_all_rows * na);
+    R->pct_pool.resize(C.want_percentiles ? n_all_rows * na * 100 : 0);
     // pass 2: one row per live cell.  Rows own disjoint pool slots, so ranges of cells are
     // finished by worker threads when there are enough of them to pay for the threads.
     auto work = [&](size_t i0, size_t i1, CellAcc *tot, std::vector<std::vector<int64_t>> *tot_vals) {
@@ -835,8 +1047,8 @@ int query_finalize(Query *q, Result **out) {
             const int64_t cell = live[i];
             load_cell(cell, acc);
             // (hash group-by: the composite key is [time bucket || group key], the dense arrays are in key order)
-            const int64_t ckey = hashed ? (int64_t)q->h_dense_keys[(size_t)cell] : cell;
-            const int64_t tbi = hashed && !q->time_mode ? 0 : ckey / gcells, gcell = ckey - tbi * gcells;
+            const int64_t ckey = hashed ? (int64_t)C.q->h_dense_keys[(size_t)cell] : cell;
+            const int64_t tbi = hashed && !C.time_mode ? 0 : ckey / gcells, gcell = ckey - tbi * gcells;
             RowStore &row = cell_rows[i];
             row.agg_off = (int64_t)(i * na);
             row.cell = cell;
@@ -844,13 +1056,13 @@ int query_finalize(Query *q, Result **out) {
                 row.key = ks->key((size_t)gcell);
                 row.gbkp = &ks->gbk[(size_t)gcell];
             } else {
-                build_key(q, gcell, ks->key(i), ks->gbk[i]);
+                build_key(C.q, gcell, ks->key(i), ks->gbk[i]);
                 row.key = ks->key(i);
                 row.gbkp = &ks->gbk[i];
             }
-            row.time_bucket = q->time_mode ? (P.tb_min + tbi) * P.time_bucket : 0;  // (rows are recycled: assign every field)
+            row.time_bucket = C.time_mode ? (P.tb_min + tbi) * P.time_bucket : 0;  // (rows are recycled: assign every field)
             finish_row(q, R, acc, row, out_usable);
-            if (!q->time_mode) {
+            if (!C.time_mode) {
                 for (size_t a = 0; a < na; a++) {
                     AggAcc &d = tot->aggs[a];
                     const AggAcc &s = acc.aggs[a];
@@ -867,7 +1079,7 @@ int query_finalize(Query *q, Result **out) {
                     d.nmin = std::max(d.nmin, s.nmin);
                     if (s.values) {
                         int64_t *tv = (*tot_vals)[a].data();
-                        for (int64_t k = 0; k < q->aggs[a].d.n_values; k++) tv[k] += s.values[k];
+                        for (int64_t k = 0; k < C.aggs[a].d.n_values; k++) tv[k] += s.values[k];
                     }
                 }
             }
@@ -878,7 +1090,7 @@ int query_finalize(Query *q, Result **out) {
     size_t n_threads = 1;
     {
         // cost estimate: buckets touched per row dominate in full-histogram mode
-        size_t per_row = 64 + (size_t)(q->want_percentiles ? P.hist_stride * 3 : 0);
+        size_t per_row = 64 + (size_t)(C.want_percentiles ? P.hist_stride * 3 : 0);
         size_t cost = live.size() * per_row;
         n_threads = std::max<size_t>(1, std::min(WorkerPool::cap(), cost / (1u << 20)));
     }
@@ -924,13 +1136,11 @@ int query_finalize(Query *q, Result **out) {
             }
         }
     }
-    if (summary)
-        for (size_t a = 0; a < na; a++)
-            if (!R->total_vals[a].empty())
-                memcpy(R->total_vals[a].data(), q->h_total + P.hist_agg_off[a], R->total_vals[a].size() * sizeof(int64_t));
-    trace.mark("rows");
+    if (summary) R->total_vals = summary_totals;
+    for (size_t a = 0; a < na; a++)
+        if (!R->total_vals[a].empty()) total.aggs[a].values = R->total_vals[a].data();
     size_t next_slot = live.size();
-    if (q->time_mode) {
+    if (C.time_mode) {
         // all-time Results carry Count/Samples only (aggregate.go:156-169)
         R->rows[0].resize(alltime.size());
         for (size_t i = 0; i < alltime.size(); i++) {
@@ -940,7 +1150,7 @@ int query_finalize(Query *q, Result **out) {
             row.time_bucket = 0;
             row.cell = -1;  // (rows are recycled)
             const size_t e = keys_cached ? (size_t)g : next_slot + i;
-            if (!keys_cached) build_key(q, g, ks->key(e), ks->gbk[e]);
+            if (!keys_cached) build_key(C.q, g, ks->key(e), ks->gbk[e]);
             row.key = ks->key(e);
             row.gbkp = &ks->gbk[e];
             CellAcc a2;
@@ -960,163 +1170,36 @@ int query_finalize(Query *q, Result **out) {
         if (!keys_cached) {
             memset(ks->key(e), 0, KeyStore::kKeyBytes);
             ks->gbk[e] = "TOTAL";
-            for (size_t g = 1; g < q->groups.size(); g++) ks->gbk[e] += "\t";
+            for (size_t g = 1; g < C.n_groups; g++) ks->gbk[e] += "\t";
         }
         row.key = ks->key(e);
         row.gbkp = &ks->gbk[e];
         row.cell = -1;
         finish_row(q, R, total, row, out_usable);
     }
-
-    // ---- count distinct (query_spec.go:87,180-188): every row's sketch and its Cardinality()
-    R->has_distinct = q->n_distinct > 0;
-    if (R->has_distinct) {
-        R->hll_cells = P.n_cells;
-        R->hll.resize((size_t)(P.n_cells + 2) * kHllRegs);
-        // the pass that fills the sketches (and their all-reduce) was queued on the context's stream: copy behind it
-        SYBL_HIP(hipMemcpyAsync(R->hll.data(), q->d_hll, (size_t)q->hll_bytes, hipMemcpyDeviceToHost, q->ctx->stream));
-        SYBL_HIP(hipStreamSynchronize(q->ctx->stream));
-        uint8_t *total_regs = R->hll.data() + (size_t)P.n_cells * kHllRegs;
-        memset(total_regs, 0, 2 * (size_t)kHllRegs);
-        if (!q->time_mode) {
-            // Cumulative combines every Result (aggregate.go:431-434): the register-wise maximum.  (In a time series it
-            // combines the all-time Results, whose sketches stay empty: aggregate.go:156-169 only counts there.)
-            for (const RowStore &row : R->rows[0]) {
-                const uint8_t *regs = R->row_registers(0, row);
-                for (int k = 0; k < kHllRegs; k++) total_regs[k] = std::max(total_regs[k], regs[k]);
-            }
-        }
-        for (int w = 0; w < 3; w++) {
-            R->distinct[w].resize(R->rows[w].size());
-            parallel_ranges(R->rows[w].size(), 256, [&, w](size_t i0, size_t i1) {
-                for (size_t i = i0; i < i1; i++) R->distinct[w][i] = (int64_t)hll_cardinality(R->row_registers(w, R->rows[w][i]));
-            });
-        }
-    }
-
-    // ---- outlier values (plan.h: outlier log) -> the rows that own them
+    // the outliers' values -> the rows that own them
     {
-        const int64_t n_log = n_out_log;
-        const bool usable = out_usable;
-        R->outlier_vals.clear();
-        if (usable && n_log > 0) {
-            std::vector<int64_t> log((size_t)n_log * kOutLogWords);
-            SYBL_HIP(hipMemcpy(log.data(), q->d_out_log, log.size() * 8, hipMemcpyDeviceToHost));
-            // (pool slot of the row's aggregation, value), sorted: slots ascending, values ascending inside a slot
-            std::vector<std::pair<int64_t, int64_t>> recs;
-            recs.reserve((size_t)n_log);
-            for (int64_t i = 0; i < n_log; i++) {
-                int64_t cell = log[(size_t)i * kOutLogWords];
-                const int64_t a = log[(size_t)i * kOutLogWords + 1];
-                if (hashed) {  // the log names the group by its composite key
-                    auto it = std::lower_bound(q->h_dense_keys.begin(), q->h_dense_keys.begin() + ncell, (uint64_t)cell);
-                    if (it == q->h_dense_keys.begin() + ncell || *it != (uint64_t)cell) continue;
-                    cell = (int64_t)(it - q->h_dense_keys.begin());
-                }
-                auto lv = std::lower_bound(live.begin(), live.end(), cell);
-                if (lv == live.end() || *lv != cell || a < 0 || a >= (int64_t)na) continue;
-                recs.emplace_back((int64_t)((size_t)(lv - live.begin()) * na + (size_t)a), log[(size_t)i * kOutLogWords + 2]);
-            }
-            std::sort(recs.begin(), recs.end());
-            R->outlier_vals.resize(recs.size());
-            for (size_t i = 0; i < recs.size(); i++) R->outlier_vals[i] = recs[i].second;
-            for (size_t i = 0; i < recs.size();) {
-                size_t j = i;
-                while (j < recs.size() && recs[j].first == recs[i].first) j++;
-                sybl_agg_out &o = R->agg_pool[(size_t)recs[i].first];  // (cell rows own the first live.size() * na pool slots)
-                o.outlier_values = R->outlier_vals.data() + i;
-                o.n_outlier_values = (int64_t)(j - i);
-                i = j;
-            }
+        const std::vector<std::pair<int64_t, int64_t>> &recs = R->out_recs;
+        R->outlier_vals.resize(recs.size());
+        for (size_t i = 0; i < recs.size(); i++) R->outlier_vals[i] = recs[i].second;
+        for (size_t i = 0; i < recs.size();) {
+            size_t j = i;
+            while (j < recs.size() && recs[j].first == recs[i].first) j++;
+            sybl_agg_out &o = R->agg_pool[(size_t)recs[i].first];  // (cell rows own the first live.size() * na pool slots)
+            o.outlier_values = R->outlier_vals.data() + i;
+            o.n_outlier_values = (int64_t)(j - i);
+            i = j;
         }
     }
-    trace.mark("alltime+total");
-    // SortResults, aggregate.go:497-525 (stable over the canonical key order)
-    if (!q->order_by.empty()) {
-        int by = -1;
-        if (q->order_by != "$COUNT") {
-            for (size_t a = 0; a < na; a++)
-                if (q->aggs[a].name == q->order_by) by = (int)a;
-            if (by < 0) {
-                delete R;
-                return fail(SYBL_E_INVAL, "order_by '%s' is neither $COUNT nor an aggregated column", q->order_by.c_str());
+    // the printed rows' bucket arrays (fetch_top_values)
+    for (size_t i = 0; i < R->top_n; i++)
+        for (size_t a = 0; a < na; a++)
+            if (R->agg_pool[(size_t)R->sorted0(i).agg_off + a].present) {
+                const size_t k = (size_t)R->sorted0(i).agg_off + a;
+                R->val_pool[k] = R->top_vals.data() + i * (size_t)P.hist_stride + P.hist_agg_off[a];
+                R->agg_pool[k].values = R->val_pool[k];
             }
-        }
-        std::vector<RowStore> &rows = R->rows[0];
-        const size_t n = rows.size();
-        std::vector<uint32_t> &order = R->order0;
-        order.resize(n);
-        if (n < 8192) {
-            for (size_t i = 0; i < n; i++) order[i] = (uint32_t)i;
-            auto less = [&](uint32_t ix, uint32_t iy) {
-                const RowStore &x = rows[ix], &y = rows[iy];
-                if (by < 0) return x.count > y.count;
-                const sybl_agg_out &ax = R->agg_pool[(size_t)x.agg_off + by], &ay = R->agg_pool[(size_t)y.agg_off + by];
-                double mx = ax.present ? ax.avg : -INFINITY;
-                double my = ay.present ? ay.avg : -INFINITY;
-                return mx > my;
-            };
-            std::stable_sort(order.begin(), order.end(), less);
-        } else {
-            // many groups: stable LSD radix sort (16-bit digits) of (key, index) pairs, the key's ascending unsigned
-            // order being the descending order of Count / of the mean.  Digits every key agrees on are skipped
-            // (counts of a uniform 65536-group table differ in their low 16 bits only: one pass).
-            struct KeyIx {
-                uint64_t key;
-                uint64_t ix;
-            };
-            std::vector<KeyIx> cur(n), nxt(n);
-            uint64_t differ = 0;
-            for (size_t i = 0; i < n; i++) {
-                uint64_t u;
-                if (by < 0) {
-                    u = (uint64_t)rows[i].count ^ 0x8000000000000000ull;
-                } else {
-                    const sybl_agg_out &ax = R->agg_pool[(size_t)rows[i].agg_off + by];
-                    double m = ax.present ? ax.avg : -INFINITY;
-                    if (m == 0.0) m = 0.0;  // -0.0 and +0.0 compare equal
-                    uint64_t b;
-                    memcpy(&b, &m, 8);
-                    u = (b >> 63) ? ~b : (b | 0x8000000000000000ull);
-                }
-                cur[i].key = ~u;
-                cur[i].ix = i;
-                differ |= cur[i].key ^ cur[0].key;
-            }
-            std::vector<uint32_t> cnt(65536);
-            for (int shift = 0; shift < 64; shift += 16) {
-                if (((differ >> shift) & 0xFFFFu) == 0) continue;
-                std::fill(cnt.begin(), cnt.end(), 0u);
-                for (size_t i = 0; i < n; i++) cnt[(cur[i].key >> shift) & 0xFFFFu]++;
-                uint32_t run = 0;
-                for (size_t d = 0; d < 65536; d++) {
-                    uint32_t c2 = cnt[d];
-                    cnt[d] = run;
-                    run += c2;
-                }
-                for (size_t i = 0; i < n; i++) nxt[cnt[(cur[i].key >> shift) & 0xFFFFu]++] = cur[i];
-                cur.swap(nxt);
-            }
-            for (size_t i = 0; i < n; i++) order[i] = (uint32_t)cur[i].ix;
-        }
-        if (q->order_asc) std::reverse(order.begin(), order.end());
-    } else {
-        R->order0.clear();
-    }
-    trace.mark("sort");
-    R->top_vals.clear();
-    if (summary && !q->snap_has_buckets) {
-        int rc = attach_top_values(q, R, std::min<size_t>((size_t)q->limit, R->rows[0].size()));
-        if (rc) {
-            delete R;
-            return rc;
-        }
-        trace.mark("top-values");
-    }
     make_views(R);
-    trace.mark("views");
-    *out = R;
-    return SYBL_OK;
 }
 
 }  // namespace sybl
@@ -1126,6 +1209,7 @@ using namespace sybl;
 extern "C" {
 
 int sybl_result_rows(const sybl_result *r, int which, const sybl_group_row **rows, int64_t *n) {
+    if (r) result_ensure_rows((Result *)r);
     const Result *R = (const Result *)r;
     if (!R || which < 0 || which > 2) return fail(SYBL_E_INVAL, "sybl_result_rows: bad argument");
     if (rows) *rows = R->view[which].data();

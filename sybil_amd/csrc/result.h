@@ -90,6 +90,26 @@ struct ResultPool {
     ResultStore spare;
 };
 
+// What building the rows of a result needs, owned by the result: the rows of a big direct-mapped result (a time series of
+// 360 000 buckets x groups, 65 536 histogram groups) are built when a caller first asks for them -- sybl_result_rows, a
+// renderer, the encoder -- not by sybl_query_finalize, which only finds the live cells, sorts them and keeps the
+// snapshot: the reference's Results ARE its accumulators (aggregate.go:186-203), there is nothing to build before the
+// printers walk them.  Everything here is a copy or a reference-counted snapshot, so the query may be scanned again
+// (or freed) in between.
+struct FinCtx {
+    int op = 0;
+    bool weighted = false, loghist = false, want_percentiles = false, time_mode = false, hashed = false, summary = false;
+    bool out_usable = false, keys_cached = false;
+    std::vector<AggInfo> aggs;
+    ScanPlan P;
+    int64_t ncell = 0, gcells = 0;
+    size_t n_groups = 0;
+    const int64_t *F = nullptr, *hm = nullptr, *H = nullptr;  // cell fields / extrema / bucket arrays of the snapshot
+    const int64_t *h_pct = nullptr;                           // GPU-computed percentiles (Result::keep_pct)
+    std::vector<int64_t> mom, hm_copy;                        // bucket moments / extrema: copied (the query's buffers are reused)
+    const Query *q = nullptr;                                 // eager builds only (per-row keys: hash group-by)
+};
+
 struct Result : ResultStore {
     const RowStore &sorted0(size_t i) const { return rows[0][order0.empty() ? i : order0[i]]; }
     RowStore &sorted0(size_t i) { return rows[0][order0.empty() ? i : order0[i]]; }
@@ -103,6 +123,15 @@ struct Result : ResultStore {
         }
     }
     int64_t matched = 0;
+    FinCtx fin;
+    bool rows_pending = false;                    // the rows have not been built yet (result_ensure_rows)
+    std::mutex rows_m;
+    size_t top_n = 0;                             // rows of the sort order whose bucket arrays sit in top_vals
+    std::vector<std::pair<int64_t, int64_t>> out_recs;  // outlier values by (pool slot of the row's aggregation, value), sorted
+    int64_t row0_cell(size_t i) const {           // the cell behind row i of the sort order (built or not)
+        const size_t ix = order0.empty() ? i : order0[i];
+        return fin.time_mode ? -1 : live[ix];
+    }
     std::shared_ptr<KeyStore> keys;               // what the rows' key / gbkp point into (the query's cache or own_keys)
     std::shared_ptr<HostBuf> keep_pct;            // the snapshot of the GPU-computed percentiles the rows point into
     std::shared_ptr<HostBuf> keep;                // the pinned snapshot of the partial table the bucket
@@ -146,5 +175,7 @@ struct Result : ResultStore {
     bool order_asc = false;
     std::string encoded;
 };
+
+void result_ensure_rows(Result *R);  // (result.cpp) builds the rows of a lazily finalized result; cheap when they exist
 
 }  // namespace sybl

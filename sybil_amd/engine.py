@@ -429,6 +429,13 @@ class Result:
     def matched(self):
         return N.lib().sybl_result_matched(self._h)
 
+    def materialize(self, which=0):
+        """sybl_result_rows without converting anything: the number of rows (a big result builds its rows on this first call)."""
+        rows = C.POINTER(N.GroupRow)()
+        n = C.c_int64()
+        N.check(N.lib().sybl_result_rows(self._h, which, C.byref(rows), C.byref(n)))
+        return n.value
+
     def rows(self, which=0, want_values=True):
         rows = C.POINTER(N.GroupRow)()
         n = C.c_int64()
