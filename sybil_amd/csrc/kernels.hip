@@ -566,23 +566,28 @@ __device__ __noinline__ void part_log_wrap(const PartHistPlan &P, uint32_t pair,
 }
 
 // (rare path) a value beyond the last bucket: remembered exactly -- n, sum(o), sum(o^2) in four 32-bit limbs, as the GEN row
-// body does (scan_fast.h: fast_accumulate) -- in the cell's outlier fields (zeroed by the scan: these are atomics, several
-// workgroups may share a cell's pairs), and the value itself in the log when one is kept
-__device__ __noinline__ void part_outlier(const PartHistPlan &P, uint32_t pair, uint32_t n32) {
+// body does (scan_fast.h: fast_accumulate) -- per pair in LDS (round 3: six device-scope atomics per outlier straight into
+// the cell's fields; 1 % outliers of 1e9 values were 6e7 of them) and added to the cell's outlier fields once per item; the
+// value itself goes to the log when one is kept
+struct PartOutLds {
+    uint32_t *n;               // [kPartCells]
+    unsigned long long *sum;   // [kPartCells]
+    unsigned long long *sq;    // [kPartCells][4]
+};
+__device__ __noinline__ void part_outlier(const PartHistPlan &P, const PartOutLds O, uint32_t local, uint32_t pair, uint32_t n32) {
     const uint32_t na = (uint32_t)P.n_aggs, cell = pair / na, a = pair % na;
     const int64_t x = (int64_t)((uint64_t)P.hmin[a] + (uint64_t)n32);
     if (P.f_out[a] < 0) {  // declared bounds violated: reported by finalize
         gadd(P.sum_out + kHdrOverflow, 1);
         return;
     }
-    int64_t *F = P.sum_out + kHeaderWords + (int64_t)P.f_out[a] * P.n_cells + cell;
     const unsigned __int128 sq = (unsigned __int128)((__int128)x * (__int128)x);
-    gadd(F, 1);
-    gadd(F + P.n_cells, x);
-    gadd(F + 2 * (int64_t)P.n_cells, (int64_t)(uint64_t)(sq & 0xFFFFFFFFu));
-    gadd(F + 3 * (int64_t)P.n_cells, (int64_t)(uint64_t)((sq >> 32) & 0xFFFFFFFFu));
-    gadd(F + 4 * (int64_t)P.n_cells, (int64_t)(uint64_t)((sq >> 64) & 0xFFFFFFFFu));
-    gadd(F + 5 * (int64_t)P.n_cells, (int64_t)(uint64_t)(sq >> 96));
+    __hip_atomic_fetch_add(O.n + local, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_add(O.sum + local, (unsigned long long)x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_add(O.sq + local * 4u, (unsigned long long)(uint64_t)(sq & 0xFFFFFFFFu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_add(O.sq + local * 4u + 1, (unsigned long long)(uint64_t)((sq >> 32) & 0xFFFFFFFFu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_add(O.sq + local * 4u + 2, (unsigned long long)(uint64_t)((sq >> 64) & 0xFFFFFFFFu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_add(O.sq + local * 4u + 3, (unsigned long long)(uint64_t)(sq >> 96), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (P.out_log) log_outlier(P.out_log, P.out_cap, (int64_t)cell, P.agg0 + (int)a, x);
 }
 
@@ -611,6 +616,10 @@ __global__ __launch_bounds__(kWgThreads) void k_part_hist(const PartHistPlan P) 
     uint2 *regions = (uint2 *)(vmax + kPartCells);                                          // [n_reg_max] {first chunk, pieces}
     const uint32_t lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     uint32_t *ctl = (uint32_t *)(regions + n_reg_max);  // [1] region cursor, [2], [3] the item claimed / the next one
+    PartOutLds O;                                       // (OUT) the pairs' outlier sums, behind the cursors
+    O.sum = (unsigned long long *)(ctl + 4);
+    O.sq = O.sum + kPartCells;
+    O.n = (uint32_t *)(O.sq + 4 * kPartCells);
     // (diagnostic, SYBL_PARTHIST_TRACE: the 100 MHz wall clock at the phase boundaries of every item; word 0 claimed, 1 tables
     // zeroed and regions read, 2 records walked, 4 table written, 5 the compute unit, 16.. when each wave finished its walk)
     uint32_t item = 0;
@@ -645,6 +654,7 @@ __global__ __launch_bounds__(kWgThreads) void k_part_hist(const PartHistPlan P) 
         }
         if (tid < kPartSumRep * kPartCells) sum[tid] = 0;
         if (tid < kPartCells) vmax[tid] = INT64_MIN;
+        if (OUT && tid < 6 * kPartCells) O.sum[tid] = 0;  // (sum | sq | n: 5 x 8 + 4 bytes per pair, contiguous)
         __syncthreads();
         item = __builtin_amdgcn_readfirstlane(ctl[2u + turn]);
         if (item >= n_items) break;
@@ -691,7 +701,7 @@ __global__ __launch_bounds__(kWgThreads) void k_part_hist(const PartHistPlan P) 
                 // Outlier (hist_basic.go:132-135): clipped into the last bucket and remembered (part_outlier)
                 const uint32_t nva = two && (local & 1u) ? nv1 : nv0;
                 if (f > nva) {
-                    part_outlier(P, pair0 + local, val - (two && (local & 1u) ? bs1 : bs0));
+                    part_outlier(P, O, local, pair0 + local, val - (two && (local & 1u) ? bs1 : bs0));
                     f = nva;
                 }
             }
@@ -839,6 +849,13 @@ __global__ __launch_bounds__(kWgThreads) void k_part_hist(const PartHistPlan P) 
             // Result.Count of the cell is the count of any of its aggregations
             // (the records carry v - h.Min + BucketSize)
             const int64_t vsum = (int64_t)(vs + (unsigned long long)n * ((unsigned long long)P.hmin[a] - (unsigned long long)P.bucket_size[a]));
+            if (OUT && lane == 0 && P.f_out[a] >= 0 && O.n[l] != 0) {
+                // (the cell's outlier fields start from zero with every scan and are added to: shares of a pair, and passes)
+                int64_t *Fo = F + (int64_t)P.f_out[a] * P.n_cells + cell;
+                gadd(Fo, (int64_t)O.n[l]);
+                gadd(Fo + P.n_cells, (int64_t)O.sum[l]);
+                for (int k = 0; k < 4; k++) gadd(Fo + (int64_t)(2 + k) * P.n_cells, (int64_t)O.sq[l * 4u + (uint32_t)k]);
+            }
             if (lane == 0) {
                 if (split == 1) {
                     if (a == 0 && !P.no_count) F[cell] = (int64_t)n;
@@ -903,7 +920,8 @@ static hipError_t part_hist_launch(const PartHistPlan &P, size_t lds, hipStream_
 hipError_t launch_part_hist(const PartHistPlan &P, hipStream_t st) {
     if (P.n_parts <= 0) return hipSuccess;
     const uint32_t n_reg = ((uint32_t)P.n_wg + (uint32_t)P.split - 1u) / (uint32_t)P.split;
-    size_t lds = (size_t)kPartCells * ((P.nv_max + 2) / 2) * 4 + (size_t)kPartCells * (kPartSumRep + 1) * 8 + (size_t)n_reg * 8 + 16;  // + item / region cursors
+    size_t lds = (size_t)kPartCells * ((P.nv_max + 2) / 2) * 4 + (size_t)kPartCells * (kPartSumRep + 1) * 8 + (size_t)n_reg * 8 + 16 +  // + item / region cursors
+                 (size_t)kPartCells * 48;  // + the pairs' outlier sums (OUT)
     const bool track_max = P.m_max[0] >= 0 || (P.n_aggs > 1 && P.m_max[1] >= 0);
     if (P.n_aggs == 1) return track_max ? part_hist_launch<1, true>(P, lds, st) : part_hist_launch<1, false>(P, lds, st);
     if (P.n_aggs == 2) return track_max ? part_hist_launch<2, true>(P, lds, st) : part_hist_launch<2, false>(P, lds, st);
