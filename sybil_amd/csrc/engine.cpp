@@ -76,6 +76,7 @@ hipError_t create_side_stream(hipStream_t *out, int toward) {
 
 static void free_query(Query *q) {
     if (!q) return;
+    query_finish_lazy_results(q);  // (their rows are built from this query's metadata: now, or never)
     if (q->d_plan) hipFree(q->d_plan);
     if (q->d_segs) hipFree(q->d_segs);
     if (q->d_wg_seg_begin) hipFree(q->d_wg_seg_begin);
@@ -563,7 +564,7 @@ int sybl_query_hash_keys(sybl_query *q, const uint64_t **keys, int64_t *n) {
     SYBL_HIP(hipSetDevice(q->ctx->device));
     int rc = query_hash_compact(q);
     if (rc) return rc;
-    *keys = q->h_dense_keys.data();
+    *keys = q->h_dense_keys;
     *n = q->hash_live;
     return SYBL_OK;
 }

@@ -392,7 +392,9 @@ struct Query {
     void *d_sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
     uint64_t *d_hash_count = nullptr;
-    std::vector<uint64_t> h_dense_keys;     // host copy of the sorted keys (finalize, multi-rank union)
+    std::shared_ptr<HostBuf> h_keys_buf;    // pinned host copy of the sorted keys (finalize, multi-rank union), shared with results
+    uint64_t *h_dense_keys = nullptr;       // = h_keys_buf->p
+    std::vector<Result *> lazy_results;     // results whose rows are still to be built and need this query for it (result.cpp)
     int64_t h_max_words = 0;                // capacity of h_max
     // role-specialised kernel (scan_fast.h)
     bool fast = false, fast_gen = false, fast_packed = false;
@@ -422,6 +424,9 @@ int query_rescan_without_part_hist(Query *q);
 
 constexpr int kMaxScatterRanks = 64;  // the SUM section is padded so that a reduce-scatter over up to this many ranks fits in place
 bool query_wants_hist_summary(const Query *q);
+int query_acquire_host_buf(Query *q, int64_t words, std::shared_ptr<HostBuf> &cur);  // (result.cpp) a pinned buffer no result holds
+int query_host_keys(Query *q, int64_t n);  // (result.cpp) q->h_dense_keys with room for n keys, not shared with a live result
+void query_finish_lazy_results(Query *q);  // (result.cpp) builds the rows of results that still need the query (before it goes away)
 int query_summary_buffers(Query *q);  // (result.cpp) d_pct / d_mom / d_total + their pinned twins
 // rccl.cpp: collectives on the ctx communicator and stream (SYBL_E_STATE without a communicator)
 int comm_allgather_inplace(Ctx *ctx, int64_t *buf, size_t words_per_rank);

@@ -366,8 +366,11 @@ int query_hash_compact(Query *q) {
                                (const uint64_t *)q->d_dense_keys, (const uint32_t *)q->d_dense_slots, (const uint64_t *)nullptr, (int64_t)0,
                                q->d_dense_sum + kHeaderWords + (int64_t)F * n);
     }
-    q->h_dense_keys.resize((size_t)n);
-    if (n > 0) SYBL_HIP(hipMemcpyAsync(q->h_dense_keys.data(), q->d_dense_keys, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+    {
+        int rc = query_host_keys(q, n);
+        if (rc) return rc;
+    }
+    if (n > 0) SYBL_HIP(hipMemcpyAsync(q->h_dense_keys, q->d_dense_keys, (size_t)n * 8, hipMemcpyDeviceToHost, st));
     SYBL_HIP(hipStreamSynchronize(st));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "hash compaction");
@@ -418,8 +421,11 @@ int query_hash_install_union_device(Query *q, const uint64_t *d_union, int64_t n
     }
     uint64_t missing = 0;
     SYBL_HIP(hipMemcpyAsync(&missing, q->d_hash_count, 8, hipMemcpyDeviceToHost, st));
-    q->h_dense_keys.resize((size_t)n);
-    if (n > 0) SYBL_HIP(hipMemcpyAsync(q->h_dense_keys.data(), new_keys, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+    {
+        int rc = query_host_keys(q, n);
+        if (rc) return rc;
+    }
+    if (n > 0) SYBL_HIP(hipMemcpyAsync(q->h_dense_keys, new_keys, (size_t)n * 8, hipMemcpyDeviceToHost, st));
     SYBL_HIP(hipStreamSynchronize(st));
     e = hipGetLastError();
     if (e != hipSuccess || missing) {

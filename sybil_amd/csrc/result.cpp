@@ -368,7 +368,7 @@ static void make_views(Result *R) {
 // A pinned host buffer of at least `words` int64 that no result holds any more (use count 1: only the query's list),
 // or a new one: results keep the snapshot their rows point into, and a pipelined host frees a result only after the
 // query's next snapshot was queued -- allocating 52 MB of pinned memory per step instead cost 1.8 ms of every step.
-static int acquire_host_buf(Query *q, int64_t words, std::shared_ptr<HostBuf> &cur) {
+int query_acquire_host_buf(Query *q, int64_t words, std::shared_ptr<HostBuf> &cur) {
     cur.reset();
     for (auto &b : q->host_bufs)
         if (b.use_count() == 1 && b->words >= words) {
@@ -384,6 +384,27 @@ static int acquire_host_buf(Query *q, int64_t words, std::shared_ptr<HostBuf> &c
     q->host_bufs.push_back(nb);
     cur = nb;
     return SYBL_OK;
+}
+
+// The pinned host copy of a hash group-by's sorted keys: a lazily finalized result shares it, so a buffer some result still
+// holds is left alone and another one taken.
+int query_host_keys(Query *q, int64_t n) {
+    const int64_t words = std::max<int64_t>(n, 1);
+    if (!q->h_keys_buf || q->h_keys_buf.use_count() > 2 || q->h_keys_buf->words < words) {
+        int rc = query_acquire_host_buf(q, words, q->h_keys_buf);
+        if (rc) return rc;
+    }
+    q->h_dense_keys = (uint64_t *)q->h_keys_buf->p;
+    return SYBL_OK;
+}
+
+void query_finish_lazy_results(Query *q) {
+    std::vector<Result *> pending;
+    pending.swap(q->lazy_results);
+    for (Result *R : pending) {
+        R->owner = nullptr;  // (no unregistering from inside: the list is gone)
+        result_ensure_rows(R);
+    }
 }
 
 int query_summary_buffers(Query *q) {
@@ -420,7 +441,7 @@ int query_snapshot(Query *q) {
     const int64_t sum_words = q->hash_mode ? hash_dense_sum_words(q, q->hash_live) : q->n_sum_words;
     const int64_t max_words = q->hash_mode ? hash_dense_max_words(q, q->hash_live) : q->n_max_words;
     if (!q->h_sum_buf || q->h_sum_buf.use_count() > 2 || q->h_sum_buf->words < sum_words) {
-        int rc = acquire_host_buf(q, sum_words, q->h_sum_buf);
+        int rc = query_acquire_host_buf(q, sum_words, q->h_sum_buf);
         if (rc) return rc;
     }
     if (!q->h_max || q->h_max_words < max_words) {
@@ -447,9 +468,9 @@ int query_snapshot(Query *q) {
             // a pipelined host holds the previous result of this query while the next snapshot is queued: two buffers
             // from the start (allocating the second one when it is first missed costs a step 3.5 ms of pinned allocation)
             std::shared_ptr<HostBuf> spare;
-            int rc = acquire_host_buf(q, pairs * 100, spare);
+            int rc = query_acquire_host_buf(q, pairs * 100, spare);
             if (rc) return rc;
-            rc = acquire_host_buf(q, pairs * 100, q->h_pct_buf);  // (`spare` is held: a second buffer)
+            rc = query_acquire_host_buf(q, pairs * 100, q->h_pct_buf);  // (`spare` is held: a second buffer)
             if (rc) return rc;
             // first device write into each of them now (a 52 MB copy into a pinned buffer the device has not written
             // before was seen to block its hipMemcpyAsync for 13-18 ms: once, but inside a timed region of ten steps)
@@ -458,7 +479,7 @@ int query_snapshot(Query *q) {
             SYBL_HIP(hipStreamSynchronize(st));
         }
         if (q->h_pct_buf.use_count() > 2 || q->h_pct_buf->words < pairs * 100) {
-            int rc = acquire_host_buf(q, pairs * 100, q->h_pct_buf);
+            int rc = query_acquire_host_buf(q, pairs * 100, q->h_pct_buf);
             if (rc) return rc;
         }
         q->h_pct = q->h_pct_buf->p;
@@ -686,6 +707,8 @@ int query_finalize(Query *q, Result **out) {
     C.hm = hm;
     C.h_pct = summary ? q->h_pct : nullptr;
     C.q = q;
+    C.keys_buf = hashed ? q->h_keys_buf : nullptr;
+    C.dense_keys = hashed ? q->h_dense_keys : nullptr;
 
     R->total_vals.resize(na);
     for (size_t a = 0; a < na; a++) {
@@ -771,7 +794,6 @@ int query_finalize(Query *q, Result **out) {
     // BinaryByKey / GroupByKey per group cell: the query's cache (built by its first finalize), or per row
     const bool keys_cached = !hashed && gcells <= ((int64_t)1 << 18);
     C.keys_cached = keys_cached;
-    const size_t n_all_rows = live.size() + alltime.size() + 1;
     std::shared_ptr<KeyStore> ks;
     if (keys_cached) {
         if (!q->key_cache) {
@@ -788,8 +810,7 @@ int query_finalize(Query *q, Result **out) {
         ks = q->key_cache;
     } else {
         if (!R->own_keys) R->own_keys = std::make_shared<KeyStore>();
-        ks = R->own_keys;
-        ks->resize(n_all_rows);
+        ks = R->own_keys;  // (sized when the rows are built)
     }
     R->keys = ks;
     trace.mark("alloc");
@@ -799,7 +820,9 @@ int query_finalize(Query *q, Result **out) {
     // reference counted.  Small results are built right away (the threshold only keeps trivial results simple to debug),
     // count-distinct results as well (their sketches are fetched here).
     // (SYBL_LAZY_ROWS=1: whatever the size -- the test suite runs once that way)
-    const bool lazy = keys_cached && !q->n_distinct && (live.size() >= 2048 || getenv("SYBL_LAZY_ROWS")) && !getenv("SYBL_EAGER_ROWS");
+    // Rows with keys of their own (hash group-by, very wide key spaces) are built from the query's group columns and the
+    // table's dictionaries: such a result registers with its query, which builds the rows before it goes away.
+    const bool lazy = !q->n_distinct && (live.size() >= 2048 || getenv("SYBL_LAZY_ROWS")) && !getenv("SYBL_EAGER_ROWS");
     if (summary) {
         C.mom.assign(q->h_mom, q->h_mom + (size_t)P.n_cells * na * 2);
         for (size_t a = 0; a < na; a++)
@@ -807,7 +830,11 @@ int query_finalize(Query *q, Result **out) {
                 memcpy(R->total_vals[a].data(), q->h_total + P.hist_agg_off[a], R->total_vals[a].size() * sizeof(int64_t));
     }
     if (lazy && P.n_max_fields > 0) {
-        C.hm_copy.assign(hm, hm + (size_t)q->n_max_words);
+        // (worker threads: 9.5e7 hash groups are 0.76 GB of extrema, 150 ms for one thread)
+        const size_t words = (size_t)(hashed ? hash_dense_max_words(q, ncell) : q->n_max_words);
+        C.hm_copy.resize(words);
+        int64_t *dst = C.hm_copy.data();
+        parallel_ranges(words, (size_t)1 << 20, [&](size_t i0, size_t i1) { memcpy(dst + i0, hm + i0, (i1 - i0) * sizeof(int64_t)); });
         C.hm = C.hm_copy.data();
     }
     R->rows_pending = true;
@@ -827,9 +854,9 @@ int query_finalize(Query *q, Result **out) {
             int64_t cell = log[(size_t)i * kOutLogWords];
             const int64_t a = log[(size_t)i * kOutLogWords + 1];
             if (hashed) {  // the log names the group by its composite key
-                auto it = std::lower_bound(q->h_dense_keys.begin(), q->h_dense_keys.begin() + ncell, (uint64_t)cell);
-                if (it == q->h_dense_keys.begin() + ncell || *it != (uint64_t)cell) continue;
-                cell = (int64_t)(it - q->h_dense_keys.begin());
+                auto it = std::lower_bound(q->h_dense_keys, q->h_dense_keys + ncell, (uint64_t)cell);
+                if (it == q->h_dense_keys + ncell || *it != (uint64_t)cell) continue;
+                cell = (int64_t)(it - q->h_dense_keys);
             }
             auto lv = std::lower_bound(live.begin(), live.end(), cell);
             if (lv == live.end() || *lv != cell || a < 0 || a >= (int64_t)na) continue;
@@ -962,7 +989,12 @@ int query_finalize(Query *q, Result **out) {
     } else {
         R->has_distinct = false;
     }
-    C.q = nullptr;  // (nothing built later may look at the query)
+    if (lazy && !keys_cached) {
+        R->owner = q;
+        q->lazy_results.push_back(R);
+    } else {
+        C.q = nullptr;  // (nothing built later may look at the query)
+    }
     *out = R;
     return SYBL_OK;
 }
@@ -983,6 +1015,7 @@ void result_ensure_rows(Result *R) {
     const size_t na = C.aggs.size();
     std::vector<int64_t> &live = R->live, &alltime = R->alltime, &all_count = R->all_count, &all_samples = R->all_samples;
     KeyStore *ks = R->keys.get();
+    if (!keys_cached) ks->resize(live.size() + alltime.size() + 1);
     auto load_cell = [&](int64_t cell, CellAcc &acc) -> bool {
         acc.count = F[cell];
         acc.samples = P.f_samples >= 0 ? F[(int64_t)P.f_samples * ncell + cell] : acc.count;
@@ -1047,7 +1080,7 @@ void result_ensure_rows(Result *R) {
             const int64_t cell = live[i];
             load_cell(cell, acc);
             // (hash group-by: the composite key is [time bucket || group key], the dense arrays are in key order)
-            const int64_t ckey = hashed ? (int64_t)C.q->h_dense_keys[(size_t)cell] : cell;
+            const int64_t ckey = hashed ? (int64_t)C.dense_keys[(size_t)cell] : cell;
             const int64_t tbi = hashed && !C.time_mode ? 0 : ckey / gcells, gcell = ckey - tbi * gcells;
             RowStore &row = cell_rows[i];
             row.agg_off = (int64_t)(i * na);
@@ -1200,6 +1233,12 @@ void result_ensure_rows(Result *R) {
                 R->agg_pool[k].values = R->val_pool[k];
             }
     make_views(R);
+    if (R->owner) {
+        auto &v = R->owner->lazy_results;
+        v.erase(std::remove(v.begin(), v.end(), R), v.end());
+        R->owner = nullptr;
+    }
+    R->fin.q = nullptr;
 }
 
 }  // namespace sybl

@@ -107,14 +107,25 @@ struct FinCtx {
     const int64_t *F = nullptr, *hm = nullptr, *H = nullptr;  // cell fields / extrema / bucket arrays of the snapshot
     const int64_t *h_pct = nullptr;                           // GPU-computed percentiles (Result::keep_pct)
     std::vector<int64_t> mom, hm_copy;                        // bucket moments / extrema: copied (the query's buffers are reused)
-    const Query *q = nullptr;                                 // eager builds only (per-row keys: hash group-by)
+    const Query *q = nullptr;                                 // rows with keys of their own (hash group-by): built while the query lives
+    std::shared_ptr<HostBuf> keys_buf;                        // the sorted composite keys of a hash group-by (pinned, shared)
+    const uint64_t *dense_keys = nullptr;
 };
 
 struct Result : ResultStore {
     const RowStore &sorted0(size_t i) const { return rows[0][order0.empty() ? i : order0[i]]; }
     RowStore &sorted0(size_t i) { return rows[0][order0.empty() ? i : order0[i]]; }
     std::shared_ptr<ResultPool> pool;  // where the arrays go back to when the result is freed
+    Query *owner = nullptr;  // the query a lazily finalized result with per-row keys is registered with
     ~Result() {
+        if (owner) {
+            auto &v = owner->lazy_results;
+            for (size_t i = 0; i < v.size(); i++)
+                if (v[i] == this) {
+                    v.erase(v.begin() + (long)i);
+                    break;
+                }
+        }
         if (!pool) return;
         std::lock_guard<std::mutex> lk(pool->m);
         if (!pool->full) {
