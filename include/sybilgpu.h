@@ -343,9 +343,16 @@ int sybl_query_collective_finalize(const sybl_query *q);
  * enqueued behind it -- a host serving a stream of queries overlaps the finalize of one query with
  * the scan of the next (two prepared queries, alternating). */
 int sybl_query_snapshot(sybl_query *q);
-/* Copies the (reduced) partials to the host (unless sybl_query_snapshot already did), derives
- * avg/stddev/percentiles, builds GroupByKey strings, sorts and applies the limit.  Waits for the
- * copy (hence for the scan and the all-reduce before it). */
+/* Copies the (reduced) partials to the host (unless sybl_query_snapshot already did), finds the groups that exist and
+ * sorts them (SortResults, aggregate.go:497-525).  Waits for the copy (hence for the scan and the all-reduce before
+ * it).  The ROWS of a result with 2048 groups or more -- avg / stddev / percentiles, GroupByKey strings, the
+ * sybl_group_row array -- are built when first asked for (sybl_result_rows, sybl_result_render, sybl_result_encode),
+ * from the result's own reference-counted snapshot: the reference's Results are its accumulators (aggregate.go:186-203),
+ * nothing has to be built before a printer walks them, and a time series of 360 000 rows or a 65 536-group histogram
+ * costs the step that finalizes it nothing it does not print.  The query may be scanned again in between.  A result
+ * whose rows carry keys of their own (hash group-by, key spaces beyond 2^18 cells) builds them from the query's group
+ * columns and the table's dictionaries: it stays registered with its query, and sybl_query_free builds the rows of
+ * such results that are still alive before the query goes away (the table must outlive its queries, as always). */
 int sybl_query_finalize(sybl_query *q, sybl_result **out);
 
 /* ------------------------------------------------------------------ results */
@@ -399,7 +406,8 @@ typedef struct {
 } sybl_subhist;
 int sybl_result_subhists(const sybl_result *r, int agg, const sybl_subhist **subs, int64_t *n);
 
-/* which: 0 = Results (every group, sorted by order_by; the limit is applied when rendering,
+/* (the first call on a lazily finalized result builds its rows: see sybl_query_finalize)
+ * which: 0 = Results (every group, sorted by order_by; the limit is applied when rendering,
  *            as printSortedResults does), 1 = TimeResults (by bucket, then key),
  *        2 = Cumulative ("TOTAL", one row) */
 int sybl_result_rows(const sybl_result *r, int which, const sybl_group_row **rows, int64_t *n);

@@ -159,6 +159,7 @@ int table_ensure_stats(Table *t);
 int table_reserve(Table *t, Column *c, int64_t phys_rows);
 int valid_reserve(Table *t, Column *c, int64_t phys_rows);
 int64_t table_drop_dead_tail(Table *t, int64_t keep_blocks);  // trailing blocks without rows give their row range back
+int table_reclaim_dead_rows(Table *t, bool force);           // rows of dead blocks in the MIDDLE of the table: the live blocks close up
 void column_free(Column *c);
 int32_t dict_intern(Column *c, const std::string &s);
 int column_upload_set(Table *t, Column *c);

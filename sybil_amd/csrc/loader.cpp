@@ -922,7 +922,7 @@ static int refresh_table(Table *t, int64_t *n_added, int64_t *n_dropped, int64_t
         }
         // vanished, moved to another rank's share, or rewritten: its rows leave the scan.  Those of trailing blocks are
         // reused by the blocks loaded below (table_drop_dead_tail: the rewritten last block of an ingest loop); rows in
-        // the middle of the table stay in HBM, unreferenced, until it is reopened
+        // the middle of the table are given back once there are enough of them (table_reclaim_dead_rows)
         if (lb.index >= 0 && lb.index < (int64_t)t->blocks.size() && t->blocks[(size_t)lb.index].n > 0) {
             const int64_t n = t->blocks[(size_t)lb.index].n;
             t->blocks[(size_t)lb.index].n = 0;
@@ -947,6 +947,8 @@ static int refresh_table(Table *t, int64_t *n_added, int64_t *n_dropped, int64_t
     int64_t keep_blocks = 0;
     for (auto &lb : t->loaded) keep_blocks = std::max(keep_blocks, lb.index + 1);
     table_drop_dead_tail(t, keep_blocks);
+    // (blocks that vanished from the middle -- trim / expire: once their rows are a quarter of the table the rest closes up)
+    if ((rc = table_reclaim_dead_rows(t, getenv("SYBL_RECLAIM_ALWAYS") != nullptr))) return rc;
     if (!to_load.empty() && (rc = load_blocks(ctx, t, t->src_dir, to_load))) return rc;
     if (n_added) *n_added = added;
     if (n_dropped) *n_dropped = dropped;

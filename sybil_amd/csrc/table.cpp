@@ -546,6 +546,90 @@ int64_t table_drop_dead_tail(Table *t, int64_t keep_blocks) {
     return dropped;
 }
 
+// Blocks that vanished from the middle of a followed table (sybil trim / expire, table_trim.go) leave their rows behind:
+// the scan skips them (a block of zero rows), but a host that runs for weeks would keep every expired block in HBM.  Once
+// the dead rows are a quarter of the table (and a block's worth), the live blocks close up: every column's rows and
+// validity words move down block by block (through a scratch block: a block's new place may overlap its old one), the set
+// columns' host CSR is rebuilt, block numbers stay (the loader's directory refers to them).  Extrema and dictionaries
+// stay valid: bounds and dictionaries of a superset.  The reference re-lists the directory per query and never holds
+// what it does not scan (table_query.go:40-106).
+int table_reclaim_dead_rows(Table *t, bool force) {
+    const int64_t nb = (int64_t)t->blocks.size();
+    std::vector<int64_t> to((size_t)nb, 0);
+    int64_t w = 0;
+    bool moves = false;
+    for (int64_t b = 0; b < nb; b++) {
+        to[(size_t)b] = w;
+        if (t->blocks[(size_t)b].n > 0) {
+            moves = moves || t->blocks[(size_t)b].start != w;
+            w += (t->blocks[(size_t)b].n + 31) / 32 * 32;
+        }
+    }
+    int64_t last_live = -1;
+    for (int64_t b = 0; b < nb; b++)
+        if (t->blocks[(size_t)b].n > 0) last_live = b;
+    const int64_t new_phys = last_live >= 0 ? to[(size_t)last_live] + t->blocks[(size_t)last_live].n : 0;
+    const int64_t dead = t->phys_rows - new_phys;
+    if (!moves || dead <= 0) return SYBL_OK;
+    if (!force && !(dead >= 65536 && dead * 4 >= t->phys_rows)) return SYBL_OK;
+    Ctx *ctx = t->ctx;
+    hipStream_t st = ctx->stream;
+    int rc = load_sync_all(ctx);
+    if (rc) return rc;
+    SYBL_HIP(hipStreamSynchronize(st));
+    int64_t max_n = 0;
+    for (auto &b : t->blocks) max_n = std::max(max_n, b.n);
+    DevOwner scratch;
+    SYBL_HIP(hipMalloc(&scratch.p, (size_t)max_n * 8 + (size_t)(max_n / 32 + 2) * 4));
+    uint8_t *sc_rows = (uint8_t *)scratch.p;
+    uint32_t *sc_valid = (uint32_t *)(sc_rows + (size_t)max_n * 8);
+    for (auto &cp : t->cols) {
+        Column *c = cp.get();
+        if (c->type == SYBL_SET_VAL) {
+            if (c->h_set_off.empty()) continue;
+            std::vector<int64_t> off;
+            std::vector<int32_t> vals;
+            off.reserve((size_t)w + 1);
+            off.push_back(0);
+            for (int64_t b = 0; b < nb; b++) {
+                const Segment &blk = t->blocks[(size_t)b];
+                if (blk.n <= 0) continue;
+                const int64_t rows = b == last_live ? blk.n : (blk.n + 31) / 32 * 32;  // (the table ends with its last row)
+                for (int64_t r = 0; r < rows; r++) {
+                    const int64_t src = blk.start + r;
+                    if (src + 1 < (int64_t)c->h_set_off.size()) {
+                        const int64_t lo = c->h_set_off[(size_t)src], hi = c->h_set_off[(size_t)src + 1];
+                        vals.insert(vals.end(), c->h_set_vals.begin() + lo, c->h_set_vals.begin() + hi);
+                    }
+                    off.push_back((int64_t)vals.size());
+                }
+            }
+            c->h_set_off.swap(off);
+            c->h_set_vals.swap(vals);
+            c->set_dirty = true;
+        } else if (c->d_data) {
+            for (int64_t b = 0; b < nb; b++) {
+                const Segment &blk = t->blocks[(size_t)b];
+                if (blk.n <= 0 || blk.start == to[(size_t)b]) continue;
+                const size_t bytes = (size_t)blk.n * (size_t)c->elem;
+                SYBL_HIP(hipMemcpyAsync(sc_rows, (const uint8_t *)c->d_data + (size_t)blk.start * (size_t)c->elem, bytes, hipMemcpyDeviceToDevice, st));
+                SYBL_HIP(hipMemcpyAsync((uint8_t *)c->d_data + (size_t)to[(size_t)b] * (size_t)c->elem, sc_rows, bytes, hipMemcpyDeviceToDevice, st));
+                if (c->d_valid) {
+                    const size_t words = (size_t)((blk.n + 31) / 32);
+                    SYBL_HIP(hipMemcpyAsync(sc_valid, c->d_valid + blk.start / 32, words * 4, hipMemcpyDeviceToDevice, st));
+                    SYBL_HIP(hipMemcpyAsync(c->d_valid + to[(size_t)b] / 32, sc_valid, words * 4, hipMemcpyDeviceToDevice, st));
+                }
+            }
+        }
+        if (c->gdict_blocks >= 0) c->gdict_blocks = -1;
+    }
+    SYBL_HIP(hipStreamSynchronize(st));
+    for (int64_t b = 0; b < nb; b++) t->blocks[(size_t)b].start = to[(size_t)b];
+    t->phys_rows = new_phys;
+    t->version++;
+    return SYBL_OK;
+}
+
 // ------------------------------------------------------------------ group dictionaries
 // Direct mapping needs one cell per value of the key RANGE; a sparse key (user ids, raw
 // timestamps) gets one cell per DISTINCT value instead: k_distinct collects the distinct values

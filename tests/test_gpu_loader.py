@@ -355,3 +355,40 @@ def test_append_block_with_set_column(ctx, oracle):
     with pytest.raises(sybil_amd.SyblError):
         tb.query(groups=["tags"])     # cmd_query.go:254: cannot group by a set column
     tb.free()
+
+
+def test_refresh_gives_back_the_rows_of_blocks_that_vanished_mid_table(ctx, tmp_path, monkeypatch):
+    """sybil trim / expire removes whole block directories from the middle of a table.  A resident table that follows its
+    directory drops them from the scan at once; once their rows are worth it (here: always, SYBL_RECLAIM_ALWAYS) the live
+    blocks close up -- rows, validity bits, set members -- so a host that runs for weeks does not keep every expired block
+    in HBM.  The table answers like a freshly opened one afterwards, and blocks that appear later land behind it."""
+    import shutil
+    monkeypatch.setenv("SYBL_RECLAIM_ALWAYS", "1")
+    blocks, _ = _make_blocks(6, 3000, seed=57, ragged=False)
+    info = {"big": (-(1 << 40), 1 << 40)}
+    root, spare = str(tmp_path / "db"), str(tmp_path / "spare")
+    F.write_table(root, "events", blocks[:5], threshold=8, int_info=info)
+    F.write_table(spare, "events", blocks, threshold=8, int_info=info)
+    tb = ctx.open_table(root, "events", compact=True)
+    hbm5 = tb.hbm_bytes
+    queries = [dict(groups=["age"], aggs=["big", "time"]), dict(filters=[("tags", "in", "tag3")], groups=["name"], aggs=["age"], op="hist")]
+    tdir, sdir = str(tmp_path / "db" / "events"), str(tmp_path / "spare" / "events")
+    shutil.rmtree(tdir + "/block000000002")
+    shutil.rmtree(tdir + "/block000000003")
+    assert tb.refresh() == (0, 2, 0)
+    assert tb.rows == 9000 and tb.broken_blocks == 0
+    fresh = ctx.open_table(root, "events", compact=True)
+    for q in queries:
+        assert _summary(tb, q) == _summary(fresh, q), q
+    fresh.free()
+    # a block appears: it lands behind the closed-up rows, and the table is no bigger than it was with five blocks
+    shutil.copytree(sdir + "/block000000006", tdir + "/block000000006")
+    shutil.copy(sdir + "/info.db", tdir + "/info.db")
+    assert tb.refresh() == (1, 0, 0)
+    assert tb.rows == 12000
+    fresh = ctx.open_table(root, "events", compact=True)
+    for q in queries:
+        assert _summary(tb, q) == _summary(fresh, q), q
+    fresh.free()
+    assert tb.hbm_bytes <= hbm5 * 1.05, (tb.hbm_bytes, hbm5)
+    tb.free()
