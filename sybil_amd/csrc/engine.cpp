@@ -78,6 +78,8 @@ static void free_query(Query *q) {
     if (!q) return;
     query_finish_lazy_results(q);  // (their rows are built from this query's metadata: now, or never)
     if (q->d_plan) hipFree(q->d_plan);
+    if (q->d_preplan) hipFree(q->d_preplan);
+    if (q->d_prebits) hipFree(q->d_prebits);
     if (q->d_segs) hipFree(q->d_segs);
     if (q->d_wg_seg_begin) hipFree(q->d_wg_seg_begin);
     if (q->d_wg_cell_base) hipFree(q->d_wg_cell_base);
@@ -274,6 +276,11 @@ static int scan(Query *q) {
         if (e != hipSuccess) return hip_fail(e, "k_fill64");
     }
     SYBL_HIP(hipEventRecord(q->ev[0], st));
+    if (ran && q->pre_n_slots) {
+        // the filters the packed bodies do not evaluate: a row bitmap first (planner.cpp: Planner::prefilter)
+        e = launch_prefilter(q->d_preplan, q->pre_n_slots, q->d_prebits, q->n_wg, st);
+        if (e != hipSuccess) return hip_fail(e, "k_prefilter");
+    }
     if (ran && q->hash_mode) {
         if (q->hash_fast) {
             q->fplan.sum_out = q->d_sum;

@@ -395,6 +395,12 @@ struct Query {
     uint64_t *d_hash_count = nullptr;
     std::shared_ptr<HostBuf> h_keys_buf;    // pinned host copy of the sorted keys (finalize, multi-rank union), shared with results
     uint64_t *h_dense_keys = nullptr;       // = h_keys_buf->p
+    // filter pre-pass (planner.cpp: Planner::prefilter): the filters the packed bodies cannot evaluate run first, as a
+    // kernel of their own that writes a row bitmap the scan then reads like a validity word
+    ScanPlan preplan;
+    ScanPlan *d_preplan = nullptr;
+    uint32_t *d_prebits = nullptr;
+    int pre_n_slots = 0;
     std::vector<Result *> lazy_results;     // results whose rows are still to be built and need this query for it (result.cpp)
     int64_t h_max_words = 0;                // capacity of h_max
     // role-specialised kernel (scan_fast.h)

@@ -87,7 +87,9 @@ __global__ __launch_bounds__(kWgThreads) void k_scan_hash_packed(const FastPlan 
             }
         }
     };
-    auto one_row = [&](const PackedTile<MF> &f, const PackedTile<MG> &g, const PackedTile<NA> &a, const PackedTile<1> &t, const int r, bool pass) {
+    auto one_row = [&](const PackedTile<MF> &f, const PackedTile<MG> &g, const PackedTile<NA> &a, const PackedTile<1> &t, const int r, bool pass,
+                       const uint32_t xpop) {
+        if (NUL) pass = pass & ((xpop >> r) & 1u);  // the filter pre-pass's verdict (FastPlan::xvalid)
         // (packed_row's filters and key, scan_packed.h: one predicate, no short-circuit)
 #pragma unroll
         for (int c = 0; c < MF; c++) {
@@ -194,6 +196,7 @@ __global__ __launch_bounds__(kWgThreads) void k_scan_hash_packed(const FastPlan 
             PackedTile<MG> g;
             PackedTile<NA> a;
             PackedTile<1> t;
+            uint32_t xw = 0xFFFFFFFFu, xpop = 0xFu;
             auto issue = [&](uint32_t r) {
                 const uint32_t r0 = __builtin_amdgcn_readfirstlane(r);
                 const uint32_t lane_row = r - r0;
@@ -203,6 +206,7 @@ __global__ __launch_bounds__(kWgThreads) void k_scan_hash_packed(const FastPlan 
                 };
                 if (NUL) {
                     const int64_t wd = (first + r) >> 5;
+                    if (P.xvalid) xw = P.xvalid[wd];
                     if (time) rt.pw[0] = P.tvalid ? P.tvalid[wd] : 0xFFFFFFFFu;
 #pragma unroll
                     for (int c = 0; c < MF; c++)
@@ -226,6 +230,7 @@ __global__ __launch_bounds__(kWgThreads) void k_scan_hash_packed(const FastPlan 
             auto decode = [&](uint32_t r) {
                 const uint32_t bit0 = (uint32_t)(first + r) & 31u;
                 if (NUL) {
+                    xpop = (xw >> bit0) & 0xFu;
                     if (time) t.pop[0] = (rt.pw[0] >> bit0) & 0xFu;
 #pragma unroll
                     for (int c = 0; c < MF; c++)
@@ -257,7 +262,7 @@ __global__ __launch_bounds__(kWgThreads) void k_scan_hash_packed(const FastPlan 
                 if (more) issue(rn);
                 const uint32_t left = n - r;
 #pragma unroll
-                for (int k = 0; k < kPackedRows; k++) one_row(f, g, a, t, k, (uint32_t)k < left);
+                for (int k = 0; k < kPackedRows; k++) one_row(f, g, a, t, k, (uint32_t)k < left, xpop);
                 if (more) decode(rn);
             }
         }

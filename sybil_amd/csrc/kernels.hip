@@ -1113,6 +1113,54 @@ static hipError_t launch_scan_nc(const ScanPlan *d_plan, int n_wg, bool use_lds,
     return hipGetLastError();
 }
 
+// k_prefilter: the filter pre-pass (planner.cpp: Planner::prefilter).  The plan holds only filter slots -- set members,
+// the filter columns beyond the packed bodies' four --; every row's verdict (the generic row_prepare: filter.go:171-285)
+// becomes one bit of a bitmap indexed by physical row.  A lane holds two consecutive rows, sixteen lanes a word: their bits
+// are ORed together with four butterfly steps and the first lane of the sixteen stores the word (runs of rows start on
+// 32-row boundaries, so words never straddle workgroups).
+template <int NC>
+__global__ __launch_bounds__(kWgThreads) void k_prefilter(CPlan *Pp, uint32_t *bits) {
+    CPlan &P = *Pp;
+    const int tid = threadIdx.x;
+    const int s0 = P.wg_seg_begin[blockIdx.x], s1 = P.wg_seg_begin[blockIdx.x + 1];
+    for (int si = s0; si < s1; si++) {
+        const Segment seg = P.segs[si];
+        const int64_t end = seg.start + seg.n;
+        int64_t row = seg.start + (int64_t)tid * kRowsPerThread;
+        Tile<NC> cur;
+        RawTile<NC> raw;
+        if (row < end) issue_tile<NC>(P, row, raw);
+        decode_tile<NC>(P, row, row < end, raw, cur);
+        for (int64_t base = seg.start; base < end; base += kTileRows) {
+            const int64_t nrow = row + kTileRows;
+            if (nrow < end) issue_tile<NC>(P, nrow, raw);
+            uint32_t v = 0;
+#pragma unroll
+            for (int r = 0; r < kRowsPerThread; r++) {
+                uint64_t key;
+                int64_t w;
+                const bool pass = row + r < end && row_prepare<NC>(P, cur, r, row, key, w) != kRowFail;
+                v |= (pass ? 1u : 0u) << (((uint32_t)row + (uint32_t)r) & 31u);
+            }
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) v |= __shfl_xor(v, o, 64);
+            if ((tid & 15) == 0 && row < end) bits[row >> 5] = v;
+            decode_tile<NC>(P, nrow, nrow < end, raw, cur);
+            row = nrow;
+        }
+    }
+}
+
+hipError_t launch_prefilter(const ScanPlan *d_plan, int n_slots, uint32_t *bits, int n_wg, hipStream_t st) {
+#define SYBL_PF(N) case N: hipLaunchKernelGGL((k_prefilter<N>), dim3(n_wg), dim3(kWgThreads), 0, st, (CPlan *)d_plan, bits); break;
+    switch (n_slots) {
+        SYBL_PF(1) SYBL_PF(2) SYBL_PF(3) SYBL_PF(4) SYBL_PF(5) SYBL_PF(6) SYBL_PF(7) SYBL_PF(8)
+    default: return hipErrorInvalidValue;
+    }
+#undef SYBL_PF
+    return hipGetLastError();
+}
+
 hipError_t launch_scan(const ScanPlan *d_plan, int n_slots, int n_wg, bool use_lds, size_t lds_bytes, hipStream_t st) {
     switch (n_slots) {
     case 1: return launch_scan_nc<1>(d_plan, n_wg, use_lds, lds_bytes, st);

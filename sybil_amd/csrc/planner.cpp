@@ -148,6 +148,7 @@ static bool fill_fast_columns(Table *t, Query *q, const std::vector<int> &slot_c
     if (packed) *packed = false;
     for (size_t s = 0; s < slot_col.size(); s++) {
         const SlotDesc &sd = P.slot[s];
+        if (sd.flags == 0 && q->pre_n_slots > 0) continue;  // (a column only the filter pre-pass reads: Planner::prefilter)
         const Column *c = t->cols[(size_t)slot_col[s]].get();
         bool plain = c->type == SYBL_INT_VAL && !c->d_valid && !c->has_missing;
         any_packed = any_packed || c->packed();
@@ -1231,6 +1232,62 @@ struct Planner {
         return SYBL_OK;
     }
 
+    // ---- filter pre-pass.  The packed row bodies evaluate <= 4 filter columns (ranges, neq constants, dictionary-id masks);
+    // a set-membership filter, or a fifth filter column, used to send the whole query to the plan-interpreting k_scan (28 ms
+    // per 1e9 rows of config 3 against 2.7).  Now those filters run first, as a kernel of their own over only their columns
+    // (k_prefilter: the generic row_prepare, filters only) that writes one bit per row, and the scan proper reads that bitmap
+    // like one more validity word (FastPlan::xvalid, the NUL variants).  Tried here, tentatively: the slots' filter flags
+    // move to q->preplan; prefilter_commit keeps the split only if the rest of the query then runs a packed body.
+    std::vector<uint32_t> pre_saved;  // the moved slots' original flags (by slot), 0 = not moved
+    int prefilter() {
+        q->pre_n_slots = 0;
+        pre_saved.assign((size_t)P.n_slots, 0);
+        if (getenv("SYBL_NO_PREFILTER") || q->loghist || q->hash_mode || !t->compact_mode || q->never_matches || d->n_distincts > 0) return SYBL_OK;
+        if (q->op == SYBL_AGG_HIST && q->want_percentiles) return SYBL_OK;  // (the partitioned histograms have no NUL variants)
+        std::vector<int> move;
+        int n_fast = 0;
+        for (int s = 0; s < P.n_slots; s++) {
+            const uint32_t fl = P.slot[s].flags;
+            if (fl & kSlotSet) {
+                move.push_back(s);
+            } else if (fl & kSlotFilter) {
+                if (n_fast == kFastMaxF) move.push_back(s);
+                else n_fast++;
+            }
+        }
+        if (move.empty()) return SYBL_OK;
+        ScanPlan &R = q->preplan;
+        memset(&R, 0, sizeof(R));
+        R.time_slot = -1;
+        R.weight_slot = -1;
+        R.f_samples = -1;
+        R.n_slots = (int)move.size();
+        for (size_t k = 0; k < move.size(); k++) {
+            SlotDesc &dst = R.slot[k];
+            dst = P.slot[move[k]];
+            dst.flags &= (kSlotFilter | kSlotSet);
+            dst.gmissing = -1;
+            dst.gmissing64 = -1;
+            dst.agg_index = -1;
+            pre_saved[(size_t)move[k]] = P.slot[move[k]].flags;
+            P.slot[move[k]].flags &= ~(uint32_t)(kSlotFilter | kSlotSet);
+        }
+        q->pre_n_slots = (int)move.size();
+        return SYBL_OK;
+    }
+    void prefilter_commit() {
+        if (!q->pre_n_slots) return;
+        if (q->fast && (q->fast_packed || q->fast_packed_n) && q->fplan.hist_lds == 0) {
+            q->fplan.nul = 1;  // (the variants that read validity words read the bitmap)
+            return;            // (the bitmap itself: device_copies)
+        }
+        // the rest of the query does not run a packed body: everything stays with the plan interpreter
+        for (int s = 0; s < P.n_slots; s++)
+            if (pre_saved[(size_t)s]) P.slot[s].flags = pre_saved[(size_t)s];
+        q->pre_n_slots = 0;
+        select_fast_path(t, q, slot_col);
+    }
+
     int strategy() {
         // ---- strategy: cell table in LDS when it fits (DESIGN.md "Strategies")
         q->n_wg = ctx->n_cus > 0 ? ctx->n_cus : 256;
@@ -1368,6 +1425,7 @@ struct Planner {
             }
         }
         select_fast_path(t, q, slot_col);
+        prefilter_commit();
         select_hash_fast(t, q, slot_col);
         if ((rc = select_part_hist(t, q, slot_col, rows_scanned))) return rc;
         q->stats.rows_scanned = rows_scanned;
@@ -1431,6 +1489,16 @@ struct Planner {
             P.multi = q->d_multi;
         }
         SYBL_HIP(hipMalloc((void **)&q->d_plan, sizeof(ScanPlan)));
+        if (q->pre_n_slots) {
+            const size_t words = (size_t)(t->phys_rows / 32 + 2);
+            SYBL_HIP(hipMalloc((void **)&q->d_prebits, words * 4));
+            SYBL_HIP(hipMemset(q->d_prebits, 0, words * 4));
+            q->preplan.segs = q->d_segs;
+            q->preplan.wg_seg_begin = q->d_wg_seg_begin;
+            SYBL_HIP(hipMalloc((void **)&q->d_preplan, sizeof(ScanPlan)));
+            SYBL_HIP(hipMemcpy(q->d_preplan, &q->preplan, sizeof(ScanPlan), hipMemcpyHostToDevice));
+            q->fplan.xvalid = q->d_prebits;
+        }
         for (auto &e : q->ev) SYBL_HIP(hipEventCreate(&e));
         q->plan_dirty = true;
         return SYBL_OK;
@@ -1520,6 +1588,7 @@ struct Planner {
         if ((rc = weight())) return rc;
         if ((rc = aggregations())) return rc;
         if ((rc = finish_slots())) return rc;
+        if ((rc = prefilter())) return rc;
         if ((rc = strategy())) return rc;
         if ((rc = work())) return rc;
         if ((rc = window())) return rc;

@@ -91,6 +91,10 @@ struct FastPlan {
     uint32_t alo[kFastMaxA], ahi[kFastMaxA];
     int32_t nul, pad4_;
     const int32_t *wg_cell_base;
+    // The row bitmap of the filter pre-pass (k_prefilter, kernels.hip): bit per physical row, 1 = the row passes the
+    // filters the packed bodies do not evaluate themselves (set members, a fifth filter column); nullptr = none.  Read
+    // by the NUL variants next to the validity words: a row whose bit is 0 fails like a row that fails a filter.
+    const uint32_t *xvalid;
     int64_t *out_log;   // outlier log (plan.h), nullptr = not kept
     int64_t out_cap;
     int64_t *sum_out, *max_out, *ws_sum, *ws_max;
@@ -204,6 +208,7 @@ hipError_t launch_count(const EmitPlan &P, int nf, int ng, int n_wg, hipStream_t
 hipError_t launch_count_packed(const EmitPlan &P, int nf, int ng, int n_wg, hipStream_t st);
 hipError_t launch_emit(const EmitPlan &P, int nf, int ng, int na, int n_wg, hipStream_t st);
 hipError_t launch_part_hist(const PartHistPlan &P, hipStream_t st);
+hipError_t launch_prefilter(const ScanPlan *d_plan, int n_slots, uint32_t *bits, int n_wg, hipStream_t st);
 hipError_t launch_part_fix(const PartHistPlan &P, hipStream_t st);
 
 #ifdef __HIPCC__

@@ -244,7 +244,8 @@ __device__ __forceinline__ uint32_t packed_udiv(uint32_t n, uint32_t d, double i
 template <int NF, int NG, int NA, int MODE, bool TIME, bool NUL, bool FRESH = false>
 __device__ __forceinline__ void packed_row(const FastPlan &P0, const PackedTile<NF> &f, const PackedTile<NG> &g,
                                            const PackedTile<NA> &a, const PackedTile<1> &t, const int r, bool pass, int64_t *lds,
-                                           const FastLds &L, uint32_t &matched, uint32_t &overflow) {
+                                           const FastLds &L, uint32_t &matched, uint32_t &overflow, const uint32_t xpop = 0xFu) {
+    if (NUL) pass = pass & ((xpop >> r) & 1u);  // the filter pre-pass's verdict (FastPlan::xvalid; all ones without one)
     // no short-circuit anywhere: one predicate, one exec-masked region per row
 #pragma unroll
     for (int c = 0; c < NF; c++) {
@@ -440,6 +441,7 @@ __global__ __launch_bounds__(kWgThreads, SYBL_PACKED_WAVES_PER_EU) void k_scan_p
             PackedRaw<NG> rg;
             PackedRaw<NA> ra;
             PackedRaw<1> rt;
+            uint32_t xw = 0xFFFFFFFFu, xpop = 0xFu;  // (NUL) the pre-pass bitmap's word / the lane's four bits of it
             if (kPackedLate && !NUL && NF > 0 && NG + NA + (TIME ? 1 : 0) > 0) {
                 // Late materialisation (the reference's row loop leaves a row at its first failing filter, aggregate.go:105-116):
                 // the filter columns run one tile ahead of the key / aggregation / time columns, the tile's predicate is
@@ -531,7 +533,9 @@ __global__ __launch_bounds__(kWgThreads, SYBL_PACKED_WAVES_PER_EU) void k_scan_p
             uint32_t r = tid * kPackedRows;
             if (r < n) {
                 packed_issue_all<NF, NG, NA, TIME, G1, NUL, FRESH>(P, B, r, rf, rg, ra, rt);
+                if (NUL && P.xvalid) xw = P.xvalid[(first + r) >> 5];
                 packed_decode_all<NF, NG, NA, TIME, G1, NUL, FRESH>(P, rf, rg, ra, rt, f, g, a, t, (uint32_t)(first + r) & 31u);
+                if (NUL) xpop = (xw >> ((uint32_t)(first + r) & 31u)) & 0xFu;
             }
             for (; r < n; r += kPackedTileRows) {
                 // the next tile's loads are in flight while this one is consumed; they are decoded
@@ -539,11 +543,13 @@ __global__ __launch_bounds__(kWgThreads, SYBL_PACKED_WAVES_PER_EU) void k_scan_p
                 const uint32_t rn = r + kPackedTileRows;
                 const bool more = rn < n;
                 if (more) packed_issue_all<NF, NG, NA, TIME, G1, NUL, FRESH>(P, B, rn, rf, rg, ra, rt);
+                if (NUL && more && P.xvalid) xw = P.xvalid[(first + rn) >> 5];
                 const uint32_t left = n - r;
 #pragma unroll
                 for (int k = 0; k < kPackedRows; k++)
-                    packed_row<NF, NG, NA, MODE, TIME, NUL, FRESH>(P, f, g, a, t, k, (uint32_t)k < left, lds, L, matched, overflow);
+                    packed_row<NF, NG, NA, MODE, TIME, NUL, FRESH>(P, f, g, a, t, k, (uint32_t)k < left, lds, L, matched, overflow, xpop);
                 if (more) packed_decode_all<NF, NG, NA, TIME, G1, NUL, FRESH>(P, rf, rg, ra, rt, f, g, a, t, (uint32_t)(first + rn) & 31u);
+                if (NUL && more) xpop = (xw >> ((uint32_t)(first + rn) & 31u)) & 0xFu;
             }
         }
     }

@@ -340,3 +340,69 @@ def test_three_and_four_aggregation_columns_run_the_packed_body(ctx, oracle, mon
             gres.free()
             query.free()
     tb.free()
+
+
+def test_set_filters_and_a_fifth_filter_column_run_the_packed_body(ctx, oracle, monkeypatch):
+    """Filters the packed row bodies do not evaluate -- set members (filter.go:252-285), a fifth and sixth filter column --
+    used to send the whole query to the plan-interpreting kernel.  They now run first (k_prefilter writes a row bitmap) and
+    the scan proper stays on the packed body, reading the bitmap like a validity word: same results as the oracle and as
+    the plan interpreter (SYBL_NO_PREFILTER)."""
+    rng = np.random.default_rng(91)
+    n = 600_000
+    ints = {k: rng.integers(0, 1000, n, dtype=np.int64) for k in ("a", "b", "c", "d", "e", "f")}
+    g = rng.integers(0, 40, n, dtype=np.int64)
+    v = rng.integers(0, 1_000_000, n, dtype=np.int64)
+    v_pop = (rng.random(n) > 0.1).astype(np.uint8)
+    # set column: 0-3 members per row out of six tags
+    cnt = rng.integers(0, 4, n)
+    off = np.zeros(n + 1, dtype=np.int64)
+    off[1:] = np.cumsum(cnt)
+    members = rng.integers(0, 6, int(off[-1])).astype(np.int32)
+    tags = ["t%d" % i for i in range(6)]
+    tb = ctx.create_table("pre")
+    for k in ints:
+        tb.add_column(k, "int", 0, 999)
+    tb.add_column("g", "int", 0, 39)
+    tb.add_column("v", "int", 0, 999_999)
+    tb.add_column("tags", "set")
+    for r0 in range(0, n, 65536):
+        r1 = min(r0 + 65536, n)
+        blk = {k: x[r0:r1] for k, x in ints.items()}
+        blk["g"] = g[r0:r1]
+        blk["v"] = (v[r0:r1], v_pop[r0:r1])
+        blk["tags"] = {"ids": members[off[r0]:off[r1]], "offsets": off[r0:r1 + 1] - off[r0], "strings": tags}
+        tb.append_block(r1 - r0, blk)
+    tb.compact()
+    names = list(ints) + ["g", "v", "tags"]
+    ocols = [{"type": "int", "data": ints[k]} for k in ints] + [{"type": "int", "data": g}, {"type": "int", "data": v, "populated": v_pop},
+                                                               {"type": "set", "data": members, "offsets": off}]
+    info = dict({k: (0, 999) for k in ints}, g=(0, 39), v=(0, 999_999))
+    six = [(k, "gt", 150) for k in ints]
+    cases = [
+        dict(filters=[("tags", "in", "t2")], groups=["g"], aggs=["v"], op="avg"),
+        dict(filters=[("tags", "in", "t1"), ("tags", "nin", "t4"), ("a", "lt", 700), ("b", "gt", 100)], groups=["g"], aggs=["v"], op="hist", want_percentiles=False),
+        dict(filters=six, groups=["g"], aggs=["v"], op="avg"),
+        dict(filters=six + [("tags", "nin", "t0")], groups=["g"], aggs=["v"], op="hist", want_percentiles=False),
+        dict(filters=[("tags", "in", "nope")], groups=["g"], aggs=["v"], op="avg"),   # a tag no row has
+    ]
+    for q in cases:
+        okw = parity.oracle_query_kwargs(names, info, q)
+        okw["filters"] = [(f[0], f[1], tags.index(f[2]) if f[2] in tags else -1) if isinstance(f[2], str) else f for f in okw["filters"]]
+        ores = oracle.run_query(ocols, **okw)
+        digests = {}
+        for pre in (True, False):
+            if pre:
+                monkeypatch.delenv("SYBL_NO_PREFILTER", raising=False)
+            else:
+                monkeypatch.setenv("SYBL_NO_PREFILTER", "1")
+            query = tb.query(**q)
+            gres = query.run()
+            st = query.stats()
+            assert st["packed_kernel"] == (1 if pre else 0), (q, st)
+            parity.compare(gres, ores, op=q.get("op", "avg"), full=False, n_aggs=1)
+            digests[pre] = (gres.matched, sorted((r["key"], r["count"], r["hists"][0]["sum"]) for r in gres.results))
+            gres.free()
+            query.free()
+        assert digests[True] == digests[False], q
+    monkeypatch.delenv("SYBL_NO_PREFILTER", raising=False)
+    tb.free()
