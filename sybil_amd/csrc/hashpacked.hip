@@ -196,7 +196,10 @@ __global__ __launch_bounds__(kWgThreads) void k_scan_hash_packed(const FastPlan 
             PackedTile<MG> g;
             PackedTile<NA> a;
             PackedTile<1> t;
-            uint32_t xw = 0xFFFFFFFFu, xpop = 0xFu;
+            // (the filter pre-pass's bitmap: as in k_scan_packed -- the word of the tile after next is fetched a tile early and
+            // a wave with no passing row in a tile loads nothing of it)
+            uint32_t xpop = 0xFu, xw_n = 0xFFFFFFFFu;
+            const bool xv = NUL && P.xvalid != nullptr;
             auto issue = [&](uint32_t r) {
                 const uint32_t r0 = __builtin_amdgcn_readfirstlane(r);
                 const uint32_t lane_row = r - r0;
@@ -206,7 +209,6 @@ __global__ __launch_bounds__(kWgThreads) void k_scan_hash_packed(const FastPlan 
                 };
                 if (NUL) {
                     const int64_t wd = (first + r) >> 5;
-                    if (P.xvalid) xw = P.xvalid[wd];
                     if (time) rt.pw[0] = P.tvalid ? P.tvalid[wd] : 0xFFFFFFFFu;
 #pragma unroll
                     for (int c = 0; c < MF; c++)
@@ -230,7 +232,6 @@ __global__ __launch_bounds__(kWgThreads) void k_scan_hash_packed(const FastPlan 
             auto decode = [&](uint32_t r) {
                 const uint32_t bit0 = (uint32_t)(first + r) & 31u;
                 if (NUL) {
-                    xpop = (xw >> bit0) & 0xFu;
                     if (time) t.pop[0] = (rt.pw[0] >> bit0) & 0xFu;
 #pragma unroll
                     for (int c = 0; c < MF; c++)
@@ -254,16 +255,23 @@ __global__ __launch_bounds__(kWgThreads) void k_scan_hash_packed(const FastPlan 
             uint32_t r = tid * kPackedRows;
             if (r < n) {
                 issue(r);
+                if (xv) {
+                    xpop = (P.xvalid[(first + r) >> 5] >> ((uint32_t)(first + r) & 31u)) & 0xFu;
+                    if (r + kPackedTileRows < n) xw_n = P.xvalid[(first + r + kPackedTileRows) >> 5];
+                }
                 decode(r);
             }
             for (; r < n; r += kPackedTileRows) {
                 const uint32_t rn = r + kPackedTileRows;
-                const bool more = rn < n;
+                const uint32_t xpop_n = xv ? (xw_n >> ((uint32_t)(first + rn) & 31u)) & 0xFu : 0xFu;
+                const bool more = rn < n && (!xv || __builtin_amdgcn_ballot_w64(xpop_n != 0) != 0);  // (wave-uniform)
                 if (more) issue(rn);
+                if (xv && rn + kPackedTileRows < n) xw_n = P.xvalid[(first + rn + kPackedTileRows) >> 5];
                 const uint32_t left = n - r;
 #pragma unroll
                 for (int k = 0; k < kPackedRows; k++) one_row(f, g, a, t, k, (uint32_t)k < left, xpop);
                 if (more) decode(rn);
+                xpop = xpop_n;
             }
         }
     }

@@ -1242,7 +1242,7 @@ struct Planner {
     int prefilter() {
         q->pre_n_slots = 0;
         pre_saved.assign((size_t)P.n_slots, 0);
-        if (getenv("SYBL_NO_PREFILTER") || q->loghist || q->hash_mode || !t->compact_mode || q->never_matches || d->n_distincts > 0) return SYBL_OK;
+        if (getenv("SYBL_NO_PREFILTER") || q->loghist || !t->compact_mode || q->never_matches || d->n_distincts > 0) return SYBL_OK;
         if (q->op == SYBL_AGG_HIST && q->want_percentiles) return SYBL_OK;  // (the partitioned histograms have no NUL variants)
         std::vector<int> move;
         int n_fast = 0;
@@ -1275,9 +1275,12 @@ struct Planner {
         q->pre_n_slots = (int)move.size();
         return SYBL_OK;
     }
+    // (called behind select_fast_path and select_hash_fast: a direct-mapped query must have taken a packed LDS body, a
+    // hashed one the packed hash body -- both have variants that read validity words, and with them the bitmap)
     void prefilter_commit() {
         if (!q->pre_n_slots) return;
-        if (q->fast && (q->fast_packed || q->fast_packed_n) && q->fplan.hist_lds == 0) {
+        const bool ok = q->hash_mode ? (q->hash_fast && q->hash_packed) : (q->fast && (q->fast_packed || q->fast_packed_n) && q->fplan.hist_lds == 0);
+        if (ok) {
             q->fplan.nul = 1;  // (the variants that read validity words read the bitmap)
             return;            // (the bitmap itself: device_copies)
         }
@@ -1286,6 +1289,7 @@ struct Planner {
             if (pre_saved[(size_t)s]) P.slot[s].flags = pre_saved[(size_t)s];
         q->pre_n_slots = 0;
         select_fast_path(t, q, slot_col);
+        select_hash_fast(t, q, slot_col);
     }
 
     int strategy() {
@@ -1425,8 +1429,8 @@ struct Planner {
             }
         }
         select_fast_path(t, q, slot_col);
-        prefilter_commit();
         select_hash_fast(t, q, slot_col);
+        prefilter_commit();
         if ((rc = select_part_hist(t, q, slot_col, rows_scanned))) return rc;
         q->stats.rows_scanned = rows_scanned;
         q->stats.blocks_skipped = skipped;

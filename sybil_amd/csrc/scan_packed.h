@@ -441,7 +441,11 @@ __global__ __launch_bounds__(kWgThreads, SYBL_PACKED_WAVES_PER_EU) void k_scan_p
             PackedRaw<NG> rg;
             PackedRaw<NA> ra;
             PackedRaw<1> rt;
-            uint32_t xw = 0xFFFFFFFFu, xpop = 0xFu;  // (NUL) the pre-pass bitmap's word / the lane's four bits of it
+            // (NUL) the filter pre-pass's bitmap (FastPlan::xvalid): the lane's four bits for the tile being consumed, and
+            // the word of the tile after it -- fetched a tile early, so that a wave none of whose 256 rows passed the
+            // pre-pass issues no load at all for that tile
+            uint32_t xpop = 0xFu, xw_n = 0xFFFFFFFFu;
+            const bool xv = NUL && P.xvalid != nullptr;
             if (kPackedLate && !NUL && NF > 0 && NG + NA + (TIME ? 1 : 0) > 0) {
                 // Late materialisation (the reference's row loop leaves a row at its first failing filter, aggregate.go:105-116):
                 // the filter columns run one tile ahead of the key / aggregation / time columns, the tile's predicate is
@@ -533,23 +537,26 @@ __global__ __launch_bounds__(kWgThreads, SYBL_PACKED_WAVES_PER_EU) void k_scan_p
             uint32_t r = tid * kPackedRows;
             if (r < n) {
                 packed_issue_all<NF, NG, NA, TIME, G1, NUL, FRESH>(P, B, r, rf, rg, ra, rt);
-                if (NUL && P.xvalid) xw = P.xvalid[(first + r) >> 5];
+                if (xv) {
+                    xpop = (P.xvalid[(first + r) >> 5] >> ((uint32_t)(first + r) & 31u)) & 0xFu;
+                    if (r + kPackedTileRows < n) xw_n = P.xvalid[(first + r + kPackedTileRows) >> 5];
+                }
                 packed_decode_all<NF, NG, NA, TIME, G1, NUL, FRESH>(P, rf, rg, ra, rt, f, g, a, t, (uint32_t)(first + r) & 31u);
-                if (NUL) xpop = (xw >> ((uint32_t)(first + r) & 31u)) & 0xFu;
             }
             for (; r < n; r += kPackedTileRows) {
                 // the next tile's loads are in flight while this one is consumed; they are decoded
                 // (the first use of the loaded registers) only after the rows below
                 const uint32_t rn = r + kPackedTileRows;
-                const bool more = rn < n;
+                const uint32_t xpop_n = xv ? (xw_n >> ((uint32_t)(first + rn) & 31u)) & 0xFu : 0xFu;
+                const bool more = rn < n && (!xv || __builtin_amdgcn_ballot_w64(xpop_n != 0) != 0);  // (wave-uniform)
                 if (more) packed_issue_all<NF, NG, NA, TIME, G1, NUL, FRESH>(P, B, rn, rf, rg, ra, rt);
-                if (NUL && more && P.xvalid) xw = P.xvalid[(first + rn) >> 5];
+                if (xv && rn + kPackedTileRows < n) xw_n = P.xvalid[(first + rn + kPackedTileRows) >> 5];
                 const uint32_t left = n - r;
 #pragma unroll
                 for (int k = 0; k < kPackedRows; k++)
                     packed_row<NF, NG, NA, MODE, TIME, NUL, FRESH>(P, f, g, a, t, k, (uint32_t)k < left, lds, L, matched, overflow, xpop);
                 if (more) packed_decode_all<NF, NG, NA, TIME, G1, NUL, FRESH>(P, rf, rg, ra, rt, f, g, a, t, (uint32_t)(first + rn) & 31u);
-                if (NUL && more) xpop = (xw >> ((uint32_t)(first + rn) & 31u)) & 0xFu;
+                xpop = xpop_n;
             }
         }
     }

@@ -12,7 +12,9 @@ wl = synth.WORKLOADS["cfg3_filter3_group2_stddev"]
 t = ctx.synth_table("a", synth.SEED, rows, 0, rows, synth.synth_cols(wl["columns"] + ["c09", "c03"]))
 t.compact()
 f5 = wl["query"]["filters"] + [("c09", "lt", 450), ("c03", "gt", 1000)]
-cases = [("config 3 + filters on c09 and c03 (five filter columns)", dict(wl["query"], filters=f5, order_by=None))]
+f5s = wl["query"]["filters"] + [("c09", "lt", 450), ("c03", "gt", 65208)]  # the fifth filter column passes 0.5 % of the rows
+cases = [("config 3 + filters on c09 and c03 (five filter columns)", dict(wl["query"], filters=f5, order_by=None)),
+         ("the same with c03 > 65208 (the pre-pass column passes 0.5 %: most tiles hold no passing row)", dict(wl["query"], filters=f5s, order_by=None))]
 for label, q in cases:
     for env in ({}, {"SYBL_NO_PREFILTER": "1"}):
         os.environ.update(env)
