@@ -362,7 +362,8 @@ def main():
             out = {"dt": dt, "stats": stats, "kernel_ms": (sum(scan_ms) / len(scan_ms)) if scan_ms else stats["scan_ms"],
                    "host_ms": dict({k: round(sum(v) / len(v), 3) if v else None for k, v in host_ms.items()},
                                    finish_median=round(sorted(host_ms["finish"])[len(host_ms["finish"]) // 2], 3) if host_ms["finish"] else None,
-                                   finish_max=round(max(host_ms["finish"]), 3) if host_ms["finish"] else None)}
+                                   finish_max=round(max(host_ms["finish"]), 3) if host_ms["finish"] else None,
+                                   **({"finish_all": [round(x, 2) for x in host_ms["finish"]]} if os.environ.get("SYBL_BENCH_TRACE") else {}))}
             if rank == 0:
                 # every step scans the same table: the merged result must not change from step to step (it
                 # would if the all-reduce ever ran ahead of a rank's scan) and group counts must add up

@@ -145,6 +145,10 @@ static bool fill_fast_columns(Table *t, Query *q, const std::vector<int> &slot_c
     // else the GEN kernels (any width); the plain kernels read canonical int64 only
     bool any_packed = false, all_narrow = true;
     bool heavy = false;  // GEN features k_scan_packed<NUL> leaves out: weights, h.Max
+    // what the NUL variants of the packed bodies exist for: validity bits, id masks, neq constants, per-aggregation counts,
+    // outliers.  A fully populated str column as a group key needs none of it (its ids are offsets like any int's): such
+    // queries run the plain packed body -- with late materialisation -- instead of paying for the NUL one (round 4)
+    bool nul_needed = false;
     if (packed) *packed = false;
     for (size_t s = 0; s < slot_col.size(); s++) {
         const SlotDesc &sd = P.slot[s];
@@ -160,6 +164,7 @@ static bool fill_fast_columns(Table *t, Query *q, const std::vector<int> &slot_c
             bool str_ok = c->type == SYBL_STR_VAL && (r2 == kSlotGroup || r2 == kSlotIdMask || r2 == (kSlotGroup | kSlotIdMask));
             if (c->type != SYBL_INT_VAL && !str_ok) return false;
             *gen = true;
+            if (c->d_valid || c->has_missing || (sd.flags & kSlotIdMask)) nul_needed = true;
         }
         uint32_t roles = sd.flags & (kSlotFilter | kSlotGroup | kSlotAgg);
         if (sd.flags & (kSlotSet | kSlotDict)) return false;
@@ -187,11 +192,13 @@ static bool fill_fast_columns(Table *t, Query *q, const std::vector<int> &slot_c
             FP.nneq[nf] = sd.n_neq;
             for (int k = 0; k < sd.n_neq; k++) FP.neq[nf][k] = sd.neq[k];
             *gen = true;  // the neq constants are compared in the GEN / NUL row bodies
+            nul_needed = true;
         }
         if (sd.flags & kSlotIdMask) {
             FP.fmask[nf] = sd.idmask;
             FP.fmask_bits[nf] = sd.idmask_bits;
             *gen = true;
+            nul_needed = true;
         }
         nf++;
     }
@@ -202,6 +209,7 @@ static bool fill_fast_columns(Table *t, Query *q, const std::vector<int> &slot_c
             if (slot_col[k] == gi.col) s = (int)k;
         const SlotDesc &sd = P.slot[s];
         if (sd.gmissing >= 0 && !allow_gen) return false;
+        if (sd.gmissing >= 0 || sd.gvalues != sd.gcard) nul_needed = true;
         FP.gvalid[ng] = sd.valid;
         FP.gwid[ng] = sd.width;
         FP.gbase[ng] = sd.vbase;
@@ -225,6 +233,7 @@ static bool fill_fast_columns(Table *t, Query *q, const std::vector<int> &slot_c
         // (part: the scan half of the partitioned histograms only emits v - h.Min; outliers are k_part_hist's business)
         if ((A.f_smp >= 0 || (A.f_out >= 0 && !part)) && !allow_gen) return false;
         if (A.f_out >= 0 && !part) *gen = true;  // outliers: the GEN body, or the NUL variants of the packed bodies
+        if (A.f_out >= 0 && !part) nul_needed = true;
         if (q->op == SYBL_AGG_HIST && A.m_max >= 0) {
             *gen = true;  // h.Max lives in the GEN body
             heavy = true;
@@ -233,6 +242,7 @@ static bool fill_fast_columns(Table *t, Query *q, const std::vector<int> &slot_c
         if (A.f_cnt >= 0 || A.f_pop >= 0) {
             if (!allow_gen) return false;
             *gen = true;  // rejects / missing values: per-aggregation counts
+            nul_needed = true;
         }
         if (q->op == SYBL_AGG_HIST) {
             if (A.big_div || A.bucket_size >= ((int64_t)1 << 32)) return false;
@@ -293,7 +303,7 @@ static bool fill_fast_columns(Table *t, Query *q, const std::vector<int> &slot_c
     if (any_packed) {
         if ((!*gen || (allow_gen && !heavy)) && all_narrow && packed && fill_packed(t, q, slot_col, FP, nf, ng, na)) {
             *packed = true;
-            FP.nul = *gen ? 1 : 0;  // missing rows / str ids / reject gate: k_scan_packed<NUL>
+            FP.nul = nul_needed || getenv("SYBL_FORCE_NUL") ? 1 : 0;  // missing rows / id masks / reject gate: k_scan_packed<NUL> (SYBL_FORCE_NUL: A/B)
         } else if (allow_gen) {
             *gen = true;
         } else {

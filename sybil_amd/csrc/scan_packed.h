@@ -446,6 +446,20 @@ __global__ __launch_bounds__(kWgThreads, SYBL_PACKED_WAVES_PER_EU) void k_scan_p
             // pre-pass issues no load at all for that tile
             uint32_t xpop = 0xFu, xw_n = 0xFFFFFFFFu;
             const bool xv = NUL && P.xvalid != nullptr;
+            // The NUL row body costs twice the plain one (config 3 forced through it: 5.8 against 2.85 ms per 1e9 rows) --
+            // validity bits, the MISSING digit, per-aggregation counts, the outlier test, each a branch per row and column.
+            // Most tiles of most tables need none of it: a str group column, or a bitmap that is all ones where it is read.
+            // `light` (wave-uniform, once): the plan itself asks for nothing the plain body lacks; a tile all of whose
+            // values are populated (and pass the pre-pass) then runs the plain body.
+            bool light = NUL;
+            if (NUL) {
+#pragma unroll
+                for (int c = 0; c < NF; c++) light = light && P.fmask[c] == nullptr && P.npneq[c] == 0;
+#pragma unroll
+                for (int c = 0; c < NG; c++) light = light && (uint32_t)P.gvalues[c] == P.gcard[c];
+#pragma unroll
+                for (int c = 0; c < NA; c++) light = light && P.f_pop[c] < 0 && P.f_cnt[c] < 0 && P.f_out[c] < 0;
+            }
             if (kPackedLate && !NUL && NF > 0 && NG + NA + (TIME ? 1 : 0) > 0) {
                 // Late materialisation (the reference's row loop leaves a row at its first failing filter, aggregate.go:105-116):
                 // the filter columns run one tile ahead of the key / aggregation / time columns, the tile's predicate is
@@ -552,9 +566,27 @@ __global__ __launch_bounds__(kWgThreads, SYBL_PACKED_WAVES_PER_EU) void k_scan_p
                 if (more) packed_issue_all<NF, NG, NA, TIME, G1, NUL, FRESH>(P, B, rn, rf, rg, ra, rt);
                 if (xv && rn + kPackedTileRows < n) xw_n = P.xvalid[(first + rn + kPackedTileRows) >> 5];
                 const uint32_t left = n - r;
+                bool plain_tile = false;
+                if (NUL && light) {
+                    uint32_t allpop = xpop;
+                    if (TIME) allpop &= t.pop[0];
 #pragma unroll
-                for (int k = 0; k < kPackedRows; k++)
-                    packed_row<NF, NG, NA, MODE, TIME, NUL, FRESH>(P, f, g, a, t, k, (uint32_t)k < left, lds, L, matched, overflow, xpop);
+                    for (int c = 0; c < NF; c++) allpop &= f.pop[c];
+#pragma unroll
+                    for (int c = 0; c < NG; c++) allpop &= g.pop[c];
+#pragma unroll
+                    for (int c = 0; c < NA; c++) allpop &= a.pop[c];
+                    plain_tile = __builtin_amdgcn_ballot_w64(allpop != 0xFu) == 0;  // (wave-uniform)
+                }
+                if (plain_tile) {
+#pragma unroll
+                    for (int k = 0; k < kPackedRows; k++)
+                        packed_row<NF, NG, NA, MODE, TIME, false, FRESH>(P, f, g, a, t, k, (uint32_t)k < left, lds, L, matched, overflow);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < kPackedRows; k++)
+                        packed_row<NF, NG, NA, MODE, TIME, NUL, FRESH>(P, f, g, a, t, k, (uint32_t)k < left, lds, L, matched, overflow, xpop);
+                }
                 if (more) packed_decode_all<NF, NG, NA, TIME, G1, NUL, FRESH>(P, rf, rg, ra, rt, f, g, a, t, (uint32_t)(first + rn) & 31u);
                 xpop = xpop_n;
             }
