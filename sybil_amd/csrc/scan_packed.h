@@ -241,7 +241,9 @@ __device__ __forceinline__ uint32_t packed_udiv(uint32_t n, uint32_t d, double i
     return q;
 }
 
-template <int NF, int NG, int NA, int MODE, bool TIME, bool NUL, bool FRESH = false>
+// (OUT: the plain body with the outlier test -- a value beyond the last bucket is clipped and remembered, hist_basic.go:132-135:
+// what a fully populated tile of a NUL kernel runs when outliers are the only thing its plan asks of the NUL body)
+template <int NF, int NG, int NA, int MODE, bool TIME, bool NUL, bool FRESH = false, bool OUT = false>
 __device__ __forceinline__ void packed_row(const FastPlan &P0, const PackedTile<NF> &f, const PackedTile<NG> &g,
                                            const PackedTile<NA> &a, const PackedTile<1> &t, const int r, bool pass, int64_t *lds,
                                            const FastLds &L, uint32_t &matched, uint32_t &overflow, const uint32_t xpop = 0xFu) {
@@ -332,7 +334,7 @@ __device__ __forceinline__ void packed_row(const FastPlan &P0, const PackedTile<
             // bucket_value := (value - h.Min) / BucketSize, hist_basic.go:130; the planner guarantees
             // 0 <= value - h.Min < 2^32 and that no value reaches len(Values)
             uint32_t b = packed_udiv(u + P.adoff[c], P.bucket_size[c], P.pinv_bucket[c]);
-            if (NUL && b >= (uint32_t)P.n_values[c]) {
+            if ((NUL || OUT) && b >= (uint32_t)P.n_values[c]) {
                 // Outlier (hist_basic.go:132-135; BucketSize = size / 1000 truncates, so the top of many a column's range
                 // lies beyond the last bucket): clipped into the last bucket AND remembered as exact n, sum(o), sum(o^2)
                 // in four 32-bit limbs (+ the value itself in the log when bucket arrays are kept); a cold path
@@ -451,14 +453,17 @@ __global__ __launch_bounds__(kWgThreads, SYBL_PACKED_WAVES_PER_EU) void k_scan_p
             // Most tiles of most tables need none of it: a str group column, or a bitmap that is all ones where it is read.
             // `light` (wave-uniform, once): the plan itself asks for nothing the plain body lacks; a tile all of whose
             // values are populated (and pass the pre-pass) then runs the plain body.
-            bool light = NUL;
+            bool light = NUL, outliers = false;
             if (NUL) {
 #pragma unroll
                 for (int c = 0; c < NF; c++) light = light && P.fmask[c] == nullptr && P.npneq[c] == 0;
 #pragma unroll
                 for (int c = 0; c < NG; c++) light = light && (uint32_t)P.gvalues[c] == P.gcard[c];
 #pragma unroll
-                for (int c = 0; c < NA; c++) light = light && P.f_pop[c] < 0 && P.f_cnt[c] < 0 && P.f_out[c] < 0;
+                for (int c = 0; c < NA; c++) {
+                    light = light && P.f_pop[c] < 0 && P.f_cnt[c] < 0;
+                    outliers = outliers || P.f_out[c] >= 0;  // (BucketSize = size / 1000 truncates: an ordinary column's top values)
+                }
             }
             if (kPackedLate && !NUL && NF > 0 && NG + NA + (TIME ? 1 : 0) > 0) {
                 // Late materialisation (the reference's row loop leaves a row at its first failing filter, aggregate.go:105-116):
@@ -578,10 +583,14 @@ __global__ __launch_bounds__(kWgThreads, SYBL_PACKED_WAVES_PER_EU) void k_scan_p
                     for (int c = 0; c < NA; c++) allpop &= a.pop[c];
                     plain_tile = __builtin_amdgcn_ballot_w64(allpop != 0xFu) == 0;  // (wave-uniform)
                 }
-                if (plain_tile) {
+                if (plain_tile && !outliers) {
 #pragma unroll
                     for (int k = 0; k < kPackedRows; k++)
                         packed_row<NF, NG, NA, MODE, TIME, false, FRESH>(P, f, g, a, t, k, (uint32_t)k < left, lds, L, matched, overflow);
+                } else if (plain_tile) {
+#pragma unroll
+                    for (int k = 0; k < kPackedRows; k++)
+                        packed_row<NF, NG, NA, MODE, TIME, false, FRESH, true>(P, f, g, a, t, k, (uint32_t)k < left, lds, L, matched, overflow);
                 } else {
 #pragma unroll
                     for (int k = 0; k < kPackedRows; k++)
