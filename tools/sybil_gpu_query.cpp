@@ -129,8 +129,9 @@ int main(int argc, char **argv) {
     sybl_table *tab = nullptr;
     std::vector<const char *> cptr;
     for (auto &c : cols) cptr.push_back(c.c_str());
-    if (sybl_table_open(ctx, f["dir"].c_str(), f["table"].c_str(), cptr.empty() ? nullptr : cptr.data(), (int32_t)cptr.size(), 0, 1,
-                        &tab))
+    // (compact storage: the columns at the narrowest width that holds their range -- what the packed scan kernels read)
+    if (sybl_table_open_flags(ctx, f["dir"].c_str(), f["table"].c_str(), cptr.empty() ? nullptr : cptr.data(), (int32_t)cptr.size(), 0, 1,
+                              SYBL_OPEN_COMPACT, &tab))
         return die("open table");
 
     static const std::map<std::string, int> opcode = {{"gt", SYBL_OP_GT}, {"lt", SYBL_OP_LT}, {"eq", SYBL_OP_EQ},
