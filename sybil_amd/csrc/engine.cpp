@@ -76,7 +76,13 @@ hipError_t create_side_stream(hipStream_t *out, int toward) {
 
 static void free_query(Query *q) {
     if (!q) return;
-    query_finish_lazy_results(q);  // (their rows are built from this query's metadata: now, or never)
+    if (!q->table_gone) {
+        query_finish_lazy_results(q);  // (their rows are built from this query's metadata and its table's dictionaries: now, or never)
+        if (q->t) {
+            auto &v = q->t->queries;
+            v.erase(std::remove(v.begin(), v.end(), q), v.end());
+        }
+    }
     if (q->d_plan) hipFree(q->d_plan);
     if (q->d_preplan) hipFree(q->d_preplan);
     if (q->d_prebits) hipFree(q->d_prebits);
@@ -424,6 +430,7 @@ int sybl_query_prepare(sybl_table *t, const sybl_query_desc *desc, sybl_query **
         return rc;
     }
     q->table_version = t->version;  // after planning: building a group dictionary does not count
+    t->queries.push_back(q);
     *out = q;
     return SYBL_OK;
 }

@@ -132,6 +132,7 @@ struct LoadedBlock {
     int64_t index = -1;              // into Table::blocks; -1: skipped as broken / unreadable
 };
 
+struct Query;
 struct Table {
     Ctx *ctx = nullptr;
     std::string name;
@@ -152,6 +153,7 @@ struct Table {
     std::string src_dir;           // <dir>/<table> the table was opened from ("" = built through the ABI)
     int src_rank = 0, src_nranks = 1;
     std::vector<LoadedBlock> loaded;
+    std::vector<Query *> queries;  // prepared queries that are alive (a table that goes away first has their pending lazy results built)
     Column *find(const char *name) const;
 };
 
@@ -401,6 +403,7 @@ struct Query {
     ScanPlan *d_preplan = nullptr;
     uint32_t *d_prebits = nullptr;
     int pre_n_slots = 0;
+    bool table_gone = false;       // sybl_table_free ran before sybl_query_free: nothing of q->t may be touched any more
     std::vector<Result *> lazy_results;     // results whose rows are still to be built and need this query for it (result.cpp)
     int64_t h_max_words = 0;                // capacity of h_max
     // role-specialised kernel (scan_fast.h)

@@ -764,6 +764,11 @@ void sybl_table_free(sybl_table *t) {
     if (!t) return;
     hipSetDevice(t->ctx->device);
     hipStreamSynchronize(t->ctx->stream);
+    // queries that outlive their table: results of theirs whose rows are still to be built get them now (result.cpp)
+    for (Query *q : t->queries) {
+        query_finish_lazy_results(q);
+        q->table_gone = true;
+    }
     for (auto &c : t->cols) column_free(c.get());
     if (t->d_blocks) hipFree(t->d_blocks);
     if (t->d_scratch) hipFree(t->d_scratch);
@@ -980,6 +985,8 @@ int sybl_table_set_dict(sybl_table *t, const char *name, const char *const *stri
     Column *c = t->find(name);
     if (!c || c->type == SYBL_INT_VAL) return fail(SYBL_E_INVAL, "unknown str/set column '%s'", name ? name : "(null)");
     SYBL_HIP(hipSetDevice(t->ctx->device));
+    // (results whose rows are still to be built read this dictionary by the ids it has now)
+    for (Query *q : t->queries) query_finish_lazy_results(q);
     std::vector<std::string> nd;
     std::unordered_map<std::string, int32_t> nix;
     for (int64_t i = 0; i < n; i++) {

@@ -313,3 +313,34 @@ def test_time_series_through_the_hash_table(ctx, oracle, monkeypatch):
     gres.free()
     query.free()
     t.free()
+
+
+@pytest.mark.parametrize("first", ["query", "table", "rescan"])
+def test_lazy_rows_of_a_hashed_result_outlive_query_and_table(ctx, oracle, first):
+    """A hash group-by's result of >= 2048 groups builds its rows when first asked for, from the query's group columns and
+    the table's dictionaries: freeing the query (or the table, or scanning the query again) before anybody looked at the
+    rows must build them then -- the result stays valid, and equals the oracle's."""
+    rng = np.random.default_rng(3)
+    n = 200_000
+    cols = {"k": rng.integers(-(1 << 38), 1 << 38, n, dtype=np.int64) // 7 * 7, "v": rng.integers(0, 1000, n, dtype=np.int64)}
+    cols["k"][: n // 2] = cols["k"][n // 2:]  # (every key twice)
+    tb = _table(ctx, cols, info={"v": (0, 999)})
+    q = tb.query(groups=["k"], aggs=["v"], op="avg")
+    r = q.scan().finalize()
+    assert q.stats()["strategy"] == 7
+    if first == "query":
+        q.free()
+        tb.free()
+    elif first == "table":
+        tb.free()
+        q.free()
+    else:
+        q.scan()
+        ctx.sync()
+    o = oracle.run_query(_ocols(cols), groups=[0], aggs=[(1, 0, 999)], op="avg")
+    parity.compare(r, o, op="avg", full=False, n_aggs=1)
+    assert len(r.results) == n // 2
+    r.free()
+    if first == "rescan":
+        q.free()
+        tb.free()
