@@ -284,8 +284,17 @@ static int scan(Query *q) {
     SYBL_HIP(hipEventRecord(q->ev[0], st));
     if (ran && q->pre_n_slots) {
         // the filters the packed bodies do not evaluate: a row bitmap first (planner.cpp: Planner::prefilter)
-        e = launch_prefilter(q->d_preplan, q->pre_n_slots, q->d_prebits, q->n_wg, st);
-        if (e != hipSuccess) return hip_fail(e, "k_prefilter");
+        bool wrote = false;
+        if (q->pre_generic_slots) {
+            e = launch_prefilter(q->d_preplan, q->pre_generic_slots, q->d_prebits, q->n_wg, st);
+            if (e != hipSuccess) return hip_fail(e, "k_prefilter");
+            wrote = true;
+        }
+        for (size_t k = 0; k < q->pre_fps.size(); k++) {
+            e = launch_prefilter_packed(q->pre_fps[k], q->pre_fp_nf[k], q->d_prebits, wrote, q->n_wg, st);
+            if (e != hipSuccess) return hip_fail(e, "k_prefilter_packed");
+            wrote = true;
+        }
     }
     if (ran && q->hash_mode) {
         if (q->hash_fast) {

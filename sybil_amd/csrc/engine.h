@@ -402,7 +402,10 @@ struct Query {
     ScanPlan preplan;
     ScanPlan *d_preplan = nullptr;
     uint32_t *d_prebits = nullptr;
-    int pre_n_slots = 0;
+    int pre_n_slots = 0;            // slots of the pre-pass in all
+    int pre_generic_slots = 0;      // ... of them evaluated by the generic k_prefilter (set members, 8-byte columns): preplan's slots
+    std::vector<FastPlan> pre_fps;  // ... the others: <= kFastMaxF filter columns per launch of k_prefilter_packed
+    std::vector<int> pre_fp_nf;
     bool table_gone = false;       // sybl_table_free ran before sybl_query_free: nothing of q->t may be touched any more
     std::vector<Result *> lazy_results;     // results whose rows are still to be built and need this query for it (result.cpp)
     int64_t h_max_words = 0;                // capacity of h_max
@@ -444,6 +447,7 @@ int comm_allreduce_sum(Ctx *ctx, int64_t *buf, size_t words);
 // hashgroup.hip
 hipError_t launch_scan_hash(const ScanPlan *d_plan, int n_slots, int n_wg, size_t lds_bytes, hipStream_t st);
 hipError_t launch_scan_packed_n(const FastPlan &P, int nf, int ng, int na, int mode, bool time, int n_wg, size_t lds_bytes, hipStream_t st);
+hipError_t launch_prefilter_packed(const FastPlan &P, int nf, uint32_t *bits, bool and_into, int n_wg, hipStream_t st);
 hipError_t launch_scan_hash_packed(const FastPlan &P, uint64_t *keys, int nf, int ng, int na, int mode, bool time, int L, int F, int M, int n_wg,
                                    size_t lds_bytes, hipStream_t st);
 hipError_t launch_scan_hash_fast(const FastPlan &P, uint64_t *keys, int nf, int ng, int na, int mode, bool time, int L, int F, int M, int n_wg,

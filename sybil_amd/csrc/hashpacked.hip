@@ -356,6 +356,93 @@ static hipError_t packed_n_mode(const FastPlan &P, int nf, int ng, int mode, int
 #undef SYBL_PN
 }
 
+// k_prefilter_packed: the filter pre-pass (planner.cpp: Planner::prefilter) for plain filter columns over compact storage
+// -- ranges, neq constants, dictionary-id masks, validity: what packed_row<NUL> evaluates, four rows per lane in the offset
+// domain -- instead of the generic two-rows-per-lane tile (k_prefilter, kernels.hip: 2.4 ms per 1e9 rows of one 2-byte
+// column).  Up to kFastMaxF columns per launch; AND: a later launch of the same pre-pass narrows the bitmap of an earlier
+// one.  A lane's four rows are a nibble of the word eight lanes share: three butterfly steps, the first lane stores.
+template <bool AND>
+__global__ __launch_bounds__(kWgThreads) void k_prefilter_packed(const FastPlan P, const int nf, uint32_t *bits) {
+    const uint32_t tid = threadIdx.x;
+    constexpr int MF = kFastMaxF;
+    const int s0 = P.wg_seg_begin[blockIdx.x], s1 = P.wg_seg_begin[blockIdx.x + 1];
+    for (int si = s0; si < s1; si++) {
+        const Segment seg = P.segs[si];
+        for (int64_t c0 = 0; c0 < seg.n; c0 += kPackedChunkRows) {
+            const int64_t first = seg.start + c0;
+            const uint32_t n = (uint32_t)(seg.n - c0 < kPackedChunkRows ? seg.n - c0 : kPackedChunkRows);
+            PackedRaw<MF> rf;
+            PackedTile<MF> f;
+            auto issue = [&](uint32_t r) {
+                const uint32_t r0 = __builtin_amdgcn_readfirstlane(r);
+                const uint32_t lane_row = r - r0;
+                const int64_t wd = (first + r) >> 5;
+#pragma unroll
+                for (int c = 0; c < MF; c++)
+                    if (c < nf) {
+                        rf.pw[c] = P.fvalid[c] ? P.fvalid[c][wd] : 0xFFFFFFFFu;
+                        const int ws = P.fwid[c] >> 1;
+                        packed_issue((const uint8_t *)P.fcol[c] + (size_t)(first + r0) * (size_t)P.fwid[c], ws, lane_row << ws, rf.v[c]);
+                    }
+            };
+            auto decode = [&](uint32_t r) {
+                const uint32_t bit0 = (uint32_t)(first + r) & 31u;
+#pragma unroll
+                for (int c = 0; c < MF; c++)
+                    if (c < nf) {
+                        f.pop[c] = (rf.pw[c] >> bit0) & 0xFu;
+                        packed_decode(P.fwid[c], rf.v[c], f.u[c]);
+                    }
+            };
+            uint32_t r = tid * kPackedRows;
+            if (r < n) {
+                issue(r);
+                decode(r);
+            }
+            for (; r < n; r += kPackedTileRows) {
+                const uint32_t rn = r + kPackedTileRows;
+                const bool more = rn < n;
+                if (more) issue(rn);
+                const uint32_t left = n - r;
+                uint32_t nib = 0;
+#pragma unroll
+                for (int k = 0; k < kPackedRows; k++) {
+                    bool pass = (uint32_t)k < left;
+#pragma unroll
+                    for (int c = 0; c < MF; c++) {
+                        if (c >= nf) break;
+                        const uint32_t u = f.u[c][k];
+                        bool ok = (u >= P.plo[c]) & (u <= P.phi[c]);
+                        if (P.fmask[c]) {
+                            const uint32_t id = u + (uint32_t)P.fbase[c];
+                            ok = id < (uint32_t)P.fmask_bits[c];
+                            if (ok) ok = (P.fmask[c][id >> 5] >> (id & 31)) & 1u;
+                        }
+                        for (int j = 0; j < P.npneq[c]; j++) ok = ok & (u != P.pneq[c][j]);
+                        ok = ok & ((f.pop[c] >> k) & 1u);
+                        pass = pass & ok;
+                    }
+                    nib |= pass ? 1u << k : 0u;
+                }
+                uint32_t v = nib << ((uint32_t)(first + r) & 31u);
+#pragma unroll
+                for (int o = 1; o < 8; o <<= 1) v |= __shfl_xor(v, o, 64);
+                if ((tid & 7u) == 0) {
+                    uint32_t *w = bits + ((first + r) >> 5);
+                    *w = AND ? (*w & v) : v;
+                }
+                if (more) decode(rn);
+            }
+        }
+    }
+}
+
+hipError_t launch_prefilter_packed(const FastPlan &P, int nf, uint32_t *bits, bool and_into, int n_wg, hipStream_t st) {
+    if (and_into) hipLaunchKernelGGL(k_prefilter_packed<true>, dim3(n_wg), dim3(kWgThreads), 0, st, P, nf, bits);
+    else hipLaunchKernelGGL(k_prefilter_packed<false>, dim3(n_wg), dim3(kWgThreads), 0, st, P, nf, bits);
+    return hipGetLastError();
+}
+
 hipError_t launch_scan_packed_n(const FastPlan &P, int nf, int ng, int na, int mode, bool time, int n_wg, size_t lds_bytes, hipStream_t st) {
     switch (na) {
     case 0: return packed_n_mode<0>(P, nf, ng, mode, time ? 1 : 0, n_wg, lds_bytes, st);

@@ -1271,17 +1271,60 @@ struct Planner {
         R.time_slot = -1;
         R.weight_slot = -1;
         R.f_samples = -1;
-        R.n_slots = (int)move.size();
+        q->pre_fps.clear();
+        q->pre_fp_nf.clear();
+        int n_generic = 0;
         for (size_t k = 0; k < move.size(); k++) {
-            SlotDesc &dst = R.slot[k];
-            dst = P.slot[move[k]];
-            dst.flags &= (kSlotFilter | kSlotSet);
-            dst.gmissing = -1;
-            dst.gmissing64 = -1;
-            dst.agg_index = -1;
+            const SlotDesc &src = P.slot[move[k]];
+            const Column *c = t->cols[(size_t)slot_col[(size_t)move[k]]].get();
+            // plain filter columns of <= 4 stored bytes: the offset-domain pre-pass (k_prefilter_packed), four to a launch
+            const bool packed_ok = !(src.flags & kSlotSet) && c->type != SYBL_SET_VAL && c->elem <= 4 && !getenv("SYBL_NO_PREFILTER_PACKED");
+            if (packed_ok) {
+                if (q->pre_fps.empty() || q->pre_fp_nf.back() == kFastMaxF) {
+                    q->pre_fps.emplace_back();
+                    memset(&q->pre_fps.back(), 0, sizeof(FastPlan));
+                    q->pre_fp_nf.push_back(0);
+                }
+                FastPlan &FP = q->pre_fps.back();
+                const int i = q->pre_fp_nf.back()++;
+                FP.fcol[i] = (const int64_t *)src.base;
+                FP.fwid[i] = src.width;
+                FP.fbase[i] = src.vbase;
+                FP.fvalid[i] = src.valid;
+                // (rebased onto the stored offsets as fill_packed does)
+                const __int128 umax = ((__int128)1 << (8 * src.width)) - 1;
+                const __int128 L = (__int128)((src.flags & kSlotRange) ? src.lo : INT64_MIN) - src.vbase;
+                const __int128 H = (__int128)((src.flags & kSlotRange) ? src.hi : INT64_MAX) - src.vbase;
+                if (H < 0 || L > umax || L > H) {
+                    FP.plo[i] = 1;
+                    FP.phi[i] = 0;
+                } else {
+                    FP.plo[i] = (uint32_t)(L < 0 ? 0 : L);
+                    FP.phi[i] = (uint32_t)(H > umax ? umax : H);
+                }
+                FP.npneq[i] = 0;
+                if (src.flags & kSlotNeq)
+                    for (int j = 0; j < src.n_neq; j++) {
+                        const __int128 off = (__int128)src.neq[j] - src.vbase;
+                        if (off >= 0 && off <= umax) FP.pneq[i][FP.npneq[i]++] = (uint32_t)off;
+                    }
+                if (src.flags & kSlotIdMask) {
+                    FP.fmask[i] = src.idmask;
+                    FP.fmask_bits[i] = src.idmask_bits;
+                }
+            } else {
+                SlotDesc &dst = R.slot[n_generic++];
+                dst = src;
+                dst.flags &= (kSlotFilter | kSlotSet);
+                dst.gmissing = -1;
+                dst.gmissing64 = -1;
+                dst.agg_index = -1;
+            }
             pre_saved[(size_t)move[k]] = P.slot[move[k]].flags;
             P.slot[move[k]].flags &= ~(uint32_t)(kSlotFilter | kSlotSet);
         }
+        R.n_slots = n_generic;
+        q->pre_generic_slots = n_generic;
         q->pre_n_slots = (int)move.size();
         return SYBL_OK;
     }
@@ -1509,6 +1552,10 @@ struct Planner {
             SYBL_HIP(hipMemset(q->d_prebits, 0, words * 4));
             q->preplan.segs = q->d_segs;
             q->preplan.wg_seg_begin = q->d_wg_seg_begin;
+            for (auto &fp : q->pre_fps) {
+                fp.segs = q->d_segs;
+                fp.wg_seg_begin = q->d_wg_seg_begin;
+            }
             SYBL_HIP(hipMalloc((void **)&q->d_preplan, sizeof(ScanPlan)));
             SYBL_HIP(hipMemcpy(q->d_preplan, &q->preplan, sizeof(ScanPlan), hipMemcpyHostToDevice));
             q->fplan.xvalid = q->d_prebits;

@@ -316,7 +316,7 @@ def test_time_series_through_the_hash_table(ctx, oracle, monkeypatch):
 
 
 @pytest.mark.parametrize("first", ["query", "table", "rescan"])
-def test_lazy_rows_of_a_hashed_result_outlive_query_and_table(ctx, oracle, first):
+def test_lazy_rows_of_a_hashed_result_outlive_query_and_table(ctx, oracle, monkeypatch, first):
     """A hash group-by's result of >= 2048 groups builds its rows when first asked for, from the query's group columns and
     the table's dictionaries: freeing the query (or the table, or scanning the query again) before anybody looked at the
     rows must build them then -- the result stays valid, and equals the oracle's."""
@@ -325,7 +325,11 @@ def test_lazy_rows_of_a_hashed_result_outlive_query_and_table(ctx, oracle, first
     cols = {"k": rng.integers(-(1 << 38), 1 << 38, n, dtype=np.int64) // 7 * 7, "v": rng.integers(0, 1000, n, dtype=np.int64)}
     cols["k"][: n // 2] = cols["k"][n // 2:]  # (every key twice)
     tb = _table(ctx, cols, info={"v": (0, 999)})
+    monkeypatch.setenv("SYBL_FORCE_HASH", "1")  # (100 000 distinct keys would get a dictionary digit otherwise)
+    monkeypatch.setenv("SYBL_NO_GDICT", "1")
     q = tb.query(groups=["k"], aggs=["v"], op="avg")
+    monkeypatch.delenv("SYBL_FORCE_HASH")
+    monkeypatch.delenv("SYBL_NO_GDICT")
     r = q.scan().finalize()
     assert q.stats()["strategy"] == 7
     if first == "query":
