@@ -1438,7 +1438,8 @@ struct Planner {
             P.lds_cells = (int32_t)L;
             q->lds_bytes = (size_t)(L * 8 * (1 + F + M));
         }
-        if (!q->use_lds && q->time_mode && !getenv("SYBL_NO_WINDOW") && !t->blocks.empty()) {
+        // (a hashed query keeps its staging table: the window below is a direct-mapped slice of [time bucket][cell])
+        if (!q->use_lds && !q->hash_mode && q->time_mode && !getenv("SYBL_NO_WINDOW") && !t->blocks.empty()) {
             const Column *tc = t->cols[(size_t)slot_col[(size_t)P.time_slot]].get();
             std::vector<int32_t> base((size_t)q->n_wg, 0);
             int64_t wmax = 1;

@@ -69,12 +69,13 @@ def _random_query(rng, info, side=None):
 # 205, 206, 238, 294: found by tools/fuzz_more.py (a partition whose record range ended less than four records
 # after a 16-byte boundary lost its tail in k_part_hist)
 # 1585, 1641: weighted sums of signed values that cancel exactly (mean 0.0 against the running mean's 1e-12 residue)
-@pytest.mark.parametrize("seed", list(range(40)) + [205, 206, 238, 294] + list(range(300, 312)) + [1585, 1641])
+# 2020, 2056: hash-forced time series over a few keys took the LDS time window as well (fuzz_more.py hashes every fourth seed)
+@pytest.mark.parametrize("seed", list(range(40)) + [205, 206, 238, 294] + list(range(300, 312)) + [1585, 1641, 2020, 2056])
 def test_random_queries(ctx, oracle, seed, monkeypatch):
-    if 300 <= seed < 312:
-        # grouped queries without a time column go through the hash table (strategy 7), half of them without LDS staging
+    if 300 <= seed < 312 or seed in (2020, 2056):
+        # grouped queries go through the hash table (strategy 7), half of them without LDS staging
         monkeypatch.setenv("SYBL_FORCE_HASH", "1")
-        if seed % 2:
+        if seed % 2 or seed == 2056:
             monkeypatch.setenv("SYBL_NO_HASH_LDS", "1")
     rng = np.random.default_rng(1000 + seed)
     n = int(rng.integers(1, 60_000))
