@@ -391,6 +391,7 @@ int sybl_init(int device, sybl_ctx **out) {
 void sybl_shutdown(sybl_ctx *ctx) {
     if (!ctx) return;
     sybl_comm_free(ctx);
+    ctx_free_load_arena(ctx);
     if (ctx->aux_stream) hipStreamDestroy(ctx->aux_stream);
     if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
     for (auto &ls : ctx->load_streams)

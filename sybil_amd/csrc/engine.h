@@ -52,6 +52,9 @@ hipError_t launch_decode_bins(const void *recs, int rec_width, const int64_t *bi
 hipError_t launch_decode_delta(const void *deltas, int val_width, int64_t n, bool value_encoded, void *col, int out_width, int64_t vbase,
                                hipStream_t st);
 hipError_t launch_remap_ids(const void *local, int local_width, const int32_t *lut, int32_t n_lut, int64_t n, int32_t *col, hipStream_t st);
+// one block's bucket-encoded / value-encoded columns, a launch each (loader.cpp: DecodeBatches); arguments as above
+hipError_t launch_decode_bins_multi(const DecodeBinsBatch &B, hipStream_t st);
+hipError_t launch_decode_delta_multi(const DecodeDeltaBatch &B, hipStream_t st);
 
 hipError_t launch_hist_summary(const HistSummaryPlan &S, int64_t *total, hipStream_t st);
 hipError_t launch_hist_gather(const int64_t *H, int64_t hist_stride, const int64_t *d_cells, int64_t n, int64_t cell0, int64_t cell1,
@@ -78,7 +81,13 @@ struct Ctx {
     hipStream_t load_streams[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int n_load_streams = 0;
     bool load_multi = false;
+    // the loader's staging arena (loader.cpp: SlabPool), kept between loads: pinning and unpinning a few hundred MB cost
+    // every sybl_table_open / sybl_table_refresh tens of milliseconds.  Freed by sybl_shutdown (SYBL_LOADER_KEEP_ARENA=0:
+    // by the load that allocated it).
+    char *load_arena_h = nullptr, *load_arena_d = nullptr;
+    size_t load_arena_bytes = 0;
 };
+void ctx_free_load_arena(Ctx *ctx);
 int load_sync_all(Ctx *ctx);  // waits for every load stream (no-op outside a multi-stream load)
 
 struct Column {

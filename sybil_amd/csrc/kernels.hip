@@ -380,12 +380,11 @@ __device__ __forceinline__ uint32_t block_inclusive_scan_256(uint32_t v, uint32_
 // stored type -- canonical (int64 values / 32-bit dictionary ids, vbase 0) or, when the block goes straight into compact
 // storage, the column's narrow unsigned offset from vbase.
 template <typename T, typename R>
-__global__ __launch_bounds__(256) void k_decode_bins(const R *__restrict__ recs, const int64_t *__restrict__ bin_off,
-                                                     const int64_t *__restrict__ bin_val, int delta_encoded, int64_t vbase,
-                                                     T *__restrict__ col, uint32_t *__restrict__ valid, uint32_t nrows) {
-    __shared__ uint32_t wave_tot[4];
-    const int64_t b0 = bin_off[blockIdx.x], b1 = bin_off[blockIdx.x + 1];
-    const T value = (T)((uint64_t)bin_val[blockIdx.x] - (uint64_t)vbase);
+__device__ __forceinline__ void decode_bins_body(const R *__restrict__ recs, const int64_t *__restrict__ bin_off,
+                                                 const int64_t *__restrict__ bin_val, int delta_encoded, int64_t vbase, T *__restrict__ col,
+                                                 uint32_t *__restrict__ valid, uint32_t nrows, uint32_t bin, uint32_t *wave_tot /*[4]*/) {
+    const int64_t b0 = bin_off[bin], b1 = bin_off[bin + 1];
+    const T value = (T)((uint64_t)bin_val[bin] - (uint64_t)vbase);
     uint32_t carry = 0;
     for (int64_t base = b0; base < b1; base += 256) {
         const int64_t i = base + threadIdx.x;
@@ -403,6 +402,34 @@ __global__ __launch_bounds__(256) void k_decode_bins(const R *__restrict__ recs,
     }
 }
 
+template <typename T, typename R>
+__global__ __launch_bounds__(256) void k_decode_bins(const R *__restrict__ recs, const int64_t *__restrict__ bin_off,
+                                                     const int64_t *__restrict__ bin_val, int delta_encoded, int64_t vbase,
+                                                     T *__restrict__ col, uint32_t *__restrict__ valid, uint32_t nrows) {
+    __shared__ uint32_t wave_tot[4];
+    decode_bins_body<T, R>(recs, bin_off, bin_val, delta_encoded, vbase, col, valid, nrows, blockIdx.x, wave_tot);
+}
+
+// Every bucket-encoded column of one block in ONE launch (blockIdx.y = column, blockIdx.x = bin; a column with fewer
+// bins than the widest leaves its surplus workgroups idle): a block's decode was seven launches of a few microseconds
+// of work each, and launching them -- not the work -- was a third of the loading thread's time per block.
+template <typename R>
+__device__ __forceinline__ void decode_bins_job(const DecodeBinsJob &J, uint32_t nrows, uint32_t bin, uint32_t *wave_tot) {
+    switch (J.out_w) {
+    case 1: decode_bins_body<uint8_t, R>((const R *)J.recs, J.bin_off, J.bin_val, J.delta, J.vbase, (uint8_t *)J.col, J.valid, nrows, bin, wave_tot); break;
+    case 2: decode_bins_body<uint16_t, R>((const R *)J.recs, J.bin_off, J.bin_val, J.delta, J.vbase, (uint16_t *)J.col, J.valid, nrows, bin, wave_tot); break;
+    case 4: decode_bins_body<uint32_t, R>((const R *)J.recs, J.bin_off, J.bin_val, J.delta, J.vbase, (uint32_t *)J.col, J.valid, nrows, bin, wave_tot); break;
+    default: decode_bins_body<int64_t, R>((const R *)J.recs, J.bin_off, J.bin_val, J.delta, J.vbase, (int64_t *)J.col, J.valid, nrows, bin, wave_tot); break;
+    }
+}
+__global__ __launch_bounds__(256) void k_decode_bins_multi(const DecodeBinsBatch B) {
+    __shared__ uint32_t wave_tot[4];
+    const DecodeBinsJob &J = B.job[blockIdx.y];
+    if ((int32_t)blockIdx.x >= J.n_bins) return;
+    if (J.rec_w == 2) decode_bins_job<uint16_t>(J, B.nrows, blockIdx.x, wave_tot);
+    else decode_bins_job<uint32_t>(J, B.nrows, blockIdx.x, wave_tot);
+}
+
 // Value-encoded int column: Values[r] is a delta from Values[r-1] (column_store_io.go:109-113,748-777).
 // A block (<= 65536 rows in the reference) is split into segments of 1024 x kDeltaPerThread values, one workgroup each:
 // the workgroup first sums the deltas AHEAD of its segment (a plain reduction: up to 56 values per lane), then scans its
@@ -413,11 +440,10 @@ __global__ __launch_bounds__(256) void k_decode_bins(const R *__restrict__ recs,
 constexpr int kDeltaPerThread = 8;
 constexpr int64_t kDeltaSegment = 1024 * kDeltaPerThread;
 template <typename V, typename O>
-__global__ __launch_bounds__(1024) void k_decode_delta(const V *__restrict__ deltas, int64_t n, int value_encoded, int64_t vbase,
-                                                       O *__restrict__ col) {
-    __shared__ int64_t wave_tot[16];
+__device__ __forceinline__ void decode_delta_body(const V *__restrict__ deltas, int64_t n, int value_encoded, int64_t vbase, O *__restrict__ col,
+                                                  uint32_t segment, int64_t *wave_tot /*[16]*/) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t base = (int64_t)blockIdx.x * kDeltaSegment;
+    const int64_t base = (int64_t)segment * kDeltaSegment;
     int64_t carry = 0;  // the sum of everything ahead of this segment
     if (value_encoded && base > 0) {
         int64_t t = 0;
@@ -454,6 +480,31 @@ __global__ __launch_bounds__(1024) void k_decode_delta(const V *__restrict__ del
 #pragma unroll
     for (int j = 0; j < kDeltaPerThread; j++)
         if (i0 + j < n) col[i0 + j] = (O)((uint64_t)v[j] - (uint64_t)vbase);
+}
+
+template <typename V, typename O>
+__global__ __launch_bounds__(1024) void k_decode_delta(const V *__restrict__ deltas, int64_t n, int value_encoded, int64_t vbase,
+                                                       O *__restrict__ col) {
+    __shared__ int64_t wave_tot[16];
+    decode_delta_body<V, O>(deltas, n, value_encoded, vbase, col, blockIdx.x, wave_tot);
+}
+
+// every value-encoded int column of one block in one launch (see k_decode_bins_multi)
+template <typename V>
+__device__ __forceinline__ void decode_delta_job(const DecodeDeltaJob &J, uint32_t segment, int64_t *wave_tot) {
+    switch (J.out_w) {
+    case 1: decode_delta_body<V, uint8_t>((const V *)J.deltas, J.n, J.venc, J.vbase, (uint8_t *)J.col, segment, wave_tot); break;
+    case 2: decode_delta_body<V, uint16_t>((const V *)J.deltas, J.n, J.venc, J.vbase, (uint16_t *)J.col, segment, wave_tot); break;
+    case 4: decode_delta_body<V, uint32_t>((const V *)J.deltas, J.n, J.venc, J.vbase, (uint32_t *)J.col, segment, wave_tot); break;
+    default: decode_delta_body<V, int64_t>((const V *)J.deltas, J.n, J.venc, J.vbase, (int64_t *)J.col, segment, wave_tot); break;
+    }
+}
+__global__ __launch_bounds__(1024) void k_decode_delta_multi(const DecodeDeltaBatch B) {
+    __shared__ int64_t wave_tot[16];
+    const DecodeDeltaJob &J = B.job[blockIdx.y];
+    if ((int64_t)blockIdx.x * kDeltaSegment >= J.n) return;
+    if (J.val_w == 4) decode_delta_job<int32_t>(J, blockIdx.x, wave_tot);
+    else decode_delta_job<int64_t>(J, blockIdx.x, wave_tot);
 }
 
 // Per-row block-local dictionary ids -> table-global ids (non-bucket str columns)
@@ -511,6 +562,22 @@ hipError_t launch_decode_delta(const void *deltas, int val_width, int64_t n, boo
     if (n <= 0) return hipSuccess;
     if (val_width == 4) decode_delta_t<int32_t>(deltas, n, value_encoded ? 1 : 0, col, out_width, vbase, st);
     else decode_delta_t<int64_t>(deltas, n, value_encoded ? 1 : 0, col, out_width, vbase, st);
+    return hipGetLastError();
+}
+
+hipError_t launch_decode_bins_multi(const DecodeBinsBatch &B, hipStream_t st) {
+    int max_bins = 0;
+    for (int i = 0; i < B.n; i++) max_bins = B.job[i].n_bins > max_bins ? B.job[i].n_bins : max_bins;
+    if (B.n <= 0 || max_bins <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_decode_bins_multi, dim3((unsigned)max_bins, (unsigned)B.n), dim3(256), 0, st, B);
+    return hipGetLastError();
+}
+
+hipError_t launch_decode_delta_multi(const DecodeDeltaBatch &B, hipStream_t st) {
+    int64_t max_n = 0;
+    for (int i = 0; i < B.n; i++) max_n = B.job[i].n > max_n ? B.job[i].n : max_n;
+    if (B.n <= 0 || max_n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_decode_delta_multi, dim3((unsigned)((max_n + kDeltaSegment - 1) / kDeltaSegment), (unsigned)B.n), dim3(1024), 0, st, B);
     return hipGetLastError();
 }
 

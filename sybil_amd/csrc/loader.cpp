@@ -14,6 +14,7 @@
 #include <dirent.h>
 #include <string.h>
 #include <sys/stat.h>
+#include <time.h>
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -27,6 +28,10 @@
 #include <future>
 #include <mutex>
 #include <thread>
+
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 #include "engine.h"
 #include "gob.h"
@@ -49,7 +54,26 @@ static bool looks_like_block(const std::string &name) {
 }
 
 static std::atomic<int64_t> g_file_bytes{0};   // (statistics of the load in progress: sybl_table_load_stats)
-static std::atomic<int64_t> g_parse_ns{0};
+static std::atomic<int64_t> g_parse_ns{0};      // CPU time of the workers (CLOCK_THREAD_CPUTIME_ID)
+static std::atomic<int64_t> g_parse_wall_ns{0};  // their elapsed time: more than the CPU time when the cgroup throttles them
+static int64_t thread_cpu_ns() {
+    struct timespec ts;
+    if (clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts) != 0) return 0;
+    return (int64_t)ts.tv_sec * 1000000000ll + ts.tv_nsec;
+}
+// the cgroup's CPU throttling so far (cgroup v2 cpu.stat: periods throttled, microseconds throttled); zeros when unreadable
+static void cgroup_throttle(int64_t *periods, int64_t *usec) {
+    *periods = *usec = 0;
+    FILE *f = fopen("/sys/fs/cgroup/cpu.stat", "r");
+    if (!f) return;
+    char key[64];
+    long long v;
+    while (fscanf(f, "%63s %lld", key, &v) == 2) {
+        if (!strcmp(key, "nr_throttled")) *periods = v;
+        else if (!strcmp(key, "throttled_usec")) *usec = v;
+    }
+    fclose(f);
+}
 
 static bool decode_file(const std::string &path, gob::Value &v, std::string &err) {
     static thread_local std::vector<uint8_t> data;  // (reused: no allocation / page faults per file)
@@ -82,9 +106,23 @@ struct SlabPool {
     std::deque<int> pending;  // applied, event recorded, not yet known to be finished
     size_t slab_bytes = 0, max_slabs = 0;
     char *arena_h = nullptr, *arena_d = nullptr;
-    int init() {
-        SYBL_HIP(hipHostMalloc((void **)&arena_h, slab_bytes * max_slabs, hipHostMallocDefault));
-        SYBL_HIP(hipMalloc((void **)&arena_d, slab_bytes * max_slabs));
+    Ctx *ctx = nullptr;
+    // (the arena belongs to the context and outlives the load: Ctx::load_arena_h)
+    int init(Ctx *c) {
+        ctx = c;
+        const size_t need = slab_bytes * max_slabs;
+        if (c->load_arena_bytes < need) {
+            ctx_free_load_arena(c);
+            SYBL_HIP(hipHostMalloc((void **)&c->load_arena_h, need, hipHostMallocDefault));
+            hipError_t e = hipMalloc((void **)&c->load_arena_d, need);
+            if (e != hipSuccess) {
+                ctx_free_load_arena(c);
+                return hip_fail(e, "hipMalloc(loader arena)");
+            }
+            c->load_arena_bytes = need;
+        }
+        arena_h = c->load_arena_h;
+        arena_d = c->load_arena_d;
         return SYBL_OK;
     }
     // *out = -1 when no slab can be had right now (must_wait: block until the oldest pending one is done)
@@ -127,10 +165,16 @@ struct SlabPool {
                 (void)hipEventSynchronize(s.done);
                 (void)hipEventDestroy(s.done);
             }
-        if (arena_h) (void)hipHostFree(arena_h);
-        if (arena_d) (void)hipFree(arena_d);
+        if (ctx && getenv("SYBL_LOADER_KEEP_ARENA") && atoi(getenv("SYBL_LOADER_KEEP_ARENA")) == 0) ctx_free_load_arena(ctx);
     }
 };
+
+void ctx_free_load_arena(Ctx *ctx) {
+    if (ctx->load_arena_h) (void)hipHostFree(ctx->load_arena_h);
+    if (ctx->load_arena_d) (void)hipFree(ctx->load_arena_d);
+    ctx->load_arena_h = ctx->load_arena_d = nullptr;
+    ctx->load_arena_bytes = 0;
+}
 
 // Worker threads of one table load (std::async started a thread per block: 1600 thread creations, 27 us each on the
 // calling thread, for a 100 M-row table).
@@ -209,6 +253,7 @@ struct PreparedBlock {
     std::vector<PreparedCol> cols;
     size_t bytes = 0;          // of the slab that are in use
     char *own_h = nullptr, *own_d = nullptr;  // a block too large for the pool's slabs brings its own pair
+    std::pair<int64_t, int64_t> sig{-1, -1};  // block_signature, taken by the worker before it reads the block
 };
 
 static inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
@@ -227,6 +272,7 @@ struct ColSpec {
 constexpr int64_t kMaxBlockRows = (int64_t)1 << 24;  // 256 x the reference's block size
 
 static PreparedBlock prepare_block_unguarded(const std::string &bdir, const std::vector<ColSpec> &specs, char *slab_h, size_t slab_cap, int device);
+static std::pair<int64_t, int64_t> block_signature(const std::string &bdir);
 // A worker thread must not let an exception escape (std::bad_alloc / length_error from a damaged file): it
 // would be rethrown by future::get() and leave the extern "C" entry point.  The block is skipped instead,
 // like every other block the reference cannot read.
@@ -234,13 +280,22 @@ static PreparedBlock prepare_block(const std::string &bdir, const std::vector<Co
     const auto t0 = std::chrono::steady_clock::now();
     struct Tally {
         std::chrono::steady_clock::time_point t0;
-        ~Tally() { g_parse_ns += (int64_t)(seconds_since(t0) * 1e9); }
-    } tally{t0};
+        int64_t c0;
+        ~Tally() {
+            g_parse_wall_ns += (int64_t)(seconds_since(t0) * 1e9);
+            g_parse_ns += thread_cpu_ns() - c0;
+        }
+    } tally{t0, thread_cpu_ns()};
+    // (what the block looked like BEFORE it was read: a rewrite in between makes the next refresh load it again)
+    const std::pair<int64_t, int64_t> sig = block_signature(bdir);
     try {
-        return prepare_block_unguarded(bdir, specs, slab_h, slab_cap, device);
+        PreparedBlock pb = prepare_block_unguarded(bdir, specs, slab_h, slab_cap, device);
+        pb.sig = sig;
+        return pb;
     } catch (const std::exception &) {
         PreparedBlock pb;
         pb.unreadable = true;
+        pb.sig = sig;
         return pb;
     }
 }
@@ -276,6 +331,79 @@ struct BinsView {
     }
 };
 
+// ---- the copies that narrow a decoded int64 array on its way into the slab, and the extrema of one.  Plain loops, plus
+// AVX-512 forms picked at run time (the baseline x86-64 the library is built for has no 64-bit min / max and narrows
+// through shuffles): with the varint walk out of the way these passes were a quarter of a worker's time per block.
+#if defined(__x86_64__)
+static const bool g_cpu512 = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") && !getenv("SYBL_LOADER_NO_AVX512");
+__attribute__((target("avx512f,avx512bw"))) static uint64_t narrow16_512(const int64_t *src, uint16_t *dst, int64_t n) {
+    __m512i acc = _mm512_setzero_si512();
+    int64_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        const __m512i v = _mm512_loadu_si512((const void *)(src + i));
+        acc = _mm512_or_si512(acc, v);
+        _mm_storeu_si128((__m128i *)(dst + i), _mm512_cvtepi64_epi16(v));
+    }
+    uint64_t bits = (uint64_t)_mm512_reduce_or_epi64(acc);
+    for (; i < n; i++) {
+        bits |= (uint64_t)src[i];
+        dst[i] = (uint16_t)src[i];
+    }
+    return bits;
+}
+__attribute__((target("avx512f,avx512bw"))) static void narrow32_512(const int64_t *src, int32_t *dst, int64_t n) {
+    int64_t i = 0;
+    for (; i + 8 <= n; i += 8) _mm256_storeu_si256((__m256i *)(dst + i), _mm512_cvtepi64_epi32(_mm512_loadu_si512((const void *)(src + i))));
+    for (; i < n; i++) dst[i] = (int32_t)src[i];
+}
+__attribute__((target("avx512f,avx512bw"))) static void minmax_512(const int64_t *src, int64_t n, int64_t *lo, int64_t *hi) {
+    __m512i mn = _mm512_set1_epi64(INT64_MAX), mx = _mm512_set1_epi64(INT64_MIN);
+    int64_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        const __m512i v = _mm512_loadu_si512((const void *)(src + i));
+        mn = _mm512_min_epi64(mn, v);
+        mx = _mm512_max_epi64(mx, v);
+    }
+    int64_t a = _mm512_reduce_min_epi64(mn), b = _mm512_reduce_max_epi64(mx);
+    for (; i < n; i++) {
+        a = std::min(a, src[i]);
+        b = std::max(b, src[i]);
+    }
+    *lo = a;
+    *hi = b;
+}
+#else
+static const bool g_cpu512 = false;
+static uint64_t narrow16_512(const int64_t *, uint16_t *, int64_t) { return 0; }
+static void narrow32_512(const int64_t *, int32_t *, int64_t) {}
+static void minmax_512(const int64_t *, int64_t, int64_t *, int64_t *) {}
+#endif
+// dst[i] = (uint16_t)src[i]; returns the OR of the source values (anything beyond 16 bits shows there)
+static uint64_t narrow16(const int64_t *src, uint16_t *dst, int64_t n) {
+    if (g_cpu512) return narrow16_512(src, dst, n);
+    uint64_t bits = 0;
+    for (int64_t i = 0; i < n; i++) {
+        bits |= (uint64_t)src[i];
+        dst[i] = (uint16_t)src[i];
+    }
+    return bits;
+}
+static void narrow32(const int64_t *src, int32_t *dst, int64_t n) {
+    if (g_cpu512) return narrow32_512(src, dst, n);
+    for (int64_t i = 0; i < n; i++) dst[i] = (int32_t)src[i];
+}
+// extrema of src[0, n) (n = 0: INT64_MAX, INT64_MIN)
+static void minmax64(const int64_t *src, int64_t n, int64_t *lo, int64_t *hi) {
+    if (g_cpu512) return minmax_512(src, n, lo, hi);
+    int64_t a = INT64_MAX, b = INT64_MIN;
+    for (int64_t i = 0; i < n; i++) {
+        a = std::min(a, src[i]);
+        b = std::max(b, src[i]);
+    }
+    *lo = a;
+    *hi = b;
+}
+
 // Bins -> slab: bin values (int64), bin offsets (int64, n_bins + 1) and the record ids as they are in the file
 // (absolute or delta-encoded) at rec_w bytes each.  False: an id beyond NumRecords.
 static bool fill_bins(const BinsView &bv, bool delta, int64_t num_records, char *base, PreparedCol &pc) {
@@ -284,6 +412,30 @@ static bool fill_bins(const BinsView &bv, bool delta, int64_t num_records, char 
     uint32_t *r32 = (uint32_t *)(base + pc.rec_at);
     if (bv.n > 0) memcpy(val, bv.val, (size_t)bv.n * 8);
     memcpy(off, bv.off, (size_t)(bv.n + 1) * 8);
+    if (delta && pc.rec_w == 2) {
+        // the common case (delta-encoded ids, a block of <= 65536 rows) without a branch per id: the deltas are unsigned,
+        // so a bin's ids are ascending and its last one -- the sum -- is the one to hold against NumRecords; an id that
+        // does not fit 32 bits (a negative delta of a damaged file among them) shows in the OR.  Both loops vectorise;
+        // the id-by-id loop below was a quarter of a worker's time per block.
+        const int64_t total = bv.off[bv.n];
+        uint64_t any = 0;
+        for (int64_t k = 0; k < bv.n; k++) {
+            uint64_t sum = 0;
+            for (int64_t i = bv.off[k]; i < bv.off[k + 1]; i++) sum += (uint64_t)bv.recs[i];
+            any |= sum;  // (a sum of < 2^32 values below 2^32 does not wrap; one that is not below 2^32 shows here or below)
+        }
+        const uint64_t bits = narrow16(bv.recs, r16, total);
+        if ((bits >> 32) != 0) return false;
+        if (any >= (uint64_t)num_records) {
+            // (some bin's last id is out of range -- or the OR of in-range sums merely looks so: ask bin by bin)
+            for (int64_t k = 0; k < bv.n; k++) {
+                uint64_t sum = 0;
+                for (int64_t i = bv.off[k]; i < bv.off[k + 1]; i++) sum += (uint64_t)bv.recs[i];
+                if (sum >= (uint64_t)num_records) return false;
+            }
+        }
+        return true;
+    }
     for (int64_t k = 0; k < bv.n; k++) {
         uint64_t abs = 0;
         for (int64_t i = bv.off[k]; i < bv.off[k + 1]; i++) {
@@ -362,12 +514,10 @@ static PreparedBlock prepare_block_unguarded(const std::string &bdir, const std:
             if (specs[ci].type == SYBL_INT_VAL) {
                 pc.kind = PreparedCol::kIntValues;
                 pc.n_vals = n;
-                pc.val_w = 4;
-                for (int64_t k = 0; ok && k < n; k++)
-                    if (vals->ints[(size_t)k] < INT32_MIN || vals->ints[(size_t)k] > INT32_MAX) {
-                        pc.val_w = 8;
-                        break;
-                    }
+                // (the stored values / deltas travel as int32 when they all fit; without an exit from the loop it vectorises)
+                int64_t lo = 0, hi = 0;
+                if (ok && n > 0) minmax64(vals->ints.data(), n, &lo, &hi);
+                pc.val_w = lo < INT32_MIN || hi > INT32_MAX ? 8 : 4;
                 pc.val_at = reserve((size_t)std::max<int64_t>(n, 1) * (size_t)pc.val_w);
             } else {
                 pc.kind = PreparedCol::kStrValues;
@@ -434,17 +584,32 @@ static PreparedBlock prepare_block_unguarded(const std::string &bdir, const std:
             break;
         }
         case PreparedCol::kIntValues: {
-            int64_t run = 0, k = 0;  // every row below len(Values) is populated (column_store_io.go:758-766)
+            // every row below len(Values) is populated (column_store_io.go:758-766)
             int32_t *o32 = (int32_t *)(base + pc.val_at);
             int64_t *o64 = (int64_t *)(base + pc.val_at);
-            if (vals && vals->kind == gob::Value::kIntVec)
-                for (int64_t x : vals->ints) {
-                    run = pc.venc ? (int64_t)((uint64_t)run + (uint64_t)x) : x;
-                    pc.vmin = std::min(pc.vmin, run);
-                    pc.vmax = std::max(pc.vmax, run);
-                    if (pc.val_w == 4) o32[k++] = (int32_t)x;
-                    else o64[k++] = x;
+            if (vals && vals->kind == gob::Value::kIntVec && vals->ints.size() > 0) {
+                const int64_t *src = vals->ints.data();
+                const int64_t nv = (int64_t)vals->ints.size();
+                int64_t mn = INT64_MAX, mx = INT64_MIN;
+                if (pc.venc) {
+                    // (the running sum is the only chain in this loop; the copy below is a loop of its own so that it vectorises)
+                    uint64_t run = 0;
+                    for (int64_t k = 0; k < nv; k++) {
+                        run += (uint64_t)src[k];
+                        mn = std::min(mn, (int64_t)run);
+                        mx = std::max(mx, (int64_t)run);
+                    }
+                } else {
+                    minmax64(src, nv, &mn, &mx);
                 }
+                pc.vmin = std::min(pc.vmin, mn);
+                pc.vmax = std::max(pc.vmax, mx);
+                if (pc.val_w == 4) {
+                    narrow32(src, o32, nv);
+                } else {
+                    memcpy(o64, src, (size_t)nv * 8);
+                }
+            }
             pc.vpop = pc.n_vals;
             pc.have_stats = true;
             break;
@@ -524,11 +689,13 @@ static PreparedBlock prepare_block_unguarded(const std::string &bdir, const std:
 // dictionaries first (they decide what some slab bytes are): block-local id -> table-global id tables, written into
 // the slab where the kernels expect them
 static void apply_dictionaries(Table *t, PreparedBlock &pb, char *H, std::vector<std::vector<int32_t>> &luts) {
-    luts.assign(t->cols.size(), std::vector<int32_t>());
+    luts.resize(t->cols.size());
     for (size_t ci = 0; ci < t->cols.size(); ci++) {
         PreparedCol &pc = pb.cols[ci];
         Column *c = t->cols[ci].get();
         std::vector<int32_t> &lut = luts[ci];
+        lut.clear();
+        if (pc.strings.empty() && pc.kind != PreparedCol::kStrBins && pc.kind != PreparedCol::kStrValues && pc.kind != PreparedCol::kSet) continue;
         for (auto &s : pc.strings) lut.push_back(dict_intern(c, s));
         if (pc.kind == PreparedCol::kStrBins) {
             int64_t *val = (int64_t *)(H + pc.binval_at);
@@ -541,7 +708,34 @@ static void apply_dictionaries(Table *t, PreparedBlock &pb, char *H, std::vector
     }
 }
 
-static int apply_col(BlockWriter &w, Column *c, PreparedCol &pc, const char *H, char *D, size_t n_strings) {
+// The decode launches of one block, gathered while its columns are placed and issued together (DecodeBinsBatch /
+// DecodeDeltaBatch: a launch per kind instead of one per column).  SYBL_LOADER_FUSED=0: a launch per column, as before
+// round 4.
+struct DecodeBatches {
+    bool on = true;
+    DecodeBinsBatch bins;
+    DecodeDeltaBatch deltas;
+    void begin(uint32_t nrows) {
+        bins.n = deltas.n = 0;
+        bins.nrows = nrows;
+    }
+    int flush_bins(hipStream_t st) {
+        hipError_t e = launch_decode_bins_multi(bins, st);
+        bins.n = 0;
+        return e == hipSuccess ? SYBL_OK : hip_fail(e, "k_decode_bins_multi");
+    }
+    int flush_deltas(hipStream_t st) {
+        hipError_t e = launch_decode_delta_multi(deltas, st);
+        deltas.n = 0;
+        return e == hipSuccess ? SYBL_OK : hip_fail(e, "k_decode_delta_multi");
+    }
+    int flush(hipStream_t st) {
+        int rc = flush_bins(st);
+        return rc ? rc : flush_deltas(st);
+    }
+};
+
+static int apply_col(BlockWriter &w, Column *c, PreparedCol &pc, const char *H, char *D, size_t n_strings, DecodeBatches &batch) {
     Table *t = w.t;
     hipStream_t st = t->ctx->stream;
     void *col = nullptr;
@@ -569,10 +763,26 @@ static int apply_col(BlockWriter &w, Column *c, PreparedCol &pc, const char *H, 
         bool direct = false;
         if (stats && (rc = block_col_direct(w, c, all, mn, mx, pop, &col, &valid, &direct))) return rc;
         if (!direct && (rc = block_col_device(w, c, all, &col, &valid))) return rc;
-        hipError_t e = launch_decode_bins(D + pc.rec_at, pc.rec_w, (const int64_t *)(D + pc.binoff_at), (const int64_t *)(D + pc.binval_at),
-                                          (int)pc.n_bins, pc.delta, col, direct ? c->elem : c->canon(), direct ? c->vbase : 0, valid,
-                                          (uint32_t)w.nrows, st);
-        if (e != hipSuccess) return hip_fail(e, "k_decode_bins");
+        if (batch.on && pc.n_bins > 0) {
+            if (batch.bins.n == kDecodeBatchMax && (rc = batch.flush_bins(st))) return rc;
+            DecodeBinsJob &J = batch.bins.job[batch.bins.n++];
+            J.recs = D + pc.rec_at;
+            J.bin_off = (const int64_t *)(D + pc.binoff_at);
+            J.bin_val = (const int64_t *)(D + pc.binval_at);
+            J.col = col;
+            J.valid = valid;
+            J.vbase = direct ? c->vbase : 0;
+            J.n_bins = (int32_t)pc.n_bins;
+            J.rec_w = (uint8_t)pc.rec_w;
+            J.out_w = (uint8_t)(direct ? c->elem : c->canon());
+            J.delta = pc.delta ? 1 : 0;
+            J.pad = 0;
+        } else {
+            hipError_t e = launch_decode_bins(D + pc.rec_at, pc.rec_w, (const int64_t *)(D + pc.binoff_at), (const int64_t *)(D + pc.binval_at),
+                                              (int)pc.n_bins, pc.delta, col, direct ? c->elem : c->canon(), direct ? c->vbase : 0, valid,
+                                              (uint32_t)w.nrows, st);
+            if (e != hipSuccess) return hip_fail(e, "k_decode_bins");
+        }
         if (!direct && stats) block_col_stats(w, c, mn, mx, pop);
         return SYBL_OK;
     }
@@ -585,7 +795,18 @@ static int apply_col(BlockWriter &w, Column *c, PreparedCol &pc, const char *H, 
         if (!direct && (rc = block_col_device(w, c, n == w.nrows, &col, &valid))) return rc;
         if (valid && pc.bits_words > 0)
             SYBL_HIP(hipMemcpyAsync(valid, D + pc.bits_at, (size_t)pc.bits_words * 4, hipMemcpyDeviceToDevice, st));
-        if (n > 0) {
+        if (n > 0 && ints && batch.on) {
+            if (batch.deltas.n == kDecodeBatchMax && (rc = batch.flush_deltas(st))) return rc;
+            DecodeDeltaJob &J = batch.deltas.job[batch.deltas.n++];
+            memset(&J, 0, sizeof(J));
+            J.deltas = D + pc.val_at;
+            J.col = col;
+            J.n = n;
+            J.vbase = direct ? c->vbase : 0;
+            J.val_w = (uint8_t)pc.val_w;
+            J.out_w = (uint8_t)(direct ? c->elem : 8);
+            J.venc = pc.venc ? 1 : 0;
+        } else if (n > 0) {
             hipError_t e = ints ? launch_decode_delta(D + pc.val_at, pc.val_w, n, pc.venc, col, direct ? c->elem : 8, direct ? c->vbase : 0, st)
                                 : launch_remap_ids(D + pc.local_at, pc.local_w, (const int32_t *)(D + pc.lut_at), (int32_t)n_strings, n,
                                                    (int32_t *)col, st);
@@ -631,9 +852,14 @@ static int list_blocks(const std::string &tdir, int32_t rank, int32_t nranks, st
     while (struct dirent *e = readdir(d)) {
         std::string name = e->d_name;
         if (name == "." || name == "..") continue;
-        struct stat st;
-        if (stat((tdir + "/" + name).c_str(), &st) != 0 || !S_ISDIR(st.st_mode)) continue;
-        if (looks_like_block(name)) blocks.push_back(name);
+        if (!looks_like_block(name)) continue;
+        // (the directory entry says what it is on most file systems: 1600 stat calls were part of every open)
+        if (e->d_type != DT_DIR) {
+            struct stat st;
+            if (e->d_type != DT_UNKNOWN && e->d_type != DT_LNK) continue;
+            if (stat((tdir + "/" + name).c_str(), &st) != 0 || !S_ISDIR(st.st_mode)) continue;
+        }
+        blocks.push_back(name);
     }
     closedir(d);
     std::sort(blocks.begin(), blocks.end());
@@ -657,8 +883,6 @@ static std::pair<int64_t, int64_t> block_signature(const std::string &bdir) {
 static int load_blocks(Ctx *ctx, Table *t, const std::string &tdir, const std::vector<std::string> &names) {
     int rc;
     const size_t n_names = names.size();
-    std::vector<std::pair<int64_t, int64_t>> sigs(n_names);
-    for (size_t i = 0; i < n_names; i++) sigs[i] = block_signature(tdir + "/" + names[i]);
     std::vector<ColSpec> specs;
     for (auto &cp : t->cols) specs.push_back({cp->name, cp->type});
     // worker threads decode a window of blocks ahead of the (serial, in-order) GPU phase
@@ -676,7 +900,7 @@ static int load_blocks(Ctx *ctx, Table *t, const std::string &tdir, const std::v
         if (const char *e = getenv("SYBL_LOADER_SLAB_BYTES")) pool.slab_bytes = align16((size_t)std::max(16, atoi(e)));  // (tests: over-sized blocks)
         pool.max_slabs = std::min<size_t>(std::max<size_t>(((size_t)512 << 20) / pool.slab_bytes, 4), std::max<size_t>(2 * n_workers, 4));
         pool.max_slabs = std::min<size_t>(pool.max_slabs, std::max<size_t>(n_names, 1));
-        if ((rc = pool.init())) return (rc);
+        if ((rc = pool.init(ctx))) return (rc);
     }
     const size_t window = std::min(n_workers * 2, pool.max_slabs);
     struct InFlight {
@@ -739,9 +963,14 @@ static int load_blocks(Ctx *ctx, Table *t, const std::string &tdir, const std::v
     const auto t_open = std::chrono::steady_clock::now();
     g_file_bytes = 0;
     g_parse_ns = 0;
+    g_parse_wall_ns = 0;
+    int64_t thr_n0, thr_us0;
+    cgroup_throttle(&thr_n0, &thr_us0);
     double wait_s = 0, apply_s = 0;
     int64_t h2d_bytes = 0;
     std::vector<std::vector<int32_t>> luts;
+    DecodeBatches batch;
+    if (const char *e = getenv("SYBL_LOADER_FUSED")) batch.on = atoi(e) != 0;
     // SYBL_LOADER_TRACE=1: where the calling thread's time goes (stderr)
     const bool trace = getenv("SYBL_LOADER_TRACE") != nullptr;
     double tr[5] = {0, 0, 0, 0, 0};  // dictionaries, copy, column kernels, commit, submit
@@ -777,7 +1006,7 @@ static int load_blocks(Ctx *ctx, Table *t, const std::string &tdir, const std::v
         };
         if (pb.unreadable || pb.broken) {
             t->broken_blocks++;
-            t->loaded.push_back(LoadedBlock{names[name_ix], sigs[name_ix].first, sigs[name_ix].second, -1});
+            t->loaded.push_back(LoadedBlock{names[name_ix], pb.sig.first, pb.sig.second, -1});
             pool.give_back(slab);
             if ((rc = submit())) return fail_out(rc);
             continue;
@@ -795,11 +1024,13 @@ static int load_blocks(Ctx *ctx, Table *t, const std::string &tdir, const std::v
         lap(1, tl);
         BlockWriter w;
         if ((rc = block_begin(t, pb.nrows, &w))) return fail_out(rc);
+        batch.begin((uint32_t)pb.nrows);
         for (size_t ci = 0; ci < t->cols.size(); ci++)
-            if ((rc = apply_col(w, t->cols[ci].get(), pb.cols[ci], H, D, luts[ci].size()))) return fail_out(rc);
+            if ((rc = apply_col(w, t->cols[ci].get(), pb.cols[ci], H, D, luts[ci].size(), batch))) return fail_out(rc);
+        if ((rc = batch.flush(ctx->stream))) return fail_out(rc);
         lap(2, tl);
         if ((rc = block_commit(w))) return fail_out(rc);
-        t->loaded.push_back(LoadedBlock{names[name_ix], sigs[name_ix].first, sigs[name_ix].second, (int64_t)t->blocks.size() - 1});
+        t->loaded.push_back(LoadedBlock{names[name_ix], pb.sig.first, pb.sig.second, (int64_t)t->blocks.size() - 1});
         lap(3, tl);
         if (pb.own_h) {
             // an over-sized block's private pair: wait for its kernels, then let it go
@@ -813,6 +1044,12 @@ static int load_blocks(Ctx *ctx, Table *t, const std::string &tdir, const std::v
         }
         if ((rc = submit())) return fail_out(rc);
         lap(4, tl);
+    }
+    if (trace) {
+        int64_t thr_n1, thr_us1;
+        cgroup_throttle(&thr_n1, &thr_us1);
+        fprintf(stderr, "loader: %zu workers, parse %.3f s CPU in %.3f s of worker time; cgroup throttled %lld periods, %.3f s\n", n_workers,
+                (double)g_parse_ns.load() * 1e-9, (double)g_parse_wall_ns.load() * 1e-9, (long long)(thr_n1 - thr_n0), (double)(thr_us1 - thr_us0) * 1e-6);
     }
     if (trace)
         fprintf(stderr, "loader: dictionaries %.3f s, copy %.3f s, column kernels %.3f s, commit %.3f s, submit %.3f s, wait %.3f s, slabs %zu x %zu KB\n",

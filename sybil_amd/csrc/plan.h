@@ -210,4 +210,32 @@ enum Header : int {
     kHdrOutLog = 5,       // outlier log: records appended (k_outlog_gather; more than the log's capacity: some were dropped)
 };
 
+// ---- table load: one block's bucket-encoded / value-encoded columns, a launch each (loader.cpp, kernels.hip:
+// k_decode_bins_multi / k_decode_delta_multi); the fields are the single-column launchers' arguments (engine.h)
+constexpr int kDecodeBatchMax = 16;
+struct DecodeBinsJob {
+    const void *recs;
+    const int64_t *bin_off, *bin_val;
+    void *col;
+    uint32_t *valid;
+    int64_t vbase;
+    int32_t n_bins;
+    uint8_t rec_w, out_w, delta, pad;
+};
+struct DecodeBinsBatch {
+    DecodeBinsJob job[kDecodeBatchMax];
+    uint32_t nrows;
+    int32_t n;
+};
+struct DecodeDeltaJob {
+    const void *deltas;
+    void *col;
+    int64_t n, vbase;
+    uint8_t val_w, out_w, venc, pad[5];
+};
+struct DecodeDeltaBatch {
+    DecodeDeltaJob job[kDecodeBatchMax];
+    int32_t n;
+};
+
 }  // namespace sybl

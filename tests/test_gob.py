@@ -241,3 +241,68 @@ def test_cxx_reader_survives_truncated_and_corrupted_column_files(tmp_path):
                 N.lib().sybl_debug_gob_to_json(p)
                 tried += 1
     assert tried > 2500
+
+
+def _check_int_slices(tmp):
+    """Int / uint slices of every encoded length through the C++ reader (Reader::ints: the 64-byte windows of ints_vbmi on a
+    host that has AVX-512 VBMI, the scalar loops elsewhere and under SYBL_GOB_NO_VBMI): value-encoded `Values []int64` and
+    the bins' `Records []uint32`, in the mixes that steer the loops -- runs of one-byte values, one/two/three-byte deltas at
+    random, markers of five to eight data bytes, slices shorter than a window, values that straddle a window's end."""
+    rng = np.random.default_rng(11)
+
+    def ints(n, kind):
+        if kind == "bytes":  # one-byte values only (zig-zag of -64..63)
+            return [int(x) for x in rng.integers(-64, 64, size=n)]
+        if kind == "mixed":  # every length, equally likely
+            bits = rng.integers(1, 64, size=n)
+            return [int(rng.integers(0, 1 << 62) >> (62 - b)) * (1 if rng.random() < 0.5 else -1) for b in bits]
+        if kind == "deltas":  # what a value-encoded column holds: three data bytes, now and then two
+            return [int(x) for x in rng.integers(-1_000_000, 1_000_000, size=n)]
+        if kind == "extremes":
+            pool = [0, -1, 1, 63, 64, -64, -65, 127, 128, 255, 256, 65535, 65536, (1 << 31) - 1, -(1 << 31), (1 << 55), (1 << 56) - 1, 1 << 56,
+                    (1 << 62), (1 << 63) - 1, -(1 << 63), -(1 << 56), -(1 << 55) - 1]
+            return [pool[int(i)] for i in rng.integers(0, len(pool), size=n)]
+        runs, out = [], []  # "runs": long one-byte stretches broken by wide values
+        while len(out) < n:
+            out += [int(x) for x in rng.integers(-60, 60, size=int(rng.integers(1, 200)))]
+            out += [int(rng.integers(-(1 << 40), 1 << 40)) for _ in range(int(rng.integers(1, 4)))]
+        return out[:n]
+
+    k = 0
+    for kind in ("bytes", "mixed", "deltas", "extremes", "runs"):
+        for n in (0, 1, 7, 15, 16, 17, 63, 64, 65, 200, 1000, 5003):
+            vals = ints(n, kind)
+            col = {"Name": "v", "ValueEncoded": True, "Values": vals, "VERSION": 1}
+            p = os.path.join(tmp, "v%d.db" % k)
+            k += 1
+            open(p, "wb").write(G.encode(G.saved_int_column(), col))
+            got = _cxx_json(p)
+            assert got.get("Values", []) == vals, (kind, n)
+    # Records []uint32 (unsigned; ids below 65536 are at most two data bytes, the type allows four) inside bins of many sizes
+    for trial in range(12):
+        bins = []
+        for b in range(int(rng.integers(1, 40))):
+            m = int(rng.choice([0, 1, 2, 15, 16, 17, 64, 65, 130, 700]))
+            top = int(rng.choice([100, 128, 300, 70000, (1 << 32) - 1]))
+            bins.append({"Value": int(rng.integers(-(1 << 40), 1 << 40)), "Records": [int(x) for x in rng.integers(0, top, size=m, endpoint=True)]})
+        col = {"Name": "b", "DeltaEncodedIDs": True, "BucketEncoded": True, "Bins": bins, "VERSION": 1}
+        p = os.path.join(tmp, "b%d.db" % trial)
+        open(p, "wb").write(G.encode(G.saved_int_column(), col))
+        got = _cxx_json(p)
+        want = [{kk: vv for kk, vv in b.items() if vv not in (0, [])} for b in bins]  # (gob omits zero fields)
+        assert [{kk: vv for kk, vv in b.items() if vv not in (0, [])} for b in got["Bins"]] == want, trial
+
+
+def test_cxx_reader_int_slices_of_every_length(tmp_path):
+    _check_int_slices(str(tmp_path))
+
+
+def test_cxx_reader_int_slices_without_the_window_path(tmp_path):
+    """The same check with the AVX-512 path switched off (a host without VBMI runs this one twice, harmlessly)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, SYBL_GOB_NO_VBMI="1")
+    code = "import sys; sys.path.insert(0, %r); from tests.test_gob import _check_int_slices; _check_int_slices(%r)" % (
+        os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(tmp_path))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
