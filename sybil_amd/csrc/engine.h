@@ -78,7 +78,8 @@ struct Ctx {
     // tiny launches, and on one stream the GPU ran them strictly one after another.  While load_multi is set,
     // `stream` is one of load_streams; code that touches state shared between blocks (a column's staging block, a
     // reallocation) calls load_sync_all first.
-    hipStream_t load_streams[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    static constexpr int kMaxLoadStreams = 32;
+    hipStream_t load_streams[kMaxLoadStreams] = {};
     int n_load_streams = 0;
     bool load_multi = false;
     // the loader's staging arena (loader.cpp: SlabPool), kept between loads: pinning and unpinning a few hundred MB cost

@@ -46,11 +46,13 @@ struct TypeDef {
 // chain is longer than this one's table reads.)
 // Returns the values decoded; *pp moves behind them.  Stops early -- the caller's checked reader takes that value, or
 // reports it, and comes back -- at a marker with eight data bytes or a byte that is no marker.
-template <bool SIGNED>
-__attribute__((target("avx512f,avx512bw,avx512dq,avx512vbmi,bmi,bmi2,lzcnt,popcnt"))) static uint64_t ints_vbmi(const uint8_t **pp, const uint8_t *end,
-                                                                                                               int64_t *dst, uint64_t n) {
+// OUT: int64_t, or a narrower element (int32_t / uint16_t) -- *ovf then collects, as set bits, what did not fit.
+template <bool SIGNED, typename OUT>
+__attribute__((target("avx512f,avx512bw,avx512dq,avx512vbmi,avx512vl,bmi,bmi2,lzcnt,popcnt"))) static uint64_t ints_vbmi(const uint8_t **pp, const uint8_t *end,
+                                                                                                                        OUT *dst, uint64_t n, uint64_t *ovf) {
     const uint8_t *q = *pp;
     uint64_t k = 0;
+    __m512i misfit = _mm512_setzero_si512();
     alignas(64) uint8_t J1[128], J2[64], J4[64], S[128];
     alignas(64) static const uint8_t kIota[64] = {0,  1,  2,  3,  4,  5,  6,  7,  8,  9,  10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21,
                                                   22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 36, 37, 38, 39, 40, 41, 42, 43,
@@ -69,7 +71,10 @@ __attribute__((target("avx512f,avx512bw,avx512dq,avx512vbmi,bmi,bmi2,lzcnt,popcn
             for (int g = 0; g < 8; g++) {
                 __m512i v = _mm512_cvtepu8_epi64(_mm_loadl_epi64((const __m128i *)(q + 8 * g)));
                 if (SIGNED) v = _mm512_xor_si512(_mm512_srli_epi64(v, 1), _mm512_sub_epi64(_mm512_setzero_si512(), _mm512_and_si512(v, _mm512_set1_epi64(1))));
-                _mm512_storeu_si512((void *)(dst + k + 8 * g), v);
+                // (one-byte values fit every element type)
+                if (sizeof(OUT) == 8) _mm512_storeu_si512((void *)(dst + k + 8 * g), v);
+                else if (sizeof(OUT) == 4) _mm256_storeu_si256((__m256i *)(dst + k + 8 * g), _mm512_cvtepi64_epi32(v));
+                else _mm_storeu_si128((__m128i *)(dst + k + 8 * g), _mm512_cvtepi64_epi16(v));
             }
             k += 64;
             q += 64;
@@ -122,17 +127,28 @@ __attribute__((target("avx512f,avx512bw,avx512dq,avx512vbmi,bmi,bmi2,lzcnt,popcn
             __m512i v = _mm512_maskz_permutex2var_epi8(km, x, _mm512_sub_epi8(last, lane_b), x2);
             if (SIGNED) v = _mm512_xor_si512(_mm512_srli_epi64(v, 1), _mm512_sub_epi64(_mm512_setzero_si512(), _mm512_and_si512(v, _mm512_set1_epi64(1))));
             const unsigned left = take - g;
-            _mm512_mask_storeu_epi64((void *)(dst + k + g), left >= 8 ? (__mmask8)0xFF : (__mmask8)((1u << left) - 1), v);
+            const __mmask8 lanes = left >= 8 ? (__mmask8)0xFF : (__mmask8)((1u << left) - 1);
+            if (sizeof(OUT) == 8) {
+                _mm512_mask_storeu_epi64((void *)(dst + k + g), lanes, v);
+            } else if (sizeof(OUT) == 4) {
+                // fits int32: v + 2^31 is below 2^32
+                misfit = _mm512_mask_or_epi64(misfit, lanes, misfit, _mm512_srli_epi64(_mm512_add_epi64(v, _mm512_set1_epi64((int64_t)1 << 31)), 32));
+                _mm512_mask_cvtepi64_storeu_epi32((void *)(dst + k + g), lanes, v);
+            } else {
+                misfit = _mm512_mask_or_epi64(misfit, lanes, misfit, _mm512_srli_epi64(v, 16));
+                _mm512_mask_cvtepi64_storeu_epi16((void *)(dst + k + g), lanes, v);
+            }
         }
         k += take;
         q += S[take];
         if (stop) break;
     }
     *pp = q;
+    if (sizeof(OUT) != 8) *ovf |= (uint64_t)_mm512_reduce_or_epi64(misfit);
     return k;
 }
 static const bool g_have_vbmi = __builtin_cpu_supports("avx512vbmi") && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512dq") &&
-                                __builtin_cpu_supports("bmi2") && !getenv("SYBL_GOB_NO_VBMI");
+                                __builtin_cpu_supports("avx512vl") && __builtin_cpu_supports("bmi2") && !getenv("SYBL_GOB_NO_VBMI");
 #endif
 
 struct Reader {
@@ -170,15 +186,23 @@ struct Reader {
     // + 8 of slack for the unaligned load) every value is one byte test and, past 127, ONE unaligned big-endian 8-byte
     // load shifted down -- no per-byte loop, no per-value bounds checks: the record-id lists of bucket-encoded columns
     // are 65 536 values per column and block, and this loop was most of a table load's 3.3 s of parse CPU.
-    template <bool SIGNED>
-    bool ints(int64_t *dst, uint64_t n) {
+    // OUT: int64_t, or int32_t / uint16_t -- `misfit` then collects (as set bits) what did not fit the element.
+    uint64_t misfit = 0;
+    template <typename OUT>
+    void put(OUT *dst, uint64_t k, int64_t v) {
+        if (sizeof(OUT) == 4) misfit |= ((uint64_t)v + ((uint64_t)1 << 31)) >> 32;
+        else if (sizeof(OUT) == 2) misfit |= (uint64_t)v >> 16;
+        dst[k] = (OUT)v;
+    }
+    template <bool SIGNED, typename OUT = int64_t>
+    bool ints(OUT *dst, uint64_t n) {
         uint64_t k = 0;
 #if defined(__x86_64__)
         // (the 64-byte windows of ints_vbmi; a value it leaves alone goes through the checked reader, one at a time)
         while (g_have_vbmi && n - k >= 16 && left() >= 136) {
-            k += ints_vbmi<SIGNED>(&p, end, dst + k, n - k);
+            k += ints_vbmi<SIGNED, OUT>(&p, end, dst + k, n - k, &misfit);
             if (k < n && left() >= 136) {
-                dst[k++] = SIGNED ? svarint() : (int64_t)uvarint();
+                put(dst, k++, SIGNED ? svarint() : (int64_t)uvarint());
                 if (!ok) return false;
             }
         }
@@ -204,11 +228,11 @@ struct Reader {
                 }
                 // (zig-zag without a branch: the sign bit of a value-encoded column's deltas is a coin toss, and as a
                 // branch it cost more than the rest of the loop -- 8.5 against 3.0 ns per value)
-                dst[k] = SIGNED ? (int64_t)((v >> 1) ^ (0 - (v & 1))) : (int64_t)v;
+                put(dst, k, SIGNED ? (int64_t)((v >> 1) ^ (0 - (v & 1))) : (int64_t)v);
             }
             p = bad ? q - 1 : q;  // (bad: back onto the length byte of the value that stopped the fast loop)
         }
-        for (; k < n && ok; k++) dst[k] = SIGNED ? svarint() : (int64_t)uvarint();
+        for (; k < n && ok; k++) put(dst, k, SIGNED ? svarint() : (int64_t)uvarint());
         return ok;
     }
     double float64() {
@@ -231,6 +255,7 @@ struct Reader {
 struct Decoder {
     std::map<int64_t, TypeDef> types;
     std::string *err;
+    DecodeOpts opts;
 
     bool fail(const std::string &m) {
         *err = "gob: " + m;
@@ -389,6 +414,18 @@ struct Decoder {
             if (n > r.left()) return fail("slice longer than the message");
             if (is_int_kind(td.elem)) {
                 out.kind = Value::kIntVec;
+                if (opts.narrow && depth <= 1) {
+                    // as int32 when every value fits (DecodeOpts); the reader goes back and takes them as int64 when not
+                    const Reader at = r;
+                    out.ints.w = 4;
+                    out.ints.resize((size_t)n);
+                    r.misfit = 0;
+                    const bool fine = td.elem == tInt ? r.ints<true, int32_t>((int32_t *)out.ints.data(), n) : r.ints<false, int32_t>((int32_t *)out.ints.data(), n);
+                    if (!fine) return false;
+                    if (r.misfit == 0) return true;
+                    r = at;
+                    out.ints.w = 8;
+                }
                 out.ints.resize((size_t)n);
                 return td.elem == tInt ? r.ints<true>(out.ints.data(), n) : r.ints<false>(out.ints.data(), n);
             }
@@ -415,9 +452,19 @@ struct Decoder {
                 if (fv >= 0 && fr >= 0) {
                     out.kind = Value::kBinVec;
                     out.bin_order = fr < fv ? 1 : 0;
+                    // (DecodeOpts::narrow: the records as uint16 while they fit; one that does not sends the reader back
+                    // to the first bin to take them all as int64 -- a block of more than 65536 rows, or a damaged file)
+                    bool narrow = opts.narrow && !rs;
+                    const Reader first_bin = r;
+                again:
+                    out.ints.w = narrow ? 2 : 8;
+                    out.ints.resize(0);
+                    out.bin_val.clear();
+                    out.bin_has.clear();
                     out.bin_off.assign(1, 0);
                     out.bin_val.reserve((size_t)n);
                     out.bin_has.reserve((size_t)n);
+                    r.misfit = 0;
                     for (uint64_t k = 0; k < n; k++) {
                         int64_t f = -1, val = 0;
                         uint8_t has = 0;
@@ -435,9 +482,18 @@ struct Decoder {
                                 if (m > r.left()) return fail("slice longer than the message");
                                 const size_t at = out.ints.size();
                                 out.ints.resize(at + (size_t)m);
-                                int64_t *dst = out.ints.data() + at;
-                                if (rs) r.ints<true>(dst, m);
-                                else r.ints<false>(dst, m);
+                                if (narrow) {
+                                    r.ints<false, uint16_t>((uint16_t *)out.ints.data() + at, m);
+                                    if (r.ok && r.misfit) {
+                                        r = first_bin;
+                                        narrow = false;
+                                        goto again;
+                                    }
+                                } else {
+                                    int64_t *dst = out.ints.data() + at;
+                                    if (rs) r.ints<true>(dst, m);
+                                    else r.ints<false>(dst, m);
+                                }
                                 has |= 2;
                             } else {
                                 return fail("struct field index out of range in " + et->second.name);
@@ -547,12 +603,13 @@ void IntBuf::release() {
 }
 
 void IntBuf::resize(size_t m) {
-    if (m > cap) {
+    const size_t need = (m * (size_t)w + 7) / 8;  // int64 units
+    if (need > cap) {
         IntStock &S = g_stock;
         // the smallest stocked buffer that is large enough; else grow (doubling: a bucket-encoded file appends bin by bin)
         int best = -1;
         for (int i = 0; i < S.n; i++)
-            if (S.cap[i] >= m && (best < 0 || S.cap[i] < S.cap[best])) best = i;
+            if (S.cap[i] >= need && (best < 0 || S.cap[i] < S.cap[best])) best = i;
         if (best >= 0 && !p) {
             p = S.p[best];
             cap = S.cap[best];
@@ -560,7 +617,7 @@ void IntBuf::resize(size_t m) {
             S.cap[best] = S.cap[S.n - 1];
             S.n--;
         } else {
-            size_t want = cap * 2 > m ? cap * 2 : m;
+            size_t want = cap * 2 > need ? cap * 2 : need;
             if (want < 4096) want = 4096;
             int64_t *q = (int64_t *)realloc(p, want * sizeof(int64_t));
             if (!q) throw std::bad_alloc();
@@ -572,8 +629,15 @@ void IntBuf::resize(size_t m) {
 }
 
 void IntBuf::assign(const int64_t *src, size_t m) {
+    w = 8;
     resize(m);
     if (m) memcpy(p, src, m * sizeof(int64_t));
+}
+
+void IntBuf::copy_from(const IntBuf &o) {
+    w = o.w;
+    resize(o.n);
+    if (o.n) memcpy(p, o.p, o.n * (size_t)w);
 }
 
 const Value *Value::field(const char *name) const {
@@ -592,9 +656,10 @@ int64_t Value::as_int(int64_t dflt) const {
     }
 }
 
-bool decode(const uint8_t *data, size_t size, Value &out, std::string &err) {
+bool decode(const uint8_t *data, size_t size, Value &out, std::string &err, const DecodeOpts *opts) {
     Decoder d;
     d.err = &err;
+    if (opts) d.opts = *opts;
     return d.run(data, size, out);
 }
 
@@ -735,7 +800,7 @@ void to_json(const Value &v, std::string &o) {
                     o += "\"Records\":[";
                     for (int64_t i = v.bin_off[k]; i < v.bin_off[k + 1]; i++) {
                         if (i > v.bin_off[k]) o += ",";
-                        snprintf(b, sizeof(b), "%lld", (long long)v.ints[(size_t)i]);
+                        snprintf(b, sizeof(b), "%lld", (long long)v.ints.at((size_t)i));
                         o += b;
                     }
                     o += "]";
@@ -754,7 +819,7 @@ void to_json(const Value &v, std::string &o) {
         o += "[";
         for (size_t i = 0; i < v.ints.size(); i++) {
             if (i) o += ",";
-            snprintf(b, sizeof(b), "%lld", (long long)v.ints[i]);
+            snprintf(b, sizeof(b), "%lld", (long long)v.ints.at(i));
             o += b;
         }
         o += "]";

@@ -28,19 +28,20 @@ typedef std::shared_ptr<Value> ValuePtr;
 // the buffers recycled.  IntBuf keeps a few released buffers per thread and does not zero what the decoder is about to
 // fill.
 struct IntBuf {
-    int64_t *p = nullptr;
-    size_t n = 0, cap = 0;
+    int64_t *p = nullptr;   // (as int32_t / uint16_t when w is 4 / 2: data32 / data16)
+    size_t n = 0, cap = 0;  // elements; capacity in int64 units
+    int w = 8;              // bytes per element: 8 everywhere, except where the caller asked for narrow slices (DecodeOpts)
     IntBuf() {}
-    IntBuf(const IntBuf &o) { assign(o.p, o.n); }
-    IntBuf(IntBuf &&o) noexcept : p(o.p), n(o.n), cap(o.cap) { o.p = nullptr, o.n = o.cap = 0; }
+    IntBuf(const IntBuf &o) { copy_from(o); }
+    IntBuf(IntBuf &&o) noexcept : p(o.p), n(o.n), cap(o.cap), w(o.w) { o.p = nullptr, o.n = o.cap = 0; }
     IntBuf &operator=(const IntBuf &o) {
-        if (this != &o) assign(o.p, o.n);
+        if (this != &o) copy_from(o);
         return *this;
     }
     IntBuf &operator=(IntBuf &&o) noexcept {
         if (this != &o) {
             release();
-            p = o.p, n = o.n, cap = o.cap;
+            p = o.p, n = o.n, cap = o.cap, w = o.w;
             o.p = nullptr, o.n = o.cap = 0;
         }
         return *this;
@@ -48,15 +49,30 @@ struct IntBuf {
     ~IntBuf() { release(); }
     size_t size() const { return n; }
     bool empty() const { return n == 0; }
+    // (the int64 view: w == 8)
     int64_t *data() { return p; }
     const int64_t *data() const { return p; }
     int64_t &operator[](size_t i) { return p[i]; }
     const int64_t &operator[](size_t i) const { return p[i]; }
     const int64_t *begin() const { return p; }
     const int64_t *end() const { return p + n; }
-    void resize(size_t m);  // (new elements are NOT initialised)
+    const int32_t *data32() const { return (const int32_t *)p; }
+    const uint16_t *data16() const { return (const uint16_t *)p; }
+    int64_t at(size_t i) const { return w == 8 ? p[i] : w == 4 ? (int64_t)data32()[i] : (int64_t)data16()[i]; }  // any width
+    void resize(size_t m);  // (new elements are NOT initialised; m elements of w bytes)
     void assign(const int64_t *src, size_t m);
     void release();
+
+   private:
+    void copy_from(const IntBuf &o);
+};
+
+// What the caller wants of the int slices (the loader: a block's record ids travel to the GPU as uint16 and its value
+// deltas as int32 -- decoded straight into that form they never exist as 512 KB int64 arrays, which was most of the memory
+// traffic of a load).  narrow: `Records` of a kBinVec come out as uint16 (IntBuf::w == 2) when every one of them fits, a
+// top-level int slice as int32 (w == 4) when every value fits; int64 otherwise, so a reader must look at w.
+struct DecodeOpts {
+    bool narrow = false;
 };
 
 struct Value {
@@ -87,7 +103,7 @@ struct Value {
 };
 
 // Decodes the first top-level value of a gob stream.  Returns false and sets err on failure.
-bool decode(const uint8_t *data, size_t size, Value &out, std::string &err);
+bool decode(const uint8_t *data, size_t size, Value &out, std::string &err, const DecodeOpts *opts = nullptr);
 
 // Reads a file, transparently gunzipping "*.gz" (or trying "<path>.gz" when <path> is missing,
 // like GetFileDecoder, file_decoder.go:55-81).

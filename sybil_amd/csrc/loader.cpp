@@ -75,11 +75,14 @@ static void cgroup_throttle(int64_t *periods, int64_t *usec) {
     fclose(f);
 }
 
-static bool decode_file(const std::string &path, gob::Value &v, std::string &err) {
+// narrow: the int slices in the form they travel in (gob::DecodeOpts) -- the int / str column files of a block
+static bool decode_file(const std::string &path, gob::Value &v, std::string &err, bool narrow = false) {
     static thread_local std::vector<uint8_t> data;  // (reused: no allocation / page faults per file)
     if (!gob::read_file(path, data, err)) return false;
     g_file_bytes += (int64_t)data.size();
-    return gob::decode(data.data(), data.size(), v, err);
+    gob::DecodeOpts opts;
+    opts.narrow = narrow;
+    return gob::decode(data.data(), data.size(), v, err, &opts);
 }
 
 static double seconds_since(std::chrono::steady_clock::time_point t0) {
@@ -305,6 +308,7 @@ static PreparedBlock prepare_block(const std::string &bdir, const std::vector<Co
 struct BinsView {
     int64_t n = 0;
     const int64_t *val = nullptr, *off = nullptr, *recs = nullptr;
+    const uint16_t *recs16 = nullptr;  // the records when the reader produced them as uint16 (then recs is nullptr)
     std::vector<int64_t> own_val, own_off, own_recs;
     explicit BinsView(const gob::Value *bins) {
         static const int64_t zero = 0;
@@ -314,7 +318,8 @@ struct BinsView {
             n = (int64_t)bins->bin_val.size();
             val = bins->bin_val.data();
             off = bins->bin_off.data();
-            recs = bins->ints.data();
+            if (bins->ints.w == 2) recs16 = bins->ints.data16();
+            else recs = bins->ints.data();
             return;
         }
         own_off.push_back(0);
@@ -372,8 +377,38 @@ __attribute__((target("avx512f,avx512bw"))) static void minmax_512(const int64_t
     *lo = a;
     *hi = b;
 }
+// extrema of the running sums of src[0, n) (a value-encoded column's values are the running sums of its deltas): the scan
+// of eight lanes is three shifted adds, the carry into the next eight one broadcast -- the scalar loop's add / min / max
+// chain was 1 ns per value, a tenth of a worker's time per block
+template <typename T>
+__attribute__((target("avx512f,avx512bw"))) static void scan_minmax_512(const T *src, int64_t n, int64_t *lo, int64_t *hi) {
+    const __m512i zero = _mm512_setzero_si512(), last = _mm512_set1_epi64(7);
+    __m512i mn = _mm512_set1_epi64(INT64_MAX), mx = _mm512_set1_epi64(INT64_MIN), carry = zero;
+    int64_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        __m512i d = sizeof(T) == 4 ? _mm512_cvtepi32_epi64(_mm256_loadu_si256((const __m256i *)(src + i))) : _mm512_loadu_si512((const void *)(src + i));
+        d = _mm512_add_epi64(d, _mm512_alignr_epi64(d, zero, 7));
+        d = _mm512_add_epi64(d, _mm512_alignr_epi64(d, zero, 6));
+        d = _mm512_add_epi64(d, _mm512_alignr_epi64(d, zero, 4));
+        d = _mm512_add_epi64(d, carry);
+        mn = _mm512_min_epi64(mn, d);
+        mx = _mm512_max_epi64(mx, d);
+        carry = _mm512_permutexvar_epi64(last, d);
+    }
+    int64_t a = _mm512_reduce_min_epi64(mn), b = _mm512_reduce_max_epi64(mx);
+    uint64_t run = (uint64_t)_mm_cvtsi128_si64(_mm512_castsi512_si128(carry));
+    for (; i < n; i++) {
+        run += (uint64_t)(int64_t)src[i];
+        a = std::min(a, (int64_t)run);
+        b = std::max(b, (int64_t)run);
+    }
+    *lo = a;
+    *hi = b;
+}
 #else
 static const bool g_cpu512 = false;
+template <typename T>
+static void scan_minmax_512(const T *, int64_t, int64_t *, int64_t *) {}
 static uint64_t narrow16_512(const int64_t *, uint16_t *, int64_t) { return 0; }
 static void narrow32_512(const int64_t *, int32_t *, int64_t) {}
 static void minmax_512(const int64_t *, int64_t, int64_t *, int64_t *) {}
@@ -404,6 +439,21 @@ static void minmax64(const int64_t *src, int64_t n, int64_t *lo, int64_t *hi) {
     *hi = b;
 }
 
+// extrema of the running sums of src[0, n) (n = 0: INT64_MAX, INT64_MIN); sums wrap like the reference's int64
+template <typename T>
+static void scan_minmax(const T *src, int64_t n, int64_t *lo, int64_t *hi) {
+    if (g_cpu512) return scan_minmax_512<T>(src, n, lo, hi);
+    int64_t a = INT64_MAX, b = INT64_MIN;
+    uint64_t run = 0;
+    for (int64_t i = 0; i < n; i++) {
+        run += (uint64_t)(int64_t)src[i];
+        a = std::min(a, (int64_t)run);
+        b = std::max(b, (int64_t)run);
+    }
+    *lo = a;
+    *hi = b;
+}
+
 // Bins -> slab: bin values (int64), bin offsets (int64, n_bins + 1) and the record ids as they are in the file
 // (absolute or delta-encoded) at rec_w bytes each.  False: an id beyond NumRecords.
 static bool fill_bins(const BinsView &bv, bool delta, int64_t num_records, char *base, PreparedCol &pc) {
@@ -412,6 +462,27 @@ static bool fill_bins(const BinsView &bv, bool delta, int64_t num_records, char 
     uint32_t *r32 = (uint32_t *)(base + pc.rec_at);
     if (bv.n > 0) memcpy(val, bv.val, (size_t)bv.n * 8);
     memcpy(off, bv.off, (size_t)(bv.n + 1) * 8);
+    if (bv.recs16) {
+        // the reader produced uint16 already (every id / delta is below 65536): what is left is NumRecords
+        const int64_t total = bv.off[bv.n];
+        for (int64_t k = 0; k < bv.n; k++) {
+            const uint16_t *r = bv.recs16 + bv.off[k];
+            const int64_t m = bv.off[k + 1] - bv.off[k];
+            uint64_t top = 0;  // the bin's largest id: the sum of its (unsigned) deltas, or the maximum of its ids
+            if (delta) {
+                for (int64_t i = 0; i < m; i++) top += r[i];
+            } else {
+                for (int64_t i = 0; i < m; i++) top = std::max<uint64_t>(top, r[i]);
+            }
+            if (m > 0 && top >= (uint64_t)num_records) return false;
+        }
+        if (pc.rec_w == 2) {
+            if (total > 0) memcpy(r16, bv.recs16, (size_t)total * 2);
+        } else {
+            for (int64_t i = 0; i < total; i++) r32[i] = bv.recs16[i];
+        }
+        return true;
+    }
     if (delta && pc.rec_w == 2) {
         // the common case (delta-encoded ids, a block of <= 65536 rows) without a branch per id: the deltas are unsigned,
         // so a bin's ids are ascending and its last one -- the sum -- is the one to hold against NumRecords; an id that
@@ -485,7 +556,8 @@ static PreparedBlock prepare_block_unguarded(const std::string &bdir, const std:
         gob::Value &v = trees[ci];
         // a missing file = column unpopulated in this block; "DECODE COL ERR": the reference logs and
         // carries on with an empty column
-        if (!decode_file(path, v, err)) continue;
+        static const bool wide = getenv("SYBL_LOADER_WIDE_DECODE") != nullptr;  // (A/B: int64 slices, narrowed afterwards)
+        if (!decode_file(path, v, err, specs[ci].type != SYBL_SET_VAL && !wide)) continue;
         have[ci] = 1;
         const gob::Value *f;
         const bool bucket = (f = v.field("BucketEncoded")) && f->as_bool();
@@ -515,19 +587,22 @@ static PreparedBlock prepare_block_unguarded(const std::string &bdir, const std:
                 pc.kind = PreparedCol::kIntValues;
                 pc.n_vals = n;
                 // (the stored values / deltas travel as int32 when they all fit; without an exit from the loop it vectorises)
+                // (decode_file asked the reader for int32 where they fit: IntBuf::w says whether they did)
                 int64_t lo = 0, hi = 0;
-                if (ok && n > 0) minmax64(vals->ints.data(), n, &lo, &hi);
+                if (ok && n > 0 && vals->ints.w == 8) minmax64(vals->ints.data(), n, &lo, &hi);
                 pc.val_w = lo < INT32_MIN || hi > INT32_MAX ? 8 : 4;
                 pc.val_at = reserve((size_t)std::max<int64_t>(n, 1) * (size_t)pc.val_w);
             } else {
                 pc.kind = PreparedCol::kStrValues;
                 pc.n_local = n;
                 pc.local_w = 2;
-                for (int64_t k = 0; ok && k < n; k++)
-                    if (vals->ints[(size_t)k] < 0 || vals->ints[(size_t)k] > 65535) {
+                for (int64_t k = 0; ok && k < n; k++) {
+                    const int64_t x = vals->ints.at((size_t)k);
+                    if (x < 0 || x > 65535) {
                         pc.local_w = 4;
                         break;
                     }
+                }
                 pc.local_at = reserve((size_t)std::max<int64_t>(n, 1) * (size_t)pc.local_w);
                 pc.lut_at = reserve(std::max<size_t>(pc.strings.size(), 1) * 4);
             }
@@ -587,18 +662,30 @@ static PreparedBlock prepare_block_unguarded(const std::string &bdir, const std:
             // every row below len(Values) is populated (column_store_io.go:758-766)
             int32_t *o32 = (int32_t *)(base + pc.val_at);
             int64_t *o64 = (int64_t *)(base + pc.val_at);
-            if (vals && vals->kind == gob::Value::kIntVec && vals->ints.size() > 0) {
+            if (vals && vals->kind == gob::Value::kIntVec && vals->ints.size() > 0 && vals->ints.w == 4) {
+                // the reader produced int32 (the form they travel in): extrema from the 256 KB array, then one copy
+                const int32_t *src = vals->ints.data32();
+                const int64_t nv = (int64_t)vals->ints.size();
+                int64_t mn = INT64_MAX, mx = INT64_MIN;
+                if (pc.venc) {
+                    scan_minmax(src, nv, &mn, &mx);
+                } else {
+                    int32_t a = INT32_MAX, b = INT32_MIN;
+                    for (int64_t k = 0; k < nv; k++) {
+                        a = std::min(a, src[k]);
+                        b = std::max(b, src[k]);
+                    }
+                    mn = a, mx = b;
+                }
+                pc.vmin = std::min(pc.vmin, mn);
+                pc.vmax = std::max(pc.vmax, mx);
+                memcpy(o32, src, (size_t)nv * 4);
+            } else if (vals && vals->kind == gob::Value::kIntVec && vals->ints.size() > 0) {
                 const int64_t *src = vals->ints.data();
                 const int64_t nv = (int64_t)vals->ints.size();
                 int64_t mn = INT64_MAX, mx = INT64_MIN;
                 if (pc.venc) {
-                    // (the running sum is the only chain in this loop; the copy below is a loop of its own so that it vectorises)
-                    uint64_t run = 0;
-                    for (int64_t k = 0; k < nv; k++) {
-                        run += (uint64_t)src[k];
-                        mn = std::min(mn, (int64_t)run);
-                        mx = std::max(mx, (int64_t)run);
-                    }
+                    scan_minmax(src, nv, &mn, &mx);
                 } else {
                     minmax64(src, nv, &mn, &mx);
                 }
@@ -618,11 +705,14 @@ static PreparedBlock prepare_block_unguarded(const std::string &bdir, const std:
             int64_t k = 0;
             uint16_t *o16 = (uint16_t *)(base + pc.local_at);
             int32_t *o32 = (int32_t *)(base + pc.local_at);
-            if (vals && vals->kind == gob::Value::kIntVec)
-                for (int64_t x : vals->ints) {
-                    if (pc.local_w == 2) o16[k++] = (uint16_t)x;
-                    else o32[k++] = (int32_t)x;
+            if (vals && vals->kind == gob::Value::kIntVec) {
+                const int64_t nv = (int64_t)vals->ints.size();
+                for (; k < nv; k++) {
+                    const int64_t x = vals->ints.at((size_t)k);
+                    if (pc.local_w == 2) o16[k] = (uint16_t)x;
+                    else o32[k] = (int32_t)x;
                 }
+            }
             break;
         }
         default: break;
@@ -899,6 +989,7 @@ static int load_blocks(Ctx *ctx, Table *t, const std::string &tdir, const std::v
         pool.slab_bytes = align16(per_block);
         if (const char *e = getenv("SYBL_LOADER_SLAB_BYTES")) pool.slab_bytes = align16((size_t)std::max(16, atoi(e)));  // (tests: over-sized blocks)
         pool.max_slabs = std::min<size_t>(std::max<size_t>(((size_t)512 << 20) / pool.slab_bytes, 4), std::max<size_t>(2 * n_workers, 4));
+        if (const char *e = getenv("SYBL_LOADER_SLABS")) pool.max_slabs = (size_t)std::max(2, atoi(e));  // (tuning)
         pool.max_slabs = std::min<size_t>(pool.max_slabs, std::max<size_t>(n_names, 1));
         if ((rc = pool.init(ctx))) return (rc);
     }
@@ -949,8 +1040,12 @@ static int load_blocks(Ctx *ctx, Table *t, const std::string &tdir, const std::v
         }
     } stream_guard{ctx, ctx->stream};
     {
-        int ns = 4;
-        if (const char *e = getenv("SYBL_LOADER_STREAMS")) ns = std::max(1, std::min(8, atoi(e)));
+        // (sixteen: a block's copy -> decode kernels -> event chain is ~100 us of GPU timeline on its stream, mostly the gaps
+        // between dependent commands, and a slab is only handed to the next block when that chain has finished -- with four
+        // streams the workers ran out of slabs: the 7-column bench table loaded in 0.116 s with four, 0.084 s with eight,
+        // 0.063 s with sixteen, tools/r04 sweep in profiles/r04_loader_sweep.txt)
+        int ns = 16;
+        if (const char *e = getenv("SYBL_LOADER_STREAMS")) ns = std::max(1, std::min((int)Ctx::kMaxLoadStreams, atoi(e)));
         if (ns > 1) {
             SYBL_HIP(hipStreamSynchronize(ctx->stream));  // whatever the caller queued comes first
             for (int i = 0; i < ns; i++)
@@ -1241,7 +1336,8 @@ const char *sybl_debug_gob_to_json(const char *path) {
     static thread_local std::string out;
     std::string err;
     gob::Value v;
-    if (!path || !decode_file(path, v, err)) {
+    // (SYBL_DEBUG_GOB_NARROW: the reader's narrow slices, as the loader asks for them -- the JSON must not change)
+    if (!path || !decode_file(path, v, err, getenv("SYBL_DEBUG_GOB_NARROW") != nullptr)) {
         set_error("%s", err.empty() ? "sybl_debug_gob_to_json: bad argument" : err.c_str());
         return nullptr;
     }

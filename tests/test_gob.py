@@ -297,11 +297,19 @@ def test_cxx_reader_int_slices_of_every_length(tmp_path):
     _check_int_slices(str(tmp_path))
 
 
-def test_cxx_reader_int_slices_without_the_window_path(tmp_path):
-    """The same check with the AVX-512 path switched off (a host without VBMI runs this one twice, harmlessly)."""
+import pytest
+
+
+@pytest.mark.parametrize("switches", [{"SYBL_GOB_NO_VBMI": "1"}, {"SYBL_DEBUG_GOB_NARROW": "1"},
+                                      {"SYBL_DEBUG_GOB_NARROW": "1", "SYBL_GOB_NO_VBMI": "1"}],
+                         ids=["scalar", "narrow", "narrow-scalar"])
+def test_cxx_reader_int_slices_other_paths(tmp_path, switches):
+    """The same check with the AVX-512 windows switched off (a host without VBMI runs that one twice, harmlessly) and with
+    the narrow slices the loader asks for (uint16 records / int32 values where they fit, a second pass as int64 where one
+    does not: the JSON is the same)."""
     import subprocess
     import sys
-    env = dict(os.environ, SYBL_GOB_NO_VBMI="1")
+    env = dict(os.environ, **switches)
     code = "import sys; sys.path.insert(0, %r); from tests.test_gob import _check_int_slices; _check_int_slices(%r)" % (
         os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(tmp_path))
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
