@@ -134,13 +134,22 @@ def load_path(ctx, names, rows=100 * 1024 * 1024 // 65536 * 65536, scan_workload
         tdir = os.path.join(root, "loadbench")
         size = sum(os.path.getsize(os.path.join(dp, f)) for dp, _, fs in os.walk(tdir) for f in fs)
         best, scanned = None, None
-        for _ in range(2):
+        opens = []
+        # Three opens from idle, then three back to back.  An open is a burst of ~2 s of CPU in ~0.07 s (32 parser
+        # threads): the GPU boxes' containers have a CFS quota of 16 CPUs per 100 ms period, so an open that starts
+        # behind another burst (the save above, the previous open) is throttled in its middle and takes 0.10-0.14 s,
+        # one that starts from idle is not.  "rows_per_s" is the best open from idle; "back_to_back" says what a host
+        # that reloads continuously gets (the quota's 16 CPUs, not the loader, bound it).
+        for i in range(6):
+            if i < 3:
+                time.sleep(0.3)
             t0 = time.perf_counter()
             tb = ctx.open_table(root, "loadbench", compact=True)
             dt = time.perf_counter() - t0
             assert tb.rows == rows
             st = tb.load_stats()
             hbm = tb.hbm_bytes
+            opens.append(round(dt, 4))
             if scan_workload and scanned is None:
                 q = dict(synth.WORKLOADS[scan_workload]["query"])
                 qy = tb.query(**q)
@@ -163,12 +172,15 @@ def load_path(ctx, names, rows=100 * 1024 * 1024 // 65536 * 65536, scan_workload
                 res.free()
                 qy.free()
             tb.free()
-            if best is None or dt < best[0]:
+            if i < 3 and (best is None or dt < best[0]):
                 best = (dt, st, hbm)
         dt, st, hbm = best
+        b2b = sum(opens[3:]) / len(opens[3:])
         return {"loaded_table_scan": scanned, "rows_per_s": rows / dt, "rows": rows, "columns": names, "seconds": round(dt, 3), "bytes_on_disk": size,
                 "disk_bytes_per_row": size / rows, "hbm_bytes": hbm, "stage_breakdown": st, "save_seconds": round(save_s, 2),
-                "what": "sybl_table_save -> sybl_table_open_flags(SYBL_OPEN_COMPACT), best of 2 (page cache warm)"}
+                "open_seconds": opens, "back_to_back": {"seconds": round(b2b, 4), "rows_per_s": rows / b2b},
+                "what": "sybl_table_save -> sybl_table_open_flags(SYBL_OPEN_COMPACT), page cache warm: best of 3 opens that each start "
+                        "0.3 s after the previous CPU burst; back_to_back: mean of 3 opens without the pause (CFS quota throttling)"}
     finally:
         shutil.rmtree(root, ignore_errors=True)
 
