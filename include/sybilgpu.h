@@ -484,6 +484,15 @@ int64_t sybl_debug_hll_cardinality(const uint8_t *registers);
  * with the library's gob reader.  Library-owned buffer, valid until the next call on the thread. */
 const char *sybl_debug_gob_to_json(const char *path);
 
+/* Test/diagnostic hook: what the loader's worker half (no GPU involved) makes of ONE block directory -- the staging
+ * slab it would send across PCIe -- as a text summary: the block's row count, per column its kind / element widths /
+ * counts / extrema, and an FNV-1a digest of every region of the slab (bin values, bin offsets, record ids, values,
+ * block-local ids, validity prefix) and of the block's string table.  types[i]: SYBL_INT_VAL / SYBL_STR_VAL /
+ * SYBL_SET_VAL.  The CPU test suite holds the decode variants (AVX-512 windows / scalar loops, narrow / wide slices)
+ * against each other with it.  NULL (and sybl_last_error) when the arguments are bad; an unreadable or broken block
+ * is reported in the text.  Library-owned buffer, valid until the next call on the thread. */
+const char *sybl_debug_block_layout(const char *block_dir, const char *const *columns, const int32_t *types, int32_t n_columns);
+
 #ifdef __cplusplus
 }
 #endif

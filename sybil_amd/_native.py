@@ -122,6 +122,7 @@ SIGNATURES = {
     "sybl_table_broken_blocks": (C.c_int64, [P]),
     "sybl_table_load_stats": (C.c_int, [P, C.POINTER(LoadStats)]),
     "sybl_debug_gob_to_json": (C.c_char_p, [C.c_char_p]),
+    "sybl_debug_block_layout": (C.c_char_p, [C.c_char_p, C.POINTER(C.c_char_p), C.POINTER(C.c_int32), C.c_int32]),
     "sybl_debug_regex_match": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int64]),
     "sybl_debug_regex_replace": (C.c_char_p, [C.c_char_p, C.c_char_p, C.c_char_p]),
     "sybl_table_rows": (C.c_int64, [P]),

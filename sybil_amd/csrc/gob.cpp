@@ -53,7 +53,7 @@ __attribute__((target("avx512f,avx512bw,avx512dq,avx512vbmi,avx512vl,bmi,bmi2,lz
     const uint8_t *q = *pp;
     uint64_t k = 0;
     __m512i misfit = _mm512_setzero_si512();
-    alignas(64) uint8_t J1[128], J2[64], J4[64], S[128];
+    alignas(64) uint8_t J1[128], J2[64], J4[64], S[128] = {};  // (S: lanes beyond a window's starts are read, masked out, never used)
     alignas(64) static const uint8_t kIota[64] = {0,  1,  2,  3,  4,  5,  6,  7,  8,  9,  10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21,
                                                   22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 36, 37, 38, 39, 40, 41, 42, 43,
                                                   44, 45, 46, 47, 48, 49, 50, 51, 52, 53, 54, 55, 56, 57, 58, 59, 60, 61, 62, 63};

@@ -622,7 +622,8 @@ static PreparedBlock prepare_block_unguarded(const std::string &bdir, const std:
     char *base = slab_h;
     if (pb.bytes > slab_cap) {
         // larger than the pool's slabs (an over-sized block): a pinned / device pair of its own
-        if (hipSetDevice(device) != hipSuccess || hipHostMalloc((void **)&pb.own_h, pb.bytes, hipHostMallocDefault) != hipSuccess ||
+        // (device < 0: sybl_debug_block_layout, which has no device to ask -- the caller reads pb.bytes and stops)
+        if (device < 0 || hipSetDevice(device) != hipSuccess || hipHostMalloc((void **)&pb.own_h, pb.bytes, hipHostMallocDefault) != hipSuccess ||
             hipMalloc((void **)&pb.own_d, pb.bytes) != hipSuccess) {
             if (pb.own_h) (void)hipHostFree(pb.own_h);
             pb.own_h = pb.own_d = nullptr;
@@ -1343,6 +1344,67 @@ const char *sybl_debug_gob_to_json(const char *path) {
     }
     out.clear();
     gob::to_json(v, out);
+    return out.c_str();
+}
+
+const char *sybl_debug_block_layout(const char *block_dir, const char *const *columns, const int32_t *types, int32_t n_columns) {
+    static thread_local std::string out;
+    if (!block_dir || n_columns < 0 || (n_columns > 0 && (!columns || !types))) {
+        set_error("sybl_debug_block_layout: bad argument");
+        return nullptr;
+    }
+    std::vector<ColSpec> specs;
+    for (int32_t i = 0; i < n_columns; i++) {
+        if (!columns[i] || (types[i] != SYBL_INT_VAL && types[i] != SYBL_STR_VAL && types[i] != SYBL_SET_VAL)) {
+            set_error("sybl_debug_block_layout: bad column %d", (int)i);
+            return nullptr;
+        }
+        specs.push_back({columns[i], (int)types[i]});
+    }
+    // (a plain host buffer of the size load_blocks gives a slab; a block that needs more is reported, not loaded: the
+    // pinned pair of its own would ask for a device)
+    size_t cap = 65536;
+    for (auto &sp : specs) cap += sp.type == SYBL_SET_VAL ? 0 : (size_t)65536 * (sp.type == SYBL_STR_VAL ? 12 : 8) + ((size_t)96 << 10);
+    std::vector<char> slab(cap);
+    PreparedBlock pb;
+    try {
+        pb = prepare_block_unguarded(block_dir, specs, slab.data(), cap, -1);
+    } catch (const std::exception &e) {
+        out = std::string("exception: ") + e.what();
+        return out.c_str();
+    }
+    char b[512];
+    auto fnv = [](const void *p, size_t n, uint64_t h = 1469598103934665603ull) {
+        const unsigned char *c = (const unsigned char *)p;
+        for (size_t i = 0; i < n; i++) h = (h ^ c[i]) * 1099511628211ull;
+        return h;
+    };
+    snprintf(b, sizeof(b), "rows=%lld unreadable=%d broken=%d bytes=%zu%s\n", (long long)pb.nrows, (int)pb.unreadable, (int)pb.broken, pb.bytes,
+             pb.bytes > cap ? " (beyond a slab)" : "");
+    out = b;
+    if (pb.unreadable || pb.broken || pb.bytes > cap) return out.c_str();  // (beyond a slab: marked unreadable above, nothing was laid out)
+    const char *H = slab.data();
+    for (size_t ci = 0; ci < pb.cols.size(); ci++) {
+        const PreparedCol &pc = pb.cols[ci];
+        uint64_t hs = 1469598103934665603ull;
+        for (auto &st : pc.strings) hs = fnv(st.data(), st.size() + 1, hs);
+        uint64_t hset = fnv(pc.set_off.data(), pc.set_off.size() * 8);
+        hset = fnv(pc.set_ids.data(), pc.set_ids.size() * 4, hset);
+        hset = fnv(pc.set_pop.data(), pc.set_pop.size(), hset);
+        const bool bins = pc.kind == PreparedCol::kIntBins || pc.kind == PreparedCol::kStrBins;
+        snprintf(b, sizeof(b),
+                 "%s kind=%d delta=%d venc=%d rec_w=%d val_w=%d local_w=%d recs=%lld bins=%lld vals=%lld local=%lld bits=%lld stats=%d min=%lld max=%lld pop=%lld "
+                 "strings=%zu:%016llx binval=%016llx binoff=%016llx rec=%016llx val=%016llx loc=%016llx valid=%016llx set=%016llx\n",
+                 specs[ci].name.c_str(), (int)pc.kind, (int)pc.delta, (int)pc.venc, pc.rec_w, pc.val_w, pc.local_w, (long long)pc.n_recs, (long long)pc.n_bins,
+                 (long long)pc.n_vals, (long long)pc.n_local, (long long)pc.bits_words, (int)pc.have_stats, (long long)(pc.have_stats ? pc.vmin : 0),
+                 (long long)(pc.have_stats ? pc.vmax : 0), (long long)pc.vpop, pc.strings.size(), (unsigned long long)hs,
+                 (unsigned long long)(bins ? fnv(H + pc.binval_at, (size_t)pc.n_bins * 8) : 0), (unsigned long long)(bins ? fnv(H + pc.binoff_at, (size_t)(pc.n_bins + 1) * 8) : 0),
+                 (unsigned long long)(bins ? fnv(H + pc.rec_at, (size_t)pc.n_recs * (size_t)pc.rec_w) : 0),
+                 (unsigned long long)(pc.kind == PreparedCol::kIntValues ? fnv(H + pc.val_at, (size_t)pc.n_vals * (size_t)pc.val_w) : 0),
+                 (unsigned long long)(pc.kind == PreparedCol::kStrValues ? fnv(H + pc.local_at, (size_t)pc.n_local * (size_t)pc.local_w) : 0),
+                 (unsigned long long)(pc.bits_words > 0 ? fnv(H + pc.bits_at, (size_t)pc.bits_words * 4) : 0), (unsigned long long)hset);
+        out += b;
+    }
     return out.c_str();
 }
 

@@ -1,0 +1,148 @@
+"""The loader's worker half on the CPU (csrc/loader.cpp:prepare_block through the sybl_debug_block_layout hook): what one
+block directory in the reference's on-disk format (column_store_io.go:64-358) becomes before it crosses PCIe -- element
+widths, counts, extrema, and a digest of every region of the staging slab.  The decode variants must agree byte for byte:
+the AVX-512 VBMI varint windows against the scalar loops, slices decoded straight to uint16 / int32 against int64 slices
+narrowed afterwards, the AVX-512 copies / scans against the plain loops.  (What the GPU then makes of the slab is
+tests/test_gpu_loader.py's business.)"""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from tests import sybil_fixture as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TYPES = {"int": 1, "str": 2, "set": 3}
+
+
+def layout(block_dir, cols):
+    """cols: [(name, "int" | "str" | "set")]"""
+    from sybil_amd import _native as N
+    names = (C.c_char_p * len(cols))(*[c.encode() for c, _ in cols])
+    types = (C.c_int32 * len(cols))(*[TYPES[t] for _, t in cols])
+    s = N.lib().sybl_debug_block_layout(block_dir.encode(), names, types, len(cols))
+    assert s is not None, N.lib().sybl_last_error()
+    return s.decode()
+
+
+def _fields(line):
+    name, rest = line.split(" ", 1)
+    return name, dict(kv.split("=", 1) for kv in rest.split())
+
+
+def _blocks(root):
+    """A table whose blocks walk through the encodings: (block rows, {column: spec})."""
+    rng = np.random.default_rng(21)
+    out = []
+    for n in (1, 100, 5003, 65536):
+        pop = rng.random(n) > 0.25
+        vocab = ["host%05d" % i for i in range(7000)]
+        few = [None if rng.random() < 0.1 else vocab[int(i)] for i in rng.integers(0, 40, n)]
+        many = [vocab[int(i)] for i in rng.integers(0, 7000, n)]
+        tags = [None if rng.random() < 0.2 else ["t%d" % x for x in rng.integers(0, 9, size=int(rng.integers(1, 4)))] for _ in range(n)]
+        out.append({
+            "low": ("int", rng.integers(-5, 40, n)),                               # bucket encoded, one-byte id deltas
+            "mid": ("int", rng.integers(0, 1000, n)),                              # bucket encoded, one/two/three-byte deltas
+            "holes": ("int", rng.integers(0, 50, n), pop),                         # bucket encoded with missing rows
+            "vals": ("int", rng.integers(0, 1_000_000, n)),                        # value encoded above 5000 distinct: int32 deltas
+            "wide": ("int", rng.integers(-(1 << 45), 1 << 45, n)),                 # value encoded, deltas beyond int32
+            "vholes": ("int", rng.integers(0, 1_000_000, n), pop),                 # value encoded with missing rows
+            "const": ("int", np.full(n, 7)),
+            "few": ("str", few), "many": ("str", many), "tags": ("set", tags)})
+    F.write_table(root, "t", out, extra_dirs=False)
+    return out
+
+
+COLS = [("low", "int"), ("mid", "int"), ("holes", "int"), ("vals", "int"), ("wide", "int"), ("vholes", "int"), ("const", "int"),
+        ("few", "str"), ("many", "str"), ("tags", "set"), ("absent", "int")]
+
+
+@pytest.fixture(scope="module")
+def table(tmp_path_factory):
+    root = str(tmp_path_factory.mktemp("layout"))
+    return root, _blocks(root)
+
+
+def _all_layouts(root, n_blocks):
+    return [layout(os.path.join(root, "t", "block%09d" % (b + 1)), COLS) for b in range(n_blocks)]
+
+
+def test_layout_of_known_blocks(table):
+    root, blocks = table
+    for b, text in enumerate(_all_layouts(root, len(blocks))):
+        lines = text.strip().split("\n")
+        head = dict(kv.split("=") for kv in lines[0].split()[:3])
+        n = len(blocks[b]["low"][1])
+        assert head == {"rows": str(n), "unreadable": "0", "broken": "0"}, lines[0]
+        cols = dict(_fields(l) for l in lines[1:])
+        assert set(cols) == {c for c, _ in COLS}
+        # fully populated int columns: the worker's extrema are the column's
+        for name in ("low", "mid", "vals", "wide", "const"):
+            v = np.asarray(blocks[b][name][1], dtype=np.int64)
+            f = cols[name]
+            assert f["stats"] == "1" and int(f["min"]) == v.min() and int(f["max"]) == v.max() and int(f["pop"]) == n, (b, name, f)
+        # encodings as the writer chose them (CARDINALITY_THRESHOLD = 5000): bins below, per-row values above
+        assert cols["low"]["kind"] == "1" and int(cols["low"]["bins"]) == len(set(blocks[b]["low"][1].tolist()))
+        assert int(cols["low"]["recs"]) == n and cols["low"]["rec_w"] == "2"
+        assert cols["few"]["kind"] == "3" and cols["tags"]["kind"] == "5" and cols["absent"]["kind"] == "0"
+        if n == 65536:
+            assert cols["vals"]["kind"] == "2" and cols["vals"]["venc"] == "1" and cols["vals"]["val_w"] == "4" and int(cols["vals"]["vals"]) == n
+            assert cols["wide"]["kind"] == "2" and cols["wide"]["val_w"] == "8"
+            assert cols["many"]["kind"] == "4" and cols["many"]["local_w"] == "2" and int(cols["many"]["strings"].split(":")[0]) > 5000
+        # rows without a value: the ids cover the populated rows only
+        holes = blocks[b]["holes"]
+        assert int(cols["holes"]["recs"]) == int(np.count_nonzero(holes[2]))
+
+
+SWITCHES = [{"SYBL_LOADER_WIDE_DECODE": "1"}, {"SYBL_GOB_NO_VBMI": "1", "SYBL_LOADER_NO_AVX512": "1"},
+            {"SYBL_LOADER_WIDE_DECODE": "1", "SYBL_GOB_NO_VBMI": "1", "SYBL_LOADER_NO_AVX512": "1"}]
+
+
+@pytest.mark.parametrize("switches", SWITCHES, ids=["wide", "scalar", "wide-scalar"])
+def test_decode_variants_lay_out_the_same_slab(table, switches):
+    """(the switches are read when the library loads: a process each)"""
+    root, blocks = table
+    want = _all_layouts(root, len(blocks))
+    code = ("import sys, json; sys.path.insert(0, %r); from tests.test_loader_layout import _all_layouts; "
+            "print(json.dumps(_all_layouts(%r, %d)))" % (ROOT, root, len(blocks)))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **switches), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = json.loads(r.stdout.strip().split("\n")[-1])
+    for b in range(len(blocks)):
+        assert got[b] == want[b], "block %d:\n%s\n--- default:\n%s" % (b + 1, got[b], want[b])
+
+
+def test_damaged_blocks_are_reported_not_laid_out(tmp_path):
+    """A record id at or beyond NumRecords, more values than rows: "BLOCK SIZE CHANGED DURING QUERY" (column_store_io.go:
+    524-526,572-574,733-735) -- the block is marked broken whichever decode path saw it; a missing info.db: unreadable."""
+    from tests import gobfmt as G
+    root = str(tmp_path)
+    rng = np.random.default_rng(2)
+    n = 3000
+    F.write_table(root, "t", [{"a": ("int", rng.integers(0, 20, n)), "b": ("int", rng.integers(0, 1_000_000, n))}], threshold=10, extra_dirs=False)
+    bdir = os.path.join(root, "t", "block000000001")
+    cols = [("a", "int"), ("b", "int")]
+    assert "broken=0" in layout(bdir, cols)
+    good = open(os.path.join(bdir, "int_a.db"), "rb").read()
+    # an id beyond the block (delta-encoded: the bin's ids sum past NumRecords)
+    col = {"Name": "a", "DeltaEncodedIDs": True, "BucketEncoded": True, "VERSION": 1,
+           "Bins": [{"Value": 1, "Records": [5, 10, 2990]}, {"Value": 2, "Records": [0, 1]}]}
+    open(os.path.join(bdir, "int_a.db"), "wb").write(G.encode(G.saved_int_column(), col))
+    assert "broken=1" in layout(bdir, cols)
+    col["Bins"][0]["Records"] = [5, 10, 70000]  # (does not fit uint16: the narrow reader goes back for int64)
+    open(os.path.join(bdir, "int_a.db"), "wb").write(G.encode(G.saved_int_column(), col))
+    assert "broken=1" in layout(bdir, cols)
+    col["Bins"][0]["Records"] = [5, 10, 2984]   # the last row exactly: fine
+    open(os.path.join(bdir, "int_a.db"), "wb").write(G.encode(G.saved_int_column(), col))
+    assert "broken=0" in layout(bdir, cols)
+    open(os.path.join(bdir, "int_a.db"), "wb").write(good)
+    # more values than NumRecords
+    vcol = {"Name": "b", "ValueEncoded": True, "Values": [1] * (n + 1), "VERSION": 1}
+    open(os.path.join(bdir, "int_b.db"), "wb").write(G.encode(G.saved_int_column(), vcol))
+    assert "broken=1" in layout(bdir, cols)
+    os.remove(os.path.join(bdir, "info.db"))
+    assert "unreadable=1" in layout(bdir, cols)
