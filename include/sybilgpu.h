@@ -169,7 +169,7 @@ const void *sybl_debug_encode_column(int kind, const char *name, const int64_t *
  * order. */
 typedef struct {
     double wall_s;          /* sybl_table_open, start to finish */
-    double parse_cpu_s;     /* summed over worker threads: file read + gob decode + flatten */
+    double parse_cpu_s;     /* CPU time (CLOCK_THREAD_CPUTIME_ID) summed over worker threads: file read + gob decode + flatten */
     double wait_s;          /* calling thread blocked on the next block's worker */
     double apply_s;         /* calling thread: dictionaries, pinned-ring copies, kernel launches, block commit */
     int64_t file_bytes;     /* bytes read from column / info files (after gunzip) */
