@@ -61,6 +61,12 @@ static int64_t thread_cpu_ns() {
     if (clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts) != 0) return 0;
     return (int64_t)ts.tv_sec * 1000000000ll + ts.tv_nsec;
 }
+// CPU time of the whole process so far (every thread: the workers, the loading thread, the HIP runtime's own)
+static double process_cpu_s() {
+    struct timespec ts;
+    if (clock_gettime(CLOCK_PROCESS_CPUTIME_ID, &ts) != 0) return 0;
+    return (double)ts.tv_sec + (double)ts.tv_nsec * 1e-9;
+}
 // the cgroup's CPU throttling so far (cgroup v2 cpu.stat: periods throttled, microseconds throttled); zeros when unreadable
 static void cgroup_throttle(int64_t *periods, int64_t *usec) {
     *periods = *usec = 0;
@@ -1062,6 +1068,7 @@ static int load_blocks(Ctx *ctx, Table *t, const std::string &tdir, const std::v
     g_parse_wall_ns = 0;
     int64_t thr_n0, thr_us0;
     cgroup_throttle(&thr_n0, &thr_us0);
+    const double cpu0 = process_cpu_s();
     double wait_s = 0, apply_s = 0;
     int64_t h2d_bytes = 0;
     std::vector<std::vector<int32_t>> luts;
@@ -1144,8 +1151,9 @@ static int load_blocks(Ctx *ctx, Table *t, const std::string &tdir, const std::v
     if (trace) {
         int64_t thr_n1, thr_us1;
         cgroup_throttle(&thr_n1, &thr_us1);
-        fprintf(stderr, "loader: %zu workers, parse %.3f s CPU in %.3f s of worker time; cgroup throttled %lld periods, %.3f s\n", n_workers,
-                (double)g_parse_ns.load() * 1e-9, (double)g_parse_wall_ns.load() * 1e-9, (long long)(thr_n1 - thr_n0), (double)(thr_us1 - thr_us0) * 1e-6);
+        fprintf(stderr, "loader: %zu workers, parse %.3f s CPU in %.3f s of worker time, the whole process %.3f s CPU; cgroup throttled %lld periods, %.3f s\n",
+                n_workers, (double)g_parse_ns.load() * 1e-9, (double)g_parse_wall_ns.load() * 1e-9, process_cpu_s() - cpu0, (long long)(thr_n1 - thr_n0),
+                (double)(thr_us1 - thr_us0) * 1e-6);
     }
     if (trace)
         fprintf(stderr, "loader: dictionaries %.3f s, copy %.3f s, column kernels %.3f s, commit %.3f s, submit %.3f s, wait %.3f s, slabs %zu x %zu KB\n",
