@@ -135,7 +135,7 @@ def load_path(ctx, names, rows=100 * 1024 * 1024 // 65536 * 65536, scan_workload
         size = sum(os.path.getsize(os.path.join(dp, f)) for dp, _, fs in os.walk(tdir) for f in fs)
         best, scanned = None, None
         opens = []
-        # Three opens from idle, then three back to back.  An open is a burst of ~2 s of CPU in ~0.07 s (32 parser
+        # Three opens from idle, then three back to back.  An open is a burst of ~1.8 s of CPU in ~0.07 s (32 parser
         # threads): the GPU boxes' containers have a CFS quota of 16 CPUs per 100 ms period, so an open that starts
         # behind another burst (the save above, the previous open) is throttled in its middle and takes 0.10-0.14 s,
         # one that starts from idle is not.  "rows_per_s" is the best open from idle; "back_to_back" says what a host
