@@ -40,10 +40,12 @@ struct TypeDef {
 // a value that would start at byte i); J2 = J1 o J1 and J4 = J2 o J2 come from one byte permute each (vpermb), so the walk
 // from value to value advances FOUR values per dependent table read and only collects where values start.  The values
 // themselves are then gathered eight at a time: one two-table byte permute (vpermi2b) moves every value's data bytes,
-// reversed, into its own 64-bit lane.  (Measured on this round's build host, ns per value, scalar -> windows: a column
-// of 1000 distinct values 4.4 -> 2.2, of 64 2.8 -> 1.2, of 16 0.9 -> 0.25, value-encoded 3.2 -> 2.3.  A variant that
-// finds all 64 starts by doubling in registers -- J8 .. J32, six masked permutes -- came out the same: its window-to-window
-// chain is longer than this one's table reads.)
+// reversed, into its own 64-bit lane.  Two shortcuts in front of the walk: a leading run of one-byte values is copied, and a
+// leading run of six or more values of three data bytes -- a value-encoded column's deltas -- is turned into numbers by one
+// byte shuffle (every fourth byte is the marker 0xFD, so those are the starts).  (Measured on this round's build host, ns
+// per value, scalar -> windows: a column of 1000 distinct values 4.4 -> 2.0, of 64 2.8 -> 1.0, of 16 0.9 -> 0.25,
+// value-encoded 3.2 -> 1.6-1.9.  A variant that finds all 64 starts by doubling in registers -- J8 .. J32, six masked
+// permutes -- came out the same as the walk: its window-to-window chain is longer than this one's table reads.)
 // Returns the values decoded; *pp moves behind them.  Stops early -- the caller's checked reader takes that value, or
 // reports it, and comes back -- at a marker with eight data bytes or a byte that is no marker.
 // OUT: int64_t, or a narrower element (int32_t / uint16_t) -- *ovf then collects, as set bits, what did not fit.
@@ -63,22 +65,59 @@ __attribute__((target("avx512f,avx512bw,avx512dq,avx512vbmi,avx512vl,bmi,bmi2,lz
     _mm512_store_si512((void *)(J1 + 64), _mm512_add_epi8(iota, c64));
     const __m512i lane_b = _mm512_set1_epi64(0x0706050403020100ll);  // a byte's place in its 64-bit lane
     const __m512i rep0 = _mm512_broadcast_i32x4(_mm_set_epi8(8, 8, 8, 8, 8, 8, 8, 8, 0, 0, 0, 0, 0, 0, 0, 0));  // a lane's low byte, eight times
+// eight raw values in 64-bit lanes -> zig-zag (SIGNED) -> dst[0 .. 7] under a lane mask, as OUT; what does not fit OUT is noted
+// (a macro, not a lambda: a lambda is a function of its own and does not inherit the target attribute)
+#define SYBL_EMIT8(RAW, LANES, DST)                                                                                                              \
+    do {                                                                                                                                         \
+        __m512i v_ = (RAW);                                                                                                                      \
+        const __mmask8 m_ = (LANES);                                                                                                             \
+        if (SIGNED) v_ = _mm512_xor_si512(_mm512_srli_epi64(v_, 1), _mm512_sub_epi64(_mm512_setzero_si512(), _mm512_and_si512(v_, _mm512_set1_epi64(1)))); \
+        if (sizeof(OUT) == 8) {                                                                                                                  \
+            _mm512_mask_storeu_epi64((void *)(DST), m_, v_);                                                                                     \
+        } else if (sizeof(OUT) == 4) { /* fits int32: v + 2^31 is below 2^32 */                                                                  \
+            misfit = _mm512_mask_or_epi64(misfit, m_, misfit, _mm512_srli_epi64(_mm512_add_epi64(v_, _mm512_set1_epi64((int64_t)1 << 31)), 32));  \
+            _mm512_mask_cvtepi64_storeu_epi32((void *)(DST), m_, v_);                                                                            \
+        } else {                                                                                                                                 \
+            misfit = _mm512_mask_or_epi64(misfit, m_, misfit, _mm512_srli_epi64(v_, 16));                                                         \
+            _mm512_mask_cvtepi64_storeu_epi16((void *)(DST), m_, v_);                                                                            \
+        }                                                                                                                                        \
+    } while (0)
+    // a dword "FD b2 b1 b0" (memory order) -> b2 b1 b0 as a little-endian number
+    const __m512i be24 = _mm512_broadcast_i32x4(_mm_set_epi8((char)0x80, 13, 14, 15, (char)0x80, 9, 10, 11, (char)0x80, 5, 6, 7, (char)0x80, 1, 2, 3));
     while (k < n && (size_t)(end - q) >= 136) {
         const __m512i x = _mm512_loadu_si512((const void *)q), x2 = _mm512_loadu_si512((const void *)(q + 64));
         const __mmask64 hi = _mm512_movepi8_mask(x);  // bytes >= 128
-        if (hi == 0 && n - k >= 64) {
-            // 64 one-byte values
-            for (int g = 0; g < 8; g++) {
-                __m512i v = _mm512_cvtepu8_epi64(_mm_loadl_epi64((const __m128i *)(q + 8 * g)));
-                if (SIGNED) v = _mm512_xor_si512(_mm512_srli_epi64(v, 1), _mm512_sub_epi64(_mm512_setzero_si512(), _mm512_and_si512(v, _mm512_set1_epi64(1))));
-                // (one-byte values fit every element type)
-                if (sizeof(OUT) == 8) _mm512_storeu_si512((void *)(dst + k + 8 * g), v);
-                else if (sizeof(OUT) == 4) _mm256_storeu_si256((__m256i *)(dst + k + 8 * g), _mm512_cvtepi64_epi32(v));
-                else _mm_storeu_si128((__m128i *)(dst + k + 8 * g), _mm512_cvtepi64_epi16(v));
+        {
+            // A run of values of three data bytes -- what a value-encoded column's deltas are, nineteen in twenty -- needs no
+            // walk: the window starts on a value, so while every fourth byte is the marker 0xFD those ARE the starts.  One
+            // byte shuffle turns up to sixteen of them into numbers (the general path below is ~5 cycles per value).
+            const uint64_t fd = _mm512_cmpeq_epi8_mask(x, _mm512_set1_epi8((char)0xFD));
+            const unsigned run = (unsigned)_tzcnt_u64(~(fd | ~0x1111111111111111ull)) >> 2;  // leading values "FD b b b"
+            if (run >= 6) {
+                const unsigned take = (unsigned)(n - k < run ? n - k : run);
+                const __m512i w = _mm512_shuffle_epi8(x, be24);
+                SYBL_EMIT8(_mm512_cvtepu32_epi64(_mm512_castsi512_si256(w)), take >= 8 ? (__mmask8)0xFF : (__mmask8)((1u << take) - 1), dst + k);
+                if (take > 8)
+                    SYBL_EMIT8(_mm512_cvtepu32_epi64(_mm512_extracti64x4_epi64(w, 1)), take >= 16 ? (__mmask8)0xFF : (__mmask8)((1u << (take - 8)) - 1),
+                               dst + k + 8);
+                k += take;
+                q += 4 * take;
+                continue;
             }
-            k += 64;
-            q += 64;
-            continue;
+        }
+        {
+            // a leading run of one-byte values (the whole window for a column whose id deltas all fit seven bits) is copied, not walked
+            const unsigned run = hi ? (unsigned)_tzcnt_u64(hi) : 64;
+            if (run >= 8) {
+                const unsigned take = (unsigned)(n - k < run ? n - k : run);
+                for (unsigned g = 0; g < take; g += 8) {
+                    const unsigned left = take - g;
+                    SYBL_EMIT8(_mm512_cvtepu8_epi64(_mm_loadl_epi64((const __m128i *)(q + g))), left >= 8 ? (__mmask8)0xFF : (__mmask8)((1u << left) - 1), dst + k + g);
+                }
+                k += take;
+                q += take;
+                continue;
+            }
         }
         // data bytes behind byte i if a value starts there: 0 below 128, else 256 - x = -x (mod 256)
         __m512i u = _mm512_maskz_sub_epi8(hi, _mm512_setzero_si512(), x);
@@ -125,19 +164,8 @@ __attribute__((target("avx512f,avx512bw,avx512dq,avx512vbmi,avx512vl,bmi,bmi2,lz
             // lane byte b <- window byte last - b for b < u (b = 0 always): the data bytes, least significant first
             const __mmask64 km = _mm512_cmplt_epu8_mask(lane_b, ub) | 0x0101010101010101ull;
             __m512i v = _mm512_maskz_permutex2var_epi8(km, x, _mm512_sub_epi8(last, lane_b), x2);
-            if (SIGNED) v = _mm512_xor_si512(_mm512_srli_epi64(v, 1), _mm512_sub_epi64(_mm512_setzero_si512(), _mm512_and_si512(v, _mm512_set1_epi64(1))));
             const unsigned left = take - g;
-            const __mmask8 lanes = left >= 8 ? (__mmask8)0xFF : (__mmask8)((1u << left) - 1);
-            if (sizeof(OUT) == 8) {
-                _mm512_mask_storeu_epi64((void *)(dst + k + g), lanes, v);
-            } else if (sizeof(OUT) == 4) {
-                // fits int32: v + 2^31 is below 2^32
-                misfit = _mm512_mask_or_epi64(misfit, lanes, misfit, _mm512_srli_epi64(_mm512_add_epi64(v, _mm512_set1_epi64((int64_t)1 << 31)), 32));
-                _mm512_mask_cvtepi64_storeu_epi32((void *)(dst + k + g), lanes, v);
-            } else {
-                misfit = _mm512_mask_or_epi64(misfit, lanes, misfit, _mm512_srli_epi64(v, 16));
-                _mm512_mask_cvtepi64_storeu_epi16((void *)(dst + k + g), lanes, v);
-            }
+            SYBL_EMIT8(v, left >= 8 ? (__mmask8)0xFF : (__mmask8)((1u << left) - 1), dst + k + g);
         }
         k += take;
         q += S[take];
@@ -146,6 +174,7 @@ __attribute__((target("avx512f,avx512bw,avx512dq,avx512vbmi,avx512vl,bmi,bmi2,lz
     *pp = q;
     if (sizeof(OUT) != 8) *ovf |= (uint64_t)_mm512_reduce_or_epi64(misfit);
     return k;
+#undef SYBL_EMIT8
 }
 static const bool g_have_vbmi = __builtin_cpu_supports("avx512vbmi") && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512dq") &&
                                 __builtin_cpu_supports("avx512vl") && __builtin_cpu_supports("bmi2") && !getenv("SYBL_GOB_NO_VBMI");

@@ -262,6 +262,12 @@ def _check_int_slices(tmp):
             pool = [0, -1, 1, 63, 64, -64, -65, 127, 128, 255, 256, 65535, 65536, (1 << 31) - 1, -(1 << 31), (1 << 55), (1 << 56) - 1, 1 << 56,
                     (1 << 62), (1 << 63) - 1, -(1 << 63), -(1 << 56), -(1 << 55) - 1]
             return [pool[int(i)] for i in rng.integers(0, len(pool), size=n)]
+        if kind == "runs3":  # stretches of 1..20 values of three data bytes (the reader's shuffle path takes six or more) between others
+            out = []
+            while len(out) < n:
+                out += [int(x) * (1 if rng.random() < 0.5 else -1) for x in rng.integers(1 << 15, 1 << 23, size=int(rng.integers(1, 21)))]
+                out.append([5, -300, 1 << 40, -(1 << 62), 70000][int(rng.integers(0, 5))])
+            return out[:n]
         runs, out = [], []  # "runs": long one-byte stretches broken by wide values
         while len(out) < n:
             out += [int(x) for x in rng.integers(-60, 60, size=int(rng.integers(1, 200)))]
@@ -269,7 +275,7 @@ def _check_int_slices(tmp):
         return out[:n]
 
     k = 0
-    for kind in ("bytes", "mixed", "deltas", "extremes", "runs"):
+    for kind in ("bytes", "mixed", "deltas", "extremes", "runs", "runs3"):
         for n in (0, 1, 7, 15, 16, 17, 63, 64, 65, 200, 1000, 5003):
             vals = ints(n, kind)
             col = {"Name": "v", "ValueEncoded": True, "Values": vals, "VERSION": 1}

@@ -11,8 +11,21 @@ int main() {
     for (int t = 0; t < 200000; t++) {
         size_t len = 136 + rng() % 600;
         std::vector<uint8_t> buf(len);
-        int mode = rng() % 4;
-        for (auto &b : buf) {
+        int mode = rng() % 5;
+        if (mode == 4) {
+            // valid values, nearly all of three data bytes (a value-encoded column's deltas), now and then another length
+            size_t i = 0;
+            while (i + 10 < len) {
+                const unsigned nb = rng() % 12 == 0 ? (unsigned)(rng() % 9) : 3;
+                if (nb == 0) buf[i++] = (uint8_t)(rng() % 128);
+                else {
+                    buf[i++] = (uint8_t)(256 - nb);
+                    for (unsigned j = 0; j < nb; j++) buf[i++] = (uint8_t)rng();
+                }
+            }
+            for (; i < len; i++) buf[i] = 0;
+        }
+        if (mode != 4) for (auto &b : buf) {
             uint64_t r = rng();
             if (mode == 0) b = (uint8_t)r;                                   // soup
             else if (mode == 1) b = (r % 10 < 7) ? (uint8_t)(r >> 8) % 128 : (uint8_t)(0xF8 + (r >> 8) % 8);   // markers and small
