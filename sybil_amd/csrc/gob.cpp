@@ -631,7 +631,7 @@ void IntBuf::release() {
     n = cap = 0;
 }
 
-void IntBuf::resize(size_t m) {
+void IntBuf::grow(size_t m) {
     const size_t need = (m * (size_t)w + 7) / 8;  // int64 units
     if (need > cap) {
         IntStock &S = g_stock;

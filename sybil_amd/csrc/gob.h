@@ -59,12 +59,18 @@ struct IntBuf {
     const int32_t *data32() const { return (const int32_t *)p; }
     const uint16_t *data16() const { return (const uint16_t *)p; }
     int64_t at(size_t i) const { return w == 8 ? p[i] : w == 4 ? (int64_t)data32()[i] : (int64_t)data16()[i]; }  // any width
-    void resize(size_t m);  // (new elements are NOT initialised; m elements of w bytes)
+    // (new elements are NOT initialised; m elements of w bytes.  Inline while the buffer holds them: a bucket-encoded file
+    // appends bin by bin, a thousand times per column file)
+    void resize(size_t m) {
+        if ((m * (size_t)w + 7) / 8 <= cap) n = m;
+        else grow(m);
+    }
     void assign(const int64_t *src, size_t m);
     void release();
 
    private:
     void copy_from(const IntBuf &o);
+    void grow(size_t m);
 };
 
 // What the caller wants of the int slices (the loader: a block's record ids travel to the GPU as uint16 and its value
