@@ -655,6 +655,7 @@ int query_finalize(Query *q, Result **out) {
                     (long long)hs[kHdrOverflow]);
 
     Result *R = new Result();
+    std::unique_ptr<Result> r_guard(R);  // (every early return below gives the result back)
     if (!q->rpool) q->rpool = std::make_shared<ResultPool>();
     R->pool = q->rpool;
     {
@@ -883,10 +884,7 @@ int query_finalize(Query *q, Result **out) {
         if (q->order_by != "$COUNT") {
             for (size_t a = 0; a < na; a++)
                 if (q->aggs[a].name == q->order_by) by = (int)a;
-            if (by < 0) {
-                delete R;
-                return fail(SYBL_E_INVAL, "order_by '%s' is neither $COUNT nor an aggregated column", q->order_by.c_str());
-            }
+            if (by < 0) return fail(SYBL_E_INVAL, "order_by '%s' is neither $COUNT nor an aggregated column", q->order_by.c_str());
         }
         const size_t n = q->time_mode ? alltime.size() : live.size();
         auto row_count = [&](size_t i) -> int64_t { return q->time_mode ? all_count[hashed ? i : (size_t)alltime[i]] : F[live[i]]; };
@@ -963,10 +961,7 @@ int query_finalize(Query *q, Result **out) {
     R->top_vals.clear();
     if (summary && !q->snap_has_buckets) {
         int rc = fetch_top_values(q, R, std::min<size_t>((size_t)q->limit, q->time_mode ? alltime.size() : live.size()));
-        if (rc) {
-            delete R;
-            return rc;
-        }
+        if (rc) return rc;
         trace.mark("top-values");
     }
     if (!lazy) {
@@ -1006,7 +1001,7 @@ int query_finalize(Query *q, Result **out) {
     } else {
         C.q = nullptr;  // (nothing built later may look at the query)
     }
-    *out = R;
+    *out = r_guard.release();
     return SYBL_OK;
 }
 
