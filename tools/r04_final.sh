@@ -1,7 +1,9 @@
 #!/bin/bash
 # Round-4 closing run: the whole GPU suite, the default bench line, and every profile the bench line cites regenerated from
 # the same HEAD (headline kernel trace + PMC, configs 2 / 4 / 5 kernel trace + PMC), smoke().  Afterwards, in the repo:
-#   cp gpurun_out/prof/r04_* gpurun_out/prof_r04_cfg*/r04_cfg* profiles/ && python tools/make_traffic.py r04
+#   cp gpurun_out/prof/r04_* profiles/; for c in cfg2 cfg4 cfg5; do cp gpurun_out/prof_r04_$c/r04_${c}_* profiles/; done
+#   python tools/make_traffic.py r04; cp gpurun_out/r04_final_bench.json profiles/r04_bench_1gpu.json
+# (not prof_r04_cfg*: gpurun_out keeps the round's experiment directories -- prof_r04_cfg4_b, ... -- beside the closing run's)
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
 if [ -z "$SKIP_TESTS" ]; then
 timeout -k 10 700 python -m pytest tests -m gpu -q --tb=short > gpurun_out/r04_final_tests.log 2>&1
