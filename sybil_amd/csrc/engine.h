@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include <map>
+#include <atomic>
 #include <memory>
 #include <string>
 #include <unordered_map>
@@ -171,6 +172,7 @@ int table_ensure_stats(Table *t);
 int table_reserve(Table *t, Column *c, int64_t phys_rows);
 int valid_reserve(Table *t, Column *c, int64_t phys_rows);
 int64_t table_drop_dead_tail(Table *t, int64_t keep_blocks);  // trailing blocks without rows give their row range back
+int table_upload_blocks(Table *t);                          // host segments -> t->d_blocks (before k_block_minmax / k_distinct)
 int table_reclaim_dead_rows(Table *t, bool force);           // rows of dead blocks in the MIDDLE of the table: the live blocks close up
 void column_free(Column *c);
 int32_t dict_intern(Column *c, const std::string &s);
@@ -265,9 +267,33 @@ struct DevOwner {
 struct HostBuf {
     int64_t *p = nullptr;
     int64_t words = 0;
+    std::atomic<int> pins{0};  // results whose rows point into this buffer (HostPin): the query leaves it alone while > 0
     ~HostBuf() {
         if (p) (void)hipHostFree(p);
     }
+};
+
+// A result's hold on a pinned snapshot buffer.  The query that owns the buffer decides whether it may write the next
+// snapshot into it from HostBuf::pins -- an explicit count of these holders -- not from shared_ptr::use_count(), which
+// also counts the query's own list, its current-buffer pointers and any temporary.
+struct HostPin {
+    std::shared_ptr<HostBuf> b;
+    HostPin() = default;
+    HostPin(const HostPin &o) : b(o.b) {
+        if (b) b->pins.fetch_add(1);
+    }
+    HostPin &operator=(const std::shared_ptr<HostBuf> &nb) {
+        if (nb) nb->pins.fetch_add(1);
+        if (b) b->pins.fetch_sub(1);
+        b = nb;
+        return *this;
+    }
+    HostPin &operator=(const HostPin &o) { return *this = o.b; }
+    ~HostPin() {
+        if (b) b->pins.fetch_sub(1);
+    }
+    HostBuf *operator->() const { return b.get(); }
+    explicit operator bool() const { return (bool)b; }
 };
 
 // -str-replace on one str column: dictionary id -> id of the rewritten string (first id that rewrites to it)
@@ -360,6 +386,7 @@ struct Query {
     bool snap_has_buckets = true;   // the last snapshot carried the bucket arrays
     int64_t *d_pct = nullptr, *d_mom = nullptr, *d_total = nullptr;
     std::shared_ptr<HostBuf> h_pct_buf;          // pinned snapshot of the GPU-computed percentiles (shared with results)
+    std::shared_ptr<HostBuf> h_spare_buf;        // (held only while query_snapshot takes its first two percentile buffers)
     std::vector<std::shared_ptr<HostBuf>> host_bufs;  // pinned snapshot buffers of this query, reused once no result holds them
     int64_t *h_pct = nullptr, *h_mom = nullptr, *h_total = nullptr;  // pinned (h_pct = h_pct_buf->p)
     std::shared_ptr<struct KeyStore> key_cache;  // the group cells' BinaryByKey / GroupByKey (result.h), built by the first finalize

@@ -15,30 +15,42 @@ namespace sybl {
 // (ballot of the active lanes, the first one adds their number, the others take their rank's offset), and (b) the wave
 // appends to one of kOutStripes staging stripes, each behind a cursor on a line of its own, chosen by workgroup and wave
 // number -- with ~1 % outliers only one or two lanes of a wave meet here, so it is the stripes that spread the
-// contention.  A full stripe is noticed with a load and left alone (its cursor then says "more than its share").
+// contention.  Round 5: a stripe that is full (noticed with a load) or that fills up under the reservation passes the
+// lanes it has no room for on to the next stripe, up to kOutSpill of them -- skewed outliers (one block, one time range)
+// no longer lose values while the log as a whole has room; a record that found no place after that is COUNTED in its
+// home stripe's second word, so k_outlog_gather knows exactly how many were dropped.
+constexpr int kOutSpill = 8;
 __device__ __forceinline__ void log_outlier(int64_t *stage, int64_t cap, int64_t where, int agg, int64_t value) {
-    const uint32_t stripe = ((blockIdx.x * 16u + (threadIdx.x >> 6)) * 0x9E3779B1u) >> 26;  // (wave-uniform; kOutStripes = 64)
+    const uint32_t home = ((blockIdx.x * 16u + (threadIdx.x >> 6)) * 0x9E3779B1u) >> 26;  // (wave-uniform; kOutStripes = 64)
     static_assert(kOutStripes == 64, "six hash bits pick the stripe");
-    int64_t *cursor = stage + (size_t)stripe * kOutCursorWords;
     const int64_t per = cap / kOutStripes;
-    if (__hip_atomic_load(cursor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > per) return;
-    const unsigned long long here = __builtin_amdgcn_ballot_w64(true);  // the lanes in this branch together
-    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(here >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)here, 0u));
-    uint32_t lo = 0, hi = 0;
-    if (rank == 0) {
-        const int64_t b = __hip_atomic_fetch_add(cursor, (int64_t)__builtin_popcountll(here), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        lo = (uint32_t)(uint64_t)b;
-        hi = (uint32_t)((uint64_t)b >> 32);
+    bool pending = true;
+#pragma unroll 1
+    for (int t = 0; t < kOutSpill; t++) {
+        const uint32_t stripe = (home + (uint32_t)t) & (kOutStripes - 1);
+        int64_t *cursor = stage + (size_t)stripe * kOutCursorWords;
+        if (__hip_atomic_load(cursor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= per) continue;
+        const unsigned long long here = __builtin_amdgcn_ballot_w64(true);  // the lanes still looking for a place together
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(here >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)here, 0u));
+        uint32_t lo = 0, hi = 0;
+        if (rank == 0) {
+            const int64_t b = __hip_atomic_fetch_add(cursor, (int64_t)__builtin_popcountll(here), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            lo = (uint32_t)(uint64_t)b;
+            hi = (uint32_t)((uint64_t)b >> 32);
+        }
+        lo = __builtin_amdgcn_readfirstlane(lo);  // (the first active lane is the one of rank 0)
+        hi = __builtin_amdgcn_readfirstlane(hi);
+        const int64_t i = (int64_t)((uint64_t)lo | (uint64_t)hi << 32) + (int64_t)rank;
+        if (i < per) {
+            int64_t *rec = stage + (size_t)kOutStripes * kOutCursorWords + ((size_t)stripe * (size_t)per + (size_t)i) * kOutLogWords;
+            rec[0] = where;
+            rec[1] = agg;
+            rec[2] = value;
+            pending = false;
+            break;
+        }
     }
-    lo = __builtin_amdgcn_readfirstlane(lo);  // (the first active lane is the one of rank 0)
-    hi = __builtin_amdgcn_readfirstlane(hi);
-    const int64_t i = (int64_t)((uint64_t)lo | (uint64_t)hi << 32) + (int64_t)rank;
-    if (i < per) {
-        int64_t *rec = stage + (size_t)kOutStripes * kOutCursorWords + ((size_t)stripe * (size_t)per + (size_t)i) * kOutLogWords;
-        rec[0] = where;
-        rec[1] = agg;
-        rec[2] = value;
-    }
+    if (pending) __hip_atomic_fetch_add(stage + (size_t)home * kOutCursorWords + 1, (int64_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 #endif  // __HIPCC__
 

@@ -369,15 +369,19 @@ static void make_views(Result *R) {
 // or a new one: results keep the snapshot their rows point into, and a pipelined host frees a result only after the
 // query's next snapshot was queued -- allocating 52 MB of pinned memory per step instead cost 1.8 ms of every step.
 int query_acquire_host_buf(Query *q, int64_t words, std::shared_ptr<HostBuf> &cur) {
-    cur.reset();
+    cur.reset();  // (the caller's current buffer, if no result holds it, is a candidate again)
     // best fit among the buffers no result holds: a query keeps buffers of several sizes (the cell-table snapshot, 52 MB of
     // percentiles, a hash group-by's keys) -- first fit let a small request take the big buffer, the big request then
     // found none, dropped every free one as "too small" and allocated 52 MB of pinned memory inside a step (8.5 ms, twice
     // in twenty steps of config 4)
+    // free = no result's rows point into it (HostBuf::pins) and it is not one of the query's current snapshot targets
+    auto is_free = [&](const std::shared_ptr<HostBuf> &b) {
+        return b->pins.load() == 0 && b != q->h_sum_buf && b != q->h_pct_buf && b != q->h_keys_buf && b != q->h_spare_buf;
+    };
     int best = -1;
     for (size_t i = 0; i < q->host_bufs.size(); i++) {
         auto &b = q->host_bufs[i];
-        if (b.use_count() == 1 && b->words >= words && (best < 0 || b->words < q->host_bufs[(size_t)best]->words)) best = (int)i;
+        if (is_free(b) && b->words >= words && (best < 0 || b->words < q->host_bufs[(size_t)best]->words)) best = (int)i;
     }
     if (best >= 0 && q->host_bufs[(size_t)best]->words <= std::max<int64_t>(4 * words, (int64_t)1 << 17)) {
         cur = q->host_bufs[(size_t)best];
@@ -385,7 +389,7 @@ int query_acquire_host_buf(Query *q, int64_t words, std::shared_ptr<HostBuf> &cu
     }
     if (q->host_bufs.size() >= 12) {  // (a bound on what a query hoards: the free ones go)
         for (size_t i = 0; i < q->host_bufs.size();) {
-            if (q->host_bufs[i].use_count() == 1) q->host_bufs.erase(q->host_bufs.begin() + (long)i);
+            if (is_free(q->host_bufs[i])) q->host_bufs.erase(q->host_bufs.begin() + (long)i);
             else i++;
         }
     }
@@ -401,7 +405,7 @@ int query_acquire_host_buf(Query *q, int64_t words, std::shared_ptr<HostBuf> &cu
 // holds is left alone and another one taken.
 int query_host_keys(Query *q, int64_t n) {
     const int64_t words = std::max<int64_t>(n, 1);
-    if (!q->h_keys_buf || q->h_keys_buf.use_count() > 2 || q->h_keys_buf->words < words) {
+    if (!q->h_keys_buf || q->h_keys_buf->pins.load() > 0 || q->h_keys_buf->words < words) {
         int rc = query_acquire_host_buf(q, words, q->h_keys_buf);
         if (rc) return rc;
     }
@@ -451,7 +455,7 @@ int query_snapshot(Query *q) {
     // a hash group-by snapshots its dense, key-ordered arrays, whose size follows the keys found
     const int64_t sum_words = q->hash_mode ? hash_dense_sum_words(q, q->hash_live) : q->n_sum_words;
     const int64_t max_words = q->hash_mode ? hash_dense_max_words(q, q->hash_live) : q->n_max_words;
-    if (!q->h_sum_buf || q->h_sum_buf.use_count() > 2 || q->h_sum_buf->words < sum_words) {
+    if (!q->h_sum_buf || q->h_sum_buf->pins.load() > 0 || q->h_sum_buf->words < sum_words) {
         int rc = query_acquire_host_buf(q, sum_words, q->h_sum_buf);
         if (rc) return rc;
     }
@@ -478,18 +482,19 @@ int query_snapshot(Query *q) {
         if (!q->h_pct_buf) {
             // a pipelined host holds the previous result of this query while the next snapshot is queued: two buffers
             // from the start (allocating the second one when it is first missed costs a step 3.5 ms of pinned allocation)
-            std::shared_ptr<HostBuf> spare;
+            std::shared_ptr<HostBuf> &spare = q->h_spare_buf;  // (held while the second one is taken: two distinct buffers)
             int rc = query_acquire_host_buf(q, pairs * 100, spare);
             if (rc) return rc;
-            rc = query_acquire_host_buf(q, pairs * 100, q->h_pct_buf);  // (`spare` is held: a second buffer)
+            rc = query_acquire_host_buf(q, pairs * 100, q->h_pct_buf);
             if (rc) return rc;
             // first device write into each of them now (a 52 MB copy into a pinned buffer the device has not written
             // before was seen to block its hipMemcpyAsync for 13-18 ms: once, but inside a timed region of ten steps)
             SYBL_HIP(hipMemcpyAsync(spare->p, q->d_pct, (size_t)pairs * 100 * 8, hipMemcpyDeviceToHost, st));
             SYBL_HIP(hipMemcpyAsync(q->h_pct_buf->p, q->d_pct, (size_t)pairs * 100 * 8, hipMemcpyDeviceToHost, st));
             SYBL_HIP(hipStreamSynchronize(st));
+            spare.reset();  // (back among the query's free buffers)
         }
-        if (q->h_pct_buf.use_count() > 2 || q->h_pct_buf->words < pairs * 100) {
+        if (q->h_pct_buf->pins.load() > 0 || q->h_pct_buf->words < pairs * 100) {
             int rc = query_acquire_host_buf(q, pairs * 100, q->h_pct_buf);
             if (rc) return rc;
         }

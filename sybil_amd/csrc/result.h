@@ -108,7 +108,7 @@ struct FinCtx {
     const int64_t *h_pct = nullptr;                           // GPU-computed percentiles (Result::keep_pct)
     std::vector<int64_t> mom, hm_copy;                        // bucket moments / extrema: copied (the query's buffers are reused)
     const Query *q = nullptr;                                 // rows with keys of their own (hash group-by): built while the query lives
-    std::shared_ptr<HostBuf> keys_buf;                        // the sorted composite keys of a hash group-by (pinned, shared)
+    HostPin keys_buf;                                         // the sorted composite keys of a hash group-by (pinned, shared)
     const uint64_t *dense_keys = nullptr;
 };
 
@@ -144,8 +144,8 @@ struct Result : ResultStore {
         return fin.time_mode ? -1 : live[ix];
     }
     std::shared_ptr<KeyStore> keys;               // what the rows' key / gbkp point into (the query's cache or own_keys)
-    std::shared_ptr<HostBuf> keep_pct;            // the snapshot of the GPU-computed percentiles the rows point into
-    std::shared_ptr<HostBuf> keep;                // the pinned snapshot of the partial table the bucket
+    HostPin keep_pct;                             // the snapshot of the GPU-computed percentiles the rows point into
+    HostPin keep;                                 // the pinned snapshot of the partial table the bucket
                                                   // arrays of the rows point into
     std::vector<std::vector<int64_t>> total_vals; // Cumulative bucket arrays
     std::vector<int64_t> top_vals;                // bucket arrays of the first `limit` rows (GPU summary path)

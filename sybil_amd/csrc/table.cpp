@@ -66,6 +66,22 @@ int valid_reserve(Table *t, Column *c, int64_t phys_rows) {
     return SYBL_OK;
 }
 
+// The device copy of the block segments (start, n) that k_block_minmax / k_distinct walk.  Uploaded by whoever is about to
+// launch one of them: a reclaim or a dropped tail moves blocks without any column's statistics becoming pending.
+int table_upload_blocks(Table *t) {
+    const int64_t nb = (int64_t)t->blocks.size();
+    if (nb == 0) return SYBL_OK;
+    if (t->d_blocks_n < nb) {
+        if (t->d_blocks) SYBL_HIP(hipFree(t->d_blocks));
+        t->d_blocks = nullptr;
+        t->d_blocks_n = 0;
+        SYBL_HIP(hipMalloc((void **)&t->d_blocks, (size_t)nb * sizeof(Segment)));
+        t->d_blocks_n = nb;
+    }
+    SYBL_HIP(hipMemcpyAsync(t->d_blocks, t->blocks.data(), (size_t)nb * sizeof(Segment), hipMemcpyHostToDevice, t->ctx->stream));
+    return SYBL_OK;
+}
+
 int table_ensure_stats(Table *t) {
     int64_t nb = (int64_t)t->blocks.size();
     bool pending = false;
@@ -73,12 +89,8 @@ int table_ensure_stats(Table *t) {
         if (c->type != SYBL_SET_VAL && c->stats_blocks < nb) pending = true;
     if (!pending) return SYBL_OK;
     hipStream_t st = t->ctx->stream;
-    if (t->d_blocks_n < nb) {
-        if (t->d_blocks) SYBL_HIP(hipFree(t->d_blocks));
-        SYBL_HIP(hipMalloc((void **)&t->d_blocks, (size_t)nb * sizeof(Segment)));
-        t->d_blocks_n = nb;
-    }
-    SYBL_HIP(hipMemcpyAsync(t->d_blocks, t->blocks.data(), (size_t)nb * sizeof(Segment), hipMemcpyHostToDevice, st));
+    int urc = table_upload_blocks(t);
+    if (urc) return urc;
     int64_t *d_out = nullptr;
     SYBL_HIP(hipMalloc((void **)&d_out, (size_t)nb * 3 * sizeof(int64_t)));
     std::vector<int64_t> h((size_t)nb * 3);
@@ -651,6 +663,9 @@ int column_build_gdict(Table *t, Column *c) {
     hipStream_t st = t->ctx->stream;
     int rc = table_ensure_stats(t);
     if (rc) return rc;
+    // (the segments as they are NOW: table_ensure_stats uploads them only when some column's statistics are pending, and
+    // a trim-only refresh moves live blocks -- table_reclaim_dead_rows -- without making any pending)
+    if ((rc = table_upload_blocks(t))) return rc;
     int64_t want = std::min<int64_t>(4 * kDictMaxDistinct, std::max<int64_t>(1024, 4 * c->n_pop));
     uint32_t cap = 1024;
     while ((int64_t)cap < want) cap <<= 1;
@@ -685,6 +700,8 @@ int column_build_gdict(Table *t, Column *c) {
     std::vector<int64_t> h(cap);
     SYBL_HIP(hipMemcpy(h.data(), d_keys, (size_t)cap * 8, hipMemcpyDeviceToHost));
     cleanup();
+    // (results whose rows are still to be built turn key digits into values through the dictionary as it is now)
+    for (Query *q : t->queries) query_finish_lazy_results(q);
     c->gdict.clear();
     c->gdict.reserve((size_t)n);
     for (int64_t x : h)
@@ -959,6 +976,7 @@ int sybl_table_set_group_dict(sybl_table *t, const char *name, const int64_t *va
     std::vector<int64_t> v(values, values + n);
     std::sort(v.begin(), v.end());
     v.erase(std::unique(v.begin(), v.end()), v.end());
+    for (Query *q : t->queries) query_finish_lazy_results(q);  // (as above: pending rows read the dictionary they were scanned with)
     c->gdict.swap(v);
     c->gdict_blocks = -2;
     t->version++;
