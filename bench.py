@@ -205,6 +205,8 @@ def main():
                     help="rccl: the library's own communicator (sybl_comm_init / sybl_query_allreduce -- what a Go host "
                          "calls, the product path); torch: torch.distributed all-reduces of the bound partial tables")
     ap.add_argument("--no-load", action="store_true", help="skip the disk -> HBM load measurement (N=1 only)")
+    ap.add_argument("--summarise-every-row", action="store_true",
+                    help="config 4: derive percentiles / stddev for all 65 536 rows every step (printed_only = 0), as rounds 1-4 measured it")
     ap.add_argument("--no-configs", action="store_true",
                     help="only the headline workload: skip the cfg2 / cfg4 / cfg5 records of the `configs` key")
     ap.add_argument("--no-oracle-check", action="store_true",
@@ -270,6 +272,10 @@ def main():
         names, q = wl["columns"], dict(wl["query"])
         if workload == "cfg4_hist_highcard":
             q["limit"] = 100  # FLAGS.LIMIT defaults to 100 (cmd_query.go): only the printed rows carry their bucket arrays
+            # `sybil query` is a printer: GetPercentiles / GetStdDev run at print time for the rows it prints (printer.go:60-76,
+            # 291-308).  The step below is that query (sybl_query_desc.printed_only); the same step with every one of the
+            # 65 536 rows summarised (what -encode-results needs) is measured beside it: `every_row_summarised`.
+            q["printed_only"] = not args.summarise_every_row
         total_rows = total_rows or wl["rows"]
         bytes_per_row = 8 * len(names)
         # fit check (single GPU must hold its shard)
@@ -423,6 +429,29 @@ def main():
         if storage == "compact":
             table.compact()
         head = run_phase(steps, warmup)
+        extra = {}
+        if workload == "cfg4_hist_highcard" and q.get("printed_only"):
+            q["printed_only"] = False
+            alt = run_phase(min(steps, 10), min(warmup, 2))
+            q["printed_only"] = True
+            if rank == 0:
+                assert alt["digest"] == head["digest"], "a printer's query and the fully summarised one disagree"
+                extra["every_row_summarised"] = {"ms_per_step": alt["dt"] / min(steps, 10) * 1e3, "kernel_ms": alt["kernel_ms"], "steps": min(steps, 10),
+                                                 "host_ms_per_step": alt["host_ms"], "rows_first_access_ms": alt.get("rows_first_access_ms"),
+                                                 "what": "the same step with percentiles / stddev derived for all 65 536 groups (k_hist_summary over the "
+                                                         "525 MB table + 52 MB of percentiles to the host per step): what -encode-results needs"}
+        if workload == "cfg4_hist_highcard":
+            # scans back to back (no finalize between them: the GPU never idles, clocks stay up): the kernels' own figure
+            qy = table.query(**q)
+            ms = []
+            for _ in range(12):
+                qy.scan()
+                ctx.sync()
+                ms.append(qy.stats()["scan_ms"])
+            qy.free()
+            extra["back_to_back_scan_ms"] = {"median": round(sorted(ms[2:])[len(ms[2:]) // 2], 4), "min": round(min(ms[2:]), 4), "scans": len(ms) - 2,
+                                             "what": "hipEvent time of the scan kernels over 10 scans queued back to back, no finalize in between; "
+                                                     "`roofline.kernel_ms` is the mean over the pipelined steps of the timed region"}
         out = None
         if rank == 0:
             if canon is not None:
@@ -447,6 +476,7 @@ def main():
                            "rows_first_access_ms": head.get("rows_first_access_ms")},
                 "roofline": roofline(head),
             }
+            out.update(extra)
             if canon is not None:
                 out["canonical_storage"] = {"value": total_rows * min(steps, 10) / canon["dt"], "unit": "rows/s",
                                             "steps": min(steps, 10), "roofline": roofline(canon)}

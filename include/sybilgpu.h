@@ -20,9 +20,15 @@
  *    matching *_free.
  *  - no globals: everything the reference reads from FLAGS/OPTS (config.go:119-120)
  *    is an explicit field of sybl_query_desc.
- *  - one sybl_ctx per GPU (one process per GPU under RCCL); calls on different ctx
- *    objects may run concurrently from any OS thread; calls on one ctx are serialised
- *    by the caller.
+ *  - one sybl_ctx per GPU (one process per GPU under RCCL).  Thread-safe for concurrent
+ *    calls from arbitrary OS threads (the reference queries blocks from 16 goroutines,
+ *    table_query.go:110,230-231): calls on different ctx objects run concurrently; calls
+ *    that take a handle of ONE ctx -- the ctx, its tables, queries and results -- are
+ *    serialised by the library (a per-ctx lock held for the length of each call), so a
+ *    thread may read a result's rows while another scans or frees the query behind it.
+ *    What stays the caller's business is ORDER, not exclusion: a handle must not be used
+ *    after its *_free, and scan -> [allreduce] -> [snapshot] -> finalize of one query are
+ *    issued in that order.
  *  - there is NO CPU fallback: without a usable HIP device every compute call fails
  *    with SYBL_E_NODEVICE.
  */
@@ -36,7 +42,7 @@
 extern "C" {
 #endif
 
-#define SYBL_ABI_VERSION 3
+#define SYBL_ABI_VERSION 4
 
 enum {
     SYBL_OK = 0,
@@ -295,6 +301,17 @@ typedef struct {
      * github.com/logv/loglogbeta restated from the published algorithms (PARITY UNPINNED: DESIGN.md section 7). */
     int32_t n_distincts;
     const char *const *distincts;
+    /* ABI 4.  1 = the caller is a PRINTER (printSortedResults / printResults / -json: printer.go:25-308): of Results it looks
+     * at the first `limit` rows of the sort order and at Cumulative, as the reference does -- GetPercentiles / GetStdDev are
+     * print-time calls there (printer.go:60-76), made for the rows that are printed.  With limit > 0, op HIST, bucket arrays
+     * kept and 2048 group cells or more, percentiles / stddev / bucket arrays are then produced for those rows and
+     * Cumulative only: the other rows of sybl_result_rows carry count / samples / sum / avg / min / max, percentiles = NULL,
+     * values = NULL and stddev = NaN.  What it saves: the summary pass over every group's bucket array per query (config 4:
+     * 0.28 ms and 52 MB of percentiles per step) and, across ranks, the reduce-scatter of the whole bucket table -- only the
+     * cell fields, Cumulative's buckets and the printed rows' arrays travel (~1 MB instead of 263 MB per rank;
+     * sybl_query_collective_finalize is then 1: snapshot and finalize are collective).  0 (the default, and what
+     * -encode-results needs: every Result travels whole, printer.go:263-289): every row carries everything. */
+    int32_t printed_only;
 } sybl_query_desc;
 
 int sybl_query_prepare(sybl_table *t, const sybl_query_desc *desc, sybl_query **out);
@@ -332,10 +349,12 @@ int sybl_query_allreduce(sybl_query *q);
 int sybl_query_hash_keys(sybl_query *q, const uint64_t **keys, int64_t *n);
 int sybl_query_hash_install_union(sybl_query *q, const uint64_t *keys, int64_t n);
 
-/* 1 when the last sybl_query_allreduce merged the bucket arrays by reduce-scatter (big histogram tables with a
- * row limit: every rank keeps the reduced arrays of a slice of the cells, derives its percentiles there and the
- * summaries are all-gathered).  sybl_query_snapshot and sybl_query_finalize are then COLLECTIVE: every rank
- * calls them, in the same order; every rank gets the full result.  0: rank-local calls as usual. */
+/* 1 when the last sybl_query_allreduce left part of the merge to the finalize: big histogram tables with a row limit
+ * are either reduce-SCATTERED (every rank keeps the reduced arrays of a slice of the cells, derives its percentiles there
+ * and the summaries are all-gathered) or, for a printer (sybl_query_desc.printed_only), not sent at all -- the ranks
+ * all-reduce the cell fields, derive the same sort order, and sum Cumulative's buckets and the printed rows' arrays
+ * only.  sybl_query_snapshot and sybl_query_finalize are then COLLECTIVE: every rank calls them, in the same order;
+ * every rank gets the full result.  0: rank-local calls as usual. */
 int sybl_query_collective_finalize(const sybl_query *q);
 
 /* Optional: enqueue the device -> host copy of the (reduced) partials now (after the all-reduce on

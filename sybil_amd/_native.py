@@ -54,7 +54,7 @@ class QueryDesc(C.Structure):
                 ("time_col", C.c_char_p), ("time_bucket", C.c_int64), ("weight_col", C.c_char_p),
                 ("order_by", C.c_char_p), ("order_asc", C.c_int32), ("limit", C.c_int32),
                 ("block_skip", C.c_int32), ("loghist", C.c_int32), ("n_str_replace", C.c_int32), ("str_replace", C.POINTER(StrReplace)),
-                ("n_distincts", C.c_int32), ("distincts", C.POINTER(C.c_char_p))]
+                ("n_distincts", C.c_int32), ("distincts", C.POINTER(C.c_char_p)), ("printed_only", C.c_int32)]
 
 
 class AggOut(C.Structure):

@@ -25,8 +25,37 @@ __device__ __forceinline__ void hll_raise(uint8_t *regs, uint64_t hash) {
     }
 }
 
+// the slow path over several columns, one of them a str column: aggregate.go:224-239
+template <int NC>
+__device__ __noinline__ uint64_t distinct_hash_mixed(CPlan &P, const Tile<NC> &t, int r) {
+    Metro64Stream S;
+    S.init(kHllSeed);
+    for (int i = 0; i < P.n_distinct; i++) {
+        bool pop = false;
+        int64_t v = 0;
+#pragma unroll
+        for (int c = 0; c < NC; c++)
+            if (c == P.distinct_slot[i] && ((t.pop[c] >> r) & 1u)) {
+                pop = true;
+                v = r == 0 ? t.v[c].x : t.v[c].y;
+            }
+        if (pop) {
+            const char *chars = P.hll_chars[i];
+            if (!chars) {
+                S.put_decimal(v);
+            } else if ((uint64_t)v < (uint64_t)P.hll_nids[i]) {
+                const int64_t e = P.hll_stroff[i][v + 1];
+                for (int64_t k = P.hll_stroff[i][v]; k < e; k++) S.put((uint8_t)chars[k]);
+            }
+        }
+        S.put((uint8_t)'\t');
+    }
+    return S.finish();
+}
+
 template <int NC>
 __device__ __forceinline__ uint64_t distinct_hash(CPlan &P, const Tile<NC> &t, int r) {
+    if (P.hll_mixed) return distinct_hash_mixed<NC>(P, t, r);
     if (P.hll_idhash) {
         // one str column: the string's hash by dictionary id
         int64_t id = -1;

@@ -297,6 +297,7 @@ static void gob_result_map(GobW &w, const Result *R, const std::vector<RowStore>
 }  // namespace
 
 const void *sybl_result_encode(sybl_result *r, int64_t *n_bytes) {
+    SYBL_API_GUARD(r);
     Result *R = (Result *)r;
     if (R) result_ensure_rows(R);
     if (!R || !n_bytes) {

@@ -83,6 +83,7 @@ static void free_query(Query *q) {
             v.erase(std::remove(v.begin(), v.end(), q), v.end());
         }
     }
+    if (q->eff_weight) column_free(q->eff_weight.get());
     if (q->d_plan) hipFree(q->d_plan);
     if (q->d_preplan) hipFree(q->d_preplan);
     if (q->d_prebits) hipFree(q->d_prebits);
@@ -120,6 +121,8 @@ static void free_query(Query *q) {
     if (q->d_dplan) hipFree(q->d_dplan);
     if (q->d_hll) hipFree(q->d_hll);
     if (q->d_hll_idhash) hipFree(q->d_hll_idhash);
+    if (q->d_hll_chars) hipFree(q->d_hll_chars);
+    if (q->d_hll_stroff) hipFree(q->d_hll_stroff);
     for (auto &kv : q->replaced) {
         if (kv.second->d_keys) hipFree(kv.second->d_keys);
         if (kv.second->d_ranks) hipFree(kv.second->d_ranks);
@@ -167,6 +170,7 @@ static int scan(Query *q) {
     if (rc) return rc;
     trace.mark("partials");
     q->rs_active = false;
+    q->top_merge = false;
     q->out_log_partial = false;
     hipStream_t st = q->ctx->stream;
     ScanPlan &P = q->plan;
@@ -389,6 +393,7 @@ int sybl_init(int device, sybl_ctx **out) {
 }
 
 void sybl_shutdown(sybl_ctx *ctx) {
+    SYBL_API_GUARD(ctx);
     if (!ctx) return;
     sybl_comm_free(ctx);
     ctx_free_load_arena(ctx);
@@ -404,6 +409,7 @@ void sybl_shutdown(sybl_ctx *ctx) {
 }
 
 int sybl_ctx_set_stream(sybl_ctx *ctx, void *hip_stream) {
+    SYBL_API_GUARD(ctx);
     if (!ctx) return fail(SYBL_E_INVAL, "ctx is NULL");
     SYBL_HIP(hipSetDevice(ctx->device));
     ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
@@ -411,6 +417,7 @@ int sybl_ctx_set_stream(sybl_ctx *ctx, void *hip_stream) {
 }
 
 int sybl_ctx_sync(sybl_ctx *ctx) {
+    SYBL_API_GUARD(ctx);
     if (!ctx) return fail(SYBL_E_INVAL, "ctx is NULL");
     SYBL_HIP(hipSetDevice(ctx->device));
     SYBL_HIP(hipStreamSynchronize(ctx->stream));
@@ -418,6 +425,7 @@ int sybl_ctx_sync(sybl_ctx *ctx) {
 }
 
 int sybl_device_info(sybl_ctx *ctx, char *name, size_t name_cap, int *n_cus, int64_t *hbm_bytes) {
+    SYBL_API_GUARD(ctx);
     if (!ctx) return fail(SYBL_E_INVAL, "ctx is NULL");
     if (name && name_cap) snprintf(name, name_cap, "%s", ctx->dev_name.c_str());
     if (n_cus) *n_cus = ctx->n_cus;
@@ -428,6 +436,7 @@ int sybl_device_info(sybl_ctx *ctx, char *name, size_t name_cap, int *n_cus, int
 // ------------------------------------------------------------------ queries
 
 int sybl_query_prepare(sybl_table *t, const sybl_query_desc *desc, sybl_query **out) {
+    SYBL_API_GUARD(t);
     if (!t || !desc || !out) return fail(SYBL_E_INVAL, "sybl_query_prepare: NULL argument");
     *out = nullptr;
     SYBL_HIP(hipSetDevice(t->ctx->device));
@@ -446,6 +455,7 @@ int sybl_query_prepare(sybl_table *t, const sybl_query_desc *desc, sybl_query **
 }
 
 void sybl_query_free(sybl_query *q) {
+    SYBL_API_GUARD(q);
     if (!q) return;
     hipSetDevice(q->ctx->device);
     hipStreamSynchronize(q->ctx->stream);
@@ -453,6 +463,7 @@ void sybl_query_free(sybl_query *q) {
 }
 
 int sybl_query_scan(sybl_query *q) {
+    SYBL_API_GUARD(q);
     if (!q) return fail(SYBL_E_INVAL, "query is NULL");
     if (q->table_version != q->t->version)
         return fail(SYBL_E_STATE, "the table changed (blocks appended, bounds or dictionaries set) after this query was prepared");
@@ -461,6 +472,7 @@ int sybl_query_scan(sybl_query *q) {
 }
 
 int sybl_query_partials(sybl_query *q, void **d_sum, int64_t *n_sum_words, void **d_max, int64_t *n_max_words) {
+    SYBL_API_GUARD(q);
     if (!q) return fail(SYBL_E_INVAL, "query is NULL");
     SYBL_HIP(hipSetDevice(q->ctx->device));
     if (q->hash_mode) {
@@ -486,6 +498,7 @@ int sybl_query_partials(sybl_query *q, void **d_sum, int64_t *n_sum_words, void 
 }
 
 int sybl_query_bind_partials(sybl_query *q, void *d_sum, void *d_max) {
+    SYBL_API_GUARD(q);
     if (!q || !d_sum || !d_max) return fail(SYBL_E_INVAL, "sybl_query_bind_partials: NULL argument");
     SYBL_HIP(hipSetDevice(q->ctx->device));
     if (q->hash_mode)
@@ -507,6 +520,7 @@ int sybl_query_bind_partials(sybl_query *q, void *d_sum, void *d_max) {
 }
 
 int sybl_query_stats(sybl_query *q, sybl_run_stats *out) {
+    SYBL_API_GUARD(q);
     if (!q || !out) return fail(SYBL_E_INVAL, "NULL argument");
     if (q->scanned) {
         SYBL_HIP(hipSetDevice(q->ctx->device));
@@ -549,6 +563,7 @@ const char *sybl_debug_regex_replace(const char *pattern, const char *text, cons
 }
 
 int sybl_debug_query_cells(sybl_query *q, int which, int agg, int64_t *out, int64_t cap, int64_t *n_cells) {
+    SYBL_API_GUARD(q);
     if (!q || !out || !n_cells) return fail(SYBL_E_INVAL, "NULL argument");
     if (!q->scanned || !q->h_sum || q->snapshot_pending) return fail(SYBL_E_STATE, "sybl_debug_query_cells: no finalized scan");
     if (which < 0 || which > 3 || (which > 0 && (agg < 0 || agg >= (int)q->aggs.size()))) return fail(SYBL_E_INVAL, "bad field");
@@ -577,9 +592,10 @@ int sybl_debug_query_cells(sybl_query *q, int which, int agg, int64_t *out, int6
     return SYBL_OK;
 }
 
-int sybl_query_collective_finalize(const sybl_query *q) { return q && q->rs_active ? 1 : 0; }
+int sybl_query_collective_finalize(const sybl_query *q) { SYBL_API_GUARD(q); return q && (q->rs_active || q->top_merge) ? 1 : 0; }
 
 int sybl_query_hash_keys(sybl_query *q, const uint64_t **keys, int64_t *n) {
+    SYBL_API_GUARD(q);
     if (!q || !keys || !n) return fail(SYBL_E_INVAL, "NULL argument");
     *keys = nullptr;
     *n = 0;
@@ -594,6 +610,7 @@ int sybl_query_hash_keys(sybl_query *q, const uint64_t **keys, int64_t *n) {
 }
 
 int sybl_query_hash_install_union(sybl_query *q, const uint64_t *keys, int64_t n) {
+    SYBL_API_GUARD(q);
     if (!q) return fail(SYBL_E_INVAL, "NULL argument");
     if (!q->hash_mode) return fail(SYBL_E_STATE, "the query is direct-mapped (sybl_query_hash_keys returned no keys)");
     if (!q->scanned) return fail(SYBL_E_STATE, "sybl_query_hash_install_union before sybl_query_scan");
@@ -604,6 +621,7 @@ int sybl_query_hash_install_union(sybl_query *q, const uint64_t *keys, int64_t n
 }
 
 int sybl_query_snapshot(sybl_query *q) {
+    SYBL_API_GUARD(q);
     if (!q) return fail(SYBL_E_INVAL, "NULL argument");
     if (!q->scanned) return fail(SYBL_E_STATE, "sybl_query_snapshot before sybl_query_scan");
     SYBL_HIP(hipSetDevice(q->ctx->device));
@@ -611,6 +629,7 @@ int sybl_query_snapshot(sybl_query *q) {
 }
 
 int sybl_query_finalize(sybl_query *q, sybl_result **out) {
+    SYBL_API_GUARD(q);
     if (!q || !out) return fail(SYBL_E_INVAL, "NULL argument");
     if (!q->scanned) return fail(SYBL_E_STATE, "sybl_query_finalize before sybl_query_scan");
     SYBL_HIP(hipSetDevice(q->ctx->device));

@@ -6,6 +6,7 @@
 #include <map>
 #include <atomic>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <string.h>
@@ -58,12 +59,19 @@ hipError_t launch_decode_bins_multi(const DecodeBinsBatch &B, hipStream_t st);
 hipError_t launch_decode_delta_multi(const DecodeDeltaBatch &B, hipStream_t st);
 
 hipError_t launch_hist_summary(const HistSummaryPlan &S, int64_t *total, hipStream_t st);
+hipError_t launch_weight_carry(const void *col, int width, int64_t vbase, const uint32_t *valid, const Segment *d_blocks, int n_blocks, int64_t *out, hipStream_t st);
+hipError_t launch_hist_total(const int64_t *H, int64_t hist_stride, int64_t cell0, int64_t cell1, int64_t *total, hipStream_t st);
 hipError_t launch_hist_gather(const int64_t *H, int64_t hist_stride, const int64_t *d_cells, int64_t n, int64_t cell0, int64_t cell1,
                               int64_t *out, hipStream_t st);
 
 hipError_t create_side_stream(hipStream_t *out, int toward);  // engine.cpp: a stream on a priority level (and so hardware queues) of its own
 
 struct Ctx {
+    // Every sybl_* entry point that takes a handle of this ctx (the ctx, its tables, queries and results) holds this lock
+    // for the length of the call (SYBL_API_GUARD): calls on one ctx from arbitrary OS threads -- 16 goroutines in the
+    // reference, table_query.go:110,230-231 -- serialise HERE, not in the caller.  Recursive: entry points call each
+    // other.  Shared: a result may outlive its ctx, and sybl_shutdown holds the lock while it deletes the ctx.
+    std::shared_ptr<std::recursive_mutex> api_m = std::make_shared<std::recursive_mutex>();
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;  // stream in force (own or the host framework's)
@@ -350,12 +358,20 @@ struct Query {
     ScanPlan *d_dplan = nullptr;
     uint8_t *d_hll = nullptr;          // [n_cells][kHllRegs]
     uint64_t *d_hll_idhash = nullptr;  // one str column: hash per dictionary id
+    char *d_hll_chars = nullptr;       // several columns, a str column among them: the dictionaries' strings + offsets (plan.h: hll_mixed)
+    int64_t *d_hll_stroff = nullptr;
     int64_t hll_bytes = 0;
     bool time_mode = false;
     int64_t time_bucket = 0;
     std::string order_by;
     bool order_asc = false;
     int limit = 0;
+    // a weight column with unpopulated rows: the weight in force at every row (k_weight_carry), a dense int64 column of this
+    // query's own that the scan reads in the weight column's place (planner.cpp: Planner::weight)
+    std::unique_ptr<Column> eff_weight;
+    bool printed_only = false;  // sybl_query_desc.printed_only: percentiles / stddev / bucket arrays for the printed rows + Cumulative only
+    bool top_only = false;      // ... and this query is one it applies to (query_snapshot: summary shape, limit > 0)
+    bool top_merge = false;     // ... across ranks: the bucket table stayed rank-local, finalize sums the printed rows' arrays (rccl.cpp)
     std::vector<GroupInfo> groups;
     std::vector<AggInfo> aggs;
     // plan
@@ -508,3 +524,22 @@ int query_finalize(Query *q, Result **out);
 struct sybl_ctx : sybl::Ctx {};
 struct sybl_table : sybl::Table {};
 struct sybl_query : sybl::Query {};
+
+namespace sybl {
+struct ApiGuard {
+    std::shared_ptr<std::recursive_mutex> m;
+    explicit ApiGuard(std::shared_ptr<std::recursive_mutex> mm) : m(std::move(mm)) {
+        if (m) m->lock();
+    }
+    ~ApiGuard() {
+        if (m) m->unlock();
+    }
+    ApiGuard(const ApiGuard &) = delete;
+    ApiGuard &operator=(const ApiGuard &) = delete;
+};
+inline std::shared_ptr<std::recursive_mutex> api_mutex_of(const sybl_ctx *c) { return c ? c->api_m : nullptr; }
+inline std::shared_ptr<std::recursive_mutex> api_mutex_of(const sybl_table *t) { return t && t->ctx ? t->ctx->api_m : nullptr; }
+inline std::shared_ptr<std::recursive_mutex> api_mutex_of(const sybl_query *q) { return q && q->ctx ? q->ctx->api_m : nullptr; }
+std::shared_ptr<std::recursive_mutex> api_mutex_of(const sybl_result *r);  // (result.cpp: the ctx's lock, kept alive by the result)
+}  // namespace sybl
+#define SYBL_API_GUARD(handle) sybl::ApiGuard api_guard__(sybl::api_mutex_of(handle))

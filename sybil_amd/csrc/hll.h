@@ -133,6 +133,82 @@ inline uint64_t metro64_bytes(const uint8_t *p, size_t len, uint64_t seed) {
     return hash;
 }
 
+// MetroHash64 of a byte string that arrives piece by piece (the slow path over several columns, aggregate.go:224-239: the
+// decimal digits of an int, a dictionary string, a "\t" after each) -- host and device.  The algorithm consumes 32-byte
+// blocks while at least 32 bytes remain, so a block can be folded in the moment the 32 pending bytes are complete; the
+// pending words are four named registers (an array indexed at run time would live in scratch memory on the GPU).
+struct Metro64Stream {
+    static constexpr uint64_t k0 = 0xD6D018F5ull, k1 = 0xA2AA033Bull, k2 = 0x62992FC1ull, k3 = 0x30BC5B29ull;
+    uint64_t hash, v0, v1, v2, v3, b0, b1, b2, b3;
+    uint32_t fill;
+    bool blocks;
+    SYBL_HD void init(uint64_t seed) {
+        hash = (seed + k2) * k0;
+        v0 = v1 = v2 = v3 = hash;
+        b0 = b1 = b2 = b3 = 0;
+        fill = 0;
+        blocks = false;
+    }
+    SYBL_HD void put(uint8_t c) {
+        const uint64_t x = (uint64_t)c << ((fill & 7u) * 8u);
+        const uint32_t w = fill >> 3;
+        b0 |= w == 0 ? x : 0;
+        b1 |= w == 1 ? x : 0;
+        b2 |= w == 2 ? x : 0;
+        b3 |= w == 3 ? x : 0;
+        if (++fill == 32) {
+            v0 += b0 * k0; v0 = hll_rotr(v0, 29) + v2;
+            v1 += b1 * k1; v1 = hll_rotr(v1, 29) + v3;
+            v2 += b2 * k2; v2 = hll_rotr(v2, 29) + v0;
+            v3 += b3 * k3; v3 = hll_rotr(v3, 29) + v1;
+            b0 = b1 = b2 = b3 = 0;
+            fill = 0;
+            blocks = true;
+        }
+    }
+    SYBL_HD uint64_t word(uint32_t i) const { return i == 0 ? b0 : i == 1 ? b1 : i == 2 ? b2 : b3; }
+    // n <= 8 pending bytes from byte offset `at` (a multiple of n: the tail steps halve)
+    SYBL_HD uint64_t take(uint32_t at, uint32_t n) const {
+        const uint64_t x = word(at >> 3) >> ((at & 7u) * 8u);
+        return n == 8 ? x : x & (((uint64_t)1 << (n * 8u)) - 1);
+    }
+    SYBL_HD uint64_t finish() {
+        uint64_t h = hash;
+        if (blocks) {
+            v2 ^= hll_rotr(((v0 + v3) * k0) + v1, 37) * k1;
+            v3 ^= hll_rotr(((v1 + v2) * k1) + v0, 37) * k0;
+            v0 ^= hll_rotr(((v0 + v2) * k0) + v3, 37) * k1;
+            v1 ^= hll_rotr(((v1 + v3) * k1) + v2, 37) * k0;
+            h += v0 ^ v1;
+        }
+        uint32_t at = 0;
+        if (fill - at >= 16) {
+            uint64_t x0 = h + take(at, 8) * k2; x0 = hll_rotr(x0, 29) * k3;
+            uint64_t x1 = h + take(at + 8, 8) * k2; x1 = hll_rotr(x1, 29) * k3;
+            x0 ^= hll_rotr(x0 * k0, 21) + x1;
+            x1 ^= hll_rotr(x1 * k3, 21) + x0;
+            h += x1;
+            at += 16;
+        }
+        if (fill - at >= 8) { h += take(at, 8) * k3; at += 8; h ^= hll_rotr(h, 55) * k1; }
+        if (fill - at >= 4) { h += take(at, 4) * k3; at += 4; h ^= hll_rotr(h, 26) * k1; }
+        if (fill - at >= 2) { h += take(at, 2) * k3; at += 2; h ^= hll_rotr(h, 48) * k1; }
+        if (fill - at >= 1) { h += take(at, 1) * k3; h ^= hll_rotr(h, 37) * k1; }
+        h ^= hll_rotr(h, 28);
+        h *= k0;
+        h ^= hll_rotr(h, 29);
+        return h;
+    }
+    // strconv.FormatInt(v, 10)
+    SYBL_HD void put_decimal(int64_t v) {
+        uint64_t u = v < 0 ? (uint64_t)0 - (uint64_t)v : (uint64_t)v;
+        if (v < 0) put((uint8_t)'-');
+        uint64_t p = 1;
+        while (u / p >= 10) p *= 10;  // (the highest power of ten not above u; u / p < 10 cannot overflow p)
+        for (; p > 0; p /= 10) put((uint8_t)('0' + (u / p) % 10));
+    }
+};
+
 // LogLogBeta.Cardinality: alpha m (m - ez) / (beta(ez) + sum 2^-reg), the registers summed in index order
 uint64_t hll_cardinality(const uint8_t *regs);  // result.cpp
 

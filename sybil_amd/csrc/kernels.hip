@@ -286,6 +286,41 @@ __global__ __launch_bounds__(256) void k_block_minmax(const void *__restrict__ c
     }
 }
 
+// ---------------------------------------------------------------- the weight a row aggregates with
+// aggregate.go:68,100-102: `weight` is declared once per FilterAndAggRecords call -- per block -- as 1, and a row sets it
+// only when its weight column is populated: a row WITHOUT a weight aggregates with the weight of the last row before it
+// in its block that had one (whether or not that row passed the filters), or with 1.  One workgroup per block: every
+// thread finds the last populated row of its contiguous share, the shares' carries are resolved through LDS, and the
+// second walk writes the weight in force at every row -- a dense int64 column the scan kernels read like any fully
+// populated weight column.
+__global__ __launch_bounds__(256) void k_weight_carry(const void *__restrict__ col, int width, int64_t vbase, const uint32_t *__restrict__ valid,
+                                                      const Segment *__restrict__ blocks, int64_t *__restrict__ out) {
+    const Segment b = blocks[blockIdx.x];
+    __shared__ int64_t last_of[256];
+    const int64_t per = (b.n + 255) / 256;
+    const int64_t i0 = (int64_t)threadIdx.x * per < b.n ? (int64_t)threadIdx.x * per : b.n, i1 = i0 + per < b.n ? i0 + per : b.n;
+    int64_t last = -1;
+    for (int64_t i = i0; i < i1; i++) {
+        const int64_t row = b.start + i;
+        if (!valid || ((valid[row >> 5] >> (row & 31)) & 1u)) last = i;
+    }
+    last_of[threadIdx.x] = last;
+    __syncthreads();
+    int64_t carry = -1;
+    for (int k = (int)threadIdx.x - 1; k >= 0 && carry < 0; k--) carry = last_of[k];
+    int64_t w = carry >= 0 ? load_val(col, width, vbase, b.start + carry) : 1;
+    for (int64_t i = i0; i < i1; i++) {
+        const int64_t row = b.start + i;
+        if (!valid || ((valid[row >> 5] >> (row & 31)) & 1u)) w = load_val(col, width, vbase, row);
+        out[row] = w;
+    }
+}
+hipError_t launch_weight_carry(const void *col, int width, int64_t vbase, const uint32_t *valid, const Segment *d_blocks, int n_blocks, int64_t *out, hipStream_t st) {
+    if (n_blocks <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_weight_carry, dim3((unsigned)n_blocks), dim3(256), 0, st, col, width, vbase, valid, d_blocks, out);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------- distinct values of a column
 // Inserts every populated value into an open-addressing set (capacity = mask + 1, empty =
 // kDictEmpty).  Most probes hit an existing key with a plain load; only first sightings CAS.
@@ -1155,6 +1190,14 @@ hipError_t launch_hist_summary(const HistSummaryPlan &S, int64_t *total, hipStre
         hipLaunchKernelGGL(k_hist_total, dim3((unsigned)((S.cell1 - S.cell0 + cpb - 1) / cpb)), dim3(256), 0, st, S.H, S.hist_stride, S.cell0,
                        S.cell1, cpb, total);
     hipLaunchKernelGGL(k_hist_summary, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, st, S);
+    return hipGetLastError();
+}
+
+// Cumulative's buckets alone (a printer's query: result.cpp query_snapshot, top_only)
+hipError_t launch_hist_total(const int64_t *H, int64_t hist_stride, int64_t cell0, int64_t cell1, int64_t *total, hipStream_t st) {
+    if (cell1 <= cell0 || hist_stride <= 0) return hipSuccess;
+    const int64_t cpb = 128;
+    hipLaunchKernelGGL(k_hist_total, dim3((unsigned)((cell1 - cell0 + cpb - 1) / cpb)), dim3(256), 0, st, H, hist_stride, cell0, cell1, cpb, total);
     return hipGetLastError();
 }
 

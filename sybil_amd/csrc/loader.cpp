@@ -1305,11 +1305,13 @@ extern "C" {
 
 int sybl_table_open(sybl_ctx *ctx, const char *dir, const char *table, const char *const *columns, int32_t n_columns,
                     int32_t rank, int32_t nranks, sybl_table **out) {
+    SYBL_API_GUARD(ctx);
     return sybl_table_open_flags(ctx, dir, table, columns, n_columns, rank, nranks, 0, out);
 }
 
 int sybl_table_open_flags(sybl_ctx *ctx, const char *dir, const char *table, const char *const *columns, int32_t n_columns,
                           int32_t rank, int32_t nranks, int32_t flags, sybl_table **out) {
+    SYBL_API_GUARD(ctx);
     if (!ctx || !table || !out || rank < 0 || (nranks > 0 && rank >= nranks)) return fail(SYBL_E_INVAL, "sybl_table_open: bad argument");
     *out = nullptr;
     SYBL_HIP(hipSetDevice(ctx->device));
@@ -1322,6 +1324,7 @@ int sybl_table_open_flags(sybl_ctx *ctx, const char *dir, const char *table, con
 }
 
 int sybl_table_refresh(sybl_table *t, int64_t *n_added, int64_t *n_dropped, int64_t *n_reloaded) {
+    SYBL_API_GUARD(t);
     if (!t) return fail(SYBL_E_INVAL, "sybl_table_refresh: NULL table");
     SYBL_HIP(hipSetDevice(t->ctx->device));
     try {
@@ -1331,9 +1334,10 @@ int sybl_table_refresh(sybl_table *t, int64_t *n_added, int64_t *n_dropped, int6
     }
 }
 
-int64_t sybl_table_broken_blocks(const sybl_table *t) { return t ? t->broken_blocks : 0; }
+int64_t sybl_table_broken_blocks(const sybl_table *t) { SYBL_API_GUARD(t); return t ? t->broken_blocks : 0; }
 
 int sybl_table_load_stats(const sybl_table *t, sybl_load_stats *out) {
+    SYBL_API_GUARD(t);
     if (!t || !out) return fail(SYBL_E_INVAL, "NULL argument");
     *out = t->load_stats;
     return SYBL_OK;

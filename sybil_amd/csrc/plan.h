@@ -177,7 +177,14 @@ struct ScanPlan {
     int64_t hll_ids;
     int32_t n_distinct;
     int32_t distinct_slot[8];
-    int32_t pad_distinct_;
+    // The slow path over SEVERAL columns with a str column among them (aggregate.go:224-239): the hashed buffer is, per
+    // column, the decimal digits of an int / the dictionary string of a str id / nothing for a row without the column,
+    // each followed by "\t" -- assembled and hashed per row (hll.h: Metro64Stream).  hll_chars[i] / hll_stroff[i]: the i-th
+    // column's dictionary strings back to back (as -str-replace left them) and their [ids + 1] offsets; NULL = int column.
+    int32_t hll_mixed;
+    const char *hll_chars[8];
+    const int64_t *hll_stroff[8];
+    int64_t hll_nids[8];
 };
 
 // finalize-side histogram summaries (kernels.hip: k_hist_summary / k_hist_total)

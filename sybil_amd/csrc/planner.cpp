@@ -76,6 +76,13 @@ static bool should_scan_block(const Table *t, const sybl_query_desc *d, int64_t 
 
 // k_scan_packed works on stored offsets: rebases filter bounds, key digits, bucket numerators and
 // the time value onto each column's base.  False when a quantity does not fit the 32-bit domain.
+// A slot's column: a column of the table, or -- for the slot of a weight column with unpopulated rows -- the query's own
+// dense column of the weights in force (Query::eff_weight; Planner::weight).
+constexpr int kEffWeightCol = -2;
+static inline Column *slot_column(const Table *t, const Query *q, int ci) {
+    return ci == kEffWeightCol ? q->eff_weight.get() : t->cols[(size_t)ci].get();
+}
+
 static bool fill_packed(Table *t, Query *q, const std::vector<int> &slot_col, FastPlan &FP, int nf, int ng, int na) {
     const ScanPlan &P = q->plan;
     if (getenv("SYBL_NO_PACKED")) return false;
@@ -117,7 +124,7 @@ static bool fill_packed(Table *t, Query *q, const std::vector<int> &slot_col, Fa
     }
     if (q->time_mode) {
         const SlotDesc &ts = P.slot[P.time_slot];
-        const Column *tc = t->cols[(size_t)slot_col[(size_t)P.time_slot]].get();
+        const Column *tc = slot_column(t, q, slot_col[(size_t)P.time_slot]);
         if (P.tb_big_div || P.time_bucket >= ((int64_t)1 << 32)) return false;
         if (tc->n_pop > 0 && tc->exact_min < 0) return false;  // truncation == floor only for val >= 0
         const __int128 t0 = (__int128)P.tb_min * P.time_bucket;
@@ -153,7 +160,7 @@ static bool fill_fast_columns(Table *t, Query *q, const std::vector<int> &slot_c
     for (size_t s = 0; s < slot_col.size(); s++) {
         const SlotDesc &sd = P.slot[s];
         if (sd.flags == 0 && q->pre_n_slots > 0) continue;  // (a column only the filter pre-pass reads: Planner::prefilter)
-        const Column *c = t->cols[(size_t)slot_col[s]].get();
+        const Column *c = slot_column(t, q, slot_col[s]);
         bool plain = c->type == SYBL_INT_VAL && !c->d_valid && !c->has_missing;
         any_packed = any_packed || c->packed();
         all_narrow = all_narrow && c->elem <= 4;
@@ -654,6 +661,7 @@ struct Planner {
         q->order_by = d->order_by ? d->order_by : "";
         q->order_asc = d->order_asc != 0;
         q->limit = d->limit;
+        q->printed_only = d->printed_only != 0;
         q->time_mode = d->time_bucket > 0 && d->time_col && d->time_col[0];
         q->time_bucket = q->time_mode ? d->time_bucket : 0;
         q->weighted = d->weight_col && d->weight_col[0];
@@ -704,7 +712,7 @@ struct Planner {
             const sybl_filter &f = d->filters[i];
             int s;
             if ((rc = slot_of(f.col, &s))) return rc;
-            Column *c = t->cols[(size_t)slot_col[(size_t)s]].get();
+            Column *c = slot_column(t, q, slot_col[(size_t)s]);
             HostFilterFold &ff = folds[(size_t)s];
             if (c->type == SYBL_INT_VAL) {
                 int64_t v = f.int_value;
@@ -796,7 +804,7 @@ struct Planner {
         for (int g = 0; g < d->n_groups; g++) {
             int s;
             if ((rc = slot_of(d->groups[g], &s))) return rc;
-            Column *c = t->cols[(size_t)slot_col[(size_t)s]].get();
+            Column *c = slot_column(t, q, slot_col[(size_t)s]);
             if (c->type == SYBL_SET_VAL) return fail(SYBL_E_INVAL, "cannot group by set column '%s' (cmd_query.go:254)", c->name.c_str());
             if (P.slot[s].flags & kSlotGroup) return fail(SYBL_E_INVAL, "column '%s' grouped twice", c->name.c_str());
             GroupInfo gi;
@@ -953,7 +961,7 @@ struct Planner {
         if (q->time_mode) {
             int s;
             if ((rc = slot_of(d->time_col, &s))) return rc;
-            Column *c = t->cols[(size_t)slot_col[(size_t)s]].get();
+            Column *c = slot_column(t, q, slot_col[(size_t)s]);
             if (c->type != SYBL_INT_VAL) return fail(SYBL_E_INVAL, "time column '%s' is not an int column", c->name.c_str());
             P.slot[s].flags |= kSlotTime;
             P.time_slot = s;
@@ -998,12 +1006,45 @@ struct Planner {
         // ---- weight column (aggregate.go:100-102)
         if (q->weighted) {
             int s;
+            const size_t slots_before = slot_col.size();
             if ((rc = slot_of(d->weight_col, &s))) return rc;
-            Column *c = t->cols[(size_t)slot_col[(size_t)s]].get();
+            const bool fresh_slot = slot_col.size() > slots_before;  // (no other role has this column so far)
+            Column *c = slot_column(t, q, slot_col[(size_t)s]);
             if (c->type != SYBL_INT_VAL) return fail(SYBL_E_INVAL, "weight column '%s' is not an int column", c->name.c_str());
-            if (c->has_missing)
-                return fail(SYBL_E_INVAL, "weight column '%s' has missing rows (the reference's carry-over of the previous "
-                            "row's weight, aggregate.go:68, is not reproduced)", c->name.c_str());
+            if (c->has_missing || c->d_valid) {
+                // aggregate.go:68,100-102: a row without a weight aggregates with the weight of the last row of its block
+                // that had one (1 before the first).  The weights in force are laid out once, as a dense column of this
+                // query's own, and the weight role moves to a slot of that column (the table's column keeps the slot it
+                // has if the query also filters / groups / aggregates it).
+                auto e = std::make_unique<Column>();
+                e->name = c->name;
+                e->type = SYBL_INT_VAL;
+                e->elem = 8;
+                if ((rc = table_reserve(t, e.get(), t->phys_rows))) return rc;
+                if ((rc = table_upload_blocks(t))) {
+                    column_free(e.get());
+                    return rc;
+                }
+                hipError_t he = launch_weight_carry(c->d_data, c->elem, c->vbase, c->d_valid, t->d_blocks, (int)t->blocks.size(), (int64_t *)e->d_data, t->ctx->stream);
+                if (he == hipSuccess) he = hipStreamSynchronize(t->ctx->stream);
+                if (he != hipSuccess) {
+                    column_free(e.get());
+                    return hip_fail(he, "k_weight_carry");
+                }
+                e->exact_min = std::min<int64_t>(c->exact_min, 1);
+                e->exact_max = std::max<int64_t>(c->exact_max, 1);
+                e->n_pop = t->logical_rows;
+                e->stats_blocks = (int64_t)t->blocks.size();
+                q->eff_weight = std::move(e);
+                if (fresh_slot) {
+                    slot_col[(size_t)s] = kEffWeightCol;  // (the slot slot_of just made for the weight alone: it becomes the dense column's)
+                } else {
+                    if ((int)slot_col.size() >= kMaxSlots) return fail(SYBL_E_INVAL, "query references more than %d columns", kMaxSlots);
+                    slot_col.push_back(kEffWeightCol);
+                    folds.emplace_back();
+                    s = (int)slot_col.size() - 1;
+                }
+            }
             P.slot[s].flags |= kSlotWeight;
             P.weight_slot = s;
         }
@@ -1020,7 +1061,7 @@ struct Planner {
         for (int a = 0; a < d->n_aggs; a++) {
             int s;
             if ((rc = slot_of(d->aggs[a], &s))) return rc;
-            Column *c = t->cols[(size_t)slot_col[(size_t)s]].get();
+            Column *c = slot_column(t, q, slot_col[(size_t)s]);
             if (c->type != SYBL_INT_VAL) {
                 // the reference silently ignores non-int aggregation columns (aggregate.go:247-248)
                 return fail(SYBL_E_INVAL, "aggregation column '%s' is not an int column", c->name.c_str());
@@ -1197,7 +1238,7 @@ struct Planner {
         }
         P.n_slots = (int)slot_col.size();
         for (int s = 0; s < P.n_slots; s++) {
-            Column *c = t->cols[(size_t)slot_col[(size_t)s]].get();
+            Column *c = slot_column(t, q, slot_col[(size_t)s]);
             SlotDesc &sd = P.slot[s];
             sd.base = c->d_data;
             sd.valid = c->d_valid;
@@ -1276,7 +1317,7 @@ struct Planner {
         int n_generic = 0;
         for (size_t k = 0; k < move.size(); k++) {
             const SlotDesc &src = P.slot[move[k]];
-            const Column *c = t->cols[(size_t)slot_col[(size_t)move[k]]].get();
+            const Column *c = slot_column(t, q, slot_col[(size_t)move[k]]);
             // plain filter columns of <= 4 stored bytes: the offset-domain pre-pass (k_prefilter_packed), four to a launch
             const bool packed_ok = !(src.flags & kSlotSet) && c->type != SYBL_SET_VAL && c->elem <= 4 && !getenv("SYBL_NO_PREFILTER_PACKED");
             if (packed_ok) {
@@ -1440,7 +1481,7 @@ struct Planner {
         }
         // (a hashed query keeps its staging table: the window below is a direct-mapped slice of [time bucket][cell])
         if (!q->use_lds && !q->hash_mode && q->time_mode && !getenv("SYBL_NO_WINDOW") && !t->blocks.empty()) {
-            const Column *tc = t->cols[(size_t)slot_col[(size_t)P.time_slot]].get();
+            const Column *tc = slot_column(t, q, slot_col[(size_t)P.time_slot]);
             std::vector<int32_t> base((size_t)q->n_wg, 0);
             int64_t wmax = 1;
             bool ok = true;
@@ -1492,7 +1533,7 @@ struct Planner {
         int64_t width = 0, canon_width = 0;
         int64_t set_bytes = 0;
         for (int s = 0; s < P.n_slots; s++) {
-            const Column *c = t->cols[(size_t)slot_col[(size_t)s]].get();
+            const Column *c = slot_column(t, q, slot_col[(size_t)s]);
             if (c->type == SYBL_SET_VAL) {
                 width += 8;  // one CSR offset per row
                 canon_width += 8;
@@ -1585,10 +1626,8 @@ struct Planner {
             n_str += c->type == SYBL_STR_VAL;
             cols.push_back(c);
         }
-        // only_ints_in_distinct (:84-91) or the slow path over one str column (its hash follows from the dictionary id);
-        // a buffer concatenated from several columns' strings has no per-column decomposition
-        if (n_str > 0 && n != 1)
-            return fail(SYBL_E_INVAL, "count distinct over a str column together with other columns is not supported");
+        // only_ints_in_distinct (:84-91), the slow path over one str column (its hash follows from the dictionary id), or
+        // the slow path over several columns (round 5: the buffer -- digits / strings / "\t" -- is assembled and hashed per row)
         ScanPlan &D = q->dplan;
         D = P;
         for (int i = 0; i < n; i++) {
@@ -1616,7 +1655,44 @@ struct Planner {
         q->hll_bytes = n_cells * (int64_t)kHllRegs;
         SYBL_HIP(hipMalloc((void **)&q->d_hll, (size_t)q->hll_bytes));
         D.hll = q->d_hll;
-        if (n_str) {
+        D.hll_mixed = n_str > 0 && n > 1;
+        for (int i = 0; i < 8; i++) {
+            D.hll_chars[i] = nullptr;
+            D.hll_stroff[i] = nullptr;
+            D.hll_nids[i] = 0;
+        }
+        if (D.hll_mixed) {
+            // the str columns' dictionaries on the device, as -str-replace left them: chars back to back + offsets
+            std::string chars;
+            std::vector<std::vector<int64_t>> offs((size_t)n);
+            for (int i = 0; i < n; i++) {
+                Column *c = cols[(size_t)i];
+                if (c->type != SYBL_STR_VAL) continue;
+                const StrReplaced *rep = nullptr;
+                auto it = q->replaced.find(t->col_ix[c->name]);
+                if (it != q->replaced.end()) rep = it->second.get();
+                offs[(size_t)i].reserve(c->dict.size() + 1);
+                for (size_t id = 0; id < c->dict.size(); id++) {
+                    offs[(size_t)i].push_back((int64_t)chars.size());
+                    chars += rep ? rep->strs[(size_t)rep->remap[id]] : c->dict[id];
+                }
+                offs[(size_t)i].push_back((int64_t)chars.size());
+            }
+            size_t n_off = 0;
+            for (auto &o : offs) n_off += o.size();
+            SYBL_HIP(hipMalloc((void **)&q->d_hll_chars, std::max<size_t>(chars.size(), 1)));
+            SYBL_HIP(hipMalloc((void **)&q->d_hll_stroff, std::max<size_t>(n_off, 1) * 8));
+            SYBL_HIP(hipMemcpy(q->d_hll_chars, chars.data(), chars.size(), hipMemcpyHostToDevice));
+            size_t at = 0;
+            for (int i = 0; i < n; i++) {
+                if (offs[(size_t)i].empty()) continue;
+                SYBL_HIP(hipMemcpy(q->d_hll_stroff + at, offs[(size_t)i].data(), offs[(size_t)i].size() * 8, hipMemcpyHostToDevice));
+                D.hll_chars[i] = q->d_hll_chars;  // (the offsets are absolute)
+                D.hll_stroff[i] = q->d_hll_stroff + at;
+                D.hll_nids[i] = (int64_t)offs[(size_t)i].size() - 1;
+                at += offs[(size_t)i].size();
+            }
+        } else if (n_str) {
             // aggregate.go:225-239: the string, then GROUP_DELIMITER; a row without the column hashes the delimiter alone.
             // (-str-replace rewrote the dictionary at load time in the reference: the rewritten string is what is hashed)
             Column *c = cols[0];

@@ -159,6 +159,7 @@ int sybl_comm_unique_id(void *id128) {
 }
 
 int sybl_comm_init(sybl_ctx *ctx, const void *id128, int32_t nranks, int32_t rank) {
+    SYBL_API_GUARD(ctx);
     if (!ctx || !id128 || nranks <= 0 || rank < 0 || rank >= nranks) return fail(SYBL_E_INVAL, "sybl_comm_init: bad argument");
     if (ctx->comm) return fail(SYBL_E_STATE, "communicator already initialised");
     SYBL_HIP(hipSetDevice(ctx->device));
@@ -173,6 +174,7 @@ int sybl_comm_init(sybl_ctx *ctx, const void *id128, int32_t nranks, int32_t ran
 }
 
 int sybl_comm_free(sybl_ctx *ctx) {
+    SYBL_API_GUARD(ctx);
     if (!ctx || !ctx->comm) return SYBL_OK;
     hipSetDevice(ctx->device);
     ncclCommDestroy((ncclComm_t)ctx->comm);
@@ -183,6 +185,7 @@ int sybl_comm_free(sybl_ctx *ctx) {
 }
 
 int sybl_query_allreduce(sybl_query *q) {
+    SYBL_API_GUARD(q);
     if (!q) return fail(SYBL_E_INVAL, "query is NULL");
     if (!q->scanned) return fail(SYBL_E_STATE, "sybl_query_allreduce before sybl_query_scan");
     Ctx *ctx = q->ctx;
@@ -212,8 +215,14 @@ int sybl_query_allreduce(sybl_query *q) {
     // rank receives 1/R of the table), every rank summarises its slice (k_hist_summary / k_hist_total in
     // query_snapshot) and the summaries are all-gathered: 52 MB of percentiles instead of 525 MB of buckets.
     // snapshot and finalize then are collective calls.
-    const bool scatter = P.hist_stride > 0 && query_wants_hist_summary(q) && q->limit > 0 && ctx->comm_nranks <= kMaxScatterRanks &&
-                         (ctx->comm_nranks > 1 || getenv("SYBL_FORCE_SCATTER"));
+    const bool big_limited = P.hist_stride > 0 && query_wants_hist_summary(q) && q->limit > 0 && (ctx->comm_nranks > 1 || getenv("SYBL_FORCE_SCATTER"));
+    // A printer (sybl_query_desc.printed_only) looks at `limit` rows and Cumulative (aggregate.go:469-525, printer.go:291-308):
+    // the bucket table then does not travel at all.  The cell fields are all-reduced here -- every rank derives the same
+    // sort order from them --, Cumulative's buckets are summed locally and all-reduced by the snapshot (8 KB), the printed
+    // rows' arrays gathered locally and all-reduced by the finalize (config 4, -limit 100: 0.8 MB; the reduce-scatter
+    // below moves 263 MB per rank and step, and the summaries 52 MB more).
+    const bool top_merge = big_limited && q->printed_only;
+    const bool scatter = big_limited && !top_merge && ctx->comm_nranks <= kMaxScatterRanks;
     // int32 slices: decided once per query, from a bound every rank computes alike -- the largest shard's rows (one
     // blocking MAX all-reduce at the query's first collective) times the ranks; a bucket of the merged table cannot
     // exceed that.  Weighted queries keep int64 (a bucket holds a sum of weights).
@@ -239,7 +248,10 @@ int sybl_query_allreduce(sybl_query *q) {
         if (e != hipSuccess) return hip_fail(e, "k_pack32");
     }
     SYBL_NCCL(ncclGroupStart());
-    if (!scatter) {
+    if (top_merge) {
+        SYBL_NCCL_G(ncclAllReduce(q->d_sum, q->d_sum, (size_t)small_words, ncclInt64, ncclSum, comm, ctx->stream));
+        q->top_merge = true;
+    } else if (!scatter) {
         SYBL_NCCL_G(ncclAllReduce(q->d_sum, q->d_sum, (size_t)(small_words + hist_words), ncclInt64, ncclSum, comm, ctx->stream));
     } else {
         const int64_t R = ctx->comm_nranks, per = (P.n_cells + R - 1) / R, count = per * P.hist_stride;

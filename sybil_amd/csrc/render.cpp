@@ -224,6 +224,7 @@ using namespace sybl;
 extern "C" {
 
 const char *sybl_result_render(sybl_result *r, int format) {
+    SYBL_API_GUARD(r);
     Result *R = (Result *)r;
     if (R) result_ensure_rows(R);
     if (!R || (format != 0 && format != 1)) {

@@ -172,6 +172,8 @@ static void agg_finish(const Q *q, Result *R, const AggInfo &ai, const AggAcc &a
                                    : 0.0L;
         var += out_term;
         o.stddev = cnt == 0 ? (double)NAN : (var > 0 ? (double)sqrtl(var) : 0.0);  // Go: 0/0 ratios -> NaN
+        // (a printer's result: a row beyond the printed ones has neither bucket array nor bucket moments)
+        if (q->top_only && A.hist_full && !a.values) o.stddev = (double)NAN;
     }
 }
 
@@ -422,6 +424,15 @@ void query_finish_lazy_results(Query *q) {
     }
 }
 
+// Cumulative's bucket sums (k_hist_total) and their pinned twin: all a printer's query needs of the summary buffers
+static int query_total_buffers(Query *q) {
+    if (q->d_total) return SYBL_OK;
+    const ScanPlan &P = q->plan;
+    SYBL_HIP(hipMalloc((void **)&q->d_total, (size_t)P.hist_stride * 8));
+    SYBL_HIP(hipHostMalloc((void **)&q->h_total, (size_t)P.hist_stride * 8, hipHostMallocDefault));
+    return SYBL_OK;
+}
+
 int query_summary_buffers(Query *q) {
     if (q->d_pct) return SYBL_OK;
     const ScanPlan &P = q->plan;
@@ -429,10 +440,8 @@ int query_summary_buffers(Query *q) {
     const int64_t pairs = ((int64_t)P.n_cells + kMaxScatterRanks) * (int64_t)q->aggs.size();
     SYBL_HIP(hipMalloc((void **)&q->d_pct, (size_t)pairs * 100 * 8));
     SYBL_HIP(hipMalloc((void **)&q->d_mom, (size_t)pairs * 2 * 8));
-    SYBL_HIP(hipMalloc((void **)&q->d_total, (size_t)P.hist_stride * 8));
     SYBL_HIP(hipHostMalloc((void **)&q->h_mom, (size_t)pairs * 2 * 8, hipHostMallocDefault));
-    SYBL_HIP(hipHostMalloc((void **)&q->h_total, (size_t)P.hist_stride * 8, hipHostMallocDefault));
-    return SYBL_OK;
+    return query_total_buffers(q);
 }
 
 bool query_wants_hist_summary(const Query *q) {
@@ -468,10 +477,24 @@ int query_snapshot(Query *q) {
     q->h_sum = q->h_sum_buf->p;
     trace.mark("buffers");
     q->hist_summary = query_wants_hist_summary(q);
+    // a printer's query (sybl_query_desc.printed_only): only Cumulative's buckets are summed here; the printed rows'
+    // percentiles / stddev come from their bucket arrays, fetched after the sort (query_finalize)
+    q->top_only = q->hist_summary && q->printed_only && q->limit > 0;
+    if (q->top_merge && !q->top_only) return fail(SYBL_E_STATE, "the all-reduce left the bucket table rank-local but the snapshot is not a printer's");
     // the bucket arrays cross PCIe only when every row's are wanted (no limit); otherwise the printed
     // rows' arrays are gathered after the sort (query_finalize)
     q->snap_has_buckets = !q->hist_summary || q->limit <= 0;
-    if (q->hist_summary) {
+    if (q->top_only) {
+        int rc = query_total_buffers(q);
+        if (rc) return rc;
+        SYBL_HIP(hipMemsetAsync(q->d_total, 0, (size_t)P.hist_stride * 8, st));
+        hipError_t e = launch_hist_total(q->d_sum + P.hist_off, P.hist_stride, 0, P.n_cells, q->d_total, st);
+        if (e != hipSuccess) return hip_fail(e, "k_hist_total");
+        if (q->top_merge) {
+            int rc2 = comm_allreduce_sum(q->ctx, q->d_total, (size_t)P.hist_stride);
+            if (rc2) return rc2;
+        }
+    } else if (q->hist_summary) {
         // (sized for the padded cell count an in-place all-gather of equal slices needs)
         const int64_t pairs = ((int64_t)P.n_cells + kMaxScatterRanks) * (int64_t)q->aggs.size();
         {
@@ -536,7 +559,7 @@ int query_snapshot(Query *q) {
     // of it (config 4, 10 pipelined steps: 7.3 ms per step with the copy on the main stream, 6.4 ms this way).  Small ones (config 3: 57 KB) stay on the main stream -- an event
     // round trip costs more than they do.
     trace.mark("summary-kernels");
-    const int64_t real_pairs = q->hist_summary ? (int64_t)P.n_cells * (int64_t)q->aggs.size() : 0;
+    const int64_t real_pairs = q->hist_summary && !q->top_only ? (int64_t)P.n_cells * (int64_t)q->aggs.size() : 0;
     const int64_t main_words = q->hash_mode ? sum_words : (q->snap_has_buckets ? q->n_sum_words : P.hist_off);
     hipStream_t cs = st;
     q->snap_on_aux = false;
@@ -550,7 +573,9 @@ int query_snapshot(Query *q) {
         q->snap_on_aux = true;
     }
     trace.mark("copy-stream");
-    if (q->hist_summary) {
+    if (q->top_only) {
+        SYBL_HIP(hipMemcpyAsync(q->h_total, q->d_total, (size_t)P.hist_stride * 8, hipMemcpyDeviceToHost, cs));
+    } else if (q->hist_summary) {
         SYBL_HIP(hipMemcpyAsync(q->h_pct, q->d_pct, (size_t)real_pairs * 100 * 8, hipMemcpyDeviceToHost, cs));
         trace.mark("pct");
         SYBL_HIP(hipMemcpyAsync(q->h_mom, q->d_mom, (size_t)real_pairs * 2 * 8, hipMemcpyDeviceToHost, cs));
@@ -592,12 +617,14 @@ static int fetch_top_values(Query *q, Result *R, size_t top) {
     std::vector<int64_t> cells(top);
     for (size_t i = 0; i < top; i++) cells[i] = R->row0_cell(i);
     R->top_vals.resize(top * (size_t)P.hist_stride);
-    if (q->rs_active) {
-        // the printed rows' bucket arrays live on the ranks that own their cells: every rank gathers its own (zeros for
-        // the others) and the buffers are summed -- on the main stream, in step with the other collectives
+    if (q->rs_active || q->top_merge) {
+        // the printed rows' bucket arrays live on the ranks that own their cells (reduce-scatter), or every rank holds its
+        // own part of each (a printer's merge: the table stayed rank-local): every rank gathers what it has (zeros for
+        // cells it does not own) and the buffers are summed -- on the main stream, in step with the other collectives
         hipStream_t st = ctx->stream;
+        const int64_t own0 = q->rs_active ? q->rs_cell0 : 0, own1 = q->rs_active ? q->rs_cell1 : (int64_t)P.n_cells;
         SYBL_HIP(hipMemcpyAsync(q->d_top_cells, cells.data(), top * 8, hipMemcpyHostToDevice, st));
-        hipError_t e = launch_hist_gather(q->d_sum + P.hist_off, P.hist_stride, q->d_top_cells, (int64_t)top, q->rs_cell0, q->rs_cell1, q->d_top, st);
+        hipError_t e = launch_hist_gather(q->d_sum + P.hist_off, P.hist_stride, q->d_top_cells, (int64_t)top, own0, own1, q->d_top, st);
         if (e != hipSuccess) return hip_fail(e, "k_hist_gather");
         int rc = comm_allreduce_sum(ctx, q->d_top, top * (size_t)P.hist_stride);
         if (rc) return rc;
@@ -661,6 +688,7 @@ int query_finalize(Query *q, Result **out) {
 
     Result *R = new Result();
     std::unique_ptr<Result> r_guard(R);  // (every early return below gives the result back)
+    R->api_m = q->ctx->api_m;
     if (!q->rpool) q->rpool = std::make_shared<ResultPool>();
     R->pool = q->rpool;
     {
@@ -698,7 +726,7 @@ int query_finalize(Query *q, Result **out) {
     if (P.hist_stride > 0 && q->snap_has_buckets) H = hashed ? F + (int64_t)P.n_sum_fields * ncell : hs + P.hist_off;
     R->keep = q->h_sum_buf;  // the rows are built from (and their bucket arrays live in) the snapshot
     const bool summary = q->hist_summary;
-    if (summary) R->keep_pct = q->h_pct_buf;  // the rows' percentiles live in the snapshot
+    if (summary && !q->top_only) R->keep_pct = q->h_pct_buf;  // the rows' percentiles live in the snapshot
     const size_t na = q->aggs.size();
     // outlier values (plan.h: outlier log): usable when every one of them was logged
     const bool out_logged = q->d_out_log != nullptr;
@@ -722,7 +750,8 @@ int query_finalize(Query *q, Result **out) {
     C.F = F;
     C.H = H;
     C.hm = hm;
-    C.h_pct = summary ? q->h_pct : nullptr;
+    C.top_only = q->top_only;
+    C.h_pct = summary && !q->top_only ? q->h_pct : nullptr;
     C.q = q;
     C.keys_buf = hashed ? q->h_keys_buf : nullptr;
     C.dense_keys = hashed ? q->h_dense_keys : nullptr;
@@ -841,7 +870,8 @@ int query_finalize(Query *q, Result **out) {
     // table's dictionaries: such a result registers with its query, which builds the rows before it goes away.
     const bool lazy = !q->n_distinct && (live.size() >= 2048 || getenv("SYBL_LAZY_ROWS")) && !getenv("SYBL_EAGER_ROWS");
     if (summary) {
-        C.mom.assign(q->h_mom, q->h_mom + (size_t)P.n_cells * na * 2);
+        if (!q->top_only) C.mom.assign(q->h_mom, q->h_mom + (size_t)P.n_cells * na * 2);
+        else C.mom.clear();
         for (size_t a = 0; a < na; a++)
             if (!R->total_vals[a].empty())
                 memcpy(R->total_vals[a].data(), q->h_total + P.hist_agg_off[a], R->total_vals[a].size() * sizeof(int64_t));
@@ -1053,7 +1083,7 @@ void result_ensure_rows(Result *R) {
             if (A.m_max >= 0) x.vmax = hm[(int64_t)A.m_max * ncell + cell];
             if (A.m_nmin >= 0) x.nmin = hm[(int64_t)A.m_nmin * ncell + cell];
             if (A.hist_full && H) x.values = H + cell * P.hist_stride + P.hist_agg_off[a];
-            if (A.hist_full && summary) {
+            if (A.hist_full && summary && !C.top_only) {
                 const int64_t pair = cell * (int64_t)na + (int64_t)a;
                 x.pct_gpu = C.h_pct + pair * 100;
                 x.sb = C.mom[(size_t)pair * 2];
@@ -1085,11 +1115,21 @@ void result_ensure_rows(Result *R) {
     R->pct_pool.resize(C.want_percentiles ? n_all_rows * na * 100 : 0);
     // pass 2: one row per live cell.  Rows own disjoint pool slots, so ranges of cells are
     // finished by worker threads when there are enough of them to pay for the threads.
+    // a printer's result (FinCtx::top_only): the rows of the sort order's first top_n places get percentiles and stddev
+    // from their bucket arrays (fetch_top_values), exactly as a small result's rows do; the others have neither
+    std::vector<int32_t> top_ix;
+    if (C.top_only) {
+        top_ix.assign(live.size(), -1);
+        for (size_t i = 0; i < R->top_n && i < live.size(); i++) top_ix[R->order0.empty() ? i : R->order0[i]] = (int32_t)i;
+    }
     auto work = [&](size_t i0, size_t i1, CellAcc *tot, std::vector<std::vector<int64_t>> *tot_vals) {
         CellAcc acc;
         for (size_t i = i0; i < i1; i++) {
             const int64_t cell = live[i];
             load_cell(cell, acc);
+            if (C.top_only && top_ix[i] >= 0)
+                for (size_t a = 0; a < na; a++)
+                    if (C.aggs[a].d.hist_full) acc.aggs[a].values = R->top_vals.data() + (size_t)top_ix[i] * (size_t)P.hist_stride + P.hist_agg_off[a];
             // (hash group-by: the composite key is [time bucket || group key], the dense arrays are in key order)
             const int64_t ckey = hashed ? (int64_t)C.dense_keys[(size_t)cell] : cell;
             const int64_t tbi = hashed && !C.time_mode ? 0 : ckey / gcells, gcell = ckey - tbi * gcells;
@@ -1259,6 +1299,7 @@ using namespace sybl;
 extern "C" {
 
 int sybl_result_rows(const sybl_result *r, int which, const sybl_group_row **rows, int64_t *n) {
+    SYBL_API_GUARD(r);
     if (r) result_ensure_rows((Result *)r);
     const Result *R = (const Result *)r;
     if (!R || which < 0 || which > 2) return fail(SYBL_E_INVAL, "sybl_result_rows: bad argument");
@@ -1268,6 +1309,7 @@ int sybl_result_rows(const sybl_result *r, int which, const sybl_group_row **row
 }
 
 int sybl_result_subhists(const sybl_result *r, int agg, const sybl_subhist **subs, int64_t *n) {
+    SYBL_API_GUARD(r);
     const Result *R = (const Result *)r;
     if (!R || !subs || !n || agg < 0 || agg >= R->n_aggs) return fail(SYBL_E_INVAL, "sybl_result_subhists: bad argument");
     *subs = (size_t)agg < R->subs.size() && !R->subs[(size_t)agg].empty() ? R->subs[(size_t)agg].data() : nullptr;
@@ -1276,6 +1318,7 @@ int sybl_result_subhists(const sybl_result *r, int agg, const sybl_subhist **sub
 }
 
 int sybl_result_distinct(const sybl_result *r, int which, int64_t row, int64_t *cardinality, const uint8_t **registers) {
+    SYBL_API_GUARD(r);
     const Result *R = (const Result *)r;
     if (!R || !R->has_distinct) return fail(SYBL_E_INVAL, "not a count-distinct result");
     if (which < 0 || which > 2 || row < 0 || row >= (int64_t)R->rows[which].size()) return fail(SYBL_E_INVAL, "no such row");
@@ -1300,7 +1343,13 @@ int sybl_debug_hll_ints(const int64_t *values, const uint8_t *populated, int64_t
 }
 
 uint64_t sybl_debug_hll_bytes(const uint8_t *bytes, int64_t len, uint8_t *registers) {
-    const uint64_t h = metro64_bytes(bytes, (size_t)len, kHllSeed);
+    uint64_t h = metro64_bytes(bytes, (size_t)len, kHllSeed);
+    // (the piecewise form the device's slow path over several columns uses must agree, whatever the length: a difference
+    // is reported as a hash no checker will accept)
+    Metro64Stream S;
+    S.init(kHllSeed);
+    for (int64_t i = 0; i < len; i++) S.put(bytes[i]);
+    if (S.finish() != h) h = ~h;
     if (registers) {
         uint32_t reg, rank;
         hll_place(h, reg, rank);
@@ -1311,8 +1360,14 @@ uint64_t sybl_debug_hll_bytes(const uint8_t *bytes, int64_t len, uint8_t *regist
 
 int64_t sybl_debug_hll_cardinality(const uint8_t *registers) { return registers ? (int64_t)hll_cardinality(registers) : -1; }
 
-int64_t sybl_result_matched(const sybl_result *r) { return r ? ((const Result *)r)->matched : 0; }
+}  // extern "C"
+namespace sybl {
+std::shared_ptr<std::recursive_mutex> api_mutex_of(const sybl_result *r) { return r ? ((const Result *)r)->api_m : nullptr; }
+}
+extern "C" {
 
-void sybl_result_free(sybl_result *r) { delete (Result *)r; }
+int64_t sybl_result_matched(const sybl_result *r) { SYBL_API_GUARD(r); return r ? ((const Result *)r)->matched : 0; }
+
+void sybl_result_free(sybl_result *r) { SYBL_API_GUARD(r); delete (Result *)r; }
 
 }  // extern "C"

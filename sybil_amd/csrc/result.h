@@ -100,6 +100,7 @@ struct FinCtx {
     int op = 0;
     bool weighted = false, loghist = false, want_percentiles = false, time_mode = false, hashed = false, summary = false;
     bool out_usable = false, keys_cached = false;
+    bool top_only = false;  // a printer's result: percentiles / stddev / buckets for the printed rows and Cumulative only
     std::vector<AggInfo> aggs;
     ScanPlan P;
     int64_t ncell = 0, gcells = 0;
@@ -117,6 +118,7 @@ struct Result : ResultStore {
     RowStore &sorted0(size_t i) { return rows[0][order0.empty() ? i : order0[i]]; }
     std::shared_ptr<ResultPool> pool;  // where the arrays go back to when the result is freed
     Query *owner = nullptr;  // the query a lazily finalized result with per-row keys is registered with
+    std::shared_ptr<std::recursive_mutex> api_m;  // the ctx's entry-point lock (engine.h: Ctx::api_m), alive as long as this result
     ~Result() {
         if (owner) {
             auto &v = owner->lazy_results;

@@ -769,6 +769,7 @@ extern "C" {
 // ------------------------------------------------------------------ tables
 
 int sybl_table_create(sybl_ctx *ctx, const char *name, sybl_table **out) {
+    SYBL_API_GUARD(ctx);
     if (!ctx || !out) return fail(SYBL_E_INVAL, "sybl_table_create: NULL argument");
     sybl_table *t = new sybl_table();
     t->ctx = ctx;
@@ -778,6 +779,7 @@ int sybl_table_create(sybl_ctx *ctx, const char *name, sybl_table **out) {
 }
 
 void sybl_table_free(sybl_table *t) {
+    SYBL_API_GUARD(t);
     if (!t) return;
     hipSetDevice(t->ctx->device);
     hipStreamSynchronize(t->ctx->stream);
@@ -793,6 +795,7 @@ void sybl_table_free(sybl_table *t) {
 }
 
 int sybl_table_add_column(sybl_table *t, const char *name, int type, int64_t info_min, int64_t info_max) {
+    SYBL_API_GUARD(t);
     if (!t || !name) return fail(SYBL_E_INVAL, "sybl_table_add_column: NULL argument");
     if (type != SYBL_INT_VAL && type != SYBL_STR_VAL && type != SYBL_SET_VAL) return fail(SYBL_E_INVAL, "bad column type %d", type);
     if (t->col_ix.count(name)) return fail(SYBL_E_INVAL, "column '%s' already exists", name);
@@ -810,6 +813,7 @@ int sybl_table_add_column(sybl_table *t, const char *name, int type, int64_t inf
 }
 
 int sybl_table_append_block(sybl_table *t, int64_t nrows, int32_t ncols, const sybl_col_view *cols) {
+    SYBL_API_GUARD(t);
     if (!t || nrows < 0 || (ncols > 0 && !cols)) return fail(SYBL_E_INVAL, "sybl_table_append_block: bad argument");
     SYBL_HIP(hipSetDevice(t->ctx->device));
     for (int i = 0; i < ncols; i++) {
@@ -869,6 +873,7 @@ int sybl_table_append_block(sybl_table *t, int64_t nrows, int32_t ncols, const s
 
 int sybl_table_create_synth(sybl_ctx *ctx, const char *name, uint64_t seed, int64_t total_rows, int64_t row0,
                             int64_t nrows, int32_t ncols, const sybl_synth_col *cols, sybl_table **out) {
+    SYBL_API_GUARD(ctx);
     if (!ctx || !out || !cols || ncols <= 0 || nrows < 0 || total_rows <= 0 || row0 < 0 || row0 + nrows > total_rows)
         return fail(SYBL_E_INVAL, "sybl_table_create_synth: bad argument");
     SYBL_HIP(hipSetDevice(ctx->device));
@@ -911,10 +916,11 @@ int sybl_table_create_synth(sybl_ctx *ctx, const char *name, uint64_t seed, int6
     return SYBL_OK;
 }
 
-int64_t sybl_table_rows(const sybl_table *t) { return t ? t->logical_rows : 0; }
-int64_t sybl_table_blocks(const sybl_table *t) { return t ? (int64_t)t->blocks.size() : 0; }
+int64_t sybl_table_rows(const sybl_table *t) { SYBL_API_GUARD(t); return t ? t->logical_rows : 0; }
+int64_t sybl_table_blocks(const sybl_table *t) { SYBL_API_GUARD(t); return t ? (int64_t)t->blocks.size() : 0; }
 
 int64_t sybl_table_hbm_bytes(const sybl_table *t) {
+    SYBL_API_GUARD(t);
     if (!t) return 0;
     int64_t b = 0;
     for (auto &c : t->cols) b += c->cap_rows * c->elem + c->valid_cap_words * 4 + c->set_vals_cap * 4;
@@ -923,6 +929,7 @@ int64_t sybl_table_hbm_bytes(const sybl_table *t) {
 
 int sybl_table_column_info(const sybl_table *tc, const char *name, int *type, int64_t *exact_min, int64_t *exact_max,
                            int64_t *info_min, int64_t *info_max, int *has_missing) {
+    SYBL_API_GUARD(tc);
     sybl_table *t = const_cast<sybl_table *>(tc);
     if (!t) return fail(SYBL_E_INVAL, "table is NULL");
     Column *c = t->find(name);
@@ -940,6 +947,7 @@ int sybl_table_column_info(const sybl_table *tc, const char *name, int *type, in
 }
 
 int sybl_table_set_bounds(sybl_table *t, const char *name, int64_t lo, int64_t hi, int has_missing) {
+    SYBL_API_GUARD(t);
     if (!t) return fail(SYBL_E_INVAL, "table is NULL");
     Column *c = t->find(name);
     if (!c) return fail(SYBL_E_INVAL, "unknown column '%s'", name ? name : "(null)");
@@ -956,6 +964,7 @@ int sybl_table_set_bounds(sybl_table *t, const char *name, int64_t lo, int64_t h
 }
 
 int sybl_table_column_distinct(sybl_table *t, const char *name, const int64_t **values, int64_t *n) {
+    SYBL_API_GUARD(t);
     if (!t || !values || !n) return fail(SYBL_E_INVAL, "NULL argument");
     Column *c = t->find(name);
     if (!c || c->type == SYBL_SET_VAL) return fail(SYBL_E_INVAL, "unknown int/str column '%s'", name ? name : "(null)");
@@ -968,6 +977,7 @@ int sybl_table_column_distinct(sybl_table *t, const char *name, const int64_t **
 }
 
 int sybl_table_set_group_dict(sybl_table *t, const char *name, const int64_t *values, int64_t n) {
+    SYBL_API_GUARD(t);
     if (!t || (n > 0 && !values) || n < 0) return fail(SYBL_E_INVAL, "bad argument");
     Column *c = t->find(name);
     if (!c || c->type == SYBL_SET_VAL) return fail(SYBL_E_INVAL, "unknown int/str column '%s'", name ? name : "(null)");
@@ -988,6 +998,7 @@ int sybl_table_set_group_dict(sybl_table *t, const char *name, const int64_t *va
 // evaluated per id) means the same thing everywhere.  Hosts gather sybl_table_column_dict from every
 // rank and install the (sorted) union with sybl_table_set_dict; resident ids are remapped in place.
 int sybl_table_column_dict(sybl_table *t, const char *name, const char *const **strings, int64_t *n) {
+    SYBL_API_GUARD(t);
     if (!t || !strings || !n) return fail(SYBL_E_INVAL, "NULL argument");
     Column *c = t->find(name);
     if (!c || c->type == SYBL_INT_VAL) return fail(SYBL_E_INVAL, "unknown str/set column '%s'", name ? name : "(null)");
@@ -999,6 +1010,7 @@ int sybl_table_column_dict(sybl_table *t, const char *name, const char *const **
 }
 
 int sybl_table_set_dict(sybl_table *t, const char *name, const char *const *strings, int64_t n) {
+    SYBL_API_GUARD(t);
     if (!t || n < 0 || (n > 0 && !strings)) return fail(SYBL_E_INVAL, "bad argument");
     Column *c = t->find(name);
     if (!c || c->type == SYBL_INT_VAL) return fail(SYBL_E_INVAL, "unknown str/set column '%s'", name ? name : "(null)");
@@ -1059,6 +1071,7 @@ static int compact_column(Table *t, Column *c) {
 }
 
 int sybl_table_compact(sybl_table *t) {
+    SYBL_API_GUARD(t);
     if (!t) return fail(SYBL_E_INVAL, "NULL table");
     SYBL_HIP(hipSetDevice(t->ctx->device));
     int rc = table_ensure_stats(t);
@@ -1073,6 +1086,7 @@ int sybl_table_compact(sybl_table *t) {
 }
 
 int sybl_table_column_storage(const sybl_table *t, const char *name, int32_t *width, int64_t *base) {
+    SYBL_API_GUARD(t);
     if (!t) return fail(SYBL_E_INVAL, "NULL table");
     Column *c = t->find(name);
     if (!c) return fail(SYBL_E_INVAL, "unknown column '%s'", name ? name : "(null)");
@@ -1082,6 +1096,7 @@ int sybl_table_column_storage(const sybl_table *t, const char *name, int32_t *wi
 }
 
 int sybl_table_read_int(const sybl_table *t, const char *name, int64_t row0, int64_t n, int64_t *out) {
+    SYBL_API_GUARD(t);
     if (!t || !out) return fail(SYBL_E_INVAL, "NULL argument");
     Column *c = t->find(name);
     if (!c || c->type != SYBL_INT_VAL) return fail(SYBL_E_INVAL, "unknown int column '%s'", name ? name : "(null)");

@@ -296,6 +296,7 @@ extern "C" const void *sybl_debug_encode_column(int kind, const char *name, cons
 }
 
 extern "C" int sybl_table_save(sybl_table *t, const char *dir) {
+    SYBL_API_GUARD(t);
     if (!t || !dir) return fail(SYBL_E_INVAL, "sybl_table_save: NULL argument");
     SYBL_HIP(hipSetDevice(t->ctx->device));
     SYBL_HIP(hipStreamSynchronize(t->ctx->stream));

@@ -238,9 +238,11 @@ class Table:
 
     def query(self, filters=(), groups=(), aggs=(), op="avg", hist_bucket=0, want_percentiles=True, time_col=None,
               time_bucket=0, weight_col=None, order_by="$COUNT", order_asc=False, limit=0, block_skip=False, loghist=False, str_replace=(),
-              distincts=()):
+              distincts=(), printed_only=False):
         """str_replace: [(col, pattern, replacement)] or [(col, [replaced string per dictionary id])] (-str-replace).
-        distincts: columns of a count-distinct query (-distinct): rows then carry "distinct" (Result.distinct())."""
+        distincts: columns of a count-distinct query (-distinct): rows then carry "distinct" (Result.distinct()).
+        printed_only: the caller is a printer (sybl_query_desc.printed_only): with limit > 0 and many histogram groups only the
+        first `limit` rows of the sort order and Cumulative carry percentiles / stddev / bucket arrays."""
         keep = []
         farr = (N.Filter * max(len(filters), 1))()
         for i, f in enumerate(filters):
@@ -292,6 +294,7 @@ class Table:
         dn = [_b(x) for x in distincts]
         darr = (C.c_char_p * max(len(dn), 1))(*dn)
         d.n_distincts, d.distincts = len(dn), C.cast(darr, C.POINTER(C.c_char_p))
+        d.printed_only = 1 if printed_only else 0
         h = C.c_void_p()
         N.check(N.lib().sybl_query_prepare(self._h, C.byref(d), C.byref(h)))
         qy = Query(self, h, list(groups), list(aggs))

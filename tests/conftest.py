@@ -17,3 +17,13 @@ def oracle():
     from oracle import oracle as orc
     orc.lib()
     return orc
+
+
+@pytest.fixture(params=["default", "lazy"])
+def rows_mode(request, monkeypatch):
+    """Runs a test twice: as is, and with SYBL_LAZY_ROWS=1 -- every result, whatever its size, builds its rows on first
+    access (result.cpp: result_ensure_rows), so the lazy path sees every query shape of the file that asks for this fixture
+    (pytestmark usefixtures in the hash / CLI / loghist files)."""
+    if request.param == "lazy":
+        monkeypatch.setenv("SYBL_LAZY_ROWS", "1")
+    return request.param

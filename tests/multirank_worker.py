@@ -23,6 +23,9 @@ CASES = {
     "scatter32": (["c03", "c07"], dict(groups=["c03"], aggs=["c07"], op="hist", limit=50), {}, dict(compact=True)),
     "scatter64": (["c03", "c07"], dict(groups=["c03"], aggs=["c07"], op="hist", limit=50), {"SYBL_NO_SCATTER32": "1"}, {}),
     # (-hist-bucket 990 puts the top ~1 % of c07 beyond the last bucket: ~60 000 outliers, spread over every rank's log)
+    # a printer's merge (sybl_query_desc.printed_only): the bucket table stays rank-local, the cell fields are all-reduced, every
+    # rank derives the same top-`limit` order, and only Cumulative's buckets and those rows' arrays are summed
+    "printer": (["c03", "c07"], dict(groups=["c03"], aggs=["c07"], op="hist", limit=50, printed_only=True), {}, dict(compact=True)),
     "outliers": (["c01", "c07"], dict(groups=["c01"], aggs=["c07"], op="hist", hist_bucket=990), {}, {}),
     "hash": (["c04", "c05", "c06", "c01", "c02", "c07", "c08"], _CFG3, {"SYBL_FORCE_HASH": "1"}, {}),
     "hash_extrema": (["c02", "c09", "c08"], dict(groups=["c02", "c09"], aggs=["c08"], op="avg"), {"SYBL_FORCE_HASH": "1"}, dict(compact=True)),

@@ -11,7 +11,7 @@ import pytest
 
 from tests import sybil_fixture as F
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("rows_mode")]  # (each test also with SYBL_LAZY_ROWS=1: conftest.py)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CLI = os.path.join(ROOT, "sybil_amd", "sybil-gpu-query")
 

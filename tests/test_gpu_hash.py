@@ -9,7 +9,7 @@ import sybil_amd
 from sybil_amd import synth
 from tests import parity
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("rows_mode")]  # (each test also with SYBL_LAZY_ROWS=1: conftest.py)
 
 
 @pytest.fixture(scope="module")

@@ -392,3 +392,34 @@ def test_refresh_gives_back_the_rows_of_blocks_that_vanished_mid_table(ctx, tmp_
     fresh.free()
     assert tb.hbm_bytes <= hbm5 * 1.05, (tb.hbm_bytes, hbm5)
     tb.free()
+
+
+def test_group_dictionary_after_a_trim_only_refresh_reads_the_moved_blocks(ctx, tmp_path, monkeypatch):
+    """table_reclaim_dead_rows moves the live blocks' rows, but the device copy of the block segments was only
+    uploaded when some column's statistics were pending -- not after a refresh that only DROPS blocks.  The next sparse-key
+    group dictionary (k_distinct walks those segments) then read the old row ranges: values of a moved block were missing
+    from the dictionary and its rows fell out of the result.  Sequence: a sparse int key grouped once (dictionary built,
+    segments uploaded), a block dropped without reclaim (its n = 0 uploaded with the next statistics), a second block
+    dropped WITH reclaim and nothing added, the key grouped again."""
+    import shutil
+    blocks, _ = _make_blocks(6, 3000, seed=91, ragged=False)
+    info = {"big": (-(1 << 40), 1 << 40)}
+    root = str(tmp_path / "db")
+    F.write_table(root, "events", blocks, threshold=8, int_info=info)
+    tb = ctx.open_table(root, "events", compact=True)
+    q = dict(groups=["big"], aggs=["age"])
+    tdir = str(tmp_path / "db" / "events")
+    first = _summary(tb, q)
+    assert len(first[1]) > 10_000  # (a sparse key: nearly every populated row a group of its own)
+    shutil.rmtree(tdir + "/block000000002")
+    assert tb.refresh() == (0, 1, 0)  # below the reclaim threshold: the block just leaves the scan
+    assert _summary(tb, dict(groups=["age"], aggs=["time"]))[0] == 15000
+    monkeypatch.setenv("SYBL_RECLAIM_ALWAYS", "1")
+    shutil.rmtree(tdir + "/block000000001")
+    assert tb.refresh() == (0, 1, 0)  # trim only: the live blocks close up, no column's statistics become pending
+    fresh = ctx.open_table(root, "events", compact=True)
+    got, want = _summary(tb, q), _summary(fresh, q)
+    assert got == want
+    assert got[0] == 12000
+    fresh.free()
+    tb.free()

@@ -8,7 +8,7 @@ import pytest
 import sybil_amd
 from tests import parity
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("rows_mode")]  # (each test also with SYBL_LAZY_ROWS=1: conftest.py)
 
 
 @pytest.fixture(scope="module")

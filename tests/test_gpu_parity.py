@@ -820,6 +820,104 @@ def test_many_groups_with_limit_fetches_only_printed_bucket_arrays(ctx, oracle):
     gres.free()
 
 
+@pytest.mark.parametrize("compact", [False, True])
+def test_weight_column_with_unpopulated_rows_carries_the_last_weight(ctx, oracle, compact):
+    """aggregate.go:68,100-102 (refused until round 5): a row without a weight aggregates with the last weight seen in its
+    block, 1 before the first.  k_weight_carry lays the weights in force out as a dense column of the query's own; every
+    row body that takes a weight column then runs unchanged -- the GEN kernels (avg, moments), the LDS histograms, the
+    generic kernel (weighted bucket arrays, the weight column also filtered / aggregated), a time series, the hash table."""
+    n, block = 200_000, 7000
+    rng = np.random.default_rng(41)
+    g = rng.integers(0, 12, size=n).astype(np.int64)
+    v = rng.integers(0, 50_000, size=n).astype(np.int64)
+    vpop = (rng.random(n) > 0.2).astype(np.uint8)
+    f = rng.integers(0, 1000, size=n).astype(np.int64)
+    t = (1_700_000_000 + np.sort(rng.integers(0, 86_400 * 3, size=n))).astype(np.int64)
+    w = rng.integers(1, 9, size=n).astype(np.int64)
+    wpop = (rng.random(n) > 0.7).astype(np.uint8)   # most rows inherit
+    wpop[block * 3:block * 3 + 900] = 0             # a block that starts without a weight
+    wpop[block * 5:block * 6] = 0                   # a block without any
+    tb = ctx.create_table("wc")
+    tb.add_column("g", "int")
+    tb.add_column("v", "int", 0, 49_999)
+    tb.add_column("f", "int")
+    tb.add_column("t", "int")
+    tb.add_column("w", "int")
+    _append_in_blocks(tb, n, block, {"g": g, "v": (v, vpop), "f": f, "t": t, "w": (w, wpop)})
+    if compact:
+        tb.compact()
+    ocols = [{"type": "int", "data": g}, {"type": "int", "data": v, "populated": vpop}, {"type": "int", "data": f}, {"type": "int", "data": t},
+             {"type": "int", "data": w, "populated": wpop}]
+    names = ["g", "v", "f", "t", "w"]
+    info = {"v": (0, 49_999), "w": (1, 8)}
+    import os
+    for q, env in ((dict(filters=[("f", "gt", 100), ("f", "lt", 800)], groups=["g"], aggs=["v"], op="avg", weight_col="w"), {}),
+                   (dict(groups=["g"], aggs=["v"], op="hist", want_percentiles=False, weight_col="w"), {}),
+                   (dict(groups=["g"], aggs=["v"], op="hist", want_percentiles=True, weight_col="w"), {}),
+                   (dict(filters=[("w", "lt", 7)], groups=["g"], aggs=["v", "w"], op="avg", weight_col="w"), {}),   # the column in three roles
+                   (dict(groups=["g"], aggs=["v"], op="avg", weight_col="w", time_col="t", time_bucket=3600), {}),
+                   (dict(groups=["g", "f"], aggs=["v"], op="avg", weight_col="w"), {"SYBL_FORCE_HASH": "1"})):
+        os.environ.update(env)
+        try:
+            query = tb.query(**q)
+        finally:
+            for k in env:
+                del os.environ[k]
+        gres = query.run()
+        ores = oracle.run_query(ocols, block_rows=block, **parity.oracle_query_kwargs(names, info, q))
+        parity.compare(gres, ores, op=q["op"], full=q.get("want_percentiles", False), n_aggs=len(q["aggs"]), time_mode=bool(q.get("time_col")))
+        gres.free()
+        query.free()
+    tb.free()
+
+
+@pytest.mark.parametrize("order", [dict(order_by="$COUNT"), dict(order_by="c07", order_asc=True)])
+def test_printers_query_summarises_only_the_printed_rows(ctx, oracle, order):
+    """sybl_query_desc.printed_only (ABI 4): the reference calls GetPercentiles / GetStdDev at print time, for the `Limit`
+    rows it prints (printer.go:60-76,291-308).  A printer's query over 65 536 groups x 1002 buckets therefore runs no
+    summary pass over every group: the printed rows' percentiles and stddev come from their own bucket arrays, Cumulative's
+    from k_hist_total; the other rows carry count / sum / avg / extrema only.  Both printers must not notice."""
+    from sybil_amd import synth
+    wl = _wl("cfg4_hist_highcard")
+    rows = 500_000
+    t = ctx.synth_table("pr", synth.SEED, rows, 0, rows, synth.synth_cols(wl["columns"]))
+    t.compact()
+    q = dict(wl["query"], limit=25, **order)
+    full_q = t.query(**q)
+    full = full_q.run()
+    pr_q = t.query(**dict(q, printed_only=True))
+    pr = pr_q.run()
+    assert pr_q.stats()["strategy"] == 5
+    info = {c: (synth.COLUMNS[c][4], synth.COLUMNS[c][5]) for c in wl["columns"]}
+    o = oracle.run_query(parity.oracle_synth_cols(oracle, wl["columns"], rows, 0, rows), n_threads=4, **parity.oracle_query_kwargs(wl["columns"], info, q))
+    omap = {r["key"]: r for r in o["results"]}
+    got, ref = pr.results, full.results
+    assert [g["key"] for g in got] == [g["key"] for g in ref] and len(got) == len(omap)
+    for i, g in enumerate(got):
+        oh, h = omap[g["key"]]["hists"][0], g["hists"][0]
+        assert (g["count"], h["count"], h["sum"], h["min"], h["max"]) == (omap[g["key"]]["count"], oh["count"], oh["sum_exact"], oh["min"], oh["max"])
+        assert h["avg"] == ref[i]["hists"][0]["avg"]
+        if i < 25:
+            assert np.array_equal(h["values"], oh["values"]) and np.array_equal(h["percentiles"], oh["percentiles"])
+            assert parity._close(h["stddev"], oh["stddev_exact"], 1e-9, max(abs(oh["avg"]), oh["bucket_size"], 1.0))
+            assert parity._close(h["stddev"], ref[i]["hists"][0]["stddev"], 1e-9, max(abs(oh["avg"]), oh["bucket_size"], 1.0))
+        else:
+            assert "values" not in h and "percentiles" not in h and h["stddev"] != h["stddev"]
+    parity.compare_hist(pr.cumulative["hists"][0], o["cumulative"]["hists"][0], "hist", True, ctx="cumulative", cumulative=True)
+    # (the summary path derives stddev from exact bucket moments in long double, the printed rows' own arrays go through
+    # GetStdDev's float loop: the last digits may differ, so the printers are compared on everything but that field)
+    import json
+    import re
+    def strip(s):
+        return re.sub(r'"(stddev|std)":\s*[-0-9.eE+]+', '"stddev": 0', s)
+    assert json.loads(strip(pr.render("json"))) == json.loads(strip(full.render("json")))
+    pr.free()
+    full.free()
+    pr_q.free()
+    full_q.free()
+    t.free()
+
+
 def test_outlier_values_are_kept_and_printed(ctx, oracle, monkeypatch):
     """-hist-bucket leaves NumBuckets at 1000, so values beyond Min + 1001 * bucket are Outliers: clipped into the last
     bucket AND remembered (hist_basic.go:132-142).  GetStrBuckets prints each under its own value (:239-257) and the gob

@@ -121,6 +121,34 @@ def test_missing_values_and_weights(oracle):
     assert r["matched"] == int(vp.sum())
 
 
+def test_weight_carries_over_rows_without_one_inside_a_block(oracle):
+    """aggregate.go:68,100-102: `weight` is declared before the row loop of FilterAndAggRecords (one call per block) as 1 and
+    only assigned when the row's weight column is populated -- a row without one aggregates with the last weight seen in
+    its block, whether or not the row that carried it passed the filters.  Checked against a numpy restatement."""
+    n, block = 5000, 700
+    rng = np.random.default_rng(11)
+    g = rng.integers(0, 5, size=n).astype(np.int64)
+    v = rng.integers(0, 100, size=n).astype(np.int64)
+    f = rng.integers(0, 10, size=n).astype(np.int64)
+    w = rng.integers(2, 9, size=n).astype(np.int64)
+    wp = (rng.random(n) > 0.6).astype(np.uint8)
+    wp[block * 2:block * 2 + 50] = 0  # a block that starts without weights: 1 until the first one
+    eff = np.empty(n, dtype=np.int64)
+    for b0 in range(0, n, block):
+        cur = 1
+        for i in range(b0, min(b0 + block, n)):
+            if wp[i]:
+                cur = w[i]
+            eff[i] = cur
+    cols = [{"type": "int", "data": g}, {"type": "int", "data": v}, {"type": "int", "data": w, "populated": wp}, {"type": "int", "data": f}]
+    r = oracle.run_query(cols, filters=[(3, "gt", 2)], groups=[0], aggs=[(1, 0, 99)], weight_col=2, block_rows=block)
+    assert len(r["results"]) == 5
+    for x in r["results"]:
+        sel = (g == x["key_vals"][0]) & (f > 2)
+        assert x["samples"] == int(sel.sum()) and x["count"] == int(eff[sel].sum())
+        assert x["hists"][0]["count"] == int(eff[sel].sum()) and x["hists"][0]["sum_exact"] == int((v[sel] * eff[sel]).sum())
+
+
 def test_block_skip_is_result_neutral(oracle):
     age, t, f1 = _people(5000)
     cols = [{"type": "int", "data": t}, {"type": "int", "data": f1}]
