@@ -464,8 +464,13 @@ int query_snapshot(Query *q) {
     // a hash group-by snapshots its dense, key-ordered arrays, whose size follows the keys found
     const int64_t sum_words = q->hash_mode ? hash_dense_sum_words(q, q->hash_live) : q->n_sum_words;
     const int64_t max_words = q->hash_mode ? hash_dense_max_words(q, q->hash_live) : q->n_max_words;
-    if (!q->h_sum_buf || q->h_sum_buf->pins.load() > 0 || q->h_sum_buf->words < sum_words) {
-        int rc = query_acquire_host_buf(q, sum_words, q->h_sum_buf);
+    // (what the copy below will bring: the whole table, or -- GPU summary path with a row limit -- everything before the
+    // bucket arrays.  Config 4's pinned snapshots were sized for the 525 MB table they never receive: 22 ms of pinned
+    // allocation for each of the four a pipelined pair of queries takes, 2 GB of pinned host memory)
+    const bool will_summarise = query_wants_hist_summary(q);
+    const int64_t snap_words = q->hash_mode ? sum_words : ((!will_summarise || q->limit <= 0) ? q->n_sum_words : (int64_t)P.hist_off);
+    if (!q->h_sum_buf || q->h_sum_buf->pins.load() > 0 || q->h_sum_buf->words < snap_words) {
+        int rc = query_acquire_host_buf(q, snap_words, q->h_sum_buf);
         if (rc) return rc;
     }
     if (!q->h_max || q->h_max_words < max_words) {
@@ -476,7 +481,7 @@ int query_snapshot(Query *q) {
     }
     q->h_sum = q->h_sum_buf->p;
     trace.mark("buffers");
-    q->hist_summary = query_wants_hist_summary(q);
+    q->hist_summary = will_summarise;
     // a printer's query (sybl_query_desc.printed_only): only Cumulative's buckets are summed here; the printed rows'
     // percentiles / stddev come from their bucket arrays, fetched after the sort (query_finalize)
     q->top_only = q->hist_summary && q->printed_only && q->limit > 0;
