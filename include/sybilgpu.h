@@ -90,6 +90,11 @@ void sybl_shutdown(sybl_ctx *ctx);
  * current stream); NULL restores the ctx's own stream. */
 int sybl_ctx_set_stream(sybl_ctx *ctx, void *hip_stream);
 int sybl_ctx_sync(sybl_ctx *ctx);
+/* Gives back what the ctx keeps between calls for speed and a long-running host may not want to pay for: the loader's
+ * staging arena (up to ~512 MB of pinned host memory and as much HBM, kept from one sybl_table_open / sybl_table_refresh to
+ * the next because pinning it costs every load tens of milliseconds).  A host that opens its tables once and then only
+ * queries them calls this after the last open; the next load allocates the arena again.  ABI 4. */
+int sybl_ctx_trim(sybl_ctx *ctx);
 int sybl_device_info(sybl_ctx *ctx, char *name, size_t name_cap, int *n_cus, int64_t *hbm_bytes);
 
 /* ------------------------------------------------------------------ tables

@@ -7,6 +7,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+# The library reads its diagnostic switches (SYBL_*) from the environment once and answers from that snapshot afterwards (a
+# cgo host may setenv from other threads); the test suite and the tools flip switches between queries: live reads for them.
+os.environ.setdefault("SYBL_ENV_LIVE", "1")
 # (SYBL_LIBRARY: another build of the same library, for same-box A/B timing runs)
 LIB_PATH = os.environ.get("SYBL_LIBRARY") or os.path.join(_HERE, "libsybilgpu.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "sybilgpu.h")
@@ -104,6 +107,7 @@ SIGNATURES = {
     "sybl_shutdown": (None, [P]),
     "sybl_ctx_set_stream": (C.c_int, [P, P]),
     "sybl_ctx_sync": (C.c_int, [P]),
+    "sybl_ctx_trim": (C.c_int, [P]),
     "sybl_device_info": (C.c_int, [P, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
     "sybl_table_create": (C.c_int, [P, C.c_char_p, C.POINTER(P)]),
     "sybl_table_free": (None, [P]),

@@ -19,10 +19,32 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
+#include <unordered_map>
+#include <string>
 #include <vector>
 #include <regex>
 
 namespace sybl {
+
+extern "C" char **environ;
+const char *env(const char *name) {
+    static std::unordered_map<std::string, std::string> snap;
+    static bool live = false;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (char **e = environ; e && *e; e++) {
+            if (strncmp(*e, "SYBL_", 5) != 0) continue;
+            const char *eq = strchr(*e, '=');
+            if (eq) snap.emplace(std::string(*e, (size_t)(eq - *e)), std::string(eq + 1));
+        }
+        live = snap.count("SYBL_ENV_LIVE") != 0;
+    });
+    if (live) return getenv(name);
+    auto it = snap.find(name);
+    return it == snap.end() ? nullptr : it->second.c_str();
+}
+
 
 static thread_local std::string g_err;
 
@@ -226,7 +248,7 @@ static int scan(Query *q) {
         if (e != hipSuccess) return hip_fail(e, "k_emit");
         trace.mark("emit");
         // SYBL_PARTHIST_TRACE=<file> (diagnostic): k_part_hist's phase timestamps of this scan, one line per workgroup
-        const char *ph_trace = getenv("SYBL_PARTHIST_TRACE");
+        const char *ph_trace = env("SYBL_PARTHIST_TRACE");
         DevOwner own_trace;
         const size_t trace_words = (size_t)q->pplan.n_parts * (size_t)q->pplan.split * kPartTraceWords;
         q->pplan.trace = nullptr;

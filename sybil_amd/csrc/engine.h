@@ -242,7 +242,7 @@ struct PhaseTrace {
     const char *what_ = "finalize";
     PhaseTrace() {}
     explicit PhaseTrace(const char *w) : what_(w) {}
-    bool on = getenv("SYBL_FINALIZE_TRACE") != nullptr;
+    bool on = env("SYBL_FINALIZE_TRACE") != nullptr;
     std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
     std::string line;
     void mark(const char *what) {

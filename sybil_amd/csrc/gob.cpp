@@ -177,7 +177,7 @@ __attribute__((target("avx512f,avx512bw,avx512dq,avx512vbmi,avx512vl,bmi,bmi2,lz
 #undef SYBL_EMIT8
 }
 static const bool g_have_vbmi = __builtin_cpu_supports("avx512vbmi") && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512dq") &&
-                                __builtin_cpu_supports("avx512vl") && __builtin_cpu_supports("bmi2") && !getenv("SYBL_GOB_NO_VBMI");
+                                __builtin_cpu_supports("avx512vl") && __builtin_cpu_supports("bmi2") && !env("SYBL_GOB_NO_VBMI");
 #endif
 
 struct Reader {
@@ -607,8 +607,10 @@ struct Decoder {
 namespace {
 struct IntStock {
     static constexpr int kKeep = 16;
+    static constexpr size_t kKeepUnits = (size_t)1 << 23;  // int64 units a thread's stock holds in all (64 MB: ADVICE r4)
     int64_t *p[kKeep];
     size_t cap[kKeep];
+    size_t total = 0;
     int n = 0;
     ~IntStock() {
         for (int i = 0; i < n; i++) free(p[i]);
@@ -620,9 +622,10 @@ thread_local IntStock g_stock;
 void IntBuf::release() {
     if (!p) return;
     IntStock &S = g_stock;
-    if (S.n < IntStock::kKeep && cap <= ((size_t)1 << 22)) {
+    if (S.n < IntStock::kKeep && cap <= ((size_t)1 << 22) && S.total + cap <= IntStock::kKeepUnits) {
         S.p[S.n] = p;
         S.cap[S.n] = cap;
+        S.total += cap;
         S.n++;
     } else {
         free(p);
@@ -642,6 +645,7 @@ void IntBuf::grow(size_t m) {
         if (best >= 0 && !p) {
             p = S.p[best];
             cap = S.cap[best];
+            S.total -= cap;
             S.p[best] = S.p[S.n - 1];
             S.cap[best] = S.cap[S.n - 1];
             S.n--;

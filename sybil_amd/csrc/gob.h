@@ -17,6 +17,8 @@
 #include <vector>
 
 namespace sybl {
+const char *env(const char *name);  // (plan.h / engine.cpp: the diagnostic switches, read once)
+
 namespace gob {
 
 struct Value;

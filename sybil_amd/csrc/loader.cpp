@@ -174,7 +174,7 @@ struct SlabPool {
                 (void)hipEventSynchronize(s.done);
                 (void)hipEventDestroy(s.done);
             }
-        if (ctx && getenv("SYBL_LOADER_KEEP_ARENA") && atoi(getenv("SYBL_LOADER_KEEP_ARENA")) == 0) ctx_free_load_arena(ctx);
+        if (ctx && env("SYBL_LOADER_KEEP_ARENA") && atoi(env("SYBL_LOADER_KEEP_ARENA")) == 0) ctx_free_load_arena(ctx);
     }
 };
 
@@ -346,7 +346,7 @@ struct BinsView {
 // AVX-512 forms picked at run time (the baseline x86-64 the library is built for has no 64-bit min / max and narrows
 // through shuffles): with the varint walk out of the way these passes were a quarter of a worker's time per block.
 #if defined(__x86_64__)
-static const bool g_cpu512 = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") && !getenv("SYBL_LOADER_NO_AVX512");
+static const bool g_cpu512 = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") && !env("SYBL_LOADER_NO_AVX512");
 __attribute__((target("avx512f,avx512bw"))) static uint64_t narrow16_512(const int64_t *src, uint16_t *dst, int64_t n) {
     __m512i acc = _mm512_setzero_si512();
     int64_t i = 0;
@@ -562,7 +562,7 @@ static PreparedBlock prepare_block_unguarded(const std::string &bdir, const std:
         gob::Value &v = trees[ci];
         // a missing file = column unpopulated in this block; "DECODE COL ERR": the reference logs and
         // carries on with an empty column
-        static const bool wide = getenv("SYBL_LOADER_WIDE_DECODE") != nullptr;  // (A/B: int64 slices, narrowed afterwards)
+        static const bool wide = env("SYBL_LOADER_WIDE_DECODE") != nullptr;  // (A/B: int64 slices, narrowed afterwards)
         if (!decode_file(path, v, err, specs[ci].type != SYBL_SET_VAL && !wide)) continue;
         have[ci] = 1;
         const gob::Value *f;
@@ -986,7 +986,7 @@ static int load_blocks(Ctx *ctx, Table *t, const std::string &tdir, const std::v
     // (twice the CPUs this process may use: a container's CFS quota -- 16 CPUs on the 256-thread GPU boxes of round 2 --
     // throttles every thread of the group once a burst of 128 workers has spent the period's budget)
     size_t n_workers = std::min<size_t>(128, std::max<size_t>(2, 2 * usable_cpus()));
-    if (const char *e = getenv("SYBL_LOADER_THREADS")) n_workers = (size_t)std::max(1, atoi(e));
+    if (const char *e = env("SYBL_LOADER_THREADS")) n_workers = (size_t)std::max(1, atoi(e));
     // one slab per block in flight: sized for a reference block (65536 rows) of every requested column -- a value-
     // encoded int column is at most 8 bytes per row, a str column adds its look-up table; larger blocks bring their own
     SlabPool pool;
@@ -994,9 +994,9 @@ static int load_blocks(Ctx *ctx, Table *t, const std::string &tdir, const std::v
         size_t per_block = 65536;
         for (auto &sp : specs) per_block += sp.type == SYBL_SET_VAL ? 0 : (size_t)65536 * (sp.type == SYBL_STR_VAL ? 12 : 8) + ((size_t)96 << 10);
         pool.slab_bytes = align16(per_block);
-        if (const char *e = getenv("SYBL_LOADER_SLAB_BYTES")) pool.slab_bytes = align16((size_t)std::max(16, atoi(e)));  // (tests: over-sized blocks)
+        if (const char *e = env("SYBL_LOADER_SLAB_BYTES")) pool.slab_bytes = align16((size_t)std::max(16, atoi(e)));  // (tests: over-sized blocks)
         pool.max_slabs = std::min<size_t>(std::max<size_t>(((size_t)512 << 20) / pool.slab_bytes, 4), std::max<size_t>(2 * n_workers, 4));
-        if (const char *e = getenv("SYBL_LOADER_SLABS")) pool.max_slabs = (size_t)std::max(2, atoi(e));  // (tuning)
+        if (const char *e = env("SYBL_LOADER_SLABS")) pool.max_slabs = (size_t)std::max(2, atoi(e));  // (tuning)
         pool.max_slabs = std::min<size_t>(pool.max_slabs, std::max<size_t>(n_names, 1));
         if ((rc = pool.init(ctx))) return (rc);
     }
@@ -1052,7 +1052,7 @@ static int load_blocks(Ctx *ctx, Table *t, const std::string &tdir, const std::v
         // streams the workers ran out of slabs: the 7-column bench table loaded in 0.116 s with four, 0.084 s with eight,
         // 0.063 s with sixteen, tools/r04 sweep in profiles/r04_loader_sweep.txt)
         int ns = 16;
-        if (const char *e = getenv("SYBL_LOADER_STREAMS")) ns = std::max(1, std::min((int)Ctx::kMaxLoadStreams, atoi(e)));
+        if (const char *e = env("SYBL_LOADER_STREAMS")) ns = std::max(1, std::min((int)Ctx::kMaxLoadStreams, atoi(e)));
         if (ns > 1) {
             SYBL_HIP(hipStreamSynchronize(ctx->stream));  // whatever the caller queued comes first
             for (int i = 0; i < ns; i++)
@@ -1073,9 +1073,9 @@ static int load_blocks(Ctx *ctx, Table *t, const std::string &tdir, const std::v
     int64_t h2d_bytes = 0;
     std::vector<std::vector<int32_t>> luts;
     DecodeBatches batch;
-    if (const char *e = getenv("SYBL_LOADER_FUSED")) batch.on = atoi(e) != 0;
+    if (const char *e = env("SYBL_LOADER_FUSED")) batch.on = atoi(e) != 0;
     // SYBL_LOADER_TRACE=1: where the calling thread's time goes (stderr)
-    const bool trace = getenv("SYBL_LOADER_TRACE") != nullptr;
+    const bool trace = env("SYBL_LOADER_TRACE") != nullptr;
     double tr[5] = {0, 0, 0, 0, 0};  // dictionaries, copy, column kernels, commit, submit
     auto lap = [&](int k, std::chrono::steady_clock::time_point &t0) {
         if (!trace) return;
@@ -1289,7 +1289,7 @@ static int refresh_table(Table *t, int64_t *n_added, int64_t *n_dropped, int64_t
     for (auto &lb : t->loaded) keep_blocks = std::max(keep_blocks, lb.index + 1);
     table_drop_dead_tail(t, keep_blocks);
     // (blocks that vanished from the middle -- trim / expire: once their rows are a quarter of the table the rest closes up)
-    if ((rc = table_reclaim_dead_rows(t, getenv("SYBL_RECLAIM_ALWAYS") != nullptr))) return rc;
+    if ((rc = table_reclaim_dead_rows(t, env("SYBL_RECLAIM_ALWAYS") != nullptr))) return rc;
     if (!to_load.empty() && (rc = load_blocks(ctx, t, t->src_dir, to_load))) return rc;
     if (n_added) *n_added = added;
     if (n_dropped) *n_dropped = dropped;
@@ -1336,6 +1336,15 @@ int sybl_table_refresh(sybl_table *t, int64_t *n_added, int64_t *n_dropped, int6
 
 int64_t sybl_table_broken_blocks(const sybl_table *t) { SYBL_API_GUARD(t); return t ? t->broken_blocks : 0; }
 
+int sybl_ctx_trim(sybl_ctx *ctx) {
+    SYBL_API_GUARD(ctx);
+    if (!ctx) return fail(SYBL_E_INVAL, "ctx is NULL");
+    SYBL_HIP(hipSetDevice(ctx->device));
+    SYBL_HIP(hipStreamSynchronize(ctx->stream));
+    ctx_free_load_arena(ctx);  // (the next sybl_table_open / sybl_table_refresh allocates it again)
+    return SYBL_OK;
+}
+
 int sybl_table_load_stats(const sybl_table *t, sybl_load_stats *out) {
     SYBL_API_GUARD(t);
     if (!t || !out) return fail(SYBL_E_INVAL, "NULL argument");
@@ -1350,7 +1359,7 @@ const char *sybl_debug_gob_to_json(const char *path) {
     std::string err;
     gob::Value v;
     // (SYBL_DEBUG_GOB_NARROW: the reader's narrow slices, as the loader asks for them -- the JSON must not change)
-    if (!path || !decode_file(path, v, err, getenv("SYBL_DEBUG_GOB_NARROW") != nullptr)) {
+    if (!path || !decode_file(path, v, err, env("SYBL_DEBUG_GOB_NARROW") != nullptr)) {
         set_error("%s", err.empty() ? "sybl_debug_gob_to_json: bad argument" : err.c_str());
         return nullptr;
     }

@@ -9,6 +9,14 @@
 
 namespace sybl {
 
+// The diagnostic switches (SYBL_*).  The process environment is read ONCE -- the first time the library asks -- into a
+// table of the library's own, and every later question is answered from it: no entry point calls getenv() at query time
+// (getenv is not safe against a setenv from another thread of a multi-threaded Go host).  SYBL_ENV_LIVE=1
+// in that first snapshot (the Python wrapper sets it: the test suite and the tools flip switches between queries) makes
+// every question a getenv() again.
+const char *env(const char *name);
+
+
 constexpr int kMaxSlots = 12;
 constexpr int kMaxAggs = 6;   // == SYBL_MAX_AGGS
 constexpr int kMaxNeq = 4;    // neq constants folded per slot

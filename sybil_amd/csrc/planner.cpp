@@ -85,7 +85,7 @@ static inline Column *slot_column(const Table *t, const Query *q, int ci) {
 
 static bool fill_packed(Table *t, Query *q, const std::vector<int> &slot_col, FastPlan &FP, int nf, int ng, int na) {
     const ScanPlan &P = q->plan;
-    if (getenv("SYBL_NO_PACKED")) return false;
+    if (env("SYBL_NO_PACKED")) return false;
     if (P.n_cells >= (1 << 24)) return false;  // 24-bit multiplies build the cell index
     for (int c = 0; c < nf; c++) {
         const __int128 umax = ((__int128)1 << (8 * FP.fwid[c])) - 1;
@@ -310,7 +310,7 @@ static bool fill_fast_columns(Table *t, Query *q, const std::vector<int> &slot_c
     if (any_packed) {
         if ((!*gen || (allow_gen && !heavy)) && all_narrow && packed && fill_packed(t, q, slot_col, FP, nf, ng, na)) {
             *packed = true;
-            FP.nul = nul_needed || getenv("SYBL_FORCE_NUL") ? 1 : 0;  // missing rows / id masks / reject gate: k_scan_packed<NUL> (SYBL_FORCE_NUL: A/B)
+            FP.nul = nul_needed || env("SYBL_FORCE_NUL") ? 1 : 0;  // missing rows / id masks / reject gate: k_scan_packed<NUL> (SYBL_FORCE_NUL: A/B)
         } else if (allow_gen) {
             *gen = true;
         } else {
@@ -324,7 +324,7 @@ static bool fill_fast_columns(Table *t, Query *q, const std::vector<int> &slot_c
 static void select_fast_path(Table *t, Query *q, const std::vector<int> &slot_col) {
     q->fast = false;
     const ScanPlan &P = q->plan;
-    if (getenv("SYBL_NO_FAST") || q->loghist) return;  // (MultiHist: the plan-interpreting kernels only)
+    if (env("SYBL_NO_FAST") || q->loghist) return;  // (MultiHist: the plan-interpreting kernels only)
     if (!q->use_lds) return;
     if (q->time_mode && P.tb_big_div) return;
     FastPlan &FP = q->fplan;
@@ -332,11 +332,11 @@ static void select_fast_path(Table *t, Query *q, const std::vector<int> &slot_co
     bool any_max, all_max, gen, packed = false;
     q->fast_packed = false;
     q->fast_packed_n = false;
-    if (!fill_fast_columns(t, q, slot_col, FP, &nf, &ng, &na, &any_max, &all_max, !getenv("SYBL_NO_FASTGEN"), &gen, &packed)) {
+    if (!fill_fast_columns(t, q, slot_col, FP, &nf, &ng, &na, &any_max, &all_max, !env("SYBL_NO_FASTGEN"), &gen, &packed)) {
         // three or four group columns, three or four aggregation columns over compact storage: the packed row body with
         // run-time column counts (k_scan_hash_packed<.., HASH = false>, hashpacked.hip); no bucket arrays
         const bool wide = (int)q->groups.size() > kFastTemplatedG || (int)q->aggs.size() > kFastTemplatedA;
-        if (!wide || (int)q->groups.size() > kFastMaxG || (int)q->aggs.size() > kFastMaxA || getenv("SYBL_NO_PACKED_N") || getenv("SYBL_NO_FASTGEN")) return;
+        if (!wide || (int)q->groups.size() > kFastMaxG || (int)q->aggs.size() > kFastMaxA || env("SYBL_NO_PACKED_N") || env("SYBL_NO_FASTGEN")) return;
         if (q->op == SYBL_AGG_HIST && q->want_percentiles) return;
         packed = false;
         if (!fill_fast_columns(t, q, slot_col, FP, &nf, &ng, &na, &any_max, &all_max, true, &gen, &packed, kFastMaxG, kFastMaxA) || !packed) return;
@@ -366,7 +366,7 @@ static void select_fast_path(Table *t, Query *q, const std::vector<int> &slot_co
         mode = any_max ? kFastAvgMax : kFastAvg;
     }
     FP.hist_lds = 0;
-    if (mode == kFastHist && !P.windowed && !getenv("SYBL_NO_LDSHIST")) {
+    if (mode == kFastHist && !P.windowed && !env("SYBL_NO_LDSHIST")) {
         // few cells: the bucket arrays themselves fit in LDS as uint32 next to the cell table
         // (a workgroup scans far fewer than 2^32 rows); shrink the lane replication to make room
         int64_t hist_bytes = (int64_t)P.n_cells * P.hist_stride * 4;
@@ -394,7 +394,7 @@ static void select_fast_path(Table *t, Query *q, const std::vector<int> &slot_co
 static void select_hash_fast(Table *t, Query *q, const std::vector<int> &slot_col) {
     q->hash_fast = false;
     const ScanPlan &P = q->plan;
-    if (!q->hash_mode || getenv("SYBL_NO_FAST") || getenv("SYBL_NO_HASH_FAST") || getenv("SYBL_NO_FASTGEN") || q->loghist) return;
+    if (!q->hash_mode || env("SYBL_NO_FAST") || env("SYBL_NO_HASH_FAST") || env("SYBL_NO_FASTGEN") || q->loghist) return;
     if (q->time_mode && P.tb_big_div) return;
     FastPlan &FP = q->fplan;
     int nf, ng, na;
@@ -403,7 +403,7 @@ static void select_hash_fast(Table *t, Query *q, const std::vector<int> &slot_co
     bool packed = false;
     q->hash_packed = false;
     const unsigned __int128 key_space = (unsigned __int128)q->group_cells * (unsigned __int128)std::max(P.n_tb, 1);
-    const bool try_packed = !getenv("SYBL_NO_HASH_PACKED") && key_space < ((unsigned __int128)1 << 32) &&
+    const bool try_packed = !env("SYBL_NO_HASH_PACKED") && key_space < ((unsigned __int128)1 << 32) &&
                             !(q->op == SYBL_AGG_HIST && q->want_percentiles) && q->groups.size() <= 2;
     if (!fill_fast_columns(t, q, slot_col, FP, &nf, &ng, &na, &any_max, &all_max, true, &gen, try_packed ? &packed : nullptr,
                            try_packed ? 2 : kFastMaxG, try_packed ? kFastMaxA : kFastTemplatedA))
@@ -561,13 +561,13 @@ static void bind_part_pass(Query *q, int a0, const PartGeom &G, uint32_t *d_recs
     // few partitions: several workgroups share one so the whole chip is busy
     H.split = (int32_t)std::max<int64_t>(1, (int64_t)q->n_wg / G.n_parts);
     H.n_cus = q->ctx->n_cus;
-    H.tail_mode = getenv("SYBL_PARTHIST_TAIL") ? atoi(getenv("SYBL_PARTHIST_TAIL")) : 1;
+    H.tail_mode = env("SYBL_PARTHIST_TAIL") ? atoi(env("SYBL_PARTHIST_TAIL")) : 1;
 }
 
 static int select_part_hist(Table *t, Query *q, const std::vector<int> &slot_col, int64_t rows_scanned) {
     q->part_hist = false;
     q->part_more.clear();
-    if (getenv("SYBL_NO_PARTHIST") || q->hash_mode || q->loghist) return SYBL_OK;
+    if (env("SYBL_NO_PARTHIST") || q->hash_mode || q->loghist) return SYBL_OK;
     if (q->op != SYBL_AGG_HIST || !q->want_percentiles || q->time_mode || q->weighted || q->aggs.empty()) return SYBL_OK;
     if (q->fast && q->fplan.hist_lds) return SYBL_OK;  // the bucket arrays already live in LDS
     // k_emit / k_part_hist take one or two aggregations: a query with three or four runs the sequence twice (same rows,
@@ -866,8 +866,8 @@ struct Planner {
                 }
             }
             // sparse / wide key range: one digit per DISTINCT value instead of one per value of the range
-            const bool hash_ok = !getenv("SYBL_NO_HASH");
-            if (c->type == SYBL_INT_VAL && !getenv("SYBL_NO_GDICT") &&
+            const bool hash_ok = !env("SYBL_NO_HASH");
+            if (c->type == SYBL_INT_VAL && !env("SYBL_NO_GDICT") &&
                 (c->gdict_blocks == -2 || card > ((unsigned __int128)1 << 22) || card * (unsigned __int128)cells > ((unsigned __int128)1 << 27))) {
                 rc = column_build_gdict(t, c);
                 if (rc == SYBL_OK) {
@@ -913,7 +913,7 @@ struct Planner {
             q->groups.push_back(gi);
             cells *= (int64_t)card;
         }
-        if (getenv("SYBL_FORCE_HASH") && !q->groups.empty()) q->hash_mode = true;  // (tests: small key spaces too)
+        if (env("SYBL_FORCE_HASH") && !q->groups.empty()) q->hash_mode = true;  // (tests: small key spaces too)
         // strides: first group column is the most significant digit (keeps canonical key order
         // equal to cell order)
         {
@@ -976,7 +976,7 @@ struct Planner {
             if (!q->hash_mode && (unsigned __int128)ntb * (unsigned __int128)cells > ((unsigned __int128)1 << 27)) {
                 // the reference groups arbitrary keys inside every time bucket (aggregate.go:146-200): [time bucket || key]
                 // through the hash table when the product does not direct-map
-                if (getenv("SYBL_NO_HASH") || q->groups.empty())
+                if (env("SYBL_NO_HASH") || q->groups.empty())
                     return fail(SYBL_E_INVAL, "time buckets x groups exceeds 2^27 cells");
                 q->hash_mode = true;
             }
@@ -991,7 +991,7 @@ struct Planner {
             // slots: twice the keys the table can possibly hold (a row each / the whole key space), a power of two
             const unsigned __int128 space = (unsigned __int128)cells * (unsigned __int128)P.n_tb;
             int64_t want = 2 * (int64_t)std::min<unsigned __int128>((unsigned __int128)std::max<int64_t>(t->logical_rows, 1), space);
-            if (const char *e = getenv("SYBL_HASH_SLOTS")) want = atoll(e);
+            if (const char *e = env("SYBL_HASH_SLOTS")) want = atoll(e);
             int64_t slots = 1 << 12;
             while (slots < want && slots < kHashMaxSlots) slots <<= 1;
             n_cells = slots;
@@ -1202,9 +1202,9 @@ struct Planner {
         {
             bool any_out = false;
             for (auto &ai : q->aggs) any_out = any_out || ai.d.f_out >= 0;
-            if (any_out && q->want_percentiles && !getenv("SYBL_NO_OUTLIER_LOG")) {
+            if (any_out && q->want_percentiles && !env("SYBL_NO_OUTLIER_LOG")) {
                 q->out_cap = kOutLogDefaultCap;
-                if (const char *e = getenv("SYBL_OUTLIER_LOG_CAP")) q->out_cap = std::max<int64_t>(1, atoll(e));
+                if (const char *e = env("SYBL_OUTLIER_LOG_CAP")) q->out_cap = std::max<int64_t>(1, atoll(e));
                 q->out_cap = (q->out_cap + kOutStripes - 1) / kOutStripes * kOutStripes;  // (equal stripes)
                 SYBL_HIP(hipMalloc((void **)&q->d_out_log, (size_t)q->out_cap * kOutLogWords * 8));
                 SYBL_HIP(hipMalloc((void **)&q->d_out_stage, ((size_t)kOutStripes * kOutCursorWords + (size_t)q->out_cap * kOutLogWords) * 8));
@@ -1293,7 +1293,7 @@ struct Planner {
     int prefilter() {
         q->pre_n_slots = 0;
         pre_saved.assign((size_t)P.n_slots, 0);
-        if (getenv("SYBL_NO_PREFILTER") || q->loghist || !t->compact_mode || q->never_matches || d->n_distincts > 0) return SYBL_OK;
+        if (env("SYBL_NO_PREFILTER") || q->loghist || !t->compact_mode || q->never_matches || d->n_distincts > 0) return SYBL_OK;
         if (q->op == SYBL_AGG_HIST && q->want_percentiles) return SYBL_OK;  // (the partitioned histograms have no NUL variants)
         std::vector<int> move;
         int n_fast = 0;
@@ -1319,7 +1319,7 @@ struct Planner {
             const SlotDesc &src = P.slot[move[k]];
             const Column *c = slot_column(t, q, slot_col[(size_t)move[k]]);
             // plain filter columns of <= 4 stored bytes: the offset-domain pre-pass (k_prefilter_packed), four to a launch
-            const bool packed_ok = !(src.flags & kSlotSet) && c->type != SYBL_SET_VAL && c->elem <= 4 && !getenv("SYBL_NO_PREFILTER_PACKED");
+            const bool packed_ok = !(src.flags & kSlotSet) && c->type != SYBL_SET_VAL && c->elem <= 4 && !env("SYBL_NO_PREFILTER_PACKED");
             if (packed_ok) {
                 if (q->pre_fps.empty() || q->pre_fp_nf.back() == kFastMaxF) {
                     q->pre_fps.emplace_back();
@@ -1389,7 +1389,7 @@ struct Planner {
     int strategy() {
         // ---- strategy: cell table in LDS when it fits (DESIGN.md "Strategies")
         q->n_wg = ctx->n_cus > 0 ? ctx->n_cus : 256;
-        if (const char *e = getenv("SYBL_WG_PER_CU")) q->n_wg *= std::max(1, atoi(e));
+        if (const char *e = env("SYBL_WG_PER_CU")) q->n_wg *= std::max(1, atoi(e));
         int64_t lds_words = (int64_t)(F + M) * n_cells;
         q->use_lds = lds_words * 8 <= kLdsBudgetBytes && !q->hash_mode;
         P.rep_shift = 0;
@@ -1397,7 +1397,7 @@ struct Planner {
             int rs = 0;
             // (SYBL_REP_BUDGET_KB: tuning -- a smaller cell table lets SYBL_WG_PER_CU workgroups share a CU)
             int64_t rep_budget = kLdsBudgetBytes;
-            if (const char *e = getenv("SYBL_REP_BUDGET_KB")) rep_budget = std::min<int64_t>(kLdsBudgetBytes, std::max<int64_t>(1, atoll(e)) * 1024);
+            if (const char *e = env("SYBL_REP_BUDGET_KB")) rep_budget = std::min<int64_t>(kLdsBudgetBytes, std::max<int64_t>(1, atoll(e)) * 1024);
             while (rs < 6 && (lds_words * 8 << (rs + 1)) <= rep_budget) rs++;
             P.rep_shift = rs;
             q->lds_bytes = (size_t)(lds_words * 8) << rs;
@@ -1471,7 +1471,7 @@ struct Planner {
             // LDS staging table of k_scan_hash: keys + every cell field per slot, as many slots (a power of two) as fit.
             // Bucket arrays cannot be staged (they live in the global table only).
             int64_t L = 0;
-            if (hist_stride == 0 && !getenv("SYBL_NO_HASH_LDS")) {
+            if (hist_stride == 0 && !env("SYBL_NO_HASH_LDS")) {
                 L = 1;
                 while (2 * L * 8 * (1 + F + M) <= kLdsBudgetBytes) L <<= 1;
                 if (L < 64) L = 0;
@@ -1480,7 +1480,7 @@ struct Planner {
             q->lds_bytes = (size_t)(L * 8 * (1 + F + M));
         }
         // (a hashed query keeps its staging table: the window below is a direct-mapped slice of [time bucket][cell])
-        if (!q->use_lds && !q->hash_mode && q->time_mode && !getenv("SYBL_NO_WINDOW") && !t->blocks.empty()) {
+        if (!q->use_lds && !q->hash_mode && q->time_mode && !env("SYBL_NO_WINDOW") && !t->blocks.empty()) {
             const Column *tc = slot_column(t, q, slot_col[(size_t)P.time_slot]);
             std::vector<int32_t> base((size_t)q->n_wg, 0);
             int64_t wmax = 1;

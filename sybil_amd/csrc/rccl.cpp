@@ -197,7 +197,7 @@ int sybl_query_allreduce(sybl_query *q) {
     // (hist_basic.go:132-142,221-257: printed as buckets of their own).  The local count is read before the header is
     // summed -- a host round trip, but only queries whose column bounds allow an outlier at all keep a log.
     int64_t out_local = -1;
-    if (q->d_out_log && (ctx->comm_nranks > 1 || getenv("SYBL_FORCE_SCATTER"))) {
+    if (q->d_out_log && (ctx->comm_nranks > 1 || env("SYBL_FORCE_SCATTER"))) {
         SYBL_HIP(hipMemcpyAsync(&out_local, q->d_sum + kHdrOutLog, 8, hipMemcpyDeviceToHost, ctx->stream));
         SYBL_HIP(hipStreamSynchronize(ctx->stream));
     }
@@ -215,7 +215,7 @@ int sybl_query_allreduce(sybl_query *q) {
     // rank receives 1/R of the table), every rank summarises its slice (k_hist_summary / k_hist_total in
     // query_snapshot) and the summaries are all-gathered: 52 MB of percentiles instead of 525 MB of buckets.
     // snapshot and finalize then are collective calls.
-    const bool big_limited = P.hist_stride > 0 && query_wants_hist_summary(q) && q->limit > 0 && (ctx->comm_nranks > 1 || getenv("SYBL_FORCE_SCATTER"));
+    const bool big_limited = P.hist_stride > 0 && query_wants_hist_summary(q) && q->limit > 0 && (ctx->comm_nranks > 1 || env("SYBL_FORCE_SCATTER"));
     // A printer (sybl_query_desc.printed_only) looks at `limit` rows and Cumulative (aggregate.go:469-525, printer.go:291-308):
     // the bucket table then does not travel at all.  The cell fields are all-reduced here -- every rank derives the same
     // sort order from them --, Cumulative's buckets are summed locally and all-reduced by the snapshot (8 KB), the printed
@@ -237,7 +237,7 @@ int sybl_query_allreduce(sybl_query *q) {
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (nr != ncclSuccess) return nccl_fail(nr, "ncclAllReduce(shard rows)");
         if (e != hipSuccess) return hip_fail(e, "shard rows");
-        q->rs_int32 = (!q->weighted && !getenv("SYBL_NO_SCATTER32") && rows * (int64_t)ctx->comm_nranks < ((int64_t)1 << 31)) ? 1 : 0;
+        q->rs_int32 = (!q->weighted && !env("SYBL_NO_SCATTER32") && rows * (int64_t)ctx->comm_nranks < ((int64_t)1 << 31)) ? 1 : 0;
     }
     // (everything that can fail on its own -- the int32 staging buffer, k_pack32 -- runs before the group is opened: an
     // early return between ncclGroupStart and ncclGroupEnd would leave the group open)

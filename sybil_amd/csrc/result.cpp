@@ -259,7 +259,7 @@ class WorkerPool {
         // (the CPUs the process may actually use: 22 ranges on a 16-CPU quota run as two rounds)
         static const size_t usable = usable_cpus();
         size_t c = std::min<size_t>(usable, 32);
-        if (const char *e = getenv("SYBL_FINALIZE_THREADS")) c = (size_t)std::max(1, atoi(e));
+        if (const char *e = env("SYBL_FINALIZE_THREADS")) c = (size_t)std::max(1, atoi(e));
         return c;
     }
     template <typename F>
@@ -446,7 +446,7 @@ int query_summary_buffers(Query *q) {
 
 bool query_wants_hist_summary(const Query *q) {
     const ScanPlan &P = q->plan;
-    if (getenv("SYBL_NO_HISTSUMMARY") || q->hash_mode || q->loghist) return false;
+    if (env("SYBL_NO_HISTSUMMARY") || q->hash_mode || q->loghist) return false;
     if (q->op != SYBL_AGG_HIST || !q->want_percentiles || q->time_mode || P.hist_stride <= 0 || q->aggs.empty()) return false;
     for (auto &a : q->aggs)
         if (!a.d.hist_full) return false;
@@ -568,7 +568,7 @@ int query_snapshot(Query *q) {
     const int64_t main_words = q->hash_mode ? sum_words : (q->snap_has_buckets ? q->n_sum_words : P.hist_off);
     hipStream_t cs = st;
     q->snap_on_aux = false;
-    if ((real_pairs * 102 + main_words) * 8 >= ((int64_t)4 << 20) && !getenv("SYBL_NO_COPY_STREAM")) {
+    if ((real_pairs * 102 + main_words) * 8 >= ((int64_t)4 << 20) && !env("SYBL_NO_COPY_STREAM")) {
         Ctx *ctx = q->ctx;
         if (!ctx->copy_stream) SYBL_HIP(create_side_stream(&ctx->copy_stream, +1));
         if (!q->ev_ready) SYBL_HIP(hipEventCreateWithFlags(&q->ev_ready, hipEventDisableTiming));
@@ -635,7 +635,7 @@ static int fetch_top_values(Query *q, Result *R, size_t top) {
         if (rc) return rc;
         SYBL_HIP(hipMemcpyAsync(R->top_vals.data(), q->d_top, R->top_vals.size() * 8, hipMemcpyDeviceToHost, st));
         SYBL_HIP(hipStreamSynchronize(st));
-    } else if (top <= kTopDmaRows && !getenv("SYBL_TOP_GATHER_KERNEL")) {
+    } else if (top <= kTopDmaRows && !env("SYBL_TOP_GATHER_KERNEL")) {
         // A printer's worth of rows: one asynchronous copy per row, straight out of the table into pinned memory.
         // Measured on config 4 (two queries pipelined): the gather kernel below, queued on the auxiliary stream with
         // pageable source / destination buffers, completed only when the other query's k_emit had ended (4.7 ms per
@@ -873,7 +873,7 @@ int query_finalize(Query *q, Result **out) {
     // (SYBL_LAZY_ROWS=1: whatever the size -- the test suite runs once that way)
     // Rows with keys of their own (hash group-by, very wide key spaces) are built from the query's group columns and the
     // table's dictionaries: such a result registers with its query, which builds the rows before it goes away.
-    const bool lazy = !q->n_distinct && (live.size() >= 2048 || getenv("SYBL_LAZY_ROWS")) && !getenv("SYBL_EAGER_ROWS");
+    const bool lazy = !q->n_distinct && (live.size() >= 2048 || env("SYBL_LAZY_ROWS")) && !env("SYBL_EAGER_ROWS");
     if (summary) {
         if (!q->top_only) C.mom.assign(q->h_mom, q->h_mom + (size_t)P.n_cells * na * 2);
         else C.mom.clear();

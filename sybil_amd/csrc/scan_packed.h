@@ -815,7 +815,7 @@ static hipError_t packed_launch_k1(const FastPlan &P, int n_wg, size_t lds_bytes
                                   (NF == 0 && NG == 1 && NA == 2 && MODE == kFastAvgMax && !TIME && G1) ||
                                   (NF == 0 && NG == 1 && NA == 1 && MODE == kFastAvg && TIME && !G1));
     if (kAb) {
-        if (const char *e = getenv("SYBL_PACKED_RING")) {
+        if (const char *e = env("SYBL_PACKED_RING")) {
             const int d = atoi(e);
             auto launch = [&](auto kern) {
                 hipError_t e2 = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);

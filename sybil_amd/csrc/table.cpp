@@ -248,7 +248,7 @@ int block_col_device(BlockWriter &w, Column *c, bool all_populated, void **col, 
 int block_col_direct(BlockWriter &w, Column *c, bool all_populated, int64_t mn, int64_t mx, int64_t pop, void **col, uint32_t **valid, bool *ok) {
     Table *t = w.t;
     *ok = false;
-    if (!t->compact_mode || c->type == SYBL_SET_VAL || !c->d_data || w.nrows == 0 || getenv("SYBL_NO_DIRECT_DECODE")) return SYBL_OK;
+    if (!t->compact_mode || c->type == SYBL_SET_VAL || !c->d_data || w.nrows == 0 || env("SYBL_NO_DIRECT_DECODE")) return SYBL_OK;
     if (c->stats_blocks != (int64_t)t->blocks.size()) return SYBL_OK;  // (block statistics are appended at commit)
     if (pop > 0 && c->elem < 8) {
         const __int128 top = (__int128)c->vbase + (((__int128)1 << (8 * c->elem)) - 1);

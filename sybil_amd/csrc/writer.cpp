@@ -377,7 +377,7 @@ extern "C" int sybl_table_save(sybl_table *t, const char *dir) {
     };
     {
         size_t n_threads = std::min<size_t>(std::max<unsigned>(1, std::thread::hardware_concurrency()), 16);
-        if (const char *e = getenv("SYBL_WRITER_THREADS")) n_threads = (size_t)std::max(1, atoi(e));
+        if (const char *e = env("SYBL_WRITER_THREADS")) n_threads = (size_t)std::max(1, atoi(e));
         n_threads = std::min(n_threads, std::max<size_t>(t->blocks.size(), 1));
         std::vector<std::vector<IntStat>> part(n_threads, std::vector<IntStat>(t->cols.size()));
         std::vector<int> rcs(n_threads, SYBL_OK);

@@ -38,6 +38,10 @@ class Context:
     def sync(self):
         N.check(N.lib().sybl_ctx_sync(self._h))
 
+    def trim(self):
+        """Frees the loader's staging arena (sybl_ctx_trim); the next open / refresh allocates it again."""
+        N.check(N.lib().sybl_ctx_trim(self._h))
+
     def device_info(self):
         name = C.create_string_buffer(256)
         cus, hbm = C.c_int(), C.c_int64()

@@ -423,3 +423,26 @@ def test_group_dictionary_after_a_trim_only_refresh_reads_the_moved_blocks(ctx, 
     assert got[0] == 12000
     fresh.free()
     tb.free()
+
+
+def test_ctx_trim_gives_the_loaders_arena_back_and_the_next_load_takes_it_again(ctx, tmp_path):
+    """sybl_ctx_trim: the staging arena a load leaves behind for the next one is freed on request; resident tables
+    keep answering, and a refresh afterwards allocates the arena again."""
+    import shutil
+    blocks, _ = _make_blocks(4, 3000, seed=5, ragged=False)
+    root, spare = str(tmp_path / "db"), str(tmp_path / "spare")
+    F.write_table(root, "events", blocks[:3], threshold=8)
+    F.write_table(spare, "events", blocks, threshold=8)
+    tb = ctx.open_table(root, "events", compact=True)
+    q = dict(groups=["age"], aggs=["time"])
+    before = _summary(tb, q)
+    ctx.trim()
+    ctx.trim()  # (idempotent)
+    assert _summary(tb, q) == before
+    shutil.copytree(spare + "/events/block000000004", root + "/events/block000000004")
+    shutil.copy(spare + "/events/info.db", root + "/events/info.db")
+    assert tb.refresh() == (1, 0, 0)
+    fresh = ctx.open_table(root, "events", compact=True)
+    assert _summary(tb, q) == _summary(fresh, q) and tb.rows == 12000
+    fresh.free()
+    tb.free()
