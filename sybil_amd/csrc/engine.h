@@ -59,6 +59,8 @@ hipError_t launch_decode_bins_multi(const DecodeBinsBatch &B, hipStream_t st);
 hipError_t launch_decode_delta_multi(const DecodeDeltaBatch &B, hipStream_t st);
 
 hipError_t launch_hist_summary(const HistSummaryPlan &S, int64_t *total, hipStream_t st);
+hipError_t launch_rank_column(const void *col, int width, int64_t vbase, const uint32_t *valid, const int64_t *dkeys, const int32_t *dranks, uint32_t dmask,
+                              int64_t n, void *out, int ow, uint32_t miss, hipStream_t st);
 hipError_t launch_weight_carry(const void *col, int width, int64_t vbase, const uint32_t *valid, const Segment *d_blocks, int n_blocks, int64_t *out, hipStream_t st);
 hipError_t launch_hist_total(const int64_t *H, int64_t hist_stride, int64_t cell0, int64_t cell1, int64_t *total, hipStream_t st);
 hipError_t launch_hist_gather(const int64_t *H, int64_t hist_stride, const int64_t *d_cells, int64_t n, int64_t cell0, int64_t cell1,
@@ -128,6 +130,11 @@ struct Column {
     int64_t *d_gdict_keys = nullptr;
     int32_t *d_gdict_ranks = nullptr;
     uint32_t gdict_mask = 0;
+    int64_t gdict_gen = 0;             // bumped whenever gdict / its device map change (column_install_gdict)
+    // The column as RANKS in its group dictionary (table.cpp: column_build_rank): a narrow derived column that a group-by on
+    // a sparse int key direct-maps through -- rank_col->d_valid is BORROWED from this column.  Valid for (gdict_gen, Table::version).
+    std::unique_ptr<Column> rank_col;
+    int64_t rank_gen = -1, rank_version = -1;
     // table-global dictionary (str / set)
     std::vector<std::string> dict;
     std::unordered_map<std::string, int32_t> dict_ix;
@@ -185,7 +192,8 @@ int table_reclaim_dead_rows(Table *t, bool force);           // rows of dead blo
 void column_free(Column *c);
 int32_t dict_intern(Column *c, const std::string &s);
 int column_upload_set(Table *t, Column *c);
-int column_build_gdict(Table *t, Column *c);           // distinct values of the resident rows
+int column_build_gdict(Table *t, Column *c);
+int column_build_rank(Table *t, Column *c);            // Column::rank_col for the current dictionary and table version           // distinct values of the resident rows
 int column_install_gdict(Table *t, Column *c);         // sorted gdict -> device value->rank map
 int column_repack(Table *t, Column *c, int width, int64_t vbase);  // change the stored width in place
 
@@ -321,6 +329,8 @@ struct GroupInfo {
     int64_t value_card;  // digits that are real values
     int64_t missing_digit;  // digit missing rows map to (-1: column has no missing rows)
     bool dict = false;      // digits are ranks in the column's sorted distinct values (Column::gdict)
+    bool rank = false;      // ... read from the column's derived rank column (Column::rank_col), not probed per row
+    int slot = -1;          // the slot the scan reads the key digit from
     const StrReplaced *replaced = nullptr;  // -str-replace: digits are ids of the rewritten strings
     bool has_missing;
 };

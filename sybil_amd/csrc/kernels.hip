@@ -286,6 +286,45 @@ __global__ __launch_bounds__(256) void k_block_minmax(const void *__restrict__ c
     }
 }
 
+// ---------------------------------------------------------------- a sparse key column as ranks in its group dictionary
+// out[row] = rank of the row's value among the column's sorted distinct values (Column::gdict, through its device map), at
+// the narrowest width that holds the dictionary's size; `miss` (a digit no cell has) for a value the dictionary lacks --
+// only a host-supplied dictionary can lack one -- so that the scan reports the row as outside the declared key space, as
+// the probing kernels do.  Built once per (dictionary, table version): a group-by on the column then direct-maps on the
+// derived column and runs the specialised row bodies instead of probing the dictionary per row in the plan interpreter.
+__global__ __launch_bounds__(256) void k_rank_column(const void *__restrict__ col, int width, int64_t vbase, const uint32_t *__restrict__ valid,
+                                                     const int64_t *__restrict__ dkeys, const int32_t *__restrict__ dranks, uint32_t dmask, int64_t n,
+                                                     void *__restrict__ out, int ow, uint32_t miss) {
+    for (int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < n; row += (int64_t)gridDim.x * blockDim.x) {
+        uint32_t rank = 0;
+        if (!valid || ((valid[row >> 5] >> (row & 31)) & 1u)) {
+            const int64_t x = load_val(col, width, vbase, row);
+            rank = miss;
+            uint32_t h = dict_hash(x) & dmask;
+            for (uint32_t probe = 0; probe <= dmask; probe++) {
+                const int64_t kx = dkeys[h];
+                if (kx == x) {
+                    rank = (uint32_t)dranks[h];
+                    break;
+                }
+                if (kx == kDictEmpty) break;
+                h = (h + 1) & dmask;
+            }
+        }
+        if (ow == 1) ((uint8_t *)out)[row] = (uint8_t)rank;
+        else if (ow == 2) ((uint16_t *)out)[row] = (uint16_t)rank;
+        else ((uint32_t *)out)[row] = rank;
+    }
+}
+hipError_t launch_rank_column(const void *col, int width, int64_t vbase, const uint32_t *valid, const int64_t *dkeys, const int32_t *dranks, uint32_t dmask,
+                              int64_t n, void *out, int ow, uint32_t miss, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    const int64_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(k_rank_column, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, st, col, width, vbase, valid, dkeys, dranks, dmask, n, out,
+                       ow, miss);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------- the weight a row aggregates with
 // aggregate.go:68,100-102: `weight` is declared once per FilterAndAggRecords call -- per block -- as 1, and a row sets it
 // only when its weight column is populated: a row WITHOUT a weight aggregates with the weight of the last row before it

@@ -79,7 +79,9 @@ static bool should_scan_block(const Table *t, const sybl_query_desc *d, int64_t 
 // A slot's column: a column of the table, or -- for the slot of a weight column with unpopulated rows -- the query's own
 // dense column of the weights in force (Query::eff_weight; Planner::weight).
 constexpr int kEffWeightCol = -2;
+constexpr int kRankColBase = -100;  // slot_col = kRankColBase - i: the rank column of table column i (Column::rank_col)
 static inline Column *slot_column(const Table *t, const Query *q, int ci) {
+    if (ci <= kRankColBase) return t->cols[(size_t)(kRankColBase - ci)]->rank_col.get();
     return ci == kEffWeightCol ? q->eff_weight.get() : t->cols[(size_t)ci].get();
 }
 
@@ -141,6 +143,13 @@ static bool fill_packed(Table *t, Query *q, const std::vector<int> &slot_col, Fa
 // Fills the column / filter / group / bucket part of a FastPlan when the query has the shape the
 // role-specialised kernels cover: <= 4 range-filter, <= 2 group, <= 2 aggregation columns, all
 // fully populated int64, one role per column, no rejects / outliers / minima to track.
+// SYBL_PLAN_TRACE=1 (diagnostic): says on stderr which test sent a query away from the role-specialised row bodies
+#define FF_REJECT(...)                                                                                  \
+    do {                                                                                                \
+        if (env("SYBL_PLAN_TRACE")) fprintf(stderr, "fast path: rejected at planner.cpp:%d\n", __LINE__); \
+        return __VA_ARGS__;                                                                             \
+    } while (0)
+
 static bool fill_fast_columns(Table *t, Query *q, const std::vector<int> &slot_col, FastPlan &FP, int *pnf, int *png,
                               int *pna, bool *any_max, bool *all_max, bool allow_gen, bool *gen, bool *packed = nullptr,
                               int max_groups = kFastTemplatedG, int max_aggs = kFastTemplatedA, bool part = false) {
@@ -166,29 +175,29 @@ static bool fill_fast_columns(Table *t, Query *q, const std::vector<int> &slot_c
         all_narrow = all_narrow && c->elem <= 4;
         if (!plain) {
             // GEN kernels: int columns with missing rows in any role, str columns as group keys
-            if (!allow_gen) return false;
+            if (!allow_gen) FF_REJECT(false);
             uint32_t r2 = sd.flags & (kSlotFilter | kSlotGroup | kSlotAgg | kSlotTime);
             bool str_ok = c->type == SYBL_STR_VAL && (r2 == kSlotGroup || r2 == kSlotIdMask || r2 == (kSlotGroup | kSlotIdMask));
-            if (c->type != SYBL_INT_VAL && !str_ok) return false;
+            if (c->type != SYBL_INT_VAL && !str_ok) FF_REJECT(false);
             *gen = true;
             if (c->d_valid || c->has_missing || (sd.flags & kSlotIdMask)) nul_needed = true;
         }
         uint32_t roles = sd.flags & (kSlotFilter | kSlotGroup | kSlotAgg);
-        if (sd.flags & (kSlotSet | kSlotDict)) return false;
-        if ((sd.flags & kSlotNeq) && (!allow_gen || c->type != SYBL_INT_VAL)) return false;
-        if ((sd.flags & kSlotIdMask) && !allow_gen) return false;
-        if ((sd.flags & kSlotWeight) && (roles != 0 || (sd.flags & kSlotTime) || !allow_gen)) return false;
+        if (sd.flags & (kSlotSet | kSlotDict)) FF_REJECT(false);
+        if ((sd.flags & kSlotNeq) && (!allow_gen || c->type != SYBL_INT_VAL)) FF_REJECT(false);
+        if ((sd.flags & kSlotIdMask) && !allow_gen) FF_REJECT(false);
+        if ((sd.flags & kSlotWeight) && (roles != 0 || (sd.flags & kSlotTime) || !allow_gen)) FF_REJECT(false);
         // a column may be filtered AND be a key / an aggregation input / the time column (it is then
         // streamed once per role; the second read hits L1/L2), but not key and aggregation input at once
         uint32_t fpart = roles & kSlotFilter, rest = roles & (kSlotGroup | kSlotAgg);
-        if (fpart != 0 && fpart != kSlotRange && fpart != kSlotIdMask && fpart != kSlotNeq && fpart != (kSlotRange | kSlotNeq)) return false;
-        if (rest == (kSlotGroup | kSlotAgg)) return false;
-        if ((sd.flags & kSlotTime) && rest != 0) return false;
+        if (fpart != 0 && fpart != kSlotRange && fpart != kSlotIdMask && fpart != kSlotNeq && fpart != (kSlotRange | kSlotNeq)) FF_REJECT(false);
+        if (rest == (kSlotGroup | kSlotAgg)) FF_REJECT(false);
+        if ((sd.flags & kSlotTime) && rest != 0) FF_REJECT(false);
     }
     for (size_t s = 0; s < slot_col.size(); s++) {
         const SlotDesc &sd = P.slot[s];
         if (!(sd.flags & (kSlotRange | kSlotIdMask | kSlotNeq))) continue;
-        if (nf >= kFastMaxF) return false;
+        if (nf >= kFastMaxF) FF_REJECT(false);
         FP.fcol[nf] = (const int64_t *)sd.base;
         FP.fwid[nf] = sd.width;
         FP.fbase[nf] = sd.vbase;
@@ -210,12 +219,12 @@ static bool fill_fast_columns(Table *t, Query *q, const std::vector<int> &slot_c
         nf++;
     }
     for (auto &gi : q->groups) {
-        if (ng >= max_groups) return false;
-        int s = -1;
-        for (size_t k = 0; k < slot_col.size(); k++)
+        if (ng >= max_groups) FF_REJECT(false);
+        int s = gi.slot;
+        for (size_t k = 0; s < 0 && k < slot_col.size(); k++)
             if (slot_col[k] == gi.col) s = (int)k;
         const SlotDesc &sd = P.slot[s];
-        if (sd.gmissing >= 0 && !allow_gen) return false;
+        if (sd.gmissing >= 0 && !allow_gen) FF_REJECT(false);
         if (sd.gmissing >= 0 || sd.gvalues != sd.gcard) nul_needed = true;
         FP.gvalid[ng] = sd.valid;
         FP.gwid[ng] = sd.width;
@@ -234,11 +243,11 @@ static bool fill_fast_columns(Table *t, Query *q, const std::vector<int> &slot_c
     *any_max = false;
     *all_max = true;
     for (auto &ai : q->aggs) {
-        if (na >= max_aggs) return false;
+        if (na >= max_aggs) FF_REJECT(false);
         const AggDesc &A = ai.d;
-        if (A.m_nmin >= 0) return false;
+        if (A.m_nmin >= 0) FF_REJECT(false);
         // (part: the scan half of the partitioned histograms only emits v - h.Min; outliers are k_part_hist's business)
-        if ((A.f_smp >= 0 || (A.f_out >= 0 && !part)) && !allow_gen) return false;
+        if ((A.f_smp >= 0 || (A.f_out >= 0 && !part)) && !allow_gen) FF_REJECT(false);
         if (A.f_out >= 0 && !part) *gen = true;  // outliers: the GEN body, or the NUL variants of the packed bodies
         if (A.f_out >= 0 && !part) nul_needed = true;
         if (q->op == SYBL_AGG_HIST && A.m_max >= 0) {
@@ -247,16 +256,16 @@ static bool fill_fast_columns(Table *t, Query *q, const std::vector<int> &slot_c
         }
         if (A.f_smp >= 0) heavy = true;
         if (A.f_cnt >= 0 || A.f_pop >= 0) {
-            if (!allow_gen) return false;
+            if (!allow_gen) FF_REJECT(false);
             *gen = true;  // rejects / missing values: per-aggregation counts
             nul_needed = true;
         }
         if (q->op == SYBL_AGG_HIST) {
-            if (A.big_div || A.bucket_size >= ((int64_t)1 << 32)) return false;
+            if (A.big_div || A.bucket_size >= ((int64_t)1 << 32)) FF_REJECT(false);
             const Column *c = t->cols[(size_t)ai.col].get();
             int64_t hi = c->bounds_set ? c->bound_hi : c->exact_max;
             if (c->n_pop > 0 || c->bounds_set)
-                if ((unsigned __int128)((__int128)hi - (__int128)A.hmin) >= ((unsigned __int128)1 << 32)) return false;
+                if ((unsigned __int128)((__int128)hi - (__int128)A.hmin) >= ((unsigned __int128)1 << 32)) FF_REJECT(false);
         }
         *any_max = *any_max || A.m_max >= 0;
         *all_max = *all_max && A.m_max >= 0;
@@ -286,7 +295,7 @@ static bool fill_fast_columns(Table *t, Query *q, const std::vector<int> &slot_c
     }
     FP.f_samples = P.f_samples;
     if (q->weighted) {
-        if (!allow_gen) return false;
+        if (!allow_gen) FF_REJECT(false);
         FP.wcol = (const int64_t *)P.slot[P.weight_slot].base;
         FP.wwid = P.slot[P.weight_slot].width;
         FP.wbase = P.slot[P.weight_slot].vbase;
@@ -314,7 +323,7 @@ static bool fill_fast_columns(Table *t, Query *q, const std::vector<int> &slot_c
         } else if (allow_gen) {
             *gen = true;
         } else {
-            return false;
+            FF_REJECT(false);
         }
     }
     return true;
@@ -324,9 +333,9 @@ static bool fill_fast_columns(Table *t, Query *q, const std::vector<int> &slot_c
 static void select_fast_path(Table *t, Query *q, const std::vector<int> &slot_col) {
     q->fast = false;
     const ScanPlan &P = q->plan;
-    if (env("SYBL_NO_FAST") || q->loghist) return;  // (MultiHist: the plan-interpreting kernels only)
-    if (!q->use_lds) return;
-    if (q->time_mode && P.tb_big_div) return;
+    if (env("SYBL_NO_FAST") || q->loghist) FF_REJECT();  // (MultiHist: the plan-interpreting kernels only)
+    if (!q->use_lds) FF_REJECT();
+    if (q->time_mode && P.tb_big_div) FF_REJECT();
     FastPlan &FP = q->fplan;
     int nf, ng, na;
     bool any_max, all_max, gen, packed = false;
@@ -336,16 +345,16 @@ static void select_fast_path(Table *t, Query *q, const std::vector<int> &slot_co
         // three or four group columns, three or four aggregation columns over compact storage: the packed row body with
         // run-time column counts (k_scan_hash_packed<.., HASH = false>, hashpacked.hip); no bucket arrays
         const bool wide = (int)q->groups.size() > kFastTemplatedG || (int)q->aggs.size() > kFastTemplatedA;
-        if (!wide || (int)q->groups.size() > kFastMaxG || (int)q->aggs.size() > kFastMaxA || env("SYBL_NO_PACKED_N") || env("SYBL_NO_FASTGEN")) return;
-        if (q->op == SYBL_AGG_HIST && q->want_percentiles) return;
+        if (!wide || (int)q->groups.size() > kFastMaxG || (int)q->aggs.size() > kFastMaxA || env("SYBL_NO_PACKED_N") || env("SYBL_NO_FASTGEN")) FF_REJECT();
+        if (q->op == SYBL_AGG_HIST && q->want_percentiles) FF_REJECT();
         packed = false;
-        if (!fill_fast_columns(t, q, slot_col, FP, &nf, &ng, &na, &any_max, &all_max, true, &gen, &packed, kFastMaxG, kFastMaxA) || !packed) return;
+        if (!fill_fast_columns(t, q, slot_col, FP, &nf, &ng, &na, &any_max, &all_max, true, &gen, &packed, kFastMaxG, kFastMaxA) || !packed) FF_REJECT();
         q->fast_packed_n = true;
     }
-    if (q->op == SYBL_AGG_HIST && any_max && !gen) return;
-    if (q->weighted && q->op == SYBL_AGG_HIST && q->want_percentiles) return;  // weighted bucket increments: generic kernel
+    if (q->op == SYBL_AGG_HIST && any_max && !gen) FF_REJECT();
+    if (q->weighted && q->op == SYBL_AGG_HIST && q->want_percentiles) FF_REJECT();  // weighted bucket increments: generic kernel
     q->fast_gen = gen;
-    if (nf + ng + na == 0 && !q->time_mode) return;  // nothing to stream: the generic kernel picks a driver column
+    if (nf + ng + na == 0 && !q->time_mode) FF_REJECT();  // nothing to stream: the generic kernel picks a driver column
     if (q->time_mode) {
         FP.tcol = (const int64_t *)P.slot[P.time_slot].base;
         FP.tvalid = P.slot[P.time_slot].valid;
@@ -362,7 +371,7 @@ static void select_fast_path(Table *t, Query *q, const std::vector<int> &slot_co
     if (q->op == SYBL_AGG_HIST) {
         mode = q->want_percentiles ? kFastHist : kFastMoments;
     } else {
-        if (any_max && !all_max) return;
+        if (any_max && !all_max) FF_REJECT();
         mode = any_max ? kFastAvgMax : kFastAvg;
     }
     FP.hist_lds = 0;
@@ -387,6 +396,8 @@ static void select_fast_path(Table *t, Query *q, const std::vector<int> &slot_co
     q->fast_na = na;
     q->fast_mode = mode;
 }
+
+#undef FF_REJECT
 
 // Hash group-by (strategy 7) through the role-specialised row body (k_scan_hash_fast, hashgroup.hip) when the query has
 // the shape select_fast_path takes -- with up to four group columns; everything else runs the plan-interpreting
@@ -803,7 +814,9 @@ struct Planner {
         cells = 1;
         for (int g = 0; g < d->n_groups; g++) {
             int s;
+            const size_t slots_before = slot_col.size();
             if ((rc = slot_of(d->groups[g], &s))) return rc;
+            const bool fresh_slot = slot_col.size() > slots_before;  // (no other role has this column so far)
             Column *c = slot_column(t, q, slot_col[(size_t)s]);
             if (c->type == SYBL_SET_VAL) return fail(SYBL_E_INVAL, "cannot group by set column '%s' (cmd_query.go:254)", c->name.c_str());
             if (P.slot[s].flags & kSlotGroup) return fail(SYBL_E_INVAL, "column '%s' grouped twice", c->name.c_str());
@@ -873,6 +886,26 @@ struct Planner {
                 if (rc == SYBL_OK) {
                     gi.dict = true;
                     card = c->gdict.size();
+                    // Round 5: the ranks are laid out once, as a narrow derived column (Column::rank_col), and the group
+                    // role moves to a slot of that column -- a plain direct-mapped key (gmin 0, one digit per distinct value)
+                    // that every specialised row body takes; the dictionary is no longer probed per row by the plan
+                    // interpreter (config 3 grouped through a dictionary digit: 28 ms per 1e9 rows in k_scan).  The table's
+                    // column keeps the slot it has if the query also filters / aggregates it.
+                    if (!env("SYBL_NO_RANKCOL") && !c->gdict.empty()) {
+                        if ((rc = column_build_rank(t, c))) return rc;
+                        gi.rank = true;
+                        lo = 0;
+                        hi = (int64_t)c->gdict.size() - 1;
+                        const int sentinel = kRankColBase - gi.col;
+                        if (fresh_slot) {
+                            slot_col[(size_t)s] = sentinel;
+                        } else {
+                            if ((int)slot_col.size() >= kMaxSlots) return fail(SYBL_E_INVAL, "query references more than %d columns", kMaxSlots);
+                            slot_col.push_back(sentinel);
+                            folds.emplace_back();
+                            s = (int)slot_col.size() - 1;
+                        }
+                    }
                 } else if (rc == SYBL_E_INVAL && hash_ok && card < ((unsigned __int128)1 << 62)) {
                     // more distinct values than a dictionary holds: the digit is the value's offset in its range and the
                     // query goes through the hash table
@@ -910,6 +943,7 @@ struct Planner {
             }
             gi.gmin = lo;
             gi.gcard = (int64_t)card;
+            gi.slot = s;
             q->groups.push_back(gi);
             cells *= (int64_t)card;
         }
@@ -920,9 +954,7 @@ struct Planner {
             int64_t stride = cells;
             for (size_t g = 0; g < q->groups.size(); g++) {
                 stride /= q->groups[g].gcard;
-                int s = -1;
-                for (size_t k = 0; k < slot_col.size(); k++)
-                    if (slot_col[k] == q->groups[g].col) s = (int)k;
+                const int s = q->groups[g].slot;
                 SlotDesc &sd = P.slot[s];
                 sd.flags |= kSlotGroup;
                 sd.gmin = q->groups[g].gmin;
@@ -939,7 +971,7 @@ struct Planner {
                     sd.dkeys = q->groups[g].replaced->d_keys;
                     sd.dranks = q->groups[g].replaced->d_ranks;
                     sd.dmask = q->groups[g].replaced->mask;
-                } else if (q->groups[g].dict) {
+                } else if (q->groups[g].dict && !q->groups[g].rank) {
                     const Column *gc = t->cols[(size_t)q->groups[g].col].get();
                     sd.flags |= kSlotDict;
                     sd.dkeys = gc->d_gdict_keys;

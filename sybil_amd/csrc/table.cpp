@@ -151,6 +151,11 @@ int column_repack(Table *t, Column *c, int width, int64_t vbase) {
 }
 
 void column_free(Column *c) {
+    if (c->rank_col) {
+        c->rank_col->d_valid = nullptr;  // (borrowed from c)
+        column_free(c->rank_col.get());
+        c->rank_col.reset();
+    }
     if (c->d_data) hipFree(c->d_data);
     if (c->d_valid) hipFree(c->d_valid);
     if (c->d_set_off) hipFree(c->d_set_off);
@@ -736,6 +741,48 @@ int column_install_gdict(Table *t, Column *c) {
     SYBL_HIP(hipMemcpy(c->d_gdict_keys, keys.data(), (size_t)cap * 8, hipMemcpyHostToDevice));
     SYBL_HIP(hipMemcpy(c->d_gdict_ranks, ranks.data(), (size_t)cap * 4, hipMemcpyHostToDevice));
     c->gdict_mask = cap - 1;
+    c->gdict_gen++;
+    return SYBL_OK;
+}
+
+int column_build_rank(Table *t, Column *c) {
+    const int64_t D = (int64_t)c->gdict.size();
+    const int ow = D + 1 <= 256 ? 1 : D + 1 <= 65536 ? 2 : 4;
+    auto adopt = [&](Column *r) {
+        r->d_valid = c->d_valid;  // borrowed (column_free knows)
+        r->has_missing = c->has_missing;
+        r->n_pop = c->n_pop;
+    };
+    if (c->rank_col && c->rank_gen == c->gdict_gen && c->rank_version == t->version && c->rank_col->elem == ow) {
+        adopt(c->rank_col.get());
+        return SYBL_OK;
+    }
+    if (c->rank_col) {
+        c->rank_col->d_valid = nullptr;
+        column_free(c->rank_col.get());
+        c->rank_col.reset();
+    }
+    auto r = std::make_unique<Column>();
+    r->name = c->name;
+    r->type = SYBL_INT_VAL;
+    r->elem = ow;
+    r->vbase = 0;
+    int rc = table_reserve(t, r.get(), t->phys_rows);
+    if (rc) return rc;
+    hipError_t e = launch_rank_column(c->d_data, c->elem, c->vbase, c->d_valid, c->d_gdict_keys, c->d_gdict_ranks, c->gdict_mask, t->phys_rows, r->d_data, ow,
+                                      (uint32_t)D, t->ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(t->ctx->stream);
+    if (e != hipSuccess) {
+        column_free(r.get());
+        return hip_fail(e, "k_rank_column");
+    }
+    r->exact_min = 0;
+    r->exact_max = D > 0 ? D - 1 : 0;
+    r->stats_blocks = (int64_t)t->blocks.size();
+    adopt(r.get());
+    c->rank_col = std::move(r);
+    c->rank_gen = c->gdict_gen;
+    c->rank_version = t->version;
     return SYBL_OK;
 }
 

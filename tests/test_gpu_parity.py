@@ -585,6 +585,68 @@ def test_group_by_sparse_keys(ctx, oracle):
     tb.free()
 
 
+@pytest.mark.parametrize("compact", [False, True])
+def test_dictionary_digit_keys_run_the_specialised_bodies_through_a_rank_column(ctx, oracle, monkeypatch, compact):
+    """Round 5: a sparse int key's digits (ranks in the column's distinct values) used to be found by probing the dictionary
+    per row in the plan-interpreting k_scan (0.07 of peak).  The ranks are now laid out once as a narrow derived column
+    (k_rank_column, Column::rank_col) that the group-by direct-maps through: the query takes the same row bodies as any
+    dense key -- k_scan_packed over a compact table -- and SYBL_NO_RANKCOL=1 (the probing path) must agree with it.  The
+    key is also filtered and aggregated in one of the queries (its own values stay in a slot of their own), has missing
+    rows and the value -1 (the MISSING_VALUE group), and the table grows between two queries (the ranks are rebuilt)."""
+    rng = np.random.default_rng(21)
+    n = 400_000
+    pool = np.unique(rng.integers(-(1 << 30), 1 << 30, size=900))
+    pool = np.concatenate([pool, [-1]])
+    uid = pool[rng.integers(0, pool.size, size=n)].astype(np.int64)
+    upop = (rng.random(n) > 0.05).astype(np.uint8)
+    f = rng.integers(0, 1000, size=n).astype(np.int64)
+    v = rng.integers(0, 100_000, size=n).astype(np.int64)
+    tb = ctx.create_table("rk")
+    tb.add_column("uid", "int")
+    tb.add_column("f", "int")
+    tb.add_column("v", "int", 0, 99_999)
+    half = n // 2
+    _append_in_blocks(tb, half, 65536, {"uid": (uid[:half], upop[:half]), "f": f[:half], "v": v[:half]})
+    if compact:
+        tb.compact()
+    names = ["uid", "f", "v"]
+    info = {"v": (0, 99_999), "uid": (-(1 << 30), 1 << 30), "f": (0, 999)}
+    queries = (dict(filters=[("f", "gt", 99), ("f", "lt", 900)], groups=["uid"], aggs=["v"], op="hist", want_percentiles=False),
+               dict(groups=["uid"], aggs=["v"], op="avg"),
+               # (the key's own values are filtered on -- they keep a slot of their own next to the rank column's)
+               dict(filters=[("uid", "gt", 0)], groups=["uid"], aggs=["f", "v"], op="avg"),
+               # ... and aggregated: negative values in avg mode track a minimum, which only the plan interpreter does
+               dict(filters=[("uid", "lt", 1 << 29)], groups=["uid"], aggs=["uid", "v"], op="avg"))
+
+    def check(rows):
+        ocols = [{"type": "int", "data": uid[:rows], "populated": upop[:rows]}, {"type": "int", "data": f[:rows]}, {"type": "int", "data": v[:rows]}]
+        for q in queries:
+            ores = oracle.run_query(ocols, block_rows=65536, **parity.oracle_query_kwargs(names, info, q))
+            seen = {}
+            for off in (False, True):
+                if off:
+                    monkeypatch.setenv("SYBL_NO_RANKCOL", "1")
+                query = tb.query(**q)
+                if off:
+                    monkeypatch.delenv("SYBL_NO_RANKCOL")
+                gres = query.run()
+                st = query.stats()
+                seen[off] = (st["strategy"], st["packed_kernel"])
+                parity.compare(gres, ores, op=q["op"], full=False, n_aggs=len(q["aggs"]))
+                gres.free()
+                query.free()
+            assert seen[True][0] in (0, 1), seen      # the probing path: the plan interpreter
+            if "uid" not in q["aggs"]:
+                assert seen[False][0] == 2, seen      # the rank column: a role-specialised body ...
+                if compact:
+                    assert seen[False][1] == 1, seen  # ... the packed one when every column it reads is narrow
+
+    check(half)
+    _append_in_blocks(tb, n - half, 65536, {"uid": (uid[half:], upop[half:]), "f": f[half:], "v": v[half:]})
+    check(n)
+    tb.free()
+
+
 def test_sparse_keys_across_ranks(ctx, oracle):
     """Two shards see different subsets of the ids: with the union dictionary installed on both,
     their partial tables add up to the table of the whole."""
