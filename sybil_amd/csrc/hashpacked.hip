@@ -62,7 +62,14 @@ __global__ __launch_bounds__(kWgThreads) void k_scan_hash_packed(const FastPlan 
             }
             const int64_t x = (int64_t)((uint64_t)P.abase[c] + u);
             fast_add64<LDS>(tab, (uint64_t)(uint32_t)P.f_sum[c] * ncell + slot, x);
-            if (MODE == kFastAvgMax) fast_max64<LDS>(maxtab, (uint64_t)(uint32_t)P.m_max[c] * ncell + slot, x);
+            if (MODE == kFastAvgMax) {
+                if (!P.ext_general) {
+                    fast_max64<LDS>(maxtab, (uint64_t)(uint32_t)P.m_max[c] * ncell + slot, x);
+                } else {
+                    if (P.m_max[c] >= 0) fast_max64<LDS>(maxtab, (uint64_t)(uint32_t)P.m_max[c] * ncell + slot, x);
+                    if (P.m_nmin[c] >= 0) fast_max64<LDS>(maxtab, (uint64_t)(uint32_t)P.m_nmin[c] * ncell + slot, x == INT64_MIN ? INT64_MAX : -x);
+                }
+            }
             if (MODE == kFastMoments) {
                 uint32_t b = packed_udiv(u + P.adoff[c], P.bucket_size[c], P.pinv_bucket[c]);
                 if (NUL && b >= (uint32_t)P.n_values[c]) {

@@ -242,10 +242,13 @@ static bool fill_fast_columns(Table *t, Query *q, const std::vector<int> &slot_c
     }
     *any_max = false;
     *all_max = true;
+    bool any_min = false;
     for (auto &ai : q->aggs) {
         if (na >= max_aggs) FF_REJECT(false);
         const AggDesc &A = ai.d;
-        if (A.m_nmin >= 0) FF_REJECT(false);
+        // (a tracked minimum -- avg mode over negative values -- is the row bodies' business since round 5: ext_general)
+        if (A.m_nmin >= 0 && (q->op == SYBL_AGG_HIST || env("SYBL_NO_FAST_MIN"))) FF_REJECT(false);
+        any_min = any_min || A.m_nmin >= 0;
         // (part: the scan half of the partitioned histograms only emits v - h.Min; outliers are k_part_hist's business)
         if ((A.f_smp >= 0 || (A.f_out >= 0 && !part)) && !allow_gen) FF_REJECT(false);
         if (A.f_out >= 0 && !part) *gen = true;  // outliers: the GEN body, or the NUL variants of the packed bodies
@@ -290,9 +293,14 @@ static bool fill_fast_columns(Table *t, Query *q, const std::vector<int> &slot_c
         FP.f_sb[na] = A.f_sb;
         FP.f_sb2[na] = A.f_sb2;
         FP.m_max[na] = A.m_max;
+        FP.m_nmin[na] = A.m_nmin;
         FP.hist_agg_off[na] = P.hist_agg_off[na];
         na++;
     }
+    // avg mode: "every aggregation tracks a maximum and nothing else" is what the kFastAvgMax bodies assume unless told
+    FP.ext_general = (any_min || (*any_max && !*all_max)) ? 1 : 0;
+    if (any_min) *any_max = *all_max = true;  // (-> kFastAvgMax; the bodies test m_max / m_nmin per aggregation)
+    else if (*any_max && !*all_max && q->op != SYBL_AGG_HIST) *all_max = true;
     FP.f_samples = P.f_samples;
     if (q->weighted) {
         if (!allow_gen) FF_REJECT(false);

@@ -44,6 +44,13 @@ struct FastPlan {
     uint32_t bucket_size[kFastMaxA];
     int32_t n_values[kFastMaxA];
     int32_t f_sum[kFastMaxA], f_sb[kFastMaxA], f_sb2[kFastMaxA], m_max[kFastMaxA];
+    // avg mode over a column with negative values tracks a MINIMUM too (BasicHist.Min starts at Go's zero value,
+    // hist_basic.go:72-85), as max(-v); and an aggregation whose values never exceed 0 tracks no maximum.  ext_general says
+    // that some aggregation of a kFastAvgMax query departs from "every aggregation tracks a maximum and nothing else":
+    // the row bodies then test m_max / m_nmin per aggregation (wave-uniform) instead of assuming it (round 5: such
+    // queries used to run the plan interpreter).
+    int32_t m_nmin[kFastMaxA];
+    int32_t ext_general;
     int64_t hist_agg_off[kFastMaxA];
     int64_t hist_off, hist_stride;
     int32_t n_cells, n_sum_fields, n_max_fields, rep_shift;
@@ -458,7 +465,14 @@ __device__ __forceinline__ void fast_accumulate(const FastPlan &P0, const FastTi
             if (P.f_smp[c] >= 0) fast_add64<LDS>(tab, (((uint64_t)(uint32_t)P.f_smp[c] * ncell) << rs) + cidx, 1);  // h.Samples++
         }
         fast_add64<LDS>(tab, (((uint64_t)(uint32_t)P.f_sum[c] * ncell) << rs) + cidx, times_w(x));
-        if (MODE == kFastAvgMax) fast_max64<LDS>(maxtab, (((uint64_t)(uint32_t)P.m_max[c] * ncell) << rs) + cidx, x);
+        if (MODE == kFastAvgMax) {
+            if (!P.ext_general) {
+                fast_max64<LDS>(maxtab, (((uint64_t)(uint32_t)P.m_max[c] * ncell) << rs) + cidx, x);
+            } else {
+                if (P.m_max[c] >= 0) fast_max64<LDS>(maxtab, (((uint64_t)(uint32_t)P.m_max[c] * ncell) << rs) + cidx, x);
+                if (P.m_nmin[c] >= 0) fast_max64<LDS>(maxtab, (((uint64_t)(uint32_t)P.m_nmin[c] * ncell) << rs) + cidx, x == INT64_MIN ? INT64_MAX : -x);
+            }
+        }
         if (MODE == kFastMoments || MODE == kFastHist) {
             // bucket_value := (value - h.Min) / BucketSize, hist_basic.go:130.  The planner only
             // selects this kernel when 0 <= value - h.Min < 2^32 and no value can reach

@@ -327,8 +327,21 @@ __device__ __forceinline__ void packed_row(const FastPlan &P0, const PackedTile<
         const int64_t x = (int64_t)((uint64_t)P.abase[c] + u);
         add((uint32_t)P.f_sum[c], x);
         if (MODE == kFastAvgMax) {
-            int64_t *m = (int64_t *)(cell_p + ((uint32_t)P.n_sum_fields + (uint32_t)P.m_max[c]) * fstep);
-            if (x > *m) __hip_atomic_fetch_max(m, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (!P.ext_general) {
+                int64_t *m = (int64_t *)(cell_p + ((uint32_t)P.n_sum_fields + (uint32_t)P.m_max[c]) * fstep);
+                if (x > *m) __hip_atomic_fetch_max(m, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else {
+                // (FastPlan::ext_general: a minimum is tracked as well -- negative values in avg mode --, or not every maximum)
+                if (P.m_max[c] >= 0) {
+                    int64_t *m = (int64_t *)(cell_p + ((uint32_t)P.n_sum_fields + (uint32_t)P.m_max[c]) * fstep);
+                    if (x > *m) __hip_atomic_fetch_max(m, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                if (P.m_nmin[c] >= 0) {
+                    int64_t *m = (int64_t *)(cell_p + ((uint32_t)P.n_sum_fields + (uint32_t)P.m_nmin[c]) * fstep);
+                    const int64_t nx = x == INT64_MIN ? INT64_MAX : -x;
+                    if (nx > *m) __hip_atomic_fetch_max(m, nx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
         }
         if (MODE == kFastMoments || MODE == kFastHist) {
             // bucket_value := (value - h.Min) / BucketSize, hist_basic.go:130; the planner guarantees

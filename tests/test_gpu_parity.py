@@ -647,6 +647,49 @@ def test_dictionary_digit_keys_run_the_specialised_bodies_through_a_rank_column(
     tb.free()
 
 
+@pytest.mark.parametrize("compact", [False, True])
+def test_avg_over_negative_values_tracks_the_minimum_in_the_specialised_bodies(ctx, oracle, monkeypatch, compact):
+    """`-op avg` starts BasicHist.Min / Max at Go's zero value (hist_basic.go:72-85): a column with negative values needs its
+    minimum tracked, one that never exceeds 0 needs no maximum.  Round 5: the role-specialised bodies do both (as max(-v) in
+    the MAX section, FastPlan::ext_general) -- such queries used to fall to the plan interpreter.  Three aggregations: mixed
+    signs (min and max), all negative (min only), all positive (max only); with SYBL_NO_FAST_MIN=1 the old path must agree."""
+    rng = np.random.default_rng(33)
+    n = 300_000
+    g = rng.integers(0, 40, size=n).astype(np.int64)
+    f = rng.integers(0, 1000, size=n).astype(np.int64)
+    a = rng.integers(-50_000, 50_000, size=n).astype(np.int64)
+    b = rng.integers(-90_000, -10, size=n).astype(np.int64)
+    c = rng.integers(5, 70_000, size=n).astype(np.int64)
+    bpop = (rng.random(n) > 0.1).astype(np.uint8)
+    tb = ctx.create_table("mn")
+    for name in ("g", "f", "a", "b", "c"):
+        tb.add_column(name, "int")
+    _append_in_blocks(tb, n, 65536, {"g": g, "f": f, "a": a, "b": (b, bpop), "c": c})
+    if compact:
+        tb.compact()
+    ocols = [{"type": "int", "data": g}, {"type": "int", "data": f}, {"type": "int", "data": a}, {"type": "int", "data": b, "populated": bpop},
+             {"type": "int", "data": c}]
+    names = ["g", "f", "a", "b", "c"]
+    info = {"a": (-50_000, 49_999), "b": (-90_000, -11), "c": (5, 69_999)}
+    for q in (dict(filters=[("f", "gt", 99), ("f", "lt", 900)], groups=["g"], aggs=["a", "c"], op="avg"),
+              dict(groups=["g"], aggs=["a", "b"], op="avg"),
+              dict(groups=["g"], aggs=["b"], op="avg")):
+        ores = oracle.run_query(ocols, block_rows=65536, **parity.oracle_query_kwargs(names, info, q))
+        for off in (False, True):
+            if off:
+                monkeypatch.setenv("SYBL_NO_FAST_MIN", "1")
+            query = tb.query(**q)
+            if off:
+                monkeypatch.delenv("SYBL_NO_FAST_MIN")
+            gres = query.run()
+            assert query.stats()["strategy"] == (0 if off else 2), (q, off, query.stats())
+            parity.compare(gres, ores, op="avg", n_aggs=len(q["aggs"]))
+            assert all(h["min"] < 0 for r in gres.results for h in r["hists"][:1])
+            gres.free()
+            query.free()
+    tb.free()
+
+
 def test_sparse_keys_across_ranks(ctx, oracle):
     """Two shards see different subsets of the ids: with the union dictionary installed on both,
     their partial tables add up to the table of the whole."""
