@@ -220,6 +220,14 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # SYBL_BENCH_ONE_DEVICE=1 (tests/test_gpu_bench_multirank.py): a FUNCTIONAL check of this file's N > 1 flow on a box with
+    # one GPU -- every rank on device 0, the library's collectives through the test-only shared-memory RCCL stand-in the
+    # launcher preloads (tests/rccl_standin/), torch's process group on gloo.  Its timings mean nothing and are marked so.
+    one_device = os.environ.get("SYBL_BENCH_ONE_DEVICE") == "1"
+    if one_device:
+        local_rank = 0
+        if args.collective != "rccl":
+            raise SystemExit("SYBL_BENCH_ONE_DEVICE needs --collective rccl (the in-library path)")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
@@ -231,7 +239,10 @@ def main():
     if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
+        if one_device:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
 
     ctx = sybil_amd.Context(local_rank)
     dev = ctx.device_info()
@@ -373,7 +384,7 @@ def main():
             fence()
             dt = time.perf_counter() - t0
             if multi:
-                tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+                tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if one_device else device)
                 dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
                 dt = float(tmax.item())
             stats = queries[0].stats()
@@ -432,7 +443,7 @@ def main():
         extra = {}
         if workload == "cfg4_hist_highcard" and q.get("printed_only"):
             q["printed_only"] = False
-            alt = run_phase(min(steps, 10), min(warmup, 2))
+            alt = run_phase(min(steps, 10), warmup)  # (the same warm-up: its first steps allocate the pinned 52 MB percentile buffers)
             q["printed_only"] = True
             if rank == 0:
                 assert alt["digest"] == head["digest"], "a printer's query and the fully summarised one disagree"
@@ -477,10 +488,12 @@ def main():
                 "roofline": roofline(head),
             }
             out.update(extra)
+            if one_device:
+                out["one_device_standin"] = "every rank on GPU 0 through the test-only RCCL stand-in: a functional check, not a measurement"
             if canon is not None:
                 out["canonical_storage"] = {"value": total_rows * min(steps, 10) / canon["dt"], "unit": "rows/s",
                                             "steps": min(steps, 10), "roofline": roofline(canon)}
-            if world == 1 and not args.no_oracle_check:
+            if (world == 1 or one_device) and not args.no_oracle_check:
                 out["oracle_check"] = oracle_check(workload, q, total_rows, head)
         table.free()
         return out
@@ -506,7 +519,7 @@ def main():
                 # warm-up steps, 2.4 with four or more; the record names the steps and warm-up it used)
                 rec = measure(name, 0, min(args.steps, 20), 8, "compact", False)
                 recs.append({k: rec[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "config", "roofline")
-                             + (("oracle_check",) if "oracle_check" in rec else ())})
+                             + tuple(k for k in ("oracle_check", "every_row_summarised", "back_to_back_scan_ms") if k in rec)})
                 recs[-1]["kernel_ms"] = rec["roofline"]["kernel_ms"]
                 if name == "cfg1_count_range" and not args.no_cpu_baseline:
                     # BASELINE.json configs[0] is the reference's own CPU-runnable case: the oracle on the whole table beside it
