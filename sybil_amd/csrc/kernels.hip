@@ -1071,9 +1071,9 @@ hipError_t launch_part_hist(const PartHistPlan &P, hipStream_t st) {
 
 // k_outlog_gather: the staging stripes of the outlier log (outlog.h) closed up into the query's dense log, stripe after
 // stripe, and the number of records appended into the header.  A stripe's cursor may stand beyond its share (the lanes
-// that found it filling up went on to the next stripe: outlog.h); its second word counts the records that found no place
-// in kOutSpill stripes.  With any of those the header says "more than the capacity" (the printers treat the values as
-// unavailable, as when the whole log overflowed) -- or the true total when that is larger still.
+// that found it filling up went on to the next stripe: outlog.h); its second word is non-zero when some record found no
+// place in kOutSpill stripes.  The header then says "more than the capacity" (the printers treat the values as
+// unavailable, as when the whole log overflowed).
 __global__ __launch_bounds__(256) void k_outlog_gather(const int64_t *__restrict__ stage, int64_t cap, int64_t *__restrict__ log, int64_t *header) {
     const int64_t per = cap / kOutStripes;
     const int s = blockIdx.x;
@@ -1089,7 +1089,7 @@ __global__ __launch_bounds__(256) void k_outlog_gather(const int64_t *__restrict
     const int64_t *src = stage + (size_t)kOutStripes * kOutCursorWords + (size_t)s * (size_t)per * kOutLogWords;
     int64_t *dst = log + before * kOutLogWords;
     for (int64_t i = threadIdx.x; i < mine * kOutLogWords; i += blockDim.x) dst[i] = src[i];
-    if (s == 0 && threadIdx.x == 0) header[kHdrOutLog] = dropped > 0 && kept + dropped <= cap ? cap + 1 : kept + dropped;
+    if (s == 0 && threadIdx.x == 0) header[kHdrOutLog] = dropped != 0 ? cap + 1 : kept;
 }
 hipError_t launch_outlog_gather(const int64_t *stage, int64_t cap, int64_t *log, int64_t *header, hipStream_t st) {
     hipLaunchKernelGGL(k_outlog_gather, dim3(kOutStripes), dim3(256), 0, st, stage, cap, log, header);
