@@ -30,6 +30,10 @@ CASES = {
     "hash": (["c04", "c05", "c06", "c01", "c02", "c07", "c08"], _CFG3, {"SYBL_FORCE_HASH": "1"}, {}),
     "hash_extrema": (["c02", "c09", "c08"], dict(groups=["c02", "c09"], aggs=["c08"], op="avg"), {"SYBL_FORCE_HASH": "1"}, dict(compact=True)),
     "timeseries": (["c00", "c09", "c07"], dict(groups=["c09"], aggs=["c07"], op="avg", time_col="c00", time_bucket=3600), {}, dict(compact=True)),
+    # three blocks over 2 / 4 / 8 ranks: ranks WITHOUT A ROW (at world 4 and 8 rank 0, the one that finalizes, is one of them)
+    "tiny": (["c04", "c01", "c02", "c07"], dict(filters=[("c04", "gt", 99)], groups=["c01", "c02"], aggs=["c07"], op="avg"), {}, dict(compact=True, total=150_000)),
+    "tiny_hash": (["c01", "c02", "c07"], dict(groups=["c01", "c02"], aggs=["c07"], op="hist", want_percentiles=False), {"SYBL_FORCE_HASH": "1"},
+                  dict(total=150_000)),
     "distinct": (["c01", "c05", "c06"], dict(groups=["c01"], distincts=["c05", "c06"], filters=[("c06", "lt", 500)]), {}, {}),
 }
 
@@ -56,12 +60,13 @@ def main():
     while not os.path.exists(uid_path):
         time.sleep(0.02)
     ctx.comm_init(open(uid_path, "rb").read(), world, rank)
-    row0, nrows = synth.shard(TOTAL, rank, world)
     results = {}
     for name in names:
         cols, q, env, opt = CASES[name]
         os.environ.update(env)
-        t = ctx.synth_table("mr", synth.SEED, TOTAL, row0, nrows, synth.synth_cols(cols))
+        total = opt.get("total", TOTAL)
+        row0, nrows = synth.shard(total, rank, world)
+        t = ctx.synth_table("mr", synth.SEED, total, row0, nrows, synth.synth_cols(cols))
         for n in cols:  # identical direct-mapped layout on every rank: the generator's bounds
             kind, _, a, b, _, _ = synth.COLUMNS[n]
             t.set_bounds(n, a, a + 4 * (b - 1) if kind == synth.BELL else a + b - 1)

@@ -15,7 +15,8 @@ k_pack32 / k_unpack32, slice summaries and the collective finalize on every rank
 place (`scatter64`), outlier logs all-gathered and closed up in rank order (`outliers`), the hash group-by's key-union
 protocol with SUM (`hash`) and SUM + MAX (`hash_extrema`), a time series (`timeseries`), count-distinct sketches merged with a
 uint8 MAX (`distinct`), a printer's limit-aware merge -- cell fields all-reduced, Cumulative's buckets and the printed rows'
-arrays summed in the collective snapshot / finalize, the bucket table never sent (`printer`)."""
+arrays summed in the collective snapshot / finalize, the bucket table never sent (`printer`), ranks without a single row -- the
+finalizing rank among them -- direct-mapped and hashed (`tiny`, `tiny_hash`)."""
 import os
 import pickle
 import subprocess
@@ -96,7 +97,8 @@ def oracle_for(orc, name):
         kw = parity.oracle_query_kwargs(cols, info, q)
         if q.get("distincts"):
             kw.update(distincts=[cols.index(c) for c in q["distincts"]], want_registers=True)
-        _ORACLE[name] = orc.run_query(parity.oracle_synth_cols(orc, cols, W.TOTAL, 0, W.TOTAL), n_threads=8, **kw)
+        total = opt.get("total", W.TOTAL)
+        _ORACLE[name] = orc.run_query(parity.oracle_synth_cols(orc, cols, total, 0, total), n_threads=8, **kw)
     return _ORACLE[name]
 
 
@@ -143,7 +145,7 @@ def check_case(name, got, o):
         parity.compare(g, o, op=q.get("op", "avg"), full=q.get("want_percentiles", True), n_aggs=n_aggs, time_mode=bool(q.get("time_col")))
     if name.startswith("scatter") or name == "printer":
         assert got["strategy"] == 5 and got["everyone"], (name, got["strategy"], got["everyone"])
-    if name.startswith("hash"):
+    if name.startswith("hash") or name == "tiny_hash":
         assert got["strategy"] == 7
     if name == "outliers":
         assert any(h.get("outlier_values") is not None and len(h["outlier_values"]) for r in g.rows(0) for h in r["hists"])
