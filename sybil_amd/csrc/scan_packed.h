@@ -786,9 +786,74 @@ __global__ __launch_bounds__(kWgThreads, 4) void k_count_packed(const EmitPlan E
     count_finish(E, elds);
 }
 
+// k_count_key: the counting pass for its commonest shape -- ONE key column, no filter, one bin per partition (sub_shift 0:
+// config 4) -- with every lane's 16-byte load FULL of keys (eight 2-byte keys, sixteen 1-byte, four 4-byte) instead of the
+// four rows k_count_packed shares with k_emit_packed's row -> lane mapping (a 2-byte key column then brings 8 useful
+// bytes per 16-byte instruction: half the load instructions and half the tile overhead for the same 2 GB).  With one bin
+// per partition the count of a (workgroup, bin) does not depend on WHICH lane saw a row, only on the workgroup's row range,
+// which is the plan's: k_emit_packed's regions come out the same.  (SYBL_NO_COUNT16=1: k_count_packed.)
+template <int W>
+__global__ __launch_bounds__(kWgThreads, 4) void k_count_key(const EmitPlan E) {
+    extern __shared__ uint32_t elds[];
+    const FastPlan &P = E.fp;
+    const uint32_t tid = threadIdx.x;
+    uint32_t *bins = count_begin(E, elds);  // (sub_shift 0: the counters themselves)
+    const uint32_t na = (uint32_t)E.n_aggs;
+    constexpr uint32_t R = 16u / (uint32_t)W;       // keys per lane and tile
+    constexpr uint32_t kTile = kWgThreads * R;       // rows per workgroup and tile
+    constexpr int D = 4;                             // tiles of loads in flight
+    const uint32_t gdoff = P.gdoff[0], gcard = P.gcard[0], gstride = (uint32_t)P.gstride[0];
+    const int s0 = P.wg_seg_begin[blockIdx.x], s1 = P.wg_seg_begin[blockIdx.x + 1];
+    for (int si = s0; si < s1; si++) {
+        const Segment seg = P.segs[si];
+        for (int64_t c0 = 0; c0 < seg.n; c0 += kPackedChunkRows) {
+            const int64_t first = seg.start + c0;
+            const uint32_t n = (uint32_t)(seg.n - c0 < kPackedChunkRows ? seg.n - c0 : kPackedChunkRows);
+            const uint8_t *col = (const uint8_t *)P.gcol[0] + first * W;
+            // one descriptor for the chunk: a lane (or a dword of it) past row n reads zeros without touching memory; the
+            // rows it would stand for are masked by `left` below
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)col, 0, (int)(((n * (uint32_t)W) + 3u) & ~3u), (int)kBufferRsrcWord3);
+            pu32x4 raw[D];
+            const uint32_t r_first = tid * R;
+            const uint32_t n_tiles = (n + kTile - 1) / kTile;
+#pragma unroll
+            for (int d = 0; d < D; d++) raw[d] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)((r_first + (uint32_t)d * kTile) * (uint32_t)W), 0, 2);
+            for (uint32_t it0 = 0; it0 < n_tiles; it0 += D) {
+#pragma unroll
+                for (int d = 0; d < D; d++) {
+                    const uint32_t r = r_first + (it0 + d) * kTile;  // (< 2^28 + 2^16: no wrap)
+                    const pu32x4 v = raw[d];
+                    raw[d] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)((r + (uint32_t)D * kTile) * (uint32_t)W), 0, 2);
+                    const uint32_t left = r < n ? n - r : 0u;
+                    const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (uint32_t k = 0; k < R; k++) {
+                        uint32_t u;
+                        if (W == 4) u = w4[k];
+                        else if (W == 2) u = (w4[k >> 1] >> ((k & 1u) * 16u)) & 0xFFFFu;
+                        else u = (w4[k >> 2] >> ((k & 3u) * 8u)) & 0xFFu;
+                        const uint32_t dgt = u + gdoff;
+                        if (k < left && dgt < gcard)
+                            __hip_atomic_fetch_add(bins + ((__umul24(dgt, gstride) * na) >> kPartCellBits), na, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+            }
+        }
+    }
+    count_finish(E, elds);
+}
+
 template <int NF>
 static hipError_t count_packed_launch_nf(const EmitPlan &E, int ng, int n_wg, hipStream_t st) {
     const size_t lds = count_lds_bytes(E);
+    if (NF == 0 && ng == 1 && E.sub_shift == 0 && !env("SYBL_NO_COUNT16")) {
+        switch (E.fp.gwid[0]) {
+        case 1: hipLaunchKernelGGL((k_count_key<1>), dim3(n_wg), dim3(kWgThreads), lds, st, E); return hipGetLastError();
+        case 2: hipLaunchKernelGGL((k_count_key<2>), dim3(n_wg), dim3(kWgThreads), lds, st, E); return hipGetLastError();
+        case 4: hipLaunchKernelGGL((k_count_key<4>), dim3(n_wg), dim3(kWgThreads), lds, st, E); return hipGetLastError();
+        default: break;
+        }
+    }
     switch (ng) {
     case 0: hipLaunchKernelGGL((k_count_packed<NF, 0>), dim3(n_wg), dim3(kWgThreads), lds, st, E); break;
     case 1: hipLaunchKernelGGL((k_count_packed<NF, 1>), dim3(n_wg), dim3(kWgThreads), lds, st, E); break;
