@@ -133,11 +133,18 @@ def agree_str_dict(table, column, group=None):
     dictionary id -- and with it a str group cell or a per-id filter mask -- means the same string on
     every rank (the reference merges blocks by translated string key, aggregate.go:284-324)."""
     mine = table.column_dict(column)
+    missing = bool(table.column_info(column)["has_missing"])
     if dist.is_initialized() and dist.get_world_size(group) > 1:
         parts = [None] * dist.get_world_size(group)
-        dist.all_gather_object(parts, mine, group=group)
-        union = sorted(set(s for p in parts for s in p))
+        dist.all_gather_object(parts, (mine, missing), group=group)
+        union = sorted(set(s for p, _ in parts for s in p))
+        missing = any(m for _, m in parts)
     else:
         union = sorted(set(mine))
     table.set_dict(column, union)
+    # ... and whether ANY rank has a row without the column: the MISSING key digit of a str group-by (aggregate.go:138) must
+    # exist on every rank or on none, or the partial tables differ by a cell (found by check_layout on a loaded table whose
+    # missing names all sat in one rank's blocks: tests/test_gpu_multirank.py::test_loaded_table_across_ranks)
+    if missing:
+        table.set_bounds(column, 0, -1, True)
     return union

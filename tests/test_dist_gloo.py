@@ -137,9 +137,16 @@ def test_single_process_is_a_noop():
 class _FakeTable:
     """Stands in for sybil_amd.Table on a box without a GPU: only the dictionary accessors."""
 
-    def __init__(self, distinct, strings):
+    def __init__(self, distinct, strings, str_missing=False):
         self.distinct, self.strings = np.asarray(distinct, dtype=np.int64), list(strings)
         self.installed = {}
+        self.str_missing = str_missing
+
+    def column_info(self, name):
+        return {"has_missing": self.str_missing}
+
+    def set_bounds(self, name, lo, hi, has_missing=False):
+        self.installed["b:" + name] = (lo, hi, has_missing)
 
     def column_distinct(self, name):
         return self.distinct
@@ -160,9 +167,11 @@ def _dict_worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from sybil_amd import dist as sdist
-        t = _FakeTable([5, 1 << 40, -3] if rank == 0 else [7, 5, 9], ["b", "a"] if rank == 0 else ["c", "a"])
+        # (only rank 1 has rows without the str column: the MISSING key digit must still be declared on both)
+        t = _FakeTable([5, 1 << 40, -3] if rank == 0 else [7, 5, 9], ["b", "a"] if rank == 0 else ["c", "a"], str_missing=rank == 1)
         u = sdist.agree_group_dict(t, "uid")
         s = sdist.agree_str_dict(t, "host")
+        assert t.installed["b:host"] == (0, -1, True)
         q.put((rank, u.tolist(), s, t.installed["g:uid"].tolist(), t.installed["s:host"]))
     finally:
         dist.destroy_process_group()

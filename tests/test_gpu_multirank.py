@@ -177,3 +177,55 @@ def test_standin_synchronous_steps(tmp_path, oracle):
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="the real RCCL needs >= 2 GPUs on this box")
 def test_inlibrary_collectives_across_gpus(tmp_path, oracle):
     check_world(run_world(tmp_path, min(torch.cuda.device_count(), 8), standin=False), oracle)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_loaded_table_across_ranks(tmp_path, world):
+    """The whole multi-GPU host protocol on a table that came from disk (tests/multirank_loaded_worker.py): ranks open their
+    block ranges, agree on bounds / str and set dictionaries / the sparse key's group dictionary over gloo, merge in the
+    library through the stand-in; rank 0's results must equal those of ONE rank that opened the whole table (whose parity with
+    the oracle is tests/test_gpu_loader.py's business) -- str keys, a sparse int key through the union dictionary's rank
+    column, a set-member filter, a regex id mask with negative values, a time series."""
+    import sybil_amd
+    from tests import multirank_loaded_worker as LW
+    from tests import sybil_fixture as F
+    from tests.test_gpu_loader import _make_blocks
+    blocks, _ = _make_blocks(7, 3000, seed=77, ragged=True)
+    root = str(tmp_path / "db")
+    F.write_table(root, "events", blocks, threshold=8, int_info={"big": (-(1 << 40), 1 << 40)})
+    ctx = sybil_amd.Context(0)
+    tb = ctx.open_table(root, "events", compact=True)
+    want = []
+    for q in LW.QUERIES:
+        qy = tb.query(**q)
+        r = qy.run()
+        want.append(LW.summarise(r))
+        r.free()
+        qy.free()
+    total_rows = tb.rows
+    tb.free()
+    ctx.close()
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0", LD_PRELOAD=STANDIN, SYBL_STANDIN_TIMEOUT_S="240")
+    if not os.path.exists(STANDIN):
+        subprocess.check_call(["make", "-s", "-C", os.path.dirname(STANDIN)])
+    work = str(tmp_path)
+    logs = [open(os.path.join(work, "lerr%d.txt" % r), "wb") for r in range(world)]
+    procs = [subprocess.Popen([sys.executable, "-m", "tests.multirank_loaded_worker", work, str(world), str(r), "0", root], cwd=ROOT, env=env,
+                              stdout=subprocess.DEVNULL, stderr=logs[r]) for r in range(world)]
+    try:
+        for p in procs:
+            p.wait(timeout=600)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        for f in logs:
+            f.close()
+    errs = [open(os.path.join(work, "lerr%d.txt" % r), "rb").read().decode(errors="replace")[-2000:] for r in range(world)]
+    assert [p.returncode for p in procs] == [0] * world, "\n".join(errs)
+    got = pickle.load(open(os.path.join(work, "loaded.pkl"), "rb"))
+    assert len(got["results"]) == len(want)
+    for i, (g, w) in enumerate(zip(got["results"], want)):
+        assert g["matched"] == w["matched"], (i, LW.QUERIES[i])
+        assert g["rows"] == w["rows"], (i, LW.QUERIES[i])
+    assert sum(1 for _ in blocks) == 7 and total_rows == sum(len(b["age"][1]) for b in blocks)
