@@ -10,6 +10,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "eager_only: not repeated with SYBL_LAZY_ROWS=1 by the rows_mode fixture")
 
 
 @pytest.fixture(scope="session")
@@ -25,5 +26,7 @@ def rows_mode(request, monkeypatch):
     access (result.cpp: result_ensure_rows), so the lazy path sees every query shape of the file that asks for this fixture
     (pytestmark usefixtures in the hash / CLI / loghist files)."""
     if request.param == "lazy":
+        if request.node.get_closest_marker("eager_only"):
+            pytest.skip("a minute-long test whose results are lazy anyway (>= 2048 rows): run once")
         monkeypatch.setenv("SYBL_LAZY_ROWS", "1")
     return request.param

@@ -285,6 +285,7 @@ def test_table_full_at_default_sizing_fails_fast(ctx):
     t.free()
 
 
+@pytest.mark.eager_only
 def test_time_series_through_the_hash_table(ctx, oracle, monkeypatch):
     """The reference groups arbitrary keys inside every time bucket (aggregate.go:146-200).  (a) config 5's 721 x 500
     cells forced through the table; (b) 721 hourly buckets x a key of 2^20 values = 7.6e8 cells, more than direct mapping

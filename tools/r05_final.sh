@@ -5,7 +5,7 @@
 # temperature log beside config 4's kernel trace (item 3d), the loads-only microbenchmark of config 2's shape (item 7), smoke().
 # Afterwards, in the repo:
 #   cp gpurun_out/prof/r05_* profiles/; for c in cfg2 cfg4 cfg5; do cp gpurun_out/prof_r05_$c/r05_${c}_* profiles/; done
-#   cp gpurun_out/r05/r05_*.txt profiles/; python tools/make_traffic.py r05; cp gpurun_out/r05_final_bench.json profiles/r05_bench_1gpu.json
+#   for f in gpurun_out/r05/r05_*.txt; do grep -v amdgpu.ids $f > profiles/$(basename $f); done; python tools/make_traffic.py r05; cp gpurun_out/r05_final_bench.json profiles/r05_bench_1gpu.json
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r05
 O=gpurun_out/r05
 if [ -z "$SKIP_TESTS" ]; then
@@ -39,7 +39,11 @@ if [ -z "$SKIP_TABLES" ]; then
   echo "# selectivity table: 51 %, 10 %, 1 %, 0.1 %, 1e-6, 0 -- four scans each)"; python tools/rocpd_summary.py $O/sel_pmc/*.db 2>/dev/null | grep -v "rocclr\|k_synth\|k_block_minmax\|k_fill\|k_repack"; python tools/rocpd_dispatches.py $O/sel_pmc/*.db k_scan_packed FETCH_SIZE 2>/dev/null; } > $O/r05_selectivity_fetch_size.txt
 rm -rf $O/sel_pmc
 { echo "# tools/micro/loadpat_cfg2 (MI355X, $(date -u +%Y-%m-%dT%H:%MZ))"; timeout -k 10 120 tools/micro/loadpat_cfg2; } > $O/r05_loadpat_cfg2.txt 2>&1
-tail -4 $O/r05_variants.txt; tail -7 $O/r05_selectivity.txt | cut -c1-160; tail -14 $O/r05_loadpat_cfg2.txt
+{ echo "# tools/bench_dictkey.py (MI355X, $(date -u +%Y-%m-%dT%H:%MZ))"; timeout -k 10 300 python tools/bench_dictkey.py; } > $O/r05_dictkey.txt 2>&1
+{ echo "# tools/clock_scan.py cfg4 25 3 (MI355X, $(date -u +%Y-%m-%dT%H:%MZ)): config 4's scan kernels back to back for 25 s after 3 s of idle"; timeout -k 10 200 python tools/clock_scan.py cfg4 25 3; } > $O/r05_cfg4_clock_power_temp_scan.txt 2>&1
+{ echo "# tools/emit_placement.py (MI355X, $(date -u +%Y-%m-%dT%H:%MZ))"; timeout -k 10 200 python tools/emit_placement.py 6 3; } > $O/r05_emit_placement.txt 2>&1
+{ echo "# tools/ab_scan.py cfg4 (MI355X, $(date -u +%Y-%m-%dT%H:%MZ)): k_count_key (16-byte key loads) against k_count_packed (SYBL_NO_COUNT16=1)"; timeout -k 10 400 python tools/ab_scan.py cfg4 3 count_key=- count_packed=-,SYBL_NO_COUNT16=1; } > $O/r05_ab_count_key.txt 2>&1
+tail -4 $O/r05_variants.txt; tail -7 $O/r05_selectivity.txt | cut -c1-160; tail -14 $O/r05_loadpat_cfg2.txt; tail -3 $O/r05_dictkey.txt; tail -4 $O/r05_emit_placement.txt; tail -3 $O/r05_ab_count_key.txt; tail -6 $O/r05_cfg4_clock_power_temp_scan.txt
 fi
 timeout -k 10 120 python bench.py --force-dist --no-cpu-baseline --no-load --no-canonical --no-configs --steps 10 --warmup 2 2>/dev/null | python -c "
 import json,sys
