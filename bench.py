@@ -422,7 +422,8 @@ def main():
                 kernel = ("k_scan_packed" if stats["packed_kernel"] else "k_scan_fast") + shape
             elif stats["strategy"] == 5:
                 pk = "_packed" if stats["packed_kernel"] else ""
-                kernel = "k_count%s + k_emit%s + k_part_hist + k_part_fix" % (pk, pk)
+                # (one key column, no filter, one bin per partition -- config 4 -- counts with k_count_key: scan_packed.h)
+                kernel = "%s + k_emit%s + k_part_hist + k_part_fix" % ("k_count_key" if pk and len(names) == 2 else "k_count" + pk, pk)
             else:
                 kernel = "k_scan<%d>" % len(names)
             traffic, traffic_source = measured_traffic(stats, names)

@@ -236,6 +236,7 @@ static int scan(Query *q) {
         SYBL_HIP(hipMemsetAsync(q->pplan.wrap_log, 0, 8, st));
         SYBL_HIP(hipEventRecord(q->ev[0], st));
         q->eplan.sum_out = q->d_sum;
+        q->eplan.store_nt = env("SYBL_EMIT_NT") ? 1 : 0;
         q->pplan.sum_out = q->d_sum;
         q->pplan.max_out = q->d_max;
         // counting sort: count per (workgroup, bin) -> exact regions -> scatter

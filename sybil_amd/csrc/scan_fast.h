@@ -171,8 +171,9 @@ struct EmitPlan {
     int32_t sub_shift;               // bins per partition = 1 << sub_shift (a lane's sub-bin follows from its lane
                                      // number, in k_count and k_emit alike, so that few partitions do not serialise
                                      // on a handful of LDS counters)
-    int32_t quiet, pad_;             // quiet: a later pass over the same rows (the third / fourth aggregation of a query,
+    int32_t quiet, store_nt;         // quiet: a later pass over the same rows (the third / fourth aggregation of a query,
                                      // Query::part_more): matched / overflow were counted by the first
+                                     // store_nt (SYBL_EMIT_NT, experiment): the chunk stores carry the non-temporal hint
     int64_t *sum_out;                // header: matched / overflow
 };
 
@@ -723,12 +724,14 @@ struct EmitLds {
     uint32_t *out;          // the workgroup's output in recs
     uint32_t out_bytes;
     uint32_t nb, ss, sub;
+    uint32_t nt;            // EmitPlan::store_nt
 };
 
 __device__ __forceinline__ EmitLds emit_begin(const EmitPlan &E, uint32_t *elds) {
     EmitLds S;
     const uint32_t tid = threadIdx.x;
     S.ss = (uint32_t)E.sub_shift;
+    S.nt = (uint32_t)E.store_nt;
     S.nb = (uint32_t)E.n_parts << S.ss;      // staging bins
     S.sub = tid & ((1u << S.ss) - 1);        // this lane's sub-bin
     S.chunk = elds;                          // [nb][2][16]  (128-byte rows)
@@ -836,7 +839,8 @@ __device__ __forceinline__ void emit_copy_full(const EmitLds &S, const uint32_t 
 #pragma unroll
             for (uint32_t k = 0; k < 2; k++) {
                 const uint32_t off = valid[k] ? (st[k] + qe[k].y) * (kEmitChunk * 4u) + j * 16u : kEmitDropOffset;
-                __builtin_amdgcn_raw_buffer_store_b128(piece[k], rsrc, (int)off, 0, 0);
+                if (S.nt) __builtin_amdgcn_raw_buffer_store_b128(piece[k], rsrc, (int)off, 0, 2);  // (wave-uniform; aux 2 = nt)
+                else __builtin_amdgcn_raw_buffer_store_b128(piece[k], rsrc, (int)off, 0, 0);
             }
 #pragma unroll
             for (uint32_t k = 0; k < 2; k++)

@@ -33,7 +33,7 @@ jobs = [
     ("7_cols_strategy_2_packed", "%s_pmc.txt" % tag, 1e9, lambda k: "k_scan_packed<3, 2, 2" in k, "the headline, compact storage: 16 stored B/row"),
     ("3_cols_strategy_2_packed", "%s_cfg2_pmc.txt" % tag, 1e8, lambda k: "k_scan_packed<0, 1, 2" in k or "k_fold" in k, "config 2, compact storage: 9 stored B/row"),
     ("3_cols_strategy_4_packed", "%s_cfg5_pmc.txt" % tag, 1e9, lambda k: "k_scan_packed<0, 1, 1" in k, "config 5, compact storage: 10 stored B/row"),
-    ("2_cols_strategy_5_packed", "%s_cfg4_pmc.txt" % tag, 1e9, lambda k: any(x in k for x in ("k_count_packed", "k_emit_packed", "k_part_hist", "k_part_fix")),
+    ("2_cols_strategy_5_packed", "%s_cfg4_pmc.txt" % tag, 1e9, lambda k: any(x in k for x in ("k_count_packed", "k_count_key", "k_emit_packed", "k_part_hist", "k_part_fix")),
      "config 4, compact storage: 6 stored B/row + 4 B of record written and read per value + the 525 MB bucket table written"),
 ]
 for key, fn, rows, pick, what in jobs:

@@ -25,8 +25,8 @@ if [ -z "$SKIP_PROFILES" ]; then
 PROF_TAG=r05 BENCH_ARGS="--no-load --no-configs --no-oracle-check --no-canonical" bash tools/prof_r01.sh > gpurun_out/r05_final_prof.log 2>&1
 head -8 gpurun_out/prof/r05_kernel_trace_stats.txt | cut -c1-150
 for wl in cfg2 cfg5; do WL=$wl TAG=r05_$wl bash tools/prof_cfg.sh > gpurun_out/r05_final_prof_$wl.log 2>&1; head -7 gpurun_out/prof_r05_$wl/r05_${wl}_kernel_trace.txt | tail -4 | cut -c1-150; done
-# config 4 with the clock / power / temperature samples of the same minutes beside the trace
-python tools/clock_watch.py $O/r05_cfg4_clock_power_temp.txt -- env WL=cfg4 TAG=r05_cfg4 bash tools/prof_cfg.sh > gpurun_out/r05_final_prof_cfg4.log 2>&1
+# (config 4's clock / power / temperature evidence is tools/clock_scan.py below: scans back to back on the process' own GPU)
+env WL=cfg4 TAG=r05_cfg4 bash tools/prof_cfg.sh > gpurun_out/r05_final_prof_cfg4.log 2>&1
 head -7 gpurun_out/prof_r05_cfg4/r05_cfg4_kernel_trace.txt | tail -4 | cut -c1-150
 fi
 if [ -z "$SKIP_TABLES" ]; then
