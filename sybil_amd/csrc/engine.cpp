@@ -236,7 +236,10 @@ static int scan(Query *q) {
         SYBL_HIP(hipMemsetAsync(q->pplan.wrap_log, 0, 8, st));
         SYBL_HIP(hipEventRecord(q->ev[0], st));
         q->eplan.sum_out = q->d_sum;
-        q->eplan.store_nt = env("SYBL_EMIT_NT") ? 1 : 0;
+        // (the 64-byte chunk stores are written once and read once, by another kernel: the non-temporal hint is worth 1-2 % of
+        // the scan on every placement tried -- profiles/r05_emit_nt.txt; SYBL_EMIT_PLAIN_STORES=1: without it)
+        q->eplan.store_nt = env("SYBL_EMIT_PLAIN_STORES") ? 0 : 1;
+        for (auto &pp : q->part_more) pp.E.store_nt = q->eplan.store_nt;
         q->pplan.sum_out = q->d_sum;
         q->pplan.max_out = q->d_max;
         // counting sort: count per (workgroup, bin) -> exact regions -> scatter

@@ -173,7 +173,7 @@ struct EmitPlan {
                                      // on a handful of LDS counters)
     int32_t quiet, store_nt;         // quiet: a later pass over the same rows (the third / fourth aggregation of a query,
                                      // Query::part_more): matched / overflow were counted by the first
-                                     // store_nt (SYBL_EMIT_NT, experiment): the chunk stores carry the non-temporal hint
+                                     // store_nt: the chunk stores carry the non-temporal hint (round 5; SYBL_EMIT_PLAIN_STORES=1: off)
     int64_t *sum_out;                // header: matched / overflow
 };
 

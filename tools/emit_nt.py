@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """k_emit's chunk stores with and without the non-temporal hint, on the SAME prepared queries (same buffers: the placement
-lottery of tools/emit_placement.py cancels): SYBL_EMIT_NT is read at every scan.   usage: emit_nt.py [queries] [rounds]"""
+lottery of tools/emit_placement.py cancels): SYBL_EMIT_PLAIN_STORES is read at every scan.   usage: emit_nt.py [queries] [rounds]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sybil_amd
@@ -20,13 +20,13 @@ for r in range(rounds):
     for q in qs:
         pair = []
         for nt in (False, True):
-            if nt: os.environ["SYBL_EMIT_NT"] = "1"
-            else: os.environ.pop("SYBL_EMIT_NT", None)
+            if nt: os.environ.pop("SYBL_EMIT_PLAIN_STORES", None)
+            else: os.environ["SYBL_EMIT_PLAIN_STORES"] = "1"
             ms = []
             for _ in range(8):
                 q.scan(); ctx.sync(); ms.append(q.stats()["scan_ms"])
             pair.append(sorted(ms)[4])
         row.append("%.3f/%.3f" % tuple(pair))
-    os.environ.pop("SYBL_EMIT_NT", None)
+    os.environ.pop("SYBL_EMIT_PLAIN_STORES", None)
     print("round %d: " % r + "  ".join(row))
 r = qs[0].finalize(); print("matched", r.matched); r.free()
