@@ -268,3 +268,77 @@ def test_random_queries_with_strings_and_sets(ctx, oracle, seed):
         gres.free()
         query.free()
     tb.free()
+
+
+def _round5_table(rng, n):
+    pool = np.unique(rng.integers(-(1 << 40), 1 << 40, size=int(rng.integers(3, 400))))
+    if rng.random() < 0.5:
+        pool = np.concatenate([pool, [-1]])  # shares the MISSING_VALUE group
+    cols = {"g_sparse": pool[rng.integers(0, pool.size, size=n)],
+            "g_small": rng.integers(0, int(rng.integers(1, 30)), size=n),
+            "f1": rng.integers(0, 1000, size=n),
+            "v_any": rng.integers(-50_000, 50_000, size=n),
+            "v_neg": rng.integers(-90_000, -3, size=n),
+            "v_pos": rng.integers(0, int(rng.integers(10, 2_000_000)), size=n),
+            "t": np.sort(1_700_000_000 + rng.integers(0, int(rng.integers(1, 40)) * 3600, size=n)),
+            "w": rng.integers(1, 6, size=n)}
+    pops = {}
+    for name, p in (("g_sparse", 0.4), ("v_any", 0.4), ("w", 0.7)):
+        if rng.random() < p:
+            pops[name] = (rng.random(n) > float(rng.choice([0.05, 0.5, 0.95]))).astype(np.uint8)
+    return {k: v.astype(np.int64) for k, v in cols.items()}, pops
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_queries_round5_shapes(ctx, oracle, seed):
+    """The shapes round 5 moved or accepted, drawn at random: a sparse int key (dictionary digits through the rank column),
+    weights with unpopulated rows (carried within the block), avg over negative values (tracked minima in the specialised
+    bodies), alone and together, with filters on the key itself, time series, moments and bucket arrays; canonical and
+    compact storage, three block sizes."""
+    rng = np.random.default_rng(50_000 + seed)
+    n = int(rng.integers(1, 80_000))
+    block_rows = int(rng.choice([997, 4096, 65536]))
+    cols, pops = _round5_table(rng, n)
+    names = list(cols)
+    info = {c: (int(cols[c].min()), int(cols[c].max())) for c in names}
+    tb = ctx.create_table("fuzz5")
+    for c in names:
+        tb.add_column(c, "int", info[c][0], info[c][1])
+    if seed % 3 == 2:
+        tb.compact()
+    for r0 in range(0, n, block_rows):
+        r1 = min(r0 + block_rows, n)
+        tb.append_block(r1 - r0, {c: ((cols[c][r0:r1], pops[c][r0:r1]) if c in pops else cols[c][r0:r1]) for c in names})
+    if seed % 3 == 1:
+        tb.compact()
+    ocols = [{"type": "int", "data": cols[c], **({"populated": pops[c]} if c in pops else {})} for c in names]
+    for k in range(6):
+        q = {"filters": []}
+        for _ in range(int(rng.integers(0, 3))):
+            c = str(rng.choice(["f1", "g_sparse", "v_any"]))
+            lo, hi = info[c]
+            q["filters"].append((c, str(rng.choice(["gt", "lt", "neq"])), int(rng.integers(lo, hi + 1))))
+        q["groups"] = [str(x) for x in rng.choice(["g_sparse", "g_small"], size=int(rng.integers(1, 3)), replace=False)]
+        q["aggs"] = [str(x) for x in rng.choice(["v_any", "v_neg", "v_pos"], size=int(rng.integers(1, 3)), replace=False)]
+        q["op"] = str(rng.choice(["avg", "avg", "hist"]))
+        if q["op"] == "hist":
+            q["want_percentiles"] = bool(rng.random() < 0.4)
+        if rng.random() < 0.2:
+            q["time_col"], q["time_bucket"] = "t", int(rng.choice([3600, 86400]))
+        if rng.random() < 0.5:
+            q["weight_col"] = "w"
+        try:
+            query = tb.query(**q)
+        except sybil_amd.SyblError as e:
+            assert "histogram budget" in str(e) or "exceeds 2^27" in str(e) or "2^20 bucket words" in str(e), str(e)
+            continue
+        gres = query.run()
+        ores = oracle.run_query(ocols, block_rows=block_rows, **parity.oracle_query_kwargs(names, info, q))
+        try:
+            parity.compare(gres, ores, op=q["op"], full=q.get("want_percentiles", True) and q["op"] == "hist", n_aggs=len(q["aggs"]),
+                           time_mode=bool(q.get("time_col")))
+        except AssertionError as e:
+            raise AssertionError("seed %d query %d %r strategy %d: %s" % (seed, k, q, query.stats()["strategy"], e))
+        gres.free()
+        query.free()
+    tb.free()

@@ -32,11 +32,14 @@ for seed in seeds:
         os.environ["SYBL_FORCE_HASH"] = "1"
         if seed % 8 == 0:
             os.environ["SYBL_NO_HASH_LDS"] = "1"
-    for fn in (T.test_random_queries, T.test_random_queries_many_tiles_per_workgroup, T.test_random_queries_with_strings_and_sets):
+    for fn in (T.test_random_queries, T.test_random_queries_many_tiles_per_workgroup, T.test_random_queries_with_strings_and_sets,
+               T.test_random_queries_round5_shapes):
         if fn is T.test_random_queries_many_tiles_per_workgroup and seed % 5:
             continue  # (bigger tables: every fifth seed)
         try:
-            if fn is not T.test_random_queries_with_strings_and_sets:
+            if fn is T.test_random_queries_round5_shapes:
+                fn(ctx, orc, seed)
+            elif fn is not T.test_random_queries_with_strings_and_sets:
                 fn(ctx, orc, seed, _Env())
             else:
                 fn(ctx, orc, seed)
