@@ -192,8 +192,8 @@ int table_reclaim_dead_rows(Table *t, bool force);           // rows of dead blo
 void column_free(Column *c);
 int32_t dict_intern(Column *c, const std::string &s);
 int column_upload_set(Table *t, Column *c);
-int column_build_gdict(Table *t, Column *c);
-int column_build_rank(Table *t, Column *c);            // Column::rank_col for the current dictionary and table version           // distinct values of the resident rows
+int column_build_gdict(Table *t, Column *c);           // distinct values of the resident rows
+int column_build_rank(Table *t, Column *c);            // Column::rank_col for the current dictionary and table version
 int column_install_gdict(Table *t, Column *c);         // sorted gdict -> device value->rank map
 int column_repack(Table *t, Column *c, int width, int64_t vbase);  // change the stored width in place
 
