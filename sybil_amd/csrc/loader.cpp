@@ -280,7 +280,8 @@ struct ColSpec {
 
 constexpr int64_t kMaxBlockRows = (int64_t)1 << 24;  // 256 x the reference's block size
 
-static PreparedBlock prepare_block_unguarded(const std::string &bdir, const std::vector<ColSpec> &specs, char *slab_h, size_t slab_cap, int device);
+static PreparedBlock prepare_block_unguarded(const std::string &bdir, const std::vector<ColSpec> &specs, char *slab_h, size_t slab_cap, int device,
+                                             bool streamed = true);
 static std::pair<int64_t, int64_t> block_signature(const std::string &bdir);
 // A worker thread must not let an exception escape (std::bad_alloc / length_error from a damaged file): it
 // would be rethrown by future::get() and leave the extern "C" entry point.  The block is skipped instead,
@@ -528,7 +529,8 @@ static bool fill_bins(const BinsView &bv, bool delta, int64_t num_records, char 
     return true;
 }
 
-static PreparedBlock prepare_block_unguarded(const std::string &bdir, const std::vector<ColSpec> &specs, char *slab_h, size_t slab_cap, int device) {
+static PreparedBlock prepare_block_unguarded(const std::string &bdir, const std::vector<ColSpec> &specs, char *slab_h, size_t slab_cap, int device,
+                                             bool streamed) {
     static const char *prefix[] = {"", "int_", "str_", "set_"};
     PreparedBlock pb;
     std::string err;
@@ -546,8 +548,15 @@ static PreparedBlock prepare_block_unguarded(const std::string &bdir, const std:
         return pb;
     }
     pb.cols.resize(specs.size());
-    // ---- pass 1: decode the files, plan the slab layout
-    std::vector<gob::Value> trees(specs.size());
+    // Column by column (streamed, the normal case): a file is decoded, its pieces get their place in the slab -- the layout
+    // is the running total of the columns before it -- and are written there at once, while the decoder's arrays are still in
+    // this core's cache; the tree then goes back to the thread's stock and the next file decodes into the same memory.  Round
+    // 5: decoding all files first and filling the slab in a second pass kept 1.2 MB of decoded arrays alive per worker, read
+    // back cold (profiles/r05_loader_streamed.txt).  A block that outgrows the pool's slab starts over in two passes
+    // (plan everything, then a buffer of its own): SYBL_LOADER_TWO_PASS=1 does that for every block (A/B).
+    static const bool two_pass_always = env("SYBL_LOADER_TWO_PASS") != nullptr;
+    if (two_pass_always) streamed = false;
+    std::vector<gob::Value> trees(streamed ? 0 : specs.size());
     std::vector<char> have(specs.size(), 0), bucketed(specs.size(), 0);
     size_t total = 0;
     auto reserve = [&](size_t bytes) {
@@ -556,14 +565,14 @@ static PreparedBlock prepare_block_unguarded(const std::string &bdir, const std:
         total += bytes;
         return at;
     };
-    for (size_t ci = 0; ci < specs.size(); ci++) {
+    // ---- plan: decode column ci's file into v, decide what travels and where in the slab.  False: the block is broken.
+    auto plan = [&](size_t ci, gob::Value &v) -> bool {
         PreparedCol &pc = pb.cols[ci];
         std::string path = bdir + "/" + prefix[specs[ci].type] + specs[ci].name + ".db";
-        gob::Value &v = trees[ci];
         // a missing file = column unpopulated in this block; "DECODE COL ERR": the reference logs and
         // carries on with an empty column
         static const bool wide = env("SYBL_LOADER_WIDE_DECODE") != nullptr;  // (A/B: int64 slices, narrowed afterwards)
-        if (!decode_file(path, v, err, specs[ci].type != SYBL_SET_VAL && !wide)) continue;
+        if (!decode_file(path, v, err, specs[ci].type != SYBL_SET_VAL && !wide)) return true;
         have[ci] = 1;
         const gob::Value *f;
         const bool bucket = (f = v.field("BucketEncoded")) && f->as_bool();
@@ -571,7 +580,7 @@ static PreparedBlock prepare_block_unguarded(const std::string &bdir, const std:
         pc.delta = (f = v.field("DeltaEncodedIDs")) && f->as_bool();
         pc.venc = (f = v.field("ValueEncoded")) && f->as_bool();
         bool ok = true;
-        if (specs[ci].type == SYBL_SET_VAL) continue;  // sets stay on the host (CSR mirror)
+        if (specs[ci].type == SYBL_SET_VAL) return true;  // sets stay on the host (CSR mirror)
         if (specs[ci].type == SYBL_STR_VAL) {
             string_table(v, pc.strings);
             ok = (int64_t)pc.strings.size() <= pb.nrows;
@@ -621,28 +630,14 @@ static PreparedBlock prepare_block_unguarded(const std::string &bdir, const std:
         if (!ok) {
             pb.broken = true;  // "ERROR DURING COLUMN UNPACK ... SKIPPING BLOCK" (table_block_io.go:297-301)
             pb.why = "BLOCK SIZE CHANGED DURING QUERY in column '" + specs[ci].name + "'";
-            return pb;
+            return false;
         }
-    }
-    pb.bytes = align16(total);
-    char *base = slab_h;
-    if (pb.bytes > slab_cap) {
-        // larger than the pool's slabs (an over-sized block): a pinned / device pair of its own
-        // (device < 0: sybl_debug_block_layout, which has no device to ask -- the caller reads pb.bytes and stops)
-        if (device < 0 || hipSetDevice(device) != hipSuccess || hipHostMalloc((void **)&pb.own_h, pb.bytes, hipHostMallocDefault) != hipSuccess ||
-            hipMalloc((void **)&pb.own_d, pb.bytes) != hipSuccess) {
-            if (pb.own_h) (void)hipHostFree(pb.own_h);
-            pb.own_h = pb.own_d = nullptr;
-            pb.unreadable = true;
-            return pb;
-        }
-        base = pb.own_h;
-    }
-    // ---- pass 2: fill
-    for (size_t ci = 0; ci < specs.size(); ci++) {
+        return true;
+    };
+    // ---- fill: column ci's pieces into their places under `base`.  False: the block is broken.
+    auto fill = [&](size_t ci, const gob::Value &v, char *base) -> bool {
         PreparedCol &pc = pb.cols[ci];
-        if (!have[ci]) continue;
-        const gob::Value &v = trees[ci];
+        if (!have[ci]) return true;
         const gob::Value *bins = v.field("Bins"), *vals = v.field("Values");
         bool ok = true;
         switch (pc.kind) {
@@ -775,9 +770,40 @@ static PreparedBlock prepare_block_unguarded(const std::string &bdir, const std:
         if (!ok) {
             pb.broken = true;
             pb.why = "BLOCK SIZE CHANGED DURING QUERY in column '" + specs[ci].name + "'";
+            return false;
+        }
+        return true;
+    };
+    if (streamed) {
+        for (size_t ci = 0; ci < specs.size(); ci++) {
+            gob::Value v;
+            if (!plan(ci, v)) return pb;
+            if (align16(total) > slab_cap) return prepare_block_unguarded(bdir, specs, slab_h, slab_cap, device, false);  // (an over-sized block)
+            if (!fill(ci, v, slab_h)) return pb;
+        }
+        pb.bytes = align16(total);
+        return pb;
+    }
+    // ---- two passes: plan every column, then fill
+    for (size_t ci = 0; ci < specs.size(); ci++)
+        if (!plan(ci, trees[ci])) return pb;
+    pb.bytes = align16(total);
+    char *base = slab_h;
+    if (pb.bytes > slab_cap) {
+        // larger than the pool's slabs (an over-sized block): a pinned / device pair of its own
+        // (device < 0: sybl_debug_block_layout, which has no device to ask -- the caller reads pb.bytes and stops)
+        if (device < 0 || hipSetDevice(device) != hipSuccess || hipHostMalloc((void **)&pb.own_h, pb.bytes, hipHostMallocDefault) != hipSuccess ||
+            hipMalloc((void **)&pb.own_d, pb.bytes) != hipSuccess) {
+            if (pb.own_h) (void)hipHostFree(pb.own_h);
+            pb.own_h = pb.own_d = nullptr;
+            pb.unreadable = true;
             return pb;
         }
+        base = pb.own_h;
     }
+    // ---- pass 2: fill
+    for (size_t ci = 0; ci < specs.size(); ci++)
+        if (!fill(ci, trees[ci], base)) return pb;
     return pb;
 }
 
