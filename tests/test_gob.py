@@ -320,3 +320,19 @@ def test_cxx_reader_int_slices_other_paths(tmp_path, switches):
         os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(tmp_path))
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
+
+
+def test_varint_windows_against_the_checked_reader_on_random_streams(tmp_path):
+    """tools/micro/gobints_fuzz.cpp: Reader::ints -- the AVX-512 VBMI windows where the host has them -- against the checked
+    value-by-value reader on random byte strings (valid streams of the shapes column files have, marker soup, bytes that
+    are no marker, damage), as int64 and as the narrow element types the loader asks for: the same values, the same
+    position behind them, the same verdict, `misfit` set exactly when a value does not fit."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "gobints_fuzz")
+    b = subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(root, "sybil_amd", "csrc"), "-I", os.path.join(root, "include"),
+                        os.path.join(root, "tools", "micro", "gobints_fuzz.cpp"), "-lz", "-o", exe], capture_output=True, text=True, timeout=600)
+    assert b.returncode == 0, b.stderr[-3000:]
+    for env in ({}, {"SYBL_GOB_NO_VBMI": "1"}):
+        r = subprocess.run([exe, "60000"], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and " 0 mismatches" in r.stdout, (r.stdout[-500:], r.stderr[-500:])

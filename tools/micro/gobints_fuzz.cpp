@@ -1,7 +1,8 @@
 // Reader::ints (csrc/gob.cpp) with the AVX-512 VBMI windows against the checked value-by-value reader, on random byte
 // strings -- valid streams, marker soup, bytes that are no marker, values of eight data bytes: the same values, the same
 // position behind them, the same verdict.  Build and run (any host; without VBMI both sides are the scalar loops):
-//   hipcc -O2 -std=c++17 -x c++ -I../../sybil_amd/csrc -I../../include gobints_fuzz.cpp -lz -o gobints_fuzz && ./gobints_fuzz
+//   g++ -O2 -std=c++17 -I../../sybil_amd/csrc -I../../include gobints_fuzz.cpp -lz -o gobints_fuzz && ./gobints_fuzz [trials = 400000]
+// (tests/test_gob.py builds and runs it with 60 000)
 #include "../../sybil_amd/csrc/gob.cpp"
 #include <random>
 namespace sybl {
@@ -44,10 +45,11 @@ static bool narrow_agrees(const std::vector<uint8_t> &buf, uint64_t n, const std
     return any == (r.misfit != 0);
 }
 
-int main() {
+int main(int argc, char **argv) {
     std::mt19937_64 rng(99);
     long trials = 0, bad = 0;
-    for (int t = 0; t < 400000; t++) {
+    const int n_trials = argc > 1 ? atoi(argv[1]) : 400000;
+    for (int t = 0; t < n_trials; t++) {
         size_t len = 136 + rng() % 900;
         std::vector<uint8_t> buf(len);
         int mode = rng() % 11;
