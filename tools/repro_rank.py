@@ -7,6 +7,7 @@ whether a second prepare of the same query (rank column / probing path) repeats 
 One unexplained failure of that test (999 groups for 901 in one run) is what this looks for.
 
     python tools/repro_rank.py [seconds] > gpurun_out/repro_rank.log
+    python tools/repro_rank.py 0        # one table, then exit (run in a shell loop: a fresh process each time)
 """
 import os
 import sys
@@ -70,6 +71,7 @@ def dump(tag, tb, query_kwargs, uid, upop, f, v, rows, exp, have, st):
 
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
+    once = budget <= 0  # (0: one table in this process -- the failure looked for was the first table of its process)
     rng = np.random.default_rng(21)
     n = 400_000
     pool = np.unique(rng.integers(-(1 << 30), 1 << 30, size=900))
@@ -85,7 +87,7 @@ def main():
     ctx = sybil_amd.Context(0)
     t0 = time.time()
     it = fails = checks = 0
-    while time.time() - t0 < budget:
+    while time.time() - t0 < budget or (once and it == 0):
         compact = it % 2 == 1
         if it % 4 >= 2:
             os.environ["SYBL_PLAN_TRACE"] = "1"
