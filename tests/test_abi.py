@@ -74,3 +74,18 @@ int main(void){ printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(sybl_col_view), s
         out = subprocess.check_output([os.path.join(d, "s")]).split()
     sizes = [ctypes.sizeof(x) for x in (N.ColView, N.SynthCol, N.Filter, N.QueryDesc, N.AggOut, N.GroupRow, N.RunStats)]
     assert [int(x) for x in out] == sizes
+
+
+def test_every_environment_switch_of_the_library_is_documented():
+    """DESIGN.md section 6 lists the diagnostic switches; a switch the sources read and no document names is drift."""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    names = set()
+    for path in glob.glob(os.path.join(root, "sybil_amd", "csrc", "*")):
+        if path.endswith((".cpp", ".h", ".hip")):
+            names |= set(re.findall(r'env\("(SYBL_[A-Z0-9_]+)"\)', open(path).read()))
+    assert len(names) > 40
+    docs = "".join(open(os.path.join(root, d)).read() for d in ("DESIGN.md", "INTEGRATION.md", "README.md"))
+    missing = sorted(n for n in names if n not in docs)
+    assert not missing, missing
