@@ -89,3 +89,23 @@ def test_every_environment_switch_of_the_library_is_documented():
     docs = "".join(open(os.path.join(root, d)).read() for d in ("DESIGN.md", "INTEGRATION.md", "README.md"))
     missing = sorted(n for n in names if n not in docs)
     assert not missing, missing
+
+
+def test_documents_name_files_and_tests_that_exist():
+    """A `profiles/...`, `tools/...`, `tests/...` path a document quotes must be in the tree (a prefix such as `profiles/r05_`
+    must match something), and a `tests/file.py::test_name` must be a test of that file."""
+    import glob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    bad = []
+    for d in ("DESIGN.md", "BASELINE.md", "README.md", "INTEGRATION.md"):
+        text = open(os.path.join(root, d)).read()
+        for m in re.findall(r'`((?:profiles|tools|tests|oracle|include|sybil_amd)/[A-Za-z0-9_./\-]+)', text):
+            path = m.rstrip(".,;:)")
+            if path == "oracle/_ref":  # (built, git-ignored)
+                continue
+            if not os.path.exists(os.path.join(root, path)) and not glob.glob(os.path.join(root, path) + "*"):
+                bad.append((d, path))
+        for f, t in re.findall(r'`(tests/[A-Za-z0-9_]+\.py)::(test_[A-Za-z0-9_]+)[`\[]', text):
+            if os.path.exists(os.path.join(root, f)) and ("def " + t + "(") not in open(os.path.join(root, f)).read():
+                bad.append((d, f + "::" + t))
+    assert not bad, bad
