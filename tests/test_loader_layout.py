@@ -146,3 +146,25 @@ def test_damaged_blocks_are_reported_not_laid_out(tmp_path):
     assert "broken=1" in layout(bdir, cols)
     os.remove(os.path.join(bdir, "info.db"))
     assert "unreadable=1" in layout(bdir, cols)
+
+
+def test_damaged_blocks_under_the_sanitizers(table, tmp_path):
+    """tools/micro/loader_block_fuzz.cpp: prepare_block over copies of two of the table's blocks with one file damaged per
+    trial (bytes overwritten / inserted / removed, the tail cut off, a huge length planted, the file removed) into a heap slab
+    of exactly a worker's size -- now and then one that is too small --, built with AddressSanitizer and
+    UndefinedBehaviorSanitizer: a write past the slab, a read past a decoded array or undefined arithmetic on a hostile
+    length ends the run.  Both forms of the pass (column by column, and SYBL_LOADER_TWO_PASS=1)."""
+    root, _ = table
+    exe = str(tmp_path / "loader_block_fuzz")
+    b = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-std=c++17", "-x", "hip",
+                        os.path.join(ROOT, "tools", "micro", "loader_block_fuzz.cpp"), "-o", exe, "-I", os.path.join(ROOT, "sybil_amd", "csrc"),
+                        "-I", os.path.join(ROOT, "include"), "-L", os.path.join(ROOT, "sybil_amd"), "-lsybilgpu",
+                        "-Wl,-rpath," + os.path.join(ROOT, "sybil_amd"), "-Wl,-rpath,/opt/rocm/lib"], capture_output=True, text=True, timeout=900)
+    assert b.returncode == 0, b.stderr[-3000:]
+    specs = ["%s:%d" % (n, TYPES[t]) for n, t in COLS]
+    env = dict(os.environ, ASAN_OPTIONS="allocator_may_return_null=1:detect_leaks=0")
+    for block, trials, extra in ((3, 1200, {}), (4, 250, {}), (3, 500, {"SYBL_LOADER_TWO_PASS": "1"})):
+        r = subprocess.run([exe, os.path.join(root, "t", "block%09d" % block), str(tmp_path / ("scratch%d" % block)), str(trials)] + specs,
+                           env=dict(env, **extra), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0 and "laid out" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
+        assert " 0 exceptions" in r.stdout, r.stdout  # (std::bad_alloc / length_error would mean a hostile length sized something)
