@@ -206,3 +206,19 @@ def test_random_replacements_agree_with_python_re_sub():
             assert out.decode() == rx.sub(py_t, text), (pat, text, go_t)
             checked += 1
     assert checked > 5_000
+
+
+def test_random_patterns_and_texts_under_the_sanitizers(tmp_path):
+    """tools/micro/re2lite_fuzz.cpp built with AddressSanitizer + UndefinedBehaviorSanitizer: pieces of RE2 syntax glued
+    together at random and byte soup as patterns, texts with multi-byte runes and invalid UTF-8 in exact-size buffers,
+    random replacement templates -- compile / search / replace_all must return, nothing more."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "re2lite_fuzz")
+    b = subprocess.run(["g++", "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-std=c++17", "-I", os.path.join(root, "sybil_amd", "csrc"),
+                        os.path.join(root, "tools", "micro", "re2lite_fuzz.cpp"), os.path.join(root, "sybil_amd", "csrc", "re2lite.cpp"), "-o", exe],
+                       capture_output=True, text=True, timeout=600)
+    assert b.returncode == 0, b.stderr[-3000:]
+    r = subprocess.run([exe, "40000"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "compiled" in r.stdout, (r.stdout[-300:], r.stderr[-3000:])
