@@ -1012,7 +1012,7 @@ orc_results *orc_query_run(const orc_query *q, const orc_col *cols, int32_t ncol
     for (int w = 0; w < 2; w++) {
         rmap *m = w == 0 ? &R->results : &R->time_results;
         R->sorted[w] = (orc_result **)malloc((size_t)(m->n ? m->n : 1) * sizeof(orc_result *));
-        memcpy(R->sorted[w], m->items, (size_t)m->n * sizeof(orc_result *));
+        if (m->n) memcpy(R->sorted[w], m->items, (size_t)m->n * sizeof(orc_result *));
         g_cmp_groups = q->n_groups;
         qsort(R->sorted[w], (size_t)m->n, sizeof(orc_result *), cmp_result);
     }
