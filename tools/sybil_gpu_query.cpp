@@ -43,8 +43,19 @@ int main(int argc, char **argv) {
         {"sort", "$COUNT"}, {"sort-asc", "false"}, {"time", "false"}, {"time-col", "time"}, {"time-bucket", "3600"},
         {"weight-col", ""}, {"int-filter", ""}, {"str-filter", ""}, {"set-filter", ""}, {"int-bucket", "0"},
         {"int", ""}, {"str", ""}, {"set", ""}, {"group", ""}, {"field-separator", ","}, {"filter-separator", ":"},
-        {"device", "0"}, {"block-skip", "true"}, {"stats", "false"}, {"encode-results", "false"}, {"loghist", "false"}, {"str-replace", ""}, {"distinct", ""}};
-    const std::set<std::string> bools = {"print", "json", "sort-asc", "time", "block-skip", "stats", "encode-results", "loghist"};
+        {"device", "0"}, {"block-skip", "true"}, {"stats", "false"}, {"encode-results", "false"}, {"loghist", "false"}, {"str-replace", ""}, {"distinct", ""},
+        // accepted so that a command line written for `sybil query` runs unchanged; without effect here:
+        //  -prune-sort / -distinct-limit bound the reference's intermediate results (aggregate.go:347-359, table_query.go:258-279:
+        //   which groups survive depends on block completion order) -- this engine aggregates every group exactly and cuts at
+        //   -limit after the sort (note 9);
+        //  -recycle-mem / -fast-recycle / -shorten-key-table / -cache-queries / -debug steer the Go runtime's memory, caches and log
+        {"prune-sort", "$COUNT"}, {"distinct-limit", "-1"}, {"recycle-mem", "true"}, {"fast-recycle", "true"}, {"shorten-key-table", "true"},
+        {"cache-queries", "false"}, {"debug", "false"}};
+    const std::set<std::string> bools = {"print", "json", "sort-asc", "time", "block-skip", "stats", "encode-results", "loghist",
+                                         "recycle-mem", "fast-recycle", "shorten-key-table", "cache-queries", "debug"};
+    // flags of `sybil query` whose work is not the aggregation path (samples and exports read the row store, -tables / -info /
+    // -update-info the table directory, the flag codecs feed the reference's own multi-host scripts): named, not "undefined"
+    const std::set<std::string> elsewhere = {"samples", "sample-cols", "export", "read-log", "tables", "info", "update-info", "encode-flags", "decode-flags", "tdigest"};
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         if (a.size() < 2 || a[0] != '-') {
@@ -58,6 +69,10 @@ int main(int argc, char **argv) {
         if (has_val) {
             val = a.substr(eq + 1);
             a = a.substr(0, eq);
+        }
+        if (elsewhere.count(a)) {
+            fprintf(stderr, "-%s is a flag of `sybil query` that this binary does not serve (it runs the filter / group / aggregate path only)\n", a.c_str());
+            return 2;
         }
         if (!f.count(a)) {
             fprintf(stderr, "flag provided but not defined: -%s\n", a.c_str());
