@@ -109,3 +109,15 @@ def test_documents_name_files_and_tests_that_exist():
             if os.path.exists(os.path.join(root, f)) and ("def " + t + "(") not in open(os.path.join(root, f)).read():
                 bad.append((d, f + "::" + t))
     assert not bad, bad
+
+
+def test_the_cgo_shim_in_the_integration_notes_names_what_the_header_declares():
+    """INTEGRATION.md shows the binding a maintainer of the reference would add; a C.sybl_* call or a `sybl_*` name in it that
+    the header does not declare is a shim that would not compile."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    hdr = open(os.path.join(root, "include", "sybilgpu.h")).read()
+    names = set(re.findall(r"C\.(sybl_[a-z0-9_]+)", doc)) | set(re.findall(r"`(sybl_[a-z0-9_]+)[`(]", doc)) | set(re.findall(r"C\.(SYBL_[A-Z0-9_]+)", doc))
+    assert len(names) >= 30
+    missing = sorted(n for n in names if not re.search(r"\b" + n + r"\b", hdr))
+    assert not missing, missing
