@@ -2,6 +2,7 @@
 // ("Encoding Details"); sybil's use of it: column_store_io.go, table_io.go, file_decoder.go.
 #include "gob.h"
 
+#include <errno.h>
 #include <fcntl.h>
 #include <stdio.h>
 #include <string.h>
@@ -696,7 +697,21 @@ bool decode(const uint8_t *data, size_t size, Value &out, std::string &err, cons
     return d.run(data, size, out);
 }
 
-bool read_file(const std::string &path, std::vector<uint8_t> &out, std::string &err) {
+FileBuf::~FileBuf() { free(p); }
+
+static bool filebuf_reserve(FileBuf &b, size_t want) {
+    if (want <= b.cap) return true;
+    size_t cap = b.cap + b.cap / 2;
+    if (cap < want) cap = want;
+    if (cap < 4096) cap = 4096;
+    uint8_t *q = (uint8_t *)realloc(b.p, cap);
+    if (!q) return false;
+    b.p = q;
+    b.cap = cap;
+    return true;
+}
+
+bool read_file(const std::string &path, FileBuf &out, std::string &err) {
     // one open per candidate name, no existence probes: these are the syscalls of every column file of every block
     std::string use = path;
     int fd = open(use.c_str(), O_RDONLY | O_CLOEXEC);
@@ -709,7 +724,7 @@ bool read_file(const std::string &path, std::vector<uint8_t> &out, std::string &
         return false;
     }
     const bool gz = use.size() > 3 && use.compare(use.size() - 3, 3, ".gz") == 0;
-    out.clear();
+    out.n = 0;
     if (gz) {
         gzFile g = gzdopen(fd, "rb");  // (takes the descriptor over)
         if (!g) {
@@ -717,12 +732,19 @@ bool read_file(const std::string &path, std::vector<uint8_t> &out, std::string &
             err = "cannot gzopen " + use;
             return false;
         }
-        uint8_t buf[1 << 16];
-        int n;
-        while ((n = gzread(g, buf, sizeof(buf))) > 0) out.insert(out.end(), buf, buf + n);
-        bool bad = n < 0;
+        int n = 0;
+        for (;;) {
+            if (!filebuf_reserve(out, out.n + ((size_t)1 << 16))) {
+                gzclose(g);
+                err = "out of memory reading " + use;
+                return false;
+            }
+            n = gzread(g, out.p + out.n, 1 << 16);
+            if (n <= 0) break;
+            out.n += (size_t)n;
+        }
         gzclose(g);
-        if (bad) {
+        if (n < 0) {
             err = "gzip error in " + use;
             return false;
         }
@@ -734,31 +756,41 @@ bool read_file(const std::string &path, std::vector<uint8_t> &out, std::string &
         err = "cannot stat " + use;
         return false;
     }
-    // (reserve + read at the end: resize() would zero-fill every byte first)
+    // the size fstat reported, plus one byte: a read that fills it means the file grew under us ("short read" as before)
     const size_t want = (size_t)st.st_size;
-    out.reserve(want + 1);
+    if (!filebuf_reserve(out, want + 1)) {
+        close(fd);
+        err = "out of memory reading " + use;
+        return false;
+    }
     size_t got = 0;
-    uint8_t chunk[1 << 16];
-    if (want <= out.capacity()) {
-        // std::vector has no uninitialised resize: append in cache-sized chunks (one extra copy out of L2, no page faults
-        // on a fresh buffer when the caller reuses `out`)
-        for (;;) {
-            const ssize_t n = read(fd, chunk, sizeof(chunk));
-            if (n < 0) {
-                close(fd);
-                err = "read error on " + use;
-                return false;
-            }
-            if (n == 0) break;
-            out.insert(out.end(), chunk, chunk + n);
-            got += (size_t)n;
+    while (got <= want) {
+        const ssize_t n = read(fd, out.p + got, want + 1 - got);
+        if (n < 0) {
+            if (errno == EINTR) continue;
+            close(fd);
+            err = "read error on " + use;
+            return false;
         }
+        if (n == 0) break;
+        got += (size_t)n;
     }
     close(fd);
     if (got != want) {
         err = "short read on " + use;
         return false;
     }
+    out.n = got;
+    return true;
+}
+
+bool read_file(const std::string &path, std::vector<uint8_t> &out, std::string &err) {
+    FileBuf b;
+    if (!read_file(path, b, err)) {
+        out.clear();
+        return false;
+    }
+    out.assign(b.p, b.p + b.n);
     return true;
 }
 

@@ -116,6 +116,18 @@ bool decode(const uint8_t *data, size_t size, Value &out, std::string &err, cons
 // Reads a file, transparently gunzipping "*.gz" (or trying "<path>.gz" when <path> is missing,
 // like GetFileDecoder, file_decoder.go:55-81).
 bool read_file(const std::string &path, std::vector<uint8_t> &out, std::string &err);
+// ... into a buffer the caller keeps between files (the loader's workers: one per thread): grown with realloc, never zeroed,
+// never shrunk -- a plain file arrives with one read() straight into it (std::vector has no uninitialised resize: the vector
+// form read 64 KB at a time through the stack and appended, a second copy of every byte and four system calls per file).
+struct FileBuf {
+    uint8_t *p = nullptr;
+    size_t n = 0, cap = 0;  // bytes of the file, bytes allocated
+    FileBuf() {}
+    FileBuf(const FileBuf &) = delete;
+    FileBuf &operator=(const FileBuf &) = delete;
+    ~FileBuf();
+};
+bool read_file(const std::string &path, FileBuf &out, std::string &err);
 
 // JSON rendering of a decoded tree (struct field order = wire order); used by tests.
 void to_json(const Value &v, std::string &out);

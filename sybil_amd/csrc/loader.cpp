@@ -83,12 +83,12 @@ static void cgroup_throttle(int64_t *periods, int64_t *usec) {
 
 // narrow: the int slices in the form they travel in (gob::DecodeOpts) -- the int / str column files of a block
 static bool decode_file(const std::string &path, gob::Value &v, std::string &err, bool narrow = false) {
-    static thread_local std::vector<uint8_t> data;  // (reused: no allocation / page faults per file)
+    static thread_local gob::FileBuf data;  // (reused: no allocation / page faults / zero-fill per file)
     if (!gob::read_file(path, data, err)) return false;
-    g_file_bytes += (int64_t)data.size();
+    g_file_bytes += (int64_t)data.n;
     gob::DecodeOpts opts;
     opts.narrow = narrow;
-    return gob::decode(data.data(), data.size(), v, err, &opts);
+    return gob::decode(data.p, data.n, v, err, &opts);
 }
 
 static double seconds_since(std::chrono::steady_clock::time_point t0) {
