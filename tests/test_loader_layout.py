@@ -168,3 +168,85 @@ def test_damaged_blocks_under_the_sanitizers(table, tmp_path):
                            env=dict(env, **extra), capture_output=True, text=True, timeout=900)
         assert r.returncode == 0 and "laid out" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
         assert " 0 exceptions" in r.stdout, r.stdout  # (std::bad_alloc / length_error would mean a hostile length sized something)
+
+
+def _fnv(data, h=1469598103934665603):
+    for byte in data:
+        h = ((h ^ byte) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def _check_regions(bdir, n, cols_spec, seen):
+    from tests import gobfmt as G
+    prefix = {"int": "int_", "str": "str_", "set": "set_"}
+    cols = dict(_fields(l) for l in layout(bdir, cols_spec).strip().split("\n")[1:])
+    for name, typ in cols_spec:
+        f = cols[name]
+        path = os.path.join(bdir, prefix[typ] + name + ".db")
+        if not os.path.exists(path):
+            assert f["kind"] == "0", (name, f)
+            continue
+        col = G.decode(open(path, "rb").read())
+        if typ != "int":
+            strings = col.get("StringTable", [])
+            assert f["strings"] == "%d:%016x" % (len(strings), _fnv(b"".join(x.encode() + b"\0" for x in strings))), (bdir, name)
+        if typ == "set":
+            continue  # (sets stay on the host as CSR: the GPU tests' business)
+        if col.get("BucketEncoded"):
+            bins = col.get("Bins", [])
+            vals = np.array([x.get("Value", 0) for x in bins], dtype=np.int64)
+            recs = [x.get("Records", []) for x in bins]
+            off = np.cumsum([0] + [len(r) for r in recs]).astype(np.int64)
+            flat = np.array([d for r in recs for d in r], dtype=np.uint16)
+            assert (int(f["bins"]), int(f["recs"]), f["rec_w"], f["delta"]) == (len(bins), flat.size, "2", "1"), (bdir, name, f)
+            assert f["binval"] == "%016x" % _fnv(vals.tobytes()), (bdir, name)
+            assert f["binoff"] == "%016x" % _fnv(off.tobytes()), (bdir, name)
+            assert f["rec"] == "%016x" % _fnv(flat.tobytes()), (bdir, name)
+            seen.add(typ + "-bins")
+            continue
+        values = col.get("Values", [])
+        if typ == "int":
+            wide = any(v < -(1 << 31) or v >= (1 << 31) for v in values)
+            arr = np.array(values, dtype=np.int64 if wide else np.int32)
+            assert (int(f["vals"]), f["val_w"], f["venc"]) == (len(values), "8" if wide else "4", "1" if col.get("ValueEncoded") else "0"), (bdir, name, f)
+            assert f["val"] == "%016x" % _fnv(arr.tobytes()), (bdir, name)
+            seen.add("int-values-%d" % (8 if wide else 4))
+        else:
+            arr = np.array(values, dtype=np.uint16)
+            assert (int(f["local"]), f["local_w"]) == (len(values), "2"), (bdir, name, f)
+            assert f["loc"] == "%016x" % _fnv(arr.tobytes()), (bdir, name)
+            seen.add("str-values")
+        if 0 < len(values) < n:
+            words = (n + 31) // 32
+            bits = np.zeros(words, dtype=np.uint32)
+            for w in range(words):
+                lo = w * 32
+                bits[w] = 0xFFFFFFFF if len(values) >= lo + 32 else ((1 << (len(values) - lo)) - 1 if len(values) > lo else 0)
+            assert int(f["bits"]) == words and f["valid"] == "%016x" % _fnv(bits.tobytes()), (bdir, name)
+            seen.add("validity-prefix")
+        else:
+            assert f["bits"] == "0", (bdir, name, f)
+
+
+def test_slab_regions_hold_what_the_files_hold(table, tmp_path):
+    """Independent of every C++ decode path: the column files are read back with the Python gob reader (tests/gobfmt.py, pinned
+    on the reference's golden gobs) and each region of the slab is computed here -- bin values and offsets as int64, the record
+    ids as they are in the file (deltas) at uint16, value-encoded columns' deltas at int32 (int64 when one does not fit), str
+    columns' block-local ids at uint16, the validity prefix of a column with fewer values than rows, the string table -- and
+    its FNV-1a digest held against the one the worker's slab gives (sybl_debug_block_layout)."""
+    root, blocks = table
+    seen = set()
+    for b in (0, 1, 2):  # 1, 100 and 5003 rows: pure-Python digests of a 65 536-row block would take a minute
+        _check_regions(os.path.join(root, "t", "block%09d" % (b + 1)), len(blocks[b]["low"][1]), COLS, seen)
+    # the per-row encodings at a size Python digests in a second: a table written with a cardinality threshold of 8
+    rng = np.random.default_rng(5)
+    n = 3000
+    tail = np.arange(n) < n - 77  # (the last 77 rows have no value: Values is shorter than the block)
+    vocab = ["name%04d" % i for i in range(900)]
+    small = {"vals": ("int", rng.integers(0, 1_000_000, n)), "wide": ("int", rng.integers(-(1 << 45), 1 << 45, n)),
+             "short": ("int", rng.integers(0, 1_000_000, n), tail), "few": ("int", rng.integers(0, 5, n)),
+             "many": ("str", [vocab[int(i)] if keep else None for i, keep in zip(rng.integers(0, 900, n), tail)])}
+    F.write_table(str(tmp_path), "v", [small], threshold=8, extra_dirs=False)
+    _check_regions(os.path.join(str(tmp_path), "v", "block000000001"), n,
+                   [("vals", "int"), ("wide", "int"), ("short", "int"), ("few", "int"), ("many", "str")], seen)
+    assert seen >= {"int-bins", "str-bins", "int-values-4", "int-values-8", "str-values", "validity-prefix"}, seen
