@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define SYBL_ABI_VERSION 4
+#define SYBL_ABI_VERSION 5
 
 enum {
     SYBL_OK = 0,
@@ -340,7 +340,27 @@ int sybl_query_bind_partials(sybl_query *q, void *d_sum, void *d_max);
 int sybl_comm_unique_id(void *id128);
 int sybl_comm_init(sybl_ctx *ctx, const void *id128, int32_t nranks, int32_t rank);
 int sybl_comm_free(sybl_ctx *ctx);
+/* COLLECTIVE (every rank, same order).  The first call on a query also compares the ranks' partial-table layouts and
+ * fails with SYBL_E_STATE on EVERY rank when they differ (bounds or dictionaries were not agreed: sybl_table_agree) --
+ * instead of summing unrelated words or hanging.  Collectives hold the ctx's lock while they wait for the other ranks. */
 int sybl_query_allreduce(sybl_query *q);
+/* rank / number of ranks of the ctx's communicator (0 / 1 without one).  ABI 5. */
+int sybl_comm_info(const sybl_ctx *ctx, int32_t *rank, int32_t *nranks);
+/* COLLECTIVE over the ctx's communicator (sybl_comm_init), called by every rank once its shard of the table is resident
+ * (sybl_table_open with rank / nranks, or appended blocks) and again after a sybl_table_refresh that loaded blocks: the
+ * whole agreement a multi-GPU job needs before its partial tables line up, so that a host without a collective runtime
+ * of its own -- the Go host -- runs N ranks through this library alone.  (1) the ranks must hold the same columns
+ * (SYBL_E_STATE on every rank otherwise); (2) INT columns: bounds = the extrema over ALL ranks' rows (one MAX all-reduce,
+ * minima complemented), has_missing = any rank's -- what sybl_table_set_bounds declares by hand; (3) STR / SET columns:
+ * every rank installs the SORTED union of the ranks' dictionaries (sybl_table_set_dict; resident ids renumbered in place)
+ * and the union of has_missing; (4) for each int column of `group_cols` (the columns the host is about to group by, in
+ * -group order; NULL / 0 = none) whose agreed range the planner would group through a dictionary of distinct values: the
+ * union of the ranks' distinct values becomes every rank's dictionary (sybl_table_set_group_dict); when some rank -- or the
+ * union -- holds more values than a dictionary may, every rank's planner takes the hash table instead.  Without a
+ * communicator (one GPU) the call only sorts the str / set dictionaries, so that the order of equal-count groups in the
+ * output does not depend on how many GPUs ran the query.  Prepared queries must be prepared again.  Replaces the
+ * reference's key translation at merge time (aggregate.go:284-324,414-467; node_aggregator.go:147-177).  ABI 5. */
+int sybl_table_agree(sybl_table *t, const char *const *group_cols, int32_t n_group_cols);
 
 /* Hash group-by (group keys that do not direct-map: more than 2^27 possible cells, or a key column with more than 2^22
  * distinct values -- the reference's map[string]*Result, aggregate.go:186-200).  The scan aggregates into an

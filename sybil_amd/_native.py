@@ -151,6 +151,8 @@ SIGNATURES = {
     "sybl_comm_init": (C.c_int, [P, P, C.c_int32, C.c_int32]),
     "sybl_comm_free": (C.c_int, [P]),
     "sybl_query_allreduce": (C.c_int, [P]),
+    "sybl_comm_info": (C.c_int, [P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "sybl_table_agree": (C.c_int, [P, C.POINTER(C.c_char_p), C.c_int32]),
     "sybl_query_hash_keys": (C.c_int, [P, C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.c_int64)]),
     "sybl_query_hash_install_union": (C.c_int, [P, P, C.c_int64]),
     "sybl_query_finalize": (C.c_int, [P, C.POINTER(P)]),

@@ -130,6 +130,7 @@ struct Column {
     int64_t *d_gdict_keys = nullptr;
     int32_t *d_gdict_ranks = nullptr;
     uint32_t gdict_mask = 0;
+    bool gdict_refused = false;        // sybl_table_agree: some rank holds more distinct values than a dictionary may -- every rank's planner hashes
     int64_t gdict_gen = 0;             // bumped whenever gdict / its device map change (column_install_gdict)
     // The column as RANKS in its group dictionary (table.cpp: column_build_rank): a narrow derived column that a group-by on
     // a sparse int key direct-maps through -- rank_col->d_valid is BORROWED from this column.  Valid for (gdict_gen, Table::version).
@@ -439,6 +440,7 @@ struct Query {
     int64_t out_cap = 0;
     bool out_log_partial = false;  // the partial tables were merged across ranks: the log only holds this rank's values
     bool scanned = false;
+    bool layout_checked = false;   // the ranks compared their partial-table layouts (agree.cpp: query_check_layout, first collective of the query)
     sybl_run_stats stats{};
     bool never_matches = false;
     // hash group-by (strategy 7, hashgroup.hip): the cell table is an open-addressing table over the composite key; after
@@ -507,6 +509,9 @@ int query_summary_buffers(Query *q);  // (result.cpp) d_pct / d_mom / d_total + 
 // rccl.cpp: collectives on the ctx communicator and stream (SYBL_E_STATE without a communicator)
 int comm_allgather_inplace(Ctx *ctx, int64_t *buf, size_t words_per_rank);
 int comm_allreduce_sum(Ctx *ctx, int64_t *buf, size_t words);
+// agree.cpp
+bool group_key_wants_dict(unsigned __int128 card, int64_t cells);  // the planner's test, shared with sybl_table_agree
+int query_check_layout(Query *q);                                  // collective; an error on EVERY rank when the layouts differ
 // hashgroup.hip
 hipError_t launch_scan_hash(const ScanPlan *d_plan, int n_slots, int n_wg, size_t lds_bytes, hipStream_t st);
 hipError_t launch_scan_packed_n(const FastPlan &P, int nf, int ng, int na, int mode, bool time, int n_wg, size_t lds_bytes, hipStream_t st);

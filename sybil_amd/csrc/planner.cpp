@@ -889,8 +889,9 @@ struct Planner {
             // sparse / wide key range: one digit per DISTINCT value instead of one per value of the range
             const bool hash_ok = !env("SYBL_NO_HASH");
             if (c->type == SYBL_INT_VAL && !env("SYBL_NO_GDICT") &&
-                (c->gdict_blocks == -2 || card > ((unsigned __int128)1 << 22) || card * (unsigned __int128)cells > ((unsigned __int128)1 << 27))) {
-                rc = column_build_gdict(t, c);
+                (c->gdict_blocks == -2 || group_key_wants_dict(card, cells))) {
+                // (gdict_refused: the ranks found more distinct values between them than a dictionary holds -- sybl_table_agree)
+                rc = c->gdict_refused ? SYBL_E_INVAL : column_build_gdict(t, c);
                 if (rc == SYBL_OK) {
                     gi.dict = true;
                     card = c->gdict.size();

@@ -192,6 +192,10 @@ int sybl_query_allreduce(sybl_query *q) {
     if (!ctx->comm) return fail(SYBL_E_STATE, "no communicator: call sybl_comm_init first");
     SYBL_HIP(hipSetDevice(ctx->device));
     ncclComm_t comm = (ncclComm_t)ctx->comm;
+    {
+        int lrc = query_check_layout(q);
+        if (lrc) return lrc;
+    }
     if (ctx->comm_nranks > 1) q->out_log_partial = true;  // (until gather_outlier_logs has brought every rank's in)
     // Outlier values (plan.h: outlier log): every rank logged its own; the merged result needs all of them
     // (hist_basic.go:132-142,221-257: printed as buckets of their own).  The local count is read before the header is

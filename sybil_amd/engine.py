@@ -61,6 +61,11 @@ class Context:
     def comm_free(self):
         N.check(N.lib().sybl_comm_free(self._h))
 
+    def comm_info(self):
+        r, n = C.c_int32(), C.c_int32()
+        N.check(N.lib().sybl_comm_info(self._h, C.byref(r), C.byref(n)))
+        return r.value, n.value
+
     def create_table(self, name):
         h = C.c_void_p()
         N.check(N.lib().sybl_table_create(self._h, _b(name), C.byref(h)))
@@ -180,6 +185,12 @@ class Table:
 
     def set_bounds(self, name, lo, hi, has_missing=False):
         N.check(N.lib().sybl_table_set_bounds(self._h, _b(name), lo, hi, 1 if has_missing else 0))
+
+    def agree(self, group_cols=()):
+        """COLLECTIVE over the ctx's communicator (sybl_table_agree): bounds, has_missing, str / set dictionaries and the
+        group dictionaries of the sparse int keys among group_cols, identical on every rank afterwards."""
+        arr = (C.c_char_p * max(1, len(group_cols)))(*[_b(g) for g in group_cols])
+        N.check(N.lib().sybl_table_agree(self._h, arr if group_cols else None, len(group_cols)))
 
     def column_distinct(self, name):
         vals, n = C.POINTER(C.c_int64)(), C.c_int64()

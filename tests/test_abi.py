@@ -25,7 +25,7 @@ def test_header_symbols_are_exported_and_bound():
         assert hasattr(lib, name), "libsybilgpu.so does not export %s" % name
         assert name in _native.SIGNATURES, "no ctypes signature for %s" % name
     assert sorted(_native.SIGNATURES) == declared
-    assert lib.sybl_abi_version() == 4
+    assert lib.sybl_abi_version() == 5
 
 
 def test_header_compiles_as_plain_c(tmp_path):

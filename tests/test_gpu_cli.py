@@ -274,3 +274,13 @@ def test_c_example_runs(db, tmp_path):
     assert lines[1].split() == ["edge", "count", "4", "avg", "400.00", "p50", "500", "p99", "600"]
     assert lines[2].split()[:5] == ["gecko", "count", "2", "avg", "200.00"] and lines[3].split()[:5] == ["webkit", "count", "2", "avg", "700.00"]
     assert lines[4].startswith("-encode-results:")
+    # ... and as two ranks of a multi-GPU job (the table's two blocks: one each), the collectives through the test-only RCCL
+    # stand-in on this one device: rank 0 prints the same rows, rank 1 nothing
+    standin = os.path.join(ROOT, "tests", "rccl_standin", "librccl_standin.so")
+    env = dict(os.environ, LD_PRELOAD=standin, HSA_ENABLE_IPC_MODE_LEGACY="0", SYBL_STANDIN_TIMEOUT_S="120")
+    idf = str(tmp_path / "id")
+    procs = [subprocess.Popen([exe, db, "pages", "browser", "load", "100", str(r), "2", idf], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+             for r in range(2)]
+    outs = [pp.communicate(timeout=300) for pp in procs]
+    assert [pp.returncode for pp in procs] == [0, 0], outs
+    assert outs[0][0].decode().splitlines()[:4] == lines[:4] and outs[1][0] == b""

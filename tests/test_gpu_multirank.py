@@ -180,26 +180,30 @@ def test_inlibrary_collectives_across_gpus(tmp_path, oracle):
 
 
 @pytest.mark.parametrize("world", [2, 4])
-def test_loaded_table_across_ranks(tmp_path, world):
-    """The whole multi-GPU host protocol on a table that came from disk (tests/multirank_loaded_worker.py): ranks open their
-    block ranges, agree on bounds / str and set dictionaries / the sparse key's group dictionary over gloo, merge in the
-    library through the stand-in; rank 0's results must equal those of ONE rank that opened the whole table (whose parity with
-    the oracle is tests/test_gpu_loader.py's business) -- str keys, a sparse int key through the union dictionary's rank
-    column, a set-member filter, a regex id mask with negative values, a time series."""
+def test_loaded_table_across_ranks(tmp_path, world, oracle):
+    """The whole multi-GPU host protocol on a table that came from disk, through the C ABI alone
+    (tests/multirank_loaded_worker.py): ranks open their block ranges, agree on bounds / str and set dictionaries / the sparse
+    keys' group dictionaries inside the library (sybl_table_agree over the stand-in), merge, and rank 0's results must equal
+    the ORACLE's over the table's logical content -- and those of one rank that opened the whole table: str keys, a sparse int
+    key through the union dictionary's rank column, a set-member filter, a regex id mask with negative values, a time series,
+    a hashed two-key group-by whose keys both go through union dictionaries."""
     import sybil_amd
+    from tests import loaded_oracle as LO
     from tests import multirank_loaded_worker as LW
     from tests import sybil_fixture as F
     from tests.test_gpu_loader import _make_blocks
-    blocks, _ = _make_blocks(7, 3000, seed=77, ragged=True)
+    blocks, logical = _make_blocks(7, 3000, seed=77, ragged=True)
     root = str(tmp_path / "db")
-    F.write_table(root, "events", blocks, threshold=8, int_info={"big": (-(1 << 40), 1 << 40)})
+    F.write_table(root, "events", blocks, threshold=8, int_info={"big": LO.INFO_BIG})
+    lo = LO.LoadedOracle(oracle, logical, 8)
+    want = [LO.summarise_oracle(lo, q, lo.run(q)) for q in LW.QUERIES]
     ctx = sybil_amd.Context(0)
     tb = ctx.open_table(root, "events", compact=True)
-    want = []
+    one = []
     for q in LW.QUERIES:
         qy = tb.query(**q)
         r = qy.run()
-        want.append(LW.summarise(r))
+        one.append(LO.summarise_engine(r, q.get("op", "avg")))
         r.free()
         qy.free()
     total_rows = tb.rows
@@ -225,7 +229,9 @@ def test_loaded_table_across_ranks(tmp_path, world):
     assert [p.returncode for p in procs] == [0] * world, "\n".join(errs)
     got = pickle.load(open(os.path.join(work, "loaded.pkl"), "rb"))
     assert len(got["results"]) == len(want)
-    for i, (g, w) in enumerate(zip(got["results"], want)):
-        assert g["matched"] == w["matched"], (i, LW.QUERIES[i])
-        assert g["rows"] == w["rows"], (i, LW.QUERIES[i])
-    assert sum(1 for _ in blocks) == 7 and total_rows == sum(len(b["age"][1]) for b in blocks)
+    for i, (g, w, o) in enumerate(zip(got["results"], want, one)):
+        assert g["matched"] == w["matched"] == o["matched"], (i, LW.QUERIES[i])
+        assert g["rows"] == w["rows"], (i, LW.QUERIES[i], "vs the oracle")
+        assert g["rows"] == o["rows"], (i, LW.QUERIES[i], "vs one rank")
+    assert got["results"][-1]["strategy"] == 7
+    assert sum(1 for _ in blocks) == 7 and total_rows == sum(len(b["age"][1]) for b in blocks) == lo.n

@@ -7,9 +7,18 @@
 //
 //   sybil-gpu-query -dir db -table events -group browser,device -int pageload -op hist
 //       -int-filter "pageload:gt:100" -json
+//
+// Several GPUs: one process per GPU, each started with the same query plus  -gpu-rank i -gpu-ranks n -gpu-id-file path
+// (-device picks the GPU).  Rank i loads the i-th contiguous share of the table's block directories; rank 0 writes the
+// communicator's 128-byte id to the id file (as the reference ships its encoded flags to other hosts as files,
+// scripts/basic_aggregation_test.sh:12-21, config.go -encode-flags), the others wait for it; the ranks agree on bounds and
+// dictionaries (sybl_table_agree), scan, merge over RCCL (sybl_query_allreduce) and rank 0 prints -- the whole result,
+// where the reference's `sybil aggregate` (node_aggregator.go:147-177, cmd_aggregate.go:10) re-reads per-host gob files.
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
+#include <unistd.h>
 
 #include <map>
 #include <set>
@@ -43,7 +52,7 @@ int main(int argc, char **argv) {
         {"sort", "$COUNT"}, {"sort-asc", "false"}, {"time", "false"}, {"time-col", "time"}, {"time-bucket", "3600"},
         {"weight-col", ""}, {"int-filter", ""}, {"str-filter", ""}, {"set-filter", ""}, {"int-bucket", "0"},
         {"int", ""}, {"str", ""}, {"set", ""}, {"group", ""}, {"field-separator", ","}, {"filter-separator", ":"},
-        {"device", "0"}, {"block-skip", "true"}, {"stats", "false"}, {"encode-results", "false"}, {"loghist", "false"}, {"str-replace", ""}, {"distinct", ""},
+        {"device", "0"}, {"gpu-rank", "0"}, {"gpu-ranks", "1"}, {"gpu-id-file", ""}, {"block-skip", "true"}, {"stats", "false"}, {"encode-results", "false"}, {"loghist", "false"}, {"str-replace", ""}, {"distinct", ""},
         // accepted so that a command line written for `sybil query` runs unchanged; without effect here:
         //  -prune-sort / -distinct-limit bound the reference's intermediate results (aggregate.go:347-359, table_query.go:258-279:
         //   which groups survive depends on block completion order) -- this engine aggregates every group exactly and cuts at
@@ -139,15 +148,62 @@ int main(int argc, char **argv) {
     if (on("time")) use(f["time-col"]);
     use(f["weight-col"]);
 
+    const int rank = atoi(f["gpu-rank"].c_str()), nranks = atoi(f["gpu-ranks"].c_str());
+    if (nranks < 1 || rank < 0 || rank >= nranks) {
+        fprintf(stderr, "-gpu-rank %d is not one of -gpu-ranks %d\n", rank, nranks);
+        return 2;
+    }
+    if (nranks > 1 && f["gpu-id-file"].empty()) {
+        fprintf(stderr, "-gpu-ranks %d needs -gpu-id-file (rank 0 writes the communicator id there, the others read it)\n", nranks);
+        return 2;
+    }
     sybl_ctx *ctx = nullptr;
     if (sybl_init(atoi(f["device"].c_str()), &ctx)) return die("init");
+    if (nranks > 1) {
+        unsigned char id[128];
+        const std::string path = f["gpu-id-file"], tmp = path + ".tmp";
+        if (rank == 0) {
+            if (sybl_comm_unique_id(id)) return die("communicator id");
+            FILE *fp = fopen(tmp.c_str(), "wb");
+            if (!fp || fwrite(id, 1, sizeof(id), fp) != sizeof(id) || fclose(fp) != 0 || rename(tmp.c_str(), path.c_str()) != 0) {
+                fprintf(stderr, "sybil-gpu-query: cannot write %s\n", path.c_str());
+                return 1;
+            }
+        } else {
+            // (the file appears whole: rank 0 renames it into place)
+            const char *to = getenv("SYBIL_GPU_ID_TIMEOUT_S");
+            const time_t give_up = time(nullptr) + (to ? atoi(to) : 300);
+            size_t got = 0;
+            while (got != sizeof(id)) {
+                if (FILE *fp = fopen(path.c_str(), "rb")) {
+                    got = fread(id, 1, sizeof(id), fp);
+                    fclose(fp);
+                }
+                if (got != sizeof(id)) {
+                    if (time(nullptr) > give_up) {
+                        fprintf(stderr, "sybil-gpu-query: rank %d: no communicator id in %s\n", rank, path.c_str());
+                        return 1;
+                    }
+                    usleep(2000);
+                }
+            }
+        }
+        if (sybl_comm_init(ctx, id, nranks, rank)) return die("communicator");
+    }
     sybl_table *tab = nullptr;
     std::vector<const char *> cptr;
     for (auto &c : cols) cptr.push_back(c.c_str());
     // (compact storage: the columns at the narrowest width that holds their range -- what the packed scan kernels read)
-    if (sybl_table_open_flags(ctx, f["dir"].c_str(), f["table"].c_str(), cptr.empty() ? nullptr : cptr.data(), (int32_t)cptr.size(), 0, 1,
+    if (sybl_table_open_flags(ctx, f["dir"].c_str(), f["table"].c_str(), cptr.empty() ? nullptr : cptr.data(), (int32_t)cptr.size(), rank, nranks,
                               SYBL_OPEN_COMPACT, &tab))
         return die("open table");
+    // the ranks' bounds, dictionaries and sparse-key dictionaries become one (collective); one rank: dictionaries are sorted,
+    // so the output is the same whatever the number of GPUs
+    if (!getenv("SYBL_CLI_SKIP_AGREE")) {  // (the switch: tests/test_gpu_cli_multirank.py shows what the layout check then says)
+        std::vector<const char *> gp;
+        for (auto &g : groups) gp.push_back(g.c_str());
+        if (sybl_table_agree(tab, gp.empty() ? nullptr : gp.data(), (int32_t)gp.size())) return die("agree");
+    }
 
     static const std::map<std::string, int> opcode = {{"gt", SYBL_OP_GT}, {"lt", SYBL_OP_LT}, {"eq", SYBL_OP_EQ},
                                                       {"neq", SYBL_OP_NEQ}, {"re", SYBL_OP_RE}, {"nre", SYBL_OP_NRE},
@@ -217,9 +273,14 @@ int main(int argc, char **argv) {
     sybl_query *q = nullptr;
     if (sybl_query_prepare(tab, &d, &q)) return die("prepare");
     if (sybl_query_scan(q)) return die("scan");
+    if (nranks > 1 && sybl_query_allreduce(q)) return die("allreduce");
+    // (every rank finalizes: after a reduce-scatter or a printer's merge the finalize is itself collective --
+    // sybl_query_collective_finalize -- and a rank that only merged has nothing else left to do)
     sybl_result *res = nullptr;
     if (sybl_query_finalize(q, &res)) return die("finalize");
-    if (on("encode-results")) {
+    if (rank != 0) {
+        // rank 0 prints
+    } else if (on("encode-results")) {
         // PrintResults: -encode-results wins over -print (printer.go:291-297); gob NodeResults on stdout
         int64_t n = 0;
         const void *bytes = sybl_result_encode(res, &n);
@@ -233,6 +294,7 @@ int main(int argc, char **argv) {
     if (on("stats")) {
         sybl_run_stats st;
         sybl_query_stats(q, &st);
+        if (nranks > 1) fprintf(stderr, "rank %d/%d: ", rank, nranks);
         fprintf(stderr, "rows=%lld blocks=%lld skipped=%lld scan_ms=%.3f GB/s=%.1f strategy=%d\n", (long long)st.rows_scanned,
                 (long long)st.blocks_scanned, (long long)st.blocks_skipped, st.scan_ms,
                 st.scan_ms > 0 ? st.algorithmic_bytes / (st.scan_ms * 1e-3) / 1e9 : 0.0, st.strategy);
@@ -240,6 +302,7 @@ int main(int argc, char **argv) {
     sybl_result_free(res);
     sybl_query_free(q);
     sybl_table_free(tab);
+    if (nranks > 1) sybl_comm_free(ctx);
     sybl_shutdown(ctx);
     return 0;
 }
