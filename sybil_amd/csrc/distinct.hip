@@ -88,8 +88,8 @@ __device__ __forceinline__ void distinct_row(CPlan &P, const Tile<NC> &t, int r,
     hll_raise(P.hll + key * (uint64_t)kHllRegs, distinct_hash<NC>(P, t, r));
 }
 
-template <int NC>
-__global__ __launch_bounds__(kWgThreads) void k_scan_distinct(CPlan *Pp) {
+template <int NC, int T>  // (T threads per workgroup: kernels.hip, k_scan)
+__global__ __launch_bounds__(T) void k_scan_distinct(CPlan *Pp) {
     CPlan &P = *Pp;
     const int tid = threadIdx.x;
     const int s0 = P.wg_seg_begin[blockIdx.x], s1 = P.wg_seg_begin[blockIdx.x + 1];
@@ -101,8 +101,8 @@ __global__ __launch_bounds__(kWgThreads) void k_scan_distinct(CPlan *Pp) {
         RawTile<NC> raw;
         if (row < end) issue_tile<NC>(P, row, raw);
         decode_tile<NC>(P, row, row < end, raw, cur);
-        for (int64_t base = seg.start; base < end; base += kTileRows) {
-            const int64_t nrow = row + kTileRows;
+        for (int64_t base = seg.start; base < end; base += (T * kRowsPerThread)) {
+            const int64_t nrow = row + (T * kRowsPerThread);
             if (nrow < end) issue_tile<NC>(P, nrow, raw);
             const int64_t left = end - row;
             const int nvalid = left >= kRowsPerThread ? kRowsPerThread : (left > 0 ? (int)left : 0);
@@ -116,7 +116,15 @@ __global__ __launch_bounds__(kWgThreads) void k_scan_distinct(CPlan *Pp) {
 
 template <int NC>
 static hipError_t launch_nc(const ScanPlan *d_plan, int n_wg, hipStream_t st) {
-    hipLaunchKernelGGL((k_scan_distinct<NC>), dim3(n_wg), dim3(kWgThreads), 0, st, (CPlan *)d_plan);
+    int T = 1024;
+#ifdef SYBL_THREADS_AB  // (kernels.hip: launch_scan_nc)
+    if (const char *e = env("SYBL_SCAN_THREADS")) T = atoi(e);
+    if (T != 512 && T != 768) T = 1024;
+    auto kfn = T == 512 ? k_scan_distinct<NC, 512> : T == 768 ? k_scan_distinct<NC, 768> : k_scan_distinct<NC, 1024>;
+#else
+    auto kfn = k_scan_distinct<NC, 1024>;
+#endif
+    hipLaunchKernelGGL(kfn, dim3(n_wg), dim3(T), 0, st, (CPlan *)d_plan);
     return hipGetLastError();
 }
 

@@ -21,8 +21,13 @@ namespace sybl {
 // instantiation per (aggregations, mode, time) instead of one per column-count combination -- times two: MG = 2 or
 // kFastMaxG group columns compiled in (the tiles of every column a kernel could take are register arrays; with four
 // group columns next to three filters and two aggregations the 128 registers of a 1024-thread workgroup spilled).
-template <int NA, int MODE, bool TIME, int MG>
-__global__ __launch_bounds__(kWgThreads) void k_scan_hash_fast(const FastPlan P, uint64_t *hash_keys, const int nf, const int ng, const int L_,
+// T threads per workgroup: at 1024 the body is capped at 128 VGPRs and 20 of its 48 instantiations reserve scratch
+// (profiles/r05_kernel_resources.txt); at 768 / 512 threads none does (95-163 VGPRs) -- and config 3 through this kernel takes
+// 19.0 / 26.8 ms instead of 15.6 (profiles/r06_wg_threads_ab.txt, -DSYBL_THREADS_AB): what the body needs is waves in flight
+// (LDS round trips, scalar loads of the plan), not registers.  The spill is the cheaper evil; 1024 it stays.
+constexpr int kHashFastThreads = 1024;
+template <int NA, int MODE, bool TIME, int MG, int T>
+__global__ __launch_bounds__(T) void k_scan_hash_fast(const FastPlan P, uint64_t *hash_keys, const int nf, const int ng, const int L_,
                                                                const int F, const int M) {
     extern __shared__ int64_t lds[];
     __shared__ uint32_t l_used;
@@ -30,9 +35,9 @@ __global__ __launch_bounds__(kWgThreads) void k_scan_hash_fast(const FastPlan P,
     const uint32_t L = (uint32_t)L_;  // LDS staging slots (a power of two); 0: every row goes to the global table
     uint64_t *lkeys = (uint64_t *)lds;
     int64_t *lsum = lds + L, *lmax = lsum + (size_t)F * L;
-    for (uint32_t i = tid; i < L; i += kWgThreads) lkeys[i] = kHashEmpty;
-    for (uint32_t i = tid; i < (uint32_t)F * L; i += kWgThreads) lsum[i] = 0;
-    for (uint32_t i = tid; i < (uint32_t)M * L; i += kWgThreads) lmax[i] = INT64_MIN;
+    for (uint32_t i = tid; i < L; i += T) lkeys[i] = kHashEmpty;
+    for (uint32_t i = tid; i < (uint32_t)F * L; i += T) lsum[i] = 0;
+    for (uint32_t i = tid; i < (uint32_t)M * L; i += T) lmax[i] = INT64_MIN;
     if (tid == 0) l_used = 0;
     __syncthreads();
     int64_t *gsum = P.sum_out + kHeaderWords, *gmax = P.max_out;
@@ -133,8 +138,8 @@ __global__ __launch_bounds__(kWgThreads) void k_scan_hash_fast(const FastPlan P,
             issue(row);
             decode(row);
         }
-        for (; row < end; row += kTileRows) {
-            const int64_t nrow = row + kTileRows;
+        for (; row < end; row += (T * kRowsPerThread)) {
+            const int64_t nrow = row + (T * kRowsPerThread);
             if (nrow < end) issue(nrow);
             one_row(f0, g0, a0, t0, w0, 0);
             if (row + 1 < end) one_row(f0, g0, a0, t0, w0, 1);
@@ -145,7 +150,7 @@ __global__ __launch_bounds__(kWgThreads) void k_scan_hash_fast(const FastPlan P,
     // flush the staging table: one find-or-claim per staged key, one atomic per non-zero field
     if (L > 0) {
         __syncthreads();
-        for (uint32_t i = tid; i < L; i += kWgThreads) {
+        for (uint32_t i = tid; i < L; i += T) {
             const uint64_t k = lkeys[i];
             if (k == kHashEmpty) continue;
             const int32_t gs = hash_find_or_insert(hash_keys, gmask, k, P.sum_out);
@@ -173,10 +178,17 @@ __global__ __launch_bounds__(kWgThreads) void k_scan_hash_fast(const FastPlan P,
 
 template <int NA, int MODE, bool TIME>
 static hipError_t hash_fast_launch(const FastPlan &P, uint64_t *keys, int nf, int ng, int L, int F, int M, int n_wg, size_t lds_bytes, hipStream_t st) {
-    auto kfn = ng <= 2 ? k_scan_hash_fast<NA, MODE, TIME, 2> : k_scan_hash_fast<NA, MODE, TIME, kFastMaxG>;
+    int T = kHashFastThreads;
+    auto kfn = ng <= 2 ? k_scan_hash_fast<NA, MODE, TIME, 2, kHashFastThreads> : k_scan_hash_fast<NA, MODE, TIME, kFastMaxG, kHashFastThreads>;
+#ifdef SYBL_THREADS_AB
+    if (const char *e = env("SYBL_HASH_FAST_THREADS")) T = atoi(e);
+    if (T == 768) kfn = ng <= 2 ? k_scan_hash_fast<NA, MODE, TIME, 2, 768> : k_scan_hash_fast<NA, MODE, TIME, kFastMaxG, 768>;
+    if (T == 512) kfn = ng <= 2 ? k_scan_hash_fast<NA, MODE, TIME, 2, 512> : k_scan_hash_fast<NA, MODE, TIME, kFastMaxG, 512>;
+    if (T != 768 && T != 512) T = kHashFastThreads;
+#endif
     hipError_t e = hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max<size_t>(lds_bytes, 16));
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kfn, dim3(n_wg), dim3(kWgThreads), lds_bytes, st, P, keys, nf, ng, L, F, M);
+    hipLaunchKernelGGL(kfn, dim3(n_wg), dim3(T), lds_bytes, st, P, keys, nf, ng, L, F, M);
     return hipGetLastError();
 }
 

@@ -90,8 +90,8 @@ __device__ __forceinline__ void hash_row(CPlan &P, const Tile<NC> &cur, const in
     }
 }
 
-template <int NC>
-__global__ __launch_bounds__(kWgThreads) void k_scan_hash(CPlan *Pp) {
+template <int NC, int T>  // (T threads per workgroup: kernels.hip, k_scan)
+__global__ __launch_bounds__(T) void k_scan_hash(CPlan *Pp) {
     CPlan &P = *Pp;
     extern __shared__ int64_t lds[];
     __shared__ uint32_t l_used;
@@ -100,9 +100,9 @@ __global__ __launch_bounds__(kWgThreads) void k_scan_hash(CPlan *Pp) {
     const int F = P.n_sum_fields, M = P.n_max_fields;
     uint64_t *lkeys = (uint64_t *)lds;
     int64_t *lsum = lds + L, *lmax = lsum + (int64_t)F * L;
-    for (int64_t i = tid; i < L; i += kWgThreads) lkeys[i] = kHashEmpty;
-    for (int64_t i = tid; i < (int64_t)F * L; i += kWgThreads) lsum[i] = 0;
-    for (int64_t i = tid; i < (int64_t)M * L; i += kWgThreads) lmax[i] = INT64_MIN;
+    for (int64_t i = tid; i < L; i += T) lkeys[i] = kHashEmpty;
+    for (int64_t i = tid; i < (int64_t)F * L; i += T) lsum[i] = 0;
+    for (int64_t i = tid; i < (int64_t)M * L; i += T) lmax[i] = INT64_MIN;
     if (tid == 0) l_used = 0;
     __syncthreads();
     int64_t *gsum = P.sum_out + kHeaderWords, *gmax = P.max_out;
@@ -118,8 +118,8 @@ __global__ __launch_bounds__(kWgThreads) void k_scan_hash(CPlan *Pp) {
         RawTile<NC> raw;
         if (row < end) issue_tile<NC>(P, row, raw);
         decode_tile<NC>(P, row, row < end, raw, cur);
-        for (int64_t base = seg.start; base < end; base += kTileRows) {
-            const int64_t nrow = row + kTileRows;
+        for (int64_t base = seg.start; base < end; base += (T * kRowsPerThread)) {
+            const int64_t nrow = row + (T * kRowsPerThread);
             if (nrow < end) issue_tile<NC>(P, nrow, raw);
             const int64_t left = end - row;
             static_assert(kRowsPerThread == 2, "two rows per lane and tile");
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(kWgThreads) void k_scan_hash(CPlan *Pp) {
     // flush the staging table: one find-or-claim per staged key, one atomic per non-zero field
     if (L > 0) {
         __syncthreads();
-        for (int64_t i = tid; i < L; i += kWgThreads) {
+        for (int64_t i = tid; i < L; i += T) {
             const uint64_t k = lkeys[i];
             if (k == kHashEmpty) continue;
             const int32_t g = hash_find_or_insert(P.hash_keys, gmask, k, P.sum_out);
@@ -164,10 +164,17 @@ __global__ __launch_bounds__(kWgThreads) void k_scan_hash(CPlan *Pp) {
 
 template <int NC>
 static hipError_t launch_scan_hash_nc(const ScanPlan *d_plan, int n_wg, size_t lds_bytes, hipStream_t st) {
-    auto kfn = k_scan_hash<NC>;
+    int T = 1024;
+#ifdef SYBL_THREADS_AB  // (kernels.hip: launch_scan_nc)
+    if (const char *e = env("SYBL_SCAN_THREADS")) T = atoi(e);
+    if (T != 512 && T != 768) T = 1024;
+    auto kfn = T == 512 ? k_scan_hash<NC, 512> : T == 768 ? k_scan_hash<NC, 768> : k_scan_hash<NC, 1024>;
+#else
+    auto kfn = k_scan_hash<NC, 1024>;
+#endif
     hipError_t e = hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max<size_t>(lds_bytes, 16));
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kfn, dim3(n_wg), dim3(kWgThreads), lds_bytes, st, (CPlan *)d_plan);
+    hipLaunchKernelGGL(kfn, dim3(n_wg), dim3(T), lds_bytes, st, (CPlan *)d_plan);
     return hipGetLastError();
 }
 

@@ -20,8 +20,10 @@ namespace sybl {
 // with a multiplicative 32-bit hash; misses and the flush go through hash_find_or_insert like every other writer of the
 // global table.  nf / ng / time are run-time (wave-uniform) so that one instantiation per (aggregations, mode, NUL)
 // serves every column count; bucket arrays (hist mode) never stage in LDS and stay with k_scan_hash_fast.
-template <int NA, int MODE, bool NUL, bool HASH>
-__global__ __launch_bounds__(kWgThreads) void k_scan_hash_packed(const FastPlan P, uint64_t *hash_keys, const int nf, const int ng, const int time,
+// T threads per workgroup (hashfast.hip: 1024 threads cap the body at 128 VGPRs, and 30 of its 60 instantiations spilled
+// inside the row loop).
+template <int NA, int MODE, bool NUL, bool HASH, int T>
+__global__ __launch_bounds__(T) void k_scan_hash_packed(const FastPlan P, uint64_t *hash_keys, const int nf, const int ng, const int time,
                                                                  const int L_, const int F, const int M) {
     extern __shared__ int64_t lds[];
     __shared__ uint32_t l_used;
@@ -31,13 +33,13 @@ __global__ __launch_bounds__(kWgThreads) void k_scan_hash_packed(const FastPlan 
     int64_t *lsum = lds + L, *lmax = lsum + (size_t)F * L;
     FastLds DL = {};  // !HASH: the direct-mapped cell table of the k_scan_fast family (replicas, LDS window)
     if (HASH) {
-        for (uint32_t i = tid; i < L; i += kWgThreads) lkeys[i] = kHashEmpty;
-        for (uint32_t i = tid; i < (uint32_t)F * L; i += kWgThreads) lsum[i] = 0;
-        for (uint32_t i = tid; i < (uint32_t)M * L; i += kWgThreads) lmax[i] = INT64_MIN;
+        for (uint32_t i = tid; i < L; i += T) lkeys[i] = kHashEmpty;
+        for (uint32_t i = tid; i < (uint32_t)F * L; i += T) lsum[i] = 0;
+        for (uint32_t i = tid; i < (uint32_t)M * L; i += T) lmax[i] = INT64_MIN;
         if (tid == 0) l_used = 0;
         __syncthreads();
     } else {
-        DL = fast_begin<MODE>(P, lds);
+        DL = fast_begin<MODE, T>(P, lds);
     }
     int64_t *gsum = P.sum_out + kHeaderWords, *gmax = P.max_out;
     const uint32_t gmask = (uint32_t)P.n_cells - 1u;
@@ -264,16 +266,16 @@ __global__ __launch_bounds__(kWgThreads) void k_scan_hash_packed(const FastPlan 
                 issue(r);
                 if (xv) {
                     xpop = (P.xvalid[(first + r) >> 5] >> ((uint32_t)(first + r) & 31u)) & 0xFu;
-                    if (r + kPackedTileRows < n) xw_n = P.xvalid[(first + r + kPackedTileRows) >> 5];
+                    if (r + (uint32_t)(T * kPackedRows) < n) xw_n = P.xvalid[(first + r + (uint32_t)(T * kPackedRows)) >> 5];
                 }
                 decode(r);
             }
-            for (; r < n; r += kPackedTileRows) {
-                const uint32_t rn = r + kPackedTileRows;
+            for (; r < n; r += (uint32_t)(T * kPackedRows)) {
+                const uint32_t rn = r + (uint32_t)(T * kPackedRows);
                 const uint32_t xpop_n = xv ? (xw_n >> ((uint32_t)(first + rn) & 31u)) & 0xFu : 0xFu;
                 const bool more = rn < n && (!xv || __builtin_amdgcn_ballot_w64(xpop_n != 0) != 0);  // (wave-uniform)
                 if (more) issue(rn);
-                if (xv && rn + kPackedTileRows < n) xw_n = P.xvalid[(first + rn + kPackedTileRows) >> 5];
+                if (xv && rn + (uint32_t)(T * kPackedRows) < n) xw_n = P.xvalid[(first + rn + (uint32_t)(T * kPackedRows)) >> 5];
                 const uint32_t left = n - r;
 #pragma unroll
                 for (int k = 0; k < kPackedRows; k++) one_row(f, g, a, t, k, (uint32_t)k < left, xpop);
@@ -284,12 +286,12 @@ __global__ __launch_bounds__(kWgThreads) void k_scan_hash_packed(const FastPlan 
     }
 
     if (!HASH) {
-        fast_finish(P, lds, DL, matched, overflow);
+        fast_finish<T>(P, lds, DL, matched, overflow);
         return;
     }
     if (L > 0) {
         __syncthreads();
-        for (uint32_t i = tid; i < L; i += kWgThreads) {
+        for (uint32_t i = tid; i < L; i += T) {
             const uint64_t k = lkeys[i];
             if (k == kHashEmpty) continue;
             const int32_t gs = hash_find_or_insert(hash_keys, gmask, k, P.sum_out);
@@ -318,10 +320,17 @@ __global__ __launch_bounds__(kWgThreads) void k_scan_hash_packed(const FastPlan 
 template <int NA, int MODE, bool NUL, bool HASH = true>
 static hipError_t hash_packed_launch(const FastPlan &P, uint64_t *keys, int nf, int ng, int time, int L, int F, int M, int n_wg, size_t lds_bytes,
                                      hipStream_t st) {
-    auto kfn = k_scan_hash_packed<NA, MODE, NUL, HASH>;
+    int T = 1024;
+    auto kfn = k_scan_hash_packed<NA, MODE, NUL, HASH, 1024>;
+#ifdef SYBL_THREADS_AB  // (hashfast.hip: fewer threads, no spills -- and slower)
+    if (const char *e = env("SYBL_HASH_PACKED_THREADS")) T = atoi(e);
+    if (T == 768) kfn = k_scan_hash_packed<NA, MODE, NUL, HASH, 768>;
+    else if (T == 512) kfn = k_scan_hash_packed<NA, MODE, NUL, HASH, 512>;
+    else T = 1024;
+#endif
     hipError_t e = hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max<size_t>(lds_bytes, 16));
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kfn, dim3(n_wg), dim3(kWgThreads), lds_bytes, st, P, keys, nf, ng, time, L, F, M);
+    hipLaunchKernelGGL(kfn, dim3(n_wg), dim3(T), lds_bytes, st, P, keys, nf, ng, time, L, F, M);
     return hipGetLastError();
 }
 

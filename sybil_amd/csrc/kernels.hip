@@ -67,8 +67,9 @@ __device__ __forceinline__ void process_tile(CPlan &P, const Tile<NC> &t, int64_
     }
 }
 
-template <int NC, bool USE_LDS>
-__global__ __launch_bounds__(kWgThreads) void k_scan(CPlan *Pp) {
+// T threads per workgroup: at 1024 the wide bodies (NC >= 5) sat at the 128-VGPR cap and spilled inside the row loop.
+template <int NC, bool USE_LDS, int T>
+__global__ __launch_bounds__(T) void k_scan(CPlan *Pp) {
     CPlan &P = *Pp;
     extern __shared__ int64_t lds[];
     const int tid = threadIdx.x;
@@ -82,8 +83,8 @@ __global__ __launch_bounds__(kWgThreads) void k_scan(CPlan *Pp) {
         const int R = 1 << P.rep_shift;
         sumtab = lds;
         maxtab = lds + words_sum * R;
-        for (int64_t i = tid; i < words_sum * R; i += kWgThreads) sumtab[i] = 0;
-        for (int64_t i = tid; i < words_max * R; i += kWgThreads) maxtab[i] = INT64_MIN;
+        for (int64_t i = tid; i < words_sum * R; i += T) sumtab[i] = 0;
+        for (int64_t i = tid; i < words_max * R; i += T) maxtab[i] = INT64_MIN;
         rep = tid & (R - 1);
         __syncthreads();
     } else {
@@ -101,10 +102,10 @@ __global__ __launch_bounds__(kWgThreads) void k_scan(CPlan *Pp) {
         RawTile<NC> raw;
         if (row < end) issue_tile<NC>(P, row, raw);
         decode_tile<NC>(P, row, row < end, raw, cur);
-        for (int64_t base = seg.start; base < end; base += kTileRows) {
+        for (int64_t base = seg.start; base < end; base += (T * kRowsPerThread)) {
             // prefetch: the next tile's raw bits are in flight under the LDS work and are decoded (their
             // first use) only after it
-            const int64_t nrow = row + kTileRows;
+            const int64_t nrow = row + (T * kRowsPerThread);
             if (nrow < end) issue_tile<NC>(P, nrow, raw);
             int64_t left = end - row;
             int nvalid = left >= kRowsPerThread ? kRowsPerThread : (left > 0 ? (int)left : 0);
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(kWgThreads) void k_scan(CPlan *Pp) {
         if (P.windowed) {
             // flush the window into the global table: only touched cells, device-scope atomics
             int64_t *gs = P.sum_out + kHeaderWords;
-            for (int64_t i = tid; i < words_sum; i += kWgThreads) {
+            for (int64_t i = tid; i < words_sum; i += T) {
                 int64_t a = 0;
                 for (int k = 0; k < R; k++) a += sumtab[(i << P.rep_shift) + k];
                 if (a != 0) {
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(kWgThreads) void k_scan(CPlan *Pp) {
                     gadd(gs + f * P.n_cells + cell_base + c, a);
                 }
             }
-            for (int64_t i = tid; i < words_max; i += kWgThreads) {
+            for (int64_t i = tid; i < words_max; i += T) {
                 int64_t a = INT64_MIN;
                 for (int k = 0; k < R; k++) {
                     int64_t b = maxtab[(i << P.rep_shift) + k];
@@ -150,13 +151,13 @@ __global__ __launch_bounds__(kWgThreads) void k_scan(CPlan *Pp) {
             return;
         }
         int64_t *ws = P.ws_sum + (int64_t)blockIdx.x * words_sum;
-        for (int64_t i = tid; i < words_sum; i += kWgThreads) {
+        for (int64_t i = tid; i < words_sum; i += T) {
             int64_t a = 0;
             for (int k = 0; k < R; k++) a += sumtab[(i << P.rep_shift) + k];
             ws[i] = a;
         }
         int64_t *wm = P.ws_max + (int64_t)blockIdx.x * words_max;
-        for (int64_t i = tid; i < words_max; i += kWgThreads) {
+        for (int64_t i = tid; i < words_max; i += T) {
             int64_t a = INT64_MIN;
             for (int k = 0; k < R; k++) {
                 int64_t b = maxtab[(i << P.rep_shift) + k];
@@ -1251,13 +1252,27 @@ hipError_t launch_hist_gather(const int64_t *H, int64_t hist_stride, const int64
 
 template <int NC>
 static hipError_t launch_scan_nc(const ScanPlan *d_plan, int n_wg, bool use_lds, size_t lds_bytes, hipStream_t st) {
+    int T = 1024;
+#ifdef SYBL_THREADS_AB  // (tools/bench_threads.py: 768 / 512 threads measured 1.1x / 1.5x SLOWER, profiles/r06_wg_threads_ab.txt)
+    if (const char *e = env("SYBL_SCAN_THREADS")) T = atoi(e);
+    if (T != 512 && T != 768) T = 1024;
+#endif
     if (use_lds) {
-        auto kfn = k_scan<NC, true>;
+#ifdef SYBL_THREADS_AB
+        auto kfn = T == 512 ? k_scan<NC, true, 512> : T == 768 ? k_scan<NC, true, 768> : k_scan<NC, true, 1024>;
+#else
+        auto kfn = k_scan<NC, true, 1024>;
+#endif
         hipError_t e = hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kfn, dim3(n_wg), dim3(kWgThreads), lds_bytes, st, (CPlan *)d_plan);
+        hipLaunchKernelGGL(kfn, dim3(n_wg), dim3(T), lds_bytes, st, (CPlan *)d_plan);
     } else {
-        hipLaunchKernelGGL((k_scan<NC, false>), dim3(n_wg), dim3(kWgThreads), 0, st, (CPlan *)d_plan);
+#ifdef SYBL_THREADS_AB
+        auto kfn = T == 512 ? k_scan<NC, false, 512> : T == 768 ? k_scan<NC, false, 768> : k_scan<NC, false, 1024>;
+#else
+        auto kfn = k_scan<NC, false, 1024>;
+#endif
+        hipLaunchKernelGGL(kfn, dim3(n_wg), dim3(T), 0, st, (CPlan *)d_plan);
     }
     return hipGetLastError();
 }

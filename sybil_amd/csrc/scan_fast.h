@@ -552,7 +552,8 @@ struct FastLds {
     uint32_t *hist32;
 };
 
-template <int MODE>
+// (T: threads of the workgroup -- the strides of the table loops)
+template <int MODE, int T = kWgThreads>
 __device__ __forceinline__ FastLds fast_begin(const FastPlan &P, int64_t *lds) {
     FastLds L;
     const uint32_t tid = threadIdx.x;
@@ -562,11 +563,11 @@ __device__ __forceinline__ FastLds fast_begin(const FastPlan &P, int64_t *lds) {
     L.words_max = (uint32_t)P.n_max_fields * L.tab_cells;
     L.max_base = L.words_sum << P.rep_shift;
     L.cell_base = P.windowed ? (uint32_t)P.wg_cell_base[blockIdx.x] : 0u;
-    for (uint32_t i = tid; i < L.words_sum * R; i += kWgThreads) lds[i] = 0;
-    for (uint32_t i = tid; i < L.words_max * R; i += kWgThreads) lds[L.max_base + i] = INT64_MIN;
+    for (uint32_t i = tid; i < L.words_sum * R; i += T) lds[i] = 0;
+    for (uint32_t i = tid; i < L.words_max * R; i += T) lds[L.max_base + i] = INT64_MIN;
     L.hist32 = (uint32_t *)(lds + L.max_base + (L.words_max << P.rep_shift));
     L.hist_words = (MODE == kFastHist && P.hist_lds) ? L.tab_cells * (uint32_t)P.hist_stride : 0u;
-    for (uint32_t i = tid; i < L.hist_words; i += kWgThreads) L.hist32[i] = 0;
+    for (uint32_t i = tid; i < L.hist_words; i += T) L.hist32[i] = 0;
     L.rep = tid & (R - 1);
     __syncthreads();
     return L;
@@ -574,6 +575,7 @@ __device__ __forceinline__ FastLds fast_begin(const FastPlan &P, int64_t *lds) {
 
 // Publishes the workgroup's results: matched / overflow counters, LDS bucket arrays, and the cell
 // table -- flushed with atomics (LDS window) or stored to the workgroup's slice for k_fold.
+template <int T = kWgThreads>
 __device__ __forceinline__ void fast_finish(const FastPlan &P, int64_t *lds, const FastLds &L, uint32_t matched, uint32_t overflow) {
     const uint32_t tid = threadIdx.x;
     const uint32_t R = 1u << P.rep_shift;
@@ -591,7 +593,7 @@ __device__ __forceinline__ void fast_finish(const FastPlan &P, int64_t *lds, con
 
     __syncthreads();
     // LDS bucket arrays: one atomic per touched bucket per workgroup into the zeroed global table
-    for (uint32_t i = tid; i < L.hist_words; i += kWgThreads) {
+    for (uint32_t i = tid; i < L.hist_words; i += T) {
         const uint32_t x = L.hist32[i];
         if (x) __hip_atomic_fetch_add(P.sum_out + P.hist_off + (int64_t)L.cell_base * P.hist_stride + i, (int64_t)x, __ATOMIC_RELAXED,
                                      __HIP_MEMORY_SCOPE_AGENT);
@@ -599,7 +601,7 @@ __device__ __forceinline__ void fast_finish(const FastPlan &P, int64_t *lds, con
     if (P.windowed) {
         // flush the touched cells of this workgroup's window into the global table
         int64_t *gs = P.sum_out + kHeaderWords;
-        for (uint32_t i = tid; i < words_sum; i += kWgThreads) {
+        for (uint32_t i = tid; i < words_sum; i += T) {
             int64_t acc = 0;
             for (uint32_t k = 0; k < R; k++) acc += lds[(i << P.rep_shift) + k];
             if (acc != 0) {
@@ -607,7 +609,7 @@ __device__ __forceinline__ void fast_finish(const FastPlan &P, int64_t *lds, con
                 __hip_atomic_fetch_add(gs + (int64_t)fi * P.n_cells + L.cell_base + c, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
-        for (uint32_t i = tid; i < words_max; i += kWgThreads) {
+        for (uint32_t i = tid; i < words_max; i += T) {
             int64_t acc = INT64_MIN;
             for (uint32_t k = 0; k < R; k++) {
                 const int64_t b = lds[max_base + (i << P.rep_shift) + k];
@@ -622,13 +624,13 @@ __device__ __forceinline__ void fast_finish(const FastPlan &P, int64_t *lds, con
     }
     // fold the lane replicas and publish this workgroup's table (plain stores)
     int64_t *ws = P.ws_sum + (int64_t)blockIdx.x * words_sum;
-    for (uint32_t i = tid; i < words_sum; i += kWgThreads) {
+    for (uint32_t i = tid; i < words_sum; i += T) {
         int64_t acc = 0;
         for (uint32_t k = 0; k < R; k++) acc += lds[(i << P.rep_shift) + k];
         ws[i] = acc;
     }
     int64_t *wm = P.ws_max + (int64_t)blockIdx.x * words_max;
-    for (uint32_t i = tid; i < words_max; i += kWgThreads) {
+    for (uint32_t i = tid; i < words_max; i += T) {
         int64_t acc = INT64_MIN;
         for (uint32_t k = 0; k < R; k++) {
             const int64_t b = lds[max_base + (i << P.rep_shift) + k];
