@@ -1499,6 +1499,36 @@ struct Planner {
         return SYBL_OK;
     }
 
+    // FastPlan::cshift (scan_fast.h): in avg mode over compact storage, with every value populated, Result.Count shares an LDS
+    // word with aggregation 0's sum of stored offsets.  A word belongs to one (cell, replica): it takes the rows of the
+    // 1024 >> rep_shift lanes of that replica, each of which sees four rows of every tile of its workgroup -- that many rows, and
+    // that many times the column's largest offset, must fit below and above bit `cshift`.
+    void plan_count_packing() {
+        FastPlan &FP = q->fplan;
+        FP.cshift = 0;
+        if (!q->fast || !q->fast_packed || q->fast_packed_n || q->part_hist || FP.nul || q->fast_na < 1 || env("SYBL_NO_CPACK")) return;
+        if (q->fast_mode != kFastAvg && q->fast_mode != kFastAvgMax) return;
+        int64_t lane_rows = 0;
+        for (int w = 0; w < q->n_wg; w++) {
+            int64_t mine = 0;
+            for (int32_t si = q->wg_seg_begin[(size_t)w]; si < q->wg_seg_begin[(size_t)w + 1]; si++)
+                mine += (q->segs[(size_t)si].n + kPackedTileRows - 1) / kPackedTileRows * kPackedRows;
+            lane_rows = std::max(lane_rows, mine);
+        }
+        const unsigned __int128 slot_rows = (unsigned __int128)std::max<int64_t>(lane_rows, 1) * (unsigned __int128)(kWgThreads >> P.rep_shift);
+        const Column *c = t->cols[(size_t)q->aggs[0].col].get();
+        // (the stored offsets of the resident rows: exact extrema minus the storage base, never above what the width holds)
+        unsigned __int128 umax = c->elem >= 4 ? 0xFFFFFFFFull : c->elem == 2 ? 0xFFFFull : 0xFFull;
+        if (c->n_pop > 0 && c->exact_max >= c->vbase) umax = std::min<unsigned __int128>(umax, (unsigned __int128)((__int128)c->exact_max - (__int128)c->vbase));
+        auto bits = [](unsigned __int128 x) {
+            int b = 0;
+            while (x) b++, x >>= 1;
+            return b;
+        };
+        const int sum_bits = std::max(1, bits(umax * slot_rows)), count_bits = bits(slot_rows);
+        if (sum_bits + count_bits <= 64 && sum_bits < 63) FP.cshift = sum_bits;
+    }
+
     int window() {
         int rc;
         // ---- LDS-window strategy: a time-series table too large for LDS, scanned by workgroups whose
@@ -1568,6 +1598,7 @@ struct Planner {
         select_hash_fast(t, q, slot_col);
         prefilter_commit();
         if ((rc = select_part_hist(t, q, slot_col, rows_scanned))) return rc;
+        plan_count_packing();
         q->stats.rows_scanned = rows_scanned;
         q->stats.blocks_skipped = skipped;
         q->stats.blocks_scanned = (int64_t)t->blocks.size() - skipped;

@@ -80,7 +80,11 @@ struct FastPlan {
     int64_t info_min[kFastMaxA], max10[kFastMaxA];
     const int64_t *wcol;           // weight column (OPTS.WEIGHT_COL, aggregate.go:100-102), fully populated
     int32_t f_samples;             // Result.Samples field when weighted, else -1
-    int32_t pad2_;
+    // k_scan_packed, avg modes, every value populated: Result.Count rides in the high bits of aggregation 0's sum word --
+    // the row adds (1 << cshift) + offset with ONE LDS atomic instead of two (the LDS atomic unit is what bounds these bodies:
+    // profiles/r06_ldsrate.txt) -- and fast_finish takes the words apart replica by replica.  The planner sets it when a
+    // replica's rows and their offsets' sum provably fit (planner.cpp: plan_count_packing); 0 = Count has a word of its own.
+    int32_t cshift;
     // stored width (bytes: 1, 2, 4, 8) and value base per column: value = base + zero-extended raw
     // (canonical int64 columns: width 8, base 0 -- loaded as they are)
     int32_t fwid[kFastMaxF], gwid[kFastMaxG], awid[kFastMaxA], twid, wwid;
@@ -554,7 +558,7 @@ struct FastLds {
 
 // (T: threads of the workgroup -- the strides of the table loops)
 template <int MODE, int T = kWgThreads>
-__device__ __forceinline__ FastLds fast_begin(const FastPlan &P, int64_t *lds) {
+__device__ __forceinline__ FastLds fast_begin(const FastPlan &P, int64_t *lds, const bool max32 = false) {
     FastLds L;
     const uint32_t tid = threadIdx.x;
     const uint32_t R = 1u << P.rep_shift;
@@ -564,7 +568,8 @@ __device__ __forceinline__ FastLds fast_begin(const FastPlan &P, int64_t *lds) {
     L.max_base = L.words_sum << P.rep_shift;
     L.cell_base = P.windowed ? (uint32_t)P.wg_cell_base[blockIdx.x] : 0u;
     for (uint32_t i = tid; i < L.words_sum * R; i += T) lds[i] = 0;
-    for (uint32_t i = tid; i < L.words_max * R; i += T) lds[L.max_base + i] = INT64_MIN;
+    // (max32, k_scan_packed in avg mode: the MAX words hold uint32 OFFSETS in their low halves -- see fast_finish)
+    for (uint32_t i = tid; i < L.words_max * R; i += T) lds[L.max_base + i] = max32 ? 0 : INT64_MIN;
     L.hist32 = (uint32_t *)(lds + L.max_base + (L.words_max << P.rep_shift));
     L.hist_words = (MODE == kFastHist && P.hist_lds) ? L.tab_cells * (uint32_t)P.hist_stride : 0u;
     for (uint32_t i = tid; i < L.hist_words; i += T) L.hist32[i] = 0;
@@ -575,11 +580,52 @@ __device__ __forceinline__ FastLds fast_begin(const FastPlan &P, int64_t *lds) {
 
 // Publishes the workgroup's results: matched / overflow counters, LDS bucket arrays, and the cell
 // table -- flushed with atomics (LDS window) or stored to the workgroup's slice for k_fold.
+// max32 (k_scan_packed, avg mode): the MAX words hold the largest stored OFFSET of the field's aggregation in their low half; the
+// maximum is abase[a] + that offset where the cell's Count is not zero, and untouched (INT64_MIN) where it is.  FastPlan::cshift: Count and aggregation 0's sum of offsets share a word per replica.
 template <int T = kWgThreads>
-__device__ __forceinline__ void fast_finish(const FastPlan &P, int64_t *lds, const FastLds &L, uint32_t matched, uint32_t overflow) {
+__device__ __forceinline__ void fast_finish(const FastPlan &P, int64_t *lds, const FastLds &L, uint32_t matched, uint32_t overflow, const bool max32 = false) {
     const uint32_t tid = threadIdx.x;
     const uint32_t R = 1u << P.rep_shift;
-    const uint32_t words_sum = L.words_sum, words_max = L.words_max, max_base = L.max_base, tab_cells = L.tab_cells;
+    const uint32_t words_sum = L.words_sum, words_max = L.words_max, tab_cells = L.tab_cells;
+    const uint32_t cshift = (uint32_t)P.cshift, f_sum0 = (uint32_t)P.f_sum[0];
+    auto sum_of = [&](uint32_t i) -> int64_t {  // word i of the SUM section, replicas folded
+        if (cshift) {
+            const uint32_t fi = i / L.tab_cells, c = i - fi * L.tab_cells;
+            if (fi == 0 || fi == f_sum0) {
+                // (replica by replica: the replicas' sums added up may carry into the count's bits)
+                uint64_t cnt = 0, sm = 0;
+                const uint64_t mask = ((uint64_t)1 << cshift) - 1;
+                for (uint32_t k = 0; k < R; k++) {
+                    const uint64_t w = (uint64_t)lds[((f_sum0 * L.tab_cells + c) << P.rep_shift) + k];
+                    cnt += w >> cshift;
+                    sm += w & mask;
+                }
+                return fi == 0 ? (int64_t)cnt : (int64_t)(sm + cnt * (uint64_t)P.abase[0]);
+            }
+        }
+        int64_t acc = 0;
+        for (uint32_t k = 0; k < R; k++) acc += lds[(i << P.rep_shift) + k];
+        return acc;
+    };
+    auto max_of = [&](uint32_t i) -> int64_t {  // word i of the MAX section
+        if (max32) {
+            const uint32_t fi = i / L.tab_cells, c = i - fi * L.tab_cells;
+            if (sum_of(c) == 0) return INT64_MIN;  // (field 0: the cell's Count)
+            int64_t base = 0;
+#pragma unroll
+            for (int a = kFastMaxA - 1; a >= 0; a--)  // (downwards: the entries behind the query's aggregations are zeros)
+                if ((uint32_t)P.m_max[a] == fi) base = P.abase[a];
+            uint32_t m = 0;
+            for (uint32_t k = 0; k < R; k++) m = max(m, (uint32_t)(uint64_t)lds[L.max_base + (i << P.rep_shift) + k]);
+            return (int64_t)((uint64_t)base + (uint64_t)m);
+        }
+        int64_t acc = INT64_MIN;
+        for (uint32_t k = 0; k < R; k++) {
+            const int64_t b = lds[L.max_base + (i << P.rep_shift) + k];
+            acc = b > acc ? b : acc;
+        }
+        return acc;
+    };
     // matched rows: one add per wave (64-wide butterfly)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -602,19 +648,14 @@ __device__ __forceinline__ void fast_finish(const FastPlan &P, int64_t *lds, con
         // flush the touched cells of this workgroup's window into the global table
         int64_t *gs = P.sum_out + kHeaderWords;
         for (uint32_t i = tid; i < words_sum; i += T) {
-            int64_t acc = 0;
-            for (uint32_t k = 0; k < R; k++) acc += lds[(i << P.rep_shift) + k];
+            const int64_t acc = sum_of(i);
             if (acc != 0) {
                 const uint32_t fi = i / tab_cells, c = i - fi * tab_cells;
                 __hip_atomic_fetch_add(gs + (int64_t)fi * P.n_cells + L.cell_base + c, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         for (uint32_t i = tid; i < words_max; i += T) {
-            int64_t acc = INT64_MIN;
-            for (uint32_t k = 0; k < R; k++) {
-                const int64_t b = lds[max_base + (i << P.rep_shift) + k];
-                acc = b > acc ? b : acc;
-            }
+            const int64_t acc = max_of(i);
             if (acc != INT64_MIN) {
                 const uint32_t fi = i / tab_cells, c = i - fi * tab_cells;
                 __hip_atomic_fetch_max(P.max_out + (int64_t)fi * P.n_cells + L.cell_base + c, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -624,20 +665,9 @@ __device__ __forceinline__ void fast_finish(const FastPlan &P, int64_t *lds, con
     }
     // fold the lane replicas and publish this workgroup's table (plain stores)
     int64_t *ws = P.ws_sum + (int64_t)blockIdx.x * words_sum;
-    for (uint32_t i = tid; i < words_sum; i += T) {
-        int64_t acc = 0;
-        for (uint32_t k = 0; k < R; k++) acc += lds[(i << P.rep_shift) + k];
-        ws[i] = acc;
-    }
+    for (uint32_t i = tid; i < words_sum; i += T) ws[i] = sum_of(i);
     int64_t *wm = P.ws_max + (int64_t)blockIdx.x * words_max;
-    for (uint32_t i = tid; i < words_max; i += T) {
-        int64_t acc = INT64_MIN;
-        for (uint32_t k = 0; k < R; k++) {
-            const int64_t b = lds[max_base + (i << P.rep_shift) + k];
-            acc = b > acc ? b : acc;
-        }
-        wm[i] = acc;
-    }
+    for (uint32_t i = tid; i < words_max; i += T) wm[i] = max_of(i);
 }
 
 template <int NF, int NG, int NA, int MODE, bool TIME, bool GEN>

@@ -243,7 +243,8 @@ __device__ __forceinline__ uint32_t packed_udiv(uint32_t n, uint32_t d, double i
 
 // (OUT: the plain body with the outlier test -- a value beyond the last bucket is clipped and remembered, hist_basic.go:132-135:
 // what a fully populated tile of a NUL kernel runs when outliers are the only thing its plan asks of the NUL body)
-template <int NF, int NG, int NA, int MODE, bool TIME, bool NUL, bool FRESH = false, bool OUT = false>
+// (MAX32: avg mode's maxima as 32-bit OFFSETS -- see the kFastAvgMax branch; the caller has checked !ext_general once per tile)
+template <int NF, int NG, int NA, int MODE, bool TIME, bool NUL, bool FRESH = false, bool OUT = false, bool MAX32 = false>
 __device__ __forceinline__ void packed_row(const FastPlan &P0, const PackedTile<NF> &f, const PackedTile<NG> &g,
                                            const PackedTile<NA> &a, const PackedTile<1> &t, const int r, bool pass, int64_t *lds,
                                            const FastLds &L, uint32_t &matched, uint32_t &overflow, const uint32_t xpop = 0xFu) {
@@ -311,7 +312,10 @@ __device__ __forceinline__ void packed_row(const FastPlan &P0, const PackedTile<
     auto add = [&](uint32_t field, int64_t v) {
         __hip_atomic_fetch_add((int64_t *)(cell_p + field * fstep), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
-    add(0, 1);  // Result.Count++ (aggregate.go:203)
+    // avg modes with every value populated: Result.Count rides in the high bits of aggregation 0's sum word (FastPlan::cshift,
+    // wave-uniform; 0 = it has a word of its own) -- one LDS atomic less per row
+    const uint32_t cshift = ((MODE == kFastAvg || MODE == kFastAvgMax) && !NUL && !OUT && NA > 0) ? (uint32_t)P.cshift : 0u;
+    if (!cshift) add(0, 1);  // Result.Count++ (aggregate.go:203)
 #pragma unroll
     for (int c = 0; c < NA; c++) {
         const FastPlan &P = plan_fresh<FRESH>(P0);
@@ -325,9 +329,19 @@ __device__ __forceinline__ void packed_row(const FastPlan &P0, const PackedTile<
             }
         }
         const int64_t x = (int64_t)((uint64_t)P.abase[c] + u);
-        add((uint32_t)P.f_sum[c], x);
+        if (c == 0 && cshift) add((uint32_t)P.f_sum[0], (int64_t)(((uint64_t)1 << cshift) + u));  // Count++ and sum of OFFSETS
+        else add((uint32_t)P.f_sum[c], x);
         if (MODE == kFastAvgMax) {
-            if (!P.ext_general) {
+            if (MAX32) {
+                // BasicHist.Max (hist_basic.go:118-120) in the offset domain: max(v) = base + max(offset), so the lane's replica
+                // of the MAX word holds the largest OFFSET in its low half -- one ds_max_u32 that returns nothing, where the
+                // 64-bit form read the word, waited for it, compared and branched around a ds_max_i64 (two of those round trips
+                // per row of config 2).  (A gate read of an unreplicated uint32 table in front of a rare atomic measured SLOWER
+                // than the blind atomic: tools/micro/ldsrate.hip, profiles/r06_ldsrate.txt.)  A cell's maximum exists iff its
+                // Count is not zero: fast_finish rebuilds the value.
+                __hip_atomic_fetch_max((uint32_t *)(cell_p + ((uint32_t)P.n_sum_fields + (uint32_t)P.m_max[c]) * fstep), u, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else if (!P.ext_general) {
                 int64_t *m = (int64_t *)(cell_p + ((uint32_t)P.n_sum_fields + (uint32_t)P.m_max[c]) * fstep);
                 if (x > *m) __hip_atomic_fetch_max(m, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             } else {
@@ -399,7 +413,9 @@ template <int NF, int NG, int NA, int MODE, bool TIME, bool G1, bool NUL, int RI
 __global__ __launch_bounds__(kWgThreads, SYBL_PACKED_WAVES_PER_EU) void k_scan_packed(const FastPlan P) {
     extern __shared__ int64_t lds[];
     const uint32_t tid = threadIdx.x;
-    const FastLds L = fast_begin<MODE>(P, lds);
+    // avg mode, every value populated (the NUL kernels mix row bodies: they keep 64-bit maxima): maxima as 32-bit offsets
+    constexpr bool kMax32 = MODE == kFastAvgMax && !NUL;
+    const FastLds L = fast_begin<MODE>(P, lds, kMax32 && !P.ext_general);
 
     uint32_t matched = 0, overflow = 0;
     const int s0 = P.wg_seg_begin[blockIdx.x], s1 = P.wg_seg_begin[blockIdx.x + 1];
@@ -445,9 +461,15 @@ __global__ __launch_bounds__(kWgThreads, SYBL_PACKED_WAVES_PER_EU) void k_scan_p
                         packed_decode_all<NF, NG, NA, TIME, G1, false>(P, rf[d], rg[d], ra[d], rt[d], f, g, a, t, 0u);
                         packed_issue_ring<NF, NG, NA, TIME, G1>(P, B, r + (uint32_t)D * kPackedTileRows, n, rf[d], rg[d], ra[d], rt[d]);
                         const uint32_t left = r < n ? n - r : 0u;
+                        if (kMax32 && !P.ext_general) {  // (wave-uniform, once per tile)
 #pragma unroll
-                        for (int k = 0; k < kPackedRows; k++)
-                            packed_row<NF, NG, NA, MODE, TIME, false>(P, f, g, a, t, k, (uint32_t)k < left, lds, L, matched, overflow);
+                            for (int k = 0; k < kPackedRows; k++)
+                                packed_row<NF, NG, NA, MODE, TIME, false, false, false, true>(P, f, g, a, t, k, (uint32_t)k < left, lds, L, matched, overflow);
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < kPackedRows; k++)
+                                packed_row<NF, NG, NA, MODE, TIME, false>(P, f, g, a, t, k, (uint32_t)k < left, lds, L, matched, overflow);
+                        }
                     }
                 }
                 continue;
@@ -559,9 +581,15 @@ __global__ __launch_bounds__(kWgThreads, SYBL_PACKED_WAVES_PER_EU) void k_scan_p
                         issue_rest(r + kPackedTileRows, __builtin_amdgcn_ballot_w64(next_bits != 0) != 0);
                     }
                     issue_filters(r + 2u * kPackedTileRows);
+                    if (kMax32 && !P.ext_general) {  // (wave-uniform, once per tile)
 #pragma unroll
-                    for (int k = 0; k < kPackedRows; k++)
-                        packed_row<0, NG, NA, MODE, TIME, false>(P, f0, g, a, t, k, (bits >> k) & 1u, lds, L, matched, overflow);
+                        for (int k = 0; k < kPackedRows; k++)
+                            packed_row<0, NG, NA, MODE, TIME, false, false, false, true>(P, f0, g, a, t, k, (bits >> k) & 1u, lds, L, matched, overflow);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < kPackedRows; k++)
+                            packed_row<0, NG, NA, MODE, TIME, false>(P, f0, g, a, t, k, (bits >> k) & 1u, lds, L, matched, overflow);
+                    }
                     bits = next_bits;
                 }
                 continue;
@@ -604,6 +632,10 @@ __global__ __launch_bounds__(kWgThreads, SYBL_PACKED_WAVES_PER_EU) void k_scan_p
 #pragma unroll
                     for (int k = 0; k < kPackedRows; k++)
                         packed_row<NF, NG, NA, MODE, TIME, false, FRESH, true>(P, f, g, a, t, k, (uint32_t)k < left, lds, L, matched, overflow);
+                } else if (kMax32 && !P.ext_general) {  // (wave-uniform, once per tile; kMax32: not a NUL kernel)
+#pragma unroll
+                    for (int k = 0; k < kPackedRows; k++)
+                        packed_row<NF, NG, NA, MODE, TIME, false, FRESH, false, true>(P, f, g, a, t, k, (uint32_t)k < left, lds, L, matched, overflow);
                 } else {
 #pragma unroll
                     for (int k = 0; k < kPackedRows; k++)
@@ -614,7 +646,7 @@ __global__ __launch_bounds__(kWgThreads, SYBL_PACKED_WAVES_PER_EU) void k_scan_p
             }
         }
     }
-    fast_finish(P, lds, L, matched, overflow);
+    fast_finish(P, lds, L, matched, overflow, kMax32 && !P.ext_general);
 }
 
 // k_emit over compact storage (strategy 5, see k_emit in scan_fast.h): the same records, staged and
