@@ -423,6 +423,8 @@ void sybl_shutdown(sybl_ctx *ctx) {
     if (!ctx) return;
     sybl_comm_free(ctx);
     ctx_free_load_arena(ctx);
+    if (ctx->h2d_stage) (void)hipHostFree(ctx->h2d_stage);
+    if (ctx->d_copy_digest) (void)hipFree(ctx->d_copy_digest);
     if (ctx->aux_stream) hipStreamDestroy(ctx->aux_stream);
     if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
     for (auto &ls : ctx->load_streams)

@@ -66,6 +66,7 @@ hipError_t launch_hist_total(const int64_t *H, int64_t hist_stride, int64_t cell
 hipError_t launch_hist_gather(const int64_t *H, int64_t hist_stride, const int64_t *d_cells, int64_t n, int64_t cell0, int64_t cell1,
                               int64_t *out, hipStream_t st);
 
+hipError_t launch_copy_digest(const void *p, int64_t n_words, unsigned long long *out, hipStream_t st);  // SYBL_VERIFY_COPIES
 hipError_t create_side_stream(hipStream_t *out, int toward);  // engine.cpp: a stream on a priority level (and so hardware queues) of its own
 
 struct Ctx {
@@ -98,7 +99,16 @@ struct Ctx {
     // by the load that allocated it).
     char *load_arena_h = nullptr, *load_arena_d = nullptr;
     size_t load_arena_bytes = 0;
+    // host_to_device (table.cpp): the pinned staging buffer every copy of CALLER memory -- sybl_table_append_block's
+    // columns, dictionaries, look-up tables -- goes through (round 6; they were pageable hipMemcpyAsync before), and the
+    // device word SYBL_VERIFY_COPIES digests into
+    char *h2d_stage = nullptr;
+    size_t h2d_stage_bytes = 0;
+    unsigned long long *d_copy_digest = nullptr;
 };
+// dst (device) <- src (any host memory), `bytes` a multiple of 4, on the ctx stream, complete on return; under
+// SYBL_VERIFY_COPIES=1 the bytes in HBM are digested and compared with the host's: SYBL_E_NODEVICE when they differ
+int host_to_device(Ctx *ctx, void *dst, const void *src, size_t bytes, const char *what);
 void ctx_free_load_arena(Ctx *ctx);
 int load_sync_all(Ctx *ctx);  // waits for every load stream (no-op outside a multi-stream load)
 

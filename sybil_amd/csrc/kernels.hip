@@ -207,6 +207,28 @@ __global__ __launch_bounds__(256) void k_fill64(int64_t *p, int64_t n, int64_t v
     for (; i < n; i += stride) p[i] = v;
 }
 
+// ---------------------------------------------------------------- SYBL_VERIFY_COPIES
+// k_copy_digest: an order-free digest of n 32-bit words as they lie in HBM -- the sum of splitmix64(word + (index << 32)) --
+// compared with the same sum over the host bytes a host -> device copy was made from (table.cpp: host_to_device).  One
+// small kernel and an 8-byte read-back per copy, only under SYBL_VERIFY_COPIES=1: it exists because of ONE unexplained
+// event (round 5, DESIGN.md section 5: a freshly appended key column held ~1 KB of its neighbour's bytes) -- a repeat fails
+// at the copy that went wrong, not at a group count much later.
+__global__ __launch_bounds__(256) void k_copy_digest(const uint32_t *__restrict__ p, int64_t n, unsigned long long *out) {
+    unsigned long long acc = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        acc += splitmix64((uint64_t)p[i] + ((uint64_t)i << 32));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0 && acc) __hip_atomic_fetch_add(out, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+hipError_t launch_copy_digest(const void *p, int64_t n_words, unsigned long long *out, hipStream_t st) {
+    if (n_words <= 0) return hipSuccess;
+    const unsigned nb = (unsigned)std::min<int64_t>(1024, (n_words + 255) / 256);
+    hipLaunchKernelGGL(k_copy_digest, dim3(nb), dim3(256), 0, st, (const uint32_t *)p, n_words, out);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------- synthetic columns
 // Bit-identical to oracle/sybil_oracle.c:orc_synth_fill (the generator is ours, not the
 // reference's: SURVEY.md 8d).

@@ -14,6 +14,47 @@ namespace sybl {
 
 static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
+// Every copy of caller / heap memory into HBM on the append path (engine.h).  The bytes cross in pieces of the ctx's pinned
+// staging buffer -- the runtime's own staging of pageable hipMemcpyAsync sources is out of the picture --, each piece complete
+// before the buffer is reused.
+int host_to_device(Ctx *ctx, void *dst, const void *src, size_t bytes, const char *what) {
+    if (bytes == 0) return SYBL_OK;
+    constexpr size_t kPiece = (size_t)4 << 20;
+    hipStream_t st = ctx->stream;
+    if (!ctx->h2d_stage) {
+        SYBL_HIP(hipHostMalloc((void **)&ctx->h2d_stage, kPiece, hipHostMallocDefault));
+        ctx->h2d_stage_bytes = kPiece;
+    }
+    for (size_t at = 0; at < bytes; at += kPiece) {
+        const size_t n = std::min(kPiece, bytes - at);
+        memcpy(ctx->h2d_stage, (const char *)src + at, n);
+        SYBL_HIP(hipMemcpyAsync((char *)dst + at, ctx->h2d_stage, n, hipMemcpyHostToDevice, st));
+        SYBL_HIP(hipStreamSynchronize(st));
+    }
+    if (!env("SYBL_VERIFY_COPIES")) return SYBL_OK;
+    if (bytes % 4) return fail(SYBL_E_INVAL, "host_to_device(%s): %zu bytes are not whole words", what, bytes);
+    if (!ctx->d_copy_digest) SYBL_HIP(hipMalloc((void **)&ctx->d_copy_digest, 8));
+    // (test hook: one word of the destination is overwritten behind the copy -- what the guard is there to notice)
+    if (env("SYBL_VERIFY_COPIES_FAULT")) SYBL_HIP(hipMemsetAsync((char *)dst + (bytes / 8) * 4, 0x5A, 4, st));
+    SYBL_HIP(hipMemsetAsync(ctx->d_copy_digest, 0, 8, st));
+    hipError_t e = launch_copy_digest(dst, (int64_t)(bytes / 4), ctx->d_copy_digest, st);
+    if (e != hipSuccess) return hip_fail(e, "k_copy_digest");
+    unsigned long long got = 0, want = 0;
+    SYBL_HIP(hipMemcpyAsync(&got, ctx->d_copy_digest, 8, hipMemcpyDeviceToHost, st));
+    SYBL_HIP(hipStreamSynchronize(st));
+    const uint32_t *w = (const uint32_t *)src;
+    for (size_t i = 0; i < bytes / 4; i++) {
+        uint64_t z = (uint64_t)w[i] + ((uint64_t)i << 32) + 0x9E3779B97F4A7C15ull;  // splitmix64 (scan_generic.h)
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        want += z ^ (z >> 31);
+    }
+    if (got != want)
+        return fail(SYBL_E_NODEVICE, "SYBL_VERIFY_COPIES: %zu bytes of %s differ in HBM from the host bytes they were copied from (digest %016llx, expected %016llx)",
+                    bytes, what, got, want);
+    return SYBL_OK;
+}
+
 // ------------------------------------------------------------------ device arrays
 
 int table_reserve(Table *t, Column *c, int64_t phys_rows) {
@@ -78,7 +119,11 @@ int table_upload_blocks(Table *t) {
         SYBL_HIP(hipMalloc((void **)&t->d_blocks, (size_t)nb * sizeof(Segment)));
         t->d_blocks_n = nb;
     }
-    SYBL_HIP(hipMemcpyAsync(t->d_blocks, t->blocks.data(), (size_t)nb * sizeof(Segment), hipMemcpyHostToDevice, t->ctx->stream));
+    static_assert(sizeof(Segment) % 4 == 0, "whole words");
+    {
+        int rc = host_to_device(t->ctx, t->d_blocks, t->blocks.data(), (size_t)nb * sizeof(Segment), "block segments");
+        if (rc) return rc;
+    }
     return SYBL_OK;
 }
 
@@ -295,8 +340,7 @@ static int put_valid_bits(BlockWriter &w, Column *c, const uint8_t *populated, b
         std::vector<uint32_t> bits((size_t)(round_up(w.nrows, 32) / 32), 0);
         for (int64_t r = 0; r < w.nrows; r++)
             if (!populated || populated[r]) bits[(size_t)(r >> 5)] |= 1u << (r & 31);
-        SYBL_HIP(hipMemcpyAsync(valid, bits.data(), bits.size() * 4, hipMemcpyHostToDevice, w.t->ctx->stream));
-        SYBL_HIP(hipStreamSynchronize(w.t->ctx->stream));
+        if ((rc = host_to_device(w.t->ctx, valid, bits.data(), bits.size() * 4, "validity words"))) return rc;
     }
     return SYBL_OK;
 }
@@ -333,9 +377,7 @@ int block_col_int_host(BlockWriter &w, Column *c, const int64_t *vals, const uin
             }
         block_col_stats(w, c, mn, mx, pop);
     }
-    SYBL_HIP(hipMemcpyAsync(col, vals, (size_t)w.nrows * 8, hipMemcpyHostToDevice, st));
-    SYBL_HIP(hipStreamSynchronize(st));
-    return SYBL_OK;
+    return host_to_device(w.t->ctx, col, vals, (size_t)w.nrows * 8, c->name.c_str());
 }
 
 // ids: table-global dictionary ids
@@ -354,9 +396,7 @@ int block_col_str_host(BlockWriter &w, Column *c, const int32_t *global_ids, con
             }
         block_col_stats(w, c, mn, mx, pop);
     }
-    SYBL_HIP(hipMemcpyAsync(col, global_ids, (size_t)w.nrows * 4, hipMemcpyHostToDevice, st));
-    SYBL_HIP(hipStreamSynchronize(st));
-    return SYBL_OK;
+    return host_to_device(w.t->ctx, col, global_ids, (size_t)w.nrows * 4, c->name.c_str());
 }
 
 // CSR over the block's rows; member ids are table-global.  The host keeps the CSR mirror and
@@ -738,8 +778,9 @@ int column_install_gdict(Table *t, Column *c) {
     c->d_gdict_ranks = nullptr;
     SYBL_HIP(hipMalloc((void **)&c->d_gdict_keys, (size_t)cap * 8));
     SYBL_HIP(hipMalloc((void **)&c->d_gdict_ranks, (size_t)cap * 4));
-    SYBL_HIP(hipMemcpy(c->d_gdict_keys, keys.data(), (size_t)cap * 8, hipMemcpyHostToDevice));
-    SYBL_HIP(hipMemcpy(c->d_gdict_ranks, ranks.data(), (size_t)cap * 4, hipMemcpyHostToDevice));
+    int rc;
+    if ((rc = host_to_device(t->ctx, c->d_gdict_keys, keys.data(), (size_t)cap * 8, "group dictionary keys"))) return rc;
+    if ((rc = host_to_device(t->ctx, c->d_gdict_ranks, ranks.data(), (size_t)cap * 4, "group dictionary ranks"))) return rc;
     c->gdict_mask = cap - 1;
     c->gdict_gen++;
     return SYBL_OK;
@@ -797,11 +838,16 @@ int column_upload_set(Table *t, Column *c) {
     c->d_set_off = nullptr;
     c->d_set_vals = nullptr;
     SYBL_HIP(hipMalloc((void **)&c->d_set_off, off.size() * 8));
-    SYBL_HIP(hipMemcpy(c->d_set_off, off.data(), off.size() * 8, hipMemcpyHostToDevice));
+    {
+        int rc = host_to_device(t->ctx, c->d_set_off, off.data(), off.size() * 8, "set offsets");
+        if (rc) return rc;
+    }
     size_t nv = std::max<size_t>(c->h_set_vals.size(), 1);
     SYBL_HIP(hipMalloc((void **)&c->d_set_vals, nv * 4));
-    if (!c->h_set_vals.empty())
-        SYBL_HIP(hipMemcpy(c->d_set_vals, c->h_set_vals.data(), c->h_set_vals.size() * 4, hipMemcpyHostToDevice));
+    if (!c->h_set_vals.empty()) {
+        int rc = host_to_device(t->ctx, c->d_set_vals, c->h_set_vals.data(), c->h_set_vals.size() * 4, "set members");
+        if (rc) return rc;
+    }
     c->set_vals_cap = (int64_t)nv;
     c->set_dirty = false;
     return SYBL_OK;
@@ -1082,7 +1128,13 @@ int sybl_table_set_dict(sybl_table *t, const char *name, const char *const *stri
         if (rc) return rc;
         int32_t *d_lut = nullptr;
         SYBL_HIP(hipMalloc((void **)&d_lut, lut.size() * 4));
-        SYBL_HIP(hipMemcpyAsync(d_lut, lut.data(), lut.size() * 4, hipMemcpyHostToDevice, st));
+        {
+            int rc2 = host_to_device(t->ctx, d_lut, lut.data(), lut.size() * 4, "dictionary look-up table");
+            if (rc2) {
+                hipFree(d_lut);
+                return rc2;
+            }
+        }
         hipError_t e = launch_remap_ids((const int32_t *)c->d_data, 4, d_lut, (int32_t)lut.size(), t->phys_rows, (int32_t *)c->d_data, st);
         if (e != hipSuccess) {
             hipFree(d_lut);

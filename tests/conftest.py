@@ -6,6 +6,10 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# The whole suite runs with the append path's copy guard on (csrc/table.cpp: host_to_device -- every host -> device copy of
+# caller memory is digested in HBM and compared with the host bytes; child processes inherit it).  It exists because of one
+# unexplained wrong-keys event in round 5: a repeat fails at the copy, loudly.
+os.environ.setdefault("SYBL_VERIFY_COPIES", "1")
 
 
 def pytest_configure(config):
