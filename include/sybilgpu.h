@@ -482,6 +482,9 @@ typedef struct {
     int32_t n_sum_fields;     /* int64 fields per cell in the SUM section */
     int32_t n_max_fields;     /* fields per cell in the MAX section; 0 = nothing to MAX-reduce */
     int32_t packed_kernel;    /* 1: the scan ran k_scan_packed (compact storage, 32-bit offset domain) */
+    int32_t count_pass_reused;/* strategy 5: 1 = the last scan reused the per-(workgroup, bin) record counts its query's first scan
+                               * took (they depend on the table's rows, the filters and the key columns only) and skipped the
+                               * counting pass over the key column.  ABI 5. */
 } sybl_run_stats;
 /* Valid after the stream has been synchronised (sybl_query_finalize / sybl_ctx_sync). */
 int sybl_query_stats(sybl_query *q, sybl_run_stats *out);

@@ -92,7 +92,7 @@ class RunStats(C.Structure):
                 ("algorithmic_bytes", C.c_int64), ("canonical_bytes", C.c_int64), ("scan_ms", C.c_double), ("reduce_ms", C.c_double),
                 ("n_cells", C.c_int32), ("strategy", C.c_int32), ("lds_bytes", C.c_int32),
                 ("n_workgroups", C.c_int32), ("replicas", C.c_int32), ("n_sum_fields", C.c_int32),
-                ("n_max_fields", C.c_int32), ("packed_kernel", C.c_int32)]
+                ("n_max_fields", C.c_int32), ("packed_kernel", C.c_int32), ("count_pass_reused", C.c_int32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -10,7 +10,6 @@
 // (node_aggregator.go:147-177, aggregate.go:414-467: CombineResults by GroupByKey), so it needs no agreement -- and
 // ships every group of every node to one host.  Here keys are digits of a direct-mapped cell, and a digit must mean the
 // same value on every GPU.
-#include <rccl/rccl.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -19,6 +18,7 @@
 #include <vector>
 
 #include "engine.h"
+#include "rccl_lazy.h"
 
 using namespace sybl;
 

@@ -84,7 +84,20 @@ __device__ __forceinline__ void distinct_row(CPlan &P, const Tile<NC> &t, int r,
     int64_t w;
     // rows the scan drops or reports (no time value; key outside the declared bounds) own no Result here either
     if (row_prepare<NC>(P, t, r, row0, key, w) != kRowOk) return;
-    if (key >= (uint64_t)P.n_cells) return;
+    if (P.hll_keys) {
+        // hashed group-by: the row's Result is the one of its composite key (aggregate.go:186-200: map[string]*Result) -- its
+        // place in the sorted key list (a key the table could not take has none)
+        int64_t lo = 0, hi = P.hll_nkeys;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (P.hll_keys[mid] < key) lo = mid + 1;
+            else hi = mid;
+        }
+        if (lo >= P.hll_nkeys || P.hll_keys[lo] != key) return;
+        key = (uint64_t)lo;
+    } else if (key >= (uint64_t)P.n_cells) {
+        return;
+    }
     hll_raise(P.hll + key * (uint64_t)kHllRegs, distinct_hash<NC>(P, t, r));
 }
 

@@ -22,7 +22,7 @@ using gobenc::Fields;
 enum GobId : int {  // builtin ids, then ours in definition order
     G_BOOL = 1, G_INT = 2, G_FLOAT = 4, G_STRING = 6, G_IFACE = 8,
     T_NODE = 65, T_QSPEC, T_QPARAMS, T_GROUPING, T_GROUPINGS, T_AGG, T_AGGS, T_QRESULTS, T_RESULT, T_HISTMAP, T_RESULTMAP,
-    T_TIMEMAP, T_SORTED, T_HISTCOMPAT, T_BASICHIST, T_CACHED, T_I64S, T_INTINFO, T_F64S, T_MULTICOMPAT, T_MULTI, T_SUBHISTS,
+    T_TIMEMAP, T_SORTED, T_HISTCOMPAT, T_BASICHIST, T_CACHED, T_I64S, T_INTINFO, T_F64S, T_MULTICOMPAT, T_MULTI, T_SUBHISTS, T_LOGLOG,
 };
 
 struct GobStream {
@@ -71,6 +71,17 @@ struct GobStream {
         common(w, name, id);
         w.u(1);
         w.i(elem);
+        w.u(0);
+        w.u(0);
+        message(w.b);
+    }
+    // a type that marshals itself (wireType.BinaryMarshalerT: gobEncoderType{CommonType}); its values travel as byte strings
+    void def_binary_marshaler(int id, const char *name) {
+        GobW w;
+        w.i(-id);
+        w.u(6);  // wireType.BinaryMarshalerT
+        w.u(1);
+        common(w, name, id);
         w.u(0);
         w.u(0);
         message(w.b);
@@ -260,7 +271,7 @@ static void gob_hist(GobW &w, const Result *R, const sybl_agg_out &o, int a) {
     w.b += v.b;
 }
 
-static void gob_result(GobW &w, const Result *R, const RowStore &row, size_t n_groups) {
+static void gob_result(GobW &w, const Result *R, const RowStore &row, size_t n_groups, const uint8_t *regs = nullptr) {
     Fields f(w);
     bool any = false;
     for (int a = 0; a < R->n_aggs; a++) any = any || R->agg_pool[(size_t)row.agg_off + a].present;
@@ -283,14 +294,25 @@ static void gob_result(GobW &w, const Result *R, const RowStore &row, size_t n_g
     }
     f.put_int(3, row.count);
     f.put_int(4, row.samples);
+    if (R->has_distinct && regs) {
+        // Result.Distinct *hll.LogLogBeta (query_spec.go:87) as a self-marshalling value: one byte of precision (14) and the
+        // 16384 registers, in register order.  PARITY UNPINNED: github.com/logv/loglogbeta is not in the reference tree and
+        // no reference test holds an encoded sketch; a `sybil aggregate` built against the real dependency may expect
+        // another blob.  The registers are the ones sybl_result_distinct hands out (merge = register-wise maximum).
+        f.at(5);
+        w.u((uint64_t)(1 + SYBL_HLL_REGISTERS));
+        const char prec = 14;
+        w.b.append(&prec, 1);
+        w.b.append((const char *)regs, (size_t)SYBL_HLL_REGISTERS);
+    }
     f.end();
 }
 
-static void gob_result_map(GobW &w, const Result *R, const std::vector<RowStore> &rows, size_t i0, size_t i1, size_t n_groups) {
+static void gob_result_map(GobW &w, const Result *R, const std::vector<RowStore> &rows, size_t i0, size_t i1, size_t n_groups, int which = 0) {
     w.u(i1 - i0);
     for (size_t i = i0; i < i1; i++) {
         w.s(rows[i].gbk());
-        gob_result(w, R, rows[i], n_groups);
+        gob_result(w, R, rows[i], n_groups, R->has_distinct ? R->row_registers(which, rows[i]) : nullptr);
     }
 }
 
@@ -302,12 +324,6 @@ const void *sybl_result_encode(sybl_result *r, int64_t *n_bytes) {
     if (R) result_ensure_rows(R);
     if (!R || !n_bytes) {
         set_error("sybl_result_encode: NULL argument");
-        return nullptr;
-    }
-    if (R->has_distinct) {
-        // Result.Distinct is a *hll.LogLogBeta: how gob sees it is the dependency's business (its only field is
-        // unexported), and that library is not in the reference tree -- sybl_result_distinct hands the registers out
-        set_error("-encode-results of a count-distinct result is not supported (the wire form of loglogbeta's sketch is unpinned)");
         return nullptr;
     }
     if (R->loghist) {
@@ -338,8 +354,15 @@ const void *sybl_result_encode(sybl_result *r, int64_t *n_bytes) {
     S.def_struct(T_QRESULTS, "QueryResults",
                  {{"Cumulative", T_RESULT}, {"Results", T_RESULTMAP}, {"TimeResults", T_TIMEMAP}, {"MatchedCount", G_INT},
                   {"Sorted", T_SORTED}});
-    S.def_struct(T_RESULT, "Result",
-                 {{"Hists", T_HISTMAP}, {"GroupByKey", G_STRING}, {"BinaryByKey", G_STRING}, {"Count", G_INT}, {"Samples", G_INT}});
+    if (R->has_distinct) {
+        S.def_struct(T_RESULT, "Result",
+                     {{"Hists", T_HISTMAP}, {"GroupByKey", G_STRING}, {"BinaryByKey", G_STRING}, {"Count", G_INT}, {"Samples", G_INT},
+                      {"Distinct", T_LOGLOG}});
+        S.def_binary_marshaler(T_LOGLOG, "LogLogBeta");
+    } else {
+        S.def_struct(T_RESULT, "Result",
+                     {{"Hists", T_HISTMAP}, {"GroupByKey", G_STRING}, {"BinaryByKey", G_STRING}, {"Count", G_INT}, {"Samples", G_INT}});
+    }
     S.def_map(T_HISTMAP, "map[string]sybil.Histogram", G_STRING, G_IFACE);
     S.def_map(T_RESULTMAP, "ResultMap", G_STRING, T_RESULT);
     S.def_map(T_TIMEMAP, "map[int]sybil.ResultMap", G_INT, T_RESULTMAP);
@@ -403,7 +426,7 @@ const void *sybl_result_encode(sybl_result *r, int64_t *n_bytes) {
     {
         Fields qr(w);
         qr.at(0);  // Cumulative
-        gob_result(w, R, R->rows[2][0], 0);
+        gob_result(w, R, R->rows[2][0], 0, R->has_distinct ? R->row_registers(2, R->rows[2][0]) : nullptr);
         if (!R->rows[0].empty()) {
             qr.at(1);  // Results
             gob_result_map(w, R, R->rows[0], 0, R->rows[0].size(), ng);
@@ -418,7 +441,7 @@ const void *sybl_result_encode(sybl_result *r, int64_t *n_bytes) {
                 size_t j = i;
                 while (j < tr.size() && tr[j].time_bucket == tr[i].time_bucket) j++;
                 w.i(tr[i].time_bucket);
-                gob_result_map(w, R, tr, i, j, ng);
+                gob_result_map(w, R, tr, i, j, ng, 1);
                 i = j;
             }
         }
@@ -426,7 +449,8 @@ const void *sybl_result_encode(sybl_result *r, int64_t *n_bytes) {
         if (!R->rows[0].empty() && !R->order_by.empty()) {
             qr.at(4);  // Sorted []*Result (SortResults, aggregate.go:497-525): the rows are already in that order
             w.u(R->rows[0].size());
-            for (size_t i = 0; i < R->rows[0].size(); i++) gob_result(w, R, R->sorted0(i), ng);
+            for (size_t i = 0; i < R->rows[0].size(); i++)
+                gob_result(w, R, R->sorted0(i), ng, R->has_distinct ? R->row_registers(0, R->sorted0(i)) : nullptr);
         }
         qr.end();
     }

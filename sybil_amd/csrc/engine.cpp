@@ -10,6 +10,7 @@
 //   sybl_query_scan           <- the block loop of LoadAndQueryRecords (table_query.go:96-231)
 // There is no CPU fallback in this file: without a HIP device every call fails.
 #include "engine.h"
+#include "hll.h"
 #include "re2lite.h"
 
 #include <math.h>
@@ -166,10 +167,46 @@ static int ensure_partials(Query *q) {
 // Count distinct: the sketches start empty and are filled by a pass of their own behind the scan (distinct.hip).
 static int scan_distinct(Query *q, bool ran, hipStream_t st) {
     if (!q->n_distinct) return SYBL_OK;
+    if (q->hash_mode) {
+        // which Results exist is only known once the table has been compacted (and, across ranks, the key sets united): the
+        // pass runs then, over the same rows (query_hash_distinct, from the snapshot / the all-reduce)
+        q->distinct_pending = ran;
+        q->hll_bytes = 0;
+        return SYBL_OK;
+    }
     SYBL_HIP(hipMemsetAsync(q->d_hll, 0, (size_t)q->hll_bytes, st));
     if (!ran) return SYBL_OK;
     hipError_t e = launch_scan_distinct(q->d_dplan, q->dplan.n_slots, q->n_wg, st);
     if (e != hipSuccess) return hip_fail(e, "k_scan_distinct");
+    return SYBL_OK;
+}
+
+// Count distinct over a hashed group-by (aggregate.go:205-243 with the map of aggregate.go:186-200): a sketch per key of the
+// dense, sorted key list -- sized here, because only now is the list final --, filled by k_scan_distinct over the rows the scan
+// saw, each row finding its key's place by binary search.
+int query_hash_distinct(Query *q) {
+    if (!q->hash_mode || !q->n_distinct) return SYBL_OK;
+    hipStream_t st = q->ctx->stream;
+    const int64_t n = q->hash_live;
+    const int64_t bytes = std::max<int64_t>(n, 1) * (int64_t)kHllRegs;
+    if (bytes > ((int64_t)8 << 30))
+        return fail(SYBL_E_INVAL, "count distinct: %lld groups x 16 KB of sketch exceed 8 GiB", (long long)n);
+    if (!q->distinct_pending && q->hll_bytes == bytes) return SYBL_OK;  // (the sketches of this key set are there)
+    if (q->d_hll) SYBL_HIP(hipFree(q->d_hll));
+    q->d_hll = nullptr;
+    SYBL_HIP(hipMalloc((void **)&q->d_hll, (size_t)bytes));
+    SYBL_HIP(hipMemsetAsync(q->d_hll, 0, (size_t)bytes, st));
+    q->hll_bytes = bytes;
+    if (n > 0 && q->scanned) {
+        q->dplan.hll = q->d_hll;
+        q->dplan.hll_keys = q->d_dense_keys;
+        q->dplan.hll_nkeys = n;
+        SYBL_HIP(hipMemcpyAsync(q->d_dplan, &q->dplan, sizeof(ScanPlan), hipMemcpyHostToDevice, st));
+        SYBL_HIP(hipStreamSynchronize(st));  // (the plan is read from pageable memory)
+        hipError_t e = launch_scan_distinct(q->d_dplan, q->dplan.n_slots, q->n_wg, st);
+        if (e != hipSuccess) return hip_fail(e, "k_scan_distinct");
+    }
+    q->distinct_pending = false;
     return SYBL_OK;
 }
 
@@ -242,10 +279,20 @@ static int scan(Query *q) {
         for (auto &pp : q->part_more) pp.E.store_nt = q->eplan.store_nt;
         q->pplan.sum_out = q->d_sum;
         q->pplan.max_out = q->d_max;
-        // counting sort: count per (workgroup, bin) -> exact regions -> scatter
-        e = q->part_packed ? launch_count_packed(q->eplan, q->part_nf, q->part_ng, q->n_wg, st)
-                           : launch_count(q->eplan, q->part_nf, q->part_ng, q->n_wg, st);
-        if (e != hipSuccess) return hip_fail(e, "k_count");
+        // counting sort: count per (workgroup, bin) -> exact regions -> scatter.  The counts are a function of the table's rows,
+        // the query's filters and key columns and the workgroups' row shares -- all fixed for the life of a prepared query (a
+        // table that changes makes it stale: SYBL_E_STATE) -- and nothing downstream writes them (k_emit and k_part_hist read
+        // boff; wbase is re-derived from it): like the block statistics they are taken once, by the query's first scan, and a
+        // rescan skips the pass (config 4: 0.32 ms and a 2 GB read of the key column per step).  Queries of three or four
+        // aggregations run the sequence twice over the one table of counts and keep counting.  SYBL_NO_COUNT_CACHE=1: every scan.
+        const bool reuse_counts = q->count_cached && q->part_more.empty() && !env("SYBL_NO_COUNT_CACHE");
+        if (!reuse_counts) {
+            e = q->part_packed ? launch_count_packed(q->eplan, q->part_nf, q->part_ng, q->n_wg, st)
+                               : launch_count(q->eplan, q->part_nf, q->part_ng, q->n_wg, st);
+            if (e != hipSuccess) return hip_fail(e, "k_count");
+            q->count_cached = q->part_more.empty();
+        }
+        q->stats.count_pass_reused = reuse_counts ? 1 : 0;
         trace.mark("count");
         e = q->part_packed ? launch_emit_packed(q->eplan, q->part_nf, q->part_ng, q->part_na, q->n_wg, st)
                            : launch_emit(q->eplan, q->part_nf, q->part_ng, q->part_na, q->n_wg, st);

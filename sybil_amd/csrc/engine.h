@@ -97,8 +97,14 @@ struct Ctx {
     // the loader's staging arena (loader.cpp: SlabPool), kept between loads: pinning and unpinning a few hundred MB cost
     // every sybl_table_open / sybl_table_refresh tens of milliseconds.  Freed by sybl_shutdown (SYBL_LOADER_KEEP_ARENA=0:
     // by the load that allocated it).
-    char *load_arena_h = nullptr, *load_arena_d = nullptr;
-    size_t load_arena_bytes = 0;
+    // (round 6: it grows in CHUNKS of a few slabs, each pinned when the load first needs it -- a cold open used to pin all
+    // ~280 MB before its first worker had a slab to parse into: ~0.1 s of a 0.28 s open in a fresh process)
+    struct ArenaChunk {
+        char *h = nullptr, *d = nullptr;
+        size_t slabs = 0;
+    };
+    std::vector<ArenaChunk> load_chunks;
+    size_t load_slab_bytes = 0;  // bytes per slab the chunks were carved for (another size: the arena starts over)
     // host_to_device (table.cpp): the pinned staging buffer every copy of CALLER memory -- sybl_table_append_block's
     // columns, dictionaries, look-up tables -- goes through (round 6; they were pageable hipMemcpyAsync before), and the
     // device word SYBL_VERIFY_COPIES digests into
@@ -382,6 +388,7 @@ struct Query {
     char *d_hll_chars = nullptr;       // several columns, a str column among them: the dictionaries' strings + offsets (plan.h: hll_mixed)
     int64_t *d_hll_stroff = nullptr;
     int64_t hll_bytes = 0;
+    bool distinct_pending = false;     // hashed group-by: the sketch pass has yet to run over the final key set (query_hash_distinct)
     bool time_mode = false;
     int64_t time_bucket = 0;
     std::string order_by;
@@ -505,6 +512,7 @@ struct Query {
     };
     std::vector<PartPass> part_more;
     uint32_t *d_recs = nullptr, *d_cursor = nullptr;
+    bool count_cached = false;  // d_cursor holds the count pass's regions for this query's rows (engine.cpp: a rescan skips k_count)
 };
 
 int plan_query(Table *t, const sybl_query_desc *d, Query *q);  // planner.cpp
@@ -534,6 +542,7 @@ hipError_t launch_scan_hash_fast(const FastPlan &P, uint64_t *keys, int nf, int 
 hipError_t launch_scan_distinct(const ScanPlan *d_plan, int n_slots, int n_wg, hipStream_t st);
 int query_hash_reset(Query *q);     // every slot free (before a scan)
 int query_hash_compact(Query *q);   // live slots -> dense arrays in key order
+int query_hash_distinct(Query *q);  // (engine.cpp) count distinct over a hashed group-by: the sketch pass, once the dense keys are final
 int query_hash_install_union(Query *q, const uint64_t *keys, int64_t n);                // host keys
 int query_hash_install_union_device(Query *q, const uint64_t *d_union, int64_t n);      // device keys
 int hash_union_of_lists(Query *q, const uint64_t *d_lists, int64_t total, uint64_t **out, int64_t *n_out);

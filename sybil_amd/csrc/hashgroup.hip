@@ -451,6 +451,7 @@ int query_hash_install_union_device(Query *q, const uint64_t *d_union, int64_t n
     q->d_dense_keys = own_keys.release<uint64_t>();
     q->dense_keys_cap = key_cap;
     q->hash_live = n;
+    if (q->n_distinct) q->distinct_pending = true;  // (count distinct: the sketches follow the key list -- engine.cpp: query_hash_distinct)
     return SYBL_OK;
 }
 

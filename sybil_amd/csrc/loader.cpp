@@ -114,24 +114,33 @@ struct SlabPool {
     std::vector<int> free_;
     std::deque<int> pending;  // applied, event recorded, not yet known to be finished
     size_t slab_bytes = 0, max_slabs = 0;
-    char *arena_h = nullptr, *arena_d = nullptr;
     Ctx *ctx = nullptr;
-    // (the arena belongs to the context and outlives the load: Ctx::load_arena_h)
+    static constexpr size_t kChunkSlabs = 8;
+    // (the arena belongs to the context and outlives the load: Ctx::load_chunks)
     int init(Ctx *c) {
         ctx = c;
-        const size_t need = slab_bytes * max_slabs;
-        if (c->load_arena_bytes < need) {
+        if (c->load_slab_bytes != slab_bytes) {
             ctx_free_load_arena(c);
-            SYBL_HIP(hipHostMalloc((void **)&c->load_arena_h, need, hipHostMallocDefault));
-            hipError_t e = hipMalloc((void **)&c->load_arena_d, need);
+            c->load_slab_bytes = slab_bytes;
+        }
+        return SYBL_OK;
+    }
+    // the k-th slab's pinned / device pair; the chunk that holds it is allocated now if this load is the first to get there
+    int slab_memory(size_t k, char **h, char **d) {
+        const size_t ci = k / kChunkSlabs;
+        while (ctx->load_chunks.size() <= ci) {
+            Ctx::ArenaChunk ch;
+            ch.slabs = kChunkSlabs;
+            SYBL_HIP(hipHostMalloc((void **)&ch.h, slab_bytes * kChunkSlabs, hipHostMallocDefault));
+            hipError_t e = hipMalloc((void **)&ch.d, slab_bytes * kChunkSlabs);
             if (e != hipSuccess) {
-                ctx_free_load_arena(c);
+                (void)hipHostFree(ch.h);
                 return hip_fail(e, "hipMalloc(loader arena)");
             }
-            c->load_arena_bytes = need;
+            ctx->load_chunks.push_back(ch);
         }
-        arena_h = c->load_arena_h;
-        arena_d = c->load_arena_d;
+        *h = ctx->load_chunks[ci].h + (k % kChunkSlabs) * slab_bytes;
+        *d = ctx->load_chunks[ci].d + (k % kChunkSlabs) * slab_bytes;
         return SYBL_OK;
     }
     // *out = -1 when no slab can be had right now (must_wait: block until the oldest pending one is done)
@@ -151,8 +160,8 @@ struct SlabPool {
         }
         if (free_.empty() && slabs.size() < max_slabs) {
             Slab s;
-            s.h = arena_h + slabs.size() * slab_bytes;
-            s.d = arena_d + slabs.size() * slab_bytes;
+            int rc = slab_memory(slabs.size(), &s.h, &s.d);
+            if (rc) return rc;
             SYBL_HIP(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
             s.cap = slab_bytes;
             slabs.push_back(s);
@@ -179,10 +188,12 @@ struct SlabPool {
 };
 
 void ctx_free_load_arena(Ctx *ctx) {
-    if (ctx->load_arena_h) (void)hipHostFree(ctx->load_arena_h);
-    if (ctx->load_arena_d) (void)hipFree(ctx->load_arena_d);
-    ctx->load_arena_h = ctx->load_arena_d = nullptr;
-    ctx->load_arena_bytes = 0;
+    for (auto &ch : ctx->load_chunks) {
+        if (ch.h) (void)hipHostFree(ch.h);
+        if (ch.d) (void)hipFree(ch.d);
+    }
+    ctx->load_chunks.clear();
+    ctx->load_slab_bytes = 0;
 }
 
 // Worker threads of one table load (std::async started a thread per block: 1600 thread creations, 27 us each on the

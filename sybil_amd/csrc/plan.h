@@ -179,7 +179,11 @@ struct ScanPlan {
     // raises one register of its cell's sketch.  Int columns: the hashed buffer holds 8 bytes per column in list order
     // (distinct_slot[i] = the slot of the i-th column).  One str column: the hash of (string + "\t") was computed per
     // dictionary id on the host (hll_idhash; hll_missing for a row without the column).
-    uint8_t *hll;                // [n_cells][kHllRegs]
+    uint8_t *hll;                // [n_cells][kHllRegs]; hashed group-by: [hll_nkeys][kHllRegs], a sketch per dense key
+    // hashed group-by (round 6): the query's sorted composite keys as they stand when the pass runs -- after the scan's
+    // compaction and, across ranks, the key union --; a row's sketch is the one of its key's place in that list
+    const uint64_t *hll_keys;
+    int64_t hll_nkeys;
     const uint64_t *hll_idhash;
     uint64_t hll_missing;
     int64_t hll_ids;

@@ -1686,8 +1686,9 @@ struct Planner {
         const int n = d->n_distincts;
         if (n <= 0) return SYBL_OK;
         if (n > kMaxDistinct) return fail(SYBL_E_INVAL, "too many distinct columns (%d > %d)", n, kMaxDistinct);
-        if (q->hash_mode) return fail(SYBL_E_INVAL, "count distinct needs a group key that maps directly to cells (this one goes through the hash table)");
-        if (n_cells * (int64_t)kHllRegs > ((int64_t)8 << 30))
+        // (a hashed group-by keeps a sketch per key it FOUND: sized, filled and merged once the key set is final --
+        // engine.cpp: query_hash_distinct)
+        if (!q->hash_mode && n_cells * (int64_t)kHllRegs > ((int64_t)8 << 30))
             return fail(SYBL_E_INVAL, "count distinct: %lld groups x 16 KB of sketch exceed 8 GiB", (long long)n_cells);
         std::vector<Column *> cols;
         int n_str = 0;
@@ -1724,8 +1725,10 @@ struct Planner {
             D.distinct_slot[i] = s;
         }
         D.n_distinct = n;
-        q->hll_bytes = n_cells * (int64_t)kHllRegs;
-        SYBL_HIP(hipMalloc((void **)&q->d_hll, (size_t)q->hll_bytes));
+        D.hll_keys = nullptr;
+        D.hll_nkeys = 0;
+        q->hll_bytes = q->hash_mode ? 0 : n_cells * (int64_t)kHllRegs;
+        if (!q->hash_mode) SYBL_HIP(hipMalloc((void **)&q->d_hll, (size_t)q->hll_bytes));
         D.hll = q->d_hll;
         D.hll_mixed = n_str > 0 && n > 1;
         for (int i = 0; i < 8; i++) {

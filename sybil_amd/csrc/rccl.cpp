@@ -6,16 +6,49 @@
 // (node_aggregator.go:147-177).  Here every rank holds an identically laid out integer
 // table, so the merge is one SUM all-reduce (counts, sums, buckets) plus one MAX
 // all-reduce (extrema; minima are stored negated) over RCCL / xGMI.
-#include <rccl/rccl.h>
+#include <dlfcn.h>
 #include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
 #include <vector>
 
 #include "engine.h"
+#include "rccl_lazy.h"
 
 using namespace sybl;
+
+namespace sybl {
+const RcclApi &rccl() {
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, []() {
+        void *lib = nullptr;
+        auto find = [&](const char *name) -> void * {
+            if (void *p = dlsym(RTLD_DEFAULT, name)) return p;  // already in the process (the host's, torch's, a preloaded stand-in)
+            if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+            if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+            return lib ? dlsym(lib, name) : nullptr;
+        };
+#define SYBL_BIND(field, sym) api.field = (decltype(api.field))find(sym)
+        SYBL_BIND(GetUniqueId, "ncclGetUniqueId");
+        SYBL_BIND(CommInitRank, "ncclCommInitRank");
+        SYBL_BIND(CommDestroy, "ncclCommDestroy");
+        SYBL_BIND(GetErrorString, "ncclGetErrorString");
+        SYBL_BIND(AllReduce, "ncclAllReduce");
+        SYBL_BIND(AllGather, "ncclAllGather");
+        SYBL_BIND(ReduceScatter, "ncclReduceScatter");
+        SYBL_BIND(GroupStart, "ncclGroupStart");
+        SYBL_BIND(GroupEnd, "ncclGroupEnd");
+#undef SYBL_BIND
+        api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.GetErrorString && api.AllReduce && api.AllGather && api.ReduceScatter &&
+                 api.GroupStart && api.GroupEnd;
+        if (!api.ok) api.why = "librccl.so.1 is neither in this process nor on the library path";
+    });
+    return api;
+}
+}  // namespace sybl
 
 static int nccl_fail(ncclResult_t r, const char *what) {
     return fail(SYBL_E_NODEVICE, "RCCL error: %s in %s", ncclGetErrorString(r), what);
@@ -92,7 +125,13 @@ static int query_hash_allreduce(Query *q) {
         if (rc) return rc;
     }
     const int64_t n = q->hash_live;
+    // count distinct: every rank fills a sketch per key of the UNION (its own rows), then the register-wise maximum
+    if (q->n_distinct) {
+        q->distinct_pending = true;  // (the key set just changed under whatever an earlier pass made)
+        if ((rc = query_hash_distinct(q))) return rc;
+    }
     SYBL_NCCL(ncclGroupStart());
+    if (q->n_distinct && n > 0) SYBL_NCCL_G(ncclAllReduce(q->d_hll, q->d_hll, (size_t)q->hll_bytes, ncclUint8, ncclMax, comm, st));
     SYBL_NCCL_G(ncclAllReduce(q->d_dense_sum, q->d_dense_sum, (size_t)hash_dense_sum_words(q, n), ncclInt64, ncclSum, comm, st));
     if (q->plan.n_max_fields > 0 && n > 0)
         SYBL_NCCL_G(ncclAllReduce(q->d_dense_max, q->d_dense_max, (size_t)hash_dense_max_words(q, n), ncclInt64, ncclMax, comm, st));
@@ -152,6 +191,7 @@ extern "C" {
 int sybl_comm_unique_id(void *id128) {
     if (!id128) return fail(SYBL_E_INVAL, "id buffer is NULL");
     static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    if (!rccl().ok) return fail(SYBL_E_NODEVICE, "no RCCL: %s", rccl().why);
     ncclUniqueId id;
     SYBL_NCCL(ncclGetUniqueId(&id));
     memcpy(id128, &id, sizeof(id));
@@ -162,6 +202,7 @@ int sybl_comm_init(sybl_ctx *ctx, const void *id128, int32_t nranks, int32_t ran
     SYBL_API_GUARD(ctx);
     if (!ctx || !id128 || nranks <= 0 || rank < 0 || rank >= nranks) return fail(SYBL_E_INVAL, "sybl_comm_init: bad argument");
     if (ctx->comm) return fail(SYBL_E_STATE, "communicator already initialised");
+    if (!rccl().ok) return fail(SYBL_E_NODEVICE, "no RCCL: %s", rccl().why);
     SYBL_HIP(hipSetDevice(ctx->device));
     ncclUniqueId id;
     memcpy(&id, id128, sizeof(id));

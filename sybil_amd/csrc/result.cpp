@@ -459,6 +459,7 @@ int query_snapshot(Query *q) {
     const ScanPlan &P = q->plan;
     if (q->hash_mode) {
         int rc = query_hash_compact(q);  // (no-op when the all-reduce already did it)
+        if (!rc) rc = query_hash_distinct(q);  // (count distinct: the sketches of the final key set, unless the all-reduce made them)
         if (rc) return rc;
     }
     // a hash group-by snapshots its dense, key-ordered arrays, whose size follows the keys found
@@ -1010,12 +1011,14 @@ int query_finalize(Query *q, Result **out) {
         // ---- count distinct (query_spec.go:87,180-188): every row's sketch and its Cardinality()
         R->has_distinct = q->n_distinct > 0;
         if (R->has_distinct) {
-            R->hll_cells = P.n_cells;
-            R->hll.resize((size_t)(P.n_cells + 2) * kHllRegs);
+            // (a hashed group-by: a sketch per dense key -- a row's cell is its key's place in the sorted list)
+            const int64_t hll_cells = q->hash_mode ? q->hash_live : (int64_t)P.n_cells;
+            R->hll_cells = hll_cells;
+            R->hll.resize((size_t)(hll_cells + 2) * kHllRegs);
             // the pass that fills the sketches (and their all-reduce) was queued on the context's stream: copy behind it
             SYBL_HIP(hipMemcpyAsync(R->hll.data(), q->d_hll, (size_t)q->hll_bytes, hipMemcpyDeviceToHost, q->ctx->stream));
             SYBL_HIP(hipStreamSynchronize(q->ctx->stream));
-            uint8_t *total_regs = R->hll.data() + (size_t)P.n_cells * kHllRegs;
+            uint8_t *total_regs = R->hll.data() + (size_t)hll_cells * kHllRegs;
             memset(total_regs, 0, 2 * (size_t)kHllRegs);
             if (!q->time_mode) {
                 // Cumulative combines every Result (aggregate.go:431-434): the register-wise maximum.  (In a time series it

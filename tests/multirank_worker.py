@@ -35,6 +35,8 @@ CASES = {
     "tiny_hash": (["c01", "c02", "c07"], dict(groups=["c01", "c02"], aggs=["c07"], op="hist", want_percentiles=False), {"SYBL_FORCE_HASH": "1"},
                   dict(total=150_000)),
     "distinct": (["c01", "c05", "c06"], dict(groups=["c01"], distincts=["c05", "c06"], filters=[("c06", "lt", 500)]), {}, {}),
+    # ... over a hashed group-by (round 6): the sketch pass runs on every rank over the UNION of the ranks' keys, then the MAX
+    "distinct_hash": (["c01", "c02", "c05"], dict(groups=["c01", "c02"], distincts=["c05"]), {"SYBL_FORCE_HASH": "1"}, {}),
 }
 
 

@@ -221,3 +221,64 @@ def test_cli_text_and_json(ctx, oracle, tmp_path):
     gres.free()
     q.free()
     tb.free()
+
+
+@pytest.mark.parametrize("forced", [True, False])
+def test_hashed_group_by_keeps_a_sketch_per_key_it_found(ctx, oracle, monkeypatch, forced):
+    """Count distinct over a group-by that goes through the hash table (round 6; refused before): the sketch pass runs once
+    the dense key list is final, every row finding its key's place by binary search.  forced: a small key space sent
+    through the table (SYBL_FORCE_HASH); else two keys whose product of ranges does not direct-map."""
+    rng = np.random.default_rng(23)
+    n = 600_000
+    if forced:
+        monkeypatch.setenv("SYBL_FORCE_HASH", "1")
+        cols = {"g": rng.integers(0, 40, n), "h": rng.integers(-5, 5, n), "user": rng.integers(0, 50_000, n), "f": rng.integers(0, 1000, n)}
+    else:
+        # 2^31 x 2^31 possible cells, a few thousand live ones
+        pool_g, pool_h = rng.integers(0, 1 << 31, 60), rng.integers(0, 1 << 31, 50)
+        cols = {"g": pool_g[rng.integers(0, 60, n)], "h": pool_h[rng.integers(0, 50, n)], "user": rng.integers(0, 50_000, n), "f": rng.integers(0, 1000, n)}
+        monkeypatch.setenv("SYBL_NO_GDICT", "1")  # (the keys stay offsets in their ranges: 2^62 cells, hashed)
+    pops = {"user": (rng.random(n) > 0.05).astype(np.uint8)}
+    tb = _int_table(ctx, cols, pops)
+    q = tb.query(filters=[("f", "gt", 99), ("f", "lt", 900)], groups=["g", "h"], distincts=["user"], aggs=["f"], op="avg")
+    gres = q.run()
+    assert q.stats()["strategy"] == 7
+    ores = oracle.run_query([{"type": "int", "data": cols["g"]}, {"type": "int", "data": cols["h"]},
+                             {"type": "int", "data": cols["user"], "populated": pops["user"]}, {"type": "int", "data": cols["f"]}],
+                            filters=[(3, "gt", 99), (3, "lt", 900)], groups=[0, 1], aggs=[(3, 0, 999)], distincts=[2], n_threads=4, want_registers=True)
+    _compare(gres, ores)
+    gres.free()
+    # a rescan of the same query: the pass runs again over the (same) key list
+    gres = q.run()
+    _compare(gres, ores)
+    gres.free()
+    q.free()
+    tb.free()
+
+
+def test_encode_results_carries_the_sketches(ctx, oracle):
+    """-encode-results of a count-distinct result (printer.go:284-289; refused before round 6): Result.Distinct travels as a
+    self-marshalling value -- a precision byte and the 16384 registers.  PARITY UNPINNED (the reference's dependency is absent):
+    what is pinned here is that the blob holds exactly the registers sybl_result_distinct hands out, row by row."""
+    from tests import gobfmt
+    rng = np.random.default_rng(31)
+    n = 200_000
+    cols = {"g": rng.integers(0, 6, n), "user": rng.integers(0, 20_000, n)}
+    tb = _int_table(ctx, cols)
+    q = tb.query(groups=["g"], distincts=["user"], order_by="$COUNT")
+    r = q.run()
+    v, types = gobfmt.decode(r.encode(), want_types=True)
+    assert ("opaque", "LogLogBeta") in [(k, nm) for _, k, nm in types]
+    res = v["QuerySpec"]["QueryResults"]
+    rows = r.rows(0)
+    assert len(res["Results"]) == len(rows) == 6
+    for i, row in enumerate(rows):
+        blob = res["Results"][row["group_by_key"]]["Distinct"]
+        card, regs = r.distinct(0, i, registers=True)
+        assert len(blob) == 1 + 16384 and blob[0] == 14 and np.array_equal(np.frombuffer(blob[1:], dtype=np.uint8), regs)
+    card, regs = r.distinct(2, 0, registers=True)
+    assert np.array_equal(np.frombuffer(res["Cumulative"]["Distinct"][1:], dtype=np.uint8), regs)
+    assert [s["GroupByKey"] for s in res["Sorted"]] == [row["group_by_key"] for row in rows]
+    r.free()
+    q.free()
+    tb.free()

@@ -40,6 +40,24 @@ static std::vector<std::string> split(const std::string &s, const std::string &s
     return out;
 }
 
+// -stats: where a cold run's wall time goes (stderr), phase by phase
+static double now_s() {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+struct Phases {
+    double t0 = now_s(), last = t0;
+    std::string line;
+    void mark(const char *what) {
+        const double t = now_s();
+        char b[64];
+        snprintf(b, sizeof(b), " %s=%.1fms", what, (t - last) * 1e3);
+        line += b;
+        last = t;
+    }
+};
+
 static int die(const char *what) {
     fprintf(stderr, "sybil-gpu-query: %s: %s\n", what, sybl_last_error());
     return 1;
@@ -157,8 +175,10 @@ int main(int argc, char **argv) {
         fprintf(stderr, "-gpu-ranks %d needs -gpu-id-file (rank 0 writes the communicator id there, the others read it)\n", nranks);
         return 2;
     }
+    Phases ph;
     sybl_ctx *ctx = nullptr;
     if (sybl_init(atoi(f["device"].c_str()), &ctx)) return die("init");
+    ph.mark("init");
     if (nranks > 1) {
         unsigned char id[128];
         const std::string path = f["gpu-id-file"], tmp = path + ".tmp";
@@ -197,6 +217,7 @@ int main(int argc, char **argv) {
     if (sybl_table_open_flags(ctx, f["dir"].c_str(), f["table"].c_str(), cptr.empty() ? nullptr : cptr.data(), (int32_t)cptr.size(), rank, nranks,
                               SYBL_OPEN_COMPACT, &tab))
         return die("open table");
+    ph.mark("open");
     // the ranks' bounds, dictionaries and sparse-key dictionaries become one (collective); one rank: dictionaries are sorted,
     // so the output is the same whatever the number of GPUs
     if (!getenv("SYBL_CLI_SKIP_AGREE")) {  // (the switch: tests/test_gpu_cli_multirank.py shows what the layout check then says)
@@ -270,14 +291,17 @@ int main(int argc, char **argv) {
     d.n_distincts = (int32_t)dptr.size();
     d.distincts = dptr.empty() ? nullptr : dptr.data();
 
+    ph.mark("agree");
     sybl_query *q = nullptr;
     if (sybl_query_prepare(tab, &d, &q)) return die("prepare");
+    ph.mark("prepare");
     if (sybl_query_scan(q)) return die("scan");
     if (nranks > 1 && sybl_query_allreduce(q)) return die("allreduce");
     // (every rank finalizes: after a reduce-scatter or a printer's merge the finalize is itself collective --
     // sybl_query_collective_finalize -- and a rank that only merged has nothing else left to do)
     sybl_result *res = nullptr;
     if (sybl_query_finalize(q, &res)) return die("finalize");
+    ph.mark("scan+finalize");
     if (rank != 0) {
         // rank 0 prints
     } else if (on("encode-results")) {
@@ -290,6 +314,16 @@ int main(int argc, char **argv) {
         const char *out = sybl_result_render(res, on("json") ? 1 : 0);
         if (!out) return die("render");
         fputs(out, stdout);
+    }
+    ph.mark("print");
+    // A one-shot CLI has nothing to give back that the process exit does not: the result is printed -- leave.  Freeing 1-2 GB of
+    // HBM buffer by buffer, unpinning the loader's arena and tearing the HIP runtime down cost a cold query ~0.1 s of its
+    // ~0.7 (profiles/r06_cold_cli_phases.txt); the reference's `sybil query` frees nothing either.  -stats and the multi-rank
+    // runs (the communicator is torn down in step with the other ranks) take the orderly way out.
+    if (!on("stats") && nranks == 1 && !getenv("SYBIL_GPU_ORDERLY_EXIT")) {
+        fflush(stdout);
+        fflush(stderr);
+        _exit(0);
     }
     if (on("stats")) {
         sybl_run_stats st;
@@ -304,5 +338,9 @@ int main(int argc, char **argv) {
     sybl_table_free(tab);
     if (nranks > 1) sybl_comm_free(ctx);
     sybl_shutdown(ctx);
+    if (on("stats")) {
+        ph.mark("free");
+        fprintf(stderr, "phases (since main):%s total=%.1fms\n", ph.line.c_str(), (now_s() - ph.t0) * 1e3);
+    }
     return 0;
 }
