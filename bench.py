@@ -432,6 +432,8 @@ def main():
                 assert sum(g["count"] for g in rows_out) == res.matched
                 out["matched"] = res.matched
                 out["groups"] = len(rows_out)
+                if workload == "cfg4_hist_highcard":
+                    out["printed"] = res.render("text")  # (what the CLI's text printer shows of this result)
                 out["digest"] = sorted((g["time_bucket"], g["key"], g["count"]) + tuple(h["sum"] for h in g["hists"]) for g in rows_out)
                 res.free()
             for qy in queries:
@@ -473,10 +475,42 @@ def main():
             q["printed_only"] = True
             if rank == 0:
                 assert alt["digest"] == head["digest"], "a printer's query and the fully summarised one disagree"
-                extra["every_row_summarised"] = {"ms_per_step": alt["dt"] / min(steps, 10) * 1e3, "kernel_ms": alt["kernel_ms"], "steps": min(steps, 10),
+                # (rounds 1-4 timed the every-row step as THE config 4 figure; since round 5 the record's value / ms_per_step
+                # are the printer's query -- both are first-class here, each with its own rows/s, and the record says which is which)
+                extra["metric_definition"] = ("value / ms_per_step: the PRINTER's query (sybl_query_desc.printed_only = 1, what `sybil query` runs; "
+                                              "since round 5); every_row_summarised.value: every group's percentiles / stddev derived per step "
+                                              "(printed_only = 0, what -encode-results needs; the definition rounds 1-4 reported)")
+                extra["every_row_summarised"] = {"value": total_rows * min(steps, 10) / alt["dt"], "unit": "rows/s",
+                                                 "ms_per_step": alt["dt"] / min(steps, 10) * 1e3, "kernel_ms": alt["kernel_ms"], "steps": min(steps, 10),
                                                  "host_ms_per_step": alt["host_ms"], "rows_first_access_ms": alt.get("rows_first_access_ms"),
                                                  "what": "the same step with percentiles / stddev derived for all 65 536 groups (k_hist_summary over the "
                                                          "525 MB table + 52 MB of percentiles to the host per step): what -encode-results needs"}
+        if workload == "cfg4_hist_highcard" and q.get("printed_only") and world == 1:
+            # -limit pushed INTO the scan (sybl_query_desc.printed_only = 2, csrc/pushdown.hip): the printer's query when the
+            # rows beyond the limit need nothing but their Count -- group counts from the key column, the printed groups chosen
+            # on the device, one pass over key + value for Cumulative and those groups.  A SEPARATE, labelled measurement: never
+            # config 4's roofline figure (that stays the full path above, every group's buckets built).
+            q["printed_only"] = 2
+            pd = run_phase(min(steps, 10), warmup)
+            q["printed_only"] = True
+            if rank == 0:
+                assert pd["stats"]["strategy"] == 8, pd["stats"]["strategy"]
+                assert pd["matched"] == head["matched"] and pd["printed"] == head["printed"], "the pushed-down printer prints something else"
+                assert [r[:3] for r in pd["digest"]] == [r[:3] for r in head["digest"]], "group counts differ"
+                alg_pd = pd["stats"]["rows_scanned"] * (2 * table.column_storage(names[0])[0] + table.column_storage(names[1])[0])
+                extra["printer_pushdown"] = {"value": total_rows * min(steps, 10) / pd["dt"], "unit": "rows/s", "ms_per_step": pd["dt"] / min(steps, 10) * 1e3,
+                                             "kernel_ms": pd["kernel_ms"], "steps": min(steps, 10), "host_ms_per_step": pd["host_ms"],
+                                             "bytes_read_per_step": alg_pd,
+                                             "achieved_GBps": alg_pd / (pd["kernel_ms"] * 1e-3) / 1e9, "frac_of_hbm_peak": alg_pd / (pd["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                             "checked": "text printer's output byte-equal to the full path's; matched rows and every group's Count equal",
+                                             "what": "printed_only = 2: -limit %d pushed into the scan (k_pd_count over the key column, k_pd_select, "
+                                                     "k_pd_scan over key + value): no records, no bucket table; the rows beyond the limit carry their "
+                                                     "Count only.  Not the roofline figure of config 4" % q["limit"]}
+        if head["stats"].get("strategy") == 5:
+            extra["count_pass"] = {"reused": bool(head["stats"].get("count_pass_reused")),
+                                   "what": "the counting pass over the key column (k_count*: per-(workgroup, bin) record counts) runs in a prepared "
+                                           "query's FIRST scan; rescans of the unchanged table reuse its regions, as they reuse block statistics "
+                                           "(SYBL_NO_COUNT_CACHE=1: every scan) -- the timed steps are rescans"}
         if workload == "cfg4_hist_highcard":
             # scans back to back (no finalize between them: the GPU never idles, clocks stay up): the kernels' own figure
             qy = table.query(**q)
@@ -545,7 +579,7 @@ def main():
                 # warm-up steps, 2.4 with four or more; the record names the steps and warm-up it used)
                 rec = measure(name, 0, min(args.steps, 20), 8, "compact", False)
                 recs.append({k: rec[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "config", "roofline")
-                             + tuple(k for k in ("oracle_check", "every_row_summarised", "back_to_back_scan_ms") if k in rec)})
+                             + tuple(k for k in ("oracle_check", "metric_definition", "every_row_summarised", "printer_pushdown", "back_to_back_scan_ms", "count_pass") if k in rec)})
                 recs[-1]["kernel_ms"] = rec["roofline"]["kernel_ms"]
                 if name == "cfg1_count_range" and not args.no_cpu_baseline:
                     # BASELINE.json configs[0] is the reference's own CPU-runnable case: the oracle on the whole table beside it

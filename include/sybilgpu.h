@@ -315,7 +315,13 @@ typedef struct {
      * 0.28 ms and 52 MB of percentiles per step) and, across ranks, the reduce-scatter of the whole bucket table -- only the
      * cell fields, Cumulative's buckets and the printed rows' arrays travel (~1 MB instead of 263 MB per rank;
      * sybl_query_collective_finalize is then 1: snapshot and finalize are collective).  0 (the default, and what
-     * -encode-results needs: every Result travels whole, printer.go:263-289): every row carries everything. */
+     * -encode-results needs: every Result travels whole, printer.go:263-289): every row carries everything.
+     * 2 (ABI 5): as 1, and the rows beyond `limit` need nothing but their Count -- what both printers of the reference look at
+     * (printer.go:154-158: sorted[:Limit]).  When the order is $COUNT descending the limit is then pushed INTO the scan
+     * (csrc/pushdown.hip): group counts from the key column alone, the printed groups chosen on the device, one pass over key
+     * and value columns for Cumulative and those groups -- no bucket array exists for any other group.  Taken for a single
+     * direct-mapped key of at most 65 536 cells without filters on one GPU (sybl_run_stats.strategy = 8); any other query
+     * answers as with 1.  The rows beyond the limit then report sum 0 / avg 0 / min, max at their initial values. */
     int32_t printed_only;
 } sybl_query_desc;
 
@@ -477,7 +483,8 @@ typedef struct {
                                * (role-specialised kernel), 3 / 4 = per-workgroup LDS time window (generic /
                                * role-specialised kernel), 5 = partitioned histograms, 6 = cell table AND
                                * bucket arrays in LDS, 7 = hash group-by (open-addressing table in HBM behind an
-                               * LDS staging table; n_cells = slots of the table) */
+                               * LDS staging table; n_cells = slots of the table), 8 = -limit pushed into the scan of a
+                               * printer's histogram query (printed_only = 2; csrc/pushdown.hip) */
     int32_t lds_bytes, n_workgroups, replicas;
     int32_t n_sum_fields;     /* int64 fields per cell in the SUM section */
     int32_t n_max_fields;     /* fields per cell in the MAX section; 0 = nothing to MAX-reduce */

@@ -106,7 +106,7 @@ static void free_query(Query *q) {
             v.erase(std::remove(v.begin(), v.end(), q), v.end());
         }
     }
-    if (q->eff_weight) column_free(q->eff_weight.get());
+    q->eff_weight.reset();  // (shared with the weight column's cache: freed with its last holder)
     if (q->d_plan) hipFree(q->d_plan);
     if (q->d_preplan) hipFree(q->d_preplan);
     if (q->d_prebits) hipFree(q->d_prebits);
@@ -142,6 +142,7 @@ static void free_query(Query *q) {
     if (q->d_out_stage) hipFree(q->d_out_stage);
     if (q->d_multi) hipFree(q->d_multi);
     if (q->d_dplan) hipFree(q->d_dplan);
+    if (q->d_pd) hipFree(q->d_pd);
     if (q->d_hll) hipFree(q->d_hll);
     if (q->d_hll_idhash) hipFree(q->d_hll_idhash);
     if (q->d_hll_chars) hipFree(q->d_hll_chars);
@@ -250,6 +251,34 @@ static int scan(Query *q) {
     const bool ran = !q->never_matches && !q->segs.empty();
     hipError_t e = hipSuccess;
     if ((rc = out_log_begin(q, st))) return rc;
+    if (q->pushdown && ran) {
+        // -limit pushed into the scan (pushdown.hip): group counts from the key column, the printed cells chosen on the
+        // device, then ONE pass over key + value that fills Cumulative and the printed groups only
+        PushdownPlan &D = q->dplan_pd;
+        const ScanPlan &PP = q->plan;
+        if ((rc = query_total_buffers(q))) return rc;
+        // header, every cell field (Count is rewritten by the fold; the sums start from zero), Cumulative's buckets, the carries
+        SYBL_HIP(hipMemsetAsync(q->d_sum, 0, ((size_t)kHeaderWords + (size_t)PP.n_sum_fields * (size_t)PP.n_cells) * 8, st));
+        SYBL_HIP(hipMemsetAsync(q->d_total, 0, (size_t)PP.hist_stride * 8, st));
+        SYBL_HIP(hipMemsetAsync(D.carry, 0, (size_t)PP.n_cells * 4, st));
+        SYBL_HIP(hipMemsetAsync(D.n_top, 0, 4, st));
+        e = launch_fill64(q->d_max, q->n_max_words, INT64_MIN, st);
+        if (e == hipSuccess) e = launch_fill64(q->d_sum + kHdrPdMax, kMaxAggs, INT64_MIN, st);
+        if (e != hipSuccess) return hip_fail(e, "k_fill64");
+        SYBL_HIP(hipEventRecord(q->ev[0], st));
+        D.fp.segs = q->d_segs;
+        D.fp.wg_seg_begin = q->d_wg_seg_begin;
+        D.sum_out = q->d_sum;
+        D.max_out = q->d_max;
+        D.total = q->d_total;
+        e = launch_pushdown(D, st);
+        if (e != hipSuccess) return hip_fail(e, "k_pd_*");
+        SYBL_HIP(hipEventRecord(q->ev[1], st));
+        SYBL_HIP(hipEventRecord(q->ev[2], st));
+        q->scanned = true;
+        q->snapshot_pending = false;
+        return SYBL_OK;
+    }
     if (q->part_hist && ran) {
         // k_part_hist overwrites every cell field, bucket and extremum: only the header and the
         // partition cursors start from zero

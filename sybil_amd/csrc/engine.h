@@ -152,6 +152,11 @@ struct Column {
     // a sparse int key direct-maps through -- rank_col->d_valid is BORROWED from this column.  Valid for (gdict_gen, Table::version).
     std::unique_ptr<Column> rank_col;
     int64_t rank_gen = -1, rank_version = -1;
+    // A weight column with unpopulated rows: the weights IN FORCE, row by row, as a dense int64 column (k_weight_carry;
+    // planner.cpp: Planner::weight), shared by the prepared queries that weigh by this column and valid for one Table::version
+    // (round 6: every prepare used to build its own -- a pass over the column and 8 B/row of HBM per weighted query).
+    std::shared_ptr<Column> carried_weight;
+    int64_t carried_version = -1;
     // table-global dictionary (str / set)
     std::vector<std::string> dict;
     std::unordered_map<std::string, int32_t> dict_ix;
@@ -396,7 +401,8 @@ struct Query {
     int limit = 0;
     // a weight column with unpopulated rows: the weight in force at every row (k_weight_carry), a dense int64 column of this
     // query's own that the scan reads in the weight column's place (planner.cpp: Planner::weight)
-    std::unique_ptr<Column> eff_weight;
+    std::shared_ptr<Column> eff_weight;  // (= the weight column's Column::carried_weight)
+    int printed_level = 0;      // sybl_query_desc.printed_only as given (2: the rows beyond the limit may carry their Count alone)
     bool printed_only = false;  // sybl_query_desc.printed_only: percentiles / stddev / bucket arrays for the printed rows + Cumulative only
     bool top_only = false;      // ... and this query is one it applies to (query_snapshot: summary shape, limit > 0)
     bool top_merge = false;     // ... across ranks: the bucket table stayed rank-local, finalize sums the printed rows' arrays (rccl.cpp)
@@ -512,6 +518,11 @@ struct Query {
     };
     std::vector<PartPass> part_more;
     uint32_t *d_recs = nullptr, *d_cursor = nullptr;
+    // -limit pushed into the scan (pushdown.hip): sybl_query_desc.printed_only = 2 on a query strategy 5 would take, one
+    // direct-mapped key of <= 65536 cells, no filter, sorted by $COUNT descending, one GPU
+    bool pushdown = false;
+    PushdownPlan dplan_pd;
+    uint32_t *d_pd = nullptr;  // ws | carry | cnt | bitmap | top_cells | n_top in one allocation
     bool count_cached = false;  // d_cursor holds the count pass's regions for this query's rows (engine.cpp: a rescan skips k_count)
 };
 
@@ -524,6 +535,7 @@ int query_acquire_host_buf(Query *q, int64_t words, std::shared_ptr<HostBuf> &cu
 int query_host_keys(Query *q, int64_t n);  // (result.cpp) q->h_dense_keys with room for n keys, not shared with a live result
 void query_finish_lazy_results(Query *q);  // (result.cpp) builds the rows of results that still need the query (before it goes away)
 int query_summary_buffers(Query *q);  // (result.cpp) d_pct / d_mom / d_total + their pinned twins
+int query_total_buffers(Query *q);    // (result.cpp) d_total + its pinned twin alone: a printer's query
 // rccl.cpp: collectives on the ctx communicator and stream (SYBL_E_STATE without a communicator)
 int comm_allgather_inplace(Ctx *ctx, int64_t *buf, size_t words_per_rank);
 int comm_allreduce_sum(Ctx *ctx, int64_t *buf, size_t words);

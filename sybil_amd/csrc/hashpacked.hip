@@ -22,6 +22,12 @@ namespace sybl {
 // serves every column count; bucket arrays (hist mode) never stage in LDS and stay with k_scan_hash_fast.
 // T threads per workgroup (hashfast.hip: 1024 threads cap the body at 128 VGPRs, and 30 of its 60 instantiations spilled
 // inside the row loop).
+// SYBL_HASH_PACKED_LATE=0 at build time: without late materialisation (same-box A/B builds)
+#ifndef SYBL_HASH_PACKED_LATE
+#define SYBL_HASH_PACKED_LATE 1
+#endif
+constexpr bool kHashPackedLate = SYBL_HASH_PACKED_LATE != 0;
+
 template <int NA, int MODE, bool NUL, bool HASH, int T>
 __global__ __launch_bounds__(T) void k_scan_hash_packed(const FastPlan P, uint64_t *hash_keys, const int nf, const int ng, const int time,
                                                                  const int L_, const int F, const int M) {
@@ -96,13 +102,14 @@ __global__ __launch_bounds__(T) void k_scan_hash_packed(const FastPlan P, uint64
             }
         }
     };
+    // (nfe: filter columns still to be evaluated for the row -- nf, or 0 when `pass` already is their verdict: the late path)
     auto one_row = [&](const PackedTile<MF> &f, const PackedTile<MG> &g, const PackedTile<NA> &a, const PackedTile<1> &t, const int r, bool pass,
-                       const uint32_t xpop) {
+                       const uint32_t xpop, const int nfe) {
         if (NUL) pass = pass & ((xpop >> r) & 1u);  // the filter pre-pass's verdict (FastPlan::xvalid)
         // (packed_row's filters and key, scan_packed.h: one predicate, no short-circuit)
 #pragma unroll
         for (int c = 0; c < MF; c++) {
-            if (c >= nf) break;
+            if (c >= nfe) break;
             const uint32_t u = f.u[c][r];
             bool ok = (u >= P.plo[c]) & (u <= P.phi[c]);
             if (NUL) {
@@ -261,6 +268,76 @@ __global__ __launch_bounds__(T) void k_scan_hash_packed(const FastPlan P, uint64
 #pragma unroll
                 for (int c = 0; c < NA; c++) packed_decode(P.awid[c], ra.v[c], a.u[c]);
             };
+            if (kHashPackedLate && !NUL && nf > 0) {
+                // Late materialisation (the reference's row loop leaves a row at its first failing filter, aggregate.go:105-116),
+                // as in k_scan_packed (scan_packed.h): the filter columns run one tile ahead of the key / aggregation / time
+                // columns, and a WAVE none of whose 256 rows passes does not read the other columns of that tile -- the loads
+                // are still issued, through a descriptor of zero records, so the count in flight is the same on every path.
+                // Iteration t: decode keys / values of tile t and the filters of t + 1, issue keys / values of t + 1 (or
+                // nothing) and the filters of t + 2, then the rows of t with the predicate bits kept from last time.
+                const uint32_t r_first = tid * kPackedRows;
+                const uint32_t n_tiles = (n + (uint32_t)(T * kPackedRows) - 1) / (uint32_t)(T * kPackedRows);
+                auto ldn = [&](const void *col, int width, pu32x4 &raw, uint32_t r0, uint32_t lane_row, uint32_t rows) {
+                    const int ws = width >> 1;
+                    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                        (void *)((const uint8_t *)col + (size_t)(first + (rows ? r0 : 0u)) * (size_t)width), 0, (int)(rows << ws), (int)kBufferRsrcWord3);
+                    raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(lane_row << ws), 0, 2);
+                };
+                auto rows_of = [&](uint32_t r0) -> uint32_t {
+                    return r0 < n ? (n - r0 < 64u * kPackedRows ? (n - r0 + kPackedRows - 1) & ~(uint32_t)(kPackedRows - 1) : 64u * kPackedRows) : 0u;
+                };
+                auto issue_filters = [&](uint32_t r) {
+                    const uint32_t r0 = __builtin_amdgcn_readfirstlane(r), lane_row = r - r0, rows = rows_of(r0);
+#pragma unroll
+                    for (int c = 0; c < MF; c++)
+                        if (c < nf) ldn(P.fcol[c], P.fwid[c], rf.v[c], r0, lane_row, rows);
+                };
+                auto issue_rest = [&](uint32_t r, bool wanted) {
+                    const uint32_t r0 = __builtin_amdgcn_readfirstlane(r), lane_row = r - r0, rows = wanted ? rows_of(r0) : 0u;
+                    if (time) ldn(P.tcol, P.twid, rt.v[0], r0, lane_row, rows);
+#pragma unroll
+                    for (int c = 0; c < MG; c++)
+                        if (c < ng) ldn(P.gcol[c], P.gwid[c], rg.v[c], r0, lane_row, rows);
+#pragma unroll
+                    for (int c = 0; c < NA; c++) ldn(P.acol[c], P.awid[c], ra.v[c], r0, lane_row, rows);
+                };
+                auto filter_bits = [&](uint32_t r) -> uint32_t {
+#pragma unroll
+                    for (int c = 0; c < MF; c++)
+                        if (c < nf) packed_decode(P.fwid[c], rf.v[c], f.u[c]);
+                    const uint32_t left = r < n ? n - r : 0u;
+                    uint32_t bits = 0;
+#pragma unroll
+                    for (int k = 0; k < kPackedRows; k++) {
+                        bool pass = (uint32_t)k < left;
+#pragma unroll
+                        for (int c = 0; c < MF; c++)
+                            if (c < nf) pass = pass & (f.u[c][k] >= P.plo[c]) & (f.u[c][k] <= P.phi[c]);
+                        bits |= pass ? 1u << k : 0u;
+                    }
+                    return bits;
+                };
+                issue_filters(r_first);
+                uint32_t bits = filter_bits(r_first);
+                issue_rest(r_first, __builtin_amdgcn_ballot_w64(bits != 0) != 0);
+                issue_filters(r_first + (uint32_t)(T * kPackedRows));
+                for (uint32_t it = 0; it < n_tiles; it++) {
+                    const uint32_t r = r_first + it * (uint32_t)(T * kPackedRows);
+                    if (time) packed_decode(P.twid, rt.v[0], t.u[0]);
+#pragma unroll
+                    for (int c = 0; c < MG; c++)
+                        if (c < ng) packed_decode(P.gwid[c], rg.v[c], g.u[c]);
+#pragma unroll
+                    for (int c = 0; c < NA; c++) packed_decode(P.awid[c], ra.v[c], a.u[c]);
+                    const uint32_t next_bits = filter_bits(r + (uint32_t)(T * kPackedRows));
+                    issue_rest(r + (uint32_t)(T * kPackedRows), __builtin_amdgcn_ballot_w64(next_bits != 0) != 0);
+                    issue_filters(r + 2u * (uint32_t)(T * kPackedRows));
+#pragma unroll
+                    for (int k = 0; k < kPackedRows; k++) one_row(f, g, a, t, k, (bits >> k) & 1u, 0xFu, 0);
+                    bits = next_bits;
+                }
+                continue;
+            }
             uint32_t r = tid * kPackedRows;
             if (r < n) {
                 issue(r);
@@ -278,7 +355,7 @@ __global__ __launch_bounds__(T) void k_scan_hash_packed(const FastPlan P, uint64
                 if (xv && rn + (uint32_t)(T * kPackedRows) < n) xw_n = P.xvalid[(first + rn + (uint32_t)(T * kPackedRows)) >> 5];
                 const uint32_t left = n - r;
 #pragma unroll
-                for (int k = 0; k < kPackedRows; k++) one_row(f, g, a, t, k, (uint32_t)k < left, xpop);
+                for (int k = 0; k < kPackedRows; k++) one_row(f, g, a, t, k, (uint32_t)k < left, xpop, nf);
                 if (more) decode(rn);
                 xpop = xpop_n;
             }

@@ -565,8 +565,7 @@ static PreparedBlock prepare_block_unguarded(const std::string &bdir, const std:
     // 5: decoding all files first and filling the slab in a second pass kept 1.2 MB of decoded arrays alive per worker, read
     // back cold (profiles/r05_loader_streamed.txt).  A block that outgrows the pool's slab starts over in two passes
     // (plan everything, then a buffer of its own): SYBL_LOADER_TWO_PASS=1 does that for every block (A/B).
-    static const bool two_pass_always = env("SYBL_LOADER_TWO_PASS") != nullptr;
-    if (two_pass_always) streamed = false;
+    if (env("SYBL_LOADER_TWO_PASS")) streamed = false;  // (read per call: under SYBL_ENV_LIVE a test may flip it between loads)
     std::vector<gob::Value> trees(streamed ? 0 : specs.size());
     std::vector<char> have(specs.size(), 0), bucketed(specs.size(), 0);
     size_t total = 0;
@@ -582,7 +581,7 @@ static PreparedBlock prepare_block_unguarded(const std::string &bdir, const std:
         std::string path = bdir + "/" + prefix[specs[ci].type] + specs[ci].name + ".db";
         // a missing file = column unpopulated in this block; "DECODE COL ERR": the reference logs and
         // carries on with an empty column
-        static const bool wide = env("SYBL_LOADER_WIDE_DECODE") != nullptr;  // (A/B: int64 slices, narrowed afterwards)
+        const bool wide = env("SYBL_LOADER_WIDE_DECODE") != nullptr;  // (A/B: int64 slices, narrowed afterwards; read per call)
         if (!decode_file(path, v, err, specs[ci].type != SYBL_SET_VAL && !wide)) return true;
         have[ci] = 1;
         const gob::Value *f;

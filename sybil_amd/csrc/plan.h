@@ -227,6 +227,8 @@ enum Header : int {
     kHdrEmitStall = 3,    // partitioned histograms: a lane gave up waiting for a staging chunk (must be 0: a bug)
     kHdrHashFull = 4,     // hash group-by: rows whose key found no free slot (more distinct keys than the table holds)
     kHdrOutLog = 5,       // outlier log: records appended (k_outlog_gather; more than the log's capacity: some were dropped)
+    kHdrPdSum = 8,        // .. 8 + kMaxAggs: a pushed-down printer's query (pushdown.hip): sum(v) of EVERY row, per aggregation --
+    kHdrPdMax = 16,       // .. and max(v): Cumulative's, the cell fields of the rows beyond the limit being empty in that mode
 };
 
 // ---- table load: one block's bucket-encoded / value-encoded columns, a launch each (loader.cpp, kernels.hip:

@@ -681,6 +681,7 @@ struct Planner {
         q->order_asc = d->order_asc != 0;
         q->limit = d->limit;
         q->printed_only = d->printed_only != 0;
+        q->printed_level = d->printed_only;
         q->time_mode = d->time_bucket > 0 && d->time_col && d->time_col[0];
         q->time_bucket = q->time_mode ? d->time_bucket : 0;
         q->weighted = d->weight_col && d->weight_col[0];
@@ -1057,26 +1058,29 @@ struct Planner {
                 // that had one (1 before the first).  The weights in force are laid out once, as a dense column of this
                 // query's own, and the weight role moves to a slot of that column (the table's column keeps the slot it
                 // has if the query also filters / groups / aggregates it).
-                auto e = std::make_unique<Column>();
-                e->name = c->name;
-                e->type = SYBL_INT_VAL;
-                e->elem = 8;
-                if ((rc = table_reserve(t, e.get(), t->phys_rows))) return rc;
-                if ((rc = table_upload_blocks(t))) {
-                    column_free(e.get());
-                    return rc;
+                // (one per column and table version, shared by the queries that weigh by it: Column::carried_weight)
+                if (!c->carried_weight || c->carried_version != t->version) {
+                    std::shared_ptr<Column> e(new Column(), [](Column *x) {
+                        column_free(x);
+                        delete x;
+                    });
+                    e->name = c->name;
+                    e->type = SYBL_INT_VAL;
+                    e->elem = 8;
+                    if ((rc = table_reserve(t, e.get(), t->phys_rows))) return rc;
+                    if ((rc = table_upload_blocks(t))) return rc;
+                    hipError_t he = launch_weight_carry(c->d_data, c->elem, c->vbase, c->d_valid, t->d_blocks, (int)t->blocks.size(), (int64_t *)e->d_data,
+                                                        t->ctx->stream);
+                    if (he == hipSuccess) he = hipStreamSynchronize(t->ctx->stream);
+                    if (he != hipSuccess) return hip_fail(he, "k_weight_carry");
+                    e->exact_min = std::min<int64_t>(c->exact_min, 1);
+                    e->exact_max = std::max<int64_t>(c->exact_max, 1);
+                    e->n_pop = t->logical_rows;
+                    e->stats_blocks = (int64_t)t->blocks.size();
+                    c->carried_weight = e;
+                    c->carried_version = t->version;
                 }
-                hipError_t he = launch_weight_carry(c->d_data, c->elem, c->vbase, c->d_valid, t->d_blocks, (int)t->blocks.size(), (int64_t *)e->d_data, t->ctx->stream);
-                if (he == hipSuccess) he = hipStreamSynchronize(t->ctx->stream);
-                if (he != hipSuccess) {
-                    column_free(e.get());
-                    return hip_fail(he, "k_weight_carry");
-                }
-                e->exact_min = std::min<int64_t>(c->exact_min, 1);
-                e->exact_max = std::max<int64_t>(c->exact_max, 1);
-                e->n_pop = t->logical_rows;
-                e->stats_blocks = (int64_t)t->blocks.size();
-                q->eff_weight = std::move(e);
+                q->eff_weight = c->carried_weight;
                 if (fresh_slot) {
                     slot_col[(size_t)s] = kEffWeightCol;  // (the slot slot_of just made for the weight alone: it becomes the dense column's)
                 } else {
@@ -1529,6 +1533,44 @@ struct Planner {
         if (sum_bits + count_bits <= 64 && sum_bits < 63) FP.cshift = sum_bits;
     }
 
+    // -limit pushed into the scan (pushdown.hip).  Taken when the caller said the rows beyond the limit need nothing but their
+    // Count (printed_only = 2), the query is one strategy 5 runs in a single pass over compact storage with ONE key column
+    // and no filter, the order is $COUNT descending, and there is one GPU (the ranks of a job would have to agree on the
+    // printed cells before pass 2: they keep the limit-aware merge of round 5).
+    int plan_pushdown() {
+        q->pushdown = false;
+        if (q->printed_level != 2 || env("SYBL_NO_PUSHDOWN")) return SYBL_OK;
+        if (!q->part_hist || !q->part_packed || !q->part_more.empty() || q->part_nf != 0 || q->part_ng != 1) return SYBL_OK;
+        if (q->limit <= 0 || q->order_by != "$COUNT" || q->order_asc || ctx->comm_nranks > 1) return SYBL_OK;
+        if (P.n_cells < 2048 || P.n_cells > 65536 || q->part_na < 1 || q->part_na > 2 || q->n_distinct) return SYBL_OK;
+        const FastPlan &FP = q->eplan.fp;
+        if (FP.gcard[0] != (uint32_t)P.n_cells || FP.gstride[0] != 1 || P.hist_stride > 8192) return SYBL_OK;
+        for (int a = 0; a < q->part_na; a++)
+            if (q->aggs[(size_t)a].d.f_out >= 0 || !q->aggs[(size_t)a].d.hist_full) return SYBL_OK;  // (an outlier is possible: the full path remembers it)
+        PushdownPlan &D = q->dplan_pd;
+        memset(&D, 0, sizeof(D));
+        D.fp = FP;
+        // (the emit plan's records carry v - h.Min + BucketSize -- plan_part_pass biased adoff --; the buckets here are plain)
+        for (int a = 0; a < q->part_na; a++) D.fp.adoff[a] -= D.fp.bucket_size[a];
+        D.n_cells = P.n_cells;
+        D.n_aggs = q->part_na;
+        D.n_wg = q->n_wg;
+        D.limit = q->limit;
+        D.hist_off = P.hist_off;
+        D.hist_stride = P.hist_stride;
+        const size_t words = ((size_t)P.n_cells + 1) / 2, bm = ((size_t)P.n_cells + 31) / 32;
+        const size_t total = (size_t)q->n_wg * words + 2 * (size_t)P.n_cells + bm + (size_t)q->limit + 4;
+        SYBL_HIP(hipMalloc((void **)&q->d_pd, total * 4));
+        D.ws = q->d_pd;
+        D.carry = D.ws + (size_t)q->n_wg * words;
+        D.cnt = D.carry + P.n_cells;
+        D.bitmap = D.cnt + P.n_cells;
+        D.top_cells = (int32_t *)(D.bitmap + bm);
+        D.n_top = D.top_cells + q->limit;
+        q->pushdown = true;
+        return SYBL_OK;
+    }
+
     int window() {
         int rc;
         // ---- LDS-window strategy: a time-series table too large for LDS, scanned by workgroups whose
@@ -1599,6 +1641,7 @@ struct Planner {
         prefilter_commit();
         if ((rc = select_part_hist(t, q, slot_col, rows_scanned))) return rc;
         plan_count_packing();
+        if ((rc = plan_pushdown())) return rc;
         q->stats.rows_scanned = rows_scanned;
         q->stats.blocks_skipped = skipped;
         q->stats.blocks_scanned = (int64_t)t->blocks.size() - skipped;
@@ -1619,7 +1662,7 @@ struct Planner {
         q->stats.canonical_bytes = rows_scanned * canon_width + set_bytes;
         q->stats.n_cells = (int32_t)n_cells;
         q->stats.packed_kernel = q->part_hist ? q->part_packed : (q->fast && q->fast_packed);
-        q->stats.strategy = q->part_hist ? 5 : (q->use_lds ? (P.windowed ? (q->fast ? 4 : 3) : (q->fast ? (q->fplan.hist_lds ? 6 : 2) : 0)) : (q->hash_mode ? 7 : 1));
+        q->stats.strategy = q->pushdown ? 8 : q->part_hist ? 5 : (q->use_lds ? (P.windowed ? (q->fast ? 4 : 3) : (q->fast ? (q->fplan.hist_lds ? 6 : 2) : 0)) : (q->hash_mode ? 7 : 1));
         q->stats.lds_bytes = (int32_t)q->lds_bytes;
         q->stats.n_workgroups = q->n_wg;
         q->stats.replicas = 1 << P.rep_shift;

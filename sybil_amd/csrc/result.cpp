@@ -425,7 +425,7 @@ void query_finish_lazy_results(Query *q) {
 }
 
 // Cumulative's bucket sums (k_hist_total) and their pinned twin: all a printer's query needs of the summary buffers
-static int query_total_buffers(Query *q) {
+int query_total_buffers(Query *q) {
     if (q->d_total) return SYBL_OK;
     const ScanPlan &P = q->plan;
     SYBL_HIP(hipMalloc((void **)&q->d_total, (size_t)P.hist_stride * 8));
@@ -493,9 +493,11 @@ int query_snapshot(Query *q) {
     if (q->top_only) {
         int rc = query_total_buffers(q);
         if (rc) return rc;
-        SYBL_HIP(hipMemsetAsync(q->d_total, 0, (size_t)P.hist_stride * 8, st));
-        hipError_t e = launch_hist_total(q->d_sum + P.hist_off, P.hist_stride, 0, P.n_cells, q->d_total, st);
-        if (e != hipSuccess) return hip_fail(e, "k_hist_total");
+        if (!q->pushdown) {  // (a pushed-down scan summed Cumulative's buckets itself, from every row: pushdown.hip)
+            SYBL_HIP(hipMemsetAsync(q->d_total, 0, (size_t)P.hist_stride * 8, st));
+            hipError_t e = launch_hist_total(q->d_sum + P.hist_off, P.hist_stride, 0, P.n_cells, q->d_total, st);
+            if (e != hipSuccess) return hip_fail(e, "k_hist_total");
+        }
         if (q->top_merge) {
             int rc2 = comm_allreduce_sum(q->ctx, q->d_total, (size_t)P.hist_stride);
             if (rc2) return rc2;
@@ -757,6 +759,12 @@ int query_finalize(Query *q, Result **out) {
     C.H = H;
     C.hm = hm;
     C.top_only = q->top_only;
+    C.pushdown = q->pushdown && q->top_only;
+    if (C.pushdown)
+        for (int a = 0; a < kMaxAggs; a++) {
+            C.pd_sum[a] = hs[kHdrPdSum + a];
+            C.pd_max[a] = hs[kHdrPdMax + a];
+        }
     C.h_pct = summary && !q->top_only ? q->h_pct : nullptr;
     C.q = q;
     C.keys_buf = hashed ? q->h_keys_buf : nullptr;
@@ -1231,6 +1239,11 @@ void result_ensure_rows(Result *R) {
     if (summary) R->total_vals = summary_totals;
     for (size_t a = 0; a < na; a++)
         if (!R->total_vals[a].empty()) total.aggs[a].values = R->total_vals[a].data();
+    if (C.pushdown)  // (the cells beyond the limit carry no sums: Cumulative's come from the scan's own totals over every row)
+        for (size_t a = 0; a < na; a++) {
+            total.aggs[a].sum = (uint64_t)C.pd_sum[a];
+            total.aggs[a].vmax = C.aggs[a].d.m_max >= 0 ? C.pd_max[a] : total.aggs[a].vmax;
+        }
     size_t next_slot = live.size();
     if (C.time_mode) {
         // all-time Results carry Count/Samples only (aggregate.go:156-169)

@@ -101,6 +101,10 @@ struct FinCtx {
     bool weighted = false, loghist = false, want_percentiles = false, time_mode = false, hashed = false, summary = false;
     bool out_usable = false, keys_cached = false;
     bool top_only = false;  // a printer's result: percentiles / stddev / buckets for the printed rows and Cumulative only
+    // -limit pushed into the scan (pushdown.hip): the cells beyond the limit hold their Count only, so Cumulative's sum(v) and
+    // max(v) come from what the scan added up over EVERY row (header words kHdrPdSum / kHdrPdMax), not from the cells
+    bool pushdown = false;
+    int64_t pd_sum[kMaxAggs] = {0}, pd_max[kMaxAggs] = {0};
     std::vector<AggInfo> aggs;
     ScanPlan P;
     int64_t ncell = 0, gcells = 0;

@@ -207,6 +207,21 @@ struct PartHistPlan {
 };
 constexpr int kPartTraceWords = 32;
 
+// ---- -limit pushed into the scan (pushdown.hip): a printer's histogram query sorted by $COUNT
+struct PushdownPlan {
+    FastPlan fp;             // the key column (gcol / gwid / gdoff / gcard [0]), the value columns and their bucket geometry
+    int32_t n_cells, n_aggs, n_wg, limit;
+    uint32_t *ws;            // [n_wg][(n_cells + 1) / 2] the workgroups' counter tables, two 15-bit fields to a word
+    uint32_t *carry;         // [n_cells] units of 32768 taken out of a field that filled up
+    uint32_t *cnt;           // [n_cells] the folded counts
+    uint32_t *bitmap;        // [(n_cells + 31) / 32] the printed cells
+    int32_t *top_cells;      // [limit] ... as a list (any order)
+    int32_t *n_top;
+    int64_t *sum_out, *max_out, *total;  // the query's SUM / MAX sections and Cumulative's buckets (Query::d_total)
+    int64_t hist_off, hist_stride;
+};
+hipError_t launch_pushdown(const PushdownPlan &D, hipStream_t st);
+
 // tiles of column loads a lane keeps in flight: a tile is only 8..16 bytes per column and lane, and a CU needs
 // ~64 KB on the way to keep HBM busy; bounded by registers (one 16-byte register quad per column and tile)
 constexpr int emit_depth(int n_cols) { return n_cols <= 2 ? 4 : n_cols <= 4 ? 2 : 1; }

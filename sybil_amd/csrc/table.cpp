@@ -104,6 +104,7 @@ int valid_reserve(Table *t, Column *c, int64_t phys_rows) {
     if (c->d_valid) SYBL_HIP(hipFree(c->d_valid));
     c->d_valid = nd;
     c->valid_cap_words = cap;
+    if (c->rank_col) c->rank_col->d_valid = nd;  // (the derived rank column BORROWS this bitmap: never left pointing at the freed one)
     return SYBL_OK;
 }
 
@@ -201,6 +202,7 @@ void column_free(Column *c) {
         column_free(c->rank_col.get());
         c->rank_col.reset();
     }
+    c->carried_weight.reset();  // (queries that weigh by it keep their share)
     if (c->d_data) hipFree(c->d_data);
     if (c->d_valid) hipFree(c->d_valid);
     if (c->d_set_off) hipFree(c->d_set_off);
@@ -1016,7 +1018,12 @@ int64_t sybl_table_hbm_bytes(const sybl_table *t) {
     SYBL_API_GUARD(t);
     if (!t) return 0;
     int64_t b = 0;
-    for (auto &c : t->cols) b += c->cap_rows * c->elem + c->valid_cap_words * 4 + c->set_vals_cap * 4;
+    for (auto &c : t->cols) {
+        b += c->cap_rows * c->elem + c->valid_cap_words * 4 + c->set_vals_cap * 4;
+        // ... and the columns derived from it: a sparse key's rank column, a weight column's carried weights
+        if (c->rank_col) b += c->rank_col->cap_rows * c->rank_col->elem;
+        if (c->carried_weight) b += c->carried_weight->cap_rows * c->carried_weight->elem;
+    }
     return b;
 }
 

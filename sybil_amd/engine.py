@@ -309,7 +309,7 @@ class Table:
         dn = [_b(x) for x in distincts]
         darr = (C.c_char_p * max(len(dn), 1))(*dn)
         d.n_distincts, d.distincts = len(dn), C.cast(darr, C.POINTER(C.c_char_p))
-        d.printed_only = 1 if printed_only else 0
+        d.printed_only = int(printed_only)  # (False / True / 2: the rows beyond the limit need their Count only -- limit pushdown)
         h = C.c_void_p()
         N.check(N.lib().sybl_query_prepare(self._h, C.byref(d), C.byref(h)))
         qy = Query(self, h, list(groups), list(aggs))

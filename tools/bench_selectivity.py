@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Config 3 (3 ANDed int-range filters, group-by 2, moments of 2 columns) at different selectivities on compact
 storage: does the row body's LDS-atomic issue still cost time when almost no row matches?
-usage: bench_selectivity.py [rows] [steps]"""
+usage: bench_selectivity.py [rows] [steps] [packed|hash|wide]
+  hash: the same queries through the hash table (SYBL_FORCE_HASH=1: k_scan_hash_packed); wide: four aggregation columns
+  (k_scan_hash_packed<4, .., HASH = false>, the run-time-count direct-mapped body)"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sybil_amd
@@ -9,9 +11,17 @@ from sybil_amd import synth
 
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000_000
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+variant = sys.argv[3] if len(sys.argv) > 3 else "packed"
 wl = synth.WORKLOADS["cfg3_filter3_group2_stddev"]
+base = dict(wl["query"])
+cols = list(wl["columns"])
+if variant == "hash":
+    os.environ["SYBL_FORCE_HASH"] = "1"
+elif variant == "wide":
+    cols += ["c09"]
+    base["aggs"] = ["c07", "c08", "c09", "c04"]
 ctx = sybil_amd.Context(0)
-t = ctx.synth_table("sel", synth.SEED, rows, 0, rows, synth.synth_cols(wl["columns"]))
+t = ctx.synth_table("sel", synth.SEED, rows, 0, rows, synth.synth_cols(cols))
 t.compact()
 cases = [
     ("51% (gt:99,lt:900 x3: the headline)", wl["query"]["filters"]),
@@ -22,7 +32,7 @@ cases = [
     ("0 (gt:999 on c04)", [("c04", "gt", 999), ("c05", "gt", -1), ("c06", "gt", -1)]),
 ]
 for label, filters in cases:
-    q = t.query(**dict(wl["query"], filters=filters))
+    q = t.query(**dict(base, filters=filters))
     ms = []
     for _ in range(steps + 3):  # (back-to-back scans, no finalize in between: the GPU stays at its working clocks)
         q.scan()
@@ -34,7 +44,7 @@ for label, filters in cases:
     r.free()
     st = q.stats()
     k = sorted(ms)[len(ms) // 2]
-    print(json.dumps({"selectivity": label, "rows": rows, "matched": matched, "match_frac": matched / rows, "kernel_ms": round(k, 3),
+    print(json.dumps({"variant": variant, "selectivity": label, "rows": rows, "matched": matched, "match_frac": matched / rows, "kernel_ms": round(k, 3),
                       "GBps": st["algorithmic_bytes"] / (k * 1e-3) / 1e9, "packed_kernel": st["packed_kernel"], "strategy": st["strategy"]}))
     sys.stdout.flush()
     q.free()

@@ -33,8 +33,11 @@ jobs = [
     ("7_cols_strategy_2_packed", "%s_pmc.txt" % tag, 1e9, lambda k: "k_scan_packed<3, 2, 2" in k, "the headline, compact storage: 16 stored B/row"),
     ("3_cols_strategy_2_packed", "%s_cfg2_pmc.txt" % tag, 1e8, lambda k: "k_scan_packed<0, 1, 2" in k or "k_fold" in k, "config 2, compact storage: 9 stored B/row"),
     ("3_cols_strategy_4_packed", "%s_cfg5_pmc.txt" % tag, 1e9, lambda k: "k_scan_packed<0, 1, 1" in k, "config 5, compact storage: 10 stored B/row"),
-    ("2_cols_strategy_5_packed", "%s_cfg4_pmc.txt" % tag, 1e9, lambda k: any(x in k for x in ("k_count_packed", "k_count_key", "k_emit_packed", "k_part_hist", "k_part_fix")),
-     "config 4, compact storage: 6 stored B/row + 4 B of record written and read per value + the 525 MB bucket table written"),
+    # (from round 6 the counting pass -- k_count_key -- runs in a prepared query's first scan only: a step's traffic is without it)
+    ("2_cols_strategy_5_packed", "%s_cfg4_pmc.txt" % tag, 1e9,
+     lambda k: any(x in k for x in ("k_emit_packed", "k_part_hist", "k_part_fix") + (("k_count_packed", "k_count_key") if tag < "r06" else ())),
+     "config 4, compact storage: 6 stored B/row + 4 B of record written and read per value + the 525 MB bucket table written"
+     + ("; the counting pass over the key column runs once per prepared query, not per step" if tag >= "r06" else "")),
 ]
 for key, fn, rows, pick, what in jobs:
     p = os.path.join(root, fn)

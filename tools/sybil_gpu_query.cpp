@@ -269,7 +269,8 @@ int main(int argc, char **argv) {
     d.block_skip = on("block-skip");
     d.loghist = on("loghist");  // FLAGS.LOG_HIST (cmd_query.go:43)
     // a printer looks at `limit` rows and Cumulative (printer.go:291-308); -encode-results ships every Result whole (:263-289)
-    d.printed_only = on("encode-results") ? 0 : 1;
+    // (2: ... and the rows beyond -limit need nothing but their Count -- with -sort $COUNT the library pushes the limit into the scan)
+    d.printed_only = on("encode-results") ? 0 : 2;
     // -str-replace col:find:replace[,col:find:replace...]  (cmd_query.go:51, table_query.go:33-46: split on ':' whatever the
     // filter separator is; fewer than three tokens = ignored)
     std::vector<std::vector<std::string>> sr_tok;
