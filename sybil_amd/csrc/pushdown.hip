@@ -63,6 +63,9 @@ __global__ __launch_bounds__(kWgThreads, 4) void k_pd_count(const PushdownPlan D
                     raw[d] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)((r + (uint32_t)DEPTH * kTile) * (uint32_t)W), 0, 2);
                     const uint32_t left = r < n ? n - r : 0u;
                     const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+                    // the tile's adds first, every lane's R of them in flight together, their returns looked at afterwards (a
+                    // check between two adds made each wait for the one before it)
+                    uint32_t cells[R], olds[R];
 #pragma unroll
                     for (uint32_t k = 0; k < R; k++) {
                         uint32_t u;
@@ -70,17 +73,19 @@ __global__ __launch_bounds__(kWgThreads, 4) void k_pd_count(const PushdownPlan D
                         else if (W == 2) u = (w4[k >> 1] >> ((k & 1u) * 16u)) & 0xFFFFu;
                         else u = (w4[k >> 2] >> ((k & 3u) * 8u)) & 0xFFu;
                         const uint32_t cell = u + gdoff;
-                        if (k >= left) continue;
-                        if (cell >= gcard) {
-                            overflow += 1;
-                            continue;
-                        }
-                        const uint32_t sh = (cell & 1u) << 4;
-                        const uint32_t old = __hip_atomic_fetch_add(plds + (cell >> 1), 1u << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        if (((old >> sh) & 0x7FFFu) == 0x7FFFu) {
+                        const bool in = k < left && cell < gcard;
+                        overflow += (k < left && cell >= gcard) ? 1u : 0u;
+                        cells[k] = in ? cell : 0xFFFFFFFFu;
+                        olds[k] = 0;
+                        if (in) olds[k] = __hip_atomic_fetch_add(plds + (cell >> 1), 1u << ((cell & 1u) << 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+#pragma unroll
+                    for (uint32_t k = 0; k < R; k++) {
+                        const uint32_t cell = cells[k], sh = (cell & 1u) << 4;
+                        if (cell != 0xFFFFFFFFu && ((olds[k] >> sh) & 0x7FFFu) == 0x7FFFu) {
                             // this add took the field to 32768: the guard bit holds it (nothing carried into the neighbour) until
                             // the 32768 are taken out here and remembered device-side.  (Another full wrap of the field inside
-                            // that window would need 32767 more adds to this cell before this lane's next instruction.)
+                            // that window would need 32767 more adds to this cell before this lane gets here.)
                             __hip_atomic_fetch_sub(plds + (cell >> 1), kPdGuard << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                             __hip_atomic_fetch_add(D.carry + cell, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         }
@@ -141,17 +146,39 @@ __global__ __launch_bounds__(1024) void k_pd_select(const PushdownPlan D) {
         __syncthreads();
         return s_total;
     };
-    auto count_ge = [&](uint32_t t) -> uint32_t {  // live cells with count >= t
+    // the counts of this thread's cells, once, in registers (n <= 65536: at most 64 per thread); every probe of the search
+    // below is then 64 compares and one block sum, and the search runs over [1, largest count] only
+    constexpr uint32_t kPer = 64;
+    uint32_t mine[kPer];
+    uint32_t top = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < kPer; k++) {
+        const uint32_t i = tid + k * 1024u;
+        mine[k] = i < n ? D.cnt[i] : 0u;
+        top = mine[k] > top ? mine[k] : top;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t m = __shfl_xor(top, o, 64);
+        top = m > top ? m : top;
+    }
+    if ((tid & 63u) == 0) red[tid >> 6] = top;
+    __syncthreads();
+    top = 0;
+    for (int k = 0; k < 16; k++) top = red[k] > top ? red[k] : top;
+    __syncthreads();
+    auto count_ge = [&](uint32_t t) -> uint32_t {  // live cells with count >= t (t >= 1)
         uint32_t c = 0;
-        for (uint32_t i = tid; i < n; i += 1024) c += (D.cnt[i] >= t && D.cnt[i] > 0) ? 1u : 0u;
+#pragma unroll
+        for (uint32_t k = 0; k < kPer; k++) c += mine[k] >= t ? 1u : 0u;
         return block_sum(c);
     };
     // T = the largest t >= 1 with count_ge(t) >= L; fewer than L live cells: T = 1 (all of them are printed)
     uint32_t T = 1;
-    if (count_ge(1) >= L) {
-        uint32_t lo = 1, hi = 0xFFFFFFFFu;  // invariant: count_ge(lo) >= L
+    if (top >= 1 && count_ge(1) >= L) {
+        uint32_t lo = 1, hi = top;  // invariant: count_ge(lo) >= L
         while (lo < hi) {
-            const uint32_t mid = lo + (uint32_t)(((uint64_t)hi - lo + 1) >> 1);
+            const uint32_t mid = lo + ((hi - lo + 1) >> 1);
             if (count_ge(mid) >= L) lo = mid;
             else hi = mid - 1;
         }

@@ -44,14 +44,17 @@ for v in hash wide; do { echo "# tools/bench_selectivity.py 1000000000 5 $v at H
 { echo "# rocprofv3 --pmc FETCH_SIZE -- python tools/bench_selectivity.py 1000000000 1 hash   (k_scan_hash_packed with late materialisation, round 6; KiB per dispatch; x2 on gfx950;"
   echo "# dispatches in the order of the selectivity table: 51 %, 10 %, 1 %, 0.1 %, 1e-6, 0 -- four scans each)"; python tools/rocpd_dispatches.py $O/selh_pmc/*.db k_scan_hash_packed FETCH_SIZE 2>/dev/null; } > $O/r06_selectivity_hash_fetch_size.txt
 rm -rf $O/selh_pmc
+( cd /tmp && export TMPDIR=/tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$O/pdkt -o kt -- python $GRAFT_REPO_ROOT/tools/bench_pushdown.py > $GRAFT_REPO_ROOT/$O/pd.log 2>&1 )
+{ echo "# rocprofv3 --kernel-trace --stats -- python tools/bench_pushdown.py (MI355X, $(date -u +%Y-%m-%dT%H:%MZ)): config 4 as a printer's query, the full path (printed_only = 1, strategy 5) and -limit 100 pushed into the scan (printed_only = 2, strategy 8), ten back-to-back scans each"; grep "^{" $O/pd.log; python tools/rocpd_summary.py $O/pdkt/*.db 2>/dev/null | grep -v "rocclr\|k_synth\|k_block_minmax\|k_fill\|k_repack"; } > $O/r06_pushdown_kernel_trace.txt
+rm -rf $O/pdkt
 { echo "# tools/micro/ldsrate (MI355X, $(date -u +%Y-%m-%dT%H:%MZ)): LDS atomic issue rates per CU with k_scan_packed's low-cardinality table layout"; timeout -k 10 120 tools/micro/ldsrate; } > $O/r06_ldsrate.txt 2>&1
 { echo "# tools/cold_cli_phases.py (MI355X, $(date -u +%Y-%m-%dT%H:%MZ)): sybil-gpu-query -stats on the saved 104.9 M-row, 7-column table, a fresh process each; the last line: the process without a table"; SYBL_LOADER_TRACE=1 timeout -k 10 300 python tools/cold_cli_phases.py; } > $O/r06_cold_cli_phases.txt 2>&1
 { echo "# tools/micro/loadpat_cfg2 (MI355X, $(date -u +%Y-%m-%dT%H:%MZ))"; timeout -k 10 120 tools/micro/loadpat_cfg2; } > $O/r06_loadpat_cfg2.txt 2>&1
 { echo "# tools/bench_dictkey.py (MI355X, $(date -u +%Y-%m-%dT%H:%MZ))"; timeout -k 10 300 python tools/bench_dictkey.py; } > $O/r06_dictkey.txt 2>&1
 { echo "# tools/clock_scan.py cfg4 25 3 (MI355X, $(date -u +%Y-%m-%dT%H:%MZ)): config 4's scan kernels back to back for 25 s after 3 s of idle"; timeout -k 10 200 python tools/clock_scan.py cfg4 25 3; } > $O/r06_cfg4_clock_power_temp_scan.txt 2>&1
 { echo "# tools/emit_placement.py (MI355X, $(date -u +%Y-%m-%dT%H:%MZ))"; timeout -k 10 200 python tools/emit_placement.py 6 3; } > $O/r06_emit_placement.txt 2>&1
-{ echo "# tools/ab_scan.py cfg4 (MI355X, $(date -u +%Y-%m-%dT%H:%MZ)): k_count_key (16-byte key loads) against k_count_packed (SYBL_NO_COUNT16=1)"; timeout -k 10 400 python tools/ab_scan.py cfg4 3 count_key=- count_packed=-,SYBL_NO_COUNT16=1; } > $O/r06_ab_count_key.txt 2>&1
-tail -3 $O/r06_selectivity_hash.txt | cut -c1-160; tail -6 $O/r06_cold_cli_phases.txt | cut -c1-400; tail -4 $O/r06_variants.txt; tail -7 $O/r06_selectivity.txt | cut -c1-160; tail -14 $O/r06_loadpat_cfg2.txt; tail -3 $O/r06_dictkey.txt; tail -4 $O/r06_emit_placement.txt; tail -3 $O/r06_ab_count_key.txt; tail -6 $O/r06_cfg4_clock_power_temp_scan.txt
+{ echo "# tools/ab_scan.py cfg4 (MI355X, $(date -u +%Y-%m-%dT%H:%MZ)): the counting pass reused across rescans against counted by every scan (SYBL_NO_COUNT_CACHE=1)"; timeout -k 10 400 python tools/ab_scan.py cfg4 3 count_cached=- count_every_scan=-,SYBL_NO_COUNT_CACHE=1; } > $O/r06_ab_count_cache.txt 2>&1
+tail -3 $O/r06_selectivity_hash.txt | cut -c1-160; tail -6 $O/r06_cold_cli_phases.txt | cut -c1-400; tail -4 $O/r06_variants.txt; tail -7 $O/r06_selectivity.txt | cut -c1-160; tail -14 $O/r06_loadpat_cfg2.txt; tail -3 $O/r06_dictkey.txt; tail -4 $O/r06_emit_placement.txt; tail -3 $O/r06_ab_count_cache.txt; tail -6 $O/r06_cfg4_clock_power_temp_scan.txt
 fi
 timeout -k 10 120 python bench.py --force-dist --no-cpu-baseline --no-load --no-canonical --no-configs --steps 10 --warmup 2 2>/dev/null | python -c "
 import json,sys
