@@ -251,7 +251,9 @@ static int scan(Query *q) {
     const bool ran = !q->never_matches && !q->segs.empty();
     hipError_t e = hipSuccess;
     if ((rc = out_log_begin(q, st))) return rc;
+    q->pushdown_ran = false;
     if (q->pushdown && ran) {
+        q->pushdown_ran = true;
         // -limit pushed into the scan (pushdown.hip): group counts from the key column, the printed cells chosen on the
         // device, then ONE pass over key + value that fills Cumulative and the printed groups only
         PushdownPlan &D = q->dplan_pd;

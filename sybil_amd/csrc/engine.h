@@ -521,6 +521,7 @@ struct Query {
     // -limit pushed into the scan (pushdown.hip): sybl_query_desc.printed_only = 2 on a query strategy 5 would take, one
     // direct-mapped key of <= 65536 cells, no filter, sorted by $COUNT descending, one GPU
     bool pushdown = false;
+    bool pushdown_ran = false;  // the last scan went through it (a query that matches nothing, an empty table: the ordinary zeroed tables)
     PushdownPlan dplan_pd;
     uint32_t *d_pd = nullptr;  // ws | carry | cnt | bitmap | top_cells | n_top in one allocation
     bool count_cached = false;  // d_cursor holds the count pass's regions for this query's rows (engine.cpp: a rescan skips k_count)

@@ -493,7 +493,7 @@ int query_snapshot(Query *q) {
     if (q->top_only) {
         int rc = query_total_buffers(q);
         if (rc) return rc;
-        if (!q->pushdown) {  // (a pushed-down scan summed Cumulative's buckets itself, from every row: pushdown.hip)
+        if (!(q->pushdown && q->pushdown_ran)) {  // (a pushed-down scan summed Cumulative's buckets itself, from every row: pushdown.hip)
             SYBL_HIP(hipMemsetAsync(q->d_total, 0, (size_t)P.hist_stride * 8, st));
             hipError_t e = launch_hist_total(q->d_sum + P.hist_off, P.hist_stride, 0, P.n_cells, q->d_total, st);
             if (e != hipSuccess) return hip_fail(e, "k_hist_total");
@@ -759,7 +759,7 @@ int query_finalize(Query *q, Result **out) {
     C.H = H;
     C.hm = hm;
     C.top_only = q->top_only;
-    C.pushdown = q->pushdown && q->top_only;
+    C.pushdown = q->pushdown && q->pushdown_ran && q->top_only;
     if (C.pushdown)
         for (int a = 0; a < kMaxAggs; a++) {
             C.pd_sum[a] = hs[kHdrPdSum + a];

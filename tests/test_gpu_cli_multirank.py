@@ -112,6 +112,20 @@ def _check_json(name, rows, lo, q):
                 assert r[col] == pytest.approx(oh["sum_exact"] / oh["count"], rel=1e-6), (name, key, col)
 
 
+def test_ranks_without_a_block(tmp_path, oracle):
+    """Three blocks over four ranks: one rank opens nothing -- no rows, no extrema, empty dictionaries -- and still takes part in
+    every collective of the agreement and the merge; the output is the one-process CLI's."""
+    from tests.test_gpu_loader import _make_blocks
+    root = str(tmp_path / "db3")
+    blocks, _ = _make_blocks(3, 2000, seed=5, ragged=True)
+    F.write_table(root, "events", blocks, threshold=8, int_info={"big": LO.INFO_BIG})
+    for name in ("str_key_json", "sparse_key_json", "hashed_json", "timeseries_text", "set_filter_hist_json"):
+        args = QUERIES[name][0]
+        want = _one(root, args)
+        outs = _world(root, args, 4, str(tmp_path), "e" + name)
+        assert outs[0] == want and len(want) > 0, (name, outs[0][:300], want[:300])
+
+
 def test_cli_rank_arguments_are_checked(db):
     root, _ = db
     for extra in (["-gpu-ranks", "2"], ["-gpu-rank", "2", "-gpu-ranks", "2", "-gpu-id-file", "/tmp/x"], ["-gpu-rank", "-1", "-gpu-id-file", "/tmp/x"]):

@@ -127,3 +127,31 @@ def test_queries_the_pushdown_does_not_take_answer_as_a_printer(ctx):
         r.free()
         qy.free()
     tb.free()
+
+
+def test_nothing_to_scan_and_odd_shapes(ctx):
+    """An empty table, a table whose key space is odd in size, and a limit of one: the pushed-down path and the full path print
+    the same (an empty table scans nothing: the ordinary zeroed tables answer)."""
+    rng = np.random.default_rng(17)
+    for n, card in ((0, 3001), (400_000, 3001), (300_000, 2049)):
+        tb = ctx.create_table("odd")
+        tb.add_column("k", "int", 0, card - 1)
+        tb.add_column("v", "int", 0, 9999)
+        key, val = rng.integers(0, card, n), rng.integers(0, 10_000, n)
+        for r0 in range(0, n, 65536):
+            tb.append_block(min(65536, n - r0), {"k": key[r0:r0 + 65536], "v": val[r0:r0 + 65536]})
+        tb.set_bounds("k", 0, card - 1)
+        tb.set_bounds("v", 0, 9999)
+        tb.compact()
+        for limit in (1, 10):
+            q = dict(groups=["k"], aggs=["v"], op="hist", want_percentiles=True, limit=limit, order_by="$COUNT")
+            (r1, q1, s1), (r2, q2, s2) = _both(tb, q)
+            if n:
+                assert s2["strategy"] == 8, s2["strategy"]
+            assert r2.render("text") == r1.render("text") and r2.render("json") == r1.render("json"), (n, card, limit)
+            assert r2.matched == r1.matched == n
+            for r in (r1, r2):
+                r.free()
+            q1.free()
+            q2.free()
+        tb.free()

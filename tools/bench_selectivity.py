@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Config 3 (3 ANDed int-range filters, group-by 2, moments of 2 columns) at different selectivities on compact
 storage: does the row body's LDS-atomic issue still cost time when almost no row matches?
-usage: bench_selectivity.py [rows] [steps] [packed|hash|wide]
+usage: bench_selectivity.py [rows] [steps] [packed|hash|wide|nul]
+  nul: the NUL variant of k_scan_packed forced (SYBL_FORCE_NUL=1: validity words, per-aggregation gates)
   hash: the same queries through the hash table (SYBL_FORCE_HASH=1: k_scan_hash_packed); wide: four aggregation columns
   (k_scan_hash_packed<4, .., HASH = false>, the run-time-count direct-mapped body)"""
 import json, os, sys, time
@@ -17,6 +18,8 @@ base = dict(wl["query"])
 cols = list(wl["columns"])
 if variant == "hash":
     os.environ["SYBL_FORCE_HASH"] = "1"
+elif variant == "nul":
+    os.environ["SYBL_FORCE_NUL"] = "1"
 elif variant == "wide":
     cols += ["c09"]
     base["aggs"] = ["c07", "c08", "c09", "c04"]

@@ -39,7 +39,7 @@ if [ -z "$SKIP_TABLES" ]; then
 { echo "# rocprofv3 --pmc FETCH_SIZE -- python tools/bench_selectivity.py 1000000000 1   (KiB per dispatch; x2 on gfx950; dispatches in the order of the"
   echo "# selectivity table: 51 %, 10 %, 1 %, 0.1 %, 1e-6, 0 -- four scans each)"; python tools/rocpd_summary.py $O/sel_pmc/*.db 2>/dev/null | grep -v "rocclr\|k_synth\|k_block_minmax\|k_fill\|k_repack"; python tools/rocpd_dispatches.py $O/sel_pmc/*.db k_scan_packed FETCH_SIZE 2>/dev/null; } > $O/r06_selectivity_fetch_size.txt
 rm -rf $O/sel_pmc
-for v in hash wide; do { echo "# tools/bench_selectivity.py 1000000000 5 $v at HEAD (MI355X, $(date -u +%Y-%m-%dT%H:%MZ)): config 3's shape through k_scan_hash_packed (hash: SYBL_FORCE_HASH=1; wide: four aggregations, direct-mapped) at different selectivities"; timeout -k 10 300 python tools/bench_selectivity.py 1000000000 5 $v; } > $O/r06_selectivity_$v.txt 2>&1; done
+for v in hash wide nul; do { echo "# tools/bench_selectivity.py 1000000000 5 $v at HEAD (MI355X, $(date -u +%Y-%m-%dT%H:%MZ)): config 3's shape through k_scan_hash_packed (hash: SYBL_FORCE_HASH=1; wide: four aggregations, direct-mapped) at different selectivities"; timeout -k 10 300 python tools/bench_selectivity.py 1000000000 5 $v; } > $O/r06_selectivity_$v.txt 2>&1; done
 ( cd /tmp && export TMPDIR=/tmp && timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE -d $GRAFT_REPO_ROOT/$O/selh_pmc -o sel -- python $GRAFT_REPO_ROOT/tools/bench_selectivity.py 1000000000 1 hash > $GRAFT_REPO_ROOT/$O/selh_pmc.log 2>&1 )
 { echo "# rocprofv3 --pmc FETCH_SIZE -- python tools/bench_selectivity.py 1000000000 1 hash   (k_scan_hash_packed with late materialisation, round 6; KiB per dispatch; x2 on gfx950;"
   echo "# dispatches in the order of the selectivity table: 51 %, 10 %, 1 %, 0.1 %, 1e-6, 0 -- four scans each)"; python tools/rocpd_dispatches.py $O/selh_pmc/*.db k_scan_hash_packed FETCH_SIZE 2>/dev/null; } > $O/r06_selectivity_hash_fetch_size.txt
