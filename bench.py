@@ -555,6 +555,9 @@ def main():
                                             "steps": min(steps, 10), "roofline": roofline(canon)}
             if (world == 1 or one_device) and not args.no_oracle_check:
                 out["oracle_check"] = oracle_check(workload, q, total_rows, head)
+                # (the check burns every host thread for seconds: the container's CPU quota throttles whatever follows inside the
+                # same accounting periods -- the next config's host half once took 25 ms for one finalize.  Let the periods pass.)
+                time.sleep(0.5)
         table.free()
         return out
 

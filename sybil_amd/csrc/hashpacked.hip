@@ -28,7 +28,10 @@ namespace sybl {
 #endif
 constexpr bool kHashPackedLate = SYBL_HASH_PACKED_LATE != 0;
 
-template <int NA, int MODE, bool NUL, bool HASH, int T>
+// LATE: the kernel IS the late path (filter columns a tile ahead).  A kernel of its own, not a branch of the plain one: with both
+// loops in one body the register allocator served neither -- the plain loop ran at 7.97 ms where it takes 4.62 alone (config 3
+// through the table), the late one at 4.85 (profiles/r06_late_path_ab.txt).
+template <int NA, int MODE, bool NUL, bool HASH, int T, bool LATE = false>
 __global__ __launch_bounds__(T) void k_scan_hash_packed(const FastPlan P, uint64_t *hash_keys, const int nf, const int ng, const int time,
                                                                  const int L_, const int F, const int M) {
     extern __shared__ int64_t lds[];
@@ -268,7 +271,7 @@ __global__ __launch_bounds__(T) void k_scan_hash_packed(const FastPlan P, uint64
 #pragma unroll
                 for (int c = 0; c < NA; c++) packed_decode(P.awid[c], ra.v[c], a.u[c]);
             };
-            if (kHashPackedLate && !NUL && nf > 0) {
+            if (kHashPackedLate && LATE && !NUL) {
                 // Late materialisation (the reference's row loop leaves a row at its first failing filter, aggregate.go:105-116),
                 // as in k_scan_packed (scan_packed.h): the filter columns run one tile ahead of the key / aggregation / time
                 // columns, and a WAVE none of whose 256 rows passes does not read the other columns of that tile -- the loads
@@ -399,6 +402,9 @@ static hipError_t hash_packed_launch(const FastPlan &P, uint64_t *keys, int nf, 
                                      hipStream_t st) {
     int T = 1024;
     auto kfn = k_scan_hash_packed<NA, MODE, NUL, HASH, 1024>;
+    if constexpr (kHashPackedLate && !NUL) {
+        if (nf > 0 && P.late) kfn = k_scan_hash_packed<NA, MODE, NUL, HASH, 1024, true>;
+    }
 #ifdef SYBL_THREADS_AB  // (hashfast.hip: fewer threads, no spills -- and slower)
     if (const char *e = env("SYBL_HASH_PACKED_THREADS")) T = atoi(e);
     if (T == 768) kfn = k_scan_hash_packed<NA, MODE, NUL, HASH, 768>;

@@ -105,6 +105,26 @@ static bool fill_packed(Table *t, Query *q, const std::vector<int> &slot_col, Fa
             if (off >= 0 && off <= umax) FP.pneq[c][FP.npneq[c]++] = (uint32_t)off;  // (else: no stored value equals it)
         }
     }
+    {
+        // (FastPlan::late) the share of rows the range filters let through, were the columns' values uniform over their extrema
+        double pass = 1.0;
+        for (int c = 0; c < nf; c++) {
+            const Column *col = nullptr;
+            for (auto &cp : t->cols) {
+                if (cp->d_data == (const void *)FP.fcol[c]) col = cp.get();
+                if (cp->rank_col && cp->rank_col->d_data == (const void *)FP.fcol[c]) col = cp->rank_col.get();
+            }
+            if (FP.plo[c] > FP.phi[c]) {
+                pass = 0.0;
+            } else if (col && col->n_pop > 0 && col->exact_max >= col->vbase && !FP.fmask[c]) {
+                const double top = (double)((__int128)col->exact_max - (__int128)col->vbase);
+                const double hi = std::min((double)FP.phi[c], top), lo = (double)FP.plo[c];
+                pass *= hi >= lo ? std::min(1.0, (hi - lo + 1.0) / (top + 1.0)) : 0.0;
+            }
+        }
+        FP.late = nf > 0 && pass < 0.005 ? 1 : 0;
+        if (const char *e = env("SYBL_LATE_PATH")) FP.late = atoi(e) != 0;  // (A/B: 0 / 1 whatever the estimate)
+    }
     for (int c = 0; c < ng; c++) FP.gdoff[c] = (uint32_t)((uint64_t)FP.gbase[c] - (uint64_t)FP.gmin[c]);
     for (int c = 0; c < na; c++) {
         // Info.Min <= v <= Info.Max*10 (hist_basic.go:104) as a range of offsets; only looked at when the

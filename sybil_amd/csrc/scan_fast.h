@@ -95,7 +95,11 @@ struct FastPlan {
     uint32_t gdoff[kFastMaxG];                 // gbase - gmin   (mod 2^32)
     uint32_t adoff[kFastMaxA];                 // abase - h.Min  (mod 2^32)
     uint32_t tdoff;                            // tbase - tb_min * time_bucket
-    int32_t pad3_;
+    // k_scan_hash_packed: take the late path (filter columns a tile ahead, the other columns loaded only for waves with a
+    // passing row) -- it wins below ~0.5 % of the rows passing and costs 4-17 % of the kernel when most rows pass
+    // (profiles/r06_selectivity_hash.txt), so the planner turns it on from the filters' ranges against the columns' extrema
+    // (fill_packed; uniform values assumed: a wrong guess costs that much, never a result)
+    int32_t late;
     double pinv_bucket[kFastMaxA], pinv_time;  // reciprocals scaled by (1 - 2^-40): never above the true quotient
     // k_scan_packed<NUL>: columns with missing rows / str ids / the Info.Min..Max*10 reject gate, rebased:
     // a value is accepted iff alo <= offset <= ahi

@@ -405,11 +405,10 @@ constexpr bool kPackedLate = SYBL_PACKED_LATE != 0;
 #define SYBL_PACKED_LATE_BRANCH 1
 #endif
 constexpr bool kPackedLateBranch = SYBL_PACKED_LATE_BRANCH != 0;
-// SYBL_PACKED_LATE_NUL=0 at build time: the NUL variants without their late path (round 6; same-box A/B builds)
-#ifndef SYBL_PACKED_LATE_NUL
-#define SYBL_PACKED_LATE_NUL 1
-#endif
-constexpr bool kPackedLateNul = SYBL_PACKED_LATE_NUL != 0;
+// (A late path inside the NUL variants was built and measured in round 6 and taken out again: in one body with the plain loop it
+// cost the variant 268 B of scratch and its plain path 3.3 -> 4.05 ms per 1e9 rows of config 3, for 2.95 -> 2.79 ms at 0.1 %
+// selectivity -- the NUL row body's own floor; profiles/r06_late_path_ab.txt.  As a kernel of its own it would be ~390 more
+// instantiations of this template.)
 
 #ifndef SYBL_PACKED_WAVES_PER_EU
 #define SYBL_PACKED_WAVES_PER_EU 4
@@ -594,141 +593,6 @@ __global__ __launch_bounds__(kWgThreads, SYBL_PACKED_WAVES_PER_EU) void k_scan_p
 #pragma unroll
                         for (int k = 0; k < kPackedRows; k++)
                             packed_row<0, NG, NA, MODE, TIME, false>(P, f0, g, a, t, k, (bits >> k) & 1u, lds, L, matched, overflow);
-                    }
-                    bits = next_bits;
-                }
-                continue;
-            }
-            if (kPackedLateNul && NUL && NF > 0 && NG + NA + (TIME ? 1 : 0) > 0) {
-                // Late materialisation for the NUL variants (round 6): the same schedule as above -- filter columns a tile ahead,
-                // the other columns' loads through a zero-record descriptor when no row of the wave's tile passes -- with the
-                // whole of a NUL filter in the predicate: the offset range or the dictionary-id mask, the neq constants, the
-                // value's validity bit and the pre-pass bitmap's verdict.  The rows then run the body without filters
-                // (packed_row<0, ..>): the plain one when the tile's key / value / time columns are fully populated and the
-                // plan asks for nothing else (`light`), the NUL one otherwise.
-                const uint32_t r_first = tid * kPackedRows;
-                const uint32_t n_tiles = (n + kPackedTileRows - 1) / kPackedTileRows;
-                PackedTile<0> f0;
-                uint32_t xw = 0xFFFFFFFFu;
-                auto rows_of = [&](uint32_t r0) -> uint32_t {
-                    return r0 < n ? (n - r0 < 64u * kPackedRows ? (n - r0 + kPackedRows - 1) & ~(uint32_t)(kPackedRows - 1) : 64u * kPackedRows) : 0u;
-                };
-                auto issue_filters = [&](uint32_t r) {
-                    const uint32_t r0 = __builtin_amdgcn_readfirstlane(r), lane_row = r - r0, rows = rows_of(r0);
-                    const uint32_t base_row = rows ? r0 : 0u;
-                    const bool in = r < n;
-                    const int64_t wd = (first + (in ? r : 0u)) >> 5;
-                    xw = (xv && in) ? P.xvalid[wd] : 0xFFFFFFFFu;
-#pragma unroll
-                    for (int c = 0; c < NF; c++) {
-                        rf.pw[c] = (P.fvalid[c] && in) ? P.fvalid[c][wd] : 0xFFFFFFFFu;
-                        const int ws = P.fwid[c] >> 1;
-                        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(B.f[c] + ((size_t)base_row << ws)), 0, (int)(rows << ws), (int)kBufferRsrcWord3);
-                        rf.v[c] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(lane_row << ws), 0, 2);
-                    }
-                };
-                auto issue_rest = [&](uint32_t r, bool wanted) {
-                    const uint32_t r0 = __builtin_amdgcn_readfirstlane(r), lane_row = r - r0;
-                    const uint32_t rows = wanted ? rows_of(r0) : 0u, base_row = rows ? r0 : 0u;
-                    const bool in = wanted && r < n;
-                    const int64_t wd = (first + (in ? r : 0u)) >> 5;
-                    auto issue = [&](const uint8_t *col, int width, pu32x4 &raw) {
-                        const int ws = width >> 1;
-                        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(col + ((size_t)base_row << ws)), 0, (int)(rows << ws), (int)kBufferRsrcWord3);
-                        raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(lane_row << ws), 0, 2);
-                    };
-                    if (TIME) {
-                        rt.pw[0] = (P.tvalid && in) ? P.tvalid[wd] : 0xFFFFFFFFu;
-                        issue(B.t, P.twid, rt.v[0]);
-                    }
-#pragma unroll
-                    for (int c = 0; c < NG; c++) {
-                        rg.pw[c] = (P.gvalid[c] && in) ? P.gvalid[c][wd] : 0xFFFFFFFFu;
-                        if (G1) {
-                            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(B.g[c] + (size_t)base_row), 0, (int)rows, (int)kBufferRsrcWord3);
-                            rg.v[c].x = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)lane_row, 0, 2);
-                        } else {
-                            issue(B.g[c], P.gwid[c], rg.v[c]);
-                        }
-                    }
-#pragma unroll
-                    for (int c = 0; c < NA; c++) {
-                        ra.pw[c] = (P.avalid[c] && in) ? P.avalid[c][wd] : 0xFFFFFFFFu;
-                        issue(B.a[c], P.awid[c], ra.v[c]);
-                    }
-                };
-                auto filter_bits = [&](uint32_t r) -> uint32_t {
-                    const uint32_t bit0 = (uint32_t)(first + r) & 31u;
-                    const uint32_t left = r < n ? n - r : 0u;
-                    uint32_t bits = (xw >> bit0) & 0xFu;  // the pre-pass's verdict (all ones without one)
-#pragma unroll
-                    for (int c = 0; c < NF; c++) {
-                        packed_decode(P.fwid[c], rf.v[c], f.u[c]);
-                        bits &= (rf.pw[c] >> bit0) & 0xFu;  // an unpopulated value fails every filter
-                    }
-                    uint32_t out = 0;
-#pragma unroll
-                    for (int k = 0; k < kPackedRows; k++) {
-                        bool pass = ((uint32_t)k < left) & ((bits >> k) & 1u);
-#pragma unroll
-                        for (int c = 0; c < NF; c++) {
-                            const uint32_t u = f.u[c][k];
-                            bool ok = (u >= P.plo[c]) & (u <= P.phi[c]);
-                            if (P.fmask[c]) {
-                                const uint32_t id = u + (uint32_t)P.fbase[c];
-                                ok = id < (uint32_t)P.fmask_bits[c];
-                                if (ok) ok = (P.fmask[c][id >> 5] >> (id & 31)) & 1u;
-                            }
-                            for (int j = 0; j < P.npneq[c]; j++) ok = ok & (u != P.pneq[c][j]);
-                            pass = pass & ok;
-                        }
-                        out |= pass ? 1u << k : 0u;
-                    }
-                    return out;
-                };
-                issue_filters(r_first);
-                uint32_t bits = filter_bits(r_first);
-                issue_rest(r_first, __builtin_amdgcn_ballot_w64(bits != 0) != 0);
-                issue_filters(r_first + kPackedTileRows);
-                for (uint32_t it = 0; it < n_tiles; it++) {
-                    const uint32_t r = r_first + it * kPackedTileRows;
-                    const uint32_t bit0 = (uint32_t)(first + r) & 31u;
-                    uint32_t allpop = 0xFu;
-                    if (TIME) {
-                        packed_decode(P.twid, rt.v[0], t.u[0]);
-                        t.pop[0] = (rt.pw[0] >> bit0) & 0xFu;
-                        allpop &= t.pop[0];
-                    }
-#pragma unroll
-                    for (int c = 0; c < NG; c++) {
-                        packed_decode(G1 ? 1 : P.gwid[c], rg.v[c], g.u[c]);
-                        g.pop[c] = (rg.pw[c] >> bit0) & 0xFu;
-                        allpop &= g.pop[c];
-                    }
-#pragma unroll
-                    for (int c = 0; c < NA; c++) {
-                        packed_decode(P.awid[c], ra.v[c], a.u[c]);
-                        a.pop[c] = (ra.pw[c] >> bit0) & 0xFu;
-                        allpop &= a.pop[c];
-                    }
-                    const uint32_t next_bits = filter_bits(r + kPackedTileRows);
-                    issue_rest(r + kPackedTileRows, __builtin_amdgcn_ballot_w64(next_bits != 0) != 0);
-                    issue_filters(r + 2u * kPackedTileRows);
-                    // (light: decided once per kernel above; a tile none of whose rows passes was not loaded -- its validity
-                    // words read all ones, its rows do nothing)
-                    const bool plain_tile = light && __builtin_amdgcn_ballot_w64(allpop != 0xFu) == 0;
-                    if (plain_tile && !outliers) {
-#pragma unroll
-                        for (int k = 0; k < kPackedRows; k++)
-                            packed_row<0, NG, NA, MODE, TIME, false, FRESH>(P, f0, g, a, t, k, (bits >> k) & 1u, lds, L, matched, overflow);
-                    } else if (plain_tile) {
-#pragma unroll
-                        for (int k = 0; k < kPackedRows; k++)
-                            packed_row<0, NG, NA, MODE, TIME, false, FRESH, true>(P, f0, g, a, t, k, (bits >> k) & 1u, lds, L, matched, overflow);
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < kPackedRows; k++)
-                            packed_row<0, NG, NA, MODE, TIME, true, FRESH>(P, f0, g, a, t, k, (bits >> k) & 1u, lds, L, matched, overflow);
                     }
                     bits = next_bits;
                 }

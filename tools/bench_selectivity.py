@@ -47,7 +47,7 @@ for label, filters in cases:
     r.free()
     st = q.stats()
     k = sorted(ms)[len(ms) // 2]
-    print(json.dumps({"variant": variant, "selectivity": label, "rows": rows, "matched": matched, "match_frac": matched / rows, "kernel_ms": round(k, 3),
+    print(json.dumps({"variant": variant, "late_path": os.environ.get("SYBL_LATE_PATH", "planner's estimate"), "selectivity": label, "rows": rows, "matched": matched, "match_frac": matched / rows, "kernel_ms": round(k, 3),
                       "GBps": st["algorithmic_bytes"] / (k * 1e-3) / 1e9, "packed_kernel": st["packed_kernel"], "strategy": st["strategy"]}))
     sys.stdout.flush()
     q.free()
