@@ -186,6 +186,9 @@ typedef struct {
     int64_t file_bytes;     /* bytes read from column / info files (after gunzip) */
     int64_t h2d_bytes;      /* bytes that crossed PCIe */
     int32_t workers, blocks;
+    /* SYBL_LOADER_GPU_VARINT=1 (ABI 5): column files whose varints were walked on the GPU (csrc/gobgpu.hip), and blocks the
+     * host parser then loaded again because a walk reported damage or values outside the block's info.db bounds */
+    int32_t gpu_varint_cols, gpu_varint_redone;
 } sybl_load_stats;
 int sybl_table_load_stats(const sybl_table *t, sybl_load_stats *out);
 

@@ -81,7 +81,8 @@ class GroupRow(C.Structure):
 
 class LoadStats(C.Structure):
     _fields_ = [("wall_s", C.c_double), ("parse_cpu_s", C.c_double), ("wait_s", C.c_double), ("apply_s", C.c_double),
-                ("file_bytes", C.c_int64), ("h2d_bytes", C.c_int64), ("workers", C.c_int32), ("blocks", C.c_int32)]
+                ("file_bytes", C.c_int64), ("h2d_bytes", C.c_int64), ("workers", C.c_int32), ("blocks", C.c_int32),
+                ("gpu_varint_cols", C.c_int32), ("gpu_varint_redone", C.c_int32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

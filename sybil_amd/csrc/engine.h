@@ -57,6 +57,7 @@ hipError_t launch_remap_ids(const void *local, int local_width, const int32_t *l
 // one block's bucket-encoded / value-encoded columns, a launch each (loader.cpp: DecodeBatches); arguments as above
 hipError_t launch_decode_bins_multi(const DecodeBinsBatch &B, hipStream_t st);
 hipError_t launch_decode_delta_multi(const DecodeDeltaBatch &B, hipStream_t st);
+hipError_t launch_gob_values(const GobValuesBatch &B, hipStream_t st);  // gobgpu.hip: the varint walk of value-encoded int columns
 
 hipError_t launch_hist_summary(const HistSummaryPlan &S, int64_t *total, hipStream_t st);
 hipError_t launch_rank_column(const void *col, int width, int64_t vbase, const uint32_t *valid, const int64_t *dkeys, const int32_t *dranks, uint32_t dmask,

@@ -286,6 +286,8 @@ struct Decoder {
     std::map<int64_t, TypeDef> types;
     std::string *err;
     DecodeOpts opts;
+    bool stop = false;                      // DecodeOpts::raw_values was found: unwind
+    const std::string *cur_field = nullptr; // name of the top-level struct's field being decoded
 
     bool fail(const std::string &m) {
         *err = "gob: " + m;
@@ -433,8 +435,10 @@ struct Decoder {
                 f += (int64_t)d;
                 if (f < 0 || f >= (int64_t)td.fields.size()) return fail("struct field index out of range in " + td.name);
                 ValuePtr v = std::make_shared<Value>();
+                if (depth == 0) cur_field = &td.fields[(size_t)f].first;
                 if (!value(r, td.fields[(size_t)f].second, *v, depth + 1)) return false;
                 out.fields.emplace_back(td.fields[(size_t)f].first, v);
+                if (stop) return true;
             }
         }
         case TypeDef::kArray:
@@ -444,6 +448,14 @@ struct Decoder {
             if (n > r.left()) return fail("slice longer than the message");
             if (is_int_kind(td.elem)) {
                 out.kind = Value::kIntVec;
+                if (opts.raw_values && depth == 1 && td.elem == tInt && cur_field && *cur_field == "Values") {
+                    opts.raw_values->p = r.p;
+                    opts.raw_values->end = r.end;
+                    opts.raw_values->n = n;
+                    opts.raw_values->hit = true;
+                    stop = true;
+                    return true;
+                }
                 if (opts.narrow && depth <= 1) {
                     // as int32 when every value fits (DecodeOpts); the reader goes back and takes them as int64 when not
                     const Reader at = r;

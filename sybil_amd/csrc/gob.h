@@ -79,8 +79,18 @@ struct IntBuf {
 // deltas as int32 -- decoded straight into that form they never exist as 512 KB int64 arrays, which was most of the memory
 // traffic of a load).  narrow: `Records` of a kBinVec come out as uint16 (IntBuf::w == 2) when every one of them fits, a
 // top-level int slice as int32 (w == 4) when every value fits; int64 otherwise, so a reader must look at w.
+// Where the top-level `Values []int64` slice of a column file lies, for a reader that wants the BYTES, not the numbers (the
+// loader's GPU varint walk, gobgpu.hip): its first element, the end of the value message, the count its header announced.
+struct RawInts {
+    const uint8_t *p = nullptr, *end = nullptr;
+    uint64_t n = 0;
+    bool hit = false;
+};
 struct DecodeOpts {
     bool narrow = false;
+    // non-null: a top-level struct's signed-int slice field named "Values" is not decoded -- *raw_values says where it lies and
+    // the decode STOPS there (the fields behind it, VERSION, are not read; the tree holds the fields before it)
+    RawInts *raw_values = nullptr;
 };
 
 struct Value {

@@ -538,7 +538,8 @@ constexpr int kDeltaPerThread = 8;
 constexpr int64_t kDeltaSegment = 1024 * kDeltaPerThread;
 template <typename V, typename O>
 __device__ __forceinline__ void decode_delta_body(const V *__restrict__ deltas, int64_t n, int value_encoded, int64_t vbase, O *__restrict__ col,
-                                                  uint32_t segment, int64_t *wave_tot /*[16]*/) {
+                                                  uint32_t segment, int64_t *wave_tot /*[16]*/, unsigned long long *chk_flags = nullptr,
+                                                  int64_t chk_min = 0, int64_t chk_max = 0) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t base = (int64_t)segment * kDeltaSegment;
     int64_t carry = 0;  // the sum of everything ahead of this segment
@@ -577,6 +578,13 @@ __device__ __forceinline__ void decode_delta_body(const V *__restrict__ deltas, 
 #pragma unroll
     for (int j = 0; j < kDeltaPerThread; j++)
         if (i0 + j < n) col[i0 + j] = (O)((uint64_t)v[j] - (uint64_t)vbase);
+    if (chk_flags) {
+        // (the loader's GPU varint walk, gobgpu.hip: the block was placed by its info.db bounds before anyone had seen a value)
+        bool out = false;
+#pragma unroll
+        for (int j = 0; j < kDeltaPerThread; j++) out = out || (i0 + j < n && (v[j] < chk_min || v[j] > chk_max));
+        if (__any(out) && lane == 0) atomicOr(chk_flags, (unsigned long long)kGobOutOfBounds);
+    }
 }
 
 template <typename V, typename O>
@@ -590,10 +598,10 @@ __global__ __launch_bounds__(1024) void k_decode_delta(const V *__restrict__ del
 template <typename V>
 __device__ __forceinline__ void decode_delta_job(const DecodeDeltaJob &J, uint32_t segment, int64_t *wave_tot) {
     switch (J.out_w) {
-    case 1: decode_delta_body<V, uint8_t>((const V *)J.deltas, J.n, J.venc, J.vbase, (uint8_t *)J.col, segment, wave_tot); break;
-    case 2: decode_delta_body<V, uint16_t>((const V *)J.deltas, J.n, J.venc, J.vbase, (uint16_t *)J.col, segment, wave_tot); break;
-    case 4: decode_delta_body<V, uint32_t>((const V *)J.deltas, J.n, J.venc, J.vbase, (uint32_t *)J.col, segment, wave_tot); break;
-    default: decode_delta_body<V, int64_t>((const V *)J.deltas, J.n, J.venc, J.vbase, (int64_t *)J.col, segment, wave_tot); break;
+    case 1: decode_delta_body<V, uint8_t>((const V *)J.deltas, J.n, J.venc, J.vbase, (uint8_t *)J.col, segment, wave_tot, J.chk_flags, J.chk_min, J.chk_max); break;
+    case 2: decode_delta_body<V, uint16_t>((const V *)J.deltas, J.n, J.venc, J.vbase, (uint16_t *)J.col, segment, wave_tot, J.chk_flags, J.chk_min, J.chk_max); break;
+    case 4: decode_delta_body<V, uint32_t>((const V *)J.deltas, J.n, J.venc, J.vbase, (uint32_t *)J.col, segment, wave_tot, J.chk_flags, J.chk_min, J.chk_max); break;
+    default: decode_delta_body<V, int64_t>((const V *)J.deltas, J.n, J.venc, J.vbase, (int64_t *)J.col, segment, wave_tot, J.chk_flags, J.chk_min, J.chk_max); break;
     }
 }
 __global__ __launch_bounds__(1024) void k_decode_delta_multi(const DecodeDeltaBatch B) {

@@ -82,12 +82,15 @@ static void cgroup_throttle(int64_t *periods, int64_t *usec) {
 }
 
 // narrow: the int slices in the form they travel in (gob::DecodeOpts) -- the int / str column files of a block
-static bool decode_file(const std::string &path, gob::Value &v, std::string &err, bool narrow = false) {
+// raw: the file's top-level `Values` slice is located, not decoded (gob::RawInts: pointers into this thread's file buffer, valid
+// until the thread's next decode_file)
+static bool decode_file(const std::string &path, gob::Value &v, std::string &err, bool narrow = false, gob::RawInts *raw = nullptr) {
     static thread_local gob::FileBuf data;  // (reused: no allocation / page faults / zero-fill per file)
     if (!gob::read_file(path, data, err)) return false;
     g_file_bytes += (int64_t)data.n;
     gob::DecodeOpts opts;
     opts.narrow = narrow;
+    opts.raw_values = raw;
     return gob::decode(data.p, data.n, v, err, &opts);
 }
 
@@ -263,6 +266,12 @@ struct PreparedCol {
     // without asking the GPU for them)
     bool have_stats = false;
     int64_t vmin = INT64_MAX, vmax = INT64_MIN, vpop = 0;
+    // SYBL_LOADER_GPU_VARINT (round 6, gobgpu.hip): a value-encoded int column whose file bytes travel as they are --
+    // raw_at / raw_len: the `Values` region in the slab; val_at (int64 values) and tok_at (uint32 offsets) are DEVICE-ONLY
+    // scratch, relative to PreparedBlock::scratch_at (behind the bytes that cross PCIe).  vmin / vmax are then the block
+    // info.db's IntInfo, which the kernel's own extrema are checked against when the load ends.
+    int64_t raw_len = 0;
+    size_t raw_at = 0, tok_at = 0;
 };
 
 struct PreparedBlock {
@@ -272,6 +281,7 @@ struct PreparedBlock {
     std::string why;
     std::vector<PreparedCol> cols;
     size_t bytes = 0;          // of the slab that are in use
+    size_t scratch_at = 0;     // device-only scratch behind them (GPU varint walk): not copied
     char *own_h = nullptr, *own_d = nullptr;  // a block too large for the pool's slabs brings its own pair
     std::pair<int64_t, int64_t> sig{-1, -1};  // block_signature, taken by the worker before it reads the block
 };
@@ -292,12 +302,13 @@ struct ColSpec {
 constexpr int64_t kMaxBlockRows = (int64_t)1 << 24;  // 256 x the reference's block size
 
 static PreparedBlock prepare_block_unguarded(const std::string &bdir, const std::vector<ColSpec> &specs, char *slab_h, size_t slab_cap, int device,
-                                             bool streamed = true);
+                                             bool streamed = true, bool gpu_varint = false);
 static std::pair<int64_t, int64_t> block_signature(const std::string &bdir);
 // A worker thread must not let an exception escape (std::bad_alloc / length_error from a damaged file): it
 // would be rethrown by future::get() and leave the extern "C" entry point.  The block is skipped instead,
 // like every other block the reference cannot read.
-static PreparedBlock prepare_block(const std::string &bdir, const std::vector<ColSpec> &specs, char *slab_h, size_t slab_cap, int device) {
+static PreparedBlock prepare_block(const std::string &bdir, const std::vector<ColSpec> &specs, char *slab_h, size_t slab_cap, int device,
+                                   bool gpu_varint = false) {
     const auto t0 = std::chrono::steady_clock::now();
     struct Tally {
         std::chrono::steady_clock::time_point t0;
@@ -310,7 +321,7 @@ static PreparedBlock prepare_block(const std::string &bdir, const std::vector<Co
     // (what the block looked like BEFORE it was read: a rewrite in between makes the next refresh load it again)
     const std::pair<int64_t, int64_t> sig = block_signature(bdir);
     try {
-        PreparedBlock pb = prepare_block_unguarded(bdir, specs, slab_h, slab_cap, device);
+        PreparedBlock pb = prepare_block_unguarded(bdir, specs, slab_h, slab_cap, device, true, gpu_varint);
         pb.sig = sig;
         return pb;
     } catch (const std::exception &) {
@@ -540,8 +551,22 @@ static bool fill_bins(const BinsView &bv, bool delta, int64_t num_records, char 
     return true;
 }
 
+// <block>/info.db's IntInfoMap[name] (Min / Max: what the reference itself goes by when it skips blocks, table_block_io.go:120-135)
+static bool block_int_bounds(const gob::Value &binfo, const std::string &name, int64_t *mn, int64_t *mx) {
+    const gob::Value *m = binfo.field("IntInfoMap");
+    if (!m) return false;
+    for (auto &e : m->entries) {
+        if (!e.first || e.first->s != name || !e.second) continue;
+        const gob::Value *a = e.second->field("Min"), *b = e.second->field("Max");
+        *mn = a ? a->as_int() : 0;  // (gob leaves a zero field out)
+        *mx = b ? b->as_int() : 0;
+        return *mn <= *mx;
+    }
+    return false;
+}
+
 static PreparedBlock prepare_block_unguarded(const std::string &bdir, const std::vector<ColSpec> &specs, char *slab_h, size_t slab_cap, int device,
-                                             bool streamed) {
+                                             bool streamed, bool gpu_varint) {
     static const char *prefix[] = {"", "int_", "str_", "set_"};
     PreparedBlock pb;
     std::string err;
@@ -568,7 +593,8 @@ static PreparedBlock prepare_block_unguarded(const std::string &bdir, const std:
     if (env("SYBL_LOADER_TWO_PASS")) streamed = false;  // (read per call: under SYBL_ENV_LIVE a test may flip it between loads)
     std::vector<gob::Value> trees(streamed ? 0 : specs.size());
     std::vector<char> have(specs.size(), 0), bucketed(specs.size(), 0);
-    size_t total = 0;
+    size_t total = 0, scratch = 0;  // bytes that travel; device-only bytes behind them (GPU varint walk)
+    gob::RawInts raw;               // (streamed only: a column is planned and filled before the next file is read)
     auto reserve = [&](size_t bytes) {
         total = align16(total);
         const size_t at = total;
@@ -582,7 +608,13 @@ static PreparedBlock prepare_block_unguarded(const std::string &bdir, const std:
         // a missing file = column unpopulated in this block; "DECODE COL ERR": the reference logs and
         // carries on with an empty column
         const bool wide = env("SYBL_LOADER_WIDE_DECODE") != nullptr;  // (A/B: int64 slices, narrowed afterwards; read per call)
-        if (!decode_file(path, v, err, specs[ci].type != SYBL_SET_VAL && !wide)) return true;
+        // GPU varint walk (gobgpu.hip): an int column's `Values` slice is located, not decoded -- when the block's info.db
+        // says what its extrema are (the decode kernels' destinations are chosen before they run) and the block goes column
+        // by column
+        int64_t info_mn = 0, info_mx = 0;
+        const bool try_raw = gpu_varint && streamed && specs[ci].type == SYBL_INT_VAL && block_int_bounds(binfo, specs[ci].name, &info_mn, &info_mx);
+        raw = gob::RawInts();
+        if (!decode_file(path, v, err, specs[ci].type != SYBL_SET_VAL && !wide, try_raw ? &raw : nullptr)) return true;
         have[ci] = 1;
         const gob::Value *f;
         const bool bucket = (f = v.field("BucketEncoded")) && f->as_bool();
@@ -608,7 +640,24 @@ static PreparedBlock prepare_block_unguarded(const std::string &bdir, const std:
         } else if (ok) {
             const int64_t n = vals && vals->kind == gob::Value::kIntVec ? (int64_t)vals->ints.size() : 0;
             ok = n <= pb.nrows;  // unpackIntCol / unpackStrCol: more values than NumRecords
-            if (specs[ci].type == SYBL_INT_VAL) {
+            if (specs[ci].type == SYBL_INT_VAL && raw.hit && raw.n > 0 && raw.end > raw.p && (size_t)(raw.end - raw.p) <= (size_t)kGobMaxWgs * kGobWgBytes) {
+                // the file's bytes travel; the values exist on the device only (int64, behind the slab's travelling part)
+                pc.kind = PreparedCol::kIntValues;
+                ok = raw.n <= (uint64_t)pb.nrows;
+                pc.n_vals = (int64_t)raw.n;
+                pc.val_w = 8;
+                pc.raw_len = (int64_t)(raw.end - raw.p);
+                // (k_gob_values reads whole 64-byte chunks and sixteen bytes behind the last one)
+                pc.raw_at = reserve((((size_t)pc.raw_len + 63) & ~(size_t)63) + 16);
+                pc.val_at = scratch;
+                scratch += align16((size_t)pc.n_vals * 8);
+                pc.vmin = info_mn;
+                pc.vmax = info_mx;
+                if (ok && pc.n_vals < pb.nrows) {
+                    pc.bits_words = (pb.nrows + 31) / 32;
+                    pc.bits_at = reserve((size_t)pc.bits_words * 4);
+                }
+            } else if (specs[ci].type == SYBL_INT_VAL) {
                 pc.kind = PreparedCol::kIntValues;
                 pc.n_vals = n;
                 // (the stored values / deltas travel as int32 when they all fit; without an exit from the loop it vectorises)
@@ -631,7 +680,7 @@ static PreparedBlock prepare_block_unguarded(const std::string &bdir, const std:
                 pc.local_at = reserve((size_t)std::max<int64_t>(n, 1) * (size_t)pc.local_w);
                 pc.lut_at = reserve(std::max<size_t>(pc.strings.size(), 1) * 4);
             }
-            if (ok && n < pb.nrows && n > 0) {
+            if (ok && n < pb.nrows && n > 0 && pc.raw_len == 0) {
                 // every row below len(Values) becomes populated, holes included (column_store_io.go:758-766)
                 pc.bits_words = (pb.nrows + 31) / 32;
                 pc.bits_at = reserve((size_t)pc.bits_words * 4);
@@ -671,6 +720,12 @@ static PreparedBlock prepare_block_unguarded(const std::string &bdir, const std:
             break;
         }
         case PreparedCol::kIntValues: {
+            if (pc.raw_len > 0) {
+                memcpy(base + pc.raw_at, raw.p, (size_t)pc.raw_len);
+                pc.vpop = pc.n_vals;
+                pc.have_stats = true;
+                break;
+            }
             // every row below len(Values) is populated (column_store_io.go:758-766)
             int32_t *o32 = (int32_t *)(base + pc.val_at);
             int64_t *o64 = (int64_t *)(base + pc.val_at);
@@ -788,10 +843,10 @@ static PreparedBlock prepare_block_unguarded(const std::string &bdir, const std:
         for (size_t ci = 0; ci < specs.size(); ci++) {
             gob::Value v;
             if (!plan(ci, v)) return pb;
-            if (align16(total) > slab_cap) return prepare_block_unguarded(bdir, specs, slab_h, slab_cap, device, false);  // (an over-sized block)
+            if (align16(total) + scratch > slab_cap) return prepare_block_unguarded(bdir, specs, slab_h, slab_cap, device, false);  // (an over-sized block)
             if (!fill(ci, v, slab_h)) return pb;
         }
-        pb.bytes = align16(total);
+        pb.bytes = pb.scratch_at = align16(total);
         return pb;
     }
     // ---- two passes: plan every column, then fill
@@ -844,13 +899,32 @@ static void apply_dictionaries(Table *t, PreparedBlock &pb, char *H, std::vector
 // The decode launches of one block, gathered while its columns are placed and issued together (DecodeBinsBatch /
 // DecodeDeltaBatch: a launch per kind instead of one per column).  SYBL_LOADER_FUSED=0: a launch per column, as before
 // round 4.
+// One GPU varint walk of a load (SYBL_LOADER_GPU_VARINT): what the calling thread holds the kernel's status words against
+// when the load ends.
+struct GobCheck {
+    size_t name_ix;      // of the block, in the load's list of names
+    int64_t block;       // its index in Table::blocks (set at the commit)
+    size_t col;
+    int64_t n, mn, mx;   // the count the slice header announced; the info.db bounds the block was placed by
+};
+
 struct DecodeBatches {
     bool on = true;
     DecodeBinsBatch bins;
     DecodeDeltaBatch deltas;
+    GobValuesBatch gobs;
+    char *scratch = nullptr;                  // this block's device-only scratch (PreparedBlock::scratch_at)
+    unsigned long long *d_state = nullptr;    // [kGobStateWords] per walk of the load, zeroed
+    std::vector<GobCheck> checks;
+    size_t name_ix = 0, col_ix = 0;  // the block / column being applied
     void begin(uint32_t nrows) {
-        bins.n = deltas.n = 0;
+        bins.n = deltas.n = gobs.n = 0;
         bins.nrows = nrows;
+    }
+    int flush_gobs(hipStream_t st) {
+        hipError_t e = launch_gob_values(gobs, st);
+        gobs.n = 0;
+        return e == hipSuccess ? SYBL_OK : hip_fail(e, "k_gob_values");
     }
     int flush_bins(hipStream_t st) {
         hipError_t e = launch_decode_bins_multi(bins, st);
@@ -858,6 +932,10 @@ struct DecodeBatches {
         return e == hipSuccess ? SYBL_OK : hip_fail(e, "k_decode_bins_multi");
     }
     int flush_deltas(hipStream_t st) {
+        if (gobs.n > 0) {  // (the walks write what the delta kernel reads)
+            int rc = flush_gobs(st);
+            if (rc) return rc;
+        }
         hipError_t e = launch_decode_delta_multi(deltas, st);
         deltas.n = 0;
         return e == hipSuccess ? SYBL_OK : hip_fail(e, "k_decode_delta_multi");
@@ -928,19 +1006,43 @@ static int apply_col(BlockWriter &w, Column *c, PreparedCol &pc, const char *H, 
         if (!direct && (rc = block_col_device(w, c, n == w.nrows, &col, &valid))) return rc;
         if (valid && pc.bits_words > 0)
             SYBL_HIP(hipMemcpyAsync(valid, D + pc.bits_at, (size_t)pc.bits_words * 4, hipMemcpyDeviceToDevice, st));
-        if (n > 0 && ints && batch.on) {
+        const char *values = D + pc.val_at;
+        unsigned long long *gob_state = nullptr;
+        if (ints && pc.raw_len > 0) {
+            // the varint walk first: file bytes -> int64 values in the block's device-only scratch
+            if (batch.gobs.n == kGobBatchMax && (rc = batch.flush_deltas(st))) return rc;
+            GobValuesJob &G = batch.gobs.job[batch.gobs.n++];
+            memset(&G, 0, sizeof(G));
+            G.bytes = (const uint8_t *)(D + pc.raw_at);
+            G.n_bytes = (uint32_t)pc.raw_len;
+            G.n = (uint32_t)n;
+            G.out = (long long *)(batch.scratch + pc.val_at);
+            G.state = batch.d_state + (size_t)kGobStateWords * batch.checks.size();
+            G.n_wgs = (int32_t)(((pc.raw_len + 63) / 64 + kGobWgThreads - 1) / kGobWgThreads);
+            gob_state = G.state;
+            batch.checks.push_back(GobCheck{batch.name_ix, -1, batch.col_ix, n, pc.vmin, pc.vmax});
+            values = batch.scratch + pc.val_at;
+        }
+        if (n > 0 && ints && (batch.on || gob_state)) {
             if (batch.deltas.n == kDecodeBatchMax && (rc = batch.flush_deltas(st))) return rc;
             DecodeDeltaJob &J = batch.deltas.job[batch.deltas.n++];
             memset(&J, 0, sizeof(J));
-            J.deltas = D + pc.val_at;
+            J.deltas = values;
             J.col = col;
             J.n = n;
             J.vbase = direct ? c->vbase : 0;
             J.val_w = (uint8_t)pc.val_w;
             J.out_w = (uint8_t)(direct ? c->elem : 8);
             J.venc = pc.venc ? 1 : 0;
+            if (gob_state) {
+                // (the block was placed by its info.db bounds: the kernel that first sees the column's values checks them)
+                J.chk_flags = gob_state + kGobStateFlags;
+                J.chk_min = pc.vmin;
+                J.chk_max = pc.vmax;
+                if (!batch.on && (rc = batch.flush_deltas(st))) return rc;
+            }
         } else if (n > 0) {
-            hipError_t e = ints ? launch_decode_delta(D + pc.val_at, pc.val_w, n, pc.venc, col, direct ? c->elem : 8, direct ? c->vbase : 0, st)
+            hipError_t e = ints ? launch_decode_delta(values, pc.val_w, n, pc.venc, col, direct ? c->elem : 8, direct ? c->vbase : 0, st)
                                 : launch_remap_ids(D + pc.local_at, pc.local_w, (const int32_t *)(D + pc.lut_at), (int32_t)n_strings, n,
                                                    (int32_t *)col, st);
             if (e != hipSuccess) return hip_fail(e, ints ? "k_decode_delta" : "k_remap_ids");
@@ -1010,14 +1112,36 @@ static std::pair<int64_t, int64_t> block_signature(const std::string &bdir) {
     return {(int64_t)st.st_mtim.tv_sec * 1000000000ll + (int64_t)st.st_mtim.tv_nsec, (int64_t)st.st_size};
 }
 
+// A resident block's rows leave the scan (its directory vanished, was rewritten, or its load has to be done again)
+static void table_retire_block(Table *t, int64_t index) {
+    if (index < 0 || index >= (int64_t)t->blocks.size() || t->blocks[(size_t)index].n <= 0) return;
+    const int64_t n = t->blocks[(size_t)index].n;
+    t->blocks[(size_t)index].n = 0;
+    t->logical_rows -= n;
+    for (auto &cp : t->cols) {
+        Column *c = cp.get();
+        if (c->type == SYBL_SET_VAL || (int64_t)c->blk_pop.size() <= index) continue;
+        c->n_pop -= c->blk_pop[(size_t)index];
+        c->blk_pop[(size_t)index] = 0;  // (exact_min / exact_max stay: bounds of a superset are still bounds)
+    }
+}
+
 // Loads the named block directories of tdir, in order, behind the table's resident blocks (the pipeline of
 // sybl_table_open and sybl_table_refresh).  Every block is committed atomically; on an error the blocks appended so far
 // stay.
-static int load_blocks(Ctx *ctx, Table *t, const std::string &tdir, const std::vector<std::string> &names) {
+static int load_blocks_once(Ctx *ctx, Table *t, const std::string &tdir, const std::vector<std::string> &names, bool allow_gpu_varint,
+                            std::vector<std::string> &again) {
     int rc;
     const size_t n_names = names.size();
     std::vector<ColSpec> specs;
     for (auto &cp : t->cols) specs.push_back({cp->name, cp->type});
+    // SYBL_LOADER_GPU_VARINT=1 (round 6, opt-in): int columns stored as `Values` cross PCIe as file bytes and are walked on the
+    // GPU (gobgpu.hip); a block whose walk reports anything unexpected is loaded again by the host parser when the load ends
+    bool gpu_varint = false;
+    if (const char *e = env("SYBL_LOADER_GPU_VARINT")) gpu_varint = allow_gpu_varint && atoi(e) != 0;
+    size_t n_int_cols = 0;
+    for (auto &sp : specs) n_int_cols += sp.type == SYBL_INT_VAL ? 1 : 0;
+    if (n_int_cols == 0) gpu_varint = false;
     // worker threads decode a window of blocks ahead of the (serial, in-order) GPU phase
     // (twice the CPUs this process may use: a container's CFS quota -- 16 CPUs on the 256-thread GPU boxes of round 2 --
     // throttles every thread of the group once a burst of 128 workers has spent the period's budget)
@@ -1029,6 +1153,8 @@ static int load_blocks(Ctx *ctx, Table *t, const std::string &tdir, const std::v
     {
         size_t per_block = 65536;
         for (auto &sp : specs) per_block += sp.type == SYBL_SET_VAL ? 0 : (size_t)65536 * (sp.type == SYBL_STR_VAL ? 12 : 8) + ((size_t)96 << 10);
+        // (the file's bytes -- at most nine per value -- next to the int64 values they become, which exist on the device only)
+        if (gpu_varint) per_block += n_int_cols * ((size_t)65536 * 9 + 256);
         pool.slab_bytes = align16(per_block);
         if (const char *e = env("SYBL_LOADER_SLAB_BYTES")) pool.slab_bytes = align16((size_t)std::max(16, atoi(e)));  // (tests: over-sized blocks)
         pool.max_slabs = std::min<size_t>(std::max<size_t>(((size_t)512 << 20) / pool.slab_bytes, 4), std::max<size_t>(2 * n_workers, 4));
@@ -1057,7 +1183,7 @@ static int load_blocks(Ctx *ctx, Table *t, const std::string &tdir, const std::v
             const size_t scap = pool.slabs[(size_t)slab].cap;
             auto prom = std::make_shared<std::promise<PreparedBlock>>();
             inflight.push_back(InFlight{prom->get_future(), slab, next - 1});
-            workers.run([prom, bdir, &specs, sh, scap, device]() { prom->set_value(prepare_block(bdir, specs, sh, scap, device)); });
+            workers.run([prom, bdir, &specs, sh, scap, device, gpu_varint]() { prom->set_value(prepare_block(bdir, specs, sh, scap, device, gpu_varint)); });
         }
         return SYBL_OK;
     };
@@ -1110,6 +1236,19 @@ static int load_blocks(Ctx *ctx, Table *t, const std::string &tdir, const std::v
     std::vector<std::vector<int32_t>> luts;
     DecodeBatches batch;
     if (const char *e = env("SYBL_LOADER_FUSED")) batch.on = atoi(e) != 0;
+    // the walks' state words (flags, values found, the workgroups' look-back words), zero before a kernel has seen them
+    struct StateGuard {
+        unsigned long long *d = nullptr;
+        ~StateGuard() {
+            if (d) (void)hipFree(d);
+        }
+    } status;
+    const size_t n_status = gpu_varint ? n_names * n_int_cols : 0;
+    if (n_status > 0) {
+        SYBL_HIP(hipMalloc((void **)&status.d, n_status * kGobStateWords * 8));
+        SYBL_HIP(hipMemset(status.d, 0, n_status * kGobStateWords * 8));
+        batch.d_state = status.d;
+    }
     // SYBL_LOADER_TRACE=1: where the calling thread's time goes (stderr)
     const bool trace = env("SYBL_LOADER_TRACE") != nullptr;
     double tr[5] = {0, 0, 0, 0, 0};  // dictionaries, copy, column kernels, commit, submit
@@ -1164,11 +1303,17 @@ static int load_blocks(Ctx *ctx, Table *t, const std::string &tdir, const std::v
         BlockWriter w;
         if ((rc = block_begin(t, pb.nrows, &w))) return fail_out(rc);
         batch.begin((uint32_t)pb.nrows);
-        for (size_t ci = 0; ci < t->cols.size(); ci++)
+        batch.scratch = D + pb.scratch_at;
+        batch.name_ix = name_ix;
+        const size_t checks0 = batch.checks.size();
+        for (size_t ci = 0; ci < t->cols.size(); ci++) {
+            batch.col_ix = ci;
             if ((rc = apply_col(w, t->cols[ci].get(), pb.cols[ci], H, D, luts[ci].size(), batch))) return fail_out(rc);
+        }
         if ((rc = batch.flush(ctx->stream))) return fail_out(rc);
         lap(2, tl);
         if ((rc = block_commit(w))) return fail_out(rc);
+        for (size_t k = checks0; k < batch.checks.size(); k++) batch.checks[k].block = (int64_t)t->blocks.size() - 1;
         t->loaded.push_back(LoadedBlock{names[name_ix], pb.sig.first, pb.sig.second, (int64_t)t->blocks.size() - 1});
         lap(3, tl);
         if (pb.own_h) {
@@ -1196,6 +1341,31 @@ static int load_blocks(Ctx *ctx, Table *t, const std::string &tdir, const std::v
                 tr[0], tr[1], tr[2], tr[3], tr[4], wait_s, pool.slabs.size(), pool.slab_bytes >> 10);
     if ((rc = load_sync_all(ctx))) return (rc);
     SYBL_HIP(hipStreamSynchronize(ctx->stream));  // the table is resident when the call returns (and the wall time says so)
+    // the GPU varint walks' verdicts: anything but "every announced value found, all of them within the bounds the block was
+    // placed by" sends the block through the host parser again (its rows here leave the scan, like a rewritten block's)
+    t->load_stats.gpu_varint_cols = t->load_stats.gpu_varint_redone = 0;
+    if (!batch.checks.empty()) {
+        std::vector<unsigned long long> got(batch.checks.size() * kGobStateWords);
+        SYBL_HIP(hipMemcpy(got.data(), status.d, got.size() * 8, hipMemcpyDeviceToHost));
+        std::vector<char> bad_name(n_names, 0);
+        for (size_t k = 0; k < batch.checks.size(); k++) {
+            const GobCheck &ck = batch.checks[k];
+            const unsigned long long *g = &got[(size_t)kGobStateWords * k];
+            if (g[kGobStateFlags] == 0 && g[kGobStateFound] >= (unsigned long long)ck.n) continue;
+            if (bad_name[ck.name_ix]) continue;
+            bad_name[ck.name_ix] = 1;
+            table_retire_block(t, ck.block);
+            for (auto &lb : t->loaded)
+                if (lb.index == ck.block) lb.index = -2;  // (forgotten below)
+            again.push_back(names[ck.name_ix]);
+        }
+        if (!again.empty()) {
+            t->loaded.erase(std::remove_if(t->loaded.begin(), t->loaded.end(), [](const LoadedBlock &lb) { return lb.index == -2; }), t->loaded.end());
+            t->version++;
+        }
+        t->load_stats.gpu_varint_cols = (int32_t)std::min<size_t>(batch.checks.size(), INT32_MAX);
+        t->load_stats.gpu_varint_redone = (int32_t)again.size();
+    }
     t->load_stats.wall_s = seconds_since(t_open);
     t->load_stats.parse_cpu_s = (double)g_parse_ns.load() * 1e-9;
     t->load_stats.wait_s = wait_s;
@@ -1204,6 +1374,21 @@ static int load_blocks(Ctx *ctx, Table *t, const std::string &tdir, const std::v
     t->load_stats.h2d_bytes = h2d_bytes;
     t->load_stats.workers = (int32_t)n_workers;
     t->load_stats.blocks = (int32_t)n_names;
+    return SYBL_OK;
+}
+
+static int load_blocks(Ctx *ctx, Table *t, const std::string &tdir, const std::vector<std::string> &names) {
+    std::vector<std::string> again, none;
+    int rc = load_blocks_once(ctx, t, tdir, names, true, again);
+    if (rc || again.empty()) return rc;
+    // blocks whose GPU varint walk did not come out as announced: the host parser takes them (behind the others)
+    const sybl_load_stats first = t->load_stats;
+    if ((rc = load_blocks_once(ctx, t, tdir, again, false, none))) return rc;
+    sybl_load_stats &ls = t->load_stats;
+    ls.wall_s += first.wall_s, ls.parse_cpu_s += first.parse_cpu_s, ls.wait_s += first.wait_s, ls.apply_s += first.apply_s;
+    ls.file_bytes += first.file_bytes, ls.h2d_bytes += first.h2d_bytes;
+    ls.workers = first.workers, ls.blocks = first.blocks;
+    ls.gpu_varint_cols = first.gpu_varint_cols, ls.gpu_varint_redone = first.gpu_varint_redone;
     return SYBL_OK;
 }
 
@@ -1301,15 +1486,7 @@ static int refresh_table(Table *t, int64_t *n_added, int64_t *n_dropped, int64_t
         // reused by the blocks loaded below (table_drop_dead_tail: the rewritten last block of an ingest loop); rows in
         // the middle of the table are given back once there are enough of them (table_reclaim_dead_rows)
         if (lb.index >= 0 && lb.index < (int64_t)t->blocks.size() && t->blocks[(size_t)lb.index].n > 0) {
-            const int64_t n = t->blocks[(size_t)lb.index].n;
-            t->blocks[(size_t)lb.index].n = 0;
-            t->logical_rows -= n;
-            for (auto &cp : t->cols) {
-                Column *c = cp.get();
-                if (c->type == SYBL_SET_VAL || (int64_t)c->blk_pop.size() <= lb.index) continue;
-                c->n_pop -= c->blk_pop[(size_t)lb.index];
-                c->blk_pop[(size_t)lb.index] = 0;  // (exact_min / exact_max stay: bounds of a superset are still bounds)
-            }
+            table_retire_block(t, lb.index);
         } else if (lb.index < 0) {
             t->broken_blocks--;
         }
@@ -1422,10 +1599,16 @@ const char *sybl_debug_block_layout(const char *block_dir, const char *const *co
     // pinned pair of its own would ask for a device)
     size_t cap = 65536;
     for (auto &sp : specs) cap += sp.type == SYBL_SET_VAL ? 0 : (size_t)65536 * (sp.type == SYBL_STR_VAL ? 12 : 8) + ((size_t)96 << 10);
+    // (SYBL_LOADER_GPU_VARINT: the worker half of the GPU varint walk -- the lines gain raw=<bytes>:<digest of the file's
+    // `Values` region as it would travel>; val= is then empty, the values exist on the device only)
+    bool gpu_varint = false;
+    if (const char *e = env("SYBL_LOADER_GPU_VARINT")) gpu_varint = atoi(e) != 0;
+    if (gpu_varint)
+        for (auto &sp : specs) cap += sp.type == SYBL_INT_VAL ? (size_t)65536 * 9 + 256 : 0;
     std::vector<char> slab(cap);
     PreparedBlock pb;
     try {
-        pb = prepare_block_unguarded(block_dir, specs, slab.data(), cap, -1);
+        pb = prepare_block_unguarded(block_dir, specs, slab.data(), cap, -1, true, gpu_varint);
     } catch (const std::exception &e) {
         out = std::string("exception: ") + e.what();
         return out.c_str();
@@ -1457,10 +1640,15 @@ const char *sybl_debug_block_layout(const char *block_dir, const char *const *co
                  (long long)(pc.have_stats ? pc.vmax : 0), (long long)pc.vpop, pc.strings.size(), (unsigned long long)hs,
                  (unsigned long long)(bins ? fnv(H + pc.binval_at, (size_t)pc.n_bins * 8) : 0), (unsigned long long)(bins ? fnv(H + pc.binoff_at, (size_t)(pc.n_bins + 1) * 8) : 0),
                  (unsigned long long)(bins ? fnv(H + pc.rec_at, (size_t)pc.n_recs * (size_t)pc.rec_w) : 0),
-                 (unsigned long long)(pc.kind == PreparedCol::kIntValues ? fnv(H + pc.val_at, (size_t)pc.n_vals * (size_t)pc.val_w) : 0),
+                 (unsigned long long)(pc.kind == PreparedCol::kIntValues && pc.raw_len == 0 ? fnv(H + pc.val_at, (size_t)pc.n_vals * (size_t)pc.val_w) : 0),
                  (unsigned long long)(pc.kind == PreparedCol::kStrValues ? fnv(H + pc.local_at, (size_t)pc.n_local * (size_t)pc.local_w) : 0),
                  (unsigned long long)(pc.bits_words > 0 ? fnv(H + pc.bits_at, (size_t)pc.bits_words * 4) : 0), (unsigned long long)hset);
         out += b;
+        if (pc.raw_len > 0) {
+            out.pop_back();
+            snprintf(b, sizeof(b), " raw=%lld:%016llx\n", (long long)pc.raw_len, (unsigned long long)fnv(H + pc.raw_at, (size_t)pc.raw_len));
+            out += b;
+        }
     }
     return out.c_str();
 }

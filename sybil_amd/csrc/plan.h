@@ -231,6 +231,30 @@ enum Header : int {
     kHdrPdMax = 16,       // .. and max(v): Cumulative's, the cell fields of the rows beyond the limit being empty in that mode
 };
 
+// ---- table load, round 6: the int columns of one block whose `Values` varints are walked on the GPU (gobgpu.hip)
+constexpr int kGobWgThreads = 256;                       // one 64-byte chunk per thread: a workgroup walks 16 KB of a file
+constexpr int kGobWgBytes = kGobWgThreads * 64;
+constexpr int kGobMaxWgs = 64;                           // per file (the look-back is one wave wide): 1 MB of values
+// a job's state words (zeroed before the launch): flags | values found | the workgroups' exit maps | their value counts
+constexpr int kGobStateFlags = 0, kGobStateFound = 1, kGobStateMaps = 2, kGobStateCounts = 2 + kGobMaxWgs, kGobStateWords = 2 + 2 * kGobMaxWgs;
+struct GobValuesJob {
+    const uint8_t *bytes;        // device, 16-byte aligned: the first value of the file's `Values` slice (behind its count) ...
+    uint32_t n_bytes, n;         // ... to the end of the file's value message; the count the slice header announced
+    long long *out;              // [n] the values as the file holds them (deltas when the column is value-encoded), int64
+    unsigned long long *state;   // [kGobStateWords]
+    int32_t n_wgs, pad_;
+};
+constexpr uint32_t kGobBadByte = 1u;    // flags: a value starts with a byte 0x80..0xF7
+constexpr uint32_t kGobShort = 2u;      // fewer values in the region than the slice header announced
+constexpr uint32_t kGobTruncated = 4u;  // a value reaches beyond the region
+constexpr uint32_t kGobOutOfBounds = 8u;  // a column value outside the bounds the block was placed by (k_decode_delta)
+constexpr uint32_t kGobGaveUp = 16u;    // a look-back word did not arrive
+constexpr int kGobBatchMax = 16;
+struct GobValuesBatch {
+    GobValuesJob job[kGobBatchMax];
+    int32_t n;
+};
+
 // ---- table load: one block's bucket-encoded / value-encoded columns, a launch each (loader.cpp, kernels.hip:
 // k_decode_bins_multi / k_decode_delta_multi); the fields are the single-column launchers' arguments (engine.h)
 constexpr int kDecodeBatchMax = 16;
@@ -253,6 +277,9 @@ struct DecodeDeltaJob {
     void *col;
     int64_t n, vbase;
     uint8_t val_w, out_w, venc, pad[5];
+    // non-null (the GPU varint walk's columns): kGobOutOfBounds is set there when a column value lies outside [chk_min, chk_max]
+    unsigned long long *chk_flags;
+    int64_t chk_min, chk_max;
 };
 struct DecodeDeltaBatch {
     DecodeDeltaJob job[kDecodeBatchMax];

@@ -1,0 +1,225 @@
+"""GPU: SYBL_LOADER_GPU_VARINT=1 -- the varint walk of an int column's `Values` slice on the GPU (csrc/gobgpu.hip) against the
+host parser (gob.cpp) on the same files: unpackIntCol, src/lib/column_store_io.go:690-780, reads them through encoding/gob
+(decodeUint / decodeInt).  The two loads must produce the same resident columns, the same verdict on damaged blocks and the
+same query results; a walk that meets anything it was not told to expect (values outside the block's info.db bounds, a short
+or damaged slice) hands its block back to the host parser, which this file provokes on purpose."""
+import os
+
+import numpy as np
+import pytest
+
+from tests import gobfmt as G
+from tests import sybil_fixture as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import sybil_amd
+    c = sybil_amd.Context(0)
+    yield c
+    c.close()
+
+
+def _open_both(ctx, monkeypatch, root, table, **kw):
+    monkeypatch.delenv("SYBL_LOADER_GPU_VARINT", raising=False)
+    host = ctx.open_table(root, table, **kw)
+    monkeypatch.setenv("SYBL_LOADER_GPU_VARINT", "1")
+    gpu = ctx.open_table(root, table, **kw)
+    monkeypatch.delenv("SYBL_LOADER_GPU_VARINT", raising=False)
+    return host, gpu
+
+
+def _same_columns(host, gpu, cols):
+    assert gpu.rows == host.rows and gpu.blocks == host.blocks and gpu.broken_blocks == host.broken_blocks
+    n = host.rows
+    for c in cols:
+        assert np.array_equal(gpu.read_int(c, 0, n), host.read_int(c, 0, n)), c
+        a, b = host.column_info(c), gpu.column_info(c)
+        assert a == b, (c, a, b)
+
+
+def _summary(tb, **q):
+    query = tb.query(**q)
+    r = query.run()
+    out = (r.matched, sorted((x["group_by_key"], x["count"], tuple((h["count"], h["sum"], h["min"], h["max"]) for h in x["hists"]))
+                             for x in r.results))
+    r.free()
+    query.free()
+    return out
+
+
+def _values_of_every_length(rng, n):
+    """Deltas whose zig-zag forms take 1..9 bytes on the wire, both signs, the int64 extremes among them."""
+    bits = rng.integers(0, 63, size=n)
+    mag = (rng.integers(0, 1 << 62, size=n, dtype=np.int64) >> (62 - bits)).astype(np.int64)
+    v = np.where(rng.random(n) < 0.5, mag, -mag - 1)
+    v = v.astype(np.int64)
+    edge = np.array([np.iinfo(np.int64).max, np.iinfo(np.int64).min, 0, -1], dtype=np.int64)
+    v[:min(n, 4)] = edge[:min(n, 4)]
+    return v
+
+
+@pytest.mark.parametrize("compact", [False, True])
+def test_value_encoded_columns_load_the_same_either_way(ctx, tmp_path, monkeypatch, compact):
+    rng = np.random.default_rng(41)
+    blocks = []
+    for b in range(5):
+        n = 65536 if b < 2 else int(rng.integers(1, 30000))
+        t = (1_700_000_000 + b * 7200 + np.sort(rng.integers(0, 7200, size=n))).astype(np.int64)   # one- and two-byte deltas
+        wide = rng.integers(-(1 << 40), 1 << 40, size=n).astype(np.int64)                          # six-byte deltas
+        small = rng.integers(0, 1000, size=n).astype(np.int64)
+        key = rng.integers(0, 7, size=n).astype(np.int64)                                          # stays bucket encoded
+        blocks.append({"time": ("int", t), "wide": ("int", wide), "small": ("int", small), "key": ("int", key)})
+    root = str(tmp_path / "db")
+    F.write_table(root, "events", blocks, threshold=100)
+    host, gpu = _open_both(ctx, monkeypatch, root, "events", compact=compact)
+    st = gpu.load_stats()
+    assert st["gpu_varint_cols"] == 15 and st["gpu_varint_redone"] == 0, st   # time, wide, small of five blocks
+    assert host.load_stats()["gpu_varint_cols"] == 0
+    _same_columns(host, gpu, ("time", "wide", "small", "key"))
+    for q in (dict(groups=["key"], aggs=["wide", "time"], op="hist"), dict(filters=[("small", "gt", 500)], groups=["key"], aggs=["time"])):
+        assert _summary(gpu, **q) == _summary(host, **q)
+    gpu.free()
+    host.free()
+
+
+def test_holes_put_values_outside_the_blocks_bounds_and_the_host_parser_takes_those_blocks(ctx, tmp_path, monkeypatch):
+    """A value-encoded column's unset rows hold 0 (SaveIntsToColumns, column_store_io.go:97-114) and become populated on load
+    (:758-766); the block's IntInfo was kept over the set values only, so 0 may lie outside it.  The walk's own extrema
+    notice, and the block is loaded again by the host parser: same columns, same answers."""
+    rng = np.random.default_rng(5)
+    blocks = []
+    for b in range(4):
+        n = 20000
+        age = rng.integers(10, 300, size=n).astype(np.int64)
+        pop = rng.random(n) > (0.2 if b % 2 else 0.0)     # blocks 1 and 3 have holes: 0 < Min = 10
+        key = rng.integers(0, 5, size=n).astype(np.int64)
+        blocks.append({"age": ("int", age, pop), "key": ("int", key)})
+    root = str(tmp_path / "db")
+    F.write_table(root, "events", blocks, threshold=50)
+    host, gpu = _open_both(ctx, monkeypatch, root, "events")
+    st = gpu.load_stats()
+    assert st["gpu_varint_cols"] == 4 and st["gpu_varint_redone"] == 2, st
+    assert gpu.rows == host.rows and gpu.broken_blocks == host.broken_blocks == 0
+    # (the two blocks loaded again stand behind the others: compare the answers, not the row order)
+    for q in (dict(groups=["key"], aggs=["age"], op="hist"), dict(filters=[("age", "lt", 5)], groups=["key"], aggs=["age"])):
+        assert _summary(gpu, **q) == _summary(host, **q)
+    assert sorted(gpu.read_int("age", 0, gpu.rows).tolist()) == sorted(host.read_int("age", 0, host.rows).tolist())
+    gpu.free()
+    host.free()
+
+
+def _write_block(tdir, index, cols, nrows, infos):
+    bdir = os.path.join(tdir, "block%09d" % index)
+    os.makedirs(bdir, exist_ok=True)
+    for name, data in cols.items():
+        with open(os.path.join(bdir, "int_%s.db" % name), "wb") as f:
+            f.write(data)
+    with open(os.path.join(bdir, "info.db"), "wb") as f:
+        f.write(G.encode(G.saved_column_info(), {"NumRecords": nrows, "IntInfoMap": infos}))
+    return bdir
+
+
+def _info(vals):
+    return {"Min": int(vals.min()), "Max": int(vals.max()), "Avg": 0.0, "M2": 0.0, "Count": int(vals.size)}
+
+
+def _table_info(tdir, table, names, lo, hi):
+    tbl = {"Name": table, "KeyTable": {n: i for i, n in enumerate(names)}, "KeyTypes": {i: F.INT_VAL for i in range(len(names))},
+           "IntInfo": {i: {"Min": lo, "Max": hi, "Avg": 0.0, "M2": 0.0, "Count": 1} for i in range(len(names))}}
+    with open(os.path.join(tdir, "info.db"), "wb") as f:
+        f.write(G.encode(G.table_info(), tbl))
+
+
+def test_every_varint_length_plain_and_value_encoded(ctx, tmp_path, monkeypatch):
+    """`Values` as plain numbers (ValueEncoded false) and as deltas, with zig-zag forms of one to nine bytes and the int64
+    extremes; files of 1 value, of a few, and of a size that leaves most of the kernel's threads without a chunk."""
+    rng = np.random.default_rng(77)
+    root = str(tmp_path / "db")
+    tdir = os.path.join(root, "events")
+    os.makedirs(tdir)
+    sizes = [1, 2, 7, 63, 64, 65, 1000, 65536]
+    for bi, n in enumerate(sizes):
+        plain = _values_of_every_length(rng, n)
+        deltas = _values_of_every_length(rng, n) >> 8        # (running sums stay inside int64)
+        running = np.cumsum(deltas)
+        cols = {"plain": G.encode(G.saved_int_column(), {"Name": "plain", "DeltaEncodedIDs": True, "VERSION": 1, "Values": [int(x) for x in plain]}),
+                "run": G.encode(G.saved_int_column(), {"Name": "run", "DeltaEncodedIDs": True, "ValueEncoded": True, "VERSION": 1,
+                                                       "Values": [int(x) for x in deltas]})}
+        _write_block(tdir, bi + 1, cols, n, {"plain": _info(plain), "run": _info(running)})
+    _table_info(tdir, "events", ["plain", "run"], -(1 << 62), 1 << 62)
+    host, gpu = _open_both(ctx, monkeypatch, root, "events")
+    st = gpu.load_stats()
+    assert st["gpu_varint_cols"] == 2 * len(sizes) and st["gpu_varint_redone"] == 0, st
+    _same_columns(host, gpu, ("plain", "run"))
+    gpu.free()
+    host.free()
+
+
+def test_damaged_value_slices_get_the_host_parsers_verdict(ctx, tmp_path, monkeypatch):
+    """A slice that announces more values than its bytes hold, one cut in the middle of a value, a byte that cannot start a
+    value, more values than NumRecords, and info.db bounds that do not cover the values: whatever the host parser makes of
+    each block (skipped, column empty, loaded), the GPU path ends up with the same."""
+    rng = np.random.default_rng(8)
+    root = str(tmp_path / "db")
+    tdir = os.path.join(root, "events")
+    os.makedirs(tdir)
+    n = 5000
+    vals = rng.integers(0, 1 << 20, size=n).astype(np.int64)
+    good = G.encode(G.saved_int_column(), {"Name": "v", "DeltaEncodedIDs": True, "VERSION": 1, "Values": [int(x) for x in vals]})
+    other = G.encode(G.saved_int_column(), {"Name": "w", "DeltaEncodedIDs": True, "VERSION": 1, "Values": [int(x) for x in vals[::-1]]})
+    info = {"v": _info(vals), "w": _info(vals)}
+    _write_block(tdir, 1, {"v": good, "w": other}, n, info)
+    # 2: cut in the middle (the message length no longer matches: a decode error, the column stays empty)
+    _write_block(tdir, 2, {"v": good[: len(good) // 2], "w": other}, n, info)
+    # 3: a byte 0x90 where a value starts (the last value's first byte: 3-byte values are FE hi lo ... find one from the end)
+    bad = bytearray(good)
+    at = len(bad) - 12
+    bad[at] = 0x90
+    _write_block(tdir, 3, {"v": bytes(bad), "w": other}, n, info)
+    # 4: more values than NumRecords ("BLOCK SIZE CHANGED DURING QUERY": the block is skipped)
+    _write_block(tdir, 4, {"v": good, "w": other}, n - 1, info)
+    # 5: bounds that do not cover the values (the walk notices; the host parser loads the block as it is)
+    _write_block(tdir, 5, {"v": good, "w": other}, n, {"v": {"Min": 5, "Max": 6, "Avg": 0.0, "M2": 0.0, "Count": 1}, "w": _info(vals)})
+    # 6: no IntInfoMap entry at all (the host parser from the start)
+    _write_block(tdir, 6, {"v": good, "w": other}, n, {"w": _info(vals)})
+    _table_info(tdir, "events", ["v", "w"], 0, 1 << 20)
+    host, gpu = _open_both(ctx, monkeypatch, root, "events")
+    st = gpu.load_stats()
+    assert st["gpu_varint_cols"] > 0 and st["gpu_varint_redone"] >= 1, st
+    # (a block loaded again leaves its first copy behind as an empty block: rows and verdicts must agree, not the block count)
+    assert gpu.rows == host.rows and gpu.broken_blocks == host.broken_blocks
+    assert host.broken_blocks >= 1
+    for c in ("v", "w"):
+        assert sorted(gpu.read_int(c, 0, gpu.rows).tolist()) == sorted(host.read_int(c, 0, host.rows).tolist()), c
+    q = dict(filters=[("v", "gt", 1000)], aggs=["v", "w"], op="hist")
+    assert _summary(gpu, **q) == _summary(host, **q)
+    gpu.free()
+    host.free()
+
+
+def test_refresh_loads_new_blocks_through_the_same_path(ctx, tmp_path, monkeypatch):
+    rng = np.random.default_rng(3)
+
+    def block(b):
+        n = 10000
+        return {"t": ("int", (1000 * b + np.sort(rng.integers(0, 1000, size=n))).astype(np.int64)), "k": ("int", rng.integers(0, 4, size=n).astype(np.int64))}
+
+    blocks = [block(b) for b in range(3)]
+    root = str(tmp_path / "db")
+    F.write_table(root, "events", blocks[:2], threshold=100)
+    monkeypatch.setenv("SYBL_LOADER_GPU_VARINT", "1")
+    tb = ctx.open_table(root, "events")
+    assert tb.load_stats()["gpu_varint_cols"] == 2
+    F.write_table(root, "events", blocks, threshold=100)
+    tb.refresh()
+    assert tb.load_stats()["gpu_varint_cols"] >= 1
+    monkeypatch.delenv("SYBL_LOADER_GPU_VARINT")
+    ref = ctx.open_table(root, "events")
+    q = dict(groups=["k"], aggs=["t"], op="hist")
+    assert _summary(tb, **q) == _summary(ref, **q)
+    assert sorted(tb.read_int("t", 0, tb.rows).tolist()) == sorted(ref.read_int("t", 0, ref.rows).tolist())
+    tb.free()
+    ref.free()

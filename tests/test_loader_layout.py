@@ -250,3 +250,44 @@ def test_slab_regions_hold_what_the_files_hold(table, tmp_path):
     _check_regions(os.path.join(str(tmp_path), "v", "block000000001"), n,
                    [("vals", "int"), ("wide", "int"), ("short", "int"), ("few", "int"), ("many", "str")], seen)
     assert seen >= {"int-bins", "str-bins", "int-values-4", "int-values-8", "str-values", "validity-prefix"}, seen
+
+
+def test_gpu_varint_worker_half_hands_over_the_files_value_bytes(tmp_path, monkeypatch):
+    """SYBL_LOADER_GPU_VARINT (csrc/gobgpu.hip walks the varints): what travels for an int column stored as `Values` is the
+    file's own bytes from the slice's first value to the end of the message -- here held against the encoder's bytes
+    (tests/gobfmt.py) -- with the announced count and the block's info.db bounds; bucket-encoded columns and columns the
+    block's info.db says nothing about go the host parser's way."""
+    from tests import gobfmt as G
+    rng = np.random.default_rng(12)
+    n = 4000
+    t = np.sort(rng.integers(0, 10 ** 6, n)).astype(np.int64)
+    wide = rng.integers(-(1 << 50), 1 << 50, n).astype(np.int64)
+    few = rng.integers(0, 5, n).astype(np.int64)
+    root = str(tmp_path / "db")
+    F.write_table(root, "t", [{"t": ("int", t), "wide": ("int", wide), "few": ("int", few)}], threshold=8)
+    bdir = os.path.join(root, "t", "block000000001")
+    cols = [("t", "int"), ("wide", "int"), ("few", "int")]
+    plain = dict(_fields(l) for l in layout(bdir, cols).splitlines()[1:])
+    monkeypatch.setenv("SYBL_LOADER_GPU_VARINT", "1")
+    lines = dict(_fields(l) for l in layout(bdir, cols).splitlines()[1:])
+    monkeypatch.delenv("SYBL_LOADER_GPU_VARINT")
+    for name, vals in (("t", t), ("wide", wide)):
+        f = lines[name]
+        deltas = np.diff(vals, prepend=0)
+        body = b"".join(G.enc_int(int(d)) for d in deltas)
+        data = open(os.path.join(bdir, "int_%s.db" % name), "rb").read()
+        at = data.index(body)
+        region = data[at:]
+        assert data[:at].endswith(G.enc_uint(n))                       # the slice's count stands right before it
+        assert f["raw"] == "%d:%016x" % (len(region), _fnv(region)), name
+        assert f["vals"] == str(n) and f["val_w"] == "8" and f["venc"] == "1" and f["kind"] == plain[name]["kind"]
+        assert (int(f["min"]), int(f["max"]), int(f["pop"])) == (int(vals.min()), int(vals.max()), n)
+        assert (plain[name]["min"], plain[name]["max"]) == (f["min"], f["max"]) and "raw" not in plain[name]
+    assert "raw" not in lines["few"] and lines["few"] == plain["few"]
+    # no IntInfoMap entry for the column: nothing to place the block by, the host parser takes it
+    info = G.decode(open(os.path.join(bdir, "info.db"), "rb").read())
+    del info["IntInfoMap"]["wide"]
+    open(os.path.join(bdir, "info.db"), "wb").write(G.encode(G.saved_column_info(), info))
+    monkeypatch.setenv("SYBL_LOADER_GPU_VARINT", "1")
+    lines = dict(_fields(l) for l in layout(bdir, cols).splitlines()[1:])
+    assert "raw" in lines["t"] and lines["wide"] == plain["wide"]
