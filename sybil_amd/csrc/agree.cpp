@@ -249,7 +249,7 @@ int sybl_table_agree(sybl_table *t, const char *const *group_cols, int32_t n_gro
         } else {
             lo = c->exact_min, hi = c->exact_max;
         }
-        if (c->n_pop == 0 && !c->bounds_set) lo = 0, hi = -1;
+        if (c->n_pop == 0 && !c->bounds_set && (c->type != SYBL_STR_VAL || c->dict.empty())) lo = 0, hi = -1;
         unsigned __int128 card = hi >= lo ? (unsigned __int128)((__int128)hi - (__int128)lo) + 1 : 0;
         bool dict = false;
         if (multi && c->type == SYBL_INT_VAL && !env("SYBL_NO_GDICT") && (c->gdict_blocks == -2 || group_key_wants_dict(card, cells))) {

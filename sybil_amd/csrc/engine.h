@@ -56,8 +56,8 @@ hipError_t launch_decode_delta(const void *deltas, int val_width, int64_t n, boo
 hipError_t launch_remap_ids(const void *local, int local_width, const int32_t *lut, int32_t n_lut, int64_t n, int32_t *col, hipStream_t st);
 // one block's bucket-encoded / value-encoded columns, a launch each (loader.cpp: DecodeBatches); arguments as above
 hipError_t launch_decode_bins_multi(const DecodeBinsBatch &B, hipStream_t st);
-hipError_t launch_decode_delta_multi(const DecodeDeltaBatch &B, hipStream_t st);
-hipError_t launch_gob_values(const GobValuesBatch &B, hipStream_t st);  // gobgpu.hip: the varint walk of value-encoded int columns
+hipError_t launch_decode_delta_multi(const DecodeDeltaBatch &B, const GobBinsBatch &G, hipStream_t st);  // (G: gob_bins.h's jobs ride along)
+hipError_t launch_gob_values(const GobValuesBatch &B, hipStream_t st);  // gobgpu.hip: the varint walk of int column files ...
 
 hipError_t launch_hist_summary(const HistSummaryPlan &S, int64_t *total, hipStream_t st);
 hipError_t launch_rank_column(const void *col, int width, int64_t vbase, const uint32_t *valid, const int64_t *dkeys, const int32_t *dranks, uint32_t dmask,
@@ -105,6 +105,7 @@ struct Ctx {
         size_t slabs = 0;
     };
     std::vector<ArenaChunk> load_chunks;
+    size_t load_scratch_bytes = 0;  // device-only bytes behind every slab's twin
     size_t load_slab_bytes = 0;  // bytes per slab the chunks were carved for (another size: the arena starts over)
     // host_to_device (table.cpp): the pinned staging buffer every copy of CALLER memory -- sybl_table_append_block's
     // columns, dictionaries, look-up tables -- goes through (round 6; they were pageable hipMemcpyAsync before), and the

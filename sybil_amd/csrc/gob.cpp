@@ -493,6 +493,15 @@ struct Decoder {
                 }
                 if (fv >= 0 && fr >= 0) {
                     out.kind = Value::kBinVec;
+                    if (opts.raw_bins && depth == 1 && fv == 0 && fr == 1 && vs && !rs && cur_field && *cur_field == "Bins") {
+                        opts.raw_bins->p = r.p;
+                        opts.raw_bins->end = r.end;
+                        opts.raw_bins->n = n;
+                        opts.raw_bins->hit = true;
+                        out.bin_off.assign(1, 0);
+                        stop = true;
+                        return true;
+                    }
                     out.bin_order = fr < fv ? 1 : 0;
                     // (DecodeOpts::narrow: the records as uint16 while they fit; one that does not sends the reader back
                     // to the first bin to take them all as int64 -- a block of more than 65536 rows, or a damaged file)

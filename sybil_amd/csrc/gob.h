@@ -91,6 +91,9 @@ struct DecodeOpts {
     // non-null: a top-level struct's signed-int slice field named "Values" is not decoded -- *raw_values says where it lies and
     // the decode STOPS there (the fields behind it, VERSION, are not read; the tree holds the fields before it)
     RawInts *raw_values = nullptr;
+    // non-null: likewise for a top-level `Bins` slice of struct{Value int; Records []uint} (SavedIntBucket, in that order): *raw_bins
+    // says where the first bucket lies and how many the slice announced; the decode stops there
+    RawInts *raw_bins = nullptr;
 };
 
 struct Value {

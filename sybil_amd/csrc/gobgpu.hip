@@ -61,6 +61,11 @@ __device__ __forceinline__ unsigned long long shfl_up64(unsigned long long v, in
     return ((unsigned long long)hi << 32) | lo;
 }
 
+__device__ __forceinline__ unsigned long long shfl_up64_xor(unsigned long long v, int o) {
+    const uint32_t lo = __shfl_xor((uint32_t)v, o, 64), hi = __shfl_xor((uint32_t)(v >> 32), o, 64);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
 // waits for a look-back word to be published; 0 (not ready) when it gives up
 __device__ __forceinline__ unsigned long long gob_wait(const unsigned long long *word) {
     for (uint32_t spin = 0; spin < kSpinLimit; spin++) {
@@ -77,9 +82,9 @@ __device__ __forceinline__ unsigned long long gob_wait(const unsigned long long 
 __global__ __launch_bounds__(kGobWgThreads) void k_gob_values(const GobValuesBatch B) {
     __shared__ uint32_t stage[19 * kGobWgThreads];   // pass 3: the chunks, [dword][thread]
     __shared__ unsigned long long wave_map[4];
-    __shared__ uint32_t wave_cnt[4];
-    __shared__ unsigned long long ahead_map;
-    __shared__ uint32_t ahead_cnt, gave_up;
+    __shared__ unsigned long long wave_cnt[4];
+    __shared__ unsigned long long ahead_map, ahead_cnt;
+    __shared__ uint32_t gave_up;
     const GobValuesJob &J = B.job[blockIdx.y];
     const uint32_t g = blockIdx.x;
     if (g >= (uint32_t)J.n_wgs) return;
@@ -158,39 +163,44 @@ __global__ __launch_bounds__(kGobWgThreads) void k_gob_values(const GobValuesBat
     }
 
     // ---- pass 2: the bytes values start on, counted
-    unsigned long long starts = 0;
+    // (`Bins`: the values that are 0 -- single bytes 00 -- are counted beside them: their ranks go into a list of their own)
+    const bool want_zeros = J.zpos != nullptr;
+    unsigned long long starts = 0, zeros = 0;
     if (has) {
 #pragma unroll
         for (int p = 0; p < kChunk; p++) {
             const uint32_t b = (w[p >> 2] >> (8 * (p & 3))) & 0xFFu;
             const bool hit = (uint32_t)p == cur;
             cur = hit ? cur + 1u + gob_extra(b) : cur;
-            starts |= hit && (uint32_t)p < valid ? 1ull << p : 0ull;
+            const bool start = hit && (uint32_t)p < valid;
+            starts |= start ? 1ull << p : 0ull;
+            zeros |= start && b == 0u ? 1ull << p : 0ull;
         }
     }
-    const uint32_t mine = (uint32_t)__popcll(starts);
-    uint32_t incl = mine;
+    // one scan for both counts: values in the low half, zeros in the high half (neither reaches 2^24 in a region of 1 MB)
+    const unsigned long long mine = (unsigned long long)__popcll(starts) | (want_zeros ? (unsigned long long)__popcll(zeros) << 32 : 0ull);
+    unsigned long long incl = mine;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t prev = __shfl_up(incl, o, 64);
+        const unsigned long long prev = shfl_up64(incl, o);
         if ((int)lane >= o) incl += prev;
     }
     if (lane == 63) wave_cnt[wave] = incl;
     __syncthreads();
-    uint32_t k = incl - mine;
-    for (uint32_t q = 0; q < wave; q++) k += wave_cnt[q];
+    unsigned long long kz = incl - mine;
+    for (uint32_t q = 0; q < wave; q++) kz += wave_cnt[q];
     if (tid == kGobWgThreads - 1)
-        __hip_atomic_store(&state[kGobStateCounts + g], (unsigned long long)(k + mine) | kReady, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&state[kGobStateCounts + g], (kz + mine) | kReady, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (wave == 0) {
-        uint32_t a = 0;
+        unsigned long long a = 0;
         bool ok = true;
         if (lane < g) {
             const unsigned long long v = gob_wait(&state[kGobStateCounts + lane]);
             ok = v != 0;
-            a = (uint32_t)v;
+            a = v & ~kReady;
         }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+        for (int o = 32; o > 0; o >>= 1) a += shfl_up64_xor(a, o);
         if (!ok) atomicOr(&gave_up, 1u);
         if (lane == 0) ahead_cnt = a;
     }
@@ -198,13 +208,18 @@ __global__ __launch_bounds__(kGobWgThreads) void k_gob_values(const GobValuesBat
 #pragma unroll
     for (int q = 0; q < 19; q++) stage[q * kGobWgThreads + tid] = w[q];
     __syncthreads();
-    k += ahead_cnt;
+    kz += ahead_cnt;
+    uint32_t k = (uint32_t)kz, zk = (uint32_t)(kz >> 32);
     uint32_t bad = gave_up ? kGobGaveUp : 0u;
     long long *out = J.out;
     if (tid == kGobWgThreads - 1 && g + 1 == (uint32_t)J.n_wgs) {
-        state[kGobStateFound] = (unsigned long long)(k + mine);
-        if (k + mine < want) bad |= kGobShort;
+        const unsigned long long all = kz + mine;
+        state[kGobStateFound] = all & 0xFFFFFFFFull;
+        state[kGobStateZeros] = all >> 32;
+        if ((uint32_t)all < want && !want_zeros) bad |= kGobShort;  // (`Values`: the slice announced `want` of them)
     }
+    const uint32_t n_zpos = J.n_zpos;
+    uint32_t *zpos = J.zpos;
     while (starts != 0 && !gave_up) {
         const uint32_t p = (uint32_t)__builtin_ctzll(starts);
         starts &= starts - 1;
@@ -221,7 +236,11 @@ __global__ __launch_bounds__(kGobWgThreads) void k_gob_values(const GobValuesBat
         if (k < want) {
             if (b >= 128u && b < 0xF8u) bad |= kGobBadByte;
             if (p + nb >= valid) bad |= kGobTruncated;  // (valid >= 64 + 8 unless the file ends here)
-            out[k] = (long long)((u >> 1) ^ (0ull - (u & 1ull)));
+            out[k] = want_zeros ? (long long)u : (long long)((u >> 1) ^ (0ull - (u & 1ull)));
+            if (want_zeros && b == 0u) {
+                if (zk < n_zpos) zpos[zk] = k;
+                zk++;
+            }
         }
         k++;
     }

@@ -26,6 +26,7 @@
 #include <algorithm>
 
 #include "plan.h"
+#include "gob_bins.h"
 #include "scan_fast.h"
 #include "scan_generic.h"
 
@@ -479,13 +480,18 @@ __device__ __forceinline__ uint32_t block_inclusive_scan_256(uint32_t v, uint32_
 template <typename T, typename R>
 __device__ __forceinline__ void decode_bins_body(const R *__restrict__ recs, const int64_t *__restrict__ bin_off,
                                                  const int64_t *__restrict__ bin_val, int delta_encoded, int64_t vbase, T *__restrict__ col,
-                                                 uint32_t *__restrict__ valid, uint32_t nrows, uint32_t bin, uint32_t *wave_tot /*[4]*/) {
-    const int64_t b0 = bin_off[bin], b1 = bin_off[bin + 1];
+                                                 uint32_t *__restrict__ valid, uint32_t nrows, uint32_t bin, uint32_t *wave_tot /*[4]*/,
+                                                 unsigned long long *chk_flags = nullptr) {
+    // (R = 64-bit values: the GPU varint walk's columns, a [first, one-past-last) pair per bucket -- plan.h: DecodeBinsJob)
+    constexpr bool kTok = sizeof(R) == 8;
+    const int64_t b0 = kTok ? bin_off[2 * (size_t)bin] : bin_off[bin], b1 = kTok ? bin_off[2 * (size_t)bin + 1] : bin_off[bin + 1];
+    bool stray = false;
     const T value = (T)((uint64_t)bin_val[bin] - (uint64_t)vbase);
     uint32_t carry = 0;
     for (int64_t base = b0; base < b1; base += 256) {
         const int64_t i = base + threadIdx.x;
         uint32_t d = i < b1 ? (uint32_t)recs[i] : 0u;
+        if (kTok && i < b1) stray = stray || (uint64_t)recs[i] >= (uint64_t)nrows;  // (a delta or an id that large cannot be in the block)
         uint32_t r = d;
         if (delta_encoded) {
             uint32_t total;
@@ -496,7 +502,9 @@ __device__ __forceinline__ void decode_bins_body(const R *__restrict__ recs, con
             col[r] = value;
             if (valid) atomicOr(&valid[r >> 5], 1u << (r & 31));
         }
+        if (kTok && i < b1 && r >= nrows) stray = true;
     }
+    if (kTok && chk_flags && __any(stray) && (threadIdx.x & 63) == 0) atomicOr(chk_flags, (unsigned long long)kGobOutOfBounds);
 }
 
 template <typename T, typename R>
@@ -513,10 +521,10 @@ __global__ __launch_bounds__(256) void k_decode_bins(const R *__restrict__ recs,
 template <typename R>
 __device__ __forceinline__ void decode_bins_job(const DecodeBinsJob &J, uint32_t nrows, uint32_t bin, uint32_t *wave_tot) {
     switch (J.out_w) {
-    case 1: decode_bins_body<uint8_t, R>((const R *)J.recs, J.bin_off, J.bin_val, J.delta, J.vbase, (uint8_t *)J.col, J.valid, nrows, bin, wave_tot); break;
-    case 2: decode_bins_body<uint16_t, R>((const R *)J.recs, J.bin_off, J.bin_val, J.delta, J.vbase, (uint16_t *)J.col, J.valid, nrows, bin, wave_tot); break;
-    case 4: decode_bins_body<uint32_t, R>((const R *)J.recs, J.bin_off, J.bin_val, J.delta, J.vbase, (uint32_t *)J.col, J.valid, nrows, bin, wave_tot); break;
-    default: decode_bins_body<int64_t, R>((const R *)J.recs, J.bin_off, J.bin_val, J.delta, J.vbase, (int64_t *)J.col, J.valid, nrows, bin, wave_tot); break;
+    case 1: decode_bins_body<uint8_t, R>((const R *)J.recs, J.bin_off, J.bin_val, J.delta, J.vbase, (uint8_t *)J.col, J.valid, nrows, bin, wave_tot, J.chk_flags); break;
+    case 2: decode_bins_body<uint16_t, R>((const R *)J.recs, J.bin_off, J.bin_val, J.delta, J.vbase, (uint16_t *)J.col, J.valid, nrows, bin, wave_tot, J.chk_flags); break;
+    case 4: decode_bins_body<uint32_t, R>((const R *)J.recs, J.bin_off, J.bin_val, J.delta, J.vbase, (uint32_t *)J.col, J.valid, nrows, bin, wave_tot, J.chk_flags); break;
+    default: decode_bins_body<int64_t, R>((const R *)J.recs, J.bin_off, J.bin_val, J.delta, J.vbase, (int64_t *)J.col, J.valid, nrows, bin, wave_tot, J.chk_flags); break;
     }
 }
 __global__ __launch_bounds__(256) void k_decode_bins_multi(const DecodeBinsBatch B) {
@@ -524,6 +532,7 @@ __global__ __launch_bounds__(256) void k_decode_bins_multi(const DecodeBinsBatch
     const DecodeBinsJob &J = B.job[blockIdx.y];
     if ((int32_t)blockIdx.x >= J.n_bins) return;
     if (J.rec_w == 2) decode_bins_job<uint16_t>(J, B.nrows, blockIdx.x, wave_tot);
+    else if (J.rec_w == 8) decode_bins_job<unsigned long long>(J, B.nrows, blockIdx.x, wave_tot);
     else decode_bins_job<uint32_t>(J, B.nrows, blockIdx.x, wave_tot);
 }
 
@@ -604,8 +613,14 @@ __device__ __forceinline__ void decode_delta_job(const DecodeDeltaJob &J, uint32
     default: decode_delta_body<V, int64_t>((const V *)J.deltas, J.n, J.venc, J.vbase, (int64_t *)J.col, segment, wave_tot, J.chk_flags, J.chk_min, J.chk_max); break;
     }
 }
-__global__ __launch_bounds__(1024) void k_decode_delta_multi(const DecodeDeltaBatch B) {
+// (blockIdx.y beyond the delta jobs: the bucket parsers of the GPU varint walk's bucket-encoded columns, gob_bins.h -- one
+// workgroup each; like the delta jobs they wait for the walk only, so they share its successor launch)
+__global__ __launch_bounds__(1024) void k_decode_delta_multi(const DecodeDeltaBatch B, const GobBinsBatch G) {
     __shared__ int64_t wave_tot[16];
+    if ((int32_t)blockIdx.y >= B.n) {
+        if (blockIdx.x == 0) gob_bins_body(G.job[blockIdx.y - B.n]);
+        return;
+    }
     const DecodeDeltaJob &J = B.job[blockIdx.y];
     if ((int64_t)blockIdx.x * kDeltaSegment >= J.n) return;
     if (J.val_w == 4) decode_delta_job<int32_t>(J, blockIdx.x, wave_tot);
@@ -678,11 +693,19 @@ hipError_t launch_decode_bins_multi(const DecodeBinsBatch &B, hipStream_t st) {
     return hipGetLastError();
 }
 
-hipError_t launch_decode_delta_multi(const DecodeDeltaBatch &B, hipStream_t st) {
+hipError_t launch_decode_delta_multi(const DecodeDeltaBatch &B, const GobBinsBatch &G, hipStream_t st) {
     int64_t max_n = 0;
     for (int i = 0; i < B.n; i++) max_n = B.job[i].n > max_n ? B.job[i].n : max_n;
-    if (B.n <= 0 || max_n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_decode_delta_multi, dim3((unsigned)((max_n + kDeltaSegment - 1) / kDeltaSegment), (unsigned)B.n), dim3(1024), 0, st, B);
+    const int n_delta = max_n > 0 ? B.n : 0, n_gob = G.n > 0 ? G.n : 0;
+    if (n_delta <= 0 && n_gob <= 0) return hipSuccess;
+    if (n_delta == 0) {  // (no delta job with values: only the bucket parsers run)
+        DecodeDeltaBatch none;
+        none.n = 0;
+        hipLaunchKernelGGL(k_decode_delta_multi, dim3(1u, (unsigned)n_gob), dim3(1024), 0, st, none, G);
+        return hipGetLastError();
+    }
+    const unsigned segments = (unsigned)((max_n + kDeltaSegment - 1) / kDeltaSegment);
+    hipLaunchKernelGGL(k_decode_delta_multi, dim3(segments, (unsigned)(B.n + n_gob)), dim3(1024), 0, st, B, G);
     return hipGetLastError();
 }
 

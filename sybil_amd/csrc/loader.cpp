@@ -84,13 +84,15 @@ static void cgroup_throttle(int64_t *periods, int64_t *usec) {
 // narrow: the int slices in the form they travel in (gob::DecodeOpts) -- the int / str column files of a block
 // raw: the file's top-level `Values` slice is located, not decoded (gob::RawInts: pointers into this thread's file buffer, valid
 // until the thread's next decode_file)
-static bool decode_file(const std::string &path, gob::Value &v, std::string &err, bool narrow = false, gob::RawInts *raw = nullptr) {
+static bool decode_file(const std::string &path, gob::Value &v, std::string &err, bool narrow = false, gob::RawInts *raw = nullptr,
+                        gob::RawInts *raw_bins = nullptr) {
     static thread_local gob::FileBuf data;  // (reused: no allocation / page faults / zero-fill per file)
     if (!gob::read_file(path, data, err)) return false;
     g_file_bytes += (int64_t)data.n;
     gob::DecodeOpts opts;
     opts.narrow = narrow;
     opts.raw_values = raw;
+    opts.raw_bins = raw_bins;
     return gob::decode(data.p, data.n, v, err, &opts);
 }
 
@@ -106,7 +108,7 @@ static double seconds_since(std::chrono::steady_clock::time_point t0) {
 // measured its share at 0.38 s of a 0.46 s load when it still copied 2.1 GB of decoded pieces into a pinned ring itself.
 struct Slab {
     char *h = nullptr, *d = nullptr;
-    size_t cap = 0;
+    size_t cap = 0;             // of both; the device twin has SlabPool::scratch_bytes more behind it
     hipEvent_t done = nullptr;  // recorded behind the last kernel that reads d
 };
 
@@ -117,14 +119,16 @@ struct SlabPool {
     std::vector<int> free_;
     std::deque<int> pending;  // applied, event recorded, not yet known to be finished
     size_t slab_bytes = 0, max_slabs = 0;
+    size_t scratch_bytes = 0;  // device only, behind every slab's twin (the GPU varint walk's values)
     Ctx *ctx = nullptr;
     static constexpr size_t kChunkSlabs = 8;
     // (the arena belongs to the context and outlives the load: Ctx::load_chunks)
     int init(Ctx *c) {
         ctx = c;
-        if (c->load_slab_bytes != slab_bytes) {
+        if (c->load_slab_bytes != slab_bytes || c->load_scratch_bytes != scratch_bytes) {
             ctx_free_load_arena(c);
             c->load_slab_bytes = slab_bytes;
+            c->load_scratch_bytes = scratch_bytes;
         }
         return SYBL_OK;
     }
@@ -135,7 +139,7 @@ struct SlabPool {
             Ctx::ArenaChunk ch;
             ch.slabs = kChunkSlabs;
             SYBL_HIP(hipHostMalloc((void **)&ch.h, slab_bytes * kChunkSlabs, hipHostMallocDefault));
-            hipError_t e = hipMalloc((void **)&ch.d, slab_bytes * kChunkSlabs);
+            hipError_t e = hipMalloc((void **)&ch.d, (slab_bytes + scratch_bytes) * kChunkSlabs);
             if (e != hipSuccess) {
                 (void)hipHostFree(ch.h);
                 return hip_fail(e, "hipMalloc(loader arena)");
@@ -143,7 +147,7 @@ struct SlabPool {
             ctx->load_chunks.push_back(ch);
         }
         *h = ctx->load_chunks[ci].h + (k % kChunkSlabs) * slab_bytes;
-        *d = ctx->load_chunks[ci].d + (k % kChunkSlabs) * slab_bytes;
+        *d = ctx->load_chunks[ci].d + (k % kChunkSlabs) * (slab_bytes + scratch_bytes);
         return SYBL_OK;
     }
     // *out = -1 when no slab can be had right now (must_wait: block until the oldest pending one is done)
@@ -196,7 +200,7 @@ void ctx_free_load_arena(Ctx *ctx) {
         if (ch.d) (void)hipFree(ch.d);
     }
     ctx->load_chunks.clear();
-    ctx->load_slab_bytes = 0;
+    ctx->load_slab_bytes = ctx->load_scratch_bytes = 0;
 }
 
 // Worker threads of one table load (std::async started a thread per block: 1600 thread creations, 27 us each on the
@@ -270,7 +274,10 @@ struct PreparedCol {
     // raw_at / raw_len: the `Values` region in the slab; val_at (int64 values) and tok_at (uint32 offsets) are DEVICE-ONLY
     // scratch, relative to PreparedBlock::scratch_at (behind the bytes that cross PCIe).  vmin / vmax are then the block
     // info.db's IntInfo, which the kernel's own extrema are checked against when the load ends.
-    int64_t raw_len = 0;
+    // A bucket-encoded one likewise (raw_len > 0, rec_w == 8): the `Bins` region travels; the region's values (val_at), the ranks
+    // of its zeros (tok_at), the buckets' values (binval_at) and record ranges (binoff_at) are device-only scratch; n_recs is the
+    // block info.db's Count, which k_gob_bins holds the buckets' records against.
+    int64_t raw_len = 0, tok_cap = 0;
     size_t raw_at = 0, tok_at = 0;
 };
 
@@ -302,13 +309,13 @@ struct ColSpec {
 constexpr int64_t kMaxBlockRows = (int64_t)1 << 24;  // 256 x the reference's block size
 
 static PreparedBlock prepare_block_unguarded(const std::string &bdir, const std::vector<ColSpec> &specs, char *slab_h, size_t slab_cap, int device,
-                                             bool streamed = true, bool gpu_varint = false);
+                                             bool streamed = true, size_t scratch_cap = 0);
 static std::pair<int64_t, int64_t> block_signature(const std::string &bdir);
 // A worker thread must not let an exception escape (std::bad_alloc / length_error from a damaged file): it
 // would be rethrown by future::get() and leave the extern "C" entry point.  The block is skipped instead,
 // like every other block the reference cannot read.
 static PreparedBlock prepare_block(const std::string &bdir, const std::vector<ColSpec> &specs, char *slab_h, size_t slab_cap, int device,
-                                   bool gpu_varint = false) {
+                                   size_t scratch_cap = 0) {
     const auto t0 = std::chrono::steady_clock::now();
     struct Tally {
         std::chrono::steady_clock::time_point t0;
@@ -321,7 +328,7 @@ static PreparedBlock prepare_block(const std::string &bdir, const std::vector<Co
     // (what the block looked like BEFORE it was read: a rewrite in between makes the next refresh load it again)
     const std::pair<int64_t, int64_t> sig = block_signature(bdir);
     try {
-        PreparedBlock pb = prepare_block_unguarded(bdir, specs, slab_h, slab_cap, device, true, gpu_varint);
+        PreparedBlock pb = prepare_block_unguarded(bdir, specs, slab_h, slab_cap, device, true, scratch_cap);
         pb.sig = sig;
         return pb;
     } catch (const std::exception &) {
@@ -552,7 +559,7 @@ static bool fill_bins(const BinsView &bv, bool delta, int64_t num_records, char 
 }
 
 // <block>/info.db's IntInfoMap[name] (Min / Max: what the reference itself goes by when it skips blocks, table_block_io.go:120-135)
-static bool block_int_bounds(const gob::Value &binfo, const std::string &name, int64_t *mn, int64_t *mx) {
+static bool block_int_bounds(const gob::Value &binfo, const std::string &name, int64_t *mn, int64_t *mx, int64_t *count) {
     const gob::Value *m = binfo.field("IntInfoMap");
     if (!m) return false;
     for (auto &e : m->entries) {
@@ -560,13 +567,17 @@ static bool block_int_bounds(const gob::Value &binfo, const std::string &name, i
         const gob::Value *a = e.second->field("Min"), *b = e.second->field("Max");
         *mn = a ? a->as_int() : 0;  // (gob leaves a zero field out)
         *mx = b ? b->as_int() : 0;
+        const gob::Value *n = e.second->field("Count");
+        *count = n ? n->as_int() : 0;
         return *mn <= *mx;
     }
     return false;
 }
 
+// scratch_cap > 0: the GPU varint walk is on (SYBL_LOADER_GPU_VARINT) and the slab's device twin has that many bytes behind it
 static PreparedBlock prepare_block_unguarded(const std::string &bdir, const std::vector<ColSpec> &specs, char *slab_h, size_t slab_cap, int device,
-                                             bool streamed, bool gpu_varint) {
+                                             bool streamed, size_t scratch_cap) {
+    const bool gpu_varint = scratch_cap > 0;
     static const char *prefix[] = {"", "int_", "str_", "set_"};
     PreparedBlock pb;
     std::string err;
@@ -594,7 +605,7 @@ static PreparedBlock prepare_block_unguarded(const std::string &bdir, const std:
     std::vector<gob::Value> trees(streamed ? 0 : specs.size());
     std::vector<char> have(specs.size(), 0), bucketed(specs.size(), 0);
     size_t total = 0, scratch = 0;  // bytes that travel; device-only bytes behind them (GPU varint walk)
-    gob::RawInts raw;               // (streamed only: a column is planned and filled before the next file is read)
+    gob::RawInts raw, raw_bins;     // (streamed only: a column is planned and filled before the next file is read)
     auto reserve = [&](size_t bytes) {
         total = align16(total);
         const size_t at = total;
@@ -611,10 +622,10 @@ static PreparedBlock prepare_block_unguarded(const std::string &bdir, const std:
         // GPU varint walk (gobgpu.hip): an int column's `Values` slice is located, not decoded -- when the block's info.db
         // says what its extrema are (the decode kernels' destinations are chosen before they run) and the block goes column
         // by column
-        int64_t info_mn = 0, info_mx = 0;
-        const bool try_raw = gpu_varint && streamed && specs[ci].type == SYBL_INT_VAL && block_int_bounds(binfo, specs[ci].name, &info_mn, &info_mx);
-        raw = gob::RawInts();
-        if (!decode_file(path, v, err, specs[ci].type != SYBL_SET_VAL && !wide, try_raw ? &raw : nullptr)) return true;
+        int64_t info_mn = 0, info_mx = 0, info_n = 0;
+        const bool try_raw = gpu_varint && streamed && specs[ci].type == SYBL_INT_VAL && block_int_bounds(binfo, specs[ci].name, &info_mn, &info_mx, &info_n);
+        raw = raw_bins = gob::RawInts();
+        if (!decode_file(path, v, err, specs[ci].type != SYBL_SET_VAL && !wide, try_raw ? &raw : nullptr, try_raw ? &raw_bins : nullptr)) return true;
         have[ci] = 1;
         const gob::Value *f;
         const bool bucket = (f = v.field("BucketEncoded")) && f->as_bool();
@@ -628,7 +639,43 @@ static PreparedBlock prepare_block_unguarded(const std::string &bdir, const std:
             ok = (int64_t)pc.strings.size() <= pb.nrows;
         }
         const gob::Value *bins = v.field("Bins"), *vals = v.field("Values");
-        if (ok && bucket) {
+        // (the walk's state words hold a workgroup each for 1 MB of file; the bucket parser's workgroup 8192 buckets; the records
+        // of all buckets are the column's set rows, which info.db counted)
+        const size_t bins_len = raw_bins.hit && raw_bins.end > raw_bins.p ? (size_t)(raw_bins.end - raw_bins.p) : 0;
+        if (ok && bucket && specs[ci].type == SYBL_INT_VAL && bins_len > 0 && bins_len <= (size_t)kGobMaxWgs * kGobWgBytes && raw_bins.n >= 1 &&
+            raw_bins.n <= (uint64_t)kGobMaxBins && (int64_t)raw_bins.n <= pb.nrows && info_n >= 1 && info_n <= pb.nrows) {
+            pc.kind = PreparedCol::kIntBins;
+            pc.n_bins = (int64_t)raw_bins.n;
+            pc.n_recs = info_n;
+            pc.rec_w = 8;
+            pc.raw_len = (int64_t)bins_len;
+            pc.raw_at = reserve(((bins_len + 63) & ~(size_t)63) + 16);
+            pc.tok_cap = info_n + 5 * pc.n_bins + 16;
+            auto take = [&](size_t bytes) {
+                const size_t at = scratch;
+                scratch += align16(bytes);
+                return at;
+            };
+            pc.val_at = take((size_t)pc.tok_cap * 8);          // the region's values
+            pc.tok_at = take((size_t)(pc.n_bins + 8) * 4);     // ranks of the zeros
+            pc.binval_at = take((size_t)pc.n_bins * 8);
+            pc.binoff_at = take((size_t)pc.n_bins * 16);       // [first, one-past-last) of every bucket's records
+            pc.vmin = info_mn;
+            pc.vmax = info_mx;
+            pc.vpop = std::min<int64_t>(info_n, pb.nrows);
+            pc.have_stats = true;
+        } else if (ok && bucket) {
+            if (raw_bins.hit) {
+                // (not a case for the GPU: the file once more, through the whole reader)
+                raw = raw_bins = gob::RawInts();
+                v = gob::Value();
+                if (!decode_file(path, v, err, specs[ci].type != SYBL_SET_VAL && !wide)) {
+                    have[ci] = 0;
+                    return true;
+                }
+                bins = v.field("Bins");
+                vals = v.field("Values");
+            }
             pc.kind = specs[ci].type == SYBL_INT_VAL ? PreparedCol::kIntBins : PreparedCol::kStrBins;
             const BinsView bv(bins);
             pc.n_bins = bv.n;
@@ -651,8 +698,12 @@ static PreparedBlock prepare_block_unguarded(const std::string &bdir, const std:
                 pc.raw_at = reserve((((size_t)pc.raw_len + 63) & ~(size_t)63) + 16);
                 pc.val_at = scratch;
                 scratch += align16((size_t)pc.n_vals * 8);
+                pc.tok_cap = pc.n_vals;
                 pc.vmin = info_mn;
                 pc.vmax = info_mx;
+                // fewer set values than the slice is long: the rows in between hold 0 and become populated with it
+                // (column_store_io.go:97-114, 758-766), which info.db's extrema -- kept over the set values -- do not say
+                if (info_n < pc.n_vals) pc.vmin = std::min<int64_t>(pc.vmin, 0), pc.vmax = std::max<int64_t>(pc.vmax, 0);
                 if (ok && pc.n_vals < pb.nrows) {
                     pc.bits_words = (pb.nrows + 31) / 32;
                     pc.bits_at = reserve((size_t)pc.bits_words * 4);
@@ -702,6 +753,10 @@ static PreparedBlock prepare_block_unguarded(const std::string &bdir, const std:
         switch (pc.kind) {
         case PreparedCol::kIntBins:
         case PreparedCol::kStrBins: {
+            if (pc.raw_len > 0) {
+                memcpy(base + pc.raw_at, raw_bins.p, (size_t)pc.raw_len);
+                break;
+            }
             ok = fill_bins(BinsView(bins), pc.delta, pb.nrows, base, pc);
             const int64_t *off = (const int64_t *)(base + pc.binoff_at), *val = (const int64_t *)(base + pc.binval_at);
             if (ok && pc.kind == PreparedCol::kIntBins) {
@@ -843,10 +898,11 @@ static PreparedBlock prepare_block_unguarded(const std::string &bdir, const std:
         for (size_t ci = 0; ci < specs.size(); ci++) {
             gob::Value v;
             if (!plan(ci, v)) return pb;
-            if (align16(total) + scratch > slab_cap) return prepare_block_unguarded(bdir, specs, slab_h, slab_cap, device, false);  // (an over-sized block)
+            if (align16(total) > slab_cap || scratch > scratch_cap) return prepare_block_unguarded(bdir, specs, slab_h, slab_cap, device, false);  // (an over-sized block)
             if (!fill(ci, v, slab_h)) return pb;
         }
-        pb.bytes = pb.scratch_at = align16(total);
+        pb.bytes = align16(total);
+        pb.scratch_at = slab_cap;  // (the device twin's scratch lies behind the whole slab)
         return pb;
     }
     // ---- two passes: plan every column, then fill
@@ -913,12 +969,13 @@ struct DecodeBatches {
     DecodeBinsBatch bins;
     DecodeDeltaBatch deltas;
     GobValuesBatch gobs;
+    GobBinsBatch gbins;
     char *scratch = nullptr;                  // this block's device-only scratch (PreparedBlock::scratch_at)
     unsigned long long *d_state = nullptr;    // [kGobStateWords] per walk of the load, zeroed
     std::vector<GobCheck> checks;
     size_t name_ix = 0, col_ix = 0;  // the block / column being applied
     void begin(uint32_t nrows) {
-        bins.n = deltas.n = gobs.n = 0;
+        bins.n = deltas.n = gobs.n = gbins.n = 0;
         bins.nrows = nrows;
     }
     int flush_gobs(hipStream_t st) {
@@ -927,6 +984,10 @@ struct DecodeBatches {
         return e == hipSuccess ? SYBL_OK : hip_fail(e, "k_gob_values");
     }
     int flush_bins(hipStream_t st) {
+        if (gobs.n > 0 || gbins.n > 0) {  // (the walks and the bucket parsers write what the bins kernel reads)
+            int rc = flush_deltas(st);
+            if (rc) return rc;
+        }
         hipError_t e = launch_decode_bins_multi(bins, st);
         bins.n = 0;
         return e == hipSuccess ? SYBL_OK : hip_fail(e, "k_decode_bins_multi");
@@ -936,13 +997,14 @@ struct DecodeBatches {
             int rc = flush_gobs(st);
             if (rc) return rc;
         }
-        hipError_t e = launch_decode_delta_multi(deltas, st);
-        deltas.n = 0;
+        // (the bucket parsers of walked `Bins` regions ride along: they wait for the walk only, like the delta jobs)
+        hipError_t e = launch_decode_delta_multi(deltas, gbins, st);
+        deltas.n = gbins.n = 0;
         return e == hipSuccess ? SYBL_OK : hip_fail(e, "k_decode_delta_multi");
     }
     int flush(hipStream_t st) {
-        int rc = flush_bins(st);
-        return rc ? rc : flush_deltas(st);
+        int rc = flush_deltas(st);
+        return rc ? rc : flush_bins(st);
     }
 };
 
@@ -974,12 +1036,46 @@ static int apply_col(BlockWriter &w, Column *c, PreparedCol &pc, const char *H, 
         bool direct = false;
         if (stats && (rc = block_col_direct(w, c, all, mn, mx, pop, &col, &valid, &direct))) return rc;
         if (!direct && (rc = block_col_device(w, c, all, &col, &valid))) return rc;
-        if (batch.on && pc.n_bins > 0) {
+        const bool walked = pc.raw_len > 0;
+        unsigned long long *gob_state = nullptr;
+        if (walked) {
+            // the varint walk of the `Bins` region, then its buckets: file bytes -> values -> bucket values and record ranges,
+            // all in the block's device-only scratch
+            if ((batch.gobs.n == kGobBatchMax || batch.bins.n == kDecodeBatchMax) && (rc = batch.flush(st))) return rc;
+            gob_state = batch.d_state + (size_t)kGobStateWords * batch.checks.size();
+            GobValuesJob &G = batch.gobs.job[batch.gobs.n++];
+            memset(&G, 0, sizeof(G));
+            G.bytes = (const uint8_t *)(D + pc.raw_at);
+            G.n_bytes = (uint32_t)pc.raw_len;
+            G.n = (uint32_t)pc.tok_cap;
+            G.out = (long long *)(batch.scratch + pc.val_at);
+            G.state = gob_state;
+            G.zpos = (uint32_t *)(batch.scratch + pc.tok_at);
+            G.n_zpos = (uint32_t)(pc.n_bins + 8);
+            G.n_wgs = (int32_t)(((pc.raw_len + 63) / 64 + kGobWgThreads - 1) / kGobWgThreads);
+            GobBinsJob &P = batch.gbins.job[batch.gbins.n++];
+            memset(&P, 0, sizeof(P));
+            P.tok = (const unsigned long long *)G.out;
+            P.zpos = G.zpos;
+            P.state = gob_state;
+            P.bin_val = (long long *)(batch.scratch + pc.binval_at);
+            P.bin_rng = (long long *)(batch.scratch + pc.binoff_at);
+            P.n_bins = (uint32_t)pc.n_bins;
+            P.tok_cap = (uint32_t)pc.tok_cap;
+            P.zpos_cap = G.n_zpos;
+            P.n_recs = pc.n_recs;
+            P.chk_min = pc.vmin;
+            P.chk_max = pc.vmax;
+            batch.checks.push_back(GobCheck{batch.name_ix, -1, batch.col_ix, 0, pc.vmin, pc.vmax});
+        }
+        if ((batch.on || walked) && pc.n_bins > 0) {
             if (batch.bins.n == kDecodeBatchMax && (rc = batch.flush_bins(st))) return rc;
             DecodeBinsJob &J = batch.bins.job[batch.bins.n++];
-            J.recs = D + pc.rec_at;
-            J.bin_off = (const int64_t *)(D + pc.binoff_at);
-            J.bin_val = (const int64_t *)(D + pc.binval_at);
+            memset(&J, 0, sizeof(J));
+            J.recs = walked ? batch.scratch + pc.val_at : D + pc.rec_at;
+            J.bin_off = (const int64_t *)(walked ? batch.scratch + pc.binoff_at : D + pc.binoff_at);
+            J.bin_val = (const int64_t *)(walked ? batch.scratch + pc.binval_at : D + pc.binval_at);
+            J.chk_flags = walked ? gob_state + kGobStateFlags : nullptr;
             J.col = col;
             J.valid = valid;
             J.vbase = direct ? c->vbase : 0;
@@ -988,6 +1084,7 @@ static int apply_col(BlockWriter &w, Column *c, PreparedCol &pc, const char *H, 
             J.out_w = (uint8_t)(direct ? c->elem : c->canon());
             J.delta = pc.delta ? 1 : 0;
             J.pad = 0;
+            if (!batch.on && (rc = batch.flush_bins(st))) return rc;
         } else {
             hipError_t e = launch_decode_bins(D + pc.rec_at, pc.rec_w, (const int64_t *)(D + pc.binoff_at), (const int64_t *)(D + pc.binval_at),
                                               (int)pc.n_bins, pc.delta, col, direct ? c->elem : c->canon(), direct ? c->vbase : 0, valid,
@@ -1010,7 +1107,7 @@ static int apply_col(BlockWriter &w, Column *c, PreparedCol &pc, const char *H, 
         unsigned long long *gob_state = nullptr;
         if (ints && pc.raw_len > 0) {
             // the varint walk first: file bytes -> int64 values in the block's device-only scratch
-            if (batch.gobs.n == kGobBatchMax && (rc = batch.flush_deltas(st))) return rc;
+            if (batch.gobs.n == kGobBatchMax && (rc = batch.flush(st))) return rc;
             GobValuesJob &G = batch.gobs.job[batch.gobs.n++];
             memset(&G, 0, sizeof(G));
             G.bytes = (const uint8_t *)(D + pc.raw_at);
@@ -1153,8 +1250,12 @@ static int load_blocks_once(Ctx *ctx, Table *t, const std::string &tdir, const s
     {
         size_t per_block = 65536;
         for (auto &sp : specs) per_block += sp.type == SYBL_SET_VAL ? 0 : (size_t)65536 * (sp.type == SYBL_STR_VAL ? 12 : 8) + ((size_t)96 << 10);
-        // (the file's bytes -- at most nine per value -- next to the int64 values they become, which exist on the device only)
-        if (gpu_varint) per_block += n_int_cols * ((size_t)65536 * 9 + 256);
+        // (the file's bytes travel -- at most nine per value; the int64 values they become, the buckets' values and record ranges
+        // and the ranks of the zeros exist behind the slab's device twin only)
+        if (gpu_varint) {
+            per_block += n_int_cols * ((size_t)65536 * 9 + 4096);
+            pool.scratch_bytes = align16(n_int_cols * ((size_t)65536 * 8 + (size_t)kGobMaxBins * 72 + 4096));
+        }
         pool.slab_bytes = align16(per_block);
         if (const char *e = env("SYBL_LOADER_SLAB_BYTES")) pool.slab_bytes = align16((size_t)std::max(16, atoi(e)));  // (tests: over-sized blocks)
         pool.max_slabs = std::min<size_t>(std::max<size_t>(((size_t)512 << 20) / pool.slab_bytes, 4), std::max<size_t>(2 * n_workers, 4));
@@ -1183,7 +1284,8 @@ static int load_blocks_once(Ctx *ctx, Table *t, const std::string &tdir, const s
             const size_t scap = pool.slabs[(size_t)slab].cap;
             auto prom = std::make_shared<std::promise<PreparedBlock>>();
             inflight.push_back(InFlight{prom->get_future(), slab, next - 1});
-            workers.run([prom, bdir, &specs, sh, scap, device, gpu_varint]() { prom->set_value(prepare_block(bdir, specs, sh, scap, device, gpu_varint)); });
+            const size_t xcap = pool.scratch_bytes;
+            workers.run([prom, bdir, &specs, sh, scap, device, xcap]() { prom->set_value(prepare_block(bdir, specs, sh, scap, device, xcap)); });
         }
         return SYBL_OK;
     };
@@ -1351,7 +1453,12 @@ static int load_blocks_once(Ctx *ctx, Table *t, const std::string &tdir, const s
         for (size_t k = 0; k < batch.checks.size(); k++) {
             const GobCheck &ck = batch.checks[k];
             const unsigned long long *g = &got[(size_t)kGobStateWords * k];
+            // (`Values`: every announced value found; `Bins`: n = 0 -- k_gob_bins has held the buckets against what was announced)
             if (g[kGobStateFlags] == 0 && g[kGobStateFound] >= (unsigned long long)ck.n) continue;
+            if (trace)
+                fprintf(stderr, "loader: gpu varint walk of block %s column %zu: flags 0x%llx, found %llu of %lld values, %llu zeros, %llu records\n",
+                        names[ck.name_ix].c_str(), ck.col, (unsigned long long)g[kGobStateFlags], (unsigned long long)g[kGobStateFound], (long long)ck.n,
+                        (unsigned long long)g[kGobStateZeros], (unsigned long long)g[kGobStateRecs]);
             if (bad_name[ck.name_ix]) continue;
             bad_name[ck.name_ix] = 1;
             table_retire_block(t, ck.block);
@@ -1603,12 +1710,14 @@ const char *sybl_debug_block_layout(const char *block_dir, const char *const *co
     // `Values` region as it would travel>; val= is then empty, the values exist on the device only)
     bool gpu_varint = false;
     if (const char *e = env("SYBL_LOADER_GPU_VARINT")) gpu_varint = atoi(e) != 0;
+    size_t xcap = 0;
     if (gpu_varint)
-        for (auto &sp : specs) cap += sp.type == SYBL_INT_VAL ? (size_t)65536 * 9 + 256 : 0;
+        for (auto &sp : specs)
+            if (sp.type == SYBL_INT_VAL) cap += (size_t)65536 * 9 + 4096, xcap += (size_t)65536 * 8 + (size_t)kGobMaxBins * 72 + 4096;
     std::vector<char> slab(cap);
     PreparedBlock pb;
     try {
-        pb = prepare_block_unguarded(block_dir, specs, slab.data(), cap, -1, true, gpu_varint);
+        pb = prepare_block_unguarded(block_dir, specs, slab.data(), cap, -1, true, xcap);
     } catch (const std::exception &e) {
         out = std::string("exception: ") + e.what();
         return out.c_str();
@@ -1631,7 +1740,7 @@ const char *sybl_debug_block_layout(const char *block_dir, const char *const *co
         uint64_t hset = fnv(pc.set_off.data(), pc.set_off.size() * 8);
         hset = fnv(pc.set_ids.data(), pc.set_ids.size() * 4, hset);
         hset = fnv(pc.set_pop.data(), pc.set_pop.size(), hset);
-        const bool bins = pc.kind == PreparedCol::kIntBins || pc.kind == PreparedCol::kStrBins;
+        const bool bins = (pc.kind == PreparedCol::kIntBins || pc.kind == PreparedCol::kStrBins) && pc.raw_len == 0;  // (walked on the GPU: device-only)
         snprintf(b, sizeof(b),
                  "%s kind=%d delta=%d venc=%d rec_w=%d val_w=%d local_w=%d recs=%lld bins=%lld vals=%lld local=%lld bits=%lld stats=%d min=%lld max=%lld pop=%lld "
                  "strings=%zu:%016llx binval=%016llx binoff=%016llx rec=%016llx val=%016llx loc=%016llx valid=%016llx set=%016llx\n",

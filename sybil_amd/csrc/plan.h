@@ -235,23 +235,44 @@ enum Header : int {
 constexpr int kGobWgThreads = 256;                       // one 64-byte chunk per thread: a workgroup walks 16 KB of a file
 constexpr int kGobWgBytes = kGobWgThreads * 64;
 constexpr int kGobMaxWgs = 64;                           // per file (the look-back is one wave wide): 1 MB of values
-// a job's state words (zeroed before the launch): flags | values found | the workgroups' exit maps | their value counts
-constexpr int kGobStateFlags = 0, kGobStateFound = 1, kGobStateMaps = 2, kGobStateCounts = 2 + kGobMaxWgs, kGobStateWords = 2 + 2 * kGobMaxWgs;
+// a job's state words (zeroed before the launch): flags | values found | zero values found | records in the bins (k_gob_bins) |
+// the workgroups' exit maps | their value counts
+constexpr int kGobStateFlags = 0, kGobStateFound = 1, kGobStateZeros = 2, kGobStateRecs = 3, kGobStateMaps = 4, kGobStateCounts = 4 + kGobMaxWgs,
+              kGobStateWords = 4 + 2 * kGobMaxWgs;
 struct GobValuesJob {
-    const uint8_t *bytes;        // device, 16-byte aligned: the first value of the file's `Values` slice (behind its count) ...
-    uint32_t n_bytes, n;         // ... to the end of the file's value message; the count the slice header announced
-    long long *out;              // [n] the values as the file holds them (deltas when the column is value-encoded), int64
+    const uint8_t *bytes;        // device, 16-byte aligned: the first value of the file's slice (behind its count) ...
+    uint32_t n_bytes, n;         // ... to the end of the file's value message; how many values to take from it at most
+    long long *out;              // [n] `Values`: the signed values as the file holds them (deltas when the column is value-encoded);
+                                 // `Bins` (zpos != null): the unsigned form of every value of the region
     unsigned long long *state;   // [kGobStateWords]
-    int32_t n_wgs, pad_;
+    uint32_t *zpos;              // `Bins`: [n_zpos] the ranks of the values that are 0 (the buckets' terminators, mostly), in order
+    uint32_t n_zpos;
+    int32_t n_wgs;
 };
 constexpr uint32_t kGobBadByte = 1u;    // flags: a value starts with a byte 0x80..0xF7
 constexpr uint32_t kGobShort = 2u;      // fewer values in the region than the slice header announced
 constexpr uint32_t kGobTruncated = 4u;  // a value reaches beyond the region
 constexpr uint32_t kGobOutOfBounds = 8u;  // a column value outside the bounds the block was placed by (k_decode_delta)
 constexpr uint32_t kGobGaveUp = 16u;    // a look-back word did not arrive
+constexpr uint32_t kGobBadBins = 32u;   // the buckets do not parse (k_gob_bins), or hold another number of records than announced
 constexpr int kGobBatchMax = 16;
 struct GobValuesBatch {
     GobValuesJob job[kGobBatchMax];
+    int32_t n;
+};
+// the buckets of one bucket-encoded int column file, from the values k_gob_values found in its `Bins` region (k_gob_bins)
+constexpr int kGobMaxBins = 8192;
+struct GobBinsJob {
+    const unsigned long long *tok;  // the region's values, unsigned form
+    const uint32_t *zpos;           // ranks of the zero values
+    unsigned long long *state;      // the walk's state words (values / zeros found; flags and the record total go back there)
+    long long *bin_val;             // [n_bins] out
+    long long *bin_rng;             // [2 * n_bins] out: first and one-past-last rank of every bucket's records in tok
+    uint32_t n_bins, tok_cap, zpos_cap, pad_;
+    long long n_recs, chk_min, chk_max;  // what the block's info.db announced: records in all buckets; bounds of the values
+};
+struct GobBinsBatch {
+    GobBinsJob job[kGobBatchMax];
     int32_t n;
 };
 
@@ -266,6 +287,9 @@ struct DecodeBinsJob {
     int64_t vbase;
     int32_t n_bins;
     uint8_t rec_w, out_w, delta, pad;
+    // rec_w == 8 (the GPU varint walk's columns): recs are the walk's 64-bit values and bin_off holds a [first, one-past-last)
+    // pair per bucket (GobBinsJob::bin_rng); kGobOutOfBounds is set in *chk_flags for a record id that is no row of the block
+    unsigned long long *chk_flags;
 };
 struct DecodeBinsBatch {
     DecodeBinsJob job[kDecodeBatchMax];

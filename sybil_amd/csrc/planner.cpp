@@ -864,7 +864,10 @@ struct Planner {
                 lo = c->exact_min;
                 hi = c->exact_max;
             }
-            if (c->n_pop == 0 && !c->bounds_set) {
+            // (no value anywhere in the column: no key range.  A str column's range is its dictionary whatever THIS rank holds --
+            // after sybl_table_agree that is the ranks' union, and a rank without a row of the column must still lay its partial
+            // table out like the others: tests/test_gpu_cli_multirank.py::test_ranks_without_a_block)
+            if (c->n_pop == 0 && !c->bounds_set && (c->type != SYBL_STR_VAL || c->dict.empty())) {
                 lo = 0;
                 hi = -1;
             }

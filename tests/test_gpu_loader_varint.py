@@ -76,7 +76,7 @@ def test_value_encoded_columns_load_the_same_either_way(ctx, tmp_path, monkeypat
     F.write_table(root, "events", blocks, threshold=100)
     host, gpu = _open_both(ctx, monkeypatch, root, "events", compact=compact)
     st = gpu.load_stats()
-    assert st["gpu_varint_cols"] == 15 and st["gpu_varint_redone"] == 0, st   # time, wide, small of five blocks
+    assert st["gpu_varint_cols"] == 20 and st["gpu_varint_redone"] == 0, st   # time, wide, small (values) and key (buckets) of five blocks
     assert host.load_stats()["gpu_varint_cols"] == 0
     _same_columns(host, gpu, ("time", "wide", "small", "key"))
     for q in (dict(groups=["key"], aggs=["wide", "time"], op="hist"), dict(filters=[("small", "gt", 500)], groups=["key"], aggs=["time"])):
@@ -85,25 +85,50 @@ def test_value_encoded_columns_load_the_same_either_way(ctx, tmp_path, monkeypat
     host.free()
 
 
-def test_holes_put_values_outside_the_blocks_bounds_and_the_host_parser_takes_those_blocks(ctx, tmp_path, monkeypatch):
+def test_unset_rows_of_a_value_encoded_column_are_zeros_the_bounds_must_cover(ctx, tmp_path, monkeypatch):
     """A value-encoded column's unset rows hold 0 (SaveIntsToColumns, column_store_io.go:97-114) and become populated on load
-    (:758-766); the block's IntInfo was kept over the set values only, so 0 may lie outside it.  The walk's own extrema
-    notice, and the block is loaded again by the host parser: same columns, same answers."""
+    (:758-766); the block's IntInfo was kept over the set values only, so 0 may lie outside its Min / Max.  Its Count says
+    whether there are such rows (fewer set values than the slice is long): the block is then placed by bounds that include 0,
+    exactly the extrema the host parser finds, and nothing has to be loaded twice."""
     rng = np.random.default_rng(5)
     blocks = []
     for b in range(4):
         n = 20000
         age = rng.integers(10, 300, size=n).astype(np.int64)
-        pop = rng.random(n) > (0.2 if b % 2 else 0.0)     # blocks 1 and 3 have holes: 0 < Min = 10
+        pop = rng.random(n) > (0.2 if b % 2 else 0.0)     # blocks 1 and 3 have unset rows: 0 < Min = 10
         key = rng.integers(0, 5, size=n).astype(np.int64)
         blocks.append({"age": ("int", age, pop), "key": ("int", key)})
     root = str(tmp_path / "db")
     F.write_table(root, "events", blocks, threshold=50)
     host, gpu = _open_both(ctx, monkeypatch, root, "events")
     st = gpu.load_stats()
-    assert st["gpu_varint_cols"] == 4 and st["gpu_varint_redone"] == 2, st
+    assert st["gpu_varint_cols"] == 8 and st["gpu_varint_redone"] == 0, st
+    _same_columns(host, gpu, ("age", "key"))
+    for q in (dict(groups=["key"], aggs=["age"], op="hist"), dict(filters=[("age", "lt", 5)], groups=["key"], aggs=["age"])):
+        assert _summary(gpu, **q) == _summary(host, **q)
+    gpu.free()
+    host.free()
+
+
+def test_a_block_whose_bounds_do_not_cover_its_values_is_loaded_again_by_the_host_parser(ctx, tmp_path, monkeypatch):
+    """info.db says Min = 10 and every row is set, but the file holds a 3: k_decode_delta notices, the block's rows leave the
+    scan and the host parser loads the block again behind the others -- same rows, same answers."""
+    rng = np.random.default_rng(6)
+    blocks = []
+    for b in range(3):
+        n = 9000
+        blocks.append({"age": ("int", rng.integers(10, 300, size=n).astype(np.int64)), "key": ("int", rng.integers(0, 5, size=n).astype(np.int64))})
+    root = str(tmp_path / "db")
+    F.write_table(root, "events", blocks, threshold=50)
+    # block 2's file rewritten with a value below the recorded minimum
+    vals = np.asarray(blocks[1]["age"][1]).copy()
+    vals[4000] = 3
+    with open(os.path.join(root, "events", "block000000002", "int_age.db"), "wb") as f:
+        f.write(F.int_column("age", vals, None, 50))
+    host, gpu = _open_both(ctx, monkeypatch, root, "events")
+    st = gpu.load_stats()
+    assert st["gpu_varint_cols"] == 6 and st["gpu_varint_redone"] == 1, st
     assert gpu.rows == host.rows and gpu.broken_blocks == host.broken_blocks == 0
-    # (the two blocks loaded again stand behind the others: compare the answers, not the row order)
     for q in (dict(groups=["key"], aggs=["age"], op="hist"), dict(filters=[("age", "lt", 5)], groups=["key"], aggs=["age"])):
         assert _summary(gpu, **q) == _summary(host, **q)
     assert sorted(gpu.read_int("age", 0, gpu.rows).tolist()) == sorted(host.read_int("age", 0, host.rows).tolist())
@@ -212,7 +237,7 @@ def test_refresh_loads_new_blocks_through_the_same_path(ctx, tmp_path, monkeypat
     F.write_table(root, "events", blocks[:2], threshold=100)
     monkeypatch.setenv("SYBL_LOADER_GPU_VARINT", "1")
     tb = ctx.open_table(root, "events")
-    assert tb.load_stats()["gpu_varint_cols"] == 2
+    assert tb.load_stats()["gpu_varint_cols"] == 4
     F.write_table(root, "events", blocks, threshold=100)
     tb.refresh()
     assert tb.load_stats()["gpu_varint_cols"] >= 1
@@ -223,3 +248,102 @@ def test_refresh_loads_new_blocks_through_the_same_path(ctx, tmp_path, monkeypat
     assert sorted(tb.read_int("t", 0, tb.rows).tolist()) == sorted(ref.read_int("t", 0, ref.rows).tolist())
     tb.free()
     ref.free()
+
+
+def _bucket_file(name, values, pop=None, delta=True):
+    """A bucket-encoded int column file (SaveIntsToColumns, column_store_io.go:64-131): buckets in order of first appearance,
+    record ids ascending, as differences when DeltaEncodedIDs."""
+    values = np.asarray(values, dtype=np.int64)
+    rows = np.arange(len(values)) if pop is None else np.nonzero(pop)[0]
+    order, ids = [], {}
+    for r in rows:
+        v = int(values[r])
+        if v not in ids:
+            ids[v] = []
+            order.append(v)
+        ids[v].append(int(r))
+    bins = []
+    for v in order:
+        r = np.asarray(ids[v], dtype=np.int64)
+        bins.append({"Value": v, "Records": [int(x) for x in (np.diff(r, prepend=0) if delta else r)]})
+    col = {"Name": name, "BucketEncoded": True, "Bins": bins, "VERSION": 1}
+    if delta:
+        col["DeltaEncodedIDs"] = True
+    return G.encode(G.saved_int_column(), col)
+
+
+@pytest.mark.parametrize("compact", [False, True])
+def test_bucket_encoded_columns_load_the_same_either_way(ctx, tmp_path, monkeypatch, compact):
+    """The buckets of bucket-encoded columns (k_gob_bins) in the shapes the wire format has: the bucket of row 0 (its first
+    record is a 0 among the terminators) with one record, with many, and first or last among the buckets; Value 0 (the field is
+    left out); negative and 64-bit values; ids as differences and absolute; rows without a value; one bucket holding every
+    row; thousands of buckets; a one-row block."""
+    rng = np.random.default_rng(19)
+    root = str(tmp_path / "db")
+    tdir = os.path.join(root, "events")
+    os.makedirs(tdir)
+    names = ["few", "zero", "neg", "abs", "holes", "one", "many", "solo0"]
+    sizes = [65536, 1, 2, 300, 5000, 20000]
+    for bi, n in enumerate(sizes):
+        few = rng.integers(0, 7, size=n) * 1000 + 5
+        zero = rng.integers(0, 3, size=n)                                  # a bucket with Value 0
+        neg = rng.choice(np.array([-(1 << 62), -5, 0, 7, (1 << 62) + 12345], dtype=np.int64), size=n)
+        ab = rng.integers(0, 40, size=n)
+        holes = rng.integers(10, 20, size=n)
+        hp = rng.random(n) > 0.3
+        hp[0] = bi % 2 == 0                                                # row 0 with and without a value
+        if not hp.any():
+            hp[-1] = True
+        one = np.full(n, 42)
+        many = rng.integers(0, min(n, 6000), size=n)
+        solo0 = np.arange(n) % min(max(n - 1, 1), 3000) + 100                       # row 0's value appears once when n > 2: a bucket [2][1][0][0]
+        solo0[0] = 7
+        vals = {"few": few, "zero": zero, "neg": neg, "abs": ab, "holes": holes, "one": one, "many": many, "solo0": solo0}
+        cols = {c: _bucket_file(c, v, pop=hp if c == "holes" else None, delta=c != "abs") for c, v in vals.items()}
+        infos = {c: _info(np.asarray(v, dtype=np.int64)[hp] if c == "holes" else np.asarray(v, dtype=np.int64)) for c, v in vals.items()}
+        _write_block(tdir, bi + 1, cols, n, infos)
+    _table_info(tdir, "events", names, -(1 << 62), 1 << 62)
+    host, gpu = _open_both(ctx, monkeypatch, root, "events", compact=compact)
+    st = gpu.load_stats()
+    assert st["gpu_varint_cols"] == len(names) * len(sizes) and st["gpu_varint_redone"] == 0, st
+    _same_columns(host, gpu, names)
+    for q in (dict(groups=["few"], aggs=["neg", "holes"], op="hist"), dict(filters=[("holes", "gt", 14)], groups=["zero"], aggs=["many"])):
+        assert _summary(gpu, **q) == _summary(host, **q)
+    gpu.free()
+    host.free()
+
+
+def test_damaged_buckets_get_the_host_parsers_verdict(ctx, tmp_path, monkeypatch):
+    """Buckets that do not hold what they announce: a record id beyond NumRecords ("BLOCK SIZE CHANGED DURING QUERY": the
+    block is skipped), a count larger than the records that follow, a file cut short, info.db announcing another number of set
+    rows or bounds that do not cover the values (the host parser loads those as they are)."""
+    rng = np.random.default_rng(23)
+    root = str(tmp_path / "db")
+    tdir = os.path.join(root, "events")
+    os.makedirs(tdir)
+    n = 4000
+    vals = rng.integers(0, 9, size=n).astype(np.int64) + 3
+    other = rng.integers(0, 5, size=n).astype(np.int64)
+    good, good2 = _bucket_file("v", vals), _bucket_file("w", other)
+    info = {"v": _info(vals), "w": _info(other)}
+    _write_block(tdir, 1, {"v": good, "w": good2}, n, info)
+    _write_block(tdir, 2, {"v": good, "w": good2}, n - 100, {"v": dict(_info(vals), Count=n - 100), "w": dict(_info(other), Count=n - 100)})   # ids beyond NumRecords
+    _write_block(tdir, 3, {"v": good[: len(good) - 40], "w": good2}, n, info)                                 # cut short
+    wrong = dict(_info(vals), Count=n - 1)
+    _write_block(tdir, 4, {"v": good, "w": good2}, n, {"v": wrong, "w": _info(other)})                         # another Count
+    _write_block(tdir, 5, {"v": good, "w": good2}, n, {"v": dict(_info(vals), Min=4), "w": _info(other)})      # bounds too narrow
+    c0 = int((vals == vals[0]).sum())                                      # the first bucket's count: one more than there are
+    head = b"\x01" + G.enc_int(int(vals[0])) + b"\x01"
+    assert len(G.enc_uint(c0)) == len(G.enc_uint(c0 + 1)) and good.count(head + G.enc_uint(c0)) == 1
+    _write_block(tdir, 6, {"v": good.replace(head + G.enc_uint(c0), head + G.enc_uint(c0 + 1)), "w": good2}, n, info)
+    _table_info(tdir, "events", ["v", "w"], 0, 100)
+    host, gpu = _open_both(ctx, monkeypatch, root, "events")
+    st = gpu.load_stats()
+    assert st["gpu_varint_cols"] > 0 and st["gpu_varint_redone"] >= 3, st
+    assert gpu.rows == host.rows and gpu.broken_blocks == host.broken_blocks
+    for c in ("v", "w"):
+        assert sorted(gpu.read_int(c, 0, gpu.rows).tolist()) == sorted(host.read_int(c, 0, host.rows).tolist()), c
+    q = dict(groups=["w"], aggs=["v"], op="hist")
+    assert _summary(gpu, **q) == _summary(host, **q)
+    gpu.free()
+    host.free()

@@ -283,7 +283,18 @@ def test_gpu_varint_worker_half_hands_over_the_files_value_bytes(tmp_path, monke
         assert f["vals"] == str(n) and f["val_w"] == "8" and f["venc"] == "1" and f["kind"] == plain[name]["kind"]
         assert (int(f["min"]), int(f["max"]), int(f["pop"])) == (int(vals.min()), int(vals.max()), n)
         assert (plain[name]["min"], plain[name]["max"]) == (f["min"], f["max"]) and "raw" not in plain[name]
-    assert "raw" not in lines["few"] and lines["few"] == plain["few"]
+    # the bucket-encoded column: its `Bins` region travels, from the first bucket to the end of the message; the count of the
+    # buckets' records is info.db's Count
+    f = lines["few"]
+    data = open(os.path.join(bdir, "int_few.db"), "rb").read()
+    ids = {int(v): np.nonzero(few == v)[0] for v in np.unique(few)}
+    starts = [data.index(b"".join([b"\x01", G.enc_int(v), b"\x01"] if v else [b"\x02"]) + G.enc_uint(len(r)) +
+                         b"".join(G.enc_uint(int(d)) for d in np.diff(r, prepend=0))) for v, r in ids.items()]
+    region = data[min(starts):]
+    assert data[:min(starts)].endswith(G.enc_uint(len(ids)))
+    assert f["raw"] == "%d:%016x" % (len(region), _fnv(region))
+    assert (f["bins"], f["recs"], f["rec_w"], f["delta"]) == (str(len(ids)), str(n), "8", "1")
+    assert (int(f["min"]), int(f["max"]), int(f["pop"])) == (int(few.min()), int(few.max()), n) and "raw" not in plain["few"]
     # no IntInfoMap entry for the column: nothing to place the block by, the host parser takes it
     info = G.decode(open(os.path.join(bdir, "info.db"), "rb").read())
     del info["IntInfoMap"]["wide"]
