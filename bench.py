@@ -176,6 +176,32 @@ def load_path(ctx, names, rows=100 * 1024 * 1024 // 65536 * 65536, scan_workload
                 best = (dt, st, hbm)
         dt, st, hbm = best
         b2b = sum(opens[3:]) / len(opens[3:])
+        # The same open with every column file through the host parser (SYBL_LOADER_GPU_VARINT=0: gob.cpp's AVX-512 varint
+        # windows on the worker threads, the only path before round 6; the default now walks the int columns' Values / Bins
+        # slices on the GPU, csrc/gobgpu.hip).  Its first open also rebuilds the staging arena for the other slab size and is
+        # not counted; best of three from idle.
+        hp = None
+        os.environ["SYBL_LOADER_GPU_VARINT"] = "0"
+        try:
+            runs = []
+            for i in range(4):
+                time.sleep(0.3)
+                t0 = time.perf_counter()
+                tb = ctx.open_table(root, "loadbench", compact=True)
+                dtv = time.perf_counter() - t0
+                assert tb.rows == rows
+                stv = tb.load_stats()
+                tb.free()
+                if i > 0:
+                    runs.append((dtv, stv))
+            dtv, stv = min(runs, key=lambda r: r[0])
+            hp = {"rows_per_s": rows / dtv, "seconds": round(dtv, 4), "open_seconds": [round(r[0], 4) for r in runs], "stage_breakdown": stv,
+                  "what": "SYBL_LOADER_GPU_VARINT=0: every column file parsed by the worker threads (gob.cpp); best of 3 opens from idle"}
+        finally:
+            os.environ.pop("SYBL_LOADER_GPU_VARINT", None)
+        # (back to the default slab size before anything else is timed)
+        tb = ctx.open_table(root, "loadbench", compact=True)
+        tb.free()
         cold = None
         if scan_workload:
             # SURVEY 8d's end-to-end figure: `sybil query` itself, cold -- process start -> library load -> HIP context -> table
@@ -201,10 +227,11 @@ def load_path(ctx, names, rows=100 * 1024 * 1024 // 65536 * 65536, scan_workload
                     "resident_step_ms": None if scanned is None else scanned["kernel_ms"],
                     "what": "wall time of the CLI process, start to exit, on the saved table (files in the page cache): what a cold "
                             "`sybil query` replacement costs end to end; `seconds` above is the open alone, `loaded_table_scan` the resident scan"}
-        return {"cold_cli": cold, "loaded_table_scan": scanned, "rows_per_s": rows / dt, "rows": rows, "columns": names, "seconds": round(dt, 3), "bytes_on_disk": size,
+        return {"cold_cli": cold, "loaded_table_scan": scanned, "host_parser": hp, "rows_per_s": rows / dt, "rows": rows, "columns": names, "seconds": round(dt, 3), "bytes_on_disk": size,
                 "disk_bytes_per_row": size / rows, "hbm_bytes": hbm, "stage_breakdown": st, "save_seconds": round(save_s, 2),
                 "open_seconds": opens, "back_to_back": {"seconds": round(b2b, 4), "rows_per_s": rows / b2b},
-                "what": "sybl_table_save -> sybl_table_open_flags(SYBL_OPEN_COMPACT), page cache warm: best of 3 opens that each start "
+                "what": "sybl_table_save -> sybl_table_open_flags(SYBL_OPEN_COMPACT), page cache warm, the int columns' varints walked on the GPU "
+                        "(the default; host_parser: the same open with SYBL_LOADER_GPU_VARINT=0): best of 3 opens that each start "
                         "0.3 s after the previous CPU burst; back_to_back: mean of 3 opens without the pause (CFS quota throttling)"}
     finally:
         shutil.rmtree(root, ignore_errors=True)

@@ -492,6 +492,16 @@ int sybl_init(int device, sybl_ctx **out) {
         return hip_fail(e, "hipStreamCreate");
     }
     c->stream = c->own_stream;
+    // The loader's streams, made NOW: the runtime spreads streams over its few hardware queues as they are created, and a
+    // process that had made and destroyed many streams before its first load (bench.py after its query configs) got all
+    // sixteen onto one or two of them -- the blocks' kernel chains then ran one after the other, a 0.065 s open took 0.14 s
+    // (profiles/r06_gpu_varint.txt).  SYBL_LOADER_STREAMS says how many a load uses.
+    for (int i = 0; i < 16; i++)
+        if (hipStreamCreateWithFlags(&c->load_streams[i], hipStreamNonBlocking) != hipSuccess) {
+            c->load_streams[i] = nullptr;
+            (void)hipGetLastError();
+            break;
+        }
     *out = c;
     return SYBL_OK;
 }

@@ -1232,9 +1232,10 @@ static int load_blocks_once(Ctx *ctx, Table *t, const std::string &tdir, const s
     const size_t n_names = names.size();
     std::vector<ColSpec> specs;
     for (auto &cp : t->cols) specs.push_back({cp->name, cp->type});
-    // SYBL_LOADER_GPU_VARINT=1 (round 6, opt-in): int columns stored as `Values` cross PCIe as file bytes and are walked on the
-    // GPU (gobgpu.hip); a block whose walk reports anything unexpected is loaded again by the host parser when the load ends
-    bool gpu_varint = false;
+    // Round 6: the `Values` / `Bins` slices of int column files cross PCIe as file bytes and are walked on the GPU (gobgpu.hip);
+    // a block whose walk reports anything unexpected is loaded again by the host parser when the load ends.
+    // SYBL_LOADER_GPU_VARINT=0: every file through the host parser (gob.cpp), as before.
+    bool gpu_varint = allow_gpu_varint;
     if (const char *e = env("SYBL_LOADER_GPU_VARINT")) gpu_varint = allow_gpu_varint && atoi(e) != 0;
     size_t n_int_cols = 0;
     for (auto &sp : specs) n_int_cols += sp.type == SYBL_INT_VAL ? 1 : 0;
@@ -1250,10 +1251,11 @@ static int load_blocks_once(Ctx *ctx, Table *t, const std::string &tdir, const s
     {
         size_t per_block = 65536;
         for (auto &sp : specs) per_block += sp.type == SYBL_SET_VAL ? 0 : (size_t)65536 * (sp.type == SYBL_STR_VAL ? 12 : 8) + ((size_t)96 << 10);
-        // (the file's bytes travel -- at most nine per value; the int64 values they become, the buckets' values and record ranges
-        // and the ranks of the zeros exist behind the slab's device twin only)
+        // (an int column's file bytes travel instead of what a worker would have made of them -- at most nine per value; the
+        // int64 values they become, the buckets' values and record ranges and the ranks of the zeros exist behind the slab's
+        // device twin only)
         if (gpu_varint) {
-            per_block += n_int_cols * ((size_t)65536 * 9 + 4096);
+            per_block += n_int_cols * ((size_t)65536 + 4096);
             pool.scratch_bytes = align16(n_int_cols * ((size_t)65536 * 8 + (size_t)kGobMaxBins * 72 + 4096));
         }
         pool.slab_bytes = align16(per_block);
@@ -1348,7 +1350,9 @@ static int load_blocks_once(Ctx *ctx, Table *t, const std::string &tdir, const s
     const size_t n_status = gpu_varint ? n_names * n_int_cols : 0;
     if (n_status > 0) {
         SYBL_HIP(hipMalloc((void **)&status.d, n_status * kGobStateWords * 8));
-        SYBL_HIP(hipMemset(status.d, 0, n_status * kGobStateWords * 8));
+        // (the load's streams do not wait for the null stream: the zeros are there before the first walk is queued)
+        SYBL_HIP(hipMemsetAsync(status.d, 0, n_status * kGobStateWords * 8, ctx->stream));
+        SYBL_HIP(hipStreamSynchronize(ctx->stream));
         batch.d_state = status.d;
     }
     // SYBL_LOADER_TRACE=1: where the calling thread's time goes (stderr)
@@ -1713,7 +1717,7 @@ const char *sybl_debug_block_layout(const char *block_dir, const char *const *co
     size_t xcap = 0;
     if (gpu_varint)
         for (auto &sp : specs)
-            if (sp.type == SYBL_INT_VAL) cap += (size_t)65536 * 9 + 4096, xcap += (size_t)65536 * 8 + (size_t)kGobMaxBins * 72 + 4096;
+            if (sp.type == SYBL_INT_VAL) cap += (size_t)65536 + 4096, xcap += (size_t)65536 * 8 + (size_t)kGobMaxBins * 72 + 4096;
     std::vector<char> slab(cap);
     PreparedBlock pb;
     try {

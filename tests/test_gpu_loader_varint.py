@@ -1,4 +1,4 @@
-"""GPU: SYBL_LOADER_GPU_VARINT=1 -- the varint walk of an int column's `Values` slice on the GPU (csrc/gobgpu.hip) against the
+"""GPU: the loader's default since round 6 (SYBL_LOADER_GPU_VARINT=0 turns it off) -- the varint walk of an int column's `Values` slice on the GPU (csrc/gobgpu.hip) against the
 host parser (gob.cpp) on the same files: unpackIntCol, src/lib/column_store_io.go:690-780, reads them through encoding/gob
 (decodeUint / decodeInt).  The two loads must produce the same resident columns, the same verdict on damaged blocks and the
 same query results; a walk that meets anything it was not told to expect (values outside the block's info.db bounds, a short
@@ -23,11 +23,10 @@ def ctx():
 
 
 def _open_both(ctx, monkeypatch, root, table, **kw):
-    monkeypatch.delenv("SYBL_LOADER_GPU_VARINT", raising=False)
+    monkeypatch.setenv("SYBL_LOADER_GPU_VARINT", "0")
     host = ctx.open_table(root, table, **kw)
-    monkeypatch.setenv("SYBL_LOADER_GPU_VARINT", "1")
+    monkeypatch.delenv("SYBL_LOADER_GPU_VARINT", raising=False)   # (the default: on)
     gpu = ctx.open_table(root, table, **kw)
-    monkeypatch.delenv("SYBL_LOADER_GPU_VARINT", raising=False)
     return host, gpu
 
 
@@ -235,13 +234,13 @@ def test_refresh_loads_new_blocks_through_the_same_path(ctx, tmp_path, monkeypat
     blocks = [block(b) for b in range(3)]
     root = str(tmp_path / "db")
     F.write_table(root, "events", blocks[:2], threshold=100)
-    monkeypatch.setenv("SYBL_LOADER_GPU_VARINT", "1")
+    monkeypatch.delenv("SYBL_LOADER_GPU_VARINT", raising=False)
     tb = ctx.open_table(root, "events")
     assert tb.load_stats()["gpu_varint_cols"] == 4
     F.write_table(root, "events", blocks, threshold=100)
     tb.refresh()
     assert tb.load_stats()["gpu_varint_cols"] >= 1
-    monkeypatch.delenv("SYBL_LOADER_GPU_VARINT")
+    monkeypatch.setenv("SYBL_LOADER_GPU_VARINT", "0")
     ref = ctx.open_table(root, "events")
     q = dict(groups=["k"], aggs=["t"], op="hist")
     assert _summary(tb, **q) == _summary(ref, **q)

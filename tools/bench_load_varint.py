@@ -35,10 +35,7 @@ def main():
         ref = None
         for i in range(2 * args.opens):
             gpu = i >= args.opens   # (not alternating: the staging arena is rebuilt when the slab size changes)
-            if gpu:
-                os.environ["SYBL_LOADER_GPU_VARINT"] = "1"
-            else:
-                os.environ.pop("SYBL_LOADER_GPU_VARINT", None)
+            os.environ["SYBL_LOADER_GPU_VARINT"] = "1" if gpu else "0"
             time.sleep(0.3)
             t0 = time.perf_counter()
             tb = ctx.open_table(root, "loadbench", compact=True)

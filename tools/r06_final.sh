@@ -18,7 +18,7 @@ python - <<'Q'
 import json
 try:
     d=json.loads([l for l in open('gpurun_out/r06_final_bench.json') if l.startswith('{')][-1])
-    print('bench', d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['kernel_ms'], 'cpu', d['cpu_baseline']['value'], 'load', d.get('load',{}).get('rows_per_s'), 'loaded scan', d.get('loaded_table_scan',{}).get('kernel_ms'))
+    print('bench', d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['kernel_ms'], 'cpu', d['cpu_baseline']['value'], 'load', d.get('load',{}).get('rows_per_s'), d.get('load',{}).get('stage_breakdown',{}).get('parse_cpu_s'), 'host parser', (d.get('load',{}).get('host_parser') or {}).get('rows_per_s'), 'loaded scan', d.get('loaded_table_scan',{}).get('kernel_ms'))
     for c in d.get('configs',[]): print('  ', c.get('config',{}).get('workload'), c.get('ms_per_step'), c.get('roofline',{}).get('kernel_ms'), c.get('config',{}).get('host_ms_per_step'), c.get('every_row_summarised',{}).get('ms_per_step'), c.get('back_to_back_scan_ms'), c.get('error'))
 except Exception as e: print('bench parse failed', e)
 Q
@@ -49,6 +49,7 @@ rm -rf $O/selh_pmc
 rm -rf $O/pdkt
 { echo "# tools/micro/ldsrate (MI355X, $(date -u +%Y-%m-%dT%H:%MZ)): LDS atomic issue rates per CU with k_scan_packed's low-cardinality table layout"; timeout -k 10 120 tools/micro/ldsrate; } > $O/r06_ldsrate.txt 2>&1
 { echo "# tools/cold_cli_phases.py (MI355X, $(date -u +%Y-%m-%dT%H:%MZ)): sybil-gpu-query -stats on the saved 104.9 M-row, 7-column table, a fresh process each; the last line: the process without a table"; SYBL_LOADER_TRACE=1 timeout -k 10 300 python tools/cold_cli_phases.py; } > $O/r06_cold_cli_phases.txt 2>&1
+{ echo "# tools/bench_load_varint.py (MI355X, $(date -u +%Y-%m-%dT%H:%MZ)): the bench's saved table opened four times by the host parser (SYBL_LOADER_GPU_VARINT=0), then four times with the int columns' varints walked on the GPU (the default)"; timeout -k 10 300 python tools/bench_load_varint.py; } > $O/r06_gpu_varint_ab.txt 2>&1
 { echo "# tools/micro/loadpat_cfg2 (MI355X, $(date -u +%Y-%m-%dT%H:%MZ))"; timeout -k 10 120 tools/micro/loadpat_cfg2; } > $O/r06_loadpat_cfg2.txt 2>&1
 { echo "# tools/bench_dictkey.py (MI355X, $(date -u +%Y-%m-%dT%H:%MZ))"; timeout -k 10 300 python tools/bench_dictkey.py; } > $O/r06_dictkey.txt 2>&1
 { echo "# tools/clock_scan.py cfg4 25 3 (MI355X, $(date -u +%Y-%m-%dT%H:%MZ)): config 4's scan kernels back to back for 25 s after 3 s of idle"; timeout -k 10 200 python tools/clock_scan.py cfg4 25 3; } > $O/r06_cfg4_clock_power_temp_scan.txt 2>&1
