@@ -288,6 +288,8 @@ struct Decoder {
     DecodeOpts opts;
     bool stop = false;                      // DecodeOpts::raw_values was found: unwind
     const std::string *cur_field = nullptr; // name of the top-level struct's field being decoded
+    bool cur_ends_plain = false;            // ... and what may follow it is at most ONE more field, `tail_delta` further on, of an
+    int64_t cur_tail_delta = 0;             // integer type: [0] or [tail_delta][value][0] is then all the struct can end with
 
     bool fail(const std::string &m) {
         *err = "gob: " + m;
@@ -435,7 +437,17 @@ struct Decoder {
                 f += (int64_t)d;
                 if (f < 0 || f >= (int64_t)td.fields.size()) return fail("struct field index out of range in " + td.name);
                 ValuePtr v = std::make_shared<Value>();
-                if (depth == 0) cur_field = &td.fields[(size_t)f].first;
+                if (depth == 0) {
+                    cur_field = &td.fields[(size_t)f].first;
+                    // (DecodeOpts::raw_*: the caller will hold what stands behind the slice against "[0] or [d][int][0]" -- that is
+                    // only what THIS reader would accept there if every later field is an integer and the last one is d further on)
+                    // (the field right behind a `Bins` slice -- `Values` -- may be anything: the bucket parser sends a file in which it
+                    // shows up to the host parser)
+                    cur_ends_plain = true;
+                    const bool is_bins = *cur_field == "Bins";
+                    for (size_t k = (size_t)f + (is_bins ? 2 : 1); k < td.fields.size(); k++) cur_ends_plain = cur_ends_plain && is_int_kind(td.fields[k].second);
+                    cur_tail_delta = (int64_t)td.fields.size() - 1 - f;
+                }
                 if (!value(r, td.fields[(size_t)f].second, *v, depth + 1)) return false;
                 out.fields.emplace_back(td.fields[(size_t)f].first, v);
                 if (stop) return true;
@@ -448,7 +460,7 @@ struct Decoder {
             if (n > r.left()) return fail("slice longer than the message");
             if (is_int_kind(td.elem)) {
                 out.kind = Value::kIntVec;
-                if (opts.raw_values && depth == 1 && td.elem == tInt && cur_field && *cur_field == "Values") {
+                if (opts.raw_values && depth == 1 && td.elem == tInt && cur_field && *cur_field == "Values" && cur_ends_plain && cur_tail_delta == 1) {
                     opts.raw_values->p = r.p;
                     opts.raw_values->end = r.end;
                     opts.raw_values->n = n;
@@ -493,7 +505,8 @@ struct Decoder {
                 }
                 if (fv >= 0 && fr >= 0) {
                     out.kind = Value::kBinVec;
-                    if (opts.raw_bins && depth == 1 && fv == 0 && fr == 1 && vs && !rs && cur_field && *cur_field == "Bins") {
+                    if (opts.raw_bins && depth == 1 && fv == 0 && fr == 1 && vs && !rs && cur_field && *cur_field == "Bins" && cur_ends_plain &&
+                        cur_tail_delta == 2) {
                         opts.raw_bins->p = r.p;
                         opts.raw_bins->end = r.end;
                         opts.raw_bins->n = n;

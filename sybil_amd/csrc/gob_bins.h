@@ -122,6 +122,12 @@ __device__ __forceinline__ void gob_bins_body(const GobBinsJob &J) {
             if (in_use && (S[e] < 2 || (unsigned long long)(Z[e] - S[e]) + 1ull != tok[S[e] - 2])) bad |= kGobBadBins;
             continue;
         }
+        if (k == n_bins) {
+            // behind the last bucket the struct ends: [0], or [2][VERSION][0] (SavedIntColumn's field behind Bins and the -- empty
+            // -- Values), and with it the region; anything else the host parser shall look at
+            const uint32_t len = Z[e] - S[e];
+            if (Z[e] + 1u != n_tok || !(len == 0 || (len == 2 && tok[S[e]] == 2ull))) bad |= kGobBadBins;
+        }
         if (k < n_bins) {
             if (!fine[e]) bad |= kGobBadBins;
             const unsigned long long u = hdr[e] == 4 ? tok[S[e] + 1] : 0ull;
@@ -154,7 +160,7 @@ __device__ __forceinline__ void gob_bins_body(const GobBinsJob &J) {
         unsigned long long all = 0;
         for (int q = 0; q < 16; q++) all += wave_recs[q];
         J.state[kGobStateRecs] = all;
-        if (found < n_bins || all != (unsigned long long)J.n_recs) bad |= kGobBadBins;
+        if (found < n_bins + 1u || all != (unsigned long long)J.n_recs) bad |= kGobBadBins;  // (+ 1: the piece the struct ends with)
     }
     if (lane == 0 && bad) atomicOr(&J.state[kGobStateFlags], (unsigned long long)bad);
 }

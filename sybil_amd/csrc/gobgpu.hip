@@ -241,6 +241,11 @@ __global__ __launch_bounds__(kGobWgThreads) void k_gob_values(const GobValuesBat
                 if (zk < n_zpos) zpos[zk] = k;
                 zk++;
             }
+        } else if (!want_zeros && k < want + 3u && p < valid) {
+            // what stands behind the slice (loader.cpp holds it against a struct's end): values like the others
+            if (b >= 128u && b < 0xF8u) bad |= kGobBadByte;
+            if (p + nb >= valid) bad |= kGobTruncated;
+            state[kGobStateTail + (k - want)] = u + 1ull;
         }
         k++;
     }

@@ -1458,7 +1458,12 @@ static int load_blocks_once(Ctx *ctx, Table *t, const std::string &tdir, const s
             const GobCheck &ck = batch.checks[k];
             const unsigned long long *g = &got[(size_t)kGobStateWords * k];
             // (`Values`: every announced value found; `Bins`: n = 0 -- k_gob_bins has held the buckets against what was announced)
-            if (g[kGobStateFlags] == 0 && g[kGobStateFound] >= (unsigned long long)ck.n) continue;
+            // `Values`: behind the n-th value the struct ends -- [0], or [1][VERSION][0] (SavedIntColumn's last field) -- and with
+            // it the region: what the host parser would have read there
+            const unsigned long long *tl = g + kGobStateTail;
+            const bool ends = ck.n == 0 || (g[kGobStateFound] == (unsigned long long)ck.n + 1 && tl[0] == 1) ||
+                              (g[kGobStateFound] == (unsigned long long)ck.n + 3 && tl[0] == 2 && tl[2] == 1);
+            if (g[kGobStateFlags] == 0 && ends) continue;
             if (trace)
                 fprintf(stderr, "loader: gpu varint walk of block %s column %zu: flags 0x%llx, found %llu of %lld values, %llu zeros, %llu records\n",
                         names[ck.name_ix].c_str(), ck.col, (unsigned long long)g[kGobStateFlags], (unsigned long long)g[kGobStateFound], (long long)ck.n,

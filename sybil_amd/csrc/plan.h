@@ -237,8 +237,9 @@ constexpr int kGobWgBytes = kGobWgThreads * 64;
 constexpr int kGobMaxWgs = 64;                           // per file (the look-back is one wave wide): 1 MB of values
 // a job's state words (zeroed before the launch): flags | values found | zero values found | records in the bins (k_gob_bins) |
 // the workgroups' exit maps | their value counts
-constexpr int kGobStateFlags = 0, kGobStateFound = 1, kGobStateZeros = 2, kGobStateRecs = 3, kGobStateMaps = 4, kGobStateCounts = 4 + kGobMaxWgs,
-              kGobStateWords = 4 + 2 * kGobMaxWgs;
+// (Tail: `Values` -- the three values behind the announced ones, each + 1, 0 = there is none: what the struct ends with)
+constexpr int kGobStateFlags = 0, kGobStateFound = 1, kGobStateZeros = 2, kGobStateRecs = 3, kGobStateTail = 4, kGobStateMaps = 8,
+              kGobStateCounts = 8 + kGobMaxWgs, kGobStateWords = 8 + 2 * kGobMaxWgs;
 struct GobValuesJob {
     const uint8_t *bytes;        // device, 16-byte aligned: the first value of the file's slice (behind its count) ...
     uint32_t n_bytes, n;         // ... to the end of the file's value message; how many values to take from it at most

@@ -346,3 +346,76 @@ def test_damaged_buckets_get_the_host_parsers_verdict(ctx, tmp_path, monkeypatch
     assert _summary(gpu, **q) == _summary(host, **q)
     gpu.free()
     host.free()
+
+
+def _mutate(rng, data, lo):
+    """One random piece of damage at or behind byte `lo`: a flipped byte, a run overwritten, a cut, bytes inserted or removed."""
+    data = bytearray(data)
+    kind = rng.integers(0, 6)
+    at = int(rng.integers(lo, len(data)))
+    if kind == 0:
+        data[at] ^= 1 << int(rng.integers(0, 8))
+    elif kind == 1:
+        data[at] = int(rng.integers(0, 256))
+    elif kind == 2:
+        n = int(rng.integers(1, 9))
+        data[at:at + n] = bytes(rng.integers(0, 256, size=min(n, len(data) - at), dtype=np.uint8))
+    elif kind == 3:
+        del data[at:]
+    elif kind == 4:
+        data[at:at] = bytes(rng.integers(0, 256, size=int(rng.integers(1, 5)), dtype=np.uint8))
+    else:
+        del data[at:at + int(rng.integers(1, 5))]
+    return bytes(data), "%s at %d" % (["bit flip", "byte", "run", "cut", "insert", "remove"][kind], at)
+
+
+# (SYBL_FUZZ_SEEDS=n: n more seeds -- profiles/r06_gpu_varint_fuzz.txt is such a run)
+@pytest.mark.parametrize("seed", [1, 2, 3] + list(range(100, 100 + int(os.environ.get("SYBL_FUZZ_SEEDS", "0")))))
+def test_damaged_files_load_like_the_host_parser_loads_them(ctx, tmp_path, monkeypatch, seed):
+    """Fuzz: 120 blocks, each with one value-encoded and one bucket-encoded column file damaged somewhere behind its type
+    definitions (the same damage for both loads), beside an intact column that names the block.  Whatever the host parser
+    makes of a block -- skipped, the column empty, the column loaded with other values -- the default load must end up with
+    exactly the same rows per block: the walk's checks send everything it is not sure of back through the host parser."""
+    rng = np.random.default_rng(seed)
+    root = str(tmp_path / "db")
+    tdir = os.path.join(root, "events")
+    os.makedirs(tdir)
+    n_blocks, what = 120, {}
+    for b in range(n_blocks):
+        n = int(rng.integers(1, 3000))
+        vals = np.cumsum(rng.integers(-50, 60, size=n)).astype(np.int64) if rng.random() < 0.7 else _values_of_every_length(rng, n) >> 16
+        few = rng.integers(0, int(rng.integers(1, 40)), size=n).astype(np.int64) * 7 - 20
+        fv = F.int_column("v", vals, None, 0)            # value encoded
+        fb = _bucket_file("b", few, delta=bool(rng.integers(0, 2)))
+        blk = _bucket_file("blk", np.full(n, b))
+        # (the first 60 bytes or so are the type definitions and the struct's first fields: damage there never reaches the walk)
+        if b % 10 != 0:
+            fv, w1 = _mutate(rng, fv, int(rng.integers(0, len(fv) - 1)) if rng.random() < 0.15 else max(len(fv) - int(rng.integers(1, 3 * n + 40)), 0))
+            fb, w2 = _mutate(rng, fb, int(rng.integers(0, len(fb) - 1)) if rng.random() < 0.15 else max(len(fb) - int(rng.integers(1, 2 * n + 60)), 0))
+            what[b] = (w1, w2)
+        _write_block(tdir, b + 1, {"v": fv, "b": fb, "blk": blk}, n, {"v": _info(vals), "b": _info(few), "blk": _info(np.full(n, b))})
+    _table_info(tdir, "events", ["v", "b", "blk"], -(1 << 62), 1 << 62)
+    host, gpu = _open_both(ctx, monkeypatch, root, "events")
+    st = gpu.load_stats()
+    assert st["gpu_varint_cols"] > n_blocks and st["gpu_varint_redone"] > 0, st
+    assert gpu.rows == host.rows and gpu.broken_blocks == host.broken_blocks, (gpu.rows, host.rows, gpu.broken_blocks, host.broken_blocks)
+
+    def per_block(tb):
+        out = {}
+        for col in ("v", "b"):
+            query = tb.query(groups=["blk"], aggs=[col], op="hist")
+            r = query.run()
+            for x in r.results:
+                h = x["hists"][0]
+                # (an aggregation no row of the group has a value for is absent from the output: its other fields mean nothing)
+                out[(int(x["group_by_key"]), col)] = (x["count"], h["present"]) + ((h["count"], h["sum"], h["min"], h["max"]) if h["present"] else ())
+            r.free()
+            query.free()
+        return out
+
+    a, b = per_block(host), per_block(gpu)
+    diff = {k: (a.get(k), b.get(k), what.get(k[0])) for k in set(a) | set(b) if a.get(k) != b.get(k)}
+    assert not diff, dict(list(diff.items())[:5])
+    # (no comparison of the stored columns here: what a row WITHOUT a value holds is nobody's business, and damaged buckets leave such rows)
+    gpu.free()
+    host.free()
