@@ -153,7 +153,8 @@ def test_damaged_blocks_under_the_sanitizers(table, tmp_path):
     trial (bytes overwritten / inserted / removed, the tail cut off, a huge length planted, the file removed) into a heap slab
     of exactly a worker's size -- now and then one that is too small --, built with AddressSanitizer and
     UndefinedBehaviorSanitizer: a write past the slab, a read past a decoded array or undefined arithmetic on a hostile
-    length ends the run.  Both forms of the pass (column by column, and SYBL_LOADER_TWO_PASS=1)."""
+    length ends the run.  Both forms of the pass (column by column, and SYBL_LOADER_TWO_PASS=1), and the worker half of the default
+    load (SYBL_LOADER_GPU_VARINT=1: slices located and copied as file bytes instead of decoded)."""
     root, _ = table
     exe = str(tmp_path / "loader_block_fuzz")
     b = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-std=c++17", "-x", "hip",
@@ -163,7 +164,8 @@ def test_damaged_blocks_under_the_sanitizers(table, tmp_path):
     assert b.returncode == 0, b.stderr[-3000:]
     specs = ["%s:%d" % (n, TYPES[t]) for n, t in COLS]
     env = dict(os.environ, ASAN_OPTIONS="allocator_may_return_null=1:detect_leaks=0")
-    for block, trials, extra in ((3, 1200, {}), (4, 250, {}), (3, 500, {"SYBL_LOADER_TWO_PASS": "1"})):
+    for block, trials, extra in ((3, 1200, {}), (4, 250, {}), (3, 500, {"SYBL_LOADER_TWO_PASS": "1"}), (3, 1200, {"SYBL_LOADER_GPU_VARINT": "1"}),
+                                 (4, 250, {"SYBL_LOADER_GPU_VARINT": "1"})):
         r = subprocess.run([exe, os.path.join(root, "t", "block%09d" % block), str(tmp_path / ("scratch%d" % block)), str(trials)] + specs,
                            env=dict(env, **extra), capture_output=True, text=True, timeout=900)
         assert r.returncode == 0 and "laid out" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])

@@ -6,7 +6,7 @@
 //   hipcc --offload-arch=gfx950 -O1 -g -fsanitize=address,undefined -std=c++17 -x hip loader_block_fuzz.cpp -o loader_block_fuzz \
 //         -I../../sybil_amd/csrc -I../../include -L../../sybil_amd -lsybilgpu -Wl,-rpath,$PWD/../../sybil_amd -Wl,-rpath,/opt/rocm/lib
 //   ./loader_block_fuzz <block dir> <scratch dir> <trials> name:type ...        (type: 1 int, 2 str, 3 set)
-// SYBL_LOADER_TWO_PASS=1: the two-pass form of every block.
+// SYBL_LOADER_TWO_PASS=1: the two-pass form of every block.  SYBL_LOADER_GPU_VARINT=1: the worker half of the default load.
 #include "../../sybil_amd/csrc/loader.cpp"
 
 #include <dirent.h>
@@ -59,6 +59,13 @@ int main(int argc, char **argv) {
     // (the slab a worker gets: load_blocks' per-column bound, as sybl_debug_block_layout computes it)
     size_t cap = 65536;
     for (auto &sp : specs) cap += sp.type == SYBL_SET_VAL ? 0 : (size_t)65536 * (sp.type == SYBL_STR_VAL ? 12 : 8) + ((size_t)96 << 10);
+    // SYBL_LOADER_GPU_VARINT=1: the worker half of the default load -- the int columns' slices located, their file bytes copied
+    // into the slab (what the GPU then makes of them is tests/test_gpu_loader_varint.py's fuzzer's business)
+    size_t xcap = 0;
+    if (const char *e = getenv("SYBL_LOADER_GPU_VARINT"))
+        if (atoi(e) != 0)
+            for (auto &sp : specs)
+                if (sp.type == SYBL_INT_VAL) cap += (size_t)65536 + 4096, xcap += (size_t)65536 * 8 + (size_t)kGobMaxBins * 72 + 4096;
     std::mt19937_64 rng(777);
     long ok = 0, broken = 0, unreadable = 0, thrown = 0, small_slab = 0;
     for (int t = 0; t <= trials; t++) {
@@ -94,7 +101,7 @@ int main(int argc, char **argv) {
         small_slab += this_cap != cap;
         std::unique_ptr<char[]> slab(new char[this_cap ? this_cap : 1]);
         try {
-            PreparedBlock pb = prepare_block_unguarded(dst, specs, slab.get(), this_cap, -1);
+            PreparedBlock pb = prepare_block_unguarded(dst, specs, slab.get(), this_cap, -1, true, xcap);
             if (pb.unreadable) unreadable++;
             else if (pb.broken) broken++;
             else ok++;
