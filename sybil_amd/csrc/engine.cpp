@@ -74,6 +74,10 @@ int hip_fail(hipError_t e, const char *what) {
 }
 
 int load_sync_all(Ctx *ctx) {
+    if (ctx->load_flush) {  // (launches the load still holds back: loader.cpp)
+        int rc = ctx->load_flush();
+        if (rc) return rc;
+    }
     if (!ctx->load_multi) return SYBL_OK;
     for (int i = 0; i < ctx->n_load_streams; i++) SYBL_HIP(hipStreamSynchronize(ctx->load_streams[i]));
     return SYBL_OK;

@@ -5,6 +5,7 @@
 
 #include <map>
 #include <atomic>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -95,6 +96,9 @@ struct Ctx {
     hipStream_t load_streams[kMaxLoadStreams] = {};
     int n_load_streams = 0;
     bool load_multi = false;
+    // a load in progress keeps the decode launches of a few consecutive blocks back to issue them together: whoever is about to
+    // wait for the load's streams (load_sync_all -- a column about to be reallocated, a widening repack) has them issued first
+    std::function<int()> load_flush;
     // the loader's staging arena (loader.cpp: SlabPool), kept between loads: pinning and unpinning a few hundred MB cost
     // every sybl_table_open / sybl_table_refresh tens of milliseconds.  Freed by sybl_shutdown (SYBL_LOADER_KEEP_ARENA=0:
     // by the load that allocated it).

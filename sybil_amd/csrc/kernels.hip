@@ -531,9 +531,9 @@ __global__ __launch_bounds__(256) void k_decode_bins_multi(const DecodeBinsBatch
     __shared__ uint32_t wave_tot[4];
     const DecodeBinsJob &J = B.job[blockIdx.y];
     if ((int32_t)blockIdx.x >= J.n_bins) return;
-    if (J.rec_w == 2) decode_bins_job<uint16_t>(J, B.nrows, blockIdx.x, wave_tot);
-    else if (J.rec_w == 8) decode_bins_job<unsigned long long>(J, B.nrows, blockIdx.x, wave_tot);
-    else decode_bins_job<uint32_t>(J, B.nrows, blockIdx.x, wave_tot);
+    if (J.rec_w == 2) decode_bins_job<uint16_t>(J, J.nrows, blockIdx.x, wave_tot);
+    else if (J.rec_w == 8) decode_bins_job<unsigned long long>(J, J.nrows, blockIdx.x, wave_tot);
+    else decode_bins_job<uint32_t>(J, J.nrows, blockIdx.x, wave_tot);
 }
 
 // Value-encoded int column: Values[r] is a delta from Values[r-1] (column_store_io.go:109-113,748-777).

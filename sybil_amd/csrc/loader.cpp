@@ -974,10 +974,14 @@ struct DecodeBatches {
     unsigned long long *d_state = nullptr;    // [kGobStateWords] per walk of the load, zeroed
     std::vector<GobCheck> checks;
     size_t name_ix = 0, col_ix = 0;  // the block / column being applied
-    void begin(uint32_t nrows) {
-        bins.n = deltas.n = gobs.n = gbins.n = 0;
-        bins.nrows = nrows;
+    uint32_t nrows = 0;  // of the block being applied
+    void begin() { bins.n = deltas.n = gobs.n = gbins.n = 0; }
+    // another block's worth of jobs fits every batch
+    bool room_for(size_t n_cols) const {
+        return (size_t)bins.n + n_cols <= (size_t)kDecodeBatchMax && (size_t)deltas.n + n_cols <= (size_t)kDecodeBatchMax &&
+               (size_t)gobs.n + n_cols <= (size_t)kGobBatchMax;
     }
+    bool empty() const { return bins.n == 0 && deltas.n == 0 && gobs.n == 0 && gbins.n == 0; }
     int flush_gobs(hipStream_t st) {
         hipError_t e = launch_gob_values(gobs, st);
         gobs.n = 0;
@@ -1084,6 +1088,7 @@ static int apply_col(BlockWriter &w, Column *c, PreparedCol &pc, const char *H, 
             J.out_w = (uint8_t)(direct ? c->elem : c->canon());
             J.delta = pc.delta ? 1 : 0;
             J.pad = 0;
+            J.nrows = (uint32_t)w.nrows;
             if (!batch.on && (rc = batch.flush_bins(st))) return rc;
         } else {
             hipError_t e = launch_decode_bins(D + pc.rec_at, pc.rec_w, (const int64_t *)(D + pc.binoff_at), (const int64_t *)(D + pc.binval_at),
@@ -1369,6 +1374,32 @@ static int load_blocks_once(Ctx *ctx, Table *t, const std::string &tdir, const s
         decltype(drain) &d;
         ~DrainGuard() { d(); }
     } drain_guard{drain};
+    // Consecutive blocks share a stream and their decode launches: the columns of up to kGroupBlocks blocks (as many as the job
+    // tables hold) go into ONE walk, ONE delta + bucket and ONE bins launch -- a block's chain of copy -> walk -> delta -> bins
+    // is ~90 us of mostly latency whatever it carries, the load's sixteen streams share a handful of hardware queues, and the
+    // calling thread pays every launch.  SYBL_LOADER_GROUP=1: a launch set per block, as before.  A block that needs its
+    // kernels issued before its commit (columns staged for a repack, a serial block, a slab of its own) ends its group.
+    size_t kGroupBlocks = 4;
+    if (const char *e = env("SYBL_LOADER_GROUP")) kGroupBlocks = (size_t)std::max(1, atoi(e));
+    struct Group {
+        hipStream_t st = nullptr;
+        std::vector<int> slabs;
+        size_t blocks = 0;
+    } group;
+    auto flush_group = [&]() -> int {
+        int frc = SYBL_OK;
+        if (!batch.empty()) frc = batch.flush(group.st);
+        for (int sl : group.slabs) pool.release_after(sl, group.st);  // (behind the kernels that read them)
+        group.slabs.clear();
+        group.blocks = 0;
+        return frc;
+    };
+    // (whoever waits for the load's streams -- a column about to grow, a widening repack -- has the held launches issued first)
+    struct FlushHook {
+        Ctx *ctx;
+        ~FlushHook() { ctx->load_flush = nullptr; }
+    } flush_hook{ctx};
+    ctx->load_flush = flush_group;
     if ((rc = submit())) return (rc);
     while (!inflight.empty()) {
         auto tw = std::chrono::steady_clock::now();
@@ -1383,7 +1414,11 @@ static int load_blocks_once(Ctx *ctx, Table *t, const std::string &tdir, const s
             ~Apply() { *acc += seconds_since(t0); }
         } apply{std::chrono::steady_clock::now(), &apply_s};
         auto fail_out = [&](int code) {
-            if (pb.own_h) (void)hipHostFree(pb.own_h);
+            (void)flush_group();  // (blocks committed earlier in the group keep their decode)
+            if (pb.own_h) {
+                (void)hipStreamSynchronize(ctx->stream);
+                (void)hipHostFree(pb.own_h);
+            }
             if (pb.own_d) (void)hipFree(pb.own_d);
             drain();
             return code;
@@ -1396,7 +1431,11 @@ static int load_blocks_once(Ctx *ctx, Table *t, const std::string &tdir, const s
             continue;
         }
         char *H = pb.own_h ? pb.own_h : pool.slabs[(size_t)slab].h, *D = pb.own_h ? pb.own_d : pool.slabs[(size_t)slab].d;
-        if (ctx->load_multi) ctx->stream = ctx->load_streams[block_no++ % ctx->n_load_streams];
+        if (group.blocks == 0) {
+            group.st = ctx->load_multi ? ctx->load_streams[block_no++ % ctx->n_load_streams] : ctx->stream;
+            batch.begin();
+        }
+        ctx->stream = group.st;
         auto tl = std::chrono::steady_clock::now();
         apply_dictionaries(t, pb, H, luts);
         lap(0, tl);
@@ -1408,7 +1447,7 @@ static int load_blocks_once(Ctx *ctx, Table *t, const std::string &tdir, const s
         lap(1, tl);
         BlockWriter w;
         if ((rc = block_begin(t, pb.nrows, &w))) return fail_out(rc);
-        batch.begin((uint32_t)pb.nrows);
+        batch.nrows = (uint32_t)pb.nrows;
         batch.scratch = D + pb.scratch_at;
         batch.name_ix = name_ix;
         const size_t checks0 = batch.checks.size();
@@ -1416,7 +1455,9 @@ static int load_blocks_once(Ctx *ctx, Table *t, const std::string &tdir, const s
             batch.col_ix = ci;
             if ((rc = apply_col(w, t->cols[ci].get(), pb.cols[ci], H, D, luts[ci].size(), batch))) return fail_out(rc);
         }
-        if ((rc = batch.flush(ctx->stream))) return fail_out(rc);
+        // (a commit that packs staged columns or drains the stream reads what the decode kernels wrote: they go first)
+        const bool ends_group = !w.staged.empty() || w.serial || pb.own_h != nullptr || !batch.on;
+        if (ends_group && (rc = batch.flush(group.st))) return fail_out(rc);
         lap(2, tl);
         if ((rc = block_commit(w))) return fail_out(rc);
         for (size_t k = checks0; k < batch.checks.size(); k++) batch.checks[k].block = (int64_t)t->blocks.size() - 1;
@@ -1430,11 +1471,19 @@ static int load_blocks_once(Ctx *ctx, Table *t, const std::string &tdir, const s
             pb.own_h = pb.own_d = nullptr;
             pool.give_back(slab);
         } else {
-            pool.release_after(slab, ctx->stream);
+            group.slabs.push_back(slab);
+        }
+        group.blocks++;
+        // (the queue running dry also ends a group: nothing is gained by holding launches back while the workers are behind)
+        if (ends_group || group.blocks >= kGroupBlocks || !batch.room_for(t->cols.size()) || inflight.empty() ||
+            inflight.front().fut.wait_for(std::chrono::seconds(0)) != std::future_status::ready) {
+            if ((rc = flush_group())) return fail_out(rc);
         }
         if ((rc = submit())) return fail_out(rc);
         lap(4, tl);
     }
+    if ((rc = flush_group())) return rc;
+    ctx->load_flush = nullptr;
     if (trace) {
         int64_t thr_n1, thr_us1;
         cgroup_throttle(&thr_n1, &thr_us1);

@@ -288,13 +288,13 @@ struct DecodeBinsJob {
     int64_t vbase;
     int32_t n_bins;
     uint8_t rec_w, out_w, delta, pad;
+    uint32_t nrows, pad2_;  // of the job's block (a launch may hold the columns of several blocks)
     // rec_w == 8 (the GPU varint walk's columns): recs are the walk's 64-bit values and bin_off holds a [first, one-past-last)
     // pair per bucket (GobBinsJob::bin_rng); kGobOutOfBounds is set in *chk_flags for a record id that is no row of the block
     unsigned long long *chk_flags;
 };
 struct DecodeBinsBatch {
     DecodeBinsJob job[kDecodeBatchMax];
-    uint32_t nrows;
     int32_t n;
 };
 struct DecodeDeltaJob {

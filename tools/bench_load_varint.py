@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--rows", type=int, default=100 * 1024 * 1024 // 65536 * 65536)
     ap.add_argument("--opens", type=int, default=4)
     ap.add_argument("--workload", default="cfg3_filter3_group2_stddev")
+    ap.add_argument("--groups", default="", help="e.g. 1,2,4: also time the default path with SYBL_LOADER_GROUP set to each, interleaved")
     args = ap.parse_args()
     import sybil_amd
     from sybil_amd import synth
@@ -54,6 +55,23 @@ def main():
                 best[gpu] = (dt, st)
             tb.free()
         os.environ.pop("SYBL_LOADER_GPU_VARINT", None)
+        if args.groups:
+            # blocks per launch set (SYBL_LOADER_GROUP), interleaved in one process: the default path only
+            res = {}
+            for rnd in range(args.opens):
+                for g in args.groups.split(","):
+                    os.environ["SYBL_LOADER_GROUP"] = g
+                    time.sleep(0.3)
+                    t0 = time.perf_counter()
+                    tb = ctx.open_table(root, "loadbench", compact=True)
+                    dt = time.perf_counter() - t0
+                    st = tb.load_stats()
+                    tb.free()
+                    res.setdefault(g, []).append((dt, st["parse_cpu_s"], st["apply_s"], st["wait_s"]))
+            os.environ.pop("SYBL_LOADER_GROUP", None)
+            for g, r in res.items():
+                print("group %-2s opens %s  best %.4f s = %.3e rows/s  (parse_cpu %.3f, apply %.3f, wait %.3f of the best)"
+                      % (g, " ".join("%.4f" % x[0] for x in r), min(r)[0], args.rows / min(r)[0], min(r)[1], min(r)[2], min(r)[3]))
         for gpu in (False, True):
             dt, st = best[gpu]
             print("best %-5s %.4f s = %.3e rows/s, parse_cpu %.3f s" % ("gpu" if gpu else "host", dt, args.rows / dt, st["parse_cpu_s"]))
