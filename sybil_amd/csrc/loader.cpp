@@ -975,6 +975,7 @@ struct DecodeBatches {
     std::vector<GobCheck> checks;
     size_t name_ix = 0, col_ix = 0;  // the block / column being applied
     uint32_t nrows = 0;  // of the block being applied
+    DecodeBatches() { begin(); }  // (a load without a block flushes, too)
     void begin() { bins.n = deltas.n = gobs.n = gbins.n = 0; }
     // another block's worth of jobs fits every batch
     bool room_for(size_t n_cols) const {

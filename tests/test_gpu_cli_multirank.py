@@ -59,7 +59,8 @@ def _one(db_root, args):
 def _world(db_root, args, world, work, tag):
     if not os.path.exists(STANDIN):
         subprocess.check_call(["make", "-s", "-C", os.path.dirname(STANDIN)])
-    env = dict(os.environ, TZ="UTC", HSA_ENABLE_IPC_MODE_LEGACY="0", LD_PRELOAD=STANDIN, SYBL_STANDIN_TIMEOUT_S="240")
+    env = dict(os.environ, TZ="UTC", HSA_ENABLE_IPC_MODE_LEGACY="0", LD_PRELOAD=STANDIN, SYBL_CLI_BACKTRACE="1",
+               SYBL_STANDIN_TIMEOUT_S=os.environ.get("SYBL_STANDIN_TIMEOUT_S", "120"))
     idf = os.path.join(work, "id_%s_%d" % (tag, world))
     procs = [subprocess.Popen([CLI, "-dir", db_root, "-table", "events"] + args + ["-gpu-rank", str(r), "-gpu-ranks", str(world), "-gpu-id-file", idf],
                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env) for r in range(world)]
@@ -71,7 +72,7 @@ def _world(db_root, args, world, work, tag):
         for p in procs:
             if p.poll() is None:
                 p.kill()
-    assert [p.returncode for p in procs] == [0] * world, b"\n".join(e for _, e in outs).decode(errors="replace")[-3000:]
+    assert [p.returncode for p in procs] == [0] * world, (tag, b"\n".join(e for _, e in outs).decode(errors="replace")[-6000:])
     return [o for o, _ in outs]
 
 

@@ -19,6 +19,8 @@
 #include <string.h>
 #include <time.h>
 #include <unistd.h>
+#include <execinfo.h>
+#include <signal.h>
 
 #include <map>
 #include <set>
@@ -63,7 +65,24 @@ static int die(const char *what) {
     return 1;
 }
 
+// SYBL_CLI_BACKTRACE=1: a crash prints where it happened (module + offset per frame) before the process dies -- the multi-rank
+// tests set it, so a rank that falls over says more than "-11"
+static void crash_trace(int sig) {
+    void *frames[64];
+    const int n = backtrace(frames, 64);
+    const char msg[] = "sybil-gpu-query: fatal signal; frames:\n";
+    (void)!write(2, msg, sizeof(msg) - 1);
+    backtrace_symbols_fd(frames, n, 2);
+    signal(sig, SIG_DFL);
+    raise(sig);
+}
+
 int main(int argc, char **argv) {
+    if (getenv("SYBL_CLI_BACKTRACE")) {
+        signal(SIGSEGV, crash_trace);
+        signal(SIGBUS, crash_trace);
+        signal(SIGABRT, crash_trace);
+    }
     // flag defaults: src/cmd/cmd_query.go:19-74, src/lib/config.go:147-176
     std::map<std::string, std::string> f = {
         {"dir", "./db/"}, {"table", ""}, {"op", "avg"}, {"limit", "100"}, {"print", "true"}, {"json", "false"},
