@@ -655,7 +655,22 @@ __global__ __launch_bounds__(kWgThreads, SYBL_PACKED_WAVES_PER_EU) void k_scan_p
 
 // k_emit over compact storage (strategy 5, see k_emit in scan_fast.h): the same records, staged and
 // flushed the same way; rows are loaded and filtered in the offset domain like k_scan_packed.
-template <int NF, int NG, int NA>
+// One column's four rows for this lane with a descriptor that ends at row n -- or holds nothing at all (`wanted` false,
+// wave-uniform): the range check then returns zeros without touching memory.  What the late paths below issue.
+__device__ __forceinline__ void packed_issue_clamped(const uint8_t *col, int width, uint32_t r, uint32_t n, bool wanted, pu32x4 &raw) {
+    const uint32_t r0 = __builtin_amdgcn_readfirstlane(r);
+    const uint32_t lane_row = r - r0;
+    const uint32_t rows = wanted && r0 < n ? (n - r0 < 64u * kPackedRows ? (n - r0 + kPackedRows - 1) & ~(uint32_t)(kPackedRows - 1) : 64u * kPackedRows) : 0u;
+    const int ws = width >> 1;
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void *)(col + ((size_t)(rows ? r0 : 0u) << ws)), 0, (int)(rows << ws), (int)kBufferRsrcWord3);
+    raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(lane_row << ws), 0, 2);
+}
+
+// LATE (round 6, a kernel of its own -- two loops in one body wreck the other's register allocation): the filter
+// columns run a tile ahead; the key and value columns of a tile are only requested when some row of the wave passed.  Chosen
+// by the planner's selectivity estimate (FastPlan::late): at 0.1 % most waves never touch them.
+template <int NF, int NG, int NA, bool LATE = false>
 __global__ __launch_bounds__(kWgThreads, 4) void k_emit_packed(const EmitPlan E) {
     extern __shared__ uint32_t elds[];
     const FastPlan &P = E.fp;
@@ -678,6 +693,68 @@ __global__ __launch_bounds__(kWgThreads, 4) void k_emit_packed(const EmitPlan E)
 #pragma unroll
             for (int c = 0; c < NA; c++) B.a[c] = (const uint8_t *)P.acol[c] + first * P.awid[c];
             B.t = nullptr;
+            if constexpr (LATE) {
+                const uint32_t n_tiles = (n + kTile - 1) / kTile;
+                const uint32_t r_first = tid * kPackedRows;
+                PackedRaw<NF> rfn;
+                PackedRaw<NG> rgl;
+                PackedRaw<NA> ral;
+#pragma unroll
+                for (int c = 0; c < NF; c++) packed_issue_clamped(B.f[c], P.fwid[c], r_first, n, true, rfn.v[c]);
+                for (uint32_t it = 0; it < n_tiles; it++) {
+                    const uint32_t r = r_first + it * kTile;
+                    uint32_t fu[NF > 0 ? NF : 1][kPackedRows];
+#pragma unroll
+                    for (int c = 0; c < NF; c++) packed_decode(P.fwid[c], rfn.v[c], fu[c]);
+#pragma unroll
+                    for (int c = 0; c < NF; c++) packed_issue_clamped(B.f[c], P.fwid[c], r + kTile, n, true, rfn.v[c]);
+                    const uint32_t left = r < n ? n - r : 0u;
+                    bool pass[kPackedRows], any = false;
+#pragma unroll
+                    for (int k = 0; k < kPackedRows; k++) {
+                        pass[k] = (uint32_t)k < left;
+#pragma unroll
+                        for (int c = 0; c < NF; c++) pass[k] = pass[k] & (fu[c][k] >= P.plo[c]) & (fu[c][k] <= P.phi[c]);
+                        any = any | pass[k];
+                        matched += pass[k] ? 1u : 0u;
+                    }
+                    if (!__builtin_amdgcn_ballot_w64(any)) continue;  // (wave-uniform: no row of these 256 passed)
+#pragma unroll
+                    for (int c = 0; c < NG; c++) packed_issue_clamped(B.g[c], P.gwid[c], r, n, true, rgl.v[c]);
+#pragma unroll
+                    for (int c = 0; c < NA; c++) packed_issue_clamped(B.a[c], P.awid[c], r, n, true, ral.v[c]);
+                    uint32_t gu[NG > 0 ? NG : 1][kPackedRows], au[NA > 0 ? NA : 1][kPackedRows];
+#pragma unroll
+                    for (int c = 0; c < NG; c++) packed_decode(P.gwid[c], rgl.v[c], gu[c]);
+#pragma unroll
+                    for (int c = 0; c < NA; c++) packed_decode(P.awid[c], ral.v[c], au[c]);
+                    uint32_t bin[kPackedRows * NA], rec[kPackedRows * NA];
+                    bool act[kPackedRows * NA];
+#pragma unroll
+                    for (int k = 0; k < kPackedRows; k++) {
+                        uint32_t cell = 0;
+                        bool inb = true;
+#pragma unroll
+                        for (int c = 0; c < NG; c++) {
+                            const uint32_t d = gu[c][k] + P.gdoff[c];
+                            inb = inb & (d < P.gcard[c]);
+                            cell += __umul24(d, (uint32_t)P.gstride[c]);
+                        }
+                        overflow += (pass[k] & !inb) ? 1u : 0u;
+#pragma unroll
+                        for (int c = 0; c < NA; c++) {
+                            const uint32_t n32 = au[c][k] + P.adoff[c];  // value - h.Min
+                            const uint32_t pair = cell * (uint32_t)NA + (uint32_t)c;
+                            const int at = k * NA + c;
+                            bin[at] = emit_bin(S, pair);
+                            rec[at] = emit_record(pair, n32);
+                            act[at] = pass[k] & inb;
+                        }
+                    }
+                    emit_push_all<kPackedRows * NA, kEmitQueue>(E, S, bin, rec, act);
+                }
+                continue;
+            }
             // D tiles of loads in flight per lane (narrow queries move few bytes per tile)
             constexpr int D = emit_depth(NF + NG + NA);
             // With one aggregation a tile is only four records per lane, and a push is a chain of ~7 dependent LDS round
@@ -754,7 +831,7 @@ __global__ __launch_bounds__(kWgThreads, 4) void k_emit_packed(const EmitPlan E)
 }
 
 // k_count over compact storage: the counting pass of k_emit_packed (see k_count in scan_fast.h).
-template <int NF, int NG>
+template <int NF, int NG, bool LATE = false>
 __global__ __launch_bounds__(kWgThreads, 4) void k_count_packed(const EmitPlan E) {
     extern __shared__ uint32_t elds[];
     const FastPlan &P = E.fp;
@@ -774,6 +851,51 @@ __global__ __launch_bounds__(kWgThreads, 4) void k_count_packed(const EmitPlan E
             for (int c = 0; c < NG; c++) B.g[c] = (const uint8_t *)P.gcol[c] + first * P.gwid[c];
             B.a[0] = nullptr;
             B.t = nullptr;
+            if constexpr (LATE) {
+                // (see k_emit_packed<.., LATE>: the same rows pass, so the regions it fills are the ones counted here)
+                const uint32_t n_tiles = (n + kPackedTileRows - 1) / kPackedTileRows;
+                const uint32_t r_first = tid * kPackedRows;
+                PackedRaw<NF> rfn;
+                PackedRaw<NG> rgl;
+#pragma unroll
+                for (int c = 0; c < NF; c++) packed_issue_clamped(B.f[c], P.fwid[c], r_first, n, true, rfn.v[c]);
+                for (uint32_t it = 0; it < n_tiles; it++) {
+                    const uint32_t r = r_first + it * kPackedTileRows;
+                    uint32_t fu[NF > 0 ? NF : 1][kPackedRows];
+#pragma unroll
+                    for (int c = 0; c < NF; c++) packed_decode(P.fwid[c], rfn.v[c], fu[c]);
+#pragma unroll
+                    for (int c = 0; c < NF; c++) packed_issue_clamped(B.f[c], P.fwid[c], r + kPackedTileRows, n, true, rfn.v[c]);
+                    const uint32_t left = r < n ? n - r : 0u;
+                    bool pass[kPackedRows], any = false;
+#pragma unroll
+                    for (int k = 0; k < kPackedRows; k++) {
+                        pass[k] = (uint32_t)k < left;
+#pragma unroll
+                        for (int c = 0; c < NF; c++) pass[k] = pass[k] & (fu[c][k] >= P.plo[c]) & (fu[c][k] <= P.phi[c]);
+                        any = any | pass[k];
+                    }
+                    if (!__builtin_amdgcn_ballot_w64(any)) continue;
+#pragma unroll
+                    for (int c = 0; c < NG; c++) packed_issue_clamped(B.g[c], P.gwid[c], r, n, true, rgl.v[c]);
+                    uint32_t gu[NG > 0 ? NG : 1][kPackedRows];
+#pragma unroll
+                    for (int c = 0; c < NG; c++) packed_decode(P.gwid[c], rgl.v[c], gu[c]);
+#pragma unroll
+                    for (int k = 0; k < kPackedRows; k++) {
+                        uint32_t cell = 0;
+                        bool ok = pass[k];
+#pragma unroll
+                        for (int c = 0; c < NG; c++) {
+                            const uint32_t d = gu[c][k] + P.gdoff[c];
+                            ok = ok & (d < P.gcard[c]);
+                            cell += __umul24(d, (uint32_t)P.gstride[c]);
+                        }
+                        if (ok) __hip_atomic_fetch_add(mine + (((cell * na) >> kPartCellBits) << ss), na, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+                continue;
+            }
             constexpr int D = count_depth(NF + NG);
             PackedRaw<NF> rf[D];
             PackedRaw<NG> rg[D];
@@ -890,6 +1012,17 @@ static hipError_t count_packed_launch_nf(const EmitPlan &E, int ng, int n_wg, hi
         default: break;
         }
     }
+    if constexpr (NF > 0) {
+        if (E.fp.late) {  // (the planner's estimate: few rows pass -- filters first, keys for the waves with a match)
+            switch (ng) {
+            case 0: hipLaunchKernelGGL((k_count_packed<NF, 0, true>), dim3(n_wg), dim3(kWgThreads), lds, st, E); break;
+            case 1: hipLaunchKernelGGL((k_count_packed<NF, 1, true>), dim3(n_wg), dim3(kWgThreads), lds, st, E); break;
+            case 2: hipLaunchKernelGGL((k_count_packed<NF, 2, true>), dim3(n_wg), dim3(kWgThreads), lds, st, E); break;
+            default: return hipErrorInvalidValue;
+            }
+            return hipGetLastError();
+        }
+    }
     switch (ng) {
     case 0: hipLaunchKernelGGL((k_count_packed<NF, 0>), dim3(n_wg), dim3(kWgThreads), lds, st, E); break;
     case 1: hipLaunchKernelGGL((k_count_packed<NF, 1>), dim3(n_wg), dim3(kWgThreads), lds, st, E); break;
@@ -910,6 +1043,28 @@ static hipError_t emit_packed_launch_nf(const EmitPlan &E, int ng, int na, int n
         hipLaunchKernelGGL(k, dim3(n_wg), dim3(kWgThreads), lds, st, E);                                   \
         return hipGetLastError();                                                                          \
     }
+#define SYBL_EMITL_CASE(G, A)                                                                              \
+    case (G)*3 + (A): {                                                                                    \
+        auto k = k_emit_packed<NF, G, A, true>;                                                            \
+        hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (e != hipSuccess) return e;                                                                     \
+        hipLaunchKernelGGL(k, dim3(n_wg), dim3(kWgThreads), lds, st, E);                                   \
+        return hipGetLastError();                                                                          \
+    }
+    if constexpr (NF > 0) {
+        if (E.fp.late) {
+            switch (ng * 3 + na) {
+                SYBL_EMITL_CASE(0, 1)
+                SYBL_EMITL_CASE(0, 2)
+                SYBL_EMITL_CASE(1, 1)
+                SYBL_EMITL_CASE(1, 2)
+                SYBL_EMITL_CASE(2, 1)
+                SYBL_EMITL_CASE(2, 2)
+            default: return hipErrorInvalidValue;
+            }
+        }
+    }
+#undef SYBL_EMITL_CASE
     switch (ng * 3 + na) {
         SYBL_EMITP_CASE(0, 1)
         SYBL_EMITP_CASE(0, 2)

@@ -1264,3 +1264,30 @@ def test_wrapping_last_bucket_of_an_odd_bucket_count(ctx, oracle, two):
     r.free()
     q.free()
     tb.free()
+
+
+@pytest.mark.parametrize("late", ["0", "1"])
+@pytest.mark.parametrize("compact", [False, True])
+def test_filtered_partitioned_histograms_either_order_of_loads(ctx, oracle, monkeypatch, late, compact):
+    """Strategy 5 with filters: the counting and emitting kernels as they were (all columns of a tile requested together) and
+    their LATE forms (filters a tile ahead, key and value columns only for waves with a passing row: k_count_packed /
+    k_emit_packed<.., LATE>, which the planner takes at an estimated selectivity below 0.5 % -- SYBL_LATE_PATH forces either):
+    config 4 with one, two and three range filters at ~10 %, ~1 % and ~0.1 %, config 3's two keys and three aggregations in two
+    passes, a filter nothing passes, and one that everything passes."""
+    monkeypatch.setenv("SYBL_LATE_PATH", late)
+    wl = _wl("cfg4_hist_highcard")
+    cols = wl["columns"] + ["c04", "c05", "c06"]
+    for filters in ([("c04", "gt", 899)], [("c04", "gt", 899), ("c05", "lt", 100)], [("c04", "gt", 899), ("c05", "gt", 899), ("c06", "gt", 899)],
+                    [("c04", "gt", 999)], [("c04", "gt", -1)]):
+        q = dict(wl["query"], filters=filters)
+        gres, ores, stats = parity.run_both(ctx, oracle, cols, 500_000, 0, 500_000, q, compact=compact)
+        assert stats["strategy"] == 5, stats
+        parity.compare(gres, ores, op="hist", full=True, n_aggs=1)
+        gres.free()
+    wl = _wl("cfg3_filter3_group2_stddev")
+    q = dict(wl["query"], aggs=["c07", "c08", "c09"], want_percentiles=True, hist_bucket=990,
+             filters=[("c04", "gt", 949), ("c05", "lt", 500)])
+    gres, ores, stats = parity.run_both(ctx, oracle, wl["columns"] + ["c09"], 700_000, 0, 700_000, q, compact=compact)
+    assert stats["strategy"] == 5, stats
+    parity.compare(gres, ores, op="hist", full=True, n_aggs=3)
+    gres.free()

@@ -4,7 +4,9 @@ storage: does the row body's LDS-atomic issue still cost time when almost no row
 usage: bench_selectivity.py [rows] [steps] [packed|hash|wide|nul]
   nul: the NUL variant of k_scan_packed forced (SYBL_FORCE_NUL=1: validity words, per-aggregation gates)
   hash: the same queries through the hash table (SYBL_FORCE_HASH=1: k_scan_hash_packed); wide: four aggregation columns
-  (k_scan_hash_packed<4, .., HASH = false>, the run-time-count direct-mapped body)"""
+  (k_scan_hash_packed<4, .., HASH = false>, the run-time-count direct-mapped body)
+  parthist: config 4 (histograms by 65 536 groups: k_count_packed + k_emit_packed + k_part_hist) with the same filters;
+  SYBL_NO_COUNT_CACHE=1 is set so that every scan pays its counting pass"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sybil_amd
@@ -23,6 +25,11 @@ elif variant == "nul":
 elif variant == "wide":
     cols += ["c09"]
     base["aggs"] = ["c07", "c08", "c09", "c04"]
+elif variant == "parthist":
+    w4 = synth.WORKLOADS["cfg4_hist_highcard"]
+    base = dict(w4["query"])
+    cols = list(w4["columns"]) + ["c04", "c05", "c06"]
+    os.environ["SYBL_NO_COUNT_CACHE"] = "1"
 ctx = sybil_amd.Context(0)
 t = ctx.synth_table("sel", synth.SEED, rows, 0, rows, synth.synth_cols(cols))
 t.compact()

@@ -44,6 +44,12 @@ for v in hash wide nul; do { echo "# tools/bench_selectivity.py 1000000000 5 $v 
 { echo "# rocprofv3 --pmc FETCH_SIZE -- python tools/bench_selectivity.py 1000000000 1 hash   (k_scan_hash_packed with late materialisation, round 6; KiB per dispatch; x2 on gfx950;"
   echo "# dispatches in the order of the selectivity table: 51 %, 10 %, 1 %, 0.1 %, 1e-6, 0 -- four scans each)"; python tools/rocpd_dispatches.py $O/selh_pmc/*.db k_scan_hash_packed FETCH_SIZE 2>/dev/null; } > $O/r06_selectivity_hash_fetch_size.txt
 rm -rf $O/selh_pmc
+# config 4's kernels with filters (k_count_packed / k_emit_packed<.., LATE>): the planner's choice, then each form forced
+{ echo "# tools/bench_selectivity.py 1000000000 5 parthist at HEAD (MI355X, $(date -u +%Y-%m-%dT%H:%MZ)): config 4 (65 536 groups, full histograms: counting pass + emit + k_part_hist, the counting pass in every scan) with config 3's three filter columns; the planner's estimate, then SYBL_LATE_PATH=0 and =1"; timeout -k 10 300 python tools/bench_selectivity.py 1000000000 5 parthist; SYBL_LATE_PATH=0 timeout -k 10 300 python tools/bench_selectivity.py 1000000000 5 parthist; SYBL_LATE_PATH=1 timeout -k 10 300 python tools/bench_selectivity.py 1000000000 5 parthist; } > $O/r06_selectivity_parthist.txt 2>&1
+( cd /tmp && export TMPDIR=/tmp && timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE -d $GRAFT_REPO_ROOT/$O/selp_pmc -o sel -- python $GRAFT_REPO_ROOT/tools/bench_selectivity.py 1000000000 1 parthist > $GRAFT_REPO_ROOT/$O/selp_pmc.log 2>&1 )
+{ echo "# rocprofv3 --pmc FETCH_SIZE -- python tools/bench_selectivity.py 1000000000 1 parthist   (KiB per dispatch; x2 on gfx950; dispatches in the order of the"
+  echo "# selectivity table: 51 %, 10 %, 1 %, 0.1 %, 1e-6, 0 -- four scans each; the planner takes the LATE kernels from 0.1 % down)"; python tools/rocpd_dispatches.py $O/selp_pmc/*.db k_emit_packed FETCH_SIZE 2>/dev/null; python tools/rocpd_dispatches.py $O/selp_pmc/*.db k_count_packed FETCH_SIZE 2>/dev/null; } > $O/r06_selectivity_parthist_fetch_size.txt
+rm -rf $O/selp_pmc
 ( cd /tmp && export TMPDIR=/tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$O/pdkt -o kt -- python $GRAFT_REPO_ROOT/tools/bench_pushdown.py > $GRAFT_REPO_ROOT/$O/pd.log 2>&1 )
 { echo "# rocprofv3 --kernel-trace --stats -- python tools/bench_pushdown.py (MI355X, $(date -u +%Y-%m-%dT%H:%MZ)): config 4 as a printer's query, the full path (printed_only = 1, strategy 5) and -limit 100 pushed into the scan (printed_only = 2, strategy 8), ten back-to-back scans each"; grep "^{" $O/pd.log; python tools/rocpd_summary.py $O/pdkt/*.db 2>/dev/null | grep -v "rocclr\|k_synth\|k_block_minmax\|k_fill\|k_repack"; } > $O/r06_pushdown_kernel_trace.txt
 rm -rf $O/pdkt
