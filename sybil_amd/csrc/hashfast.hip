@@ -169,10 +169,10 @@ __global__ __launch_bounds__(T) void k_scan_hash_fast(const FastPlan P, uint64_t
         }
     }
     int64_t m64 = wave_sum((int64_t)matched), o64 = wave_sum((int64_t)overflow), f64 = wave_sum((int64_t)full);
-    if ((tid & 63) == 0) {
-        if (m64) gadd(P.sum_out + kHdrMatched, m64);
-        if (o64) gadd(P.sum_out + kHdrOverflow, o64);
-        if (f64) gadd(P.sum_out + kHdrHashFull, f64);
+    {
+        const int slot[3] = {kHdrMatched, kHdrOverflow, kHdrHashFull};
+        const int64_t v[3] = {m64, o64, f64};
+        wg_header_add<3>(P.sum_out, slot, v);  // (one atomic per workgroup and counter: scan_generic.h)
     }
 }
 

@@ -155,10 +155,10 @@ __global__ __launch_bounds__(T) void k_scan_hash(CPlan *Pp) {
     matched = wave_sum(matched);
     overflow = wave_sum(overflow);
     full = wave_sum(full);
-    if ((tid & 63) == 0) {
-        if (matched) gadd(P.sum_out + kHdrMatched, matched);
-        if (overflow) gadd(P.sum_out + kHdrOverflow, overflow);
-        if (full) gadd(P.sum_out + kHdrHashFull, full);
+    {
+        const int slot[3] = {kHdrMatched, kHdrOverflow, kHdrHashFull};
+        const int64_t v[3] = {(int64_t)matched, (int64_t)overflow, (int64_t)full};
+        wg_header_add<3>(P.sum_out, slot, v);  // (one atomic per workgroup and counter: scan_generic.h)
     }
 }
 

@@ -118,9 +118,10 @@ __global__ __launch_bounds__(T) void k_scan(CPlan *Pp) {
 
     matched = wave_sum(matched);
     overflow = wave_sum(overflow);
-    if ((tid & 63) == 0) {
-        if (matched) gadd(P.sum_out + kHdrMatched, matched);
-        if (overflow) gadd(P.sum_out + kHdrOverflow, overflow);
+    {
+        const int slot[2] = {kHdrMatched, kHdrOverflow};
+        const int64_t v[2] = {(int64_t)matched, (int64_t)overflow};
+        wg_header_add<2>(P.sum_out, slot, v);  // (one atomic per workgroup and counter: scan_generic.h)
     }
 
     if (USE_LDS) {

@@ -314,13 +314,28 @@ __global__ __launch_bounds__(kWgThreads, 4) void k_pd_scan(const PushdownPlan D)
             vmax[a] = m > vmax[a] ? m : vmax[a];
         }
     }
-    if ((tid & 63u) == 0) {
-        if (matched) __hip_atomic_fetch_add(D.sum_out + kHdrMatched, (int64_t)matched, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (per WORKGROUP, not per wave: thousands of atomics on one device-scope word are serialised by the memory side -- tens of
+    // microseconds at the end of the launch, scan_generic.h: wg_header_add)
+    {
+        __shared__ unsigned long long wsum[1 + NA];
+        __shared__ long long wmax[NA];
+        if (tid < 1u + (uint32_t)NA) wsum[tid] = 0;
+        if (tid < (uint32_t)NA) wmax[tid] = INT64_MIN;
+        __syncthreads();
+        if ((tid & 63u) == 0) {
+            if (matched) __hip_atomic_fetch_add(&wsum[0], (unsigned long long)matched, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
-        for (int a = 0; a < NA; a++) {
-            __hip_atomic_fetch_add(D.sum_out + kHdrPdSum + a, (int64_t)sum[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_fetch_max(D.sum_out + kHdrPdMax + a, (int64_t)vmax[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int a = 0; a < NA; a++) {
+                __hip_atomic_fetch_add(&wsum[1 + a], (unsigned long long)sum[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_max(&wmax[a], (long long)vmax[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
         }
+        __syncthreads();
+        if (tid == 0 && wsum[0]) __hip_atomic_fetch_add(D.sum_out + kHdrMatched, (int64_t)wsum[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid >= 1u && tid < 1u + (uint32_t)NA)
+            __hip_atomic_fetch_add(D.sum_out + kHdrPdSum + (tid - 1u), (int64_t)wsum[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid >= 64u && tid < 64u + (uint32_t)NA)
+            __hip_atomic_fetch_max(D.sum_out + kHdrPdMax + (tid - 64u), (int64_t)wmax[tid - 64u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 

@@ -15,6 +15,7 @@
 
 #include "plan.h"
 #include "outlog.h"
+#include "wg_header.h"
 
 namespace sybl {
 
@@ -651,9 +652,10 @@ __device__ __forceinline__ void fast_finish(const FastPlan &P, int64_t *lds, con
         matched += __shfl_xor(matched, o, 64);
         overflow += __shfl_xor(overflow, o, 64);
     }
-    if ((tid & 63) == 0) {
-        if (matched) __hip_atomic_fetch_add(P.sum_out + kHdrMatched, (int64_t)matched, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (overflow) __hip_atomic_fetch_add(P.sum_out + kHdrOverflow, (int64_t)overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    {
+        const int slot[2] = {kHdrMatched, kHdrOverflow};
+        const int64_t v[2] = {(int64_t)matched, (int64_t)overflow};
+        wg_header_add<2>(P.sum_out, slot, v);  // (one atomic per workgroup and counter, not per wave: scan_generic.h)
     }
 
     __syncthreads();
@@ -1029,9 +1031,10 @@ __device__ __forceinline__ void emit_finish(const EmitPlan &E, const EmitLds &S,
         matched += __shfl_xor(matched, o, 64);
         overflow += __shfl_xor(overflow, o, 64);
     }
-    if ((threadIdx.x & 63) == 0) {
-        if (matched && !E.quiet) __hip_atomic_fetch_add(E.sum_out + kHdrMatched, (int64_t)matched, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (overflow && !E.quiet) __hip_atomic_fetch_add(E.sum_out + kHdrOverflow, (int64_t)overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!E.quiet) {  // (wave-uniform, the whole workgroup alike)
+        const int slot[2] = {kHdrMatched, kHdrOverflow};
+        const int64_t v[2] = {(int64_t)matched, (int64_t)overflow};
+        wg_header_add<2>(E.sum_out, slot, v);
     }
 }
 

@@ -10,6 +10,7 @@
 
 #include "plan.h"
 #include "outlog.h"
+#include "wg_header.h"
 
 namespace sybl {
 
