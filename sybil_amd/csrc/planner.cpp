@@ -1499,29 +1499,6 @@ struct Planner {
         for (auto &r : runs) total_tiles += (r.n + kTileRows - 1) / kTileRows;
         q->segs.clear();
         q->wg_seg_begin.assign((size_t)q->n_wg + 1, 0);
-        // SYBL_TILE_INTERLEAVE=k (A/B): pieces of k tiles dealt out to the workgroups in turn instead of one contiguous share
-        // each -- all workgroups then stream neighbouring memory at any moment
-        int64_t deal = 0;
-        if (const char *e = env("SYBL_TILE_INTERLEAVE")) deal = std::max(0, atoi(e));
-        if (deal > 0) {
-            std::vector<std::vector<Segment>> per((size_t)q->n_wg);
-            int64_t piece = 0;
-            for (auto &r : runs) {
-                const int64_t run_tiles = (r.n + kTileRows - 1) / kTileRows;
-                for (int64_t t0 = 0; t0 < run_tiles; t0 += deal, piece++) {
-                    Segment sg;
-                    sg.start = r.start + t0 * kTileRows;
-                    sg.n = std::min(r.start + r.n, sg.start + deal * kTileRows) - sg.start;
-                    per[(size_t)(piece % q->n_wg)].push_back(sg);
-                }
-            }
-            for (int w = 0; w < q->n_wg; w++) {
-                q->wg_seg_begin[(size_t)w] = (int32_t)q->segs.size();
-                q->segs.insert(q->segs.end(), per[(size_t)w].begin(), per[(size_t)w].end());
-            }
-            q->wg_seg_begin[(size_t)q->n_wg] = (int32_t)q->segs.size();
-            return SYBL_OK;
-        }
         {
             size_t ri = 0;
             int64_t tile_in_run = 0;  // tiles of runs[ri] already handed out
