@@ -19,6 +19,17 @@ def ctx():
     c.close()
 
 
+@pytest.fixture(params=["gpu_walk", "host_parser"], autouse=True)
+def loader_path(request, monkeypatch):
+    """Every test of this module twice: with the int column files' varints walked on the GPU (the default since round 6,
+    csrc/gobgpu.hip) and with every file through the host parser (SYBL_LOADER_GPU_VARINT=0, the only path before)."""
+    if request.param == "host_parser":
+        monkeypatch.setenv("SYBL_LOADER_GPU_VARINT", "0")
+    else:
+        monkeypatch.delenv("SYBL_LOADER_GPU_VARINT", raising=False)
+    return request.param
+
+
 def _make_blocks(n_blocks, rows, seed=3, ragged=True):
     rng = np.random.default_rng(seed)
     blocks, logical = [], []
