@@ -323,8 +323,11 @@ typedef struct {
      * (printer.go:154-158: sorted[:Limit]).  When the order is $COUNT descending the limit is then pushed INTO the scan
      * (csrc/pushdown.hip): group counts from the key column alone, the printed groups chosen on the device, one pass over key
      * and value columns for Cumulative and those groups -- no bucket array exists for any other group.  Taken for a single
-     * direct-mapped key of at most 65 536 cells without filters on one GPU (sybl_run_stats.strategy = 8); any other query
-     * answers as with 1.  The rows beyond the limit then report sum 0 / avg 0 / min, max at their initial values. */
+     * direct-mapped key of at most 65 536 cells without filters (sybl_run_stats.strategy = 8); any other query answers as
+     * with 1.  The rows beyond the limit then report sum 0 / avg 0 / min, max at their initial values.
+     * Across ranks (sybl_comm_init): sybl_query_scan of such a query is a COLLECTIVE call -- at the first scan the ranks ask
+     * each other whether every one of them planned the pushed-down scan (a rank without rows cannot; then none takes it), and
+     * every pushed-down scan all-reduces the groups' counts between its two passes so that all ranks print the same groups. */
     int32_t printed_only;
 } sybl_query_desc;
 

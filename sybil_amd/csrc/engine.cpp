@@ -147,6 +147,7 @@ static void free_query(Query *q) {
     if (q->d_multi) hipFree(q->d_multi);
     if (q->d_dplan) hipFree(q->d_dplan);
     if (q->d_pd) hipFree(q->d_pd);
+    if (q->d_pd_max) hipFree(q->d_pd_max);
     if (q->d_hll) hipFree(q->d_hll);
     if (q->d_hll_idhash) hipFree(q->d_hll_idhash);
     if (q->d_hll_chars) hipFree(q->d_hll_chars);
@@ -253,10 +254,19 @@ static int scan(Query *q) {
         q->plan_dirty = false;
     }
     const bool ran = !q->never_matches && !q->segs.empty();
+    // several ranks: the pushed-down scan is only taken when EVERY rank planned it (a rank without rows plans no partitioned
+    // histograms at all) -- asked once per prepared query, a collective call of every rank's first scan
+    if (q->pd_static && q->pd_agreed < 0) {
+        bool all = false;
+        if ((rc = comm_all_agree(q->ctx, q->pushdown, &all))) return rc;
+        q->pd_agreed = all ? 1 : 0;
+        if (!all) q->pushdown = false;
+    }
+    const bool pd_ranks = q->pushdown && q->ctx->comm && q->ctx->comm_nranks > 1;  // (its count all-reduce: every rank, rows or not)
     hipError_t e = hipSuccess;
     if ((rc = out_log_begin(q, st))) return rc;
     q->pushdown_ran = false;
-    if (q->pushdown && ran) {
+    if (q->pushdown && (ran || pd_ranks)) {
         q->pushdown_ran = true;
         // -limit pushed into the scan (pushdown.hip): group counts from the key column, the printed cells chosen on the
         // device, then ONE pass over key + value that fills Cumulative and the printed groups only
@@ -277,7 +287,12 @@ static int scan(Query *q) {
         D.sum_out = q->d_sum;
         D.max_out = q->d_max;
         D.total = q->d_total;
-        e = launch_pushdown(D, st);
+        e = launch_pushdown_count(D, st);
+        if (e != hipSuccess) return hip_fail(e, "k_pd_count");
+        // across ranks: the groups' counts over ALL shards decide which cells are printed (the cells' Count fields stay this
+        // rank's own: the merge sums them later)
+        if (pd_ranks && (rc = comm_allreduce_u32_sum(q->ctx, D.cnt, (size_t)PP.n_cells))) return rc;
+        e = launch_pushdown_scan(D, st);
         if (e != hipSuccess) return hip_fail(e, "k_pd_*");
         SYBL_HIP(hipEventRecord(q->ev[1], st));
         SYBL_HIP(hipEventRecord(q->ev[2], st));

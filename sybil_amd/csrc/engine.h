@@ -530,6 +530,9 @@ struct Query {
     bool pushdown_ran = false;  // the last scan went through it (a query that matches nothing, an empty table: the ordinary zeroed tables)
     PushdownPlan dplan_pd;
     uint32_t *d_pd = nullptr;  // ws | carry | cnt | bitmap | top_cells | n_top in one allocation
+    bool pd_static = false;  // several ranks, and the query alone does not rule the pushdown out: the ranks agree at the first scan ...
+    int pd_agreed = -1;      // ... 1: every rank planned it, 0: some rank did not (none takes it), -1: not asked yet
+    int64_t *d_pd_max = nullptr;  // across ranks: the header's Cumulative maxima set aside for their MAX all-reduce (rccl.cpp)
     bool count_cached = false;  // d_cursor holds the count pass's regions for this query's rows (engine.cpp: a rescan skips k_count)
 };
 
@@ -546,6 +549,8 @@ int query_total_buffers(Query *q);    // (result.cpp) d_total + its pinned twin 
 // rccl.cpp: collectives on the ctx communicator and stream (SYBL_E_STATE without a communicator)
 int comm_allgather_inplace(Ctx *ctx, int64_t *buf, size_t words_per_rank);
 int comm_allreduce_sum(Ctx *ctx, int64_t *buf, size_t words);
+int comm_all_agree(Ctx *ctx, bool mine, bool *all);  // (a blocking MIN over the ranks: rccl.cpp)
+int comm_allreduce_u32_sum(Ctx *ctx, uint32_t *buf, size_t n);  // (the pushed-down scan's group counts between its passes)
 // agree.cpp
 bool group_key_wants_dict(unsigned __int128 card, int64_t cells);  // the planner's test, shared with sybl_table_agree
 int query_check_layout(Query *q);                                  // collective; an error on EVERY rank when the layouts differ

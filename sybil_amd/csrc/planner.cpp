@@ -1558,13 +1558,23 @@ struct Planner {
 
     // -limit pushed into the scan (pushdown.hip).  Taken when the caller said the rows beyond the limit need nothing but their
     // Count (printed_only = 2), the query is one strategy 5 runs in a single pass over compact storage with ONE key column
-    // and no filter, the order is $COUNT descending, and there is one GPU (the ranks of a job would have to agree on the
-    // printed cells before pass 2: they keep the limit-aware merge of round 5).
+    // and no filter, and the order is $COUNT descending.  The ranks of a job agree on the printed cells before pass 2: the
+    // groups' counts are SUM-all-reduced between the passes (engine.cpp: scan -- sybl_query_scan is then a collective call);
+    // every rank picks the same cells from them and the merge is round 5's limit-aware one (cell fields, Cumulative, the
+    // printed rows' arrays).  Whether it is taken is itself agreed: what follows depends on a rank's rows, so the ranks ask
+    // each other once per prepared query (pd_static / pd_agreed) and take it only if every one of them planned it.
     int plan_pushdown() {
         q->pushdown = false;
+        // (what depends on the query alone, the same on every rank: whether the ranks have to ask each other at the first scan --
+        // what follows depends on this rank's rows too, and a rank without any plans no partitioned histograms at all)
+        q->pd_static = q->printed_level == 2 && !env("SYBL_NO_PUSHDOWN") && !env("SYBL_NO_PUSHDOWN_RANKS") && q->limit > 0 && q->order_by == "$COUNT" &&
+                       !q->order_asc && d->n_groups == 1 && d->n_filters == 0 && d->op == SYBL_AGG_HIST && d->n_aggs >= 1 && d->n_aggs <= 2 &&
+                       d->n_distincts == 0 && ctx->comm && ctx->comm_nranks > 1;
+        q->pd_agreed = -1;
         if (q->printed_level != 2 || env("SYBL_NO_PUSHDOWN")) return SYBL_OK;
         if (!q->part_hist || !q->part_packed || !q->part_more.empty() || q->part_nf != 0 || q->part_ng != 1) return SYBL_OK;
-        if (q->limit <= 0 || q->order_by != "$COUNT" || q->order_asc || ctx->comm_nranks > 1) return SYBL_OK;
+        if (q->limit <= 0 || q->order_by != "$COUNT" || q->order_asc) return SYBL_OK;
+        if (ctx->comm_nranks > 1 && env("SYBL_NO_PUSHDOWN_RANKS")) return SYBL_OK;  // (A/B: the limit-aware merge of round 5 instead)
         if (P.n_cells < 2048 || P.n_cells > 65536 || q->part_na < 1 || q->part_na > 2 || q->n_distinct) return SYBL_OK;
         const FastPlan &FP = q->eplan.fp;
         if (FP.gcard[0] != (uint32_t)P.n_cells || FP.gstride[0] != 1 || P.hist_stride > 8192) return SYBL_OK;

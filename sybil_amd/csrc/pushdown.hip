@@ -341,7 +341,8 @@ __global__ __launch_bounds__(kWgThreads, 4) void k_pd_scan(const PushdownPlan D)
 
 // the whole sequence on one stream; the caller has zeroed the header, the sum fields, carry, n_top and d_total and filled the
 // MAX section with INT64_MIN
-hipError_t launch_pushdown(const PushdownPlan &D, hipStream_t st) {
+// pass 1: every group's count (D.cnt; the cells' Count fields)
+hipError_t launch_pushdown_count(const PushdownPlan &D, hipStream_t st) {
     const uint32_t words = ((uint32_t)D.n_cells + 1u) >> 1;
     const size_t lds1 = (size_t)words * 4;
     hipError_t e;
@@ -361,6 +362,12 @@ hipError_t launch_pushdown(const PushdownPlan &D, hipStream_t st) {
     default: return hipErrorInvalidValue;
     }
     hipLaunchKernelGGL(k_pd_fold, dim3((words + 255) / 256), dim3(256), 0, st, D);
+    return hipGetLastError();
+}
+
+// the printed cells from D.cnt (across ranks: the all-reduced counts), then pass 2
+hipError_t launch_pushdown_scan(const PushdownPlan &D, hipStream_t st) {
+    hipError_t e;
     hipLaunchKernelGGL(k_pd_select, dim3(1), dim3(1024), 0, st, D);
     hipLaunchKernelGGL(k_pd_clear, dim3((unsigned)std::max(D.limit, 1)), dim3(256), 0, st, D);
     const size_t lds2 = ((((size_t)D.n_cells + 31) >> 5) + (size_t)D.hist_stride) * 4;

@@ -83,6 +83,28 @@ int comm_allreduce_sum(Ctx *ctx, int64_t *buf, size_t words) {
     return SYBL_OK;
 }
 
+// true on every rank iff `mine` is true on every rank (one int64 MIN all-reduce, waited for)
+int comm_all_agree(Ctx *ctx, bool mine, bool *all) {
+    if (!ctx->comm) return fail(SYBL_E_STATE, "no communicator");
+    DevOwner own;
+    SYBL_HIP(hipMalloc(&own.p, 8));
+    int64_t v = mine ? 1 : 0;
+    SYBL_HIP(hipMemcpyAsync(own.p, &v, 8, hipMemcpyHostToDevice, ctx->stream));
+    ncclResult_t nr = ncclAllReduce(own.p, own.p, 1, ncclInt64, ncclMin, (ncclComm_t)ctx->comm, ctx->stream);
+    hipError_t e = nr == ncclSuccess ? hipMemcpyAsync(&v, own.p, 8, hipMemcpyDeviceToHost, ctx->stream) : hipSuccess;
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (nr != ncclSuccess) return nccl_fail(nr, "ncclAllReduce(agree)");
+    if (e != hipSuccess) return hip_fail(e, "agree");
+    *all = v != 0;
+    return SYBL_OK;
+}
+
+int comm_allreduce_u32_sum(Ctx *ctx, uint32_t *buf, size_t n) {
+    if (!ctx->comm) return fail(SYBL_E_STATE, "no communicator");
+    SYBL_NCCL(ncclAllReduce(buf, buf, n, ncclUint32, ncclSum, (ncclComm_t)ctx->comm, ctx->stream));
+    return SYBL_OK;
+}
+
 // Hash group-by across ranks: which keys exist differs from rank to rank, so the ranks first agree on the sorted union of
 // their key lists (all-gather of the counts, all-gather of the padded lists, sort + unique on every GPU), re-lay their
 // dense arrays out over it, and then merge with the usual SUM (+ MAX) all-reduce.
@@ -292,7 +314,15 @@ int sybl_query_allreduce(sybl_query *q) {
         hipError_t e = launch_pack32(q->d_sum + P.hist_off, q->d_h32, count * R, ctx->stream);
         if (e != hipSuccess) return hip_fail(e, "k_pack32");
     }
+    // a pushed-down scan (pushdown.hip) keeps Cumulative's maxima in header words: they merge by MAX, not with the header's SUM --
+    // set aside before the group, all-reduced in it, put back behind it
+    const bool pd_max = q->pushdown && q->pushdown_ran;
+    if (pd_max) {
+        if (!q->d_pd_max) SYBL_HIP(hipMalloc((void **)&q->d_pd_max, (size_t)kMaxAggs * 8));
+        SYBL_HIP(hipMemcpyAsync(q->d_pd_max, q->d_sum + kHdrPdMax, (size_t)kMaxAggs * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    }
     SYBL_NCCL(ncclGroupStart());
+    if (pd_max) SYBL_NCCL_G(ncclAllReduce(q->d_pd_max, q->d_pd_max, (size_t)kMaxAggs, ncclInt64, ncclMax, comm, ctx->stream));
     if (top_merge) {
         SYBL_NCCL_G(ncclAllReduce(q->d_sum, q->d_sum, (size_t)small_words, ncclInt64, ncclSum, comm, ctx->stream));
         q->top_merge = true;
@@ -317,6 +347,7 @@ int sybl_query_allreduce(sybl_query *q) {
     // count distinct: Result.Combine merges the sketches register by register (query_spec.go:180-188)
     if (q->n_distinct) SYBL_NCCL_G(ncclAllReduce(q->d_hll, q->d_hll, (size_t)q->hll_bytes, ncclUint8, ncclMax, comm, ctx->stream));
     SYBL_NCCL(ncclGroupEnd());
+    if (pd_max) SYBL_HIP(hipMemcpyAsync(q->d_sum + kHdrPdMax, q->d_pd_max, (size_t)kMaxAggs * 8, hipMemcpyDeviceToDevice, ctx->stream));
     if (scatter && q->rs_int32 == 1) {
         const int64_t R = ctx->comm_nranks, per = (P.n_cells + R - 1) / R, count = per * P.hist_stride;
         hipError_t e = launch_unpack32(q->d_h32 + count * R, q->d_sum + P.hist_off + (int64_t)ctx->comm_rank * count, count, ctx->stream);

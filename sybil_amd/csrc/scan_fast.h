@@ -225,7 +225,8 @@ struct PushdownPlan {
     int64_t *sum_out, *max_out, *total;  // the query's SUM / MAX sections and Cumulative's buckets (Query::d_total)
     int64_t hist_off, hist_stride;
 };
-hipError_t launch_pushdown(const PushdownPlan &D, hipStream_t st);
+hipError_t launch_pushdown_count(const PushdownPlan &D, hipStream_t st);  // pass 1: the groups' counts ...
+hipError_t launch_pushdown_scan(const PushdownPlan &D, hipStream_t st);   // ... the printed cells chosen from them, pass 2
 
 // tiles of column loads a lane keeps in flight: a tile is only 8..16 bytes per column and lane, and a CU needs
 // ~64 KB on the way to keep HBM busy; bounded by registers (one 16-byte register quad per column and tile)

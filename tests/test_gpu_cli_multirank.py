@@ -11,6 +11,7 @@ import json
 import os
 import subprocess
 
+import numpy as np
 import pytest
 
 from tests import loaded_oracle as LO
@@ -145,3 +146,38 @@ def test_layout_mismatch_is_an_error_on_every_rank(db, tmp_path):
     outs = [p.communicate(timeout=300) for p in procs]
     assert [p.returncode for p in procs] == [1, 1], outs
     assert all(b"partial tables differ across ranks" in e for _, e in outs), outs
+
+
+@pytest.mark.parametrize("world,n_blocks", [(2, 9), (4, 9), (4, 3)])
+def test_limit_pushed_into_the_scan_across_ranks(tmp_path, world, n_blocks):
+    """A printer's $COUNT-sorted histogram query with -limit (strategy 8, csrc/pushdown.hip) on N ranks: the groups' counts are
+    all-reduced between the two passes, so every rank prints -- and fills -- the same cells; the merge is the limit-aware one.
+    Output byte-equal to the one-process CLI's in text and -json; (4, 3): three blocks over four ranks -- the rank without rows
+    cannot plan the pushed-down scan, the ranks find out at their first scan (one MIN all-reduce) and all take the full path."""
+    rng = np.random.default_rng(7)
+    root = str(tmp_path / "dbp")
+    # (the shape the pushdown takes, tests/test_gpu_pushdown.py: a few thousand groups, values that cannot be outliers)
+    blocks = []
+    for b in range(n_blocks):
+        n = 40_000 - 1_000 * b
+        blocks.append({"k": ("int", rng.integers(0, 3001, n).astype(np.int64)), "v": ("int", rng.integers(0, 1000, n).astype(np.int64)),
+                       "w": ("int", rng.integers(0, 1000, n).astype(np.int64))})
+    blocks[0]["k"][1][:3001] = np.arange(3001)   # (every key and both ends of the values somewhere: the bounds are the full ranges)
+    blocks[0]["v"][1][:2] = [0, 999]
+    blocks[0]["w"][1][:2] = [0, 999]
+    F.write_table(root, "events", blocks, threshold=8)
+    for tag, args in (("pd_text", ["-group", "k", "-int", "v", "-op", "hist", "-limit", "12"]),
+                      ("pd_json", ["-group", "k", "-int", "v,w", "-op", "hist", "-limit", "7", "-json"])):
+        want = _one(root, args)
+        assert len(want) > 0
+        # (-stats: rank 0 says on stderr which strategy its scan took)
+        env = dict(os.environ, TZ="UTC", HSA_ENABLE_IPC_MODE_LEGACY="0", LD_PRELOAD=STANDIN, SYBL_CLI_BACKTRACE="1",
+                   SYBL_STANDIN_TIMEOUT_S=os.environ.get("SYBL_STANDIN_TIMEOUT_S", "120"))
+        idf = os.path.join(str(tmp_path), "id_%s_%d_%d" % (tag, world, n_blocks))
+        procs = [subprocess.Popen([CLI, "-dir", root, "-table", "events"] + args + ["-stats", "-gpu-rank", str(r), "-gpu-ranks", str(world), "-gpu-id-file", idf],
+                                  stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env) for r in range(world)]
+        outs = [p.communicate(timeout=600) for p in procs]
+        assert [p.returncode for p in procs] == [0] * world, (tag, b"\n".join(e for _, e in outs).decode(errors="replace")[-4000:])
+        # (a rank without rows plans no pushed-down scan; the ranks ask each other at the first scan and then none takes it)
+        assert (b"strategy=8" if n_blocks >= world else b"strategy=5") in outs[0][1], (tag, outs[0][1][-600:])
+        assert outs[0][0] == want, (tag, world, outs[0][0][:400], want[:400])
