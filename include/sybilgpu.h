@@ -327,7 +327,9 @@ typedef struct {
      * with 1.  The rows beyond the limit then report sum 0 / avg 0 / min, max at their initial values.
      * Across ranks (sybl_comm_init): sybl_query_scan of such a query is a COLLECTIVE call -- at the first scan the ranks ask
      * each other whether every one of them planned the pushed-down scan (a rank without rows cannot; then none takes it), and
-     * every pushed-down scan all-reduces the groups' counts between its two passes so that all ranks print the same groups. */
+     * every pushed-down scan all-reduces the groups' counts between its two passes so that all ranks print the same groups.
+     * (A host that merges the ranks' partial tables with collectives of its own -- sybl_query_partials -- must pass 0 or 1: the
+     * library cannot make its ranks agree on the printed groups.) */
     int32_t printed_only;
 } sybl_query_desc;
 
